@@ -1,0 +1,164 @@
+/*
+ * mom6hip.h -- C ABI of libmom6hip, the MI355X (gfx950) implementation of the MOM6
+ * split-RK2 dynamical-core hot path.
+ *
+ * The reference (mnlevy1981/MOM6) has no FFI: its drop-in boundary is the public Fortran module
+ * procedure.  Every entry point below replaces one such procedure; the Fortran side binds to it
+ * through ISO_C_BINDING interfaces (mom6_amd/fortran/mom6hip_c_api.F90) in the style the reference
+ * itself uses for libc (src/framework/posix.F90:52-229).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - All reals are IEEE fp64 (the reference promotes `real` with -fdefault-real-8).
+ *  - Arrays are whole Fortran allocations, column-major, i fastest, symmetric memory
+ *    (config_src/memory/dynamic_symmetric/MOM_memory.h):
+ *        h-point  (isd:ied,   jsd:jed  [,nk])
+ *        u-point  (isd-1:ied, jsd:jed  [,nk])      "SZIB_"
+ *        v-point  (isd:ied,   jsd-1:jed[,nk])      "SZJB_"
+ *        q-point  (isd-1:ied, jsd-1:jed[,nk])
+ *  - `memspace` says where the field pointers of a call live: MOM6HIP_MEM_HOST (the Fortran
+ *    drop-in: arrays are staged to HBM, the kernels run, results are copied back to the same host
+ *    arrays) or MOM6HIP_MEM_DEVICE (state already resident in HBM; no copies).  The 2-D metric
+ *    arrays in mom6hip_grid_t are always HOST pointers; mom6hip_grid_create uploads them once.
+ *  - Every function returns 0 on success, nonzero on error; mom6hip_last_error() gives the text.
+ *    The Fortran shim turns nonzero into MOM_error(FATAL, ...) (src/framework/MOM_error_handler.F90:148).
+ *  - One process <-> one tile <-> one GPU; calls come from one thread, never re-entrantly.
+ */
+#ifndef MOM6HIP_H
+#define MOM6HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOM6HIP_MEM_HOST   0
+#define MOM6HIP_MEM_DEVICE 1
+
+/* TRACER_ADVECTION_SCHEME, src/tracer/MOM_tracer_advect.F90:1116-1134 */
+#define MOM6HIP_ADV_PLM    0
+#define MOM6HIP_ADV_PPM_H3 1   /* "PPM:H3": usePPM & useHuynh   */
+#define MOM6HIP_ADV_PPM    2   /* "PPM"   : usePPM & .not.useHuynh (Colella-Woodward) */
+
+/*
+ * Horizontal grid, index ranges and the scalar constants the kernels read.  Mirrors the members of
+ * ocean_grid_type (src/core/MOM_grid.F90), hor_index_type (src/framework/MOM_hor_index.F90) and
+ * verticalGrid_type (src/core/MOM_verticalGrid.F90) that the hot path touches.
+ * Index ranges are Fortran-style inclusive, in the tile-local numbering of hor_index_type.
+ * Unused metric pointers may be NULL; a kernel that needs a NULL metric fails with an error.
+ */
+typedef struct mom6hip_grid {
+  int32_t isc, iec, jsc, jec;       /* compute domain */
+  int32_t isd, ied, jsd, jed;       /* data domain (compute + halo) */
+  int32_t nk;                       /* GV%ke */
+  int32_t symmetric;                /* must be 1: u/v/q arrays start at isd-1 / jsd-1 */
+  int32_t reentrant_x, reentrant_y; /* REENTRANT_X / REENTRANT_Y of a single-tile domain */
+  int32_t first_direction;          /* G%first_direction */
+  int32_t reserved0;
+  double Angstrom_H;                /* GV%Angstrom_H */
+  double H_subroundoff;             /* GV%H_subroundoff */
+  double dZ_subroundoff;            /* GV%dZ_subroundoff */
+  double H_to_Z, Z_to_H;            /* GV%H_to_Z, GV%Z_to_H */
+  double g_Earth, Rho0;             /* GV%g_Earth, GV%Rho0 */
+  double reserved1[8];
+  /* h-points */
+  const double *mask2dT, *areaT, *IareaT, *dxT, *dyT, *IdxT, *IdyT, *bathyT;
+  /* u-points */
+  const double *mask2dCu, *dxCu, *dyCu, *dy_Cu, *IdxCu, *IdyCu, *areaCu, *IareaCu;
+  /* v-points */
+  const double *mask2dCv, *dxCv, *dyCv, *dx_Cv, *IdxCv, *IdyCv, *areaCv, *IareaCv;
+  /* q-points */
+  const double *mask2dBu, *dxBu, *dyBu, *areaBu, *IareaBu, *CoriolisBu;
+  const void *reserved2[8];
+} mom6hip_grid_t;
+
+/* Opaque handle: device copies of the metrics + scratch owned by the library. */
+typedef struct mom6hip_ctx mom6hip_ctx_t;
+
+/* ---- library / context ------------------------------------------------------------------- */
+
+/* Selects the HIP device (hipSetDevice).  Fails loudly if no gfx950 device is usable. */
+int mom6hip_init(int device);
+
+/* Text of the last error on this thread's context ("" if none). */
+const char *mom6hip_last_error(void);
+
+/* Uploads the metric arrays of `grid` (host pointers) and returns a context.  `stream` is the
+ * hipStream_t (as void*) all work of this context is enqueued on; NULL = the default stream. */
+int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t **ctx);
+int mom6hip_grid_destroy(mom6hip_ctx_t *ctx);
+
+/* Blocks until all work enqueued by this context is done (hipStreamSynchronize). */
+int mom6hip_sync(mom6hip_ctx_t *ctx);
+
+/* Plain device allocation helpers for hosts without another device allocator (Fortran driver). */
+int mom6hip_malloc(void **dptr, uint64_t bytes);
+int mom6hip_free(void *dptr);
+int mom6hip_sync_to_device(mom6hip_ctx_t *ctx, void *dptr, const void *hptr, uint64_t bytes);
+int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint64_t bytes);
+
+/* ---- MOM_domains: single-tile halo update ------------------------------------------------- */
+
+/* Staggering of a field, for halo updates (MOM_domains AGRID/CGRID_NE positions). */
+#define MOM6HIP_POS_H 0
+#define MOM6HIP_POS_U 1
+#define MOM6HIP_POS_V 2
+#define MOM6HIP_POS_Q 3
+
+/* pass_var / pass_vector on a one-tile domain (config_src/infra/FMS2/MOM_domain_infra.F90:171,660):
+ * fills the halo of `nfields` device arrays from the tile's own compute domain where the
+ * domain is re-entrant; halos at closed edges are left untouched.  nk_each[f] is 1 for 2-D. */
+int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,
+                        const int32_t *nk_each, int32_t nfields);
+
+/* ---- MOM_tracer_advect -------------------------------------------------------------------- */
+
+/* tracer_advect_CS, src/tracer/MOM_tracer_advect.F90:30-40 */
+typedef struct mom6hip_tracer_advect_cs {
+  double dt;                 /* CS%dt: baroclinic time step [T] */
+  int32_t scheme;            /* MOM6HIP_ADV_* */
+  int32_t use_huynh_stencil_bug; /* CS%useHuynhStencilBug (default 0) */
+} mom6hip_tracer_advect_cs_t;
+
+/* What advect_tracer reports back (not in the reference signature; used by tests and the bench). */
+typedef struct mom6hip_advect_stats {
+  int32_t iterations;        /* passes of the itt loop executed (:203) */
+  int32_t halo_updates;      /* do_group_pass calls (:206) */
+  int32_t domore_remaining;  /* sum(domore_k) when the loop ended */
+  int32_t reserved;
+} mom6hip_advect_stats_t;
+
+/*
+ * advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first_in, vol_prev, max_iter_in,
+ *               update_vol_prev, uhr_out, vhr_out)            src/tracer/MOM_tracer_advect.F90:52
+ *
+ *  tr[m]            Reg%Tr(m)%t, h-point 3-D, updated in place, m = 0..ntr-1
+ *  conc_underflow   Reg%Tr(m)%conc_underflow per tracer (NULL = all zero)
+ *  x_first_in       <0 = absent (use mod(G%first_direction,2)==0), 0/1 = value
+ *  vol_prev         NULL = absent (hprev is reconstructed from h_end and the fluxes, :160-172)
+ *  max_iter_in      <=0 = absent
+ *  update_vol_prev  0/1 (only meaningful with vol_prev)
+ *  uhr_out/vhr_out  NULL = absent
+ *  OBC must not be associated (open boundaries are out of scope; the shim FATALs).
+ */
+int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, const double *uhtr,
+                          const double *vhtr, double dt, const mom6hip_tracer_advect_cs_t *cs,
+                          double *const *tr, const double *conc_underflow, int32_t ntr,
+                          int32_t x_first_in, double *vol_prev, int32_t max_iter_in,
+                          int32_t update_vol_prev, double *uhr_out, double *vhr_out,
+                          int32_t memspace, mom6hip_advect_stats_t *stats);
+
+/* Per-kernel device time of the last advect_tracer call, from HIP events on the context's stream:
+ * ms_x / ms_y are the summed durations of the advect_x / advect_y kernels, n_x / n_y their launch
+ * counts, ms_total the whole call.  Only filled when timing was enabled before the call. */
+typedef struct mom6hip_advect_timing {
+  double ms_total, ms_setup, ms_x, ms_y, ms_halo;
+  int32_t n_x, n_y;
+} mom6hip_advect_timing_t;
+int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable);
+int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOM6HIP_H */

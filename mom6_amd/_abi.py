@@ -1,0 +1,48 @@
+"""ctypes mirror of include/mom6hip.h (the C ABI of libmom6hip).
+
+Field order and types must match the header exactly; tests/test_abi.py checks sizes/offsets
+against the compiled library (mom6hip_abi_sizeof_*).
+"""
+import ctypes as C
+
+MEM_HOST, MEM_DEVICE = 0, 1
+ADV_PLM, ADV_PPM_H3, ADV_PPM = 0, 1, 2
+POS_H, POS_U, POS_V, POS_Q = 0, 1, 2, 3
+
+ADV_SCHEMES = {"PLM": ADV_PLM, "PPM:H3": ADV_PPM_H3, "PPM": ADV_PPM}
+
+_dp = C.POINTER(C.c_double)
+
+H_METRICS = ("mask2dT", "areaT", "IareaT", "dxT", "dyT", "IdxT", "IdyT", "bathyT")
+U_METRICS = ("mask2dCu", "dxCu", "dyCu", "dy_Cu", "IdxCu", "IdyCu", "areaCu", "IareaCu")
+V_METRICS = ("mask2dCv", "dxCv", "dyCv", "dx_Cv", "IdxCv", "IdyCv", "areaCv", "IareaCv")
+Q_METRICS = ("mask2dBu", "dxBu", "dyBu", "areaBu", "IareaBu", "CoriolisBu")
+ALL_METRICS = H_METRICS + U_METRICS + V_METRICS + Q_METRICS
+
+
+class GridStruct(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("isc", "iec", "jsc", "jec", "isd", "ied", "jsd", "jed", "nk",
+                                  "symmetric", "reentrant_x", "reentrant_y", "first_direction",
+                                  "reserved0")]
+        + [(n, C.c_double) for n in ("Angstrom_H", "H_subroundoff", "dZ_subroundoff", "H_to_Z",
+                                     "Z_to_H", "g_Earth", "Rho0")]
+        + [("reserved1", C.c_double * 8)]
+        + [(n, _dp) for n in ALL_METRICS]
+        + [("reserved2", C.c_void_p * 8)]
+    )
+
+
+class TracerAdvectCS(C.Structure):
+    _fields_ = [("dt", C.c_double), ("scheme", C.c_int32), ("use_huynh_stencil_bug", C.c_int32)]
+
+
+class AdvectStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("halo_updates", C.c_int32),
+                ("domore_remaining", C.c_int32), ("reserved", C.c_int32)]
+
+
+class AdvectTiming(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_setup", C.c_double), ("ms_x", C.c_double),
+                ("ms_y", C.c_double), ("ms_halo", C.c_double), ("n_x", C.c_int32),
+                ("n_y", C.c_int32)]

@@ -1,0 +1,62 @@
+"""Loader of libmom6hip.so (the product).  There is no CPU fallback: if the library is missing or
+no gfx950 device is usable, every operation raises."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmom6hip.so")
+_LIB = None
+_dp = C.POINTER(C.c_double)
+
+# every symbol include/mom6hip.h declares
+EXPORTS = (
+    "mom6hip_init", "mom6hip_last_error", "mom6hip_grid_create", "mom6hip_grid_destroy",
+    "mom6hip_sync", "mom6hip_malloc", "mom6hip_free", "mom6hip_sync_to_device",
+    "mom6hip_sync_to_host", "mom6hip_halo_update", "mom6hip_advect_tracer", "mom6hip_set_timing",
+    "mom6hip_advect_get_timing",
+)
+
+
+class Mom6HipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mom6HipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C mom6_amd/csrc). mom6_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.mom6hip_last_error.restype = C.c_char_p
+        L.mom6hip_init.argtypes = [C.c_int]
+        L.mom6hip_grid_create.argtypes = [C.POINTER(_abi.GridStruct), C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mom6hip_grid_destroy.argtypes = [C.c_void_p]
+        L.mom6hip_sync.argtypes = [C.c_void_p]
+        L.mom6hip_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
+        L.mom6hip_free.argtypes = [C.c_void_p]
+        L.mom6hip_sync_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mom6hip_sync_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mom6hip_halo_update.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), C.c_int32]
+        L.mom6hip_advect_tracer.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+            C.POINTER(_abi.TracerAdvectCS), C.POINTER(C.c_void_p), _dp, C.c_int32, C.c_int32,
+            C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+            C.POINTER(_abi.AdvectStats)]
+        L.mom6hip_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        L.mom6hip_advect_get_timing.argtypes = [C.c_void_p, C.POINTER(_abi.AdvectTiming)]
+        for n in ("grid", "tracer_advect_cs", "advect_stats", "advect_timing"):
+            getattr(L, f"mom6hip_abi_sizeof_{n}").restype = C.c_uint64
+        L.mom6hip_abi_offsetof_grid_mask2dT.restype = C.c_uint64
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mom6hip_last_error().decode("utf-8", "replace")
+        raise Mom6HipError(f"{what}: {msg} (rc={rc})")

@@ -1,0 +1,81 @@
+// common.hpp -- context, error handling and index helpers shared by the libmom6hip sources.
+// gfx950 (MI355X) only.  All arithmetic is fp64 and the library is built with -ffp-contract=off so
+// that every expression is evaluated with the reference's explicit parenthesisation.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mom6hip.h"
+
+namespace m6 {
+
+// ---- errors --------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define M6_HIP(call)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      m6::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return 1;                                                                             \
+    }                                                                                       \
+  } while (0)
+
+#define M6_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      m6::set_error(__VA_ARGS__);        \
+      return 2;                          \
+    }                                    \
+  } while (0)
+
+// ---- device-side view of the grid -------------------------------------------------------------
+// Index ranges + device pointers to the metrics; passed to kernels by value.
+struct GridDev {
+  int isc, iec, jsc, jec, isd, ied, jsd, jed, nk;
+  int nih, njh;             // data-domain extents of h-point arrays
+  double Angstrom_H, H_subroundoff;
+  const double *areaT, *mask2dT, *mask2dCu, *mask2dCv;
+  const double *uh_neglect, *vh_neglect;   // derived: MOM_tracer_advect.F90:182-188
+  // linear offsets, Fortran indices, k zero-based
+  __host__ __device__ inline long h2(int i, int j) const { return (long)(i - isd) + (long)nih * (j - jsd); }
+  __host__ __device__ inline long u2(int I, int j) const { return (long)(I - isd + 1) + (long)(nih + 1) * (j - jsd); }
+  __host__ __device__ inline long v2(int i, int J) const { return (long)(i - isd) + (long)nih * (J - jsd + 1); }
+  __host__ __device__ inline long h3(int i, int j, int k) const { return h2(i, j) + (long)nih * njh * k; }
+  __host__ __device__ inline long u3(int I, int j, int k) const { return u2(I, j) + (long)(nih + 1) * njh * k; }
+  __host__ __device__ inline long v3(int i, int J, int k) const { return v2(i, J) + (long)nih * (njh + 1) * k; }
+  __host__ __device__ inline long nh3() const { return (long)nih * njh * nk; }
+  __host__ __device__ inline long nu3() const { return (long)(nih + 1) * njh * nk; }
+  __host__ __device__ inline long nv3() const { return (long)nih * (njh + 1) * nk; }
+};
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t n);
+  void release();
+};
+
+}  // namespace m6
+
+// The opaque context of the C ABI.
+struct mom6hip_ctx {
+  mom6hip_grid_t host;          // copy of the caller's struct (host metric pointers not retained)
+  m6::GridDev g;                // device view
+  hipStream_t stream = nullptr;
+  std::vector<void *> metric_allocs;
+  double *d_metric[64] = {};    // device copies in the order of the struct's pointer members
+
+  // advect_tracer work space (device)
+  m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
+  int *h_domore_k = nullptr;    // pinned host mirror of domore_k
+  // timing
+  bool timing = false;
+  mom6hip_advect_timing_t adv_timing = {};
+};

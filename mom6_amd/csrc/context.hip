@@ -1,0 +1,281 @@
+// context.hip -- library/context entry points of the C ABI and the single-tile halo update.
+#include <cstdarg>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace m6 {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int DevBuf::reserve(size_t n) {
+  if (n <= bytes) return 0;
+  if (p) {
+    if (hipFree(p) != hipSuccess) { set_error("hipFree failed"); return 1; }
+    p = nullptr; bytes = 0;
+  }
+  hipError_t e = hipMalloc(&p, n);
+  if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); p = nullptr; return 1; }
+  bytes = n;
+  return 0;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr; bytes = 0;
+}
+
+}  // namespace m6
+
+using m6::set_error;
+
+extern "C" {
+
+const char *mom6hip_last_error(void) { return m6::g_err.c_str(); }
+
+int mom6hip_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("mom6hip_init: no HIP device available (%s); libmom6hip has no CPU fallback",
+              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return 1;
+  }
+  M6_REQUIRE(device >= 0 && device < n, "mom6hip_init: device %d out of range (0..%d)", device, n - 1);
+  M6_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  M6_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("mom6hip_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return 1;
+  }
+  return 0;
+}
+
+int mom6hip_malloc(void **dptr, uint64_t bytes) {
+  M6_REQUIRE(dptr != nullptr, "mom6hip_malloc: null out pointer");
+  M6_HIP(hipMalloc(dptr, bytes));
+  return 0;
+}
+
+int mom6hip_free(void *dptr) {
+  M6_HIP(hipFree(dptr));
+  return 0;
+}
+
+int mom6hip_sync(mom6hip_ctx_t *ctx) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_sync: null context");
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mom6hip_sync_to_device(mom6hip_ctx_t *ctx, void *dptr, const void *hptr, uint64_t bytes) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_sync_to_device: null context");
+  M6_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint64_t bytes) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_sync_to_host: null context");
+  M6_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_set_timing: null context");
+  ctx->timing = enable != 0;
+  return 0;
+}
+
+// ABI self-description, used by tests to check the ctypes mirror.
+uint64_t mom6hip_abi_sizeof_grid(void) { return sizeof(mom6hip_grid_t); }
+uint64_t mom6hip_abi_sizeof_tracer_advect_cs(void) { return sizeof(mom6hip_tracer_advect_cs_t); }
+uint64_t mom6hip_abi_sizeof_advect_stats(void) { return sizeof(mom6hip_advect_stats_t); }
+uint64_t mom6hip_abi_sizeof_advect_timing(void) { return sizeof(mom6hip_advect_timing_t); }
+uint64_t mom6hip_abi_offsetof_grid_mask2dT(void) { return offsetof(mom6hip_grid_t, mask2dT); }
+
+static int upload2d(mom6hip_ctx_t *ctx, const double *h, size_t n, double **d) {
+  *d = nullptr;
+  if (!h) return 0;
+  void *p = nullptr;
+  M6_HIP(hipMalloc(&p, n * sizeof(double)));
+  ctx->metric_allocs.push_back(p);
+  M6_HIP(hipMemcpyAsync(p, h, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  *d = (double *)p;
+  return 0;
+}
+
+int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t **out) {
+  M6_REQUIRE(grid && out, "mom6hip_grid_create: null argument");
+  M6_REQUIRE(grid->symmetric == 1, "mom6hip_grid_create: only SYMMETRIC_MEMORY_ layouts are supported");
+  M6_REQUIRE(grid->isd <= grid->isc && grid->isc <= grid->iec && grid->iec <= grid->ied &&
+             grid->jsd <= grid->jsc && grid->jsc <= grid->jec && grid->jec <= grid->jed && grid->nk >= 1,
+             "mom6hip_grid_create: inconsistent index ranges");
+  M6_REQUIRE(grid->areaT != nullptr, "mom6hip_grid_create: areaT is required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("mom6hip_grid_create: no HIP device available; libmom6hip has no CPU fallback");
+    return 1;
+  }
+  mom6hip_ctx_t *ctx = new mom6hip_ctx();
+  ctx->host = *grid;
+  ctx->stream = (hipStream_t)stream;
+  const int nih = grid->ied - grid->isd + 1, njh = grid->jed - grid->jsd + 1;
+  const size_t nH = (size_t)nih * njh, nU = (size_t)(nih + 1) * njh, nV = (size_t)nih * (njh + 1),
+               nQ = (size_t)(nih + 1) * (njh + 1);
+  // pointer members in declaration order: 8 h, 8 u, 8 v, 6 q
+  const double *const *src = &grid->mask2dT;
+  int rc = 0;
+  for (int m = 0; m < 30 && rc == 0; m++) {
+    size_t n = m < 8 ? nH : (m < 16 ? nU : (m < 24 ? nV : nQ));
+    rc = upload2d(ctx, src[m], n, &ctx->d_metric[m]);
+  }
+  if (rc) { mom6hip_grid_destroy(ctx); return rc; }
+
+  m6::GridDev &g = ctx->g;
+  g.isc = grid->isc; g.iec = grid->iec; g.jsc = grid->jsc; g.jec = grid->jec;
+  g.isd = grid->isd; g.ied = grid->ied; g.jsd = grid->jsd; g.jed = grid->jed; g.nk = grid->nk;
+  g.nih = nih; g.njh = njh;
+  g.Angstrom_H = grid->Angstrom_H; g.H_subroundoff = grid->H_subroundoff;
+  g.mask2dT = ctx->d_metric[0]; g.areaT = ctx->d_metric[1];
+  g.mask2dCu = ctx->d_metric[8]; g.mask2dCv = ctx->d_metric[16];
+
+  // uh_neglect / vh_neglect, src/tracer/MOM_tracer_advect.F90:182-188 (a property of the grid)
+  {
+    std::vector<double> un(nU, 0.0), vn(nV, 0.0);
+    const double *aT = grid->areaT;
+    auto H2 = [&](int i, int j) { return (size_t)(i - grid->isd) + (size_t)nih * (j - grid->jsd); };
+    for (int j = grid->jsd; j <= grid->jed; j++)
+      for (int i = grid->isd; i <= grid->ied - 1; i++)
+        un[g.u2(i, j)] = grid->H_subroundoff * fmin(aT[H2(i, j)], aT[H2(i + 1, j)]);
+    for (int j = grid->jsd; j <= grid->jed - 1; j++)
+      for (int i = grid->isd; i <= grid->ied; i++)
+        vn[g.v2(i, j)] = grid->H_subroundoff * fmin(aT[H2(i, j)], aT[H2(i, j + 1)]);
+    double *d = nullptr;
+    rc = upload2d(ctx, un.data(), nU, &d); g.uh_neglect = d;
+    if (!rc) { rc = upload2d(ctx, vn.data(), nV, &d); g.vh_neglect = d; }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("grid upload failed"); rc = 1; }
+    if (rc) { mom6hip_grid_destroy(ctx); return rc; }
+  }
+  if (hipHostMalloc((void **)&ctx->h_domore_k, sizeof(int) * (size_t)(grid->nk + 1), hipHostMallocDefault) != hipSuccess) {
+    set_error("hipHostMalloc failed"); mom6hip_grid_destroy(ctx); return 1;
+  }
+  *out = ctx;
+  return 0;
+}
+
+int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
+  if (!ctx) return 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (void *p : ctx->metric_allocs) (void)hipFree(p);
+  ctx->hprev.release(); ctx->uhr.release(); ctx->vhr.release(); ctx->flags.release();
+  for (auto &b : ctx->stage) b.release();
+  for (auto &b : ctx->tr_stage) b.release();
+  if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
+  delete ctx;
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- halo update ---------------------------------------------------------------------------------
+// One launch fills both re-entrant directions of one field: x wrap for the rows of the compute
+// domain, then (a second launch, because it reads what the first wrote) the y wrap over full rows.
+namespace {
+
+struct HaloDesc {
+  double *f;
+  int ilo, jlo;        // first allocated index in i, j
+  int nis, njs, nk;    // allocated extents
+  int ics, ice, jcs, jce, ni, nj, ihi, jhi;
+};
+
+__global__ void halo_x_kernel(HaloDesc d) {
+  // threads over (halo column index h, j in compute rows, k)
+  const int nwl = d.ics - d.ilo, nwr = d.ihi - d.ice;       // widths of the west / east halos
+  const int nw = nwl + nwr;
+  const long total = (long)nw * (d.jce - d.jcs + 1) * d.nk;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int h = (int)(t % nw);
+    long r = t / nw;
+    int j = d.jcs + (int)(r % (d.jce - d.jcs + 1));
+    int k = (int)(r / (d.jce - d.jcs + 1));
+    int i, src;
+    if (h < nwl) { i = d.ilo + h; src = i + d.ni; } else { i = d.ice + 1 + (h - nwl); src = i - d.ni; }
+    long base = (long)d.nis * ((long)(j - d.jlo) + (long)d.njs * k);
+    d.f[base + (i - d.ilo)] = d.f[base + (src - d.ilo)];
+  }
+}
+
+__global__ void halo_y_kernel(HaloDesc d) {
+  const int nws = d.jcs - d.jlo, nwn = d.jhi - d.jce;
+  const int nw = nws + nwn;
+  const long total = (long)d.nis * nw * d.nk;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int ii = (int)(t % d.nis);
+    long r = t / d.nis;
+    int h = (int)(r % nw);
+    int k = (int)(r / nw);
+    int j, src;
+    if (h < nws) { j = d.jlo + h; src = j + d.nj; } else { j = d.jce + 1 + (h - nws); src = j - d.nj; }
+    long kb = (long)d.nis * d.njs * k;
+    d.f[kb + (long)d.nis * (j - d.jlo) + ii] = d.f[kb + (long)d.nis * (src - d.jlo) + ii];
+  }
+}
+
+}  // namespace
+
+namespace m6 {
+
+// Enqueue the halo fill of one device field (see oracle/domains.c for the semantics).
+int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
+  const mom6hip_grid_t &G = ctx->host;
+  if (!G.reentrant_x && !G.reentrant_y) return 0;
+  const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0;
+  const int ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
+  HaloDesc d;
+  d.f = f; d.ilo = G.isd - xs; d.jlo = G.jsd - ys; d.ihi = G.ied; d.jhi = G.jed;
+  d.nis = d.ihi - d.ilo + 1; d.njs = d.jhi - d.jlo + 1; d.nk = nk;
+  d.ics = G.isc - xs; d.ice = G.iec; d.jcs = G.jsc - ys; d.jce = G.jec;
+  d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1;
+  if (G.reentrant_x) {
+    long total = (long)((d.ics - d.ilo) + (d.ihi - d.ice)) * (d.jce - d.jcs + 1) * nk;
+    if (total > 0) {
+      int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(halo_x_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d);
+    }
+  }
+  if (G.reentrant_y) {
+    long total = (long)d.nis * ((d.jcs - d.jlo) + (d.jhi - d.jce)) * nk;
+    if (total > 0) {
+      int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(halo_y_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d);
+    }
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace m6
+
+extern "C" int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,
+                                   const int32_t *nk_each, int32_t nfields) {
+  M6_REQUIRE(ctx && fields && pos && nk_each, "mom6hip_halo_update: null argument");
+  for (int f = 0; f < nfields; f++) {
+    M6_REQUIRE(fields[f] != nullptr, "mom6hip_halo_update: field %d is null", f);
+    int rc = m6::halo_update_field(ctx, fields[f], pos[f], nk_each[f]);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,824 @@
+// tracer_advect.hip -- advect_tracer / advect_x / advect_y (src/tracer/MOM_tracer_advect.F90:52-1087)
+// as gfx950 stencil kernels.
+//
+// Design (DESIGN.md "advect_tracer"):
+//  * Everything is updated IN PLACE, like the reference, so an extra iteration or an inactive
+//    row/layer costs no copy traffic.  In-place is made race-free by the thread mapping:
+//      - advect_x: one 64-lane wavefront owns one (j,k) row and sweeps it west->east in 64-cell
+//        chunks.  A wave-private LDS tile keeps the pre-update values of the chunk plus a 3-cell halo
+//        on both sides (the left halo is carried over from the previous chunk, the right halo is read
+//        before anything to its east is written), so every stencil operand is the reference's
+//        "T_tmp"/old hprev/old uhr.  West-face fluxes come from the neighbouring lane by a wavefront
+//        shuffle.  No __syncthreads anywhere.
+//      - advect_y: one lane owns one i column of a layer and marches south->north with the j stencil
+//        in a register ring (rows J-1..J+3); a row is written only after every row the stencil needs
+//        has been read by the same lane.  All loads/stores are i-contiguous (512 B per wave).
+//  * Algorithmic traffic per pass = read+write of Tr(ntr), hprev and the remaining transport:
+//    (ntr+2)*16 B per cell; unchanged values (land, inactive faces) are not written back.
+//  * domore_u/domore_v/domore_k stay on the device; only domore_k (nk ints) is read back per
+//    iteration for the exit test (the reference's sum_across_PEs at :305).
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace m6 { int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk); }
+
+namespace {
+
+constexpr int MAXG = 4;      // tracers processed per kernel instance (register budget)
+constexpr int XHALO = 3;     // i-halo of the advect_x tile (Colella-Woodward PPM needs 3)
+constexpr int XTW = 64 + 2 * XHALO;
+
+enum { PLM = MOM6HIP_ADV_PLM, H3 = MOM6HIP_ADV_PPM_H3, CW = MOM6HIP_ADV_PPM };
+
+struct AdvArgs {
+  m6::GridDev g;
+  double *tr[MAXG];
+  double cu[MAXG];           // conc_underflow
+  double *hprev, *uhr, *vhr;
+  int *domore_u;             // (jsd:jed, nk)
+  int *domore_v_in;          // (jsd-1:jed, nk), state on entry
+  int *domore_v_out;         // state on exit
+  const int *domore_k;       // (nk)
+  int is, ie, js, je;        // the reference's advect_x/advect_y range arguments
+  int write_mass;            // 1: this tracer group also updates hprev / uhr|vhr / domore flags
+  int any_cu;                // any conc_underflow > 0 in this group
+};
+
+// Orders this wave's LDS traffic: the hardware executes one wave's LDS instructions in order, so
+// all that is needed is to stop the compiler from moving loads/stores across this point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
+__device__ __forceinline__ double min3(double a, double b, double c) { return fmin(fmin(a, b), c); }
+
+// limited slope, MOM_tracer_advect.F90:427-431 / :809-813
+__device__ __forceinline__ double plm_slope(double Tp, double Tc, double Tm, double mask) {
+  double dMx = max3(Tp, Tc, Tm) - Tc;
+  double dMn = Tc - min3(Tp, Tc, Tm);
+  return mask * copysign(min3(0.5 * fabs(Tp - Tm), 2.0 * dMx, 2.0 * dMn), Tp - Tm);
+}
+
+// Flux limiting of the remaining transport through one face, :486-513 / :872-899.
+//   r_c      remaining transport through this face (positive towards +i / +j)
+//   r_m, r_p remaining transport through the faces on the minus / plus side
+//   h_m, h_p volumes of the cells on the minus / plus side;  a_m, a_p their areas
+__device__ __forceinline__ void face_transport(double r_c, double r_m, double r_p, double h_m, double h_p,
+                                               double a_m, double a_p, double min_h, double &hh,
+                                               double &CFL, bool &limited) {
+  const double tiny_h = DBL_MIN;
+  limited = false;
+  if ((r_c == 0.0) || ((r_c < 0.0) && (h_p <= tiny_h)) || ((r_c > 0.0) && (h_m <= tiny_h))) {
+    hh = 0.0; CFL = 0.0;
+  } else if (r_c < 0.0) {
+    double hup = h_p - a_p * min_h;
+    double hlos = fmax(0.0, r_p);
+    if ((((hup - hlos) + r_c) < 0.0) && ((0.5 * hup + r_c) < 0.0)) {
+      hh = min3(-0.5 * hup, -hup + hlos, 0.0);
+      limited = true;
+    } else {
+      hh = r_c;
+    }
+    CFL = -hh / h_p;
+  } else {
+    double hup = h_m - a_m * min_h;
+    double hlos = fmax(0.0, -r_m);
+    if ((((hup - hlos) - r_c) < 0.0) && ((0.5 * hup - r_c) < 0.0)) {
+      hh = max3(0.5 * hup, hup - hlos, 0.0);
+      limited = true;
+    } else {
+      hh = r_c;
+    }
+    CFL = hh / h_m;
+  }
+}
+
+// PPM edge values, CW84 monotonicity and the CFL-integrated flux, :526-556 / :911-941
+template <int SCHEME>
+__device__ __forceinline__ double ppm_flux(double Tp, double Tc, double Tm, double sm, double sc, double sp,
+                                           double mask_prod, double hh, double CFL) {
+  double aL, aR;
+  if (SCHEME == H3) {
+    aL = (5. * Tc + (2. * Tm - Tp)) / 6.;
+    aL = fmax(fmin(Tc, Tm), aL); aL = fmin(fmax(Tc, Tm), aL);
+    aR = (5. * Tc + (2. * Tp - Tm)) / 6.;
+    aR = fmax(fmin(Tc, Tp), aR); aR = fmin(fmax(Tc, Tp), aR);
+  } else {
+    aL = 0.5 * ((Tm + Tc) + (sm - sc) / 3.);
+    aR = 0.5 * ((Tc + Tp) + (sc - sp) / 3.);
+  }
+  double dA = aR - aL, mA = 0.5 * (aR + aL);
+  if (mask_prod * (Tp - Tc) * (Tc - Tm) <= 0.) {
+    aL = Tc; aR = Tc;
+  } else if (dA * (Tc - mA) > (dA * dA) / 6.) {
+    aL = 3. * Tc - 2. * aR;
+  } else if (dA * (Tc - mA) < -(dA * dA) / 6.) {
+    aR = 3. * Tc - 2. * aL;
+  }
+  double a6 = 6. * Tc - 3. * (aR + aL);
+  if (hh >= 0.0)
+    return hh * (aR - 0.5 * CFL * ((aR - aL) - a6 * (1. - 2. / 3. * CFL)));
+  else
+    return hh * (aL + 0.5 * CFL * ((aR - aL) + a6 * (1. - 2. / 3. * CFL)));
+}
+
+// New cell volume and the factors of the tracer update, :637-648 (x) / :1030-1039 (y).
+template <bool CLAMP0>
+__device__ __forceinline__ bool cell_volume(double hh_p, double hh_m, double h_old, double areaT,
+                                            double h_neglect, double &h_new, double &hlst, double &Ihnew) {
+  // returns do_i
+  if ((hh_p != 0.0) || (hh_m != 0.0)) {
+    hlst = h_old;
+    h_new = h_old - (hh_p - hh_m);
+    if (CLAMP0) h_new = fmax(h_new, 0.0);
+    if (h_new <= 0.0) { Ihnew = 0.0; return false; }
+    else if (h_new < h_neglect * areaT) {
+      hlst = hlst + (h_neglect * areaT - h_new);
+      Ihnew = 1.0 / (h_neglect * areaT);
+    } else {
+      Ihnew = 1.0 / h_new;
+    }
+    return true;
+  }
+  h_new = h_old; hlst = h_old; Ihnew = 0.0;
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// setup: uhr, vhr, hprev   (:152-178)
+__global__ __launch_bounds__(256) void adv_setup_kernel(m6::GridDev g, const double *__restrict__ h_end,
+                                                        const double *__restrict__ uhtr,
+                                                        const double *__restrict__ vhtr,
+                                                        const double *__restrict__ vol_prev,
+                                                        double *__restrict__ hprev, double *__restrict__ uhr,
+                                                        double *__restrict__ vhr) {
+  // thread <-> (I, J) over the q-point extent (isd-1:ied, jsd-1:jed), which covers every array
+  const int I = g.isd - 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int J = g.jsd - 1 + blockIdx.y;
+  const int k = blockIdx.z;
+  if (I > g.ied) return;
+  const bool in_i = (I >= g.isc && I <= g.iec), in_j = (J >= g.jsc && J <= g.jec);
+  if (J >= g.jsd) {   // u-point (I, j=J)
+    double v = 0.0;
+    if (in_j && I >= g.isc - 1 && I <= g.iec) v = uhtr[g.u3(I, J, k)];
+    uhr[g.u3(I, J, k)] = v;
+  }
+  if (I >= g.isd) {   // v-point (i=I, J)
+    double v = 0.0;
+    if (in_i && J >= g.jsc - 1 && J <= g.jec) v = vhtr[g.v3(I, J, k)];
+    vhr[g.v3(I, J, k)] = v;
+  }
+  if (I >= g.isd && J >= g.jsd) {   // h-point
+    double hp = 0.0;
+    if (in_i && in_j) {
+      if (vol_prev) {
+        hp = vol_prev[g.h3(I, J, k)];
+      } else {
+        const double aT = g.areaT[g.h2(I, J)], he = h_end[g.h3(I, J, k)];
+        hp = fmax(0.0, aT * he + ((uhtr[g.u3(I, J, k)] - uhtr[g.u3(I - 1, J, k)]) +
+                                  (vhtr[g.v3(I, J, k)] - vhtr[g.v3(I, J - 1, k)])));
+        hp = hp + fmax(0.0, 1.0e-13 * hp - aT * he);
+      }
+    }
+    hprev[g.h3(I, J, k)] = hp;
+  }
+}
+
+// domore_u / domore_v re-evaluation, :215-225.  One block per (row, k).
+struct ScanArgs {
+  m6::GridDev g;
+  const double *uhr, *vhr;
+  int *domore_u, *domore_v;
+  const int *domore_k;
+  int ju0, ju1, iu0, iu1;   // u rows j and the I range scanned
+  int jv0, jv1, iv0, iv1;   // v rows J and the i range scanned
+};
+
+__global__ __launch_bounds__(256) void adv_scan_kernel(ScanArgs a) {
+  const m6::GridDev &g = a.g;
+  const int k = blockIdx.y;
+  if (a.domore_k[k] <= 0) return;
+  const int r = blockIdx.x;            // row index over (jsd-1 : jed)
+  // u row j = jsd-1+r
+  {
+    const int j = g.jsd - 1 + r;
+    if (j >= a.ju0 && j <= a.ju1 && j >= g.jsd) {
+      int *flag = &a.domore_u[(j - g.jsd) + g.njh * k];
+      if (!*flag) {
+        for (int I0 = a.iu0; I0 <= a.iu1; I0 += blockDim.x) {
+          const int I = I0 + threadIdx.x;
+          int nz = (I <= a.iu1) && (a.uhr[g.u3(I, j, k)] != 0.0);
+          if (__syncthreads_or(nz)) { if (threadIdx.x == 0) *flag = 1; break; }
+        }
+      }
+    }
+  }
+  {
+    const int J = g.jsd - 1 + r;
+    if (J >= a.jv0 && J <= a.jv1) {
+      int *flag = &a.domore_v[(J - g.jsd + 1) + (g.njh + 1) * k];
+      if (!*flag) {
+        for (int i0 = a.iv0; i0 <= a.iv1; i0 += blockDim.x) {
+          const int i = i0 + threadIdx.x;
+          int nz = (i <= a.iv1) && (a.vhr[g.v3(i, J, k)] != 0.0);
+          if (__syncthreads_or(nz)) { if (threadIdx.x == 0) *flag = 1; break; }
+        }
+      }
+    }
+  }
+}
+
+// domore_k(k) = any(domore_u(ju0:ju1,k)) .or. any(domore_v(jv0:jv1,k)), only where domore_k(k) > 0
+// (:229-231, :265-267, :287-289).  One wave per k.
+__global__ void adv_domore_k_kernel(m6::GridDev g, const int *domore_u, const int *domore_v, int *domore_k,
+                                    int ju0, int ju1, int jv0, int jv1) {
+  const int k = blockIdx.x;
+  if (domore_k[k] <= 0) return;
+  int any = 0;
+  for (int j = ju0 + threadIdx.x; j <= ju1; j += blockDim.x) any |= domore_u[(j - g.jsd) + g.njh * k];
+  for (int J = jv0 + threadIdx.x; J <= jv1; J += blockDim.x) any |= domore_v[(J - g.jsd + 1) + (g.njh + 1) * k];
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) domore_k[k] = any ? 1 : 0;
+}
+
+// domore_v_out = domore_v_in, except that rows advect_y is about to process are cleared (:869).
+__global__ void adv_vflags_prep_kernel(m6::GridDev g, const int *in, int *out, const int *domore_k, int js, int je) {
+  const int n = (g.njh + 1) * g.nk;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int k = t / (g.njh + 1);
+    const int J = g.jsd - 1 + (t - k * (g.njh + 1));
+    int v = in[t];
+    if (domore_k[k] > 0 && J >= js - 1 && J <= je) v = 0;
+    out[t] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// advect_x: one wavefront per (j,k) row.
+template <int NT, int SCHEME>
+__global__ __launch_bounds__(256) void adv_x_kernel(AdvArgs p) {
+  const m6::GridDev &g = p.g;
+  __shared__ double s_T[4][NT][XTW];
+  __shared__ double s_h[4][XTW];
+  __shared__ double s_u[4][XTW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.y;
+  const int j = p.js + blockIdx.x * 4 + wave;
+  if (j > p.je) return;
+  if (p.domore_k[k] <= 0) return;
+  int *flag = &p.domore_u[(j - g.jsd) + g.njh * k];
+  const bool active = (*flag != 0);
+  if (!active && !p.any_cu) return;
+
+  const double min_h = 0.1 * g.Angstrom_H;
+  const double h_neglect = g.H_subroundoff;
+  const long rowH = g.h3(g.isd, j, k);          // offset of (isd, j, k) in h-point arrays
+  const long rowU = g.u3(g.isd, j, k);          // offset of face I = isd
+  const long row2H = g.h2(g.isd, j), row2U = g.u2(g.isd, j);
+
+  if (!active) {
+    // only the user-controlled underflow applies to this row (:683-687)
+    for (int i = p.is + lane; i <= p.ie; i += 64) {
+#pragma unroll
+      for (int m = 0; m < NT; m++) if (p.cu[m] > 0.0) {
+        double t = p.tr[m][rowH + (i - g.isd)];
+        if (fabs(t) < p.cu[m] && t != 0.0) p.tr[m][rowH + (i - g.isd)] = 0.0;
+      }
+    }
+    return;
+  }
+
+  double(*sT)[XTW] = s_T[wave];
+  double *sh = s_h[wave], *su = s_u[wave];
+
+  // chunks are aligned to the start of the array row
+  const int c0 = (p.is - 1 - g.isd) >> 6, c1 = (p.ie - g.isd) >> 6;
+  auto ldH = [&](const double *a, int i) -> double { return (i >= g.isd && i <= g.ied) ? a[rowH + (i - g.isd)] : 0.0; };
+  auto ldU = [&](const double *a, int I) -> double { return (I >= g.isd - 1 && I <= g.ied) ? a[rowU + (I - g.isd)] : 0.0; };
+
+  // first tile: cells i0-XHALO .. i0+63+XHALO
+  {
+    const int i0 = g.isd + 64 * c0;
+    for (int q = lane; q < XTW; q += 64) {
+      const int i = i0 - XHALO + q;
+#pragma unroll
+      for (int m = 0; m < NT; m++) sT[m][q] = ldH(p.tr[m], i);
+      sh[q] = ldH(p.hprev, i);
+      su[q] = ldU(p.uhr, i);
+    }
+  }
+  double hh_carry = 0.0, fl_carry[NT];
+#pragma unroll
+  for (int m = 0; m < NT; m++) fl_carry[m] = 0.0;
+  bool any_limited = false;
+
+  for (int c = c0; c <= c1; c++) {
+    const int i0 = g.isd + 64 * c;
+    const int i = i0 + lane;                 // this lane's cell, and its east face I = i
+    const int P = XHALO + lane;
+    // prefetch the part of the next tile that is not already in LDS: cells i0+64+XHALO+lane
+    double nT[NT], nh = 0.0, nu = 0.0;
+    const bool more = (c < c1);
+    if (more) {
+      const int in = i0 + 64 + XHALO + lane;
+#pragma unroll
+      for (int m = 0; m < NT; m++) nT[m] = ldH(p.tr[m], in);
+      nh = ldH(p.hprev, in);
+      nu = ldU(p.uhr, in);
+    }
+    wave_sync();
+
+    const bool face_ok = (i >= p.is - 1 && i <= p.ie);
+    const bool cell_ok = (i >= p.is && i <= p.ie);
+    double hh = 0.0, CFL = 0.0, flux[NT];
+#pragma unroll
+    for (int m = 0; m < NT; m++) flux[m] = 0.0;
+    const double u_c = su[P];
+    const double h_c = sh[P];
+    double aT_c = 0.0;
+    if (face_ok) {
+      aT_c = g.areaT[row2H + (i - g.isd)];
+      const double aT_e = g.areaT[row2H + (i + 1 - g.isd)];
+      bool lim;
+      face_transport(u_c, su[P - 1], su[P + 1], h_c, sh[P + 1], aT_c, aT_e, min_h, hh, CFL, lim);
+      any_limited |= lim;
+      const int up = (hh >= 0.0) ? 0 : 1;        // i_up = i + up
+      const int Pu = P + up;
+      if (SCHEME == PLM) {
+        const double mk = g.mask2dCu[row2U + (i + up - g.isd)] * g.mask2dCu[row2U + (i + up - 1 - g.isd)];
+#pragma unroll
+        for (int m = 0; m < NT; m++) {
+          const double Tc = sT[m][Pu];
+          const double sl = plm_slope(sT[m][Pu + 1], Tc, sT[m][Pu - 1], mk);
+          if (hh >= 0.0) flux[m] = hh * (Tc + 0.5 * sl * (1. - CFL));
+          else           flux[m] = hh * (Tc - 0.5 * sl * (1. - CFL));
+        }
+      } else {
+        const double mk_c = g.mask2dCu[row2U + (i + up - g.isd)] * g.mask2dCu[row2U + (i + up - 1 - g.isd)];
+        double mk_m = 0.0, mk_p = 0.0;
+        if (SCHEME == CW) {
+          mk_m = g.mask2dCu[row2U + (i + up - 1 - g.isd)] * g.mask2dCu[row2U + (i + up - 2 - g.isd)];
+          mk_p = g.mask2dCu[row2U + (i + up + 1 - g.isd)] * g.mask2dCu[row2U + (i + up - g.isd)];
+        }
+#pragma unroll
+        for (int m = 0; m < NT; m++) {
+          const double Tp = sT[m][Pu + 1], Tc = sT[m][Pu], Tm = sT[m][Pu - 1];
+          double sm = 0., sc = 0., sp = 0.;
+          if (SCHEME == CW) {
+            sm = plm_slope(Tc, Tm, sT[m][Pu - 2], mk_m);
+            sc = plm_slope(Tp, Tc, Tm, mk_c);
+            sp = plm_slope(sT[m][Pu + 2], Tp, Tc, mk_p);
+          }
+          flux[m] = ppm_flux<SCHEME>(Tp, Tc, Tm, sm, sc, sp, mk_c, hh, CFL);
+        }
+      }
+    }
+    // west-face values from the neighbouring lane (lane 0: carried from the previous chunk)
+    double hh_w = __shfl_up(hh, 1);
+    if (lane == 0) hh_w = hh_carry;
+    double fl_w[NT];
+#pragma unroll
+    for (int m = 0; m < NT; m++) {
+      fl_w[m] = __shfl_up(flux[m], 1);
+      if (lane == 0) fl_w[m] = fl_carry[m];
+    }
+    hh_carry = __shfl(hh, 63);
+#pragma unroll
+    for (int m = 0; m < NT; m++) fl_carry[m] = __shfl(flux[m], 63);
+
+    // remaining transport, :632-635
+    if (face_ok && p.write_mass) {
+      double u_new = u_c - hh;
+      if (fabs(u_new) < g.uh_neglect[row2U + (i - g.isd)]) u_new = 0.0;
+      if (u_new != u_c) p.uhr[rowU + (i - g.isd)] = u_new;
+    }
+    // cell volume and tracers, :636-662, and underflow :683-687
+    if (cell_ok) {
+      double h_new, hlst, Ihnew;
+      const bool do_i = cell_volume<false>(hh, hh_w, h_c, aT_c, h_neglect, h_new, hlst, Ihnew);
+      if (p.write_mass && h_new != h_c) p.hprev[rowH + (i - g.isd)] = h_new;
+#pragma unroll
+      for (int m = 0; m < NT; m++) {
+        const double t_old = sT[m][P];
+        double t_new = t_old;
+        if (do_i && Ihnew > 0.0) t_new = (t_old * hlst - (flux[m] - fl_w[m])) * Ihnew;
+        if (p.cu[m] > 0.0 && fabs(t_new) < p.cu[m]) t_new = 0.0;
+        if (t_new != t_old) p.tr[m][rowH + (i - g.isd)] = t_new;
+      }
+    }
+    wave_sync();
+    // slide the tile east by 64 cells
+    if (more) {
+      double kT[NT], kh = 0.0, ku = 0.0;
+      if (lane < 2 * XHALO) {
+#pragma unroll
+        for (int m = 0; m < NT; m++) kT[m] = sT[m][64 + lane];
+        kh = sh[64 + lane]; ku = su[64 + lane];
+      }
+      wave_sync();
+      if (lane < 2 * XHALO) {
+#pragma unroll
+        for (int m = 0; m < NT; m++) sT[m][lane] = kT[m];
+        sh[lane] = kh; su[lane] = ku;
+      }
+#pragma unroll
+      for (int m = 0; m < NT; m++) sT[m][2 * XHALO + lane] = nT[m];
+      sh[2 * XHALO + lane] = nh; su[2 * XHALO + lane] = nu;
+    }
+  }
+  if (p.write_mass) {
+    const int lim = __any(any_limited ? 1 : 0);
+    if (lane == 0) *flag = lim ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// advect_y: one lane per (i,k) column, marching J = js-1 .. je.
+template <int NT, int SCHEME>
+__global__ __launch_bounds__(64) void adv_y_kernel(AdvArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = p.is + blockIdx.x * 64 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (p.domore_k[k] <= 0) return;
+  const bool lane_ok = (i <= p.ie);
+  const int ii = lane_ok ? i : p.ie;           // inactive lanes shadow a valid column, never store
+  const double min_h = 0.1 * g.Angstrom_H;
+  const double h_neglect = g.H_subroundoff;
+  const long colH = g.h3(ii, g.jsd, k), colV = g.v3(ii, g.jsd, k);
+  const long col2H = g.h2(ii, g.jsd), col2V = g.v2(ii, g.jsd);
+  const int sH = g.nih;                        // j stride of h- and v-point arrays
+  auto ldH = [&](const double *a, int j) -> double { return (j >= g.jsd && j <= g.jed) ? a[colH + (long)sH * (j - g.jsd)] : 0.0; };
+  auto ldV = [&](const double *a, int J) -> double { return (J >= g.jsd - 1 && J <= g.jed) ? a[colV + (long)sH * (J - g.jsd)] : 0.0; };
+  auto ldA = [&](int j) -> double { return (j >= g.jsd && j <= g.jed) ? g.areaT[col2H + (long)sH * (j - g.jsd)] : 0.0; };
+  auto ldM = [&](int J) -> double { return (J >= g.jsd - 1 && J <= g.jed) ? g.mask2dCv[col2V + (long)sH * (J - g.jsd)] : 0.0; };
+  const int *dv_in = p.domore_v_in + (long)(g.njh + 1) * k - (g.jsd - 1);
+  int *dv_out = p.domore_v_out + (long)(g.njh + 1) * k - (g.jsd - 1);
+
+  const int J0 = p.js - 1, J1 = p.je;
+  // rings at step J: T rows J-2..J+3 (t0..t5), hprev rows J, J+1, vhr rows J-1..J+1,
+  // areaT rows J, J+1, mask2dCv rows J-2..J+2
+  double t0[NT], t1[NT], t2[NT], t3[NT], t4[NT], t5[NT];
+#pragma unroll
+  for (int m = 0; m < NT; m++) {
+    t0[m] = (SCHEME == CW) ? ldH(p.tr[m], J0 - 2) : 0.0;
+    t1[m] = ldH(p.tr[m], J0 - 1); t2[m] = ldH(p.tr[m], J0); t3[m] = ldH(p.tr[m], J0 + 1);
+    t4[m] = ldH(p.tr[m], J0 + 2);
+    t5[m] = (SCHEME == CW) ? ldH(p.tr[m], J0 + 3) : 0.0;
+  }
+  double h_c = ldH(p.hprev, J0), h_n = ldH(p.hprev, J0 + 1);
+  double v_s = ldV(p.vhr, J0 - 1), v_c = ldV(p.vhr, J0), v_n = ldV(p.vhr, J0 + 1);
+  double a_c = ldA(J0), a_n = ldA(J0 + 1);
+  double m_ss = (SCHEME == CW) ? ldM(J0 - 2) : 0.0, m_s = ldM(J0 - 1), m_c = ldM(J0), m_n = ldM(J0 + 1);
+  double m_nn = (SCHEME == CW) ? ldM(J0 + 2) : 0.0;
+  double hh_prev = 0.0, fl_prev[NT];
+#pragma unroll
+  for (int m = 0; m < NT; m++) fl_prev[m] = 0.0;
+
+  for (int J = J0; J <= J1; J++) {
+    const int j = J;
+    // issue the loads of the rows that enter the rings at the next step
+    double nt[NT];
+#pragma unroll
+    for (int m = 0; m < NT; m++) nt[m] = ldH(p.tr[m], (SCHEME == CW) ? J + 4 : J + 3);
+    const double nh = ldH(p.hprev, J + 2), nv = ldV(p.vhr, J + 2), na = ldA(J + 2);
+    const double nm = ldM((SCHEME == CW) ? J + 3 : J + 2);
+
+    const bool act = dv_in[J] != 0;
+    double hh = 0.0, CFL = 0.0, flux[NT];
+#pragma unroll
+    for (int m = 0; m < NT; m++) flux[m] = 0.0;
+    if (act) {
+      bool lim;
+      face_transport(v_c, v_s, v_n, h_c, h_n, a_c, a_n, min_h, hh, CFL, lim);
+      if (p.write_mass && __any((lim && lane_ok) ? 1 : 0) && threadIdx.x == 0) dv_out[J] = 1;
+      const bool up = !(hh >= 0.0);              // j_up = j + up
+      // masks mask2dCv(i,J_up)*mask2dCv(i,J_up-1) of the rows j_up-1, j_up, j_up+1
+      const double mk_c = up ? (m_n * m_c) : (m_c * m_s);
+#pragma unroll
+      for (int m = 0; m < NT; m++) {
+        const double Tm = up ? t2[m] : t1[m], Tc = up ? t3[m] : t2[m], Tp = up ? t4[m] : t3[m];
+        if (SCHEME == PLM) {
+          const double sl = plm_slope(Tp, Tc, Tm, mk_c);
+          if (hh >= 0.0) flux[m] = hh * (Tc + 0.5 * sl * (1. - CFL));
+          else           flux[m] = hh * (Tc - 0.5 * sl * (1. - CFL));
+        } else {
+          double sm = 0., sc = 0., sp = 0.;
+          if (SCHEME == CW) {
+            const double Tmm = up ? t1[m] : t0[m], Tpp = up ? t5[m] : t4[m];
+            const double mk_m = up ? (m_c * m_s) : (m_s * m_ss);
+            const double mk_p = up ? (m_nn * m_n) : (m_n * m_c);
+            sm = plm_slope(Tc, Tm, Tmm, mk_m);
+            sc = plm_slope(Tp, Tc, Tm, mk_c);
+            sp = plm_slope(Tpp, Tp, Tc, mk_p);
+          }
+          flux[m] = ppm_flux<SCHEME>(Tp, Tc, Tm, sm, sc, sp, mk_c, hh, CFL);
+        }
+      }
+    }
+    // remaining transport, :1021-1024 (every row J, active or not)
+    if (p.write_mass && lane_ok) {
+      double v_new = v_c - hh;
+      if (fabs(v_new) < g.vh_neglect[col2V + (long)sH * (J - g.jsd)]) v_new = 0.0;
+      if (v_new != v_c) p.vhr[colV + (long)sH * (J - g.jsd)] = v_new;
+    }
+    // cell j = J, :1028-1059, and underflow :1062-1066
+    if (J >= p.js && lane_ok) {
+      double h_new, hlst, Ihnew;
+      const bool do_i = cell_volume<true>(hh, hh_prev, h_c, a_c, h_neglect, h_new, hlst, Ihnew);
+      if (p.write_mass && h_new != h_c) p.hprev[colH + (long)sH * (j - g.jsd)] = h_new;
+#pragma unroll
+      for (int m = 0; m < NT; m++) {
+        const double t_old = t2[m];
+        double t_new = t_old;
+        if (do_i) t_new = (t_old * hlst - (flux[m] - fl_prev[m])) * Ihnew;
+        if (p.cu[m] > 0.0 && fabs(t_new) < p.cu[m]) t_new = 0.0;
+        if (t_new != t_old) p.tr[m][colH + (long)sH * (j - g.jsd)] = t_new;
+      }
+    }
+    // advance the rings
+    hh_prev = hh;
+#pragma unroll
+    for (int m = 0; m < NT; m++) {
+      fl_prev[m] = flux[m];
+      t0[m] = t1[m]; t1[m] = t2[m]; t2[m] = t3[m]; t3[m] = t4[m];
+      if (SCHEME == CW) { t4[m] = t5[m]; t5[m] = nt[m]; } else { t4[m] = nt[m]; }
+    }
+    h_c = h_n; h_n = nh;
+    v_s = v_c; v_c = v_n; v_n = nv;
+    a_c = a_n; a_n = na;
+    m_ss = m_s; m_s = m_c; m_c = m_n;
+    if (SCHEME == CW) { m_n = m_nn; m_nn = nm; } else { m_n = nm; }
+  }
+}
+
+template <int NT>
+void launch_x(int scheme, dim3 grid, hipStream_t s, const AdvArgs &a) {
+  switch (scheme) {
+    case PLM: hipLaunchKernelGGL((adv_x_kernel<NT, PLM>), grid, dim3(256), 0, s, a); break;
+    case H3:  hipLaunchKernelGGL((adv_x_kernel<NT, H3>), grid, dim3(256), 0, s, a); break;
+    default:  hipLaunchKernelGGL((adv_x_kernel<NT, CW>), grid, dim3(256), 0, s, a); break;
+  }
+}
+template <int NT>
+void launch_y(int scheme, dim3 grid, hipStream_t s, const AdvArgs &a) {
+  switch (scheme) {
+    case PLM: hipLaunchKernelGGL((adv_y_kernel<NT, PLM>), grid, dim3(64), 0, s, a); break;
+    case H3:  hipLaunchKernelGGL((adv_y_kernel<NT, H3>), grid, dim3(64), 0, s, a); break;
+    default:  hipLaunchKernelGGL((adv_y_kernel<NT, CW>), grid, dim3(64), 0, s, a); break;
+  }
+}
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on = false;
+  hipStream_t s;
+  Timer(bool enable, hipStream_t st) : on(enable), s(st) {
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+  }
+  ~Timer() { if (on) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+  void start() { if (on) (void)hipEventRecord(a, s); }
+  // returns ms; synchronises (timing mode only)
+  double stop() {
+    if (!on) return 0.0;
+    (void)hipEventRecord(b, s); (void)hipEventSynchronize(b);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+  }
+};
+
+}  // namespace
+
+extern "C" int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t) {
+  M6_REQUIRE(ctx && t, "mom6hip_advect_get_timing: null argument");
+  *t = ctx->adv_timing;
+  return 0;
+}
+
+extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, const double *uhtr,
+                                     const double *vhtr, double dt, const mom6hip_tracer_advect_cs_t *cs,
+                                     double *const *tr, const double *conc_underflow, int32_t ntr,
+                                     int32_t x_first_in, double *vol_prev, int32_t max_iter_in,
+                                     int32_t update_vol_prev, double *uhr_out, double *vhr_out,
+                                     int32_t memspace, mom6hip_advect_stats_t *stats) {
+  M6_REQUIRE(ctx != nullptr, "advect_tracer: null context (tracer_advect_init must be called before advect_tracer)");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  M6_REQUIRE(ntr >= 0, "advect_tracer: ntr < 0");
+  if (ntr == 0) return 0;   // :124
+  M6_REQUIRE(cs != nullptr, "advect_tracer: tracer_advect_init must be called before advect_tracer");
+  M6_REQUIRE(h_end && uhtr && vhtr && tr, "advect_tracer: null field pointer");
+  M6_REQUIRE(cs->scheme == PLM || cs->scheme == H3 || cs->scheme == CW,
+             "MOM_tracer_advect: Unknown TRACER_ADVECTION_SCHEME = %d", cs->scheme);
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "advect_tracer: bad memspace");
+  M6_REQUIRE(ntr <= 64, "advect_tracer: at most 64 tracers are supported");
+  M6_REQUIRE(dt > 0.0 && cs->dt > 0.0, "advect_tracer: dt must be positive");
+  for (int m = 0; m < ntr; m++) M6_REQUIRE(tr[m] != nullptr, "advect_tracer: tracer %d is null", m);
+
+  m6::GridDev &g = ctx->g;
+  hipStream_t s = ctx->stream;
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec, nz = g.nk;
+  const size_t bH = (size_t)g.nh3() * 8, bU = (size_t)g.nu3() * 8, bV = (size_t)g.nv3() * 8;
+
+  int stencil = 2;
+  const bool usePPM = cs->scheme != PLM;
+  if (usePPM && !cs->use_huynh_stencil_bug) stencil = 3;
+  M6_REQUIRE(is - g.isd >= stencil && g.ied - ie >= stencil && js - g.jsd >= stencil && g.jed - je >= stencil,
+             "advect_tracer: halo (%d) narrower than the advection stencil (%d)", is - g.isd, stencil);
+  bool x_first = (ctx->host.first_direction % 2) == 0;
+  int max_iter = 2 * (int)ceil(dt / cs->dt) + 1;
+  if (max_iter_in > 0) max_iter = max_iter_in;
+  if (x_first_in >= 0) x_first = x_first_in != 0;
+
+  Timer t_all(ctx->timing, s), t_k(ctx->timing, s);
+  mom6hip_advect_timing_t tm = {};
+  t_all.start();
+
+  // ---- device views of the caller's arrays ----
+  const double *d_hend = h_end, *d_uhtr = uhtr, *d_vhtr = vhtr;
+  double *d_vol = vol_prev;
+  std::vector<double *> d_tr(ntr);
+  if (memspace == MOM6HIP_MEM_HOST) {
+    if (ctx->stage[0].reserve(bH) || ctx->stage[1].reserve(bU) || ctx->stage[2].reserve(bV)) return 1;
+    M6_HIP(hipMemcpyAsync(ctx->stage[0].p, h_end, bH, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(ctx->stage[1].p, uhtr, bU, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(ctx->stage[2].p, vhtr, bV, hipMemcpyHostToDevice, s));
+    d_hend = (double *)ctx->stage[0].p; d_uhtr = (double *)ctx->stage[1].p; d_vhtr = (double *)ctx->stage[2].p;
+    if (vol_prev) {
+      if (ctx->stage[3].reserve(bH)) return 1;
+      M6_HIP(hipMemcpyAsync(ctx->stage[3].p, vol_prev, bH, hipMemcpyHostToDevice, s));
+      d_vol = (double *)ctx->stage[3].p;
+    }
+    for (int m = 0; m < ntr; m++) {
+      if (ctx->tr_stage[m].reserve(bH)) return 1;
+      M6_HIP(hipMemcpyAsync(ctx->tr_stage[m].p, tr[m], bH, hipMemcpyHostToDevice, s));
+      d_tr[m] = (double *)ctx->tr_stage[m].p;
+    }
+  } else {
+    for (int m = 0; m < ntr; m++) d_tr[m] = tr[m];
+  }
+
+  // ---- work space ----
+  const size_t nfu = (size_t)g.njh * nz, nfv = (size_t)(g.njh + 1) * nz;
+  if (ctx->hprev.reserve(bH) || ctx->uhr.reserve(bU) || ctx->vhr.reserve(bV) ||
+      ctx->flags.reserve((nfu + 2 * nfv + nz) * sizeof(int)))
+    return 1;
+  double *hprev = (double *)ctx->hprev.p, *uhr = (double *)ctx->uhr.p, *vhr = (double *)ctx->vhr.p;
+  int *domore_u = (int *)ctx->flags.p, *domore_v = domore_u + nfu, *domore_v2 = domore_v + nfv;
+  int *domore_k = domore_v2 + nfv;
+  M6_HIP(hipMemsetAsync(domore_u, 0, (nfu + 2 * nfv) * sizeof(int), s));
+  for (int k = 0; k < nz; k++) ctx->h_domore_k[k] = 1;
+  M6_HIP(hipMemcpyAsync(domore_k, ctx->h_domore_k, nz * sizeof(int), hipMemcpyHostToDevice, s));
+
+  // ---- :152-178 ----
+  t_k.start();
+  {
+    dim3 grid((g.nih + 1 + 255) / 256, g.njh + 1, nz);
+    hipLaunchKernelGGL(adv_setup_kernel, grid, dim3(256), 0, s, g, d_hend, d_uhtr, d_vhtr, (const double *)d_vol,
+                       hprev, uhr, vhr);
+    M6_HIP(hipGetLastError());
+  }
+  tm.ms_setup += t_k.stop();
+
+  const int ngroups = (ntr + MAXG - 1) / MAXG;
+  auto group_args = [&](int grp, AdvArgs &a) -> int {
+    a.g = g; a.hprev = hprev; a.uhr = uhr; a.vhr = vhr;
+    a.domore_u = domore_u; a.domore_k = domore_k;
+    const int m0 = grp * MAXG;
+    const int n = (ntr - m0 < MAXG) ? ntr - m0 : MAXG;
+    a.any_cu = 0;
+    for (int m = 0; m < MAXG; m++) {
+      a.tr[m] = (m < n) ? d_tr[m0 + m] : nullptr;
+      a.cu[m] = (m < n && conc_underflow) ? conc_underflow[m0 + m] : 0.0;
+      if (a.cu[m] > 0.0) a.any_cu = 1;
+    }
+    a.write_mass = (grp == ngroups - 1);   // earlier groups must see the pre-pass hprev/uhr/vhr/flags
+    return n;
+  };
+  auto run_x = [&](int xis, int xie, int xjs, int xje) -> int {
+    t_k.start();
+    for (int grp = 0; grp < ngroups; grp++) {
+      AdvArgs a; const int n = group_args(grp, a);
+      a.is = xis; a.ie = xie; a.js = xjs; a.je = xje;
+      a.domore_v_in = domore_v; a.domore_v_out = domore_v;
+      dim3 grid((xje - xjs + 1 + 3) / 4, nz);
+      switch (n) {
+        case 1: launch_x<1>(cs->scheme, grid, s, a); break;
+        case 2: launch_x<2>(cs->scheme, grid, s, a); break;
+        case 3: launch_x<3>(cs->scheme, grid, s, a); break;
+        default: launch_x<4>(cs->scheme, grid, s, a); break;
+      }
+      M6_HIP(hipGetLastError());
+      tm.n_x++;
+    }
+    tm.ms_x += t_k.stop();
+    return 0;
+  };
+  auto run_y = [&](int yis, int yie, int yjs, int yje) -> int {
+    t_k.start();
+    hipLaunchKernelGGL(adv_vflags_prep_kernel, dim3(64), dim3(256), 0, s, g, (const int *)domore_v, domore_v2,
+                       (const int *)domore_k, yjs, yje);
+    for (int grp = 0; grp < ngroups; grp++) {
+      AdvArgs a; const int n = group_args(grp, a);
+      a.is = yis; a.ie = yie; a.js = yjs; a.je = yje;
+      a.domore_v_in = domore_v; a.domore_v_out = domore_v2;
+      dim3 grid((yie - yis + 1 + 63) / 64, nz);
+      switch (n) {
+        case 1: launch_y<1>(cs->scheme, grid, s, a); break;
+        case 2: launch_y<2>(cs->scheme, grid, s, a); break;
+        case 3: launch_y<3>(cs->scheme, grid, s, a); break;
+        default: launch_y<4>(cs->scheme, grid, s, a); break;
+      }
+      M6_HIP(hipGetLastError());
+      tm.n_y++;
+    }
+    { int *t = domore_v; domore_v = domore_v2; domore_v2 = t; }
+    tm.ms_y += t_k.stop();
+    return 0;
+  };
+
+  int isv = is, iev = ie, jsv = js, jev = je;
+  int itt = 1, halo_updates = 0, remaining = nz;
+  for (itt = 1; itt <= max_iter; itt++) {
+    if (isv > is - stencil) {
+      // do_group_pass(CS%pass_uhr_vhr_t_hprev), :206
+      t_k.start();
+      if (m6::halo_update_field(ctx, uhr, MOM6HIP_POS_U, nz) || m6::halo_update_field(ctx, vhr, MOM6HIP_POS_V, nz) ||
+          m6::halo_update_field(ctx, hprev, MOM6HIP_POS_H, nz))
+        return 1;
+      for (int m = 0; m < ntr; m++)
+        if (m6::halo_update_field(ctx, d_tr[m], MOM6HIP_POS_H, nz)) return 1;
+      halo_updates++;
+      tm.ms_halo += t_k.stop();
+
+      int mh = is - g.isd;
+      if (g.ied - ie < mh) mh = g.ied - ie;
+      if (js - g.jsd < mh) mh = js - g.jsd;
+      if (g.jed - je < mh) mh = g.jed - je;
+      const int nsten_halo = mh / stencil;
+      isv = is - nsten_halo * stencil; jsv = js - nsten_halo * stencil;
+      iev = ie + nsten_halo * stencil; jev = je + nsten_halo * stencil;
+      if ((nsten_halo > 1) || (itt == 1)) {
+        t_k.start();
+        ScanArgs sa;
+        sa.g = g; sa.uhr = uhr; sa.vhr = vhr; sa.domore_u = domore_u; sa.domore_v = domore_v; sa.domore_k = domore_k;
+        sa.ju0 = jsv; sa.ju1 = jev; sa.iu0 = isv + stencil - 1; sa.iu1 = iev - stencil;
+        sa.jv0 = jsv + stencil - 1; sa.jv1 = jev - stencil; sa.iv0 = isv + stencil; sa.iv1 = iev - stencil;
+        hipLaunchKernelGGL(adv_scan_kernel, dim3(g.njh + 1, nz), dim3(256), 0, s, sa);
+        hipLaunchKernelGGL(adv_domore_k_kernel, dim3(nz), dim3(64), 0, s, g, (const int *)domore_u,
+                           (const int *)domore_v, domore_k, jsv, jev, jsv + stencil - 1, jev - stencil);
+        M6_HIP(hipGetLastError());
+        tm.ms_setup += t_k.stop();
+      }
+    }
+
+    isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
+
+    if (x_first) {
+      if (run_x(isv, iev, jsv - stencil, jev + stencil)) return 1;
+      if (run_y(isv, iev, jsv, jev)) return 1;
+      hipLaunchKernelGGL(adv_domore_k_kernel, dim3(nz), dim3(64), 0, s, g, (const int *)domore_u,
+                         (const int *)domore_v, domore_k, jsv - stencil, jev + stencil, jsv - 1, jev);
+    } else {
+      if (run_y(isv - stencil, iev + stencil, jsv, jev)) return 1;
+      if (run_x(isv, iev, jsv, jev)) return 1;
+      hipLaunchKernelGGL(adv_domore_k_kernel, dim3(nz), dim3(64), 0, s, g, (const int *)domore_u,
+                         (const int *)domore_v, domore_k, jsv, jev, jsv - 1, jev);
+    }
+    M6_HIP(hipGetLastError());
+
+    if (itt >= max_iter) break;
+    if (isv > is - stencil) {
+      // sum_across_PEs(domore_k), :305 -- the one host read-back per iteration
+      M6_HIP(hipMemcpyAsync(ctx->h_domore_k, domore_k, nz * sizeof(int), hipMemcpyDeviceToHost, s));
+      M6_HIP(hipStreamSynchronize(s));
+      remaining = 0;
+      for (int k = 0; k < nz; k++) remaining += ctx->h_domore_k[k];
+      if (remaining == 0) break;
+    }
+  }
+  if (itt > max_iter) itt = max_iter;
+
+  // ---- outputs ----
+  if (memspace == MOM6HIP_MEM_HOST) {
+    for (int m = 0; m < ntr; m++) M6_HIP(hipMemcpyAsync(tr[m], d_tr[m], bH, hipMemcpyDeviceToHost, s));
+    if (uhr_out) M6_HIP(hipMemcpyAsync(uhr_out, uhr, bU, hipMemcpyDeviceToHost, s));
+    if (vhr_out) M6_HIP(hipMemcpyAsync(vhr_out, vhr, bV, hipMemcpyDeviceToHost, s));
+    if (vol_prev && update_vol_prev) M6_HIP(hipMemcpyAsync(vol_prev, hprev, bH, hipMemcpyDeviceToHost, s));
+  } else {
+    if (uhr_out) M6_HIP(hipMemcpyAsync(uhr_out, uhr, bU, hipMemcpyDeviceToDevice, s));
+    if (vhr_out) M6_HIP(hipMemcpyAsync(vhr_out, vhr, bV, hipMemcpyDeviceToDevice, s));
+    if (vol_prev && update_vol_prev) M6_HIP(hipMemcpyAsync(vol_prev, hprev, bH, hipMemcpyDeviceToDevice, s));
+  }
+  if (stats || memspace == MOM6HIP_MEM_HOST) {
+    M6_HIP(hipMemcpyAsync(ctx->h_domore_k, domore_k, nz * sizeof(int), hipMemcpyDeviceToHost, s));
+    M6_HIP(hipStreamSynchronize(s));
+    remaining = 0;
+    for (int k = 0; k < nz; k++) remaining += ctx->h_domore_k[k];
+  }
+  if (stats) { stats->iterations = itt; stats->halo_updates = halo_updates; stats->domore_remaining = remaining; }
+  if (ctx->timing) { tm.ms_total = t_all.stop(); ctx->adv_timing = tm; }
+  return 0;
+}

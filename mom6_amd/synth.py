@@ -1,0 +1,217 @@
+"""Seeded synthetic grids and model states for the configurations of BASELINE.json / SURVEY.md section 8d.
+
+None of the named experiment directories (double_gyre, benchmark, Phillips_2layer, OM4_025) exist in
+the reference tree, so the shapes are synthesised here: Mercator-like metrics, a bowl bathymetry with
+a land mask, layer thicknesses with vanished layers, and transports bounded like a model run.
+
+2-D metrics are numpy (cheap).  3-D state is built with torch so that the same code fills host
+arrays for the parity tests and HBM-resident arrays for the bench.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from .grid import Grid
+
+# shapes named by BASELINE.json "configs" (NI, NJ, NK)
+CONFIGS = {
+    "tc1": (10, 8, 8),
+    "double_gyre": (44, 40, 2),
+    "benchmark": (360, 180, 75),
+    "phillips_2layer": (480, 320, 2),
+    "om4_025": (1440, 1080, 75),
+}
+
+
+def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=True,
+              reentrant_y=False, max_depth=5500.0, first_direction=0) -> Grid:
+    """Mercator-like C-grid with a bowl bathymetry and about `land_frac` land."""
+    g = Grid(ni=ni, nj=nj, nk=nk, halo=halo, reentrant_x=reentrant_x, reentrant_y=reentrant_y,
+             first_direction=first_direction)
+    rng = np.random.default_rng(seed)
+    nih, njh, h = g.nih, g.njh, halo
+    Re = 6.378e6
+    lat0, lat1 = -70.0, 70.0
+    dlat = (lat1 - lat0) / nj
+    dlon = 360.0 / ni
+    # global (periodic in i) index of every data-domain point
+    jg_h = np.arange(njh) - h                       # h-point rows: centre latitude index
+    jg_v = np.arange(njh + 1) - h - 0.5 + 0.0       # v/q rows: J = jsd-1.. -> north faces
+    lat_h = np.clip(lat0 + (jg_h + 0.5) * dlat, -89.0, 89.0)
+    lat_v = np.clip(lat0 + (jg_v + 1.0) * dlat, -89.0, 89.0)
+    dy = Re * math.radians(dlat)
+    dx_h = Re * math.radians(dlon) * np.cos(np.radians(lat_h))
+    dx_v = Re * math.radians(dlon) * np.cos(np.radians(lat_v))
+
+    def bc(col, n):  # broadcast a per-row vector to (rows, n)
+        return np.repeat(col[:, None], n, axis=1)
+
+    dxT, dyT = bc(dx_h, nih), np.full((njh, nih), dy)
+    dxCu, dyCu = bc(dx_h, nih + 1), np.full((njh, nih + 1), dy)
+    dxCv, dyCv = bc(dx_v, nih), np.full((njh + 1, nih), dy)
+    dxBu, dyBu = bc(dx_v, nih + 1), np.full((njh + 1, nih + 1), dy)
+
+    # bathymetry on the compute domain, periodic in i, then wrapped/closed into the halos
+    ii = (np.arange(ni) + 0.5) / ni
+    jj = (np.arange(nj) + 0.5) / nj
+    X, Y = np.meshgrid(ii, jj)
+    bowl = (np.sin(np.pi * Y) ** 0.5) * (0.65 + 0.35 * np.cos(2 * np.pi * X) * np.cos(np.pi * Y))
+    rough = 0.12 * np.sin(6 * np.pi * X + 1.0) * np.sin(4 * np.pi * Y) + 0.04 * rng.standard_normal((nj, ni))
+    field = bowl + rough
+    thr = np.quantile(field, land_frac) if land_frac > 0 else -np.inf
+    ocean = field > thr
+    depth_c = np.where(ocean, max_depth * np.clip((field - thr) / (field.max() - thr), 0.02, 1.0), 0.0)
+
+    def embed_h(a_c, fill=0.0):
+        a = np.full((njh, nih), fill, dtype=np.float64)
+        a[h:h + nj, h:h + ni] = a_c
+        if reentrant_x:
+            a[h:h + nj, :h] = a_c[:, ni - h:]
+            a[h:h + nj, h + ni:] = a_c[:, :h]
+        if reentrant_y:
+            a[:h, :] = a[nj:nj + h, :]
+            a[h + nj:, :] = a[h:2 * h, :]
+        return a
+
+    mask2dT = embed_h(ocean.astype(np.float64))
+    bathyT = embed_h(depth_c)
+    # face masks: open only between two ocean cells.  u-array column index c <-> I = isd-1+c,
+    # lying between h-columns c-1 and c.
+    mT = mask2dT
+    mCu = np.zeros((njh, nih + 1)); mCu[:, 1:nih] = mT[:, :-1] * mT[:, 1:]
+    mCv = np.zeros((njh + 1, nih)); mCv[1:njh, :] = mT[:-1, :] * mT[1:, :]
+    mBu = np.zeros((njh + 1, nih + 1))
+    mBu[1:njh, 1:nih] = mT[:-1, :-1] * mT[:-1, 1:] * mT[1:, :-1] * mT[1:, 1:]
+
+    def inv(a):
+        out = np.zeros_like(a)
+        np.divide(1.0, a, out=out, where=a > 0)
+        return out
+
+    areaT = dxT * dyT
+    g.set_metric("mask2dT", mask2dT); g.set_metric("bathyT", bathyT)
+    g.set_metric("dxT", dxT); g.set_metric("dyT", dyT)
+    g.set_metric("IdxT", inv(dxT)); g.set_metric("IdyT", inv(dyT))
+    g.set_metric("areaT", areaT); g.set_metric("IareaT", inv(areaT))
+    g.set_metric("mask2dCu", mCu); g.set_metric("dxCu", dxCu); g.set_metric("dyCu", dyCu)
+    g.set_metric("dy_Cu", dyCu * mCu); g.set_metric("IdxCu", inv(dxCu)); g.set_metric("IdyCu", inv(dyCu))
+    g.set_metric("areaCu", dxCu * dyCu); g.set_metric("IareaCu", inv(dxCu * dyCu))
+    g.set_metric("mask2dCv", mCv); g.set_metric("dxCv", dxCv); g.set_metric("dyCv", dyCv)
+    g.set_metric("dx_Cv", dxCv * mCv); g.set_metric("IdxCv", inv(dxCv)); g.set_metric("IdyCv", inv(dyCv))
+    g.set_metric("areaCv", dxCv * dyCv); g.set_metric("IareaCv", inv(dxCv * dyCv))
+    g.set_metric("mask2dBu", mBu); g.set_metric("dxBu", dxBu); g.set_metric("dyBu", dyBu)
+    g.set_metric("areaBu", dxBu * dyBu); g.set_metric("IareaBu", inv(dxBu * dyBu))
+    omega = 7.2921e-5
+    g.set_metric("CoriolisBu", bc(2 * omega * np.sin(np.radians(lat_v)), nih + 1))
+    return g
+
+
+def _embed(g: Grid, a_c: torch.Tensor, pos: int) -> torch.Tensor:
+    """Place a compute-domain array (nk, nj[+1], ni[+1]) into a zeroed data-domain array."""
+    out = torch.zeros(g.shape3(pos, a_c.shape[0]), dtype=torch.float64, device=a_c.device)
+    sj, si = g.csl(pos)
+    out[:, sj, si] = a_c
+    return out
+
+
+def make_advection_state(g: Grid, ntr=4, seed=1, device="cpu", cfl=0.15, hot_frac=0.004,
+                         hot_cfl=0.65, vanish_frac=0.05, dtype=torch.float64):
+    """Inputs of advect_tracer: h_end, uhtr, vhtr and `ntr` tracers on grid `g`.
+
+    Transports are `c * min(upwind volumes)` with |c| <= cfl (smooth flow + noise) so a model-like
+    run needs one iteration, except around a fraction `hot_frac` of cells where x-divergence of 2*hot_cfl triggers the
+    flux limiter (domore_u/v, src/tracer/MOM_tracer_advect.F90:494-497) and a second iteration.
+    About `vanish_frac` of the ocean cells are vanished layers (h = Angstrom_H).
+    """
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    nk, ni, nj = g.nk, g.ni, g.nj
+    sjh, sih = g.csl(_abi.POS_H)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device=dev)
+    area = t(g.areaT[sjh, sih]); mT = t(g.mask2dT[sjh, sih]); depth = t(g.bathyT[sjh, sih])
+    sju, siu = g.csl(_abi.POS_U); sjv, siv = g.csl(_abi.POS_V)
+    mCu = t(g.mask2dCu[sju, siu]); mCv = t(g.mask2dCv[sjv, siv])   # (nj, ni+1), (nj+1, ni)
+    rnd = lambda *s: torch.rand(*s, generator=gen, dtype=dtype, device=dev)
+    rndn = lambda *s: torch.randn(*s, generator=gen, dtype=dtype, device=dev)
+
+    x = (torch.arange(ni, dtype=dtype, device=dev) + 0.5) / ni
+    y = (torch.arange(nj, dtype=dtype, device=dev) + 0.5) / nj
+    kk = (torch.arange(nk, dtype=dtype, device=dev) + 0.5) / nk
+    X, Y, K = x[None, None, :], y[None, :, None], kk[:, None, None]
+
+    # z*-like thicknesses: nominal dz growing with depth, stretched to the local depth; layers are
+    # vanished where the nominal column is deeper than the bathymetry, plus random vanished blobs.
+    dz_nom = 2.0 + 300.0 * K ** 2
+    dz_nom = dz_nom * (5500.0 / dz_nom.sum())
+    ztop = torch.cumsum(dz_nom, 0) - dz_nom                      # nominal top of each layer
+    h0 = torch.clamp(torch.minimum(dz_nom.expand(nk, nj, ni), depth[None] - ztop), min=0.0)
+    blob = torch.sin(9 * math.pi * X + 3 * K) * torch.sin(7 * math.pi * Y - 2 * K) + 0.3 * rndn(nk, nj, ni)
+    if vanish_frac > 0:
+        q = torch.quantile(blob.flatten()[:: max(1, blob.numel() // 200000)], 1.0 - vanish_frac)
+        h0 = torch.where(blob > q, torch.zeros_like(h0), h0)
+    h0 = torch.clamp(h0 * (1.0 + 0.05 * rndn(nk, nj, ni)), min=0.0)
+    h0 = torch.where(h0 < 1.0e-3, torch.full_like(h0, g.Angstrom_H), h0)
+    h0 = torch.where(mT[None] > 0, h0, torch.full_like(h0, g.Angstrom_H))
+    vol0 = area[None] * h0
+
+    # face CFL-like fractions: large-scale rotational flow + noise, a few "hot" faces
+    cu = cfl * (0.7 * torch.sin(2 * math.pi * (Y + 0.3 * K)) * torch.cos(2 * math.pi * X) + 0.3 * (2 * rnd(nk, nj, ni) - 1))
+    cv = cfl * (0.7 * torch.cos(2 * math.pi * (X - 0.2 * K)) * torch.sin(2 * math.pi * Y) + 0.3 * (2 * rnd(nk, nj, ni) - 1))
+    if hot_frac > 0:
+        # "hot" cells: strongly divergent in x (both x faces push out hot_cfl of the volume), fed by
+        # convergent y faces -- the situation in which the reference's flux limiter (:494-497) has to
+        # postpone part of the transport to a later iteration.
+        hc = rnd(nk, nj, ni) < hot_frac
+        hw = torch.roll(hc, -1, 2)          # face I=i is the west face of hot cell i+1
+        hs = torch.roll(hc, -1, 1)
+        cu = torch.where(hc, torch.full_like(cu, hot_cfl), cu)
+        cu = torch.where(hw & ~hc, torch.full_like(cu, -hot_cfl), cu)
+        cv = torch.where(hc, torch.full_like(cv, -0.5 * hot_cfl), cv)
+        cv = torch.where(hs & ~hc, torch.full_like(cv, 0.5 * hot_cfl), cv)
+    # east face of cell i lies between i and i+1 (periodic in x if re-entrant, else closed by mask)
+    vol_e = torch.roll(vol0, -1, 2); vol_n = torch.roll(vol0, -1, 1)
+    uh_e = cu * torch.minimum(vol0, vol_e)            # faces I = isc..iec
+    vh_n = cv * torch.minimum(vol0, vol_n)            # faces J = jsc..jec
+    uh_e = uh_e * mCu[None, :, 1:]; vh_n = vh_n * mCv[None, 1:, :]
+    # keep the data model-like: a cell may push out more than it holds only if inflow makes up for
+    # it (that is what makes advect_tracer iterate); the net loss never exceeds 80 % of the volume.
+    zero = torch.zeros_like(vol0)
+    for _ in range(4):
+        uh_w = torch.roll(uh_e, 1, 2); vh_s = torch.roll(vh_n, 1, 1)
+        out = (torch.maximum(uh_e, zero) + torch.maximum(-uh_w, zero)
+               + torch.maximum(vh_n, zero) + torch.maximum(-vh_s, zero))
+        inn = (torch.maximum(-uh_e, zero) + torch.maximum(uh_w, zero)
+               + torch.maximum(-vh_n, zero) + torch.maximum(vh_s, zero))
+        sc = torch.clamp((0.8 * vol0 + inn) / torch.clamp(out, min=1e-300), max=1.0)
+        uh_e = torch.where(uh_e >= 0, uh_e * sc, uh_e * torch.roll(sc, -1, 2))
+        vh_n = torch.where(vh_n >= 0, vh_n * sc, vh_n * torch.roll(sc, -1, 1))
+    uh = torch.cat([uh_e[:, :, -1:], uh_e], 2) * mCu[None]      # I = isc-1..iec
+    vh = torch.cat([vh_n[:, -1:, :], vh_n], 1) * mCv[None]      # J = jsc-1..jec
+    div = (uh[:, :, 1:] - uh[:, :, :-1]) + (vh[:, 1:, :] - vh[:, :-1, :])
+    h_end = torch.clamp(vol0 - div, min=0.0) / area[None]
+    h_end = torch.where(h_end < g.Angstrom_H, torch.full_like(h_end, g.Angstrom_H), h_end)
+
+    tr = []
+    zmid = ztop + 0.5 * dz_nom
+    for m in range(ntr):
+        if m == 0:      # temperature-like
+            a = 20.0 * torch.exp(-zmid / 1000.0) + 2.0 * torch.cos(math.pi * Y) + 0.01 * rndn(nk, nj, ni)
+        elif m == 1:    # salinity-like
+            a = 35.0 + 0.5 * torch.sin(2 * math.pi * X) * torch.sin(math.pi * Y) + 0.01 * rndn(nk, nj, ni)
+        elif m % 2 == 0:  # smooth blob
+            a = torch.exp(-((X - 0.4) ** 2 + (Y - 0.5) ** 2) / 0.02) * torch.ones_like(K)
+        else:           # step
+            a = ((X > 0.3) & (X < 0.6) & (Y > 0.2) & (Y < 0.7)).to(dtype) * torch.ones_like(K)
+        tr.append(_embed(g, (a * mT[None]).contiguous(), _abi.POS_H))
+
+    return {
+        "h_end": _embed(g, h_end, _abi.POS_H),
+        "uhtr": _embed(g, uh, _abi.POS_U),
+        "vhtr": _embed(g, vh, _abi.POS_V),
+        "tr": tr,
+        "vol0": _embed(g, vol0, _abi.POS_H),
+    }

@@ -1,0 +1,156 @@
+"""Host-side mirror of MOM_tracer_advect (reference: src/tracer/MOM_tracer_advect.F90).
+
+Same names, argument meaning and error behaviour as the reference's public procedures
+(`tracer_advect_init`, `advect_tracer`, `tracer_advect_end`); the work is done by libmom6hip's
+HIP kernels through the C ABI (include/mom6hip.h).  Fields are either numpy arrays (host: the
+drop-in path, staged to HBM and back) or torch CUDA tensors (resident in HBM, no copies).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+
+_dp = C.POINTER(C.c_double)
+
+
+class DeviceGrid:
+    """A grid uploaded to the GPU (mom6hip_ctx_t): metrics in HBM plus the library's work space."""
+
+    def __init__(self, grid, device=0, stream=None):
+        L = lib()
+        check(L.mom6hip_init(int(device)), "mom6hip_init")
+        self.grid = grid
+        self._h = C.c_void_p()
+        check(L.mom6hip_grid_create(C.byref(grid.struct()), C.c_void_p(stream or 0), C.byref(self._h)),
+              "mom6hip_grid_create")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise Mom6HipError("DeviceGrid used after close()")
+        return self._h
+
+    def sync(self):
+        check(lib().mom6hip_sync(self.handle), "mom6hip_sync")
+
+    def set_timing(self, enable=True):
+        check(lib().mom6hip_set_timing(self.handle, int(enable)), "mom6hip_set_timing")
+
+    def advect_timing(self):
+        t = _abi.AdvectTiming()
+        check(lib().mom6hip_advect_get_timing(self.handle, C.byref(t)), "mom6hip_advect_get_timing")
+        return t
+
+    def halo_update(self, fields, positions):
+        """pass_var / pass_vector on this one-tile domain for torch CUDA tensors."""
+        n = len(fields)
+        ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in fields])
+        pos = (C.c_int32 * n)(*positions)
+        nks = (C.c_int32 * n)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
+        check(lib().mom6hip_halo_update(self.handle, ptrs, pos, nks, n), "mom6hip_halo_update")
+
+    def close(self):
+        if self._h:
+            lib().mom6hip_grid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TracerAdvectCS:
+    """tracer_advect_CS (MOM_tracer_advect.F90:30-40)."""
+
+    def __init__(self, dt, scheme="PLM", use_huynh_stencil_bug=False):
+        if scheme not in _abi.ADV_SCHEMES:
+            # MOM_tracer_advect.F90:1131-1133
+            raise Mom6HipError("MOM_tracer_advect, tracer_advect_init: Unknown TRACER_ADVECTION_SCHEME = " + str(scheme))
+        self.dt = float(dt)
+        self.scheme = scheme
+        self.use_huynh_stencil_bug = bool(use_huynh_stencil_bug)
+
+    def struct(self):
+        return _abi.TracerAdvectCS(self.dt, _abi.ADV_SCHEMES[self.scheme], int(self.use_huynh_stencil_bug))
+
+
+def tracer_advect_init(dt, scheme="PLM", use_huynh_stencil_bug=False):
+    """tracer_advect_init (MOM_tracer_advect.F90:1090): DT and TRACER_ADVECTION_SCHEME."""
+    return TracerAdvectCS(dt, scheme, use_huynh_stencil_bug)
+
+
+def _ptr_space(a):
+    """(address, memspace) of a numpy array or a torch CUDA tensor."""
+    if isinstance(a, np.ndarray):
+        if a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise Mom6HipError("fields must be contiguous float64")
+        return a.ctypes.data, _abi.MEM_HOST
+    if str(a.dtype) != "torch.float64" or not a.is_contiguous():
+        raise Mom6HipError("fields must be contiguous float64")
+    if not a.is_cuda:
+        raise Mom6HipError("torch fields must live on the GPU (use numpy arrays for host fields)")
+    return a.data_ptr(), _abi.MEM_DEVICE
+
+
+def advect_tracer(h_end, uhtr, vhtr, OBC, dt, G: DeviceGrid, CS: TracerAdvectCS, Reg, x_first_in=None,
+                  vol_prev=None, max_iter_in=None, update_vol_prev=None, uhr_out=None, vhr_out=None,
+                  conc_underflow=None):
+    """advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first_in, vol_prev, max_iter_in,
+    update_vol_prev, uhr_out, vhr_out)  -- MOM_tracer_advect.F90:52.
+
+    `Reg` is the list of tracer arrays Reg%Tr(m)%t (updated in place); GV/US are folded into `G`.
+    Returns the AdvectStats of the call.
+    """
+    if CS is None:
+        raise Mom6HipError("MOM_tracer_advect: tracer_advect_init must be called before advect_tracer.")
+    if Reg is None:
+        raise Mom6HipError("MOM_tracer_advect: register_tracer must be called before advect_tracer.")
+    if OBC is not None:
+        raise Mom6HipError("MOM_tracer_advect (HIP): open boundary conditions are not supported on this path")
+    ntr = len(Reg)
+    st = _abi.AdvectStats()
+    if ntr == 0:
+        return st
+    g = G.grid
+    spaces = set()
+    shapes = {"h": g.shape3(_abi.POS_H), "u": g.shape3(_abi.POS_U), "v": g.shape3(_abi.POS_V)}
+
+    def P(a, kind, name):
+        if a is None:
+            return None
+        if tuple(a.shape) != shapes[kind]:
+            raise Mom6HipError(f"advect_tracer: {name} has shape {tuple(a.shape)}, expected {shapes[kind]}")
+        p, s = _ptr_space(a)
+        spaces.add(s)
+        return C.c_void_p(p)
+
+    ph, pu, pv = P(h_end, "h", "h_end"), P(uhtr, "u", "uhtr"), P(vhtr, "v", "vhtr")
+    trp = (C.c_void_p * ntr)(*[P(t, "h", f"Reg%Tr({m+1})%t") for m, t in enumerate(Reg)])
+    pvol, puo, pvo = P(vol_prev, "h", "vol_prev"), P(uhr_out, "u", "uhr_out"), P(vhr_out, "v", "vhr_out")
+    if len(spaces) != 1:
+        raise Mom6HipError("advect_tracer: all fields must be in the same memory space")
+    cu = None
+    if conc_underflow is not None:
+        cu = np.ascontiguousarray(conc_underflow, dtype=np.float64)
+        if cu.shape != (ntr,):
+            raise Mom6HipError("advect_tracer: conc_underflow must have one entry per tracer")
+    cs = CS.struct()
+    rc = lib().mom6hip_advect_tracer(
+        G.handle, ph, pu, pv, float(dt), C.byref(cs), trp,
+        None if cu is None else cu.ctypes.data_as(_dp), ntr,
+        -1 if x_first_in is None else int(bool(x_first_in)), pvol,
+        0 if max_iter_in is None else int(max_iter_in), int(bool(update_vol_prev)), puo, pvo,
+        spaces.pop(), C.byref(st))
+    check(rc, "advect_tracer")
+    return st
+
+
+def tracer_advect_end(CS):
+    """tracer_advect_end (MOM_tracer_advect.F90:1153)."""
+    return None

@@ -1,0 +1,59 @@
+/*
+ * mom6_oracle.h -- CPU restatement of the MOM6 dynamical-core hot path (TEST INFRASTRUCTURE).
+ *
+ * This directory is the parity oracle, not the product: plain C99, scalar, one thread, written to
+ * follow the reference Fortran loop for loop (each function cites the reference file:line it
+ * restates).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product (mom6_amd/, libmom6hip.so) never links or calls anything in here.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - ALE reconstruction pieces, EOS: pinned by the reference's own known-answer vectors
+ *     (src/ALE/MOM_remapping.F90:1339-1780, src/equation_of_state/MOM_EOS.F90:1902-2032).
+ *   - advect_tracer: PARITY UNPINNED -- the reference holds no known-answer vectors for it and
+ *     src/tracer/MOM_tracer_advect.F90 cannot be built here without stand-ins for FMS-backed modules.
+ *     It is checked through the invariants the reference's own test-suite relies on instead
+ *     (conservation, x/y rotation equivalence, layout independence).
+ *
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction, so the evaluation is the source's explicit
+ * parenthesisation in IEEE fp64, the same as the HIP build).
+ */
+#ifndef MOM6_ORACLE_H
+#define MOM6_ORACLE_H
+
+#include "../include/mom6hip.h"   /* the grid POD only; every pointer in it is a HOST pointer here */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- index helpers: Fortran (i,j,k) with k 1-based, symmetric memory --------------------- */
+#define ORC_NIH(G)  ((G)->ied - (G)->isd + 1)
+#define ORC_NJH(G)  ((G)->jed - (G)->jsd + 1)
+#define ORC_H2(G,i,j)   ((long)((i)-(G)->isd)     + (long)ORC_NIH(G)    *((j)-(G)->jsd))
+#define ORC_U2(G,I,j)   ((long)((I)-(G)->isd+1)   + (long)(ORC_NIH(G)+1)*((j)-(G)->jsd))
+#define ORC_V2(G,i,J)   ((long)((i)-(G)->isd)     + (long)ORC_NIH(G)    *((J)-(G)->jsd+1))
+#define ORC_Q2(G,I,J)   ((long)((I)-(G)->isd+1)   + (long)(ORC_NIH(G)+1)*((J)-(G)->jsd+1))
+#define ORC_H3(G,i,j,k) (ORC_H2(G,i,j) + (long)ORC_NIH(G)    *ORC_NJH(G)    *((k)-1))
+#define ORC_U3(G,I,j,k) (ORC_U2(G,I,j) + (long)(ORC_NIH(G)+1)*ORC_NJH(G)    *((k)-1))
+#define ORC_V3(G,i,J,k) (ORC_V2(G,i,J) + (long)ORC_NIH(G)    *(ORC_NJH(G)+1)*((k)-1))
+#define ORC_Q3(G,I,J,k) (ORC_Q2(G,I,J) + (long)(ORC_NIH(G)+1)*(ORC_NJH(G)+1)*((k)-1))
+
+/* ---- MOM_domains, one tile --------------------------------------------------------------- */
+/* pass_var / pass_vector / do_group_pass on a single-PE domain
+ * (config_src/infra/FMS2/MOM_domain_infra.F90:171,660,1141): re-entrant edges are filled from the
+ * tile's own compute domain (corners included), closed edges are left untouched.
+ * pos: MOM6HIP_POS_H/U/V/Q.  nk = 1 for a 2-D field. */
+void orc_halo_update(const mom6hip_grid_t *G, double *f, int pos, int nk);
+
+/* ---- MOM_tracer_advect -------------------------------------------------------------------- */
+/* advect_tracer, src/tracer/MOM_tracer_advect.F90:52-324 (OBC not associated). */
+int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double *uhtr,
+                      const double *vhtr, double dt, const mom6hip_tracer_advect_cs_t *cs,
+                      double *const *tr, const double *conc_underflow, int ntr,
+                      int x_first_in, double *vol_prev, int max_iter_in, int update_vol_prev,
+                      double *uhr_out, double *vhr_out, mom6hip_advect_stats_t *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,151 @@
+"""GPU parity tests: libmom6hip's advect_tracer (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar: BIT-EXACT fp64 (tolerance 0) for every tracer, the remaining transports, the
+cell volumes and the iteration statistics -- both sides evaluate the reference's expressions with
+its parenthesisation and without FMA contraction."""
+import numpy as np
+import pytest
+import torch
+
+from mom6_amd import _abi
+from mom6_amd.tracer_advect import DeviceGrid, advect_tracer, tracer_advect_init
+from helpers import advect_case, run_oracle, bits_equal, interior
+
+pytestmark = pytest.mark.gpu
+SCHEMES = ["PLM", "PPM:H3", "PPM"]
+
+
+def run_hip(g, case, scheme, dt=3600.0, cs_dt=900.0, x_first=None, use_vol=True, conc_underflow=None,
+            max_iter=None, device_resident=False, dg=None):
+    own = dg is None
+    dg = dg or DeviceGrid(g)
+    CS = tracer_advect_init(cs_dt, scheme)
+    tr = [t.copy() for t in case["tr"]]
+    vol = case["vol0"].copy() if use_vol else None
+    uhr = g.zeros3(_abi.POS_U); vhr = g.zeros3(_abi.POS_V)
+    if device_resident:
+        dev = lambda a: None if a is None else torch.from_numpy(a).cuda()
+        d_tr = [dev(t) for t in tr]; d_vol = dev(vol); d_uhr = dev(uhr); d_vhr = dev(vhr)
+        st = advect_tracer(dev(case["h_end"]), dev(case["uhtr"]), dev(case["vhtr"]), None, dt, dg, CS, d_tr,
+                           x_first_in=x_first, vol_prev=d_vol, max_iter_in=max_iter, update_vol_prev=use_vol,
+                           uhr_out=d_uhr, vhr_out=d_vhr, conc_underflow=conc_underflow)
+        dg.sync()
+        tr = [t.cpu().numpy() for t in d_tr]
+        vol = None if d_vol is None else d_vol.cpu().numpy()
+        uhr, vhr = d_uhr.cpu().numpy(), d_vhr.cpu().numpy()
+    else:
+        st = advect_tracer(case["h_end"], case["uhtr"], case["vhtr"], None, dt, dg, CS, tr, x_first_in=x_first,
+                           vol_prev=vol, max_iter_in=max_iter, update_vol_prev=use_vol, uhr_out=uhr, vhr_out=vhr,
+                           conc_underflow=conc_underflow)
+    if own:
+        dg.close()
+    return {"tr": tr, "vol": vol, "uhr": uhr, "vhr": vhr, "stats": st}
+
+
+def assert_same(g, a, b, what=""):
+    assert (a["stats"].iterations, a["stats"].halo_updates, a["stats"].domore_remaining) == \
+           (b["stats"].iterations, b["stats"].halo_updates, b["stats"].domore_remaining), what
+    for m, (ta, tb) in enumerate(zip(a["tr"], b["tr"])):
+        if not bits_equal(ta, tb):
+            d = np.argwhere(ta != tb)
+            raise AssertionError(f"{what}: tracer {m} differs at {len(d)} points, first (k,j,i)={d[0]}, "
+                                 f"oracle={ta[tuple(d[0])]!r} hip={tb[tuple(d[0])]!r}")
+    for name in ("uhr", "vhr", "vol"):
+        if a[name] is not None:
+            # halos of the work arrays are filled identically by the group pass; compare everything
+            assert bits_equal(a[name], b[name]), f"{what}: {name} differs at {np.argwhere(a[name] != b[name])[:3]}"
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("x_first", [True, False])
+@pytest.mark.parametrize("resident", [False, True])
+def test_parity_basic(oracle, scheme, x_first, resident):
+    g, case = advect_case(ni=24, nj=20, nk=3, ntr=3)
+    ref = run_oracle(oracle, g, case, scheme, x_first=x_first)
+    out = run_hip(g, case, scheme, x_first=x_first, device_resident=resident)
+    assert_same(g, ref, out, f"{scheme} x_first={x_first} resident={resident}")
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("ntr", [1, 2, 4, 5, 9])
+def test_parity_tracer_counts_multichunk(oracle, scheme, ntr):
+    # 150 columns -> three 64-cell chunks per row in advect_x, three column strips in advect_y
+    g, case = advect_case(ni=150, nj=37, nk=2, ntr=ntr, seed=11)
+    ref = run_oracle(oracle, g, case, scheme)
+    out = run_hip(g, case, scheme)
+    assert_same(g, ref, out, f"{scheme} ntr={ntr}")
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("x_first", [True, False])
+def test_parity_limiter_iterations(oracle, scheme, x_first):
+    g, case = advect_case(ni=70, nj=33, nk=4, ntr=2, hot_frac=0.05, seed=5, cfl=0.1)
+    ref = run_oracle(oracle, g, case, scheme, x_first=x_first)
+    assert ref["stats"].iterations >= 2
+    out = run_hip(g, case, scheme, x_first=x_first)
+    assert_same(g, ref, out, f"{scheme} limiter")
+    ref1 = run_oracle(oracle, g, case, scheme, x_first=x_first, max_iter=1)
+    out1 = run_hip(g, case, scheme, x_first=x_first, max_iter=1)
+    assert ref1["stats"].domore_remaining > 0
+    assert_same(g, ref1, out1, f"{scheme} limiter max_iter=1")
+
+
+@pytest.mark.parametrize("topo", [(True, True), (False, False), (False, True)])
+def test_parity_topologies(oracle, topo):
+    rx, ry = topo
+    g, case = advect_case(ni=40, nj=28, nk=2, ntr=2, reentrant_x=rx, reentrant_y=ry, seed=7)
+    for scheme in SCHEMES:
+        ref = run_oracle(oracle, g, case, scheme)
+        out = run_hip(g, case, scheme)
+        assert_same(g, ref, out, f"{scheme} reentrant=({rx},{ry})")
+
+
+def test_parity_reconstructed_hprev_and_underflow(oracle):
+    g, case = advect_case(ni=66, nj=21, nk=3, ntr=3, seed=9)
+    case["tr"][2] = case["tr"][2] * 1e-6
+    cu = [0.0, 0.0, 1e-7]
+    for scheme in SCHEMES:
+        ref = run_oracle(oracle, g, case, scheme, use_vol=False, conc_underflow=cu)
+        out = run_hip(g, case, scheme, use_vol=False, conc_underflow=cu)
+        assert_same(g, ref, out, f"{scheme} hprev+underflow")
+        assert np.any(interior(g, out["tr"][2]) == 0.0)
+
+
+def test_parity_tc1_and_double_gyre_shapes(oracle):
+    """BASELINE.json configs[0] (tc1: 10x8x8) and configs[1] (double_gyre 44x40x2) shapes."""
+    for (ni, nj, nk) in [(10, 8, 8), (44, 40, 2)]:
+        g, case = advect_case(ni=ni, nj=nj, nk=nk, ntr=2, seed=ni)
+        for scheme in SCHEMES:
+            ref = run_oracle(oracle, g, case, scheme)
+            out = run_hip(g, case, scheme)
+            assert_same(g, ref, out, f"{scheme} {ni}x{nj}x{nk}")
+
+
+def test_context_reuse_and_errors(oracle):
+    g, case = advect_case(ni=24, nj=20, nk=3, ntr=2)
+    dg = DeviceGrid(g)
+    ref = run_oracle(oracle, g, case, "PPM:H3")
+    for _ in range(3):
+        out = run_hip(g, case, "PPM:H3", dg=dg)
+        assert_same(g, ref, out, "reuse")
+    from mom6_amd._lib import Mom6HipError
+    with pytest.raises(Mom6HipError, match="tracer_advect_init must be called"):
+        advect_tracer(case["h_end"], case["uhtr"], case["vhtr"], None, 3600.0, dg, None, case["tr"])
+    with pytest.raises(Mom6HipError, match="shape"):
+        advect_tracer(case["h_end"][:, :-1], case["uhtr"], case["vhtr"], None, 3600.0, dg,
+                      tracer_advect_init(900.0, "PLM"), case["tr"])
+    with pytest.raises(Mom6HipError, match="Unknown TRACER_ADVECTION_SCHEME"):
+        tracer_advect_init(900.0, "WENO")
+    dg.close()
+
+
+def test_halo_update_matches_oracle(oracle):
+    g, case = advect_case(ni=24, nj=20, nk=3, ntr=1, reentrant_x=True, reentrant_y=True)
+    dg = DeviceGrid(g)
+    rng = np.random.default_rng(0)
+    for pos in (_abi.POS_H, _abi.POS_U, _abi.POS_V, _abi.POS_Q):
+        a = rng.standard_normal(g.shape3(pos))
+        b = torch.from_numpy(a.copy()).cuda()
+        oracle.halo_update(g, a, pos)
+        dg.halo_update([b], [pos]); dg.sync()
+        assert bits_equal(a, b.cpu().numpy()), pos
+    dg.close()
