@@ -53,6 +53,11 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// "changed" in the bit-pattern sense (so that -0.0 -> +0.0 is written back like the reference does)
+__device__ __forceinline__ bool changed(double a, double b) {
+  return __double_as_longlong(a) != __double_as_longlong(b);
+}
+
 __device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
 __device__ __forceinline__ double min3(double a, double b, double c) { return fmin(fmin(a, b), c); }
 
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void adv_x_kernel(AdvArgs p) {
 #pragma unroll
       for (int m = 0; m < NT; m++) if (p.cu[m] > 0.0) {
         double t = p.tr[m][rowH + (i - g.isd)];
-        if (fabs(t) < p.cu[m] && t != 0.0) p.tr[m][rowH + (i - g.isd)] = 0.0;
+        if (fabs(t) < p.cu[m] && changed(t, 0.0)) p.tr[m][rowH + (i - g.isd)] = 0.0;
       }
     }
     return;
@@ -394,20 +399,20 @@ __global__ __launch_bounds__(256) void adv_x_kernel(AdvArgs p) {
     if (face_ok && p.write_mass) {
       double u_new = u_c - hh;
       if (fabs(u_new) < g.uh_neglect[row2U + (i - g.isd)]) u_new = 0.0;
-      if (u_new != u_c) p.uhr[rowU + (i - g.isd)] = u_new;
+      if (changed(u_new, u_c)) p.uhr[rowU + (i - g.isd)] = u_new;
     }
     // cell volume and tracers, :636-662, and underflow :683-687
     if (cell_ok) {
       double h_new, hlst, Ihnew;
       const bool do_i = cell_volume<false>(hh, hh_w, h_c, aT_c, h_neglect, h_new, hlst, Ihnew);
-      if (p.write_mass && h_new != h_c) p.hprev[rowH + (i - g.isd)] = h_new;
+      if (p.write_mass && changed(h_new, h_c)) p.hprev[rowH + (i - g.isd)] = h_new;
 #pragma unroll
       for (int m = 0; m < NT; m++) {
         const double t_old = sT[m][P];
         double t_new = t_old;
         if (do_i && Ihnew > 0.0) t_new = (t_old * hlst - (flux[m] - fl_w[m])) * Ihnew;
         if (p.cu[m] > 0.0 && fabs(t_new) < p.cu[m]) t_new = 0.0;
-        if (t_new != t_old) p.tr[m][rowH + (i - g.isd)] = t_new;
+        if (changed(t_new, t_old)) p.tr[m][rowH + (i - g.isd)] = t_new;
       }
     }
     wave_sync();
@@ -523,20 +528,20 @@ __global__ __launch_bounds__(64) void adv_y_kernel(AdvArgs p) {
     if (p.write_mass && lane_ok) {
       double v_new = v_c - hh;
       if (fabs(v_new) < g.vh_neglect[col2V + (long)sH * (J - g.jsd)]) v_new = 0.0;
-      if (v_new != v_c) p.vhr[colV + (long)sH * (J - g.jsd)] = v_new;
+      if (changed(v_new, v_c)) p.vhr[colV + (long)sH * (J - g.jsd)] = v_new;
     }
     // cell j = J, :1028-1059, and underflow :1062-1066
     if (J >= p.js && lane_ok) {
       double h_new, hlst, Ihnew;
       const bool do_i = cell_volume<true>(hh, hh_prev, h_c, a_c, h_neglect, h_new, hlst, Ihnew);
-      if (p.write_mass && h_new != h_c) p.hprev[colH + (long)sH * (j - g.jsd)] = h_new;
+      if (p.write_mass && changed(h_new, h_c)) p.hprev[colH + (long)sH * (j - g.jsd)] = h_new;
 #pragma unroll
       for (int m = 0; m < NT; m++) {
         const double t_old = t2[m];
         double t_new = t_old;
         if (do_i) t_new = (t_old * hlst - (flux[m] - fl_prev[m])) * Ihnew;
         if (p.cu[m] > 0.0 && fabs(t_new) < p.cu[m]) t_new = 0.0;
-        if (t_new != t_old) p.tr[m][colH + (long)sH * (j - g.jsd)] = t_new;
+        if (changed(t_new, t_old)) p.tr[m][colH + (long)sH * (j - g.jsd)] = t_new;
       }
     }
     // advance the rings

@@ -80,12 +80,14 @@ def test_parity_tracer_counts_multichunk(oracle, scheme, ntr):
 def test_parity_limiter_iterations(oracle, scheme, x_first):
     g, case = advect_case(ni=70, nj=33, nk=4, ntr=2, hot_frac=0.05, seed=5, cfl=0.1)
     ref = run_oracle(oracle, g, case, scheme, x_first=x_first)
-    assert ref["stats"].iterations >= 2
+    if x_first:   # the hot cells diverge in x: only an x-first sweep has to postpone transport
+        assert ref["stats"].iterations >= 2
     out = run_hip(g, case, scheme, x_first=x_first)
     assert_same(g, ref, out, f"{scheme} limiter")
     ref1 = run_oracle(oracle, g, case, scheme, x_first=x_first, max_iter=1)
     out1 = run_hip(g, case, scheme, x_first=x_first, max_iter=1)
-    assert ref1["stats"].domore_remaining > 0
+    if x_first:
+        assert ref1["stats"].domore_remaining > 0
     assert_same(g, ref1, out1, f"{scheme} limiter max_iter=1")
 
 
