@@ -1,0 +1,196 @@
+!> Drop-in replacement for module MOM_tracer_advect (src/tracer/MOM_tracer_advect.F90): the same
+!! public procedures with the same dummy-argument lists, so src/core/MOM.F90 (:1438),
+!! src/tracer/MOM_offline_main.F90 and the other callers compile unchanged; the work is done by
+!! libmom6hip's HIP kernels through mom6hip_c_api.
+!!
+!! Build note: this file is compiled INSIDE a MOM6 source tree in place of
+!! src/tracer/MOM_tracer_advect.F90 (it uses the real MOM_grid, MOM_tracer_registry, ... modules), and
+!! the executable is linked with -lmom6hip.  It cannot be compiled in this repository's container
+!! (those modules need FMS); tests/fortran/advect_driver.F90 exercises the same C binding without them.
+module MOM_tracer_advect
+
+use, intrinsic :: iso_c_binding
+use mom6hip_c_api
+use MOM_cpu_clock,       only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
+use MOM_diag_mediator,   only : diag_ctrl, time_type
+use MOM_error_handler,   only : MOM_error, FATAL, WARNING
+use MOM_file_parser,     only : get_param, log_version, param_file_type
+use MOM_grid,            only : ocean_grid_type
+use MOM_open_boundary,   only : ocean_OBC_type
+use MOM_tracer_registry, only : tracer_registry_type
+use MOM_unit_scaling,    only : unit_scale_type
+use MOM_verticalGrid,    only : verticalGrid_type
+implicit none ; private
+
+#include <MOM_memory.h>
+
+public advect_tracer
+public tracer_advect_init
+public tracer_advect_end
+
+!> Control structure for this module (same role as the reference's tracer_advect_CS, :30-40)
+type, public :: tracer_advect_CS ; private
+  real    :: dt                    !< The baroclinic dynamics time step [T ~> s].
+  type(diag_ctrl), pointer :: diag => NULL()
+  logical :: debug
+  logical :: usePPM
+  logical :: useHuynh
+  logical :: useHuynhStencilBug = .false.
+  type(c_ptr) :: ctx = c_null_ptr  !< mom6hip_ctx_t: metrics and work space resident on the GPU
+end type tracer_advect_CS
+
+integer :: id_clock_advect
+
+contains
+
+!> Same interface as the reference advect_tracer (src/tracer/MOM_tracer_advect.F90:52).
+subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first_in, &
+                         vol_prev, max_iter_in, update_vol_prev, uhr_out, vhr_out)
+  type(ocean_grid_type),   intent(inout) :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(in) :: h_end
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: uhtr
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(in) :: vhtr
+  type(ocean_OBC_type),    pointer       :: OBC
+  real,                    intent(in)    :: dt
+  type(unit_scale_type),   intent(in)    :: US
+  type(tracer_advect_CS),  pointer       :: CS
+  type(tracer_registry_type), pointer    :: Reg
+  logical,       optional, intent(in)    :: x_first_in
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, optional, intent(inout) :: vol_prev
+  integer,       optional, intent(in)    :: max_iter_in
+  logical,       optional, intent(in)    :: update_vol_prev
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, optional, intent(out) :: uhr_out
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, optional, intent(out) :: vhr_out
+
+  type(c_ptr), allocatable :: tr(:)
+  real(c_double), allocatable, target :: cu(:)
+  type(mom6hip_tracer_advect_cs_t) :: ccs
+  type(mom6hip_advect_stats_t) :: stats
+  type(c_ptr) :: p_vol, p_uhr, p_vhr
+  integer(c_int32_t) :: xf, mi, uv
+  integer :: m, rc
+
+  if (.not. associated(CS)) call MOM_error(FATAL, "MOM_tracer_advect: "// &
+       "tracer_advect_init must be called before advect_tracer.")
+  if (.not. associated(Reg)) call MOM_error(FATAL, "MOM_tracer_advect: "// &
+       "register_tracer must be called before advect_tracer.")
+  if (Reg%ntr==0) return
+  if (associated(OBC)) call MOM_error(FATAL, "MOM_tracer_advect (HIP): open boundary conditions "// &
+       "are not supported by the GPU tracer advection.")
+  call cpu_clock_begin(id_clock_advect)
+
+  if (.not. c_associated(CS%ctx)) call create_context(G, GV, CS)
+
+  allocate(tr(Reg%ntr), cu(Reg%ntr))
+  do m=1,Reg%ntr
+    if (associated(Reg%Tr(m)%ad_x) .or. associated(Reg%Tr(m)%ad_y) .or. &
+        associated(Reg%Tr(m)%advection_xy) .or. associated(Reg%Tr(m)%ad2d_x) .or. &
+        associated(Reg%Tr(m)%ad2d_y)) call MOM_error(FATAL, "MOM_tracer_advect (HIP): "// &
+        "advective flux diagnostics are not provided by the GPU tracer advection.")
+    tr(m) = c_loc(Reg%Tr(m)%t)
+    cu(m) = Reg%Tr(m)%conc_underflow
+  enddo
+
+  ccs%dt = CS%dt ; ccs%use_huynh_stencil_bug = merge(1, 0, CS%useHuynhStencilBug)
+  ccs%scheme = MOM6HIP_ADV_PLM
+  if (CS%usePPM .and. CS%useHuynh) ccs%scheme = MOM6HIP_ADV_PPM_H3
+  if (CS%usePPM .and. .not.CS%useHuynh) ccs%scheme = MOM6HIP_ADV_PPM
+
+  xf = -1 ; if (present(x_first_in)) xf = merge(1, 0, x_first_in)
+  mi = 0 ; if (present(max_iter_in)) mi = max_iter_in
+  uv = 0 ; if (present(update_vol_prev)) uv = merge(1, 0, update_vol_prev)
+  p_vol = c_null_ptr ; if (present(vol_prev)) p_vol = c_loc(vol_prev)
+  p_uhr = c_null_ptr ; if (present(uhr_out)) p_uhr = c_loc(uhr_out)
+  p_vhr = c_null_ptr ; if (present(vhr_out)) p_vhr = c_loc(vhr_out)
+
+  rc = mom6hip_advect_tracer(CS%ctx, c_loc(h_end), c_loc(uhtr), c_loc(vhtr), dt, ccs, tr, c_loc(cu), &
+                             int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, &
+                             MOM6HIP_MEM_HOST, stats)
+  if (rc /= 0) call MOM_error(FATAL, "MOM_tracer_advect (HIP): "//mom6hip_error_string())
+
+  call cpu_clock_end(id_clock_advect)
+end subroutine advect_tracer
+
+!> Upload the grid metrics once and keep the context in the control structure.
+subroutine create_context(G, GV, CS)
+  type(ocean_grid_type), target, intent(in) :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(tracer_advect_CS),  intent(inout) :: CS
+  type(mom6hip_grid_t) :: cg
+  integer :: rc
+
+  if (.not. G%symmetric) call MOM_error(FATAL, "MOM_tracer_advect (HIP): SYMMETRIC_MEMORY_ is required.")
+  cg%isc = G%isc ; cg%iec = G%iec ; cg%jsc = G%jsc ; cg%jec = G%jec
+  cg%isd = G%isd ; cg%ied = G%ied ; cg%jsd = G%jsd ; cg%jed = G%jed
+  cg%nk = GV%ke ; cg%symmetric = 1 ; cg%first_direction = G%first_direction
+  ! One tile per process: the wrap-around is then done by the library; with more than one tile the
+  ! halo exchange is the RCCL path (see INTEGRATION.md) and both flags are 0.
+  cg%reentrant_x = 0 ; cg%reentrant_y = 0
+  cg%Angstrom_H = GV%Angstrom_H ; cg%H_subroundoff = GV%H_subroundoff
+  cg%dZ_subroundoff = GV%dZ_subroundoff ; cg%H_to_Z = GV%H_to_Z ; cg%Z_to_H = GV%Z_to_H
+  cg%g_Earth = GV%g_Earth ; cg%Rho0 = GV%Rho0
+  cg%mask2dT = c_loc(G%mask2dT) ; cg%areaT = c_loc(G%areaT) ; cg%IareaT = c_loc(G%IareaT)
+  cg%mask2dCu = c_loc(G%mask2dCu) ; cg%mask2dCv = c_loc(G%mask2dCv)
+  rc = mom6hip_init(0)
+  if (rc == 0) rc = mom6hip_grid_create(cg, c_null_ptr, CS%ctx)
+  if (rc /= 0) call MOM_error(FATAL, "MOM_tracer_advect (HIP): "//mom6hip_error_string())
+end subroutine create_context
+
+!> Same parameters as the reference tracer_advect_init (:1090-1150).
+subroutine tracer_advect_init(Time, G, US, param_file, diag, CS)
+  type(time_type), target, intent(in)    :: Time
+  type(ocean_grid_type),   intent(in)    :: G
+  type(unit_scale_type),   intent(in)    :: US
+  type(param_file_type),   intent(in)    :: param_file
+  type(diag_ctrl), target, intent(inout) :: diag
+  type(tracer_advect_CS),  pointer       :: CS
+# include "version_variable.h"
+  character(len=40)  :: mdl = "MOM_tracer_advect"
+  character(len=256) :: mesg
+
+  if (associated(CS)) then
+    call MOM_error(WARNING, "tracer_advect_init called with associated control structure.")
+    return
+  endif
+  allocate(CS)
+  CS%diag => diag
+  call log_version(param_file, mdl, version, "")
+  call get_param(param_file, mdl, "DT", CS%dt, fail_if_missing=.true., &
+          desc="The (baroclinic) dynamics time step.", units="s", scale=US%s_to_T)
+  call get_param(param_file, mdl, "DEBUG", CS%debug, default=.false.)
+  call get_param(param_file, mdl, "TRACER_ADVECTION_SCHEME", mesg, &
+          desc="The horizontal transport scheme for tracers:\n"//&
+          "  PLM    - Piecewise Linear Method\n"//&
+          "  PPM:H3 - Piecewise Parabolic Method (Huyhn 3rd order)\n"// &
+          "  PPM    - Piecewise Parabolic Method (Colella-Woodward)" &
+          , default='PLM')
+  select case (trim(mesg))
+    case ("PLM")
+      CS%usePPM = .false. ; CS%useHuynh = .false.
+    case ("PPM:H3")
+      CS%usePPM = .true. ; CS%useHuynh = .true.
+    case ("PPM")
+      CS%usePPM = .true. ; CS%useHuynh = .false.
+    case default
+      call MOM_error(FATAL, "MOM_tracer_advect, tracer_advect_init: "//&
+           "Unknown TRACER_ADVECTION_SCHEME = "//trim(mesg))
+  end select
+  if (CS%useHuynh) then
+    call get_param(param_file, mdl, "USE_HUYNH_STENCIL_BUG", CS%useHuynhStencilBug, &
+        desc="If true, use a stencil width of 2 in PPM:H3 tracer advection.", default=.false.)
+  endif
+  id_clock_advect = cpu_clock_id('(Ocean advect tracer)', grain=CLOCK_MODULE)
+end subroutine tracer_advect_init
+
+!> Close the tracer advection module and release the GPU context.
+subroutine tracer_advect_end(CS)
+  type(tracer_advect_CS), pointer :: CS
+  integer :: rc
+  if (associated(CS)) then
+    if (c_associated(CS%ctx)) rc = mom6hip_grid_destroy(CS%ctx)
+    deallocate(CS)
+  endif
+end subroutine tracer_advect_end
+
+end module MOM_tracer_advect
