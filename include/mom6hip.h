@@ -153,6 +153,7 @@ int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, const double 
  * counts, ms_total the whole call.  Only filled when timing was enabled before the call. */
 typedef struct mom6hip_advect_timing {
   double ms_total, ms_setup, ms_x, ms_y, ms_halo;
+  double ms_x1, ms_y1;       /* the launches of the first iteration only (every row active) */
   int32_t n_x, n_y;
 } mom6hip_advect_timing_t;
 int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable);

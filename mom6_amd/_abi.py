@@ -44,5 +44,6 @@ class AdvectStats(C.Structure):
 
 class AdvectTiming(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_setup", C.c_double), ("ms_x", C.c_double),
-                ("ms_y", C.c_double), ("ms_halo", C.c_double), ("n_x", C.c_int32),
+                ("ms_y", C.c_double), ("ms_halo", C.c_double), ("ms_x1", C.c_double),
+                ("ms_y1", C.c_double), ("n_x", C.c_int32),
                 ("n_y", C.c_int32)]

@@ -19,6 +19,8 @@
 //    iteration for the exit test (the reference's sum_across_PEs at :305).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -61,6 +63,24 @@ __device__ __forceinline__ bool changed(double a, double b) {
 __device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
 __device__ __forceinline__ double min3(double a, double b, double c) { return fmin(fmin(a, b), c); }
 
+// x / d for a constant d (6 or 3), bit-identical to the IEEE division the reference performs but
+// without the ~13-slot v_div/v_rcp sequence: q = x*RN(1/d) is within 1 ulp, the FMA residual
+// r = x - d*q is exact, and RN(q + r*RN(1/d)) is then the correctly rounded quotient (Markstein's
+// correction step; checked against x/d on 4e8 random operands in tests/).  Zero keeps its sign and
+// operands outside [2^-900, 2^900] (where the residual could under/overflow) take the real division.
+template <int D>
+__device__ __forceinline__ double div_const(double x) {
+  constexpr double d = (double)D, c = 1.0 / (double)D;
+  const double q = x * c;
+  const double r = __fma_rn(-d, q, x);
+  const double qq = __fma_rn(r, c, q);
+  const double ax = fabs(x);
+  const bool fast = (ax > 0x1p-900) && (ax < 0x1p900);
+  double res = fast ? qq : x;
+  if (__builtin_expect(!fast && ax != 0.0, 0)) res = x / d;
+  return res;
+}
+
 // limited slope, MOM_tracer_advect.F90:427-431 / :809-813
 __device__ __forceinline__ double plm_slope(double Tp, double Tc, double Tm, double mask) {
   double dMx = max3(Tp, Tc, Tm) - Tc;
@@ -77,29 +97,27 @@ __device__ __forceinline__ void face_transport(double r_c, double r_m, double r_
                                                double &CFL, bool &limited) {
   const double tiny_h = DBL_MIN;
   limited = false;
-  if ((r_c == 0.0) || ((r_c < 0.0) && (h_p <= tiny_h)) || ((r_c > 0.0) && (h_m <= tiny_h))) {
-    hh = 0.0; CFL = 0.0;
-  } else if (r_c < 0.0) {
-    double hup = h_p - a_p * min_h;
-    double hlos = fmax(0.0, r_p);
+  const bool none = (r_c == 0.0) || ((r_c < 0.0) && (h_p <= tiny_h)) || ((r_c > 0.0) && (h_m <= tiny_h));
+  const bool neg = r_c < 0.0;
+  hh = r_c;
+  if (neg) {
+    const double hup = h_p - a_p * min_h;
+    const double hlos = fmax(0.0, r_p);
     if ((((hup - hlos) + r_c) < 0.0) && ((0.5 * hup + r_c) < 0.0)) {
       hh = min3(-0.5 * hup, -hup + hlos, 0.0);
       limited = true;
-    } else {
-      hh = r_c;
     }
-    CFL = -hh / h_p;
   } else {
-    double hup = h_m - a_m * min_h;
-    double hlos = fmax(0.0, -r_m);
+    const double hup = h_m - a_m * min_h;
+    const double hlos = fmax(0.0, -r_m);
     if ((((hup - hlos) - r_c) < 0.0) && ((0.5 * hup - r_c) < 0.0)) {
       hh = max3(0.5 * hup, hup - hlos, 0.0);
       limited = true;
-    } else {
-      hh = r_c;
     }
-    CFL = hh / h_m;
   }
+  // CFL = -uhh/hprev(i+1) or uhh/hprev(i): one division, the negation is exact
+  const double q = (neg ? -hh : hh) / (neg ? h_p : h_m);
+  if (none) { hh = 0.0; CFL = 0.0; limited = false; } else { CFL = q; }
 }
 
 // PPM edge values, CW84 monotonicity and the CFL-integrated flux, :526-556 / :911-941
@@ -108,20 +126,21 @@ __device__ __forceinline__ double ppm_flux(double Tp, double Tc, double Tm, doub
                                            double mask_prod, double hh, double CFL) {
   double aL, aR;
   if (SCHEME == H3) {
-    aL = (5. * Tc + (2. * Tm - Tp)) / 6.;
+    aL = div_const<6>(5. * Tc + (2. * Tm - Tp));
     aL = fmax(fmin(Tc, Tm), aL); aL = fmin(fmax(Tc, Tm), aL);
-    aR = (5. * Tc + (2. * Tp - Tm)) / 6.;
+    aR = div_const<6>(5. * Tc + (2. * Tp - Tm));
     aR = fmax(fmin(Tc, Tp), aR); aR = fmin(fmax(Tc, Tp), aR);
   } else {
-    aL = 0.5 * ((Tm + Tc) + (sm - sc) / 3.);
-    aR = 0.5 * ((Tc + Tp) + (sc - sp) / 3.);
+    aL = 0.5 * ((Tm + Tc) + div_const<3>(sm - sc));
+    aR = 0.5 * ((Tc + Tp) + div_const<3>(sc - sp));
   }
   double dA = aR - aL, mA = 0.5 * (aR + aL);
+  const double dA2_6 = div_const<6>(dA * dA);
   if (mask_prod * (Tp - Tc) * (Tc - Tm) <= 0.) {
     aL = Tc; aR = Tc;
-  } else if (dA * (Tc - mA) > (dA * dA) / 6.) {
+  } else if (dA * (Tc - mA) > dA2_6) {
     aL = 3. * Tc - 2. * aR;
-  } else if (dA * (Tc - mA) < -(dA * dA) / 6.) {
+  } else if (dA * (Tc - mA) < -dA2_6) {
     aR = 3. * Tc - 2. * aL;
   }
   double a6 = 6. * Tc - 3. * (aR + aL);
@@ -140,13 +159,12 @@ __device__ __forceinline__ bool cell_volume(double hh_p, double hh_m, double h_o
     hlst = h_old;
     h_new = h_old - (hh_p - hh_m);
     if (CLAMP0) h_new = fmax(h_new, 0.0);
+    const double hmin = h_neglect * areaT;
+    const bool thin = h_new < hmin;
+    const double inv = 1.0 / (thin ? hmin : h_new);
     if (h_new <= 0.0) { Ihnew = 0.0; return false; }
-    else if (h_new < h_neglect * areaT) {
-      hlst = hlst + (h_neglect * areaT - h_new);
-      Ihnew = 1.0 / (h_neglect * areaT);
-    } else {
-      Ihnew = 1.0 / h_new;
-    }
+    if (thin) hlst = hlst + (hmin - h_new);
+    Ihnew = inv;
     return true;
   }
   h_new = h_old; hlst = h_old; Ihnew = 0.0;
@@ -264,7 +282,9 @@ __global__ void adv_vflags_prep_kernel(m6::GridDev g, const int *in, int *out, c
 
 // ---------------------------------------------------------------------------------------------
 // advect_x: one wavefront per (j,k) row.
-template <int NT, int SCHEME>
+// FIRST tags the launches of iteration 1 (every row active); the code is identical, the separate
+// symbol keeps profiler statistics of the dense pass apart from the sparse later iterations.
+template <int NT, int SCHEME, bool FIRST>
 __global__ __launch_bounds__(256) void adv_x_kernel(AdvArgs p) {
   const m6::GridDev &g = p.g;
   __shared__ double s_T[4][NT][XTW];
@@ -442,66 +462,137 @@ __global__ __launch_bounds__(256) void adv_x_kernel(AdvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// advect_y: one lane per (i,k) column, marching J = js-1 .. je.
-template <int NT, int SCHEME>
-__global__ __launch_bounds__(64) void adv_y_kernel(AdvArgs p) {
+// advect_y: one lane per (i,k) column.  The J range [js-1, je] of a 64-column strip is cut into
+// `nseg` segments, one per wavefront of the block (occupancy: a single marching wave per strip leaves
+// most of the chip idle).  In-place safety across segments: before the block's only barrier every wave
+// has (a) filled its register ring with the rows at and below its first face and (b) copied the rows
+// just above its last face -- which the next wave will overwrite early in its own march -- into LDS;
+// after the barrier a wave reads global memory only inside its own segment.  Each wave starts with one
+// face-only step at J = Ja-1 (recomputing the flux its southern neighbour also computes) so that no
+// flux has to cross a wave boundary.
+constexpr int YSEG_MAX = 8;
+
+template <int NT, int SCHEME, bool FIRST>
+__global__ __launch_bounds__(64 * YSEG_MAX, 2) void adv_y_kernel(AdvArgs p, int seglen) {
   const m6::GridDev &g = p.g;
-  const int i = p.is + blockIdx.x * 64 + threadIdx.x;
+  constexpr int NHR = (SCHEME == CW) ? 3 : 2;        // foreign T rows needed above the segment's last face
+  __shared__ double s_halo[YSEG_MAX][NHR * NT + 2][64];
+  const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = p.is + blockIdx.x * 64 + lane;
   const int k = blockIdx.y;
-  if (p.domore_k[k] <= 0) return;
+  if (p.domore_k[k] <= 0) return;                    // block-uniform
   const bool lane_ok = (i <= p.ie);
-  const int ii = lane_ok ? i : p.ie;           // inactive lanes shadow a valid column, never store
+  const int ii = lane_ok ? i : p.ie;                 // idle lanes shadow a valid column, never store
   const double min_h = 0.1 * g.Angstrom_H;
   const double h_neglect = g.H_subroundoff;
   const long colH = g.h3(ii, g.jsd, k), colV = g.v3(ii, g.jsd, k);
   const long col2H = g.h2(ii, g.jsd), col2V = g.v2(ii, g.jsd);
-  const int sH = g.nih;                        // j stride of h- and v-point arrays
-  auto ldH = [&](const double *a, int j) -> double { return (j >= g.jsd && j <= g.jed) ? a[colH + (long)sH * (j - g.jsd)] : 0.0; };
-  auto ldV = [&](const double *a, int J) -> double { return (J >= g.jsd - 1 && J <= g.jed) ? a[colV + (long)sH * (J - g.jsd)] : 0.0; };
+  const int sH = g.nih;                              // j stride of h- and v-point arrays
+  auto gH = [&](const double *a, int j) -> double { return (j >= g.jsd && j <= g.jed) ? a[colH + (long)sH * (j - g.jsd)] : 0.0; };
+  auto gV = [&](const double *a, int J) -> double { return (J >= g.jsd - 1 && J <= g.jed) ? a[colV + (long)sH * (J - g.jsd)] : 0.0; };
   auto ldA = [&](int j) -> double { return (j >= g.jsd && j <= g.jed) ? g.areaT[col2H + (long)sH * (j - g.jsd)] : 0.0; };
   auto ldM = [&](int J) -> double { return (J >= g.jsd - 1 && J <= g.jed) ? g.mask2dCv[col2V + (long)sH * (J - g.jsd)] : 0.0; };
   const int *dv_in = p.domore_v_in + (long)(g.njh + 1) * k - (g.jsd - 1);
   int *dv_out = p.domore_v_out + (long)(g.njh + 1) * k - (g.jsd - 1);
-
+  // is face J one advect_y works on (:868)?  (uniform)
   const int J0 = p.js - 1, J1 = p.je;
-  // rings at step J: T rows J-2..J+3 (t0..t5), hprev rows J, J+1, vhr rows J-1..J+1,
-  // areaT rows J, J+1, mask2dCv rows J-2..J+2
+  auto act_face = [&](int J) -> unsigned { return ((J >= J0 && J <= J1) && dv_in[J] != 0) ? 1u : 0u; };
+
+  const int Ja = J0 + seg * seglen;                  // first face this wave owns
+  const int Jb = (Ja + seglen - 1 < J1) ? Ja + seglen - 1 : J1;
+  const bool have = (Ja <= J1);
+  const int Js = (seg == 0) ? J0 : Ja - 1;           // first step (face-only when seg > 0)
+
+  // Row-level sparsity for iterations >= 2: fb bit n = "face J-3+n is active" at step J (a wave-uniform
+  // shift register, refilled one flag per step, two steps ahead of its first use).
+  // T(r) feeds the fluxes of faces r-2..r+1 (CW: r-3..r+2); hprev(r) those of faces r-1, r; a cell is
+  // updated only if one of its two faces is active, which the same masks cover.
+  unsigned fb = 0;
+  if (have) for (int n = 0; n < 16; n++) fb |= act_face(Js - 3 + n) << n;
+  const unsigned all = p.any_cu ? 1u : 0u;           // the underflow test needs every cell
+  auto need_T = [&](unsigned bits, int d) -> bool {  // row r = J + d
+    const unsigned m = (SCHEME == CW) ? (0x3Fu << d) : (0xFu << (d + 1));
+    return ((bits & m) | all) != 0;
+  };
+  auto need_h = [&](unsigned bits, int d) -> bool { return ((bits & (0x3u << (d + 4))) | all) != 0; };   // row r = J+2+d: faces r-1, r
+
+  // ---- before the barrier: ring at step Js, and the rows above Jb into LDS ----
   double t0[NT], t1[NT], t2[NT], t3[NT], t4[NT], t5[NT];
+  double h_c = 0., h_n = 0., v_s = 0., v_c = 0., v_n = 0., a_c = 0., a_n = 0.;
+  double m_ss = 0., m_s = 0., m_c = 0., m_n = 0., m_nn = 0.;
 #pragma unroll
-  for (int m = 0; m < NT; m++) {
-    t0[m] = (SCHEME == CW) ? ldH(p.tr[m], J0 - 2) : 0.0;
-    t1[m] = ldH(p.tr[m], J0 - 1); t2[m] = ldH(p.tr[m], J0); t3[m] = ldH(p.tr[m], J0 + 1);
-    t4[m] = ldH(p.tr[m], J0 + 2);
-    t5[m] = (SCHEME == CW) ? ldH(p.tr[m], J0 + 3) : 0.0;
+  for (int m = 0; m < NT; m++) { t0[m] = t1[m] = t2[m] = t3[m] = t4[m] = t5[m] = 0.0; }
+  if (have) {
+#pragma unroll
+    for (int m = 0; m < NT; m++) {
+      if (SCHEME == CW) t0[m] = gH(p.tr[m], Js - 2);
+      t1[m] = gH(p.tr[m], Js - 1);
+      t2[m] = gH(p.tr[m], Js);
+      t3[m] = gH(p.tr[m], Js + 1);
+      t4[m] = gH(p.tr[m], Js + 2);
+      if (SCHEME == CW) t5[m] = gH(p.tr[m], Js + 3);
+    }
+    h_c = gH(p.hprev, Js); h_n = gH(p.hprev, Js + 1);
+    v_s = gV(p.vhr, Js - 1); v_c = gV(p.vhr, Js); v_n = gV(p.vhr, Js + 1);
+    a_c = ldA(Js); a_n = ldA(Js + 1);
+    if (SCHEME == CW) { m_ss = ldM(Js - 2); m_nn = ldM(Js + 2); }
+    m_s = ldM(Js - 1); m_c = ldM(Js); m_n = ldM(Js + 1);
+    double(*hl)[64] = s_halo[seg];
+#pragma unroll
+    for (int r = 0; r < NHR; r++) {
+#pragma unroll
+      for (int m = 0; m < NT; m++) hl[r * NT + m][lane] = gH(p.tr[m], Jb + 1 + r);
+    }
+    hl[NHR * NT][lane] = gH(p.hprev, Jb + 1);
+    hl[NHR * NT + 1][lane] = gV(p.vhr, Jb + 1);
   }
-  double h_c = ldH(p.hprev, J0), h_n = ldH(p.hprev, J0 + 1);
-  double v_s = ldV(p.vhr, J0 - 1), v_c = ldV(p.vhr, J0), v_n = ldV(p.vhr, J0 + 1);
-  double a_c = ldA(J0), a_n = ldA(J0 + 1);
-  double m_ss = (SCHEME == CW) ? ldM(J0 - 2) : 0.0, m_s = ldM(J0 - 1), m_c = ldM(J0), m_n = ldM(J0 + 1);
-  double m_nn = (SCHEME == CW) ? ldM(J0 + 2) : 0.0;
+  __syncthreads();
+  if (!have) return;
+  const double(*hl)[64] = s_halo[seg];
+
   double hh_prev = 0.0, fl_prev[NT];
 #pragma unroll
   for (int m = 0; m < NT; m++) fl_prev[m] = 0.0;
+  constexpr int DT_ = (SCHEME == CW) ? 4 : 3;        // the T row entering the ring is J + DT_
+  unsigned pend = act_face(Js + 13);
 
-  for (int J = J0; J <= J1; J++) {
+  // One step of the march.  TAIL = the new rows may lie above Jb and then come from LDS.
+  auto step = [&](const int J, auto tail_tag) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int j = J;
+    const bool own = (J >= Ja);                  // false only on the face-only first step of seg > 0
     // issue the loads of the rows that enter the rings at the next step
-    double nt[NT];
+    double nt[NT], nh, nv;
+    const int rT = J + DT_;
+    if (!TAIL) {
+      const bool nT = need_T(fb, DT_);
 #pragma unroll
-    for (int m = 0; m < NT; m++) nt[m] = ldH(p.tr[m], (SCHEME == CW) ? J + 4 : J + 3);
-    const double nh = ldH(p.hprev, J + 2), nv = ldV(p.vhr, J + 2), na = ldA(J + 2);
+      for (int m = 0; m < NT; m++) nt[m] = nT ? p.tr[m][colH + (long)sH * (rT - g.jsd)] : 0.0;
+      nh = need_h(fb, 0) ? p.hprev[colH + (long)sH * (J + 2 - g.jsd)] : 0.0;
+      nv = p.vhr[colV + (long)sH * (J + 2 - g.jsd)];
+    } else {
+#pragma unroll
+      for (int m = 0; m < NT; m++) {
+        if (rT <= Jb) nt[m] = p.tr[m][colH + (long)sH * (rT - g.jsd)];
+        else nt[m] = (rT <= Jb + NHR) ? hl[(rT - Jb - 1) * NT + m][lane] : 0.0;
+      }
+      if (J + 2 <= Jb) { nh = p.hprev[colH + (long)sH * (J + 2 - g.jsd)]; nv = p.vhr[colV + (long)sH * (J + 2 - g.jsd)]; }
+      else { nh = (J + 2 == Jb + 1) ? hl[NHR * NT][lane] : 0.0; nv = (J + 2 == Jb + 1) ? hl[NHR * NT + 1][lane] : 0.0; }
+    }
+    const double na = ldA(J + 2);
     const double nm = ldM((SCHEME == CW) ? J + 3 : J + 2);
+    const unsigned pend_next = act_face(J + 14);
 
-    const bool act = dv_in[J] != 0;
+    const bool act = (fb >> 3) & 1u;
     double hh = 0.0, CFL = 0.0, flux[NT];
 #pragma unroll
     for (int m = 0; m < NT; m++) flux[m] = 0.0;
     if (act) {
       bool lim;
       face_transport(v_c, v_s, v_n, h_c, h_n, a_c, a_n, min_h, hh, CFL, lim);
-      if (p.write_mass && __any((lim && lane_ok) ? 1 : 0) && threadIdx.x == 0) dv_out[J] = 1;
+      if (own && p.write_mass && __any((lim && lane_ok) ? 1 : 0) && lane == 0) dv_out[J] = 1;
       const bool up = !(hh >= 0.0);              // j_up = j + up
-      // masks mask2dCv(i,J_up)*mask2dCv(i,J_up-1) of the rows j_up-1, j_up, j_up+1
+      // mask2dCv(i,J_up)*mask2dCv(i,J_up-1)
       const double mk_c = up ? (m_n * m_c) : (m_c * m_s);
 #pragma unroll
       for (int m = 0; m < NT; m++) {
@@ -525,13 +616,13 @@ __global__ __launch_bounds__(64) void adv_y_kernel(AdvArgs p) {
       }
     }
     // remaining transport, :1021-1024 (every row J, active or not)
-    if (p.write_mass && lane_ok) {
+    if (own && p.write_mass && lane_ok) {
       double v_new = v_c - hh;
       if (fabs(v_new) < g.vh_neglect[col2V + (long)sH * (J - g.jsd)]) v_new = 0.0;
       if (changed(v_new, v_c)) p.vhr[colV + (long)sH * (J - g.jsd)] = v_new;
     }
     // cell j = J, :1028-1059, and underflow :1062-1066
-    if (J >= p.js && lane_ok) {
+    if (own && J >= p.js && lane_ok) {
       double h_new, hlst, Ihnew;
       const bool do_i = cell_volume<true>(hh, hh_prev, h_c, a_c, h_neglect, h_new, hlst, Ihnew);
       if (p.write_mass && changed(h_new, h_c)) p.hprev[colH + (long)sH * (j - g.jsd)] = h_new;
@@ -557,24 +648,42 @@ __global__ __launch_bounds__(64) void adv_y_kernel(AdvArgs p) {
     a_c = a_n; a_n = na;
     m_ss = m_s; m_s = m_c; m_c = m_n;
     if (SCHEME == CW) { m_n = m_nn; m_nn = nm; } else { m_n = nm; }
-  }
+    fb = (fb >> 1) | (pend << 15);
+    pend = pend_next;
+  };
+
+  // main part: every row that enters the rings lies inside the segment (and inside the array)
+  int J = Js;
+  const int Jmain = ((Jb - DT_ < g.jed - DT_) ? Jb - DT_ : g.jed - DT_);
+  for (; J <= Jmain; J++) step(J, std::false_type{});
+  for (; J <= Jb; J++) step(J, std::true_type{});
 }
 
-template <int NT>
-void launch_x(int scheme, dim3 grid, hipStream_t s, const AdvArgs &a) {
+template <int NT, bool FIRST>
+void launch_x2(int scheme, dim3 grid, hipStream_t s, const AdvArgs &a) {
   switch (scheme) {
-    case PLM: hipLaunchKernelGGL((adv_x_kernel<NT, PLM>), grid, dim3(256), 0, s, a); break;
-    case H3:  hipLaunchKernelGGL((adv_x_kernel<NT, H3>), grid, dim3(256), 0, s, a); break;
-    default:  hipLaunchKernelGGL((adv_x_kernel<NT, CW>), grid, dim3(256), 0, s, a); break;
+    case PLM: hipLaunchKernelGGL((adv_x_kernel<NT, PLM, FIRST>), grid, dim3(256), 0, s, a); break;
+    case H3:  hipLaunchKernelGGL((adv_x_kernel<NT, H3, FIRST>), grid, dim3(256), 0, s, a); break;
+    default:  hipLaunchKernelGGL((adv_x_kernel<NT, CW, FIRST>), grid, dim3(256), 0, s, a); break;
   }
 }
 template <int NT>
-void launch_y(int scheme, dim3 grid, hipStream_t s, const AdvArgs &a) {
+void launch_x(int scheme, bool first, dim3 grid, hipStream_t s, const AdvArgs &a) {
+  if (first) launch_x2<NT, true>(scheme, grid, s, a); else launch_x2<NT, false>(scheme, grid, s, a);
+}
+template <int NT, bool FIRST>
+void launch_y2(int scheme, dim3 grid, int nseg, int seglen, hipStream_t s, const AdvArgs &a) {
+  const dim3 block(64 * nseg);
   switch (scheme) {
-    case PLM: hipLaunchKernelGGL((adv_y_kernel<NT, PLM>), grid, dim3(64), 0, s, a); break;
-    case H3:  hipLaunchKernelGGL((adv_y_kernel<NT, H3>), grid, dim3(64), 0, s, a); break;
-    default:  hipLaunchKernelGGL((adv_y_kernel<NT, CW>), grid, dim3(64), 0, s, a); break;
+    case PLM: hipLaunchKernelGGL((adv_y_kernel<NT, PLM, FIRST>), grid, block, 0, s, a, seglen); break;
+    case H3:  hipLaunchKernelGGL((adv_y_kernel<NT, H3, FIRST>), grid, block, 0, s, a, seglen); break;
+    default:  hipLaunchKernelGGL((adv_y_kernel<NT, CW, FIRST>), grid, block, 0, s, a, seglen); break;
   }
+}
+template <int NT>
+void launch_y(int scheme, bool first, dim3 grid, int nseg, int seglen, hipStream_t s, const AdvArgs &a) {
+  if (first) launch_y2<NT, true>(scheme, grid, nseg, seglen, s, a);
+  else launch_y2<NT, false>(scheme, grid, nseg, seglen, s, a);
 }
 
 struct Timer {
@@ -687,6 +796,7 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
   }
   tm.ms_setup += t_k.stop();
 
+  int itt = 1;
   const int ngroups = (ntr + MAXG - 1) / MAXG;
   auto group_args = [&](int grp, AdvArgs &a) -> int {
     a.g = g; a.hprev = hprev; a.uhr = uhr; a.vhr = vhr;
@@ -710,15 +820,15 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
       a.domore_v_in = domore_v; a.domore_v_out = domore_v;
       dim3 grid((xje - xjs + 1 + 3) / 4, nz);
       switch (n) {
-        case 1: launch_x<1>(cs->scheme, grid, s, a); break;
-        case 2: launch_x<2>(cs->scheme, grid, s, a); break;
-        case 3: launch_x<3>(cs->scheme, grid, s, a); break;
-        default: launch_x<4>(cs->scheme, grid, s, a); break;
+        case 1: launch_x<1>(cs->scheme, itt == 1, grid, s, a); break;
+        case 2: launch_x<2>(cs->scheme, itt == 1, grid, s, a); break;
+        case 3: launch_x<3>(cs->scheme, itt == 1, grid, s, a); break;
+        default: launch_x<4>(cs->scheme, itt == 1, grid, s, a); break;
       }
       M6_HIP(hipGetLastError());
       tm.n_x++;
     }
-    tm.ms_x += t_k.stop();
+    { const double ms = t_k.stop(); tm.ms_x += ms; if (itt == 1) tm.ms_x1 += ms; }
     return 0;
   };
   auto run_y = [&](int yis, int yie, int yjs, int yje) -> int {
@@ -730,22 +840,28 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
       a.is = yis; a.ie = yie; a.js = yjs; a.je = yje;
       a.domore_v_in = domore_v; a.domore_v_out = domore_v2;
       dim3 grid((yie - yis + 1 + 63) / 64, nz);
+      // segments of at least 8 faces, at most YSEG_MAX waves per column strip
+      const int nfaces = yje - yjs + 2;
+      int nseg_max = 4;   // measured best on MI355X (8: one block per CU; 1-2: too few waves)
+      if (const char *e = getenv("MOM6HIP_YSEG")) { int v = atoi(e); if (v >= 1 && v <= YSEG_MAX) nseg_max = v; }
+      int nseg = nfaces / 8; if (nseg < 1) nseg = 1; if (nseg > nseg_max) nseg = nseg_max;
+      const int seglen = (nfaces + nseg - 1) / nseg;
       switch (n) {
-        case 1: launch_y<1>(cs->scheme, grid, s, a); break;
-        case 2: launch_y<2>(cs->scheme, grid, s, a); break;
-        case 3: launch_y<3>(cs->scheme, grid, s, a); break;
-        default: launch_y<4>(cs->scheme, grid, s, a); break;
+        case 1: launch_y<1>(cs->scheme, itt == 1, grid, nseg, seglen, s, a); break;
+        case 2: launch_y<2>(cs->scheme, itt == 1, grid, nseg, seglen, s, a); break;
+        case 3: launch_y<3>(cs->scheme, itt == 1, grid, nseg, seglen, s, a); break;
+        default: launch_y<4>(cs->scheme, itt == 1, grid, nseg, seglen, s, a); break;
       }
       M6_HIP(hipGetLastError());
       tm.n_y++;
     }
     { int *t = domore_v; domore_v = domore_v2; domore_v2 = t; }
-    tm.ms_y += t_k.stop();
+    { const double ms = t_k.stop(); tm.ms_y += ms; if (itt == 1) tm.ms_y1 += ms; }
     return 0;
   };
 
   int isv = is, iev = ie, jsv = js, jev = je;
-  int itt = 1, halo_updates = 0, remaining = nz;
+  int halo_updates = 0, remaining = nz;
   for (itt = 1; itt <= max_iter; itt++) {
     if (isv > is - stencil) {
       // do_group_pass(CS%pass_uhr_vhr_t_hprev), :206

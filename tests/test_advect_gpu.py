@@ -91,6 +91,17 @@ def test_parity_limiter_iterations(oracle, scheme, x_first):
     assert_same(g, ref1, out1, f"{scheme} limiter max_iter=1")
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_parity_tall_grid_many_segments(oracle, scheme):
+    # 130 rows: advect_y splits the march over several waves per column strip (segment hand-over rows
+    # staged through LDS); hot cells force a sparse second iteration across the segment boundaries
+    g, case = advect_case(ni=70, nj=130, nk=2, ntr=4, hot_frac=0.01, seed=21, cfl=0.1)
+    for x_first in (True, False):
+        ref = run_oracle(oracle, g, case, scheme, x_first=x_first)
+        out = run_hip(g, case, scheme, x_first=x_first)
+        assert_same(g, ref, out, f"{scheme} tall x_first={x_first}")
+
+
 @pytest.mark.parametrize("topo", [(True, True), (False, False), (False, True)])
 def test_parity_topologies(oracle, topo):
     rx, ry = topo
