@@ -1,0 +1,20 @@
+#!/bin/bash
+# Compiles, UNMODIFIED and where they lie under /root/reference, the reference source files of the hot
+# path that need nothing but themselves (no MOM_error_handler / MOM_grid / FMS behind them), plus our
+# bind(C) caller oracle/ref_wrap.F90, into oracle/_ref/libmom6ref.so.  Everything else on the path
+# `use`s modules that end in FMS (not vendored) and is treated as unbuildable here.
+# -O0 -ffp-contract=off: the unfused IEEE evaluation of the source's parenthesisation.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF=/root/reference
+FC=${FC:-/opt/rocm/bin/amdflang}
+[ -d "$REF" ] || { echo "build_ref.sh: $REF not present, skipping"; exit 0; }
+[ -x "$FC" ] || { echo "build_ref.sh: $FC not present, skipping"; exit 0; }
+OUT="$HERE/_ref"
+mkdir -p "$OUT/mod"
+FLAGS="-fdefault-real-8 -O0 -ffp-contract=off -fPIC -J $OUT/mod -I $OUT/mod"
+$FC $FLAGS -c "$REF/src/ALE/PCM_functions.F90" -o "$OUT/PCM_functions.o"
+$FC $FLAGS -c "$REF/src/ALE/PLM_functions.F90" -o "$OUT/PLM_functions.o"
+$FC $FLAGS -c "$HERE/ref_wrap.F90" -o "$OUT/ref_wrap.o"
+$FC -shared -o "$OUT/libmom6ref.so" "$OUT/PCM_functions.o" "$OUT/PLM_functions.o" "$OUT/ref_wrap.o"
+echo "built $OUT/libmom6ref.so"

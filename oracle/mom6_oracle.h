@@ -53,6 +53,41 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
                       int x_first_in, double *vol_prev, int max_iter_in, int update_vol_prev,
                       double *uhr_out, double *vhr_out, mom6hip_advect_stats_t *stats);
 
+/* ---- ALE reconstruction + remapping (oracle/remapping.c) ------------------------------------ */
+/* REMAPPING_* and INTEGRATION_* of src/ALE/MOM_remapping.F90:50-64 */
+#define ORC_REMAP_PCM     0
+#define ORC_REMAP_PLM     2
+#define ORC_REMAP_PPM_H4  4
+#define ORC_INT_PCM 0
+#define ORC_INT_PLM 1
+#define ORC_INT_PPM 3
+/* E(k,1:2) and coef(k,1:3) are Fortran-ordered: E[side*n + k], coef[d*n + k]. */
+void orc_pcm_reconstruction(int n, const double *u, double *E, double *coef);
+double orc_plm_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r);
+double orc_plm_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r);
+double orc_plm_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c);
+void orc_plm_reconstruction(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);
+void orc_plm_boundary_extrapolation(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);
+void orc_bound_edge_values(int n, const double *h, const double *u, double *E);
+void orc_check_discontinuous_edge_values(int n, const double *u, double *E);
+void orc_end_value_h4(const double dz[4], const double u[4], double Csys[4]);
+void orc_edge_values_explicit_h4(int n, const double *h, const double *u, double *E, double h_neglect);
+void orc_ppm_limiter_standard(int n, const double *h, const double *u, double *E);
+void orc_ppm_reconstruction(int n, const double *h, const double *u, double *E, double *coef);
+void orc_ppm_boundary_extrapolation(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);
+double orc_average_value_ppoly(int n, const double *u0, const double *E, const double *coef, int method,
+                               int i0, double xa, double xb);
+void orc_remap_via_sub_cells(int n0, const double *h0, const double *u0, const double *E, const double *coef,
+                             int n1, const double *h1, int method, int force_bounds_in_subcell,
+                             double *u1, double *uh_err);
+int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
+                                 double *coef, double *E, double h_neglect, double h_neglect_edge);
+int orc_remapping_core_h(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
+                         int n1, const double *h1, double *u1, double h_neglect, double h_neglect_edge);
+int orc_remapping_core_w(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
+                         int n1, const double *dx, double *u1, double h_neglect, double h_neglect_edge);
+void orc_dz_from_h1h2(int n1, const double *h1, int n2, const double *h2, double *dx);
+
 #ifdef __cplusplus
 }
 #endif

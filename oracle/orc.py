@@ -64,3 +64,117 @@ def advect_tracer(grid, h_end, uhtr, vhtr, dt, cs_dt, scheme, tr, conc_underflow
     if rc != 0:
         raise RuntimeError(f"orc_advect_tracer failed rc={rc}")
     return st
+
+
+# ---- ALE reconstruction + remapping ---------------------------------------------------------------
+REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PPM_H4": 4}
+INT_PCM, INT_PLM, INT_PPM = 0, 1, 3
+_ip = C.POINTER(C.c_int)
+
+
+def _remap_lib():
+    L = lib()
+    if not getattr(L, "_remap_ready", False):
+        d, i = C.c_double, C.c_int
+        L.orc_pcm_reconstruction.argtypes = [i, _dp, _dp, _dp]
+        L.orc_plm_slope_wa.argtypes = [d] * 7; L.orc_plm_slope_wa.restype = d
+        L.orc_plm_monotonized_slope.argtypes = [d] * 6; L.orc_plm_monotonized_slope.restype = d
+        L.orc_plm_extrapolate_slope.argtypes = [d] * 5; L.orc_plm_extrapolate_slope.restype = d
+        L.orc_plm_reconstruction.argtypes = [i, _dp, _dp, _dp, _dp, d]
+        L.orc_plm_boundary_extrapolation.argtypes = [i, _dp, _dp, _dp, _dp, d]
+        L.orc_edge_values_explicit_h4.argtypes = [i, _dp, _dp, _dp, d]
+        L.orc_ppm_reconstruction.argtypes = [i, _dp, _dp, _dp, _dp]
+        L.orc_ppm_boundary_extrapolation.argtypes = [i, _dp, _dp, _dp, _dp, d]
+        L.orc_remap_via_sub_cells.argtypes = [i, _dp, _dp, _dp, _dp, i, _dp, i, i, _dp, _dp]
+        L.orc_build_reconstructions_1d.argtypes = [i, i, i, _dp, _dp, _dp, _dp, d, d]
+        L.orc_build_reconstructions_1d.restype = i
+        L.orc_remapping_core_h.argtypes = [i, i, i, _dp, _dp, i, _dp, _dp, d, d]
+        L.orc_remapping_core_w.argtypes = [i, i, i, _dp, _dp, i, _dp, _dp, d, d]
+        L.orc_dz_from_h1h2.argtypes = [i, _dp, i, _dp, _dp]
+        for n in ("orc_pcm_reconstruction", "orc_plm_reconstruction", "orc_plm_boundary_extrapolation",
+                  "orc_edge_values_explicit_h4", "orc_ppm_reconstruction", "orc_ppm_boundary_extrapolation",
+                  "orc_remap_via_sub_cells", "orc_dz_from_h1h2"):
+            getattr(L, n).restype = None
+        L._remap_ready = True
+    return L
+
+
+def _a(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def pcm_reconstruction(u):
+    u = _a(u); n = len(u); E = np.zeros((2, n)); co = np.zeros((3, n))
+    _remap_lib().orc_pcm_reconstruction(n, _p(u), _p(E), _p(co))
+    return E, co
+
+
+def plm_reconstruction(h, u, h_neglect=1e-30, extrapolate=False):
+    h, u = _a(h), _a(u); n = len(u); E = np.zeros((2, n)); co = np.zeros((3, n))
+    L = _remap_lib()
+    L.orc_plm_reconstruction(n, _p(h), _p(u), _p(E), _p(co), h_neglect)
+    if extrapolate:
+        L.orc_plm_boundary_extrapolation(n, _p(h), _p(u), _p(E), _p(co), h_neglect)
+    return E, co
+
+
+def edge_values_explicit_h4(h, u, h_neglect=1e-30):
+    h, u = _a(h), _a(u); n = len(u); E = np.zeros((2, n))
+    _remap_lib().orc_edge_values_explicit_h4(n, _p(h), _p(u), _p(E), h_neglect)
+    return E
+
+
+def ppm_reconstruction(h, u, E, h_neglect=1e-30, extrapolate=False):
+    h, u = _a(h), _a(u); n = len(u); E = _a(E).copy(); co = np.zeros((3, n))
+    L = _remap_lib()
+    L.orc_ppm_reconstruction(n, _p(h), _p(u), _p(E), _p(co))
+    if extrapolate:
+        L.orc_ppm_boundary_extrapolation(n, _p(h), _p(u), _p(E), _p(co), h_neglect)
+    return E, co
+
+
+def remap_via_sub_cells(h0, u0, E, coef, h1, method, force_bounds_in_subcell=False):
+    h0, u0, h1, E, coef = _a(h0), _a(u0), _a(h1), _a(E), _a(coef)
+    u1 = np.zeros(len(h1)); err = C.c_double()
+    _remap_lib().orc_remap_via_sub_cells(len(h0), _p(h0), _p(u0), _p(E), _p(coef), len(h1), _p(h1), method,
+                                         int(force_bounds_in_subcell), _p(u1), C.cast(C.byref(err), _dp))
+    return u1, err.value
+
+
+def remapping_core_h(scheme, h0, u0, h1, h_neglect=1e-30, h_neglect_edge=1e-10, boundary_extrapolation=True):
+    h0, u0, h1 = _a(h0), _a(u0), _a(h1); u1 = np.zeros(len(h1))
+    rc = _remap_lib().orc_remapping_core_h(REMAP_SCHEMES[scheme], int(boundary_extrapolation), len(h0), _p(h0),
+                                          _p(u0), len(h1), _p(h1), _p(u1), h_neglect, h_neglect_edge)
+    if rc:
+        raise RuntimeError("MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid")
+    return u1
+
+
+def remapping_core_w(scheme, h0, u0, dx, h_neglect=1e-30, h_neglect_edge=1e-10, boundary_extrapolation=True):
+    h0, u0, dx = _a(h0), _a(u0), _a(dx); n1 = len(dx) - 1; u1 = np.zeros(n1)
+    rc = _remap_lib().orc_remapping_core_w(REMAP_SCHEMES[scheme], int(boundary_extrapolation), len(h0), _p(h0),
+                                          _p(u0), n1, _p(dx), _p(u1), h_neglect, h_neglect_edge)
+    if rc:
+        raise RuntimeError("MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid")
+    return u1
+
+
+def dz_from_h1h2(h1, h2):
+    h1, h2 = _a(h1), _a(h2); dx = np.zeros(len(h2) + 1)
+    _remap_lib().orc_dz_from_h1h2(len(h1), _p(h1), len(h2), _p(h2), _p(dx))
+    return dx
+
+
+# ---- oracle/_ref: reference sources compiled unmodified (only where they were built) ---------------
+def ref_lib():
+    path = os.path.join(_HERE, "_ref", "libmom6ref.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    d, i = C.c_double, C.c_int
+    L.ref_plm_reconstruction.argtypes = [i, _dp, _dp, _dp, _dp, d, i]; L.ref_plm_reconstruction.restype = None
+    L.ref_pcm_reconstruction.argtypes = [i, _dp, _dp, _dp]; L.ref_pcm_reconstruction.restype = None
+    L.ref_plm_slope_wa.argtypes = [d] * 7; L.ref_plm_slope_wa.restype = d
+    L.ref_plm_monotonized_slope.argtypes = [d] * 6; L.ref_plm_monotonized_slope.restype = d
+    L.ref_plm_extrapolate_slope.argtypes = [d] * 5; L.ref_plm_extrapolate_slope.restype = d
+    return L

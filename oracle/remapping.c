@@ -1,0 +1,590 @@
+/*
+ * remapping.c -- CPU restatement of the ALE column reconstruction + remapping (TEST INFRASTRUCTURE).
+ *
+ * Restates, with the same evaluation order, the latest-vintage (answer_date >= 20190101) branches of
+ *   PCM_reconstruction              src/ALE/PCM_functions.F90:18-37
+ *   PLM_slope_wa, PLM_monotonized_slope, PLM_extrapolate_slope, PLM_reconstruction,
+ *   PLM_boundary_extrapolation      src/ALE/PLM_functions.F90:22-307
+ *   bound_edge_values, check_discontinuous_edge_values, edge_values_explicit_h4, end_value_h4
+ *                                   src/ALE/regrid_edge_values.F90:44-110,141-159,222-363,658-771
+ *   PPM_reconstruction, PPM_limiter_standard, PPM_boundary_extrapolation
+ *                                   src/ALE/PPM_functions.F90:28-316
+ *   buildGridFromH, remapping_core_h, remapping_core_w, build_reconstructions_1d (PCM, PLM, PPM_H4),
+ *   remap_via_sub_cells, average_value_ppoly, dzFromH1H2
+ *                                   src/ALE/MOM_remapping.F90:145-386,463-852,998-1099,1235-1256
+ *
+ * PINNED by the reference's own known-answer vectors (remapping_unit_tests,
+ * src/ALE/MOM_remapping.F90:1339-1569; fixtures in tests/golden/remapping_unit_tests.json) and, for the
+ * PCM/PLM routines, bit-for-bit against the reference source compiled unmodified (oracle/_ref).
+ *
+ * Array convention: E(k,1:2) and coef(k,1:deg+1) are stored Fortran-style, E[(side)*n + k], k 0-based.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mom6_oracle.h"
+
+static inline double max2(double a, double b) { return a > b ? a : b; }
+static inline double min2(double a, double b) { return a < b ? a : b; }
+static inline double max3(double a, double b, double c) { return max2(max2(a, b), c); }
+static inline double min3(double a, double b, double c) { return min2(min2(a, b), c); }
+static inline double fsign(double a, double b) { return copysign(fabs(a), b); }
+
+#define E_(a,k,s)  (a)[(size_t)(s)*n + (k)]     /* k 0-based, s = 0 (left/top) or 1 (right/bottom) */
+#define C_(a,k,d)  (a)[(size_t)(d)*n + (k)]     /* polynomial coefficient d of cell k */
+
+/* ---- PCM ---------------------------------------------------------------------------------- */
+void orc_pcm_reconstruction(int n, const double *u, double *E, double *coef)
+{
+  for (int k = 0; k < n; k++) { C_(coef,k,0) = u[k]; E_(E,k,0) = u[k]; E_(E,k,1) = u[k]; }
+}
+
+/* ---- PLM ---------------------------------------------------------------------------------- */
+/* PLM_slope_wa, PLM_functions.F90:22-65 */
+double orc_plm_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r)
+{
+  double sigma_r = u_r - u_c;
+  double sigma_l = u_c - u_l;
+  double sigma_c = 2.0 * ( u_r - u_l ) * ( h_c / ( h_l + 2.0*h_c + h_r + h_neglect) );
+  double u_min = min3( u_l, u_c, u_r );
+  double u_max = max3( u_l, u_c, u_r );
+  double slope;
+  if ( (sigma_l * sigma_r) > 0.0 ) {
+    slope = fsign( min2( fabs(sigma_c), 2.*min2( u_c - u_min, u_max - u_c ) ), sigma_c );
+  } else {
+    slope = 0.0;
+  }
+  if (u_c - 0.5*fabs(slope) < u_min || u_c + 0.5*fabs(slope) > u_max) {
+    slope = slope * ( 1. - DBL_EPSILON );
+  }
+  if (fabs(slope) < 1.E-140) slope = 0.;
+  return slope;
+}
+
+/* PLM_monotonized_slope, PLM_functions.F90:124-159 */
+double orc_plm_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r)
+{
+  double almost_two = 2. * ( 1. - DBL_EPSILON );
+  double e_r = u_l + 0.5*s_l;
+  double e_l = u_r - 0.5*s_r;
+  double slp = fabs(s_c);
+  double edge = u_c - 0.5 * s_c;
+  if ( ( edge - e_r ) * ( u_c - edge ) < 0. ) {
+    edge = 0.5 * ( edge + e_r );
+    slp = min2( slp, fabs( edge - u_c ) * almost_two );
+  }
+  edge = u_c + 0.5 * s_c;
+  if ( ( edge - u_c ) * ( e_l - edge ) < 0. ) {
+    edge = 0.5 * ( edge + e_l );
+    slp = min2( slp, fabs( edge - u_c ) * almost_two );
+  }
+  return fsign( slp, s_c );
+}
+
+/* PLM_extrapolate_slope, PLM_functions.F90:164-183 */
+double orc_plm_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c)
+{
+  double hl = h_l + h_neglect;
+  double hc = h_c + h_neglect;
+  double left_edge = (u_l*hc + u_c*hl) / (hl + hc);
+  return 2.0 * ( u_c - left_edge );
+}
+
+/* PLM_reconstruction, PLM_functions.F90:190-260 */
+void orc_plm_reconstruction(int n, const double *h, const double *u, double *E, double *coef, double h_neglect)
+{
+  double almost_one = 1. - DBL_EPSILON;
+  double *slp = calloc(n, sizeof(double)), *mslp = calloc(n, sizeof(double));
+  for (int k = 1; k < n-1; k++)
+    slp[k] = orc_plm_slope_wa(h[k-1], h[k], h[k+1], h_neglect, u[k-1], u[k], u[k+1]);
+  slp[0] = 0.; slp[n-1] = 0.;
+  for (int k = 1; k < n-1; k++)
+    mslp[k] = orc_plm_monotonized_slope( u[k-1], u[k], u[k+1], slp[k-1], slp[k], slp[k+1] );
+  mslp[0] = 0.; mslp[n-1] = 0.;
+
+  E_(E,0,0) = u[0]; E_(E,0,1) = u[0]; C_(coef,0,0) = u[0]; C_(coef,0,1) = 0.;
+  for (int k = 1; k < n-1; k++) {
+    double slope = mslp[k];
+    double u_l = u[k] - 0.5 * slope;
+    double u_r = u[k] + 0.5 * slope;
+    E_(E,k,0) = u_l; E_(E,k,1) = u_r;
+    C_(coef,k,0) = u_l;
+    C_(coef,k,1) = ( u_r - u_l );
+    double edge = C_(coef,k,1) + C_(coef,k,0);
+    double e_r = u[k+1] - 0.5 * fsign( mslp[k+1], slp[k+1] );
+    if ( (edge-u[k])*(e_r-edge) < 0.) C_(coef,k,1) = C_(coef,k,1) * almost_one;
+  }
+  E_(E,n-1,0) = u[n-1]; E_(E,n-1,1) = u[n-1]; C_(coef,n-1,0) = u[n-1]; C_(coef,n-1,1) = 0.;
+  free(slp); free(mslp);
+}
+
+/* PLM_boundary_extrapolation, PLM_functions.F90:272-307 */
+void orc_plm_boundary_extrapolation(int n, const double *h, const double *u, double *E, double *coef, double h_neglect)
+{
+  double slope = - orc_plm_extrapolate_slope( h[1], h[0], h_neglect, u[1], u[0] );
+  E_(E,0,0) = u[0] - 0.5 * slope;
+  E_(E,0,1) = u[0] + 0.5 * slope;
+  C_(coef,0,0) = E_(E,0,0);
+  C_(coef,0,1) = E_(E,0,1) - E_(E,0,0);
+  slope = orc_plm_extrapolate_slope( h[n-2], h[n-1], h_neglect, u[n-2], u[n-1] );
+  E_(E,n-1,0) = u[n-1] - 0.5 * slope;
+  E_(E,n-1,1) = u[n-1] + 0.5 * slope;
+  C_(coef,n-1,0) = E_(E,n-1,0);
+  C_(coef,n-1,1) = E_(E,n-1,1) - E_(E,n-1,0);
+}
+
+/* ---- edge values ---------------------------------------------------------------------------- */
+static const double hMinFrac = 1.e-5;   /* regrid_edge_values.F90:30 */
+
+/* bound_edge_values (answer_date >= 20190101), regrid_edge_values.F90:44-110 */
+void orc_bound_edge_values(int n, const double *h, const double *u, double *E)
+{
+  for (int k = 0; k < n; k++) {
+    int km1 = (k-1 > 0) ? k-1 : 0, kp1 = (k+1 < n-1) ? k+1 : n-1;
+    double slope_x_h = 0.0;
+    if ( ((h[km1] + h[kp1]) + 2.0*h[k]) > 0.0 ) {
+      double sigma_l = ( u[k] - u[km1] );
+      double sigma_c = ( u[kp1] - u[km1] ) * ( h[k] / ((h[km1] + h[kp1]) + 2.0*h[k]) );
+      double sigma_r = ( u[kp1] - u[k] );
+      if ( (sigma_l * sigma_r) > 0.0 )
+        slope_x_h = fsign( min3(fabs(sigma_l),fabs(sigma_c),fabs(sigma_r)), sigma_c );
+    }
+    if ( (u[km1]-E_(E,k,0)) * (E_(E,k,0)-u[k]) < 0.0 )
+      E_(E,k,0) = u[k] - fsign( min2( fabs(slope_x_h), fabs(E_(E,k,0)-u[k]) ), slope_x_h );
+    if ( (u[kp1]-E_(E,k,1)) * (E_(E,k,1)-u[k]) < 0.0 )
+      E_(E,k,1) = u[k] + fsign( min2( fabs(slope_x_h), fabs(E_(E,k,1)-u[k]) ), slope_x_h );
+    E_(E,k,0) = max2( min2( E_(E,k,0), max2(u[km1], u[k]) ), min2(u[km1], u[k]) );
+    E_(E,k,1) = max2( min2( E_(E,k,1), max2(u[kp1], u[k]) ), min2(u[kp1], u[k]) );
+  }
+}
+
+/* check_discontinuous_edge_values, regrid_edge_values.F90:141-159 */
+void orc_check_discontinuous_edge_values(int n, const double *u, double *E)
+{
+  for (int k = 0; k < n-1; k++) {
+    if ( (E_(E,k+1,0) - E_(E,k,1)) * (u[k+1] - u[k]) < 0.0 ) {
+      double u0_avg = 0.5 * ( E_(E,k,1) + E_(E,k+1,0) );
+      u0_avg = max2( min2( u0_avg, max2(u[k], u[k+1]) ), min2(u[k], u[k+1]) );
+      E_(E,k,1) = u0_avg;
+      E_(E,k+1,0) = u0_avg;
+    }
+  }
+}
+
+/* end_value_h4, regrid_edge_values.F90:658-771 */
+void orc_end_value_h4(const double dz[4], const double u[4], double Csys[4])
+{
+  const double min_frac = 1.0e-6;
+  double Wt[3][4];   /* Wt[j-1][n-1] = Wt(j,n) */
+  double h1 = dz[0], h2 = dz[1], h3 = dz[2], h4 = dz[3];
+  if ((h2+h3) < min_frac*h1) h3 = min_frac*h1 - h2;
+  if ((h3+h4) < min_frac*h1) h4 = min_frac*h1 - h3;
+  double h12 = h1+h2, h23 = h2+h3, h34 = h3+h4;
+  double h123 = h12 + h3, h234 = h2 + h34, h1234 = h12 + h34;
+  double I_denB3 = 1.0 / (h123 * h12 * h23);
+  double I_h12 = (h123 * h23) * I_denB3;
+  double I_h23 = (h12 * h123) * I_denB3;
+  double I_h123 = (h12 * h23) * I_denB3;
+  double I_denom = 1.0 / ( h1234 * (h234 * h34) );
+  double I_h234 = (h1234 * h34) * I_denom;
+  double I_h1234 = (h234 * h34) * I_denom;
+
+  Wt[0][0] = -h1 * (I_h1234 + I_h123 + I_h12);
+  Wt[1][0] =  h1 * h12 * ( I_h234 * I_h1234 + I_h23 * (I_h234 + I_h123) );
+  Wt[2][0] = -h1 * h12 * h123 * I_denom;
+
+  Wt[0][1] =  2.0 * (I_h12*(1.0 + (h1+h12) * (I_h1234 + I_h123)) + h1 * I_h1234*I_h123);
+  Wt[1][1] = -2.0 * ((h1 * h12 * I_h1234) *       (I_h23 * (I_h234 + I_h123)) +
+                     (h1+h12) * ( I_h1234*I_h234 + I_h23 * (I_h234 + I_h123) ) );
+  Wt[2][1] =  2.0 * ((h1+h12) * h123 + h1*h12 ) * I_denom;
+
+  Wt[0][2] = -3.0 * I_h12 * I_h123* ( 1.0 + I_h1234 * ((h1+h12)+h123) );
+  Wt[1][2] =  3.0 * I_h23 * ( I_h123 + I_h1234 * ((h1+h12)+h123) * (I_h123 + I_h234) );
+  Wt[2][2] = -3.0 * ((h1+h12)+h123) * I_denom;
+
+  Wt[0][3] =  4.0 * I_h1234 * I_h123 * I_h12;
+  Wt[1][3] = -4.0 * I_h1234 * (I_h23 * (I_h123 + I_h234));
+  Wt[2][3] =  4.0 * I_denom;
+
+  Csys[0] = ((u[0] + Wt[0][0] * (u[1]-u[0])) + Wt[1][0] * (u[2]-u[1])) + Wt[2][0] * (u[3]-u[2]);
+  Csys[1] = (Wt[0][1] * (u[1]-u[0]) + Wt[1][1] * (u[2]-u[1])) + Wt[2][1] * (u[3]-u[2]);
+  Csys[2] = (Wt[0][2] * (u[1]-u[0]) + Wt[1][2] * (u[2]-u[1])) + Wt[2][2] * (u[3]-u[2]);
+  Csys[3] = (Wt[0][3] * (u[1]-u[0]) + Wt[1][3] * (u[2]-u[1])) + Wt[2][3] * (u[3]-u[2]);
+}
+
+/* edge_values_explicit_h4 (answer_date >= 20190101), regrid_edge_values.F90:222-363.  n >= 4. */
+void orc_edge_values_explicit_h4(int n, const double *h, const double *u, double *E, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  for (int i = 2; i <= n-2; i++) {            /* Fortran i = 3..N-1 */
+    double h0 = h[i-2], h1 = h[i-1], h2 = h[i], h3 = h[i+1];
+    if (h0+h1==0.0 || h1+h2==0.0 || h2+h3==0.0) {
+      double h_min = hMinFrac*max2( hNeglect, (h0+h1)+(h2+h3) );
+      h0 = max2( h_min, h[i-2] );
+      h1 = max2( h_min, h[i-1] );
+      h2 = max2( h_min, h[i] );
+      h3 = max2( h_min, h[i+1] );
+    }
+    double I_h12 = 1.0 / (h1+h2);
+    double I_den_et2 = 1.0 / ( ((h0+h1)+h2)*(h0+h1) ); double I_h012 = (h0+h1) * I_den_et2;
+    double I_den_et3 = 1.0 / ( (h1+(h2+h3))*(h2+h3) ); double I_h123 = (h2+h3) * I_den_et3;
+
+    double et1 = ( 1.0 + (h1 * I_h012 + (h0+h1) * I_h123) ) * I_h12 * (h2*(h2+h3)) * u[i-1] +
+                 ( 1.0 + (h2 * I_h123 + (h2+h3) * I_h012) ) * I_h12 * (h1*(h0+h1)) * u[i];
+    double et2 = ( h1 * (h2*(h2+h3)) * I_den_et2 ) * (u[i-1]-u[i-2]);
+    double et3 = ( h2 * (h1*(h0+h1)) * I_den_et3 ) * (u[i] - u[i+1]);
+    E_(E,i,0) = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
+    E_(E,i-1,1) = E_(E,i,0);
+  }
+  double dz[4], ut[4], C[4];
+  for (int i = 0; i < 4; i++) { dz[i] = max2(hNeglect, h[i]); ut[i] = u[i]; }
+  orc_end_value_h4(dz, ut, C);
+  E_(E,0,0) = C[0];
+  E_(E,0,1) = C[0] + dz[0]*(C[1] + dz[0]*(C[2] + dz[0]*C[3]));
+  E_(E,1,0) = E_(E,0,1);
+  for (int i = 0; i < 4; i++) { dz[i] = max2(hNeglect, h[n-1-i]); ut[i] = u[n-1-i]; }
+  orc_end_value_h4(dz, ut, C);
+  E_(E,n-1,1) = C[0];
+  E_(E,n-1,0) = C[0] + dz[0]*(C[1] + dz[0]*(C[2] + dz[0]*C[3]));
+  E_(E,n-2,1) = E_(E,n-1,0);
+}
+
+/* ---- PPM ---------------------------------------------------------------------------------- */
+/* PPM_limiter_standard, PPM_functions.F90:62-128 */
+void orc_ppm_limiter_standard(int n, const double *h, const double *u, double *E)
+{
+  orc_bound_edge_values(n, h, u, E);
+  orc_check_discontinuous_edge_values(n, u, E);
+  for (int k = 1; k < n-1; k++) {
+    double u_l = u[k-1], u_c = u[k], u_r = u[k+1];
+    double edge_l = E_(E,k,0), edge_r = E_(E,k,1);
+    if ( (u_r - u_c)*(u_c - u_l) <= 0.0) {
+      edge_l = u_c; edge_r = u_c;
+    } else {
+      double expr1 = 3.0 * (edge_r - edge_l) * ( (u_c - edge_l) + (u_c - edge_r));
+      double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
+      if ( expr1 > expr2 ) {
+        edge_l = u_c + 2.0 * ( u_c - edge_r );
+        edge_l = max2( min2( edge_l, max2(u_l, u_c) ), min2(u_l, u_c) );
+      } else if ( expr1 < -expr2 ) {
+        edge_r = u_c + 2.0 * ( u_c - edge_l );
+        edge_r = max2( min2( edge_r, max2(u_r, u_c) ), min2(u_r, u_c) );
+      }
+    }
+    if ( fabs( edge_r - edge_l ) < max2(1.e-60, DBL_EPSILON*fabs(u_c)) ) {
+      edge_l = u_c; edge_r = u_c;
+    }
+    E_(E,k,0) = edge_l; E_(E,k,1) = edge_r;
+  }
+  E_(E,0,0) = u[0]; E_(E,0,1) = u[0];
+  E_(E,n-1,0) = u[n-1]; E_(E,n-1,1) = u[n-1];
+}
+
+/* PPM_reconstruction, PPM_functions.F90:28-57 */
+void orc_ppm_reconstruction(int n, const double *h, const double *u, double *E, double *coef)
+{
+  orc_ppm_limiter_standard(n, h, u, E);
+  for (int k = 0; k < n; k++) {
+    double edge_l = E_(E,k,0), edge_r = E_(E,k,1);
+    C_(coef,k,0) = edge_l;
+    C_(coef,k,1) = 4.0 * ( u[k] - edge_l ) + 2.0 * ( u[k] - edge_r );
+    C_(coef,k,2) = 3.0 * ( ( edge_r - u[k] ) + ( edge_l - u[k] ) );
+  }
+}
+
+/* PPM_boundary_extrapolation, PPM_functions.F90:162-316 */
+void orc_ppm_boundary_extrapolation(int n, const double *h, const double *u, double *E, double *coef, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  /* left boundary */
+  int i0 = 0, i1 = 1;
+  double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1];
+  double b = C_(coef,i1,1);
+  double u1_r = b *((h0+hNeglect)/(h1+hNeglect));
+  double slope = 2.0 * ( u1 - u0 );
+  if ( fabs(u1_r) > fabs(slope) ) u1_r = slope;
+  double u0_r = E_(E,i1,0);
+  double u0_l = 3.0 * u0 + 0.5 * u1_r - 2.0 * u0_r;
+  double exp1 = (u0_r - u0_l) * (u0 - 0.5*(u0_l+u0_r));
+  double exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+  if ( exp1 > exp2 ) u0_l = 3.0 * u0 - 2.0 * u0_r;
+  if ( exp1 < -exp2 ) u0_r = 3.0 * u0 - 2.0 * u0_l;
+  E_(E,i0,0) = u0_l; E_(E,i0,1) = u0_r;
+  C_(coef,i0,0) = u0_l;
+  C_(coef,i0,1) = 6.0 * u0 - 4.0 * u0_l - 2.0 * u0_r;
+  C_(coef,i0,2) = 3.0 * ( u0_r + u0_l - 2.0 * u0 );
+
+  /* right boundary */
+  i0 = n-2; i1 = n-1;
+  h0 = h[i0]; h1 = h[i1]; u0 = u[i0]; u1 = u[i1];
+  b = C_(coef,i0,1);
+  double c = C_(coef,i0,2);
+  double u1_l = (b + 2*c);
+  u1_l = u1_l * ((h1+hNeglect)/(h0+hNeglect));
+  slope = 2.0 * ( u1 - u0 );
+  if ( fabs(u1_l) > fabs(slope) ) u1_l = slope;
+  u0_l = E_(E,i0,1);
+  u0_r = 3.0 * u1 - 0.5 * u1_l - 2.0 * u0_l;
+  exp1 = (u0_r - u0_l) * (u1 - 0.5*(u0_l+u0_r));
+  exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+  if ( exp1 > exp2 ) u0_l = 3.0 * u1 - 2.0 * u0_r;
+  if ( exp1 < -exp2 ) u0_r = 3.0 * u1 - 2.0 * u0_l;
+  E_(E,i1,0) = u0_l; E_(E,i1,1) = u0_r;
+  C_(coef,i1,0) = u0_l;
+  C_(coef,i1,1) = 6.0 * u1 - 4.0 * u0_l - 2.0 * u0_r;
+  C_(coef,i1,2) = 3.0 * ( u0_r + u0_l - 2.0 * u1 );
+}
+
+/* ---- remapping ---------------------------------------------------------------------------- */
+/* average_value_ppoly, MOM_remapping.F90:998-1099 (method: ORC_INT_PCM/PLM/PPM; i0 0-based) */
+double orc_average_value_ppoly(int n, const double *u0, const double *E, const double *coef, int method,
+                               int i0, double xa, double xb)
+{
+  double u_ave = 0.0;
+  if (xb > xa) {
+    if (method == ORC_INT_PCM) {
+      u_ave = u0[i0];
+    } else if (method == ORC_INT_PLM) {
+      u_ave = ( C_(coef,i0,0) + C_(coef,i0,1) * 0.5 * ( xb + xa ) );
+    } else {
+      double mx = 0.5 * ( xa + xb );
+      double a_L = E_(E,i0,0), a_R = E_(E,i0,1), u_c = u0[i0];
+      double a_c = 0.5 * ( ( u_c - a_L ) + ( u_c - a_R ) );
+      if (mx < 0.5) {
+        double xa2b2ab = (xa*xa+xb*xb)+xa*xb;
+        u_ave = a_L + ( ( a_R - a_L ) * mx + a_c * ( 3. * ( xb + xa ) - 2.*xa2b2ab ) );
+      } else {
+        double Ya = 1. - xa, Yb = 1. - xb;
+        double my = 0.5 * ( Ya + Yb );
+        double Ya2b2ab = (Ya*Ya+Yb*Yb)+Ya*Yb;
+        u_ave = a_R  + ( ( a_L - a_R ) * my + a_c * ( 3. * ( Yb + Ya ) - 2.*Ya2b2ab ) );
+      }
+    }
+  } else {
+    if (method == ORC_INT_PCM) {
+      u_ave = C_(coef,i0,0);
+    } else if (method == ORC_INT_PLM) {
+      double a_L = E_(E,i0,0), a_R = E_(E,i0,1);
+      double Ya = 1. - xa;
+      if (xa < 0.5) u_ave = a_L + xa * ( a_R - a_L );
+      else          u_ave = a_R + Ya * ( a_L - a_R );
+    } else {
+      double a_L = E_(E,i0,0), a_R = E_(E,i0,1), u_c = u0[i0];
+      double a_c = 3. * ( ( u_c - a_L ) + ( u_c - a_R ) );
+      double Ya = 1. - xa;
+      if (xa < 0.5) u_ave = a_L + xa * ( ( a_R - a_L ) + a_c * Ya );
+      else          u_ave = a_R + Ya * ( ( a_L - a_R ) + a_c * xa );
+    }
+  }
+  return u_ave;
+}
+
+/* remap_via_sub_cells, MOM_remapping.F90:463-852 (force_bounds_in_subcell as argument;
+ * force_bounds_in_target and adjust_thickest_subcell are .true. parameters there). */
+void orc_remap_via_sub_cells(int n0, const double *h0, const double *u0, const double *E, const double *coef,
+                             int n1, const double *h1, int method, int force_bounds_in_subcell,
+                             double *u1, double *uh_err_out)
+{
+  const int n = n0;   /* for the E_/C_ macros */
+  const int ns = n0 + n1 + 1;
+  /* 1-based work arrays to keep the reference's index arithmetic */
+  double *h_sub = calloc(ns+2, sizeof(double)), *uh_sub = calloc(ns+2, sizeof(double)), *u_sub = calloc(ns+2, sizeof(double));
+  int *isub_src = calloc(ns+2, sizeof(int));
+  int *isrc_start = calloc(n0+2, sizeof(int)), *isrc_end = calloc(n0+2, sizeof(int)), *isrc_max = calloc(n0+2, sizeof(int));
+  double *h0_eff = calloc(n0+2, sizeof(double)), *u0_min = calloc(n0+2, sizeof(double)), *u0_max = calloc(n0+2, sizeof(double));
+  int *itgt_start = calloc(n1+2, sizeof(int)), *itgt_end = calloc(n1+2, sizeof(int));
+#define H0(i) h0[(i)-1]
+#define H1(i) h1[(i)-1]
+#define U0(i) u0[(i)-1]
+  int i0_last_thick_cell = 0;
+  for (int i0 = 1; i0 <= n0; i0++) {
+    u0_min[i0] = min2(E_(E,i0-1,0), E_(E,i0-1,1));
+    u0_max[i0] = max2(E_(E,i0-1,0), E_(E,i0-1,1));
+    if (H0(i0) > 0.) i0_last_thick_cell = i0;
+  }
+  double h0_supply = H0(1), h1_supply = H1(1);
+  int src_has_volume = 1, tgt_has_volume = 1;
+  int i0 = 1, i1 = 1, i_start0 = 1, i_start1 = 1, i_max = 1;
+  double dh_max = 0., dh0_eff = 0., dh;
+  h_sub[1] = 0.;
+  isrc_start[1] = 1; isrc_end[1] = 1; isrc_max[1] = 1; isub_src[1] = 1;
+
+  for (int i_sub = 2; i_sub <= ns; i_sub++) {
+    dh = min2(h0_supply, h1_supply);
+    dh0_eff = dh0_eff + min2(dh, h0_supply);
+    isub_src[i_sub] = i0;
+    h_sub[i_sub] = dh;
+    if (dh >= dh_max) { i_max = i_sub; dh_max = dh; }
+    if (h0_supply <= h1_supply && src_has_volume) {
+      h1_supply = h1_supply - dh;
+      isrc_start[i0] = i_start0; isrc_end[i0] = i_sub; i_start0 = i_sub + 1;
+      isrc_max[i0] = i_max; i_max = i_sub + 1; dh_max = 0.;
+      h0_eff[i0] = dh0_eff;
+      if (i0 < n0) { i0 = i0 + 1; h0_supply = H0(i0); dh0_eff = 0.; }
+      else { h0_supply = 0.; src_has_volume = 0; }
+    } else if (h0_supply >= h1_supply && tgt_has_volume) {
+      h0_supply = h0_supply - dh;
+      itgt_start[i1] = i_start1; itgt_end[i1] = i_sub; i_start1 = i_sub + 1;
+      if (i1 < n1) { i1 = i1 + 1; h1_supply = H1(i1); }
+      else { h1_supply = 0.; tgt_has_volume = 0; }
+    } else if (src_has_volume) {
+      h_sub[i_sub] = h0_supply;
+      isrc_start[i0] = i_start0; isrc_end[i0] = i_sub; i_start0 = i_sub + 1;
+      isrc_max[i0] = i_max; i_max = i_sub + 1; dh_max = 0.;
+      h0_eff[i0] = dh0_eff;
+      if (i0 < n0) { i0 = i0 + 1; h0_supply = H0(i0); dh0_eff = 0.; }
+      else { h0_supply = 0.; src_has_volume = 0; }
+    } else if (tgt_has_volume) {
+      h_sub[i_sub] = h1_supply;
+      itgt_start[i1] = i_start1; itgt_end[i1] = i_sub; i_start1 = i_sub + 1;
+      if (i1 < n1) { i1 = i1 + 1; h1_supply = H1(i1); }
+      else { h1_supply = 0.; tgt_has_volume = 0; }
+    } else {
+      abort();   /* 'remap_via_sub_cells: THIS SHOULD NEVER HAPPEN!' */
+    }
+  }
+
+  double xa = 0., xb;
+  dh0_eff = 0.;
+  uh_sub[1] = 0.;
+  u_sub[1] = E_(E,0,0);
+  double u02_err = 0.;
+  for (int i_sub = 2; i_sub <= n0+n1; i_sub++) {
+    dh = h_sub[i_sub];
+    i0 = isub_src[i_sub];
+    dh0_eff = dh0_eff + dh;
+    if (h0_eff[i0] > 0.) {
+      xb = dh0_eff / h0_eff[i0];
+      xb = min2(1., xb);
+      u_sub[i_sub] = orc_average_value_ppoly( n0, u0, E, coef, method, i0-1, xa, xb);
+    } else {
+      xb = 1.;
+      u_sub[i_sub] = U0(i0);
+    }
+    if (force_bounds_in_subcell) {
+      double u_orig = u_sub[i_sub];
+      u_sub[i_sub] = max2( u_sub[i_sub], u0_min[i0] );
+      u_sub[i_sub] = min2( u_sub[i_sub], u0_max[i0] );
+      u02_err = u02_err + dh*fabs( u_sub[i_sub] - u_orig );
+    }
+    uh_sub[i_sub] = dh * u_sub[i_sub];
+    if (isub_src[i_sub+1] != i0) { dh0_eff = 0.; xa = 0.; }
+    else { xa = xb; }
+  }
+  u_sub[ns] = E_(E,n0-1,1);
+  uh_sub[ns] = E_(E,n0-1,1) * h_sub[ns];
+
+  /* adjust_thickest_subcell */
+  for (i0 = 1; i0 <= i0_last_thick_cell; i0++) {
+    i_max = isrc_max[i0];
+    dh_max = h_sub[i_max];
+    if (dh_max > 0.) {
+      double duh = 0.;
+      for (int i_sub = isrc_start[i0]; i_sub <= isrc_end[i0]; i_sub++)
+        if (i_sub != i_max) duh = duh + uh_sub[i_sub];
+      uh_sub[i_max] = U0(i0)*H0(i0) - duh;
+      u02_err = u02_err + max3( fabs(uh_sub[i_max]), fabs(U0(i0)*H0(i0)), fabs(duh) );
+    }
+  }
+
+  double uh_err = 0.;
+  for (i1 = 1; i1 <= n1; i1++) {
+    if (H1(i1) > 0.) {
+      double duh = 0.; dh = 0.;
+      int i_sub = itgt_start[i1];
+      double u1min = u_sub[i_sub], u1max = u_sub[i_sub];
+      for (i_sub = itgt_start[i1]; i_sub <= itgt_end[i1]; i_sub++) {
+        u1min = min2(u1min, u_sub[i_sub]);
+        u1max = max2(u1max, u_sub[i_sub]);
+        dh = dh + h_sub[i_sub];
+        duh = duh + uh_sub[i_sub];
+        uh_err = uh_err + max2(fabs(duh),fabs(uh_sub[i_sub]))*DBL_EPSILON;
+      }
+      u1[i1-1] = duh / dh;
+      uh_err = uh_err + fabs(duh)*DBL_EPSILON;
+      double u_orig = u1[i1-1];
+      u1[i1-1] = max2(u1min, min2(u1max, u1[i1-1]));
+      uh_err = uh_err + dh*fabs( u1[i1-1]-u_orig );
+    } else {
+      u1[i1-1] = u_sub[itgt_start[i1]];
+    }
+  }
+  uh_err = uh_err + u02_err;
+  if (uh_err_out) *uh_err_out = uh_err;
+#undef H0
+#undef H1
+#undef U0
+  free(h_sub); free(uh_sub); free(u_sub); free(isub_src); free(isrc_start); free(isrc_end); free(isrc_max);
+  free(h0_eff); free(u0_min); free(u0_max); free(itgt_start); free(itgt_end);
+}
+
+/* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PPM_H4; no PCM_cell).
+ * E and coef must hold 2*n0 and 3*n0 doubles.  Returns the integration method. */
+int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
+                                 double *coef, double *E, double h_neglect, double h_neglect_edge)
+{
+  const int n = n0;
+  memset(E, 0, sizeof(double)*2*n0);
+  memset(coef, 0, sizeof(double)*3*n0);
+  int local = scheme;
+  if (n0 <= 1) local = ORC_REMAP_PCM;
+  else if (n0 <= 3) local = (local < ORC_REMAP_PLM) ? local : ORC_REMAP_PLM;
+  else if (n0 <= 4) local = (local < ORC_REMAP_PPM_H4) ? local : ORC_REMAP_PPM_H4;
+  (void)n;
+  switch (local) {
+    case ORC_REMAP_PCM:
+      orc_pcm_reconstruction(n0, u0, E, coef);
+      return ORC_INT_PCM;
+    case ORC_REMAP_PLM:
+      orc_plm_reconstruction(n0, h0, u0, E, coef, h_neglect);
+      if (boundary_extrapolation) orc_plm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PLM;
+    case ORC_REMAP_PPM_H4:
+      orc_edge_values_explicit_h4(n0, h0, u0, E, h_neglect_edge);
+      orc_ppm_reconstruction(n0, h0, u0, E, coef);
+      if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PPM;
+    default:
+      return -999;   /* 'The selected remapping method is invalid' */
+  }
+}
+
+/* remapping_core_h, MOM_remapping.F90:160-201 */
+int orc_remapping_core_h(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
+                         int n1, const double *h1, double *u1, double h_neglect, double h_neglect_edge)
+{
+  double *E = calloc((size_t)2*n0, sizeof(double)), *coef = calloc((size_t)3*n0, sizeof(double));
+  int method = orc_build_reconstructions_1d(scheme, boundary_extrapolation, n0, h0, u0, coef, E, h_neglect, h_neglect_edge);
+  if (method < 0) { free(E); free(coef); return 1; }
+  double uh_err;
+  orc_remap_via_sub_cells(n0, h0, u0, E, coef, n1, h1, method, 0, u1, &uh_err);
+  free(E); free(coef);
+  return 0;
+}
+
+/* dzFromH1H2, MOM_remapping.F90:1235-1256 */
+void orc_dz_from_h1h2(int n1, const double *h1, int n2, const double *h2, double *dx)
+{
+  double x1 = 0.0, x2 = 0.0;
+  int nmax = n1 > n2 ? n1 : n2;
+  dx[0] = 0.0;
+  for (int k = 1; k <= nmax; k++) {
+    if (k <= n1) x1 = x1 + h1[k-1];
+    if (k <= n2) { x2 = x2 + h2[k-1]; dx[k] = x2 - x1; }
+  }
+}
+
+/* remapping_core_w, MOM_remapping.F90:205-254 */
+int orc_remapping_core_w(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
+                         int n1, const double *dx, double *u1, double h_neglect, double h_neglect_edge)
+{
+  double *h1 = calloc(n1, sizeof(double));
+  for (int k = 1; k <= n1; k++) {
+    if (k <= n0) h1[k-1] = max2( 0., h0[k-1] + ( dx[k] - dx[k-1] ) );
+    else         h1[k-1] = max2( 0., dx[k] - dx[k-1] );
+  }
+  int rc = orc_remapping_core_h(scheme, boundary_extrapolation, n0, h0, u0, n1, h1, u1, h_neglect, h_neglect_edge);
+  free(h1);
+  return rc;
+}

@@ -1,0 +1,124 @@
+"""The remapping oracle (oracle/remapping.c) against (1) the known-answer vectors of the reference's own
+remapping_unit_tests (tests/golden/remapping_unit_tests.json, data from src/ALE/MOM_remapping.F90:1339-1569,
+checked with the reference's tolerances) and (2) the reference PLM/PCM sources compiled unmodified
+(oracle/_ref, bit-for-bit on random columns; only where oracle/_ref was built)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bits_equal
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "remapping_unit_tests.json")))
+EPS = GOLD["eps"]
+
+
+def check(u, u_true, tol=0.0):
+    # test_answer, MOM_remapping.F90:1683: fails if abs(u - u_true) > tol
+    assert not np.any(np.abs(np.asarray(u) - np.asarray(u_true)) > tol), (u, u_true, tol)
+
+
+def test_remapping_core_w_ppm_h4(oracle):
+    c = GOLD["remapping_core_w"]
+    dx = oracle.dz_from_h1h2(c["h0"], c["h1"])
+    u1 = oracle.remapping_core_w(c["scheme"], c["h0"], c["u0"], dx, c["h_neglect"], c["h_neglect_edge"])
+    check(u1, c["u1"], c["tol_eps"] * EPS)
+
+
+def test_remap_via_sub_cells_ppm(oracle):
+    c = GOLD["remap_via_sub_cells_ppm"]
+    E = oracle.edge_values_explicit_h4(c["h0"], c["u0"], c["edge_h_neglect"])
+    E, co = oracle.ppm_reconstruction(c["h0"], c["u0"], E, c["h_neglect"], extrapolate=True)
+    u2, _ = oracle.remap_via_sub_cells(c["h0"], c["u0"], E, co, c["h2"], oracle.INT_PPM)
+    check(u2, c["u2"], c["tol_eps"] * EPS)
+    # the two further calls of the reference test (:1434-1440) must simply run and conserve
+    for h in ([0.125] * 6, [2.25, 1.5, 1.0]):
+        u, _ = oracle.remap_via_sub_cells(c["h0"], c["u0"], E, co, h, oracle.INT_PPM)
+        assert np.all(np.isfinite(u))
+
+
+def test_pcm(oracle):
+    c = GOLD["pcm"]
+    E, co = oracle.pcm_reconstruction(c["u"])
+    check(E[0], c["left"]); check(E[1], c["right"]); check(co[0], c["P0"])
+
+
+@pytest.mark.parametrize("c", GOLD["plm"], ids=lambda c: c["label"])
+def test_plm_tables(oracle, c):
+    E, co = oracle.plm_reconstruction(c["h"], c["u"], 1e-30)
+    check(E[0], c["left"]); check(E[1], c["right"]); check(co[0], c["P0"]); check(co[1], c["P1"])
+
+
+@pytest.mark.parametrize("c", GOLD["edge_values_explicit_h4"], ids=lambda c: c["label"])
+def test_edge_values_explicit_h4(oracle, c):
+    E = oracle.edge_values_explicit_h4(c["h"], c["u"], c["h_neglect"])
+    check(E[0], c["left"], c["tol_left"]); check(E[1], c["right"], c["tol_right"])
+
+
+@pytest.mark.parametrize("c", GOLD["ppm_reconstruction"], ids=lambda c: c["label"])
+def test_ppm_tables(oracle, c):
+    E0 = np.array([c["left_in"], c["right_in"]])
+    E, co = oracle.ppm_reconstruction(c["h"], c["u"], E0)
+    if "left" in c:
+        check(E[0], c["left"]); check(E[1], c["right"])
+    check(co[0], c["P0"]); check(co[1], c["P1"]); check(co[2], c["P2"])
+
+
+def test_plm_vanished_layers_and_remap(oracle):
+    c = GOLD["plm_vanished"]
+    E, co = oracle.plm_reconstruction(c["h"], c["u"], 1e-30)
+    check(E[0], c["left"]); check(E[1], c["right"])
+    u1, _ = oracle.remap_via_sub_cells(c["h"], c["u"], E, co, c["h1"], oracle.INT_PLM)
+    check(u1, c["u1"])
+
+
+# ---- properties the scheme guarantees (conservative, bounded) on random columns ------------------------
+@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PPM_H4"])
+def test_remap_conserves_and_is_bounded(oracle, scheme):
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        n0, n1 = int(rng.integers(5, 40)), int(rng.integers(1, 40))
+        h0 = rng.random(n0) * 10.0
+        h0[rng.random(n0) < 0.15] = 0.0          # vanished layers
+        if h0.sum() == 0.0:
+            h0[0] = 1.0
+        w = rng.random(n1); w[rng.random(n1) < 0.15] = 0.0
+        if w.sum() == 0.0:
+            w[0] = 1.0
+        h1 = w / w.sum() * h0.sum()
+        u0 = rng.standard_normal(n0) * 5.0 + 10.0
+        u1 = oracle.remapping_core_h(scheme, h0, u0, h1, 1e-30, 1e-10, boundary_extrapolation=False)
+        tot0, tot1 = float(np.dot(h0, u0)), float(np.dot(h1, u1))
+        assert abs(tot1 - tot0) <= 1e-12 * max(1.0, np.dot(h0, np.abs(u0))), (scheme, trial)
+        assert u1.max() <= u0.max() + 1e-12 and u1.min() >= u0.min() - 1e-12
+
+
+# ---- bit-for-bit against the reference's own code where it compiles with no stand-ins ------------------
+def test_plm_matches_reference_build(oracle):
+    R = oracle.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (the reference sources only exist in the build container)")
+    rng = np.random.default_rng(11)
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    for trial in range(300):
+        n = int(rng.integers(2, 60))
+        h = rng.random(n) * 10.0 ** rng.integers(-3, 3)
+        h[rng.random(n) < 0.2] = 0.0
+        u = rng.standard_normal(n) * 10.0 ** rng.integers(-2, 3)
+        if trial % 5 == 0:
+            u = np.round(u)                      # ties / exact extrema
+        for extrap in (0, 1):
+            E, co = oracle.plm_reconstruction(h, u, 1e-30, extrapolate=bool(extrap))
+            Er, cr = np.zeros((2, n)), np.zeros((2, n))
+            R.ref_plm_reconstruction(n, P(h), P(u), P(Er), P(cr), 1e-30, extrap)
+            assert bits_equal(E, Er) and bits_equal(co[:2], cr), (trial, extrap)
+    for _ in range(2000):
+        a = rng.standard_normal(7) * 10.0 ** rng.integers(-3, 3, 7)
+        hh = np.abs(a[:3])
+        assert oracle._remap_lib().orc_plm_slope_wa(hh[0], hh[1], hh[2], 1e-30, a[3], a[4], a[5]) == \
+            R.ref_plm_slope_wa(hh[0], hh[1], hh[2], 1e-30, a[3], a[4], a[5])
+        assert oracle._remap_lib().orc_plm_extrapolate_slope(hh[0], hh[1], 1e-30, a[3], a[4]) == \
+            R.ref_plm_extrapolate_slope(hh[0], hh[1], 1e-30, a[3], a[4])
