@@ -159,6 +159,31 @@ typedef struct mom6hip_advect_timing {
 int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable);
 int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t);
 
+/* ---- MOM_ALE / MOM_remapping ----------------------------------------------------------------- */
+
+/* REMAPPING_SCHEME values, src/ALE/MOM_remapping.F90:50-59 (the ones libmom6hip provides) */
+#define MOM6HIP_REMAP_PCM     0
+#define MOM6HIP_REMAP_PLM     2
+#define MOM6HIP_REMAP_PPM_H4  4
+
+/* remapping_CS, src/ALE/MOM_remapping.F90:25-41 */
+typedef struct mom6hip_remapping_cs {
+  int32_t remapping_scheme;         /* MOM6HIP_REMAP_* */
+  int32_t boundary_extrapolation;   /* REMAP_BOUNDARY_EXTRAP */
+  int32_t force_bounds_in_subcell;  /* REMAP_BOUND_INTERMEDIATE_VALUES (must be 0) */
+  int32_t answer_date;              /* REMAPPING_ANSWER_DATE (must be >= 20190101) */
+} mom6hip_remapping_cs_t;
+
+/*
+ * ALE_remap_tracers(CS, G, GV, h_old, h_new, Reg, debug, dt, PCM_cell)    src/ALE/MOM_ALE.F90:737
+ * Remaps every tracer column of the compute domain (ocean points only) from the grid h_old to the
+ * grid h_new with remapping_core_h (src/ALE/MOM_remapping.F90:160).  tr[m] is updated in place.
+ * PCM_cell (hybgen only) and the tendency diagnostics (dt) are not provided.
+ */
+int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remapping_cs_t *cs, const double *h_old,
+                              const double *h_new, double *const *tr, const double *conc_underflow,
+                              int32_t ntr, int32_t memspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,3 +47,11 @@ class AdvectTiming(C.Structure):
                 ("ms_y", C.c_double), ("ms_halo", C.c_double), ("ms_x1", C.c_double),
                 ("ms_y1", C.c_double), ("n_x", C.c_int32),
                 ("n_y", C.c_int32)]
+
+
+REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PPM_H4": 4}
+
+
+class RemappingCS(C.Structure):
+    _fields_ = [("remapping_scheme", C.c_int32), ("boundary_extrapolation", C.c_int32),
+                ("force_bounds_in_subcell", C.c_int32), ("answer_date", C.c_int32)]

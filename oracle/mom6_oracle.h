@@ -87,6 +87,9 @@ int orc_remapping_core_h(int scheme, int boundary_extrapolation, int n0, const d
 int orc_remapping_core_w(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                          int n1, const double *dx, double *u1, double h_neglect, double h_neglect_edge);
 void orc_dz_from_h1h2(int n1, const double *h1, int n2, const double *h2, double *dx);
+/* ALE_remap_tracers, src/ALE/MOM_ALE.F90:737-867 (no PCM_cell, no tendency diagnostics) */
+int orc_ale_remap_tracers(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t *cs, const double *h_old,
+                          const double *h_new, double *const *tr, const double *conc_underflow, int ntr);
 
 #ifdef __cplusplus
 }

@@ -178,3 +178,16 @@ def ref_lib():
     L.ref_plm_monotonized_slope.argtypes = [d] * 6; L.ref_plm_monotonized_slope.restype = d
     L.ref_plm_extrapolate_slope.argtypes = [d] * 5; L.ref_plm_extrapolate_slope.restype = d
     return L
+
+
+def ale_remap_tracers(grid, scheme, h_old, h_new, tr, conc_underflow=None, boundary_extrapolation=False):
+    L = lib()
+    L.orc_ale_remap_tracers.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.RemappingCS), _dp, _dp,
+                                        C.POINTER(_dp), _dp, C.c_int]
+    cs = _abi.RemappingCS(_abi.REMAP_SCHEMES[scheme], int(boundary_extrapolation), 0, 99991231)
+    ntr = len(tr)
+    trp = (_dp * ntr)(*[_p(t) for t in tr])
+    cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
+    rc = L.orc_ale_remap_tracers(C.byref(grid.struct()), C.byref(cs), _p(h_old), _p(h_new), trp, _p(cu), ntr)
+    if rc:
+        raise RuntimeError("orc_ale_remap_tracers failed")
