@@ -184,6 +184,36 @@ int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remapping_cs_t *
                               const double *h_new, double *const *tr, const double *conc_underflow,
                               int32_t ntr, int32_t memspace);
 
+/* ---- MOM_CoriolisAdv ----------------------------------------------------------------------- */
+
+/* CORIOLIS_SCHEME / KE_SCHEME enumeration values, src/core/MOM_CoriolisAdv.F90:93-112 */
+#define MOM6HIP_SADOURNY75_ENERGY 1
+#define MOM6HIP_ARAKAWA_HSU90     2
+#define MOM6HIP_SADOURNY75_ENSTRO 4
+#define MOM6HIP_KE_ARAKAWA        10
+#define MOM6HIP_KE_SIMPLE_GUDONOV 11
+#define MOM6HIP_KE_GUDONOV        12
+
+/* CoriolisAdv_CS, src/core/MOM_CoriolisAdv.F90:30-91 (the members the provided branches read) */
+typedef struct mom6hip_coriolisadv_cs {
+  int32_t coriolis_scheme;   /* CORIOLIS_SCHEME: SADOURNY75_ENERGY (default), SADOURNY75_ENSTRO, ARAKAWA_HSU90 */
+  int32_t ke_scheme;         /* KE_SCHEME: KE_ARAKAWA (default), KE_SIMPLE_GUDONOV, KE_GUDONOV */
+  int32_t no_slip;           /* NOSLIP */
+  int32_t bound_coriolis;    /* BOUND_CORIOLIS */
+  int32_t coriolis_en_dis;   /* CORIOLIS_EN_DIS (must be 0) */
+  int32_t reserved[3];
+} mom6hip_coriolisadv_cs_t;
+
+/*
+ * CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Waves)   src/core/MOM_CoriolisAdv.F90:125
+ * OBC, Waves must not be associated, pbv must be all ones, AD diagnostics are not provided.
+ * Needs the metrics mask2dT, areaT, IareaT, dxCu, IdxCu, areaCu, dyCv, IdyCv, areaCv, mask2dBu, IareaBu,
+ * CoriolisBu.  CAu is written on (isc-1:iec, jsc:jec), CAv on (isc:iec, jsc-1:jec); other points are untouched.
+ */
+int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, const double *u, const double *v,
+                      const double *h, const double *uh, const double *vh, double *CAu, double *CAv,
+                      int32_t memspace);
+
 #ifdef __cplusplus
 }
 #endif

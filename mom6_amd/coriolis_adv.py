@@ -1,0 +1,56 @@
+"""Host-side mirror of MOM_CoriolisAdv (reference: src/core/MOM_CoriolisAdv.F90): CoriolisAdv_init / CorAdCalc."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+from .tracer_advect import DeviceGrid, _ptr_space
+
+
+class CoriolisAdvCS:
+    """CoriolisAdv_CS (MOM_CoriolisAdv.F90:30-91) as set by CoriolisAdv_init (:1054-1184)."""
+
+    def __init__(self, coriolis_scheme="SADOURNY75_ENERGY", ke_scheme="KE_ARAKAWA", no_slip=False,
+                 bound_coriolis=False, coriolis_en_dis=False):
+        if coriolis_scheme not in _abi.CORIOLIS_SCHEMES:
+            # MOM_CoriolisAdv.F90:1122-1123
+            raise Mom6HipError("CoriolisAdv_init: #define CORIOLIS_SCHEME " + str(coriolis_scheme)
+                               + " found in input file is not provided by libmom6hip.")
+        if ke_scheme not in _abi.KE_SCHEMES:
+            raise Mom6HipError("CoriolisAdv_init: #define KE_SCHEME " + str(ke_scheme) + " in input file is invalid.")
+        self.coriolis_scheme, self.ke_scheme = coriolis_scheme, ke_scheme
+        self.no_slip, self.bound_coriolis, self.coriolis_en_dis = bool(no_slip), bool(bound_coriolis), bool(coriolis_en_dis)
+
+    def struct(self):
+        return _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES[self.coriolis_scheme], _abi.KE_SCHEMES[self.ke_scheme],
+                                  int(self.no_slip), int(self.bound_coriolis), int(self.coriolis_en_dis))
+
+
+def CoriolisAdv_init(**kw):
+    return CoriolisAdvCS(**kw)
+
+
+def CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, G: DeviceGrid, CS: CoriolisAdvCS, Waves=None):
+    """CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Waves) -- MOM_CoriolisAdv.F90:125."""
+    if CS is None:
+        raise Mom6HipError("MOM_CoriolisAdv: Module must be initialized before it is used.")
+    if OBC is not None or Waves is not None:
+        raise Mom6HipError("MOM_CoriolisAdv (HIP): open boundaries and Stokes vortex force are not supported")
+    g = G.grid
+    shp = {"h": g.shape3(_abi.POS_H), "u": g.shape3(_abi.POS_U), "v": g.shape3(_abi.POS_V)}
+    spaces = set()
+
+    def P(a, kind, name):
+        if tuple(a.shape) != shp[kind]:
+            raise Mom6HipError(f"CorAdCalc: {name} has shape {tuple(a.shape)}, expected {shp[kind]}")
+        p, s = _ptr_space(a)
+        spaces.add(s)
+        return C.c_void_p(p)
+
+    args = [P(u, "u", "u"), P(v, "v", "v"), P(h, "h", "h"), P(uh, "u", "uh"), P(vh, "v", "vh"),
+            P(CAu, "u", "CAu"), P(CAv, "v", "CAv")]
+    if len(spaces) != 1:
+        raise Mom6HipError("CorAdCalc: all fields must be in the same memory space")
+    cs = CS.struct()
+    check(lib().mom6hip_coradcalc(G.handle, C.byref(cs), *args, spaces.pop()), "CorAdCalc")

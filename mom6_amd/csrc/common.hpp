@@ -40,12 +40,17 @@ struct GridDev {
   int isc, iec, jsc, jec, isd, ied, jsd, jed, nk;
   int nih, njh;             // data-domain extents of h-point arrays
   double Angstrom_H, H_subroundoff;
-  const double *areaT, *mask2dT, *mask2dCu, *mask2dCv;
+  // device copies of the metric arrays of mom6hip_grid_t (null if the caller did not provide them)
+  const double *mask2dT, *areaT, *IareaT, *dxT, *dyT, *IdxT, *IdyT, *bathyT;
+  const double *mask2dCu, *dxCu, *dyCu, *dy_Cu, *IdxCu, *IdyCu, *areaCu, *IareaCu;
+  const double *mask2dCv, *dxCv, *dyCv, *dx_Cv, *IdxCv, *IdyCv, *areaCv, *IareaCv;
+  const double *mask2dBu, *dxBu, *dyBu, *areaBu, *IareaBu, *CoriolisBu;
   const double *uh_neglect, *vh_neglect;   // derived: MOM_tracer_advect.F90:182-188
   // linear offsets, Fortran indices, k zero-based
   __host__ __device__ inline long h2(int i, int j) const { return (long)(i - isd) + (long)nih * (j - jsd); }
   __host__ __device__ inline long u2(int I, int j) const { return (long)(I - isd + 1) + (long)(nih + 1) * (j - jsd); }
   __host__ __device__ inline long v2(int i, int J) const { return (long)(i - isd) + (long)nih * (J - jsd + 1); }
+  __host__ __device__ inline long q2(int I, int J) const { return (long)(I - isd + 1) + (long)(nih + 1) * (J - jsd + 1); }
   __host__ __device__ inline long h3(int i, int j, int k) const { return h2(i, j) + (long)nih * njh * k; }
   __host__ __device__ inline long u3(int I, int j, int k) const { return u2(I, j) + (long)(nih + 1) * njh * k; }
   __host__ __device__ inline long v3(int i, int J, int k) const { return v2(i, J) + (long)nih * (njh + 1) * k; }
@@ -53,6 +58,12 @@ struct GridDev {
   __host__ __device__ inline long nu3() const { return (long)(nih + 1) * njh * nk; }
   __host__ __device__ inline long nv3() const { return (long)nih * (njh + 1) * nk; }
 };
+
+// min/max with the compare-and-select semantics of the oracle's (and a Fortran compiler's usual) MIN/MAX
+// lowering: min2(a,b) = a < b ? a : b.  Unlike v_min_f64/v_max_f64 this is deterministic for (-0.0, +0.0)
+// ties, which occur at every masked point; use it wherever exact zeros are common.
+__device__ __forceinline__ double min2(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double max2(double a, double b) { return a > b ? a : b; }
 
 // grow-only device buffer
 struct DevBuf {

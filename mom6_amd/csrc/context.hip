@@ -148,8 +148,11 @@ int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t 
   g.isd = grid->isd; g.ied = grid->ied; g.jsd = grid->jsd; g.jed = grid->jed; g.nk = grid->nk;
   g.nih = nih; g.njh = njh;
   g.Angstrom_H = grid->Angstrom_H; g.H_subroundoff = grid->H_subroundoff;
-  g.mask2dT = ctx->d_metric[0]; g.areaT = ctx->d_metric[1];
-  g.mask2dCu = ctx->d_metric[8]; g.mask2dCv = ctx->d_metric[16];
+  {
+    // same declaration order in mom6hip_grid_t and GridDev
+    const double **dst = &g.mask2dT;
+    for (int m = 0; m < 30; m++) dst[m] = ctx->d_metric[m];
+  }
 
   // uh_neglect / vh_neglect, src/tracer/MOM_tracer_advect.F90:182-188 (a property of the grid)
   {

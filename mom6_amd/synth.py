@@ -62,7 +62,7 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     bowl = (np.sin(np.pi * Y) ** 0.5) * (0.65 + 0.35 * np.cos(2 * np.pi * X) * np.cos(np.pi * Y))
     rough = 0.12 * np.sin(6 * np.pi * X + 1.0) * np.sin(4 * np.pi * Y) + 0.04 * rng.standard_normal((nj, ni))
     field = bowl + rough
-    thr = np.quantile(field, land_frac) if land_frac > 0 else -np.inf
+    thr = np.quantile(field, land_frac) if land_frac > 0 else field.min() - 0.05 * (field.max() - field.min())
     ocean = field > thr
     depth_c = np.where(ocean, max_depth * np.clip((field - thr) / (field.max() - thr), 0.02, 1.0), 0.0)
 
@@ -215,3 +215,77 @@ def make_advection_state(g: Grid, ntr=4, seed=1, device="cpu", cfl=0.15, hot_fra
         "tr": tr,
         "vol0": _embed(g, vol0, _abi.POS_H),
     }
+
+
+def fill_halo(g: Grid, a: torch.Tensor, pos: int) -> torch.Tensor:
+    """pass_var on the one-tile domain (same semantics as oracle/domains.c), in place, for a torch array."""
+    xs = 1 if pos in (_abi.POS_U, _abi.POS_Q) else 0
+    ys = 1 if pos in (_abi.POS_V, _abi.POS_Q) else 0
+    h, ni, nj = g.halo, g.ni, g.nj
+    if g.reentrant_x:
+        # compute columns: [h, h+ni+xs) ; west halo [0,h) <- +ni ; east halo [h+ni+xs, end) <- -ni
+        a[..., h:h + nj + ys, :h] = a[..., h:h + nj + ys, ni:ni + h]
+        a[..., h:h + nj + ys, h + ni + xs:] = a[..., h:h + nj + ys, h + xs:2 * h + xs]
+    if g.reentrant_y:
+        a[..., :h, :] = a[..., nj:nj + h, :]
+        a[..., h + nj + ys:, :] = a[..., h + ys:2 * h + ys, :]
+    return a
+
+
+def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.3, dtype=torch.float64):
+    """A model-like state for the dynamical core: h, u, v, uh, vh, T, S with valid halos.
+
+    h: z*-like layers with vanished layers (Angstrom_H) below the topography and in random blobs;
+    u, v: a smooth rotational flow plus noise, zero on masked faces; uh, vh: upwind transports
+    u*h*dy_Cu, v*h*dx_Cv (what a continuity call would hand to CorAdCalc).
+    """
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    nk, ni, nj = g.nk, g.ni, g.nj
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device=dev)
+    rnd = lambda *s: torch.rand(*s, generator=gen, dtype=dtype, device=dev)
+    rndn = lambda *s: torch.randn(*s, generator=gen, dtype=dtype, device=dev)
+    sjh, sih = g.csl(_abi.POS_H); sju, siu = g.csl(_abi.POS_U); sjv, siv = g.csl(_abi.POS_V)
+    mT = t(g.mask2dT[sjh, sih]); depth = t(g.bathyT[sjh, sih])
+    x = (torch.arange(ni, dtype=dtype, device=dev) + 0.5) / ni
+    y = (torch.arange(nj, dtype=dtype, device=dev) + 0.5) / nj
+    kk = (torch.arange(nk, dtype=dtype, device=dev) + 0.5) / nk
+    X, Y, K = x[None, None, :], y[None, :, None], kk[:, None, None]
+    dz_nom = 2.0 + 300.0 * K ** 2
+    dz_nom = dz_nom * (5500.0 / dz_nom.sum())
+    ztop = torch.cumsum(dz_nom, 0) - dz_nom
+    h0 = torch.clamp(torch.minimum(dz_nom.expand(nk, nj, ni), depth[None] - ztop), min=0.0)
+    if vanish_frac > 0:
+        blob = torch.sin(9 * math.pi * X + 3 * K) * torch.sin(7 * math.pi * Y - 2 * K) + 0.3 * rndn(nk, nj, ni)
+        q = torch.quantile(blob.flatten()[:: max(1, blob.numel() // 200000)], 1.0 - vanish_frac)
+        h0 = torch.where(blob > q, torch.zeros_like(h0), h0)
+    h0 = torch.clamp(h0 * (1.0 + 0.05 * rndn(nk, nj, ni)), min=0.0)
+    h0 = torch.where(h0 < 1.0e-3, torch.full_like(h0, g.Angstrom_H), h0)
+    h0 = torch.where(mT[None] > 0, h0, torch.full_like(h0, g.Angstrom_H))
+    h = fill_halo(g, _embed(g, h0, _abi.POS_H) + 0.0, _abi.POS_H)
+    # closed-edge halos: keep a positive thickness there too
+    h = torch.where(h <= 0, torch.full_like(h, g.Angstrom_H), h)
+
+    amp = umax * torch.exp(-3.0 * K)
+    ue = amp * (0.7 * torch.sin(2 * math.pi * (Y + 0.3 * K)) * torch.cos(2 * math.pi * X) + 0.3 * rndn(nk, nj, ni))
+    vn = amp * (0.7 * torch.cos(2 * math.pi * (X - 0.2 * K)) * torch.sin(2 * math.pi * Y) + 0.3 * rndn(nk, nj, ni))
+    mCu = t(g.mask2dCu[sju, siu]); mCv = t(g.mask2dCv[sjv, siv])
+    u_c = torch.cat([ue[:, :, -1:], ue], 2) * mCu[None]
+    v_c = torch.cat([vn[:, -1:, :], vn], 1) * mCv[None]
+    u = fill_halo(g, _embed(g, u_c, _abi.POS_U), _abi.POS_U)
+    v = fill_halo(g, _embed(g, v_c, _abi.POS_V), _abi.POS_V)
+    # upwind transports on every face of the data domain that has both neighbours
+    dy_Cu, dx_Cv = t(g.dy_Cu), t(g.dx_Cv)
+    hW, hE = h[:, :, :-1], h[:, :, 1:]
+    uh = torch.zeros_like(u)
+    uh[:, :, 1:-1] = u[:, :, 1:-1] * torch.where(u[:, :, 1:-1] >= 0, hW, hE) * dy_Cu[None, :, 1:-1]
+    hS, hN = h[:, :-1, :], h[:, 1:, :]
+    vh = torch.zeros_like(v)
+    vh[:, 1:-1, :] = v[:, 1:-1, :] * torch.where(v[:, 1:-1, :] >= 0, hS, hN) * dx_Cv[None, 1:-1, :]
+    zmid = (ztop + 0.5 * dz_nom)
+    T = 20.0 * torch.exp(-zmid / 1000.0) + 2.0 * torch.cos(math.pi * Y) + 0.01 * rndn(nk, nj, ni)
+    S = 35.0 + 0.5 * torch.sin(2 * math.pi * X) * torch.sin(math.pi * Y) + 0.01 * rndn(nk, nj, ni)
+    T = fill_halo(g, _embed(g, (T * mT[None]).contiguous(), _abi.POS_H), _abi.POS_H)
+    S = fill_halo(g, _embed(g, (S * mT[None]).contiguous(), _abi.POS_H), _abi.POS_H)
+    return {"h": h.contiguous(), "u": u.contiguous(), "v": v.contiguous(), "uh": uh.contiguous(),
+            "vh": vh.contiguous(), "T": T.contiguous(), "S": S.contiguous()}

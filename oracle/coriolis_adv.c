@@ -1,0 +1,180 @@
+/*
+ * coriolis_adv.c -- CPU restatement of CorAdCalc / gradKE (TEST INFRASTRUCTURE, see mom6_oracle.h).
+ *
+ * Restates src/core/MOM_CoriolisAdv.F90:125-965 (CorAdCalc) and :969-1051 (gradKE) for the configuration
+ * of the hot path: OBC not associated, no Stokes vortex force, porous barriers = 1, no acceleration
+ * diagnostics, CORIOLIS_EN_DIS = False.  Coriolis schemes SADOURNY75_ENERGY (default), SADOURNY75_ENSTRO and
+ * ARAKAWA_HSU90; KE schemes KE_ARAKAWA (default), KE_SIMPLE_GUDONOV, KE_GUDONOV; NOSLIP and BOUND_CORIOLIS.
+ *
+ * PARITY UNPINNED: the reference holds no known-answer vectors for CorAdCalc.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include "mom6_oracle.h"
+
+static inline double max2(double a, double b) { return a > b ? a : b; }
+static inline double min2(double a, double b) { return a < b ? a : b; }
+static inline double max4(double a, double b, double c, double d) { return max2(max2(max2(a, b), c), d); }
+static inline double min4(double a, double b, double c, double d) { return min2(min2(min2(a, b), c), d); }
+
+int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const double *u, const double *v,
+                  const double *h, const double *uh, const double *vh, double *CAu, double *CAv)
+{
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const double vol_neglect = G->H_subroundoff * (1e-4 * 1.0)*(1e-4 * 1.0);   /* :241, US%m_to_L = 1 */
+  const double C1_12 = 1.0 / 12.0;
+  if (CS->coriolis_en_dis) return 1;
+  const long nH = (long)ORC_NIH(G)*ORC_NJH(G), nU = (long)(ORC_NIH(G)+1)*ORC_NJH(G);
+  const long nV = (long)ORC_NIH(G)*(ORC_NJH(G)+1), nQ = (long)(ORC_NIH(G)+1)*(ORC_NJH(G)+1);
+  double *Area_h = calloc(nH, 8), *Area_q = calloc(nQ, 8), *q = calloc(nQ, 8), *Ih_q = calloc(nQ, 8);
+  double *abs_vort = calloc(nQ, 8), *dvdx = calloc(nQ, 8), *dudy = calloc(nQ, 8), *rel_vort = calloc(nQ, 8);
+  double *hArea_u = calloc(nU, 8), *hArea_v = calloc(nV, 8), *KE = calloc(nH, 8), *KEx = calloc(nU, 8), *KEy = calloc(nV, 8);
+  double *a = calloc(nU, 8), *b = calloc(nU, 8), *c = calloc(nU, 8), *d = calloc(nU, 8);
+#define H2(i,j) ORC_H2(G,i,j)
+#define U2(i,j) ORC_U2(G,i,j)
+#define V2(i,j) ORC_V2(G,i,j)
+#define Q2(i,j) ORC_Q2(G,i,j)
+#define H3(i,j,k) ORC_H3(G,i,j,k)
+#define U3(i,j,k) ORC_U3(G,i,j,k)
+#define V3(i,j,k) ORC_V3(G,i,j,k)
+
+  /* :246-248 */
+  for (int j = Jsq-1; j <= Jeq+2; j++) for (int i = Isq-1; i <= Ieq+2; i++)
+    Area_h[H2(i,j)] = G->mask2dT[H2(i,j)] * G->areaT[H2(i,j)];
+  /* :271-274 */
+  for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++)
+    Area_q[Q2(I,J)] = (Area_h[H2(I,J)] + Area_h[H2(I+1,J+1)]) + (Area_h[H2(I+1,J)] + Area_h[H2(I,J+1)]);
+
+  for (int k = 1; k <= nz; k++) {
+    /* :314-324 */
+    for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++) {
+      const int i = I, j = J;
+      dvdx[Q2(I,J)] = (v[V3(i+1,J,k)]*G->dyCv[V2(i+1,J)] - v[V3(i,J,k)]*G->dyCv[V2(i,J)]);
+      dudy[Q2(I,J)] = (u[U3(I,j+1,k)]*G->dxCu[U2(I,j+1)] - u[U3(I,j,k)]*G->dxCu[U2(I,j)]);
+    }
+    for (int J = Jsq-1; J <= Jeq+1; J++) for (int i = Isq-1; i <= Ieq+2; i++) {
+      const int j = J;
+      hArea_v[V2(i,J)] = 0.5*(Area_h[H2(i,j)] * h[H3(i,j,k)] + Area_h[H2(i,j+1)] * h[H3(i,j+1,k)]);
+    }
+    for (int j = Jsq-1; j <= Jeq+2; j++) for (int I = Isq-1; I <= Ieq+1; I++) {
+      const int i = I;
+      hArea_u[U2(I,j)] = 0.5*(Area_h[H2(i,j)] * h[H3(i,j,k)] + Area_h[H2(i+1,j)] * h[H3(i+1,j,k)]);
+    }
+    /* :459-473 */
+    for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++) {
+      if (CS->no_slip)
+        rel_vort[Q2(I,J)] = (2.0 - G->mask2dBu[Q2(I,J)]) * (dvdx[Q2(I,J)] - dudy[Q2(I,J)]) * G->IareaBu[Q2(I,J)];
+      else
+        rel_vort[Q2(I,J)] = G->mask2dBu[Q2(I,J)] * (dvdx[Q2(I,J)] - dudy[Q2(I,J)]) * G->IareaBu[Q2(I,J)];
+    }
+    /* :483-491 */
+    for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++)
+      abs_vort[Q2(I,J)] = G->CoriolisBu[Q2(I,J)] + rel_vort[Q2(I,J)];
+    for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++) {
+      const int i = I, j = J;
+      double hArea_q = (hArea_u[U2(I,j)] + hArea_u[U2(I,j+1)]) + (hArea_v[V2(i,J)] + hArea_v[V2(i+1,J)]);
+      Ih_q[Q2(I,J)] = Area_q[Q2(I,J)] / (hArea_q + vol_neglect);
+      q[Q2(I,J)] = abs_vort[Q2(I,J)] * Ih_q[Q2(I,J)];
+    }
+    /* :523-533 */
+    if (CS->coriolis_scheme == MOM6HIP_ARAKAWA_HSU90) {
+      for (int j = Jsq; j <= Jeq+1; j++) {
+        const int J = j;
+        for (int I = is-1; I <= Ieq; I++) {
+          a[U2(I,j)] = (q[Q2(I,J)] + (q[Q2(I+1,J)] + q[Q2(I,J-1)])) * C1_12;
+          d[U2(I,j)] = ((q[Q2(I,J)] + q[Q2(I+1,J-1)]) + q[Q2(I,J-1)]) * C1_12;
+        }
+        for (int I = Isq; I <= Ieq; I++) {
+          b[U2(I,j)] = (q[Q2(I,J)] + (q[Q2(I-1,J)] + q[Q2(I,J-1)])) * C1_12;
+          c[U2(I,j)] = ((q[Q2(I,J)] + q[Q2(I-1,J-1)]) + q[Q2(I,J-1)]) * C1_12;
+        }
+      }
+    }
+    /* gradKE, :994-1035 */
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+      const int I = i, J = j;
+      if (CS->ke_scheme == MOM6HIP_KE_ARAKAWA) {
+        KE[H2(i,j)] = ( ( G->areaCu[U2(I,j)]*(u[U3(I,j,k)]*u[U3(I,j,k)]) +
+                          G->areaCu[U2(I-1,j)]*(u[U3(I-1,j,k)]*u[U3(I-1,j,k)]) ) +
+                        ( G->areaCv[V2(i,J)]*(v[V3(i,J,k)]*v[V3(i,J,k)]) +
+                          G->areaCv[V2(i,J-1)]*(v[V3(i,J-1,k)]*v[V3(i,J-1,k)]) ) )*0.25*G->IareaT[H2(i,j)];
+      } else {
+        double up = 0.5*( u[U3(I-1,j,k)] + fabs( u[U3(I-1,j,k)] ) );
+        double um = 0.5*( u[U3(I,j,k)] - fabs( u[U3(I,j,k)] ) );
+        double vp = 0.5*( v[V3(i,J-1,k)] + fabs( v[V3(i,J-1,k)] ) );
+        double vm = 0.5*( v[V3(i,J,k)] - fabs( v[V3(i,J,k)] ) );
+        if (CS->ke_scheme == MOM6HIP_KE_SIMPLE_GUDONOV) {
+          double up2 = up*up, um2 = um*um, vp2 = vp*vp, vm2 = vm*vm;
+          KE[H2(i,j)] = ( max2(up2,um2) + max2(vp2,vm2) ) *0.5;
+        } else {
+          double up2a = up*up*G->areaCu[U2(I-1,j)], um2a = um*um*G->areaCu[U2(I,j)];
+          double vp2a = vp*vp*G->areaCv[V2(i,J-1)], vm2a = vm*vm*G->areaCv[V2(i,J)];
+          KE[H2(i,j)] = ( max2(um2a,up2a) + max2(vm2a,vp2a) )*0.5*G->IareaT[H2(i,j)];
+        }
+      }
+    }
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      KEx[U2(I,j)] = (KE[H2(I+1,j)] - KE[H2(I,j)]) * G->IdxCu[U2(I,j)];
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      KEy[V2(i,J)] = (KE[H2(i,J+1)] - KE[H2(i,J)]) * G->IdyCv[V2(i,J)];
+
+    /* CAu, :644-752 */
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
+      const int i = I, J = j;
+      double ca;
+      if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY) {
+        ca = 0.25 *
+            (q[Q2(I,J)] * (vh[V3(i+1,J,k)] + vh[V3(i,J,k)]) +
+             q[Q2(I,J-1)] * (vh[V3(i,J-1,k)] + vh[V3(i+1,J-1,k)])) * G->IdxCu[U2(I,j)];
+      } else if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENSTRO) {
+        ca = 0.125 * (G->IdxCu[U2(I,j)] * (q[Q2(I,J)] + q[Q2(I,J-1)])) *
+                     ((vh[V3(i+1,J,k)] + vh[V3(i,J,k)]) + (vh[V3(i,J-1,k)] + vh[V3(i+1,J-1,k)]));
+      } else {
+        ca = ((a[U2(I,j)] * vh[V3(i+1,J,k)] +  c[U2(I,j)] * vh[V3(i,J-1,k)])  +
+              (b[U2(I,j)] * vh[V3(i,J,k)] +  d[U2(I,j)] * vh[V3(i+1,J-1,k)])) * G->IdxCu[U2(I,j)];
+      }
+      if (CS->bound_coriolis) {
+        double fv1 = abs_vort[Q2(I,J)] * v[V3(i+1,J,k)];
+        double fv2 = abs_vort[Q2(I,J)] * v[V3(i,J,k)];
+        double fv3 = abs_vort[Q2(I,J-1)] * v[V3(i+1,J-1,k)];
+        double fv4 = abs_vort[Q2(I,J-1)] * v[V3(i,J-1,k)];
+        double max_fv = max4(fv1, fv2, fv3, fv4), min_fv = min4(fv1, fv2, fv3, fv4);
+        ca = min2(ca, max_fv);
+        ca = max2(ca, min_fv);
+      }
+      CAu[U3(I,j,k)] = ca - KEx[U2(I,j)];
+    }
+    /* CAv, :763-876 */
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) {
+      const int I = i, j = J;
+      double ca;
+      if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY) {
+        ca = - 0.25*
+              (q[Q2(I-1,J)]*(uh[U3(I-1,j,k)] + uh[U3(I-1,j+1,k)]) +
+               q[Q2(I,J)]*(uh[U3(I,j,k)] + uh[U3(I,j+1,k)])) * G->IdyCv[V2(i,J)];
+      } else if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENSTRO) {
+        ca = -0.125 * (G->IdyCv[V2(i,J)] * (q[Q2(I-1,J)] + q[Q2(I,J)])) *
+                     ((uh[U3(I-1,j,k)] + uh[U3(I-1,j+1,k)]) + (uh[U3(I,j,k)] + uh[U3(I,j+1,k)]));
+      } else {
+        ca = - ((a[U2(I-1,j)]   * uh[U3(I-1,j,k)] +
+                 c[U2(I,j+1)]   * uh[U3(I,j+1,k)])
+              + (b[U2(I,j)]     * uh[U3(I,j,k)] +
+                 d[U2(I-1,j+1)] * uh[U3(I-1,j+1,k)])) * G->IdyCv[V2(i,J)];
+      }
+      if (CS->bound_coriolis) {
+        double fu1 = -abs_vort[Q2(I,J)] * u[U3(I,j+1,k)];
+        double fu2 = -abs_vort[Q2(I,J)] * u[U3(I,j,k)];
+        double fu3 = -abs_vort[Q2(I-1,J)] * u[U3(I-1,j+1,k)];
+        double fu4 = -abs_vort[Q2(I-1,J)] * u[U3(I-1,j,k)];
+        double max_fu = max4(fu1, fu2, fu3, fu4), min_fu = min4(fu1, fu2, fu3, fu4);
+        ca = min2(ca, max_fu);
+        ca = max2(ca, min_fu);
+      }
+      CAv[V3(i,J,k)] = ca - KEy[V2(i,J)];
+    }
+  }
+  free(Area_h); free(Area_q); free(q); free(Ih_q); free(abs_vort); free(dvdx); free(dudy); free(rel_vort);
+  free(hArea_u); free(hArea_v); free(KE); free(KEx); free(KEy); free(a); free(b); free(c); free(d);
+  return 0;
+}

@@ -91,6 +91,10 @@ void orc_dz_from_h1h2(int n1, const double *h1, int n2, const double *h2, double
 int orc_ale_remap_tracers(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t *cs, const double *h_old,
                           const double *h_new, double *const *tr, const double *conc_underflow, int ntr);
 
+/* ---- MOM_CoriolisAdv (oracle/coriolis_adv.c) ------------------------------------------------ */
+int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const double *u, const double *v,
+                  const double *h, const double *uh, const double *vh, double *CAu, double *CAv);
+
 #ifdef __cplusplus
 }
 #endif

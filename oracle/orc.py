@@ -191,3 +191,17 @@ def ale_remap_tracers(grid, scheme, h_old, h_new, tr, conc_underflow=None, bound
     rc = L.orc_ale_remap_tracers(C.byref(grid.struct()), C.byref(cs), _p(h_old), _p(h_new), trp, _p(cu), ntr)
     if rc:
         raise RuntimeError("orc_ale_remap_tracers failed")
+
+
+def coradcalc(grid, u, v, h, uh, vh, coriolis_scheme="SADOURNY75_ENERGY", ke_scheme="KE_ARAKAWA", no_slip=False,
+              bound_coriolis=False):
+    """CorAdCalc on numpy arrays; returns (CAu, CAv) (zero outside the computed ranges)."""
+    L = lib()
+    L.orc_coradcalc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.CoriolisAdvCS)] + [_dp] * 7
+    cs = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES[coriolis_scheme], _abi.KE_SCHEMES[ke_scheme], int(no_slip),
+                            int(bound_coriolis), 0)
+    CAu = np.zeros_like(u); CAv = np.zeros_like(v)
+    rc = L.orc_coradcalc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(uh), _p(vh), _p(CAu), _p(CAv))
+    if rc:
+        raise RuntimeError("orc_coradcalc failed")
+    return CAu, CAv
