@@ -214,6 +214,44 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
                       const double *h, const double *uh, const double *vh, double *CAu, double *CAv,
                       int32_t memspace);
 
+/* ---- MOM_continuity_PPM --------------------------------------------------------------------- */
+
+/* continuity_PPM_CS, src/core/MOM_continuity_PPM.F90:35-67; defaults of continuity_PPM_init :2679-2757 */
+typedef struct mom6hip_continuity_cs {
+  int32_t upwind_1st;        /* UPWIND_1ST_CONTINUITY      (False) */
+  int32_t monotonic;         /* MONOTONIC_CONTINUITY       (False: positive-definite limiter) */
+  int32_t simple_2nd;        /* SIMPLE_2ND_PPM_CONTINUITY  (False) */
+  int32_t aggress_adjust;    /* CONT_PPM_AGGRESS_ADJUST    (False) */
+  int32_t vol_CFL;           /* CONT_PPM_VOLUME_BASED_CFL  (= aggress_adjust) */
+  int32_t better_iter;       /* CONT_PPM_BETTER_ITER       (True) */
+  int32_t use_visc_rem_max;  /* CONT_PPM_USE_VISC_REM_MAX  (True) */
+  int32_t marginal_faces;    /* CONT_PPM_MARGINAL_FACE_AREAS (True) */
+  double tol_eta;            /* ETA_TOLERANCE [H]          (0.5*NK*Angstrom) */
+  double tol_vel;            /* VELOCITY_TOLERANCE [L T-1] (3e8) */
+  double CFL_limit_adjust;   /* CONTINUITY_CFL_LIMIT       (0.5) */
+} mom6hip_continuity_cs_t;
+
+/* BT_cont_type, src/core/MOM_variables.F90 (the members continuity_PPM sets).  2-D face arrays;
+ * h_u / h_v are 3-D and may be NULL (they are only allocated for BT_THICK_SCHEME = FROM_BT_CONT). */
+typedef struct mom6hip_bt_cont {
+  double *FA_u_W0, *FA_u_WW, *FA_u_E0, *FA_u_EE, *uBT_WW, *uBT_EE;   /* u-points */
+  double *FA_v_S0, *FA_v_SS, *FA_v_N0, *FA_v_NN, *vBT_SS, *vBT_NN;   /* v-points */
+  double *h_u, *h_v;
+} mom6hip_bt_cont_t;
+
+/*
+ * continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, visc_rem_u, visc_rem_v,
+ *                u_cor, v_cor, BT_cont, du_cor, dv_cor)                 src/core/MOM_continuity_PPM.F90:86
+ * Optional arguments are NULL when absent.  h may be the same array as hin.  OBC must not be associated and
+ * pbv must be all ones.  Metrics needed: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, dy_Cu, dx_Cv, dxCu, dyCv,
+ * mask2dCu, mask2dCv.
+ */
+int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, const double *u, const double *v,
+                       const double *hin, double *h, double *uh, double *vh, double dt, const double *uhbt,
+                       const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor,
+                       double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor,
+                       int32_t memspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,3 +63,17 @@ KE_SCHEMES = {"KE_ARAKAWA": 10, "KE_SIMPLE_GUDONOV": 11, "KE_GUDONOV": 12}
 class CoriolisAdvCS(C.Structure):
     _fields_ = [("coriolis_scheme", C.c_int32), ("ke_scheme", C.c_int32), ("no_slip", C.c_int32),
                 ("bound_coriolis", C.c_int32), ("coriolis_en_dis", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class ContinuityCS(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("upwind_1st", "monotonic", "simple_2nd", "aggress_adjust", "vol_CFL",
+                                         "better_iter", "use_visc_rem_max", "marginal_faces")] + \
+               [("tol_eta", C.c_double), ("tol_vel", C.c_double), ("CFL_limit_adjust", C.c_double)]
+
+
+BT_CONT_U = ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE")
+BT_CONT_V = ("FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN")
+
+
+class BTCont(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in BT_CONT_U + BT_CONT_V + ("h_u", "h_v")]

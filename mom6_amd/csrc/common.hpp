@@ -12,6 +12,8 @@
 
 #include "../../include/mom6hip.h"
 
+struct mom6hip_ctx;
+
 namespace m6 {
 
 // ---- errors --------------------------------------------------------------------------------
@@ -85,8 +87,36 @@ struct mom6hip_ctx {
 
   // advect_tracer work space (device)
   m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
+  m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   int *h_domore_k = nullptr;    // pinned host mirror of domore_k
   // timing
   bool timing = false;
   mom6hip_advect_timing_t adv_timing = {};
 };
+
+namespace m6 {
+
+// Gives a kernel driver device views of the caller's arrays.  MOM6HIP_MEM_DEVICE: the pointers are used
+// as they are.  MOM6HIP_MEM_HOST: inputs are copied to pooled device buffers, outputs are copied back by
+// finish().  The same host pointer always maps to the same device buffer (h may alias hin, ...).
+class Stager {
+ public:
+  Stager(mom6hip_ctx *ctx, int memspace) : ctx_(ctx), host_(memspace == MOM6HIP_MEM_HOST) {}
+  // in: read by the kernels; out: written; inout: both.  A null pointer stays null.
+  template <typename T> const T *in(const T *p, size_t bytes) { return (const T *)map((void *)p, bytes, true, false); }
+  template <typename T> T *out(T *p, size_t bytes) { return (T *)map((void *)p, bytes, false, true); }
+  template <typename T> T *inout(T *p, size_t bytes) { return (T *)map((void *)p, bytes, true, true); }
+  // device scratch that is not visible to the caller
+  void *scratch(size_t bytes);
+  bool failed() const { return fail_; }
+  int finish();   // copies the outputs back (HOST) and synchronises the stream in that case
+ private:
+  void *map(void *p, size_t bytes, bool rd, bool wr);
+  struct Ent { void *host, *dev; size_t bytes; bool wr; };
+  mom6hip_ctx *ctx_;
+  bool host_, fail_ = false;
+  int next_ = 0;
+  std::vector<Ent> ents_;
+};
+
+}  // namespace m6

@@ -34,6 +34,37 @@ void DevBuf::release() {
   p = nullptr; bytes = 0;
 }
 
+void *Stager::scratch(size_t bytes) {
+  if (next_ >= 64) { set_error("Stager: out of pool buffers"); fail_ = true; return nullptr; }
+  DevBuf &b = ctx_->pool[next_++];
+  if (b.reserve(bytes)) { fail_ = true; return nullptr; }
+  return b.p;
+}
+
+void *Stager::map(void *p, size_t bytes, bool rd, bool wr) {
+  if (!p) return nullptr;
+  if (!host_) return p;
+  for (auto &e : ents_) if (e.host == p) { e.wr = e.wr || wr; return e.dev; }
+  void *d = scratch(bytes);
+  if (!d) return nullptr;
+  if (rd && hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx_->stream) != hipSuccess) {
+    set_error("Stager: host-to-device copy failed"); fail_ = true; return nullptr;
+  }
+  ents_.push_back({p, d, bytes, wr});
+  return d;
+}
+
+int Stager::finish() {
+  if (fail_) return 1;
+  if (!host_) return 0;
+  for (auto &e : ents_)
+    if (e.wr && hipMemcpyAsync(e.host, e.dev, e.bytes, hipMemcpyDeviceToHost, ctx_->stream) != hipSuccess) {
+      set_error("Stager: device-to-host copy failed"); return 1;
+    }
+  if (hipStreamSynchronize(ctx_->stream) != hipSuccess) { set_error("Stager: stream synchronise failed"); return 1; }
+  return 0;
+}
+
 }  // namespace m6
 
 using m6::set_error;
@@ -185,6 +216,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   ctx->hprev.release(); ctx->uhr.release(); ctx->vhr.release(); ctx->flags.release();
   for (auto &b : ctx->stage) b.release();
   for (auto &b : ctx->tr_stage) b.release();
+  for (auto &b : ctx->pool) b.release();
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
   delete ctx;
   return 0;

@@ -1,0 +1,538 @@
+// continuity.hip -- continuity_PPM (src/core/MOM_continuity_PPM.F90:86-194 and everything it calls) as
+// gfx950 kernels.
+//
+// Per direction (zonal / meridional; the reference's two sets of routines are mirror images, so the
+// kernels are templated on DIR and walk an "along/cross" index pair):
+//   cont_edge_kernel<DIR>   PPM_reconstruction_x/y + PPM_limit_pos | PPM_limit_CW84   (:2310-2662)
+//                           one thread per cell, lanes along i -> every access is i-contiguous
+//   cont_flux_kernel<DIR>   zonal/meridional_mass_flux (:519-820): one lane per FACE COLUMN (all nk layers):
+//                           the layer transports and marginal areas (flux_layer :896-972), the CFL
+//                           brackets, the per-column Newton/bisection solve for the barotropic velocity
+//                           correction (flux_adjust :1094-1243: the reference iterates a whole row until
+//                           its slowest column is done; each lane here iterates only its own column --
+//                           the arithmetic per column is identical), u_cor, and the BT_cont face-area fits
+//                           (set_zonal_BT_cont :1247-1410) and h_u (flux_thickness :976-1057).
+//                           Lanes run along i in both directions, the k loop is inside the lane, so the
+//                           k-strided loads are 512-byte rows across the wave.  Layer transports are
+//                           written straight to uh/vh on every re-evaluation (no per-lane k arrays).
+//   cont_conv_kernel<DIR>   continuity_*_convergence (:348-417)
+// Algorithmic traffic per call: read u, v, hin, visc_rem_u/v, write h, uh, vh, u_cor, v_cor = 96 B/cell
+// (SURVEY.md section 8d); this first version also materialises the edge values like the reference does
+// (+32 B/cell written and re-read per direction).
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+using m6::max2;
+using m6::min2;
+__device__ __forceinline__ double max3(double a, double b, double c) { return max2(max2(a, b), c); }
+__device__ __forceinline__ double min3(double a, double b, double c) { return min2(min2(a, b), c); }
+
+struct ContOpts {
+  int upwind_1st, monotonic, simple_2nd, aggress_adjust, vol_CFL, better_iter, use_visc_rem_max, marginal_faces;
+  double tol_eta, tol_vel, CFL_limit_adjust;
+};
+
+// Index helper for one direction.  Cells are addressed by their real (i,j); `sa` is the h-point stride of
+// the along direction (1 or nih); faces by (I,j) or (i,J).
+template <int DIR>
+struct Dir {
+  const m6::GridDev &g;
+  __device__ Dir(const m6::GridDev &g_) : g(g_) {}
+  __device__ __forceinline__ long sa() const { return DIR ? (long)g.nih : 1L; }
+  __device__ __forceinline__ long f2(int i, int j) const { return DIR ? g.v2(i, j) : g.u2(i, j); }
+  __device__ __forceinline__ long fplane() const { return DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh; }
+  // stride of the along direction in the FACE arrays
+  __device__ __forceinline__ long fsa() const { return DIR ? (long)g.nih : 1L; }
+  __device__ __forceinline__ const double *dL_face() const { return DIR ? g.dx_Cv : g.dy_Cu; }
+  __device__ __forceinline__ const double *IdL_T() const { return DIR ? g.IdyT : g.IdxT; }
+  __device__ __forceinline__ const double *dL_T() const { return DIR ? g.dyT : g.dxT; }
+  __device__ __forceinline__ const double *dLC_face() const { return DIR ? g.dyCv : g.dxCu; }
+  __device__ __forceinline__ const double *mask_face() const { return DIR ? g.mask2dCv : g.mask2dCu; }
+};
+
+// ---- edge values ---------------------------------------------------------------------------------
+struct EdgeArgs {
+  m6::GridDev g;
+  ContOpts o;
+  const double *h_in;
+  double *h_L, *h_R;
+  int i0, i1, j0, j1;      // cells to reconstruct (already including the +-1 along the direction)
+};
+
+template <int DIR>
+__global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = p.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = p.j0 + blockIdx.y;
+  const int k = blockIdx.z;
+  if (i > p.i1) return;
+  const long s = DIR ? (long)g.nih : 1L;
+  const long o2 = g.h2(i, j), o3 = o2 + (long)g.nih * g.njh * k;
+  const double *h = p.h_in + o3;
+  const double *m = g.mask2dT + o2;
+  const double hc = h[0];
+  if (p.o.upwind_1st) { p.h_L[o3] = hc; p.h_R[o3] = hc; return; }
+  const double hm = h[-s], hp = h[s];
+  const double mm = m[-s], mp = m[s];
+  const double h_m1 = mm * hm + (1.0 - mm) * hc;
+  const double h_p1 = mp * hp + (1.0 - mp) * hc;
+  double L, R;
+  if (p.o.simple_2nd) {
+    L = 0.5 * (h_m1 + hc);
+    R = 0.5 * (h_p1 + hc);
+  } else {
+    // slopes of cells a-1, a, a+1 (:2371-2381)
+    auto slope = [&](double hl, double hcc, double hr, double ml, double mc, double mr) -> double {
+      if ((ml * mc * mr) == 0.0) return 0.0;
+      double sl = 0.5 * (hr - hl);
+      const double dMx = max3(hr, hl, hcc) - hcc;
+      const double dMn = hcc - min3(hr, hl, hcc);
+      return copysign(1., sl) * min2(fabs(sl), 2. * min2(dMx, dMn));
+    };
+    const double hmm = h[-2 * s], hpp = h[2 * s];
+    const double mmm = m[-2 * s], mc = m[0], mpp = m[2 * s];
+    const double slp_m = slope(hmm, hm, hc, mmm, mm, mc);
+    const double slp_c = slope(hm, hc, hp, mm, mc, mp);
+    const double slp_p = slope(hc, hp, hpp, mc, mp, mpp);
+    const double oneSixth = 1. / 6.;
+    L = 0.5 * (h_m1 + hc) + oneSixth * (slp_m - slp_c);
+    R = 0.5 * (h_p1 + hc) + oneSixth * (slp_c - slp_p);
+  }
+  if (p.o.monotonic) {          // PPM_limit_CW84 :2625
+    if ((R - hc) * (hc - L) <= 0.) {
+      L = hc; R = hc;
+    } else {
+      const double RLdiff = R - L;
+      const double RLmean = 0.5 * (R + L);
+      const double FunFac = 6. * RLdiff * (hc - RLmean);
+      const double RLdiff2 = RLdiff * RLdiff;
+      if (FunFac > RLdiff2) L = 3. * hc - 2. * R;
+      if (FunFac < -RLdiff2) R = 3. * hc - 2. * L;
+    }
+  } else {                      // PPM_limit_pos :2583
+    const double h_min = 2.0 * g.Angstrom_H;
+    const double curv = 3.0 * (L + R - 2.0 * hc);
+    if (curv > 0.0) {
+      const double dh = R - L;
+      if (fabs(dh) < curv) {
+        if (hc <= h_min) {
+          L = hc; R = hc;
+        } else if (12.0 * curv * (hc - h_min) < (curv * curv + 3.0 * (dh * dh))) {
+          const double scale = 12.0 * curv * (hc - h_min) / (curv * curv + 3.0 * (dh * dh));
+          L = hc + scale * (L - hc);
+          R = hc + scale * (R - hc);
+        }
+      }
+    }
+  }
+  p.h_L[o3] = L; p.h_R[o3] = R;
+}
+
+// ---- mass fluxes ---------------------------------------------------------------------------------
+struct FluxArgs {
+  m6::GridDev g;
+  ContOpts o;
+  const double *u, *h_in, *h_L, *h_R, *uhbt, *visc_rem;
+  double *uh, *u_cor, *du_cor;
+  double *FA_0m, *FA_mm, *FA_0p, *FA_pp, *uBT_mm, *uBT_pp, *h_face;   // BT_cont members of this direction
+  int set_BT_cont;
+  double dt;
+  int fi0, fi1, fj0, fj1;    // face index ranges: zonal (I = ish-1..ieh, j = jsh..jeh); meridional (i, J)
+};
+
+// flux_layer :896-972 for one face; o = offset of the minus-side cell in the h-point arrays
+template <int DIR>
+__device__ __forceinline__ double flux_layer(const FluxArgs &p, const Dir<DIR> &D, double u, long o3, long o2, long f2,
+                                             double visc_rem, double &duhdu) {
+  const m6::GridDev &g = p.g;
+  const long s = D.sa();
+  const double dLf = D.dL_face()[f2];
+  double CFL, curv_3, h_marg, uh;
+  if (u > 0.0) {
+    if (p.o.vol_CFL) CFL = (u * p.dt) * (dLf * g.IareaT[o2]);
+    else CFL = u * p.dt * D.IdL_T()[o2];
+    const double hW = p.h_L[o3], hE = p.h_R[o3], hc = p.h_in[o3];
+    curv_3 = hW + hE - 2.0 * hc;
+    uh = (dLf * 1.0) * u * (hE + CFL * (0.5 * (hW - hE) + curv_3 * (CFL - 1.5)));
+    h_marg = hE + CFL * ((hW - hE) + 3.0 * curv_3 * (CFL - 1.0));
+  } else if (u < 0.0) {
+    if (p.o.vol_CFL) CFL = (-u * p.dt) * (dLf * g.IareaT[o2 + s]);
+    else CFL = -u * p.dt * D.IdL_T()[o2 + s];
+    const double hW = p.h_L[o3 + s], hE = p.h_R[o3 + s], hc = p.h_in[o3 + s];
+    curv_3 = hW + hE - 2.0 * hc;
+    uh = (dLf * 1.0) * u * (hW + CFL * (0.5 * (hE - hW) + curv_3 * (CFL - 1.5)));
+    h_marg = hW + CFL * ((hE - hW) + 3.0 * curv_3 * (CFL - 1.0));
+  } else {
+    uh = 0.0;
+    h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+  }
+  duhdu = (dLf * 1.0) * h_marg * visc_rem;
+  return uh;
+}
+
+__device__ __forceinline__ double ratio_max(double a, double b, double maxrat) {
+  if (fabs(a) > fabs(maxrat * b)) return maxrat;
+  return a / b;
+}
+
+// flux_adjust :1094-1243 for this lane's face column.  If write_uh, the re-evaluated layer transports
+// are stored to p.uh (the reference's uh_3d argument).
+template <int DIR>
+__device__ double flux_adjust(const FluxArgs &p, const Dir<DIR> &D, long o3_0, long o2, long f3_0, long f2, double uhbt,
+                              double uh_tot_0, double duhdu_tot_0, double du_max_CFL, double du_min_CFL,
+                              bool write_uh) {
+  const m6::GridDev &g = p.g;
+  const int nz = g.nk, max_itts = 20;
+  const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
+  double du = 0.0, du_max = du_max_CFL, du_min = du_min_CFL;
+  double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0, uh_err_best = fabs(uh_err);
+  bool do_I = true;
+  const double IaT = min2(g.IareaT[o2], g.IareaT[o2 + D.sa()]);
+  for (int itt = 1; itt <= max_itts; itt++) {
+    double tol_eta;
+    if (itt <= 1) tol_eta = 1e-6 * p.o.tol_eta;
+    else if (itt == 2) tol_eta = 1e-4 * p.o.tol_eta;
+    else if (itt == 3) tol_eta = 1e-2 * p.o.tol_eta;
+    else tol_eta = p.o.tol_eta;
+    const double tol_vel = p.o.tol_vel;
+    if (uh_err > 0.0) du_max = du;
+    else if (uh_err < 0.0) du_min = du;
+    else do_I = false;
+    bool domore = false;
+    if (do_I) {
+      if ((p.dt * IaT * fabs(uh_err) > tol_eta) ||
+          (p.o.better_iter && ((fabs(uh_err) > tol_vel * duhdu_tot) || (fabs(uh_err) > uh_err_best)))) {
+        const double ddu = -uh_err / duhdu_tot;
+        const double du_prev = du;
+        du = du + ddu;
+        if (fabs(ddu) < 1.0e-15 * fabs(du)) {
+          do_I = false;
+        } else if (ddu > 0.0) {
+          if (du >= du_max) {
+            du = 0.5 * (du_prev + du_max);
+            if (du_max - du_prev < 1.0e-15 * fabs(du)) do_I = false;
+          }
+        } else {
+          if (du <= du_min) {
+            du = 0.5 * (du_prev + du_min);
+            if (du_prev - du_min < 1.0e-15 * fabs(du)) do_I = false;
+          }
+        }
+        if (do_I) domore = true;
+      } else {
+        do_I = false;
+      }
+    }
+    if (!domore) break;
+    if ((itt < max_itts) || write_uh) {
+      double usum = -uhbt, dsum = 0.0;
+      for (int k = 0; k < nz; k++) {
+        const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+        const double u_new = p.u[f3_0 + k * fpl] + du * vr;
+        double dd;
+        const double uhk = flux_layer<DIR>(p, D, u_new, o3_0 + k * hpl, o2, f2, vr, dd);
+        if (write_uh) p.uh[f3_0 + k * fpl] = uhk;
+        usum = usum + uhk; dsum = dsum + dd;
+      }
+      if (itt < max_itts) {
+        uh_err = usum; duhdu_tot = dsum;
+        uh_err_best = min2(uh_err_best, fabs(uh_err));
+      }
+    }
+  }
+  return du;
+}
+
+template <int DIR>
+__global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
+  const m6::GridDev &g = p.g;
+  const Dir<DIR> D(g);
+  const int fi = p.fi0 + blockIdx.x * 64 + threadIdx.x;     // I (zonal) or i (meridional)
+  const int fj = p.fj0 + blockIdx.y;                        // j (zonal) or J (meridional)
+  if (fi > p.fi1) return;
+  const int nz = g.nk;
+  const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
+  const long s = D.sa(), fs = D.fsa();
+  // minus-side cell of the face is (fi, fj) in both directions
+  const long o2 = g.h2(fi, fj), o3_0 = o2;
+  const long f2 = D.f2(fi, fj), f3_0 = f2;
+
+  // layer transports and marginal areas, :622-635
+  double uh_tot_0 = 0.0, duhdu_tot_0 = 0.0, visc_rem_max = 0.0;
+  for (int k = 0; k < nz; k++) {
+    const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+    double dd;
+    const double uhk = flux_layer<DIR>(p, D, p.u[f3_0 + k * fpl], o3_0 + k * hpl, o2, f2, vr, dd);
+    p.uh[f3_0 + k * fpl] = uhk;
+    duhdu_tot_0 = duhdu_tot_0 + dd;
+    uh_tot_0 = uh_tot_0 + uhk;
+    visc_rem_max = max2(visc_rem_max, vr);
+  }
+  if (p.du_cor) p.du_cor[f2] = 0.0;
+  if (!(p.uhbt || p.set_BT_cont)) return;
+
+  if (!(p.visc_rem && p.o.use_visc_rem_max)) visc_rem_max = 1.0;
+  double CFL_dt = p.o.CFL_limit_adjust / p.dt;
+  const double I_dt = 1.0 / p.dt;
+  if (p.o.aggress_adjust) CFL_dt = I_dt;
+  double I_vrm = 0.0;
+  if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+  double dx_W, dx_E;
+  if (p.o.vol_CFL) {
+    dx_W = ratio_max(g.areaT[o2], D.dL_face()[f2], 1000.0 * D.dL_T()[o2]);
+    dx_E = ratio_max(g.areaT[o2 + s], D.dL_face()[f2], 1000.0 * D.dL_T()[o2 + s]);
+  } else { dx_W = D.dL_T()[o2]; dx_E = D.dL_T()[o2 + s]; }
+  double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
+  double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
+  const double mface = D.mask_face()[f2];
+  for (int k = 0; k < nz; k++) {      // :663-716
+    const double uk = p.u[f3_0 + k * fpl];
+    if (p.visc_rem) {
+      const double vr = p.visc_rem[f3_0 + k * fpl];
+      if (p.o.aggress_adjust) {
+        double du_lim = 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f3_0 + k * fpl - fs]));
+        if (du_max_CFL * vr > du_lim) du_max_CFL = du_lim / vr;
+        du_lim = 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f3_0 + k * fpl + fs]));
+        if (du_min_CFL * vr < du_lim) du_min_CFL = du_lim / vr;
+      } else {
+        if (du_max_CFL * vr > dx_W * CFL_dt - uk * mface) du_max_CFL = (dx_W * CFL_dt - uk) / vr;
+        if (du_min_CFL * vr < -dx_E * CFL_dt - uk * mface) du_min_CFL = -(dx_E * CFL_dt + uk) / vr;
+      }
+    } else {
+      if (p.o.aggress_adjust) {
+        du_max_CFL = min2(du_max_CFL, 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f3_0 + k * fpl - fs])));
+        du_min_CFL = max2(du_min_CFL, 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f3_0 + k * fpl + fs])));
+      } else {
+        du_max_CFL = min2(du_max_CFL, dx_W * CFL_dt - uk);
+        du_min_CFL = max2(du_min_CFL, -(dx_E * CFL_dt + uk));
+      }
+    }
+  }
+  du_max_CFL = max2(du_max_CFL, 0.0);
+  du_min_CFL = min2(du_min_CFL, 0.0);
+
+  double du = 0.0;
+  if (p.uhbt) {      // :737-754
+    du = flux_adjust<DIR>(p, D, o3_0, o2, f3_0, f2, p.uhbt[f2], uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL, true);
+    if (p.u_cor)
+      for (int k = 0; k < nz; k++) {
+        const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+        p.u_cor[f3_0 + k * fpl] = p.u[f3_0 + k * fpl] + du * vr;
+      }
+    if (p.du_cor) p.du_cor[f2] = du;
+  }
+
+  if (p.set_BT_cont) {      // set_zonal_BT_cont :1247-1410
+    const double min_visc_rem = 0.1, CFL_min = 1e-6;
+    const double du0 = flux_adjust<DIR>(p, D, o3_0, o2, f3_0, f2, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL, false);
+    const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
+    double duR = min2(0.0, du0 - du_CFL);
+    double duL = max2(0.0, du0 + du_CFL);
+    for (int k = 0; k < nz; k++) {
+      const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+      const double visc_rem_lim = max2(vr, min_visc_rem * visc_rem_max);
+      const double uk = p.u[f3_0 + k * fpl];
+      if (visc_rem_lim > 0.0) {
+        if (uk + duR * visc_rem_lim > -du_CFL * vr) duR = -(uk + du_CFL * vr) / visc_rem_lim;
+        if (uk + duL * visc_rem_lim < du_CFL * vr) duL = -(uk - du_CFL * vr) / visc_rem_lim;
+      }
+    }
+    double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
+    for (int k = 0; k < nz; k++) {
+      const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+      const double uk = p.u[f3_0 + k * fpl];
+      const double u_L = uk + duL * vr, u_R = uk + duR * vr, u_0 = uk + du0 * vr;
+      double d0, dL, dR;
+      (void)flux_layer<DIR>(p, D, u_0, o3_0 + k * hpl, o2, f2, vr, d0);
+      const double uh_L = flux_layer<DIR>(p, D, u_L, o3_0 + k * hpl, o2, f2, vr, dL);
+      const double uh_R = flux_layer<DIR>(p, D, u_R, o3_0 + k * hpl, o2, f2, vr, dR);
+      FAmt_0 = FAmt_0 + d0; FAmt_L = FAmt_L + dL; FAmt_R = FAmt_R + dR;
+      uhtot_L = uhtot_L + uh_L; uhtot_R = uhtot_R + uh_R;
+    }
+    double FA_0 = FAmt_0, FA_avg = FAmt_0;
+    if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
+    if (FA_avg > max2(FA_0, FAmt_L)) FA_avg = max2(FA_0, FAmt_L);
+    else if (FA_avg < min2(FA_0, FAmt_L)) FA_0 = FA_avg;
+    p.FA_0m[f2] = FA_0; p.FA_mm[f2] = FAmt_L;
+    if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) p.uBT_mm[f2] = 0.0;
+    else p.uBT_mm[f2] = (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0));
+
+    FA_0 = FAmt_0; FA_avg = FAmt_0;
+    if ((duR - du0) != 0.0) FA_avg = uhtot_R / (duR - du0);
+    if (FA_avg > max2(FA_0, FAmt_R)) FA_avg = max2(FA_0, FAmt_R);
+    else if (FA_avg < min2(FA_0, FAmt_R)) FA_0 = FA_avg;
+    p.FA_0p[f2] = FA_0; p.FA_pp[f2] = FAmt_R;
+    if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) p.uBT_pp[f2] = 0.0;
+    else p.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+
+    if (p.h_face) {      // flux_thickness :976-1057 with u_cor if present (:809-815)
+      for (int k = 0; k < nz; k++) {
+        const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+        double uk = p.u[f3_0 + k * fpl];
+        if (p.uhbt && p.u_cor) uk = uk + du * vr;      // the value just stored in u_cor
+        const long o3 = o3_0 + k * hpl;
+        double CFL, curv_3, h_avg, h_marg;
+        if (uk > 0.0) {
+          if (p.o.vol_CFL) CFL = (uk * p.dt) * (D.dL_face()[f2] * g.IareaT[o2]);
+          else CFL = uk * p.dt * D.IdL_T()[o2];
+          const double hW = p.h_L[o3], hE = p.h_R[o3];
+          curv_3 = hW + hE - 2.0 * p.h_in[o3];
+          h_avg = hE + CFL * (0.5 * (hW - hE) + curv_3 * (CFL - 1.5));
+          h_marg = hE + CFL * ((hW - hE) + 3.0 * curv_3 * (CFL - 1.0));
+        } else if (uk < 0.0) {
+          if (p.o.vol_CFL) CFL = (-uk * p.dt) * (D.dL_face()[f2] * g.IareaT[o2 + s]);
+          else CFL = -uk * p.dt * D.IdL_T()[o2 + s];
+          const double hW = p.h_L[o3 + s], hE = p.h_R[o3 + s];
+          curv_3 = hW + hE - 2.0 * p.h_in[o3 + s];
+          h_avg = hW + CFL * (0.5 * (hE - hW) + curv_3 * (CFL - 1.5));
+          h_marg = hW + CFL * ((hE - hW) + 3.0 * curv_3 * (CFL - 1.0));
+        } else {
+          h_avg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+          h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+        }
+        double hu = p.o.marginal_faces ? h_marg : h_avg;
+        if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
+        p.h_face[f3_0 + k * fpl] = hu;
+      }
+    }
+  }
+}
+
+// ---- convergence ---------------------------------------------------------------------------------
+struct ConvArgs {
+  m6::GridDev g;
+  const double *hin, *uh;
+  double *h;
+  double dt, h_min;
+  int i0, i1, j0, j1;
+};
+
+template <int DIR>
+__global__ __launch_bounds__(256) void cont_conv_kernel(ConvArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = p.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = p.j0 + blockIdx.y;
+  const int k = blockIdx.z;
+  if (i > p.i1) return;
+  const long o2 = g.h2(i, j), o3 = o2 + (long)g.nih * g.njh * k;
+  double uhp, uhm;
+  if (DIR) {
+    const long f = g.v2(i, j) + (long)g.nih * (g.njh + 1) * k;
+    uhp = p.uh[f]; uhm = p.uh[f - g.nih];
+  } else {
+    const long f = g.u2(i, j) + (long)(g.nih + 1) * g.njh * k;
+    uhp = p.uh[f]; uhm = p.uh[f - 1];
+  }
+  p.h[o3] = max2(p.hin[o3] - p.dt * g.IareaT[o2] * (uhp - uhm), p.h_min);
+}
+
+}  // namespace
+
+extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, const double *u,
+                                  const double *v, const double *hin, double *h, double *uh, double *vh, double dt,
+                                  const double *uhbt, const double *vhbt, const double *visc_rem_u,
+                                  const double *visc_rem_v, double *u_cor, double *v_cor,
+                                  const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "MOM_continuity_PPM: Module must be initialized before it is used.");
+  M6_REQUIRE(cs && u && v && hin && h && uh && vh, "continuity_PPM: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "continuity_PPM: bad memspace");
+  M6_REQUIRE((visc_rem_u != nullptr) == (visc_rem_v != nullptr),
+             "MOM_continuity_PPM: Either both visc_rem_u and visc_rem_v or neither one must be present in call to "
+             "continuity_PPM.");
+  M6_REQUIRE(dt > 0.0, "continuity_PPM: dt must be positive");
+  m6::GridDev &g = ctx->g;
+  M6_REQUIRE(g.mask2dT && g.areaT && g.IareaT && g.dxT && g.dyT && g.IdxT && g.IdyT && g.dy_Cu && g.dx_Cv && g.dxCu &&
+             g.dyCv && g.mask2dCu && g.mask2dCv, "continuity_PPM: a required grid metric is missing");
+  int stencil = 3; if (cs->simple_2nd) stencil = 2; if (cs->upwind_1st) stencil = 1;
+  const int rstencil = (cs->simple_2nd || cs->upwind_1st) ? 1 : 2;
+  {
+    const int need = stencil + 1 + rstencil;     // first pass: stencil rows + 1 cell + reconstruction stencil
+    (void)need;
+    const int halo = g.isc - g.isd;
+    // PPM_reconstruction_x :2350-2361: "called with a x-halo that needs to be increased by ..."
+    M6_REQUIRE(halo >= stencil && g.ied - g.iec >= stencil && g.jsc - g.jsd >= stencil && g.jed - g.jec >= stencil &&
+               halo >= 1 + rstencil, "In MOM_continuity_PPM, PPM_reconstruction called with a halo that needs to be increased");
+  }
+  hipStream_t s = ctx->stream;
+  const size_t bH = (size_t)g.nh3() * 8, bU = (size_t)g.nu3() * 8, bV = (size_t)g.nv3() * 8;
+  const size_t bU2 = (size_t)(g.nih + 1) * g.njh * 8, bV2 = (size_t)g.nih * (g.njh + 1) * 8;
+
+  m6::Stager st(ctx, memspace);
+  const double *d_u = st.in(u, bU), *d_v = st.in(v, bV), *d_hin = st.in(hin, bH);
+  // arrays that are only partly written keep the caller's other values: stage them in/out
+  double *d_h = st.inout(h, bH);
+  if (h == hin) d_hin = d_h;
+  double *d_uh = st.inout(uh, bU), *d_vh = st.inout(vh, bV);
+  const double *d_uhbt = st.in(uhbt, bU2), *d_vhbt = st.in(vhbt, bV2);
+  const double *d_vru = st.in(visc_rem_u, bU), *d_vrv = st.in(visc_rem_v, bV);
+  double *d_ucor = st.inout(u_cor, bU), *d_vcor = st.inout(v_cor, bV);
+  double *d_ducor = st.out(du_cor, bU2), *d_dvcor = st.out(dv_cor, bV2);
+  mom6hip_bt_cont_t bt = {};
+  if (BT_cont) {
+    double *const *src = &BT_cont->FA_u_W0;
+    double **dst = &bt.FA_u_W0;
+    for (int n = 0; n < 6; n++) { M6_REQUIRE(src[n], "continuity_PPM: BT_cont member %d is null", n); dst[n] = st.inout(src[n], bU2); }
+    for (int n = 6; n < 12; n++) { M6_REQUIRE(src[n], "continuity_PPM: BT_cont member %d is null", n); dst[n] = st.inout(src[n], bV2); }
+    bt.h_u = st.inout(BT_cont->h_u, bU); bt.h_v = st.inout(BT_cont->h_v, bV);
+  }
+  double *h_L = (double *)st.scratch(bH), *h_R = (double *)st.scratch(bH);
+  if (st.failed()) return 1;
+  // du_cor(:,:) = 0.0 over the whole array, :601
+  if (d_ducor) M6_HIP(hipMemsetAsync(d_ducor, 0, bU2, s));
+  if (d_dvcor) M6_HIP(hipMemsetAsync(d_dvcor, 0, bV2, s));
+
+  ContOpts o;
+  o.upwind_1st = cs->upwind_1st; o.monotonic = cs->monotonic; o.simple_2nd = cs->simple_2nd;
+  o.aggress_adjust = cs->aggress_adjust; o.vol_CFL = cs->vol_CFL; o.better_iter = cs->better_iter;
+  o.use_visc_rem_max = cs->use_visc_rem_max; o.marginal_faces = cs->marginal_faces;
+  o.tol_eta = cs->tol_eta; o.tol_vel = cs->tol_vel; o.CFL_limit_adjust = cs->CFL_limit_adjust;
+
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec;
+  const bool x_first = (ctx->host.first_direction % 2) == 0;
+  const double h_min = g.Angstrom_H;
+
+  auto zonal = [&](const double *hsrc, int jsh, int jeh, double hmin) -> int {
+    EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+    e.i0 = is - 1; e.i1 = ie + 1; e.j0 = jsh; e.j1 = jeh;
+    hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, e);
+    FluxArgs f; f.g = g; f.o = o; f.u = d_u; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_uhbt; f.visc_rem = d_vru;
+    f.uh = d_uh; f.u_cor = d_ucor; f.du_cor = d_ducor;
+    f.FA_0m = bt.FA_u_W0; f.FA_mm = bt.FA_u_WW; f.FA_0p = bt.FA_u_E0; f.FA_pp = bt.FA_u_EE; f.uBT_mm = bt.uBT_WW;
+    f.uBT_pp = bt.uBT_EE; f.h_face = bt.h_u; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
+    f.fi0 = is - 1; f.fi1 = ie; f.fj0 = jsh; f.fj1 = jeh;
+    hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((f.fi1 - f.fi0 + 64) / 64, jeh - jsh + 1), dim3(64), 0, s, f);
+    ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = d_h; c.dt = dt; c.h_min = hmin;
+    c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh;
+    hipLaunchKernelGGL(cont_conv_kernel<0>, dim3((ie - is + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, c);
+    M6_HIP(hipGetLastError());
+    return 0;
+  };
+  auto merid = [&](const double *hsrc, int ish, int ieh, double hmin) -> int {
+    EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+    e.i0 = ish; e.i1 = ieh; e.j0 = js - 1; e.j1 = je + 1;
+    hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, e.j1 - e.j0 + 1, g.nk), dim3(256), 0, s, e);
+    FluxArgs f; f.g = g; f.o = o; f.u = d_v; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_vhbt; f.visc_rem = d_vrv;
+    f.uh = d_vh; f.u_cor = d_vcor; f.du_cor = d_dvcor;
+    f.FA_0m = bt.FA_v_S0; f.FA_mm = bt.FA_v_SS; f.FA_0p = bt.FA_v_N0; f.FA_pp = bt.FA_v_NN; f.uBT_mm = bt.vBT_SS;
+    f.uBT_pp = bt.vBT_NN; f.h_face = bt.h_v; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
+    f.fi0 = ish; f.fi1 = ieh; f.fj0 = js - 1; f.fj1 = je;
+    hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((ieh - ish + 64) / 64, f.fj1 - f.fj0 + 1), dim3(64), 0, s, f);
+    ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
+    c.i0 = ish; c.i1 = ieh; c.j0 = js; c.j1 = je;
+    hipLaunchKernelGGL(cont_conv_kernel<1>, dim3((ieh - ish + 256) / 256, je - js + 1, g.nk), dim3(256), 0, s, c);
+    M6_HIP(hipGetLastError());
+    return 0;
+  };
+
+  if (x_first) {
+    if (zonal(d_hin, js - stencil, je + stencil, 0.0)) return 1;
+    if (merid(d_h, is, ie, h_min)) return 1;
+  } else {
+    if (merid(d_hin, is - stencil, ie + stencil, 0.0)) return 1;
+    if (zonal(d_h, js, je, h_min)) return 1;
+  }
+  return st.finish();
+}

@@ -95,6 +95,12 @@ int orc_ale_remap_tracers(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t 
 int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const double *u, const double *v,
                   const double *h, const double *uh, const double *vh, double *CAu, double *CAv);
 
+/* ---- MOM_continuity_PPM (oracle/continuity.c) ---------------------------------------------- */
+int orc_continuity(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, const double *u, const double *v,
+                   const double *hin, double *h, double *uh, double *vh, double dt, const double *uhbt,
+                   const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor,
+                   double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,3 +205,40 @@ def coradcalc(grid, u, v, h, uh, vh, coriolis_scheme="SADOURNY75_ENERGY", ke_sch
     if rc:
         raise RuntimeError("orc_coradcalc failed")
     return CAu, CAv
+
+
+def continuity_cs(nk, Angstrom=1e-10, **kw):
+    """continuity_PPM_CS with the defaults of continuity_PPM_init (MOM_continuity_PPM.F90:2679-2757)."""
+    d = dict(upwind_1st=0, monotonic=0, simple_2nd=0, aggress_adjust=0, vol_CFL=None, better_iter=1,
+             use_visc_rem_max=1, marginal_faces=1, tol_eta=0.5 * nk * Angstrom, tol_vel=3.0e8, CFL_limit_adjust=0.5)
+    d.update(kw)
+    if d["vol_CFL"] is None:
+        d["vol_CFL"] = d["aggress_adjust"]
+    return _abi.ContinuityCS(*[int(d[n]) for n in ("upwind_1st", "monotonic", "simple_2nd", "aggress_adjust", "vol_CFL",
+                                                   "better_iter", "use_visc_rem_max", "marginal_faces")],
+                             float(d["tol_eta"]), float(d["tol_vel"]), float(d["CFL_limit_adjust"]))
+
+
+def make_bt_cont(grid, with_h=False):
+    """Zeroed BT_cont arrays (numpy) and the struct pointing at them."""
+    arrs = {n: grid.zeros2(_abi.POS_U) for n in _abi.BT_CONT_U}
+    arrs.update({n: grid.zeros2(_abi.POS_V) for n in _abi.BT_CONT_V})
+    if with_h:
+        arrs["h_u"] = grid.zeros3(_abi.POS_U); arrs["h_v"] = grid.zeros3(_abi.POS_V)
+    st = _abi.BTCont()
+    for n, a in arrs.items():
+        setattr(st, n, a.ctypes.data)
+    return arrs, st
+
+
+def continuity(grid, cs, u, v, hin, h, uh, vh, dt, uhbt=None, vhbt=None, visc_rem_u=None, visc_rem_v=None,
+               u_cor=None, v_cor=None, bt_cont=None, du_cor=None, dv_cor=None):
+    L = lib()
+    L.orc_continuity.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.ContinuityCS)] + [_dp] * 6 + [C.c_double]
+                                 + [_dp] * 6 + [C.POINTER(_abi.BTCont)] + [_dp] * 2)
+    rc = L.orc_continuity(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(hin), _p(h), _p(uh), _p(vh), float(dt),
+                          _p(uhbt), _p(vhbt), _p(visc_rem_u), _p(visc_rem_v), _p(u_cor), _p(v_cor),
+                          None if bt_cont is None else C.byref(bt_cont), _p(du_cor), _p(dv_cor))
+    if rc:
+        raise RuntimeError("MOM_continuity_PPM: Either both visc_rem_u and visc_rem_v or neither one must be present "
+                           "in call to continuity_PPM.")
