@@ -252,6 +252,46 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
                        double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor,
                        int32_t memspace);
 
+/* ---- MOM_EOS / MOM_PressureForce_FV --------------------------------------------------------- */
+
+/* EQN_OF_STATE forms provided (src/equation_of_state/MOM_EOS.F90:145-173; default "WRIGHT") */
+#define MOM6HIP_EOS_LINEAR 1   /* MOM_EOS_linear.F90 */
+#define MOM6HIP_EOS_WRIGHT 3   /* MOM_EOS_Wright.F90 (the "WRIGHT" form; density is identical to WRIGHT_REDUCED) */
+
+typedef struct mom6hip_eos {
+  int32_t form;                /* MOM6HIP_EOS_* */
+  int32_t reserved;
+  double Rho_T0_S0, dRho_dT, dRho_dS;   /* linear EOS: RHO_T0_S0, DRHO_DT, DRHO_DS */
+} mom6hip_eos_t;
+
+/* PressureForce_FV_CS, src/core/MOM_PressureForce_FV.F90 (the members the provided branch reads) */
+typedef struct mom6hip_pressureforce_cs {
+  double Rho0;                 /* RHO_PGF_REF (default GV%Rho0) */
+  double GFS_scale;            /* must be 1.0 */
+  double Z_ref;                /* G%Z_ref */
+  int32_t reconstruct;         /* RECONSTRUCT_FOR_PRESSURE (must be 1) */
+  int32_t Recon_Scheme;        /* PRESSURE_RECONSTRUCTION_SCHEME (must be 1 = PLM) */
+  int32_t boundary_extrap;     /* BOUNDARY_EXTRAPOLATION_PRESSURE (default True) */
+  int32_t useMassWghtInterp;   /* MASS_WEIGHT_IN_PRESSURE_GRADIENT (default False) */
+} mom6hip_pressureforce_cs_t;
+
+/*
+ * PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)
+ *                                                            src/core/MOM_PressureForce_FV.F90:462
+ * tv%T, tv%S are passed as T, S; p_atm (2-D), pbce (3-D), eta (2-D) may be NULL.  Tides, SAL, the Stanley
+ * SGS terms, GFS_scale < 1 and the non-ALE / PPM reconstructions are not provided.
+ * Metrics needed: bathyT, IdxCu, IdyCv.
+ */
+int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs, const mom6hip_eos_t *eos,
+                                   const double *h, const double *T, const double *S, const double *p_atm,
+                                   double *PFu, double *PFv, double *pbce, double *eta, int32_t memspace);
+
+/* calculate_density(T, S, pressure, rho, EOS, dom, rho_ref) on n points (src/equation_of_state/MOM_EOS.F90:299);
+ * use_rho_ref = 0: in-situ density. */
+int mom6hip_calculate_density(mom6hip_ctx_t *ctx, const mom6hip_eos_t *eos, const double *T, const double *S,
+                              const double *pressure, double *rho, int64_t n, int32_t use_rho_ref, double rho_ref,
+                              int32_t memspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,16 @@ BT_CONT_V = ("FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN")
 
 class BTCont(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BT_CONT_U + BT_CONT_V + ("h_u", "h_v")]
+
+
+EOS_FORMS = {"LINEAR": 1, "WRIGHT": 3}
+
+
+class EOS(C.Structure):
+    _fields_ = [("form", C.c_int32), ("reserved", C.c_int32), ("Rho_T0_S0", C.c_double), ("dRho_dT", C.c_double),
+                ("dRho_dS", C.c_double)]
+
+
+class PressureForceCS(C.Structure):
+    _fields_ = [("Rho0", C.c_double), ("GFS_scale", C.c_double), ("Z_ref", C.c_double), ("reconstruct", C.c_int32),
+                ("Recon_Scheme", C.c_int32), ("boundary_extrap", C.c_int32), ("useMassWghtInterp", C.c_int32)]

@@ -41,7 +41,7 @@ void set_error(const char *fmt, ...);
 struct GridDev {
   int isc, iec, jsc, jec, isd, ied, jsd, jed, nk;
   int nih, njh;             // data-domain extents of h-point arrays
-  double Angstrom_H, H_subroundoff;
+  double Angstrom_H, H_subroundoff, dZ_subroundoff, H_to_Z, Z_to_H, g_Earth, Rho0;
   // device copies of the metric arrays of mom6hip_grid_t (null if the caller did not provide them)
   const double *mask2dT, *areaT, *IareaT, *dxT, *dyT, *IdxT, *IdyT, *bathyT;
   const double *mask2dCu, *dxCu, *dyCu, *dy_Cu, *IdxCu, *IdyCu, *areaCu, *IareaCu;

@@ -179,6 +179,8 @@ int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t 
   g.isd = grid->isd; g.ied = grid->ied; g.jsd = grid->jsd; g.jed = grid->jed; g.nk = grid->nk;
   g.nih = nih; g.njh = njh;
   g.Angstrom_H = grid->Angstrom_H; g.H_subroundoff = grid->H_subroundoff;
+  g.dZ_subroundoff = grid->dZ_subroundoff; g.H_to_Z = grid->H_to_Z; g.Z_to_H = grid->Z_to_H;
+  g.g_Earth = grid->g_Earth; g.Rho0 = grid->Rho0;
   {
     // same declaration order in mom6hip_grid_t and GridDev
     const double **dst = &g.mask2dT;

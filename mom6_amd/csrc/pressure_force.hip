@@ -1,0 +1,407 @@
+// pressure_force.hip -- PressureForce_FV_Bouss (src/core/MOM_PressureForce_FV.F90:462-919) with the analytic
+// finite-volume pressure-gradient integrals of int_density_dz_generic_plm
+// (src/core/MOM_density_integrals.F90:369-769), PLM edge values of T and S (ALE_PLM_edge_values,
+// src/ALE/MOM_ALE.F90:1520-1579), Set_pbce_Bouss (src/core/MOM_PressureForce_Montgomery.F90:649-748) and the
+// Wright / linear equations of state (src/equation_of_state/MOM_EOS_Wright.F90:80-206, MOM_EOS_linear.F90).
+//
+// This operator is fp64-VALU bound, not HBM bound: 35 equation-of-state evaluations per cell-layer (5 for
+// the vertical Boole quadrature, 3x5 on each of the two faces), each ~45 flops and one IEEE division,
+// against ~64 B of algorithmic traffic.  Two kernels, both one lane per column with the k loop inside the
+// lane (the pressure anomaly pa and the interface heights e are running sums in k) and lanes along i:
+//   pgf_column_kernel  per h-point column: e (bottom-up), then top-down the PLM edge values of T and S with
+//                      a rolling k window, the vertical integrals dpa / intz_dpa (5 EOS evaluations), pbce
+//                      and eta.  Writes e, T_t, T_b, S_t, S_b, dpa, intz_dpa.
+//   pgf_face_kernel    per (I,j)/(i,J) face pair: the 15+15 EOS evaluations of intx_dpa / inty_dpa and the
+//                      PFu / PFv formulas (:794-811), carrying pa, intx_pa, inty_pa down the column.
+// Splitting at the column kernel keeps the EOS count at the reference's 35 per cell (a single fused
+// kernel would have to recompute the neighbours' vertical integrals: 45).
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+using m6::max2;
+using m6::min2;
+__device__ __forceinline__ double max3(double a, double b, double c) { return max2(max2(a, b), c); }
+__device__ __forceinline__ double min3(double a, double b, double c) { return min2(min2(a, b), c); }
+__device__ __forceinline__ double fsign(double a, double b) { return copysign(fabs(a), b); }
+
+// ---- equations of state ------------------------------------------------------------------------
+struct EosDev { int form; double Rho_T0_S0, dRho_dT, dRho_dS; };
+
+// Wright 1997 coefficients, MOM_EOS_Wright.F90:23-38
+constexpr double a0 = 7.057924e-4, a1 = 3.480336e-7, a2 = -1.112733e-7;
+constexpr double b0 = 5.790749e8, b1 = 3.516535e6, b2 = -4.002714e4, b3 = 2.084372e2, b4 = 5.944068e5, b5 = -9.643486e3;
+constexpr double c0 = 1.704853e5, c1 = 7.904722e2, c2 = -7.984422, c3 = 5.140652e-2, c4 = -2.302158e2, c5 = -3.079464;
+
+// density_elem :80-95
+__device__ __forceinline__ double eos_density(const EosDev &E, double T, double S, double pressure) {
+  if (E.form == MOM6HIP_EOS_LINEAR) return E.Rho_T0_S0 + E.dRho_dT * T + E.dRho_dS * S;
+  const double al0 = (a0 + a1 * T) + a2 * S;
+  const double p0 = (b0 + b4 * S) + T * (b1 + T * (b2 + b3 * T) + b5 * S);
+  const double lambda = (c0 + c4 * S) + T * (c1 + T * (c2 + c3 * T) + c5 * S);
+  return (pressure + p0) / (lambda + al0 * (pressure + p0));
+}
+
+// density_anomaly_elem :98-129
+__device__ __forceinline__ double eos_density_anomaly(const EosDev &E, double T, double S, double pressure, double rho_ref) {
+  if (E.form == MOM6HIP_EOS_LINEAR) return (E.Rho_T0_S0 - rho_ref) + (E.dRho_dT * T + E.dRho_dS * S);
+  const double pa_000 = (b0 * (1.0 - a0 * rho_ref) - rho_ref * c0);
+  const double al_TS = a1 * T + a2 * S;
+  const double al0 = a0 + al_TS;
+  const double p_TSp = pressure + (b4 * S + T * (b1 + (T * (b2 + b3 * T) + b5 * S)));
+  const double lam_TS = c4 * S + T * (c1 + (T * (c2 + c3 * T) + c5 * S));
+  return (pa_000 + (p_TSp - rho_ref * (p_TSp * al0 + (b0 * al_TS + lam_TS)))) / ((c0 + lam_TS) + al0 * (b0 + p_TSp));
+}
+
+// calculate_density_derivs_elem :178-206
+__device__ __forceinline__ void eos_density_derivs(const EosDev &E, double T, double S, double pressure, double &drho_dT,
+                                                   double &drho_dS) {
+  if (E.form == MOM6HIP_EOS_LINEAR) { drho_dT = E.dRho_dT; drho_dS = E.dRho_dS; return; }
+  const double al0 = (a0 + a1 * T) + a2 * S;
+  const double p0 = (b0 + b4 * S) + T * (b1 + T * ((b2 + b3 * T)) + b5 * S);
+  const double lambda = (c0 + c4 * S) + T * (c1 + T * ((c2 + c3 * T)) + c5 * S);
+  double I_denom2 = 1.0 / (lambda + al0 * (pressure + p0));
+  I_denom2 = I_denom2 * I_denom2;
+  drho_dT = I_denom2 * (lambda * (b1 + T * (2.0 * b2 + 3.0 * b3 * T) + b5 * S) -
+                        (pressure + p0) * ((pressure + p0) * a1 + (c1 + T * (c2 * 2.0 + c3 * 3.0 * T) + c5 * S)));
+  drho_dS = I_denom2 * (lambda * (b4 + b5 * T) - (pressure + p0) * ((pressure + p0) * a2 + (c4 + c5 * T)));
+}
+
+// ---- PLM_functions.F90 ---------------------------------------------------------------------------
+__device__ double plm_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r) {
+  const double sigma_r = u_r - u_c;
+  const double sigma_l = u_c - u_l;
+  const double sigma_c = 2.0 * (u_r - u_l) * (h_c / (h_l + 2.0 * h_c + h_r + h_neglect));
+  const double u_min = min3(u_l, u_c, u_r);
+  const double u_max = max3(u_l, u_c, u_r);
+  double slope = 0.0;
+  if ((sigma_l * sigma_r) > 0.0) slope = fsign(min2(fabs(sigma_c), 2. * min2(u_c - u_min, u_max - u_c)), sigma_c);
+  if (u_c - 0.5 * fabs(slope) < u_min || u_c + 0.5 * fabs(slope) > u_max) slope = slope * (1. - 2.220446049250313e-16);
+  if (fabs(slope) < 1.E-140) slope = 0.;
+  return slope;
+}
+__device__ double plm_monotonized_slope(double u_l, double u_c, double u_r, double s_l, double s_c, double s_r) {
+  const double almost_two = 2. * (1. - 2.220446049250313e-16);
+  const double e_r = u_l + 0.5 * s_l;
+  const double e_l = u_r - 0.5 * s_r;
+  double slp = fabs(s_c);
+  double edge = u_c - 0.5 * s_c;
+  if ((edge - e_r) * (u_c - edge) < 0.) { edge = 0.5 * (edge + e_r); slp = min2(slp, fabs(edge - u_c) * almost_two); }
+  edge = u_c + 0.5 * s_c;
+  if ((edge - u_c) * (e_l - edge) < 0.) { edge = 0.5 * (edge + e_l); slp = min2(slp, fabs(edge - u_c) * almost_two); }
+  return fsign(slp, s_c);
+}
+__device__ double plm_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c) {
+  const double hl = h_l + h_neglect, hc = h_c + h_neglect;
+  const double left_edge = (u_l * hc + u_c * hl) / (hl + hc);
+  return 2.0 * (u_c - left_edge);
+}
+
+struct PgfArgs {
+  m6::GridDev g;
+  EosDev eos;
+  const double *h, *T, *S, *p_atm;
+  double *e, *T_t, *T_b, *S_t, *S_b, *dpa, *intz_dpa;     // scratch (e has nk+1 planes)
+  double *PFu, *PFv, *pbce, *eta;
+  double rho_ref, Z_ref, GFS_scale;
+  int boundary_extrap, massw;
+};
+
+// ---- column kernel -------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pgf_column_kernel(PgfArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.jsc - 1 + blockIdx.y;
+  if (i > g.iec + 1) return;
+  const int nz = g.nk;
+  const long o2 = g.h2(i, j), pl = (long)g.nih * g.njh;
+  const double h_neglect = g.H_subroundoff;
+  // :572 / :646-648, bottom-up
+  double ek = -g.bathyT[o2];
+  p.e[o2 + pl * nz] = ek;
+  for (int k = nz - 1; k >= 0; k--) {
+    ek = ek + p.h[o2 + pl * k] * g.H_to_Z;
+    p.e[o2 + pl * k] = ek;
+  }
+  const double e_top = ek, e_bot = -g.bathyT[o2];
+  if (p.eta) p.eta[o2] = e_top * g.Z_to_H;      // :842
+
+  const double G_e = g.g_Earth, rho_0 = p.rho_ref, rho_ref = p.rho_ref;
+  const double GxRho = G_e * rho_0;
+  const double C1_90 = 1.0 / 90.0;
+  const double Rho0xG = p.rho_ref * g.g_Earth, G_Rho0 = g.g_Earth / g.Rho0;
+  const double Ihtot = g.H_to_Z / ((e_top - e_bot) + g.dZ_subroundoff);
+
+  // rolling window over k (0-based level kk): values at kk-1 (m), kk (c), kk+1 (p), kk+2 (q)
+  auto ld = [&](const double *a, int kk) -> double { return (kk >= 0 && kk < nz) ? a[o2 + pl * kk] : 0.0; };
+  double h_m = 0., h_c = ld(p.h, 0), h_p = ld(p.h, 1), h_q = ld(p.h, 2);
+  double T_m = 0., T_c = ld(p.T, 0), T_p = ld(p.T, 1), T_q = ld(p.T, 2);
+  double S_m = 0., S_c = ld(p.S, 0), S_p = ld(p.S, 1), S_q = ld(p.S, 2);
+  // slp at kk-1, kk, kk+1 (Fortran slp(1) = slp(nz) = 0)
+  double sT_m = 0., sT_c = 0., sT_p = 0., sS_m = 0., sS_c = 0., sS_p = 0.;
+  if (nz >= 3) {   // slp of level 1 (Fortran k=2)
+    sT_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, T_c, T_p, T_q);
+    sS_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, S_c, S_p, S_q);
+  }
+  double e_K = e_top, pbce_prev = 0.0;
+  for (int kk = 0; kk < nz; kk++) {
+    const long o3 = o2 + pl * kk;
+    // ---- ALE_PLM_edge_values :1549-1576 ----
+    double Tt, Tb, St, Sb;
+    if (kk >= 1 && kk <= nz - 2) {
+      const double mT = plm_monotonized_slope(T_m, T_c, T_p, sT_m, sT_c, sT_p);
+      Tt = T_c - 0.5 * mT; Tb = T_c + 0.5 * mT;
+      const double mS = plm_monotonized_slope(S_m, S_c, S_p, sS_m, sS_c, sS_p);
+      St = S_c - 0.5 * mS; Sb = S_c + 0.5 * mS;
+    } else if (p.boundary_extrap) {
+      if (kk == 0) {
+        const double mT = -plm_extrapolate_slope(h_p, h_c, h_neglect, T_p, T_c);
+        Tt = T_c - 0.5 * mT; Tb = T_c + 0.5 * mT;
+        const double mS = -plm_extrapolate_slope(h_p, h_c, h_neglect, S_p, S_c);
+        St = S_c - 0.5 * mS; Sb = S_c + 0.5 * mS;
+      } else {
+        const double mT = plm_extrapolate_slope(h_m, h_c, h_neglect, T_m, T_c);
+        Tt = T_c - 0.5 * mT; Tb = T_c + 0.5 * mT;
+        const double mS = plm_extrapolate_slope(h_m, h_c, h_neglect, S_m, S_c);
+        St = S_c - 0.5 * mS; Sb = S_c + 0.5 * mS;
+      }
+    } else {
+      Tt = T_c; Tb = T_c; St = S_c; Sb = S_c;
+    }
+    p.T_t[o3] = Tt; p.T_b[o3] = Tb; p.S_t[o3] = St; p.S_b[o3] = Sb;
+
+    // ---- vertical integrals, MOM_density_integrals.F90:519-554 ----
+    const double e_Kp1 = p.e[o3 + pl];
+    const double dz = e_K - e_Kp1;
+    double r5[5];
+#pragma unroll
+    for (int n = 1; n <= 5; n++) {
+      const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+      const double p5 = -GxRho * ((e_K - p.Z_ref) - 0.25 * (double)(n - 1) * dz);
+      const double S5 = wt_t * St + wt_b * Sb;
+      const double T5 = wt_t * Tt + wt_b * Tb;
+      r5[n - 1] = eos_density_anomaly(p.eos, T5, S5, p5, rho_ref);
+    }
+    const double rho_anom = C1_90 * (7.0 * (r5[0] + r5[4]) + 32.0 * (r5[1] + r5[3]) + 12.0 * r5[2]);
+    p.dpa[o3] = G_e * dz * rho_anom;
+    const double iz = 0.5 * G_e * (dz * dz) * (rho_anom - C1_90 * (16.0 * (r5[3] - r5[1]) + 7.0 * (r5[4] - r5[0])));
+    p.intz_dpa[o3] = iz * g.Z_to_H;      // MOM_PressureForce_FV.F90:772
+
+    // ---- Set_pbce_Bouss :702-729 ----
+    if (p.pbce) {
+      const double press = -Rho0xG * (e_K - p.Z_ref);
+      double pb;
+      if (kk == 0) {
+        const double rho_in_situ = eos_density(p.eos, T_c, S_c, press);
+        pb = G_Rho0 * (p.GFS_scale * rho_in_situ) * g.H_to_Z;
+      } else {
+        const double T_int = 0.5 * (T_m + T_c), S_int = 0.5 * (S_m + S_c);
+        double dR_dT, dR_dS;
+        eos_density_derivs(p.eos, T_int, S_int, press, dR_dT, dR_dS);
+        pb = pbce_prev + G_Rho0 * ((e_K - e_bot) * Ihtot) * (dR_dT * (T_c - T_m) + dR_dS * (S_c - S_m));
+      }
+      p.pbce[o3] = pb;
+      pbce_prev = pb;
+    }
+
+    // ---- advance the window ----
+    e_K = e_Kp1;
+    h_m = h_c; h_c = h_p; h_p = h_q; h_q = ld(p.h, kk + 3);
+    T_m = T_c; T_c = T_p; T_p = T_q; T_q = ld(p.T, kk + 3);
+    S_m = S_c; S_c = S_p; S_p = S_q; S_q = ld(p.S, kk + 3);
+    sT_m = sT_c; sT_c = sT_p; sS_m = sS_c; sS_c = sS_p;
+    // slope of the new level kk+2 (needs levels kk+1, kk+2, kk+3); zero at the bottom level and beyond
+    if (kk + 2 <= nz - 2) {
+      sT_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, T_c, T_p, T_q);
+      sS_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, S_c, S_p, S_q);
+    } else {
+      sT_p = 0.; sS_p = 0.;
+    }
+  }
+}
+
+// ---- face kernel ---------------------------------------------------------------------------------
+// 15 EOS evaluations across one face between the columns at offsets oL (left/south) and oR (right/north)
+__device__ __forceinline__ double face_integral(const PgfArgs &p, long oL3, long oR3, long oL2, long oR2, double eL_K,
+                                                double eL_Kp1, double eR_K, double eR_Kp1) {
+  const m6::GridDev &g = p.g;
+  const double G_e = g.g_Earth, GxRho = G_e * p.rho_ref, rho_ref = p.rho_ref;
+  const double C1_90 = 1.0 / 90.0;
+  double Ttl, Tbl, Ttr, Tbr, Stl, Sbl, Str, Sbr;
+  const double TtL = p.T_t[oL3], TtR = p.T_t[oR3], TbL = p.T_b[oL3], TbR = p.T_b[oR3];
+  const double StL = p.S_t[oL3], StR = p.S_t[oR3], SbL = p.S_b[oL3], SbR = p.S_b[oR3];
+  double hWght = (p.massw ? 1. : 0.) * max3(0., -g.bathyT[oL2] - eR_K, -g.bathyT[oR2] - eL_K);
+  if (hWght > 0.) {
+    const double hL = (eL_K - eL_Kp1) + g.dZ_subroundoff;
+    const double hR = (eR_K - eR_Kp1) + g.dZ_subroundoff;
+    const double rr = (hL - hR) / (hL + hR);
+    hWght = hWght * (rr * rr);
+    const double iDenom = 1. / (hWght * (hR + hL) + hL * hR);
+    Ttl = ((hWght * hR) * TtR + (hWght * hL + hR * hL) * TtL) * iDenom;
+    Ttr = ((hWght * hL) * TtL + (hWght * hR + hR * hL) * TtR) * iDenom;
+    Tbl = ((hWght * hR) * TbR + (hWght * hL + hR * hL) * TbL) * iDenom;
+    Tbr = ((hWght * hL) * TbL + (hWght * hR + hR * hL) * TbR) * iDenom;
+    Stl = ((hWght * hR) * StR + (hWght * hL + hR * hL) * StL) * iDenom;
+    Str = ((hWght * hL) * StL + (hWght * hR + hR * hL) * StR) * iDenom;
+    Sbl = ((hWght * hR) * SbR + (hWght * hL + hR * hL) * SbL) * iDenom;
+    Sbr = ((hWght * hL) * SbL + (hWght * hR + hR * hL) * SbR) * iDenom;
+  } else {
+    Ttl = TtL; Tbl = TbL; Ttr = TtR; Tbr = TbR;
+    Stl = StL; Sbl = SbL; Str = StR; Sbr = SbR;
+  }
+  double intz[5];
+  intz[0] = p.dpa[oL3]; intz[4] = p.dpa[oR3];
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double w_left = 0.25 * (double)(5 - m), w_right = 1.0 - w_left;
+    const double dz_x = w_left * (eL_K - eL_Kp1) + w_right * (eR_K - eR_Kp1);
+    const double T1 = w_left * Ttl + w_right * Ttr, T5 = w_left * Tbl + w_right * Tbr;
+    const double S1 = w_left * Stl + w_right * Str, S5 = w_left * Sbl + w_right * Sbr;
+    double pn = -GxRho * ((w_left * eL_K + w_right * eR_K) - p.Z_ref);
+    double r[5];
+#pragma unroll
+    for (int n = 1; n <= 5; n++) {
+      if (n > 1) pn = pn + GxRho * 0.25 * dz_x;
+      double Tn, Sn;
+      if (n == 1) { Tn = T1; Sn = S1; }
+      else if (n == 5) { Tn = T5; Sn = S5; }
+      else {
+        const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
+        Sn = wt_t * S1 + wt_b * S5;
+        Tn = wt_t * T1 + wt_b * T5;
+      }
+      r[n - 1] = eos_density_anomaly(p.eos, Tn, Sn, pn, rho_ref);
+    }
+    intz[m - 1] = G_e * dz_x * (C1_90 * (7.0 * (r[0] + r[4]) + 32.0 * (r[1] + r[3]) + 12.0 * r[2]));
+  }
+  return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
+}
+
+__global__ __launch_bounds__(64) void pgf_face_kernel(PgfArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;      // I (x face) / i (y face)
+  const int j = g.jsc - 1 + blockIdx.y;                         // j (x face) / J (y face)
+  if (i > g.iec) return;
+  const bool do_x = (j >= g.jsc), do_y = (i >= g.isc);          // j <= jec and i <= iec by the grid size
+  if (!do_x && !do_y) return;
+  const int nz = g.nk;
+  const long pl = (long)g.nih * g.njh, plU = (long)(g.nih + 1) * g.njh, plV = (long)g.nih * (g.njh + 1);
+  const long oc = g.h2(i, j), oe = oc + 1, on = oc + g.nih;
+  const double h_neglect = g.H_subroundoff, I_Rho0 = 1.0 / g.Rho0;
+  const double rg = p.rho_ref * g.g_Earth;
+  auto pa0 = [&](long o2) -> double {
+    double v = rg * (p.e[o2] - p.Z_ref);
+    if (p.p_atm) v = v + p.p_atm[o2];
+    return v;
+  };
+  double pa_c = pa0(oc), pa_e = do_x ? pa0(oe) : 0.0, pa_n = do_y ? pa0(on) : 0.0;
+  double intx_pa = 0.5 * (pa_c + pa_e), inty_pa = 0.5 * (pa_c + pa_n);
+  const double fx = do_x ? (2.0 * I_Rho0 * g.IdxCu[g.u2(i, j)]) : 0.0;
+  const double fy = do_y ? (2.0 * I_Rho0 * g.IdyCv[g.v2(i, j)]) : 0.0;
+  double ec_K = p.e[oc], ee_K = do_x ? p.e[oe] : 0.0, en_K = do_y ? p.e[on] : 0.0;
+  for (int k = 0; k < nz; k++) {
+    const long c3 = oc + pl * k;
+    const double ec_Kp1 = p.e[c3 + pl];
+    const double h_c = p.h[c3], dpa_c = p.dpa[c3], iz_c = p.intz_dpa[c3];
+    if (do_x) {
+      const long e3 = c3 + 1;
+      const double ee_Kp1 = p.e[e3 + pl];
+      const double h_e = p.h[e3];
+      const double intx_dpa = face_integral(p, c3, e3, oc, oe, ec_K, ec_Kp1, ee_K, ee_Kp1);
+      p.PFu[g.u2(i, j) + plU * k] = (((pa_c * h_c + iz_c) - (pa_e * h_e + p.intz_dpa[e3])) +
+                                     ((h_e - h_c) * intx_pa - (ee_Kp1 - ec_Kp1) * intx_dpa * g.Z_to_H)) *
+                                    (fx / ((h_c + h_e) + h_neglect));
+      intx_pa = intx_pa + intx_dpa;
+      pa_e = pa_e + p.dpa[e3];
+      ee_K = ee_Kp1;
+    }
+    if (do_y) {
+      const long n3 = c3 + g.nih;
+      const double en_Kp1 = p.e[n3 + pl];
+      const double h_n = p.h[n3];
+      const double inty_dpa = face_integral(p, c3, n3, oc, on, ec_K, ec_Kp1, en_K, en_Kp1);
+      p.PFv[g.v2(i, j) + plV * k] = (((pa_c * h_c + iz_c) - (pa_n * h_n + p.intz_dpa[n3])) +
+                                     ((h_n - h_c) * inty_pa - (en_Kp1 - ec_Kp1) * inty_dpa * g.Z_to_H)) *
+                                    (fy / ((h_c + h_n) + h_neglect));
+      inty_pa = inty_pa + inty_dpa;
+      pa_n = pa_n + p.dpa[n3];
+      en_K = en_Kp1;
+    }
+    pa_c = pa_c + dpa_c;
+    ec_K = ec_Kp1;
+  }
+}
+
+__global__ void eos_density_kernel(EosDev E, const double *T, const double *S, const double *pr, double *rho, long n,
+                                   int use_ref, double rho_ref) {
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    rho[t] = use_ref ? eos_density_anomaly(E, T[t], S[t], pr[t], rho_ref) : eos_density(E, T[t], S[t], pr[t]);
+}
+
+int check_eos(const mom6hip_eos_t *eos) {
+  M6_REQUIRE(eos != nullptr, "MOM_EOS: the equation of state must be initialized (EOS_init) before it is used");
+  M6_REQUIRE(eos->form == MOM6HIP_EOS_WRIGHT || eos->form == MOM6HIP_EOS_LINEAR,
+             "MOM_EOS: EQN_OF_STATE form %d is not provided by libmom6hip (WRIGHT, LINEAR)", eos->form);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mom6hip_calculate_density(mom6hip_ctx_t *ctx, const mom6hip_eos_t *eos, const double *T, const double *S,
+                                         const double *pressure, double *rho, int64_t n, int32_t use_rho_ref,
+                                         double rho_ref, int32_t memspace) {
+  M6_REQUIRE(ctx && T && S && pressure && rho && n >= 0, "calculate_density: bad argument");
+  if (check_eos(eos)) return 2;
+  if (n == 0) return 0;
+  m6::Stager st(ctx, memspace);
+  const double *dT = st.in(T, n * 8), *dS = st.in(S, n * 8), *dp = st.in(pressure, n * 8);
+  double *dr = st.out(rho, n * 8);
+  if (st.failed()) return 1;
+  EosDev E{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS};
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(eos_density_kernel, dim3(blocks), dim3(256), 0, ctx->stream, E, dT, dS, dp, dr, (long)n,
+                     (int)use_rho_ref, rho_ref);
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs,
+                                              const mom6hip_eos_t *eos, const double *h, const double *T,
+                                              const double *S, const double *p_atm, double *PFu, double *PFv,
+                                              double *pbce, double *eta, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr && cs != nullptr, "MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.");
+  M6_REQUIRE(h && T && S && PFu && PFv, "PressureForce_FV_Bouss: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "PressureForce_FV_Bouss: bad memspace");
+  if (check_eos(eos)) return 2;
+  M6_REQUIRE(cs->reconstruct && cs->Recon_Scheme == 1,
+             "PressureForce_FV_Bouss: only RECONSTRUCT_FOR_PRESSURE=True with PRESSURE_RECONSTRUCTION_SCHEME=1 is provided");
+  M6_REQUIRE(cs->GFS_scale == 1.0, "PressureForce_FV_Bouss: GFS_scale < 1 is not provided");
+  m6::GridDev &g = ctx->g;
+  M6_REQUIRE(g.bathyT && g.IdxCu && g.IdyCv, "PressureForce_FV_Bouss: a required grid metric is missing");
+  M6_REQUIRE(g.nk >= 2, "PressureForce_FV_Bouss: at least 2 layers are needed");
+  M6_REQUIRE(g.isc - g.isd >= 1 && g.ied - g.iec >= 1 && g.jsc - g.jsd >= 1 && g.jed - g.jec >= 1,
+             "PressureForce_FV_Bouss: needs a halo of at least 1");
+  hipStream_t s = ctx->stream;
+  const size_t bH = (size_t)g.nh3() * 8, bU = (size_t)g.nu3() * 8, bV = (size_t)g.nv3() * 8;
+  const size_t bH2 = (size_t)g.nih * g.njh * 8;
+  m6::Stager st(ctx, memspace);
+  PgfArgs a;
+  a.g = g;
+  a.eos = EosDev{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS};
+  a.h = st.in(h, bH); a.T = st.in(T, bH); a.S = st.in(S, bH); a.p_atm = st.in(p_atm, bH2);
+  a.PFu = st.inout(PFu, bU); a.PFv = st.inout(PFv, bV); a.pbce = st.inout(pbce, bH); a.eta = st.inout(eta, bH2);
+  a.e = (double *)st.scratch(bH + bH2);
+  a.T_t = (double *)st.scratch(bH); a.T_b = (double *)st.scratch(bH);
+  a.S_t = (double *)st.scratch(bH); a.S_b = (double *)st.scratch(bH);
+  a.dpa = (double *)st.scratch(bH); a.intz_dpa = (double *)st.scratch(bH);
+  if (st.failed()) return 1;
+  a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale;
+  a.boundary_extrap = cs->boundary_extrap; a.massw = cs->useMassWghtInterp;
+  const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
+  hipLaunchKernelGGL(pgf_column_kernel, dim3((ncol_i + 63) / 64, ncol_j), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(pgf_face_kernel, dim3((ncol_i - 1 + 63) / 64, ncol_j - 1), dim3(64), 0, s, a);
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}

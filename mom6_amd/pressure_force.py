@@ -1,0 +1,47 @@
+"""Host-side mirror of MOM_PressureForce / MOM_PressureForce_FV and the part of MOM_EOS the pressure force
+uses (reference: src/core/MOM_PressureForce.F90:41, src/core/MOM_PressureForce_FV.F90:462,
+src/equation_of_state/MOM_EOS.F90)."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+from .tracer_advect import DeviceGrid, _ptr_space
+
+
+def EOS_init(form="WRIGHT", Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.8):
+    """EOS_init (MOM_EOS.F90): EQN_OF_STATE and, for LINEAR, RHO_T0_S0 / DRHO_DT / DRHO_DS."""
+    if form not in _abi.EOS_FORMS:
+        raise Mom6HipError("interpret_eos_selection: EQN_OF_STATE " + str(form) + " is not provided by libmom6hip "
+                           "(WRIGHT, LINEAR)")
+    return _abi.EOS(_abi.EOS_FORMS[form], 0, float(Rho_T0_S0), float(dRho_dT), float(dRho_dS))
+
+
+def PressureForce_init(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False, Z_ref=0.0):
+    """PressureForce_FV_init (MOM_PressureForce_FV.F90:921): RHO_PGF_REF, BOUNDARY_EXTRAPOLATION_PRESSURE,
+    MASS_WEIGHT_IN_PRESSURE_GRADIENT; ANALYTIC_FV_PGF with PLM reconstruction is what is provided."""
+    return _abi.PressureForceCS(float(grid.Rho0 if Rho0 is None else Rho0), 1.0, float(Z_ref), 1, 1,
+                                int(bool(boundary_extrap)), int(bool(useMassWghtInterp)))
+
+
+def PressureForce(h, tv, PFu, PFv, G: DeviceGrid, CS, ALE_CSp=None, p_atm=None, pbce=None, eta=None):
+    """PressureForce(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta) -- MOM_PressureForce.F90:41.
+    `tv` is (T, S, EOS)."""
+    if CS is None:
+        raise Mom6HipError("MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.")
+    T, S, EOS = tv
+    spaces = set()
+
+    def P(a):
+        if a is None:
+            return None
+        p, s = _ptr_space(a)
+        spaces.add(s)
+        return C.c_void_p(p)
+
+    args = [P(x) for x in (h, T, S, p_atm, PFu, PFv, pbce, eta)]
+    if len(spaces) != 1:
+        raise Mom6HipError("PressureForce: all fields must be in the same memory space")
+    check(lib().mom6hip_pressureforce_fv_bouss(G.handle, C.byref(CS), C.byref(EOS), *args, spaces.pop()),
+          "PressureForce_FV_Bouss")

@@ -101,6 +101,16 @@ int orc_continuity(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, c
                    const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor,
                    double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor);
 
+/* ---- MOM_EOS / MOM_PressureForce_FV (oracle/pressure_force.c) ------------------------------ */
+double orc_eos_density(const mom6hip_eos_t *E, double T, double S, double p);
+double orc_eos_density_anomaly(const mom6hip_eos_t *E, double T, double S, double p, double rho_ref);
+void orc_eos_density_derivs(const mom6hip_eos_t *E, double T, double S, double p, double *dT, double *dS);
+void orc_ale_plm_edge_values(const mom6hip_grid_t *G, const double *h, const double *Q, int bdry_extrap,
+                             double *Q_t, double *Q_b);
+int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
+                               const double *h, const double *T, const double *S, const double *p_atm,
+                               double *PFu, double *PFv, double *pbce, double *eta);
+
 #ifdef __cplusplus
 }
 #endif

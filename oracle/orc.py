@@ -242,3 +242,45 @@ def continuity(grid, cs, u, v, hin, h, uh, vh, dt, uhbt=None, vhbt=None, visc_re
     if rc:
         raise RuntimeError("MOM_continuity_PPM: Either both visc_rem_u and visc_rem_v or neither one must be present "
                            "in call to continuity_PPM.")
+
+
+def eos(form="WRIGHT", Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.8):
+    return _abi.EOS(_abi.EOS_FORMS[form], 0, Rho_T0_S0, dRho_dT, dRho_dS)
+
+
+def eos_density(E, T, S, p, rho_ref=None):
+    L = lib()
+    L.orc_eos_density.argtypes = [C.POINTER(_abi.EOS)] + [C.c_double] * 3; L.orc_eos_density.restype = C.c_double
+    L.orc_eos_density_anomaly.argtypes = [C.POINTER(_abi.EOS)] + [C.c_double] * 4
+    L.orc_eos_density_anomaly.restype = C.c_double
+    if rho_ref is None:
+        return L.orc_eos_density(C.byref(E), T, S, p)
+    return L.orc_eos_density_anomaly(C.byref(E), T, S, p, rho_ref)
+
+
+def eos_density_derivs(E, T, S, p):
+    L = lib()
+    L.orc_eos_density_derivs.argtypes = [C.POINTER(_abi.EOS)] + [C.c_double] * 3 + [_dp, _dp]
+    L.orc_eos_density_derivs.restype = None
+    a, b = C.c_double(), C.c_double()
+    L.orc_eos_density_derivs(C.byref(E), T, S, p, C.cast(C.byref(a), _dp), C.cast(C.byref(b), _dp))
+    return a.value, b.value
+
+
+def pressureforce_cs(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False):
+    return _abi.PressureForceCS(grid.Rho0 if Rho0 is None else Rho0, 1.0, 0.0, 1, 1, int(boundary_extrap),
+                                int(useMassWghtInterp))
+
+
+def pressureforce(grid, cs, E, h, T, S, p_atm=None, want_pbce=True, want_eta=True):
+    L = lib()
+    L.orc_pressureforce_fv_bouss.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.PressureForceCS),
+                                             C.POINTER(_abi.EOS)] + [_dp] * 8
+    PFu, PFv = grid.zeros3(_abi.POS_U), grid.zeros3(_abi.POS_V)
+    pbce = grid.zeros3(_abi.POS_H) if want_pbce else None
+    eta = grid.zeros2(_abi.POS_H) if want_eta else None
+    rc = L.orc_pressureforce_fv_bouss(C.byref(grid.struct()), C.byref(cs), C.byref(E), _p(h), _p(T), _p(S), _p(p_atm),
+                                      _p(PFu), _p(PFv), _p(pbce), _p(eta))
+    if rc:
+        raise RuntimeError("orc_pressureforce_fv_bouss: unsupported configuration")
+    return PFu, PFv, pbce, eta

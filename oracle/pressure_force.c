@@ -1,0 +1,315 @@
+/*
+ * pressure_force.c -- CPU restatement of PressureForce_FV_Bouss and what it calls (TEST INFRASTRUCTURE).
+ *
+ * Restates, for the hot-path configuration (Boussinesq, ALE with PLM reconstruction of T and S for the
+ * pressure gradient -- RECONSTRUCT_FOR_PRESSURE=True, PRESSURE_RECONSTRUCTION_SCHEME=1 --, an equation of
+ * state, GFS_scale = 1, no tides / SAL, no Stanley SGS terms, use_inaccurate_pgf_rho_anom = False):
+ *   PressureForce_FV_Bouss          src/core/MOM_PressureForce_FV.F90:462-919
+ *   int_density_dz_generic_plm      src/core/MOM_density_integrals.F90:369-769
+ *   TS_PLM_edge_values / ALE_PLM_edge_values   src/ALE/MOM_ALE.F90:1495-1579
+ *   Set_pbce_Bouss (use_EOS branch) src/core/MOM_PressureForce_Montgomery.F90:649-748
+ *   calculate_density_1d with rho_ref, calculate_density_derivs    src/equation_of_state/MOM_EOS.F90:299
+ *   Wright (1997) "WRIGHT" form: density_elem / density_anomaly_elem / calculate_density_derivs_elem
+ *                                   src/equation_of_state/MOM_EOS_Wright.F90:80-206
+ *   linear EOS                      src/equation_of_state/MOM_EOS_linear.F90:59-130
+ *
+ * The EOS functions are PINNED by the reference's EOS_unit_tests check values
+ * (src/equation_of_state/MOM_EOS.F90:1931,1944,1996; tests/golden/eos_check_values.json); the PLM slopes
+ * are pinned through oracle/remapping.c.  The assembled pressure force has no known-answer vector in the
+ * reference (parity unpinned for the assembly; checked through hydrostatic-consistency properties).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mom6_oracle.h"
+
+static inline double max2(double a, double b) { return a > b ? a : b; }
+static inline double max3(double a, double b, double c) { return max2(max2(a, b), c); }
+
+/* ---- Wright 1997, MOM_EOS_Wright.F90:23-38 ---- */
+static const double a0 = 7.057924e-4, a1 = 3.480336e-7, a2 = -1.112733e-7;
+static const double b0 = 5.790749e8, b1 = 3.516535e6, b2 = -4.002714e4, b3 = 2.084372e2, b4 = 5.944068e5, b5 = -9.643486e3;
+static const double c0 = 1.704853e5, c1 = 7.904722e2, c2 = -7.984422, c3 = 5.140652e-2, c4 = -2.302158e2, c5 = -3.079464;
+
+/* density_elem_buggy_Wright :80-95 */
+static double wright_density(double T, double S, double pressure) {
+  double al0 = (a0 + a1*T) +a2*S;
+  double p0 = (b0 + b4*S) + T * (b1 + T*(b2 + b3*T) + b5*S);
+  double lambda = (c0 +c4*S) + T * (c1 + T*(c2 + c3*T) + c5*S);
+  return (pressure + p0) / (lambda + al0*(pressure + p0));
+}
+
+/* density_anomaly_elem_buggy_Wright :98-129 */
+static double wright_density_anomaly(double T, double S, double pressure, double rho_ref) {
+  double pa_000 = (b0*(1.0 - a0*rho_ref) - rho_ref*c0);
+  double al_TS = a1*T +a2*S;
+  double al0 = a0 + al_TS;
+  double p_TSp = pressure + (b4*S + T * (b1 + (T*(b2 + b3*T) + b5*S)));
+  double lam_TS = c4*S + T * (c1 + (T*(c2 + c3*T) + c5*S));
+  return (pa_000 + (p_TSp - rho_ref*(p_TSp*al0 + (b0*al_TS + lam_TS)))) /
+         ( (c0 + lam_TS) + al0*(b0 + p_TSp) );
+}
+
+/* calculate_density_derivs_elem_buggy_Wright :178-206 */
+static void wright_density_derivs(double T, double S, double pressure, double *drho_dT, double *drho_dS) {
+  double al0 = (a0 + a1*T) + a2*S;
+  double p0 = (b0 + b4*S) + T * (b1 + T*((b2 + b3*T)) + b5*S);
+  double lambda = (c0 +c4*S) + T * (c1 + T*((c2 + c3*T)) + c5*S);
+  double I_denom2 = 1.0 / (lambda + al0*(pressure + p0));
+  I_denom2 = I_denom2 *I_denom2;
+  *drho_dT = I_denom2 *
+    (lambda* (b1 + T*(2.0*b2 + 3.0*b3*T) + b5*S) -
+     (pressure+p0) * ( (pressure+p0)*a1 +
+      (c1 + T*(c2*2.0 + c3*3.0*T) + c5*S) ));
+  *drho_dS = I_denom2 * (lambda* (b4 + b5*T) -
+    (pressure+p0) * ( (pressure+p0)*a2 + (c4 + c5*T) ));
+}
+
+/* calculate_density (no rho_ref) / with rho_ref / derivs for the EOS forms provided */
+double orc_eos_density(const mom6hip_eos_t *E, double T, double S, double p) {
+  if (E->form == MOM6HIP_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT*T + E->dRho_dS*S;
+  return wright_density(T, S, p);
+}
+double orc_eos_density_anomaly(const mom6hip_eos_t *E, double T, double S, double p, double rho_ref) {
+  if (E->form == MOM6HIP_EOS_LINEAR) return (E->Rho_T0_S0 - rho_ref) + (E->dRho_dT*T + E->dRho_dS*S);
+  return wright_density_anomaly(T, S, p, rho_ref);
+}
+void orc_eos_density_derivs(const mom6hip_eos_t *E, double T, double S, double p, double *dT, double *dS) {
+  if (E->form == MOM6HIP_EOS_LINEAR) { *dT = E->dRho_dT; *dS = E->dRho_dS; return; }
+  wright_density_derivs(T, S, p, dT, dS);
+}
+
+/* ALE_PLM_edge_values, MOM_ALE.F90:1520-1579 (answer_date >= 20190101) */
+void orc_ale_plm_edge_values(const mom6hip_grid_t *G, const double *h, const double *Q, int bdry_extrap,
+                             double *Q_t, double *Q_b)
+{
+  const int nz = G->nk;
+  const double h_neglect = G->H_subroundoff;
+  double *slp = calloc(nz+2, sizeof(double));
+#define HH(k) h[ORC_H3(G,i,j,k)]
+#define QQ(k) Q[ORC_H3(G,i,j,k)]
+  for (int j = G->jsc-1; j <= G->jec+1; j++) for (int i = G->isc-1; i <= G->iec+1; i++) {
+    slp[1] = 0.;
+    for (int k = 2; k <= nz-1; k++)
+      slp[k] = orc_plm_slope_wa(HH(k-1), HH(k), HH(k+1), h_neglect, QQ(k-1), QQ(k), QQ(k+1));
+    slp[nz] = 0.;
+    for (int k = 2; k <= nz-1; k++) {
+      double mslp = orc_plm_monotonized_slope(QQ(k-1), QQ(k), QQ(k+1), slp[k-1], slp[k], slp[k+1]);
+      Q_t[ORC_H3(G,i,j,k)] = QQ(k) - 0.5 * mslp;
+      Q_b[ORC_H3(G,i,j,k)] = QQ(k) + 0.5 * mslp;
+    }
+    if (bdry_extrap) {
+      double mslp = - orc_plm_extrapolate_slope(HH(2), HH(1), h_neglect, QQ(2), QQ(1));
+      Q_t[ORC_H3(G,i,j,1)] = QQ(1) - 0.5 * mslp;
+      Q_b[ORC_H3(G,i,j,1)] = QQ(1) + 0.5 * mslp;
+      mslp = orc_plm_extrapolate_slope(HH(nz-1), HH(nz), h_neglect, QQ(nz-1), QQ(nz));
+      Q_t[ORC_H3(G,i,j,nz)] = QQ(nz) - 0.5 * mslp;
+      Q_b[ORC_H3(G,i,j,nz)] = QQ(nz) + 0.5 * mslp;
+    } else {
+      Q_t[ORC_H3(G,i,j,1)] = QQ(1); Q_b[ORC_H3(G,i,j,1)] = QQ(1);
+      Q_t[ORC_H3(G,i,j,nz)] = QQ(nz); Q_b[ORC_H3(G,i,j,nz)] = QQ(nz);
+    }
+  }
+#undef HH
+#undef QQ
+  free(slp);
+}
+
+/* e(i,j,K), K = 1..nz+1 */
+#define E3(i,j,K) e[ORC_H2(G,i,j) + nH2*((K)-1)]
+
+/* int_density_dz_generic_plm, MOM_density_integrals.F90:369-769 (use_rho_ref, no Stanley terms) */
+static void int_density_dz_generic_plm(const mom6hip_grid_t *G, const mom6hip_eos_t *EOS, int k, const double *T_t,
+                                       const double *T_b, const double *S_t, const double *S_b, const double *e,
+                                       double rho_ref, double rho_0, double G_e, double dz_subroundoff,
+                                       int useMassWghtInterp, double z0pres, double *dpa, double *intz_dpa,
+                                       double *intx_dpa, double *inty_dpa)
+{
+  const long nH2 = (long)ORC_NIH(G)*ORC_NJH(G);
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const double C1_90 = 1.0/90.0;
+  const double GxRho = G_e * rho_0;
+  const double massWeightToggle = useMassWghtInterp ? 1. : 0.;
+  const double *bathyT = G->bathyT;
+  double wt_t[6], wt_b[6];
+  for (int n = 1; n <= 5; n++) { wt_t[n] = 0.25 * (double)(5-n); wt_b[n] = 1.0 - wt_t[n]; }
+#define TT(i,j) T_t[ORC_H3(G,i,j,k)]
+#define TB(i,j) T_b[ORC_H3(G,i,j,k)]
+#define ST(i,j) S_t[ORC_H3(G,i,j,k)]
+#define SB(i,j) S_b[ORC_H3(G,i,j,k)]
+  const int K = k;
+  /* 1. vertical integrals */
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+    double dz = E3(i,j,K) - E3(i,j,K+1);
+    double r5[6];
+    for (int n = 1; n <= 5; n++) {
+      double p5 = -GxRho*((E3(i,j,K) - z0pres) - 0.25*(double)(n-1)*dz);
+      double S5 = wt_t[n] * ST(i,j) + wt_b[n] * SB(i,j);
+      double T5 = wt_t[n] * TT(i,j) + wt_b[n] * TB(i,j);
+      r5[n] = orc_eos_density_anomaly(EOS, T5, S5, p5, rho_ref);
+    }
+    double rho_anom = C1_90*(7.0*(r5[1]+r5[5]) + 32.0*(r5[2]+r5[4]) + 12.0*r5[3]);
+    dpa[ORC_H2(G,i,j)] = G_e*dz*rho_anom;
+    intz_dpa[ORC_H2(G,i,j)] = 0.5*G_e*(dz*dz) *
+            (rho_anom - C1_90*(16.0*(r5[4]-r5[2]) + 7.0*(r5[5]-r5[1])) );
+  }
+  /* 2./3. horizontal integrals; dir 0: x faces (I,j), dir 1: y faces (i,J) */
+  for (int dir = 0; dir < 2; dir++) {
+    const int j0 = dir ? Jsq : G->jsc, j1 = dir ? Jeq : G->jec;
+    const int i0 = dir ? G->isc : Isq, i1 = dir ? G->iec : Ieq;
+    for (int j = j0; j <= j1; j++) for (int i = i0; i <= i1; i++) {
+      const int ip = dir ? i : i+1, jp = dir ? j+1 : j;      /* the cell on the "right" of the face */
+      double Ttl, Tbl, Ttr, Tbr, Stl, Sbl, Str, Sbr;
+      double hWght = massWeightToggle *
+              max3(0., -bathyT[ORC_H2(G,i,j)]-E3(ip,jp,K), -bathyT[ORC_H2(G,ip,jp)]-E3(i,j,K));
+      if (hWght > 0.) {
+        double hL = (E3(i,j,K) - E3(i,j,K+1)) + dz_subroundoff;
+        double hR = (E3(ip,jp,K) - E3(ip,jp,K+1)) + dz_subroundoff;
+        double rr = (hL-hR)/(hL+hR);
+        hWght = hWght * ( rr*rr );
+        double iDenom = 1./( hWght*(hR + hL) + hL*hR );
+        Ttl = ( (hWght*hR)*TT(ip,jp) + (hWght*hL + hR*hL)*TT(i,j) ) * iDenom;
+        Ttr = ( (hWght*hL)*TT(i,j) + (hWght*hR + hR*hL)*TT(ip,jp) ) * iDenom;
+        Tbl = ( (hWght*hR)*TB(ip,jp) + (hWght*hL + hR*hL)*TB(i,j) ) * iDenom;
+        Tbr = ( (hWght*hL)*TB(i,j) + (hWght*hR + hR*hL)*TB(ip,jp) ) * iDenom;
+        Stl = ( (hWght*hR)*ST(ip,jp) + (hWght*hL + hR*hL)*ST(i,j) ) * iDenom;
+        Str = ( (hWght*hL)*ST(i,j) + (hWght*hR + hR*hL)*ST(ip,jp) ) * iDenom;
+        Sbl = ( (hWght*hR)*SB(ip,jp) + (hWght*hL + hR*hL)*SB(i,j) ) * iDenom;
+        Sbr = ( (hWght*hL)*SB(i,j) + (hWght*hR + hR*hL)*SB(ip,jp) ) * iDenom;
+      } else {
+        Ttl = TT(i,j); Tbl = TB(i,j); Ttr = TT(ip,jp); Tbr = TB(ip,jp);
+        Stl = ST(i,j); Sbl = SB(i,j); Str = ST(ip,jp); Sbr = SB(ip,jp);
+      }
+      double intz[6];
+      intz[1] = dpa[ORC_H2(G,i,j)]; intz[5] = dpa[ORC_H2(G,ip,jp)];
+      for (int m = 2; m <= 4; m++) {
+        double w_left = wt_t[m], w_right = wt_b[m];
+        double dz_x = w_left*(E3(i,j,K) - E3(i,j,K+1)) + w_right*(E3(ip,jp,K) - E3(ip,jp,K+1));
+        double T15[6], S15[6], p15[6], r15[6];
+        T15[1] = w_left*Ttl + w_right*Ttr;
+        T15[5] = w_left*Tbl + w_right*Tbr;
+        S15[1] = w_left*Stl + w_right*Str;
+        S15[5] = w_left*Sbl + w_right*Sbr;
+        p15[1] = -GxRho*((w_left*E3(i,j,K) + w_right*E3(ip,jp,K)) - z0pres);
+        for (int n = 2; n <= 5; n++) p15[n] = p15[n-1] + GxRho*0.25*dz_x;
+        for (int n = 2; n <= 4; n++) {
+          S15[n] = wt_t[n] * S15[1] + wt_b[n] * S15[5];
+          T15[n] = wt_t[n] * T15[1] + wt_b[n] * T15[5];
+        }
+        for (int n = 1; n <= 5; n++) r15[n] = orc_eos_density_anomaly(EOS, T15[n], S15[n], p15[n], rho_ref);
+        intz[m] = G_e*dz_x*( C1_90*(7.0*(r15[1]+r15[5]) + 32.0*(r15[2]+r15[4]) + 12.0*r15[3]) );
+      }
+      double val = C1_90*(7.0*(intz[1]+intz[5]) + 32.0*(intz[2]+intz[4]) + 12.0*intz[3]);
+      if (dir) inty_dpa[ORC_V2(G,i,j)] = val; else intx_dpa[ORC_U2(G,i,j)] = val;
+    }
+  }
+#undef TT
+#undef TB
+#undef ST
+#undef SB
+}
+
+/* PressureForce_FV_Bouss, MOM_PressureForce_FV.F90:462-919 */
+int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
+                               const double *h, const double *T, const double *S, const double *p_atm,
+                               double *PFu, double *PFv, double *pbce, double *eta)
+{
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const long nH2 = (long)ORC_NIH(G)*ORC_NJH(G), nH3 = nH2*nz;
+  if (!(CS->reconstruct && CS->Recon_Scheme == 1) || CS->GFS_scale != 1.0) return 1;
+  const double h_neglect = G->H_subroundoff;
+  const double dz_neglect = G->dZ_subroundoff;
+  const double I_Rho0 = 1.0 / G->Rho0;
+  const double G_Rho0 = G->g_Earth / G->Rho0;
+  const double rho_ref = CS->Rho0;
+  const double Z_ref = CS->Z_ref;
+  double *e = calloc(nH2*(nz+1), 8);
+  double *T_t = calloc(nH3, 8), *T_b = calloc(nH3, 8), *S_t = calloc(nH3, 8), *S_b = calloc(nH3, 8);
+  double *pa = calloc(nH2, 8), *dpa = calloc(nH2, 8), *intz_dpa = calloc(nH2, 8);
+  double *intx_pa = calloc((size_t)(ORC_NIH(G)+1)*ORC_NJH(G), 8), *intx_dpa = calloc((size_t)(ORC_NIH(G)+1)*ORC_NJH(G), 8);
+  double *inty_pa = calloc((size_t)ORC_NIH(G)*(ORC_NJH(G)+1), 8), *inty_dpa = calloc((size_t)ORC_NIH(G)*(ORC_NJH(G)+1), 8);
+
+  /* :571-573 / :639-641 (no SAL, no tides) */
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+    E3(i,j,nz+1) = -G->bathyT[ORC_H2(G,i,j)];
+  /* :646-648 */
+  for (int j = Jsq; j <= Jeq+1; j++) for (int k = nz; k >= 1; k--) for (int i = Isq; i <= Ieq+1; i++)
+    E3(i,j,k) = E3(i,j,k+1) + h[ORC_H3(G,i,j,k)]*G->H_to_Z;
+
+  /* :712-718 */
+  orc_ale_plm_edge_values(G, h, S, CS->boundary_extrap, S_t, S_b);
+  orc_ale_plm_edge_values(G, h, T, CS->boundary_extrap, T_t, T_b);
+
+  /* :723-741 */
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+    if (p_atm) pa[ORC_H2(G,i,j)] = (rho_ref*G->g_Earth)*(E3(i,j,1) - Z_ref) + p_atm[ORC_H2(G,i,j)];
+    else       pa[ORC_H2(G,i,j)] = (rho_ref*G->g_Earth)*(E3(i,j,1) - Z_ref);
+  }
+  for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+    intx_pa[ORC_U2(G,I,j)] = 0.5*(pa[ORC_H2(G,I,j)] + pa[ORC_H2(G,I+1,j)]);
+  for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+    inty_pa[ORC_V2(G,i,J)] = 0.5*(pa[ORC_H2(G,i,J)] + pa[ORC_H2(G,i,J+1)]);
+
+  for (int k = 1; k <= nz; k++) {
+    int_density_dz_generic_plm(G, EOS, k, T_t, T_b, S_t, S_b, e, rho_ref, CS->Rho0, G->g_Earth, dz_neglect,
+                               CS->useMassWghtInterp, Z_ref, dpa, intz_dpa, intx_dpa, inty_dpa);
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+      intz_dpa[ORC_H2(G,i,j)] = intz_dpa[ORC_H2(G,i,j)]*G->Z_to_H;
+#define HK(i,j) h[ORC_H3(G,i,j,k)]
+    /* :793-801 */
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
+      const int i = I;
+      PFu[ORC_U3(G,I,j,k)] = (((pa[ORC_H2(G,i,j)]*HK(i,j) + intz_dpa[ORC_H2(G,i,j)]) -
+                   (pa[ORC_H2(G,i+1,j)]*HK(i+1,j) + intz_dpa[ORC_H2(G,i+1,j)])) +
+                   ((HK(i+1,j) - HK(i,j)) * intx_pa[ORC_U2(G,I,j)] -
+                   (E3(i+1,j,k+1) - E3(i,j,k+1)) * intx_dpa[ORC_U2(G,I,j)] * G->Z_to_H)) *
+                   ((2.0*I_Rho0*G->IdxCu[ORC_U2(G,I,j)]) /
+                   ((HK(i,j) + HK(i+1,j)) + h_neglect));
+      intx_pa[ORC_U2(G,I,j)] = intx_pa[ORC_U2(G,I,j)] + intx_dpa[ORC_U2(G,I,j)];
+    }
+    /* :804-812 */
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) {
+      const int j = J;
+      PFv[ORC_V3(G,i,J,k)] = (((pa[ORC_H2(G,i,j)]*HK(i,j) + intz_dpa[ORC_H2(G,i,j)]) -
+                   (pa[ORC_H2(G,i,j+1)]*HK(i,j+1) + intz_dpa[ORC_H2(G,i,j+1)])) +
+                   ((HK(i,j+1) - HK(i,j)) * inty_pa[ORC_V2(G,i,J)] -
+                   (E3(i,j+1,k+1) - E3(i,j,k+1)) * inty_dpa[ORC_V2(G,i,J)] * G->Z_to_H)) *
+                   ((2.0*I_Rho0*G->IdyCv[ORC_V2(G,i,J)]) /
+                   ((HK(i,j) + HK(i,j+1)) + h_neglect));
+      inty_pa[ORC_V2(G,i,J)] = inty_pa[ORC_V2(G,i,J)] + inty_dpa[ORC_V2(G,i,J)];
+    }
+#undef HK
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+      pa[ORC_H2(G,i,j)] = pa[ORC_H2(G,i,j)] + dpa[ORC_H2(G,i,j)];
+  }
+
+  /* Set_pbce_Bouss (use_EOS, no rho_star), MOM_PressureForce_Montgomery.F90:702-729 */
+  if (pbce) {
+    const double Rho0xG = CS->Rho0 * G->g_Earth;
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+      double Ihtot = G->H_to_Z / ((E3(i,j,1)-E3(i,j,nz+1)) + dz_neglect);
+      double press = -Rho0xG*(E3(i,j,1) - Z_ref);
+      double rho_in_situ = orc_eos_density(EOS, T[ORC_H3(G,i,j,1)], S[ORC_H3(G,i,j,1)], press);
+      pbce[ORC_H3(G,i,j,1)] = G_Rho0*(CS->GFS_scale * rho_in_situ) * G->H_to_Z;
+      for (int k = 2; k <= nz; k++) {
+        press = -Rho0xG*(E3(i,j,k) - Z_ref);
+        double T_int = 0.5*(T[ORC_H3(G,i,j,k-1)]+T[ORC_H3(G,i,j,k)]);
+        double S_int = 0.5*(S[ORC_H3(G,i,j,k-1)]+S[ORC_H3(G,i,j,k)]);
+        double dR_dT, dR_dS;
+        orc_eos_density_derivs(EOS, T_int, S_int, press, &dR_dT, &dR_dS);
+        pbce[ORC_H3(G,i,j,k)] = pbce[ORC_H3(G,i,j,k-1)] + G_Rho0 *
+               ((E3(i,j,k) - E3(i,j,nz+1)) * Ihtot) *
+               (dR_dT*(T[ORC_H3(G,i,j,k)]-T[ORC_H3(G,i,j,k-1)]) +
+                dR_dS*(S[ORC_H3(G,i,j,k)]-S[ORC_H3(G,i,j,k-1)]));
+      }
+    }
+  }
+  /* :839-843 */
+  if (eta) for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+    eta[ORC_H2(G,i,j)] = E3(i,j,1)*G->Z_to_H;
+
+  free(e); free(T_t); free(T_b); free(S_t); free(S_b); free(pa); free(dpa); free(intz_dpa);
+  free(intx_pa); free(intx_dpa); free(inty_pa); free(inty_dpa);
+  return 0;
+}

@@ -1,0 +1,105 @@
+"""EOS + PressureForce_FV_Bouss: the oracle (oracle/pressure_force.c) against the reference's EOS check values
+(tests/golden/eos_check_values.json, from EOS_unit_tests) and hydrostatic-consistency properties; GPU parity of
+libmom6hip against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mom6_amd import _abi, synth
+from helpers import bits_equal, interior
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eos_check_values.json")))
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.mark.parametrize("c", GOLD["cases"], ids=lambda c: c["form"] + c["_line"][:4])
+def test_eos_check_values(oracle, c):
+    E = oracle.eos(c["form"], c.get("Rho_T0_S0", 1000.0), c.get("dRho_dT", -0.2), c.get("dRho_dS", 0.8))
+    rho_ref = GOLD["rho_ref"]
+    rho = oracle.eos_density(E, c["T"], c["S"], c["p"], rho_ref=rho_ref)
+    assert abs(c["rho_check"] - (rho_ref + rho)) < GOLD["rel_tol_eps"] * EPS * (rho_ref + rho)
+    # the anomaly form and the in-situ form agree (test_EOS_consistency's own cross-check)
+    rho2 = oracle.eos_density(E, c["T"], c["S"], c["p"])
+    assert abs((rho_ref + rho) - rho2) < 1e-9
+
+
+def test_eos_derivs_match_finite_differences(oracle):
+    E = oracle.eos("WRIGHT")
+    T, S, p = 10.0, 34.0, 2.0e7
+    dT, dS = oracle.eos_density_derivs(E, T, S, p)
+    fdT = (oracle.eos_density(E, T + 1e-4, S, p) - oracle.eos_density(E, T - 1e-4, S, p)) / 2e-4
+    fdS = (oracle.eos_density(E, T, S + 1e-4, p) - oracle.eos_density(E, T, S - 1e-4, p)) / 2e-4
+    assert abs(dT - fdT) < 1e-6 * abs(dT) and abs(dS - fdS) < 1e-6 * abs(dS)
+
+
+def pgf_case(ni=30, nj=22, nk=6, seed=3, **kw):
+    g = synth.make_grid(ni, nj, nk, seed=seed + 10, **kw)
+    st = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed).items()}
+    return g, st
+
+
+def test_resting_stratified_ocean_has_no_pressure_force(oracle):
+    """Flat interfaces and horizontally uniform T,S in every layer: PFu = PFv = 0 up to roundoff relative to
+    g (the finite-volume form is exactly hydrostatically consistent, Adcroft et al. 2008)."""
+    g = synth.make_grid(20, 16, 5, seed=1, land_frac=0.0, max_depth=4000.0)
+    g.set_metric("bathyT", np.full_like(g.bathyT, 4000.0))
+    shp = g.shape3(_abi.POS_H)
+    h = np.empty(shp); T = np.empty(shp); S = np.empty(shp)
+    dz = np.array([50.0, 150.0, 800.0, 1000.0, 2000.0])
+    for k in range(5):
+        h[k] = dz[k]; T[k] = 20.0 - 4.0 * k; S[k] = 34.0 + 0.2 * k
+    E = oracle.eos("WRIGHT")
+    PFu, PFv, pbce, eta = oracle.pressureforce(g, oracle.pressureforce_cs(g), E, h, T, S)
+    assert np.max(np.abs(interior(g, PFu, _abi.POS_U))) < 1e-12
+    assert np.max(np.abs(interior(g, PFv, _abi.POS_V))) < 1e-12
+    assert np.allclose(interior(g, eta), 0.0, atol=1e-9)
+    assert np.all(interior(g, pbce)[0] > 9.0) and np.all(np.diff(interior(g, pbce), axis=0) > 0)
+
+
+def test_sea_surface_slope_gives_g_times_slope(oracle):
+    g = synth.make_grid(20, 16, 3, seed=1, land_frac=0.0, reentrant_x=False)
+    g.set_metric("bathyT", np.full_like(g.bathyT, 1000.0))
+    shp = g.shape3(_abi.POS_H)
+    x = np.arange(shp[2])[None, :] * np.ones((shp[1], 1))
+    h = np.empty(shp); h[0] = 100.0 + 0.01 * x; h[1] = 300.0; h[2] = 600.0
+    T = np.full(shp, 10.0); S = np.full(shp, 35.0)
+    E = oracle.eos("LINEAR", 1035.0, 0.0, 0.0)
+    PFu, PFv, _, eta = oracle.pressureforce(g, oracle.pressureforce_cs(g, Rho0=1035.0), E, h, T, S)
+    expect = -g.g_Earth * 0.01 * interior(g, g.IdxCu, _abi.POS_U)
+    got = interior(g, PFu, _abi.POS_U)[0]
+    assert np.allclose(got[:, 1:-1], expect[:, 1:-1], rtol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["WRIGHT", "LINEAR"])
+@pytest.mark.parametrize("opts", [(True, False), (False, True)])
+def test_gpu_parity(oracle, form, opts):
+    import torch
+    from mom6_amd.pressure_force import PressureForce, PressureForce_init, EOS_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    extrap, massw = opts
+    for (ni, nj, nk, topo) in [(70, 21, 5, (True, False)), (44, 40, 2, (True, True)), (10, 8, 8, (False, False)),
+                               (130, 9, 3, (True, False))]:
+        g, st = pgf_case(ni, nj, nk, seed=ni, reentrant_x=topo[0], reentrant_y=topo[1])
+        E = oracle.eos(form, 1000.0, -0.2, 0.8)
+        cs = oracle.pressureforce_cs(g, boundary_extrap=extrap, useMassWghtInterp=massw)
+        rng = np.random.default_rng(ni)
+        for p_atm in (None, np.ascontiguousarray(1.0e5 + 500.0 * rng.standard_normal(g.shape2(_abi.POS_H)))):
+            ref = oracle.pressureforce(g, cs, E, st["h"], st["T"], st["S"], p_atm)
+            dg = DeviceGrid(g)
+            CS = PressureForce_init(g, boundary_extrap=extrap, useMassWghtInterp=massw)
+            EOS = EOS_init(form, 1000.0, -0.2, 0.8)
+            for resident in (False, True):
+                X = (lambda a: None if a is None else torch.from_numpy(a.copy()).cuda()) if resident else \
+                    (lambda a: None if a is None else a.copy())
+                PFu, PFv = X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V))
+                pbce, eta = X(g.zeros3(_abi.POS_H)), X(g.zeros2(_abi.POS_H))
+                PressureForce(X(st["h"]), (X(st["T"]), X(st["S"]), EOS), PFu, PFv, dg, CS, p_atm=X(p_atm), pbce=pbce, eta=eta)
+                dg.sync()
+                N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+                for name, a, b in (("PFu", ref[0], PFu), ("PFv", ref[1], PFv), ("pbce", ref[2], pbce), ("eta", ref[3], eta)):
+                    assert bits_equal(a, N(b)), (form, opts, (ni, nj, nk), p_atm is not None, resident, name,
+                                                 np.argwhere(a != N(b))[:3])
+            dg.close()
