@@ -52,23 +52,41 @@ def shape_of(name):
 
 
 class Step:
-    """The hot-path step on one tile, state resident in HBM."""
+    """The hot-path step on one tile of the global grid, state resident in HBM.  `dom` is the tile's Domain
+    (mom6_amd/domains.py); every rank generates the same global synthetic state on its own GPU, keeps the
+    window of its tile and frees the rest, so N ranks step exactly the problem one rank steps."""
 
-    def __init__(self, grid, device, scheme, rank=0):
+    def __init__(self, gg, dom, device, scheme):
         from mom6_amd import _abi, synth
         from mom6_amd.ale import initialize_remapping
         from mom6_amd.continuity import BT_cont_type, continuity_PPM_init
         from mom6_amd.coriolis_adv import CoriolisAdv_init
         from mom6_amd.pressure_force import EOS_init, PressureForce_init
         from mom6_amd.tracer_advect import DeviceGrid, tracer_advect_init
-        self.g = grid
+        self.dom = dom
+        grid = self.g = dom.tile_grid(gg) if dom.nranks > 1 else gg
         self.dg = DeviceGrid(grid, device=device.index)
+        if dom.nranks > 1:
+            self.dg.set_domain(dom)
         dev = str(device)
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+
+        def tile(state, pos_of):
+            out = {}
+            for k, v in state.items():
+                pos = pos_of(k)
+                out[k] = [dom.cut(t, pos).clone() for t in v] if isinstance(v, list) else dom.cut(v, pos).clone()
+            return out
         Z = lambda pos, k3=True: torch.zeros(grid.shape3(pos) if k3 else grid.shape2(pos), dtype=torch.float64, device=dev)
         # tracer-advection inputs (h_end, uhtr, vhtr, tracers): hot_frac = about one cell in 50 000 needs the
         # flux limiter and with it a second, sparse iteration
-        self.adv = synth.make_advection_state(grid, ntr=NTR, seed=1 + rank, device=dev, hot_frac=HOT_FRAC)
-        self.dyn = synth.make_dynamics_state(grid, seed=11 + rank, device=dev)
+        adv = synth.make_advection_state(gg, ntr=NTR, seed=1, device=dev, hot_frac=HOT_FRAC)
+        self.adv = tile(adv, lambda k: {"uhtr": U, "vhtr": V}.get(k, H))
+        del adv
+        dyn = synth.make_dynamics_state(gg, seed=11, device=dev)
+        self.dyn = tile(dyn, lambda k: {"u": U, "uh": U, "v": V, "vh": V}.get(k, H))
+        del dyn
+        torch.cuda.empty_cache()
         d = self.dyn
         kk = (torch.arange(grid.nk, device=dev, dtype=torch.float64) + 0.5) / grid.nk
         self.vru = torch.clamp(1.0 - 0.8 * kk[:, None, None] ** 4 + 0 * d["u"], 0.05, 1.0).contiguous()
@@ -109,19 +127,32 @@ class Step:
         from mom6_amd.tracer_advect import advect_tracer
         d, dg = self.dyn, self.dg
         vr = dict(visc_rem_u=self.vru, visc_rem_v=self.vrv)
+        H, U, V = 0, 1, 2      # _abi.POS_H, POS_U, POS_V
+
+        def gp(fields, pos, halo):
+            # do_group_pass: one tile = the library's own wrap kernels; N tiles = torch.distributed (RCCL)
+            if self.dom.nranks == 1:
+                return lambda: dg.halo_update(fields, pos)
+            return lambda: self.dom.pass_var(fields, pos, halo=halo)
+
         out = [
             ("PressureForce", lambda: PressureForce(d["h"], (d["T"], d["S"], self.eos), self.PFu, self.PFv, dg, self.pgf_cs,
                                                     pbce=self.pbce, eta=self.eta)),
+            ("pass_eta", gp([self.eta], [H], 1)),                                                        # :610
             ("continuity[BT_cont]", lambda: continuity(d["u"], d["v"], d["h"], self.hp, self.uh, self.vh, DT, dg,
                                                        self.cont_cs, BT_cont=self.bt, **vr)),
+            ("pass_visc_rem+uvp", gp([self.vru, self.vrv, d["u"], d["v"]], [U, V, U, V], 3)),           # :747,:751
             ("continuity[uhbt+BT_cont]", lambda: continuity(d["u"], d["v"], d["h"], self.hp, self.uh, self.vh, DT, dg,
                                                             self.cont_cs, uhbt=self.uhbt, vhbt=self.vhbt, u_cor=self.u_av,
                                                             v_cor=self.v_av, BT_cont=self.bt, **vr)),
+            ("pass_hp_uv", gp([self.hp, self.u_av, self.v_av, self.uh, self.vh], [H, U, V, U, V], 2)),   # :763
             ("CorAdCalc", lambda: CorAdCalc(self.u_av, self.v_av, self.hp, self.uh, self.vh, self.CAu, self.CAv, None, dg,
                                             self.cor_cs)),
+            ("pass_visc_rem+uv", gp([self.vru, self.vrv, d["u"], d["v"]], [U, V, U, V], 3)),            # :1004,:1008
             # the reference updates h in place here (:1015); a separate output keeps the bench state stationary
             ("continuity[uhbt]", lambda: continuity(d["u"], d["v"], d["h"], self.h2, self.uh, self.vh, DT, dg, self.cont_cs,
                                                     uhbt=self.uhbt, vhbt=self.vhbt, u_cor=self.u_av, v_cor=self.v_av, **vr)),
+            ("pass_h+av_uvh", gp([self.h2, self.u_av, self.v_av, self.uh, self.vh], [H, U, V, U, V], 3)),  # :1018,:1027
             ("CorAdCalc[pred]", lambda: CorAdCalc(self.u_av, self.v_av, self.h2, self.uh, self.vh, self.CAu, self.CAv, None, dg,
                                                   self.cor_cs)),
         ]
@@ -202,20 +233,30 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # MOM6HIP_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("MOM6HIP_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from mom6_amd import synth
+    from mom6_amd.domains import Domain
 
     NI, NJ, NK = shape_of(a.workload)
-    # N>1: independent replicas of the same tile per rank until the RCCL halo exchange lands
-    # (DESIGN.md "Multi-GPU"); scaling is then weak by construction.
+    # N>1: the global grid is cut into `world` latitude bands (layout 1 x N, the x direction stays a local wrap);
+    # halos travel between neighbouring GPUs through the reference's group passes (DESIGN.md "Multi-GPU").
+    # The total work is fixed: strong scaling.
     grid = synth.make_grid(NI, NJ, NK, seed=20241020)
-    S = Step(grid, device, a.scheme, rank)
+    dom = Domain(NI, NJ, (1, world), rank, grid.halo, grid.reentrant_x, grid.reentrant_y)
+    S = Step(grid, dom, device, a.scheme)
     cells = NI * NJ * NK
 
     def barrier():
@@ -235,17 +276,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     sec_per_step = elapsed / a.steps
-    sypd = world * DT / sec_per_step / 365.0      # whole job: `world` replicas of the tile
+    sypd = DT / sec_per_step / 365.0      # whole job: all ranks together advance the one global grid
     spa = S.steps_per_advect
     out = {
         "metric": "simulated-years/day (SYPD) of the hot-path kernels built so far",
         "value": sypd, "unit": "SYPD", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / cells,
         "config": {
@@ -258,11 +299,12 @@ def main():
             "not_yet_in_step": ["btstep (2/step)", "RK2 momentum-update sweeps", "ALE regrid + velocity remap",
                                 "vertvisc / horizontal_viscosity (SURVEY 8f)"],
             "advect_iterations_last_call": None if S.last_adv is None else int(S.last_adv.iterations),
-            "parallelism": "1 tile per GPU" if world == 1 else f"{world} independent tile replicas",
+            "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
+                                                               "group passes over RCCL p2p",
         },
     }
 
-    if rank == 0 and not a.no_roofline:
+    if world == 1 and not a.no_roofline:
         # per-call device time, HIP events on the stream the library launches on (the null stream, which is
         # also torch's current stream here)
         comp = {}

@@ -111,6 +111,19 @@ int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint6
 int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,
                         const int32_t *nk_each, int32_t nfields);
 
+/* Multi-tile domains.  The library itself never talks to another process: when the tile has neighbours,
+ * the host registers the two collective operations of MOM_domains / MOM_coms that happen INSIDE library
+ * calls (the group pass and sum_across_PEs in advect_tracer, src/tracer/MOM_tracer_advect.F90:206,305).
+ * In this repository they are torch.distributed point-to-point / all-reduce over RCCL (mom6_amd/domains.py);
+ * in a MOM6 executable they would be MOM6's own do_group_pass / sum_across_PEs on the device buffers.
+ *   halo_fn: fill the halos of `nfields` DEVICE arrays (positions `pos`, layer counts `nk`); the library has
+ *            synchronised its stream before the call and continues on it after the call returns.
+ *   sum_fn:  element-wise sum over all PEs of `n` HOST int32 values, in place.
+ * Passing NULLs restores the one-tile behaviour. */
+typedef int (*mom6hip_halo_fn)(void *user, double *const *fields, const int32_t *pos, const int32_t *nk, int32_t nfields);
+typedef int (*mom6hip_sum_fn)(void *user, int32_t *values, int32_t n);
+int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mom6hip_sum_fn sum_fn, void *user);
+
 /* ---- MOM_tracer_advect -------------------------------------------------------------------- */
 
 /* tracer_advect_CS, src/tracer/MOM_tracer_advect.F90:30-40 */

@@ -15,7 +15,7 @@ EXPORTS = (
     "mom6hip_init", "mom6hip_last_error", "mom6hip_grid_create", "mom6hip_grid_destroy",
     "mom6hip_sync", "mom6hip_malloc", "mom6hip_free", "mom6hip_sync_to_device",
     "mom6hip_sync_to_host", "mom6hip_halo_update", "mom6hip_advect_tracer", "mom6hip_set_timing",
-    "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_calculate_density",
+    "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
 )
 
 
@@ -58,6 +58,7 @@ def lib():
                                                      + [C.c_void_p] * 8 + [C.c_int32])
         L.mom6hip_calculate_density.argtypes = ([C.c_void_p, C.POINTER(_abi.EOS)] + [C.c_void_p] * 4
                                                 + [C.c_int64, C.c_int32, C.c_double, C.c_int32])
+        L.mom6hip_set_domain_callbacks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for n in ("grid", "tracer_advect_cs", "advect_stats", "advect_timing"):
             getattr(L, f"mom6hip_abi_sizeof_{n}").restype = C.c_uint64
         L.mom6hip_abi_offsetof_grid_mask2dT.restype = C.c_uint64

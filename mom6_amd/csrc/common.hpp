@@ -89,6 +89,10 @@ struct mom6hip_ctx {
   m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   int *h_domore_k = nullptr;    // pinned host mirror of domore_k
+  // multi-tile collectives provided by the host (null on a one-tile domain)
+  mom6hip_halo_fn halo_cb = nullptr;
+  mom6hip_sum_fn sum_cb = nullptr;
+  void *cb_user = nullptr;
   // timing
   bool timing = false;
   mom6hip_advect_timing_t adv_timing = {};

@@ -123,6 +123,13 @@ int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint6
   return 0;
 }
 
+int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mom6hip_sum_fn sum_fn, void *user) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_set_domain_callbacks: null context");
+  M6_REQUIRE((halo_fn == nullptr) == (sum_fn == nullptr), "mom6hip_set_domain_callbacks: give both callbacks or neither");
+  ctx->halo_cb = halo_fn; ctx->sum_cb = sum_fn; ctx->cb_user = user;
+  return 0;
+}
+
 int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_set_timing: null context");
   ctx->timing = enable != 0;

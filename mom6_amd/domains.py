@@ -1,0 +1,181 @@
+"""Horizontal domain decomposition and halo exchange: the part of MOM_domains the hot path needs
+(reference: src/framework/MOM_domains.F90:66 MOM_domains_init; config_src/infra/FMS2/MOM_domain_infra.F90:130
+MOM_domain_type, :171 pass_var, :660 pass_vector, :1141 do_group_pass; MOM_coms_infra.F90:42-66 sum/min/max
+across PEs).
+
+One process per GPU, one tile per process.  The transport is torch.distributed point-to-point
+(backend "nccl" = RCCL over xGMI on the GPU node; "gloo" for the CPU tests), not a translation of FMS's MPI
+code: every group pass is, per direction, one batch of isend/irecv with the (at most two) neighbours, with
+the E/W exchange done before the N/S exchange so that corners arrive without extra messages.  With one tile
+in a re-entrant direction the wrap-around is a local copy.
+
+Semantics kept from the reference: data domain = compute domain + halo; symmetric
+memory adds one extra column/row of u/v/q points at the SW edge that belongs to the compute domain; halos
+beyond a closed edge are left untouched; C-grid vector components are exchanged like scalars at their own
+staggering (no tripolar fold here).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _abi
+from .grid import Grid
+
+
+def compute_extent(n_global: int, ndiv: int):
+    """Start (0-based) and size of each of `ndiv` blocks of `n_global` points, as even as possible with the
+    remainder given to the first blocks.  (FMS mpp_compute_extent, which the reference uses through
+    MOM_domains, is not vendored; any partition gives the same answers because halo updates carry no
+    arithmetic -- the reference's own test.layout criterion.)"""
+    base, rem = divmod(n_global, ndiv)
+    sizes = [base + (1 if p < rem else 0) for p in range(ndiv)]
+    starts = [sum(sizes[:p]) for p in range(ndiv)]
+    return starts, sizes
+
+
+class Domain:
+    """MOM_domain_type for one tile of an (npi x npj) layout of a global (NI x NJ) grid."""
+
+    def __init__(self, NI, NJ, layout=(1, 1), rank=0, halo=4, reentrant_x=True, reentrant_y=False, group=None):
+        self.NI, self.NJ = int(NI), int(NJ)
+        self.npi, self.npj = int(layout[0]), int(layout[1])
+        self.nranks = self.npi * self.npj
+        self.rank = int(rank)
+        self.halo = int(halo)
+        self.reentrant_x, self.reentrant_y = bool(reentrant_x), bool(reentrant_y)
+        self.group = group
+        self.pi, self.pj = self.rank % self.npi, self.rank // self.npi          # PE numbering: i fastest
+        self.i_starts, self.i_sizes = compute_extent(self.NI, self.npi)
+        self.j_starts, self.j_sizes = compute_extent(self.NJ, self.npj)
+        self.ni, self.nj = self.i_sizes[self.pi], self.j_sizes[self.pj]
+        self.i0, self.j0 = self.i_starts[self.pi], self.j_starts[self.pj]      # global 0-based index of (isc, jsc)
+        if min(self.i_sizes) < self.halo or min(self.j_sizes) < self.halo:
+            raise ValueError("MOM_domains: a tile is narrower than the halo")
+
+    # ---- neighbours ---------------------------------------------------------------------------------
+    def _nbr(self, dpi, dpj):
+        """Rank of the neighbour tile in direction (dpi, dpj), or None across a closed edge."""
+        pi, pj = self.pi + dpi, self.pj + dpj
+        if pi < 0 or pi >= self.npi:
+            if not self.reentrant_x:
+                return None
+            pi %= self.npi
+        if pj < 0 or pj >= self.npj:
+            if not self.reentrant_y:
+                return None
+            pj %= self.npj
+        return pj * self.npi + pi
+
+    # ---- tile grid ------------------------------------------------------------------------------------
+    def tile_grid(self, gg: Grid) -> Grid:
+        """The Grid of this tile, with metrics cut out of the one-tile global grid `gg` (whose halos are
+        already wrapped/closed), so every rank holds the same numbers a one-tile run holds there."""
+        if gg.ni != self.NI or gg.nj != self.NJ or gg.halo != self.halo:
+            raise ValueError("tile_grid: global grid does not match the domain")
+        t = Grid(ni=self.ni, nj=self.nj, nk=gg.nk, halo=self.halo,
+                 reentrant_x=self.reentrant_x and self.npi == 1, reentrant_y=self.reentrant_y and self.npj == 1,
+                 first_direction=gg.first_direction, Angstrom_H=gg.Angstrom_H, H_to_Z=gg.H_to_Z, Z_to_H=gg.Z_to_H,
+                 g_Earth=gg.g_Earth, Rho0=gg.Rho0)
+        for name, a in gg.metrics.items():
+            t.set_metric(name, self.cut(a, gg.pos_of(name)))
+        return t
+
+    def cut(self, a, pos):
+        """The data-domain window of this tile out of a one-tile global array (numpy or torch), any rank."""
+        xs = 1 if pos in (_abi.POS_U, _abi.POS_Q) else 0
+        ys = 1 if pos in (_abi.POS_V, _abi.POS_Q) else 0
+        h = self.halo
+        sl = (slice(self.j0, self.j0 + self.nj + 2 * h + ys), slice(self.i0, self.i0 + self.ni + 2 * h + xs))
+        w = a[(..., *sl)]
+        return np.ascontiguousarray(w) if isinstance(w, np.ndarray) else w.contiguous()
+
+    # ---- halo update ----------------------------------------------------------------------------------
+    def _ranges(self, pos):
+        xs = 1 if pos in (_abi.POS_U, _abi.POS_Q) else 0
+        ys = 1 if pos in (_abi.POS_V, _abi.POS_Q) else 0
+        return xs, ys
+
+    def pass_var(self, fields, positions, halo=None):
+        """do_group_pass: fill the halos of `fields` (torch tensors, last two axes (j,i), allocated with this
+        tile's data-domain shape) from the neighbours / the tile itself."""
+        import torch.distributed as dist
+        h = self.halo
+        w = h if halo is None else min(int(halo), h)
+        backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else None
+        stage = backend == "gloo"      # gloo moves host memory only
+
+        def exchange(direction):
+            ops, recvs, keep = [], [], []
+            for f, pos in zip(fields, positions):
+                xs, ys = self._ranges(pos)
+                if direction == "x":
+                    n, s, lo_nbr, hi_nbr, ax = self.ni, xs, self._nbr(-1, 0), self._nbr(+1, 0), -1
+                    rows = slice(h, h + self.nj + ys)          # compute rows only; the y pass brings the corners
+                else:
+                    n, s, lo_nbr, hi_nbr, ax = self.nj, ys, self._nbr(0, -1), self._nbr(0, +1), -2
+                    rows = slice(None)
+
+                def sl(a, b):
+                    idx = [slice(None)] * f.dim()
+                    idx[ax] = slice(a, b)
+                    if direction == "x":
+                        idx[-2] = rows
+                    return tuple(idx)
+
+                # low halo [h-w, h) <- low neighbour's [n+h-w, n+h)  ;  high halo [h+n+s, h+n+s+w) <- high neighbour's [h+s, h+s+w)
+                lo_halo, hi_halo = sl(h - w, h), sl(h + n + s, h + n + s + w)
+                to_hi, to_lo = sl(n + h - w, n + h), sl(h + s, h + s + w)
+                if hi_nbr == self.rank or lo_nbr == self.rank:
+                    # one tile in a re-entrant direction: local wrap
+                    f[hi_halo] = f[to_lo]
+                    f[lo_halo] = f[to_hi]
+                    continue
+                # Messages between one pair of ranks are matched in posting order.  When both neighbours are
+                # the same rank (two tiles, re-entrant) the peer's first message is its "to-high" block, which
+                # lands in my LOW halo: post [send->hi, recv<-lo, send->lo, recv<-hi].
+                plan = [("s", hi_nbr, to_hi), ("r", lo_nbr, lo_halo), ("s", lo_nbr, to_lo), ("r", hi_nbr, hi_halo)]
+                for kind, nbr, sl_ in plan:
+                    if nbr is None:
+                        continue
+                    if kind == "s":
+                        sbuf = f[sl_].contiguous()
+                        if stage and sbuf.is_cuda:
+                            sbuf = sbuf.cpu()
+                        keep.append(sbuf)
+                        ops.append(dist.P2POp(dist.isend, sbuf, nbr, group=self.group))
+                    else:
+                        rbuf = torch.empty(f[sl_].shape, dtype=f.dtype, device="cpu" if (stage and f.is_cuda) else f.device)
+                        ops.append(dist.P2POp(dist.irecv, rbuf, nbr, group=self.group))
+                        recvs.append((f, sl_, rbuf))
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+                for f, recv_sl, rbuf in recvs:
+                    f[recv_sl] = rbuf.to(f.device)
+
+        exchange("x")
+        exchange("y")
+
+    # ---- reductions (MOM_coms) -------------------------------------------------------------------------
+    def sum_across_PEs(self, t: torch.Tensor):
+        import torch.distributed as dist
+        if self.nranks > 1:
+            backend = dist.get_backend(self.group)
+            if backend == "gloo" and t.is_cuda:
+                c = t.cpu(); dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group); t.copy_(c)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def min_across_PEs(self, t: torch.Tensor):
+        import torch.distributed as dist
+        if self.nranks > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return t
+
+    def max_across_PEs(self, t: torch.Tensor):
+        import torch.distributed as dist
+        if self.nranks > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t

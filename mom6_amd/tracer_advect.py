@@ -53,6 +53,53 @@ class DeviceGrid:
         nks = (C.c_int32 * n)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
         check(lib().mom6hip_halo_update(self.handle, ptrs, pos, nks, n), "mom6hip_halo_update")
 
+    def set_domain(self, domain):
+        """Attach a multi-tile Domain (mom6_amd/domains.py): the group pass and sum_across_PEs that happen
+        inside library calls are then done by the domain over torch.distributed."""
+        import torch
+        HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32)
+        SUM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int32)
+        grid = self.grid
+
+        class _DevArray:      # a device array described to torch through __cuda_array_interface__
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                                 "version": 2, "strides": None}
+
+        def halo(user, fields, pos, nk, n):
+            try:
+                ts, ps = [], []
+                for f in range(n):
+                    shp = grid.shape2(pos[f]) if nk[f] == 1 else grid.shape3(pos[f], nk[f])
+                    ts.append(torch.as_tensor(_DevArray(fields[f], shp), device="cuda")); ps.append(int(pos[f]))
+                domain.pass_var(ts, ps)
+                torch.cuda.synchronize()
+                return 0
+            except Exception as e:      # never let an exception cross the C boundary
+                import traceback; traceback.print_exc()
+                return 1
+
+        def sumf(user, values, n):
+            try:
+                t = torch.tensor([values[q] for q in range(n)], dtype=torch.int32)
+                if domain.nranks > 1:
+                    import torch.distributed as dist
+                    if dist.get_backend(domain.group) == "nccl":
+                        t = t.cuda()
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=domain.group)
+                    t = t.cpu()
+                for q in range(n):
+                    values[q] = int(t[q])
+                return 0
+            except Exception:
+                import traceback; traceback.print_exc()
+                return 1
+
+        self._cb = (HALO(halo), SUM(sumf))      # keep the thunks alive
+        check(lib().mom6hip_set_domain_callbacks(self.handle, C.cast(self._cb[0], C.c_void_p),
+                                                 C.cast(self._cb[1], C.c_void_p), None), "mom6hip_set_domain_callbacks")
+        self.domain = domain
+
     def close(self):
         if self._h:
             lib().mom6hip_grid_destroy(self._h)

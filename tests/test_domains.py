@@ -1,0 +1,57 @@
+"""MOM_domains: tile extents, and the N>1 path on two processes over gloo -- Domain.pass_var against the
+one-tile halo update of the oracle (bitwise), sum_across_PEs; on the GPU box the reference's test.layout
+criterion for advect_tracer (two tiles == one tile, bitwise)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from mom6_amd.domains import Domain, compute_extent
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_compute_extent_partitions():
+    for n, d in ((1080, 8), (1440, 4), (23, 2), (17, 3)):
+        starts, sizes = compute_extent(n, d)
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1 and starts[0] == 0
+        assert all(starts[p + 1] == starts[p] + sizes[p] for p in range(d - 1))
+
+
+def test_neighbours():
+    d = Domain(1440, 1080, (1, 8), rank=0, reentrant_x=True, reentrant_y=False)
+    assert d._nbr(0, -1) is None and d._nbr(0, 1) == 1 and d._nbr(1, 0) == 0 and d._nbr(-1, 0) == 0
+    d = Domain(1440, 1080, (2, 4), rank=7, reentrant_x=True, reentrant_y=False)
+    assert (d.pi, d.pj) == (1, 3) and d._nbr(1, 0) == 6 and d._nbr(0, 1) is None and d._nbr(0, -1) == 5
+
+
+@pytest.mark.parametrize("layout", [(1, 2), (2, 1)])
+@pytest.mark.parametrize("topo", [(True, False), (True, True), (False, False)])
+def test_pass_var_two_ranks_gloo(tmp_path, layout, topo):
+    import torch.multiprocessing as mp
+    from mp_workers import halo_worker
+    mp.spawn(halo_worker, args=(2, free_port(), layout, topo[0], topo[1], str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [(1, 2), (2, 1)])
+@pytest.mark.parametrize("scheme", ["PPM:H3", "PLM"])
+def test_advect_tracer_layout_independence(tmp_path, layout, scheme):
+    """Two processes share cuda:0 and exchange halos over gloo (RCCL cannot put two ranks on one device)."""
+    import torch.multiprocessing as mp
+    from mp_workers import advect_layout_worker
+    mp.spawn(advect_layout_worker, args=(2, free_port(), layout, scheme, str(tmp_path)), nprocs=2, join=True)
+    glob = np.load(tmp_path / "global.npz")
+    ntr = 3
+    for r in range(2):
+        t = np.load(tmp_path / f"tile{r}.npz")
+        i0, j0, ni, nj, its = t["ij"]
+        assert its == glob["it"][0]
+        for m in range(ntr):
+            a = t[f"arr_{m}"]; b = glob[f"arr_{m}"][:, j0:j0 + nj, i0:i0 + ni]
+            assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, scheme, r, m)
