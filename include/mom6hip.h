@@ -305,6 +305,96 @@ int mom6hip_calculate_density(mom6hip_ctx_t *ctx, const mom6hip_eos_t *eos, cons
                               const double *pressure, double *rho, int64_t n, int32_t use_rho_ref, double rho_ref,
                               int32_t memspace);
 
+/* ---- MOM_barotropic ------------------------------------------------------------------------- */
+
+/* BT_THICK_SCHEME (src/core/MOM_barotropic.F90:400-403; default FROM_BT_CONT when USE_BT_CONT_TYPE) */
+#define MOM6HIP_BT_HARMONIC     1
+#define MOM6HIP_BT_ARITHMETIC   2
+#define MOM6HIP_BT_HYBRID       3
+#define MOM6HIP_BT_FROM_BT_CONT 4
+
+/*
+ * barotropic_CS, src/core/MOM_barotropic.F90:104-332: the run-time parameters of barotropic_init (:4376) that
+ * the provided branch reads, and the state the reference keeps in the control structure between calls.
+ * The barotropic domain has the halo of the grid (BTHALO = 0, the default: clone_MOM_domain with min_halo 0,
+ * :4741), so every 2-D array here has the shape of the grid's h/u/v/q arrays.
+ * The switches in `unsupported` must all be 0 (their reference defaults); btstep fails with an error otherwise.
+ * The array members are caller-owned, in the memory space of the call that uses them.
+ */
+typedef struct mom6hip_barotropic_cs {
+  double dtbt;                 /* CS%dtbt: the barotropic time step [s] (set_dtbt or DTBT > 0) */
+  double dtbt_max;             /* CS%dtbt_max (set_dtbt) */
+  double dtbt_fraction;        /* -DTBT when DTBT < 0 (default 0.98) */
+  double bebt;                 /* BEBT (0.1) */
+  double dt_bt_filter;         /* DT_BT_FILTER (-0.25) */
+  double vel_underflow;        /* VEL_UNDERFLOW (0) */
+  double G_extra;              /* G_BT_EXTRA (0) */
+  double BT_Coriolis_scale;    /* BT_CORIOLIS_SCALE (1) */
+  double Z_ref;                /* G%Z_ref, REFERENCE_HEIGHT (0) */
+  double reserved0[7];
+  int32_t Sadourny;            /* SADOURNY (1) */
+  int32_t linearized_BT_PV;    /* LINEARIZED_BT_CORIOLIS (1) */
+  int32_t strong_drag;         /* BT_STRONG_DRAG (0) */
+  int32_t visc_rem_u_uh0;      /* BT_USE_VISC_REM_U_UH0 (0) */
+  int32_t adjust_BT_cont;      /* ADJUST_BT_CONT (0) */
+  int32_t use_wide_halos;      /* BT_USE_WIDE_HALOS (1) */
+  int32_t hvel_scheme;         /* MOM6HIP_BT_* */
+  int32_t nstep_last;          /* CS%nstep_last (out) */
+  /* INTEGRAL_BT_CONTINUITY, BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION, GRADUAL_BT_ICS,
+   * BT_NONLIN_STRESS, DYNAMIC_SURFACE_PRESSURE, BT_LINEAR_WAVE_DRAG, CLIP_BT_VELOCITY, CALCULATE_SAL,
+   * BT_USE_OLD_CORIOLIS_BRACKET_BUG, BAROTROPIC_ANSWER_DATE < 20190101 */
+  int32_t unsupported[12];
+  int32_t reserved1[4];
+  double *frhatu, *frhatv;     /* 3-D u / v: layer weights (btcalc) */
+  double *eta_cor;             /* 2-D h: mass source over a baroclinic step (bt_mass_source) */
+  double *IDatu, *IDatv;       /* 2-D u / v: inverse total depth at velocity points (barotropic_init :5070-5087) */
+  double *ubtav, *vbtav;       /* 2-D u / v: time-filtered barotropic velocities (btstep) */
+  double *q_D;                 /* 2-D q: f / D with the resting depth (linearized_BT_PV; barotropic_init :4838) */
+  double *D_u_Cor, *D_v_Cor;   /* 2-D u / v: resting depths at velocity points */
+  void *reserved2[6];
+} mom6hip_barotropic_cs_t;
+
+/* The time-invariant arrays of barotropic_init (:4826-4858, :5070-5087): IDatu, IDatv, q_D, D_u_Cor, D_v_Cor
+ * (with their halos); zeroes frhatu, frhatv, eta_cor, ubtav, vbtav.  Metrics needed: bathyT, areaT, mask2dT,
+ * mask2dCu, mask2dCv, CoriolisBu. */
+int mom6hip_barotropic_init(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, int32_t memspace);
+
+/* btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC)              src/core/MOM_barotropic.F90:3394
+ * h_u / h_v may be NULL; OBC must not be associated. */
+int mom6hip_btcalc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *h_u,
+                   const double *h_v, int32_t may_use_default, int32_t memspace);
+
+/* bt_mass_source(h, eta, set_cor, G, GV, CS)                         src/core/MOM_barotropic.F90:4318 */
+int mom6hip_bt_mass_source(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *eta,
+                           int32_t set_cor, int32_t memspace);
+
+/* set_dtbt(G, GV, US, CS, eta, pbce, BT_cont, gtot_est, SSH_add)     src/core/MOM_barotropic.F90:2801
+ * Sets cs->dtbt_max to the maximum stable step OF THIS TILE and cs->dtbt = dtbt_fraction * dtbt_max; with more
+ * than one tile the caller applies min_across_PEs to dtbt_max (:2915) and rescales.  pbce or gtot_est is used
+ * (pbce may be NULL); BT_cont may be NULL. */
+int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *pbce,
+                     const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add, int32_t memspace);
+
+/*
+ * btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_in, U_Cor, V_Cor, accel_layer_u,
+ *        accel_layer_v, eta_out, uhbtav, vhbtav, G, GV, US, CS, visc_rem_u, visc_rem_v, SpV_avg, ADp, OBC, BT_cont,
+ *        eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav)    src/core/MOM_barotropic.F90:423
+ * forces%taux / forces%tauy are passed as taux, tauy [R L Z T-2] together with RZ_to_H = GV%RZ_to_H.
+ * Optional / pointer arguments are NULL when absent: BT_cont, eta_PF_start, taux_bot + tauy_bot,
+ * uh0 + vh0 + u_uh0 + v_vh0, etaav.  OBC must not be associated (SpV_avg, ADp are not read).
+ * eta_out may be the same array as eta_in.
+ * The one transcendental of the routine, bt_rem = av_rem ** (1/nstep) (:1529), is evaluated with a correctly
+ * rounded pow; the reference's is the libm pow of its build (DESIGN.md "btstep").
+ */
+int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *U_in, const double *V_in,
+                   const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v,
+                   const double *taux, const double *tauy, double RZ_to_H, const double *pbce,
+                   const double *eta_PF_in, const double *U_Cor, const double *V_Cor, double *accel_layer_u,
+                   double *accel_layer_v, double *eta_out, double *uhbtav, double *vhbtav,
+                   const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
+                   const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
+                   const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav, int32_t memspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,15 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     mCv = np.zeros((njh + 1, nih)); mCv[1:njh, :] = mT[:-1, :] * mT[1:, :]
     mBu = np.zeros((njh + 1, nih + 1))
     mBu[1:njh, 1:nih] = mT[:-1, :-1] * mT[:-1, 1:] * mT[1:, :-1] * mT[1:, 1:]
+    # the outermost face / corner points of the symmetric data domain have no h-neighbour on one side inside the
+    # array; in a re-entrant direction they are the periodic image of an interior point (what MOM6's halo update of
+    # the grid metrics gives), elsewhere they stay closed
+    if reentrant_x:
+        for m in (mCu, mBu):
+            m[:, 0] = m[:, ni]; m[:, -1] = m[:, -1 - ni]
+    if reentrant_y:
+        for m in (mCv, mBu):
+            m[0, :] = m[nj, :]; m[-1, :] = m[-1 - nj, :]
 
     def inv(a):
         out = np.zeros_like(a)

@@ -13,6 +13,9 @@
  *     src/tracer/MOM_tracer_advect.F90 cannot be built here without stand-ins for FMS-backed modules.
  *     It is checked through the invariants the reference's own test-suite relies on instead
  *     (conservation, x/y rotation equivalence, layout independence).
+ *   - CorAdCalc, continuity_PPM, PressureForce_FV assembly, btstep: PARITY UNPINNED for the same reason
+ *     (invariants in tests/: energy / enstrophy conservation, transport matching, hydrostatic consistency,
+ *     barotropic mass budget).
  *
  * Build: gcc -O2 -ffp-contract=off (no FMA contraction, so the evaluation is the source's explicit
  * parenthesisation in IEEE fp64, the same as the HIP build).
@@ -110,6 +113,22 @@ void orc_ale_plm_edge_values(const mom6hip_grid_t *G, const double *h, const dou
 int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
                                const double *h, const double *T, const double *S, const double *p_atm,
                                double *PFu, double *PFv, double *pbce, double *eta);
+
+/* ---- MOM_barotropic (oracle/barotropic.c) ----------------------------------------------------- */
+double orc_cr_pow(double x, double y);   /* correctly rounded x**y, 0 < x <= 1, 0 < y <= 1 */
+int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS);
+int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
+               const double *h_v, int may_use_default);
+int orc_bt_mass_source(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *eta, int set_cor);
+int orc_set_dtbt(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *pbce, const mom6hip_bt_cont_t *BT_cont,
+                 double gtot_est, double SSH_add);
+int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *U_in, const double *V_in,
+               const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux,
+               const double *tauy, double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor,
+               const double *V_Cor, double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav,
+               double *vhbtav, const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
+               const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
+               const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav);
 
 #ifdef __cplusplus
 }

@@ -284,3 +284,77 @@ def pressureforce(grid, cs, E, h, T, S, p_atm=None, want_pbce=True, want_eta=Tru
     if rc:
         raise RuntimeError("orc_pressureforce_fv_bouss: unsupported configuration")
     return PFu, PFv, pbce, eta
+
+
+# ---- MOM_barotropic -------------------------------------------------------------------------------------
+def cr_pow(x, y):
+    L = lib(); L.orc_cr_pow.argtypes = [C.c_double, C.c_double]; L.orc_cr_pow.restype = C.c_double
+    return L.orc_cr_pow(float(x), float(y))
+
+
+def barotropic_cs(grid, dtbt=0.0, hvel_scheme="FROM_BT_CONT", **kw):
+    """barotropic_CS with the defaults of barotropic_init (MOM_barotropic.F90:4376) and numpy state arrays.
+    Returns (struct, arrays); keep `arrays` alive as long as the struct is used."""
+    d = dict(dtbt_max=0.0, dtbt_fraction=0.98, bebt=0.1, dt_bt_filter=-0.25, vel_underflow=0.0, G_extra=0.0,
+             BT_Coriolis_scale=1.0, Z_ref=0.0, Sadourny=1, linearized_BT_PV=1, strong_drag=0, visc_rem_u_uh0=0,
+             adjust_BT_cont=0, use_wide_halos=1)
+    d.update(kw)
+    cs = _abi.BarotropicCS()
+    cs.dtbt = float(dtbt)
+    for k, v in d.items():
+        setattr(cs, k, v)
+    cs.hvel_scheme = _abi.BT_THICK_SCHEMES[hvel_scheme]
+    arrs = {}
+    for n, pos, nd in _abi.BT_CS_ARRAYS:
+        arrs[n] = grid.zeros3(pos) if nd == 3 else grid.zeros2(pos)
+        setattr(cs, n, arrs[n].ctypes.data)
+    return cs, arrs
+
+
+def barotropic_init(grid, cs):
+    L = lib(); L.orc_barotropic_init.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS)]
+    if L.orc_barotropic_init(C.byref(grid.struct()), C.byref(cs)):
+        raise RuntimeError("orc_barotropic_init: unsupported configuration")
+
+
+def btcalc(grid, cs, h, h_u=None, h_v=None, may_use_default=False):
+    L = lib(); L.orc_btcalc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, _dp, _dp, C.c_int]
+    if L.orc_btcalc(C.byref(grid.struct()), C.byref(cs), _p(h), _p(h_u), _p(h_v), int(may_use_default)):
+        raise RuntimeError("btcalc: Inconsistent settings of optional arguments and hvel_scheme.")
+
+
+def bt_mass_source(grid, cs, h, eta, set_cor):
+    L = lib(); L.orc_bt_mass_source.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, _dp, C.c_int]
+    L.orc_bt_mass_source(C.byref(grid.struct()), C.byref(cs), _p(h), _p(eta), int(set_cor))
+
+
+def set_dtbt(grid, cs, pbce=None, bt_cont=None, gtot_est=0.0, SSH_add=0.0):
+    L = lib()
+    L.orc_set_dtbt.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, C.POINTER(_abi.BTCont),
+                               C.c_double, C.c_double]
+    L.orc_set_dtbt(C.byref(grid.struct()), C.byref(cs), _p(pbce), None if bt_cont is None else C.byref(bt_cont),
+                   float(gtot_est), float(SSH_add))
+    return cs.dtbt_max
+
+
+def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor,
+           visc_rem_u, visc_rem_v, RZ_to_H=None, bt_cont=None, eta_PF_start=None, taux_bot=None, tauy_bot=None, uh0=None,
+           vh0=None, u_uh0=None, v_vh0=None, want_etaav=False):
+    """btstep on numpy arrays.  Returns dict(accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav[, etaav])."""
+    L = lib()
+    L.orc_btstep.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS)] + [_dp] * 3 + [C.c_double] + [_dp] * 4
+                             + [C.c_double] + [_dp] * 11 + [C.POINTER(_abi.BTCont)] + [_dp] * 8)
+    out = dict(accel_layer_u=grid.zeros3(_abi.POS_U), accel_layer_v=grid.zeros3(_abi.POS_V), eta_out=grid.zeros2(_abi.POS_H),
+               uhbtav=grid.zeros2(_abi.POS_U), vhbtav=grid.zeros2(_abi.POS_V))
+    if want_etaav:
+        out["etaav"] = grid.zeros2(_abi.POS_H)
+    rz = (1.0 / grid.Rho0) * grid.Z_to_H if RZ_to_H is None else RZ_to_H
+    rc = L.orc_btstep(C.byref(grid.struct()), C.byref(cs), _p(U_in), _p(V_in), _p(eta_in), float(dt), _p(bc_accel_u),
+                      _p(bc_accel_v), _p(taux), _p(tauy), float(rz), _p(pbce), _p(eta_PF_in), _p(U_Cor), _p(V_Cor),
+                      _p(out["accel_layer_u"]), _p(out["accel_layer_v"]), _p(out["eta_out"]), _p(out["uhbtav"]),
+                      _p(out["vhbtav"]), _p(visc_rem_u), _p(visc_rem_v), None if bt_cont is None else C.byref(bt_cont),
+                      _p(eta_PF_start), _p(taux_bot), _p(tauy_bot), _p(uh0), _p(vh0), _p(u_uh0), _p(v_vh0),
+                      _p(out.get("etaav")))
+    if rc:
+        raise RuntimeError(f"orc_btstep failed rc={rc}")
+    return out

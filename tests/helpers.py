@@ -31,3 +31,78 @@ def interior(g, a, pos=_abi.POS_H):
 
 def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+def barotropic_case(orc, ni=22, nj=18, nk=4, seed=5, reentrant_x=True, reentrant_y=False, land_frac=0.2, dt=900.0,
+                    use_bt_cont=True, hvel_scheme=None, rest=False, nstep_min=13, **cs_kw):
+    """Inputs of btstep built the way step_MOM_dyn_split_RK2 builds them (src/core/MOM_dynamics_split_RK2.F90:586-658),
+    with the oracle's continuity / PressureForce providing BT_cont, uh0/vh0, pbce and eta_PF."""
+    g = synth.make_grid(ni, nj, nk, land_frac=land_frac, seed=seed + 200, reentrant_x=reentrant_x, reentrant_y=reentrant_y)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.0 if rest else 0.3).items()}
+    rng = np.random.default_rng(seed)
+    kk = (np.arange(nk) + 0.5) / nk
+    vru = np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["u"], 0.0, 1.0) * (g.mask2dCu[None] > 0)
+    vrv = np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["v"], 0.0, 1.0) * (g.mask2dCv[None] > 0)
+    vru = np.ascontiguousarray(vru); vrv = np.ascontiguousarray(vrv)
+    E = orc.eos("WRIGHT")
+    if rest:   # a flat, homogeneous ocean: eta = 0 everywhere, no pressure gradients
+        h = d["h"]
+        tot = h.sum(0)
+        d["h"] = np.ascontiguousarray(h * np.where(tot > 0, g.bathyT * g.Z_to_H / np.maximum(tot, 1e-30), 1.0)[None])
+        d["T"][:] = 10.0; d["S"][:] = 35.0
+    PFu, PFv, pbce, eta_PF = orc.pressureforce(g, orc.pressureforce_cs(g), E, d["h"], d["T"], d["S"])
+    hp = d["h"].copy(); uh = np.zeros_like(d["u"]); vh = np.zeros_like(d["v"])
+    ccs = orc.continuity_cs(nk, g.Angstrom_H)
+    arrs, bt = orc.make_bt_cont(g, with_h=True)
+    orc.continuity(g, ccs, d["u"], d["v"], d["h"], hp, uh, vh, dt, visc_rem_u=vru, visc_rem_v=vrv, bt_cont=bt)
+    for a in (uh, ):
+        orc.halo_update(g, a, _abi.POS_U)
+    orc.halo_update(g, vh, _abi.POS_V)
+    if hvel_scheme is None:
+        hvel_scheme = "FROM_BT_CONT" if use_bt_cont else "HARMONIC"
+    cs, cs_arrs = orc.barotropic_cs(g, hvel_scheme=hvel_scheme, **cs_kw)
+    orc.barotropic_init(g, cs)
+    if hvel_scheme == "FROM_BT_CONT":
+        orc.btcalc(g, cs, d["h"], arrs["h_u"], arrs["h_v"])
+    else:
+        orc.btcalc(g, cs, d["h"])
+    eta = np.ascontiguousarray(d["h"].sum(0) - g.bathyT * g.Z_to_H)
+    if not rest:   # the free surface the barotropic solver carries drifts a little from the layer sum
+        eta = eta + 0.01 * rng.standard_normal(eta.shape) * g.mask2dT
+    orc.halo_update(g, eta, _abi.POS_H)
+    orc.bt_mass_source(g, cs, d["h"], eta, True)
+    orc.set_dtbt(g, cs, pbce=pbce, bt_cont=bt if use_bt_cont else None, gtot_est=g.g_Earth, SSH_add=10.0)
+    # the coarse test grids allow a barotropic step longer than DT: shorten it (DTBT > 0 in the reference's terms)
+    cs.dtbt = min(cs.dtbt, dt / (nstep_min - 0.4))
+    amp = 0.0 if rest else 1.0
+    case = dict(U_in=d["u"], V_in=d["v"], eta_in=eta, dt=dt,
+                bc_accel_u=np.ascontiguousarray(amp * (PFu + 1e-6 * rng.standard_normal(PFu.shape)) * (g.mask2dCu[None] > 0)),
+                bc_accel_v=np.ascontiguousarray(amp * (PFv + 1e-6 * rng.standard_normal(PFv.shape)) * (g.mask2dCv[None] > 0)),
+                taux=np.ascontiguousarray(amp * 0.1 * np.cos(np.linspace(0, 3, g.shape2(_abi.POS_U)[0]))[:, None] * g.mask2dCu),
+                tauy=np.ascontiguousarray(amp * 0.02 * rng.standard_normal(g.shape2(_abi.POS_V)) * g.mask2dCv),
+                pbce=pbce, eta_PF_in=eta_PF, U_Cor=d["u"], V_Cor=d["v"], visc_rem_u=vru, visc_rem_v=vrv,
+                bt_cont=bt if use_bt_cont else None, uh0=uh, vh0=vh, u_uh0=d["u"], v_vh0=d["v"])
+    keep = dict(bt_arrs=arrs, cs_arrs=cs_arrs, h=d["h"], continuity_cs=ccs)
+    return g, cs, case, keep
+
+
+def btstep_weights(cs, dt):
+    """nstep, nfilter and the normalised filter weights of btstep (src/core/MOM_barotropic.F90:788, :1753-1808)."""
+    import math
+    nstep = math.ceil(dt / cs.dtbt - 0.0001)
+    dtbt = dt * (1.0 / nstep)
+    f = cs.dt_bt_filter
+    dt_filt = 0.5 * max(0.0, min(f, 2.0 * dt)) if f >= 0 else 0.5 * max(0.0, dt * min(-f, 2.0))
+    nfilter = math.ceil(dt_filt / dtbt)
+    nt = nstep + nfilter
+    w = np.zeros(nt + 2)
+    for n in range(1, nt + 1):
+        if n == nstep or dt_filt - abs(n - nstep) * dtbt >= 0.0:
+            w[n] = 1.0
+        elif dtbt + dt_filt - abs(n - nstep) * dtbt > 0.0:
+            w[n] = 1.0 + dt_filt / dtbt - abs(n - nstep)
+    wt_eta = w / w.sum()
+    T = np.cumsum(w[::-1])[::-1]          # T(m) = sum_{n>=m} w(n)
+    wt_trans = T / T[1:nt + 1].sum()
+    return dict(nstep=nstep, nfilter=nfilter, dtbt=dtbt, wt_eta=wt_eta, wt_trans=wt_trans,
+                dt_eff=dtbt * T[1:nt + 1].sum() / w.sum(), n_eff=float((np.arange(nt + 2) * wt_eta).sum()))
