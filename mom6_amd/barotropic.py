@@ -1,0 +1,193 @@
+"""Host-side mirror of MOM_barotropic (reference: src/core/MOM_barotropic.F90): barotropic_init, btcalc,
+bt_mass_source, set_dtbt, btstep, with the reference's argument names and error behaviour."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+from .continuity import BT_cont_type
+from .tracer_advect import DeviceGrid, _ptr_space
+
+_DEFAULTS = dict(dtbt_fraction=0.98, bebt=0.1, dt_bt_filter=-0.25, vel_underflow=0.0, G_extra=0.0, BT_Coriolis_scale=1.0,
+                 Z_ref=0.0, Sadourny=True, linearized_BT_PV=True, strong_drag=False, visc_rem_u_uh0=False,
+                 adjust_BT_cont=False, use_wide_halos=True)
+_PARAM_NAMES = {"BEBT": "bebt", "DT_BT_FILTER": "dt_bt_filter", "VEL_UNDERFLOW": "vel_underflow", "G_BT_EXTRA": "G_extra",
+                "BT_CORIOLIS_SCALE": "BT_Coriolis_scale", "REFERENCE_HEIGHT": "Z_ref", "SADOURNY": "Sadourny",
+                "LINEARIZED_BT_CORIOLIS": "linearized_BT_PV", "BT_STRONG_DRAG": "strong_drag",
+                "BT_USE_VISC_REM_U_UH0": "visc_rem_u_uh0", "ADJUST_BT_CONT": "adjust_BT_cont",
+                "BT_USE_WIDE_HALOS": "use_wide_halos"}
+
+
+class barotropic_CS:
+    """barotropic_CS (:104-332): run-time parameters + the arrays the reference keeps in the control structure.
+    The arrays live where `device` says ("cuda" tensors, or numpy on the host for the staged path)."""
+
+    def __init__(self, G, device="cuda", DTBT=-0.98, BT_THICK_SCHEME=None, USE_BT_CONT_TYPE=True, **params):
+        g = G.grid if isinstance(G, DeviceGrid) else G
+        d = dict(_DEFAULTS)
+        unsupported = [0] * 12
+        for k, v in params.items():
+            if k in _PARAM_NAMES:
+                d[_PARAM_NAMES[k]] = v
+            elif k in d:
+                d[k] = v
+            elif k in _abi.BT_UNSUPPORTED:
+                unsupported[_abi.BT_UNSUPPORTED.index(k)] = int(bool(v))
+            else:
+                raise Mom6HipError(f"barotropic_init: unknown parameter {k}")
+        st = _abi.BarotropicCS()
+        for k, v in d.items():
+            setattr(st, k, float(v) if isinstance(getattr(st, k), float) else int(bool(v)))
+        if BT_THICK_SCHEME is None:
+            BT_THICK_SCHEME = "FROM_BT_CONT" if USE_BT_CONT_TYPE else "HYBRID"     # :4614-4628
+        if BT_THICK_SCHEME == "FROM_BT_CONT" and not USE_BT_CONT_TYPE:
+            raise Mom6HipError("barotropic_init: BT_THICK_SCHEME FROM_BT_CONT can only be used if USE_BT_CONT_TYPE is defined.")
+        st.hvel_scheme = _abi.BT_THICK_SCHEMES[BT_THICK_SCHEME]
+        for q in range(12):
+            st.unsupported[q] = unsupported[q]
+        # DTBT: > 0 a time step in s, <= 0 minus the fraction of the stable maximum (0 = -0.98) (:4725-4735, :5012-5022)
+        self.dtbt_input = float(DTBT)
+        st.dtbt_fraction = 0.98 if DTBT >= 0.0 else -float(DTBT)
+        st.dtbt = float(DTBT) if DTBT > 0.0 else 0.0
+        self.grid, self.device, self.st = g, device, st
+        self.arrays = {}
+        for n, pos, nd in _abi.BT_CS_ARRAYS:
+            shp = g.shape3(pos) if nd == 3 else g.shape2(pos)
+            a = np.zeros(shp) if device == "cpu" else torch.zeros(shp, dtype=torch.float64, device=device)
+            self.arrays[n] = a
+            setattr(st, n, _ptr_space(a)[0])
+        self.space = _ptr_space(self.arrays["frhatu"])[1]
+        self.module_is_initialized = False
+
+    def __getattr__(self, n):
+        a = self.__dict__.get("arrays", {})
+        if n in a:
+            return a[n]
+        st = self.__dict__.get("st")
+        if st is not None and hasattr(st, n):
+            return getattr(st, n)
+        raise AttributeError(n)
+
+
+def _P(spaces, a):
+    if a is None:
+        return None
+    p, s = _ptr_space(a)
+    spaces.add(s)
+    return C.c_void_p(p)
+
+
+def _one_space(spaces, CS, who):
+    spaces.add(CS.space)
+    if len(spaces) != 1:
+        raise Mom6HipError(f"{who}: all fields and the control structure must be in the same memory space")
+    return spaces.pop()
+
+
+def _setup():
+    L = lib()
+    if not getattr(L, "_bt_ready", False):
+        cs = C.POINTER(_abi.BarotropicCS)
+        L.mom6hip_barotropic_init.argtypes = [C.c_void_p, cs, C.c_int32]
+        L.mom6hip_btcalc.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.mom6hip_bt_mass_source.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.mom6hip_set_dtbt.argtypes = [C.c_void_p, cs, C.c_void_p, C.POINTER(_abi.BTCont), C.c_double, C.c_double, C.c_int32]
+        L.mom6hip_btstep.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4 + [C.c_double]
+                                     + [C.c_void_p] * 11 + [C.POINTER(_abi.BTCont)] + [C.c_void_p] * 8 + [C.c_int32])
+        L._bt_ready = True
+    return L
+
+
+def barotropic_init(G: DeviceGrid, device="cuda", gtot_estimate=None, SSH_extra=None, **params) -> barotropic_CS:
+    """barotropic_init (:4376): parameters (reference names, e.g. BEBT=0.1, DTBT=-0.98, BT_STRONG_DRAG=False), the
+    time-invariant arrays, and the first set_dtbt from an estimate of the total reduced gravity (:5006-5022)."""
+    CS = barotropic_CS(G, device=device, **params)
+    L = _setup()
+    check(L.mom6hip_barotropic_init(G.handle, C.byref(CS.st), CS.space), "barotropic_init")
+    CS.module_is_initialized = True
+    g = CS.grid
+    if gtot_estimate is None:
+        gtot_estimate = g.H_to_Z * g.g_Earth       # a one-layer estimate: sum_k H_to_Z*g_prime(K) >= g
+    if SSH_extra is None:
+        SSH_extra = min(10.0, 0.05 * float(np.max(g.bathyT)))
+    dtbt_in = CS.dtbt_input
+    set_dtbt(G, CS, gtot_est=gtot_estimate, SSH_add=SSH_extra)
+    if dtbt_in > 0.0:
+        CS.st.dtbt = dtbt_in
+    return CS
+
+
+def btcalc(h, G: DeviceGrid, CS: barotropic_CS, h_u=None, h_v=None, may_use_default=False, OBC=None):
+    """btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC) -- :3394."""
+    if not CS.module_is_initialized:
+        raise Mom6HipError("btcalc: Module MOM_barotropic must be initialized before it is used.")
+    if OBC is not None:
+        raise Mom6HipError("btcalc (HIP): open boundaries are not supported")
+    sp = set()
+    args = [_P(sp, h), _P(sp, h_u), _P(sp, h_v)]
+    check(_setup().mom6hip_btcalc(G.handle, C.byref(CS.st), *args, int(bool(may_use_default)), _one_space(sp, CS, "btcalc")), "btcalc")
+
+
+def bt_mass_source(h, eta, set_cor, G: DeviceGrid, CS: barotropic_CS):
+    """bt_mass_source(h, eta, set_cor, G, GV, CS) -- :4318."""
+    if not CS.module_is_initialized:
+        raise Mom6HipError("bt_mass_source: Module MOM_barotropic must be initialized before it is used.")
+    sp = set()
+    args = [_P(sp, h), _P(sp, eta)]
+    check(_setup().mom6hip_bt_mass_source(G.handle, C.byref(CS.st), *args, int(bool(set_cor)), _one_space(sp, CS, "bt_mass_source")),
+          "bt_mass_source")
+
+
+def set_dtbt(G: DeviceGrid, CS: barotropic_CS, eta=None, pbce=None, BT_cont: BT_cont_type | None = None, gtot_est=None,
+             SSH_add=0.0):
+    """set_dtbt(G, GV, US, CS, eta, pbce, BT_cont, gtot_est, SSH_add) -- :2801.  With a multi-tile domain attached
+    to G the maximum stable step is the minimum over the tiles (min_across_PEs, :2915)."""
+    if not CS.module_is_initialized:
+        raise Mom6HipError("set_dtbt: Module MOM_barotropic must be initialized before it is used.")
+    if pbce is None and gtot_est is None:
+        raise Mom6HipError("set_dtbt: Either pbce or gtot_est must be present.")
+    sp = set()
+    p = _P(sp, pbce)
+    bt = None if BT_cont is None else BT_cont.struct(sp)
+    check(_setup().mom6hip_set_dtbt(G.handle, C.byref(CS.st), p, None if bt is None else C.byref(bt),
+                                    0.0 if gtot_est is None else float(gtot_est), float(SSH_add), _one_space(sp, CS, "set_dtbt")),
+          "set_dtbt")
+    dom = getattr(G, "domain", None)
+    if dom is not None and dom.nranks > 1:
+        t = torch.tensor([CS.st.dtbt_max], dtype=torch.float64)
+        dom.min_across_PEs(t.cuda() if torch.distributed.get_backend(dom.group) == "nccl" else t)
+        CS.st.dtbt_max = float(t[0]) if t.device.type == "cpu" else float(t.cpu()[0])
+        CS.st.dtbt = CS.st.dtbt_fraction * CS.st.dtbt_max
+    return CS.st.dtbt_max
+
+
+def btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_in, U_Cor, V_Cor, accel_layer_u,
+           accel_layer_v, eta_out, uhbtav, vhbtav, G: DeviceGrid, CS: barotropic_CS, visc_rem_u, visc_rem_v, SpV_avg=None,
+           ADp=None, OBC=None, BT_cont: BT_cont_type | None = None, eta_PF_start=None, taux_bot=None, tauy_bot=None, uh0=None,
+           vh0=None, u_uh0=None, v_vh0=None, etaav=None):
+    """btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_in, U_Cor, V_Cor, accel_layer_u,
+    accel_layer_v, eta_out, uhbtav, vhbtav, G, GV, US, CS, visc_rem_u, visc_rem_v, SpV_avg, ADp, OBC, BT_cont,
+    eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav) -- :423.
+    `forces` is a (taux, tauy) pair of 2-D wind-stress arrays [Pa] (mech_forcing%taux, %tauy)."""
+    if not CS.module_is_initialized:
+        raise Mom6HipError("btstep: Module MOM_barotropic must be initialized before it is used.")
+    if OBC is not None:
+        raise Mom6HipError("btstep (HIP): open boundaries are not supported")
+    if (uh0 is not None) and (vh0 is None or u_uh0 is None or v_vh0 is None):
+        raise Mom6HipError("btstep: vh0, u_uh0, and v_vh0 must be associated if uh0 is used.")
+    g = CS.grid
+    taux, tauy = forces
+    sp = set()
+    P = lambda a: _P(sp, a)
+    a1 = [P(U_in), P(V_in), P(eta_in)]
+    a2 = [P(bc_accel_u), P(bc_accel_v), P(taux), P(tauy)]
+    a3 = [P(x) for x in (pbce, eta_PF_in, U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v)]
+    bt = None if BT_cont is None else BT_cont.struct(sp)
+    a4 = [P(x) for x in (eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav)]
+    RZ_to_H = g.Z_to_H / g.Rho0          # GV%RZ_to_H, Boussinesq (MOM_verticalGrid.F90)
+    check(_setup().mom6hip_btstep(G.handle, C.byref(CS.st), *a1, float(dt), *a2, float(RZ_to_H), *a3,
+                                  None if bt is None else C.byref(bt), *a4, _one_space(sp, CS, "btstep")), "btstep")

@@ -1,0 +1,995 @@
+// barotropic.hip -- MOM_barotropic on MI355X: btstep, btcalc, bt_mass_source, set_dtbt, barotropic_init.
+//
+// Reference: src/core/MOM_barotropic.F90 (btstep :423-2797, set_dtbt :2801, btcalc :3394, find_uhbt :3683,
+// set_local_BT_cont_types :3949, adjust_local_BT_cont_types :4085, find_face_areas :4221, bt_mass_source :4318,
+// barotropic_init :4376).  Provided branch: Boussinesq, no OBC, no SAL, BTHALO = 0, the reference defaults for the
+// switches in mom6hip_barotropic_cs_t.unsupported.
+//
+// Layout of the work: the 3-D inputs are read exactly once by two "face-column" kernels (one lane per u- or v-point,
+// marching k with i-contiguous wave loads; all the vertical sums of the reference's setup are accumulated in
+// registers in its k order), the subcycle runs on 2-D arrays with four small kernels per barotropic step on the
+// shrinking valid range of the reference's wide-halo march (one group pass every `num_cycles` steps), and the
+// per-layer accelerations are written by one more face-column kernel.  The transport of the instantaneous velocity
+// that the next step's predictor needs (find_uhbt(ubt)+uhbt0, :1884) is produced by the velocity kernel that already
+// holds the BT_cont fit of that face in registers, and travels with eta/ubt/vbt in the group pass; it is the same
+// pure function of (ubt, fit, uhbt0) that the reference evaluates after the pass.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <initializer_list>
+#include <utility>
+
+namespace m6 {
+int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+}
+
+namespace {
+
+constexpr double SUBROUNDOFF = 1e-30;   // MOM_barotropic.F90:413
+
+// ---- correctly rounded x**y for 0 < x <= 1, 0 < y <= 1 (bt_rem = av_rem ** Instep, :1529) ---------------------------
+// double-double log and exp from + - * / fma only, rounded once; the test suite's CPU checker repeats this operation
+// order so that the two agree bit for bit (DESIGN.md "btstep").
+struct dd_t { double hi, lo; };
+__device__ __forceinline__ dd_t dd_fast2sum(double a, double b) { double s = a + b; return {s, b - (s - a)}; }
+__device__ __forceinline__ dd_t dd_2sum(double a, double b) {
+  double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd_t dd_2prod(double a, double b) { double p = a * b; return {p, __builtin_fma(a, b, -p)}; }
+__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) {
+  dd_t s = dd_2sum(a.hi, b.hi), t = dd_2sum(a.lo, b.lo);
+  s.lo += t.hi; s = dd_fast2sum(s.hi, s.lo); s.lo += t.lo; return dd_fast2sum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd_t dd_add_d(dd_t a, double b) {
+  dd_t s = dd_2sum(a.hi, b); s.lo += a.lo; return dd_fast2sum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd_t dd_mul(dd_t a, dd_t b) {
+  dd_t p = dd_2prod(a.hi, b.hi); p.lo += a.hi * b.lo + a.lo * b.hi; return dd_fast2sum(p.hi, p.lo);
+}
+__device__ __forceinline__ dd_t dd_mul_d(dd_t a, double b) {
+  dd_t p = dd_2prod(a.hi, b); p.lo += a.lo * b; return dd_fast2sum(p.hi, p.lo);
+}
+__device__ dd_t dd_div(dd_t a, dd_t b) {
+  double q1 = a.hi / b.hi;
+  dd_t r = dd_add(a, dd_mul_d(b, -q1));
+  double q2 = r.hi / b.hi;
+  r = dd_add(r, dd_mul_d(b, -q2));
+  double q3 = r.hi / b.hi;
+  dd_t q = dd_fast2sum(q1, q2);
+  return dd_add_d(q, q3);
+}
+__device__ double cr_pow(double x, double y) {
+  if (x == 1.0) return 1.0;
+  const dd_t LN2 = {0.6931471805599453094, 2.3190468138462995584e-17};
+  // log
+  int e;
+  double m = frexp(x, &e);
+  if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
+  dd_t s = dd_div(dd_2sum(m, -1.0), dd_2sum(m, 1.0)), s2 = dd_mul(s, s);
+  dd_t sum = {0.0, 0.0};
+  for (int k = 24; k >= 1; k--) {
+    dd_t c = {1.0, 0.0}, dk = {(double)(2 * k + 1), 0.0};
+    sum = dd_mul(dd_add(dd_div(c, dk), sum), s2);
+  }
+  sum = dd_add_d(sum, 1.0);
+  dd_t r = dd_mul(s, sum); r.hi *= 2.0; r.lo *= 2.0;
+  dd_t t = dd_mul_d(dd_add(dd_mul_d(LN2, (double)e), r), y);
+  // exp
+  double kd = rint(t.hi * 1.4426950408889634074);
+  r = dd_add(t, dd_mul_d(LN2, -kd));
+  r.hi *= 0.00390625; r.lo *= 0.00390625;
+  sum = {0.0, 0.0};
+  for (int k = 12; k >= 1; k--) {
+    dd_t one_plus = dd_add_d(sum, 1.0), dk = {(double)k, 0.0};
+    sum = dd_mul(dd_div(r, dk), one_plus);
+  }
+  for (int q = 0; q < 8; q++) {
+    dd_t sq = dd_mul(sum, sum); sum.hi *= 2.0; sum.lo *= 2.0; sum = dd_add(sum, sq);
+  }
+  dd_t res = dd_add_d(sum, 1.0);
+  return ldexp(res.hi, (int)kd);
+}
+
+// ---- launch helper: one thread per point of an inclusive index range, i fastest ------------------------------------
+template <class F> __global__ void __launch_bounds__(256) range2d_kernel(int i0, int i1, int j0, int j1, F f) {
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (i <= i1 && j <= j1) f(i, j);
+}
+template <class F> void launch2d(hipStream_t st, int i0, int i1, int j0, int j1, F f) {
+  if (i1 < i0 || j1 < j0) return;
+  dim3 grid((i1 - i0 + 64) / 64, (j1 - j0 + 4) / 4), block(64, 4);
+  hipLaunchKernelGGL(range2d_kernel<F>, grid, block, 0, st, i0, i1, j0, j1, f);
+}
+
+// ---- the BT_cont fit at a face: local_BT_cont_u_type / _v_type as a structure of arrays (:335-372) -------------------
+struct Btcl { double *FA_EE, *FA_E0, *FA_W0, *FA_WW, *uBT_WW, *uBT_EE, *uh_crvW, *uh_crvE, *uh_WW, *uh_EE; };
+
+// find_uhbt :3683 / find_vhbt :3817
+__device__ __forceinline__ double find_uhbt(double u, const Btcl &B, long n) {
+  if (u == 0.0) return 0.0;
+  const double ee = B.uBT_EE[n];
+  if (u < ee) return (u - ee) * B.FA_EE[n] + B.uh_EE[n];
+  if (u < 0.0) return u * (B.FA_E0[n] + B.uh_crvE[n] * (u * u));
+  const double ww = B.uBT_WW[n];
+  if (u <= ww) return u * (B.FA_W0[n] + B.uh_crvW[n] * (u * u));
+  return (u - ww) * B.FA_WW[n] + B.uh_WW[n];
+}
+
+// every 2-D work array of btstep (device pointers into one scratch block)
+struct Work {
+  // u-points
+  double *ubt, *bt_rem_u, *BT_force_u, *u_accel_bt, *uhbt, *uhbt0, *uhbtp, *azon, *bzon, *czon, *dzon, *Cor_ref_u,
+      *DCor_u, *Datu, *ubt_Cor, *ubt0, *uhbtS, *amer, *bmer, *cmer, *dmer;
+  // v-points
+  double *vbt, *bt_rem_v, *BT_force_v, *v_accel_bt, *vhbt, *vhbt0, *vhbtp, *Cor_ref_v, *DCor_v, *Datv, *vbt_Cor, *vbt0,
+      *vhbtS;
+  // h-points
+  double *eta, *eta_pred, *eta_sum, *eta_wtd, *eta_PF, *eta_PF_1, *d_eta_PF, *gtot_E, *gtot_W, *gtot_N, *gtot_S,
+      *eta_src, *e_anom;
+  double *q;
+  Btcl BU, BV;
+};
+
+// scalars of one btstep call
+struct Par {
+  double dtbt, Instep, dgeo_de, vel_underflow, trans_wt1, trans_wt2, RZ_to_H;
+  int nstep, use_BT_cont, interp_eta_PF, add_uh0, strong_drag, visc_rem_u_uh0, find_etaav, have_bot;
+};
+
+// ---- face-column kernel: all the vertical sums of the setup (:1035-1372, :1505-1541) --------------------------------
+// DIR 0: u-points (I = is-1..ie, j = js..je); DIR 1: v-points (i = is..ie, J = js-1..je).
+template <int DIR>
+__global__ void __launch_bounds__(256)
+bt_pre_face_kernel(m6::GridDev g, Work w, Par p, const double *__restrict__ frhat, const double *__restrict__ visc_rem,
+                   const double *__restrict__ vel_Cor, const double *__restrict__ pbce, const double *__restrict__ uh0,
+                   const double *__restrict__ u_uh0, const double *__restrict__ vel_in, const double *__restrict__ bc_accel,
+                   const double *__restrict__ tau, const double *__restrict__ tau_bot, const double *__restrict__ IDat) {
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y * 4 + threadIdx.y;
+  if (i > g.iec || j > g.jec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const long fstr = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long hm = g.h2(i, j), hp = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j), hstr = (long)g.nih * g.njh;
+  const double mask = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2];
+
+  double vel_cor = 0.0, gt_m = 0.0, gt_p = 0.0, uhS = 0.0, u0 = 0.0, ub = 0.0, av_rem = 0.0, force;
+  if (mask > 0.0) {
+    force = tau[f2] * p.RZ_to_H * IDat[f2] * visc_rem[f2];
+    if (p.have_bot) force = force - tau_bot[f2] * p.RZ_to_H * IDat[f2];
+  } else {
+    force = 0.0;
+  }
+  for (int k = 0; k < g.nk; k++) {
+    const long f3 = f2 + fstr * k;
+    const double fr = frhat[f3], vr_in = visc_rem[f3];
+    double vr = m6::min2(vr_in, 1.);
+    vr = m6::max2(vr, 1. - 0.5 * p.Instep / (vr + SUBROUNDOFF));
+    vr = m6::max2(vr, 0.);
+    const double wt = fr * vr;
+    vel_cor = vel_cor + wt * vel_Cor[f3];
+    gt_m = gt_m + pbce[hm + hstr * k] * wt;
+    gt_p = gt_p + pbce[hp + hstr * k] * wt;
+    if (p.add_uh0) {
+      uhS = uhS + uh0[f3];
+      u0 = u0 + (p.visc_rem_u_uh0 ? wt : fr) * u_uh0[f3];
+    }
+    ub = ub + wt * vel_in[f3];
+    force = force + wt * bc_accel[f3];
+    av_rem = av_rem + fr * vr_in;
+  }
+  if (fabs(ub) < p.vel_underflow) ub = 0.0;
+  double rem;
+  if (p.strong_drag) {
+    rem = mask * ((p.nstep * av_rem) / (1.0 + (p.nstep - 1) * av_rem));
+  } else {
+    rem = 0.0;
+    if (mask * av_rem > 0.0) rem = mask * cr_pow(av_rem, p.Instep);
+  }
+  if (DIR == 0) {
+    w.ubt_Cor[f2] = vel_cor; w.gtot_E[hm] = gt_m; w.gtot_W[hp] = gt_p; w.uhbtS[f2] = uhS; w.ubt0[f2] = u0;
+    w.ubt[f2] = ub; w.BT_force_u[f2] = force; w.bt_rem_u[f2] = rem;
+  } else {
+    w.vbt_Cor[f2] = vel_cor; w.gtot_N[hm] = gt_m; w.gtot_S[hp] = gt_p; w.vhbtS[f2] = uhS; w.vbt0[f2] = u0;
+    w.vbt[f2] = ub; w.BT_force_v[f2] = force; w.bt_rem_v[f2] = rem;
+  }
+}
+
+// ---- per-layer accelerations (:2576-2589) ------------------------------------------------------------------------
+template <int DIR>
+__global__ void __launch_bounds__(256)
+bt_accel_layer_kernel(m6::GridDev g, Work w, const double *__restrict__ pbce, double *__restrict__ accel, double accel_underflow) {
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y * 4 + threadIdx.y;
+  if (i > g.iec || j > g.jec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const long fstr = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long hm = g.h2(i, j), hp = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j), hstr = (long)g.nih * g.njh;
+  const double abt = DIR ? w.v_accel_bt[f2] : w.u_accel_bt[f2];
+  const double gp = DIR ? w.gtot_S[hp] : w.gtot_W[hp], gm = DIR ? w.gtot_N[hm] : w.gtot_E[hm];
+  const double ep = w.e_anom[hp], em = w.e_anom[hm];
+  const double Id = DIR ? g.IdyCv[f2] : g.IdxCu[f2];
+  for (int k = 0; k < g.nk; k++) {
+    double a = (abt - ((pbce[hp + hstr * k] - gp) * ep - (pbce[hm + hstr * k] - gm) * em) * Id);
+    if (fabs(a) < accel_underflow) a = 0.0;
+    accel[f2 + fstr * k] = a;
+  }
+}
+
+// ---- the four kernels of one barotropic step ---------------------------------------------------------------------
+// predictor continuity (:1882-1909) + eta_sum (:1921)
+__global__ void __launch_bounds__(256)
+bt_eta_pred_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, double wt_accel2) {
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (i > i1 || j > j1) return;
+  const long n = g.h2(i, j);
+  const double ep = (w.eta[n] + w.eta_src[n]) + (p.dtbt * g.IareaT[n]) *
+      ((w.uhbtp[g.u2(i - 1, j)] - w.uhbtp[g.u2(i, j)]) + (w.vhbtp[g.v2(i, j - 1)] - w.vhbtp[g.v2(i, j)]));
+  w.eta_pred[n] = ep;
+  if (p.find_etaav && i >= g.isc && i <= g.iec && j >= g.jsc && j <= g.jec) w.eta_sum[n] = w.eta_sum[n] + wt_accel2 * ep;
+}
+
+// corrector continuity (:2414-2421)
+__global__ void __launch_bounds__(256)
+bt_eta_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, double wt_eta) {
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (i > i1 || j > j1) return;
+  const long n = g.h2(i, j);
+  const double e = (w.eta[n] + w.eta_src[n]) + (p.dtbt * g.IareaT[n]) *
+      ((w.uhbt[g.u2(i - 1, j)] - w.uhbt[g.u2(i, j)]) + (w.vhbt[g.v2(i, j - 1)] - w.vhbt[g.v2(i, j)]));
+  w.eta[n] = e;
+  w.eta_wtd[n] = w.eta_wtd[n] + e * wt_eta;
+}
+
+__device__ __forceinline__ double eta_pf_at(const Work &w, const Par &p, long n, double wt_end) {
+  return p.interp_eta_PF ? (w.eta_PF_1[n] + wt_end * w.d_eta_PF[n]) : w.eta_PF[n];
+}
+
+// meridional velocity update (:1975-2044 when v goes first, :2217-2290 when second) + running sums (:2349-2354)
+__global__ void __launch_bounds__(256)
+bt_vbt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, double wt_accel, double wt_trans, double wt_end,
+              double *__restrict__ vbt_sum, double *__restrict__ vhbt_sum) {
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x, J = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (i > i1 || J > j1) return;
+  const int j = J;
+  const long n = g.v2(i, J);
+  const double Cor_v = -1.0 * ((w.amer[g.u2(i - 1, j)] * w.ubt[g.u2(i - 1, j)] + w.cmer[g.u2(i, j + 1)] * w.ubt[g.u2(i, j + 1)]) +
+                               (w.bmer[g.u2(i, j)] * w.ubt[g.u2(i, j)] + w.dmer[g.u2(i - 1, j + 1)] * w.ubt[g.u2(i - 1, j + 1)])) -
+                       w.Cor_ref_v[n];
+  const long hs = g.h2(i, j), hn = g.h2(i, j + 1);
+  const double PFv = ((w.eta_pred[hs] - eta_pf_at(w, p, hs, wt_end)) * w.gtot_N[hs] -
+                      (w.eta_pred[hn] - eta_pf_at(w, p, hn, wt_end)) * w.gtot_S[hn]) * p.dgeo_de * g.IdyCv[n];
+  const double vel_prev = w.vbt[n];
+  double vb = w.bt_rem_v[n] * (vel_prev + p.dtbt * ((w.BT_force_v[n] + Cor_v) + PFv));
+  if (fabs(vb) < p.vel_underflow) vb = 0.0;
+  const double vtrans = p.trans_wt1 * vb + p.trans_wt2 * vel_prev;
+  w.vbt[n] = vb;
+  w.v_accel_bt[n] = w.v_accel_bt[n] + wt_accel * (Cor_v + PFv);
+  const double vh0 = w.vhbt0[n];
+  double vh, vhp;
+  if (p.use_BT_cont) { vh = find_uhbt(vtrans, w.BV, n) + vh0; vhp = find_uhbt(vb, w.BV, n) + vh0; }
+  else { const double D = w.Datv[n]; vh = D * vtrans + vh0; vhp = D * vb + vh0; }
+  w.vhbt[n] = vh; w.vhbtp[n] = vhp;
+  if (i >= g.isc && i <= g.iec && J >= g.jsc - 1 && J <= g.jec) {
+    vbt_sum[n] = vbt_sum[n] + wt_trans * vtrans;
+    vhbt_sum[n] = vhbt_sum[n] + wt_trans * vh;
+  }
+}
+
+// zonal velocity update (:2047-2127 when second, :2130-2207 when first) + running sums (:2342-2347)
+__global__ void __launch_bounds__(256)
+bt_ubt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, double wt_accel, double wt_trans, double wt_end,
+              double *__restrict__ ubt_sum, double *__restrict__ uhbt_sum) {
+  const int I = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (I > i1 || j > j1) return;
+  const int i = I;
+  const long n = g.u2(I, j);
+  const double Cor_u = ((w.azon[n] * w.vbt[g.v2(i + 1, j)] + w.czon[n] * w.vbt[g.v2(i, j - 1)]) +
+                        (w.bzon[n] * w.vbt[g.v2(i, j)] + w.dzon[n] * w.vbt[g.v2(i + 1, j - 1)])) - w.Cor_ref_u[n];
+  const long hw = g.h2(i, j), he = g.h2(i + 1, j);
+  const double PFu = ((w.eta_pred[hw] - eta_pf_at(w, p, hw, wt_end)) * w.gtot_E[hw] -
+                      (w.eta_pred[he] - eta_pf_at(w, p, he, wt_end)) * w.gtot_W[he]) * p.dgeo_de * g.IdxCu[n];
+  const double vel_prev = w.ubt[n];
+  double ub = w.bt_rem_u[n] * (vel_prev + p.dtbt * ((w.BT_force_u[n] + Cor_u) + PFu));
+  if (fabs(ub) < p.vel_underflow) ub = 0.0;
+  const double utrans = p.trans_wt1 * ub + p.trans_wt2 * vel_prev;
+  w.ubt[n] = ub;
+  w.u_accel_bt[n] = w.u_accel_bt[n] + wt_accel * (Cor_u + PFu);
+  const double uh0 = w.uhbt0[n];
+  double uh, uhp;
+  if (p.use_BT_cont) { uh = find_uhbt(utrans, w.BU, n) + uh0; uhp = find_uhbt(ub, w.BU, n) + uh0; }
+  else { const double D = w.Datu[n]; uh = D * utrans + uh0; uhp = D * ub + uh0; }
+  w.uhbt[n] = uh; w.uhbtp[n] = uhp;
+  if (I >= g.isc - 1 && I <= g.iec && j >= g.jsc && j <= g.jec) {
+    ubt_sum[n] = ubt_sum[n] + wt_trans * utrans;
+    uhbt_sum[n] = uhbt_sum[n] + wt_trans * uh;
+  }
+}
+
+// ---- set_dtbt: per-cell stability limit + min ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bt_dtbt_kernel(m6::GridDev g, const double *__restrict__ pbce, const double *__restrict__ frhatu, const double *__restrict__ frhatv,
+               const double *__restrict__ Datu, const double *__restrict__ Datv, double gtot_est, double bebt, double cor_scale,
+               unsigned long long *__restrict__ result) {
+  const int i = g.isc + blockIdx.x * 64 + threadIdx.x, j = g.jsc + blockIdx.y * 4 + threadIdx.y;
+  double cand = 1.0e38;
+  if (i <= g.iec && j <= g.jec) {
+    const long n = g.h2(i, j);
+    double gE = 0.0, gW = 0.0, gN = 0.0, gS = 0.0;
+    if (pbce) {
+      const long hstr = (long)g.nih * g.njh, ustr = (long)(g.nih + 1) * g.njh, vstr = (long)g.nih * (g.njh + 1);
+      for (int k = 0; k < g.nk; k++) {
+        const double pb = pbce[n + hstr * k];
+        gE = gE + pb * frhatu[g.u2(i, j) + ustr * k];
+        gW = gW + pb * frhatu[g.u2(i - 1, j) + ustr * k];
+        gN = gN + pb * frhatv[g.v2(i, j) + vstr * k];
+        gS = gS + pb * frhatv[g.v2(i, j - 1) + vstr * k];
+      }
+    } else {
+      gE = gW = gN = gS = gtot_est;
+    }
+    const double f00 = g.CoriolisBu[g.q2(i, j)], f11 = g.CoriolisBu[g.q2(i - 1, j - 1)], f10 = g.CoriolisBu[g.q2(i - 1, j)],
+                 f01 = g.CoriolisBu[g.q2(i, j - 1)];
+    const double Idt_max2 = 0.5 * (1.0 + 2.0 * bebt) * (g.IareaT[n] *
+        ((gE * Datu[g.u2(i, j)] * g.IdxCu[g.u2(i, j)] + gW * Datu[g.u2(i - 1, j)] * g.IdxCu[g.u2(i - 1, j)]) +
+         (gN * Datv[g.v2(i, j)] * g.IdyCv[g.v2(i, j)] + gS * Datv[g.v2(i, j - 1)] * g.IdyCv[g.v2(i, j - 1)])) +
+        ((f00 * f00 + f11 * f11) + (f10 * f10 + f01 * f01)) * (cor_scale * cor_scale));
+    if (Idt_max2 * 1.0e38 > 1.0) cand = 1.0 / Idt_max2;
+  }
+  // positive doubles order like their bit patterns: atomicMin on the bits is the exact minimum
+  __shared__ unsigned long long smin;
+  if (threadIdx.x == 0 && threadIdx.y == 0) smin = 0x7FF0000000000000ull;
+  __syncthreads();
+  atomicMin(&smin, (unsigned long long)__double_as_longlong(cand));
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) atomicMin(result, smin);
+}
+
+int check_cs(const mom6hip_barotropic_cs_t *cs, const char *who) {
+  M6_REQUIRE(cs != nullptr, "%s: null control structure", who);
+  static const char *names[12] = {"INTEGRAL_BT_CONTINUITY", "BT_PROJECT_VELOCITY", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION",
+                                  "GRADUAL_BT_ICS", "BT_NONLIN_STRESS", "DYNAMIC_SURFACE_PRESSURE", "BT_LINEAR_WAVE_DRAG",
+                                  "CLIP_BT_VELOCITY", "CALCULATE_SAL", "BT_USE_OLD_CORIOLIS_BRACKET_BUG",
+                                  "BAROTROPIC_ANSWER_DATE < 20190101"};
+  for (int q = 0; q < 12; q++)
+    M6_REQUIRE(cs->unsupported[q] == 0, "%s: %s is not provided by libmom6hip", who, names[q]);
+  return 0;
+}
+
+struct Sizes { size_t h2, u2, v2, q2, h3, u3, v3; };
+Sizes sizes_of(const m6::GridDev &g) {
+  Sizes s;
+  s.h2 = sizeof(double) * (size_t)g.nih * g.njh; s.u2 = sizeof(double) * (size_t)(g.nih + 1) * g.njh;
+  s.v2 = sizeof(double) * (size_t)g.nih * (g.njh + 1); s.q2 = sizeof(double) * (size_t)(g.nih + 1) * (g.njh + 1);
+  s.h3 = s.h2 * g.nk; s.u3 = s.u2 * g.nk; s.v3 = s.v2 * g.nk;
+  return s;
+}
+
+// the state arrays of the control structure, staged like any other argument
+struct CsDev { double *frhatu, *frhatv, *eta_cor, *IDatu, *IDatv, *ubtav, *vbtav, *q_D, *D_u_Cor, *D_v_Cor; };
+
+dim3 grid2d(int i0, int i1, int j0, int j1) { return dim3((i1 - i0 + 64) / 64, (j1 - j0 + 4) / 4); }
+
+}  // namespace
+
+extern "C" {
+
+int mom6hip_barotropic_init(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "barotropic_init: null context");
+  if (int rc = check_cs(cs, "barotropic_init")) return rc;
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.bathyT && g.areaT && g.mask2dT && g.mask2dCu && g.mask2dCv && g.CoriolisBu,
+             "barotropic_init: bathyT, areaT, mask2dT, mask2dCu, mask2dCv and CoriolisBu are needed");
+  M6_REQUIRE(cs->frhatu && cs->frhatv && cs->eta_cor && cs->IDatu && cs->IDatv && cs->ubtav && cs->vbtav,
+             "barotropic_init: the control structure's state arrays must be allocated");
+  M6_REQUIRE(!cs->linearized_BT_PV || (cs->q_D && cs->D_u_Cor && cs->D_v_Cor), "barotropic_init: q_D, D_u_Cor, D_v_Cor needed");
+  const Sizes sz = sizes_of(g);
+  m6::Stager st(ctx, memspace);
+  CsDev d;
+  d.frhatu = st.out(cs->frhatu, sz.u3); d.frhatv = st.out(cs->frhatv, sz.v3); d.eta_cor = st.out(cs->eta_cor, sz.h2);
+  d.IDatu = st.out(cs->IDatu, sz.u2); d.IDatv = st.out(cs->IDatv, sz.v2); d.ubtav = st.out(cs->ubtav, sz.u2);
+  d.vbtav = st.out(cs->vbtav, sz.v2);
+  const bool lin = cs->linearized_BT_PV != 0;
+  d.q_D = lin ? st.out(cs->q_D, sz.q2) : nullptr; d.D_u_Cor = lin ? st.out(cs->D_u_Cor, sz.u2) : nullptr;
+  d.D_v_Cor = lin ? st.out(cs->D_v_Cor, sz.v2) : nullptr;
+  M6_REQUIRE(!st.failed(), "barotropic_init: staging failed");
+  hipStream_t s = ctx->stream;
+  M6_HIP(hipMemsetAsync(d.frhatu, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(d.frhatv, 0, sz.v3, s));
+  M6_HIP(hipMemsetAsync(d.eta_cor, 0, sz.h2, s)); M6_HIP(hipMemsetAsync(d.IDatu, 0, sz.u2, s));
+  M6_HIP(hipMemsetAsync(d.IDatv, 0, sz.v2, s)); M6_HIP(hipMemsetAsync(d.ubtav, 0, sz.u2, s));
+  M6_HIP(hipMemsetAsync(d.vbtav, 0, sz.v2, s));
+  const double Z_to_H = g.Z_to_H, Mean_SL = cs->Z_ref, scale = cs->BT_Coriolis_scale, hsub = g.H_subroundoff;
+  if (cs->linearized_BT_PV) {   // :4826-4858
+    M6_HIP(hipMemsetAsync(d.q_D, 0, sz.q2, s)); M6_HIP(hipMemsetAsync(d.D_u_Cor, 0, sz.u2, s));
+    M6_HIP(hipMemsetAsync(d.D_v_Cor, 0, sz.v2, s));
+    launch2d(s, g.isc - 1, g.iec, g.jsc, g.jec, [=] __device__(int I, int j) {
+      d.D_u_Cor[g.u2(I, j)] = 0.5 * (m6::max2(Mean_SL + g.bathyT[g.h2(I + 1, j)], 0.0) + m6::max2(Mean_SL + g.bathyT[g.h2(I, j)], 0.0)) * Z_to_H;
+    });
+    launch2d(s, g.isc, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int J) {
+      d.D_v_Cor[g.v2(i, J)] = 0.5 * (m6::max2(Mean_SL + g.bathyT[g.h2(i, J + 1)], 0.0) + m6::max2(Mean_SL + g.bathyT[g.h2(i, J)], 0.0)) * Z_to_H;
+    });
+    launch2d(s, g.isc - 1, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int j) {
+      auto BT = [&](int a, int b) { return g.bathyT[g.h2(a, b)]; };
+      auto AT = [&](int a, int b) { return g.areaT[g.h2(a, b)]; };
+      auto MT = [&](int a, int b) { return g.mask2dT[g.h2(a, b)]; };
+      double qv = 0.;
+      if (MT(i, j) + MT(i, j + 1) + MT(i + 1, j) + MT(i + 1, j + 1) > 0.) {
+        qv = 0.25 * (scale * g.CoriolisBu[g.q2(i, j)]) * ((AT(i, j) + AT(i + 1, j + 1)) + (AT(i + 1, j) + AT(i, j + 1))) /
+             (Z_to_H * m6::max2(((AT(i, j) * m6::max2(Mean_SL + BT(i, j), 0.0) + AT(i + 1, j + 1) * m6::max2(Mean_SL + BT(i + 1, j + 1), 0.0)) +
+                                 (AT(i + 1, j) * m6::max2(Mean_SL + BT(i + 1, j), 0.0) + AT(i, j + 1) * m6::max2(Mean_SL + BT(i, j + 1), 0.0))),
+                                hsub));
+      }
+      d.q_D[g.q2(i, j)] = qv;
+    });
+    double *f[3] = {d.q_D, d.D_u_Cor, d.D_v_Cor};
+    const int32_t pos[3] = {MOM6HIP_POS_Q, MOM6HIP_POS_U, MOM6HIP_POS_V}, nk[3] = {1, 1, 1};
+    if (int rc = m6::group_pass(ctx, f, pos, nk, 3)) return rc;
+  }
+  launch2d(s, g.isc - 1, g.iec, g.jsc, g.jec, [=] __device__(int I, int j) {   // :5073-5079
+    const double m = g.mask2dCu[g.u2(I, j)];
+    d.IDatu[g.u2(I, j)] = (m > 0.) ? m * 2.0 / (Z_to_H * ((g.bathyT[g.h2(I + 1, j)] + g.bathyT[g.h2(I, j)]) + 2.0 * Mean_SL)) : 0.;
+  });
+  launch2d(s, g.isc, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int J) {   // :5080-5086
+    const double m = g.mask2dCv[g.v2(i, J)];
+    d.IDatv[g.v2(i, J)] = (m > 0.) ? m * 2.0 / (Z_to_H * ((g.bathyT[g.h2(i, J + 1)] + g.bathyT[g.h2(i, J)]) + 2.0 * Mean_SL)) : 0.;
+  });
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+int mom6hip_btcalc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *h_u, const double *h_v,
+                   int32_t may_use_default, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr && cs != nullptr && h != nullptr, "btcalc: null argument");
+  const m6::GridDev g = ctx->g;
+  const int sch = cs->hvel_scheme;
+  int use_default = 0;
+  const bool given = h_u && h_v;
+  if (!(given || sch == MOM6HIP_BT_HARMONIC || sch == MOM6HIP_BT_HYBRID || sch == MOM6HIP_BT_ARITHMETIC)) {
+    M6_REQUIRE(may_use_default, "btcalc: Inconsistent settings of optional arguments and hvel_scheme.");
+    use_default = 1;
+  }
+  const Sizes sz = sizes_of(g);
+  m6::Stager st(ctx, memspace);
+  const double *dh = st.in(h, sz.h3), *dhu = given ? st.in(h_u, sz.u3) : nullptr, *dhv = given ? st.in(h_v, sz.v3) : nullptr;
+  double *fru = st.inout(cs->frhatu, sz.u3), *frv = st.inout(cs->frhatv, sz.v3);
+  M6_REQUIRE(!st.failed(), "btcalc: staging failed");
+  const double h_neglect = g.H_subroundoff, Z_to_H = g.Z_to_H;
+  const int hybrid = (sch == MOM6HIP_BT_HYBRID || use_default), arith = (sch == MOM6HIP_BT_ARITHMETIC);
+  for (int dir = 0; dir < 2; dir++) {
+    const double *hw = dir ? dhv : dhu;
+    double *fr = dir ? frv : fru;
+    const long fstr = dir ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh, hstr = (long)g.nih * g.njh;
+    launch2d(ctx->stream, dir ? g.isc : g.isc - 1, g.iec, dir ? g.jsc - 1 : g.jsc, g.jec, [=] __device__(int i, int j) {
+      const long f2 = dir ? g.v2(i, j) : g.u2(i, j);
+      const long hm = g.h2(i, j), hp = dir ? g.h2(i, j + 1) : g.h2(i + 1, j);
+      const double mask = dir ? g.mask2dCv[f2] : g.mask2dCu[f2];
+      const int nz = g.nk;
+      double tot;
+      if (hw) {
+        tot = hw[f2];
+        for (int k = 1; k < nz; k++) tot = tot + hw[f2 + fstr * k];
+        const double Ihat = mask / (tot + h_neglect);
+        for (int k = 0; k < nz; k++) fr[f2 + fstr * k] = hw[f2 + fstr * k] * Ihat;
+        return;
+      }
+      if (arith) {
+        tot = 0.0;
+        for (int k = 0; k < nz; k++) {
+          const double v = 0.5 * (dh[hp + hstr * k] + dh[hm + hstr * k]);
+          fr[f2 + fstr * k] = v;
+          tot = (k == 0) ? v : tot + v;
+        }
+      } else if (hybrid) {
+        const double bp = g.bathyT[hp], bm = g.bathyT[hm];
+        double e_below = -0.5 * Z_to_H * (bp + bm);
+        const double D_shallow = -Z_to_H * m6::min2(bp, bm);
+        tot = 0.0;
+        for (int k = nz - 1; k >= 0; k--) {
+          const double a = dh[hp + hstr * k], b = dh[hm + hstr * k];
+          const double e_here = e_below + 0.5 * (a + b);
+          const double h_arith = 0.5 * (a + b);
+          double v;
+          if (e_below >= D_shallow) {
+            v = h_arith;
+          } else {
+            const double h_harm = (a * b) / (h_arith + h_neglect);
+            if (e_here <= D_shallow) {
+              v = h_harm;
+            } else {
+              const double wt_arith = (e_here - D_shallow) / (h_arith + h_neglect);
+              v = wt_arith * h_arith + (1.0 - wt_arith) * h_harm;
+            }
+          }
+          fr[f2 + fstr * k] = v;
+          tot = tot + v;
+          e_below = e_here;
+        }
+      } else {   // HARMONIC
+        tot = 0.0;
+        for (int k = 0; k < nz; k++) {
+          const double a = dh[hp + hstr * k], b = dh[hm + hstr * k];
+          const double v = 2.0 * (a * b) / ((a + b) + h_neglect);
+          fr[f2 + fstr * k] = v;
+          tot = (k == 0) ? v : tot + v;
+        }
+      }
+      const double Ihat = mask / (tot + h_neglect);
+      for (int k = 0; k < nz; k++) fr[f2 + fstr * k] = fr[f2 + fstr * k] * Ihat;
+    });
+  }
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+int mom6hip_bt_mass_source(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *eta, int32_t set_cor,
+                           int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr && cs != nullptr && h != nullptr && eta != nullptr, "bt_mass_source: null argument");
+  const m6::GridDev g = ctx->g;
+  const Sizes sz = sizes_of(g);
+  m6::Stager st(ctx, memspace);
+  const double *dh = st.in(h, sz.h3), *de = st.in(eta, sz.h2);
+  double *cor = st.inout(cs->eta_cor, sz.h2);
+  M6_REQUIRE(!st.failed(), "bt_mass_source: staging failed");
+  const long hstr = (long)g.nih * g.njh;
+  const double Z_to_H = g.Z_to_H;
+  launch2d(ctx->stream, g.isc, g.iec, g.jsc, g.jec, [=] __device__(int i, int j) {
+    const long n = g.h2(i, j);
+    double eta_h = dh[n] - g.bathyT[n] * Z_to_H;
+    for (int k = 1; k < g.nk; k++) eta_h = eta_h + dh[n + hstr * k];
+    const double d_eta = eta_h - de[n];
+    cor[n] = set_cor ? d_eta : cor[n] + d_eta;
+  });
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *pbce, const mom6hip_bt_cont_t *BT_cont,
+                     double gtot_est, double SSH_add, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "set_dtbt: null context");
+  if (int rc = check_cs(cs, "set_dtbt")) return rc;
+  const m6::GridDev g = ctx->g;
+  const Sizes sz = sizes_of(g);
+  m6::Stager st(ctx, memspace);
+  const double *dp = pbce ? st.in(pbce, sz.h3) : nullptr;
+  const double *fru = pbce ? st.in((const double *)cs->frhatu, sz.u3) : nullptr, *frv = pbce ? st.in((const double *)cs->frhatv, sz.v3) : nullptr;
+  double *Datu = (double *)st.scratch(sz.u2), *Datv = (double *)st.scratch(sz.v2);
+  unsigned long long *res = (unsigned long long *)st.scratch(sizeof(unsigned long long));
+  const double *FA[8] = {};
+  if (BT_cont) {
+    const double *src[8] = {BT_cont->FA_u_EE, BT_cont->FA_u_E0, BT_cont->FA_u_W0, BT_cont->FA_u_WW,
+                            BT_cont->FA_v_NN, BT_cont->FA_v_N0, BT_cont->FA_v_S0, BT_cont->FA_v_SS};
+    for (int q = 0; q < 8; q++) { M6_REQUIRE(src[q], "set_dtbt: BT_cont is incomplete"); FA[q] = st.in(src[q], q < 4 ? sz.u2 : sz.v2); }
+  }
+  M6_REQUIRE(!st.failed() && Datu && Datv && res, "set_dtbt: staging failed");
+  hipStream_t s = ctx->stream;
+  M6_HIP(hipMemsetAsync(Datu, 0, sz.u2, s)); M6_HIP(hipMemsetAsync(Datv, 0, sz.v2, s));
+  const unsigned long long inf_bits = 0x7FF0000000000000ull;
+  M6_HIP(hipMemcpyAsync(res, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, s));
+  if (BT_cont) {   // BT_cont_to_face_areas :4182, halo = 0
+    const double *a0 = FA[0], *a1 = FA[1], *a2 = FA[2], *a3 = FA[3], *b0 = FA[4], *b1 = FA[5], *b2 = FA[6], *b3 = FA[7];
+    launch2d(s, g.isc - 1, g.iec, g.jsc, g.jec, [=] __device__(int I, int j) {
+      const long n = g.u2(I, j);
+      Datu[n] = m6::max2(m6::max2(m6::max2(a0[n], a1[n]), a2[n]), a3[n]);
+    });
+    launch2d(s, g.isc, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int J) {
+      const long n = g.v2(i, J);
+      Datv[n] = m6::max2(m6::max2(m6::max2(b0[n], b1[n]), b2[n]), b3[n]);
+    });
+  } else {   // find_face_areas with add_max :4283-4295, halo 0
+    const double Z_to_H = g.Z_to_H, add = cs->Z_ref + SSH_add;
+    launch2d(s, g.isc - 1, g.iec, g.jsc, g.jec, [=] __device__(int I, int j) {
+      Datu[g.u2(I, j)] = g.dy_Cu[g.u2(I, j)] * Z_to_H * m6::max2(m6::max2(g.bathyT[g.h2(I + 1, j)], g.bathyT[g.h2(I, j)]) + add, 0.0);
+    });
+    launch2d(s, g.isc, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int J) {
+      Datv[g.v2(i, J)] = g.dx_Cv[g.v2(i, J)] * Z_to_H * m6::max2(m6::max2(g.bathyT[g.h2(i, J + 1)], g.bathyT[g.h2(i, J)]) + add, 0.0);
+    });
+  }
+  hipLaunchKernelGGL(bt_dtbt_kernel, grid2d(g.isc, g.iec, g.jsc, g.jec), dim3(64, 4), 0, s, g, dp, fru, frv, Datu, Datv, gtot_est,
+                     cs->bebt, cs->BT_Coriolis_scale, res);
+  M6_HIP(hipGetLastError());
+  unsigned long long bits = 0;
+  M6_HIP(hipMemcpyAsync(&bits, res, sizeof(bits), hipMemcpyDeviceToHost, s));
+  M6_HIP(hipStreamSynchronize(s));
+  double min_max_dt2;
+  memcpy(&min_max_dt2, &bits, sizeof(double));
+  if (!(min_max_dt2 < 1.0e38)) min_max_dt2 = 1.0e38;
+  const double dgeo_de = 1.0 + (cs->G_extra > 0.0 ? cs->G_extra : 0.0);
+  const double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
+  cs->dtbt = cs->dtbt_fraction * dtbt_max;
+  cs->dtbt_max = dtbt_max;
+  return st.finish();
+}
+
+int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *U_in, const double *V_in, const double *eta_in,
+                   double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux, const double *tauy,
+                   double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor, const double *V_Cor,
+                   double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav, double *vhbtav,
+                   const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont, const double *eta_PF_start,
+                   const double *taux_bot, const double *tauy_bot, const double *uh0, const double *vh0, const double *u_uh0,
+                   const double *v_vh0, double *etaav, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "btstep: null context");
+  if (int rc = check_cs(cs, "btstep")) return rc;
+  M6_REQUIRE(U_in && V_in && eta_in && bc_accel_u && bc_accel_v && taux && tauy && pbce && eta_PF_in && U_Cor && V_Cor &&
+                 accel_layer_u && accel_layer_v && eta_out && uhbtav && vhbtav && visc_rem_u && visc_rem_v,
+             "btstep: a required argument is null");
+  M6_REQUIRE((uh0 != nullptr) == (vh0 != nullptr && u_uh0 != nullptr && v_vh0 != nullptr),
+             "btstep: vh0, u_uh0, and v_vh0 must be associated if uh0 is used.");
+  M6_REQUIRE(cs->dtbt > 0.0 && dt > 0.0, "btstep: dt and CS%%dtbt must be positive (call set_dtbt first)");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.bathyT && g.IareaT && g.areaT && g.IdxCu && g.IdyCv && g.dy_Cu && g.dx_Cv && g.mask2dT && g.mask2dCu &&
+                 g.mask2dCv && g.CoriolisBu, "btstep: a metric array it needs was not given to grid_create");
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec;
+  const Sizes sz = sizes_of(g);
+  const bool use_BT_cont = BT_cont != nullptr, interp = eta_PF_start != nullptr, add_uh0 = uh0 != nullptr;
+  const bool find_etaav = etaav != nullptr, have_bot = taux_bot && tauy_bot;
+  const int stencil = 1;
+
+  int num_cycles = 1;
+  if (cs->use_wide_halos) num_cycles = std::min((is - g.isd) / stencil, (js - g.jsd) / stencil);
+  M6_REQUIRE(num_cycles >= 1, "btstep: the grid has no halo");
+  const int isvf = is - (num_cycles - 1) * stencil, ievf = ie + (num_cycles - 1) * stencil;
+  const int jsvf = js - (num_cycles - 1) * stencil, jevf = je + (num_cycles - 1) * stencil;
+  const int nstep = (int)ceil(dt / cs->dtbt - 0.0001);
+  M6_REQUIRE(nstep >= 1, "btstep: nstep < 1");
+  cs->nstep_last = nstep;
+
+  Par p;
+  p.Instep = 1.0 / (double)nstep; p.dtbt = dt * p.Instep; p.dgeo_de = 1.0 + cs->G_extra; p.vel_underflow = cs->vel_underflow;
+  p.trans_wt1 = cs->bebt; p.trans_wt2 = (1.0 - cs->bebt); p.RZ_to_H = RZ_to_H; p.nstep = nstep; p.use_BT_cont = use_BT_cont;
+  p.interp_eta_PF = interp; p.add_uh0 = add_uh0; p.strong_drag = cs->strong_drag; p.visc_rem_u_uh0 = cs->visc_rem_u_uh0;
+  p.find_etaav = find_etaav; p.have_bot = have_bot;
+  const double accel_underflow = cs->vel_underflow * (1.0 / dt);
+
+  // filter weights :1753-1808 (host: a few dozen scalars, handed to the kernels by value)
+  double dt_filt;
+  if (cs->dt_bt_filter >= 0.0) dt_filt = 0.5 * std::max(0.0, std::min(cs->dt_bt_filter, 2.0 * dt));
+  else dt_filt = 0.5 * std::max(0.0, dt * std::min(-cs->dt_bt_filter, 2.0));
+  const int nfilter = (int)ceil(dt_filt / p.dtbt);
+  const int nt = nstep + nfilter;
+  M6_REQUIRE(nt > 0, "btstep: number of barotropic step (nstep+nfilter) is 0");
+  std::vector<double> wt_vel(nt + 2, 0.0), wt_eta(nt + 2, 0.0), wt_trans(nt + 2, 0.0), wt_accel(nt + 2, 0.0), wt_accel2(nt + 2, 0.0);
+  {
+    double sum_wt_vel = 0.0, sum_wt_eta = 0.0, sum_wt_accel = 0.0, sum_wt_trans = 0.0;
+    for (int n = 1; n <= nt; n++) {
+      if ((n == nstep) || (dt_filt - abs(n - nstep) * p.dtbt >= 0.0)) { wt_vel[n] = 1.0; wt_eta[n] = 1.0; }
+      else if (p.dtbt + dt_filt - abs(n - nstep) * p.dtbt > 0.0) { wt_vel[n] = 1.0 + (dt_filt / p.dtbt) - abs(n - nstep); wt_eta[n] = wt_vel[n]; }
+      else { wt_vel[n] = 0.0; wt_eta[n] = 0.0; }
+      sum_wt_vel = sum_wt_vel + wt_vel[n]; sum_wt_eta = sum_wt_eta + wt_eta[n];
+    }
+    for (int n = nt; n >= 1; n--) {
+      wt_trans[n] = wt_trans[n + 1] + wt_eta[n];
+      wt_accel[n] = wt_accel[n + 1] + wt_vel[n];
+      sum_wt_accel = sum_wt_accel + wt_accel[n]; sum_wt_trans = sum_wt_trans + wt_trans[n];
+    }
+    const double Iv = 1.0 / sum_wt_vel, Ia = 1.0 / sum_wt_accel, Ie = 1.0 / sum_wt_eta, It = 1.0 / sum_wt_trans;
+    for (int n = 1; n <= nt; n++) {
+      wt_vel[n] = wt_vel[n] * Iv; wt_accel2[n] = wt_accel[n] * Ia; wt_trans[n] = wt_trans[n] * It;
+      wt_accel[n] = wt_accel[n] * Ia; wt_eta[n] = wt_eta[n] * Ie;
+    }
+  }
+
+  // ---- stage the arguments
+  m6::Stager st(ctx, memspace);
+  const double *dU = st.in(U_in, sz.u3), *dV = st.in(V_in, sz.v3), *deta_in = st.in(eta_in, sz.h2);
+  const double *dbu = st.in(bc_accel_u, sz.u3), *dbv = st.in(bc_accel_v, sz.v3), *dtx = st.in(taux, sz.u2), *dty = st.in(tauy, sz.v2);
+  const double *dpb = st.in(pbce, sz.h3), *depf = st.in(eta_PF_in, sz.h2), *dUc = st.in(U_Cor, sz.u3), *dVc = st.in(V_Cor, sz.v3);
+  const double *dvru = st.in(visc_rem_u, sz.u3), *dvrv = st.in(visc_rem_v, sz.v3);
+  const double *depfs = st.in(eta_PF_start, sz.h2), *dtbx = have_bot ? st.in(taux_bot, sz.u2) : nullptr,
+               *dtby = have_bot ? st.in(tauy_bot, sz.v2) : nullptr;
+  const double *duh0 = st.in(uh0, sz.u3), *dvh0 = st.in(vh0, sz.v3), *duu0 = st.in(u_uh0, sz.u3), *dvv0 = st.in(v_vh0, sz.v3);
+  // outputs that are written on the compute domain only are staged in and out, so the rest keeps the caller's values
+  double *dalu = st.inout(accel_layer_u, sz.u3), *dalv = st.inout(accel_layer_v, sz.v3);
+  double *deta_out = st.inout(eta_out, sz.h2);
+  double *duhbtav = st.inout(uhbtav, sz.u2), *dvhbtav = st.inout(vhbtav, sz.v2), *detaav = st.inout(etaav, sz.h2);
+  CsDev c;
+  c.frhatu = st.inout(cs->frhatu, sz.u3); c.frhatv = st.inout(cs->frhatv, sz.v3); c.eta_cor = st.inout(cs->eta_cor, sz.h2);
+  c.IDatu = st.inout(cs->IDatu, sz.u2); c.IDatv = st.inout(cs->IDatv, sz.v2);
+  c.ubtav = st.inout(cs->ubtav, sz.u2); c.vbtav = st.inout(cs->vbtav, sz.v2);
+  c.q_D = cs->linearized_BT_PV ? st.inout(cs->q_D, sz.q2) : nullptr;
+  c.D_u_Cor = cs->linearized_BT_PV ? st.inout(cs->D_u_Cor, sz.u2) : nullptr;
+  c.D_v_Cor = cs->linearized_BT_PV ? st.inout(cs->D_v_Cor, sz.v2) : nullptr;
+  M6_REQUIRE(!cs->linearized_BT_PV || (c.q_D && c.D_u_Cor && c.D_v_Cor), "btstep: q_D, D_u_Cor and D_v_Cor are needed (barotropic_init)");
+  const double *bcU[6] = {}, *bcV[6] = {};
+  if (use_BT_cont) {
+    const double *su[6] = {BT_cont->FA_u_EE, BT_cont->FA_u_E0, BT_cont->FA_u_W0, BT_cont->FA_u_WW, BT_cont->uBT_EE, BT_cont->uBT_WW};
+    const double *sv[6] = {BT_cont->FA_v_NN, BT_cont->FA_v_N0, BT_cont->FA_v_S0, BT_cont->FA_v_SS, BT_cont->vBT_NN, BT_cont->vBT_SS};
+    for (int q = 0; q < 6; q++) {
+      M6_REQUIRE(su[q] && sv[q], "btstep: BT_cont is incomplete");
+      bcU[q] = st.in(su[q], sz.u2); bcV[q] = st.in(sv[q], sz.v2);
+    }
+  }
+  // one zero-filled block for every 2-D work array
+  const int NU_ARR = 21 + 10, NV_ARR = 13 + 10, NH_ARR = 13;
+  const size_t total = NU_ARR * sz.u2 + NV_ARR * sz.v2 + NH_ARR * sz.h2 + sz.q2;
+  char *blk = (char *)st.scratch(total);
+  M6_REQUIRE(!st.failed() && blk, "btstep: staging failed");
+  hipStream_t s = ctx->stream;
+  M6_HIP(hipMemsetAsync(blk, 0, total, s));
+  Work w;
+  {
+    char *q = blk;
+    auto U = [&]() { double *r = (double *)q; q += sz.u2; return r; };
+    auto V = [&]() { double *r = (double *)q; q += sz.v2; return r; };
+    auto H = [&]() { double *r = (double *)q; q += sz.h2; return r; };
+    w.ubt = U(); w.bt_rem_u = U(); w.BT_force_u = U(); w.u_accel_bt = U(); w.uhbt = U(); w.uhbt0 = U(); w.uhbtp = U();
+    w.azon = U(); w.bzon = U(); w.czon = U(); w.dzon = U(); w.Cor_ref_u = U(); w.DCor_u = U(); w.Datu = U(); w.ubt_Cor = U();
+    w.ubt0 = U(); w.uhbtS = U(); w.amer = U(); w.bmer = U(); w.cmer = U(); w.dmer = U();
+    double **bu = (double **)&w.BU; for (int k = 0; k < 10; k++) bu[k] = U();
+    w.vbt = V(); w.bt_rem_v = V(); w.BT_force_v = V(); w.v_accel_bt = V(); w.vhbt = V(); w.vhbt0 = V(); w.vhbtp = V();
+    w.Cor_ref_v = V(); w.DCor_v = V(); w.Datv = V(); w.vbt_Cor = V(); w.vbt0 = V(); w.vhbtS = V();
+    double **bv = (double **)&w.BV; for (int k = 0; k < 10; k++) bv[k] = V();
+    w.eta = H(); w.eta_pred = H(); w.eta_sum = H(); w.eta_wtd = H(); w.eta_PF = H(); w.eta_PF_1 = H(); w.d_eta_PF = H();
+    w.gtot_E = H(); w.gtot_W = H(); w.gtot_N = H(); w.gtot_S = H(); w.eta_src = H(); w.e_anom = H();
+    w.q = (double *)q;
+  }
+  auto pass = [&](std::initializer_list<std::pair<double *, int>> fl) -> int {
+    std::vector<double *> f; std::vector<int32_t> pos, nk;
+    for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second); nk.push_back(1); }
+    return m6::group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size());
+  };
+  const int PH = MOM6HIP_POS_H, PU = MOM6HIP_POS_U, PV = MOM6HIP_POS_V, PQ = MOM6HIP_POS_Q;
+
+  // ---- q, DCor_u, DCor_v :884-945
+  if (cs->linearized_BT_PV) {
+    M6_HIP(hipMemcpyAsync(w.q, c.q_D, sz.q2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.DCor_u, c.D_u_Cor, sz.u2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.DCor_v, c.D_v_Cor, sz.v2, hipMemcpyDeviceToDevice, s));
+  } else {
+    const double Z_to_H = g.Z_to_H, scale = cs->BT_Coriolis_scale, h_neglect = g.H_subroundoff;
+    launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) {
+      w.DCor_u[g.u2(I, j)] = 0.5 * (m6::max2(Z_to_H * g.bathyT[g.h2(I + 1, j)] + deta_in[g.h2(I + 1, j)], 0.0) +
+                                    m6::max2(Z_to_H * g.bathyT[g.h2(I, j)] + deta_in[g.h2(I, j)], 0.0));
+    });
+    launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) {   // eta_in(i+1,j): as written in the reference (:911)
+      w.DCor_v[g.v2(i, J)] = 0.5 * (m6::max2(Z_to_H * g.bathyT[g.h2(i, J + 1)] + deta_in[g.h2(i + 1, J)], 0.0) +
+                                    m6::max2(Z_to_H * g.bathyT[g.h2(i, J)] + deta_in[g.h2(i, J)], 0.0));
+    });
+    launch2d(s, is - 1, ie, js - 1, je, [=] __device__(int i, int j) {
+      auto AT = [&](int a, int b) { return g.areaT[g.h2(a, b)]; };
+      auto HT = [&](int a, int b) { return m6::max2(Z_to_H * g.bathyT[g.h2(a, b)] + deta_in[g.h2(a, b)], 0.0); };
+      w.q[g.q2(i, j)] = 0.25 * (scale * g.CoriolisBu[g.q2(i, j)]) * ((AT(i, j) + AT(i + 1, j + 1)) + (AT(i + 1, j) + AT(i, j + 1))) /
+                        (m6::max2((AT(i, j) * HT(i, j) + AT(i + 1, j + 1) * HT(i + 1, j + 1)) +
+                                  (AT(i + 1, j) * HT(i + 1, j) + AT(i, j + 1) * HT(i, j + 1)), h_neglect));
+    });
+    if (int rc = pass({{w.q, PQ}, {w.DCor_u, PU}, {w.DCor_v, PV}})) return rc;
+  }
+
+  // ---- copies of the inputs on the data domain :1011-1033
+  M6_HIP(hipMemcpyAsync(w.eta, deta_in, sz.h2, hipMemcpyDeviceToDevice, s));
+  if (interp) {
+    M6_HIP(hipMemcpyAsync(w.eta_PF_1, depfs, sz.h2, hipMemcpyDeviceToDevice, s));
+    launch2d(s, g.isd, g.ied, g.jsd, g.jed, [=] __device__(int i, int j) { w.d_eta_PF[g.h2(i, j)] = depf[g.h2(i, j)] - depfs[g.h2(i, j)]; });
+  } else {
+    M6_HIP(hipMemcpyAsync(w.eta_PF, depf, sz.h2, hipMemcpyDeviceToDevice, s));
+  }
+
+  // ---- open face areas :1136-1148
+  const int hs = 1 + ievf - ie;
+  if (use_BT_cont) {   // set_local_BT_cont_types :3949 (dt = 1)
+    const Btcl BU = w.BU, BV = w.BV;
+    const double *a0 = bcU[0], *a1 = bcU[1], *a2 = bcU[2], *a3 = bcU[3], *a4 = bcU[4], *a5 = bcU[5];
+    const double *b0 = bcV[0], *b1 = bcV[1], *b2 = bcV[2], *b3 = bcV[3], *b4 = bcV[4], *b5 = bcV[5];
+    launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) {
+      const long n = g.u2(I, j);
+      BU.FA_EE[n] = a0[n]; BU.FA_E0[n] = a1[n]; BU.FA_W0[n] = a2[n]; BU.FA_WW[n] = a3[n]; BU.uBT_EE[n] = a4[n]; BU.uBT_WW[n] = a5[n];
+    });
+    launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) {
+      const long n = g.v2(i, J);
+      BV.FA_EE[n] = b0[n]; BV.FA_E0[n] = b1[n]; BV.FA_W0[n] = b2[n]; BV.FA_WW[n] = b3[n]; BV.uBT_EE[n] = b4[n]; BV.uBT_WW[n] = b5[n];
+    });
+    if (int rc = pass({{BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PU}, {BV.FA_EE, PV},
+                       {BU.FA_E0, PU}, {BV.FA_E0, PV}, {BU.FA_W0, PU}, {BV.FA_W0, PV}, {BU.FA_WW, PU}, {BV.FA_WW, PV}})) return rc;
+    for (int dir = 0; dir < 2; dir++) {
+      const Btcl B = dir ? BV : BU;
+      launch2d(s, (dir ? is : is - 1) - hs, ie + hs, (dir ? js - 1 : js) - hs, je + hs, [=] __device__(int i, int j) {
+        const long n = dir ? g.v2(i, j) : g.u2(i, j);
+        const double C1_3 = 1.0 / 3.0;
+        const double ee = 1.0 * B.uBT_EE[n], ww = 1.0 * B.uBT_WW[n];
+        B.uBT_EE[n] = ee; B.uBT_WW[n] = ww;
+        B.uh_EE[n] = ee * (C1_3 * (2.0 * B.FA_E0[n] + B.FA_EE[n]));
+        B.uh_WW[n] = ww * (C1_3 * (2.0 * B.FA_W0[n] + B.FA_WW[n]));
+        double cw = 0.0, ce = 0.0;
+        if (fabs(ww) > 0.0) cw = (C1_3 * (B.FA_WW[n] - B.FA_W0[n])) / (ww * ww);
+        if (fabs(ee) > 0.0) ce = (C1_3 * (B.FA_EE[n] - B.FA_E0[n])) / (ee * ee);
+        B.uh_crvW[n] = cw; B.uh_crvE[n] = ce;
+      });
+    }
+  } else {   // find_face_areas :4297-4310, halo 1
+    const double Z_to_H = g.Z_to_H, Zr = cs->Z_ref;
+    launch2d(s, is - 2, ie + 1, js - 1, je + 1, [=] __device__(int I, int j) {
+      const double H1 = (g.bathyT[g.h2(I, j)] + Zr) * Z_to_H, H2 = (g.bathyT[g.h2(I + 1, j)] + Zr) * Z_to_H;
+      double D = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) D = g.dy_Cu[g.u2(I, j)] * (2.0 * H1 * H2) / (H1 + H2);
+      w.Datu[g.u2(I, j)] = D;
+    });
+    launch2d(s, is - 1, ie + 1, js - 2, je + 1, [=] __device__(int i, int J) {
+      const double H1 = (g.bathyT[g.h2(i, J)] + Zr) * Z_to_H, H2 = (g.bathyT[g.h2(i, J + 1)] + Zr) * Z_to_H;
+      double D = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) D = g.dx_Cv[g.v2(i, J)] * (2.0 * H1 * H2) / (H1 + H2);
+      w.Datv[g.v2(i, J)] = D;
+    });
+  }
+
+  // ---- the vertical sums :1035-1372, :1505-1541
+  hipLaunchKernelGGL(bt_pre_face_kernel<0>, grid2d(is - 1, ie, js, je), dim3(64, 4), 0, s, g, w, p, c.frhatu, dvru, dUc, dpb, duh0, duu0,
+                     dU, dbu, dtx, dtbx, c.IDatu);
+  hipLaunchKernelGGL(bt_pre_face_kernel<1>, grid2d(is, ie, js - 1, je), dim3(64, 4), 0, s, g, w, p, c.frhatv, dvrv, dVc, dpb, dvh0, dvv0,
+                     dV, dbv, dty, dtby, c.IDatv);
+
+  // ---- uhbt0, vhbt0 :1165-1252
+  if (add_uh0) {
+    if (use_BT_cont && cs->adjust_BT_cont) {   // adjust_local_BT_cont_types :4085 (dt = 1)
+      if (int rc = pass({{w.ubt0, PU}, {w.vbt0, PV}, {w.uhbtS, PU}, {w.vhbtS, PV}})) return rc;
+      for (int dir = 0; dir < 2; dir++) {
+        const Btcl B = dir ? w.BV : w.BU;
+        const double *ubt = dir ? w.vbt0 : w.ubt0, *uhbt = dir ? w.vhbtS : w.uhbtS;
+        launch2d(s, (dir ? is : is - 1) - hs, ie + hs, (dir ? js - 1 : js) - hs, je + hs, [=] __device__(int i, int j) {
+          const long n = dir ? g.v2(i, j) : g.u2(i, j);
+          const double ub = ubt[n], uh = uhbt[n], dtl = 1.0;
+          if ((dtl * ub > B.uBT_WW[n]) && (dtl * uh > B.uh_WW[n])) {
+            B.uBT_WW[n] = dtl * ub;
+            if (3.0 * uh < 2.0 * ub * B.FA_W0[n]) {
+              B.uh_crvW[n] = (uh - ub * B.FA_W0[n]) / ((dtl * dtl) * ((ub * ub) * ub));
+            } else {
+              B.FA_W0[n] = 1.5 * uh / ub;
+              B.uh_crvW[n] = -0.5 * uh / ((dtl * dtl) * ((ub * ub) * ub));
+            }
+            B.uh_WW[n] = dtl * uh;
+          } else if ((dtl * ub < B.uBT_EE[n]) && (dtl * uh < B.uh_EE[n])) {
+            B.uBT_EE[n] = dtl * ub;
+            if (3.0 * uh < 2.0 * ub * B.FA_E0[n]) {
+              B.uh_crvE[n] = (uh - ub * B.FA_E0[n]) / ((dtl * dtl) * ((ub * ub) * ub));
+            } else {
+              B.FA_E0[n] = 1.5 * uh / ub;
+              B.uh_crvE[n] = -0.5 * uh / ((dtl * dtl) * ((ub * ub) * ub));
+            }
+            B.uh_EE[n] = dtl * uh;
+          }
+        });
+      }
+    }
+    launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) {
+      const long n = g.u2(I, j);
+      w.uhbt0[n] = w.uhbtS[n] - (use_BT_cont ? find_uhbt(w.ubt0[n], w.BU, n) : w.Datu[n] * w.ubt0[n]);
+    });
+    launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) {
+      const long n = g.v2(i, J);
+      w.vhbt0[n] = w.vhbtS[n] - (use_BT_cont ? find_uhbt(w.vbt0[n], w.BV, n) : w.Datv[n] * w.vbt0[n]);
+    });
+  }
+
+  // ---- weighted Coriolis parameters :1421-1458
+  {
+    const int sad = cs->Sadourny;
+    launch2d(s, isvf - 1, ievf + 1, jsvf - 1, jevf, [=] __device__(int i, int j) {
+      const double q00 = w.q[g.q2(i, j)], qm0 = w.q[g.q2(i - 1, j)];
+      if (sad) {
+        w.amer[g.u2(i - 1, j)] = w.DCor_u[g.u2(i - 1, j)] * qm0;
+        w.bmer[g.u2(i, j)] = w.DCor_u[g.u2(i, j)] * q00;
+        w.cmer[g.u2(i, j + 1)] = w.DCor_u[g.u2(i, j + 1)] * q00;
+        w.dmer[g.u2(i - 1, j + 1)] = w.DCor_u[g.u2(i - 1, j + 1)] * qm0;
+      } else {
+        const double qmm = w.q[g.q2(i - 1, j - 1)], q0m = w.q[g.q2(i, j - 1)], q0p = w.q[g.q2(i, j + 1)], qmp = w.q[g.q2(i - 1, j + 1)];
+        w.amer[g.u2(i - 1, j)] = w.DCor_u[g.u2(i - 1, j)] * ((q00 + qmm) + qm0) / 3.0;
+        w.bmer[g.u2(i, j)] = w.DCor_u[g.u2(i, j)] * (q00 + (qm0 + q0m)) / 3.0;
+        w.cmer[g.u2(i, j + 1)] = w.DCor_u[g.u2(i, j + 1)] * (q00 + (qm0 + q0p)) / 3.0;
+        w.dmer[g.u2(i - 1, j + 1)] = w.DCor_u[g.u2(i - 1, j + 1)] * ((q00 + qmp) + qm0) / 3.0;
+      }
+    });
+    launch2d(s, isvf - 1, ievf, jsvf - 1, jevf + 1, [=] __device__(int i, int j) {
+      const long n = g.u2(i, j);
+      const double q00 = w.q[g.q2(i, j)], q0m = w.q[g.q2(i, j - 1)];
+      if (sad) {
+        w.azon[n] = w.DCor_v[g.v2(i + 1, j)] * q00;
+        w.bzon[n] = w.DCor_v[g.v2(i, j)] * q00;
+        w.czon[n] = w.DCor_v[g.v2(i, j - 1)] * q0m;
+        w.dzon[n] = w.DCor_v[g.v2(i + 1, j - 1)] * q0m;
+      } else {
+        const double qp0 = w.q[g.q2(i + 1, j)], qm0 = w.q[g.q2(i - 1, j)], qmm = w.q[g.q2(i - 1, j - 1)], qpm = w.q[g.q2(i + 1, j - 1)];
+        w.azon[n] = w.DCor_v[g.v2(i + 1, j)] * (q00 + (qp0 + q0m)) / 3.0;
+        w.bzon[n] = w.DCor_v[g.v2(i, j)] * (q00 + (qm0 + q0m)) / 3.0;
+        w.czon[n] = w.DCor_v[g.v2(i, j - 1)] * ((q00 + qmm) + q0m) / 3.0;
+        w.dzon[n] = w.DCor_v[g.v2(i + 1, j - 1)] * ((q00 + qpm) + q0m) / 3.0;
+      }
+    });
+  }
+
+  // ---- pass_gtot, pass_ubt_Cor :1460-1476 ; Cor_ref :1478-1490
+  if (int rc = pass({{w.gtot_E, PH}, {w.gtot_N, PH}, {w.gtot_W, PH}, {w.gtot_S, PH}, {w.ubt_Cor, PU}, {w.vbt_Cor, PV}})) return rc;
+  launch2d(s, is - 1, ie, js, je, [=] __device__(int i, int j) {
+    const long n = g.u2(i, j);
+    w.Cor_ref_u[n] = ((w.azon[n] * w.vbt_Cor[g.v2(i + 1, j)] + w.czon[n] * w.vbt_Cor[g.v2(i, j - 1)]) +
+                      (w.bzon[n] * w.vbt_Cor[g.v2(i, j)] + w.dzon[n] * w.vbt_Cor[g.v2(i + 1, j - 1)]));
+  });
+  launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int j) {
+    w.Cor_ref_v[g.v2(i, j)] = -1.0 * ((w.amer[g.u2(i - 1, j)] * w.ubt_Cor[g.u2(i - 1, j)] + w.cmer[g.u2(i, j + 1)] * w.ubt_Cor[g.u2(i, j + 1)]) +
+                                      (w.bmer[g.u2(i, j)] * w.ubt_Cor[g.u2(i, j)] + w.dmer[g.u2(i - 1, j + 1)] * w.ubt_Cor[g.u2(i - 1, j + 1)]));
+  });
+
+  // ---- eta_src :1626-1628 and the transport of the initial velocities (what :1884-1891 evaluates after the first pass)
+  {
+    const double Instep = p.Instep;
+    const double *cor = c.eta_cor;
+    launch2d(s, is, ie, js, je, [=] __device__(int i, int j) { w.eta_src[g.h2(i, j)] = g.mask2dT[g.h2(i, j)] * (Instep * cor[g.h2(i, j)]); });
+    launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) {
+      const long n = g.u2(I, j);
+      w.uhbtp[n] = (use_BT_cont ? find_uhbt(w.ubt[n], w.BU, n) : w.Datu[n] * w.ubt[n]) + w.uhbt0[n];
+    });
+    launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) {
+      const long n = g.v2(i, J);
+      w.vhbtp[n] = (use_BT_cont ? find_uhbt(w.vbt[n], w.BV, n) : w.Datv[n] * w.vbt[n]) + w.vhbt0[n];
+    });
+  }
+
+  // ---- pass_eta_bt_rem, pass_Dat_uv, pass_force_hbt0_Cor_ref :1672-1697
+  {
+    std::vector<double *> f; std::vector<int32_t> pos;
+    auto add = [&](double *a, int ps) { f.push_back(a); pos.push_back(ps); };
+    if (interp) { add(w.eta_PF_1, PH); add(w.d_eta_PF, PH); } else add(w.eta_PF, PH);
+    add(w.eta_src, PH); add(w.bt_rem_u, PU); add(w.bt_rem_v, PV);
+    if (!use_BT_cont) { add(w.Datu, PU); add(w.Datv, PV); }
+    add(w.BT_force_u, PU); add(w.BT_force_v, PV);
+    if (add_uh0) { add(w.uhbt0, PU); add(w.vhbt0, PV); }
+    add(w.Cor_ref_u, PU); add(w.Cor_ref_v, PV);
+    std::vector<int32_t> nk(f.size(), 1);
+    if (int rc = m6::group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size())) return rc;
+  }
+
+  // the filtered sums accumulate straight into the outputs: ubtav, vbtav (CS) and uhbtav, vhbtav
+  launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) { c.ubtav[g.u2(I, j)] = 0.0; duhbtav[g.u2(I, j)] = 0.0; });
+  launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) { c.vbtav[g.v2(i, J)] = 0.0; dvhbtav[g.v2(i, J)] = 0.0; });
+  M6_HIP(hipGetLastError());
+
+  // ---- the barotropic time steps :1812-2462
+  int isv = is, iev = ie, jsv = js, jev = je;
+  for (int n = 1; n <= nt; n++) {
+    if ((iev - stencil < ie) || (jev - stencil < je)) {
+      if (int rc = pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}})) return rc;
+      isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
+    } else {
+      isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
+    }
+    const double wt_end = n * p.Instep;
+    hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, s, g, w, p, isv - 1, iev + 1,
+                       jsv - 1, jev + 1, wt_accel2[n]);
+    const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;
+    for (int ps = 0; ps < 2; ps++) {
+      const bool do_v = (ps == 0) ? v_first : !v_first;
+      if (do_v) {
+        const int i0 = v_first ? isv - 1 : isv, i1 = v_first ? iev + 1 : iev;
+        hipLaunchKernelGGL(bt_vbt_kernel, grid2d(i0, i1, jsv - 1, jev), dim3(64, 4), 0, s, g, w, p, i0, i1, jsv - 1, jev, wt_accel[n],
+                           wt_trans[n], wt_end, c.vbtav, dvhbtav);
+      } else {
+        const int j0 = v_first ? jsv : jsv - 1, j1 = v_first ? jev : jev + 1;
+        hipLaunchKernelGGL(bt_ubt_kernel, grid2d(isv - 1, iev, j0, j1), dim3(64, 4), 0, s, g, w, p, isv - 1, iev, j0, j1, wt_accel[n],
+                           wt_trans[n], wt_end, c.ubtav, duhbtav);
+      }
+    }
+    hipLaunchKernelGGL(bt_eta_kernel, grid2d(isv, iev, jsv, jev), dim3(64, 4), 0, s, g, w, p, isv, iev, jsv, jev, wt_eta[n]);
+  }
+  M6_HIP(hipGetLastError());
+
+  // ---- epilogue :2467-2590
+  {
+    const double dgeo_de = p.dgeo_de;
+    launch2d(s, is, ie, js, je, [=] __device__(int i, int j) {
+      const long n = g.h2(i, j);
+      double ea;
+      if (interp) ea = dgeo_de * (0.5 * (w.eta[n] + deta_in[n]) - (w.eta_PF_1[n] + 0.5 * w.d_eta_PF[n]));
+      else ea = dgeo_de * (0.5 * (w.eta[n] + deta_in[n]) - w.eta_PF[n]);
+      w.e_anom[n] = ea;
+      if (find_etaav) detaav[n] = w.eta_sum[n] * 1.0;
+      deta_out[n] = w.eta_wtd[n] * 1.0;
+    });
+    if (find_etaav) { if (int rc = pass({{detaav, PH}, {w.e_anom, PH}})) return rc; }
+    else { if (int rc = pass({{w.e_anom, PH}})) return rc; }
+    if (int rc = pass({{c.ubtav, PU}, {c.vbtav, PV}, {duhbtav, PU}, {dvhbtav, PV}})) return rc;
+    hipLaunchKernelGGL(bt_accel_layer_kernel<0>, grid2d(is - 1, ie, js, je), dim3(64, 4), 0, s, g, w, dpb, dalu, accel_underflow);
+    hipLaunchKernelGGL(bt_accel_layer_kernel<1>, grid2d(is, ie, js - 1, je), dim3(64, 4), 0, s, g, w, dpb, dalv, accel_underflow);
+  }
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+}  // extern "C"

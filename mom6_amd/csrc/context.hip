@@ -311,6 +311,18 @@ int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
   return 0;
 }
 
+// do_group_pass: the host's collective when the tile has neighbours, the local wrap kernels otherwise
+int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
+  if (ctx->halo_cb) {
+    M6_HIP(hipStreamSynchronize(ctx->stream));
+    M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, pos, nk, n) == 0, "group pass: the domain halo callback failed");
+    return 0;
+  }
+  for (int f = 0; f < n; f++)
+    if (int rc = halo_update_field(ctx, fields[f], pos[f], nk[f])) return rc;
+  return 0;
+}
+
 }  // namespace m6
 
 extern "C" int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,

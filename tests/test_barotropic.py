@@ -107,3 +107,136 @@ def test_btstep_options_change_the_answer_where_they_should():
     # accel_layer differs between layers only through pbce - gtot
     a = base["accel_layer_u"]
     assert np.abs(a[0] - a[-1]).max() > 0
+
+
+# ---- GPU: the HIP path against the oracle, bit for bit ----------------------------------------------------------
+def _gpu_cs(g, cs_o, dg, device, hvel_scheme, **kw):
+    """A barotropic_CS of the product with the oracle CS's parameters; state arrays filled by the product's own
+    barotropic_init / btcalc / bt_mass_source / set_dtbt so that those are checked on the way."""
+    from mom6_amd.barotropic import barotropic_init
+    return barotropic_init(dg, device=device, BT_THICK_SCHEME=hvel_scheme, **kw)
+
+
+def _to(device, a):
+    import torch
+    if a is None:
+        return None
+    return a.copy() if device == "cpu" else torch.from_numpy(a).cuda()
+
+
+def _np(a):
+    return a if isinstance(a, np.ndarray) else a.cpu().numpy()
+
+
+BT_CASES = [
+    dict(),                                                     # defaults: BT_cont fits, layer fluxes, pow drag
+    dict(use_bt_cont=False),                                    # linear face areas, BT_THICK_SCHEME = HARMONIC
+    dict(strong_drag=1),
+    dict(reentrant_x=False),
+    dict(reentrant_x=True, reentrant_y=True),
+    dict(linearized_BT_PV=0),
+    dict(Sadourny=0),
+    dict(adjust_BT_cont=1),
+    dict(visc_rem_u_uh0=1, vel_underflow=1e-9),
+    dict(ni=70, nj=9, nk=3, seed=9),
+    dict(hvel_scheme="HYBRID"), dict(hvel_scheme="ARITHMETIC"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("space", ["device", "host"])
+@pytest.mark.parametrize("kw", BT_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in BT_CASES])
+def test_btstep_matches_oracle_bitwise(kw, space):
+    import torch
+    from mom6_amd.barotropic import barotropic_init, bt_mass_source, btcalc, btstep, set_dtbt
+    from mom6_amd.continuity import BT_cont_type
+    from mom6_amd.tracer_advect import DeviceGrid
+    if space == "host" and kw not in (dict(), dict(use_bt_cont=False)):
+        pytest.skip("the staged path is covered on two cases")
+    device = "cuda" if space == "device" else "cpu"
+    g, cs_o, case, keep = barotropic_case(orc, **kw)
+    dg = DeviceGrid(g)
+    T = lambda a: _to(device, a)
+    cs_kw = {k: v for k, v in kw.items() if k in ("strong_drag", "linearized_BT_PV", "Sadourny", "adjust_BT_cont", "visc_rem_u_uh0",
+                                                  "vel_underflow")}
+    use_bt = kw.get("use_bt_cont", True)
+    scheme = kw.get("hvel_scheme") or ("FROM_BT_CONT" if use_bt else "HARMONIC")
+    CS = barotropic_init(dg, device=device, BT_THICK_SCHEME=scheme, USE_BT_CONT_TYPE=True, **cs_kw)
+    for n in ("IDatu", "IDatv", "q_D", "D_u_Cor", "D_v_Cor"):
+        assert bits_equal(_np(CS.arrays[n]), keep["cs_arrs"][n]), n
+    bt_arrs = {n: T(a) for n, a in keep["bt_arrs"].items()}
+    BT = BT_cont_type(**bt_arrs)
+    h = T(keep["h"])
+    if scheme == "FROM_BT_CONT":
+        btcalc(h, dg, CS, bt_arrs["h_u"], bt_arrs["h_v"])
+    else:
+        btcalc(h, dg, CS)
+    assert bits_equal(_np(CS.frhatu), keep["cs_arrs"]["frhatu"]) and bits_equal(_np(CS.frhatv), keep["cs_arrs"]["frhatv"])
+    bt_mass_source(h, T(case["eta_in"]), True, dg, CS)
+    assert bits_equal(_np(CS.eta_cor), keep["cs_arrs"]["eta_cor"])
+    set_dtbt(dg, CS, pbce=T(case["pbce"]), BT_cont=BT if use_bt else None, gtot_est=g.g_Earth, SSH_add=10.0)
+    assert CS.st.dtbt_max == cs_o.dtbt_max
+    CS.st.dtbt = cs_o.dtbt
+
+    ref = run_oracle(g, cs_o, case, want_etaav=True)
+    out = dict(accel_layer_u=T(g.zeros3(_abi.POS_U)), accel_layer_v=T(g.zeros3(_abi.POS_V)), eta_out=T(g.zeros2(_abi.POS_H)),
+               uhbtav=T(g.zeros2(_abi.POS_U)), vhbtav=T(g.zeros2(_abi.POS_V)), etaav=T(g.zeros2(_abi.POS_H)))
+    c = {k: T(v) for k, v in case.items() if isinstance(v, np.ndarray)}
+    btstep(c["U_in"], c["V_in"], c["eta_in"], case["dt"], c["bc_accel_u"], c["bc_accel_v"], (c["taux"], c["tauy"]), c["pbce"],
+           c["eta_PF_in"], c["U_Cor"], c["V_Cor"], out["accel_layer_u"], out["accel_layer_v"], out["eta_out"], out["uhbtav"],
+           out["vhbtav"], dg, CS, c["visc_rem_u"], c["visc_rem_v"], BT_cont=BT if use_bt else None, uh0=c["uh0"], vh0=c["vh0"],
+           u_uh0=c["u_uh0"], v_vh0=c["v_vh0"], etaav=out["etaav"])
+    dg.sync()
+    assert CS.st.nstep_last == cs_o.nstep_last
+    for n in ("uhbtav", "vhbtav", "eta_out", "etaav", "accel_layer_u", "accel_layer_v"):
+        a, b = _np(out[n]), ref[n]
+        assert bits_equal(a, b), (n, float(np.abs(a - b).max()), int((a != b).sum()))
+    assert bits_equal(_np(CS.ubtav), keep["cs_arrs"]["ubtav"]) and bits_equal(_np(CS.vbtav), keep["cs_arrs"]["vbtav"])
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_btstep_optional_arguments_gpu():
+    """Predictor-style call: no etaav, eta_PF_start given, bottom stress given, no layer fluxes; eta_out aliases eta_in."""
+    import torch
+    from mom6_amd.barotropic import barotropic_init, bt_mass_source, btcalc, btstep
+    from mom6_amd.continuity import BT_cont_type
+    from mom6_amd.tracer_advect import DeviceGrid
+    g, cs_o, case, keep = barotropic_case(orc, seed=11)
+    rng = np.random.default_rng(3)
+    eps = np.ascontiguousarray(case["eta_PF_in"] + 0.01 * rng.standard_normal(case["eta_PF_in"].shape) * g.mask2dT)
+    tbx = np.ascontiguousarray(0.01 * rng.standard_normal(g.shape2(_abi.POS_U)) * g.mask2dCu)
+    tby = np.ascontiguousarray(0.01 * rng.standard_normal(g.shape2(_abi.POS_V)) * g.mask2dCv)
+    ref = run_oracle(g, cs_o, case, eta_PF_start=eps, taux_bot=tbx, tauy_bot=tby, uh0=None, vh0=None, u_uh0=None, v_vh0=None)
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(a).cuda()
+    CS = barotropic_init(dg, BT_THICK_SCHEME="FROM_BT_CONT")
+    bt_arrs = {n: T(a) for n, a in keep["bt_arrs"].items()}
+    BT = BT_cont_type(**bt_arrs)
+    btcalc(T(keep["h"]), dg, CS, bt_arrs["h_u"], bt_arrs["h_v"])
+    bt_mass_source(T(keep["h"]), T(case["eta_in"]), True, dg, CS)
+    CS.st.dtbt = cs_o.dtbt
+    c = {k: T(v) for k, v in case.items() if isinstance(v, np.ndarray)}
+    alu, alv = T(g.zeros3(_abi.POS_U)), T(g.zeros3(_abi.POS_V))
+    uhb, vhb = T(g.zeros2(_abi.POS_U)), T(g.zeros2(_abi.POS_V))
+    eta = c["eta_in"].clone()
+    btstep(c["U_in"], c["V_in"], eta, case["dt"], c["bc_accel_u"], c["bc_accel_v"], (c["taux"], c["tauy"]), c["pbce"], c["eta_PF_in"],
+           c["U_Cor"], c["V_Cor"], alu, alv, eta, uhb, vhb, dg, CS, c["visc_rem_u"], c["visc_rem_v"], BT_cont=BT, eta_PF_start=T(eps),
+           taux_bot=T(tbx), tauy_bot=T(tby))
+    dg.sync()
+    sj, si = g.csl(_abi.POS_H)
+    assert bits_equal(eta.cpu().numpy()[sj, si], ref["eta_out"][sj, si])
+    assert bits_equal(uhb.cpu().numpy(), ref["uhbtav"]) and bits_equal(alv.cpu().numpy(), ref["accel_layer_v"])
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_btstep_refuses_what_it_does_not_provide():
+    from mom6_amd._lib import Mom6HipError
+    from mom6_amd.barotropic import barotropic_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    g, cs_o, case, keep = barotropic_case(orc)
+    dg = DeviceGrid(g)
+    with pytest.raises(Mom6HipError, match="INTEGRAL_BT_CONTINUITY"):
+        barotropic_init(dg, INTEGRAL_BT_CONTINUITY=True)
+    dg.close()
