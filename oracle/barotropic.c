@@ -23,7 +23,9 @@
  * + - * / fma only and rounded once, so that the HIP kernel can reproduce it bit for bit.  orc_cr_pow and libm
  * differ only where libm's result is not the correctly rounded one (tests/test_barotropic.py counts them).
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,6 +36,11 @@ static inline double min2(double a, double b) { return a < b ? a : b; }
 static inline double max4(double a, double b, double c, double d) { return max2(max2(max2(a, b), c), d); }
 
 #define SUBROUNDOFF 1e-30 /* MOM_barotropic.F90:413 */
+
+/* wall time the last orc_btstep call spent in its time-step loop (the 2-D part, independent of nk); lets bench.py's
+ * cpu_baseline scale the 3-D and the 2-D parts of a reduced-layer sample separately */
+double orc_btstep_loop_seconds = 0.0;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 /* ------------------------------------------------------------------------------------------------
  * A correctly rounded x**y for 0 < x <= 1, 0 < y <= 1 (the only use: av_rem ** (1/nstep)).
@@ -725,6 +732,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
 
   /* ---- the barotropic time steps :1812-2462 */
   int isv = is, iev = ie, jsv = js, jev = je;
+  const double t_loop0 = now_s();
   for (int n = 1; n <= nt; n++) {
     if ((iev - stencil < ie) || (jev - stencil < je)) {
       orc_halo_update(G, eta, MOM6HIP_POS_H, 1); orc_halo_update(G, ubt, MOM6HIP_POS_U, 1); orc_halo_update(G, vbt, MOM6HIP_POS_V, 1);
@@ -818,6 +826,8 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       eta_wtd[H2(i, j)] = eta_wtd[H2(i, j)] + eta[H2(i, j)] * wt_eta[n];
     }
   }
+
+  orc_btstep_loop_seconds = now_s() - t_loop0;
 
   /* ---- epilogue :2467-2590 (answer_date >= 20190101: the I_sum_wt are 1) */
   if (find_etaav) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) etaav[H2(i, j)] = eta_sum[H2(i, j)] * 1.0;

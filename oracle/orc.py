@@ -348,7 +348,7 @@ def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy,
                uhbtav=grid.zeros2(_abi.POS_U), vhbtav=grid.zeros2(_abi.POS_V))
     if want_etaav:
         out["etaav"] = grid.zeros2(_abi.POS_H)
-    rz = (1.0 / grid.Rho0) * grid.Z_to_H if RZ_to_H is None else RZ_to_H
+    rz = grid.Z_to_H / grid.Rho0 if RZ_to_H is None else RZ_to_H
     rc = L.orc_btstep(C.byref(grid.struct()), C.byref(cs), _p(U_in), _p(V_in), _p(eta_in), float(dt), _p(bc_accel_u),
                       _p(bc_accel_v), _p(taux), _p(tauy), float(rz), _p(pbce), _p(eta_PF_in), _p(U_Cor), _p(V_Cor),
                       _p(out["accel_layer_u"]), _p(out["accel_layer_v"]), _p(out["eta_out"]), _p(out["uhbtav"]),

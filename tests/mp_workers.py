@@ -107,3 +107,58 @@ def advect_layout_worker(rank, world, port, layout, scheme, out_dir):
             dg1.close()
     finally:
         dist.destroy_process_group()
+
+
+def btstep_layout_worker(rank, world, port, layout, topo, out_dir):
+    """test.layout for btstep on the GPU: each tile runs barotropic_init / btcalc / bt_mass_source / btstep with the
+    group passes going through the domain callbacks; the compute-domain results must equal the one-tile oracle run."""
+    import numpy as np
+    import torch
+    from helpers import barotropic_case
+    from mom6_amd import _abi
+    from mom6_amd.barotropic import barotropic_init, bt_mass_source, btcalc, btstep, set_dtbt
+    from mom6_amd.continuity import BT_cont_type
+    from mom6_amd.domains import Domain
+    from mom6_amd.tracer_advect import DeviceGrid
+    from oracle import orc
+    dist = _init(rank, world, port)
+    try:
+        gg, cs_o, case, keep = barotropic_case(orc, ni=36, nj=24, nk=3, seed=21, reentrant_x=topo[0], reentrant_y=topo[1])
+        dom = Domain(gg.ni, gg.nj, layout, rank, gg.halo, topo[0], topo[1])
+        tg = dom.tile_grid(gg)
+        dg = DeviceGrid(tg)
+        dg.set_domain(dom)
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+        pos = dict(U_in=U, V_in=V, eta_in=H, bc_accel_u=U, bc_accel_v=V, taux=U, tauy=V, pbce=H, eta_PF_in=H, U_Cor=U, V_Cor=V,
+                   visc_rem_u=U, visc_rem_v=V, uh0=U, vh0=V, u_uh0=U, v_vh0=V)
+        c = {k: torch.from_numpy(dom.cut(case[k], p)).cuda() for k, p in pos.items()}
+        bt_arrs = {}
+        for n, a in keep["bt_arrs"].items():
+            p = U if (n in _abi.BT_CONT_U or n == "h_u") else V
+            bt_arrs[n] = torch.from_numpy(dom.cut(a, p)).cuda()
+        BT = BT_cont_type(**bt_arrs)
+        CS = barotropic_init(dg, BT_THICK_SCHEME="FROM_BT_CONT")
+        h = torch.from_numpy(dom.cut(keep["h"], H)).cuda()
+        btcalc(h, dg, CS, bt_arrs["h_u"], bt_arrs["h_v"])
+        bt_mass_source(h, c["eta_in"], True, dg, CS)
+        dtbt_max = set_dtbt(dg, CS, pbce=c["pbce"], BT_cont=BT)          # min_across_PEs inside
+        CS.st.dtbt = cs_o.dtbt
+        Z = lambda p, k3: torch.zeros(tg.shape3(p) if k3 else tg.shape2(p), dtype=torch.float64, device="cuda")
+        out = dict(accel_layer_u=Z(U, True), accel_layer_v=Z(V, True), eta_out=Z(H, False), uhbtav=Z(U, False), vhbtav=Z(V, False),
+                   etaav=Z(H, False))
+        btstep(c["U_in"], c["V_in"], c["eta_in"], case["dt"], c["bc_accel_u"], c["bc_accel_v"], (c["taux"], c["tauy"]), c["pbce"],
+               c["eta_PF_in"], c["U_Cor"], c["V_Cor"], out["accel_layer_u"], out["accel_layer_v"], out["eta_out"], out["uhbtav"],
+               out["vhbtav"], dg, CS, c["visc_rem_u"], c["visc_rem_v"], BT_cont=BT, uh0=c["uh0"], vh0=c["vh0"], u_uh0=c["u_uh0"],
+               v_vh0=c["v_vh0"], etaav=out["etaav"])
+        dg.sync()
+        np.savez(os.path.join(out_dir, f"bt_tile{rank}.npz"), ij=np.array([dom.i0, dom.j0, dom.ni, dom.nj]), dtbt_max=dtbt_max,
+                 **{k: v.cpu().numpy() for k, v in out.items()})
+        dg.close()
+        if rank == 0:
+            orc.set_dtbt(gg, cs_o, pbce=case["pbce"], bt_cont=case["bt_cont"])
+            dm = cs_o.dtbt_max
+            cs_o.dtbt = CS.st.dtbt
+            ref = orc.btstep(gg, cs_o, **{k: case[k] for k in pos}, dt=case["dt"], bt_cont=case["bt_cont"], want_etaav=True)
+            np.savez(os.path.join(out_dir, "bt_global.npz"), dtbt_max=dm, **ref)
+    finally:
+        dist.destroy_process_group()

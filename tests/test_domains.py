@@ -55,3 +55,21 @@ def test_advect_tracer_layout_independence(tmp_path, layout, scheme):
         for m in range(ntr):
             a = t[f"arr_{m}"]; b = glob[f"arr_{m}"][:, j0:j0 + nj, i0:i0 + ni]
             assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, scheme, r, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,topo", [((1, 2), (True, False)), ((2, 1), (True, False)), ((2, 1), (False, False)), ((1, 2), (True, True))])
+def test_btstep_layout_independence(tmp_path, layout, topo):
+    import torch.multiprocessing as mp
+    from mp_workers import btstep_layout_worker
+    mp.spawn(btstep_layout_worker, args=(2, free_port(), layout, topo, str(tmp_path)), nprocs=2, join=True)
+    glob = np.load(tmp_path / "bt_global.npz")
+    h = 4
+    for r in range(2):
+        t = np.load(tmp_path / f"bt_tile{r}.npz")
+        i0, j0, ni, nj = t["ij"]
+        assert float(t["dtbt_max"]) == float(glob["dtbt_max"])
+        for n, (xs, ys) in dict(eta_out=(0, 0), etaav=(0, 0), uhbtav=(1, 0), vhbtav=(0, 1), accel_layer_u=(1, 0), accel_layer_v=(0, 1)).items():
+            a = t[n][..., h:h + nj + ys, h:h + ni + xs]
+            b = glob[n][..., h + j0:h + j0 + nj + ys, h + i0:h + i0 + ni + xs]
+            assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, topo, r, n)
