@@ -395,6 +395,76 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
                    const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
                    const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav, int32_t memspace);
 
+/* ---- MOM_dynamics_split_RK2 ------------------------------------------------------------------ */
+
+/*
+ * The parameterisation calls inside the split RK2 step that this library does not provide:
+ * set_viscous_ML + vertvisc_coef + vertvisc_remnant (src/core/MOM_dynamics_split_RK2.F90:592-600),
+ * vertvisc_coef + vertvisc + vertvisc_remnant (:717-744 with dt_pred, :974-994 with dt) and
+ * horizontal_viscosity (:860).  A host that has them registers them here; they are called at the reference's
+ * seams with DEVICE pointers after the library has synchronised its stream.  With no hooks the step is the
+ * inviscid one: visc_rem_u = visc_rem_v = 1, diffu = diffv = 0, velocities untouched by vertvisc.
+ */
+typedef struct mom6hip_visc_hooks {
+  void *user;
+  int (*visc_remnant_pred)(void *user, const double *up, const double *vp, const double *h, double dt,
+                           double *visc_rem_u, double *visc_rem_v);
+  int (*vertvisc)(void *user, double *u, double *v, const double *h, double dt, double *visc_rem_u, double *visc_rem_v);
+  int (*horizontal_viscosity)(void *user, const double *u_av, const double *v_av, const double *h_av, double *diffu,
+                              double *diffv);
+} mom6hip_visc_hooks_t;
+
+/*
+ * MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84-268: the parameters the provided branch reads, the
+ * control structures of the modules the step calls, and the arrays the reference keeps in the control structure
+ * between steps.  Every array is a DEVICE array owned by the caller (a MOM6 executable would keep these mirrors
+ * for the whole run and copy out only what diagnostics and restarts need).
+ */
+typedef struct mom6hip_dyn_split_rk2_cs {
+  double be;                     /* BE (0.6) */
+  double begw;                   /* BEGW; must be 0 */
+  int32_t BT_use_layer_fluxes;   /* BT_USE_LAYER_FLUXES (1) */
+  int32_t store_CAu;             /* STORE_CORIOLIS_ACCEL (1) */
+  int32_t CAu_pred_stored;       /* state: CAu_pred / CAv_pred hold the next predictor's Coriolis terms */
+  int32_t split_bottom_stress;   /* SPLIT_BOTTOM_STRESS; must be 0 */
+  int32_t reserved0[4];
+  const mom6hip_continuity_cs_t *continuity_CSp;
+  const mom6hip_coriolisadv_cs_t *CoriolisAdv;
+  const mom6hip_pressureforce_cs_t *PressureForce_CSp;
+  const mom6hip_eos_t *eqn_of_state;          /* tv%eqn_of_state */
+  mom6hip_barotropic_cs_t *barotropic_CSp;    /* its arrays are DEVICE arrays too */
+  const mom6hip_bt_cont_t *BT_cont;           /* NULL: USE_BT_CONT_TYPE = False */
+  const mom6hip_visc_hooks_t *hooks;          /* NULL: inviscid */
+  const void *reserved1[3];
+  /* 3-D */
+  double *CAu, *CAv, *CAu_pred, *CAv_pred, *PFu, *PFv, *diffu, *diffv, *visc_rem_u, *visc_rem_v, *u_accel_bt,
+      *v_accel_bt, *u_av, *v_av, *h_av, *pbce;
+  /* 2-D */
+  double *eta, *eta_PF, *uhbt, *vhbt;
+  void *reserved2[4];
+} mom6hip_dyn_split_rk2_cs_t;
+
+/* The part of initialize_dyn_split_RK2 (:1326) that sets state: eta from the layer thicknesses (:1521-1535),
+ * u_av = u, v_av = v (:1552-1558), diffu/diffv (hook or zero), visc_rem = 1 without hooks, and for store_CAu the
+ * first uh, vh, h_av, CAu_pred, CAv_pred (:1560-1588) with their halo passes (:1615-1622).
+ * barotropic_init must have been called on cs->barotropic_CSp. */
+int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, const double *u, const double *v,
+                               const double *h, double *uh, double *vh, double dt);
+
+/*
+ * step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
+ *                        vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves)
+ *                                                                  src/core/MOM_dynamics_split_RK2.F90:289
+ * tv%T, tv%S are passed as T, S; forces%taux, %tauy as taux, tauy with RZ_to_H; p_surf_begin / p_surf_end, OBC, Waves,
+ * FPMIX and BEGW /= 0 are not provided.  All arrays are DEVICE arrays.  The whole step is enqueued on the context's
+ * stream without host synchronisation, except for set_dtbt when calc_dtbt /= 0, the group passes of a multi-tile
+ * domain and the hooks.
+ */
+int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_inst, double *v_inst,
+                               double *h, const double *T, const double *S, double dt, const double *taux,
+                               const double *tauy, double RZ_to_H, double *uh, double *vh, double *uhtr, double *vhtr,
+                               double *eta_av, int32_t calc_dtbt);
+
 #ifdef __cplusplus
 }
 #endif

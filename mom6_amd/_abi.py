@@ -111,3 +111,21 @@ class BarotropicCS(C.Structure):
                 + [("unsupported", C.c_int32 * 12), ("reserved1", C.c_int32 * 4)]
                 + [(n, C.c_void_p) for n, _, _ in BT_CS_ARRAYS]
                 + [("reserved2", C.c_void_p * 6)])
+
+
+# ---- MOM_dynamics_split_RK2 -----------------------------------------------------------------------------
+RK2_ARRAYS_3D = (("CAu", POS_U), ("CAv", POS_V), ("CAu_pred", POS_U), ("CAv_pred", POS_V), ("PFu", POS_U), ("PFv", POS_V),
+                 ("diffu", POS_U), ("diffv", POS_V), ("visc_rem_u", POS_U), ("visc_rem_v", POS_V), ("u_accel_bt", POS_U),
+                 ("v_accel_bt", POS_V), ("u_av", POS_U), ("v_av", POS_V), ("h_av", POS_H), ("pbce", POS_H))
+RK2_ARRAYS_2D = (("eta", POS_H), ("eta_PF", POS_H), ("uhbt", POS_U), ("vhbt", POS_V))
+
+
+class DynSplitRK2CS(C.Structure):
+    """mom6hip_dyn_split_rk2_cs_t (include/mom6hip.h)."""
+    _fields_ = ([("be", C.c_double), ("begw", C.c_double), ("BT_use_layer_fluxes", C.c_int32), ("store_CAu", C.c_int32),
+                 ("CAu_pred_stored", C.c_int32), ("split_bottom_stress", C.c_int32), ("reserved0", C.c_int32 * 4),
+                 ("continuity_CSp", C.c_void_p), ("CoriolisAdv", C.c_void_p), ("PressureForce_CSp", C.c_void_p),
+                 ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
+                 ("reserved1", C.c_void_p * 3)]
+                + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
+                + [("reserved2", C.c_void_p * 4)])

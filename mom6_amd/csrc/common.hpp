@@ -88,6 +88,7 @@ struct mom6hip_ctx {
   // advect_tracer work space (device)
   m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
+  m6::DevBuf rk2_scratch;       // the automatic arrays of step_MOM_dyn_split_RK2
   int *h_domore_k = nullptr;    // pinned host mirror of domore_k
   // multi-tile collectives provided by the host (null on a one-tile domain)
   mom6hip_halo_fn halo_cb = nullptr;

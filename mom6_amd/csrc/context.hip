@@ -226,6 +226,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->stage) b.release();
   for (auto &b : ctx->tr_stage) b.release();
   for (auto &b : ctx->pool) b.release();
+  ctx->rk2_scratch.release();
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
   delete ctx;
   return 0;

@@ -1,0 +1,281 @@
+// dyn_split_rk2.hip -- step_MOM_dyn_split_RK2 on MI355X: the orchestration of the split RK2 step and its own
+// streaming sweeps (src/core/MOM_dynamics_split_RK2.F90:289-1176; state initialisation :1521-1622).
+//
+// The whole step is enqueued on the context's stream in the reference's order: PressureForce, [CorAdCalc],
+// continuity[BT_cont], btcalc, bt_mass_source, btstep (predictor), continuity (predictor), CorAdCalc, btstep
+// (corrector), continuity (corrector), [CorAdCalc for the next predictor], with the group passes of the reference at
+// the reference's seams.  The momentum sweeps (:557-564, :582-589, :667-676, :785-787, :879-886, :930-939,
+// :1000-1002, :1038-1053) are plain i-contiguous streaming kernels; each is HBM-bound at 24-40 B/cell.
+// All arrays are device arrays: nothing is staged, and without hooks / multi-tile passes / calc_dtbt nothing
+// synchronises with the host.
+#include "common.hpp"
+
+#include <initializer_list>
+#include <utility>
+
+namespace m6 {
+int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+}
+
+namespace {
+
+template <class F> __global__ void __launch_bounds__(256) range3d_kernel(int i0, int i1, int j0, int j1, F f) {
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (i <= i1 && j <= j1) f(i, j, (int)blockIdx.z);
+}
+// one thread per (i, j, k) of an inclusive horizontal range, all layers, i fastest
+template <class F> void launch3d(hipStream_t st, int i0, int i1, int j0, int j1, int nk, F f) {
+  if (i1 < i0 || j1 < j0) return;
+  dim3 grid((i1 - i0 + 64) / 64, (j1 - j0 + 4) / 4, nk), block(64, 4);
+  hipLaunchKernelGGL(range3d_kernel<F>, grid, block, 0, st, i0, i1, j0, j1, f);
+}
+
+struct Sz { size_t h2, h3, u3, v3; };
+Sz sizes(const m6::GridDev &g) {
+  Sz s;
+  s.h2 = sizeof(double) * (size_t)g.nih * g.njh; s.h3 = s.h2 * g.nk;
+  s.u3 = sizeof(double) * (size_t)(g.nih + 1) * g.njh * g.nk; s.v3 = sizeof(double) * (size_t)g.nih * (g.njh + 1) * g.nk;
+  return s;
+}
+
+int pass(mom6hip_ctx_t *ctx, std::initializer_list<std::pair<double *, int>> fl, int nk3) {
+  std::vector<double *> f; std::vector<int32_t> pos, nk;
+  for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second & 3); nk.push_back((e.second & 4) ? 1 : nk3); }
+  return m6::group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size());
+}
+constexpr int PH = MOM6HIP_POS_H, PU = MOM6HIP_POS_U, PV = MOM6HIP_POS_V, P2D = 4;
+
+int check(const mom6hip_dyn_split_rk2_cs_t *cs, const char *who) {
+  M6_REQUIRE(cs != nullptr, "%s: null control structure", who);
+  M6_REQUIRE(cs->begw == 0.0, "%s: BEGW /= 0 is not provided", who);
+  M6_REQUIRE(!cs->split_bottom_stress, "%s: SPLIT_BOTTOM_STRESS is not provided", who);
+  M6_REQUIRE(cs->continuity_CSp && cs->CoriolisAdv && cs->PressureForce_CSp && cs->eqn_of_state && cs->barotropic_CSp,
+             "%s: a sub-module control structure is missing", who);
+  M6_REQUIRE(cs->CAu && cs->CAv && cs->CAu_pred && cs->CAv_pred && cs->PFu && cs->PFv && cs->diffu && cs->diffv && cs->visc_rem_u &&
+                 cs->visc_rem_v && cs->u_accel_bt && cs->v_accel_bt && cs->u_av && cs->v_av && cs->h_av && cs->pbce && cs->eta &&
+                 cs->eta_PF && cs->uhbt && cs->vhbt, "%s: an array of the control structure is not allocated", who);
+  return 0;
+}
+
+#define CALL(x) do { if (int rc_ = (x)) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, const double *u, const double *v, const double *h,
+                               double *uh, double *vh, double dt) {
+  M6_REQUIRE(ctx && u && v && h && uh && vh, "dyn_split_rk2_init: null argument");
+  CALL(check(cs, "dyn_split_rk2_init"));
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  hipStream_t s = ctx->stream;
+  const int D = MOM6HIP_MEM_DEVICE;
+  // eta :1521-1535
+  {
+    double *eta = cs->eta;
+    const double Z_to_H = g.Z_to_H;
+    const long hstr = (long)g.nih * g.njh;
+    const int nz = g.nk;
+    launch3d(s, g.isc, g.iec, g.jsc, g.jec, 1, [=] __device__(int i, int j, int) {
+      const long n = g.h2(i, j);
+      double e = -Z_to_H * g.bathyT[n];
+      for (int k = 0; k < nz; k++) e = e + h[n + hstr * k];
+      eta[n] = e;
+    });
+  }
+  M6_HIP(hipMemsetAsync(cs->diffu, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(cs->diffv, 0, sz.v3, s));
+  if (cs->hooks && cs->hooks->horizontal_viscosity) {   // :1543-1550
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(cs->hooks->horizontal_viscosity(cs->hooks->user, u, v, h, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
+  }
+  {
+    double *vru = cs->visc_rem_u, *vrv = cs->visc_rem_v;
+    launch3d(s, g.isd - 1, g.ied, g.jsd, g.jed, g.nk, [=] __device__(int i, int j, int k) { vru[g.u3(i, j, k)] = 1.0; });
+    launch3d(s, g.isd, g.ied, g.jsd - 1, g.jed, g.nk, [=] __device__(int i, int j, int k) { vrv[g.v3(i, j, k)] = 1.0; });
+  }
+  M6_HIP(hipMemcpyAsync(cs->u_av, u, sz.u3, hipMemcpyDeviceToDevice, s));     // :1552-1558
+  M6_HIP(hipMemcpyAsync(cs->v_av, v, sz.v3, hipMemcpyDeviceToDevice, s));
+  // :1560-1610: first transports, h_av and (store_CAu) the predictor's Coriolis terms
+  {
+    double *h_tmp = cs->CAu;   // free at this point; CAu is rewritten by the first step before it is read
+    M6_REQUIRE(sz.u3 >= sz.h3, "dyn_split_rk2_init: internal scratch too small");
+    M6_HIP(hipMemcpyAsync(h_tmp, h, sz.h3, hipMemcpyDeviceToDevice, s));
+    const double *uu = cs->store_CAu ? cs->u_av : u, *vv = cs->store_CAu ? cs->v_av : v;
+    CALL(mom6hip_continuity(ctx, cs->continuity_CSp, uu, vv, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, D));
+    CALL(pass(ctx, {{h_tmp, PH}}, g.nk));
+    double *h_av = cs->h_av;
+    launch3d(s, g.isd, g.ied, g.jsd, g.jed, g.nk, [=] __device__(int i, int j, int k) {
+      const long n = g.h3(i, j, k);
+      h_av[n] = 0.5 * (h[n] + h_tmp[n]);
+    });
+  }
+  if (cs->store_CAu) {
+    CALL(pass(ctx, {{cs->u_av, PU}, {cs->v_av, PV}, {uh, PU}, {vh, PV}}, g.nk));
+    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, cs->u_av, cs->v_av, cs->h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+    cs->CAu_pred_stored = 1;
+    CALL(pass(ctx, {{cs->u_av, PU}, {cs->v_av, PV}, {cs->CAu_pred, PU}, {cs->CAv_pred, PV}}, g.nk));   // :1615-1622
+  } else {
+    cs->CAu_pred_stored = 0;
+    CALL(pass(ctx, {{cs->u_av, PU}, {cs->v_av, PV}, {cs->h_av, PH}, {uh, PU}, {vh, PV}}, g.nk));
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
+int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_inst, double *v_inst, double *h,
+                               const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
+                               double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int32_t calc_dtbt) {
+  M6_REQUIRE(ctx && u_inst && v_inst && h && T && S && taux && tauy && uh && vh && uhtr && vhtr && eta_av,
+             "step_MOM_dyn_split_RK2: null argument");
+  CALL(check(cs, "step_MOM_dyn_split_RK2"));
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  hipStream_t s = ctx->stream;
+  const int D = MOM6HIP_MEM_DEVICE;
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec, nz = g.nk;
+  const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+  mom6hip_barotropic_cs_t *BT = cs->barotropic_CSp;
+  const mom6hip_bt_cont_t *BTC = cs->BT_cont;
+  const bool BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
+  const mom6hip_visc_hooks_t *hk = cs->hooks;
+
+  // the step's automatic arrays (:336-369): one grow-only block in the context's pool
+  // (its own buffer: the modules called below hand out the pool's buffers from the start in every call)
+  M6_REQUIRE(ctx->rk2_scratch.reserve(3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2) == 0, "step_MOM_dyn_split_RK2: out of device memory");
+  char *blk = (char *)ctx->rk2_scratch.p;
+  double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3);
+  double *vp = (double *)(blk + 3 * sz.u3), *v_bc = (double *)(blk + 3 * sz.u3 + sz.v3), *vh_in = (double *)(blk + 3 * sz.u3 + 2 * sz.v3);
+  double *hp = (double *)(blk + 3 * sz.u3 + 3 * sz.v3), *eta_pred = (double *)(blk + 3 * sz.u3 + 3 * sz.v3 + sz.h3);
+  double *u_av = cs->u_av, *v_av = cs->v_av, *h_av = cs->h_av, *eta = cs->eta;
+
+  M6_HIP(hipMemsetAsync(up, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(vp, 0, sz.v3, s));                 // :419-421
+  M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :422
+  M6_HIP(hipMemsetAsync(u_bc, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(v_bc, 0, sz.v3, s));
+  M6_HIP(hipMemsetAsync(uh_in, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(vh_in, 0, sz.v3, s));
+  M6_HIP(hipMemsetAsync(eta_pred, 0, sz.h2, s));
+
+  // PressureForce :495
+  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,
+                                      cs->eta_PF, D));
+  if (!cs->CAu_pred_stored)   // :544-552
+    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+
+  // u_bc_accel = (CAu_pred + PFu) + diffu ; up = mask*(u + dt*u_bc_accel)   :557-564, :582-589
+  auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
+    const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      const double a = (CAu[n] + PFu[n]) + diffu[n];
+      u_bc[n] = a;
+      if (first_up) up[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt * a);
+    });
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      const double a = (CAv[n] + PFv[n]) + diffv[n];
+      v_bc[n] = a;
+      if (first_up) vp[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt * a);
+    });
+  };
+  bc_accel(cs->CAu_pred, cs->CAv_pred, true);
+  if (hk && hk->visc_remnant_pred) {   // set_viscous_ML, vertvisc_coef, vertvisc_remnant :592-600
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
+  }
+  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}}, nz));                 // :610-611
+
+  // btcalc, bt_mass_source :627-630 ; continuity for BT_cont and the layer fluxes :634-644
+  if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));
+  CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
+  if (BTC || cs->BT_use_layer_fluxes) {
+    CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,
+                            cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
+    if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));
+  }
+  if (calc_dtbt) CALL(mom6hip_set_dtbt(ctx, BT, cs->pbce, nullptr, 0.0, 0.0, D));                       // :651
+  const bool lf = cs->BT_use_layer_fluxes != 0;
+  CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :655
+                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                      nullptr, lf ? uh_in : nullptr, lf ? vh_in : nullptr, lf ? u_inst : nullptr, lf ? v_inst : nullptr, nullptr, D));
+
+  // up = u + dt_pred*(u_bc_accel + u_accel_bt) :663-676
+  const double dt_pred = dt * cs->be;
+  {
+    const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      vp[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt_pred * (v_bc[n] + abv[n]));
+    });
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      up[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt_pred * (u_bc[n] + abu[n]));
+    });
+  }
+  if (hk && hk->vertvisc) {   // vertvisc_coef, vertvisc, vertvisc_remnant :717-744
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->vertvisc(hk->user, up, vp, h, dt_pred, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
+  }
+  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {up, PU}, {vp, PV}}, nz));            // :747, :751
+  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
+                          u_av, v_av, BTC, nullptr, nullptr, D));
+  CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :763
+  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {             // :785-787
+    const long n = g.h3(i, j, k);
+    h_av[n] = 0.5 * (h[n] + hp[n]);
+  });
+  CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :797
+  if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :843
+  if (hk && hk->horizontal_viscosity) {   // :860
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->horizontal_viscosity(hk->user, u_av, v_av, h_av, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
+  }
+  CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
+  bc_accel(cs->CAu, cs->CAv, false);                                                                  // :879-886
+  CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :911
+                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                      nullptr, lf ? uh : nullptr, lf ? vh : nullptr, lf ? u_av : nullptr, lf ? v_av : nullptr, eta_av, D));
+  launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :918
+  {   // u = u + dt*(u_bc_accel + u_accel_bt) :928-939
+    const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      u_inst[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt * (u_bc[n] + abu[n]));
+    });
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      v_inst[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt * (v_bc[n] + abv[n]));
+    });
+  }
+  if (hk && hk->vertvisc) {   // :974-994
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->vertvisc(hk->user, u_inst, v_inst, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
+  }
+  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
+  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {u_inst, PU}, {v_inst, PV}}, nz));     // :1004, :1008
+  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :1015
+                          cs->visc_rem_v, u_av, v_av, nullptr, nullptr, nullptr, D));
+  CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :1018, :1027
+  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {              // :1038-1040
+    const long n = g.h3(i, j, k);
+    h_av[n] = 0.5 * (h_av[n] + h[n]);
+  });
+  launch3d(s, Isq - 2, Ieq + 2, js - 2, je + 2, nz, [=] __device__(int I, int j, int k) {            // :1046-1053
+    const long n = g.u3(I, j, k);
+    uhtr[n] = uhtr[n] + uh[n] * dt;
+  });
+  launch3d(s, is - 2, ie + 2, Jsq - 2, Jeq + 2, nz, [=] __device__(int i, int J, int k) {
+    const long n = g.v3(i, J, k);
+    vhtr[n] = vhtr[n] + vh[n] * dt;
+  });
+  if (cs->store_CAu) {   // :1055-1069
+    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+    cs->CAu_pred_stored = 1;
+  } else {
+    cs->CAu_pred_stored = 0;
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

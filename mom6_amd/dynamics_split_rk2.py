@@ -1,0 +1,106 @@
+"""Host-side mirror of MOM_dynamics_split_RK2 (reference: src/core/MOM_dynamics_split_RK2.F90):
+initialize_dyn_split_RK2 (:1326) and step_MOM_dyn_split_RK2 (:289).  The step itself is one call into the library,
+which enqueues every kernel of the step on the GPU in the reference's order; this module only owns the control
+structures and the device arrays the reference keeps in MOM_dyn_split_RK2_CS."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+from .barotropic import barotropic_CS, barotropic_init
+from .continuity import BT_cont_type, continuity_PPM_init
+from .coriolis_adv import CoriolisAdv_init
+from .pressure_force import EOS_init, PressureForce_init
+from .tracer_advect import DeviceGrid
+
+
+def _setup():
+    L = lib()
+    if not getattr(L, "_rk2_ready", False):
+        cs = C.POINTER(_abi.DynSplitRK2CS)
+        L.mom6hip_dyn_split_rk2_init.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [C.c_double]
+        L.mom6hip_step_dyn_split_rk2.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 5 + [C.c_double] + [C.c_void_p] * 2 + [C.c_double]
+                                                 + [C.c_void_p] * 5 + [C.c_int32])
+        L._rk2_ready = True
+    return L
+
+
+class MOM_dyn_split_RK2_CS:
+    """MOM_dyn_split_RK2_CS (:84-268)."""
+
+    def __init__(self, G: DeviceGrid, BE=0.6, BEGW=0.0, BT_USE_LAYER_FLUXES=True, STORE_CORIOLIS_ACCEL=True, USE_BT_CONT_TYPE=True,
+                 EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None):
+        g = G.grid
+        dev = "cuda"
+        self.G = G
+        self.continuity_CSp = continuity_PPM_init(G, **(continuity or {}))
+        self.CoriolisAdv = CoriolisAdv_init(**(coriolis or {}))
+        self.PressureForce_CSp = PressureForce_init(g, **(pressure_force or {}))
+        self.eqn_of_state = EOS_init(EQN_OF_STATE)
+        Z3 = lambda pos: torch.zeros(g.shape3(pos), dtype=torch.float64, device=dev)
+        Z2 = lambda pos: torch.zeros(g.shape2(pos), dtype=torch.float64, device=dev)
+        self.BT_cont = None
+        if USE_BT_CONT_TYPE:      # alloc_BT_cont_type, with h_u / h_v for BT_THICK_SCHEME = FROM_BT_CONT
+            self.BT_cont = BT_cont_type(**{n: Z2(_abi.POS_U) for n in _abi.BT_CONT_U}, **{n: Z2(_abi.POS_V) for n in _abi.BT_CONT_V},
+                                        h_u=Z3(_abi.POS_U), h_v=Z3(_abi.POS_V))
+        bkw = dict(barotropic or {})
+        bkw.setdefault("USE_BT_CONT_TYPE", USE_BT_CONT_TYPE)
+        self.barotropic_CSp: barotropic_CS = barotropic_init(G, **bkw)
+        st = self.st = _abi.DynSplitRK2CS()
+        st.be, st.begw = float(BE), float(BEGW)
+        st.BT_use_layer_fluxes, st.store_CAu = int(bool(BT_USE_LAYER_FLUXES)), int(bool(STORE_CORIOLIS_ACCEL))
+        self._cor_struct = self.CoriolisAdv.struct()
+        st.continuity_CSp = C.addressof(self.continuity_CSp); st.CoriolisAdv = C.addressof(self._cor_struct)
+        st.PressureForce_CSp = C.addressof(self.PressureForce_CSp); st.eqn_of_state = C.addressof(self.eqn_of_state)
+        st.barotropic_CSp = C.addressof(self.barotropic_CSp.st)
+        if self.BT_cont is not None:
+            self._bt_struct = self.BT_cont.struct(set())
+            st.BT_cont = C.addressof(self._bt_struct)
+        self.arrays = {}
+        for n, pos in _abi.RK2_ARRAYS_3D:
+            self.arrays[n] = Z3(pos); setattr(st, n, self.arrays[n].data_ptr())
+        for n, pos in _abi.RK2_ARRAYS_2D:
+            self.arrays[n] = Z2(pos); setattr(st, n, self.arrays[n].data_ptr())
+        self.module_is_initialized = False
+
+    def __getattr__(self, n):
+        a = self.__dict__.get("arrays", {})
+        if n in a:
+            return a[n]
+        raise AttributeError(n)
+
+
+def initialize_dyn_split_RK2(u, v, h, uh, vh, dt, G: DeviceGrid, **params) -> MOM_dyn_split_RK2_CS:
+    """initialize_dyn_split_RK2 (:1326): control structures of the step and of the modules it calls (parameters by
+    their reference names, e.g. BE=0.6, barotropic=dict(BEBT=0.1, DTBT=-0.98)), then the state the first step needs."""
+    CS = MOM_dyn_split_RK2_CS(G, **params)
+    check(_setup().mom6hip_dyn_split_rk2_init(G.handle, C.byref(CS.st), u.data_ptr(), v.data_ptr(), h.data_ptr(), uh.data_ptr(),
+                                              vh.data_ptr(), float(dt)), "initialize_dyn_split_RK2")
+    CS.module_is_initialized = True
+    return CS
+
+
+def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av,
+                           G: DeviceGrid, CS: MOM_dyn_split_RK2_CS, calc_dtbt=False, VarMix=None, MEKE=None,
+                           thickness_diffuse_CSp=None, pbv=None, STOCH=None, Waves=None):
+    """step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
+    vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves) -- :289.
+    tv = (T, S); forces = (taux, tauy).  visc / VarMix / MEKE / ... belong to parameterisations this build does not
+    provide and must be None."""
+    if CS is None or not CS.module_is_initialized:
+        raise Mom6HipError("step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
+    if p_surf_begin is not None or p_surf_end is not None or Waves is not None or pbv is not None:
+        raise Mom6HipError("step_MOM_dyn_split_RK2 (HIP): surface pressure, waves and porous barriers are not supported")
+    g = G.grid
+    T, S = tv[0], tv[1]
+    taux, tauy = forces
+    for a in (u_inst, v_inst, h, T, S, taux, tauy, uh, vh, uhtr, vhtr, eta_av):
+        if not (a.is_cuda and a.is_contiguous() and a.dtype == torch.float64):
+            raise Mom6HipError("step_MOM_dyn_split_RK2: all fields must be contiguous float64 CUDA tensors")
+    P = lambda a: C.c_void_p(a.data_ptr())
+    check(_setup().mom6hip_step_dyn_split_rk2(G.handle, C.byref(CS.st), P(u_inst), P(v_inst), P(h), P(T), P(S), float(dt), P(taux),
+                                              P(tauy), g.Z_to_H / g.Rho0, P(uh), P(vh), P(uhtr), P(vhtr), P(eta_av),
+                                              int(bool(calc_dtbt))), "step_MOM_dyn_split_RK2")

@@ -241,7 +241,7 @@ def fill_halo(g: Grid, a: torch.Tensor, pos: int) -> torch.Tensor:
     return a
 
 
-def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.3, dtype=torch.float64):
+def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.3, dtype=torch.float64, eta_amp=None):
     """A model-like state for the dynamical core: h, u, v, uh, vh, T, S with valid halos.
 
     h: z*-like layers with vanished layers (Angstrom_H) below the topography and in random blobs;
@@ -271,6 +271,12 @@ def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.
     h0 = torch.clamp(h0 * (1.0 + 0.05 * rndn(nk, nj, ni)), min=0.0)
     h0 = torch.where(h0 < 1.0e-3, torch.full_like(h0, g.Angstrom_H), h0)
     h0 = torch.where(mT[None] > 0, h0, torch.full_like(h0, g.Angstrom_H))
+    if eta_amp is not None:
+        # a state that can be time-stepped: the layers fill the column up to a smooth free surface of amplitude
+        # eta_amp [m] (without this the 5 % thickness noise adds up to ~100 m of sea-surface height noise)
+        eta0 = eta_amp * torch.sin(2 * math.pi * X[0]) * torch.sin(math.pi * Y[0])
+        tot = h0.sum(0)
+        h0 = torch.where(mT[None] > 0, h0 * ((depth * g.Z_to_H + eta0) / torch.clamp(tot, min=1e-30))[None], h0)
     h = fill_halo(g, _embed(g, h0, _abi.POS_H) + 0.0, _abi.POS_H)
     # closed-edge halos: keep a positive thickness there too
     h = torch.where(h <= 0, torch.full_like(h, g.Angstrom_H), h)

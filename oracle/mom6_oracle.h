@@ -130,6 +130,13 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
                const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav);
 
+/* ---- MOM_dynamics_split_RK2 (oracle/dyn_split_rk2.c); every pointer in CS is a HOST pointer ------------------- */
+int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *u, const double *v,
+                           const double *h, double *uh, double *vh, double dt);
+int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, double *u_inst, double *v_inst, double *h,
+                           const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
+                           double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int calc_dtbt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -358,3 +358,54 @@ def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy,
     if rc:
         raise RuntimeError(f"orc_btstep failed rc={rc}")
     return out
+
+
+# ---- MOM_dynamics_split_RK2 -------------------------------------------------------------------------------
+class DynState:
+    """Everything one oracle run of the split RK2 step owns: sub-module control structures, the control structure of
+    the step with numpy arrays behind its pointers, and the prognostic state."""
+
+    def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
+                 bound_coriolis=True, dtbt=None, **bt_kw):
+        g = self.grid = grid
+        self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
+        self.ccs = continuity_cs(g.nk, g.Angstrom_H)
+        self.cor = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES["SADOURNY75_ENERGY"], _abi.KE_SCHEMES["KE_ARAKAWA"], 0, int(bound_coriolis), 0)
+        self.pcs = pressureforce_cs(g)
+        self.eos = eos("WRIGHT")
+        self.bt_arrs, self.bt = make_bt_cont(g, with_h=True) if use_bt_cont else ({}, None)
+        self.bcs, self.bcs_arrs = barotropic_cs(g, hvel_scheme="FROM_BT_CONT" if use_bt_cont else "HARMONIC", **bt_kw)
+        barotropic_init(g, self.bcs)
+        cs = self.cs = _abi.DynSplitRK2CS()
+        cs.be, cs.begw, cs.BT_use_layer_fluxes, cs.store_CAu = be, 0.0, int(BT_use_layer_fluxes), int(store_CAu)
+        cs.continuity_CSp = C.addressof(self.ccs); cs.CoriolisAdv = C.addressof(self.cor)
+        cs.PressureForce_CSp = C.addressof(self.pcs); cs.eqn_of_state = C.addressof(self.eos)
+        cs.barotropic_CSp = C.addressof(self.bcs); cs.BT_cont = C.addressof(self.bt) if use_bt_cont else None
+        self.arrs = {}
+        for n, pos in _abi.RK2_ARRAYS_3D:
+            self.arrs[n] = grid.zeros3(pos); setattr(cs, n, self.arrs[n].ctypes.data)
+        for n, pos in _abi.RK2_ARRAYS_2D:
+            self.arrs[n] = grid.zeros2(pos); setattr(cs, n, self.arrs[n].ctypes.data)
+        self.uh, self.vh = grid.zeros3(_abi.POS_U), grid.zeros3(_abi.POS_V)
+        self.uhtr, self.vhtr = grid.zeros3(_abi.POS_U), grid.zeros3(_abi.POS_V)
+        self.eta_av = grid.zeros2(_abi.POS_H)
+        self.dt = float(dt)
+        L = lib()
+        L.orc_dyn_split_rk2_init.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.DynSplitRK2CS)] + [_dp] * 5 + [C.c_double]
+        L.orc_step_dyn_split_rk2.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.DynSplitRK2CS)] + [_dp] * 5 + [C.c_double]
+                                             + [_dp] * 2 + [C.c_double] + [_dp] * 5 + [C.c_int])
+        rc = L.orc_dyn_split_rk2_init(C.byref(g.struct()), C.byref(cs), _p(self.u), _p(self.v), _p(self.h), _p(self.uh), _p(self.vh), self.dt)
+        if rc:
+            raise RuntimeError(f"orc_dyn_split_rk2_init rc={rc}")
+        if dtbt is not None:
+            self.bcs.dtbt = float(dtbt)
+        self.nsteps = 0
+
+    def step(self, taux, tauy, calc_dtbt=False):
+        g = self.grid
+        rc = lib().orc_step_dyn_split_rk2(C.byref(g.struct()), C.byref(self.cs), _p(self.u), _p(self.v), _p(self.h), _p(self.T),
+                                          _p(self.S), self.dt, _p(taux), _p(tauy), g.Z_to_H / g.Rho0, _p(self.uh), _p(self.vh),
+                                          _p(self.uhtr), _p(self.vhtr), _p(self.eta_av), int(calc_dtbt))
+        if rc:
+            raise RuntimeError(f"orc_step_dyn_split_rk2 rc={rc}")
+        self.nsteps += 1

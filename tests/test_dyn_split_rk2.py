@@ -1,0 +1,104 @@
+"""step_MOM_dyn_split_RK2: the oracle's step (oracle/dyn_split_rk2.c, the reference's order of calls with zero
+viscosities) against invariants on the CPU, and the library's step against the oracle on the GPU, bit for bit,
+over several steps."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi, synth
+from oracle import orc
+
+
+def make_case(ni=20, nj=16, nk=3, seed=4, reentrant_x=True, reentrant_y=False, land_frac=0.2, umax=0.1, rest=False):
+    g = synth.make_grid(ni, nj, nk, land_frac=land_frac, seed=seed + 300, reentrant_x=reentrant_x, reentrant_y=reentrant_y)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.0 if rest else umax, eta_amp=0.2).items()}
+    if rest:
+        tot = d["h"].sum(0)
+        d["h"] = np.ascontiguousarray(d["h"] * np.where(tot > 0, g.bathyT * g.Z_to_H / np.maximum(tot, 1e-30), 1.0)[None])
+        d["T"][:] = 10.0; d["S"][:] = 35.0
+    yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
+    taux = np.ascontiguousarray((0.0 if rest else 0.1) * np.cos(2 * yy)[:, None] * g.mask2dCu)
+    tauy = np.ascontiguousarray(0.0 * g.mask2dCv)
+    return g, d, taux, tauy
+
+
+def volume(g, h):
+    return float((interior(g, h) * interior(g, g.areaT)[None] * interior(g, g.mask2dT)[None]).sum())
+
+
+@pytest.mark.parametrize("use_bt_cont", [True, False])
+def test_oracle_step_conserves_volume_and_keeps_eta_consistent(use_bt_cont):
+    g, d, taux, tauy = make_case()
+    dt = 1800.0
+    st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, use_bt_cont=use_bt_cont)
+    st.bcs.dtbt = dt / 12.6
+    v0 = volume(g, st.h)
+    for n in range(4):
+        st.step(taux, tauy)
+        assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0
+    # continuity is flux-form: the ocean's volume is conserved to roundoff
+    assert abs(volume(g, st.h) - v0) <= 1e-12 * v0
+    # the barotropic free surface tracks the layer sum (bt_mass_source feeds the difference back)
+    eta_h = interior(g, st.h.sum(0) - g.bathyT * g.Z_to_H)
+    err = np.abs(interior(g, st.arrs["eta"]) - eta_h)[interior(g, g.mask2dT) > 0]
+    assert err.max() < 1e-6
+    # accumulated transports are the time integral of uh
+    assert np.abs(st.uhtr).max() > 0 and st.cs.CAu_pred_stored == 1
+    assert np.abs(st.u).max() < 3.0
+
+
+def test_oracle_ocean_at_rest_stays_at_rest():
+    g, d, taux, tauy = make_case(rest=True, land_frac=0.0)
+    st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], 1800.0)
+    st.bcs.dtbt = 1800.0 / 10.6
+    for n in range(3):
+        st.step(taux, tauy)
+    # a homogeneous (T, S) ocean under terrain-following layers: the compressible EOS leaves a truncation-level
+    # pressure force (analytically zero); nothing else may move
+    assert np.abs(st.u).max() < 1e-3 and np.abs(st.v).max() < 1e-3
+    assert np.abs(interior(g, st.arrs["eta"])).max() < 1e-3
+
+
+RK2_CASES = [dict(), dict(use_bt_cont=False), dict(reentrant_x=False), dict(reentrant_y=True), dict(store_CAu=False),
+             dict(BT_use_layer_fluxes=False), dict(ni=70, nj=10, nk=2, seed=8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", RK2_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in RK2_CASES])
+def test_step_matches_oracle_bitwise(kw):
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    kw = dict(kw)
+    opts = {k: kw.pop(k) for k in ("use_bt_cont", "store_CAu", "BT_use_layer_fluxes") if k in kw}
+    g, d, taux, tauy = make_case(**kw)
+    dt = 1800.0
+    use_bt = opts.get("use_bt_cont", True)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, use_bt_cont=use_bt, store_CAu=opts.get("store_CAu", True),
+                       BT_use_layer_fluxes=opts.get("BT_use_layer_fluxes", True))
+    ref.bcs.dtbt = dt / 9.6
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, USE_BT_CONT_TYPE=use_bt, STORE_CORIOLIS_ACCEL=opts.get("store_CAu", True),
+                                  BT_USE_LAYER_FLUXES=opts.get("BT_use_layer_fluxes", True), coriolis=dict(bound_coriolis=True),
+                                  barotropic=dict(BT_THICK_SCHEME="FROM_BT_CONT" if use_bt else "HARMONIC"))
+    CS.barotropic_CSp.st.dtbt = ref.bcs.dtbt
+    for n in ("eta", "h_av", "CAu_pred", "u_av"):
+        assert bits_equal(CS.arrays[n].cpu().numpy(), ref.arrs[n]), ("init", n)
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy, calc_dtbt=(n == 1))
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
+                               calc_dtbt=(n == 1))
+        dg.sync()
+        assert CS.barotropic_CSp.st.dtbt == ref.bcs.dtbt
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("vh", vh, ref.vh),
+                           ("uhtr", uhtr, ref.uhtr), ("eta_av", eta_av, ref.eta_av), ("eta", CS.eta, ref.arrs["eta"]),
+                           ("u_av", CS.u_av, ref.arrs["u_av"]), ("h_av", CS.h_av, ref.arrs["h_av"]),
+                           ("CAu_pred", CS.CAu_pred, ref.arrs["CAu_pred"])):
+            an = a.cpu().numpy()
+            assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+    dg.close()
