@@ -4,13 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one baroclinic time step (DT) of the hot path on the synthetic global C-grid named in
-`config.workload`, in the order of step_MOM_dyn_split_RK2 (src/core/MOM_dynamics_split_RK2.F90:289-1176):
-PressureForce (:495), continuity (:636, BT_cont), continuity (:757, uhbt + BT_cont), CorAdCalc (:869),
-continuity (:1015, uhbt), CorAdCalc (:1061), and every DT_THERM/DT-th step advect_tracer
-(src/core/MOM.F90:1438) and ALE_remap_tracers (:1662).  `config.kernels` lists what runs in the step and
-`config.not_yet_in_step` what the reference's step also does but this build does not yet provide.
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one baroclinic time step (DT) of the model on the synthetic global C-grid named in
+`config.workload`: step_MOM_dyn_split_RK2 (src/core/MOM_dynamics_split_RK2.F90:289-1176) -- PressureForce,
+continuity x3, btstep x2 (+ btcalc, bt_mass_source), CorAdCalc x2, the momentum sweeps and the group passes --
+and every DT_THERM/DT-th step advect_tracer (src/core/MOM.F90:1438) and ALE_remap_tracers (:1662).  The state
+evolves: every step starts from the previous step's u, v, h, T, S.  `config.not_yet_in_step` lists what the
+reference's step also does but this build does not provide.  The state is resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line; `components_ms_per_call` times each operator on its own.
 """
 import argparse
 import json
@@ -51,8 +51,76 @@ def shape_of(name):
     return tuple(int(x) for x in name.lower().split("x"))
 
 
-class Step:
-    """The hot-path step on one tile of the global grid, state resident in HBM.  `dom` is the tile's Domain
+class Model:
+    """The time-stepping model on one tile of the global grid: prognostic state, control structures, and step()."""
+
+    def __init__(self, gg, dom, device, scheme):
+        from mom6_amd import _abi, synth
+        from mom6_amd.ale import initialize_remapping
+        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2
+        from mom6_amd.tracer_advect import DeviceGrid, tracer_advect_init
+        self.dom = dom
+        grid = self.g = dom.tile_grid(gg) if dom.nranks > 1 else gg
+        self.dg = DeviceGrid(grid, device=device.index)
+        if dom.nranks > 1:
+            self.dg.set_domain(dom)
+        dev = str(device)
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+        Z = lambda pos, k3=True: torch.zeros(grid.shape3(pos) if k3 else grid.shape2(pos), dtype=torch.float64, device=dev)
+        # every rank generates the same global state on its own GPU and keeps its tile
+        dyn = synth.make_dynamics_state(gg, seed=11, device=dev, umax=0.1, eta_amp=0.2, terrain_following=True)
+        cut = lambda a, pos: dom.cut(a, pos).clone()
+        self.u, self.v, self.h = cut(dyn["u"], U), cut(dyn["v"], V), cut(dyn["h"], H)
+        self.T, self.S = cut(dyn["T"], H), cut(dyn["S"], H)
+        del dyn
+        adv = synth.make_advection_state(gg, ntr=4, seed=1, device=dev, hot_frac=0.0)
+        self.passive = [cut(t, H) for t in adv["tr"][0:4]]      # 4 passive tracers; the first two are advected with T, S
+        del adv
+        torch.cuda.empty_cache()
+        self.uh, self.vh, self.uhtr, self.vhtr = Z(U), Z(V), Z(U), Z(V)
+        self.eta_av = Z(H, False)
+        mu = torch.as_tensor(grid.mask2dCu, device=dev)
+        j0 = dom.j0 if dom.nranks > 1 else 0
+        yy = (torch.arange(grid.shape2(U)[0], device=dev, dtype=torch.float64) + j0) / (gg.nj + 2 * gg.halo) * 3.1416
+        self.taux = (0.1 * torch.cos(2 * yy)[:, None] * mu).contiguous()
+        self.tauy = Z(V, False)
+        self.CS = initialize_dyn_split_RK2(self.u, self.v, self.h, self.uh, self.vh, DT, self.dg, coriolis=dict(bound_coriolis=True))
+        self.adv_cs = tracer_advect_init(DT, scheme)
+        self.remap_cs = initialize_remapping(REMAP_SCHEME)
+        kk = (torch.arange(grid.nk, device=dev, dtype=torch.float64) + 0.5) / grid.nk
+        self.remap_w = (1.0 + 0.05 * torch.sin(6.2832 * kk))[:, None, None]
+        self.h_new = torch.empty_like(self.h)
+        self.steps_per_advect = int(round(DT_THERM / DT))
+        self.last_adv = None
+        self.nstep = 0
+        self.dg.sync()
+
+    def step(self):
+        from mom6_amd.ale import ALE_remap_tracers
+        from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
+        from mom6_amd.tracer_advect import advect_tracer
+        n = self.nstep
+        step_MOM_dyn_split_RK2(self.u, self.v, self.h, (self.T, self.S), None, None, DT, (self.taux, self.tauy), None, None,
+                               self.uh, self.vh, self.uhtr, self.vhtr, self.eta_av, self.dg, self.CS, calc_dtbt=(n == 0))
+        if (n + 1) % self.steps_per_advect == 0:      # step_MOM_thermo / step_MOM_tracer_dyn (src/core/MOM.F90:1438, :1662)
+            tr = [self.T, self.S] + self.passive[:2]
+            self.last_adv = advect_tracer(self.h, self.uhtr, self.vhtr, None, DT_THERM, self.dg, self.adv_cs, tr)
+            self.uhtr.zero_(); self.vhtr.zero_()
+            # the target grid of the remap (stand-in for ALE_regrid until the z* regridding lands): the same columns,
+            # slightly re-partitioned; the passive tracers are remapped onto it, h itself stays
+            hw = self.h * self.remap_w
+            torch.mul(hw, self.h.sum(0, keepdim=True) / hw.sum(0, keepdim=True), out=self.h_new)
+            ALE_remap_tracers(self.remap_cs, self.dg, self.h, self.h_new, self.passive)
+        self.nstep += 1
+
+    def health(self):
+        """max |u|, max |v|, min h, any NaN -- the bench refuses to report a number for a state that blew up"""
+        bad = not bool(torch.isfinite(self.u).all() and torch.isfinite(self.h).all() and torch.isfinite(self.T).all())
+        return dict(umax=float(self.u.abs().max()), vmax=float(self.v.abs().max()), hmin=float(self.h.min()), nan=bad)
+
+
+class Components:
+    """The operators of the step called one by one on a stationary synthetic state (for the per-operator timings).  `dom` is the tile's Domain
     (mom6_amd/domains.py); every rank generates the same global synthetic state on its own GPU, keeps the
     window of its tile and frees the rest, so N ranks step exactly the problem one rank steps."""
 
@@ -206,72 +274,45 @@ class Step:
 
 def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     """The CPU oracle (oracle/*.c, a scalar C restatement of the reference routines; kind "port") timed on a
-    bounded sample of the same workload: the same horizontal grid with 2 of the layers, one full cycle of
-    steps_per_advect baroclinic steps.  The 3-D work is scaled per cell to the full grid; the barotropic
-    subcycle is 2-D (independent of the layer count) and is counted as measured."""
+    bounded sample of the same workload: the same horizontal grid with 2 of the layers, one cycle of
+    steps_per_advect baroclinic steps + tracer advection + remap, the same calls as the GPU step.  The 3-D work is
+    scaled per cell to the full grid; the barotropic subcycle is 2-D (independent of the layer count) and is counted
+    as measured."""
     import ctypes as C
     import numpy as np
     from mom6_amd import _abi, synth
     from oracle import orc
     nk_s = 2
-    g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020)
-    adv = synth.make_advection_state(g, ntr=NTR, seed=1, hot_frac=HOT_FRAC)
-    dyn = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11).items()}
-    tr = [t.numpy() for t in adv["tr"]]
-    h_end, uhtr, vhtr = adv["h_end"].numpy(), adv["uhtr"].numpy(), adv["vhtr"].numpy()
-    cs = orc.continuity_cs(nk_s, g.Angstrom_H)
-    vru = np.ones_like(dyn["u"]); vrv = np.ones_like(dyn["v"])
-    hp = dyn["h"].copy(); uh = np.zeros_like(dyn["u"]); vh = np.zeros_like(dyn["v"])
-    ucor, vcor = np.zeros_like(uh), np.zeros_like(vh)
-    arrs, bt = orc.make_bt_cont(g, with_h=True)
-    orc.continuity(g, cs, dyn["u"], dyn["v"], dyn["h"], hp, uh, vh, DT, visc_rem_u=vru, visc_rem_v=vrv, bt_cont=bt)
-    uhbt = np.ascontiguousarray(uh.sum(0) * 1.02); vhbt = np.ascontiguousarray(vh.sum(0) * 0.98)
-    E = orc.eos("WRIGHT"); pcs = orc.pressureforce_cs(g)
-    PFu, PFv, pbce, eta = orc.pressureforce(g, pcs, E, dyn["h"], dyn["T"], dyn["S"])
-    bcs, bcs_arrs = orc.barotropic_cs(g)
-    orc.barotropic_init(g, bcs)
-    orc.btcalc(g, bcs, dyn["h"], arrs["h_u"], arrs["h_v"])
-    orc.set_dtbt(g, bcs, pbce=pbce, bt_cont=bt)
-    bc_u = np.ascontiguousarray(np.clip(PFu, -3e-5, 3e-5) * g.mask2dCu); bc_v = np.ascontiguousarray(np.clip(PFv, -3e-5, 3e-5) * g.mask2dCv)
-    taux = np.ascontiguousarray(0.1 * g.mask2dCu); tauy = np.ascontiguousarray(0.0 * g.mask2dCv)
+    g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020, rough_noise=0.0)
+    dyn = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11, umax=0.1, eta_amp=0.2, terrain_following=True).items()}
+    adv = synth.make_advection_state(g, ntr=4, seed=1, hot_frac=0.0)
+    passive = [t.numpy() for t in adv["tr"]]
+    del adv
+    st = orc.DynState(g, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], DT)
+    yy = np.arange(g.shape2(_abi.POS_U)[0]) / (g.nj + 2 * g.halo) * 3.1416
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = g.zeros2(_abi.POS_V)
     loop_s = C.c_double.in_dll(orc.lib(), "orc_btstep_loop_seconds")
-    h_new = np.ascontiguousarray(dyn["h"] * 1.0)
-    t_used, t_2d, cycles = 0.0, 0.0, 0
-
-    def bts(etaav):
-        nonlocal t_2d
-        orc.btstep(g, bcs, dyn["u"], dyn["v"], eta, DT, bc_u, bc_v, taux, tauy, pbce, eta, ucor, vcor, vru, vrv, bt_cont=bt,
-                   uh0=uh, vh0=vh, u_uh0=dyn["u"], v_vh0=dyn["v"], want_etaav=etaav)
-        t_2d += loop_s.value
-
-    while t_used < 12.0 and cycles < 3:
-        t0 = time.perf_counter()
-        for n in range(steps_per_advect):
-            orc.pressureforce(g, pcs, E, dyn["h"], dyn["T"], dyn["S"])
-            orc.continuity(g, cs, dyn["u"], dyn["v"], dyn["h"], hp, uh, vh, DT, visc_rem_u=vru, visc_rem_v=vrv, bt_cont=bt)
-            orc.btcalc(g, bcs, dyn["h"], arrs["h_u"], arrs["h_v"])
-            orc.bt_mass_source(g, bcs, dyn["h"], eta, True)
-            bts(False)
-            orc.continuity(g, cs, dyn["u"], dyn["v"], dyn["h"], hp, uh, vh, DT, uhbt=uhbt, vhbt=vhbt, visc_rem_u=vru,
-                           visc_rem_v=vrv, u_cor=ucor, v_cor=vcor, bt_cont=bt)
-            orc.coradcalc(g, ucor, vcor, hp, uh, vh, bound_coriolis=True)
-            bts(True)
-            orc.continuity(g, cs, dyn["u"], dyn["v"], dyn["h"], hp, uh, vh, DT, uhbt=uhbt, vhbt=vhbt, visc_rem_u=vru,
-                           visc_rem_v=vrv, u_cor=ucor, v_cor=vcor)
-            orc.coradcalc(g, ucor, vcor, hp, uh, vh, bound_coriolis=True)
-        orc.advect_tracer(g, h_end, uhtr, vhtr, DT_THERM, DT, scheme, tr)
-        orc.ale_remap_tracers(g, REMAP_SCHEME, dyn["h"], h_new, tr)
-        t_used += time.perf_counter() - t0
-        cycles += 1
+    w = (1.0 + 0.05 * np.sin(6.2832 * (np.arange(nk_s) + 0.5) / nk_s))[:, None, None]
+    st.step(taux, tauy, calc_dtbt=True)        # the first step sets DTBT, as on the GPU
+    loop_s.value = 0.0
+    t0 = time.perf_counter()
+    for n in range(steps_per_advect):
+        st.step(taux, tauy)
+    orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, DT_THERM, DT, scheme, [st.T, st.S] + passive[:2])
+    hw = st.h * w
+    h_new = np.ascontiguousarray(hw * (st.h.sum(0, keepdims=True) / hw.sum(0, keepdims=True)))
+    orc.ale_remap_tracers(g, REMAP_SCHEME, st.h, h_new, passive)
+    t_used = time.perf_counter() - t0
+    t_2d = loop_s.value
     t_3d = t_used - t_2d
-    sec_per_step = (t_3d / (g.ni * g.nj * nk_s) * full_cells + t_2d) / cycles / steps_per_advect
+    sec_per_step = (t_3d / (g.ni * g.nj * nk_s) * full_cells + t_2d) / steps_per_advect
     return {
         "value": DT / sec_per_step / 365.0, "unit": "SYPD", "cores": 1, "kind": "port",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / full_cells,
-        "sample": f"{cycles} cycle(s) of {steps_per_advect} baroclinic steps (same calls as the GPU step) on "
+        "sample": f"1 cycle of {steps_per_advect} baroclinic steps + advect_tracer + ALE_remap_tracers (the GPU step's calls) on "
                   f"{g.ni}x{g.nj}x{nk_s} (same horizontal grid, 2 of {grid.nk} layers); 3-D work ({t_3d:.1f} s) scaled per "
-                  f"cell to the full grid, the 2-D barotropic subcycle ({t_2d:.1f} s, nstep={bcs.nstep_last}) counted as measured; "
-                  f"{t_used:.1f} s of CPU",
+                  f"cell to the full grid, the 2-D barotropic subcycle ({t_2d:.1f} s, nstep={st.bcs.nstep_last}) counted as "
+                  f"measured; {t_used:.1f} s of CPU",
     }
 
 
@@ -311,9 +352,9 @@ def main():
     # N>1: the global grid is cut into `world` latitude bands (layout 1 x N, the x direction stays a local wrap);
     # halos travel between neighbouring GPUs through the reference's group passes (DESIGN.md "Multi-GPU").
     # The total work is fixed: strong scaling.
-    grid = synth.make_grid(NI, NJ, NK, seed=20241020)
+    grid = synth.make_grid(NI, NJ, NK, seed=20241020, rough_noise=0.0)     # smooth bathymetry: see Model
     dom = Domain(NI, NJ, (1, world), rank, grid.halo, grid.reentrant_x, grid.reentrant_y)
-    S = Step(grid, dom, device, a.scheme)
+    M = Model(grid, dom, device, a.scheme)
     cells = NI * NJ * NK
 
     def barrier():
@@ -323,49 +364,56 @@ def main():
         torch.cuda.synchronize()
 
     for n in range(a.warmup):
-        S.run(n)
-    S.dg.sync()
+        M.step()
+    M.dg.sync()
     barrier()
     t0 = time.perf_counter()
     for n in range(a.steps):
-        S.run(n)
-    S.dg.sync()
+        M.step()
+    M.dg.sync()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    health = M.health()
+    if health["nan"] or health["umax"] > 50.0 or health["hmin"] < 0.0:
+        sys.exit(f"bench.py: the model state is not healthy after {M.nstep} steps: {health}")
 
     sec_per_step = elapsed / a.steps
     sypd = DT / sec_per_step / 365.0      # whole job: all ranks together advance the one global grid
-    spa = S.steps_per_advect
+    spa = M.steps_per_advect
+    bcs = M.CS.barotropic_CSp.st
     out = {
-        "metric": "simulated-years/day (SYPD) of the hot-path kernels built so far",
+        "metric": "simulated-years/day (SYPD) of the split-RK2 dynamical core + tracer advection + ALE remap",
         "value": sypd, "unit": "SYPD", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / cells,
         "config": {
-            "btstep_nstep": int(S.bt_cs.st.nstep_last), "dtbt_s": float(S.bt_cs.st.dtbt),
             "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x, ~25% land, "
-                        f"{NTR} tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
-            "kernels": {"PressureForce_FV_Bouss": "Wright EOS, PLM, 1/step", "continuity_PPM": "3/step (BT_cont; uhbt+BT_cont; uhbt)",
-                        "CorAdCalc": "Sadourny75 energy + BOUND_CORIOLIS, 2/step",
-                        "btstep": "BT_cont fits, layer fluxes, wide-halo march, 2/step (+ btcalc, bt_mass_source 1/step)",
-                        "advect_tracer": f"{a.scheme}, 1 per {spa} steps",
-                        "ALE_remap_tracers": f"{REMAP_SCHEME}, {NTR} tracers, 1 per {spa} steps"},
-            "not_yet_in_step": ["RK2 momentum-update sweeps", "ALE regrid + velocity remap",
-                                "vertvisc / horizontal_viscosity (SURVEY 8f)"],
-            "advect_iterations_last_call": None if S.last_adv is None else int(S.last_adv.iterations),
+                        f"T, S + 2 passive tracers advected, 4 remapped, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
+            "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
+                    "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], momentum sweeps, "
+                    f"group passes); every {spa} steps advect_tracer [{a.scheme}] + ALE_remap_tracers [{REMAP_SCHEME}]",
+            "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
+            "not_yet_in_step": ["vertvisc / set_viscous_ML / horizontal_viscosity (SURVEY 8f: the step runs with zero viscosities)",
+                                "ALE regrid + velocity remap (the remap target is a stand-in grid)"],
+            "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),
+            "state_after_run": health, "model_steps_taken": M.nstep,
             "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
                                                                "group passes over RCCL p2p",
         },
     }
+    M.dg.close()
+    del M
+    torch.cuda.empty_cache()
 
     if world == 1 and not a.no_roofline:
-        # per-call device time, HIP events on the stream the library launches on (the null stream, which is
-        # also torch's current stream here)
+        # per-operator device time on a stationary synthetic state, HIP events on the stream the library launches on
+        # (the null stream, which is also torch's current stream here)
+        S = Components(grid, dom, device, a.scheme)
         comp = {}
         for n in range(spa):
             for name, f in S.parts(n):
@@ -389,23 +437,22 @@ def main():
         cand = {k: (ALG_BYTES[k] * cells, ms) for k, ms in comp_ms.items() if k in ALG_BYTES}
         cand["adv_x_kernel<4,PPM:H3,first>"] = ((NTR + 2) * 16.0 * cells, tx)
         cand["adv_y_kernel<4,PPM:H3,first>"] = ((NTR + 2) * 16.0 * cells, ty)
-        dom = max(per_step, key=per_step.get)
-        dom_key = dom if dom in cand else ("adv_y_kernel<4,PPM:H3,first>" if ty >= tx else "adv_x_kernel<4,PPM:H3,first>")
-        b, ms = cand[dom_key]
+        dom_k = max((k for k in per_step if k in cand), key=per_step.get)
+        b, ms = cand[dom_k]
         out["roofline"] = {
-            "kernel": dom_key, "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "kernel": dom_k, "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": b, "avg_launch_ms": ms,
             "all": {k: {"GBs": bb / (m * 1e-3) / 1e9, "frac": bb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": m}
                     for k, (bb, m) in cand.items()},
         }
+        S.dg.close()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(grid, a.scheme, cells, spa)
 
     if rank == 0:
         print(json.dumps(out))
-    S.dg.close()
     if dist is not None:
         dist.destroy_process_group()
 

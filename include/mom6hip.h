@@ -197,6 +197,46 @@ int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remapping_cs_t *
                               const double *h_new, double *const *tr, const double *conc_underflow,
                               int32_t ntr, int32_t memspace);
 
+/* ---- ALE regridding (z*) and velocity remapping ------------------------------------------------ */
+
+#define MOM6HIP_REGRIDDING_ZSTAR 2   /* regrid_consts.F90:14 */
+
+/* regridding_CS, src/ALE/MOM_regridding.F90:50-150, the members the z* branch of regridding_main reads */
+typedef struct mom6hip_regridding_cs {
+  int32_t regridding_scheme;             /* must be MOM6HIP_REGRIDDING_ZSTAR */
+  int32_t nk;                            /* CS%nk; must equal GV%ke */
+  double min_thickness;                  /* MIN_THICKNESS [H] (default 1e-3 m) */
+  double old_grid_weight;                /* REGRID_TIME_SCALE -> ALE_update_regrid_weights (default 0) */
+  double depth_of_time_filter_shallow;   /* REGRID_FILTER_SHALLOW_DEPTH [H] (0) */
+  double depth_of_time_filter_deep;      /* REGRID_FILTER_DEEP_DEPTH [H] (0) */
+  double Z_ref;                          /* G%Z_ref */
+  const double *coordinateResolution;    /* nk nominal thicknesses [Z]; always a HOST pointer */
+} mom6hip_regridding_cs_t;
+
+/*
+ * ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, CS, frac_shelf_h, PCM_cell)      src/ALE/MOM_ALE.F90:484
+ *   -> regridding_main (MOM_regridding.F90:763), REGRIDDING_ZSTAR: build_zstar_grid (:1174) with build_zstar_column
+ *      (coord_zlike.F90:63), filtered_grid_motion (:1022), adjust_interface_motion (:1713), calc_h_new_by_dz (:925).
+ * Boussinesq, no ice shelf.  h_new and dzRegrid (nk+1 levels) are written on (isc-1:iec+1, jsc-1:jec+1); dzRegrid is
+ * zeroed everywhere first (:508).  The FATAL checks of the reference (negative thickness beyond roundoff) are not
+ * evaluated on the device.
+ */
+int mom6hip_ale_regrid(mom6hip_ctx_t *ctx, const mom6hip_regridding_cs_t *cs, const double *h, double *h_new,
+                       double *dzRegrid, int32_t memspace);
+
+/* ALE_remap_set_h_vel(CS, G, GV, h_new, h_u, h_v, OBC, debug)                    src/ALE/MOM_ALE.F90:870
+ * PARTIAL_CELL_VELOCITY_REMAP = False, OBC not associated.  Only open faces are written. */
+int mom6hip_ale_remap_set_h_vel(mom6hip_ctx_t *ctx, const double *h_new, double *h_u, double *h_v, int32_t memspace);
+
+/* ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
+ *                                                                                src/ALE/MOM_ALE.F90:1061
+ * cs is CS%vel_remapCS; REMAP_VEL_CONSERVE_KE = False, REMAP_VEL_MASK_BBL_THICK <= 0, no KE diagnostics.
+ * remap_dyn_split_RK2_aux_vars (MOM_dynamics_split_RK2.F90:1273) is this routine applied to (u_av, v_av),
+ * (CAu_pred, CAv_pred) and (diffu, diffv). */
+int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_remapping_cs_t *cs, const double *h_old_u,
+                                 const double *h_old_v, const double *h_new_u, const double *h_new_v, double *u,
+                                 double *v, int32_t memspace);
+
 /* ---- MOM_CoriolisAdv ----------------------------------------------------------------------- */
 
 /* CORIOLIS_SCHEME / KE_SCHEME enumeration values, src/core/MOM_CoriolisAdv.F90:93-112 */

@@ -28,7 +28,7 @@ CONFIGS = {
 
 
 def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=True,
-              reentrant_y=False, max_depth=5500.0, first_direction=0) -> Grid:
+              reentrant_y=False, max_depth=5500.0, first_direction=0, rough_noise=0.04) -> Grid:
     """Mercator-like C-grid with a bowl bathymetry and about `land_frac` land."""
     g = Grid(ni=ni, nj=nj, nk=nk, halo=halo, reentrant_x=reentrant_x, reentrant_y=reentrant_y,
              first_direction=first_direction)
@@ -60,7 +60,7 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     jj = (np.arange(nj) + 0.5) / nj
     X, Y = np.meshgrid(ii, jj)
     bowl = (np.sin(np.pi * Y) ** 0.5) * (0.65 + 0.35 * np.cos(2 * np.pi * X) * np.cos(np.pi * Y))
-    rough = 0.12 * np.sin(6 * np.pi * X + 1.0) * np.sin(4 * np.pi * Y) + 0.04 * rng.standard_normal((nj, ni))
+    rough = 0.12 * np.sin(6 * np.pi * X + 1.0) * np.sin(4 * np.pi * Y) + rough_noise * rng.standard_normal((nj, ni))
     field = bowl + rough
     thr = np.quantile(field, land_frac) if land_frac > 0 else field.min() - 0.05 * (field.max() - field.min())
     ocean = field > thr
@@ -241,7 +241,8 @@ def fill_halo(g: Grid, a: torch.Tensor, pos: int) -> torch.Tensor:
     return a
 
 
-def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.3, dtype=torch.float64, eta_amp=None):
+def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.3, dtype=torch.float64, eta_amp=None,
+                        terrain_following=False):
     """A model-like state for the dynamical core: h, u, v, uh, vh, T, S with valid halos.
 
     h: z*-like layers with vanished layers (Angstrom_H) below the topography and in random blobs;
@@ -263,12 +264,19 @@ def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.
     dz_nom = 2.0 + 300.0 * K ** 2
     dz_nom = dz_nom * (5500.0 / dz_nom.sum())
     ztop = torch.cumsum(dz_nom, 0) - dz_nom
-    h0 = torch.clamp(torch.minimum(dz_nom.expand(nk, nj, ni), depth[None] - ztop), min=0.0)
-    if vanish_frac > 0:
-        blob = torch.sin(9 * math.pi * X + 3 * K) * torch.sin(7 * math.pi * Y - 2 * K) + 0.3 * rndn(nk, nj, ni)
-        q = torch.quantile(blob.flatten()[:: max(1, blob.numel() // 200000)], 1.0 - vanish_frac)
-        h0 = torch.where(blob > q, torch.zeros_like(h0), h0)
-    h0 = torch.clamp(h0 * (1.0 + 0.05 * rndn(nk, nj, ni)), min=0.0)
+    if terrain_following:
+        # every layer keeps the same fraction of the local depth: no vanished layers anywhere.  This is the state the
+        # time-stepping bench uses: without vertical viscosity nothing couples a vanished layer to its
+        # neighbours and its velocity grows without bound.
+        h0 = dz_nom.expand(nk, nj, ni) * (depth[None] / 5500.0)
+        h0 = torch.clamp(h0 * (1.0 + 0.01 * rndn(nk, nj, ni)), min=0.0)
+    else:
+        h0 = torch.clamp(torch.minimum(dz_nom.expand(nk, nj, ni), depth[None] - ztop), min=0.0)
+        if vanish_frac > 0:
+            blob = torch.sin(9 * math.pi * X + 3 * K) * torch.sin(7 * math.pi * Y - 2 * K) + 0.3 * rndn(nk, nj, ni)
+            q = torch.quantile(blob.flatten()[:: max(1, blob.numel() // 200000)], 1.0 - vanish_frac)
+            h0 = torch.where(blob > q, torch.zeros_like(h0), h0)
+        h0 = torch.clamp(h0 * (1.0 + 0.05 * rndn(nk, nj, ni)), min=0.0)
     h0 = torch.where(h0 < 1.0e-3, torch.full_like(h0, g.Angstrom_H), h0)
     h0 = torch.where(mT[None] > 0, h0, torch.full_like(h0, g.Angstrom_H))
     if eta_amp is not None:
@@ -298,6 +306,8 @@ def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.
     vh = torch.zeros_like(v)
     vh[:, 1:-1, :] = v[:, 1:-1, :] * torch.where(v[:, 1:-1, :] >= 0, hS, hN) * dx_Cv[None, 1:-1, :]
     zmid = (ztop + 0.5 * dz_nom)
+    if terrain_following:
+        zmid = zmid * (depth[None] / 5500.0)        # temperature is a function of the actual depth: flat isotherms
     T = 20.0 * torch.exp(-zmid / 1000.0) + 2.0 * torch.cos(math.pi * Y) + 0.01 * rndn(nk, nj, ni)
     S = 35.0 + 0.5 * torch.sin(2 * math.pi * X) * torch.sin(math.pi * Y) + 0.01 * rndn(nk, nj, ni)
     T = fill_halo(g, _embed(g, (T * mT[None]).contiguous(), _abi.POS_H), _abi.POS_H)

@@ -37,8 +37,8 @@ static inline double max4(double a, double b, double c, double d) { return max2(
 
 #define SUBROUNDOFF 1e-30 /* MOM_barotropic.F90:413 */
 
-/* wall time the last orc_btstep call spent in its time-step loop (the 2-D part, independent of nk); lets bench.py's
- * cpu_baseline scale the 3-D and the 2-D parts of a reduced-layer sample separately */
+/* wall time orc_btstep calls have spent in the time-step loop (the 2-D part, independent of nk) since the caller
+ * last zeroed it; lets bench.py's cpu_baseline scale the 3-D and the 2-D parts of a reduced-layer sample separately */
 double orc_btstep_loop_seconds = 0.0;
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -827,7 +827,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     }
   }
 
-  orc_btstep_loop_seconds = now_s() - t_loop0;
+  orc_btstep_loop_seconds += now_s() - t_loop0;
 
   /* ---- epilogue :2467-2590 (answer_date >= 20190101: the I_sum_wt are 1) */
   if (find_etaav) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) etaav[H2(i, j)] = eta_sum[H2(i, j)] * 1.0;

@@ -94,6 +94,12 @@ void orc_dz_from_h1h2(int n1, const double *h1, int n2, const double *h2, double
 int orc_ale_remap_tracers(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t *cs, const double *h_old,
                           const double *h_new, double *const *tr, const double *conc_underflow, int ntr);
 
+/* ---- z* regridding and velocity remapping (oracle/regridding.c) ------------------------------------------ */
+int orc_ale_regrid(const mom6hip_grid_t *G, const mom6hip_regridding_cs_t *CS, const double *h, double *h_new, double *dzRegrid);
+int orc_ale_remap_set_h_vel(const mom6hip_grid_t *G, const double *h_new, double *h_u, double *h_v);
+int orc_ale_remap_velocities(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t *cs, const double *h_old_u, const double *h_old_v,
+                             const double *h_new_u, const double *h_new_v, double *u, double *v);
+
 /* ---- MOM_CoriolisAdv (oracle/coriolis_adv.c) ------------------------------------------------ */
 int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const double *u, const double *v,
                   const double *h, const double *uh, const double *vh, double *CAu, double *CAv);
