@@ -129,3 +129,14 @@ class DynSplitRK2CS(C.Structure):
                  ("reserved1", C.c_void_p * 3)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
                 + [("reserved2", C.c_void_p * 4)])
+
+
+# ---- z* regridding ----------------------------------------------------------------------------------------
+REGRIDDING_ZSTAR = 2
+
+
+class RegriddingCS(C.Structure):
+    """mom6hip_regridding_cs_t (include/mom6hip.h)."""
+    _fields_ = [("regridding_scheme", C.c_int32), ("nk", C.c_int32), ("min_thickness", C.c_double), ("old_grid_weight", C.c_double),
+                ("depth_of_time_filter_shallow", C.c_double), ("depth_of_time_filter_deep", C.c_double), ("Z_ref", C.c_double),
+                ("coordinateResolution", C.c_void_p)]

@@ -18,6 +18,7 @@ EXPORTS = (
     "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
     "mom6hip_barotropic_init", "mom6hip_btcalc", "mom6hip_bt_mass_source", "mom6hip_set_dtbt", "mom6hip_btstep",
     "mom6hip_dyn_split_rk2_init", "mom6hip_step_dyn_split_rk2",
+    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_velocities",
 )
 
 

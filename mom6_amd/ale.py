@@ -64,3 +64,72 @@ def ALE_remap_tracers(CS: RemappingCS, G: DeviceGrid, h_old, h_new, Reg, conc_un
     check(lib().mom6hip_ale_remap_tracers(G.handle, C.byref(cs), ph0, ph1, trp,
                                           None if cu is None else cu.ctypes.data_as(_dp), ntr, spaces.pop()),
           "ALE_remap_tracers")
+
+
+class regridding_CS:
+    """regridding_CS (src/ALE/MOM_regridding.F90:50-150) for REGRIDDING_COORDINATE_MODE = "Z*"."""
+
+    def __init__(self, coordinateResolution, regridding_scheme="Z*", min_thickness=1.0e-3, old_grid_weight=0.0,
+                 depth_of_time_filter_shallow=0.0, depth_of_time_filter_deep=0.0, Z_ref=0.0):
+        if regridding_scheme not in ("Z*", "ZSTAR"):
+            raise Mom6HipError("MOM_regridding, regridding_main: only the z* regridding scheme is provided by libmom6hip")
+        self.res = np.ascontiguousarray(coordinateResolution, dtype=np.float64)
+        self.st = _abi.RegriddingCS(_abi.REGRIDDING_ZSTAR, int(self.res.size), float(min_thickness), float(old_grid_weight),
+                                    float(depth_of_time_filter_shallow), float(depth_of_time_filter_deep), float(Z_ref),
+                                    self.res.ctypes.data)
+
+
+def initialize_regridding(G, coordinateResolution=None, max_depth=None, **kw):
+    """initialize_regridding (MOM_regridding.F90:200): ALE_COORDINATE_CONFIG "UNIFORM" (dz = MAXIMUM_DEPTH / nk) unless
+    the nominal thicknesses are given; MIN_THICKNESS etc. by keyword."""
+    g = G.grid if isinstance(G, DeviceGrid) else G
+    if coordinateResolution is None:
+        if max_depth is None:
+            max_depth = float(np.max(g.bathyT))
+        coordinateResolution = np.full(g.nk, max_depth / g.nk)
+    return regridding_CS(coordinateResolution, **kw)
+
+
+def _setup_regrid():
+    L = lib()
+    if not getattr(L, "_regrid_ready", False):
+        L.mom6hip_ale_regrid.argtypes = [C.c_void_p, C.POINTER(_abi.RegriddingCS)] + [C.c_void_p] * 3 + [C.c_int32]
+        L.mom6hip_ale_remap_set_h_vel.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int32]
+        L.mom6hip_ale_remap_velocities.argtypes = [C.c_void_p, C.POINTER(_abi.RemappingCS)] + [C.c_void_p] * 6 + [C.c_int32]
+        L._regrid_ready = True
+    return L
+
+
+def _ptrs(arrs, who):
+    spaces, out = set(), []
+    for a in arrs:
+        p, s = _ptr_space(a)
+        spaces.add(s); out.append(C.c_void_p(p))
+    if len(spaces) != 1:
+        raise Mom6HipError(f"{who}: all fields must be in the same memory space")
+    return out, spaces.pop()
+
+
+def ALE_regrid(G: DeviceGrid, h, h_new, dzRegrid, tv, CS: regridding_CS, frac_shelf_h=None, PCM_cell=None):
+    """ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, CS, frac_shelf_h, PCM_cell) -- MOM_ALE.F90:484 (z*: tv is not read)."""
+    if frac_shelf_h is not None or PCM_cell is not None:
+        raise Mom6HipError("ALE_regrid (HIP): ice shelves and PCM_cell (hybgen) are not supported")
+    p, sp = _ptrs([h, h_new, dzRegrid], "ALE_regrid")
+    check(_setup_regrid().mom6hip_ale_regrid(G.handle, C.byref(CS.st), *p, sp), "ALE_regrid")
+
+
+def ALE_remap_set_h_vel(CS, G: DeviceGrid, h_new, h_u, h_v, OBC=None, debug=False):
+    """ALE_remap_set_h_vel(CS, G, GV, h_new, h_u, h_v, OBC, debug) -- MOM_ALE.F90:870."""
+    if OBC is not None:
+        raise Mom6HipError("ALE_remap_set_h_vel (HIP): open boundaries are not supported")
+    p, sp = _ptrs([h_new, h_u, h_v], "ALE_remap_set_h_vel")
+    check(_setup_regrid().mom6hip_ale_remap_set_h_vel(G.handle, *p, sp), "ALE_remap_set_h_vel")
+
+
+def ALE_remap_velocities(CS: RemappingCS, G: DeviceGrid, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug=False, dt=None,
+                         allow_preserve_variance=False):
+    """ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
+    -- MOM_ALE.F90:1061; CS is the velocity remapping control structure (CS%vel_remapCS)."""
+    p, sp = _ptrs([h_old_u, h_old_v, h_new_u, h_new_v, u, v], "ALE_remap_velocities")
+    cs = CS.struct()
+    check(_setup_regrid().mom6hip_ale_remap_velocities(G.handle, C.byref(cs), *p, sp), "ALE_remap_velocities")

@@ -485,6 +485,148 @@ __global__ __launch_bounds__(64) void ale_remap_tracers_kernel(RemapArgs a) {
   }
 }
 
+// ---- ALE_remap_velocities (MOM_ALE.F90:1061): the tracer kernel at velocity points -----------------------------
+struct VelRemapArgs {
+  m6::GridDev g;
+  const double *h_old, *h_new;   // h_old_u / h_new_u (DIR 0) or h_old_v / h_new_v (DIR 1)
+  double *vel;
+  int scheme, extrap, dir;
+  double h_neglect, h_neglect_edge;
+};
+
+template <int NK>
+__global__ __launch_bounds__(64) void ale_remap_velocity_kernel(VelRemapArgs a) {
+  const m6::GridDev &g = a.g;
+  const int i = (a.dir ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (a.dir ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long base = a.dir ? g.v2(i, j) : g.u2(i, j);
+  const long stride = a.dir ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  if (!((a.dir ? g.mask2dCv[base] : g.mask2dCu[base]) > 0.)) return;     // :1137, :1205
+  const int nz = g.nk;
+  Col<NK> c;
+  double *t = a.vel + base;
+  for (int k = 0; k < nz; k++) { c.h0[k] = a.h_old[base + k * stride]; c.h1[k] = a.h_new[base + k * stride]; c.u0[k] = t[k * stride]; }
+  const int last_thick = build_sub_cells(c, nz, nz);
+  const int method = build_reconstructions(c, a.scheme, a.extrap != 0, nz, a.h_neglect, a.h_neglect_edge);
+  integrate_sub_cells(c, nz, nz, method, last_thick, 0.0, t, stride);
+}
+
+// ---- ALE_regrid, z* (MOM_regridding.F90:763-889, :1174-1284; coord_zlike.F90:63-144) ------------------------------
+struct RegridArgs {
+  m6::GridDev g;
+  const double *h;
+  double *h_new, *dz;
+  const double *res;       // coordinateResolution on the device (nk values)
+  double min_thickness, old_grid_weight, zs, zd, Z_ref;
+};
+
+template <int NK>
+__global__ __launch_bounds__(64) void ale_regrid_zstar_kernel(RegridArgs a) {
+  const m6::GridDev &g = a.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.jsc - 1 + blockIdx.y;
+  if (i > g.iec + 1) return;
+  const long n2 = g.h2(i, j), hstr = (long)g.nih * g.njh;
+  const int nz = g.nk;
+  if (g.mask2dT[n2] == 0.) {        // :1213 ; calc_h_new_by_dz keeps the old thicknesses on land (:951)
+    for (int k = 0; k <= nz; k++) a.dz[n2 + hstr * k] = 0.;
+    for (int k = 0; k < nz; k++) a.h_new[n2 + hstr * k] = a.h[n2 + hstr * k];
+    return;
+  }
+  // 1-based columns as in the reference
+  double hc[NK + 2], zOld[NK + 2], zNew[NK + 2], dz[NK + 2];
+  const double Z_to_H = g.Z_to_H;
+  const double depth = m6::max2((g.bathyT[n2] + a.Z_ref) * Z_to_H, 0.0);                   // :833
+  double total = 0.0;
+  for (int k = 1; k <= nz; k++) { hc[k] = a.h[n2 + hstr * (k - 1)]; total = total + hc[k]; }
+  zOld[nz + 1] = -depth;
+  for (int k = nz; k >= 1; k--) zOld[k] = zOld[k + 1] + hc[k];
+  // build_zstar_column, no rigid top
+  {
+    const double min_thickness = m6::min2(a.min_thickness, total / (double)nz);
+    const double eta = total - depth;
+    const double stretching = total / (depth + 0.);
+    zNew[1] = eta;
+    for (int k = 1; k <= nz; k++) {
+      const double dh = stretching * a.res[k - 1] * Z_to_H;
+      zNew[k + 1] = zNew[k] - dh;
+    }
+    zNew[nz + 1] = -depth;
+    for (int k = nz; k >= 1; k--)
+      if (zNew[k] < (zNew[k + 1] + min_thickness)) zNew[k] = zNew[k + 1] + min_thickness;
+  }
+  // filtered_grid_motion :1022
+  {
+    double sgn;
+    const double prod = (zOld[nz + 1] - zOld[1]) * (zNew[nz + 1] - zNew[1]);
+    bool done = false;
+    if (prod == 0.0) { for (int k = 1; k <= nz + 1; k++) dz[k] = 0.0; done = true; }
+    else if ((zOld[nz + 1] - zOld[1]) + (zNew[nz + 1] - zNew[1]) > 0.0) sgn = 1.0;
+    else sgn = -1.0;
+    if (!done) {
+      const double zs = a.zs, zd = a.zd;
+      const double wtd = 1.0 - a.old_grid_weight, Iwtd = 1.0 / wtd;
+      const double dzwt = (zd - zs);
+      double Idzwt = 0.0; if (fabs(zd - zs) > 0.0) Idzwt = 1.0 / (zd - zs);
+      const double dInt_zs_zd = 0.5 * (1.0 + Iwtd) * (zd - zs);
+      const double Aq = 0.5 * (Iwtd - 1.0);
+      dz[1] = 0.0;
+      for (int k = 2; k <= nz + 1; k++) {
+        const double z_old_k = zOld[k];
+        const double dz_tgt = sgn * (zNew[k] - z_old_k);
+        const double zr1 = sgn * (z_old_k - zOld[1]);
+        double r;
+        if ((zr1 > zd) && (zr1 + wtd * dz_tgt > zd)) {
+          r = sgn * wtd * dz_tgt;
+        } else if ((zr1 < zs) && (zr1 + dz_tgt < zs)) {
+          r = sgn * dz_tgt;
+        } else {
+          double Int_zd, Int_zs;
+          if (zr1 >= zd) { Int_zd = Iwtd * (zd - zr1); Int_zs = Int_zd - dInt_zs_zd; }
+          else if (zr1 <= zs) { Int_zs = (zs - zr1); Int_zd = dInt_zs_zd + (zs - zr1); }
+          else {
+            Int_zd = (zd - zr1) * (Iwtd * (0.5 * (zd + zr1) - zs) + 0.5 * (zd - zr1)) * Idzwt;
+            Int_zs = (zs - zr1) * (0.5 * Iwtd * ((zr1 - zs)) + (zd - 0.5 * (zr1 + zs))) * Idzwt;
+          }
+          if (dz_tgt >= Int_zd) r = sgn * ((zd - zr1) + wtd * (dz_tgt - Int_zd));
+          else if (dz_tgt <= Int_zs) r = sgn * ((zs - zr1) + (dz_tgt - Int_zs));
+          else {
+            double dz0, z0, F0;
+            if (zr1 <= zs) { dz0 = zs - zr1; z0 = zs; F0 = dz_tgt - Int_zs; }
+            else if (zr1 >= zd) { dz0 = zd - zr1; z0 = zd; F0 = dz_tgt - Int_zd; }
+            else { dz0 = 0.0; z0 = zr1; F0 = dz_tgt; }
+            const double Bq = (dzwt + 2.0 * Aq * (z0 - zs));
+            r = sgn * (dz0 + 2.0 * F0 * dzwt / (Bq + sqrt(Bq * Bq + 4.0 * Aq * F0 * dzwt)));
+          }
+        }
+        dz[k] = r;
+      }
+    }
+  }
+  // adjust_interface_motion :1754-1772 (the FATAL checks are not evaluated on the device)
+  {
+    const double eps = 2.220446049250313e-16;
+    for (int k = nz; k >= 2; k--) {
+      double hn = hc[k] + (dz[k] - dz[k + 1]);
+      if (hn < a.min_thickness) dz[k] = (dz[k + 1] - hc[k]) + a.min_thickness;
+      hn = hc[k] + (dz[k] - dz[k + 1]);
+      if (hn < 0.) dz[k] = (1. - eps) * (dz[k + 1] - hc[k]);
+    }
+  }
+  for (int k = 1; k <= nz + 1; k++) a.dz[n2 + hstr * (k - 1)] = dz[k];
+  for (int k = 1; k <= nz; k++) a.h_new[n2 + hstr * (k - 1)] = m6::max2(0., hc[k] + (dz[k] - dz[k + 1]));   // calc_h_new_by_dz :943
+}
+
+// ALE_remap_set_h_vel :892-899: one thread per (I/i, j/J, k) of the union of the two face ranges
+__global__ __launch_bounds__(64) void ale_set_h_vel_kernel(m6::GridDev g, const double *__restrict__ h, double *__restrict__ h_u,
+                                                           double *__restrict__ h_v) {
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, k = blockIdx.z;
+  if (i > g.iec) return;
+  if (j >= g.jsc && g.mask2dCu[g.u2(i, j)] > 0.) h_u[g.u3(i, j, k)] = 0.5 * (h[g.h3(i, j, k)] + h[g.h3(i + 1, j, k)]);
+  if (i >= g.isc && g.mask2dCv[g.v2(i, j)] > 0.) h_v[g.v3(i, j, k)] = 0.5 * (h[g.h3(i, j, k)] + h[g.h3(i, j + 1, k)]);
+}
+
 }  // namespace
 
 // ALE_remap_tracers(CS, G, GV, h_old, h_new, Reg, debug, dt, PCM_cell), src/ALE/MOM_ALE.F90:737.
@@ -549,4 +691,80 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
     M6_HIP(hipStreamSynchronize(s));
   }
   return 0;
+}
+
+// ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, CS, frac_shelf_h, PCM_cell), src/ALE/MOM_ALE.F90:484 (z*).
+extern "C" int mom6hip_ale_regrid(mom6hip_ctx_t *ctx, const mom6hip_regridding_cs_t *cs, const double *h, double *h_new,
+                                  double *dzRegrid, int32_t memspace) {
+  M6_REQUIRE(ctx && cs && h && h_new && dzRegrid, "ALE_regrid: null argument");
+  M6_REQUIRE(cs->regridding_scheme == MOM6HIP_REGRIDDING_ZSTAR,
+             "MOM_regridding, regridding_main: only the z* regridding scheme is provided by libmom6hip");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(cs->nk == g.nk && cs->coordinateResolution, "ALE_regrid: CS%%nk must equal GV%%ke and coordinateResolution must be set");
+  M6_REQUIRE(g.nk <= 128 && g.mask2dT && g.bathyT, "ALE_regrid: at most 128 layers; mask2dT and bathyT are needed");
+  M6_REQUIRE(g.isc - 1 >= g.isd && g.jsc - 1 >= g.jsd, "ALE_regrid: a halo of at least 1 is needed");
+  hipStream_t s = ctx->stream;
+  const size_t b2 = sizeof(double) * (size_t)g.nih * g.njh, b3 = b2 * g.nk, b3i = b2 * (g.nk + 1);
+  m6::Stager st(ctx, memspace);
+  RegridArgs a;
+  a.g = g; a.h = st.in(h, b3); a.h_new = st.inout(h_new, b3); a.dz = st.out(dzRegrid, b3i);
+  double *res = (double *)st.scratch(sizeof(double) * g.nk);
+  M6_REQUIRE(!st.failed() && res, "ALE_regrid: staging failed");
+  M6_HIP(hipMemcpyAsync(res, cs->coordinateResolution, sizeof(double) * g.nk, hipMemcpyHostToDevice, s));
+  M6_HIP(hipMemsetAsync(a.dz, 0, b3i, s));                                       // dzRegrid(:,:,:) = 0.0  (:508)
+  a.res = res; a.min_thickness = cs->min_thickness; a.old_grid_weight = cs->old_grid_weight;
+  a.zs = cs->depth_of_time_filter_shallow; a.zd = cs->depth_of_time_filter_deep; a.Z_ref = cs->Z_ref;
+  dim3 grid((g.iec - g.isc + 3 + 63) / 64, g.jec - g.jsc + 3);
+  if (g.nk <= 8) hipLaunchKernelGGL(ale_regrid_zstar_kernel<8>, grid, dim3(64), 0, s, a);
+  else if (g.nk <= 32) hipLaunchKernelGGL(ale_regrid_zstar_kernel<32>, grid, dim3(64), 0, s, a);
+  else if (g.nk <= 80) hipLaunchKernelGGL(ale_regrid_zstar_kernel<80>, grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(ale_regrid_zstar_kernel<128>, grid, dim3(64), 0, s, a);
+  M6_HIP(hipGetLastError());
+  M6_HIP(hipStreamSynchronize(s));      // coordinateResolution was copied from the caller's host array
+  return st.finish();
+}
+
+// ALE_remap_set_h_vel(CS, G, GV, h_new, h_u, h_v, OBC, debug), src/ALE/MOM_ALE.F90:870.
+extern "C" int mom6hip_ale_remap_set_h_vel(mom6hip_ctx_t *ctx, const double *h_new, double *h_u, double *h_v, int32_t memspace) {
+  M6_REQUIRE(ctx && h_new && h_u && h_v, "ALE_remap_set_h_vel: null argument");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv, "ALE_remap_set_h_vel: mask2dCu and mask2dCv are needed");
+  const size_t b3 = sizeof(double) * (size_t)g.nh3(), bu = sizeof(double) * (size_t)g.nu3(), bv = sizeof(double) * (size_t)g.nv3();
+  m6::Stager st(ctx, memspace);
+  const double *dh = st.in(h_new, b3);
+  double *du = st.inout(h_u, bu), *dv = st.inout(h_v, bv);
+  M6_REQUIRE(!st.failed(), "ALE_remap_set_h_vel: staging failed");
+  hipLaunchKernelGGL(ale_set_h_vel_kernel, dim3((g.iec - g.isc + 2 + 63) / 64, g.jec - g.jsc + 2, g.nk), dim3(64), 0, ctx->stream, g, dh, du, dv);
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+// ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, ...), src/ALE/MOM_ALE.F90:1061.
+extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_remapping_cs_t *cs, const double *h_old_u,
+                                            const double *h_old_v, const double *h_new_u, const double *h_new_v, double *u,
+                                            double *v, int32_t memspace) {
+  M6_REQUIRE(ctx && cs && h_old_u && h_old_v && h_new_u && h_new_v && u && v, "ALE_remap_velocities: null argument");
+  M6_REQUIRE(cs->remapping_scheme == REMAP_PCM || cs->remapping_scheme == REMAP_PLM || cs->remapping_scheme == REMAP_PPM_H4,
+             "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
+             "(libmom6hip provides PCM, PLM and PPM_H4)");
+  M6_REQUIRE(cs->answer_date >= 20190101 && !cs->force_bounds_in_subcell, "ALE_remap_velocities: unsupported remapping options");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.nk <= 128 && g.mask2dCu && g.mask2dCv, "ALE_remap_velocities: at most 128 layers; face masks are needed");
+  const size_t bu = sizeof(double) * (size_t)g.nu3(), bv = sizeof(double) * (size_t)g.nv3();
+  m6::Stager st(ctx, memspace);
+  VelRemapArgs a[2];
+  a[0].h_old = st.in(h_old_u, bu); a[0].h_new = st.in(h_new_u, bu); a[0].vel = st.inout(u, bu); a[0].dir = 0;
+  a[1].h_old = st.in(h_old_v, bv); a[1].h_new = st.in(h_new_v, bv); a[1].vel = st.inout(v, bv); a[1].dir = 1;
+  M6_REQUIRE(!st.failed(), "ALE_remap_velocities: staging failed");
+  for (int d = 0; d < 2; d++) {
+    a[d].g = g; a[d].scheme = cs->remapping_scheme; a[d].extrap = cs->boundary_extrapolation;
+    a[d].h_neglect = g.H_subroundoff; a[d].h_neglect_edge = g.H_subroundoff;      // :1118-1119
+    dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
+    if (g.nk <= 8) hipLaunchKernelGGL(ale_remap_velocity_kernel<8>, grid, dim3(64), 0, ctx->stream, a[d]);
+    else if (g.nk <= 32) hipLaunchKernelGGL(ale_remap_velocity_kernel<32>, grid, dim3(64), 0, ctx->stream, a[d]);
+    else if (g.nk <= 80) hipLaunchKernelGGL(ale_remap_velocity_kernel<80>, grid, dim3(64), 0, ctx->stream, a[d]);
+    else hipLaunchKernelGGL(ale_remap_velocity_kernel<128>, grid, dim3(64), 0, ctx->stream, a[d]);
+  }
+  M6_HIP(hipGetLastError());
+  return st.finish();
 }

@@ -409,3 +409,36 @@ class DynState:
         if rc:
             raise RuntimeError(f"orc_step_dyn_split_rk2 rc={rc}")
         self.nsteps += 1
+
+
+# ---- z* regridding + velocity remapping ---------------------------------------------------------------------
+def regridding_cs(res, min_thickness=1.0e-3, old_grid_weight=0.0, zs=0.0, zd=0.0, Z_ref=0.0):
+    res = np.ascontiguousarray(res, dtype=np.float64)
+    cs = _abi.RegriddingCS(_abi.REGRIDDING_ZSTAR, int(res.size), min_thickness, old_grid_weight, zs, zd, Z_ref, res.ctypes.data)
+    cs._keep = res
+    return cs
+
+
+def ale_regrid(grid, cs, h):
+    L = lib(); L.orc_ale_regrid.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.RegriddingCS), _dp, _dp, _dp]
+    h_new = grid.zeros3(_abi.POS_H); dz = np.zeros((grid.nk + 1,) + grid.shape2(_abi.POS_H))
+    rc = L.orc_ale_regrid(C.byref(grid.struct()), C.byref(cs), _p(h), _p(h_new), _p(dz))
+    if rc:
+        raise RuntimeError(f"orc_ale_regrid rc={rc}")
+    return h_new, dz
+
+
+def ale_remap_set_h_vel(grid, h_new, h_u=None, h_v=None):
+    L = lib(); L.orc_ale_remap_set_h_vel.argtypes = [C.POINTER(_abi.GridStruct), _dp, _dp, _dp]
+    h_u = grid.zeros3(_abi.POS_U) if h_u is None else h_u
+    h_v = grid.zeros3(_abi.POS_V) if h_v is None else h_v
+    L.orc_ale_remap_set_h_vel(C.byref(grid.struct()), _p(h_new), _p(h_u), _p(h_v))
+    return h_u, h_v
+
+
+def ale_remap_velocities(grid, scheme, h_old_u, h_old_v, h_new_u, h_new_v, u, v, boundary_extrapolation=False):
+    L = lib(); L.orc_ale_remap_velocities.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.RemappingCS)] + [_dp] * 6
+    cs = _abi.RemappingCS(REMAP_SCHEMES[scheme], int(boundary_extrapolation), 0, 99991231)
+    rc = L.orc_ale_remap_velocities(C.byref(grid.struct()), C.byref(cs), _p(h_old_u), _p(h_old_v), _p(h_new_u), _p(h_new_v), _p(u), _p(v))
+    if rc:
+        raise RuntimeError(f"orc_ale_remap_velocities rc={rc}")
