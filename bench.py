@@ -7,7 +7,8 @@
 A "step" is one baroclinic time step (DT) of the model on the synthetic global C-grid named in
 `config.workload`: step_MOM_dyn_split_RK2 (src/core/MOM_dynamics_split_RK2.F90:289-1176) -- PressureForce,
 continuity x3, btstep x2 (+ btcalc, bt_mass_source), CorAdCalc x2, the momentum sweeps and the group passes --
-and every DT_THERM/DT-th step advect_tracer (src/core/MOM.F90:1438) and ALE_remap_tracers (:1662).  The state
+and every DT_THERM/DT-th step advect_tracer (src/core/MOM.F90:1438) and the ALE block (:1647-1700: ALE_regrid,
+ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities).  The state
 evolves: every step starts from the previous step's u, v, h, T, S.  `config.not_yet_in_step` lists what the
 reference's step also does but this build does not provide.  The state is resident in HBM before
 the timed region.  Rank 0 prints ONE JSON line; `components_ms_per_call` times each operator on its own.
@@ -30,6 +31,7 @@ NTR = 4                    # T, S + 2 passive tracers
 SCHEME = "PPM:H3"
 REMAP_SCHEME = "PPM_H4"    # OM4-class remapping scheme
 HOT_FRAC = 2.0e-5
+REGRID_OLD_WEIGHT = 0.98   # REGRID_TIME_SCALE >> DT_THERM: each ALE call moves the grid 2 % of the way to z* (see Model)
 
 
 def parse():
@@ -74,7 +76,7 @@ class Model:
         self.T, self.S = cut(dyn["T"], H), cut(dyn["S"], H)
         del dyn
         adv = synth.make_advection_state(gg, ntr=4, seed=1, device=dev, hot_frac=0.0)
-        self.passive = [cut(t, H) for t in adv["tr"][0:4]]      # 4 passive tracers; the first two are advected with T, S
+        self.passive = [cut(t, H) for t in adv["tr"][2:4]]      # 2 passive tracers (a smooth blob and a step)
         del adv
         torch.cuda.empty_cache()
         self.uh, self.vh, self.uhtr, self.vhtr = Z(U), Z(V), Z(U), Z(V)
@@ -87,30 +89,48 @@ class Model:
         self.CS = initialize_dyn_split_RK2(self.u, self.v, self.h, self.uh, self.vh, DT, self.dg, coriolis=dict(bound_coriolis=True))
         self.adv_cs = tracer_advect_init(DT, scheme)
         self.remap_cs = initialize_remapping(REMAP_SCHEME)
-        kk = (torch.arange(grid.nk, device=dev, dtype=torch.float64) + 0.5) / grid.nk
-        self.remap_w = (1.0 + 0.05 * torch.sin(6.2832 * kk))[:, None, None]
-        self.h_new = torch.empty_like(self.h)
+        # z* target: the nominal layer thicknesses of the synthetic state (synth.make_dynamics_state).  The state
+        # starts terrain-following and relaxes towards z* with REGRID_TIME_SCALE >> DT_THERM (old_grid_weight close to
+        # 1): every ALE call does the full regrid + remap work, but the grid does not reach the vanished layers of a z*
+        # grid over topography, which the inviscid step (no vertvisc yet) cannot carry.
+        from mom6_amd.ale import initialize_regridding
+        import numpy as _np
+        kn = (_np.arange(grid.nk) + 0.5) / grid.nk
+        dz_nom = 2.0 + 300.0 * kn ** 2
+        self.regrid_cs = initialize_regridding(self.dg, coordinateResolution=dz_nom * (5500.0 / dz_nom.sum()),
+                                               old_grid_weight=REGRID_OLD_WEIGHT)
+        self.h_new = self.h.clone()
+        self.dzRegrid = torch.zeros((grid.nk + 1,) + grid.shape2(H), dtype=torch.float64, device=dev)
+        self.h_old_u, self.h_old_v, self.h_new_u, self.h_new_v = Z(U), Z(V), Z(U), Z(V)
         self.steps_per_advect = int(round(DT_THERM / DT))
         self.last_adv = None
         self.nstep = 0
         self.dg.sync()
 
     def step(self):
-        from mom6_amd.ale import ALE_remap_tracers
+        from mom6_amd.ale import ALE_regrid, ALE_remap_set_h_vel, ALE_remap_tracers, ALE_remap_velocities
         from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
         from mom6_amd.tracer_advect import advect_tracer
         n = self.nstep
         step_MOM_dyn_split_RK2(self.u, self.v, self.h, (self.T, self.S), None, None, DT, (self.taux, self.tauy), None, None,
                                self.uh, self.vh, self.uhtr, self.vhtr, self.eta_av, self.dg, self.CS, calc_dtbt=(n == 0))
         if (n + 1) % self.steps_per_advect == 0:      # step_MOM_thermo / step_MOM_tracer_dyn (src/core/MOM.F90:1438, :1662)
-            tr = [self.T, self.S] + self.passive[:2]
+            tr = [self.T, self.S] + self.passive
             self.last_adv = advect_tracer(self.h, self.uhtr, self.vhtr, None, DT_THERM, self.dg, self.adv_cs, tr)
             self.uhtr.zero_(); self.vhtr.zero_()
-            # the target grid of the remap (stand-in for ALE_regrid until the z* regridding lands): the same columns,
-            # slightly re-partitioned; the passive tracers are remapped onto it, h itself stays
-            hw = self.h * self.remap_w
-            torch.mul(hw, self.h.sum(0, keepdim=True) / hw.sum(0, keepdim=True), out=self.h_new)
-            ALE_remap_tracers(self.remap_cs, self.dg, self.h, self.h_new, self.passive)
+            # ALE (src/core/MOM.F90:1647-1700): regrid, remap tracers, remap velocities, adopt the new grid
+            dg = self.dg
+            ALE_regrid(dg, self.h, self.h_new, self.dzRegrid, None, self.regrid_cs)
+            ALE_remap_tracers(self.remap_cs, dg, self.h, self.h_new, tr)
+            ALE_remap_set_h_vel(None, dg, self.h, self.h_old_u, self.h_old_v)
+            ALE_remap_set_h_vel(None, dg, self.h_new, self.h_new_u, self.h_new_v)
+            ALE_remap_velocities(self.remap_cs, dg, self.h_old_u, self.h_old_v, self.h_new_u, self.h_new_v, self.u, self.v)
+            self.h, self.h_new = self.h_new, self.h           # h(:,:,:) = h_new(:,:,:) on js-1:je+1 (:1697)
+            fields, pos = [self.u, self.v, self.T, self.S, self.h], [1, 2, 0, 0, 0]      # pass_uv_T_S_h (:1713-1719)
+            if self.dom.nranks == 1:
+                dg.halo_update(fields, pos)
+            else:
+                self.dom.pass_var(fields, pos)
         self.nstep += 1
 
     def health(self):
@@ -286,22 +306,28 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020, rough_noise=0.0)
     dyn = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11, umax=0.1, eta_amp=0.2, terrain_following=True).items()}
     adv = synth.make_advection_state(g, ntr=4, seed=1, hot_frac=0.0)
-    passive = [t.numpy() for t in adv["tr"]]
+    passive = [t.numpy() for t in adv["tr"][2:4]]
     del adv
     st = orc.DynState(g, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], DT)
     yy = np.arange(g.shape2(_abi.POS_U)[0]) / (g.nj + 2 * g.halo) * 3.1416
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = g.zeros2(_abi.POS_V)
     loop_s = C.c_double.in_dll(orc.lib(), "orc_btstep_loop_seconds")
-    w = (1.0 + 0.05 * np.sin(6.2832 * (np.arange(nk_s) + 0.5) / nk_s))[:, None, None]
     st.step(taux, tauy, calc_dtbt=True)        # the first step sets DTBT, as on the GPU
     loop_s.value = 0.0
     t0 = time.perf_counter()
     for n in range(steps_per_advect):
         st.step(taux, tauy)
-    orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, DT_THERM, DT, scheme, [st.T, st.S] + passive[:2])
-    hw = st.h * w
-    h_new = np.ascontiguousarray(hw * (st.h.sum(0, keepdims=True) / hw.sum(0, keepdims=True)))
-    orc.ale_remap_tracers(g, REMAP_SCHEME, st.h, h_new, passive)
+    tr = [st.T, st.S] + passive
+    orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, DT_THERM, DT, scheme, tr)
+    kn = (np.arange(nk_s) + 0.5) / nk_s
+    dz_nom = 2.0 + 300.0 * kn ** 2
+    rcs = orc.regridding_cs(dz_nom * (5500.0 / dz_nom.sum()), old_grid_weight=REGRID_OLD_WEIGHT)
+    h_new, dzr = orc.ale_regrid(g, rcs, st.h)
+    orc.ale_remap_tracers(g, REMAP_SCHEME, st.h, h_new, tr)
+    hou, hov = orc.ale_remap_set_h_vel(g, st.h); hnu, hnv = orc.ale_remap_set_h_vel(g, h_new)
+    orc.ale_remap_velocities(g, REMAP_SCHEME, hou, hov, hnu, hnv, st.u, st.v)
+    for f, ps in ((st.u, 1), (st.v, 2), (st.T, 0), (st.S, 0), (h_new, 0)):
+        orc.halo_update(g, f, ps)
     t_used = time.perf_counter() - t0
     t_2d = loop_s.value
     t_3d = t_used - t_2d
@@ -309,7 +335,7 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     return {
         "value": DT / sec_per_step / 365.0, "unit": "SYPD", "cores": 1, "kind": "port",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / full_cells,
-        "sample": f"1 cycle of {steps_per_advect} baroclinic steps + advect_tracer + ALE_remap_tracers (the GPU step's calls) on "
+        "sample": f"1 cycle of {steps_per_advect} baroclinic steps + advect_tracer + ALE regrid/remap (the GPU step's calls) on "
                   f"{g.ni}x{g.nj}x{nk_s} (same horizontal grid, 2 of {grid.nk} layers); 3-D work ({t_3d:.1f} s) scaled per "
                   f"cell to the full grid, the 2-D barotropic subcycle ({t_2d:.1f} s, nstep={st.bcs.nstep_last}) counted as "
                   f"measured; {t_used:.1f} s of CPU",
@@ -393,13 +419,14 @@ def main():
         "ns_per_gridpoint_step": sec_per_step * 1e9 / cells,
         "config": {
             "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x, ~25% land, "
-                        f"T, S + 2 passive tracers advected, 4 remapped, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
+                        f"T, S + 2 passive tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
             "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
                     "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], momentum sweeps, "
-                    f"group passes); every {spa} steps advect_tracer [{a.scheme}] + ALE_remap_tracers [{REMAP_SCHEME}]",
+                    f"group passes); every {spa} steps advect_tracer [{a.scheme}] + ALE regrid/remap [{REMAP_SCHEME}]",
             "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
-            "not_yet_in_step": ["vertvisc / set_viscous_ML / horizontal_viscosity (SURVEY 8f: the step runs with zero viscosities)",
-                                "ALE regrid + velocity remap (the remap target is a stand-in grid)"],
+            "not_yet_in_step": ["vertvisc / set_viscous_ML / horizontal_viscosity (SURVEY 8f: the step runs with zero viscosities)"],
+            "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE >> DT_THERM), remap of T, S + 2 tracers "
+                   f"and of u, v [{REMAP_SCHEME}]",
             "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),
             "state_after_run": health, "model_steps_taken": M.nstep,
             "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
