@@ -123,6 +123,18 @@ int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t
 typedef int (*mom6hip_halo_fn)(void *user, double *const *fields, const int32_t *pos, const int32_t *nk, int32_t nfields);
 typedef int (*mom6hip_sum_fn)(void *user, int32_t *values, int32_t n);
 int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mom6hip_sum_fn sum_fn, void *user);
+/* min_across_PEs (MOM_coms) of `n` HOST doubles, in place: used by set_dtbt (src/core/MOM_barotropic.F90:2915). */
+typedef int (*mom6hip_min_fn)(void *user, double *values, int32_t n);
+int mom6hip_set_min_callback(mom6hip_ctx_t *ctx, mom6hip_min_fn min_fn, void *user);
+
+/* Packing for the multi-tile group pass: gathers (pack = 1) the slabs [a0[f], a0[f] + width) along direction `dir`
+ * (0: i, rows restricted to the compute rows of each field; 1: j, full rows) of `nfields` DEVICE arrays into the
+ * contiguous DEVICE buffer `buf`, field after field, or scatters them back (pack = 0).  a0 is 0-based in the
+ * allocated array of each field.  Returns the number of doubles moved in *count (may be NULL).  This is what a
+ * do_group_pass packs into one message per neighbour (mom6_amd/domains.py sends `buf` with torch.distributed). */
+int mom6hip_halo_pack(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each,
+                      const int32_t *a0, int32_t nfields, int32_t dir, int32_t width, double *buf, int32_t pack,
+                      int64_t *count);
 
 /* ---- MOM_tracer_advect -------------------------------------------------------------------- */
 
@@ -409,8 +421,8 @@ int mom6hip_bt_mass_source(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, cons
                            int32_t set_cor, int32_t memspace);
 
 /* set_dtbt(G, GV, US, CS, eta, pbce, BT_cont, gtot_est, SSH_add)     src/core/MOM_barotropic.F90:2801
- * Sets cs->dtbt_max to the maximum stable step OF THIS TILE and cs->dtbt = dtbt_fraction * dtbt_max; with more
- * than one tile the caller applies min_across_PEs to dtbt_max (:2915) and rescales.  pbce or gtot_est is used
+ * Sets cs->dtbt_max to the maximum stable step and cs->dtbt = dtbt_fraction * dtbt_max; with more than one tile the
+ * minimum over the tiles is taken through the registered min callback (min_across_PEs, :2915).  pbce or gtot_est is used
  * (pbce may be NULL); BT_cont may be NULL. */
 int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *pbce,
                      const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add, int32_t memspace);

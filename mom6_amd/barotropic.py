@@ -145,7 +145,7 @@ def bt_mass_source(h, eta, set_cor, G: DeviceGrid, CS: barotropic_CS):
 def set_dtbt(G: DeviceGrid, CS: barotropic_CS, eta=None, pbce=None, BT_cont: BT_cont_type | None = None, gtot_est=None,
              SSH_add=0.0):
     """set_dtbt(G, GV, US, CS, eta, pbce, BT_cont, gtot_est, SSH_add) -- :2801.  With a multi-tile domain attached
-    to G the maximum stable step is the minimum over the tiles (min_across_PEs, :2915)."""
+    to G the maximum stable step is the minimum over the tiles (min_across_PEs, :2915, through the context's callback)."""
     if not CS.module_is_initialized:
         raise Mom6HipError("set_dtbt: Module MOM_barotropic must be initialized before it is used.")
     if pbce is None and gtot_est is None:
@@ -156,12 +156,6 @@ def set_dtbt(G: DeviceGrid, CS: barotropic_CS, eta=None, pbce=None, BT_cont: BT_
     check(_setup().mom6hip_set_dtbt(G.handle, C.byref(CS.st), p, None if bt is None else C.byref(bt),
                                     0.0 if gtot_est is None else float(gtot_est), float(SSH_add), _one_space(sp, CS, "set_dtbt")),
           "set_dtbt")
-    dom = getattr(G, "domain", None)
-    if dom is not None and dom.nranks > 1:
-        t = torch.tensor([CS.st.dtbt_max], dtype=torch.float64)
-        dom.min_across_PEs(t.cuda() if torch.distributed.get_backend(dom.group) == "nccl" else t)
-        CS.st.dtbt_max = float(t[0]) if t.device.type == "cpu" else float(t.cpu()[0])
-        CS.st.dtbt = CS.st.dtbt_fraction * CS.st.dtbt_max
     return CS.st.dtbt_max
 
 

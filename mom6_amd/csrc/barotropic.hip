@@ -595,7 +595,9 @@ int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const doub
   memcpy(&min_max_dt2, &bits, sizeof(double));
   if (!(min_max_dt2 < 1.0e38)) min_max_dt2 = 1.0e38;
   const double dgeo_de = 1.0 + (cs->G_extra > 0.0 ? cs->G_extra : 0.0);
-  const double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
+  double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
+  if (ctx->min_cb)      // min_across_PEs(dtbt_max) :2915
+    M6_REQUIRE(ctx->min_cb(ctx->min_user, &dtbt_max, 1) == 0, "set_dtbt: the min_across_PEs callback failed");
   cs->dtbt = cs->dtbt_fraction * dtbt_max;
   cs->dtbt_max = dtbt_max;
   return st.finish();

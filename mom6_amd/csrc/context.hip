@@ -130,6 +130,12 @@ int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mo
   return 0;
 }
 
+int mom6hip_set_min_callback(mom6hip_ctx_t *ctx, mom6hip_min_fn min_fn, void *user) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_set_min_callback: null context");
+  ctx->min_cb = min_fn; ctx->min_user = user;
+  return 0;
+}
+
 int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_set_timing: null context");
   ctx->timing = enable != 0;
@@ -334,5 +340,65 @@ extern "C" int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, co
     int rc = m6::halo_update_field(ctx, fields[f], pos[f], nk_each[f]);
     if (rc) return rc;
   }
+  return 0;
+}
+
+// ---- packing for the multi-tile group pass -------------------------------------------------------------
+namespace {
+struct PackDesc {
+  double *f[24];
+  long off[25];          // prefix offsets into the buffer, in doubles
+  int ni[24], nj[24], nk[24], a0[24], r0[24], r1[24];
+  int n, dir, w, pack;
+};
+
+__global__ void __launch_bounds__(256) halo_pack_kernel(PackDesc d, double *__restrict__ buf) {
+  const long total = d.off[d.n];
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int q = 0;
+    while (t >= d.off[q + 1]) q++;
+    long r = t - d.off[q];
+    long idx;
+    if (d.dir == 0) {       // columns [a0, a0+w) of rows [r0, r1]
+      const int i = (int)(r % d.w); r /= d.w;
+      const int nr = d.r1[q] - d.r0[q] + 1;
+      const int j = d.r0[q] + (int)(r % nr);
+      const int k = (int)(r / nr);
+      idx = ((long)k * d.nj[q] + j) * d.ni[q] + d.a0[q] + i;
+    } else {                // rows [a0, a0+w), all columns
+      const int i = (int)(r % d.ni[q]); r /= d.ni[q];
+      const int j = d.a0[q] + (int)(r % d.w);
+      const int k = (int)(r / d.w);
+      idx = ((long)k * d.nj[q] + j) * d.ni[q] + i;
+    }
+    if (d.pack) buf[t] = d.f[q][idx]; else d.f[q][idx] = buf[t];
+  }
+}
+}  // namespace
+
+extern "C" int mom6hip_halo_pack(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each,
+                                 const int32_t *a0, int32_t nfields, int32_t dir, int32_t width, double *buf, int32_t pack,
+                                 int64_t *count) {
+  M6_REQUIRE(ctx && fields && pos && nk_each && a0, "mom6hip_halo_pack: null argument");
+  M6_REQUIRE(nfields >= 0 && nfields <= 24, "mom6hip_halo_pack: at most 24 fields per message");
+  const mom6hip_grid_t &G = ctx->host;
+  const int h = G.isc - G.isd, nih = G.ied - G.isd + 1, njh = G.jed - G.jsd + 1, nj = G.jec - G.jsc + 1;
+  PackDesc d;
+  d.n = nfields; d.dir = dir; d.w = width; d.pack = pack;
+  d.off[0] = 0;
+  for (int q = 0; q < nfields; q++) {
+    const int xs = (pos[q] == MOM6HIP_POS_U || pos[q] == MOM6HIP_POS_Q) ? 1 : 0;
+    const int ys = (pos[q] == MOM6HIP_POS_V || pos[q] == MOM6HIP_POS_Q) ? 1 : 0;
+    d.f[q] = fields[q]; d.ni[q] = nih + xs; d.nj[q] = njh + ys; d.nk[q] = nk_each[q]; d.a0[q] = a0[q];
+    d.r0[q] = h; d.r1[q] = h + nj + ys - 1;
+    const long cnt = dir == 0 ? (long)nk_each[q] * (d.r1[q] - d.r0[q] + 1) * width : (long)nk_each[q] * width * d.ni[q];
+    M6_REQUIRE(a0[q] >= 0 && a0[q] + width <= (dir == 0 ? d.ni[q] : d.nj[q]), "mom6hip_halo_pack: slab out of range");
+    d.off[q + 1] = d.off[q] + cnt;
+  }
+  if (count) *count = d.off[nfields];
+  if (d.off[nfields] == 0 || buf == nullptr) return 0;
+  int blocks = (int)((d.off[nfields] + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(halo_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, buf);
+  M6_HIP(hipGetLastError());
   return 0;
 }

@@ -52,6 +52,8 @@ class Domain:
         self.i0, self.j0 = self.i_starts[self.pi], self.j_starts[self.pj]      # global 0-based index of (isc, jsc)
         if min(self.i_sizes) < self.halo or min(self.j_sizes) < self.halo:
             raise ValueError("MOM_domains: a tile is narrower than the halo")
+        self._dg = None          # the DeviceGrid of this tile (DeviceGrid.set_domain): enables the packed exchange
+        self._bufs = {}
 
     # ---- neighbours ---------------------------------------------------------------------------------
     def _nbr(self, dpi, dpj):
@@ -104,6 +106,8 @@ class Domain:
         w = h if halo is None else min(int(halo), h)
         backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else None
         stage = backend == "gloo"      # gloo moves host memory only
+        if self._dg is not None and len(fields) <= 24 and all(f.is_cuda for f in fields):
+            return self._pass_packed(fields, positions, w, stage)
 
         def exchange(direction):
             ops, recvs, keep = [], [], []
@@ -156,6 +160,86 @@ class Domain:
 
         exchange("x")
         exchange("y")
+
+    def _pass_packed(self, fields, positions, w, stage):
+        """The group pass for device fields: one message per neighbour and direction.  The library packs the send slabs
+        of every field of the group into one buffer (mom6hip_halo_pack), torch.distributed moves the buffers (RCCL
+        send/recv over xGMI; staged through the host only for the gloo rehearsal), the library unpacks into the halos.
+        A direction with a single tile is the library's own wrap kernel."""
+        import ctypes as C
+        import torch.distributed as dist
+        from ._lib import check, lib
+        dg, L = self._dg, lib()
+        h, nf = self.halo, len(fields)
+        ptrs = (C.c_void_p * nf)(*[f.data_ptr() for f in fields])
+        pos = (C.c_int32 * nf)(*positions)
+        nks = (C.c_int32 * nf)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
+
+        def local_wrap():
+            check(L.mom6hip_halo_update(dg.handle, ptrs, pos, nks, nf), "mom6hip_halo_update")
+
+        def pack(a0, direction, buf, do_pack):
+            cnt = C.c_int64(0)
+            arr = (C.c_int32 * nf)(*a0)
+            check(L.mom6hip_halo_pack(dg.handle, ptrs, pos, nks, arr, nf, direction, w, None if buf is None else buf.data_ptr(),
+                                      int(do_pack), C.byref(cnt)), "mom6hip_halo_pack")
+            return cnt.value
+
+        def exchange(direction):
+            if direction == 0:
+                n, lo, hi = self.ni, self._nbr(-1, 0), self._nbr(+1, 0)
+            else:
+                n, lo, hi = self.nj, self._nbr(0, -1), self._nbr(0, +1)
+            s = [self._ranges(p)[direction] for p in positions]
+            to_hi, to_lo = [n + h - w] * nf, [h + sf for sf in s]
+            lo_halo, hi_halo = [h - w] * nf, [h + n + sf for sf in s]
+            cnt = pack(to_hi, direction, None, 1)
+            key = (direction, cnt)
+            if key not in self._bufs:
+                self._bufs[key] = [torch.empty(cnt, dtype=torch.float64, device=fields[0].device) for _ in range(4)]
+            s_hi, s_lo, r_lo, r_hi = self._bufs[key]
+            if hi is not None:
+                pack(to_hi, direction, s_hi, 1)
+            if lo is not None:
+                pack(to_lo, direction, s_lo, 1)
+            ops, keep = [], []
+
+            def snd(buf, nbr):
+                b = buf.cpu() if stage else buf
+                keep.append(b); ops.append(dist.P2POp(dist.isend, b, nbr, group=self.group))
+
+            def rcv(buf, nbr):
+                b = torch.empty(buf.shape, dtype=buf.dtype) if stage else buf
+                keep.append((b, buf)); ops.append(dist.P2POp(dist.irecv, b, nbr, group=self.group))
+
+            # posting order as in pass_var: [send->hi, recv<-lo, send->lo, recv<-hi]
+            if hi is not None: snd(s_hi, hi)
+            if lo is not None: rcv(r_lo, lo)
+            if lo is not None: snd(s_lo, lo)
+            if hi is not None: rcv(r_hi, hi)
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+                if stage:
+                    for item in keep:
+                        if isinstance(item, tuple):
+                            item[1].copy_(item[0])
+            if lo is not None:
+                pack(lo_halo, direction, r_lo, 0)
+            if hi is not None:
+                pack(hi_halo, direction, r_hi, 0)
+
+        did_local = False
+        if self.npi == 1:
+            if self.reentrant_x or (self.npj == 1 and self.reentrant_y):
+                local_wrap(); did_local = True
+        else:
+            exchange(0)
+        if self.npj == 1:
+            if self.reentrant_y and not did_local:
+                local_wrap()
+        else:
+            exchange(1)
 
     # ---- reductions (MOM_coms) -------------------------------------------------------------------------
     def sum_across_PEs(self, t: torch.Tensor):

@@ -95,10 +95,30 @@ class DeviceGrid:
                 import traceback; traceback.print_exc()
                 return 1
 
-        self._cb = (HALO(halo), SUM(sumf))      # keep the thunks alive
+        MINF = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+
+        def minf(user, values, n):
+            try:
+                t = torch.tensor([values[q] for q in range(n)], dtype=torch.float64)
+                if domain.nranks > 1:
+                    import torch.distributed as dist
+                    if dist.get_backend(domain.group) == "nccl":
+                        t = t.cuda()
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=domain.group)
+                    t = t.cpu()
+                for q in range(n):
+                    values[q] = float(t[q])
+                return 0
+            except Exception:
+                import traceback; traceback.print_exc()
+                return 1
+
+        self._cb = (HALO(halo), SUM(sumf), MINF(minf))      # keep the thunks alive
+        check(lib().mom6hip_set_min_callback(self.handle, C.cast(self._cb[2], C.c_void_p), None), "mom6hip_set_min_callback")
         check(lib().mom6hip_set_domain_callbacks(self.handle, C.cast(self._cb[0], C.c_void_p),
                                                  C.cast(self._cb[1], C.c_void_p), None), "mom6hip_set_domain_callbacks")
         self.domain = domain
+        domain._dg = self
 
     def close(self):
         if self._h:

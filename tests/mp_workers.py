@@ -162,3 +162,44 @@ def btstep_layout_worker(rank, world, port, layout, topo, out_dir):
             np.savez(os.path.join(out_dir, "bt_global.npz"), dtbt_max=dm, **ref)
     finally:
         dist.destroy_process_group()
+
+
+def rk2_layout_worker(rank, world, port, layout, topo, out_dir):
+    """test.layout for the whole split RK2 step on the GPU: two tiles, group passes through the packed exchange."""
+    import numpy as np
+    import torch
+    from mom6_amd import _abi
+    from mom6_amd.domains import Domain
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from oracle import orc
+    from test_dyn_split_rk2 import make_case
+    dist = _init(rank, world, port)
+    try:
+        gg, d, taux, tauy = make_case(ni=32, nj=24, nk=3, seed=13, reentrant_x=topo[0], reentrant_y=topo[1])
+        dt = 1800.0
+        dom = Domain(gg.ni, gg.nj, layout, rank, gg.halo, topo[0], topo[1])
+        tg = dom.tile_grid(gg)
+        dg = DeviceGrid(tg)
+        dg.set_domain(dom)
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+        T = lambda a, p: torch.from_numpy(dom.cut(a, p)).cuda()
+        u, v, h, Tt, Ss = T(d["u"], U), T(d["v"], V), T(d["h"], H), T(d["T"], H), T(d["S"], H)
+        Z = lambda p, k3=True: torch.zeros(tg.shape3(p) if k3 else tg.shape2(p), dtype=torch.float64, device="cuda")
+        uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+        CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True))
+        tx, ty = T(taux, U), T(tauy, V)
+        for n in range(2):
+            step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
+                                   calc_dtbt=(n == 0))
+        dg.sync()
+        np.savez(os.path.join(out_dir, f"rk2_tile{rank}.npz"), ij=np.array([dom.i0, dom.j0, dom.ni, dom.nj]), u=u.cpu().numpy(),
+                 v=v.cpu().numpy(), h=h.cpu().numpy(), eta=CS.eta.cpu().numpy(), uhtr=uhtr.cpu().numpy(), dtbt=CS.barotropic_CSp.st.dtbt)
+        dg.close()
+        if rank == 0:
+            ref = orc.DynState(gg, d["u"], d["v"], d["h"], d["T"], d["S"], dt)
+            for n in range(2):
+                ref.step(taux, tauy, calc_dtbt=(n == 0))
+            np.savez(os.path.join(out_dir, "rk2_global.npz"), u=ref.u, v=ref.v, h=ref.h, eta=ref.arrs["eta"], uhtr=ref.uhtr, dtbt=ref.bcs.dtbt)
+    finally:
+        dist.destroy_process_group()

@@ -73,3 +73,21 @@ def test_btstep_layout_independence(tmp_path, layout, topo):
             a = t[n][..., h:h + nj + ys, h:h + ni + xs]
             b = glob[n][..., h + j0:h + j0 + nj + ys, h + i0:h + i0 + ni + xs]
             assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, topo, r, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,topo", [((1, 2), (True, False)), ((2, 1), (True, False)), ((1, 2), (True, True))])
+def test_rk2_step_layout_independence(tmp_path, layout, topo):
+    import torch.multiprocessing as mp
+    from mp_workers import rk2_layout_worker
+    mp.spawn(rk2_layout_worker, args=(2, free_port(), layout, topo, str(tmp_path)), nprocs=2, join=True)
+    glob = np.load(tmp_path / "rk2_global.npz")
+    h = 4
+    for r in range(2):
+        t = np.load(tmp_path / f"rk2_tile{r}.npz")
+        i0, j0, ni, nj = t["ij"]
+        assert float(t["dtbt"]) == float(glob["dtbt"])
+        for n, (xs, ys) in dict(h=(0, 0), eta=(0, 0), u=(1, 0), v=(0, 1), uhtr=(1, 0)).items():
+            a = t[n][..., h:h + nj + ys, h:h + ni + xs]
+            b = glob[n][..., h + j0:h + j0 + nj + ys, h + i0:h + i0 + ni + xs]
+            assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, topo, r, n)
