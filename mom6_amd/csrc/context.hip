@@ -147,6 +147,15 @@ uint64_t mom6hip_abi_sizeof_grid(void) { return sizeof(mom6hip_grid_t); }
 uint64_t mom6hip_abi_sizeof_tracer_advect_cs(void) { return sizeof(mom6hip_tracer_advect_cs_t); }
 uint64_t mom6hip_abi_sizeof_advect_stats(void) { return sizeof(mom6hip_advect_stats_t); }
 uint64_t mom6hip_abi_sizeof_advect_timing(void) { return sizeof(mom6hip_advect_timing_t); }
+uint64_t mom6hip_abi_sizeof_remapping_cs(void) { return sizeof(mom6hip_remapping_cs_t); }
+uint64_t mom6hip_abi_sizeof_regridding_cs(void) { return sizeof(mom6hip_regridding_cs_t); }
+uint64_t mom6hip_abi_sizeof_coriolisadv_cs(void) { return sizeof(mom6hip_coriolisadv_cs_t); }
+uint64_t mom6hip_abi_sizeof_continuity_cs(void) { return sizeof(mom6hip_continuity_cs_t); }
+uint64_t mom6hip_abi_sizeof_bt_cont(void) { return sizeof(mom6hip_bt_cont_t); }
+uint64_t mom6hip_abi_sizeof_eos(void) { return sizeof(mom6hip_eos_t); }
+uint64_t mom6hip_abi_sizeof_pressureforce_cs(void) { return sizeof(mom6hip_pressureforce_cs_t); }
+uint64_t mom6hip_abi_sizeof_barotropic_cs(void) { return sizeof(mom6hip_barotropic_cs_t); }
+uint64_t mom6hip_abi_sizeof_dyn_split_rk2_cs(void) { return sizeof(mom6hip_dyn_split_rk2_cs_t); }
 uint64_t mom6hip_abi_offsetof_grid_mask2dT(void) { return offsetof(mom6hip_grid_t, mask2dT); }
 
 static int upload2d(mom6hip_ctx_t *ctx, const double *h, size_t n, double **d) {

@@ -5,7 +5,7 @@
 module mom6hip_c_api
 
 use, intrinsic :: iso_c_binding, only : c_int, c_int32_t, c_int64_t, c_double, c_ptr, c_char, &
-                                        c_null_ptr, c_null_char, c_loc, c_associated, c_f_pointer
+                                        c_null_ptr, c_null_char, c_loc, c_associated, c_f_pointer, c_funptr
 implicit none ; public
 
 integer(c_int32_t), parameter :: MOM6HIP_MEM_HOST = 0, MOM6HIP_MEM_DEVICE = 1
@@ -41,6 +41,82 @@ end type mom6hip_tracer_advect_cs_t
 type, bind(c) :: mom6hip_advect_stats_t
   integer(c_int32_t) :: iterations, halo_updates, domore_remaining, reserved
 end type mom6hip_advect_stats_t
+
+!> mom6hip_remapping_cs_t (remapping_CS, src/ALE/MOM_remapping.F90:25)
+type, bind(c) :: mom6hip_remapping_cs_t
+  integer(c_int32_t) :: remapping_scheme, boundary_extrapolation, force_bounds_in_subcell, answer_date
+end type mom6hip_remapping_cs_t
+
+!> mom6hip_regridding_cs_t (regridding_CS, src/ALE/MOM_regridding.F90:50; z* only)
+type, bind(c) :: mom6hip_regridding_cs_t
+  integer(c_int32_t) :: regridding_scheme, nk
+  real(c_double) :: min_thickness, old_grid_weight, depth_of_time_filter_shallow, depth_of_time_filter_deep, Z_ref
+  type(c_ptr) :: coordinateResolution
+end type mom6hip_regridding_cs_t
+
+!> mom6hip_coriolisadv_cs_t (CoriolisAdv_CS, src/core/MOM_CoriolisAdv.F90:30)
+type, bind(c) :: mom6hip_coriolisadv_cs_t
+  integer(c_int32_t) :: coriolis_scheme, ke_scheme, no_slip, bound_coriolis, coriolis_en_dis
+  integer(c_int32_t) :: reserved(3)
+end type mom6hip_coriolisadv_cs_t
+
+!> mom6hip_continuity_cs_t (continuity_PPM_CS, src/core/MOM_continuity_PPM.F90:35)
+type, bind(c) :: mom6hip_continuity_cs_t
+  integer(c_int32_t) :: upwind_1st, monotonic, simple_2nd, aggress_adjust, vol_CFL, better_iter, use_visc_rem_max, &
+                        marginal_faces
+  real(c_double) :: tol_eta, tol_vel, CFL_limit_adjust
+end type mom6hip_continuity_cs_t
+
+!> mom6hip_bt_cont_t (BT_cont_type, src/core/MOM_variables.F90): c_loc of each member array
+type, bind(c) :: mom6hip_bt_cont_t
+  type(c_ptr) :: FA_u_W0, FA_u_WW, FA_u_E0, FA_u_EE, uBT_WW, uBT_EE
+  type(c_ptr) :: FA_v_S0, FA_v_SS, FA_v_N0, FA_v_NN, vBT_SS, vBT_NN
+  type(c_ptr) :: h_u, h_v
+end type mom6hip_bt_cont_t
+
+!> mom6hip_eos_t (EOS_type members of the provided forms, src/equation_of_state/MOM_EOS.F90)
+type, bind(c) :: mom6hip_eos_t
+  integer(c_int32_t) :: form, reserved
+  real(c_double) :: Rho_T0_S0, dRho_dT, dRho_dS
+end type mom6hip_eos_t
+
+!> mom6hip_pressureforce_cs_t (PressureForce_FV_CS, src/core/MOM_PressureForce_FV.F90)
+type, bind(c) :: mom6hip_pressureforce_cs_t
+  real(c_double) :: Rho0, GFS_scale, Z_ref
+  integer(c_int32_t) :: reconstruct, Recon_Scheme, boundary_extrap, useMassWghtInterp
+end type mom6hip_pressureforce_cs_t
+
+!> mom6hip_barotropic_cs_t (barotropic_CS, src/core/MOM_barotropic.F90:104)
+type, bind(c) :: mom6hip_barotropic_cs_t
+  real(c_double) :: dtbt, dtbt_max, dtbt_fraction, bebt, dt_bt_filter, vel_underflow, G_extra, BT_Coriolis_scale, Z_ref
+  real(c_double) :: reserved0(7)
+  integer(c_int32_t) :: Sadourny, linearized_BT_PV, strong_drag, visc_rem_u_uh0, adjust_BT_cont, use_wide_halos, &
+                        hvel_scheme, nstep_last
+  integer(c_int32_t) :: unsupported(12)
+  integer(c_int32_t) :: reserved1(4)
+  type(c_ptr) :: frhatu, frhatv, eta_cor, IDatu, IDatv, ubtav, vbtav, q_D, D_u_Cor, D_v_Cor
+  type(c_ptr) :: reserved2(6)
+end type mom6hip_barotropic_cs_t
+
+!> mom6hip_visc_hooks_t: the host's viscosity parameterisations, called at the reference's seams with device pointers
+type, bind(c) :: mom6hip_visc_hooks_t
+  type(c_ptr) :: user
+  type(c_funptr) :: visc_remnant_pred, vertvisc, horizontal_viscosity
+end type mom6hip_visc_hooks_t
+
+!> mom6hip_dyn_split_rk2_cs_t (MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84); every array is a DEVICE
+!! array obtained from mom6hip_malloc
+type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
+  real(c_double) :: be, begw
+  integer(c_int32_t) :: BT_use_layer_fluxes, store_CAu, CAu_pred_stored, split_bottom_stress
+  integer(c_int32_t) :: reserved0(4)
+  type(c_ptr) :: continuity_CSp, CoriolisAdv, PressureForce_CSp, eqn_of_state, barotropic_CSp, BT_cont, hooks
+  type(c_ptr) :: reserved1(3)
+  type(c_ptr) :: CAu, CAv, CAu_pred, CAv_pred, PFu, PFv, diffu, diffv, visc_rem_u, visc_rem_v, u_accel_bt, v_accel_bt, &
+                 u_av, v_av, h_av, pbce
+  type(c_ptr) :: eta, eta_PF, uhbt, vhbt
+  type(c_ptr) :: reserved2(4)
+end type mom6hip_dyn_split_rk2_cs_t
 
 interface
   function mom6hip_init(device) bind(c, name="mom6hip_init") result(rc)
@@ -92,6 +168,196 @@ interface
     type(mom6hip_advect_stats_t), intent(out) :: stats
     integer(c_int) :: rc
   end function mom6hip_advect_tracer
+
+  function mom6hip_malloc(dptr, bytes) bind(c, name="mom6hip_malloc") result(rc)
+    import :: c_int, c_ptr, c_int64_t
+    type(c_ptr), intent(out) :: dptr
+    integer(c_int64_t), value :: bytes
+    integer(c_int) :: rc
+  end function mom6hip_malloc
+
+  function mom6hip_free(dptr) bind(c, name="mom6hip_free") result(rc)
+    import :: c_int, c_ptr
+    type(c_ptr), value :: dptr
+    integer(c_int) :: rc
+  end function mom6hip_free
+
+  function mom6hip_sync_to_device(ctx, dptr, hptr, bytes) bind(c, name="mom6hip_sync_to_device") result(rc)
+    import :: c_int, c_ptr, c_int64_t
+    type(c_ptr), value :: ctx, dptr, hptr
+    integer(c_int64_t), value :: bytes
+    integer(c_int) :: rc
+  end function mom6hip_sync_to_device
+
+  function mom6hip_sync_to_host(ctx, hptr, dptr, bytes) bind(c, name="mom6hip_sync_to_host") result(rc)
+    import :: c_int, c_ptr, c_int64_t
+    type(c_ptr), value :: ctx, hptr, dptr
+    integer(c_int64_t), value :: bytes
+    integer(c_int) :: rc
+  end function mom6hip_sync_to_host
+
+  function mom6hip_halo_update(ctx, fields, pos, nk_each, nfields) bind(c, name="mom6hip_halo_update") result(rc)
+    import :: c_int, c_int32_t, c_ptr
+    type(c_ptr), value :: ctx
+    type(c_ptr), intent(in) :: fields(*)
+    integer(c_int32_t), intent(in) :: pos(*), nk_each(*)
+    integer(c_int32_t), value :: nfields
+    integer(c_int) :: rc
+  end function mom6hip_halo_update
+
+  !> halo_fn / sum_fn: bind(c) procedures of the host wrapping do_group_pass / sum_across_PEs on device buffers
+  function mom6hip_set_domain_callbacks(ctx, halo_fn, sum_fn, user) bind(c, name="mom6hip_set_domain_callbacks") result(rc)
+    import :: c_int, c_ptr, c_funptr
+    type(c_ptr), value :: ctx, user
+    type(c_funptr), value :: halo_fn, sum_fn
+    integer(c_int) :: rc
+  end function mom6hip_set_domain_callbacks
+
+  function mom6hip_set_min_callback(ctx, min_fn, user) bind(c, name="mom6hip_set_min_callback") result(rc)
+    import :: c_int, c_ptr, c_funptr
+    type(c_ptr), value :: ctx, user
+    type(c_funptr), value :: min_fn
+    integer(c_int) :: rc
+  end function mom6hip_set_min_callback
+
+  function mom6hip_ale_remap_tracers(ctx, cs, h_old, h_new, tr, conc_underflow, ntr, memspace) &
+                                     bind(c, name="mom6hip_ale_remap_tracers") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_remapping_cs_t
+    type(c_ptr), value :: ctx, h_old, h_new, conc_underflow
+    type(mom6hip_remapping_cs_t), intent(in) :: cs
+    type(c_ptr), intent(in) :: tr(*)
+    integer(c_int32_t), value :: ntr, memspace
+    integer(c_int) :: rc
+  end function mom6hip_ale_remap_tracers
+
+  function mom6hip_ale_regrid(ctx, cs, h, h_new, dzRegrid, memspace) bind(c, name="mom6hip_ale_regrid") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_regridding_cs_t
+    type(c_ptr), value :: ctx, h, h_new, dzRegrid
+    type(mom6hip_regridding_cs_t), intent(in) :: cs
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_ale_regrid
+
+  function mom6hip_ale_remap_set_h_vel(ctx, h_new, h_u, h_v, memspace) bind(c, name="mom6hip_ale_remap_set_h_vel") result(rc)
+    import :: c_int, c_int32_t, c_ptr
+    type(c_ptr), value :: ctx, h_new, h_u, h_v
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_ale_remap_set_h_vel
+
+  function mom6hip_ale_remap_velocities(ctx, cs, h_old_u, h_old_v, h_new_u, h_new_v, u, v, memspace) &
+                                        bind(c, name="mom6hip_ale_remap_velocities") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_remapping_cs_t
+    type(c_ptr), value :: ctx, h_old_u, h_old_v, h_new_u, h_new_v, u, v
+    type(mom6hip_remapping_cs_t), intent(in) :: cs
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_ale_remap_velocities
+
+  function mom6hip_coradcalc(ctx, cs, u, v, h, uh, vh, CAu, CAv, memspace) bind(c, name="mom6hip_coradcalc") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_coriolisadv_cs_t
+    type(c_ptr), value :: ctx, u, v, h, uh, vh, CAu, CAv
+    type(mom6hip_coriolisadv_cs_t), intent(in) :: cs
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_coradcalc
+
+  !> Optional Fortran arguments arrive as c_null_ptr; BT_cont is c_loc of a mom6hip_bt_cont_t or c_null_ptr
+  function mom6hip_continuity(ctx, cs, u, v, hin, h, uh, vh, dt, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, &
+                              BT_cont, du_cor, dv_cor, memspace) bind(c, name="mom6hip_continuity") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_continuity_cs_t
+    type(c_ptr), value :: ctx, u, v, hin, h, uh, vh, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor, dv_cor
+    type(mom6hip_continuity_cs_t), intent(in) :: cs
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_continuity
+
+  function mom6hip_pressureforce_fv_bouss(ctx, cs, eos, h, T, S, p_atm, PFu, PFv, pbce, eta, memspace) &
+                                          bind(c, name="mom6hip_pressureforce_fv_bouss") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_pressureforce_cs_t, mom6hip_eos_t
+    type(c_ptr), value :: ctx, h, T, S, p_atm, PFu, PFv, pbce, eta
+    type(mom6hip_pressureforce_cs_t), intent(in) :: cs
+    type(mom6hip_eos_t), intent(in) :: eos
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_pressureforce_fv_bouss
+
+  function mom6hip_calculate_density(ctx, eos, T, S, pressure, rho, n, use_rho_ref, rho_ref, memspace) &
+                                     bind(c, name="mom6hip_calculate_density") result(rc)
+    import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr, mom6hip_eos_t
+    type(c_ptr), value :: ctx, T, S, pressure, rho
+    type(mom6hip_eos_t), intent(in) :: eos
+    integer(c_int64_t), value :: n
+    integer(c_int32_t), value :: use_rho_ref, memspace
+    real(c_double), value :: rho_ref
+    integer(c_int) :: rc
+  end function mom6hip_calculate_density
+
+  function mom6hip_barotropic_init(ctx, cs, memspace) bind(c, name="mom6hip_barotropic_init") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_barotropic_cs_t
+    type(c_ptr), value :: ctx
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_barotropic_init
+
+  function mom6hip_btcalc(ctx, cs, h, h_u, h_v, may_use_default, memspace) bind(c, name="mom6hip_btcalc") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_barotropic_cs_t
+    type(c_ptr), value :: ctx, h, h_u, h_v
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    integer(c_int32_t), value :: may_use_default, memspace
+    integer(c_int) :: rc
+  end function mom6hip_btcalc
+
+  function mom6hip_bt_mass_source(ctx, cs, h, eta, set_cor, memspace) bind(c, name="mom6hip_bt_mass_source") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_barotropic_cs_t
+    type(c_ptr), value :: ctx, h, eta
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    integer(c_int32_t), value :: set_cor, memspace
+    integer(c_int) :: rc
+  end function mom6hip_bt_mass_source
+
+  function mom6hip_set_dtbt(ctx, cs, pbce, BT_cont, gtot_est, SSH_add, memspace) bind(c, name="mom6hip_set_dtbt") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_barotropic_cs_t
+    type(c_ptr), value :: ctx, pbce, BT_cont
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    real(c_double), value :: gtot_est, SSH_add
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_set_dtbt
+
+  function mom6hip_btstep(ctx, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, RZ_to_H, pbce, eta_PF_in, &
+                          U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, &
+                          BT_cont, eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav, memspace) &
+                          bind(c, name="mom6hip_btstep") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_barotropic_cs_t
+    type(c_ptr), value :: ctx, U_in, V_in, eta_in, bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor, &
+                          accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, BT_cont, &
+                          eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    real(c_double), value :: dt, RZ_to_H
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_btstep
+
+  function mom6hip_dyn_split_rk2_init(ctx, cs, u, v, h, uh, vh, dt) bind(c, name="mom6hip_dyn_split_rk2_init") result(rc)
+    import :: c_int, c_double, c_ptr, mom6hip_dyn_split_rk2_cs_t
+    type(c_ptr), value :: ctx, u, v, h, uh, vh
+    type(mom6hip_dyn_split_rk2_cs_t), intent(inout) :: cs
+    real(c_double), value :: dt
+    integer(c_int) :: rc
+  end function mom6hip_dyn_split_rk2_init
+
+  function mom6hip_step_dyn_split_rk2(ctx, cs, u_inst, v_inst, h, T, S, dt, taux, tauy, RZ_to_H, uh, vh, uhtr, vhtr, &
+                                      eta_av, calc_dtbt) bind(c, name="mom6hip_step_dyn_split_rk2") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_dyn_split_rk2_cs_t
+    type(c_ptr), value :: ctx, u_inst, v_inst, h, T, S, taux, tauy, uh, vh, uhtr, vhtr, eta_av
+    type(mom6hip_dyn_split_rk2_cs_t), intent(inout) :: cs
+    real(c_double), value :: dt, RZ_to_H
+    integer(c_int32_t), value :: calc_dtbt
+    integer(c_int) :: rc
+  end function mom6hip_step_dyn_split_rk2
 end interface
 
 contains

@@ -28,6 +28,12 @@ def test_struct_layout_matches():
     assert L.mom6hip_abi_sizeof_tracer_advect_cs() == C.sizeof(_abi.TracerAdvectCS)
     assert L.mom6hip_abi_sizeof_advect_stats() == C.sizeof(_abi.AdvectStats)
     assert L.mom6hip_abi_sizeof_advect_timing() == C.sizeof(_abi.AdvectTiming)
+    for n, t in (("remapping_cs", _abi.RemappingCS), ("regridding_cs", _abi.RegriddingCS), ("coriolisadv_cs", _abi.CoriolisAdvCS),
+                 ("continuity_cs", _abi.ContinuityCS), ("bt_cont", _abi.BTCont), ("eos", _abi.EOS),
+                 ("pressureforce_cs", _abi.PressureForceCS), ("barotropic_cs", _abi.BarotropicCS),
+                 ("dyn_split_rk2_cs", _abi.DynSplitRK2CS)):
+        f = getattr(L, f"mom6hip_abi_sizeof_{n}"); f.restype = C.c_uint64
+        assert f() == C.sizeof(t), n
 
 
 def test_no_cpu_fallback():
