@@ -182,6 +182,15 @@ typedef struct mom6hip_advect_timing {
   int32_t n_x, n_y;
 } mom6hip_advect_timing_t;
 int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable);
+
+/* Per-kernel HIP-event timing on the context's stream for the roofline line of bench.py.  Slots:
+ * 0 = cont_flux_kernel<0> (zonal), 1 = cont_flux_kernel<1> (meridional).  mom6hip_kernel_timing(enable = 1) starts
+ * recording (an event pair around every launch of the slot's kernel); a later call returns the summed duration and the
+ * number of launches since then (it synchronises the stream) and, with enable = 0, stops recording. */
+#define MOM6HIP_KT_CONT_FLUX_X 0
+#define MOM6HIP_KT_CONT_FLUX_Y 1
+#define MOM6HIP_KT_SLOTS 2
+int mom6hip_kernel_timing(mom6hip_ctx_t *ctx, int32_t enable, double *ms_total, int64_t *launches);
 int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t);
 
 /* ---- MOM_ALE / MOM_remapping ----------------------------------------------------------------- */

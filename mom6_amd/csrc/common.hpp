@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mom6hip.h"
@@ -97,6 +98,8 @@ struct mom6hip_ctx {
   void *min_user = nullptr;
   void *cb_user = nullptr;
   // timing
+  bool ktiming = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kt_events[MOM6HIP_KT_SLOTS];
   bool timing = false;
   mom6hip_advect_timing_t adv_timing = {};
 };
@@ -106,6 +109,21 @@ namespace m6 {
 // Gives a kernel driver device views of the caller's arrays.  MOM6HIP_MEM_DEVICE: the pointers are used
 // as they are.  MOM6HIP_MEM_HOST: inputs are copied to pooled device buffers, outputs are copied back by
 // finish().  The same host pointer always maps to the same device buffer (h may alias hin, ...).
+// event pair around a kernel launch when per-kernel timing is on (mom6hip_kernel_timing)
+struct KTimer {
+  mom6hip_ctx *c; int slot; hipEvent_t e0 = nullptr, e1 = nullptr;
+  KTimer(mom6hip_ctx *ctx, int s) : c(ctx), slot(s) {
+    if (!c->ktiming) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    (void)hipEventRecord(e0, c->stream);
+  }
+  ~KTimer() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->kt_events[slot].push_back({e0, e1});
+  }
+};
+
 class Stager {
  public:
   Stager(mom6hip_ctx *ctx, int memspace) : ctx_(ctx), host_(memspace == MOM6HIP_MEM_HOST) {}

@@ -136,6 +136,24 @@ int mom6hip_set_min_callback(mom6hip_ctx_t *ctx, mom6hip_min_fn min_fn, void *us
   return 0;
 }
 
+int mom6hip_kernel_timing(mom6hip_ctx_t *ctx, int32_t enable, double *ms_total, int64_t *launches) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_kernel_timing: null context");
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < MOM6HIP_KT_SLOTS; s++) {
+    double ms = 0.0;
+    for (auto &e : ctx->kt_events[s]) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) ms += t;
+      (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    if (ms_total) ms_total[s] = ms;
+    if (launches) launches[s] = (int64_t)ctx->kt_events[s].size();
+    ctx->kt_events[s].clear();
+  }
+  ctx->ktiming = enable != 0;
+  return 0;
+}
+
 int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_set_timing: null context");
   ctx->timing = enable != 0;

@@ -503,7 +503,8 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     f.FA_0m = bt.FA_u_W0; f.FA_mm = bt.FA_u_WW; f.FA_0p = bt.FA_u_E0; f.FA_pp = bt.FA_u_EE; f.uBT_mm = bt.uBT_WW;
     f.uBT_pp = bt.uBT_EE; f.h_face = bt.h_u; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = is - 1; f.fi1 = ie; f.fj0 = jsh; f.fj1 = jeh;
-    hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((f.fi1 - f.fi0 + 64) / 64, jeh - jsh + 1), dim3(64), 0, s, f);
+    { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_X);
+      hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((f.fi1 - f.fi0 + 64) / 64, jeh - jsh + 1), dim3(64), 0, s, f); }
     ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = d_h; c.dt = dt; c.h_min = hmin;
     c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh;
     hipLaunchKernelGGL(cont_conv_kernel<0>, dim3((ie - is + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, c);
@@ -519,7 +520,8 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     f.FA_0m = bt.FA_v_S0; f.FA_mm = bt.FA_v_SS; f.FA_0p = bt.FA_v_N0; f.FA_pp = bt.FA_v_NN; f.uBT_mm = bt.vBT_SS;
     f.uBT_pp = bt.vBT_NN; f.h_face = bt.h_v; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = ish; f.fi1 = ieh; f.fj0 = js - 1; f.fj1 = je;
-    hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((ieh - ish + 64) / 64, f.fj1 - f.fj0 + 1), dim3(64), 0, s, f);
+    { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_Y);
+      hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((ieh - ish + 64) / 64, f.fj1 - f.fj0 + 1), dim3(64), 0, s, f); }
     ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
     c.i0 = ish; c.i1 = ieh; c.j0 = js; c.j1 = je;
     hipLaunchKernelGGL(cont_conv_kernel<1>, dim3((ieh - ish + 256) / 256, je - js + 1, g.nk), dim3(256), 0, s, c);

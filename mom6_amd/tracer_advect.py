@@ -45,6 +45,12 @@ class DeviceGrid:
         check(lib().mom6hip_advect_get_timing(self.handle, C.byref(t)), "mom6hip_advect_get_timing")
         return t
 
+    def kernel_timing(self, enable):
+        """(ms_total, launches) per timing slot since recording was switched on (mom6hip_kernel_timing)."""
+        ms = (C.c_double * 2)(); n = (C.c_int64 * 2)()
+        check(lib().mom6hip_kernel_timing(self.handle, int(bool(enable)), ms, n), "mom6hip_kernel_timing")
+        return [(ms[q], n[q]) for q in range(2)]
+
     def halo_update(self, fields, positions):
         """pass_var / pass_vector on this one-tile domain for torch CUDA tensors."""
         n = len(fields)
