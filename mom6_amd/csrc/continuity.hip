@@ -62,38 +62,25 @@ struct EdgeArgs {
   int i0, i1, j0, j1;      // cells to reconstruct (already including the +-1 along the direction)
 };
 
-template <int DIR>
-__global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
-  const m6::GridDev &g = p.g;
-  const int i = p.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = p.j0 + blockIdx.y;
-  const int k = blockIdx.z;
-  if (i > p.i1) return;
-  const long s = DIR ? (long)g.nih : 1L;
-  const long o2 = g.h2(i, j), o3 = o2 + (long)g.nih * g.njh * k;
-  const double *h = p.h_in + o3;
-  const double *m = g.mask2dT + o2;
-  const double hc = h[0];
-  if (p.o.upwind_1st) { p.h_L[o3] = hc; p.h_R[o3] = hc; return; }
-  const double hm = h[-s], hp = h[s];
-  const double mm = m[-s], mp = m[s];
+// PPM_reconstruction + limiter for one cell from its five-point stencil along the direction (:2310-2662)
+__device__ __forceinline__ void edge_values(const ContOpts &o, double Angstrom_H, double hmm, double hm, double hc, double hp,
+                                            double hpp, double mmm, double mm, double mc, double mp, double mpp, double &L,
+                                            double &R) {
+  if (o.upwind_1st) { L = hc; R = hc; return; }
   const double h_m1 = mm * hm + (1.0 - mm) * hc;
   const double h_p1 = mp * hp + (1.0 - mp) * hc;
-  double L, R;
-  if (p.o.simple_2nd) {
+  if (o.simple_2nd) {
     L = 0.5 * (h_m1 + hc);
     R = 0.5 * (h_p1 + hc);
   } else {
     // slopes of cells a-1, a, a+1 (:2371-2381)
-    auto slope = [&](double hl, double hcc, double hr, double ml, double mc, double mr) -> double {
-      if ((ml * mc * mr) == 0.0) return 0.0;
+    auto slope = [&](double hl, double hcc, double hr, double ml, double mcc, double mr) -> double {
+      if ((ml * mcc * mr) == 0.0) return 0.0;
       double sl = 0.5 * (hr - hl);
       const double dMx = max3(hr, hl, hcc) - hcc;
       const double dMn = hcc - min3(hr, hl, hcc);
       return copysign(1., sl) * min2(fabs(sl), 2. * min2(dMx, dMn));
     };
-    const double hmm = h[-2 * s], hpp = h[2 * s];
-    const double mmm = m[-2 * s], mc = m[0], mpp = m[2 * s];
     const double slp_m = slope(hmm, hm, hc, mmm, mm, mc);
     const double slp_c = slope(hm, hc, hp, mm, mc, mp);
     const double slp_p = slope(hc, hp, hpp, mc, mp, mpp);
@@ -101,7 +88,7 @@ __global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
     L = 0.5 * (h_m1 + hc) + oneSixth * (slp_m - slp_c);
     R = 0.5 * (h_p1 + hc) + oneSixth * (slp_c - slp_p);
   }
-  if (p.o.monotonic) {          // PPM_limit_CW84 :2625
+  if (o.monotonic) {          // PPM_limit_CW84 :2625
     if ((R - hc) * (hc - L) <= 0.) {
       L = hc; R = hc;
     } else {
@@ -113,7 +100,7 @@ __global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
       if (FunFac < -RLdiff2) R = 3. * hc - 2. * L;
     }
   } else {                      // PPM_limit_pos :2583
-    const double h_min = 2.0 * g.Angstrom_H;
+    const double h_min = 2.0 * Angstrom_H;
     const double curv = 3.0 * (L + R - 2.0 * hc);
     if (curv > 0.0) {
       const double dh = R - L;
@@ -128,7 +115,53 @@ __global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
       }
     }
   }
-  p.h_L[o3] = L; p.h_R[o3] = R;
+}
+
+// DIR 0: one thread per cell (the stencil is along the lanes).  DIR 1: one thread per column of EDGE_RJ rows, marching
+// in j with the five-row stencil in registers, so a row of h is fetched once per block instead of five times.
+constexpr int EDGE_RJ = 16;
+
+template <int DIR>
+__global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = p.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.z;
+  if (i > p.i1) return;
+  const long hpl = (long)g.nih * g.njh;
+  const bool wide = !(p.o.upwind_1st || p.o.simple_2nd);      // the 5-point stencil is only read by the PPM branch
+  if (DIR == 0) {
+    const int j = p.j0 + blockIdx.y;
+    const long o2 = g.h2(i, j), o3 = o2 + hpl * k;
+    const double *h = p.h_in + o3;
+    const double *m = g.mask2dT + o2;
+    double L, R;
+    if (p.o.upwind_1st) { L = h[0]; R = h[0]; }
+    else edge_values(p.o, g.Angstrom_H, wide ? h[-2] : 0.0, h[-1], h[0], h[1], wide ? h[2] : 0.0, wide ? m[-2] : 0.0, m[-1], m[0],
+                     m[1], wide ? m[2] : 0.0, L, R);
+    p.h_L[o3] = L; p.h_R[o3] = R;
+  } else {
+    const int ja = p.j0 + blockIdx.y * EDGE_RJ;
+    const int jb = min(ja + EDGE_RJ - 1, p.j1);
+    const long s = g.nih;
+    long o2 = g.h2(i, ja), o3 = o2 + hpl * k;
+    const double *h = p.h_in + o3;
+    const double *m = g.mask2dT + o2;
+    if (p.o.upwind_1st) {
+      for (int j = ja; j <= jb; j++, h += s, o3 += s) { p.h_L[o3] = h[0]; p.h_R[o3] = h[0]; }
+      return;
+    }
+    double hmm = wide ? h[-2 * s] : 0.0, hm = h[-s], hc = h[0], hp = h[s];
+    double mmm = wide ? m[-2 * s] : 0.0, mm = m[-s], mc = m[0], mp = m[s];
+    for (int j = ja; j <= jb; j++) {
+      const double hpp = wide ? h[2 * s] : 0.0, mpp = wide ? m[2 * s] : 0.0;
+      double L, R;
+      edge_values(p.o, g.Angstrom_H, hmm, hm, hc, hp, hpp, mmm, mm, mc, mp, mpp, L, R);
+      p.h_L[o3] = L; p.h_R[o3] = R;
+      hmm = hm; hm = hc; hc = hp; hp = wide ? hpp : (j < jb ? h[2 * s] : 0.0);
+      mmm = mm; mm = mc; mc = mp; mp = wide ? mpp : (j < jb ? m[2 * s] : 0.0);
+      h += s; m += s; o3 += s;
+    }
+  }
 }
 
 // ---- mass fluxes ---------------------------------------------------------------------------------
@@ -317,7 +350,7 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
   double du = 0.0;
   if (p.uhbt) {      // :737-754
     du = flux_adjust<DIR>(p, D, o3_0, o2, f3_0, f2, p.uhbt[f2], uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL, true);
-    if (p.u_cor)
+    if (p.u_cor && !p.set_BT_cont)      // with BT_cont, u_cor is written in the pass that evaluates the three fits below
       for (int k = 0; k < nz; k++) {
         const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
         p.u_cor[f3_0 + k * fpl] = p.u[f3_0 + k * fpl] + du * vr;
@@ -341,6 +374,7 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
       }
     }
     double FAmt_L = 0.0, FAmt_R = 0.0, FAmt_0 = 0.0, uhtot_L = 0.0, uhtot_R = 0.0;
+    const bool cor = p.uhbt && p.u_cor;
     for (int k = 0; k < nz; k++) {
       const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
       const double uk = p.u[f3_0 + k * fpl];
@@ -351,6 +385,34 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
       const double uh_R = flux_layer<DIR>(p, D, u_R, o3_0 + k * hpl, o2, f2, vr, dR);
       FAmt_0 = FAmt_0 + d0; FAmt_L = FAmt_L + dL; FAmt_R = FAmt_R + dR;
       uhtot_L = uhtot_L + uh_L; uhtot_R = uhtot_R + uh_R;
+      // u_cor (:744-748) and flux_thickness (:976-1057, with u_cor if present :809-815) ride on the same layer data
+      double uc = uk;
+      if (cor) { uc = uk + du * vr; p.u_cor[f3_0 + k * fpl] = uc; }
+      if (p.h_face) {
+        const long o3 = o3_0 + k * hpl;
+        double CFL, curv_3, h_avg, h_marg;
+        if (uc > 0.0) {
+          if (p.o.vol_CFL) CFL = (uc * p.dt) * (D.dL_face()[f2] * g.IareaT[o2]);
+          else CFL = uc * p.dt * D.IdL_T()[o2];
+          const double hW = p.h_L[o3], hE = p.h_R[o3];
+          curv_3 = hW + hE - 2.0 * p.h_in[o3];
+          h_avg = hE + CFL * (0.5 * (hW - hE) + curv_3 * (CFL - 1.5));
+          h_marg = hE + CFL * ((hW - hE) + 3.0 * curv_3 * (CFL - 1.0));
+        } else if (uc < 0.0) {
+          if (p.o.vol_CFL) CFL = (-uc * p.dt) * (D.dL_face()[f2] * g.IareaT[o2 + s]);
+          else CFL = -uc * p.dt * D.IdL_T()[o2 + s];
+          const double hW = p.h_L[o3 + s], hE = p.h_R[o3 + s];
+          curv_3 = hW + hE - 2.0 * p.h_in[o3 + s];
+          h_avg = hW + CFL * (0.5 * (hE - hW) + curv_3 * (CFL - 1.5));
+          h_marg = hW + CFL * ((hE - hW) + 3.0 * curv_3 * (CFL - 1.0));
+        } else {
+          h_avg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+          h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+        }
+        double hu = p.o.marginal_faces ? h_marg : h_avg;
+        if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
+        p.h_face[f3_0 + k * fpl] = hu;
+      }
     }
     double FA_0 = FAmt_0, FA_avg = FAmt_0;
     if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
@@ -368,36 +430,6 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
     if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) p.uBT_pp[f2] = 0.0;
     else p.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
 
-    if (p.h_face) {      // flux_thickness :976-1057 with u_cor if present (:809-815)
-      for (int k = 0; k < nz; k++) {
-        const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
-        double uk = p.u[f3_0 + k * fpl];
-        if (p.uhbt && p.u_cor) uk = uk + du * vr;      // the value just stored in u_cor
-        const long o3 = o3_0 + k * hpl;
-        double CFL, curv_3, h_avg, h_marg;
-        if (uk > 0.0) {
-          if (p.o.vol_CFL) CFL = (uk * p.dt) * (D.dL_face()[f2] * g.IareaT[o2]);
-          else CFL = uk * p.dt * D.IdL_T()[o2];
-          const double hW = p.h_L[o3], hE = p.h_R[o3];
-          curv_3 = hW + hE - 2.0 * p.h_in[o3];
-          h_avg = hE + CFL * (0.5 * (hW - hE) + curv_3 * (CFL - 1.5));
-          h_marg = hE + CFL * ((hW - hE) + 3.0 * curv_3 * (CFL - 1.0));
-        } else if (uk < 0.0) {
-          if (p.o.vol_CFL) CFL = (-uk * p.dt) * (D.dL_face()[f2] * g.IareaT[o2 + s]);
-          else CFL = -uk * p.dt * D.IdL_T()[o2 + s];
-          const double hW = p.h_L[o3 + s], hE = p.h_R[o3 + s];
-          curv_3 = hW + hE - 2.0 * p.h_in[o3 + s];
-          h_avg = hW + CFL * (0.5 * (hE - hW) + curv_3 * (CFL - 1.5));
-          h_marg = hW + CFL * ((hE - hW) + 3.0 * curv_3 * (CFL - 1.0));
-        } else {
-          h_avg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
-          h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
-        }
-        double hu = p.o.marginal_faces ? h_marg : h_avg;
-        if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
-        p.h_face[f3_0 + k * fpl] = hu;
-      }
-    }
   }
 }
 
@@ -514,7 +546,7 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
   auto merid = [&](const double *hsrc, int ish, int ieh, double hmin) -> int {
     EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
     e.i0 = ish; e.i1 = ieh; e.j0 = js - 1; e.j1 = je + 1;
-    hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, e.j1 - e.j0 + 1, g.nk), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, s, e);
     FluxArgs f; f.g = g; f.o = o; f.u = d_v; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_vhbt; f.visc_rem = d_vrv;
     f.uh = d_vh; f.u_cor = d_vcor; f.du_cor = d_dvcor;
     f.FA_0m = bt.FA_v_S0; f.FA_mm = bt.FA_v_SS; f.FA_0p = bt.FA_v_N0; f.FA_pp = bt.FA_v_NN; f.uBT_mm = bt.vBT_SS;

@@ -143,18 +143,20 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
 
   // the step's automatic arrays (:336-369): one grow-only block in the context's pool
   // (its own buffer: the modules called below hand out the pool's buffers from the start in every call)
-  M6_REQUIRE(ctx->rk2_scratch.reserve(3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2) == 0, "step_MOM_dyn_split_RK2: out of device memory");
+  const size_t blk_bytes = 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2;
+  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes;
+  M6_REQUIRE(ctx->rk2_scratch.reserve(blk_bytes) == 0, "step_MOM_dyn_split_RK2: out of device memory");
   char *blk = (char *)ctx->rk2_scratch.p;
   double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3);
   double *vp = (double *)(blk + 3 * sz.u3), *v_bc = (double *)(blk + 3 * sz.u3 + sz.v3), *vh_in = (double *)(blk + 3 * sz.u3 + 2 * sz.v3);
   double *hp = (double *)(blk + 3 * sz.u3 + 3 * sz.v3), *eta_pred = (double *)(blk + 3 * sz.u3 + 3 * sz.v3 + sz.h3);
   double *u_av = cs->u_av, *v_av = cs->v_av, *h_av = cs->h_av, *eta = cs->eta;
 
-  M6_HIP(hipMemsetAsync(up, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(vp, 0, sz.v3, s));                 // :419-421
+  // up = vp = 0, hp = h (:419-422).  The zeros only matter where nothing writes afterwards: the halo faces beyond a
+  // closed edge (every other point of up, vp is recomputed or refilled by pass_uvp each step; u_bc_accel, uh_in and
+  // eta_pred are read only where they are written), so the block is zeroed when it is allocated, not every step.
+  if (fresh) M6_HIP(hipMemsetAsync(blk, 0, blk_bytes, s));
   M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :422
-  M6_HIP(hipMemsetAsync(u_bc, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(v_bc, 0, sz.v3, s));
-  M6_HIP(hipMemsetAsync(uh_in, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(vh_in, 0, sz.v3, s));
-  M6_HIP(hipMemsetAsync(eta_pred, 0, sz.h2, s));
 
   // PressureForce :495
   CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,
