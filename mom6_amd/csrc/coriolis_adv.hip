@@ -33,8 +33,10 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   __shared__ double s_q[TJ + 2][TI + 2];      // q(I0-1 .. I0+64, J0-1 .. J0+8) (the +1 column/row: Arakawa-Hsu)
   __shared__ double s_av[TJ + 2][TI + 2];     // abs_vort, same points
   __shared__ double s_ke[TJ + 1][TI + 1];     // KE(i = I0 .. I0+64, j = J0 .. J0+8)
-  const int k = blockIdx.z;
-  const int I0 = g.isc - 1 + blockIdx.x * TI, J0 = g.jsc - 1 + blockIdx.y * TJ;
+  // k is the fastest grid dimension: the blocks of one tile at k, k+8, ... land on the same XCD close in time, so
+  // the 2-D metrics of the tile are served by that XCD's L2 instead of being fetched again for every layer
+  const int k = blockIdx.x;
+  const int I0 = g.isc - 1 + blockIdx.y * TI, J0 = g.jsc - 1 + blockIdx.z * TJ;
   const int tid = threadIdx.y * TI + threadIdx.x;
   const long kH = (long)g.nih * g.njh * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
   auto H = [&](const double *a, int i, int j) { return a[kH + g.h2(i, j)]; };
@@ -199,7 +201,7 @@ extern "C" int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_c
   }
   a.scheme = cs->coriolis_scheme; a.ke_scheme = cs->ke_scheme; a.no_slip = cs->no_slip; a.bound = cs->bound_coriolis;
   a.vol_neglect = g.H_subroundoff * (1e-4 * 1.0) * (1e-4 * 1.0);   // :241
-  dim3 grid((g.iec - g.isc + 2 + TI - 1) / TI, (g.jec - g.jsc + 2 + TJ - 1) / TJ, g.nk);
+  dim3 grid(g.nk, (g.iec - g.isc + 2 + TI - 1) / TI, (g.jec - g.jsc + 2 + TJ - 1) / TJ);
   hipLaunchKernelGGL(coradcalc_kernel, grid, dim3(TI, TJ), 0, s, a);
   M6_HIP(hipGetLastError());
   if (memspace == MOM6HIP_MEM_HOST) {
