@@ -123,6 +123,9 @@ int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t
 typedef int (*mom6hip_halo_fn)(void *user, double *const *fields, const int32_t *pos, const int32_t *nk, int32_t nfields);
 typedef int (*mom6hip_sum_fn)(void *user, int32_t *values, int32_t n);
 int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mom6hip_sum_fn sum_fn, void *user);
+/* stream_ordered = 1: halo_fn enqueues its work on (or in order with) the context's stream, so the library does not
+ * synchronise the stream before calling it (default 0: it does). */
+int mom6hip_set_callback_stream_ordered(mom6hip_ctx_t *ctx, int32_t stream_ordered);
 /* min_across_PEs (MOM_coms) of `n` HOST doubles, in place: used by set_dtbt (src/core/MOM_barotropic.F90:2915). */
 typedef int (*mom6hip_min_fn)(void *user, double *values, int32_t n);
 int mom6hip_set_min_callback(mom6hip_ctx_t *ctx, mom6hip_min_fn min_fn, void *user);

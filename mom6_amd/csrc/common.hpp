@@ -94,6 +94,7 @@ struct mom6hip_ctx {
   // multi-tile collectives provided by the host (null on a one-tile domain)
   mom6hip_halo_fn halo_cb = nullptr;
   mom6hip_sum_fn sum_cb = nullptr;
+  bool cb_stream_ordered = false;
   mom6hip_min_fn min_cb = nullptr;
   void *min_user = nullptr;
   void *cb_user = nullptr;

@@ -130,6 +130,12 @@ int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mo
   return 0;
 }
 
+int mom6hip_set_callback_stream_ordered(mom6hip_ctx_t *ctx, int32_t stream_ordered) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_set_callback_stream_ordered: null context");
+  ctx->cb_stream_ordered = stream_ordered != 0;
+  return 0;
+}
+
 int mom6hip_set_min_callback(mom6hip_ctx_t *ctx, mom6hip_min_fn min_fn, void *user) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_set_min_callback: null context");
   ctx->min_cb = min_fn; ctx->min_user = user;
@@ -348,7 +354,7 @@ int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
 // do_group_pass: the host's collective when the tile has neighbours, the local wrap kernels otherwise
 int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
   if (ctx->halo_cb) {
-    M6_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->cb_stream_ordered) M6_HIP(hipStreamSynchronize(ctx->stream));
     M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, pos, nk, n) == 0, "group pass: the domain halo callback failed");
     return 0;
   }

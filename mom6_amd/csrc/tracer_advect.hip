@@ -871,7 +871,7 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
         std::vector<double *> flds = {uhr, vhr, hprev};
         std::vector<int32_t> pos = {MOM6HIP_POS_U, MOM6HIP_POS_V, MOM6HIP_POS_H}, nks = {nz, nz, nz};
         for (int m = 0; m < ntr; m++) { flds.push_back(d_tr[m]); pos.push_back(MOM6HIP_POS_H); nks.push_back(nz); }
-        M6_HIP(hipStreamSynchronize(s));
+        if (!ctx->cb_stream_ordered) M6_HIP(hipStreamSynchronize(s));
         M6_REQUIRE(ctx->halo_cb(ctx->cb_user, flds.data(), pos.data(), nks.data(), (int32_t)flds.size()) == 0,
                    "advect_tracer: the host's halo update failed");
       } else {

@@ -107,7 +107,8 @@ class Domain:
         backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else None
         stage = backend == "gloo"      # gloo moves host memory only
         if self._dg is not None and len(fields) <= 24 and all(f.is_cuda for f in fields):
-            return self._pass_packed(fields, positions, w, stage)
+            return self.pass_ptrs([f.data_ptr() for f in fields], positions, [1 if f.dim() == 2 else f.shape[0] for f in fields],
+                                  w, stage)
 
         def exchange(direction):
             ops, recvs, keep = [], [], []
@@ -161,56 +162,67 @@ class Domain:
         exchange("x")
         exchange("y")
 
-    def _pass_packed(self, fields, positions, w, stage):
+    def pass_ptrs(self, ptr_list, positions, nk_list, w=None, stage=None):
         """The group pass for device fields: one message per neighbour and direction.  The library packs the send slabs
         of every field of the group into one buffer (mom6hip_halo_pack), torch.distributed moves the buffers (RCCL
         send/recv over xGMI; staged through the host only for the gloo rehearsal), the library unpacks into the halos.
-        A direction with a single tile is the library's own wrap kernel."""
+        A direction with a single tile is the library's own wrap kernel.  Everything is enqueued in stream order on the
+        current stream; the plan of a group (ctypes argument blocks, offsets, buffers) is built once and reused."""
         import ctypes as C
         import torch.distributed as dist
         from ._lib import check, lib
         dg, L = self._dg, lib()
-        h, nf = self.halo, len(fields)
-        ptrs = (C.c_void_p * nf)(*[f.data_ptr() for f in fields])
-        pos = (C.c_int32 * nf)(*positions)
-        nks = (C.c_int32 * nf)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
+        h, nf = self.halo, len(ptr_list)
+        if w is None:
+            w = h
+        if stage is None:
+            stage = dist.get_backend(self.group) == "gloo"
+        key = (tuple(ptr_list), tuple(positions), tuple(nk_list), w)
+        plan = self._bufs.get(key)
+        if plan is None:
+            ptrs = (C.c_void_p * nf)(*ptr_list)
+            pos = (C.c_int32 * nf)(*positions)
+            nks = (C.c_int32 * nf)(*nk_list)
+            plan = dict(ptrs=ptrs, pos=pos, nks=nks, dirs={})
+            for direction, n, lo, hi, ntile in ((0, self.ni, self._nbr(-1, 0), self._nbr(+1, 0), self.npi),
+                                               (1, self.nj, self._nbr(0, -1), self._nbr(0, +1), self.npj)):
+                if ntile == 1:
+                    continue
+                s = [self._ranges(p)[direction] for p in positions]
+                a0 = {name: (C.c_int32 * nf)(*v) for name, v in (("to_hi", [n + h - w] * nf), ("to_lo", [h + sf for sf in s]),
+                                                                  ("lo_halo", [h - w] * nf), ("hi_halo", [h + n + sf for sf in s]))}
+                cnt = C.c_int64(0)
+                check(L.mom6hip_halo_pack(dg.handle, ptrs, pos, nks, a0["to_hi"], nf, direction, w, None, 1, C.byref(cnt)),
+                      "mom6hip_halo_pack")
+                bufs = [torch.empty(cnt.value, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device())) for _ in range(4)]
+                plan["dirs"][direction] = dict(lo=lo, hi=hi, a0=a0, bufs=bufs)
+            self._bufs[key] = plan
+        ptrs, pos, nks = plan["ptrs"], plan["pos"], plan["nks"]
 
         def local_wrap():
             check(L.mom6hip_halo_update(dg.handle, ptrs, pos, nks, nf), "mom6hip_halo_update")
 
-        def pack(a0, direction, buf, do_pack):
-            cnt = C.c_int64(0)
-            arr = (C.c_int32 * nf)(*a0)
-            check(L.mom6hip_halo_pack(dg.handle, ptrs, pos, nks, arr, nf, direction, w, None if buf is None else buf.data_ptr(),
-                                      int(do_pack), C.byref(cnt)), "mom6hip_halo_pack")
-            return cnt.value
-
         def exchange(direction):
-            if direction == 0:
-                n, lo, hi = self.ni, self._nbr(-1, 0), self._nbr(+1, 0)
-            else:
-                n, lo, hi = self.nj, self._nbr(0, -1), self._nbr(0, +1)
-            s = [self._ranges(p)[direction] for p in positions]
-            to_hi, to_lo = [n + h - w] * nf, [h + sf for sf in s]
-            lo_halo, hi_halo = [h - w] * nf, [h + n + sf for sf in s]
-            cnt = pack(to_hi, direction, None, 1)
-            key = (direction, cnt)
-            if key not in self._bufs:
-                self._bufs[key] = [torch.empty(cnt, dtype=torch.float64, device=fields[0].device) for _ in range(4)]
-            s_hi, s_lo, r_lo, r_hi = self._bufs[key]
+            d = plan["dirs"][direction]
+            lo, hi, a0 = d["lo"], d["hi"], d["a0"]
+            s_hi, s_lo, r_lo, r_hi = d["bufs"]
+
+            def pack(which, buf, do_pack):
+                check(L.mom6hip_halo_pack(dg.handle, ptrs, pos, nks, a0[which], nf, direction, w, buf.data_ptr(), do_pack, None),
+                      "mom6hip_halo_pack")
             if hi is not None:
-                pack(to_hi, direction, s_hi, 1)
+                pack("to_hi", s_hi, 1)
             if lo is not None:
-                pack(to_lo, direction, s_lo, 1)
-            ops, keep = [], []
+                pack("to_lo", s_lo, 1)
+            ops, staged = [], []
 
             def snd(buf, nbr):
                 b = buf.cpu() if stage else buf
-                keep.append(b); ops.append(dist.P2POp(dist.isend, b, nbr, group=self.group))
+                staged.append(b); ops.append(dist.P2POp(dist.isend, b, nbr, group=self.group))
 
             def rcv(buf, nbr):
                 b = torch.empty(buf.shape, dtype=buf.dtype) if stage else buf
-                keep.append((b, buf)); ops.append(dist.P2POp(dist.irecv, b, nbr, group=self.group))
+                staged.append((b, buf)); ops.append(dist.P2POp(dist.irecv, b, nbr, group=self.group))
 
             # posting order as in pass_var: [send->hi, recv<-lo, send->lo, recv<-hi]
             if hi is not None: snd(s_hi, hi)
@@ -221,13 +233,13 @@ class Domain:
                 for r in dist.batch_isend_irecv(ops):
                     r.wait()
                 if stage:
-                    for item in keep:
+                    for item in staged:
                         if isinstance(item, tuple):
                             item[1].copy_(item[0])
             if lo is not None:
-                pack(lo_halo, direction, r_lo, 0)
+                pack("lo_halo", r_lo, 0)
             if hi is not None:
-                pack(hi_halo, direction, r_hi, 0)
+                pack("hi_halo", r_hi, 0)
 
         did_local = False
         if self.npi == 1:

@@ -24,6 +24,7 @@ class DeviceGrid:
         L = lib()
         check(L.mom6hip_init(int(device)), "mom6hip_init")
         self.grid = grid
+        self.stream = stream
         self._h = C.c_void_p()
         check(L.mom6hip_grid_create(C.byref(grid.struct()), C.c_void_p(stream or 0), C.byref(self._h)),
               "mom6hip_grid_create")
@@ -67,21 +68,13 @@ class DeviceGrid:
         SUM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int32)
         grid = self.grid
 
-        class _DevArray:      # a device array described to torch through __cuda_array_interface__
-            def __init__(self, ptr, shape):
-                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
-                                                 "version": 2, "strides": None}
-
         def halo(user, fields, pos, nk, n):
             try:
-                ts, ps = [], []
-                for f in range(n):
-                    shp = grid.shape2(pos[f]) if nk[f] == 1 else grid.shape3(pos[f], nk[f])
-                    ts.append(torch.as_tensor(_DevArray(fields[f], shp), device="cuda")); ps.append(int(pos[f]))
-                domain.pass_var(ts, ps)
-                torch.cuda.synchronize()
+                # device pointers go straight to the packed exchange (one message per neighbour and direction), in stream
+                # order on the current stream
+                domain.pass_ptrs([int(fields[f] or 0) for f in range(n)], [int(pos[f]) for f in range(n)], [int(nk[f]) for f in range(n)])
                 return 0
-            except Exception as e:      # never let an exception cross the C boundary
+            except Exception:      # never let an exception cross the C boundary
                 import traceback; traceback.print_exc()
                 return 1
 
@@ -125,6 +118,15 @@ class DeviceGrid:
                                                  C.cast(self._cb[1], C.c_void_p), None), "mom6hip_set_domain_callbacks")
         self.domain = domain
         domain._dg = self
+        import torch.distributed as dist
+        # torch.distributed's RCCL ops wait for the current stream, which is the stream the library launches on (the
+        # null stream); the gloo rehearsal stages through the host with blocking copies.  No host synchronisation needed.
+        ordered = self._stream_is_current()
+        check(lib().mom6hip_set_callback_stream_ordered(self.handle, int(ordered)), "mom6hip_set_callback_stream_ordered")
+
+    def _stream_is_current(self):
+        import torch
+        return self.stream in (None, 0) and torch.cuda.current_stream().cuda_stream == 0
 
     def close(self):
         if self._h:
