@@ -447,9 +447,14 @@ int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const doub
  * Optional / pointer arguments are NULL when absent: BT_cont, eta_PF_start, taux_bot + tauy_bot,
  * uh0 + vh0 + u_uh0 + v_vh0, etaav.  OBC must not be associated (SpV_avg, ADp are not read).
  * eta_out may be the same array as eta_in.
+ * On a one-tile domain the barotropic subcycle is captured as a hipGraph (cached in the context, keyed on pointers,
+ * ranges and weights) and replayed with one launch; MOM6HIP_BT_GRAPH=0 in the environment disables that.
  * The one transcendental of the routine, bt_rem = av_rem ** (1/nstep) (:1529), is evaluated with a correctly
  * rounded pow; the reference's is the libm pow of its build (DESIGN.md "btstep").
  */
+/* How often btstep captured its subcycle as a hipGraph and how often it replayed one (one-tile domains). */
+int mom6hip_bt_graph_stats(mom6hip_ctx_t *ctx, int64_t *captures, int64_t *launches);
+
 int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *U_in, const double *V_in,
                    const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v,
                    const double *taux, const double *tauy, double RZ_to_H, const double *pbce,

@@ -18,7 +18,7 @@ EXPORTS = (
     "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
     "mom6hip_barotropic_init", "mom6hip_btcalc", "mom6hip_bt_mass_source", "mom6hip_set_dtbt", "mom6hip_btstep",
     "mom6hip_dyn_split_rk2_init", "mom6hip_step_dyn_split_rk2",
-    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered",
+    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats",
 )
 
 
@@ -63,6 +63,7 @@ def lib():
                                                 + [C.c_int64, C.c_int32, C.c_double, C.c_int32])
         L.mom6hip_set_domain_callbacks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mom6hip_kernel_timing.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.mom6hip_bt_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.mom6hip_set_callback_stream_ordered.argtypes = [C.c_void_p, C.c_int32]
         L.mom6hip_set_min_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mom6hip_halo_pack.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -16,6 +16,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <string>
 #include <cmath>
 #include <cstdlib>
 #include <initializer_list>
@@ -944,31 +945,75 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   M6_HIP(hipGetLastError());
 
   // ---- the barotropic time steps :1812-2462
-  int isv = is, iev = ie, jsv = js, jev = je;
-  for (int n = 1; n <= nt; n++) {
-    if ((iev - stencil < ie) || (jev - stencil < je)) {
-      if (int rc = pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}})) return rc;
-      isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
-    } else {
-      isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
-    }
-    const double wt_end = n * p.Instep;
-    hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, s, g, w, p, isv - 1, iev + 1,
-                       jsv - 1, jev + 1, wt_accel2[n]);
-    const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;
-    for (int ps = 0; ps < 2; ps++) {
-      const bool do_v = (ps == 0) ? v_first : !v_first;
-      if (do_v) {
-        const int i0 = v_first ? isv - 1 : isv, i1 = v_first ? iev + 1 : iev;
-        hipLaunchKernelGGL(bt_vbt_kernel, grid2d(i0, i1, jsv - 1, jev), dim3(64, 4), 0, s, g, w, p, i0, i1, jsv - 1, jev, wt_accel[n],
-                           wt_trans[n], wt_end, c.vbtav, dvhbtav);
+  // One tile: the whole subcycle (4 kernels per barotropic step + the wrap kernels of the group pass every num_cycles
+  // steps; ~100-250 nodes) is captured once as a hipGraph and replayed as a single launch; the graph is keyed on
+  // everything that is baked into its nodes (pointers, ranges, weights) and cached in the context.  With neighbours
+  // the group pass crosses the host (domain callback), so the loop is enqueued kernel by kernel.
+  auto run_loop = [&](hipStream_t st) -> int {
+    int isv = is, iev = ie, jsv = js, jev = je;
+    for (int n = 1; n <= nt; n++) {
+      if ((iev - stencil < ie) || (jev - stencil < je)) {
+        if (int rc = pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}})) return rc;
+        isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
       } else {
-        const int j0 = v_first ? jsv : jsv - 1, j1 = v_first ? jev : jev + 1;
-        hipLaunchKernelGGL(bt_ubt_kernel, grid2d(isv - 1, iev, j0, j1), dim3(64, 4), 0, s, g, w, p, isv - 1, iev, j0, j1, wt_accel[n],
-                           wt_trans[n], wt_end, c.ubtav, duhbtav);
+        isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
       }
+      const double wt_end = n * p.Instep;
+      hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev + 1,
+                         jsv - 1, jev + 1, wt_accel2[n]);
+      const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;
+      for (int ps = 0; ps < 2; ps++) {
+        const bool do_v = (ps == 0) ? v_first : !v_first;
+        if (do_v) {
+          const int i0 = v_first ? isv - 1 : isv, i1 = v_first ? iev + 1 : iev;
+          hipLaunchKernelGGL(bt_vbt_kernel, grid2d(i0, i1, jsv - 1, jev), dim3(64, 4), 0, st, g, w, p, i0, i1, jsv - 1, jev, wt_accel[n],
+                             wt_trans[n], wt_end, c.vbtav, dvhbtav);
+        } else {
+          const int j0 = v_first ? jsv : jsv - 1, j1 = v_first ? jev : jev + 1;
+          hipLaunchKernelGGL(bt_ubt_kernel, grid2d(isv - 1, iev, j0, j1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev, j0, j1, wt_accel[n],
+                             wt_trans[n], wt_end, c.ubtav, duhbtav);
+        }
+      }
+      hipLaunchKernelGGL(bt_eta_kernel, grid2d(isv, iev, jsv, jev), dim3(64, 4), 0, st, g, w, p, isv, iev, jsv, jev, wt_eta[n]);
     }
-    hipLaunchKernelGGL(bt_eta_kernel, grid2d(isv, iev, jsv, jev), dim3(64, 4), 0, s, g, w, p, isv, iev, jsv, jev, wt_eta[n]);
+    return 0;
+  };
+  static const bool graph_off = getenv("MOM6HIP_BT_GRAPH") && atoi(getenv("MOM6HIP_BT_GRAPH")) == 0;
+  if (ctx->halo_cb || graph_off) {
+    if (int rc = run_loop(s)) return rc;
+  } else {
+    std::string key;
+    auto add = [&](const void *q, size_t nbytes) { key.append((const char *)q, nbytes); };
+    add(&w, sizeof(w)); add(&p, sizeof(p)); add(&nt, sizeof(nt)); add(&ctx->host.first_direction, sizeof(int32_t));
+    add(&c.ubtav, sizeof(double *)); add(&c.vbtav, sizeof(double *)); add(&duhbtav, sizeof(double *)); add(&dvhbtav, sizeof(double *));
+    add(wt_vel.data(), sizeof(double) * wt_vel.size()); add(wt_eta.data(), sizeof(double) * wt_eta.size());
+    add(wt_trans.data(), sizeof(double) * wt_trans.size()); add(wt_accel.data(), sizeof(double) * wt_accel.size());
+    add(wt_accel2.data(), sizeof(double) * wt_accel2.size());
+    hipGraphExec_t exec = nullptr;
+    for (auto &e : ctx->bt_graphs) if (e.first == key) { exec = (hipGraphExec_t)e.second; break; }
+    if (!exec) {
+      if (!ctx->cap_stream) M6_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+      hipStream_t saved = ctx->stream;
+      ctx->stream = ctx->cap_stream;      // the wrap kernels of the group pass launch on the context's stream
+      hipError_t e0 = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed);
+      int rc = (e0 == hipSuccess) ? run_loop(ctx->cap_stream) : 1;
+      hipGraph_t graph = nullptr;
+      hipError_t e1 = (e0 == hipSuccess) ? hipStreamEndCapture(ctx->cap_stream, &graph) : e0;
+      ctx->stream = saved;
+      M6_REQUIRE(rc == 0 && e1 == hipSuccess && graph, "btstep: capturing the barotropic subcycle as a hipGraph failed (%s)",
+                 hipGetErrorString(e1));
+      hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      M6_REQUIRE(e2 == hipSuccess && exec, "btstep: hipGraphInstantiate failed (%s)", hipGetErrorString(e2));
+      if (ctx->bt_graphs.size() >= 8) {      // drop the oldest
+        (void)hipGraphExecDestroy((hipGraphExec_t)ctx->bt_graphs.front().second);
+        ctx->bt_graphs.erase(ctx->bt_graphs.begin());
+      }
+      ctx->bt_graphs.push_back({key, (void *)exec});
+      ctx->bt_graph_captures++;
+    }
+    M6_HIP(hipGraphLaunch(exec, s));
+    ctx->bt_graph_launches++;
   }
   M6_HIP(hipGetLastError());
 

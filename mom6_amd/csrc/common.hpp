@@ -90,6 +90,10 @@ struct mom6hip_ctx {
   m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   m6::DevBuf rk2_scratch;       // the automatic arrays of step_MOM_dyn_split_RK2
+  // hipGraphs of the barotropic subcycle, keyed on everything baked into their nodes (barotropic.hip)
+  std::vector<std::pair<std::string, void *>> bt_graphs;
+  hipStream_t cap_stream = nullptr;
+  long bt_graph_captures = 0, bt_graph_launches = 0;
   int *h_domore_k = nullptr;    // pinned host mirror of domore_k
   // multi-tile collectives provided by the host (null on a one-tile domain)
   mom6hip_halo_fn halo_cb = nullptr;

@@ -130,6 +130,13 @@ int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mo
   return 0;
 }
 
+int mom6hip_bt_graph_stats(mom6hip_ctx_t *ctx, int64_t *captures, int64_t *launches) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_bt_graph_stats: null context");
+  if (captures) *captures = ctx->bt_graph_captures;
+  if (launches) *launches = ctx->bt_graph_launches;
+  return 0;
+}
+
 int mom6hip_set_callback_stream_ordered(mom6hip_ctx_t *ctx, int32_t stream_ordered) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_set_callback_stream_ordered: null context");
   ctx->cb_stream_ordered = stream_ordered != 0;
@@ -266,6 +273,8 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->tr_stage) b.release();
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
+  for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);
+  if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
   delete ctx;
   return 0;

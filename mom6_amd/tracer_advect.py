@@ -46,6 +46,12 @@ class DeviceGrid:
         check(lib().mom6hip_advect_get_timing(self.handle, C.byref(t)), "mom6hip_advect_get_timing")
         return t
 
+    def bt_graph_stats(self):
+        """(captures, launches) of the hipGraph of btstep's subcycle (mom6hip_bt_graph_stats)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().mom6hip_bt_graph_stats(self.handle, C.byref(a), C.byref(b)), "mom6hip_bt_graph_stats")
+        return a.value, b.value
+
     def kernel_timing(self, enable):
         """(ms_total, launches) per timing slot since recording was switched on (mom6hip_kernel_timing)."""
         ms = (C.c_double * 2)(); n = (C.c_int64 * 2)()

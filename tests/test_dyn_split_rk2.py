@@ -101,4 +101,6 @@ def test_step_matches_oracle_bitwise(kw):
                            ("CAu_pred", CS.CAu_pred, ref.arrs["CAu_pred"])):
             an = a.cpu().numpy()
             assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+    cap, lau = dg.bt_graph_stats()      # one-tile domain: every btstep replays a hipGraph of its subcycle
+    assert lau == 6 and 1 <= cap <= 6, (cap, lau)
     dg.close()
