@@ -19,6 +19,7 @@
 #include <string>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <initializer_list>
 #include <utility>
 
@@ -769,6 +770,8 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
 
   // ---- open face areas :1136-1148
   const int hs = 1 + ievf - ie;
+  const bool early_btcl_pass = use_BT_cont && add_uh0 && cs->adjust_BT_cont;
+  std::function<void(int)> btcl_derive;
   if (use_BT_cont) {   // set_local_BT_cont_types :3949 (dt = 1)
     const Btcl BU = w.BU, BV = w.BV;
     const double *a0 = bcU[0], *a1 = bcU[1], *a2 = bcU[2], *a3 = bcU[3], *a4 = bcU[4], *a5 = bcU[5];
@@ -781,22 +784,33 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       const long n = g.v2(i, J);
       BV.FA_EE[n] = b0[n]; BV.FA_E0[n] = b1[n]; BV.FA_W0[n] = b2[n]; BV.FA_WW[n] = b3[n]; BV.uBT_EE[n] = b4[n]; BV.uBT_WW[n] = b5[n];
     });
-    if (int rc = pass({{BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PU}, {BV.FA_EE, PV},
-                       {BU.FA_E0, PU}, {BV.FA_E0, PV}, {BU.FA_W0, PU}, {BV.FA_W0, PV}, {BU.FA_WW, PU}, {BV.FA_WW, PV}})) return rc;
-    for (int dir = 0; dir < 2; dir++) {
-      const Btcl B = dir ? BV : BU;
-      launch2d(s, (dir ? is : is - 1) - hs, ie + hs, (dir ? js - 1 : js) - hs, je + hs, [=] __device__(int i, int j) {
-        const long n = dir ? g.v2(i, j) : g.u2(i, j);
-        const double C1_3 = 1.0 / 3.0;
-        const double ee = 1.0 * B.uBT_EE[n], ww = 1.0 * B.uBT_WW[n];
-        B.uBT_EE[n] = ee; B.uBT_WW[n] = ww;
-        B.uh_EE[n] = ee * (C1_3 * (2.0 * B.FA_E0[n] + B.FA_EE[n]));
-        B.uh_WW[n] = ww * (C1_3 * (2.0 * B.FA_W0[n] + B.FA_WW[n]));
-        double cw = 0.0, ce = 0.0;
-        if (fabs(ww) > 0.0) cw = (C1_3 * (B.FA_WW[n] - B.FA_W0[n])) / (ww * ww);
-        if (fabs(ee) > 0.0) ce = (C1_3 * (B.FA_EE[n] - B.FA_E0[n])) / (ee * ee);
-        B.uh_crvW[n] = cw; B.uh_crvE[n] = ce;
-      });
+    // The halo pass of the six raw arrays per direction is merged with pass_gtot below (one message instead of two):
+    // only the compute-range fits are needed until then (uhbt0), and the derived values are pure functions of the raw
+    // ones, so they are evaluated on the compute range now and on the widened range after the pass.  With
+    // ADJUST_BT_CONT the fits are modified on the widened range before uhbt0, so the reference's order is kept.
+    btcl_derive = [=](int hs_) {
+      for (int dir = 0; dir < 2; dir++) {
+        const Btcl B = dir ? BV : BU;
+        launch2d(s, (dir ? is : is - 1) - hs_, ie + hs_, (dir ? js - 1 : js) - hs_, je + hs_, [=] __device__(int i, int j) {
+          const long n = dir ? g.v2(i, j) : g.u2(i, j);
+          const double C1_3 = 1.0 / 3.0;
+          const double ee = 1.0 * B.uBT_EE[n], ww = 1.0 * B.uBT_WW[n];
+          B.uBT_EE[n] = ee; B.uBT_WW[n] = ww;
+          B.uh_EE[n] = ee * (C1_3 * (2.0 * B.FA_E0[n] + B.FA_EE[n]));
+          B.uh_WW[n] = ww * (C1_3 * (2.0 * B.FA_W0[n] + B.FA_WW[n]));
+          double cw = 0.0, ce = 0.0;
+          if (fabs(ww) > 0.0) cw = (C1_3 * (B.FA_WW[n] - B.FA_W0[n])) / (ww * ww);
+          if (fabs(ee) > 0.0) ce = (C1_3 * (B.FA_EE[n] - B.FA_E0[n])) / (ee * ee);
+          B.uh_crvW[n] = cw; B.uh_crvE[n] = ce;
+        });
+      }
+    };
+    if (early_btcl_pass) {
+      if (int rc = pass({{BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PU}, {BV.FA_EE, PV},
+                         {BU.FA_E0, PU}, {BV.FA_E0, PV}, {BU.FA_W0, PU}, {BV.FA_W0, PV}, {BU.FA_WW, PU}, {BV.FA_WW, PV}})) return rc;
+      btcl_derive(hs);
+    } else {
+      btcl_derive(0);
     }
   } else {   // find_face_areas :4297-4310, halo 1
     const double Z_to_H = g.Z_to_H, Zr = cs->Z_ref;
@@ -899,7 +913,15 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   }
 
   // ---- pass_gtot, pass_ubt_Cor :1460-1476 ; Cor_ref :1478-1490
-  if (int rc = pass({{w.gtot_E, PH}, {w.gtot_N, PH}, {w.gtot_W, PH}, {w.gtot_S, PH}, {w.ubt_Cor, PU}, {w.vbt_Cor, PV}})) return rc;
+  if (use_BT_cont && !early_btcl_pass) {
+    const Btcl BU = w.BU, BV = w.BV;
+    if (int rc = pass({{w.gtot_E, PH}, {w.gtot_N, PH}, {w.gtot_W, PH}, {w.gtot_S, PH}, {w.ubt_Cor, PU}, {w.vbt_Cor, PV},
+                       {BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PU}, {BV.FA_EE, PV},
+                       {BU.FA_E0, PU}, {BV.FA_E0, PV}, {BU.FA_W0, PU}, {BV.FA_W0, PV}, {BU.FA_WW, PU}, {BV.FA_WW, PV}})) return rc;
+    btcl_derive(hs);
+  } else {
+    if (int rc = pass({{w.gtot_E, PH}, {w.gtot_N, PH}, {w.gtot_W, PH}, {w.gtot_S, PH}, {w.ubt_Cor, PU}, {w.vbt_Cor, PV}})) return rc;
+  }
   launch2d(s, is - 1, ie, js, je, [=] __device__(int i, int j) {
     const long n = g.u2(i, j);
     w.Cor_ref_u[n] = ((w.azon[n] * w.vbt_Cor[g.v2(i + 1, j)] + w.czon[n] * w.vbt_Cor[g.v2(i, j - 1)]) +
@@ -1029,9 +1051,9 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       if (find_etaav) detaav[n] = w.eta_sum[n] * 1.0;
       deta_out[n] = w.eta_wtd[n] * 1.0;
     });
-    if (find_etaav) { if (int rc = pass({{detaav, PH}, {w.e_anom, PH}})) return rc; }
-    else { if (int rc = pass({{w.e_anom, PH}})) return rc; }
-    if (int rc = pass({{c.ubtav, PU}, {c.vbtav, PV}, {duhbtav, PU}, {dvhbtav, PV}})) return rc;
+    // pass_etaav, pass_e_anom and pass_ubta_uhbta (:2527-2570) as one group
+    if (find_etaav) { if (int rc = pass({{detaav, PH}, {w.e_anom, PH}, {c.ubtav, PU}, {c.vbtav, PV}, {duhbtav, PU}, {dvhbtav, PV}})) return rc; }
+    else { if (int rc = pass({{w.e_anom, PH}, {c.ubtav, PU}, {c.vbtav, PV}, {duhbtav, PU}, {dvhbtav, PV}})) return rc; }
     hipLaunchKernelGGL(bt_accel_layer_kernel<0>, grid2d(is - 1, ie, js, je), dim3(64, 4), 0, s, g, w, dpb, dalu, accel_underflow);
     hipLaunchKernelGGL(bt_accel_layer_kernel<1>, grid2d(is, ie, js - 1, je), dim3(64, 4), 0, s, g, w, dpb, dalv, accel_underflow);
   }
