@@ -165,19 +165,25 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
 
   // u_bc_accel = (CAu_pred + PFu) + diffu ; up = mask*(u + dt*u_bc_accel)   :557-564, :582-589
+  // Without viscosity hooks diffu = diffv = +0.0 everywhere (set by dyn_split_rk2_init): (a + 0.0) is a, except that
+  // -0.0 + 0.0 = +0.0, so the array need not be read; and the first up, vp (:582-589) are only read by vertvisc_coef.
+  const bool inviscid = (hk == nullptr);
   auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
     const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
+    const bool need_up = first_up && !inviscid;
     launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
       const long n = g.u3(I, j, k);
-      const double a = (CAu[n] + PFu[n]) + diffu[n];
+      double a = (CAu[n] + PFu[n]);
+      if (inviscid) a = (a == 0.0) ? 0.0 : a; else a = a + diffu[n];
       u_bc[n] = a;
-      if (first_up) up[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt * a);
+      if (need_up) up[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt * a);
     });
     launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
       const long n = g.v3(i, J, k);
-      const double a = (CAv[n] + PFv[n]) + diffv[n];
+      double a = (CAv[n] + PFv[n]);
+      if (inviscid) a = (a == 0.0) ? 0.0 : a; else a = a + diffv[n];
       v_bc[n] = a;
-      if (first_up) vp[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt * a);
+      if (need_up) vp[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt * a);
     });
   };
   bc_accel(cs->CAu_pred, cs->CAv_pred, true);
