@@ -627,6 +627,500 @@ __global__ __launch_bounds__(64) void ale_set_h_vel_kernel(m6::GridDev g, const 
   if (i >= g.isc && g.mask2dCv[g.v2(i, j)] > 0.) h_v[g.v3(i, j, k)] = 0.5 * (h[g.h3(i, j, k)] + h[g.h3(i, j + 1, k)]);
 }
 
+// ======================================================================================================================
+// Wave-cooperative remapping: one 64-lane wave per column, every per-column array in LDS.
+// The lane-per-column kernels above keep ~12 KB of per-lane arrays in scratch and are bound by that traffic (96 GB per
+// 4-tracer call on the 1/4-degree grid).  Here the work is split by its shape:
+//   ale_sub_cells_kernel   lane per column: the merge of the old and new grids into sub-cells (build_sub_cells) is a
+//                          serial walk with no arrays of its own; it reads h_old / h_new and writes the structure
+//                          (h_sub, h0_eff, the end / thickest sub-cell of every source cell, the end of every target
+//                          cell) to a global buffer laid out in tiles of WR_NCOL columns.
+//   ale_remap_wave_kernel  a block of WR_NCOL waves owns WR_NCOL consecutive columns: it loads their structure tile
+//                          and layers with contiguous rows into LDS, then each wave works on its own column with the
+//                          arithmetic of the functions above, unchanged -- the k loops of the reconstructions run across
+//                          the lanes (they are stencils), and the three passes of remap_via_sub_cells that sum over
+//                          sub-cells run one lane per source / target cell, each lane adding its few sub-cells in the
+//                          reference's order.  Results are bit-identical to the serial form.
+// ======================================================================================================================
+constexpr int WR_NCOL = 8;
+
+// Structure tile of WR_NCOL columns in global memory: rows of WR_NCOL entries.
+//   doubles: h_sub[0 .. 2nz+1], h0_eff[0 .. nz]           shorts: isrc_end[0 .. nz], isrc_max[0 .. nz], itgt_end[0 .. nz], last_thick
+// (1-based rows as in the reference; itgt_end(i1) is stored negated where h1(i1) <= 0.)
+__host__ __device__ inline int sub_drows(int nz) { return (2 * nz + 2) + (nz + 1); }
+__host__ __device__ inline int sub_srows(int nz) { return 3 * (nz + 1) + 1; }
+__host__ __device__ inline size_t sub_tile_bytes(int nz) { return (size_t)sub_drows(nz) * WR_NCOL * 8 + (size_t)sub_srows(nz) * WR_NCOL * 2; }
+
+struct SubArgs {
+  m6::GridDev g;
+  const double *h_old, *h_new;
+  char *sub;        // structure tiles
+  int pos, nbx;     // staggering; tiles per row
+};
+
+// build_sub_cells (MOM_remapping.F90:519-651), one lane per column, 1-based indices kept
+__global__ __launch_bounds__(64) void ale_sub_cells_kernel(SubArgs a) {
+  const m6::GridDev &g = a.g;
+  const int nz = g.nk, n0 = nz, n1 = nz;
+  const int xs = (a.pos == MOM6HIP_POS_U) ? 1 : 0, ys = (a.pos == MOM6HIP_POS_V) ? 1 : 0;
+  const int ci = blockIdx.x * 64 + threadIdx.x;      // column within the row of the compute range
+  const int i = g.isc - xs + ci, j = g.jsc - ys + blockIdx.y;
+  if (i > g.iec) return;
+  const long n2 = a.pos == MOM6HIP_POS_U ? g.u2(i, j) : (a.pos == MOM6HIP_POS_V ? g.v2(i, j) : g.h2(i, j));
+  const double msk = a.pos == MOM6HIP_POS_U ? g.mask2dCu[n2] : (a.pos == MOM6HIP_POS_V ? g.mask2dCv[n2] : g.mask2dT[n2]);
+  if (!(msk > 0.)) return;
+  const long stride = (long)(g.nih + xs) * (g.njh + ys);
+  const double *h0 = a.h_old + n2, *h1 = a.h_new + n2;
+  char *tile = a.sub + sub_tile_bytes(nz) * ((size_t)blockIdx.y * a.nbx + ci / WR_NCOL);
+  const int cc = ci % WR_NCOL;
+  double *h_sub = (double *)tile + cc, *h0_eff = h_sub + (size_t)(2 * nz + 2) * WR_NCOL;
+  short *isrc_end = (short *)((double *)tile + (size_t)sub_drows(nz) * WR_NCOL) + cc;
+  short *isrc_max = isrc_end + (nz + 1) * WR_NCOL, *itgt_end = isrc_max + (nz + 1) * WR_NCOL, *meta = itgt_end + (nz + 1) * WR_NCOL;
+
+  int i0_last_thick_cell = 0;
+  for (int i0 = 1; i0 <= n0; i0++) if (h0[(i0 - 1) * stride] > 0.) i0_last_thick_cell = i0;
+  meta[0] = (short)i0_last_thick_cell;
+  double h0_supply = h0[0], h1_supply = h1[0];
+  double h1_cur = h1_supply;      // h1 of the open target cell
+  bool src_has_volume = true, tgt_has_volume = true;
+  int i0 = 1, i1 = 1, i_max = 1;
+  double dh_max = 0., dh0_eff = 0.;
+  h_sub[1 * WR_NCOL] = 0.;
+  const int ns = n0 + n1 + 1;
+  for (int i_sub = 2; i_sub <= ns; i_sub++) {
+    const double dh = fmin(h0_supply, h1_supply);
+    dh0_eff = dh0_eff + fmin(dh, h0_supply);
+    double hs = dh;
+    if (dh >= dh_max) { i_max = i_sub; dh_max = dh; }
+    bool end_src = false, end_tgt = false;
+    if (h0_supply <= h1_supply && src_has_volume) {
+      h1_supply = h1_supply - dh;
+      end_src = true;
+    } else if (h0_supply >= h1_supply && tgt_has_volume) {
+      h0_supply = h0_supply - dh;
+      end_tgt = true;
+    } else if (src_has_volume) {
+      hs = h0_supply;
+      end_src = true;
+    } else if (tgt_has_volume) {
+      hs = h1_supply;
+      end_tgt = true;
+    }
+    h_sub[(size_t)i_sub * WR_NCOL] = hs;
+    if (end_src) {
+      isrc_end[i0 * WR_NCOL] = (short)i_sub;
+      isrc_max[i0 * WR_NCOL] = (short)i_max; i_max = i_sub + 1; dh_max = 0.;
+      h0_eff[(size_t)i0 * WR_NCOL] = dh0_eff;
+      if (i0 < n0) { i0 = i0 + 1; h0_supply = h0[(i0 - 1) * stride]; dh0_eff = 0.; }
+      else { h0_supply = 0.; src_has_volume = false; }
+    } else if (end_tgt) {
+      itgt_end[i1 * WR_NCOL] = (short)((h1_cur > 0.) ? i_sub : -i_sub);
+      if (i1 < n1) { i1 = i1 + 1; h1_supply = h1[(i1 - 1) * stride]; h1_cur = h1_supply; }
+      else { h1_supply = 0.; tgt_has_volume = false; }
+    }
+  }
+}
+
+struct WCol {   // LDS arrays of one column (doubles first, then shorts); the first block mirrors the structure tile's rows
+  double *h_sub, *h0_eff, *h0, *u0, *EL, *ER, *C1, *u_sub, *uh_sub;
+  short *isrc_end, *isrc_max, *itgt_end;   // (+ last_thick at itgt_end[nz + 1])
+};
+__host__ __device__ inline size_t wcol_doubles(int nz) { return (size_t)sub_drows(nz) + 5 * nz + 2 * (2 * nz + 2); }
+__host__ __device__ inline size_t wcol_bytes(int nz) { return (wcol_doubles(nz) * 8 + (size_t)sub_srows(nz) * 2 + 7) / 8 * 8; }
+__device__ inline WCol wcol_at(char *base, int nz) {
+  WCol c;
+  double *d = (double *)base;
+  c.h_sub = d; d += 2 * nz + 2; c.h0_eff = d; d += nz + 1;
+  c.h0 = d; d += nz; c.u0 = d; d += nz; c.EL = d; d += nz; c.ER = d; d += nz; c.C1 = d; d += nz;
+  c.u_sub = d; d += 2 * nz + 2; c.uh_sub = d; d += 2 * nz + 2;
+  short *sh = (short *)d;
+  c.isrc_end = sh; sh += nz + 1; c.isrc_max = sh; sh += nz + 1; c.itgt_end = sh;
+  return c;
+}
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// build_reconstructions_1d across the lanes; returns the integration method (uniform over the wave).
+// Of ppoly_coef only the slope column is stored: coef(:,1) always equals the left edge value, and coef(:,3) is only read
+// by the PPM boundary extrapolation, which recomputes it from the final edges with the expression that defined it.
+__device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool extrap, int n, double h_neglect, double h_neglect_edge) {
+  const double *h = c.h0, *u = c.u0;
+  double *EL = c.EL, *ER = c.ER;
+  int local = scheme;
+  if (n <= 1) local = REMAP_PCM;
+  else if (n <= 3) local = (local < REMAP_PLM) ? local : REMAP_PLM;
+  else if (n <= 4) local = (local < REMAP_PPM_H4) ? local : REMAP_PPM_H4;
+  if (local == REMAP_PCM) {
+    for (int k = lane; k < n; k += 64) { EL[k] = u[k]; ER[k] = u[k]; c.C1[k] = 0.; }
+    wsync();
+    return INT_PCM;
+  }
+  if (local == REMAP_PLM) {      // PLM_reconstruction :190-260
+    const double almost_one = 1. - DBL_EPSILON;
+    double *slp = c.u_sub, *mslp = c.uh_sub;      // free until the sub-cell pass
+    for (int k = lane; k < n; k += 64)
+      slp[k] = (k >= 1 && k < n - 1) ? plm_slope_wa(h[k - 1], h[k], h[k + 1], h_neglect, u[k - 1], u[k], u[k + 1]) : 0.;
+    wsync();
+    for (int k = lane; k < n; k += 64)
+      mslp[k] = (k >= 1 && k < n - 1) ? plm_monotonized_slope(u[k - 1], u[k], u[k + 1], slp[k - 1], slp[k], slp[k + 1]) : 0.;
+    wsync();
+    for (int k = lane; k < n; k += 64) {
+      if (k >= 1 && k < n - 1) {
+        const double slope = mslp[k];
+        const double u_l = u[k] - 0.5 * slope;
+        const double u_r = u[k] + 0.5 * slope;
+        EL[k] = u_l; ER[k] = u_r;
+        double c1 = (u_r - u_l);
+        const double edge = c1 + u_l;
+        const double e_r = u[k + 1] - 0.5 * fsign(mslp[k + 1], slp[k + 1]);
+        if ((edge - u[k]) * (e_r - edge) < 0.) c1 = c1 * almost_one;
+        c.C1[k] = c1;
+      } else {
+        EL[k] = u[k]; ER[k] = u[k]; c.C1[k] = 0.;
+      }
+    }
+    wsync();
+    if (extrap && lane == 0) {      // PLM_boundary_extrapolation :272-307
+      double slope = -plm_extrapolate_slope(h[1], h[0], h_neglect, u[1], u[0]);
+      EL[0] = u[0] - 0.5 * slope; ER[0] = u[0] + 0.5 * slope;
+      c.C1[0] = ER[0] - EL[0];
+      slope = plm_extrapolate_slope(h[n - 2], h[n - 1], h_neglect, u[n - 2], u[n - 1]);
+      EL[n - 1] = u[n - 1] - 0.5 * slope; ER[n - 1] = u[n - 1] + 0.5 * slope;
+      c.C1[n - 1] = ER[n - 1] - EL[n - 1];
+    }
+    wsync();
+    return INT_PLM;
+  }
+  // ---- PPM_H4: edge_values_explicit_h4 :222-363
+  {
+    const double hMinFrac = 1.e-5, hNeglect = h_neglect_edge;
+    for (int i = lane + 2; i <= n - 2; i += 64) {
+      double h0 = h[i - 2], h1 = h[i - 1], h2 = h[i], h3 = h[i + 1];
+      if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
+        const double h_min = hMinFrac * fmax(hNeglect, (h0 + h1) + (h2 + h3));
+        h0 = fmax(h_min, h[i - 2]); h1 = fmax(h_min, h[i - 1]); h2 = fmax(h_min, h[i]); h3 = fmax(h_min, h[i + 1]);
+      }
+      const double I_h12 = 1.0 / (h1 + h2);
+      const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)); const double I_h012 = (h0 + h1) * I_den_et2;
+      const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)); const double I_h123 = (h2 + h3) * I_den_et3;
+      const double et1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3)) * u[i - 1] +
+                         (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1)) * u[i];
+      const double et2 = (h1 * (h2 * (h2 + h3)) * I_den_et2) * (u[i - 1] - u[i - 2]);
+      const double et3 = (h2 * (h1 * (h0 + h1)) * I_den_et3) * (u[i] - u[i + 1]);
+      const double ev = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
+      EL[i] = ev; ER[i - 1] = ev;
+    }
+    if (lane == 62) {      // (the end values on lanes that have no second interior edge to do)
+      double dz[4], ut[4], Cs[4];
+      for (int i = 0; i < 4; i++) { dz[i] = fmax(hNeglect, h[i]); ut[i] = u[i]; }
+      end_value_h4(dz, ut, Cs);
+      EL[0] = Cs[0];
+      ER[0] = Cs[0] + dz[0] * (Cs[1] + dz[0] * (Cs[2] + dz[0] * Cs[3]));
+      EL[1] = ER[0];
+    } else if (lane == 63) {
+      double dz[4], ut[4], Cs[4];
+      for (int i = 0; i < 4; i++) { dz[i] = fmax(hNeglect, h[n - 1 - i]); ut[i] = u[n - 1 - i]; }
+      end_value_h4(dz, ut, Cs);
+      ER[n - 1] = Cs[0];
+      EL[n - 1] = Cs[0] + dz[0] * (Cs[1] + dz[0] * (Cs[2] + dz[0] * Cs[3]));
+      ER[n - 2] = EL[n - 1];
+    }
+    wsync();
+  }
+  // ---- PPM_reconstruction: bound_edge_values, check_discontinuous_edge_values, PPM_limiter_standard
+  for (int k = lane; k < n; k += 64) {
+    const int km1 = (k - 1 > 0) ? k - 1 : 0, kp1 = (k + 1 < n - 1) ? k + 1 : n - 1;
+    double slope_x_h = 0.0;
+    if (((h[km1] + h[kp1]) + 2.0 * h[k]) > 0.0) {
+      const double sigma_l = (u[k] - u[km1]);
+      const double sigma_c = (u[kp1] - u[km1]) * (h[k] / ((h[km1] + h[kp1]) + 2.0 * h[k]));
+      const double sigma_r = (u[kp1] - u[k]);
+      if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(min3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+    }
+    double el = EL[k], er = ER[k];
+    if ((u[km1] - el) * (el - u[k]) < 0.0) el = u[k] - fsign(fmin(fabs(slope_x_h), fabs(el - u[k])), slope_x_h);
+    if ((u[kp1] - er) * (er - u[k]) < 0.0) er = u[k] + fsign(fmin(fabs(slope_x_h), fabs(er - u[k])), slope_x_h);
+    el = fmax(fmin(el, fmax(u[km1], u[k])), fmin(u[km1], u[k]));
+    er = fmax(fmin(er, fmax(u[kp1], u[k])), fmin(u[kp1], u[k]));
+    EL[k] = el; ER[k] = er;
+  }
+  wsync();
+  for (int k = lane; k < n - 1; k += 64) {
+    if ((EL[k + 1] - ER[k]) * (u[k + 1] - u[k]) < 0.0) {
+      double u0_avg = 0.5 * (ER[k] + EL[k + 1]);
+      u0_avg = fmax(fmin(u0_avg, fmax(u[k], u[k + 1])), fmin(u[k], u[k + 1]));
+      ER[k] = u0_avg; EL[k + 1] = u0_avg;
+    }
+  }
+  wsync();
+  for (int k = lane; k < n; k += 64) {
+    double edge_l, edge_r;
+    if (k >= 1 && k < n - 1) {
+      const double u_l = u[k - 1], u_c = u[k], u_r = u[k + 1];
+      edge_l = EL[k]; edge_r = ER[k];
+      if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
+        edge_l = u_c; edge_r = u_c;
+      } else {
+        const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
+        const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
+        if (expr1 > expr2) {
+          edge_l = u_c + 2.0 * (u_c - edge_r);
+          edge_l = fmax(fmin(edge_l, fmax(u_l, u_c)), fmin(u_l, u_c));
+        } else if (expr1 < -expr2) {
+          edge_r = u_c + 2.0 * (u_c - edge_l);
+          edge_r = fmax(fmin(edge_r, fmax(u_r, u_c)), fmin(u_r, u_c));
+        }
+      }
+      if (fabs(edge_r - edge_l) < fmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
+    } else {
+      edge_l = u[k]; edge_r = u[k];
+    }
+    EL[k] = edge_l; ER[k] = edge_r;
+    c.C1[k] = 4.0 * (u[k] - edge_l) + 2.0 * (u[k] - edge_r);
+  }
+  wsync();
+  if (extrap && lane == 0) {      // PPM_boundary_extrapolation, PPM_functions.F90:162-316
+    int i0 = 0, i1 = 1;
+    double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1];
+    double b = c.C1[i1];
+    double u1_r = b * ((h0 + h_neglect) / (h1 + h_neglect));
+    double slope = 2.0 * (u1 - u0);
+    if (fabs(u1_r) > fabs(slope)) u1_r = slope;
+    double u0_r = EL[i1];
+    double u0_l = 3.0 * u0 + 0.5 * u1_r - 2.0 * u0_r;
+    double exp1 = (u0_r - u0_l) * (u0 - 0.5 * (u0_l + u0_r));
+    double exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+    if (exp1 > exp2) u0_l = 3.0 * u0 - 2.0 * u0_r;
+    if (exp1 < -exp2) u0_r = 3.0 * u0 - 2.0 * u0_l;
+    EL[i0] = u0_l; ER[i0] = u0_r;
+    c.C1[i0] = 6.0 * u0 - 4.0 * u0_l - 2.0 * u0_r;
+    i0 = n - 2; i1 = n - 1;
+    h0 = h[i0]; h1 = h[i1]; u0 = u[i0]; u1 = u[i1];
+    b = c.C1[i0];
+    const double cc = 3.0 * ((ER[i0] - u[i0]) + (EL[i0] - u[i0]));      // ppoly_coef(i0,3)
+    double u1_l = (b + 2 * cc);
+    u1_l = u1_l * ((h1 + h_neglect) / (h0 + h_neglect));
+    slope = 2.0 * (u1 - u0);
+    if (fabs(u1_l) > fabs(slope)) u1_l = slope;
+    u0_l = ER[i0];
+    u0_r = 3.0 * u1 - 0.5 * u1_l - 2.0 * u0_l;
+    exp1 = (u0_r - u0_l) * (u1 - 0.5 * (u0_l + u0_r));
+    exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
+    if (exp1 > exp2) u0_l = 3.0 * u1 - 2.0 * u0_r;
+    if (exp1 < -exp2) u0_r = 3.0 * u1 - 2.0 * u0_l;
+    EL[i1] = u0_l; ER[i1] = u0_r;
+    c.C1[i1] = 6.0 * u1 - 4.0 * u0_l - 2.0 * u0_r;
+  }
+  wsync();
+  return INT_PPM;
+}
+
+// average_value_ppoly :998-1099 on the LDS column
+__device__ __forceinline__ double w_average_value_ppoly(const WCol &c, int method, int i0, double xa, double xb) {
+  if (xb > xa) {
+    if (method == INT_PCM) return c.u0[i0];
+    if (method == INT_PLM) return (c.EL[i0] + c.C1[i0] * 0.5 * (xb + xa));
+    const double mx = 0.5 * (xa + xb);
+    const double a_L = c.EL[i0], a_R = c.ER[i0], u_c = c.u0[i0];
+    const double a_c = 0.5 * ((u_c - a_L) + (u_c - a_R));
+    if (mx < 0.5) {
+      const double xa2b2ab = (xa * xa + xb * xb) + xa * xb;
+      return a_L + ((a_R - a_L) * mx + a_c * (3. * (xb + xa) - 2. * xa2b2ab));
+    } else {
+      const double Ya = 1. - xa, Yb = 1. - xb;
+      const double my = 0.5 * (Ya + Yb);
+      const double Ya2b2ab = (Ya * Ya + Yb * Yb) + Ya * Yb;
+      return a_R + ((a_L - a_R) * my + a_c * (3. * (Yb + Ya) - 2. * Ya2b2ab));
+    }
+  } else {
+    if (method == INT_PCM) return c.EL[i0];
+    const double a_L = c.EL[i0], a_R = c.ER[i0];
+    const double Ya = 1. - xa;
+    if (method == INT_PLM) {
+      if (xa < 0.5) return a_L + xa * (a_R - a_L);
+      return a_R + Ya * (a_L - a_R);
+    }
+    const double u_c = c.u0[i0];
+    const double a_c = 3. * ((u_c - a_L) + (u_c - a_R));
+    if (xa < 0.5) return a_L + xa * ((a_R - a_L) + a_c * Ya);
+    return a_R + Ya * ((a_L - a_R) + a_c * xa);
+  }
+}
+
+// The field-dependent part of remap_via_sub_cells :653-766; the result replaces u0.
+__device__ void w_integrate_sub_cells(const WCol &c, int lane, int n0, int n1, int method, double cu) {
+  const int ns = n0 + n1 + 1;
+  const int i0_last_thick_cell = c.itgt_end[n1 + 1];
+  // u_sub / uh_sub of the sub-cells 2 .. n0+n1: the running (xa, dh0_eff) restart with every source cell, so one lane
+  // walks the sub-cells of one source cell; the sub-cells after the source column has run out keep i0 = n0 and the
+  // running values, so the lane of the last source cell walks on to n0+n1.
+  for (int i0 = lane + 1; i0 <= n0; i0 += 64) {
+    int first = (i0 > 1) ? c.isrc_end[i0 - 1] + 1 : 2;
+    int last = (i0 == n0) ? n0 + n1 : c.isrc_end[i0];
+    double xa = 0., xb, dh0_eff = 0.;
+    const double h0e = c.h0_eff[i0];
+    for (int i_sub = first; i_sub <= last; i_sub++) {
+      const double dh = c.h_sub[i_sub];
+      dh0_eff = dh0_eff + dh;
+      double us;
+      if (h0e > 0.) {
+        xb = dh0_eff / h0e;
+        xb = fmin(1., xb);
+        us = w_average_value_ppoly(c, method, i0 - 1, xa, xb);
+      } else {
+        xb = 1.;
+        us = c.u0[i0 - 1];
+      }
+      c.u_sub[i_sub] = us;
+      c.uh_sub[i_sub] = dh * us;
+      xa = xb;
+    }
+  }
+  if (lane == 0) {
+    c.uh_sub[1] = 0.; c.u_sub[1] = c.EL[0];
+    c.u_sub[ns] = c.ER[n0 - 1];
+    c.uh_sub[ns] = c.ER[n0 - 1] * c.h_sub[ns];
+  }
+  wsync();
+  // the thickest sub-cell of every source cell with volume takes the remainder :700-718
+  for (int i0 = lane + 1; i0 <= i0_last_thick_cell; i0 += 64) {
+    const int i_max = c.isrc_max[i0];
+    const double dh_max = c.h_sub[i_max];
+    if (dh_max > 0.) {
+      double duh = 0.;
+      const int first = (i0 > 1) ? c.isrc_end[i0 - 1] + 1 : 1, last = c.isrc_end[i0];
+      for (int i_sub = first; i_sub <= last; i_sub++)
+        if (i_sub != i_max) duh = duh + c.uh_sub[i_sub];
+      c.uh_sub[i_max] = c.u0[i0 - 1] * c.h0[i0 - 1] - duh;
+    }
+  }
+  wsync();
+  // target cells :720-766; u0 is dead after the pass above, so the result goes there
+  for (int i1 = lane + 1; i1 <= n1; i1 += 64) {
+    const int e_prev = (i1 > 1) ? c.itgt_end[i1 - 1] : 0, e = c.itgt_end[i1];
+    const int first = ((e_prev < 0) ? -e_prev : e_prev) + 1;
+    double r;
+    if (e > 0) {      // h1(i1) > 0
+      double duh = 0., dh = 0.;
+      double u1min = c.u_sub[first], u1max = c.u_sub[first];
+      for (int i_sub = first; i_sub <= e; i_sub++) {
+        u1min = fmin(u1min, c.u_sub[i_sub]);
+        u1max = fmax(u1max, c.u_sub[i_sub]);
+        dh = dh + c.h_sub[i_sub];
+        duh = duh + c.uh_sub[i_sub];
+      }
+      r = duh / dh;
+      r = fmax(u1min, fmin(u1max, r));
+    } else {
+      r = c.u_sub[first];
+    }
+    if (cu > 0.0 && fabs(r) < cu) r = 0.0;      // ALE_remap_tracers: conc_underflow, MOM_ALE.F90:812-814
+    c.u0[i1 - 1] = r;
+  }
+  wsync();
+}
+
+struct WRemapArgs {
+  m6::GridDev g;
+  const double *h_old, *h_new;   // thicknesses at the points of the fields (h, u or v points)
+  double *const *fld;            // device array of nfld pointers, or
+  double *single;                // the one field (nfld = 1) when fld is null
+  const double *cu;              // underflow per field or null
+  const char *sub;               // structure tiles from ale_sub_cells_kernel
+  int nfld, scheme, extrap, pos; // pos: MOM6HIP_POS_H / _U / _V
+  double h_neglect, h_neglect_edge;
+};
+
+__global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs a) {
+  extern __shared__ char wsm[];
+  const m6::GridDev &g = a.g;
+  const int nz = g.nk;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int xs = (a.pos == MOM6HIP_POS_U) ? 1 : 0, ys = (a.pos == MOM6HIP_POS_V) ? 1 : 0;
+  const int i_first = g.isc - xs + blockIdx.x * WR_NCOL, j = g.jsc - ys + blockIdx.y;
+  const long stride = (long)(g.nih + xs) * (g.njh + ys);
+  auto col2 = [&](int i) -> long { return a.pos == MOM6HIP_POS_U ? g.u2(i, j) : (a.pos == MOM6HIP_POS_V ? g.v2(i, j) : g.h2(i, j)); };
+  auto active = [&](int i) -> bool {
+    if (i > g.iec) return false;
+    const long n2 = col2(i);
+    const double m = a.pos == MOM6HIP_POS_U ? g.mask2dCu[n2] : (a.pos == MOM6HIP_POS_V ? g.mask2dCv[n2] : g.mask2dT[n2]);
+    return m > 0.;
+  };
+  const size_t cb = wcol_bytes(nz);
+  const WCol c = wcol_at(wsm + cb * wv, nz);
+  const bool mine = active(i_first + wv);
+  const int nd = sub_drows(nz), nsr = sub_srows(nz);
+
+  // the structure tile: contiguous rows of WR_NCOL entries; entry (row, column) goes to that column's LDS block, whose
+  // leading arrays have the order of the tile's rows  (tiles of inactive columns hold garbage, never used)
+  {
+    const char *tile = a.sub + sub_tile_bytes(nz) * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    const double *td = (const double *)tile;
+    for (int t = threadIdx.x; t < nd * WR_NCOL; t += 64 * WR_NCOL)
+      ((double *)(wsm + cb * (t % WR_NCOL)))[t / WR_NCOL] = td[t];
+    const short *ts = (const short *)(td + (size_t)nd * WR_NCOL);
+    const size_t soff = wcol_doubles(nz) * 8;
+    for (int t = threadIdx.x; t < nsr * WR_NCOL; t += 64 * WR_NCOL)
+      ((short *)(wsm + cb * (t % WR_NCOL) + soff))[t / WR_NCOL] = ts[t];
+  }
+  // cooperative, row-contiguous load of a (k, column) tile: thread t handles column t % NCOL, layers t / NCOL, ...
+  auto tile_load = [&](const double *src, int slot) {     // slot: 0 h0, 1 u0
+    for (int t = threadIdx.x; t < nz * WR_NCOL; t += 64 * WR_NCOL) {
+      const int cidx = t % WR_NCOL, k = t / WR_NCOL;
+      const int i = i_first + cidx;
+      if (i <= g.iec) ((double *)(wsm + cb * cidx))[nd + slot * nz + k] = src[col2(i) + stride * k];
+    }
+  };
+  tile_load(a.h_old, 0);
+  for (int m = 0; m < a.nfld; m++) {
+    double *f = a.fld ? a.fld[m] : a.single;
+    tile_load(f, 1);
+    __syncthreads();
+    if (mine) {
+      const int method = w_build_reconstructions(c, lane, a.scheme, a.extrap != 0, nz, a.h_neglect, a.h_neglect_edge);
+      w_integrate_sub_cells(c, lane, nz, nz, method, a.cu ? a.cu[m] : 0.0);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nz * WR_NCOL; t += 64 * WR_NCOL) {
+      const int cidx = t % WR_NCOL, k = t / WR_NCOL;
+      const int i = i_first + cidx;
+      if (active(i)) f[col2(i) + stride * k] = ((const double *)(wsm + cb * cidx))[nd + nz + k];
+    }
+    __syncthreads();
+  }
+}
+
+// MOM6HIP_ALE_LANE_PER_COLUMN=1 selects the older lane-per-column kernels (kept for comparison runs)
+bool lane_per_column() {
+  static const int v = [] { const char *e = getenv("MOM6HIP_ALE_LANE_PER_COLUMN"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
+// the two launches of the wave-cooperative path over the compute range of the given staggering
+int launch_wave_remap(mom6hip_ctx_t *ctx, WRemapArgs a) {
+  const m6::GridDev &g = a.g;
+  const int xs = (a.pos == MOM6HIP_POS_U) ? 1 : 0, ys = (a.pos == MOM6HIP_POS_V) ? 1 : 0;
+  const size_t lds = wcol_bytes(g.nk) * WR_NCOL;
+  M6_REQUIRE(lds <= 160 * 1024, "ALE remap: too many layers for the LDS-resident kernel");
+  static bool attr_set = false;
+  if (!attr_set) {
+    M6_HIP(hipFuncSetAttribute((const void *)ale_remap_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int ncol = g.iec - g.isc + 1 + xs, nrow = g.jec - g.jsc + 1 + ys;
+  const int nbx = (ncol + WR_NCOL - 1) / WR_NCOL;
+  M6_REQUIRE(ctx->ale_sub.reserve(sub_tile_bytes(g.nk) * (size_t)nbx * nrow) == 0, "ALE remap: out of device memory");
+  SubArgs sa;
+  sa.g = g; sa.h_old = a.h_old; sa.h_new = a.h_new; sa.sub = (char *)ctx->ale_sub.p; sa.pos = a.pos; sa.nbx = nbx;
+  hipLaunchKernelGGL(ale_sub_cells_kernel, dim3((ncol + 63) / 64, nrow), dim3(64), 0, ctx->stream, sa);
+  a.sub = (const char *)ctx->ale_sub.p;
+  hipLaunchKernelGGL(ale_remap_wave_kernel, dim3(nbx, nrow), dim3(64 * WR_NCOL), lds, ctx->stream, a);
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 // ALE_remap_tracers(CS, G, GV, h_old, h_new, Reg, debug, dt, PCM_cell), src/ALE/MOM_ALE.F90:737.
@@ -680,11 +1174,18 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
   a.scheme = cs->remapping_scheme; a.extrap = cs->boundary_extrapolation;
   // MOM_ALE.F90:770-771 (answer_date >= 20190101)
   a.h_neglect = g.H_subroundoff; a.h_neglect_edge = g.H_subroundoff;
+  if (!lane_per_column()) {
+    WRemapArgs w;
+    w.g = g; w.h_old = d_hold; w.h_new = d_hnew; w.fld = d_ptrs; w.single = nullptr; w.cu = d_cu; w.nfld = ntr;
+    w.scheme = a.scheme; w.extrap = a.extrap; w.pos = MOM6HIP_POS_H; w.h_neglect = a.h_neglect; w.h_neglect_edge = a.h_neglect_edge;
+    if (launch_wave_remap(ctx, w)) return 1;
+  } else {
   dim3 grid((g.iec - g.isc + 1 + 63) / 64, g.jec - g.jsc + 1);
   if (g.nk <= 8) hipLaunchKernelGGL(ale_remap_tracers_kernel<8>, grid, dim3(64), 0, s, a);
   else if (g.nk <= 32) hipLaunchKernelGGL(ale_remap_tracers_kernel<32>, grid, dim3(64), 0, s, a);
   else if (g.nk <= 80) hipLaunchKernelGGL(ale_remap_tracers_kernel<80>, grid, dim3(64), 0, s, a);
   else hipLaunchKernelGGL(ale_remap_tracers_kernel<128>, grid, dim3(64), 0, s, a);
+  }
   M6_HIP(hipGetLastError());
   if (memspace == MOM6HIP_MEM_HOST) {
     for (int m = 0; m < ntr; m++) M6_HIP(hipMemcpyAsync(tr[m], d_tr[m], bH, hipMemcpyDeviceToHost, s));
@@ -759,6 +1260,14 @@ extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_re
   for (int d = 0; d < 2; d++) {
     a[d].g = g; a[d].scheme = cs->remapping_scheme; a[d].extrap = cs->boundary_extrapolation;
     a[d].h_neglect = g.H_subroundoff; a[d].h_neglect_edge = g.H_subroundoff;      // :1118-1119
+    if (!lane_per_column()) {
+      WRemapArgs w;
+      w.g = g; w.h_old = a[d].h_old; w.h_new = a[d].h_new; w.fld = nullptr; w.single = a[d].vel; w.cu = nullptr; w.nfld = 1;
+      w.scheme = a[d].scheme; w.extrap = a[d].extrap; w.pos = d ? MOM6HIP_POS_V : MOM6HIP_POS_U;
+      w.h_neglect = a[d].h_neglect; w.h_neglect_edge = a[d].h_neglect_edge;
+      if (launch_wave_remap(ctx, w)) return 1;
+      continue;
+    }
     dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
     if (g.nk <= 8) hipLaunchKernelGGL(ale_remap_velocity_kernel<8>, grid, dim3(64), 0, ctx->stream, a[d]);
     else if (g.nk <= 32) hipLaunchKernelGGL(ale_remap_velocity_kernel<32>, grid, dim3(64), 0, ctx->stream, a[d]);

@@ -273,6 +273,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->tr_stage) b.release();
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
+  ctx->ale_sub.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
