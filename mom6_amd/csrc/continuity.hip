@@ -20,6 +20,7 @@
 // (SURVEY.md section 8d); this first version also materialises the edge values like the reference does
 // (+32 B/cell written and re-read per direction).
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -433,6 +434,401 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
   }
 }
 
+// ---- mass fluxes, block-cooperative form -----------------------------------------------------------
+// cont_flux_kernel re-reads five 3-D arrays on every pass over k (the first evaluation, every Newton iteration of
+// flux_adjust, the BT_cont fits): 3.6x the algorithmic bytes on the 1/4-degree grid, and that traffic is its run time.
+// Here a block of FC_NW waves owns 64 face columns and keeps them in REGISTERS for all passes: wave w holds layers
+// [w*KS, (w+1)*KS) of the 64 faces (u, visc_rem and the edge values / thickness of the cells on both sides: 8 doubles a
+// layer), so every 3-D input is read once.  A pass evaluates flux_layer for the wave's own layers and leaves the layer
+// values in LDS; the reference's k-ordered sums are then formed by ONE wave per sum, adding the nk values of each face in
+// order (same rounding as the reference's loop), and handed to all waves through LDS.  The scalar Newton / bracket logic
+// of each face is run redundantly by the eight waves (same inputs, same instructions, same result), which keeps the loop
+// trip count uniform over the block without any further exchange.  The two loops whose state runs through k
+// (the CFL brackets :663-716 and the duL/duR limits of set_*_BT_cont) are serial chains: two waves walk one chain each
+// over u and visc_rem staged in LDS.
+constexpr int FC_NW = 8;
+
+struct FaceConst { double dLf, cm, cp, dt; };
+
+// Marks a register value as redefined here, so that products of it are formed where the reference forms them (inside
+// the pass) instead of being hoisted out of the Newton loop and held in registers for every layer.
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }      // cm / cp: the CFL factor of the minus / plus side cell
+
+// flux_layer :896-972 from the per-layer register set: upwind edge value, edge difference and curvature of the cell on
+// either side (mE, mD = h_L - h_R, mC = (h_L + h_R) - 2 h of the minus-side cell; pW, pD = h_R - h_L, pC of the plus-side
+// cell) -- the sub-expressions the reference forms first, so the arithmetic that follows is its own.  The upwind side
+// is picked with selects (|u| dt = u dt or -u dt, bit for bit), the u = 0 branch by a final select.
+__device__ __forceinline__ double flux_reg(const FaceConst &F, double u, double vr, double mE, double mD, double mC, double pW,
+                                           double pD, double pC, double &duhdu) {
+  const bool pos = u > 0.0;
+  const double E = pos ? mE : pW, Dd = pos ? mD : pD, Cc = pos ? mC : pC, cf = pos ? F.cm : F.cp;
+  const double CFL = (fabs(u) * F.dt) * cf;
+  double uh = (F.dLf * 1.0) * u * (E + CFL * (0.5 * Dd + Cc * (CFL - 1.5)));
+  double h_marg = E + CFL * (Dd + 3.0 * Cc * (CFL - 1.0));
+  if (u == 0.0) { uh = 0.0; h_marg = 0.5 * (pW + mE); }
+  duhdu = (F.dLf * 1.0) * h_marg * vr;
+  return uh;
+}
+
+// The k-ordered sums of the layer values the waves left in the LDS planes 0 .. nsum-1, each started from its init value:
+// wave q < nsum adds plane q; every wave gets all results.
+__device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int lane, int w, int nz, int nsum, double i0, double i1,
+                                      double i2, double &r0, double &r1, double &r2) {
+  __syncthreads();
+  if (w < nsum) {
+    double acc = (w == 0) ? i0 : ((w == 1) ? i1 : i2);
+    const int base = w * plane + lane;
+    for (int k = 0; k < nz; k++) acc = acc + fsm[base + k * 64];
+    fsm[roff + w * 64 + lane] = acc;
+  }
+  __syncthreads();
+  r0 = fsm[roff + lane];
+  r1 = (nsum > 1) ? fsm[roff + 64 + lane] : 0.;
+  r2 = (nsum > 2) ? fsm[roff + 128 + lane] : 0.;
+}
+
+template <int DIR, int KS>
+__global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) {
+  extern __shared__ double fsm[];      // three [KS*FC_NW][64] planes of layer values, then results [8][64], visc_rem max [FC_NW][64]
+  const m6::GridDev &g = p.g;
+  const Dir<DIR> D(g);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nz = g.nk;
+  const int fi_raw = p.fi0 + blockIdx.x * 64 + lane;
+  const bool valid = fi_raw <= p.fi1;
+  const int fi = valid ? fi_raw : p.fi1;      // lanes past the row repeat its last face (no stores), so barriers stay uniform
+  const int fj = p.fj0 + blockIdx.y;
+  const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
+  const long s = D.sa(), fs = D.fsa();
+  const long o2 = g.h2(fi, fj), f2 = D.f2(fi, fj);
+  constexpr int PL = KS * FC_NW * 64;          // one plane
+  constexpr int RO = 3 * PL, VO = RO + 8 * 64; // results, visc_rem max
+  const int k0 = w * KS;
+  const int sl = k0 * 64 + lane;               // this thread's slot of layer k0 in a plane
+
+  FaceConst F;
+  F.dLf = D.dL_face()[f2]; F.dt = p.dt;
+  F.cm = p.o.vol_CFL ? (F.dLf * g.IareaT[o2]) : D.IdL_T()[o2];
+  F.cp = p.o.vol_CFL ? (F.dLf * g.IareaT[o2 + s]) : D.IdL_T()[o2 + s];
+
+  // ---- the wave's layers into registers
+  const bool wide = !(p.o.upwind_1st || p.o.simple_2nd);      // the 5-point stencil is only read by the PPM branch
+  double mk[6];                                               // mask2dT of cells -2 .. +3 along the direction
+  {
+    const double *mm = g.mask2dT + o2;
+    mk[0] = wide ? mm[-2 * s] : 0.0; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s]; mk[5] = wide ? mm[3 * s] : 0.0;
+  }
+  double ru[KS], rvr[KS], mE[KS], mD[KS], mC[KS], pW[KS], pD[KS], pC[KS];
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    const int k = k0 + m;
+    if (k < nz) {
+      const long f3 = f2 + k * fpl, o3 = o2 + k * hpl;
+      ru[m] = p.u[f3]; rvr[m] = p.visc_rem ? p.visc_rem[f3] : 1.0;
+      // the edge values of the two cells (cont_edge_kernel's arithmetic, PPM_reconstruction_x/y :2310-2662) from the six
+      // thicknesses along the direction: h_L / h_R never go through memory
+      const double *hh = p.h_in + o3;
+      const double hm1 = hh[-s], hc0 = hh[0], hp1 = hh[s], hp2 = hh[2 * s];
+      double Lm, Rm, Lp, Rp;
+      if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; Lp = hp1; Rp = hp1; }
+      else {
+        const double hm2 = wide ? hh[-2 * s] : 0.0, hp3 = wide ? hh[3 * s] : 0.0;
+        edge_values(p.o, g.Angstrom_H, hm2, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3], wide ? mk[4] : 0.0, Lm, Rm);
+        edge_values(p.o, g.Angstrom_H, wide ? hm1 : 0.0, hc0, hp1, hp2, hp3, wide ? mk[1] : 0.0, mk[2], mk[3], mk[4], mk[5], Lp, Rp);
+      }
+      mE[m] = Rm; mD[m] = Lm - Rm; mC[m] = Lm + Rm - 2.0 * hc0;
+      pW[m] = Lp; pD[m] = Rp - Lp; pC[m] = Lp + Rp - 2.0 * hp1;
+    } else {
+      ru[m] = 0.; rvr[m] = 0.; mE[m] = 0.; mD[m] = 0.; mC[m] = 0.; pW[m] = 0.; pD[m] = 0.; pC[m] = 0.;
+    }
+  }
+
+  // ---- layer transports and marginal areas, :622-635
+  double vmax_w = 0.0;
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    if (k0 + m < nz) {
+      double dd;
+      const double uhk = flux_reg(F, ru[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
+      if (valid) p.uh[f2 + (k0 + m) * fpl] = uhk;
+      fsm[sl + m * 64] = uhk; fsm[PL + sl + m * 64] = dd;
+      vmax_w = max2(vmax_w, rvr[m]);
+    }
+  }
+  fsm[VO + w * 64 + lane] = vmax_w;
+  double uh_tot_0, duhdu_tot_0, dummy;
+  ksums(fsm, PL, RO, lane, w, nz, 2, 0.0, 0.0, 0.0, uh_tot_0, duhdu_tot_0, dummy);
+  double visc_rem_max = 0.0;
+  for (int q = 0; q < FC_NW; q++) visc_rem_max = max2(visc_rem_max, fsm[VO + q * 64 + lane]);      // (max is order-free)
+  if (!(p.visc_rem && p.o.use_visc_rem_max)) visc_rem_max = 1.0;
+
+  // ---- the CFL brackets of the velocity correction, :637-716: two chains through k over u and visc_rem staged in LDS
+  double CFL_dt = p.o.CFL_limit_adjust / p.dt;
+  const double I_dt = 1.0 / p.dt;
+  if (p.o.aggress_adjust) CFL_dt = I_dt;
+  double I_vrm = 0.0;
+  if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+  double dx_W, dx_E;
+  if (p.o.vol_CFL) {
+    dx_W = ratio_max(g.areaT[o2], D.dL_face()[f2], 1000.0 * D.dL_T()[o2]);
+    dx_E = ratio_max(g.areaT[o2 + s], D.dL_face()[f2], 1000.0 * D.dL_T()[o2 + s]);
+  } else { dx_W = D.dL_T()[o2]; dx_E = D.dL_T()[o2 + s]; }
+  const double mface = D.mask_face()[f2];
+  __syncthreads();      // the sums in planes 0 / 1 have been read
+#pragma unroll
+  for (int m = 0; m < KS; m++)
+    if (k0 + m < nz) { fsm[sl + m * 64] = ru[m]; fsm[PL + sl + m * 64] = rvr[m]; }
+  __syncthreads();
+  if (w == 0) {
+    double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
+    for (int k = 0; k < nz; k++) {
+      const double uk = fsm[k * 64 + lane];
+      if (p.visc_rem) {
+        const double vr = fsm[PL + k * 64 + lane];
+        if (p.o.aggress_adjust) {
+          const double du_lim = 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f2 + k * fpl - fs]));
+          if (du_max_CFL * vr > du_lim) du_max_CFL = du_lim / vr;
+        } else {
+          if (du_max_CFL * vr > dx_W * CFL_dt - uk * mface) du_max_CFL = (dx_W * CFL_dt - uk) / vr;
+        }
+      } else {
+        if (p.o.aggress_adjust) du_max_CFL = min2(du_max_CFL, 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f2 + k * fpl - fs])));
+        else du_max_CFL = min2(du_max_CFL, dx_W * CFL_dt - uk);
+      }
+    }
+    fsm[RO + lane] = max2(du_max_CFL, 0.0);
+  } else if (w == 1) {
+    double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
+    for (int k = 0; k < nz; k++) {
+      const double uk = fsm[k * 64 + lane];
+      if (p.visc_rem) {
+        const double vr = fsm[PL + k * 64 + lane];
+        if (p.o.aggress_adjust) {
+          const double du_lim = 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f2 + k * fpl + fs]));
+          if (du_min_CFL * vr < du_lim) du_min_CFL = du_lim / vr;
+        } else {
+          if (du_min_CFL * vr < -dx_E * CFL_dt - uk * mface) du_min_CFL = -(dx_E * CFL_dt + uk) / vr;
+        }
+      } else {
+        if (p.o.aggress_adjust) du_min_CFL = max2(du_min_CFL, 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f2 + k * fpl + fs])));
+        else du_min_CFL = max2(du_min_CFL, -(dx_E * CFL_dt + uk));
+      }
+    }
+    fsm[RO + 64 + lane] = min2(du_min_CFL, 0.0);
+  }
+  __syncthreads();
+  const double du_max_CFL = fsm[RO + lane], du_min_CFL = fsm[RO + 64 + lane];
+  const double IaT = min2(g.IareaT[o2], g.IareaT[o2 + s]);
+
+  // ---- flux_adjust :1094-1243 for the 64 faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
+  // phase 1 finds the correction that gives no net transport for set_*_BT_cont (:1290-1292)
+  double du_ph[2] = {0.0, 0.0};
+#pragma unroll 1
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 0 ? (p.uhbt == nullptr) : !p.set_BT_cont) continue;
+    const bool write_uh = (phase == 0);
+    const double uhbt = (phase == 0) ? p.uhbt[f2] : 0.0;
+    const int max_itts = 20;
+    double du = 0.0, du_max = du_max_CFL, du_min = du_min_CFL;
+    double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0, uh_err_best = fabs(uh_err);
+    bool do_I = true, alive = true;
+#pragma unroll 1
+    for (int itt = 1; itt <= max_itts; itt++) {
+      bool domore = false;
+      if (alive) {
+        double tol_eta;
+        if (itt <= 1) tol_eta = 1e-6 * p.o.tol_eta;
+        else if (itt == 2) tol_eta = 1e-4 * p.o.tol_eta;
+        else if (itt == 3) tol_eta = 1e-2 * p.o.tol_eta;
+        else tol_eta = p.o.tol_eta;
+        const double tol_vel = p.o.tol_vel;
+        if (uh_err > 0.0) du_max = du;
+        else if (uh_err < 0.0) du_min = du;
+        else do_I = false;
+        if (do_I) {
+          if ((p.dt * IaT * fabs(uh_err) > tol_eta) ||
+              (p.o.better_iter && ((fabs(uh_err) > tol_vel * duhdu_tot) || (fabs(uh_err) > uh_err_best)))) {
+            const double ddu = -uh_err / duhdu_tot;
+            const double du_prev = du;
+            du = du + ddu;
+            if (fabs(ddu) < 1.0e-15 * fabs(du)) {
+              do_I = false;
+            } else if (ddu > 0.0) {
+              if (du >= du_max) {
+                du = 0.5 * (du_prev + du_max);
+                if (du_max - du_prev < 1.0e-15 * fabs(du)) do_I = false;
+              }
+            } else {
+              if (du <= du_min) {
+                du = 0.5 * (du_prev + du_min);
+                if (du_prev - du_min < 1.0e-15 * fabs(du)) do_I = false;
+              }
+            }
+            if (do_I) domore = true;
+          } else {
+            do_I = false;
+          }
+        }
+        if (!domore) alive = false;
+      }
+      if (!__any(alive)) break;      // the same in every wave of the block: they hold the same values
+      if ((itt < max_itts) || write_uh) {
+        __syncthreads();             // the results of the previous pass have been read
+        const bool st = write_uh && alive && valid;
+#pragma unroll
+        for (int m = 0; m < KS; m++) {
+          if (k0 + m < nz) {
+            double dd;
+            pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
+            const double uhk = flux_reg(F, ru[m] + du * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
+            if (st) p.uh[f2 + (k0 + m) * fpl] = uhk;
+            fsm[sl + m * 64] = uhk; fsm[PL + sl + m * 64] = dd;
+          }
+        }
+        double usum, dsum, d2;
+        ksums(fsm, PL, RO, lane, w, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2);
+        if (alive && itt < max_itts) {
+          uh_err = usum; duhdu_tot = dsum;
+          uh_err_best = min2(uh_err_best, fabs(uh_err));
+        }
+      }
+    }
+    du_ph[phase] = du;
+  }
+  const double du = du_ph[0], du0 = du_ph[1];
+
+  if (valid) {
+    if (p.uhbt && p.u_cor && !p.set_BT_cont) {      // with BT_cont, u_cor is written in the pass of the three fits below
+#pragma unroll
+      for (int m = 0; m < KS; m++)
+        if (k0 + m < nz) p.u_cor[f2 + (k0 + m) * fpl] = ru[m] + du * rvr[m];
+    }
+    if (w == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
+  }
+  if (!p.set_BT_cont) return;
+
+  // ---- set_zonal_BT_cont :1247-1410
+  const double min_visc_rem = 0.1, CFL_min = 1e-6;
+  const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < KS; m++)
+    if (k0 + m < nz) { fsm[sl + m * 64] = ru[m]; fsm[PL + sl + m * 64] = rvr[m]; }
+  __syncthreads();
+  if (w == 0) {
+    double duR = min2(0.0, du0 - du_CFL);
+    for (int k = 0; k < nz; k++) {
+      const double vr = fsm[PL + k * 64 + lane], uk = fsm[k * 64 + lane];
+      const double visc_rem_lim = max2(vr, min_visc_rem * visc_rem_max);
+      if (visc_rem_lim > 0.0)
+        if (uk + duR * visc_rem_lim > -du_CFL * vr) duR = -(uk + du_CFL * vr) / visc_rem_lim;
+    }
+    fsm[RO + lane] = duR;
+  } else if (w == 1) {
+    double duL = max2(0.0, du0 + du_CFL);
+    for (int k = 0; k < nz; k++) {
+      const double vr = fsm[PL + k * 64 + lane], uk = fsm[k * 64 + lane];
+      const double visc_rem_lim = max2(vr, min_visc_rem * visc_rem_max);
+      if (visc_rem_lim > 0.0)
+        if (uk + duL * visc_rem_lim < du_CFL * vr) duL = -(uk - du_CFL * vr) / visc_rem_lim;
+    }
+    fsm[RO + 64 + lane] = duL;
+  }
+  __syncthreads();
+  const double duR = fsm[RO + lane], duL = fsm[RO + 64 + lane];
+  __syncthreads();      // the results area is written again below
+  const bool cor = p.uhbt && p.u_cor;
+  // the three evaluations of every layer; the marginal areas are summed first, the two transports after
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    if (k0 + m < nz) {
+      const long f3 = f2 + (k0 + m) * fpl;
+      const double vr = rvr[m], uk = ru[m];
+      double d0, dL, dR;
+      pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
+      (void)flux_reg(F, uk + du0 * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], d0);
+      (void)flux_reg(F, uk + duL * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
+      (void)flux_reg(F, uk + duR * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
+      fsm[sl + m * 64] = d0; fsm[PL + sl + m * 64] = dL; fsm[2 * PL + sl + m * 64] = dR;
+      // u_cor (:744-748) and flux_thickness (:976-1057, with u_cor if present :809-815) ride on the same layer data
+      double uc = uk;
+      if (cor) { uc = uk + du * vr; if (valid) p.u_cor[f3] = uc; }
+      if (p.h_face) {
+        const bool pos = uc > 0.0;
+        const double E = pos ? mE[m] : pW[m], Dd = pos ? mD[m] : pD[m], Cc = pos ? mC[m] : pC[m], cf = pos ? F.cm : F.cp;
+        const double CFL = (fabs(uc) * p.dt) * cf;
+        double h_avg = E + CFL * (0.5 * Dd + Cc * (CFL - 1.5));
+        double h_marg = E + CFL * (Dd + 3.0 * Cc * (CFL - 1.0));
+        if (uc == 0.0) { h_avg = 0.5 * (pW[m] + mE[m]); h_marg = 0.5 * (pW[m] + mE[m]); }
+        double hu = p.o.marginal_faces ? h_marg : h_avg;
+        if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
+        if (valid) p.h_face[f3] = hu;
+      }
+    }
+  }
+  double FAmt_0, FAmt_L, FAmt_R, uhtot_L, uhtot_R, d2;
+  ksums(fsm, PL, RO, lane, w, nz, 3, 0.0, 0.0, 0.0, FAmt_0, FAmt_L, FAmt_R);
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    if (k0 + m < nz) {
+      double dL, dR;
+      pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
+      fsm[sl + m * 64] = flux_reg(F, ru[m] + duL * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
+      fsm[PL + sl + m * 64] = flux_reg(F, ru[m] + duR * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
+    }
+  }
+  ksums(fsm, PL, RO, lane, w, nz, 2, 0.0, 0.0, 0.0, uhtot_L, uhtot_R, d2);
+  if (w == 0 && valid) {
+    double FA_0 = FAmt_0, FA_avg = FAmt_0;
+    if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
+    if (FA_avg > max2(FA_0, FAmt_L)) FA_avg = max2(FA_0, FAmt_L);
+    else if (FA_avg < min2(FA_0, FAmt_L)) FA_0 = FA_avg;
+    p.FA_0m[f2] = FA_0; p.FA_mm[f2] = FAmt_L;
+    if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) p.uBT_mm[f2] = 0.0;
+    else p.uBT_mm[f2] = (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0));
+
+    FA_0 = FAmt_0; FA_avg = FAmt_0;
+    if ((duR - du0) != 0.0) FA_avg = uhtot_R / (duR - du0);
+    if (FA_avg > max2(FA_0, FAmt_R)) FA_avg = max2(FA_0, FAmt_R);
+    else if (FA_avg < min2(FA_0, FAmt_R)) FA_0 = FA_avg;
+    p.FA_0p[f2] = FA_0; p.FA_pp[f2] = FAmt_R;
+    if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) p.uBT_pp[f2] = 0.0;
+    else p.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+  }
+}
+
+// MOM6HIP_CONT_FLUX_LANE=1 keeps the lane-per-column kernel for every call (comparison runs)
+bool flux_lane_only() {
+  static const int v = [] { const char *e = getenv("MOM6HIP_CONT_FLUX_LANE"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
+// Whether a flux launch takes the block-cooperative kernel (which forms the edge values itself): when there is a velocity
+// correction or BT_cont to compute and the layers fit its registers; the single-pass lane-per-column kernel otherwise.
+bool flux_is_coop(const FluxArgs &f) {
+  return (f.uhbt || f.set_BT_cont) && f.g.nk <= 10 * FC_NW && !flux_lane_only();
+}
+
+template <int DIR>
+int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) {
+  const int nk = f.g.nk;
+  const dim3 grid((n_along + 63) / 64, n_rows);
+  if (flux_is_coop(f)) {
+    auto go = [&](auto kern, int KS) -> int {
+      const size_t lds = ((size_t)3 * KS * FC_NW * 64 + 8 * 64 + FC_NW * 64) * sizeof(double);
+      M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, dim3(64 * FC_NW), lds, ctx->stream, f);
+      return 0;
+    };
+    if (nk <= FC_NW) return go(cont_flux_coop_kernel<DIR, 1>, 1);
+    if (nk <= 4 * FC_NW) return go(cont_flux_coop_kernel<DIR, 4>, 4);
+    return go(cont_flux_coop_kernel<DIR, 10>, 10);
+  }
+  hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
+  return 0;
+}
+
 // ---- convergence ---------------------------------------------------------------------------------
 struct ConvArgs {
   m6::GridDev g;
@@ -527,16 +923,18 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
   const double h_min = g.Angstrom_H;
 
   auto zonal = [&](const double *hsrc, int jsh, int jeh, double hmin) -> int {
-    EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
-    e.i0 = is - 1; e.i1 = ie + 1; e.j0 = jsh; e.j1 = jeh;
-    hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, e);
     FluxArgs f; f.g = g; f.o = o; f.u = d_u; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_uhbt; f.visc_rem = d_vru;
     f.uh = d_uh; f.u_cor = d_ucor; f.du_cor = d_ducor;
     f.FA_0m = bt.FA_u_W0; f.FA_mm = bt.FA_u_WW; f.FA_0p = bt.FA_u_E0; f.FA_pp = bt.FA_u_EE; f.uBT_mm = bt.uBT_WW;
     f.uBT_pp = bt.uBT_EE; f.h_face = bt.h_u; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = is - 1; f.fi1 = ie; f.fj0 = jsh; f.fj1 = jeh;
+    if (!flux_is_coop(f)) {
+      EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+      e.i0 = is - 1; e.i1 = ie + 1; e.j0 = jsh; e.j1 = jeh;
+      hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, e);
+    }
     { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_X);
-      hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((f.fi1 - f.fi0 + 64) / 64, jeh - jsh + 1), dim3(64), 0, s, f); }
+      if (launch_flux<0>(ctx, f, f.fi1 - f.fi0 + 1, jeh - jsh + 1)) return 1; }
     ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = d_h; c.dt = dt; c.h_min = hmin;
     c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh;
     hipLaunchKernelGGL(cont_conv_kernel<0>, dim3((ie - is + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, c);
@@ -544,16 +942,18 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     return 0;
   };
   auto merid = [&](const double *hsrc, int ish, int ieh, double hmin) -> int {
-    EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
-    e.i0 = ish; e.i1 = ieh; e.j0 = js - 1; e.j1 = je + 1;
-    hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, s, e);
     FluxArgs f; f.g = g; f.o = o; f.u = d_v; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_vhbt; f.visc_rem = d_vrv;
     f.uh = d_vh; f.u_cor = d_vcor; f.du_cor = d_dvcor;
     f.FA_0m = bt.FA_v_S0; f.FA_mm = bt.FA_v_SS; f.FA_0p = bt.FA_v_N0; f.FA_pp = bt.FA_v_NN; f.uBT_mm = bt.vBT_SS;
     f.uBT_pp = bt.vBT_NN; f.h_face = bt.h_v; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = ish; f.fi1 = ieh; f.fj0 = js - 1; f.fj1 = je;
+    if (!flux_is_coop(f)) {
+      EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+      e.i0 = ish; e.i1 = ieh; e.j0 = js - 1; e.j1 = je + 1;
+      hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, s, e);
+    }
     { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_Y);
-      hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((ieh - ish + 64) / 64, f.fj1 - f.fj0 + 1), dim3(64), 0, s, f); }
+      if (launch_flux<1>(ctx, f, ieh - ish + 1, f.fj1 - f.fj0 + 1)) return 1; }
     ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
     c.i0 = ish; c.i1 = ieh; c.j0 = js; c.j1 = je;
     hipLaunchKernelGGL(cont_conv_kernel<1>, dim3((ieh - ish + 256) / 256, je - js + 1, g.nk), dim3(256), 0, s, c);
