@@ -439,29 +439,30 @@ def main():
     del M
     torch.cuda.empty_cache()
 
-    # roofline of the dominant KERNEL of the step: cont_flux_kernel<1> (meridional_mass_flux + flux_adjust + BT_cont,
-    # mom6_amd/csrc/continuity.hip; profiles/r01_e_bench_om4_kernel_stats.csv).  Duration: HIP events around its launches
-    # inside the timed region.  Algorithmic bytes per cell and launch: read v, visc_rem_v, h,
-    # h_L, h_R (40 B), write vh (8 B) [+ v_cor (8 B) with vhbt] [+ h_v (8 B) with BT_cont] -> 56 / 64 / 56 B for
-    # the three calls of a step.
+    # roofline of the dominant KERNEL of the step: cont_flux_coop_kernel<1,10> (meridional_mass_flux: edge values,
+    # flux_adjust, BT_cont fits; mom6_amd/csrc/continuity.hip; profiles/r01_f_bench_om4_kernel_stats.csv).  Duration: HIP
+    # events around its launches inside the timed region.  Algorithmic bytes per cell and launch:
+    # read v, visc_rem_v, h (24 B), write vh (8 B) [+ v_cor (8 B) with vhbt] [+ h_v (8 B) with BT_cont] -> 40 / 48 / 40 B
+    # for the three calls of a step.
     if rank == 0:
         ms_y, n_y = ktime[1]
         ms_x, n_x = ktime[0]
         if n_y > 0:
-            alg = (56.0 + 64.0 + 56.0) / 3.0 * cells / world
+            alg = (40.0 + 48.0 + 40.0) / 3.0 * cells / world
             avg_ms = ms_y / n_y
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc.json")))["kernels"]["cont_flux_kernel<1>"]
+                kern = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc.json")))["kernels"]
+                pmc = [v for k, v in kern.items() if k.startswith("cont_flux_coop_kernel<1")][0]
                 if a.workload == "om4_025" and world == 1:
                     traffic = pmc["fetch_bytes"] + pmc["write_bytes"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 passes
             except Exception:
                 pass
             out["roofline"] = {
-                "kernel": "cont_flux_kernel<1>", "bound": "hbm", "achieved": alg / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "cont_flux_coop_kernel<1,10>", "bound": "hbm", "achieved": alg / (avg_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n_y),
-                "also": {"cont_flux_kernel<0>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
+                "also": {"cont_flux_coop_kernel<0,10>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
             }
 
     if world == 1 and not a.no_roofline:
