@@ -444,8 +444,8 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
 // order (same rounding as the reference's loop), and handed to all waves through LDS.  The scalar Newton / bracket logic
 // of each face is run redundantly by the eight waves (same inputs, same instructions, same result), which keeps the loop
 // trip count uniform over the block without any further exchange.  The two loops whose state runs through k
-// (the CFL brackets :663-716 and the duL/duR limits of set_*_BT_cont) are serial chains: two waves walk one chain each
-// over u and visc_rem staged in LDS.
+// (the CFL brackets :663-716 and the duL/duR limits of set_*_BT_cont) are serial chains walked by one wave; the
+// divisions in them do not depend on the running state and are formed by all waves beforehand.
 constexpr int FC_NW = 8;
 
 struct FaceConst { double dLf, cm, cp, dt; };
@@ -574,45 +574,70 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
     dx_E = ratio_max(g.areaT[o2 + s], D.dL_face()[f2], 1000.0 * D.dL_T()[o2 + s]);
   } else { dx_W = D.dL_T()[o2]; dx_E = D.dL_T()[o2 + s]; }
   const double mface = D.mask_face()[f2];
+  // The state of these loops runs through k, so one wave walks them; what it needs per layer -- the bound the bracket
+  // is tested against and the value it takes when the test fails (a division) -- does not depend on that state and is
+  // formed by all waves for their own layers first: planes 0 / 1 / 2 = visc_rem, bound, new bracket.
   __syncthreads();      // the sums in planes 0 / 1 have been read
 #pragma unroll
-  for (int m = 0; m < KS; m++)
-    if (k0 + m < nz) { fsm[sl + m * 64] = ru[m]; fsm[PL + sl + m * 64] = rvr[m]; }
+  for (int m = 0; m < KS; m++) {
+    if (k0 + m < nz) {
+      const double uk = ru[m], vr = rvr[m];
+      double bound, cand;
+      if (p.o.aggress_adjust) {
+        bound = 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f2 + (k0 + m) * fpl - fs]));
+        cand = p.visc_rem ? bound / vr : bound;
+      } else if (p.visc_rem) {
+        bound = dx_W * CFL_dt - uk * mface; cand = (dx_W * CFL_dt - uk) / vr;
+      } else {
+        bound = dx_W * CFL_dt - uk; cand = bound;
+      }
+      fsm[sl + m * 64] = vr; fsm[PL + sl + m * 64] = bound; fsm[2 * PL + sl + m * 64] = cand;
+    }
+  }
   __syncthreads();
   if (w == 0) {
     double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
-    for (int k = 0; k < nz; k++) {
-      const double uk = fsm[k * 64 + lane];
-      if (p.visc_rem) {
-        const double vr = fsm[PL + k * 64 + lane];
-        if (p.o.aggress_adjust) {
-          const double du_lim = 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f2 + k * fpl - fs]));
-          if (du_max_CFL * vr > du_lim) du_max_CFL = du_lim / vr;
-        } else {
-          if (du_max_CFL * vr > dx_W * CFL_dt - uk * mface) du_max_CFL = (dx_W * CFL_dt - uk) / vr;
-        }
-      } else {
-        if (p.o.aggress_adjust) du_max_CFL = min2(du_max_CFL, 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f2 + k * fpl - fs])));
-        else du_max_CFL = min2(du_max_CFL, dx_W * CFL_dt - uk);
+    if (p.visc_rem) {
+#pragma unroll 8
+      for (int k = 0; k < nz; k++) {      // (all three loads up front: no LDS round trip inside the dependent chain)
+        const double vr = fsm[k * 64 + lane], bound = fsm[PL + k * 64 + lane], cand = fsm[2 * PL + k * 64 + lane];
+        du_max_CFL = (du_max_CFL * vr > bound) ? cand : du_max_CFL;
       }
+    } else {
+#pragma unroll 8
+      for (int k = 0; k < nz; k++) du_max_CFL = min2(du_max_CFL, fsm[2 * PL + k * 64 + lane]);
     }
     fsm[RO + lane] = max2(du_max_CFL, 0.0);
-  } else if (w == 1) {
-    double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
-    for (int k = 0; k < nz; k++) {
-      const double uk = fsm[k * 64 + lane];
-      if (p.visc_rem) {
-        const double vr = fsm[PL + k * 64 + lane];
-        if (p.o.aggress_adjust) {
-          const double du_lim = 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f2 + k * fpl + fs]));
-          if (du_min_CFL * vr < du_lim) du_min_CFL = du_lim / vr;
-        } else {
-          if (du_min_CFL * vr < -dx_E * CFL_dt - uk * mface) du_min_CFL = -(dx_E * CFL_dt + uk) / vr;
-        }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    if (k0 + m < nz) {
+      const double uk = ru[m], vr = rvr[m];
+      double bound, cand;
+      if (p.o.aggress_adjust) {
+        bound = 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f2 + (k0 + m) * fpl + fs]));
+        cand = p.visc_rem ? bound / vr : bound;
+      } else if (p.visc_rem) {
+        bound = -dx_E * CFL_dt - uk * mface; cand = -(dx_E * CFL_dt + uk) / vr;
       } else {
-        if (p.o.aggress_adjust) du_min_CFL = max2(du_min_CFL, 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f2 + k * fpl + fs])));
-        else du_min_CFL = max2(du_min_CFL, -(dx_E * CFL_dt + uk));
+        bound = -(dx_E * CFL_dt + uk); cand = bound;
       }
+      fsm[PL + sl + m * 64] = bound; fsm[2 * PL + sl + m * 64] = cand;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
+    if (p.visc_rem) {
+#pragma unroll 8
+      for (int k = 0; k < nz; k++) {
+        const double vr = fsm[k * 64 + lane], bound = fsm[PL + k * 64 + lane], cand = fsm[2 * PL + k * 64 + lane];
+        du_min_CFL = (du_min_CFL * vr < bound) ? cand : du_min_CFL;
+      }
+    } else {
+#pragma unroll 8
+      for (int k = 0; k < nz; k++) du_min_CFL = max2(du_min_CFL, fsm[2 * PL + k * 64 + lane]);
     }
     fsm[RO + 64 + lane] = min2(du_min_CFL, 0.0);
   }
@@ -710,6 +735,7 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
   // ---- set_zonal_BT_cont :1247-1410
   const double min_visc_rem = 0.1, CFL_min = 1e-6;
   const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
+  // the duR / duL limits (:1321-1330) are chains through k as well: two waves walk one each over u and visc_rem in LDS
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < KS; m++)
