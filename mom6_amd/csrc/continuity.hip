@@ -494,9 +494,12 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
   const Dir<DIR> D(g);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nz = g.nk;
-  const int fi_raw = p.fi0 + blockIdx.x * 64 + lane;
-  const bool valid = fi_raw <= p.fi1;
-  const int fi = valid ? fi_raw : p.fi1;      // lanes past the row repeat its last face (no stores), so barriers stay uniform
+  constexpr int FPB = (DIR == 0) ? 63 : 64;      // faces per block
+  const int fi_raw = p.fi0 + blockIdx.x * FPB + lane;
+  const bool valid = lane < FPB && fi_raw <= p.fi1;
+  // lanes past the row (and the 64th lane of a zonal block) do everything but store, so barriers stay uniform; they sit
+  // on the cell after the last face, whose reconstruction the last face needs, and never iterate (see `alive`)
+  const int fi = (fi_raw <= p.fi1 + 1) ? fi_raw : p.fi1 + 1;
   const int fj = p.fj0 + blockIdx.y;
   const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
   const long s = D.sa(), fs = D.fsa();
@@ -525,16 +528,23 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
     if (k < nz) {
       const long f3 = f2 + k * fpl, o3 = o2 + k * hpl;
       ru[m] = p.u[f3]; rvr[m] = p.visc_rem ? p.visc_rem[f3] : 1.0;
-      // the edge values of the two cells (cont_edge_kernel's arithmetic, PPM_reconstruction_x/y :2310-2662) from the six
-      // thicknesses along the direction: h_L / h_R never go through memory
+      // the edge values of the two cells (cont_edge_kernel's arithmetic, PPM_reconstruction_x/y :2310-2662) from the
+      // thicknesses along the direction: h_L / h_R never go through memory.  Zonal: the plus-side cell of a face is the
+      // minus-side cell of the next lane's face, so each lane reconstructs one cell and hands it down one lane (the
+      // 64th lane of a block only serves its neighbour; blocks advance by FPB = 63 faces).  Meridional: both cells.
       const double *hh = p.h_in + o3;
       const double hm1 = hh[-s], hc0 = hh[0], hp1 = hh[s], hp2 = hh[2 * s];
       double Lm, Rm, Lp, Rp;
-      if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; Lp = hp1; Rp = hp1; }
-      else {
-        const double hm2 = wide ? hh[-2 * s] : 0.0, hp3 = wide ? hh[3 * s] : 0.0;
-        edge_values(p.o, g.Angstrom_H, hm2, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3], wide ? mk[4] : 0.0, Lm, Rm);
-        edge_values(p.o, g.Angstrom_H, wide ? hm1 : 0.0, hc0, hp1, hp2, hp3, wide ? mk[1] : 0.0, mk[2], mk[3], mk[4], mk[5], Lp, Rp);
+      if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; }
+      else edge_values(p.o, g.Angstrom_H, wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
+                       wide ? mk[4] : 0.0, Lm, Rm);
+      if (DIR == 0) {
+        Lp = __shfl_down(Lm, 1); Rp = __shfl_down(Rm, 1);
+      } else if (p.o.upwind_1st) {
+        Lp = hp1; Rp = hp1;
+      } else {
+        edge_values(p.o, g.Angstrom_H, wide ? hm1 : 0.0, hc0, hp1, hp2, wide ? hh[3 * s] : 0.0, wide ? mk[1] : 0.0, mk[2], mk[3],
+                    mk[4], mk[5], Lp, Rp);
       }
       mE[m] = Rm; mD[m] = Lm - Rm; mC[m] = Lm + Rm - 2.0 * hc0;
       pW[m] = Lp; pD[m] = Rp - Lp; pC[m] = Lp + Rp - 2.0 * hp1;
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
     const int max_itts = 20;
     double du = 0.0, du_max = du_max_CFL, du_min = du_min_CFL;
     double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0, uh_err_best = fabs(uh_err);
-    bool do_I = true, alive = true;
+    bool do_I = true, alive = valid;
 #pragma unroll 1
     for (int itt = 1; itt <= max_itts; itt++) {
       bool domore = false;
@@ -839,8 +849,9 @@ bool flux_is_coop(const FluxArgs &f) {
 template <int DIR>
 int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) {
   const int nk = f.g.nk;
-  const dim3 grid((n_along + 63) / 64, n_rows);
+  dim3 grid((n_along + 63) / 64, n_rows);
   if (flux_is_coop(f)) {
+    if (DIR == 0) grid.x = (n_along + 62) / 63;      // a zonal block yields 63 faces (cont_flux_coop_kernel)
     auto go = [&](auto kern, int KS) -> int {
       const size_t lds = ((size_t)3 * KS * FC_NW * 64 + 8 * 64 + FC_NW * 64) * sizeof(double);
       M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
