@@ -464,6 +464,72 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
                    const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
                    const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav, int32_t memspace);
 
+/* ---- MOM_vert_friction ------------------------------------------------------------------------ */
+
+/*
+ * vertvisc_CS, src/parameterizations/vertical/MOM_vert_friction.F90:40-190: the parameters the provided branch reads
+ * (defaults of vertvisc_init :2465-2961 in brackets) and the arrays the module keeps between its three entry points.
+ * a_u / a_v: (nk+1) interfaces at u / v points [H T-1]; h_u / h_v: nk layers [H].
+ * Provided: BOTTOMDRAGLAW or KV_EXTRA_BBL or neither, HARMONIC_VISC, HARMONIC_BL_SCALE, KV_ML_INVZ2 with HMIX_FIXED,
+ * visc%Kv_shear, visc%Ray_u/v, DIRECT_STRESS, the CFL-based or MAXVEL velocity truncation.  Not provided (refused by
+ * name): DYNAMIC_VISCOUS_ML, bulk mixed layer (nkml > 0), FIXED_DEPTH_LOTW_ML, LOTW_VISCOUS_ML_FLOOR, USE_GL90_IN_SSW,
+ * STOKES_MIXING_COMBINED / FPMIX, ice shelves, OBC, visc%Kv_shear_Bu, VERT_FRICTION_ANSWER_DATE < 20190101,
+ * non-Boussinesq, U_TRUNC_FILE / V_TRUNC_FILE.
+ */
+typedef struct mom6hip_vertvisc_cs {
+  double Hmix;            /* HMIX_FIXED [Z] */
+  double Hmix_stress;     /* HMIX_STRESS [H] (DIRECT_STRESS) */
+  double Kvml_invZ2;      /* KV_ML_INVZ2 [H Z T-1] (0) */
+  double Kv;              /* KV [H Z T-1] */
+  double Hbbl;            /* HBBL [Z] */
+  double Kv_extra_bbl;    /* KV_EXTRA_BBL [H Z T-1] (0), read if !bottomdraglaw */
+  double harm_BL_val;     /* HARMONIC_BL_SCALE (0) */
+  double maxvel;          /* MAXVEL [L T-1] (3e8) */
+  double CFL_trunc;       /* CFL_TRUNCATE (0.5) */
+  double vel_underflow;   /* VEL_UNDERFLOW [L T-1] (0) */
+  double H_to_RZ;         /* GV%H_to_RZ */
+  double reserved0[5];
+  int32_t bottomdraglaw;  /* BOTTOMDRAGLAW (1) */
+  int32_t harmonic_visc;  /* HARMONIC_VISC (0) */
+  int32_t direct_stress;  /* DIRECT_STRESS (0) */
+  int32_t CFL_based_trunc;/* CFL_BASED_TRUNCATIONS (1) */
+  int32_t answer_date;    /* VERT_FRICTION_ANSWER_DATE (99991231); >= 20190101 */
+  int32_t unsupported[7]; /* dynamic_viscous_ML, nkml, fixed_LOTW_ML, apply_LOTW_floor, use_GL90_in_SSW, StokesMixing,
+                             non_Boussinesq: any nonzero is refused */
+  int64_t ntrunc;         /* CS%ntrunc: velocity truncations so far (see mom6hip_vertvisc_ntrunc) */
+  double *a_u, *a_v, *h_u, *h_v;
+  void *reserved1[4];
+} mom6hip_vertvisc_cs_t;
+
+/* The members of vertvisc_type (src/core/MOM_variables.F90:218-283) the provided branch reads. */
+typedef struct mom6hip_vertvisc_type {
+  const double *Kv_bbl_u, *Kv_bbl_v;        /* 2-D, u / v points [H Z T-1]   (BOTTOMDRAGLAW) */
+  const double *bbl_thick_u, *bbl_thick_v;  /* 2-D, u / v points [Z]         (BOTTOMDRAGLAW) */
+  const double *Ray_u, *Ray_v;              /* 3-D, u / v points [H T-1], or NULL */
+  const double *Kv_shear;                   /* (nk+1) interfaces at h points [H Z T-1], or NULL */
+  const double *Kv_shear_Bu;                /* must be NULL */
+  const void *reserved[4];
+} mom6hip_vertvisc_type_t;
+
+/* vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, VarMix)       MOM_vert_friction.F90:1168
+ * (+ find_coupling_coef :1768).  dz = NULL stands for the Boussinesq thickness_to_dz, dz = GV%H_to_Z*h. */
+int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, const double *u, const double *v, const double *h,
+                          const double *dz, const mom6hip_vertvisc_type_t *visc, double dt, int32_t memspace);
+
+/* vertvisc(u, v, h, forces, visc, dt, OBC, ADp, CDp, G, GV, US, CS, taux_bot, tauy_bot, fpmix, Waves)        :526
+ * including vertvisc_limit_vel (:2259).  forces%taux / %tauy are passed as taux, tauy; taux_bot / tauy_bot may be NULL. */
+int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *taux,
+                     const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
+                     int32_t memspace);
+
+/* CS%ntrunc: vertvisc counts truncations on the device; this adds the count since the last call to cs->ntrunc
+ * (synchronises the stream).  With MOM6HIP_MEM_HOST vertvisc does it itself. */
+int mom6hip_vertvisc_ntrunc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs);
+
+/* vertvisc_remnant(visc, visc_rem_u, visc_rem_v, dt, G, GV, US, CS)                                            :1064 */
+int mom6hip_vertvisc_remnant(mom6hip_ctx_t *ctx, const mom6hip_vertvisc_cs_t *cs, const mom6hip_vertvisc_type_t *visc,
+                             double *visc_rem_u, double *visc_rem_v, double dt, int32_t memspace);
+
 /* ---- MOM_dynamics_split_RK2 ------------------------------------------------------------------ */
 
 /*
@@ -503,8 +569,10 @@ typedef struct mom6hip_dyn_split_rk2_cs {
   const mom6hip_eos_t *eqn_of_state;          /* tv%eqn_of_state */
   mom6hip_barotropic_cs_t *barotropic_CSp;    /* its arrays are DEVICE arrays too */
   const mom6hip_bt_cont_t *BT_cont;           /* NULL: USE_BT_CONT_TYPE = False */
-  const mom6hip_visc_hooks_t *hooks;          /* NULL: inviscid */
-  const void *reserved1[3];
+  const mom6hip_visc_hooks_t *hooks;          /* NULL: no host-side parameterisations */
+  mom6hip_vertvisc_cs_t *vertvisc_CSp;        /* NULL: no vertical viscosity from this library (its arrays are DEVICE arrays) */
+  const mom6hip_vertvisc_type_t *visc;        /* the visc argument of the step (DEVICE arrays); needed with vertvisc_CSp */
+  const void *reserved1[1];
   /* 3-D */
   double *CAu, *CAv, *CAu_pred, *CAv_pred, *PFu, *PFv, *diffu, *diffv, *visc_rem_u, *visc_rem_v, *u_accel_bt,
       *v_accel_bt, *u_av, *v_av, *h_av, *pbce;

@@ -126,9 +126,31 @@ class DynSplitRK2CS(C.Structure):
                  ("CAu_pred_stored", C.c_int32), ("split_bottom_stress", C.c_int32), ("reserved0", C.c_int32 * 4),
                  ("continuity_CSp", C.c_void_p), ("CoriolisAdv", C.c_void_p), ("PressureForce_CSp", C.c_void_p),
                  ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
-                 ("reserved1", C.c_void_p * 3)]
+                 ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("reserved1", C.c_void_p * 1)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
                 + [("reserved2", C.c_void_p * 4)])
+
+
+# ---- MOM_vert_friction ------------------------------------------------------------------------------------
+VERTVISC_UNSUPPORTED = ("dynamic_viscous_ML", "nkml", "fixed_LOTW_ML", "apply_LOTW_floor", "use_GL90_in_SSW", "StokesMixing",
+                        "non_Boussinesq")
+VERTVISC_CS_ARRAYS = (("a_u", POS_U, 1), ("a_v", POS_V, 1), ("h_u", POS_U, 0), ("h_v", POS_V, 0))      # (name, pos, extra interfaces)
+
+
+class VertviscCS(C.Structure):
+    """mom6hip_vertvisc_cs_t (include/mom6hip.h)."""
+    _fields_ = ([(n, C.c_double) for n in ("Hmix", "Hmix_stress", "Kvml_invZ2", "Kv", "Hbbl", "Kv_extra_bbl", "harm_BL_val", "maxvel",
+                                           "CFL_trunc", "vel_underflow", "H_to_RZ")]
+                + [("reserved0", C.c_double * 5)]
+                + [(n, C.c_int32) for n in ("bottomdraglaw", "harmonic_visc", "direct_stress", "CFL_based_trunc", "answer_date")]
+                + [("unsupported", C.c_int32 * 7), ("ntrunc", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("a_u", "a_v", "h_u", "h_v")] + [("reserved1", C.c_void_p * 4)])
+
+
+class VertviscType(C.Structure):
+    """mom6hip_vertvisc_type_t (include/mom6hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("Kv_bbl_u", "Kv_bbl_v", "bbl_thick_u", "bbl_thick_v", "Ray_u", "Ray_v", "Kv_shear",
+                                           "Kv_shear_Bu")] + [("reserved", C.c_void_p * 4)])
 
 
 # ---- z* regridding ----------------------------------------------------------------------------------------

@@ -187,6 +187,8 @@ uint64_t mom6hip_abi_sizeof_eos(void) { return sizeof(mom6hip_eos_t); }
 uint64_t mom6hip_abi_sizeof_pressureforce_cs(void) { return sizeof(mom6hip_pressureforce_cs_t); }
 uint64_t mom6hip_abi_sizeof_barotropic_cs(void) { return sizeof(mom6hip_barotropic_cs_t); }
 uint64_t mom6hip_abi_sizeof_dyn_split_rk2_cs(void) { return sizeof(mom6hip_dyn_split_rk2_cs_t); }
+uint64_t mom6hip_abi_sizeof_vertvisc_cs(void) { return sizeof(mom6hip_vertvisc_cs_t); }
+uint64_t mom6hip_abi_sizeof_vertvisc_type(void) { return sizeof(mom6hip_vertvisc_type_t); }
 uint64_t mom6hip_abi_offsetof_grid_mask2dT(void) { return offsetof(mom6hip_grid_t, mask2dT); }
 
 static int upload2d(mom6hip_ctx_t *ctx, const double *h, size_t n, double **d) {
@@ -274,6 +276,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
   ctx->ale_sub.release();
+  ctx->vv_ntrunc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);

@@ -140,6 +140,8 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   const mom6hip_bt_cont_t *BTC = cs->BT_cont;
   const bool BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
   const mom6hip_visc_hooks_t *hk = cs->hooks;
+  mom6hip_vertvisc_cs_t *VV = cs->vertvisc_CSp;
+  M6_REQUIRE(!VV || cs->visc, "step_MOM_dyn_split_RK2: vertvisc_CSp needs the visc argument (cs->visc)");
 
   // the step's automatic arrays (:336-369): one grow-only block in the context's pool
   // (its own buffer: the modules called below hand out the pool's buffers from the start in every call)
@@ -167,10 +169,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   // u_bc_accel = (CAu_pred + PFu) + diffu ; up = mask*(u + dt*u_bc_accel)   :557-564, :582-589
   // Without viscosity hooks diffu = diffv = +0.0 everywhere (set by dyn_split_rk2_init): (a + 0.0) is a, except that
   // -0.0 + 0.0 = +0.0, so the array need not be read; and the first up, vp (:582-589) are only read by vertvisc_coef.
-  const bool inviscid = (hk == nullptr);
+  const bool inviscid = (hk == nullptr);      // diffu = diffv = 0
   auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
     const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
-    const bool need_up = first_up && !inviscid;
+    const bool need_up = first_up && (!inviscid || VV);
     launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
       const long n = g.u3(I, j, k);
       double a = (CAu[n] + PFu[n]);
@@ -190,6 +192,9 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (hk && hk->visc_remnant_pred) {   // set_viscous_ML, vertvisc_coef, vertvisc_remnant :592-600
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
+  } else if (VV) {                     // vertvisc_coef, vertvisc_remnant :598-600 (set_viscous_ML :592 is not provided)
+    CALL(mom6hip_vertvisc_coef(ctx, VV, up, vp, h, nullptr, cs->visc, dt, D));
+    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt, D));
   }
   CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}}, nz));                 // :610-611
 
@@ -223,6 +228,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (hk && hk->vertvisc) {   // vertvisc_coef, vertvisc, vertvisc_remnant :717-744
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, up, vp, h, dt_pred, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
+  } else if (VV) {            // :717-744
+    CALL(mom6hip_vertvisc_coef(ctx, VV, up, vp, h, nullptr, cs->visc, dt_pred, D));
+    CALL(mom6hip_vertvisc(ctx, VV, up, vp, h, taux, tauy, cs->visc, dt_pred, nullptr, nullptr, D));
+    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt_pred, D));
   }
   CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {up, PU}, {vp, PV}}, nz));            // :747, :751
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
@@ -258,6 +267,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (hk && hk->vertvisc) {   // :974-994
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, u_inst, v_inst, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
+  } else if (VV) {            // :974-994
+    CALL(mom6hip_vertvisc_coef(ctx, VV, u_inst, v_inst, h, nullptr, cs->visc, dt, D));
+    CALL(mom6hip_vertvisc(ctx, VV, u_inst, v_inst, h, taux, tauy, cs->visc, dt, nullptr, nullptr, D));
+    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt, D));
   }
   launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
   CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {u_inst, PU}, {v_inst, PV}}, nz));     // :1004, :1008

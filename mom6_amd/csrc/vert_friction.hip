@@ -1,0 +1,447 @@
+// vert_friction.hip -- vertvisc_coef (+ find_coupling_coef), vertvisc (+ vertvisc_limit_vel) and vertvisc_remnant of
+// src/parameterizations/vertical/MOM_vert_friction.F90 (:1168, :1768, :526, :2259, :1064) as gfx950 kernels.
+//
+// Everything here is a recurrence in k over one velocity column, independent between columns: one lane per face column,
+// lanes along i, so every k-strided access is a contiguous row across the wave.
+//   vv_coef_kernel<DIR>    one bottom-up sweep: the thickness at the velocity point (harmonic / arithmetic blend with the
+//                          bottom function), the normalised height z_i, and the coupling coefficient of the interface
+//                          between the layer just done and the one below it -- two layers of state in registers, no
+//                          per-column arrays.  (KV_ML_INVZ2 > 0 adds a top-down sweep first, which leaves its
+//                          viscosities in a_u.)
+//   vv_solve_kernel<DIR>   the implicit solve: forward elimination writing the modified right-hand side in place and
+//                          c1 to a work array, back substitution; the same kernel gives visc_rem (vertvisc_remnant).
+//   vv_limit_kernel<DIR>   vertvisc_limit_vel, one thread per point; truncations are counted with an atomic.
+// Algorithmic traffic per cell: coef 8 (h) + 4 (vel) + 16 (a, h_vel) [B, both directions: x2 on vel/a/h_vel];
+// solve: read a, h_vel, x, write x, c1, read both again, write x.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+using m6::max2;
+using m6::min2;
+
+struct VVPar {      // the scalars of vertvisc_CS the kernels read
+  double Hmix, Hmix_stress, Kvml_invZ2, Kv, Hbbl, Kv_extra_bbl, harm_BL_val, maxvel, CFL_trunc, vel_underflow, H_to_RZ;
+  int bottomdraglaw, harmonic_visc, direct_stress, CFL_based_trunc;
+};
+
+struct CoefArgs {
+  m6::GridDev g;
+  VVPar p;
+  const double *vel, *h, *dz, *kv_bbl, *bbl_thick, *Kv_shear;
+  double *a, *hv;
+};
+
+template <int DIR>
+__global__ __launch_bounds__(64) void vv_coef_kernel(CoefArgs A) {
+  const m6::GridDev &g = A.g;
+  const VVPar &P = A.p;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  if (!((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0)) return;      // do_i
+  const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  const long hpl = (long)g.nih * g.njh, fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const int nz = g.nk;
+  const double h_neglect = g.H_subroundoff, dz_neglect = g.dZ_subroundoff;
+  const double a_cpl_max = 1.0e37 * g.Z_to_H * 1.0;                 // :1283
+  double I_Hbbl = 1.0 / (P.Hbbl + dz_neglect);                      // :1284
+  const double I_valBL = (P.harm_BL_val > 0.0) ? 1.0 / P.harm_BL_val : 0.0;
+  double kv_bbl = 0.0, bbl_thick = 0.0;
+  if (P.bottomdraglaw) {                                            // :1318-1322
+    kv_bbl = A.kv_bbl[f2];
+    bbl_thick = A.bbl_thick[f2] + dz_neglect;
+    I_Hbbl = 1.0 / bbl_thick;
+  }
+  const double hn = dz_neglect, I_amax = 0.0;                        // find_coupling_coef :1846, :1858
+  auto DZ = [&](long c, int k) { return A.dz ? A.dz[c + hpl * k] : g.H_to_Z * A.h[c + hpl * k]; };
+
+  // ---- KV_ML_INVZ2: the top-down viscosity profile :1873-1886, parked in a(K) ----
+  const bool kvml = P.Kvml_invZ2 > 0.0;
+  if (kvml) {
+    const double I_Hmix = 1.0 / (P.Hmix + hn);
+    double z_t = hn * I_Hmix;
+    for (int K = 1; K < nz; K++) {
+      const double d0 = DZ(c0, K - 1), d1 = DZ(c1, K - 1);
+      const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+      z_t = z_t + dz_harm * I_Hmix;
+      A.a[f2 + fpl * K] = P.Kv + P.Kvml_invZ2 / ((z_t * z_t) * (1.0 + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
+    }
+  }
+
+  // ---- the bottom-up sweep ----
+  const double Dmin = min2(g.bathyT[c0], g.bathyT[c1]);              // :1331
+  double zh = 0.0, zcol0 = -g.bathyT[c0], zcol1 = -g.bathyT[c1];
+  double z_i_below = 0.0;        // z_i(k+1)
+  double dzv_below = 0.0;        // dz_vel(k+1)
+  for (int k = nz - 1; k >= 0; k--) {
+    const double h0 = A.h[c0 + hpl * k], h1 = A.h[c1 + hpl * k];
+    const double h_harm = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);      // :1324-1330
+    const double h_arith = 0.5 * (h1 + h0);
+    const double h_delta = h1 - h0;
+    const double d0 = DZ(c0, k), d1 = DZ(c1, k);
+    const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+    const double dz_arith = 0.5 * (d1 + d0);
+    const double vel = A.vel[f2 + fpl * k];
+    double hvel, dz_vel, z_i;
+    if (P.harmonic_visc) {                                           // :1363-1375
+      hvel = h_harm; dz_vel = dz_harm;
+      if (vel * h_delta < 0) {
+        const double z2 = z_i_below, botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        hvel = (1.0 - botfn) * h_harm + botfn * h_arith;
+        dz_vel = (1.0 - botfn) * dz_harm + botfn * dz_arith;
+      }
+      z_i = z_i_below + dz_harm * I_Hbbl;
+    } else {                                                         // :1376-1408
+      zcol0 = zcol0 + d0; zcol1 = zcol1 + d1;
+      zh = zh + dz_harm;
+      const double z_clear = max2(zcol0, zcol1) + Dmin;
+      z_i = max2(zh, z_clear) * I_Hbbl;
+      hvel = h_arith; dz_vel = dz_arith;
+      if (vel * h_delta > 0) {
+        if (zh * I_Hbbl < P.harm_BL_val) {
+          hvel = h_harm; dz_vel = dz_harm;
+        } else {
+          double z2_wt = 1.0;
+          if (zh * I_Hbbl < 2.0 * P.harm_BL_val) z2_wt = max2(0.0, min2(1.0, zh * I_Hbbl * I_valBL - 1.0));
+          const double z2 = z2_wt * (max2(zh, z_clear) * I_Hbbl);
+          const double botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+          hvel = (1.0 - botfn) * h_arith + botfn * h_harm;
+          dz_vel = (1.0 - botfn) * dz_arith + botfn * dz_harm;
+        }
+      }
+    }
+    A.hv[f2 + fpl * k] = hvel + h_neglect;                           // :1510
+
+    // the interface below this layer, K = k+1 (find_coupling_coef :1948-2007 with hvel = dz_vel)
+    const int K = k + 1;
+    double a_cpl;
+    if (K == nz) {
+      const double Kv_tot = P.Kv;
+      if (P.bottomdraglaw) {
+        const double dhc = dz_vel * 0.5;
+        if (dhc < bbl_thick) a_cpl = kv_bbl / ((dhc + hn) + I_amax * kv_bbl);
+        else a_cpl = kv_bbl / ((bbl_thick + hn) + I_amax * kv_bbl);
+      } else if (fabs(P.Kv_extra_bbl) > 0.0) {
+        a_cpl = (Kv_tot + P.Kv_extra_bbl) / ((0.5 * dz_vel + hn) + I_amax * (Kv_tot + P.Kv_extra_bbl));
+      } else {
+        a_cpl = Kv_tot / ((0.5 * dz_vel + hn) + I_amax * Kv_tot);
+      }
+    } else {
+      double Kv_tot = kvml ? A.a[f2 + fpl * K] : P.Kv;
+      if (A.Kv_shear) {                                              // :1888-1928
+        const double Kv_add = 0.5 * (A.Kv_shear[c0 + hpl * K] + A.Kv_shear[c1 + hpl * K]);
+        Kv_tot = Kv_tot + Kv_add;
+      }
+      if (P.bottomdraglaw) {
+        const double z2 = z_i_below, botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot = Kv_tot + (kv_bbl - P.Kv) * botfn;
+        const double dhc = 0.5 * (dzv_below + dz_vel);
+        double h_shear;
+        if (dhc > bbl_thick) h_shear = ((1.0 - botfn) * dhc + botfn * bbl_thick) + hn;
+        else h_shear = dhc + hn;
+        a_cpl = Kv_tot / (h_shear + (I_amax * Kv_tot));
+      } else if (fabs(P.Kv_extra_bbl) > 0.0) {
+        const double z2 = z_i_below, botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot = Kv_tot + P.Kv_extra_bbl * botfn;
+        const double h_shear = 0.5 * (dzv_below + dz_vel + hn);
+        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
+      } else {
+        const double h_shear = 0.5 * (dzv_below + dz_vel + hn);
+        a_cpl = Kv_tot / (h_shear + I_amax * Kv_tot);
+      }
+    }
+    A.a[f2 + fpl * K] = min2(a_cpl_max, a_cpl + 0.0);                 // :1504 (a_cpl_gl90 = 0)
+    z_i_below = z_i; dzv_below = dz_vel;
+  }
+  A.a[f2] = min2(a_cpl_max, 0.0 + 0.0);                               // a_cpl(:,1) = 0: no surface boundary layer scheme
+}
+
+struct SolveArgs {
+  m6::GridDev g;
+  VVPar p;
+  const double *a, *hv, *Ray, *h, *tau;
+  double *x, *c1, *tbot;
+  double dt;
+  int remnant;
+};
+
+// vertvisc :646-760 / :862-960 and vertvisc_remnant :1105-1155 for one face column
+template <int DIR>
+__global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
+  const m6::GridDev &g = A.g;
+  const VVPar &P = A.p;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const long fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const int nz = g.nk;
+  const double dt = A.dt;
+  const double mask = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2];
+  const bool do_i = mask > 0.0;
+  double *x = A.x;
+  if (do_i) {
+    double surface_stress = 0.0;
+    if (!A.remnant) {
+      const double dt_Rho0 = dt / P.H_to_RZ;                          // :611
+      if (P.direct_stress) {                                         // :671-685
+        const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+        const long hpl = (long)g.nih * g.njh;
+        const double Hmix = P.Hmix_stress, I_Hmix = 1.0 / Hmix;
+        double zDS = 0.0;
+        const double stress = dt_Rho0 * A.tau[f2];
+        for (int k = 0; k < nz; k++) {
+          const double h_a = 0.5 * (A.h[c0 + hpl * k] + A.h[c1 + hpl * k]) + g.H_subroundoff;
+          double hfr = 1.0;
+          if ((zDS + h_a) > Hmix) hfr = (Hmix - zDS) / h_a;
+          x[f2 + fpl * k] = x[f2 + fpl * k] + I_Hmix * hfr * stress;
+          zDS = zDS + h_a;
+          if (zDS >= Hmix) break;
+        }
+      } else {
+        surface_stress = dt_Rho0 * (mask * A.tau[f2]);               // :687
+      }
+    }
+    double b_denom_1 = A.hv[f2] + dt * ((A.Ray ? A.Ray[f2] : 0.0) + A.a[f2]);
+    double b1 = 1.0 / (b_denom_1 + dt * A.a[f2 + fpl]);
+    double d1 = b_denom_1 * b1;
+    double xk;
+    if (A.remnant) xk = b1 * A.hv[f2];
+    else xk = b1 * (A.hv[f2] * x[f2] + surface_stress);
+    x[f2] = xk;
+    double a_next = A.a[f2 + fpl];
+    for (int k = 1; k < nz; k++) {
+      const long n = f2 + fpl * k;
+      const double ak = a_next, hvk = A.hv[n];
+      a_next = A.a[n + fpl];
+      A.c1[n] = dt * ak * b1;
+      b_denom_1 = hvk + dt * ((A.Ray ? A.Ray[n] : 0.0) + ak * d1);
+      b1 = 1.0 / (b_denom_1 + dt * a_next);
+      d1 = b_denom_1 * b1;
+      if (A.remnant) xk = (hvk + dt * ak * xk) * b1;
+      else xk = (hvk * x[n] + dt * ak * xk) * b1;
+      x[n] = xk;
+    }
+    for (int k = nz - 2; k >= 0; k--) {
+      const long n = f2 + fpl * k;
+      xk = x[n] + A.c1[n + fpl] * xk;
+      x[n] = xk;
+    }
+  }
+  if (A.tbot) {                                                      // :798-805
+    double tb = P.H_to_RZ * (x[f2 + fpl * (nz - 1)] * A.a[f2 + fpl * nz]);
+    if (A.Ray) for (int k = 0; k < nz; k++) tb = tb + P.H_to_RZ * (A.Ray[f2 + fpl * k] * x[f2 + fpl * k]);
+    A.tbot[f2] = tb;
+  }
+}
+
+struct LimitArgs {
+  m6::GridDev g;
+  VVPar p;
+  const double *h;
+  double *x;
+  unsigned long long *ntrunc;
+  double dt;
+};
+
+// vertvisc_limit_vel :2346-2370 / :2431-2455 (no truncation files)
+template <int DIR>
+__global__ __launch_bounds__(256) void vv_limit_kernel(LimitArgs A) {
+  const m6::GridDev &g = A.g;
+  const VVPar &P = A.p;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 256 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  const int k = blockIdx.z;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const long fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh, hpl = (long)g.nih * g.njh;
+  const long n = f2 + fpl * k;
+  const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  const double dL = DIR ? g.dx_Cv[f2] : g.dy_Cu[f2];
+  const double H_report = 6.0 * g.Angstrom_H;
+  const double xv = A.x[n];
+  const double dt = A.dt;
+  bool trunc = false;
+  if (P.CFL_based_trunc) {
+    if (fabs(xv) < P.vel_underflow) { A.x[n] = 0.0; }
+    else if ((xv * (dt * dL)) * g.IareaT[c1] < -P.CFL_trunc) {
+      A.x[n] = (-0.9 * P.CFL_trunc) * (g.areaT[c1] / (dt * dL));
+      trunc = true;
+    } else if ((xv * (dt * dL)) * g.IareaT[c0] > P.CFL_trunc) {
+      A.x[n] = (0.9 * P.CFL_trunc) * (g.areaT[c0] / (dt * dL));
+      trunc = true;
+    }
+  } else {
+    const double maxvel = P.maxvel, truncvel = 0.9 * maxvel;
+    if (fabs(xv) < P.vel_underflow) { A.x[n] = 0.0; }
+    else if (fabs(xv) > maxvel) {
+      A.x[n] = copysign(truncvel, xv);
+      trunc = true;
+    }
+  }
+  if (trunc && (A.h[c0 + hpl * k] + A.h[c1 + hpl * k] > H_report)) atomicAdd(A.ntrunc, 1ull);
+}
+
+int check_cs(const mom6hip_vertvisc_cs_t *cs, const char *who) {
+  static const char *names[7] = {"DYNAMIC_VISCOUS_ML", "a bulk mixed layer (nkml > 0)", "FIXED_DEPTH_LOTW_ML", "LOTW_VISCOUS_ML_FLOOR",
+                                 "USE_GL90_IN_SSW", "STOKES_MIXING_COMBINED", "non-Boussinesq mode"};
+  for (int n = 0; n < 7; n++) M6_REQUIRE(!cs->unsupported[n], "%s: %s is not provided by libmom6hip", who, names[n]);
+  M6_REQUIRE(cs->answer_date >= 20190101, "%s: VERT_FRICTION_ANSWER_DATE < 20190101 is not provided", who);
+  M6_REQUIRE(cs->a_u && cs->a_v && cs->h_u && cs->h_v, "%s: the a_u, a_v, h_u, h_v arrays of the control structure are required", who);
+  return 0;
+}
+
+VVPar par_of(const mom6hip_vertvisc_cs_t *cs) {
+  VVPar p;
+  p.Hmix = cs->Hmix; p.Hmix_stress = cs->Hmix_stress; p.Kvml_invZ2 = cs->Kvml_invZ2; p.Kv = cs->Kv; p.Hbbl = cs->Hbbl;
+  p.Kv_extra_bbl = cs->Kv_extra_bbl; p.harm_BL_val = cs->harm_BL_val; p.maxvel = cs->maxvel; p.CFL_trunc = cs->CFL_trunc;
+  p.vel_underflow = cs->vel_underflow; p.H_to_RZ = cs->H_to_RZ;
+  p.bottomdraglaw = cs->bottomdraglaw; p.harmonic_visc = cs->harmonic_visc; p.direct_stress = cs->direct_stress;
+  p.CFL_based_trunc = cs->CFL_based_trunc;
+  return p;
+}
+
+struct Sz { size_t h2, u2, v2, h3, u3, v3, ui, vi, hi; };
+Sz sizes(const m6::GridDev &g) {
+  Sz s;
+  s.h2 = sizeof(double) * (size_t)g.nih * g.njh; s.u2 = sizeof(double) * (size_t)(g.nih + 1) * g.njh;
+  s.v2 = sizeof(double) * (size_t)g.nih * (g.njh + 1);
+  s.h3 = s.h2 * g.nk; s.u3 = s.u2 * g.nk; s.v3 = s.v2 * g.nk;
+  s.ui = s.u2 * (g.nk + 1); s.vi = s.v2 * (g.nk + 1); s.hi = s.h2 * (g.nk + 1);
+  return s;
+}
+
+}  // namespace
+
+extern "C" int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, const double *u, const double *v,
+                                     const double *h, const double *dz, const mom6hip_vertvisc_type_t *visc, double dt,
+                                     int32_t memspace) {
+  (void)dt;
+  M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(coef): Module must be initialized before it is used.");
+  M6_REQUIRE(cs && u && v && h && visc, "vertvisc_coef: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "vertvisc_coef: bad memspace");
+  if (check_cs(cs, "vertvisc_coef")) return 1;
+  M6_REQUIRE(visc->Kv_shear_Bu == nullptr, "vertvisc_coef: visc%%Kv_shear_Bu is not provided by libmom6hip");
+  M6_REQUIRE(!cs->bottomdraglaw || (visc->Kv_bbl_u && visc->Kv_bbl_v && visc->bbl_thick_u && visc->bbl_thick_v),
+             "vertvisc_coef: BOTTOMDRAGLAW needs visc%%Kv_bbl_u/v and visc%%bbl_thick_u/v");
+  M6_REQUIRE(!(cs->Kvml_invZ2 > 0.0) || cs->Hmix > 0.0, "vertvisc_coef: KV_ML_INVZ2 needs HMIX_FIXED");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.bathyT, "vertvisc_coef: mask2dCu, mask2dCv and bathyT are required");
+  const Sz sz = sizes(g);
+  m6::Stager st(ctx, memspace);
+  CoefArgs A[2];
+  A[0].vel = st.in(u, sz.u3); A[1].vel = st.in(v, sz.v3);
+  const double *dh = st.in(h, sz.h3), *ddz = st.in(dz, sz.h3), *dks = st.in(visc->Kv_shear, sz.hi);
+  A[0].kv_bbl = st.in(visc->Kv_bbl_u, sz.u2); A[1].kv_bbl = st.in(visc->Kv_bbl_v, sz.v2);
+  A[0].bbl_thick = st.in(visc->bbl_thick_u, sz.u2); A[1].bbl_thick = st.in(visc->bbl_thick_v, sz.v2);
+  A[0].a = st.inout(cs->a_u, sz.ui); A[1].a = st.inout(cs->a_v, sz.vi);
+  A[0].hv = st.inout(cs->h_u, sz.u3); A[1].hv = st.inout(cs->h_v, sz.v3);
+  M6_REQUIRE(!st.failed(), "vertvisc_coef: staging failed");
+  for (int d = 0; d < 2; d++) {
+    A[d].g = g; A[d].p = par_of(cs); A[d].h = dh; A[d].dz = ddz; A[d].Kv_shear = dks;
+    const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
+    if (d == 0) hipLaunchKernelGGL(vv_coef_kernel<0>, grid, dim3(64), 0, ctx->stream, A[d]);
+    else hipLaunchKernelGGL(vv_coef_kernel<1>, grid, dim3(64), 0, ctx->stream, A[d]);
+  }
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+namespace {
+// the solve of both directions: velocities (remnant = 0) or visc_rem (remnant = 1)
+int run_solve(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_vertvisc_cs_t *cs, const double *const a[2], const double *const hv[2],
+              const double *const Ray[2], const double *dh, const double *const tau[2], double *const x[2], double *const tbot[2],
+              double dt, int remnant) {
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  double *c1 = (double *)st.scratch(sz.u3 > sz.v3 ? sz.u3 : sz.v3);
+  M6_REQUIRE(!st.failed() && c1, "vertvisc: out of device memory");
+  for (int d = 0; d < 2; d++) {
+    SolveArgs A;
+    A.g = g; A.p = par_of(cs); A.a = a[d]; A.hv = hv[d]; A.Ray = Ray[d]; A.h = dh; A.tau = tau[d]; A.x = x[d]; A.c1 = c1;
+    A.tbot = tbot[d]; A.dt = dt; A.remnant = remnant;
+    const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
+    if (d == 0) hipLaunchKernelGGL(vv_solve_kernel<0>, grid, dim3(64), 0, ctx->stream, A);
+    else hipLaunchKernelGGL(vv_solve_kernel<1>, grid, dim3(64), 0, ctx->stream, A);
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
+                                const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
+                                double *taux_bot, double *tauy_bot, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(visc): Module must be initialized before it is used.");
+  M6_REQUIRE(cs && u && v && h && taux && tauy && visc, "vertvisc: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "vertvisc: bad memspace");
+  if (check_cs(cs, "vertvisc")) return 1;
+  M6_REQUIRE(dt > 0.0 && cs->H_to_RZ > 0.0, "vertvisc: dt and GV%%H_to_RZ must be positive");
+  M6_REQUIRE(!cs->direct_stress || cs->Hmix_stress > 0.0, "vertvisc_init: HMIX_STRESS must be set to a positive value if DIRECT_STRESS is true.");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.areaT && g.IareaT && g.dy_Cu && g.dx_Cv, "vertvisc: a required grid metric is missing");
+  const Sz sz = sizes(g);
+  m6::Stager st(ctx, memspace);
+  double *x[2] = {st.inout(u, sz.u3), st.inout(v, sz.v3)};
+  const double *dh = st.in(h, sz.h3);
+  const double *tau[2] = {st.in(taux, sz.u2), st.in(tauy, sz.v2)};
+  const double *a[2] = {st.in((const double *)cs->a_u, sz.ui), st.in((const double *)cs->a_v, sz.vi)};
+  const double *hv[2] = {st.in((const double *)cs->h_u, sz.u3), st.in((const double *)cs->h_v, sz.v3)};
+  const double *Ray[2] = {st.in(visc->Ray_u, sz.u3), st.in(visc->Ray_v, sz.v3)};
+  double *tbot[2] = {st.inout(taux_bot, sz.u2), st.inout(tauy_bot, sz.v2)};      // (only the compute rows are written)
+  M6_REQUIRE(!st.failed(), "vertvisc: staging failed");
+  if (run_solve(ctx, st, cs, a, hv, Ray, dh, tau, x, tbot, dt, 0)) return 1;
+  // vertvisc_limit_vel :986
+  if (ctx->vv_ntrunc.reserve(sizeof(unsigned long long)) || !ctx->vv_ntrunc.p) return 1;
+  if (!ctx->vv_ntrunc_ready) {
+    M6_HIP(hipMemsetAsync(ctx->vv_ntrunc.p, 0, sizeof(unsigned long long), ctx->stream));
+    ctx->vv_ntrunc_ready = true;
+  }
+  for (int d = 0; d < 2; d++) {
+    LimitArgs L;
+    L.g = g; L.p = par_of(cs); L.h = dh; L.x = x[d]; L.ntrunc = (unsigned long long *)ctx->vv_ntrunc.p; L.dt = dt;
+    const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 255) / 256, g.jec - g.jsc + 1 + (d ? 1 : 0), g.nk);
+    if (d == 0) hipLaunchKernelGGL(vv_limit_kernel<0>, grid, dim3(256), 0, ctx->stream, L);
+    else hipLaunchKernelGGL(vv_limit_kernel<1>, grid, dim3(256), 0, ctx->stream, L);
+  }
+  M6_HIP(hipGetLastError());
+  const int rc = st.finish();
+  if (rc == 0 && memspace == MOM6HIP_MEM_HOST) return mom6hip_vertvisc_ntrunc(ctx, cs);
+  return rc;
+}
+
+// Adds the truncations counted on the device since the last call to cs->ntrunc (synchronises the stream).
+extern "C" int mom6hip_vertvisc_ntrunc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs) {
+  M6_REQUIRE(ctx && cs, "vertvisc_ntrunc: null argument");
+  if (!ctx->vv_ntrunc_ready) return 0;
+  unsigned long long n = 0;
+  M6_HIP(hipMemcpyAsync(&n, ctx->vv_ntrunc.p, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  M6_HIP(hipMemsetAsync(ctx->vv_ntrunc.p, 0, sizeof(n), ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  cs->ntrunc += (int64_t)n;
+  return 0;
+}
+
+extern "C" int mom6hip_vertvisc_remnant(mom6hip_ctx_t *ctx, const mom6hip_vertvisc_cs_t *cs, const mom6hip_vertvisc_type_t *visc,
+                                        double *visc_rem_u, double *visc_rem_v, double dt, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(remant): Module must be initialized before it is used.");
+  M6_REQUIRE(cs && visc && visc_rem_u && visc_rem_v, "vertvisc_remnant: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "vertvisc_remnant: bad memspace");
+  if (check_cs(cs, "vertvisc_remnant")) return 1;
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  m6::Stager st(ctx, memspace);
+  double *x[2] = {st.inout(visc_rem_u, sz.u3), st.inout(visc_rem_v, sz.v3)};
+  const double *a[2] = {st.in((const double *)cs->a_u, sz.ui), st.in((const double *)cs->a_v, sz.vi)};
+  const double *hv[2] = {st.in((const double *)cs->h_u, sz.u3), st.in((const double *)cs->h_v, sz.v3)};
+  const double *Ray[2] = {st.in(visc->Ray_u, sz.u3), st.in(visc->Ray_v, sz.v3)};
+  const double *tau[2] = {nullptr, nullptr};
+  double *tbot[2] = {nullptr, nullptr};
+  M6_REQUIRE(!st.failed(), "vertvisc_remnant: staging failed");
+  if (run_solve(ctx, st, cs, a, hv, Ray, nullptr, tau, x, tbot, dt, 1)) return 1;
+  return st.finish();
+}

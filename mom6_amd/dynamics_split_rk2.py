@@ -32,7 +32,7 @@ class MOM_dyn_split_RK2_CS:
     """MOM_dyn_split_RK2_CS (:84-268)."""
 
     def __init__(self, G: DeviceGrid, BE=0.6, BEGW=0.0, BT_USE_LAYER_FLUXES=True, STORE_CORIOLIS_ACCEL=True, USE_BT_CONT_TYPE=True,
-                 EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None):
+                 EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None, vertvisc=None):
         g = G.grid
         dev = "cuda"
         self.G = G
@@ -64,6 +64,12 @@ class MOM_dyn_split_RK2_CS:
             self.arrays[n] = Z3(pos); setattr(st, n, self.arrays[n].data_ptr())
         for n, pos in _abi.RK2_ARRAYS_2D:
             self.arrays[n] = Z2(pos); setattr(st, n, self.arrays[n].data_ptr())
+        # vertvisc_init (:1500): vertvisc=dict(KV=..., HBBL=..., ...) switches the library's vertical viscosity on
+        self.vertvisc_CSp = None
+        if vertvisc is not None:
+            from .vert_friction import vertvisc_init
+            self.vertvisc_CSp = vertvisc_init(G, **vertvisc)
+            st.vertvisc_CSp = C.addressof(self.vertvisc_CSp.st)
         self.module_is_initialized = False
 
     def __getattr__(self, n):
@@ -88,8 +94,9 @@ def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, 
                            thickness_diffuse_CSp=None, pbv=None, STOCH=None, Waves=None):
     """step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
     vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves) -- :289.
-    tv = (T, S); forces = (taux, tauy).  visc / VarMix / MEKE / ... belong to parameterisations this build does not
-    provide and must be None."""
+    tv = (T, S); forces = (taux, tauy); visc is a vert_friction.vertvisc_type (device arrays) when the control structure
+    was made with vertvisc=..., else None.  VarMix / MEKE / ... belong to parameterisations this build does not provide
+    and must be None."""
     if CS is None or not CS.module_is_initialized:
         raise Mom6HipError("step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
     if p_surf_begin is not None or p_surf_end is not None or Waves is not None or pbv is not None:
@@ -97,6 +104,13 @@ def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, 
     g = G.grid
     T, S = tv[0], tv[1]
     taux, tauy = forces
+    if CS.vertvisc_CSp is not None:
+        if visc is None:
+            raise Mom6HipError("step_MOM_dyn_split_RK2: the control structure has vertical viscosity on, visc is required")
+        CS._visc = visc      # keep the arrays and the struct alive
+        CS.st.visc = C.addressof(visc.st)
+    elif visc is not None:
+        raise Mom6HipError("step_MOM_dyn_split_RK2: visc given but the control structure was made without vertvisc=...")
     for a in (u_inst, v_inst, h, T, S, taux, tauy, uh, vh, uhtr, vhtr, eta_av):
         if not (a.is_cuda and a.is_contiguous() and a.dtype == torch.float64):
             raise Mom6HipError("step_MOM_dyn_split_RK2: all fields must be contiguous float64 CUDA tensors")

@@ -29,7 +29,7 @@ static void pass3(const mom6hip_grid_t *G, double *f, int pos) { orc_halo_update
 int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *u, const double *v,
                            const double *h, double *uh, double *vh, double dt) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
-  if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks) return 1;
+  if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || (CS->vertvisc_CSp && !CS->visc)) return 1;
   /* eta :1521-1535 */
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) CS->eta[H2(i, j)] = -G->Z_to_H * G->bathyT[H2(i, j)];
   for (int k = 1; k <= nz; k++) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
@@ -73,7 +73,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
                            double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int calc_dtbt) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
-  if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks) return 1;
+  if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || (CS->vertvisc_CSp && !CS->visc)) return 1;
   mom6hip_barotropic_cs_t *BT = CS->barotropic_CSp;
   const mom6hip_bt_cont_t *BTC = CS->BT_cont;
   const int BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
@@ -106,7 +106,12 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       vp[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_inst[V3(i, J, k)] + dt * v_bc_accel[V3(i, J, k)]);
   }
-  /* [set_viscous_ML, vertvisc_coef, vertvisc_remnant :592-600: visc_rem stays 1] ; pass_eta, pass_visc_rem :610-611 */
+  /* [set_viscous_ML :592 not provided]; vertvisc_coef, vertvisc_remnant :598-600 (without them visc_rem stays 1) */
+  if (CS->vertvisc_CSp) {
+    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt));
+    CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
+  }
+  /* pass_eta, pass_visc_rem :610-611 */
   orc_halo_update(G, eta, MOM6HIP_POS_H, 1);
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
   /* btcalc, bt_mass_source :627-630 */
@@ -134,7 +139,13 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
       up[U3(I, j, k)] = G->mask2dCu[ORC_U2(G, I, j)] * (u_inst[U3(I, j, k)] + dt_pred * (u_bc_accel[U3(I, j, k)] + CS->u_accel_bt[U3(I, j, k)]));
   }
-  /* [vertvisc_coef, vertvisc, vertvisc_remnant :717-744] ; pass_visc_rem :747, pass_uvp :751 */
+  /* vertvisc_coef, vertvisc, vertvisc_remnant :717-744 */
+  if (CS->vertvisc_CSp) {
+    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt_pred));
+    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL));
+    CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt_pred));
+  }
+  /* pass_visc_rem :747, pass_uvp :751 */
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
   pass3(G, up, MOM6HIP_POS_U); pass3(G, vp, MOM6HIP_POS_V);
   /* continuity :757 */
@@ -171,7 +182,13 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       v_inst[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_inst[V3(i, J, k)] + dt * (v_bc_accel[V3(i, J, k)] + CS->v_accel_bt[V3(i, J, k)]));
   }
-  /* [vertvisc_coef, vertvisc, vertvisc_remnant :974-994] ; h_av = h :1000-1002 */
+  /* vertvisc_coef, vertvisc, vertvisc_remnant :974-994 */
+  if (CS->vertvisc_CSp) {
+    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, u_inst, v_inst, h, NULL, CS->visc, dt));
+    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL));
+    CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
+  }
+  /* h_av = h :1000-1002 */
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = h[H3(i, j, k)];
   /* pass_visc_rem :1004, pass_uv :1008 */

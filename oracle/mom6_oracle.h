@@ -137,6 +137,14 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav);
 
 /* ---- MOM_dynamics_split_RK2 (oracle/dyn_split_rk2.c); every pointer in CS is a HOST pointer ------------------- */
+/* ---- MOM_vert_friction (oracle/vert_friction.c) ---- */
+int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const double *u, const double *v, const double *h,
+                      const double *dz, const mom6hip_vertvisc_type_t *visc, double dt);
+int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, double *v, const double *h, const double *taux,
+                 const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot);
+int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
+                         double *visc_rem_u, double *visc_rem_v, double dt);
+
 int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *u, const double *v,
                            const double *h, double *uh, double *vh, double dt);
 int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, double *u_inst, double *v_inst, double *h,

@@ -366,7 +366,7 @@ class DynState:
     the step with numpy arrays behind its pointers, and the prognostic state."""
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
-                 bound_coriolis=True, dtbt=None, **bt_kw):
+                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, **bt_kw):
         g = self.grid = grid
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
         self.ccs = continuity_cs(g.nk, g.Angstrom_H)
@@ -381,6 +381,9 @@ class DynState:
         cs.continuity_CSp = C.addressof(self.ccs); cs.CoriolisAdv = C.addressof(self.cor)
         cs.PressureForce_CSp = C.addressof(self.pcs); cs.eqn_of_state = C.addressof(self.eos)
         cs.barotropic_CSp = C.addressof(self.bcs); cs.BT_cont = C.addressof(self.bt) if use_bt_cont else None
+        if vertvisc is not None:      # (vertvisc_cs(...) struct, vertvisc_type(...) struct) of this module
+            self.vvcs, self.visc = vertvisc, visc
+            cs.vertvisc_CSp = C.addressof(vertvisc); cs.visc = C.addressof(visc)
         self.arrs = {}
         for n, pos in _abi.RK2_ARRAYS_3D:
             self.arrs[n] = grid.zeros3(pos); setattr(cs, n, self.arrs[n].ctypes.data)
@@ -409,6 +412,57 @@ class DynState:
         if rc:
             raise RuntimeError(f"orc_step_dyn_split_rk2 rc={rc}")
         self.nsteps += 1
+
+
+# ---- MOM_vert_friction -------------------------------------------------------------------------------------------
+def vertvisc_cs(grid, Kv, Hbbl, Hmix=0.0, bottomdraglaw=True, harmonic_visc=False, harm_BL_val=0.0, direct_stress=False,
+                Hmix_stress=None, Kvml_invZ2=0.0, Kv_extra_bbl=0.0, maxvel=3.0e8, CFL_based_trunc=True, CFL_trunc=0.5,
+                vel_underflow=0.0, answer_date=99991231):
+    """mom6hip_vertvisc_cs_t with numpy arrays behind a_u, a_v, h_u, h_v (kept on the struct as ._arrs)."""
+    cs = _abi.VertviscCS()
+    cs.Kv, cs.Hbbl, cs.Hmix = Kv, Hbbl, Hmix
+    cs.bottomdraglaw, cs.harmonic_visc, cs.direct_stress = int(bottomdraglaw), int(harmonic_visc), int(direct_stress)
+    cs.harm_BL_val = harm_BL_val
+    cs.Hmix_stress = (Hmix_stress if Hmix_stress is not None else Hmix) * grid.Z_to_H
+    cs.Kvml_invZ2, cs.Kv_extra_bbl = Kvml_invZ2, Kv_extra_bbl
+    cs.maxvel, cs.CFL_based_trunc, cs.CFL_trunc, cs.vel_underflow, cs.answer_date = maxvel, int(CFL_based_trunc), CFL_trunc, vel_underflow, answer_date
+    cs.H_to_RZ = grid.Rho0 * grid.H_to_Z
+    cs._arrs = {}
+    for n, pos, extra in _abi.VERTVISC_CS_ARRAYS:
+        shp = grid.shape3(pos)
+        cs._arrs[n] = np.zeros((shp[0] + extra,) + tuple(shp[1:]))
+        setattr(cs, n, cs._arrs[n].ctypes.data)
+    return cs
+
+
+def vertvisc_type(**arrays):
+    vt = _abi.VertviscType()
+    vt._keep = {n: np.ascontiguousarray(a) for n, a in arrays.items() if a is not None}
+    for n, a in vt._keep.items():
+        setattr(vt, n, a.ctypes.data)
+    return vt
+
+
+def vertvisc_coef(grid, cs, u, v, h, visc, dt, dz=None):
+    L = lib(); L.orc_vertvisc_coef.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS)] + [_dp] * 4 + [C.POINTER(_abi.VertviscType), C.c_double]
+    rc = L.orc_vertvisc_coef(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), None if dz is None else _p(dz), C.byref(visc), dt)
+    if rc:
+        raise RuntimeError(f"orc_vertvisc_coef rc={rc}")
+
+
+def vertvisc(grid, cs, u, v, h, taux, tauy, visc, dt, taux_bot=None, tauy_bot=None):
+    L = lib(); L.orc_vertvisc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS)] + [_dp] * 5 + [C.POINTER(_abi.VertviscType), C.c_double, _dp, _dp]
+    rc = L.orc_vertvisc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(taux), _p(tauy), C.byref(visc), dt,
+                        None if taux_bot is None else _p(taux_bot), None if tauy_bot is None else _p(tauy_bot))
+    if rc:
+        raise RuntimeError(f"orc_vertvisc rc={rc}")
+
+
+def vertvisc_remnant(grid, cs, visc, visc_rem_u, visc_rem_v, dt):
+    L = lib(); L.orc_vertvisc_remnant.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS), C.POINTER(_abi.VertviscType), _dp, _dp, C.c_double]
+    rc = L.orc_vertvisc_remnant(C.byref(grid.struct()), C.byref(cs), C.byref(visc), _p(visc_rem_u), _p(visc_rem_v), dt)
+    if rc:
+        raise RuntimeError(f"orc_vertvisc_remnant rc={rc}")
 
 
 # ---- z* regridding + velocity remapping ---------------------------------------------------------------------

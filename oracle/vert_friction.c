@@ -1,0 +1,283 @@
+/*
+ * vert_friction.c -- CPU restatement (TEST INFRASTRUCTURE, see mom6_oracle.h) of
+ * src/parameterizations/vertical/MOM_vert_friction.F90: vertvisc_coef (:1168-1763) with find_coupling_coef
+ * (:1768-2254), vertvisc (:526-1059) with vertvisc_limit_vel (:2259-2462), vertvisc_remnant (:1064-1162), for the
+ * branch libmom6hip provides (include/mom6hip.h, "MOM_vert_friction").  PARITY UNPINNED: the reference holds no
+ * known-answer vectors for this module; tests/test_vert_friction.py checks it through what the scheme guarantees
+ * (momentum budget of the implicit solve, bounds of visc_rem, the bottom-stress limit).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mom6_oracle.h"
+
+static inline double max2(double a, double b) { return a > b ? a : b; }
+static inline double min2(double a, double b) { return a < b ? a : b; }
+
+static int unsupported(const mom6hip_vertvisc_cs_t *CS) {
+  for (int n = 0; n < 7; n++) if (CS->unsupported[n]) return 1;
+  return CS->answer_date < 20190101;
+}
+
+/* one face column of vertvisc_coef + find_coupling_coef.  c0 / c1: 2-D offsets of the two cells; f2: of the face;
+ * hpl / fpl: plane strides of h-point and face arrays. */
+static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
+                        const double *vel, const double *h, const double *dz, long c0, long c1, long f2, long hpl, long fpl,
+                        const double *kv_bbl_2d, const double *bbl_thick_2d, double *a_out, double *h_out) {
+  const int nz = G->nk;
+  const double h_neglect = G->H_subroundoff, dz_neglect = G->dZ_subroundoff;
+  const double a_cpl_max = 1.0e37 * G->Z_to_H * 1.0;      /* 1.0e37 * GV%m_to_H * US%T_to_s :1283 */
+  double I_Hbbl = 1.0 / (CS->Hbbl + dz_neglect);          /* :1284 */
+  const double I_valBL = (CS->harm_BL_val > 0.0) ? 1.0 / CS->harm_BL_val : 0.0;   /* :1288 */
+  double kv_bbl = 0.0, bbl_thick = 0.0;
+  if (CS->bottomdraglaw) {      /* :1318-1322 */
+    kv_bbl = kv_bbl_2d[f2];
+    bbl_thick = bbl_thick_2d[f2] + dz_neglect;
+    I_Hbbl = 1.0 / bbl_thick;
+  }
+  double *w = (double *)malloc(sizeof(double) * (size_t)(7 * nz + 3 * (nz + 1)));
+  double *h_harm = w, *h_arith = w + nz, *h_delta = w + 2 * nz, *dz_harm = w + 3 * nz, *dz_arith = w + 4 * nz, *hvel = w + 5 * nz,
+         *dz_vel = w + 6 * nz, *z_i = w + 7 * nz, *a_cpl = z_i + (nz + 1), *Kv_tot = a_cpl + (nz + 1);
+#define DZ(c, k) (dz ? dz[(c) + hpl * (k)] : G->H_to_Z * h[(c) + hpl * (k)])      /* thickness_to_dz, Boussinesq */
+  for (int k = 0; k < nz; k++) {      /* :1324-1330 */
+    const double h0 = h[c0 + hpl * k], h1 = h[c1 + hpl * k];
+    h_harm[k] = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);
+    h_arith[k] = 0.5 * (h1 + h0);
+    h_delta[k] = h1 - h0;
+    const double d0 = DZ(c0, k), d1 = DZ(c1, k);
+    dz_harm[k] = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+    dz_arith[k] = 0.5 * (d1 + d0);
+  }
+  const double Dmin = min2(G->bathyT[c0], G->bathyT[c1]);      /* :1331 */
+  if (CS->harmonic_visc) {      /* :1363-1375 */
+    z_i[nz] = 0.0;
+    for (int k = nz - 1; k >= 0; k--) {
+      hvel[k] = h_harm[k];
+      dz_vel[k] = dz_harm[k];
+      if (vel[f2 + fpl * k] * h_delta[k] < 0) {
+        const double z2 = z_i[k + 1], botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        hvel[k] = (1.0 - botfn) * h_harm[k] + botfn * h_arith[k];
+        dz_vel[k] = (1.0 - botfn) * dz_harm[k] + botfn * dz_arith[k];
+      }
+      z_i[k] = z_i[k + 1] + dz_harm[k] * I_Hbbl;
+    }
+  } else {      /* :1376-1408 */
+    double zh = 0.0, zcol0 = -G->bathyT[c0], zcol1 = -G->bathyT[c1];
+    z_i[nz] = 0.0;
+    for (int k = nz - 1; k >= 0; k--) {
+      zcol0 = zcol0 + DZ(c0, k); zcol1 = zcol1 + DZ(c1, k);
+      zh = zh + dz_harm[k];
+      const double z_clear = max2(zcol0, zcol1) + Dmin;
+      z_i[k] = max2(zh, z_clear) * I_Hbbl;
+      hvel[k] = h_arith[k];
+      dz_vel[k] = dz_arith[k];
+      if (vel[f2 + fpl * k] * h_delta[k] > 0) {
+        if (zh * I_Hbbl < CS->harm_BL_val) {
+          hvel[k] = h_harm[k];
+          dz_vel[k] = dz_harm[k];
+        } else {
+          double z2_wt = 1.0;
+          if (zh * I_Hbbl < 2.0 * CS->harm_BL_val) z2_wt = max2(0.0, min2(1.0, zh * I_Hbbl * I_valBL - 1.0));
+          const double z2 = z2_wt * (max2(zh, z_clear) * I_Hbbl);
+          const double botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+          hvel[k] = (1.0 - botfn) * h_arith[k] + botfn * h_harm[k];
+          dz_vel[k] = (1.0 - botfn) * dz_arith[k] + botfn * dz_harm[k];
+        }
+      }
+    }
+  }
+
+  /* ---- find_coupling_coef(a_cpl, dz_vel, do_i, dz_harm, bbl_thick, kv_bbl, z_i, ...) :1768; its hvel is dz_vel, its
+   * h_harm is dz_harm, its h_neglect is GV%dZ_subroundoff ---- */
+  {
+    const double hn = dz_neglect, I_amax = 0.0;      /* :1846, :1858 (answer_date >= 20190101) */
+    for (int K = 0; K <= nz; K++) { a_cpl[K] = 0.0; Kv_tot[K] = 0.0; }
+    Kv_tot[0] = 0.0;                                  /* :1868 */
+    for (int K = 1; K <= nz; K++) Kv_tot[K] = CS->Kv; /* :1869-1871 */
+    if (CS->Kvml_invZ2 > 0.0) {                       /* :1873-1886 */
+      const double I_Hmix = 1.0 / (CS->Hmix + hn);
+      double z_t = hn * I_Hmix;
+      for (int K = 1; K < nz; K++) {
+        z_t = z_t + dz_harm[K - 1] * I_Hmix;
+        Kv_tot[K] = CS->Kv + CS->Kvml_invZ2 / ((z_t * z_t) * (1.0 + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
+      }
+    }
+    if (visc->Kv_shear) {                             /* :1888-1928 */
+      for (int K = 1; K < nz; K++) {
+        const double Kv_add = 0.5 * (visc->Kv_shear[c0 + hpl * K] + visc->Kv_shear[c1 + hpl * K]);
+        Kv_tot[K] = Kv_tot[K] + Kv_add;
+      }
+    }
+    if (CS->bottomdraglaw) {                          /* :1948-1976 */
+      double dhc = dz_vel[nz - 1] * 0.5;
+      if (dhc < bbl_thick) a_cpl[nz] = kv_bbl / ((dhc + hn) + I_amax * kv_bbl);
+      else a_cpl[nz] = kv_bbl / ((bbl_thick + hn) + I_amax * kv_bbl);
+      for (int K = nz - 1; K >= 1; K--) {
+        const double z2 = z_i[K], botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot[K] = Kv_tot[K] + (kv_bbl - CS->Kv) * botfn;
+        dhc = 0.5 * (dz_vel[K] + dz_vel[K - 1]);
+        double h_shear;
+        if (dhc > bbl_thick) h_shear = ((1.0 - botfn) * dhc + botfn * bbl_thick) + hn;
+        else h_shear = dhc + hn;
+        a_cpl[K] = Kv_tot[K] / (h_shear + (I_amax * Kv_tot[K]));
+      }
+    } else if (fabs(CS->Kv_extra_bbl) > 0.0) {        /* :1977-1995 */
+      a_cpl[nz] = (Kv_tot[nz] + CS->Kv_extra_bbl) / ((0.5 * dz_vel[nz - 1] + hn) + I_amax * (Kv_tot[nz] + CS->Kv_extra_bbl));
+      for (int K = nz - 1; K >= 1; K--) {
+        const double z2 = z_i[K], botfn = 1.0 / (1.0 + 0.09 * z2 * z2 * z2 * z2 * z2 * z2);
+        Kv_tot[K] = Kv_tot[K] + CS->Kv_extra_bbl * botfn;
+        const double h_shear = 0.5 * (dz_vel[K] + dz_vel[K - 1] + hn);
+        a_cpl[K] = Kv_tot[K] / (h_shear + I_amax * Kv_tot[K]);
+      }
+    } else {                                          /* :1996-2007 */
+      a_cpl[nz] = Kv_tot[nz] / ((0.5 * dz_vel[nz - 1] + hn) + I_amax * Kv_tot[nz]);
+      for (int K = nz - 1; K >= 1; K--) {
+        const double h_shear = 0.5 * (dz_vel[K] + dz_vel[K - 1] + hn);
+        a_cpl[K] = Kv_tot[K] / (h_shear + I_amax * Kv_tot[K]);
+      }
+    }
+    /* no shelf, no surface boundary layer scheme (:2012-2252 not taken) */
+  }
+  for (int K = 0; K <= nz; K++) a_out[f2 + fpl * K] = min2(a_cpl_max, a_cpl[K] + 0.0);      /* :1504-1506 (a_cpl_gl90 = 0) */
+  for (int k = 0; k < nz; k++) h_out[f2 + fpl * k] = hvel[k] + h_neglect;                  /* :1510 */
+#undef DZ
+  free(w);
+}
+
+int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const double *u, const double *v, const double *h,
+                      const double *dz, const mom6hip_vertvisc_type_t *visc, double dt) {
+  (void)dt;
+  if (unsupported(CS) || visc->Kv_shear_Bu) return 1;
+  if (CS->bottomdraglaw && !(visc->Kv_bbl_u && visc->Kv_bbl_v && visc->bbl_thick_u && visc->bbl_thick_v)) return 1;
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
+  const long nih = ORC_NIH(G), njh = ORC_NJH(G), hpl = nih * njh, upl = (nih + 1) * njh, vpl = nih * (njh + 1);
+  for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
+    if (!(G->mask2dCu[ORC_U2(G, I, j)] > 0.0)) continue;
+    coef_column(G, CS, visc, u, h, dz, ORC_H2(G, I, j), ORC_H2(G, I + 1, j), ORC_U2(G, I, j), hpl, upl, visc->Kv_bbl_u,
+                visc->bbl_thick_u, CS->a_u, CS->h_u);
+  }
+  for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
+    if (!(G->mask2dCv[ORC_V2(G, i, J)] > 0.0)) continue;
+    coef_column(G, CS, visc, v, h, dz, ORC_H2(G, i, J), ORC_H2(G, i, J + 1), ORC_V2(G, i, J), hpl, vpl, visc->Kv_bbl_v,
+                visc->bbl_thick_v, CS->a_v, CS->h_v);
+  }
+  return 0;
+}
+
+/* the implicit solve of one face column, :646-760 (u) and :862-960 (v): `x` is the velocity (vertvisc) or, with
+ * remnant != 0, visc_rem (vertvisc_remnant :1105-1124).  c1 is work space of nz doubles. */
+static void solve_column(int nz, double dt, const double *a, const double *hv, const double *Ray, long f2, long fpl, double *x,
+                         double surface_stress, int remnant, double *c1) {
+  double b_denom_1 = hv[f2] + dt * ((Ray ? Ray[f2] : 0.0) + a[f2]);
+  double b1 = 1.0 / (b_denom_1 + dt * a[f2 + fpl]);
+  double d1 = b_denom_1 * b1;
+  if (remnant) x[f2] = b1 * hv[f2];
+  else x[f2] = b1 * (hv[f2] * x[f2] + surface_stress);
+  for (int k = 1; k < nz; k++) {
+    const long n = f2 + fpl * k;
+    c1[k] = dt * a[n] * b1;
+    b_denom_1 = hv[n] + dt * ((Ray ? Ray[n] : 0.0) + a[n] * d1);
+    b1 = 1.0 / (b_denom_1 + dt * a[n + fpl]);
+    d1 = b_denom_1 * b1;
+    if (remnant) x[n] = (hv[n] + dt * a[n] * x[n - fpl]) * b1;
+    else x[n] = (hv[n] * x[n] + dt * a[n] * x[n - fpl]) * b1;
+  }
+  for (int k = nz - 2; k >= 0; k--) x[f2 + fpl * k] = x[f2 + fpl * k] + c1[k + 1] * x[f2 + fpl * (k + 1)];
+}
+
+int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, double *v, const double *h, const double *taux,
+                 const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot) {
+  if (unsupported(CS)) return 1;
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const long nih = ORC_NIH(G), njh = ORC_NJH(G), hpl = nih * njh, upl = (nih + 1) * njh, vpl = nih * (njh + 1);
+  const double dt_Rho0 = dt / CS->H_to_RZ, h_neglect = G->H_subroundoff;      /* :611-612 */
+  double Hmix = 0.0, I_Hmix = 0.0;
+  if (CS->direct_stress) { Hmix = CS->Hmix_stress; I_Hmix = 1.0 / Hmix; }       /* :607-610 */
+  double *c1 = (double *)malloc(sizeof(double) * (size_t)nz);
+  for (int dir = 0; dir < 2; dir++) {
+    double *x = dir ? v : u;
+    const double *tau = dir ? tauy : taux, *mask = dir ? G->mask2dCv : G->mask2dCu, *a = dir ? CS->a_v : CS->a_u,
+                 *hv = dir ? CS->h_v : CS->h_u, *Ray = dir ? visc->Ray_v : visc->Ray_u;
+    double *tbot = dir ? tauy_bot : taux_bot;
+    const long fpl = dir ? vpl : upl;
+    for (int j = (dir ? js - 1 : js); j <= je; j++) for (int i = (dir ? is : is - 1); i <= ie; i++) {
+      const long f2 = dir ? ORC_V2(G, i, j) : ORC_U2(G, i, j);
+      const long c0 = ORC_H2(G, i, j), cc1 = dir ? ORC_H2(G, i, j + 1) : ORC_H2(G, i + 1, j);
+      const int do_i = mask[f2] > 0.0;
+      double surface_stress;
+      if (CS->direct_stress) {      /* :671-685 */
+        surface_stress = 0.0;
+        if (do_i) {
+          double zDS = 0.0;
+          const double stress = dt_Rho0 * tau[f2];
+          for (int k = 0; k < nz; k++) {
+            const double h_a = 0.5 * (h[c0 + hpl * k] + h[cc1 + hpl * k]) + h_neglect;
+            double hfr = 1.0;
+            if ((zDS + h_a) > Hmix) hfr = (Hmix - zDS) / h_a;
+            x[f2 + fpl * k] = x[f2 + fpl * k] + I_Hmix * hfr * stress;
+            zDS = zDS + h_a;
+            if (zDS >= Hmix) break;
+          }
+        }
+      } else {
+        surface_stress = dt_Rho0 * (mask[f2] * tau[f2]);      /* :687 */
+      }
+      if (do_i) solve_column(nz, dt, a, hv, Ray, f2, fpl, x, surface_stress, 0, c1);
+      if (tbot) {      /* :798-805 (every point of the row, masked or not) */
+        tbot[f2] = CS->H_to_RZ * (x[f2 + fpl * (nz - 1)] * a[f2 + fpl * nz]);
+        if (Ray) for (int k = 0; k < nz; k++) tbot[f2] = tbot[f2] + CS->H_to_RZ * (Ray[f2 + fpl * k] * x[f2 + fpl * k]);
+      }
+    }
+  }
+  free(c1);
+  /* vertvisc_limit_vel :2259-2462 (no U_TRUNC_FILE / V_TRUNC_FILE) */
+  {
+    const double maxvel = CS->maxvel, truncvel = 0.9 * maxvel, H_report = 6.0 * G->Angstrom_H;
+    for (int dir = 0; dir < 2; dir++) {
+      double *x = dir ? v : u;
+      const double *dL = dir ? G->dx_Cv : G->dy_Cu;
+      const long fpl = dir ? vpl : upl;
+      for (int k = 0; k < nz; k++) for (int j = (dir ? js - 1 : js); j <= je; j++) for (int i = (dir ? is : is - 1); i <= ie; i++) {
+        const long f2 = dir ? ORC_V2(G, i, j) : ORC_U2(G, i, j), n = f2 + fpl * k;
+        const long c0 = ORC_H2(G, i, j), cc1 = dir ? ORC_H2(G, i, j + 1) : ORC_H2(G, i + 1, j);
+        const double hsum = h[c0 + hpl * k] + h[cc1 + hpl * k];
+        if (CS->CFL_based_trunc) {
+          if (fabs(x[n]) < CS->vel_underflow) { x[n] = 0.0; }
+          else if ((x[n] * (dt * dL[f2])) * G->IareaT[cc1] < -CS->CFL_trunc) {
+            x[n] = (-0.9 * CS->CFL_trunc) * (G->areaT[cc1] / (dt * dL[f2]));
+            if (hsum > H_report) CS->ntrunc = CS->ntrunc + 1;
+          } else if ((x[n] * (dt * dL[f2])) * G->IareaT[c0] > CS->CFL_trunc) {
+            x[n] = (0.9 * CS->CFL_trunc) * (G->areaT[c0] / (dt * dL[f2]));
+            if (hsum > H_report) CS->ntrunc = CS->ntrunc + 1;
+          }
+        } else {
+          if (fabs(x[n]) < CS->vel_underflow) { x[n] = 0.0; }
+          else if (fabs(x[n]) > maxvel) {
+            x[n] = copysign(truncvel, x[n]);
+            if (hsum > H_report) CS->ntrunc = CS->ntrunc + 1;
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
+                         double *visc_rem_u, double *visc_rem_v, double dt) {
+  if (unsupported(CS)) return 1;
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const long nih = ORC_NIH(G), njh = ORC_NJH(G), upl = (nih + 1) * njh, vpl = nih * (njh + 1);
+  double *c1 = (double *)malloc(sizeof(double) * (size_t)nz);
+  for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
+    const long f2 = ORC_U2(G, I, j);
+    if (G->mask2dCu[f2] > 0.0) solve_column(nz, dt, CS->a_u, CS->h_u, visc->Ray_u, f2, upl, visc_rem_u, 0.0, 1, c1);
+  }
+  for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
+    const long f2 = ORC_V2(G, i, J);
+    if (G->mask2dCv[f2] > 0.0) solve_column(nz, dt, CS->a_v, CS->h_v, visc->Ray_v, f2, vpl, visc_rem_v, 0.0, 1, c1);
+  }
+  free(c1);
+  return 0;
+}

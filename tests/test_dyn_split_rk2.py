@@ -104,3 +104,73 @@ def test_step_matches_oracle_bitwise(kw):
     cap, lau = dg.bt_graph_stats()      # one-tile domain: every btstep replays a hipGraph of its subcycle
     assert lau == 6 and 1 <= cap <= 6, (cap, lau)
     dg.close()
+
+
+def _visc_arrays(g, seed=9):
+    rng = np.random.default_rng(seed)
+    su, sv = g.shape2(_abi.POS_U), g.shape2(_abi.POS_V)
+    return dict(Kv_bbl_u=1.0e-3 * (0.5 + rng.random(su)), Kv_bbl_v=1.0e-3 * (0.5 + rng.random(sv)),
+                bbl_thick_u=2.0 + 8.0 * rng.random(su), bbl_thick_v=2.0 + 8.0 * rng.random(sv))
+
+
+def test_oracle_step_with_vertvisc_conserves_volume_and_damps():
+    """the step with the library's vertical viscosity: volume is still conserved, visc_rem < 1 feeds the
+    barotropic solver, and the bottom drag takes kinetic energy out compared with the inviscid step"""
+    g, d, taux, tauy = make_case()
+    dt = 1800.0
+    arrs = _visc_arrays(g)
+    inv = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt)
+    vis = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, vertvisc=orc.vertvisc_cs(g, Kv=1.0e-2, Hbbl=10.0),
+                       visc=orc.vertvisc_type(**arrs))
+    v0 = volume(g, vis.h)
+    for st in (inv, vis):
+        st.bcs.dtbt = dt / 12.6
+        for n in range(4):
+            st.step(0.0 * taux, tauy)
+            assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0
+    # (flux-form continuity; only the Angstrom floor of nearly vanished layers adds volume)
+    assert abs(volume(g, vis.h) - v0) <= 1e-9 * v0
+    vr = vis.arrs["visc_rem_u"]
+    assert vr.max() <= 1.0 + 1e-12 and vr[:, np.asarray(g.mask2dCu) > 0].min() < 1.0
+    ke = lambda s: float((s.u ** 2).sum() + (s.v ** 2).sum())
+    assert ke(vis) < ke(inv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(ni=44, nj=40, nk=2, reentrant_y=True), dict(use_bt_cont=False, nk=5)],
+                         ids=["default", "44x40x2", "no_bt_cont"])
+def test_step_with_vertvisc_matches_oracle_bitwise(kw):
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    kw = dict(kw)
+    use_bt = kw.pop("use_bt_cont", True)
+    g, d, taux, tauy = make_case(**kw)
+    dt = 1800.0
+    arrs = _visc_arrays(g)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, use_bt_cont=use_bt,
+                       vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=1.0e-3), visc=orc.vertvisc_type(**arrs))
+    ref.bcs.dtbt = dt / 9.6
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, USE_BT_CONT_TYPE=use_bt, coriolis=dict(bound_coriolis=True),
+                                  barotropic=dict(BT_THICK_SCHEME="FROM_BT_CONT" if use_bt else "HARMONIC"),
+                                  vertvisc=dict(KV=1.0e-3, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-3))
+    CS.barotropic_CSp.st.dtbt = ref.bcs.dtbt
+    visc = vertvisc_type(**{n: T(a) for n, a in arrs.items()})
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy)
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS)
+        dg.sync()
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("vh", vh, ref.vh),
+                           ("eta_av", eta_av, ref.eta_av), ("visc_rem_u", CS.visc_rem_u, ref.arrs["visc_rem_u"]),
+                           ("visc_rem_v", CS.visc_rem_v, ref.arrs["visc_rem_v"]), ("a_u", CS.vertvisc_CSp.a_u, ref.vvcs._arrs["a_u"]),
+                           ("u_av", CS.u_av, ref.arrs["u_av"])):
+            an = a.cpu().numpy()
+            assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+    dg.close()
