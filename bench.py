@@ -6,7 +6,8 @@
 
 A "step" is one baroclinic time step (DT) of the model on the synthetic global C-grid named in
 `config.workload`: step_MOM_dyn_split_RK2 (src/core/MOM_dynamics_split_RK2.F90:289-1176) -- PressureForce,
-continuity x3, btstep x2 (+ btcalc, bt_mass_source), CorAdCalc x2, the momentum sweeps and the group passes --
+continuity x3, btstep x2 (+ btcalc, bt_mass_source), CorAdCalc x2, vertvisc_coef x3 / vertvisc x2 / vertvisc_remnant x3,
+the momentum sweeps and the group passes --
 and every DT_THERM/DT-th step advect_tracer (src/core/MOM.F90:1438) and the ALE block (:1647-1700: ALE_regrid,
 ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities).  The state
 evolves: every step starts from the previous step's u, v, h, T, S.  `config.not_yet_in_step` lists what the
@@ -30,6 +31,10 @@ DT_THERM = 3600.0          # tracer/thermodynamic step [s]
 NTR = 4                    # T, S + 2 passive tracers
 SCHEME = "PPM:H3"
 REMAP_SCHEME = "PPM_H4"    # OM4-class remapping scheme
+# vertvisc_init parameters: background viscosity, and the fixed-depth mixed-layer viscosity KV_ML_INVZ2 over HMIX_FIXED that
+# carries the wind stress into the top 20 m (no boundary-layer scheme feeds visc%Kv_shear here)
+VERTVISC = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
+KV_BBL = 0.003 * 0.1 * 10.0   # cdrag * |u| * HBBL [m2 s-1]
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.98   # REGRID_TIME_SCALE >> DT_THERM: each ALE call moves the grid 2 % of the way to z* (see Model)
 
@@ -86,7 +91,14 @@ class Model:
         yy = (torch.arange(grid.shape2(U)[0], device=dev, dtype=torch.float64) + j0) / (gg.nj + 2 * gg.halo) * 3.1416
         self.taux = (0.1 * torch.cos(2 * yy)[:, None] * mu).contiguous()
         self.tauy = Z(V, False)
-        self.CS = initialize_dyn_split_RK2(self.u, self.v, self.h, self.uh, self.vh, DT, self.dg, coriolis=dict(bound_coriolis=True))
+        self.CS = initialize_dyn_split_RK2(self.u, self.v, self.h, self.uh, self.vh, DT, self.dg, coriolis=dict(bound_coriolis=True),
+                                           vertvisc=VERTVISC)
+        # visc%Kv_bbl_[uv], visc%bbl_thick_[uv]: set_viscous_BBL is not provided, the bottom boundary layer
+        # is prescribed: HBBL thick with the viscosity a linear drag law of 0.1 m/s would give
+        from mom6_amd.vert_friction import vertvisc_type
+        mv = torch.as_tensor(grid.mask2dCv, device=dev)
+        self.visc = vertvisc_type(Kv_bbl_u=(KV_BBL * mu).contiguous(), Kv_bbl_v=(KV_BBL * mv).contiguous(),
+                                  bbl_thick_u=(VERTVISC["HBBL"] * mu).contiguous(), bbl_thick_v=(VERTVISC["HBBL"] * mv).contiguous())
         self.adv_cs = tracer_advect_init(DT, scheme)
         self.remap_cs = initialize_remapping(REMAP_SCHEME)
         # z* target: the nominal layer thicknesses of the synthetic state (synth.make_dynamics_state).  The state
@@ -112,7 +124,7 @@ class Model:
         from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
         from mom6_amd.tracer_advect import advect_tracer
         n = self.nstep
-        step_MOM_dyn_split_RK2(self.u, self.v, self.h, (self.T, self.S), None, None, DT, (self.taux, self.tauy), None, None,
+        step_MOM_dyn_split_RK2(self.u, self.v, self.h, (self.T, self.S), self.visc, None, DT, (self.taux, self.tauy), None, None,
                                self.uh, self.vh, self.uhtr, self.vhtr, self.eta_av, self.dg, self.CS, calc_dtbt=(n == 0))
         if (n + 1) % self.steps_per_advect == 0:      # step_MOM_thermo / step_MOM_tracer_dyn (src/core/MOM.F90:1438, :1662)
             tr = [self.T, self.S] + self.passive
@@ -278,6 +290,28 @@ class Components:
             ("CorAdCalc[pred]", lambda: CorAdCalc(self.u_av, self.v_av, self.h2, self.uh, self.vh, self.CAu, self.CAv, None, dg,
                                                   self.cor_cs)),
         ]
+        # the vertical viscosity of the step: vertvisc_coef + vertvisc_remnant (:598-600), then twice vertvisc_coef +
+        # vertvisc + vertvisc_remnant (:717-744, :974-994); velocities are copies so the bench state stays stationary
+        from mom6_amd.vert_friction import vertvisc, vertvisc_coef, vertvisc_remnant
+        if not hasattr(self, "vv_cs"):
+            from mom6_amd.vert_friction import vertvisc_init, vertvisc_type
+            self.vv_cs = vertvisc_init(dg, **VERTVISC)
+            g = self.g
+            mu, mv = (torch.as_tensor(m, device=d["u"].device) for m in (g.mask2dCu, g.mask2dCv))
+            self.vv_visc = vertvisc_type(Kv_bbl_u=(KV_BBL * mu).contiguous(), Kv_bbl_v=(KV_BBL * mv).contiguous(),
+                                         bbl_thick_u=(VERTVISC["HBBL"] * mu).contiguous(), bbl_thick_v=(VERTVISC["HBBL"] * mv).contiguous())
+            self.vv_u, self.vv_v = d["u"].clone(), d["v"].clone()
+            self.vv_ru, self.vv_rv = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
+
+        def vv_full(dt):
+            self.vv_u.copy_(d["u"]); self.vv_v.copy_(d["v"])
+            vertvisc_coef(self.vv_u, self.vv_v, d["h"], None, None, self.vv_visc, None, dt, dg, self.vv_cs)
+            vertvisc(self.vv_u, self.vv_v, d["h"], (self.taux, self.tauy), self.vv_visc, dt, None, None, None, dg, self.vv_cs)
+            vertvisc_remnant(self.vv_visc, self.vv_ru, self.vv_rv, dt, dg, self.vv_cs)
+        out.append(("vertvisc_coef+remnant", lambda: (vertvisc_coef(d["u"], d["v"], d["h"], None, None, self.vv_visc, None, DT, dg, self.vv_cs),
+                                                    vertvisc_remnant(self.vv_visc, self.vv_ru, self.vv_rv, DT, dg, self.vv_cs))))
+        out.append(("vertvisc[pred]", lambda: vv_full(0.6 * DT)))
+        out.append(("vertvisc[corr]", lambda: vv_full(DT)))
         if (n + 1) % self.steps_per_advect == 0:
             a = self.adv
 
@@ -308,7 +342,10 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     adv = synth.make_advection_state(g, ntr=4, seed=1, hot_frac=0.0)
     passive = [t.numpy() for t in adv["tr"][2:4]]
     del adv
-    st = orc.DynState(g, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], DT)
+    vv = orc.vertvisc_cs(g, Kv=VERTVISC["KV"], Hbbl=VERTVISC["HBBL"], Hmix=VERTVISC["HMIX_FIXED"], Kvml_invZ2=VERTVISC["KV_ML_INVZ2"])
+    mu, mv = np.asarray(g.mask2dCu), np.asarray(g.mask2dCv)
+    visc = orc.vertvisc_type(Kv_bbl_u=KV_BBL * mu, Kv_bbl_v=KV_BBL * mv, bbl_thick_u=VERTVISC["HBBL"] * mu, bbl_thick_v=VERTVISC["HBBL"] * mv)
+    st = orc.DynState(g, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], DT, vertvisc=vv, visc=visc)
     yy = np.arange(g.shape2(_abi.POS_U)[0]) / (g.nj + 2 * g.halo) * 3.1416
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = g.zeros2(_abi.POS_V)
     loop_s = C.c_double.in_dll(orc.lib(), "orc_btstep_loop_seconds")
@@ -406,6 +443,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     health = M.health()
+    from mom6_amd.vert_friction import vertvisc_ntrunc
+    vertvisc_ntrunc(M.dg, M.CS.vertvisc_CSp)      # CS%ntrunc: velocity truncations during the run
     if health["nan"] or health["umax"] > 50.0 or health["hmin"] < 0.0:
         sys.exit(f"bench.py: the model state is not healthy after {M.nstep} steps: {health}")
 
@@ -423,10 +462,13 @@ def main():
             "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x, ~25% land, "
                         f"T, S + 2 passive tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
             "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
-                    "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], momentum sweeps, "
+                    "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], vertvisc_coef x3 + "
+                    "vertvisc x2 + vertvisc_remnant x3 [BOTTOMDRAGLAW, prescribed bottom boundary layer], momentum sweeps, "
                     f"group passes); every {spa} steps advect_tracer [{a.scheme}] + ALE regrid/remap [{REMAP_SCHEME}]",
             "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
-            "not_yet_in_step": ["vertvisc / set_viscous_ML / horizontal_viscosity (SURVEY 8f: the step runs with zero viscosities)"],
+            "not_yet_in_step": ["set_viscous_BBL / set_viscous_ML (the bottom boundary layer is prescribed: "
+                                f"bbl_thick = {VERTVISC['HBBL']} m, Kv_bbl = {KV_BBL} m2/s)", "horizontal_viscosity (diffu = diffv = 0)"],
+            "vertvisc": dict(VERTVISC, Kv_bbl=KV_BBL, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)),
             "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE >> DT_THERM), remap of T, S + 2 tracers "
                    f"and of u, v [{REMAP_SCHEME}]",
             "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),
@@ -470,6 +512,10 @@ def main():
         # (the null stream, which is also torch's current stream here)
         S = Components(grid, dom, device, a.scheme)
         comp = {}
+        for n in range(spa):      # untimed pass: work-space allocations and first-launch costs stay out of the timings
+            for name, f in S.parts(n):
+                f()
+        torch.cuda.synchronize()
         for n in range(spa):
             for name, f in S.parts(n):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -522,6 +522,12 @@ int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, d
                      const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
                      int32_t memspace);
 
+/* vertvisc followed by vertvisc_remnant with the same dt -- the pair the split RK2 step calls at :731-744 and :985-994 --
+ * in one pass over the coupling coefficients; the results are those of the two calls. */
+int mom6hip_vertvisc_and_remnant(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
+                                 const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
+                                 double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v, int32_t memspace);
+
 /* CS%ntrunc: vertvisc counts truncations on the device; this adds the count since the last call to cs->ntrunc
  * (synchronises the stream).  With MOM6HIP_MEM_HOST vertvisc does it itself. */
 int mom6hip_vertvisc_ntrunc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs);

@@ -164,12 +164,43 @@ struct SolveArgs {
   m6::GridDev g;
   VVPar p;
   const double *a, *hv, *Ray, *h, *tau;
-  double *x, *c1, *tbot;
+  double *x, *xr, *c1, *tbot;      // x: velocity (or null), xr: visc_rem (or null)
+  unsigned long long *ntrunc;      // non-null: vertvisc_limit_vel is applied as the final velocities are stored
   double dt;
-  int remnant;
 };
 
-// vertvisc :646-760 / :862-960 and vertvisc_remnant :1105-1155 for one face column
+// vertvisc_limit_vel :2346-2370 / :2431-2455 for one point (no truncation files); returns the value to store
+template <int DIR>
+__device__ __forceinline__ double limit_vel(const m6::GridDev &g, const VVPar &P, double xv, double dt, double dL, long c0, long c1,
+                                            const double *h, long hoff, unsigned long long *ntrunc) {
+  bool trunc = false;
+  double out = xv;
+  if (P.CFL_based_trunc) {
+    if (fabs(xv) < P.vel_underflow) { out = 0.0; }
+    else if ((xv * (dt * dL)) * g.IareaT[c1] < -P.CFL_trunc) {
+      out = (-0.9 * P.CFL_trunc) * (g.areaT[c1] / (dt * dL));
+      trunc = true;
+    } else if ((xv * (dt * dL)) * g.IareaT[c0] > P.CFL_trunc) {
+      out = (0.9 * P.CFL_trunc) * (g.areaT[c0] / (dt * dL));
+      trunc = true;
+    }
+  } else {
+    const double maxvel = P.maxvel, truncvel = 0.9 * maxvel;
+    if (fabs(xv) < P.vel_underflow) { out = 0.0; }
+    else if (fabs(xv) > maxvel) {
+      out = copysign(truncvel, xv);
+      trunc = true;
+    }
+  }
+  if (trunc && (h[c0 + hoff] + h[c1 + hoff] > 6.0 * g.Angstrom_H)) atomicAdd(ntrunc, 1ull);
+  return out;
+}
+
+// vertvisc :646-760 / :862-960 and vertvisc_remnant :1105-1155 for one face column.  The two solves share the matrix
+// (b1, d1, c1 depend on a, h_vel, Ray and dt only), so when the caller wants both -- the RK2 step always calls them
+// as a pair with the same dt -- they are done in one pass over a and h_vel.  The truncation of vertvisc_limit_vel acts on
+// the finished velocities only: the back substitution carries the untruncated value in a register and stores the
+// truncated one.
 template <int DIR>
 __global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
   const m6::GridDev &g = A.g;
@@ -178,24 +209,26 @@ __global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
   const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
   if (i > g.iec) return;
   const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
-  const long fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh, hpl = (long)g.nih * g.njh;
+  const long c0 = g.h2(i, j), cc1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
   const int nz = g.nk;
   const double dt = A.dt;
   const double mask = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2];
   const bool do_i = mask > 0.0;
-  double *x = A.x;
+  double *x = A.x, *xr = A.xr;
+  const bool lim = A.ntrunc != nullptr;
+  const double dL = lim ? (DIR ? g.dx_Cv[f2] : g.dy_Cu[f2]) : 0.0;
+  double x_bot = 0.0;      // the untruncated bottom velocity (for taux_bot)
   if (do_i) {
     double surface_stress = 0.0;
-    if (!A.remnant) {
+    if (x) {
       const double dt_Rho0 = dt / P.H_to_RZ;                          // :611
       if (P.direct_stress) {                                         // :671-685
-        const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
-        const long hpl = (long)g.nih * g.njh;
         const double Hmix = P.Hmix_stress, I_Hmix = 1.0 / Hmix;
         double zDS = 0.0;
         const double stress = dt_Rho0 * A.tau[f2];
         for (int k = 0; k < nz; k++) {
-          const double h_a = 0.5 * (A.h[c0 + hpl * k] + A.h[c1 + hpl * k]) + g.H_subroundoff;
+          const double h_a = 0.5 * (A.h[c0 + hpl * k] + A.h[cc1 + hpl * k]) + g.H_subroundoff;
           double hfr = 1.0;
           if ((zDS + h_a) > Hmix) hfr = (Hmix - zDS) / h_a;
           x[f2 + fpl * k] = x[f2 + fpl * k] + I_Hmix * hfr * stress;
@@ -209,10 +242,9 @@ __global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
     double b_denom_1 = A.hv[f2] + dt * ((A.Ray ? A.Ray[f2] : 0.0) + A.a[f2]);
     double b1 = 1.0 / (b_denom_1 + dt * A.a[f2 + fpl]);
     double d1 = b_denom_1 * b1;
-    double xk;
-    if (A.remnant) xk = b1 * A.hv[f2];
-    else xk = b1 * (A.hv[f2] * x[f2] + surface_stress);
-    x[f2] = xk;
+    double xk = 0.0, rk = 0.0;
+    if (x) { xk = b1 * (A.hv[f2] * x[f2] + surface_stress); if (nz > 1 || !lim) x[f2] = xk; }
+    if (xr) { rk = b1 * A.hv[f2]; xr[f2] = rk; }
     double a_next = A.a[f2 + fpl];
     for (int k = 1; k < nz; k++) {
       const long n = f2 + fpl * k;
@@ -222,18 +254,27 @@ __global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
       b_denom_1 = hvk + dt * ((A.Ray ? A.Ray[n] : 0.0) + ak * d1);
       b1 = 1.0 / (b_denom_1 + dt * a_next);
       d1 = b_denom_1 * b1;
-      if (A.remnant) xk = (hvk + dt * ak * xk) * b1;
-      else xk = (hvk * x[n] + dt * ak * xk) * b1;
-      x[n] = xk;
+      if (x) { xk = (hvk * x[n] + dt * ak * xk) * b1; if (k < nz - 1 || !lim) x[n] = xk; }
+      if (xr) { rk = (hvk + dt * ak * rk) * b1; xr[n] = rk; }
     }
+    x_bot = xk;
+    if (x && lim) x[f2 + fpl * (nz - 1)] = limit_vel<DIR>(g, P, xk, dt, dL, c0, cc1, A.h, hpl * (nz - 1), A.ntrunc);
     for (int k = nz - 2; k >= 0; k--) {
       const long n = f2 + fpl * k;
-      xk = x[n] + A.c1[n + fpl] * xk;
-      x[n] = xk;
+      const double c = A.c1[n + fpl];
+      if (x) {
+        xk = x[n] + c * xk;
+        x[n] = lim ? limit_vel<DIR>(g, P, xk, dt, dL, c0, cc1, A.h, hpl * k, A.ntrunc) : xk;
+      }
+      if (xr) { rk = xr[n] + c * rk; xr[n] = rk; }
     }
+  } else if (x) {
+    x_bot = x[f2 + fpl * (nz - 1)];
+    if (lim)      // vertvisc_limit_vel runs over every face of the compute rows, masked or not
+      for (int k = 0; k < nz; k++) x[f2 + fpl * k] = limit_vel<DIR>(g, P, x[f2 + fpl * k], dt, dL, c0, cc1, A.h, hpl * k, A.ntrunc);
   }
-  if (A.tbot) {                                                      // :798-805
-    double tb = P.H_to_RZ * (x[f2 + fpl * (nz - 1)] * A.a[f2 + fpl * nz]);
+  if (A.tbot) {                                                      // :798-805 (before the truncation)
+    double tb = P.H_to_RZ * (x_bot * A.a[f2 + fpl * nz]);
     if (A.Ray) for (int k = 0; k < nz; k++) tb = tb + P.H_to_RZ * (A.Ray[f2 + fpl * k] * x[f2 + fpl * k]);
     A.tbot[f2] = tb;
   }
@@ -352,41 +393,63 @@ extern "C" int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
 }
 
 namespace {
-// the solve of both directions: velocities (remnant = 0) or visc_rem (remnant = 1)
+// the solve of both directions: velocities x (with vertvisc_limit_vel fused when the Rayleigh drag is off), visc_rem xr,
+// or both at once
 int run_solve(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_vertvisc_cs_t *cs, const double *const a[2], const double *const hv[2],
-              const double *const Ray[2], const double *dh, const double *const tau[2], double *const x[2], double *const tbot[2],
-              double dt, int remnant) {
+              const double *const Ray[2], const double *dh, const double *const tau[2], double *const x[2], double *const xr[2],
+              double *const tbot[2], double dt, bool want_limit) {
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);
   double *c1 = (double *)st.scratch(sz.u3 > sz.v3 ? sz.u3 : sz.v3);
   M6_REQUIRE(!st.failed() && c1, "vertvisc: out of device memory");
+  unsigned long long *cnt = nullptr;
+  if (want_limit) {
+    if (ctx->vv_ntrunc.reserve(sizeof(unsigned long long)) || !ctx->vv_ntrunc.p) return 1;
+    if (!ctx->vv_ntrunc_ready) {
+      M6_HIP(hipMemsetAsync(ctx->vv_ntrunc.p, 0, sizeof(unsigned long long), ctx->stream));
+      ctx->vv_ntrunc_ready = true;
+    }
+    cnt = (unsigned long long *)ctx->vv_ntrunc.p;
+  }
+  // with Rayleigh drag taux_bot sums Ray*u over the untruncated velocities in k order: the truncation stays a separate pass
+  const bool fuse_limit = want_limit && !(Ray[0] || Ray[1]);
   for (int d = 0; d < 2; d++) {
     SolveArgs A;
-    A.g = g; A.p = par_of(cs); A.a = a[d]; A.hv = hv[d]; A.Ray = Ray[d]; A.h = dh; A.tau = tau[d]; A.x = x[d]; A.c1 = c1;
-    A.tbot = tbot[d]; A.dt = dt; A.remnant = remnant;
+    A.g = g; A.p = par_of(cs); A.a = a[d]; A.hv = hv[d]; A.Ray = Ray[d]; A.h = dh; A.tau = tau[d]; A.x = x[d]; A.xr = xr[d]; A.c1 = c1;
+    A.tbot = tbot[d]; A.dt = dt; A.ntrunc = fuse_limit ? cnt : nullptr;
     const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
     if (d == 0) hipLaunchKernelGGL(vv_solve_kernel<0>, grid, dim3(64), 0, ctx->stream, A);
     else hipLaunchKernelGGL(vv_solve_kernel<1>, grid, dim3(64), 0, ctx->stream, A);
   }
+  if (want_limit && !fuse_limit) {
+    for (int d = 0; d < 2; d++) {
+      LimitArgs L;
+      L.g = g; L.p = par_of(cs); L.h = dh; L.x = x[d]; L.ntrunc = cnt; L.dt = dt;
+      const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 255) / 256, g.jec - g.jsc + 1 + (d ? 1 : 0), g.nk);
+      if (d == 0) hipLaunchKernelGGL(vv_limit_kernel<0>, grid, dim3(256), 0, ctx->stream, L);
+      else hipLaunchKernelGGL(vv_limit_kernel<1>, grid, dim3(256), 0, ctx->stream, L);
+    }
+  }
   M6_HIP(hipGetLastError());
   return 0;
 }
-}  // namespace
 
-extern "C" int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
-                                const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
-                                double *taux_bot, double *tauy_bot, int32_t memspace) {
+int vertvisc_impl(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *taux,
+                  const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
+                  double *visc_rem_u, double *visc_rem_v, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(visc): Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && taux && tauy && visc, "vertvisc: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "vertvisc: bad memspace");
   if (check_cs(cs, "vertvisc")) return 1;
   M6_REQUIRE(dt > 0.0 && cs->H_to_RZ > 0.0, "vertvisc: dt and GV%%H_to_RZ must be positive");
   M6_REQUIRE(!cs->direct_stress || cs->Hmix_stress > 0.0, "vertvisc_init: HMIX_STRESS must be set to a positive value if DIRECT_STRESS is true.");
+  M6_REQUIRE((visc_rem_u != nullptr) == (visc_rem_v != nullptr), "vertvisc: visc_rem_u and visc_rem_v come as a pair");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.areaT && g.IareaT && g.dy_Cu && g.dx_Cv, "vertvisc: a required grid metric is missing");
   const Sz sz = sizes(g);
   m6::Stager st(ctx, memspace);
   double *x[2] = {st.inout(u, sz.u3), st.inout(v, sz.v3)};
+  double *xr[2] = {st.inout(visc_rem_u, sz.u3), st.inout(visc_rem_v, sz.v3)};
   const double *dh = st.in(h, sz.h3);
   const double *tau[2] = {st.in(taux, sz.u2), st.in(tauy, sz.v2)};
   const double *a[2] = {st.in((const double *)cs->a_u, sz.ui), st.in((const double *)cs->a_v, sz.vi)};
@@ -394,24 +457,27 @@ extern "C" int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, d
   const double *Ray[2] = {st.in(visc->Ray_u, sz.u3), st.in(visc->Ray_v, sz.v3)};
   double *tbot[2] = {st.inout(taux_bot, sz.u2), st.inout(tauy_bot, sz.v2)};      // (only the compute rows are written)
   M6_REQUIRE(!st.failed(), "vertvisc: staging failed");
-  if (run_solve(ctx, st, cs, a, hv, Ray, dh, tau, x, tbot, dt, 0)) return 1;
-  // vertvisc_limit_vel :986
-  if (ctx->vv_ntrunc.reserve(sizeof(unsigned long long)) || !ctx->vv_ntrunc.p) return 1;
-  if (!ctx->vv_ntrunc_ready) {
-    M6_HIP(hipMemsetAsync(ctx->vv_ntrunc.p, 0, sizeof(unsigned long long), ctx->stream));
-    ctx->vv_ntrunc_ready = true;
-  }
-  for (int d = 0; d < 2; d++) {
-    LimitArgs L;
-    L.g = g; L.p = par_of(cs); L.h = dh; L.x = x[d]; L.ntrunc = (unsigned long long *)ctx->vv_ntrunc.p; L.dt = dt;
-    const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 255) / 256, g.jec - g.jsc + 1 + (d ? 1 : 0), g.nk);
-    if (d == 0) hipLaunchKernelGGL(vv_limit_kernel<0>, grid, dim3(256), 0, ctx->stream, L);
-    else hipLaunchKernelGGL(vv_limit_kernel<1>, grid, dim3(256), 0, ctx->stream, L);
-  }
-  M6_HIP(hipGetLastError());
+  if (run_solve(ctx, st, cs, a, hv, Ray, dh, tau, x, xr, tbot, dt, true)) return 1;      // incl. vertvisc_limit_vel :986
   const int rc = st.finish();
   if (rc == 0 && memspace == MOM6HIP_MEM_HOST) return mom6hip_vertvisc_ntrunc(ctx, cs);
   return rc;
+}
+}  // namespace
+
+extern "C" int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
+                                const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
+                                double *taux_bot, double *tauy_bot, int32_t memspace) {
+  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, nullptr, nullptr, memspace);
+}
+
+// vertvisc followed by vertvisc_remnant with the same dt -- the pair step_MOM_dyn_split_RK2 calls at :731-744 and :985-994
+// -- in one pass over the coupling coefficients.  Same results as the two calls.
+extern "C" int mom6hip_vertvisc_and_remnant(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
+                                            const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
+                                            double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v,
+                                            int32_t memspace) {
+  M6_REQUIRE(visc_rem_u && visc_rem_v, "vertvisc_and_remnant: null argument");
+  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, visc_rem_u, visc_rem_v, memspace);
 }
 
 // Adds the truncations counted on the device since the last call to cs->ntrunc (synchronises the stream).
@@ -440,8 +506,8 @@ extern "C" int mom6hip_vertvisc_remnant(mom6hip_ctx_t *ctx, const mom6hip_vertvi
   const double *hv[2] = {st.in((const double *)cs->h_u, sz.u3), st.in((const double *)cs->h_v, sz.v3)};
   const double *Ray[2] = {st.in(visc->Ray_u, sz.u3), st.in(visc->Ray_v, sz.v3)};
   const double *tau[2] = {nullptr, nullptr};
-  double *tbot[2] = {nullptr, nullptr};
+  double *tbot[2] = {nullptr, nullptr}, *none[2] = {nullptr, nullptr};
   M6_REQUIRE(!st.failed(), "vertvisc_remnant: staging failed");
-  if (run_solve(ctx, st, cs, a, hv, Ray, nullptr, tau, x, tbot, dt, 1)) return 1;
+  if (run_solve(ctx, st, cs, a, hv, Ray, nullptr, tau, none, x, tbot, dt, false)) return 1;
   return st.finish();
 }

@@ -21,6 +21,7 @@ def _setup():
         L.mom6hip_vertvisc.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [vt, C.c_double, C.c_void_p, C.c_void_p, C.c_int32]
         L.mom6hip_vertvisc_remnant.argtypes = [C.c_void_p, cs, vt, C.c_void_p, C.c_void_p, C.c_double, C.c_int32]
         L.mom6hip_vertvisc_ntrunc.argtypes = [C.c_void_p, cs]
+        L.mom6hip_vertvisc_and_remnant.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [vt, C.c_double] + [C.c_void_p] * 4 + [C.c_int32]
         L._vv_ready = True
     return L
 
@@ -139,6 +140,17 @@ def vertvisc(u, v, h, forces, visc: vertvisc_type, dt, OBC, ADp, CDp, G: DeviceG
         raise Mom6HipError("vertvisc: visc must be in the same memory space as the fields")
     check(_setup().mom6hip_vertvisc(G.handle, C.byref(CS.st), pu, pv, ph, ptx, pty, C.byref(visc.st), float(dt), pbx, pby, space),
           "vertvisc")
+
+
+def vertvisc_and_remnant(u, v, h, forces, visc: vertvisc_type, dt, G: DeviceGrid, CS: vertvisc_CS, visc_rem_u, visc_rem_v, taux_bot=None,
+                         tauy_bot=None):
+    """vertvisc followed by vertvisc_remnant with the same dt (the pair of MOM_dynamics_split_RK2.F90:731-744, :985-994) in one
+    pass; the results are those of the two calls."""
+    taux, tauy = forces
+    (pu, pv, ph, ptx, pty, pbx, pby, pru, prv), space = _space_of(CS, (u, v, h, taux, tauy, taux_bot, tauy_bot, visc_rem_u, visc_rem_v),
+                                                                  "vertvisc_and_remnant")
+    check(_setup().mom6hip_vertvisc_and_remnant(G.handle, C.byref(CS.st), pu, pv, ph, ptx, pty, C.byref(visc.st), float(dt), pbx, pby,
+                                                pru, prv, space), "vertvisc_and_remnant")
 
 
 def vertvisc_ntrunc(G: DeviceGrid, CS: vertvisc_CS) -> int:

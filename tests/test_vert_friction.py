@@ -112,7 +112,8 @@ def test_truncation_counts_and_limits(oracle):
 def test_gpu_parity(oracle, variant):
     import torch
     from mom6_amd.tracer_advect import DeviceGrid
-    from mom6_amd.vert_friction import vertvisc, vertvisc_coef, vertvisc_init, vertvisc_ntrunc, vertvisc_remnant, vertvisc_type
+    from mom6_amd.vert_friction import (vertvisc, vertvisc_and_remnant, vertvisc_coef, vertvisc_init, vertvisc_ntrunc, vertvisc_remnant,
+                                        vertvisc_type)
     kw = VARIANTS[variant]
     pk = dict(KV=1.0e-4, HBBL=10.0)
     names = dict(harmonic_visc="HARMONIC_VISC", harm_BL_val="HARMONIC_BL_SCALE", Kvml_invZ2="KV_ML_INVZ2", Hmix="HMIX_FIXED",
@@ -153,6 +154,13 @@ def test_gpu_parity(oracle, variant):
             assert bits_equal(rv, N(v)), (what, "v", np.argwhere(rv != N(v))[:3])
             assert bits_equal(rtbx, N(tbx)) and bits_equal(rtby, N(tby)), (what, "tau_bot")
             assert vertvisc_ntrunc(dg, CS) == rcs.ntrunc, (what, "ntrunc", CS.ntrunc, rcs.ntrunc)
+            # the fused pair gives what the two calls give
+            u2, v2, r2u, r2v = X(st["u"]), X(st["v"]), X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V))
+            tbx, tby = X(g.zeros2(_abi.POS_U)), X(g.zeros2(_abi.POS_V))
+            vertvisc_and_remnant(u2, v2, h, (X(taux), X(tauy)), visc, dt, dg, CS, r2u, r2v, tbx, tby)
+            assert bits_equal(ru, N(u2)) and bits_equal(rv, N(v2)) and bits_equal(rvru, N(r2u)) and bits_equal(rvrv, N(r2v)), (what, "fused")
+            assert bits_equal(rtbx, N(tbx)) and bits_equal(rtby, N(tby)), (what, "fused tau_bot")
+            assert vertvisc_ntrunc(dg, CS) == 2 * rcs.ntrunc, (what, "fused ntrunc")
         dg.close()
 
 
