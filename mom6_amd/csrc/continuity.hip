@@ -560,7 +560,7 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
     if (k0 + m < nz) {
       double dd;
       const double uhk = flux_reg(F, ru[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
-      if (valid) p.uh[f2 + (k0 + m) * fpl] = uhk;
+      if (valid && !p.uhbt) p.uh[f2 + (k0 + m) * fpl] = uhk;      // (with uhbt, uh is stored once, after the solve)
       fsm[sl + m * 64] = uhk; fsm[PL + sl + m * 64] = dd;
       vmax_w = max2(vmax_w, rvr[m]);
     }
@@ -667,6 +667,7 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
     double du = 0.0, du_max = du_max_CFL, du_min = du_min_CFL;
     double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0, uh_err_best = fabs(uh_err);
     bool do_I = true, alive = valid;
+    double du_eval = 0.0;      // du of this face's last re-evaluation of the transports (what uh_3d holds in the reference)
 #pragma unroll 1
     for (int itt = 1; itt <= max_itts; itt++) {
       bool domore = false;
@@ -709,14 +710,13 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       if (!__any(alive)) break;      // the same in every wave of the block: they hold the same values
       if ((itt < max_itts) || write_uh) {
         __syncthreads();             // the results of the previous pass have been read
-        const bool st = write_uh && alive && valid;
+        if (alive) du_eval = du;
 #pragma unroll
         for (int m = 0; m < KS; m++) {
           if (k0 + m < nz) {
             double dd;
             pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
             const double uhk = flux_reg(F, ru[m] + du * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
-            if (st) p.uh[f2 + (k0 + m) * fpl] = uhk;
             fsm[sl + m * 64] = uhk; fsm[PL + sl + m * 64] = dd;
           }
         }
@@ -729,6 +729,18 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       }
     }
     du_ph[phase] = du;
+    if (write_uh && valid) {
+      // The reference stores the layer transports on every re-evaluation (uh_3d); what remains is the last one of each
+      // face, or the first evaluation for a face that never iterated (du_eval = 0: u + 0*visc_rem is u).  Stored once here.
+#pragma unroll
+      for (int m = 0; m < KS; m++) {
+        if (k0 + m < nz) {
+          double dd;
+          pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
+          p.uh[f2 + (k0 + m) * fpl] = flux_reg(F, ru[m] + du_eval * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
+        }
+      }
+    }
   }
   const double du = du_ph[0], du0 = du_ph[1];
 

@@ -104,6 +104,23 @@ type, bind(c) :: mom6hip_visc_hooks_t
   type(c_funptr) :: visc_remnant_pred, vertvisc, horizontal_viscosity
 end type mom6hip_visc_hooks_t
 
+!> mom6hip_vertvisc_cs_t (vertvisc_CS, src/parameterizations/vertical/MOM_vert_friction.F90:40)
+type, bind(c) :: mom6hip_vertvisc_cs_t
+  real(c_double) :: Hmix, Hmix_stress, Kvml_invZ2, Kv, Hbbl, Kv_extra_bbl, harm_BL_val, maxvel, CFL_trunc, vel_underflow, H_to_RZ
+  real(c_double) :: reserved0(5)
+  integer(c_int32_t) :: bottomdraglaw, harmonic_visc, direct_stress, CFL_based_trunc, answer_date
+  integer(c_int32_t) :: unsupported(7)
+  integer(c_int64_t) :: ntrunc
+  type(c_ptr) :: a_u, a_v, h_u, h_v
+  type(c_ptr) :: reserved1(4)
+end type mom6hip_vertvisc_cs_t
+
+!> mom6hip_vertvisc_type_t (the members of vertvisc_type, src/core/MOM_variables.F90:218, that are read)
+type, bind(c) :: mom6hip_vertvisc_type_t
+  type(c_ptr) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Ray_u, Ray_v, Kv_shear, Kv_shear_Bu
+  type(c_ptr) :: reserved(4)
+end type mom6hip_vertvisc_type_t
+
 !> mom6hip_dyn_split_rk2_cs_t (MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84); every array is a DEVICE
 !! array obtained from mom6hip_malloc
 type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
@@ -111,7 +128,9 @@ type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
   integer(c_int32_t) :: BT_use_layer_fluxes, store_CAu, CAu_pred_stored, split_bottom_stress
   integer(c_int32_t) :: reserved0(4)
   type(c_ptr) :: continuity_CSp, CoriolisAdv, PressureForce_CSp, eqn_of_state, barotropic_CSp, BT_cont, hooks
-  type(c_ptr) :: reserved1(3)
+  type(c_ptr) :: vertvisc_CSp   !< c_loc of a mom6hip_vertvisc_cs_t, or c_null_ptr
+  type(c_ptr) :: visc           !< c_loc of a mom6hip_vertvisc_type_t (the visc argument of the step)
+  type(c_ptr) :: reserved1(1)
   type(c_ptr) :: CAu, CAv, CAu_pred, CAv_pred, PFu, PFv, diffu, diffv, visc_rem_u, visc_rem_v, u_accel_bt, v_accel_bt, &
                  u_av, v_av, h_av, pbce
   type(c_ptr) :: eta, eta_PF, uhbt, vhbt
@@ -340,6 +359,61 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_btstep
+
+  !> vertvisc_coef (MOM_vert_friction.F90:1168); dz = c_null_ptr stands for the Boussinesq thickness_to_dz
+  function mom6hip_vertvisc_coef(ctx, cs, u, v, h, dz, visc, dt, memspace) bind(c, name="mom6hip_vertvisc_coef") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, u, v, h, dz
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_coef
+
+  !> vertvisc (:526) with vertvisc_limit_vel; taux_bot / tauy_bot may be c_null_ptr
+  function mom6hip_vertvisc(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, memspace) &
+                            bind(c, name="mom6hip_vertvisc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, u, v, h, taux, tauy, taux_bot, tauy_bot
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc
+
+  !> vertvisc followed by vertvisc_remnant with the same dt, in one pass
+  function mom6hip_vertvisc_and_remnant(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, visc_rem_u, visc_rem_v, &
+                                        memspace) bind(c, name="mom6hip_vertvisc_and_remnant") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, u, v, h, taux, tauy, taux_bot, tauy_bot, visc_rem_u, visc_rem_v
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_and_remnant
+
+  !> CS%ntrunc: adds the truncations counted on the device since the last call (synchronises)
+  function mom6hip_vertvisc_ntrunc(ctx, cs) bind(c, name="mom6hip_vertvisc_ntrunc") result(rc)
+    import :: c_int, c_ptr, mom6hip_vertvisc_cs_t
+    type(c_ptr), value :: ctx
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_ntrunc
+
+  !> vertvisc_remnant (:1064)
+  function mom6hip_vertvisc_remnant(ctx, cs, visc, visc_rem_u, visc_rem_v, dt, memspace) &
+                                    bind(c, name="mom6hip_vertvisc_remnant") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, visc_rem_u, visc_rem_v
+    type(mom6hip_vertvisc_cs_t), intent(in) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_remnant
 
   function mom6hip_dyn_split_rk2_init(ctx, cs, u, v, h, uh, vh, dt) bind(c, name="mom6hip_dyn_split_rk2_init") result(rc)
     import :: c_int, c_double, c_ptr, mom6hip_dyn_split_rk2_cs_t

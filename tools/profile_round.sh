@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the profiles/ set of a round on the GPU box:  tools/profile_round.sh r01_f
+# (kernel trace of bench.py -> kernel stats; two PMC passes FETCH_SIZE / WRITE_SIZE -> per-kernel bytes).
+set -e
+TAG=${1:-r01_x}
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace -d /tmp/kt_$TAG -o kt -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-roofline > $OUT/bench_under_trace.json 2> /tmp/kt_$TAG.err
+python3 tools/rocpd_stats.py $(find /tmp/kt_$TAG -name "*.db" | head -n 1) $OUT/${TAG}_bench_om4_kernel_stats.csv > $OUT/${TAG}_kernel_stats.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${TAG}_$c -o p -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.json 2> /tmp/pmc_$c.err
+  python3 tools/rocpd_pmc.py $(find /tmp/pmc_${TAG}_$c -name "*.db" | head -n 1) > $OUT/${TAG}_pmc_$c.txt
+done
+echo done
