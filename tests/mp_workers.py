@@ -187,17 +187,24 @@ def rk2_layout_worker(rank, world, port, layout, topo, out_dir):
         u, v, h, Tt, Ss = T(d["u"], U), T(d["v"], V), T(d["h"], H), T(d["T"], H), T(d["S"], H)
         Z = lambda p, k3=True: torch.zeros(tg.shape3(p) if k3 else tg.shape2(p), dtype=torch.float64, device="cuda")
         uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
-        CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True))
+        # the step runs with the library's vertical viscosity: visc%Kv_bbl / bbl_thick are cut per tile like any field
+        from mom6_amd.vert_friction import vertvisc_type
+        from test_dyn_split_rk2 import _visc_arrays
+        va = _visc_arrays(gg)
+        pos_of = dict(Kv_bbl_u=U, Kv_bbl_v=V, bbl_thick_u=U, bbl_thick_v=V)
+        visc = vertvisc_type(**{n: T(a, pos_of[n]) for n, a in va.items()})
+        CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0))
         tx, ty = T(taux, U), T(tauy, V)
         for n in range(2):
-            step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
+            step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
                                    calc_dtbt=(n == 0))
         dg.sync()
         np.savez(os.path.join(out_dir, f"rk2_tile{rank}.npz"), ij=np.array([dom.i0, dom.j0, dom.ni, dom.nj]), u=u.cpu().numpy(),
                  v=v.cpu().numpy(), h=h.cpu().numpy(), eta=CS.eta.cpu().numpy(), uhtr=uhtr.cpu().numpy(), dtbt=CS.barotropic_CSp.st.dtbt)
         dg.close()
         if rank == 0:
-            ref = orc.DynState(gg, d["u"], d["v"], d["h"], d["T"], d["S"], dt)
+            ref = orc.DynState(gg, d["u"], d["v"], d["h"], d["T"], d["S"], dt, vertvisc=orc.vertvisc_cs(gg, Kv=1.0e-3, Hbbl=10.0),
+                               visc=orc.vertvisc_type(**va))
             for n in range(2):
                 ref.step(taux, tauy, calc_dtbt=(n == 0))
             np.savez(os.path.join(out_dir, "rk2_global.npz"), u=ref.u, v=ref.v, h=ref.h, eta=ref.arrs["eta"], uhtr=ref.uhtr, dtbt=ref.bcs.dtbt)
