@@ -528,6 +528,15 @@ int mom6hip_vertvisc_and_remnant(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, 
                                  const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
                                  double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v, int32_t memspace);
 
+/* vertvisc_coef, then (update_velocities /= 0) vertvisc, then vertvisc_remnant with the same dt -- the sequences of the split
+ * RK2 step at :598-600 (velocities untouched), :717-744 and :974-994 -- in one kernel per direction (each lane sweeps its
+ * column for the coefficients and then solves it); the results are those of the separate calls.  taux / tauy / taux_bot /
+ * tauy_bot are only used with update_velocities. */
+int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *dz,
+                          const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
+                          int32_t update_velocities, double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v,
+                          int32_t memspace);
+
 /* CS%ntrunc: vertvisc counts truncations on the device; this adds the count since the last call to cs->ntrunc
  * (synchronises the stream).  With MOM6HIP_MEM_HOST vertvisc does it itself. */
 int mom6hip_vertvisc_ntrunc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs);

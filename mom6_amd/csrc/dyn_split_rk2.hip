@@ -193,8 +193,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
   } else if (VV) {                     // vertvisc_coef, vertvisc_remnant :598-600 (set_viscous_ML :592 is not provided)
-    CALL(mom6hip_vertvisc_coef(ctx, VV, up, vp, h, nullptr, cs->visc, dt, D));
-    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt, D));
+    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}}, nz));                 // :610-611
 
@@ -229,8 +228,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, up, vp, h, dt_pred, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
   } else if (VV) {            // :717-744
-    CALL(mom6hip_vertvisc_coef(ctx, VV, up, vp, h, nullptr, cs->visc, dt_pred, D));
-    CALL(mom6hip_vertvisc_and_remnant(ctx, VV, up, vp, h, taux, tauy, cs->visc, dt_pred, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {up, PU}, {vp, PV}}, nz));            // :747, :751
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
@@ -267,8 +265,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, u_inst, v_inst, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
   } else if (VV) {            // :974-994
-    CALL(mom6hip_vertvisc_coef(ctx, VV, u_inst, v_inst, h, nullptr, cs->visc, dt, D));
-    CALL(mom6hip_vertvisc_and_remnant(ctx, VV, u_inst, v_inst, h, taux, tauy, cs->visc, dt, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+    CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
   CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {u_inst, PU}, {v_inst, PV}}, nz));     // :1004, :1008

@@ -34,15 +34,12 @@ struct CoefArgs {
   double *a, *hv;
 };
 
+// vertvisc_coef + find_coupling_coef for the face column (i, j); the caller has checked do_i
 template <int DIR>
-__global__ __launch_bounds__(64) void vv_coef_kernel(CoefArgs A) {
+__device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   const m6::GridDev &g = A.g;
   const VVPar &P = A.p;
-  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
-  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
-  if (i > g.iec) return;
   const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
-  if (!((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0)) return;      // do_i
   const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
   const long hpl = (long)g.nih * g.njh, fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
   const int nz = g.nk;
@@ -160,6 +157,17 @@ __global__ __launch_bounds__(64) void vv_coef_kernel(CoefArgs A) {
   A.a[f2] = min2(a_cpl_max, 0.0 + 0.0);                               // a_cpl(:,1) = 0: no surface boundary layer scheme
 }
 
+template <int DIR>
+__global__ __launch_bounds__(64) void vv_coef_kernel(CoefArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  if (!((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0)) return;      // do_i
+  coef_column<DIR>(A, i, j);
+}
+
 struct SolveArgs {
   m6::GridDev g;
   VVPar p;
@@ -202,12 +210,9 @@ __device__ __forceinline__ double limit_vel(const m6::GridDev &g, const VVPar &P
 // the finished velocities only: the back substitution carries the untruncated value in a register and stores the
 // truncated one.
 template <int DIR>
-__global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
+__device__ __forceinline__ void solve_column(const SolveArgs &A, int i, int j) {
   const m6::GridDev &g = A.g;
   const VVPar &P = A.p;
-  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
-  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
-  if (i > g.iec) return;
   const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
   const long fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh, hpl = (long)g.nih * g.njh;
   const long c0 = g.h2(i, j), cc1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
@@ -278,6 +283,28 @@ __global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
     if (A.Ray) for (int k = 0; k < nz; k++) tb = tb + P.H_to_RZ * (A.Ray[f2 + fpl * k] * x[f2 + fpl * k]);
     A.tbot[f2] = tb;
   }
+}
+
+template <int DIR>
+__global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  solve_column<DIR>(A, i, j);
+}
+
+// vertvisc_coef followed by the solve(s) of the same column: the coupling coefficients and thicknesses the bottom-up sweep
+// has just stored are read back by the same lane while they are still in L2, instead of by a second kernel from HBM.
+template <int DIR>
+__global__ __launch_bounds__(64) void vv_coef_solve_kernel(CoefArgs C, SolveArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  if ((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0) coef_column<DIR>(C, i, j);
+  solve_column<DIR>(A, i, j);
 }
 
 struct LimitArgs {
@@ -478,6 +505,72 @@ extern "C" int mom6hip_vertvisc_and_remnant(mom6hip_ctx_t *ctx, mom6hip_vertvisc
                                             int32_t memspace) {
   M6_REQUIRE(visc_rem_u && visc_rem_v, "vertvisc_and_remnant: null argument");
   return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, visc_rem_u, visc_rem_v, memspace);
+}
+
+// vertvisc_coef, then (update_velocities) vertvisc, then vertvisc_remnant, all with the same dt: the sequences of
+// step_MOM_dyn_split_RK2 at :598-600 (velocities untouched), :717-744 and :974-994.  One kernel per direction: each lane
+// runs the bottom-up coefficient sweep and then the solve of its own column.  Same results as the separate calls.
+extern "C" int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
+                                     const double *dz, const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc,
+                                     double dt, int32_t update_velocities, double *taux_bot, double *tauy_bot, double *visc_rem_u,
+                                     double *visc_rem_v, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(visc): Module must be initialized before it is used.");
+  M6_REQUIRE(cs && u && v && h && visc && visc_rem_u && visc_rem_v, "vertvisc_step: null argument");
+  M6_REQUIRE(!update_velocities || (taux && tauy), "vertvisc_step: the wind stress is needed to update the velocities");
+  if (visc->Ray_u || visc->Ray_v) {      // the Rayleigh-drag bottom stress needs the separate truncation pass: plain sequence
+    if (int rc = mom6hip_vertvisc_coef(ctx, cs, u, v, h, dz, visc, dt, memspace)) return rc;
+    if (update_velocities)
+      if (int rc = mom6hip_vertvisc(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, memspace)) return rc;
+    return mom6hip_vertvisc_remnant(ctx, cs, visc, visc_rem_u, visc_rem_v, dt, memspace);
+  }
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "vertvisc_step: bad memspace");
+  if (check_cs(cs, "vertvisc_step")) return 1;
+  M6_REQUIRE(dt > 0.0 && cs->H_to_RZ > 0.0, "vertvisc: dt and GV%%H_to_RZ must be positive");
+  M6_REQUIRE(visc->Kv_shear_Bu == nullptr, "vertvisc_coef: visc%%Kv_shear_Bu is not provided by libmom6hip");
+  M6_REQUIRE(!cs->bottomdraglaw || (visc->Kv_bbl_u && visc->Kv_bbl_v && visc->bbl_thick_u && visc->bbl_thick_v),
+             "vertvisc_coef: BOTTOMDRAGLAW needs visc%%Kv_bbl_u/v and visc%%bbl_thick_u/v");
+  M6_REQUIRE(!(cs->Kvml_invZ2 > 0.0) || cs->Hmix > 0.0, "vertvisc_coef: KV_ML_INVZ2 needs HMIX_FIXED");
+  M6_REQUIRE(!cs->direct_stress || cs->Hmix_stress > 0.0, "vertvisc_init: HMIX_STRESS must be set to a positive value if DIRECT_STRESS is true.");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.bathyT && g.areaT && g.IareaT && g.dy_Cu && g.dx_Cv, "vertvisc: a required grid metric is missing");
+  const Sz sz = sizes(g);
+  m6::Stager st(ctx, memspace);
+  double *x[2] = {update_velocities ? st.inout(u, sz.u3) : (double *)st.in((const double *)u, sz.u3),
+                  update_velocities ? st.inout(v, sz.v3) : (double *)st.in((const double *)v, sz.v3)};
+  double *xr[2] = {st.inout(visc_rem_u, sz.u3), st.inout(visc_rem_v, sz.v3)};
+  const double *dh = st.in(h, sz.h3), *ddz = st.in(dz, sz.h3), *dks = st.in(visc->Kv_shear, sz.hi);
+  const double *tau[2] = {st.in(taux, sz.u2), st.in(tauy, sz.v2)};
+  const double *kvb[2] = {st.in(visc->Kv_bbl_u, sz.u2), st.in(visc->Kv_bbl_v, sz.v2)};
+  const double *bth[2] = {st.in(visc->bbl_thick_u, sz.u2), st.in(visc->bbl_thick_v, sz.v2)};
+  double *a[2] = {st.inout(cs->a_u, sz.ui), st.inout(cs->a_v, sz.vi)};
+  double *hv[2] = {st.inout(cs->h_u, sz.u3), st.inout(cs->h_v, sz.v3)};
+  double *tbot[2] = {update_velocities ? st.inout(taux_bot, sz.u2) : nullptr, update_velocities ? st.inout(tauy_bot, sz.v2) : nullptr};
+  double *c1 = (double *)st.scratch(sz.u3 > sz.v3 ? sz.u3 : sz.v3);
+  M6_REQUIRE(!st.failed() && c1, "vertvisc_step: staging failed");
+  unsigned long long *cnt = nullptr;
+  if (update_velocities) {
+    if (ctx->vv_ntrunc.reserve(sizeof(unsigned long long)) || !ctx->vv_ntrunc.p) return 1;
+    if (!ctx->vv_ntrunc_ready) {
+      M6_HIP(hipMemsetAsync(ctx->vv_ntrunc.p, 0, sizeof(unsigned long long), ctx->stream));
+      ctx->vv_ntrunc_ready = true;
+    }
+    cnt = (unsigned long long *)ctx->vv_ntrunc.p;
+  }
+  for (int d = 0; d < 2; d++) {
+    CoefArgs C;
+    C.g = g; C.p = par_of(cs); C.vel = x[d]; C.h = dh; C.dz = ddz; C.kv_bbl = kvb[d]; C.bbl_thick = bth[d]; C.Kv_shear = dks;
+    C.a = a[d]; C.hv = hv[d];
+    SolveArgs A;
+    A.g = g; A.p = C.p; A.a = a[d]; A.hv = hv[d]; A.Ray = nullptr; A.h = dh; A.tau = tau[d]; A.x = update_velocities ? x[d] : nullptr;
+    A.xr = xr[d]; A.c1 = c1; A.tbot = tbot[d]; A.dt = dt; A.ntrunc = cnt;
+    const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
+    if (d == 0) hipLaunchKernelGGL(vv_coef_solve_kernel<0>, grid, dim3(64), 0, ctx->stream, C, A);
+    else hipLaunchKernelGGL(vv_coef_solve_kernel<1>, grid, dim3(64), 0, ctx->stream, C, A);
+  }
+  M6_HIP(hipGetLastError());
+  const int rc = st.finish();
+  if (rc == 0 && update_velocities && memspace == MOM6HIP_MEM_HOST) return mom6hip_vertvisc_ntrunc(ctx, cs);
+  return rc;
 }
 
 // Adds the truncations counted on the device since the last call to cs->ntrunc (synchronises the stream).

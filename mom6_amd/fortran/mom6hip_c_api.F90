@@ -395,6 +395,18 @@ interface
     integer(c_int) :: rc
   end function mom6hip_vertvisc_and_remnant
 
+  !> vertvisc_coef, then (update_velocities /= 0) vertvisc, then vertvisc_remnant with the same dt, one kernel per direction
+  function mom6hip_vertvisc_step(ctx, cs, u, v, h, dz, taux, tauy, visc, dt, update_velocities, taux_bot, tauy_bot, &
+                                 visc_rem_u, visc_rem_v, memspace) bind(c, name="mom6hip_vertvisc_step") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, u, v, h, dz, taux, tauy, taux_bot, tauy_bot, visc_rem_u, visc_rem_v
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: update_velocities, memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_step
+
   !> CS%ntrunc: adds the truncations counted on the device since the last call (synchronises)
   function mom6hip_vertvisc_ntrunc(ctx, cs) bind(c, name="mom6hip_vertvisc_ntrunc") result(rc)
     import :: c_int, c_ptr, mom6hip_vertvisc_cs_t

@@ -22,6 +22,7 @@ def _setup():
         L.mom6hip_vertvisc_remnant.argtypes = [C.c_void_p, cs, vt, C.c_void_p, C.c_void_p, C.c_double, C.c_int32]
         L.mom6hip_vertvisc_ntrunc.argtypes = [C.c_void_p, cs]
         L.mom6hip_vertvisc_and_remnant.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [vt, C.c_double] + [C.c_void_p] * 4 + [C.c_int32]
+        L.mom6hip_vertvisc_step.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 6 + [vt, C.c_double, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32])
         L._vv_ready = True
     return L
 
@@ -151,6 +152,17 @@ def vertvisc_and_remnant(u, v, h, forces, visc: vertvisc_type, dt, G: DeviceGrid
                                                                   "vertvisc_and_remnant")
     check(_setup().mom6hip_vertvisc_and_remnant(G.handle, C.byref(CS.st), pu, pv, ph, ptx, pty, C.byref(visc.st), float(dt), pbx, pby,
                                                 pru, prv, space), "vertvisc_and_remnant")
+
+
+def vertvisc_step(u, v, h, dz, forces, visc: vertvisc_type, dt, G: DeviceGrid, CS: vertvisc_CS, visc_rem_u, visc_rem_v, update_velocities=True,
+                  taux_bot=None, tauy_bot=None):
+    """vertvisc_coef, then (update_velocities) vertvisc, then vertvisc_remnant with the same dt -- the sequences of
+    MOM_dynamics_split_RK2.F90:598-600 / :717-744 / :974-994 -- in one kernel per direction; same results as the calls."""
+    taux, tauy = forces if forces is not None else (None, None)
+    (pu, pv, ph, pdz, ptx, pty, pbx, pby, pru, prv), space = _space_of(
+        CS, (u, v, h, dz, taux, tauy, taux_bot, tauy_bot, visc_rem_u, visc_rem_v), "vertvisc_step")
+    check(_setup().mom6hip_vertvisc_step(G.handle, C.byref(CS.st), pu, pv, ph, pdz, ptx, pty, C.byref(visc.st), float(dt),
+                                         int(bool(update_velocities)), pbx, pby, pru, prv, space), "vertvisc_step")
 
 
 def vertvisc_ntrunc(G: DeviceGrid, CS: vertvisc_CS) -> int:

@@ -113,7 +113,7 @@ def test_gpu_parity(oracle, variant):
     import torch
     from mom6_amd.tracer_advect import DeviceGrid
     from mom6_amd.vert_friction import (vertvisc, vertvisc_and_remnant, vertvisc_coef, vertvisc_init, vertvisc_ntrunc, vertvisc_remnant,
-                                        vertvisc_type)
+                                        vertvisc_step, vertvisc_type)
     kw = VARIANTS[variant]
     pk = dict(KV=1.0e-4, HBBL=10.0)
     names = dict(harmonic_visc="HARMONIC_VISC", harm_BL_val="HARMONIC_BL_SCALE", Kvml_invZ2="KV_ML_INVZ2", Hmix="HMIX_FIXED",
@@ -161,6 +161,19 @@ def test_gpu_parity(oracle, variant):
             assert bits_equal(ru, N(u2)) and bits_equal(rv, N(v2)) and bits_equal(rvru, N(r2u)) and bits_equal(rvrv, N(r2v)), (what, "fused")
             assert bits_equal(rtbx, N(tbx)) and bits_equal(rtby, N(tby)), (what, "fused tau_bot")
             assert vertvisc_ntrunc(dg, CS) == 2 * rcs.ntrunc, (what, "fused ntrunc")
+            # coefficients + solve in one kernel, on a fresh control structure
+            CS3 = vertvisc_init(dg, device_arrays=resident, **pk)
+            u3, v3, r3u, r3v = X(st["u"]), X(st["v"]), X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V))
+            tbx, tby = X(g.zeros2(_abi.POS_U)), X(g.zeros2(_abi.POS_V))
+            vertvisc_step(u3, v3, h, X(dz), (X(taux), X(tauy)), visc, dt, dg, CS3, r3u, r3v, True, tbx, tby)
+            for n in ("a_u", "a_v", "h_u", "h_v"):
+                assert bits_equal(rcs._arrs[n], N(CS3.arrays[n])), (what, "step", n)
+            assert bits_equal(ru, N(u3)) and bits_equal(rv, N(v3)) and bits_equal(rvru, N(r3u)) and bits_equal(rvrv, N(r3v)), (what, "step")
+            assert bits_equal(rtbx, N(tbx)) and bits_equal(rtby, N(tby)), (what, "step tau_bot")
+            assert vertvisc_ntrunc(dg, CS3) == rcs.ntrunc, (what, "step ntrunc")
+            u4, v4 = X(st["u"]), X(st["v"])
+            vertvisc_step(u4, v4, h, X(dz), None, visc, dt, dg, CS3, r3u, r3v, False)      # :598-600: velocities untouched
+            assert bits_equal(st["u"], N(u4)) and bits_equal(rvru, N(r3u)) and bits_equal(rvrv, N(r3v)), (what, "step, remnant only")
         dg.close()
 
 
