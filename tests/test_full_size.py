@@ -1,0 +1,167 @@
+"""The hot path at BASELINE.json's full sizes (benchmark 360x180x75, OM4_025-shaped 1440x1080x75), checked through
+size-independent properties -- the oracle needs minutes at these sizes, the properties need none: conservation (tracer
+mass, volume), bounds / monotonicity, uniform-field preservation, the barotropic transport match, the momentum budget of
+the implicit viscous solve, idempotence of remapping onto the same grid.  Everything runs device-resident through the
+C ABI; reductions are fp64 torch sums on the device (tolerances are those of the summation, not of the kernels)."""
+import numpy as np
+import pytest
+
+from mom6_amd import _abi, synth
+
+SIZES = [(360, 180, 75), (1440, 1080, 75)]
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+
+
+def _inner(g, a, pos=H):
+    sj, si = g.csl(pos)
+    return a[..., sj, si]
+
+
+@pytest.fixture(scope="module", params=SIZES, ids=[f"{a}x{b}x{c}" for a, b, c in SIZES])
+def world(request):
+    import torch
+    from mom6_amd.tracer_advect import DeviceGrid
+    ni, nj, nk = request.param
+    g = synth.make_grid(ni, nj, nk, seed=20241020, rough_noise=0.0)
+    dg = DeviceGrid(g)
+    dyn = synth.make_dynamics_state(g, seed=11, device="cuda", umax=0.1, eta_amp=0.2, terrain_following=True)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device="cuda")
+    w = dict(g=g, dg=dg, dyn=dyn, areaT=T(g.areaT), mT=T(g.mask2dT), mu=T(g.mask2dCu), mv=T(g.mask2dCv))
+    yield w
+    dg.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_advect_tracer_conserves_and_stays_bounded(world):
+    import torch
+    from mom6_amd.tracer_advect import advect_tracer, tracer_advect_init
+    g, dg = world["g"], world["dg"]
+    st = synth.make_advection_state(g, ntr=4, seed=1, device="cuda", hot_frac=0.0)
+    tr = [t.clone() for t in st["tr"]] + [torch.full_like(st["tr"][0], 3.25)]      # + a uniform tracer
+    A = _inner(g, world["areaT"] * world["mT"])[None]
+    # the tracer amount before: concentrations times the volume the scheme starts from, h_end + dt*div(uhtr, vhtr)
+    sj, si = g.csl(H)
+    uh, vh = st["uhtr"], st["vhtr"]
+    div = (uh[:, sj, si.start + 1:si.stop + 1] - uh[:, sj, si.start:si.stop]) + (vh[:, sj.start + 1:sj.stop + 1, si] - vh[:, sj.start:sj.stop, si])
+    vol0 = _inner(g, st["h_end"]) * A + div
+    vol1 = _inner(g, st["h_end"]) * A
+    before = [float((_inner(g, t) * vol0).sum()) for t in tr]
+    lo = [float(_inner(g, t)[:, _inner(g, world["mT"]) > 0].min()) for t in tr]
+    hi = [float(_inner(g, t)[:, _inner(g, world["mT"]) > 0].max()) for t in tr]
+    stats = advect_tracer(st["h_end"], st["uhtr"], st["vhtr"], None, 3600.0, dg, tracer_advect_init(900.0, "PPM:H3"), tr)
+    dg.sync()
+    assert stats.iterations >= 1
+    for m, t in enumerate(tr):
+        after = float((_inner(g, t) * vol1).sum())
+        assert abs(after - before[m]) <= 1e-9 * abs(before[m]), (m, before[m], after)
+        x = _inner(g, t)[:, _inner(g, world["mT"]) > 0]
+        assert float(x.min()) >= lo[m] - 1e-12 * abs(lo[m]) and float(x.max()) <= hi[m] + 1e-12 * abs(hi[m]), m
+    # a uniform tracer stays uniform (flux form: to roundoff of (c*vol + c*in - c*out)/vol_new)
+    assert float((_inner(g, tr[-1])[:, _inner(g, world["mT"]) > 0] - 3.25).abs().max()) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_continuity_conserves_volume_and_matches_the_barotropic_transport(world):
+    import torch
+    from mom6_amd.continuity import continuity, continuity_PPM_init
+    g, dg, d = world["g"], world["dg"], world["dyn"]
+    cs = continuity_PPM_init(dg)
+    h1 = d["h"].clone(); uh = torch.zeros_like(d["u"]); vh = torch.zeros_like(d["v"])
+    continuity(d["u"], d["v"], d["h"], h1, uh, vh, 900.0, dg, cs)
+    A = _inner(g, world["areaT"] * world["mT"])[None]
+    v0, v1 = float((_inner(g, d["h"]) * A).sum()), float((_inner(g, h1) * A).sum())
+    # flux form: what leaves one cell enters its neighbour; the closed N/S edges and the re-entrant E/W edge lose nothing
+    # (only the Angstrom floor of vanished layers can add volume)
+    assert abs(v1 - v0) <= 1e-10 * v0
+    assert float(_inner(g, h1).min()) >= g.Angstrom_H
+    # with uhbt the layer transports are adjusted until their sum matches it to ETA_TOLERANCE
+    uhbt = (uh.sum(0) * 1.03).contiguous(); vhbt = (vh.sum(0) * 0.97).contiguous()
+    ucor, vcor = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
+    h2 = d["h"].clone()
+    continuity(d["u"], d["v"], d["h"], h2, uh, vh, 900.0, dg, cs, uhbt=uhbt, vhbt=vhbt, u_cor=ucor, v_cor=vcor)
+    sj, si = g.csl(U)
+    err = (uh.sum(0) - uhbt)[sj, si].abs() * 900.0
+    tol = 0.5 * g.nk * g.Angstrom_H * float(world["areaT"].max())      # dt*|uh_err| < tol_eta*area (:1162)
+    assert float(err.max()) <= 2.0 * tol + 1e-9 * float(uhbt.abs().max()) * 900.0
+
+
+@pytest.mark.gpu
+def test_remapping_conserves_and_is_the_identity_on_the_same_grid(world):
+    import torch
+    from mom6_amd.ale import ALE_remap_tracers, initialize_remapping
+    g, dg, d = world["g"], world["dg"], world["dyn"]
+    R = initialize_remapping("PPM_H4")
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    w = torch.rand(d["h"].shape, generator=gen, dtype=torch.float64, device="cuda") * 0.2 + 0.9
+    hn = (w * d["h"]); hn = (hn * (d["h"].sum(0, keepdim=True) / hn.sum(0, keepdim=True))).contiguous()
+    Tn, Sn = d["T"].clone(), d["S"].clone()
+    ALE_remap_tracers(R, dg, d["h"], hn, [Tn, Sn])
+    m = _inner(g, world["mT"]) > 0
+    for old, new in ((d["T"], Tn), (d["S"], Sn)):
+        c0 = (_inner(g, old) * _inner(g, d["h"])).sum(0)[m]; c1 = (_inner(g, new) * _inner(g, hn)).sum(0)[m]
+        assert float(((c1 - c0).abs() / c0.abs().clamp(min=1e-30)).max()) <= 1e-11      # column inventories
+        lo, hi = _inner(g, old).amin(0)[m], _inner(g, old).amax(0)[m]
+        x = _inner(g, new)[:, m]
+        assert bool((x >= lo[None] - 1e-12).all()) and bool((x <= hi[None] + 1e-12).all())
+    Ti = d["T"].clone()
+    ALE_remap_tracers(R, dg, d["h"], d["h"], [Ti])
+    assert float((_inner(g, Ti) - _inner(g, d["T"]))[:, m].abs().max()) <= 1e-12 * float(d["T"].abs().max())
+
+
+@pytest.mark.gpu
+def test_vertical_viscosity_budget_and_remnant_bounds(world):
+    import torch
+    from mom6_amd.vert_friction import vertvisc_init, vertvisc_step, vertvisc_type
+    g, dg, d = world["g"], world["dg"], world["dyn"]
+    CS = vertvisc_init(dg, KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2, CFL_BASED_TRUNCATIONS=False)
+    mu, mv = world["mu"], world["mv"]
+    visc = vertvisc_type(Kv_bbl_u=(3.0e-3 * mu).contiguous(), Kv_bbl_v=(3.0e-3 * mv).contiguous(),
+                         bbl_thick_u=(10.0 * mu).contiguous(), bbl_thick_v=(10.0 * mv).contiguous())
+    taux = (0.1 * mu).contiguous(); tauy = (-0.05 * mv).contiguous()
+    u, v = d["u"].clone(), d["v"].clone()
+    ru, rv = torch.zeros_like(u), torch.zeros_like(v)
+    tbx, tby = torch.zeros_like(mu), torch.zeros_like(mv)
+    dt = 900.0
+    vertvisc_step(u, v, d["h"], None, (taux, tauy), visc, dt, dg, CS, ru, rv, True, tbx, tby)
+    dg.sync()
+    for pos, new, old, tau, tb, hn, rem, mask in ((U, u, d["u"], taux, tbx, "h_u", ru, mu), (V, v, d["v"], tauy, tby, "h_v", rv, mv)):
+        sj, si = g.csl(pos)
+        m = mask[sj, si] > 0
+        hv = CS.arrays[hn][:, sj, si]
+        lhs = ((hv * new[:, sj, si]).sum(0) - (hv * old[:, sj, si]).sum(0))[m]
+        rhs = (dt * (tau[sj, si] - tb[sj, si]) / CS.st.H_to_RZ)[m]
+        scale = ((hv * old[:, sj, si]).abs().sum(0) + (dt * tau[sj, si] / CS.st.H_to_RZ).abs())[m] + 1e-30
+        assert float(((lhs - rhs).abs() / scale).max()) <= 1e-10
+        r = rem[:, sj, si][:, m]
+        assert float(r.min()) >= 0.0 and float(r.max()) <= 1.0 + 1e-13
+
+
+@pytest.mark.gpu
+def test_rk2_step_conserves_volume_and_stays_sane(world):
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.vert_friction import vertvisc_type
+    g, dg, d = world["g"], world["dg"], world["dyn"]
+    u, v, h, Tt, Ss = (d[k].clone() for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    mu, mv = world["mu"], world["mv"]
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, 900.0, dg, coriolis=dict(bound_coriolis=True),
+                                  vertvisc=dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2))
+    visc = vertvisc_type(Kv_bbl_u=(3.0e-3 * mu).contiguous(), Kv_bbl_v=(3.0e-3 * mv).contiguous(),
+                         bbl_thick_u=(10.0 * mu).contiguous(), bbl_thick_v=(10.0 * mv).contiguous())
+    taux, tauy = (0.1 * mu).contiguous(), Z(V, False)
+    A = _inner(g, world["areaT"] * world["mT"])[None]
+    v0 = float((_inner(g, h) * A).sum())
+    for n in range(2):
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, 900.0, (taux, tauy), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
+                               calc_dtbt=(n == 0))
+    dg.sync()
+    assert bool(torch.isfinite(u).all() and torch.isfinite(v).all() and torch.isfinite(h).all())
+    assert float(u.abs().max()) < 3.0 and float(_inner(g, h).min()) >= g.Angstrom_H
+    assert abs(float((_inner(g, h) * A).sum()) - v0) <= 1e-10 * v0
+    # the barotropic free surface stays the layer sum to the solver's tolerance (bt_mass_source feeds the difference back)
+    eta_h = _inner(g, h.sum(0) - torch.as_tensor(np.asarray(g.bathyT), device="cuda") * g.Z_to_H)
+    m = _inner(g, world["mT"]) > 0
+    assert float((eta_h - _inner(g, CS.eta))[m].abs().max()) < 0.05
