@@ -437,16 +437,20 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
 // ---- mass fluxes, block-cooperative form -----------------------------------------------------------
 // cont_flux_kernel re-reads five 3-D arrays on every pass over k (the first evaluation, every Newton iteration of
 // flux_adjust, the BT_cont fits): 3.6x the algorithmic bytes on the 1/4-degree grid, and that traffic is its run time.
-// Here a block of FC_NW waves owns 64 face columns and keeps them in REGISTERS for all passes: wave w holds layers
-// [w*KS, (w+1)*KS) of the 64 faces (u, visc_rem and the edge values / thickness of the cells on both sides: 8 doubles a
-// layer), so every 3-D input is read once.  A pass evaluates flux_layer for the wave's own layers and leaves the layer
-// values in LDS; the reference's k-ordered sums are then formed by ONE wave per sum, adding the nk values of each face in
-// order (same rounding as the reference's loop), and handed to all waves through LDS.  The scalar Newton / bracket logic
-// of each face is run redundantly by the eight waves (same inputs, same instructions, same result), which keeps the loop
-// trip count uniform over the block without any further exchange.  The two loops whose state runs through k
-// (the CFL brackets :663-716 and the duL/duR limits of set_*_BT_cont) are serial chains walked by one wave; the
-// divisions in them do not depend on the running state and are formed by all waves beforehand.
-constexpr int FC_NW = 8;
+// Here a block of FC_NW = 4 waves owns 32 face columns and keeps them in REGISTERS for all passes: every half-wave (32
+// lanes = the 32 faces) holds one slab of KS layers (u, visc_rem and the edge values / thickness of the cells on both
+// sides: 8 doubles a layer), eight slabs per block, so every 3-D input is read once.  (254 VGPRs and 65 KB of LDS: two
+// blocks per CU, whose load and arithmetic phases interleave.)  A pass evaluates flux_layer for the thread's own layers
+// and leaves the layer values in LDS; the reference's k-ordered sums are then formed by ONE half-wave per sum, adding the
+// nk values of each face in order (same rounding as the reference's loop), and handed to all threads through LDS.  The
+// scalar Newton / bracket logic of each face is run redundantly by the eight half-waves (same inputs, same instructions,
+// same result), which keeps the loop trip count uniform over the block without any further exchange.  The two loops
+// whose state runs through k (the CFL brackets :663-716 and the duL/duR limits of set_*_BT_cont) are serial chains
+// walked by one (half-)wave; the divisions of the bracket chain do not depend on the running state and are formed by all
+// threads beforehand.
+constexpr int FC_NW = 4;      // waves per block
+constexpr int FC_FL = 32;     // face columns per block: a wave is two half-waves of 32 faces holding different layers
+constexpr int FC_NS = 2 * FC_NW;      // layer slabs per block (one per half-wave)
 
 struct FaceConst { double dLf, cm, cp, dt; };
 
@@ -471,43 +475,44 @@ __device__ __forceinline__ double flux_reg(const FaceConst &F, double u, double 
 }
 
 // The k-ordered sums of the layer values the waves left in the LDS planes 0 .. nsum-1, each started from its init value:
-// wave q < nsum adds plane q; every wave gets all results.
-__device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int lane, int w, int nz, int nsum, double i0, double i1,
+// half-wave q < nsum adds plane q; every thread gets all results.
+__device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int fl, int sb, int nz, int nsum, double i0, double i1,
                                       double i2, double &r0, double &r1, double &r2) {
   __syncthreads();
-  if (w < nsum) {
-    double acc = (w == 0) ? i0 : ((w == 1) ? i1 : i2);
-    const int base = w * plane + lane;
-    for (int k = 0; k < nz; k++) acc = acc + fsm[base + k * 64];
-    fsm[roff + w * 64 + lane] = acc;
+  if (sb < nsum) {
+    double acc = (sb == 0) ? i0 : ((sb == 1) ? i1 : i2);
+    const int base = sb * plane + fl;
+    for (int k = 0; k < nz; k++) acc = acc + fsm[base + k * FC_FL];
+    fsm[roff + sb * FC_FL + fl] = acc;
   }
   __syncthreads();
-  r0 = fsm[roff + lane];
-  r1 = (nsum > 1) ? fsm[roff + 64 + lane] : 0.;
-  r2 = (nsum > 2) ? fsm[roff + 128 + lane] : 0.;
+  r0 = fsm[roff + fl];
+  r1 = (nsum > 1) ? fsm[roff + FC_FL + fl] : 0.;
+  r2 = (nsum > 2) ? fsm[roff + 2 * FC_FL + fl] : 0.;
 }
 
 template <int DIR, int KS>
-__global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) {
-  extern __shared__ double fsm[];      // three [KS*FC_NW][64] planes of layer values, then results [8][64], visc_rem max [FC_NW][64]
+__global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs p) {
+  extern __shared__ double fsm[];      // three [KS*FC_NS][FC_FL] planes of layer values, then results [8][FC_FL], visc_rem max [FC_NS][FC_FL]
   const m6::GridDev &g = p.g;
   const Dir<DIR> D(g);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fl = lane & (FC_FL - 1), sb = 2 * w + (lane >> 5);      // face within the block; layer slab of this half-wave
   const int nz = g.nk;
-  constexpr int FPB = (DIR == 0) ? 63 : 64;      // faces per block
-  const int fi_raw = p.fi0 + blockIdx.x * FPB + lane;
-  const bool valid = lane < FPB && fi_raw <= p.fi1;
-  // lanes past the row (and the 64th lane of a zonal block) do everything but store, so barriers stay uniform; they sit
+  constexpr int FPB = (DIR == 0) ? FC_FL - 1 : FC_FL;      // faces per block
+  const int fi_raw = p.fi0 + blockIdx.x * FPB + fl;
+  const bool valid = fl < FPB && fi_raw <= p.fi1;
+  // lanes past the row (and the last lane of a zonal half-wave) do everything but store, so barriers stay uniform; they sit
   // on the cell after the last face, whose reconstruction the last face needs, and never iterate (see `alive`)
   const int fi = (fi_raw <= p.fi1 + 1) ? fi_raw : p.fi1 + 1;
   const int fj = p.fj0 + blockIdx.y;
   const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
   const long s = D.sa(), fs = D.fsa();
   const long o2 = g.h2(fi, fj), f2 = D.f2(fi, fj);
-  constexpr int PL = KS * FC_NW * 64;          // one plane
-  constexpr int RO = 3 * PL, VO = RO + 8 * 64; // results, visc_rem max
-  const int k0 = w * KS;
-  const int sl = k0 * 64 + lane;               // this thread's slot of layer k0 in a plane
+  constexpr int PL = KS * FC_NS * FC_FL;          // one plane
+  constexpr int RO = 3 * PL, VO = RO + 8 * FC_FL; // results, visc_rem max
+  const int k0 = sb * KS;
+  const int sl = k0 * FC_FL + fl;                 // this thread's slot of layer k0 in a plane
 
   FaceConst F;
   F.dLf = D.dL_face()[f2]; F.dt = p.dt;
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       // the edge values of the two cells (cont_edge_kernel's arithmetic, PPM_reconstruction_x/y :2310-2662) from the
       // thicknesses along the direction: h_L / h_R never go through memory.  Zonal: the plus-side cell of a face is the
       // minus-side cell of the next lane's face, so each lane reconstructs one cell and hands it down one lane (the
-      // 64th lane of a block only serves its neighbour; blocks advance by FPB = 63 faces).  Meridional: both cells.
+      // last lane of a half-wave only serves its neighbour; blocks advance by FPB = 31 faces).  Meridional: both cells.
       const double *hh = p.h_in + o3;
       const double hm1 = hh[-s], hc0 = hh[0], hp1 = hh[s], hp2 = hh[2 * s];
       double Lm, Rm, Lp, Rp;
@@ -561,15 +566,15 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       double dd;
       const double uhk = flux_reg(F, ru[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
       if (valid && !p.uhbt) p.uh[f2 + (k0 + m) * fpl] = uhk;      // (with uhbt, uh is stored once, after the solve)
-      fsm[sl + m * 64] = uhk; fsm[PL + sl + m * 64] = dd;
+      fsm[sl + m * FC_FL] = uhk; fsm[PL + sl + m * FC_FL] = dd;
       vmax_w = max2(vmax_w, rvr[m]);
     }
   }
-  fsm[VO + w * 64 + lane] = vmax_w;
+  fsm[VO + sb * FC_FL + fl] = vmax_w;
   double uh_tot_0, duhdu_tot_0, dummy;
-  ksums(fsm, PL, RO, lane, w, nz, 2, 0.0, 0.0, 0.0, uh_tot_0, duhdu_tot_0, dummy);
+  ksums(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, uh_tot_0, duhdu_tot_0, dummy);
   double visc_rem_max = 0.0;
-  for (int q = 0; q < FC_NW; q++) visc_rem_max = max2(visc_rem_max, fsm[VO + q * 64 + lane]);      // (max is order-free)
+  for (int q = 0; q < FC_NS; q++) visc_rem_max = max2(visc_rem_max, fsm[VO + q * FC_FL + fl]);      // (max is order-free)
   if (!(p.visc_rem && p.o.use_visc_rem_max)) visc_rem_max = 1.0;
 
   // ---- the CFL brackets of the velocity correction, :637-716: two chains through k over u and visc_rem staged in LDS
@@ -601,23 +606,23 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       } else {
         bound = dx_W * CFL_dt - uk; cand = bound;
       }
-      fsm[sl + m * 64] = vr; fsm[PL + sl + m * 64] = bound; fsm[2 * PL + sl + m * 64] = cand;
+      fsm[sl + m * FC_FL] = vr; fsm[PL + sl + m * FC_FL] = bound; fsm[2 * PL + sl + m * FC_FL] = cand;
     }
   }
   __syncthreads();
-  if (w == 0) {
+  if (sb == 0) {
     double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
     if (p.visc_rem) {
 #pragma unroll 8
       for (int k = 0; k < nz; k++) {      // (all three loads up front: no LDS round trip inside the dependent chain)
-        const double vr = fsm[k * 64 + lane], bound = fsm[PL + k * 64 + lane], cand = fsm[2 * PL + k * 64 + lane];
+        const double vr = fsm[k * FC_FL + fl], bound = fsm[PL + k * FC_FL + fl], cand = fsm[2 * PL + k * FC_FL + fl];
         du_max_CFL = (du_max_CFL * vr > bound) ? cand : du_max_CFL;
       }
     } else {
 #pragma unroll 8
-      for (int k = 0; k < nz; k++) du_max_CFL = min2(du_max_CFL, fsm[2 * PL + k * 64 + lane]);
+      for (int k = 0; k < nz; k++) du_max_CFL = min2(du_max_CFL, fsm[2 * PL + k * FC_FL + fl]);
     }
-    fsm[RO + lane] = max2(du_max_CFL, 0.0);
+    fsm[RO + fl] = max2(du_max_CFL, 0.0);
   }
   __syncthreads();
 #pragma unroll
@@ -633,29 +638,29 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       } else {
         bound = -(dx_E * CFL_dt + uk); cand = bound;
       }
-      fsm[PL + sl + m * 64] = bound; fsm[2 * PL + sl + m * 64] = cand;
+      fsm[PL + sl + m * FC_FL] = bound; fsm[2 * PL + sl + m * FC_FL] = cand;
     }
   }
   __syncthreads();
-  if (w == 0) {
+  if (sb == 0) {
     double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
     if (p.visc_rem) {
 #pragma unroll 8
       for (int k = 0; k < nz; k++) {
-        const double vr = fsm[k * 64 + lane], bound = fsm[PL + k * 64 + lane], cand = fsm[2 * PL + k * 64 + lane];
+        const double vr = fsm[k * FC_FL + fl], bound = fsm[PL + k * FC_FL + fl], cand = fsm[2 * PL + k * FC_FL + fl];
         du_min_CFL = (du_min_CFL * vr < bound) ? cand : du_min_CFL;
       }
     } else {
 #pragma unroll 8
-      for (int k = 0; k < nz; k++) du_min_CFL = max2(du_min_CFL, fsm[2 * PL + k * 64 + lane]);
+      for (int k = 0; k < nz; k++) du_min_CFL = max2(du_min_CFL, fsm[2 * PL + k * FC_FL + fl]);
     }
-    fsm[RO + 64 + lane] = min2(du_min_CFL, 0.0);
+    fsm[RO + FC_FL + fl] = min2(du_min_CFL, 0.0);
   }
   __syncthreads();
-  const double du_max_CFL = fsm[RO + lane], du_min_CFL = fsm[RO + 64 + lane];
+  const double du_max_CFL = fsm[RO + fl], du_min_CFL = fsm[RO + FC_FL + fl];
   const double IaT = min2(g.IareaT[o2], g.IareaT[o2 + s]);
 
-  // ---- flux_adjust :1094-1243 for the 64 faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
+  // ---- flux_adjust :1094-1243 for the faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
   // phase 1 finds the correction that gives no net transport for set_*_BT_cont (:1290-1292)
   double du_ph[2] = {0.0, 0.0};
 #pragma unroll 1
@@ -717,11 +722,11 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
             double dd;
             pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
             const double uhk = flux_reg(F, ru[m] + du * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
-            fsm[sl + m * 64] = uhk; fsm[PL + sl + m * 64] = dd;
+            fsm[sl + m * FC_FL] = uhk; fsm[PL + sl + m * FC_FL] = dd;
           }
         }
         double usum, dsum, d2;
-        ksums(fsm, PL, RO, lane, w, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2);
+        ksums(fsm, PL, RO, fl, sb, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2);
         if (alive && itt < max_itts) {
           uh_err = usum; duhdu_tot = dsum;
           uh_err_best = min2(uh_err_best, fabs(uh_err));
@@ -750,40 +755,34 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       for (int m = 0; m < KS; m++)
         if (k0 + m < nz) p.u_cor[f2 + (k0 + m) * fpl] = ru[m] + du * rvr[m];
     }
-    if (w == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
+    if (sb == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
   }
   if (!p.set_BT_cont) return;
 
   // ---- set_zonal_BT_cont :1247-1410
   const double min_visc_rem = 0.1, CFL_min = 1e-6;
   const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
-  // the duR / duL limits (:1321-1330) are chains through k as well: two waves walk one each over u and visc_rem in LDS
+  // the duR / duL limits (:1321-1330) are chains through k as well: the two half-waves of wave 0 walk one each over u and
+  // visc_rem in LDS, in one loop (the chains differ in a sign and in the sense of the test: c = +-du_CFL)
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < KS; m++)
-    if (k0 + m < nz) { fsm[sl + m * 64] = ru[m]; fsm[PL + sl + m * 64] = rvr[m]; }
+    if (k0 + m < nz) { fsm[sl + m * FC_FL] = ru[m]; fsm[PL + sl + m * FC_FL] = rvr[m]; }
   __syncthreads();
   if (w == 0) {
-    double duR = min2(0.0, du0 - du_CFL);
+    const bool isL = (sb == 1);
+    const double c = isL ? -du_CFL : du_CFL;      // duR: du0 - du_CFL, test "> -du_CFL*vr";  duL: du0 + du_CFL, test "< du_CFL*vr"
+    double dlim = isL ? max2(0.0, du0 - c) : min2(0.0, du0 - c);
     for (int k = 0; k < nz; k++) {
-      const double vr = fsm[PL + k * 64 + lane], uk = fsm[k * 64 + lane];
+      const double vr = fsm[PL + k * FC_FL + fl], uk = fsm[k * FC_FL + fl];
       const double visc_rem_lim = max2(vr, min_visc_rem * visc_rem_max);
-      if (visc_rem_lim > 0.0)
-        if (uk + duR * visc_rem_lim > -du_CFL * vr) duR = -(uk + du_CFL * vr) / visc_rem_lim;
+      const double t = uk + dlim * visc_rem_lim, r = -c * vr;
+      if ((visc_rem_lim > 0.0) && (isL ? (t < r) : (t > r))) dlim = -(uk + c * vr) / visc_rem_lim;
     }
-    fsm[RO + lane] = duR;
-  } else if (w == 1) {
-    double duL = max2(0.0, du0 + du_CFL);
-    for (int k = 0; k < nz; k++) {
-      const double vr = fsm[PL + k * 64 + lane], uk = fsm[k * 64 + lane];
-      const double visc_rem_lim = max2(vr, min_visc_rem * visc_rem_max);
-      if (visc_rem_lim > 0.0)
-        if (uk + duL * visc_rem_lim < du_CFL * vr) duL = -(uk - du_CFL * vr) / visc_rem_lim;
-    }
-    fsm[RO + 64 + lane] = duL;
+    fsm[RO + sb * FC_FL + fl] = dlim;
   }
   __syncthreads();
-  const double duR = fsm[RO + lane], duL = fsm[RO + 64 + lane];
+  const double duR = fsm[RO + fl], duL = fsm[RO + FC_FL + fl];
   __syncthreads();      // the results area is written again below
   const bool cor = p.uhbt && p.u_cor;
   // the three evaluations of every layer; the marginal areas are summed first, the two transports after
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
       (void)flux_reg(F, uk + du0 * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], d0);
       (void)flux_reg(F, uk + duL * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
       (void)flux_reg(F, uk + duR * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
-      fsm[sl + m * 64] = d0; fsm[PL + sl + m * 64] = dL; fsm[2 * PL + sl + m * 64] = dR;
+      fsm[sl + m * FC_FL] = d0; fsm[PL + sl + m * FC_FL] = dL; fsm[2 * PL + sl + m * FC_FL] = dR;
       // u_cor (:744-748) and flux_thickness (:976-1057, with u_cor if present :809-815) ride on the same layer data
       double uc = uk;
       if (cor) { uc = uk + du * vr; if (valid) p.u_cor[f3] = uc; }
@@ -815,19 +814,19 @@ __global__ __launch_bounds__(64 * FC_NW) void cont_flux_coop_kernel(FluxArgs p) 
     }
   }
   double FAmt_0, FAmt_L, FAmt_R, uhtot_L, uhtot_R, d2;
-  ksums(fsm, PL, RO, lane, w, nz, 3, 0.0, 0.0, 0.0, FAmt_0, FAmt_L, FAmt_R);
+  ksums(fsm, PL, RO, fl, sb, nz, 3, 0.0, 0.0, 0.0, FAmt_0, FAmt_L, FAmt_R);
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     if (k0 + m < nz) {
       double dL, dR;
       pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
-      fsm[sl + m * 64] = flux_reg(F, ru[m] + duL * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
-      fsm[PL + sl + m * 64] = flux_reg(F, ru[m] + duR * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
+      fsm[sl + m * FC_FL] = flux_reg(F, ru[m] + duL * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
+      fsm[PL + sl + m * FC_FL] = flux_reg(F, ru[m] + duR * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
     }
   }
-  ksums(fsm, PL, RO, lane, w, nz, 2, 0.0, 0.0, 0.0, uhtot_L, uhtot_R, d2);
-  if (w == 0 && valid) {
+  ksums(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, uhtot_L, uhtot_R, d2);
+  if (sb == 0 && valid) {
     double FA_0 = FAmt_0, FA_avg = FAmt_0;
     if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
     if (FA_avg > max2(FA_0, FAmt_L)) FA_avg = max2(FA_0, FAmt_L);
@@ -855,7 +854,7 @@ bool flux_lane_only() {
 // Whether a flux launch takes the block-cooperative kernel (which forms the edge values itself): when there is a velocity
 // correction or BT_cont to compute and the layers fit its registers; the single-pass lane-per-column kernel otherwise.
 bool flux_is_coop(const FluxArgs &f) {
-  return (f.uhbt || f.set_BT_cont) && f.g.nk <= 10 * FC_NW && !flux_lane_only();
+  return (f.uhbt || f.set_BT_cont) && f.g.nk <= 10 * FC_NS && !flux_lane_only();
 }
 
 template <int DIR>
@@ -863,15 +862,15 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
   const int nk = f.g.nk;
   dim3 grid((n_along + 63) / 64, n_rows);
   if (flux_is_coop(f)) {
-    if (DIR == 0) grid.x = (n_along + 62) / 63;      // a zonal block yields 63 faces (cont_flux_coop_kernel)
+    grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {
-      const size_t lds = ((size_t)3 * KS * FC_NW * 64 + 8 * 64 + FC_NW * 64) * sizeof(double);
+      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL) * sizeof(double);
       M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, dim3(64 * FC_NW), lds, ctx->stream, f);
       return 0;
     };
-    if (nk <= FC_NW) return go(cont_flux_coop_kernel<DIR, 1>, 1);
-    if (nk <= 4 * FC_NW) return go(cont_flux_coop_kernel<DIR, 4>, 4);
+    if (nk <= FC_NS) return go(cont_flux_coop_kernel<DIR, 1>, 1);
+    if (nk <= 4 * FC_NS) return go(cont_flux_coop_kernel<DIR, 4>, 4);
     return go(cont_flux_coop_kernel<DIR, 10>, 10);
   }
   hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
