@@ -63,28 +63,25 @@ struct EdgeArgs {
   int i0, i1, j0, j1;      // cells to reconstruct (already including the +-1 along the direction)
 };
 
-// PPM_reconstruction + limiter for one cell from its five-point stencil along the direction (:2310-2662)
-__device__ __forceinline__ void edge_values(const ContOpts &o, double Angstrom_H, double hmm, double hm, double hc, double hp,
-                                            double hpp, double mmm, double mm, double mc, double mp, double mpp, double &L,
-                                            double &R) {
-  if (o.upwind_1st) { L = hc; R = hc; return; }
+// slope of a cell from its neighbours along the direction, masked (:2371-2381)
+__device__ __forceinline__ double ppm_slope(double hl, double hcc, double hr, double ml, double mcc, double mr) {
+  if ((ml * mcc * mr) == 0.0) return 0.0;
+  double sl = 0.5 * (hr - hl);
+  const double dMx = max3(hr, hl, hcc) - hcc;
+  const double dMn = hcc - min3(hr, hl, hcc);
+  return copysign(1., sl) * min2(fabs(sl), 2. * min2(dMx, dMn));
+}
+
+// the edge values of a cell from its own and its neighbours' thicknesses, their masks and (PPM) the three slopes, then the
+// limiter: the part of PPM_reconstruction_x/y (:2383-2420) + PPM_limit_pos / PPM_limit_CW84 after the slopes
+__device__ __forceinline__ void edge_finish(const ContOpts &o, double Angstrom_H, double hm, double hc, double hp, double mm, double mp,
+                                            double slp_m, double slp_c, double slp_p, double &L, double &R) {
   const double h_m1 = mm * hm + (1.0 - mm) * hc;
   const double h_p1 = mp * hp + (1.0 - mp) * hc;
   if (o.simple_2nd) {
     L = 0.5 * (h_m1 + hc);
     R = 0.5 * (h_p1 + hc);
   } else {
-    // slopes of cells a-1, a, a+1 (:2371-2381)
-    auto slope = [&](double hl, double hcc, double hr, double ml, double mcc, double mr) -> double {
-      if ((ml * mcc * mr) == 0.0) return 0.0;
-      double sl = 0.5 * (hr - hl);
-      const double dMx = max3(hr, hl, hcc) - hcc;
-      const double dMn = hcc - min3(hr, hl, hcc);
-      return copysign(1., sl) * min2(fabs(sl), 2. * min2(dMx, dMn));
-    };
-    const double slp_m = slope(hmm, hm, hc, mmm, mm, mc);
-    const double slp_c = slope(hm, hc, hp, mm, mc, mp);
-    const double slp_p = slope(hc, hp, hpp, mc, mp, mpp);
     const double oneSixth = 1. / 6.;
     L = 0.5 * (h_m1 + hc) + oneSixth * (slp_m - slp_c);
     R = 0.5 * (h_p1 + hc) + oneSixth * (slp_c - slp_p);
@@ -116,6 +113,35 @@ __device__ __forceinline__ void edge_values(const ContOpts &o, double Angstrom_H
       }
     }
   }
+}
+
+// PPM_reconstruction + limiter for one cell from its five-point stencil along the direction (:2310-2662)
+__device__ __forceinline__ void edge_values(const ContOpts &o, double Angstrom_H, double hmm, double hm, double hc, double hp,
+                                            double hpp, double mmm, double mm, double mc, double mp, double mpp, double &L,
+                                            double &R) {
+  if (o.upwind_1st) { L = hc; R = hc; return; }
+  double slp_m = 0.0, slp_c = 0.0, slp_p = 0.0;
+  if (!o.simple_2nd) {      // slopes of cells a-1, a, a+1
+    slp_m = ppm_slope(hmm, hm, hc, mmm, mm, mc);
+    slp_c = ppm_slope(hm, hc, hp, mm, mc, mp);
+    slp_p = ppm_slope(hc, hp, hpp, mc, mp, mpp);
+  }
+  edge_finish(o, Angstrom_H, hm, hc, hp, mm, mp, slp_m, slp_c, slp_p, L, R);
+}
+
+// the same for two neighbouring cells a, a+1 from the six thicknesses a-2 .. a+3: the slopes of a and a+1 serve both
+__device__ __forceinline__ void edge_values2(const ContOpts &o, double Angstrom_H, const double hh[6], const double mk[6], double &La,
+                                             double &Ra, double &Lb, double &Rb) {
+  if (o.upwind_1st) { La = hh[2]; Ra = hh[2]; Lb = hh[3]; Rb = hh[3]; return; }
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;      // slopes of cells a-1, a, a+1, a+2
+  if (!o.simple_2nd) {
+    s1 = ppm_slope(hh[0], hh[1], hh[2], mk[0], mk[1], mk[2]);
+    s2 = ppm_slope(hh[1], hh[2], hh[3], mk[1], mk[2], mk[3]);
+    s3 = ppm_slope(hh[2], hh[3], hh[4], mk[2], mk[3], mk[4]);
+    s4 = ppm_slope(hh[3], hh[4], hh[5], mk[3], mk[4], mk[5]);
+  }
+  edge_finish(o, Angstrom_H, hh[1], hh[2], hh[3], mk[1], mk[3], s1, s2, s3, La, Ra);
+  edge_finish(o, Angstrom_H, hh[2], hh[3], hh[4], mk[2], mk[4], s2, s3, s4, Lb, Rb);
 }
 
 // DIR 0: one thread per cell (the stencil is along the lanes).  DIR 1: one thread per column of EDGE_RJ rows, marching
@@ -540,16 +566,14 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
       const double *hh = p.h_in + o3;
       const double hm1 = hh[-s], hc0 = hh[0], hp1 = hh[s], hp2 = hh[2 * s];
       double Lm, Rm, Lp, Rp;
-      if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; }
-      else edge_values(p.o, g.Angstrom_H, wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
-                       wide ? mk[4] : 0.0, Lm, Rm);
       if (DIR == 0) {
+        if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; }
+        else edge_values(p.o, g.Angstrom_H, wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
+                         wide ? mk[4] : 0.0, Lm, Rm);
         Lp = __shfl_down(Lm, 1); Rp = __shfl_down(Rm, 1);
-      } else if (p.o.upwind_1st) {
-        Lp = hp1; Rp = hp1;
-      } else {
-        edge_values(p.o, g.Angstrom_H, wide ? hm1 : 0.0, hc0, hp1, hp2, wide ? hh[3 * s] : 0.0, wide ? mk[1] : 0.0, mk[2], mk[3],
-                    mk[4], mk[5], Lp, Rp);
+      } else {      // both cells at once: the slopes of the two cells serve both reconstructions
+        const double h6[6] = {wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, hp2, wide ? hh[3 * s] : 0.0};
+        edge_values2(p.o, g.Angstrom_H, h6, mk, Lm, Rm, Lp, Rp);
       }
       mE[m] = Rm; mD[m] = Lm - Rm; mC[m] = Lm + Rm - 2.0 * hc0;
       pW[m] = Lp; pD[m] = Rp - Lp; pC[m] = Lp + Rp - 2.0 * hp1;
