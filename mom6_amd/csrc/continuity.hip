@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   const long o2 = g.h2(fi, fj), f2 = D.f2(fi, fj);
   constexpr int PL = KS * FC_NS * FC_FL;          // one plane
   constexpr int RO = 3 * PL, VO = RO + 8 * FC_FL; // results, visc_rem max
+  constexpr int CO = VO + FC_NS * FC_FL;          // per-face values parked between the phases (instead of held in registers)
   const int k0 = sb * KS;
   const int sl = k0 * FC_FL + fl;                 // this thread's slot of layer k0 in a plane
 
@@ -681,7 +682,13 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     fsm[RO + FC_FL + fl] = min2(du_min_CFL, 0.0);
   }
   __syncthreads();
-  const double du_max_CFL = fsm[RO + fl], du_min_CFL = fsm[RO + FC_FL + fl];
+  // park the per-face values the later phases read once each (every half-wave holds the same values)
+  if (sb == 0) {
+    fsm[CO + fl] = fsm[RO + fl]; fsm[CO + FC_FL + fl] = fsm[RO + FC_FL + fl];      // du_max_CFL, du_min_CFL
+    fsm[CO + 2 * FC_FL + fl] = uh_tot_0; fsm[CO + 3 * FC_FL + fl] = duhdu_tot_0;
+    fsm[CO + 4 * FC_FL + fl] = visc_rem_max;
+  }
+  __syncthreads();
   const double IaT = min2(g.IareaT[o2], g.IareaT[o2 + s]);
 
   // ---- flux_adjust :1094-1243 for the faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
@@ -693,8 +700,8 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     const bool write_uh = (phase == 0);
     const double uhbt = (phase == 0) ? p.uhbt[f2] : 0.0;
     const int max_itts = 20;
-    double du = 0.0, du_max = du_max_CFL, du_min = du_min_CFL;
-    double uh_err = uh_tot_0 - uhbt, duhdu_tot = duhdu_tot_0, uh_err_best = fabs(uh_err);
+    double du = 0.0, du_max = fsm[CO + fl], du_min = fsm[CO + FC_FL + fl];
+    double uh_err = fsm[CO + 2 * FC_FL + fl] - uhbt, duhdu_tot = fsm[CO + 3 * FC_FL + fl], uh_err_best = fabs(uh_err);
     bool do_I = true, alive = valid;
     double du_eval = 0.0;      // du of this face's last re-evaluation of the transports (what uh_3d holds in the reference)
 #pragma unroll 1
@@ -795,11 +802,12 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   __syncthreads();
   if (w == 0) {
     const bool isL = (sb == 1);
+    const double vrm_bt = fsm[CO + 4 * FC_FL + fl];
     const double c = isL ? -du_CFL : du_CFL;      // duR: du0 - du_CFL, test "> -du_CFL*vr";  duL: du0 + du_CFL, test "< du_CFL*vr"
     double dlim = isL ? max2(0.0, du0 - c) : min2(0.0, du0 - c);
     for (int k = 0; k < nz; k++) {
       const double vr = fsm[PL + k * FC_FL + fl], uk = fsm[k * FC_FL + fl];
-      const double visc_rem_lim = max2(vr, min_visc_rem * visc_rem_max);
+      const double visc_rem_lim = max2(vr, min_visc_rem * vrm_bt);
       const double t = uk + dlim * visc_rem_lim, r = -c * vr;
       if ((visc_rem_lim > 0.0) && (isL ? (t < r) : (t > r))) dlim = -(uk + c * vr) / visc_rem_lim;
     }
@@ -888,7 +896,7 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
   if (flux_is_coop(f)) {
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {
-      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL) * sizeof(double);
+      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 6 * FC_FL) * sizeof(double);
       M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, dim3(64 * FC_NW), lds, ctx->stream, f);
       return 0;
