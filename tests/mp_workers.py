@@ -16,7 +16,7 @@ def _init(rank, world, port):
     return dist
 
 
-def halo_worker(rank, world, port, layout, rx, ry, out_dir):
+def halo_worker(rank, world, port, layout, rx, ry, out_dir, dims=(23, 17)):
     """Every rank fills the halos of its tile of random global fields through Domain.pass_var; the result must
     equal the same window of the one-tile halo update (oracle/domains.c), bit for bit."""
     import numpy as np
@@ -26,7 +26,7 @@ def halo_worker(rank, world, port, layout, rx, ry, out_dir):
     from oracle import orc
     dist = _init(rank, world, port)
     try:
-        NI, NJ, NK, halo = 23, 17, 3, 4
+        (NI, NJ), NK, halo = dims, 3, 4
         gg = synth.make_grid(NI, NJ, NK, halo=halo, reentrant_x=rx, reentrant_y=ry)
         dom = Domain(NI, NJ, layout, rank, halo, rx, ry)
         rng = np.random.default_rng(5)

@@ -38,6 +38,18 @@ def test_pass_var_two_ranks_gloo(tmp_path, layout, topo):
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
 
 
+@pytest.mark.parametrize("layout,topo", [((1, 4), (True, False)), ((2, 2), (True, True)), ((4, 1), (False, False)), ((1, 8), (True, False)),
+                                         ((2, 4), (True, False))])
+def test_pass_var_many_ranks_gloo(tmp_path, layout, topo):
+    """the layouts bench.py --gpus 4 / 8 uses (1xN latitude bands) and 2-D layouts, on CPU ranks"""
+    import torch.multiprocessing as mp
+    from mp_workers import halo_worker
+    n = layout[0] * layout[1]
+    dims = (max(23, 6 * layout[0] + 1), max(17, 5 * layout[1] + 2))      # uneven tiles, every tile at least as wide as the halo
+    mp.spawn(halo_worker, args=(n, free_port(), layout, topo[0], topo[1], str(tmp_path), dims), nprocs=n, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(n)] == ["1"] * n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [(1, 2), (2, 1)])
 @pytest.mark.parametrize("scheme", ["PPM:H3", "PLM"])
