@@ -38,10 +38,12 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   const int k = blockIdx.x;
   const int I0 = g.isc - 1 + blockIdx.y * TI, J0 = g.jsc - 1 + blockIdx.z * TJ;
   const int tid = threadIdx.y * TI + threadIdx.x;
+  // Index arithmetic in 32 bits from one base per point (the 2-D offsets fit easily): the 64-bit h2 / u2 / v2 / q2 of every
+  // access were most of this kernel's instructions.  uk / vk / hk ...: the layer's planes (wave-uniform pointers).
   const long kH = (long)g.nih * g.njh * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
-  auto H = [&](const double *a, int i, int j) { return a[kH + g.h2(i, j)]; };
-  auto U = [&](const double *a, int I, int j) { return a[kU + g.u2(I, j)]; };
-  auto V = [&](const double *a, int i, int J) { return a[kV + g.v2(i, J)]; };
+  const double *__restrict__ hk = p.h + kH, *__restrict__ uk = p.u + kU, *__restrict__ vk = p.v + kV;
+  const double *__restrict__ uhk = p.uh + kU, *__restrict__ vhk = p.vh + kV;
+  const int nih = g.nih, sU = g.nih + 1;      // row strides: h- and v-point arrays; u- and q-point arrays
   const int Iqmax = g.iec + 1, Jqmax = g.jec + 1;      // q is defined on (Isq-1:Ieq+1, Jsq-1:Jeq+1)
 
   for (int t = tid; t < (TI + 2) * (TJ + 2); t += TI * TJ) {
@@ -51,22 +53,25 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       const int I = I0 - 1 + tx, J = J0 - 1 + ty;
       double qv = 0.0, av = 0.0;
       if (I <= Iqmax && J <= Jqmax) {
-        const int i = I, j = J;
-        const double A00 = g.mask2dT[g.h2(i, j)] * g.areaT[g.h2(i, j)];
-        const double A10 = g.mask2dT[g.h2(i + 1, j)] * g.areaT[g.h2(i + 1, j)];
-        const double A01 = g.mask2dT[g.h2(i, j + 1)] * g.areaT[g.h2(i, j + 1)];
-        const double A11 = g.mask2dT[g.h2(i + 1, j + 1)] * g.areaT[g.h2(i + 1, j + 1)];
+        const int oh = (I - g.isd) + nih * (J - g.jsd);               // h2(i, j)
+        const int ou = (I - g.isd + 1) + sU * (J - g.jsd);            // u2(I, j)
+        const int ov = (I - g.isd) + nih * (J - g.jsd + 1);           // v2(i, J)
+        const int oq = (I - g.isd + 1) + sU * (J - g.jsd + 1);        // q2(I, J)
+        const double A00 = g.mask2dT[oh] * g.areaT[oh];
+        const double A10 = g.mask2dT[oh + 1] * g.areaT[oh + 1];
+        const double A01 = g.mask2dT[oh + nih] * g.areaT[oh + nih];
+        const double A11 = g.mask2dT[oh + nih + 1] * g.areaT[oh + nih + 1];
         const double Area_q = (A00 + A11) + (A10 + A01);
-        const double dvdx = (V(p.v, i + 1, J) * g.dyCv[g.v2(i + 1, J)] - V(p.v, i, J) * g.dyCv[g.v2(i, J)]);
-        const double dudy = (U(p.u, I, j + 1) * g.dxCu[g.u2(I, j + 1)] - U(p.u, I, j) * g.dxCu[g.u2(I, j)]);
-        const double h00 = H(p.h, i, j), h10 = H(p.h, i + 1, j), h01 = H(p.h, i, j + 1), h11 = H(p.h, i + 1, j + 1);
+        const double dvdx = (vk[ov + 1] * g.dyCv[ov + 1] - vk[ov] * g.dyCv[ov]);
+        const double dudy = (uk[ou + sU] * g.dxCu[ou + sU] - uk[ou] * g.dxCu[ou]);
+        const double h00 = hk[oh], h10 = hk[oh + 1], h01 = hk[oh + nih], h11 = hk[oh + nih + 1];
         const double hArea_u0 = 0.5 * (A00 * h00 + A10 * h10);     // hArea_u(I,j)
         const double hArea_u1 = 0.5 * (A01 * h01 + A11 * h11);     // hArea_u(I,j+1)
         const double hArea_v0 = 0.5 * (A00 * h00 + A01 * h01);     // hArea_v(i,J)
         const double hArea_v1 = 0.5 * (A10 * h10 + A11 * h11);     // hArea_v(i+1,J)
-        const double mB = g.mask2dBu[g.q2(I, J)];
-        const double rel_vort = (p.no_slip ? (2.0 - mB) : mB) * (dvdx - dudy) * g.IareaBu[g.q2(I, J)];
-        av = g.CoriolisBu[g.q2(I, J)] + rel_vort;
+        const double mB = g.mask2dBu[oq];
+        const double rel_vort = (p.no_slip ? (2.0 - mB) : mB) * (dvdx - dudy) * g.IareaBu[oq];
+        av = g.CoriolisBu[oq] + rel_vort;
         const double hArea_q = (hArea_u0 + hArea_u1) + (hArea_v0 + hArea_v1);
         const double Ih_q = Area_q / (hArea_q + p.vol_neglect);
         qv = av * Ih_q;
@@ -78,20 +83,20 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       const int i = I0 + tx, j = J0 + ty;
       double ke = 0.0;
       if (i <= g.iec + 1 && j <= g.jec + 1) {
-        const int I = i, J = j;
-        const double uE = U(p.u, I, j), uW = U(p.u, I - 1, j), vN = V(p.v, i, J), vS = V(p.v, i, J - 1);
+        const int oh = (i - g.isd) + nih * (j - g.jsd), ou = (i - g.isd + 1) + sU * (j - g.jsd), ov = (i - g.isd) + nih * (j - g.jsd + 1);
+        const double uE = uk[ou], uW = uk[ou - 1], vN = vk[ov], vS = vk[ov - nih];
         if (p.ke_scheme == MOM6HIP_KE_ARAKAWA) {
-          ke = ((g.areaCu[g.u2(I, j)] * (uE * uE) + g.areaCu[g.u2(I - 1, j)] * (uW * uW)) +
-                (g.areaCv[g.v2(i, J)] * (vN * vN) + g.areaCv[g.v2(i, J - 1)] * (vS * vS))) * 0.25 * g.IareaT[g.h2(i, j)];
+          ke = ((g.areaCu[ou] * (uE * uE) + g.areaCu[ou - 1] * (uW * uW)) +
+                (g.areaCv[ov] * (vN * vN) + g.areaCv[ov - nih] * (vS * vS))) * 0.25 * g.IareaT[oh];
         } else {
           const double up = 0.5 * (uW + fabs(uW)), um = 0.5 * (uE - fabs(uE));
           const double vp = 0.5 * (vS + fabs(vS)), vm = 0.5 * (vN - fabs(vN));
           if (p.ke_scheme == MOM6HIP_KE_SIMPLE_GUDONOV) {
             ke = (max2(up * up, um * um) + max2(vp * vp, vm * vm)) * 0.5;
           } else {
-            const double up2a = up * up * g.areaCu[g.u2(I - 1, j)], um2a = um * um * g.areaCu[g.u2(I, j)];
-            const double vp2a = vp * vp * g.areaCv[g.v2(i, J - 1)], vm2a = vm * vm * g.areaCv[g.v2(i, J)];
-            ke = (max2(um2a, up2a) + max2(vm2a, vp2a)) * 0.5 * g.IareaT[g.h2(i, j)];
+            const double up2a = up * up * g.areaCu[ou - 1], um2a = um * um * g.areaCu[ou];
+            const double vp2a = vp * vp * g.areaCv[ov - nih], vm2a = vm * vm * g.areaCv[ov];
+            ke = (max2(um2a, up2a) + max2(vm2a, vp2a)) * 0.5 * g.IareaT[oh];
           }
         }
       }
@@ -102,14 +107,14 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
 
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int I = I0 + tx, J = J0 + ty;           // this thread's u-point (I, j=J) and v-point (i=I, J)
+  const int ou = (I - g.isd + 1) + sU * (J - g.jsd), ov = (I - g.isd) + nih * (J - g.jsd + 1);      // u2(I, J), v2(I, J)
   // tile coordinates: q(I,J) = s_q[ty+1][tx+1]; KE(i,j) = s_ke[ty][tx]
   const double C1_12 = 1.0 / 12.0;
   // ---- CAu(I, j), j = J >= jsc, I <= iec : :644-752 ----
   if (J >= g.jsc && J <= g.jec && I <= g.iec) {
-    const int i = I, j = J;
     const double qN = s_q[ty + 1][tx + 1], qS = s_q[ty][tx + 1];           // q(I,J), q(I,J-1)
-    const double vh_ne = V(p.vh, i + 1, J), vh_nw = V(p.vh, i, J), vh_sw = V(p.vh, i, J - 1), vh_se = V(p.vh, i + 1, J - 1);
-    const double IdxCu = g.IdxCu[g.u2(I, j)];
+    const double vh_ne = vhk[ov + 1], vh_nw = vhk[ov], vh_sw = vhk[ov - nih], vh_se = vhk[ov - nih + 1];
+    const double IdxCu = g.IdxCu[ou];
     double ca;
     if (p.scheme == MOM6HIP_SADOURNY75_ENERGY) {
       ca = 0.25 * (qN * (vh_ne + vh_nw) + qS * (vh_sw + vh_se)) * IdxCu;
@@ -125,20 +130,19 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     }
     if (p.bound) {
       const double avN = s_av[ty + 1][tx + 1], avS = s_av[ty][tx + 1];
-      const double fv1 = avN * V(p.v, i + 1, J), fv2 = avN * V(p.v, i, J);
-      const double fv3 = avS * V(p.v, i + 1, J - 1), fv4 = avS * V(p.v, i, J - 1);
+      const double fv1 = avN * vk[ov + 1], fv2 = avN * vk[ov];
+      const double fv3 = avS * vk[ov - nih + 1], fv4 = avS * vk[ov - nih];
       ca = min2(ca, max4(fv1, fv2, fv3, fv4));
       ca = max2(ca, min4(fv1, fv2, fv3, fv4));
     }
     const double KEx = (s_ke[ty][tx + 1] - s_ke[ty][tx]) * IdxCu;
-    p.CAu[kU + g.u2(I, j)] = ca - KEx;
+    p.CAu[kU + ou] = ca - KEx;
   }
   // ---- CAv(i, J), i = I >= isc, J <= jec : :763-876 ----
   if (I >= g.isc && I <= g.iec && J <= g.jec) {
-    const int i = I, j = J;
     const double qE = s_q[ty + 1][tx + 1], qW = s_q[ty + 1][tx];           // q(I,J), q(I-1,J)
-    const double uh_sw = U(p.uh, I - 1, j), uh_nw = U(p.uh, I - 1, j + 1), uh_se = U(p.uh, I, j), uh_ne = U(p.uh, I, j + 1);
-    const double IdyCv = g.IdyCv[g.v2(i, J)];
+    const double uh_sw = uhk[ou - 1], uh_nw = uhk[ou - 1 + sU], uh_se = uhk[ou], uh_ne = uhk[ou + sU];
+    const double IdyCv = g.IdyCv[ov];
     double ca;
     if (p.scheme == MOM6HIP_SADOURNY75_ENERGY) {
       ca = -0.25 * (qW * (uh_sw + uh_nw) + qE * (uh_se + uh_ne)) * IdyCv;
@@ -155,13 +159,13 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     }
     if (p.bound) {
       const double avE = s_av[ty + 1][tx + 1], avW = s_av[ty + 1][tx];
-      const double fu1 = -avE * U(p.u, I, j + 1), fu2 = -avE * U(p.u, I, j);
-      const double fu3 = -avW * U(p.u, I - 1, j + 1), fu4 = -avW * U(p.u, I - 1, j);
+      const double fu1 = -avE * uk[ou + sU], fu2 = -avE * uk[ou];
+      const double fu3 = -avW * uk[ou - 1 + sU], fu4 = -avW * uk[ou - 1];
       ca = min2(ca, max4(fu1, fu2, fu3, fu4));
       ca = max2(ca, min4(fu1, fu2, fu3, fu4));
     }
     const double KEy = (s_ke[ty + 1][tx] - s_ke[ty][tx]) * IdyCv;
-    p.CAv[kV + g.v2(i, J)] = ca - KEy;
+    p.CAv[kV + ov] = ca - KEy;
   }
 }
 
