@@ -817,18 +817,18 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   const double duR = fsm[RO + fl], duL = fsm[RO + FC_FL + fl];
   __syncthreads();      // the results area is written again below
   const bool cor = p.uhbt && p.u_cor;
-  // the three evaluations of every layer; the marginal areas are summed first, the two transports after
+  // the three evaluations of every layer, each done once: the first round sums FAmt_0, FAmt_L and uhtot_L, the second
+  // FAmt_R and uhtot_R (three planes)
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     if (k0 + m < nz) {
       const long f3 = f2 + (k0 + m) * fpl;
       const double vr = rvr[m], uk = ru[m];
-      double d0, dL, dR;
+      double d0, dL;
       pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
       (void)flux_reg(F, uk + du0 * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], d0);
-      (void)flux_reg(F, uk + duL * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
-      (void)flux_reg(F, uk + duR * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
-      fsm[sl + m * FC_FL] = d0; fsm[PL + sl + m * FC_FL] = dL; fsm[2 * PL + sl + m * FC_FL] = dR;
+      const double uh_L = flux_reg(F, uk + duL * vr, vr, mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
+      fsm[sl + m * FC_FL] = d0; fsm[PL + sl + m * FC_FL] = dL; fsm[2 * PL + sl + m * FC_FL] = uh_L;
       // u_cor (:744-748) and flux_thickness (:976-1057, with u_cor if present :809-815) ride on the same layer data
       double uc = uk;
       if (cor) { uc = uk + du * vr; if (valid) p.u_cor[f3] = uc; }
@@ -846,18 +846,18 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     }
   }
   double FAmt_0, FAmt_L, FAmt_R, uhtot_L, uhtot_R, d2;
-  ksums(fsm, PL, RO, fl, sb, nz, 3, 0.0, 0.0, 0.0, FAmt_0, FAmt_L, FAmt_R);
+  ksums(fsm, PL, RO, fl, sb, nz, 3, 0.0, 0.0, 0.0, FAmt_0, FAmt_L, uhtot_L);
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     if (k0 + m < nz) {
-      double dL, dR;
+      double dR;
       pin(mD[m]); pin(mC[m]); pin(pD[m]); pin(pC[m]);
-      fsm[sl + m * FC_FL] = flux_reg(F, ru[m] + duL * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dL);
-      fsm[PL + sl + m * FC_FL] = flux_reg(F, ru[m] + duR * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
+      const double uh_R = flux_reg(F, ru[m] + duR * rvr[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dR);
+      fsm[sl + m * FC_FL] = dR; fsm[PL + sl + m * FC_FL] = uh_R;
     }
   }
-  ksums(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, uhtot_L, uhtot_R, d2);
+  ksums(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, FAmt_R, uhtot_R, d2);
   if (sb == 0 && valid) {
     double FA_0 = FAmt_0, FA_avg = FAmt_0;
     if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
