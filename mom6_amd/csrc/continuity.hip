@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   // The state of these loops runs through k, so one wave walks them; what it needs per layer -- the bound the bracket
   // is tested against and the value it takes when the test fails (a division) -- does not depend on that state and is
   // formed by all waves for their own layers first: planes 0 / 1 / 2 = visc_rem, bound, new bracket.
-  __syncthreads();      // the sums in planes 0 / 1 have been read
+  // (no barrier needed before the planes are rewritten: every read of them lies between the two barriers of ksums)
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     if (k0 + m < nz) {
@@ -647,7 +647,9 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
 #pragma unroll 8
       for (int k = 0; k < nz; k++) du_max_CFL = min2(du_max_CFL, fsm[2 * PL + k * FC_FL + fl]);
     }
-    fsm[RO + fl] = max2(du_max_CFL, 0.0);
+    fsm[CO + fl] = max2(du_max_CFL, 0.0);
+    // park the per-face values the later phases read once each (every half-wave holds the same values)
+    fsm[CO + 2 * FC_FL + fl] = uh_tot_0; fsm[CO + 3 * FC_FL + fl] = duhdu_tot_0; fsm[CO + 4 * FC_FL + fl] = visc_rem_max;
   }
   __syncthreads();
 #pragma unroll
@@ -679,14 +681,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
 #pragma unroll 8
       for (int k = 0; k < nz; k++) du_min_CFL = max2(du_min_CFL, fsm[2 * PL + k * FC_FL + fl]);
     }
-    fsm[RO + FC_FL + fl] = min2(du_min_CFL, 0.0);
-  }
-  __syncthreads();
-  // park the per-face values the later phases read once each (every half-wave holds the same values)
-  if (sb == 0) {
-    fsm[CO + fl] = fsm[RO + fl]; fsm[CO + FC_FL + fl] = fsm[RO + FC_FL + fl];      // du_max_CFL, du_min_CFL
-    fsm[CO + 2 * FC_FL + fl] = uh_tot_0; fsm[CO + 3 * FC_FL + fl] = duhdu_tot_0;
-    fsm[CO + 4 * FC_FL + fl] = visc_rem_max;
+    fsm[CO + FC_FL + fl] = min2(du_min_CFL, 0.0);
   }
   __syncthreads();
   const double IaT = min2(g.IareaT[o2], g.IareaT[o2 + s]);
@@ -745,7 +740,6 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
       }
       if (!__any(alive)) break;      // the same in every wave of the block: they hold the same values
       if ((itt < max_itts) || write_uh) {
-        __syncthreads();             // the results of the previous pass have been read
         if (alive) du_eval = du;
 #pragma unroll
         for (int m = 0; m < KS; m++) {
@@ -795,7 +789,6 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
   // the duR / duL limits (:1321-1330) are chains through k as well: the two half-waves of wave 0 walk one each over u and
   // visc_rem in LDS, in one loop (the chains differ in a sign and in the sense of the test: c = +-du_CFL)
-  __syncthreads();
 #pragma unroll
   for (int m = 0; m < KS; m++)
     if (k0 + m < nz) { fsm[sl + m * FC_FL] = ru[m]; fsm[PL + sl + m * FC_FL] = rvr[m]; }
@@ -815,7 +808,6 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   }
   __syncthreads();
   const double duR = fsm[RO + fl], duL = fsm[RO + FC_FL + fl];
-  __syncthreads();      // the results area is written again below
   const bool cor = p.uhbt && p.u_cor;
   // the three evaluations of every layer, each done once: the first round sums FAmt_0, FAmt_L and uhtot_L, the second
   // FAmt_R and uhtot_R (three planes)
@@ -847,7 +839,6 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   }
   double FAmt_0, FAmt_L, FAmt_R, uhtot_L, uhtot_R, d2;
   ksums(fsm, PL, RO, fl, sb, nz, 3, 0.0, 0.0, 0.0, FAmt_0, FAmt_L, uhtot_L);
-  __syncthreads();
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     if (k0 + m < nz) {
