@@ -350,10 +350,15 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = g.zeros2(_abi.POS_V)
     loop_s = C.c_double.in_dll(orc.lib(), "orc_btstep_loop_seconds")
     st.step(taux, tauy, calc_dtbt=True)        # the first step sets DTBT, as on the GPU
+    # two of the cycle's baroclinic steps are timed (every step does the same work), then the thermodynamic block once
+    n_dyn = min(2, steps_per_advect)
     loop_s.value = 0.0
     t0 = time.perf_counter()
-    for n in range(steps_per_advect):
+    for n in range(n_dyn):
         st.step(taux, tauy)
+    t_dyn = time.perf_counter() - t0
+    t_2d = loop_s.value
+    t0 = time.perf_counter()
     tr = [st.T, st.S] + passive
     orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, DT_THERM, DT, scheme, tr)
     kn = (np.arange(nk_s) + 0.5) / nk_s
@@ -365,17 +370,17 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     orc.ale_remap_velocities(g, REMAP_SCHEME, hou, hov, hnu, hnv, st.u, st.v)
     for f, ps in ((st.u, 1), (st.v, 2), (st.T, 0), (st.S, 0), (h_new, 0)):
         orc.halo_update(g, f, ps)
-    t_used = time.perf_counter() - t0
-    t_2d = loop_s.value
-    t_3d = t_used - t_2d
-    sec_per_step = (t_3d / (g.ni * g.nj * nk_s) * full_cells + t_2d) / steps_per_advect
+    t_thermo = time.perf_counter() - t0
+    t_used = t_dyn + t_thermo
+    scale = full_cells / (g.ni * g.nj * nk_s)
+    sec_per_step = ((t_dyn - t_2d) * scale + t_2d) / n_dyn + t_thermo * scale / steps_per_advect
     return {
         "value": DT / sec_per_step / 365.0, "unit": "SYPD", "cores": 1, "kind": "port",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / full_cells,
-        "sample": f"1 cycle of {steps_per_advect} baroclinic steps + advect_tracer + ALE regrid/remap (the GPU step's calls) on "
-                  f"{g.ni}x{g.nj}x{nk_s} (same horizontal grid, 2 of {grid.nk} layers); 3-D work ({t_3d:.1f} s) scaled per "
-                  f"cell to the full grid, the 2-D barotropic subcycle ({t_2d:.1f} s, nstep={st.bcs.nstep_last}) counted as "
-                  f"measured; {t_used:.1f} s of CPU",
+        "sample": f"{n_dyn} baroclinic steps ({t_dyn:.1f} s) and one advect_tracer + ALE regrid/remap block ({t_thermo:.1f} s, counted "
+                  f"1/{steps_per_advect} per step) -- the GPU step's calls -- on {g.ni}x{g.nj}x{nk_s} (same horizontal grid, 2 of "
+                  f"{grid.nk} layers); 3-D work scaled per cell to the full grid, the 2-D barotropic subcycle "
+                  f"({t_2d:.1f} s, nstep={st.bcs.nstep_last}) counted as measured; {t_used:.1f} s of CPU",
     }
 
 
