@@ -19,8 +19,10 @@
 // Algorithmic traffic per call: read u, v, hin, visc_rem_u/v, write h, uh, vh, u_cor, v_cor = 96 B/cell
 // (SURVEY.md section 8d); this first version also materialises the edge values like the reference does
 // (+32 B/cell written and re-read per direction).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -888,7 +890,11 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {
       const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 6 * FC_FL) * sizeof(double);
-      M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      static std::vector<const void *> configured;      // (one process drives one device)
+      if (std::find(configured.begin(), configured.end(), (const void *)kern) == configured.end()) {
+        M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured.push_back((const void *)kern);
+      }
       hipLaunchKernelGGL(kern, grid, dim3(64 * FC_NW), lds, ctx->stream, f);
       return 0;
     };
