@@ -8,6 +8,7 @@
 // The sub-cell decomposition depends only on (h_old, h_new): it is built once per column and reused
 // for every tracer (the reference rebuilds it per tracer; the results are identical).
 // Algorithmic traffic: read h_old, h_new once + read/write each tracer = (16 + 16*ntr) B per cell.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -1104,10 +1105,10 @@ int launch_wave_remap(mom6hip_ctx_t *ctx, WRemapArgs a) {
   const int xs = (a.pos == MOM6HIP_POS_U) ? 1 : 0, ys = (a.pos == MOM6HIP_POS_V) ? 1 : 0;
   const size_t lds = wcol_bytes(g.nk) * WR_NCOL;
   M6_REQUIRE(lds <= 160 * 1024, "ALE remap: too many layers for the LDS-resident kernel");
-  static bool attr_set = false;
-  if (!attr_set) {
+  std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context
+  if (std::find(configured.begin(), configured.end(), (const void *)ale_remap_wave_kernel) == configured.end()) {
     M6_HIP(hipFuncSetAttribute((const void *)ale_remap_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    configured.push_back((const void *)ale_remap_wave_kernel);
   }
   const int ncol = g.iec - g.isc + 1 + xs, nrow = g.jec - g.jsc + 1 + ys;
   const int nbx = (ncol + WR_NCOL - 1) / WR_NCOL;

@@ -91,6 +91,7 @@ struct mom6hip_ctx {
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   m6::DevBuf rk2_scratch;       // the automatic arrays of step_MOM_dyn_split_RK2
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
+  std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)
   bool vv_ntrunc_ready = false;
   // hipGraphs of the barotropic subcycle, keyed on everything baked into their nodes (barotropic.hip)

@@ -532,7 +532,9 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   const bool valid = fl < FPB && fi_raw <= p.fi1;
   // lanes past the row (and the last lane of a zonal half-wave) do everything but store, so barriers stay uniform; they sit
   // on the cell after the last face, whose reconstruction the last face needs, and never iterate (see `alive`)
-  const int fi = (fi_raw <= p.fi1 + 1) ? fi_raw : p.fi1 + 1;
+  // (meridionally nothing is handed between lanes: idle lanes sit on the last face, which is always inside the row)
+  const int fi_last = (DIR == 0) ? p.fi1 + 1 : p.fi1;
+  const int fi = (fi_raw <= fi_last) ? fi_raw : fi_last;
   const int fj = p.fj0 + blockIdx.y;
   const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
   const long s = D.sa(), fs = D.fsa();
@@ -553,7 +555,8 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   double mk[6];                                               // mask2dT of cells -2 .. +3 along the direction
   {
     const double *mm = g.mask2dT + o2;
-    mk[0] = wide ? mm[-2 * s] : 0.0; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s]; mk[5] = wide ? mm[3 * s] : 0.0;
+    mk[0] = wide ? mm[-2 * s] : 0.0; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s];
+    mk[5] = (wide && DIR == 1) ? mm[3 * s] : 0.0;      // (only the meridional pair of reconstructions reads cell +3)
   }
   double ru[KS], rvr[KS], mE[KS], mD[KS], mC[KS], pW[KS], pD[KS], pC[KS];
 #pragma unroll
@@ -890,7 +893,7 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {
       const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 6 * FC_FL) * sizeof(double);
-      static std::vector<const void *> configured;      // (one process drives one device)
+      std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context
       if (std::find(configured.begin(), configured.end(), (const void *)kern) == configured.end()) {
         M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured.push_back((const void *)kern);

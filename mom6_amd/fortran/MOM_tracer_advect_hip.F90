@@ -4,13 +4,14 @@
 !! libmom6hip's HIP kernels through mom6hip_c_api.
 !!
 !! Build note: this file is compiled INSIDE a MOM6 source tree in place of
-!! src/tracer/MOM_tracer_advect.F90 (it uses the real MOM_grid, MOM_tracer_registry, ... modules), and
-!! the executable is linked with -lmom6hip.  It cannot be compiled in this repository's container
-!! (those modules need FMS); tests/fortran/advect_driver.F90 exercises the same C binding without them.
+!! src/tracer/MOM_tracer_advect.F90 (it uses the real MOM_grid, MOM_tracer_registry, ... modules), together with
+!! mom6hip_c_api.F90 and mom6hip_MOM_glue.F90, and the executable is linked with -lmom6hip.  In this repository it is
+!! compiled against the type-only stand-ins of tests/fortran/stubs (tests/test_fortran_abi.py).
 module MOM_tracer_advect
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
+use mom6hip_MOM_glue,    only : mom6hip_context_create, mom6hip_read_topology
 use MOM_cpu_clock,       only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
 use MOM_diag_mediator,   only : diag_ctrl, time_type
 use MOM_error_handler,   only : MOM_error, FATAL, WARNING
@@ -36,6 +37,7 @@ type, public :: tracer_advect_CS ; private
   logical :: usePPM
   logical :: useHuynh
   logical :: useHuynhStencilBug = .false.
+  logical :: reentrant(2) = .false. !< REENTRANT_X, REENTRANT_Y (for the library's own wrap on a one-tile domain)
   type(c_ptr) :: ctx = c_null_ptr  !< mom6hip_ctx_t: metrics and work space resident on the GPU
 end type tracer_advect_CS
 
@@ -80,7 +82,9 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
        "are not supported by the GPU tracer advection.")
   call cpu_clock_begin(id_clock_advect)
 
-  if (.not. c_associated(CS%ctx)) call create_context(G, GV, CS)
+  ! the context: metrics on the GPU, the device of this PE, and MOM6's pass_var / sum_across_PEs behind the group pass
+  ! of every iteration (do_group_pass(CS%pass_uhr_vhr_t_hprev), :205-206) whenever the tile has neighbours
+  if (.not. c_associated(CS%ctx)) call mom6hip_context_create(G, GV, CS%ctx, CS%reentrant)
 
   allocate(tr(Reg%ntr), cu(Reg%ntr))
   do m=1,Reg%ntr
@@ -111,31 +115,6 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
 
   call cpu_clock_end(id_clock_advect)
 end subroutine advect_tracer
-
-!> Upload the grid metrics once and keep the context in the control structure.
-subroutine create_context(G, GV, CS)
-  type(ocean_grid_type), target, intent(in) :: G
-  type(verticalGrid_type), intent(in)    :: GV
-  type(tracer_advect_CS),  intent(inout) :: CS
-  type(mom6hip_grid_t) :: cg
-  integer :: rc
-
-  if (.not. G%symmetric) call MOM_error(FATAL, "MOM_tracer_advect (HIP): SYMMETRIC_MEMORY_ is required.")
-  cg%isc = G%isc ; cg%iec = G%iec ; cg%jsc = G%jsc ; cg%jec = G%jec
-  cg%isd = G%isd ; cg%ied = G%ied ; cg%jsd = G%jsd ; cg%jed = G%jed
-  cg%nk = GV%ke ; cg%symmetric = 1 ; cg%first_direction = G%first_direction
-  ! One tile per process: the wrap-around is then done by the library; with more than one tile the
-  ! halo exchange is the RCCL path (see INTEGRATION.md) and both flags are 0.
-  cg%reentrant_x = 0 ; cg%reentrant_y = 0
-  cg%Angstrom_H = GV%Angstrom_H ; cg%H_subroundoff = GV%H_subroundoff
-  cg%dZ_subroundoff = GV%dZ_subroundoff ; cg%H_to_Z = GV%H_to_Z ; cg%Z_to_H = GV%Z_to_H
-  cg%g_Earth = GV%g_Earth ; cg%Rho0 = GV%Rho0
-  cg%mask2dT = c_loc(G%mask2dT) ; cg%areaT = c_loc(G%areaT) ; cg%IareaT = c_loc(G%IareaT)
-  cg%mask2dCu = c_loc(G%mask2dCu) ; cg%mask2dCv = c_loc(G%mask2dCv)
-  rc = mom6hip_init(0)
-  if (rc == 0) rc = mom6hip_grid_create(cg, c_null_ptr, CS%ctx)
-  if (rc /= 0) call MOM_error(FATAL, "MOM_tracer_advect (HIP): "//mom6hip_error_string())
-end subroutine create_context
 
 !> Same parameters as the reference tracer_advect_init (:1090-1150).
 subroutine tracer_advect_init(Time, G, US, param_file, diag, CS)
@@ -180,6 +159,7 @@ subroutine tracer_advect_init(Time, G, US, param_file, diag, CS)
     call get_param(param_file, mdl, "USE_HUYNH_STENCIL_BUG", CS%useHuynhStencilBug, &
         desc="If true, use a stencil width of 2 in PPM:H3 tracer advection.", default=.false.)
   endif
+  call mom6hip_read_topology(param_file, CS%reentrant)
   id_clock_advect = cpu_clock_id('(Ocean advect tracer)', grain=CLOCK_MODULE)
 end subroutine tracer_advect_init
 

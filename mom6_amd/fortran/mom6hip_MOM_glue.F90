@@ -1,0 +1,165 @@
+!> What every drop-in module shim needs from the host model: a GPU context built from ocean_grid_type /
+!! verticalGrid_type (all metrics the kernels read, SURVEY.md section 8b), the GPU chosen from the node-local rank, and
+!! the collectives that happen INSIDE library calls routed to MOM6's own MOM_domains / MOM_coms:
+!!   * the group passes (src/tracer/MOM_tracer_advect.F90:205-206, src/core/MOM_barotropic.F90:1842-1850,
+!!     src/core/MOM_dynamics_split_RK2.F90:541 ...) -> pass_var on host copies of the device arrays;
+!!   * sum_across_PEs(domore_k) (MOM_tracer_advect.F90:305) and min_across_PEs(dtbt_max) (MOM_barotropic.F90:2915).
+!! The library's own wrap kernels are only used when the whole domain is one tile AND the shim knows the topology
+!! (REENTRANT_X / REENTRANT_Y read from the parameter file); otherwise reentrant_x = reentrant_y = 0 and every halo update
+!! goes through MOM6's pass_var, which is correct for any layout, mask table or periodicity (a tripolar fold is refused).
+!!
+!! Compiled inside a MOM6 source tree (it uses the real MOM_grid, MOM_domains, MOM_coms); tests/fortran/stubs holds
+!! type-only stand-ins so that this repository can at least compile and drive it on one PE.
+module mom6hip_MOM_glue
+
+use, intrinsic :: iso_c_binding
+use mom6hip_c_api
+use MOM_coms,          only : num_PEs, PE_here, sum_across_PEs, min_across_PEs
+use MOM_domains,       only : pass_var, CENTER, EAST_FACE, NORTH_FACE, CORNER
+use MOM_error_handler, only : MOM_error, FATAL
+use MOM_file_parser,   only : get_param, param_file_type
+use MOM_grid,          only : ocean_grid_type
+use MOM_verticalGrid,  only : verticalGrid_type
+implicit none ; private
+
+public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_fatal_if
+
+!> The grid of the (single) ocean instance the callbacks act on
+type(ocean_grid_type), pointer, save :: G_cb => NULL()
+type(c_ptr), save :: ctx_cb = c_null_ptr   !< the context whose stream the staged copies use
+integer, save :: nk_cb = 0
+
+contains
+
+!> Turn a nonzero return code of the library into MOM_error(FATAL) with the library's message (SURVEY.md 8b "Errors")
+subroutine mom6hip_fatal_if(rc, who)
+  integer(c_int),   intent(in) :: rc
+  character(len=*), intent(in) :: who
+  if (rc /= 0) call MOM_error(FATAL, trim(who)//" (HIP): "//mom6hip_error_string())
+end subroutine mom6hip_fatal_if
+
+!> REENTRANT_X / REENTRANT_Y as MOM_domains reads them (src/framework/MOM_domains.F90:184-190); the fold is refused.
+!! Called from a module's *_init (which has the parameter file) so that the one-tile fast path knows the topology.
+subroutine mom6hip_read_topology(param_file, reentrant)
+  type(param_file_type), intent(in)  :: param_file
+  logical,               intent(out) :: reentrant(2)
+  logical :: tripolar_N
+  call get_param(param_file, "mom6hip", "REENTRANT_X", reentrant(1), default=.true., do_not_log=.true.)
+  call get_param(param_file, "mom6hip", "REENTRANT_Y", reentrant(2), default=.false., do_not_log=.true.)
+  call get_param(param_file, "mom6hip", "TRIPOLAR_N", tripolar_N, default=.false., do_not_log=.true.)
+  if (tripolar_N) call MOM_error(FATAL, "mom6hip: TRIPOLAR_N (the northern fold) is not supported by the GPU path.")
+end subroutine mom6hip_read_topology
+
+!> Upload the metrics of G once and return the context; registers the collectives when they are needed.
+subroutine mom6hip_context_create(G, GV, ctx, reentrant)
+  type(ocean_grid_type), target,   intent(inout) :: G
+  type(verticalGrid_type),         intent(in)    :: GV
+  type(c_ptr),                     intent(out)   :: ctx
+  logical,               optional, intent(in)    :: reentrant(2) !< from mom6hip_read_topology: enables the one-tile fast path
+  type(mom6hip_grid_t) :: cg
+  logical :: reentrant_x, reentrant_y, know_topology
+  integer :: gpus_per_node, rc
+  character(len=16) :: env
+
+  if (.not. G%symmetric) call MOM_error(FATAL, "mom6hip: SYMMETRIC_MEMORY_ is required.")
+  cg%isc = G%isc ; cg%iec = G%iec ; cg%jsc = G%jsc ; cg%jec = G%jec
+  cg%isd = G%isd ; cg%ied = G%ied ; cg%jsd = G%jsd ; cg%jed = G%jed
+  cg%nk = GV%ke ; cg%symmetric = 1 ; cg%first_direction = G%first_direction
+  know_topology = present(reentrant) ; reentrant_x = .false. ; reentrant_y = .false.
+  if (know_topology) then ; reentrant_x = reentrant(1) ; reentrant_y = reentrant(2) ; endif
+  cg%reentrant_x = 0 ; cg%reentrant_y = 0
+  if (know_topology .and. (num_PEs() == 1)) then
+    ! the whole domain is this tile: the library's wrap kernels are the halo update
+    cg%reentrant_x = merge(1, 0, reentrant_x) ; cg%reentrant_y = merge(1, 0, reentrant_y)
+  endif
+  cg%Angstrom_H = GV%Angstrom_H ; cg%H_subroundoff = GV%H_subroundoff
+  cg%dZ_subroundoff = GV%dZ_subroundoff ; cg%H_to_Z = GV%H_to_Z ; cg%Z_to_H = GV%Z_to_H
+  cg%g_Earth = GV%g_Earth ; cg%Rho0 = GV%Rho0
+  cg%mask2dT = c_loc(G%mask2dT) ; cg%areaT = c_loc(G%areaT) ; cg%IareaT = c_loc(G%IareaT)
+  cg%dxT = c_loc(G%dxT) ; cg%dyT = c_loc(G%dyT) ; cg%IdxT = c_loc(G%IdxT) ; cg%IdyT = c_loc(G%IdyT)
+  cg%bathyT = c_loc(G%bathyT)
+  cg%mask2dCu = c_loc(G%mask2dCu) ; cg%dxCu = c_loc(G%dxCu) ; cg%dyCu = c_loc(G%dyCu) ; cg%dy_Cu = c_loc(G%dy_Cu)
+  cg%IdxCu = c_loc(G%IdxCu) ; cg%IdyCu = c_loc(G%IdyCu) ; cg%areaCu = c_loc(G%areaCu) ; cg%IareaCu = c_loc(G%IareaCu)
+  cg%mask2dCv = c_loc(G%mask2dCv) ; cg%dxCv = c_loc(G%dxCv) ; cg%dyCv = c_loc(G%dyCv) ; cg%dx_Cv = c_loc(G%dx_Cv)
+  cg%IdxCv = c_loc(G%IdxCv) ; cg%IdyCv = c_loc(G%IdyCv) ; cg%areaCv = c_loc(G%areaCv) ; cg%IareaCv = c_loc(G%IareaCv)
+  cg%mask2dBu = c_loc(G%mask2dBu) ; cg%dxBu = c_loc(G%dxBu) ; cg%dyBu = c_loc(G%dyBu) ; cg%areaBu = c_loc(G%areaBu)
+  cg%IareaBu = c_loc(G%IareaBu) ; cg%CoriolisBu = c_loc(G%CoriolisBu)
+
+  ! one PE <-> one GPU: the node-local rank picks the device (MOM6HIP_GPUS_PER_NODE, default 8 on an MI355X node)
+  gpus_per_node = 8
+  call get_environment_variable("MOM6HIP_GPUS_PER_NODE", env, status=rc)
+  if (rc == 0) read(env, *, iostat=rc) gpus_per_node
+  if (gpus_per_node < 1) gpus_per_node = 1
+  rc = mom6hip_init(int(mod(PE_here(), gpus_per_node), c_int))
+  if (rc == 0) rc = mom6hip_grid_create(cg, c_null_ptr, ctx)
+  call mom6hip_fatal_if(rc, "mom6hip_context_create")
+
+  if ((cg%reentrant_x == 0 .and. cg%reentrant_y == 0) .or. (num_PEs() > 1)) then
+    ! every halo update inside a library call is MOM6's own pass_var; sums and minima are MOM_coms'
+    G_cb => G ; ctx_cb = ctx ; nk_cb = GV%ke
+    rc = mom6hip_set_domain_callbacks(ctx, c_funloc(halo_cb), c_funloc(sum_cb), c_null_ptr)
+    if (rc == 0) rc = mom6hip_set_min_callback(ctx, c_funloc(min_cb), c_null_ptr)
+    call mom6hip_fatal_if(rc, "mom6hip_context_create")
+  endif
+end subroutine mom6hip_context_create
+
+!> mom6hip_halo_fn: the library hands over DEVICE arrays; they are copied to host scratch of the reference's shape for
+!! their staggering, updated with pass_var on G%Domain, and copied back.
+function halo_cb(user, fields, pos, nk, nfields) bind(c) result(rc)
+  type(c_ptr),        value      :: user
+  type(c_ptr),        intent(in) :: fields(*)
+  integer(c_int32_t), intent(in) :: pos(*), nk(*)
+  integer(c_int32_t), value      :: nfields
+  integer(c_int) :: rc
+  real(c_double), allocatable, target :: buf(:,:,:)
+  integer :: f, i0, j0, position
+  integer(c_int64_t) :: bytes
+
+  rc = 1
+  if (.not. associated(G_cb)) return
+  do f = 1, nfields
+    if (.not. c_associated(fields(f))) cycle
+    i0 = G_cb%isd ; j0 = G_cb%jsd ; position = CENTER
+    select case (pos(f))
+      case (MOM6HIP_POS_U) ; i0 = G_cb%IsdB ; position = EAST_FACE
+      case (MOM6HIP_POS_V) ; j0 = G_cb%JsdB ; position = NORTH_FACE
+      case (MOM6HIP_POS_Q) ; i0 = G_cb%IsdB ; j0 = G_cb%JsdB ; position = CORNER
+    end select
+    allocate(buf(i0:G_cb%ied, j0:G_cb%jed, nk(f)))
+    bytes = int(size(buf), c_int64_t) * 8_c_int64_t
+    if (mom6hip_sync_to_host(ctx_cb, c_loc(buf), fields(f), bytes) /= 0) return
+    call pass_var(buf, G_cb%Domain, position=position)
+    if (mom6hip_sync_to_device(ctx_cb, fields(f), c_loc(buf), bytes) /= 0) return
+    deallocate(buf)
+  enddo
+  rc = 0
+end function halo_cb
+
+!> mom6hip_sum_fn: sum_across_PEs of n integers
+function sum_cb(user, values, n) bind(c) result(rc)
+  type(c_ptr),        value         :: user
+  integer(c_int32_t), intent(inout) :: values(*)
+  integer(c_int32_t), value         :: n
+  integer(c_int) :: rc
+  integer, allocatable :: v(:)
+  allocate(v(n)) ; v(:) = values(1:n)
+  call sum_across_PEs(v, n)
+  values(1:n) = int(v(:), c_int32_t)
+  rc = 0
+end function sum_cb
+
+!> mom6hip_min_fn: min_across_PEs of n reals
+function min_cb(user, values, n) bind(c) result(rc)
+  type(c_ptr),    value         :: user
+  real(c_double), intent(inout) :: values(*)
+  integer(c_int32_t), value     :: n
+  integer(c_int) :: rc
+  integer :: q
+  real :: x
+  do q = 1, n
+    x = values(q) ; call min_across_PEs(x) ; values(q) = x
+  enddo
+  rc = 0
+end function min_cb
+
+end module mom6hip_MOM_glue

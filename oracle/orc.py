@@ -366,13 +366,13 @@ class DynState:
     the step with numpy arrays behind its pointers, and the prognostic state."""
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
-                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, **bt_kw):
+                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", **bt_kw):
         g = self.grid = grid
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
         self.ccs = continuity_cs(g.nk, g.Angstrom_H)
         self.cor = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES["SADOURNY75_ENERGY"], _abi.KE_SCHEMES["KE_ARAKAWA"], 0, int(bound_coriolis), 0)
         self.pcs = pressureforce_cs(g)
-        self.eos = eos("WRIGHT")
+        self.eos = eos(eos_form)
         self.bt_arrs, self.bt = make_bt_cont(g, with_h=True) if use_bt_cont else ({}, None)
         self.bcs, self.bcs_arrs = barotropic_cs(g, hvel_scheme="FROM_BT_CONT" if use_bt_cont else "HARMONIC", **bt_kw)
         barotropic_init(g, self.bcs)

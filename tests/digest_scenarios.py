@@ -1,0 +1,438 @@
+"""The full-size golden-digest scenarios (TEST INFRASTRUCTURE): one sequence of hot-path calls on machine-independent
+synthetic inputs (tests/exact_synth.py), written once and run by two back ends with the same interface --
+
+* `OracleOps`: the CPU oracle (oracle/*.c).  tools/make_golden_digests.py runs it in the build container and stores
+  the SHA-256 of every output's bits (and a few sample values) under tests/golden/digests_*.json;
+* `HipOps`: libmom6hip through the host mirror, device-resident arrays.  tests/test_golden_digests.py (-m gpu) runs
+  it on the GPU box and compares the digests.
+
+This is the bitwise parity test at sizes where the launch geometry is non-trivial (benchmark 360x180x75, a 1440-wide
+band of the OM4 grid, a 1080-row tall strip): multi-block rows, the 31-face zonal stride of the block-cooperative
+continuity kernel, the J-segments of advect_y, the hipGraph of the barotropic subcycle at its real step count."""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+
+import exact_synth as xs
+from mom6_amd import _abi
+
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+SIZES = {"benchmark": (360, 180, 75), "om4_band": (1440, 64, 75), "tall": (48, 1080, 3)}
+DT = 900.0
+VV = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
+CONT_VARIANTS = OrderedDict([
+    ("plain", dict(cs={}, uhbt=False, bt=False, visc=False)),
+    ("bt_cont", dict(cs={}, uhbt=False, bt=True, visc=True)),
+    ("uhbt_bt_cont", dict(cs={}, uhbt=True, bt=True, visc=True)),
+    ("uhbt_monotonic", dict(cs=dict(monotonic=1), uhbt=True, bt=False, visc=True)),
+])
+
+
+def digest(a):
+    a = np.ascontiguousarray(a)
+    flat = a.ravel()
+    nz = np.flatnonzero(flat)
+    return {"sha256": hashlib.sha256(a.tobytes()).hexdigest(), "shape": list(a.shape),
+            "first8": [float(x).hex() for x in flat[:8]], "last8": [float(x).hex() for x in flat[-8:]],
+            "nonzero": int(nz.size), "first_nonzero": [int(nz[0]), float(flat[nz[0]]).hex()] if nz.size else None}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class OracleOps:
+    name = "oracle"
+
+    def __init__(self, g):
+        from oracle import orc
+        self.orc, self.g = orc, g
+
+    def close(self):
+        pass
+
+    def continuity(self, u, v, hin, dt, cs=None, uhbt=None, vhbt=None, vru=None, vrv=None, want_bt=False):
+        orc, g = self.orc, self.g
+        ccs = orc.continuity_cs(g.nk, g.Angstrom_H, **(cs or {}))
+        out = dict(h=hin.copy(), uh=np.zeros_like(u), vh=np.zeros_like(v))
+        kw = {}
+        if uhbt is not None:
+            out.update(u_cor=np.zeros_like(u), v_cor=np.zeros_like(v), du_cor=g.zeros2(U), dv_cor=g.zeros2(V))
+            kw.update(uhbt=uhbt, vhbt=vhbt, u_cor=out["u_cor"], v_cor=out["v_cor"], du_cor=out["du_cor"], dv_cor=out["dv_cor"])
+        if want_bt:
+            arrs, st = orc.make_bt_cont(g, with_h=True)
+            out.update(arrs); kw["bt_cont"] = st; out["_bt"] = (arrs, st)
+        orc.continuity(g, ccs, u, v, hin, out["h"], out["uh"], out["vh"], dt, visc_rem_u=vru, visc_rem_v=vrv, **kw)
+        return out
+
+    def coradcalc(self, u, v, h, uh, vh, **kw):
+        return self.orc.coradcalc(self.g, u, v, h, uh, vh, **kw)
+
+    def pressureforce(self, h, T, S):
+        orc, g = self.orc, self.g
+        return orc.pressureforce(g, orc.pressureforce_cs(g), orc.eos("WRIGHT"), h, T, S)
+
+    def halo_update(self, a, pos):
+        self.orc.halo_update(self.g, a, pos)
+
+    def btstep(self, d, pf, c, vru, vrv, taux, tauy, dt):
+        """the barotropic solver set up and called the way step_MOM_dyn_split_RK2 does (:586-658)"""
+        orc, g = self.orc, self.g
+        PFu, PFv, pbce, eta_PF = pf
+        arrs, bt = c["_bt"]
+        cs, cs_arrs = orc.barotropic_cs(g, hvel_scheme="FROM_BT_CONT")
+        orc.barotropic_init(g, cs)
+        orc.btcalc(g, cs, d["h"], arrs["h_u"], arrs["h_v"])
+        eta = bt_eta_in(g, d["h"])
+        orc.halo_update(g, eta, H)
+        orc.bt_mass_source(g, cs, d["h"], eta, True)
+        orc.set_dtbt(g, cs, pbce=pbce, bt_cont=bt, gtot_est=g.g_Earth, SSH_add=10.0)
+        bcu, bcv = bt_forcing(g, PFu, PFv)
+        out = orc.btstep(g, cs, d["u"], d["v"], eta, dt, bcu, bcv, taux, tauy, pbce, eta_PF, d["u"], d["v"], vru, vrv, bt_cont=bt,
+                         uh0=c["uh"], vh0=c["vh"], u_uh0=d["u"], v_vh0=d["v"], want_etaav=True)
+        out.update(frhatu=cs_arrs["frhatu"], eta_cor=cs_arrs["eta_cor"], ubtav=cs_arrs["ubtav"],
+                   dtbt_max=np.array([cs.dtbt_max]), nstep=np.array([float(cs.nstep_last)]))
+        return out
+
+    def advect_tracer(self, h_end, uhtr, vhtr, dt, scheme, tr):
+        tr = [t.copy() for t in tr]
+        st = self.orc.advect_tracer(self.g, h_end, uhtr, vhtr, dt, DT, scheme, tr)
+        return tr, int(st.iterations)
+
+    def ale(self, h, tr, u, v, scheme, old_grid_weight=0.0):
+        orc, g = self.orc, self.g
+        rcs = orc.regridding_cs(xs.nominal_dz(g.nk), old_grid_weight=old_grid_weight)
+        h_new, dz = orc.ale_regrid(g, rcs, h)
+        tr = [t.copy() for t in tr]; u, v = u.copy(), v.copy()
+        orc.ale_remap_tracers(g, scheme, h, h_new, tr)
+        hou, hov = orc.ale_remap_set_h_vel(g, h); hnu, hnv = orc.ale_remap_set_h_vel(g, h_new)
+        orc.ale_remap_velocities(g, scheme, hou, hov, hnu, hnv, u, v)
+        return dict(h_new=h_new, dzRegrid=dz, tr=tr, h_new_u=hnu, h_new_v=hnv, u=u, v=v)
+
+    def vertvisc(self, u, v, h, taux, tauy, bbl, dt, **opts):
+        orc, g = self.orc, self.g
+        cs = orc.vertvisc_cs(g, Kv=VV["KV"], Hbbl=VV["HBBL"], Hmix=VV["HMIX_FIXED"], Kvml_invZ2=VV["KV_ML_INVZ2"], **opts)
+        visc = orc.vertvisc_type(**bbl)
+        u, v = u.copy(), v.copy()
+        vru, vrv = np.zeros_like(u), np.zeros_like(v)
+        orc.vertvisc_coef(g, cs, u, v, h, visc, dt)
+        orc.vertvisc(g, cs, u, v, h, taux, tauy, visc, dt)
+        orc.vertvisc_remnant(g, cs, visc, vru, vrv, dt)
+        return dict(u=u, v=v, visc_rem_u=vru, visc_rem_v=vrv, a_u=cs._arrs["a_u"], a_v=cs._arrs["a_v"], h_u=cs._arrs["h_u"])
+
+    # the time-stepping model
+    def model_init(self, d, bbl, dt):
+        orc, g = self.orc, self.g
+        self.st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt,
+                               vertvisc=orc.vertvisc_cs(g, Kv=VV["KV"], Hbbl=VV["HBBL"], Hmix=VV["HMIX_FIXED"], Kvml_invZ2=VV["KV_ML_INVZ2"]),
+                               visc=orc.vertvisc_type(**bbl))
+
+    def model_step(self, taux, tauy, calc_dtbt):
+        self.st.step(taux, tauy, calc_dtbt=calc_dtbt)
+
+    def model_fields(self):
+        s = self.st
+        out = OrderedDict(u=s.u, v=s.v, h=s.h, uh=s.uh, vh=s.vh, uhtr=s.uhtr, vhtr=s.vhtr, eta_av=s.eta_av)
+        for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt"):
+            out[n] = s.arrs[n]
+        out["nstep_dtbt"] = np.array([float(s.bcs.nstep_last), s.bcs.dtbt])
+        return out
+
+    def model_state(self):
+        s = self.st
+        return dict(u=s.u, v=s.v, h=s.h, T=s.T, S=s.S, uhtr=s.uhtr, vhtr=s.vhtr)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class HipOps:
+    name = "hip"
+
+    def __init__(self, g):
+        import torch
+        from mom6_amd.tracer_advect import DeviceGrid
+        self.torch, self.g = torch, g
+        self.dg = DeviceGrid(g)
+
+    def close(self):
+        self.dg.close()
+
+    def T(self, a):
+        return None if a is None else self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def Z(self, pos, k3=True):
+        g = self.g
+        return self.torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=self.torch.float64, device="cuda")
+
+    def N(self, a):
+        self.dg.sync()
+        return a.cpu().numpy()
+
+    def continuity(self, u, v, hin, dt, cs=None, uhbt=None, vhbt=None, vru=None, vrv=None, want_bt=False):
+        from mom6_amd.continuity import BT_cont_type, continuity, continuity_PPM_init
+        T, Z = self.T, self.Z
+        ccs = continuity_PPM_init(self.dg, **{k: bool(x) for k, x in (cs or {}).items()})
+        o = dict(h=T(hin), uh=Z(U), vh=Z(V))
+        kw = {}
+        if uhbt is not None:
+            o.update(u_cor=Z(U), v_cor=Z(V), du_cor=Z(U, False), dv_cor=Z(V, False))
+            kw.update(uhbt=T(uhbt), vhbt=T(vhbt), u_cor=o["u_cor"], v_cor=o["v_cor"], du_cor=o["du_cor"], dv_cor=o["dv_cor"])
+        bt, arrs = None, {}
+        if want_bt:
+            arrs = {n: Z(U, False) for n in _abi.BT_CONT_U}; arrs.update({n: Z(V, False) for n in _abi.BT_CONT_V})
+            arrs["h_u"] = Z(U); arrs["h_v"] = Z(V)
+            o.update(arrs); bt = BT_cont_type(**arrs); kw["BT_cont"] = bt
+        continuity(T(u), T(v), T(hin), o["h"], o["uh"], o["vh"], dt, self.dg, ccs, visc_rem_u=T(vru), visc_rem_v=T(vrv), **kw)
+        out = {k: self.N(a) for k, a in o.items()}
+        out["_bt"] = (bt, arrs, o)
+        return out
+
+    def coradcalc(self, u, v, h, uh, vh, **kw):
+        from mom6_amd.coriolis_adv import CorAdCalc, CoriolisAdv_init
+        CS = CoriolisAdv_init(**kw)
+        CAu, CAv = self.Z(U), self.Z(V)
+        T = self.T
+        CorAdCalc(T(u), T(v), T(h), T(uh), T(vh), CAu, CAv, None, self.dg, CS)
+        return self.N(CAu), self.N(CAv)
+
+    def pressureforce(self, h, T_, S):
+        from mom6_amd.pressure_force import EOS_init, PressureForce, PressureForce_init
+        T, Z = self.T, self.Z
+        o = (Z(U), Z(V), Z(H), Z(H, False))
+        PressureForce(T(h), (T(T_), T(S), EOS_init("WRIGHT")), o[0], o[1], self.dg, PressureForce_init(self.g), pbce=o[2], eta=o[3])
+        return tuple(self.N(a) for a in o)
+
+    def halo_update(self, a, pos):
+        t = self.T(a)
+        self.dg.halo_update([t], [pos])
+        a[...] = self.N(t)
+
+    def btstep(self, d, pf, c, vru, vrv, taux, tauy, dt):
+        from mom6_amd.barotropic import barotropic_init, bt_mass_source, btcalc, btstep, set_dtbt
+        g, dg, T, Z = self.g, self.dg, self.T, self.Z
+        PFu, PFv, pbce, eta_PF = pf
+        BT, arrs, o = c["_bt"]
+        CS = barotropic_init(dg, BT_THICK_SCHEME="FROM_BT_CONT", USE_BT_CONT_TYPE=True)
+        h = T(d["h"])
+        btcalc(h, dg, CS, arrs["h_u"], arrs["h_v"])
+        eta = T(bt_eta_in(g, d["h"]))
+        dg.halo_update([eta], [H])
+        bt_mass_source(h, eta, True, dg, CS)
+        dpbce = T(pbce)
+        set_dtbt(dg, CS, pbce=dpbce, BT_cont=BT, gtot_est=g.g_Earth, SSH_add=10.0)
+        bcu, bcv = bt_forcing(g, PFu, PFv)
+        out = dict(accel_layer_u=Z(U), accel_layer_v=Z(V), eta_out=Z(H, False), uhbtav=Z(U, False), vhbtav=Z(V, False), etaav=Z(H, False))
+        du, dv = T(d["u"]), T(d["v"])
+        # uh0 / vh0: the halo-updated transports of the continuity call (host copies were updated by the scenario)
+        btstep(du, dv, eta, dt, T(bcu), T(bcv), (T(taux), T(tauy)), dpbce, T(eta_PF), du, dv, out["accel_layer_u"], out["accel_layer_v"],
+               out["eta_out"], out["uhbtav"], out["vhbtav"], dg, CS, T(vru), T(vrv), BT_cont=BT, uh0=T(c["uh"]), vh0=T(c["vh"]),
+               u_uh0=du, v_vh0=dv, etaav=out["etaav"])
+        res = {k: self.N(a) for k, a in out.items()}
+        res.update(frhatu=self.N(CS.frhatu), eta_cor=self.N(CS.eta_cor), ubtav=self.N(CS.ubtav),
+                   dtbt_max=np.array([CS.st.dtbt_max]), nstep=np.array([float(CS.st.nstep_last)]))
+        return res
+
+    def advect_tracer(self, h_end, uhtr, vhtr, dt, scheme, tr):
+        from mom6_amd.tracer_advect import advect_tracer, tracer_advect_init
+        T = self.T
+        dtr = [T(t.copy()) for t in tr]
+        st = advect_tracer(T(h_end), T(uhtr), T(vhtr), None, dt, self.dg, tracer_advect_init(DT, scheme), dtr)
+        return [self.N(t) for t in dtr], int(st.iterations)
+
+    def ale(self, h, tr, u, v, scheme, old_grid_weight=0.0):
+        from mom6_amd.ale import (ALE_regrid, ALE_remap_set_h_vel, ALE_remap_tracers, ALE_remap_velocities, initialize_regridding,
+                                  initialize_remapping)
+        g, dg, T, Z = self.g, self.dg, self.T, self.Z
+        rcs = initialize_regridding(dg, coordinateResolution=xs.nominal_dz(g.nk), old_grid_weight=old_grid_weight)
+        cs = initialize_remapping(scheme)
+        dh, h_new = T(h), Z(H)
+        dz = self.torch.zeros((g.nk + 1,) + g.shape2(H), dtype=self.torch.float64, device="cuda")
+        ALE_regrid(dg, dh, h_new, dz, None, rcs)
+        dtr = [T(t.copy()) for t in tr]; du, dv = T(u.copy()), T(v.copy())
+        ALE_remap_tracers(cs, dg, dh, h_new, dtr)
+        hou, hov, hnu, hnv = Z(U), Z(V), Z(U), Z(V)
+        ALE_remap_set_h_vel(None, dg, dh, hou, hov); ALE_remap_set_h_vel(None, dg, h_new, hnu, hnv)
+        ALE_remap_velocities(cs, dg, hou, hov, hnu, hnv, du, dv)
+        N = self.N
+        return dict(h_new=N(h_new), dzRegrid=N(dz), tr=[N(t) for t in dtr], h_new_u=N(hnu), h_new_v=N(hnv), u=N(du), v=N(dv))
+
+    def vertvisc(self, u, v, h, taux, tauy, bbl, dt, **opts):
+        from mom6_amd.vert_friction import vertvisc, vertvisc_coef, vertvisc_init, vertvisc_remnant, vertvisc_type
+        names = dict(harmonic_visc="HARMONIC_VISC", direct_stress="DIRECT_STRESS", Kv_extra_bbl="KV_EXTRA_BBL", harm_BL_val="HARMONIC_BL_SCALE",
+                     bottomdraglaw="BOTTOMDRAGLAW")
+        dg, T = self.dg, self.T
+        CS = vertvisc_init(dg, **VV, **{names[k]: x for k, x in opts.items()})
+        visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
+        du, dv, dh = T(u.copy()), T(v.copy()), T(h)
+        vru, vrv = self.Z(U), self.Z(V)
+        vertvisc_coef(du, dv, dh, None, None, visc, None, dt, dg, CS)
+        vertvisc(du, dv, dh, (T(taux), T(tauy)), visc, dt, None, None, None, dg, CS)
+        vertvisc_remnant(visc, vru, vrv, dt, dg, CS)
+        N = self.N
+        return dict(u=N(du), v=N(dv), visc_rem_u=N(vru), visc_rem_v=N(vrv), a_u=N(CS.a_u), a_v=N(CS.a_v), h_u=N(CS.h_u))
+
+    def model_init(self, d, bbl, dt):
+        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2
+        from mom6_amd.vert_friction import vertvisc_type
+        T, Z = self.T, self.Z
+        m = self.m = dict(u=T(d["u"]), v=T(d["v"]), h=T(d["h"]), T=T(d["T"]), S=T(d["S"]), uh=Z(U), vh=Z(V), uhtr=Z(U), vhtr=Z(V),
+                          eta_av=Z(H, False))
+        self.dt = dt
+        self.CS = initialize_dyn_split_RK2(m["u"], m["v"], m["h"], m["uh"], m["vh"], dt, self.dg, coriolis=dict(bound_coriolis=True),
+                                           vertvisc=VV)
+        self.visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
+
+    def model_step(self, taux, tauy, calc_dtbt):
+        from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
+        m = self.m
+        if not hasattr(self, "_tau"):
+            self._tau = (self.T(taux), self.T(tauy))
+        step_MOM_dyn_split_RK2(m["u"], m["v"], m["h"], (m["T"], m["S"]), self.visc, None, self.dt, self._tau, None, None, m["uh"],
+                               m["vh"], m["uhtr"], m["vhtr"], m["eta_av"], self.dg, self.CS, calc_dtbt=calc_dtbt)
+
+    def model_fields(self):
+        m, N = self.m, self.N
+        out = OrderedDict((n, N(m[n])) for n in ("u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"))
+        for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt"):
+            out[n] = N(self.CS.arrays[n])
+        st = self.CS.barotropic_CSp.st
+        out["nstep_dtbt"] = np.array([float(st.nstep_last), st.dtbt])
+        return out
+
+    def model_state(self):
+        m, N = self.m, self.N
+        return {n: N(m[n]) for n in ("u", "v", "h", "T", "S", "uhtr", "vhtr")}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def bt_eta_in(g, h):
+    """the free surface the barotropic solver carries: the layer sum plus a smooth centimetre-scale offset"""
+    ny, nx = g.shape2(H)
+    X = ((np.arange(nx) - g.halo + 0.5) / g.ni)[None, :]
+    Y = ((np.arange(ny) - g.halo + 0.5) / g.nj)[:, None]
+    return np.ascontiguousarray((xs.ksum(h) - g.bathyT * g.Z_to_H) + 0.01 * xs.psin(2.0 * X) * xs.pcos(Y) * g.mask2dT)
+
+
+def bt_forcing(g, PFu, PFv):
+    bcu = np.ascontiguousarray(np.clip(PFu, -3.0e-5, 3.0e-5) * (g.mask2dCu[None] > 0))
+    bcv = np.ascontiguousarray(np.clip(PFv, -3.0e-5, 3.0e-5) * (g.mask2dCv[None] > 0))
+    return bcu, bcv
+
+
+def visc_rem(g, like, pos):
+    kk = ((np.arange(g.nk) + 0.5) / g.nk)[:, None, None]
+    m = g.mask2dCu if pos == U else g.mask2dCv
+    return np.ascontiguousarray(np.clip(1.0 - 0.8 * kk * kk * kk * kk + 0.0 * like, 0.05, 1.0) * (m[None] > 0))
+
+
+def make_inputs(size):
+    ni, nj, nk = SIZES[size] if isinstance(size, str) else size
+    g = xs.make_grid(ni, nj, nk, seed=7)
+    d = xs.make_state(g, seed=1, umax=0.1, eta_amp=0.2)                       # z*-like, vanished layers
+    dm = xs.make_state(g, seed=3, umax=0.1, eta_amp=0.2, terrain_following=True)   # the state the model is stepped from
+    taux, tauy = xs.wind_stress(g)
+    return g, d, dm, taux, tauy, xs.bbl_arrays(g)
+
+
+def operators(ops, g, d, taux, tauy, bbl, only=None):
+    """every operator on its own; yields (name, array)"""
+    want = lambda n: only is None or n in only
+    vru, vrv = visc_rem(g, d["u"], U), visc_rem(g, d["v"], V)
+    c_bt = None
+    for name, var in CONT_VARIANTS.items():
+        if not (want("continuity") or (name == "bt_cont" and (want("btstep") or want("coradcalc")))):
+            continue
+        kw = dict(cs=var["cs"], want_bt=var["bt"])
+        if var["visc"]:
+            kw.update(vru=vru, vrv=vrv)
+        if var["uhbt"]:      # target transports: the layer sums of the bt_cont call, nudged
+            kw.update(uhbt=np.ascontiguousarray(xs.ksum(c_bt["uh"]) * 1.02), vhbt=np.ascontiguousarray(xs.ksum(c_bt["vh"]) * 0.98))
+        c = ops.continuity(d["u"], d["v"], d["h"], DT, **kw)
+        if name == "bt_cont":
+            c_bt = c
+        for k, a in c.items():
+            if not k.startswith("_"):
+                yield f"continuity[{name}].{k}", a
+    if want("coradcalc"):
+        uh, vh = (c_bt["uh"], c_bt["vh"]) if c_bt is not None else (np.zeros_like(d["u"]), np.zeros_like(d["v"]))
+        for nm, kw in (("default", dict(bound_coriolis=True)), ("arakawa_hsu_noslip", dict(coriolis_scheme="ARAKAWA_HSU90", no_slip=True,
+                                                                                          ke_scheme="KE_GUDONOV"))):
+            CAu, CAv = ops.coradcalc(d["u"], d["v"], d["h"], uh, vh, **kw)
+            yield f"CorAdCalc[{nm}].CAu", CAu
+            yield f"CorAdCalc[{nm}].CAv", CAv
+    pf = None
+    if want("pressureforce") or want("btstep"):
+        pf = ops.pressureforce(d["h"], d["T"], d["S"])
+        for k, a in zip(("PFu", "PFv", "pbce", "eta"), pf):
+            yield f"PressureForce.{k}", a
+    if want("btstep"):
+        ops.halo_update(c_bt["uh"], U); ops.halo_update(c_bt["vh"], V)
+        out = ops.btstep(d, pf, c_bt, vru, vrv, taux, tauy, DT)
+        for k, a in out.items():
+            yield f"btstep.{k}", a
+    if want("advect"):
+        adv = xs.make_advection_inputs(g, d["h"])
+        tr = [d["T"], d["S"]] + d["tr"]
+        for scheme in ("PPM:H3", "PLM", "PPM"):
+            res, it = ops.advect_tracer(adv["h_end"], adv["uhtr"], adv["vhtr"], 4 * DT, scheme, tr)
+            yield f"advect_tracer[{scheme}].iterations", np.array([float(it)])
+            for m, a in enumerate(res):
+                yield f"advect_tracer[{scheme}].tr{m}", a
+    if want("ale"):
+        tr = [d["T"], d["S"]] + d["tr"]
+        for scheme in ("PPM_H4", "PLM"):
+            r = ops.ale(d["h"], tr, d["u"], d["v"], scheme)
+            for k in ("h_new", "dzRegrid", "h_new_u", "h_new_v", "u", "v"):
+                yield f"ALE[{scheme}].{k}", r[k]
+            for m, a in enumerate(r["tr"]):
+                yield f"ALE[{scheme}].tr{m}", a
+    if want("vertvisc"):
+        for nm, kw in (("default", {}), ("harmonic_direct", dict(harmonic_visc=True, direct_stress=True, Kv_extra_bbl=1.0e-4))):
+            r = ops.vertvisc(d["u"], d["v"], d["h"], taux, tauy, bbl, DT, **kw)
+            for k, a in r.items():
+                yield f"vertvisc[{nm}].{k}", a
+
+
+def model(ops, g, dm, taux, tauy, bbl, nsteps=2):
+    """initialize_dyn_split_RK2, nsteps x step_MOM_dyn_split_RK2 (vertical viscosity on, DTBT set in the first step), then
+    the thermodynamic block: advect_tracer over the accumulated transports and the ALE regrid / remap"""
+    ops.model_init(dm, bbl, DT)
+    for k, a in ops.model_fields().items():
+        if k in ("eta", "h_av", "u_av", "CAu_pred", "uh"):
+            yield f"model.init.{k}", a
+    for n in range(nsteps):
+        ops.model_step(taux, tauy, calc_dtbt=(n == 0))
+        for k, a in ops.model_fields().items():
+            yield f"model.step{n + 1}.{k}", a
+    s = ops.model_state()
+    tr = [s["T"], s["S"]] + dm["tr"]
+    res, it = ops.advect_tracer(s["h"], s["uhtr"], s["vhtr"], nsteps * DT, "PPM:H3", tr)
+    yield "model.advect_tracer.iterations", np.array([float(it)])
+    for m, a in enumerate(res):
+        yield f"model.advect_tracer.tr{m}", a
+    r = ops.ale(s["h"], res, s["u"], s["v"], "PPM_H4", old_grid_weight=0.5)
+    for k in ("h_new", "dzRegrid", "u", "v"):
+        yield f"model.ALE.{k}", r[k]
+    for m, a in enumerate(r["tr"]):
+        yield f"model.ALE.tr{m}", a
+
+
+def run(ops_cls, size, parts=("operators", "model"), only=None, progress=None):
+    g, d, dm, taux, tauy, bbl = make_inputs(size)
+    out = OrderedDict()
+    out["input.h"] = digest(d["h"]); out["input.u"] = digest(d["u"]); out["input.T"] = digest(d["T"])
+    out["input.bathyT"] = digest(g.bathyT); out["input.model_h"] = digest(dm["h"])
+    ops = ops_cls(g)
+    try:
+        gens = []
+        if "operators" in parts:
+            gens.append(operators(ops, g, d, taux, tauy, bbl, only))
+        if "model" in parts:
+            gens.append(model(ops, g, dm, taux, tauy, bbl))
+        for gen in gens:
+            for name, a in gen:
+                out[name] = digest(a)
+                if progress:
+                    progress(name)
+    finally:
+        ops.close()
+    return out

@@ -210,3 +210,48 @@ def rk2_layout_worker(rank, world, port, layout, topo, out_dir):
             np.savez(os.path.join(out_dir, "rk2_global.npz"), u=ref.u, v=ref.v, h=ref.h, eta=ref.arrs["eta"], uhtr=ref.uhtr, dtbt=ref.bcs.dtbt)
     finally:
         dist.destroy_process_group()
+
+
+def phillips_layout_worker(rank, world, port, layout, out_dir, nsteps=2):
+    """test.layout on BASELINE configs[3] (Phillips_2layer 480x320x2, LINEAR equation of state): the tiles of the layout
+    against the one-tile oracle run; the barotropic subcycle has dozens of steps between its group passes."""
+    import numpy as np
+    import torch
+    import exact_synth as xs
+    from mom6_amd import _abi
+    from mom6_amd.domains import Domain
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from oracle import orc
+    dist = _init(rank, world, port)
+    try:
+        gg, d, _ = xs.make_phillips()
+        dt = 1800.0
+        dom = Domain(gg.ni, gg.nj, layout, rank, gg.halo, True, False)
+        tg = dom.tile_grid(gg)
+        dg = DeviceGrid(tg)
+        dg.set_domain(dom)
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+        T = lambda a, p: torch.from_numpy(dom.cut(a, p)).cuda()
+        u, v, h, Tt, Ss = T(d["u"], U), T(d["v"], V), T(d["h"], H), T(d["T"], H), T(d["S"], H)
+        Z = lambda p, k3=True: torch.zeros(tg.shape3(p) if k3 else tg.shape2(p), dtype=torch.float64, device="cuda")
+        uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+        CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, EQN_OF_STATE="LINEAR", coriolis=dict(bound_coriolis=True))
+        tx, ty = Z(U, False), Z(V, False)
+        for n in range(nsteps):
+            step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
+                                   calc_dtbt=(n == 0))
+        dg.sync()
+        st = CS.barotropic_CSp.st
+        np.savez(os.path.join(out_dir, f"ph_tile{rank}.npz"), ij=np.array([dom.i0, dom.j0, dom.ni, dom.nj]), u=u.cpu().numpy(),
+                 v=v.cpu().numpy(), h=h.cpu().numpy(), eta=CS.eta.cpu().numpy(), uhtr=uhtr.cpu().numpy(), dtbt=st.dtbt, nstep=st.nstep_last)
+        dg.close()
+        if rank == 0:
+            ref = orc.DynState(gg, d["u"], d["v"], d["h"], d["T"], d["S"], dt, eos_form="LINEAR")
+            tz = (gg.zeros2(U), gg.zeros2(V))
+            for n in range(nsteps):
+                ref.step(tz[0], tz[1], calc_dtbt=(n == 0))
+            np.savez(os.path.join(out_dir, "ph_global.npz"), u=ref.u, v=ref.v, h=ref.h, eta=ref.arrs["eta"], uhtr=ref.uhtr, dtbt=ref.bcs.dtbt,
+                     nstep=ref.bcs.nstep_last)
+    finally:
+        dist.destroy_process_group()
