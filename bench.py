@@ -36,7 +36,12 @@ REMAP_SCHEME = "PPM_H4"    # OM4-class remapping scheme
 VERTVISC = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
 KV_BBL = 0.003 * 0.1 * 10.0   # cdrag * |u| * HBBL [m2 s-1]
 HOT_FRAC = 2.0e-5
-REGRID_OLD_WEIGHT = 0.98   # REGRID_TIME_SCALE >> DT_THERM: each ALE call moves the grid 2 % of the way to z* (see Model)
+REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
+LAND_FRAC = 0.30
+ROUGH_NOISE = 0.04         # grid-scale bathymetric roughness (fraction of the depth range)
+# the synthetic state (mom6_amd/synth.py): z* layers over the rough bathymetry -- every layer below the local bottom is
+# vanished (Angstrom thick) --, a stratification that is a function of depth, so the state is close to rest balance
+STATE = dict(umax=0.1, eta_amp=0.2, terrain_following=False, vanish_frac=0.0, h_noise=1.0e-3)
 
 
 def parse():
@@ -75,7 +80,7 @@ class Model:
         H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
         Z = lambda pos, k3=True: torch.zeros(grid.shape3(pos) if k3 else grid.shape2(pos), dtype=torch.float64, device=dev)
         # every rank generates the same global state on its own GPU and keeps its tile
-        dyn = synth.make_dynamics_state(gg, seed=11, device=dev, umax=0.1, eta_amp=0.2, terrain_following=True)
+        dyn = synth.make_dynamics_state(gg, seed=11, device=dev, **STATE)
         cut = lambda a, pos: dom.cut(a, pos).clone()
         self.u, self.v, self.h = cut(dyn["u"], U), cut(dyn["v"], V), cut(dyn["h"], H)
         self.T, self.S = cut(dyn["T"], H), cut(dyn["S"], H)
@@ -101,10 +106,7 @@ class Model:
                                   bbl_thick_u=(VERTVISC["HBBL"] * mu).contiguous(), bbl_thick_v=(VERTVISC["HBBL"] * mv).contiguous())
         self.adv_cs = tracer_advect_init(DT, scheme)
         self.remap_cs = initialize_remapping(REMAP_SCHEME)
-        # z* target: the nominal layer thicknesses of the synthetic state (synth.make_dynamics_state).  The state
-        # starts terrain-following and relaxes towards z* with REGRID_TIME_SCALE >> DT_THERM (old_grid_weight close to
-        # 1): every ALE call does the full regrid + remap work, but the grid does not reach the vanished layers of a z*
-        # grid over topography, which the inviscid step (no vertvisc yet) cannot carry.
+        # z* target: the nominal layer thicknesses of the synthetic state (synth.make_dynamics_state)
         from mom6_amd.ale import initialize_regridding
         import numpy as _np
         kn = (_np.arange(grid.nk) + 0.5) / grid.nk
@@ -146,9 +148,20 @@ class Model:
         self.nstep += 1
 
     def health(self):
-        """max |u|, max |v|, min h, any NaN -- the bench refuses to report a number for a state that blew up"""
+        """max |u|, max |v|, min h, max |eta|, kinetic energy per unit area, the vanished fraction, any NaN -- the bench
+        refuses to report a number for a state that blew up or is on a growing trajectory"""
         bad = not bool(torch.isfinite(self.u).all() and torch.isfinite(self.h).all() and torch.isfinite(self.T).all())
-        return dict(umax=float(self.u.abs().max()), vmax=float(self.v.abs().max()), hmin=float(self.h.min()), nan=bad)
+        g = self.g
+        sj, si = g.csl(0)
+        mT = torch.as_tensor(g.mask2dT, device=self.u.device)[sj, si]
+        hc = self.h[:, sj, si]
+        ke = 0.25 * (hc * (self.u[:, sj, si.start:si.stop] ** 2 + self.u[:, sj, si.start + 1:si.stop + 1] ** 2
+                           + self.v[:, sj.start:sj.stop, si] ** 2 + self.v[:, sj.start + 1:sj.stop + 1, si] ** 2)).sum(0)
+        nocean = float(mT.sum())
+        vanished = float(((hc < 1.0e-6) * mT[None]).sum()) / max(nocean * g.nk, 1.0)
+        return dict(umax=float(self.u.abs().max()), vmax=float(self.v.abs().max()), hmin=float(self.h.min()),
+                    eta_max=float((self.CS.eta[sj, si] * mT).abs().max()), ke_mean=float((ke * mT).sum()) / max(nocean, 1.0),
+                    vanished_layer_fraction=vanished, nan=bad)
 
 
 class Components:
@@ -326,19 +339,18 @@ class Components:
             f()
 
 
-def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
-    """The CPU oracle (oracle/*.c, a scalar C restatement of the reference routines; kind "port") timed on a
-    bounded sample of the same workload: the same horizontal grid with 2 of the layers, one cycle of
-    steps_per_advect baroclinic steps + tracer advection + remap, the same calls as the GPU step.  The 3-D work is
-    scaled per cell to the full grid; the barotropic subcycle is 2-D (independent of the layer count) and is counted
-    as measured."""
+def _cpu_sample(grid, scheme, nk_s, steps_per_advect, threads):
+    """One timed sample of the CPU oracle on the benchmark's horizontal grid with nk_s layers: the first step (sets DTBT),
+    then min(2, steps_per_advect) timed baroclinic steps and one thermodynamic block (advect_tracer + ALE regrid / remap)
+    -- the calls of the GPU step.  Returns (seconds per dynamic step spent in 3-D work, in the 2-D barotropic subcycle,
+    seconds of the thermodynamic block, nstep, threads used, CPU seconds)."""
     import ctypes as C
     import numpy as np
     from mom6_amd import _abi, synth
     from oracle import orc
-    nk_s = 2
-    g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020, rough_noise=0.0)
-    dyn = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11, umax=0.1, eta_amp=0.2, terrain_following=True).items()}
+    used = orc.set_threads(threads)
+    g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020, land_frac=LAND_FRAC, rough_noise=ROUGH_NOISE)
+    dyn = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11, **STATE).items()}
     adv = synth.make_advection_state(g, ntr=4, seed=1, hot_frac=0.0)
     passive = [t.numpy() for t in adv["tr"][2:4]]
     del adv
@@ -350,7 +362,6 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = g.zeros2(_abi.POS_V)
     loop_s = C.c_double.in_dll(orc.lib(), "orc_btstep_loop_seconds")
     st.step(taux, tauy, calc_dtbt=True)        # the first step sets DTBT, as on the GPU
-    # two of the cycle's baroclinic steps are timed (every step does the same work), then the thermodynamic block once
     n_dyn = min(2, steps_per_advect)
     loop_s.value = 0.0
     t0 = time.perf_counter()
@@ -371,17 +382,48 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     for f, ps in ((st.u, 1), (st.v, 2), (st.T, 0), (st.S, 0), (h_new, 0)):
         orc.halo_update(g, f, ps)
     t_thermo = time.perf_counter() - t0
-    t_used = t_dyn + t_thermo
-    scale = full_cells / (g.ni * g.nj * nk_s)
-    sec_per_step = ((t_dyn - t_2d) * scale + t_2d) / n_dyn + t_thermo * scale / steps_per_advect
-    return {
-        "value": DT / sec_per_step / 365.0, "unit": "SYPD", "cores": 1, "kind": "port",
-        "ns_per_gridpoint_step": sec_per_step * 1e9 / full_cells,
-        "sample": f"{n_dyn} baroclinic steps ({t_dyn:.1f} s) and one advect_tracer + ALE regrid/remap block ({t_thermo:.1f} s, counted "
-                  f"1/{steps_per_advect} per step) -- the GPU step's calls -- on {g.ni}x{g.nj}x{nk_s} (same horizontal grid, 2 of "
-                  f"{grid.nk} layers); 3-D work scaled per cell to the full grid, the 2-D barotropic subcycle "
-                  f"({t_2d:.1f} s, nstep={st.bcs.nstep_last}) counted as measured; {t_used:.1f} s of CPU",
-    }
+    nstep = int(st.bcs.nstep_last)
+    orc.set_threads(1)
+    return dict(t3d=(t_dyn - t_2d) / n_dyn, t2d=t_2d / n_dyn, thermo=t_thermo, nstep=nstep, threads=used, cpu_s=t_dyn + t_thermo,
+                n_dyn=n_dyn, cells=g.ni * g.nj * nk_s)
+
+
+def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
+    """The CPU oracle (oracle/*.c, a C restatement of the reference routines; kind "port") timed on the GPU box's host cores
+    on bounded samples of the same workload (the same horizontal grid with fewer layers; the GPU step's calls):
+      * all cores: libmom6oracle_omp.so (OpenMP over the loops the reference marks !$OMP: k / j loops of continuity,
+        CorAdCalc, PressureForce, btstep, advect_tracer, the ALE and vertvisc columns) on 16 of the layers -> `value`;
+      * one core: the scalar oracle on 2 of the layers -> `one_core`.
+    The 3-D work is scaled per cell to the full grid; the barotropic subcycle is 2-D (independent of the layer count) and is
+    counted as measured.  The reference Fortran itself cannot be built here (FMS is not vendored), so the calibration of this
+    port against a flang build of the reference exists only for the PLM/PCM pieces of oracle/_ref."""
+    host_cores = len(os.sched_getaffinity(0))
+
+    def rate(smp):
+        scale = full_cells / smp["cells"]
+        sec = smp["t3d"] * scale + smp["t2d"] + smp["thermo"] * scale / steps_per_advect
+        return DT / sec / 365.0, sec
+
+    one = _cpu_sample(grid, scheme, 2, steps_per_advect, 1)
+    sy1, sec1 = rate(one)
+    out = {"unit": "SYPD", "kind": "port", "host_cores": host_cores,
+           "compiler": "gcc -O2 -std=c99 -ffp-contract=off -fno-fast-math (+ -fopenmp for the all-cores build)",
+           "calibration_vs_reference_build": "not possible beyond PLM/PCM (oracle/_ref): the hot-path modules end in FMS, which is not vendored",
+           "one_core": {"value": sy1, "cores": 1, "ns_per_gridpoint_step": sec1 * 1e9 / full_cells,
+                        "sample": f"{one['n_dyn']} baroclinic steps + one advect_tracer / ALE block on {grid.ni}x{grid.nj}x2 (2 of {grid.nk} "
+                                  f"layers), 3-D work scaled per cell, the 2-D barotropic subcycle ({one['t2d']:.1f} s per step, "
+                                  f"nstep={one['nstep']}) as measured; {one['cpu_s']:.1f} s of CPU"}}
+    nk_all = min(16, grid.nk)
+    if host_cores > 1:
+        al = _cpu_sample(grid, scheme, nk_all, steps_per_advect, 0)
+        sya, seca = rate(al)
+        out.update({"value": sya, "cores": al["threads"], "ns_per_gridpoint_step": seca * 1e9 / full_cells,
+                    "sample": f"{al['n_dyn']} baroclinic steps + one advect_tracer / ALE block on {grid.ni}x{grid.nj}x{nk_all} ({nk_all} of "
+                              f"{grid.nk} layers) on {al['threads']} OpenMP threads, 3-D work scaled per cell, the 2-D barotropic "
+                              f"subcycle ({al['t2d']:.1f} s per step, nstep={al['nstep']}) as measured; {al['cpu_s']:.1f} s of wall clock"})
+    else:
+        out.update({"value": sy1, "cores": 1, "ns_per_gridpoint_step": sec1 * 1e9 / full_cells, "sample": out["one_core"]["sample"]})
+    return out
 
 
 # algorithmic bytes per cell and call (SURVEY.md section 8d / DESIGN.md section 4)
@@ -420,7 +462,7 @@ def main():
     # N>1: the global grid is cut into `world` latitude bands (layout 1 x N, the x direction stays a local wrap);
     # halos travel between neighbouring GPUs through the reference's group passes (DESIGN.md "Multi-GPU").
     # The total work is fixed: strong scaling.
-    grid = synth.make_grid(NI, NJ, NK, seed=20241020, rough_noise=0.0)     # smooth bathymetry: see Model
+    grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=LAND_FRAC, rough_noise=ROUGH_NOISE)
     dom = Domain(NI, NJ, (1, world), rank, grid.halo, grid.reentrant_x, grid.reentrant_y)
     M = Model(grid, dom, device, a.scheme)
     cells = NI * NJ * NK
@@ -431,9 +473,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    health0 = M.health()
     for n in range(a.warmup):
         M.step()
     M.dg.sync()
+    health_w = M.health()
     barrier()
     M.dg.kernel_timing(True)            # HIP events around the dominant kernel's launches, on the library's stream
     t0 = time.perf_counter()
@@ -450,8 +494,13 @@ def main():
     health = M.health()
     from mom6_amd.vert_friction import vertvisc_ntrunc
     vertvisc_ntrunc(M.dg, M.CS.vertvisc_CSp)      # CS%ntrunc: velocity truncations during the run
-    if health["nan"] or health["umax"] > 50.0 or health["hmin"] < 0.0:
-        sys.exit(f"bench.py: the model state is not healthy after {M.nstep} steps: {health}")
+    # sustained growth over the timed steps (more than doubling of the free-surface amplitude or of the kinetic energy from
+    # a state that is already energetic) is refused as well as NaNs: a number from a run that is blowing up is not a benchmark
+    growing = ((health["eta_max"] > 2.0 * max(health_w["eta_max"], 0.5)) or
+               (health["ke_mean"] > 2.0 * max(health_w["ke_mean"], 10.0)))
+    if health["nan"] or health["umax"] > 5.0 or health["hmin"] < 0.0 or growing:
+        sys.exit(f"bench.py: the model state is not healthy after {M.nstep} steps: start {health0}, after warm-up {health_w}, "
+                 f"at the end {health}")
 
     sec_per_step = elapsed / a.steps
     sypd = DT / sec_per_step / 365.0      # whole job: all ranks together advance the one global grid
@@ -464,7 +513,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / cells,
         "config": {
-            "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x, ~25% land, "
+            "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x, {100 * LAND_FRAC:.0f}% land, rough bathymetry, z* "
+                        f"layers ({100 * health['vanished_layer_fraction']:.0f}% of the ocean cells are vanished layers below the bottom), "
                         f"T, S + 2 passive tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
             "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
                     "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], vertvisc_coef x3 + "
@@ -474,10 +524,10 @@ def main():
             "not_yet_in_step": ["set_viscous_BBL / set_viscous_ML (the bottom boundary layer is prescribed: "
                                 f"bbl_thick = {VERTVISC['HBBL']} m, Kv_bbl = {KV_BBL} m2/s)", "horizontal_viscosity (diffu = diffv = 0)"],
             "vertvisc": dict(VERTVISC, Kv_bbl=KV_BBL, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)),
-            "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE >> DT_THERM), remap of T, S + 2 tracers "
+            "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE = 0, the default), remap of T, S + 2 tracers "
                    f"and of u, v [{REMAP_SCHEME}]",
             "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),
-            "state_after_run": health, "model_steps_taken": M.nstep,
+            "state_at_start": health0, "state_after_warmup": health_w, "state_after_run": health, "model_steps_taken": M.nstep,
             "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
                                                                "group passes over RCCL p2p",
         },

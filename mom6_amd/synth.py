@@ -242,7 +242,7 @@ def fill_halo(g: Grid, a: torch.Tensor, pos: int) -> torch.Tensor:
 
 
 def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.3, dtype=torch.float64, eta_amp=None,
-                        terrain_following=False):
+                        terrain_following=False, h_noise=0.05):
     """A model-like state for the dynamical core: h, u, v, uh, vh, T, S with valid halos.
 
     h: z*-like layers with vanished layers (Angstrom_H) below the topography and in random blobs;
@@ -276,7 +276,7 @@ def make_dynamics_state(g: Grid, seed=1, device="cpu", vanish_frac=0.05, umax=0.
             blob = torch.sin(9 * math.pi * X + 3 * K) * torch.sin(7 * math.pi * Y - 2 * K) + 0.3 * rndn(nk, nj, ni)
             q = torch.quantile(blob.flatten()[:: max(1, blob.numel() // 200000)], 1.0 - vanish_frac)
             h0 = torch.where(blob > q, torch.zeros_like(h0), h0)
-        h0 = torch.clamp(h0 * (1.0 + 0.05 * rndn(nk, nj, ni)), min=0.0)
+        h0 = torch.clamp(h0 * (1.0 + h_noise * rndn(nk, nj, ni)), min=0.0)
     h0 = torch.where(h0 < 1.0e-3, torch.full_like(h0, g.Angstrom_H), h0)
     h0 = torch.where(mT[None] > 0, h0, torch.full_like(h0, g.Angstrom_H))
     if eta_amp is not None:

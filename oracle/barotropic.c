@@ -149,6 +149,7 @@ static void set_local_bt_cont(const mom6hip_grid_t *G, int u, const double *FA_E
   const int pos = u ? MOM6HIP_POS_U : MOM6HIP_POS_V;
   const int a0 = u ? is - 1 : is, b0 = u ? js : js - 1;
 #define IX(i, j) (u ? ORC_U2(G, i, j) : ORC_V2(G, i, j))
+  ORC_PAR
   for (int j = b0; j <= je; j++) for (int i = a0; i <= ie; i++) {
     long n = IX(i, j);
     B->uBT_EE[n] = uBT_EE[n]; B->uBT_WW[n] = uBT_WW[n];
@@ -157,6 +158,7 @@ static void set_local_bt_cont(const mom6hip_grid_t *G, int u, const double *FA_E
   orc_halo_update(G, B->uBT_EE, pos, 1); orc_halo_update(G, B->uBT_WW, pos, 1);
   orc_halo_update(G, B->FA_EE, pos, 1); orc_halo_update(G, B->FA_E0, pos, 1);
   orc_halo_update(G, B->FA_W0, pos, 1); orc_halo_update(G, B->FA_WW, pos, 1);
+  ORC_PAR
   for (int j = b0 - hs; j <= je + hs; j++) for (int i = a0 - hs; i <= ie + hs; i++) {
     long n = IX(i, j);
     /* dt = 1.0: uBT_EE = dt*uBT_EE */
@@ -175,6 +177,7 @@ static void adjust_local_bt_cont(const mom6hip_grid_t *G, int u, const double *u
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
   const int a0 = u ? is - 1 : is, b0 = u ? js : js - 1;
   const double dt = 1.0;
+  ORC_PAR
   for (int j = b0 - hs; j <= je + hs; j++) for (int i = a0 - hs; i <= ie + hs; i++) {
     long n = u ? ORC_U2(G, i, j) : ORC_V2(G, i, j);
     double ub = ubt[n], uh = uhbt[n];
@@ -206,18 +209,22 @@ static void find_face_areas(const mom6hip_grid_t *G, const mom6hip_barotropic_cs
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
   const double Z_to_H = G->Z_to_H;
   if (have_add_max) {
+    ORC_PAR
     for (int j = js - hs; j <= je + hs; j++) for (int I = is - 1 - hs; I <= ie + hs; I++)
       Datu[ORC_U2(G, I, j)] = G->dy_Cu[ORC_U2(G, I, j)] * Z_to_H *
           max2(max2(G->bathyT[ORC_H2(G, I + 1, j)], G->bathyT[ORC_H2(G, I, j)]) + (CS->Z_ref + add_max), 0.0);
+    ORC_PAR
     for (int J = js - 1 - hs; J <= je + hs; J++) for (int i = is - hs; i <= ie + hs; i++)
       Datv[ORC_V2(G, i, J)] = G->dx_Cv[ORC_V2(G, i, J)] * Z_to_H *
           max2(max2(G->bathyT[ORC_H2(G, i, J + 1)], G->bathyT[ORC_H2(G, i, J)]) + (CS->Z_ref + add_max), 0.0);
   } else {
+    ORC_PAR
     for (int j = js - hs; j <= je + hs; j++) for (int I = is - 1 - hs; I <= ie + hs; I++) {
       double H1 = (G->bathyT[ORC_H2(G, I, j)] + CS->Z_ref) * Z_to_H, H2 = (G->bathyT[ORC_H2(G, I + 1, j)] + CS->Z_ref) * Z_to_H;
       Datu[ORC_U2(G, I, j)] = 0.0;
       if ((H1 > 0.0) && (H2 > 0.0)) Datu[ORC_U2(G, I, j)] = G->dy_Cu[ORC_U2(G, I, j)] * (2.0 * H1 * H2) / (H1 + H2);
     }
+    ORC_PAR
     for (int J = js - 1 - hs; J <= je + hs; J++) for (int i = is - hs; i <= ie + hs; i++) {
       double H1 = (G->bathyT[ORC_H2(G, i, J)] + CS->Z_ref) * Z_to_H, H2 = (G->bathyT[ORC_H2(G, i, J + 1)] + CS->Z_ref) * Z_to_H;
       Datv[ORC_V2(G, i, J)] = 0.0;
@@ -251,10 +258,13 @@ int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS) {
 #define BT(i, j) G->bathyT[ORC_H2(G, i, j)]
 #define AT(i, j) G->areaT[ORC_H2(G, i, j)]
 #define MT(i, j) G->mask2dT[ORC_H2(G, i, j)]
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++)
       CS->D_u_Cor[ORC_U2(G, I, j)] = 0.5 * (max2(Mean_SL + BT(I + 1, j), 0.0) + max2(Mean_SL + BT(I, j), 0.0)) * Z_to_H;
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++)
       CS->D_v_Cor[ORC_V2(G, i, J)] = 0.5 * (max2(Mean_SL + BT(i, J + 1), 0.0) + max2(Mean_SL + BT(i, J), 0.0)) * Z_to_H;
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int I = is - 1; I <= ie; I++) {
       int i = I, j = J;
       if (MT(i, j) + MT(i, j + 1) + MT(i + 1, j) + MT(i + 1, j + 1) > 0.) {
@@ -272,10 +282,12 @@ int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS) {
     orc_halo_update(G, CS->D_v_Cor, MOM6HIP_POS_V, 1);
   }
   /* .not.nonlin_stress :5070 */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
     double m = G->mask2dCu[ORC_U2(G, I, j)];
     CS->IDatu[ORC_U2(G, I, j)] = (m > 0.) ? m * 2.0 / (Z_to_H * ((BT(I + 1, j) + BT(I, j)) + 2.0 * Mean_SL)) : 0.;
   }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
     double m = G->mask2dCv[ORC_V2(G, i, J)];
     CS->IDatv[ORC_V2(G, i, J)] = (m > 0.) ? m * 2.0 / (Z_to_H * ((BT(i, J + 1) + BT(i, J)) + 2.0 * Mean_SL)) : 0.;
@@ -293,13 +305,14 @@ int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   if (!((h_u && h_v) || sch == MOM6HIP_BT_HARMONIC || sch == MOM6HIP_BT_HYBRID || sch == MOM6HIP_BT_ARITHMETIC)) {
     if (may_use_default) use_default = 1; else return 2;
   }
-  double *e = (double *)malloc(sizeof(double) * (nz + 2));
   for (int dir = 0; dir < 2; dir++) {
     /* dir 0: u-points j=js..je, I=is-1..ie ; dir 1: v-points J=js-1..je, i=is..ie */
     const int j0 = dir ? js - 1 : js, i0 = dir ? is : is - 1;
     const double *hw = dir ? h_v : h_u;
     double *fr = dir ? CS->frhatv : CS->frhatu;
+    ORC_PAR
     for (int j = j0; j <= je; j++) for (int i = i0; i <= ie; i++) {
+      double e[nz + 2];      /* interface heights of this face column (HYBRID) */
 #define F3(k) (dir ? ORC_V3(G, i, j, k) : ORC_U3(G, i, j, k))
 #define HP(k) h[dir ? ORC_H3(G, i, j + 1, k) : ORC_H3(G, i + 1, j, k)]
 #define HM(k) h[ORC_H3(G, i, j, k)]
@@ -350,13 +363,13 @@ int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
 #undef HM
     }
   }
-  free(e);
   return 0;
 }
 
 /* bt_mass_source :4318 (Boussinesq) */
 int orc_bt_mass_source(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *eta, int set_cor) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
     double eta_h = h[ORC_H3(G, i, j, 1)] - G->bathyT[ORC_H2(G, i, j)] * G->Z_to_H;
     for (int k = 2; k <= nz; k++) eta_h = eta_h + h[ORC_H3(G, i, j, k)];
@@ -379,6 +392,7 @@ int orc_set_dtbt(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const dou
       long n = ORC_U2(G, I, j);
       Datu[n] = max4(BT_cont->FA_u_EE[n], BT_cont->FA_u_E0[n], BT_cont->FA_u_W0[n], BT_cont->FA_u_WW[n]);
     }
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
       long n = ORC_V2(G, i, J);
       Datv[n] = max4(BT_cont->FA_v_NN[n], BT_cont->FA_v_N0[n], BT_cont->FA_v_S0[n], BT_cont->FA_v_SS[n]);
@@ -397,10 +411,11 @@ int orc_set_dtbt(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const dou
       gt[3][n] = gt[3][n] + p * CS->frhatv[ORC_V3(G, i, j - 1, k)];
     }
   } else {
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
       for (int q = 0; q < 4; q++) gt[q][ORC_H2(G, i, j)] = gtot_est;
   }
-  double min_max_dt2 = 1.0e38;
+  double min_max_dt2 = 1.0e38;      /* (a running minimum: serial) */
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
     long n = ORC_H2(G, i, j);
 #define FB(I, J) G->CoriolisBu[ORC_Q2(G, I, J)]
@@ -482,15 +497,21 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
 
   /* ---- Coriolis coefficients: q, DCor_u, DCor_v  :884-945 */
   if (CS->linearized_BT_PV) {
+    ORC_PAR
     for (int J = jsvf - 2; J <= jevf + 1; J++) for (int I = isvf - 2; I <= ievf + 1; I++) q[Q2(I, J)] = CS->q_D[Q2(I, J)];
+    ORC_PAR
     for (int j = jsvf - 1; j <= jevf + 1; j++) for (int I = isvf - 2; I <= ievf + 1; I++) DCor_u[U2(I, j)] = CS->D_u_Cor[U2(I, j)];
+    ORC_PAR
     for (int J = jsvf - 2; J <= jevf + 1; J++) for (int i = isvf - 1; i <= ievf + 1; i++) DCor_v[V2(i, J)] = CS->D_v_Cor[V2(i, J)];
   } else {
     const double Z_to_H = G->Z_to_H;
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++)
       DCor_u[U2(I, j)] = 0.5 * (max2(Z_to_H * BTH(I + 1, j) + eta_in[H2(I + 1, j)], 0.0) + max2(Z_to_H * BTH(I, j) + eta_in[H2(I, j)], 0.0));
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) /* eta_in(i+1,j): reproduced as written (:911) */
       DCor_v[V2(i, J)] = 0.5 * (max2(Z_to_H * BTH(i, J + 1) + eta_in[H2(i + 1, J)], 0.0) + max2(Z_to_H * BTH(i, J) + eta_in[H2(i, J)], 0.0));
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int I = is - 1; I <= ie; I++) {
       int i = I, j = J;
       q[Q2(I, J)] = 0.25 * (CS->BT_Coriolis_scale * G->CoriolisBu[Q2(I, J)]) *
@@ -504,6 +525,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   }
 
   /* ---- copy inputs into the wide arrays :1011-1033 */
+  ORC_PAR
   for (int j = jsd; j <= jed; j++) for (int i = isd; i <= ied; i++) {
     eta[H2(i, j)] = eta_in[H2(i, j)];
     if (interp_eta_PF) {
@@ -529,16 +551,20 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   }
 
   /* ---- ubt_Cor, vbt_Cor :1057-1070 */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int k = 1; k <= nz; k++) for (int I = is - 1; I <= ie; I++)
     ubt_Cor[U2(I, j)] = ubt_Cor[U2(I, j)] + wt_u[ORC_U3(G, I, j, k)] * U_Cor[ORC_U3(G, I, j, k)];
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int k = 1; k <= nz; k++) for (int i = is; i <= ie; i++)
     vbt_Cor[V2(i, J)] = vbt_Cor[V2(i, J)] + wt_v[ORC_V3(G, i, J, k)] * V_Cor[ORC_V3(G, i, J, k)];
 
   /* ---- gtot :1072-1091 */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int k = 1; k <= nz; k++) for (int I = is - 1; I <= ie; I++) {
     gtot_E[H2(I, j)] = gtot_E[H2(I, j)] + pbce[ORC_H3(G, I, j, k)] * wt_u[ORC_U3(G, I, j, k)];
     gtot_W[H2(I + 1, j)] = gtot_W[H2(I + 1, j)] + pbce[ORC_H3(G, I + 1, j, k)] * wt_u[ORC_U3(G, I, j, k)];
   }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int k = 1; k <= nz; k++) for (int i = is; i <= ie; i++) {
     gtot_N[H2(i, J)] = gtot_N[H2(i, J)] + pbce[ORC_H3(G, i, J, k)] * wt_v[ORC_V3(G, i, J, k)];
     gtot_S[H2(i, J + 1)] = gtot_S[H2(i, J + 1)] + pbce[ORC_H3(G, i, J + 1, k)] * wt_v[ORC_V3(G, i, J, k)];
@@ -557,12 +583,16 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
 
   /* ---- uhbt0, vhbt0 :1165-1252 */
   if (add_uh0) {
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) { uhbt[U2(I, j)] = 0.0; ubt[U2(I, j)] = 0.0; }
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) { vhbt[V2(i, J)] = 0.0; vbt[V2(i, J)] = 0.0; }
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int k = 1; k <= nz; k++) for (int I = is - 1; I <= ie; I++) {
       uhbt[U2(I, j)] = uhbt[U2(I, j)] + uh0[ORC_U3(G, I, j, k)];
       ubt[U2(I, j)] = ubt[U2(I, j)] + (CS->visc_rem_u_uh0 ? wt_u[ORC_U3(G, I, j, k)] : CS->frhatu[ORC_U3(G, I, j, k)]) * u_uh0[ORC_U3(G, I, j, k)];
     }
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int k = 1; k <= nz; k++) for (int i = is; i <= ie; i++) {
       vhbt[V2(i, J)] = vhbt[V2(i, J)] + vh0[ORC_V3(G, i, J, k)];
       vbt[V2(i, J)] = vbt[V2(i, J)] + (CS->visc_rem_u_uh0 ? wt_v[ORC_V3(G, i, J, k)] : CS->frhatv[ORC_V3(G, i, J, k)]) * v_vh0[ORC_V3(G, i, J, k)];
@@ -574,50 +604,67 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       adjust_local_bt_cont(G, 0, vbt, vhbt, &BV, 1 + ievf - ie);
     }
     if (use_BT_cont) {
+      ORC_PAR
       for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++)
         uhbt0[U2(I, j)] = uhbt[U2(I, j)] - find_uhbt(ubt[U2(I, j)], &BU, U2(I, j));
+      ORC_PAR
       for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++)
         vhbt0[V2(i, J)] = vhbt[V2(i, J)] - find_uhbt(vbt[V2(i, J)], &BV, V2(i, J));
     } else {
+      ORC_PAR
       for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++)
         uhbt0[U2(I, j)] = uhbt[U2(I, j)] - Datu[U2(I, j)] * ubt[U2(I, j)];
+      ORC_PAR
       for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++)
         vhbt0[V2(i, J)] = vhbt[V2(i, J)] - Datv[V2(i, J)] * vbt[V2(i, J)];
     }
   }
 
   /* ---- initial barotropic velocities :1254-1291 */
+  ORC_PAR
   for (int j = jsvf - 1; j <= jevf + 1; j++) for (int I = isvf - 2; I <= ievf + 1; I++) { ubt[U2(I, j)] = 0.0; uhbt[U2(I, j)] = 0.0; u_accel_bt[U2(I, j)] = 0.0; }
+  ORC_PAR
   for (int J = jsvf - 2; J <= jevf + 1; J++) for (int i = isvf - 1; i <= ievf + 1; i++) { vbt[V2(i, J)] = 0.0; vhbt[V2(i, J)] = 0.0; v_accel_bt[V2(i, J)] = 0.0; }
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int k = 1; k <= nz; k++) for (int I = is - 1; I <= ie; I++)
     ubt[U2(I, j)] = ubt[U2(I, j)] + wt_u[ORC_U3(G, I, j, k)] * U_in[ORC_U3(G, I, j, k)];
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int k = 1; k <= nz; k++) for (int i = is; i <= ie; i++)
     vbt[V2(i, J)] = vbt[V2(i, J)] + wt_v[ORC_V3(G, i, J, k)] * V_in[ORC_V3(G, i, J, k)];
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) if (fabs(ubt[U2(I, j)]) < CS->vel_underflow) ubt[U2(I, j)] = 0.0;
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) if (fabs(vbt[V2(i, J)]) < CS->vel_underflow) vbt[V2(i, J)] = 0.0;
 
   /* ---- BT_force :1303-1372 (.not.nonlin_stress) */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
     if (G->mask2dCu[U2(I, j)] > 0.0) BT_force_u[U2(I, j)] = taux[U2(I, j)] * RZ_to_H * CS->IDatu[U2(I, j)] * visc_rem_u[ORC_U3(G, I, j, 1)];
     else BT_force_u[U2(I, j)] = 0.0;
   }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
     if (G->mask2dCv[V2(i, J)] > 0.0) BT_force_v[V2(i, J)] = tauy[V2(i, J)] * RZ_to_H * CS->IDatv[V2(i, J)] * visc_rem_v[ORC_V3(G, i, J, 1)];
     else BT_force_v[V2(i, J)] = 0.0;
   }
   if (taux_bot && tauy_bot) {
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) if (G->mask2dCu[U2(I, j)] > 0.0)
       BT_force_u[U2(I, j)] = BT_force_u[U2(I, j)] - taux_bot[U2(I, j)] * RZ_to_H * CS->IDatu[U2(I, j)];
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) if (G->mask2dCv[V2(i, J)] > 0.0)
       BT_force_v[V2(i, J)] = BT_force_v[V2(i, J)] - tauy_bot[V2(i, J)] * RZ_to_H * CS->IDatv[V2(i, J)];
   }
   /* Isq = is-1, Jsq = js-1 in symmetric memory */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int k = 1; k <= nz; k++) for (int I = is - 1; I <= ie; I++)
     BT_force_u[U2(I, j)] = BT_force_u[U2(I, j)] + wt_u[ORC_U3(G, I, j, k)] * bc_accel_u[ORC_U3(G, I, j, k)];
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int k = 1; k <= nz; k++) for (int i = is; i <= ie; i++)
     BT_force_v[V2(i, J)] = BT_force_v[V2(i, J)] + wt_v[ORC_V3(G, i, J, k)] * bc_accel_v[ORC_V3(G, i, J, k)];
 
   /* ---- weighted Coriolis parameters :1421-1458 */
+  ORC_PAR
   for (int j = jsvf - 1; j <= jevf; j++) for (int i = isvf - 1; i <= ievf + 1; i++) {
     if (CS->Sadourny) {
       amer[U2(i - 1, j)] = DCor_u[U2(i - 1, j)] * q[Q2(i - 1, j)];
@@ -631,6 +678,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       dmer[U2(i - 1, j + 1)] = DCor_u[U2(i - 1, j + 1)] * ((q[Q2(i, j)] + q[Q2(i - 1, j + 1)]) + q[Q2(i - 1, j)]) / 3.0;
     }
   }
+  ORC_PAR
   for (int j = jsvf - 1; j <= jevf + 1; j++) for (int i = isvf - 1; i <= ievf; i++) {
     if (CS->Sadourny) {
       azon[U2(i, j)] = DCor_v[V2(i + 1, j)] * q[Q2(i, j)];
@@ -651,11 +699,13 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   orc_halo_update(G, ubt_Cor, MOM6HIP_POS_U, 1); orc_halo_update(G, vbt_Cor, MOM6HIP_POS_V, 1);
 
   /* ---- Cor_ref :1478-1490 */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
     int i = I;
     Cor_ref_u[U2(I, j)] = ((azon[U2(I, j)] * vbt_Cor[V2(i + 1, j)] + czon[U2(I, j)] * vbt_Cor[V2(i, j - 1)]) +
                            (bzon[U2(I, j)] * vbt_Cor[V2(i, j)] + dzon[U2(I, j)] * vbt_Cor[V2(i + 1, j - 1)]));
   }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
     int j = J;
     Cor_ref_v[V2(i, J)] = -1.0 * ((amer[U2(i - 1, j)] * ubt_Cor[U2(i - 1, j)] + cmer[U2(i, j + 1)] * ubt_Cor[U2(i, j + 1)]) +
@@ -663,20 +713,26 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   }
 
   /* ---- av_rem, bt_rem :1505-1541 */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int k = 1; k <= nz; k++) for (int I = is - 1; I <= ie; I++)
     av_rem_u[U2(I, j)] = av_rem_u[U2(I, j)] + CS->frhatu[ORC_U3(G, I, j, k)] * visc_rem_u[ORC_U3(G, I, j, k)];
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int k = 1; k <= nz; k++) for (int i = is; i <= ie; i++)
     av_rem_v[V2(i, J)] = av_rem_v[V2(i, J)] + CS->frhatv[ORC_V3(G, i, J, k)] * visc_rem_v[ORC_V3(G, i, J, k)];
   if (CS->strong_drag) {
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++)
       bt_rem_u[U2(I, j)] = G->mask2dCu[U2(I, j)] * ((nstep * av_rem_u[U2(I, j)]) / (1.0 + (nstep - 1) * av_rem_u[U2(I, j)]));
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++)
       bt_rem_v[V2(i, J)] = G->mask2dCv[V2(i, J)] * ((nstep * av_rem_v[V2(i, J)]) / (1.0 + (nstep - 1) * av_rem_v[V2(i, J)]));
   } else {
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
       bt_rem_u[U2(I, j)] = 0.0;
       if (G->mask2dCu[U2(I, j)] * av_rem_u[U2(I, j)] > 0.0) bt_rem_u[U2(I, j)] = G->mask2dCu[U2(I, j)] * orc_cr_pow(av_rem_u[U2(I, j)], Instep);
     }
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
       bt_rem_v[V2(i, J)] = 0.0;
       if (G->mask2dCv[V2(i, J)] * av_rem_v[V2(i, J)] > 0.0) bt_rem_v[V2(i, J)] = G->mask2dCv[V2(i, J)] * orc_cr_pow(av_rem_v[V2(i, J)], Instep);
@@ -684,6 +740,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   }
 
   /* ---- eta_src :1583-1628 (.not.bound_BT_corr) */
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
     eta_src[H2(i, j)] = G->mask2dT[H2(i, j)] * (Instep * CS->eta_cor[H2(i, j)]);
 
@@ -743,14 +800,18 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
 
     /* predictor continuity :1870-1909 */
     if (use_BT_cont) {
+      ORC_PAR
       for (int j = jsv - 1; j <= jev + 1; j++) for (int I = isv - 2; I <= iev + 1; I++)
         uhbt[U2(I, j)] = find_uhbt(ubt[U2(I, j)], &BU, U2(I, j)) + uhbt0[U2(I, j)];
+      ORC_PAR
       for (int J = jsv - 2; J <= jev + 1; J++) for (int i = isv - 1; i <= iev + 1; i++)
         vhbt[V2(i, J)] = find_uhbt(vbt[V2(i, J)], &BV, V2(i, J)) + vhbt0[V2(i, J)];
+      ORC_PAR
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++)
         eta_pred[H2(i, j)] = (eta[H2(i, j)] + eta_src[H2(i, j)]) + (dtbt * G->IareaT[H2(i, j)]) *
             ((uhbt[U2(i - 1, j)] - uhbt[U2(i, j)]) + (vhbt[V2(i, j - 1)] - vhbt[V2(i, j)]));
     } else {
+      ORC_PAR
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++)
         eta_pred[H2(i, j)] = (eta[H2(i, j)] + eta_src[H2(i, j)]) + (dtbt * G->IareaT[H2(i, j)]) *
             (((Datu[U2(i - 1, j)] * ubt[U2(i - 1, j)] + uhbt0[U2(i - 1, j)]) - (Datu[U2(i, j)] * ubt[U2(i, j)] + uhbt0[U2(i, j)])) +
@@ -760,6 +821,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       eta_sum[H2(i, j)] = eta_sum[H2(i, j)] + wt_accel2[n] * eta_PF_BT[H2(i, j)];
     if (interp_eta_PF) {
       const double wt_end = n * Instep;
+      ORC_PAR
       for (int j = jsv - 1; j <= jev + 1; j++) for (int i = isv - 1; i <= iev + 1; i++)
         eta_PF[H2(i, j)] = eta_PF_1[H2(i, j)] + wt_end * d_eta_PF[H2(i, j)];
     }
@@ -770,6 +832,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       if (do_v) {
         /* v-first: i=isv-1..iev+1 (:1975) ; v-second: i=isv..iev (:2217) */
         const int i0 = v_first ? isv - 1 : isv, i1 = v_first ? iev + 1 : iev;
+        ORC_PAR
         for (int J = jsv - 1; J <= jev; J++) for (int i = i0; i <= i1; i++) {
           int j = J;
           Cor_v[V2(i, J)] = -1.0 * ((amer[U2(i - 1, j)] * ubt[U2(i - 1, j)] + cmer[U2(i, j + 1)] * ubt[U2(i, j + 1)]) +
@@ -777,6 +840,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
           PFv[V2(i, J)] = ((eta_PF_BT[H2(i, j)] - eta_PF[H2(i, j)]) * gtot_N[H2(i, j)] -
                            (eta_PF_BT[H2(i, j + 1)] - eta_PF[H2(i, j + 1)]) * gtot_S[H2(i, j + 1)]) * dgeo_de * G->IdyCv[V2(i, J)];
         }
+        ORC_PAR
         for (int J = jsv - 1; J <= jev; J++) for (int i = i0; i <= i1; i++) {
           double vel_prev = vbt[V2(i, J)];
           vbt[V2(i, J)] = bt_rem_v[V2(i, J)] * (vbt[V2(i, J)] + dtbt * ((BT_force_v[V2(i, J)] + Cor_v[V2(i, J)]) + PFv[V2(i, J)]));
@@ -789,6 +853,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       } else {
         /* u-second: j=jsv..jev (:2047) ; u-first: j=jsv-1..jev+1 (:2130) */
         const int j0 = v_first ? jsv : jsv - 1, j1 = v_first ? jev : jev + 1;
+        ORC_PAR
         for (int j = j0; j <= j1; j++) for (int I = isv - 1; I <= iev; I++) {
           int i = I;
           Cor_u[U2(I, j)] = ((azon[U2(I, j)] * vbt[V2(i + 1, j)] + czon[U2(I, j)] * vbt[V2(i, j - 1)]) +
@@ -796,6 +861,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
           PFu[U2(I, j)] = ((eta_PF_BT[H2(i, j)] - eta_PF[H2(i, j)]) * gtot_E[H2(i, j)] -
                            (eta_PF_BT[H2(i + 1, j)] - eta_PF[H2(i + 1, j)]) * gtot_W[H2(i + 1, j)]) * dgeo_de * G->IdxCu[U2(I, j)];
         }
+        ORC_PAR
         for (int j = j0; j <= j1; j++) for (int I = isv - 1; I <= iev; I++) {
           double vel_prev = ubt[U2(I, j)];
           ubt[U2(I, j)] = bt_rem_u[U2(I, j)] * (ubt[U2(I, j)] + dtbt * ((BT_force_u[U2(I, j)] + Cor_u[U2(I, j)]) + PFu[U2(I, j)]));
@@ -809,17 +875,20 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     }
 
     /* running sums :2341-2355 */
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
       ubt_sum[U2(I, j)] = ubt_sum[U2(I, j)] + wt_trans[n] * ubt_trans[U2(I, j)];
       uhbt_sum[U2(I, j)] = uhbt_sum[U2(I, j)] + wt_trans[n] * uhbt[U2(I, j)];
       ubt_wtd[U2(I, j)] = ubt_wtd[U2(I, j)] + wt_vel[n] * ubt[U2(I, j)];
     }
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
       vbt_sum[V2(i, J)] = vbt_sum[V2(i, J)] + wt_trans[n] * vbt_trans[V2(i, J)];
       vhbt_sum[V2(i, J)] = vhbt_sum[V2(i, J)] + wt_trans[n] * vhbt[V2(i, J)];
       vbt_wtd[V2(i, J)] = vbt_wtd[V2(i, J)] + wt_vel[n] * vbt[V2(i, J)];
     }
     /* corrector continuity :2414-2421 */
+    ORC_PAR
     for (int j = jsv; j <= jev; j++) for (int i = isv; i <= iev; i++) {
       eta[H2(i, j)] = (eta[H2(i, j)] + eta_src[H2(i, j)]) + (dtbt * G->IareaT[H2(i, j)]) *
           ((uhbt[U2(i - 1, j)] - uhbt[U2(i, j)]) + (vhbt[V2(i, j - 1)] - vhbt[V2(i, j)]));
@@ -837,15 +906,19 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     else
       e_anom[H2(i, j)] = dgeo_de * (0.5 * (eta[H2(i, j)] + eta_in[H2(i, j)]) - eta_PF[H2(i, j)]);
   }
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta_out[H2(i, j)] = eta_wtd[H2(i, j)] * 1.0;
   if (find_etaav) orc_halo_update(G, etaav, MOM6HIP_POS_H, 1);
   orc_halo_update(G, e_anom, MOM6HIP_POS_H, 1);
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) { CS->ubtav[U2(I, j)] = ubt_sum[U2(I, j)]; uhbtav[U2(I, j)] = uhbt_sum[U2(I, j)]; }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) { CS->vbtav[V2(i, J)] = vbt_sum[V2(i, J)]; vhbtav[V2(i, J)] = vhbt_sum[V2(i, J)]; }
   orc_halo_update(G, CS->ubtav, MOM6HIP_POS_U, 1); orc_halo_update(G, CS->vbtav, MOM6HIP_POS_V, 1);
   orc_halo_update(G, uhbtav, MOM6HIP_POS_U, 1); orc_halo_update(G, vhbtav, MOM6HIP_POS_V, 1);
 
   for (int k = 1; k <= nz; k++) {
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
       int i = I;
       double a = (u_accel_bt[U2(I, j)] - ((pbce[ORC_H3(G, i + 1, j, k)] - gtot_W[H2(i + 1, j)]) * e_anom[H2(i + 1, j)] -
@@ -853,6 +926,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       if (fabs(a) < accel_underflow) a = 0.0;
       accel_layer_u[ORC_U3(G, I, j, k)] = a;
     }
+    ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
       int j = J;
       double a = (v_accel_bt[V2(i, J)] - ((pbce[ORC_H3(G, i, j + 1, k)] - gtot_S[H2(i, j + 1)]) * e_anom[H2(i, j + 1)] -

@@ -59,12 +59,14 @@ static void edge_thickness(const dirx_t *D, const mom6hip_continuity_cs_t *CS, c
   const double oneSixth = 1./6.;
   const int al = a0-1, ah = a1+1;                 /* isl, iel */
   const long n2 = (long)ORC_NIH(G)*ORC_NJH(G);
-  double *slp = calloc(n2, sizeof(double));
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
+    double *slp = calloc(n2, sizeof(double));      /* (the reference's slp is a 2-D automatic array inside its k loop) */
     if (CS->upwind_1st) {
       for (int c = c0; c <= c1; c++) for (int a = a0-1; a <= a1+1; a++) {
         h_L[H3d(D,a,c,k)] = h_in[H3d(D,a,c,k)]; h_R[H3d(D,a,c,k)] = h_in[H3d(D,a,c,k)];
       }
+      free(slp);
       continue;
     }
 #define HI(a,c) h_in[H3d(D,a,c,k)]
@@ -132,8 +134,8 @@ static void edge_thickness(const dirx_t *D, const mom6hip_continuity_cs_t *CS, c
     }
 #undef HI
 #undef MT
+    free(slp);
   }
-  free(slp);
 }
 
 /* zonal_flux_layer :896-972 for one face: returns uh, sets *duhdu */
@@ -253,8 +255,10 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
     long n = D->dir ? (long)ORC_NIH(G)*(ORC_NJH(G)+1) : (long)(ORC_NIH(G)+1)*ORC_NJH(G);
     memset(du_cor, 0, n*sizeof(double));
   }
+  ORC_PAR_DYN
+  for (int c = c0; c <= c1; c++) {
   double *vr = calloc(nz+1, sizeof(double)), *duhdu = calloc(nz+1, sizeof(double));
-  for (int c = c0; c <= c1; c++) for (int A = a0-1; A <= a1; A++) {
+  for (int A = a0-1; A <= a1; A++) {
     const int a = A;
     for (int k = 1; k <= nz; k++) {
       vr[k] = use_visc_rem ? visc_rem_u[F3d(D,A,c,k)] : 1.0;
@@ -357,10 +361,13 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
       else BT->uBT_pp[F2d(D,A,c)] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
     }
   }
+  free(vr); free(duhdu);
+  }
 
   /* zonal_flux_thickness :976-1057 */
   if (set_BT_cont && BT->h_face) {
     const double *uu = u_cor ? u_cor : u;
+    ORC_PAR
     for (int k = 1; k <= nz; k++) for (int c = c0; c <= c1; c++) for (int A = a0-1; A <= a1; A++) {
       const int a = A;
       const double uk = uu[F3d(D,A,c,k)];
@@ -389,7 +396,6 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
       BT->h_face[F3d(D,A,c,k)] = hu;
     }
   }
-  free(vr); free(duhdu);
 }
 
 /* continuity_zonal_convergence :348-381 / continuity_merdional_convergence :384-417 */
@@ -397,6 +403,7 @@ static void convergence(const dirx_t *D, double *h, const double *uh, double dt,
                         const double *hin, double h_min)
 {
   const mom6hip_grid_t *G = D->G;
+  ORC_PAR
   for (int k = 1; k <= G->nk; k++) for (int c = c0; c <= c1; c++) for (int a = a0; a <= a1; a++) {
     const double *src = hin ? hin : h;
     h[H3d(D,a,c,k)] = max2( src[H3d(D,a,c,k)] - dt * G->IareaT[H2d(D,a,c)] *

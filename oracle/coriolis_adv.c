@@ -27,10 +27,7 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   if (CS->coriolis_en_dis) return 1;
   const long nH = (long)ORC_NIH(G)*ORC_NJH(G), nU = (long)(ORC_NIH(G)+1)*ORC_NJH(G);
   const long nV = (long)ORC_NIH(G)*(ORC_NJH(G)+1), nQ = (long)(ORC_NIH(G)+1)*(ORC_NJH(G)+1);
-  double *Area_h = calloc(nH, 8), *Area_q = calloc(nQ, 8), *q = calloc(nQ, 8), *Ih_q = calloc(nQ, 8);
-  double *abs_vort = calloc(nQ, 8), *dvdx = calloc(nQ, 8), *dudy = calloc(nQ, 8), *rel_vort = calloc(nQ, 8);
-  double *hArea_u = calloc(nU, 8), *hArea_v = calloc(nV, 8), *KE = calloc(nH, 8), *KEx = calloc(nU, 8), *KEy = calloc(nV, 8);
-  double *a = calloc(nU, 8), *b = calloc(nU, 8), *c = calloc(nU, 8), *d = calloc(nU, 8);
+  double *Area_h = calloc(nH, 8), *Area_q = calloc(nQ, 8);
 #define H2(i,j) ORC_H2(G,i,j)
 #define U2(i,j) ORC_U2(G,i,j)
 #define V2(i,j) ORC_V2(G,i,j)
@@ -46,6 +43,14 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++)
     Area_q[Q2(I,J)] = (Area_h[H2(I,J)] + Area_h[H2(I+1,J+1)]) + (Area_h[H2(I+1,J)] + Area_h[H2(I,J+1)]);
 
+  /* the layers are independent (the reference: !$OMP parallel do over k, :281-284); the 2-D work arrays are per thread */
+  _Pragma("omp parallel")
+  {
+  double *q = calloc(nQ, 8), *Ih_q = calloc(nQ, 8);
+  double *abs_vort = calloc(nQ, 8), *dvdx = calloc(nQ, 8), *dudy = calloc(nQ, 8), *rel_vort = calloc(nQ, 8);
+  double *hArea_u = calloc(nU, 8), *hArea_v = calloc(nV, 8), *KE = calloc(nH, 8), *KEx = calloc(nU, 8), *KEy = calloc(nV, 8);
+  double *a = calloc(nU, 8), *b = calloc(nU, 8), *c = calloc(nU, 8), *d = calloc(nU, 8);
+  _Pragma("omp for schedule(static)")
   for (int k = 1; k <= nz; k++) {
     /* :314-324 */
     for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++) {
@@ -174,7 +179,9 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
       CAv[V3(i,J,k)] = ca - KEy[V2(i,J)];
     }
   }
-  free(Area_h); free(Area_q); free(q); free(Ih_q); free(abs_vort); free(dvdx); free(dudy); free(rel_vort);
+  free(q); free(Ih_q); free(abs_vort); free(dvdx); free(dudy); free(rel_vort);
   free(hArea_u); free(hArea_v); free(KE); free(KEx); free(KEy); free(a); free(b); free(c); free(d);
+  }
+  free(Area_h); free(Area_q);
   return 0;
 }

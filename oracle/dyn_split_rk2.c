@@ -93,6 +93,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   if (!CS->CAu_pred_stored)   /* :544-552 */
     CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
   /* u_bc_accel :557-564 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
       u_bc_accel[U3(I, j, k)] = (CS->CAu_pred[U3(I, j, k)] + CS->PFu[U3(I, j, k)]) + CS->diffu[U3(I, j, k)];
@@ -100,6 +101,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
       v_bc_accel[V3(i, J, k)] = (CS->CAv_pred[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
   }
   /* up :582-589 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
       up[U3(I, j, k)] = G->mask2dCu[ORC_U2(G, I, j)] * (u_inst[U3(I, j, k)] + dt * u_bc_accel[U3(I, j, k)]);
@@ -133,6 +135,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
   /* up = u + dt_pred*(u_bc_accel + u_accel_bt) :663-676 */
   const double dt_pred = dt * CS->be;
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       vp[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_inst[V3(i, J, k)] + dt_pred * (v_bc_accel[V3(i, J, k)] + CS->v_accel_bt[V3(i, J, k)]));
@@ -154,6 +157,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   /* pass_hp_uv :763 */
   pass3(G, hp, MOM6HIP_POS_H); pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
   /* h_av :785-787 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
   orc_bt_mass_source(G, BT, hp, eta_pred, 0);                                                          /* :797 */
@@ -161,6 +165,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   /* [horizontal_viscosity :860: diffu stays 0] ; CorAdCalc :869 */
   CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
   /* u_bc_accel :879-886 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
       u_bc_accel[U3(I, j, k)] = (CS->CAu[U3(I, j, k)] + CS->PFu[U3(I, j, k)]) + CS->diffu[U3(I, j, k)];
@@ -176,6 +181,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[H2(i, j)] = eta_pred[H2(i, j)];   /* :918 */
   /* u = u + dt*(u_bc_accel + u_accel_bt) :928-939 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
       u_inst[U3(I, j, k)] = G->mask2dCu[ORC_U2(G, I, j)] * (u_inst[U3(I, j, k)] + dt * (u_bc_accel[U3(I, j, k)] + CS->u_accel_bt[U3(I, j, k)]));
@@ -189,6 +195,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
   }
   /* h_av = h :1000-1002 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = h[H3(i, j, k)];
   /* pass_visc_rem :1004, pass_uv :1008 */
@@ -201,9 +208,11 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   pass3(G, h, MOM6HIP_POS_H);
   pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
   /* h_av :1038-1040 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = 0.5 * (h_av[H3(i, j, k)] + h[H3(i, j, k)]);
   /* uhtr, vhtr :1046-1053 */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     for (int j = js - 2; j <= je + 2; j++) for (int I = Isq - 2; I <= Ieq + 2; I++)
       uhtr[U3(I, j, k)] = uhtr[U3(I, j, k)] + uh[U3(I, j, k)] * dt;

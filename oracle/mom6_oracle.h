@@ -29,6 +29,14 @@
 extern "C" {
 #endif
 
+/* ---- threading: the oracle is scalar code; loops whose iterations are independent (the ones the reference marks
+ * !$OMP parallel do, e.g. src/core/MOM_continuity_PPM.F90:615-618, src/core/MOM_CoriolisAdv.F90:281-284,
+ * src/core/MOM_barotropic.F90:1869-2422) carry ORC_PAR.  The default build ignores it (one thread);
+ * libmom6oracle_omp.so (make omp: -fopenmp) runs them on all cores for bench.py's all-cores CPU baseline.  The
+ * results are bit-identical either way (tests/test_oracle_omp.py): no reduction crosses a parallel loop. */
+#define ORC_PAR _Pragma("omp parallel for schedule(static)")
+#define ORC_PAR_DYN _Pragma("omp parallel for schedule(dynamic, 1)")
+
 /* ---- index helpers: Fortran (i,j,k) with k 1-based, symmetric memory --------------------- */
 #define ORC_NIH(G)  ((G)->ied - (G)->isd + 1)
 #define ORC_NJH(G)  ((G)->jed - (G)->jsd + 1)

@@ -17,13 +17,40 @@ def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
 
+_THREADS = 1
+_LIBS = {}
+
+
+def set_threads(n):
+    """n = 1: the scalar oracle (libmom6oracle.so).  n > 1 (or 0 = all cores): libmom6oracle_omp.so, the same sources
+    built with -fopenmp -- the loops the reference marks !$OMP run on n threads, results bit-identical
+    (tests/test_oracle_omp.py).  Used by bench.py's all-cores CPU baseline."""
+    global _THREADS, _LIB
+    n = int(n)
+    if n == 0:
+        n = len(os.sched_getaffinity(0))
+    _THREADS = n
+    _LIB = None
+    L = lib()
+    if n > 1:
+        L._gomp.omp_set_num_threads(n)
+    return n
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libmom6oracle.so")
+        omp = _THREADS > 1
+        if omp in _LIBS:
+            _LIB = _LIBS[omp]
+            return _LIB
+        path = os.path.join(_HERE, "libmom6oracle_omp.so" if omp else "libmom6oracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
+        if omp:
+            L._gomp = C.CDLL("libgomp.so.1")
+        _LIBS[omp] = L
         L.orc_halo_update.argtypes = [C.POINTER(_abi.GridStruct), _dp, C.c_int, C.c_int]
         L.orc_halo_update.restype = None
         L.orc_advect_tracer.argtypes = [

@@ -85,10 +85,10 @@ void orc_ale_plm_edge_values(const mom6hip_grid_t *G, const double *h, const dou
 {
   const int nz = G->nk;
   const double h_neglect = G->H_subroundoff;
-  double *slp = calloc(nz+2, sizeof(double));
 #define HH(k) h[ORC_H3(G,i,j,k)]
 #define QQ(k) Q[ORC_H3(G,i,j,k)]
-  for (int j = G->jsc-1; j <= G->jec+1; j++) for (int i = G->isc-1; i <= G->iec+1; i++) {
+  ORC_PAR
+  for (int j = G->jsc-1; j <= G->jec+1; j++) { double *slp = calloc(nz+2, sizeof(double)); for (int i = G->isc-1; i <= G->iec+1; i++) {
     slp[1] = 0.;
     for (int k = 2; k <= nz-1; k++)
       slp[k] = orc_plm_slope_wa(HH(k-1), HH(k), HH(k+1), h_neglect, QQ(k-1), QQ(k), QQ(k+1));
@@ -109,10 +109,9 @@ void orc_ale_plm_edge_values(const mom6hip_grid_t *G, const double *h, const dou
       Q_t[ORC_H3(G,i,j,1)] = QQ(1); Q_b[ORC_H3(G,i,j,1)] = QQ(1);
       Q_t[ORC_H3(G,i,j,nz)] = QQ(nz); Q_b[ORC_H3(G,i,j,nz)] = QQ(nz);
     }
-  }
+  } free(slp); }
 #undef HH
 #undef QQ
-  free(slp);
 }
 
 /* e(i,j,K), K = 1..nz+1 */
@@ -139,6 +138,7 @@ static void int_density_dz_generic_plm(const mom6hip_grid_t *G, const mom6hip_eo
 #define SB(i,j) S_b[ORC_H3(G,i,j,k)]
   const int K = k;
   /* 1. vertical integrals */
+  ORC_PAR
   for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
     double dz = E3(i,j,K) - E3(i,j,K+1);
     double r5[6];
@@ -157,6 +157,7 @@ static void int_density_dz_generic_plm(const mom6hip_grid_t *G, const mom6hip_eo
   for (int dir = 0; dir < 2; dir++) {
     const int j0 = dir ? Jsq : G->jsc, j1 = dir ? Jeq : G->jec;
     const int i0 = dir ? G->isc : Isq, i1 = dir ? G->iec : Ieq;
+    ORC_PAR
     for (int j = j0; j <= j1; j++) for (int i = i0; i <= i1; i++) {
       const int ip = dir ? i : i+1, jp = dir ? j+1 : j;      /* the cell on the "right" of the face */
       double Ttl, Tbl, Ttr, Tbr, Stl, Sbl, Str, Sbr;
@@ -234,6 +235,7 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
   for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
     E3(i,j,nz+1) = -G->bathyT[ORC_H2(G,i,j)];
   /* :646-648 */
+  ORC_PAR
   for (int j = Jsq; j <= Jeq+1; j++) for (int k = nz; k >= 1; k--) for (int i = Isq; i <= Ieq+1; i++)
     E3(i,j,k) = E3(i,j,k+1) + h[ORC_H3(G,i,j,k)]*G->H_to_Z;
 
@@ -258,6 +260,7 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
       intz_dpa[ORC_H2(G,i,j)] = intz_dpa[ORC_H2(G,i,j)]*G->Z_to_H;
 #define HK(i,j) h[ORC_H3(G,i,j,k)]
     /* :793-801 */
+    ORC_PAR
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
       const int i = I;
       PFu[ORC_U3(G,I,j,k)] = (((pa[ORC_H2(G,i,j)]*HK(i,j) + intz_dpa[ORC_H2(G,i,j)]) -
@@ -269,6 +272,7 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
       intx_pa[ORC_U2(G,I,j)] = intx_pa[ORC_U2(G,I,j)] + intx_dpa[ORC_U2(G,I,j)];
     }
     /* :804-812 */
+    ORC_PAR
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) {
       const int j = J;
       PFv[ORC_V3(G,i,J,k)] = (((pa[ORC_H2(G,i,j)]*HK(i,j) + intz_dpa[ORC_H2(G,i,j)]) -
@@ -287,6 +291,7 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
   /* Set_pbce_Bouss (use_EOS, no rho_star), MOM_PressureForce_Montgomery.F90:702-729 */
   if (pbce) {
     const double Rho0xG = CS->Rho0 * G->g_Earth;
+    ORC_PAR
     for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
       double Ihtot = G->H_to_Z / ((E3(i,j,1)-E3(i,j,nz+1)) + dz_neglect);
       double press = -Rho0xG*(E3(i,j,1) - Z_ref);

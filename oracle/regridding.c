@@ -119,10 +119,10 @@ int orc_ale_regrid(const mom6hip_grid_t *G, const mom6hip_regridding_cs_t *CS, c
   const long nh2 = (long)ORC_NIH(G) * ORC_NJH(G);
   const double Z_to_H = G->Z_to_H;
   memset(dzRegrid, 0, sizeof(double) * nh2 * (nz + 1));                         /* MOM_ALE.F90:508 */
-  double *zOld = (double *)calloc(nz + 2, sizeof(double)), *zNew = (double *)calloc(nz + 2, sizeof(double));
-  double *dz = (double *)calloc(nz + 2, sizeof(double)), *hc = (double *)calloc(nz + 2, sizeof(double));
   int rc = 0;
-  for (int j = G->jsc - 1; j <= G->jec + 1 && !rc; j++) for (int i = G->isc - 1; i <= G->iec + 1; i++) {
+  ORC_PAR      /* the columns are independent */
+  for (int j = G->jsc - 1; j <= G->jec + 1; j++) for (int i = G->isc - 1; i <= G->iec + 1; i++) {
+    double zOld[nz + 2], zNew[nz + 2], dz[nz + 2], hc[nz + 2];
     const long n2 = ORC_H2(G, i, j);
 #define DZ(k) dzRegrid[n2 + nh2 * ((k) - 1)]
     if (G->mask2dT[n2] == 0.) {
@@ -135,9 +135,9 @@ int orc_ale_regrid(const mom6hip_grid_t *G, const mom6hip_regridding_cs_t *CS, c
       for (int k = nz; k >= 1; k--) zOld[k] = zOld[k + 1] + hc[k];
       build_zstar_column(CS, nominalDepth, totalThickness, zNew, Z_to_H);
       for (int k = 1; k <= nz + 1; k++) dz[k] = DZ(k);
-      rc = filtered_grid_motion(CS, nz, zOld, zNew, dz);
-      if (!rc) rc = adjust_interface_motion(CS, nz, hc, dz);
-      if (rc) break;
+      int rc1 = filtered_grid_motion(CS, nz, zOld, zNew, dz);
+      if (!rc1) rc1 = adjust_interface_motion(CS, nz, hc, dz);
+      if (rc1) { rc = rc1; continue; }
       for (int k = 1; k <= nz + 1; k++) DZ(k) = dz[k];
     }
     /* calc_h_new_by_dz :925 */
@@ -148,14 +148,15 @@ int orc_ale_regrid(const mom6hip_grid_t *G, const mom6hip_regridding_cs_t *CS, c
     }
 #undef DZ
   }
-  free(zOld); free(zNew); free(dz); free(hc);
   return rc;
 }
 
 /* ALE_remap_set_h_vel :870 */
 int orc_ale_remap_set_h_vel(const mom6hip_grid_t *G, const double *h_new, double *h_u, double *h_v) {
+  ORC_PAR
   for (int k = 1; k <= G->nk; k++) for (int j = G->jsc; j <= G->jec; j++) for (int I = G->isc - 1; I <= G->iec; I++)
     if (G->mask2dCu[ORC_U2(G, I, j)] > 0.) h_u[ORC_U3(G, I, j, k)] = 0.5 * (h_new[ORC_H3(G, I, j, k)] + h_new[ORC_H3(G, I + 1, j, k)]);
+  ORC_PAR
   for (int k = 1; k <= G->nk; k++) for (int J = G->jsc - 1; J <= G->jec; J++) for (int i = G->isc; i <= G->iec; i++)
     if (G->mask2dCv[ORC_V2(G, i, J)] > 0.) h_v[ORC_V3(G, i, J, k)] = 0.5 * (h_new[ORC_H3(G, i, J, k)] + h_new[ORC_H3(G, i, J + 1, k)]);
   return 0;
@@ -166,23 +167,24 @@ int orc_ale_remap_velocities(const mom6hip_grid_t *G, const mom6hip_remapping_cs
                              const double *h_new_u, const double *h_new_v, double *u, double *v) {
   const int nz = G->nk;
   const double h_neglect = G->H_subroundoff, h_neglect_edge = G->H_subroundoff;
-  double *h1 = (double *)calloc(nz, sizeof(double)), *h2 = (double *)calloc(nz, sizeof(double));
-  double *src = (double *)calloc(nz, sizeof(double)), *tgt = (double *)calloc(nz, sizeof(double));
   int rc = 0;
-  for (int j = G->jsc; j <= G->jec && !rc; j++) for (int I = G->isc - 1; I <= G->iec; I++) {
+  ORC_PAR
+  for (int j = G->jsc; j <= G->jec; j++) for (int I = G->isc - 1; I <= G->iec; I++) {
+    double h1[nz], h2[nz], src[nz], tgt[nz];
     if (!(G->mask2dCu[ORC_U2(G, I, j)] > 0.)) continue;
     for (int k = 1; k <= nz; k++) { h1[k - 1] = h_old_u[ORC_U3(G, I, j, k)]; h2[k - 1] = h_new_u[ORC_U3(G, I, j, k)]; src[k - 1] = u[ORC_U3(G, I, j, k)]; }
-    rc = orc_remapping_core_h(cs->remapping_scheme, cs->boundary_extrapolation, nz, h1, src, nz, h2, tgt, h_neglect, h_neglect_edge);
-    if (rc) break;
+    const int rc1 = orc_remapping_core_h(cs->remapping_scheme, cs->boundary_extrapolation, nz, h1, src, nz, h2, tgt, h_neglect, h_neglect_edge);
+    if (rc1) { rc = rc1; continue; }
     for (int k = 1; k <= nz; k++) u[ORC_U3(G, I, j, k)] = tgt[k - 1];
   }
-  for (int J = G->jsc - 1; J <= G->jec && !rc; J++) for (int i = G->isc; i <= G->iec; i++) {
+  ORC_PAR
+  for (int J = G->jsc - 1; J <= G->jec; J++) for (int i = G->isc; i <= G->iec; i++) {
+    double h1[nz], h2[nz], src[nz], tgt[nz];
     if (!(G->mask2dCv[ORC_V2(G, i, J)] > 0.)) continue;
     for (int k = 1; k <= nz; k++) { h1[k - 1] = h_old_v[ORC_V3(G, i, J, k)]; h2[k - 1] = h_new_v[ORC_V3(G, i, J, k)]; src[k - 1] = v[ORC_V3(G, i, J, k)]; }
-    rc = orc_remapping_core_h(cs->remapping_scheme, cs->boundary_extrapolation, nz, h1, src, nz, h2, tgt, h_neglect, h_neglect_edge);
-    if (rc) break;
+    const int rc1 = orc_remapping_core_h(cs->remapping_scheme, cs->boundary_extrapolation, nz, h1, src, nz, h2, tgt, h_neglect, h_neglect_edge);
+    if (rc1) { rc = rc1; continue; }
     for (int k = 1; k <= nz; k++) v[ORC_V3(G, i, J, k)] = tgt[k - 1];
   }
-  free(h1); free(h2); free(src); free(tgt);
   return rc;
 }

@@ -596,23 +596,24 @@ int orc_ale_remap_tracers(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t 
   const int nz = G->nk;
   /* :770-771, answer_date >= 20190101 */
   const double h_neglect = G->H_subroundoff, h_neglect_edge = G->H_subroundoff;
-  double *h1 = calloc(nz, sizeof(double)), *h2 = calloc(nz, sizeof(double));
-  double *col = calloc(nz, sizeof(double)), *tr_column = calloc(nz, sizeof(double));
   int rc = 0;
   for (int m = 0; m < ntr && !rc; m++) {
-    for (int j = G->jsc; j <= G->jec && !rc; j++) for (int i = G->isc; i <= G->iec; i++) {
-      if (!(G->mask2dT[ORC_H2(G,i,j)] > 0.)) continue;
-      for (int k = 1; k <= nz; k++) {
-        h1[k-1] = h_old[ORC_H3(G,i,j,k)]; h2[k-1] = h_new[ORC_H3(G,i,j,k)]; col[k-1] = tr[m][ORC_H3(G,i,j,k)];
+    ORC_PAR      /* the columns are independent (the reference: !$OMP parallel do over j, MOM_ALE.F90:779) */
+    for (int j = G->jsc; j <= G->jec; j++) {
+      double h1[nz], h2[nz], col[nz], tr_column[nz];
+      for (int i = G->isc; i <= G->iec; i++) {
+        if (!(G->mask2dT[ORC_H2(G,i,j)] > 0.)) continue;
+        for (int k = 1; k <= nz; k++) {
+          h1[k-1] = h_old[ORC_H3(G,i,j,k)]; h2[k-1] = h_new[ORC_H3(G,i,j,k)]; col[k-1] = tr[m][ORC_H3(G,i,j,k)];
+        }
+        const int rc1 = orc_remapping_core_h(cs->remapping_scheme, cs->boundary_extrapolation, nz, h1, col, nz, h2, tr_column,
+                                             h_neglect, h_neglect_edge);
+        if (rc1) { rc = rc1; break; }      /* (an unknown scheme: the same for every column) */
+        if (conc_underflow && conc_underflow[m] > 0.0)
+          for (int k = 0; k < nz; k++) if (fabs(tr_column[k]) < conc_underflow[m]) tr_column[k] = 0.0;
+        for (int k = 1; k <= nz; k++) tr[m][ORC_H3(G,i,j,k)] = tr_column[k-1];
       }
-      rc = orc_remapping_core_h(cs->remapping_scheme, cs->boundary_extrapolation, nz, h1, col, nz, h2, tr_column,
-                                h_neglect, h_neglect_edge);
-      if (rc) break;
-      if (conc_underflow && conc_underflow[m] > 0.0)
-        for (int k = 0; k < nz; k++) if (fabs(tr_column[k]) < conc_underflow[m]) tr_column[k] = 0.0;
-      for (int k = 1; k <= nz; k++) tr[m][ORC_H3(G,i,j,k)] = tr_column[k-1];
     }
   }
-  free(h1); free(h2); free(col); free(tr_column);
   return rc;
 }

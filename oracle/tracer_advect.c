@@ -422,6 +422,7 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
   (void)IsdB; (void)IedB; (void)JsdB; (void)JedB;
 
   /* :152-178 (uhr, vhr, hprev already zero from calloc) */
+  ORC_PAR
   for (int k = 1; k <= nz; k++) {
     domore_k[k] = 1;
     for (int j = js; j <= je; j++) for (int I = is-1; I <= ie; I++)
@@ -469,6 +470,7 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
       isv = is-nsten_halo*stencil ; jsv = js-nsten_halo*stencil;
       iev = ie+nsten_halo*stencil ; jev = je+nsten_halo*stencil;
       if ((nsten_halo > 1) || (itt == 1)) {
+        ORC_PAR
         for (int k = 1; k <= nz; k++) if (domore_k[k] > 0) {
           for (int j = jsv; j <= jev; j++) if (!DU(&A,j,k)) {
             for (int i = isv+stencil-1; i <= iev-stencil; i++) if (A.uhr[ORC_U3(G,i,j,k)] != 0.0) {
@@ -491,8 +493,10 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
     jsv = jsv + stencil ; jev = jev - stencil;
 
     if (x_first) {
+      ORC_PAR_DYN      /* the layers are independent (the reference: !$OMP parallel do over k, :228-275) */
       for (int k = 1; k <= nz; k++) if (domore_k[k] > 0)
         advect_x(&A, isv, iev, jsv-stencil, jev+stencil, k);
+      ORC_PAR_DYN
       for (int k = 1; k <= nz; k++) if (domore_k[k] > 0) {
         advect_y(&A, isv, iev, jsv, jev, k);
         domore_k[k] = 0;
@@ -500,8 +504,10 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
         for (int J = jsv-1; J <= jev; J++) if (DV(&A,J,k)) domore_k[k] = 1;
       }
     } else {
+      ORC_PAR_DYN
       for (int k = 1; k <= nz; k++) if (domore_k[k] > 0)
         advect_y(&A, isv-stencil, iev+stencil, jsv, jev, k);
+      ORC_PAR_DYN
       for (int k = 1; k <= nz; k++) if (domore_k[k] > 0) {
         advect_x(&A, isv, iev, jsv, jev, k);
         domore_k[k] = 0;

@@ -152,11 +152,13 @@ int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const 
   if (CS->bottomdraglaw && !(visc->Kv_bbl_u && visc->Kv_bbl_v && visc->bbl_thick_u && visc->bbl_thick_v)) return 1;
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
   const long nih = ORC_NIH(G), njh = ORC_NJH(G), hpl = nih * njh, upl = (nih + 1) * njh, vpl = nih * (njh + 1);
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
     if (!(G->mask2dCu[ORC_U2(G, I, j)] > 0.0)) continue;
     coef_column(G, CS, visc, u, h, dz, ORC_H2(G, I, j), ORC_H2(G, I + 1, j), ORC_U2(G, I, j), hpl, upl, visc->Kv_bbl_u,
                 visc->bbl_thick_u, CS->a_u, CS->h_u);
   }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
     if (!(G->mask2dCv[ORC_V2(G, i, J)] > 0.0)) continue;
     coef_column(G, CS, visc, v, h, dz, ORC_H2(G, i, J), ORC_H2(G, i, J + 1), ORC_V2(G, i, J), hpl, vpl, visc->Kv_bbl_v,
@@ -194,14 +196,15 @@ int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, 
   const double dt_Rho0 = dt / CS->H_to_RZ, h_neglect = G->H_subroundoff;      /* :611-612 */
   double Hmix = 0.0, I_Hmix = 0.0;
   if (CS->direct_stress) { Hmix = CS->Hmix_stress; I_Hmix = 1.0 / Hmix; }       /* :607-610 */
-  double *c1 = (double *)malloc(sizeof(double) * (size_t)nz);
   for (int dir = 0; dir < 2; dir++) {
     double *x = dir ? v : u;
     const double *tau = dir ? tauy : taux, *mask = dir ? G->mask2dCv : G->mask2dCu, *a = dir ? CS->a_v : CS->a_u,
                  *hv = dir ? CS->h_v : CS->h_u, *Ray = dir ? visc->Ray_v : visc->Ray_u;
     double *tbot = dir ? tauy_bot : taux_bot;
     const long fpl = dir ? vpl : upl;
+    ORC_PAR      /* the columns are independent (the reference: !$OMP parallel do over j, :640) */
     for (int j = (dir ? js - 1 : js); j <= je; j++) for (int i = (dir ? is : is - 1); i <= ie; i++) {
+      double c1[nz];
       const long f2 = dir ? ORC_V2(G, i, j) : ORC_U2(G, i, j);
       const long c0 = ORC_H2(G, i, j), cc1 = dir ? ORC_H2(G, i, j + 1) : ORC_H2(G, i + 1, j);
       const int do_i = mask[f2] > 0.0;
@@ -230,7 +233,6 @@ int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, 
       }
     }
   }
-  free(c1);
   /* vertvisc_limit_vel :2259-2462 (no U_TRUNC_FILE / V_TRUNC_FILE) */
   {
     const double maxvel = CS->maxvel, truncvel = 0.9 * maxvel, H_report = 6.0 * G->Angstrom_H;
@@ -238,6 +240,8 @@ int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, 
       double *x = dir ? v : u;
       const double *dL = dir ? G->dx_Cv : G->dy_Cu;
       const long fpl = dir ? vpl : upl;
+      long ntr = 0;
+      _Pragma("omp parallel for schedule(static) reduction(+:ntr)")
       for (int k = 0; k < nz; k++) for (int j = (dir ? js - 1 : js); j <= je; j++) for (int i = (dir ? is : is - 1); i <= ie; i++) {
         const long f2 = dir ? ORC_V2(G, i, j) : ORC_U2(G, i, j), n = f2 + fpl * k;
         const long c0 = ORC_H2(G, i, j), cc1 = dir ? ORC_H2(G, i, j + 1) : ORC_H2(G, i + 1, j);
@@ -246,19 +250,20 @@ int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, 
           if (fabs(x[n]) < CS->vel_underflow) { x[n] = 0.0; }
           else if ((x[n] * (dt * dL[f2])) * G->IareaT[cc1] < -CS->CFL_trunc) {
             x[n] = (-0.9 * CS->CFL_trunc) * (G->areaT[cc1] / (dt * dL[f2]));
-            if (hsum > H_report) CS->ntrunc = CS->ntrunc + 1;
+            if (hsum > H_report) ntr = ntr + 1;
           } else if ((x[n] * (dt * dL[f2])) * G->IareaT[c0] > CS->CFL_trunc) {
             x[n] = (0.9 * CS->CFL_trunc) * (G->areaT[c0] / (dt * dL[f2]));
-            if (hsum > H_report) CS->ntrunc = CS->ntrunc + 1;
+            if (hsum > H_report) ntr = ntr + 1;
           }
         } else {
           if (fabs(x[n]) < CS->vel_underflow) { x[n] = 0.0; }
           else if (fabs(x[n]) > maxvel) {
             x[n] = copysign(truncvel, x[n]);
-            if (hsum > H_report) CS->ntrunc = CS->ntrunc + 1;
+            if (hsum > H_report) ntr = ntr + 1;
           }
         }
       }
+      CS->ntrunc = CS->ntrunc + ntr;
     }
   }
   return 0;
@@ -269,15 +274,17 @@ int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *C
   if (unsupported(CS)) return 1;
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const long nih = ORC_NIH(G), njh = ORC_NJH(G), upl = (nih + 1) * njh, vpl = nih * (njh + 1);
-  double *c1 = (double *)malloc(sizeof(double) * (size_t)nz);
+  ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
+    double c1[nz];
     const long f2 = ORC_U2(G, I, j);
     if (G->mask2dCu[f2] > 0.0) solve_column(nz, dt, CS->a_u, CS->h_u, visc->Ray_u, f2, upl, visc_rem_u, 0.0, 1, c1);
   }
+  ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
+    double c1[nz];
     const long f2 = ORC_V2(G, i, J);
     if (G->mask2dCv[f2] > 0.0) solve_column(nz, dt, CS->a_v, CS->h_v, visc->Ray_v, f2, vpl, visc_rem_v, 0.0, 1, c1);
   }
-  free(c1);
   return 0;
 }

@@ -259,7 +259,8 @@ def make_advection_inputs(g: Grid, h, seed=21, cfl=0.15, hot_frac=2.0e-4, hot_cf
         uh_w = np.roll(uh_e, 1, 2); vh_s = np.roll(vh_n, 1, 1)
         out = np.maximum(uh_e, 0.0) + np.maximum(-uh_w, 0.0) + np.maximum(vh_n, 0.0) + np.maximum(-vh_s, 0.0)
         inn = np.maximum(-uh_e, 0.0) + np.maximum(uh_w, 0.0) + np.maximum(-vh_n, 0.0) + np.maximum(vh_s, 0.0)
-        sc = np.minimum((0.8 * vol0 + inn) / np.maximum(out, 1e-300), 1.0)
+        with np.errstate(over="ignore"):
+            sc = np.minimum((0.8 * vol0 + inn) / np.maximum(out, 1e-300), 1.0)
         uh_e = np.where(uh_e >= 0, uh_e * sc, uh_e * np.roll(sc, -1, 2))
         vh_n = np.where(vh_n >= 0, vh_n * sc, vh_n * np.roll(sc, -1, 1))
     uh = np.concatenate([uh_e[:, :, -1:], uh_e], 2) * mCu[None]
