@@ -68,8 +68,8 @@ typedef struct mom6hip_grid {
   /* v-points */
   const double *mask2dCv, *dxCv, *dyCv, *dx_Cv, *IdxCv, *IdyCv, *areaCv, *IareaCv;
   /* q-points */
-  const double *mask2dBu, *dxBu, *dyBu, *areaBu, *IareaBu, *CoriolisBu;
-  const void *reserved2[8];
+  const double *mask2dBu, *dxBu, *dyBu, *areaBu, *IareaBu, *CoriolisBu, *IdxBu, *IdyBu;
+  const void *reserved2[6];
 } mom6hip_grid_t;
 
 /* Opaque handle: device copies of the metrics + scratch owned by the library. */
@@ -545,6 +545,115 @@ int mom6hip_vertvisc_ntrunc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs);
 int mom6hip_vertvisc_remnant(mom6hip_ctx_t *ctx, const mom6hip_vertvisc_cs_t *cs, const mom6hip_vertvisc_type_t *visc,
                              double *visc_rem_u, double *visc_rem_v, double dt, int32_t memspace);
 
+/* ---- MOM_set_viscosity ------------------------------------------------------------------------ */
+
+/*
+ * set_visc_CS, src/parameterizations/vertical/MOM_set_viscosity.F90:48-130, as set by set_visc_init (:2886-3190): the
+ * parameters set_viscous_BBL's provided branch reads (defaults in brackets).
+ * Provided: BOTTOMDRAGLAW with the quadratic or LINEAR_DRAG law, DRAG_BG_VEL, BBL_USE_EOS (Wright / linear equation of
+ * state) or the layer target densities GV%Rlay, BBL_THICK_MIN, KV_BBL_MIN, CORRECT_BBL_BOUNDS, DRAG_AS_BODY_FORCE, the
+ * kappa-shear cap of the layer thickness (RiNo_mix).  Not provided (refused by name): CHANNEL_DRAG, BBL_USE_TIDAL_BG,
+ * a bulk mixed layer (nkml > 0), non-Boussinesq mode (tv%SpV_avg), tv%p_surf, OBC, porous barriers.
+ * set_viscous_ML (:1898) does nothing unless DYNAMIC_VISCOUS_ML or an ice shelf is present (:2043-2044); both are refused,
+ * so mom6hip_set_viscous_ML returns at once like the reference.
+ */
+typedef struct mom6hip_set_visc_cs {
+  double cdrag;            /* CDRAG (0.003) */
+  double drag_bg_vel;      /* DRAG_BG_VEL [L T-1] (0) */
+  double Hbbl;             /* HBBL in thickness units [H] (:3127) */
+  double dz_bbl;           /* HBBL [Z] */
+  double BBL_thick_min;    /* BBL_THICK_MIN [Z] (0) */
+  double Kv_BBL_min;       /* KV_BBL_MIN [H Z T-1] (KV) */
+  double BBL_thick_max;    /* G%Rad_Earth_L*US%L_to_Z [Z] (6.378e6) */
+  double H_to_RZ;          /* GV%H_to_RZ */
+  double reserved0[8];
+  int32_t bottomdraglaw;   /* BOTTOMDRAGLAW (1): without it set_viscous_BBL returns at once (:321) */
+  int32_t linear_drag;     /* LINEAR_DRAG (0) */
+  int32_t BBL_use_EOS;     /* BBL_USE_EOS (= USE_EOS) */
+  int32_t correct_BBL_bounds; /* CORRECT_BBL_BOUNDS (0) */
+  int32_t body_force_drag; /* DRAG_AS_BODY_FORCE (0): needs visc%Ray_u / %Ray_v */
+  int32_t RiNo_mix;        /* kappa_shear_is_used (0) */
+  int32_t initialized;
+  int32_t unsupported[9];  /* Channel_drag, BBL_use_tidal_bg, dynamic_viscous_ML, nkml, non_Boussinesq, p_surf, OBC, pbv, ice_shelf:
+                              any nonzero is refused */
+  const double *Rlay;      /* GV%Rlay(1:nk) [R] (HOST array), read when BBL_use_EOS = 0 */
+  void *reserved1[3];
+} mom6hip_set_visc_cs_t;
+
+/* set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)                                   MOM_set_viscosity.F90:134
+ * tv%T, tv%S and tv%eqn_of_state are passed as T, S, eos (may be NULL when BBL_use_EOS = 0).  Sets visc%bbl_thick_u/v,
+ * visc%Kv_bbl_u/v on the ocean faces of the compute domain (I = IscB..IecB, j = jsc..jec; i = isc..iec, J = JscB..JecB)
+ * and, when they are present, zeroes visc%Ray_u/v (:416-417) and adds the body-force drag.  The members of `visc` this
+ * call writes are declared const in mom6hip_vertvisc_type_t because vertvisc only reads them. */
+int mom6hip_set_viscous_BBL(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+                            const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
+                            const mom6hip_vertvisc_type_t *visc, int32_t memspace);
+
+/* set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)                                                :1898
+ * returns at once unless DYNAMIC_VISCOUS_ML (refused by mom6hip_vertvisc_* as well) or an ice shelf is present. */
+int mom6hip_set_viscous_ML(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs);
+
+/* ---- MOM_hor_visc ----------------------------------------------------------------------------- */
+
+/*
+ * hor_visc_CS, src/parameterizations/lateral/MOM_hor_visc.F90:40-243, as set by hor_visc_init (:1984-2876): the
+ * parameters the provided branch reads (defaults in brackets) and the static 2-D arrays hor_visc_init computes.
+ * Provided: LAPLACIAN (KH, KH_VEL_SCALE, KH_BG_MIN, SMAGORINSKY_KH + SMAG_LAP_CONST, ADD_LES_VISCOSITY, BOUND_KH,
+ * BETTER_BOUND_KH), BIHARMONIC (AH, AH_VEL_SCALE, AH_TIME_SCALE, SMAGORINSKY_AH + SMAG_BI_CONST, BOUND_CORIOLIS_BIHARM,
+ * BOUND_AH, BETTER_BOUND_AH), NOSLIP, USE_LAND_MASK_FOR_HVISC, HORVISC_BOUND_COEF, USE_CONT_THICKNESS.
+ * Not provided (refused by name): LEITH_KH / LEITH_AH / USE_LEITHY and their options, USE_MEKE, USE_GME,
+ * ANISOTROPIC_VISCOSITY, RE_AH, KH_SIN_LAT, USE_KH_BG_2D, ZB2020, resolution-scaled viscosities (VarMix), OBC, the
+ * FrictWork diagnostics, HOR_VISC_ANSWER_DATE < 20190101.
+ * The arrays are caller-owned (h-point arrays *_xx, q-point arrays *_xy) and filled by mom6hip_hor_visc_init.
+ */
+typedef struct mom6hip_hor_visc_cs {
+  double Kh;               /* KH [L2 T-1] (0) */
+  double Kh_bg_min;        /* KH_BG_MIN (0) */
+  double Kh_vel_scale;     /* KH_VEL_SCALE [L T-1] (0) */
+  double Smag_Lap_const;   /* SMAG_LAP_CONST (0) */
+  double Ah;               /* AH [L4 T-1] (0) */
+  double Ah_vel_scale;     /* AH_VEL_SCALE [L T-1] (0) */
+  double Ah_time_scale;    /* AH_TIME_SCALE [T] (0) */
+  double Smag_bi_const;    /* SMAG_BI_CONST (0) */
+  double bound_Cor_vel;    /* BOUND_CORIOLIS_VEL [L T-1] (MAXVEL) */
+  double bound_coef;       /* HORVISC_BOUND_COEF (0.8) */
+  double reserved0[6];
+  int32_t Laplacian;       /* LAPLACIAN (0) */
+  int32_t biharmonic;      /* BIHARMONIC (1) */
+  int32_t Smagorinsky_Kh;  /* SMAGORINSKY_KH (0) */
+  int32_t Smagorinsky_Ah;  /* SMAGORINSKY_AH (0) */
+  int32_t bound_Kh;        /* BOUND_KH (1) */
+  int32_t better_bound_Kh; /* BETTER_BOUND_KH (= BOUND_KH) */
+  int32_t bound_Ah;        /* BOUND_AH (1) */
+  int32_t better_bound_Ah; /* BETTER_BOUND_AH (= BOUND_AH) */
+  int32_t bound_Coriolis;  /* BOUND_CORIOLIS_BIHARM (= BOUND_CORIOLIS) */
+  int32_t add_LES_viscosity; /* ADD_LES_VISCOSITY (0) */
+  int32_t no_slip;         /* NOSLIP (0) */
+  int32_t use_land_mask;   /* USE_LAND_MASK_FOR_HVISC (1) */
+  int32_t use_cont_thick;  /* USE_CONT_THICKNESS (0) */
+  int32_t initialized;     /* set by mom6hip_hor_visc_init */
+  int32_t unsupported[10]; /* Leith_Kh, Leith_Ah, use_Leithy, use_MEKE, use_GME, anisotropic, Re_Ah, Kh_sin_lat, use_Kh_bg_2d,
+                              use_ZB2020: any nonzero is refused */
+  /* h points */
+  double *Kh_bg_xx, *Kh_Max_xx, *Ah_bg_xx, *Ah_Max_xx, *Laplac2_const_xx, *Biharm_const_xx, *Biharm_const2_xx, *reduction_xx;
+  /* q points */
+  double *Kh_bg_xy, *Kh_Max_xy, *Ah_bg_xy, *Ah_Max_xy, *Laplac2_const_xy, *Biharm_const_xy, *Biharm_const2_xy, *reduction_xy;
+  void *reserved1[4];
+} mom6hip_hor_visc_cs_t;
+
+/* The computational part of hor_visc_init (:2440-2760): the static arrays of the control structure from the grid metrics
+ * and dt (the baroclinic time step, for the stability bounds). */
+int mom6hip_hor_visc_init(mom6hip_ctx_t *ctx, mom6hip_hor_visc_cs_t *cs, double dt, int32_t memspace);
+
+/* horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, CS, tv, dt, OBC, BT, TD, ADp, hu_cont, hv_cont,
+ *                      STOCH)                                     src/parameterizations/lateral/MOM_hor_visc.F90:245
+ * MEKE, VarMix, OBC, BT, TD, ADp, STOCH belong to branches that are not provided.  hu_cont / hv_cont may be NULL (they
+ * are read only with USE_CONT_THICKNESS).  diffu is written for I = IscB..IecB, j = jsc..jec, diffv for i = isc..iec,
+ * J = JscB..JecB; u, v need valid halos of width 2, h of width 2 (hor_visc_vel_stencil :2879). */
+int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,
+                                 const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
+                                 const double *hv_cont, int32_t memspace);
+
 /* ---- MOM_dynamics_split_RK2 ------------------------------------------------------------------ */
 
 /*
@@ -587,7 +696,7 @@ typedef struct mom6hip_dyn_split_rk2_cs {
   const mom6hip_visc_hooks_t *hooks;          /* NULL: no host-side parameterisations */
   mom6hip_vertvisc_cs_t *vertvisc_CSp;        /* NULL: no vertical viscosity from this library (its arrays are DEVICE arrays) */
   const mom6hip_vertvisc_type_t *visc;        /* the visc argument of the step (DEVICE arrays); needed with vertvisc_CSp */
-  const void *reserved1[1];
+  const mom6hip_hor_visc_cs_t *hor_visc;      /* NULL: no horizontal viscosity from this library (diffu = diffv = 0, or the hook) */
   /* 3-D */
   double *CAu, *CAv, *CAu_pred, *CAv_pred, *PFu, *PFv, *diffu, *diffv, *visc_rem_u, *visc_rem_v, *u_accel_bt,
       *v_accel_bt, *u_av, *v_av, *h_av, *pbce;

@@ -16,7 +16,7 @@ _dp = C.POINTER(C.c_double)
 H_METRICS = ("mask2dT", "areaT", "IareaT", "dxT", "dyT", "IdxT", "IdyT", "bathyT")
 U_METRICS = ("mask2dCu", "dxCu", "dyCu", "dy_Cu", "IdxCu", "IdyCu", "areaCu", "IareaCu")
 V_METRICS = ("mask2dCv", "dxCv", "dyCv", "dx_Cv", "IdxCv", "IdyCv", "areaCv", "IareaCv")
-Q_METRICS = ("mask2dBu", "dxBu", "dyBu", "areaBu", "IareaBu", "CoriolisBu")
+Q_METRICS = ("mask2dBu", "dxBu", "dyBu", "areaBu", "IareaBu", "CoriolisBu", "IdxBu", "IdyBu")
 ALL_METRICS = H_METRICS + U_METRICS + V_METRICS + Q_METRICS
 
 
@@ -29,7 +29,7 @@ class GridStruct(C.Structure):
                                      "Z_to_H", "g_Earth", "Rho0")]
         + [("reserved1", C.c_double * 8)]
         + [(n, _dp) for n in ALL_METRICS]
-        + [("reserved2", C.c_void_p * 8)]
+        + [("reserved2", C.c_void_p * 6)]
     )
 
 
@@ -113,6 +113,40 @@ class BarotropicCS(C.Structure):
                 + [("reserved2", C.c_void_p * 6)])
 
 
+# ---- MOM_set_viscosity ------------------------------------------------------------------------------------
+SET_VISC_UNSUPPORTED = ("Channel_drag", "BBL_use_tidal_bg", "dynamic_viscous_ML", "nkml", "non_Boussinesq", "p_surf", "OBC", "pbv", "ice_shelf")
+
+
+class SetViscCS(C.Structure):
+    """mom6hip_set_visc_cs_t (include/mom6hip.h)."""
+    _fields_ = ([(n, C.c_double) for n in ("cdrag", "drag_bg_vel", "Hbbl", "dz_bbl", "BBL_thick_min", "Kv_BBL_min", "BBL_thick_max", "H_to_RZ")]
+                + [("reserved0", C.c_double * 8)]
+                + [(n, C.c_int32) for n in ("bottomdraglaw", "linear_drag", "BBL_use_EOS", "correct_BBL_bounds", "body_force_drag", "RiNo_mix",
+                                           "initialized")]
+                + [("unsupported", C.c_int32 * 9)]
+                + [("Rlay", C.c_void_p), ("reserved1", C.c_void_p * 3)])
+
+
+# ---- MOM_hor_visc -----------------------------------------------------------------------------------------
+HOR_VISC_UNSUPPORTED = ("Leith_Kh", "Leith_Ah", "use_Leithy", "use_MEKE", "use_GME", "anisotropic", "Re_Ah", "Kh_sin_lat", "use_Kh_bg_2d",
+                        "use_ZB2020")
+HOR_VISC_ARRAYS_H = ("Kh_bg_xx", "Kh_Max_xx", "Ah_bg_xx", "Ah_Max_xx", "Laplac2_const_xx", "Biharm_const_xx", "Biharm_const2_xx", "reduction_xx")
+HOR_VISC_ARRAYS_Q = ("Kh_bg_xy", "Kh_Max_xy", "Ah_bg_xy", "Ah_Max_xy", "Laplac2_const_xy", "Biharm_const_xy", "Biharm_const2_xy", "reduction_xy")
+
+
+class HorViscCS(C.Structure):
+    """mom6hip_hor_visc_cs_t (include/mom6hip.h)."""
+    _fields_ = ([(n, C.c_double) for n in ("Kh", "Kh_bg_min", "Kh_vel_scale", "Smag_Lap_const", "Ah", "Ah_vel_scale", "Ah_time_scale",
+                                           "Smag_bi_const", "bound_Cor_vel", "bound_coef")]
+                + [("reserved0", C.c_double * 6)]
+                + [(n, C.c_int32) for n in ("Laplacian", "biharmonic", "Smagorinsky_Kh", "Smagorinsky_Ah", "bound_Kh", "better_bound_Kh",
+                                           "bound_Ah", "better_bound_Ah", "bound_Coriolis", "add_LES_viscosity", "no_slip", "use_land_mask",
+                                           "use_cont_thick", "initialized")]
+                + [("unsupported", C.c_int32 * 10)]
+                + [(n, C.c_void_p) for n in HOR_VISC_ARRAYS_H + HOR_VISC_ARRAYS_Q]
+                + [("reserved1", C.c_void_p * 4)])
+
+
 # ---- MOM_dynamics_split_RK2 -----------------------------------------------------------------------------
 RK2_ARRAYS_3D = (("CAu", POS_U), ("CAv", POS_V), ("CAu_pred", POS_U), ("CAv_pred", POS_V), ("PFu", POS_U), ("PFv", POS_V),
                  ("diffu", POS_U), ("diffv", POS_V), ("visc_rem_u", POS_U), ("visc_rem_v", POS_V), ("u_accel_bt", POS_U),
@@ -126,7 +160,7 @@ class DynSplitRK2CS(C.Structure):
                  ("CAu_pred_stored", C.c_int32), ("split_bottom_stress", C.c_int32), ("reserved0", C.c_int32 * 4),
                  ("continuity_CSp", C.c_void_p), ("CoriolisAdv", C.c_void_p), ("PressureForce_CSp", C.c_void_p),
                  ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
-                 ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("reserved1", C.c_void_p * 1)]
+                 ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("hor_visc", C.c_void_p)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
                 + [("reserved2", C.c_void_p * 4)])
 

@@ -47,7 +47,7 @@ struct GridDev {
   const double *mask2dT, *areaT, *IareaT, *dxT, *dyT, *IdxT, *IdyT, *bathyT;
   const double *mask2dCu, *dxCu, *dyCu, *dy_Cu, *IdxCu, *IdyCu, *areaCu, *IareaCu;
   const double *mask2dCv, *dxCv, *dyCv, *dx_Cv, *IdxCv, *IdyCv, *areaCv, *IareaCv;
-  const double *mask2dBu, *dxBu, *dyBu, *areaBu, *IareaBu, *CoriolisBu;
+  const double *mask2dBu, *dxBu, *dyBu, *areaBu, *IareaBu, *CoriolisBu, *IdxBu, *IdyBu;
   const double *uh_neglect, *vh_neglect;   // derived: MOM_tracer_advect.F90:182-188
   // linear offsets, Fortran indices, k zero-based
   __host__ __device__ inline long h2(int i, int j) const { return (long)(i - isd) + (long)nih * (j - jsd); }
@@ -90,6 +90,8 @@ struct mom6hip_ctx {
   m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   m6::DevBuf rk2_scratch;       // the automatic arrays of step_MOM_dyn_split_RK2
+  m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
+  m6::DevBuf hv_scratch;        // the work arrays of horizontal_viscosity (hor_visc.hip)
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
   std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)
@@ -132,6 +134,15 @@ struct KTimer {
     c->kt_events[slot].push_back({e0, e1});
   }
 };
+
+// horizontal_viscosity on device arrays (hor_visc.hip); called by the split RK2 step at :860 and :1543
+int horizontal_viscosity_dev(mom6hip_ctx *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,
+                             double *diffu, double *diffv, const double *hu_cont, const double *hv_cont);
+
+// set_viscous_BBL on device arrays (set_viscosity.hip)
+int set_viscous_BBL_dev(mom6hip_ctx *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
+                        const double *T, const double *S, const mom6hip_eos_t *eos, double *bbl_thick_u, double *bbl_thick_v,
+                        double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v);
 
 class Stager {
  public:

@@ -220,10 +220,10 @@ int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t 
   const int nih = grid->ied - grid->isd + 1, njh = grid->jed - grid->jsd + 1;
   const size_t nH = (size_t)nih * njh, nU = (size_t)(nih + 1) * njh, nV = (size_t)nih * (njh + 1),
                nQ = (size_t)(nih + 1) * (njh + 1);
-  // pointer members in declaration order: 8 h, 8 u, 8 v, 6 q
+  // pointer members in declaration order: 8 h, 8 u, 8 v, 8 q
   const double *const *src = &grid->mask2dT;
   int rc = 0;
-  for (int m = 0; m < 30 && rc == 0; m++) {
+  for (int m = 0; m < 32 && rc == 0; m++) {
     size_t n = m < 8 ? nH : (m < 16 ? nU : (m < 24 ? nV : nQ));
     rc = upload2d(ctx, src[m], n, &ctx->d_metric[m]);
   }
@@ -239,7 +239,7 @@ int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t 
   {
     // same declaration order in mom6hip_grid_t and GridDev
     const double **dst = &g.mask2dT;
-    for (int m = 0; m < 30; m++) dst[m] = ctx->d_metric[m];
+    for (int m = 0; m < 32; m++) dst[m] = ctx->d_metric[m];
   }
 
   // uh_neglect / vh_neglect, src/tracer/MOM_tracer_advect.F90:182-188 (a property of the grid)
@@ -275,6 +275,8 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->tr_stage) b.release();
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
+  ctx->hv_scratch.release();
+  ctx->sv_rlay.release();
   ctx->ale_sub.release();
   ctx->vv_ntrunc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);

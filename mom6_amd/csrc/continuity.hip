@@ -203,7 +203,6 @@ struct FluxArgs {
   int set_BT_cont;
   double dt;
   int fi0, fi1, fj0, fj1;    // face index ranges: zonal (I = ish-1..ieh, j = jsh..jeh); meridional (i, J)
-  int dbg;                   // MOM6HIP_CONT_DBG: timing experiments only (results are wrong when nonzero)
 };
 
 // flux_layer :896-972 for one face; o = offset of the minus-side cell in the h-point arrays
@@ -506,23 +505,12 @@ __device__ __forceinline__ double flux_reg(const FaceConst &F, double u, double 
 // The k-ordered sums of the layer values the waves left in the LDS planes 0 .. nsum-1, each started from its init value:
 // half-wave q < nsum adds plane q; every thread gets all results.
 __device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int fl, int sb, int nz, int nsum, double i0, double i1,
-                                      double i2, double &r0, double &r1, double &r2, int dbg = 0) {
+                                      double i2, double &r0, double &r1, double &r2) {
   __syncthreads();
   if (sb < nsum) {
     double acc = (sb == 0) ? i0 : ((sb == 1) ? i1 : i2);
     const int base = sb * plane + fl;
-    const int nzz = (dbg & 1) ? 1 : nz;
-    // batches of KB values are fetched before they are added: the chain of additions is serial (the reference's order),
-    // the LDS reads behind it are not (one exposed LDS round trip per layer was most of a pass)
-    constexpr int KB = 16;
-    for (int kb = 0; kb < nzz; kb += KB) {
-      double v[KB];
-#pragma unroll
-      for (int q = 0; q < KB; q++) v[q] = fsm[base + min(kb + q, nzz - 1) * FC_FL];
-#pragma unroll
-      for (int q = 0; q < KB; q++)
-        if (kb + q < nzz) acc = acc + v[q];
-    }
+    for (int k = 0; k < nz; k++) acc = acc + fsm[base + k * FC_FL];
     fsm[roff + sb * FC_FL + fl] = acc;
   }
   __syncthreads();
@@ -584,8 +572,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
       const double *hh = p.h_in + o3;
       const double hm1 = hh[-s], hc0 = hh[0], hp1 = hh[s], hp2 = hh[2 * s];
       double Lm, Rm, Lp, Rp;
-      if (p.dbg & 8) { Lm = hc0; Rm = hm1; Lp = hp1; Rp = hp2; }
-      else if (DIR == 0) {
+      if (DIR == 0) {
         if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; }
         else edge_values(p.o, g.Angstrom_H, wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
                          wide ? mk[4] : 0.0, Lm, Rm);
@@ -769,8 +756,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
           }
         }
         double usum, dsum, d2;
-        ksums(fsm, PL, RO, fl, sb, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2, p.dbg);
-        if (p.dbg & 2) alive = false;
+        ksums(fsm, PL, RO, fl, sb, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2);
         if (alive && itt < max_itts) {
           uh_err = usum; duhdu_tot = dsum;
           uh_err_best = min2(uh_err_best, fabs(uh_err));
@@ -801,7 +787,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     }
     if (sb == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
   }
-  if (!p.set_BT_cont || (p.dbg & 4)) return;
+  if (!p.set_BT_cont) return;
 
   // ---- set_zonal_BT_cont :1247-1410
   const double min_visc_rem = 0.1, CFL_min = 1e-6;
@@ -817,23 +803,11 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     const double vrm_bt = fsm[CO + 4 * FC_FL + fl];
     const double c = isL ? -du_CFL : du_CFL;      // duR: du0 - du_CFL, test "> -du_CFL*vr";  duL: du0 + du_CFL, test "< du_CFL*vr"
     double dlim = isL ? max2(0.0, du0 - c) : min2(0.0, du0 - c);
-    constexpr int KB = 8;      // (reads fetched in batches ahead of the serial chain, as in ksums)
-    for (int kb = 0; kb < nz; kb += KB) {
-      double vv[KB], uu[KB];
-#pragma unroll
-      for (int q = 0; q < KB; q++) {
-        const int k = min(kb + q, nz - 1);
-        vv[q] = fsm[PL + k * FC_FL + fl]; uu[q] = fsm[k * FC_FL + fl];
-      }
-#pragma unroll
-      for (int q = 0; q < KB; q++) {
-        if (kb + q < nz) {
-          const double vr = vv[q], uk = uu[q];
-          const double visc_rem_lim = max2(vr, min_visc_rem * vrm_bt);
-          const double t = uk + dlim * visc_rem_lim, r = -c * vr;
-          if ((visc_rem_lim > 0.0) && (isL ? (t < r) : (t > r))) dlim = -(uk + c * vr) / visc_rem_lim;
-        }
-      }
+    for (int k = 0; k < nz; k++) {
+      const double vr = fsm[PL + k * FC_FL + fl], uk = fsm[k * FC_FL + fl];
+      const double visc_rem_lim = max2(vr, min_visc_rem * vrm_bt);
+      const double t = uk + dlim * visc_rem_lim, r = -c * vr;
+      if ((visc_rem_lim > 0.0) && (isL ? (t < r) : (t > r))) dlim = -(uk + c * vr) / visc_rem_lim;
     }
     fsm[RO + sb * FC_FL + fl] = dlim;
   }
@@ -915,8 +889,6 @@ template <int DIR>
 int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) {
   const int nk = f.g.nk;
   dim3 grid((n_along + 63) / 64, n_rows);
-  static const int dbg = [] { const char *e = getenv("MOM6HIP_CONT_DBG"); return e ? atoi(e) : 0; }();
-  const_cast<FluxArgs &>(f).dbg = dbg;
   if (flux_is_coop(f)) {
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {

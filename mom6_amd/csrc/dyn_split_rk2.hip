@@ -85,7 +85,11 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     });
   }
   M6_HIP(hipMemsetAsync(cs->diffu, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(cs->diffv, 0, sz.v3, s));
-  if (cs->hooks && cs->hooks->horizontal_viscosity) {   // :1543-1550
+  if (cs->hor_visc) {   // :1543-1550
+    const mom6hip_bt_cont_t *B = cs->BT_cont;
+    M6_REQUIRE(cs->hor_visc->initialized, "MOM_hor_visc: Module must be initialized before it is used.");
+    if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u, v, h, cs->diffu, cs->diffv, B ? B->h_u : nullptr, B ? B->h_v : nullptr)) return 1;
+  } else if (cs->hooks && cs->hooks->horizontal_viscosity) {
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(cs->hooks->horizontal_viscosity(cs->hooks->user, u, v, h, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
   }
@@ -169,7 +173,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   // u_bc_accel = (CAu_pred + PFu) + diffu ; up = mask*(u + dt*u_bc_accel)   :557-564, :582-589
   // Without viscosity hooks diffu = diffv = +0.0 everywhere (set by dyn_split_rk2_init): (a + 0.0) is a, except that
   // -0.0 + 0.0 = +0.0, so the array need not be read; and the first up, vp (:582-589) are only read by vertvisc_coef.
-  const bool inviscid = (hk == nullptr);      // diffu = diffv = 0
+  const bool inviscid = (hk == nullptr) && (cs->hor_visc == nullptr);      // diffu = diffv = 0
   auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
     const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
     const bool need_up = first_up && (!inviscid || VV);
@@ -240,7 +244,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   });
   CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :797
   if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :843
-  if (hk && hk->horizontal_viscosity) {   // :860
+  if (cs->hor_visc) {   // :860 (hu_cont, hv_cont = BT_cont%h_u, %h_v: read only with USE_CONT_THICKNESS)
+    if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, BTC ? BTC->h_u : nullptr,
+                                     BTC ? BTC->h_v : nullptr)) return 1;
+  } else if (hk && hk->horizontal_viscosity) {
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->horizontal_viscosity(hk->user, u_av, v_av, h_av, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
   }

@@ -1,0 +1,338 @@
+// set_viscosity.hip -- set_viscous_BBL (and the early return of set_viscous_ML) of
+// src/parameterizations/vertical/MOM_set_viscosity.F90 (:134-1100, :1898-2044) as a gfx950 kernel.
+//
+// The bottom-boundary-layer thickness and viscosity of a velocity column come from three sweeps through its layers: the
+// pressure at the bottom (top down, for the density derivatives), the thickness-weighted speed within HBBL of the bottom
+// (bottom up, usually a few layers: every term needs the transverse velocity averaged from four neighbours,
+// set_v_at_u / set_u_at_v), and the height to which the turbulent energy 400 u*^2 can mix the stratification (bottom up,
+// stops where it is used up).  One lane per face column, lanes along i; the reference's per-row work arrays h_at_vel,
+// dz_at_vel, T_vel, S_vel are re-formed from h, T, S where they are read (no per-lane arrays).
+// Algorithmic traffic: read u or v, h, T, S at both cells (mostly the bottom layers), write two 2-D fields.
+#include <cmath>
+
+#include "common.hpp"
+#include "eos.hpp"
+
+namespace {
+
+using m6::max2;
+using m6::min2;
+using namespace m6::eos;
+
+struct BBLArgs {
+  m6::GridDev g;
+  EosDev E;
+  double cdrag, drag_bg_vel, Hbbl, dz_bbl, BBL_thick_min, Kv_BBL_min, BBL_thick_max, H_to_RZ;
+  int linear_drag, use_BBL_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix;
+  const double *u, *v, *h, *T, *S, *Rlay;      // Rlay: device copy of GV%Rlay
+  double *bbl_thick, *Kv_bbl, *Ray;            // of this direction
+};
+
+// set_v_at_u :1804-1846 / set_u_at_v :1849-1891 (no OBC): the transverse velocity at the face (i, j) of layer k
+template <int DIR>
+__device__ __forceinline__ double transverse_vel(const BBLArgs &A, int i, int j, long kH, long kU, long kV) {
+  const m6::GridDev &g = A.g;
+  if (DIR == 0) {      // v at the u point (I = i, j)
+    const int J = j;
+    double hwt[2][2];
+#pragma unroll
+    for (int j0 = -1; j0 <= 0; j0++)
+#pragma unroll
+      for (int i0 = 0; i0 <= 1; i0++) {
+        const int i1 = i + i0, J1 = J + j0;
+        hwt[i0][j0 + 1] = (A.h[g.h2(i1, J1) + kH] + A.h[g.h2(i1, J1 + 1) + kH]) * g.mask2dCv[g.v2(i1, J1)];
+      }
+    const double hwt_tot = (hwt[0][0] + hwt[1][1]) + (hwt[1][0] + hwt[0][1]);
+    double r = 0.0;
+    if (hwt_tot > 0.0)
+      r = ((hwt[0][1] * A.v[g.v2(i, J) + kV] + hwt[1][0] * A.v[g.v2(i + 1, J - 1) + kV]) +
+           (hwt[1][1] * A.v[g.v2(i + 1, J) + kV] + hwt[0][0] * A.v[g.v2(i, J - 1) + kV])) / hwt_tot;
+    return r;
+  } else {      // u at the v point (i, J = j)
+    const int I = i;
+    double hwt[2][2];
+#pragma unroll
+    for (int j0 = 0; j0 <= 1; j0++)
+#pragma unroll
+      for (int i0 = -1; i0 <= 0; i0++) {
+        const int I1 = I + i0, j1 = j + j0;
+        hwt[i0 + 1][j0] = (A.h[g.h2(I1, j1) + kH] + A.h[g.h2(I1 + 1, j1) + kH]) * g.mask2dCu[g.u2(I1, j1)];
+      }
+    const double hwt_tot = (hwt[0][0] + hwt[1][1]) + (hwt[1][0] + hwt[0][1]);
+    double r = 0.0;
+    if (hwt_tot > 0.0)
+      r = ((hwt[1][0] * A.u[g.u2(I, j) + kU] + hwt[0][1] * A.u[g.u2(I - 1, j + 1) + kU]) +
+           (hwt[0][0] * A.u[g.u2(I - 1, j) + kU] + hwt[1][1] * A.u[g.u2(I, j + 1) + kU])) / hwt_tot;
+    return r;
+  }
+}
+
+template <int DIR>
+__global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  if (!((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0)) return;      // do_i
+  const int nz = g.nk;
+  const long hpl = (long)g.nih * g.njh, upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1);
+  const long fpl = DIR ? vpl : upl;
+  const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  const double *vel = DIR ? A.v : A.u;
+  const double h_neglect = g.H_subroundoff, dz_neglect = g.dZ_subroundoff;
+  const double Rho0x400_G = 400.0 * (A.H_to_RZ / (1.0 * 1.0 * g.g_Earth));
+  const double cdrag_sqrt = sqrt(A.cdrag);
+  const double cdrag_sqrt_H = cdrag_sqrt * 1.0 * g.Z_to_H;
+  const double cdrag_L_to_H = A.cdrag * 1.0 * g.Z_to_H;
+  const bool use_EOS = A.use_BBL_EOS;
+
+  // h_at_vel(k), dz_at_vel(k) :431-470 for the zero-based layer k (dz = GV%H_to_Z*h: Boussinesq thickness_to_dz)
+  auto at_vel = [&](int k, double &hat, double &dzat) {
+    const double h0 = A.h[c0 + hpl * k], h1 = A.h[c1 + hpl * k];
+    const double d0 = g.H_to_Z * h0, d1 = g.H_to_Z * h1;
+    if (vel[f2 + fpl * k] * (h1 - h0) >= 0) {
+      hat = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);
+      dzat = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+    } else {
+      hat = 0.5 * (h0 + h1);
+      dzat = 0.5 * (d0 + d1);
+    }
+  };
+  auto T_vel = [&](int k) { return 0.5 * (A.T[c0 + hpl * k] + A.T[c1 + hpl * k]); };
+  auto S_vel = [&](int k) { return 0.5 * (A.S[c0 + hpl * k] + A.S[c1 + hpl * k]); };
+
+  // ---- the near-bottom velocity magnitude and ustar :565-660
+  double ustar, umag_avg = 0.0, h_bbl_drag = 0.0, dz_bbl_drag = 0.0, T_EOS = 0.0, S_EOS = 0.0;
+  if (use_EOS || A.body_force_drag || !A.linear_drag) {
+    double htot_vel = 0.0, hwtot = 0.0, hutot = 0.0, dztot_vel = 0.0, dzwtot = 0.0, Thtot = 0.0, Shtot = 0.0;
+    const double u2_bg = A.drag_bg_vel * A.drag_bg_vel;
+    for (int k = nz - 1; k >= 0; k--) {
+      if (htot_vel >= A.Hbbl) break;
+      double hat, dzat;
+      at_vel(k, hat, dzat);
+      const double hweight = min2(A.Hbbl - htot_vel, hat);
+      if (hweight < 1.5 * g.Angstrom_H + h_neglect) continue;
+      const double dzweight = min2(A.dz_bbl - dztot_vel, dzat);
+      htot_vel = htot_vel + hat;
+      hwtot = hwtot + hweight;
+      dztot_vel = dztot_vel + dzat;
+      dzwtot = dzwtot + dzweight;
+      if ((!A.linear_drag) && (hweight >= 0.0)) {
+        const double vt = transverse_vel<DIR>(A, i, j, hpl * k, upl * k, vpl * k);
+        const double vn = vel[f2 + fpl * k];
+        hutot = hutot + hweight * sqrt(vn * vn + vt * vt + u2_bg);
+      }
+      if (use_EOS && (hweight >= 0.0)) {
+        Thtot = Thtot + hweight * T_vel(k);
+        Shtot = Shtot + hweight * S_vel(k);
+      }
+    }
+    double I_hwtot = 0.0; if (hwtot > 0.0) I_hwtot = 1.0 / hwtot;
+    if ((hwtot <= 0.0) || A.linear_drag) ustar = cdrag_sqrt_H * A.drag_bg_vel;
+    else ustar = cdrag_sqrt_H * hutot / hwtot;
+    umag_avg = hutot * I_hwtot;
+    h_bbl_drag = hwtot;
+    dz_bbl_drag = dzwtot;
+    if (use_EOS) {
+      if (hwtot > 0.0) { T_EOS = Thtot / hwtot; S_EOS = Shtot / hwtot; }
+      else { T_EOS = 0.0; S_EOS = 0.0; }
+    }
+  } else {
+    ustar = cdrag_sqrt_H * A.drag_bg_vel;
+  }
+  double dR_dT = 0.0, dR_dS = 0.0;
+  if (use_EOS) {      // :662-680
+    double press = 0.0;
+    for (int k = 0; k < nz; k++) press = press + (A.H_to_RZ * g.g_Earth) * (0.5 * (A.h[c0 + hpl * k] + A.h[c1 + hpl * k]));
+    eos_density_derivs(A.E, T_EOS, S_EOS, press, dR_dT, dR_dS);
+  }
+  // ---- the thickness of the bottom boundary layer :682-790
+  const double ustarsq = Rho0x400_G * (ustar * ustar);
+  double htot = 0.0, dztot = 0.0;
+  if (use_EOS) {
+    double Thtot = 0.0, Shtot = 0.0, oldfn = 0.0;
+    for (int k = nz - 1; k >= 1; k--) {
+      double hat, dzat;
+      at_vel(k, hat, dzat);
+      if (hat <= 0.0) continue;
+      const double Tk = T_vel(k), Sk = S_vel(k);
+      oldfn = dR_dT * (Thtot - Tk * htot) + dR_dS * (Shtot - Sk * htot);
+      if (oldfn >= ustarsq) break;
+      const double Dfn = (dR_dT * (Tk - T_vel(k - 1)) + dR_dS * (Sk - S_vel(k - 1))) * (hat + htot);
+      double Dh, Ddz;
+      if ((oldfn + Dfn) <= ustarsq) {
+        Dh = hat;
+        Ddz = dzat;
+      } else {
+        const double frac_used = sqrt((ustarsq - oldfn) / (Dfn));
+        Dh = hat * frac_used;
+        Ddz = dzat * frac_used;
+      }
+      htot = htot + Dh;
+      dztot = dztot + Ddz;
+      Thtot = Thtot + Tk * Dh; Shtot = Shtot + Sk * Dh;
+    }
+    double hat1, dzat1;
+    at_vel(0, hat1, dzat1);
+    if ((oldfn < ustarsq) && hat1 > 0.0) {
+      if (dR_dT * (Thtot - T_vel(0) * htot) + dR_dS * (Shtot - S_vel(0) * htot) < ustarsq) {
+        htot = htot + hat1;
+        dztot = dztot + dzat1;
+      }
+    }
+  } else {
+    double Rhtot = 0.0;
+    for (int k = nz - 1; k >= 1; k--) {      // k = nz .. K2 = 2 of the reference
+      const double oldfn = Rhtot - A.Rlay[k] * htot;
+      const double Dfn_r = (A.Rlay[k] - A.Rlay[k - 1]);
+      if (oldfn >= ustarsq) continue;
+      double hat, dzat;
+      at_vel(k, hat, dzat);
+      const double Dfn = Dfn_r * (hat + htot);
+      double Dh, Ddz;
+      if ((oldfn + Dfn) <= ustarsq) {
+        Dh = hat;
+        Ddz = dzat;
+      } else {
+        const double frac_used = sqrt((ustarsq - oldfn) / (Dfn));
+        Dh = hat * frac_used;
+        Ddz = dzat * frac_used;
+      }
+      htot = htot + Dh;
+      dztot = dztot + Ddz;
+      Rhtot = Rhtot + A.Rlay[k] * Dh;
+    }
+    if (Rhtot - A.Rlay[0] * htot < ustarsq) {
+      double hat1, dzat1;
+      at_vel(0, hat1, dzat1);
+      htot = htot + hat1;
+      dztot = dztot + dzat1;
+    }
+  }
+  // :792-830
+  double C2f;
+  if (DIR == 0) C2f = g.CoriolisBu[g.q2(i, j - 1)] + g.CoriolisBu[g.q2(i, j)];
+  else C2f = g.CoriolisBu[g.q2(i - 1, j)] + g.CoriolisBu[g.q2(i, j)];
+  const double u2_bg = A.drag_bg_vel * A.drag_bg_vel;
+  double bbl_thick;
+  if (A.cdrag * u2_bg <= 0.0) {
+    const double ustH = ustar, root = sqrt(0.25 * (ustH * ustH) + (htot * C2f) * (htot * C2f));
+    if (dztot * ustH <= (A.BBL_thick_min + dz_neglect) * (0.5 * ustH + root)) bbl_thick = A.BBL_thick_min;
+    else bbl_thick = (dztot * ustH) / (0.5 * ustH + root);
+  } else {
+    bbl_thick = dztot / (0.5 + sqrt(0.25 + htot * htot * C2f * C2f / (ustar * ustar)));
+    if (bbl_thick < A.BBL_thick_min) bbl_thick = A.BBL_thick_min;
+  }
+  if ((bbl_thick > 0.5 * A.dz_bbl) && (A.RiNo_mix)) bbl_thick = 0.5 * A.dz_bbl;
+  if (A.body_force_drag) bbl_thick = dz_bbl_drag;
+  // not channel drag :1010-1022
+  double kv_bbl;
+  if (A.correct_BBL_bounds && cdrag_sqrt * ustar * bbl_thick <= A.Kv_BBL_min) {
+    kv_bbl = A.Kv_BBL_min;
+    if ((cdrag_sqrt * ustar) * A.BBL_thick_max > kv_bbl) bbl_thick = kv_bbl / (cdrag_sqrt * ustar);
+    else bbl_thick = A.BBL_thick_max;
+  } else {
+    kv_bbl = (cdrag_sqrt * ustar) * bbl_thick;
+  }
+  if (A.body_force_drag) {      // :1024-1046
+    if (h_bbl_drag > 0.0) {
+      double h_sum = 0.0;
+      const double I_hwtot = 1.0 / h_bbl_drag;
+      for (int k = nz - 1; k >= 0; k--) {
+        double hat, dzat;
+        at_vel(k, hat, dzat);
+        const double h_bbl_fr = min2(h_bbl_drag - h_sum, hat) * I_hwtot;
+        const double cdrag_conv = cdrag_L_to_H;
+        A.Ray[f2 + fpl * k] = A.Ray[f2 + fpl * k] + (cdrag_conv * umag_avg) * h_bbl_fr;
+        h_sum = h_sum + hat;
+        if (h_sum >= h_bbl_drag) break;
+      }
+      kv_bbl = A.Kv_BBL_min;
+    }
+  }
+  kv_bbl = max2(A.Kv_BBL_min, kv_bbl);
+  A.bbl_thick[f2] = bbl_thick;
+  if (A.Kv_bbl) A.Kv_bbl[f2] = kv_bbl;
+}
+
+int check_cs(const mom6hip_set_visc_cs_t *cs, const char *who) {
+  static const char *names[9] = {"CHANNEL_DRAG", "BBL_USE_TIDAL_BG", "DYNAMIC_VISCOUS_ML", "a bulk mixed layer (nkml > 0)",
+                                 "non-Boussinesq mode (tv%SpV_avg)", "tv%p_surf", "open boundary conditions", "porous barriers",
+                                 "ice shelves"};
+  M6_REQUIRE(cs->initialized, "%s: Module must be initialized before it is used.", who);
+  for (int n = 0; n < 9; n++) M6_REQUIRE(!cs->unsupported[n], "%s: %s is not provided by libmom6hip", who, names[n]);
+  return 0;
+}
+
+}  // namespace
+
+// the launches on device arrays (also called by bench / the model drivers between steps); Rlay is a host array
+namespace m6 {
+int set_viscous_BBL_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
+                        const double *T, const double *S, const mom6hip_eos_t *eos, double *bbl_thick_u, double *bbl_thick_v,
+                        double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v) {
+  const m6::GridDev g = ctx->g;
+  hipStream_t s = ctx->stream;
+  const bool use_EOS = (eos != nullptr) && cs->BBL_use_EOS;
+  BBLArgs A;
+  A.g = g;
+  A.E.form = eos ? eos->form : MOM6HIP_EOS_LINEAR; A.E.Rho_T0_S0 = eos ? eos->Rho_T0_S0 : 0.0;
+  A.E.dRho_dT = eos ? eos->dRho_dT : 0.0; A.E.dRho_dS = eos ? eos->dRho_dS : 0.0;
+  A.cdrag = cs->cdrag; A.drag_bg_vel = cs->drag_bg_vel; A.Hbbl = cs->Hbbl; A.dz_bbl = cs->dz_bbl; A.BBL_thick_min = cs->BBL_thick_min;
+  A.Kv_BBL_min = cs->Kv_BBL_min; A.BBL_thick_max = cs->BBL_thick_max; A.H_to_RZ = cs->H_to_RZ;
+  A.linear_drag = cs->linear_drag; A.use_BBL_EOS = use_EOS; A.correct_BBL_bounds = cs->correct_BBL_bounds;
+  A.body_force_drag = cs->body_force_drag; A.RiNo_mix = cs->RiNo_mix;
+  A.u = u; A.v = v; A.h = h; A.T = T; A.S = S; A.Rlay = nullptr;
+  if (!use_EOS) {
+    M6_REQUIRE(ctx->sv_rlay.reserve(sizeof(double) * (size_t)g.nk) == 0, "set_viscous_BBL: out of device memory");
+    M6_HIP(hipMemcpyAsync(ctx->sv_rlay.p, cs->Rlay, sizeof(double) * (size_t)g.nk, hipMemcpyHostToDevice, s));
+    A.Rlay = (const double *)ctx->sv_rlay.p;
+  }
+  if (Ray_u) M6_HIP(hipMemsetAsync(Ray_u, 0, sizeof(double) * (size_t)g.nu3(), s));      // :416-417
+  if (Ray_v) M6_HIP(hipMemsetAsync(Ray_v, 0, sizeof(double) * (size_t)g.nv3(), s));
+  const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
+  A.bbl_thick = bbl_thick_u; A.Kv_bbl = Kv_bbl_u; A.Ray = Ray_u;
+  hipLaunchKernelGGL(set_viscous_bbl_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
+  A.bbl_thick = bbl_thick_v; A.Kv_bbl = Kv_bbl_v; A.Ray = Ray_v;
+  hipLaunchKernelGGL(set_viscous_bbl_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+  M6_HIP(hipGetLastError());
+  if (!use_EOS) M6_HIP(hipStreamSynchronize(s));      // (the host's Rlay may change after the call)
+  return 0;
+}
+}  // namespace m6
+
+extern "C" int mom6hip_set_viscous_ML(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs) {
+  M6_REQUIRE(ctx != nullptr && cs != nullptr, "MOM_set_viscosity(visc_ML): null argument");
+  if (check_cs(cs, "MOM_set_viscosity(visc_ML)")) return 1;
+  return 0;      // :2043-2044: nothing to do without DYNAMIC_VISCOUS_ML or an ice shelf
+}
+
+extern "C" int mom6hip_set_viscous_BBL(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+                                       const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
+                                       const mom6hip_vertvisc_type_t *visc, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "MOM_set_viscosity(BBL): Module must be initialized before it is used.");
+  M6_REQUIRE(cs && u && v && h && visc, "set_viscous_BBL: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "set_viscous_BBL: bad memspace");
+  if (check_cs(cs, "MOM_set_viscosity(BBL)")) return 1;
+  if (!cs->bottomdraglaw) return 0;      // :321
+  const bool use_EOS = (eos != nullptr) && cs->BBL_use_EOS;
+  M6_REQUIRE(!use_EOS || (T && S), "set_viscous_BBL: BBL_USE_EOS needs tv%%T and tv%%S");
+  M6_REQUIRE(use_EOS || cs->Rlay, "set_viscous_BBL: GV%%Rlay is required without BBL_USE_EOS");
+  M6_REQUIRE(!eos || eos->form == MOM6HIP_EOS_LINEAR || eos->form == MOM6HIP_EOS_WRIGHT, "set_viscous_BBL: this equation of state is not provided");
+  M6_REQUIRE(visc->bbl_thick_u && visc->bbl_thick_v, "set_viscous_BBL: visc%%bbl_thick_u and visc%%bbl_thick_v are required");
+  M6_REQUIRE(!cs->body_force_drag || (visc->Ray_u && visc->Ray_v), "set_viscous_BBL: DRAG_AS_BODY_FORCE needs visc%%Ray_u and visc%%Ray_v");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.CoriolisBu, "set_viscous_BBL: mask2dCu, mask2dCv and CoriolisBu are required");
+  M6_REQUIRE(g.isc - g.isd >= 1 && g.jsc - g.jsd >= 1, "set_viscous_BBL: the halo must be at least 1 point wide");
+  const size_t bH = sizeof(double) * (size_t)g.nh3(), bU = sizeof(double) * (size_t)g.nu3(), bV = sizeof(double) * (size_t)g.nv3();
+  const size_t bU2 = sizeof(double) * (size_t)(g.nih + 1) * g.njh, bV2 = sizeof(double) * (size_t)g.nih * (g.njh + 1);
+  m6::Stager st(ctx, memspace);
+  const double *du = st.in(u, bU), *dv = st.in(v, bV), *dh = st.in(h, bH), *dT = st.in(T, bH), *dS = st.in(S, bH);
+  double *btu = st.inout((double *)visc->bbl_thick_u, bU2), *btv = st.inout((double *)visc->bbl_thick_v, bV2);
+  double *kvu = st.inout((double *)visc->Kv_bbl_u, bU2), *kvv = st.inout((double *)visc->Kv_bbl_v, bV2);
+  double *ru = st.inout((double *)visc->Ray_u, bU), *rv = st.inout((double *)visc->Ray_v, bV);
+  M6_REQUIRE(!st.failed(), "set_viscous_BBL: staging failed");
+  if (m6::set_viscous_BBL_dev(ctx, cs, du, dv, dh, dT, dS, eos, btu, btv, kvu, kvv, ru, rv)) return 1;
+  return st.finish();
+}

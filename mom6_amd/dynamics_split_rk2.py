@@ -32,7 +32,8 @@ class MOM_dyn_split_RK2_CS:
     """MOM_dyn_split_RK2_CS (:84-268)."""
 
     def __init__(self, G: DeviceGrid, BE=0.6, BEGW=0.0, BT_USE_LAYER_FLUXES=True, STORE_CORIOLIS_ACCEL=True, USE_BT_CONT_TYPE=True,
-                 EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None, vertvisc=None):
+                 EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None, vertvisc=None, hor_visc=None,
+                 DT=None):
         g = G.grid
         dev = "cuda"
         self.G = G
@@ -70,6 +71,14 @@ class MOM_dyn_split_RK2_CS:
             from .vert_friction import vertvisc_init
             self.vertvisc_CSp = vertvisc_init(G, **vertvisc)
             st.vertvisc_CSp = C.addressof(self.vertvisc_CSp.st)
+        # hor_visc_init (:1497): hor_visc=dict(BIHARMONIC=True, AH_VEL_SCALE=..., ...) switches the library's horizontal viscosity on
+        self.hor_visc = None
+        if hor_visc is not None:
+            from .hor_visc import hor_visc_init
+            if DT is None:
+                raise Mom6HipError("initialize_dyn_split_RK2: hor_visc needs DT (the baroclinic time step)")
+            self.hor_visc = hor_visc_init(G, DT, **hor_visc)
+            st.hor_visc = C.addressof(self.hor_visc.st)
         self.module_is_initialized = False
 
     def __getattr__(self, n):
@@ -82,6 +91,7 @@ class MOM_dyn_split_RK2_CS:
 def initialize_dyn_split_RK2(u, v, h, uh, vh, dt, G: DeviceGrid, **params) -> MOM_dyn_split_RK2_CS:
     """initialize_dyn_split_RK2 (:1326): control structures of the step and of the modules it calls (parameters by
     their reference names, e.g. BE=0.6, barotropic=dict(BEBT=0.1, DTBT=-0.98)), then the state the first step needs."""
+    params.setdefault("DT", dt)
     CS = MOM_dyn_split_RK2_CS(G, **params)
     check(_setup().mom6hip_dyn_split_rk2_init(G.handle, C.byref(CS.st), u.data_ptr(), v.data_ptr(), h.data_ptr(), uh.data_ptr(),
                                               vh.data_ptr(), float(dt)), "initialize_dyn_split_RK2")

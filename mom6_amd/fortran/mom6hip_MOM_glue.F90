@@ -84,6 +84,7 @@ subroutine mom6hip_context_create(G, GV, ctx, reentrant)
   cg%IdxCv = c_loc(G%IdxCv) ; cg%IdyCv = c_loc(G%IdyCv) ; cg%areaCv = c_loc(G%areaCv) ; cg%IareaCv = c_loc(G%IareaCv)
   cg%mask2dBu = c_loc(G%mask2dBu) ; cg%dxBu = c_loc(G%dxBu) ; cg%dyBu = c_loc(G%dyBu) ; cg%areaBu = c_loc(G%areaBu)
   cg%IareaBu = c_loc(G%IareaBu) ; cg%CoriolisBu = c_loc(G%CoriolisBu)
+  cg%IdxBu = c_loc(G%IdxBu) ; cg%IdyBu = c_loc(G%IdyBu)
 
   ! one PE <-> one GPU: the node-local rank picks the device (MOM6HIP_GPUS_PER_NODE, default 8 on an MI355X node)
   gpus_per_node = 8

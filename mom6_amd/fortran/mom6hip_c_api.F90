@@ -26,8 +26,8 @@ type, bind(c) :: mom6hip_grid_t
   type(c_ptr) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
   type(c_ptr) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
   type(c_ptr) :: mask2dCv, dxCv, dyCv, dx_Cv, IdxCv, IdyCv, areaCv, IareaCv
-  type(c_ptr) :: mask2dBu, dxBu, dyBu, areaBu, IareaBu, CoriolisBu
-  type(c_ptr) :: reserved2(8)
+  type(c_ptr) :: mask2dBu, dxBu, dyBu, areaBu, IareaBu, CoriolisBu, IdxBu, IdyBu
+  type(c_ptr) :: reserved2(6)
 end type mom6hip_grid_t
 
 !> mom6hip_tracer_advect_cs_t

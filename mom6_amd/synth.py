@@ -114,6 +114,7 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     g.set_metric("areaCv", dxCv * dyCv); g.set_metric("IareaCv", inv(dxCv * dyCv))
     g.set_metric("mask2dBu", mBu); g.set_metric("dxBu", dxBu); g.set_metric("dyBu", dyBu)
     g.set_metric("areaBu", dxBu * dyBu); g.set_metric("IareaBu", inv(dxBu * dyBu))
+    g.set_metric("IdxBu", inv(dxBu)); g.set_metric("IdyBu", inv(dyBu))
     omega = 7.2921e-5
     g.set_metric("CoriolisBu", bc(2 * omega * np.sin(np.radians(lat_v)), nih + 1))
     return g

@@ -35,6 +35,11 @@ int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   for (int k = 1; k <= nz; k++) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
     CS->eta[H2(i, j)] = CS->eta[H2(i, j)] + h[H3(i, j, k)];
   memset(CS->diffu, 0, sizeof(double) * n_u3(G)); memset(CS->diffv, 0, sizeof(double) * n_v3(G));
+  if (CS->hor_visc) {   /* :1543-1550 */
+    int rc = orc_horizontal_viscosity(G, CS->hor_visc, u, v, h, CS->diffu, CS->diffv, dt, CS->BT_cont ? CS->BT_cont->h_u : NULL,
+                                      CS->BT_cont ? CS->BT_cont->h_v : NULL);
+    if (rc) return rc;
+  }
   for (long n = 0; n < n_u3(G); n++) CS->visc_rem_u[n] = 1.0;
   for (long n = 0; n < n_v3(G); n++) CS->visc_rem_v[n] = 1.0;
   memcpy(CS->u_av, u, sizeof(double) * n_u3(G)); memcpy(CS->v_av, v, sizeof(double) * n_v3(G));   /* :1552-1558 */
@@ -162,7 +167,10 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
   orc_bt_mass_source(G, BT, hp, eta_pred, 0);                                                          /* :797 */
   if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                           /* :843 */
-  /* [horizontal_viscosity :860: diffu stays 0] ; CorAdCalc :869 */
+  /* horizontal_viscosity :860 (without it diffu stays 0) */
+  if (CS->hor_visc)
+    CHECK(orc_horizontal_viscosity(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL));
+  /* CorAdCalc :869 */
   CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
   /* u_bc_accel :879-886 */
   ORC_PAR

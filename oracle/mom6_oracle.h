@@ -153,6 +153,18 @@ int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, 
 int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
                          double *visc_rem_u, double *visc_rem_v, double dt);
 
+/* ---- MOM_set_viscosity (oracle/set_viscosity.c) ---------------------------------------------------------------------- */
+int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
+                        const double *T, const double *S, const mom6hip_eos_t *EOS, const mom6hip_vertvisc_type_t *visc);
+int orc_set_viscous_ML(const mom6hip_set_visc_cs_t *CS);
+
+/* ---- MOM_hor_visc (oracle/hor_visc.c) ------------------------------------------------------------------------------- */
+/* hor_visc_init (the static arrays, :2440-2760) and horizontal_viscosity (:245-1979); all arrays HOST arrays */
+int orc_hor_visc_init(const mom6hip_grid_t *G, mom6hip_hor_visc_cs_t *CS, double dt);
+int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_t *CS, const double *u, const double *v,
+                             const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
+                             const double *hv_cont);
+
 int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *u, const double *v,
                            const double *h, double *uh, double *vh, double dt);
 int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, double *u_inst, double *v_inst, double *h,

@@ -393,7 +393,7 @@ class DynState:
     the step with numpy arrays behind its pointers, and the prognostic state."""
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
-                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", **bt_kw):
+                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, **bt_kw):
         g = self.grid = grid
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
         self.ccs = continuity_cs(g.nk, g.Angstrom_H)
@@ -411,6 +411,9 @@ class DynState:
         if vertvisc is not None:      # (vertvisc_cs(...) struct, vertvisc_type(...) struct) of this module
             self.vvcs, self.visc = vertvisc, visc
             cs.vertvisc_CSp = C.addressof(vertvisc); cs.visc = C.addressof(visc)
+        if hor_visc is not None:      # a hor_visc_cs(...) struct of this module
+            self.hvcs = hor_visc
+            cs.hor_visc = C.addressof(hor_visc)
         self.arrs = {}
         for n, pos in _abi.RK2_ARRAYS_3D:
             self.arrs[n] = grid.zeros3(pos); setattr(cs, n, self.arrs[n].ctypes.data)
@@ -490,6 +493,77 @@ def vertvisc_remnant(grid, cs, visc, visc_rem_u, visc_rem_v, dt):
     rc = L.orc_vertvisc_remnant(C.byref(grid.struct()), C.byref(cs), C.byref(visc), _p(visc_rem_u), _p(visc_rem_v), dt)
     if rc:
         raise RuntimeError(f"orc_vertvisc_remnant rc={rc}")
+
+
+# ---- MOM_set_viscosity -------------------------------------------------------------------------------------------
+def set_visc_cs(grid, Hbbl, Kv, cdrag=0.003, drag_bg_vel=0.0, BBL_thick_min=0.0, Kv_BBL_min=None, bottomdraglaw=True, linear_drag=False,
+                BBL_use_EOS=True, correct_BBL_bounds=False, body_force_drag=False, RiNo_mix=False, Rlay=None, **unsupported):
+    """mom6hip_set_visc_cs_t with the defaults of set_visc_init (MOM_set_viscosity.F90:2886-3190)."""
+    cs = _abi.SetViscCS()
+    cs.cdrag, cs.drag_bg_vel, cs.dz_bbl, cs.Hbbl = cdrag, drag_bg_vel, Hbbl, Hbbl * grid.Z_to_H
+    cs.BBL_thick_min, cs.Kv_BBL_min, cs.BBL_thick_max = BBL_thick_min, (Kv if Kv_BBL_min is None else Kv_BBL_min), 6.378e6
+    cs.H_to_RZ = grid.Rho0 * grid.H_to_Z
+    cs.bottomdraglaw, cs.linear_drag, cs.BBL_use_EOS = int(bottomdraglaw), int(linear_drag), int(BBL_use_EOS)
+    cs.correct_BBL_bounds, cs.body_force_drag, cs.RiNo_mix, cs.initialized = int(correct_BBL_bounds), int(body_force_drag), int(RiNo_mix), 1
+    for k, v in unsupported.items():
+        cs.unsupported[_abi.SET_VISC_UNSUPPORTED.index(k)] = int(bool(v))
+    if Rlay is not None:
+        cs._rlay = np.ascontiguousarray(Rlay, dtype=np.float64)
+        cs.Rlay = cs._rlay.ctypes.data
+    return cs
+
+
+def set_viscous_BBL(grid, cs, u, v, h, T, S, E, visc):
+    L = lib(); L.orc_set_viscous_BBL.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.SetViscCS)] + [_dp] * 5
+                                                + [C.POINTER(_abi.EOS), C.POINTER(_abi.VertviscType)])
+    rc = L.orc_set_viscous_BBL(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(T), _p(S), None if E is None else C.byref(E),
+                               C.byref(visc))
+    if rc:
+        raise RuntimeError(f"orc_set_viscous_BBL rc={rc}")
+
+
+# ---- MOM_hor_visc ---------------------------------------------------------------------------------------------------
+def hor_visc_cs(grid, dt, **kw):
+    """mom6hip_hor_visc_cs_t with the defaults of hor_visc_init (MOM_hor_visc.F90:2062-2300), numpy arrays behind its
+    pointers (kept on the struct as ._arrs), initialised by orc_hor_visc_init."""
+    d = dict(Kh=0.0, Kh_bg_min=0.0, Kh_vel_scale=0.0, Smag_Lap_const=0.0, Ah=0.0, Ah_vel_scale=0.0, Ah_time_scale=0.0, Smag_bi_const=0.0,
+             bound_Cor_vel=3.0e8, bound_coef=0.8, Laplacian=0, biharmonic=1, Smagorinsky_Kh=0, Smagorinsky_Ah=0, bound_Kh=1,
+             better_bound_Kh=None, bound_Ah=1, better_bound_Ah=None, bound_Coriolis=0, add_LES_viscosity=0, no_slip=0, use_land_mask=1,
+             use_cont_thick=0)
+    unsupported = {k: kw.pop(k) for k in list(kw) if k in _abi.HOR_VISC_UNSUPPORTED}
+    d.update(kw)
+    if d["better_bound_Kh"] is None:
+        d["better_bound_Kh"] = d["bound_Kh"]
+    if d["better_bound_Ah"] is None:
+        d["better_bound_Ah"] = d["bound_Ah"]
+    if not d["Smagorinsky_Ah"]:
+        d["bound_Coriolis"] = 0
+    cs = _abi.HorViscCS()
+    for k, v in d.items():
+        setattr(cs, k, float(v) if isinstance(getattr(cs, k), float) else int(bool(v)))
+    for k, v in unsupported.items():
+        cs.unsupported[_abi.HOR_VISC_UNSUPPORTED.index(k)] = int(bool(v))
+    cs._arrs = {}
+    for n in _abi.HOR_VISC_ARRAYS_H:
+        cs._arrs[n] = grid.zeros2(_abi.POS_H); setattr(cs, n, cs._arrs[n].ctypes.data)
+    for n in _abi.HOR_VISC_ARRAYS_Q:
+        cs._arrs[n] = grid.zeros2(_abi.POS_Q); setattr(cs, n, cs._arrs[n].ctypes.data)
+    L = lib(); L.orc_hor_visc_init.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.HorViscCS), C.c_double]
+    rc = L.orc_hor_visc_init(C.byref(grid.struct()), C.byref(cs), float(dt))
+    if rc:
+        raise RuntimeError(f"orc_hor_visc_init rc={rc}: an option of MOM_hor_visc that is not provided")
+    return cs
+
+
+def horizontal_viscosity(grid, cs, u, v, h, dt, hu_cont=None, hv_cont=None, diffu=None, diffv=None):
+    L = lib(); L.orc_horizontal_viscosity.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.HorViscCS)] + [_dp] * 5 + [C.c_double, _dp, _dp]
+    diffu = grid.zeros3(_abi.POS_U) if diffu is None else diffu
+    diffv = grid.zeros3(_abi.POS_V) if diffv is None else diffv
+    rc = L.orc_horizontal_viscosity(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(diffu), _p(diffv), float(dt),
+                                    _p(hu_cont), _p(hv_cont))
+    if rc:
+        raise RuntimeError(f"orc_horizontal_viscosity rc={rc}")
+    return diffu, diffv
 
 
 # ---- z* regridding + velocity remapping ---------------------------------------------------------------------

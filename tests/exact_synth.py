@@ -122,6 +122,7 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.3, seed=7, reentrant_x=True, reent
     S("mask2dCv", mCv); S("dxCv", dxCv); S("dyCv", dyCv); S("dx_Cv", dxCv * mCv); S("IdxCv", inv(dxCv)); S("IdyCv", inv(dyCv))
     S("areaCv", dxCv * dyCv); S("IareaCv", inv(dxCv * dyCv))
     S("mask2dBu", mBu); S("dxBu", dxBu); S("dyBu", dyBu); S("areaBu", dxBu * dyBu); S("IareaBu", inv(dxBu * dyBu))
+    S("IdxBu", inv(dxBu)); S("IdyBu", inv(dyBu))
     f = (1.0e-4 + 2.0e-5 * yv) if beta_plane else 1.4e-4 * yv * (1.5 - 0.5 * yv * yv)
     S("CoriolisBu", bc(f, nih + 1))
     return g

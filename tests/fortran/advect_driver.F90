@@ -72,7 +72,7 @@ cg%IdxCu = c_null_ptr ; cg%IdyCu = c_null_ptr ; cg%areaCu = c_null_ptr ; cg%Iare
 cg%mask2dCv = c_loc(mask2dCv) ; cg%dxCv = c_null_ptr ; cg%dyCv = c_null_ptr ; cg%dx_Cv = c_null_ptr
 cg%IdxCv = c_null_ptr ; cg%IdyCv = c_null_ptr ; cg%areaCv = c_null_ptr ; cg%IareaCv = c_null_ptr
 cg%mask2dBu = c_null_ptr ; cg%dxBu = c_null_ptr ; cg%dyBu = c_null_ptr ; cg%areaBu = c_null_ptr
-cg%IareaBu = c_null_ptr ; cg%CoriolisBu = c_null_ptr
+cg%IareaBu = c_null_ptr ; cg%CoriolisBu = c_null_ptr ; cg%IdxBu = c_null_ptr ; cg%IdyBu = c_null_ptr
 cg%reserved2(:) = c_null_ptr
 
 ! inputs, for the checker

@@ -1,0 +1,158 @@
+"""horizontal_viscosity: CPU checks of the oracle (oracle/hor_visc.c) through what the operator
+guarantees, and GPU parity of libmom6hip against the oracle (bit-exact fp64), alone and inside step_MOM_dyn_split_RK2.
+The reference holds no known-answer vectors for MOM_hor_visc (parity unpinned)."""
+import numpy as np
+import pytest
+
+import exact_synth as xs
+from helpers import bits_equal, interior
+from mom6_amd import _abi
+from oracle import orc
+
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+DT = 900.0
+VARIANTS = {
+    "biharmonic_default": dict(),      # BIHARMONIC with AH = 0: only the bounds act (diffu = 0)
+    "biharm_vel_scale": dict(Ah_vel_scale=0.05),
+    "smag_ah": dict(Ah_vel_scale=0.01, Smagorinsky_Ah=1, Smag_bi_const=0.06),
+    "smag_ah_bound_cor": dict(Ah_vel_scale=0.01, Smagorinsky_Ah=1, Smag_bi_const=0.06, bound_Coriolis=1, bound_Cor_vel=6.0),
+    "lap_plus_biharm": dict(Laplacian=1, Kh_vel_scale=0.01, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Ah_vel_scale=0.05, Smagorinsky_Ah=1,
+                            Smag_bi_const=0.06),
+    "legacy_bounds": dict(Laplacian=1, Kh=500.0, Smagorinsky_Kh=1, Smag_Lap_const=0.15, better_bound_Kh=0, Ah=1.0e11, better_bound_Ah=0,
+                          Smagorinsky_Ah=1, Smag_bi_const=0.06, add_LES_viscosity=1),
+    "laplacian_noslip": dict(Laplacian=1, biharmonic=0, Kh=300.0, no_slip=1, use_land_mask=0),
+    "cont_thickness": dict(Ah_vel_scale=0.05, use_cont_thick=1),
+}
+REF_NAMES = dict(Ah_vel_scale="AH_VEL_SCALE", Smagorinsky_Ah="SMAGORINSKY_AH", Smag_bi_const="SMAG_BI_CONST", bound_Coriolis="BOUND_CORIOLIS_BIHARM",
+                 bound_Cor_vel="BOUND_CORIOLIS_VEL", Laplacian="LAPLACIAN", Kh_vel_scale="KH_VEL_SCALE", Smagorinsky_Kh="SMAGORINSKY_KH",
+                 Smag_Lap_const="SMAG_LAP_CONST", Kh="KH", better_bound_Kh="BETTER_BOUND_KH", Ah="AH", better_bound_Ah="BETTER_BOUND_AH",
+                 add_LES_viscosity="ADD_LES_VISCOSITY", biharmonic="BIHARMONIC", no_slip="NOSLIP", use_land_mask="USE_LAND_MASK_FOR_HVISC",
+                 use_cont_thick="USE_CONT_THICKNESS")
+
+
+def case(ni=40, nj=28, nk=3, land_frac=0.25, umax=0.3, **kw):
+    g = xs.make_grid(ni, nj, nk, land_frac=land_frac, **kw)
+    return g, xs.make_state(g, umax=umax)
+
+
+def test_uniform_flow_and_rest_feel_no_stress():
+    """on a grid with uniform spacing and no land a uniform flow has no strain: diffu = diffv = 0; so has an ocean at rest"""
+    g, d = case(land_frac=0.0, uniform=True, reentrant_y=True, spacing=20000.0)
+    cs = orc.hor_visc_cs(g, DT, Laplacian=1, Kh=500.0, Ah=1.0e11, Smagorinsky_Ah=1, Smag_bi_const=0.06)
+    for u0, v0 in ((0.0, 0.0), (0.3, -0.2)):
+        u = np.full_like(d["u"], u0); v = np.full_like(d["v"], v0)
+        du, dv = orc.horizontal_viscosity(g, cs, u, v, d["h"], DT)
+        assert np.all(du == 0.0) and np.all(dv == 0.0)
+
+
+@pytest.mark.parametrize("name", ["biharm_vel_scale", "lap_plus_biharm", "laplacian_noslip"])
+def test_viscosity_dissipates_energy_and_conserves_momentum(name):
+    """thickness-weighted: sum h_u u diffu dA <= 0 (the stress does negative work), and on a doubly periodic uniform grid
+    without land the layer momentum sum h_u diffu dA vanishes to roundoff (the stress divergence telescopes)"""
+    g, d = case(ni=36, nj=24, nk=2, land_frac=0.0, uniform=True, reentrant_y=True, spacing=20000.0)
+    # valid halos of the doubly periodic state
+    for n, p in (("u", U), ("v", V), ("h", H)):
+        orc.halo_update(g, d[n], p)
+    kw = dict(VARIANTS[name]); kw["use_land_mask"] = 0
+    cs = orc.hor_visc_cs(g, DT, **kw)
+    du, dv = orc.horizontal_viscosity(g, cs, d["u"], d["v"], d["h"], DT)
+    sj, si = g.csl(H)
+    hu = 0.5 * (d["h"][:, sj, si.start - 1:si.stop] + d["h"][:, sj, si.start:si.stop + 1])      # h_u(I,j), I = is-1..ie
+    A = g.areaT[sj, si][0, 0]
+    uu, dd = interior(g, d["u"], U), interior(g, du, U)
+    work = float((hu[:, :, 1:] * uu[:, :, 1:] * dd[:, :, 1:]).sum())      # each periodic face once
+    hv = 0.5 * (d["h"][:, sj.start - 1:sj.stop, si] + d["h"][:, sj.start:sj.stop + 1, si])
+    vv, dvv = interior(g, d["v"], V), interior(g, dv, V)
+    work += float((hv[:, 1:, :] * vv[:, 1:, :] * dvv[:, 1:, :]).sum())
+    assert work < 0.0
+    mom = float((hu[:, :, 1:] * dd[:, :, 1:]).sum()) * A
+    scale = float(np.abs(hu[:, :, 1:] * dd[:, :, 1:]).sum()) * A
+    assert abs(mom) <= 1e-10 * scale
+
+
+def test_bounds_limit_the_viscosity():
+    """with BETTER_BOUND_AH a huge background AH is cut down to the stable value: the result equals that of any larger AH"""
+    g, d = case()
+    a = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, DT, Ah=1.0e16), d["u"], d["v"], d["h"], DT)
+    b = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, DT, Ah=1.0e18), d["u"], d["v"], d["h"], DT)
+    assert bits_equal(a[0], b[0]) and bits_equal(a[1], b[1]) and np.abs(a[0]).max() > 0
+    # and one explicit forward step with the bounded operator does not amplify the grid-scale noise
+    u1 = d["u"] + DT * a[0]
+    assert np.abs(interior(g, u1, U)).max() <= np.abs(interior(g, d["u"], U)).max() * (1 + 1e-12)
+
+
+def test_refuses_what_it_does_not_provide():
+    g, d = case(ni=12, nj=10, nk=2)
+    with pytest.raises(RuntimeError):
+        orc.hor_visc_cs(g, DT, Leith_Kh=1)
+    with pytest.raises(RuntimeError):
+        orc.hor_visc_cs(g, DT, no_slip=1)      # NOSLIP and BIHARMONIC (the default) together
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_gpu_parity(name):
+    import torch
+    from mom6_amd.hor_visc import hor_visc_init, horizontal_viscosity
+    from mom6_amd.tracer_advect import DeviceGrid
+    kw = VARIANTS[name]
+    for (ni, nj, nk, topo, land) in [(70, 21, 3, (True, False), 0.25), (44, 40, 2, (True, True), 0.3), (10, 8, 8, (False, False), 0.2),
+                                     (300, 9, 2, (True, False), 0.25)]:
+        g = xs.make_grid(ni, nj, nk, land_frac=land, reentrant_x=topo[0], reentrant_y=topo[1])
+        d = xs.make_state(g, umax=0.3)
+        hu_c = np.ascontiguousarray(0.5 * (d["h"][:, :, :-1] + d["h"][:, :, 1:]) * 1.01)
+        hu = np.zeros_like(d["u"]); hu[:, :, 1:-1] = hu_c
+        hv = np.zeros_like(d["v"]); hv[:, 1:-1, :] = 0.5 * (d["h"][:, :-1, :] + d["h"][:, 1:, :]) * 0.99
+        cont = dict(hu_cont=hu, hv_cont=hv) if kw.get("use_cont_thick") else {}
+        cs_o = orc.hor_visc_cs(g, DT, **kw)
+        ref = orc.horizontal_viscosity(g, cs_o, d["u"], d["v"], d["h"], DT, **cont)
+        dg = DeviceGrid(g)
+        for resident in (True, False):
+            CS = hor_visc_init(dg, DT, device_arrays=resident, **{REF_NAMES[k]: v for k, v in kw.items()})
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            dg.sync()
+            for n in _abi.HOR_VISC_ARRAYS_H + _abi.HOR_VISC_ARRAYS_Q:
+                assert bits_equal(N(CS.arrays[n]), cs_o._arrs[n]), (name, (ni, nj, nk), n)
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a.copy())
+            du, dv = X(np.zeros_like(d["u"])), X(np.zeros_like(d["v"]))
+            horizontal_viscosity(X(d["u"]), X(d["v"]), X(d["h"]), du, dv, None, None, dg, CS, **{k: X(a) for k, a in cont.items()})
+            dg.sync()
+            assert bits_equal(N(du), ref[0]), (name, (ni, nj, nk), resident, "diffu", np.argwhere(N(du) != ref[0])[:3])
+            assert bits_equal(N(dv), ref[1]), (name, (ni, nj, nk), resident, "diffv", np.argwhere(N(dv) != ref[1])[:3])
+        dg.close()
+
+
+@pytest.mark.gpu
+def test_step_with_hor_visc_matches_oracle_bitwise():
+    """step_MOM_dyn_split_RK2 with the library's horizontal and vertical viscosity: no hooks, nothing prescribed to zero"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    g = xs.make_grid(44, 40, 4, land_frac=0.25)
+    d = xs.make_state(g, umax=0.1, terrain_following=True)
+    taux, tauy = xs.wind_stress(g); bbl = xs.bbl_arrays(g)
+    dt = 1800.0
+    hv = dict(Laplacian=1, Kh_vel_scale=0.01, Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0),
+                       visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **hv))
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0),
+                                  hor_visc={REF_NAMES[k]: x for k, x in hv.items()})
+    assert bits_equal(CS.diffu.cpu().numpy(), ref.arrs["diffu"]) and np.abs(ref.arrs["diffu"]).max() > 0
+    visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy, calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS,
+                               calc_dtbt=(n == 0))
+        dg.sync()
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("eta_av", eta_av, ref.eta_av),
+                           ("diffu", CS.diffu, ref.arrs["diffu"]), ("diffv", CS.diffv, ref.arrs["diffv"]), ("u_av", CS.u_av, ref.arrs["u_av"])):
+            an = a.cpu().numpy()
+            assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+    dg.close()
