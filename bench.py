@@ -6,12 +6,12 @@
 
 A "step" is one baroclinic time step (DT) of the model on the synthetic global C-grid named in
 `config.workload`: step_MOM_dyn_split_RK2 (src/core/MOM_dynamics_split_RK2.F90:289-1176) -- PressureForce,
-continuity x3, btstep x2 (+ btcalc, bt_mass_source), CorAdCalc x2, vertvisc_coef x3 / vertvisc x2 / vertvisc_remnant x3,
-the momentum sweeps and the group passes --
+continuity x3, btstep x2 (+ btcalc, bt_mass_source), CorAdCalc x2, horizontal_viscosity, vertvisc_coef x3 / vertvisc x2 /
+vertvisc_remnant x3, the momentum sweeps and the group passes -- preceded every DT_THERM by set_viscous_BBL (MOM.F90:1205),
 and every DT_THERM/DT-th step advect_tracer (src/core/MOM.F90:1438) and the ALE block (:1647-1700: ALE_regrid,
 ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities).  The state
-evolves: every step starts from the previous step's u, v, h, T, S.  `config.not_yet_in_step` lists what the
-reference's step also does but this build does not provide.  The state is resident in HBM before
+evolves: every step starts from the previous step's u, v, h, T, S.  Every operator of the reference's dynamic step on this configuration is
+the library's own (nothing is prescribed or set to zero).  The state is resident in HBM before
 the timed region.  Rank 0 prints ONE JSON line; `components_ms_per_call` times each operator on its own.
 """
 import argparse
@@ -34,7 +34,9 @@ REMAP_SCHEME = "PPM_H4"    # OM4-class remapping scheme
 # vertvisc_init parameters: background viscosity, and the fixed-depth mixed-layer viscosity KV_ML_INVZ2 over HMIX_FIXED that
 # carries the wind stress into the top 20 m (no boundary-layer scheme feeds visc%Kv_shear here)
 VERTVISC = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
-KV_BBL = 0.003 * 0.1 * 10.0   # cdrag * |u| * HBBL [m2 s-1]
+# hor_visc_init parameters: biharmonic Smagorinsky viscosity with a grid-scale background (the OM4_025 choice)
+HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL_SCALE=0.01)
+SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
 LAND_FRAC = 0.30
@@ -97,13 +99,14 @@ class Model:
         self.taux = (0.1 * torch.cos(2 * yy)[:, None] * mu).contiguous()
         self.tauy = Z(V, False)
         self.CS = initialize_dyn_split_RK2(self.u, self.v, self.h, self.uh, self.vh, DT, self.dg, coriolis=dict(bound_coriolis=True),
-                                           vertvisc=VERTVISC)
-        # visc%Kv_bbl_[uv], visc%bbl_thick_[uv]: set_viscous_BBL is not provided, the bottom boundary layer
-        # is prescribed: HBBL thick with the viscosity a linear drag law of 0.1 m/s would give
+                                           vertvisc=VERTVISC, hor_visc=HOR_VISC)
+        # visc%Kv_bbl_[uv], visc%bbl_thick_[uv]: set by set_viscous_BBL at the start of every thermodynamic cycle (MOM.F90:1200-1208)
+        from mom6_amd.pressure_force import EOS_init
+        from mom6_amd.set_viscosity import set_visc_init
         from mom6_amd.vert_friction import vertvisc_type
-        mv = torch.as_tensor(grid.mask2dCv, device=dev)
-        self.visc = vertvisc_type(Kv_bbl_u=(KV_BBL * mu).contiguous(), Kv_bbl_v=(KV_BBL * mv).contiguous(),
-                                  bbl_thick_u=(VERTVISC["HBBL"] * mu).contiguous(), bbl_thick_v=(VERTVISC["HBBL"] * mv).contiguous())
+        self.visc = vertvisc_type(Kv_bbl_u=Z(U, False), Kv_bbl_v=Z(V, False), bbl_thick_u=Z(U, False), bbl_thick_v=Z(V, False))
+        self.set_visc_cs = set_visc_init(self.dg, **SET_VISC)
+        self.eos = EOS_init("WRIGHT")
         self.adv_cs = tracer_advect_init(DT, scheme)
         self.remap_cs = initialize_remapping(REMAP_SCHEME)
         # z* target: the nominal layer thicknesses of the synthetic state (synth.make_dynamics_state)
@@ -126,6 +129,9 @@ class Model:
         from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
         from mom6_amd.tracer_advect import advect_tracer
         n = self.nstep
+        if n % self.steps_per_advect == 0:      # bbl_time_int > 0: the first dynamic step of a thermodynamic cycle (MOM.F90:1200)
+            from mom6_amd.set_viscosity import set_viscous_BBL
+            set_viscous_BBL(self.u, self.v, self.h, (self.T, self.S, self.eos), self.visc, self.dg, self.set_visc_cs)
         step_MOM_dyn_split_RK2(self.u, self.v, self.h, (self.T, self.S), self.visc, None, DT, (self.taux, self.tauy), None, None,
                                self.uh, self.vh, self.uhtr, self.vhtr, self.eta_av, self.dg, self.CS, calc_dtbt=(n == 0))
         if (n + 1) % self.steps_per_advect == 0:      # step_MOM_thermo / step_MOM_tracer_dyn (src/core/MOM.F90:1438, :1662)
@@ -310,9 +316,14 @@ class Components:
             from mom6_amd.vert_friction import vertvisc_init, vertvisc_type
             self.vv_cs = vertvisc_init(dg, **VERTVISC)
             g = self.g
-            mu, mv = (torch.as_tensor(m, device=d["u"].device) for m in (g.mask2dCu, g.mask2dCv))
-            self.vv_visc = vertvisc_type(Kv_bbl_u=(KV_BBL * mu).contiguous(), Kv_bbl_v=(KV_BBL * mv).contiguous(),
-                                         bbl_thick_u=(VERTVISC["HBBL"] * mu).contiguous(), bbl_thick_v=(VERTVISC["HBBL"] * mv).contiguous())
+            from mom6_amd.hor_visc import hor_visc_init
+            from mom6_amd.set_viscosity import set_visc_init, set_viscous_BBL
+            Zf = lambda pos: torch.zeros(g.shape2(pos), dtype=torch.float64, device=d["u"].device)
+            self.vv_visc = vertvisc_type(Kv_bbl_u=Zf(1), Kv_bbl_v=Zf(2), bbl_thick_u=Zf(1), bbl_thick_v=Zf(2))
+            self.sv_cs = set_visc_init(dg, **SET_VISC)
+            set_viscous_BBL(d["u"], d["v"], d["h"], (d["T"], d["S"], self.eos), self.vv_visc, dg, self.sv_cs)
+            self.hv_cs = hor_visc_init(dg, DT, **HOR_VISC)
+            self.diffu, self.diffv = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
             self.vv_u, self.vv_v = d["u"].clone(), d["v"].clone()
             self.vv_ru, self.vv_rv = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
 
@@ -325,6 +336,13 @@ class Components:
                                                     vertvisc_remnant(self.vv_visc, self.vv_ru, self.vv_rv, DT, dg, self.vv_cs))))
         out.append(("vertvisc[pred]", lambda: vv_full(0.6 * DT)))
         out.append(("vertvisc[corr]", lambda: vv_full(DT)))
+        from mom6_amd.hor_visc import horizontal_viscosity
+        out.append(("horizontal_viscosity", lambda: horizontal_viscosity(d["u"], d["v"], d["h"], self.diffu, self.diffv, None, None, dg,
+                                                                       self.hv_cs)))
+        if n % self.steps_per_advect == 0:
+            from mom6_amd.set_viscosity import set_viscous_BBL
+            out.append(("set_viscous_BBL", lambda: set_viscous_BBL(d["u"], d["v"], d["h"], (d["T"], d["S"], self.eos), self.vv_visc, dg,
+                                                                   self.sv_cs)))
         if (n + 1) % self.steps_per_advect == 0:
             a = self.adv
 
@@ -355,9 +373,12 @@ def _cpu_sample(grid, scheme, nk_s, steps_per_advect, threads):
     passive = [t.numpy() for t in adv["tr"][2:4]]
     del adv
     vv = orc.vertvisc_cs(g, Kv=VERTVISC["KV"], Hbbl=VERTVISC["HBBL"], Hmix=VERTVISC["HMIX_FIXED"], Kvml_invZ2=VERTVISC["KV_ML_INVZ2"])
-    mu, mv = np.asarray(g.mask2dCu), np.asarray(g.mask2dCv)
-    visc = orc.vertvisc_type(Kv_bbl_u=KV_BBL * mu, Kv_bbl_v=KV_BBL * mv, bbl_thick_u=VERTVISC["HBBL"] * mu, bbl_thick_v=VERTVISC["HBBL"] * mv)
-    st = orc.DynState(g, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], DT, vertvisc=vv, visc=visc)
+    visc = orc.vertvisc_type(Kv_bbl_u=g.zeros2(_abi.POS_U), Kv_bbl_v=g.zeros2(_abi.POS_V), bbl_thick_u=g.zeros2(_abi.POS_U),
+                             bbl_thick_v=g.zeros2(_abi.POS_V))
+    svcs = orc.set_visc_cs(g, SET_VISC["HBBL"], SET_VISC["KV"], cdrag=SET_VISC["CDRAG"], BBL_use_EOS=SET_VISC["BBL_USE_EOS"])
+    hvcs = orc.hor_visc_cs(g, DT, biharmonic=1, Smagorinsky_Ah=1, Smag_bi_const=HOR_VISC["SMAG_BI_CONST"], Ah_vel_scale=HOR_VISC["AH_VEL_SCALE"])
+    orc.set_viscous_BBL(g, svcs, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], orc.eos("WRIGHT"), visc)
+    st = orc.DynState(g, dyn["u"], dyn["v"], dyn["h"], dyn["T"], dyn["S"], DT, vertvisc=vv, visc=visc, hor_visc=hvcs)
     yy = np.arange(g.shape2(_abi.POS_U)[0]) / (g.nj + 2 * g.halo) * 3.1416
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = g.zeros2(_abi.POS_V)
     loop_s = C.c_double.in_dll(orc.lib(), "orc_btstep_loop_seconds")
@@ -365,9 +386,12 @@ def _cpu_sample(grid, scheme, nk_s, steps_per_advect, threads):
     n_dyn = min(2, steps_per_advect)
     loop_s.value = 0.0
     t0 = time.perf_counter()
+    orc.set_viscous_BBL(g, svcs, st.u, st.v, st.h, st.T, st.S, orc.eos("WRIGHT"), visc)      # once per thermodynamic cycle
+    t_bbl = time.perf_counter() - t0
+    t0 = time.perf_counter()
     for n in range(n_dyn):
         st.step(taux, tauy)
-    t_dyn = time.perf_counter() - t0
+    t_dyn = time.perf_counter() - t0 + t_bbl * n_dyn / steps_per_advect
     t_2d = loop_s.value
     t0 = time.perf_counter()
     tr = [st.T, st.S] + passive
@@ -429,7 +453,7 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
 # algorithmic bytes per cell and call (SURVEY.md section 8d / DESIGN.md section 4)
 ALG_BYTES = {
     "PressureForce": 64.0, "continuity[BT_cont]": 96.0, "continuity[uhbt+BT_cont]": 96.0, "continuity[uhbt]": 96.0,
-    "CorAdCalc": 56.0, "CorAdCalc[pred]": 56.0, "ALE_remap_tracers": 16.0 + 16.0 * NTR,
+    "CorAdCalc": 56.0, "CorAdCalc[pred]": 56.0, "ALE_remap_tracers": 16.0 + 16.0 * NTR, "horizontal_viscosity": 40.0,
 }
 
 
@@ -517,13 +541,13 @@ def main():
                         f"layers ({100 * health['vanished_layer_fraction']:.0f}% of the ocean cells are vanished layers below the bottom), "
                         f"T, S + 2 passive tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
             "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
-                    "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], vertvisc_coef x3 + "
-                    "vertvisc x2 + vertvisc_remnant x3 [BOTTOMDRAGLAW, prescribed bottom boundary layer], momentum sweeps, "
-                    f"group passes); every {spa} steps advect_tracer [{a.scheme}] + ALE regrid/remap [{REMAP_SCHEME}]",
+                    "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], horizontal_viscosity "
+                    "[biharmonic Smagorinsky, BETTER_BOUND_AH], vertvisc_coef x3 + vertvisc x2 + vertvisc_remnant x3 [BOTTOMDRAGLAW], "
+                    f"momentum sweeps, group passes); every {spa} steps set_viscous_BBL [BBL_USE_EOS], advect_tracer [{a.scheme}] + "
+                    f"ALE regrid/remap [{REMAP_SCHEME}]",
             "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
-            "not_yet_in_step": ["set_viscous_BBL / set_viscous_ML (the bottom boundary layer is prescribed: "
-                                f"bbl_thick = {VERTVISC['HBBL']} m, Kv_bbl = {KV_BBL} m2/s)", "horizontal_viscosity (diffu = diffv = 0)"],
-            "vertvisc": dict(VERTVISC, Kv_bbl=KV_BBL, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)),
+            "not_yet_in_step": [],
+            "vertvisc": dict(VERTVISC, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)), "hor_visc": HOR_VISC, "set_visc": SET_VISC,
             "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE = 0, the default), remap of T, S + 2 tracers "
                    f"and of u, v [{REMAP_SCHEME}]",
             "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),

@@ -130,6 +130,23 @@ int mom6hip_set_callback_stream_ordered(mom6hip_ctx_t *ctx, int32_t stream_order
 typedef int (*mom6hip_min_fn)(void *user, double *values, int32_t n);
 int mom6hip_set_min_callback(mom6hip_ctx_t *ctx, mom6hip_min_fn min_fn, void *user);
 
+/* The native multi-tile domain: one process = one tile = one GPU, the group passes and reductions inside library calls go
+ * over RCCL point-to-point on a second HIP stream (mom6_amd/csrc/domain_rccl.hip) -- no host callback, no host
+ * synchronisation.  Rank r of `nranks` owns the tile whose neighbours in W / E / S / N are the given ranks (-1: a closed
+ * edge, or a direction with one tile, where the grid's reentrant_x / reentrant_y select the library's own wrap).
+ * Rank 0 obtains the 128-byte RCCL unique id and the host distributes it (MPI_Bcast in MOM6, torch.distributed here);
+ * every rank then calls mom6hip_domain_init_rccl.  The callback path above stays available (an MPI host). */
+typedef struct mom6hip_domain {
+  int32_t nranks, rank;
+  int32_t nbr_w, nbr_e, nbr_s, nbr_n;
+  int32_t reserved[2];
+} mom6hip_domain_t;
+int mom6hip_rccl_get_unique_id(void *id, int32_t nbytes);
+int mom6hip_domain_init_rccl(mom6hip_ctx_t *ctx, const mom6hip_domain_t *dom, const void *unique_id, int32_t nbytes);
+/* Device time of the exchanges (pack + RCCL + unpack on the communication stream) since the previous call, and their
+ * number; `enable` switches the recording for the calls that follow. */
+int mom6hip_domain_exchange_timing(mom6hip_ctx_t *ctx, int32_t enable, double *ms_total, int64_t *npasses);
+
 /* Packing for the multi-tile group pass: gathers (pack = 1) the slabs [a0[f], a0[f] + width) along direction `dir`
  * (0: i, rows restricted to the compute rows of each field; 1: j, full rows) of `nfields` DEVICE arrays into the
  * contiguous DEVICE buffer `buf`, field after field, or scatters them back (pack = 0).  a0 is 0-based in the
@@ -555,7 +572,7 @@ int mom6hip_vertvisc_remnant(mom6hip_ctx_t *ctx, const mom6hip_vertvisc_cs_t *cs
  * kappa-shear cap of the layer thickness (RiNo_mix).  Not provided (refused by name): CHANNEL_DRAG, BBL_USE_TIDAL_BG,
  * a bulk mixed layer (nkml > 0), non-Boussinesq mode (tv%SpV_avg), tv%p_surf, OBC, porous barriers.
  * set_viscous_ML (:1898) does nothing unless DYNAMIC_VISCOUS_ML or an ice shelf is present (:2043-2044); both are refused,
- * so mom6hip_set_viscous_ML returns at once like the reference.
+ * so mom6hip_set_viscous_ml returns at once like the reference.
  */
 typedef struct mom6hip_set_visc_cs {
   double cdrag;            /* CDRAG (0.003) */
@@ -585,13 +602,13 @@ typedef struct mom6hip_set_visc_cs {
  * visc%Kv_bbl_u/v on the ocean faces of the compute domain (I = IscB..IecB, j = jsc..jec; i = isc..iec, J = JscB..JecB)
  * and, when they are present, zeroes visc%Ray_u/v (:416-417) and adds the body-force drag.  The members of `visc` this
  * call writes are declared const in mom6hip_vertvisc_type_t because vertvisc only reads them. */
-int mom6hip_set_viscous_BBL(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
                             const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
                             const mom6hip_vertvisc_type_t *visc, int32_t memspace);
 
 /* set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)                                                :1898
  * returns at once unless DYNAMIC_VISCOUS_ML (refused by mom6hip_vertvisc_* as well) or an ice shelf is present. */
-int mom6hip_set_viscous_ML(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs);
+int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs);
 
 /* ---- MOM_hor_visc ----------------------------------------------------------------------------- */
 

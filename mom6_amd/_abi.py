@@ -33,6 +33,11 @@ class GridStruct(C.Structure):
     )
 
 
+class DomainStruct(C.Structure):
+    """mom6hip_domain_t (include/mom6hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("nranks", "rank", "nbr_w", "nbr_e", "nbr_s", "nbr_n")] + [("reserved", C.c_int32 * 2)]
+
+
 class TracerAdvectCS(C.Structure):
     _fields_ = [("dt", C.c_double), ("scheme", C.c_int32), ("use_huynh_stencil_bug", C.c_int32)]
 

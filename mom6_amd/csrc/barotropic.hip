@@ -24,7 +24,7 @@
 #include <utility>
 
 namespace m6 {
-int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+
 }
 
 namespace {
@@ -598,8 +598,7 @@ int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const doub
   if (!(min_max_dt2 < 1.0e38)) min_max_dt2 = 1.0e38;
   const double dgeo_de = 1.0 + (cs->G_extra > 0.0 ? cs->G_extra : 0.0);
   double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
-  if (ctx->min_cb)      // min_across_PEs(dtbt_max) :2915
-    M6_REQUIRE(ctx->min_cb(ctx->min_user, &dtbt_max, 1) == 0, "set_dtbt: the min_across_PEs callback failed");
+  if (int rc = m6::min_across_PEs(ctx, &dtbt_max, 1)) return rc;      // min_across_PEs(dtbt_max) :2915
   cs->dtbt = cs->dtbt_fraction * dtbt_max;
   cs->dtbt_max = dtbt_max;
   return st.finish();
@@ -1001,7 +1000,7 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     return 0;
   };
   static const bool graph_off = getenv("MOM6HIP_BT_GRAPH") && atoi(getenv("MOM6HIP_BT_GRAPH")) == 0;
-  if (ctx->halo_cb || graph_off) {
+  if (m6::multi_tile(ctx) || graph_off) {
     if (int rc = run_loop(s)) return rc;
   } else {
     std::string key;

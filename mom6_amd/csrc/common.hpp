@@ -14,6 +14,7 @@
 #include "../../include/mom6hip.h"
 
 struct mom6hip_ctx;
+struct m6_native_domain;      // the RCCL domain of a context (domain_rccl.hip)
 
 namespace m6 {
 
@@ -101,6 +102,7 @@ struct mom6hip_ctx {
   hipStream_t cap_stream = nullptr;
   long bt_graph_captures = 0, bt_graph_launches = 0;
   int *h_domore_k = nullptr;    // pinned host mirror of domore_k
+  m6_native_domain *native = nullptr;      // set by mom6hip_domain_init_rccl: the group pass and the reductions are the library's own
   // multi-tile collectives provided by the host (null on a one-tile domain)
   mom6hip_halo_fn halo_cb = nullptr;
   mom6hip_sum_fn sum_cb = nullptr;
@@ -135,6 +137,24 @@ struct KTimer {
   }
 };
 
+// MOM_domains inside the library (context.hip, domain_rccl.hip).  do_group_pass = start + complete; with a native (RCCL)
+// domain the exchange runs on the communication stream between the two, otherwise start does the whole pass on the compute
+// stream (the host's callback, or the local wrap kernels) and complete does nothing.
+int group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+int start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+int complete_group_pass(mom6hip_ctx *ctx);
+int halo_wrap_dir(mom6hip_ctx *ctx, double *f, int pos, int nk, int dir, hipStream_t stream);
+int halo_pack_on(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each, const int32_t *a0, int32_t nfields,
+                 int32_t dir, int32_t width, double *buf, int32_t pack, int64_t *count, hipStream_t stream);
+int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+int native_complete_group_pass(mom6hip_ctx *ctx);
+int native_allreduce(mom6hip_ctx *ctx, void *values, int n, bool is_int_sum);
+void native_domain_destroy(mom6hip_ctx *ctx);
+// sum_across_PEs of n host int32 / min_across_PEs of n host doubles, in place (the native domain, the host's callback, or nothing)
+int sum_across_PEs(mom6hip_ctx *ctx, int32_t *values, int n);
+int min_across_PEs(mom6hip_ctx *ctx, double *values, int n);
+inline bool multi_tile(const mom6hip_ctx *ctx);
+
 // horizontal_viscosity on device arrays (hor_visc.hip); called by the split RK2 step at :860 and :1543
 int horizontal_viscosity_dev(mom6hip_ctx *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,
                              double *diffu, double *diffv, const double *hu_cont, const double *hv_cont);
@@ -164,4 +184,8 @@ class Stager {
   std::vector<Ent> ents_;
 };
 
+}  // namespace m6
+
+namespace m6 {
+inline bool multi_tile(const mom6hip_ctx *ctx) { return ctx->native != nullptr || ctx->halo_cb != nullptr; }
 }  // namespace m6

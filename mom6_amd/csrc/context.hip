@@ -189,6 +189,8 @@ uint64_t mom6hip_abi_sizeof_barotropic_cs(void) { return sizeof(mom6hip_barotrop
 uint64_t mom6hip_abi_sizeof_dyn_split_rk2_cs(void) { return sizeof(mom6hip_dyn_split_rk2_cs_t); }
 uint64_t mom6hip_abi_sizeof_vertvisc_cs(void) { return sizeof(mom6hip_vertvisc_cs_t); }
 uint64_t mom6hip_abi_sizeof_vertvisc_type(void) { return sizeof(mom6hip_vertvisc_type_t); }
+uint64_t mom6hip_abi_sizeof_hor_visc_cs(void) { return sizeof(mom6hip_hor_visc_cs_t); }
+uint64_t mom6hip_abi_sizeof_set_visc_cs(void) { return sizeof(mom6hip_set_visc_cs_t); }
 uint64_t mom6hip_abi_offsetof_grid_mask2dT(void) { return offsetof(mom6hip_grid_t, mask2dT); }
 
 static int upload2d(mom6hip_ctx_t *ctx, const double *h, size_t n, double **d) {
@@ -269,6 +271,7 @@ int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t 
 int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   if (!ctx) return 0;
   (void)hipStreamSynchronize(ctx->stream);
+  m6::native_domain_destroy(ctx);
   for (void *p : ctx->metric_allocs) (void)hipFree(p);
   ctx->hprev.release(); ctx->uhr.release(); ctx->vhr.release(); ctx->flags.release();
   for (auto &b : ctx->stage) b.release();
@@ -337,10 +340,9 @@ __global__ void halo_y_kernel(HaloDesc d) {
 
 namespace m6 {
 
-// Enqueue the halo fill of one device field (see oracle/domains.c for the semantics).
-int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
+// The wrap of one re-entrant direction of one device field on `stream` (dir 0: x, the compute rows; dir 1: y, full rows).
+int halo_wrap_dir(mom6hip_ctx_t *ctx, double *f, int pos, int nk, int dir, hipStream_t stream) {
   const mom6hip_grid_t &G = ctx->host;
-  if (!G.reentrant_x && !G.reentrant_y) return 0;
   const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0;
   const int ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
   HaloDesc d;
@@ -348,33 +350,63 @@ int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
   d.nis = d.ihi - d.ilo + 1; d.njs = d.jhi - d.jlo + 1; d.nk = nk;
   d.ics = G.isc - xs; d.ice = G.iec; d.jcs = G.jsc - ys; d.jce = G.jec;
   d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1;
-  if (G.reentrant_x) {
+  if (dir == 0) {
     long total = (long)((d.ics - d.ilo) + (d.ihi - d.ice)) * (d.jce - d.jcs + 1) * nk;
     if (total > 0) {
       int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(halo_x_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d);
+      hipLaunchKernelGGL(halo_x_kernel, dim3(blocks), dim3(256), 0, stream, d);
     }
-  }
-  if (G.reentrant_y) {
+  } else {
     long total = (long)d.nis * ((d.jcs - d.jlo) + (d.jhi - d.jce)) * nk;
     if (total > 0) {
       int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(halo_y_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d);
+      hipLaunchKernelGGL(halo_y_kernel, dim3(blocks), dim3(256), 0, stream, d);
     }
   }
   M6_HIP(hipGetLastError());
   return 0;
 }
 
-// do_group_pass: the host's collective when the tile has neighbours, the local wrap kernels otherwise
-int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
-  if (ctx->halo_cb) {
+// Enqueue the halo fill of one device field (see oracle/domains.c for the semantics).
+int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
+  const mom6hip_grid_t &G = ctx->host;
+  if (G.reentrant_x) if (int rc = halo_wrap_dir(ctx, f, pos, nk, 0, ctx->stream)) return rc;
+  if (G.reentrant_y) if (int rc = halo_wrap_dir(ctx, f, pos, nk, 1, ctx->stream)) return rc;
+  return 0;
+}
+
+// start_group_pass / complete_group_pass / do_group_pass (MOM_domain_infra.F90:1141-1182)
+int start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
+  if (ctx->native) return native_start_group_pass(ctx, fields, pos, nk, n);
+  if (ctx->halo_cb) {      // the host's collective
     if (!ctx->cb_stream_ordered) M6_HIP(hipStreamSynchronize(ctx->stream));
     M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, pos, nk, n) == 0, "group pass: the domain halo callback failed");
     return 0;
   }
-  for (int f = 0; f < n; f++)
+  for (int f = 0; f < n; f++)      // one tile: the local wrap kernels
     if (int rc = halo_update_field(ctx, fields[f], pos[f], nk[f])) return rc;
+  return 0;
+}
+
+int complete_group_pass(mom6hip_ctx_t *ctx) {
+  if (ctx->native) return native_complete_group_pass(ctx);
+  return 0;
+}
+
+int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
+  if (int rc = start_group_pass(ctx, fields, pos, nk, n)) return rc;
+  return complete_group_pass(ctx);
+}
+
+int sum_across_PEs(mom6hip_ctx_t *ctx, int32_t *values, int n) {
+  if (ctx->native) return native_allreduce(ctx, values, n, true);
+  if (ctx->sum_cb) M6_REQUIRE(ctx->sum_cb(ctx->cb_user, values, n) == 0, "the host's sum_across_PEs failed");
+  return 0;
+}
+
+int min_across_PEs(mom6hip_ctx_t *ctx, double *values, int n) {
+  if (ctx->native) return native_allreduce(ctx, values, n, false);
+  if (ctx->min_cb) M6_REQUIRE(ctx->min_cb(ctx->min_user, values, n) == 0, "the host's min_across_PEs failed");
   return 0;
 }
 
@@ -383,6 +415,7 @@ int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, co
 extern "C" int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,
                                    const int32_t *nk_each, int32_t nfields) {
   M6_REQUIRE(ctx && fields && pos && nk_each, "mom6hip_halo_update: null argument");
+  if (ctx->native) return m6::group_pass(ctx, fields, pos, nk_each, nfields);      // the library's own multi-tile group pass
   for (int f = 0; f < nfields; f++) {
     M6_REQUIRE(fields[f] != nullptr, "mom6hip_halo_update: field %d is null", f);
     int rc = m6::halo_update_field(ctx, fields[f], pos[f], nk_each[f]);
@@ -427,6 +460,12 @@ __global__ void __launch_bounds__(256) halo_pack_kernel(PackDesc d, double *__re
 extern "C" int mom6hip_halo_pack(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each,
                                  const int32_t *a0, int32_t nfields, int32_t dir, int32_t width, double *buf, int32_t pack,
                                  int64_t *count) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_halo_pack: null argument");
+  return m6::halo_pack_on(ctx, fields, pos, nk_each, a0, nfields, dir, width, buf, pack, count, ctx->stream);
+}
+
+int m6::halo_pack_on(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each, const int32_t *a0,
+                     int32_t nfields, int32_t dir, int32_t width, double *buf, int32_t pack, int64_t *count, hipStream_t stream) {
   M6_REQUIRE(ctx && fields && pos && nk_each && a0, "mom6hip_halo_pack: null argument");
   M6_REQUIRE(nfields >= 0 && nfields <= 24, "mom6hip_halo_pack: at most 24 fields per message");
   const mom6hip_grid_t &G = ctx->host;
@@ -446,7 +485,7 @@ extern "C" int mom6hip_halo_pack(mom6hip_ctx_t *ctx, double *const *fields, cons
   if (count) *count = d.off[nfields];
   if (d.off[nfields] == 0 || buf == nullptr) return 0;
   int blocks = (int)((d.off[nfields] + 255) / 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(halo_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d, buf);
+  hipLaunchKernelGGL(halo_pack_kernel, dim3(blocks), dim3(256), 0, stream, d, buf);
   M6_HIP(hipGetLastError());
   return 0;
 }

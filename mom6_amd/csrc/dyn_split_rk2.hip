@@ -14,7 +14,7 @@
 #include <utility>
 
 namespace m6 {
-int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
+
 }
 
 namespace {

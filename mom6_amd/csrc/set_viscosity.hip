@@ -302,13 +302,13 @@ int set_viscous_BBL_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, con
 }
 }  // namespace m6
 
-extern "C" int mom6hip_set_viscous_ML(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs) {
+extern "C" int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs) {
   M6_REQUIRE(ctx != nullptr && cs != nullptr, "MOM_set_viscosity(visc_ML): null argument");
   if (check_cs(cs, "MOM_set_viscosity(visc_ML)")) return 1;
   return 0;      // :2043-2044: nothing to do without DYNAMIC_VISCOUS_ML or an ice shelf
 }
 
-extern "C" int mom6hip_set_viscous_BBL(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+extern "C" int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
                                        const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
                                        const mom6hip_vertvisc_type_t *visc, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_set_viscosity(BBL): Module must be initialized before it is used.");

@@ -24,7 +24,7 @@
 
 #include "common.hpp"
 
-namespace m6 { int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk); }
+namespace m6 { int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk); }      // (group_pass etc.: common.hpp)
 
 namespace {
 
@@ -866,20 +866,11 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
     if (isv > is - stencil) {
       // do_group_pass(CS%pass_uhr_vhr_t_hprev), :206
       t_k.start();
-      if (ctx->halo_cb) {
-        // multi-tile domain: the host's group pass over every field of the group
+      {      // (one tile: the local wrap kernels; several: the native exchange or the host's group pass)
         std::vector<double *> flds = {uhr, vhr, hprev};
         std::vector<int32_t> pos = {MOM6HIP_POS_U, MOM6HIP_POS_V, MOM6HIP_POS_H}, nks = {nz, nz, nz};
         for (int m = 0; m < ntr; m++) { flds.push_back(d_tr[m]); pos.push_back(MOM6HIP_POS_H); nks.push_back(nz); }
-        if (!ctx->cb_stream_ordered) M6_HIP(hipStreamSynchronize(s));
-        M6_REQUIRE(ctx->halo_cb(ctx->cb_user, flds.data(), pos.data(), nks.data(), (int32_t)flds.size()) == 0,
-                   "advect_tracer: the host's halo update failed");
-      } else {
-        if (m6::halo_update_field(ctx, uhr, MOM6HIP_POS_U, nz) || m6::halo_update_field(ctx, vhr, MOM6HIP_POS_V, nz) ||
-            m6::halo_update_field(ctx, hprev, MOM6HIP_POS_H, nz))
-          return 1;
-        for (int m = 0; m < ntr; m++)
-          if (m6::halo_update_field(ctx, d_tr[m], MOM6HIP_POS_H, nz)) return 1;
+        if (int rc = m6::group_pass(ctx, flds.data(), pos.data(), nks.data(), (int)flds.size())) return rc;
       }
       halo_updates++;
       tm.ms_halo += t_k.stop();
@@ -925,9 +916,9 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
       // sum_across_PEs(domore_k), :305 -- the one host read-back per iteration
       M6_HIP(hipMemcpyAsync(ctx->h_domore_k, domore_k, nz * sizeof(int), hipMemcpyDeviceToHost, s));
       M6_HIP(hipStreamSynchronize(s));
-      if (ctx->sum_cb) {
+      if (m6::multi_tile(ctx)) {
         // domore_k becomes the global count and is what the next iteration tests (:215, :252)
-        M6_REQUIRE(ctx->sum_cb(ctx->cb_user, ctx->h_domore_k, nz) == 0, "advect_tracer: the host's sum_across_PEs failed");
+        if (int rc = m6::sum_across_PEs(ctx, ctx->h_domore_k, nz)) return rc;
         M6_HIP(hipMemcpyAsync(domore_k, ctx->h_domore_k, nz * sizeof(int), hipMemcpyHostToDevice, s));
       }
       remaining = 0;

@@ -37,7 +37,7 @@ def compute_extent(n_global: int, ndiv: int):
 class Domain:
     """MOM_domain_type for one tile of an (npi x npj) layout of a global (NI x NJ) grid."""
 
-    def __init__(self, NI, NJ, layout=(1, 1), rank=0, halo=4, reentrant_x=True, reentrant_y=False, group=None):
+    def __init__(self, NI, NJ, layout=(1, 1), rank=0, halo=4, reentrant_x=True, reentrant_y=False, group=None, self_exchange=False):
         self.NI, self.NJ = int(NI), int(NJ)
         self.npi, self.npj = int(layout[0]), int(layout[1])
         self.nranks = self.npi * self.npj
@@ -45,6 +45,9 @@ class Domain:
         self.halo = int(halo)
         self.reentrant_x, self.reentrant_y = bool(reentrant_x), bool(reentrant_y)
         self.group = group
+        # self_exchange: a re-entrant direction with ONE tile goes through the exchange with this rank as its own neighbour
+        # instead of the local wrap (rehearses the native RCCL path on a single GPU)
+        self.self_exchange = bool(self_exchange)
         self.pi, self.pj = self.rank % self.npi, self.rank // self.npi          # PE numbering: i fastest
         self.i_starts, self.i_sizes = compute_extent(self.NI, self.npi)
         self.j_starts, self.j_sizes = compute_extent(self.NJ, self.npj)
@@ -76,7 +79,8 @@ class Domain:
         if gg.ni != self.NI or gg.nj != self.NJ or gg.halo != self.halo:
             raise ValueError("tile_grid: global grid does not match the domain")
         t = Grid(ni=self.ni, nj=self.nj, nk=gg.nk, halo=self.halo,
-                 reentrant_x=self.reentrant_x and self.npi == 1, reentrant_y=self.reentrant_y and self.npj == 1,
+                 reentrant_x=self.reentrant_x and self.npi == 1 and not self.self_exchange,
+                 reentrant_y=self.reentrant_y and self.npj == 1 and not self.self_exchange,
                  first_direction=gg.first_direction, Angstrom_H=gg.Angstrom_H, H_to_Z=gg.H_to_Z, Z_to_H=gg.Z_to_H,
                  g_Earth=gg.g_Earth, Rho0=gg.Rho0)
         for name, a in gg.metrics.items():
@@ -106,6 +110,8 @@ class Domain:
         w = h if halo is None else min(int(halo), h)
         backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else None
         stage = backend == "gloo"      # gloo moves host memory only
+        if getattr(self, "native", False) and all(f.is_cuda for f in fields):
+            return self._dg.halo_update(fields, positions)      # the library's group pass (RCCL)
         if self._dg is not None and len(fields) <= 24 and all(f.is_cuda for f in fields):
             return self.pass_ptrs([f.data_ptr() for f in fields], positions, [1 if f.dim() == 2 else f.shape[0] for f in fields],
                                   w, stage)
@@ -252,6 +258,49 @@ class Domain:
                 local_wrap()
         else:
             exchange(1)
+
+    # ---- the native (RCCL) domain of the library -----------------------------------------------------------
+    def attach_native(self, dg):
+        """mom6hip_domain_init_rccl: the group passes and reductions inside library calls become the library's own RCCL
+        exchange on its communication stream (mom6_amd/csrc/domain_rccl.hip).  Rank 0 draws the RCCL unique id, the
+        process group (any backend) broadcasts it."""
+        import ctypes as C
+        from ._lib import check, lib
+        L = lib()
+        L.mom6hip_rccl_get_unique_id.argtypes = [C.c_void_p, C.c_int32]
+        L.mom6hip_domain_init_rccl.argtypes = [C.c_void_p, C.POINTER(_abi.DomainStruct), C.c_void_p, C.c_int32]
+        uid = np.zeros(128, dtype=np.uint8)
+        if self.rank == 0:
+            check(L.mom6hip_rccl_get_unique_id(uid.ctypes.data, 128), "mom6hip_rccl_get_unique_id")
+        if self.nranks > 1:
+            import torch.distributed as dist
+            t = torch.from_numpy(uid)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=self.group)
+            uid = t.cpu().numpy().copy()
+
+        def nb(dpi, dpj, ntile, reentrant):
+            if ntile == 1:
+                return self.rank if (self.self_exchange and reentrant) else -1
+            r = self._nbr(dpi, dpj)
+            return -1 if r is None else r
+        dom = _abi.DomainStruct(self.nranks, self.rank, nb(-1, 0, self.npi, self.reentrant_x), nb(+1, 0, self.npi, self.reentrant_x),
+                                nb(0, -1, self.npj, self.reentrant_y), nb(0, +1, self.npj, self.reentrant_y))
+        check(L.mom6hip_domain_init_rccl(dg.handle, C.byref(dom), uid.ctypes.data, 128), "mom6hip_domain_init_rccl")
+        self._dg = dg
+        dg.domain = self
+        self.native = True
+
+    def exchange_timing(self, enable=True):
+        """(ms, passes) of the native exchanges since the last call (mom6hip_domain_exchange_timing)."""
+        import ctypes as C
+        from ._lib import check, lib
+        L = lib()
+        L.mom6hip_domain_exchange_timing.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(L.mom6hip_domain_exchange_timing(self._dg.handle, int(enable), C.byref(ms), C.byref(n)), "mom6hip_domain_exchange_timing")
+        return ms.value, n.value
 
     # ---- reductions (MOM_coms) -------------------------------------------------------------------------
     def sum_across_PEs(self, t: torch.Tensor):

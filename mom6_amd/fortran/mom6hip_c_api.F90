@@ -121,6 +121,28 @@ type, bind(c) :: mom6hip_vertvisc_type_t
   type(c_ptr) :: reserved(4)
 end type mom6hip_vertvisc_type_t
 
+!> mom6hip_set_visc_cs_t (set_visc_CS, src/parameterizations/vertical/MOM_set_viscosity.F90:48)
+type, bind(c) :: mom6hip_set_visc_cs_t
+  real(c_double) :: cdrag, drag_bg_vel, Hbbl, dz_bbl, BBL_thick_min, Kv_BBL_min, BBL_thick_max, H_to_RZ
+  real(c_double) :: reserved0(8)
+  integer(c_int32_t) :: bottomdraglaw, linear_drag, BBL_use_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix, initialized
+  integer(c_int32_t) :: unsupported(9)
+  type(c_ptr) :: Rlay           !< c_loc of GV%Rlay (host), read without BBL_USE_EOS
+  type(c_ptr) :: reserved1(3)
+end type mom6hip_set_visc_cs_t
+
+!> mom6hip_hor_visc_cs_t (hor_visc_CS, src/parameterizations/lateral/MOM_hor_visc.F90:40)
+type, bind(c) :: mom6hip_hor_visc_cs_t
+  real(c_double) :: Kh, Kh_bg_min, Kh_vel_scale, Smag_Lap_const, Ah, Ah_vel_scale, Ah_time_scale, Smag_bi_const, bound_Cor_vel, bound_coef
+  real(c_double) :: reserved0(6)
+  integer(c_int32_t) :: Laplacian, biharmonic, Smagorinsky_Kh, Smagorinsky_Ah, bound_Kh, better_bound_Kh, bound_Ah, better_bound_Ah, &
+                        bound_Coriolis, add_LES_viscosity, no_slip, use_land_mask, use_cont_thick, initialized
+  integer(c_int32_t) :: unsupported(10)
+  type(c_ptr) :: Kh_bg_xx, Kh_Max_xx, Ah_bg_xx, Ah_Max_xx, Laplac2_const_xx, Biharm_const_xx, Biharm_const2_xx, reduction_xx
+  type(c_ptr) :: Kh_bg_xy, Kh_Max_xy, Ah_bg_xy, Ah_Max_xy, Laplac2_const_xy, Biharm_const_xy, Biharm_const2_xy, reduction_xy
+  type(c_ptr) :: reserved1(4)
+end type mom6hip_hor_visc_cs_t
+
 !> mom6hip_dyn_split_rk2_cs_t (MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84); every array is a DEVICE
 !! array obtained from mom6hip_malloc
 type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
@@ -130,7 +152,7 @@ type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
   type(c_ptr) :: continuity_CSp, CoriolisAdv, PressureForce_CSp, eqn_of_state, barotropic_CSp, BT_cont, hooks
   type(c_ptr) :: vertvisc_CSp   !< c_loc of a mom6hip_vertvisc_cs_t, or c_null_ptr
   type(c_ptr) :: visc           !< c_loc of a mom6hip_vertvisc_type_t (the visc argument of the step)
-  type(c_ptr) :: reserved1(1)
+  type(c_ptr) :: hor_visc       !< c_loc of a mom6hip_hor_visc_cs_t, or c_null_ptr
   type(c_ptr) :: CAu, CAv, CAu_pred, CAv_pred, PFu, PFv, diffu, diffv, visc_rem_u, visc_rem_v, u_accel_bt, v_accel_bt, &
                  u_av, v_av, h_av, pbce
   type(c_ptr) :: eta, eta_PF, uhbt, vhbt
@@ -426,6 +448,45 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_vertvisc_remnant
+
+  !> set_viscous_BBL (MOM_set_viscosity.F90:134); tv%T, tv%S, tv%eqn_of_state as T, S, eos
+  function mom6hip_set_viscous_bbl(ctx, cs, u, v, h, T, S, eos, visc, memspace) bind(c, name="mom6hip_set_viscous_bbl") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_set_visc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, u, v, h, T, S, eos
+    type(mom6hip_set_visc_cs_t), intent(in) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_set_viscous_bbl
+
+  !> set_viscous_ML (:1898): the reference's early return (:2043)
+  function mom6hip_set_viscous_ml(ctx, cs) bind(c, name="mom6hip_set_viscous_ml") result(rc)
+    import :: c_int, c_ptr, mom6hip_set_visc_cs_t
+    type(c_ptr), value :: ctx
+    type(mom6hip_set_visc_cs_t), intent(in) :: cs
+    integer(c_int) :: rc
+  end function mom6hip_set_viscous_ml
+
+  !> hor_visc_init (MOM_hor_visc.F90:1984): the static arrays of the control structure
+  function mom6hip_hor_visc_init(ctx, cs, dt, memspace) bind(c, name="mom6hip_hor_visc_init") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_hor_visc_cs_t
+    type(c_ptr), value :: ctx
+    type(mom6hip_hor_visc_cs_t), intent(inout) :: cs
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_hor_visc_init
+
+  !> horizontal_viscosity (:245)
+  function mom6hip_horizontal_viscosity(ctx, cs, u, v, h, diffu, diffv, dt, hu_cont, hv_cont, memspace) &
+                                        bind(c, name="mom6hip_horizontal_viscosity") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_hor_visc_cs_t
+    type(c_ptr), value :: ctx, u, v, h, diffu, diffv, hu_cont, hv_cont
+    type(mom6hip_hor_visc_cs_t), intent(in) :: cs
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_horizontal_viscosity
 
   function mom6hip_dyn_split_rk2_init(ctx, cs, u, v, h, uh, vh, dt) bind(c, name="mom6hip_dyn_split_rk2_init") result(rc)
     import :: c_int, c_double, c_ptr, mom6hip_dyn_split_rk2_cs_t

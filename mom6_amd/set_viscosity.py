@@ -1,0 +1,90 @@
+"""Host-side mirror of MOM_set_viscosity (reference: src/parameterizations/vertical/MOM_set_viscosity.F90): set_visc_init
+(:2886), set_viscous_BBL (:134), set_viscous_ML (:1898).  The work is done by libmom6hip (mom6_amd/csrc/set_viscosity.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+from .tracer_advect import DeviceGrid, _ptr_space
+
+_UNSUPPORTED = {"CHANNEL_DRAG": "Channel_drag", "BBL_USE_TIDAL_BG": "BBL_use_tidal_bg", "DYNAMIC_VISCOUS_ML": "dynamic_viscous_ML",
+                "NKML": "nkml", "NON_BOUSSINESQ": "non_Boussinesq"}
+
+
+def _setup():
+    L = lib()
+    if not getattr(L, "_sv_ready", False):
+        cs = C.POINTER(_abi.SetViscCS)
+        L.mom6hip_set_viscous_bbl.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [C.POINTER(_abi.EOS), C.POINTER(_abi.VertviscType), C.c_int32]
+        L.mom6hip_set_viscous_ml.argtypes = [C.c_void_p, cs]
+        L._sv_ready = True
+    return L
+
+
+class set_visc_CS:
+    """set_visc_CS (:48-130) as set by set_visc_init: parameters by their reference names (defaults :2920-3130)."""
+
+    def __init__(self, G: DeviceGrid, HBBL, KV, CDRAG=0.003, DRAG_BG_VEL=0.0, BBL_THICK_MIN=0.0, KV_BBL_MIN=None, BOTTOMDRAGLAW=True,
+                 LINEAR_DRAG=False, BBL_USE_EOS=True, CORRECT_BBL_BOUNDS=False, DRAG_AS_BODY_FORCE=False, USE_JACKSON_PARAM=False,
+                 Rlay=None, **unsupported):
+        g = G.grid if isinstance(G, DeviceGrid) else G
+        st = self.st = _abi.SetViscCS()
+        for k, v in unsupported.items():
+            if k not in _UNSUPPORTED:
+                raise Mom6HipError(f"set_visc_init: unknown parameter {k}")
+            st.unsupported[_abi.SET_VISC_UNSUPPORTED.index(_UNSUPPORTED[k])] = int(bool(v))
+        st.cdrag, st.drag_bg_vel, st.dz_bbl = float(CDRAG), float(DRAG_BG_VEL), float(HBBL)
+        st.Hbbl = float(HBBL) * g.Z_to_H      # :3127
+        st.BBL_thick_min = float(BBL_THICK_MIN)
+        st.Kv_BBL_min = float(KV if KV_BBL_MIN is None else KV_BBL_MIN)
+        st.BBL_thick_max = 6.378e6            # G%Rad_Earth_L * US%L_to_Z
+        st.H_to_RZ = g.Rho0 * g.H_to_Z
+        st.bottomdraglaw, st.linear_drag, st.BBL_use_EOS = int(bool(BOTTOMDRAGLAW)), int(bool(LINEAR_DRAG)), int(bool(BBL_USE_EOS))
+        st.correct_BBL_bounds, st.body_force_drag = int(bool(CORRECT_BBL_BOUNDS)), int(bool(DRAG_AS_BODY_FORCE))
+        st.RiNo_mix = int(bool(USE_JACKSON_PARAM))      # kappa_shear_is_used (:2954)
+        if Rlay is not None:
+            self._rlay = np.ascontiguousarray(Rlay, dtype=np.float64)
+            if self._rlay.shape != (g.nk,):
+                raise Mom6HipError("set_visc_init: GV%Rlay must have one entry per layer")
+            st.Rlay = self._rlay.ctypes.data
+        st.initialized = 1
+
+
+def set_visc_init(G: DeviceGrid, **params) -> set_visc_CS:
+    """set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS, OBC) -- :2886."""
+    return set_visc_CS(G, **params)
+
+
+def set_viscous_BBL(u, v, h, tv, visc, G: DeviceGrid, CS: set_visc_CS, pbv=None):
+    """set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv) -- :134.  tv = (T, S, EOS) or None; visc is a
+    vert_friction.vertvisc_type whose bbl_thick_u/v, Kv_bbl_u/v (and Ray_u/v) are set."""
+    if CS is None or not CS.st.initialized:
+        raise Mom6HipError("MOM_set_viscosity(BBL): Module must be initialized before it is used.")
+    if pbv is not None:
+        raise Mom6HipError("set_viscous_BBL (HIP): porous barriers are not supported on this path")
+    T, S, EOS = tv if tv is not None else (None, None, None)
+    spaces = set()
+    ptrs = []
+    for a in (u, v, h, T, S):
+        if a is None:
+            ptrs.append(None)
+            continue
+        p, s = _ptr_space(a)
+        spaces.add(s); ptrs.append(C.c_void_p(p))
+    if visc.space is not None:
+        spaces.add(visc.space)
+    if len(spaces) != 1:
+        raise Mom6HipError("set_viscous_BBL: the fields and visc must be in the same memory space")
+    check(_setup().mom6hip_set_viscous_bbl(G.handle, C.byref(CS.st), *ptrs, None if EOS is None else C.byref(EOS), C.byref(visc.st),
+                                           spaces.pop()), "set_viscous_BBL")
+
+
+def set_viscous_ML(u, v, h, tv, forces, visc, dt, G: DeviceGrid, CS: set_visc_CS):
+    """set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS) -- :1898: returns at once unless DYNAMIC_VISCOUS_ML or an
+    ice shelf is present (:2043), which this build refuses."""
+    if CS is None or not CS.st.initialized:
+        raise Mom6HipError("MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
+    check(_setup().mom6hip_set_viscous_ml(G.handle, C.byref(CS.st)), "set_viscous_ML")

@@ -23,6 +23,7 @@ H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
 SIZES = {"benchmark": (360, 180, 75), "om4_band": (1440, 64, 75), "tall": (48, 1080, 3)}
 DT = 900.0
 VV = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
+HV = dict(Ah_vel_scale=0.01, Smagorinsky_Ah=1, Smag_bi_const=0.06)      # the model's horizontal viscosity (biharmonic Smagorinsky)
 CONT_VARIANTS = OrderedDict([
     ("plain", dict(cs={}, uhbt=False, bt=False, visc=False)),
     ("bt_cont", dict(cs={}, uhbt=False, bt=True, visc=True)),
@@ -120,12 +121,25 @@ class OracleOps:
         orc.vertvisc_remnant(g, cs, visc, vru, vrv, dt)
         return dict(u=u, v=v, visc_rem_u=vru, visc_rem_v=vrv, a_u=cs._arrs["a_u"], a_v=cs._arrs["a_v"], h_u=cs._arrs["h_u"])
 
+    def hor_visc(self, u, v, h, dt, **kw):
+        orc, g = self.orc, self.g
+        cs = orc.hor_visc_cs(g, dt, **kw)
+        du, dv = orc.horizontal_viscosity(g, cs, u, v, h, dt)
+        return dict(diffu=du, diffv=dv, Ah_Max_xx=cs._arrs["Ah_Max_xx"], Ah_Max_xy=cs._arrs["Ah_Max_xy"], Kh_Max_xx=cs._arrs["Kh_Max_xx"])
+
+    def set_viscous_BBL(self, u, v, h, T, S, **kw):
+        orc, g = self.orc, self.g
+        arrs = dict(Kv_bbl_u=g.zeros2(U), Kv_bbl_v=g.zeros2(V), bbl_thick_u=g.zeros2(U), bbl_thick_v=g.zeros2(V))
+        visc = orc.vertvisc_type(**arrs)
+        orc.set_viscous_BBL(g, orc.set_visc_cs(g, VV["HBBL"], VV["KV"], **kw), u, v, h, T, S, orc.eos("WRIGHT"), visc)
+        return visc._keep
+
     # the time-stepping model
     def model_init(self, d, bbl, dt):
         orc, g = self.orc, self.g
         self.st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt,
                                vertvisc=orc.vertvisc_cs(g, Kv=VV["KV"], Hbbl=VV["HBBL"], Hmix=VV["HMIX_FIXED"], Kvml_invZ2=VV["KV_ML_INVZ2"]),
-                               visc=orc.vertvisc_type(**bbl))
+                               visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **HV))
 
     def model_step(self, taux, tauy, calc_dtbt):
         self.st.step(taux, tauy, calc_dtbt=calc_dtbt)
@@ -133,7 +147,7 @@ class OracleOps:
     def model_fields(self):
         s = self.st
         out = OrderedDict(u=s.u, v=s.v, h=s.h, uh=s.uh, vh=s.vh, uhtr=s.uhtr, vhtr=s.vhtr, eta_av=s.eta_av)
-        for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt"):
+        for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt", "diffu", "diffv"):
             out[n] = s.arrs[n]
         out["nstep_dtbt"] = np.array([float(s.bcs.nstep_last), s.bcs.dtbt])
         return out
@@ -270,6 +284,27 @@ class HipOps:
         N = self.N
         return dict(u=N(du), v=N(dv), visc_rem_u=N(vru), visc_rem_v=N(vrv), a_u=N(CS.a_u), a_v=N(CS.a_v), h_u=N(CS.h_u))
 
+    def hor_visc(self, u, v, h, dt, **kw):
+        from mom6_amd.hor_visc import hor_visc_init, horizontal_viscosity
+        from test_hor_visc import REF_NAMES
+        T, Z, N = self.T, self.Z, self.N
+        CS = hor_visc_init(self.dg, dt, **{REF_NAMES[k]: x for k, x in kw.items()})
+        du, dv = Z(U), Z(V)
+        horizontal_viscosity(T(u), T(v), T(h), du, dv, None, None, self.dg, CS)
+        return dict(diffu=N(du), diffv=N(dv), Ah_Max_xx=N(CS.Ah_Max_xx), Ah_Max_xy=N(CS.Ah_Max_xy), Kh_Max_xx=N(CS.Kh_Max_xx))
+
+    def set_viscous_BBL(self, u, v, h, T_, S, **kw):
+        from mom6_amd.pressure_force import EOS_init
+        from mom6_amd.set_viscosity import set_visc_init, set_viscous_BBL
+        from mom6_amd.vert_friction import vertvisc_type
+        from test_set_viscosity import REF
+        T, Z, N = self.T, self.Z, self.N
+        arrs = dict(Kv_bbl_u=Z(U, False), Kv_bbl_v=Z(V, False), bbl_thick_u=Z(U, False), bbl_thick_v=Z(V, False))
+        visc = vertvisc_type(**arrs)
+        CS = set_visc_init(self.dg, HBBL=VV["HBBL"], KV=VV["KV"], **{REF[k]: x for k, x in kw.items()})
+        set_viscous_BBL(T(u), T(v), T(h), (T(T_), T(S), EOS_init("WRIGHT")), visc, self.dg, CS)
+        return {n: N(a) for n, a in arrs.items()}
+
     def model_init(self, d, bbl, dt):
         from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2
         from mom6_amd.vert_friction import vertvisc_type
@@ -277,8 +312,9 @@ class HipOps:
         m = self.m = dict(u=T(d["u"]), v=T(d["v"]), h=T(d["h"]), T=T(d["T"]), S=T(d["S"]), uh=Z(U), vh=Z(V), uhtr=Z(U), vhtr=Z(V),
                           eta_av=Z(H, False))
         self.dt = dt
+        from test_hor_visc import REF_NAMES
         self.CS = initialize_dyn_split_RK2(m["u"], m["v"], m["h"], m["uh"], m["vh"], dt, self.dg, coriolis=dict(bound_coriolis=True),
-                                           vertvisc=VV)
+                                           vertvisc=VV, hor_visc={REF_NAMES[k]: x for k, x in HV.items()})
         self.visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
 
     def model_step(self, taux, tauy, calc_dtbt):
@@ -292,7 +328,7 @@ class HipOps:
     def model_fields(self):
         m, N = self.m, self.N
         out = OrderedDict((n, N(m[n])) for n in ("u", "v", "h", "uh", "vh", "uhtr", "vhtr", "eta_av"))
-        for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt"):
+        for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt", "diffu", "diffv"):
             out[n] = N(self.CS.arrays[n])
         st = self.CS.barotropic_CSp.st
         out["nstep_dtbt"] = np.array([float(st.nstep_last), st.dtbt])
@@ -385,6 +421,18 @@ def operators(ops, g, d, taux, tauy, bbl, only=None):
                 yield f"ALE[{scheme}].{k}", r[k]
             for m, a in enumerate(r["tr"]):
                 yield f"ALE[{scheme}].tr{m}", a
+    if want("hor_visc"):
+        for nm, kw in (("biharm_smag", HV), ("lap_biharm", dict(Laplacian=1, Kh_vel_scale=0.01, Smagorinsky_Kh=1, Smag_Lap_const=0.15,
+                                                                 Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06, bound_Coriolis=1,
+                                                                 bound_Cor_vel=6.0))):
+            r = ops.hor_visc(d["u"], d["v"], d["h"], DT, **kw)
+            for k, a in r.items():
+                yield f"hor_visc[{nm}].{k}", a
+    if want("set_viscous_BBL"):
+        for nm, kw in (("default", {}), ("bg_vel_bounds", dict(drag_bg_vel=0.05, BBL_thick_min=0.5, correct_BBL_bounds=True))):
+            r = ops.set_viscous_BBL(d["u"], d["v"], d["h"], d["T"], d["S"], **kw)
+            for k, a in r.items():
+                yield f"set_viscous_BBL[{nm}].{k}", a
     if want("vertvisc"):
         for nm, kw in (("default", {}), ("harmonic_direct", dict(harmonic_visc=True, direct_stress=True, Kv_extra_bbl=1.0e-4))):
             r = ops.vertvisc(d["u"], d["v"], d["h"], taux, tauy, bbl, DT, **kw)
@@ -395,9 +443,12 @@ def operators(ops, g, d, taux, tauy, bbl, only=None):
 def model(ops, g, dm, taux, tauy, bbl, nsteps=2):
     """initialize_dyn_split_RK2, nsteps x step_MOM_dyn_split_RK2 (vertical viscosity on, DTBT set in the first step), then
     the thermodynamic block: advect_tracer over the accumulated transports and the ALE regrid / remap"""
+    bbl = ops.set_viscous_BBL(dm["u"], dm["v"], dm["h"], dm["T"], dm["S"])      # MOM.F90:1205, before the dynamic steps
+    for k, a in bbl.items():
+        yield f"model.set_viscous_BBL.{k}", a
     ops.model_init(dm, bbl, DT)
     for k, a in ops.model_fields().items():
-        if k in ("eta", "h_av", "u_av", "CAu_pred", "uh"):
+        if k in ("eta", "h_av", "u_av", "CAu_pred", "uh", "diffu"):
             yield f"model.init.{k}", a
     for n in range(nsteps):
         ops.model_step(taux, tauy, calc_dtbt=(n == 0))

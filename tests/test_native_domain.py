@@ -1,0 +1,97 @@
+"""The library's own group pass over RCCL (mom6_amd/csrc/domain_rccl.hip), rehearsed on ONE GPU: a one-tile domain whose
+re-entrant directions go through ncclSend / ncclRecv with the rank as its own neighbour (Domain(self_exchange=True)) instead
+of the local wrap kernels.  Packing, the message order, the communication stream and its events, the reductions -- all
+of the native path except a second device -- are exercised, and the results must equal the oracle's bit for bit.  (The
+neighbour logic itself is covered by the two-rank gloo tests of tests/test_domains.py.)"""
+import numpy as np
+import pytest
+
+import exact_synth as xs
+from helpers import bits_equal
+from mom6_amd import _abi
+from oracle import orc
+
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+
+
+def native_grid(g):
+    import torch  # noqa: F401
+    from mom6_amd.domains import Domain
+    from mom6_amd.tracer_advect import DeviceGrid
+    dom = Domain(g.ni, g.nj, (1, 1), 0, g.halo, g.reentrant_x, g.reentrant_y, self_exchange=True)
+    tg = dom.tile_grid(g)
+    assert not tg.reentrant_x and not tg.reentrant_y
+    dg = DeviceGrid(tg)
+    dom.attach_native(dg)
+    return dom, dg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("topo", [(True, False), (True, True), (False, True)])
+def test_halo_update_through_rccl_self_exchange(topo):
+    import torch
+    g = xs.make_grid(37, 23, 3, reentrant_x=topo[0], reentrant_y=topo[1])
+    dom, dg = native_grid(g)
+    rng = np.random.default_rng(3)
+    fields, poss, expect = [], [], []
+    for pos in (H, U, V, _abi.POS_Q):
+        for three_d in (True, False):
+            shp = g.shape3(pos) if three_d else g.shape2(pos)
+            a = rng.standard_normal(shp)
+            sj, si = g.csl(pos)
+            if topo[0] and pos in (U, _abi.POS_Q):
+                a[..., sj, g.halo] = a[..., sj, g.halo + g.ni]
+            if topo[1] and pos in (V, _abi.POS_Q):
+                a[..., g.halo, si] = a[..., g.halo + g.nj, si]
+            e = a.copy(); orc.halo_update(g, e, pos)
+            fields.append(torch.from_numpy(a).cuda()); poss.append(pos); expect.append(e)
+    dom.exchange_timing(True)
+    dg.halo_update(fields, poss)
+    dg.sync()
+    ms, n = dom.exchange_timing(False)
+    assert n == 1 and ms > 0.0
+    for f, e, pos in zip(fields, expect, poss):
+        assert bits_equal(f.cpu().numpy(), e), (topo, pos, f.dim())
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_model_steps_through_the_native_exchange():
+    """initialize + two RK2 steps (both viscosities) + advect_tracer on a re-entrant grid, every group pass and both
+    reductions going through RCCL: the oracle's bits"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import advect_tracer, tracer_advect_init
+    from mom6_amd.vert_friction import vertvisc_type
+    g = xs.make_grid(44, 40, 4, reentrant_x=True, reentrant_y=True, land_frac=0.2)
+    d = xs.make_state(g, umax=0.1, terrain_following=True)
+    taux, tauy = xs.wind_stress(g); bbl = xs.bbl_arrays(g)
+    dt = 1800.0
+    hv = dict(Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0),
+                       visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **hv))
+    dom, dg = native_grid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0),
+                                  hor_visc=dict(AH_VEL_SCALE=0.05, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06))
+    visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
+    tx, ty = T(taux), T(tauy)
+    for n in range(2):
+        ref.step(taux, tauy, calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        assert CS.barotropic_CSp.st.dtbt == ref.bcs.dtbt
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uhtr", uhtr, ref.uhtr), ("eta_av", eta_av, ref.eta_av)):
+            assert bits_equal(a.cpu().numpy(), b), (n, name)
+    tr = [Tt.clone(), Ss.clone()]
+    rtr = [ref.T.copy(), ref.S.copy()]
+    st = advect_tracer(h, uhtr, vhtr, None, 2 * dt, dg, tracer_advect_init(dt, "PPM:H3"), tr)
+    rst = orc.advect_tracer(g, ref.h, ref.uhtr, ref.vhtr, 2 * dt, dt, "PPM:H3", rtr)
+    dg.sync()
+    assert st.iterations == rst.iterations
+    for a, b in zip(tr, rtr):
+        assert bits_equal(a.cpu().numpy(), b)
+    dg.close()

@@ -1,0 +1,126 @@
+"""set_viscous_BBL / set_viscous_ML (second half): CPU checks of the oracle (oracle/set_viscosity.c) and GPU
+parity of libmom6hip against it (bit-exact fp64).  The reference holds no known-answer vectors for MOM_set_viscosity (parity
+unpinned)."""
+import numpy as np
+import pytest
+
+import exact_synth as xs
+from helpers import bits_equal, interior
+from mom6_amd import _abi
+from oracle import orc
+
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+VARIANTS = {
+    "default": dict(),
+    "rlay": dict(BBL_use_EOS=False),
+    "linear_drag": dict(linear_drag=True, drag_bg_vel=0.1),
+    "bg_vel": dict(drag_bg_vel=0.05, BBL_thick_min=0.5),
+    "body_force": dict(body_force_drag=True),
+    "correct_bounds": dict(correct_BBL_bounds=True, BBL_thick_min=0.1, Kv_BBL_min=2.0e-3),
+    "rino_mix": dict(RiNo_mix=True),
+}
+REF = dict(BBL_use_EOS="BBL_USE_EOS", linear_drag="LINEAR_DRAG", drag_bg_vel="DRAG_BG_VEL", BBL_thick_min="BBL_THICK_MIN",
+           body_force_drag="DRAG_AS_BODY_FORCE", correct_BBL_bounds="CORRECT_BBL_BOUNDS", Kv_BBL_min="KV_BBL_MIN", RiNo_mix="USE_JACKSON_PARAM")
+
+
+def visc_arrays(g, d):
+    su, sv = g.shape2(U), g.shape2(V)
+    return dict(Kv_bbl_u=np.zeros(su), Kv_bbl_v=np.zeros(sv), bbl_thick_u=np.zeros(su), bbl_thick_v=np.zeros(sv),
+                Ray_u=np.zeros_like(d["u"]), Ray_v=np.zeros_like(d["v"]))
+
+
+def rlay(nk):
+    return 1025.0 + 0.5 * np.arange(nk)
+
+
+def run_oracle(g, d, **kw):
+    arrs = visc_arrays(g, d)
+    visc = orc.vertvisc_type(**arrs)
+    if not kw.get("BBL_use_EOS", True):
+        kw = dict(kw, Rlay=rlay(g.nk))
+    cs = orc.set_visc_cs(g, 10.0, 1.0e-4, **kw)
+    orc.set_viscous_BBL(g, cs, d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), visc)
+    return visc._keep
+
+
+def test_bbl_is_sane_and_scales_with_the_flow():
+    g = xs.make_grid(40, 28, 12)
+    d = xs.make_state(g, umax=0.3)
+    a = run_oracle(g, d)
+    mu = interior(g, g.mask2dCu, U) > 0
+    bt, kv = interior(g, a["bbl_thick_u"], U)[mu], interior(g, a["Kv_bbl_u"], U)[mu]
+    assert np.all(np.isfinite(bt)) and bt.min() >= 0.0 and bt.max() < 200.0
+    assert kv.min() >= 1.0e-4 and kv.max() < 1.0      # never below KV_BBL_MIN
+    # land faces are untouched
+    assert np.all(interior(g, a["bbl_thick_u"], U)[~mu] == 0.0)
+    # a faster flow has a larger friction velocity: kv = cdrag_sqrt*ustar*bbl_thick grows
+    d2 = dict(d, u=d["u"] * 3.0, v=d["v"] * 3.0)
+    b = run_oracle(g, d2)
+    assert interior(g, b["Kv_bbl_u"], U)[mu].mean() > 1.5 * kv.mean()
+
+
+def test_linear_drag_gives_the_analytic_ustar():
+    """LINEAR_DRAG: ustar = sqrt(cdrag)*DRAG_BG_VEL everywhere; with an unstratified column (the layer densities all equal)
+    and f = 0 the layer reaches the surface: bbl_thick = the column's thickness at the face (:815-822 with C2f = 0)"""
+    g = xs.make_grid(24, 16, 6, land_frac=0.0, flat_bottom=True, max_depth=600.0, beta_plane=True)
+    g.CoriolisBu[:] = 0.0
+    g._struct = None
+    d = xs.make_state(g, umax=0.1, vanish_frac=0.0)
+    arrs = visc_arrays(g, d)
+    visc = orc.vertvisc_type(**arrs)
+    cs = orc.set_visc_cs(g, 10.0, 1.0e-4, linear_drag=True, drag_bg_vel=0.1, BBL_use_EOS=False, Rlay=np.full(6, 1030.0))
+    orc.set_viscous_BBL(g, cs, d["u"], d["v"], d["h"], d["T"], d["S"], None, visc)
+    a = visc._keep
+    sj, si = g.csl(U)
+    ustar = np.sqrt(0.003) * 0.1
+    bt = a["bbl_thick_u"][sj, si]
+    assert np.allclose(a["Kv_bbl_u"][sj, si], np.sqrt(0.003) * ustar * bt, rtol=1e-14)
+    tot = d["h"].sum(0)
+    col = 0.5 * (tot[:, :-1] + tot[:, 1:])[g.csl(H)[0], g.halo - 1:g.halo + g.ni]
+    assert np.all(np.abs(bt - col) < 0.02 * col)      # (the upwind-biased harmonic mean differs a little from the arithmetic one)
+
+
+def test_set_viscous_ML_is_the_reference_no_op_and_refuses_the_rest():
+    g = xs.make_grid(12, 10, 3)
+    cs = orc.set_visc_cs(g, 10.0, 1.0e-4)
+    L = orc.lib()
+    import ctypes as C
+    L.orc_set_viscous_ML.argtypes = [C.POINTER(_abi.SetViscCS)]
+    assert L.orc_set_viscous_ML(C.byref(cs)) == 0
+    cs2 = orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True)
+    assert L.orc_set_viscous_ML(C.byref(cs2)) != 0
+    cs3 = orc.set_visc_cs(g, 10.0, 1.0e-4, Channel_drag=True)
+    d = xs.make_state(g)
+    with pytest.raises(RuntimeError):
+        orc.set_viscous_BBL(g, cs3, d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), orc.vertvisc_type(**visc_arrays(g, d)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_gpu_parity(name):
+    import torch
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.set_viscosity import set_visc_init, set_viscous_BBL, set_viscous_ML
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    kw = VARIANTS[name]
+    for (ni, nj, nk, topo) in [(70, 21, 8, (True, False)), (44, 40, 2, (True, True)), (10, 8, 30, (False, False)), (200, 9, 75, (True, False))]:
+        g = xs.make_grid(ni, nj, nk, reentrant_x=topo[0], reentrant_y=topo[1])
+        d = xs.make_state(g, umax=0.3)
+        ref = run_oracle(g, d, **kw)
+        dg = DeviceGrid(g)
+        pk = {REF[k]: v for k, v in kw.items()}
+        if not kw.get("BBL_use_EOS", True):
+            pk["Rlay"] = rlay(nk)
+        CS = set_visc_init(dg, HBBL=10.0, KV=1.0e-4, **pk)
+        for resident in (True, False):
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a.copy())
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            arrs = {n: X(a) for n, a in visc_arrays(g, d).items()}
+            visc = vertvisc_type(**arrs)
+            set_viscous_BBL(X(d["u"]), X(d["v"]), X(d["h"]), (X(d["T"]), X(d["S"]), EOS_init("WRIGHT")), visc, dg, CS)
+            set_viscous_ML(None, None, None, None, None, visc, 900.0, dg, CS)
+            dg.sync()
+            for n in ("bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "Ray_u", "Ray_v"):
+                assert bits_equal(N(arrs[n]), ref[n]), (name, (ni, nj, nk), resident, n, np.argwhere(N(arrs[n]) != ref[n])[:3])
+        dg.close()

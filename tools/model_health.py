@@ -1,0 +1,30 @@
+"""Health of the time-stepping model of bench.py over a longer run (one GPU): max |u|, max |eta|, mean kinetic energy and
+velocity truncations every few steps, for a given bathymetric roughness.
+    python tools/model_health.py --steps 48 --rough 0.04 [--workload om4_025]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from mom6_amd import synth
+from mom6_amd.domains import Domain
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=48); ap.add_argument("--every", type=int, default=4)
+ap.add_argument("--rough", type=float, default=bench.ROUGH_NOISE); ap.add_argument("--workload", default="om4_025")
+ap.add_argument("--land", type=float, default=bench.LAND_FRAC)
+a = ap.parse_args()
+NI, NJ, NK = bench.shape_of(a.workload)
+grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=a.land, rough_noise=a.rough)
+dom = Domain(NI, NJ, (1, 1), 0, grid.halo, grid.reentrant_x, grid.reentrant_y)
+M = bench.Model(grid, dom, torch.device("cuda", 0), bench.SCHEME)
+print(json.dumps(dict(step=0, **M.health())), flush=True)
+from mom6_amd.vert_friction import vertvisc_ntrunc
+for n in range(a.steps):
+    M.step()
+    if (n + 1) % a.every == 0:
+        h = M.health()
+        au = M.u.abs(); idx = int(au.argmax()); k, r = divmod(idx, au.shape[1] * au.shape[2]); j, i = divmod(r, au.shape[2])
+        h.update(step=n + 1, ntrunc=int(vertvisc_ntrunc(M.dg, M.CS.vertvisc_CSp)), umax_at=(k, j, i))
+        print(json.dumps(h), flush=True)
+        if h["nan"]:
+            break
