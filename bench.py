@@ -40,7 +40,13 @@ SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
 LAND_FRAC = 0.30
-ROUGH_NOISE = 0.04         # grid-scale bathymetric roughness (fraction of the depth range)
+# grid-scale bathymetric roughness (white noise, as a fraction of the depth range) with a fixed SLOPE: 0.04 on a 3-degree
+# grid, 0.0025 (14 m rms) at 1/4 degree.  With the amplitude held at 0.04 the 1/4-degree bathymetry had 200 m steps between
+# neighbouring cells and the run went to 5 m/s within 16 steps (tools/model_health.py).
+def rough_noise(ni):
+    return min(0.04, 3.6 / ni)
+
+
 # the synthetic state (mom6_amd/synth.py): z* layers over the rough bathymetry -- every layer below the local bottom is
 # vanished (Angstrom thick) --, a stratification that is a function of depth, so the state is close to rest balance
 STATE = dict(umax=0.1, eta_amp=0.2, terrain_following=False, vanish_frac=0.0, h_noise=1.0e-3)
@@ -68,7 +74,7 @@ def shape_of(name):
 class Model:
     """The time-stepping model on one tile of the global grid: prognostic state, control structures, and step()."""
 
-    def __init__(self, gg, dom, device, scheme):
+    def __init__(self, gg, dom, device, scheme, exchange="python"):
         from mom6_amd import _abi, synth
         from mom6_amd.ale import initialize_remapping
         from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2
@@ -76,8 +82,27 @@ class Model:
         self.dom = dom
         grid = self.g = dom.tile_grid(gg) if dom.nranks > 1 else gg
         self.dg = DeviceGrid(grid, device=device.index)
+        self.exchange = exchange
         if dom.nranks > 1:
-            self.dg.set_domain(dom)
+            if exchange == "rccl":      # the library's own group passes: RCCL send / recv on its communication stream
+                import torch.distributed as dist
+                err = None
+                try:
+                    dom.attach_native(self.dg)
+                except Exception as e:      # e.g. librccl not loadable: every rank falls back to the callbacks, and says so
+                    err = e
+                ok = torch.tensor([0 if err else 1], device=str(device) if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    print(f"bench.py: native RCCL exchange not attached on every rank ({err!r}); using torch.distributed callbacks",
+                          file=sys.stderr, flush=True)
+                    if err is None:
+                        self.dg.close()
+                        self.dg = DeviceGrid(grid, device=device.index)
+                        dom.native = False
+                    self.exchange = "python"
+            if self.exchange != "rccl":     # MOM6's group passes as callbacks into torch.distributed (any backend)
+                self.dg.set_domain(dom)
         dev = str(device)
         H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
         Z = lambda pos, k3=True: torch.zeros(grid.shape3(pos) if k3 else grid.shape2(pos), dtype=torch.float64, device=dev)
@@ -175,7 +200,7 @@ class Components:
     (mom6_amd/domains.py); every rank generates the same global synthetic state on its own GPU, keeps the
     window of its tile and frees the rest, so N ranks step exactly the problem one rank steps."""
 
-    def __init__(self, gg, dom, device, scheme):
+    def __init__(self, gg, dom, device, scheme, exchange="python"):
         from mom6_amd import _abi, synth
         from mom6_amd.ale import initialize_remapping
         from mom6_amd.continuity import BT_cont_type, continuity_PPM_init
@@ -185,8 +210,27 @@ class Components:
         self.dom = dom
         grid = self.g = dom.tile_grid(gg) if dom.nranks > 1 else gg
         self.dg = DeviceGrid(grid, device=device.index)
+        self.exchange = exchange
         if dom.nranks > 1:
-            self.dg.set_domain(dom)
+            if exchange == "rccl":      # the library's own group passes: RCCL send / recv on its communication stream
+                import torch.distributed as dist
+                err = None
+                try:
+                    dom.attach_native(self.dg)
+                except Exception as e:      # e.g. librccl not loadable: every rank falls back to the callbacks, and says so
+                    err = e
+                ok = torch.tensor([0 if err else 1], device=str(device) if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    print(f"bench.py: native RCCL exchange not attached on every rank ({err!r}); using torch.distributed callbacks",
+                          file=sys.stderr, flush=True)
+                    if err is None:
+                        self.dg.close()
+                        self.dg = DeviceGrid(grid, device=device.index)
+                        dom.native = False
+                    self.exchange = "python"
+            if self.exchange != "rccl":     # MOM6's group passes as callbacks into torch.distributed (any backend)
+                self.dg.set_domain(dom)
         dev = str(device)
         H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
 
@@ -367,7 +411,7 @@ def _cpu_sample(grid, scheme, nk_s, steps_per_advect, threads):
     from mom6_amd import _abi, synth
     from oracle import orc
     used = orc.set_threads(threads)
-    g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020, land_frac=LAND_FRAC, rough_noise=ROUGH_NOISE)
+    g = synth.make_grid(grid.ni, grid.nj, nk_s, halo=grid.halo, seed=20241020, land_frac=LAND_FRAC, rough_noise=rough_noise(grid.ni))
     dyn = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11, **STATE).items()}
     adv = synth.make_advection_state(g, ntr=4, seed=1, hot_frac=0.0)
     passive = [t.numpy() for t in adv["tr"][2:4]]
@@ -412,16 +456,70 @@ def _cpu_sample(grid, scheme, nk_s, steps_per_advect, threads):
                 n_dyn=n_dyn, cells=g.ni * g.nj * nk_s)
 
 
+def _cpu_quota():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a box whose mask lists every
+    core of the host may still be entitled to a few of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def _pick_threads(grid, limit):
+    """The OpenMP thread count the all-cores sample runs on: the fastest of 4, 8, 16, ... <= limit for one continuity call
+    on two layers of the benchmark grid (the sweep stops once a count is slower than the best so far; an over-subscribed
+    box -- more threads than its CPU share -- is several times slower than one core in the 2-D subcycle)."""
+    import numpy as np
+    from mom6_amd import _abi, synth
+    from oracle import orc
+    g = synth.make_grid(grid.ni, grid.nj, 2, halo=grid.halo, seed=20241020, land_frac=LAND_FRAC, rough_noise=rough_noise(grid.ni))
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=11, **STATE).items()}
+    cs = orc.continuity_cs(2)
+    cands = [n for n in (4, 8, 16, 32, 64, 128, 256, 512) if n < limit] + [limit]
+    best, tbest, sweep = 1, None, {}
+    for n in cands:
+        orc.set_threads(n)
+        h = np.zeros_like(d["h"]); uh = g.zeros3(_abi.POS_U); vh = g.zeros3(_abi.POS_V)
+        orc.continuity(g, cs, d["u"], d["v"], d["h"], h, uh, vh, DT)          # warms the thread pool
+        t0 = time.perf_counter()
+        for _ in range(2):
+            orc.continuity(g, cs, d["u"], d["v"], d["h"], h, uh, vh, DT)
+        t = (time.perf_counter() - t0) / 2
+        sweep[n] = round(t, 4)
+        if tbest is None or t < tbest:
+            best, tbest = n, t
+        elif t > 1.3 * tbest:
+            break
+    orc.set_threads(1)
+    return best, sweep
+
+
 def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     """The CPU oracle (oracle/*.c, a C restatement of the reference routines; kind "port") timed on the GPU box's host cores
     on bounded samples of the same workload (the same horizontal grid with fewer layers; the GPU step's calls):
       * all cores: libmom6oracle_omp.so (OpenMP over the loops the reference marks !$OMP: k / j loops of continuity,
-        CorAdCalc, PressureForce, btstep, advect_tracer, the ALE and vertvisc columns) on 16 of the layers -> `value`;
+        CorAdCalc, PressureForce, btstep, advect_tracer, the ALE and vertvisc columns) on 16 of the layers -> `value`, on
+        the thread count that a short sweep finds fastest within the box's CPU share (`cores`; `host_cores` is the
+        affinity mask, `cpu_quota` the cgroup share);
       * one core: the scalar oracle on 2 of the layers -> `one_core`.
     The 3-D work is scaled per cell to the full grid; the barotropic subcycle is 2-D (independent of the layer count) and is
     counted as measured.  The reference Fortran itself cannot be built here (FMS is not vendored), so the calibration of this
     port against a flang build of the reference exists only for the PLM/PCM pieces of oracle/_ref."""
     host_cores = len(os.sched_getaffinity(0))
+    quota = _cpu_quota()
 
     def rate(smp):
         scale = full_cells / smp["cells"]
@@ -430,7 +528,7 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
 
     one = _cpu_sample(grid, scheme, 2, steps_per_advect, 1)
     sy1, sec1 = rate(one)
-    out = {"unit": "SYPD", "kind": "port", "host_cores": host_cores,
+    out = {"unit": "SYPD", "kind": "port", "host_cores": host_cores, "cpu_quota": quota,
            "compiler": "gcc -O2 -std=c99 -ffp-contract=off -fno-fast-math (+ -fopenmp for the all-cores build)",
            "calibration_vs_reference_build": "not possible beyond PLM/PCM (oracle/_ref): the hot-path modules end in FMS, which is not vendored",
            "one_core": {"value": sy1, "cores": 1, "ns_per_gridpoint_step": sec1 * 1e9 / full_cells,
@@ -438,8 +536,10 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
                                   f"layers), 3-D work scaled per cell, the 2-D barotropic subcycle ({one['t2d']:.1f} s per step, "
                                   f"nstep={one['nstep']}) as measured; {one['cpu_s']:.1f} s of CPU"}}
     nk_all = min(16, grid.nk)
-    if host_cores > 1:
-        al = _cpu_sample(grid, scheme, nk_all, steps_per_advect, 0)
+    if quota > 1:
+        nthreads, sweep = _pick_threads(grid, quota)
+        out["thread_sweep_seconds_per_continuity_call"] = sweep
+        al = _cpu_sample(grid, scheme, nk_all, steps_per_advect, nthreads)
         sya, seca = rate(al)
         out.update({"value": sya, "cores": al["threads"], "ns_per_gridpoint_step": seca * 1e9 / full_cells,
                     "sample": f"{al['n_dyn']} baroclinic steps + one advect_tracer / ALE block on {grid.ni}x{grid.nj}x{nk_all} ({nk_all} of "
@@ -486,9 +586,13 @@ def main():
     # N>1: the global grid is cut into `world` latitude bands (layout 1 x N, the x direction stays a local wrap);
     # halos travel between neighbouring GPUs through the reference's group passes (DESIGN.md "Multi-GPU").
     # The total work is fixed: strong scaling.
-    grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=LAND_FRAC, rough_noise=ROUGH_NOISE)
+    grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=LAND_FRAC, rough_noise=rough_noise(NI))
     dom = Domain(NI, NJ, (1, world), rank, grid.halo, grid.reentrant_x, grid.reentrant_y)
-    M = Model(grid, dom, device, a.scheme)
+    # the halo exchange of the N>1 run: "rccl" = the library's native group pass (mom6_amd/csrc/domain_rccl.hip; needs one GPU
+    # per rank), "python" = callbacks into torch.distributed (the gloo rehearsal, or MOM6HIP_BENCH_EXCHANGE=python)
+    exchange = os.environ.get("MOM6HIP_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "python") if world > 1 else None
+    M = Model(grid, dom, device, a.scheme, exchange=exchange)
+    exchange = M.exchange
     cells = NI * NJ * NK
 
     def barrier():
@@ -504,6 +608,8 @@ def main():
     health_w = M.health()
     barrier()
     M.dg.kernel_timing(True)            # HIP events around the dominant kernel's launches, on the library's stream
+    if exchange == "rccl":
+        dom.exchange_timing(True)       # HIP events around every group pass, on the library's communication stream
     t0 = time.perf_counter()
     for n in range(a.steps):
         M.step()
@@ -511,18 +617,32 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ktime = M.dg.kernel_timing(False)
+    exch = None
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        on = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=on, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if exchange == "rccl":          # per rank: milliseconds per step inside group passes (pack, send / recv, unpack), passes per step
+            ms, npass = dom.exchange_timing(False)
+            mine = torch.tensor([ms / a.steps, npass / a.steps], device=on, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            exch = {"kind": "native RCCL send/recv on the library's communication stream (mom6hip_domain_init_rccl)",
+                    "ms_per_step_per_rank": [round(float(e[0]), 3) for e in every],
+                    "group_passes_per_step": float(every[0][1])}
+        else:
+            exch = {"kind": f"torch.distributed callbacks ({backend})"}
     health = M.health()
     from mom6_amd.vert_friction import vertvisc_ntrunc
-    vertvisc_ntrunc(M.dg, M.CS.vertvisc_CSp)      # CS%ntrunc: velocity truncations during the run
-    # sustained growth over the timed steps (more than doubling of the free-surface amplitude or of the kinetic energy from
-    # a state that is already energetic) is refused as well as NaNs: a number from a run that is blowing up is not a benchmark
-    growing = ((health["eta_max"] > 2.0 * max(health_w["eta_max"], 0.5)) or
-               (health["ke_mean"] > 2.0 * max(health_w["ke_mean"], 10.0)))
-    if health["nan"] or health["umax"] > 5.0 or health["hmin"] < 0.0 or growing:
+    ntrunc = int(vertvisc_ntrunc(M.dg, M.CS.vertvisc_CSp))      # CS%ntrunc: velocity truncations during the run
+    # growth over the timed steps is refused as well as NaNs (a number from a run that is blowing up is not a benchmark): the
+    # largest speed may not pass 1 m/s nor 4x its value after the warm-up, the free surface may not pass 3 m, no velocity may
+    # have been truncated.  (The adjustment of the synthetic state to geostrophic balance roughly doubles the mean kinetic
+    # energy over the first 12 steps with max |u| unchanged: that is not growth of this kind.)
+    speed = max(health["umax"], health["vmax"]); speed_w = max(health_w["umax"], health_w["vmax"])
+    growing = speed > max(1.0, 4.0 * speed_w) or health["eta_max"] > 3.0 or ntrunc > 0
+    if health["nan"] or health["hmin"] < 0.0 or growing:
         sys.exit(f"bench.py: the model state is not healthy after {M.nstep} steps: start {health0}, after warm-up {health_w}, "
                  f"at the end {health}")
 
@@ -554,6 +674,7 @@ def main():
             "state_at_start": health0, "state_after_warmup": health_w, "state_after_run": health, "model_steps_taken": M.nstep,
             "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
                                                                "group passes over RCCL p2p",
+            "exchange": exch,
         },
     }
     M.dg.close()

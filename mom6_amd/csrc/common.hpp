@@ -92,7 +92,6 @@ struct mom6hip_ctx {
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   m6::DevBuf rk2_scratch;       // the automatic arrays of step_MOM_dyn_split_RK2
   m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
-  m6::DevBuf hv_scratch;        // the work arrays of horizontal_viscosity (hor_visc.hip)
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
   std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)

@@ -278,7 +278,6 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->tr_stage) b.release();
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
-  ctx->hv_scratch.release();
   ctx->sv_rlay.release();
   ctx->ale_sub.release();
   ctx->vv_ntrunc.release();

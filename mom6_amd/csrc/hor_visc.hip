@@ -2,18 +2,11 @@
 // src/parameterizations/lateral/MOM_hor_visc.F90 (:1984-2876, :245-1979) as gfx950 kernels.
 //
 // horizontal_viscosity is a chain of four 2-D stencils per layer (velocities -> strains -> Laplacian of the velocity ->
-// stresses -> accelerations).  Every layer is independent: thread per point, lanes along i, blockIdx.z = k.
-//   hv_strain_kernel   sh_xx at h points, sh_xy at q points                                          (:693-705, :852-864)
-//   hv_del2_kernel     Del2u, Del2v (biharmonic only)                                                (:882-891)
-//   hv_stress_kernel   the viscosities (background, Smagorinsky, the stability bounds) and the layer-integrated
-//                      stresses str_xx at h points, str_xy at q points                               (:1056-1741)
-//   hv_accel_kernel    diffu, diffv                                                                  (:1744-1770)
-// The reference's 2-D work arrays become six 3-D arrays of the context's scratch (sh_xx, sh_xy, Del2u, Del2v, str_xx,
-// str_xy); the thicknesses at velocity points, hq, the shear magnitudes and the bounds are formed where they are used.
+// stresses -> accelerations), every layer independent.  hv_fused_kernel does the chain for one tile of one layer with the
+// intermediates (the reference's 2-D work arrays sh_xx, sh_xy, Del2u, Del2v, str_xx, str_xy, h_u, h_v) in LDS: see there.
 // The products hor_visc_init keeps in the control structure (dx2h = dxT*dxT, DX_dyT = dxT*IdyT, Idx2dyCu ...) are single
 // multiplications of grid metrics and are evaluated in place (the same bits as the stored arrays).
-// Algorithmic traffic: read u, v, h, write diffu, diffv = 40 B per cell; this first form moves the six work arrays through
-// HBM as well (about 180 B per cell).
+// Algorithmic traffic: read u, v, h, write diffu, diffv = 40 B per cell.
 #include <cmath>
 
 #include "common.hpp"
@@ -256,7 +249,6 @@ struct HVArgs {
   HVOpt o;
   HVStatic s;
   const double *u, *v, *h, *hu_cont, *hv_cont;
-  double *sh_xx, *sh_xy, *Del2u, *Del2v, *str_xx, *str_xy;      // work arrays: h, q, u, v, h, q shaped, nk layers
   double *diffu, *diffv;
 };
 
@@ -278,223 +270,245 @@ __device__ __forceinline__ double hv_at(const HVArgs &A, const double *hk, const
 
 struct Planes {      // the layer's planes of every array (wave-uniform pointers)
   const double *u, *v, *h, *huc, *hvc;
-  double *sh_xx, *sh_xy, *Del2u, *Del2v, *str_xx, *str_xy, *diffu, *diffv;
+  double *diffu, *diffv;
 };
 __device__ __forceinline__ Planes planes_of(const HVArgs &A, int k) {
   const m6::GridDev &g = A.g;
   const long kH = (long)g.nih * g.njh * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
-  const long kQ = (long)(g.nih + 1) * (g.njh + 1) * k;
   Planes P;
   P.u = A.u + kU; P.v = A.v + kV; P.h = A.h + kH;
   const bool cont = A.o.use_cont_thick && A.hu_cont && A.hv_cont;
   P.huc = cont ? A.hu_cont + kU : nullptr; P.hvc = cont ? A.hv_cont + kV : nullptr;
-  P.sh_xx = A.sh_xx + kH; P.sh_xy = A.sh_xy + kQ; P.Del2u = A.Del2u + kU; P.Del2v = A.Del2v + kV;
-  P.str_xx = A.str_xx + kH; P.str_xy = A.str_xy + kQ; P.diffu = A.diffu + kU; P.diffv = A.diffv + kV;
+  P.diffu = A.diffu + kU; P.diffv = A.diffv + kV;
   return P;
 }
 
-// thread (i, j) over (is-2 : ie+2, js-2 : je+2)
-__global__ __launch_bounds__(256) void hv_strain_kernel(HVArgs A) {
-  const m6::GridDev &g = A.g;
-  const int i = g.isc - 2 + blockIdx.x * blockDim.x + threadIdx.x, j = g.jsc - 2 + blockIdx.y;
-  if (i > g.iec + 2) return;
-  const Planes P = planes_of(A, blockIdx.z);
-  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec;
-  const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
-  const int I = i, J = j;
-  if (j >= Jsq - 1 && j <= Jeq + 2 && i >= Isq - 1 && i <= Ieq + 2) {      // horizontal tension :693-699
-    const double dudx = DY_dxT(i, j) * (g.IdyCu[U2(I, j)] * P.u[U2(I, j)] - g.IdyCu[U2(I - 1, j)] * P.u[U2(I - 1, j)]);
-    const double dvdy = DX_dyT(i, j) * (g.IdxCv[V2(i, J)] * P.v[V2(i, J)] - g.IdxCv[V2(i, J - 1)] * P.v[V2(i, J - 1)]);
-    P.sh_xx[H2(i, j)] = dudx - dvdy;
-  }
-  if (J >= js - 2 && J <= Jeq + 1 && I >= is - 2 && I <= Ieq + 1) {      // shearing strain :702-705, :852-864
-    const double dvdx = DY_dxBu(I, J) * (P.v[V2(i + 1, J)] * g.IdyCv[V2(i + 1, J)] - P.v[V2(i, J)] * g.IdyCv[V2(i, J)]);
-    const double dudy = DX_dyBu(I, J) * (P.u[U2(I, j + 1)] * g.IdxCu[U2(I, j + 1)] - P.u[U2(I, j)] * g.IdxCu[U2(I, j)]);
-    if (A.o.no_slip) P.sh_xy[Q2(I, J)] = (2.0 - g.mask2dBu[Q2(I, J)]) * (dvdx + dudy);
-    else P.sh_xy[Q2(I, J)] = g.mask2dBu[Q2(I, J)] * (dvdx + dudy);
-  }
-}
+// ---- the fused kernel ------------------------------------------------------------------------------------------------
+// One block = one tile of HV_TI x HV_TJ points of one layer.  The tile is treated as the reference treats a PE's compute
+// domain (is_t : ie_t, js_t : je_t): every intermediate is formed over the reference's index ranges relative to the tile
+// (sh_xx over is_t-2 : ie_t+2, Del2u over is_t-2 : ie_t+1, str_xx over is_t-1 : ie_t+1 ...), held in LDS in one local frame
+// (li, lj) <-> (i0 - 2 + li, j0 - 2 + lj), and only the tile's own diffu / diffv go back to HBM -- every value is the
+// result of the same operations on the same operands as in the layer-wide form.  The stresses overwrite the strains in
+// LDS (the strains are dead by then).  512 threads sweep the 68 x 20 points of the frame in 3 passes per stage.
+//
+// Block order: the 30 two-dimensional metrics and coefficients a point needs are 6 times the 3-D traffic if they come from
+// HBM for every layer.  blockIdx.x is decoded so that the blocks an XCD receives back to back (ids = xcd mod 8) are the nk
+// layers of ONE tile: its metrics are read into that XCD's L2 once and hit there for the other layers.
+constexpr int HV_TI = 64, HV_TJ = 16, HV_W = HV_TI + 4, HV_H = HV_TJ + 4, HV_NP = HV_W * HV_H, HV_NT = 512;
+constexpr int HV_NIT = (HV_NP + HV_NT - 1) / HV_NT;
 
-// thread (i, j) over (is-2 : ie+1, js-2 : je+1): Del2u(I, j), Del2v(i, J) :882-891
-__global__ __launch_bounds__(256) void hv_del2_kernel(HVArgs A) {
-  const m6::GridDev &g = A.g;
-  const int i = g.isc - 2 + blockIdx.x * blockDim.x + threadIdx.x, j = g.jsc - 2 + blockIdx.y;
-  if (i > g.iec + 1) return;
-  const Planes P = planes_of(A, blockIdx.z);
-  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec;
-  const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
-  const int I = i, J = j;
-  if (j >= js - 1 && j <= Jeq + 1 && I >= Isq - 1 && I <= Ieq + 1)
-    P.Del2u[U2(I, j)] = Idxdy2u(I, j) * (dy2h(i + 1, j) * P.sh_xx[H2(i + 1, j)] - dy2h(i, j) * P.sh_xx[H2(i, j)]) +
-                        Idx2dyCu(I, j) * (dx2q(I, J) * P.sh_xy[Q2(I, J)] - dx2q(I, J - 1) * P.sh_xy[Q2(I, J - 1)]);
-  if (J >= Jsq - 1 && J <= Jeq + 1 && i >= is - 1 && i <= Ieq + 1)
-    P.Del2v[V2(i, J)] = Idxdy2v(i, J) * (dy2q(I, J) * P.sh_xy[Q2(I, J)] - dy2q(I - 1, J) * P.sh_xy[Q2(I - 1, J)]) -
-                        Idx2dyCv(i, J) * (dx2h(i, j + 1) * P.sh_xx[H2(i, j + 1)] - dx2h(i, j) * P.sh_xx[H2(i, j)]);
-}
-
-// thread (i, j) over (is-1 : ie+1, js-1 : je+1): str_xx(i, j) and str_xy(I, J), layer-integrated
-__global__ __launch_bounds__(256) void hv_stress_kernel(HVArgs A) {
+__global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVArgs A, int ntx, int ntiles) {
+  __shared__ double s_xx[HV_NP], s_xy[HV_NP], s_d2u[HV_NP], s_d2v[HV_NP], s_hu[HV_NP], s_hv[HV_NP];
   const m6::GridDev &g = A.g;
   const HVOpt &o = A.o;
-  const int i = g.isc - 1 + blockIdx.x * blockDim.x + threadIdx.x, j = g.jsc - 1 + blockIdx.y;
-  if (i > g.iec + 1) return;
-  const Planes P = planes_of(A, blockIdx.z);
-  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec;
+  const int L = blockIdx.x, m = L >> 3;
+  const int k = m % g.nk, tile = (m / g.nk) * 8 + (L & 7);
+  if (tile >= ntiles) return;
+  const int i0 = g.isc + (tile % ntx) * HV_TI, j0 = g.jsc + (tile / ntx) * HV_TJ;
+  const int ib = i0 - 2, jb = j0 - 2;
+  // the tile as a compute domain
+  const int is = i0, ie = min(i0 + HV_TI - 1, g.iec), js = j0, je = min(j0 + HV_TJ - 1, g.jec);
   const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
-  const int I = i, J = j;
+  const Planes P = planes_of(A, k);
   const double h_neglect = g.H_subroundoff;
+#define LX(a, i, j) a[((j) - jb) * HV_W + ((i) - ib)]
+#define FOR_POINTS                                                   \
+  _Pragma("unroll") for (int it = 0; it < HV_NIT; it++) {            \
+    const int p = (int)threadIdx.x + it * HV_NT;                     \
+    const int lj = p / HV_W, li = p - lj * HV_W;                     \
+    const int i = ib + li, j = jb + lj, I = i, J = j;                \
+    if (p < HV_NP)
+#define END_POINTS }
+
+  // ---- strains and the thicknesses at velocity points ----
+  FOR_POINTS {
+    if (j >= Jsq - 1 && j <= Jeq + 2 && i >= Isq - 1 && i <= Ieq + 2) {      // horizontal tension :693-699
+      const double dudx = DY_dxT(i, j) * (g.IdyCu[U2(I, j)] * P.u[U2(I, j)] - g.IdyCu[U2(I - 1, j)] * P.u[U2(I - 1, j)]);
+      const double dvdy = DX_dyT(i, j) * (g.IdxCv[V2(i, J)] * P.v[V2(i, J)] - g.IdxCv[V2(i, J - 1)] * P.v[V2(i, J - 1)]);
+      LX(s_xx, i, j) = dudx - dvdy;
+    }
+    if (J >= js - 2 && J <= Jeq + 1 && I >= is - 2 && I <= Ieq + 1) {      // shearing strain :702-705, :852-864
+      const double dvdx = DY_dxBu(I, J) * (P.v[V2(i + 1, J)] * g.IdyCv[V2(i + 1, J)] - P.v[V2(i, J)] * g.IdyCv[V2(i, J)]);
+      const double dudy = DX_dyBu(I, J) * (P.u[U2(I, j + 1)] * g.IdxCu[U2(I, j + 1)] - P.u[U2(I, j)] * g.IdxCu[U2(I, j)]);
+      if (o.no_slip) LX(s_xy, I, J) = (2.0 - g.mask2dBu[Q2(I, J)]) * (dvdx + dudy);
+      else LX(s_xy, I, J) = g.mask2dBu[Q2(I, J)] * (dvdx + dudy);
+    }
+    if (j >= js - 1 && j <= je + 1 && I >= is - 2 && I <= ie + 1) LX(s_hu, I, j) = hu_at(A, P.h, P.huc, I, j);      // :740-765
+    if (J >= js - 2 && J <= je + 1 && i >= is - 1 && i <= ie + 1) LX(s_hv, i, J) = hv_at(A, P.h, P.hvc, i, J);
+  } END_POINTS
+  __syncthreads();
+
+  // ---- the Laplacian of the velocity :882-891 ----
+  if (o.biharmonic) {
+    FOR_POINTS {
+      if (j >= js - 1 && j <= Jeq + 1 && I >= Isq - 1 && I <= Ieq + 1)
+        LX(s_d2u, I, j) = Idxdy2u(I, j) * (dy2h(i + 1, j) * LX(s_xx, i + 1, j) - dy2h(i, j) * LX(s_xx, i, j)) +
+                          Idx2dyCu(I, j) * (dx2q(I, J) * LX(s_xy, I, J) - dx2q(I, J - 1) * LX(s_xy, I, J - 1));
+      if (J >= Jsq - 1 && J <= Jeq + 1 && i >= is - 1 && i <= Ieq + 1)
+        LX(s_d2v, i, J) = Idxdy2v(i, J) * (dy2q(I, J) * LX(s_xy, I, J) - dy2q(I - 1, J) * LX(s_xy, I - 1, J)) -
+                          Idx2dyCv(i, J) * (dx2h(i, j + 1) * LX(s_xx, i, j + 1) - dx2h(i, j) * LX(s_xx, i, j));
+    } END_POINTS
+    __syncthreads();
+  }
+
+  // ---- viscosities and layer-integrated stresses :1056-1741 (into registers: they replace the strains in LDS) ----
   const double h_neglect3 = h_neglect * h_neglect * h_neglect;
   const bool legacy_bound = o.Smagorinsky_Kh && (o.bound_Kh && !o.better_bound_Kh);
   const bool smag = o.Smagorinsky_Kh || o.Smagorinsky_Ah, bb = o.better_bound_Ah || o.better_bound_Kh;
-
-  if (j >= Jsq && j <= Jeq + 1 && i >= Isq && i <= Ieq + 1) {      // ---- h point (is_Kh : ie_Kh, js_Kh : je_Kh) ----
-    const double sxx = P.sh_xx[H2(i, j)];
-    double Shear_mag = 0.0, hrat_min = 0.0, visc_bound_rem = 0.0;
-    if (smag) {      // :1056-1063
-      const double sh_xx_sq = sxx * sxx;
-      const double sh_xy_sq = 0.25 * ((P.sh_xy[Q2(I - 1, J - 1)] * P.sh_xy[Q2(I - 1, J - 1)] + P.sh_xy[Q2(I, J)] * P.sh_xy[Q2(I, J)]) +
-                                      (P.sh_xy[Q2(I - 1, J)] * P.sh_xy[Q2(I - 1, J)] + P.sh_xy[Q2(I, J - 1)] * P.sh_xy[Q2(I, J - 1)]));
-      Shear_mag = sqrt(sh_xx_sq + sh_xy_sq);
-    }
-    if (bb) {      // :1065-1076
-      const double h_min = min4(hu_at(A, P.h, P.huc, I, j), hu_at(A, P.h, P.huc, I - 1, j), hv_at(A, P.h, P.hvc, i, J),
-                                hv_at(A, P.h, P.hvc, i, J - 1));
-      hrat_min = min2(1.0, h_min / (P.h[H2(i, j)] + h_neglect));
-      if (o.better_bound_Kh) visc_bound_rem = 1.0;
-    }
-    double str = 0.0;
-    if (o.Laplacian) {      // :1078-1214
-      double K_ = A.s.Kh_bg_xx[H2(i, j)];
-      if (o.add_LES_viscosity) {
-        if (o.Smagorinsky_Kh) K_ = K_ + A.s.Laplac2_const_xx[H2(i, j)] * Shear_mag;
-      } else {
-        if (o.Smagorinsky_Kh) K_ = max2(K_, A.s.Laplac2_const_xx[H2(i, j)] * Shear_mag);
+  double r_xx[HV_NIT], r_xy[HV_NIT];
+  FOR_POINTS {
+    r_xx[it] = 0.0; r_xy[it] = 0.0;
+    if (j >= Jsq && j <= Jeq + 1 && i >= Isq && i <= Ieq + 1) {      // ---- h point (is_Kh : ie_Kh, js_Kh : je_Kh) ----
+      const double sxx = LX(s_xx, i, j);
+      double Shear_mag = 0.0, hrat_min = 0.0, visc_bound_rem = 0.0;
+      if (smag) {      // :1056-1063
+        const double sh_xx_sq = sxx * sxx;
+        const double sh_xy_sq = 0.25 * ((LX(s_xy, I - 1, J - 1) * LX(s_xy, I - 1, J - 1) + LX(s_xy, I, J) * LX(s_xy, I, J)) +
+                                        (LX(s_xy, I - 1, J) * LX(s_xy, I - 1, J) + LX(s_xy, I, J - 1) * LX(s_xy, I, J - 1)));
+        Shear_mag = sqrt(sh_xx_sq + sh_xy_sq);
       }
-      if (legacy_bound) K_ = min2(K_, A.s.Kh_Max_xx[H2(i, j)]);
-      K_ = max2(K_, o.Kh_bg_min);
-      if (o.better_bound_Kh) {
-        if (K_ >= hrat_min * A.s.Kh_Max_xx[H2(i, j)]) {
-          visc_bound_rem = 0.0;
-          K_ = hrat_min * A.s.Kh_Max_xx[H2(i, j)];
+      if (bb) {      // :1065-1076
+        const double h_min = min4(LX(s_hu, I, j), LX(s_hu, I - 1, j), LX(s_hv, i, J), LX(s_hv, i, J - 1));
+        hrat_min = min2(1.0, h_min / (P.h[H2(i, j)] + h_neglect));
+        if (o.better_bound_Kh) visc_bound_rem = 1.0;
+      }
+      double str = 0.0;
+      if (o.Laplacian) {      // :1078-1214
+        double K_ = A.s.Kh_bg_xx[H2(i, j)];
+        if (o.add_LES_viscosity) {
+          if (o.Smagorinsky_Kh) K_ = K_ + A.s.Laplac2_const_xx[H2(i, j)] * Shear_mag;
         } else {
-          visc_bound_rem = 1.0 - K_ / (hrat_min * A.s.Kh_Max_xx[H2(i, j)]);
+          if (o.Smagorinsky_Kh) K_ = max2(K_, A.s.Laplac2_const_xx[H2(i, j)] * Shear_mag);
         }
+        if (legacy_bound) K_ = min2(K_, A.s.Kh_Max_xx[H2(i, j)]);
+        K_ = max2(K_, o.Kh_bg_min);
+        if (o.better_bound_Kh) {
+          if (K_ >= hrat_min * A.s.Kh_Max_xx[H2(i, j)]) {
+            visc_bound_rem = 0.0;
+            K_ = hrat_min * A.s.Kh_Max_xx[H2(i, j)];
+          } else {
+            visc_bound_rem = 1.0 - K_ / (hrat_min * A.s.Kh_Max_xx[H2(i, j)]);
+          }
+        }
+        str = -K_ * sxx;
       }
-      str = -K_ * sxx;
+      if (o.biharmonic) {      // :1227-1380
+        double A_ = A.s.Ah_bg_xx[H2(i, j)];
+        if (o.Smagorinsky_Ah) {
+          double AhSm;
+          if (o.bound_Coriolis) AhSm = Shear_mag * (A.s.Biharm_const_xx[H2(i, j)] + A.s.Biharm_const2_xx[H2(i, j)] * Shear_mag);
+          else AhSm = A.s.Biharm_const_xx[H2(i, j)] * Shear_mag;
+          A_ = max2(A_, AhSm);
+          if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, A.s.Ah_Max_xx[H2(i, j)]);
+        }
+        if (o.better_bound_Ah) {
+          if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * A.s.Ah_Max_xx[H2(i, j)]);
+          else A_ = min2(A_, hrat_min * A.s.Ah_Max_xx[H2(i, j)]);
+        }
+        const double d_del2u = g.IdyCu[U2(I, j)] * LX(s_d2u, I, j) - g.IdyCu[U2(I - 1, j)] * LX(s_d2u, I - 1, j);
+        const double d_del2v = g.IdxCv[V2(i, J)] * LX(s_d2v, i, J) - g.IdxCv[V2(i, J - 1)] * LX(s_d2v, i, J - 1);
+        const double d_str = A_ * (DY_dxT(i, j) * d_del2u - DX_dyT(i, j) * d_del2v);
+        str = str + d_str;
+      }
+      r_xx[it] = str * (P.h[H2(i, j)] * A.s.reduction_xx[H2(i, j)]);      // :1728
     }
-    if (o.biharmonic) {      // :1227-1380
-      double A_ = A.s.Ah_bg_xx[H2(i, j)];
-      if (o.Smagorinsky_Ah) {
-        double AhSm;
-        if (o.bound_Coriolis) AhSm = Shear_mag * (A.s.Biharm_const_xx[H2(i, j)] + A.s.Biharm_const2_xx[H2(i, j)] * Shear_mag);
-        else AhSm = A.s.Biharm_const_xx[H2(i, j)] * Shear_mag;
-        A_ = max2(A_, AhSm);
-        if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, A.s.Ah_Max_xx[H2(i, j)]);
-      }
-      if (o.better_bound_Ah) {
-        if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * A.s.Ah_Max_xx[H2(i, j)]);
-        else A_ = min2(A_, hrat_min * A.s.Ah_Max_xx[H2(i, j)]);
-      }
-      const double d_del2u = g.IdyCu[U2(I, j)] * P.Del2u[U2(I, j)] - g.IdyCu[U2(I - 1, j)] * P.Del2u[U2(I - 1, j)];
-      const double d_del2v = g.IdxCv[V2(i, J)] * P.Del2v[V2(i, J)] - g.IdxCv[V2(i, J - 1)] * P.Del2v[V2(i, J - 1)];
-      const double d_str = A_ * (DY_dxT(i, j) * d_del2u - DX_dyT(i, j) * d_del2v);
-      str = str + d_str;
-    }
-    P.str_xx[H2(i, j)] = str * (P.h[H2(i, j)] * A.s.reduction_xx[H2(i, j)]);      // :1728
-  }
 
-  if (J >= js - 1 && J <= Jeq && I >= is - 1 && I <= Ieq) {      // ---- q point ----
-    const double sxy = P.sh_xy[Q2(I, J)];
-    double Shear_mag = 0.0;
-    if (smag) {      // :1414-1421
-      const double sh_xy_sq = sxy * sxy;
-      const double sh_xx_sq = 0.25 * ((P.sh_xx[H2(i, j)] * P.sh_xx[H2(i, j)] + P.sh_xx[H2(i + 1, j + 1)] * P.sh_xx[H2(i + 1, j + 1)]) +
-                                      (P.sh_xx[H2(i, j + 1)] * P.sh_xx[H2(i, j + 1)] + P.sh_xx[H2(i + 1, j)] * P.sh_xx[H2(i + 1, j)]));
-      Shear_mag = sqrt(sh_xy_sq + sh_xx_sq);
-    }
-    const double hu0 = hu_at(A, P.h, P.huc, I, j), hu1 = hu_at(A, P.h, P.huc, I, j + 1);
-    const double hv0 = hv_at(A, P.h, P.hvc, i, J), hv1 = hv_at(A, P.h, P.hvc, i + 1, J);
-    const double h2uq = 4.0 * (hu0 * hu1);      // :1423-1428
-    const double h2vq = 4.0 * (hv0 * hv1);
-    double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
-    double hrat_min = 0.0, visc_bound_rem = 0.0;
-    if (bb) {      // :1430-1441
-      const double h_min = min4(hu0, hu1, hv0, hv1);
-      hrat_min = min2(1.0, h_min / (hq + h_neglect));
-      if (o.better_bound_Kh) visc_bound_rem = 1.0;
-    }
-    if (o.no_slip && (g.mask2dBu[Q2(I, J)] < 0.5)) {      // coastal vorticity points :1443-1466
-      if ((g.mask2dCu[U2(I, j)] + g.mask2dCu[U2(I, j + 1)]) + (g.mask2dCv[V2(i, J)] + g.mask2dCv[V2(i + 1, J)]) > 0.0) {
-        const double hu = g.mask2dCu[U2(I, j)] * hu0 + g.mask2dCu[U2(I, j + 1)] * hu1;
-        const double hv = g.mask2dCv[V2(i, J)] * hv0 + g.mask2dCv[V2(i + 1, J)] * hv1;
-        if ((g.mask2dCu[U2(I, j)] + g.mask2dCu[U2(I, j + 1)]) * (g.mask2dCv[V2(i, J)] + g.mask2dCv[V2(i + 1, J)]) == 0.0) {
-          hq = hu + hv;
-          hrat_min = 1.0;
-        } else {
-          hq = 2.0 * (hu * hv) / ((hu + hv) + h_neglect);
-          hrat_min = min2(1.0, min2(hu, hv) / (hq + h_neglect));
+    if (J >= js - 1 && J <= Jeq && I >= is - 1 && I <= Ieq) {      // ---- q point ----
+      const double sxy = LX(s_xy, I, J);
+      double Shear_mag = 0.0;
+      if (smag) {      // :1414-1421
+        const double sh_xy_sq = sxy * sxy;
+        const double sh_xx_sq = 0.25 * ((LX(s_xx, i, j) * LX(s_xx, i, j) + LX(s_xx, i + 1, j + 1) * LX(s_xx, i + 1, j + 1)) +
+                                        (LX(s_xx, i, j + 1) * LX(s_xx, i, j + 1) + LX(s_xx, i + 1, j) * LX(s_xx, i + 1, j)));
+        Shear_mag = sqrt(sh_xy_sq + sh_xx_sq);
+      }
+      const double hu0 = LX(s_hu, I, j), hu1 = LX(s_hu, I, j + 1);
+      const double hv0 = LX(s_hv, i, J), hv1 = LX(s_hv, i + 1, J);
+      const double h2uq = 4.0 * (hu0 * hu1);      // :1423-1428
+      const double h2vq = 4.0 * (hv0 * hv1);
+      double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
+      double hrat_min = 0.0, visc_bound_rem = 0.0;
+      if (bb) {      // :1430-1441
+        const double h_min = min4(hu0, hu1, hv0, hv1);
+        hrat_min = min2(1.0, h_min / (hq + h_neglect));
+        if (o.better_bound_Kh) visc_bound_rem = 1.0;
+      }
+      if (o.no_slip && (g.mask2dBu[Q2(I, J)] < 0.5)) {      // coastal vorticity points :1443-1466
+        if ((g.mask2dCu[U2(I, j)] + g.mask2dCu[U2(I, j + 1)]) + (g.mask2dCv[V2(i, J)] + g.mask2dCv[V2(i + 1, J)]) > 0.0) {
+          const double hu = g.mask2dCu[U2(I, j)] * hu0 + g.mask2dCu[U2(I, j + 1)] * hu1;
+          const double hv = g.mask2dCv[V2(i, J)] * hv0 + g.mask2dCv[V2(i + 1, J)] * hv1;
+          if ((g.mask2dCu[U2(I, j)] + g.mask2dCu[U2(I, j + 1)]) * (g.mask2dCv[V2(i, J)] + g.mask2dCv[V2(i + 1, J)]) == 0.0) {
+            hq = hu + hv;
+            hrat_min = 1.0;
+          } else {
+            hq = 2.0 * (hu * hv) / ((hu + hv) + h_neglect);
+            hrat_min = min2(1.0, min2(hu, hv) / (hq + h_neglect));
+          }
         }
       }
-    }
-    double str = 0.0;
-    if (o.Laplacian) {      // :1473-1585
-      double K_ = A.s.Kh_bg_xy[Q2(I, J)];
-      if (o.Smagorinsky_Kh) {
-        if (o.add_LES_viscosity) K_ = K_ + A.s.Laplac2_const_xy[Q2(I, J)] * Shear_mag;
-        else K_ = max2(K_, A.s.Laplac2_const_xy[Q2(I, J)] * Shear_mag);
-      }
-      if (legacy_bound) K_ = min2(K_, A.s.Kh_Max_xy[Q2(I, J)]);
-      K_ = max2(K_, o.Kh_bg_min);
-      if (o.better_bound_Kh) {
-        if (K_ >= hrat_min * A.s.Kh_Max_xy[Q2(I, J)]) {
-          visc_bound_rem = 0.0;
-          K_ = hrat_min * A.s.Kh_Max_xy[Q2(I, J)];
-        } else if (hrat_min * A.s.Kh_Max_xy[Q2(I, J)] > 0.) {
-          visc_bound_rem = 1.0 - K_ / (hrat_min * A.s.Kh_Max_xy[Q2(I, J)]);
+      double str = 0.0;
+      if (o.Laplacian) {      // :1473-1585
+        double K_ = A.s.Kh_bg_xy[Q2(I, J)];
+        if (o.Smagorinsky_Kh) {
+          if (o.add_LES_viscosity) K_ = K_ + A.s.Laplac2_const_xy[Q2(I, J)] * Shear_mag;
+          else K_ = max2(K_, A.s.Laplac2_const_xy[Q2(I, J)] * Shear_mag);
         }
+        if (legacy_bound) K_ = min2(K_, A.s.Kh_Max_xy[Q2(I, J)]);
+        K_ = max2(K_, o.Kh_bg_min);
+        if (o.better_bound_Kh) {
+          if (K_ >= hrat_min * A.s.Kh_Max_xy[Q2(I, J)]) {
+            visc_bound_rem = 0.0;
+            K_ = hrat_min * A.s.Kh_Max_xy[Q2(I, J)];
+          } else if (hrat_min * A.s.Kh_Max_xy[Q2(I, J)] > 0.) {
+            visc_bound_rem = 1.0 - K_ / (hrat_min * A.s.Kh_Max_xy[Q2(I, J)]);
+          }
+        }
+        str = -K_ * sxy;
       }
-      str = -K_ * sxy;
+      if (o.biharmonic) {      // :1598-1693, with the gradient of the Laplacian :1382-1387
+        double A_ = A.s.Ah_bg_xy[Q2(I, J)];
+        if (o.Smagorinsky_Ah) {
+          double AhSm;
+          if (o.bound_Coriolis) AhSm = Shear_mag * (A.s.Biharm_const_xy[Q2(I, J)] + A.s.Biharm_const2_xy[Q2(I, J)] * Shear_mag);
+          else AhSm = A.s.Biharm_const_xy[Q2(I, J)] * Shear_mag;
+          A_ = max2(A_, AhSm);
+          if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, A.s.Ah_Max_xy[Q2(I, J)]);
+        }
+        if (o.better_bound_Ah) {
+          if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * A.s.Ah_Max_xy[Q2(I, J)]);
+          else A_ = min2(A_, hrat_min * A.s.Ah_Max_xy[Q2(I, J)]);
+        }
+        const double dDel2vdx = DY_dxBu(I, J) * (LX(s_d2v, i + 1, J) * g.IdyCv[V2(i + 1, J)] - LX(s_d2v, i, J) * g.IdyCv[V2(i, J)]);
+        const double dDel2udy = DX_dyBu(I, J) * (LX(s_d2u, I, j + 1) * g.IdxCu[U2(I, j + 1)] - LX(s_d2u, I, j) * g.IdxCu[U2(I, j)]);
+        const double d_str = A_ * (dDel2vdx + dDel2udy);
+        str = str + d_str;
+      }
+      if (o.no_slip) r_xy[it] = str * (hq * A.s.reduction_xy[Q2(I, J)]);      // :1733-1740
+      else r_xy[it] = str * (hq * g.mask2dBu[Q2(I, J)] * A.s.reduction_xy[Q2(I, J)]);
     }
-    if (o.biharmonic) {      // :1598-1693, with the gradient of the Laplacian :1382-1387
-      double A_ = A.s.Ah_bg_xy[Q2(I, J)];
-      if (o.Smagorinsky_Ah) {
-        double AhSm;
-        if (o.bound_Coriolis) AhSm = Shear_mag * (A.s.Biharm_const_xy[Q2(I, J)] + A.s.Biharm_const2_xy[Q2(I, J)] * Shear_mag);
-        else AhSm = A.s.Biharm_const_xy[Q2(I, J)] * Shear_mag;
-        A_ = max2(A_, AhSm);
-        if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, A.s.Ah_Max_xy[Q2(I, J)]);
-      }
-      if (o.better_bound_Ah) {
-        if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * A.s.Ah_Max_xy[Q2(I, J)]);
-        else A_ = min2(A_, hrat_min * A.s.Ah_Max_xy[Q2(I, J)]);
-      }
-      const double dDel2vdx = DY_dxBu(I, J) * (P.Del2v[V2(i + 1, J)] * g.IdyCv[V2(i + 1, J)] - P.Del2v[V2(i, J)] * g.IdyCv[V2(i, J)]);
-      const double dDel2udy = DX_dyBu(I, J) * (P.Del2u[U2(I, j + 1)] * g.IdxCu[U2(I, j + 1)] - P.Del2u[U2(I, j)] * g.IdxCu[U2(I, j)]);
-      const double d_str = A_ * (dDel2vdx + dDel2udy);
-      str = str + d_str;
-    }
-    if (o.no_slip) P.str_xy[Q2(I, J)] = str * (hq * A.s.reduction_xy[Q2(I, J)]);      // :1733-1740
-    else P.str_xy[Q2(I, J)] = str * (hq * g.mask2dBu[Q2(I, J)] * A.s.reduction_xy[Q2(I, J)]);
-  }
-}
+  } END_POINTS
+  __syncthreads();
+  FOR_POINTS {
+    LX(s_xx, i, j) = r_xx[it];
+    LX(s_xy, I, J) = r_xy[it];
+  } END_POINTS
+  __syncthreads();
 
-// thread (i, j) over (is-1 : ie, js-1 : je): diffu(I, j), diffv(i, J) :1744-1770
-__global__ __launch_bounds__(256) void hv_accel_kernel(HVArgs A) {
-  const m6::GridDev &g = A.g;
-  const int i = g.isc - 1 + blockIdx.x * blockDim.x + threadIdx.x, j = g.jsc - 1 + blockIdx.y;
-  if (i > g.iec) return;
-  const Planes P = planes_of(A, blockIdx.z);
-  const int is = g.isc, js = g.jsc;
-  const int I = i, J = j;
-  const double h_neglect = g.H_subroundoff;
-  if (j >= js)
-    P.diffu[U2(I, j)] = ((g.IdyCu[U2(I, j)] * (dy2h(i, j) * P.str_xx[H2(i, j)] - dy2h(i + 1, j) * P.str_xx[H2(i + 1, j)]) +
-                          g.IdxCu[U2(I, j)] * (dx2q(I, J - 1) * P.str_xy[Q2(I, J - 1)] - dx2q(I, J) * P.str_xy[Q2(I, J)])) *
-                         g.IareaCu[U2(I, j)]) / (hu_at(A, P.h, P.huc, I, j) + h_neglect);
-  if (i >= is)
-    P.diffv[V2(i, J)] = ((g.IdyCv[V2(i, J)] * (dy2q(I - 1, J) * P.str_xy[Q2(I - 1, J)] - dy2q(I, J) * P.str_xy[Q2(I, J)]) -
-                          g.IdxCv[V2(i, J)] * (dx2h(i, j) * P.str_xx[H2(i, j)] - dx2h(i, j + 1) * P.str_xx[H2(i, j + 1)])) *
-                         g.IareaCv[V2(i, J)]) / (hv_at(A, P.h, P.hvc, i, J) + h_neglect);
+  // ---- diffu, diffv :1744-1770: the tile's own points (the western / southern edge points belong to the first tiles) ----
+  const int Iw = (i0 == g.isc) ? is - 1 : is, Js = (j0 == g.jsc) ? js - 1 : js;
+  FOR_POINTS {
+    if (j >= js && j <= je && I >= Iw && I <= ie)
+      P.diffu[U2(I, j)] = ((g.IdyCu[U2(I, j)] * (dy2h(i, j) * LX(s_xx, i, j) - dy2h(i + 1, j) * LX(s_xx, i + 1, j)) +
+                            g.IdxCu[U2(I, j)] * (dx2q(I, J - 1) * LX(s_xy, I, J - 1) - dx2q(I, J) * LX(s_xy, I, J))) *
+                           g.IareaCu[U2(I, j)]) / (LX(s_hu, I, j) + h_neglect);
+    if (i >= is && i <= ie && J >= Js && J <= je)
+      P.diffv[V2(i, J)] = ((g.IdyCv[V2(i, J)] * (dy2q(I - 1, J) * LX(s_xy, I - 1, J) - dy2q(I, J) * LX(s_xy, I, J)) -
+                            g.IdxCv[V2(i, J)] * (dx2h(i, j) * LX(s_xx, i, j) - dx2h(i, j + 1) * LX(s_xx, i, j + 1))) *
+                           g.IareaCv[V2(i, J)]) / (LX(s_hv, i, J) + h_neglect);
+  } END_POINTS
+#undef LX
+#undef FOR_POINTS
+#undef END_POINTS
 }
 
 int check_cs(const mom6hip_hor_visc_cs_t *cs, const char *who) {
@@ -561,25 +575,17 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
                              double *diffu, double *diffv, const double *hu_cont, const double *hv_cont) {
   const m6::GridDev g = ctx->g;
   if (!(cs->Laplacian || cs->biharmonic)) return 0;      // :451
-  const size_t bH = sizeof(double) * (size_t)g.nh3(), bU = sizeof(double) * (size_t)g.nu3(), bV = sizeof(double) * (size_t)g.nv3();
-  const size_t bQ = sizeof(double) * (size_t)(g.nih + 1) * (g.njh + 1) * g.nk;
-  M6_REQUIRE(ctx->hv_scratch.reserve(2 * bH + 2 * bQ + bU + bV) == 0, "horizontal_viscosity: out of device memory");
-  char *blk = (char *)ctx->hv_scratch.p;
   HVArgs A;
   A.g = g; A.o = opt_of(cs);
   double *const *src = &cs->Kh_bg_xx;
   double **dst = &A.s.Kh_bg_xx;
   for (int n = 0; n < 16; n++) dst[n] = src[n];
   A.u = u; A.v = v; A.h = h; A.hu_cont = hu_cont; A.hv_cont = hv_cont; A.diffu = diffu; A.diffv = diffv;
-  A.sh_xx = (double *)blk; blk += bH; A.str_xx = (double *)blk; blk += bH;
-  A.sh_xy = (double *)blk; blk += bQ; A.str_xy = (double *)blk; blk += bQ;
-  A.Del2u = (double *)blk; blk += bU; A.Del2v = (double *)blk;
-  hipStream_t s = ctx->stream;
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
-  hipLaunchKernelGGL(hv_strain_kernel, dim3((ni + 5 + 255) / 256, nj + 5, g.nk), dim3(256), 0, s, A);
-  if (cs->biharmonic) hipLaunchKernelGGL(hv_del2_kernel, dim3((ni + 4 + 255) / 256, nj + 4, g.nk), dim3(256), 0, s, A);
-  hipLaunchKernelGGL(hv_stress_kernel, dim3((ni + 3 + 255) / 256, nj + 3, g.nk), dim3(256), 0, s, A);
-  hipLaunchKernelGGL(hv_accel_kernel, dim3((ni + 2 + 255) / 256, nj + 1, g.nk), dim3(256), 0, s, A);
+  const int ntx = (ni + HV_TI - 1) / HV_TI, nty = (nj + HV_TJ - 1) / HV_TJ, ntiles = ntx * nty;
+  const long nblocks = (long)((ntiles + 7) / 8) * 8 * g.nk;
+  M6_REQUIRE(nblocks < (1L << 31), "horizontal_viscosity: the grid is too large for one launch");
+  hipLaunchKernelGGL(hv_fused_kernel, dim3((unsigned)nblocks), dim3(HV_NT), 0, ctx->stream, A, ntx, ntiles);
   M6_HIP(hipGetLastError());
   return 0;
 }

@@ -10,11 +10,11 @@ from mom6_amd.domains import Domain
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=48); ap.add_argument("--every", type=int, default=4)
-ap.add_argument("--rough", type=float, default=bench.ROUGH_NOISE); ap.add_argument("--workload", default="om4_025")
+ap.add_argument("--rough", type=float, default=None); ap.add_argument("--workload", default="om4_025")
 ap.add_argument("--land", type=float, default=bench.LAND_FRAC)
 a = ap.parse_args()
 NI, NJ, NK = bench.shape_of(a.workload)
-grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=a.land, rough_noise=a.rough)
+grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=a.land, rough_noise=bench.rough_noise(NI) if a.rough is None else a.rough)
 dom = Domain(NI, NJ, (1, 1), 0, grid.halo, grid.reentrant_x, grid.reentrant_y)
 M = bench.Model(grid, dom, torch.device("cuda", 0), bench.SCHEME)
 print(json.dumps(dict(step=0, **M.health())), flush=True)
