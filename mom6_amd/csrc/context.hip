@@ -279,6 +279,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
   ctx->sv_rlay.release();
+  ctx->hv_pack.release();
   ctx->ale_sub.release();
   ctx->vv_ntrunc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);

@@ -244,45 +244,6 @@ __global__ __launch_bounds__(256) void hv_init2_kernel(InitArgs A) {
 }
 
 // ---- horizontal_viscosity ----------------------------------------------------------------------------------------------
-struct HVArgs {
-  m6::GridDev g;
-  HVOpt o;
-  HVStatic s;
-  const double *u, *v, *h, *hu_cont, *hv_cont;
-  double *diffu, *diffv;
-};
-
-// thicknesses at velocity points :740-765 (land mask or not; hu_cont / hv_cont inside their ranges with USE_CONT_THICKNESS)
-__device__ __forceinline__ double hu_at(const HVArgs &A, const double *hk, const double *huk, int I, int j) {
-  const m6::GridDev &g = A.g;
-  if (huk && I >= g.isc - 2) return huk[U2(I, j)];
-  const int i = I;
-  if (A.o.use_land_mask) return 0.5 * (g.mask2dT[H2(i, j)] * hk[H2(i, j)] + g.mask2dT[H2(i + 1, j)] * hk[H2(i + 1, j)]);
-  return 0.5 * (hk[H2(i, j)] + hk[H2(i + 1, j)]);
-}
-__device__ __forceinline__ double hv_at(const HVArgs &A, const double *hk, const double *hvk, int i, int J) {
-  const m6::GridDev &g = A.g;
-  if (hvk && J >= g.jsc - 2) return hvk[V2(i, J)];
-  const int j = J;
-  if (A.o.use_land_mask) return 0.5 * (g.mask2dT[H2(i, j)] * hk[H2(i, j)] + g.mask2dT[H2(i, j + 1)] * hk[H2(i, j + 1)]);
-  return 0.5 * (hk[H2(i, j)] + hk[H2(i, j + 1)]);
-}
-
-struct Planes {      // the layer's planes of every array (wave-uniform pointers)
-  const double *u, *v, *h, *huc, *hvc;
-  double *diffu, *diffv;
-};
-__device__ __forceinline__ Planes planes_of(const HVArgs &A, int k) {
-  const m6::GridDev &g = A.g;
-  const long kH = (long)g.nih * g.njh * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
-  Planes P;
-  P.u = A.u + kU; P.v = A.v + kV; P.h = A.h + kH;
-  const bool cont = A.o.use_cont_thick && A.hu_cont && A.hv_cont;
-  P.huc = cont ? A.hu_cont + kU : nullptr; P.hvc = cont ? A.hv_cont + kV : nullptr;
-  P.diffu = A.diffu + kU; P.diffv = A.diffv + kV;
-  return P;
-}
-
 // ---- the fused kernel ------------------------------------------------------------------------------------------------
 // One block = one tile of HV_TI x HV_TJ points of one layer.  The tile is treated as the reference treats a PE's compute
 // domain (is_t : ie_t, js_t : je_t): every intermediate is formed over the reference's index ranges relative to the tile
@@ -291,50 +252,148 @@ __device__ __forceinline__ Planes planes_of(const HVArgs &A, int k) {
 // result of the same operations on the same operands as in the layer-wide form.  The stresses overwrite the strains in
 // LDS (the strains are dead by then).  512 threads sweep the 68 x 20 points of the frame in 3 passes per stage.
 //
-// Block order: the 30 two-dimensional metrics and coefficients a point needs are 6 times the 3-D traffic if they come from
+// Block order: the two-dimensional metrics and coefficients a point needs are 6 times the 3-D traffic if they come from
 // HBM for every layer.  blockIdx.x is decoded so that the blocks an XCD receives back to back (ids = xcd mod 8) are the nk
-// layers of ONE tile: its metrics are read into that XCD's L2 once and hit there for the other layers.
+// layers of ONE tile: its metrics are read into that XCD's L2 once and hit there for the other layers (measured: 2.5 GB
+// fetched per call at 1440x1080x75 for 2.8 GB of u, v, h).
+//
+// Addressing: the 22 grid metrics (and the products hor_visc_init keeps: dx2h, DX_dyT, Idx2dyCu ...) are gathered once
+// per context into planes of ONE shape, (nih+1) x (njh+1) -- the shape of a q-point array, in which an h, u or v point
+// (i, j) sits at the same place as the q point (I, J) -- so a point needs one 32-bit byte offset for all of them, every
+// load is `global_load v, voffset, s[base] offset:imm`, and one base pointer replaces 40 (which the kernel's scalar
+// registers could not hold: the first form spent a fifth of its instructions on v_readlane of spilled pointers).
+enum HVPlane { P_DX2H, P_DY2H, P_DXDYT, P_DYDXT, P_MASKT, P_DX2Q, P_DY2Q, P_DXDYBU, P_DYDXBU, P_MASKBU,
+               P_IDXCU, P_IDYCU, P_IAREACU, P_IDX2DYCU, P_IDXDY2U, P_MASKCU, P_IDXCV, P_IDYCV, P_IAREACV, P_IDX2DYCV, P_IDXDY2V,
+               P_MASKCV, HV_NPLANES };
+
+// thread (pi, pj) over the (nih+1) x (njh+1) frame: (i, j) = (isd - 1 + pi, jsd - 1 + pj)
+__global__ __launch_bounds__(256) void hv_pack_kernel(m6::GridDev g, double *pk) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x, pj = blockIdx.y;
+  if (pi > g.nih) return;
+  const int i = g.isd - 1 + pi, j = g.jsd - 1 + pj, I = i, J = j;
+  const size_t plane = (size_t)(g.nih + 1) * (g.njh + 1), n = (size_t)pj * (g.nih + 1) + pi;
+  const bool inh = pi >= 1 && pj >= 1, inu = pj >= 1, inv = pi >= 1;
+  auto put = [&](int m, double x) { pk[plane * m + n] = x; };
+  put(P_DX2H, inh ? dx2h(i, j) : 0.0); put(P_DY2H, inh ? dy2h(i, j) : 0.0);
+  put(P_DXDYT, inh ? DX_dyT(i, j) : 0.0); put(P_DYDXT, inh ? DY_dxT(i, j) : 0.0);
+  put(P_MASKT, inh ? g.mask2dT[H2(i, j)] : 0.0);
+  put(P_DX2Q, dx2q(I, J)); put(P_DY2Q, dy2q(I, J)); put(P_DXDYBU, DX_dyBu(I, J)); put(P_DYDXBU, DY_dxBu(I, J));
+  put(P_MASKBU, g.mask2dBu[Q2(I, J)]);
+  put(P_IDXCU, inu ? g.IdxCu[U2(I, j)] : 0.0); put(P_IDYCU, inu ? g.IdyCu[U2(I, j)] : 0.0);
+  put(P_IAREACU, inu ? g.IareaCu[U2(I, j)] : 0.0); put(P_IDX2DYCU, inu ? Idx2dyCu(I, j) : 0.0);
+  put(P_IDXDY2U, inu ? Idxdy2u(I, j) : 0.0); put(P_MASKCU, inu ? g.mask2dCu[U2(I, j)] : 0.0);
+  put(P_IDXCV, inv ? g.IdxCv[V2(i, J)] : 0.0); put(P_IDYCV, inv ? g.IdyCv[V2(i, J)] : 0.0);
+  put(P_IAREACV, inv ? g.IareaCv[V2(i, J)] : 0.0); put(P_IDX2DYCV, inv ? Idx2dyCv(i, J) : 0.0);
+  put(P_IDXDY2V, inv ? Idxdy2v(i, J) : 0.0); put(P_MASKCV, inv ? g.mask2dCv[V2(i, J)] : 0.0);
+}
+
+// the options the stress stage reads, as bits of one scalar register (the struct of ints and doubles cost 40)
+struct HVFlags {
+  unsigned bits;
+  __host__ __device__ bool operator[](int n) const { return (bits >> n) & 1u; }
+};
+enum { F_LAPLACIAN, F_BIHARMONIC, F_SMAG_KH, F_SMAG_AH, F_BOUND_KH, F_BETTER_BOUND_KH, F_BOUND_AH, F_BETTER_BOUND_AH, F_BOUND_CORIOLIS,
+       F_ADD_LES, F_NO_SLIP, F_LAND_MASK, F_CONT_THICK };
+struct HVFOpt {      // HVOpt as the fused kernel sees it
+  bool Laplacian, biharmonic, Smagorinsky_Kh, Smagorinsky_Ah, bound_Kh, better_bound_Kh, bound_Ah, better_bound_Ah, bound_Coriolis,
+      add_LES_viscosity, no_slip, use_land_mask, use_cont_thick;
+  double Kh_bg_min;
+};
+
+struct HVFArgs {
+  HVFlags flags;
+  double Kh_bg_min;
+  HVStatic s;
+  const char *pk;                  // the packed metric planes
+  unsigned plane_bytes;
+  int isc, iec, jsc, jec, isd, jsd, nih, njh, nk;
+  double h_neglect;
+  const double *u, *v, *h, *hu_cont, *hv_cont;
+  double *diffu, *diffv;
+};
+
 constexpr int HV_TI = 64, HV_TJ = 16, HV_W = HV_TI + 4, HV_H = HV_TJ + 4, HV_NP = HV_W * HV_H, HV_NT = 512;
 constexpr int HV_NIT = (HV_NP + HV_NT - 1) / HV_NT;
 
-__global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVArgs A, int ntx, int ntiles) {
+// CFG = HV_GENERIC: the options are read from the argument; otherwise they are the bits of CFG at compile time (the
+// production set -- biharmonic Smagorinsky with the better bounds -- is instantiated: the branches and the static arrays it
+// does not use are gone, which is what lets the remaining base pointers stay in scalar registers).
+constexpr unsigned HV_GENERIC = ~0u;
+constexpr unsigned HV_BIH_SMAG = (1u << F_BIHARMONIC) | (1u << F_SMAG_AH) | (1u << F_BOUND_KH) | (1u << F_BETTER_BOUND_KH) | (1u << F_BOUND_AH) |
+                                 (1u << F_BETTER_BOUND_AH) | (1u << F_LAND_MASK);
+
+template <unsigned CFG>
+__global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVFArgs A, int ntx, int ntiles) {
   __shared__ double s_xx[HV_NP], s_xy[HV_NP], s_d2u[HV_NP], s_d2v[HV_NP], s_hu[HV_NP], s_hv[HV_NP];
-  const m6::GridDev &g = A.g;
-  const HVOpt &o = A.o;
+  const HVFlags F = {CFG == HV_GENERIC ? A.flags.bits : CFG};
+  const HVFOpt o = {F[F_LAPLACIAN], F[F_BIHARMONIC], F[F_SMAG_KH], F[F_SMAG_AH], F[F_BOUND_KH], F[F_BETTER_BOUND_KH], F[F_BOUND_AH],
+                    F[F_BETTER_BOUND_AH], F[F_BOUND_CORIOLIS], F[F_ADD_LES], F[F_NO_SLIP], F[F_LAND_MASK], F[F_CONT_THICK], A.Kh_bg_min};
   const int L = blockIdx.x, m = L >> 3;
-  const int k = m % g.nk, tile = (m / g.nk) * 8 + (L & 7);
+  const int k = m % A.nk, tile = (m / A.nk) * 8 + (L & 7);
   if (tile >= ntiles) return;
-  const int i0 = g.isc + (tile % ntx) * HV_TI, j0 = g.jsc + (tile / ntx) * HV_TJ;
+  const int i0 = A.isc + (tile % ntx) * HV_TI, j0 = A.jsc + (tile / ntx) * HV_TJ;
   const int ib = i0 - 2, jb = j0 - 2;
   // the tile as a compute domain
-  const int is = i0, ie = min(i0 + HV_TI - 1, g.iec), js = j0, je = min(j0 + HV_TJ - 1, g.jec);
+  const int is = i0, ie = min(i0 + HV_TI - 1, A.iec), js = j0, je = min(j0 + HV_TJ - 1, A.jec);
   const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
-  const Planes P = planes_of(A, k);
-  const double h_neglect = g.H_subroundoff;
-#define LX(a, i, j) a[((j) - jb) * HV_W + ((i) - ib)]
-#define FOR_POINTS                                                   \
-  _Pragma("unroll") for (int it = 0; it < HV_NIT; it++) {            \
-    const int p = (int)threadIdx.x + it * HV_NT;                     \
-    const int lj = p / HV_W, li = p - lj * HV_W;                     \
-    const int i = ib + li, j = jb + lj, I = i, J = j;                \
+  const double h_neglect = A.h_neglect;
+  // row strides in bytes: q / u shaped rows, h / v shaped rows
+  const unsigned RQ = (unsigned)(A.nih + 1) * 8u, RH = (unsigned)A.nih * 8u;
+  // the layer's planes of the 3-D arrays (wave-uniform)
+  const size_t kH = (size_t)A.nih * A.njh * k, kU = (size_t)(A.nih + 1) * A.njh * k, kV = (size_t)A.nih * (A.njh + 1) * k;
+  const char *u_k = (const char *)(A.u + kU), *v_k = (const char *)(A.v + kV), *h_k = (const char *)(A.h + kH);
+  const bool cont = o.use_cont_thick && A.hu_cont && A.hv_cont;
+  const char *huc_k = cont ? (const char *)(A.hu_cont + kU) : nullptr, *hvc_k = cont ? (const char *)(A.hv_cont + kV) : nullptr;
+  char *du_k = (char *)(A.diffu + kU), *dv_k = (char *)(A.diffv + kV);
+  const char *pk = A.pk;
+  const unsigned PB = A.plane_bytes;
+
+#define LX(a, di, dj) a[lo + (dj) * HV_W + (di)]
+// loads at the point (i + di, j + dj): packed metric plane m; an h-, u-, v- or q-shaped array with base pointer b
+#define LDB(b, off, R, di, dj) (*(const double *)(((const char *)(b) + (di) * 8) + ((dj) == 0 ? (off) : (dj) > 0 ? (off) + (R) : (off) - (R))))
+#define G(m, di, dj) LDB(pk + (size_t)(m) * PB, bq, RQ, di, dj)
+#define AH(b, di, dj) LDB(b, bh, RH, di, dj)
+#define AU(b, di, dj) LDB(b, bu, RQ, di, dj)
+#define AV(b, di, dj) LDB(b, bv, RH, di, dj)
+#define AQ(b, di, dj) LDB(b, bq, RQ, di, dj)
+#define FOR_POINTS                                                                   \
+  _Pragma("unroll") for (int it = 0; it < HV_NIT; it++) {                            \
+    const int p = (int)threadIdx.x + it * HV_NT;                                     \
+    const int lj = p / HV_W, li = p - lj * HV_W, lo = p;                             \
+    const int i = ib + li, j = jb + lj, I = i, J = j;                                \
+    const unsigned cj = (unsigned)(j - A.jsd), ci = (unsigned)(i - A.isd);           \
+    const unsigned bq = ((cj + 1u) * (unsigned)(A.nih + 1) + ci + 1u) * 8u;          \
+    const unsigned bh = (cj * (unsigned)A.nih + ci) * 8u;                            \
+    const unsigned bu = (cj * (unsigned)(A.nih + 1) + ci + 1u) * 8u;                 \
+    const unsigned bv = ((cj + 1u) * (unsigned)A.nih + ci) * 8u;                     \
+    (void)I; (void)J; (void)bq; (void)bh; (void)bu; (void)bv; (void)lo;              \
     if (p < HV_NP)
 #define END_POINTS }
+// thicknesses at velocity points :740-765 (land mask or not; hu_cont / hv_cont inside their ranges with USE_CONT_THICKNESS)
+#define HU_AT(di)                                                                                                        \
+  ((huc_k && I + (di) >= A.isc - 2) ? AU(huc_k, di, 0)                                                                    \
+   : o.use_land_mask ? 0.5 * (G(P_MASKT, di, 0) * AH(h_k, di, 0) + G(P_MASKT, (di) + 1, 0) * AH(h_k, (di) + 1, 0))          \
+                     : 0.5 * (AH(h_k, di, 0) + AH(h_k, (di) + 1, 0)))
 
   // ---- strains and the thicknesses at velocity points ----
   FOR_POINTS {
     if (j >= Jsq - 1 && j <= Jeq + 2 && i >= Isq - 1 && i <= Ieq + 2) {      // horizontal tension :693-699
-      const double dudx = DY_dxT(i, j) * (g.IdyCu[U2(I, j)] * P.u[U2(I, j)] - g.IdyCu[U2(I - 1, j)] * P.u[U2(I - 1, j)]);
-      const double dvdy = DX_dyT(i, j) * (g.IdxCv[V2(i, J)] * P.v[V2(i, J)] - g.IdxCv[V2(i, J - 1)] * P.v[V2(i, J - 1)]);
-      LX(s_xx, i, j) = dudx - dvdy;
+      const double dudx = G(P_DYDXT, 0, 0) * (G(P_IDYCU, 0, 0) * AU(u_k, 0, 0) - G(P_IDYCU, -1, 0) * AU(u_k, -1, 0));
+      const double dvdy = G(P_DXDYT, 0, 0) * (G(P_IDXCV, 0, 0) * AV(v_k, 0, 0) - G(P_IDXCV, 0, -1) * AV(v_k, 0, -1));
+      LX(s_xx, 0, 0) = dudx - dvdy;
     }
     if (J >= js - 2 && J <= Jeq + 1 && I >= is - 2 && I <= Ieq + 1) {      // shearing strain :702-705, :852-864
-      const double dvdx = DY_dxBu(I, J) * (P.v[V2(i + 1, J)] * g.IdyCv[V2(i + 1, J)] - P.v[V2(i, J)] * g.IdyCv[V2(i, J)]);
-      const double dudy = DX_dyBu(I, J) * (P.u[U2(I, j + 1)] * g.IdxCu[U2(I, j + 1)] - P.u[U2(I, j)] * g.IdxCu[U2(I, j)]);
-      if (o.no_slip) LX(s_xy, I, J) = (2.0 - g.mask2dBu[Q2(I, J)]) * (dvdx + dudy);
-      else LX(s_xy, I, J) = g.mask2dBu[Q2(I, J)] * (dvdx + dudy);
+      const double dvdx = G(P_DYDXBU, 0, 0) * (AV(v_k, 1, 0) * G(P_IDYCV, 1, 0) - AV(v_k, 0, 0) * G(P_IDYCV, 0, 0));
+      const double dudy = G(P_DXDYBU, 0, 0) * (AU(u_k, 0, 1) * G(P_IDXCU, 0, 1) - AU(u_k, 0, 0) * G(P_IDXCU, 0, 0));
+      if (o.no_slip) LX(s_xy, 0, 0) = (2.0 - G(P_MASKBU, 0, 0)) * (dvdx + dudy);
+      else LX(s_xy, 0, 0) = G(P_MASKBU, 0, 0) * (dvdx + dudy);
     }
-    if (j >= js - 1 && j <= je + 1 && I >= is - 2 && I <= ie + 1) LX(s_hu, I, j) = hu_at(A, P.h, P.huc, I, j);      // :740-765
-    if (J >= js - 2 && J <= je + 1 && i >= is - 1 && i <= ie + 1) LX(s_hv, i, J) = hv_at(A, P.h, P.hvc, i, J);
+    if (j >= js - 1 && j <= je + 1 && I >= is - 2 && I <= ie + 1) LX(s_hu, 0, 0) = HU_AT(0);      // :740-765
+    if (J >= js - 2 && J <= je + 1 && i >= is - 1 && i <= ie + 1) {
+      if (hvc_k && J >= A.jsc - 2) LX(s_hv, 0, 0) = AV(hvc_k, 0, 0);
+      else if (o.use_land_mask) LX(s_hv, 0, 0) = 0.5 * (G(P_MASKT, 0, 0) * AH(h_k, 0, 0) + G(P_MASKT, 0, 1) * AH(h_k, 0, 1));
+      else LX(s_hv, 0, 0) = 0.5 * (AH(h_k, 0, 0) + AH(h_k, 0, 1));
+    }
   } END_POINTS
   __syncthreads();
 
@@ -342,11 +401,11 @@ __global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVArgs A, int ntx, i
   if (o.biharmonic) {
     FOR_POINTS {
       if (j >= js - 1 && j <= Jeq + 1 && I >= Isq - 1 && I <= Ieq + 1)
-        LX(s_d2u, I, j) = Idxdy2u(I, j) * (dy2h(i + 1, j) * LX(s_xx, i + 1, j) - dy2h(i, j) * LX(s_xx, i, j)) +
-                          Idx2dyCu(I, j) * (dx2q(I, J) * LX(s_xy, I, J) - dx2q(I, J - 1) * LX(s_xy, I, J - 1));
+        LX(s_d2u, 0, 0) = G(P_IDXDY2U, 0, 0) * (G(P_DY2H, 1, 0) * LX(s_xx, 1, 0) - G(P_DY2H, 0, 0) * LX(s_xx, 0, 0)) +
+                          G(P_IDX2DYCU, 0, 0) * (G(P_DX2Q, 0, 0) * LX(s_xy, 0, 0) - G(P_DX2Q, 0, -1) * LX(s_xy, 0, -1));
       if (J >= Jsq - 1 && J <= Jeq + 1 && i >= is - 1 && i <= Ieq + 1)
-        LX(s_d2v, i, J) = Idxdy2v(i, J) * (dy2q(I, J) * LX(s_xy, I, J) - dy2q(I - 1, J) * LX(s_xy, I - 1, J)) -
-                          Idx2dyCv(i, J) * (dx2h(i, j + 1) * LX(s_xx, i, j + 1) - dx2h(i, j) * LX(s_xx, i, j));
+        LX(s_d2v, 0, 0) = G(P_IDXDY2V, 0, 0) * (G(P_DY2Q, 0, 0) * LX(s_xy, 0, 0) - G(P_DY2Q, -1, 0) * LX(s_xy, -1, 0)) -
+                          G(P_IDX2DYCV, 0, 0) * (G(P_DX2H, 0, 1) * LX(s_xx, 0, 1) - G(P_DX2H, 0, 0) * LX(s_xx, 0, 0));
     } END_POINTS
     __syncthreads();
   }
@@ -359,71 +418,73 @@ __global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVArgs A, int ntx, i
   FOR_POINTS {
     r_xx[it] = 0.0; r_xy[it] = 0.0;
     if (j >= Jsq && j <= Jeq + 1 && i >= Isq && i <= Ieq + 1) {      // ---- h point (is_Kh : ie_Kh, js_Kh : je_Kh) ----
-      const double sxx = LX(s_xx, i, j);
+      const double sxx = LX(s_xx, 0, 0);
       double Shear_mag = 0.0, hrat_min = 0.0, visc_bound_rem = 0.0;
       if (smag) {      // :1056-1063
         const double sh_xx_sq = sxx * sxx;
-        const double sh_xy_sq = 0.25 * ((LX(s_xy, I - 1, J - 1) * LX(s_xy, I - 1, J - 1) + LX(s_xy, I, J) * LX(s_xy, I, J)) +
-                                        (LX(s_xy, I - 1, J) * LX(s_xy, I - 1, J) + LX(s_xy, I, J - 1) * LX(s_xy, I, J - 1)));
+        const double sh_xy_sq = 0.25 * ((LX(s_xy, -1, -1) * LX(s_xy, -1, -1) + LX(s_xy, 0, 0) * LX(s_xy, 0, 0)) +
+                                        (LX(s_xy, -1, 0) * LX(s_xy, -1, 0) + LX(s_xy, 0, -1) * LX(s_xy, 0, -1)));
         Shear_mag = sqrt(sh_xx_sq + sh_xy_sq);
       }
+      const double h_here = AH(h_k, 0, 0);
       if (bb) {      // :1065-1076
-        const double h_min = min4(LX(s_hu, I, j), LX(s_hu, I - 1, j), LX(s_hv, i, J), LX(s_hv, i, J - 1));
-        hrat_min = min2(1.0, h_min / (P.h[H2(i, j)] + h_neglect));
+        const double h_min = min4(LX(s_hu, 0, 0), LX(s_hu, -1, 0), LX(s_hv, 0, 0), LX(s_hv, 0, -1));
+        hrat_min = min2(1.0, h_min / (h_here + h_neglect));
         if (o.better_bound_Kh) visc_bound_rem = 1.0;
       }
       double str = 0.0;
       if (o.Laplacian) {      // :1078-1214
-        double K_ = A.s.Kh_bg_xx[H2(i, j)];
+        double K_ = AH(A.s.Kh_bg_xx, 0, 0);
         if (o.add_LES_viscosity) {
-          if (o.Smagorinsky_Kh) K_ = K_ + A.s.Laplac2_const_xx[H2(i, j)] * Shear_mag;
+          if (o.Smagorinsky_Kh) K_ = K_ + AH(A.s.Laplac2_const_xx, 0, 0) * Shear_mag;
         } else {
-          if (o.Smagorinsky_Kh) K_ = max2(K_, A.s.Laplac2_const_xx[H2(i, j)] * Shear_mag);
+          if (o.Smagorinsky_Kh) K_ = max2(K_, AH(A.s.Laplac2_const_xx, 0, 0) * Shear_mag);
         }
-        if (legacy_bound) K_ = min2(K_, A.s.Kh_Max_xx[H2(i, j)]);
+        if (legacy_bound) K_ = min2(K_, AH(A.s.Kh_Max_xx, 0, 0));
         K_ = max2(K_, o.Kh_bg_min);
         if (o.better_bound_Kh) {
-          if (K_ >= hrat_min * A.s.Kh_Max_xx[H2(i, j)]) {
+          const double KhM = AH(A.s.Kh_Max_xx, 0, 0);
+          if (K_ >= hrat_min * KhM) {
             visc_bound_rem = 0.0;
-            K_ = hrat_min * A.s.Kh_Max_xx[H2(i, j)];
+            K_ = hrat_min * KhM;
           } else {
-            visc_bound_rem = 1.0 - K_ / (hrat_min * A.s.Kh_Max_xx[H2(i, j)]);
+            visc_bound_rem = 1.0 - K_ / (hrat_min * KhM);
           }
         }
         str = -K_ * sxx;
       }
       if (o.biharmonic) {      // :1227-1380
-        double A_ = A.s.Ah_bg_xx[H2(i, j)];
+        double A_ = AH(A.s.Ah_bg_xx, 0, 0);
         if (o.Smagorinsky_Ah) {
           double AhSm;
-          if (o.bound_Coriolis) AhSm = Shear_mag * (A.s.Biharm_const_xx[H2(i, j)] + A.s.Biharm_const2_xx[H2(i, j)] * Shear_mag);
-          else AhSm = A.s.Biharm_const_xx[H2(i, j)] * Shear_mag;
+          if (o.bound_Coriolis) AhSm = Shear_mag * (AH(A.s.Biharm_const_xx, 0, 0) + AH(A.s.Biharm_const2_xx, 0, 0) * Shear_mag);
+          else AhSm = AH(A.s.Biharm_const_xx, 0, 0) * Shear_mag;
           A_ = max2(A_, AhSm);
-          if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, A.s.Ah_Max_xx[H2(i, j)]);
+          if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, AH(A.s.Ah_Max_xx, 0, 0));
         }
         if (o.better_bound_Ah) {
-          if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * A.s.Ah_Max_xx[H2(i, j)]);
-          else A_ = min2(A_, hrat_min * A.s.Ah_Max_xx[H2(i, j)]);
+          if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * AH(A.s.Ah_Max_xx, 0, 0));
+          else A_ = min2(A_, hrat_min * AH(A.s.Ah_Max_xx, 0, 0));
         }
-        const double d_del2u = g.IdyCu[U2(I, j)] * LX(s_d2u, I, j) - g.IdyCu[U2(I - 1, j)] * LX(s_d2u, I - 1, j);
-        const double d_del2v = g.IdxCv[V2(i, J)] * LX(s_d2v, i, J) - g.IdxCv[V2(i, J - 1)] * LX(s_d2v, i, J - 1);
-        const double d_str = A_ * (DY_dxT(i, j) * d_del2u - DX_dyT(i, j) * d_del2v);
+        const double d_del2u = G(P_IDYCU, 0, 0) * LX(s_d2u, 0, 0) - G(P_IDYCU, -1, 0) * LX(s_d2u, -1, 0);
+        const double d_del2v = G(P_IDXCV, 0, 0) * LX(s_d2v, 0, 0) - G(P_IDXCV, 0, -1) * LX(s_d2v, 0, -1);
+        const double d_str = A_ * (G(P_DYDXT, 0, 0) * d_del2u - G(P_DXDYT, 0, 0) * d_del2v);
         str = str + d_str;
       }
-      r_xx[it] = str * (P.h[H2(i, j)] * A.s.reduction_xx[H2(i, j)]);      // :1728
+      r_xx[it] = str * (h_here * AH(A.s.reduction_xx, 0, 0));      // :1728
     }
 
     if (J >= js - 1 && J <= Jeq && I >= is - 1 && I <= Ieq) {      // ---- q point ----
-      const double sxy = LX(s_xy, I, J);
+      const double sxy = LX(s_xy, 0, 0);
       double Shear_mag = 0.0;
       if (smag) {      // :1414-1421
         const double sh_xy_sq = sxy * sxy;
-        const double sh_xx_sq = 0.25 * ((LX(s_xx, i, j) * LX(s_xx, i, j) + LX(s_xx, i + 1, j + 1) * LX(s_xx, i + 1, j + 1)) +
-                                        (LX(s_xx, i, j + 1) * LX(s_xx, i, j + 1) + LX(s_xx, i + 1, j) * LX(s_xx, i + 1, j)));
+        const double sh_xx_sq = 0.25 * ((LX(s_xx, 0, 0) * LX(s_xx, 0, 0) + LX(s_xx, 1, 1) * LX(s_xx, 1, 1)) +
+                                        (LX(s_xx, 0, 1) * LX(s_xx, 0, 1) + LX(s_xx, 1, 0) * LX(s_xx, 1, 0)));
         Shear_mag = sqrt(sh_xy_sq + sh_xx_sq);
       }
-      const double hu0 = LX(s_hu, I, j), hu1 = LX(s_hu, I, j + 1);
-      const double hv0 = LX(s_hv, i, J), hv1 = LX(s_hv, i + 1, J);
+      const double hu0 = LX(s_hu, 0, 0), hu1 = LX(s_hu, 0, 1);
+      const double hv0 = LX(s_hv, 0, 0), hv1 = LX(s_hv, 1, 0);
       const double h2uq = 4.0 * (hu0 * hu1);      // :1423-1428
       const double h2vq = 4.0 * (hv0 * hv1);
       double hq = (2.0 * (h2uq * h2vq)) / (h_neglect3 + (h2uq + h2vq) * ((hu0 + hu1) + (hv0 + hv1)));
@@ -433,11 +494,12 @@ __global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVArgs A, int ntx, i
         hrat_min = min2(1.0, h_min / (hq + h_neglect));
         if (o.better_bound_Kh) visc_bound_rem = 1.0;
       }
-      if (o.no_slip && (g.mask2dBu[Q2(I, J)] < 0.5)) {      // coastal vorticity points :1443-1466
-        if ((g.mask2dCu[U2(I, j)] + g.mask2dCu[U2(I, j + 1)]) + (g.mask2dCv[V2(i, J)] + g.mask2dCv[V2(i + 1, J)]) > 0.0) {
-          const double hu = g.mask2dCu[U2(I, j)] * hu0 + g.mask2dCu[U2(I, j + 1)] * hu1;
-          const double hv = g.mask2dCv[V2(i, J)] * hv0 + g.mask2dCv[V2(i + 1, J)] * hv1;
-          if ((g.mask2dCu[U2(I, j)] + g.mask2dCu[U2(I, j + 1)]) * (g.mask2dCv[V2(i, J)] + g.mask2dCv[V2(i + 1, J)]) == 0.0) {
+      if (o.no_slip && (G(P_MASKBU, 0, 0) < 0.5)) {      // coastal vorticity points :1443-1466
+        const double mu0 = G(P_MASKCU, 0, 0), mu1 = G(P_MASKCU, 0, 1), mv0 = G(P_MASKCV, 0, 0), mv1 = G(P_MASKCV, 1, 0);
+        if ((mu0 + mu1) + (mv0 + mv1) > 0.0) {
+          const double hu = mu0 * hu0 + mu1 * hu1;
+          const double hv = mv0 * hv0 + mv1 * hv1;
+          if ((mu0 + mu1) * (mv0 + mv1) == 0.0) {
             hq = hu + hv;
             hrat_min = 1.0;
           } else {
@@ -448,65 +510,73 @@ __global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVArgs A, int ntx, i
       }
       double str = 0.0;
       if (o.Laplacian) {      // :1473-1585
-        double K_ = A.s.Kh_bg_xy[Q2(I, J)];
+        double K_ = AQ(A.s.Kh_bg_xy, 0, 0);
         if (o.Smagorinsky_Kh) {
-          if (o.add_LES_viscosity) K_ = K_ + A.s.Laplac2_const_xy[Q2(I, J)] * Shear_mag;
-          else K_ = max2(K_, A.s.Laplac2_const_xy[Q2(I, J)] * Shear_mag);
+          if (o.add_LES_viscosity) K_ = K_ + AQ(A.s.Laplac2_const_xy, 0, 0) * Shear_mag;
+          else K_ = max2(K_, AQ(A.s.Laplac2_const_xy, 0, 0) * Shear_mag);
         }
-        if (legacy_bound) K_ = min2(K_, A.s.Kh_Max_xy[Q2(I, J)]);
+        if (legacy_bound) K_ = min2(K_, AQ(A.s.Kh_Max_xy, 0, 0));
         K_ = max2(K_, o.Kh_bg_min);
         if (o.better_bound_Kh) {
-          if (K_ >= hrat_min * A.s.Kh_Max_xy[Q2(I, J)]) {
+          const double KhM = AQ(A.s.Kh_Max_xy, 0, 0);
+          if (K_ >= hrat_min * KhM) {
             visc_bound_rem = 0.0;
-            K_ = hrat_min * A.s.Kh_Max_xy[Q2(I, J)];
-          } else if (hrat_min * A.s.Kh_Max_xy[Q2(I, J)] > 0.) {
-            visc_bound_rem = 1.0 - K_ / (hrat_min * A.s.Kh_Max_xy[Q2(I, J)]);
+            K_ = hrat_min * KhM;
+          } else if (hrat_min * KhM > 0.) {
+            visc_bound_rem = 1.0 - K_ / (hrat_min * KhM);
           }
         }
         str = -K_ * sxy;
       }
       if (o.biharmonic) {      // :1598-1693, with the gradient of the Laplacian :1382-1387
-        double A_ = A.s.Ah_bg_xy[Q2(I, J)];
+        double A_ = AQ(A.s.Ah_bg_xy, 0, 0);
         if (o.Smagorinsky_Ah) {
           double AhSm;
-          if (o.bound_Coriolis) AhSm = Shear_mag * (A.s.Biharm_const_xy[Q2(I, J)] + A.s.Biharm_const2_xy[Q2(I, J)] * Shear_mag);
-          else AhSm = A.s.Biharm_const_xy[Q2(I, J)] * Shear_mag;
+          if (o.bound_Coriolis) AhSm = Shear_mag * (AQ(A.s.Biharm_const_xy, 0, 0) + AQ(A.s.Biharm_const2_xy, 0, 0) * Shear_mag);
+          else AhSm = AQ(A.s.Biharm_const_xy, 0, 0) * Shear_mag;
           A_ = max2(A_, AhSm);
-          if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, A.s.Ah_Max_xy[Q2(I, J)]);
+          if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, AQ(A.s.Ah_Max_xy, 0, 0));
         }
         if (o.better_bound_Ah) {
-          if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * A.s.Ah_Max_xy[Q2(I, J)]);
-          else A_ = min2(A_, hrat_min * A.s.Ah_Max_xy[Q2(I, J)]);
+          if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * AQ(A.s.Ah_Max_xy, 0, 0));
+          else A_ = min2(A_, hrat_min * AQ(A.s.Ah_Max_xy, 0, 0));
         }
-        const double dDel2vdx = DY_dxBu(I, J) * (LX(s_d2v, i + 1, J) * g.IdyCv[V2(i + 1, J)] - LX(s_d2v, i, J) * g.IdyCv[V2(i, J)]);
-        const double dDel2udy = DX_dyBu(I, J) * (LX(s_d2u, I, j + 1) * g.IdxCu[U2(I, j + 1)] - LX(s_d2u, I, j) * g.IdxCu[U2(I, j)]);
+        const double dDel2vdx = G(P_DYDXBU, 0, 0) * (LX(s_d2v, 1, 0) * G(P_IDYCV, 1, 0) - LX(s_d2v, 0, 0) * G(P_IDYCV, 0, 0));
+        const double dDel2udy = G(P_DXDYBU, 0, 0) * (LX(s_d2u, 0, 1) * G(P_IDXCU, 0, 1) - LX(s_d2u, 0, 0) * G(P_IDXCU, 0, 0));
         const double d_str = A_ * (dDel2vdx + dDel2udy);
         str = str + d_str;
       }
-      if (o.no_slip) r_xy[it] = str * (hq * A.s.reduction_xy[Q2(I, J)]);      // :1733-1740
-      else r_xy[it] = str * (hq * g.mask2dBu[Q2(I, J)] * A.s.reduction_xy[Q2(I, J)]);
+      if (o.no_slip) r_xy[it] = str * (hq * AQ(A.s.reduction_xy, 0, 0));      // :1733-1740
+      else r_xy[it] = str * (hq * G(P_MASKBU, 0, 0) * AQ(A.s.reduction_xy, 0, 0));
     }
   } END_POINTS
   __syncthreads();
   FOR_POINTS {
-    LX(s_xx, i, j) = r_xx[it];
-    LX(s_xy, I, J) = r_xy[it];
+    LX(s_xx, 0, 0) = r_xx[it];
+    LX(s_xy, 0, 0) = r_xy[it];
   } END_POINTS
   __syncthreads();
 
   // ---- diffu, diffv :1744-1770: the tile's own points (the western / southern edge points belong to the first tiles) ----
-  const int Iw = (i0 == g.isc) ? is - 1 : is, Js = (j0 == g.jsc) ? js - 1 : js;
+  const int Iw = (i0 == A.isc) ? is - 1 : is, Js = (j0 == A.jsc) ? js - 1 : js;
   FOR_POINTS {
     if (j >= js && j <= je && I >= Iw && I <= ie)
-      P.diffu[U2(I, j)] = ((g.IdyCu[U2(I, j)] * (dy2h(i, j) * LX(s_xx, i, j) - dy2h(i + 1, j) * LX(s_xx, i + 1, j)) +
-                            g.IdxCu[U2(I, j)] * (dx2q(I, J - 1) * LX(s_xy, I, J - 1) - dx2q(I, J) * LX(s_xy, I, J))) *
-                           g.IareaCu[U2(I, j)]) / (LX(s_hu, I, j) + h_neglect);
+      *(double *)(du_k + bu) = ((G(P_IDYCU, 0, 0) * (G(P_DY2H, 0, 0) * LX(s_xx, 0, 0) - G(P_DY2H, 1, 0) * LX(s_xx, 1, 0)) +
+                                 G(P_IDXCU, 0, 0) * (G(P_DX2Q, 0, -1) * LX(s_xy, 0, -1) - G(P_DX2Q, 0, 0) * LX(s_xy, 0, 0))) *
+                                G(P_IAREACU, 0, 0)) / (LX(s_hu, 0, 0) + h_neglect);
     if (i >= is && i <= ie && J >= Js && J <= je)
-      P.diffv[V2(i, J)] = ((g.IdyCv[V2(i, J)] * (dy2q(I - 1, J) * LX(s_xy, I - 1, J) - dy2q(I, J) * LX(s_xy, I, J)) -
-                            g.IdxCv[V2(i, J)] * (dx2h(i, j) * LX(s_xx, i, j) - dx2h(i, j + 1) * LX(s_xx, i, j + 1))) *
-                           g.IareaCv[V2(i, J)]) / (LX(s_hv, i, J) + h_neglect);
+      *(double *)(dv_k + bv) = ((G(P_IDYCV, 0, 0) * (G(P_DY2Q, -1, 0) * LX(s_xy, -1, 0) - G(P_DY2Q, 0, 0) * LX(s_xy, 0, 0)) -
+                                 G(P_IDXCV, 0, 0) * (G(P_DX2H, 0, 0) * LX(s_xx, 0, 0) - G(P_DX2H, 0, 1) * LX(s_xx, 0, 1))) *
+                                G(P_IAREACV, 0, 0)) / (LX(s_hv, 0, 0) + h_neglect);
   } END_POINTS
 #undef LX
+#undef LDB
+#undef G
+#undef AH
+#undef AU
+#undef AV
+#undef AQ
+#undef HU_AT
 #undef FOR_POINTS
 #undef END_POINTS
 }
@@ -575,17 +645,35 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
                              double *diffu, double *diffv, const double *hu_cont, const double *hv_cont) {
   const m6::GridDev g = ctx->g;
   if (!(cs->Laplacian || cs->biharmonic)) return 0;      // :451
-  HVArgs A;
-  A.g = g; A.o = opt_of(cs);
+  const size_t plane = sizeof(double) * (size_t)(g.nih + 1) * (g.njh + 1);
+  M6_REQUIRE(plane < (1ull << 31) && sizeof(double) * (size_t)(g.nih + 1) * (g.njh + 1) < (1ull << 31),
+             "horizontal_viscosity: a layer is too large for 32-bit byte offsets");
+  if (!ctx->hv_pack_ready) {      // the metric planes of this grid, once per context
+    M6_REQUIRE(ctx->hv_pack.reserve(plane * HV_NPLANES) == 0, "horizontal_viscosity: out of device memory");
+    hipLaunchKernelGGL(hv_pack_kernel, dim3((g.nih + 1 + 255) / 256, g.njh + 1), dim3(256), 0, ctx->stream, g, (double *)ctx->hv_pack.p);
+    M6_HIP(hipGetLastError());
+    ctx->hv_pack_ready = true;
+  }
+  HVFArgs A;
+  const HVOpt o = opt_of(cs);
+  const int fl[13] = {o.Laplacian, o.biharmonic, o.Smagorinsky_Kh, o.Smagorinsky_Ah, o.bound_Kh, o.better_bound_Kh, o.bound_Ah, o.better_bound_Ah,
+                      o.bound_Coriolis, o.add_LES_viscosity, o.no_slip, o.use_land_mask, o.use_cont_thick};
+  A.flags.bits = 0;
+  for (int n = 0; n < 13; n++) A.flags.bits |= (fl[n] ? 1u : 0u) << n;
+  A.Kh_bg_min = o.Kh_bg_min;
   double *const *src = &cs->Kh_bg_xx;
   double **dst = &A.s.Kh_bg_xx;
   for (int n = 0; n < 16; n++) dst[n] = src[n];
+  A.pk = (const char *)ctx->hv_pack.p; A.plane_bytes = (unsigned)plane;
+  A.isc = g.isc; A.iec = g.iec; A.jsc = g.jsc; A.jec = g.jec; A.isd = g.isd; A.jsd = g.jsd; A.nih = g.nih; A.njh = g.njh; A.nk = g.nk;
+  A.h_neglect = g.H_subroundoff;
   A.u = u; A.v = v; A.h = h; A.hu_cont = hu_cont; A.hv_cont = hv_cont; A.diffu = diffu; A.diffv = diffv;
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
   const int ntx = (ni + HV_TI - 1) / HV_TI, nty = (nj + HV_TJ - 1) / HV_TJ, ntiles = ntx * nty;
   const long nblocks = (long)((ntiles + 7) / 8) * 8 * g.nk;
   M6_REQUIRE(nblocks < (1L << 31), "horizontal_viscosity: the grid is too large for one launch");
-  hipLaunchKernelGGL(hv_fused_kernel, dim3((unsigned)nblocks), dim3(HV_NT), 0, ctx->stream, A, ntx, ntiles);
+  if (A.flags.bits == HV_BIH_SMAG) hipLaunchKernelGGL(hv_fused_kernel<HV_BIH_SMAG>, dim3((unsigned)nblocks), dim3(HV_NT), 0, ctx->stream, A, ntx, ntiles);
+  else hipLaunchKernelGGL(hv_fused_kernel<HV_GENERIC>, dim3((unsigned)nblocks), dim3(HV_NT), 0, ctx->stream, A, ntx, ntiles);
   M6_HIP(hipGetLastError());
   return 0;
 }

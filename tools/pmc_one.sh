@@ -5,11 +5,11 @@
 set -e
 export TMPDIR=/tmp
 TAG=$1; shift
-GROUPS=()
-while [ "$1" != "--" ]; do GROUPS+=("$1"); shift; done
+GRPS=()
+while [ "$1" != "--" ]; do GRPS+=("$1"); shift; done
 shift
 n=0
-for grp in "${GROUPS[@]}"; do
+for grp in "${GRPS[@]}"; do
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_${TAG}_$n -o p -- python3 "$@" > /tmp/pmc_${TAG}_$n.out 2> /tmp/pmc_${TAG}_$n.err
   python3 tools/rocpd_pmc.py $(find /tmp/pmc_${TAG}_$n -name "*.db" | head -n 1) > gpurun_out/pmc_${TAG}_$n.txt
   n=$((n+1))
