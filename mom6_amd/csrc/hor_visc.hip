@@ -312,8 +312,6 @@ struct HVFArgs {
   double *diffu, *diffv;
 };
 
-constexpr int HV_TI = 64, HV_TJ = 16, HV_W = HV_TI + 4, HV_H = HV_TJ + 4, HV_NP = HV_W * HV_H, HV_NT = 512;
-constexpr int HV_NIT = (HV_NP + HV_NT - 1) / HV_NT;
 
 // CFG = HV_GENERIC: the options are read from the argument; otherwise they are the bits of CFG at compile time (the
 // production set -- biharmonic Smagorinsky with the better bounds -- is instantiated: the branches and the static arrays it
@@ -322,8 +320,9 @@ constexpr unsigned HV_GENERIC = ~0u;
 constexpr unsigned HV_BIH_SMAG = (1u << F_BIHARMONIC) | (1u << F_SMAG_AH) | (1u << F_BOUND_KH) | (1u << F_BETTER_BOUND_KH) | (1u << F_BOUND_AH) |
                                  (1u << F_BETTER_BOUND_AH) | (1u << F_LAND_MASK);
 
-template <unsigned CFG>
-__global__ __launch_bounds__(HV_NT, 4) void hv_fused_kernel(HVFArgs A, int ntx, int ntiles) {
+template <unsigned CFG, int HV_TI, int HV_TJ, int HV_NT, int WPE>
+__global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx, int ntiles) {
+  constexpr int HV_W = HV_TI + 4, HV_H = HV_TJ + 4, HV_NP = HV_W * HV_H, HV_NIT = (HV_NP + HV_NT - 1) / HV_NT;
   __shared__ double s_xx[HV_NP], s_xy[HV_NP], s_d2u[HV_NP], s_d2v[HV_NP], s_hu[HV_NP], s_hv[HV_NP];
   const HVFlags F = {CFG == HV_GENERIC ? A.flags.bits : CFG};
   const HVFOpt o = {F[F_LAPLACIAN], F[F_BIHARMONIC], F[F_SMAG_KH], F[F_SMAG_AH], F[F_BOUND_KH], F[F_BETTER_BOUND_KH], F[F_BOUND_AH],
@@ -669,11 +668,19 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
   A.h_neglect = g.H_subroundoff;
   A.u = u; A.v = v; A.h = h; A.hu_cont = hu_cont; A.hv_cont = hv_cont; A.diffu = diffu; A.diffv = diffv;
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
-  const int ntx = (ni + HV_TI - 1) / HV_TI, nty = (nj + HV_TJ - 1) / HV_TJ, ntiles = ntx * nty;
-  const long nblocks = (long)((ntiles + 7) / 8) * 8 * g.nk;
-  M6_REQUIRE(nblocks < (1L << 31), "horizontal_viscosity: the grid is too large for one launch");
-  if (A.flags.bits == HV_BIH_SMAG) hipLaunchKernelGGL(hv_fused_kernel<HV_BIH_SMAG>, dim3((unsigned)nblocks), dim3(HV_NT), 0, ctx->stream, A, ntx, ntiles);
-  else hipLaunchKernelGGL(hv_fused_kernel<HV_GENERIC>, dim3((unsigned)nblocks), dim3(HV_NT), 0, ctx->stream, A, ntx, ntiles);
+  auto launch = [&](auto kern, int TI, int TJ, int NT) {
+    const int ntx = (ni + TI - 1) / TI, nty = (nj + TJ - 1) / TJ, ntiles = ntx * nty;
+    const long nblocks = (long)((ntiles + 7) / 8) * 8 * g.nk;
+    if (nblocks >= (1L << 31)) return 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), 0, ctx->stream, A, ntx, ntiles);
+    return 0;
+  };
+  // (tiles of 64x8, 64x12, 32x16, 128x8 points and blocks of 256 / 1024 threads all ran within 5% of this one: the kernel is
+  // bound by the L2 -> L1 traffic of the metric planes, which every block reads for its tile -- profiles/r02_hor_visc.txt)
+  int rc;
+  if (A.flags.bits == HV_BIH_SMAG) rc = launch(hv_fused_kernel<HV_BIH_SMAG, 64, 16, 512, 4>, 64, 16, 512);
+  else rc = launch(hv_fused_kernel<HV_GENERIC, 64, 16, 512, 4>, 64, 16, 512);
+  M6_REQUIRE(rc == 0, "horizontal_viscosity: the grid is too large for one launch");
   M6_HIP(hipGetLastError());
   return 0;
 }
