@@ -6,7 +6,8 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmom6hip.so")
+# MOM6HIP_LIB_PATH: another build of the same library (kernel experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get("MOM6HIP_LIB_PATH") or os.path.join(_HERE, "libmom6hip.so")
 _LIB = None
 _dp = C.POINTER(C.c_double)
 

@@ -27,6 +27,11 @@ struct VVPar {      // the scalars of vertvisc_CS the kernels read
   int bottomdraglaw, harmonic_visc, direct_stress, CFL_based_trunc;
 };
 
+#ifndef VB_LAYERS
+#define VB_LAYERS 2
+#endif
+constexpr int VB = VB_LAYERS;      // layers loaded at once by the column sweeps
+
 struct CoefArgs {
   m6::GridDev g;
   VVPar p;
@@ -61,11 +66,23 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   if (kvml) {
     const double I_Hmix = 1.0 / (P.Hmix + hn);
     double z_t = hn * I_Hmix;
-    for (int K = 1; K < nz; K++) {
-      const double d0 = DZ(c0, K - 1), d1 = DZ(c1, K - 1);
-      const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
-      z_t = z_t + dz_harm * I_Hmix;
-      A.a[f2 + fpl * K] = P.Kv + P.Kvml_invZ2 / ((z_t * z_t) * (1.0 + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
+    for (int Kb = 1; Kb < nz; Kb += VB) {
+      double b_d0[VB], b_d1[VB];
+#pragma unroll
+      for (int q = 0; q < VB; q++) {
+        const int K = Kb + q;
+        b_d0[q] = b_d1[q] = 0.0;
+        if (K < nz) { b_d0[q] = DZ(c0, K - 1); b_d1[q] = DZ(c1, K - 1); }
+      }
+#pragma unroll
+      for (int q = 0; q < VB; q++) {
+        const int K = Kb + q;
+        if (K >= nz) break;
+        const double d0 = b_d0[q], d1 = b_d1[q];
+        const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+        z_t = z_t + dz_harm * I_Hmix;
+        A.a[f2 + fpl * K] = P.Kv + P.Kvml_invZ2 / ((z_t * z_t) * (1.0 + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
+      }
     }
   }
 
@@ -74,15 +91,36 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   double zh = 0.0, zcol0 = -g.bathyT[c0], zcol1 = -g.bathyT[c1];
   double z_i_below = 0.0;        // z_i(k+1)
   double dzv_below = 0.0;        // dz_vel(k+1)
-  for (int k = nz - 1; k >= 0; k--) {
-    const double h0 = A.h[c0 + hpl * k], h1 = A.h[c1 + hpl * k];
+  // The loop is a chain through k of short dependent steps: what a lane waits for is its loads.  VB layers are loaded at
+  // once (before any store of the batch, so nothing orders them behind the stores), then worked through in order.
+  for (int kb = nz - 1; kb >= 0; kb -= VB) {
+    double b_h0[VB], b_h1[VB], b_d0[VB], b_d1[VB], b_vel[VB], b_kvml[VB], b_ksh[VB];
+#pragma unroll
+    for (int q = 0; q < VB; q++) {
+      const int k = kb - q;
+      b_h0[q] = b_h1[q] = b_d0[q] = b_d1[q] = b_vel[q] = b_kvml[q] = b_ksh[q] = 0.0;
+      if (k >= 0) {
+        b_h0[q] = A.h[c0 + hpl * k]; b_h1[q] = A.h[c1 + hpl * k];
+        if (A.dz) { b_d0[q] = A.dz[c0 + hpl * k]; b_d1[q] = A.dz[c1 + hpl * k]; }
+        b_vel[q] = A.vel[f2 + fpl * k];
+        if (k + 1 < nz) {
+          if (kvml) b_kvml[q] = A.a[f2 + fpl * (k + 1)];
+          if (A.Kv_shear) b_ksh[q] = 0.5 * (A.Kv_shear[c0 + hpl * (k + 1)] + A.Kv_shear[c1 + hpl * (k + 1)]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < VB; q++) {
+    const int k = kb - q;
+    if (k < 0) break;
+    const double h0 = b_h0[q], h1 = b_h1[q];
     const double h_harm = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);      // :1324-1330
     const double h_arith = 0.5 * (h1 + h0);
     const double h_delta = h1 - h0;
-    const double d0 = DZ(c0, k), d1 = DZ(c1, k);
+    const double d0 = A.dz ? b_d0[q] : g.H_to_Z * h0, d1 = A.dz ? b_d1[q] : g.H_to_Z * h1;
     const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
     const double dz_arith = 0.5 * (d1 + d0);
-    const double vel = A.vel[f2 + fpl * k];
+    const double vel = b_vel[q];
     double hvel, dz_vel, z_i;
     if (P.harmonic_visc) {                                           // :1363-1375
       hvel = h_harm; dz_vel = dz_harm;
@@ -128,9 +166,9 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
         a_cpl = Kv_tot / ((0.5 * dz_vel + hn) + I_amax * Kv_tot);
       }
     } else {
-      double Kv_tot = kvml ? A.a[f2 + fpl * K] : P.Kv;
+      double Kv_tot = kvml ? b_kvml[q] : P.Kv;
       if (A.Kv_shear) {                                              // :1888-1928
-        const double Kv_add = 0.5 * (A.Kv_shear[c0 + hpl * K] + A.Kv_shear[c1 + hpl * K]);
+        const double Kv_add = b_ksh[q];
         Kv_tot = Kv_tot + Kv_add;
       }
       if (P.bottomdraglaw) {
@@ -153,6 +191,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
     }
     A.a[f2 + fpl * K] = min2(a_cpl_max, a_cpl + 0.0);                 // :1504 (a_cpl_gl90 = 0)
     z_i_below = z_i; dzv_below = dz_vel;
+    }
   }
   A.a[f2] = min2(a_cpl_max, 0.0 + 0.0);                               // a_cpl(:,1) = 0: no surface boundary layer scheme
 }
@@ -251,27 +290,61 @@ __device__ __forceinline__ void solve_column(const SolveArgs &A, int i, int j) {
     if (x) { xk = b1 * (A.hv[f2] * x[f2] + surface_stress); if (nz > 1 || !lim) x[f2] = xk; }
     if (xr) { rk = b1 * A.hv[f2]; xr[f2] = rk; }
     double a_next = A.a[f2 + fpl];
-    for (int k = 1; k < nz; k++) {
-      const long n = f2 + fpl * k;
-      const double ak = a_next, hvk = A.hv[n];
-      a_next = A.a[n + fpl];
-      A.c1[n] = dt * ak * b1;
-      b_denom_1 = hvk + dt * ((A.Ray ? A.Ray[n] : 0.0) + ak * d1);
-      b1 = 1.0 / (b_denom_1 + dt * a_next);
-      d1 = b_denom_1 * b1;
-      if (x) { xk = (hvk * x[n] + dt * ak * xk) * b1; if (k < nz - 1 || !lim) x[n] = xk; }
-      if (xr) { rk = (hvk + dt * ak * rk) * b1; xr[n] = rk; }
+    for (int kb = 1; kb < nz; kb += VB) {      // VB layers loaded at once, as in the coefficient sweep
+      double b_a[VB], b_hv[VB], b_x[VB], b_ray[VB];
+#pragma unroll
+      for (int q = 0; q < VB; q++) {
+        const int k = kb + q;
+        b_a[q] = b_hv[q] = b_x[q] = b_ray[q] = 0.0;
+        if (k < nz) {
+          const long n = f2 + fpl * k;
+          b_a[q] = A.a[n + fpl]; b_hv[q] = A.hv[n];
+          if (x) b_x[q] = x[n];
+          if (A.Ray) b_ray[q] = A.Ray[n];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < VB; q++) {
+        const int k = kb + q;
+        if (k >= nz) break;
+        const long n = f2 + fpl * k;
+        const double ak = a_next, hvk = b_hv[q];
+        a_next = b_a[q];
+        A.c1[n] = dt * ak * b1;
+        b_denom_1 = hvk + dt * ((A.Ray ? b_ray[q] : 0.0) + ak * d1);
+        b1 = 1.0 / (b_denom_1 + dt * a_next);
+        d1 = b_denom_1 * b1;
+        if (x) { xk = (hvk * b_x[q] + dt * ak * xk) * b1; if (k < nz - 1 || !lim) x[n] = xk; }
+        if (xr) { rk = (hvk + dt * ak * rk) * b1; xr[n] = rk; }
+      }
     }
     x_bot = xk;
     if (x && lim) x[f2 + fpl * (nz - 1)] = limit_vel<DIR>(g, P, xk, dt, dL, c0, cc1, A.h, hpl * (nz - 1), A.ntrunc);
-    for (int k = nz - 2; k >= 0; k--) {
-      const long n = f2 + fpl * k;
-      const double c = A.c1[n + fpl];
-      if (x) {
-        xk = x[n] + c * xk;
-        x[n] = lim ? limit_vel<DIR>(g, P, xk, dt, dL, c0, cc1, A.h, hpl * k, A.ntrunc) : xk;
+    for (int kb = nz - 2; kb >= 0; kb -= VB) {
+      double b_c[VB], b_x[VB], b_r[VB];
+#pragma unroll
+      for (int q = 0; q < VB; q++) {
+        const int k = kb - q;
+        b_c[q] = b_x[q] = b_r[q] = 0.0;
+        if (k >= 0) {
+          const long n = f2 + fpl * k;
+          b_c[q] = A.c1[n + fpl];
+          if (x) b_x[q] = x[n];
+          if (xr) b_r[q] = xr[n];
+        }
       }
-      if (xr) { rk = xr[n] + c * rk; xr[n] = rk; }
+#pragma unroll
+      for (int q = 0; q < VB; q++) {
+        const int k = kb - q;
+        if (k < 0) break;
+        const long n = f2 + fpl * k;
+        const double c = b_c[q];
+        if (x) {
+          xk = b_x[q] + c * xk;
+          x[n] = lim ? limit_vel<DIR>(g, P, xk, dt, dL, c0, cc1, A.h, hpl * k, A.ntrunc) : xk;
+        }
+        if (xr) { rk = b_r[q] + c * rk; xr[n] = rk; }
+      }
     }
   } else if (x) {
     x_bot = x[f2 + fpl * (nz - 1)];

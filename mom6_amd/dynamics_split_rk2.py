@@ -88,13 +88,46 @@ class MOM_dyn_split_RK2_CS:
         raise AttributeError(n)
 
 
-def initialize_dyn_split_RK2(u, v, h, uh, vh, dt, G: DeviceGrid, **params) -> MOM_dyn_split_RK2_CS:
+# the restart fields of the split scheme (register_restarts_dyn_split_RK2 :1181-1269, register_barotropic_restarts
+# MOM_barotropic.F90:5180-5220): restart name -> where it lives
+_RESTART_CS = {"sfc": "eta", "u2": "u_av", "v2": "v_av", "CAu": "CAu_pred", "CAv": "CAv_pred", "h2": "h_av", "diffu": "diffu", "diffv": "diffv"}
+_RESTART_BT = {"ubtav": "ubtav", "vbtav": "vbtav"}
+
+
+def save_restart_dyn_split_RK2(CS: MOM_dyn_split_RK2_CS, uh, vh) -> dict:
+    """What register_restarts_dyn_split_RK2 (:1181) and register_barotropic_restarts (MOM_barotropic.F90:5180) put into a
+    restart file, as copies: sfc, u2, v2, CAu, CAv (STORE_CORIOLIS_ACCEL), h2, uh, vh, diffu, diffv, ubtav, vbtav, DTBT."""
+    r = {n: getattr(CS, a).clone() for n, a in _RESTART_CS.items() if CS.st.store_CAu or n not in ("CAu", "CAv")}
+    r.update({n: getattr(CS.barotropic_CSp, a).clone() for n, a in _RESTART_BT.items()})
+    r["uh"], r["vh"] = uh.clone(), vh.clone()
+    r["DTBT"] = float(CS.barotropic_CSp.st.dtbt)
+    r["DTBT_max"] = float(CS.barotropic_CSp.st.dtbt_max)
+    return r
+
+
+def initialize_dyn_split_RK2(u, v, h, uh, vh, dt, G: DeviceGrid, restart=None, **params) -> MOM_dyn_split_RK2_CS:
     """initialize_dyn_split_RK2 (:1326): control structures of the step and of the modules it calls (parameters by
-    their reference names, e.g. BE=0.6, barotropic=dict(BEBT=0.1, DTBT=-0.98)), then the state the first step needs."""
+    their reference names, e.g. BE=0.6, barotropic=dict(BEBT=0.1, DTBT=-0.98)), then the state the first step needs.
+    restart = the fields of save_restart_dyn_split_RK2: every field present there counts as query_initialized (:1523-1610,
+    MOM_barotropic.F90:4895, :5050) and replaces what the cold start computes, uh / vh included."""
     params.setdefault("DT", dt)
     CS = MOM_dyn_split_RK2_CS(G, **params)
     check(_setup().mom6hip_dyn_split_rk2_init(G.handle, C.byref(CS.st), u.data_ptr(), v.data_ptr(), h.data_ptr(), uh.data_ptr(),
                                               vh.data_ptr(), float(dt)), "initialize_dyn_split_RK2")
+    if restart is not None:
+        for n, a in _RESTART_CS.items():
+            if n in restart:
+                getattr(CS, a).copy_(restart[n])
+        if "CAu" in restart and "CAv" in restart and CS.st.store_CAu:
+            CS.st.CAu_pred_stored = 1      # :1561-1563
+        for n, a in _RESTART_BT.items():
+            if n in restart:
+                getattr(CS.barotropic_CSp, a).copy_(restart[n])
+        if "uh" in restart:
+            uh.copy_(restart["uh"]); vh.copy_(restart["vh"])
+        if "DTBT" in restart:      # MOM_barotropic.F90:4895: the restart's DTBT when DTBT_RESET_PERIOD does not force a reset
+            CS.barotropic_CSp.st.dtbt = float(restart["DTBT"])
+            CS.barotropic_CSp.st.dtbt_max = float(restart.get("DTBT_max", CS.barotropic_CSp.st.dtbt_max))
     CS.module_is_initialized = True
     return CS
 

@@ -1,0 +1,290 @@
+"""Size-independent properties of the hot path, on the oracle (CPU) and on the library (GPU):
+
+  * rotation: a quarter turn of the grid and of the inputs turns the outputs, to the bit (the reference is written so --
+    its own .testing `test.rotate`); continuity_PPM, CorAdCalc, PressureForce, and the whole split RK2 step;
+  * dimensional rescaling: lengths, times and thicknesses scaled by powers of two scale the outputs exactly
+    (the reference's unit-scaling tests, `test.dim.*`);
+  * restart independence: two steps == one step, save the restart fields, initialise from them, one more step."""
+import numpy as np
+import pytest
+
+from helpers import interior
+from mom6_amd import _abi, synth
+from oracle import orc
+from rotation import rot, rot_vector, rotate_grid, unrot, unrot_vector
+
+
+def same(a, b):
+    """equal values (+0 == -0: a turned zero vector component is -0)"""
+    return np.array_equal(a, b)
+
+
+def case(ni=26, nj=18, nk=4, seed=3, reentrant=(True, False), land_frac=0.2):
+    g = synth.make_grid(ni, nj, nk, land_frac=land_frac, seed=seed + 400, reentrant_x=reentrant[0], reentrant_y=reentrant[1])
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.3, eta_amp=0.2).items()}
+    return g, d
+
+
+def turned(g, d):
+    gr = rotate_grid(g)
+    ur, vr = rot_vector(d["u"], d["v"])
+    dr = dict(u=ur, v=vr, h=rot(d["h"]), T=rot(d["T"]), S=rot(d["S"]))
+    return gr, dr
+
+
+class OracleOps:
+    @staticmethod
+    def continuity(g, u, v, h, dt):
+        hn = np.zeros_like(h); uh = np.zeros_like(u); vh = np.zeros_like(v)
+        orc.continuity(g, orc.continuity_cs(g.nk, g.Angstrom_H), u, v, h, hn, uh, vh, dt)
+        return hn, uh, vh
+
+    @staticmethod
+    def coradcalc(g, u, v, h, uh, vh, **kw):
+        return orc.coradcalc(g, u, v, h, uh, vh, **kw)
+
+    @staticmethod
+    def pressureforce(g, h, T, S):
+        return orc.pressureforce(g, orc.pressureforce_cs(g), orc.eos("WRIGHT"), h, T, S)
+
+
+class HipOps:
+    def __init__(self):
+        self.dgs = {}
+
+    def dg(self, g):
+        from mom6_amd.tracer_advect import DeviceGrid
+        if id(g) not in self.dgs:
+            self.dgs[id(g)] = DeviceGrid(g)
+        return self.dgs[id(g)]
+
+    def continuity(self, g, u, v, h, dt):
+        import torch
+        from mom6_amd.continuity import continuity, continuity_PPM_init
+        dg = self.dg(g)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        du, dv, dh = T(u), T(v), T(h)
+        hn, uh, vh = torch.zeros_like(dh), torch.zeros_like(du), torch.zeros_like(dv)
+        continuity(du, dv, dh, hn, uh, vh, dt, dg, continuity_PPM_init(dg))
+        return hn.cpu().numpy(), uh.cpu().numpy(), vh.cpu().numpy()
+
+    def coradcalc(self, g, u, v, h, uh, vh, **kw):
+        import torch
+        from mom6_amd.coriolis_adv import CorAdCalc, CoriolisAdv_init
+        dg = self.dg(g)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        du, dv = T(u), T(v)
+        CAu, CAv = torch.zeros_like(du), torch.zeros_like(dv)
+        CorAdCalc(du, dv, T(h), T(uh), T(vh), CAu, CAv, None, dg, CoriolisAdv_init(**kw))
+        return CAu.cpu().numpy(), CAv.cpu().numpy()
+
+    def pressureforce(self, g, h, T_, S_):
+        import torch
+        from mom6_amd.pressure_force import EOS_init, PressureForce, PressureForce_init
+        dg = self.dg(g)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+        PFu, PFv, pbce, eta = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H), Z(_abi.POS_H, False)
+        PressureForce(T(h), (T(T_), T(S_), EOS_init("WRIGHT")), PFu, PFv, dg, PressureForce_init(g), pbce=pbce, eta=eta)
+        return PFu.cpu().numpy(), PFv.cpu().numpy(), pbce.cpu().numpy(), eta.cpu().numpy()
+
+
+def check_rotation_of_operators(ops, reentrant):
+    g, d = case(reentrant=reentrant)
+    gr, dr = turned(g, d)
+    dt = 900.0
+    # continuity_PPM: the x sweep of the turned grid is the y sweep of the original (first_direction turns with the grid)
+    hn, uh, vh = ops.continuity(g, d["u"], d["v"], d["h"], dt)
+    hn_r, uh_r, vh_r = ops.continuity(gr, dr["u"], dr["v"], dr["h"], dt)
+    uh_b, vh_b = unrot_vector(uh_r, vh_r)
+    assert same(interior(g, unrot(hn_r)), interior(g, hn)), "continuity: h"
+    assert same(interior(g, uh_b, _abi.POS_U), interior(g, uh, _abi.POS_U)), "continuity: uh"
+    assert same(interior(g, vh_b, _abi.POS_V), interior(g, vh, _abi.POS_V)), "continuity: vh"
+    assert np.abs(uh).max() > 0 and np.abs(vh).max() > 0
+    # CorAdCalc (every Coriolis scheme the library has)
+    for sch in ("SADOURNY75_ENERGY", "ARAKAWA_HSU90", "SADOURNY75_ENSTRO"):
+        for a, pos in ((uh, _abi.POS_U), (vh, _abi.POS_V)):
+            orc.halo_update(g, a, pos)
+        uh_r, vh_r = rot_vector(uh, vh)
+        CAu, CAv = ops.coradcalc(g, d["u"], d["v"], d["h"], uh, vh, coriolis_scheme=sch)
+        CAu_r, CAv_r = ops.coradcalc(gr, dr["u"], dr["v"], dr["h"], uh_r, vh_r, coriolis_scheme=sch)
+        CAu_b, CAv_b = unrot_vector(CAu_r, CAv_r)
+        assert same(interior(g, CAu_b, _abi.POS_U), interior(g, CAu, _abi.POS_U)), ("CorAdCalc: CAu", sch)
+        assert same(interior(g, CAv_b, _abi.POS_V), interior(g, CAv, _abi.POS_V)), ("CorAdCalc: CAv", sch)
+        assert np.abs(CAu).max() > 0
+    # PressureForce_FV_Bouss
+    PFu, PFv, pbce, eta = ops.pressureforce(g, d["h"], d["T"], d["S"])[:4]
+    PFu_r, PFv_r, pbce_r, eta_r = ops.pressureforce(gr, dr["h"], dr["T"], dr["S"])[:4]
+    PFu_b, PFv_b = unrot_vector(PFu_r, PFv_r)
+    assert same(interior(g, PFu_b, _abi.POS_U)[..., :, 1:-1], interior(g, PFu, _abi.POS_U)[..., :, 1:-1]), "PressureForce: PFu"
+    assert same(interior(g, PFv_b, _abi.POS_V)[..., 1:-1, :], interior(g, PFv, _abi.POS_V)[..., 1:-1, :]), "PressureForce: PFv"
+    assert same(interior(g, unrot(pbce_r)), interior(g, pbce)), "PressureForce: pbce"
+
+
+@pytest.mark.parametrize("reentrant", [(True, False), (False, False), (True, True)])
+def test_oracle_operators_turn_with_the_grid(reentrant):
+    check_rotation_of_operators(OracleOps, reentrant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reentrant", [(True, False), (True, True)])
+def test_hip_operators_turn_with_the_grid(reentrant):
+    check_rotation_of_operators(HipOps(), reentrant)
+
+
+# ---- the whole split RK2 step --------------------------------------------------------------------------------------
+VV = dict(Kv=1.0e-4, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=1.0e-2)
+HV = dict(biharmonic=1, Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.01)
+
+
+def oracle_steps(g, d, taux, tauy, dt, nsteps, viscous):
+    kw = {}
+    if viscous:
+        visc = orc.vertvisc_type(Kv_bbl_u=1.0e-3 * g.mask2dCu, Kv_bbl_v=1.0e-3 * g.mask2dCv, bbl_thick_u=5.0 * g.mask2dCu,
+                                 bbl_thick_v=5.0 * g.mask2dCv)
+        kw = dict(vertvisc=orc.vertvisc_cs(g, **VV), visc=visc, hor_visc=orc.hor_visc_cs(g, dt, **HV))
+    st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, **kw)
+    for n in range(nsteps):
+        st.step(taux, tauy, calc_dtbt=(n == 0))
+    return st
+
+
+@pytest.mark.parametrize("viscous", [False, True])
+def test_oracle_rk2_step_turns_with_the_grid(viscous):
+    g, d = case(ni=22, nj=16, nk=3, seed=5)
+    gr, dr = turned(g, d)
+    yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = np.ascontiguousarray(0.02 * g.mask2dCv)
+    taux_r, tauy_r = rot_vector(taux, tauy)
+    a = oracle_steps(g, d, taux, tauy, 900.0, 2, viscous)
+    b = oracle_steps(gr, dr, taux_r, tauy_r, 900.0, 2, viscous)
+    assert a.bcs.nstep_last == b.bcs.nstep_last and a.bcs.dtbt == b.bcs.dtbt
+    ub, vb = unrot_vector(b.u, b.v)
+    assert same(interior(g, unrot(b.h)), interior(g, a.h)), "h"
+    assert same(interior(g, ub, _abi.POS_U), interior(g, a.u, _abi.POS_U)), "u"
+    assert same(interior(g, vb, _abi.POS_V), interior(g, a.v, _abi.POS_V)), "v"
+    assert same(interior(g, unrot(b.arrs["eta"])), interior(g, a.arrs["eta"])), "eta"
+    uhb, vhb = unrot_vector(b.uhtr, b.vhtr)
+    assert same(interior(g, uhb, _abi.POS_U), interior(g, a.uhtr, _abi.POS_U)), "uhtr"
+
+
+def hip_steps(g, d, taux, tauy, dt, nsteps, viscous, restart_after=None):
+    """nsteps of the library's step; restart_after = n: after step n the restart fields are saved and a NEW control
+    structure is initialised from them (and from u, v, h as they are) for the remaining steps"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, save_restart_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H, False)
+    kw, visc = dict(coriolis=dict(bound_coriolis=False)), None
+    if viscous:
+        kw.update(vertvisc=dict(KV=VV["Kv"], HBBL=VV["Hbbl"], HMIX_FIXED=VV["Hmix"], KV_ML_INVZ2=VV["Kvml_invZ2"]),
+                  hor_visc=dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=HV["Smag_bi_const"], AH_VEL_SCALE=HV["Ah_vel_scale"]))
+        visc = vertvisc_type(Kv_bbl_u=T(1.0e-3 * g.mask2dCu), Kv_bbl_v=T(1.0e-3 * g.mask2dCv), bbl_thick_u=T(5.0 * g.mask2dCu),
+                             bbl_thick_v=T(5.0 * g.mask2dCv))
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, **kw)
+    tx, ty = T(taux), T(tauy)
+    for n in range(nsteps):
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        if restart_after is not None and n + 1 == restart_after:
+            dg.sync()
+            rst = save_restart_dyn_split_RK2(CS, uh, vh)
+            del CS
+            uh, vh = Z(_abi.POS_U), Z(_abi.POS_V)      # a new run: nothing but u, v, h, T, S and the restart fields survives
+            CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, restart=rst, **kw)
+    dg.sync()
+    out = dict(u=u, v=v, h=h, uh=uh, vh=vh, uhtr=uhtr, vhtr=vhtr, eta=CS.eta, eta_av=eta_av, u_av=CS.u_av, h_av=CS.h_av)
+    out = {k: a.cpu().numpy() for k, a in out.items()}
+    out["nstep"], out["dtbt"] = int(CS.barotropic_CSp.st.nstep_last), float(CS.barotropic_CSp.st.dtbt)
+    dg.close()
+    return out
+
+
+def forcing(g):
+    yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
+    return np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu), np.ascontiguousarray(0.02 * g.mask2dCv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("viscous", [False, True])
+def test_hip_rk2_step_turns_with_the_grid(viscous):
+    g, d = case(ni=70, nj=40, nk=5, seed=5)
+    gr, dr = turned(g, d)
+    taux, tauy = forcing(g)
+    taux_r, tauy_r = rot_vector(taux, tauy)
+    a = hip_steps(g, d, taux, tauy, 900.0, 2, viscous)
+    b = hip_steps(gr, dr, taux_r, tauy_r, 900.0, 2, viscous)
+    assert a["nstep"] == b["nstep"] and a["dtbt"] == b["dtbt"]
+    ub, vb = unrot_vector(b["u"], b["v"])
+    assert same(interior(g, unrot(b["h"])), interior(g, a["h"])), "h"
+    assert same(interior(g, ub, _abi.POS_U), interior(g, a["u"], _abi.POS_U)), "u"
+    assert same(interior(g, vb, _abi.POS_V), interior(g, a["v"], _abi.POS_V)), "v"
+    assert same(interior(g, unrot(b["eta"])), interior(g, a["eta"])), "eta"
+    assert np.abs(a["u"]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("viscous", [False, True])
+def test_hip_rk2_restart_independence(viscous):
+    """3 steps == 2 steps + restart file + 1 step: the fields register_restarts_dyn_split_RK2 / register_barotropic_restarts
+    name are all the state the step carries (MOM_dynamics_split_RK2.F90:1181-1269, MOM_barotropic.F90:5180-5220)"""
+    g, d = case(ni=70, nj=40, nk=5, seed=6)
+    taux, tauy = forcing(g)
+    a = hip_steps(g, d, taux, tauy, 900.0, 3, viscous)
+    b = hip_steps(g, d, taux, tauy, 900.0, 3, viscous, restart_after=2)
+    for n in ("u", "v", "h", "uh", "vh", "eta", "eta_av", "u_av", "h_av"):
+        pos = {"u": _abi.POS_U, "uh": _abi.POS_U, "u_av": _abi.POS_U, "v": _abi.POS_V, "vh": _abi.POS_V}.get(n, _abi.POS_H)
+        assert np.array_equal(interior(g, a[n], pos).view(np.uint64), interior(g, b[n], pos).view(np.uint64)), n
+    assert a["dtbt"] == b["dtbt"] and a["nstep"] == b["nstep"]
+
+
+# ---- dimensional rescaling -------------------------------------------------------------------------------------------
+def rescaled(g, d, a, b, c):
+    """the grid and state with lengths x 2^a, times x 2^b, thicknesses x 2^c (the reference's L/T/H_RESCALE_POWER)"""
+    from mom6_amd.grid import Grid
+    L, Tm, H = 2.0 ** a, 2.0 ** b, 2.0 ** c
+    r = Grid(ni=g.ni, nj=g.nj, nk=g.nk, halo=g.halo, reentrant_x=g.reentrant_x, reentrant_y=g.reentrant_y, first_direction=g.first_direction,
+             Angstrom_H=g.Angstrom_H * H, H_to_Z=g.H_to_Z / H, Z_to_H=g.Z_to_H * H, g_Earth=g.g_Earth * L * L / (Tm * Tm), Rho0=g.Rho0)
+    r.H_subroundoff = g.H_subroundoff * H      # GV%H_subroundoff carries the H scaling (MOM_verticalGrid.F90:165)
+    for n, m in g.metrics.items():
+        s = 1.0
+        if n.startswith(("dx", "dy")): s = L
+        elif n.startswith(("Idx", "Idy")): s = 1.0 / L
+        elif n.startswith("area"): s = L * L
+        elif n.startswith("Iarea"): s = 1.0 / (L * L)
+        elif n == "CoriolisBu": s = 1.0 / Tm
+        r.set_metric(n, m * s)
+    dr = dict(u=d["u"] * (L / Tm), v=d["v"] * (L / Tm), h=d["h"] * H, T=d["T"], S=d["S"])
+    return r, dr
+
+
+def check_rescaling(ops):
+    g, d = case()
+    a, b, c = 3, -2, 5
+    L, Tm, H = 2.0 ** a, 2.0 ** b, 2.0 ** c
+    gs, ds = rescaled(g, d, a, b, c)
+    dt = 900.0
+    hn, uh, vh = ops.continuity(g, d["u"], d["v"], d["h"], dt)
+    hn_s, uh_s, vh_s = ops.continuity(gs, ds["u"], ds["v"], ds["h"], dt * Tm)
+    assert same(interior(g, hn_s), interior(g, hn) * H), "continuity: h"
+    assert same(interior(g, uh_s, _abi.POS_U), interior(g, uh, _abi.POS_U) * (H * L * L / Tm)), "continuity: uh"
+    assert same(interior(g, vh_s, _abi.POS_V), interior(g, vh, _abi.POS_V) * (H * L * L / Tm)), "continuity: vh"
+    for x, pos in ((uh, _abi.POS_U), (vh, _abi.POS_V)):
+        orc.halo_update(g, x, pos)
+    CAu, CAv = ops.coradcalc(g, d["u"], d["v"], d["h"], uh, vh)
+    CAu_s, CAv_s = ops.coradcalc(gs, ds["u"], ds["v"], ds["h"], uh * (H * L * L / Tm), vh * (H * L * L / Tm))
+    assert same(interior(g, CAu_s, _abi.POS_U), interior(g, CAu, _abi.POS_U) * (L / (Tm * Tm))), "CorAdCalc: CAu"
+    assert same(interior(g, CAv_s, _abi.POS_V), interior(g, CAv, _abi.POS_V) * (L / (Tm * Tm))), "CorAdCalc: CAv"
+
+
+def test_oracle_rescaling_by_powers_of_two():
+    check_rescaling(OracleOps)
+
+
+@pytest.mark.gpu
+def test_hip_rescaling_by_powers_of_two():
+    check_rescaling(HipOps())
