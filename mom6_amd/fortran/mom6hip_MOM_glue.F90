@@ -22,12 +22,15 @@ use MOM_grid,          only : ocean_grid_type
 use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
 
-public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_fatal_if
+public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_shared_context, mom6hip_shared_context_end
 
 !> The grid of the (single) ocean instance the callbacks act on
 type(ocean_grid_type), pointer, save :: G_cb => NULL()
 type(c_ptr), save :: ctx_cb = c_null_ptr   !< the context whose stream the staged copies use
 integer, save :: nk_cb = 0
+!> One context per process, shared by every module shim (the metrics are uploaded once): mom6hip_shared_context
+type(c_ptr), save :: ctx_shared = c_null_ptr
+logical, save :: topology_known = .false., reentrant_saved(2) = .false.
 
 contains
 
@@ -42,17 +45,39 @@ end subroutine mom6hip_fatal_if
 !! Called from a module's *_init (which has the parameter file) so that the one-tile fast path knows the topology.
 subroutine mom6hip_read_topology(param_file, reentrant)
   type(param_file_type), intent(in)  :: param_file
-  logical,               intent(out) :: reentrant(2)
-  logical :: tripolar_N
-  call get_param(param_file, "mom6hip", "REENTRANT_X", reentrant(1), default=.true., do_not_log=.true.)
-  call get_param(param_file, "mom6hip", "REENTRANT_Y", reentrant(2), default=.false., do_not_log=.true.)
+  logical,     optional, intent(out) :: reentrant(2)
+  logical :: tripolar_N, re(2)
+  call get_param(param_file, "mom6hip", "REENTRANT_X", re(1), default=.true., do_not_log=.true.)
+  call get_param(param_file, "mom6hip", "REENTRANT_Y", re(2), default=.false., do_not_log=.true.)
   call get_param(param_file, "mom6hip", "TRIPOLAR_N", tripolar_N, default=.false., do_not_log=.true.)
   if (tripolar_N) call MOM_error(FATAL, "mom6hip: TRIPOLAR_N (the northern fold) is not supported by the GPU path.")
+  topology_known = .true. ; reentrant_saved(:) = re(:)
+  if (present(reentrant)) reentrant(:) = re(:)
 end subroutine mom6hip_read_topology
+
+!> The process-wide context (created on the first call, from whichever module gets there first).  The *_init of every
+!! shim calls mom6hip_read_topology, so the one-tile fast path knows REENTRANT_X / REENTRANT_Y by then.
+function mom6hip_shared_context(G, GV) result(ctx)
+  type(ocean_grid_type), target, intent(in) :: G
+  type(verticalGrid_type),       intent(in) :: GV
+  type(c_ptr) :: ctx
+  if (.not. c_associated(ctx_shared)) then
+    if (topology_known) then ; call mom6hip_context_create(G, GV, ctx_shared, reentrant_saved)
+    else ; call mom6hip_context_create(G, GV, ctx_shared) ; endif
+  endif
+  ctx = ctx_shared
+end function mom6hip_shared_context
+
+!> Release the shared context (the *_end of the last module; harmless when called again)
+subroutine mom6hip_shared_context_end()
+  integer :: rc
+  if (c_associated(ctx_shared)) rc = mom6hip_grid_destroy(ctx_shared)
+  ctx_shared = c_null_ptr
+end subroutine mom6hip_shared_context_end
 
 !> Upload the metrics of G once and return the context; registers the collectives when they are needed.
 subroutine mom6hip_context_create(G, GV, ctx, reentrant)
-  type(ocean_grid_type), target,   intent(inout) :: G
+  type(ocean_grid_type), target,   intent(in)    :: G
   type(verticalGrid_type),         intent(in)    :: GV
   type(c_ptr),                     intent(out)   :: ctx
   logical,               optional, intent(in)    :: reentrant(2) !< from mom6hip_read_topology: enables the one-tile fast path

@@ -68,3 +68,100 @@ def test_fortran_driver_matches_oracle(tmp_path, oracle):
     r1, r2 = np.split(res, 2)
     assert bits_equal(t1.ravel(), r1) and bits_equal(t2.ravel(), r2)
     assert f"iterations={st.iterations}" in r.stdout
+
+
+# ---- the module shims (MOM_continuity_PPM, MOM_CoriolisAdv, MOM_tracer_advect) against the type-only stand-ins --------
+FDIR = os.path.join(ROOT, "mom6_amd", "fortran")
+STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
+SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_tracer_advect_hip.F90"]
+
+
+def _build_shims(tmp):
+    """amdflang with MOM6's conventions: preprocessed .F90, default real = 8 bytes"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in SHIMS] + \
+               [os.path.join(ROOT, "tests", "fortran", "shim_driver.F90")]:
+        o = str(tmp / (os.path.basename(src)[:-4] + ".o"))
+        subprocess.run([FC, *flags, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    libdir = os.path.join(ROOT, "mom6_amd")
+    exe = str(tmp / "shim_driver")
+    subprocess.run([FC, *objs, f"-L{libdir}", "-lmom6hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    return exe
+
+
+def _shim_case(path, reentrant=(True, True)):
+    """the input file of tests/fortran/shim_driver.F90 and the same inputs for the oracle"""
+    from mom6_amd import synth
+    from oracle import orc
+    ni, nj, nk, halo = 30, 14, 4, 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=77, reentrant_x=reentrant[0], reentrant_y=reentrant[1])
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=5, umax=0.3, eta_amp=0.2).items()}
+    kk = (np.arange(nk) + 0.5) / nk
+    vru = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["u"], 0.0, 1.0) * (g.mask2dCu[None] > 0))
+    vrv = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["v"], 0.0, 1.0) * (g.mask2dCv[None] > 0))
+    dt = 900.0
+    ccs = orc.continuity_cs(nk, g.Angstrom_H)
+    # call 1 (also gives the barotropic transports the second call has to match)
+    hp = d["h"].copy(); uh = np.zeros_like(d["u"]); vh = np.zeros_like(d["v"])
+    arrs, bt = orc.make_bt_cont(g, with_h=True)
+    orc.continuity(g, ccs, d["u"], d["v"], d["h"], hp, uh, vh, dt, visc_rem_u=vru, visc_rem_v=vrv, bt_cont=bt)
+    uhbt = np.ascontiguousarray(uh.sum(0) * 1.02); vhbt = np.ascontiguousarray(vh.sum(0) * 0.98)
+    with open(path, "wb") as f:
+        np.array([ni, nj, nk, halo, int(reentrant[0]), int(reentrant[1]), g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], uhbt, vhbt, vru, vrv):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+    # call 2 and CorAdCalc, as the driver does them
+    hp2 = d["h"].copy(); uh2 = np.zeros_like(d["u"]); vh2 = np.zeros_like(d["v"]); ucor = np.zeros_like(d["u"]); vcor = np.zeros_like(d["v"])
+    orc.continuity(g, ccs, d["u"], d["v"], d["h"], hp2, uh2, vh2, dt, uhbt=uhbt, vhbt=vhbt, visc_rem_u=vru, visc_rem_v=vrv, u_cor=ucor,
+                   v_cor=vcor, bt_cont=bt)
+    orc.halo_update(g, uh2, _abi.POS_U); orc.halo_update(g, vh2, _abi.POS_V)
+    CAu, CAv = orc.coradcalc(g, d["u"], d["v"], d["h"], uh2, vh2, bound_coriolis=True)
+    want = [hp, uh, vh, hp2, uh2, vh2, ucor, vcor, CAu, CAv] + [arrs[n] for n in ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE",
+                                                                                     "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN",
+                                                                                     "h_u", "h_v")]
+    names = ["hp", "uh", "vh", "hp2", "uh2", "vh2", "u_cor", "v_cor", "CAu", "CAv", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE",
+             "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"]
+    return g, names, want
+
+
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_module_shims_compile_against_type_stubs_and_fail_loudly_without_gpu(tmp_path):
+    """mom6_amd/fortran/*.F90 with the reference's module names and dummy-argument lists compile (amdflang, real*8) against
+    tests/fortran/stubs; without a GPU the first library call stops with MOM_error(FATAL) carrying the library's message"""
+    exe = _build_shims(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    _shim_case(str(tmp_path / "in.bin"))
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "FATAL" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("reentrant", [(True, True), (True, False)])
+def test_module_shims_match_oracle(tmp_path, reentrant):
+    """continuity (both call forms of the RK2 step, with BT_cont) and CorAdCalc called through MOM_continuity_PPM /
+    MOM_CoriolisAdv with the reference's argument lists on Fortran host arrays: bit-identical with the oracle.
+    (True, False): a closed y direction -- the one-tile context wraps x only, as REENTRANT_Y = False says."""
+    exe = _build_shims(tmp_path)
+    g, names, want = _shim_case(str(tmp_path / "in.bin"), reentrant)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "shim_driver ok" in r.stdout
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    got = np.split(raw, np.cumsum(sizes)[:-1])
+    from helpers import interior
+    for n, a, w in zip(names, got, want):
+        a = a.reshape(w.shape)
+        pos = _abi.POS_U if n in ("uh", "uh2", "u_cor", "CAu", "h_u") or n.startswith(("FA_u", "uBT")) else \
+            (_abi.POS_V if n in ("vh", "vh2", "v_cor", "CAv", "h_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        assert bits_equal(interior(g, a, pos), interior(g, w, pos)), n
