@@ -139,6 +139,7 @@ type :: ocean_grid_type
   integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB, ke
   integer :: first_direction = 0
   logical :: symmetric = .true.
+  real :: max_depth = 0.0, Z_ref = 0.0
   real, allocatable, dimension(:,:) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
   real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
   real, allocatable, dimension(:,:) :: mask2dCv, dxCv, dyCv, dx_Cv, IdxCv, IdyCv, areaCv, IareaCv
@@ -152,8 +153,9 @@ public :: verticalGrid_type
 type :: verticalGrid_type
   integer :: ke
   real :: Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
-          Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0
-  real, allocatable :: Rlay(:)
+          Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0
+  logical :: Boussinesq = .true.
+  real, allocatable :: Rlay(:), g_prime(:)
 end type verticalGrid_type
 end module MOM_verticalGrid
 
@@ -309,6 +311,76 @@ subroutine get_param_char(CS, modulename, varname, value, desc, units, default, 
   endif
 end subroutine get_param_char
 end module MOM_file_parser
+
+module MOM_hor_index
+implicit none ; private
+public :: hor_index_type
+type :: hor_index_type
+  integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB
+end type hor_index_type
+end module MOM_hor_index
+
+!> Restart registration that remembers nothing: every field reads as "not initialized" (a cold start)
+module MOM_restart
+implicit none ; private
+public :: MOM_restart_CS, register_restart_field, query_initialized
+type :: MOM_restart_CS
+  integer :: nfields = 0
+end type MOM_restart_CS
+interface register_restart_field
+  module procedure register_2d, register_0d
+end interface
+interface query_initialized
+  module procedure query_2d, query_0d
+end interface
+contains
+subroutine register_2d(f_ptr, name, mandatory, CS, longname, units, conversion, hor_grid, z_grid, t_grid)
+  real, dimension(:,:), target, intent(in) :: f_ptr
+  character(len=*),     intent(in)    :: name
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  character(len=*), optional, intent(in) :: longname, units, hor_grid, z_grid, t_grid
+  real,             optional, intent(in) :: conversion
+  CS%nfields = CS%nfields + 1
+end subroutine register_2d
+subroutine register_0d(f_ptr, name, mandatory, CS, longname, units, conversion, t_grid)
+  real, target,         intent(in)    :: f_ptr
+  character(len=*),     intent(in)    :: name
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  character(len=*), optional, intent(in) :: longname, units, t_grid
+  real,             optional, intent(in) :: conversion
+  CS%nfields = CS%nfields + 1
+end subroutine register_0d
+logical function query_2d(f_ptr, name, CS)
+  real, dimension(:,:), intent(in) :: f_ptr
+  character(len=*),     intent(in) :: name
+  type(MOM_restart_CS), intent(in) :: CS
+  query_2d = .false.
+end function query_2d
+logical function query_0d(f_ptr, name, CS)
+  real,                 intent(in) :: f_ptr
+  character(len=*),     intent(in) :: name
+  type(MOM_restart_CS), intent(in) :: CS
+  query_0d = .false.
+end function query_0d
+end module MOM_restart
+
+module MOM_forcing_type
+implicit none ; private
+public :: mech_forcing
+type :: mech_forcing
+  real, pointer, dimension(:,:) :: taux => NULL(), tauy => NULL()
+end type mech_forcing
+end module MOM_forcing_type
+
+module MOM_self_attr_load
+implicit none ; private
+public :: SAL_CS
+type :: SAL_CS
+  integer :: unused = 0
+end type SAL_CS
+end module MOM_self_attr_load
 
 module MOM_open_boundary
 implicit none ; private

@@ -73,20 +73,21 @@ def test_fortran_driver_matches_oracle(tmp_path, oracle):
 # ---- the module shims (MOM_continuity_PPM, MOM_CoriolisAdv, MOM_tracer_advect) against the type-only stand-ins --------
 FDIR = os.path.join(ROOT, "mom6_amd", "fortran")
 STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
-SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_tracer_advect_hip.F90"]
+SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_barotropic_hip.F90",
+         "MOM_tracer_advect_hip.F90"]
 
 
-def _build_shims(tmp):
+def _build_shims(tmp, driver="shim_driver"):
     """amdflang with MOM6's conventions: preprocessed .F90, default real = 8 bytes"""
     flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
     objs = []
     for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in SHIMS] + \
-               [os.path.join(ROOT, "tests", "fortran", "shim_driver.F90")]:
+               [os.path.join(ROOT, "tests", "fortran", driver + ".F90")]:
         o = str(tmp / (os.path.basename(src)[:-4] + ".o"))
         subprocess.run([FC, *flags, "-c", src, "-o", o], check=True)
         objs.append(o)
     libdir = os.path.join(ROOT, "mom6_amd")
-    exe = str(tmp / "shim_driver")
+    exe = str(tmp / driver)
     subprocess.run([FC, *objs, f"-L{libdir}", "-lmom6hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
     return exe
 
@@ -164,4 +165,54 @@ def test_module_shims_match_oracle(tmp_path, reentrant):
         a = a.reshape(w.shape)
         pos = _abi.POS_U if n in ("uh", "uh2", "u_cor", "CAu", "h_u") or n.startswith(("FA_u", "uBT")) else \
             (_abi.POS_V if n in ("vh", "vh2", "v_cor", "CAv", "h_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        assert bits_equal(interior(g, a, pos), interior(g, w, pos)), n
+
+
+def _bt_case(path):
+    """the input file of tests/fortran/bt_driver.F90 (the btstep inputs of helpers.barotropic_case) and the oracle's results"""
+    from helpers import barotropic_case
+    from oracle import orc
+    g, cs, case, keep = barotropic_case(orc, ni=26, nj=14, nk=4, reentrant_x=True, reentrant_y=True, dt=900.0)
+    h = keep["h"]; bt = keep["bt_arrs"]
+    with open(path, "wb") as f:
+        np.array([g.ni, g.nj, g.nk, g.halo, 1, 1, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, case["dt"], cs.dtbt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (case["U_in"], case["V_in"], h, case["eta_in"], case["bc_accel_u"], case["bc_accel_v"], case["taux"], case["tauy"], case["pbce"],
+                  case["eta_PF_in"], case["visc_rem_u"], case["visc_rem_v"], case["uh0"], case["vh0"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        for n in ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"):
+            np.ascontiguousarray(bt[n], dtype="<f8").tofile(f)
+    # ubtav / vbtav of a cold start (MOM_barotropic.F90:5050-5062): btcalc with the default thicknesses, then the k-ordered sums
+    cs0, arrs0 = orc.barotropic_cs(g, hvel_scheme="FROM_BT_CONT")
+    orc.barotropic_init(g, cs0)
+    orc.btcalc(g, cs0, h, may_use_default=True)
+    ub = g.zeros2(_abi.POS_U); vb = g.zeros2(_abi.POS_V)
+    for k in range(g.nk):
+        ub = ub + arrs0["frhatu"][k] * case["U_in"][k]; vb = vb + arrs0["frhatv"][k] * case["V_in"][k]
+    out = orc.btstep(g, cs, want_etaav=True, **{k: v for k, v in case.items()})
+    want = [out["accel_layer_u"], out["accel_layer_v"], out["eta_out"], out["uhbtav"], out["vhbtav"], out["etaav"], ub, vb]
+    names = ["accel_layer_u", "accel_layer_v", "eta_out", "uhbtav", "vhbtav", "etaav", "ubtav", "vbtav"]
+    return g, names, want, int(cs.nstep_last)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_barotropic_shim_matches_oracle(tmp_path):
+    """barotropic_init (parameters by name, DTBT > 0), btcalc, bt_mass_source and btstep with the argument list of the RK2
+    step's call (MOM_dynamics_split_RK2.F90:655) through the MOM_barotropic shim on Fortran host arrays: bit-identical."""
+    exe = _build_shims(tmp_path, "bt_driver")
+    g, names, want, nstep = _bt_case(str(tmp_path / "in.bin"))
+    assert nstep >= 10
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "bt_driver ok calc_dtbt= T" in r.stdout
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    from helpers import interior
+    for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        a = a.reshape(w.shape)
+        pos = _abi.POS_U if n in ("accel_layer_u", "uhbtav", "ubtav") else (_abi.POS_V if n in ("accel_layer_v", "vhbtav", "vbtav") else _abi.POS_H)
         assert bits_equal(interior(g, a, pos), interior(g, w, pos)), n
