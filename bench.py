@@ -39,6 +39,7 @@ HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL
 SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
+PMC_PROFILE = "r02_b_pmc.json"      # the counter passes `roofline.traffic` is read from (profiles/)
 LAND_FRAC = 0.30
 # grid-scale bathymetric roughness (white noise, as a fraction of the depth range) with a fixed SLOPE: 0.04 on a 3-degree
 # grid, 0.0025 (14 m rms) at 1/4 degree.  With the amplitude held at 0.04 the 1/4-degree bathymetry had 200 m steps between
@@ -692,17 +693,24 @@ def main():
         if n_y > 0:
             alg = (40.0 + 48.0 + 40.0) / 3.0 * cells / world
             avg_ms = ms_y / n_y
-            traffic = None
+            # HBM bytes of the kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/
+            # profile_round.sh): valid only for the kernel source they were taken with -- the profile carries the SHA-256 of
+            # continuity.hip, and a different source (or workload) makes `traffic` null instead of stale
+            traffic, traffic_from = None, None
             try:
-                kern = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc.json")))["kernels"]
-                pmc = [v for k, v in kern.items() if k.startswith("cont_flux_coop_kernel<1")][0]
-                if a.workload == "om4_025" and world == 1:
-                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 passes
+                import hashlib
+                prof = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
+                sha = hashlib.sha256(open(os.path.join(ROOT, "mom6_amd", "csrc", "continuity.hip"), "rb").read()).hexdigest()
+                pmc = [v for k, v in prof["kernels"].items() if k.startswith("cont_flux_coop_kernel<1")][0]
+                if a.workload == "om4_025" and world == 1 and prof.get("source_sha256", {}).get("continuity.hip") == sha:
+                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+                    traffic_from = f"profiles/{PMC_PROFILE} (continuity.hip sha256 {sha[:12]})"
             except Exception:
                 pass
             out["roofline"] = {
                 "kernel": "cont_flux_coop_kernel<1,10>", "bound": "hbm", "achieved": alg / (avg_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_from": traffic_from,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n_y),
                 "also": {"cont_flux_coop_kernel<0,10>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
             }

@@ -1,5 +1,5 @@
 """profiles/<tag>_pmc.json from the two rocpd_pmc.py listings (FETCH_SIZE / WRITE_SIZE, in KB) of tools/profile_round.sh:
-    python tools/pmc_json.py r01_f gpurun_out/prof_r01_f profiles"""
+    python tools/pmc_json.py TAG gpurun_out/prof_TAG profiles"""
 import json, re, sys
 tag, src, dst = sys.argv[1:4]
 kern = {}
@@ -13,7 +13,12 @@ for c, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
             continue
         e = kern.setdefault(name, {"dispatches": int(m.group(3))})
         e[key] = float(m.group(4)) * 1024.0
+import hashlib, os
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+csrc = os.path.join(root, "mom6_amd", "csrc")
 out = {
+    "source_sha256": {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc))
+                      if f.endswith((".hip", ".hpp"))},
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py --steps 4 --warmup 0 "
               "--no-cpu-baseline --no-roofline; MI355X, om4_025 1440x1080x75 (tools/profile_round.sh)",
     "units": "bytes per launch, averaged over the launches of the run (the counters are in KB; x1024).  Calibration of the gfx950 "

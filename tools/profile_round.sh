@@ -12,4 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${TAG}_$c -o p -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline > /tmp/pmc_$c.json 2> /tmp/pmc_$c.err
   python3 tools/rocpd_pmc.py $(find /tmp/pmc_${TAG}_$c -name "*.db" | head -n 1) > $OUT/${TAG}_pmc_$c.txt
 done
+# fp64-VALU evidence for the compute-bound kernels (PressureForce, continuity): instruction and cycle counters, one more pass
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d /tmp/pmc_${TAG}_sq -o p -- python3 bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline > /tmp/pmc_sq.json 2> /tmp/pmc_sq.err
+python3 tools/rocpd_pmc.py $(find /tmp/pmc_${TAG}_sq -name "*.db" | head -n 1) > $OUT/${TAG}_pmc_sq.txt
 echo done
