@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int REMAP_PCM = 0, REMAP_PLM = 2, REMAP_PPM_H4 = 4;   // MOM_remapping.F90:50-55
+constexpr int REMAP_PCM = 0, REMAP_PLM = 2, REMAP_PPM_H4 = 4, REMAP_PPM_IH4 = 5, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-56
 constexpr int INT_PCM = 0, INT_PLM = 1, INT_PPM = 3;            // :61-63
 
 __device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
@@ -752,7 +752,7 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
   int local = scheme;
   if (n <= 1) local = REMAP_PCM;
   else if (n <= 3) local = (local < REMAP_PLM) ? local : REMAP_PLM;
-  else if (n <= 4) local = (local < REMAP_PPM_H4) ? local : REMAP_PPM_H4;
+  else if (n <= 4 && local != REMAP_PPM_CW) local = (local < REMAP_PPM_H4) ? local : REMAP_PPM_H4;      // :293
   if (local == REMAP_PCM) {
     for (int k = lane; k < n; k += 64) { EL[k] = u[k]; ER[k] = u[k]; c.C1[k] = 0.; }
     wsync();
@@ -794,6 +794,103 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     wsync();
     return INT_PLM;
   }
+  if (local == REMAP_PPM_IH4) {
+    // ---- PPM_IH4: edge_values_implicit_h4 (regrid_edge_values.F90:491-654, answer_date >= 20190101).  The rows of the
+    // tridiagonal system across the lanes, the two closing rows on the last two lanes, solve_diag_dominant_tridiag
+    // (regrid_solvers.F90:246-280) as a serial walk by one lane (the solution overwrites the right-hand side).
+    const double hNeglect = h_neglect_edge;
+    double *tri_l = c.u_sub, *tri_c = c.u_sub + (n + 1), *tri_u = c.uh_sub, *tri_b = c.uh_sub + (n + 1), *c1 = c.C1;
+    for (int i = lane; i < n - 1; i += 64) {
+      double h0 = fmax(h[i], hNeglect);
+      double h1 = fmax(h[i + 1], hNeglect);
+      if (fabs(h0) < 1.0e-12 * fabs(h1)) h0 = 1.0e-12 * h1;
+      if (fabs(h1) < 1.0e-12 * fabs(h0)) h1 = 1.0e-12 * h0;
+      const double I_h2 = 1.0 / ((h0 + h1) * (h0 + h1));
+      const double alpha = (h1 * h1) * I_h2;
+      const double beta = (h0 * h0) * I_h2;
+      const double abmix = (h0 * h1) * I_h2;
+      const double a = 2.0 * alpha * (alpha + 2.0 * beta + 3.0 * abmix);
+      const double b = 2.0 * beta * (beta + 2.0 * alpha + 3.0 * abmix);
+      tri_c[i + 1] = 2.0 * abmix; tri_l[i + 1] = alpha; tri_u[i + 1] = beta;
+      tri_b[i + 1] = a * u[i] + b * u[i + 1];
+    }
+    if (lane >= 62) {      // the first (lane 62) and the last (lane 63) boundary value
+      const bool last = lane == 63;
+      double dz[4], ut[4], Cs[4];
+      for (int i = 0; i < 4; i++) { const int q = last ? n - 1 - i : i; dz[i] = fmax(hNeglect, h[q]); ut[i] = u[q]; }
+      end_value_h4(dz, ut, Cs);
+      const int row = last ? n : 0;
+      tri_b[row] = Cs[0]; tri_c[row] = 1.0; tri_u[row] = 0.0; tri_l[row] = 0.0;
+    }
+    wsync();
+    if (lane == 0) {
+      const int N = n + 1;
+      double I_pivot = 1.0 / (tri_c[0] + tri_u[0]);
+      double d1 = tri_c[0] * I_pivot;
+      c1[0] = tri_u[0] * I_pivot;
+      tri_b[0] = tri_b[0] * I_pivot;
+      for (int k = 1; k < N - 1; k++) {
+        const double denom_t1 = tri_c[k] + d1 * tri_l[k];
+        I_pivot = 1.0 / (denom_t1 + tri_u[k]);
+        d1 = denom_t1 * I_pivot;
+        c1[k] = tri_u[k] * I_pivot;
+        tri_b[k] = (tri_b[k] - tri_l[k] * tri_b[k - 1]) * I_pivot;
+      }
+      I_pivot = 1.0 / (tri_c[N - 1] + d1 * tri_l[N - 1]);
+      tri_b[N - 1] = (tri_b[N - 1] - tri_l[N - 1] * tri_b[N - 2]) * I_pivot;
+      for (int k = N - 2; k >= 0; k--) tri_b[k] = tri_b[k] - c1[k] * tri_b[k + 1];
+    }
+    wsync();
+    for (int k = lane; k < n; k += 64) { EL[k] = tri_b[k]; ER[k] = tri_b[k + 1]; }
+    wsync();
+  } else if (local == REMAP_PPM_CW) {
+    // ---- PPM_CW: edge_values_explicit_h4cw (regrid_edge_values.F90:381-463) and PPM_monotonicity (PPM_functions.F90:132)
+    const double hNeglect = h_neglect_edge;
+    double *au = c.u_sub;      // the limited slopes of Colella & Woodward eq. 1.8, 0-based cell index
+    auto dp = [&](int k) { return fmax(h[k], hNeglect); };      // 0-based; the reference's dp(k+1)
+    for (int k = lane; k < n; k += 64) {
+      double a = 0.;
+      if (k >= 1 && k <= n - 2) {
+        const double slk = u[k] - u[k - 1];
+        const double srk = u[k + 1] - u[k];
+        if (slk * srk > 0.) {
+          // h2_h123(k), h112(K), I_h12(K+1), h122(K+1), I_h12(K) of the reference with K = k+1 (1-based)
+          const double h2_h123 = dp(k) / (dp(k) + (dp(k - 1) + dp(k + 1)));
+          const double h112 = 2. * dp(k - 1) + dp(k), h122p = dp(k) + 2. * dp(k + 1);
+          const double I_h12 = 1.0 / (dp(k - 1) + dp(k)), I_h12p = 1.0 / (dp(k) + dp(k + 1));
+          const double sck = h2_h123 * (h112 * srk * I_h12p + h122p * slk * I_h12);
+          a = fsign(min3(fabs(2.0 * slk), fabs(sck), fabs(2.0 * srk)), sck);
+        }
+      }
+      au[k] = a;
+    }
+    wsync();
+    for (int k = lane; k < n; k += 64) {      // al(k): the edge between cells k-1 and k; also ar(k-1)
+      if (k >= 2 && k <= n - 2) {
+        const double I_h12 = 1.0 / (dp(k - 1) + dp(k));
+        const double I_h0123 = 1.0 / ((dp(k - 2) + dp(k - 1)) + (dp(k) + dp(k + 1)));
+        const double h01_h112 = (dp(k - 2) + dp(k - 1)) / (2.0 * dp(k - 1) + dp(k));
+        const double h23_h122 = (dp(k) + dp(k + 1)) / (dp(k - 1) + 2.0 * dp(k));
+        const double al = (dp(k) * u[k - 1] + dp(k - 1) * u[k]) * I_h12 +
+                          I_h0123 * (2. * dp(k) * dp(k - 1) * I_h12 * (u[k] - u[k - 1]) * (h01_h112 - h23_h122) +
+                                     (dp(k) * au[k - 1] * h23_h122 - dp(k - 1) * au[k] * h01_h112));
+        EL[k] = al; ER[k - 1] = al;
+      }
+    }
+    if (lane == 0) { EL[0] = u[0]; ER[0] = u[0]; EL[1] = u[0]; ER[n - 2] = u[n - 1]; EL[n - 1] = u[n - 1]; ER[n - 1] = u[n - 1]; }
+    wsync();
+    for (int k = lane + 1; k < n - 1; k += 64) {      // PPM_monotonicity
+      if ((u[k + 1] - u[k]) * (u[k] - u[k - 1]) <= 0.) {
+        EL[k] = u[k]; ER[k] = u[k];
+      } else {
+        const double da = ER[k] - EL[k];
+        const double a6 = 6.0 * u[k] - 3.0 * (EL[k] + ER[k]);
+        if (da * a6 > da * da) EL[k] = 3.0 * u[k] - 2.0 * ER[k];
+        else if (da * a6 < -da * da) ER[k] = 3.0 * u[k] - 2.0 * EL[k];
+      }
+    }
+    wsync();
+  } else
   // ---- PPM_H4: edge_values_explicit_h4 :222-363
   {
     const double hMinFrac = 1.e-5, hNeglect = h_neglect_edge;
@@ -1023,6 +1120,11 @@ __device__ void w_integrate_sub_cells(const WCol &c, int lane, int n0, int n1, i
   wsync();
 }
 
+bool lane_per_column_env() {
+  static const int v = [] { const char *e = getenv("MOM6HIP_ALE_LANE_PER_COLUMN"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
 struct WRemapArgs {
   m6::GridDev g;
   const double *h_old, *h_new;   // thicknesses at the points of the fields (h, u or v points)
@@ -1093,6 +1195,12 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
   }
 }
 
+// PPM_IH4 and PPM_CW exist in the wave-per-column kernel only
+bool scheme_provided(int scheme) {
+  if (scheme == REMAP_PCM || scheme == REMAP_PLM || scheme == REMAP_PPM_H4) return true;
+  return (scheme == REMAP_PPM_IH4 || scheme == REMAP_PPM_CW) && !lane_per_column_env();
+}
+
 // MOM6HIP_ALE_LANE_PER_COLUMN=1 selects the older lane-per-column kernels (kept for comparison runs)
 bool lane_per_column() {
   static const int v = [] { const char *e = getenv("MOM6HIP_ALE_LANE_PER_COLUMN"); return (e && e[0] == '1') ? 1 : 0; }();
@@ -1132,10 +1240,9 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "ALE_remap_tracers: bad memspace");
   if (ntr <= 0) return 0;
   M6_REQUIRE(tr != nullptr && ntr <= 64, "ALE_remap_tracers: bad tracer list");
-  M6_REQUIRE(cs->remapping_scheme == REMAP_PCM || cs->remapping_scheme == REMAP_PLM ||
-             cs->remapping_scheme == REMAP_PPM_H4,
+  M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM and PPM_H4)");
+             "(libmom6hip provides PCM, PLM, PPM_H4, PPM_IH4 and PPM_CW)");
   M6_REQUIRE(cs->answer_date >= 20190101, "ALE_remap_tracers: only REMAPPING_ANSWER_DATE >= 20190101 is provided");
   M6_REQUIRE(!cs->force_bounds_in_subcell, "ALE_remap_tracers: REMAP_BOUND_INTERMEDIATE_VALUES is not provided");
   M6_REQUIRE(ctx->g.mask2dT != nullptr, "ALE_remap_tracers: mask2dT is required");
@@ -1246,9 +1353,9 @@ extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_re
                                             const double *h_old_v, const double *h_new_u, const double *h_new_v, double *u,
                                             double *v, int32_t memspace) {
   M6_REQUIRE(ctx && cs && h_old_u && h_old_v && h_new_u && h_new_v && u && v, "ALE_remap_velocities: null argument");
-  M6_REQUIRE(cs->remapping_scheme == REMAP_PCM || cs->remapping_scheme == REMAP_PLM || cs->remapping_scheme == REMAP_PPM_H4,
+  M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM and PPM_H4)");
+             "(libmom6hip provides PCM, PLM, PPM_H4, PPM_IH4 and PPM_CW)");
   M6_REQUIRE(cs->answer_date >= 20190101 && !cs->force_bounds_in_subcell, "ALE_remap_velocities: unsupported remapping options");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.nk <= 128 && g.mask2dCu && g.mask2dCv, "ALE_remap_velocities: at most 128 layers; face masks are needed");

@@ -69,6 +69,8 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
 #define ORC_REMAP_PCM     0
 #define ORC_REMAP_PLM     2
 #define ORC_REMAP_PPM_H4  4
+#define ORC_REMAP_PPM_IH4 5
+#define ORC_REMAP_PPM_CW  10
 #define ORC_INT_PCM 0
 #define ORC_INT_PLM 1
 #define ORC_INT_PPM 3
@@ -83,6 +85,10 @@ void orc_bound_edge_values(int n, const double *h, const double *u, double *E);
 void orc_check_discontinuous_edge_values(int n, const double *u, double *E);
 void orc_end_value_h4(const double dz[4], const double u[4], double Csys[4]);
 void orc_edge_values_explicit_h4(int n, const double *h, const double *u, double *E, double h_neglect);
+void orc_edge_values_implicit_h4(int n, const double *h, const double *u, double *E, double h_neglect);
+void orc_edge_values_explicit_h4cw(int n, const double *h, const double *u, double *E, double h_neglect);
+void orc_ppm_monotonicity(int n, const double *u, double *E);
+void orc_solve_diag_dominant_tridiag(const double *Al, const double *Ac, const double *Au, const double *R, double *X, int n);
 void orc_ppm_limiter_standard(int n, const double *h, const double *u, double *E);
 void orc_ppm_reconstruction(int n, const double *h, const double *u, double *E, double *coef);
 void orc_ppm_boundary_extrapolation(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);

@@ -94,7 +94,7 @@ def advect_tracer(grid, h_end, uhtr, vhtr, dt, cs_dt, scheme, tr, conc_underflow
 
 
 # ---- ALE reconstruction + remapping ---------------------------------------------------------------
-REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PPM_H4": 4}
+REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PPM_H4": 4, "PPM_IH4": 5, "PPM_CW": 10}
 INT_PCM, INT_PLM, INT_PPM = 0, 1, 3
 _ip = C.POINTER(C.c_int)
 
@@ -166,6 +166,16 @@ def remap_via_sub_cells(h0, u0, E, coef, h1, method, force_bounds_in_subcell=Fal
     _remap_lib().orc_remap_via_sub_cells(len(h0), _p(h0), _p(u0), _p(E), _p(coef), len(h1), _p(h1), method,
                                          int(force_bounds_in_subcell), _p(u1), C.cast(C.byref(err), _dp))
     return u1, err.value
+
+
+def edge_values(kind, h, u, h_neglect=1e-10):
+    """edge_values_implicit_h4 ("ih4") / edge_values_explicit_h4cw ("h4cw") -> (left, right) edge values"""
+    h, u = _a(h), _a(u); n = len(h); E = np.zeros(2 * n)
+    L = _remap_lib()
+    f = {"ih4": L.orc_edge_values_implicit_h4, "h4cw": L.orc_edge_values_explicit_h4cw, "h4": L.orc_edge_values_explicit_h4}[kind]
+    f.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double]; f.restype = None
+    f(n, _p(h), _p(u), _p(E), h_neglect)
+    return E[:n].copy(), E[n:].copy()
 
 
 def remapping_core_h(scheme, h0, u0, h1, h_neglect=1e-30, h_neglect_edge=1e-10, boundary_extrapolation=True):

@@ -250,6 +250,129 @@ void orc_edge_values_explicit_h4(int n, const double *h, const double *u, double
   E_(E,n-2,1) = E_(E,n-1,0);
 }
 
+/* solve_diag_dominant_tridiag, regrid_solvers.F90:246-280 (Al, Ac, Au, R -> X; all of size n) */
+void orc_solve_diag_dominant_tridiag(const double *Al, const double *Ac, const double *Au, const double *R, double *X, int n)
+{
+  double *c1 = (double*)malloc(sizeof(double)*n);
+  double I_pivot = 1.0 / (Ac[0] + Au[0]);
+  double d1 = Ac[0] * I_pivot;
+  c1[0] = Au[0] * I_pivot;
+  X[0] = R[0] * I_pivot;
+  for (int k = 1; k < n-1; k++) {
+    const double denom_t1 = Ac[k] + d1 * Al[k];
+    I_pivot = 1.0 / (denom_t1 + Au[k]);
+    d1 = denom_t1 * I_pivot;
+    c1[k] = Au[k] * I_pivot;
+    X[k] = (R[k] - Al[k] * X[k-1]) * I_pivot;
+  }
+  I_pivot = 1.0 / (Ac[n-1] + d1 * Al[n-1]);
+  X[n-1] = (R[n-1] - Al[n-1] * X[n-2]) * I_pivot;
+  for (int k = n-2; k >= 0; k--) X[k] = X[k] - c1[k] * X[k+1];
+  free(c1);
+}
+
+/* edge_values_implicit_h4 (answer_date >= 20190101), regrid_edge_values.F90:491-654.  n >= 4. */
+void orc_edge_values_implicit_h4(int n, const double *h, const double *u, double *E, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  const int m = n + 1;
+  double *tri_l = (double*)calloc(5*(size_t)m, sizeof(double));
+  double *tri_c = tri_l + m, *tri_u = tri_c + m, *tri_b = tri_u + m, *tri_x = tri_b + m;
+  for (int i = 0; i < n-1; i++) {            /* Fortran i = 1..N-1; row i+1 */
+    double h0 = max2(h[i], hNeglect);
+    double h1 = max2(h[i+1], hNeglect);
+    if (fabs(h0) < 1.0e-12*fabs(h1)) h0 = 1.0e-12*h1;
+    if (fabs(h1) < 1.0e-12*fabs(h0)) h1 = 1.0e-12*h0;
+    const double I_h2 = 1.0 / ((h0 + h1)*(h0 + h1));
+    const double alpha = (h1 * h1) * I_h2;
+    const double beta = (h0 * h0) * I_h2;
+    const double abmix = (h0 * h1) * I_h2;
+    const double a = 2.0 * alpha * ( alpha + 2.0 * beta + 3.0 * abmix );
+    const double b = 2.0 * beta * ( beta + 2.0 * alpha + 3.0 * abmix );
+    tri_c[i+1] = 2.0*abmix;
+    tri_l[i+1] = alpha;
+    tri_u[i+1] = beta;
+    tri_b[i+1] = a * u[i] + b * u[i+1];
+  }
+  double dz[4], ut[4], C[4];
+  for (int i = 0; i < 4; i++) { dz[i] = max2(hNeglect, h[i]); ut[i] = u[i]; }
+  orc_end_value_h4(dz, ut, C);
+  tri_b[0] = C[0]; tri_c[0] = 1.0; tri_u[0] = 0.0;
+  for (int i = 0; i < 4; i++) { dz[i] = max2(hNeglect, h[n-1-i]); ut[i] = u[n-1-i]; }
+  orc_end_value_h4(dz, ut, C);
+  tri_b[n] = C[0]; tri_c[n] = 1.0; tri_l[n] = 0.0;
+  orc_solve_diag_dominant_tridiag(tri_l, tri_c, tri_u, tri_b, tri_x, m);
+  E_(E,0,0) = tri_x[0];
+  for (int i = 1; i < n; i++) { E_(E,i,0) = tri_x[i]; E_(E,i-1,1) = tri_x[i]; }
+  E_(E,n-1,1) = tri_x[n];
+  free(tri_l);
+}
+
+/* edge_values_explicit_h4cw, regrid_edge_values.F90:381-470 (Colella & Woodward 1984, after hybgen_ppm_coefs).  n >= 4. */
+void orc_edge_values_explicit_h4cw(int n, const double *h, const double *u, double *E, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  /* 1-based work arrays as in the reference: index k of the Fortran is [k] here */
+  const size_t m = (size_t)n + 2;
+  double *dp = (double*)calloc(10*m, sizeof(double));
+  double *au = dp + m, *al = au + m, *ar = al + m, *h112 = ar + m, *h122 = h112 + m, *I_h12 = h122 + m, *h2_h123 = I_h12 + m,
+         *I_h0123 = h2_h123 + m, *h01_h112 = I_h0123 + m;
+  double *h23_h122 = (double*)calloc(m, sizeof(double));
+#define U1(k) u[(k)-1]
+  for (int k = 1; k <= n; k++) dp[k] = max2(h[k-1], hNeglect);
+  for (int k = 2; k <= n; k++) {
+    h112[k] = 2.*dp[k-1] + dp[k];
+    h122[k] = dp[k-1] + 2.*dp[k];
+    I_h12[k] = 1.0 / (dp[k-1] + dp[k]);
+  }
+  for (int k = 2; k <= n-1; k++) h2_h123[k] = dp[k] / (dp[k] + (dp[k-1]+dp[k+1]));
+  for (int k = 3; k <= n-1; k++) {
+    I_h0123[k] = 1.0 / ((dp[k-2] + dp[k-1]) + (dp[k] + dp[k+1]));
+    h01_h112[k] = (dp[k-2] + dp[k-1]) / (2.0*dp[k-1] + dp[k]);
+    h23_h122[k] = (dp[k] + dp[k+1])   / (dp[k-1] + 2.0*dp[k]);
+  }
+  au[1] = 0.;
+  for (int k = 2; k <= n-1; k++) {
+    const double slk = U1(k)-U1(k-1);
+    const double srk = U1(k+1)-U1(k);
+    if (slk*srk > 0.) {
+      const double sck = h2_h123[k]*( h112[k]*srk*I_h12[k+1] + h122[k+1]*slk*I_h12[k] );
+      au[k] = fsign(min3(fabs(2.0*slk), fabs(sck), fabs(2.0*srk)), sck);
+    } else {
+      au[k] = 0.;
+    }
+  }
+  au[n] = 0.;
+  al[1] = U1(1); ar[1] = U1(1); al[2] = U1(1);
+  for (int k = 3; k <= n-1; k++) {
+    al[k] = (dp[k]*U1(k-1) + dp[k-1]*U1(k)) * I_h12[k]
+          + I_h0123[k]*( 2.*dp[k]*dp[k-1]*I_h12[k]*(U1(k)-U1(k-1)) *
+                         ( h01_h112[k] - h23_h122[k] )
+                  + (dp[k]*au[k-1]*h23_h122[k] - dp[k-1]*au[k]*h01_h112[k]) );
+    ar[k-1] = al[k];
+  }
+  ar[n-1] = U1(n); al[n] = U1(n); ar[n] = U1(n);
+  for (int k = 1; k <= n; k++) { E_(E,k-1,0) = al[k]; E_(E,k-1,1) = ar[k]; }
+#undef U1
+  free(dp); free(h23_h122);
+}
+
+/* PPM_monotonicity, PPM_functions.F90:132-158 */
+void orc_ppm_monotonicity(int n, const double *u, double *E)
+{
+  for (int k = 1; k < n-1; k++) {
+    if ((u[k+1]-u[k])*(u[k]-u[k-1]) <= 0.) {
+      E_(E,k,0) = u[k];
+      E_(E,k,1) = u[k];
+    } else {
+      const double da = E_(E,k,1)-E_(E,k,0);
+      const double a6 = 6.0*u[k] - 3.0*(E_(E,k,0)+E_(E,k,1));
+      if (da*a6 > da*da) E_(E,k,0) = 3.0*u[k] - 2.0*E_(E,k,1);
+      else if (da*a6 < -da*da) E_(E,k,1) = 3.0*u[k] - 2.0*E_(E,k,0);
+    }
+  }
+}
+
 /* ---- PPM ---------------------------------------------------------------------------------- */
 /* PPM_limiter_standard, PPM_functions.F90:62-128 */
 void orc_ppm_limiter_standard(int n, const double *h, const double *u, double *E)
@@ -519,7 +642,7 @@ void orc_remap_via_sub_cells(int n0, const double *h0, const double *u0, const d
   free(h0_eff); free(u0_min); free(u0_max); free(itgt_start); free(itgt_end);
 }
 
-/* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PPM_H4; no PCM_cell).
+/* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PPM_H4, PPM_IH4, PPM_CW; no PCM_cell).
  * E and coef must hold 2*n0 and 3*n0 doubles.  Returns the integration method. */
 int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                                  double *coef, double *E, double h_neglect, double h_neglect_edge)
@@ -530,7 +653,7 @@ int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0,
   int local = scheme;
   if (n0 <= 1) local = ORC_REMAP_PCM;
   else if (n0 <= 3) local = (local < ORC_REMAP_PLM) ? local : ORC_REMAP_PLM;
-  else if (n0 <= 4) local = (local < ORC_REMAP_PPM_H4) ? local : ORC_REMAP_PPM_H4;
+  else if (n0 <= 4 && local != ORC_REMAP_PPM_CW) local = (local < ORC_REMAP_PPM_H4) ? local : ORC_REMAP_PPM_H4;
   (void)n;
   switch (local) {
     case ORC_REMAP_PCM:
@@ -542,6 +665,17 @@ int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0,
       return ORC_INT_PLM;
     case ORC_REMAP_PPM_H4:
       orc_edge_values_explicit_h4(n0, h0, u0, E, h_neglect_edge);
+      orc_ppm_reconstruction(n0, h0, u0, E, coef);
+      if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PPM;
+    case ORC_REMAP_PPM_IH4:   /* :332-338 */
+      orc_edge_values_implicit_h4(n0, h0, u0, E, h_neglect_edge);
+      orc_ppm_reconstruction(n0, h0, u0, E, coef);
+      if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PPM;
+    case ORC_REMAP_PPM_CW:    /* :316-324 */
+      orc_edge_values_explicit_h4cw(n0, h0, u0, E, h_neglect_edge);
+      orc_ppm_monotonicity(n0, u0, E);
       orc_ppm_reconstruction(n0, h0, u0, E, coef);
       if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
       return ORC_INT_PPM;

@@ -74,7 +74,7 @@ def test_plm_vanished_layers_and_remap(oracle):
 
 
 # ---- properties the scheme guarantees (conservative, bounded) on random columns ------------------------
-@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PPM_H4"])
+@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PPM_H4", "PPM_IH4", "PPM_CW"])
 def test_remap_conserves_and_is_bounded(oracle, scheme):
     rng = np.random.default_rng(3)
     for trial in range(200):
@@ -92,6 +92,59 @@ def test_remap_conserves_and_is_bounded(oracle, scheme):
         tot0, tot1 = float(np.dot(h0, u0)), float(np.dot(h1, u1))
         assert abs(tot1 - tot0) <= 1e-12 * max(1.0, np.dot(h0, np.abs(u0))), (scheme, trial)
         assert u1.max() <= u0.max() + 1e-12 and u1.min() >= u0.min() - 1e-12
+
+
+# ---- PPM_IH4 / PPM_CW edge values: the reference holds no known-answer vectors for edge_values_implicit_h4 and
+# edge_values_explicit_h4cw (parity unpinned for these two); what pins the restatement is what the schemes guarantee
+def _cell_means(poly, h):
+    """exact cell averages and edge values of a polynomial (numpy poly1d) on the grid of widths h"""
+    x = np.concatenate([[0.0], np.cumsum(h)])
+    P = poly.integ()
+    return (P(x[1:]) - P(x[:-1])) / h, poly(x)
+
+
+def test_implicit_h4_is_exact_for_cubics(oracle):
+    """edge_values_implicit_h4 is fourth-order: with the one-sided cubic fits that close the system (end_value_h4) it
+    reproduces the edge values of any cubic from its cell averages, on any grid (regrid_edge_values.F90:470-490)"""
+    rng = np.random.default_rng(5)
+    for trial in range(50):
+        n = int(rng.integers(5, 30))
+        h = 0.5 + rng.random(n) * 3.0
+        poly = np.poly1d(rng.standard_normal(4))
+        ubar, edges = _cell_means(poly, h)
+        L, R = oracle.edge_values("ih4", h, ubar)
+        scale = np.abs(edges).max() + 1.0
+        assert np.abs(L - edges[:-1]).max() <= 1e-9 * scale and np.abs(R - edges[1:]).max() <= 1e-9 * scale, trial
+        assert np.array_equal(R[:-1], L[1:])      # one value per interface
+
+
+def test_explicit_h4cw_on_linear_and_monotone_data(oracle):
+    """edge_values_explicit_h4cw (Colella & Woodward eqs. 1.6-1.8): exact interior edges for linear data on a uniform grid,
+    PCM at the two ends (:437-449), and after PPM_monotonicity every cell's parabola is monotone"""
+    n = 12
+    h = np.ones(n); u = 2.0 + 3.0 * (np.arange(n) + 0.5)
+    L, R = oracle.edge_values("h4cw", h, u)
+    x = np.arange(n + 1.0)
+    assert np.allclose(L[2:n - 1], 2.0 + 3.0 * x[2:n - 1], rtol=0, atol=1e-12)
+    assert L[0] == u[0] and R[0] == u[0] and L[1] == u[0] and R[n - 2] == u[n - 1] and L[n - 1] == u[n - 1] and R[n - 1] == u[n - 1]
+    rng = np.random.default_rng(8)
+    for trial in range(50):
+        n = int(rng.integers(5, 30))
+        h = 0.2 + rng.random(n) * 3.0
+        u = np.cumsum(rng.random(n))      # monotone data: the remapped values stay within the neighbours
+        h1 = np.full(n + 3, h.sum() / (n + 3))
+        u1 = oracle.remapping_core_h("PPM_CW", h, u, h1, 1e-30, 1e-10, boundary_extrapolation=False)
+        assert np.all(np.diff(u1) >= -1e-12), trial
+        assert abs(np.dot(h1, u1) - np.dot(h, u)) <= 1e-11 * np.dot(h, np.abs(u))
+
+
+def test_small_columns_fall_back_as_the_reference_does(oracle):
+    """n0 <= 4: PPM_IH4 drops to PPM_H4 (identical results), PPM_CW is kept (MOM_remapping.F90:289-295)"""
+    h = np.array([1.0, 2.0, 1.5, 0.5]); u = np.array([1.0, 3.0, 2.0, 5.0]); h1 = np.array([2.0, 1.0, 2.0])
+    a = oracle.remapping_core_h("PPM_IH4", h, u, h1); b = oracle.remapping_core_h("PPM_H4", h, u, h1)
+    assert np.array_equal(a, b)
+    c = oracle.remapping_core_h("PPM_CW", h, u, h1)
+    assert abs(np.dot(h1, c) - np.dot(h, u)) < 1e-12
 
 
 # ---- bit-for-bit against the reference's own code where it compiles with no stand-ins ------------------
