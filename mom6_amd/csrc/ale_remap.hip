@@ -910,20 +910,14 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
       const double ev = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
       EL[i] = ev; ER[i - 1] = ev;
     }
-    if (lane == 62) {      // (the end values on lanes that have no second interior edge to do)
+    if (lane >= 62) {      // the end values, on the two lanes that have no second interior edge to do: one code path for both
+      const bool last = lane == 63;
       double dz[4], ut[4], Cs[4];
-      for (int i = 0; i < 4; i++) { dz[i] = fmax(hNeglect, h[i]); ut[i] = u[i]; }
+      for (int i = 0; i < 4; i++) { const int q = last ? n - 1 - i : i; dz[i] = fmax(hNeglect, h[q]); ut[i] = u[q]; }
       end_value_h4(dz, ut, Cs);
-      EL[0] = Cs[0];
-      ER[0] = Cs[0] + dz[0] * (Cs[1] + dz[0] * (Cs[2] + dz[0] * Cs[3]));
-      EL[1] = ER[0];
-    } else if (lane == 63) {
-      double dz[4], ut[4], Cs[4];
-      for (int i = 0; i < 4; i++) { dz[i] = fmax(hNeglect, h[n - 1 - i]); ut[i] = u[n - 1 - i]; }
-      end_value_h4(dz, ut, Cs);
-      ER[n - 1] = Cs[0];
-      EL[n - 1] = Cs[0] + dz[0] * (Cs[1] + dz[0] * (Cs[2] + dz[0] * Cs[3]));
-      ER[n - 2] = EL[n - 1];
+      const double inner = Cs[0] + dz[0] * (Cs[1] + dz[0] * (Cs[2] + dz[0] * Cs[3]));
+      if (last) { ER[n - 1] = Cs[0]; EL[n - 1] = inner; ER[n - 2] = inner; }
+      else { EL[0] = Cs[0]; ER[0] = inner; EL[1] = inner; }
     }
     wsync();
   }
