@@ -97,6 +97,19 @@ int mom6hip_free(void *dptr);
 int mom6hip_sync_to_device(mom6hip_ctx_t *ctx, void *dptr, const void *hptr, uint64_t bytes);
 int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint64_t bytes);
 
+/* ---- MOM_checksums: the bit-count checksum of a field, on the device ----------------------- */
+
+/* subchk of chksum_h_3d / chksum_u_3d / chksum_v_3d / chksum_B_3d (src/framework/MOM_checksums.F90:1387-1401, :1042-1059,
+ * :1228-1245, :739-756) and the extrema of subStats (:1403-1425): over the points (isc+di : iec+di, jsc+dj : jec+dj) of the
+ * field's own indexing (the reference deliberately uses the h-point computational domain for every staggering; symmetric
+ * /= 0 extends it by the western / southern face row as its `symmetric` argument does) and all nk layers,
+ *     *bitcount = mod( sum popcnt(transfer(abs(scale*x), 1_8)), 1000000000 )     (summed over PEs when a domain is attached)
+ * -- the number debugging runs of MOM6 print and compare across builds, here without moving the field off the GPU.
+ * (The reference accumulates in a default integer, which wraps above 2^31 set bits per PE; this sum is exact.)
+ * amin / amax may be NULL.  `field` is a device or host array of staggering `pos` (MOM6HIP_POS_*), nk layers. */
+int mom6hip_chksum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, int32_t di, int32_t dj, int32_t symmetric,
+                   double scale, int64_t *bitcount, double *amin, double *amax, int32_t memspace);
+
 /* ---- MOM_domains: single-tile halo update ------------------------------------------------- */
 
 /* Staggering of a field, for halo updates (MOM_domains AGRID/CGRID_NE positions). */

@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cmath>
 
+#include <cstring>
+
 #include "common.hpp"
 
 namespace m6 {
@@ -121,6 +123,76 @@ int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint6
   M6_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   M6_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+// ---- MOM_checksums on the device ------------------------------------------------------------------------------------
+namespace {
+// doubles as unsigned integers that sort the same way (for atomic min / max)
+__device__ __forceinline__ unsigned long long sortable(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ inline double unsortable(unsigned long long s) {
+  const unsigned long long b = (s >> 63) ? (s & 0x7fffffffffffffffull) : ~s;
+  double x; memcpy(&x, &b, 8); return x;
+}
+// out[0] += popcount, out[1] = min, out[2] = max over (i0:i1, j0:j1, 0:nk-1) of an array with row length nrow
+__global__ __launch_bounds__(256) void chksum_kernel(const double *__restrict__ a, long plane, int nrow, int ioff, int joff, int i0,
+                                                     int i1, int j0, int j1, double scale, unsigned long long *out) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, j = j0 + blockIdx.y, k = blockIdx.z;
+  unsigned long long bc = 0, mn = ~0ull, mx = 0ull;
+  if (i <= i1) {
+    const double x = a[plane * k + (long)(j - joff) * nrow + (i - ioff)];
+    bc = __popcll((unsigned long long)__double_as_longlong(fabs(scale * x)));
+    mn = mx = sortable(x);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    bc += __shfl_down(bc, off);
+    const unsigned long long m2 = __shfl_down(mn, off), x2 = __shfl_down(mx, off);
+    mn = m2 < mn ? m2 : mn; mx = x2 > mx ? x2 : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], bc); atomicMin(&out[1], mn); atomicMax(&out[2], mx); }
+}
+}  // namespace
+
+int mom6hip_chksum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, int32_t di, int32_t dj, int32_t symmetric,
+                   double scale, int64_t *bitcount, double *amin, double *amax, int32_t memspace) {
+  M6_REQUIRE(ctx && field && bitcount, "mom6hip_chksum: null argument");
+  M6_REQUIRE(pos >= MOM6HIP_POS_H && pos <= MOM6HIP_POS_Q && nk >= 1, "mom6hip_chksum: bad staggering or layer count");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "mom6hip_chksum: bad memspace");
+  const m6::GridDev g = ctx->g;
+  const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0, ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
+  const int nrow = g.nih + xs, ncol = g.njh + ys, ioff = g.isd - xs, joff = g.jsd - ys;
+  int i0 = g.isc + di, i1 = g.iec + di, j0 = g.jsc + dj, j1 = g.jec + dj;
+  if (symmetric && xs) i0 -= 1;
+  if (symmetric && ys) j0 -= 1;
+  M6_REQUIRE(i0 >= ioff && i1 < ioff + nrow && j0 >= joff && j1 < joff + ncol, "mom6hip_chksum: the shifted range leaves the array");
+  const size_t bytes = sizeof(double) * (size_t)nrow * ncol * nk;
+  m6::Stager st(ctx, memspace);
+  const double *d = st.in(field, bytes);
+  unsigned long long *out = (unsigned long long *)st.scratch(3 * sizeof(unsigned long long));
+  M6_REQUIRE(!st.failed() && d && out, "mom6hip_chksum: staging failed");
+  const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+  M6_HIP(hipMemcpyAsync(out, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(chksum_kernel, dim3((i1 - i0 + 256) / 256, j1 - j0 + 1, nk), dim3(256), 0, ctx->stream, d, (long)nrow * ncol, nrow,
+                     ioff, joff, i0, i1, j0, j1, scale, out);
+  M6_HIP(hipGetLastError());
+  unsigned long long res[3];
+  M6_HIP(hipMemcpyAsync(res, out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  // sum_across_PEs of the count (each PE's share reduced first so the 32-bit exchange cannot overflow), extrema across PEs
+  int32_t part = (int32_t)(res[0] % 1000000000ull);
+  if (m6::multi_tile(ctx)) {
+    if (int rc = m6::sum_across_PEs(ctx, &part, 1)) return rc;
+  }
+  *bitcount = (int64_t)(((long long)part % 1000000000ll + 1000000000ll) % 1000000000ll);
+  double mm[2] = {unsortable(res[1]), -unsortable(res[2])};      // (min, -max): one min reduction serves both
+  if (m6::multi_tile(ctx)) {
+    if (int rc = m6::min_across_PEs(ctx, mm, 2)) return rc;
+  }
+  if (amin) *amin = mm[0];
+  if (amax) *amax = -mm[1];
+  return st.finish();
 }
 
 int mom6hip_set_domain_callbacks(mom6hip_ctx_t *ctx, mom6hip_halo_fn halo_fn, mom6hip_sum_fn sum_fn, void *user) {

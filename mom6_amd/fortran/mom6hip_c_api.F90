@@ -295,6 +295,18 @@ interface
     integer(c_int) :: rc
   end function mom6hip_ale_remap_velocities
 
+  !> subchk / subStats of MOM_checksums (MOM_checksums.F90:1387) on a device or host field of staggering pos
+  function mom6hip_chksum(ctx, field, pos, nk, di, dj, symmetric, scale, bitcount, amin, amax, memspace) &
+                          bind(c, name="mom6hip_chksum") result(rc)
+    import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+    type(c_ptr), value :: ctx, field
+    integer(c_int32_t), value :: pos, nk, di, dj, symmetric, memspace
+    real(c_double), value :: scale
+    integer(c_int64_t), intent(out) :: bitcount
+    real(c_double), intent(out) :: amin, amax
+    integer(c_int) :: rc
+  end function mom6hip_chksum
+
   function mom6hip_coradcalc(ctx, cs, u, v, h, uh, vh, CAu, CAv, memspace) bind(c, name="mom6hip_coradcalc") result(rc)
     import :: c_int, c_int32_t, c_ptr, mom6hip_coriolisadv_cs_t
     type(c_ptr), value :: ctx, u, v, h, uh, vh, CAu, CAv
