@@ -35,6 +35,8 @@ REMAP_SCHEME = "PPM_H4"    # OM4-class remapping scheme
 # carries the wind stress into the top 20 m (no boundary-layer scheme feeds visc%Kv_shear here)
 VERTVISC = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
 # hor_visc_init parameters: biharmonic Smagorinsky viscosity with a grid-scale background (the OM4_025 choice)
+# tracer_hordiff after advect_tracer (step_MOM_tracer_dyn, MOM.F90:1438-1441): along-layer diffusion, KHTR = 50 m2 s-1
+TRACER_HORDIFF = dict(KHTR=50.0, CHECK_DIFFUSIVE_CFL=True)
 HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL_SCALE=0.01)
 SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
@@ -134,6 +136,8 @@ class Model:
         self.set_visc_cs = set_visc_init(self.dg, **SET_VISC)
         self.eos = EOS_init("WRIGHT")
         self.adv_cs = tracer_advect_init(DT, scheme)
+        from mom6_amd.tracer_hor_diff import tracer_hor_diff_init
+        self.hordiff_cs = tracer_hor_diff_init(**TRACER_HORDIFF)
         self.remap_cs = initialize_remapping(REMAP_SCHEME)
         # z* target: the nominal layer thicknesses of the synthetic state (synth.make_dynamics_state)
         from mom6_amd.ale import initialize_regridding
@@ -163,6 +167,8 @@ class Model:
         if (n + 1) % self.steps_per_advect == 0:      # step_MOM_thermo / step_MOM_tracer_dyn (src/core/MOM.F90:1438, :1662)
             tr = [self.T, self.S] + self.passive
             self.last_adv = advect_tracer(self.h, self.uhtr, self.vhtr, None, DT_THERM, self.dg, self.adv_cs, tr)
+            from mom6_amd.tracer_hor_diff import tracer_hordiff
+            self.last_hordiff = tracer_hordiff(self.h, DT_THERM, None, None, None, self.dg, self.hordiff_cs, tr)      # MOM.F90:1441
             self.uhtr.zero_(); self.vhtr.zero_()
             # ALE (src/core/MOM.F90:1647-1700): regrid, remap tracers, remap velocities, adopt the new grid
             dg = self.dg
@@ -394,6 +400,13 @@ class Components:
             def adv():
                 self.last_adv = advect_tracer(a["h_end"], a["uhtr"], a["vhtr"], None, DT_THERM, dg, self.adv_cs, a["tr"])
             out.append(("advect_tracer", adv))
+
+            def hordiff():
+                from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
+                if not hasattr(self, "hordiff_cs"):
+                    self.hordiff_cs = tracer_hor_diff_init(**TRACER_HORDIFF)
+                tracer_hordiff(a["h_end"], DT_THERM, None, None, None, dg, self.hordiff_cs, a["tr"])
+            out.append(("tracer_hordiff", hordiff))
             out.append(("ALE_remap_tracers", lambda: ALE_remap_tracers(self.remap_cs, dg, d["h"], self.h_new, a["tr"])))
         return out
 
@@ -441,6 +454,7 @@ def _cpu_sample(grid, scheme, nk_s, steps_per_advect, threads):
     t0 = time.perf_counter()
     tr = [st.T, st.S] + passive
     orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, DT_THERM, DT, scheme, tr)
+    orc.tracer_hordiff(g, st.h, DT_THERM, tr, TRACER_HORDIFF["KHTR"], check_diffusive_CFL=TRACER_HORDIFF["CHECK_DIFFUSIVE_CFL"])
     kn = (np.arange(nk_s) + 0.5) / nk_s
     dz_nom = 2.0 + 300.0 * kn ** 2
     rcs = orc.regridding_cs(dz_nom * (5500.0 / dz_nom.sum()), old_grid_weight=REGRID_OLD_WEIGHT)
@@ -554,7 +568,7 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
 # algorithmic bytes per cell and call (SURVEY.md section 8d / DESIGN.md section 4)
 ALG_BYTES = {
     "PressureForce": 64.0, "continuity[BT_cont]": 96.0, "continuity[uhbt+BT_cont]": 96.0, "continuity[uhbt]": 96.0,
-    "CorAdCalc": 56.0, "CorAdCalc[pred]": 56.0, "ALE_remap_tracers": 16.0 + 16.0 * NTR, "horizontal_viscosity": 40.0,
+    "CorAdCalc": 56.0, "CorAdCalc[pred]": 56.0, "ALE_remap_tracers": 16.0 + 16.0 * NTR, "horizontal_viscosity": 40.0, "tracer_hordiff": 8.0 + 16.0 * NTR,
 }
 
 
@@ -664,14 +678,15 @@ def main():
             "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
                     "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], horizontal_viscosity "
                     "[biharmonic Smagorinsky, BETTER_BOUND_AH], vertvisc_coef x3 + vertvisc x2 + vertvisc_remnant x3 [BOTTOMDRAGLAW], "
-                    f"momentum sweeps, group passes); every {spa} steps set_viscous_BBL [BBL_USE_EOS], advect_tracer [{a.scheme}] + "
-                    f"ALE regrid/remap [{REMAP_SCHEME}]",
+                    f"momentum sweeps, group passes); every {spa} steps set_viscous_BBL [BBL_USE_EOS], advect_tracer [{a.scheme}], "
+                    f"tracer_hordiff [KHTR={TRACER_HORDIFF['KHTR']:.0f}] + ALE regrid/remap [{REMAP_SCHEME}]",
             "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
             "not_yet_in_step": [],
             "vertvisc": dict(VERTVISC, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)), "hor_visc": HOR_VISC, "set_visc": SET_VISC,
             "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE = 0, the default), remap of T, S + 2 tracers "
                    f"and of u, v [{REMAP_SCHEME}]",
             "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),
+            "hordiff_iterations_last_call": None if getattr(M, "last_hordiff", None) is None else int(M.last_hordiff.num_itts),
             "state_at_start": health0, "state_after_warmup": health_w, "state_after_run": health, "model_steps_taken": M.nstep,
             "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
                                                                "group passes over RCCL p2p",

@@ -623,6 +623,41 @@ int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs,
  * returns at once unless DYNAMIC_VISCOUS_ML (refused by mom6hip_vertvisc_* as well) or an ice shelf is present. */
 int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs);
 
+/* ---- MOM_tracer_hor_diff ------------------------------------------------------------------------ */
+
+/*
+ * tracer_hor_diff_CS, src/tracer/MOM_tracer_hor_diff.F90:40-100, as set by tracer_hor_diff_init (:1625-1770).
+ * Provided: the along-layer diffusion of tracer_hordiff (:119-680) with a constant diffusivity -- KHTR, MAX_TR_DIFFUSION_CFL,
+ * CHECK_DIFFUSIVE_CFL (the iteration count from the largest diffusive CFL number, max_across_PEs), conc_underflow.
+ * Not provided (refused by name, any nonzero `unsupported`): USE_NEUTRAL_DIFFUSION, USE_HORIZONTAL_BOUNDARY_DIFFUSION,
+ * DIFFUSE_ML_TO_INTERIOR (tracer_epipycnal_ML_diff), variable mixing (VarMix: KHTR_SLOPE_CFF, resolution scaling,
+ * KHTR_USE_EBT_STRUCT, KHTR_PASSIVITY_COEFF), MEKE diffusivities, KHTR_MIN / KHTR_MAX (only read with VarMix), offline
+ * khdt arrays, the df_x / df_y flux diagnostics.
+ */
+typedef struct mom6hip_tracer_hor_diff_cs {
+  double KhTr;             /* KHTR [L2 T-1] (0: tracer_hordiff returns at once) */
+  double max_diff_CFL;     /* MAX_TR_DIFFUSION_CFL (-1: no limit) */
+  double reserved0[6];
+  int32_t check_diffusive_CFL;  /* CHECK_DIFFUSIVE_CFL (0) */
+  int32_t initialized;
+  int32_t unsupported[8];  /* use_neutral_diffusion, use_hor_bnd_diffusion, Diffuse_ML_interior, use_variable_mixing, MEKE%Kh,
+                              KhTr_use_ebt_struct, offline (do_online = false), flux diagnostics */
+  int32_t reserved1[6];
+} mom6hip_tracer_hor_diff_cs_t;
+
+typedef struct mom6hip_hordiff_stats {
+  int32_t num_itts;        /* iterations of the diffusion (:424-434) */
+  int32_t halo_updates;    /* do_group_pass(CS%pass_t) calls (:542) */
+  double max_CFL;          /* the largest diffusive CFL number (CHECK_DIFFUSIVE_CFL; else 0) */
+} mom6hip_hordiff_stats_t;
+
+/* tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_online_flag, read_khdt_x, read_khdt_y)       :119
+ * tr: ntr tracer arrays (Reg%Tr(m)%t), conc_underflow: ntr values or NULL.  The tracers are updated in place on the compute
+ * domain; their halos are refreshed by the group pass before every iteration (left as the last pass made them). */
+int mom6hip_tracer_hordiff(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const double *h, double dt,
+                           double *const *tr, const double *conc_underflow, int32_t ntr, int32_t memspace,
+                           mom6hip_hordiff_stats_t *stats);
+
 /* ---- MOM_hor_visc ----------------------------------------------------------------------------- */
 
 /*

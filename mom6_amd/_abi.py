@@ -139,6 +139,20 @@ HOR_VISC_ARRAYS_H = ("Kh_bg_xx", "Kh_Max_xx", "Ah_bg_xx", "Ah_Max_xx", "Laplac2_
 HOR_VISC_ARRAYS_Q = ("Kh_bg_xy", "Kh_Max_xy", "Ah_bg_xy", "Ah_Max_xy", "Laplac2_const_xy", "Biharm_const_xy", "Biharm_const2_xy", "reduction_xy")
 
 
+TRACER_HORDIFF_UNSUPPORTED = ("USE_NEUTRAL_DIFFUSION", "USE_HORIZONTAL_BOUNDARY_DIFFUSION", "DIFFUSE_ML_TO_INTERIOR", "VarMix", "MEKE",
+                              "KHTR_USE_EBT_STRUCT", "offline", "flux_diagnostics")
+
+
+class TracerHorDiffCS(C.Structure):
+    """mom6hip_tracer_hor_diff_cs_t (include/mom6hip.h)."""
+    _fields_ = [("KhTr", C.c_double), ("max_diff_CFL", C.c_double), ("reserved0", C.c_double * 6), ("check_diffusive_CFL", C.c_int32),
+                ("initialized", C.c_int32), ("unsupported", C.c_int32 * 8), ("reserved1", C.c_int32 * 6)]
+
+
+class HorDiffStats(C.Structure):
+    _fields_ = [("num_itts", C.c_int32), ("halo_updates", C.c_int32), ("max_CFL", C.c_double)]
+
+
 class HorViscCS(C.Structure):
     """mom6hip_hor_visc_cs_t (include/mom6hip.h)."""
     _fields_ = ([(n, C.c_double) for n in ("Kh", "Kh_bg_min", "Kh_vel_scale", "Smag_Lap_const", "Ah", "Ah_vel_scale", "Ah_time_scale",

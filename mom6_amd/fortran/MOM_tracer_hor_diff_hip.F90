@@ -1,0 +1,158 @@
+!> Drop-in replacement for module MOM_tracer_hor_diff (src/tracer/MOM_tracer_hor_diff.F90): tracer_hordiff (:119),
+!! tracer_hor_diff_init (:1625) and tracer_hor_diff_end (:1772) with the reference's dummy-argument lists, so
+!! step_MOM_tracer_dyn (src/core/MOM.F90:1441) compiles unchanged.  Provided: the along-layer diffusion with a constant
+!! KHTR (MAX_TR_DIFFUSION_CFL, CHECK_DIFFUSIVE_CFL, the tracers' conc_underflow) on the GPU through libmom6hip
+!! (mom6hip_tracer_hordiff, HOST memspace).  Neutral diffusion, horizontal boundary diffusion, DIFFUSE_ML_TO_INTERIOR,
+!! variable mixing / MEKE diffusivities, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
+!!
+!! Compiled INSIDE a MOM6 source tree in place of src/tracer/MOM_tracer_hor_diff.F90; here against tests/fortran/stubs.
+module MOM_tracer_hor_diff
+
+use, intrinsic :: iso_c_binding
+use mom6hip_c_api
+use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use MOM_cpu_clock,             only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
+use MOM_diabatic_driver,       only : diabatic_CS
+use MOM_diag_mediator,         only : diag_ctrl, time_type
+use MOM_EOS,                   only : EOS_type
+use MOM_error_handler,         only : MOM_error, FATAL, WARNING
+use MOM_file_parser,           only : get_param, log_version, param_file_type
+use MOM_grid,                  only : ocean_grid_type
+use MOM_lateral_mixing_coeffs, only : VarMix_CS
+use MOM_MEKE_types,            only : MEKE_type
+use MOM_tracer_registry,       only : tracer_registry_type
+use MOM_unit_scaling,          only : unit_scale_type
+use MOM_variables,             only : thermo_var_ptrs, vertvisc_type
+use MOM_verticalGrid,          only : verticalGrid_type
+implicit none ; private
+
+#include <MOM_memory.h>
+
+public tracer_hordiff, tracer_hor_diff_init, tracer_hor_diff_end
+
+!> Control structure (the members of the reference's tracer_hor_diff_CS, :40-100, that the provided branch reads)
+type, public :: tracer_hor_diff_CS ; private
+  real    :: KhTr                 !< The along-isopycnal tracer diffusivity [L2 T-1 ~> m2 s-1].
+  real    :: max_diff_CFL         !< If positive, locally limit the diffusivity to this diffusive CFL [nondim].
+  logical :: check_diffusive_CFL  !< If true, use enough iterations that the diffusive equations are stable.
+  logical :: Diffuse_ML_interior, use_neutral_diffusion, use_hor_bnd_diffusion
+  logical :: first_call = .true.
+  type(diag_ctrl), pointer :: diag => NULL()
+end type tracer_hor_diff_CS
+
+integer :: id_clock_diffuse
+
+contains
+
+!> Same interface as the reference tracer_hordiff (:119).
+subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_online_flag, read_khdt_x, read_khdt_y)
+  type(ocean_grid_type),      intent(inout) :: G
+  type(verticalGrid_type),    intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: h
+  real,                       intent(in)    :: dt
+  type(MEKE_type),            intent(in)    :: MEKE
+  type(VarMix_CS),            intent(in)    :: VarMix
+  type(vertvisc_type),        intent(in)    :: visc
+  type(unit_scale_type),      intent(in)    :: US
+  type(tracer_hor_diff_CS),   pointer       :: CS
+  type(tracer_registry_type), pointer       :: Reg
+  type(thermo_var_ptrs),      intent(in)    :: tv
+  logical,          optional, intent(in)    :: do_online_flag
+  real, dimension(SZIB_(G),SZJ_(G)), optional, intent(in) :: read_khdt_x
+  real, dimension(SZI_(G),SZJB_(G)), optional, intent(in) :: read_khdt_y
+
+  type(mom6hip_tracer_hor_diff_cs_t) :: ccs
+  type(mom6hip_hordiff_stats_t) :: stats
+  type(c_ptr), allocatable :: tr(:)
+  real(c_double), allocatable, target :: cu(:)
+  integer :: m, rc
+
+  if (.not. associated(CS)) call MOM_error(FATAL, "MOM_tracer_hor_diff: "// &
+       "register_tracer must be called before tracer_hordiff.")
+  if (.not. associated(Reg)) call MOM_error(FATAL, "MOM_tracer_hor_diff: "// &
+       "register_tracer must be called before tracer_hordiff.")
+  if (Reg%ntr == 0 .or. (CS%KhTr <= 0.0 .and. .not. VarMix%use_variable_mixing)) return
+  if (VarMix%use_variable_mixing .or. allocated(MEKE%Kh)) call MOM_error(FATAL, "tracer_hordiff (HIP): "// &
+       "variable mixing (VarMix) and MEKE tracer diffusivities are not provided by the GPU path.")
+  if (present(do_online_flag)) then ; if (.not.do_online_flag) &
+    call MOM_error(FATAL, "tracer_hordiff (HIP): offline tracer diffusion (read_khdt_x/y) is not provided by the GPU path.")
+  endif
+  call cpu_clock_begin(id_clock_diffuse)
+  CS%first_call = .false.
+
+  allocate(tr(Reg%ntr), cu(Reg%ntr))
+  do m=1,Reg%ntr
+    if (associated(Reg%Tr(m)%df_x) .or. associated(Reg%Tr(m)%df_y) .or. associated(Reg%Tr(m)%df2d_x) .or. &
+        associated(Reg%Tr(m)%df2d_y)) call MOM_error(FATAL, "tracer_hordiff (HIP): the diffusive flux diagnostics of tracer "// &
+        trim(Reg%Tr(m)%name)//" are not provided by the GPU path.")
+    tr(m) = c_loc(Reg%Tr(m)%t)
+    cu(m) = Reg%Tr(m)%conc_underflow
+  enddo
+  ccs%KhTr = CS%KhTr ; ccs%max_diff_CFL = CS%max_diff_CFL ; ccs%reserved0(:) = 0.0
+  ccs%check_diffusive_CFL = merge(1, 0, CS%check_diffusive_CFL) ; ccs%initialized = 1
+  ccs%unsupported(:) = 0 ; ccs%reserved1(:) = 0
+  rc = mom6hip_tracer_hordiff(mom6hip_shared_context(G, GV), ccs, c_loc(h), dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), &
+                              MOM6HIP_MEM_HOST, stats)
+  call mom6hip_fatal_if(rc, "tracer_hordiff")
+  call cpu_clock_end(id_clock_diffuse)
+end subroutine tracer_hordiff
+
+!> Same interface as the reference tracer_hor_diff_init (:1625), same parameters and defaults (:1652-1700).
+subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic_CSp, CS)
+  type(time_type), target,    intent(in)    :: Time
+  type(ocean_grid_type),      intent(in)    :: G
+  type(verticalGrid_type),    intent(in)    :: GV
+  type(unit_scale_type),      intent(in)    :: US
+  type(diag_ctrl), target,    intent(inout) :: diag
+  type(EOS_type),  target,    intent(in)    :: EOS
+  type(diabatic_CS), pointer, intent(in)    :: diabatic_CSp
+  type(param_file_type),      intent(in)    :: param_file
+  type(tracer_hor_diff_CS),   pointer       :: CS
+# include "version_variable.h"
+  character(len=40)  :: mdl = "MOM_tracer_hor_diff"
+  logical :: flag
+  real :: val
+
+  if (associated(CS)) then
+    call MOM_error(WARNING, "tracer_hor_diff_init called with associated control structure.")
+    return
+  endif
+  allocate(CS)
+  CS%diag => diag
+  call log_version(param_file, mdl, version, "")
+  call get_param(param_file, mdl, "KHTR", CS%KhTr, "The background along-isopycnal tracer diffusivity.", &
+                 units="m2 s-1", default=0.0, scale=US%m_to_L**2*US%T_to_s)
+  call get_param(param_file, mdl, "KHTR_USE_EBT_STRUCT", flag, default=.false.) ; call refuse(flag, "KHTR_USE_EBT_STRUCT")
+  call get_param(param_file, mdl, "KHTR_SLOPE_CFF", val, units="nondim", default=0.0) ; call refuse(val /= 0.0, "KHTR_SLOPE_CFF")
+  call get_param(param_file, mdl, "KHTR_PASSIVITY_COEFF", val, units="nondim", default=0.0)
+  call refuse(val /= 0.0, "KHTR_PASSIVITY_COEFF")
+  call get_param(param_file, mdl, "DIFFUSE_ML_TO_INTERIOR", CS%Diffuse_ML_interior, &
+                 "If true, enable epipycnal mixing between the surface boundary layer and the interior.", default=.false.)
+  call refuse(CS%Diffuse_ML_interior, "DIFFUSE_ML_TO_INTERIOR")
+  call get_param(param_file, mdl, "CHECK_DIFFUSIVE_CFL", CS%check_diffusive_CFL, &
+                 "If true, use enough iterations the diffusion to ensure that the diffusive equations are stable.", &
+                 default=.false.)
+  call get_param(param_file, mdl, "MAX_TR_DIFFUSION_CFL", CS%max_diff_CFL, &
+                 "If positive, locally limit the along-isopycnal tracer diffusivity to keep the diffusive CFL below this.", &
+                 units="nondim", default=-1.0)
+  call get_param(param_file, mdl, "USE_NEUTRAL_DIFFUSION", CS%use_neutral_diffusion, default=.false.)
+  call refuse(CS%use_neutral_diffusion, "USE_NEUTRAL_DIFFUSION")
+  call get_param(param_file, mdl, "USE_HORIZONTAL_BOUNDARY_DIFFUSION", CS%use_hor_bnd_diffusion, default=.false.)
+  call refuse(CS%use_hor_bnd_diffusion, "USE_HORIZONTAL_BOUNDARY_DIFFUSION")
+  call mom6hip_read_topology(param_file)
+  id_clock_diffuse = cpu_clock_id('(Ocean diffuse tracer)', grain=CLOCK_MODULE)
+contains
+  subroutine refuse(on, name)
+    logical,          intent(in) :: on
+    character(len=*), intent(in) :: name
+    if (on) call MOM_error(FATAL, "tracer_hor_diff_init (HIP): "//name//" is not provided by the GPU path.")
+  end subroutine refuse
+end subroutine tracer_hor_diff_init
+
+!> Same interface as the reference tracer_hor_diff_end (:1772)
+subroutine tracer_hor_diff_end(CS)
+  type(tracer_hor_diff_CS), pointer :: CS
+  if (associated(CS)) deallocate(CS)
+end subroutine tracer_hor_diff_end
+
+end module MOM_tracer_hor_diff

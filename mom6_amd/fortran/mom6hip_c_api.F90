@@ -131,6 +131,21 @@ type, bind(c) :: mom6hip_set_visc_cs_t
   type(c_ptr) :: reserved1(3)
 end type mom6hip_set_visc_cs_t
 
+!> mom6hip_tracer_hor_diff_cs_t (tracer_hor_diff_CS, src/tracer/MOM_tracer_hor_diff.F90:40)
+type, bind(c) :: mom6hip_tracer_hor_diff_cs_t
+  real(c_double) :: KhTr, max_diff_CFL
+  real(c_double) :: reserved0(6)
+  integer(c_int32_t) :: check_diffusive_CFL, initialized
+  integer(c_int32_t) :: unsupported(8)
+  integer(c_int32_t) :: reserved1(6)
+end type mom6hip_tracer_hor_diff_cs_t
+
+!> mom6hip_hordiff_stats_t
+type, bind(c) :: mom6hip_hordiff_stats_t
+  integer(c_int32_t) :: num_itts, halo_updates
+  real(c_double) :: max_CFL
+end type mom6hip_hordiff_stats_t
+
 !> mom6hip_hor_visc_cs_t (hor_visc_CS, src/parameterizations/lateral/MOM_hor_visc.F90:40)
 type, bind(c) :: mom6hip_hor_visc_cs_t
   real(c_double) :: Kh, Kh_bg_min, Kh_vel_scale, Smag_Lap_const, Ah, Ah_vel_scale, Ah_time_scale, Smag_bi_const, bound_Cor_vel, bound_coef
@@ -294,6 +309,19 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_ale_remap_velocities
+
+  !> tracer_hordiff (MOM_tracer_hor_diff.F90:119), along-layer diffusion with a constant KHTR; tr: array of ntr c_loc's
+  function mom6hip_tracer_hordiff(ctx, cs, h, dt, tr, conc_underflow, ntr, memspace, stats) bind(c, name="mom6hip_tracer_hordiff") &
+                                  result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_tracer_hor_diff_cs_t, mom6hip_hordiff_stats_t
+    type(c_ptr), value :: ctx, h, conc_underflow
+    type(mom6hip_tracer_hor_diff_cs_t), intent(in) :: cs
+    real(c_double), value :: dt
+    type(c_ptr), intent(in) :: tr(*)
+    integer(c_int32_t), value :: ntr, memspace
+    type(mom6hip_hordiff_stats_t), intent(out) :: stats
+    integer(c_int) :: rc
+  end function mom6hip_tracer_hordiff
 
   !> subchk / subStats of MOM_checksums (MOM_checksums.F90:1387) on a device or host field of staggering pos
   function mom6hip_chksum(ctx, field, pos, nk, di, dj, symmetric, scale, bitcount, amin, amax, memspace) &

@@ -1,0 +1,71 @@
+"""Host-side mirror of MOM_tracer_hor_diff (reference: src/tracer/MOM_tracer_hor_diff.F90): tracer_hor_diff_init (:1625) and
+tracer_hordiff (:119) -- the along-layer diffusion with a constant KHTR.  The work is done by libmom6hip
+(mom6_amd/csrc/tracer_hor_diff.hip)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import Mom6HipError, check, lib
+from .tracer_advect import DeviceGrid, _ptr_space
+
+_PARAMS = {"KHTR": "KhTr", "MAX_TR_DIFFUSION_CFL": "max_diff_CFL", "CHECK_DIFFUSIVE_CFL": "check_diffusive_CFL"}
+# parameters of the reference whose branches this build does not provide: accepted at their defaults, refused otherwise
+_REFUSED = {"USE_NEUTRAL_DIFFUSION": 0, "USE_HORIZONTAL_BOUNDARY_DIFFUSION": 1, "DIFFUSE_ML_TO_INTERIOR": 2, "KHTR_SLOPE_CFF": 3,
+            "KHTR_PASSIVITY_COEFF": 3, "KHTR_USE_EBT_STRUCT": 5}
+
+
+class tracer_hor_diff_CS:
+    """tracer_hor_diff_CS (:40-100); parameters by their reference names (defaults :1652-1700)."""
+
+    def __init__(self, **params):
+        st = self.st = _abi.TracerHorDiffCS()
+        st.KhTr, st.max_diff_CFL, st.check_diffusive_CFL = 0.0, -1.0, 0
+        for k, v in params.items():
+            if k in _PARAMS:
+                a = _PARAMS[k]
+                setattr(st, a, int(bool(v)) if a == "check_diffusive_CFL" else float(v))
+            elif k in _REFUSED:
+                if v:
+                    st.unsupported[_REFUSED[k]] = 1
+            else:
+                raise Mom6HipError(f"tracer_hor_diff_init: unknown parameter {k}")
+        st.initialized = 1
+        self.last = None
+
+
+def tracer_hor_diff_init(Time=None, G=None, GV=None, US=None, param_file=None, diag=None, EOS=None, diabatic_CSp=None, **params):
+    """tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic_CSp, CS) -- :1625 (parameters as keywords)."""
+    return tracer_hor_diff_CS(**params)
+
+
+def tracer_hordiff(h, dt, MEKE, VarMix, visc, G: DeviceGrid, CS: tracer_hor_diff_CS, Reg, tv=None, do_online_flag=None, read_khdt_x=None,
+                   read_khdt_y=None, conc_underflow=None):
+    """tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_online_flag, read_khdt_x, read_khdt_y) -- :119.
+    Reg: the list of tracer arrays (Reg%Tr(m)%t), updated in place.  MEKE, VarMix belong to branches this build does not
+    provide and must be None.  Returns the iteration statistics."""
+    if CS is None or Reg is None:
+        raise Mom6HipError("MOM_tracer_hor_diff: register_tracer must be called before tracer_hordiff.")
+    if MEKE is not None or VarMix is not None:
+        raise Mom6HipError("tracer_hordiff (HIP): MEKE and VarMix diffusivities are not supported on this path")
+    if do_online_flag is False or read_khdt_x is not None or read_khdt_y is not None:
+        raise Mom6HipError("tracer_hordiff (HIP): offline khdt arrays are not supported on this path")
+    L = lib()
+    L.mom6hip_tracer_hordiff.argtypes = [C.c_void_p, C.POINTER(_abi.TracerHorDiffCS), C.c_void_p, C.c_double, C.POINTER(C.c_void_p), C.c_void_p,
+                                         C.c_int32, C.c_int32, C.POINTER(_abi.HorDiffStats)]
+    tr = list(Reg)
+    spaces = set()
+    hp, s0 = _ptr_space(h); spaces.add(s0)
+    ptrs = (C.c_void_p * max(len(tr), 1))()
+    for m, t in enumerate(tr):
+        p, s = _ptr_space(t); ptrs[m] = p; spaces.add(s)
+    if len(spaces) != 1:
+        raise Mom6HipError("tracer_hordiff: h and every tracer must be in the same memory space")
+    cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
+    stats = _abi.HorDiffStats()
+    check(L.mom6hip_tracer_hordiff(G.handle, C.byref(CS.st), C.c_void_p(hp), float(dt), ptrs, None if cu is None else cu.ctypes.data,
+                                   len(tr), spaces.pop(), C.byref(stats)), "tracer_hordiff")
+    CS.last = stats
+    return stats

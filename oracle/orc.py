@@ -397,6 +397,22 @@ def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy,
     return out
 
 
+def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL=False, conc_underflow=None):
+    """tracer_hordiff (along-layer, constant KHTR) on numpy arrays; tr updated in place.  Returns the stats struct."""
+    L = lib()
+    L.orc_tracer_hordiff.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.TracerHorDiffCS), _dp, C.c_double, C.POINTER(_dp), _dp, C.c_int,
+                                     C.POINTER(_abi.HorDiffStats)]
+    cs = _abi.TracerHorDiffCS(); cs.KhTr = float(KhTr); cs.max_diff_CFL = float(max_diff_CFL); cs.check_diffusive_CFL = int(bool(check_diffusive_CFL))
+    ntr = len(tr)
+    trp = (_dp * max(ntr, 1))(*[_p(t) for t in tr])
+    cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
+    st = _abi.HorDiffStats()
+    rc = L.orc_tracer_hordiff(C.byref(grid.struct()), C.byref(cs), _p(h), float(dt), trp, _p(cu), ntr, C.byref(st))
+    if rc:
+        raise RuntimeError("orc_tracer_hordiff failed")
+    return st
+
+
 # ---- MOM_dynamics_split_RK2 -------------------------------------------------------------------------------
 class DynState:
     """Everything one oracle run of the split RK2 step owns: sub-module control structures, the control structure of

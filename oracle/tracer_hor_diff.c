@@ -1,0 +1,110 @@
+/* oracle/tracer_hor_diff.c -- TEST INFRASTRUCTURE: a C restatement of the along-layer branch of tracer_hordiff
+ * (src/tracer/MOM_tracer_hor_diff.F90:119-680) with a constant KHTR (no VarMix, MEKE, neutral or boundary diffusion, no
+ * epipycnal mixed-layer diffusion).  The reference holds no known-answer vectors for this routine: parity unpinned; the
+ * tests hold it to exact conservation, preservation of constants and the maximum principle. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include "mom6_oracle.h"
+
+static inline double min2(double a, double b) { return a < b ? a : b; }
+
+int orc_tracer_hordiff(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const double *h, double dt,
+                       double *const *tr, const double *conc_underflow, int ntr, mom6hip_hordiff_stats_t *stats)
+{
+  for (int q = 0; q < 8; q++) if (CS->unsupported[q]) return 2;
+  if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
+  if (ntr == 0 || CS->KhTr <= 0.0) return 0;                       /* :199 */
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const int isd = G->isd, jsd = G->jsd;
+  const int nih = G->ied - G->isd + 1, njh = G->jed - G->jsd + 1;
+#define H2(i,j) ((size_t)((j)-jsd)*nih + ((i)-isd))
+#define U2(I,j) ((size_t)((j)-jsd)*(nih+1) + ((I)-isd+1))
+#define V2(i,J) ((size_t)((J)-jsd+1)*nih + ((i)-isd))
+  const size_t hpl = (size_t)nih*njh;
+  const double h_neglect = G->H_subroundoff;                       /* :208 */
+  double *khdt_x = (double*)calloc((size_t)(nih+1)*njh, sizeof(double));
+  double *khdt_y = (double*)calloc((size_t)nih*(njh+1), sizeof(double));
+  double *Coef_x = (double*)calloc((size_t)(nih+1)*njh, sizeof(double));
+  double *Coef_y = (double*)calloc((size_t)nih*(njh+1), sizeof(double));
+  double *Ihdxdy = (double*)calloc(hpl, sizeof(double));
+  double *dTr = (double*)calloc(hpl, sizeof(double));
+  /* a simple constant diffusivity :340-351 */
+  for (int j = js; j <= je; j++) for (int I = is-1; I <= ie; I++)
+    khdt_x[U2(I,j)] = dt*(CS->KhTr*(G->dy_Cu[U2(I,j)]*G->IdxCu[U2(I,j)]));
+  for (int J = js-1; J <= je; J++) for (int i = is; i <= ie; i++)
+    khdt_y[V2(i,J)] = dt*(CS->KhTr*(G->dx_Cv[V2(i,J)]*G->IdyCv[V2(i,J)]));
+  if (CS->max_diff_CFL > 0.0) {                                    /* :368-398 */
+    for (int j = js; j <= je; j++) for (int I = is-1; I <= ie; I++) {
+      const int i = I;
+      const double khdt_max = 0.125*CS->max_diff_CFL * min2(G->areaT[H2(i,j)], G->areaT[H2(i+1,j)]);
+      khdt_x[U2(I,j)] = min2(khdt_x[U2(I,j)], khdt_max);
+    }
+    for (int J = js-1; J <= je; J++) for (int i = is; i <= ie; i++) {
+      const int j = J;
+      const double khdt_max = 0.125*CS->max_diff_CFL * min2(G->areaT[H2(i,j)], G->areaT[H2(i,j+1)]);
+      khdt_y[V2(i,J)] = min2(khdt_y[V2(i,J)], khdt_max);
+    }
+  }
+  int num_itts; double I_numitts, max_CFL = 0.0;
+  if (CS->check_diffusive_CFL) {                                   /* :410-423 */
+    for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+      const int I = i, J = j;
+      const double CFL = 2.0*((khdt_x[U2(I-1,j)] + khdt_x[U2(I,j)]) + (khdt_y[V2(i,J-1)] + khdt_y[V2(i,J)])) * G->IareaT[H2(i,j)];
+      if (max_CFL < CFL) max_CFL = CFL;
+    }
+    num_itts = (int)ceil(max_CFL - 4.0*DBL_EPSILON);              /* EPSILON(max_CFL): the machine epsilon of the kind */
+    if (num_itts < 1) num_itts = 1;
+    I_numitts = 1.0 / ((double)num_itts);
+  } else if (CS->max_diff_CFL > 0.0) {
+    num_itts = (int)ceil(CS->max_diff_CFL - 4.0*DBL_EPSILON);
+    if (num_itts < 1) num_itts = 1;
+    I_numitts = 1.0 / ((double)num_itts);
+  } else { num_itts = 1; I_numitts = 1.0; }
+
+  int halo_updates = 0;
+  for (int itt = 1; itt <= num_itts; itt++) {                      /* :540-604 */
+    for (int m = 0; m < ntr; m++) orc_halo_update(G, tr[m], MOM6HIP_POS_H, nz);
+    halo_updates++;
+    for (int k = 0; k < nz; k++) {
+      const double scale = I_numitts;
+      const double *hk = h + hpl*k;
+      for (int J = js-1; J <= je; J++) for (int i = is; i <= ie; i++) {
+        const int j = J;
+        Coef_y[V2(i,J)] = ((scale * khdt_y[V2(i,J)])*2.0*(hk[H2(i,j)]*hk[H2(i,j+1)])) / (hk[H2(i,j)]+hk[H2(i,j+1)]+h_neglect);
+      }
+      for (int j = js; j <= je; j++) {
+        for (int I = is-1; I <= ie; I++) {
+          const int i = I;
+          Coef_x[U2(I,j)] = ((scale * khdt_x[U2(I,j)])*2.0*(hk[H2(i,j)]*hk[H2(i+1,j)])) / (hk[H2(i,j)]+hk[H2(i+1,j)]+h_neglect);
+        }
+        for (int i = is; i <= ie; i++) Ihdxdy[H2(i,j)] = G->IareaT[H2(i,j)] / (hk[H2(i,j)]+h_neglect);
+      }
+      for (int m = 0; m < ntr; m++) {
+        double *t = tr[m] + hpl*k;
+        for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+          const int I = i, J = j;
+          dTr[H2(i,j)] = Ihdxdy[H2(i,j)] *
+            ((Coef_x[U2(I-1,j)] * (t[H2(i-1,j)] - t[H2(i,j)]) -
+              Coef_x[U2(I,j)] * (t[H2(i,j)] - t[H2(i+1,j)])) +
+             (Coef_y[V2(i,J-1)] * (t[H2(i,j-1)] - t[H2(i,j)]) -
+              Coef_y[V2(i,J)] * (t[H2(i,j)] - t[H2(i,j+1)])));
+        }
+        for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) t[H2(i,j)] = t[H2(i,j)] + dTr[H2(i,j)];
+      }
+    }
+    for (int m = 0; m < ntr; m++) if (conc_underflow && conc_underflow[m] > 0.0) {   /* :607-612 */
+      for (int k = 0; k < nz; k++) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+        double *t = tr[m] + hpl*k + H2(i,j);
+        if (fabs(*t) < conc_underflow[m]) *t = 0.0;
+      }
+    }
+  }
+  if (stats) { stats->num_itts = num_itts; stats->halo_updates = halo_updates; stats->max_CFL = max_CFL; }
+#undef H2
+#undef U2
+#undef V2
+  free(khdt_x); free(khdt_y); free(Coef_x); free(Coef_y); free(Ihdxdy); free(dTr);
+  return 0;
+}

@@ -24,6 +24,7 @@ SIZES = {"benchmark": (360, 180, 75), "om4_band": (1440, 64, 75), "tall": (48, 1
 DT = 900.0
 VV = dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=1.0e-2)
 HV = dict(Ah_vel_scale=0.01, Smagorinsky_Ah=1, Smag_bi_const=0.06)      # the model's horizontal viscosity (biharmonic Smagorinsky)
+HORDIFF_BIG_KHTR = 2.0e5      # needs several iterations at 1/4 and 1 degree (CHECK_DIFFUSIVE_CFL)
 CONT_VARIANTS = OrderedDict([
     ("plain", dict(cs={}, uhbt=False, bt=False, visc=False)),
     ("bt_cont", dict(cs={}, uhbt=False, bt=True, visc=True)),
@@ -94,6 +95,11 @@ class OracleOps:
         out.update(frhatu=cs_arrs["frhatu"], eta_cor=cs_arrs["eta_cor"], ubtav=cs_arrs["ubtav"],
                    dtbt_max=np.array([cs.dtbt_max]), nstep=np.array([float(cs.nstep_last)]))
         return out
+
+    def tracer_hordiff(self, h, dt, tr, KhTr, check):
+        tr = [t.copy() for t in tr]
+        st = self.orc.tracer_hordiff(self.g, h, dt, tr, KhTr, check_diffusive_CFL=check)
+        return tr, int(st.num_itts)
 
     def advect_tracer(self, h_end, uhtr, vhtr, dt, scheme, tr):
         tr = [t.copy() for t in tr]
@@ -244,6 +250,14 @@ class HipOps:
         res.update(frhatu=self.N(CS.frhatu), eta_cor=self.N(CS.eta_cor), ubtav=self.N(CS.ubtav),
                    dtbt_max=np.array([CS.st.dtbt_max]), nstep=np.array([float(CS.st.nstep_last)]))
         return res
+
+    def tracer_hordiff(self, h, dt, tr, KhTr, check):
+        from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
+        T = self.T
+        dtr = [T(t) for t in tr]
+        st = tracer_hordiff(T(h), dt, None, None, None, self.dg, tracer_hor_diff_init(KHTR=KhTr, CHECK_DIFFUSIVE_CFL=check), dtr)
+        self.dg.sync()
+        return [t.cpu().numpy() for t in dtr], int(st.num_itts)
 
     def advect_tracer(self, h_end, uhtr, vhtr, dt, scheme, tr):
         from mom6_amd.tracer_advect import advect_tracer, tracer_advect_init
@@ -413,6 +427,13 @@ def operators(ops, g, d, taux, tauy, bbl, only=None):
             yield f"advect_tracer[{scheme}].iterations", np.array([float(it)])
             for m, a in enumerate(res):
                 yield f"advect_tracer[{scheme}].tr{m}", a
+    if want("hordiff"):
+        tr = [d["T"], d["S"]] + d["tr"]
+        for nm, K, chk in (("khtr50", 50.0, False), ("iterated", HORDIFF_BIG_KHTR, True)):
+            res, it = ops.tracer_hordiff(d["h"], 4 * DT, tr, K, chk)
+            yield f"tracer_hordiff[{nm}].iterations", np.array([float(it)])
+            for m, a in enumerate(res):
+                yield f"tracer_hordiff[{nm}].tr{m}", a
     if want("ale"):
         tr = [d["T"], d["S"]] + d["tr"]
         for scheme in ("PPM_H4", "PLM"):

@@ -382,6 +382,39 @@ type :: SAL_CS
 end type SAL_CS
 end module MOM_self_attr_load
 
+module MOM_EOS
+implicit none ; private
+public :: EOS_type
+type :: EOS_type
+  integer :: form_of_EOS = 0
+end type EOS_type
+end module MOM_EOS
+
+module MOM_diabatic_driver
+implicit none ; private
+public :: diabatic_CS
+type :: diabatic_CS
+  integer :: unused = 0
+end type diabatic_CS
+end module MOM_diabatic_driver
+
+module MOM_MEKE_types
+implicit none ; private
+public :: MEKE_type
+type :: MEKE_type
+  real, allocatable :: Kh(:,:)
+  real :: KhTr_fac = 1.0
+end type MEKE_type
+end module MOM_MEKE_types
+
+module MOM_lateral_mixing_coeffs
+implicit none ; private
+public :: VarMix_CS
+type :: VarMix_CS
+  logical :: use_variable_mixing = .false., Resoln_scaled_KhTr = .false.
+end type VarMix_CS
+end module MOM_lateral_mixing_coeffs
+
 module MOM_open_boundary
 implicit none ; private
 public :: ocean_OBC_type
@@ -406,6 +439,9 @@ type :: tracer_type
   real :: conc_underflow = 0.0
   real, dimension(:,:,:), pointer :: ad_x => NULL(), ad_y => NULL(), advection_xy => NULL()
   real, dimension(:,:),   pointer :: ad2d_x => NULL(), ad2d_y => NULL()
+  real, dimension(:,:,:), pointer :: df_x => NULL(), df_y => NULL()
+  real, dimension(:,:),   pointer :: df2d_x => NULL(), df2d_y => NULL()
+  character(len=32) :: name = ""
 end type tracer_type
 type :: tracer_registry_type
   integer :: ntr = 0
@@ -435,6 +471,7 @@ type :: cont_diag_ptrs
 end type cont_diag_ptrs
 type :: thermo_var_ptrs
   real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL()
+  real, pointer, dimension(:,:) :: p_surf => NULL()
 end type thermo_var_ptrs
 type :: vertvisc_type
   real, allocatable, dimension(:,:) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v

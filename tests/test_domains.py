@@ -70,6 +70,23 @@ def test_advect_tracer_layout_independence(tmp_path, layout, scheme):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", [(1, 2), (2, 1)])
+def test_tracer_hordiff_layout_independence(tmp_path, layout):
+    import torch.multiprocessing as mp
+    from mp_workers import hordiff_layout_worker
+    mp.spawn(hordiff_layout_worker, args=(2, free_port(), layout, str(tmp_path)), nprocs=2, join=True)
+    glob = np.load(tmp_path / "global.npz")
+    assert glob["it"][0] > 1
+    for r in range(2):
+        t = np.load(tmp_path / f"tile{r}.npz")
+        i0, j0, ni, nj, its = t["ij"]
+        assert its == glob["it"][0] and t["cfl"][0] == glob["cfl"][0]
+        for m in range(2):
+            a = t[f"arr_{m}"]; b = glob[f"arr_{m}"][:, j0:j0 + nj, i0:i0 + ni]
+            assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, r, m)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout,topo", [((1, 2), (True, False)), ((2, 1), (True, False)), ((2, 1), (False, False)), ((1, 2), (True, True))])
 def test_btstep_layout_independence(tmp_path, layout, topo):
     import torch.multiprocessing as mp

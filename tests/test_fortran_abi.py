@@ -74,7 +74,7 @@ def test_fortran_driver_matches_oracle(tmp_path, oracle):
 FDIR = os.path.join(ROOT, "mom6_amd", "fortran")
 STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
 SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_barotropic_hip.F90",
-         "MOM_tracer_advect_hip.F90"]
+         "MOM_tracer_advect_hip.F90", "MOM_tracer_hor_diff_hip.F90"]
 
 
 def _build_shims(tmp, driver="shim_driver"):

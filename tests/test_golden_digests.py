@@ -35,7 +35,7 @@ def test_inputs_are_reproduced_bit_for_bit(size):
 def test_oracle_reproduces_its_digests():
     """the cheapest operators of the tall strip, on the CPU: the fixture belongs to this oracle"""
     gold = load("tall")
-    got = ds.run(ds.OracleOps, "tall", parts=("operators",), only=("coradcalc", "pressureforce", "vertvisc", "hor_visc", "set_viscous_BBL"))
+    got = ds.run(ds.OracleOps, "tall", parts=("operators",), only=("coradcalc", "pressureforce", "vertvisc", "hor_visc", "set_viscous_BBL", "hordiff"))
     assert len(got) > 10
     for name, dg in got.items():
         assert dg["sha256"] == gold[name]["sha256"], name
