@@ -3,19 +3,22 @@
 !!   continuity(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, visc_rem_u=, visc_rem_v=, BT_cont=)      (RK2 :634)
 !!   continuity(u, v, h, hp2, uh2, vh2, dt, ..., uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont) (RK2 :757)
 !!   CorAdCalc(u, v, h, uh2, vh2, CAu, CAv, OBC, AD, G, GV, US, CS, pbv)                                     (RK2 :869)
+!!   PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)                       (RK2 :548)
 !! on plain host arrays; the results go to the output file, which the test compares with the oracle bit for bit.
 !! Usage: shim_driver <input file> <output file>
 program shim_driver
 use, intrinsic :: iso_c_binding
 use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_PPM_stencil, continuity_PPM_CS
 use MOM_CoriolisAdv,    only : CorAdCalc, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_CS
+use MOM_PressureForce_FV, only : PressureForce_FV_Bouss, PressureForce_FV_init, PressureForce_FV_CS
+use MOM_ALE,            only : ALE_CS
 use MOM_diag_mediator,  only : diag_ctrl, time_type
 use MOM_domains,        only : MOM_domain_type, pass_var, EAST_FACE, NORTH_FACE
 use MOM_file_parser,    only : param_file_type, param_set
 use MOM_grid,           only : ocean_grid_type
 use MOM_open_boundary,  only : ocean_OBC_type
 use MOM_unit_scaling,   only : unit_scale_type
-use MOM_variables,      only : BT_cont_type, porous_barrier_type, accel_diag_ptrs, alloc_BT_cont_type
+use MOM_variables,      only : BT_cont_type, porous_barrier_type, accel_diag_ptrs, alloc_BT_cont_type, thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
 use mom6hip_MOM_glue,   only : mom6hip_shared_context_end
 implicit none
@@ -29,6 +32,12 @@ type(diag_ctrl), target :: diag
 type(accel_diag_ptrs), target :: AD
 type(continuity_PPM_CS) :: CS
 type(CoriolisAdv_CS) :: CCS
+type(PressureForce_FV_CS) :: PCS
+type(thermo_var_ptrs) :: tv
+type(ALE_CS), pointer :: ALE_CSp => NULL()
+real, pointer, dimension(:,:) :: p_atm => NULL()
+real, allocatable, dimension(:,:,:) :: PFu, PFv, pbce
+real, allocatable, dimension(:,:) :: eta
 type(ocean_OBC_type), pointer :: OBC => NULL()
 type(porous_barrier_type) :: pbv
 type(BT_cont_type), pointer :: BT => NULL()
@@ -71,7 +80,12 @@ read(u_in) G%mask2dBu, G%dxBu, G%dyBu, G%areaBu, G%IareaBu, G%CoriolisBu, G%IdxB
 allocate(u(isd-1:ied,jsd:jed,nk), v(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk), uhbt(isd-1:ied,jsd:jed), vhbt(isd:ied,jsd-1:jed), &
          vru(isd-1:ied,jsd:jed,nk), vrv(isd:ied,jsd-1:jed,nk))
 read(u_in) u, v, h, uhbt, vhbt, vru, vrv
+allocate(tv%T(isd:ied,jsd:jed,nk), tv%S(isd:ied,jsd:jed,nk))
+read(u_in) tv%T, tv%S
 close(u_in)
+allocate(PFu(isd-1:ied,jsd:jed,nk), PFv(isd:ied,jsd-1:jed,nk), pbce(isd:ied,jsd:jed,nk), eta(isd:ied,jsd:jed))
+PFu = 0.0 ; PFv = 0.0 ; pbce = 0.0 ; eta = 0.0
+allocate(GV%g_prime(nk+1)) ; GV%g_prime(:) = 0.0 ; GV%g_prime(1) = GV%g_Earth
 allocate(hp(isd:ied,jsd:jed,nk), hp2(isd:ied,jsd:jed,nk), uh(isd-1:ied,jsd:jed,nk), uh2(isd-1:ied,jsd:jed,nk), &
          vh(isd:ied,jsd-1:jed,nk), vh2(isd:ied,jsd-1:jed,nk), u_cor(isd-1:ied,jsd:jed,nk), v_cor(isd:ied,jsd-1:jed,nk), &
          CAu(isd-1:ied,jsd:jed,nk), CAv(isd:ied,jsd-1:jed,nk))
@@ -83,6 +97,8 @@ call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))
 call param_set(pf, "BOUND_CORIOLIS", "True")
 call continuity_PPM_init(Time, G, GV, US, pf, diag, CS)
 call CoriolisAdv_init(Time, G, GV, US, pf, diag, AD, CCS)
+call param_set(pf, "USE_REGRIDDING", "True")
+call PressureForce_FV_init(Time, G, GV, US, pf, diag, PCS)
 if (continuity_PPM_stencil(CS) /= 3) error stop "shim_driver: unexpected continuity stencil"
 call alloc_BT_cont_type(BT, isd, ied, jsd, jed, nk, alloc_faces=.true.)
 
@@ -90,11 +106,13 @@ call continuity_PPM(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, visc_rem_u
 call continuity_PPM(u, v, h, hp2, uh2, vh2, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, vru, vrv, u_cor, v_cor, BT_cont=BT)
 call pass_var(uh2, G%Domain, position=EAST_FACE) ; call pass_var(vh2, G%Domain, position=NORTH_FACE)
 call CorAdCalc(u, v, h, uh2, vh2, CAu, CAv, OBC, AD, G, GV, US, CCS, pbv)
+call PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, PCS, ALE_CSp, p_atm, pbce, eta)
 
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) hp, uh, vh, hp2, uh2, vh2, u_cor, v_cor, CAu, CAv
 write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_EE
 write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
+write(u_out) PFu, PFv, pbce, eta
 close(u_out)
 call CoriolisAdv_end(CCS)
 call mom6hip_shared_context_end()

@@ -163,7 +163,8 @@ module MOM_unit_scaling
 implicit none ; private
 public :: unit_scale_type
 type :: unit_scale_type
-  real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0
+  real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0, &
+          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0
 end type unit_scale_type
 end module MOM_unit_scaling
 
@@ -381,6 +382,22 @@ type :: SAL_CS
   integer :: unused = 0
 end type SAL_CS
 end module MOM_self_attr_load
+
+module MOM_ALE
+implicit none ; private
+public :: ALE_CS
+type :: ALE_CS
+  integer :: unused = 0
+end type ALE_CS
+end module MOM_ALE
+
+module MOM_tidal_forcing
+implicit none ; private
+public :: tidal_forcing_CS
+type :: tidal_forcing_CS
+  integer :: unused = 0
+end type tidal_forcing_CS
+end module MOM_tidal_forcing
 
 module MOM_EOS
 implicit none ; private

@@ -74,7 +74,7 @@ def test_fortran_driver_matches_oracle(tmp_path, oracle):
 FDIR = os.path.join(ROOT, "mom6_amd", "fortran")
 STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
 SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_barotropic_hip.F90",
-         "MOM_tracer_advect_hip.F90", "MOM_tracer_hor_diff_hip.F90"]
+         "MOM_PressureForce_FV_hip.F90", "MOM_tracer_advect_hip.F90", "MOM_tracer_hor_diff_hip.F90"]
 
 
 def _build_shims(tmp, driver="shim_driver"):
@@ -114,7 +114,7 @@ def _shim_case(path, reentrant=(True, True)):
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
         for n in _abi.ALL_METRICS:
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
-        for a in (d["u"], d["v"], d["h"], uhbt, vhbt, vru, vrv):
+        for a in (d["u"], d["v"], d["h"], uhbt, vhbt, vru, vrv, d["T"], d["S"]):
             np.ascontiguousarray(a, dtype="<f8").tofile(f)
     # call 2 and CorAdCalc, as the driver does them
     hp2 = d["h"].copy(); uh2 = np.zeros_like(d["u"]); vh2 = np.zeros_like(d["v"]); ucor = np.zeros_like(d["u"]); vcor = np.zeros_like(d["v"])
@@ -122,11 +122,12 @@ def _shim_case(path, reentrant=(True, True)):
                    v_cor=vcor, bt_cont=bt)
     orc.halo_update(g, uh2, _abi.POS_U); orc.halo_update(g, vh2, _abi.POS_V)
     CAu, CAv = orc.coradcalc(g, d["u"], d["v"], d["h"], uh2, vh2, bound_coriolis=True)
+    PFu, PFv, pbce, eta = orc.pressureforce(g, orc.pressureforce_cs(g), orc.eos("WRIGHT"), d["h"], d["T"], d["S"])[:4]
     want = [hp, uh, vh, hp2, uh2, vh2, ucor, vcor, CAu, CAv] + [arrs[n] for n in ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE",
                                                                                      "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN",
-                                                                                     "h_u", "h_v")]
+                                                                                     "h_u", "h_v")] + [PFu, PFv, pbce, eta]
     names = ["hp", "uh", "vh", "hp2", "uh2", "vh2", "u_cor", "v_cor", "CAu", "CAv", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE",
-             "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"]
+             "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "PFu", "PFv", "pbce", "eta"]
     return g, names, want
 
 
@@ -163,9 +164,14 @@ def test_module_shims_match_oracle(tmp_path, reentrant):
     from helpers import interior
     for n, a, w in zip(names, got, want):
         a = a.reshape(w.shape)
-        pos = _abi.POS_U if n in ("uh", "uh2", "u_cor", "CAu", "h_u") or n.startswith(("FA_u", "uBT")) else \
-            (_abi.POS_V if n in ("vh", "vh2", "v_cor", "CAv", "h_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
-        assert bits_equal(interior(g, a, pos), interior(g, w, pos)), n
+        pos = _abi.POS_U if n in ("uh", "uh2", "u_cor", "CAu", "h_u", "PFu") or n.startswith(("FA_u", "uBT")) else \
+            (_abi.POS_V if n in ("vh", "vh2", "v_cor", "CAv", "h_v", "PFv") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        ia, iw = interior(g, a, pos), interior(g, w, pos)
+        if n == "PFu":      # PressureForce computes the faces Isq..Ieq between computed columns (is-1..ie here needs the halo columns)
+            ia, iw = ia[..., 1:-1], iw[..., 1:-1]
+        if n == "PFv":
+            ia, iw = ia[..., 1:-1, :], iw[..., 1:-1, :]
+        assert bits_equal(ia, iw), n
 
 
 def _bt_case(path):
