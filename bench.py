@@ -711,7 +711,7 @@ def main():
             # HBM bytes of the kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/
             # profile_round.sh): valid only for the kernel source they were taken with -- the profile carries the SHA-256 of
             # continuity.hip, and a different source (or workload) makes `traffic` null instead of stale
-            traffic, traffic_from = None, None
+            traffic, traffic_from, valu = None, None, None
             try:
                 import hashlib
                 prof = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
@@ -720,12 +720,16 @@ def main():
                 if a.workload == "om4_025" and world == 1 and prof.get("source_sha256", {}).get("continuity.hip") == sha:
                     traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
                     traffic_from = f"profiles/{PMC_PROFILE} (continuity.hip sha256 {sha[:12]})"
+                    if "SQ_INSTS_VALU" in pmc:      # what actually bounds this kernel: fp64 VALU issue (4 cycles per wave instruction)
+                        issue_ms = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+                        valu = {"valu_wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "issue_ms_at_full_rate": issue_ms,
+                                "issue_frac": issue_ms / avg_ms, "instructions_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / (cells / world)}
             except Exception:
                 pass
             out["roofline"] = {
                 "kernel": "cont_flux_coop_kernel<1,10>", "bound": "hbm", "achieved": alg / (avg_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_from": traffic_from,
+                "traffic_from": traffic_from, "fp64_valu": valu,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n_y),
                 "also": {"cont_flux_coop_kernel<0,10>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
             }
