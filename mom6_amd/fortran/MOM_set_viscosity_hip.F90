@@ -1,0 +1,272 @@
+!> Drop-in replacement for module MOM_set_visc (src/parameterizations/vertical/MOM_set_viscosity.F90): set_viscous_BBL (:134),
+!! set_viscous_ML (:1898), set_visc_init (:2886), set_visc_register_restarts (:2693), set_visc_end with the reference's
+!! dummy-argument lists, so MOM.F90 (:1205) and the split RK2 step (:592) compile unchanged.  The work is done by libmom6hip
+!! (mom6hip_set_viscous_bbl, HOST memspace).  Provided: BOTTOMDRAGLAW with LINEAR_DRAG or the quadratic law (CDRAG,
+!! DRAG_BG_VEL), BBL_USE_EOS (WRIGHT / LINEAR, read from the parameter file: EOS_type is opaque) or GV%Rlay, HBBL,
+!! BBL_THICK_MIN, KV_BBL_MIN, CORRECT_BBL_BOUNDS, DRAG_AS_BODY_FORCE.  CHANNEL_DRAG, BBL_USE_TIDAL_BG, DYNAMIC_VISCOUS_ML, a
+!! bulk mixed layer, ice shelves, open boundaries and porous barriers stop with a FATAL error.
+!!
+!! Compiled INSIDE a MOM6 source tree in place of the reference file; here against tests/fortran/stubs.
+module MOM_set_visc
+
+use, intrinsic :: iso_c_binding
+use mom6hip_c_api
+use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use MOM_ALE,              only : ALE_CS
+use MOM_diag_mediator,    only : diag_ctrl, time_type
+use MOM_error_handler,    only : MOM_error, FATAL, WARNING
+use MOM_file_parser,      only : get_param, log_version, param_file_type
+use MOM_forcing_type,     only : mech_forcing
+use MOM_grid,             only : ocean_grid_type
+use MOM_hor_index,        only : hor_index_type
+use MOM_open_boundary,    only : ocean_OBC_type
+use MOM_restart,          only : register_restart_field, MOM_restart_CS
+use MOM_string_functions, only : uppercase
+use MOM_unit_scaling,     only : unit_scale_type
+use MOM_variables,        only : thermo_var_ptrs, vertvisc_type, porous_barrier_type
+use MOM_verticalGrid,     only : verticalGrid_type
+implicit none ; private
+
+#include <MOM_memory.h>
+
+public set_viscous_BBL, set_viscous_ML, set_visc_init, set_visc_end
+public set_visc_register_restarts, set_u_at_v, set_v_at_u
+public remap_vertvisc_aux_vars
+
+!> Control structure: the library's struct and the equation of state read at initialisation
+type, public :: set_visc_CS ; private
+  logical :: initialized = .false.
+  type(mom6hip_set_visc_cs_t) :: st
+  type(mom6hip_eos_t) :: eos
+  real, allocatable :: Rlay(:)
+  type(diag_ctrl), pointer :: diag => NULL()
+end type set_visc_CS
+
+contains
+
+!> Same interface as the reference set_viscous_BBL (:134).
+subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
+  type(ocean_grid_type),    intent(inout) :: G
+  type(verticalGrid_type),  intent(in)    :: GV
+  type(unit_scale_type),    intent(in)    :: US
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(in) :: v
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(in) :: h
+  type(thermo_var_ptrs),    intent(in)    :: tv
+  type(vertvisc_type), target, intent(inout) :: visc
+  type(set_visc_CS),   target, intent(inout) :: CS
+  type(porous_barrier_type),intent(in)    :: pbv
+  type(mom6hip_vertvisc_type_t) :: cv
+  type(mom6hip_eos_t), target :: eos
+  type(c_ptr) :: p_T, p_S
+  integer :: rc
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(BBL): Module must be initialized before it is used.")
+  if (CS%st%bottomdraglaw == 0) return      ! :307
+  if (allocated(pbv%por_layer_widthU)) then
+    if (any(pbv%por_layer_widthU /= 1.0) .or. any(pbv%por_layer_widthV /= 1.0)) &
+      call MOM_error(FATAL, "set_viscous_BBL (HIP): porous barriers are not supported by the GPU path.")
+  endif
+  if (.not.(allocated(visc%bbl_thick_u) .and. allocated(visc%Kv_bbl_u))) call MOM_error(FATAL, "set_viscous_BBL (HIP): "// &
+       "visc%bbl_thick_u/v and visc%Kv_bbl_u/v must be allocated (set_visc_init does it).")
+  cv%Kv_bbl_u = c_loc(visc%Kv_bbl_u) ; cv%Kv_bbl_v = c_loc(visc%Kv_bbl_v)
+  cv%bbl_thick_u = c_loc(visc%bbl_thick_u) ; cv%bbl_thick_v = c_loc(visc%bbl_thick_v)
+  cv%Ray_u = c_null_ptr ; if (allocated(visc%Ray_u)) cv%Ray_u = c_loc(visc%Ray_u)
+  cv%Ray_v = c_null_ptr ; if (allocated(visc%Ray_v)) cv%Ray_v = c_loc(visc%Ray_v)
+  cv%Kv_shear = c_null_ptr ; cv%Kv_shear_Bu = c_null_ptr ; cv%reserved(:) = c_null_ptr
+  p_T = c_null_ptr ; p_S = c_null_ptr
+  if (CS%st%BBL_use_EOS /= 0) then
+    if (.not.(associated(tv%T) .and. associated(tv%S))) &
+      call MOM_error(FATAL, "set_viscous_BBL (HIP): BBL_USE_EOS needs tv%T and tv%S.")
+    p_T = c_loc(tv%T) ; p_S = c_loc(tv%S)
+  endif
+  eos = CS%eos
+  CS%st%Rlay = c_null_ptr ; if (allocated(CS%Rlay)) CS%st%Rlay = c_loc(CS%Rlay)
+  rc = mom6hip_set_viscous_bbl(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, &
+                               MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "set_viscous_BBL")
+end subroutine set_viscous_BBL
+
+!> Same interface as the reference set_viscous_ML (:1898): returns as the reference does without DYNAMIC_VISCOUS_ML
+subroutine set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)
+  type(ocean_grid_type),   intent(inout) :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(in) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(in) :: v
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(in) :: h
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  type(mech_forcing),      intent(in)    :: forces
+  type(vertvisc_type),     intent(inout) :: visc
+  real,                    intent(in)    :: dt
+  type(set_visc_CS),       intent(inout) :: CS
+  integer :: rc
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
+  rc = mom6hip_set_viscous_ml(mom6hip_shared_context(G, GV), CS%st)
+  call mom6hip_fatal_if(rc, "set_viscous_ML")
+end subroutine set_viscous_ML
+
+!> Same interface as the reference set_visc_register_restarts (:2693): nothing of the provided branch is in the restart file
+subroutine set_visc_register_restarts(HI, G, GV, US, param_file, visc, restart_CS, use_ice_shelf)
+  type(hor_index_type),    intent(in)    :: HI
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  type(param_file_type),   intent(in)    :: param_file
+  type(vertvisc_type),     intent(inout) :: visc
+  type(MOM_restart_CS),    intent(inout) :: restart_CS
+  logical,                 intent(in)    :: use_ice_shelf
+  if (use_ice_shelf) call MOM_error(FATAL, "set_visc_register_restarts (HIP): ice shelves are not provided by the GPU path.")
+end subroutine set_visc_register_restarts
+
+!> Same interface as the reference set_visc_init (:2886), same parameters and defaults.
+subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS, OBC)
+  type(time_type), target, intent(in)    :: Time
+  type(ocean_grid_type),   intent(inout) :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  type(param_file_type),   intent(in)    :: param_file
+  type(diag_ctrl), target, intent(inout) :: diag
+  type(vertvisc_type),     intent(inout) :: visc
+  type(set_visc_CS),       intent(inout) :: CS
+  type(MOM_restart_CS),    intent(inout) :: restart_CS
+  type(ocean_OBC_type),    pointer       :: OBC
+# include "version_variable.h"
+  character(len=40)  :: mdl = "MOM_set_visc"
+  character(len=40)  :: tmpstr
+  logical :: flag, use_EOS, use_temperature, use_regridding
+  real :: Kv_background
+  integer :: isd, ied, jsd, jed
+
+  CS%initialized = .true. ; CS%diag => diag
+  isd = G%isd ; ied = G%ied ; jsd = G%jsd ; jed = G%jed
+  if (associated(OBC)) call refuse(.true., "open boundary conditions")
+  if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
+  CS%st%unsupported(:) = 0 ; CS%st%reserved0(:) = 0.0 ; CS%st%reserved1(:) = c_null_ptr ; CS%st%Rlay = c_null_ptr
+  call log_version(param_file, mdl, version, "")
+  call get_param(param_file, mdl, "BOTTOMDRAGLAW", flag, &
+                 "If true, the bottom stress is calculated with a drag law of the form c_drag*|u|*u.", default=.true.)
+  CS%st%bottomdraglaw = merge(1, 0, flag)
+  call get_param(param_file, mdl, "DRAG_AS_BODY_FORCE", flag, &
+                 "If true, the bottom stress is imposed as an explicit body force applied over a fixed distance from the bottom.", &
+                 default=.false.)
+  CS%st%body_force_drag = merge(1, 0, flag)
+  call get_param(param_file, mdl, "CHANNEL_DRAG", flag, default=.false.) ; call refuse(flag, "CHANNEL_DRAG")
+  call get_param(param_file, mdl, "LINEAR_DRAG", flag, "If LINEAR_DRAG and BOTTOMDRAGLAW are defined the drag law is cdrag*DRAG_BG_VEL*u.", &
+                 default=.false.)
+  CS%st%linear_drag = merge(1, 0, flag)
+  call get_param(param_file, mdl, "USE_JACKSON_PARAM", flag, default=.false., do_not_log=.true.)
+  CS%st%RiNo_mix = merge(1, 0, flag)
+  call get_param(param_file, mdl, "DYNAMIC_VISCOUS_ML", flag, default=.false.) ; call refuse(flag, "DYNAMIC_VISCOUS_ML")
+  call get_param(param_file, mdl, "HBBL", CS%st%dz_bbl, "The thickness of a bottom boundary layer.", units="m", &
+                 fail_if_missing=.true., scale=US%m_to_Z)
+  CS%st%Hbbl = CS%st%dz_bbl * GV%Z_to_H      ! :3127
+  call get_param(param_file, mdl, "CDRAG", CS%st%cdrag, "The drag coefficient relating the magnitude of the velocity field to the bottom stress.", &
+                 units="nondim", default=0.003)
+  call get_param(param_file, mdl, "BBL_USE_TIDAL_BG", flag, default=.false.) ; call refuse(flag, "BBL_USE_TIDAL_BG")
+  call get_param(param_file, mdl, "DRAG_BG_VEL", CS%st%drag_bg_vel, &
+                 "The assumed bottom velocity magnitude used with LINEAR_DRAG, or an unresolved velocity within the bottom boundary layer.", &
+                 units="m s-1", default=0.0, scale=US%m_s_to_L_T)
+  call get_param(param_file, "MOM", "USE_REGRIDDING", use_regridding, default=.false., do_not_log=.true.)
+  call get_param(param_file, "MOM", "ENABLE_THERMODYNAMICS", use_temperature, default=.true., do_not_log=.true.)
+  use_EOS = .false.
+  if (use_temperature) call get_param(param_file, "MOM", "USE_EOS", use_EOS, default=.true., do_not_log=.true.)
+  call get_param(param_file, mdl, "BBL_USE_EOS", flag, &
+                 "If true, use the equation of state in determining the properties of the bottom boundary layer.", &
+                 default=use_EOS, do_not_log=.not.use_temperature)
+  CS%st%BBL_use_EOS = merge(1, 0, flag)
+  call get_param(param_file, mdl, "BBL_THICK_MIN", CS%st%BBL_thick_min, "The minimum bottom boundary layer thickness.", units="m", &
+                 default=0.0, scale=US%m_to_Z)
+  call get_param(param_file, mdl, "KV", Kv_background, "The background kinematic viscosity in the interior.", units="m2 s-1", &
+                 fail_if_missing=.true., scale=US%m_to_Z**2*US%T_to_s)
+  call get_param(param_file, mdl, "KV_BBL_MIN", CS%st%Kv_BBL_min, "The minimum viscosities in the bottom boundary layer.", &
+                 units="m2 s-1", default=US%Z_to_m**2*US%s_to_T*Kv_background, scale=US%m_to_Z**2*US%T_to_s)
+  call get_param(param_file, mdl, "CORRECT_BBL_BOUNDS", flag, &
+                 "If true, uses the correct bounds on the BBL thickness and viscosity so that the bottom layer feels the intended drag.", &
+                 default=.false.)
+  CS%st%correct_BBL_bounds = merge(1, 0, flag)
+  CS%st%BBL_thick_max = 6.378e6      ! G%Rad_Earth_L * US%L_to_Z (:3128)
+  CS%st%H_to_RZ = GV%H_to_RZ
+  CS%st%initialized = 1
+  if (allocated(GV%Rlay)) then ; allocate(CS%Rlay(GV%ke)) ; CS%Rlay(:) = GV%Rlay(1:GV%ke) ; endif
+  ! the equation of state, as interpret_eos_selection reads it (MOM_EOS.F90:1474-1520)
+  CS%eos%reserved = 0 ; CS%eos%Rho_T0_S0 = 1000.0 ; CS%eos%dRho_dT = -0.2 ; CS%eos%dRho_dS = 0.8 ; CS%eos%form = MOM6HIP_EOS_WRIGHT
+  if (CS%st%BBL_use_EOS /= 0) then
+    call get_param(param_file, "MOM_EOS", "EQN_OF_STATE", tmpstr, default="WRIGHT")
+    select case (uppercase(tmpstr))
+      case ("LINEAR")
+        CS%eos%form = MOM6HIP_EOS_LINEAR
+        call get_param(param_file, "MOM_EOS", "RHO_T0_S0", CS%eos%Rho_T0_S0, units="kg m-3", default=1000.0)
+        call get_param(param_file, "MOM_EOS", "DRHO_DT", CS%eos%dRho_dT, units="kg m-3 K-1", default=-0.2)
+        call get_param(param_file, "MOM_EOS", "DRHO_DS", CS%eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
+      case ("WRIGHT")
+        CS%eos%form = MOM6HIP_EOS_WRIGHT
+      case default
+        call refuse(.true., "EQN_OF_STATE "//trim(tmpstr))
+    end select
+  endif
+  ! the arrays set_viscous_BBL fills (:3133-3140)
+  if (CS%st%bottomdraglaw /= 0) then
+    if (.not.allocated(visc%bbl_thick_u)) allocate(visc%bbl_thick_u(isd-1:ied,jsd:jed), source=0.0)
+    if (.not.allocated(visc%bbl_thick_v)) allocate(visc%bbl_thick_v(isd:ied,jsd-1:jed), source=0.0)
+    if (.not.allocated(visc%Kv_bbl_u)) allocate(visc%Kv_bbl_u(isd-1:ied,jsd:jed), source=0.0)
+    if (.not.allocated(visc%Kv_bbl_v)) allocate(visc%Kv_bbl_v(isd:ied,jsd-1:jed), source=0.0)
+  endif
+  call mom6hip_read_topology(param_file)
+contains
+  subroutine refuse(on, name)
+    logical,          intent(in) :: on
+    character(len=*), intent(in) :: name
+    if (on) call MOM_error(FATAL, "set_visc_init (HIP): "//name//" is not provided by the GPU path.")
+  end subroutine refuse
+end subroutine set_visc_init
+
+!> Same interface as the reference set_visc_end
+subroutine set_visc_end(visc, CS)
+  type(vertvisc_type), intent(inout) :: visc
+  type(set_visc_CS),   intent(inout) :: CS
+  if (allocated(visc%bbl_thick_u)) deallocate(visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v)
+  if (allocated(CS%Rlay)) deallocate(CS%Rlay)
+  CS%initialized = .false.
+end subroutine set_visc_end
+
+!> Same interface as the reference remap_vertvisc_aux_vars: the auxiliary viscosities it remaps are not provided
+subroutine remap_vertvisc_aux_vars(G, GV, visc, h_old, h_new, ALE_CSp, OBC)
+  type(ocean_grid_type),   intent(inout) :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(vertvisc_type),     intent(inout) :: visc
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in) :: h_old, h_new
+  type(ALE_CS),            pointer       :: ALE_CSp
+  type(ocean_OBC_type),    pointer       :: OBC
+  if (associated(visc%Kv_shear) .or. associated(visc%Kv_shear_Bu)) &
+    call MOM_error(FATAL, "remap_vertvisc_aux_vars (HIP): remapping of Kv_shear is not provided by the GPU path.")
+end subroutine remap_vertvisc_aux_vars
+
+!> Same interface as the reference set_u_at_v: a host helper of set_viscous_BBL, which runs on the GPU here
+function set_u_at_v(u, h, G, GV, i, j, k, mask2dCu, OBC)
+  type(ocean_grid_type),   intent(in) :: G
+  type(verticalGrid_type), intent(in) :: GV
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(in) :: u
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(in) :: h
+  integer,                 intent(in) :: i, j, k
+  real, dimension(SZIB_(G),SZJ_(G)), intent(in) :: mask2dCu
+  type(ocean_OBC_type),    pointer    :: OBC
+  real                                :: set_u_at_v
+  set_u_at_v = 0.0
+  call MOM_error(FATAL, "set_u_at_v (HIP): not provided as a host routine; set_viscous_BBL forms it on the GPU.")
+end function set_u_at_v
+
+!> Same interface as the reference set_v_at_u
+function set_v_at_u(v, h, G, GV, i, j, k, mask2dCv, OBC)
+  type(ocean_grid_type),   intent(in) :: G
+  type(verticalGrid_type), intent(in) :: GV
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(in) :: v
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(in) :: h
+  integer,                 intent(in) :: i, j, k
+  real, dimension(SZI_(G),SZJB_(G)), intent(in) :: mask2dCv
+  type(ocean_OBC_type),    pointer    :: OBC
+  real                                :: set_v_at_u
+  set_v_at_u = 0.0
+  call MOM_error(FATAL, "set_v_at_u (HIP): not provided as a host routine; set_viscous_BBL forms it on the GPU.")
+end function set_v_at_u
+
+end module MOM_set_visc

@@ -399,6 +399,33 @@ type :: tidal_forcing_CS
 end type tidal_forcing_CS
 end module MOM_tidal_forcing
 
+module MOM_io
+implicit none ; private
+public :: directories
+type :: directories
+  character(len=240) :: output_directory = "."
+end type directories
+end module MOM_io
+
+module MOM_barotropic_types_for_hor_visc
+end module MOM_barotropic_types_for_hor_visc
+
+module MOM_thickness_diffuse
+implicit none ; private
+public :: thickness_diffuse_CS
+type :: thickness_diffuse_CS
+  integer :: unused = 0
+end type thickness_diffuse_CS
+end module MOM_thickness_diffuse
+
+module MOM_stochastics
+implicit none ; private
+public :: stochastic_CS
+type :: stochastic_CS
+  integer :: unused = 0
+end type stochastic_CS
+end module MOM_stochastics
+
 module MOM_EOS
 implicit none ; private
 public :: EOS_type
@@ -491,7 +518,10 @@ type :: thermo_var_ptrs
   real, pointer, dimension(:,:) :: p_surf => NULL()
 end type thermo_var_ptrs
 type :: vertvisc_type
+  real :: Prandtl_turb = 1.0
   real, allocatable, dimension(:,:) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v
+  real, allocatable, dimension(:,:,:) :: Ray_u, Ray_v
+  real, pointer, dimension(:,:,:) :: Kv_shear => NULL(), Kv_shear_Bu => NULL()
 end type vertvisc_type
 type :: ocean_internal_state
   integer :: unused = 0

@@ -74,7 +74,8 @@ def test_fortran_driver_matches_oracle(tmp_path, oracle):
 FDIR = os.path.join(ROOT, "mom6_amd", "fortran")
 STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
 SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_barotropic_hip.F90",
-         "MOM_PressureForce_FV_hip.F90", "MOM_tracer_advect_hip.F90", "MOM_tracer_hor_diff_hip.F90"]
+         "MOM_PressureForce_FV_hip.F90", "MOM_tracer_advect_hip.F90", "MOM_tracer_hor_diff_hip.F90", "MOM_set_viscosity_hip.F90",
+         "MOM_vert_friction_hip.F90", "MOM_hor_visc_hip.F90"]
 
 
 def _build_shims(tmp, driver="shim_driver"):
@@ -278,3 +279,54 @@ def test_fortran_device_resident_rk2_steps_match_oracle(tmp_path):
     for name, a, w, pos in zip(("u", "v", "h", "eta_av", "uhtr"), np.split(raw, np.cumsum(sizes)[:-1]), want,
                                (_abi.POS_U, _abi.POS_V, _abi.POS_H, _abi.POS_H, _abi.POS_U)):
         assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), name
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_viscosity_shims_match_oracle(tmp_path):
+    """set_visc_init / set_viscous_BBL, vertvisc_init / vertvisc_coef / vertvisc / vertvisc_remnant, hor_visc_init /
+    horizontal_viscosity through the MOM_set_visc, MOM_vert_friction and MOM_hor_visc shims (parameters by name, the
+    reference's argument lists) on Fortran host arrays: bit-identical with the oracle"""
+    from mom6_amd import synth
+    from oracle import orc
+    from helpers import interior
+    exe = _build_shims(tmp_path, "visc_driver")
+    ni, nj, nk, halo = 34, 18, 5, 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=55, reentrant_x=True, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=8, umax=0.3, eta_amp=0.2).items()}
+    yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = np.ascontiguousarray(0.02 * g.mask2dCv)
+    dt = 900.0
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([ni, nj, nk, halo, 1, 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], d["T"], d["S"], taux, tauy):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+    # the oracle, with the parameters the driver sets by name
+    U, V = _abi.POS_U, _abi.POS_V
+    bb = dict(Kv_bbl_u=g.zeros2(U), Kv_bbl_v=g.zeros2(V), bbl_thick_u=g.zeros2(U), bbl_thick_v=g.zeros2(V))
+    visc = orc.vertvisc_type(**bb)
+    orc.set_viscous_BBL(g, orc.set_visc_cs(g, 10.0, 1.0e-4), d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), visc)
+    bb = visc._keep
+    vcs = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=1.0e-2)
+    u1, v1 = d["u"].copy(), d["v"].copy()
+    orc.vertvisc_coef(g, vcs, u1, v1, d["h"], visc, dt)
+    tbx, tby = g.zeros2(U), g.zeros2(V)
+    orc.vertvisc(g, vcs, u1, v1, d["h"], taux, tauy, visc, dt, taux_bot=tbx, tauy_bot=tby)
+    vru, vrv = g.zeros3(U), g.zeros3(V)
+    orc.vertvisc_remnant(g, vcs, visc, vru, vrv, dt)
+    diffu, diffv = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, dt, Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.01), d["u"], d["v"],
+                                            d["h"], dt)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "visc_driver ok ntrunc=" in r.stdout
+    want = [bb["bbl_thick_u"], bb["bbl_thick_v"], bb["Kv_bbl_u"], bb["Kv_bbl_v"], u1, v1, vru, vrv, tbx, tby, diffu, diffv]
+    names = ["bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u", "v", "visc_rem_u", "visc_rem_v", "taux_bot", "tauy_bot", "diffu", "diffv"]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        pos = V if n.endswith("_v") or n in ("v", "tauy_bot", "diffv") else U
+        assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
