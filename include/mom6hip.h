@@ -110,6 +110,26 @@ int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint6
 int mom6hip_chksum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, int32_t di, int32_t dj, int32_t symmetric,
                    double scale, int64_t *bitcount, double *amin, double *amax, int32_t memspace);
 
+/* ---- MOM_coms: the order-invariant (extended-fixed-point) sum of a field, on the device ---- */
+
+/* reproducing_sum(array(isc:iec,jsc:jec,:), sums, EFP_sum, EFP_lay_sums, err) of src/framework/MOM_coms.F90:318 (and, with
+ * nk = 1, reproducing_sum_2d :219) for a field that stays on the GPU: every value is split into the six 46-bit integer limbs
+ * of real_to_ints (:508), the limbs are added as integers -- on the device, in no particular order, which integer addition
+ * allows -- summed over PEs when a domain is attached, regularised (:643) and converted back (:545).  The result is the
+ * reference's to the bit and does not depend on the decomposition (Hallberg & Adcroft 2014).  The sum runs over the
+ * h-point computational domain in the field's own indexing for every staggering, as the means of MOM_checksums do
+ * (MOM_checksums.F90:1079), and over all nk layers.
+ *   sum       the total.  As in the reference it is the regularised EFP total converted to a real when neither lay_sums
+ *             nor efp_lay is given, and the floating-point sum of the layer values (k ascending) when either is (:421-427).
+ *   lay_sums  [nk] by-layer sums, or NULL.          efp_lay  [6*nk] their EFP integers, or NULL.
+ *   efp_sum   [6] the EFP integers of the total, or NULL.
+ *   npoints   the number of values summed, over all PEs (the divisor of subStats' means), or NULL.
+ *   err       the reference's code: 0, +1 a term too large to represent, +2 overflow of the sum, +2 a NaN in the field
+ *             (reproducing_sum_2d counts the NaN as +4 instead); when it is non-zero this PE contributes zeros.  With
+ *             err == NULL those conditions are errors (the reference's FATAL). */
+int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, double *sum, double *lay_sums,
+                            int64_t *efp_sum, int64_t *efp_lay, int64_t *npoints, int32_t *err, int32_t memspace);
+
 /* ---- MOM_domains: single-tile halo update ------------------------------------------------- */
 
 /* Staggering of a field, for halo updates (MOM_domains AGRID/CGRID_NE positions). */

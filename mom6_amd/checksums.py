@@ -29,6 +29,16 @@ def chksum(array, pos, G: DeviceGrid, di=0, dj=0, symmetric=False, scale=1.0):
     return int(bc.value), float(mn.value), float(mx.value)
 
 
+def substats(array, pos, G: DeviceGrid, symmetric=False):
+    """(aMean, aMin, aMax) of subStats (:1403 for h points, :1061 / :1247 / :1582 for the staggered ones): the extrema over the
+    computational domain (the symmetric one with sym_stats) and the mean over the h-point computational domain, from the
+    order-invariant sum of MOM_coms -- the three numbers chk_sum_msg prints beside the bit counts."""
+    from .coms import reproducing_sum
+    _, mn, mx = chksum(array, pos, G, 0, 0, symmetric)
+    rs = reproducing_sum(array, pos, G)
+    return rs.sum / float(rs.npoints), mn, mx
+
+
 def _shifted(array, pos, G, haloshift, symmetric, omit_corners, scale):
     out = {"bc0": chksum(array, pos, G, 0, 0, symmetric, scale)[0]}
     h = int(haloshift)

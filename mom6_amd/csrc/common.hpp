@@ -111,6 +111,7 @@ struct mom6hip_ctx {
   mom6hip_min_fn min_cb = nullptr;
   void *min_user = nullptr;
   void *cb_user = nullptr;
+  int num_PEs = 0;              // asked of the domain on first use (coms.hip); 0: not yet known
   // timing
   bool ktiming = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kt_events[MOM6HIP_KT_SLOTS];

@@ -336,6 +336,17 @@ interface
     integer(c_int) :: rc
   end function mom6hip_chksum
 
+  !> reproducing_sum of MOM_coms (MOM_coms.F90:318) over the h-point computational domain of a device or host field of
+  !! staggering pos; lay_sums, efp_sum(6), efp_lay(6,nk), npoints and err are c_loc of the outputs or c_null_ptr
+  function mom6hip_reproducing_sum(ctx, field, pos, nk, sum, lay_sums, efp_sum, efp_lay, npoints, err, memspace) &
+                                   bind(c, name="mom6hip_reproducing_sum") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr
+    type(c_ptr), value :: ctx, field, lay_sums, efp_sum, efp_lay, npoints, err
+    integer(c_int32_t), value :: pos, nk, memspace
+    real(c_double), intent(out) :: sum
+    integer(c_int) :: rc
+  end function mom6hip_reproducing_sum
+
   function mom6hip_coradcalc(ctx, cs, u, v, h, uh, vh, CAu, CAv, memspace) bind(c, name="mom6hip_coradcalc") result(rc)
     import :: c_int, c_int32_t, c_ptr, mom6hip_coriolisadv_cs_t
     type(c_ptr), value :: ctx, u, v, h, uh, vh, CAu, CAv

@@ -179,6 +179,14 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
                            const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
                            double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int calc_dtbt);
 
+/* ---- MOM_coms (oracle/coms.c) -------------------------------------------------------------------------------------- */
+/* reproducing_sum_3d :318 on one PE over points i0..i1, rows j0..j1 (0-based) of a (ke, ncol, nrow) array; regularize_ints
+ * :643 and ints_to_real :545 on six EFP integers */
+int orc_reproducing_sum_3d(const double *a, int nrow, int ncol, int ke, int i0, int i1, int j0, int j1, double *sum,
+                           double *lay_sums, int64_t *efp_sum, int64_t *efp_lay, int *err);
+void orc_efp_regularize(int64_t *int_sum);
+double orc_efp_to_real(const int64_t *ints);
+
 #ifdef __cplusplus
 }
 #endif

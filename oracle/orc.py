@@ -413,6 +413,34 @@ def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL
     return st
 
 
+# ---- MOM_coms ---------------------------------------------------------------------------------------------
+def reproducing_sum(grid, a, pos, by_layer=False, return_err=False):
+    """reproducing_sum_3d (MOM_coms.F90:318) over the h-point computational domain of a numpy field of staggering `pos`:
+    dict(sum, efp, [sums, efp_lay], err)."""
+    L = lib()
+    _ip = C.POINTER(C.c_int64)
+    L.orc_reproducing_sum_3d.argtypes = [_dp] + [C.c_int] * 7 + [_dp, _dp, _ip, _ip, C.POINTER(C.c_int)]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    a3 = a[None] if a.ndim == 2 else a
+    ke, ncol, nrow = a3.shape
+    xs = 1 if pos in (_abi.POS_U, _abi.POS_Q) else 0
+    ys = 1 if pos in (_abi.POS_V, _abi.POS_Q) else 0
+    i0, j0 = grid.halo + xs, grid.halo + ys
+    s, e = C.c_double(0.0), C.c_int(0)
+    tot = (C.c_int64 * 6)()
+    lay = (C.c_double * ke)() if by_layer else None
+    elay = (C.c_int64 * (6 * ke))() if by_layer else None
+    rc = L.orc_reproducing_sum_3d(_p(a3), nrow, ncol, ke, i0, i0 + grid.ni - 1, j0, j0 + grid.nj - 1, C.byref(s), lay, tot, elay,
+                                  C.byref(e) if return_err else None)
+    if rc:
+        raise RuntimeError("orc_reproducing_sum_3d: a term too large, an overflow or a NaN")
+    out = dict(sum=float(s.value), efp=[int(x) for x in tot], err=int(e.value))
+    if by_layer:
+        out["sums"] = [float(x) for x in lay]
+        out["efp_lay"] = [[int(elay[6 * k + i]) for i in range(6)] for k in range(ke)]
+    return out
+
+
 # ---- MOM_dynamics_split_RK2 -------------------------------------------------------------------------------
 class DynState:
     """Everything one oracle run of the split RK2 step owns: sub-module control structures, the control structure of

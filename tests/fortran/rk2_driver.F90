@@ -27,6 +27,9 @@ real(c_double), allocatable, target :: mT(:,:,:), mU(:,:,:), mV(:,:,:), mQ(:,:,:
 real(c_double), allocatable, target :: u(:,:,:), v(:,:,:), h(:,:,:), T(:,:,:), S(:,:,:), taux(:,:), tauy(:,:), eta_av(:,:), &
                                        uhtr(:,:,:), zeros(:)
 character(len=512) :: f_in, f_out
+integer(c_int64_t), target :: efp_h(6), efp_u(6), npts
+integer(c_int64_t) :: bc_h, bc_u
+real(c_double) :: sum_h, sum_u, amin, amax
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
@@ -111,6 +114,17 @@ do n = 1, 2
                                   d_vhtr, d_eta_av, merge(1_c_int32_t, 0_c_int32_t, n == 1))
   call check("mom6hip_step_dyn_split_rk2")
 enddo
+
+! ---- the debugging statistics of MOM_checksums / MOM_coms, formed where the fields live (no copy to the host)
+rc = mom6hip_chksum(ctx, d_h, MOM6HIP_POS_H, int(nk, c_int32_t), 0_c_int32_t, 0_c_int32_t, 0_c_int32_t, 1.0_c_double, bc_h, amin, amax, &
+                    MOM6HIP_MEM_DEVICE) ; call check("mom6hip_chksum h")
+rc = mom6hip_chksum(ctx, d_u, MOM6HIP_POS_U, int(nk, c_int32_t), 0_c_int32_t, 0_c_int32_t, 1_c_int32_t, 1.0_c_double, bc_u, amin, amax, &
+                    MOM6HIP_MEM_DEVICE) ; call check("mom6hip_chksum u")
+rc = mom6hip_reproducing_sum(ctx, d_h, MOM6HIP_POS_H, int(nk, c_int32_t), sum_h, c_null_ptr, c_loc(efp_h), c_null_ptr, c_loc(npts), &
+                             c_null_ptr, MOM6HIP_MEM_DEVICE) ; call check("mom6hip_reproducing_sum h")
+rc = mom6hip_reproducing_sum(ctx, d_u, MOM6HIP_POS_U, int(nk, c_int32_t), sum_u, c_null_ptr, c_loc(efp_u), c_null_ptr, c_null_ptr, &
+                             c_null_ptr, MOM6HIP_MEM_DEVICE) ; call check("mom6hip_reproducing_sum u")
+write(*,'(a,2(1x,i0),1x,i0,12(1x,i0))') "rk2_driver stats", bc_h, bc_u, npts, efp_h, efp_u
 
 rc = mom6hip_sync_to_host(ctx, c_loc(u), d_u, 8_c_int64_t*nu3) ; call check("sync u")
 rc = mom6hip_sync_to_host(ctx, c_loc(v), d_v, 8_c_int64_t*nv3) ; call check("sync v")

@@ -294,3 +294,45 @@ def phillips_layout_worker(rank, world, port, layout, out_dir, nsteps=2):
                      nstep=ref.bcs.nstep_last)
     finally:
         dist.destroy_process_group()
+
+
+def reproducing_sum_layout_worker(rank, world, port, layout, out_dir):
+    """reproducing_sum / the chksum statistics of fields cut into tiles against the one-tile numbers"""
+    import numpy as np
+    import torch
+    from mom6_amd import _abi, synth
+    from mom6_amd.checksums import chksum, substats
+    from mom6_amd.coms import reproducing_sum
+    from mom6_amd.domains import Domain
+    from mom6_amd.tracer_advect import DeviceGrid
+    dist = _init(rank, world, port)
+    try:
+        NI, NJ, NK, halo = 70, 40, 3, 4
+        gg = synth.make_grid(NI, NJ, NK, halo=halo, reentrant_x=True, reentrant_y=False, seed=78)
+        d = synth.make_dynamics_state(gg, seed=3, umax=0.1, eta_amp=0.2)
+        rng = np.random.default_rng(1)
+        big = torch.from_numpy(rng.standard_normal(gg.shape3(_abi.POS_H)) * 10.0 ** rng.integers(-20, 20, gg.shape3(_abi.POS_H)))
+
+        def numbers(dg, cut):
+            out = {}
+            for name, a, pos in (("h", d["h"], _abi.POS_H), ("u", d["u"], _abi.POS_U), ("v", d["v"], _abi.POS_V), ("big", big, _abi.POS_H)):
+                da = cut(a, pos)
+                r = reproducing_sum(da, pos, dg, by_layer=True)
+                t = reproducing_sum(da, pos, dg)
+                out[name + "_efp"] = np.array([e.v for e in r.EFP_lay_sums] + [r.EFP_sum.v, t.EFP_sum.v], dtype=np.int64)
+                out[name + "_sums"] = np.array(r.sums + [r.sum, t.sum, float(t.npoints)])
+                out[name + "_stats"] = np.array(substats(da, pos, dg) + (float(chksum(da, pos, dg)[0]),))
+            return out
+
+        dom = Domain(NI, NJ, layout, rank, halo, True, False)
+        dg = DeviceGrid(dom.tile_grid(gg))
+        dg.set_domain(dom)
+        res = numbers(dg, lambda a, pos: dom.cut(a, pos).cuda())
+        np.savez(os.path.join(out_dir, f"tile{rank}.npz"), **res)
+        dg.close()
+        if rank == 0:
+            dg1 = DeviceGrid(gg)
+            np.savez(os.path.join(out_dir, "global.npz"), **numbers(dg1, lambda a, pos: a.cuda()))
+            dg1.close()
+    finally:
+        dist.destroy_process_group()

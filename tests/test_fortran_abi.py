@@ -272,6 +272,12 @@ def test_fortran_device_resident_rk2_steps_match_oracle(tmp_path):
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert f"rk2_driver ok nstep={int(ref.bcs.nstep_last)} " in r.stdout
+    # the debugging statistics the driver formed on the device: MOM_checksums' bit counts, MOM_coms' order-invariant sums
+    from test_checksums import ref_chksum
+    stats = [int(x) for x in next(l for l in r.stdout.splitlines() if l.startswith("rk2_driver stats")).split()[2:]]
+    assert stats[0] == ref_chksum(g, ref.h, _abi.POS_H)[0] and stats[1] == ref_chksum(g, ref.u, _abi.POS_U, symmetric=True)[0]
+    assert stats[2] == ni * nj * nk
+    assert stats[3:9] == orc.reproducing_sum(g, ref.h, _abi.POS_H)["efp"] and stats[9:15] == orc.reproducing_sum(g, ref.u, _abi.POS_U)["efp"]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     want = [ref.u, ref.v, ref.h, ref.eta_av, ref.uhtr]
     sizes = [w.size for w in want]
