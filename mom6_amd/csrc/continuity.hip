@@ -519,8 +519,21 @@ __device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int fl, 
   r2 = (nsum > 2) ? fsm[roff + 2 * FC_FL + fl] : 0.;
 }
 
+#ifdef FC_TRACE
+// phase clock of the cooperative kernel (experiments only: tools/build_variant.sh ... -DFC_TRACE): thread 0 of every block adds
+// the s_memtime ticks between marks; slot 15 counts blocks, slot 14 counts Newton passes
+__device__ unsigned long long fc_trace[16];
+#define FC_MARK(n) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&fc_trace[n], t_ - fc_t0); fc_t0 = t_; } } while (0)
+#else
+#define FC_MARK(n) do { } while (0)
+#endif
+
 template <int DIR, int KS>
 __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs p) {
+#ifdef FC_TRACE
+  unsigned long long fc_t0 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) atomicAdd(&fc_trace[15], 1ull);
+#endif
   extern __shared__ double fsm[];      // three [KS*FC_NS][FC_FL] planes of layer values, then results [8][FC_FL], visc_rem max [FC_NS][FC_FL]
   const m6::GridDev &g = p.g;
   const Dir<DIR> D(g);
@@ -542,43 +555,105 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   constexpr int PL = KS * FC_NS * FC_FL;          // one plane
   constexpr int RO = 3 * PL, VO = RO + 8 * FC_FL; // results, visc_rem max
   constexpr int CO = VO + FC_NS * FC_FL;          // per-face values parked between the phases (instead of held in registers)
+  constexpr int PK_DXW = CO + 6 * FC_FL, PK_DXE = CO + 7 * FC_FL, PK_MF = CO + 8 * FC_FL, PK_IAT = CO + 9 * FC_FL,
+                PK_UHBT = CO + 10 * FC_FL, PK_DLC = CO + 11 * FC_FL;
   const int k0 = sb * KS;
   const int sl = k0 * FC_FL + fl;                 // this thread's slot of layer k0 in a plane
 
-  FaceConst F;
-  F.dLf = D.dL_face()[f2]; F.dt = p.dt;
-  F.cm = p.o.vol_CFL ? (F.dLf * g.IareaT[o2]) : D.IdL_T()[o2];
-  F.cp = p.o.vol_CFL ? (F.dLf * g.IareaT[o2 + s]) : D.IdL_T()[o2 + s];
-
   // ---- the wave's layers into registers
+  // The per-face metrics and masks are loaded without conditions (an address select instead of a branch where an option
+  // decides whether a value is read at all) and used only after the layer loads below have been issued: a branch on an
+  // option around a load is a memory round trip of its own in front of everything that follows.
   const bool wide = !(p.o.upwind_1st || p.o.simple_2nd);      // the 5-point stencil is only read by the PPM branch
+  const long s2w = wide ? 2 * s : 0, s3w = (wide && DIR == 1) ? 3 * s : 0;
+  double dLf_r = D.dL_face()[f2];
+  double cm_r = (p.o.vol_CFL ? g.IareaT : D.IdL_T())[o2], cp_r = (p.o.vol_CFL ? g.IareaT : D.IdL_T())[o2 + s];
   double mk[6];                                               // mask2dT of cells -2 .. +3 along the direction
   {
     const double *mm = g.mask2dT + o2;
-    mk[0] = wide ? mm[-2 * s] : 0.0; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s];
-    mk[5] = (wide && DIR == 1) ? mm[3 * s] : 0.0;      // (only the meridional pair of reconstructions reads cell +3)
+    mk[0] = mm[-s2w]; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s];
+    mk[5] = mm[s3w];      // (only the meridional pair of reconstructions reads cell +3)
   }
+  // what the later phases read of the 2-D arrays, fetched with everything else and parked in LDS (slots PK_*): a load where
+  // it is used is a memory round trip on the critical path of the block, with nothing to overlap it
+  double pk_aW = g.areaT[o2], pk_aE = g.areaT[o2 + s], pk_dW = D.dL_T()[o2], pk_dE = D.dL_T()[o2 + s], pk_mf = D.mask_face()[f2];
+  double pk_iW = g.IareaT[o2], pk_iE = g.IareaT[o2 + s], pk_ub = p.uhbt ? p.uhbt[f2] : 0.0, pk_lc = D.dLC_face()[f2];
   double ru[KS], rvr[KS], mE[KS], mD[KS], mC[KS], pW[KS], pD[KS], pC[KS];
+  // Every global load of the block is issued before anything is computed from one of them: the reconstruction below is
+  // branchy code the compiler cannot move loads across, and a load -- wait -- compute sequence per layer is KS memory round
+  // trips in a row with two waves a SIMD to hide them.  (Layers past nz read layer nz-1 and are zeroed afterwards, so the
+  // load block has no branches.)
+  constexpr int NH = (DIR == 0) ? 5 : 6;      // cells -2 .. +2 along the direction (+3 for the meridional pair)
+  double hr[KS][NH];
+  {
+    // addresses as a uniform base (the array, displaced along the direction: scalar registers) plus one 32-bit byte offset
+    // per layer: the `global_load v, v_offset, s[base]` form, one VGPR per layer instead of a 64-bit address per load
+    // (launch_flux only takes this kernel when a 3-D array is below 4 GB)
+    const char *ub = (const char *)p.u, *vb = p.visc_rem ? (const char *)p.visc_rem : ub;      // (no branch around a load)
+    const char *hb[NH];
+#pragma unroll
+    for (int q = 0; q < NH; q++) {
+      const long disp = (q == 0) ? -s2w : ((q == 5) ? s3w : (q - 2) * s);
+      hb[q] = (const char *)(p.h_in + disp);
+    }
+    const unsigned o2b = (unsigned)(o2 * 8), f2b = (unsigned)(f2 * 8), hstep = (unsigned)(hpl * 8), fstep = (unsigned)(fpl * 8);
+#pragma unroll
+    for (int m = 0; m < KS; m++) {
+      const unsigned k = (unsigned)((k0 + m < nz) ? k0 + m : nz - 1);
+      const unsigned vh = o2b + k * hstep, vf = f2b + k * fstep;
+      ru[m] = *(const double *)(ub + vf);
+      rvr[m] = *(const double *)(vb + vf);
+#pragma unroll
+      for (int q = 0; q < NH; q++) hr[m][q] = *(const double *)(hb[q] + vh);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < KS; m++) {      // (a use of every loaded value here: none of the loads can sink into the code below)
+    pin(ru[m]); pin(rvr[m]);
+#pragma unroll
+    for (int q = 0; q < NH; q++) pin(hr[m][q]);
+  }
+  pin(dLf_r); pin(cm_r); pin(cp_r);
+  FC_MARK(0);
+  if (!p.visc_rem) {
+#pragma unroll
+    for (int m = 0; m < KS; m++) rvr[m] = 1.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) pin(mk[q]);
+  if (!wide) { mk[0] = 0.0; mk[5] = 0.0; }
+  if (DIR == 0) mk[5] = 0.0;
+  FaceConst F;
+  F.dLf = dLf_r; F.dt = p.dt;
+  F.cm = p.o.vol_CFL ? (F.dLf * cm_r) : cm_r;      // the CFL factor of the minus / plus side cell
+  F.cp = p.o.vol_CFL ? (F.dLf * cp_r) : cp_r;
+  pin(pk_aW); pin(pk_aE); pin(pk_dW); pin(pk_dE); pin(pk_mf); pin(pk_iW); pin(pk_iE); pin(pk_ub); pin(pk_lc);
+  if (sb == 0) {      // (read after the barriers of the first k-ordered sums)
+    double dxw, dxe;
+    if (p.o.vol_CFL) {
+      dxw = ratio_max(pk_aW, F.dLf, 1000.0 * pk_dW);
+      dxe = ratio_max(pk_aE, F.dLf, 1000.0 * pk_dE);
+    } else { dxw = pk_dW; dxe = pk_dE; }
+    fsm[PK_DXW + fl] = dxw; fsm[PK_DXE + fl] = dxe; fsm[PK_MF + fl] = pk_mf; fsm[PK_IAT + fl] = min2(pk_iW, pk_iE);
+    fsm[PK_UHBT + fl] = pk_ub; fsm[PK_DLC + fl] = pk_lc;
+  }
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     const int k = k0 + m;
     if (k < nz) {
-      const long f3 = f2 + k * fpl, o3 = o2 + k * hpl;
-      ru[m] = p.u[f3]; rvr[m] = p.visc_rem ? p.visc_rem[f3] : 1.0;
       // the edge values of the two cells (cont_edge_kernel's arithmetic, PPM_reconstruction_x/y :2310-2662) from the
       // thicknesses along the direction: h_L / h_R never go through memory.  Zonal: the plus-side cell of a face is the
       // minus-side cell of the next lane's face, so each lane reconstructs one cell and hands it down one lane (the
       // last lane of a half-wave only serves its neighbour; blocks advance by FPB = 31 faces).  Meridional: both cells.
-      const double *hh = p.h_in + o3;
-      const double hm1 = hh[-s], hc0 = hh[0], hp1 = hh[s], hp2 = hh[2 * s];
+      const double hm1 = hr[m][1], hc0 = hr[m][2], hp1 = hr[m][3], hp2 = hr[m][4];
       double Lm, Rm, Lp, Rp;
       if (DIR == 0) {
         if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; }
-        else edge_values(p.o, g.Angstrom_H, wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
+        else edge_values(p.o, g.Angstrom_H, hr[m][0], hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
                          wide ? mk[4] : 0.0, Lm, Rm);
         Lp = __shfl_down(Lm, 1); Rp = __shfl_down(Rm, 1);
       } else {      // both cells at once: the slopes of the two cells serve both reconstructions
-        const double h6[6] = {wide ? hh[-2 * s] : 0.0, hm1, hc0, hp1, hp2, wide ? hh[3 * s] : 0.0};
+        const double h6[6] = {hr[m][0], hm1, hc0, hp1, hp2, hr[m][NH - 1]};
         edge_values2(p.o, g.Angstrom_H, h6, mk, Lm, Rm, Lp, Rp);
       }
       mE[m] = Rm; mD[m] = Lm - Rm; mC[m] = Lm + Rm - 2.0 * hc0;
@@ -588,6 +663,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     }
   }
 
+  FC_MARK(1);
   // ---- layer transports and marginal areas, :622-635
   double vmax_w = 0.0;
 #pragma unroll
@@ -607,18 +683,14 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   for (int q = 0; q < FC_NS; q++) visc_rem_max = max2(visc_rem_max, fsm[VO + q * FC_FL + fl]);      // (max is order-free)
   if (!(p.visc_rem && p.o.use_visc_rem_max)) visc_rem_max = 1.0;
 
+  FC_MARK(2);
   // ---- the CFL brackets of the velocity correction, :637-716: two chains through k over u and visc_rem staged in LDS
   double CFL_dt = p.o.CFL_limit_adjust / p.dt;
   const double I_dt = 1.0 / p.dt;
   if (p.o.aggress_adjust) CFL_dt = I_dt;
   double I_vrm = 0.0;
   if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
-  double dx_W, dx_E;
-  if (p.o.vol_CFL) {
-    dx_W = ratio_max(g.areaT[o2], D.dL_face()[f2], 1000.0 * D.dL_T()[o2]);
-    dx_E = ratio_max(g.areaT[o2 + s], D.dL_face()[f2], 1000.0 * D.dL_T()[o2 + s]);
-  } else { dx_W = D.dL_T()[o2]; dx_E = D.dL_T()[o2 + s]; }
-  const double mface = D.mask_face()[f2];
+  const double dx_W = fsm[PK_DXW + fl], dx_E = fsm[PK_DXE + fl], mface = fsm[PK_MF + fl];
   // The state of these loops runs through k, so one wave walks them; what it needs per layer -- the bound the bracket
   // is tested against and the value it takes when the test fails (a division) -- does not depend on that state and is
   // formed by all waves for their own layers first: planes 0 / 1 / 2 = visc_rem, bound, new bracket.
@@ -689,7 +761,8 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     fsm[CO + FC_FL + fl] = min2(du_min_CFL, 0.0);
   }
   __syncthreads();
-  const double IaT = min2(g.IareaT[o2], g.IareaT[o2 + s]);
+  FC_MARK(3);
+  const double IaT = fsm[PK_IAT + fl];
 
   // ---- flux_adjust :1094-1243 for the faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
   // phase 1 finds the correction that gives no net transport for set_*_BT_cont (:1290-1292)
@@ -698,7 +771,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   for (int phase = 0; phase < 2; phase++) {
     if (phase == 0 ? (p.uhbt == nullptr) : !p.set_BT_cont) continue;
     const bool write_uh = (phase == 0);
-    const double uhbt = (phase == 0) ? p.uhbt[f2] : 0.0;
+    const double uhbt = (phase == 0) ? fsm[PK_UHBT + fl] : 0.0;
     const int max_itts = 20;
     double du = 0.0, du_max = fsm[CO + fl], du_min = fsm[CO + FC_FL + fl];
     double uh_err = fsm[CO + 2 * FC_FL + fl] - uhbt, duhdu_tot = fsm[CO + 3 * FC_FL + fl], uh_err_best = fabs(uh_err);
@@ -745,6 +818,9 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
       }
       if (!__any(alive)) break;      // the same in every wave of the block: they hold the same values
       if ((itt < max_itts) || write_uh) {
+#ifdef FC_TRACE
+        if (threadIdx.x == 0) atomicAdd(&fc_trace[14], 1ull);
+#endif
         if (alive) du_eval = du;
 #pragma unroll
         for (int m = 0; m < KS; m++) {
@@ -764,6 +840,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
       }
     }
     du_ph[phase] = du;
+    FC_MARK(4 + phase);
     if (write_uh && valid) {
       // The reference stores the layer transports on every re-evaluation (uh_3d); what remains is the last one of each
       // face, or the first evaluation for a face that never iterated (du_eval = 0: u + 0*visc_rem is u).  Stored once here.
@@ -787,32 +864,50 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     }
     if (sb == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
   }
+  FC_MARK(6);
   if (!p.set_BT_cont) return;
 
   // ---- set_zonal_BT_cont :1247-1410
   const double min_visc_rem = 0.1, CFL_min = 1e-6;
-  const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
-  // the duR / duL limits (:1321-1330) are chains through k as well: the two half-waves of wave 0 walk one each over u and
-  // visc_rem in LDS, in one loop (the chains differ in a sign and in the sense of the test: c = +-du_CFL)
+  const double du_CFL = (CFL_min * I_dt) * fsm[PK_DLC + fl];
+  // The duR / duL limits (:1321-1330) are chains through k as well.  The quotient a layer hands to the chain when its test
+  // fires does not depend on the running limit, and some lane of the walking wave fires at nearly every layer, so a
+  // division inside the chain is nk of them in a row on one wave while three wait: the quotients are formed by all
+  // threads for their own layers first (planes 0 / 1 / 2 = u, visc_rem, quotient; one chain at a time, the planes
+  // hold one quotient), and the chain is left with a multiply, an add, a compare and a select per layer.
+  const double lim0 = min_visc_rem * fsm[CO + 4 * FC_FL + fl];
+#pragma unroll 1
+  for (int side = 0; side < 2; side++) {      // 0: duR (c = du_CFL, test ">"), 1: duL (c = -du_CFL, test "<")
+    const double c = side ? -du_CFL : du_CFL;
 #pragma unroll
-  for (int m = 0; m < KS; m++)
-    if (k0 + m < nz) { fsm[sl + m * FC_FL] = ru[m]; fsm[PL + sl + m * FC_FL] = rvr[m]; }
-  __syncthreads();
-  if (w == 0) {
-    const bool isL = (sb == 1);
-    const double vrm_bt = fsm[CO + 4 * FC_FL + fl];
-    const double c = isL ? -du_CFL : du_CFL;      // duR: du0 - du_CFL, test "> -du_CFL*vr";  duL: du0 + du_CFL, test "< du_CFL*vr"
-    double dlim = isL ? max2(0.0, du0 - c) : min2(0.0, du0 - c);
-    for (int k = 0; k < nz; k++) {
-      const double vr = fsm[PL + k * FC_FL + fl], uk = fsm[k * FC_FL + fl];
-      const double visc_rem_lim = max2(vr, min_visc_rem * vrm_bt);
-      const double t = uk + dlim * visc_rem_lim, r = -c * vr;
-      if ((visc_rem_lim > 0.0) && (isL ? (t < r) : (t > r))) dlim = -(uk + c * vr) / visc_rem_lim;
+    for (int m = 0; m < KS; m++) {
+      if (k0 + m < nz) {
+        const double vr = rvr[m], uk = ru[m];
+        const double visc_rem_lim = max2(vr, lim0);
+        if (side == 0) { fsm[sl + m * FC_FL] = uk; fsm[PL + sl + m * FC_FL] = vr; }
+        fsm[2 * PL + sl + m * FC_FL] = (visc_rem_lim > 0.0) ? -(uk + c * vr) / visc_rem_lim : 0.0;
+      }
     }
-    fsm[RO + sb * FC_FL + fl] = dlim;
+    __syncthreads();
+    if (sb == 0) {
+      double dlim = side ? max2(0.0, du0 - c) : min2(0.0, du0 - c);
+      // branch-free steps (the tests combined with &, the sense of the comparison carried by a sign: x < y is -x > -y to the
+      // bit), so that the LDS reads of eight layers are issued ahead of the dependent arithmetic
+      const double mc = -c, sg = side ? -1.0 : 1.0;
+#pragma unroll 8
+      for (int k = 0; k < nz; k++) {
+        const double uk = fsm[k * FC_FL + fl], vr = fsm[PL + k * FC_FL + fl], q = fsm[2 * PL + k * FC_FL + fl];
+        const double visc_rem_lim = max2(vr, lim0);
+        const double t = uk + dlim * visc_rem_lim, r = mc * vr;
+        const bool fire = (visc_rem_lim > 0.0) & (sg * t > sg * r);
+        dlim = fire ? q : dlim;
+      }
+      fsm[RO + side * FC_FL + fl] = dlim;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const double duR = fsm[RO + fl], duL = fsm[RO + FC_FL + fl];
+  FC_MARK(7);
   const bool cor = p.uhbt && p.u_cor;
   // the three evaluations of every layer, each done once: the first round sums FAmt_0, FAmt_L and uhtot_L, the second
   // FAmt_R and uhtot_R (three planes)
@@ -854,6 +949,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     }
   }
   ksums(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, FAmt_R, uhtot_R, d2);
+  FC_MARK(8);
   if (sb == 0 && valid) {
     double FA_0 = FAmt_0, FA_avg = FAmt_0;
     if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
@@ -882,7 +978,9 @@ bool flux_lane_only() {
 // Whether a flux launch takes the block-cooperative kernel (which forms the edge values itself): when there is a velocity
 // correction or BT_cont to compute and the layers fit its registers; the single-pass lane-per-column kernel otherwise.
 bool flux_is_coop(const FluxArgs &f) {
-  return (f.uhbt || f.set_BT_cont) && f.g.nk <= 10 * FC_NS && !flux_lane_only();
+  // (and a 3-D array stays below 4 GB: the kernel addresses its layers with 32-bit byte offsets)
+  const bool small = (size_t)(f.g.nih + 1) * (f.g.njh + 1) * f.g.nk * sizeof(double) < ((size_t)1 << 32);
+  return (f.uhbt || f.set_BT_cont) && f.g.nk <= 10 * FC_NS && small && !flux_lane_only();
 }
 
 template <int DIR>
@@ -892,7 +990,7 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
   if (flux_is_coop(f)) {
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {
-      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 6 * FC_FL) * sizeof(double);
+      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 12 * FC_FL) * sizeof(double);
       std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context
       if (std::find(configured.begin(), configured.end(), (const void *)kern) == configured.end()) {
         M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -938,6 +1036,15 @@ __global__ __launch_bounds__(256) void cont_conv_kernel(ConvArgs p) {
 }
 
 }  // namespace
+
+#ifdef FC_TRACE
+extern "C" int mom6hip_fc_trace(unsigned long long *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_trace), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fc_trace), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 
 extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, const double *u,
                                   const double *v, const double *hin, double *h, double *uh, double *vh, double dt,
