@@ -556,7 +556,13 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   constexpr int RO = 3 * PL, VO = RO + 8 * FC_FL; // results, visc_rem max
   constexpr int CO = VO + FC_NS * FC_FL;          // per-face values parked between the phases (instead of held in registers)
   constexpr int PK_DXW = CO + 6 * FC_FL, PK_DXE = CO + 7 * FC_FL, PK_MF = CO + 8 * FC_FL, PK_IAT = CO + 9 * FC_FL,
-                PK_UHBT = CO + 10 * FC_FL, PK_DLC = CO + 11 * FC_FL;
+                PK_UHBT = CO + 10 * FC_FL, PK_DLC = CO + 11 * FC_FL, PK_DLF = CO + 12 * FC_FL, PK_CM = CO + 13 * FC_FL,
+                PK_CP = CO + 14 * FC_FL;
+  // the bracket and best-error of the Newton iteration, one private copy per half-wave (every half-wave runs the scalar
+  // logic of its faces with the same values): in LDS instead of registers that would be spilled to scratch memory
+  constexpr int PV = CO + 15 * FC_FL;
+  const int pv = PV + sb * FC_FL + fl;
+  constexpr int PVS = FC_NS * FC_FL;      // stride between the private variables
   const int k0 = sb * KS;
   const int sl = k0 * FC_FL + fl;                 // this thread's slot of layer k0 in a plane
 
@@ -623,19 +629,20 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   for (int q = 0; q < 6; q++) pin(mk[q]);
   if (!wide) { mk[0] = 0.0; mk[5] = 0.0; }
   if (DIR == 0) mk[5] = 0.0;
-  FaceConst F;
-  F.dLf = dLf_r; F.dt = p.dt;
-  F.cm = p.o.vol_CFL ? (F.dLf * cm_r) : cm_r;      // the CFL factor of the minus / plus side cell
-  F.cp = p.o.vol_CFL ? (F.dLf * cp_r) : cp_r;
+  FaceConst F0;
+  F0.dLf = dLf_r; F0.dt = p.dt;
+  F0.cm = p.o.vol_CFL ? (F0.dLf * cm_r) : cm_r;      // the CFL factor of the minus / plus side cell
+  F0.cp = p.o.vol_CFL ? (F0.dLf * cp_r) : cp_r;
   pin(pk_aW); pin(pk_aE); pin(pk_dW); pin(pk_dE); pin(pk_mf); pin(pk_iW); pin(pk_iE); pin(pk_ub); pin(pk_lc);
   if (sb == 0) {      // (read after the barriers of the first k-ordered sums)
     double dxw, dxe;
     if (p.o.vol_CFL) {
-      dxw = ratio_max(pk_aW, F.dLf, 1000.0 * pk_dW);
-      dxe = ratio_max(pk_aE, F.dLf, 1000.0 * pk_dE);
+      dxw = ratio_max(pk_aW, F0.dLf, 1000.0 * pk_dW);
+      dxe = ratio_max(pk_aE, F0.dLf, 1000.0 * pk_dE);
     } else { dxw = pk_dW; dxe = pk_dE; }
     fsm[PK_DXW + fl] = dxw; fsm[PK_DXE + fl] = dxe; fsm[PK_MF + fl] = pk_mf; fsm[PK_IAT + fl] = min2(pk_iW, pk_iE);
     fsm[PK_UHBT + fl] = pk_ub; fsm[PK_DLC + fl] = pk_lc;
+    fsm[PK_DLF + fl] = F0.dLf; fsm[PK_CM + fl] = F0.cm; fsm[PK_CP + fl] = F0.cp;
   }
 #pragma unroll
   for (int m = 0; m < KS; m++) {
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   for (int m = 0; m < KS; m++) {
     if (k0 + m < nz) {
       double dd;
-      const double uhk = flux_reg(F, ru[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
+      const double uhk = flux_reg(F0, ru[m], rvr[m], mE[m], mD[m], mC[m], pW[m], pD[m], pC[m], dd);
       if (valid && !p.uhbt) p.uh[f2 + (k0 + m) * fpl] = uhk;      // (with uhbt, uh is stored once, after the solve)
       fsm[sl + m * FC_FL] = uhk; fsm[PL + sl + m * FC_FL] = dd;
       vmax_w = max2(vmax_w, rvr[m]);
@@ -762,7 +769,6 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   }
   __syncthreads();
   FC_MARK(3);
-  const double IaT = fsm[PK_IAT + fl];
 
   // ---- flux_adjust :1094-1243 for the faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
   // phase 1 finds the correction that gives no net transport for set_*_BT_cont (:1290-1292)
@@ -773,10 +779,11 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     const bool write_uh = (phase == 0);
     const double uhbt = (phase == 0) ? fsm[PK_UHBT + fl] : 0.0;
     const int max_itts = 20;
-    double du = 0.0, du_max = fsm[CO + fl], du_min = fsm[CO + FC_FL + fl];
-    double uh_err = fsm[CO + 2 * FC_FL + fl] - uhbt, duhdu_tot = fsm[CO + 3 * FC_FL + fl], uh_err_best = fabs(uh_err);
+    double du = 0.0;
+    double uh_err = fsm[CO + 2 * FC_FL + fl] - uhbt, duhdu_tot = fsm[CO + 3 * FC_FL + fl];
+    fsm[pv] = fsm[CO + fl]; fsm[pv + PVS] = fsm[CO + FC_FL + fl]; fsm[pv + 2 * PVS] = fabs(uh_err);      // du_max, du_min, uh_err_best
+    fsm[pv + 3 * PVS] = 0.0;      // du_eval: du of this face's last re-evaluation of the transports (what uh_3d holds in the reference)
     bool do_I = true, alive = valid;
-    double du_eval = 0.0;      // du of this face's last re-evaluation of the transports (what uh_3d holds in the reference)
 #pragma unroll 1
     for (int itt = 1; itt <= max_itts; itt++) {
       bool domore = false;
@@ -787,8 +794,10 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
         else if (itt == 3) tol_eta = 1e-2 * p.o.tol_eta;
         else tol_eta = p.o.tol_eta;
         const double tol_vel = p.o.tol_vel;
-        if (uh_err > 0.0) du_max = du;
-        else if (uh_err < 0.0) du_min = du;
+        double du_max = fsm[pv], du_min = fsm[pv + PVS];
+        const double uh_err_best = fsm[pv + 2 * PVS], IaT = fsm[PK_IAT + fl];
+        if (uh_err > 0.0) { du_max = du; fsm[pv] = du; }
+        else if (uh_err < 0.0) { du_min = du; fsm[pv + PVS] = du; }
         else do_I = false;
         if (do_I) {
           if ((p.dt * IaT * fabs(uh_err) > tol_eta) ||
@@ -821,7 +830,8 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
 #ifdef FC_TRACE
         if (threadIdx.x == 0) atomicAdd(&fc_trace[14], 1ull);
 #endif
-        if (alive) du_eval = du;
+        if (alive) fsm[pv + 3 * PVS] = du;
+        FaceConst F; F.dLf = fsm[PK_DLF + fl]; F.cm = fsm[PK_CM + fl]; F.cp = fsm[PK_CP + fl]; F.dt = p.dt;
 #pragma unroll
         for (int m = 0; m < KS; m++) {
           if (k0 + m < nz) {
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
         ksums(fsm, PL, RO, fl, sb, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2);
         if (alive && itt < max_itts) {
           uh_err = usum; duhdu_tot = dsum;
-          uh_err_best = min2(uh_err_best, fabs(uh_err));
+          fsm[pv + 2 * PVS] = min2(fsm[pv + 2 * PVS], fabs(uh_err));
         }
       }
     }
@@ -844,6 +854,8 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     if (write_uh && valid) {
       // The reference stores the layer transports on every re-evaluation (uh_3d); what remains is the last one of each
       // face, or the first evaluation for a face that never iterated (du_eval = 0: u + 0*visc_rem is u).  Stored once here.
+      const double du_eval = fsm[pv + 3 * PVS];
+      FaceConst F; F.dLf = fsm[PK_DLF + fl]; F.cm = fsm[PK_CM + fl]; F.cp = fsm[PK_CP + fl]; F.dt = p.dt;
 #pragma unroll
       for (int m = 0; m < KS; m++) {
         if (k0 + m < nz) {
@@ -866,6 +878,7 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
   }
   FC_MARK(6);
   if (!p.set_BT_cont) return;
+  FaceConst F; F.dLf = fsm[PK_DLF + fl]; F.cm = fsm[PK_CM + fl]; F.cp = fsm[PK_CP + fl]; F.dt = p.dt;
 
   // ---- set_zonal_BT_cont :1247-1410
   const double min_visc_rem = 0.1, CFL_min = 1e-6;
@@ -990,7 +1003,7 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
   if (flux_is_coop(f)) {
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
     auto go = [&](auto kern, int KS) -> int {
-      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 12 * FC_FL) * sizeof(double);
+      const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 15 * FC_FL + 4 * FC_NS * FC_FL) * sizeof(double);
       std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context
       if (std::find(configured.begin(), configured.end(), (const void *)kern) == configured.end()) {
         M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

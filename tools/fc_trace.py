@@ -22,7 +22,7 @@ uhbt = (uh.sum(0) * 1.02).contiguous(); vhbt = (vh.sum(0) * 0.98).contiguous()
 ucor = torch.zeros_like(st["u"]); vcor = torch.zeros_like(st["v"])
 L = lib()
 L.mom6hip_fc_trace.argtypes = [C.POINTER(C.c_uint64), C.c_int]
-names = ["loads", "reconstruct", "first eval + sums", "brackets", "newton uhbt", "newton du0", "u_cor", "duR/duL chain", "three fits", "  quotients", "  barrier", "  chain", "  barrier", "", "passes", "blocks"]
+names = ["loads", "reconstruct", "first eval + sums", "brackets", "newton uhbt", "newton du0", "u_cor", "duR/duL chain", "three fits", "  newton: scalar logic", "  newton: evaluation", "  newton: sums", "", "", "passes", "blocks"]
 kw = dict(uhbt=uhbt, vhbt=vhbt, visc_rem_u=vru, visc_rem_v=vrv, u_cor=ucor, v_cor=vcor, BT_cont=bt)
 f = lambda: continuity(st["u"], st["v"], st["h"], hp, uh, vh, 900.0, dg, cs, **kw)
 f(); torch.cuda.synchronize()
