@@ -97,6 +97,25 @@ int mom6hip_free(void *dptr);
 int mom6hip_sync_to_device(mom6hip_ctx_t *ctx, void *dptr, const void *hptr, uint64_t bytes);
 int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint64_t bytes);
 
+/* ---- restart / diagnostic staging: fields to the host while the model keeps stepping ------ */
+
+/* The host arrays MOM6 registers for restarts and diagnostics (register_restart_field, src/framework/MOM_restart.F90:
+ * the u, v, h, T, S ... that save_restart writes; the arrays post_data averages, src/framework/MOM_diag_mediator.F90) are
+ * filled from the device-resident fields without a stop of the compute stream:
+ *   mom6hip_stage_to_host   snapshots `bytes` of the device field on the context's stream (a device-to-device copy; the
+ *                           field may be overwritten by whatever is enqueued next) and queues the device-to-host copy of
+ *                           the snapshot on the context's copy stream.  Returns at once.  Any number of fields per batch.
+ *   mom6hip_stage_query     the number of staged copies of the current batch that have not landed yet (never blocks).
+ *   mom6hip_stage_wait      blocks until every staged copy has landed and closes the batch: call it where the host reads
+ *                           the arrays (before save_restart, before a diagnostic is posted).
+ *   mom6hip_host_register / _unregister   page-lock a host array once (hipHostRegister), so that its copies run at the
+ *                           full PCIe rate and truly asynchronously; staging works on pageable arrays too, more slowly. */
+int mom6hip_host_register(void *hptr, uint64_t bytes);
+int mom6hip_host_unregister(void *hptr);
+int mom6hip_stage_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint64_t bytes);
+int mom6hip_stage_query(mom6hip_ctx_t *ctx, int32_t *pending);
+int mom6hip_stage_wait(mom6hip_ctx_t *ctx);
+
 /* ---- MOM_checksums: the bit-count checksum of a field, on the device ----------------------- */
 
 /* subchk of chksum_h_3d / chksum_u_3d / chksum_v_3d / chksum_B_3d (src/framework/MOM_checksums.F90:1387-1401, :1042-1059,

@@ -112,6 +112,11 @@ struct mom6hip_ctx {
   void *min_user = nullptr;
   void *cb_user = nullptr;
   int num_PEs = 0;              // asked of the domain on first use (coms.hip); 0: not yet known
+  // restart / diagnostic staging (staging.hip): snapshots on the compute stream, device-to-host copies on a stream of their own
+  struct StageSlot { m6::DevBuf buf; hipEvent_t snap = nullptr, done = nullptr; };
+  std::vector<StageSlot> stage_slots;
+  int stage_next = 0;
+  hipStream_t copy_stream = nullptr;
   // timing
   bool ktiming = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kt_events[MOM6HIP_KT_SLOTS];
@@ -156,6 +161,7 @@ void native_domain_destroy(mom6hip_ctx *ctx);
 int sum_across_PEs(mom6hip_ctx *ctx, int32_t *values, int n);
 int min_across_PEs(mom6hip_ctx *ctx, double *values, int n);
 inline bool multi_tile(const mom6hip_ctx *ctx);
+void staging_destroy(mom6hip_ctx *ctx);      // staging.hip
 
 // horizontal_viscosity on device arrays (hor_visc.hip); called by the split RK2 step at :860 and :1543
 int horizontal_viscosity_dev(mom6hip_ctx *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,

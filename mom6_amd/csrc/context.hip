@@ -356,6 +356,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   ctx->vv_ntrunc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+  m6::staging_destroy(ctx);
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
   delete ctx;
   return 0;

@@ -336,6 +336,36 @@ interface
     integer(c_int) :: rc
   end function mom6hip_chksum
 
+  !> Restart / diagnostic staging: snapshot a device field and copy it to a (registered) host array on the copy stream
+  function mom6hip_stage_to_host(ctx, hptr, dptr, bytes) bind(c, name="mom6hip_stage_to_host") result(rc)
+    import :: c_int, c_int64_t, c_ptr
+    type(c_ptr), value :: ctx, hptr, dptr
+    integer(c_int64_t), value :: bytes
+    integer(c_int) :: rc
+  end function mom6hip_stage_to_host
+  function mom6hip_stage_query(ctx, pending) bind(c, name="mom6hip_stage_query") result(rc)
+    import :: c_int, c_int32_t, c_ptr
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), intent(out) :: pending
+    integer(c_int) :: rc
+  end function mom6hip_stage_query
+  function mom6hip_stage_wait(ctx) bind(c, name="mom6hip_stage_wait") result(rc)
+    import :: c_int, c_ptr
+    type(c_ptr), value :: ctx
+    integer(c_int) :: rc
+  end function mom6hip_stage_wait
+  function mom6hip_host_register(hptr, bytes) bind(c, name="mom6hip_host_register") result(rc)
+    import :: c_int, c_int64_t, c_ptr
+    type(c_ptr), value :: hptr
+    integer(c_int64_t), value :: bytes
+    integer(c_int) :: rc
+  end function mom6hip_host_register
+  function mom6hip_host_unregister(hptr) bind(c, name="mom6hip_host_unregister") result(rc)
+    import :: c_int, c_ptr
+    type(c_ptr), value :: hptr
+    integer(c_int) :: rc
+  end function mom6hip_host_unregister
+
   !> reproducing_sum of MOM_coms (MOM_coms.F90:318) over the h-point computational domain of a device or host field of
   !! staggering pos; lay_sums, efp_sum(6), efp_lay(6,nk), npoints and err are c_loc of the outputs or c_null_ptr
   function mom6hip_reproducing_sum(ctx, field, pos, nk, sum, lay_sums, efp_sum, efp_lay, npoints, err, memspace) &

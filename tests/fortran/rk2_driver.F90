@@ -126,11 +126,16 @@ rc = mom6hip_reproducing_sum(ctx, d_u, MOM6HIP_POS_U, int(nk, c_int32_t), sum_u,
                              c_null_ptr, MOM6HIP_MEM_DEVICE) ; call check("mom6hip_reproducing_sum u")
 write(*,'(a,2(1x,i0),1x,i0,12(1x,i0))') "rk2_driver stats", bc_h, bc_u, npts, efp_h, efp_u
 
-rc = mom6hip_sync_to_host(ctx, c_loc(u), d_u, 8_c_int64_t*nu3) ; call check("sync u")
-rc = mom6hip_sync_to_host(ctx, c_loc(v), d_v, 8_c_int64_t*nv3) ; call check("sync v")
-rc = mom6hip_sync_to_host(ctx, c_loc(h), d_h, 8_c_int64_t*nh3) ; call check("sync h")
-rc = mom6hip_sync_to_host(ctx, c_loc(eta_av), d_eta_av, 8_c_int64_t*nh2) ; call check("sync eta_av")
-rc = mom6hip_sync_to_host(ctx, c_loc(uhtr), d_uhtr, 8_c_int64_t*nu3) ; call check("sync uhtr")
+! ---- the state to the host the way restarts and diagnostics leave the device: staged (snapshots on the compute stream, the
+! copies on the copy stream), one wait where the host reads the arrays
+rc = mom6hip_host_register(c_loc(u), 8_c_int64_t*nu3) ; call check("host_register u")
+rc = mom6hip_stage_to_host(ctx, c_loc(u), d_u, 8_c_int64_t*nu3) ; call check("stage u")
+rc = mom6hip_stage_to_host(ctx, c_loc(v), d_v, 8_c_int64_t*nv3) ; call check("stage v")
+rc = mom6hip_stage_to_host(ctx, c_loc(h), d_h, 8_c_int64_t*nh3) ; call check("stage h")
+rc = mom6hip_stage_to_host(ctx, c_loc(eta_av), d_eta_av, 8_c_int64_t*nh2) ; call check("stage eta_av")
+rc = mom6hip_stage_to_host(ctx, c_loc(uhtr), d_uhtr, 8_c_int64_t*nu3) ; call check("stage uhtr")
+rc = mom6hip_stage_wait(ctx) ; call check("stage_wait")
+rc = mom6hip_host_unregister(c_loc(u)) ; call check("host_unregister u")
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) u, v, h, eta_av, uhtr
 close(u_out)
