@@ -13,7 +13,15 @@ for c, key in (("FETCH_SIZE", "fetch_bytes"), ("WRITE_SIZE", "write_bytes")):
             continue
         e = kern.setdefault(name, {"dispatches": int(m.group(3))})
         e[key] = float(m.group(4)) * 1024.0
-import hashlib, os
+# the SQ pass of tools/profile_round.sh (instruction and cycle counters), when present
+import os
+sq = f"{src}/{tag}_pmc_sq.txt"
+if os.path.exists(sq):
+    for line in open(sq):
+        m = re.match(r"(.{70}) (\S+)\s+dispatches\s+(\d+)\s+avg\s+([\d.]+)", line)
+        if m and m.group(1).strip() in kern:
+            kern[m.group(1).strip()][m.group(2)] = float(m.group(4))
+import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "mom6_amd", "csrc")
 out = {
