@@ -378,13 +378,15 @@ class Components:
             self.vv_u, self.vv_v = d["u"].clone(), d["v"].clone()
             self.vv_ru, self.vv_rv = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
 
+        # the fused form the RK2 step itself calls (mom6hip_vertvisc_step: vertvisc_coef, vertvisc, vertvisc_remnant of one seam in
+        # one launch per direction); the velocity copies are part of the probe, not of the model step
+        from mom6_amd.vert_friction import vertvisc_step
+
         def vv_full(dt):
             self.vv_u.copy_(d["u"]); self.vv_v.copy_(d["v"])
-            vertvisc_coef(self.vv_u, self.vv_v, d["h"], None, None, self.vv_visc, None, dt, dg, self.vv_cs)
-            vertvisc(self.vv_u, self.vv_v, d["h"], (self.taux, self.tauy), self.vv_visc, dt, None, None, None, dg, self.vv_cs)
-            vertvisc_remnant(self.vv_visc, self.vv_ru, self.vv_rv, dt, dg, self.vv_cs)
-        out.append(("vertvisc_coef+remnant", lambda: (vertvisc_coef(d["u"], d["v"], d["h"], None, None, self.vv_visc, None, DT, dg, self.vv_cs),
-                                                    vertvisc_remnant(self.vv_visc, self.vv_ru, self.vv_rv, DT, dg, self.vv_cs))))
+            vertvisc_step(self.vv_u, self.vv_v, d["h"], None, (self.taux, self.tauy), self.vv_visc, dt, dg, self.vv_cs, self.vv_ru, self.vv_rv)
+        out.append(("vertvisc_coef+remnant", lambda: vertvisc_step(d["u"], d["v"], d["h"], None, None, self.vv_visc, DT, dg, self.vv_cs,
+                                                                 self.vv_ru, self.vv_rv, update_velocities=False)))
         out.append(("vertvisc[pred]", lambda: vv_full(0.6 * DT)))
         out.append(("vertvisc[corr]", lambda: vv_full(DT)))
         from mom6_amd.hor_visc import horizontal_viscosity

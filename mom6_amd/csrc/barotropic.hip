@@ -966,19 +966,24 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   M6_HIP(hipGetLastError());
 
   // ---- the barotropic time steps :1812-2462
-  // One tile: the whole subcycle (4 kernels per barotropic step + the wrap kernels of the group pass every num_cycles
-  // steps; ~100-250 nodes) is captured once as a hipGraph and replayed as a single launch; the graph is keyed on
-  // everything that is baked into its nodes (pointers, ranges, weights) and cached in the context.  With neighbours
-  // the group pass crosses the host (domain callback), so the loop is enqueued kernel by kernel.
-  auto run_loop = [&](hipStream_t st) -> int {
+  // (replayed from hipGraphs: see graph_of below)
+  // the valid range of step n and whether a group pass precedes it (:1842-1861): a function of n alone
+  struct StepRange { int isv, iev, jsv, jev; bool pass_first; };
+  std::vector<StepRange> rng(nt + 1);
+  {
     int isv = is, iev = ie, jsv = js, jev = je;
     for (int n = 1; n <= nt; n++) {
-      if ((iev - stencil < ie) || (jev - stencil < je)) {
-        if (int rc = pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}})) return rc;
-        isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
-      } else {
-        isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil;
-      }
+      bool pf = false;
+      if ((iev - stencil < ie) || (jev - stencil < je)) { pf = true; isv = isvf; iev = ievf; jsv = jsvf; jev = jevf; }
+      else { isv += stencil; iev -= stencil; jsv += stencil; jev -= stencil; }
+      rng[n] = {isv, iev, jsv, jev, pf};
+    }
+  }
+  auto do_pass = [&]() -> int { return pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}}); };
+  // the kernels of steps n0 .. n1 (no group pass)
+  auto run_steps = [&](hipStream_t st, int n0, int n1) {
+    for (int n = n0; n <= n1; n++) {
+      const int isv = rng[n].isv, iev = rng[n].iev, jsv = rng[n].jsv, jev = rng[n].jev;
       const double wt_end = n * p.Instep;
       hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev + 1,
                          jsv - 1, jev + 1, wt_accel2[n]);
@@ -997,42 +1002,80 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       }
       hipLaunchKernelGGL(bt_eta_kernel, grid2d(isv, iev, jsv, jev), dim3(64, 4), 0, st, g, w, p, isv, iev, jsv, jev, wt_eta[n]);
     }
+  };
+  // steps n0 .. n1 with their group passes, enqueued one by one on `st`
+  auto run_loop = [&](hipStream_t st, int n0, int n1) -> int {
+    for (int n = n0; n <= n1; n++) {
+      if (rng[n].pass_first) { if (int rc = do_pass()) return rc; }
+      run_steps(st, n, n);
+    }
     return 0;
   };
-  static const bool graph_off = getenv("MOM6HIP_BT_GRAPH") && atoi(getenv("MOM6HIP_BT_GRAPH")) == 0;
-  if (m6::multi_tile(ctx) || graph_off) {
-    if (int rc = run_loop(s)) return rc;
-  } else {
-    std::string key;
-    auto add = [&](const void *q, size_t nbytes) { key.append((const char *)q, nbytes); };
+  // A hipGraph of steps n0 .. n1, keyed on everything that is baked into its nodes (pointers, ranges, weights) and cached in
+  // the context.  with_passes: the wrap kernels of a one-tile group pass are captured too.
+  std::string base_key;
+  {
+    auto add = [&](const void *q, size_t nbytes) { base_key.append((const char *)q, nbytes); };
     add(&w, sizeof(w)); add(&p, sizeof(p)); add(&nt, sizeof(nt)); add(&ctx->host.first_direction, sizeof(int32_t));
     add(&c.ubtav, sizeof(double *)); add(&c.vbtav, sizeof(double *)); add(&duhbtav, sizeof(double *)); add(&dvhbtav, sizeof(double *));
     add(wt_vel.data(), sizeof(double) * wt_vel.size()); add(wt_eta.data(), sizeof(double) * wt_eta.size());
     add(wt_trans.data(), sizeof(double) * wt_trans.size()); add(wt_accel.data(), sizeof(double) * wt_accel.size());
     add(wt_accel2.data(), sizeof(double) * wt_accel2.size());
-    hipGraphExec_t exec = nullptr;
-    for (auto &e : ctx->bt_graphs) if (e.first == key) { exec = (hipGraphExec_t)e.second; break; }
-    if (!exec) {
-      if (!ctx->cap_stream) M6_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
-      hipStream_t saved = ctx->stream;
-      ctx->stream = ctx->cap_stream;      // the wrap kernels of the group pass launch on the context's stream
-      hipError_t e0 = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed);
-      int rc = (e0 == hipSuccess) ? run_loop(ctx->cap_stream) : 1;
-      hipGraph_t graph = nullptr;
-      hipError_t e1 = (e0 == hipSuccess) ? hipStreamEndCapture(ctx->cap_stream, &graph) : e0;
-      ctx->stream = saved;
-      M6_REQUIRE(rc == 0 && e1 == hipSuccess && graph, "btstep: capturing the barotropic subcycle as a hipGraph failed (%s)",
-                 hipGetErrorString(e1));
-      hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      M6_REQUIRE(e2 == hipSuccess && exec, "btstep: hipGraphInstantiate failed (%s)", hipGetErrorString(e2));
-      if (ctx->bt_graphs.size() >= 8) {      // drop the oldest
-        (void)hipGraphExecDestroy((hipGraphExec_t)ctx->bt_graphs.front().second);
-        ctx->bt_graphs.erase(ctx->bt_graphs.begin());
-      }
-      ctx->bt_graphs.push_back({key, (void *)exec});
-      ctx->bt_graph_captures++;
+  }
+  auto graph_of = [&](int n0, int n1, bool with_passes, hipGraphExec_t *out) -> int {
+    std::string key = base_key;
+    key.append((const char *)&n0, sizeof(int)); key.append((const char *)&n1, sizeof(int)); key.push_back(with_passes ? 1 : 0);
+    for (auto &e : ctx->bt_graphs) if (e.first == key) { *out = (hipGraphExec_t)e.second; return 0; }
+    if (!ctx->cap_stream) M6_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+    hipStream_t saved = ctx->stream;
+    ctx->stream = ctx->cap_stream;      // the wrap kernels of the group pass launch on the context's stream
+    hipError_t e0 = hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed);
+    int rc = 1;
+    if (e0 == hipSuccess) {
+      if (with_passes) rc = run_loop(ctx->cap_stream, n0, n1);
+      else { run_steps(ctx->cap_stream, n0, n1); rc = 0; }
     }
+    hipGraph_t graph = nullptr;
+    hipError_t e1 = (e0 == hipSuccess) ? hipStreamEndCapture(ctx->cap_stream, &graph) : e0;
+    ctx->stream = saved;
+    M6_REQUIRE(rc == 0 && e1 == hipSuccess && graph, "btstep: capturing the barotropic subcycle as a hipGraph failed (%s)",
+               hipGetErrorString(e1));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    M6_REQUIRE(e2 == hipSuccess && exec, "btstep: hipGraphInstantiate failed (%s)", hipGetErrorString(e2));
+    if (ctx->bt_graphs.size() >= 256) {      // drop the oldest
+      (void)hipGraphExecDestroy((hipGraphExec_t)ctx->bt_graphs.front().second);
+      ctx->bt_graphs.erase(ctx->bt_graphs.begin());
+    }
+    ctx->bt_graphs.push_back({key, (void *)exec});
+    ctx->bt_graph_captures++;
+    *out = exec;
+    return 0;
+  };
+  // One tile: the whole subcycle (4 kernels per barotropic step + the wrap kernels of the group pass every num_cycles
+  // steps; ~100-250 nodes) is ONE graph, replayed as a single launch.  With neighbours the group pass leaves the stream
+  // (RCCL on the communication stream, or the host's callback), so the steps between two passes -- num_cycles of them,
+  // 4 kernels each, a few microseconds of work per kernel on a tile of an 8-GPU run -- are one graph per segment and
+  // the passes are enqueued between the graph launches: a launch per segment instead of one per kernel.
+  static const bool graph_off = getenv("MOM6HIP_BT_GRAPH") && atoi(getenv("MOM6HIP_BT_GRAPH")) == 0;
+  if (graph_off) {
+    if (int rc = run_loop(s, 1, nt)) return rc;
+  } else if (m6::multi_tile(ctx)) {
+    int n0 = 1;
+    while (n0 <= nt) {
+      int n1 = n0;
+      while (n1 + 1 <= nt && !rng[n1 + 1].pass_first) n1++;
+      if (rng[n0].pass_first) { if (int rc = do_pass()) return rc; }
+      hipGraphExec_t exec = nullptr;
+      if (int rc = graph_of(n0, n1, false, &exec)) return rc;
+      M6_HIP(hipGraphLaunch(exec, s));
+      ctx->bt_graph_launches++;
+      n0 = n1 + 1;
+    }
+  } else {
+    hipGraphExec_t exec = nullptr;
+    if (int rc = graph_of(1, nt, true, &exec)) return rc;
     M6_HIP(hipGraphLaunch(exec, s));
     ctx->bt_graph_launches++;
   }
