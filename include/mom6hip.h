@@ -335,26 +335,36 @@ int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_remapping_cs_
 /* CORIOLIS_SCHEME / KE_SCHEME enumeration values, src/core/MOM_CoriolisAdv.F90:93-112 */
 #define MOM6HIP_SADOURNY75_ENERGY 1
 #define MOM6HIP_ARAKAWA_HSU90     2
+#define MOM6HIP_ROBUST_ENSTRO     3
 #define MOM6HIP_SADOURNY75_ENSTRO 4
+#define MOM6HIP_ARAKAWA_LAMB81    5
+#define MOM6HIP_AL_BLEND          6
+#define MOM6HIP_PV_ADV_CENTERED   21
+#define MOM6HIP_PV_ADV_UPWIND1    22
 #define MOM6HIP_KE_ARAKAWA        10
 #define MOM6HIP_KE_SIMPLE_GUDONOV 11
 #define MOM6HIP_KE_GUDONOV        12
 
 /* CoriolisAdv_CS, src/core/MOM_CoriolisAdv.F90:30-91 (the members the provided branches read) */
 typedef struct mom6hip_coriolisadv_cs {
-  int32_t coriolis_scheme;   /* CORIOLIS_SCHEME: SADOURNY75_ENERGY (default), SADOURNY75_ENSTRO, ARAKAWA_HSU90 */
+  int32_t coriolis_scheme;   /* CORIOLIS_SCHEME: SADOURNY75_ENERGY (default), ARAKAWA_HSU90, ROBUST_ENSTRO, SADOURNY75_ENSTRO,
+                              * ARAKAWA_LAMB81, ARAKAWA_LAMB_BLEND (AL_BLEND): all six of the reference */
   int32_t ke_scheme;         /* KE_SCHEME: KE_ARAKAWA (default), KE_SIMPLE_GUDONOV, KE_GUDONOV */
   int32_t no_slip;           /* NOSLIP */
-  int32_t bound_coriolis;    /* BOUND_CORIOLIS */
-  int32_t coriolis_en_dis;   /* CORIOLIS_EN_DIS (must be 0) */
-  int32_t reserved[3];
+  int32_t bound_coriolis;    /* BOUND_CORIOLIS (CoriolisAdv_init sets it false with CORIOLIS_EN_DIS + SADOURNY75_ENERGY and
+                              * with ROBUST_ENSTRO, :1155-1156; CorAdCalc applies what it is given) */
+  int32_t coriolis_en_dis;   /* CORIOLIS_EN_DIS: the energy-dissipating bias of SADOURNY75_ENERGY (:326-333, :594-642) */
+  int32_t pv_adv_scheme;     /* PV_ADV_SCHEME of ROBUST_ENSTRO: PV_ADV_CENTERED (default; 0 means the default), PV_ADV_UPWIND1 */
+  int32_t reserved[2];
+  double F_eff_max_blend;    /* CORIOLIS_BLEND_F_EFF_MAX (4.0), AL_BLEND only */
+  double wt_lin_blend;       /* CORIOLIS_BLEND_WT_LIN (0.125, clipped to [1e-16, 1] by CoriolisAdv_init :1139), AL_BLEND only */
 } mom6hip_coriolisadv_cs_t;
 
 /*
  * CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Waves)   src/core/MOM_CoriolisAdv.F90:125
  * OBC, Waves must not be associated, pbv must be all ones, AD diagnostics are not provided.
  * Needs the metrics mask2dT, areaT, IareaT, dxCu, IdxCu, areaCu, dyCv, IdyCv, areaCv, mask2dBu, IareaBu,
- * CoriolisBu.  CAu is written on (isc-1:iec, jsc:jec), CAv on (isc:iec, jsc-1:jec); other points are untouched.
+ * CoriolisBu (+ IdyCu, IdxCv with ROBUST_ENSTRO; dy_Cu, dx_Cv with CORIOLIS_EN_DIS).  CAu is written on (isc-1:iec, jsc:jec), CAv on (isc:iec, jsc-1:jec); other points are untouched.
  */
 int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, const double *u, const double *v,
                       const double *h, const double *uh, const double *vh, double *CAu, double *CAv,

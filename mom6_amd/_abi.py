@@ -61,13 +61,16 @@ class RemappingCS(C.Structure):
     _fields_ = [("remapping_scheme", C.c_int32), ("boundary_extrapolation", C.c_int32),
                 ("force_bounds_in_subcell", C.c_int32), ("answer_date", C.c_int32)]
 
-CORIOLIS_SCHEMES = {"SADOURNY75_ENERGY": 1, "ARAKAWA_HSU90": 2, "SADOURNY75_ENSTRO": 4}
+CORIOLIS_SCHEMES = {"SADOURNY75_ENERGY": 1, "ARAKAWA_HSU90": 2, "ROBUST_ENSTRO": 3, "SADOURNY75_ENSTRO": 4, "ARAKAWA_LAMB81": 5,
+                    "ARAKAWA_LAMB_BLEND": 6}
+PV_ADV_SCHEMES = {"PV_ADV_CENTERED": 21, "PV_ADV_UPWIND1": 22}
 KE_SCHEMES = {"KE_ARAKAWA": 10, "KE_SIMPLE_GUDONOV": 11, "KE_GUDONOV": 12}
 
 
 class CoriolisAdvCS(C.Structure):
     _fields_ = [("coriolis_scheme", C.c_int32), ("ke_scheme", C.c_int32), ("no_slip", C.c_int32),
-                ("bound_coriolis", C.c_int32), ("coriolis_en_dis", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("bound_coriolis", C.c_int32), ("coriolis_en_dis", C.c_int32), ("pv_adv_scheme", C.c_int32), ("reserved", C.c_int32 * 2),
+                ("F_eff_max_blend", C.c_double), ("wt_lin_blend", C.c_double)]
 
 
 class ContinuityCS(C.Structure):

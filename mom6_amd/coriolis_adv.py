@@ -12,19 +12,30 @@ class CoriolisAdvCS:
     """CoriolisAdv_CS (MOM_CoriolisAdv.F90:30-91) as set by CoriolisAdv_init (:1054-1184)."""
 
     def __init__(self, coriolis_scheme="SADOURNY75_ENERGY", ke_scheme="KE_ARAKAWA", no_slip=False,
-                 bound_coriolis=False, coriolis_en_dis=False):
+                 bound_coriolis=False, coriolis_en_dis=False, pv_adv_scheme="PV_ADV_CENTERED", coriolis_blend_wt_lin=0.125,
+                 coriolis_blend_f_eff_max=4.0):
         if coriolis_scheme not in _abi.CORIOLIS_SCHEMES:
             # MOM_CoriolisAdv.F90:1122-1123
             raise Mom6HipError("CoriolisAdv_init: #define CORIOLIS_SCHEME " + str(coriolis_scheme)
                                + " found in input file is not provided by libmom6hip.")
         if ke_scheme not in _abi.KE_SCHEMES:
             raise Mom6HipError("CoriolisAdv_init: #define KE_SCHEME " + str(ke_scheme) + " in input file is invalid.")
-        self.coriolis_scheme, self.ke_scheme = coriolis_scheme, ke_scheme
+        if pv_adv_scheme not in _abi.PV_ADV_SCHEMES:      # :1196-1199
+            raise Mom6HipError("CoriolisAdv_init: #DEFINE PV_ADV_SCHEME in input file is invalid.")
+        self.coriolis_scheme, self.ke_scheme, self.pv_adv_scheme = coriolis_scheme, ke_scheme, pv_adv_scheme
         self.no_slip, self.bound_coriolis, self.coriolis_en_dis = bool(no_slip), bool(bound_coriolis), bool(coriolis_en_dis)
+        # CORIOLIS_BLEND_WT_LIN / CORIOLIS_BLEND_F_EFF_MAX :1126-1141
+        self.wt_lin_blend = min(1.0, max(float(coriolis_blend_wt_lin), 1e-16))
+        self.F_eff_max_blend = float(coriolis_blend_f_eff_max)
+        # :1155-1156: the bounds are switched off where they cannot apply
+        if (self.coriolis_en_dis and coriolis_scheme == "SADOURNY75_ENERGY") or coriolis_scheme == "ROBUST_ENSTRO":
+            self.bound_coriolis = False
 
     def struct(self):
-        return _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES[self.coriolis_scheme], _abi.KE_SCHEMES[self.ke_scheme],
-                                  int(self.no_slip), int(self.bound_coriolis), int(self.coriolis_en_dis))
+        cs = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES[self.coriolis_scheme], _abi.KE_SCHEMES[self.ke_scheme],
+                                int(self.no_slip), int(self.bound_coriolis), int(self.coriolis_en_dis), _abi.PV_ADV_SCHEMES[self.pv_adv_scheme])
+        cs.F_eff_max_blend, cs.wt_lin_blend = self.F_eff_max_blend, self.wt_lin_blend
+        return cs
 
 
 def CoriolisAdv_init(**kw):

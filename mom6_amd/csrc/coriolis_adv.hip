@@ -21,6 +21,9 @@ struct CorArgs {
   double *CAu, *CAv;
   int scheme, ke_scheme, no_slip, bound;
   double vol_neglect;
+  // the schemes beyond the production three (coradcalc_kernel<true>)
+  int en_dis, upwind1;
+  double Fe_m2, rat_lin, wt_lin_blend, eps_vel, h_tiny;
 };
 
 using m6::max2;
@@ -28,8 +31,73 @@ using m6::min2;
 __device__ __forceinline__ double max4(double a, double b, double c, double d) { return max2(max2(max2(a, b), c), d); }
 __device__ __forceinline__ double min4(double a, double b, double c, double d) { return min2(min2(min2(a, b), c), d); }
 
+// The a / b / c / d weights and the ep_u / ep_v of ARAKAWA_LAMB81 (:534-542) and ARAKAWA_LAMB_BLEND (:543-590) that the
+// reference forms in one loop pass (I, j) from the four q around the h-point (i, j): a(I-1,j), d(I-1,j), b(I,j), c(I,j),
+// ep_u(i,j), ep_v(i,j).  q11 = q(I,J), q00 = q(I-1,J-1), q01 = q(I-1,J), q10 = q(I,J-1); ih.. the Ih_q at the same points.
+struct Quad { double am1, dm1, b, c, epu, epv; };
+__device__ __forceinline__ Quad al_quad(const CorArgs &p, double q11, double q00, double q01, double q10, double ih11, double ih00,
+                                        double ih01, double ih10) {
+  const double C1_24 = 1.0 / 24.0;
+  Quad r;
+  if (p.scheme == MOM6HIP_ARAKAWA_LAMB81) {
+    r.am1 = (2.0 * (q11 + q00) + (q01 + q10)) * C1_24;
+    r.dm1 = ((q11 + q00) + 2.0 * (q01 + q10)) * C1_24;
+    r.b = ((q11 + q00) + 2.0 * (q01 + q10)) * C1_24;
+    r.c = (2.0 * (q11 + q00) + (q01 + q10)) * C1_24;
+    r.epu = ((q11 - q00) + (q01 - q10)) * C1_24;
+    r.epv = (-(q11 - q00) + (q01 - q10)) * C1_24;
+    return r;
+  }
+  const double min_Ihq = min4(ih00, ih10, ih01, ih11), max_Ihq = max4(ih00, ih10, ih01, ih11);
+  double rat_m1 = 1.0e15;
+  if (max_Ihq < 1.0e15 * min_Ihq) rat_m1 = max_Ihq / min_Ihq - 1.0;
+  double AL_wt, Sad_wt;
+  if (rat_m1 <= p.Fe_m2) AL_wt = 1.0;
+  else if (rat_m1 < 1.5 * p.Fe_m2) AL_wt = 3.0 * p.Fe_m2 / rat_m1 - 2.0;
+  else AL_wt = 0.0;
+  if (rat_m1 <= 1.5 * p.Fe_m2) Sad_wt = 0.0;
+  else if (rat_m1 <= p.rat_lin) Sad_wt = 1.0 - (1.5 * p.Fe_m2) / rat_m1;
+  else if (rat_m1 < 2.0 * p.rat_lin) Sad_wt = 1.0 - (p.wt_lin_blend / p.rat_lin) * (rat_m1 - 2.0 * p.rat_lin);
+  else Sad_wt = 1.0;
+  r.am1 = Sad_wt * 0.25 * q01 + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q01 + AL_wt * q10) + 2.0 * (q11 + q00)) * C1_24;
+  r.dm1 = Sad_wt * 0.25 * q00 + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q00 + AL_wt * q11) + 2.0 * (q01 + q10)) * C1_24;
+  r.b = Sad_wt * 0.25 * q11 + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q11 + AL_wt * q00) + 2.0 * (q01 + q10)) * C1_24;
+  r.c = Sad_wt * 0.25 * q10 + (1.0 - Sad_wt) * (((2.0 - AL_wt) * q10 + AL_wt * q01) + 2.0 * (q11 + q00)) * C1_24;
+  r.epu = AL_wt * ((q11 - q00) + (q01 - q10)) * C1_24;
+  r.epv = AL_wt * (-(q11 - q00) + (q01 - q10)) * C1_24;
+  return r;
+}
+
+// uh_min / uh_max (or vh_min / vh_max) of CORIOLIS_EN_DIS at one face (:594-642): hc = the centred estimate of the transport
+// (uh_center / vh_center :328, :331), hm = the transport of the continuity solver, dL = dy_Cu / dx_Cv
+__device__ __forceinline__ void en_dis_range(double dL, double vel, double hsum, double hm, double &tmin, double &tmax) {
+  const double c1 = 1.0 - 1.5 * 0.5, c2 = 1.0 - 0.5, c3 = 2.0, slope = 0.5;
+  double hc = 0.5 * ((dL * 1.0) * vel) * hsum;
+  if (dL == 0.0) hc = hm;
+  if (fabs(hc) < 0.1 * fabs(hm)) {
+    hm = 10.0 * hc;
+  } else if (fabs(hc) > c1 * fabs(hm)) {
+    if (fabs(hc) < c2 * fabs(hm)) hc = (3.0 * hc + (1.0 - c2 * 3.0) * hm);
+    else if (fabs(hc) <= c3 * fabs(hm)) hc = hm;
+    else hc = slope * hc + (1.0 - c3 * slope) * hm;
+  }
+  if (hc > hm) { tmin = hm; tmax = hc; } else { tmax = hm; tmin = hc; }
+}
+
+// Heff of ROBUST_ENSTRO (:692-703): |transport * IdL| / (eps_vel + |vel|), held between the two thicknesses of the face
+__device__ __forceinline__ double robust_heff(double tr, double IdL, double vel, double ha, double hb, double eps_vel) {
+  double He = fabs(tr * IdL) / (eps_vel + fabs(vel));
+  He = max2(He, min2(ha, hb));
+  He = min2(He, max2(ha, hb));
+  return He;
+}
+
+// EXT = false: the three schemes of production runs (SADOURNY75_ENERGY, SADOURNY75_ENSTRO, ARAKAWA_HSU90), unchanged;
+// EXT = true: also ROBUST_ENSTRO, ARAKAWA_LAMB81, ARAKAWA_LAMB_BLEND and CORIOLIS_EN_DIS (Ih_q staged in LDS as well).
+template <bool EXT>
 __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   const m6::GridDev &g = p.g;
+  __shared__ double s_ihq[EXT ? TJ + 2 : 1][EXT ? TI + 2 : 1];      // Ih_q at the q-points of s_q (ARAKAWA_LAMB_BLEND)
   __shared__ double s_q[TJ + 2][TI + 2];      // q(I0-1 .. I0+64, J0-1 .. J0+8) (the +1 column/row: Arakawa-Hsu)
   __shared__ double s_av[TJ + 2][TI + 2];     // abs_vort, same points
   __shared__ double s_ke[TJ + 1][TI + 1];     // KE(i = I0 .. I0+64, j = J0 .. J0+8)
@@ -51,7 +119,7 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     // ---- q-point (I,J) = (I0-1+tx, J0-1+ty), :246-274, :314-324, :459-491 ----
     {
       const int I = I0 - 1 + tx, J = J0 - 1 + ty;
-      double qv = 0.0, av = 0.0;
+      double qv = 0.0, av = 0.0, ihq = 0.0;
       if (I <= Iqmax && J <= Jqmax) {
         const int oh = (I - g.isd) + nih * (J - g.jsd);               // h2(i, j)
         const int ou = (I - g.isd + 1) + sU * (J - g.jsd);            // u2(I, j)
@@ -74,9 +142,10 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
         av = g.CoriolisBu[oq] + rel_vort;
         const double hArea_q = (hArea_u0 + hArea_u1) + (hArea_v0 + hArea_v1);
         const double Ih_q = Area_q / (hArea_q + p.vol_neglect);
-        qv = av * Ih_q;
+        qv = av * Ih_q; ihq = Ih_q;
       }
       s_q[ty][tx] = qv; s_av[ty][tx] = av;
+      if (EXT) s_ihq[ty][tx] = ihq;
     }
     // ---- h-point (i,j) = (I0+tx, J0+ty): KE, :995-1025 ----
     if (tx <= TI && ty <= TJ) {
@@ -116,10 +185,49 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     const double vh_ne = vhk[ov + 1], vh_nw = vhk[ov], vh_sw = vhk[ov - nih], vh_se = vhk[ov - nih + 1];
     const double IdxCu = g.IdxCu[ou];
     double ca;
-    if (p.scheme == MOM6HIP_SADOURNY75_ENERGY) {
+    const bool al = EXT && (p.scheme == MOM6HIP_ARAKAWA_LAMB81 || p.scheme == MOM6HIP_AL_BLEND);
+    if (EXT && p.scheme == MOM6HIP_SADOURNY75_ENERGY && p.en_dis) {      // :645-665
+      const int oh = (I - g.isd) + nih * (J - g.jsd);                     // h2(i, j)
+      const double uI = uk[ou];
+      // vh_min / vh_max at the faces (i, J), (i+1, J), (i, J-1), (i+1, J-1)
+      double mnN0, mxN0, mnN1, mxN1, mnS0, mxS0, mnS1, mxS1;
+      en_dis_range(g.dx_Cv[ov], vk[ov], hk[oh] + hk[oh + nih], vh_nw, mnN0, mxN0);
+      en_dis_range(g.dx_Cv[ov + 1], vk[ov + 1], hk[oh + 1] + hk[oh + nih + 1], vh_ne, mnN1, mxN1);
+      en_dis_range(g.dx_Cv[ov - nih], vk[ov - nih], hk[oh - nih] + hk[oh], vh_sw, mnS0, mxS0);
+      en_dis_range(g.dx_Cv[ov - nih + 1], vk[ov - nih + 1], hk[oh - nih + 1] + hk[oh + 1], vh_se, mnS1, mxS1);
+      double temp1, temp2;
+      if (qN * uI == 0.0) temp1 = qN * ((mxN0 + mxN1) + (mnN0 + mnN1)) * 0.5;
+      else if (qN * uI < 0.0) temp1 = qN * (mxN0 + mxN1);
+      else temp1 = qN * (mnN0 + mnN1);
+      if (qS * uI == 0.0) temp2 = qS * ((mxS0 + mxS1) + (mnS0 + mnS1)) * 0.5;
+      else if (qS * uI < 0.0) temp2 = qS * (mxS0 + mxS1);
+      else temp2 = qS * (mnS0 + mnS1);
+      ca = 0.25 * IdxCu * (temp1 + temp2);
+    } else if (p.scheme == MOM6HIP_SADOURNY75_ENERGY) {
       ca = 0.25 * (qN * (vh_ne + vh_nw) + qS * (vh_sw + vh_se)) * IdxCu;
     } else if (p.scheme == MOM6HIP_SADOURNY75_ENSTRO) {
       ca = 0.125 * (IdxCu * (qN + qS)) * ((vh_ne + vh_nw) + (vh_sw + vh_se));
+    } else if (EXT && p.scheme == MOM6HIP_ROBUST_ENSTRO) {      // :687-714
+      const int oh = (I - g.isd) + nih * (J - g.jsd);
+      const double Heff1 = robust_heff(vh_nw, g.IdxCv[ov], vk[ov], hk[oh], hk[oh + nih], p.eps_vel);
+      const double Heff2 = robust_heff(vh_sw, g.IdxCv[ov - nih], vk[ov - nih], hk[oh - nih], hk[oh], p.eps_vel);
+      const double Heff3 = robust_heff(vh_ne, g.IdxCv[ov + 1], vk[ov + 1], hk[oh + 1], hk[oh + nih + 1], p.eps_vel);
+      const double Heff4 = robust_heff(vh_se, g.IdxCv[ov - nih + 1], vk[ov - nih + 1], hk[oh - nih + 1], hk[oh + 1], p.eps_vel);
+      const double avN = s_av[ty + 1][tx + 1], avS = s_av[ty][tx + 1];
+      if (!p.upwind1) {
+        ca = 0.5 * (avN + avS) * ((vh_nw + vh_se) + (vh_sw + vh_ne)) / (p.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdxCu;
+      } else {
+        const double VHeff = ((vh_nw + vh_se) + (vh_sw + vh_ne));
+        const double QVHeff = 0.5 * ((avN + avS) * VHeff - (avN - avS) * fabs(VHeff));
+        ca = (QVHeff / (p.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3)))) * IdxCu;
+      }
+    } else if (al) {      // ARAKAWA_LAMB81 / _BLEND: b, c, ep_u(i) of the point's own pass, a, d, ep_u(i+1) of the next one's
+      const Quad q0 = al_quad(p, s_q[ty + 1][tx + 1], s_q[ty][tx], s_q[ty + 1][tx], s_q[ty][tx + 1], s_ihq[ty + 1][tx + 1], s_ihq[ty][tx],
+                              s_ihq[ty + 1][tx], s_ihq[ty][tx + 1]);
+      const Quad q1 = al_quad(p, s_q[ty + 1][tx + 2], s_q[ty][tx + 1], s_q[ty + 1][tx + 1], s_q[ty][tx + 2], s_ihq[ty + 1][tx + 2],
+                              s_ihq[ty][tx + 1], s_ihq[ty + 1][tx + 1], s_ihq[ty][tx + 2]);
+      ca = ((q1.am1 * vh_ne + q0.c * vh_sw) + (q0.b * vh_nw + q1.dm1 * vh_se)) * IdxCu;
+      ca = ca + (q0.epu * uhk[ou - 1] - q1.epu * uhk[ou + 1]) * IdxCu;      // :717-721
     } else {   // ARAKAWA_HSU90, :526-531 and :684-685
       const double qE = s_q[ty + 1][tx + 2], qSE = s_q[ty][tx + 2], qW = s_q[ty + 1][tx], qSW = s_q[ty][tx];
       const double a = (qN + (qE + qS)) * C1_12;
@@ -144,10 +252,49 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     const double uh_sw = uhk[ou - 1], uh_nw = uhk[ou - 1 + sU], uh_se = uhk[ou], uh_ne = uhk[ou + sU];
     const double IdyCv = g.IdyCv[ov];
     double ca;
-    if (p.scheme == MOM6HIP_SADOURNY75_ENERGY) {
+    const bool al = EXT && (p.scheme == MOM6HIP_ARAKAWA_LAMB81 || p.scheme == MOM6HIP_AL_BLEND);
+    if (EXT && p.scheme == MOM6HIP_SADOURNY75_ENERGY && p.en_dis) {      // :764-785
+      const int oh = (I - g.isd) + nih * (J - g.jsd);                     // h2(i, j)
+      const double vJ = vk[ov];
+      // uh_min / uh_max at the faces (I-1, j), (I-1, j+1), (I, j), (I, j+1)
+      double mnW0, mxW0, mnW1, mxW1, mnE0, mxE0, mnE1, mxE1;
+      en_dis_range(g.dy_Cu[ou - 1], uk[ou - 1], hk[oh - 1] + hk[oh], uh_sw, mnW0, mxW0);
+      en_dis_range(g.dy_Cu[ou - 1 + sU], uk[ou - 1 + sU], hk[oh + nih - 1] + hk[oh + nih], uh_nw, mnW1, mxW1);
+      en_dis_range(g.dy_Cu[ou], uk[ou], hk[oh] + hk[oh + 1], uh_se, mnE0, mxE0);
+      en_dis_range(g.dy_Cu[ou + sU], uk[ou + sU], hk[oh + nih] + hk[oh + nih + 1], uh_ne, mnE1, mxE1);
+      double temp1, temp2;
+      if (qW * vJ == 0.0) temp1 = qW * ((mxW0 + mxW1) + (mnW0 + mnW1)) * 0.5;
+      else if (qW * vJ > 0.0) temp1 = qW * (mxW0 + mxW1);
+      else temp1 = qW * (mnW0 + mnW1);
+      if (qE * vJ == 0.0) temp2 = qE * ((mxE0 + mxE1) + (mnE0 + mnE1)) * 0.5;
+      else if (qE * vJ > 0.0) temp2 = qE * (mxE0 + mxE1);
+      else temp2 = qE * (mnE0 + mnE1);
+      ca = -0.25 * IdyCv * (temp1 + temp2);
+    } else if (p.scheme == MOM6HIP_SADOURNY75_ENERGY) {
       ca = -0.25 * (qW * (uh_sw + uh_nw) + qE * (uh_se + uh_ne)) * IdyCv;
     } else if (p.scheme == MOM6HIP_SADOURNY75_ENSTRO) {
       ca = -0.125 * (IdyCv * (qW + qE)) * ((uh_sw + uh_nw) + (uh_se + uh_ne));
+    } else if (EXT && p.scheme == MOM6HIP_ROBUST_ENSTRO) {      // :808-838
+      const int oh = (I - g.isd) + nih * (J - g.jsd);
+      const double Heff1 = robust_heff(uh_se, g.IdyCu[ou], uk[ou], hk[oh], hk[oh + 1], p.eps_vel);
+      const double Heff2 = robust_heff(uh_sw, g.IdyCu[ou - 1], uk[ou - 1], hk[oh - 1], hk[oh], p.eps_vel);
+      const double Heff3 = robust_heff(uh_ne, g.IdyCu[ou + sU], uk[ou + sU], hk[oh + nih], hk[oh + nih + 1], p.eps_vel);
+      const double Heff4 = robust_heff(uh_nw, g.IdyCu[ou - 1 + sU], uk[ou - 1 + sU], hk[oh + nih - 1], hk[oh + nih], p.eps_vel);
+      const double avE = s_av[ty + 1][tx + 1], avW = s_av[ty + 1][tx];
+      if (!p.upwind1) {
+        ca = -0.5 * (avE + avW) * ((uh_se + uh_nw) + (uh_sw + uh_ne)) / (p.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdyCv;
+      } else {
+        const double UHeff = ((uh_se + uh_nw) + (uh_sw + uh_ne));
+        const double QUHeff = 0.5 * ((avE + avW) * UHeff - (avE - avW) * fabs(UHeff));
+        ca = -QUHeff / (p.h_tiny + ((Heff1 + Heff4) + (Heff2 + Heff3))) * IdyCv;
+      }
+    } else if (al) {      // a(I-1,j), b(I,j), ep_v(i,j) of the pass (I, j = J); c(I,j+1), d(I-1,j+1), ep_v(i,j+1) of (I, J+1)
+      const Quad q0 = al_quad(p, s_q[ty + 1][tx + 1], s_q[ty][tx], s_q[ty + 1][tx], s_q[ty][tx + 1], s_ihq[ty + 1][tx + 1], s_ihq[ty][tx],
+                              s_ihq[ty + 1][tx], s_ihq[ty][tx + 1]);
+      const Quad q1 = al_quad(p, s_q[ty + 2][tx + 1], s_q[ty + 1][tx], s_q[ty + 2][tx], s_q[ty + 1][tx + 1], s_ihq[ty + 2][tx + 1],
+                              s_ihq[ty + 1][tx], s_ihq[ty + 2][tx], s_ihq[ty + 1][tx + 1]);
+      ca = -((q0.am1 * uh_sw + q1.c * uh_ne) + (q0.b * uh_se + q1.dm1 * uh_nw)) * IdyCv;
+      ca = ca + (q0.epv * vhk[ov - nih] - q1.epv * vhk[ov + nih]) * IdyCv;      // :841-845
     } else {   // ARAKAWA_HSU90: a(I-1,j), c(I,j+1), b(I,j), d(I-1,j+1)
       // q(I,J) = s_q[ty+1][tx+1]
       auto Q = [&](int dI, int dJ) { return s_q[ty + 1 + dJ][tx + 1 + dI]; };
@@ -177,15 +324,19 @@ extern "C" int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_c
   M6_REQUIRE(ctx != nullptr, "MOM_CoriolisAdv: Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && uh && vh && CAu && CAv, "CorAdCalc: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "CorAdCalc: bad memspace");
-  M6_REQUIRE(cs->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY || cs->coriolis_scheme == MOM6HIP_SADOURNY75_ENSTRO ||
-             cs->coriolis_scheme == MOM6HIP_ARAKAWA_HSU90,
-             "CoriolisAdv_init: CORIOLIS_SCHEME %d is not provided (SADOURNY75_ENERGY, SADOURNY75_ENSTRO, ARAKAWA_HSU90)",
-             cs->coriolis_scheme);
+  M6_REQUIRE(cs->coriolis_scheme >= MOM6HIP_SADOURNY75_ENERGY && cs->coriolis_scheme <= MOM6HIP_AL_BLEND,
+             "CoriolisAdv_init: Unrecognized setting #define CORIOLIS_SCHEME %d", cs->coriolis_scheme);
   M6_REQUIRE(cs->ke_scheme >= MOM6HIP_KE_ARAKAWA && cs->ke_scheme <= MOM6HIP_KE_GUDONOV, "CoriolisAdv_init: invalid KE_SCHEME");
-  M6_REQUIRE(!cs->coriolis_en_dis, "CorAdCalc: CORIOLIS_EN_DIS is not provided");
+  M6_REQUIRE(cs->pv_adv_scheme == 0 || cs->pv_adv_scheme == MOM6HIP_PV_ADV_CENTERED || cs->pv_adv_scheme == MOM6HIP_PV_ADV_UPWIND1,
+             "CoriolisAdv_init: #DEFINE PV_ADV_SCHEME in input file is invalid.");
+  const bool en_dis = cs->coriolis_en_dis && cs->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY;      // (read by that scheme only)
+  const bool ext = en_dis || cs->coriolis_scheme == MOM6HIP_ROBUST_ENSTRO || cs->coriolis_scheme == MOM6HIP_ARAKAWA_LAMB81 ||
+                   cs->coriolis_scheme == MOM6HIP_AL_BLEND;
   m6::GridDev &g = ctx->g;
   M6_REQUIRE(g.mask2dT && g.areaT && g.IareaT && g.dxCu && g.IdxCu && g.areaCu && g.dyCv && g.IdyCv && g.areaCv &&
              g.mask2dBu && g.IareaBu && g.CoriolisBu, "CorAdCalc: a required grid metric is missing");
+  M6_REQUIRE(cs->coriolis_scheme != MOM6HIP_ROBUST_ENSTRO || (g.IdyCu && g.IdxCv), "CorAdCalc: ROBUST_ENSTRO needs the metrics IdyCu, IdxCv");
+  M6_REQUIRE(!en_dis || (g.dy_Cu && g.dx_Cv), "CorAdCalc: CORIOLIS_EN_DIS needs the metrics dy_Cu, dx_Cv");
   M6_REQUIRE(g.isc - g.isd >= 2 && g.ied - g.iec >= 2 && g.jsc - g.jsd >= 2 && g.jed - g.jec >= 2,
              "CorAdCalc: needs a halo of at least 2");
   hipStream_t s = ctx->stream;
@@ -206,7 +357,14 @@ extern "C" int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_c
   a.scheme = cs->coriolis_scheme; a.ke_scheme = cs->ke_scheme; a.no_slip = cs->no_slip; a.bound = cs->bound_coriolis;
   a.vol_neglect = g.H_subroundoff * (1e-4 * 1.0) * (1e-4 * 1.0);   // :241
   dim3 grid(g.nk, (g.iec - g.isc + 2 + TI - 1) / TI, (g.jec - g.jsc + 2 + TJ - 1) / TJ);
-  hipLaunchKernelGGL(coradcalc_kernel, grid, dim3(TI, TJ), 0, s, a);
+  a.en_dis = en_dis ? 1 : 0; a.upwind1 = cs->pv_adv_scheme == MOM6HIP_PV_ADV_UPWIND1 ? 1 : 0;
+  a.eps_vel = 1.0e-10 * 1.0; a.h_tiny = g.Angstrom_H;      // :242-243
+  a.wt_lin_blend = cs->wt_lin_blend;
+  a.Fe_m2 = cs->F_eff_max_blend - 2.0;                     // :544-548
+  a.rat_lin = 1.5 * a.Fe_m2 / fmax(cs->wt_lin_blend, 1.0e-16);
+  if (cs->F_eff_max_blend <= 2.0) { a.Fe_m2 = -1.; a.rat_lin = -1.0; }
+  if (ext) hipLaunchKernelGGL(coradcalc_kernel<true>, grid, dim3(TI, TJ), 0, s, a);
+  else hipLaunchKernelGGL(coradcalc_kernel<false>, grid, dim3(TI, TJ), 0, s, a);
   M6_HIP(hipGetLastError());
   if (memspace == MOM6HIP_MEM_HOST) {
     M6_HIP(hipMemcpyAsync(CAu, a.CAu, bU, hipMemcpyDeviceToHost, s));

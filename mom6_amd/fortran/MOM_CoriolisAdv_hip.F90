@@ -32,6 +32,7 @@ type, public :: CoriolisAdv_CS ; private
   logical :: initialized = .false.
   integer :: Coriolis_Scheme, KE_Scheme, PV_Adv_Scheme
   logical :: no_slip, bound_Coriolis, Coriolis_En_Dis
+  real :: F_eff_max_blend = 4.0, wt_lin_blend = 0.125
   type(diag_ctrl), pointer :: diag => NULL()
   type(time_type), pointer :: Time => NULL()
 end type CoriolisAdv_CS
@@ -80,7 +81,8 @@ subroutine CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Wav
 
   ccs%coriolis_scheme = CS%Coriolis_Scheme ; ccs%ke_scheme = CS%KE_Scheme
   ccs%no_slip = merge(1, 0, CS%no_slip) ; ccs%bound_coriolis = merge(1, 0, CS%bound_Coriolis)
-  ccs%coriolis_en_dis = merge(1, 0, CS%Coriolis_En_Dis) ; ccs%reserved(:) = 0
+  ccs%coriolis_en_dis = merge(1, 0, CS%Coriolis_En_Dis) ; ccs%pv_adv_scheme = CS%PV_Adv_Scheme ; ccs%reserved(:) = 0
+  ccs%F_eff_max_blend = CS%F_eff_max_blend ; ccs%wt_lin_blend = CS%wt_lin_blend
   rc = mom6hip_coradcalc(mom6hip_shared_context(G, GV), ccs, c_loc(u), c_loc(v), c_loc(h), c_loc(uh), c_loc(vh), c_loc(CAu), &
                          c_loc(CAv), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "MOM_CoriolisAdv")
@@ -115,16 +117,28 @@ subroutine CoriolisAdv_init(Time, G, GV, US, param_file, diag, AD, CS)
     case ("SADOURNY75_ENERGY") ; CS%Coriolis_Scheme = SADOURNY75_ENERGY
     case ("ARAKAWA_HSU90") ; CS%Coriolis_Scheme = ARAKAWA_HSU90
     case ("SADOURNY75_ENSTRO") ; CS%Coriolis_Scheme = SADOURNY75_ENSTRO
-    case ("ARAKAWA_LAMB81", "ARAKAWA_LAMB_BLEND", "ROBUST_ENSTRO")
-      call MOM_error(FATAL, "CoriolisAdv_init (HIP): CORIOLIS_SCHEME = "//trim(tmpstr)//" is not provided by the GPU path.")
+    case ("ROBUST_ENSTRO") ; CS%Coriolis_Scheme = ROBUST_ENSTRO
+    case ("ARAKAWA_LAMB81") ; CS%Coriolis_Scheme = ARAKAWA_LAMB81
+    case ("ARAKAWA_LAMB_BLEND") ; CS%Coriolis_Scheme = AL_BLEND
     case default
       call MOM_mesg('CoriolisAdv_init: Coriolis_Scheme ="'//trim(tmpstr)//'"', 0)
       call MOM_error(FATAL, "CoriolisAdv_init: Unrecognized setting #define CORIOLIS_SCHEME "//trim(tmpstr)//" found in input file.")
   end select
-  if (CS%Coriolis_En_Dis) call MOM_error(FATAL, "CoriolisAdv_init (HIP): CORIOLIS_EN_DIS is not provided by the GPU path.")
+  if (CS%Coriolis_Scheme == AL_BLEND) then      ! :1125-1142
+    call get_param(param_file, mdl, "CORIOLIS_BLEND_WT_LIN", CS%wt_lin_blend, &
+                 "A weighting value for the ratio of inverse thicknesses, beyond which the blending between Sadourny Energy "//&
+                 "and Arakawa & Hsu goes linearly to 0 when CORIOLIS_SCHEME is ARAWAKA_LAMB_BLEND.", units="nondim", default=0.125)
+    call get_param(param_file, mdl, "CORIOLIS_BLEND_F_EFF_MAX", CS%F_eff_max_blend, &
+                 "The factor by which the maximum effective Coriolis acceleration from any point can be increased when "//&
+                 "blending different discretizations with the ARAKAWA_LAMB_BLEND Coriolis scheme.", units="nondim", default=4.0)
+    CS%wt_lin_blend = min(1.0, max(CS%wt_lin_blend,1e-16))
+    if (CS%F_eff_max_blend < 2.0) call MOM_error(WARNING, "CoriolisAdv_init: CORIOLIS_BLEND_F_EFF_MAX should be at least 2.")
+  endif
   call get_param(param_file, mdl, "BOUND_CORIOLIS", CS%bound_Coriolis, &
                  "If true, the Coriolis terms at u-points are bounded by the four estimates of (f+rv)v from the four "//&
                  "neighboring v-points, and similarly at v-points.", default=.false.)
+  if ((CS%Coriolis_En_Dis .and. (CS%Coriolis_Scheme == SADOURNY75_ENERGY)) .or. &      ! :1155-1156
+      (CS%Coriolis_Scheme == ROBUST_ENSTRO)) CS%bound_Coriolis = .false.
   call get_param(param_file, mdl, "KE_SCHEME", tmpstr, &
                  "KE_SCHEME selects the discretization for acceleration due to the kinetic energy gradient.", default="KE_ARAKAWA")
   select case (uppercase(tmpstr))
@@ -139,8 +153,7 @@ subroutine CoriolisAdv_init(Time, G, GV, US, param_file, diag, AD, CS)
                  "PV_ADV_SCHEME selects the discretization for PV advection.", default="PV_ADV_CENTERED")
   select case (uppercase(tmpstr))
     case ("PV_ADV_CENTERED") ; CS%PV_Adv_Scheme = PV_ADV_CENTERED
-    case ("PV_ADV_UPWIND1")
-      call MOM_error(FATAL, "CoriolisAdv_init (HIP): PV_ADV_SCHEME = PV_ADV_UPWIND1 is not provided by the GPU path.")
+    case ("PV_ADV_UPWIND1") ; CS%PV_Adv_Scheme = PV_ADV_UPWIND1
     case default
       call MOM_mesg('CoriolisAdv_init: PV_Adv_Scheme ="'//trim(tmpstr)//'"', 0)
       call MOM_error(FATAL, "CoriolisAdv_init: #DEFINE PV_ADV_SCHEME in input file is invalid.")

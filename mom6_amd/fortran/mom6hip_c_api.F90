@@ -57,8 +57,9 @@ end type mom6hip_regridding_cs_t
 
 !> mom6hip_coriolisadv_cs_t (CoriolisAdv_CS, src/core/MOM_CoriolisAdv.F90:30)
 type, bind(c) :: mom6hip_coriolisadv_cs_t
-  integer(c_int32_t) :: coriolis_scheme, ke_scheme, no_slip, bound_coriolis, coriolis_en_dis
-  integer(c_int32_t) :: reserved(3)
+  integer(c_int32_t) :: coriolis_scheme, ke_scheme, no_slip, bound_coriolis, coriolis_en_dis, pv_adv_scheme
+  integer(c_int32_t) :: reserved(2)
+  real(c_double) :: F_eff_max_blend, wt_lin_blend
 end type mom6hip_coriolisadv_cs_t
 
 !> mom6hip_continuity_cs_t (continuity_PPM_CS, src/core/MOM_continuity_PPM.F90:35)

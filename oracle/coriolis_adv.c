@@ -3,8 +3,9 @@
  *
  * Restates src/core/MOM_CoriolisAdv.F90:125-965 (CorAdCalc) and :969-1051 (gradKE) for the configuration
  * of the hot path: OBC not associated, no Stokes vortex force, porous barriers = 1, no acceleration
- * diagnostics, CORIOLIS_EN_DIS = False.  Coriolis schemes SADOURNY75_ENERGY (default), SADOURNY75_ENSTRO and
- * ARAKAWA_HSU90; KE schemes KE_ARAKAWA (default), KE_SIMPLE_GUDONOV, KE_GUDONOV; NOSLIP and BOUND_CORIOLIS.
+ * diagnostics.  All six Coriolis schemes (SADOURNY75_ENERGY (default, with or without CORIOLIS_EN_DIS), ARAKAWA_HSU90,
+ * ROBUST_ENSTRO with both PV_ADV_SCHEMEs, SADOURNY75_ENSTRO, ARAKAWA_LAMB81, ARAKAWA_LAMB_BLEND); KE schemes KE_ARAKAWA
+ * (default), KE_SIMPLE_GUDONOV, KE_GUDONOV; NOSLIP and BOUND_CORIOLIS.
  *
  * PARITY UNPINNED: the reference holds no known-answer vectors for CorAdCalc.
  */
@@ -23,8 +24,13 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
   const double vol_neglect = G->H_subroundoff * (1e-4 * 1.0)*(1e-4 * 1.0);   /* :241, US%m_to_L = 1 */
-  const double C1_12 = 1.0 / 12.0;
-  if (CS->coriolis_en_dis) return 1;
+  const double C1_12 = 1.0 / 12.0, C1_24 = 1.0 / 24.0;
+  const double eps_vel = 1.0e-10 * 1.0, h_tiny = G->Angstrom_H;             /* :242-243, US%m_s_to_L_T = 1 */
+  const int sch = CS->coriolis_scheme;
+  const int al = (sch == MOM6HIP_ARAKAWA_LAMB81) || (sch == MOM6HIP_AL_BLEND);
+  const int en_dis = CS->coriolis_en_dis != 0;
+  const int upwind1 = CS->pv_adv_scheme == MOM6HIP_PV_ADV_UPWIND1;
+  if (sch < MOM6HIP_SADOURNY75_ENERGY || sch > MOM6HIP_AL_BLEND) return 1;
   const long nH = (long)ORC_NIH(G)*ORC_NJH(G), nU = (long)(ORC_NIH(G)+1)*ORC_NJH(G);
   const long nV = (long)ORC_NIH(G)*(ORC_NJH(G)+1), nQ = (long)(ORC_NIH(G)+1)*(ORC_NJH(G)+1);
   double *Area_h = calloc(nH, 8), *Area_q = calloc(nQ, 8);
@@ -50,6 +56,8 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   double *abs_vort = calloc(nQ, 8), *dvdx = calloc(nQ, 8), *dudy = calloc(nQ, 8), *rel_vort = calloc(nQ, 8);
   double *hArea_u = calloc(nU, 8), *hArea_v = calloc(nV, 8), *KE = calloc(nH, 8), *KEx = calloc(nU, 8), *KEy = calloc(nV, 8);
   double *a = calloc(nU, 8), *b = calloc(nU, 8), *c = calloc(nU, 8), *d = calloc(nU, 8);
+  double *ep_u = calloc(nH, 8), *ep_v = calloc(nH, 8);
+  double *uh_min = calloc(nU, 8), *uh_max = calloc(nU, 8), *vh_min = calloc(nV, 8), *vh_max = calloc(nV, 8);
   _Pragma("omp for schedule(static)")
   for (int k = 1; k <= nz; k++) {
     /* :314-324 */
@@ -83,7 +91,7 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
       q[Q2(I,J)] = abs_vort[Q2(I,J)] * Ih_q[Q2(I,J)];
     }
     /* :523-533 */
-    if (CS->coriolis_scheme == MOM6HIP_ARAKAWA_HSU90) {
+    if (sch == MOM6HIP_ARAKAWA_HSU90) {
       for (int j = Jsq; j <= Jeq+1; j++) {
         const int J = j;
         for (int I = is-1; I <= Ieq; I++) {
@@ -94,6 +102,83 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
           b[U2(I,j)] = (q[Q2(I,J)] + (q[Q2(I-1,J)] + q[Q2(I,J-1)])) * C1_12;
           c[U2(I,j)] = ((q[Q2(I,J)] + q[Q2(I-1,J-1)]) + q[Q2(I,J-1)]) * C1_12;
         }
+      }
+    }
+    else if (sch == MOM6HIP_ARAKAWA_LAMB81) {                    /* :534-542 */
+      for (int j = Jsq; j <= Jeq+1; j++) for (int I = Isq; I <= Ieq+1; I++) {
+        const int J = j, i = I;
+        a[U2(I-1,j)] = (2.0*(q[Q2(I,J)] + q[Q2(I-1,J-1)]) + (q[Q2(I-1,J)] + q[Q2(I,J-1)])) * C1_24;
+        d[U2(I-1,j)] = ((q[Q2(I,J)] + q[Q2(I-1,J-1)]) + 2.0*(q[Q2(I-1,J)] + q[Q2(I,J-1)])) * C1_24;
+        b[U2(I,j)] =   ((q[Q2(I,J)] + q[Q2(I-1,J-1)]) + 2.0*(q[Q2(I-1,J)] + q[Q2(I,J-1)])) * C1_24;
+        c[U2(I,j)] =   (2.0*(q[Q2(I,J)] + q[Q2(I-1,J-1)]) + (q[Q2(I-1,J)] + q[Q2(I,J-1)])) * C1_24;
+        ep_u[H2(i,j)] = ((q[Q2(I,J)] - q[Q2(I-1,J-1)]) + (q[Q2(I-1,J)] - q[Q2(I,J-1)])) * C1_24;
+        ep_v[H2(i,j)] = (-(q[Q2(I,J)] - q[Q2(I-1,J-1)]) + (q[Q2(I-1,J)] - q[Q2(I,J-1)])) * C1_24;
+      }
+    } else if (sch == MOM6HIP_AL_BLEND) {                        /* :543-590 */
+      double Fe_m2 = CS->F_eff_max_blend - 2.0;
+      double rat_lin = 1.5 * Fe_m2 / max2(CS->wt_lin_blend, 1.0e-16);
+      if (CS->F_eff_max_blend <= 2.0) { Fe_m2 = -1.; rat_lin = -1.0; }
+      for (int j = Jsq; j <= Jeq+1; j++) for (int I = Isq; I <= Ieq+1; I++) {
+        const int J = j, i = I;
+        const double min_Ihq = min4(Ih_q[Q2(I-1,J-1)], Ih_q[Q2(I,J-1)], Ih_q[Q2(I-1,J)], Ih_q[Q2(I,J)]);
+        const double max_Ihq = max4(Ih_q[Q2(I-1,J-1)], Ih_q[Q2(I,J-1)], Ih_q[Q2(I-1,J)], Ih_q[Q2(I,J)]);
+        double rat_m1 = 1.0e15;
+        if (max_Ihq < 1.0e15*min_Ihq) rat_m1 = max_Ihq / min_Ihq - 1.0;
+        double AL_wt, Sad_wt;
+        if (rat_m1 <= Fe_m2) AL_wt = 1.0;
+        else if (rat_m1 < 1.5*Fe_m2) AL_wt = 3.0*Fe_m2 / rat_m1 - 2.0;
+        else AL_wt = 0.0;
+        if (rat_m1 <= 1.5*Fe_m2) Sad_wt = 0.0;
+        else if (rat_m1 <= rat_lin) Sad_wt = 1.0 - (1.5*Fe_m2) / rat_m1;
+        else if (rat_m1 < 2.0*rat_lin) Sad_wt = 1.0 - (CS->wt_lin_blend / rat_lin) * (rat_m1 - 2.0*rat_lin);
+        else Sad_wt = 1.0;
+        a[U2(I-1,j)] = Sad_wt * 0.25 * q[Q2(I-1,J)] + (1.0 - Sad_wt) *
+                   ( ((2.0-AL_wt)* q[Q2(I-1,J)] + AL_wt*q[Q2(I,J-1)]) +
+                      2.0 * (q[Q2(I,J)] + q[Q2(I-1,J-1)]) ) * C1_24;
+        d[U2(I-1,j)] = Sad_wt * 0.25 * q[Q2(I-1,J-1)] + (1.0 - Sad_wt) *
+                   ( ((2.0-AL_wt)* q[Q2(I-1,J-1)] + AL_wt*q[Q2(I,J)]) +
+                      2.0 * (q[Q2(I-1,J)] + q[Q2(I,J-1)]) ) * C1_24;
+        b[U2(I,j)] =   Sad_wt * 0.25 * q[Q2(I,J)] + (1.0 - Sad_wt) *
+                   ( ((2.0-AL_wt)* q[Q2(I,J)] + AL_wt*q[Q2(I-1,J-1)]) +
+                      2.0 * (q[Q2(I-1,J)] + q[Q2(I,J-1)]) ) * C1_24;
+        c[U2(I,j)] =   Sad_wt * 0.25 * q[Q2(I,J-1)] + (1.0 - Sad_wt) *
+                   ( ((2.0-AL_wt)* q[Q2(I,J-1)] + AL_wt*q[Q2(I-1,J)]) +
+                      2.0 * (q[Q2(I,J)] + q[Q2(I-1,J-1)]) ) * C1_24;
+        ep_u[H2(i,j)] = AL_wt  * ((q[Q2(I,J)] - q[Q2(I-1,J-1)]) + (q[Q2(I-1,J)] - q[Q2(I,J-1)])) * C1_24;
+        ep_v[H2(i,j)] = AL_wt * (-(q[Q2(I,J)] - q[Q2(I-1,J-1)]) + (q[Q2(I-1,J)] - q[Q2(I,J-1)])) * C1_24;
+      }
+    }
+    if (en_dis) {                                               /* :326-333, :594-642 */
+      const double c1 = 1.0-1.5*0.5, c2 = 1.0-0.5, c3 = 2.0, slope = 0.5;
+      for (int j = Jsq; j <= Jeq+1; j++) for (int I = is-1; I <= ie; I++) {
+        const int i = I;
+        double uhc = 0.5 * ((G->dy_Cu[U2(I,j)]*1.0) * u[U3(I,j,k)]) * (h[H3(i,j,k)] + h[H3(i+1,j,k)]);      /* uh_center :328 */
+        double uhm = uh[U3(I,j,k)];
+        if (G->dy_Cu[U2(I,j)] == 0.0) uhc = uhm;
+        if (fabs(uhc) < 0.1*fabs(uhm)) {
+          uhm = 10.0*uhc;
+        } else if (fabs(uhc) > c1*fabs(uhm)) {
+          if (fabs(uhc) < c2*fabs(uhm)) uhc = (3.0*uhc+(1.0-c2*3.0)*uhm);
+          else if (fabs(uhc) <= c3*fabs(uhm)) uhc = uhm;
+          else uhc = slope*uhc+(1.0-c3*slope)*uhm;
+        }
+        if (uhc > uhm) { uh_min[U2(I,j)] = uhm; uh_max[U2(I,j)] = uhc; }
+        else { uh_max[U2(I,j)] = uhm; uh_min[U2(I,j)] = uhc; }
+      }
+      for (int J = js-1; J <= je; J++) for (int i = Isq; i <= Ieq+1; i++) {
+        const int j = J;
+        double vhc = 0.5 * ((G->dx_Cv[V2(i,J)]*1.0) * v[V3(i,J,k)]) * (h[H3(i,j,k)] + h[H3(i,j+1,k)]);      /* vh_center :331 */
+        double vhm = vh[V3(i,J,k)];
+        if (G->dx_Cv[V2(i,J)] == 0.0) vhc = vhm;
+        if (fabs(vhc) < 0.1*fabs(vhm)) {
+          vhm = 10.0*vhc;
+        } else if (fabs(vhc) > c1*fabs(vhm)) {
+          if (fabs(vhc) < c2*fabs(vhm)) vhc = (3.0*vhc+(1.0-c2*3.0)*vhm);
+          else if (fabs(vhc) <= c3*fabs(vhm)) vhc = vhm;
+          else vhc = slope*vhc+(1.0-c3*slope)*vhm;
+        }
+        if (vhc > vhm) { vh_min[V2(i,J)] = vhm; vh_max[V2(i,J)] = vhc; }
+        else { vh_max[V2(i,J)] = vhm; vh_min[V2(i,J)] = vhc; }
       }
     }
     /* gradKE, :994-1035 */
@@ -128,17 +213,59 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
       const int i = I, J = j;
       double ca;
-      if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY) {
+      if (sch == MOM6HIP_SADOURNY75_ENERGY && en_dis) {        /* :645-665; vh_max(i,j) is the face (i, J=j) */
+        double temp1, temp2;
+        if (q[Q2(I,J)]*u[U3(I,j,k)] == 0.0)
+          temp1 = q[Q2(I,J)] * ( (vh_max[V2(i,j)]+vh_max[V2(i+1,j)])
+                               + (vh_min[V2(i,j)]+vh_min[V2(i+1,j)]) )*0.5;
+        else if (q[Q2(I,J)]*u[U3(I,j,k)] < 0.0)
+          temp1 = q[Q2(I,J)] * (vh_max[V2(i,j)]+vh_max[V2(i+1,j)]);
+        else
+          temp1 = q[Q2(I,J)] * (vh_min[V2(i,j)]+vh_min[V2(i+1,j)]);
+        if (q[Q2(I,J-1)]*u[U3(I,j,k)] == 0.0)
+          temp2 = q[Q2(I,J-1)] * ( (vh_max[V2(i,j-1)]+vh_max[V2(i+1,j-1)])
+                                 + (vh_min[V2(i,j-1)]+vh_min[V2(i+1,j-1)]) )*0.5;
+        else if (q[Q2(I,J-1)]*u[U3(I,j,k)] < 0.0)
+          temp2 = q[Q2(I,J-1)] * (vh_max[V2(i,j-1)]+vh_max[V2(i+1,j-1)]);
+        else
+          temp2 = q[Q2(I,J-1)] * (vh_min[V2(i,j-1)]+vh_min[V2(i+1,j-1)]);
+        ca = 0.25 * G->IdxCu[U2(I,j)] * (temp1 + temp2);
+      } else if (sch == MOM6HIP_SADOURNY75_ENERGY) {
         ca = 0.25 *
             (q[Q2(I,J)] * (vh[V3(i+1,J,k)] + vh[V3(i,J,k)]) +
              q[Q2(I,J-1)] * (vh[V3(i,J-1,k)] + vh[V3(i+1,J-1,k)])) * G->IdxCu[U2(I,j)];
-      } else if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENSTRO) {
+      } else if (sch == MOM6HIP_SADOURNY75_ENSTRO) {
         ca = 0.125 * (G->IdxCu[U2(I,j)] * (q[Q2(I,J)] + q[Q2(I,J-1)])) *
                      ((vh[V3(i+1,J,k)] + vh[V3(i,J,k)]) + (vh[V3(i,J-1,k)] + vh[V3(i+1,J-1,k)]));
+      } else if (sch == MOM6HIP_ROBUST_ENSTRO) {                 /* :687-714 */
+        double Heff1 = fabs(vh[V3(i,J,k)] * G->IdxCv[V2(i,J)]) / (eps_vel+fabs(v[V3(i,J,k)]));
+        Heff1 = max2(Heff1, min2(h[H3(i,j,k)],h[H3(i,j+1,k)]));
+        Heff1 = min2(Heff1, max2(h[H3(i,j,k)],h[H3(i,j+1,k)]));
+        double Heff2 = fabs(vh[V3(i,J-1,k)] * G->IdxCv[V2(i,J-1)]) / (eps_vel+fabs(v[V3(i,J-1,k)]));
+        Heff2 = max2(Heff2, min2(h[H3(i,j-1,k)],h[H3(i,j,k)]));
+        Heff2 = min2(Heff2, max2(h[H3(i,j-1,k)],h[H3(i,j,k)]));
+        double Heff3 = fabs(vh[V3(i+1,J,k)] * G->IdxCv[V2(i+1,J)]) / (eps_vel+fabs(v[V3(i+1,J,k)]));
+        Heff3 = max2(Heff3, min2(h[H3(i+1,j,k)],h[H3(i+1,j+1,k)]));
+        Heff3 = min2(Heff3, max2(h[H3(i+1,j,k)],h[H3(i+1,j+1,k)]));
+        double Heff4 = fabs(vh[V3(i+1,J-1,k)] * G->IdxCv[V2(i+1,J-1)]) / (eps_vel+fabs(v[V3(i+1,J-1,k)]));
+        Heff4 = max2(Heff4, min2(h[H3(i+1,j-1,k)],h[H3(i+1,j,k)]));
+        Heff4 = min2(Heff4, max2(h[H3(i+1,j-1,k)],h[H3(i+1,j,k)]));
+        if (!upwind1) {
+          ca = 0.5*(abs_vort[Q2(I,J)]+abs_vort[Q2(I,J-1)]) *
+                       ((vh[V3(i,J,k)] + vh[V3(i+1,J-1,k)]) + (vh[V3(i,J-1,k)] + vh[V3(i+1,J,k)]) ) /
+                       (h_tiny + ((Heff1+Heff4) + (Heff2+Heff3)) ) * G->IdxCu[U2(I,j)];
+        } else {
+          const double VHeff = ((vh[V3(i,J,k)] + vh[V3(i+1,J-1,k)]) + (vh[V3(i,J-1,k)] + vh[V3(i+1,J,k)]) );
+          const double QVHeff = 0.5*( (abs_vort[Q2(I,J)]+abs_vort[Q2(I,J-1)])*VHeff
+                                     -(abs_vort[Q2(I,J)]-abs_vort[Q2(I,J-1)])*fabs(VHeff) );
+          ca = (QVHeff / ( h_tiny + ((Heff1+Heff4) + (Heff2+Heff3)) ) ) * G->IdxCu[U2(I,j)];
+        }
       } else {
         ca = ((a[U2(I,j)] * vh[V3(i+1,J,k)] +  c[U2(I,j)] * vh[V3(i,J-1,k)])  +
               (b[U2(I,j)] * vh[V3(i,J,k)] +  d[U2(I,j)] * vh[V3(i+1,J-1,k)])) * G->IdxCu[U2(I,j)];
       }
+      if (al)                                                    /* :717-721 */
+        ca = ca + (ep_u[H2(i,j)]*uh[U3(I-1,j,k)] - ep_u[H2(i+1,j)]*uh[U3(I+1,j,k)]) * G->IdxCu[U2(I,j)];
       if (CS->bound_coriolis) {
         double fv1 = abs_vort[Q2(I,J)] * v[V3(i+1,J,k)];
         double fv2 = abs_vort[Q2(I,J)] * v[V3(i,J,k)];
@@ -154,19 +281,64 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) {
       const int I = i, j = J;
       double ca;
-      if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY) {
+      if (sch == MOM6HIP_SADOURNY75_ENERGY && en_dis) {        /* :764-785; uh_max(i-1,j) is the face (I-1, j) */
+        double temp1, temp2;
+        if (q[Q2(I-1,J)]*v[V3(i,J,k)] == 0.0)
+          temp1 = q[Q2(I-1,J)] * ( (uh_max[U2(i-1,j)]+uh_max[U2(i-1,j+1)])
+                                 + (uh_min[U2(i-1,j)]+uh_min[U2(i-1,j+1)]) )*0.5;
+        else if (q[Q2(I-1,J)]*v[V3(i,J,k)] > 0.0)
+          temp1 = q[Q2(I-1,J)] * (uh_max[U2(i-1,j)]+uh_max[U2(i-1,j+1)]);
+        else
+          temp1 = q[Q2(I-1,J)] * (uh_min[U2(i-1,j)]+uh_min[U2(i-1,j+1)]);
+        if (q[Q2(I,J)]*v[V3(i,J,k)] == 0.0)
+          temp2 = q[Q2(I,J)] * ( (uh_max[U2(i,j)]+uh_max[U2(i,j+1)])
+                               + (uh_min[U2(i,j)]+uh_min[U2(i,j+1)]) )*0.5;
+        else if (q[Q2(I,J)]*v[V3(i,J,k)] > 0.0)
+          temp2 = q[Q2(I,J)] * (uh_max[U2(i,j)]+uh_max[U2(i,j+1)]);
+        else
+          temp2 = q[Q2(I,J)] * (uh_min[U2(i,j)]+uh_min[U2(i,j+1)]);
+        ca = -0.25 * G->IdyCv[V2(i,J)] * (temp1 + temp2);
+      } else if (sch == MOM6HIP_SADOURNY75_ENERGY) {
         ca = - 0.25*
               (q[Q2(I-1,J)]*(uh[U3(I-1,j,k)] + uh[U3(I-1,j+1,k)]) +
                q[Q2(I,J)]*(uh[U3(I,j,k)] + uh[U3(I,j+1,k)])) * G->IdyCv[V2(i,J)];
-      } else if (CS->coriolis_scheme == MOM6HIP_SADOURNY75_ENSTRO) {
+      } else if (sch == MOM6HIP_SADOURNY75_ENSTRO) {
         ca = -0.125 * (G->IdyCv[V2(i,J)] * (q[Q2(I-1,J)] + q[Q2(I,J)])) *
                      ((uh[U3(I-1,j,k)] + uh[U3(I-1,j+1,k)]) + (uh[U3(I,j,k)] + uh[U3(I,j+1,k)]));
+      } else if (sch == MOM6HIP_ROBUST_ENSTRO) {                 /* :808-838 */
+        double Heff1 = fabs(uh[U3(I,j,k)] * G->IdyCu[U2(I,j)]) / (eps_vel+fabs(u[U3(I,j,k)]));
+        Heff1 = max2(Heff1, min2(h[H3(i,j,k)],h[H3(i+1,j,k)]));
+        Heff1 = min2(Heff1, max2(h[H3(i,j,k)],h[H3(i+1,j,k)]));
+        double Heff2 = fabs(uh[U3(I-1,j,k)] * G->IdyCu[U2(I-1,j)]) / (eps_vel+fabs(u[U3(I-1,j,k)]));
+        Heff2 = max2(Heff2, min2(h[H3(i-1,j,k)],h[H3(i,j,k)]));
+        Heff2 = min2(Heff2, max2(h[H3(i-1,j,k)],h[H3(i,j,k)]));
+        double Heff3 = fabs(uh[U3(I,j+1,k)] * G->IdyCu[U2(I,j+1)]) / (eps_vel+fabs(u[U3(I,j+1,k)]));
+        Heff3 = max2(Heff3, min2(h[H3(i,j+1,k)],h[H3(i+1,j+1,k)]));
+        Heff3 = min2(Heff3, max2(h[H3(i,j+1,k)],h[H3(i+1,j+1,k)]));
+        double Heff4 = fabs(uh[U3(I-1,j+1,k)] * G->IdyCu[U2(I-1,j+1)]) / (eps_vel+fabs(u[U3(I-1,j+1,k)]));
+        Heff4 = max2(Heff4, min2(h[H3(i-1,j+1,k)],h[H3(i,j+1,k)]));
+        Heff4 = min2(Heff4, max2(h[H3(i-1,j+1,k)],h[H3(i,j+1,k)]));
+        if (!upwind1) {
+          ca = - 0.5*(abs_vort[Q2(I,J)]+abs_vort[Q2(I-1,J)]) *
+                         ((uh[U3(I  ,j  ,k)]+uh[U3(I-1,j+1,k)]) +
+                          (uh[U3(I-1,j  ,k)]+uh[U3(I  ,j+1,k)]) ) /
+                      (h_tiny + ((Heff1+Heff4) +(Heff2+Heff3)) ) * G->IdyCv[V2(i,J)];
+        } else {
+          const double UHeff = ((uh[U3(I  ,j  ,k)]+uh[U3(I-1,j+1,k)]) +
+                                (uh[U3(I-1,j  ,k)]+uh[U3(I  ,j+1,k)]) );
+          const double QUHeff = 0.5*( (abs_vort[Q2(I,J)]+abs_vort[Q2(I-1,J)])*UHeff
+                                     -(abs_vort[Q2(I,J)]-abs_vort[Q2(I-1,J)])*fabs(UHeff) );
+          ca = - QUHeff /
+                       (h_tiny + ((Heff1+Heff4) +(Heff2+Heff3)) ) * G->IdyCv[V2(i,J)];
+        }
       } else {
         ca = - ((a[U2(I-1,j)]   * uh[U3(I-1,j,k)] +
                  c[U2(I,j+1)]   * uh[U3(I,j+1,k)])
               + (b[U2(I,j)]     * uh[U3(I,j,k)] +
                  d[U2(I-1,j+1)] * uh[U3(I-1,j+1,k)])) * G->IdyCv[V2(i,J)];
       }
+      if (al)                                                    /* :841-845 */
+        ca = ca + (ep_v[H2(i,j)]*vh[V3(i,J-1,k)] - ep_v[H2(i,j+1)]*vh[V3(i,J+1,k)]) * G->IdyCv[V2(i,J)];
       if (CS->bound_coriolis) {
         double fu1 = -abs_vort[Q2(I,J)] * u[U3(I,j+1,k)];
         double fu2 = -abs_vort[Q2(I,J)] * u[U3(I,j,k)];
@@ -181,6 +353,7 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   }
   free(q); free(Ih_q); free(abs_vort); free(dvdx); free(dudy); free(rel_vort);
   free(hArea_u); free(hArea_v); free(KE); free(KEx); free(KEy); free(a); free(b); free(c); free(d);
+  free(ep_u); free(ep_v); free(uh_min); free(uh_max); free(vh_min); free(vh_max);
   }
   free(Area_h); free(Area_q);
   return 0;

@@ -231,12 +231,16 @@ def ale_remap_tracers(grid, scheme, h_old, h_new, tr, conc_underflow=None, bound
 
 
 def coradcalc(grid, u, v, h, uh, vh, coriolis_scheme="SADOURNY75_ENERGY", ke_scheme="KE_ARAKAWA", no_slip=False,
-              bound_coriolis=False):
+              bound_coriolis=False, coriolis_en_dis=False, pv_adv_scheme="PV_ADV_CENTERED", coriolis_blend_wt_lin=0.125,
+              coriolis_blend_f_eff_max=4.0):
     """CorAdCalc on numpy arrays; returns (CAu, CAv) (zero outside the computed ranges)."""
     L = lib()
     L.orc_coradcalc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.CoriolisAdvCS)] + [_dp] * 7
+    if (coriolis_en_dis and coriolis_scheme == "SADOURNY75_ENERGY") or coriolis_scheme == "ROBUST_ENSTRO":
+        bound_coriolis = False      # CoriolisAdv_init :1155-1156
     cs = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES[coriolis_scheme], _abi.KE_SCHEMES[ke_scheme], int(no_slip),
-                            int(bound_coriolis), 0)
+                            int(bound_coriolis), int(bool(coriolis_en_dis)), _abi.PV_ADV_SCHEMES[pv_adv_scheme])
+    cs.F_eff_max_blend = float(coriolis_blend_f_eff_max); cs.wt_lin_blend = min(1.0, max(float(coriolis_blend_wt_lin), 1e-16))
     CAu = np.zeros_like(u); CAv = np.zeros_like(v)
     rc = L.orc_coradcalc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(uh), _p(vh), _p(CAu), _p(CAv))
     if rc:
@@ -452,6 +456,7 @@ class DynState:
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
         self.ccs = continuity_cs(g.nk, g.Angstrom_H)
         self.cor = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES["SADOURNY75_ENERGY"], _abi.KE_SCHEMES["KE_ARAKAWA"], 0, int(bound_coriolis), 0)
+        self.cor.F_eff_max_blend, self.cor.wt_lin_blend = 4.0, 0.125
         self.pcs = pressureforce_cs(g)
         self.eos = eos(eos_form)
         self.bt_arrs, self.bt = make_bt_cont(g, with_h=True) if use_bt_cont else ({}, None)

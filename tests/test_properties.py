@@ -102,7 +102,7 @@ def check_rotation_of_operators(ops, reentrant):
     assert same(interior(g, vh_b, _abi.POS_V), interior(g, vh, _abi.POS_V)), "continuity: vh"
     assert np.abs(uh).max() > 0 and np.abs(vh).max() > 0
     # CorAdCalc (every Coriolis scheme the library has)
-    for sch in ("SADOURNY75_ENERGY", "ARAKAWA_HSU90", "SADOURNY75_ENSTRO"):
+    for sch in ("SADOURNY75_ENERGY", "ARAKAWA_HSU90", "SADOURNY75_ENSTRO", "ARAKAWA_LAMB81", "ARAKAWA_LAMB_BLEND", "ROBUST_ENSTRO"):
         for a, pos in ((uh, _abi.POS_U), (vh, _abi.POS_V)):
             orc.halo_update(g, a, pos)
         uh_r, vh_r = rot_vector(uh, vh)
