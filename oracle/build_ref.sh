@@ -15,6 +15,7 @@ mkdir -p "$OUT/mod"
 FLAGS="-fdefault-real-8 -O0 -ffp-contract=off -fPIC -J $OUT/mod -I $OUT/mod"
 $FC $FLAGS -c "$REF/src/ALE/PCM_functions.F90" -o "$OUT/PCM_functions.o"
 $FC $FLAGS -c "$REF/src/ALE/PLM_functions.F90" -o "$OUT/PLM_functions.o"
+$FC $FLAGS -c "$REF/src/framework/MOM_array_transform.F90" -o "$OUT/MOM_array_transform.o"
 $FC $FLAGS -c "$HERE/ref_wrap.F90" -o "$OUT/ref_wrap.o"
-$FC -shared -o "$OUT/libmom6ref.so" "$OUT/PCM_functions.o" "$OUT/PLM_functions.o" "$OUT/ref_wrap.o"
+$FC -shared -o "$OUT/libmom6ref.so" "$OUT/PCM_functions.o" "$OUT/PLM_functions.o" "$OUT/MOM_array_transform.o" "$OUT/ref_wrap.o"
 echo "built $OUT/libmom6ref.so"

@@ -214,6 +214,9 @@ def ref_lib():
     L.ref_plm_slope_wa.argtypes = [d] * 7; L.ref_plm_slope_wa.restype = d
     L.ref_plm_monotonized_slope.argtypes = [d] * 6; L.ref_plm_monotonized_slope.restype = d
     L.ref_plm_extrapolate_slope.argtypes = [d] * 5; L.ref_plm_extrapolate_slope.restype = d
+    if hasattr(L, "ref_rotate_array"):
+        L.ref_rotate_array.argtypes = [i, i, i, _dp, i, _dp]; L.ref_rotate_array.restype = None
+        L.ref_rotate_vector.argtypes = [i] * 5 + [_dp, _dp, i, _dp, _dp]; L.ref_rotate_vector.restype = None
     return L
 
 

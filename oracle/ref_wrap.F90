@@ -1,5 +1,6 @@
 !> bind(C) entry points around the reference routines that compile from their own source files with
-!! no stand-ins (src/ALE/PLM_functions.F90, PCM_functions.F90: no `use` of any other module).
+!! no stand-ins (src/ALE/PLM_functions.F90, PCM_functions.F90, src/framework/MOM_array_transform.F90: no `use` of any
+!! other module).
 !! This file is ours (a caller of the reference, not a copy of it); the reference sources are
 !! compiled where they lie under /root/reference by oracle/build_ref.sh into oracle/_ref/.
 module mom6_ref_wrap
@@ -7,6 +8,7 @@ use, intrinsic :: iso_c_binding
 use PLM_functions, only : PLM_reconstruction, PLM_boundary_extrapolation, PLM_slope_wa, &
                           PLM_monotonized_slope, PLM_extrapolate_slope
 use PCM_functions, only : PCM_reconstruction
+use MOM_array_transform, only : rotate_array, rotate_vector
 implicit none
 contains
 
@@ -44,5 +46,32 @@ function ref_plm_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c) bind(c, name="
   real(c_double) :: s
   s = PLM_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c)
 end function ref_plm_extrapolate_slope
+
+!> rotate_array (src/framework/MOM_array_transform.F90:26) of a 3-D field: A_in(m,n,nk) -> A (n,m,nk for odd turns)
+subroutine ref_rotate_array(m, n, nk, A_in, turns, A) bind(c, name="ref_rotate_array")
+  integer(c_int), value :: m, n, nk, turns
+  real(c_double), intent(in) :: A_in(m,n,nk)
+  real(c_double), intent(inout) :: A(*)
+  real(c_double), allocatable :: R(:,:,:)
+  if (modulo(turns, 2) /= 0) then ; allocate(R(n,m,nk)) ; else ; allocate(R(m,n,nk)) ; endif
+  call rotate_array(A_in, turns, R)
+  A(1:size(R)) = reshape(R, (/ size(R) /))
+end subroutine ref_rotate_array
+
+!> rotate_vector (:54) of a C-grid vector field on symmetric memory: u(mu,nu,nk), v(mv,nv,nk) -> the turned pair
+subroutine ref_rotate_vector(mu, nu, mv, nv, nk, u_in, v_in, turns, u, v) bind(c, name="ref_rotate_vector")
+  integer(c_int), value :: mu, nu, mv, nv, nk, turns
+  real(c_double), intent(in) :: u_in(mu,nu,nk), v_in(mv,nv,nk)
+  real(c_double), intent(inout) :: u(*), v(*)
+  real(c_double), allocatable :: Ru(:,:,:), Rv(:,:,:)
+  if (modulo(turns, 2) /= 0) then
+    allocate(Ru(nv,mv,nk)) ; allocate(Rv(nu,mu,nk))      ! the turned u points are the v points and the other way round
+  else
+    allocate(Ru(mu,nu,nk)) ; allocate(Rv(mv,nv,nk))
+  endif
+  call rotate_vector(u_in, v_in, turns, Ru, Rv)
+  u(1:size(Ru)) = reshape(Ru, (/ size(Ru) /))
+  v(1:size(Rv)) = reshape(Rv, (/ size(Rv) /))
+end subroutine ref_rotate_vector
 
 end module mom6_ref_wrap

@@ -288,3 +288,45 @@ def test_oracle_rescaling_by_powers_of_two():
 @pytest.mark.gpu
 def test_hip_rescaling_by_powers_of_two():
     check_rescaling(HipOps())
+
+
+# ---- the quarter turn itself, against the reference's own code (oracle/_ref; only where it was built) ------------------------
+def test_quarter_turn_is_the_reference_rotation():
+    """tests/rotation.py turns fields and C-grid vectors the way MOM6's rotated-grid runs do: rot(A) is rotate_array(A, turns = -1)
+    of src/framework/MOM_array_transform.F90 (compiled unmodified into oracle/_ref), rot_vector is rotate_vector with the same
+    turn, unrot / unrot_vector are the turn back -- so the rotation property above is the reference's ROTATE_INDEX test with
+    INDEX_TURNS = -1 (the reference's suite uses +1; a scheme that reproduces under one reproduces under the other, and the
+    round trip below runs both)."""
+    import ctypes as C
+    R = orc.ref_lib()
+    if R is None or not hasattr(R, "ref_rotate_array"):
+        pytest.skip("oracle/_ref not built (the reference sources only exist in the build container)")
+    dp = C.POINTER(C.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    rng = np.random.default_rng(7)
+    nk, nj, ni = 3, 7, 11
+
+    def ref_rot(a, turns):
+        a = np.ascontiguousarray(a)
+        k, n, m = a.shape                 # [k, j, i]: the Fortran array is (i = m, j = n, k)
+        out = np.zeros((k, m, n) if turns % 2 else (k, n, m))
+        R.ref_rotate_array(m, n, k, P(a), turns, P(out))
+        return out
+
+    def ref_rot_vec(u, v, turns):
+        u, v = np.ascontiguousarray(u), np.ascontiguousarray(v)
+        k, nu, mu = u.shape; _, nv, mv = v.shape
+        ou = np.zeros((k, mv, nv) if turns % 2 else u.shape); ov = np.zeros((k, mu, nu) if turns % 2 else v.shape)
+        R.ref_rotate_vector(mu, nu, mv, nv, k, P(u), P(v), turns, P(ou), P(ov))
+        return ou, ov
+
+    h = rng.standard_normal((nk, nj, ni))
+    u = rng.standard_normal((nk, nj, ni + 1)); v = rng.standard_normal((nk, nj + 1, ni))      # symmetric C-grid staggering
+    assert np.array_equal(rot(h), ref_rot(h, -1)) and np.array_equal(rot(h), ref_rot(h, 3))
+    assert np.array_equal(unrot(rot(h)), h) and np.array_equal(unrot(h), ref_rot(h, 1))
+    ur, vr = rot_vector(u, v)
+    ou, ov = ref_rot_vec(u, v, -1)
+    assert np.array_equal(ur, ou) and np.array_equal(vr, ov)
+    bu, bv = unrot_vector(ur, vr)
+    fu, fv = ref_rot_vec(ur, vr, 1)
+    assert np.array_equal(bu, u) and np.array_equal(bv, v) and np.array_equal(fu, u) and np.array_equal(fv, v)
