@@ -690,8 +690,9 @@ def main():
             "advect_iterations_last_call": None if M.last_adv is None else int(M.last_adv.iterations),
             "hordiff_iterations_last_call": None if getattr(M, "last_hordiff", None) is None else int(M.last_hordiff.num_itts),
             "state_at_start": health0, "state_after_warmup": health_w, "state_after_run": health, "model_steps_taken": M.nstep,
-            "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, "
-                                                               "group passes over RCCL p2p",
+            "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, group passes "
+                                                               + ("over RCCL send / recv inside the library (its communication stream)"
+                                                                  if exchange == "rccl" else f"through torch.distributed callbacks ({backend})"),
             "exchange": exch,
         },
     }
