@@ -149,6 +149,27 @@ int mom6hip_chksum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t
 int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, double *sum, double *lay_sums,
                             int64_t *efp_sum, int64_t *efp_lay, int64_t *npoints, int32_t *err, int32_t memspace);
 
+/* ---- MOM_sum_output: the global integrals of write_energy (the numbers of ocean.stats) ---- */
+
+typedef struct mom6hip_energy_sums {
+  double mass_tot;        /* [kg]   reproducing_sum of h*(H_to_kg_m2*areaT*mask2dT), MOM_sum_output.F90:503-510 */
+  double KE_tot;          /* [J]    :683-689 */
+  double PE_tot;          /* 0: the available potential energy (CALCULATE_APE, :625-680) is not provided */
+  double toten;           /* KE_tot + PE_tot :691 */
+  double Salt, Heat;      /* [ppt kg], [J]: EFP_to_real of the summed column integrals :693-712 (0 without T and S) */
+  double max_CFL[2];      /* the transport-based and the linear maximum CFL number :718-744 */
+  int64_t mass_EFP[6], salt_EFP[6], heat_EFP[6];      /* the extended-fixed-point integers of the three totals */
+  int64_t npoints;        /* cells summed, over all PEs */
+} mom6hip_energy_sums_t;
+
+/* The sums of write_energy(u, v, h, tv, day, n, G, GV, US, CS, tracer_CSp) (src/diagnostics/MOM_sum_output.F90:428) for
+ * device-resident (or host) fields: every total is an order-invariant extended-fixed-point sum (MOM_coms reproducing_sum), so
+ * the numbers are those the reference writes to ocean.stats, bit for bit and on any layout.  dt = CS%dt_in_T; C_p = tv%C_p;
+ * T and S may both be NULL (use_temperature = False).  mass_lay, KE_lay: [nk] by-layer sums, or NULL.  Boussinesq. */
+int mom6hip_write_energy_sums(mom6hip_ctx_t *ctx, const double *u, const double *v, const double *h, const double *T, const double *S,
+                              double dt, double C_p, double H_to_kg_m2, double *mass_lay, double *KE_lay, mom6hip_energy_sums_t *out,
+                              int32_t memspace);
+
 /* ---- MOM_domains: single-tile halo update ------------------------------------------------- */
 
 /* Staggering of a field, for halo updates (MOM_domains AGRID/CGRID_NE positions). */

@@ -218,3 +218,10 @@ class RegriddingCS(C.Structure):
     _fields_ = [("regridding_scheme", C.c_int32), ("nk", C.c_int32), ("min_thickness", C.c_double), ("old_grid_weight", C.c_double),
                 ("depth_of_time_filter_shallow", C.c_double), ("depth_of_time_filter_deep", C.c_double), ("Z_ref", C.c_double),
                 ("coordinateResolution", C.c_void_p)]
+
+
+class EnergySums(C.Structure):
+    """mom6hip_energy_sums_t"""
+    _fields_ = [("mass_tot", C.c_double), ("KE_tot", C.c_double), ("PE_tot", C.c_double), ("toten", C.c_double), ("Salt", C.c_double),
+                ("Heat", C.c_double), ("max_CFL", C.c_double * 2), ("mass_EFP", C.c_int64 * 6), ("salt_EFP", C.c_int64 * 6),
+                ("heat_EFP", C.c_int64 * 6), ("npoints", C.c_int64)]

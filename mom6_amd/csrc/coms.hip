@@ -10,76 +10,10 @@
 // after every row), so limbs 2..6 are accumulated as two 64-bit atomics each -- the low 32 bits and the arithmetic high
 // part -- which is exact for up to 2^31 waves; the host recombines them in 128-bit integers and carries.  The first limb
 // is accumulated modulo 2^64, which is the reference's own arithmetic for it.
-#include "common.hpp"
+#include "efp.hpp"
 
 namespace {
-
-constexpr int NI = 6;                         // :36
-constexpr int STRIP = 32;                     // rows per thread
-constexpr long long PREC = 1ll << 46;         // :28
-constexpr int ACC = 1 + 2 * (NI - 1);         // per layer: limb 1, then (low, high) of limbs 2..6
-
-struct EfpConst { double pr[NI], I_pr[NI], max_efp_float; };
-inline EfpConst efp_const() {
-  EfpConst c;
-  const double r_prec = 70368744177664.0;     // 2.0**46 :29
-  c.pr[0] = r_prec * r_prec; c.pr[1] = r_prec; c.pr[2] = 1.0; c.pr[3] = 1.0 / r_prec;                         // :39
-  c.pr[4] = 1.0 / (r_prec * r_prec); c.pr[5] = 1.0 / (r_prec * r_prec * r_prec);
-  c.I_pr[0] = 1.0 / (r_prec * r_prec); c.I_pr[1] = 1.0 / r_prec; c.I_pr[2] = 1.0; c.I_pr[3] = r_prec;         // :42
-  c.I_pr[4] = r_prec * r_prec; c.I_pr[5] = r_prec * r_prec * r_prec;
-  c.max_efp_float = c.pr[0] * (9223372036854775808.0 - 1.0);                                                  // :44
-  return c;
-}
-
-__device__ __forceinline__ long long shfl_down_ll(long long x, int off) {
-  return (long long)__shfl_down((unsigned long long)x, off);
-}
-
-// acc[ACC * k ...] += the limbs of a(i0:i1, j0:j1, k); misc[0] = max |term| (as bits: non-negative doubles order as
-// integers), misc[1] |= 1 for a NaN, 2 for a term with no EFP representation
-__global__ __launch_bounds__(256) void efp_sum_kernel(const double *__restrict__ a, long plane, int nrow, int i0, int i1, int j0, int j1,
-                                                      EfpConst c, unsigned long long *__restrict__ acc, unsigned long long *__restrict__ misc) {
-  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, jb = j0 + blockIdx.y * STRIP, k = blockIdx.z;
-  long long s[NI] = {0, 0, 0, 0, 0, 0};
-  unsigned long long mag = 0ull, bad = 0ull;
-  if (i <= i1) {
-    const int je = jb + STRIP - 1 < j1 ? jb + STRIP - 1 : j1;
-    const double *p = a + plane * k + (long)jb * nrow + i;
-    for (int j = jb; j <= je; j++, p += nrow) {
-      const double r = *p;
-      if ((r >= 1e30) == (r < 1e30)) { bad |= 1ull; continue; }        // increment_ints_faster :603
-      double rs = fabs(r);
-      const unsigned long long b = (unsigned long long)__double_as_longlong(rs);
-      mag = b > mag ? b : mag;
-      if (rs > c.max_efp_float) { bad |= 2ull; continue; }             // :609
-      const bool neg = r < 0.0;
-#pragma unroll
-      for (int n = 0; n < NI; n++) {
-        const long long ival = (long long)(rs * c.I_pr[n]);            // :615-617
-        rs = rs - (double)ival * c.pr[n];
-        s[n] += neg ? -ival : ival;
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int n = 0; n < NI; n++) s[n] += shfl_down_ll(s[n], off);
-    const unsigned long long m2 = __shfl_down(mag, off);
-    mag = m2 > mag ? m2 : mag;
-    bad |= __shfl_down(bad, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *o = acc + (size_t)ACC * k;
-    if (s[0]) atomicAdd(&o[0], (unsigned long long)s[0]);
-#pragma unroll
-    for (int n = 1; n < NI; n++) if (s[n]) {
-      atomicAdd(&o[2 * n - 1], (unsigned long long)s[n] & 0xffffffffull);
-      atomicAdd(&o[2 * n], (unsigned long long)(s[n] >> 32));
-    }
-    if (mag) atomicMax(&misc[0], mag);
-    if (bad) atomicOr(&misc[1], bad);
-  }
-}
+using namespace m6efp;
 
 typedef __int128 i128;
 inline long long iabs(long long x) { return x < 0 ? -x : x; }
@@ -145,35 +79,12 @@ int sum_across_PEs_i64(mom6hip_ctx *ctx, long long *v, int n) {
   return 0;
 }
 
+
 }  // namespace
 
-extern "C" int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, double *sum, double *lay_sums,
-                                       int64_t *efp_sum, int64_t *efp_lay, int64_t *npoints, int32_t *err, int32_t memspace) {
-  M6_REQUIRE(ctx && field && sum, "mom6hip_reproducing_sum: null argument");
-  M6_REQUIRE(pos >= MOM6HIP_POS_H && pos <= MOM6HIP_POS_Q && nk >= 1, "mom6hip_reproducing_sum: bad staggering or layer count");
-  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "mom6hip_reproducing_sum: bad memspace");
-  const m6::GridDev g = ctx->g;
-  const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0, ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
-  const int nrow = g.nih + xs, ncol = g.njh + ys;
-  // the h-point computational domain in the field's own indexing, whatever the staggering (MOM_checksums.F90:1079)
-  const int i0 = g.isc - (g.isd - xs), i1 = g.iec - (g.isd - xs), j0 = g.jsc - (g.jsd - ys), j1 = g.jec - (g.jsd - ys);
-  const int isz = i1 + 1 - i0, jsz = j1 + 1 - j0;
-  M6_REQUIRE(isz >= 1 && jsz >= 1, "mom6hip_reproducing_sum: empty computational domain");
+int m6efp::efp_finish(mom6hip_ctx *ctx, const std::vector<unsigned long long> &res, int nk, long long npts2d, double *sum, double *lay_sums,
+                      int64_t *efp_sum, int64_t *efp_lay, int64_t *npoints, int32_t *err, bool pe_sum_unregularized) {
   const EfpConst c = efp_const();
-
-  m6::Stager st(ctx, memspace);
-  const double *d = st.in(field, sizeof(double) * (size_t)nrow * ncol * nk);
-  const size_t nacc = (size_t)ACC * nk + 2;
-  unsigned long long *acc = (unsigned long long *)st.scratch(nacc * sizeof(unsigned long long));
-  M6_REQUIRE(!st.failed() && d && acc, "mom6hip_reproducing_sum: staging failed");
-  M6_HIP(hipMemsetAsync(acc, 0, nacc * sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(efp_sum_kernel, dim3((isz + 255) / 256, (jsz + STRIP - 1) / STRIP, nk), dim3(256), 0, ctx->stream, d, (long)nrow * ncol,
-                     nrow, i0, i1, j0, j1, c, acc, acc + (size_t)ACC * nk);
-  M6_HIP(hipGetLastError());
-  std::vector<unsigned long long> res(nacc);
-  M6_HIP(hipMemcpyAsync(res.data(), acc, nacc * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-  M6_HIP(hipStreamSynchronize(ctx->stream));
-
   // the number of PEs, for prec_error = (2**63 - 1) / num_PEs() :362 (asked of the domain once)
   if (ctx->num_PEs == 0) {
     int32_t one = 1;
@@ -220,15 +131,29 @@ extern "C" int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, 
     M6_REQUIRE(!overflow_error, "Overflow in reproducing_sum(_3d).");
   }
 
+  if (pe_sum_unregularized) {      // reproducing_EFP_sum_2d(only_on_PE) :139-213 ends in regularize_ints on every PE ...
+    for (int q = 0; q < nsum; q++) regularize(&ints[(size_t)NI * q]);
+  }
   // sum_across_PEs of the limbs (and of the number of points, for the means of MOM_checksums' subStats)
   {
     std::vector<long long> x(ints);
-    x.push_back((long long)isz * jsz);
+    x.push_back(npts2d);
     if (int rc = sum_across_PEs_i64(ctx, x.data(), (int)x.size())) return rc;
     std::copy(x.begin(), x.end() - 1, ints.begin());
     if (npoints) *npoints = (int64_t)x.back() * nk;
   }
 
+  if (pe_sum_unregularized) {      // ... and EFP_sum_across_PEs (:789-835) only carries the overflows of the sum
+    const double I_prec = 1.0 / 70368744177664.0;
+    for (int i = NI - 1; i >= 1; i--) if (iabs(ints[i]) >= PREC) {      // carry_overflow :620
+      const int num_carry = (int)((double)ints[i] * I_prec);
+      ints[i] -= (long long)num_carry * PREC; ints[i - 1] += num_carry;
+    }
+    M6_REQUIRE(iabs(ints[0]) <= prec_error, "Overflow in EFP_list_sum_across_PEs.");
+    *sum = to_real(c, ints.data());
+    if (efp_sum) for (int n = 0; n < NI; n++) efp_sum[n] = ints[n];
+    return 0;
+  }
   if (by_layer) {
     double total = 0.0;
     for (int k = 0; k < nk; k++) {
@@ -249,5 +174,27 @@ extern "C" int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, 
     *sum = to_real(c, ints.data());
     if (efp_sum) for (int n = 0; n < NI; n++) efp_sum[n] = ints[n];
   }
+  return 0;
+}
+
+extern "C" int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t nk, double *sum, double *lay_sums,
+                                       int64_t *efp_sum, int64_t *efp_lay, int64_t *npoints, int32_t *err, int32_t memspace) {
+  M6_REQUIRE(ctx && field && sum, "mom6hip_reproducing_sum: null argument");
+  M6_REQUIRE(pos >= MOM6HIP_POS_H && pos <= MOM6HIP_POS_Q && nk >= 1, "mom6hip_reproducing_sum: bad staggering or layer count");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "mom6hip_reproducing_sum: bad memspace");
+  const m6::GridDev g = ctx->g;
+  const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0, ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
+  const int nrow = g.nih + xs, ncol = g.njh + ys;
+  // the h-point computational domain in the field's own indexing, whatever the staggering (MOM_checksums.F90:1079)
+  const int i0 = g.isc - (g.isd - xs), i1 = g.iec - (g.isd - xs), j0 = g.jsc - (g.jsd - ys), j1 = g.jec - (g.jsd - ys);
+  const int isz = i1 + 1 - i0, jsz = j1 + 1 - j0;
+  M6_REQUIRE(isz >= 1 && jsz >= 1, "mom6hip_reproducing_sum: empty computational domain");
+  m6::Stager st(ctx, memspace);
+  const double *d = st.in(field, sizeof(double) * (size_t)nrow * ncol * nk);
+  M6_REQUIRE(!st.failed() && d, "mom6hip_reproducing_sum: staging failed");
+  const long plane = (long)nrow * ncol;
+  std::vector<unsigned long long> res;
+  if (int rc = efp_reduce(ctx, [=] __device__(int i, int j, int k) { return d[plane * k + (long)j * nrow + i]; }, i0, i1, j0, j1, nk, res)) return rc;
+  if (int rc = efp_finish(ctx, res, nk, (long long)isz * jsz, sum, lay_sums, efp_sum, efp_lay, npoints, err)) return rc;
   return st.finish();
 }

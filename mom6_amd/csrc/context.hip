@@ -354,6 +354,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   ctx->hv_pack.release();
   ctx->ale_sub.release();
   ctx->vv_ntrunc.release();
+  ctx->efp_acc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   m6::staging_destroy(ctx);

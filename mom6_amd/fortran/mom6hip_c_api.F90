@@ -55,6 +55,14 @@ type, bind(c) :: mom6hip_regridding_cs_t
   type(c_ptr) :: coordinateResolution
 end type mom6hip_regridding_cs_t
 
+!> mom6hip_energy_sums_t: the global integrals of write_energy (src/diagnostics/MOM_sum_output.F90:490-760)
+type, bind(c) :: mom6hip_energy_sums_t
+  real(c_double) :: mass_tot, KE_tot, PE_tot, toten, Salt, Heat
+  real(c_double) :: max_CFL(2)
+  integer(c_int64_t) :: mass_EFP(6), salt_EFP(6), heat_EFP(6)
+  integer(c_int64_t) :: npoints
+end type mom6hip_energy_sums_t
+
 !> mom6hip_coriolisadv_cs_t (CoriolisAdv_CS, src/core/MOM_CoriolisAdv.F90:30)
 type, bind(c) :: mom6hip_coriolisadv_cs_t
   integer(c_int32_t) :: coriolis_scheme, ke_scheme, no_slip, bound_coriolis, coriolis_en_dis, pv_adv_scheme
@@ -366,6 +374,17 @@ interface
     type(c_ptr), value :: hptr
     integer(c_int) :: rc
   end function mom6hip_host_unregister
+
+  !> The sums of write_energy for device or host fields; T, S, mass_lay, KE_lay may be c_null_ptr
+  function mom6hip_write_energy_sums(ctx, u, v, h, T, S, dt, C_p, H_to_kg_m2, mass_lay, KE_lay, sums, memspace) &
+                                     bind(c, name="mom6hip_write_energy_sums") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_energy_sums_t
+    type(c_ptr), value :: ctx, u, v, h, T, S, mass_lay, KE_lay
+    real(c_double), value :: dt, C_p, H_to_kg_m2
+    type(mom6hip_energy_sums_t), intent(out) :: sums
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_write_energy_sums
 
   !> reproducing_sum of MOM_coms (MOM_coms.F90:318) over the h-point computational domain of a device or host field of
   !! staggering pos; lay_sums, efp_sum(6), efp_lay(6,nk), npoints and err are c_loc of the outputs or c_null_ptr

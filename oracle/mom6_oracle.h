@@ -187,6 +187,10 @@ int orc_reproducing_sum_3d(const double *a, int nrow, int ncol, int ke, int i0, 
 void orc_efp_regularize(int64_t *int_sum);
 double orc_efp_to_real(const int64_t *ints);
 
+/* ---- MOM_sum_output (oracle/sum_output.c): the global integrals of write_energy :490-760 */
+int orc_write_energy_sums(const mom6hip_grid_t *G, const double *u, const double *v, const double *h, const double *T, const double *S,
+                          double dt, double C_p, double H_to_kg_m2, double *mass_lay, double *KE_lay, mom6hip_energy_sums_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -448,6 +448,26 @@ def reproducing_sum(grid, a, pos, by_layer=False, return_err=False):
     return out
 
 
+# ---- MOM_sum_output ---------------------------------------------------------------------------------------
+def write_energy_sums(grid, u, v, h, T, S, dt, C_p=3991.86795711963, H_to_kg_m2=1035.0):
+    """the global integrals of write_energy (MOM_sum_output.F90:490-760): dict of totals, by-layer sums and EFP integers"""
+    L = lib()
+    L.orc_write_energy_sums.argtypes = [C.POINTER(_abi.GridStruct)] + [_dp] * 5 + [C.c_double] * 3 + [_dp, _dp, C.POINTER(_abi.EnergySums)]
+    out = _abi.EnergySums()
+    ml, kl = np.zeros(grid.nk), np.zeros(grid.nk)
+    rc = L.orc_write_energy_sums(C.byref(grid.struct()), _p(u), _p(v), _p(h), _p(T), _p(S), float(dt), float(C_p), float(H_to_kg_m2),
+                                 _p(ml), _p(kl), C.byref(out))
+    if rc:
+        raise RuntimeError("orc_write_energy_sums failed")
+    return energy_dict(out, ml, kl)
+
+
+def energy_dict(out, mass_lay, KE_lay):
+    return dict(mass_tot=out.mass_tot, KE_tot=out.KE_tot, PE_tot=out.PE_tot, toten=out.toten, Salt=out.Salt, Heat=out.Heat,
+                max_CFL=[out.max_CFL[0], out.max_CFL[1]], mass_EFP=list(out.mass_EFP), salt_EFP=list(out.salt_EFP),
+                heat_EFP=list(out.heat_EFP), npoints=int(out.npoints), mass_lay=[float(x) for x in mass_lay], KE_lay=[float(x) for x in KE_lay])
+
+
 # ---- MOM_dynamics_split_RK2 -------------------------------------------------------------------------------
 class DynState:
     """Everything one oracle run of the split RK2 step owns: sub-module control structures, the control structure of

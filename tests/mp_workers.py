@@ -336,3 +336,37 @@ def reproducing_sum_layout_worker(rank, world, port, layout, out_dir):
             dg1.close()
     finally:
         dist.destroy_process_group()
+
+
+def write_energy_layout_worker(rank, world, port, layout, out_dir):
+    """write_energy's sums on tiles against the one-tile numbers"""
+    import numpy as np
+    import torch
+    from mom6_amd import _abi, synth
+    from mom6_amd.domains import Domain
+    from mom6_amd.sum_output import write_energy
+    from mom6_amd.tracer_advect import DeviceGrid
+    dist = _init(rank, world, port)
+    try:
+        NI, NJ, NK, halo = 70, 40, 3, 4
+        gg = synth.make_grid(NI, NJ, NK, halo=halo, reentrant_x=True, reentrant_y=False, seed=78, land_frac=0.2)
+        d = synth.make_dynamics_state(gg, seed=3, umax=0.3, eta_amp=0.2)
+
+        def numbers(dg, cut):
+            r = write_energy(cut(d["u"], _abi.POS_U), cut(d["v"], _abi.POS_V), cut(d["h"], _abi.POS_H),
+                             (cut(d["T"], _abi.POS_H), cut(d["S"], _abi.POS_H)), dg, 900.0)
+            return dict(mass_EFP=np.array(r["mass_EFP"], dtype=np.int64), salt_EFP=np.array(r["salt_EFP"], dtype=np.int64),
+                        heat_EFP=np.array(r["heat_EFP"], dtype=np.int64), mass_lay=np.array(r["mass_lay"]), KE_lay=np.array(r["KE_lay"]),
+                        totals=np.array([r["mass_tot"], r["KE_tot"], r["toten"], float(r["npoints"])]), max_CFL=np.array(r["max_CFL"]))
+
+        dom = Domain(NI, NJ, layout, rank, halo, True, False)
+        dg = DeviceGrid(dom.tile_grid(gg))
+        dg.set_domain(dom)
+        np.savez(os.path.join(out_dir, f"tile{rank}.npz"), **numbers(dg, lambda a, pos: dom.cut(a, pos).cuda()))
+        dg.close()
+        if rank == 0:
+            dg1 = DeviceGrid(gg)
+            np.savez(os.path.join(out_dir, "global.npz"), **numbers(dg1, lambda a, pos: a.cuda()))
+            dg1.close()
+    finally:
+        dist.destroy_process_group()
