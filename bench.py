@@ -696,6 +696,17 @@ def main():
             "exchange": exch,
         },
     }
+    # what the device delivers to plain streaming kernels on THIS box (a = b, a = b + s*c over 4 GiB arrays), next to the nominal
+    # peak the fractions are quoted against (report both)
+    measured_bw = None
+    if rank == 0 and not a.no_roofline:
+        import ctypes as C
+        from mom6_amd._lib import check, lib
+        cp, tr = C.c_double(0.0), C.c_double(0.0)
+        L = lib()
+        L.mom6hip_stream_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        check(L.mom6hip_stream_bandwidth(M.dg.handle, 4 << 30, 10, C.byref(cp), C.byref(tr)), "mom6hip_stream_bandwidth")
+        measured_bw = {"copy_GBs": cp.value, "triad_GBs": tr.value, "bytes_per_array": 4 << 30, "launches": 10}
     M.dg.close()
     del M
     torch.cuda.empty_cache()
@@ -735,6 +746,8 @@ def main():
                 "traffic_from": traffic_from, "fp64_valu": valu,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n_y),
                 "also": {"cont_flux_coop_kernel<0,10>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
+                "measured_streaming_bandwidth": measured_bw,
+                "frac_of_measured_triad": None if not measured_bw else alg / (avg_ms * 1e-3) / 1e9 / measured_bw["triad_GBs"],
             }
 
     if world == 1 and not a.no_roofline:

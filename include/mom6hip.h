@@ -116,6 +116,11 @@ int mom6hip_stage_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint
 int mom6hip_stage_query(mom6hip_ctx_t *ctx, int32_t *pending);
 int mom6hip_stage_wait(mom6hip_ctx_t *ctx);
 
+/* The bandwidth the device delivers to plain streaming kernels, measured where the model runs (a = b and a = b + s*c over arrays
+ * of bytes_per_array bytes, `reps` launches each, HIP events; GB/s counting 2 and 3 arrays of traffic): the measured companion of
+ * the nominal HBM peak that the roofline fractions of bench.py are quoted against. */
+int mom6hip_stream_bandwidth(mom6hip_ctx_t *ctx, uint64_t bytes_per_array, int32_t reps, double *copy_GBs, double *triad_GBs);
+
 /* ---- MOM_checksums: the bit-count checksum of a field, on the device ----------------------- */
 
 /* subchk of chksum_h_3d / chksum_u_3d / chksum_v_3d / chksum_B_3d (src/framework/MOM_checksums.F90:1387-1401, :1042-1059,

@@ -73,4 +73,54 @@ int mom6hip_stage_wait(mom6hip_ctx_t *ctx) {
   return 0;
 }
 
+// ---- the HBM bandwidth this device delivers to plain streaming kernels (what the roofline fractions can be read against) ----
+namespace {
+__global__ __launch_bounds__(256) void stream_copy_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = b[i];
+}
+__global__ __launch_bounds__(256) void stream_triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                           const double2 *__restrict__ c, double s, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double2 x = b[i], y = c[i];
+    a[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+  }
+}
+}  // namespace
+
+int mom6hip_stream_bandwidth(mom6hip_ctx_t *ctx, uint64_t bytes_per_array, int32_t reps, double *copy_GBs, double *triad_GBs) {
+  M6_REQUIRE(ctx && bytes_per_array >= 4096 && reps >= 1 && copy_GBs && triad_GBs, "mom6hip_stream_bandwidth: bad argument");
+  const size_t n = (size_t)(bytes_per_array / sizeof(double2));
+  double2 *a = nullptr, *b = nullptr, *c = nullptr;
+  M6_HIP(hipMalloc((void **)&a, n * sizeof(double2)));
+  if (hipMalloc((void **)&b, n * sizeof(double2)) != hipSuccess || hipMalloc((void **)&c, n * sizeof(double2)) != hipSuccess) {
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+    m6::set_error("mom6hip_stream_bandwidth: out of device memory"); return 1;
+  }
+  hipStream_t s = ctx->stream;
+  (void)hipMemsetAsync(b, 0, n * sizeof(double2), s); (void)hipMemsetAsync(c, 0, n * sizeof(double2), s);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const dim3 grid(256 * 128), block(256);      // 128 blocks a CU, grid-stride (tools/stream_probe.hip: the fastest of the forms tried)
+  auto timed = [&](bool triad) -> double {
+    if (triad) hipLaunchKernelGGL(stream_triad_kernel, grid, block, 0, s, a, b, c, 3.0, n);      // warm-up
+    else hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, s, a, b, n);
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps; r++) {
+      if (triad) hipLaunchKernelGGL(stream_triad_kernel, grid, block, 0, s, a, b, c, 3.0, n);
+      else hipLaunchKernelGGL(stream_copy_kernel, grid, block, 0, s, a, b, n);
+    }
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return (double)(triad ? 3 : 2) * (double)(n * sizeof(double2)) * reps / ((double)ms * 1.0e6);
+  };
+  *copy_GBs = timed(false);
+  *triad_GBs = timed(true);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -52,3 +52,19 @@ def test_staging_refuses_bad_arguments():
         stage_to_host(dg, np.zeros(g.shape3(_abi.POS_H)), np.zeros(g.shape3(_abi.POS_H)))      # not a device field
     stage_wait(dg)                                                # nothing staged: returns
     dg.close()
+
+
+@pytest.mark.gpu
+def test_stream_bandwidth_reports_plausible_numbers():
+    """mom6hip_stream_bandwidth: the measured companion of the nominal HBM peak (bench.py `roofline.measured_streaming_bandwidth`)"""
+    import ctypes as C
+    from mom6_amd._lib import check, lib
+    from mom6_amd.tracer_advect import DeviceGrid
+    g = synth.make_grid(20, 12, 3, seed=1)
+    dg = DeviceGrid(g)
+    L = lib()
+    L.mom6hip_stream_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    cp, tr = C.c_double(0.0), C.c_double(0.0)
+    check(L.mom6hip_stream_bandwidth(dg.handle, 256 << 20, 5, C.byref(cp), C.byref(tr)), "mom6hip_stream_bandwidth")
+    assert 500.0 < cp.value < 9000.0 and 500.0 < tr.value < 9000.0      # GB/s: above PCIe by far, below the nominal 8 TB/s + slack
+    dg.close()
