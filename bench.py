@@ -547,7 +547,7 @@ def cpu_baseline(grid, scheme, full_cells, steps_per_advect):
     sy1, sec1 = rate(one)
     out = {"unit": "SYPD", "kind": "port", "host_cores": host_cores, "cpu_quota": quota,
            "compiler": "gcc -O2 -std=c99 -ffp-contract=off -fno-fast-math (+ -fopenmp for the all-cores build)",
-           "calibration_vs_reference_build": "not possible beyond PLM/PCM (oracle/_ref): the hot-path modules end in FMS, which is not vendored",
+           "calibration_vs_reference_build": "PLM_reconstruction, the one hot-path routine the reference builds without FMS: this port runs 1.28x the time of amdflang -O2 on it, bitwise equal (profiles/r02_calibrate_ref.json, tools/calibrate_ref.py); the other modules end in FMS, which is not vendored",
            "one_core": {"value": sy1, "cores": 1, "ns_per_gridpoint_step": sec1 * 1e9 / full_cells,
                         "sample": f"{one['n_dyn']} baroclinic steps + one advect_tracer / ALE block on {grid.ni}x{grid.nj}x2 (2 of {grid.nk} "
                                   f"layers), 3-D work scaled per cell, the 2-D barotropic subcycle ({one['t2d']:.1f} s per step, "

@@ -47,6 +47,18 @@ function ref_plm_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c) bind(c, name="
   s = PLM_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c)
 end function ref_plm_extrapolate_slope
 
+!> PLM_reconstruction of ncol columns of n layers (timing the reference's code against the restatement: tools/calibrate_ref.py)
+subroutine ref_plm_batch(ncol, n, h, u, E, coef, h_neglect) bind(c, name="ref_plm_batch")
+  integer(c_int), value :: ncol, n
+  real(c_double), intent(in) :: h(n,ncol), u(n,ncol)
+  real(c_double), intent(inout) :: E(n,2,ncol), coef(n,2,ncol)
+  real(c_double), value :: h_neglect
+  integer :: c
+  do c = 1, ncol
+    call PLM_reconstruction(n, h(:,c), u(:,c), E(:,:,c), coef(:,:,c), h_neglect)
+  enddo
+end subroutine ref_plm_batch
+
 !> rotate_array (src/framework/MOM_array_transform.F90:26) of a 3-D field: A_in(m,n,nk) -> A (n,m,nk for odd turns)
 subroutine ref_rotate_array(m, n, nk, A_in, turns, A) bind(c, name="ref_rotate_array")
   integer(c_int), value :: m, n, nk, turns

@@ -92,6 +92,14 @@ double orc_plm_extrapolate_slope(double h_l, double h_c, double h_neglect, doubl
 }
 
 /* PLM_reconstruction, PLM_functions.F90:190-260 */
+void orc_plm_reconstruction(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);
+/* ncol columns of n layers, arrays [ncol][..]: the batch form tools/calibrate_ref.py times against the reference build */
+void orc_plm_batch(int ncol, int n, const double *h, const double *u, double *E, double *coef, double h_neglect)
+{
+  for (int c = 0; c < ncol; c++)
+    orc_plm_reconstruction(n, h + (size_t)c*n, u + (size_t)c*n, E + (size_t)c*2*n, coef + (size_t)c*3*n, h_neglect);
+}
+
 void orc_plm_reconstruction(int n, const double *h, const double *u, double *E, double *coef, double h_neglect)
 {
   double almost_one = 1. - DBL_EPSILON;
