@@ -159,7 +159,7 @@ int mom6hip_reproducing_sum(mom6hip_ctx_t *ctx, const double *field, int32_t pos
 typedef struct mom6hip_energy_sums {
   double mass_tot;        /* [kg]   reproducing_sum of h*(H_to_kg_m2*areaT*mask2dT), MOM_sum_output.F90:503-510 */
   double KE_tot;          /* [J]    :683-689 */
-  double PE_tot;          /* 0: the available potential energy (CALCULATE_APE, :625-680) is not provided */
+  double PE_tot;          /* 0 here: the available potential energy comes from mom6hip_write_energy_ape */
   double toten;           /* KE_tot + PE_tot :691 */
   double Salt, Heat;      /* [ppt kg], [J]: EFP_to_real of the summed column integrals :693-712 (0 without T and S) */
   double max_CFL[2];      /* the transport-based and the linear maximum CFL number :718-744 */
@@ -174,6 +174,20 @@ typedef struct mom6hip_energy_sums {
 int mom6hip_write_energy_sums(mom6hip_ctx_t *ctx, const double *u, const double *v, const double *h, const double *T, const double *S,
                               double dt, double C_p, double H_to_kg_m2, double *mass_lay, double *KE_lay, mom6hip_energy_sums_t *out,
                               int32_t memspace);
+
+/* The available potential energy of write_energy (CALCULATE_APE = True, the reference's default; :610-680):
+ *   mom6hip_depth_list_create   create_depth_list (:1109-1232) + depth_list_setup (:1101-1103): the sorted list of bottom depths
+ *                               with the ocean area at and the volume below each, kept in the context.  The tile's place in the
+ *                               global domain (niglobal x njglobal cells, the tile's first cell at (i_offset, j_offset), 0-based)
+ *                               orders the list as the reference's; the lists of the other PEs come through the domain's sum.
+ *   mom6hip_write_energy_ape    the reference height of every interface (Z_0APE [nk+1], a search of the list from the layer
+ *                               volumes vol_lay = H_to_Z/H_to_kg_m2 * mass_lay), the integrand PE_pt on the device, PE [nk+1] and
+ *                               PE_tot as extended-fixed-point sums.  mass_lay from mom6hip_write_energy_sums; g_prime [nk+1] =
+ *                               GV%g_prime.  toten of ocean.stats is KE_tot + PE_tot.  Boussinesq. */
+int mom6hip_depth_list_create(mom6hip_ctx_t *ctx, int32_t niglobal, int32_t njglobal, int32_t i_offset, int32_t j_offset, double Z_ref,
+                              double min_depth_inc, int32_t *listsize);
+int mom6hip_write_energy_ape(mom6hip_ctx_t *ctx, const double *h, const double *mass_lay, const double *g_prime, double Rho0,
+                             double H_to_kg_m2, double Z_ref, double *PE, double *PE_tot, double *Z_0APE, int32_t memspace);
 
 /* ---- MOM_domains: single-tile halo update ------------------------------------------------- */
 

@@ -22,7 +22,7 @@ EXPORTS = (
     "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats",
     "mom6hip_vertvisc_coef", "mom6hip_vertvisc", "mom6hip_vertvisc_remnant", "mom6hip_vertvisc_ntrunc", "mom6hip_vertvisc_and_remnant", "mom6hip_vertvisc_step",
     "mom6hip_hor_visc_init", "mom6hip_horizontal_viscosity", "mom6hip_set_viscous_bbl", "mom6hip_set_viscous_ml",
-    "mom6hip_chksum", "mom6hip_reproducing_sum", "mom6hip_write_energy_sums", "mom6hip_host_register", "mom6hip_host_unregister", "mom6hip_stage_to_host",
+    "mom6hip_chksum", "mom6hip_reproducing_sum", "mom6hip_write_energy_sums", "mom6hip_depth_list_create", "mom6hip_write_energy_ape", "mom6hip_host_register", "mom6hip_host_unregister", "mom6hip_stage_to_host",
     "mom6hip_stage_query", "mom6hip_stage_wait", "mom6hip_stream_bandwidth", "mom6hip_tracer_hordiff", "mom6hip_rccl_get_unique_id", "mom6hip_domain_init_rccl", "mom6hip_domain_exchange_timing",
 )
 

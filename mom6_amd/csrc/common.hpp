@@ -113,6 +113,9 @@ struct mom6hip_ctx {
   void *cb_user = nullptr;
   int num_PEs = 0;              // asked of the domain on first use (coms.hip); 0: not yet known
   m6::DevBuf efp_acc;           // the accumulators of the extended-fixed-point sums (efp.hpp)
+  // the depth list of MOM_sum_output (create_depth_list) and the remembered list positions CS%lH (sum_output.hip)
+  std::vector<double> DL_depth, DL_area, DL_vol_below;
+  std::vector<int> DL_lH;
   // restart / diagnostic staging (staging.hip): snapshots on the compute stream, device-to-host copies on a stream of their own
   struct StageSlot { m6::DevBuf buf; hipEvent_t snap = nullptr, done = nullptr; };
   std::vector<StageSlot> stage_slots;

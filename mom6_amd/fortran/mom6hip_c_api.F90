@@ -386,6 +386,27 @@ interface
     integer(c_int) :: rc
   end function mom6hip_write_energy_sums
 
+  !> create_depth_list / depth_list_setup of MOM_sum_output for CALCULATE_APE; the tile's place in the global domain (0-based offsets)
+  function mom6hip_depth_list_create(ctx, niglobal, njglobal, i_offset, j_offset, Z_ref, min_depth_inc, listsize) &
+                                     bind(c, name="mom6hip_depth_list_create") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: niglobal, njglobal, i_offset, j_offset
+    real(c_double), value :: Z_ref, min_depth_inc
+    integer(c_int32_t), intent(out) :: listsize
+    integer(c_int) :: rc
+  end function mom6hip_depth_list_create
+  !> The available potential energy of write_energy: PE(nk+1), PE_tot, Z_0APE(nk+1); mass_lay from mom6hip_write_energy_sums
+  function mom6hip_write_energy_ape(ctx, h, mass_lay, g_prime, Rho0, H_to_kg_m2, Z_ref, PE, PE_tot, Z_0APE, memspace) &
+                                    bind(c, name="mom6hip_write_energy_ape") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr
+    type(c_ptr), value :: ctx, h, mass_lay, g_prime, PE, Z_0APE
+    real(c_double), value :: Rho0, H_to_kg_m2, Z_ref
+    real(c_double), intent(out) :: PE_tot
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_write_energy_ape
+
   !> reproducing_sum of MOM_coms (MOM_coms.F90:318) over the h-point computational domain of a device or host field of
   !! staggering pos; lay_sums, efp_sum(6), efp_lay(6,nk), npoints and err are c_loc of the outputs or c_null_ptr
   function mom6hip_reproducing_sum(ctx, field, pos, nk, sum, lay_sums, efp_sum, efp_lay, npoints, err, memspace) &

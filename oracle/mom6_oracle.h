@@ -191,6 +191,13 @@ double orc_efp_to_real(const int64_t *ints);
 int orc_write_energy_sums(const mom6hip_grid_t *G, const double *u, const double *v, const double *h, const double *T, const double *S,
                           double dt, double C_p, double H_to_kg_m2, double *mass_lay, double *KE_lay, mom6hip_energy_sums_t *out);
 
+int orc_depth_list_create(int mls, const double *Dlist_in, const double *Area_in, double min_depth_inc, double **depth_out,
+                          double **area_out, double **vol_below_out);
+void orc_ape_reference_heights(int nz, int listsize, const double *DL_depth, const double *DL_area, const double *DL_vol_below,
+                               const double *vol_lay, int *lH, double *Z_0APE);
+int orc_write_energy_ape(const mom6hip_grid_t *G, const double *h, const double *mass_lay, const double *g_prime, double Rho0,
+                         double H_to_kg_m2, double Z_ref, double min_depth_inc, int *lH_io, double *PE, double *PE_tot, double *Z_0APE);
+
 #ifdef __cplusplus
 }
 #endif

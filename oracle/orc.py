@@ -462,6 +462,38 @@ def write_energy_sums(grid, u, v, h, T, S, dt, C_p=3991.86795711963, H_to_kg_m2=
     return energy_dict(out, ml, kl)
 
 
+def write_energy_ape(grid, h, mass_lay, g_prime, Rho0=1035.0, H_to_kg_m2=1035.0, Z_ref=0.0, min_depth_inc=1.0e-10, lH=None):
+    """the CALCULATE_APE part of write_energy (:610-680) with its depth list (:1109-1232): dict(PE, PE_tot, Z_0APE)"""
+    L = lib()
+    _ipt = C.POINTER(C.c_int)
+    L.orc_write_energy_ape.argtypes = [C.POINTER(_abi.GridStruct), _dp, _dp, _dp] + [C.c_double] * 4 + [_ipt, _dp, _dp, _dp]
+    nz = grid.nk
+    PE, Z0, tot = np.zeros(nz + 1), np.zeros(nz + 1), np.zeros(1)
+    ml = np.ascontiguousarray(mass_lay, dtype=np.float64); gp = np.ascontiguousarray(g_prime, dtype=np.float64)
+    lh = None if lH is None else lH.ctypes.data_as(_ipt)
+    rc = L.orc_write_energy_ape(C.byref(grid.struct()), _p(h), _p(ml), _p(gp), float(Rho0), float(H_to_kg_m2), float(Z_ref), float(min_depth_inc),
+                                lh, _p(PE), _p(tot), _p(Z0))
+    if rc:
+        raise RuntimeError("orc_write_energy_ape failed")
+    return dict(PE=[float(x) for x in PE], PE_tot=float(tot[0]), Z_0APE=[float(x) for x in Z0])
+
+
+def depth_list(Dlist, AreaList, min_depth_inc=1.0e-10):
+    """create_depth_list :1109-1232 on global lists: (depth, area, vol_below)"""
+    L = lib()
+    pp = C.POINTER(_dp)
+    L.orc_depth_list_create.argtypes = [C.c_int, _dp, _dp, C.c_double, pp, pp, pp]
+    L.orc_depth_list_create.restype = C.c_int
+    d, a = np.ascontiguousarray(Dlist, dtype=np.float64), np.ascontiguousarray(AreaList, dtype=np.float64)
+    o = [_dp(), _dp(), _dp()]
+    n = L.orc_depth_list_create(d.size, _p(d), _p(a), float(min_depth_inc), C.byref(o[0]), C.byref(o[1]), C.byref(o[2]))
+    out = tuple(np.ctypeslib.as_array(q, shape=(n,)).copy() for q in o)
+    libc = C.CDLL(None)
+    for q in o:
+        libc.free(q)
+    return out
+
+
 def energy_dict(out, mass_lay, KE_lay):
     return dict(mass_tot=out.mass_tot, KE_tot=out.KE_tot, PE_tot=out.PE_tot, toten=out.toten, Salt=out.Salt, Heat=out.Heat,
                 max_CFL=[out.max_CFL[0], out.max_CFL[1]], mass_EFP=list(out.mass_EFP), salt_EFP=list(out.salt_EFP),

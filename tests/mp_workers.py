@@ -338,8 +338,8 @@ def reproducing_sum_layout_worker(rank, world, port, layout, out_dir):
         dist.destroy_process_group()
 
 
-def write_energy_layout_worker(rank, world, port, layout, out_dir):
-    """write_energy's sums on tiles against the one-tile numbers"""
+def write_energy_layout_worker(rank, world, port, layout, out_dir, ape=False):
+    """write_energy's sums on tiles against the one-tile numbers (ape: with the depth list and the available potential energy)"""
     import numpy as np
     import torch
     from mom6_amd import _abi, synth
@@ -353,15 +353,25 @@ def write_energy_layout_worker(rank, world, port, layout, out_dir):
         d = synth.make_dynamics_state(gg, seed=3, umax=0.3, eta_amp=0.2)
 
         def numbers(dg, cut):
+            gp = None
+            extra = {}
+            if ape:
+                from mom6_amd.sum_output import depth_list_setup
+                gp = np.full(NK + 1, 9.8 * 2.0e-3); gp[0] = 9.8
+                extra["depth_list"] = np.array([float(depth_list_setup(dg, domain=dom_of(dg)))])
             r = write_energy(cut(d["u"], _abi.POS_U), cut(d["v"], _abi.POS_V), cut(d["h"], _abi.POS_H),
-                             (cut(d["T"], _abi.POS_H), cut(d["S"], _abi.POS_H)), dg, 900.0)
-            return dict(mass_EFP=np.array(r["mass_EFP"], dtype=np.int64), salt_EFP=np.array(r["salt_EFP"], dtype=np.int64),
+                             (cut(d["T"], _abi.POS_H), cut(d["S"], _abi.POS_H)), dg, 900.0, g_prime=gp)
+            if ape:
+                extra["PE"] = np.array(r["PE"]); extra["Z_0APE"] = np.array(r["Z_0APE"])
+            return dict(**extra, mass_EFP=np.array(r["mass_EFP"], dtype=np.int64), salt_EFP=np.array(r["salt_EFP"], dtype=np.int64),
                         heat_EFP=np.array(r["heat_EFP"], dtype=np.int64), mass_lay=np.array(r["mass_lay"]), KE_lay=np.array(r["KE_lay"]),
                         totals=np.array([r["mass_tot"], r["KE_tot"], r["toten"], float(r["npoints"])]), max_CFL=np.array(r["max_CFL"]))
 
         dom = Domain(NI, NJ, layout, rank, halo, True, False)
         dg = DeviceGrid(dom.tile_grid(gg))
         dg.set_domain(dom)
+        doms = {id(dg): dom}
+        dom_of = lambda g_: doms.get(id(g_))
         np.savez(os.path.join(out_dir, f"tile{rank}.npz"), **numbers(dg, lambda a, pos: dom.cut(a, pos).cuda()))
         dg.close()
         if rank == 0:
