@@ -1,0 +1,312 @@
+!> Drop-in replacement for the part of module MOM_ALE (src/ALE/MOM_ALE.F90) that step_MOM_thermo drives
+!! (src/core/MOM.F90:1647-1700): ALE_init (:168), ALE_end (:411), ALE_update_regrid_weights (:1719), ALE_set_extrap_boundaries
+!! (:328), ALE_regrid (:484), ALE_remap_tracers (:737), ALE_remap_set_h_vel (:870) and ALE_remap_velocities (:1061) with the
+!! reference's dummy-argument lists, parameter names and defaults, on the GPU through libmom6hip (HOST memspace).
+!! Provided: REGRIDDING_COORDINATE_MODE = Z* (ZSTAR) with ALE_COORDINATE_CONFIG = UNIFORM[:N[,dz]] or PARAM (ALE_RESOLUTION),
+!! REMAPPING_SCHEME / VELOCITY_REMAPPING_SCHEME in PCM, PLM, PPM_H4, PPM_IH4, PPM_CW, REMAPPING_ANSWER_DATE >= 20190101.
+!! Everything else the reference offers here (other coordinates, ice shelves, PCM_cell masks, OBC thicknesses, partial-cell
+!! velocity remapping, the KE-conserving velocity correction, the remapping tendency diagnostics) stops with a FATAL error.
+!!
+!! Compiled INSIDE a MOM6 source tree in place of src/ALE/MOM_ALE.F90; here against tests/fortran/stubs.
+module MOM_ALE
+
+use, intrinsic :: iso_c_binding
+use mom6hip_c_api
+use mom6hip_MOM_glue,    only : mom6hip_shared_context, mom6hip_fatal_if
+use MOM_error_handler,   only : MOM_error, FATAL, WARNING
+use MOM_file_parser,     only : get_param, log_version, param_file_type
+use MOM_grid,            only : ocean_grid_type
+use MOM_open_boundary,   only : ocean_OBC_type
+use MOM_string_functions, only : uppercase
+use MOM_tracer_registry, only : tracer_registry_type
+use MOM_unit_scaling,    only : unit_scale_type
+use MOM_variables,       only : thermo_var_ptrs
+use MOM_verticalGrid,    only : verticalGrid_type
+implicit none ; private
+
+#include <MOM_memory.h>
+
+public ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities
+public ALE_update_regrid_weights, ALE_set_extrap_boundaries
+
+!> ALE control structure (the members of the reference's ALE_CS :62-123 and of its regridding_CS / remapping_CS that the
+!! provided branches read)
+type :: ALE_CS ; private
+  logical :: remap_uv_using_old_alg = .false.
+  real    :: regrid_time_scale = 0.0      !< REGRID_TIME_SCALE [T ~> s]
+  integer :: nk = 0                        !< layers of the target grid
+  real    :: min_thickness = 1.0e-3        !< MIN_THICKNESS [H ~> m]
+  real    :: old_grid_weight = 0.0         !< set by ALE_update_regrid_weights
+  real    :: filter_shallow_depth = 0.0, filter_deep_depth = 0.0
+  real, allocatable :: coordinateResolution(:)      !< nominal layer thicknesses [Z ~> m]
+  integer :: remap_scheme = MOM6HIP_REMAP_PLM, vel_remap_scheme = MOM6HIP_REMAP_PLM
+  logical :: boundary_extrapolation = .false.
+  logical :: partial_cell_vel_remap = .false., conserve_ke = .false.
+  real    :: BBL_h_vel_mask = 0.0
+  integer :: answer_date = 99991231
+end type ALE_CS
+
+contains
+
+!> remappingSchemesDoc / setReconstructionType (MOM_remapping.F90:70-78, :1286-1325): the scheme's number in the library
+integer function scheme_of(string)
+  character(len=*), intent(in) :: string
+  select case (uppercase(trim(string)))
+    case ("PCM") ;     scheme_of = MOM6HIP_REMAP_PCM
+    case ("PLM") ;     scheme_of = MOM6HIP_REMAP_PLM
+    case ("PPM_H4") ;  scheme_of = MOM6HIP_REMAP_PPM_H4
+    case ("PPM_IH4") ; scheme_of = MOM6HIP_REMAP_PPM_IH4
+    case ("PPM_CW") ;  scheme_of = MOM6HIP_REMAP_PPM_CW
+    case ("PLM_HYBGEN", "PPM_HYBGEN", "WENO_HYBGEN", "PQM_IH4IH3", "PQM_IH6IH5")
+      scheme_of = -1
+      call MOM_error(FATAL, "ALE_init (HIP): REMAPPING_SCHEME = "//trim(string)//" is not provided by the GPU path "// &
+                            "(PCM, PLM, PPM_H4, PPM_IH4, PPM_CW are).")
+    case default
+      scheme_of = -1
+      call MOM_error(FATAL, "setReconstructionType: Unrecognized choice for REMAPPING_SCHEME ("//trim(string)//").")
+  end select
+end function scheme_of
+
+!> Same interface as the reference ALE_init (:168), same parameter names and defaults (:199-320, MOM_regridding.F90:180-620)
+subroutine ALE_init(param_file, GV, US, max_depth, CS)
+  type(param_file_type),   intent(in) :: param_file
+  type(verticalGrid_type), intent(in) :: GV
+  type(unit_scale_type),   intent(in) :: US
+  real,                    intent(in) :: max_depth
+  type(ALE_CS),            pointer    :: CS
+# include "version_variable.h"
+  character(len=40)  :: mdl = "MOM_ALE"
+  character(len=80)  :: string, vel_string, coord_mode
+  logical :: flag, remap_boundary_extrap, init_boundary_extrap
+  integer :: default_answer_date, ke, ic
+  real :: tmpReal
+
+  if (associated(CS)) then
+    call MOM_error(WARNING, "ALE_init called with an associated control structure.")
+    return
+  endif
+  allocate(CS)
+  call log_version(param_file, mdl, version, "")
+  call get_param(param_file, mdl, "REMAP_UV_USING_OLD_ALG", CS%remap_uv_using_old_alg, &
+                 "If true, uses the old remapping-via-a-delta-z method for remapping u and v.", default=.false.)
+  if (CS%remap_uv_using_old_alg) call MOM_error(FATAL, "ALE_init (HIP): REMAP_UV_USING_OLD_ALG is not provided by the GPU path.")
+
+  ! ALE_initRegridding :1667 -> initialize_regridding (MOM_regridding.F90:180)
+  call get_param(param_file, mdl, "REGRIDDING_COORDINATE_MODE", coord_mode, &
+                 "Coordinate mode for vertical regridding.", default="LAYER", fail_if_missing=.true.)
+  select case (uppercase(trim(coord_mode)))
+    case ("Z*", "ZSTAR")
+    case default
+      call MOM_error(FATAL, "ALE_init (HIP): REGRIDDING_COORDINATE_MODE = "//trim(coord_mode)//" is not provided by the GPU "// &
+                            "path (Z* is).")
+  end select
+  call get_param(param_file, mdl, "ALE_COORDINATE_CONFIG", string, &
+                 "Determines how to specify the coordinate resolution.", default="UNIFORM")
+  if (index(trim(string),'UNIFORM')==1) then      ! MOM_regridding.F90:337-354
+    if (len_trim(string)==7) then
+      ke = GV%ke ; tmpReal = max_depth
+    elseif (index(trim(string),'UNIFORM:')==1 .and. len_trim(string)>8) then
+      ic = index(string(9:), ',')
+      if (ic > 0) then
+        read(string(9:8+ic-1), *) ke ; read(string(9+ic:), *) tmpReal
+      else
+        read(string(9:), *) ke ; tmpReal = max_depth
+      endif
+    else
+      call MOM_error(FATAL, trim(mdl)//', initialize_regridding: Unable to interpret "'//trim(string)//'".')
+    endif
+    allocate(CS%coordinateResolution(ke))
+    CS%coordinateResolution(:) = tmpReal / real(ke)      ! uniformResolution :1916
+  elseif (trim(string)=='PARAM') then                    ! :355-360
+    ke = GV%ke
+    allocate(CS%coordinateResolution(ke))
+    call get_param(param_file, mdl, "ALE_RESOLUTION", CS%coordinateResolution, &
+                   "The distribution of vertical resolution for the target grid.", units="m", fail_if_missing=.true.)
+  else
+    call MOM_error(FATAL, "ALE_init (HIP): ALE_COORDINATE_CONFIG = "//trim(string)//" is not provided by the GPU path "// &
+                          "(UNIFORM[:N[,dz]] and PARAM are).")
+  endif
+  if (ke /= GV%ke) call MOM_error(FATAL, "ALE_init (HIP): the target grid must have GV%ke layers.")
+  CS%nk = ke
+  call get_param(param_file, mdl, "MIN_THICKNESS", CS%min_thickness, &
+                 "When regridding, this is the minimum layer thickness allowed.", units="m", default=1.0e-3, scale=GV%m_to_H)
+
+  call get_param(param_file, mdl, "REMAPPING_SCHEME", string, &
+                 "This sets the reconstruction scheme used for vertical remapping for all variables.", default="PLM")
+  call get_param(param_file, mdl, "VELOCITY_REMAPPING_SCHEME", vel_string, &
+                 "This sets the reconstruction scheme used for vertical remapping of velocities.", default=trim(string))
+  call get_param(param_file, mdl, "FATAL_CHECK_RECONSTRUCTIONS", flag, default=.false.)
+  if (flag) call MOM_error(FATAL, "ALE_init (HIP): FATAL_CHECK_RECONSTRUCTIONS is not provided by the GPU path.")
+  call get_param(param_file, mdl, "FATAL_CHECK_REMAPPING", flag, default=.false.)
+  if (flag) call MOM_error(FATAL, "ALE_init (HIP): FATAL_CHECK_REMAPPING is not provided by the GPU path.")
+  call get_param(param_file, mdl, "REMAP_BOUND_INTERMEDIATE_VALUES", flag, default=.false.)
+  if (flag) call MOM_error(FATAL, "ALE_init (HIP): REMAP_BOUND_INTERMEDIATE_VALUES is not provided by the GPU path.")
+  call get_param(param_file, mdl, "REMAP_BOUNDARY_EXTRAP", remap_boundary_extrap, &
+                 "If true, values at the interfaces of boundary cells are extrapolated instead of piecewise constant", &
+                 default=.false.)
+  call get_param(param_file, mdl, "INIT_BOUNDARY_EXTRAP", init_boundary_extrap, &
+                 "If true, values at the interfaces of boundary cells are extrapolated instead of piecewise constant during "//&
+                 "initialization.  Defaults to REMAP_BOUNDARY_EXTRAP.", default=remap_boundary_extrap)
+  call get_param(param_file, mdl, "DEFAULT_ANSWER_DATE", default_answer_date, &
+                 "This sets the default value for the various _ANSWER_DATE parameters.", default=99991231)
+  call get_param(param_file, mdl, "REMAPPING_ANSWER_DATE", CS%answer_date, &
+                 "The vintage of the expressions and order of arithmetic to use for remapping.", default=default_answer_date)
+  if (CS%answer_date < 20190101) call MOM_error(FATAL, "ALE_init (HIP): REMAPPING_ANSWER_DATE < 20190101 is not provided by "// &
+                                                       "the GPU path.")
+  CS%remap_scheme = scheme_of(string) ; CS%vel_remap_scheme = scheme_of(vel_string)
+  CS%boundary_extrapolation = init_boundary_extrap      ! initialize_remapping(..., boundary_extrapolation=init_boundary_extrap)
+
+  call get_param(param_file, mdl, "PARTIAL_CELL_VELOCITY_REMAP", CS%partial_cell_vel_remap, default=.false.)
+  if (CS%partial_cell_vel_remap) call MOM_error(FATAL, "ALE_init (HIP): PARTIAL_CELL_VELOCITY_REMAP is not provided by the GPU path.")
+  call get_param(param_file, mdl, "REGRID_TIME_SCALE", CS%regrid_time_scale, &
+                 "The time-scale used in blending between the current (old) grid and the target (new) grid.", &
+                 units="s", default=0., scale=US%s_to_T)
+  call get_param(param_file, mdl, "REGRID_FILTER_SHALLOW_DEPTH", CS%filter_shallow_depth, &
+                 "The depth above which no time-filtering is applied.", units="m", default=0., scale=GV%m_to_H)
+  call get_param(param_file, mdl, "REGRID_FILTER_DEEP_DEPTH", CS%filter_deep_depth, &
+                 "The depth below which full time-filtering is applied with time-scale REGRID_TIME_SCALE.", &
+                 units="m", default=0., scale=GV%m_to_H)
+  call get_param(param_file, mdl, "REGRID_USE_OLD_DIRECTION", flag, default=.true., do_not_log=.true.)
+  if (.not.flag) call MOM_error(FATAL, "ALE_init (HIP): REGRID_USE_OLD_DIRECTION = False is not provided by the GPU path.")
+  call get_param(param_file, mdl, "REMAP_VEL_MASK_BBL_THICK", CS%BBL_h_vel_mask, &
+                 "A thickness of a bottom boundary layer below which velocities in thin layers are zeroed out after remapping.", &
+                 units="m", default=-0.001, scale=GV%m_to_H)
+  if (CS%BBL_h_vel_mask > 0.0) call MOM_error(FATAL, "ALE_init (HIP): REMAP_VEL_MASK_BBL_THICK > 0 is not provided by the GPU path.")
+  call get_param(param_file, mdl, "REMAP_VEL_CONSERVE_KE", CS%conserve_ke, default=.false.)
+  if (CS%conserve_ke) call MOM_error(FATAL, "ALE_init (HIP): REMAP_VEL_CONSERVE_KE is not provided by the GPU path.")
+end subroutine ALE_init
+
+!> Same interface as the reference ALE_end (:411)
+subroutine ALE_end(CS)
+  type(ALE_CS), pointer :: CS
+  if (associated(CS)) then
+    if (allocated(CS%coordinateResolution)) deallocate(CS%coordinateResolution)
+    deallocate(CS)
+  endif
+end subroutine ALE_end
+
+!> Same interface as the reference ALE_update_regrid_weights (:1719)
+subroutine ALE_update_regrid_weights(dt, CS)
+  real,         intent(in) :: dt
+  type(ALE_CS), pointer    :: CS
+  real :: w
+  if (associated(CS)) then
+    w = 0.0
+    if (CS%regrid_time_scale > 0.0) w = CS%regrid_time_scale / (CS%regrid_time_scale + dt)
+    CS%old_grid_weight = w
+  endif
+end subroutine ALE_update_regrid_weights
+
+!> Same interface as the reference ALE_set_extrap_boundaries (:328)
+subroutine ALE_set_extrap_boundaries(param_file, CS)
+  type(param_file_type), intent(in) :: param_file
+  type(ALE_CS),          pointer    :: CS
+  logical :: remap_boundary_extrap
+  call get_param(param_file, "MOM_ALE", "REMAP_BOUNDARY_EXTRAP", remap_boundary_extrap, &
+                 "If true, values at the interfaces of boundary cells are extrapolated instead of piecewise constant", &
+                 default=.false.)
+  CS%boundary_extrapolation = remap_boundary_extrap
+end subroutine ALE_set_extrap_boundaries
+
+!> Same interface as the reference ALE_regrid (:484)
+subroutine ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, CS, frac_shelf_h, PCM_cell)
+  type(ocean_grid_type),                      intent(in)    :: G
+  type(verticalGrid_type),                    intent(in)    :: GV
+  type(unit_scale_type),                      intent(in)    :: US
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(in)  :: h
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(out) :: h_new
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)+1), target, intent(out) :: dzRegrid
+  type(thermo_var_ptrs),                      intent(inout) :: tv
+  type(ALE_CS),                               pointer       :: CS
+  real, dimension(SZI_(G),SZJ_(G)), optional, intent(in)    :: frac_shelf_h
+  logical, dimension(SZI_(G),SZJ_(G),SZK_(GV)), optional, intent(out) :: PCM_cell
+
+  type(mom6hip_regridding_cs_t) :: rcs
+  real(c_double), allocatable, target :: res(:)
+  integer :: rc
+
+  if (.not.associated(CS)) call MOM_error(FATAL, "ALE_regrid: the ALE control structure is not associated.")
+  if (present(frac_shelf_h)) call MOM_error(FATAL, "ALE_regrid (HIP): ice shelves (frac_shelf_h) are not provided by the GPU path.")
+  if (present(PCM_cell)) call MOM_error(FATAL, "ALE_regrid (HIP): PCM_cell is not provided by the GPU path.")
+  if (.not.GV%Boussinesq) call MOM_error(FATAL, "ALE_regrid (HIP): only the Boussinesq mode is provided by the GPU path.")
+  allocate(res(CS%nk)) ; res(:) = CS%coordinateResolution(:)
+  rcs%regridding_scheme = MOM6HIP_REGRIDDING_ZSTAR ; rcs%nk = CS%nk
+  rcs%min_thickness = CS%min_thickness ; rcs%old_grid_weight = CS%old_grid_weight
+  rcs%depth_of_time_filter_shallow = CS%filter_shallow_depth ; rcs%depth_of_time_filter_deep = CS%filter_deep_depth
+  rcs%Z_ref = G%Z_ref ; rcs%coordinateResolution = c_loc(res)
+  rc = mom6hip_ale_regrid(mom6hip_shared_context(G, GV), rcs, c_loc(h), c_loc(h_new), c_loc(dzRegrid), MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "ALE_regrid")
+end subroutine ALE_regrid
+
+!> Same interface as the reference ALE_remap_tracers (:737)
+subroutine ALE_remap_tracers(CS, G, GV, h_old, h_new, Reg, debug, dt, PCM_cell)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: h_old
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: h_new
+  type(tracer_registry_type),                pointer       :: Reg
+  logical,                         optional, intent(in)    :: debug
+  real,                            optional, intent(in)    :: dt
+  logical, dimension(SZI_(G),SZJ_(G),SZK_(GV)), optional, intent(in) :: PCM_cell
+
+  type(mom6hip_remapping_cs_t) :: mcs
+  type(c_ptr), allocatable :: tr(:)
+  real(c_double), allocatable, target :: cu(:)
+  integer :: m, ntr, rc
+
+  if (present(PCM_cell)) call MOM_error(FATAL, "ALE_remap_tracers (HIP): PCM_cell is not provided by the GPU path.")
+  ntr = 0 ; if (associated(Reg)) ntr = Reg%ntr
+  if (ntr < 1) return
+  allocate(tr(ntr), cu(ntr))
+  do m=1,ntr
+    tr(m) = c_loc(Reg%Tr(m)%t)
+    cu(m) = Reg%Tr(m)%conc_underflow
+  enddo
+  mcs%remapping_scheme = CS%remap_scheme ; mcs%boundary_extrapolation = merge(1, 0, CS%boundary_extrapolation)
+  mcs%force_bounds_in_subcell = 0 ; mcs%answer_date = CS%answer_date
+  rc = mom6hip_ale_remap_tracers(mom6hip_shared_context(G, GV), mcs, c_loc(h_old), c_loc(h_new), tr, c_loc(cu), &
+                                 int(ntr, c_int32_t), MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "ALE_remap_tracers")
+end subroutine ALE_remap_tracers
+
+!> Same interface as the reference ALE_remap_set_h_vel (:870)
+subroutine ALE_remap_set_h_vel(CS, G, GV, h_new, h_u, h_v, OBC, debug)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in)    :: h_new
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(inout) :: h_u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(inout) :: h_v
+  type(ocean_OBC_type),                      pointer       :: OBC
+  logical,                         optional, intent(in)    :: debug
+  integer :: rc
+  if (associated(OBC)) call MOM_error(FATAL, "ALE_remap_set_h_vel (HIP): open boundaries are not provided by the GPU path.")
+  rc = mom6hip_ale_remap_set_h_vel(mom6hip_shared_context(G, GV), c_loc(h_new), c_loc(h_u), c_loc(h_v), MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "ALE_remap_set_h_vel")
+end subroutine ALE_remap_set_h_vel
+
+!> Same interface as the reference ALE_remap_velocities (:1061)
+subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(in)    :: h_old_u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(in)    :: h_old_v
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(in)    :: h_new_u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(in)    :: h_new_v
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(inout) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(inout) :: v
+  logical,                         optional, intent(in)    :: debug
+  real,                            optional, intent(in)    :: dt
+  logical,                         optional, intent(in)    :: allow_preserve_variance
+  type(mom6hip_remapping_cs_t) :: mcs
+  integer :: rc
+  mcs%remapping_scheme = CS%vel_remap_scheme ; mcs%boundary_extrapolation = merge(1, 0, CS%boundary_extrapolation)
+  mcs%force_bounds_in_subcell = 0 ; mcs%answer_date = CS%answer_date
+  rc = mom6hip_ale_remap_velocities(mom6hip_shared_context(G, GV), mcs, c_loc(h_old_u), c_loc(h_old_v), c_loc(h_new_u), &
+                                    c_loc(h_new_v), c_loc(u), c_loc(v), MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "ALE_remap_velocities")
+end subroutine ALE_remap_velocities
+
+end module MOM_ALE

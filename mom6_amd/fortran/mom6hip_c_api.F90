@@ -12,6 +12,9 @@ integer(c_int32_t), parameter :: MOM6HIP_MEM_HOST = 0, MOM6HIP_MEM_DEVICE = 1
 integer(c_int32_t), parameter :: MOM6HIP_ADV_PLM = 0, MOM6HIP_ADV_PPM_H3 = 1, MOM6HIP_ADV_PPM = 2
 integer(c_int32_t), parameter :: MOM6HIP_POS_H = 0, MOM6HIP_POS_U = 1, MOM6HIP_POS_V = 2, MOM6HIP_POS_Q = 3
 integer(c_int32_t), parameter :: MOM6HIP_EOS_LINEAR = 1, MOM6HIP_EOS_WRIGHT = 3
+!> REMAPPING_* of src/ALE/MOM_remapping.F90:51-59 and REGRIDDING_ZSTAR of regrid_consts.F90:14
+integer(c_int32_t), parameter :: MOM6HIP_REMAP_PCM = 0, MOM6HIP_REMAP_PLM = 2, MOM6HIP_REMAP_PPM_H4 = 4, MOM6HIP_REMAP_PPM_IH4 = 5, &
+                                 MOM6HIP_REMAP_PPM_CW = 10, MOM6HIP_REGRIDDING_ZSTAR = 2
 
 !> mom6hip_grid_t of include/mom6hip.h
 type, bind(c) :: mom6hip_grid_t

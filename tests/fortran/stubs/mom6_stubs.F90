@@ -210,7 +210,7 @@ type :: param_file_type
   character(len=128) :: values(64)
 end type param_file_type
 interface get_param
-  module procedure get_param_logical, get_param_real, get_param_int, get_param_char
+  module procedure get_param_logical, get_param_real, get_param_int, get_param_char, get_param_real_array
 end interface
 contains
 subroutine param_set(CS, name, value)
@@ -278,6 +278,24 @@ subroutine get_param_real(CS, modulename, varname, value, desc, units, default, 
   if (present(unscaled)) unscaled = value
   if (present(scale)) value = scale * value
 end subroutine get_param_real
+subroutine get_param_real_array(CS, modulename, varname, value, desc, units, default, fail_if_missing, do_not_read, do_not_log, &
+                                debuggingParam, scale)
+  type(param_file_type), intent(in)    :: CS
+  character(len=*),      intent(in)    :: modulename, varname
+  real, dimension(:),    intent(inout) :: value
+  character(len=*), optional, intent(in) :: desc, units
+  real, optional,        intent(in)    :: default, scale
+  logical, optional,     intent(in)    :: fail_if_missing, do_not_read, do_not_log, debuggingParam
+  character(len=128) :: v ; logical :: found
+  v = lookup(CS, varname, found)
+  if (found) then
+    read(v, *) value
+  else
+    if (present(default)) value(:) = default
+    call missing(varname, fail_if_missing)
+  endif
+  if (present(scale)) value(:) = scale * value(:)
+end subroutine get_param_real_array
 subroutine get_param_int(CS, modulename, varname, value, desc, units, default, fail_if_missing, do_not_read, do_not_log, &
                          layoutParam, debuggingParam)
   type(param_file_type), intent(in)    :: CS
@@ -383,6 +401,7 @@ type :: SAL_CS
 end type SAL_CS
 end module MOM_self_attr_load
 
+#ifndef MOM6HIP_WITH_ALE_SHIM
 module MOM_ALE
 implicit none ; private
 public :: ALE_CS
@@ -390,6 +409,7 @@ type :: ALE_CS
   integer :: unused = 0
 end type ALE_CS
 end module MOM_ALE
+#endif
 
 module MOM_tidal_forcing
 implicit none ; private

@@ -336,3 +336,78 @@ def test_viscosity_shims_match_oracle(tmp_path):
     for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
         pos = V if n.endswith("_v") or n in ("v", "tauy_bot", "diffv") else U
         assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
+
+
+def _build_ale_shim(tmp):
+    """the MOM_ALE shim takes the place of the type-only stand-in of the same module (-DMOM6HIP_WITH_ALE_SHIM)"""
+    flags = ["-cpp", "-DMOM6HIP_WITH_ALE_SHIM", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in ("mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_ALE_hip.F90")] + \
+           [os.path.join(ROOT, "tests", "fortran", "ale_driver.F90")]
+    for src in srcs:
+        o = str(tmp / (os.path.basename(src)[:-4] + ".o"))
+        subprocess.run([FC, *flags, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    libdir = os.path.join(ROOT, "mom6_amd")
+    exe = str(tmp / "ale_driver")
+    subprocess.run([FC, *objs, f"-L{libdir}", "-lmom6hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_ale_shim_compiles():
+    import tempfile, pathlib
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    with tempfile.TemporaryDirectory() as d:
+        assert os.path.exists(_build_ale_shim(pathlib.Path(d)))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_ale_shim_matches_oracle(tmp_path):
+    """ALE_init (Z*, UNIFORM, PPM_H4 / PLM, REGRID_TIME_SCALE with a deep filter, REMAP_BOUNDARY_EXTRAP through
+    ALE_set_extrap_boundaries), ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel x2,
+    ALE_remap_velocities through the MOM_ALE shim on Fortran host arrays, the sequence of MOM.F90:1647-1700: the oracle's bits"""
+    from mom6_amd import synth
+    from oracle import orc
+    from helpers import interior
+    exe = _build_ale_shim(tmp_path)
+    ni, nj, nk, halo = 34, 18, 6, 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=21, reentrant_x=True, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=9, umax=0.3, eta_amp=0.5).items()}
+    dt = 1800.0
+    max_depth = float(g.bathyT.max())
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([ni, nj, nk, halo, 1, 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], d["T"], d["S"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        np.array([max_depth], dtype="<f8").tofile(f)
+    # the oracle with what the driver's parameters mean
+    res = np.full(nk, max_depth / nk)                                   # ALE_COORDINATE_CONFIG = UNIFORM
+    w = 3600.0 / (3600.0 + dt)                                          # ALE_update_regrid_weights, REGRID_TIME_SCALE = 3600
+    rcs = orc.regridding_cs(res, min_thickness=1.0e-3, old_grid_weight=w, zs=0.0, zd=500.0)
+    h_new, dz = orc.ale_regrid(g, rcs, d["h"])
+    T, S = d["T"].copy(), d["S"].copy()
+    orc.ale_remap_tracers(g, "PPM_H4", d["h"], h_new, [T, S], conc_underflow=np.array([0.0, 1.0e-30]), boundary_extrapolation=True)
+    hu0, hv0 = orc.ale_remap_set_h_vel(g, d["h"])
+    hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
+    u, v = d["u"].copy(), d["v"].copy()
+    orc.ale_remap_velocities(g, "PLM", hu0, hv0, hu1, hv1, u, v, boundary_extrapolation=True)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "ale_driver ok" in r.stdout
+    want = [h_new, dz, T, S, hu1, hv1, u, v]
+    names = ["h_new", "dzRegrid", "T", "S", "h_new_u", "h_new_v", "u", "v"]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [x.size for x in want]
+    assert raw.size == sum(sizes)
+    U, V, H = _abi.POS_U, _abi.POS_V, _abi.POS_H
+    for n, a, x in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        pos = U if n in ("h_new_u", "u") else (V if n in ("h_new_v", "v") else H)
+        assert bits_equal(interior(g, a.reshape(x.shape), pos), interior(g, x, pos)), n
+    assert not np.array_equal(interior(g, h_new), interior(g, d["h"]))
