@@ -197,9 +197,19 @@ class Model:
                            + self.v[:, sj.start:sj.stop, si] ** 2 + self.v[:, sj.start + 1:sj.stop + 1, si] ** 2)).sum(0)
         nocean = float(mT.sum())
         vanished = float(((hc < 1.0e-6) * mT[None]).sum()) / max(nocean * g.nk, 1.0)
-        return dict(umax=float(self.u.abs().max()), vmax=float(self.v.abs().max()), hmin=float(self.h.min()),
-                    eta_max=float((self.CS.eta[sj, si] * mT).abs().max()), ke_mean=float((ke * mT).sum()) / max(nocean, 1.0),
-                    vanished_layer_fraction=vanished, nan=bad)
+        out = dict(umax=float(self.u.abs().max()), vmax=float(self.v.abs().max()), hmin=float(self.h.min()),
+                   eta_max=float((self.CS.eta[sj, si] * mT).abs().max()), ke_mean=float((ke * mT).sum()) / max(nocean, 1.0),
+                   vanished_layer_fraction=vanished, nan=bad)
+        if not bad:
+            # what MOM6 would write to ocean.stats for this state (write_energy, MOM_sum_output.F90:428), formed on the device as
+            # order-invariant sums: the same numbers on any number of GPUs
+            from mom6_amd.sum_output import write_energy
+            e = write_energy(self.u, self.v, self.h, (self.T, self.S), self.dg, DT, H_to_kg_m2=float(self.g.Rho0))
+            cp = 3991.86795711963
+            out["ocean_stats"] = {"En_KE_per_mass": e["KE_tot"] / e["mass_tot"], "max_CFL": e["max_CFL"], "mass_kg": e["mass_tot"],
+                                  "mean_salin": e["Salt"] / e["mass_tot"], "mean_temp": e["Heat"] / (e["mass_tot"] * cp),
+                                  "mass_EFP": e["mass_EFP"]}
+        return out
 
 
 class Components:
