@@ -311,7 +311,10 @@ int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t);
 #define MOM6HIP_REMAP_PCM     0
 #define MOM6HIP_REMAP_PLM     2
 #define MOM6HIP_REMAP_PPM_H4  4
+#define MOM6HIP_REMAP_PLM_HYBGEN  3
 #define MOM6HIP_REMAP_PPM_IH4 5
+#define MOM6HIP_REMAP_PPM_HYBGEN  6
+#define MOM6HIP_REMAP_WENO_HYBGEN 7
 #define MOM6HIP_REMAP_PPM_CW  10
 
 /* remapping_CS, src/ALE/MOM_remapping.F90:25-41 */

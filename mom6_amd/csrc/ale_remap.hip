@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr int REMAP_PCM = 0, REMAP_PLM = 2, REMAP_PPM_H4 = 4, REMAP_PPM_IH4 = 5, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-56
+constexpr int REMAP_PCM = 0, REMAP_PLM = 2, REMAP_PLM_HYBGEN = 3, REMAP_PPM_H4 = 4, REMAP_PPM_IH4 = 5, REMAP_PPM_HYBGEN = 6,
+              REMAP_WENO_HYBGEN = 7, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-56
 constexpr int INT_PCM = 0, INT_PLM = 1, INT_PPM = 3;            // :61-63
 
 __device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
@@ -794,6 +795,85 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     wsync();
     return INT_PLM;
   }
+  if (local == REMAP_PLM_HYBGEN) {      // hybgen_plm_coefs (MOM_hybgen_remap.F90:14-88), MOM_remapping.F90:306-315
+    const double thin = h_neglect;
+    for (int k = lane; k < n; k += 64) {
+      double sl = 0.0;
+      if (k >= 1 && k < n - 1 && !(h[k] <= thin)) {
+        const double qcen = h[k] / (h[k] + 0.5 * (h[k - 1] + h[k + 1]));
+        const double ztop = 2.0 * (u[k] - u[k - 1]);
+        const double zbot = 2.0 * (u[k + 1] - u[k]);
+        const double zcen = qcen * (u[k + 1] - u[k - 1]);
+        if (ztop * zbot > 0.0) sl = fsign(min3(fabs(zcen), fabs(zbot), fabs(ztop)), zbot);
+      }
+      c.C1[k] = sl;
+      EL[k] = u[k] - 0.5 * sl;
+      ER[k] = u[k] + 0.5 * sl;
+    }
+    wsync();
+    if (extrap && lane == 0) {      // PLM_boundary_extrapolation :272-307
+      double slope = -plm_extrapolate_slope(h[1], h[0], h_neglect, u[1], u[0]);
+      EL[0] = u[0] - 0.5 * slope; ER[0] = u[0] + 0.5 * slope;
+      c.C1[0] = ER[0] - EL[0];
+      slope = plm_extrapolate_slope(h[n - 2], h[n - 1], h_neglect, u[n - 2], u[n - 1]);
+      EL[n - 1] = u[n - 1] - 0.5 * slope; ER[n - 1] = u[n - 1] + 0.5 * slope;
+      c.C1[n - 1] = ER[n - 1] - EL[n - 1];
+    }
+    wsync();
+    return INT_PLM;
+  }
+  if (local == REMAP_WENO_HYBGEN) {
+    // ---- hybgen_weno_coefs (MOM_hybgen_remap.F90:226-386): the edge slopes, the two one-sided estimates of every cell with their
+    // weights, the weighted edge values, the final limiter -- four passes across the lanes
+    const double thin = h_neglect, min_ratio = 1.0e-8;
+    auto dp = [&](int k) { return fmax(h[k], thin); };
+    double *slope_edge = c.u_sub, *zw1 = c.uh_sub, *zw2 = c.uh_sub + n, *val_edge = c.C1;      // (free until the tail / the sub-cell pass)
+    for (int K = lane + 1; K < n; K += 64) slope_edge[K] = (1.0 / (dp(K - 1) + dp(K))) * (u[K] - u[K - 1]);
+    wsync();
+    for (int k = lane; k < n; k += 64) {
+      double e1 = u[k], e2 = u[k], w1 = 0.0, w2 = 0.0;
+      if (k >= 1 && k < n - 1 && !((slope_edge[k] * slope_edge[k + 1] < 0.0) || (dp(k) <= thin))) {
+        const double dpkm2kp = dp(k - 1) + 2.0 * dp(k) + dp(k + 1);
+        const double qdpkmkp = 1.0 / (dp(k - 1) + dp(k) + dp(k + 1));
+        double seh1 = dp(k) * slope_edge[k + 1];
+        double seh2 = dp(k) * slope_edge[k];
+        const double q01 = dpkm2kp * slope_edge[k + 1];
+        const double q02 = dpkm2kp * slope_edge[k];
+        if (fabs(seh1) > fabs(q02)) seh1 = q02;
+        if (fabs(seh2) > fabs(q01)) seh2 = q01;
+        const double curv_cell = (seh1 - seh2) * qdpkmkp;
+        const double q001 = seh1 - curv_cell * dp(k + 1);
+        const double q002 = seh2 + curv_cell * dp(k - 1);
+        e2 = u[k] + q001;
+        e1 = u[k] - q002;
+        w1 = (2.0 * q001 - q002) * (2.0 * q001 - q002);
+        w2 = (2.0 * q002 - q001) * (2.0 * q002 - q001);
+      }
+      EL[k] = e1; ER[k] = e2; zw1[k] = w1; zw2[k] = w2;
+    }
+    wsync();
+    for (int K = lane + 1; K < n; K += 64) {
+      double wt1;
+      if (zw1[K] + zw2[K - 1] <= 0.0) wt1 = 0.5;
+      else if (zw1[K] <= min_ratio * (zw1[K] + zw2[K - 1])) wt1 = min_ratio;
+      else if (zw2[K - 1] <= min_ratio * (zw1[K] + zw2[K - 1])) wt1 = (1.0 - min_ratio);
+      else wt1 = zw1[K] / (zw1[K] + zw2[K - 1]);
+      val_edge[K] = wt1 * ER[K - 1] + (1.0 - wt1) * EL[K];
+    }
+    wsync();
+    for (int k = lane + 1; k < n - 1; k += 64) {
+      if (!(dp(k) <= thin)) {
+        double q01 = val_edge[k + 1] - u[k];
+        double q02 = u[k] - val_edge[k];
+        if (q01 * q02 < 0.0) { q01 = 0.0; q02 = 0.0; }
+        else if (fabs(q01) > fabs(2.0 * q02)) q01 = 2.0 * q02;
+        else if (fabs(q02) > fabs(2.0 * q01)) q02 = 2.0 * q01;
+        EL[k] = u[k] - q02;
+        ER[k] = u[k] + q01;
+      }
+    }
+    wsync();
+  } else
   if (local == REMAP_PPM_IH4) {
     // ---- PPM_IH4: edge_values_implicit_h4 (regrid_edge_values.F90:491-654, answer_date >= 20190101).  The rows of the
     // tridiagonal system across the lanes, the two closing rows on the last two lanes, solve_diag_dominant_tridiag
@@ -843,17 +923,21 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     wsync();
     for (int k = lane; k < n; k += 64) { EL[k] = tri_b[k]; ER[k] = tri_b[k + 1]; }
     wsync();
-  } else if (local == REMAP_PPM_CW) {
-    // ---- PPM_CW: edge_values_explicit_h4cw (regrid_edge_values.F90:381-463) and PPM_monotonicity (PPM_functions.F90:132)
-    const double hNeglect = h_neglect_edge;
+  } else if (local == REMAP_PPM_CW || local == REMAP_PPM_HYBGEN) {
+    // ---- PPM_CW: edge_values_explicit_h4cw (regrid_edge_values.F90:381-463) and PPM_monotonicity (PPM_functions.F90:132).
+    // ---- PPM_HYBGEN: hybgen_ppm_coefs (MOM_hybgen_remap.F90:91-222), the HYCOM routine the two above re-express: the same
+    //      arithmetic with the minimum thickness `thin` = h_neglect and layers no thicker than it treated as PCM (:140-147)
+    const bool hyb = local == REMAP_PPM_HYBGEN;
+    const double hNeglect = hyb ? h_neglect : h_neglect_edge;
     double *au = c.u_sub;      // the limited slopes of Colella & Woodward eq. 1.8, 0-based cell index
     auto dp = [&](int k) { return fmax(h[k], hNeglect); };      // 0-based; the reference's dp(k+1)
+    auto pcm = [&](int k) { return hyb && (dp(k) <= hNeglect); };
     for (int k = lane; k < n; k += 64) {
       double a = 0.;
       if (k >= 1 && k <= n - 2) {
         const double slk = u[k] - u[k - 1];
         const double srk = u[k + 1] - u[k];
-        if (slk * srk > 0.) {
+        if (!pcm(k) && slk * srk > 0.) {
           // h2_h123(k), h112(K), I_h12(K+1), h122(K+1), I_h12(K) of the reference with K = k+1 (1-based)
           const double h2_h123 = dp(k) / (dp(k) + (dp(k - 1) + dp(k + 1)));
           const double h112 = 2. * dp(k - 1) + dp(k), h122p = dp(k) + 2. * dp(k + 1);
@@ -880,7 +964,7 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     if (lane == 0) { EL[0] = u[0]; ER[0] = u[0]; EL[1] = u[0]; ER[n - 2] = u[n - 1]; EL[n - 1] = u[n - 1]; ER[n - 1] = u[n - 1]; }
     wsync();
     for (int k = lane + 1; k < n - 1; k += 64) {      // PPM_monotonicity
-      if ((u[k + 1] - u[k]) * (u[k] - u[k - 1]) <= 0.) {
+      if (pcm(k) || (u[k + 1] - u[k]) * (u[k] - u[k - 1]) <= 0.) {
         EL[k] = u[k]; ER[k] = u[k];
       } else {
         const double da = ER[k] - EL[k];
@@ -1189,10 +1273,11 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
   }
 }
 
-// PPM_IH4 and PPM_CW exist in the wave-per-column kernel only
+// PPM_IH4, PPM_CW and the three HYBGEN schemes exist in the wave-per-column kernel only
 bool scheme_provided(int scheme) {
   if (scheme == REMAP_PCM || scheme == REMAP_PLM || scheme == REMAP_PPM_H4) return true;
-  return (scheme == REMAP_PPM_IH4 || scheme == REMAP_PPM_CW) && !lane_per_column_env();
+  return (scheme == REMAP_PPM_IH4 || scheme == REMAP_PPM_CW || scheme == REMAP_PLM_HYBGEN || scheme == REMAP_PPM_HYBGEN ||
+          scheme == REMAP_WENO_HYBGEN) && !lane_per_column_env();
 }
 
 // MOM6HIP_ALE_LANE_PER_COLUMN=1 selects the older lane-per-column kernels (kept for comparison runs)
@@ -1236,7 +1321,7 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
   M6_REQUIRE(tr != nullptr && ntr <= 64, "ALE_remap_tracers: bad tracer list");
   M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM, PPM_H4, PPM_IH4 and PPM_CW)");
+             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN and PPM_CW)");
   M6_REQUIRE(cs->answer_date >= 20190101, "ALE_remap_tracers: only REMAPPING_ANSWER_DATE >= 20190101 is provided");
   M6_REQUIRE(!cs->force_bounds_in_subcell, "ALE_remap_tracers: REMAP_BOUND_INTERMEDIATE_VALUES is not provided");
   M6_REQUIRE(ctx->g.mask2dT != nullptr, "ALE_remap_tracers: mask2dT is required");
@@ -1349,7 +1434,7 @@ extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_re
   M6_REQUIRE(ctx && cs && h_old_u && h_old_v && h_new_u && h_new_v && u && v, "ALE_remap_velocities: null argument");
   M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM, PPM_H4, PPM_IH4 and PPM_CW)");
+             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN and PPM_CW)");
   M6_REQUIRE(cs->answer_date >= 20190101 && !cs->force_bounds_in_subcell, "ALE_remap_velocities: unsupported remapping options");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.nk <= 128 && g.mask2dCu && g.mask2dCv, "ALE_remap_velocities: at most 128 layers; face masks are needed");

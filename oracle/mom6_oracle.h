@@ -70,7 +70,10 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
 /* REMAPPING_* and INTEGRATION_* of src/ALE/MOM_remapping.F90:50-64 */
 #define ORC_REMAP_PCM     0
 #define ORC_REMAP_PLM     2
+#define ORC_REMAP_PLM_HYBGEN 3
 #define ORC_REMAP_PPM_H4  4
+#define ORC_REMAP_PPM_HYBGEN 6
+#define ORC_REMAP_WENO_HYBGEN 7
 #define ORC_REMAP_PPM_IH4 5
 #define ORC_REMAP_PPM_CW  10
 #define ORC_INT_PCM 0
@@ -83,6 +86,9 @@ double orc_plm_monotonized_slope(double u_l, double u_c, double u_r, double s_l,
 double orc_plm_extrapolate_slope(double h_l, double h_c, double h_neglect, double u_l, double u_c);
 void orc_plm_reconstruction(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);
 void orc_plm_boundary_extrapolation(int n, const double *h, const double *u, double *E, double *coef, double h_neglect);
+void orc_hybgen_plm_coefs(int nk, const double *si, const double *dpi, double *slope, double thin);
+void orc_hybgen_ppm_coefs(int nk, const double *s, const double *h_src, double *E, double thin);
+void orc_hybgen_weno_coefs(int nk, const double *s, const double *h_src, double *E, double thin);
 void orc_bound_edge_values(int n, const double *h, const double *u, double *E);
 void orc_check_discontinuous_edge_values(int n, const double *u, double *E);
 void orc_end_value_h4(const double dz[4], const double u[4], double Csys[4]);

@@ -94,7 +94,7 @@ def advect_tracer(grid, h_end, uhtr, vhtr, dt, cs_dt, scheme, tr, conc_underflow
 
 
 # ---- ALE reconstruction + remapping ---------------------------------------------------------------
-REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PPM_H4": 4, "PPM_IH4": 5, "PPM_CW": 10}
+REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PLM_HYBGEN": 3, "PPM_H4": 4, "PPM_IH4": 5, "PPM_HYBGEN": 6, "WENO_HYBGEN": 7, "PPM_CW": 10}
 INT_PCM, INT_PLM, INT_PPM = 0, 1, 3
 _ip = C.POINTER(C.c_int)
 
@@ -143,6 +143,17 @@ def plm_reconstruction(h, u, h_neglect=1e-30, extrapolate=False):
     if extrapolate:
         L.orc_plm_boundary_extrapolation(n, _p(h), _p(u), _p(E), _p(co), h_neglect)
     return E, co
+
+
+def hybgen_coefs(which, s, h, thin=1e-30):
+    """hybgen_plm_coefs (slope [n]) / hybgen_ppm_coefs / hybgen_weno_coefs (edges [2, n]) of MOM_hybgen_remap.F90"""
+    s, h = _a(s), _a(h); n = len(s)
+    L = _remap_lib()
+    for f in (L.orc_hybgen_plm_coefs, L.orc_hybgen_ppm_coefs, L.orc_hybgen_weno_coefs):
+        f.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double]; f.restype = None
+    out = np.zeros(n) if which == "plm" else np.zeros((2, n))
+    {"plm": L.orc_hybgen_plm_coefs, "ppm": L.orc_hybgen_ppm_coefs, "weno": L.orc_hybgen_weno_coefs}[which](n, _p(s), _p(h), _p(out), float(thin))
+    return out
 
 
 def edge_values_explicit_h4(h, u, h_neglect=1e-30):
@@ -214,6 +225,10 @@ def ref_lib():
     L.ref_plm_slope_wa.argtypes = [d] * 7; L.ref_plm_slope_wa.restype = d
     L.ref_plm_monotonized_slope.argtypes = [d] * 6; L.ref_plm_monotonized_slope.restype = d
     L.ref_plm_extrapolate_slope.argtypes = [d] * 5; L.ref_plm_extrapolate_slope.restype = d
+    if hasattr(L, "ref_hybgen_plm"):
+        L.ref_hybgen_plm.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_plm.restype = None
+        L.ref_hybgen_ppm.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_ppm.restype = None
+        L.ref_hybgen_weno.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_weno.restype = None
     if hasattr(L, "ref_rotate_array"):
         L.ref_rotate_array.argtypes = [i, i, i, _dp, i, _dp]; L.ref_rotate_array.restype = None
         L.ref_rotate_vector.argtypes = [i] * 5 + [_dp, _dp, i, _dp, _dp]; L.ref_rotate_vector.restype = None

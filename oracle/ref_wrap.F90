@@ -1,6 +1,6 @@
 !> bind(C) entry points around the reference routines that compile from their own source files with
-!! no stand-ins (src/ALE/PLM_functions.F90, PCM_functions.F90, src/framework/MOM_array_transform.F90: no `use` of any
-!! other module).
+!! no stand-ins (src/ALE/PLM_functions.F90, PCM_functions.F90, MOM_hybgen_remap.F90, src/framework/MOM_array_transform.F90: no
+!! `use` of any other module).
 !! This file is ours (a caller of the reference, not a copy of it); the reference sources are
 !! compiled where they lie under /root/reference by oracle/build_ref.sh into oracle/_ref/.
 module mom6_ref_wrap
@@ -9,6 +9,7 @@ use PLM_functions, only : PLM_reconstruction, PLM_boundary_extrapolation, PLM_sl
                           PLM_monotonized_slope, PLM_extrapolate_slope
 use PCM_functions, only : PCM_reconstruction
 use MOM_array_transform, only : rotate_array, rotate_vector
+use MOM_hybgen_remap, only : hybgen_plm_coefs, hybgen_ppm_coefs, hybgen_weno_coefs
 implicit none
 contains
 
@@ -46,6 +47,31 @@ function ref_plm_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c) bind(c, name="
   real(c_double) :: s
   s = PLM_extrapolate_slope(h_l, h_c, h_neglect, u_l, u_c)
 end function ref_plm_extrapolate_slope
+
+!> hybgen_plm_coefs / hybgen_ppm_coefs / hybgen_weno_coefs (src/ALE/MOM_hybgen_remap.F90:14, :91, :226) for one scalar field
+subroutine ref_hybgen_plm(n, s, dp, slope, thin) bind(c, name="ref_hybgen_plm")
+  integer(c_int), value :: n
+  real(c_double), intent(in) :: s(n,1), dp(n)
+  real(c_double), intent(inout) :: slope(n,1)
+  real(c_double), value :: thin
+  call hybgen_plm_coefs(s, dp, slope, n, 1, thin)
+end subroutine ref_hybgen_plm
+
+subroutine ref_hybgen_ppm(n, s, h, edges, thin) bind(c, name="ref_hybgen_ppm")
+  integer(c_int), value :: n
+  real(c_double), intent(in) :: s(n,1), h(n)
+  real(c_double), intent(inout) :: edges(n,2,1)
+  real(c_double), value :: thin
+  call hybgen_ppm_coefs(s, h, edges, n, 1, thin)
+end subroutine ref_hybgen_ppm
+
+subroutine ref_hybgen_weno(n, s, h, edges, thin) bind(c, name="ref_hybgen_weno")
+  integer(c_int), value :: n
+  real(c_double), intent(in) :: s(n,1), h(n)
+  real(c_double), intent(inout) :: edges(n,2,1)
+  real(c_double), value :: thin
+  call hybgen_weno_coefs(s, h, edges, n, 1, thin)
+end subroutine ref_hybgen_weno
 
 !> PLM_reconstruction of ncol columns of n layers (timing the reference's code against the restatement: tools/calibrate_ref.py)
 subroutine ref_plm_batch(ncol, n, h, u, E, coef, h_neglect) bind(c, name="ref_plm_batch")

@@ -650,7 +650,159 @@ void orc_remap_via_sub_cells(int n0, const double *h0, const double *u0, const d
   free(h0_eff); free(u0_min); free(u0_max); free(itgt_start); free(itgt_end);
 }
 
-/* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PPM_H4, PPM_IH4, PPM_CW; no PCM_cell).
+/* ---- MOM_hybgen_remap.F90: the HYCOM reconstructions behind PLM_HYBGEN, PPM_HYBGEN, WENO_HYBGEN (one scalar field, no PCM_lay).
+ * The reference file compiles with no other module, so these three are checked bit for bit against the reference's own code
+ * (oracle/_ref, tests/test_oracle_remapping.py). */
+
+/* hybgen_plm_coefs :14-88: slope [n] (the PLM slope times the cell width) */
+void orc_hybgen_plm_coefs(int nk, const double *si, const double *dpi, double *slope, double thin)
+{
+  slope[0] = 0.0; slope[nk-1] = 0.0;
+  for (int k = 1; k < nk-1; k++) {
+    if (dpi[k] <= thin) {
+      slope[k] = 0.0;
+    } else {
+      const double qcen = dpi[k] / (dpi[k]+0.5*(dpi[k-1]+dpi[k+1]));
+      const double ztop = 2.0*(si[k]-si[k-1]);
+      const double zbot = 2.0*(si[k+1]-si[k]);
+      const double zcen = qcen*(si[k+1]-si[k-1]);
+      if (ztop*zbot > 0.0) slope[k] = copysign(min3(fabs(zcen),fabs(zbot),fabs(ztop)), zbot);
+      else slope[k] = 0.0;
+    }
+  }
+}
+
+/* hybgen_ppm_coefs :91-222: E[0][k] the value at the interface above, E[1][k] below */
+void orc_hybgen_ppm_coefs(int nk, const double *s, const double *h_src, double *E, double thin)
+{
+  double *dp = calloc(nk+2, 8), *as = calloc(nk+2, 8), *al = calloc(nk+2, 8), *ar = calloc(nk+2, 8);
+  double *h112 = calloc(nk+3, 8), *h122 = calloc(nk+3, 8), *I_h12 = calloc(nk+3, 8), *h2_h123 = calloc(nk+2, 8);
+  double *I_h0123 = calloc(nk+2, 8), *h01_h112 = calloc(nk+3, 8), *h23_h122 = calloc(nk+3, 8);
+  int *PCM_layer = calloc(nk+2, sizeof(int));
+  /* 1-based as in the reference */
+#define S(k) s[(k)-1]
+  for (int k = 1; k <= nk; k++) dp[k] = max2(h_src[k-1], thin);
+  for (int k = 1; k <= nk; k++) PCM_layer[k] = (dp[k] <= thin);
+  for (int k = 2; k <= nk; k++) {
+    h112[k] = 2.*dp[k-1] + dp[k];
+    h122[k] = dp[k-1] + 2.*dp[k];
+    I_h12[k] = 1.0 / (dp[k-1] + dp[k]);
+  }
+  for (int k = 2; k <= nk-1; k++) h2_h123[k] = dp[k] / (dp[k] + (dp[k-1]+dp[k+1]));
+  for (int k = 3; k <= nk-1; k++) {
+    I_h0123[k] = 1.0 / ((dp[k-2] + dp[k-1]) + (dp[k] + dp[k+1]));
+    h01_h112[k] = (dp[k-2] + dp[k-1]) / (2.0*dp[k-1] + dp[k]);
+    h23_h122[k] = (dp[k] + dp[k+1])   / (dp[k-1] + 2.0*dp[k]);
+  }
+  as[1] = 0.;
+  for (int k = 2; k <= nk-1; k++) {
+    if (PCM_layer[k]) {
+      as[k] = 0.0;
+    } else {
+      const double slk = S(k)-S(k-1);
+      const double srk = S(k+1)-S(k);
+      if (slk*srk > 0.) {
+        const double sck = h2_h123[k]*( h112[k]*srk*I_h12[k+1] + h122[k+1]*slk*I_h12[k] );
+        as[k] = copysign(min3(fabs(2.0*slk), fabs(sck), fabs(2.0*srk)), sck);
+      } else {
+        as[k] = 0.;
+      }
+    }
+  }
+  as[nk] = 0.;
+  al[1] = S(1); ar[1] = S(1); al[2] = S(1);
+  for (int k = 3; k <= nk-1; k++) {
+    al[k] = (dp[k]*S(k-1) + dp[k-1]*S(k)) * I_h12[k]
+          + I_h0123[k]*( 2.*dp[k]*dp[k-1]*I_h12[k]*(S(k)-S(k-1)) *
+                         ( h01_h112[k] - h23_h122[k] )
+                  + (dp[k]*as[k-1]*h23_h122[k] - dp[k-1]*as[k]*h01_h112[k]) );
+    ar[k-1] = al[k];
+  }
+  ar[nk-1] = S(nk); al[nk] = S(nk); ar[nk] = S(nk);
+  for (int k = 2; k <= nk-1; k++) {
+    if (PCM_layer[k] || ((S(k+1)-S(k))*(S(k)-S(k-1)) <= 0.)) {
+      al[k] = S(k); ar[k] = S(k);
+    } else {
+      const double da = ar[k]-al[k];
+      const double a6 = 6.0*S(k) - 3.0*(al[k]+ar[k]);
+      if (da*a6 > da*da) al[k] = 3.0*S(k) - 2.0*ar[k];
+      else if (da*a6 < -da*da) ar[k] = 3.0*S(k) - 2.0*al[k];
+    }
+  }
+  for (int k = 1; k <= nk; k++) { E[k-1] = al[k]; E[nk + k-1] = ar[k]; }
+#undef S
+  free(dp); free(as); free(al); free(ar); free(h112); free(h122); free(I_h12); free(h2_h123); free(I_h0123); free(h01_h112);
+  free(h23_h122); free(PCM_layer);
+}
+
+/* hybgen_weno_coefs :226-386 */
+void orc_hybgen_weno_coefs(int nk, const double *s, const double *h_src, double *E, double thin)
+{
+  const double min_ratio = 1.0e-8;
+  double *dp = calloc(nk+2, 8), *qdpkm = calloc(nk+2, 8), *qdpkmkp = calloc(nk+2, 8), *dpkm2kp = calloc(nk+2, 8);
+  double *zw1 = calloc(nk+2, 8), *zw2 = calloc(nk+2, 8), *slope_edge = calloc(nk+3, 8), *val_edge = calloc(nk+3, 8);
+  double *e1 = calloc(nk+2, 8), *e2 = calloc(nk+2, 8);
+  int *PCM_layer = calloc(nk+2, sizeof(int));
+#define S(k) s[(k)-1]
+  for (int k = 1; k <= nk; k++) dp[k] = max2(h_src[k-1], thin);
+  for (int k = 1; k <= nk; k++) PCM_layer[k] = (dp[k] <= thin);
+  for (int k = 2; k <= nk-1; k++) {
+    qdpkm[k] = 1.0 / (dp[k-1] + dp[k]);
+    qdpkmkp[k] = 1.0 / (dp[k-1] + dp[k] + dp[k+1]);
+    dpkm2kp[k] = dp[k-1] + 2.0*dp[k] + dp[k+1];
+  }
+  qdpkm[nk] = 1.0 / (dp[nk-1] + dp[nk]);
+  for (int k = 2; k <= nk; k++) slope_edge[k] = qdpkm[k] * (S(k)-S(k-1));
+  e1[1] = S(1); e2[1] = S(1); zw1[1] = 0.0; zw2[1] = 0.0;
+  for (int k = 2; k <= nk-1; k++) {
+    if ((slope_edge[k]*slope_edge[k+1] < 0.0) || PCM_layer[k]) {
+      e1[k] = S(k); e2[k] = S(k); zw1[k] = 0.0; zw2[k] = 0.0;
+    } else {
+      double seh1 = dp[k]*slope_edge[k+1];
+      double seh2 = dp[k]*slope_edge[k];
+      const double q01 = dpkm2kp[k]*slope_edge[k+1];
+      const double q02 = dpkm2kp[k]*slope_edge[k];
+      if (fabs(seh1) > fabs(q02)) seh1 = q02;
+      if (fabs(seh2) > fabs(q01)) seh2 = q01;
+      const double curv_cell = (seh1 - seh2) * qdpkmkp[k];
+      const double q001 = seh1 - curv_cell*dp[k+1];
+      const double q002 = seh2 + curv_cell*dp[k-1];
+      e2[k] = S(k) + q001;
+      e1[k] = S(k) - q002;
+      zw1[k] = (2.0*q001 - q002)*(2.0*q001 - q002);
+      zw2[k] = (2.0*q002 - q001)*(2.0*q002 - q001);
+    }
+  }
+  e1[nk] = S(nk); e2[nk] = S(nk); zw1[nk] = 0.0; zw2[nk] = 0.0;
+  for (int k = 2; k <= nk; k++) {
+    double wt1;
+    if (zw1[k] + zw2[k-1] <= 0.0) wt1 = 0.5;
+    else if (zw1[k] <= min_ratio * (zw1[k] + zw2[k-1])) wt1 = min_ratio;
+    else if (zw2[k-1] <= min_ratio * (zw1[k] + zw2[k-1])) wt1 = (1.0 - min_ratio);
+    else wt1 = zw1[k] / (zw1[k] + zw2[k-1]);
+    val_edge[k] = wt1*e2[k-1] + (1.0-wt1)*e1[k];
+  }
+  val_edge[1] = 2.0*S(1)-val_edge[2];
+  val_edge[nk+1] = 2.0*S(nk)-val_edge[nk];
+  for (int k = 2; k <= nk-1; k++) {
+    if (!PCM_layer[k]) {
+      double q01 = val_edge[k+1] - S(k);
+      double q02 = S(k) - val_edge[k];
+      if (q01*q02 < 0.0) { q01 = 0.0; q02 = 0.0; }
+      else if (fabs(q01) > fabs(2.0*q02)) q01 = 2.0*q02;
+      else if (fabs(q02) > fabs(2.0*q01)) q02 = 2.0*q01;
+      e1[k] = S(k) - q02;
+      e2[k] = S(k) + q01;
+    }
+  }
+  for (int k = 1; k <= nk; k++) { E[k-1] = e1[k]; E[nk + k-1] = e2[k]; }
+#undef S
+  free(dp); free(qdpkm); free(qdpkmkp); free(dpkm2kp); free(zw1); free(zw2); free(slope_edge); free(val_edge); free(e1); free(e2);
+  free(PCM_layer);
+}
+
+/* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN,
+ * PPM_CW; no PCM_cell).
  * E and coef must hold 2*n0 and 3*n0 doubles.  Returns the integration method. */
 int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                                  double *coef, double *E, double h_neglect, double h_neglect_edge)
@@ -671,6 +823,25 @@ int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0,
       orc_plm_reconstruction(n0, h0, u0, E, coef, h_neglect);
       if (boundary_extrapolation) orc_plm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
       return ORC_INT_PLM;
+    case ORC_REMAP_PLM_HYBGEN:   /* :306-315 */
+      orc_hybgen_plm_coefs(n0, u0, h0, coef + n0, h_neglect);
+      for (int k = 0; k < n0; k++) {
+        E[k] = u0[k] - 0.5 * coef[n0 + k];
+        E[n0 + k] = u0[k] + 0.5 * coef[n0 + k];
+        coef[k] = E[k];
+      }
+      if (boundary_extrapolation) orc_plm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PLM;
+    case ORC_REMAP_PPM_HYBGEN:   /* :339-344 */
+      orc_hybgen_ppm_coefs(n0, u0, h0, E, h_neglect);
+      orc_ppm_reconstruction(n0, h0, u0, E, coef);
+      if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PPM;
+    case ORC_REMAP_WENO_HYBGEN:  /* :345-350 */
+      orc_hybgen_weno_coefs(n0, u0, h0, E, h_neglect);
+      orc_ppm_reconstruction(n0, h0, u0, E, coef);
+      if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
+      return ORC_INT_PPM;
     case ORC_REMAP_PPM_H4:
       orc_edge_values_explicit_h4(n0, h0, u0, E, h_neglect_edge);
       orc_ppm_reconstruction(n0, h0, u0, E, coef);

@@ -31,7 +31,7 @@ def remap_case(ni, nj, nk, ntr=3, seed=0, vanish=0.15):
     return g, np.ascontiguousarray(h_old), np.ascontiguousarray(h_new), tr
 
 
-@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PPM_H4", "PPM_IH4", "PPM_CW"])
+@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PLM_HYBGEN", "PPM_H4", "PPM_IH4", "PPM_HYBGEN", "WENO_HYBGEN", "PPM_CW"])
 @pytest.mark.parametrize("extrap", [False, True])
 @pytest.mark.parametrize("nk", [2, 3, 4, 8, 20, 75])
 def test_remap_tracers_parity(oracle, scheme, extrap, nk):

@@ -175,3 +175,52 @@ def test_plm_matches_reference_build(oracle):
             R.ref_plm_slope_wa(hh[0], hh[1], hh[2], 1e-30, a[3], a[4], a[5])
         assert oracle._remap_lib().orc_plm_extrapolate_slope(hh[0], hh[1], 1e-30, a[3], a[4]) == \
             R.ref_plm_extrapolate_slope(hh[0], hh[1], 1e-30, a[3], a[4])
+
+
+def test_hybgen_matches_reference_build(oracle):
+    """hybgen_plm_coefs / hybgen_ppm_coefs / hybgen_weno_coefs (src/ALE/MOM_hybgen_remap.F90, compiled unmodified into oracle/_ref):
+    the restatement gives the reference's bits on random columns with vanished layers, ties and extrema"""
+    R = oracle.ref_lib()
+    if R is None or not hasattr(R, "ref_hybgen_plm"):
+        pytest.skip("oracle/_ref not built (the reference sources only exist in the build container)")
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    P = lambda a: a.ctypes.data_as(dp)
+    rng = np.random.default_rng(23)
+    for trial in range(400):
+        n = int(rng.integers(5, 80))
+        h = rng.random(n) * 10.0 ** rng.integers(-3, 3)
+        h[rng.random(n) < 0.2] = 0.0
+        s = rng.standard_normal(n) * 10.0 ** rng.integers(-2, 3)
+        if trial % 4 == 0:
+            s = np.round(s)                      # ties / exact extrema
+        if trial % 7 == 0:
+            s = np.sort(s)                       # monotone profiles: the limiters stay open
+        thin = 1e-30 if trial % 3 else 1e-3
+        sl = np.zeros(n); R.ref_hybgen_plm(n, P(s), P(h), P(sl), thin)
+        assert bits_equal(oracle.hybgen_coefs("plm", s, h, thin), sl), ("plm", trial)
+        for which, f in (("ppm", R.ref_hybgen_ppm), ("weno", R.ref_hybgen_weno)):
+            Er = np.zeros((2, n)); f(n, P(s), P(h), P(Er), thin)
+            assert bits_equal(oracle.hybgen_coefs(which, s, h, thin), Er), (which, trial)
+
+
+@pytest.mark.parametrize("scheme", ["PLM_HYBGEN", "PPM_HYBGEN", "WENO_HYBGEN"])
+def test_hybgen_schemes_conserve_and_stay_bounded(oracle, scheme):
+    rng = np.random.default_rng(31)
+    for trial in range(60):
+        n0, n1 = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        h0 = rng.random(n0) + 0.01; h0[rng.random(n0) < 0.15] = 0.0
+        if h0.sum() == 0.0:
+            h0[0] = 1.0
+        h1 = rng.random(n1) + 0.01; h1 *= h0.sum() / h1.sum()
+        u0 = rng.standard_normal(n0)
+        u1 = oracle.remapping_core_h(scheme, h0, u0, h1, boundary_extrapolation=bool(trial % 2))
+        assert abs((u1 * h1).sum() - (u0 * h0).sum()) <= 1e-12 * max(1.0, np.abs(u0 * h0).sum())
+        if not trial % 2:
+            assert u1.min() >= u0.min() - 1e-12 and u1.max() <= u0.max() + 1e-12
+    # PPM_HYBGEN is the scheme PPM_CW re-expresses (MOM_remapping.F90:317): the same values wherever no layer is thinner than `thin`
+    h0 = rng.random(30) + 0.5; u0 = rng.standard_normal(30); h1 = rng.random(25) + 0.5; h1 *= h0.sum() / h1.sum()
+    if scheme == "PPM_HYBGEN":
+        a = oracle.remapping_core_h("PPM_HYBGEN", h0, u0, h1, h_neglect=1e-30, h_neglect_edge=1e-30)
+        b = oracle.remapping_core_h("PPM_CW", h0, u0, h1, h_neglect=1e-30, h_neglect_edge=1e-30)
+        assert np.allclose(a, b, rtol=0, atol=1e-13)
