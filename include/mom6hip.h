@@ -457,6 +457,7 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 
 /* EQN_OF_STATE forms provided (src/equation_of_state/MOM_EOS.F90:145-173; default "WRIGHT") */
 #define MOM6HIP_EOS_LINEAR 1   /* MOM_EOS_linear.F90 */
+#define MOM6HIP_EOS_UNESCO 2   /* MOM_EOS_UNESCO.F90 (Jackett & McDougall 1995) */
 #define MOM6HIP_EOS_WRIGHT 3   /* MOM_EOS_Wright.F90 (the "WRIGHT" form; density is identical to WRIGHT_REDUCED) */
 
 typedef struct mom6hip_eos {
@@ -861,7 +862,10 @@ typedef struct mom6hip_dyn_split_rk2_cs {
       *v_accel_bt, *u_av, *v_av, *h_av, *pbce;
   /* 2-D */
   double *eta, *eta_PF, *uhbt, *vhbt;
-  void *reserved2[4];
+  /* SPLIT_RK2B only (MOM_dynamics_split_RK2b.F90:141-146): the barotropic velocity increments between the filtered and
+   * the instantaneous velocities, at u / v points; restart fields du_avg_inst / dv_avg_inst (:1181-1186) */
+  double *du_av_inst, *dv_av_inst;
+  void *reserved2[2];
 } mom6hip_dyn_split_rk2_cs_t;
 
 /* The part of initialize_dyn_split_RK2 (:1326) that sets state: eta from the layer thicknesses (:1521-1535),
@@ -884,6 +888,31 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
                                double *h, const double *T, const double *S, double dt, const double *taux,
                                const double *tauy, double RZ_to_H, double *uh, double *vh, double *uhtr, double *vhtr,
                                double *eta_av, int32_t calc_dtbt);
+
+/*
+ * SPLIT_RK2B = True (MOM.F90:2198, :1236): the alternate split time stepping, in which the filtered velocities u_av, v_av
+ * are the prognostic velocities and the instantaneous ones are rebuilt from them each step,
+ * u_inst = u_av - du_av_inst*visc_rem_u (:641-646).  Same control structure as step_MOM_dyn_split_RK2 with
+ * cs->du_av_inst / dv_av_inst set; store_CAu, CAu_pred_stored and BT_use_layer_fluxes are not read (the scheme always
+ * hands btstep the layer fluxes, :663-672), and cs->u_av, cs->v_av, cs->h_av are the step's work arrays u_inst, v_inst,
+ * h_av (:338-341) -- they carry nothing from one step to the next.
+ *
+ * initialize_dyn_split_RK2b (:1220), the part that sets state: eta from the layer thicknesses (:1406-1420), du_av_inst =
+ * dv_av_inst = 0 and diffu = diffv = 0 (:1155-1166), visc_rem = 1; a restart then overwrites sfc, du_avg_inst,
+ * dv_avg_inst and the barotropic fields.
+ */
+int mom6hip_dyn_split_rk2b_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, const double *h);
+
+/*
+ * step_MOM_dyn_split_RK2b(u_av, v_av, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr,
+ *                         eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, Waves)
+ *                                                                  src/core/MOM_dynamics_split_RK2b.F90:274
+ * Arguments as for mom6hip_step_dyn_split_rk2, with the filtered velocities in place of the instantaneous ones.
+ */
+int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_av, double *v_av, double *h,
+                                const double *T, const double *S, double dt, const double *taux, const double *tauy,
+                                double RZ_to_H, double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av,
+                                int32_t calc_dtbt);
 
 #ifdef __cplusplus
 }

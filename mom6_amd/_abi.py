@@ -87,7 +87,7 @@ class BTCont(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BT_CONT_U + BT_CONT_V + ("h_u", "h_v")]
 
 
-EOS_FORMS = {"LINEAR": 1, "WRIGHT": 3}
+EOS_FORMS = {"LINEAR": 1, "UNESCO": 2, "WRIGHT": 3}
 
 
 class EOS(C.Structure):
@@ -173,7 +173,7 @@ class HorViscCS(C.Structure):
 RK2_ARRAYS_3D = (("CAu", POS_U), ("CAv", POS_V), ("CAu_pred", POS_U), ("CAv_pred", POS_V), ("PFu", POS_U), ("PFv", POS_V),
                  ("diffu", POS_U), ("diffv", POS_V), ("visc_rem_u", POS_U), ("visc_rem_v", POS_V), ("u_accel_bt", POS_U),
                  ("v_accel_bt", POS_V), ("u_av", POS_U), ("v_av", POS_V), ("h_av", POS_H), ("pbce", POS_H))
-RK2_ARRAYS_2D = (("eta", POS_H), ("eta_PF", POS_H), ("uhbt", POS_U), ("vhbt", POS_V))
+RK2_ARRAYS_2D = (("eta", POS_H), ("eta_PF", POS_H), ("uhbt", POS_U), ("vhbt", POS_V), ("du_av_inst", POS_U), ("dv_av_inst", POS_V))
 
 
 class DynSplitRK2CS(C.Structure):
@@ -184,7 +184,7 @@ class DynSplitRK2CS(C.Structure):
                  ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
                  ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("hor_visc", C.c_void_p)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
-                + [("reserved2", C.c_void_p * 4)])
+                + [("reserved2", C.c_void_p * 2)])
 
 
 # ---- MOM_vert_friction ------------------------------------------------------------------------------------

@@ -301,4 +301,213 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   return 0;
 }
 
+// ---- SPLIT_RK2B: src/core/MOM_dynamics_split_RK2b.F90 ----------------------------------------------------------
+// The same operators in another order: the step starts from the filtered velocities u_av, v_av (the model's prognostic
+// velocities in this scheme), does a first continuity + CorAdCalc + horizontal_viscosity with them, rebuilds the
+// instantaneous velocities from the stored barotropic increments (:641-646) and ends with the increments the final
+// continuity returns (du_cor, dv_cor :979-981).  cs->u_av, cs->v_av, cs->h_av are the step's u_inst, v_inst, h_av.
+
+int mom6hip_dyn_split_rk2b_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, const double *h) {
+  M6_REQUIRE(ctx && h, "dyn_split_rk2b_init: null argument");
+  CALL(check(cs, "dyn_split_rk2b_init"));
+  M6_REQUIRE(cs->du_av_inst && cs->dv_av_inst, "dyn_split_rk2b_init: du_av_inst / dv_av_inst are not allocated");
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  hipStream_t s = ctx->stream;
+  {   // eta :1406-1420
+    double *eta = cs->eta;
+    const double Z_to_H = g.Z_to_H;
+    const long hstr = (long)g.nih * g.njh;
+    const int nz = g.nk;
+    launch3d(s, g.isc, g.iec, g.jsc, g.jec, 1, [=] __device__(int i, int j, int) {
+      const long n = g.h2(i, j);
+      double e = -Z_to_H * g.bathyT[n];
+      for (int k = 0; k < nz; k++) e = e + h[n + hstr * k];
+      eta[n] = e;
+    });
+  }
+  M6_HIP(hipMemsetAsync(cs->diffu, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(cs->diffv, 0, sz.v3, s));       // :1155-1156
+  M6_HIP(hipMemsetAsync(cs->du_av_inst, 0, sz.u3 / g.nk, s)); M6_HIP(hipMemsetAsync(cs->dv_av_inst, 0, sz.v3 / g.nk, s));   // :1164-1165
+  M6_HIP(hipMemsetAsync(cs->u_av, 0, sz.u3, s)); M6_HIP(hipMemsetAsync(cs->v_av, 0, sz.v3, s));         // u_inst = v_inst = 0 :404
+  {
+    double *vru = cs->visc_rem_u, *vrv = cs->visc_rem_v;
+    launch3d(s, g.isd - 1, g.ied, g.jsd, g.jed, g.nk, [=] __device__(int i, int j, int k) { vru[g.u3(i, j, k)] = 1.0; });
+    launch3d(s, g.isd, g.ied, g.jsd - 1, g.jed, g.nk, [=] __device__(int i, int j, int k) { vrv[g.v3(i, j, k)] = 1.0; });
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
+int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_av, double *v_av, double *h,
+                                const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
+                                double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int32_t calc_dtbt) {
+  M6_REQUIRE(ctx && u_av && v_av && h && T && S && taux && tauy && uh && vh && uhtr && vhtr && eta_av,
+             "step_MOM_dyn_split_RK2b: null argument");
+  CALL(check(cs, "step_MOM_dyn_split_RK2b"));
+  M6_REQUIRE(cs->du_av_inst && cs->dv_av_inst, "step_MOM_dyn_split_RK2b: du_av_inst / dv_av_inst are not allocated");
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  hipStream_t s = ctx->stream;
+  const int D = MOM6HIP_MEM_DEVICE;
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec, nz = g.nk;
+  const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+  mom6hip_barotropic_cs_t *BT = cs->barotropic_CSp;
+  const mom6hip_bt_cont_t *BTC = cs->BT_cont;
+  const bool BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
+  const mom6hip_visc_hooks_t *hk = cs->hooks;
+  mom6hip_vertvisc_cs_t *VV = cs->vertvisc_CSp;
+  M6_REQUIRE(!VV || cs->visc, "step_MOM_dyn_split_RK2b: vertvisc_CSp needs the visc argument (cs->visc)");
+
+  const size_t blk_bytes = 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2;
+  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes;
+  M6_REQUIRE(ctx->rk2_scratch.reserve(blk_bytes) == 0, "step_MOM_dyn_split_RK2b: out of device memory");
+  char *blk = (char *)ctx->rk2_scratch.p;
+  double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3);
+  double *vp = (double *)(blk + 3 * sz.u3), *v_bc = (double *)(blk + 3 * sz.u3 + sz.v3), *vh_in = (double *)(blk + 3 * sz.u3 + 2 * sz.v3);
+  double *hp = (double *)(blk + 3 * sz.u3 + 3 * sz.v3), *eta_pred = (double *)(blk + 3 * sz.u3 + 3 * sz.v3 + sz.h3);
+  double *u_inst = cs->u_av, *v_inst = cs->v_av, *h_av = cs->h_av, *eta = cs->eta;
+  // up = vp = u_inst = v_inst = 0 (:404) matters only at the halo faces beyond a closed edge, which nothing writes:
+  // zeroed when allocated (the block) and by dyn_split_rk2b_init (u_inst, v_inst).
+  if (fresh) M6_HIP(hipMemsetAsync(blk, 0, blk_bytes, s));
+  M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :403
+
+  // continuity with the filtered velocities :488, PressureForce :498, pass_hp_uhvh :535, h_av :540-542
+  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_av, v_av, h, hp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, D));
+  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,
+                                      cs->eta_PF, D));
+  CALL(pass(ctx, {{hp, PH}, {uh, PU}, {vh, PV}}, nz));
+  auto set_h_av = [&]() {
+    launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {
+      const long n = g.h3(i, j, k);
+      h_av[n] = 0.5 * (h[n] + hp[n]);
+    });
+  };
+  set_h_av();
+  auto hor_visc = [&]() -> int {
+    if (cs->hor_visc) {
+      if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, BTC ? BTC->h_u : nullptr,
+                                       BTC ? BTC->h_v : nullptr)) return 1;
+    } else if (hk && hk->horizontal_viscosity) {
+      M6_HIP(hipStreamSynchronize(s));
+      M6_REQUIRE(hk->horizontal_viscosity(hk->user, u_av, v_av, h_av, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
+    }
+    return 0;
+  };
+  CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));   // :548
+  CALL(hor_visc());                                                                                          // :555
+
+  // u_bc_accel :561-568 ; up = mask*(u_av + dt*u_bc_accel) :587-594 (read only by vertvisc_coef)
+  auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
+    const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
+    const bool need_up = first_up && (VV || (hk && hk->visc_remnant_pred));
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      const double a = (CAu[n] + PFu[n]) + diffu[n];
+      u_bc[n] = a;
+      if (need_up) up[n] = g.mask2dCu[g.u2(I, j)] * (u_av[n] + dt * a);
+    });
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      const double a = (CAv[n] + PFv[n]) + diffv[n];
+      v_bc[n] = a;
+      if (need_up) vp[n] = g.mask2dCv[g.v2(i, J)] * (v_av[n] + dt * a);
+    });
+  };
+  bc_accel(cs->CAu_pred, cs->CAv_pred, true);
+  if (hk && hk->visc_remnant_pred) {   // set_viscous_ML, vertvisc_coef, vertvisc_remnant :598-606
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
+  } else if (VV) {
+    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+  }
+  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}}, nz));                 // :616-617
+  if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));                     // :623-625
+  CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
+  {   // the instantaneous velocities :641-646, pass_uv_inst :648
+    const double *du = cs->du_av_inst, *dv = cs->dv_av_inst, *vru = cs->visc_rem_u, *vrv = cs->visc_rem_v;
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      u_inst[n] = u_av[n] - du[g.u2(I, j)] * vru[n];
+    });
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      v_inst[n] = v_av[n] - dv[g.v2(i, J)] * vrv[n];
+    });
+  }
+  CALL(pass(ctx, {{u_inst, PU}, {v_inst, PV}}, nz));
+  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,      // :652
+                          cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
+  if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :655-658
+  if (calc_dtbt) CALL(mom6hip_set_dtbt(ctx, BT, cs->pbce, nullptr, 0.0, 0.0, D));                       // :664
+  CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :668
+                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                      nullptr, uh_in, vh_in, u_inst, v_inst, nullptr, D));
+
+  // up = u_inst + dt_pred*(u_bc_accel + u_accel_bt) :675-686
+  const double dt_pred = dt * cs->be;
+  {
+    const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      vp[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt_pred * (v_bc[n] + abv[n]));
+    });
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      up[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt_pred * (u_bc[n] + abu[n]));
+    });
+  }
+  if (hk && hk->vertvisc) {   // vertvisc_coef, vertvisc, vertvisc_remnant :724-745
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->vertvisc(hk->user, up, vp, h, dt_pred, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
+  } else if (VV) {
+    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+  }
+  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {up, PU}, {vp, PV}}, nz));            // :748, :752
+  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :758
+                          u_av, v_av, BTC, nullptr, nullptr, D));
+  CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :764
+  set_h_av();                                                                                         // :780-782
+  CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :790
+  if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :824-827
+  CALL(hor_visc());                                                                                   // :841
+  CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));     // :848
+  bc_accel(cs->CAu, cs->CAv, false);                                                                  // :854-861
+  CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :889
+                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                      nullptr, uh, vh, u_av, v_av, eta_av, D));
+  launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :898
+  {   // u_inst = u_inst + dt*(u_bc_accel + u_accel_bt) :908-919
+    const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      u_inst[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dt * (u_bc[n] + abu[n]));
+    });
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      v_inst[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt * (v_bc[n] + abv[n]));
+    });
+  }
+  if (hk && hk->vertvisc) {   // :946-963
+    M6_HIP(hipStreamSynchronize(s));
+    M6_REQUIRE(hk->vertvisc(hk->user, u_inst, v_inst, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
+  } else if (VV) {
+    CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+  }
+  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {u_inst, PU}, {v_inst, PV}}, nz));     // :967, :971
+  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :979
+                          cs->visc_rem_v, u_av, v_av, nullptr, cs->du_av_inst, cs->dv_av_inst, D));
+  CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :993
+  launch3d(s, Isq - 2, Ieq + 2, js - 2, je + 2, nz, [=] __device__(int I, int j, int k) {            // :1004-1011
+    const long n = g.u3(I, j, k);
+    uhtr[n] = uhtr[n] + uh[n] * dt;
+  });
+  launch3d(s, is - 2, ie + 2, Jsq - 2, Jeq + 2, nz, [=] __device__(int i, int J, int k) {
+    const long n = g.v3(i, J, k);
+    vhtr[n] = vhtr[n] + vh[n] * dt;
+  });
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

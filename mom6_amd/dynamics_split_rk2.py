@@ -24,6 +24,8 @@ def _setup():
         L.mom6hip_dyn_split_rk2_init.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [C.c_double]
         L.mom6hip_step_dyn_split_rk2.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 5 + [C.c_double] + [C.c_void_p] * 2 + [C.c_double]
                                                  + [C.c_void_p] * 5 + [C.c_int32])
+        L.mom6hip_dyn_split_rk2b_init.argtypes = [C.c_void_p, cs, C.c_void_p]
+        L.mom6hip_step_dyn_split_rk2b.argtypes = L.mom6hip_step_dyn_split_rk2.argtypes
         L._rk2_ready = True
     return L
 
@@ -132,9 +134,58 @@ def initialize_dyn_split_RK2(u, v, h, uh, vh, dt, G: DeviceGrid, restart=None, *
     return CS
 
 
+# ---- SPLIT_RK2B (src/core/MOM_dynamics_split_RK2b.F90) ------------------------------------------------------------
+# restart name -> where it lives (register_restarts_dyn_split_RK2b :1139-1190)
+_RESTART_CS_B = {"sfc": "eta", "du_avg_inst": "du_av_inst", "dv_avg_inst": "dv_av_inst"}
+
+
+def save_restart_dyn_split_RK2b(CS: MOM_dyn_split_RK2_CS) -> dict:
+    """What register_restarts_dyn_split_RK2b (:1139) and register_barotropic_restarts put into a restart file: sfc,
+    du_avg_inst, dv_avg_inst, ubtav, vbtav, DTBT."""
+    r = {n: getattr(CS, a).clone() for n, a in _RESTART_CS_B.items()}
+    r.update({n: getattr(CS.barotropic_CSp, a).clone() for n, a in _RESTART_BT.items()})
+    r["DTBT"] = float(CS.barotropic_CSp.st.dtbt)
+    r["DTBT_max"] = float(CS.barotropic_CSp.st.dtbt_max)
+    return r
+
+
+def initialize_dyn_split_RK2b(u, v, h, uh, vh, dt, G: DeviceGrid, restart=None, **params) -> MOM_dyn_split_RK2_CS:
+    """initialize_dyn_split_RK2b (:1220), SPLIT_RK2B = True: the same control structure as the RK2 scheme (the parameters
+    STORE_CORIOLIS_ACCEL and BT_USE_LAYER_FLUXES do not exist in this scheme and are not read); eta from h, zero
+    barotropic increments, or the fields of save_restart_dyn_split_RK2b."""
+    params.setdefault("DT", dt)
+    CS = MOM_dyn_split_RK2_CS(G, **params)
+    CS.split_RK2b = True
+    check(_setup().mom6hip_dyn_split_rk2b_init(G.handle, C.byref(CS.st), h.data_ptr()), "initialize_dyn_split_RK2b")
+    if restart is not None:
+        for n, a in _RESTART_CS_B.items():
+            if n in restart:
+                getattr(CS, a).copy_(restart[n])
+        for n, a in _RESTART_BT.items():
+            if n in restart:
+                getattr(CS.barotropic_CSp, a).copy_(restart[n])
+        if "DTBT" in restart:
+            CS.barotropic_CSp.st.dtbt = float(restart["DTBT"])
+            CS.barotropic_CSp.st.dtbt_max = float(restart.get("DTBT_max", CS.barotropic_CSp.st.dtbt_max))
+    CS.module_is_initialized = True
+    return CS
+
+
+def step_MOM_dyn_split_RK2b(u_av, v_av, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av,
+                            G: DeviceGrid, CS: MOM_dyn_split_RK2_CS, calc_dtbt=False, VarMix=None, MEKE=None,
+                            thickness_diffuse_CSp=None, pbv=None, Waves=None):
+    """step_MOM_dyn_split_RK2b(u_av, v_av, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr,
+    eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, Waves) -- MOM_dynamics_split_RK2b.F90:274."""
+    if CS is None or not CS.module_is_initialized or not getattr(CS, "split_RK2b", False):
+        raise Mom6HipError("step_MOM_dyn_split_RK2b: Module must be initialized before it is used.")
+    step_MOM_dyn_split_RK2(u_av, v_av, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av,
+                           G, CS, calc_dtbt=calc_dtbt, VarMix=VarMix, MEKE=MEKE, thickness_diffuse_CSp=thickness_diffuse_CSp,
+                           pbv=pbv, Waves=Waves, _entry="mom6hip_step_dyn_split_rk2b")
+
+
 def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av,
                            G: DeviceGrid, CS: MOM_dyn_split_RK2_CS, calc_dtbt=False, VarMix=None, MEKE=None,
-                           thickness_diffuse_CSp=None, pbv=None, STOCH=None, Waves=None):
+                           thickness_diffuse_CSp=None, pbv=None, STOCH=None, Waves=None, _entry="mom6hip_step_dyn_split_rk2"):
     """step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
     vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves) -- :289.
     tv = (T, S); forces = (taux, tauy); visc is a vert_friction.vertvisc_type (device arrays) when the control structure
@@ -158,6 +209,8 @@ def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, 
         if not (a.is_cuda and a.is_contiguous() and a.dtype == torch.float64):
             raise Mom6HipError("step_MOM_dyn_split_RK2: all fields must be contiguous float64 CUDA tensors")
     P = lambda a: C.c_void_p(a.data_ptr())
-    check(_setup().mom6hip_step_dyn_split_rk2(G.handle, C.byref(CS.st), P(u_inst), P(v_inst), P(h), P(T), P(S), float(dt), P(taux),
-                                              P(tauy), g.Z_to_H / g.Rho0, P(uh), P(vh), P(uhtr), P(vhtr), P(eta_av),
-                                              int(bool(calc_dtbt))), "step_MOM_dyn_split_RK2")
+    if getattr(CS, "split_RK2b", False) != (_entry == "mom6hip_step_dyn_split_rk2b"):
+        raise Mom6HipError("step_MOM_dyn_split_RK2: the control structure was initialized for the other split scheme (SPLIT_RK2B)")
+    check(getattr(_setup(), _entry)(G.handle, C.byref(CS.st), P(u_inst), P(v_inst), P(h), P(T), P(S), float(dt), P(taux),
+                                    P(tauy), g.Z_to_H / g.Rho0, P(uh), P(vh), P(uhtr), P(vhtr), P(eta_av),
+                                    int(bool(calc_dtbt))), "step_MOM_dyn_split_RK2")

@@ -2,7 +2,7 @@
 !! and PressureForce_FV_init (:921) with the reference's dummy-argument lists, so MOM_PressureForce.F90 (`PressureForce`,
 !! called by the split RK2 step at :548 and :795) compiles unchanged.  Provided: the analytic finite-volume pressure force
 !! in Boussinesq mode with PLM reconstruction of T and S (RECONSTRUCT_FOR_PRESSURE, PRESSURE_RECONSTRUCTION_SCHEME = 1,
-!! BOUNDARY_EXTRAPOLATION_PRESSURE, MASS_WEIGHT_IN_PRESSURE_GRADIENT, RHO_PGF_REF), the WRIGHT and LINEAR equations of state,
+!! BOUNDARY_EXTRAPOLATION_PRESSURE, MASS_WEIGHT_IN_PRESSURE_GRADIENT, RHO_PGF_REF), the WRIGHT, UNESCO and LINEAR equations of state,
 !! p_atm, pbce, eta, on the GPU through libmom6hip (mom6hip_pressureforce_fv_bouss, HOST memspace).  The equation of state
 !! is opaque in MOM6 (EOS_type is private), so its selection is read from the parameter file the way
 !! interpret_eos_selection does (MOM_EOS.F90:1474-1520).  Tides / SAL, the Stanley correction, PPM reconstruction,
@@ -155,9 +155,11 @@ subroutine PressureForce_FV_init(Time, G, GV, US, param_file, diag, CS, SAL_CSp,
       call get_param(param_file, "MOM_EOS", "DRHO_DS", CS%eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
     case ("WRIGHT")
       CS%eos%form = MOM6HIP_EOS_WRIGHT
+    case ("UNESCO")
+      CS%eos%form = MOM6HIP_EOS_UNESCO
     case default
       call MOM_error(FATAL, "PressureForce_FV_init (HIP): EQN_OF_STATE "//trim(tmpstr)//" is not provided by the GPU path "// &
-                            "(WRIGHT, LINEAR).")
+                            "(WRIGHT, UNESCO, LINEAR).")
   end select
   call mom6hip_read_topology(param_file)
 contains

@@ -2,7 +2,7 @@
 !! set_viscous_ML (:1898), set_visc_init (:2886), set_visc_register_restarts (:2693), set_visc_end with the reference's
 !! dummy-argument lists, so MOM.F90 (:1205) and the split RK2 step (:592) compile unchanged.  The work is done by libmom6hip
 !! (mom6hip_set_viscous_bbl, HOST memspace).  Provided: BOTTOMDRAGLAW with LINEAR_DRAG or the quadratic law (CDRAG,
-!! DRAG_BG_VEL), BBL_USE_EOS (WRIGHT / LINEAR, read from the parameter file: EOS_type is opaque) or GV%Rlay, HBBL,
+!! DRAG_BG_VEL), BBL_USE_EOS (WRIGHT / UNESCO / LINEAR, read from the parameter file: EOS_type is opaque) or GV%Rlay, HBBL,
 !! BBL_THICK_MIN, KV_BBL_MIN, CORRECT_BBL_BOUNDS, DRAG_AS_BODY_FORCE.  CHANNEL_DRAG, BBL_USE_TIDAL_BG, DYNAMIC_VISCOUS_ML, a
 !! bulk mixed layer, ice shelves, open boundaries and porous barriers stop with a FATAL error.
 !!
@@ -200,6 +200,8 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
         call get_param(param_file, "MOM_EOS", "DRHO_DS", CS%eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
       case ("WRIGHT")
         CS%eos%form = MOM6HIP_EOS_WRIGHT
+      case ("UNESCO")
+        CS%eos%form = MOM6HIP_EOS_UNESCO
       case default
         call refuse(.true., "EQN_OF_STATE "//trim(tmpstr))
     end select

@@ -11,7 +11,7 @@ implicit none ; public
 integer(c_int32_t), parameter :: MOM6HIP_MEM_HOST = 0, MOM6HIP_MEM_DEVICE = 1
 integer(c_int32_t), parameter :: MOM6HIP_ADV_PLM = 0, MOM6HIP_ADV_PPM_H3 = 1, MOM6HIP_ADV_PPM = 2
 integer(c_int32_t), parameter :: MOM6HIP_POS_H = 0, MOM6HIP_POS_U = 1, MOM6HIP_POS_V = 2, MOM6HIP_POS_Q = 3
-integer(c_int32_t), parameter :: MOM6HIP_EOS_LINEAR = 1, MOM6HIP_EOS_WRIGHT = 3
+integer(c_int32_t), parameter :: MOM6HIP_EOS_LINEAR = 1, MOM6HIP_EOS_UNESCO = 2, MOM6HIP_EOS_WRIGHT = 3
 !> REMAPPING_* of src/ALE/MOM_remapping.F90:51-59 and REGRIDDING_ZSTAR of regrid_consts.F90:14
 integer(c_int32_t), parameter :: MOM6HIP_REMAP_PCM = 0, MOM6HIP_REMAP_PLM = 2, MOM6HIP_REMAP_PPM_H4 = 4, MOM6HIP_REMAP_PPM_IH4 = 5, &
                                  MOM6HIP_REMAP_PPM_CW = 10, MOM6HIP_REMAP_PLM_HYBGEN = 3, MOM6HIP_REMAP_PPM_HYBGEN = 6, &
@@ -185,7 +185,8 @@ type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
   type(c_ptr) :: CAu, CAv, CAu_pred, CAv_pred, PFu, PFv, diffu, diffv, visc_rem_u, visc_rem_v, u_accel_bt, v_accel_bt, &
                  u_av, v_av, h_av, pbce
   type(c_ptr) :: eta, eta_PF, uhbt, vhbt
-  type(c_ptr) :: reserved2(4)
+  type(c_ptr) :: du_av_inst, dv_av_inst   !< SPLIT_RK2B only (MOM_dynamics_split_RK2b.F90:141-146)
+  type(c_ptr) :: reserved2(2)
 end type mom6hip_dyn_split_rk2_cs_t
 
 interface
@@ -632,6 +633,23 @@ interface
     integer(c_int32_t), value :: calc_dtbt
     integer(c_int) :: rc
   end function mom6hip_step_dyn_split_rk2
+
+  function mom6hip_dyn_split_rk2b_init(ctx, cs, h) bind(c, name="mom6hip_dyn_split_rk2b_init") result(rc)
+    import :: c_int, c_ptr, mom6hip_dyn_split_rk2_cs_t
+    type(c_ptr), value :: ctx, h
+    type(mom6hip_dyn_split_rk2_cs_t), intent(inout) :: cs
+    integer(c_int) :: rc
+  end function mom6hip_dyn_split_rk2b_init
+
+  function mom6hip_step_dyn_split_rk2b(ctx, cs, u_av, v_av, h, T, S, dt, taux, tauy, RZ_to_H, uh, vh, uhtr, vhtr, &
+                                       eta_av, calc_dtbt) bind(c, name="mom6hip_step_dyn_split_rk2b") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_dyn_split_rk2_cs_t
+    type(c_ptr), value :: ctx, u_av, v_av, h, T, S, taux, tauy, uh, vh, uhtr, vhtr, eta_av
+    type(mom6hip_dyn_split_rk2_cs_t), intent(inout) :: cs
+    real(c_double), value :: dt, RZ_to_H
+    integer(c_int32_t), value :: calc_dtbt
+    integer(c_int) :: rc
+  end function mom6hip_step_dyn_split_rk2b
 end interface
 
 contains

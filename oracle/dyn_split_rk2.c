@@ -237,3 +237,179 @@ done:
   free(up); free(vp); free(hp); free(u_bc_accel); free(v_bc_accel); free(uh_in); free(vh_in); free(eta_pred);
   return rc;
 }
+
+/* ---- SPLIT_RK2B: step_MOM_dyn_split_RK2b, src/core/MOM_dynamics_split_RK2b.F90:274-1050, and the state-setting part of
+ * initialize_dyn_split_RK2b (:1220-1420), under the same restrictions as above.  CS->u_av, CS->v_av, CS->h_av are the
+ * step's local u_inst, v_inst, h_av (:338-341).  PARITY UNPINNED (assembled from the same pieces). */
+int orc_dyn_split_rk2b_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *h) {
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || !CS->du_av_inst || !CS->dv_av_inst) return 1;
+  for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) CS->eta[H2(i, j)] = -G->Z_to_H * G->bathyT[H2(i, j)];   /* :1406-1420 */
+  for (int k = 1; k <= nz; k++) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
+    CS->eta[H2(i, j)] = CS->eta[H2(i, j)] + h[H3(i, j, k)];
+  memset(CS->diffu, 0, sizeof(double) * n_u3(G)); memset(CS->diffv, 0, sizeof(double) * n_v3(G));
+  memset(CS->du_av_inst, 0, sizeof(double) * n_u3(G) / nz); memset(CS->dv_av_inst, 0, sizeof(double) * n_v3(G) / nz);
+  for (long n = 0; n < n_u3(G); n++) CS->visc_rem_u[n] = 1.0;
+  for (long n = 0; n < n_v3(G); n++) CS->visc_rem_v[n] = 1.0;
+  return 0;
+}
+
+int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, double *u_av, double *v_av, double *h,
+                            const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
+                            double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int calc_dtbt) {
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+  if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || (CS->vertvisc_CSp && !CS->visc) || !CS->du_av_inst || !CS->dv_av_inst)
+    return 1;
+  mom6hip_barotropic_cs_t *BT = CS->barotropic_CSp;
+  const mom6hip_bt_cont_t *BTC = CS->BT_cont;
+  const int BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
+  const long NU = n_u3(G), NV = n_v3(G), NH = n_h3(G);
+  double *up = (double *)calloc(NU, sizeof(double)), *vp = (double *)calloc(NV, sizeof(double));       /* :404 */
+  double *hp = (double *)malloc(sizeof(double) * NH);
+  double *u_bc_accel = (double *)calloc(NU, sizeof(double)), *v_bc_accel = (double *)calloc(NV, sizeof(double));
+  double *uh_in = (double *)calloc(NU, sizeof(double)), *vh_in = (double *)calloc(NV, sizeof(double));
+  double *eta_pred = (double *)calloc((size_t)ORC_NIH(G) * ORC_NJH(G), sizeof(double));
+  double *u_inst = CS->u_av, *v_inst = CS->v_av, *h_av = CS->h_av, *eta = CS->eta;
+  memcpy(hp, h, sizeof(double) * NH);                                                                   /* :403 */
+  memset(u_inst, 0, sizeof(double) * NU); memset(v_inst, 0, sizeof(double) * NV);                      /* :404 */
+  int rc = 0;
+
+  /* continuity with the filtered velocities :488 */
+  CHECK(orc_continuity(G, CS->continuity_CSp, u_av, v_av, h, hp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL));
+  /* PressureForce :498 */
+  CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, NULL, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
+  /* pass_hp_uhvh :535 */
+  pass3(G, hp, MOM6HIP_POS_H); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  /* h_av :540-542 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
+    h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
+  /* CorAdCalc :548, horizontal_viscosity :555 */
+  CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
+  if (CS->hor_visc)
+    CHECK(orc_horizontal_viscosity(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL));
+  /* u_bc_accel :561-568 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      u_bc_accel[U3(I, j, k)] = (CS->CAu_pred[U3(I, j, k)] + CS->PFu[U3(I, j, k)]) + CS->diffu[U3(I, j, k)];
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      v_bc_accel[V3(i, J, k)] = (CS->CAv_pred[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
+  }
+  /* up :587-594 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      up[U3(I, j, k)] = G->mask2dCu[ORC_U2(G, I, j)] * (u_av[U3(I, j, k)] + dt * u_bc_accel[U3(I, j, k)]);
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      vp[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_av[V3(i, J, k)] + dt * v_bc_accel[V3(i, J, k)]);
+  }
+  /* [set_viscous_ML :598]; vertvisc_coef, vertvisc_remnant :605-606 */
+  if (CS->vertvisc_CSp) {
+    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt));
+    CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
+  }
+  /* pass_eta, pass_visc_rem :616-617 */
+  orc_halo_update(G, eta, MOM6HIP_POS_H, 1);
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
+  /* btcalc, bt_mass_source :623-625 */
+  if (!BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, NULL, NULL, 0));
+  orc_bt_mass_source(G, BT, h, eta, 1);
+  /* the instantaneous velocities :641-646 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      u_inst[U3(I, j, k)] = u_av[U3(I, j, k)] - CS->du_av_inst[ORC_U2(G, I, j)] * CS->visc_rem_u[U3(I, j, k)];
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      v_inst[V3(i, J, k)] = v_av[V3(i, J, k)] - CS->dv_av_inst[ORC_V2(G, i, J)] * CS->visc_rem_v[V3(i, J, k)];
+  }
+  pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);                                    /* :648 */
+  /* continuity for BT_cont and the layer fluxes :652 */
+  CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL, CS->visc_rem_u, CS->visc_rem_v,
+                       NULL, NULL, BTC, NULL, NULL));
+  if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                            /* :655-658 */
+  if (calc_dtbt) orc_set_dtbt(G, BT, CS->pbce, NULL, 0.0, 0.0);                                        /* :664 */
+  /* predictor btstep :668 */
+  CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
+                   CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
+                   NULL, uh_in, vh_in, u_inst, v_inst, NULL));
+  /* up = u_inst + dt_pred*(u_bc_accel + u_accel_bt) :675-686 */
+  const double dt_pred = dt * CS->be;
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      vp[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_inst[V3(i, J, k)] + dt_pred * (v_bc_accel[V3(i, J, k)] + CS->v_accel_bt[V3(i, J, k)]));
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      up[U3(I, j, k)] = G->mask2dCu[ORC_U2(G, I, j)] * (u_inst[U3(I, j, k)] + dt_pred * (u_bc_accel[U3(I, j, k)] + CS->u_accel_bt[U3(I, j, k)]));
+  }
+  /* vertvisc_coef, vertvisc, vertvisc_remnant :724-745 */
+  if (CS->vertvisc_CSp) {
+    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt_pred));
+    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL));
+    CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt_pred));
+  }
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);                    /* :748 */
+  pass3(G, up, MOM6HIP_POS_U); pass3(G, vp, MOM6HIP_POS_V);                                            /* :752 */
+  /* continuity :758 */
+  CHECK(orc_continuity(G, CS->continuity_CSp, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
+                       BTC, NULL, NULL));
+  /* pass_hp_uv :764 */
+  pass3(G, hp, MOM6HIP_POS_H); pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  /* h_av :780-782 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
+    h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
+  orc_bt_mass_source(G, BT, hp, eta_pred, 0);                                                          /* :790 */
+  if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                           /* :824-827 */
+  /* horizontal_viscosity :841, CorAdCalc :848 */
+  if (CS->hor_visc)
+    CHECK(orc_horizontal_viscosity(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL));
+  CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
+  /* u_bc_accel :854-861 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      u_bc_accel[U3(I, j, k)] = (CS->CAu[U3(I, j, k)] + CS->PFu[U3(I, j, k)]) + CS->diffu[U3(I, j, k)];
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      v_bc_accel[V3(i, J, k)] = (CS->CAv[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
+  }
+  /* corrector btstep :889 */
+  CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
+                   CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
+                   NULL, uh, vh, u_av, v_av, eta_av));
+  for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[H2(i, j)] = eta_pred[H2(i, j)];   /* :898 */
+  /* u_inst = u_inst + dt*(u_bc_accel + u_accel_bt) :908-919 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+      u_inst[U3(I, j, k)] = G->mask2dCu[ORC_U2(G, I, j)] * (u_inst[U3(I, j, k)] + dt * (u_bc_accel[U3(I, j, k)] + CS->u_accel_bt[U3(I, j, k)]));
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+      v_inst[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_inst[V3(i, J, k)] + dt * (v_bc_accel[V3(i, J, k)] + CS->v_accel_bt[V3(i, J, k)]));
+  }
+  /* vertvisc_coef, vertvisc, vertvisc_remnant :946-963 */
+  if (CS->vertvisc_CSp) {
+    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, u_inst, v_inst, h, NULL, CS->visc, dt));
+    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL));
+    CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
+  }
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);                    /* :967 */
+  pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);                                    /* :971 */
+  /* continuity :979-981, returning the barotropic increments */
+  CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,
+                       v_av, NULL, CS->du_av_inst, CS->dv_av_inst));
+  /* pass_h_uv :993 */
+  pass3(G, h, MOM6HIP_POS_H);
+  pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  /* uhtr, vhtr :1004-1011 */
+  ORC_PAR
+  for (int k = 1; k <= nz; k++) {
+    for (int j = js - 2; j <= je + 2; j++) for (int I = Isq - 2; I <= Ieq + 2; I++)
+      uhtr[U3(I, j, k)] = uhtr[U3(I, j, k)] + uh[U3(I, j, k)] * dt;
+    for (int J = Jsq - 2; J <= Jeq + 2; J++) for (int i = is - 2; i <= ie + 2; i++)
+      vhtr[V3(i, J, k)] = vhtr[V3(i, J, k)] + vh[V3(i, J, k)] * dt;
+  }
+done:
+  free(up); free(vp); free(hp); free(u_bc_accel); free(v_bc_accel); free(uh_in); free(vh_in); free(eta_pred);
+  return rc;
+}

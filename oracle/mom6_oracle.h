@@ -184,6 +184,11 @@ int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
 int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, double *u_inst, double *v_inst, double *h,
                            const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
                            double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int calc_dtbt);
+/* SPLIT_RK2B: MOM_dynamics_split_RK2b.F90 */
+int orc_dyn_split_rk2b_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *h);
+int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, double *u_av, double *v_av, double *h,
+                            const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
+                            double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int calc_dtbt);
 
 /* ---- MOM_coms (oracle/coms.c) -------------------------------------------------------------------------------------- */
 /* reproducing_sum_3d :318 on one PE over points i0..i1, rows j0..j1 (0-based) of a (ke, ncol, nrow) array; regularize_ints

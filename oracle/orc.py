@@ -229,6 +229,8 @@ def ref_lib():
         L.ref_hybgen_plm.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_plm.restype = None
         L.ref_hybgen_ppm.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_ppm.restype = None
         L.ref_hybgen_weno.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_weno.restype = None
+    if hasattr(L, "ref_unesco"):
+        L.ref_unesco.argtypes = [i, _dp, _dp, _dp, d, i, _dp, _dp, _dp]; L.ref_unesco.restype = None
     if hasattr(L, "ref_rotate_array"):
         L.ref_rotate_array.argtypes = [i, i, i, _dp, i, _dp]; L.ref_rotate_array.restype = None
         L.ref_rotate_vector.argtypes = [i] * 5 + [_dp, _dp, i, _dp, _dp]; L.ref_rotate_vector.restype = None
@@ -521,8 +523,10 @@ class DynState:
     the step with numpy arrays behind its pointers, and the prognostic state."""
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
-                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, **bt_kw):
+                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, rk2b=False, **bt_kw):
+        """rk2b: SPLIT_RK2B (MOM_dynamics_split_RK2b.F90); u, v are then the filtered velocities."""
         g = self.grid = grid
+        self.rk2b = bool(rk2b)
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
         self.ccs = continuity_cs(g.nk, g.Angstrom_H)
         self.cor = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES["SADOURNY75_ENERGY"], _abi.KE_SCHEMES["KE_ARAKAWA"], 0, int(bound_coriolis), 0)
@@ -556,7 +560,12 @@ class DynState:
         L.orc_dyn_split_rk2_init.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.DynSplitRK2CS)] + [_dp] * 5 + [C.c_double]
         L.orc_step_dyn_split_rk2.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.DynSplitRK2CS)] + [_dp] * 5 + [C.c_double]
                                              + [_dp] * 2 + [C.c_double] + [_dp] * 5 + [C.c_int])
-        rc = L.orc_dyn_split_rk2_init(C.byref(g.struct()), C.byref(cs), _p(self.u), _p(self.v), _p(self.h), _p(self.uh), _p(self.vh), self.dt)
+        L.orc_dyn_split_rk2b_init.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.DynSplitRK2CS), _dp]
+        L.orc_step_dyn_split_rk2b.argtypes = L.orc_step_dyn_split_rk2.argtypes
+        if self.rk2b:
+            rc = L.orc_dyn_split_rk2b_init(C.byref(g.struct()), C.byref(cs), _p(self.h))
+        else:
+            rc = L.orc_dyn_split_rk2_init(C.byref(g.struct()), C.byref(cs), _p(self.u), _p(self.v), _p(self.h), _p(self.uh), _p(self.vh), self.dt)
         if rc:
             raise RuntimeError(f"orc_dyn_split_rk2_init rc={rc}")
         if dtbt is not None:
@@ -565,9 +574,10 @@ class DynState:
 
     def step(self, taux, tauy, calc_dtbt=False):
         g = self.grid
-        rc = lib().orc_step_dyn_split_rk2(C.byref(g.struct()), C.byref(self.cs), _p(self.u), _p(self.v), _p(self.h), _p(self.T),
-                                          _p(self.S), self.dt, _p(taux), _p(tauy), g.Z_to_H / g.Rho0, _p(self.uh), _p(self.vh),
-                                          _p(self.uhtr), _p(self.vhtr), _p(self.eta_av), int(calc_dtbt))
+        f = lib().orc_step_dyn_split_rk2b if self.rk2b else lib().orc_step_dyn_split_rk2
+        rc = f(C.byref(g.struct()), C.byref(self.cs), _p(self.u), _p(self.v), _p(self.h), _p(self.T),
+               _p(self.S), self.dt, _p(taux), _p(tauy), g.Z_to_H / g.Rho0, _p(self.uh), _p(self.vh),
+               _p(self.uhtr), _p(self.vhtr), _p(self.eta_av), int(calc_dtbt))
         if rc:
             raise RuntimeError(f"orc_step_dyn_split_rk2 rc={rc}")
         self.nsteps += 1

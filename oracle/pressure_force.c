@@ -65,17 +65,87 @@ static void wright_density_derivs(double T, double S, double pressure, double *d
     (pressure+p0) * ( (pressure+p0)*a2 + (c4 + c5*T) ));
 }
 
+/* ---- UNESCO (Jackett & McDougall 1995), MOM_EOS_UNESCO.F90:14-66 (coefficients), :95-167 (density), :236-296 (derivatives).
+ * The reference file compiles with nothing but MOM_EOS_base_type: these are checked bit for bit against the reference's own
+ * code (oracle/_ref) and against its check value (MOM_EOS.F90:1918). */
+static const double R00 = 999.842594, R01 = 6.793952e-2, R02 = -9.095290e-3, R03 = 1.001685e-4, R04 = -1.120083e-6, R05 = 6.536332e-9,
+    R10 = 0.824493, R11 = -4.0899e-3, R12 = 7.6438e-5, R13 = -8.2467e-7, R14 = 5.3875e-9, R60 = -5.72466e-3, R61 = 1.0227e-4,
+    R62 = -1.6546e-6, R20 = 4.8314e-4,
+    S000 = 1.965933e4, S010 = 1.444304e2, S020 = -1.706103, S030 = 9.648704e-3, S040 = -4.190253e-5, S100 = 52.84855,
+    S110 = -3.101089e-1, S120 = 6.283263e-3, S130 = -5.084188e-5, S600 = 3.886640e-1, S610 = 9.085835e-3, S620 = -4.619924e-4,
+    S001 = 3.186519, S011 = 2.212276e-2, S021 = -2.984642e-4, S031 = 1.956415e-6, S101 = 6.704388e-3, S111 = -1.847318e-4,
+    S121 = 2.059331e-7, S601 = 1.480266e-4,
+    S002 = 2.102898e-4, S012 = -1.202016e-5, S022 = 1.394680e-7, S102 = -2.040237e-6, S112 = 6.128773e-8, S122 = 6.207323e-10;
+#define MAX0(x) ((x) > 0.0 ? (x) : 0.0)
+static double unesco_density(double T, double S, double pressure) {
+  const double p1 = pressure*1.0e-5, t1 = T;
+  const double s1 = MAX0(S), s12 = sqrt(s1);
+  const double sig0 = ( t1*(R01 + t1*(R02 + t1*(R03 + t1*(R04 + t1*R05)))) +
+           s1*((R10 + t1*(R11 + t1*(R12 + t1*(R13 + t1*R14)))) +
+               (s12*(R60 + t1*(R61 + t1*R62)) + s1*R20)) );
+  const double rho0 = R00 + sig0;
+  const double ks = (S000 + ( t1*(S010 + t1*(S020 + t1*(S030 + t1*S040))) +
+                 s1*((S100 + t1*(S110 + t1*(S120 + t1*S130))) + s12*(S600 + t1*(S610 + t1*S620))) )) +
+       p1*( (S001 + ( t1*(S011 + t1*(S021 + t1*S031)) +
+                      s1*((S101 + t1*(S111 + t1*S121)) + s12*S601) )) +
+            p1*(S002 + ( t1*(S012 + t1*S022) + s1*(S102 + t1*(S112 + t1*S122)) )) );
+  return rho0*ks / (ks - p1);
+}
+static double unesco_density_anomaly(double T, double S, double pressure, double rho_ref) {
+  const double p1 = pressure*1.0e-5, t1 = T;
+  const double s1 = MAX0(S), s12 = sqrt(s1);
+  const double sig0 = ( t1*(R01 + t1*(R02 + t1*(R03 + t1*(R04 + t1*R05)))) +
+           s1*((R10 + t1*(R11 + t1*(R12 + t1*(R13 + t1*R14)))) +
+               (s12*(R60 + t1*(R61 + t1*R62)) + s1*R20)) );
+  const double ks = (S000 + ( t1*(S010 + t1*(S020 + t1*(S030 + t1*S040))) +
+                 s1*((S100 + t1*(S110 + t1*(S120 + t1*S130))) + s12*(S600 + t1*(S610 + t1*S620))) )) +
+       p1*( (S001 + ( t1*(S011 + t1*(S021 + t1*S031)) +
+                      s1*((S101 + t1*(S111 + t1*S121)) + s12*S601) )) +
+            p1*(S002 + ( t1*(S012 + t1*S022) + s1*(S102 + t1*(S112 + t1*S122)) )) );
+  return ((R00 - rho_ref)*ks + (sig0*ks + p1*rho_ref)) / (ks - p1);
+}
+static void unesco_density_derivs(double T, double S, double pressure, double *drho_dT, double *drho_dS) {
+  const double p1 = pressure*1.0e-5, t1 = T;
+  const double s1 = MAX0(S), s12 = sqrt(s1);
+  const double rho0 = R00 + ( t1*(R01 + t1*(R02 + t1*(R03 + t1*(R04 + t1*R05)))) +
+                 s1*((R10 + t1*(R11 + t1*(R12 + t1*(R13 + t1*R14)))) +
+                     (s12*(R60 + t1*(R61 + t1*R62)) + s1*R20)) );
+  const double drho0_dT = R01 + ( t1*(2.0*R02 + t1*(3.0*R03 + t1*(4.0*R04 + t1*(5.0*R05)))) +
+                     s1*(R11 + (t1*(2.0*R12 + t1*(3.0*R13 + t1*(4.0*R14))) +
+                                s12*(R61 + t1*(2.0*R62)) )) );
+  const double drho0_dS = R10 + ( t1*(R11 + t1*(R12 + t1*(R13 + t1*R14))) +
+                     (1.5*(s12*(R60 + t1*(R61 + t1*R62))) + s1*(2.0*R20)) );
+  const double ks = ( S000 + (t1*(S010 + t1*(S020 + t1*(S030 + t1*S040))) +
+                 s1*((S100 + t1*(S110 + t1*(S120 + t1*S130))) + s12*(S600 + t1*(S610 + t1*S620)))) ) +
+       p1*( (S001 + ( t1*(S011 + t1*(S021 + t1*S031)) +
+                      s1*((S101 + t1*(S111 + t1*S121)) + s12*S601) )) +
+            p1*(S002 + ( t1*(S012 + t1*S022) + s1*(S102 + t1*(S112 + t1*S122)) )) );
+  const double dks_dT = ( S010 + (t1*(2.0*S020 + t1*(3.0*S030 + t1*(4.0*S040))) +
+                     s1*((S110 + t1*(2.0*S120 + t1*(3.0*S130))) + s12*(S610 + t1*(2.0*S620)))) ) +
+           p1*(((S011 + t1*(2.0*S021 + t1*(3.0*S031))) + s1*(S111 + t1*(2.0*S121)) ) +
+               p1*(S012 + t1*(2.0*S022) + s1*(S112 + t1*(2.0*S122))) );
+  const double dks_dS = ( S100 + (t1*(S110 + t1*(S120 + t1*S130)) + 1.5*(s12*(S600 + t1*(S610 + t1*S620)))) ) +
+           p1*((S101 + t1*(S111 + t1*S121) + s12*(1.5*S601)) +
+               p1*(S102 + t1*(S112 + t1*S122)) );
+  const double I_denom = 1.0 / (ks - p1);
+  *drho_dT = (ks*drho0_dT - dks_dT*((rho0*p1)*I_denom)) * I_denom;
+  *drho_dS = (ks*drho0_dS - dks_dS*((rho0*p1)*I_denom)) * I_denom;
+}
+
 /* calculate_density (no rho_ref) / with rho_ref / derivs for the EOS forms provided */
 double orc_eos_density(const mom6hip_eos_t *E, double T, double S, double p) {
   if (E->form == MOM6HIP_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT*T + E->dRho_dS*S;
+  if (E->form == MOM6HIP_EOS_UNESCO) return unesco_density(T, S, p);
   return wright_density(T, S, p);
 }
 double orc_eos_density_anomaly(const mom6hip_eos_t *E, double T, double S, double p, double rho_ref) {
   if (E->form == MOM6HIP_EOS_LINEAR) return (E->Rho_T0_S0 - rho_ref) + (E->dRho_dT*T + E->dRho_dS*S);
+  if (E->form == MOM6HIP_EOS_UNESCO) return unesco_density_anomaly(T, S, p, rho_ref);
   return wright_density_anomaly(T, S, p, rho_ref);
 }
 void orc_eos_density_derivs(const mom6hip_eos_t *E, double T, double S, double p, double *dT, double *dS) {
   if (E->form == MOM6HIP_EOS_LINEAR) { *dT = E->dRho_dT; *dS = E->dRho_dS; return; }
+  if (E->form == MOM6HIP_EOS_UNESCO) { unesco_density_derivs(T, S, p, dT, dS); return; }
   wright_density_derivs(T, S, p, dT, dS);
 }
 

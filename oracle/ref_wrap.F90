@@ -1,6 +1,6 @@
 !> bind(C) entry points around the reference routines that compile from their own source files with
 !! no stand-ins (src/ALE/PLM_functions.F90, PCM_functions.F90, MOM_hybgen_remap.F90, src/framework/MOM_array_transform.F90: no
-!! `use` of any other module).
+!! `use` of any other module; src/equation_of_state/MOM_EOS_UNESCO.F90 with MOM_EOS_base_type.F90, which it alone uses).
 !! This file is ours (a caller of the reference, not a copy of it); the reference sources are
 !! compiled where they lie under /root/reference by oracle/build_ref.sh into oracle/_ref/.
 module mom6_ref_wrap
@@ -10,6 +10,7 @@ use PLM_functions, only : PLM_reconstruction, PLM_boundary_extrapolation, PLM_sl
 use PCM_functions, only : PCM_reconstruction
 use MOM_array_transform, only : rotate_array, rotate_vector
 use MOM_hybgen_remap, only : hybgen_plm_coefs, hybgen_ppm_coefs, hybgen_weno_coefs
+use MOM_EOS_UNESCO, only : UNESCO_EOS
 implicit none
 contains
 
@@ -72,6 +73,22 @@ subroutine ref_hybgen_weno(n, s, h, edges, thin) bind(c, name="ref_hybgen_weno")
   real(c_double), value :: thin
   call hybgen_weno_coefs(s, h, edges, n, 1, thin)
 end subroutine ref_hybgen_weno
+
+!> calculate_density_array (MOM_EOS_base_type.F90:229; with rho_ref when use_ref /= 0) and calculate_density_derivs_array (:331)
+!! of the reference's UNESCO_EOS
+subroutine ref_unesco(n, T, S, p, rho_ref, use_ref, rho, drho_dT, drho_dS) bind(c, name="ref_unesco")
+  integer(c_int), value :: n, use_ref
+  real(c_double), intent(in) :: T(n), S(n), p(n)
+  real(c_double), value :: rho_ref
+  real(c_double), intent(inout) :: rho(n), drho_dT(n), drho_dS(n)
+  type(UNESCO_EOS) :: E
+  if (use_ref /= 0) then
+    call E%calculate_density_array(T, S, p, rho, 1, n, rho_ref=rho_ref)
+  else
+    call E%calculate_density_array(T, S, p, rho, 1, n)
+  endif
+  call E%calculate_density_derivs_array(T, S, p, drho_dT, drho_dS, 1, n)
+end subroutine ref_unesco
 
 !> PLM_reconstruction of ncol columns of n layers (timing the reference's code against the restatement: tools/calibrate_ref.py)
 subroutine ref_plm_batch(ncol, n, h, u, E, coef, h_neglect) bind(c, name="ref_plm_batch")

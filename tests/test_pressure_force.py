@@ -25,13 +25,37 @@ def test_eos_check_values(oracle, c):
     assert abs((rho_ref + rho) - rho2) < 1e-9
 
 
-def test_eos_derivs_match_finite_differences(oracle):
-    E = oracle.eos("WRIGHT")
+@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO"])
+def test_eos_derivs_match_finite_differences(oracle, form):
+    E = oracle.eos(form)
     T, S, p = 10.0, 34.0, 2.0e7
     dT, dS = oracle.eos_density_derivs(E, T, S, p)
     fdT = (oracle.eos_density(E, T + 1e-4, S, p) - oracle.eos_density(E, T - 1e-4, S, p)) / 2e-4
     fdS = (oracle.eos_density(E, T, S + 1e-4, p) - oracle.eos_density(E, T, S - 1e-4, p)) / 2e-4
     assert abs(dT - fdT) < 1e-6 * abs(dT) and abs(dS - fdS) < 1e-6 * abs(dS)
+
+
+def test_unesco_matches_reference_build(oracle):
+    """The restated UNESCO equation of state against the reference's own MOM_EOS_UNESCO.F90 (compiled unmodified into
+    oracle/_ref): density, density anomaly and both derivatives, bit for bit, over the fit range and beyond it (S < 0 is
+    clamped, :106)."""
+    R = oracle.ref_lib()
+    if R is None or not hasattr(R, "ref_unesco"):
+        pytest.skip("oracle/_ref not built (needs /root/reference and amdflang)")
+    rng = np.random.default_rng(5)
+    n = 20000
+    T = rng.uniform(-3.0, 41.0, n); S = rng.uniform(-1.0, 43.0, n); p = rng.uniform(0.0, 1.1e8, n)
+    T[:4] = [25.0, 0.0, -2.0, 40.0]; S[:4] = [35.0, 0.0, -0.5, 42.0]; p[:4] = [1.0e7, 0.0, 0.0, 1.0e8]
+    E = oracle.eos("UNESCO")
+    P = lambda a: a.ctypes.data_as(oracle._dp)
+    for use_ref, rho_ref in ((0, 0.0), (1, 1000.0), (1, 1035.0)):
+        rho = np.empty(n); dT = np.empty(n); dS = np.empty(n)
+        R.ref_unesco(n, P(T), P(S), P(p), rho_ref, use_ref, P(rho), P(dT), P(dS))
+        mine = np.array([oracle.eos_density(E, T[m], S[m], p[m], rho_ref if use_ref else None) for m in range(n)])
+        assert bits_equal(mine, rho), (use_ref, rho_ref, np.argwhere(mine != rho)[:3])
+        d = np.array([oracle.eos_density_derivs(E, T[m], S[m], p[m]) for m in range(n)])
+        assert bits_equal(d[:, 0].copy(), dT) and bits_equal(d[:, 1].copy(), dS)
+    assert abs(rho[0] + 1035.0 - 1027.54345796120) < 1000 * EPS * 1027.5
 
 
 def pgf_case(ni=30, nj=22, nk=6, seed=3, **kw):
@@ -73,7 +97,7 @@ def test_sea_surface_slope_gives_g_times_slope(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["WRIGHT", "LINEAR"])
+@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR"])
 @pytest.mark.parametrize("opts", [(True, False), (False, True)])
 def test_gpu_parity(oracle, form, opts):
     import torch

@@ -137,27 +137,28 @@ VV = dict(Kv=1.0e-4, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=1.0e-2)
 HV = dict(biharmonic=1, Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.01)
 
 
-def oracle_steps(g, d, taux, tauy, dt, nsteps, viscous):
-    kw = {}
+def oracle_steps(g, d, taux, tauy, dt, nsteps, viscous, rk2b=False):
+    kw = dict(rk2b=rk2b)
     if viscous:
         visc = orc.vertvisc_type(Kv_bbl_u=1.0e-3 * g.mask2dCu, Kv_bbl_v=1.0e-3 * g.mask2dCv, bbl_thick_u=5.0 * g.mask2dCu,
                                  bbl_thick_v=5.0 * g.mask2dCv)
-        kw = dict(vertvisc=orc.vertvisc_cs(g, **VV), visc=visc, hor_visc=orc.hor_visc_cs(g, dt, **HV))
+        kw.update(vertvisc=orc.vertvisc_cs(g, **VV), visc=visc, hor_visc=orc.hor_visc_cs(g, dt, **HV))
     st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, **kw)
     for n in range(nsteps):
         st.step(taux, tauy, calc_dtbt=(n == 0))
     return st
 
 
+@pytest.mark.parametrize("rk2b", [False, True], ids=["RK2", "RK2B"])
 @pytest.mark.parametrize("viscous", [False, True])
-def test_oracle_rk2_step_turns_with_the_grid(viscous):
+def test_oracle_rk2_step_turns_with_the_grid(viscous, rk2b):
     g, d = case(ni=22, nj=16, nk=3, seed=5)
     gr, dr = turned(g, d)
     yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = np.ascontiguousarray(0.02 * g.mask2dCv)
     taux_r, tauy_r = rot_vector(taux, tauy)
-    a = oracle_steps(g, d, taux, tauy, 900.0, 2, viscous)
-    b = oracle_steps(gr, dr, taux_r, tauy_r, 900.0, 2, viscous)
+    a = oracle_steps(g, d, taux, tauy, 900.0, 2, viscous, rk2b)
+    b = oracle_steps(gr, dr, taux_r, tauy_r, 900.0, 2, viscous, rk2b)
     assert a.bcs.nstep_last == b.bcs.nstep_last and a.bcs.dtbt == b.bcs.dtbt
     ub, vb = unrot_vector(b.u, b.v)
     assert same(interior(g, unrot(b.h)), interior(g, a.h)), "h"
@@ -168,13 +169,19 @@ def test_oracle_rk2_step_turns_with_the_grid(viscous):
     assert same(interior(g, uhb, _abi.POS_U), interior(g, a.uhtr, _abi.POS_U)), "uhtr"
 
 
-def hip_steps(g, d, taux, tauy, dt, nsteps, viscous, restart_after=None):
+def hip_steps(g, d, taux, tauy, dt, nsteps, viscous, restart_after=None, rk2b=False):
     """nsteps of the library's step; restart_after = n: after step n the restart fields are saved and a NEW control
     structure is initialised from them (and from u, v, h as they are) for the remaining steps"""
     import torch
-    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, save_restart_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd import dynamics_split_rk2 as M
     from mom6_amd.tracer_advect import DeviceGrid
     from mom6_amd.vert_friction import vertvisc_type
+    if rk2b:      # SPLIT_RK2B: u, v are the filtered velocities; the restart holds sfc, du_avg_inst, dv_avg_inst and the barotropic fields
+        initialize_dyn_split_RK2, step_MOM_dyn_split_RK2 = M.initialize_dyn_split_RK2b, M.step_MOM_dyn_split_RK2b
+        save_restart_dyn_split_RK2 = lambda CS, uh, vh: M.save_restart_dyn_split_RK2b(CS)
+    else:
+        initialize_dyn_split_RK2, step_MOM_dyn_split_RK2 = M.initialize_dyn_split_RK2, M.step_MOM_dyn_split_RK2
+        save_restart_dyn_split_RK2 = M.save_restart_dyn_split_RK2
     dg = DeviceGrid(g)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
@@ -210,14 +217,15 @@ def forcing(g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rk2b", [False, True], ids=["RK2", "RK2B"])
 @pytest.mark.parametrize("viscous", [False, True])
-def test_hip_rk2_step_turns_with_the_grid(viscous):
+def test_hip_rk2_step_turns_with_the_grid(viscous, rk2b):
     g, d = case(ni=70, nj=40, nk=5, seed=5)
     gr, dr = turned(g, d)
     taux, tauy = forcing(g)
     taux_r, tauy_r = rot_vector(taux, tauy)
-    a = hip_steps(g, d, taux, tauy, 900.0, 2, viscous)
-    b = hip_steps(gr, dr, taux_r, tauy_r, 900.0, 2, viscous)
+    a = hip_steps(g, d, taux, tauy, 900.0, 2, viscous, rk2b=rk2b)
+    b = hip_steps(gr, dr, taux_r, tauy_r, 900.0, 2, viscous, rk2b=rk2b)
     assert a["nstep"] == b["nstep"] and a["dtbt"] == b["dtbt"]
     ub, vb = unrot_vector(b["u"], b["v"])
     assert same(interior(g, unrot(b["h"])), interior(g, a["h"])), "h"
@@ -228,14 +236,17 @@ def test_hip_rk2_step_turns_with_the_grid(viscous):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rk2b", [False, True], ids=["RK2", "RK2B"])
 @pytest.mark.parametrize("viscous", [False, True])
-def test_hip_rk2_restart_independence(viscous):
+def test_hip_rk2_restart_independence(viscous, rk2b):
     """3 steps == 2 steps + restart file + 1 step: the fields register_restarts_dyn_split_RK2 / register_barotropic_restarts
     name are all the state the step carries (MOM_dynamics_split_RK2.F90:1181-1269, MOM_barotropic.F90:5180-5220)"""
     g, d = case(ni=70, nj=40, nk=5, seed=6)
     taux, tauy = forcing(g)
-    a = hip_steps(g, d, taux, tauy, 900.0, 3, viscous)
-    b = hip_steps(g, d, taux, tauy, 900.0, 3, viscous, restart_after=2)
+    a = hip_steps(g, d, taux, tauy, 900.0, 3, viscous, rk2b=rk2b)
+    b = hip_steps(g, d, taux, tauy, 900.0, 3, viscous, restart_after=2, rk2b=rk2b)
+    # (SPLIT_RK2B, MOM_dynamics_split_RK2b.F90:1139-1190: sfc, du_avg_inst, dv_avg_inst + the barotropic fields; u_av / h_av
+    #  of the control structure are then the step's work arrays and are compared as such)
     for n in ("u", "v", "h", "uh", "vh", "eta", "eta_av", "u_av", "h_av"):
         pos = {"u": _abi.POS_U, "uh": _abi.POS_U, "u_av": _abi.POS_U, "v": _abi.POS_V, "vh": _abi.POS_V}.get(n, _abi.POS_H)
         assert np.array_equal(interior(g, a[n], pos).view(np.uint64), interior(g, b[n], pos).view(np.uint64)), n

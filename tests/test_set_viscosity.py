@@ -33,13 +33,13 @@ def rlay(nk):
     return 1025.0 + 0.5 * np.arange(nk)
 
 
-def run_oracle(g, d, **kw):
+def run_oracle(g, d, eos_form="WRIGHT", **kw):
     arrs = visc_arrays(g, d)
     visc = orc.vertvisc_type(**arrs)
     if not kw.get("BBL_use_EOS", True):
         kw = dict(kw, Rlay=rlay(g.nk))
     cs = orc.set_visc_cs(g, 10.0, 1.0e-4, **kw)
-    orc.set_viscous_BBL(g, cs, d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), visc)
+    orc.set_viscous_BBL(g, cs, d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos(eos_form), visc)
     return visc._keep
 
 
@@ -124,3 +124,26 @@ def test_gpu_parity(name):
             for n in ("bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "Ray_u", "Ray_v"):
                 assert bits_equal(N(arrs[n]), ref[n]), (name, (ni, nj, nk), resident, n, np.argwhere(N(arrs[n]) != ref[n])[:3])
         dg.close()
+
+
+@pytest.mark.gpu
+def test_gpu_parity_unesco_eos():
+    """BBL_USE_EOS with EQN_OF_STATE = UNESCO: the density derivatives at the bottom pressure come from MOM_EOS_UNESCO."""
+    import torch
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.set_viscosity import set_visc_init, set_viscous_BBL
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    g = xs.make_grid(70, 21, 20)
+    d = xs.make_state(g, umax=0.3)
+    ref = run_oracle(g, d, eos_form="UNESCO")
+    assert not bits_equal(ref["bbl_thick_u"], run_oracle(g, d)["bbl_thick_u"])
+    dg = DeviceGrid(g)
+    CS = set_visc_init(dg, HBBL=10.0, KV=1.0e-4)
+    X = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    arrs = {n: X(a) for n, a in visc_arrays(g, d).items()}
+    set_viscous_BBL(X(d["u"]), X(d["v"]), X(d["h"]), (X(d["T"]), X(d["S"]), EOS_init("UNESCO")), vertvisc_type(**arrs), dg, CS)
+    dg.sync()
+    for n in ("bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "Ray_u", "Ray_v"):
+        assert bits_equal(arrs[n].cpu().numpy(), ref[n]), n
+    dg.close()
