@@ -54,7 +54,8 @@ typedef struct mom6hip_grid {
   int32_t symmetric;                /* must be 1: u/v/q arrays start at isd-1 / jsd-1 */
   int32_t reentrant_x, reentrant_y; /* REENTRANT_X / REENTRANT_Y of a single-tile domain */
   int32_t first_direction;          /* G%first_direction */
-  int32_t reserved0;
+  int32_t tripolar_n;               /* TRIPOLAR_N (src/framework/MOM_domains.F90:189): the northern edge of the domain folds onto
+                                     * itself, cell (i, nj+m) being cell (ni+1-i, nj+1-m); needs reentrant_x and one tile in x */
   double Angstrom_H;                /* GV%Angstrom_H */
   double H_subroundoff;             /* GV%H_subroundoff */
   double dZ_subroundoff;            /* GV%dZ_subroundoff */
@@ -196,6 +197,9 @@ int mom6hip_write_energy_ape(mom6hip_ctx_t *ctx, const double *h, const double *
 #define MOM6HIP_POS_U 1
 #define MOM6HIP_POS_V 2
 #define MOM6HIP_POS_Q 3
+/* ORed into the position of a u- or v-point field in a group pass: the field is one of a SCALAR_PAIR (To_All+Scalar_Pair,
+ * e.g. visc_rem_u / visc_rem_v, Datu / Datv) and does not change sign across the tripolar fold, as a vector component does */
+#define MOM6HIP_PASS_SCALAR_PAIR 8
 
 /* pass_var / pass_vector on a one-tile domain (config_src/infra/FMS2/MOM_domain_infra.F90:171,660):
  * fills the halo of `nfields` device arrays from the tile's own compute domain where the

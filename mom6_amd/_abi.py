@@ -20,11 +20,14 @@ Q_METRICS = ("mask2dBu", "dxBu", "dyBu", "areaBu", "IareaBu", "CoriolisBu", "Idx
 ALL_METRICS = H_METRICS + U_METRICS + V_METRICS + Q_METRICS
 
 
+PASS_SCALAR_PAIR = 8      # MOM6HIP_PASS_SCALAR_PAIR: ORed into the position of a u/v field that is one of a SCALAR_PAIR
+
+
 class GridStruct(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("isc", "iec", "jsc", "jec", "isd", "ied", "jsd", "jed", "nk",
                                   "symmetric", "reentrant_x", "reentrant_y", "first_direction",
-                                  "reserved0")]
+                                  "tripolar_n")]
         + [(n, C.c_double) for n in ("Angstrom_H", "H_subroundoff", "dZ_subroundoff", "H_to_Z",
                                      "Z_to_H", "g_Earth", "Rho0")]
         + [("reserved1", C.c_double * 8)]

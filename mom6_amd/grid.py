@@ -23,6 +23,7 @@ class Grid:
     halo: int = 4                # NIHALO = NJHALO (reference .testing and OM4-class runs use 4)
     reentrant_x: bool = True     # REENTRANT_X default (src/framework/MOM_domains.F90:184)
     reentrant_y: bool = False
+    tripolar_n: bool = False     # TRIPOLAR_N (src/framework/MOM_domains.F90:189)
     first_direction: int = 0
     Angstrom_H: float = 1.0e-10  # GV%Angstrom_H default ANGSTROM=1e-10 m (MOM_verticalGrid.F90)
     H_subroundoff: float = 1.0e-20 * max(1.0e-10, 1.0e-17)  # overwritten in __post_init__
@@ -98,6 +99,7 @@ class Grid:
             s.symmetric = 1
             s.reentrant_x = int(self.reentrant_x)
             s.reentrant_y = int(self.reentrant_y)
+            s.tripolar_n = int(self.tripolar_n)
             s.first_direction = int(self.first_direction)
             for n in ("Angstrom_H", "H_subroundoff", "dZ_subroundoff", "H_to_Z", "Z_to_H",
                       "g_Earth", "Rho0"):
