@@ -25,7 +25,7 @@ type, bind(c) :: mom6hip_grid_t
   integer(c_int32_t) :: symmetric
   integer(c_int32_t) :: reentrant_x, reentrant_y
   integer(c_int32_t) :: first_direction
-  integer(c_int32_t) :: reserved0
+  integer(c_int32_t) :: tripolar_n   !< TRIPOLAR_N: the northern fold (one tile in x, REENTRANT_X)
   real(c_double) :: Angstrom_H, H_subroundoff, dZ_subroundoff, H_to_Z, Z_to_H, g_Earth, Rho0
   real(c_double) :: reserved1(8)
   type(c_ptr) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT

@@ -28,8 +28,10 @@ CONFIGS = {
 
 
 def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=True,
-              reentrant_y=False, max_depth=5500.0, first_direction=0, rough_noise=0.04) -> Grid:
-    """Mercator-like C-grid with a bowl bathymetry and about `land_frac` land."""
+              reentrant_y=False, max_depth=5500.0, first_direction=0, rough_noise=0.04, fold_symmetric=False) -> Grid:
+    """Mercator-like C-grid with a bowl bathymetry and about `land_frac` land.
+    fold_symmetric: the northern half is the southern half turned by half a turn about the centre of the domain (nj even) --
+    the unfolded image of a TRIPOLAR_N grid of nj/2 rows, see fold_of()."""
     g = Grid(ni=ni, nj=nj, nk=nk, halo=halo, reentrant_x=reentrant_x, reentrant_y=reentrant_y,
              first_direction=first_direction)
     rng = np.random.default_rng(seed)
@@ -46,6 +48,13 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     dy = Re * math.radians(dlat)
     dx_h = Re * math.radians(dlon) * np.cos(np.radians(lat_h))
     dx_v = Re * math.radians(dlon) * np.cos(np.radians(lat_v))
+    f_v = 2 * 7.2921e-5 * np.sin(np.radians(lat_v))
+    if fold_symmetric:
+        assert nj % 2 == 0 and not reentrant_y
+        f_v = 2 * 7.2921e-5 * np.sin(np.radians(80.0 - np.abs(lat_v)))
+        for t in range(nj // 2):              # rows mirrored about the centre line, bit for bit
+            dx_h[h + nj - 1 - t] = dx_h[h + t]
+            dx_v[h + nj - t] = dx_v[h + t]; f_v[h + nj - t] = f_v[h + t]
 
     def bc(col, n):  # broadcast a per-row vector to (rows, n)
         return np.repeat(col[:, None], n, axis=1)
@@ -62,6 +71,8 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     bowl = (np.sin(np.pi * Y) ** 0.5) * (0.65 + 0.35 * np.cos(2 * np.pi * X) * np.cos(np.pi * Y))
     rough = 0.12 * np.sin(6 * np.pi * X + 1.0) * np.sin(4 * np.pi * Y) + rough_noise * rng.standard_normal((nj, ni))
     field = bowl + rough
+    if fold_symmetric:
+        field[nj // 2:] = field[:nj // 2][::-1, ::-1]
     thr = np.quantile(field, land_frac) if land_frac > 0 else field.min() - 0.05 * (field.max() - field.min())
     ocean = field > thr
     depth_c = np.where(ocean, max_depth * np.clip((field - thr) / (field.max() - thr), 0.02, 1.0), 0.0)
@@ -115,8 +126,19 @@ def make_grid(ni, nj, nk, halo=4, land_frac=0.25, seed=20241020, reentrant_x=Tru
     g.set_metric("mask2dBu", mBu); g.set_metric("dxBu", dxBu); g.set_metric("dyBu", dyBu)
     g.set_metric("areaBu", dxBu * dyBu); g.set_metric("IareaBu", inv(dxBu * dyBu))
     g.set_metric("IdxBu", inv(dxBu)); g.set_metric("IdyBu", inv(dyBu))
-    omega = 7.2921e-5
-    g.set_metric("CoriolisBu", bc(2 * omega * np.sin(np.radians(lat_v)), nih + 1))
+    g.set_metric("CoriolisBu", bc(f_v, nih + 1))
+    return g
+
+
+def fold_of(g2: Grid) -> Grid:
+    """The TRIPOLAR_N grid whose unfolded image is the fold-symmetric grid g2 (make_grid(..., fold_symmetric=True)): its
+    southern half, with the rows of g2 beyond the centre line as the halo beyond the fold."""
+    g = Grid(ni=g2.ni, nj=g2.nj // 2, nk=g2.nk, halo=g2.halo, reentrant_x=g2.reentrant_x, reentrant_y=False, tripolar_n=True,
+             first_direction=g2.first_direction, Angstrom_H=g2.Angstrom_H, H_to_Z=g2.H_to_Z, Z_to_H=g2.Z_to_H, g_Earth=g2.g_Earth,
+             Rho0=g2.Rho0)
+    for n, a in g2.metrics.items():
+        shp = g.shape2(g.pos_of(n))
+        g.set_metric(n, a[:shp[0], :].copy())
     return g
 
 

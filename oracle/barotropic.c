@@ -155,14 +155,23 @@ static void set_local_bt_cont(const mom6hip_grid_t *G, int u, const double *FA_E
     B->uBT_EE[n] = uBT_EE[n]; B->uBT_WW[n] = uBT_WW[n];
     B->FA_EE[n] = FA_EE[n]; B->FA_E0[n] = FA_E0[n]; B->FA_W0[n] = FA_W0[n]; B->FA_WW[n] = FA_WW[n];
   }
+  /* pass_polarity_BT (vectors, with u_polarity = 1) and pass_FA_uv (scalar pairs) :4015-4026 */
   orc_halo_update(G, B->uBT_EE, pos, 1); orc_halo_update(G, B->uBT_WW, pos, 1);
-  orc_halo_update(G, B->FA_EE, pos, 1); orc_halo_update(G, B->FA_E0, pos, 1);
-  orc_halo_update(G, B->FA_W0, pos, 1); orc_halo_update(G, B->FA_WW, pos, 1);
+  orc_halo_update(G, B->FA_EE, pos | MOM6HIP_PASS_SCALAR_PAIR, 1); orc_halo_update(G, B->FA_E0, pos | MOM6HIP_PASS_SCALAR_PAIR, 1);
+  orc_halo_update(G, B->FA_W0, pos | MOM6HIP_PASS_SCALAR_PAIR, 1); orc_halo_update(G, B->FA_WW, pos | MOM6HIP_PASS_SCALAR_PAIR, 1);
   ORC_PAR
   for (int j = b0 - hs; j <= je + hs; j++) for (int i = a0 - hs; i <= ie + hs; i++) {
     long n = IX(i, j);
     /* dt = 1.0: uBT_EE = dt*uBT_EE */
     B->uBT_EE[n] = 1.0 * B->uBT_EE[n]; B->uBT_WW[n] = 1.0 * B->uBT_WW[n];
+    /* reversed polarity in the tripolar halo regions :4036-4041, :4059-4064: u_polarity = 1 passed as a vector is -1 in the
+     * halo rows beyond the fold */
+    if (G->tripolar_n && j > je) {
+      double t;
+      t = B->FA_EE[n]; B->FA_EE[n] = B->FA_WW[n]; B->FA_WW[n] = t;
+      t = B->FA_E0[n]; B->FA_E0[n] = B->FA_W0[n]; B->FA_W0[n] = t;
+      t = B->uBT_EE[n]; B->uBT_EE[n] = B->uBT_WW[n]; B->uBT_WW[n] = t;
+    }
     B->uh_EE[n] = B->uBT_EE[n] * (C1_3 * (2.0 * B->FA_E0[n] + B->FA_EE[n]));
     B->uh_WW[n] = B->uBT_WW[n] * (C1_3 * (2.0 * B->FA_W0[n] + B->FA_WW[n]));
     B->uh_crvE[n] = 0.0; B->uh_crvW[n] = 0.0;
@@ -278,8 +287,8 @@ int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS) {
       }
     }
     orc_halo_update(G, CS->q_D, MOM6HIP_POS_Q, 1);
-    orc_halo_update(G, CS->D_u_Cor, MOM6HIP_POS_U, 1);
-    orc_halo_update(G, CS->D_v_Cor, MOM6HIP_POS_V, 1);
+    orc_halo_update(G, CS->D_u_Cor, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR, 1);      /* To_All+Scalar_Pair :4864 */
+    orc_halo_update(G, CS->D_v_Cor, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR, 1);
   }
   /* .not.nonlin_stress :5070 */
   ORC_PAR
@@ -521,7 +530,8 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                 (ART(i + 1, j) * max2(Z_to_H * BTH(i + 1, j) + eta_in[H2(i + 1, j)], 0.0) +
                  ART(i, j + 1) * max2(Z_to_H * BTH(i, j + 1) + eta_in[H2(i, j + 1)], 0.0)), h_neglect));
     }
-    orc_halo_update(G, q, MOM6HIP_POS_Q, 1); orc_halo_update(G, DCor_u, MOM6HIP_POS_U, 1); orc_halo_update(G, DCor_v, MOM6HIP_POS_V, 1);
+    orc_halo_update(G, q, MOM6HIP_POS_Q, 1); orc_halo_update(G, DCor_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR, 1);
+    orc_halo_update(G, DCor_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR, 1);      /* :823 */
   }
 
   /* ---- copy inputs into the wide arrays :1011-1033 */
@@ -697,6 +707,15 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   orc_halo_update(G, gtot_E, MOM6HIP_POS_H, 1); orc_halo_update(G, gtot_N, MOM6HIP_POS_H, 1);
   orc_halo_update(G, gtot_W, MOM6HIP_POS_H, 1); orc_halo_update(G, gtot_S, MOM6HIP_POS_H, 1);
   orc_halo_update(G, ubt_Cor, MOM6HIP_POS_U, 1); orc_halo_update(G, vbt_Cor, MOM6HIP_POS_V, 1);
+  /* "the various elements of gtot are positive definite but directional": ua_polarity / va_polarity (= 1, passed as an
+   * A-grid vector :4780-4782) are -1 in the halo rows beyond the fold :1471-1475 */
+  if (G->tripolar_n) {
+    for (int j = je + 1; j <= jevf + 1 && j <= G->jed; j++) for (int i = isvf - 1; i <= ievf + 1; i++) {
+      double t;
+      t = gtot_E[H2(i, j)]; gtot_E[H2(i, j)] = gtot_W[H2(i, j)]; gtot_W[H2(i, j)] = t;
+      t = gtot_N[H2(i, j)]; gtot_N[H2(i, j)] = gtot_S[H2(i, j)]; gtot_S[H2(i, j)] = t;
+    }
+  }
 
   /* ---- Cor_ref :1478-1490 */
   ORC_PAR
@@ -748,8 +767,8 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   if (interp_eta_PF) { orc_halo_update(G, eta_PF_1, MOM6HIP_POS_H, 1); orc_halo_update(G, d_eta_PF, MOM6HIP_POS_H, 1); }
   else orc_halo_update(G, eta_PF, MOM6HIP_POS_H, 1);
   orc_halo_update(G, eta_src, MOM6HIP_POS_H, 1);
-  orc_halo_update(G, bt_rem_u, MOM6HIP_POS_U, 1); orc_halo_update(G, bt_rem_v, MOM6HIP_POS_V, 1);
-  if (!use_BT_cont) { orc_halo_update(G, Datu, MOM6HIP_POS_U, 1); orc_halo_update(G, Datv, MOM6HIP_POS_V, 1); }
+  orc_halo_update(G, bt_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR, 1); orc_halo_update(G, bt_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR, 1);
+  if (!use_BT_cont) { orc_halo_update(G, Datu, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR, 1); orc_halo_update(G, Datv, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR, 1); }
   orc_halo_update(G, BT_force_u, MOM6HIP_POS_U, 1); orc_halo_update(G, BT_force_v, MOM6HIP_POS_V, 1);
   if (add_uh0) { orc_halo_update(G, uhbt0, MOM6HIP_POS_U, 1); orc_halo_update(G, vhbt0, MOM6HIP_POS_V, 1); }
   orc_halo_update(G, Cor_ref_u, MOM6HIP_POS_U, 1); orc_halo_update(G, Cor_ref_v, MOM6HIP_POS_V, 1);

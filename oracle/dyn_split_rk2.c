@@ -120,7 +120,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
   /* pass_eta, pass_visc_rem :610-611 */
   orc_halo_update(G, eta, MOM6HIP_POS_H, 1);
-  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   /* btcalc, bt_mass_source :627-630 */
   if (!BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, NULL, NULL, 0));
   orc_bt_mass_source(G, BT, h, eta, 1);
@@ -154,7 +154,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt_pred));
   }
   /* pass_visc_rem :747, pass_uvp :751 */
-  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   pass3(G, up, MOM6HIP_POS_U); pass3(G, vp, MOM6HIP_POS_V);
   /* continuity :757 */
   CHECK(orc_continuity(G, CS->continuity_CSp, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
@@ -207,7 +207,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = h[H3(i, j, k)];
   /* pass_visc_rem :1004, pass_uv :1008 */
-  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);
   /* continuity :1015 */
   CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,
@@ -312,7 +312,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   }
   /* pass_eta, pass_visc_rem :616-617 */
   orc_halo_update(G, eta, MOM6HIP_POS_H, 1);
-  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   /* btcalc, bt_mass_source :623-625 */
   if (!BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, NULL, NULL, 0));
   orc_bt_mass_source(G, BT, h, eta, 1);
@@ -349,7 +349,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
     CHECK(orc_vertvisc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt_pred));
   }
-  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);                    /* :748 */
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);                    /* :748 */
   pass3(G, up, MOM6HIP_POS_U); pass3(G, vp, MOM6HIP_POS_V);                                            /* :752 */
   /* continuity :758 */
   CHECK(orc_continuity(G, CS->continuity_CSp, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
@@ -393,7 +393,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
     CHECK(orc_vertvisc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
   }
-  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V);                    /* :967 */
+  pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);                    /* :967 */
   pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);                                    /* :971 */
   /* continuity :979-981, returning the barotropic increments */
   CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,

@@ -61,7 +61,7 @@ enddo ; enddo ; enddo
 cg%isc = isc ; cg%iec = iec ; cg%jsc = jsc ; cg%jec = jec
 cg%isd = isd ; cg%ied = ied ; cg%jsd = jsd ; cg%jed = jed
 cg%nk = nk ; cg%symmetric = 1 ; cg%reentrant_x = 1 ; cg%reentrant_y = 1 ; cg%first_direction = 0
-cg%reserved0 = 0
+cg%tripolar_n = 0
 cg%Angstrom_H = 1.0d-10 ; cg%H_subroundoff = 1.0d-30 ; cg%dZ_subroundoff = 1.0d-30
 cg%H_to_Z = 1.0d0 ; cg%Z_to_H = 1.0d0 ; cg%g_Earth = 9.8d0 ; cg%Rho0 = 1035.0d0
 cg%reserved1(:) = 0.0d0

@@ -51,7 +51,7 @@ maxdepth = maxval(mT(:,:,8))
 ! ---- the grid (mom6hip_grid_t: index ranges, vertical-grid scalars, c_loc of every metric in the order of the header)
 cg%isc = isd+halo ; cg%iec = ied-halo ; cg%jsc = jsd+halo ; cg%jec = jed-halo
 cg%isd = isd ; cg%ied = ied ; cg%jsd = jsd ; cg%jed = jed ; cg%nk = nk ; cg%symmetric = 1
-cg%reentrant_x = hdr(5) ; cg%reentrant_y = hdr(6) ; cg%first_direction = hdr(7) ; cg%reserved0 = 0
+cg%reentrant_x = hdr(5) ; cg%reentrant_y = hdr(6) ; cg%first_direction = hdr(7) ; cg%tripolar_n = 0
 cg%Angstrom_H = scal(1) ; cg%H_subroundoff = scal(2) ; cg%dZ_subroundoff = scal(3) ; cg%H_to_Z = scal(4) ; cg%Z_to_H = scal(5)
 cg%g_Earth = scal(6) ; cg%Rho0 = scal(7) ; cg%reserved1(:) = 0.0d0 ; cg%reserved2(:) = c_null_ptr
 cg%mask2dT = c_loc(mT(isd,jsd,1)) ; cg%areaT = c_loc(mT(isd,jsd,2)) ; cg%IareaT = c_loc(mT(isd,jsd,3)) ; cg%dxT = c_loc(mT(isd,jsd,4))
