@@ -425,7 +425,8 @@ int mom6hip_barotropic_init(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, int
       d.q_D[g.q2(i, j)] = qv;
     });
     double *f[3] = {d.q_D, d.D_u_Cor, d.D_v_Cor};
-    const int32_t pos[3] = {MOM6HIP_POS_Q, MOM6HIP_POS_U, MOM6HIP_POS_V}, nk[3] = {1, 1, 1};
+    const int32_t pos[3] = {MOM6HIP_POS_Q, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR},      // :4863-4865
+                  nk[3] = {1, 1, 1};
     if (int rc = m6::group_pass(ctx, f, pos, nk, 3)) return rc;
   }
   launch2d(s, g.isc - 1, g.iec, g.jsc, g.jec, [=] __device__(int I, int j) {   // :5073-5079
@@ -732,6 +733,7 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     return m6::group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size());
   };
   const int PH = MOM6HIP_POS_H, PU = MOM6HIP_POS_U, PV = MOM6HIP_POS_V, PQ = MOM6HIP_POS_Q;
+  const int PUs = PU | MOM6HIP_PASS_SCALAR_PAIR, PVs = PV | MOM6HIP_PASS_SCALAR_PAIR;      // To_All+Scalar_Pair: no sign change across the fold
 
   // ---- q, DCor_u, DCor_v :884-945
   if (cs->linearized_BT_PV) {
@@ -755,7 +757,7 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
                         (m6::max2((AT(i, j) * HT(i, j) + AT(i + 1, j + 1) * HT(i + 1, j + 1)) +
                                   (AT(i + 1, j) * HT(i + 1, j) + AT(i, j + 1) * HT(i, j + 1)), h_neglect));
     });
-    if (int rc = pass({{w.q, PQ}, {w.DCor_u, PU}, {w.DCor_v, PV}})) return rc;
+    if (int rc = pass({{w.q, PQ}, {w.DCor_u, PUs}, {w.DCor_v, PVs}})) return rc;      // :822-824
   }
 
   // ---- copies of the inputs on the data domain :1011-1033
@@ -793,6 +795,11 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
         launch2d(s, (dir ? is : is - 1) - hs_, ie + hs_, (dir ? js - 1 : js) - hs_, je + hs_, [=] __device__(int i, int j) {
           const long n = dir ? g.v2(i, j) : g.u2(i, j);
           const double C1_3 = 1.0 / 3.0;
+          if (g.tripolar_n && j > je) {      // reversed polarity in the tripolar halo regions :4036-4041, :4059-4064
+            double t = B.FA_EE[n]; B.FA_EE[n] = B.FA_WW[n]; B.FA_WW[n] = t;
+            t = B.FA_E0[n]; B.FA_E0[n] = B.FA_W0[n]; B.FA_W0[n] = t;
+            t = B.uBT_EE[n]; B.uBT_EE[n] = B.uBT_WW[n]; B.uBT_WW[n] = t;
+          }
           const double ee = 1.0 * B.uBT_EE[n], ww = 1.0 * B.uBT_WW[n];
           B.uBT_EE[n] = ee; B.uBT_WW[n] = ww;
           B.uh_EE[n] = ee * (C1_3 * (2.0 * B.FA_E0[n] + B.FA_EE[n]));
@@ -805,8 +812,8 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       }
     };
     if (early_btcl_pass) {
-      if (int rc = pass({{BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PU}, {BV.FA_EE, PV},
-                         {BU.FA_E0, PU}, {BV.FA_E0, PV}, {BU.FA_W0, PU}, {BV.FA_W0, PV}, {BU.FA_WW, PU}, {BV.FA_WW, PV}})) return rc;
+      if (int rc = pass({{BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PUs}, {BV.FA_EE, PVs},      // :4015-4022
+                         {BU.FA_E0, PUs}, {BV.FA_E0, PVs}, {BU.FA_W0, PUs}, {BV.FA_W0, PVs}, {BU.FA_WW, PUs}, {BV.FA_WW, PVs}})) return rc;
       btcl_derive(hs);
     } else {
       btcl_derive(0);
@@ -915,11 +922,19 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   if (use_BT_cont && !early_btcl_pass) {
     const Btcl BU = w.BU, BV = w.BV;
     if (int rc = pass({{w.gtot_E, PH}, {w.gtot_N, PH}, {w.gtot_W, PH}, {w.gtot_S, PH}, {w.ubt_Cor, PU}, {w.vbt_Cor, PV},
-                       {BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PU}, {BV.FA_EE, PV},
-                       {BU.FA_E0, PU}, {BV.FA_E0, PV}, {BU.FA_W0, PU}, {BV.FA_W0, PV}, {BU.FA_WW, PU}, {BV.FA_WW, PV}})) return rc;
+                       {BU.uBT_EE, PU}, {BV.uBT_EE, PV}, {BU.uBT_WW, PU}, {BV.uBT_WW, PV}, {BU.FA_EE, PUs}, {BV.FA_EE, PVs},
+                       {BU.FA_E0, PUs}, {BV.FA_E0, PVs}, {BU.FA_W0, PUs}, {BV.FA_W0, PVs}, {BU.FA_WW, PUs}, {BV.FA_WW, PVs}})) return rc;
     btcl_derive(hs);
   } else {
     if (int rc = pass({{w.gtot_E, PH}, {w.gtot_N, PH}, {w.gtot_W, PH}, {w.gtot_S, PH}, {w.ubt_Cor, PU}, {w.vbt_Cor, PV}})) return rc;
+  }
+  if (g.tripolar_n) {      // ua_polarity / va_polarity < 0 in the halo rows beyond the fold :1471-1475
+    const int jtop = (jevf + 1 < g.jed) ? jevf + 1 : g.jed;
+    launch2d(s, isvf - 1, ievf + 1, je + 1, jtop, [=] __device__(int i, int j) {
+      const long n = g.h2(i, j);
+      double t = w.gtot_E[n]; w.gtot_E[n] = w.gtot_W[n]; w.gtot_W[n] = t;
+      t = w.gtot_N[n]; w.gtot_N[n] = w.gtot_S[n]; w.gtot_S[n] = t;
+    });
   }
   launch2d(s, is - 1, ie, js, je, [=] __device__(int i, int j) {
     const long n = g.u2(i, j);
@@ -951,8 +966,8 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     std::vector<double *> f; std::vector<int32_t> pos;
     auto add = [&](double *a, int ps) { f.push_back(a); pos.push_back(ps); };
     if (interp) { add(w.eta_PF_1, PH); add(w.d_eta_PF, PH); } else add(w.eta_PF, PH);
-    add(w.eta_src, PH); add(w.bt_rem_u, PU); add(w.bt_rem_v, PV);
-    if (!use_BT_cont) { add(w.Datu, PU); add(w.Datv, PV); }
+    add(w.eta_src, PH); add(w.bt_rem_u, PUs); add(w.bt_rem_v, PVs);      // :847, :859: scalar pairs
+    if (!use_BT_cont) { add(w.Datu, PUs); add(w.Datv, PVs); }
     add(w.BT_force_u, PU); add(w.BT_force_v, PV);
     if (add_uh0) { add(w.uhbt0, PU); add(w.vhbt0, PV); }
     add(w.Cor_ref_u, PU); add(w.Cor_ref_v, PV);

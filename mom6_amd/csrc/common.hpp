@@ -43,6 +43,7 @@ void set_error(const char *fmt, ...);
 struct GridDev {
   int isc, iec, jsc, jec, isd, ied, jsd, jed, nk;
   int nih, njh;             // data-domain extents of h-point arrays
+  int tripolar_n;           // this tile's northern edge is the tripolar fold (TRIPOLAR_N)
   double Angstrom_H, H_subroundoff, dZ_subroundoff, H_to_Z, Z_to_H, g_Earth, Rho0;
   // device copies of the metric arrays of mom6hip_grid_t (null if the caller did not provide them)
   const double *mask2dT, *areaT, *IareaT, *dxT, *dyT, *IdxT, *IdyT, *bathyT;
@@ -155,6 +156,7 @@ int group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, cons
 int start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
 int complete_group_pass(mom6hip_ctx *ctx);
 int halo_wrap_dir(mom6hip_ctx *ctx, double *f, int pos, int nk, int dir, hipStream_t stream);
+int halo_fold_north(mom6hip_ctx *ctx, double *f, int pos_flags, int nk, hipStream_t stream);      // TRIPOLAR_N
 int halo_pack_on(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each, const int32_t *a0, int32_t nfields,
                  int32_t dir, int32_t width, double *buf, int32_t pack, int64_t *count, hipStream_t stream);
 int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);

@@ -6,6 +6,8 @@
 
 #include "common.hpp"
 
+#include <vector>
+
 namespace m6 {
 
 static thread_local std::string g_err;
@@ -279,6 +281,8 @@ static int upload2d(mom6hip_ctx_t *ctx, const double *h, size_t n, double **d) {
 int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t **out) {
   M6_REQUIRE(grid && out, "mom6hip_grid_create: null argument");
   M6_REQUIRE(grid->symmetric == 1, "mom6hip_grid_create: only SYMMETRIC_MEMORY_ layouts are supported");
+  M6_REQUIRE(!grid->tripolar_n || ((grid->iec - grid->isc + 1) % 2 == 0 && grid->jed - grid->jec <= grid->jec - grid->jsc + 1),
+             "mom6hip_grid_create: TRIPOLAR_N needs an even NIGLOBAL (MOM_domains.F90:191), one tile in x, and at least as many rows as the halo is wide");
   M6_REQUIRE(grid->isd <= grid->isc && grid->isc <= grid->iec && grid->iec <= grid->ied &&
              grid->jsd <= grid->jsc && grid->jsc <= grid->jec && grid->jec <= grid->jed && grid->nk >= 1,
              "mom6hip_grid_create: inconsistent index ranges");
@@ -307,6 +311,7 @@ int mom6hip_grid_create(const mom6hip_grid_t *grid, void *stream, mom6hip_ctx_t 
   g.isc = grid->isc; g.iec = grid->iec; g.jsc = grid->jsc; g.jec = grid->jec;
   g.isd = grid->isd; g.ied = grid->ied; g.jsd = grid->jsd; g.jed = grid->jed; g.nk = grid->nk;
   g.nih = nih; g.njh = njh;
+  g.tripolar_n = grid->tripolar_n ? 1 : 0;
   g.Angstrom_H = grid->Angstrom_H; g.H_subroundoff = grid->H_subroundoff;
   g.dZ_subroundoff = grid->dZ_subroundoff; g.H_to_Z = grid->H_to_Z; g.Z_to_H = grid->Z_to_H;
   g.g_Earth = grid->g_Earth; g.Rho0 = grid->Rho0;
@@ -410,13 +415,54 @@ __global__ void halo_y_kernel(HaloDesc d) {
   }
 }
 
+// TRIPOLAR_N: the rows beyond the northern edge are the tile's own northern rows turned by half a turn (oracle/domains.c):
+// cell (i, nj+m) is cell (ni+1-i, nj+1-m).  isum = isc + iec (- 1 for east faces / corners); ys: north faces / corners.
+__global__ void halo_fold_kernel(HaloDesc d, int isum, int ys, int negate) {
+  const int nwn = d.jhi - d.jce;
+  const long total = (long)d.nis * nwn * d.nk;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int ii = (int)(t % d.nis);
+    long r = t / d.nis;
+    const int m = 1 + (int)(r % nwn);
+    const int k = (int)(r / nwn);
+    const int si = isum - (d.ilo + ii);
+    if (si < d.ilo || si > d.ihi) continue;
+    const int j = d.jce + m, sj = ys ? d.jce - m : d.jce + 1 - m;
+    const long kb = (long)d.nis * d.njs * k;
+    const double v = d.f[kb + (long)d.nis * (sj - d.jlo) + (si - d.ilo)];
+    d.f[kb + (long)d.nis * (j - d.jlo) + ii] = negate ? -v : v;
+  }
+}
+
 }  // namespace
 
 namespace m6 {
 
-// The wrap of one re-entrant direction of one device field on `stream` (dir 0: x, the compute rows; dir 1: y, full rows).
-int halo_wrap_dir(mom6hip_ctx_t *ctx, double *f, int pos, int nk, int dir, hipStream_t stream) {
+// The fold of one device field on `stream` (pos may carry MOM6HIP_PASS_SCALAR_PAIR); after the x wrap of the same field.
+int halo_fold_north(mom6hip_ctx_t *ctx, double *f, int pos_flags, int nk, hipStream_t stream) {
   const mom6hip_grid_t &G = ctx->host;
+  const int pos = pos_flags & 3;
+  const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0;
+  const int ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
+  const int negate = ((pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_V) && !(pos_flags & MOM6HIP_PASS_SCALAR_PAIR)) ? 1 : 0;
+  HaloDesc d;
+  d.f = f; d.ilo = G.isd - xs; d.jlo = G.jsd - ys; d.ihi = G.ied; d.jhi = G.jed;
+  d.nis = d.ihi - d.ilo + 1; d.njs = d.jhi - d.jlo + 1; d.nk = nk;
+  d.ics = G.isc - xs; d.ice = G.iec; d.jcs = G.jsc - ys; d.jce = G.jec;
+  d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1;
+  const long total = (long)d.nis * (d.jhi - d.jce) * nk;
+  if (total > 0) {
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(256), 0, stream, d, G.isc + G.iec - xs, ys, negate);
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
+// The wrap of one re-entrant direction of one device field on `stream` (dir 0: x, the compute rows; dir 1: y, full rows).
+int halo_wrap_dir(mom6hip_ctx_t *ctx, double *f, int pos_flags, int nk, int dir, hipStream_t stream) {
+  const mom6hip_grid_t &G = ctx->host;
+  const int pos = pos_flags & 3;
   const int xs = (pos == MOM6HIP_POS_U || pos == MOM6HIP_POS_Q) ? 1 : 0;
   const int ys = (pos == MOM6HIP_POS_V || pos == MOM6HIP_POS_Q) ? 1 : 0;
   HaloDesc d;
@@ -446,15 +492,21 @@ int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
   const mom6hip_grid_t &G = ctx->host;
   if (G.reentrant_x) if (int rc = halo_wrap_dir(ctx, f, pos, nk, 0, ctx->stream)) return rc;
   if (G.reentrant_y) if (int rc = halo_wrap_dir(ctx, f, pos, nk, 1, ctx->stream)) return rc;
+  if (G.tripolar_n) if (int rc = halo_fold_north(ctx, f, pos, nk, ctx->stream)) return rc;
   return 0;
 }
 
 // start_group_pass / complete_group_pass / do_group_pass (MOM_domain_infra.F90:1141-1182)
 int start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
   if (ctx->native) return native_start_group_pass(ctx, fields, pos, nk, n);
-  if (ctx->halo_cb) {      // the host's collective
+  if (ctx->halo_cb) {      // the host's collective (positions without the pair flag; a tile on the fold folds its own rows)
     if (!ctx->cb_stream_ordered) M6_HIP(hipStreamSynchronize(ctx->stream));
-    M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, pos, nk, n) == 0, "group pass: the domain halo callback failed");
+    std::vector<int32_t> p(pos, pos + n);
+    for (auto &q : p) q &= 3;
+    M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, p.data(), nk, n) == 0, "group pass: the domain halo callback failed");
+    if (ctx->host.tripolar_n)
+      for (int f = 0; f < n; f++)
+        if (int rc = halo_fold_north(ctx, fields[f], pos[f], nk[f], ctx->stream)) return rc;
     return 0;
   }
   for (int f = 0; f < n; f++)      // one tile: the local wrap kernels
@@ -548,8 +600,9 @@ int m6::halo_pack_on(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *p
   d.n = nfields; d.dir = dir; d.w = width; d.pack = pack;
   d.off[0] = 0;
   for (int q = 0; q < nfields; q++) {
-    const int xs = (pos[q] == MOM6HIP_POS_U || pos[q] == MOM6HIP_POS_Q) ? 1 : 0;
-    const int ys = (pos[q] == MOM6HIP_POS_V || pos[q] == MOM6HIP_POS_Q) ? 1 : 0;
+    const int pq = pos[q] & 3;      // (without MOM6HIP_PASS_SCALAR_PAIR)
+    const int xs = (pq == MOM6HIP_POS_U || pq == MOM6HIP_POS_Q) ? 1 : 0;
+    const int ys = (pq == MOM6HIP_POS_V || pq == MOM6HIP_POS_Q) ? 1 : 0;
     d.f[q] = fields[q]; d.ni[q] = nih + xs; d.nj[q] = njh + ys; d.nk[q] = nk_each[q]; d.a0[q] = a0[q];
     d.r0[q] = h; d.r1[q] = h + nj + ys - 1;
     const long cnt = dir == 0 ? (long)nk_each[q] * (d.r1[q] - d.r0[q] + 1) * width : (long)nk_each[q] * width * d.ni[q];

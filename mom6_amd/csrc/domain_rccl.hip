@@ -135,8 +135,11 @@ void native_domain_destroy(mom6hip_ctx *ctx) {
 
 // start_group_pass: everything of the pass is enqueued on the communication stream, behind what the compute stream has
 // enqueued so far
-int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
+int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos_flags, const int32_t *nk, int n) {
   m6_native_domain *D = ctx->native;
+  std::vector<int32_t> pos_only(pos_flags, pos_flags + n);      // the staggering without MOM6HIP_PASS_SCALAR_PAIR
+  for (auto &q : pos_only) q &= 3;
+  const int32_t *pos = pos_only.data();
   const mom6hip_grid_t &G = ctx->host;
   hipStream_t cs = D->cstream;
   M6_HIP(hipEventRecord(D->ev_ready, ctx->stream));
@@ -180,6 +183,11 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
     M6_NCCL(rccl().GroupEnd());
     if (lo >= 0) if (int rc = halo_pack_on(ctx, fields, pos, nk, a_lo_halo.data(), n, dir, w, r_lo, 0, nullptr, cs)) return rc;
     if (hi >= 0) if (int rc = halo_pack_on(ctx, fields, pos, nk, a_hi_halo.data(), n, dir, w, r_hi, 0, nullptr, cs)) return rc;
+  }
+  if (G.tripolar_n) {      // this tile's northern edge is the fold (the tiles span x): its own rows, turned
+    M6_REQUIRE(D->hi[1] < 0, "group pass: a tile on the tripolar fold cannot have a northern neighbour");
+    for (int f = 0; f < n; f++)
+      if (int rc = halo_fold_north(ctx, fields[f], pos_flags[f], nk[f], cs)) return rc;
   }
   if (t0 && t1) { (void)hipEventRecord(t1, cs); D->timed.push_back({t0, t1}); }
   M6_HIP(hipEventRecord(D->ev_done, cs));

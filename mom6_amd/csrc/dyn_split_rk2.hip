@@ -40,10 +40,11 @@ Sz sizes(const m6::GridDev &g) {
 
 int pass(mom6hip_ctx_t *ctx, std::initializer_list<std::pair<double *, int>> fl, int nk3) {
   std::vector<double *> f; std::vector<int32_t> pos, nk;
-  for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second & 3); nk.push_back((e.second & 4) ? 1 : nk3); }
+  for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second & (3 | MOM6HIP_PASS_SCALAR_PAIR)); nk.push_back((e.second & 4) ? 1 : nk3); }
   return m6::group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size());
 }
 constexpr int PH = MOM6HIP_POS_H, PU = MOM6HIP_POS_U, PV = MOM6HIP_POS_V, P2D = 4;
+constexpr int PUs = PU | MOM6HIP_PASS_SCALAR_PAIR, PVs = PV | MOM6HIP_PASS_SCALAR_PAIR;      // To_All+SCALAR_PAIR (:462)
 
 int check(const mom6hip_dyn_split_rk2_cs_t *cs, const char *who) {
   M6_REQUIRE(cs != nullptr, "%s: null control structure", who);
@@ -199,7 +200,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   } else if (VV) {                     // vertvisc_coef, vertvisc_remnant :598-600 (set_viscous_ML :592 is not provided)
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}}, nz));                 // :610-611
+  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));                 // :610-611
 
   // btcalc, bt_mass_source :627-630 ; continuity for BT_cont and the layer fluxes :634-644
   if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));
@@ -234,7 +235,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   } else if (VV) {            // :717-744
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {up, PU}, {vp, PV}}, nz));            // :747, :751
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));            // :747, :751
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
                           u_av, v_av, BTC, nullptr, nullptr, D));
   CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :763
@@ -275,7 +276,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
-  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {u_inst, PU}, {v_inst, PV}}, nz));     // :1004, :1008
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));     // :1004, :1008
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :1015
                           cs->visc_rem_v, u_av, v_av, nullptr, nullptr, nullptr, D));
   CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :1018, :1027
@@ -421,7 +422,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   } else if (VV) {
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}}, nz));                 // :616-617
+  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));                 // :616-617
   if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));                     // :623-625
   CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
   {   // the instantaneous velocities :641-646, pass_uv_inst :648
@@ -463,7 +464,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   } else if (VV) {
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {up, PU}, {vp, PV}}, nz));            // :748, :752
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));            // :748, :752
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :758
                           u_av, v_av, BTC, nullptr, nullptr, D));
   CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :764
@@ -494,7 +495,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   } else if (VV) {
     CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{cs->visc_rem_u, PU}, {cs->visc_rem_v, PV}, {u_inst, PU}, {v_inst, PV}}, nz));     // :967, :971
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));     // :967, :971
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :979
                           cs->visc_rem_v, u_av, v_av, nullptr, cs->du_av_inst, cs->dv_av_inst, D));
   CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :993

@@ -37,7 +37,8 @@ def compute_extent(n_global: int, ndiv: int):
 class Domain:
     """MOM_domain_type for one tile of an (npi x npj) layout of a global (NI x NJ) grid."""
 
-    def __init__(self, NI, NJ, layout=(1, 1), rank=0, halo=4, reentrant_x=True, reentrant_y=False, group=None, self_exchange=False):
+    def __init__(self, NI, NJ, layout=(1, 1), rank=0, halo=4, reentrant_x=True, reentrant_y=False, group=None, self_exchange=False,
+                 tripolar_n=False):
         self.NI, self.NJ = int(NI), int(NJ)
         self.npi, self.npj = int(layout[0]), int(layout[1])
         self.nranks = self.npi * self.npj
@@ -55,6 +56,12 @@ class Domain:
         self.i0, self.j0 = self.i_starts[self.pi], self.j_starts[self.pj]      # global 0-based index of (isc, jsc)
         if min(self.i_sizes) < self.halo or min(self.j_sizes) < self.halo:
             raise ValueError("MOM_domains: a tile is narrower than the halo")
+        # TRIPOLAR_N (MOM_domains.F90:189): the fold is the northern edge of the northernmost row of tiles; with tiles that span
+        # x (the 1 x N latitude bands of this framework) a tile on the fold is its own neighbour across it
+        self.tripolar_n = bool(tripolar_n)
+        if self.tripolar_n and (self.npi != 1 or not self.reentrant_x or self.reentrant_y or self.NI % 2):
+            raise ValueError("MOM_domains: TRIPOLAR_N needs REENTRANT_X, an even NIGLOBAL and one tile in x (layout 1 x N)")
+        self.on_fold = self.tripolar_n and self.pj == self.npj - 1
         self._dg = None          # the DeviceGrid of this tile (DeviceGrid.set_domain): enables the packed exchange
         self._bufs = {}
 
@@ -81,7 +88,7 @@ class Domain:
         t = Grid(ni=self.ni, nj=self.nj, nk=gg.nk, halo=self.halo,
                  reentrant_x=self.reentrant_x and self.npi == 1 and not self.self_exchange,
                  reentrant_y=self.reentrant_y and self.npj == 1 and not self.self_exchange,
-                 first_direction=gg.first_direction, Angstrom_H=gg.Angstrom_H, H_to_Z=gg.H_to_Z, Z_to_H=gg.Z_to_H,
+                 tripolar_n=self.on_fold, first_direction=gg.first_direction, Angstrom_H=gg.Angstrom_H, H_to_Z=gg.H_to_Z, Z_to_H=gg.Z_to_H,
                  g_Earth=gg.g_Earth, Rho0=gg.Rho0)
         for name, a in gg.metrics.items():
             t.set_metric(name, self.cut(a, gg.pos_of(name)))
@@ -98,9 +105,19 @@ class Domain:
 
     # ---- halo update ----------------------------------------------------------------------------------
     def _ranges(self, pos):
+        pos = pos & 3      # (without PASS_SCALAR_PAIR)
         xs = 1 if pos in (_abi.POS_U, _abi.POS_Q) else 0
         ys = 1 if pos in (_abi.POS_V, _abi.POS_Q) else 0
         return xs, ys
+
+    def _fold(self, f, pos_flags):
+        """The halo beyond the tripolar fold of a tile on it: its own northern rows turned by half a turn (oracle/domains.c);
+        the components of a vector change sign, the members of a SCALAR_PAIR do not."""
+        xs, ys = self._ranges(pos_flags)
+        h, nj = self.halo, self.nj
+        vec = (pos_flags & 3) in (_abi.POS_U, _abi.POS_V) and not (pos_flags & _abi.PASS_SCALAR_PAIR)
+        src = torch.flip(f[..., nj:nj + h, :], dims=(-2, -1))
+        f[..., h + nj + ys:h + nj + ys + h, :] = -src if vec else src
 
     def pass_var(self, fields, positions, halo=None):
         """do_group_pass: fill the halos of `fields` (torch tensors, last two axes (j,i), allocated with this
@@ -167,6 +184,9 @@ class Domain:
 
         exchange("x")
         exchange("y")
+        if self.on_fold:
+            for f, pos in zip(fields, positions):
+                self._fold(f, pos)
 
     def pass_ptrs(self, ptr_list, positions, nk_list, w=None, stage=None):
         """The group pass for device fields: one message per neighbour and direction.  The library packs the send slabs

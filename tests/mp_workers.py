@@ -16,7 +16,7 @@ def _init(rank, world, port):
     return dist
 
 
-def halo_worker(rank, world, port, layout, rx, ry, out_dir, dims=(23, 17)):
+def halo_worker(rank, world, port, layout, rx, ry, out_dir, dims=(23, 17), tripolar=False):
     """Every rank fills the halos of its tile of random global fields through Domain.pass_var; the result must
     equal the same window of the one-tile halo update (oracle/domains.c), bit for bit."""
     import numpy as np
@@ -28,11 +28,14 @@ def halo_worker(rank, world, port, layout, rx, ry, out_dir, dims=(23, 17)):
     try:
         (NI, NJ), NK, halo = dims, 3, 4
         gg = synth.make_grid(NI, NJ, NK, halo=halo, reentrant_x=rx, reentrant_y=ry)
-        dom = Domain(NI, NJ, layout, rank, halo, rx, ry)
+        gg.tripolar_n = bool(tripolar); gg._struct = None
+        dom = Domain(NI, NJ, layout, rank, halo, rx, ry, tripolar_n=tripolar)
         rng = np.random.default_rng(5)
         ok = True
         fields, poss, expect = [], [], []
-        for pos in (_abi.POS_H, _abi.POS_U, _abi.POS_V, _abi.POS_Q):
+        SP = _abi.PASS_SCALAR_PAIR
+        for pos_flags in (_abi.POS_H, _abi.POS_U, _abi.POS_V, _abi.POS_Q) + ((_abi.POS_U | SP, _abi.POS_V | SP) if tripolar else ()):
+            pos = pos_flags & 3
             for three_d in (True, False):
                 shp = gg.shape3(pos) if three_d else gg.shape2(pos)
                 G = np.full(shp, -777.0)
@@ -44,7 +47,7 @@ def halo_worker(rank, world, port, layout, rx, ry, out_dir, dims=(23, 17)):
                 if ry and pos in (_abi.POS_V, _abi.POS_Q):
                     G[..., halo, si] = G[..., halo + NJ, si]
                 after = G.copy()
-                orc.halo_update(gg, after, pos)
+                orc.halo_update(gg, after, pos_flags)
                 tile = dom.cut(G, pos).copy()
                 # poison the tile's halos
                 h = halo
@@ -53,7 +56,7 @@ def halo_worker(rank, world, port, layout, rx, ry, out_dir, dims=(23, 17)):
                 keep = tile[..., h:h + dom.nj + ys, h:h + dom.ni + xs].copy()
                 tile[:] = -777.0
                 tile[..., h:h + dom.nj + ys, h:h + dom.ni + xs] = keep
-                fields.append(torch.from_numpy(tile)); poss.append(pos); expect.append(dom.cut(after, pos))
+                fields.append(torch.from_numpy(tile)); poss.append(pos_flags); expect.append(dom.cut(after, pos))
         dom.pass_var(fields, poss)
         for f, e, pos in zip(fields, expect, poss):
             a = f.numpy()
@@ -215,9 +218,15 @@ def rk2_layout_worker(rank, world, port, layout, topo, out_dir):
     from test_dyn_split_rk2 import make_case
     dist = _init(rank, world, port)
     try:
-        gg, d, taux, tauy = make_case(ni=32, nj=24, nk=3, seed=13, reentrant_x=topo[0], reentrant_y=topo[1])
+        tripolar = len(topo) > 2 and topo[2]
+        if tripolar:      # TRIPOLAR_N: the tile on the fold is its own northern neighbour
+            import tripolar as tp
+            gg, _ = tp.grids(ni=32, nj=24, nk=3, seed=13)
+            d, _, (taux, tauy), _ = tp.states(gg, _)
+        else:
+            gg, d, taux, tauy = make_case(ni=32, nj=24, nk=3, seed=13, reentrant_x=topo[0], reentrant_y=topo[1])
         dt = 1800.0
-        dom = Domain(gg.ni, gg.nj, layout, rank, gg.halo, topo[0], topo[1])
+        dom = Domain(gg.ni, gg.nj, layout, rank, gg.halo, topo[0], topo[1], tripolar_n=tripolar)
         tg = dom.tile_grid(gg)
         dg = DeviceGrid(tg)
         dg.set_domain(dom)

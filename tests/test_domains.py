@@ -38,6 +38,16 @@ def test_pass_var_two_ranks_gloo(tmp_path, layout, topo):
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_pass_var_tripolar_gloo(tmp_path, nranks):
+    """TRIPOLAR_N on 1 x N latitude bands: the tile on the fold is its own northern neighbour (vectors change sign, scalar
+    pairs do not); == the one-tile fold of oracle/domains.c"""
+    import torch.multiprocessing as mp
+    from mp_workers import halo_worker
+    mp.spawn(halo_worker, args=(nranks, free_port(), (1, nranks), True, False, str(tmp_path), (24, 22), True), nprocs=nranks, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(nranks)] == ["1"] * nranks
+
+
 @pytest.mark.parametrize("layout,topo", [((1, 4), (True, False)), ((2, 2), (True, True)), ((4, 1), (False, False)), ((1, 8), (True, False)),
                                          ((2, 4), (True, False))])
 def test_pass_var_many_ranks_gloo(tmp_path, layout, topo):
@@ -105,7 +115,7 @@ def test_btstep_layout_independence(tmp_path, layout, topo):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout,topo", [((1, 2), (True, False)), ((2, 1), (True, False)), ((1, 2), (True, True))])
+@pytest.mark.parametrize("layout,topo", [((1, 2), (True, False)), ((2, 1), (True, False)), ((1, 2), (True, True)), ((1, 2), (True, False, True))])
 def test_rk2_step_layout_independence(tmp_path, layout, topo):
     import torch.multiprocessing as mp
     from mp_workers import rk2_layout_worker
