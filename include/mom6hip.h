@@ -213,7 +213,9 @@ int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t
  * In this repository they are torch.distributed point-to-point / all-reduce over RCCL (mom6_amd/domains.py);
  * in a MOM6 executable they would be MOM6's own do_group_pass / sum_across_PEs on the device buffers.
  *   halo_fn: fill the halos of `nfields` DEVICE arrays (positions `pos`, layer counts `nk`); the library has
- *            synchronised its stream before the call and continues on it after the call returns.
+ *            synchronised its stream before the call and continues on it after the call returns.  `pos` is the staggering
+ *            (pos & 3), ORed with MOM6HIP_PASS_SCALAR_PAIR for the u/v members of a SCALAR_PAIR; halo_fn does the complete
+ *            update, the tripolar fold included (a vector component changes sign across it, a scalar pair does not).
  *   sum_fn:  element-wise sum over all PEs of `n` HOST int32 values, in place.
  * Passing NULLs restores the one-tile behaviour. */
 typedef int (*mom6hip_halo_fn)(void *user, double *const *fields, const int32_t *pos, const int32_t *nk, int32_t nfields);

@@ -499,14 +499,10 @@ int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
 // start_group_pass / complete_group_pass / do_group_pass (MOM_domain_infra.F90:1141-1182)
 int start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
   if (ctx->native) return native_start_group_pass(ctx, fields, pos, nk, n);
-  if (ctx->halo_cb) {      // the host's collective (positions without the pair flag; a tile on the fold folds its own rows)
+  if (ctx->halo_cb) {      // the host's collective: the complete update, the tripolar fold included (pos may carry
+                           // MOM6HIP_PASS_SCALAR_PAIR: only a fold tells a scalar pair from a vector)
     if (!ctx->cb_stream_ordered) M6_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int32_t> p(pos, pos + n);
-    for (auto &q : p) q &= 3;
-    M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, p.data(), nk, n) == 0, "group pass: the domain halo callback failed");
-    if (ctx->host.tripolar_n)
-      for (int f = 0; f < n; f++)
-        if (int rc = halo_fold_north(ctx, fields[f], pos[f], nk[f], ctx->stream)) return rc;
+    M6_REQUIRE(ctx->halo_cb(ctx->cb_user, fields, pos, nk, n) == 0, "group pass: the domain halo callback failed");
     return 0;
   }
   for (int f = 0; f < n; f++)      // one tile: the local wrap kernels

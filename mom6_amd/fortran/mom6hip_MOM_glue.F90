@@ -30,7 +30,8 @@ type(c_ptr), save :: ctx_cb = c_null_ptr   !< the context whose stream the stage
 integer, save :: nk_cb = 0
 !> One context per process, shared by every module shim (the metrics are uploaded once): mom6hip_shared_context
 type(c_ptr), save :: ctx_shared = c_null_ptr
-logical, save :: topology_known = .false., reentrant_saved(2) = .false.
+logical, save :: topology_known = .false., reentrant_saved(2) = .false., tripolar_saved = .false.
+logical, save :: on_fold_cb = .false.   !< this PE's tile ends at the tripolar fold (the halo callback negates vector components beyond it)
 
 contains
 
@@ -41,7 +42,7 @@ subroutine mom6hip_fatal_if(rc, who)
   if (rc /= 0) call MOM_error(FATAL, trim(who)//" (HIP): "//mom6hip_error_string())
 end subroutine mom6hip_fatal_if
 
-!> REENTRANT_X / REENTRANT_Y as MOM_domains reads them (src/framework/MOM_domains.F90:184-190); the fold is refused.
+!> REENTRANT_X / REENTRANT_Y / TRIPOLAR_N as MOM_domains reads them (src/framework/MOM_domains.F90:184-191).
 !! Called from a module's *_init (which has the parameter file) so that the one-tile fast path knows the topology.
 subroutine mom6hip_read_topology(param_file, reentrant)
   type(param_file_type), intent(in)  :: param_file
@@ -50,8 +51,8 @@ subroutine mom6hip_read_topology(param_file, reentrant)
   call get_param(param_file, "mom6hip", "REENTRANT_X", re(1), default=.true., do_not_log=.true.)
   call get_param(param_file, "mom6hip", "REENTRANT_Y", re(2), default=.false., do_not_log=.true.)
   call get_param(param_file, "mom6hip", "TRIPOLAR_N", tripolar_N, default=.false., do_not_log=.true.)
-  if (tripolar_N) call MOM_error(FATAL, "mom6hip: TRIPOLAR_N (the northern fold) is not supported by the GPU path.")
-  topology_known = .true. ; reentrant_saved(:) = re(:)
+  if (tripolar_N .and. .not.re(1)) call MOM_error(FATAL, "mom6hip: TRIPOLAR_N needs REENTRANT_X on the GPU path.")
+  topology_known = .true. ; reentrant_saved(:) = re(:) ; tripolar_saved = tripolar_N
   if (present(reentrant)) reentrant(:) = re(:)
 end subroutine mom6hip_read_topology
 
@@ -97,6 +98,15 @@ subroutine mom6hip_context_create(G, GV, ctx, reentrant)
     ! the whole domain is this tile: the library's wrap kernels are the halo update
     cg%reentrant_x = merge(1, 0, reentrant_x) ; cg%reentrant_y = merge(1, 0, reentrant_y)
   endif
+  ! TRIPOLAR_N: a tile that ends at the fold (btstep swaps the directional fits in its halo rows beyond the fold,
+  ! MOM_barotropic.F90:1471-1475, :4036-4064).  One PE: the library folds the halos itself; several PEs: MOM6's own pass_var
+  ! does (halo_cb), and the tiles must span x (LAYOUT = 1,N) for the library's index arithmetic of the swaps to hold.
+  cg%tripolar_n = 0 ; on_fold_cb = .false.
+  if (know_topology .and. tripolar_saved) then
+    if (G%jec + G%jdg_offset == G%Domain%njglobal) then ; cg%tripolar_n = 1 ; on_fold_cb = .true. ; endif
+    if (G%iec - G%isc + 1 /= G%Domain%niglobal) &
+      call MOM_error(FATAL, "mom6hip: with TRIPOLAR_N the GPU path needs tiles that span x (LAYOUT = 1,N).")
+  endif
   cg%Angstrom_H = GV%Angstrom_H ; cg%H_subroundoff = GV%H_subroundoff
   cg%dZ_subroundoff = GV%dZ_subroundoff ; cg%H_to_Z = GV%H_to_Z ; cg%Z_to_H = GV%Z_to_H
   cg%g_Earth = GV%g_Earth ; cg%Rho0 = GV%Rho0
@@ -120,7 +130,7 @@ subroutine mom6hip_context_create(G, GV, ctx, reentrant)
   if (rc == 0) rc = mom6hip_grid_create(cg, c_null_ptr, ctx)
   call mom6hip_fatal_if(rc, "mom6hip_context_create")
 
-  if ((cg%reentrant_x == 0 .and. cg%reentrant_y == 0) .or. (num_PEs() > 1)) then
+  if ((cg%reentrant_x == 0 .and. cg%reentrant_y == 0 .and. cg%tripolar_n == 0) .or. (num_PEs() > 1)) then
     ! every halo update inside a library call is MOM6's own pass_var; sums and minima are MOM_coms'
     G_cb => G ; ctx_cb = ctx ; nk_cb = GV%ke
     rc = mom6hip_set_domain_callbacks(ctx, c_funloc(halo_cb), c_funloc(sum_cb), c_null_ptr)
@@ -138,7 +148,8 @@ function halo_cb(user, fields, pos, nk, nfields) bind(c) result(rc)
   integer(c_int32_t), value      :: nfields
   integer(c_int) :: rc
   real(c_double), allocatable, target :: buf(:,:,:)
-  integer :: f, i0, j0, position
+  integer :: f, i0, j0, position, p
+  logical :: vector_cmpt
   integer(c_int64_t) :: bytes
 
   rc = 1
@@ -146,7 +157,10 @@ function halo_cb(user, fields, pos, nk, nfields) bind(c) result(rc)
   do f = 1, nfields
     if (.not. c_associated(fields(f))) cycle
     i0 = G_cb%isd ; j0 = G_cb%jsd ; position = CENTER
-    select case (pos(f))
+    p = iand(int(pos(f)), 3)
+    ! a u- or v-point field that is not one of a SCALAR_PAIR is a vector component: it changes sign across the fold
+    vector_cmpt = (p == MOM6HIP_POS_U .or. p == MOM6HIP_POS_V) .and. (iand(int(pos(f)), MOM6HIP_PASS_SCALAR_PAIR) == 0)
+    select case (p)
       case (MOM6HIP_POS_U) ; i0 = G_cb%IsdB ; position = EAST_FACE
       case (MOM6HIP_POS_V) ; j0 = G_cb%JsdB ; position = NORTH_FACE
       case (MOM6HIP_POS_Q) ; i0 = G_cb%IsdB ; j0 = G_cb%JsdB ; position = CORNER
@@ -155,6 +169,8 @@ function halo_cb(user, fields, pos, nk, nfields) bind(c) result(rc)
     bytes = int(size(buf), c_int64_t) * 8_c_int64_t
     if (mom6hip_sync_to_host(ctx_cb, c_loc(buf), fields(f), bytes) /= 0) return
     call pass_var(buf, G_cb%Domain, position=position)
+    ! (pass_var moves a scalar at this staggering: the image across the fold without the sign of a vector component)
+    if (vector_cmpt .and. on_fold_cb) buf(:, G_cb%jec+1:G_cb%jed, :) = -buf(:, G_cb%jec+1:G_cb%jed, :)
     if (mom6hip_sync_to_device(ctx_cb, fields(f), c_loc(buf), bytes) /= 0) return
     deallocate(buf)
   enddo

@@ -138,6 +138,7 @@ type :: ocean_grid_type
   type(MOM_domain_type), pointer :: Domain => NULL()
   integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB, ke
   integer :: first_direction = 0
+  integer :: idg_offset = 0, jdg_offset = 0
   logical :: symmetric = .true.
   real :: max_depth = 0.0, Z_ref = 0.0
   real, allocatable, dimension(:,:) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
