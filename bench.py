@@ -115,6 +115,12 @@ class Model:
         self.u, self.v, self.h = cut(dyn["u"], U), cut(dyn["v"], V), cut(dyn["h"], H)
         self.T, self.S = cut(dyn["T"], H), cut(dyn["S"], H)
         del dyn
+        if gg.tripolar_n:      # the generated state knows nothing of the fold: one face, one value on the fold line; folded halos
+            if dom.on_fold or dom.nranks == 1:
+                row = grid.halo + grid.nj
+                self.v[:, row, :] = 0.5 * (self.v[:, row, :] - torch.flip(self.v[:, row, :], dims=(-1,)))
+            fl, ps = [self.u, self.v, self.T, self.S, self.h], [1, 2, 0, 0, 0]
+            (dom.pass_var(fl, ps) if dom.nranks > 1 else self.dg.halo_update(fl, ps))
         adv = synth.make_advection_state(gg, ntr=4, seed=1, device=dev, hot_frac=0.0)
         self.passive = [cut(t, H) for t in adv["tr"][2:4]]      # 2 passive tracers (a smooth blob and a step)
         del adv
@@ -613,8 +619,15 @@ def main():
     # N>1: the global grid is cut into `world` latitude bands (layout 1 x N, the x direction stays a local wrap);
     # halos travel between neighbouring GPUs through the reference's group passes (DESIGN.md "Multi-GPU").
     # The total work is fixed: strong scaling.
-    grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=LAND_FRAC, rough_noise=rough_noise(NI))
-    dom = Domain(NI, NJ, (1, world), rank, grid.halo, grid.reentrant_x, grid.reentrant_y)
+    # MOM6HIP_BENCH_TRIPOLAR=1: the same shape with TRIPOLAR_N connectivity (the topology of OM4: the northern edge folds onto
+    # itself, open ocean on the fold) instead of a closed northern edge; not the default, so that the line stays comparable
+    TRIPOLAR = os.environ.get("MOM6HIP_BENCH_TRIPOLAR", "0") == "1"
+    TOPO = ", TRIPOLAR_N" if TRIPOLAR else ""
+    if TRIPOLAR:
+        grid = synth.fold_of(synth.make_grid(NI, 2 * NJ, NK, seed=20241020, land_frac=LAND_FRAC, rough_noise=rough_noise(NI), fold_symmetric=True))
+    else:
+        grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=LAND_FRAC, rough_noise=rough_noise(NI))
+    dom = Domain(NI, NJ, (1, world), rank, grid.halo, grid.reentrant_x, grid.reentrant_y, tripolar_n=TRIPOLAR)
     # the halo exchange of the N>1 run: "rccl" = the library's native group pass (mom6_amd/csrc/domain_rccl.hip; needs one GPU
     # per rank), "python" = callbacks into torch.distributed (the gloo rehearsal, or MOM6HIP_BENCH_EXCHANGE=python)
     exchange = os.environ.get("MOM6HIP_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "python") if world > 1 else None
@@ -684,7 +697,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "ns_per_gridpoint_step": sec_per_step * 1e9 / cells,
         "config": {
-            "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x, {100 * LAND_FRAC:.0f}% land, rough bathymetry, z* "
+            "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x{TOPO}, {100 * LAND_FRAC:.0f}% land, rough bathymetry, z* "
                         f"layers ({100 * health['vanished_layer_fraction']:.0f}% of the ocean cells are vanished layers below the bottom), "
                         f"T, S + 2 passive tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
             "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "

@@ -494,6 +494,17 @@ int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_pressurefor
                                    const double *h, const double *T, const double *S, const double *p_atm,
                                    double *PFu, double *PFv, double *pbce, double *eta, int32_t memspace);
 
+/*
+ * PressureForce_FV_nonBouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)   src/core/MOM_PressureForce_FV.F90:89
+ * The non-Boussinesq form (BOUSSINESQ = False): h in mass per unit area, H_to_RZ = GV%H_to_RZ (1 for kg m-2), the finite-volume
+ * integrals in pressure of the specific-volume anomaly (int_spec_vol_dp_generic_plm, MOM_density_integrals.F90:1479) with the
+ * same PLM reconstruction of T and S, Set_pbce_nonBouss (MOM_PressureForce_Montgomery.F90:752) for pbce, eta = the column mass.
+ * Same restrictions as the Boussinesq entry (no tides / SAL, GFS_scale = 1, no bulk mixed layer).
+ */
+int mom6hip_pressureforce_fv_nonbouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs, const mom6hip_eos_t *eos,
+                                      const double *h, const double *T, const double *S, const double *p_atm, double H_to_RZ,
+                                      double *PFu, double *PFv, double *pbce, double *eta, int32_t memspace);
+
 /* calculate_density(T, S, pressure, rho, EOS, dom, rho_ref) on n points (src/equation_of_state/MOM_EOS.F90:299);
  * use_rho_ref = 0: in-situ density. */
 int mom6hip_calculate_density(mom6hip_ctx_t *ctx, const mom6hip_eos_t *eos, const double *T, const double *S,

@@ -16,7 +16,7 @@ EXPORTS = (
     "mom6hip_init", "mom6hip_last_error", "mom6hip_grid_create", "mom6hip_grid_destroy",
     "mom6hip_sync", "mom6hip_malloc", "mom6hip_free", "mom6hip_sync_to_device",
     "mom6hip_sync_to_host", "mom6hip_halo_update", "mom6hip_advect_tracer", "mom6hip_set_timing",
-    "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
+    "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_pressureforce_fv_nonbouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
     "mom6hip_barotropic_init", "mom6hip_btcalc", "mom6hip_bt_mass_source", "mom6hip_set_dtbt", "mom6hip_btstep",
     "mom6hip_dyn_split_rk2_init", "mom6hip_step_dyn_split_rk2", "mom6hip_dyn_split_rk2b_init", "mom6hip_step_dyn_split_rk2b",
     "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats",
@@ -64,6 +64,8 @@ def lib():
                                          + [C.c_void_p] * 6 + [C.POINTER(_abi.BTCont)] + [C.c_void_p] * 2 + [C.c_int32])
         L.mom6hip_pressureforce_fv_bouss.argtypes = ([C.c_void_p, C.POINTER(_abi.PressureForceCS), C.POINTER(_abi.EOS)]
                                                      + [C.c_void_p] * 8 + [C.c_int32])
+        L.mom6hip_pressureforce_fv_nonbouss.argtypes = ([C.c_void_p, C.POINTER(_abi.PressureForceCS), C.POINTER(_abi.EOS)]
+                                                        + [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 4 + [C.c_int32])
         L.mom6hip_calculate_density.argtypes = ([C.c_void_p, C.POINTER(_abi.EOS)] + [C.c_void_p] * 4
                                                 + [C.c_int64, C.c_int32, C.c_double, C.c_int32])
         L.mom6hip_set_domain_callbacks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -118,5 +118,30 @@ __device__ __forceinline__ void eos_density_derivs(const EosDev &E, double T, do
   drho_dS = I_denom2 * (lambda * (b4 + b5 * T) - (pressure + p0) * ((pressure + p0) * a2 + (c4 + c5 * T)));
 }
 
+// ---- specific-volume anomaly (calculate_spec_vol with spv_ref): MOM_EOS_Wright.F90:156-174, MOM_EOS_UNESCO.F90:208-240,
+// MOM_EOS_linear.F90:102-113
+__device__ __forceinline__ double eos_spec_vol_anomaly(const EosDev &E, double T, double S, double pressure, double spv_ref) {
+  if (E.form == MOM6HIP_EOS_LINEAR)
+    return ((1.0 - E.Rho_T0_S0*spv_ref) - spv_ref*(E.dRho_dT*T + E.dRho_dS*S)) / (E.Rho_T0_S0 + (E.dRho_dT*T + E.dRho_dS*S));
+  if (E.form == MOM6HIP_EOS_UNESCO) {
+    using namespace unesco;
+    const double p1 = pressure*1.0e-5, t1 = T;
+    const double s1 = (S > 0.0 ? S : 0.0), s12 = sqrt(s1);
+    const double rho0 = R00 + ( t1*(R01 + t1*(R02 + t1*(R03 + t1*(R04 + t1*R05)))) +
+                   s1*((R10 + t1*(R11 + t1*(R12 + t1*(R13 + t1*R14)))) +
+                       (s12*(R60 + t1*(R61 + t1*R62)) + s1*R20)) );
+    const double ks = (S000 + ( t1*(S010 + t1*(S020 + t1*(S030 + t1*S040))) +
+                   s1*((S100 + t1*(S110 + t1*(S120 + t1*S130))) + s12*(S600 + t1*(S610 + t1*S620))) )) +
+         p1*( (S001 + ( t1*(S011 + t1*(S021 + t1*S031)) +
+                        s1*((S101 + t1*(S111 + t1*S121)) + s12*S601) )) +
+              p1*(S002 + ( t1*(S012 + t1*S022) + s1*(S102 + t1*(S112 + t1*S122)) )) );
+    return (ks*(1.0 - (rho0*spv_ref)) - p1) / (rho0*ks);
+  }
+  const double al0 = (a0 + a1*T) + a2*S;
+  const double p0 = (b0 + b4*S) + T * (b1 + T*((b2 + b3*T)) + b5*S);
+  const double lambda = (c0 + c4*S) + T * (c1 + T*((c2 + c3*T)) + c5*S);
+  return (lambda + (al0 - spv_ref)*(pressure + p0)) / (pressure + p0);
+}
+
 }  // namespace eos
 }  // namespace m6

@@ -67,6 +67,8 @@ struct PgfArgs {
   double *PFu, *PFv, *pbce, *eta;
   double rho_ref, Z_ref, GFS_scale;
   int boundary_extrap, massw;
+  double *za0;        // non-Boussinesq: the geopotential anomaly at the sea surface (2-D scratch)
+  double H_to_RZ;     // non-Boussinesq: GV%H_to_RZ
 };
 
 // ---- column kernel -------------------------------------------------------------------------------
@@ -294,6 +296,211 @@ __global__ __launch_bounds__(64) void pgf_face_kernel(PgfArgs p) {
   }
 }
 
+// ======== PressureForce_FV_nonBouss (MOM_PressureForce_FV.F90:89-452) ==================================================
+// The same two-kernel split: p.e holds the interface PRESSURES (nk+1 planes, top down), p.dpa the layers' dza, p.intz_dpa
+// their intp_dza (int_spec_vol_dp_generic_plm, MOM_density_integrals.F90:1479-1726), p.za0 the surface geopotential anomaly.
+__global__ __launch_bounds__(64) void pgfnb_column_kernel(PgfArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.jsc - 1 + blockIdx.y;
+  if (i > g.iec + 1) return;
+  const int nz = g.nk;
+  const long o2 = g.h2(i, j), pl = (long)g.nih * g.njh;
+  const double h_neglect = g.H_subroundoff;
+  const double H_to_RL2_T2 = g.g_Earth * p.H_to_RZ;
+  const double dp_neglect = g.g_Earth * p.H_to_RZ * g.H_subroundoff;
+  const double alpha_ref = 1.0 / p.rho_ref;
+  const double C1_90 = 1.0 / 90.0;
+  // :193-206
+  double pk = p.p_atm ? p.p_atm[o2] : 0.0;
+  const double p_top = pk;
+  p.e[o2] = pk;
+  for (int k = 0; k < nz; k++) {
+    pk = pk + H_to_RL2_T2 * p.h[o2 + pl * k];
+    p.e[o2 + pl * (k + 1)] = pk;
+  }
+  const double p_bot = pk;
+  if (p.eta) {      // :417-428
+    const double Pa_to_H = 1.0 / (g.g_Earth * p.H_to_RZ);
+    p.eta[o2] = p.p_atm ? (p_bot - p_top) * Pa_to_H : p_bot * Pa_to_H;
+  }
+  auto ld = [&](const double *a, int kk) -> double { return (kk >= 0 && kk < nz) ? a[o2 + pl * kk] : 0.0; };
+  double h_m = 0., h_c = ld(p.h, 0), h_p = ld(p.h, 1), h_q = ld(p.h, 2);
+  double T_m = 0., T_c = ld(p.T, 0), T_p = ld(p.T, 1), T_q = ld(p.T, 2);
+  double S_m = 0., S_c = ld(p.S, 0), S_p = ld(p.S, 1), S_q = ld(p.S, 2);
+  double sT_m = 0., sT_c = 0., sT_p = 0., sS_m = 0., sS_c = 0., sS_p = 0.;
+  if (nz >= 3) {
+    sT_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, T_c, T_p, T_q);
+    sS_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, S_c, S_p, S_q);
+  }
+  double p_K = p_top;
+  for (int kk = 0; kk < nz; kk++) {
+    const long o3 = o2 + pl * kk;
+    // ---- TS_PLM_edge_values (ALE_PLM_edge_values, MOM_ALE.F90:1549-1576) ----
+    double Tt, Tb, St, Sb;
+    if (kk >= 1 && kk <= nz - 2) {
+      const double mT = plm_monotonized_slope(T_m, T_c, T_p, sT_m, sT_c, sT_p);
+      Tt = T_c - 0.5 * mT; Tb = T_c + 0.5 * mT;
+      const double mS = plm_monotonized_slope(S_m, S_c, S_p, sS_m, sS_c, sS_p);
+      St = S_c - 0.5 * mS; Sb = S_c + 0.5 * mS;
+    } else if (p.boundary_extrap) {
+      if (kk == 0) {
+        const double mT = -plm_extrapolate_slope(h_p, h_c, h_neglect, T_p, T_c);
+        Tt = T_c - 0.5 * mT; Tb = T_c + 0.5 * mT;
+        const double mS = -plm_extrapolate_slope(h_p, h_c, h_neglect, S_p, S_c);
+        St = S_c - 0.5 * mS; Sb = S_c + 0.5 * mS;
+      } else {
+        const double mT = plm_extrapolate_slope(h_m, h_c, h_neglect, T_m, T_c);
+        Tt = T_c - 0.5 * mT; Tb = T_c + 0.5 * mT;
+        const double mS = plm_extrapolate_slope(h_m, h_c, h_neglect, S_m, S_c);
+        St = S_c - 0.5 * mS; Sb = S_c + 0.5 * mS;
+      }
+    } else {
+      Tt = T_c; Tb = T_c; St = S_c; Sb = S_c;
+    }
+    p.T_t[o3] = Tt; p.T_b[o3] = Tb; p.S_t[o3] = St; p.S_b[o3] = Sb;
+    // ---- the vertical integrals :1556-1574 (the weights run the other way than in int_density_dz) ----
+    const double p_Kp1 = p.e[o3 + pl];
+    double a5[5];
+#pragma unroll
+    for (int n = 1; n <= 5; n++) {
+      const double wt_t = 0.25 * (double)(n - 1), wt_b = 1.0 - wt_t;
+      const double p5 = wt_t * p_K + wt_b * p_Kp1;
+      const double S5 = wt_t * St + wt_b * Sb;
+      const double T5 = wt_t * Tt + wt_b * Tb;
+      a5[n - 1] = eos_spec_vol_anomaly(p.eos, T5, S5, p5, alpha_ref);
+    }
+    const double dp = p_Kp1 - p_K;
+    const double alpha_anom = C1_90 * ((7.0 * (a5[0] + a5[4]) + 32.0 * (a5[1] + a5[3])) + 12.0 * a5[2]);
+    p.dpa[o3] = dp * alpha_anom;
+    p.intz_dpa[o3] = 0.5 * (dp * dp) * (alpha_anom - C1_90 * (16.0 * (a5[3] - a5[1]) + 7.0 * (a5[4] - a5[0])));
+    p_K = p_Kp1;
+    h_m = h_c; h_c = h_p; h_p = h_q; h_q = ld(p.h, kk + 3);
+    T_m = T_c; T_c = T_p; T_p = T_q; T_q = ld(p.T, kk + 3);
+    S_m = S_c; S_c = S_p; S_p = S_q; S_q = ld(p.S, kk + 3);
+    sT_m = sT_c; sT_c = sT_p; sS_m = sS_c; sS_c = sS_p;
+    if (kk + 2 <= nz - 2) {
+      sT_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, T_c, T_p, T_q);
+      sS_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, S_c, S_p, S_q);
+    } else {
+      sT_p = 0.; sS_p = 0.;
+    }
+  }
+  // :299-306: za at the sea surface, summed from the bottom
+  double za = alpha_ref * p_bot - g.g_Earth * g.bathyT[o2];
+  for (int k = nz - 1; k >= 0; k--) za = za + p.dpa[o2 + pl * k];
+  p.za0[o2] = za;
+  // Set_pbce_nonBouss, MOM_PressureForce_Montgomery.F90:809-830
+  if (p.pbce) {
+    const double dP_dH = g.g_Earth * p.H_to_RZ;
+    const double C_htot = dP_dH / ((p_bot - p_top) + dp_neglect);
+    double Tk1 = p.T[o2 + pl * (nz - 1)], Sk1 = p.S[o2 + pl * (nz - 1)];
+    double pb = dP_dH / eos_density(p.eos, Tk1, Sk1, p_bot);
+    p.pbce[o2 + pl * (nz - 1)] = pb;
+    for (int k = nz - 2; k >= 0; k--) {
+      const double Tk = p.T[o2 + pl * k], Sk = p.S[o2 + pl * k];
+      const double T_int = 0.5 * (Tk + Tk1), S_int = 0.5 * (Sk + Sk1);
+      const double pi = p.e[o2 + pl * (k + 1)];
+      const double rho = eos_density(p.eos, T_int, S_int, pi);
+      double dR_dT, dR_dS;
+      eos_density_derivs(p.eos, T_int, S_int, pi, dR_dT, dR_dS);
+      pb = pb + ((pi - p_top) * C_htot) * ((dR_dT * (Tk1 - Tk) + dR_dS * (Sk1 - Sk)) / (rho * rho));
+      p.pbce[o2 + pl * k] = pb;
+      Tk1 = Tk; Sk1 = Sk;
+    }
+  }
+}
+
+// the 15 specific-volume evaluations across one face :1576-1640
+__device__ __forceinline__ double face_integral_nb(const PgfArgs &p, long L3, long R3, long oL2, long oR2, long pl, double dp_neglect,
+                                                   double alpha_ref) {
+  const int nz = p.g.nk;
+  const double C1_90 = 1.0 / 90.0;
+  const double PT_L = p.e[L3], PB_L = p.e[L3 + pl], PT_R = p.e[R3], PB_R = p.e[R3 + pl];
+  double hWght = 0.0, hWt_LL, hWt_LR, hWt_RR, hWt_RL;
+  if (p.massw) hWght = max3(0., p.e[oL2 + pl * nz] - PT_R, p.e[oR2 + pl * nz] - PT_L);
+  if (hWght > 0.) {
+    const double hL = (PB_L - PT_L) + dp_neglect;
+    const double hR = (PB_R - PT_R) + dp_neglect;
+    const double rr = (hL - hR) / (hL + hR);
+    hWght = hWght * (rr * rr);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    hWt_LL = (hWght * hL + hR * hL) * iDenom; hWt_LR = (hWght * hR) * iDenom;
+    hWt_RR = (hWght * hR + hR * hL) * iDenom; hWt_RL = (hWght * hL) * iDenom;
+  } else {
+    hWt_LL = 1.0; hWt_LR = 0.0; hWt_RR = 1.0; hWt_RL = 0.0;
+  }
+  const double TtL = p.T_t[L3], TtR = p.T_t[R3], TbL = p.T_b[L3], TbR = p.T_b[R3];
+  const double StL = p.S_t[L3], StR = p.S_t[R3], SbL = p.S_b[L3], SbR = p.S_b[R3];
+  double intp[5];
+  intp[0] = p.dpa[L3]; intp[4] = p.dpa[R3];
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = wt_L * hWt_LL + wt_R * hWt_RL, wtT_R = wt_L * hWt_LR + wt_R * hWt_RR;
+    const double P_top = wt_L * PT_L + wt_R * PT_R;
+    const double P_bot = wt_L * PB_L + wt_R * PB_R;
+    const double T_top = wtT_L * TtL + wtT_R * TtR;
+    const double T_bot = wtT_L * TbL + wtT_R * TbR;
+    const double S_top = wtT_L * StL + wtT_R * StR;
+    const double S_bot = wtT_L * SbL + wtT_R * SbR;
+    const double dp_90 = C1_90 * (P_bot - P_top);
+    double a[5];
+#pragma unroll
+    for (int n = 1; n <= 5; n++) {
+      const double wt_t = 0.25 * (double)(n - 1), wt_b = 1.0 - wt_t;
+      a[n - 1] = eos_spec_vol_anomaly(p.eos, wt_t * T_top + wt_b * T_bot, wt_t * S_top + wt_b * S_bot, wt_t * P_top + wt_b * P_bot, alpha_ref);
+    }
+    intp[m - 1] = dp_90 * ((7.0 * (a[0] + a[4]) + 32.0 * (a[1] + a[3])) + 12.0 * a[2]);
+  }
+  return C1_90 * ((7.0 * (intp[0] + intp[4]) + 32.0 * (intp[1] + intp[3])) + 12.0 * intp[2]);
+}
+
+__global__ __launch_bounds__(64) void pgfnb_face_kernel(PgfArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.jsc - 1 + blockIdx.y;
+  if (i > g.iec) return;
+  const bool do_x = (j >= g.jsc), do_y = (i >= g.isc);
+  if (!do_x && !do_y) return;
+  const int nz = g.nk;
+  const long pl = (long)g.nih * g.njh, plU = (long)(g.nih + 1) * g.njh, plV = (long)g.nih * (g.njh + 1);
+  const long oc = g.h2(i, j), oe = oc + 1, on = oc + g.nih;
+  const double H_to_RL2_T2 = g.g_Earth * p.H_to_RZ;
+  const double dp_neglect = g.g_Earth * p.H_to_RZ * g.H_subroundoff;
+  const double alpha_ref = 1.0 / p.rho_ref;
+  double za_c = p.za0[oc], za_e = do_x ? p.za0[oe] : 0.0, za_n = do_y ? p.za0[on] : 0.0;
+  double intx_za = 0.5 * (za_c + za_e), inty_za = 0.5 * (za_c + za_n);      // :366-371
+  const double fx = do_x ? (2.0 * g.IdxCu[g.u2(i, j)]) : 0.0;
+  const double fy = do_y ? (2.0 * g.IdyCv[g.v2(i, j)]) : 0.0;
+  for (int k = 0; k < nz; k++) {      // :373-399
+    const long c3 = oc + pl * k;
+    const double dp_c = H_to_RL2_T2 * p.h[c3];
+    za_c = za_c - p.dpa[c3];
+    const double ipd_c = p.intz_dpa[c3], pc_K = p.e[c3];
+    if (do_x) {
+      const long e3 = c3 + 1;
+      const double dp_e = H_to_RL2_T2 * p.h[e3];
+      za_e = za_e - p.dpa[e3];
+      const double intx_dza = face_integral_nb(p, c3, e3, oc, oe, pl, dp_neglect, alpha_ref);
+      intx_za = intx_za - intx_dza;
+      p.PFu[g.u2(i, j) + plU * k] = (((za_c * dp_c + ipd_c) - (za_e * dp_e + p.intz_dpa[e3])) +
+                                     ((dp_e - dp_c) * intx_za - (p.e[e3] - pc_K) * intx_dza)) *
+                                    (fx / ((dp_c + dp_e) + dp_neglect));
+    }
+    if (do_y) {
+      const long n3 = c3 + g.nih;
+      const double dp_n = H_to_RL2_T2 * p.h[n3];
+      za_n = za_n - p.dpa[n3];
+      const double inty_dza = face_integral_nb(p, c3, n3, oc, on, pl, dp_neglect, alpha_ref);
+      inty_za = inty_za - inty_dza;
+      p.PFv[g.v2(i, j) + plV * k] = (((za_c * dp_c + ipd_c) - (za_n * dp_n + p.intz_dpa[n3])) +
+                                     ((dp_n - dp_c) * inty_za - (p.e[n3] - pc_K) * inty_dza)) *
+                                    (fy / ((dp_c + dp_n) + dp_neglect));
+    }
+  }
+}
+
 __global__ void eos_density_kernel(EosDev E, const double *T, const double *S, const double *pr, double *rho, long n,
                                    int use_ref, double rho_ref) {
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
@@ -357,11 +564,52 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
   a.S_t = (double *)st.scratch(bH); a.S_b = (double *)st.scratch(bH);
   a.dpa = (double *)st.scratch(bH); a.intz_dpa = (double *)st.scratch(bH);
   if (st.failed()) return 1;
-  a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale;
+  a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale; a.za0 = nullptr; a.H_to_RZ = 0.0;
   a.boundary_extrap = cs->boundary_extrap; a.massw = cs->useMassWghtInterp;
   const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
   hipLaunchKernelGGL(pgf_column_kernel, dim3((ncol_i + 63) / 64, ncol_j), dim3(64), 0, s, a);
   hipLaunchKernelGGL(pgf_face_kernel, dim3((ncol_i - 1 + 63) / 64, ncol_j - 1), dim3(64), 0, s, a);
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+extern "C" int mom6hip_pressureforce_fv_nonbouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs,
+                                                 const mom6hip_eos_t *eos, const double *h, const double *T,
+                                                 const double *S, const double *p_atm, double H_to_RZ, double *PFu,
+                                                 double *PFv, double *pbce, double *eta, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr && cs != nullptr, "MOM_PressureForce_FV_nonBouss: Module must be initialized before it is used.");
+  M6_REQUIRE(h && T && S && PFu && PFv, "PressureForce_FV_nonBouss: null argument");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "PressureForce_FV_nonBouss: bad memspace");
+  if (check_eos(eos)) return 2;
+  M6_REQUIRE(cs->reconstruct && cs->Recon_Scheme == 1,
+             "PressureForce_FV_nonBouss: only RECONSTRUCT_FOR_PRESSURE=True with PRESSURE_RECONSTRUCTION_SCHEME=1 is provided");
+  M6_REQUIRE(cs->GFS_scale == 1.0, "PressureForce_FV_nonBouss: GFS_scale < 1 is not provided");
+  M6_REQUIRE(H_to_RZ > 0.0, "PressureForce_FV_nonBouss: H_to_RZ must be positive");
+  m6::GridDev &g = ctx->g;
+  M6_REQUIRE(g.bathyT && g.IdxCu && g.IdyCv, "PressureForce_FV_nonBouss: a required grid metric is missing");
+  M6_REQUIRE(g.nk >= 2, "PressureForce_FV_nonBouss: at least 2 layers are needed");
+  M6_REQUIRE(g.isc - g.isd >= 1 && g.ied - g.iec >= 1 && g.jsc - g.jsd >= 1 && g.jed - g.jec >= 1,
+             "PressureForce_FV_nonBouss: needs a halo of at least 1");
+  hipStream_t s = ctx->stream;
+  const size_t bH = (size_t)g.nh3() * 8, bU = (size_t)g.nu3() * 8, bV = (size_t)g.nv3() * 8;
+  const size_t bH2 = (size_t)g.nih * g.njh * 8;
+  m6::Stager st(ctx, memspace);
+  PgfArgs a;
+  a.g = g;
+  a.eos = EosDev{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS};
+  a.h = st.in(h, bH); a.T = st.in(T, bH); a.S = st.in(S, bH); a.p_atm = st.in(p_atm, bH2);
+  a.PFu = st.inout(PFu, bU); a.PFv = st.inout(PFv, bV); a.pbce = st.inout(pbce, bH); a.eta = st.inout(eta, bH2);
+  a.e = (double *)st.scratch(bH + bH2);
+  a.T_t = (double *)st.scratch(bH); a.T_b = (double *)st.scratch(bH);
+  a.S_t = (double *)st.scratch(bH); a.S_b = (double *)st.scratch(bH);
+  a.dpa = (double *)st.scratch(bH); a.intz_dpa = (double *)st.scratch(bH);
+  a.za0 = (double *)st.scratch(bH2);
+  if (st.failed()) return 1;
+  a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale; a.H_to_RZ = H_to_RZ;
+  a.boundary_extrap = cs->boundary_extrap; a.massw = cs->useMassWghtInterp;
+  const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
+  hipLaunchKernelGGL(pgfnb_column_kernel, dim3((ncol_i + 63) / 64, ncol_j), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(pgfnb_face_kernel, dim3((ncol_i - 1 + 63) / 64, ncol_j - 1), dim3(64), 0, s, a);
   M6_HIP(hipGetLastError());
   return st.finish();
 }

@@ -6,7 +6,8 @@
 !! p_atm, pbce, eta, on the GPU through libmom6hip (mom6hip_pressureforce_fv_bouss, HOST memspace).  The equation of state
 !! is opaque in MOM6 (EOS_type is private), so its selection is read from the parameter file the way
 !! interpret_eos_selection does (MOM_EOS.F90:1474-1520).  Tides / SAL, the Stanley correction, PPM reconstruction,
-!! USE_INACCURATE_PGF_RHO_ANOM and the non-Boussinesq form stop with a FATAL error.
+!! USE_INACCURATE_PGF_RHO_ANOM stops with a FATAL error; PressureForce_FV_nonBouss (mom6hip_pressureforce_fv_nonbouss) serves a
+!! non-Boussinesq vertical grid.
 !!
 !! Compiled INSIDE a MOM6 source tree in place of src/core/MOM_PressureForce_FV.F90; here against tests/fortran/stubs.
 module MOM_PressureForce_FV
@@ -45,21 +46,38 @@ end type PressureForce_FV_CS
 
 contains
 
-!> Same interface as the reference PressureForce_FV_nonBouss (:86): not provided
+!> Same interface as the reference PressureForce_FV_nonBouss (:89).
 subroutine PressureForce_FV_nonBouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)
   type(ocean_grid_type),   intent(in)  :: G
   type(verticalGrid_type), intent(in)  :: GV
   type(unit_scale_type),   intent(in)  :: US
-  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(in)  :: h
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(in)  :: h
   type(thermo_var_ptrs),   intent(in)  :: tv
-  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(out) :: PFu
-  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(out) :: PFv
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(out) :: PFu
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(out) :: PFv
   type(PressureForce_FV_CS), intent(in) :: CS
   type(ALE_CS),            pointer     :: ALE_CSp
   real, dimension(:,:),    pointer     :: p_atm
-  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), optional, intent(out) :: pbce
-  real, dimension(SZI_(G),SZJ_(G)),          optional, intent(out) :: eta
-  call MOM_error(FATAL, "MOM_PressureForce_FV_nonBouss (HIP): the non-Boussinesq pressure force is not provided by the GPU path.")
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, optional, intent(out) :: pbce
+  real, dimension(SZI_(G),SZJ_(G)),          target, optional, intent(out) :: eta
+
+  type(mom6hip_pressureforce_cs_t) :: ccs
+  type(c_ptr) :: p_patm, p_pbce, p_eta
+  integer :: rc
+
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_PressureForce_FV_nonBouss: Module must be initialized before it is used.")
+  if (.not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "MOM_PressureForce_FV_nonBouss (HIP): "// &
+       "the GPU path needs temperature and salinity (USE_EOS); the layered mode with GV%Rlay is not provided.")
+  if (GV%nk_rho_varies > 0) call MOM_error(FATAL, "MOM_PressureForce_FV_nonBouss (HIP): a bulk mixed layer is not provided.")
+  ccs%Rho0 = CS%Rho0 ; ccs%GFS_scale = CS%GFS_scale ; ccs%Z_ref = G%Z_ref
+  ccs%reconstruct = merge(1, 0, CS%reconstruct) ; ccs%Recon_Scheme = CS%Recon_Scheme
+  ccs%boundary_extrap = merge(1, 0, CS%boundary_extrap) ; ccs%useMassWghtInterp = merge(1, 0, CS%useMassWghtInterp)
+  p_patm = c_null_ptr ; if (associated(p_atm)) p_patm = c_loc(p_atm)
+  p_pbce = c_null_ptr ; if (present(pbce)) p_pbce = c_loc(pbce)
+  p_eta = c_null_ptr ; if (present(eta)) p_eta = c_loc(eta)
+  rc = mom6hip_pressureforce_fv_nonbouss(mom6hip_shared_context(G, GV), ccs, CS%eos, c_loc(h), c_loc(tv%T), c_loc(tv%S), p_patm, &
+                                         real(GV%H_to_RZ, c_double), c_loc(PFu), c_loc(PFv), p_pbce, p_eta, MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "MOM_PressureForce_FV_nonBouss")
 end subroutine PressureForce_FV_nonBouss
 
 !> Same interface as the reference PressureForce_FV_Bouss (:462).
@@ -139,7 +157,6 @@ subroutine PressureForce_FV_init(Time, G, GV, US, param_file, diag, CS, SAL_CSp,
                  "If true, the reconstruction of T & S for pressure in boundary cells is extrapolated.", default=.true.)
   call get_param(param_file, mdl, "USE_STANLEY_PGF", flag, default=.false.)
   call refuse(flag, "USE_STANLEY_PGF")
-  if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
   CS%GFS_scale = 1.0
   if (GV%g_prime(1) /= GV%g_Earth) CS%GFS_scale = GV%g_prime(1) / GV%g_Earth
 

@@ -453,6 +453,17 @@ interface
     integer(c_int) :: rc
   end function mom6hip_pressureforce_fv_bouss
 
+  function mom6hip_pressureforce_fv_nonbouss(ctx, cs, eos, h, T, S, p_atm, H_to_RZ, PFu, PFv, pbce, eta, memspace) &
+                                          bind(c, name="mom6hip_pressureforce_fv_nonbouss") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_pressureforce_cs_t, mom6hip_eos_t
+    type(c_ptr), value :: ctx, h, T, S, p_atm, PFu, PFv, pbce, eta
+    type(mom6hip_pressureforce_cs_t), intent(in) :: cs
+    type(mom6hip_eos_t), intent(in) :: eos
+    real(c_double), value :: H_to_RZ
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_pressureforce_fv_nonbouss
+
   function mom6hip_calculate_density(ctx, eos, T, S, pressure, rho, n, use_rho_ref, rho_ref, memspace) &
                                      bind(c, name="mom6hip_calculate_density") result(rc)
     import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr, mom6hip_eos_t

@@ -25,9 +25,10 @@ def PressureForce_init(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=
                                 int(bool(boundary_extrap)), int(bool(useMassWghtInterp)))
 
 
-def PressureForce(h, tv, PFu, PFv, G: DeviceGrid, CS, ALE_CSp=None, p_atm=None, pbce=None, eta=None):
+def PressureForce(h, tv, PFu, PFv, G: DeviceGrid, CS, ALE_CSp=None, p_atm=None, pbce=None, eta=None, Boussinesq=True, H_to_RZ=1.0):
     """PressureForce(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta) -- MOM_PressureForce.F90:41.
-    `tv` is (T, S, EOS)."""
+    `tv` is (T, S, EOS).  Boussinesq=False (GV%Boussinesq, MOM_PressureForce_FV.F90:89): PressureForce_FV_nonBouss with h in
+    mass per unit area and H_to_RZ = GV%H_to_RZ."""
     if CS is None:
         raise Mom6HipError("MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.")
     T, S, EOS = tv
@@ -43,5 +44,9 @@ def PressureForce(h, tv, PFu, PFv, G: DeviceGrid, CS, ALE_CSp=None, p_atm=None, 
     args = [P(x) for x in (h, T, S, p_atm, PFu, PFv, pbce, eta)]
     if len(spaces) != 1:
         raise Mom6HipError("PressureForce: all fields must be in the same memory space")
+    if not Boussinesq:
+        check(lib().mom6hip_pressureforce_fv_nonbouss(G.handle, C.byref(CS), C.byref(EOS), *args[:4], float(H_to_RZ), *args[4:], spaces.pop()),
+              "PressureForce_FV_nonBouss")
+        return
     check(lib().mom6hip_pressureforce_fv_bouss(G.handle, C.byref(CS), C.byref(EOS), *args, spaces.pop()),
           "PressureForce_FV_Bouss")

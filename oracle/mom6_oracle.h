@@ -141,6 +141,11 @@ void orc_ale_plm_edge_values(const mom6hip_grid_t *G, const double *h, const dou
 int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
                                const double *h, const double *T, const double *S, const double *p_atm,
                                double *PFu, double *PFv, double *pbce, double *eta);
+/* non-Boussinesq: calculate_spec_vol with spv_ref, and PressureForce_FV_nonBouss (MOM_PressureForce_FV.F90:89) + Set_pbce_nonBouss */
+double orc_eos_spec_vol_anomaly(const mom6hip_eos_t *E, double T, double S, double p, double spv_ref);
+int orc_pressureforce_fv_nonbouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
+                                  const double *h, const double *T, const double *S, const double *p_atm, double H_to_RZ,
+                                  double *PFu, double *PFv, double *pbce, double *eta);
 
 /* ---- MOM_barotropic (oracle/barotropic.c) ----------------------------------------------------- */
 double orc_cr_pow(double x, double y);   /* correctly rounded x**y, 0 < x <= 1, 0 < y <= 1 */

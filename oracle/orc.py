@@ -231,6 +231,8 @@ def ref_lib():
         L.ref_hybgen_weno.argtypes = [i, _dp, _dp, _dp, d]; L.ref_hybgen_weno.restype = None
     if hasattr(L, "ref_unesco"):
         L.ref_unesco.argtypes = [i, _dp, _dp, _dp, d, i, _dp, _dp, _dp]; L.ref_unesco.restype = None
+    if hasattr(L, "ref_unesco_spv"):
+        L.ref_unesco_spv.argtypes = [i, _dp, _dp, _dp, d, _dp]; L.ref_unesco_spv.restype = None
     if hasattr(L, "ref_rotate_array"):
         L.ref_rotate_array.argtypes = [i, i, i, _dp, i, _dp]; L.ref_rotate_array.restype = None
         L.ref_rotate_vector.argtypes = [i] * 5 + [_dp, _dp, i, _dp, _dp]; L.ref_rotate_vector.restype = None
@@ -345,6 +347,27 @@ def pressureforce(grid, cs, E, h, T, S, p_atm=None, want_pbce=True, want_eta=Tru
     if rc:
         raise RuntimeError("orc_pressureforce_fv_bouss: unsupported configuration")
     return PFu, PFv, pbce, eta
+
+
+def pressureforce_nonbouss(grid, cs, E, h, T, S, p_atm=None, H_to_RZ=1.0, want_pbce=True, want_eta=True):
+    """PressureForce_FV_nonBouss (h in kg m-2 when H_to_RZ = 1)"""
+    L = lib()
+    L.orc_pressureforce_fv_nonbouss.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.PressureForceCS), C.POINTER(_abi.EOS)] + [_dp] * 4
+                                                + [C.c_double] + [_dp] * 4)
+    PFu, PFv = grid.zeros3(_abi.POS_U), grid.zeros3(_abi.POS_V)
+    pbce = grid.zeros3(_abi.POS_H) if want_pbce else None
+    eta = grid.zeros2(_abi.POS_H) if want_eta else None
+    rc = L.orc_pressureforce_fv_nonbouss(C.byref(grid.struct()), C.byref(cs), C.byref(E), _p(h), _p(T), _p(S), _p(p_atm), float(H_to_RZ),
+                                         _p(PFu), _p(PFv), _p(pbce), _p(eta))
+    if rc:
+        raise RuntimeError("orc_pressureforce_fv_nonbouss: unsupported configuration")
+    return PFu, PFv, pbce, eta
+
+
+def eos_spec_vol_anomaly(E, T, S, p, spv_ref):
+    L = lib()
+    L.orc_eos_spec_vol_anomaly.argtypes = [C.POINTER(_abi.EOS)] + [C.c_double] * 4; L.orc_eos_spec_vol_anomaly.restype = C.c_double
+    return L.orc_eos_spec_vol_anomaly(C.byref(E), T, S, p, spv_ref)
 
 
 # ---- MOM_barotropic -------------------------------------------------------------------------------------

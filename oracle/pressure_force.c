@@ -388,3 +388,212 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
   free(intx_pa); free(intx_dpa); free(inty_pa); free(inty_dpa);
   return 0;
 }
+
+/* ======== non-Boussinesq: specific-volume forms and PressureForce_FV_nonBouss ================================================
+ * spec_vol_anomaly_elem of MOM_EOS_Wright.F90:156-174, MOM_EOS_UNESCO.F90:208-240, MOM_EOS_linear.F90:102-113 (calculate_spec_vol
+ * with spv_ref, MOM_EOS.F90; the Wright array form :910-933 calls the same function). */
+static double wright_spv_anomaly(double T, double S, double pressure, double spv_ref) {
+  const double al0 = (a0 + a1*T) + a2*S;
+  const double p0 = (b0 + b4*S) + T * (b1 + T*((b2 + b3*T)) + b5*S);
+  const double lambda = (c0 + c4*S) + T * (c1 + T*((c2 + c3*T)) + c5*S);
+  return (lambda + (al0 - spv_ref)*(pressure + p0)) / (pressure + p0);
+}
+static double unesco_spv_anomaly(double T, double S, double pressure, double spv_ref) {
+  const double p1 = pressure*1.0e-5, t1 = T;
+  const double s1 = MAX0(S), s12 = sqrt(s1);
+  const double rho0 = R00 + ( t1*(R01 + t1*(R02 + t1*(R03 + t1*(R04 + t1*R05)))) +
+                 s1*((R10 + t1*(R11 + t1*(R12 + t1*(R13 + t1*R14)))) +
+                     (s12*(R60 + t1*(R61 + t1*R62)) + s1*R20)) );
+  const double ks = (S000 + ( t1*(S010 + t1*(S020 + t1*(S030 + t1*S040))) +
+                 s1*((S100 + t1*(S110 + t1*(S120 + t1*S130))) + s12*(S600 + t1*(S610 + t1*S620))) )) +
+       p1*( (S001 + ( t1*(S011 + t1*(S021 + t1*S031)) +
+                      s1*((S101 + t1*(S111 + t1*S121)) + s12*S601) )) +
+            p1*(S002 + ( t1*(S012 + t1*S022) + s1*(S102 + t1*(S112 + t1*S122)) )) );
+  return (ks*(1.0 - (rho0*spv_ref)) - p1) / (rho0*ks);
+}
+double orc_eos_spec_vol_anomaly(const mom6hip_eos_t *E, double T, double S, double p, double spv_ref) {
+  if (E->form == MOM6HIP_EOS_LINEAR)
+    return ((1.0 - E->Rho_T0_S0*spv_ref) - spv_ref*(E->dRho_dT*T + E->dRho_dS*S)) / (E->Rho_T0_S0 + (E->dRho_dT*T + E->dRho_dS*S));
+  if (E->form == MOM6HIP_EOS_UNESCO) return unesco_spv_anomaly(T, S, p, spv_ref);
+  return wright_spv_anomaly(T, S, p, spv_ref);
+}
+
+/* int_spec_vol_dp_generic_plm, MOM_density_integrals.F90:1479-1726, for layer k (1-based); p has nz+1 planes */
+static void int_spec_vol_dp_generic_plm(const mom6hip_grid_t *G, const mom6hip_eos_t *EOS, int k, const double *T_t, const double *T_b,
+                                        const double *S_t, const double *S_b, const double *p, double alpha_ref, double dP_neglect,
+                                        int massw, double *dza, double *intp_dza, double *intx_dza, double *inty_dza) {
+  const int nz = G->nk;
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const long nH2 = (long)ORC_NIH(G)*ORC_NJH(G);
+  const double C1_90 = 1.0/90.0;
+  double wt_t[6], wt_b[6];
+  for (int n = 1; n <= 5; n++) { wt_t[n] = 0.25 * (double)(n-1); wt_b[n] = 1.0 - wt_t[n]; }      /* reversed from int_density_dz :1549 */
+#define PT(i,j) p[ORC_H2(G,i,j) + nH2*(k-1)]
+#define PB(i,j) p[ORC_H2(G,i,j) + nH2*k]
+#define BP(i,j) p[ORC_H2(G,i,j) + nH2*nz]
+#define Q3(a,i,j) a[ORC_H3(G,i,j,k)]
+  ORC_PAR
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+    double a5[6];
+    for (int n = 1; n <= 5; n++) {
+      const double p5 = wt_t[n] * PT(i,j) + wt_b[n] * PB(i,j);
+      const double S5 = wt_t[n] * Q3(S_t,i,j) + wt_b[n] * Q3(S_b,i,j);
+      const double T5 = wt_t[n] * Q3(T_t,i,j) + wt_b[n] * Q3(T_b,i,j);
+      a5[n] = orc_eos_spec_vol_anomaly(EOS, T5, S5, p5, alpha_ref);
+    }
+    const double dp = PB(i,j) - PT(i,j);
+    const double alpha_anom = C1_90*((7.0*(a5[1]+a5[5]) + 32.0*(a5[2]+a5[4])) + 12.0*a5[3]);
+    dza[ORC_H2(G,i,j)] = dp*alpha_anom;
+    intp_dza[ORC_H2(G,i,j)] = 0.5*(dp*dp) * (alpha_anom - C1_90*(16.0*(a5[4]-a5[2]) + 7.0*(a5[5]-a5[1])));
+  }
+  for (int dir = 0; dir < 2; dir++) {
+    const int j0 = dir ? Jsq : G->jsc, j1 = dir ? Jeq : G->jec, i0 = dir ? G->isc : Isq, i1 = dir ? G->iec : Ieq;
+    ORC_PAR
+    for (int j = j0; j <= j1; j++) for (int i = i0; i <= i1; i++) {
+      const int ir = dir ? i : i+1, jr = dir ? j+1 : j;
+      double hWght = 0.0, hWt_LL, hWt_LR, hWt_RR, hWt_RL;
+      if (massw) hWght = max3(0., BP(i,j)-PT(ir,jr), BP(ir,jr)-PT(i,j));
+      if (hWght > 0.) {
+        const double hL = (PB(i,j) - PT(i,j)) + dP_neglect;
+        const double hR = (PB(ir,jr) - PT(ir,jr)) + dP_neglect;
+        const double rr = (hL-hR)/(hL+hR);
+        hWght = hWght * (rr*rr);
+        const double iDenom = 1.0 / ( hWght*(hR + hL) + hL*hR );
+        hWt_LL = (hWght*hL + hR*hL) * iDenom ; hWt_LR = (hWght*hR) * iDenom;
+        hWt_RR = (hWght*hR + hR*hL) * iDenom ; hWt_RL = (hWght*hL) * iDenom;
+      } else {
+        hWt_LL = 1.0 ; hWt_LR = 0.0 ; hWt_RR = 1.0 ; hWt_RL = 0.0;
+      }
+      double intp[6];
+      intp[1] = dza[ORC_H2(G,i,j)]; intp[5] = dza[ORC_H2(G,ir,jr)];
+      for (int m = 2; m <= 4; m++) {
+        const double wt_L = 0.25*(double)(5-m), wt_R = 1.0-wt_L;
+        const double wtT_L = wt_L*hWt_LL + wt_R*hWt_RL, wtT_R = wt_L*hWt_LR + wt_R*hWt_RR;
+        const double P_top = wt_L*PT(i,j) + wt_R*PT(ir,jr);
+        const double P_bot = wt_L*PB(i,j) + wt_R*PB(ir,jr);
+        const double T_top = wtT_L*Q3(T_t,i,j) + wtT_R*Q3(T_t,ir,jr);
+        const double T_bot = wtT_L*Q3(T_b,i,j) + wtT_R*Q3(T_b,ir,jr);
+        const double S_top = wtT_L*Q3(S_t,i,j) + wtT_R*Q3(S_t,ir,jr);
+        const double S_bot = wtT_L*Q3(S_b,i,j) + wtT_R*Q3(S_b,ir,jr);
+        const double dp_90 = C1_90*(P_bot - P_top);
+        double a15[6];
+        for (int n = 1; n <= 5; n++)
+          a15[n] = orc_eos_spec_vol_anomaly(EOS, wt_t[n] * T_top + wt_b[n] * T_bot, wt_t[n] * S_top + wt_b[n] * S_bot,
+                                            wt_t[n] * P_top + wt_b[n] * P_bot, alpha_ref);
+        intp[m] = dp_90*((7.0*(a15[1]+a15[5]) + 32.0*(a15[2]+a15[4])) + 12.0*a15[3]);
+      }
+      const double v = C1_90*((7.0*(intp[1]+intp[5]) + 32.0*(intp[2]+intp[4])) + 12.0*intp[3]);
+      if (dir) inty_dza[ORC_V2(G,i,j)] = v; else intx_dza[ORC_U2(G,i,j)] = v;
+    }
+  }
+#undef PT
+#undef PB
+#undef BP
+#undef Q3
+}
+
+/* PressureForce_FV_nonBouss, MOM_PressureForce_FV.F90:89-452 (use_EOS, ALE PLM reconstruction, no tides / SAL, GFS_scale = 1,
+ * nkmb = 0) with Set_pbce_nonBouss, MOM_PressureForce_Montgomery.F90:752-861 (the use_EOS branch without alpha_star).
+ * H_to_RZ = GV%H_to_RZ (1 when thicknesses are in kg m-2).  PARITY UNPINNED as the Boussinesq assembly is; the specific-volume
+ * form of UNESCO is checked against the reference's own (oracle/_ref). */
+int orc_pressureforce_fv_nonbouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
+                                  const double *h, const double *T, const double *S, const double *p_atm, double H_to_RZ,
+                                  double *PFu, double *PFv, double *pbce, double *eta)
+{
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const long nH2 = (long)ORC_NIH(G)*ORC_NJH(G), nH3 = nH2*nz;
+  if (!(CS->reconstruct && CS->Recon_Scheme == 1) || CS->GFS_scale != 1.0) return 1;
+  const double H_to_RL2_T2 = G->g_Earth*H_to_RZ;
+  const double dp_neglect = G->g_Earth*H_to_RZ * G->H_subroundoff;
+  const double alpha_ref = 1.0 / CS->Rho0;
+  double *p = calloc(nH2*(nz+1), 8);
+  double *T_t = calloc(nH3, 8), *T_b = calloc(nH3, 8), *S_t = calloc(nH3, 8), *S_b = calloc(nH3, 8);
+  double *dza = calloc(nH3, 8), *intp_dza = calloc(nH3, 8);
+  double *intx_dza = calloc((size_t)(ORC_NIH(G)+1)*ORC_NJH(G)*nz, 8), *inty_dza = calloc((size_t)ORC_NIH(G)*(ORC_NJH(G)+1)*nz, 8);
+  double *za = calloc(nH2, 8), *dp = calloc(nH2, 8);
+  double *intx_za = calloc((size_t)(ORC_NIH(G)+1)*ORC_NJH(G), 8), *inty_za = calloc((size_t)ORC_NIH(G)*(ORC_NJH(G)+1), 8);
+  const long nU2 = (long)(ORC_NIH(G)+1)*ORC_NJH(G), nV2 = (long)ORC_NIH(G)*(ORC_NJH(G)+1);
+#define P3(i,j,K) p[ORC_H2(G,i,j) + nH2*((K)-1)]
+  /* :193-206 */
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) P3(i,j,1) = p_atm ? p_atm[ORC_H2(G,i,j)] : 0.0;
+  for (int j = Jsq; j <= Jeq+1; j++) for (int K = 2; K <= nz+1; K++) for (int i = Isq; i <= Ieq+1; i++)
+    P3(i,j,K) = P3(i,j,K-1) + H_to_RL2_T2 * h[ORC_H3(G,i,j,K-1)];
+  /* :245 TS_PLM_edge_values */
+  orc_ale_plm_edge_values(G, h, S, CS->boundary_extrap, S_t, S_b);
+  orc_ale_plm_edge_values(G, h, T, CS->boundary_extrap, T_t, T_b);
+  /* :255-262 */
+  for (int k = 1; k <= nz; k++)
+    int_spec_vol_dp_generic_plm(G, EOS, k, T_t, T_b, S_t, S_b, p, alpha_ref, dp_neglect, CS->useMassWghtInterp,
+                                dza + nH2*(k-1), intp_dza + nH2*(k-1), intx_dza + nU2*(k-1), inty_dza + nV2*(k-1));
+  /* :299-306: the geopotential anomaly at the sea surface, summed from the bottom */
+  for (int j = Jsq; j <= Jeq+1; j++) {
+    for (int i = Isq; i <= Ieq+1; i++) za[ORC_H2(G,i,j)] = alpha_ref*P3(i,j,nz+1) - G->g_Earth*G->bathyT[ORC_H2(G,i,j)];
+    for (int k = nz; k >= 1; k--) for (int i = Isq; i <= Ieq+1; i++)
+      za[ORC_H2(G,i,j)] = za[ORC_H2(G,i,j)] + dza[ORC_H2(G,i,j) + nH2*(k-1)];
+  }
+  /* :366-371 */
+  for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) intx_za[ORC_U2(G,I,j)] = 0.5*(za[ORC_H2(G,I,j)] + za[ORC_H2(G,I+1,j)]);
+  for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) inty_za[ORC_V2(G,i,J)] = 0.5*(za[ORC_H2(G,i,J)] + za[ORC_H2(G,i,J+1)]);
+  /* :373-410 */
+  for (int k = 1; k <= nz; k++) {
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+      dp[ORC_H2(G,i,j)] = H_to_RL2_T2 * h[ORC_H3(G,i,j,k)];
+      za[ORC_H2(G,i,j)] = za[ORC_H2(G,i,j)] - dza[ORC_H2(G,i,j) + nH2*(k-1)];
+    }
+#define ZA(i,j) za[ORC_H2(G,i,j)]
+#define DP(i,j) dp[ORC_H2(G,i,j)]
+#define IPD(i,j) intp_dza[ORC_H2(G,i,j) + nH2*(k-1)]
+    ORC_PAR
+    for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
+      const int i = I;
+      intx_za[ORC_U2(G,I,j)] = intx_za[ORC_U2(G,I,j)] - intx_dza[ORC_U2(G,I,j) + nU2*(k-1)];
+      PFu[ORC_U3(G,I,j,k)] = ( ((ZA(i,j)*DP(i,j) + IPD(i,j)) - (ZA(i+1,j)*DP(i+1,j) + IPD(i+1,j))) +
+                               ((DP(i+1,j) - DP(i,j)) * intx_za[ORC_U2(G,I,j)] -
+                                (P3(i+1,j,k) - P3(i,j,k)) * intx_dza[ORC_U2(G,I,j) + nU2*(k-1)]) ) *
+                             (2.0*G->IdxCu[ORC_U2(G,I,j)] / ((DP(i,j) + DP(i+1,j)) + dp_neglect));
+    }
+    ORC_PAR
+    for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) {
+      const int j = J;
+      inty_za[ORC_V2(G,i,J)] = inty_za[ORC_V2(G,i,J)] - inty_dza[ORC_V2(G,i,J) + nV2*(k-1)];
+      PFv[ORC_V3(G,i,J,k)] = (((ZA(i,j)*DP(i,j) + IPD(i,j)) - (ZA(i,j+1)*DP(i,j+1) + IPD(i,j+1))) +
+                              ((DP(i,j+1) - DP(i,j)) * inty_za[ORC_V2(G,i,J)] -
+                               (P3(i,j+1,k) - P3(i,j,k)) * inty_dza[ORC_V2(G,i,J) + nV2*(k-1)])) *
+                             (2.0*G->IdyCv[ORC_V2(G,i,J)] / ((DP(i,j) + DP(i,j+1)) + dp_neglect));
+    }
+#undef ZA
+#undef DP
+#undef IPD
+  }
+  /* Set_pbce_nonBouss :794-831 */
+  if (pbce) {
+    const double dP_dH = G->g_Earth * H_to_RZ;
+    ORC_PAR
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+      const long n2 = ORC_H2(G,i,j);
+      const double C_htot = dP_dH / ((P3(i,j,nz+1)-P3(i,j,1)) + dp_neglect);
+      double pb = dP_dH / orc_eos_density(EOS, T[ORC_H3(G,i,j,nz)], S[ORC_H3(G,i,j,nz)], P3(i,j,nz+1));
+      pbce[n2 + nH2*(nz-1)] = pb;
+      for (int k = nz-1; k >= 1; k--) {
+        const double Tk = T[ORC_H3(G,i,j,k)], Tk1 = T[ORC_H3(G,i,j,k+1)], Sk = S[ORC_H3(G,i,j,k)], Sk1 = S[ORC_H3(G,i,j,k+1)];
+        const double T_int = 0.5*(Tk+Tk1), S_int = 0.5*(Sk+Sk1);
+        const double rho = orc_eos_density(EOS, T_int, S_int, P3(i,j,k+1));
+        double dR_dT, dR_dS;
+        orc_eos_density_derivs(EOS, T_int, S_int, P3(i,j,k+1), &dR_dT, &dR_dS);
+        pb = pb + ((P3(i,j,k+1)-P3(i,j,1))*C_htot) * ((dR_dT*(Tk1-Tk) + dR_dS*(Sk1-Sk)) / (rho*rho));
+        pbce[n2 + nH2*(k-1)] = pb;
+      }
+    }
+  }
+  /* :417-428 */
+  if (eta) {
+    const double Pa_to_H = 1.0 / (G->g_Earth * H_to_RZ);
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+      eta[ORC_H2(G,i,j)] = p_atm ? (P3(i,j,nz+1) - p_atm[ORC_H2(G,i,j)])*Pa_to_H : P3(i,j,nz+1)*Pa_to_H;
+  }
+#undef P3
+  free(p); free(T_t); free(T_b); free(S_t); free(S_b); free(dza); free(intp_dza); free(intx_dza); free(inty_dza); free(za); free(dp);
+  free(intx_za); free(inty_za);
+  return 0;
+}

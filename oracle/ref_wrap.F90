@@ -90,6 +90,16 @@ subroutine ref_unesco(n, T, S, p, rho_ref, use_ref, rho, drho_dT, drho_dS) bind(
   call E%calculate_density_derivs_array(T, S, p, drho_dT, drho_dS, 1, n)
 end subroutine ref_unesco
 
+!> calculate_spec_vol_array with spv_ref (MOM_EOS_base_type.F90:291) of the reference's UNESCO_EOS
+subroutine ref_unesco_spv(n, T, S, p, spv_ref, spv) bind(c, name="ref_unesco_spv")
+  integer(c_int), value :: n
+  real(c_double), intent(in) :: T(n), S(n), p(n)
+  real(c_double), value :: spv_ref
+  real(c_double), intent(inout) :: spv(n)
+  type(UNESCO_EOS) :: E
+  call E%calculate_spec_vol_array(T, S, p, spv, 1, n, spv_ref=spv_ref)
+end subroutine ref_unesco_spv
+
 !> PLM_reconstruction of ncol columns of n layers (timing the reference's code against the restatement: tools/calibrate_ref.py)
 subroutine ref_plm_batch(ncol, n, h, u, E, coef, h_neglect) bind(c, name="ref_plm_batch")
   integer(c_int), value :: ncol, n

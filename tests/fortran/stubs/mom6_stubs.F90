@@ -155,6 +155,7 @@ type :: verticalGrid_type
   integer :: ke
   real :: Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
           Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0
+  integer :: nk_rho_varies = 0
   logical :: Boussinesq = .true.
   real, allocatable :: Rlay(:), g_prime(:)
 end type verticalGrid_type

@@ -58,6 +58,54 @@ def test_unesco_matches_reference_build(oracle):
     assert abs(rho[0] + 1035.0 - 1027.54345796120) < 1000 * EPS * 1027.5
 
 
+def test_spec_vol_forms(oracle):
+    """calculate_spec_vol with spv_ref: the reciprocal of the density of the same form (to roundoff), and for UNESCO the
+    reference's own function bit for bit (oracle/_ref)"""
+    rng = np.random.default_rng(6)
+    n = 4000
+    T = rng.uniform(-2.0, 32.0, n); S = rng.uniform(0.0, 40.0, n); p = rng.uniform(0.0, 6.0e7, n)
+    spv_ref = 1.0 / 1035.0
+    for form in ("WRIGHT", "UNESCO", "LINEAR"):
+        E = oracle.eos(form)
+        a = np.array([oracle.eos_spec_vol_anomaly(E, T[m], S[m], p[m], spv_ref) for m in range(n)])
+        rho = np.array([oracle.eos_density(E, T[m], S[m], p[m]) for m in range(n)])
+        assert np.max(np.abs((a + spv_ref) * rho - 1.0)) < 1e-13, form
+    R = oracle.ref_lib()
+    if R is not None and hasattr(R, "ref_unesco_spv"):
+        P = lambda x: x.ctypes.data_as(oracle._dp)
+        want = np.empty(n)
+        R.ref_unesco_spv(n, P(T), P(S), P(p), spv_ref, P(want))
+        E = oracle.eos("UNESCO")
+        mine = np.array([oracle.eos_spec_vol_anomaly(E, T[m], S[m], p[m], spv_ref) for m in range(n)])
+        assert bits_equal(mine, want)
+
+
+def test_nonbouss_pressure_force_tracks_the_boussinesq_one(oracle):
+    """PressureForce_FV_nonBouss on the same ocean expressed in mass per unit area: the two forms of the same physics differ by
+    the Boussinesq error (a percent), not more; a resting stratified ocean feels no force in either"""
+    g, st = pgf_case(40, 26, 8, seed=5)
+    E = oracle.eos("WRIGHT")
+    cs = oracle.pressureforce_cs(g)
+    B = oracle.pressureforce(g, cs, E, st["h"], st["T"], st["S"])
+    N = oracle.pressureforce_nonbouss(g, cs, E, st["h"] * g.Rho0, st["T"], st["S"], H_to_RZ=1.0)
+    for q, pos, mk in ((0, _abi.POS_U, g.mask2dCu), (1, _abi.POS_V, g.mask2dCv)):
+        m = interior(g, mk, pos) > 0
+        a = interior(g, B[q], pos)[:, m]; b = interior(g, N[q], pos)[:, m]
+        assert np.sqrt(((a - b) ** 2).mean()) < 0.03 * np.sqrt((a ** 2).mean())
+    # eta of the non-Boussinesq form is the column mass per unit area
+    assert np.allclose(interior(g, N[3]), interior(g, (st["h"] * g.Rho0).sum(0)), rtol=1e-13)
+    assert np.all(interior(g, N[2]) > 0)
+    # at rest
+    g2 = synth.make_grid(20, 16, 5, seed=1, land_frac=0.0, max_depth=4000.0)
+    g2.set_metric("bathyT", np.full_like(g2.bathyT, 4000.0))
+    shp = g2.shape3(_abi.POS_H)
+    h = np.empty(shp); T = np.empty(shp); S = np.empty(shp)
+    for k, dz in enumerate([50.0, 150.0, 800.0, 1000.0, 2000.0]):
+        h[k] = dz * 1035.0; T[k] = 20.0 - 4.0 * k; S[k] = 34.0 + 0.2 * k
+    PFu, PFv, _, _ = oracle.pressureforce_nonbouss(g2, oracle.pressureforce_cs(g2), E, h, T, S)
+    assert np.max(np.abs(interior(g2, PFu, _abi.POS_U))) < 1e-11 and np.max(np.abs(interior(g2, PFv, _abi.POS_V))) < 1e-11
+
+
 def pgf_case(ni=30, nj=22, nk=6, seed=3, **kw):
     g = synth.make_grid(ni, nj, nk, seed=seed + 10, **kw)
     st = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed).items()}
@@ -126,4 +174,38 @@ def test_gpu_parity(oracle, form, opts):
                 for name, a, b in (("PFu", ref[0], PFu), ("PFv", ref[1], PFv), ("pbce", ref[2], pbce), ("eta", ref[3], eta)):
                     assert bits_equal(a, N(b)), (form, opts, (ni, nj, nk), p_atm is not None, resident, name,
                                                  np.argwhere(a != N(b))[:3])
+            dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR"])
+@pytest.mark.parametrize("opts", [(True, False), (False, True)])
+def test_gpu_parity_nonbouss(oracle, form, opts):
+    """PressureForce_FV_nonBouss: library == oracle, bit for bit"""
+    import torch
+    from mom6_amd.pressure_force import PressureForce, PressureForce_init, EOS_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    extrap, massw = opts
+    for (ni, nj, nk, topo) in [(70, 21, 5, (True, False)), (44, 40, 2, (True, True)), (10, 8, 8, (False, False)), (130, 9, 75, (True, False))]:
+        g, st = pgf_case(ni, nj, nk, seed=ni, reentrant_x=topo[0], reentrant_y=topo[1])
+        hm = np.ascontiguousarray(st["h"] * g.Rho0)
+        E = oracle.eos(form, 1000.0, -0.2, 0.8)
+        cs = oracle.pressureforce_cs(g, boundary_extrap=extrap, useMassWghtInterp=massw)
+        rng = np.random.default_rng(ni)
+        for p_atm in (None, np.ascontiguousarray(1.0e5 + 500.0 * rng.standard_normal(g.shape2(_abi.POS_H)))):
+            ref = oracle.pressureforce_nonbouss(g, cs, E, hm, st["T"], st["S"], p_atm)
+            dg = DeviceGrid(g)
+            CS = PressureForce_init(g, boundary_extrap=extrap, useMassWghtInterp=massw)
+            EOS = EOS_init(form, 1000.0, -0.2, 0.8)
+            for resident in (False, True):
+                X = (lambda a: None if a is None else torch.from_numpy(a.copy()).cuda()) if resident else \
+                    (lambda a: None if a is None else a.copy())
+                PFu, PFv = X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V))
+                pbce, eta = X(g.zeros3(_abi.POS_H)), X(g.zeros2(_abi.POS_H))
+                PressureForce(X(hm), (X(st["T"]), X(st["S"]), EOS), PFu, PFv, dg, CS, p_atm=X(p_atm), pbce=pbce, eta=eta, Boussinesq=False,
+                              H_to_RZ=1.0)
+                dg.sync()
+                N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+                for name, a, b in (("PFu", ref[0], PFu), ("PFv", ref[1], PFv), ("pbce", ref[2], pbce), ("eta", ref[3], eta)):
+                    assert bits_equal(a, N(b)), (form, opts, (ni, nj, nk), p_atm is not None, resident, name, np.argwhere(a != N(b))[:3])
             dg.close()

@@ -176,3 +176,45 @@ def test_gpu_tracers_across_the_fold_match_oracle():
     for m in range(2):
         assert bits_equal(tr[m].cpu().numpy(), ref[m]), m
     dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rk2b", [False, True], ids=["RK2", "RK2B"])
+def test_gpu_folded_run_is_the_unfolded_run_at_benchmark_size(rk2b):
+    """BASELINE configs[2]'s shape, 360 x 180 x 75, as the UNFOLDED image of a 360 x 90 x 75 tripolar grid: two viscous steps of the
+    library on both (multi-block launches, the hipGraph of the barotropic subcycle, ~20 barotropic steps) agree bit for bit on
+    the folded half -- the geometry of the fold at a size the oracle is not needed for."""
+    import torch
+    from mom6_amd import dynamics_split_rk2 as M
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    g, g2 = tp.grids(ni=360, nj=90, nk=75)
+    d, d2, tau, tau2 = tp.states(g, g2)
+    dt = 3600.0
+    init, step = (M.initialize_dyn_split_RK2b, M.step_MOM_dyn_split_RK2b) if rk2b else (M.initialize_dyn_split_RK2, M.step_MOM_dyn_split_RK2)
+    res = []
+    for gg, dd, tt in ((g, d, tau), (g2, d2, tau2)):
+        dg = DeviceGrid(gg)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        u, v, h, Tt, Ss = (T(dd[k]) for k in ("u", "v", "h", "T", "S"))
+        Z = lambda pos, k3=True: torch.zeros(gg.shape3(pos) if k3 else gg.shape2(pos), dtype=torch.float64, device="cuda")
+        uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+        visc = vertvisc_type(Kv_bbl_u=T(1.0e-3 * gg.mask2dCu), Kv_bbl_v=T(1.0e-3 * gg.mask2dCv), bbl_thick_u=T(5.0 * gg.mask2dCu),
+                             bbl_thick_v=T(5.0 * gg.mask2dCv))
+        CS = init(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0),
+                  hor_visc=dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL_SCALE=0.01))
+        tx, ty = T(tt[0]), T(tt[1])
+        for n in range(2):
+            step(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        res.append(dict(u=u.cpu().numpy(), v=v.cpu().numpy(), h=h.cpu().numpy(), uhtr=uhtr.cpu().numpy(), eta=CS.eta.cpu().numpy(),
+                        nstep=int(CS.barotropic_CSp.st.nstep_last), dtbt=float(CS.barotropic_CSp.st.dtbt)))
+        dg.close()
+        del u, v, h, Tt, Ss, uh, vh, uhtr, vhtr, CS, visc
+        torch.cuda.empty_cache()
+    a, b = res
+    assert a["nstep"] == b["nstep"] and a["dtbt"] == b["dtbt"] and a["nstep"] >= 10, (a["nstep"], b["nstep"])
+    for n, pos in (("h", H), ("u", U), ("v", V), ("uhtr", U), ("eta", H)):
+        x = np.ascontiguousarray(interior(g, a[n], pos)); y = np.ascontiguousarray(interior(g, tp.folded(g, b[n], pos), pos))
+        assert bits_equal(x, y), (n, float(np.abs(x - y).max()), np.argwhere(x != y)[:3])
+    assert np.isfinite(a["u"]).all() and np.abs(a["u"]).max() > 1e-3
