@@ -464,7 +464,9 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 /* EQN_OF_STATE forms provided (src/equation_of_state/MOM_EOS.F90:145-173; default "WRIGHT") */
 #define MOM6HIP_EOS_LINEAR 1   /* MOM_EOS_linear.F90 */
 #define MOM6HIP_EOS_UNESCO 2   /* MOM_EOS_UNESCO.F90 (Jackett & McDougall 1995) */
-#define MOM6HIP_EOS_WRIGHT 3   /* MOM_EOS_Wright.F90 (the "WRIGHT" form; density is identical to WRIGHT_REDUCED) */
+#define MOM6HIP_EOS_WRIGHT 3   /* MOM_EOS_Wright.F90 (the "WRIGHT" form; its density agrees with WRIGHT_REDUCED to roundoff) */
+#define MOM6HIP_EOS_WRIGHT_FULL 4      /* MOM_EOS_Wright_full.F90 */
+#define MOM6HIP_EOS_WRIGHT_REDUCED 5   /* MOM_EOS_Wright_red.F90 */
 
 typedef struct mom6hip_eos {
   int32_t form;                /* MOM6HIP_EOS_* */

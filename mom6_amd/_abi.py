@@ -90,7 +90,7 @@ class BTCont(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BT_CONT_U + BT_CONT_V + ("h_u", "h_v")]
 
 
-EOS_FORMS = {"LINEAR": 1, "UNESCO": 2, "WRIGHT": 3}
+EOS_FORMS = {"LINEAR": 1, "UNESCO": 2, "JACKETT_MCD": 2, "WRIGHT": 3, "WRIGHT_FULL": 4, "WRIGHT_REDUCED": 5}
 
 
 class EOS(C.Structure):

@@ -81,10 +81,51 @@ __device__ __forceinline__ void density_derivs(double T, double S, double pressu
 }
 }  // namespace unesco
 
+// WRIGHT_FULL and WRIGHT_REDUCED (MOM_EOS_Wright_full.F90, MOM_EOS_Wright_red.F90: one code, two sets of coefficients)
+struct WrightCoefs { double a0, a1, a2, b0, b1, b2, b3, b4, b5, c0, c1, c2, c3, c4, c5; };
+__device__ __forceinline__ WrightCoefs wright_coefs(int form) {
+  if (form == MOM6HIP_EOS_WRIGHT_FULL) return WrightCoefs{7.133718e-4, 2.724670e-7, -1.646582e-7, 5.613770e8, 3.600337e6, -3.727194e4, 1.660557e2, 6.844158e5, -8.389457e3, 1.609893e5, 8.427815e2, -6.931554, 3.869318e-2, -1.664201e2, -2.765195};
+  return WrightCoefs{7.057924e-4, 3.480336e-7, -1.112733e-7, 5.790749e8, 3.516535e6, -4.002714e4, 2.084372e2, 5.944068e5, -9.643486e3, 1.704853e5, 7.904722e2, -7.984422, 5.140652e-2, -2.302158e2, -3.079464};
+}
+__device__ __forceinline__ double wrightx_density(const WrightCoefs W, double T, double S, double pressure) {      // :73-89
+  const double al0 = W.a0 + (W.a1*T + W.a2*S);
+  const double p0 = W.b0 + ( W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)) );
+  const double lambda = W.c0 + ( W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S)) );
+  return (pressure + p0) / (lambda + al0*(pressure + p0));
+}
+__device__ __forceinline__ double wrightx_density_anomaly(const WrightCoefs W, double T, double S, double pressure, double rho_ref) {      // :94-119
+  const double pa_000 = W.b0*(1.0 - W.a0*rho_ref) - rho_ref*W.c0;
+  const double al_TS = W.a1*T + W.a2*S;
+  const double al0 = W.a0 + al_TS;
+  const double p_TSp = pressure + (W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)));
+  const double lam_TS = W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S));
+  return (pa_000 + (p_TSp - rho_ref*(p_TSp*al0 + (W.b0*al_TS + lam_TS)))) / ( (W.c0 + lam_TS) + al0*(W.b0 + p_TSp) );
+}
+__device__ __forceinline__ double wrightx_spv_anomaly(const WrightCoefs W, double T, double S, double pressure, double spv_ref) {      // :150-170
+  const double lam_000 = W.c0 + (W.a0 - spv_ref)*W.b0;
+  const double al_TS = W.a1*T + W.a2*S;
+  const double p_TSp = pressure + (W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)));
+  const double lambda = lam_000 + ( W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S)) );
+  return al_TS + (lambda + (W.a0 - spv_ref)*p_TSp) / (W.b0 + p_TSp);
+}
+__device__ __forceinline__ void wrightx_density_derivs(const WrightCoefs W, double T, double S, double pressure, double &DT, double &DS) {      // :175-200
+  const double al0 = W.a0 + (W.a1*T + W.a2*S);
+  const double p0 = W.b0 + ( W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)) );
+  const double lambda = W.c0 + ( W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S)) );
+  const double den = (lambda + al0*(pressure + p0));
+  const double I_denom2 = 1.0 / (den*den);
+  DT = I_denom2 * (lambda * (W.b1 + (T*(2.0*W.b2 + 3.0*W.b3*T) + W.b5*S)) -
+     (pressure+p0) * ( (pressure+p0)*W.a1 + (W.c1 + (T*(W.c2*2.0 + W.c3*3.0*T) + W.c5*S)) ));
+  DS = I_denom2 * (lambda * (W.b4 + W.b5*T) -
+     (pressure+p0) * ( (pressure+p0)*W.a2 + (W.c4 + W.c5*T) ));
+}
+__device__ __forceinline__ bool is_wrightx(int form) { return form == MOM6HIP_EOS_WRIGHT_FULL || form == MOM6HIP_EOS_WRIGHT_REDUCED; }
+
 // density_elem :80-95
 __device__ __forceinline__ double eos_density(const EosDev &E, double T, double S, double pressure) {
   if (E.form == MOM6HIP_EOS_LINEAR) return E.Rho_T0_S0 + E.dRho_dT * T + E.dRho_dS * S;
   if (E.form == MOM6HIP_EOS_UNESCO) return unesco::density(T, S, pressure);
+  if (is_wrightx(E.form)) return wrightx_density(wright_coefs(E.form), T, S, pressure);
   const double al0 = (a0 + a1 * T) + a2 * S;
   const double p0 = (b0 + b4 * S) + T * (b1 + T * (b2 + b3 * T) + b5 * S);
   const double lambda = (c0 + c4 * S) + T * (c1 + T * (c2 + c3 * T) + c5 * S);
@@ -95,6 +136,7 @@ __device__ __forceinline__ double eos_density(const EosDev &E, double T, double 
 __device__ __forceinline__ double eos_density_anomaly(const EosDev &E, double T, double S, double pressure, double rho_ref) {
   if (E.form == MOM6HIP_EOS_LINEAR) return (E.Rho_T0_S0 - rho_ref) + (E.dRho_dT * T + E.dRho_dS * S);
   if (E.form == MOM6HIP_EOS_UNESCO) return unesco::density_anomaly(T, S, pressure, rho_ref);
+  if (is_wrightx(E.form)) return wrightx_density_anomaly(wright_coefs(E.form), T, S, pressure, rho_ref);
   const double pa_000 = (b0 * (1.0 - a0 * rho_ref) - rho_ref * c0);
   const double al_TS = a1 * T + a2 * S;
   const double al0 = a0 + al_TS;
@@ -108,6 +150,7 @@ __device__ __forceinline__ void eos_density_derivs(const EosDev &E, double T, do
                                                    double &drho_dS) {
   if (E.form == MOM6HIP_EOS_LINEAR) { drho_dT = E.dRho_dT; drho_dS = E.dRho_dS; return; }
   if (E.form == MOM6HIP_EOS_UNESCO) { unesco::density_derivs(T, S, pressure, drho_dT, drho_dS); return; }
+  if (is_wrightx(E.form)) { wrightx_density_derivs(wright_coefs(E.form), T, S, pressure, drho_dT, drho_dS); return; }
   const double al0 = (a0 + a1 * T) + a2 * S;
   const double p0 = (b0 + b4 * S) + T * (b1 + T * ((b2 + b3 * T)) + b5 * S);
   const double lambda = (c0 + c4 * S) + T * (c1 + T * ((c2 + c3 * T)) + c5 * S);
@@ -123,6 +166,7 @@ __device__ __forceinline__ void eos_density_derivs(const EosDev &E, double T, do
 __device__ __forceinline__ double eos_spec_vol_anomaly(const EosDev &E, double T, double S, double pressure, double spv_ref) {
   if (E.form == MOM6HIP_EOS_LINEAR)
     return ((1.0 - E.Rho_T0_S0*spv_ref) - spv_ref*(E.dRho_dT*T + E.dRho_dS*S)) / (E.Rho_T0_S0 + (E.dRho_dT*T + E.dRho_dS*S));
+  if (is_wrightx(E.form)) return wrightx_spv_anomaly(wright_coefs(E.form), T, S, pressure, spv_ref);
   if (E.form == MOM6HIP_EOS_UNESCO) {
     using namespace unesco;
     const double p1 = pressure*1.0e-5, t1 = T;

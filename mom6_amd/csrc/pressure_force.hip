@@ -509,8 +509,9 @@ __global__ void eos_density_kernel(EosDev E, const double *T, const double *S, c
 
 int check_eos(const mom6hip_eos_t *eos) {
   M6_REQUIRE(eos != nullptr, "MOM_EOS: the equation of state must be initialized (EOS_init) before it is used");
-  M6_REQUIRE(eos->form == MOM6HIP_EOS_WRIGHT || eos->form == MOM6HIP_EOS_LINEAR || eos->form == MOM6HIP_EOS_UNESCO,
-             "MOM_EOS: EQN_OF_STATE form %d is not provided by libmom6hip (WRIGHT, UNESCO, LINEAR)", eos->form);
+  M6_REQUIRE(eos->form == MOM6HIP_EOS_WRIGHT || eos->form == MOM6HIP_EOS_LINEAR || eos->form == MOM6HIP_EOS_UNESCO ||
+                 eos->form == MOM6HIP_EOS_WRIGHT_FULL || eos->form == MOM6HIP_EOS_WRIGHT_REDUCED,
+             "MOM_EOS: EQN_OF_STATE form %d is not provided by libmom6hip (WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, LINEAR)", eos->form);
   return 0;
 }
 

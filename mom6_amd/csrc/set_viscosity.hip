@@ -319,7 +319,8 @@ extern "C" int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_vis
   const bool use_EOS = (eos != nullptr) && cs->BBL_use_EOS;
   M6_REQUIRE(!use_EOS || (T && S), "set_viscous_BBL: BBL_USE_EOS needs tv%%T and tv%%S");
   M6_REQUIRE(use_EOS || cs->Rlay, "set_viscous_BBL: GV%%Rlay is required without BBL_USE_EOS");
-  M6_REQUIRE(!eos || eos->form == MOM6HIP_EOS_LINEAR || eos->form == MOM6HIP_EOS_WRIGHT || eos->form == MOM6HIP_EOS_UNESCO,
+  M6_REQUIRE(!eos || eos->form == MOM6HIP_EOS_LINEAR || eos->form == MOM6HIP_EOS_WRIGHT || eos->form == MOM6HIP_EOS_UNESCO ||
+                 eos->form == MOM6HIP_EOS_WRIGHT_FULL || eos->form == MOM6HIP_EOS_WRIGHT_REDUCED,
              "set_viscous_BBL: this equation of state is not provided");
   M6_REQUIRE(visc->bbl_thick_u && visc->bbl_thick_v, "set_viscous_BBL: visc%%bbl_thick_u and visc%%bbl_thick_v are required");
   M6_REQUIRE(!cs->body_force_drag || (visc->Ray_u && visc->Ray_v), "set_viscous_BBL: DRAG_AS_BODY_FORCE needs visc%%Ray_u and visc%%Ray_v");

@@ -172,11 +172,15 @@ subroutine PressureForce_FV_init(Time, G, GV, US, param_file, diag, CS, SAL_CSp,
       call get_param(param_file, "MOM_EOS", "DRHO_DS", CS%eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
     case ("WRIGHT")
       CS%eos%form = MOM6HIP_EOS_WRIGHT
-    case ("UNESCO")
+    case ("UNESCO", "JACKETT_MCD")
       CS%eos%form = MOM6HIP_EOS_UNESCO
+    case ("WRIGHT_FULL")
+      CS%eos%form = MOM6HIP_EOS_WRIGHT_FULL
+    case ("WRIGHT_REDUCED")
+      CS%eos%form = MOM6HIP_EOS_WRIGHT_REDUCED
     case default
       call MOM_error(FATAL, "PressureForce_FV_init (HIP): EQN_OF_STATE "//trim(tmpstr)//" is not provided by the GPU path "// &
-                            "(WRIGHT, UNESCO, LINEAR).")
+                            "(WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, LINEAR).")
   end select
   call mom6hip_read_topology(param_file)
 contains

@@ -200,8 +200,12 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
         call get_param(param_file, "MOM_EOS", "DRHO_DS", CS%eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
       case ("WRIGHT")
         CS%eos%form = MOM6HIP_EOS_WRIGHT
-      case ("UNESCO")
+      case ("UNESCO", "JACKETT_MCD")
         CS%eos%form = MOM6HIP_EOS_UNESCO
+      case ("WRIGHT_FULL")
+        CS%eos%form = MOM6HIP_EOS_WRIGHT_FULL
+      case ("WRIGHT_REDUCED")
+        CS%eos%form = MOM6HIP_EOS_WRIGHT_REDUCED
       case default
         call refuse(.true., "EQN_OF_STATE "//trim(tmpstr))
     end select

@@ -12,7 +12,8 @@ integer(c_int32_t), parameter :: MOM6HIP_MEM_HOST = 0, MOM6HIP_MEM_DEVICE = 1
 integer(c_int32_t), parameter :: MOM6HIP_ADV_PLM = 0, MOM6HIP_ADV_PPM_H3 = 1, MOM6HIP_ADV_PPM = 2
 integer(c_int32_t), parameter :: MOM6HIP_POS_H = 0, MOM6HIP_POS_U = 1, MOM6HIP_POS_V = 2, MOM6HIP_POS_Q = 3
 integer(c_int32_t), parameter :: MOM6HIP_PASS_SCALAR_PAIR = 8   !< ORed into the position of a u/v member of a SCALAR_PAIR in a group pass
-integer(c_int32_t), parameter :: MOM6HIP_EOS_LINEAR = 1, MOM6HIP_EOS_UNESCO = 2, MOM6HIP_EOS_WRIGHT = 3
+integer(c_int32_t), parameter :: MOM6HIP_EOS_LINEAR = 1, MOM6HIP_EOS_UNESCO = 2, MOM6HIP_EOS_WRIGHT = 3, &
+                                 MOM6HIP_EOS_WRIGHT_FULL = 4, MOM6HIP_EOS_WRIGHT_REDUCED = 5
 !> REMAPPING_* of src/ALE/MOM_remapping.F90:51-59 and REGRIDDING_ZSTAR of regrid_consts.F90:14
 integer(c_int32_t), parameter :: MOM6HIP_REMAP_PCM = 0, MOM6HIP_REMAP_PLM = 2, MOM6HIP_REMAP_PPM_H4 = 4, MOM6HIP_REMAP_PPM_IH4 = 5, &
                                  MOM6HIP_REMAP_PPM_CW = 10, MOM6HIP_REMAP_PLM_HYBGEN = 3, MOM6HIP_REMAP_PPM_HYBGEN = 6, &

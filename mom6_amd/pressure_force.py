@@ -14,7 +14,7 @@ def EOS_init(form="WRIGHT", Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.8):
     """EOS_init (MOM_EOS.F90): EQN_OF_STATE and, for LINEAR, RHO_T0_S0 / DRHO_DT / DRHO_DS."""
     if form not in _abi.EOS_FORMS:
         raise Mom6HipError("interpret_eos_selection: EQN_OF_STATE " + str(form) + " is not provided by libmom6hip "
-                           "(WRIGHT, UNESCO, LINEAR)")
+                           "(WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, LINEAR)")
     return _abi.EOS(_abi.EOS_FORMS[form], 0, float(Rho_T0_S0), float(dRho_dT), float(dRho_dS))
 
 

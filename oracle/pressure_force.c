@@ -132,20 +132,66 @@ static void unesco_density_derivs(double T, double S, double pressure, double *d
   *drho_dS = (ks*drho0_dS - dks_dS*((rho0*p1)*I_denom)) * I_denom;
 }
 
+/* ---- WRIGHT_FULL and WRIGHT_REDUCED (MOM_EOS_Wright_full.F90, MOM_EOS_Wright_red.F90: one code, two sets of coefficients
+ * :21-36; density :73-89, anomaly :94-119, spec_vol_anomaly :150-170, derivatives :175-200); check values MOM_EOS.F90:1923-1932 */
+typedef struct { double a0, a1, a2, b0, b1, b2, b3, b4, b5, c0, c1, c2, c3, c4, c5; } wright_coefs_t;
+static const wright_coefs_t W_FULL = {7.133718e-4, 2.724670e-7, -1.646582e-7, 5.613770e8, 3.600337e6, -3.727194e4, 1.660557e2, 6.844158e5, -8.389457e3, 1.609893e5, 8.427815e2, -6.931554, 3.869318e-2, -1.664201e2, -2.765195};
+static const wright_coefs_t W_RED = {7.057924e-4, 3.480336e-7, -1.112733e-7, 5.790749e8, 3.516535e6, -4.002714e4, 2.084372e2, 5.944068e5, -9.643486e3, 1.704853e5, 7.904722e2, -7.984422, 5.140652e-2, -2.302158e2, -3.079464};
+static double wrightx_density(const wright_coefs_t W, double T, double S, double pressure) {
+  const double al0 = W.a0 + (W.a1*T + W.a2*S);
+  const double p0 = W.b0 + ( W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)) );
+  const double lambda = W.c0 + ( W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S)) );
+  return (pressure + p0) / (lambda + al0*(pressure + p0));
+}
+static double wrightx_density_anomaly(const wright_coefs_t W, double T, double S, double pressure, double rho_ref) {
+  const double pa_000 = W.b0*(1.0 - W.a0*rho_ref) - rho_ref*W.c0;
+  const double al_TS = W.a1*T + W.a2*S;
+  const double al0 = W.a0 + al_TS;
+  const double p_TSp = pressure + (W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)));
+  const double lam_TS = W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S));
+  return (pa_000 + (p_TSp - rho_ref*(p_TSp*al0 + (W.b0*al_TS + lam_TS)))) / ( (W.c0 + lam_TS) + al0*(W.b0 + p_TSp) );
+}
+static double wrightx_spv_anomaly(const wright_coefs_t W, double T, double S, double pressure, double spv_ref) {
+  const double lam_000 = W.c0 + (W.a0 - spv_ref)*W.b0;
+  const double al_TS = W.a1*T + W.a2*S;
+  const double p_TSp = pressure + (W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)));
+  const double lambda = lam_000 + ( W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S)) );
+  return al_TS + (lambda + (W.a0 - spv_ref)*p_TSp) / (W.b0 + p_TSp);
+}
+static void wrightx_density_derivs(const wright_coefs_t W, double T, double S, double pressure, double *pDT, double *pDS) {
+  double DT, DS;
+  const double al0 = W.a0 + (W.a1*T + W.a2*S);
+  const double p0 = W.b0 + ( W.b4*S + T * (W.b1 + (T*(W.b2 + W.b3*T) + W.b5*S)) );
+  const double lambda = W.c0 + ( W.c4*S + T * (W.c1 + (T*(W.c2 + W.c3*T) + W.c5*S)) );
+  const double den = (lambda + al0*(pressure + p0));
+  const double I_denom2 = 1.0 / (den*den);
+  DT = I_denom2 * (lambda * (W.b1 + (T*(2.0*W.b2 + 3.0*W.b3*T) + W.b5*S)) -
+     (pressure+p0) * ( (pressure+p0)*W.a1 + (W.c1 + (T*(W.c2*2.0 + W.c3*3.0*T) + W.c5*S)) ));
+  DS = I_denom2 * (lambda * (W.b4 + W.b5*T) -
+     (pressure+p0) * ( (pressure+p0)*W.a2 + (W.c4 + W.c5*T) ));
+  *pDT = DT; *pDS = DS;
+}
+
 /* calculate_density (no rho_ref) / with rho_ref / derivs for the EOS forms provided */
 double orc_eos_density(const mom6hip_eos_t *E, double T, double S, double p) {
   if (E->form == MOM6HIP_EOS_LINEAR) return E->Rho_T0_S0 + E->dRho_dT*T + E->dRho_dS*S;
   if (E->form == MOM6HIP_EOS_UNESCO) return unesco_density(T, S, p);
+  if (E->form == MOM6HIP_EOS_WRIGHT_FULL) return wrightx_density(W_FULL, T, S, p);
+  if (E->form == MOM6HIP_EOS_WRIGHT_REDUCED) return wrightx_density(W_RED, T, S, p);
   return wright_density(T, S, p);
 }
 double orc_eos_density_anomaly(const mom6hip_eos_t *E, double T, double S, double p, double rho_ref) {
   if (E->form == MOM6HIP_EOS_LINEAR) return (E->Rho_T0_S0 - rho_ref) + (E->dRho_dT*T + E->dRho_dS*S);
   if (E->form == MOM6HIP_EOS_UNESCO) return unesco_density_anomaly(T, S, p, rho_ref);
+  if (E->form == MOM6HIP_EOS_WRIGHT_FULL) return wrightx_density_anomaly(W_FULL, T, S, p, rho_ref);
+  if (E->form == MOM6HIP_EOS_WRIGHT_REDUCED) return wrightx_density_anomaly(W_RED, T, S, p, rho_ref);
   return wright_density_anomaly(T, S, p, rho_ref);
 }
 void orc_eos_density_derivs(const mom6hip_eos_t *E, double T, double S, double p, double *dT, double *dS) {
   if (E->form == MOM6HIP_EOS_LINEAR) { *dT = E->dRho_dT; *dS = E->dRho_dS; return; }
   if (E->form == MOM6HIP_EOS_UNESCO) { unesco_density_derivs(T, S, p, dT, dS); return; }
+  if (E->form == MOM6HIP_EOS_WRIGHT_FULL) { wrightx_density_derivs(W_FULL, T, S, p, dT, dS); return; }
+  if (E->form == MOM6HIP_EOS_WRIGHT_REDUCED) { wrightx_density_derivs(W_RED, T, S, p, dT, dS); return; }
   wright_density_derivs(T, S, p, dT, dS);
 }
 
@@ -415,6 +461,8 @@ double orc_eos_spec_vol_anomaly(const mom6hip_eos_t *E, double T, double S, doub
   if (E->form == MOM6HIP_EOS_LINEAR)
     return ((1.0 - E->Rho_T0_S0*spv_ref) - spv_ref*(E->dRho_dT*T + E->dRho_dS*S)) / (E->Rho_T0_S0 + (E->dRho_dT*T + E->dRho_dS*S));
   if (E->form == MOM6HIP_EOS_UNESCO) return unesco_spv_anomaly(T, S, p, spv_ref);
+  if (E->form == MOM6HIP_EOS_WRIGHT_FULL) return wrightx_spv_anomaly(W_FULL, T, S, p, spv_ref);
+  if (E->form == MOM6HIP_EOS_WRIGHT_REDUCED) return wrightx_spv_anomaly(W_RED, T, S, p, spv_ref);
   return wright_spv_anomaly(T, S, p, spv_ref);
 }
 

@@ -25,7 +25,7 @@ def test_eos_check_values(oracle, c):
     assert abs((rho_ref + rho) - rho2) < 1e-9
 
 
-@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO"])
+@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 def test_eos_derivs_match_finite_differences(oracle, form):
     E = oracle.eos(form)
     T, S, p = 10.0, 34.0, 2.0e7
@@ -65,7 +65,7 @@ def test_spec_vol_forms(oracle):
     n = 4000
     T = rng.uniform(-2.0, 32.0, n); S = rng.uniform(0.0, 40.0, n); p = rng.uniform(0.0, 6.0e7, n)
     spv_ref = 1.0 / 1035.0
-    for form in ("WRIGHT", "UNESCO", "LINEAR"):
+    for form in ("WRIGHT", "UNESCO", "LINEAR", "WRIGHT_FULL", "WRIGHT_REDUCED"):
         E = oracle.eos(form)
         a = np.array([oracle.eos_spec_vol_anomaly(E, T[m], S[m], p[m], spv_ref) for m in range(n)])
         rho = np.array([oracle.eos_density(E, T[m], S[m], p[m]) for m in range(n)])
@@ -145,7 +145,7 @@ def test_sea_surface_slope_gives_g_times_slope(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR"])
+@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 @pytest.mark.parametrize("opts", [(True, False), (False, True)])
 def test_gpu_parity(oracle, form, opts):
     import torch
@@ -178,7 +178,7 @@ def test_gpu_parity(oracle, form, opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR"])
+@pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 @pytest.mark.parametrize("opts", [(True, False), (False, True)])
 def test_gpu_parity_nonbouss(oracle, form, opts):
     """PressureForce_FV_nonBouss: library == oracle, bit for bit"""
