@@ -80,8 +80,12 @@ class Model:
     def __init__(self, gg, dom, device, scheme, exchange="python"):
         from mom6_amd import _abi, synth
         from mom6_amd.ale import initialize_remapping
-        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2
+        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, initialize_dyn_split_RK2b
         from mom6_amd.tracer_advect import DeviceGrid, tracer_advect_init
+        # MOM6HIP_BENCH_RK2B=1: SPLIT_RK2B = True (MOM_dynamics_split_RK2b.F90) instead of the default split scheme; not the default
+        self.rk2b = os.environ.get("MOM6HIP_BENCH_RK2B", "0") == "1"
+        if self.rk2b:
+            initialize_dyn_split_RK2 = initialize_dyn_split_RK2b
         self.dom = dom
         grid = self.g = dom.tile_grid(gg) if dom.nranks > 1 else gg
         self.dg = DeviceGrid(grid, device=device.index)
@@ -162,8 +166,10 @@ class Model:
 
     def step(self):
         from mom6_amd.ale import ALE_regrid, ALE_remap_set_h_vel, ALE_remap_tracers, ALE_remap_velocities
-        from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
+        from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2, step_MOM_dyn_split_RK2b
         from mom6_amd.tracer_advect import advect_tracer
+        if self.rk2b:
+            step_MOM_dyn_split_RK2 = step_MOM_dyn_split_RK2b
         n = self.nstep
         if n % self.steps_per_advect == 0:      # bbl_time_int > 0: the first dynamic step of a thermodynamic cycle (MOM.F90:1200)
             from mom6_amd.set_viscosity import set_viscous_BBL
@@ -700,7 +706,8 @@ def main():
             "workload": f"{a.workload} {NI}x{NJ}x{NK} global C-grid, halo 4, reentrant-x{TOPO}, {100 * LAND_FRAC:.0f}% land, rough bathymetry, z* "
                         f"layers ({100 * health['vanished_layer_fraction']:.0f}% of the ocean cells are vanished layers below the bottom), "
                         f"T, S + 2 passive tracers, DT={DT:.0f}s DT_THERM={DT_THERM:.0f}s",
-            "step": "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
+            "step": ("step_MOM_dyn_split_RK2b [SPLIT_RK2B: continuity_PPM x4, horizontal_viscosity x2] " if M.rk2b else "") +
+                    "step_MOM_dyn_split_RK2 (1 library call: PressureForce_FV_Bouss [Wright, PLM], continuity_PPM x3, "
                     "btstep x2 + btcalc + bt_mass_source, CorAdCalc x2 [Sadourny75 energy, BOUND_CORIOLIS], horizontal_viscosity "
                     "[biharmonic Smagorinsky, BETTER_BOUND_AH], vertvisc_coef x3 + vertvisc x2 + vertvisc_remnant x3 [BOTTOMDRAGLAW], "
                     f"momentum sweeps, group passes); every {spa} steps set_viscous_BBL [BBL_USE_EOS], advect_tracer [{a.scheme}], "
