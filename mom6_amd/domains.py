@@ -59,7 +59,7 @@ class Domain:
         # TRIPOLAR_N (MOM_domains.F90:189): the fold is the northern edge of the northernmost row of tiles; with tiles that span
         # x (the 1 x N latitude bands of this framework) a tile on the fold is its own neighbour across it
         self.tripolar_n = bool(tripolar_n)
-        if self.tripolar_n and (self.npi != 1 or not self.reentrant_x or self.reentrant_y or self.NI % 2 or self.self_exchange):
+        if self.tripolar_n and (self.npi != 1 or not self.reentrant_x or self.reentrant_y or self.NI % 2):
             raise ValueError("MOM_domains: TRIPOLAR_N needs REENTRANT_X, an even NIGLOBAL and one tile in x (layout 1 x N)")
         self.on_fold = self.tripolar_n and self.pj == self.npj - 1
         self._dg = None          # the DeviceGrid of this tile (DeviceGrid.set_domain): enables the packed exchange
@@ -198,6 +198,8 @@ class Domain:
         import torch.distributed as dist
         from ._lib import check, lib
         dg, L = self._dg, lib()
+        if self.on_fold and self.self_exchange:
+            raise ValueError("MOM_domains: the self-exchange rehearsal of a tile on the tripolar fold needs the native (RCCL) domain")
         h, nf = self.halo, len(ptr_list)
         if w is None:
             w = h

@@ -18,9 +18,9 @@ def native_grid(g):
     import torch  # noqa: F401
     from mom6_amd.domains import Domain
     from mom6_amd.tracer_advect import DeviceGrid
-    dom = Domain(g.ni, g.nj, (1, 1), 0, g.halo, g.reentrant_x, g.reentrant_y, self_exchange=True)
+    dom = Domain(g.ni, g.nj, (1, 1), 0, g.halo, g.reentrant_x, g.reentrant_y, self_exchange=True, tripolar_n=g.tripolar_n)
     tg = dom.tile_grid(g)
-    assert not tg.reentrant_x and not tg.reentrant_y
+    assert not tg.reentrant_x and not tg.reentrant_y and tg.tripolar_n == g.tripolar_n
     dg = DeviceGrid(tg)
     dom.attach_native(dg)
     return dom, dg
@@ -94,4 +94,44 @@ def test_model_steps_through_the_native_exchange():
     assert st.iterations == rst.iterations
     for a, b in zip(tr, rtr):
         assert bits_equal(a.cpu().numpy(), b)
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_tripolar_fold_in_the_native_exchange():
+    """TRIPOLAR_N in the library's own group pass: x through ncclSend / ncclRecv (self-exchange), then the fold on the
+    communication stream; halo updates (vector, scalar pair, every staggering) and three viscous RK2 steps == oracle"""
+    import torch
+    import tripolar as tp
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    g, g2 = tp.grids(ni=70, nj=10, nk=3)
+    dom, dg = native_grid(g)
+    rng = np.random.default_rng(4)
+    SP = _abi.PASS_SCALAR_PAIR
+    fields, poss, want = [], [], []
+    for pf in (H, U, V, _abi.POS_Q, U | SP, V | SP):
+        a = rng.standard_normal(g.shape3(pf & 3))
+        w = a.copy(); orc.halo_update(g, w, pf)
+        fields.append(torch.from_numpy(a).cuda()); poss.append(pf); want.append(w)
+    dg.halo_update(fields, poss)
+    dg.sync()
+    for f, w, pf in zip(fields, want, poss):
+        assert bits_equal(f.cpu().numpy(), w), pf
+    d, _, (taux, tauy), _ = tp.states(g, g2)
+    dt = 900.0
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt)
+    ref.bcs.dtbt = dt / 6.6
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True))
+    CS.barotropic_CSp.st.dtbt = ref.bcs.dtbt
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy)
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS)
+    dg.sync()
+    for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uhtr", uhtr, ref.uhtr), ("eta", CS.eta, ref.arrs["eta"])):
+        assert bits_equal(a.cpu().numpy(), b), name
     dg.close()
