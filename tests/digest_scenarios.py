@@ -141,9 +141,9 @@ class OracleOps:
         return visc._keep
 
     # the time-stepping model
-    def model_init(self, d, bbl, dt):
+    def model_init(self, d, bbl, dt, rk2b=False):
         orc, g = self.orc, self.g
-        self.st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt,
+        self.st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, rk2b=rk2b,
                                vertvisc=orc.vertvisc_cs(g, Kv=VV["KV"], Hbbl=VV["HBBL"], Hmix=VV["HMIX_FIXED"], Kvml_invZ2=VV["KV_ML_INVZ2"]),
                                visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **HV))
 
@@ -156,6 +156,8 @@ class OracleOps:
         for n in ("eta", "u_av", "v_av", "h_av", "CAu_pred", "CAv_pred", "visc_rem_u", "visc_rem_v", "PFu", "pbce", "u_accel_bt", "diffu", "diffv"):
             out[n] = s.arrs[n]
         out["nstep_dtbt"] = np.array([float(s.bcs.nstep_last), s.bcs.dtbt])
+        if s.rk2b:
+            out["du_av_inst"] = s.arrs["du_av_inst"]; out["dv_av_inst"] = s.arrs["dv_av_inst"]
         return out
 
     def model_state(self):
@@ -319,9 +321,13 @@ class HipOps:
         set_viscous_BBL(T(u), T(v), T(h), (T(T_), T(S), EOS_init("WRIGHT")), visc, self.dg, CS)
         return {n: N(a) for n, a in arrs.items()}
 
-    def model_init(self, d, bbl, dt):
-        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2
+    def model_init(self, d, bbl, dt, rk2b=False):
+        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, initialize_dyn_split_RK2b
         from mom6_amd.vert_friction import vertvisc_type
+        self.rk2b = rk2b
+        self.__dict__.pop("_tau", None)
+        if rk2b:
+            initialize_dyn_split_RK2 = initialize_dyn_split_RK2b
         T, Z = self.T, self.Z
         m = self.m = dict(u=T(d["u"]), v=T(d["v"]), h=T(d["h"]), T=T(d["T"]), S=T(d["S"]), uh=Z(U), vh=Z(V), uhtr=Z(U), vhtr=Z(V),
                           eta_av=Z(H, False))
@@ -332,7 +338,9 @@ class HipOps:
         self.visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
 
     def model_step(self, taux, tauy, calc_dtbt):
-        from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2
+        from mom6_amd.dynamics_split_rk2 import step_MOM_dyn_split_RK2, step_MOM_dyn_split_RK2b
+        if self.rk2b:
+            step_MOM_dyn_split_RK2 = step_MOM_dyn_split_RK2b
         m = self.m
         if not hasattr(self, "_tau"):
             self._tau = (self.T(taux), self.T(tauy))
@@ -346,6 +354,8 @@ class HipOps:
             out[n] = N(self.CS.arrays[n])
         st = self.CS.barotropic_CSp.st
         out["nstep_dtbt"] = np.array([float(st.nstep_last), st.dtbt])
+        if self.rk2b:
+            out["du_av_inst"] = N(self.CS.arrays["du_av_inst"]); out["dv_av_inst"] = N(self.CS.arrays["dv_av_inst"])
         return out
 
     def model_state(self):
@@ -488,7 +498,18 @@ def model(ops, g, dm, taux, tauy, bbl, nsteps=2):
         yield f"model.ALE.tr{m}", a
 
 
-def run(ops_cls, size, parts=("operators", "model"), only=None, progress=None):
+def model_rk2b(ops, g, dm, taux, tauy, bbl, nsteps=2):
+    """SPLIT_RK2B: initialize_dyn_split_RK2b, nsteps x step_MOM_dyn_split_RK2b (both viscosities, DTBT set in the first step)"""
+    bbl = ops.set_viscous_BBL(dm["u"], dm["v"], dm["h"], dm["T"], dm["S"])
+    ops.model_init(dm, bbl, DT, rk2b=True)
+    for n in range(nsteps):
+        ops.model_step(taux, tauy, calc_dtbt=(n == 0))
+        for k, a in ops.model_fields().items():
+            if k not in ("CAu_pred", "CAv_pred", "PFu", "pbce"):
+                yield f"model_rk2b.step{n + 1}.{k}", a
+
+
+def run(ops_cls, size, parts=("operators", "model", "model_rk2b"), only=None, progress=None):
     g, d, dm, taux, tauy, bbl = make_inputs(size)
     out = OrderedDict()
     out["input.h"] = digest(d["h"]); out["input.u"] = digest(d["u"]); out["input.T"] = digest(d["T"])
@@ -500,6 +521,8 @@ def run(ops_cls, size, parts=("operators", "model"), only=None, progress=None):
             gens.append(operators(ops, g, d, taux, tauy, bbl, only))
         if "model" in parts:
             gens.append(model(ops, g, dm, taux, tauy, bbl))
+        if "model_rk2b" in parts:
+            gens.append(model_rk2b(ops, g, dm, taux, tauy, bbl))
         for gen in gens:
             for name, a in gen:
                 out[name] = digest(a)
