@@ -539,7 +539,8 @@ typedef struct mom6hip_barotropic_cs {
   double G_extra;              /* G_BT_EXTRA (0) */
   double BT_Coriolis_scale;    /* BT_CORIOLIS_SCALE (1) */
   double Z_ref;                /* G%Z_ref, REFERENCE_HEIGHT (0) */
-  double reserved0[7];
+  double maxCFL_BT_cont;       /* MAXCFL_BT_CONT (0.25): read with bound_BT_corr */
+  double reserved0[6];
   int32_t Sadourny;            /* SADOURNY (1) */
   int32_t linearized_BT_PV;    /* LINEARIZED_BT_CORIOLIS (1) */
   int32_t strong_drag;         /* BT_STRONG_DRAG (0) */
@@ -548,11 +549,14 @@ typedef struct mom6hip_barotropic_cs {
   int32_t use_wide_halos;      /* BT_USE_WIDE_HALOS (1) */
   int32_t hvel_scheme;         /* MOM6HIP_BT_* */
   int32_t nstep_last;          /* CS%nstep_last (out) */
-  /* INTEGRAL_BT_CONTINUITY, BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION, GRADUAL_BT_ICS,
+  /* INTEGRAL_BT_CONTINUITY, BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without BT_cont bounds, GRADUAL_BT_ICS,
    * BT_NONLIN_STRESS, DYNAMIC_SURFACE_PRESSURE, BT_LINEAR_WAVE_DRAG, CLIP_BT_VELOCITY, CALCULATE_SAL,
    * BT_USE_OLD_CORIOLIS_BRACKET_BUG, BAROTROPIC_ANSWER_DATE < 20190101 */
   int32_t unsupported[12];
-  int32_t reserved1[4];
+  int32_t bound_BT_corr;       /* BOUND_BT_CORRECTION (0) with BT_CONT_CORR_BOUNDS (its default, True) and a BT_cont argument:
+                                * the mass-source correction eta_cor is limited to what the open faces can carry at
+                                * MAXCFL_BT_CONT, and to the water in the cell (MOM_barotropic.F90:1587-1615) */
+  int32_t reserved1[3];
   double *frhatu, *frhatv;     /* 3-D u / v: layer weights (btcalc) */
   double *eta_cor;             /* 2-D h: mass source over a baroclinic step (bt_mass_source) */
   double *IDatu, *IDatv;       /* 2-D u / v: inverse total depth at velocity points (barotropic_init :5070-5087) */

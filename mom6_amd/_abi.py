@@ -105,7 +105,7 @@ class PressureForceCS(C.Structure):
 
 # ---- MOM_barotropic -----------------------------------------------------------------------------------
 BT_THICK_SCHEMES = {"HARMONIC": 1, "ARITHMETIC": 2, "HYBRID": 3, "FROM_BT_CONT": 4}
-BT_UNSUPPORTED = ("INTEGRAL_BT_CONTINUITY", "BT_PROJECT_VELOCITY", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION",
+BT_UNSUPPORTED = ("INTEGRAL_BT_CONTINUITY", "BT_PROJECT_VELOCITY", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS",
                   "GRADUAL_BT_ICS", "BT_NONLIN_STRESS", "DYNAMIC_SURFACE_PRESSURE", "BT_LINEAR_WAVE_DRAG",
                   "CLIP_BT_VELOCITY", "CALCULATE_SAL", "BT_USE_OLD_CORIOLIS_BRACKET_BUG", "BAROTROPIC_ANSWER_DATE<20190101")
 BT_CS_ARRAYS = (("frhatu", POS_U, 3), ("frhatv", POS_V, 3), ("eta_cor", POS_H, 2), ("IDatu", POS_U, 2), ("IDatv", POS_V, 2),
@@ -115,11 +115,11 @@ BT_CS_ARRAYS = (("frhatu", POS_U, 3), ("frhatv", POS_V, 3), ("eta_cor", POS_H, 2
 class BarotropicCS(C.Structure):
     """mom6hip_barotropic_cs_t (include/mom6hip.h)."""
     _fields_ = ([(n, C.c_double) for n in ("dtbt", "dtbt_max", "dtbt_fraction", "bebt", "dt_bt_filter", "vel_underflow",
-                                            "G_extra", "BT_Coriolis_scale", "Z_ref")]
-                + [("reserved0", C.c_double * 7)]
+                                            "G_extra", "BT_Coriolis_scale", "Z_ref", "maxCFL_BT_cont")]
+                + [("reserved0", C.c_double * 6)]
                 + [(n, C.c_int32) for n in ("Sadourny", "linearized_BT_PV", "strong_drag", "visc_rem_u_uh0", "adjust_BT_cont",
                                            "use_wide_halos", "hvel_scheme", "nstep_last")]
-                + [("unsupported", C.c_int32 * 12), ("reserved1", C.c_int32 * 4)]
+                + [("unsupported", C.c_int32 * 12), ("bound_BT_corr", C.c_int32), ("reserved1", C.c_int32 * 3)]
                 + [(n, C.c_void_p) for n, _, _ in BT_CS_ARRAYS]
                 + [("reserved2", C.c_void_p * 6)])
 

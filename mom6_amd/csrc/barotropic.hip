@@ -350,7 +350,7 @@ bt_dtbt_kernel(m6::GridDev g, const double *__restrict__ pbce, const double *__r
 
 int check_cs(const mom6hip_barotropic_cs_t *cs, const char *who) {
   M6_REQUIRE(cs != nullptr, "%s: null control structure", who);
-  static const char *names[12] = {"INTEGRAL_BT_CONTINUITY", "BT_PROJECT_VELOCITY", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION",
+  static const char *names[12] = {"INTEGRAL_BT_CONTINUITY", "BT_PROJECT_VELOCITY", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS / USE_BT_CONT_TYPE",
                                   "GRADUAL_BT_ICS", "BT_NONLIN_STRESS", "DYNAMIC_SURFACE_PRESSURE", "BT_LINEAR_WAVE_DRAG",
                                   "CLIP_BT_VELOCITY", "CALCULATE_SAL", "BT_USE_OLD_CORIOLIS_BRACKET_BUG",
                                   "BAROTROPIC_ANSWER_DATE < 20190101"};
@@ -949,7 +949,28 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   // ---- eta_src :1626-1628 and the transport of the initial velocities (what :1884-1891 evaluates after the first pass)
   {
     const double Instep = p.Instep;
-    const double *cor = c.eta_cor;
+    double *cor = c.eta_cor;
+    if (cs->bound_BT_corr) {      // BOUND_BT_CORRECTION with BT_CONT_CORR_BOUNDS :1587-1615 (the use_BT_cont branch): limits the state eta_cor
+      M6_REQUIRE(use_BT_cont && cs->maxCFL_BT_cont > 0.0, "btstep: BOUND_BT_CORRECTION needs the BT_cont argument (BT_CONT_CORR_BOUNDS) and MAXCFL_BT_CONT > 0");
+      const double cfl_Idt = cs->maxCFL_BT_cont * (1.0 / dt), Z_to_H = g.Z_to_H;
+      launch2d(s, is, ie, js, je, [=] __device__(int i, int j) {
+        const long n = g.h2(i, j);
+        if (!(g.mask2dT[n] > 0.0)) return;
+        const double ec = cor[n];
+        if (ec > 0.0) {
+          const double u_max_cor = g.dxT[n] * cfl_Idt, v_max_cor = g.dyT[n] * cfl_Idt;
+          const double eta_cor_max = dt * (g.IareaT[n] *
+                   (((find_uhbt(u_max_cor, w.BU, g.u2(i, j)) + w.uhbt0[g.u2(i, j)]) -
+                     (find_uhbt(-u_max_cor, w.BU, g.u2(i - 1, j)) + w.uhbt0[g.u2(i - 1, j)])) +
+                    ((find_uhbt(v_max_cor, w.BV, g.v2(i, j)) + w.vhbt0[g.v2(i, j)]) -
+                     (find_uhbt(-v_max_cor, w.BV, g.v2(i, j - 1)) + w.vhbt0[g.v2(i, j - 1)]))));
+          cor[n] = m6::min2(ec, m6::max2(0.0, eta_cor_max));
+        } else {
+          const double Htot = g.bathyT[n] * Z_to_H + w.eta[n];
+          cor[n] = m6::max2(ec, -m6::max2(0.0, Htot));
+        }
+      });
+    }
     launch2d(s, is, ie, js, je, [=] __device__(int i, int j) { w.eta_src[g.h2(i, j)] = g.mask2dT[g.h2(i, j)] * (Instep * cor[g.h2(i, j)]); });
     launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) {
       const long n = g.u2(I, j);

@@ -3,7 +3,7 @@
 !! register_barotropic_restarts (:5165) with the reference's dummy-argument lists, so MOM_dynamics_split_RK2.F90 compiles
 !! unchanged.  The work is done by libmom6hip on host arrays (HOST memspace); the barotropic subcycle of one btstep call
 !! is a single hipGraph launch on the GPU.  Options outside the library's scope (INTEGRAL_BT_CONTINUITY,
-!! BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION, GRADUAL_BT_ICS, BT_NONLIN_STRESS,
+!! BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without its BT_cont bounds, GRADUAL_BT_ICS, BT_NONLIN_STRESS,
 !! DYNAMIC_SURFACE_PRESSURE, BT_LINEAR_WAVE_DRAG, CLIP_BT_VELOCITY, CALCULATE_SAL / TIDES, the old bracket bug, answer
 !! dates before 2019, open boundaries, a non-Boussinesq vertical grid) stop in barotropic_init with a FATAL error.
 !!
@@ -235,7 +235,7 @@ subroutine barotropic_init(u, v, h, eta, Time, G, GV, US, param_file, diag, CS, 
 # include "version_variable.h"
   character(len=40)  :: mdl = "MOM_barotropic"
   character(len=32)  :: hvel_str
-  logical :: use_BT_cont_type, flag, use_tides, bug
+  logical :: use_BT_cont_type, flag, flag2, flag3, use_tides, bug
   integer :: default_answer_date, answer_date, isd, ied, jsd, jed, nz, i, j, k, rc
   real :: dtbt_input, dtbt_tmp, gtot_estimate, SSH_extra, bt_cont_bounds
 
@@ -258,7 +258,15 @@ subroutine barotropic_init(u, v, h, eta, Time, G, GV, US, param_file, diag, CS, 
                  default=.true.)
   ! the options the library does not provide are read with the reference's defaults and refused when switched on
   call get_param(param_file, mdl, "INTEGRAL_BT_CONTINUITY", flag, default=.false.) ; call refuse(flag, "INTEGRAL_BT_CONTINUITY")
-  call get_param(param_file, mdl, "BOUND_BT_CORRECTION", flag, default=.false.) ; call refuse(flag, "BOUND_BT_CORRECTION")
+  ! BOUND_BT_CORRECTION (:4485): provided with BT_CONT_CORR_BOUNDS (:4490, its default) and USE_BT_CONT_TYPE
+  call get_param(param_file, mdl, "BOUND_BT_CORRECTION", flag, default=.false.)
+  CS%st%bound_BT_corr = merge(1, 0, flag) ; CS%st%maxCFL_BT_cont = 0.25
+  if (flag) then
+    call get_param(param_file, mdl, "BT_CONT_CORR_BOUNDS", flag2, default=.true.)
+    call get_param(param_file, mdl, "USE_BT_CONT_TYPE", flag3, default=.true.)
+    call refuse(.not.(flag2 .and. flag3), "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS and USE_BT_CONT_TYPE")
+    call get_param(param_file, mdl, "MAXCFL_BT_CONT", CS%st%maxCFL_BT_cont, units="nondim", default=0.25)
+  endif
   call get_param(param_file, mdl, "GRADUAL_BT_ICS", flag, default=.false.) ; call refuse(flag, "GRADUAL_BT_ICS")
   call get_param(param_file, mdl, "NONLINEAR_BT_CONTINUITY", flag, default=.false.) ; call refuse(flag, "NONLINEAR_BT_CONTINUITY")
   call get_param(param_file, mdl, "BT_PROJECT_VELOCITY", flag, default=.false.) ; call refuse(flag, "BT_PROJECT_VELOCITY")

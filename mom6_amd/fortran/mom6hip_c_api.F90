@@ -105,11 +105,13 @@ end type mom6hip_pressureforce_cs_t
 !> mom6hip_barotropic_cs_t (barotropic_CS, src/core/MOM_barotropic.F90:104)
 type, bind(c) :: mom6hip_barotropic_cs_t
   real(c_double) :: dtbt, dtbt_max, dtbt_fraction, bebt, dt_bt_filter, vel_underflow, G_extra, BT_Coriolis_scale, Z_ref
-  real(c_double) :: reserved0(7)
+  real(c_double) :: maxCFL_BT_cont   !< MAXCFL_BT_CONT, with bound_BT_corr
+  real(c_double) :: reserved0(6)
   integer(c_int32_t) :: Sadourny, linearized_BT_PV, strong_drag, visc_rem_u_uh0, adjust_BT_cont, use_wide_halos, &
                         hvel_scheme, nstep_last
   integer(c_int32_t) :: unsupported(12)
-  integer(c_int32_t) :: reserved1(4)
+  integer(c_int32_t) :: bound_BT_corr   !< BOUND_BT_CORRECTION with BT_CONT_CORR_BOUNDS and a BT_cont argument
+  integer(c_int32_t) :: reserved1(3)
   type(c_ptr) :: frhatu, frhatv, eta_cor, IDatu, IDatv, ubtav, vbtav, q_D, D_u_Cor, D_v_Cor
   type(c_ptr) :: reserved2(6)
 end type mom6hip_barotropic_cs_t

@@ -249,6 +249,7 @@ static long n_q2(const mom6hip_grid_t *G) { return (long)(ORC_NIH(G) + 1) * (ORC
 
 static int check_cs(const mom6hip_barotropic_cs_t *CS) {
   for (int q = 0; q < 12; q++) if (CS->unsupported[q]) return 1;
+  if (CS->bound_BT_corr && !(CS->maxCFL_BT_cont > 0.0)) return 1;
   return 0;
 }
 
@@ -758,7 +759,25 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     }
   }
 
-  /* ---- eta_src :1583-1628 (.not.bound_BT_corr) */
+  /* ---- eta_src :1583-1628 */
+  /* BOUND_BT_CORRECTION with BT_CONT_CORR_BOUNDS :1587-1615 (the use_BT_cont branch): eta_cor, the state, is limited */
+  if (CS->bound_BT_corr && use_BT_cont) {      /* (without BT_cont the library refuses the option) */
+    for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) if (G->mask2dT[H2(i, j)] > 0.0) {
+      if (CS->eta_cor[H2(i, j)] > 0.0) {
+        const double u_max_cor = G->dxT[H2(i, j)] * (CS->maxCFL_BT_cont*Idt);
+        const double v_max_cor = G->dyT[H2(i, j)] * (CS->maxCFL_BT_cont*Idt);
+        const double eta_cor_max = dt * (G->IareaT[H2(i, j)] *
+                 (((find_uhbt(u_max_cor, &BU, U2(i, j)) + uhbt0[U2(i, j)]) -
+                   (find_uhbt(-u_max_cor, &BU, U2(i - 1, j)) + uhbt0[U2(i - 1, j)])) +
+                  ((find_uhbt(v_max_cor, &BV, V2(i, j)) + vhbt0[V2(i, j)]) -
+                   (find_uhbt(-v_max_cor, &BV, V2(i, j - 1)) + vhbt0[V2(i, j - 1)])) ));
+        CS->eta_cor[H2(i, j)] = min2(CS->eta_cor[H2(i, j)], max2(0.0, eta_cor_max));
+      } else {
+        const double Htot = G->bathyT[H2(i, j)]*G->Z_to_H + eta[H2(i, j)];
+        CS->eta_cor[H2(i, j)] = max2(CS->eta_cor[H2(i, j)], -max2(0.0, Htot));
+      }
+    }
+  }
   ORC_PAR
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
     eta_src[H2(i, j)] = G->mask2dT[H2(i, j)] * (Instep * CS->eta_cor[H2(i, j)]);

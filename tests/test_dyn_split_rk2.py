@@ -174,3 +174,55 @@ def test_step_with_vertvisc_matches_oracle_bitwise(kw):
             an = a.cpu().numpy()
             assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
     dg.close()
+
+
+def test_oracle_bound_bt_correction_limits_the_mass_source():
+    """BOUND_BT_CORRECTION (MOM_barotropic.F90:1587-1615): with a tiny MAXCFL_BT_CONT the positive corrections are cut to what the
+    open faces can carry; with the default 0.25 nothing is cut in a quiet ocean, and the option changes no answers"""
+    g, d, taux, tauy = make_case()
+    runs = {}
+    for name, kw in (("off", {}), ("default", dict(bound_BT_corr=1, maxCFL_BT_cont=0.25)), ("tight", dict(bound_BT_corr=1, maxCFL_BT_cont=1.0e-18))):
+        st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], 1800.0, **kw)
+        st.bcs.dtbt = 1800.0 / 9.6
+        for n in range(3):
+            st.step(taux, tauy)
+        runs[name] = st
+    assert bits_equal(runs["off"].h, runs["default"].h) and bits_equal(runs["off"].bcs_arrs["eta_cor"], runs["default"].bcs_arrs["eta_cor"])
+    # (the bound of a source is what the faces carry at MAXCFL_BT_CONT plus the divergence of uhbt0, so it is not simply small)
+    a, b = runs["off"].bcs_arrs["eta_cor"], runs["tight"].bcs_arrs["eta_cor"]
+    assert a.max() > 0 and not bits_equal(a, b)
+    assert not bits_equal(runs["off"].h, runs["tight"].h) and np.abs(runs["off"].h - runs["tight"].h).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maxcfl", [0.25, 1.0e-18])
+def test_step_with_bound_bt_correction_matches_oracle_bitwise(maxcfl):
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd._lib import Mom6HipError
+    from mom6_amd.tracer_advect import DeviceGrid
+    g, d, taux, tauy = make_case(ni=70, nj=21, nk=3, seed=6)
+    dt = 1800.0
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, bound_BT_corr=1, maxCFL_BT_cont=maxcfl)
+    ref.bcs.dtbt = dt / 9.6
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H, False)
+    with pytest.raises(Mom6HipError, match="BOUND_BT_CORRECTION"):      # without BT_cont the option is refused by name
+        initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, USE_BT_CONT_TYPE=False,
+                                 barotropic=dict(BOUND_BT_CORRECTION=True, BT_THICK_SCHEME="HARMONIC"))
+        raise Mom6HipError("BOUND_BT_CORRECTION accepted without BT_cont")
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True),
+                                  barotropic=dict(BOUND_BT_CORRECTION=True, MAXCFL_BT_CONT=maxcfl))
+    CS.barotropic_CSp.st.dtbt = ref.bcs.dtbt
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy)
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS)
+        dg.sync()
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("eta", CS.eta, ref.arrs["eta"]),
+                           ("eta_cor", CS.barotropic_CSp.eta_cor, ref.bcs_arrs["eta_cor"])):
+            assert bits_equal(a.cpu().numpy(), b), (n, name)
+    dg.close()
