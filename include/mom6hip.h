@@ -549,14 +549,16 @@ typedef struct mom6hip_barotropic_cs {
   int32_t use_wide_halos;      /* BT_USE_WIDE_HALOS (1) */
   int32_t hvel_scheme;         /* MOM6HIP_BT_* */
   int32_t nstep_last;          /* CS%nstep_last (out) */
-  /* INTEGRAL_BT_CONTINUITY, BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without BT_cont bounds, GRADUAL_BT_ICS,
+  /* INTEGRAL_BT_CONTINUITY, (free), NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without BT_cont bounds, GRADUAL_BT_ICS,
    * BT_NONLIN_STRESS, DYNAMIC_SURFACE_PRESSURE, BT_LINEAR_WAVE_DRAG, CLIP_BT_VELOCITY, CALCULATE_SAL,
    * BT_USE_OLD_CORIOLIS_BRACKET_BUG, BAROTROPIC_ANSWER_DATE < 20190101 */
   int32_t unsupported[12];
   int32_t bound_BT_corr;       /* BOUND_BT_CORRECTION (0) with BT_CONT_CORR_BOUNDS (its default, True) and a BT_cont argument:
                                 * the mass-source correction eta_cor is limited to what the open faces can carry at
                                 * MAXCFL_BT_CONT, and to the water in the cell (MOM_barotropic.F90:1587-1615) */
-  int32_t reserved1[3];
+  int32_t BT_project_velocity; /* BT_PROJECT_VELOCITY (0): the velocities are stepped first and projected for the transports
+                                * (trans_wt = 1+bebt, -bebt; the pressure force from eta instead of eta_pred: :804-808, :1751, :1870) */
+  int32_t reserved1[2];
   double *frhatu, *frhatv;     /* 3-D u / v: layer weights (btcalc) */
   double *eta_cor;             /* 2-D h: mass source over a baroclinic step (bt_mass_source) */
   double *IDatu, *IDatv;       /* 2-D u / v: inverse total depth at velocity points (barotropic_init :5070-5087) */

@@ -34,6 +34,7 @@ class barotropic_CS:
         bound = bool(params.pop("BOUND_BT_CORRECTION", False))
         cont_bounds = bool(params.pop("BT_CONT_CORR_BOUNDS", True))
         maxcfl = float(params.pop("MAXCFL_BT_CONT", 0.25))
+        project = bool(params.pop("BT_PROJECT_VELOCITY", False))      # :4536
         if bound and not (USE_BT_CONT_TYPE and cont_bounds):
             unsupported[3] = 1
         for k, v in params.items():
@@ -54,6 +55,7 @@ class barotropic_CS:
             raise Mom6HipError("barotropic_init: BT_THICK_SCHEME FROM_BT_CONT can only be used if USE_BT_CONT_TYPE is defined.")
         st.hvel_scheme = _abi.BT_THICK_SCHEMES[BT_THICK_SCHEME]
         st.bound_BT_corr, st.maxCFL_BT_cont = int(bound), maxcfl
+        st.BT_project_velocity = int(project)
         for q in range(12):
             st.unsupported[q] = unsupported[q]
         # DTBT: > 0 a time step in s, <= 0 minus the fraction of the stable maximum (0 = -0.98) (:4725-4735, :5012-5022)

@@ -137,6 +137,7 @@ struct Work {
 // scalars of one btstep call
 struct Par {
   double dtbt, Instep, dgeo_de, vel_underflow, trans_wt1, trans_wt2, RZ_to_H;
+  int project_velocity;      // BT_PROJECT_VELOCITY: the pressure force reads eta, not eta_pred (:1751); no predictor continuity (:1870)
   int nstep, use_BT_cont, interp_eta_PF, add_uh0, strong_drag, visc_rem_u_uh0, find_etaav, have_bot;
 };
 
@@ -226,9 +227,14 @@ bt_eta_pred_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1,
   const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
   if (i > i1 || j > j1) return;
   const long n = g.h2(i, j);
-  const double ep = (w.eta[n] + w.eta_src[n]) + (p.dtbt * g.IareaT[n]) *
-      ((w.uhbtp[g.u2(i - 1, j)] - w.uhbtp[g.u2(i, j)]) + (w.vhbtp[g.v2(i, j - 1)] - w.vhbtp[g.v2(i, j)]));
-  w.eta_pred[n] = ep;
+  double ep;
+  if (p.project_velocity) {
+    ep = w.eta[n];
+  } else {
+    ep = (w.eta[n] + w.eta_src[n]) + (p.dtbt * g.IareaT[n]) *
+        ((w.uhbtp[g.u2(i - 1, j)] - w.uhbtp[g.u2(i, j)]) + (w.vhbtp[g.v2(i, j - 1)] - w.vhbtp[g.v2(i, j)]));
+    w.eta_pred[n] = ep;
+  }
   if (p.find_etaav && i >= g.isc && i <= g.iec && j >= g.jsc && j <= g.jec) w.eta_sum[n] = w.eta_sum[n] + wt_accel2 * ep;
 }
 
@@ -260,8 +266,9 @@ bt_vbt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, doub
                                (w.bmer[g.u2(i, j)] * w.ubt[g.u2(i, j)] + w.dmer[g.u2(i - 1, j + 1)] * w.ubt[g.u2(i - 1, j + 1)])) -
                        w.Cor_ref_v[n];
   const long hs = g.h2(i, j), hn = g.h2(i, j + 1);
-  const double PFv = ((w.eta_pred[hs] - eta_pf_at(w, p, hs, wt_end)) * w.gtot_N[hs] -
-                      (w.eta_pred[hn] - eta_pf_at(w, p, hn, wt_end)) * w.gtot_S[hn]) * p.dgeo_de * g.IdyCv[n];
+  const double *epb = p.project_velocity ? w.eta : w.eta_pred;
+  const double PFv = ((epb[hs] - eta_pf_at(w, p, hs, wt_end)) * w.gtot_N[hs] -
+                      (epb[hn] - eta_pf_at(w, p, hn, wt_end)) * w.gtot_S[hn]) * p.dgeo_de * g.IdyCv[n];
   const double vel_prev = w.vbt[n];
   double vb = w.bt_rem_v[n] * (vel_prev + p.dtbt * ((w.BT_force_v[n] + Cor_v) + PFv));
   if (fabs(vb) < p.vel_underflow) vb = 0.0;
@@ -290,8 +297,9 @@ bt_ubt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, doub
   const double Cor_u = ((w.azon[n] * w.vbt[g.v2(i + 1, j)] + w.czon[n] * w.vbt[g.v2(i, j - 1)]) +
                         (w.bzon[n] * w.vbt[g.v2(i, j)] + w.dzon[n] * w.vbt[g.v2(i + 1, j - 1)])) - w.Cor_ref_u[n];
   const long hw = g.h2(i, j), he = g.h2(i + 1, j);
-  const double PFu = ((w.eta_pred[hw] - eta_pf_at(w, p, hw, wt_end)) * w.gtot_E[hw] -
-                      (w.eta_pred[he] - eta_pf_at(w, p, he, wt_end)) * w.gtot_W[he]) * p.dgeo_de * g.IdxCu[n];
+  const double *epb = p.project_velocity ? w.eta : w.eta_pred;
+  const double PFu = ((epb[hw] - eta_pf_at(w, p, hw, wt_end)) * w.gtot_E[hw] -
+                      (epb[he] - eta_pf_at(w, p, he, wt_end)) * w.gtot_W[he]) * p.dgeo_de * g.IdxCu[n];
   const double vel_prev = w.ubt[n];
   double ub = w.bt_rem_u[n] * (vel_prev + p.dtbt * ((w.BT_force_u[n] + Cor_u) + PFu));
   if (fabs(ub) < p.vel_underflow) ub = 0.0;
@@ -350,7 +358,7 @@ bt_dtbt_kernel(m6::GridDev g, const double *__restrict__ pbce, const double *__r
 
 int check_cs(const mom6hip_barotropic_cs_t *cs, const char *who) {
   M6_REQUIRE(cs != nullptr, "%s: null control structure", who);
-  static const char *names[12] = {"INTEGRAL_BT_CONTINUITY", "BT_PROJECT_VELOCITY", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS / USE_BT_CONT_TYPE",
+  static const char *names[12] = {"INTEGRAL_BT_CONTINUITY", "(free slot)", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS / USE_BT_CONT_TYPE",
                                   "GRADUAL_BT_ICS", "BT_NONLIN_STRESS", "DYNAMIC_SURFACE_PRESSURE", "BT_LINEAR_WAVE_DRAG",
                                   "CLIP_BT_VELOCITY", "CALCULATE_SAL", "BT_USE_OLD_CORIOLIS_BRACKET_BUG",
                                   "BAROTROPIC_ANSWER_DATE < 20190101"};
@@ -640,7 +648,9 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
 
   Par p;
   p.Instep = 1.0 / (double)nstep; p.dtbt = dt * p.Instep; p.dgeo_de = 1.0 + cs->G_extra; p.vel_underflow = cs->vel_underflow;
-  p.trans_wt1 = cs->bebt; p.trans_wt2 = (1.0 - cs->bebt); p.RZ_to_H = RZ_to_H; p.nstep = nstep; p.use_BT_cont = use_BT_cont;
+  p.project_velocity = cs->BT_project_velocity ? 1 : 0;
+  p.trans_wt1 = p.project_velocity ? (1.0 + cs->bebt) : cs->bebt; p.trans_wt2 = p.project_velocity ? -cs->bebt : (1.0 - cs->bebt);      // :804-808
+  p.RZ_to_H = RZ_to_H; p.nstep = nstep; p.use_BT_cont = use_BT_cont;
   p.interp_eta_PF = interp; p.add_uh0 = add_uh0; p.strong_drag = cs->strong_drag; p.visc_rem_u_uh0 = cs->visc_rem_u_uh0;
   p.find_etaav = find_etaav; p.have_bot = have_bot;
   const double accel_underflow = cs->vel_underflow * (1.0 / dt);

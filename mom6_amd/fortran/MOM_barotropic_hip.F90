@@ -3,7 +3,7 @@
 !! register_barotropic_restarts (:5165) with the reference's dummy-argument lists, so MOM_dynamics_split_RK2.F90 compiles
 !! unchanged.  The work is done by libmom6hip on host arrays (HOST memspace); the barotropic subcycle of one btstep call
 !! is a single hipGraph launch on the GPU.  Options outside the library's scope (INTEGRAL_BT_CONTINUITY,
-!! BT_PROJECT_VELOCITY, NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without its BT_cont bounds, GRADUAL_BT_ICS, BT_NONLIN_STRESS,
+!! NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without its BT_cont bounds, GRADUAL_BT_ICS, BT_NONLIN_STRESS,
 !! DYNAMIC_SURFACE_PRESSURE, BT_LINEAR_WAVE_DRAG, CLIP_BT_VELOCITY, CALCULATE_SAL / TIDES, the old bracket bug, answer
 !! dates before 2019, open boundaries, a non-Boussinesq vertical grid) stop in barotropic_init with a FATAL error.
 !!
@@ -269,7 +269,7 @@ subroutine barotropic_init(u, v, h, eta, Time, G, GV, US, param_file, diag, CS, 
   endif
   call get_param(param_file, mdl, "GRADUAL_BT_ICS", flag, default=.false.) ; call refuse(flag, "GRADUAL_BT_ICS")
   call get_param(param_file, mdl, "NONLINEAR_BT_CONTINUITY", flag, default=.false.) ; call refuse(flag, "NONLINEAR_BT_CONTINUITY")
-  call get_param(param_file, mdl, "BT_PROJECT_VELOCITY", flag, default=.false.) ; call refuse(flag, "BT_PROJECT_VELOCITY")
+  call get_param(param_file, mdl, "BT_PROJECT_VELOCITY", flag, default=.false.) ; CS%st%BT_project_velocity = merge(1, 0, flag)
   call get_param(param_file, mdl, "BT_NONLIN_STRESS", flag, default=.false.) ; call refuse(flag, "BT_NONLIN_STRESS")
   call get_param(param_file, mdl, "DYNAMIC_SURFACE_PRESSURE", flag, default=.false.) ; call refuse(flag, "DYNAMIC_SURFACE_PRESSURE")
   call get_param(param_file, mdl, "BT_LINEAR_WAVE_DRAG", flag, default=.false.) ; call refuse(flag, "BT_LINEAR_WAVE_DRAG")

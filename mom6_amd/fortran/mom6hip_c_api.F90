@@ -111,7 +111,8 @@ type, bind(c) :: mom6hip_barotropic_cs_t
                         hvel_scheme, nstep_last
   integer(c_int32_t) :: unsupported(12)
   integer(c_int32_t) :: bound_BT_corr   !< BOUND_BT_CORRECTION with BT_CONT_CORR_BOUNDS and a BT_cont argument
-  integer(c_int32_t) :: reserved1(3)
+  integer(c_int32_t) :: BT_project_velocity   !< BT_PROJECT_VELOCITY
+  integer(c_int32_t) :: reserved1(2)
   type(c_ptr) :: frhatu, frhatv, eta_cor, IDatu, IDatv, ubtav, vbtav, q_D, D_u_Cor, D_v_Cor
   type(c_ptr) :: reserved2(6)
 end type mom6hip_barotropic_cs_t

@@ -478,7 +478,9 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   const double Instep = 1.0 / (double)nstep;
   const double dtbt = dt * Instep;
   const double bebt = CS->bebt;
-  const double trans_wt1 = bebt, trans_wt2 = (1.0 - bebt);
+  const int project_velocity = CS->BT_project_velocity != 0;      /* :748 */
+  const double be_proj = bebt;                                     /* :801 */
+  const double trans_wt1 = project_velocity ? (1.0 + be_proj) : bebt, trans_wt2 = project_velocity ? -be_proj : (1.0 - bebt);      /* :804-808 */
 
   const long NH = n_h2(G), NU = n_u2(G), NV = n_v2(G), NQ = n_q2(G);
 #define NEWH(x) double *x = (double *)calloc((size_t)NH, sizeof(double))
@@ -496,7 +498,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   double *wt_u = (double *)calloc((size_t)NU * nz, sizeof(double)), *wt_v = (double *)calloc((size_t)NV * nz, sizeof(double));
   btcl_t BU, BV;
   btcl_alloc(&BU, NU); btcl_alloc(&BV, NV);
-  const double *eta_PF_BT = eta_pred; /* .not.project_velocity :1751 */
+  const double *eta_PF_BT = project_velocity ? eta : eta_pred;      /* :1751 */
 
 #define H2(i, j) ORC_H2(G, i, j)
 #define U2(i, j) ORC_U2(G, i, j)
@@ -836,8 +838,9 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       isv = isv + stencil; iev = iev - stencil; jsv = jsv + stencil; jev = jev - stencil;
     }
 
-    /* predictor continuity :1870-1909 */
-    if (use_BT_cont) {
+    /* predictor continuity :1870-1909 (.not.project_velocity) */
+    if (project_velocity) {
+    } else if (use_BT_cont) {
       ORC_PAR
       for (int j = jsv - 1; j <= jev + 1; j++) for (int I = isv - 2; I <= iev + 1; I++)
         uhbt[U2(I, j)] = find_uhbt(ubt[U2(I, j)], &BU, U2(I, j)) + uhbt0[U2(I, j)];

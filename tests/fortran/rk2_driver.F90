@@ -79,7 +79,7 @@ eos%form = MOM6HIP_EOS_WRIGHT ; eos%reserved = 0 ; eos%Rho_T0_S0 = 1000.0d0 ; eo
 bcs%dtbt = 0.0d0 ; bcs%dtbt_max = 0.0d0 ; bcs%dtbt_fraction = 0.98d0 ; bcs%bebt = 0.1d0 ; bcs%dt_bt_filter = -0.25d0
 bcs%vel_underflow = 0.0d0 ; bcs%G_extra = 0.0d0 ; bcs%BT_Coriolis_scale = 1.0d0 ; bcs%Z_ref = 0.0d0 ; bcs%maxCFL_BT_cont = 0.25d0 ; bcs%reserved0(:) = 0.0d0
 bcs%Sadourny = 1 ; bcs%linearized_BT_PV = 1 ; bcs%strong_drag = 0 ; bcs%visc_rem_u_uh0 = 0 ; bcs%adjust_BT_cont = 0
-bcs%use_wide_halos = 1 ; bcs%hvel_scheme = 4 ; bcs%nstep_last = 0 ; bcs%unsupported(:) = 0 ; bcs%bound_BT_corr = 0 ; bcs%reserved1(:) = 0
+bcs%use_wide_halos = 1 ; bcs%hvel_scheme = 4 ; bcs%nstep_last = 0 ; bcs%unsupported(:) = 0 ; bcs%bound_BT_corr = 0 ; bcs%BT_project_velocity = 0 ; bcs%reserved1(:) = 0
 bcs%frhatu = dalloc(nu3) ; bcs%frhatv = dalloc(nv3) ; bcs%eta_cor = dalloc(nh2) ; bcs%IDatu = dalloc(nu2) ; bcs%IDatv = dalloc(nv2)
 bcs%ubtav = dalloc(nu2) ; bcs%vbtav = dalloc(nv2) ; bcs%q_D = dalloc(nq2) ; bcs%D_u_Cor = dalloc(nu2) ; bcs%D_v_Cor = dalloc(nv2)
 bcs%reserved2(:) = c_null_ptr

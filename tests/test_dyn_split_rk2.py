@@ -226,3 +226,54 @@ def test_step_with_bound_bt_correction_matches_oracle_bitwise(maxcfl):
                            ("eta_cor", CS.barotropic_CSp.eta_cor, ref.bcs_arrs["eta_cor"])):
             assert bits_equal(a.cpu().numpy(), b), (n, name)
     dg.close()
+
+
+def test_oracle_bt_project_velocity_is_a_consistent_alternative():
+    """BT_PROJECT_VELOCITY (MOM_barotropic.F90:804-808, :1751, :1870): another second-order treatment of the barotropic transports;
+    it conserves volume and stays close to the default"""
+    g, d, taux, tauy = make_case()
+    runs = []
+    for kw in ({}, dict(BT_project_velocity=1)):
+        st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], 1800.0, **kw)
+        st.bcs.dtbt = 1800.0 / 9.6
+        v0 = volume(g, st.h)
+        for n in range(4):
+            st.step(taux, tauy)
+        assert abs(volume(g, st.h) - v0) <= 1e-12 * v0 and np.all(np.isfinite(st.u))
+        runs.append(st)
+    dh = np.abs(interior(g, runs[0].h) - interior(g, runs[1].h)).max()
+    assert 0 < dh < 0.05 * np.abs(interior(g, runs[0].h) - interior(g, d["h"])).max() + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(use_bt_cont=False), dict(om4=True)], ids=["default", "no_bt_cont", "with_bound_bt_correction"])
+def test_step_with_bt_project_velocity_matches_oracle_bitwise(kw):
+    """BT_PROJECT_VELOCITY, alone and together with BOUND_BT_CORRECTION (the barotropic settings of OM4)"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    use_bt, om4 = kw.get("use_bt_cont", True), kw.get("om4", False)
+    g, d, taux, tauy = make_case(ni=70, nj=21, nk=3, seed=7)
+    dt = 1800.0
+    okw = dict(bound_BT_corr=1, maxCFL_BT_cont=0.25) if om4 else {}
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, use_bt_cont=use_bt, BT_project_velocity=1, **okw)
+    ref.bcs.dtbt = dt / 9.6
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H, False)
+    bkw = dict(BT_PROJECT_VELOCITY=True, BT_THICK_SCHEME="FROM_BT_CONT" if use_bt else "HARMONIC")
+    if om4:
+        bkw.update(BOUND_BT_CORRECTION=True)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, USE_BT_CONT_TYPE=use_bt, coriolis=dict(bound_coriolis=True), barotropic=bkw)
+    CS.barotropic_CSp.st.dtbt = ref.bcs.dtbt
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy)
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS)
+        dg.sync()
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("eta", CS.eta, ref.arrs["eta"]), ("eta_av", eta_av, ref.eta_av),
+                           ("u_av", CS.u_av, ref.arrs["u_av"])):
+            assert bits_equal(a.cpu().numpy(), b), (n, name)
+    dg.close()
