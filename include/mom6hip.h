@@ -372,6 +372,13 @@ int mom6hip_ale_regrid(mom6hip_ctx_t *ctx, const mom6hip_regridding_cs_t *cs, co
  * PARTIAL_CELL_VELOCITY_REMAP = False, OBC not associated.  Only open faces are written. */
 int mom6hip_ale_remap_set_h_vel(mom6hip_ctx_t *ctx, const double *h_new, double *h_u, double *h_v, int32_t memspace);
 
+/* ALE_remap_set_h_vel_via_dz(CS, G, GV, h_new, h_u, h_v, OBC, h_old, dzInterface, debug)   src/ALE/MOM_ALE.F90:912
+ * What step_MOM_thermo calls for the NEW velocity-point grid when REMAP_UV_USING_OLD_ALG = True (src/core/MOM.F90:1666-1667;
+ * .testing/tc2, tc4): h_u = max(0, mean(h_old) + half the difference of the mean interface movements); dzInterface has nk+1
+ * levels (ALE_regrid's dzRegrid).  h_new is read by the reference only for OBC faces and is not an argument here. */
+int mom6hip_ale_remap_set_h_vel_via_dz(mom6hip_ctx_t *ctx, const double *h_old, const double *dzInterface, double *h_u,
+                                       double *h_v, int32_t memspace);
+
 /* ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
  *                                                                                src/ALE/MOM_ALE.F90:1061
  * cs is CS%vel_remapCS; REMAP_VEL_CONSERVE_KE = False, REMAP_VEL_MASK_BBL_THICK <= 0, no KE diagnostics.
@@ -474,22 +481,34 @@ typedef struct mom6hip_eos {
   double Rho_T0_S0, dRho_dT, dRho_dS;   /* linear EOS: RHO_T0_S0, DRHO_DT, DRHO_DS */
 } mom6hip_eos_t;
 
-/* PressureForce_FV_CS, src/core/MOM_PressureForce_FV.F90 (the members the provided branch reads) */
+/* PressureForce_FV_CS, src/core/MOM_PressureForce_FV.F90 (the members the provided branches read), and what the routine takes
+ * from its other arguments (ALE_CSp, GV, tv) to choose a branch */
 typedef struct mom6hip_pressureforce_cs {
   double Rho0;                 /* RHO_PGF_REF (default GV%Rho0) */
   double GFS_scale;            /* must be 1.0 */
   double Z_ref;                /* G%Z_ref */
-  int32_t reconstruct;         /* RECONSTRUCT_FOR_PRESSURE (must be 1) */
-  int32_t Recon_Scheme;        /* PRESSURE_RECONSTRUCTION_SCHEME (must be 1 = PLM) */
+  int32_t reconstruct;         /* RECONSTRUCT_FOR_PRESSURE (default True; .testing/tc4 sets False) */
+  int32_t Recon_Scheme;        /* PRESSURE_RECONSTRUCTION_SCHEME (1 = PLM when reconstruct) */
   int32_t boundary_extrap;     /* BOUNDARY_EXTRAPOLATION_PRESSURE (default True) */
   int32_t useMassWghtInterp;   /* MASS_WEIGHT_IN_PRESSURE_GRADIENT (default False) */
+  int32_t use_ALE;             /* associated(ALE_CSp): USE_REGRIDDING; `use_ALE = CS%reconstruct .and. use_EOS` (:562) only then */
+  int32_t nkmb;                /* GV%nk_rho_varies: the bulk mixed layer's variable-density layers (0 without one; layered mode) */
+  double P_Ref;                /* tv%P_Ref, the reference pressure of the coordinate density (read with nkmb > 0) */
+  const double *Rlay;          /* GV%Rlay(1:nk), HOST pointer: read with nkmb > 0 or without an equation of state; else NULL */
+  const double *g_prime;       /* GV%g_prime(1:nk+1), HOST pointer: Set_pbce_Bouss without an equation of state; else NULL */
 } mom6hip_pressureforce_cs_t;
 
 /*
  * PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)
  *                                                            src/core/MOM_PressureForce_FV.F90:462
- * tv%T, tv%S are passed as T, S; p_atm (2-D), pbce (3-D), eta (2-D) may be NULL.  Tides, SAL, the Stanley
- * SGS terms, GFS_scale < 1 and the non-ALE / PPM reconstructions are not provided.
+ * tv%T, tv%S are passed as T, S; p_atm (2-D), pbce (3-D), eta (2-D) may be NULL.  Branches (as the reference chooses them):
+ *   eos != NULL, use_ALE and reconstruct   int_density_dz_generic_plm on PLM edge values of T and S (:753-758)
+ *   eos != NULL otherwise                  int_density_dz (:765-768) -> the analytic integrals of the LINEAR and WRIGHT
+ *                                          forms (MOM_EOS_linear.F90:259, MOM_EOS_Wright.F90:389; EOS_QUADRATURE = False);
+ *                                          with nkmb > 0 the layers lighter than the buffer layer take its T and S (:650-670)
+ *   eos == NULL (T, S may be NULL)         the layered form with GV%Rlay (:775-789), Set_pbce_Bouss with GV%g_prime
+ * Tides, SAL, the Stanley SGS terms, GFS_scale < 1, the PPM reconstruction and the quadrature form of int_density_dz
+ * (EOS_QUADRATURE, or an equation of state without analytic integrals outside the PLM branch) are not provided.
  * Metrics needed: bathyT, IdxCu, IdyCv.
  */
 int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs, const mom6hip_eos_t *eos,

@@ -100,7 +100,8 @@ class EOS(C.Structure):
 
 class PressureForceCS(C.Structure):
     _fields_ = [("Rho0", C.c_double), ("GFS_scale", C.c_double), ("Z_ref", C.c_double), ("reconstruct", C.c_int32),
-                ("Recon_Scheme", C.c_int32), ("boundary_extrap", C.c_int32), ("useMassWghtInterp", C.c_int32)]
+                ("Recon_Scheme", C.c_int32), ("boundary_extrap", C.c_int32), ("useMassWghtInterp", C.c_int32),
+                ("use_ALE", C.c_int32), ("nkmb", C.c_int32), ("P_Ref", C.c_double), ("Rlay", C.c_void_p), ("g_prime", C.c_void_p)]
 
 
 # ---- MOM_barotropic -----------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ EXPORTS = (
     "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_pressureforce_fv_nonbouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
     "mom6hip_barotropic_init", "mom6hip_btcalc", "mom6hip_bt_mass_source", "mom6hip_set_dtbt", "mom6hip_btstep",
     "mom6hip_dyn_split_rk2_init", "mom6hip_step_dyn_split_rk2", "mom6hip_dyn_split_rk2b_init", "mom6hip_step_dyn_split_rk2b",
-    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats",
+    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_set_h_vel_via_dz", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats",
     "mom6hip_vertvisc_coef", "mom6hip_vertvisc", "mom6hip_vertvisc_remnant", "mom6hip_vertvisc_ntrunc", "mom6hip_vertvisc_and_remnant", "mom6hip_vertvisc_step",
     "mom6hip_hor_visc_init", "mom6hip_horizontal_viscosity", "mom6hip_set_viscous_bbl", "mom6hip_set_viscous_ml",
     "mom6hip_chksum", "mom6hip_reproducing_sum", "mom6hip_write_energy_sums", "mom6hip_depth_list_create", "mom6hip_write_energy_ape", "mom6hip_host_register", "mom6hip_host_unregister", "mom6hip_stage_to_host",

@@ -95,6 +95,7 @@ def _setup_regrid():
     if not getattr(L, "_regrid_ready", False):
         L.mom6hip_ale_regrid.argtypes = [C.c_void_p, C.POINTER(_abi.RegriddingCS)] + [C.c_void_p] * 3 + [C.c_int32]
         L.mom6hip_ale_remap_set_h_vel.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int32]
+        L.mom6hip_ale_remap_set_h_vel_via_dz.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32]
         L.mom6hip_ale_remap_velocities.argtypes = [C.c_void_p, C.POINTER(_abi.RemappingCS)] + [C.c_void_p] * 6 + [C.c_int32]
         L._regrid_ready = True
     return L
@@ -124,6 +125,15 @@ def ALE_remap_set_h_vel(CS, G: DeviceGrid, h_new, h_u, h_v, OBC=None, debug=Fals
         raise Mom6HipError("ALE_remap_set_h_vel (HIP): open boundaries are not supported")
     p, sp = _ptrs([h_new, h_u, h_v], "ALE_remap_set_h_vel")
     check(_setup_regrid().mom6hip_ale_remap_set_h_vel(G.handle, *p, sp), "ALE_remap_set_h_vel")
+
+
+def ALE_remap_set_h_vel_via_dz(CS, G: DeviceGrid, h_new, h_u, h_v, OBC, h_old, dzInterface, debug=False):
+    """ALE_remap_set_h_vel_via_dz(CS, G, GV, h_new, h_u, h_v, OBC, h_old, dzInterface, debug) -- MOM_ALE.F90:912
+    (REMAP_UV_USING_OLD_ALG = True, MOM.F90:1666)."""
+    if OBC is not None:
+        raise Mom6HipError("ALE_remap_set_h_vel_via_dz (HIP): open boundaries are not supported")
+    p, sp = _ptrs([h_old, dzInterface, h_u, h_v], "ALE_remap_set_h_vel_via_dz")
+    check(_setup_regrid().mom6hip_ale_remap_set_h_vel_via_dz(G.handle, *p, sp), "ALE_remap_set_h_vel_via_dz")
 
 
 def ALE_remap_velocities(CS: RemappingCS, G: DeviceGrid, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug=False, dt=None,

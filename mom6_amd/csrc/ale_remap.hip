@@ -629,6 +629,18 @@ __global__ __launch_bounds__(64) void ale_set_h_vel_kernel(m6::GridDev g, const 
   if (i >= g.isc && g.mask2dCv[g.v2(i, j)] > 0.) h_v[g.v3(i, j, k)] = 0.5 * (h[g.h3(i, j, k)] + h[g.h3(i, j + 1, k)]);
 }
 
+// ALE_remap_set_h_vel_via_dz :938-949 (REMAP_UV_USING_OLD_ALG): the same thread map; dzi has nk+1 planes
+__global__ __launch_bounds__(64) void ale_set_h_vel_via_dz_kernel(m6::GridDev g, const double *__restrict__ h, const double *__restrict__ dzi,
+                                                                  double *__restrict__ h_u, double *__restrict__ h_v) {
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, k = blockIdx.z;
+  if (i > g.iec) return;
+  const long pl = (long)g.nih * g.njh, c = g.h2(i, j) + pl * k;
+  if (j >= g.jsc && g.mask2dCu[g.u2(i, j)] > 0.)
+    h_u[g.u3(i, j, k)] = m6::max2(0., 0.5 * (h[c] + h[c + 1]) + 0.5 * ((dzi[c] + dzi[c + 1]) - (dzi[c + pl] + dzi[c + pl + 1])));
+  if (i >= g.isc && g.mask2dCv[g.v2(i, j)] > 0.)
+    h_v[g.v3(i, j, k)] = m6::max2(0., 0.5 * (h[c] + h[c + g.nih]) + 0.5 * ((dzi[c] + dzi[c + g.nih]) - (dzi[c + pl] + dzi[c + pl + g.nih])));
+}
+
 // ======================================================================================================================
 // Wave-cooperative remapping: one 64-lane wave per column, every per-column array in LDS.
 // The lane-per-column kernels above keep ~12 KB of per-lane arrays in scratch and are bound by that traffic (96 GB per
@@ -1423,6 +1435,24 @@ extern "C" int mom6hip_ale_remap_set_h_vel(mom6hip_ctx_t *ctx, const double *h_n
   double *du = st.inout(h_u, bu), *dv = st.inout(h_v, bv);
   M6_REQUIRE(!st.failed(), "ALE_remap_set_h_vel: staging failed");
   hipLaunchKernelGGL(ale_set_h_vel_kernel, dim3((g.iec - g.isc + 2 + 63) / 64, g.jec - g.jsc + 2, g.nk), dim3(64), 0, ctx->stream, g, dh, du, dv);
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+// ALE_remap_set_h_vel_via_dz(CS, G, GV, h_new, h_u, h_v, OBC, h_old, dzInterface, debug), src/ALE/MOM_ALE.F90:912.
+extern "C" int mom6hip_ale_remap_set_h_vel_via_dz(mom6hip_ctx_t *ctx, const double *h_old, const double *dzInterface, double *h_u, double *h_v,
+                                                  int32_t memspace) {
+  M6_REQUIRE(ctx && h_old && dzInterface && h_u && h_v, "ALE_remap_set_h_vel_via_dz: null argument");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv, "ALE_remap_set_h_vel_via_dz: mask2dCu and mask2dCv are needed");
+  const size_t b3 = sizeof(double) * (size_t)g.nh3(), bu = sizeof(double) * (size_t)g.nu3(), bv = sizeof(double) * (size_t)g.nv3();
+  const size_t bi = b3 + sizeof(double) * (size_t)g.nih * g.njh;
+  m6::Stager st(ctx, memspace);
+  const double *dh = st.in(h_old, b3), *dz = st.in(dzInterface, bi);
+  double *du = st.inout(h_u, bu), *dv = st.inout(h_v, bv);
+  M6_REQUIRE(!st.failed(), "ALE_remap_set_h_vel_via_dz: staging failed");
+  hipLaunchKernelGGL(ale_set_h_vel_via_dz_kernel, dim3((g.iec - g.isc + 2 + 63) / 64, g.jec - g.jsc + 2, g.nk), dim3(64), 0, ctx->stream, g, dh, dz,
+                     du, dv);
   M6_HIP(hipGetLastError());
   return st.finish();
 }

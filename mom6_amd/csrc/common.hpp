@@ -78,6 +78,15 @@ struct DevBuf {
   void release();
 };
 
+// Device copy of a short host table of doubles (GV%Rlay, GV%g_prime ...): uploaded again only when the host's values have
+// changed, so a call in the time loop neither copies nor synchronises (context.hip)
+struct HostTable {
+  DevBuf buf;
+  std::vector<double> last;
+  const double *get(const double *host, size_t n);      // nullptr on failure (error set)
+};
+enum { TABLE_PGF_RLAY = 0, TABLE_PGF_GPRIME, TABLE_SVML_RLAY, TABLE_COUNT = 8 };
+
 }  // namespace m6
 
 // The opaque context of the C ABI.
@@ -95,6 +104,7 @@ struct mom6hip_ctx {
   m6::DevBuf hv_pack;           // the grid metrics of horizontal_viscosity gathered into planes of one shape (hor_visc.hip)
   bool hv_pack_ready = false;
   m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
+  m6::HostTable tables[m6::TABLE_COUNT];      // cached device copies of short host tables (m6::HostTable)
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
   std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)

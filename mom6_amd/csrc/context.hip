@@ -38,6 +38,17 @@ void DevBuf::release() {
   p = nullptr; bytes = 0;
 }
 
+const double *HostTable::get(const double *host, size_t n) {
+  if (!host || n == 0) { set_error("HostTable: null host table"); return nullptr; }
+  if (last.size() == n && buf.p && std::memcmp(last.data(), host, n * sizeof(double)) == 0) return (const double *)buf.p;
+  // the values changed (or first use): kernels in flight may still read the old copy
+  if (hipDeviceSynchronize() != hipSuccess) { set_error("HostTable: device synchronise failed"); return nullptr; }
+  if (buf.reserve(n * sizeof(double))) return nullptr;
+  if (hipMemcpy(buf.p, host, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("HostTable: upload failed"); return nullptr; }
+  last.assign(host, host + n);
+  return (const double *)buf.p;
+}
+
 void *Stager::scratch(size_t bytes) {
   if (next_ >= 64) { set_error("Stager: out of pool buffers"); fail_ = true; return nullptr; }
   DevBuf &b = ctx_->pool[next_++];
@@ -356,6 +367,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->pool) b.release();
   ctx->rk2_scratch.release();
   ctx->sv_rlay.release();
+  for (auto &t : ctx->tables) t.buf.release();
   ctx->hv_pack.release();
   ctx->ale_sub.release();
   ctx->vv_ntrunc.release();

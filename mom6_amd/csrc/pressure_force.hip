@@ -69,6 +69,10 @@ struct PgfArgs {
   int boundary_extrap, massw;
   double *za0;        // non-Boussinesq: the geopotential anomaly at the sea surface (2-D scratch)
   double H_to_RZ;     // non-Boussinesq: GV%H_to_RZ
+  // the int_density_dz / layered branches (pgf_pcm_*_kernel)
+  const double *Rlay, *g_prime;     // device copies of GV%Rlay(1:nk), GV%g_prime(1:nk+1) (or null)
+  int nkmb;                         // GV%nk_rho_varies
+  double P_Ref;                     // tv%P_Ref
 };
 
 // ---- column kernel -------------------------------------------------------------------------------
@@ -284,6 +288,264 @@ __global__ __launch_bounds__(64) void pgf_face_kernel(PgfArgs p) {
       const double en_Kp1 = p.e[n3 + pl];
       const double h_n = p.h[n3];
       const double inty_dpa = face_integral(p, c3, n3, oc, on, ec_K, ec_Kp1, en_K, en_Kp1);
+      p.PFv[g.v2(i, j) + plV * k] = (((pa_c * h_c + iz_c) - (pa_n * h_n + p.intz_dpa[n3])) +
+                                     ((h_n - h_c) * inty_pa - (en_Kp1 - ec_Kp1) * inty_dpa * g.Z_to_H)) *
+                                    (fy / ((h_c + h_n) + h_neglect));
+      inty_pa = inty_pa + inty_dpa;
+      pa_n = pa_n + p.dpa[n3];
+      en_K = en_Kp1;
+    }
+    pa_c = pa_c + dpa_c;
+    ec_K = ec_Kp1;
+  }
+}
+
+// ======== the branches without a reconstruction (MOM_PressureForce_FV.F90:765-789) ========================================
+// MODE 0: int_density_dz -> int_density_dz_linear (MOM_EOS_linear.F90:259-424); 1: int_density_dz_wright
+// (MOM_EOS_Wright.F90:389-640); 2: no equation of state, the layered form with GV%Rlay (:775-789).
+// The same split as the PLM pair: pgf_pcm_column_kernel forms e, dpa, intz_dpa (x Z_to_H), pbce and eta per column;
+// pgf_pcm_face_kernel the face integrals and PFu / PFv.  With a bulk mixed layer (nkmb > 0) the T and S of a layer below it
+// are the buffer layer's wherever GV%Rlay(k) is lighter than the buffer layer's coordinate density (tv_tmp, :650-670);
+// the selection is re-derived per column in both kernels (one EOS evaluation) rather than stored as two 3-D arrays.
+constexpr int PCM_LINEAR = 0, PCM_WRIGHT = 1, PCM_NOEOS = 2;
+
+struct PcmCol {      // tv_tmp of one column: which layers take the buffer layer's T and S
+  double T_bl, S_bl, Rho_cv_BL;
+  int nkmb;
+};
+__device__ __forceinline__ PcmCol pcm_col(const PgfArgs &p, long o2, long pl) {
+  PcmCol c; c.nkmb = p.nkmb; c.T_bl = 0.; c.S_bl = 0.; c.Rho_cv_BL = 0.;
+  if (p.nkmb > 0) {
+    c.T_bl = p.T[o2 + pl * (p.nkmb - 1)]; c.S_bl = p.S[o2 + pl * (p.nkmb - 1)];
+    c.Rho_cv_BL = eos_density(p.eos, c.T_bl, c.S_bl, p.P_Ref);      // :662
+  }
+  return c;
+}
+__device__ __forceinline__ void pcm_TS(const PgfArgs &p, const PcmCol &c, long o3, int k, double &T, double &S) {      // k zero-based
+  if (c.nkmb > 0 && k >= c.nkmb && p.Rlay[k] < c.Rho_cv_BL) { T = c.T_bl; S = c.S_bl; }
+  else { T = p.T[o3]; S = p.S[o3]; }
+}
+struct WrightTerms { double al0, p0, lambda; };
+__device__ __forceinline__ WrightTerms wright_terms(double T, double S) {      // MOM_EOS_Wright.F90:537-539
+  WrightTerms w;
+  w.al0 = (a0 + a1 * T) + a2 * S;
+  w.p0 = (b0 + b4 * S) + T * (b1 + T * ((b2 + b3 * T)) + b5 * S);
+  w.lambda = (c0 + c4 * S) + T * (c1 + T * ((c2 + c3 * T)) + c5 * S);
+  return w;
+}
+// the layer integral of the Wright form at one point :541-557 / :587-595; returns dpa, and intz_dpa through iz when asked
+template <bool WANT_IZ>
+__device__ __forceinline__ double wright_layer(double al0, double p0, double lambda, double dz, double zsum_half, double GxRho, double g_Earth,
+                                               double I_Rho, double rho_ref, double z0pres, double &iz) {
+  const double C1_3 = 1.0 / 3.0, C1_7 = 1.0 / 7.0, C1_9 = 1.0 / 9.0;
+  const double p_ave = -GxRho * (zsum_half - z0pres);
+  const double I_al0 = 1.0 / al0;
+  const double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+  const double eps = 0.5 * GxRho * dz * I_Lzz, eps2 = eps * eps;
+  if (WANT_IZ) {
+    const double rho_anom = (p0 + p_ave) * (I_Lzz * I_al0) - rho_ref;
+    const double rem = I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2)));
+    iz = 1.0 * (0.5 * g_Earth * rho_anom * (dz * dz) - dz * (1.0 + eps) * rem);
+    return 1.0 * (g_Earth * rho_anom * dz - 2.0 * eps * rem);
+  }
+  return 1.0 * (g_Earth * dz * ((p0 + p_ave) * (I_Lzz * I_al0) - rho_ref) -
+                2.0 * eps * I_Rho * (lambda * (I_al0 * I_al0)) * eps2 * (C1_3 + eps2 * (0.2 + eps2 * (C1_7 + C1_9 * eps2))));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void pgf_pcm_column_kernel(PgfArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.jsc - 1 + blockIdx.y;
+  if (i > g.iec + 1) return;
+  const int nz = g.nk;
+  const long o2 = g.h2(i, j), pl = (long)g.nih * g.njh;
+  double ek = -g.bathyT[o2];
+  p.e[o2 + pl * nz] = ek;
+  for (int k = nz - 1; k >= 0; k--) {
+    ek = ek + p.h[o2 + pl * k] * g.H_to_Z;
+    p.e[o2 + pl * k] = ek;
+  }
+  const double e_top = ek, e_bot = -g.bathyT[o2];
+  if (p.eta) p.eta[o2] = e_top * g.Z_to_H;
+  const double G_e = g.g_Earth, rho_ref = p.rho_ref;
+  const double GxRho = G_e * p.rho_ref, I_Rho = 1.0 / p.rho_ref;      // rho_0 = CS%Rho0 (:766)
+  const double Rho0xG = p.rho_ref * g.g_Earth, G_Rho0 = g.g_Earth / g.Rho0;
+  PcmCol col; col.nkmb = 0;
+  if (MODE != PCM_NOEOS) col = pcm_col(p, o2, pl);
+  double e_K = e_top, pbce_prev = 0.0, T_m = 0., S_m = 0.;
+  const double Ihtot_eos = g.H_to_Z / ((e_top - e_bot) + g.dZ_subroundoff);
+  const double Ihtot_lay = 1.0 / ((e_top - e_bot) + g.dZ_subroundoff);
+  for (int k = 0; k < nz; k++) {
+    const long o3 = o2 + pl * k;
+    const double e_Kp1 = p.e[o3 + pl];
+    double T_c = 0., S_c = 0.;
+    if (MODE == PCM_NOEOS) {      // :777-781
+      const double hk = p.h[o3];
+      const double dz_geo = g.g_Earth * g.H_to_Z * hk;
+      p.dpa[o3] = (p.Rlay[k] - rho_ref) * dz_geo;
+      p.intz_dpa[o3] = 0.5 * (p.Rlay[k] - rho_ref) * dz_geo * hk;
+    } else {
+      pcm_TS(p, col, o3, k, T_c, S_c);
+      const double dz = e_K - e_Kp1;
+      if (MODE == PCM_LINEAR) {      // MOM_EOS_linear.F90:339-344
+        const double rho_anom = (p.eos.Rho_T0_S0 - rho_ref) + p.eos.dRho_dT * T_c + p.eos.dRho_dS * S_c;
+        p.dpa[o3] = G_e * rho_anom * dz;
+        p.intz_dpa[o3] = (0.5 * G_e * rho_anom * (dz * dz)) * g.Z_to_H;
+      } else {
+        const WrightTerms w = wright_terms(T_c, S_c);
+        double iz;
+        p.dpa[o3] = wright_layer<true>(w.al0, w.p0, w.lambda, dz, 0.5 * (e_K + e_Kp1), GxRho, G_e, I_Rho, rho_ref, p.Z_ref, iz);
+        p.intz_dpa[o3] = iz * g.Z_to_H;
+      }
+    }
+    if (p.pbce) {      // Set_pbce_Bouss(e, tv_tmp, ...) MOM_PressureForce_Montgomery.F90:702-745
+      double pb;
+      if (MODE == PCM_NOEOS) {
+        if (k == 0) pb = p.g_prime[0] * g.H_to_Z;
+        else pb = pbce_prev + (p.g_prime[k] * g.H_to_Z) * ((e_K - e_bot) * Ihtot_lay);
+      } else {
+        const double press = -Rho0xG * (e_K - p.Z_ref);
+        if (k == 0) {
+          const double rho_in_situ = eos_density(p.eos, T_c, S_c, press);
+          pb = G_Rho0 * (p.GFS_scale * rho_in_situ) * g.H_to_Z;
+        } else {
+          const double T_int = 0.5 * (T_m + T_c), S_int = 0.5 * (S_m + S_c);
+          double dR_dT, dR_dS;
+          eos_density_derivs(p.eos, T_int, S_int, press, dR_dT, dR_dS);
+          pb = pbce_prev + G_Rho0 * ((e_K - e_bot) * Ihtot_eos) * (dR_dT * (T_c - T_m) + dR_dS * (S_c - S_m));
+        }
+      }
+      p.pbce[o3] = pb;
+      pbce_prev = pb;
+    }
+    e_K = e_Kp1; T_m = T_c; S_m = S_c;
+  }
+}
+
+// one face between the columns L and R of layer k (zero-based): intx_dpa / inty_dpa
+template <int MODE>
+__device__ __forceinline__ double pcm_face_integral(const PgfArgs &p, const PcmCol &cL, const PcmCol &cR, long L3, long R3, long oL2, long oR2,
+                                                    int k, double eL_K, double eL_Kp1, double eR_K, double eR_Kp1) {
+  const m6::GridDev &g = p.g;
+  const double G_e = g.g_Earth, rho_ref = p.rho_ref;
+  const double C1_6 = 1.0 / 6.0, C1_90 = 1.0 / 90.0;
+  if (MODE == PCM_NOEOS) {      // :782-789
+    const double dzgL = g.g_Earth * g.H_to_Z * p.h[L3], dzgR = g.g_Earth * g.H_to_Z * p.h[R3];
+    return 0.5 * (p.Rlay[k] - rho_ref) * (dzgL + dzgR);
+  }
+  double TL, SL, TR, SR;
+  pcm_TS(p, cL, L3, k, TL, SL); pcm_TS(p, cR, R3, k, TR, SR);
+  double hWght = 0.0;
+  if (p.massw) hWght = max3(0., -g.bathyT[oL2] - eR_K, -g.bathyT[oR2] - eL_K);
+  if (MODE == PCM_LINEAR) {      // MOM_EOS_linear.F90:346-383
+    const double R0 = p.eos.Rho_T0_S0, dRdT = p.eos.dRho_dT, dRdS = p.eos.dRho_dS;
+    if (hWght <= 0.0) {
+      const double dzL = eL_K - eL_Kp1, dzR = eR_K - eR_Kp1;
+      const double raL = (R0 - rho_ref) + (dRdT * TL + dRdS * SL);
+      const double raR = (R0 - rho_ref) + (dRdT * TR + dRdS * SR);
+      return G_e * C1_6 * (dzL * (2.0 * raL + raR) + dzR * (2.0 * raR + raL));
+    }
+    const double hL = (eL_K - eL_Kp1) + g.dZ_subroundoff;
+    const double hR = (eR_K - eR_Kp1) + g.dZ_subroundoff;
+    const double rr = (hL - hR) / (hL + hR);
+    hWght = hWght * (rr * rr);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    const double hWt_LL = (hWght * hL + hR * hL) * iDenom, hWt_LR = (hWght * hR) * iDenom;
+    const double hWt_RR = (hWght * hR + hR * hL) * iDenom, hWt_RL = (hWght * hL) * iDenom;
+    double intz[5];
+    intz[0] = p.dpa[L3]; intz[4] = p.dpa[R3];
+#pragma unroll
+    for (int m = 2; m <= 4; m++) {
+      const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+      const double wtT_L = wt_L * hWt_LL + wt_R * hWt_RL, wtT_R = wt_L * hWt_LR + wt_R * hWt_RR;
+      const double dz = wt_L * (eL_K - eL_Kp1) + wt_R * (eR_K - eR_Kp1);
+      const double rho_anom = (R0 - rho_ref) + (dRdT * (wtT_L * TL + wtT_R * TR) + dRdS * (wtT_L * SL + wtT_R * SR));
+      intz[m - 1] = G_e * rho_anom * dz;
+    }
+    return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
+  }
+  // MOM_EOS_Wright.F90:560-599
+  double hWt_LL, hWt_LR, hWt_RR, hWt_RL;
+  if (hWght > 0.) {
+    const double hL = (eL_K - eL_Kp1) + g.dZ_subroundoff;
+    const double hR = (eR_K - eR_Kp1) + g.dZ_subroundoff;
+    const double rr = (hL - hR) / (hL + hR);
+    hWght = hWght * (rr * rr);
+    const double iDenom = 1.0 / (hWght * (hR + hL) + hL * hR);
+    hWt_LL = (hWght * hL + hR * hL) * iDenom; hWt_LR = (hWght * hR) * iDenom;
+    hWt_RR = (hWght * hR + hR * hL) * iDenom; hWt_RL = (hWght * hL) * iDenom;
+  } else {
+    hWt_LL = 1.0; hWt_LR = 0.0; hWt_RR = 1.0; hWt_RL = 0.0;
+  }
+  const WrightTerms wL = wright_terms(TL, SL), wR = wright_terms(TR, SR);
+  const double GxRho = G_e * p.rho_ref, I_Rho = 1.0 / p.rho_ref;
+  double intz[5], unused;
+  intz[0] = p.dpa[L3]; intz[4] = p.dpa[R3];
+#pragma unroll
+  for (int m = 2; m <= 4; m++) {
+    const double wt_L = 0.25 * (double)(5 - m), wt_R = 1.0 - wt_L;
+    const double wtT_L = wt_L * hWt_LL + wt_R * hWt_RL, wtT_R = wt_L * hWt_LR + wt_R * hWt_RR;
+    const double al0 = wtT_L * wL.al0 + wtT_R * wR.al0;
+    const double p0 = wtT_L * wL.p0 + wtT_R * wR.p0;
+    const double lambda = wtT_L * wL.lambda + wtT_R * wR.lambda;
+    const double dz = wt_L * (eL_K - eL_Kp1) + wt_R * (eR_K - eR_Kp1);
+    intz[m - 1] = wright_layer<false>(al0, p0, lambda, dz, 0.5 * (wt_L * (eL_K + eL_Kp1) + wt_R * (eR_K + eR_Kp1)), GxRho, G_e, I_Rho, rho_ref,
+                                      p.Z_ref, unused);
+  }
+  return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void pgf_pcm_face_kernel(PgfArgs p) {
+  const m6::GridDev &g = p.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
+  const int j = g.jsc - 1 + blockIdx.y;
+  if (i > g.iec) return;
+  const bool do_x = (j >= g.jsc), do_y = (i >= g.isc);
+  if (!do_x && !do_y) return;
+  const int nz = g.nk;
+  const long pl = (long)g.nih * g.njh, plU = (long)(g.nih + 1) * g.njh, plV = (long)g.nih * (g.njh + 1);
+  const long oc = g.h2(i, j), oe = oc + 1, on = oc + g.nih;
+  const double h_neglect = g.H_subroundoff, I_Rho0 = 1.0 / g.Rho0;
+  const double rg = p.rho_ref * g.g_Earth;
+  auto pa0 = [&](long o2) -> double {
+    double v = rg * (p.e[o2] - p.Z_ref);
+    if (p.p_atm) v = v + p.p_atm[o2];
+    return v;
+  };
+  PcmCol cc, ce, cn; cc.nkmb = ce.nkmb = cn.nkmb = 0;
+  if (MODE != PCM_NOEOS) {
+    cc = pcm_col(p, oc, pl);
+    if (do_x) ce = pcm_col(p, oe, pl);
+    if (do_y) cn = pcm_col(p, on, pl);
+  }
+  double pa_c = pa0(oc), pa_e = do_x ? pa0(oe) : 0.0, pa_n = do_y ? pa0(on) : 0.0;
+  double intx_pa = 0.5 * (pa_c + pa_e), inty_pa = 0.5 * (pa_c + pa_n);
+  const double fx = do_x ? (2.0 * I_Rho0 * g.IdxCu[g.u2(i, j)]) : 0.0;
+  const double fy = do_y ? (2.0 * I_Rho0 * g.IdyCv[g.v2(i, j)]) : 0.0;
+  double ec_K = p.e[oc], ee_K = do_x ? p.e[oe] : 0.0, en_K = do_y ? p.e[on] : 0.0;
+  for (int k = 0; k < nz; k++) {
+    const long c3 = oc + pl * k;
+    const double ec_Kp1 = p.e[c3 + pl];
+    const double h_c = p.h[c3], dpa_c = p.dpa[c3], iz_c = p.intz_dpa[c3];
+    if (do_x) {
+      const long e3 = c3 + 1;
+      const double ee_Kp1 = p.e[e3 + pl];
+      const double h_e = p.h[e3];
+      const double intx_dpa = pcm_face_integral<MODE>(p, cc, ce, c3, e3, oc, oe, k, ec_K, ec_Kp1, ee_K, ee_Kp1);
+      p.PFu[g.u2(i, j) + plU * k] = (((pa_c * h_c + iz_c) - (pa_e * h_e + p.intz_dpa[e3])) +
+                                     ((h_e - h_c) * intx_pa - (ee_Kp1 - ec_Kp1) * intx_dpa * g.Z_to_H)) *
+                                    (fx / ((h_c + h_e) + h_neglect));
+      intx_pa = intx_pa + intx_dpa;
+      pa_e = pa_e + p.dpa[e3];
+      ee_K = ee_Kp1;
+    }
+    if (do_y) {
+      const long n3 = c3 + g.nih;
+      const double en_Kp1 = p.e[n3 + pl];
+      const double h_n = p.h[n3];
+      const double inty_dpa = pcm_face_integral<MODE>(p, cc, cn, c3, n3, oc, on, k, ec_K, ec_Kp1, en_K, en_Kp1);
       p.PFv[g.v2(i, j) + plV * k] = (((pa_c * h_c + iz_c) - (pa_n * h_n + p.intz_dpa[n3])) +
                                      ((h_n - h_c) * inty_pa - (en_Kp1 - ec_Kp1) * inty_dpa * g.Z_to_H)) *
                                     (fy / ((h_c + h_n) + h_neglect));
@@ -540,36 +802,80 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
                                               const double *S, const double *p_atm, double *PFu, double *PFv,
                                               double *pbce, double *eta, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr && cs != nullptr, "MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.");
-  M6_REQUIRE(h && T && S && PFu && PFv, "PressureForce_FV_Bouss: null argument");
+  M6_REQUIRE(h && PFu && PFv, "PressureForce_FV_Bouss: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "PressureForce_FV_Bouss: bad memspace");
-  if (check_eos(eos)) return 2;
-  M6_REQUIRE(cs->reconstruct && cs->Recon_Scheme == 1,
-             "PressureForce_FV_Bouss: only RECONSTRUCT_FOR_PRESSURE=True with PRESSURE_RECONSTRUCTION_SCHEME=1 is provided");
+  const bool use_EOS = (eos != nullptr);      // associated(tv%eqn_of_state)
+  if (use_EOS) {
+    if (check_eos(eos)) return 2;
+    M6_REQUIRE(T && S, "PressureForce_FV_Bouss: tv%%T and tv%%S are needed with an equation of state");
+  }
+  const bool use_ALE = cs->use_ALE && cs->reconstruct && use_EOS;      // :561-562
+  M6_REQUIRE(!use_ALE || cs->Recon_Scheme == 1,
+             "PressureForce_FV_Bouss: with RECONSTRUCT_FOR_PRESSURE only PRESSURE_RECONSTRUCTION_SCHEME=1 (PLM) is provided");
   M6_REQUIRE(cs->GFS_scale == 1.0, "PressureForce_FV_Bouss: GFS_scale < 1 is not provided");
+  M6_REQUIRE(cs->nkmb >= 0 && cs->nkmb < ctx->g.nk, "PressureForce_FV_Bouss: GV%%nk_rho_varies must be in 0 .. nk-1");
+  M6_REQUIRE(!(use_ALE && cs->nkmb > 0), "PressureForce_FV_Bouss: a bulk mixed layer cannot be used with ALE");
+  int mode = -1;
+  if (use_EOS && !use_ALE) {
+    M6_REQUIRE(eos->form == MOM6HIP_EOS_LINEAR || eos->form == MOM6HIP_EOS_WRIGHT,
+               "PressureForce_FV_Bouss: without the PLM reconstruction (RECONSTRUCT_FOR_PRESSURE = False, or no ALE) int_density_dz is "
+               "provided for EQN_OF_STATE = LINEAR and WRIGHT (their analytic integrals; EOS_QUADRATURE = False)");
+    mode = eos->form == MOM6HIP_EOS_LINEAR ? PCM_LINEAR : PCM_WRIGHT;
+  } else if (!use_EOS) {
+    mode = PCM_NOEOS;
+    M6_REQUIRE(cs->Rlay, "PressureForce_FV_Bouss: GV%%Rlay is needed without an equation of state");
+    M6_REQUIRE(!pbce || cs->g_prime, "PressureForce_FV_Bouss: GV%%g_prime is needed for pbce without an equation of state");
+  }
+  M6_REQUIRE(cs->nkmb == 0 || cs->Rlay, "PressureForce_FV_Bouss: GV%%Rlay is needed with a bulk mixed layer");
   m6::GridDev &g = ctx->g;
   M6_REQUIRE(g.bathyT && g.IdxCu && g.IdyCv, "PressureForce_FV_Bouss: a required grid metric is missing");
-  M6_REQUIRE(g.nk >= 2, "PressureForce_FV_Bouss: at least 2 layers are needed");
+  M6_REQUIRE(g.nk >= 2 || !use_ALE, "PressureForce_FV_Bouss: at least 2 layers are needed");
   M6_REQUIRE(g.isc - g.isd >= 1 && g.ied - g.iec >= 1 && g.jsc - g.jsd >= 1 && g.jed - g.jec >= 1,
              "PressureForce_FV_Bouss: needs a halo of at least 1");
   hipStream_t s = ctx->stream;
   const size_t bH = (size_t)g.nh3() * 8, bU = (size_t)g.nu3() * 8, bV = (size_t)g.nv3() * 8;
   const size_t bH2 = (size_t)g.nih * g.njh * 8;
-  m6::Stager st(ctx, memspace);
   PgfArgs a;
+  a.Rlay = a.g_prime = nullptr;
+  if (cs->Rlay && (mode == PCM_NOEOS || cs->nkmb > 0)) {
+    a.Rlay = ctx->tables[m6::TABLE_PGF_RLAY].get(cs->Rlay, (size_t)g.nk);
+    if (!a.Rlay) return 1;
+  }
+  if (mode == PCM_NOEOS && pbce) {
+    a.g_prime = ctx->tables[m6::TABLE_PGF_GPRIME].get(cs->g_prime, (size_t)g.nk + 1);
+    if (!a.g_prime) return 1;
+  }
+  m6::Stager st(ctx, memspace);
   a.g = g;
-  a.eos = EosDev{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS};
-  a.h = st.in(h, bH); a.T = st.in(T, bH); a.S = st.in(S, bH); a.p_atm = st.in(p_atm, bH2);
+  a.eos = use_EOS ? EosDev{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS} : EosDev{0, 0., 0., 0.};
+  a.h = st.in(h, bH); a.T = use_EOS ? st.in(T, bH) : nullptr; a.S = use_EOS ? st.in(S, bH) : nullptr; a.p_atm = st.in(p_atm, bH2);
   a.PFu = st.inout(PFu, bU); a.PFv = st.inout(PFv, bV); a.pbce = st.inout(pbce, bH); a.eta = st.inout(eta, bH2);
   a.e = (double *)st.scratch(bH + bH2);
-  a.T_t = (double *)st.scratch(bH); a.T_b = (double *)st.scratch(bH);
-  a.S_t = (double *)st.scratch(bH); a.S_b = (double *)st.scratch(bH);
+  a.T_t = a.T_b = a.S_t = a.S_b = nullptr;
+  if (use_ALE) {
+    a.T_t = (double *)st.scratch(bH); a.T_b = (double *)st.scratch(bH);
+    a.S_t = (double *)st.scratch(bH); a.S_b = (double *)st.scratch(bH);
+  }
   a.dpa = (double *)st.scratch(bH); a.intz_dpa = (double *)st.scratch(bH);
   if (st.failed()) return 1;
   a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale; a.za0 = nullptr; a.H_to_RZ = 0.0;
   a.boundary_extrap = cs->boundary_extrap; a.massw = cs->useMassWghtInterp;
+  a.nkmb = use_EOS ? cs->nkmb : 0; a.P_Ref = cs->P_Ref;
   const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
-  hipLaunchKernelGGL(pgf_column_kernel, dim3((ncol_i + 63) / 64, ncol_j), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(pgf_face_kernel, dim3((ncol_i - 1 + 63) / 64, ncol_j - 1), dim3(64), 0, s, a);
+  const dim3 gc((ncol_i + 63) / 64, ncol_j), gf((ncol_i - 1 + 63) / 64, ncol_j - 1);
+  if (use_ALE) {
+    hipLaunchKernelGGL(pgf_column_kernel, gc, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pgf_face_kernel, gf, dim3(64), 0, s, a);
+  } else if (mode == PCM_LINEAR) {
+    hipLaunchKernelGGL(pgf_pcm_column_kernel<PCM_LINEAR>, gc, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pgf_pcm_face_kernel<PCM_LINEAR>, gf, dim3(64), 0, s, a);
+  } else if (mode == PCM_WRIGHT) {
+    hipLaunchKernelGGL(pgf_pcm_column_kernel<PCM_WRIGHT>, gc, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pgf_pcm_face_kernel<PCM_WRIGHT>, gf, dim3(64), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(pgf_pcm_column_kernel<PCM_NOEOS>, gc, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pgf_pcm_face_kernel<PCM_NOEOS>, gf, dim3(64), 0, s, a);
+  }
   M6_HIP(hipGetLastError());
   return st.finish();
 }
@@ -582,8 +888,8 @@ extern "C" int mom6hip_pressureforce_fv_nonbouss(mom6hip_ctx_t *ctx, const mom6h
   M6_REQUIRE(h && T && S && PFu && PFv, "PressureForce_FV_nonBouss: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "PressureForce_FV_nonBouss: bad memspace");
   if (check_eos(eos)) return 2;
-  M6_REQUIRE(cs->reconstruct && cs->Recon_Scheme == 1,
-             "PressureForce_FV_nonBouss: only RECONSTRUCT_FOR_PRESSURE=True with PRESSURE_RECONSTRUCTION_SCHEME=1 is provided");
+  M6_REQUIRE(cs->use_ALE && cs->reconstruct && cs->Recon_Scheme == 1,
+             "PressureForce_FV_nonBouss: only ALE with RECONSTRUCT_FOR_PRESSURE=True and PRESSURE_RECONSTRUCTION_SCHEME=1 is provided");
   M6_REQUIRE(cs->GFS_scale == 1.0, "PressureForce_FV_nonBouss: GFS_scale < 1 is not provided");
   M6_REQUIRE(H_to_RZ > 0.0, "PressureForce_FV_nonBouss: H_to_RZ must be positive");
   m6::GridDev &g = ctx->g;
@@ -607,6 +913,7 @@ extern "C" int mom6hip_pressureforce_fv_nonbouss(mom6hip_ctx_t *ctx, const mom6h
   a.za0 = (double *)st.scratch(bH2);
   if (st.failed()) return 1;
   a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale; a.H_to_RZ = H_to_RZ;
+  a.Rlay = a.g_prime = nullptr; a.nkmb = 0; a.P_Ref = 0.0;
   a.boundary_extrap = cs->boundary_extrap; a.massw = cs->useMassWghtInterp;
   const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
   hipLaunchKernelGGL(pgfnb_column_kernel, dim3((ncol_i + 63) / 64, ncol_j), dim3(64), 0, s, a);

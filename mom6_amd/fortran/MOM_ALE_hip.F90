@@ -27,7 +27,7 @@ implicit none ; private
 
 #include <MOM_memory.h>
 
-public ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities
+public ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_set_h_vel_via_dz, ALE_remap_velocities
 public ALE_update_regrid_weights, ALE_set_extrap_boundaries
 
 !> ALE control structure (the members of the reference's ALE_CS :62-123 and of its regridding_CS / remapping_CS that the
@@ -93,7 +93,7 @@ subroutine ALE_init(param_file, GV, US, max_depth, CS)
   call log_version(param_file, mdl, version, "")
   call get_param(param_file, mdl, "REMAP_UV_USING_OLD_ALG", CS%remap_uv_using_old_alg, &
                  "If true, uses the old remapping-via-a-delta-z method for remapping u and v.", default=.false.)
-  if (CS%remap_uv_using_old_alg) call MOM_error(FATAL, "ALE_init (HIP): REMAP_UV_USING_OLD_ALG is not provided by the GPU path.")
+  ! REMAP_UV_USING_OLD_ALG = True (.testing/tc2, tc4): MOM.F90:1666 then calls ALE_remap_set_h_vel_via_dz, which is provided
 
   ! ALE_initRegridding :1667 -> initialize_regridding (MOM_regridding.F90:180)
   call get_param(param_file, mdl, "REGRIDDING_COORDINATE_MODE", coord_mode, &
@@ -289,6 +289,25 @@ subroutine ALE_remap_set_h_vel(CS, G, GV, h_new, h_u, h_v, OBC, debug)
   rc = mom6hip_ale_remap_set_h_vel(mom6hip_shared_context(G, GV), c_loc(h_new), c_loc(h_u), c_loc(h_v), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "ALE_remap_set_h_vel")
 end subroutine ALE_remap_set_h_vel
+
+!> Same interface as the reference ALE_remap_set_h_vel_via_dz (:912), the new velocity-point grid of REMAP_UV_USING_OLD_ALG
+subroutine ALE_remap_set_h_vel_via_dz(CS, G, GV, h_new, h_u, h_v, OBC, h_old, dzInterface, debug)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h_new
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(inout) :: h_u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(inout) :: h_v
+  type(ocean_OBC_type),                      pointer       :: OBC
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in)    :: h_old
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)+1), target, intent(in)  :: dzInterface
+  logical,                         optional, intent(in)    :: debug
+  integer :: rc
+  if (associated(OBC)) call MOM_error(FATAL, "ALE_remap_set_h_vel_via_dz (HIP): open boundaries are not provided by the GPU path.")
+  rc = mom6hip_ale_remap_set_h_vel_via_dz(mom6hip_shared_context(G, GV), c_loc(h_old), c_loc(dzInterface), c_loc(h_u), c_loc(h_v), &
+                                          MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "ALE_remap_set_h_vel_via_dz")
+end subroutine ALE_remap_set_h_vel_via_dz
 
 !> Same interface as the reference ALE_remap_velocities (:1061)
 subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)

@@ -72,6 +72,7 @@ subroutine PressureForce_FV_nonBouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_
   ccs%Rho0 = CS%Rho0 ; ccs%GFS_scale = CS%GFS_scale ; ccs%Z_ref = G%Z_ref
   ccs%reconstruct = merge(1, 0, CS%reconstruct) ; ccs%Recon_Scheme = CS%Recon_Scheme
   ccs%boundary_extrap = merge(1, 0, CS%boundary_extrap) ; ccs%useMassWghtInterp = merge(1, 0, CS%useMassWghtInterp)
+  ccs%use_ALE = merge(1, 0, associated(ALE_CSp)) ; ccs%nkmb = 0 ; ccs%P_Ref = tv%P_Ref
   p_patm = c_null_ptr ; if (associated(p_atm)) p_patm = c_loc(p_atm)
   p_pbce = c_null_ptr ; if (present(pbce)) p_pbce = c_loc(pbce)
   p_eta = c_null_ptr ; if (present(eta)) p_eta = c_loc(eta)
@@ -80,35 +81,45 @@ subroutine PressureForce_FV_nonBouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_
   call mom6hip_fatal_if(rc, "MOM_PressureForce_FV_nonBouss")
 end subroutine PressureForce_FV_nonBouss
 
-!> Same interface as the reference PressureForce_FV_Bouss (:462).
+!> Same interface as the reference PressureForce_FV_Bouss (:462).  The branch is chosen as the reference chooses it (:559-562,
+!! :746-789): with an equation of state, ALE and RECONSTRUCT_FOR_PRESSURE the PLM form; with an equation of state otherwise
+!! int_density_dz (the analytic LINEAR / WRIGHT integrals), with the bulk mixed layer's replacement of light layers when
+!! GV%nk_rho_varies > 0; without an equation of state the layered form with GV%Rlay and GV%g_prime.
 subroutine PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)
   type(ocean_grid_type),   intent(in)  :: G
-  type(verticalGrid_type), intent(in)  :: GV
+  type(verticalGrid_type), target, intent(in)  :: GV
   type(unit_scale_type),   intent(in)  :: US
   real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(in)  :: h
   type(thermo_var_ptrs),   intent(in)  :: tv
   real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(out) :: PFu
   real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(out) :: PFv
-  type(PressureForce_FV_CS), intent(in) :: CS
+  type(PressureForce_FV_CS), target, intent(in) :: CS
   type(ALE_CS),            pointer     :: ALE_CSp
   real, dimension(:,:),    pointer     :: p_atm
   real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, optional, intent(out) :: pbce
   real, dimension(SZI_(G),SZJ_(G)),          target, optional, intent(out) :: eta
 
   type(mom6hip_pressureforce_cs_t) :: ccs
-  type(c_ptr) :: p_patm, p_pbce, p_eta
+  type(c_ptr) :: p_patm, p_pbce, p_eta, p_eos, p_T, p_S
+  logical :: use_EOS
   integer :: rc
 
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.")
-  if (.not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "MOM_PressureForce_FV_Bouss (HIP): "// &
-       "the GPU path needs temperature and salinity (USE_EOS); the layered mode with GV%Rlay is not provided.")
+  use_EOS = associated(tv%eqn_of_state)
+  if (use_EOS .and. .not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "MOM_PressureForce_FV_Bouss (HIP): "// &
+       "an equation of state needs tv%T and tv%S.")
   ccs%Rho0 = CS%Rho0 ; ccs%GFS_scale = CS%GFS_scale ; ccs%Z_ref = G%Z_ref
   ccs%reconstruct = merge(1, 0, CS%reconstruct) ; ccs%Recon_Scheme = CS%Recon_Scheme
   ccs%boundary_extrap = merge(1, 0, CS%boundary_extrap) ; ccs%useMassWghtInterp = merge(1, 0, CS%useMassWghtInterp)
+  ccs%use_ALE = merge(1, 0, associated(ALE_CSp)) ; ccs%nkmb = GV%nk_rho_varies ; ccs%P_Ref = tv%P_Ref
+  ccs%Rlay = c_null_ptr ; if (allocated(GV%Rlay)) ccs%Rlay = c_loc(GV%Rlay)
+  ccs%g_prime = c_null_ptr ; if (allocated(GV%g_prime)) ccs%g_prime = c_loc(GV%g_prime)
+  p_eos = c_null_ptr ; p_T = c_null_ptr ; p_S = c_null_ptr
+  if (use_EOS) then ; p_eos = c_loc(CS%eos) ; p_T = c_loc(tv%T) ; p_S = c_loc(tv%S) ; endif
   p_patm = c_null_ptr ; if (associated(p_atm)) p_patm = c_loc(p_atm)
   p_pbce = c_null_ptr ; if (present(pbce)) p_pbce = c_loc(pbce)
   p_eta = c_null_ptr ; if (present(eta)) p_eta = c_loc(eta)
-  rc = mom6hip_pressureforce_fv_bouss(mom6hip_shared_context(G, GV), ccs, CS%eos, c_loc(h), c_loc(tv%T), c_loc(tv%S), p_patm, &
+  rc = mom6hip_pressureforce_fv_bouss(mom6hip_shared_context(G, GV), ccs, p_eos, c_loc(h), p_T, p_S, p_patm, &
                                       c_loc(PFu), c_loc(PFv), p_pbce, p_eta, MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "MOM_PressureForce_FV_Bouss")
 end subroutine PressureForce_FV_Bouss

@@ -100,6 +100,11 @@ end type mom6hip_eos_t
 type, bind(c) :: mom6hip_pressureforce_cs_t
   real(c_double) :: Rho0, GFS_scale, Z_ref
   integer(c_int32_t) :: reconstruct, Recon_Scheme, boundary_extrap, useMassWghtInterp
+  integer(c_int32_t) :: use_ALE = 1   !< associated(ALE_CSp)
+  integer(c_int32_t) :: nkmb = 0      !< GV%nk_rho_varies
+  real(c_double) :: P_Ref = 2.0d7     !< tv%P_Ref
+  type(c_ptr) :: Rlay = c_null_ptr    !< GV%Rlay(1:nk): with nkmb > 0 or without an equation of state
+  type(c_ptr) :: g_prime = c_null_ptr !< GV%g_prime(1:nk+1): without an equation of state
 end type mom6hip_pressureforce_cs_t
 
 !> mom6hip_barotropic_cs_t (barotropic_CS, src/core/MOM_barotropic.F90:104)
@@ -321,6 +326,14 @@ interface
     integer(c_int) :: rc
   end function mom6hip_ale_remap_set_h_vel
 
+  function mom6hip_ale_remap_set_h_vel_via_dz(ctx, h_old, dzInterface, h_u, h_v, memspace) &
+                                              bind(c, name="mom6hip_ale_remap_set_h_vel_via_dz") result(rc)
+    import :: c_int, c_int32_t, c_ptr
+    type(c_ptr), value :: ctx, h_old, dzInterface, h_u, h_v
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_ale_remap_set_h_vel_via_dz
+
   function mom6hip_ale_remap_velocities(ctx, cs, h_old_u, h_old_v, h_new_u, h_new_v, u, v, memspace) &
                                         bind(c, name="mom6hip_ale_remap_velocities") result(rc)
     import :: c_int, c_int32_t, c_ptr, mom6hip_remapping_cs_t
@@ -447,12 +460,12 @@ interface
     integer(c_int) :: rc
   end function mom6hip_continuity
 
+  !> eos: c_loc of a mom6hip_eos_t, or c_null_ptr without an equation of state (use_EOS = .false.; T and S may be null then)
   function mom6hip_pressureforce_fv_bouss(ctx, cs, eos, h, T, S, p_atm, PFu, PFv, pbce, eta, memspace) &
                                           bind(c, name="mom6hip_pressureforce_fv_bouss") result(rc)
-    import :: c_int, c_int32_t, c_ptr, mom6hip_pressureforce_cs_t, mom6hip_eos_t
-    type(c_ptr), value :: ctx, h, T, S, p_atm, PFu, PFv, pbce, eta
+    import :: c_int, c_int32_t, c_ptr, mom6hip_pressureforce_cs_t
+    type(c_ptr), value :: ctx, eos, h, T, S, p_atm, PFu, PFv, pbce, eta
     type(mom6hip_pressureforce_cs_t), intent(in) :: cs
-    type(mom6hip_eos_t), intent(in) :: eos
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_pressureforce_fv_bouss

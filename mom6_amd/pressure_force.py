@@ -18,16 +18,26 @@ def EOS_init(form="WRIGHT", Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.8):
     return _abi.EOS(_abi.EOS_FORMS[form], 0, float(Rho_T0_S0), float(dRho_dT), float(dRho_dS))
 
 
-def PressureForce_init(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False, Z_ref=0.0):
-    """PressureForce_FV_init (MOM_PressureForce_FV.F90:921): RHO_PGF_REF, BOUNDARY_EXTRAPOLATION_PRESSURE,
-    MASS_WEIGHT_IN_PRESSURE_GRADIENT; ANALYTIC_FV_PGF with PLM reconstruction is what is provided."""
-    return _abi.PressureForceCS(float(grid.Rho0 if Rho0 is None else Rho0), 1.0, float(Z_ref), 1, 1,
-                                int(bool(boundary_extrap)), int(bool(useMassWghtInterp)))
+def PressureForce_init(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False, Z_ref=0.0, reconstruct=True, use_ALE=True,
+                       nk_rho_varies=0, P_Ref=2.0e7, Rlay=None, g_prime=None):
+    """PressureForce_FV_init (MOM_PressureForce_FV.F90:921): RHO_PGF_REF, RECONSTRUCT_FOR_PRESSURE,
+    BOUNDARY_EXTRAPOLATION_PRESSURE, MASS_WEIGHT_IN_PRESSURE_GRADIENT, and what PressureForce_FV_Bouss takes from its other
+    arguments to choose its branch: use_ALE = associated(ALE_CSp), GV%nk_rho_varies, tv%P_Ref, GV%Rlay, GV%g_prime."""
+    import numpy as np
+    cs = _abi.PressureForceCS(float(grid.Rho0 if Rho0 is None else Rho0), 1.0, float(Z_ref), int(bool(reconstruct)), 1,
+                              int(bool(boundary_extrap)), int(bool(useMassWghtInterp)), int(bool(use_ALE)), int(nk_rho_varies),
+                              float(P_Ref), None, None)
+    cs._keep = []
+    for name, a in (("Rlay", Rlay), ("g_prime", g_prime)):
+        if a is not None:
+            a = np.ascontiguousarray(a, dtype=np.float64); cs._keep.append(a)
+            setattr(cs, name, a.ctypes.data)
+    return cs
 
 
 def PressureForce(h, tv, PFu, PFv, G: DeviceGrid, CS, ALE_CSp=None, p_atm=None, pbce=None, eta=None, Boussinesq=True, H_to_RZ=1.0):
     """PressureForce(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta) -- MOM_PressureForce.F90:41.
-    `tv` is (T, S, EOS).  Boussinesq=False (GV%Boussinesq, MOM_PressureForce_FV.F90:89): PressureForce_FV_nonBouss with h in
+    `tv` is (T, S, EOS); EOS None = no equation of state (layer densities GV%Rlay; T and S may be None).  Boussinesq=False (GV%Boussinesq, MOM_PressureForce_FV.F90:89): PressureForce_FV_nonBouss with h in
     mass per unit area and H_to_RZ = GV%H_to_RZ."""
     if CS is None:
         raise Mom6HipError("MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.")
@@ -48,5 +58,5 @@ def PressureForce(h, tv, PFu, PFv, G: DeviceGrid, CS, ALE_CSp=None, p_atm=None, 
         check(lib().mom6hip_pressureforce_fv_nonbouss(G.handle, C.byref(CS), C.byref(EOS), *args[:4], float(H_to_RZ), *args[4:], spaces.pop()),
               "PressureForce_FV_nonBouss")
         return
-    check(lib().mom6hip_pressureforce_fv_bouss(G.handle, C.byref(CS), C.byref(EOS), *args, spaces.pop()),
+    check(lib().mom6hip_pressureforce_fv_bouss(G.handle, C.byref(CS), C.byref(EOS) if EOS is not None else None, *args, spaces.pop()),
           "PressureForce_FV_Bouss")

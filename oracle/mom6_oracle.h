@@ -119,6 +119,7 @@ int orc_ale_remap_tracers(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t 
 /* ---- z* regridding and velocity remapping (oracle/regridding.c) ------------------------------------------ */
 int orc_ale_regrid(const mom6hip_grid_t *G, const mom6hip_regridding_cs_t *CS, const double *h, double *h_new, double *dzRegrid);
 int orc_ale_remap_set_h_vel(const mom6hip_grid_t *G, const double *h_new, double *h_u, double *h_v);
+int orc_ale_remap_set_h_vel_via_dz(const mom6hip_grid_t *G, const double *h_old, const double *dzInterface, double *h_u, double *h_v);
 int orc_ale_remap_velocities(const mom6hip_grid_t *G, const mom6hip_remapping_cs_t *cs, const double *h_old_u, const double *h_old_v,
                              const double *h_new_u, const double *h_new_v, double *u, double *v);
 

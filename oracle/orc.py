@@ -330,20 +330,30 @@ def eos_density_derivs(E, T, S, p):
     return a.value, b.value
 
 
-def pressureforce_cs(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False):
-    return _abi.PressureForceCS(grid.Rho0 if Rho0 is None else Rho0, 1.0, 0.0, 1, 1, int(boundary_extrap),
-                                int(useMassWghtInterp))
+def pressureforce_cs(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False, reconstruct=True, use_ALE=True, nkmb=0,
+                     P_Ref=2.0e7, Rlay=None, g_prime=None):
+    """PressureForce_FV_CS + the branch selectors of PressureForce_FV_Bouss (use_ALE = associated(ALE_CSp), nkmb =
+    GV%nk_rho_varies, tv%P_Ref, GV%Rlay, GV%g_prime)"""
+    cs = _abi.PressureForceCS(grid.Rho0 if Rho0 is None else Rho0, 1.0, 0.0, int(reconstruct), 1, int(boundary_extrap),
+                              int(useMassWghtInterp), int(use_ALE), int(nkmb), float(P_Ref), None, None)
+    cs._keep = []
+    for name, a in (("Rlay", Rlay), ("g_prime", g_prime)):
+        if a is not None:
+            a = np.ascontiguousarray(a, dtype=np.float64); cs._keep.append(a)
+            setattr(cs, name, a.ctypes.data)
+    return cs
 
 
 def pressureforce(grid, cs, E, h, T, S, p_atm=None, want_pbce=True, want_eta=True):
+    """E None: no equation of state (T, S unused)"""
     L = lib()
     L.orc_pressureforce_fv_bouss.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.PressureForceCS),
                                              C.POINTER(_abi.EOS)] + [_dp] * 8
     PFu, PFv = grid.zeros3(_abi.POS_U), grid.zeros3(_abi.POS_V)
     pbce = grid.zeros3(_abi.POS_H) if want_pbce else None
     eta = grid.zeros2(_abi.POS_H) if want_eta else None
-    rc = L.orc_pressureforce_fv_bouss(C.byref(grid.struct()), C.byref(cs), C.byref(E), _p(h), _p(T), _p(S), _p(p_atm),
-                                      _p(PFu), _p(PFv), _p(pbce), _p(eta))
+    rc = L.orc_pressureforce_fv_bouss(C.byref(grid.struct()), C.byref(cs), C.byref(E) if E is not None else None, _p(h), _p(T), _p(S),
+                                      _p(p_atm), _p(PFu), _p(PFv), _p(pbce), _p(eta))
     if rc:
         raise RuntimeError("orc_pressureforce_fv_bouss: unsupported configuration")
     return PFu, PFv, pbce, eta
@@ -750,6 +760,15 @@ def ale_remap_set_h_vel(grid, h_new, h_u=None, h_v=None):
     h_u = grid.zeros3(_abi.POS_U) if h_u is None else h_u
     h_v = grid.zeros3(_abi.POS_V) if h_v is None else h_v
     L.orc_ale_remap_set_h_vel(C.byref(grid.struct()), _p(h_new), _p(h_u), _p(h_v))
+    return h_u, h_v
+
+
+def ale_remap_set_h_vel_via_dz(grid, h_old, dzInterface, h_u=None, h_v=None):
+    """ALE_remap_set_h_vel_via_dz, MOM_ALE.F90:912 (REMAP_UV_USING_OLD_ALG)"""
+    L = lib(); L.orc_ale_remap_set_h_vel_via_dz.argtypes = [C.POINTER(_abi.GridStruct), _dp, _dp, _dp, _dp]
+    h_u = grid.zeros3(_abi.POS_U) if h_u is None else h_u
+    h_v = grid.zeros3(_abi.POS_V) if h_v is None else h_v
+    L.orc_ale_remap_set_h_vel_via_dz(C.byref(grid.struct()), _p(h_old), _p(dzInterface), _p(h_u), _p(h_v))
     return h_u, h_v
 
 

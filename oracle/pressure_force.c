@@ -326,7 +326,143 @@ static void int_density_dz_generic_plm(const mom6hip_grid_t *G, const mom6hip_eo
 #undef SB
 }
 
-/* PressureForce_FV_Bouss, MOM_PressureForce_FV.F90:462-919 */
+
+/* ---- the non-PLM branch: int_density_dz (MOM_density_integrals.F90:41) -> analytic_int_density_dz (MOM_EOS.F90:1308) ----
+ * Tk, Sk: the layer's T and S planes (tv_tmp); z_t = e(:,:,K), z_b = e(:,:,K+1).  rho_scale = pres_scale = 1 (no rescaling). */
+
+/* int_density_dz_linear, MOM_EOS_linear.F90:259-424 */
+static void int_density_dz_linear(const mom6hip_grid_t *G, const double *Tk, const double *Sk, const double *z_t, const double *z_b,
+                                  double rho_ref, double G_e, double Rho_T0_S0, double dRho_dT, double dRho_dS,
+                                  double dz_neglect, int useMassWghtInterp, double *dpa, double *intz_dpa, double *intx_dpa, double *inty_dpa)
+{
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const double C1_6 = 1.0/6.0, C1_90 = 1.0/90.0;
+  const double *bathyT = G->bathyT;
+#define T2(i,j) Tk[ORC_H2(G,i,j)]
+#define S2(i,j) Sk[ORC_H2(G,i,j)]
+#define ZT(i,j) z_t[ORC_H2(G,i,j)]
+#define ZB(i,j) z_b[ORC_H2(G,i,j)]
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+    double dz = ZT(i,j) - ZB(i,j);
+    double rho_anom = (Rho_T0_S0 - rho_ref) + dRho_dT*T2(i,j) + dRho_dS*S2(i,j);
+    dpa[ORC_H2(G,i,j)] = G_e*rho_anom*dz;
+    intz_dpa[ORC_H2(G,i,j)] = 0.5*G_e*rho_anom*(dz*dz);
+  }
+  for (int dir = 0; dir < 2; dir++) {
+    const int j0 = dir ? Jsq : G->jsc, j1 = dir ? Jeq : G->jec;
+    const int i0 = dir ? G->isc : Isq, i1 = dir ? G->iec : Ieq;
+    for (int j = j0; j <= j1; j++) for (int i = i0; i <= i1; i++) {
+      const int ip = dir ? i : i+1, jp = dir ? j+1 : j;
+      double hWght = 0.0, val;
+      if (useMassWghtInterp) hWght = max3(0., -bathyT[ORC_H2(G,i,j)]-ZT(ip,jp), -bathyT[ORC_H2(G,ip,jp)]-ZT(i,j));
+      if (hWght <= 0.0) {
+        double dzL = ZT(i,j) - ZB(i,j), dzR = ZT(ip,jp) - ZB(ip,jp);
+        double raL = (Rho_T0_S0 - rho_ref) + (dRho_dT*T2(i,j) + dRho_dS*S2(i,j));
+        double raR = (Rho_T0_S0 - rho_ref) + (dRho_dT*T2(ip,jp) + dRho_dS*S2(ip,jp));
+        val = G_e*C1_6 * (dzL*(2.0*raL + raR) + dzR*(2.0*raR + raL));
+      } else {
+        double hL = (ZT(i,j) - ZB(i,j)) + dz_neglect;
+        double hR = (ZT(ip,jp) - ZB(ip,jp)) + dz_neglect;
+        double rr = (hL-hR)/(hL+hR);
+        hWght = hWght * ( rr*rr );
+        double iDenom = 1.0 / ( hWght*(hR + hL) + hL*hR );
+        double hWt_LL = (hWght*hL + hR*hL) * iDenom, hWt_LR = (hWght*hR) * iDenom;
+        double hWt_RR = (hWght*hR + hR*hL) * iDenom, hWt_RL = (hWght*hL) * iDenom;
+        double intz[6];
+        intz[1] = dpa[ORC_H2(G,i,j)]; intz[5] = dpa[ORC_H2(G,ip,jp)];
+        for (int m = 2; m <= 4; m++) {
+          double wt_L = 0.25*(double)(5-m), wt_R = 1.0-wt_L;
+          double wtT_L = wt_L*hWt_LL + wt_R*hWt_RL, wtT_R = wt_L*hWt_LR + wt_R*hWt_RR;
+          double dz = wt_L*(ZT(i,j) - ZB(i,j)) + wt_R*(ZT(ip,jp) - ZB(ip,jp));
+          double rho_anom = (Rho_T0_S0 - rho_ref) +
+                     (dRho_dT * (wtT_L*T2(i,j) + wtT_R*T2(ip,jp)) +
+                      dRho_dS * (wtT_L*S2(i,j) + wtT_R*S2(ip,jp)));
+          intz[m] = G_e*rho_anom*dz;
+        }
+        val = C1_90*(7.0*(intz[1]+intz[5]) + 32.0*(intz[2]+intz[4]) + 12.0*intz[3]);
+      }
+      if (dir) inty_dpa[ORC_V2(G,i,j)] = val; else intx_dpa[ORC_U2(G,i,j)] = val;
+    }
+  }
+}
+
+/* int_density_dz_wright, MOM_EOS_Wright.F90:389-640 (the "WRIGHT" form; no rescaling arguments) */
+static void int_density_dz_wright(const mom6hip_grid_t *G, const double *Tk, const double *Sk, const double *z_t, const double *z_b,
+                                  double rho_ref, double rho_0, double G_e, double dz_neglect, int useMassWghtInterp, double Z_0p,
+                                  double *dpa, double *intz_dpa, double *intx_dpa, double *inty_dpa)
+{
+  const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
+  const double C1_3 = 1.0/3.0, C1_7 = 1.0/7.0, C1_9 = 1.0/9.0, C1_90 = 1.0/90.0;
+  const double *bathyT = G->bathyT;
+  const long nH2 = (long)ORC_NIH(G)*ORC_NJH(G);
+  double *al0_2d = calloc(nH2, 8), *p0_2d = calloc(nH2, 8), *lambda_2d = calloc(nH2, 8);
+  const double GxRho = G_e * rho_0, g_Earth = G_e, Pa_to_RL2_T2 = 1.0;
+  const double rho_ref_mks = rho_ref, I_Rho = 1.0 / rho_0;
+  const double z0pres = Z_0p;
+  for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+    const long o = ORC_H2(G,i,j);
+    al0_2d[o] = (a0 + a1*T2(i,j)) + a2*S2(i,j);
+    p0_2d[o] = (b0 + b4*S2(i,j)) + T2(i,j) * (b1 + T2(i,j)*((b2 + b3*T2(i,j))) + b5*S2(i,j));
+    lambda_2d[o] = (c0 +c4*S2(i,j)) + T2(i,j) * (c1 + T2(i,j)*((c2 + c3*T2(i,j))) + c5*S2(i,j));
+    double al0 = al0_2d[o], p0 = p0_2d[o], lambda = lambda_2d[o];
+    double dz = ZT(i,j) - ZB(i,j);
+    double p_ave = -GxRho*(0.5*(ZT(i,j)+ZB(i,j)) - z0pres);
+    double I_al0 = 1.0 / al0;
+    double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+    double eps = 0.5*GxRho*dz*I_Lzz, eps2 = eps*eps;
+    double rho_anom = (p0 + p_ave)*(I_Lzz*I_al0) - rho_ref_mks;
+    double rem = I_Rho * (lambda * (I_al0*I_al0)) * eps2 *
+          (C1_3 + eps2*(0.2 + eps2*(C1_7 + C1_9*eps2)));
+    dpa[o] = Pa_to_RL2_T2 * (g_Earth*rho_anom*dz - 2.0*eps*rem);
+    intz_dpa[o] = Pa_to_RL2_T2 * (0.5*g_Earth*rho_anom*(dz*dz) - dz*(1.0+eps)*rem);
+  }
+  for (int dir = 0; dir < 2; dir++) {
+    const int j0 = dir ? Jsq : G->jsc, j1 = dir ? Jeq : G->jec;
+    const int i0 = dir ? G->isc : Isq, i1 = dir ? G->iec : Ieq;
+    for (int j = j0; j <= j1; j++) for (int i = i0; i <= i1; i++) {
+      const int ip = dir ? i : i+1, jp = dir ? j+1 : j;
+      const long oL = ORC_H2(G,i,j), oR = ORC_H2(G,ip,jp);
+      double hWght = 0.0, hWt_LL, hWt_LR, hWt_RR, hWt_RL;
+      if (useMassWghtInterp) hWght = max3(0., -bathyT[oL]-ZT(ip,jp), -bathyT[oR]-ZT(i,j));
+      if (hWght > 0.) {
+        double hL = (ZT(i,j) - ZB(i,j)) + dz_neglect;
+        double hR = (ZT(ip,jp) - ZB(ip,jp)) + dz_neglect;
+        double rr = (hL-hR)/(hL+hR);
+        hWght = hWght * ( rr*rr );
+        double iDenom = 1.0 / ( hWght*(hR + hL) + hL*hR );
+        hWt_LL = (hWght*hL + hR*hL) * iDenom ; hWt_LR = (hWght*hR) * iDenom;
+        hWt_RR = (hWght*hR + hR*hL) * iDenom ; hWt_RL = (hWght*hL) * iDenom;
+      } else {
+        hWt_LL = 1.0 ; hWt_LR = 0.0 ; hWt_RR = 1.0 ; hWt_RL = 0.0;
+      }
+      double intz[6];
+      intz[1] = dpa[oL]; intz[5] = dpa[oR];
+      for (int m = 2; m <= 4; m++) {
+        double wt_L = 0.25*(double)(5-m), wt_R = 1.0-wt_L;
+        double wtT_L = wt_L*hWt_LL + wt_R*hWt_RL, wtT_R = wt_L*hWt_LR + wt_R*hWt_RR;
+        double al0 = wtT_L*al0_2d[oL] + wtT_R*al0_2d[oR];
+        double p0 = wtT_L*p0_2d[oL] + wtT_R*p0_2d[oR];
+        double lambda = wtT_L*lambda_2d[oL] + wtT_R*lambda_2d[oR];
+        double dz = wt_L*(ZT(i,j) - ZB(i,j)) + wt_R*(ZT(ip,jp) - ZB(ip,jp));
+        double p_ave = -GxRho*(0.5*(wt_L*(ZT(i,j)+ZB(i,j)) + wt_R*(ZT(ip,jp)+ZB(ip,jp))) - z0pres);
+        double I_al0 = 1.0 / al0;
+        double I_Lzz = 1.0 / (p0 + (lambda * I_al0) + p_ave);
+        double eps = 0.5*GxRho*dz*I_Lzz, eps2 = eps*eps;
+        intz[m] = Pa_to_RL2_T2 * ( g_Earth*dz*((p0 + p_ave)*(I_Lzz*I_al0) - rho_ref_mks) - 2.0*eps *
+                  I_Rho * (lambda * (I_al0*I_al0)) * eps2 * (C1_3 + eps2*(0.2 + eps2*(C1_7 + C1_9*eps2))) );
+      }
+      double val = C1_90*(7.0*(intz[1]+intz[5]) + 32.0*(intz[2]+intz[4]) + 12.0*intz[3]);
+      if (dir) inty_dpa[ORC_V2(G,i,j)] = val; else intx_dpa[ORC_U2(G,i,j)] = val;
+    }
+  }
+  free(al0_2d); free(p0_2d); free(lambda_2d);
+#undef T2
+#undef S2
+#undef ZT
+#undef ZB
+}
+
+/* PressureForce_FV_Bouss, MOM_PressureForce_FV.F90:462-919.  EOS == NULL: no equation of state (use_EOS false). */
 int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressureforce_cs_t *CS, const mom6hip_eos_t *EOS,
                                const double *h, const double *T, const double *S, const double *p_atm,
                                double *PFu, double *PFv, double *pbce, double *eta)
@@ -334,7 +470,15 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
   const long nH2 = (long)ORC_NIH(G)*ORC_NJH(G), nH3 = nH2*nz;
-  if (!(CS->reconstruct && CS->Recon_Scheme == 1) || CS->GFS_scale != 1.0) return 1;
+  const int use_EOS = (EOS != NULL);
+  const int nkmb = CS->nkmb;
+  int use_ALE = 0;
+  if (CS->use_ALE) use_ALE = CS->reconstruct && use_EOS;        /* :561-562 */
+  if (CS->GFS_scale != 1.0) return 1;
+  if (use_ALE && CS->Recon_Scheme != 1) return 1;
+  if (use_EOS && !use_ALE && !(EOS->form == MOM6HIP_EOS_LINEAR || EOS->form == MOM6HIP_EOS_WRIGHT)) return 1;
+  if ((nkmb > 0 || !use_EOS) && !CS->Rlay) return 1;
+  if (!use_EOS && pbce && !CS->g_prime) return 1;
   const double h_neglect = G->H_subroundoff;
   const double dz_neglect = G->dZ_subroundoff;
   const double I_Rho0 = 1.0 / G->Rho0;
@@ -343,7 +487,9 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
   const double Z_ref = CS->Z_ref;
   double *e = calloc(nH2*(nz+1), 8);
   double *T_t = calloc(nH3, 8), *T_b = calloc(nH3, 8), *S_t = calloc(nH3, 8), *S_b = calloc(nH3, 8);
-  double *pa = calloc(nH2, 8), *dpa = calloc(nH2, 8), *intz_dpa = calloc(nH2, 8);
+  double *T_tmp = NULL, *S_tmp = NULL;
+  const double *Tt = T, *St = S;                  /* tv_tmp%T, tv_tmp%S */
+  double *pa = calloc(nH2, 8), *dpa = calloc(nH2, 8), *intz_dpa = calloc(nH2, 8), *dz_geo = calloc(nH2, 8);
   double *intx_pa = calloc((size_t)(ORC_NIH(G)+1)*ORC_NJH(G), 8), *intx_dpa = calloc((size_t)(ORC_NIH(G)+1)*ORC_NJH(G), 8);
   double *inty_pa = calloc((size_t)ORC_NIH(G)*(ORC_NJH(G)+1), 8), *inty_dpa = calloc((size_t)ORC_NIH(G)*(ORC_NJH(G)+1), 8);
 
@@ -355,9 +501,32 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
   for (int j = Jsq; j <= Jeq+1; j++) for (int k = nz; k >= 1; k--) for (int i = Isq; i <= Ieq+1; i++)
     E3(i,j,k) = E3(i,j,k+1) + h[ORC_H3(G,i,j,k)]*G->H_to_Z;
 
+  /* :650-680: with a bulk mixed layer, layers lighter than the buffer layer take its properties */
+  if (use_EOS && nkmb > 0) {
+    T_tmp = calloc(nH3, 8); S_tmp = calloc(nH3, 8);
+    for (int j = Jsq; j <= Jeq+1; j++) {
+      for (int k = 1; k <= nkmb; k++) for (int i = Isq; i <= Ieq+1; i++) {
+        T_tmp[ORC_H3(G,i,j,k)] = T[ORC_H3(G,i,j,k)]; S_tmp[ORC_H3(G,i,j,k)] = S[ORC_H3(G,i,j,k)];
+      }
+      for (int i = Isq; i <= Ieq+1; i++) {
+        const double Rho_cv_BL = orc_eos_density(EOS, T[ORC_H3(G,i,j,nkmb)], S[ORC_H3(G,i,j,nkmb)], CS->P_Ref);
+        for (int k = nkmb+1; k <= nz; k++) {
+          if (CS->Rlay[k-1] < Rho_cv_BL) {
+            T_tmp[ORC_H3(G,i,j,k)] = T[ORC_H3(G,i,j,nkmb)]; S_tmp[ORC_H3(G,i,j,k)] = S[ORC_H3(G,i,j,nkmb)];
+          } else {
+            T_tmp[ORC_H3(G,i,j,k)] = T[ORC_H3(G,i,j,k)]; S_tmp[ORC_H3(G,i,j,k)] = S[ORC_H3(G,i,j,k)];
+          }
+        }
+      }
+    }
+    Tt = T_tmp; St = S_tmp;
+  }
+
   /* :712-718 */
-  orc_ale_plm_edge_values(G, h, S, CS->boundary_extrap, S_t, S_b);
-  orc_ale_plm_edge_values(G, h, T, CS->boundary_extrap, T_t, T_b);
+  if (use_ALE) {
+    orc_ale_plm_edge_values(G, h, S, CS->boundary_extrap, S_t, S_b);
+    orc_ale_plm_edge_values(G, h, T, CS->boundary_extrap, T_t, T_b);
+  }
 
   /* :723-741 */
   for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
@@ -370,11 +539,33 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
     inty_pa[ORC_V2(G,i,J)] = 0.5*(pa[ORC_H2(G,i,J)] + pa[ORC_H2(G,i,J+1)]);
 
   for (int k = 1; k <= nz; k++) {
-    int_density_dz_generic_plm(G, EOS, k, T_t, T_b, S_t, S_b, e, rho_ref, CS->Rho0, G->g_Earth, dz_neglect,
-                               CS->useMassWghtInterp, Z_ref, dpa, intz_dpa, intx_dpa, inty_dpa);
-    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
-      intz_dpa[ORC_H2(G,i,j)] = intz_dpa[ORC_H2(G,i,j)]*G->Z_to_H;
 #define HK(i,j) h[ORC_H3(G,i,j,k)]
+    if (use_EOS) {
+      if (use_ALE) {                 /* :753-758 */
+        int_density_dz_generic_plm(G, EOS, k, T_t, T_b, S_t, S_b, e, rho_ref, CS->Rho0, G->g_Earth, dz_neglect,
+                                   CS->useMassWghtInterp, Z_ref, dpa, intz_dpa, intx_dpa, inty_dpa);
+      } else if (EOS->form == MOM6HIP_EOS_LINEAR) {       /* :765-768 -> MOM_EOS.F90:1364-1377 */
+        int_density_dz_linear(G, Tt + nH2*(k-1), St + nH2*(k-1), e + nH2*(k-1), e + nH2*k, rho_ref, G->g_Earth,
+                              EOS->Rho_T0_S0, EOS->dRho_dT, EOS->dRho_dS, dz_neglect, CS->useMassWghtInterp,
+                              dpa, intz_dpa, intx_dpa, inty_dpa);
+      } else {                                            /* MOM_EOS.F90:1378-1390 */
+        int_density_dz_wright(G, Tt + nH2*(k-1), St + nH2*(k-1), e + nH2*(k-1), e + nH2*k, rho_ref, CS->Rho0, G->g_Earth,
+                              dz_neglect, CS->useMassWghtInterp, Z_ref, dpa, intz_dpa, intx_dpa, inty_dpa);
+      }
+      for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+        intz_dpa[ORC_H2(G,i,j)] = intz_dpa[ORC_H2(G,i,j)]*G->Z_to_H;
+    } else {                         /* :775-789 */
+      const double Rl = CS->Rlay[k-1];
+      for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+        dz_geo[ORC_H2(G,i,j)] = G->g_Earth * G->H_to_Z*HK(i,j);
+        dpa[ORC_H2(G,i,j)] = (Rl - rho_ref) * dz_geo[ORC_H2(G,i,j)];
+        intz_dpa[ORC_H2(G,i,j)] = 0.5*(Rl - rho_ref) * dz_geo[ORC_H2(G,i,j)]*HK(i,j);
+      }
+      for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++)
+        intx_dpa[ORC_U2(G,I,j)] = 0.5*(Rl - rho_ref) * (dz_geo[ORC_H2(G,I,j)] + dz_geo[ORC_H2(G,I+1,j)]);
+      for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
+        inty_dpa[ORC_V2(G,i,J)] = 0.5*(Rl - rho_ref) * (dz_geo[ORC_H2(G,i,J)] + dz_geo[ORC_H2(G,i,J+1)]);
+    }
     /* :793-801 */
     ORC_PAR
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
@@ -404,34 +595,42 @@ int orc_pressureforce_fv_bouss(const mom6hip_grid_t *G, const mom6hip_pressurefo
       pa[ORC_H2(G,i,j)] = pa[ORC_H2(G,i,j)] + dpa[ORC_H2(G,i,j)];
   }
 
-  /* Set_pbce_Bouss (use_EOS, no rho_star), MOM_PressureForce_Montgomery.F90:702-729 */
-  if (pbce) {
+  /* Set_pbce_Bouss(e, tv_tmp, ...), MOM_PressureForce_Montgomery.F90:649-748 (no rho_star) */
+  if (pbce && use_EOS) {
     const double Rho0xG = CS->Rho0 * G->g_Earth;
     ORC_PAR
     for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
       double Ihtot = G->H_to_Z / ((E3(i,j,1)-E3(i,j,nz+1)) + dz_neglect);
       double press = -Rho0xG*(E3(i,j,1) - Z_ref);
-      double rho_in_situ = orc_eos_density(EOS, T[ORC_H3(G,i,j,1)], S[ORC_H3(G,i,j,1)], press);
+      double rho_in_situ = orc_eos_density(EOS, Tt[ORC_H3(G,i,j,1)], St[ORC_H3(G,i,j,1)], press);
       pbce[ORC_H3(G,i,j,1)] = G_Rho0*(CS->GFS_scale * rho_in_situ) * G->H_to_Z;
       for (int k = 2; k <= nz; k++) {
         press = -Rho0xG*(E3(i,j,k) - Z_ref);
-        double T_int = 0.5*(T[ORC_H3(G,i,j,k-1)]+T[ORC_H3(G,i,j,k)]);
-        double S_int = 0.5*(S[ORC_H3(G,i,j,k-1)]+S[ORC_H3(G,i,j,k)]);
+        double T_int = 0.5*(Tt[ORC_H3(G,i,j,k-1)]+Tt[ORC_H3(G,i,j,k)]);
+        double S_int = 0.5*(St[ORC_H3(G,i,j,k-1)]+St[ORC_H3(G,i,j,k)]);
         double dR_dT, dR_dS;
         orc_eos_density_derivs(EOS, T_int, S_int, press, &dR_dT, &dR_dS);
         pbce[ORC_H3(G,i,j,k)] = pbce[ORC_H3(G,i,j,k-1)] + G_Rho0 *
                ((E3(i,j,k) - E3(i,j,nz+1)) * Ihtot) *
-               (dR_dT*(T[ORC_H3(G,i,j,k)]-T[ORC_H3(G,i,j,k-1)]) +
-                dR_dS*(S[ORC_H3(G,i,j,k)]-S[ORC_H3(G,i,j,k-1)]));
+               (dR_dT*(Tt[ORC_H3(G,i,j,k)]-Tt[ORC_H3(G,i,j,k-1)]) +
+                dR_dS*(St[ORC_H3(G,i,j,k)]-St[ORC_H3(G,i,j,k-1)]));
       }
+    }
+  } else if (pbce) {                 /* :733-745 */
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++) {
+      double Ihtot = 1.0 / ((E3(i,j,1)-E3(i,j,nz+1)) + dz_neglect);
+      pbce[ORC_H3(G,i,j,1)] = CS->g_prime[0] * G->H_to_Z;
+      for (int k = 2; k <= nz; k++)
+        pbce[ORC_H3(G,i,j,k)] = pbce[ORC_H3(G,i,j,k-1)] +
+                      (CS->g_prime[k-1]*G->H_to_Z) * ((E3(i,j,k) - E3(i,j,nz+1)) * Ihtot);
     }
   }
   /* :839-843 */
   if (eta) for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
     eta[ORC_H2(G,i,j)] = E3(i,j,1)*G->Z_to_H;
 
-  free(e); free(T_t); free(T_b); free(S_t); free(S_b); free(pa); free(dpa); free(intz_dpa);
-  free(intx_pa); free(intx_dpa); free(inty_pa); free(inty_dpa);
+  free(e); free(T_t); free(T_b); free(S_t); free(S_b); free(pa); free(dpa); free(intz_dpa); free(dz_geo);
+  free(intx_pa); free(intx_dpa); free(inty_pa); free(inty_dpa); free(T_tmp); free(S_tmp);
   return 0;
 }
 

@@ -9,6 +9,7 @@
  *   regridding_main           :763-889 (REGRIDDING_ZSTAR, Boussinesq)
  *   ALE_regrid                src/ALE/MOM_ALE.F90:484-520
  *   ALE_remap_set_h_vel       :870-908
+ *   ALE_remap_set_h_vel_via_dz :912-960
  *   ALE_remap_velocities      :1061-1274
  * PARITY UNPINNED for the regridding (the reference's unit tests cover the remapping kernels, which the velocity
  * remap reuses); checked through invariants in tests/test_regridding.py.
@@ -159,6 +160,31 @@ int orc_ale_remap_set_h_vel(const mom6hip_grid_t *G, const double *h_new, double
   ORC_PAR
   for (int k = 1; k <= G->nk; k++) for (int J = G->jsc - 1; J <= G->jec; J++) for (int i = G->isc; i <= G->iec; i++)
     if (G->mask2dCv[ORC_V2(G, i, J)] > 0.) h_v[ORC_V3(G, i, J, k)] = 0.5 * (h_new[ORC_H3(G, i, J, k)] + h_new[ORC_H3(G, i, J + 1, k)]);
+  return 0;
+}
+
+/* ALE_remap_set_h_vel_via_dz :912-960 (REMAP_UV_USING_OLD_ALG = True, MOM.F90:1666-1667): the new velocity-point grid from the
+ * old thicknesses and the interface movements dzInterface (nk+1 planes) */
+int orc_ale_remap_set_h_vel_via_dz(const mom6hip_grid_t *G, const double *h_old, const double *dzInterface, double *h_u, double *h_v) {
+  const long nH2 = (long)ORC_NIH(G) * ORC_NJH(G);
+#define DZI(i, j, K) dzInterface[ORC_H2(G, i, j) + nH2 * ((K) - 1)]
+  ORC_PAR
+  for (int k = 1; k <= G->nk; k++) for (int j = G->jsc; j <= G->jec; j++) for (int I = G->isc - 1; I <= G->iec; I++)
+    if (G->mask2dCu[ORC_U2(G, I, j)] > 0.) {
+      const int i = I;
+      const double v = 0.5 * (h_old[ORC_H3(G, i, j, k)] + h_old[ORC_H3(G, i + 1, j, k)]) +
+                       0.5 * ((DZI(i, j, k) + DZI(i + 1, j, k)) - (DZI(i, j, k + 1) + DZI(i + 1, j, k + 1)));
+      h_u[ORC_U3(G, I, j, k)] = 0. > v ? 0. : v;     /* max(0., v) */
+    }
+  ORC_PAR
+  for (int k = 1; k <= G->nk; k++) for (int J = G->jsc - 1; J <= G->jec; J++) for (int i = G->isc; i <= G->iec; i++)
+    if (G->mask2dCv[ORC_V2(G, i, J)] > 0.) {
+      const int j = J;
+      const double v = 0.5 * (h_old[ORC_H3(G, i, j, k)] + h_old[ORC_H3(G, i, j + 1, k)]) +
+                       0.5 * ((DZI(i, j, k) + DZI(i, j + 1, k)) - (DZI(i, j, k + 1) + DZI(i, j + 1, k + 1)));
+      h_v[ORC_V3(G, i, J, k)] = 0. > v ? 0. : v;
+    }
+#undef DZI
   return 0;
 }
 

@@ -99,6 +99,7 @@ call continuity_PPM_init(Time, G, GV, US, pf, diag, CS)
 call CoriolisAdv_init(Time, G, GV, US, pf, diag, AD, CCS)
 call param_set(pf, "USE_REGRIDDING", "True")
 call PressureForce_FV_init(Time, G, GV, US, pf, diag, PCS)
+allocate(ALE_CSp) ; allocate(tv%eqn_of_state)      ! USE_REGRIDDING with an equation of state: the PLM branch
 if (continuity_PPM_stencil(CS) /= 3) error stop "shim_driver: unexpected continuity stencil"
 call alloc_BT_cont_type(BT, isd, ied, jsd, jed, nk, alloc_faces=.true.)
 

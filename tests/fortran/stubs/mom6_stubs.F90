@@ -517,6 +517,7 @@ end module MOM_tracer_registry
 
 module MOM_variables
 use MOM_domains, only : group_pass_type
+use MOM_EOS, only : EOS_type
 implicit none ; private
 public :: BT_cont_type, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, thermo_var_ptrs, vertvisc_type, &
           ocean_internal_state, alloc_BT_cont_type
@@ -538,6 +539,8 @@ end type cont_diag_ptrs
 type :: thermo_var_ptrs
   real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL()
   real, pointer, dimension(:,:) :: p_surf => NULL()
+  type(EOS_type), pointer :: eqn_of_state => NULL()      !< associated = an equation of state is used (use_EOS)
+  real :: P_Ref = 2.0e7
 end type thermo_var_ptrs
 type :: vertvisc_type
   real :: Prandtl_turb = 1.0

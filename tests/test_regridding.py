@@ -62,6 +62,43 @@ def test_velocity_remap_conserves_transport():
     assert np.abs(u).max() <= np.abs(d["u"]).max() * (1 + 1e-12)     # bounded remapping
 
 
+def test_h_vel_via_dz_is_the_mean_of_the_new_thicknesses():
+    """REMAP_UV_USING_OLD_ALG = True (.testing/tc2, tc4; MOM.F90:1666 -> ALE_remap_set_h_vel_via_dz, MOM_ALE.F90:912): the old
+    thicknesses plus the interface movements are the new thicknesses (calc_h_new_by_dz), so where nothing is clipped the two
+    routes to the velocity-point grid agree to roundoff; land faces are left alone by both"""
+    g, d, res = make()
+    h_new, dz = orc.ale_regrid(g, orc.regridding_cs(res), d["h"])
+    orc.halo_update(g, h_new, _abi.POS_H)
+    a_u, a_v = orc.ale_remap_set_h_vel(g, h_new)
+    fill = -7.0
+    b_u, b_v = orc.ale_remap_set_h_vel_via_dz(g, d["h"], dz, np.full_like(a_u, fill), np.full_like(a_v, fill))
+    for a, b, pos, mk in ((a_u, b_u, _abi.POS_U, g.mask2dCu), (a_v, b_v, _abi.POS_V, g.mask2dCv)):
+        m = np.broadcast_to(interior(g, mk, pos) > 0, interior(g, a, pos).shape)
+        assert np.allclose(interior(g, a, pos)[m], interior(g, b, pos)[m], rtol=0, atol=1e-9 * interior(g, a, pos).max())
+        assert np.all(interior(g, b, pos)[~m] == fill) and np.all(interior(g, b, pos)[m] >= 0.0)
+    assert not bits_equal(a_u, b_u)          # ... but not the same bits: the switch changes answers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_h_vel_via_dz_matches_oracle_bitwise(space):
+    import torch
+    from mom6_amd.ale import ALE_remap_set_h_vel_via_dz
+    from mom6_amd.tracer_advect import DeviceGrid
+    for kw in (dict(), dict(nk=3, ni=70, nj=9), dict(reentrant_x=False)):
+        g, d, res = make(**kw)
+        h_new, dz = orc.ale_regrid(g, orc.regridding_cs(res, old_grid_weight=0.3, zs=50.0, zd=400.0), d["h"])
+        w_u, w_v = orc.ale_remap_set_h_vel_via_dz(g, d["h"], dz)
+        dg = DeviceGrid(g)
+        T = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if space == "device" else (lambda a: np.ascontiguousarray(a).copy())
+        N = lambda a: a if isinstance(a, np.ndarray) else a.cpu().numpy()
+        hu, hv = T(np.zeros_like(w_u)), T(np.zeros_like(w_v))
+        ALE_remap_set_h_vel_via_dz(None, dg, T(h_new), hu, hv, None, T(d["h"]), T(dz))
+        dg.sync()
+        assert bits_equal(N(hu), w_u) and bits_equal(N(hv), w_v)
+        dg.close()
+
+
 REGRID_CASES = [dict(), dict(terrain=True), dict(nk=3, ni=70, nj=9), dict(nk=40, seed=6), dict(reentrant_x=False),
                 dict(old_grid_weight=0.4, zs=50.0, zd=400.0), dict(min_thickness=0.0)]
 
