@@ -67,6 +67,22 @@ def parse():
     return ap.parse_args()
 
 
+def attach_exchange(dom, dg, device, exchange):
+    """The halo exchange of a multi-tile run: the library's own RCCL group passes ("rccl") or MOM6's group passes as callbacks
+    into torch.distributed ("python").  attach_native is collective (broadcast of the unique id, ncclCommInitRank), so the
+    ranks first agree, from a LOCAL probe, that every one of them can enter it; if any cannot, all use the callbacks."""
+    if exchange == "rccl":
+        import torch.distributed as dist
+        ok = torch.tensor([1 if dom.native_available() else 0], device=str(device) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            dom.attach_native(dg)
+            return "rccl"
+        print("bench.py: RCCL cannot be loaded on every rank; using torch.distributed callbacks", file=sys.stderr, flush=True)
+    dg.set_domain(dom)
+    return "python"
+
+
 def shape_of(name):
     from mom6_amd import synth
     if name in synth.CONFIGS:
@@ -91,25 +107,7 @@ class Model:
         self.dg = DeviceGrid(grid, device=device.index)
         self.exchange = exchange
         if dom.nranks > 1:
-            if exchange == "rccl":      # the library's own group passes: RCCL send / recv on its communication stream
-                import torch.distributed as dist
-                err = None
-                try:
-                    dom.attach_native(self.dg)
-                except Exception as e:      # e.g. librccl not loadable: every rank falls back to the callbacks, and says so
-                    err = e
-                ok = torch.tensor([0 if err else 1], device=str(device) if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    print(f"bench.py: native RCCL exchange not attached on every rank ({err!r}); using torch.distributed callbacks",
-                          file=sys.stderr, flush=True)
-                    if err is None:
-                        self.dg.close()
-                        self.dg = DeviceGrid(grid, device=device.index)
-                        dom.native = False
-                    self.exchange = "python"
-            if self.exchange != "rccl":     # MOM6's group passes as callbacks into torch.distributed (any backend)
-                self.dg.set_domain(dom)
+            self.exchange = attach_exchange(dom, self.dg, device, exchange)
         dev = str(device)
         H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
         Z = lambda pos, k3=True: torch.zeros(grid.shape3(pos) if k3 else grid.shape2(pos), dtype=torch.float64, device=dev)
@@ -208,7 +206,8 @@ class Model:
         ke = 0.25 * (hc * (self.u[:, sj, si.start:si.stop] ** 2 + self.u[:, sj, si.start + 1:si.stop + 1] ** 2
                            + self.v[:, sj.start:sj.stop, si] ** 2 + self.v[:, sj.start + 1:sj.stop + 1, si] ** 2)).sum(0)
         nocean = float(mT.sum())
-        vanished = float(((hc < 1.0e-6) * mT[None]).sum()) / max(nocean * g.nk, 1.0)
+        # z* regridding leaves the layers below the bottom at MIN_THICKNESS = 1e-3 (not at Angstrom): count h <= 2 MIN_THICKNESS
+        vanished = float(((hc <= 2.0e-3) * mT[None]).sum()) / max(nocean * g.nk, 1.0)
         out = dict(umax=float(self.u.abs().max()), vmax=float(self.v.abs().max()), hmin=float(self.h.min()),
                    eta_max=float((self.CS.eta[sj, si] * mT).abs().max()), ke_mean=float((ke * mT).sum()) / max(nocean, 1.0),
                    vanished_layer_fraction=vanished, nan=bad)
@@ -241,25 +240,7 @@ class Components:
         self.dg = DeviceGrid(grid, device=device.index)
         self.exchange = exchange
         if dom.nranks > 1:
-            if exchange == "rccl":      # the library's own group passes: RCCL send / recv on its communication stream
-                import torch.distributed as dist
-                err = None
-                try:
-                    dom.attach_native(self.dg)
-                except Exception as e:      # e.g. librccl not loadable: every rank falls back to the callbacks, and says so
-                    err = e
-                ok = torch.tensor([0 if err else 1], device=str(device) if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    print(f"bench.py: native RCCL exchange not attached on every rank ({err!r}); using torch.distributed callbacks",
-                          file=sys.stderr, flush=True)
-                    if err is None:
-                        self.dg.close()
-                        self.dg = DeviceGrid(grid, device=device.index)
-                        dom.native = False
-                    self.exchange = "python"
-            if self.exchange != "rccl":     # MOM6's group passes as callbacks into torch.distributed (any backend)
-                self.dg.set_domain(dom)
+            self.exchange = attach_exchange(dom, self.dg, device, exchange)
         dev = str(device)
         H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
 

@@ -1107,6 +1107,12 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   static const bool graph_off = getenv("MOM6HIP_BT_GRAPH") && atoi(getenv("MOM6HIP_BT_GRAPH")) == 0;
   if (graph_off) {
     if (int rc = run_loop(s, 1, nt)) return rc;
+  } else if (m6::multi_tile(ctx) && [&] {      // more segments than the graph cache keeps for the two btstep calls of a step
+               int nseg = 0;                   // would recapture and re-instantiate every graph on every step: launch kernel by kernel
+               for (int n = 1; n <= nt; n++) if (n == 1 || rng[n].pass_first) nseg++;
+               return nseg > 100;
+             }()) {
+    if (int rc = run_loop(s, 1, nt)) return rc;
   } else if (m6::multi_tile(ctx)) {
     int n0 = 1;
     while (n0 <= nt) {

@@ -193,12 +193,14 @@ int mom6hip_chksum(mom6hip_ctx_t *ctx, const double *field, int32_t pos, int32_t
   unsigned long long res[3];
   M6_HIP(hipMemcpyAsync(res, out, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
   M6_HIP(hipStreamSynchronize(ctx->stream));
-  // sum_across_PEs of the count (each PE's share reduced first so the 32-bit exchange cannot overflow), extrema across PEs
-  int32_t part = (int32_t)(res[0] % 1000000000ull);
+  // sum_across_PEs of the count, exactly: each PE's share is first reduced modulo 1e9 (< 2^30) and exchanged as two pieces of
+  // 15 bits, so the 32-bit sums stay below 2^31 for up to 65536 PEs; the pieces are recombined in 64 bits before the last modulo
+  const long long share = (long long)(res[0] % 1000000000ull);
+  int32_t parts[2] = {(int32_t)(share >> 15), (int32_t)(share & 32767)};
   if (m6::multi_tile(ctx)) {
-    if (int rc = m6::sum_across_PEs(ctx, &part, 1)) return rc;
+    if (int rc = m6::sum_across_PEs(ctx, parts, 2)) return rc;
   }
-  *bitcount = (int64_t)(((long long)part % 1000000000ll + 1000000000ll) % 1000000000ll);
+  *bitcount = (int64_t)((((long long)parts[0] << 15) + (long long)parts[1]) % 1000000000ll);
   double mm[2] = {unsortable(res[1]), -unsortable(res[2])};      // (min, -max): one min reduction serves both
   if (m6::multi_tile(ctx)) {
     if (int rc = m6::min_across_PEs(ctx, mm, 2)) return rc;

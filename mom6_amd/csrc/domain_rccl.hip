@@ -142,10 +142,18 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
   const int32_t *pos = pos_only.data();
   const mom6hip_grid_t &G = ctx->host;
   hipStream_t cs = D->cstream;
+  // the fold is turned from this tile's own rows: the tile must span x and end the domain to the north
+  if (G.tripolar_n)
+    M6_REQUIRE(D->hi[1] < 0 && D->lo[0] < 0 && D->hi[0] < 0,
+               "group pass: a tile on the tripolar fold must span x (no x neighbours) and cannot have a northern neighbour");
   M6_HIP(hipEventRecord(D->ev_ready, ctx->stream));
   M6_HIP(hipStreamWaitEvent(cs, D->ev_ready, 0));
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  if (D->timing && hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, cs);
+  if (D->timing) {
+    if (hipEventCreate(&t0) != hipSuccess) t0 = nullptr;
+    else if (hipEventCreate(&t1) != hipSuccess) { (void)hipEventDestroy(t0); t0 = t1 = nullptr; }
+    else (void)hipEventRecord(t0, cs);
+  }
   const int h = G.isc - G.isd, ni = G.iec - G.isc + 1, nj = G.jec - G.jsc + 1;
   const int w = h;
   for (int dir = 0; dir < 2; dir++) {
@@ -175,17 +183,25 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
     // Messages between one pair of ranks are matched in posting order.  When both neighbours are the same rank (two tiles
     // in a re-entrant direction, or this rank itself) the peer's first message is its "to-high" block, which lands in
     // my LOW halo: post send->hi, recv<-lo, send->lo, recv<-hi.
+    // An error inside the group must not leave it open for every later call: remember the first one, always close the group.
     M6_NCCL(rccl().GroupStart());
-    if (hi >= 0) M6_NCCL(rccl().Send(s_hi, (size_t)cnt, ncclFloat64, hi, D->comm, cs));
-    if (lo >= 0) M6_NCCL(rccl().Recv(r_lo, (size_t)cnt, ncclFloat64, lo, D->comm, cs));
-    if (lo >= 0) M6_NCCL(rccl().Send(s_lo, (size_t)cnt, ncclFloat64, lo, D->comm, cs));
-    if (hi >= 0) M6_NCCL(rccl().Recv(r_hi, (size_t)cnt, ncclFloat64, hi, D->comm, cs));
-    M6_NCCL(rccl().GroupEnd());
+    ncclResult_t ge = ncclSuccess, e1;
+    const char *what = "";
+    if (hi >= 0 && (e1 = rccl().Send(s_hi, (size_t)cnt, ncclFloat64, hi, D->comm, cs)) != ncclSuccess && ge == ncclSuccess) { ge = e1; what = "ncclSend to the high neighbour"; }
+    if (lo >= 0 && (e1 = rccl().Recv(r_lo, (size_t)cnt, ncclFloat64, lo, D->comm, cs)) != ncclSuccess && ge == ncclSuccess) { ge = e1; what = "ncclRecv from the low neighbour"; }
+    if (lo >= 0 && (e1 = rccl().Send(s_lo, (size_t)cnt, ncclFloat64, lo, D->comm, cs)) != ncclSuccess && ge == ncclSuccess) { ge = e1; what = "ncclSend to the low neighbour"; }
+    if (hi >= 0 && (e1 = rccl().Recv(r_hi, (size_t)cnt, ncclFloat64, hi, D->comm, cs)) != ncclSuccess && ge == ncclSuccess) { ge = e1; what = "ncclRecv from the high neighbour"; }
+    e1 = rccl().GroupEnd();
+    if (ge != ncclSuccess || e1 != ncclSuccess) {
+      if (t0) { (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); }
+      m6::set_error("group pass (direction %d): %s failed: %s", dir, ge != ncclSuccess ? what : "ncclGroupEnd",
+                    rccl().GetErrorString(ge != ncclSuccess ? ge : e1));
+      return 1;
+    }
     if (lo >= 0) if (int rc = halo_pack_on(ctx, fields, pos, nk, a_lo_halo.data(), n, dir, w, r_lo, 0, nullptr, cs)) return rc;
     if (hi >= 0) if (int rc = halo_pack_on(ctx, fields, pos, nk, a_hi_halo.data(), n, dir, w, r_hi, 0, nullptr, cs)) return rc;
   }
   if (G.tripolar_n) {      // this tile's northern edge is the fold (the tiles span x): its own rows, turned
-    M6_REQUIRE(D->hi[1] < 0, "group pass: a tile on the tripolar fold cannot have a northern neighbour");
     for (int f = 0; f < n; f++)
       if (int rc = halo_fold_north(ctx, fields[f], pos_flags[f], nk[f], cs)) return rc;
   }

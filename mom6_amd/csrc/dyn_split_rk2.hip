@@ -151,8 +151,9 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   // the step's automatic arrays (:336-369): one grow-only block in the context's pool
   // (its own buffer: the modules called below hand out the pool's buffers from the start in every call)
   const size_t blk_bytes = 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2;
-  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes;
+  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes || ctx->rk2_scratch_layout != 1;
   M6_REQUIRE(ctx->rk2_scratch.reserve(blk_bytes) == 0, "step_MOM_dyn_split_RK2: out of device memory");
+  ctx->rk2_scratch_layout = 1;
   char *blk = (char *)ctx->rk2_scratch.p;
   double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3);
   double *vp = (double *)(blk + 3 * sz.u3), *v_bc = (double *)(blk + 3 * sz.u3 + sz.v3), *vh_in = (double *)(blk + 3 * sz.u3 + 2 * sz.v3);
@@ -360,8 +361,11 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   M6_REQUIRE(!VV || cs->visc, "step_MOM_dyn_split_RK2b: vertvisc_CSp needs the visc argument (cs->visc)");
 
   const size_t blk_bytes = 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2;
-  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes;
+  // (the block is shared with step_MOM_dyn_split_RK2, whose layout differs: after the other stepper the faces that rely on
+  // being zero hold other arrays' values, so a change of stepper zeroes the block like a new allocation)
+  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes || ctx->rk2_scratch_layout != 2;
   M6_REQUIRE(ctx->rk2_scratch.reserve(blk_bytes) == 0, "step_MOM_dyn_split_RK2b: out of device memory");
+  ctx->rk2_scratch_layout = 2;
   char *blk = (char *)ctx->rk2_scratch.p;
   double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3);
   double *vp = (double *)(blk + 3 * sz.u3), *v_bc = (double *)(blk + 3 * sz.u3 + sz.v3), *vh_in = (double *)(blk + 3 * sz.u3 + 2 * sz.v3);

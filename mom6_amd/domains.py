@@ -282,6 +282,17 @@ class Domain:
             exchange(1)
 
     # ---- the native (RCCL) domain of the library -----------------------------------------------------------
+    @staticmethod
+    def native_available():
+        """A LOCAL probe (no collective): can this process load RCCL and draw a unique id?  attach_native is itself collective
+        (broadcast, ncclCommInitRank), so every rank must agree on the answer of this probe before any rank enters it."""
+        import ctypes as C
+        from ._lib import lib
+        L = lib()
+        L.mom6hip_rccl_get_unique_id.argtypes = [C.c_void_p, C.c_int32]
+        uid = np.zeros(128, dtype=np.uint8)
+        return L.mom6hip_rccl_get_unique_id(uid.ctypes.data, 128) == 0
+
     def attach_native(self, dg):
         """mom6hip_domain_init_rccl: the group passes and reductions inside library calls become the library's own RCCL
         exchange on its communication stream (mom6_amd/csrc/domain_rccl.hip).  Rank 0 draws the RCCL unique id, the

@@ -6,7 +6,9 @@
 !!   * sum_across_PEs(domore_k) (MOM_tracer_advect.F90:305) and min_across_PEs(dtbt_max) (MOM_barotropic.F90:2915).
 !! The library's own wrap kernels are only used when the whole domain is one tile AND the shim knows the topology
 !! (REENTRANT_X / REENTRANT_Y read from the parameter file); otherwise reentrant_x = reentrant_y = 0 and every halo update
-!! goes through MOM6's pass_var, which is correct for any layout, mask table or periodicity (a tripolar fold is refused).
+!! goes through MOM6's pass_var, which is correct for any layout, mask table or periodicity.  TRIPOLAR_N is provided on ONE PE
+!! (the library's own fold, whose fold-line convention btstep's polarity swaps assume); with several PEs it is refused: FMS's
+!! pass_vector owns the sign and the fold-line row there, and that path has not run against FMS.
 !!
 !! Compiled inside a MOM6 source tree (it uses the real MOM_grid, MOM_domains, MOM_coms); tests/fortran/stubs holds
 !! type-only stand-ins so that this repository can at least compile and drive it on one PE.
@@ -99,9 +101,14 @@ subroutine mom6hip_context_create(G, GV, ctx, reentrant)
     cg%reentrant_x = merge(1, 0, reentrant_x) ; cg%reentrant_y = merge(1, 0, reentrant_y)
   endif
   ! TRIPOLAR_N: a tile that ends at the fold (btstep swaps the directional fits in its halo rows beyond the fold,
-  ! MOM_barotropic.F90:1471-1475, :4036-4064).  One PE: the library folds the halos itself; several PEs: MOM6's own pass_var
-  ! does (halo_cb), and the tiles must span x (LAYOUT = 1,N) for the library's index arithmetic of the swaps to hold.
+  ! MOM_barotropic.F90:1471-1475, :4036-4064).  One PE: the library folds the halos itself.  Several PEs are refused: a scalar
+  ! pass_var with the sign of vector components applied afterwards leaves the fold-line row (v and q at J = jec) to FMS's scalar
+  ! update, while FMS's pass_vector would enforce v(i,nj) = -v(ni+1-i,nj) and the library's fold leaves the row as computed; the
+  ! answers would depend on the layout.  (To lift this: carry the u / v partner through the callback and call pass_vector.)
   cg%tripolar_n = 0 ; on_fold_cb = .false.
+  if (know_topology .and. tripolar_saved .and. (num_PEs() > 1)) &
+    call MOM_error(FATAL, "mom6hip: TRIPOLAR_N with more than one PE is not provided by the GPU path (the fold-line "// &
+                          "convention of FMS's pass_vector has not been verified against the library's).")
   if (know_topology .and. tripolar_saved) then
     if (G%jec + G%jdg_offset == G%Domain%njglobal) then ; cg%tripolar_n = 1 ; on_fold_cb = .true. ; endif
     if (G%iec - G%isc + 1 /= G%Domain%niglobal) &
