@@ -568,7 +568,7 @@ typedef struct mom6hip_barotropic_cs {
   int32_t use_wide_halos;      /* BT_USE_WIDE_HALOS (1) */
   int32_t hvel_scheme;         /* MOM6HIP_BT_* */
   int32_t nstep_last;          /* CS%nstep_last (out) */
-  /* INTEGRAL_BT_CONTINUITY, (free), NONLINEAR_BT_CONTINUITY, BOUND_BT_CORRECTION without BT_cont bounds, GRADUAL_BT_ICS,
+  /* INTEGRAL_BT_CONTINUITY, (free), (free: NONLINEAR_BT_CONTINUITY is provided, see below), BOUND_BT_CORRECTION without BT_cont bounds, GRADUAL_BT_ICS,
    * BT_NONLIN_STRESS, DYNAMIC_SURFACE_PRESSURE, BT_LINEAR_WAVE_DRAG, CLIP_BT_VELOCITY, CALCULATE_SAL,
    * BT_USE_OLD_CORIOLIS_BRACKET_BUG, BAROTROPIC_ANSWER_DATE < 20190101 */
   int32_t unsupported[12];
@@ -577,7 +577,12 @@ typedef struct mom6hip_barotropic_cs {
                                 * MAXCFL_BT_CONT, and to the water in the cell (MOM_barotropic.F90:1587-1615) */
   int32_t BT_project_velocity; /* BT_PROJECT_VELOCITY (0): the velocities are stepped first and projected for the transports
                                 * (trans_wt = 1+bebt, -bebt; the pressure force from eta instead of eta_pred: :804-808, :1751, :1870) */
-  int32_t reserved1[2];
+  int32_t Nonlinear_continuity;       /* NONLINEAR_BT_CONTINUITY (0): without a BT_cont argument the open face areas follow the free
+                                       * surface (find_face_areas with eta, :4246-4262): in set_dtbt when eta is given (:2871), at the
+                                       * start of btstep (:1137-1138) and, with a positive update period, again before every
+                                       * Nonlin_cont_update_period-th barotropic step (:1852-1856; the stencil of the wide-halo march is 2
+                                       * then, :752-753).  With a BT_cont argument (USE_BT_CONT_TYPE, .testing/tc1, tc2) btstep ignores it. */
+  int32_t Nonlin_cont_update_period;  /* NONLIN_BT_CONT_UPDATE_PERIOD (1) */
   double *frhatu, *frhatv;     /* 3-D u / v: layer weights (btcalc) */
   double *eta_cor;             /* 2-D h: mass source over a baroclinic step (bt_mass_source) */
   double *IDatu, *IDatv;       /* 2-D u / v: inverse total depth at velocity points (barotropic_init :5070-5087) */
@@ -605,6 +610,9 @@ int mom6hip_bt_mass_source(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, cons
  * Sets cs->dtbt_max to the maximum stable step and cs->dtbt = dtbt_fraction * dtbt_max; with more than one tile the
  * minimum over the tiles is taken through the registered min callback (min_across_PEs, :2915).  pbce or gtot_est is used
  * (pbce may be NULL); BT_cont may be NULL. */
+int mom6hip_set_dtbt_eta(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *eta, const double *pbce,
+                         const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add, int32_t memspace);
+/* the same without the eta argument (eta not present) */
 int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *pbce,
                      const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add, int32_t memspace);
 

@@ -106,7 +106,7 @@ class PressureForceCS(C.Structure):
 
 # ---- MOM_barotropic -----------------------------------------------------------------------------------
 BT_THICK_SCHEMES = {"HARMONIC": 1, "ARITHMETIC": 2, "HYBRID": 3, "FROM_BT_CONT": 4}
-BT_UNSUPPORTED = ("INTEGRAL_BT_CONTINUITY", "(free slot)", "NONLINEAR_BT_CONTINUITY", "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS",
+BT_UNSUPPORTED = ("INTEGRAL_BT_CONTINUITY", "(free slot)", "(free slot 2)", "BOUND_BT_CORRECTION without BT_CONT_CORR_BOUNDS",
                   "GRADUAL_BT_ICS", "BT_NONLIN_STRESS", "DYNAMIC_SURFACE_PRESSURE", "BT_LINEAR_WAVE_DRAG",
                   "CLIP_BT_VELOCITY", "CALCULATE_SAL", "BT_USE_OLD_CORIOLIS_BRACKET_BUG", "BAROTROPIC_ANSWER_DATE<20190101")
 BT_CS_ARRAYS = (("frhatu", POS_U, 3), ("frhatv", POS_V, 3), ("eta_cor", POS_H, 2), ("IDatu", POS_U, 2), ("IDatv", POS_V, 2),
@@ -120,7 +120,8 @@ class BarotropicCS(C.Structure):
                 + [("reserved0", C.c_double * 6)]
                 + [(n, C.c_int32) for n in ("Sadourny", "linearized_BT_PV", "strong_drag", "visc_rem_u_uh0", "adjust_BT_cont",
                                            "use_wide_halos", "hvel_scheme", "nstep_last")]
-                + [("unsupported", C.c_int32 * 12), ("bound_BT_corr", C.c_int32), ("BT_project_velocity", C.c_int32), ("reserved1", C.c_int32 * 2)]
+                + [("unsupported", C.c_int32 * 12), ("bound_BT_corr", C.c_int32), ("BT_project_velocity", C.c_int32), ("Nonlinear_continuity", C.c_int32),
+                   ("Nonlin_cont_update_period", C.c_int32)]
                 + [(n, C.c_void_p) for n, _, _ in BT_CS_ARRAYS]
                 + [("reserved2", C.c_void_p * 6)])
 

@@ -35,6 +35,8 @@ class barotropic_CS:
         cont_bounds = bool(params.pop("BT_CONT_CORR_BOUNDS", True))
         maxcfl = float(params.pop("MAXCFL_BT_CONT", 0.25))
         project = bool(params.pop("BT_PROJECT_VELOCITY", False))      # :4536
+        nonlin = bool(params.pop("NONLINEAR_BT_CONTINUITY", False))   # :4526
+        nonlin_period = int(params.pop("NONLIN_BT_CONT_UPDATE_PERIOD", 1))   # :4530
         if bound and not (USE_BT_CONT_TYPE and cont_bounds):
             unsupported[3] = 1
         for k, v in params.items():
@@ -56,6 +58,7 @@ class barotropic_CS:
         st.hvel_scheme = _abi.BT_THICK_SCHEMES[BT_THICK_SCHEME]
         st.bound_BT_corr, st.maxCFL_BT_cont = int(bound), maxcfl
         st.BT_project_velocity = int(project)
+        st.Nonlinear_continuity, st.Nonlin_cont_update_period = int(nonlin), nonlin_period
         for q in range(12):
             st.unsupported[q] = unsupported[q]
         # DTBT: > 0 a time step in s, <= 0 minus the fraction of the stable maximum (0 = -0.98) (:4725-4735, :5012-5022)
@@ -105,6 +108,7 @@ def _setup():
         L.mom6hip_btcalc.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mom6hip_bt_mass_source.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mom6hip_set_dtbt.argtypes = [C.c_void_p, cs, C.c_void_p, C.POINTER(_abi.BTCont), C.c_double, C.c_double, C.c_int32]
+        L.mom6hip_set_dtbt_eta.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.POINTER(_abi.BTCont), C.c_double, C.c_double, C.c_int32]
         L.mom6hip_btstep.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4 + [C.c_double]
                                      + [C.c_void_p] * 11 + [C.POINTER(_abi.BTCont)] + [C.c_void_p] * 8 + [C.c_int32])
         L._bt_ready = True
@@ -161,8 +165,9 @@ def set_dtbt(G: DeviceGrid, CS: barotropic_CS, eta=None, pbce=None, BT_cont: BT_
         raise Mom6HipError("set_dtbt: Either pbce or gtot_est must be present.")
     sp = set()
     p = _P(sp, pbce)
+    pe = _P(sp, eta)
     bt = None if BT_cont is None else BT_cont.struct(sp)
-    check(_setup().mom6hip_set_dtbt(G.handle, C.byref(CS.st), p, None if bt is None else C.byref(bt),
+    check(_setup().mom6hip_set_dtbt_eta(G.handle, C.byref(CS.st), pe, p, None if bt is None else C.byref(bt),
                                     0.0 if gtot_est is None else float(gtot_est), float(SSH_add), _one_space(sp, CS, "set_dtbt")),
           "set_dtbt")
     return CS.st.dtbt_max

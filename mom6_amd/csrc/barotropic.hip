@@ -557,12 +557,18 @@ int mom6hip_bt_mass_source(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, cons
 
 int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *pbce, const mom6hip_bt_cont_t *BT_cont,
                      double gtot_est, double SSH_add, int32_t memspace) {
+  return mom6hip_set_dtbt_eta(ctx, cs, nullptr, pbce, BT_cont, gtot_est, SSH_add, memspace);
+}
+
+int mom6hip_set_dtbt_eta(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *eta, const double *pbce,
+                         const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "set_dtbt: null context");
   if (int rc = check_cs(cs, "set_dtbt")) return rc;
   const m6::GridDev g = ctx->g;
   const Sizes sz = sizes_of(g);
   m6::Stager st(ctx, memspace);
   const double *dp = pbce ? st.in(pbce, sz.h3) : nullptr;
+  const double *deta = (eta && !BT_cont && cs->Nonlinear_continuity) ? st.in(eta, sz.h2) : nullptr;
   const double *fru = pbce ? st.in((const double *)cs->frhatu, sz.u3) : nullptr, *frv = pbce ? st.in((const double *)cs->frhatv, sz.v3) : nullptr;
   double *Datu = (double *)st.scratch(sz.u2), *Datv = (double *)st.scratch(sz.v2);
   unsigned long long *res = (unsigned long long *)st.scratch(sizeof(unsigned long long));
@@ -586,6 +592,20 @@ int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const doub
     launch2d(s, g.isc, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int J) {
       const long n = g.v2(i, J);
       Datv[n] = m6::max2(m6::max2(m6::max2(b0[n], b1[n]), b2[n]), b3[n]);
+    });
+  } else if (deta) {   // NONLINEAR_BT_CONTINUITY with eta present :2871-2872: find_face_areas with eta :4246-4262, halo 0
+    const double Z_to_H = g.Z_to_H;
+    launch2d(s, g.isc - 1, g.iec, g.jsc, g.jec, [=] __device__(int I, int j) {
+      const double H1 = g.bathyT[g.h2(I, j)] * Z_to_H + deta[g.h2(I, j)], H2 = g.bathyT[g.h2(I + 1, j)] * Z_to_H + deta[g.h2(I + 1, j)];
+      double D = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) D = g.dy_Cu[g.u2(I, j)] * (2.0 * H1 * H2) / (H1 + H2);
+      Datu[g.u2(I, j)] = D;
+    });
+    launch2d(s, g.isc, g.iec, g.jsc - 1, g.jec, [=] __device__(int i, int J) {
+      const double H1 = g.bathyT[g.h2(i, J)] * Z_to_H + deta[g.h2(i, J)], H2 = g.bathyT[g.h2(i, J + 1)] * Z_to_H + deta[g.h2(i, J + 1)];
+      double D = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) D = g.dx_Cv[g.v2(i, J)] * (2.0 * H1 * H2) / (H1 + H2);
+      Datv[g.v2(i, J)] = D;
     });
   } else {   // find_face_areas with add_max :4283-4295, halo 0
     const double Z_to_H = g.Z_to_H, add = cs->Z_ref + SSH_add;
@@ -635,7 +655,11 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   const Sizes sz = sizes_of(g);
   const bool use_BT_cont = BT_cont != nullptr, interp = eta_PF_start != nullptr, add_uh0 = uh0 != nullptr;
   const bool find_etaav = etaav != nullptr, have_bot = taux_bot && tauy_bot;
-  const int stencil = 1;
+  // NONLINEAR_BT_CONTINUITY without a BT_cont: the face areas are refreshed from eta every Nonlin_cont_update_period steps, and
+  // the wide-halo march gives up two points a step (:751-753)
+  const bool nonlin_cont = !use_BT_cont && cs->Nonlinear_continuity;
+  const bool nonlin_update = nonlin_cont && cs->Nonlin_cont_update_period > 0;
+  const int stencil = nonlin_update ? 2 : 1;
 
   int num_cycles = 1;
   if (cs->use_wide_halos) num_cycles = std::min((is - g.isd) / stencil, (js - g.jsd) / stencil);
@@ -783,6 +807,22 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   const int hs = 1 + ievf - ie;
   const bool early_btcl_pass = use_BT_cont && add_uh0 && cs->adjust_BT_cont;
   std::function<void(int)> btcl_derive;
+  // find_face_areas with eta :4246-4262 (Boussinesq) on the stream `fs`: the harmonic mean of the two total depths
+  auto face_areas_eta = [&](hipStream_t fs, int hs) {
+    const double Z_to_H = g.Z_to_H;
+    launch2d(fs, is - 1 - hs, ie + hs, js - hs, je + hs, [=] __device__(int I, int j) {
+      const double H1 = g.bathyT[g.h2(I, j)] * Z_to_H + w.eta[g.h2(I, j)], H2 = g.bathyT[g.h2(I + 1, j)] * Z_to_H + w.eta[g.h2(I + 1, j)];
+      double D = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) D = g.dy_Cu[g.u2(I, j)] * (2.0 * H1 * H2) / (H1 + H2);
+      w.Datu[g.u2(I, j)] = D;
+    });
+    launch2d(fs, is - hs, ie + hs, js - 1 - hs, je + hs, [=] __device__(int i, int J) {
+      const double H1 = g.bathyT[g.h2(i, J)] * Z_to_H + w.eta[g.h2(i, J)], H2 = g.bathyT[g.h2(i, J + 1)] * Z_to_H + w.eta[g.h2(i, J + 1)];
+      double D = 0.0;
+      if ((H1 > 0.0) && (H2 > 0.0)) D = g.dx_Cv[g.v2(i, J)] * (2.0 * H1 * H2) / (H1 + H2);
+      w.Datv[g.v2(i, J)] = D;
+    });
+  };
   if (use_BT_cont) {   // set_local_BT_cont_types :3949 (dt = 1)
     const Btcl BU = w.BU, BV = w.BV;
     const double *a0 = bcU[0], *a1 = bcU[1], *a2 = bcU[2], *a3 = bcU[3], *a4 = bcU[4], *a5 = bcU[5];
@@ -828,6 +868,8 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     } else {
       btcl_derive(0);
     }
+  } else if (nonlin_cont) {   // :1137-1138
+    face_areas_eta(s, 1);
   } else {   // find_face_areas :4297-4310, halo 1
     const double Z_to_H = g.Z_to_H, Zr = cs->Z_ref;
     launch2d(s, is - 2, ie + 1, js - 1, je + 1, [=] __device__(int I, int j) {
@@ -1031,6 +1073,7 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     for (int n = n0; n <= n1; n++) {
       const int isv = rng[n].isv, iev = rng[n].iev, jsv = rng[n].jsv, jev = rng[n].jev;
       const double wt_end = n * p.Instep;
+      if (nonlin_update && (n > 1) && ((n - 1) % cs->Nonlin_cont_update_period == 0)) face_areas_eta(st, 1 + iev - ie);      // :1852-1856
       hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev + 1,
                          jsv - 1, jev + 1, wt_accel2[n]);
       const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;
@@ -1063,6 +1106,7 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   {
     auto add = [&](const void *q, size_t nbytes) { base_key.append((const char *)q, nbytes); };
     add(&w, sizeof(w)); add(&p, sizeof(p)); add(&nt, sizeof(nt)); add(&ctx->host.first_direction, sizeof(int32_t));
+    { const int32_t nl[2] = {nonlin_update ? 1 : 0, cs->Nonlin_cont_update_period}; add(nl, sizeof(nl)); }
     add(&c.ubtav, sizeof(double *)); add(&c.vbtav, sizeof(double *)); add(&duhbtav, sizeof(double *)); add(&dvhbtav, sizeof(double *));
     add(wt_vel.data(), sizeof(double) * wt_vel.size()); add(wt_eta.data(), sizeof(double) * wt_eta.size());
     add(wt_trans.data(), sizeof(double) * wt_trans.size()); add(wt_accel.data(), sizeof(double) * wt_accel.size());

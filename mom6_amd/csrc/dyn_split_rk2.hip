@@ -211,7 +211,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
                             cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
     if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));
   }
-  if (calc_dtbt) CALL(mom6hip_set_dtbt(ctx, BT, cs->pbce, nullptr, 0.0, 0.0, D));                       // :651
+  if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));                       // :651
   const bool lf = cs->BT_use_layer_fluxes != 0;
   CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :655
                       cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
@@ -444,7 +444,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,      // :652
                           cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
   if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :655-658
-  if (calc_dtbt) CALL(mom6hip_set_dtbt(ctx, BT, cs->pbce, nullptr, 0.0, 0.0, D));                       // :664
+  if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));                       // :664
   CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :668
                       cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
                       nullptr, uh_in, vh_in, u_inst, v_inst, nullptr, D));

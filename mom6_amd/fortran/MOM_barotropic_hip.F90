@@ -155,7 +155,7 @@ subroutine set_dtbt(G, GV, US, CS, eta, pbce, BT_cont, gtot_est, SSH_add)
   real,               optional, intent(in)    :: SSH_add
 
   type(mom6hip_bt_cont_t), target :: cbt
-  type(c_ptr) :: p_bt, p_pbce
+  type(c_ptr) :: p_bt, p_pbce, p_eta
   real :: gt, ssh
   integer :: rc
 
@@ -167,7 +167,8 @@ subroutine set_dtbt(G, GV, US, CS, eta, pbce, BT_cont, gtot_est, SSH_add)
   p_pbce = c_null_ptr ; if (present(pbce)) p_pbce = c_loc(pbce)
   gt = 0.0 ; if (present(gtot_est)) gt = gtot_est
   ssh = 0.0 ; if (present(SSH_add)) ssh = SSH_add
-  rc = mom6hip_set_dtbt(mom6hip_shared_context(G, GV), CS%st, p_pbce, p_bt, gt, ssh, MOM6HIP_MEM_HOST)
+  p_eta = c_null_ptr ; if (present(eta)) p_eta = c_loc(eta)      ! read with NONLINEAR_BT_CONTINUITY and no BT_cont (:2871)
+  rc = mom6hip_set_dtbt_eta(mom6hip_shared_context(G, GV), CS%st, p_eta, p_pbce, p_bt, gt, ssh, MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "set_dtbt")
   CS%dtbt = CS%st%dtbt
 end subroutine set_dtbt
@@ -252,7 +253,7 @@ subroutine barotropic_init(u, v, h, eta, Time, G, GV, US, param_file, diag, CS, 
   if (.not.CS%split) return
   if (.not.GV%Boussinesq) call MOM_error(FATAL, "barotropic_init (HIP): a non-Boussinesq vertical grid is not supported by the GPU path.")
 
-  CS%st%unsupported(:) = 0 ; CS%st%reserved0(:) = 0.0 ; CS%st%reserved1(:) = 0
+  CS%st%unsupported(:) = 0 ; CS%st%reserved0(:) = 0.0
   call get_param(param_file, mdl, "USE_BT_CONT_TYPE", use_BT_cont_type, &
                  "If true, use a structure with elements that describe effective face areas from the summed continuity solver.", &
                  default=.true.)
@@ -268,7 +269,12 @@ subroutine barotropic_init(u, v, h, eta, Time, G, GV, US, param_file, diag, CS, 
     call get_param(param_file, mdl, "MAXCFL_BT_CONT", CS%st%maxCFL_BT_cont, units="nondim", default=0.25)
   endif
   call get_param(param_file, mdl, "GRADUAL_BT_ICS", flag, default=.false.) ; call refuse(flag, "GRADUAL_BT_ICS")
-  call get_param(param_file, mdl, "NONLINEAR_BT_CONTINUITY", flag, default=.false.) ; call refuse(flag, "NONLINEAR_BT_CONTINUITY")
+  call get_param(param_file, mdl, "NONLINEAR_BT_CONTINUITY", flag, &
+                 "If true, use nonlinear transports in the barotropic continuity equation.", default=.false.)
+  CS%st%Nonlinear_continuity = merge(1, 0, flag)
+  call get_param(param_file, mdl, "NONLIN_BT_CONT_UPDATE_PERIOD", CS%st%Nonlin_cont_update_period, &
+                 "If NONLINEAR_BT_CONTINUITY is true, this is the number of barotropic time steps between updates to the face areas, "// &
+                 "or 0 to update only before the barotropic stepping.", units="nondim", default=1, do_not_log=.not.flag)
   call get_param(param_file, mdl, "BT_PROJECT_VELOCITY", flag, default=.false.) ; CS%st%BT_project_velocity = merge(1, 0, flag)
   call get_param(param_file, mdl, "BT_NONLIN_STRESS", flag, default=.false.) ; call refuse(flag, "BT_NONLIN_STRESS")
   call get_param(param_file, mdl, "DYNAMIC_SURFACE_PRESSURE", flag, default=.false.) ; call refuse(flag, "DYNAMIC_SURFACE_PRESSURE")

@@ -117,7 +117,8 @@ type, bind(c) :: mom6hip_barotropic_cs_t
   integer(c_int32_t) :: unsupported(12)
   integer(c_int32_t) :: bound_BT_corr   !< BOUND_BT_CORRECTION with BT_CONT_CORR_BOUNDS and a BT_cont argument
   integer(c_int32_t) :: BT_project_velocity   !< BT_PROJECT_VELOCITY
-  integer(c_int32_t) :: reserved1(2)
+  integer(c_int32_t) :: Nonlinear_continuity = 0        !< NONLINEAR_BT_CONTINUITY
+  integer(c_int32_t) :: Nonlin_cont_update_period = 1   !< NONLIN_BT_CONT_UPDATE_PERIOD
   type(c_ptr) :: frhatu, frhatv, eta_cor, IDatu, IDatv, ubtav, vbtav, q_D, D_u_Cor, D_v_Cor
   type(c_ptr) :: reserved2(6)
 end type mom6hip_barotropic_cs_t
@@ -524,6 +525,15 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_set_dtbt
+
+  function mom6hip_set_dtbt_eta(ctx, cs, eta, pbce, BT_cont, gtot_est, SSH_add, memspace) bind(c, name="mom6hip_set_dtbt_eta") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_barotropic_cs_t
+    type(c_ptr), value :: ctx, eta, pbce, BT_cont
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    real(c_double), value :: gtot_est, SSH_add
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_set_dtbt_eta
 
   function mom6hip_btstep(ctx, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, RZ_to_H, pbce, eta_PF_in, &
                           U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, &

@@ -18,6 +18,27 @@ def EOS_init(form="WRIGHT", Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.8):
     return _abi.EOS(_abi.EOS_FORMS[form], 0, float(Rho_T0_S0), float(dRho_dT), float(dRho_dS))
 
 
+def calculate_density(T, S, pressure, rho, EOS, G: DeviceGrid, rho_ref=None):
+    """calculate_density(T, S, pressure, rho, EOS, dom, rho_ref) -- MOM_EOS.F90:299, on the points of four equally shaped arrays
+    (numpy: staged; torch.cuda: in place); with rho_ref the density anomaly from it."""
+    spaces = set()
+    n = None
+    ptrs = []
+    for a in (T, S, pressure, rho):
+        p, sp = _ptr_space(a)
+        spaces.add(sp); ptrs.append(C.c_void_p(p))
+        m = int(a.numel()) if hasattr(a, "numel") else int(a.size)
+        if n is not None and m != n:
+            raise Mom6HipError("calculate_density: T, S, pressure and rho must have the same number of points")
+        n = m
+    if len(spaces) != 1:
+        raise Mom6HipError("calculate_density: all fields must be in the same memory space")
+    L = lib()
+    L.mom6hip_calculate_density.argtypes = ([C.c_void_p, C.POINTER(_abi.EOS)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_double, C.c_int32])
+    check(L.mom6hip_calculate_density(G.handle, C.byref(EOS), *ptrs, n, 0 if rho_ref is None else 1, 0.0 if rho_ref is None else float(rho_ref),
+                                      spaces.pop()), "calculate_density")
+
+
 def PressureForce_init(grid, Rho0=None, boundary_extrap=True, useMassWghtInterp=False, Z_ref=0.0, reconstruct=True, use_ALE=True,
                        nk_rho_varies=0, P_Ref=2.0e7, Rlay=None, g_prime=None):
     """PressureForce_FV_init (MOM_PressureForce_FV.F90:921): RHO_PGF_REF, RECONSTRUCT_FOR_PRESSURE,

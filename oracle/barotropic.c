@@ -242,6 +242,25 @@ static void find_face_areas(const mom6hip_grid_t *G, const mom6hip_barotropic_cs
   }
 }
 
+/* find_face_areas :4246-4262, the branch with eta (Boussinesq): harmonic-mean total depths, NONLINEAR_BT_CONTINUITY */
+static void find_face_areas_eta(const mom6hip_grid_t *G, const mom6hip_barotropic_cs_t *CS, double *Datu, double *Datv, int hs,
+                                const double *eta) {
+  const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
+  (void)CS;
+  ORC_PAR
+  for (int j = js - hs; j <= je + hs; j++) for (int I = is - 1 - hs; I <= ie + hs; I++) {
+    double H1 = G->bathyT[ORC_H2(G, I, j)] * G->Z_to_H + eta[ORC_H2(G, I, j)], H2 = G->bathyT[ORC_H2(G, I + 1, j)] * G->Z_to_H + eta[ORC_H2(G, I + 1, j)];
+    Datu[ORC_U2(G, I, j)] = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Datu[ORC_U2(G, I, j)] = G->dy_Cu[ORC_U2(G, I, j)] * (2.0 * H1 * H2) / (H1 + H2);
+  }
+  ORC_PAR
+  for (int J = js - 1 - hs; J <= je + hs; J++) for (int i = is - hs; i <= ie + hs; i++) {
+    double H1 = G->bathyT[ORC_H2(G, i, J)] * G->Z_to_H + eta[ORC_H2(G, i, J)], H2 = G->bathyT[ORC_H2(G, i, J + 1)] * G->Z_to_H + eta[ORC_H2(G, i, J + 1)];
+    Datv[ORC_V2(G, i, J)] = 0.0;
+    if ((H1 > 0.0) && (H2 > 0.0)) Datv[ORC_V2(G, i, J)] = G->dx_Cv[ORC_V2(G, i, J)] * (2.0 * H1 * H2) / (H1 + H2);
+  }
+}
+
 static long n_h2(const mom6hip_grid_t *G) { return (long)ORC_NIH(G) * ORC_NJH(G); }
 static long n_u2(const mom6hip_grid_t *G) { return (long)(ORC_NIH(G) + 1) * ORC_NJH(G); }
 static long n_v2(const mom6hip_grid_t *G) { return (long)ORC_NIH(G) * (ORC_NJH(G) + 1); }
@@ -393,6 +412,10 @@ int orc_bt_mass_source(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, con
 /* set_dtbt :2801 (one tile: min_across_PEs is the identity) */
 int orc_set_dtbt(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *pbce, const mom6hip_bt_cont_t *BT_cont,
                  double gtot_est, double SSH_add) {
+  return orc_set_dtbt_eta(G, CS, NULL, pbce, BT_cont, gtot_est, SSH_add);
+}
+int orc_set_dtbt_eta(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *eta, const double *pbce,
+                     const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   double *Datu = (double *)calloc(n_u2(G), sizeof(double)), *Datv = (double *)calloc(n_v2(G), sizeof(double));
   double *gt[4];
@@ -407,6 +430,8 @@ int orc_set_dtbt(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const dou
       long n = ORC_V2(G, i, J);
       Datv[n] = max4(BT_cont->FA_v_NN[n], BT_cont->FA_v_N0[n], BT_cont->FA_v_S0[n], BT_cont->FA_v_SS[n]);
     }
+  } else if (CS->Nonlinear_continuity && eta) {      /* :2871-2872 */
+    find_face_areas_eta(G, CS, Datu, Datv, 0, eta);
   } else {
     find_face_areas(G, CS, Datu, Datv, 0, 1, SSH_add);
   }
@@ -463,7 +488,9 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   const double accel_underflow = CS->vel_underflow * Idt;
   const int use_BT_cont = BT_cont != NULL;
   const int interp_eta_PF = eta_PF_start != NULL;
-  const int stencil = 1;
+  /* :751-753 */
+  const int nonlin_update = (!use_BT_cont) && CS->Nonlinear_continuity && (CS->Nonlin_cont_update_period > 0);
+  const int stencil = nonlin_update ? 2 : 1;
   const int find_etaav = etaav != NULL;
   const int add_uh0 = uh0 != NULL;
   (void)h_neglect;
@@ -590,6 +617,8 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                       BT_cont->uBT_WW, &BU, 1 + ievf - ie);
     set_local_bt_cont(G, 0, BT_cont->FA_v_NN, BT_cont->FA_v_N0, BT_cont->FA_v_S0, BT_cont->FA_v_SS, BT_cont->vBT_NN,
                       BT_cont->vBT_SS, &BV, 1 + ievf - ie);
+  } else if (CS->Nonlinear_continuity) {      /* :1137-1138 */
+    find_face_areas_eta(G, CS, Datu, Datv, 1, eta);
   } else {
     find_face_areas(G, CS, Datu, Datv, 1, 0, 0.0);
   }
@@ -836,6 +865,10 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       isv = isvf; iev = ievf; jsv = jsvf; jev = jevf;
     } else {
       isv = isv + stencil; iev = iev - stencil; jsv = jsv + stencil; jev = jev - stencil;
+    }
+    /* :1852-1856 */
+    if (nonlin_update) {
+      if ((n > 1) && ((n - 1) % CS->Nonlin_cont_update_period == 0)) find_face_areas_eta(G, CS, Datu, Datv, 1 + iev - ie, eta);
     }
 
     /* predictor continuity :1870-1909 (.not.project_velocity) */

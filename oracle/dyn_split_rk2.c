@@ -130,7 +130,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
                          NULL, NULL, BTC, NULL, NULL));
     if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));
   }
-  if (calc_dtbt) orc_set_dtbt(G, BT, CS->pbce, NULL, 0.0, 0.0);                                        /* :651 */
+  if (calc_dtbt) orc_set_dtbt_eta(G, BT, eta, CS->pbce, NULL, 0.0, 0.0);                                        /* :651 */
   /* predictor btstep :655 */
   {
     const int lf = CS->BT_use_layer_fluxes;
@@ -329,7 +329,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL, CS->visc_rem_u, CS->visc_rem_v,
                        NULL, NULL, BTC, NULL, NULL));
   if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                            /* :655-658 */
-  if (calc_dtbt) orc_set_dtbt(G, BT, CS->pbce, NULL, 0.0, 0.0);                                        /* :664 */
+  if (calc_dtbt) orc_set_dtbt_eta(G, BT, eta, CS->pbce, NULL, 0.0, 0.0);                                        /* :664 */
   /* predictor btstep :668 */
   CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
                    CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,

