@@ -648,8 +648,9 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
  * (defaults of vertvisc_init :2465-2961 in brackets) and the arrays the module keeps between its three entry points.
  * a_u / a_v: (nk+1) interfaces at u / v points [H T-1]; h_u / h_v: nk layers [H].
  * Provided: BOTTOMDRAGLAW or KV_EXTRA_BBL or neither, HARMONIC_VISC, HARMONIC_BL_SCALE, KV_ML_INVZ2 with HMIX_FIXED,
- * visc%Kv_shear, visc%Ray_u/v, DIRECT_STRESS, the CFL-based or MAXVEL velocity truncation.  Not provided (refused by
- * name): DYNAMIC_VISCOUS_ML, bulk mixed layer (nkml > 0), FIXED_DEPTH_LOTW_ML, LOTW_VISCOUS_ML_FLOOR, USE_GL90_IN_SSW,
+ * visc%Kv_shear, visc%Ray_u/v, DIRECT_STRESS, the CFL-based or MAXVEL velocity truncation, DYNAMIC_VISCOUS_ML and the
+ * viscous mixed layer of a bulk mixed layer (nkml > 0).  Not provided (refused by name): FIXED_DEPTH_LOTW_ML,
+ * LOTW_VISCOUS_ML_FLOOR, USE_GL90_IN_SSW,
  * STOKES_MIXING_COMBINED / FPMIX, ice shelves, OBC, visc%Kv_shear_Bu, VERT_FRICTION_ANSWER_DATE < 20190101,
  * non-Boussinesq, U_TRUNC_FILE / V_TRUNC_FILE.
  */
@@ -665,13 +666,18 @@ typedef struct mom6hip_vertvisc_cs {
   double CFL_trunc;       /* CFL_TRUNCATE (0.5) */
   double vel_underflow;   /* VEL_UNDERFLOW [L T-1] (0) */
   double H_to_RZ;         /* GV%H_to_RZ */
-  double reserved0[5];
+  double vonKar;          /* VON_KARMAN_CONST (0.41): the surface boundary layer viscosity of dynamic_viscous_ML / nkml > 0 */
+  int32_t dynamic_viscous_ML; /* DYNAMIC_VISCOUS_ML (0): find_coupling_coef adds the viscosity of a surface boundary layer whose
+                                 fractional number of layers set_viscous_ML left in visc%nkml_visc_u/v (:2047-2252, the branch
+                                 without LOTW_VISCOUS_ML_FLOOR); needs visc%ustar */
+  int32_t nkml;           /* GV%nkml (0): with a bulk mixed layer and no dynamic_viscous_ML its nkml layers are the boundary layer */
+  double reserved0[3];
   int32_t bottomdraglaw;  /* BOTTOMDRAGLAW (1) */
   int32_t harmonic_visc;  /* HARMONIC_VISC (0) */
   int32_t direct_stress;  /* DIRECT_STRESS (0) */
   int32_t CFL_based_trunc;/* CFL_BASED_TRUNCATIONS (1) */
   int32_t answer_date;    /* VERT_FRICTION_ANSWER_DATE (99991231); >= 20190101 */
-  int32_t unsupported[7]; /* dynamic_viscous_ML, nkml, fixed_LOTW_ML, apply_LOTW_floor, use_GL90_in_SSW, StokesMixing,
+  int32_t unsupported[7]; /* (free), (free), fixed_LOTW_ML, apply_LOTW_floor, use_GL90_in_SSW, StokesMixing,
                              non_Boussinesq: any nonzero is refused */
   int64_t ntrunc;         /* CS%ntrunc: velocity truncations so far (see mom6hip_vertvisc_ntrunc) */
   double *a_u, *a_v, *h_u, *h_v;
@@ -685,7 +691,12 @@ typedef struct mom6hip_vertvisc_type {
   const double *Ray_u, *Ray_v;              /* 3-D, u / v points [H T-1], or NULL */
   const double *Kv_shear;                   /* (nk+1) interfaces at h points [H Z T-1], or NULL */
   const double *Kv_shear_Bu;                /* must be NULL */
-  const void *reserved[4];
+  const double *nkml_visc_u, *nkml_visc_v;  /* 2-D, u / v points: the fractional number of layers in the viscous surface boundary
+                                               layer; WRITTEN by set_viscous_ML, read by vertvisc_coef (DYNAMIC_VISCOUS_ML) */
+  const double *ustar;                      /* 2-D, h points [Z T-1]: forces%ustar as find_ustar returns it (MOM_forcing_type.F90
+                                               :1236, Boussinesq); read by set_viscous_ML and by vertvisc_coef with
+                                               DYNAMIC_VISCOUS_ML or nkml > 0 (it is a member of `forces` in the reference) */
+  const void *reserved[1];
 } mom6hip_vertvisc_type_t;
 
 /* vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, VarMix)       MOM_vert_friction.F90:1168
@@ -731,8 +742,8 @@ int mom6hip_vertvisc_remnant(mom6hip_ctx_t *ctx, const mom6hip_vertvisc_cs_t *cs
  * state) or the layer target densities GV%Rlay, BBL_THICK_MIN, KV_BBL_MIN, CORRECT_BBL_BOUNDS, DRAG_AS_BODY_FORCE, the
  * kappa-shear cap of the layer thickness (RiNo_mix).  Not provided (refused by name): CHANNEL_DRAG, BBL_USE_TIDAL_BG,
  * a bulk mixed layer (nkml > 0), non-Boussinesq mode (tv%SpV_avg), tv%p_surf, OBC, porous barriers.
- * set_viscous_ML (:1898) does nothing unless DYNAMIC_VISCOUS_ML or an ice shelf is present (:2043-2044); both are refused,
- * so mom6hip_set_viscous_ml returns at once like the reference.
+ * set_viscous_ML (:1898) does nothing unless DYNAMIC_VISCOUS_ML or an ice shelf is present (:2043-2044); DYNAMIC_VISCOUS_ML
+ * is provided (.testing/tc1, tc2), ice shelves are not.
  */
 typedef struct mom6hip_set_visc_cs {
   double cdrag;            /* CDRAG (0.003) */
@@ -743,7 +754,14 @@ typedef struct mom6hip_set_visc_cs {
   double Kv_BBL_min;       /* KV_BBL_MIN [H Z T-1] (KV) */
   double BBL_thick_max;    /* G%Rad_Earth_L*US%L_to_Z [Z] (6.378e6) */
   double H_to_RZ;          /* GV%H_to_RZ */
-  double reserved0[8];
+  double omega;            /* OMEGA (7.2921e-5) [T-1] */
+  double omega_frac;       /* ML_OMEGA_FRAC (0) */
+  double ustar_min;        /* 2e-4*omega*(GV%Angstrom_H + GV%H_subroundoff) (:2998) */
+  double TKE_decay;        /* TKE_DECAY_VISC (= TKE_DECAY, 0) */
+  double bulk_Ri_ML;       /* BULK_RI_ML_VISC (= BULK_RI_ML, 0) */
+  double c_Smag;           /* SMAG_CONST_CHANNEL (SMAG_LAP_CONST or 0.15): CHANNEL_DRAG */
+  double Chan_drag_max_vol;/* CHANNEL_DRAG_MAX_BBL_THICK [Z] (-1: no fixed limit) */
+  double reserved0[1];
   int32_t bottomdraglaw;   /* BOTTOMDRAGLAW (1): without it set_viscous_BBL returns at once (:321) */
   int32_t linear_drag;     /* LINEAR_DRAG (0) */
   int32_t BBL_use_EOS;     /* BBL_USE_EOS (= USE_EOS) */
@@ -751,10 +769,14 @@ typedef struct mom6hip_set_visc_cs {
   int32_t body_force_drag; /* DRAG_AS_BODY_FORCE (0): needs visc%Ray_u / %Ray_v */
   int32_t RiNo_mix;        /* kappa_shear_is_used (0) */
   int32_t initialized;
-  int32_t unsupported[9];  /* Channel_drag, BBL_use_tidal_bg, dynamic_viscous_ML, nkml, non_Boussinesq, p_surf, OBC, pbv, ice_shelf:
-                              any nonzero is refused */
-  const double *Rlay;      /* GV%Rlay(1:nk) [R] (HOST array), read when BBL_use_EOS = 0 */
-  void *reserved1[3];
+  int32_t unsupported[9];  /* Channel_drag (until provided), BBL_use_tidal_bg, (free), (free), non_Boussinesq, p_surf, OBC, pbv,
+                              ice_shelf: any nonzero is refused */
+  const double *Rlay;      /* GV%Rlay(1:nk) [R] (HOST array), read when BBL_use_EOS = 0 (and by set_viscous_ML without an EOS) */
+  int32_t dynamic_viscous_ML;       /* DYNAMIC_VISCOUS_ML (0): set_viscous_ML finds the viscous mixed layer (:2111-2230, :2400-2506) */
+  int32_t nkml;                     /* GV%nkml (0; 2 with the bulk mixed layer): the layers that are always in the mixed layer */
+  int32_t Channel_drag;             /* CHANNEL_DRAG (0) */
+  int32_t concave_trigonometric_L;  /* TRIG_CHANNEL_DRAG_WIDTHS (1) */
+  void *reserved1[1];
 } mom6hip_set_visc_cs_t;
 
 /* set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)                                   MOM_set_viscosity.F90:134
@@ -767,8 +789,15 @@ int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs,
                             const mom6hip_vertvisc_type_t *visc, int32_t memspace);
 
 /* set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)                                                :1898
- * returns at once unless DYNAMIC_VISCOUS_ML (refused by mom6hip_vertvisc_* as well) or an ice shelf is present. */
-int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs);
+ * Returns at once unless DYNAMIC_VISCOUS_ML (ice shelves are not provided) (:2043-2044).  With it: the bulk-Richardson-number
+ * search down each velocity column for the base of the viscous surface boundary layer (:2111-2230 at u points, :2400-2506 at
+ * v points), written to visc->nkml_visc_u / nkml_visc_v.  tv%T, tv%S, tv%eqn_of_state as T, S, eos (eos NULL: GV%Rlay from
+ * cs->Rlay); forces%taux, %tauy as taux, tauy; forces%ustar as visc->ustar (tv%p_surf is not provided).  The reference's
+ * exp(-htot*Idecay_len_TKE) (:2178) is evaluated correctly rounded (as is btstep's power, see mom6hip_btstep).
+ * Metrics needed: mask2dCu, mask2dCv, CoriolisBu. */
+int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+                           const double *h, const double *T, const double *S, const mom6hip_eos_t *eos, const double *taux,
+                           const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, int32_t memspace);
 
 /* ---- MOM_tracer_hor_diff ------------------------------------------------------------------------ */
 
@@ -917,7 +946,9 @@ typedef struct mom6hip_dyn_split_rk2_cs {
   /* SPLIT_RK2B only (MOM_dynamics_split_RK2b.F90:141-146): the barotropic velocity increments between the filtered and
    * the instantaneous velocities, at u / v points; restart fields du_avg_inst / dv_avg_inst (:1181-1186) */
   double *du_av_inst, *dv_av_inst;
-  void *reserved2[2];
+  const mom6hip_set_visc_cs_t *set_visc_CSp;  /* NULL, or with dynamic_viscous_ML: set_viscous_ML is called at :592 (visc->ustar,
+                                                 visc->nkml_visc_u/v must be set) */
+  void *reserved2[1];
 } mom6hip_dyn_split_rk2_cs_t;
 
 /* The part of initialize_dyn_split_RK2 (:1326) that sets state: eta from the layer thicknesses (:1521-1535),

@@ -127,17 +127,20 @@ class BarotropicCS(C.Structure):
 
 
 # ---- MOM_set_viscosity ------------------------------------------------------------------------------------
-SET_VISC_UNSUPPORTED = ("Channel_drag", "BBL_use_tidal_bg", "dynamic_viscous_ML", "nkml", "non_Boussinesq", "p_surf", "OBC", "pbv", "ice_shelf")
+SET_VISC_UNSUPPORTED = ("Channel_drag", "BBL_use_tidal_bg", "(free)", "(free 2)", "non_Boussinesq", "p_surf", "OBC", "pbv", "ice_shelf")
 
 
 class SetViscCS(C.Structure):
     """mom6hip_set_visc_cs_t (include/mom6hip.h)."""
     _fields_ = ([(n, C.c_double) for n in ("cdrag", "drag_bg_vel", "Hbbl", "dz_bbl", "BBL_thick_min", "Kv_BBL_min", "BBL_thick_max", "H_to_RZ")]
-                + [("reserved0", C.c_double * 8)]
+                + [(n, C.c_double) for n in ("omega", "omega_frac", "ustar_min", "TKE_decay", "bulk_Ri_ML", "c_Smag", "Chan_drag_max_vol")]
+                + [("reserved0", C.c_double * 1)]
                 + [(n, C.c_int32) for n in ("bottomdraglaw", "linear_drag", "BBL_use_EOS", "correct_BBL_bounds", "body_force_drag", "RiNo_mix",
                                            "initialized")]
                 + [("unsupported", C.c_int32 * 9)]
-                + [("Rlay", C.c_void_p), ("reserved1", C.c_void_p * 3)])
+                + [("Rlay", C.c_void_p)]
+                + [(n, C.c_int32) for n in ("dynamic_viscous_ML", "nkml", "Channel_drag", "concave_trigonometric_L")]
+                + [("reserved1", C.c_void_p * 1)])
 
 
 # ---- MOM_hor_visc -----------------------------------------------------------------------------------------
@@ -189,11 +192,11 @@ class DynSplitRK2CS(C.Structure):
                  ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
                  ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("hor_visc", C.c_void_p)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
-                + [("reserved2", C.c_void_p * 2)])
+                + [("set_visc_CSp", C.c_void_p), ("reserved2", C.c_void_p * 1)])
 
 
 # ---- MOM_vert_friction ------------------------------------------------------------------------------------
-VERTVISC_UNSUPPORTED = ("dynamic_viscous_ML", "nkml", "fixed_LOTW_ML", "apply_LOTW_floor", "use_GL90_in_SSW", "StokesMixing",
+VERTVISC_UNSUPPORTED = ("(free)", "(free 2)", "fixed_LOTW_ML", "apply_LOTW_floor", "use_GL90_in_SSW", "StokesMixing",
                         "non_Boussinesq")
 VERTVISC_CS_ARRAYS = (("a_u", POS_U, 1), ("a_v", POS_V, 1), ("h_u", POS_U, 0), ("h_v", POS_V, 0))      # (name, pos, extra interfaces)
 
@@ -202,7 +205,7 @@ class VertviscCS(C.Structure):
     """mom6hip_vertvisc_cs_t (include/mom6hip.h)."""
     _fields_ = ([(n, C.c_double) for n in ("Hmix", "Hmix_stress", "Kvml_invZ2", "Kv", "Hbbl", "Kv_extra_bbl", "harm_BL_val", "maxvel",
                                            "CFL_trunc", "vel_underflow", "H_to_RZ")]
-                + [("reserved0", C.c_double * 5)]
+                + [("vonKar", C.c_double), ("dynamic_viscous_ML", C.c_int32), ("nkml", C.c_int32), ("reserved0", C.c_double * 3)]
                 + [(n, C.c_int32) for n in ("bottomdraglaw", "harmonic_visc", "direct_stress", "CFL_based_trunc", "answer_date")]
                 + [("unsupported", C.c_int32 * 7), ("ntrunc", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("a_u", "a_v", "h_u", "h_v")] + [("reserved1", C.c_void_p * 4)])
@@ -211,7 +214,7 @@ class VertviscCS(C.Structure):
 class VertviscType(C.Structure):
     """mom6hip_vertvisc_type_t (include/mom6hip.h)."""
     _fields_ = ([(n, C.c_void_p) for n in ("Kv_bbl_u", "Kv_bbl_v", "bbl_thick_u", "bbl_thick_v", "Ray_u", "Ray_v", "Kv_shear",
-                                           "Kv_shear_Bu")] + [("reserved", C.c_void_p * 4)])
+                                           "Kv_shear_Bu", "nkml_visc_u", "nkml_visc_v", "ustar")] + [("reserved", C.c_void_p * 1)])
 
 
 # ---- z* regridding ----------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 // holds the BT_cont fit of that face in registers, and travels with eta/ubt/vbt in the group pass; it is the same
 // pure function of (ubt, fit, uhbt0) that the reference evaluates after the pass.
 #include "common.hpp"
+#include "cr_math.hpp"
 
 #include <algorithm>
 #include <string>
@@ -31,68 +32,7 @@ namespace {
 
 constexpr double SUBROUNDOFF = 1e-30;   // MOM_barotropic.F90:413
 
-// ---- correctly rounded x**y for 0 < x <= 1, 0 < y <= 1 (bt_rem = av_rem ** Instep, :1529) ---------------------------
-// double-double log and exp from + - * / fma only, rounded once; the test suite's CPU checker repeats this operation
-// order so that the two agree bit for bit (DESIGN.md "btstep").
-struct dd_t { double hi, lo; };
-__device__ __forceinline__ dd_t dd_fast2sum(double a, double b) { double s = a + b; return {s, b - (s - a)}; }
-__device__ __forceinline__ dd_t dd_2sum(double a, double b) {
-  double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)};
-}
-__device__ __forceinline__ dd_t dd_2prod(double a, double b) { double p = a * b; return {p, __builtin_fma(a, b, -p)}; }
-__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) {
-  dd_t s = dd_2sum(a.hi, b.hi), t = dd_2sum(a.lo, b.lo);
-  s.lo += t.hi; s = dd_fast2sum(s.hi, s.lo); s.lo += t.lo; return dd_fast2sum(s.hi, s.lo);
-}
-__device__ __forceinline__ dd_t dd_add_d(dd_t a, double b) {
-  dd_t s = dd_2sum(a.hi, b); s.lo += a.lo; return dd_fast2sum(s.hi, s.lo);
-}
-__device__ __forceinline__ dd_t dd_mul(dd_t a, dd_t b) {
-  dd_t p = dd_2prod(a.hi, b.hi); p.lo += a.hi * b.lo + a.lo * b.hi; return dd_fast2sum(p.hi, p.lo);
-}
-__device__ __forceinline__ dd_t dd_mul_d(dd_t a, double b) {
-  dd_t p = dd_2prod(a.hi, b); p.lo += a.lo * b; return dd_fast2sum(p.hi, p.lo);
-}
-__device__ dd_t dd_div(dd_t a, dd_t b) {
-  double q1 = a.hi / b.hi;
-  dd_t r = dd_add(a, dd_mul_d(b, -q1));
-  double q2 = r.hi / b.hi;
-  r = dd_add(r, dd_mul_d(b, -q2));
-  double q3 = r.hi / b.hi;
-  dd_t q = dd_fast2sum(q1, q2);
-  return dd_add_d(q, q3);
-}
-__device__ double cr_pow(double x, double y) {
-  if (x == 1.0) return 1.0;
-  const dd_t LN2 = {0.6931471805599453094, 2.3190468138462995584e-17};
-  // log
-  int e;
-  double m = frexp(x, &e);
-  if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }
-  dd_t s = dd_div(dd_2sum(m, -1.0), dd_2sum(m, 1.0)), s2 = dd_mul(s, s);
-  dd_t sum = {0.0, 0.0};
-  for (int k = 24; k >= 1; k--) {
-    dd_t c = {1.0, 0.0}, dk = {(double)(2 * k + 1), 0.0};
-    sum = dd_mul(dd_add(dd_div(c, dk), sum), s2);
-  }
-  sum = dd_add_d(sum, 1.0);
-  dd_t r = dd_mul(s, sum); r.hi *= 2.0; r.lo *= 2.0;
-  dd_t t = dd_mul_d(dd_add(dd_mul_d(LN2, (double)e), r), y);
-  // exp
-  double kd = rint(t.hi * 1.4426950408889634074);
-  r = dd_add(t, dd_mul_d(LN2, -kd));
-  r.hi *= 0.00390625; r.lo *= 0.00390625;
-  sum = {0.0, 0.0};
-  for (int k = 12; k >= 1; k--) {
-    dd_t one_plus = dd_add_d(sum, 1.0), dk = {(double)k, 0.0};
-    sum = dd_mul(dd_div(r, dk), one_plus);
-  }
-  for (int q = 0; q < 8; q++) {
-    dd_t sq = dd_mul(sum, sum); sum.hi *= 2.0; sum.lo *= 2.0; sum = dd_add(sum, sq);
-  }
-  dd_t res = dd_add_d(sum, 1.0);
-  return ldexp(res.hi, (int)kd);
-}
+using m6::cr::cr_pow;
 
 // ---- launch helper: one thread per point of an inclusive index range, i fastest ------------------------------------
 template <class F> __global__ void __launch_bounds__(256) range2d_kernel(int i0, int i1, int j0, int j1, F f) {
@@ -1073,7 +1013,21 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     for (int n = n0; n <= n1; n++) {
       const int isv = rng[n].isv, iev = rng[n].iev, jsv = rng[n].jsv, jev = rng[n].jev;
       const double wt_end = n * p.Instep;
-      if (nonlin_update && (n > 1) && ((n - 1) % cs->Nonlin_cont_update_period == 0)) face_areas_eta(st, 1 + iev - ie);      // :1852-1856
+      if (nonlin_update && (n > 1) && ((n - 1) % cs->Nonlin_cont_update_period == 0)) {      // :1852-1856
+        face_areas_eta(st, 1 + iev - ie);
+        // the predictor transports of this step were formed by the velocity kernels of the previous one, with the old face
+        // areas: the reference forms them after the refresh (:1896-1903)
+        if (!p.project_velocity) {
+          launch2d(st, isv - 2, iev + 1, jsv - 1, jev + 1, [=] __device__(int I, int j) {
+            const long q = g.u2(I, j);
+            w.uhbtp[q] = w.Datu[q] * w.ubt[q] + w.uhbt0[q];
+          });
+          launch2d(st, isv - 1, iev + 1, jsv - 2, jev + 1, [=] __device__(int i, int J) {
+            const long q = g.v2(i, J);
+            w.vhbtp[q] = w.Datv[q] * w.vbt[q] + w.vhbt0[q];
+          });
+        }
+      }
       hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev + 1,
                          jsv - 1, jev + 1, wt_accel2[n]);
       const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;

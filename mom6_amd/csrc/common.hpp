@@ -189,6 +189,11 @@ int set_viscous_BBL_dev(mom6hip_ctx *ctx, const mom6hip_set_visc_cs_t *cs, const
                         const double *T, const double *S, const mom6hip_eos_t *eos, double *bbl_thick_u, double *bbl_thick_v,
                         double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v);
 
+// set_viscous_ML on device arrays (set_viscosity.hip); called by the split RK2 step at :592
+int set_viscous_ML_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
+                       const double *T, const double *S, const mom6hip_eos_t *eos, const double *taux, const double *tauy,
+                       const double *ustar, double *nkml_visc_u, double *nkml_visc_v, double dt);
+
 class Stager {
  public:
   Stager(mom6hip_ctx *ctx, int memspace) : ctx_(ctx), host_(memspace == MOM6HIP_MEM_HOST) {}

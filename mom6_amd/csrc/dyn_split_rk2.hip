@@ -198,7 +198,13 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (hk && hk->visc_remnant_pred) {   // set_viscous_ML, vertvisc_coef, vertvisc_remnant :592-600
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
-  } else if (VV) {                     // vertvisc_coef, vertvisc_remnant :598-600 (set_viscous_ML :592 is not provided)
+  } else if (VV) {                     // set_viscous_ML :592 (DYNAMIC_VISCOUS_ML), vertvisc_coef, vertvisc_remnant :598-600
+    if (cs->set_visc_CSp && cs->set_visc_CSp->dynamic_viscous_ML) {
+      M6_REQUIRE(cs->visc->ustar && cs->visc->nkml_visc_u && cs->visc->nkml_visc_v,
+                 "step_MOM_dyn_split_RK2: DYNAMIC_VISCOUS_ML needs forces%%ustar (visc->ustar) and visc%%nkml_visc_u / nkml_visc_v");
+      CALL(m6::set_viscous_ML_dev(ctx, cs->set_visc_CSp, u_inst, v_inst, h, T, S, cs->eqn_of_state, taux, tauy, cs->visc->ustar,
+                                  (double *)cs->visc->nkml_visc_u, (double *)cs->visc->nkml_visc_v, dt));
+    }
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));                 // :610-611
@@ -424,6 +430,12 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
   } else if (VV) {
+    if (cs->set_visc_CSp && cs->set_visc_CSp->dynamic_viscous_ML) {      // set_viscous_ML :598
+      M6_REQUIRE(cs->visc->ustar && cs->visc->nkml_visc_u && cs->visc->nkml_visc_v,
+                 "step_MOM_dyn_split_RK2b: DYNAMIC_VISCOUS_ML needs forces%%ustar (visc->ustar) and visc%%nkml_visc_u / nkml_visc_v");
+      CALL(m6::set_viscous_ML_dev(ctx, cs->set_visc_CSp, u_av, v_av, h, T, S, cs->eqn_of_state, taux, tauy, cs->visc->ustar,
+                                  (double *)cs->visc->nkml_visc_u, (double *)cs->visc->nkml_visc_v, dt));
+    }
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));                 // :616-617

@@ -12,6 +12,7 @@
 
 #include "common.hpp"
 #include "eos.hpp"
+#include "cr_math.hpp"
 
 namespace {
 
@@ -256,8 +257,126 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
   if (A.Kv_bbl) A.Kv_bbl[f2] = kv_bbl;
 }
 
+// ---- set_viscous_ML, the DYNAMIC_VISCOUS_ML search (:2111-2230 at u points, :2400-2506 at v points) ---------------------------
+// One lane per velocity column, lanes along i: a top-down walk that stops where the bulk Richardson number of the water above
+// reaches its critical value.  (The reference walks a row of columns together and leaves the loop when all are done; a column's
+// result does not depend on its neighbours.)  exp() is the correctly rounded one of cr_math.hpp.
+struct MLArgs {
+  m6::GridDev g;
+  m6::eos::EosDev E;
+  const double *u, *v, *h, *T, *S, *taux, *tauy, *ustar, *Rlay;
+  double *nkml_visc;
+  double dt, H_to_RZ, omega, omega_frac, ustar_min, TKE_decay, bulk_Ri_ML;
+  int nkml, use_EOS;
+};
+
+template <int DIR>
+__global__ __launch_bounds__(64) void set_viscous_ml_kernel(MLArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const int nz = g.nk, nkml = A.nkml;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const double mask = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2];
+  if (mask < 0.5) { A.nkml_visc[f2] = (double)nkml; return; }
+  const long hpl = (long)g.nih * g.njh, upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1);
+  const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  const double dt_Rho0 = A.dt / A.H_to_RZ;
+  const double h_neglect = g.H_subroundoff;
+  const double h_tiny = 2.0 * g.Angstrom_H + h_neglect;
+  const double g_H_Rho0 = (g.g_Earth * g.H_to_Z) / (g.Rho0);
+  double htot = 0.0, Thtot = 0.0, Shtot = 0.0, Rhtot = 0.0, uhtot, vhtot, absf;
+  int k_massive = nkml;
+  if (DIR == 0) {
+    uhtot = dt_Rho0 * A.taux[g.u2(i, j)];
+    vhtot = 0.25 * dt_Rho0 * ((A.tauy[g.v2(i, j)] + A.tauy[g.v2(i + 1, j - 1)]) + (A.tauy[g.v2(i, j - 1)] + A.tauy[g.v2(i + 1, j)]));
+  } else {
+    vhtot = dt_Rho0 * A.tauy[g.v2(i, j)];
+    uhtot = 0.25 * dt_Rho0 * ((A.taux[g.u2(i, j)] + A.taux[g.u2(i - 1, j + 1)]) + (A.taux[g.u2(i - 1, j)] + A.taux[g.u2(i, j + 1)]));
+  }
+  if (A.omega_frac >= 1.0) absf = 2.0 * A.omega;
+  else {
+    if (DIR == 0) absf = 0.5 * (fabs(g.CoriolisBu[g.q2(i, j)]) + fabs(g.CoriolisBu[g.q2(i, j - 1)]));
+    else absf = 0.5 * (fabs(g.CoriolisBu[g.q2(i - 1, j)]) + fabs(g.CoriolisBu[g.q2(i, j)]));
+    if (A.omega_frac > 0.0) absf = sqrt(A.omega_frac * 4.0 * (A.omega * A.omega) + (1.0 - A.omega_frac) * (absf * absf));
+  }
+  const double U_star = max2(A.ustar_min, 0.5 * (g.Z_to_H * A.ustar[c0] + g.Z_to_H * A.ustar[c1]));
+  const double Idecay_len_TKE = (absf / U_star) * A.TKE_decay;
+  double dR_dT = 0.0, dR_dS = 0.0, result = 0.0;
+  bool active = true;
+  // the other velocity component's four neighbours of this face
+  const long oa = DIR ? g.u2(i - 1, j) : g.v2(i, j), ob = DIR ? g.u2(i, j) : g.v2(i, j - 1);
+  const long oc = DIR ? g.u2(i - 1, j + 1) : g.v2(i + 1, j), od = DIR ? g.u2(i, j + 1) : g.v2(i + 1, j - 1);
+  const double *own = DIR ? A.v : A.u, *oth = DIR ? A.u : A.v;
+  const long ownpl = DIR ? vpl : upl, othpl = DIR ? upl : vpl;
+  for (int k = 0; k < nz; k++) {      // k zero-based: layer k+1
+    const double ha = A.h[c0 + hpl * k], hb = A.h[c1 + hpl * k];
+    const double w_own = own[f2 + ownpl * k];
+    const double sa = oth[oa + othpl * k] + oth[ob + othpl * k], sb = oth[oc + othpl * k] + oth[od + othpl * k];
+    double Ta = 0., Tb = 0., Sa = 0., Sb = 0.;
+    if (A.use_EOS) { Ta = A.T[c0 + hpl * k]; Tb = A.T[c1 + hpl * k]; Sa = A.S[c0 + hpl * k]; Sb = A.S[c1 + hpl * k]; }
+    if (k + 1 > nkml) {
+      if (A.use_EOS && (k + 1 == nkml + 1)) {
+        const double press = (A.H_to_RZ * g.g_Earth) * htot;
+        const int k2 = (nkml > 1 ? nkml : 1) - 1;
+        const double h2a = A.h[c0 + hpl * k2], h2b = A.h[c1 + hpl * k2];
+        const double I_2hlay = 1.0 / (h2a + h2b + h_neglect);
+        const double T_EOS = (h2a * A.T[c0 + hpl * k2] + h2b * A.T[c1 + hpl * k2]) * I_2hlay;
+        const double S_EOS = (h2a * A.S[c0 + hpl * k2] + h2b * A.S[c1 + hpl * k2]) * I_2hlay;
+        m6::eos::eos_density_derivs(A.E, T_EOS, S_EOS, press, dR_dT, dR_dS);
+      }
+      const double hlay = 0.5 * (ha + hb);
+      if (hlay > h_tiny) {
+        const double I_2hlay = 1.0 / (ha + hb);
+        const double other_at = 0.5 * (ha * sa + hb * sb) * I_2hlay;      // v_at_u :2168 / u_at_v :2449
+        double du, dv;
+        if (DIR == 0) { du = uhtot - htot * w_own; dv = vhtot - htot * other_at; }
+        else { du = uhtot - htot * other_at; dv = vhtot - htot * w_own; }
+        const double Uh2 = (du * du + dv * dv);
+        double gHprime;
+        if (A.use_EOS) {
+          const double T_lay = (ha * Ta + hb * Tb) * I_2hlay;
+          const double S_lay = (ha * Sa + hb * Sb) * I_2hlay;
+          gHprime = g_H_Rho0 * (dR_dT * (T_lay * htot - Thtot) + dR_dS * (S_lay * htot - Shtot));
+        } else {
+          gHprime = g_H_Rho0 * (A.Rlay[k] * htot - Rhtot);
+        }
+        if (gHprime > 0.0) {
+          const double RiBulk = A.bulk_Ri_ML * m6::cr::cr_exp(-htot * Idecay_len_TKE);
+          if (RiBulk * Uh2 <= (htot * htot) * gHprime) {
+            result = (double)k_massive;
+            active = false;
+          } else if (RiBulk * Uh2 <= ((htot + hlay) * (htot + hlay)) * gHprime) {
+            result = (double)k + (sqrt(RiBulk * Uh2 / gHprime) - htot) / hlay;      // real(k-1), one-based k
+            active = false;
+          }
+        }
+        k_massive = k + 1;
+      }
+      if (!active) break;
+    }
+    htot = htot + 0.5 * (ha + hb);
+    if (DIR == 0) {
+      uhtot = uhtot + 0.5 * (ha + hb) * w_own;
+      vhtot = vhtot + 0.25 * (ha * sa + hb * sb);
+    } else {
+      vhtot = vhtot + 0.5 * (ha + hb) * w_own;
+      uhtot = uhtot + 0.25 * (ha * sa + hb * sb);
+    }
+    if (A.use_EOS) {
+      Thtot = Thtot + 0.5 * (ha * Ta + hb * Tb);
+      Shtot = Shtot + 0.5 * (ha * Sa + hb * Sb);
+    } else {
+      Rhtot = Rhtot + 0.5 * (ha + hb) * A.Rlay[k];
+    }
+  }
+  if (active) result = (double)k_massive;
+  A.nkml_visc[f2] = result;
+}
+
 int check_cs(const mom6hip_set_visc_cs_t *cs, const char *who) {
-  static const char *names[9] = {"CHANNEL_DRAG", "BBL_USE_TIDAL_BG", "DYNAMIC_VISCOUS_ML", "a bulk mixed layer (nkml > 0)",
+  static const char *names[9] = {"CHANNEL_DRAG", "BBL_USE_TIDAL_BG", "(free)", "(free)",
                                  "non-Boussinesq mode (tv%SpV_avg)", "tv%p_surf", "open boundary conditions", "porous barriers",
                                  "ice shelves"};
   M6_REQUIRE(cs->initialized, "%s: Module must be initialized before it is used.", who);
@@ -302,10 +421,60 @@ int set_viscous_BBL_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, con
 }
 }  // namespace m6
 
-extern "C" int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs) {
+// set_viscous_ML on device arrays (also called by the split RK2 step at :592)
+namespace m6 {
+int set_viscous_ML_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
+                       const double *T, const double *S, const mom6hip_eos_t *eos, const double *taux, const double *tauy,
+                       const double *ustar, double *nkml_visc_u, double *nkml_visc_v, double dt) {
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.CoriolisBu, "set_viscous_ML: mask2dCu, mask2dCv and CoriolisBu are needed");
+  M6_REQUIRE(g.isc - g.isd >= 1 && g.jsc - g.jsd >= 1, "set_viscous_ML: needs a halo of at least 1");
+  MLArgs A;
+  A.g = g;
+  A.use_EOS = eos != nullptr;
+  A.E.form = eos ? eos->form : MOM6HIP_EOS_LINEAR; A.E.Rho_T0_S0 = eos ? eos->Rho_T0_S0 : 0.0;
+  A.E.dRho_dT = eos ? eos->dRho_dT : 0.0; A.E.dRho_dS = eos ? eos->dRho_dS : 0.0;
+  A.u = u; A.v = v; A.h = h; A.T = T; A.S = S; A.taux = taux; A.tauy = tauy; A.ustar = ustar; A.Rlay = nullptr;
+  if (!A.use_EOS) {
+    M6_REQUIRE(cs->Rlay, "set_viscous_ML: GV%%Rlay is needed without an equation of state");
+    A.Rlay = ctx->tables[m6::TABLE_SVML_RLAY].get(cs->Rlay, (size_t)g.nk);
+    if (!A.Rlay) return 1;
+  }
+  A.dt = dt; A.H_to_RZ = cs->H_to_RZ; A.omega = cs->omega; A.omega_frac = cs->omega_frac; A.ustar_min = cs->ustar_min;
+  A.TKE_decay = cs->TKE_decay; A.bulk_Ri_ML = cs->bulk_Ri_ML; A.nkml = cs->nkml;
+  const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
+  A.nkml_visc = nkml_visc_u;
+  hipLaunchKernelGGL(set_viscous_ml_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, ctx->stream, A);
+  A.nkml_visc = nkml_visc_v;
+  hipLaunchKernelGGL(set_viscous_ml_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, ctx->stream, A);
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+}  // namespace m6
+
+extern "C" int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+                                      const double *h, const double *T, const double *S, const mom6hip_eos_t *eos, const double *taux,
+                                      const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr && cs != nullptr, "MOM_set_viscosity(visc_ML): null argument");
   if (check_cs(cs, "MOM_set_viscosity(visc_ML)")) return 1;
-  return 0;      // :2043-2044: nothing to do without DYNAMIC_VISCOUS_ML or an ice shelf
+  if (!cs->dynamic_viscous_ML) return 0;      // :2043-2044: nothing to do without DYNAMIC_VISCOUS_ML or an ice shelf
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "set_viscous_ML: bad memspace");
+  M6_REQUIRE(u && v && h && taux && tauy && visc, "set_viscous_ML: null argument");
+  M6_REQUIRE(visc->ustar && visc->nkml_visc_u && visc->nkml_visc_v,
+             "set_viscous_ML: forces%%ustar (visc->ustar) and visc%%nkml_visc_u / nkml_visc_v must be allocated with DYNAMIC_VISCOUS_ML");
+  M6_REQUIRE(cs->nkml >= 0 && cs->nkml < ctx->g.nk, "set_viscous_ML: GV%%nkml must be in 0 .. nk-1");
+  M6_REQUIRE(!eos || (T && S), "set_viscous_ML: an equation of state needs tv%%T and tv%%S");
+  const m6::GridDev g = ctx->g;
+  const size_t bH = sizeof(double) * (size_t)g.nh3(), bU = sizeof(double) * (size_t)g.nu3(), bV = sizeof(double) * (size_t)g.nv3();
+  const size_t bH2 = sizeof(double) * (size_t)g.nih * g.njh, bU2 = sizeof(double) * (size_t)(g.nih + 1) * g.njh,
+               bV2 = sizeof(double) * (size_t)g.nih * (g.njh + 1);
+  m6::Stager st(ctx, memspace);
+  const double *du = st.in(u, bU), *dv = st.in(v, bV), *dh = st.in(h, bH), *dT = eos ? st.in(T, bH) : nullptr, *dS = eos ? st.in(S, bH) : nullptr;
+  const double *dtx = st.in(taux, bU2), *dty = st.in(tauy, bV2), *dus = st.in(visc->ustar, bH2);
+  double *nu = st.inout((double *)visc->nkml_visc_u, bU2), *nv = st.inout((double *)visc->nkml_visc_v, bV2);
+  M6_REQUIRE(!st.failed(), "set_viscous_ML: staging failed");
+  if (int rc = m6::set_viscous_ML_dev(ctx, cs, du, dv, dh, dT, dS, eos, dtx, dty, dus, nu, nv, dt)) return rc;
+  return st.finish();
 }
 
 extern "C" int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,

@@ -23,8 +23,8 @@ using m6::max2;
 using m6::min2;
 
 struct VVPar {      // the scalars of vertvisc_CS the kernels read
-  double Hmix, Hmix_stress, Kvml_invZ2, Kv, Hbbl, Kv_extra_bbl, harm_BL_val, maxvel, CFL_trunc, vel_underflow, H_to_RZ;
-  int bottomdraglaw, harmonic_visc, direct_stress, CFL_based_trunc;
+  double Hmix, Hmix_stress, Kvml_invZ2, Kv, Hbbl, Kv_extra_bbl, harm_BL_val, maxvel, CFL_trunc, vel_underflow, H_to_RZ, vonKar;
+  int bottomdraglaw, harmonic_visc, direct_stress, CFL_based_trunc, dynamic_viscous_ML, nkml;
 };
 
 #ifndef VB_LAYERS
@@ -37,6 +37,9 @@ struct CoefArgs {
   VVPar p;
   const double *vel, *h, *dz, *kv_bbl, *bbl_thick, *Kv_shear;
   double *a, *hv;
+  // the surface boundary layer of DYNAMIC_VISCOUS_ML / a bulk mixed layer (find_coupling_coef :2047-2252)
+  const double *ustar, *nkml_visc;      // forces%ustar (h points), visc%nkml_visc_u or _v
+  double *dzv;                          // scratch: dz_vel of every layer of the column (written bottom-up, read top-down)
 };
 
 // vertvisc_coef + find_coupling_coef for the face column (i, j); the caller has checked do_i
@@ -150,6 +153,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
       }
     }
     A.hv[f2 + fpl * k] = hvel + h_neglect;                           // :1510
+    if (A.dzv) A.dzv[f2 + fpl * k] = dz_vel;
 
     // the interface below this layer, K = k+1 (find_coupling_coef :1948-2007 with hvel = dz_vel)
     const int K = k + 1;
@@ -193,7 +197,40 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
     z_i_below = z_i; dzv_below = dz_vel;
     }
   }
-  A.a[f2] = min2(a_cpl_max, 0.0 + 0.0);                               // a_cpl(:,1) = 0: no surface boundary layer scheme
+  A.a[f2] = min2(a_cpl_max, 0.0 + 0.0);                               // a_cpl(:,1) = 0 (the boundary-layer scheme starts at K = 2)
+  // ---- the surface boundary layer :2047-2252 (no LOTW floor; Boussinesq): top-down over the few layers in it ----
+  if (A.dzv) {
+    const double u_star = 0.5 * (A.ustar[c0] + A.ustar[c1]);          // :2098-2112 (find_ustar: forces%ustar)
+    const double absf = DIR ? 0.5 * (fabs(g.CoriolisBu[g.q2(i - 1, j)]) + fabs(g.CoriolisBu[g.q2(i, j)]))
+                            : 0.5 * (fabs(g.CoriolisBu[g.q2(i, j - 1)]) + fabs(g.CoriolisBu[g.q2(i, j)]));
+    int nk_in_ml;
+    double h_ml = hn;
+    if (P.dynamic_viscous_ML) {                                      // :2120-2150
+      const double nkv = A.nkml_visc[f2];
+      nk_in_ml = (int)ceil(nkv);
+      for (int k = 1; k <= nk_in_ml; k++) {
+        const double dzk = A.dzv[f2 + fpl * (k - 1)];
+        if ((double)k <= nkv) h_ml = h_ml + dzk;
+        else if ((double)k < nkv + 1.0) h_ml = h_ml + ((nkv + 1.0) - (double)k) * dzk;
+      }
+    } else {                                                         // :2152-2166
+      nk_in_ml = P.nkml;
+      for (int k = 1; k <= P.nkml; k++) h_ml = h_ml + A.dzv[f2 + fpl * (k - 1)];
+    }
+    if (u_star <= 0.0) nk_in_ml = 0;                                  // :2184
+    double z_t = 0.0;
+    double dz_above = nk_in_ml >= 2 ? A.dzv[f2] : 0.0;
+    for (int K = 2; K <= nk_in_ml; K++) {                             // :2231-2250
+      const double dz_here = A.dzv[f2 + fpl * (K - 1)];
+      z_t = z_t + dz_above;
+      const double temp1 = (z_t * h_ml - z_t * z_t);
+      const double visc_ml = u_star * P.vonKar * (g.Z_to_H * temp1 * u_star) / (absf * temp1 + (h_ml + hn) * u_star);
+      const double a_ml = visc_ml / (0.25 * (dz_here + dz_above + hn) + 0.5 * I_amax * visc_ml);
+      const long n = f2 + fpl * (K - 1);
+      A.a[n] = min2(a_cpl_max, max2(A.a[n], a_ml) + 0.0);            // (a below a_cpl_max was stored unchanged)
+      dz_above = dz_here;
+    }
+  }
 }
 
 template <int DIR>
@@ -428,7 +465,7 @@ __global__ __launch_bounds__(256) void vv_limit_kernel(LimitArgs A) {
 }
 
 int check_cs(const mom6hip_vertvisc_cs_t *cs, const char *who) {
-  static const char *names[7] = {"DYNAMIC_VISCOUS_ML", "a bulk mixed layer (nkml > 0)", "FIXED_DEPTH_LOTW_ML", "LOTW_VISCOUS_ML_FLOOR",
+  static const char *names[7] = {"(free)", "(free)", "FIXED_DEPTH_LOTW_ML", "LOTW_VISCOUS_ML_FLOOR",
                                  "USE_GL90_IN_SSW", "STOKES_MIXING_COMBINED", "non-Boussinesq mode"};
   for (int n = 0; n < 7; n++) M6_REQUIRE(!cs->unsupported[n], "%s: %s is not provided by libmom6hip", who, names[n]);
   M6_REQUIRE(cs->answer_date >= 20190101, "%s: VERT_FRICTION_ANSWER_DATE < 20190101 is not provided", who);
@@ -440,7 +477,8 @@ VVPar par_of(const mom6hip_vertvisc_cs_t *cs) {
   VVPar p;
   p.Hmix = cs->Hmix; p.Hmix_stress = cs->Hmix_stress; p.Kvml_invZ2 = cs->Kvml_invZ2; p.Kv = cs->Kv; p.Hbbl = cs->Hbbl;
   p.Kv_extra_bbl = cs->Kv_extra_bbl; p.harm_BL_val = cs->harm_BL_val; p.maxvel = cs->maxvel; p.CFL_trunc = cs->CFL_trunc;
-  p.vel_underflow = cs->vel_underflow; p.H_to_RZ = cs->H_to_RZ;
+  p.vel_underflow = cs->vel_underflow; p.H_to_RZ = cs->H_to_RZ; p.vonKar = cs->vonKar;
+  p.dynamic_viscous_ML = cs->dynamic_viscous_ML; p.nkml = cs->nkml;
   p.bottomdraglaw = cs->bottomdraglaw; p.harmonic_visc = cs->harmonic_visc; p.direct_stress = cs->direct_stress;
   p.CFL_based_trunc = cs->CFL_based_trunc;
   return p;
@@ -472,9 +510,23 @@ extern "C" int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
   M6_REQUIRE(!(cs->Kvml_invZ2 > 0.0) || cs->Hmix > 0.0, "vertvisc_coef: KV_ML_INVZ2 needs HMIX_FIXED");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.mask2dCu && g.mask2dCv && g.bathyT, "vertvisc_coef: mask2dCu, mask2dCv and bathyT are required");
+  const bool surface_bl = cs->dynamic_viscous_ML || cs->nkml > 0;      // find_coupling_coef :2047
+  if (surface_bl) {
+    M6_REQUIRE(visc->ustar, "vertvisc_coef: DYNAMIC_VISCOUS_ML / a bulk mixed layer needs forces%%ustar (visc->ustar)");
+    M6_REQUIRE(!cs->dynamic_viscous_ML || (visc->nkml_visc_u && visc->nkml_visc_v),
+               "vertvisc_coef: DYNAMIC_VISCOUS_ML needs visc%%nkml_visc_u / nkml_visc_v (set_viscous_ML)");
+    M6_REQUIRE(cs->nkml >= 0 && cs->nkml <= g.nk && g.CoriolisBu, "vertvisc_coef: GV%%nkml out of range, or CoriolisBu missing");
+  }
   const Sz sz = sizes(g);
   m6::Stager st(ctx, memspace);
   CoefArgs A[2];
+  for (int d = 0; d < 2; d++) { A[d].ustar = A[d].nkml_visc = nullptr; A[d].dzv = nullptr; }
+  if (surface_bl) {
+    const double *dus = st.in(visc->ustar, sz.h2);
+    A[0].ustar = A[1].ustar = dus;
+    if (cs->dynamic_viscous_ML) { A[0].nkml_visc = st.in(visc->nkml_visc_u, sz.u2); A[1].nkml_visc = st.in(visc->nkml_visc_v, sz.v2); }
+    A[0].dzv = (double *)st.scratch(sz.u3); A[1].dzv = (double *)st.scratch(sz.v3);
+  }
   A[0].vel = st.in(u, sz.u3); A[1].vel = st.in(v, sz.v3);
   const double *dh = st.in(h, sz.h3), *ddz = st.in(dz, sz.h3), *dks = st.in(visc->Kv_shear, sz.hi);
   A[0].kv_bbl = st.in(visc->Kv_bbl_u, sz.u2); A[1].kv_bbl = st.in(visc->Kv_bbl_v, sz.v2);
@@ -590,7 +642,9 @@ extern "C" int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
   M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(visc): Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && visc && visc_rem_u && visc_rem_v, "vertvisc_step: null argument");
   M6_REQUIRE(!update_velocities || (taux && tauy), "vertvisc_step: the wind stress is needed to update the velocities");
-  if (visc->Ray_u || visc->Ray_v) {      // the Rayleigh-drag bottom stress needs the separate truncation pass: plain sequence
+  // the Rayleigh-drag bottom stress needs the separate truncation pass, the surface boundary layer of DYNAMIC_VISCOUS_ML / a
+  // bulk mixed layer its own scratch: the plain sequence
+  if (visc->Ray_u || visc->Ray_v || cs->dynamic_viscous_ML || cs->nkml > 0) {
     if (int rc = mom6hip_vertvisc_coef(ctx, cs, u, v, h, dz, visc, dt, memspace)) return rc;
     if (update_velocities)
       if (int rc = mom6hip_vertvisc(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, memspace)) return rc;
@@ -632,7 +686,7 @@ extern "C" int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
   for (int d = 0; d < 2; d++) {
     CoefArgs C;
     C.g = g; C.p = par_of(cs); C.vel = x[d]; C.h = dh; C.dz = ddz; C.kv_bbl = kvb[d]; C.bbl_thick = bth[d]; C.Kv_shear = dks;
-    C.a = a[d]; C.hv = hv[d];
+    C.a = a[d]; C.hv = hv[d]; C.ustar = C.nkml_visc = nullptr; C.dzv = nullptr;
     SolveArgs A;
     A.g = g; A.p = C.p; A.a = a[d]; A.hv = hv[d]; A.Ray = nullptr; A.h = dh; A.tau = tau[d]; A.x = update_velocities ? x[d] : nullptr;
     A.xr = xr[d]; A.c1 = c1; A.tbot = tbot[d]; A.dt = dt; A.ntrunc = cnt;

@@ -35,14 +35,14 @@ class MOM_dyn_split_RK2_CS:
 
     def __init__(self, G: DeviceGrid, BE=0.6, BEGW=0.0, BT_USE_LAYER_FLUXES=True, STORE_CORIOLIS_ACCEL=True, USE_BT_CONT_TYPE=True,
                  EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None, vertvisc=None, hor_visc=None,
-                 DT=None):
+                 DT=None, set_visc=None, eos=None):
         g = G.grid
         dev = "cuda"
         self.G = G
         self.continuity_CSp = continuity_PPM_init(G, **(continuity or {}))
         self.CoriolisAdv = CoriolisAdv_init(**(coriolis or {}))
         self.PressureForce_CSp = PressureForce_init(g, **(pressure_force or {}))
-        self.eqn_of_state = EOS_init(EQN_OF_STATE)
+        self.eqn_of_state = EOS_init(EQN_OF_STATE, **(eos or {}))      # eos=dict(Rho_T0_S0=..., dRho_dT=..., dRho_dS=...) for LINEAR
         Z3 = lambda pos: torch.zeros(g.shape3(pos), dtype=torch.float64, device=dev)
         Z2 = lambda pos: torch.zeros(g.shape2(pos), dtype=torch.float64, device=dev)
         self.BT_cont = None
@@ -81,6 +81,12 @@ class MOM_dyn_split_RK2_CS:
                 raise Mom6HipError("initialize_dyn_split_RK2: hor_visc needs DT (the baroclinic time step)")
             self.hor_visc = hor_visc_init(G, DT, **hor_visc)
             st.hor_visc = C.addressof(self.hor_visc.st)
+        # set_visc_CSp (:1500): set_visc=dict(HBBL=..., KV=..., DYNAMIC_VISCOUS_ML=True, ...) makes the step call set_viscous_ML (:592)
+        self.set_visc_CSp = None
+        if set_visc is not None:
+            from .set_viscosity import set_visc_init
+            self.set_visc_CSp = set_visc_init(G, **set_visc)
+            st.set_visc_CSp = C.addressof(self.set_visc_CSp.st)
         self.module_is_initialized = False
 
     def __getattr__(self, n):

@@ -73,6 +73,7 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   cv%Ray_u = c_null_ptr ; if (allocated(visc%Ray_u)) cv%Ray_u = c_loc(visc%Ray_u)
   cv%Ray_v = c_null_ptr ; if (allocated(visc%Ray_v)) cv%Ray_v = c_loc(visc%Ray_v)
   cv%Kv_shear = c_null_ptr ; cv%Kv_shear_Bu = c_null_ptr ; cv%reserved(:) = c_null_ptr
+  cv%nkml_visc_u = c_null_ptr ; cv%nkml_visc_v = c_null_ptr ; cv%ustar = c_null_ptr
   p_T = c_null_ptr ; p_S = c_null_ptr
   if (CS%st%BBL_use_EOS /= 0) then
     if (.not.(associated(tv%T) .and. associated(tv%S))) &
@@ -86,22 +87,45 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   call mom6hip_fatal_if(rc, "set_viscous_BBL")
 end subroutine set_viscous_BBL
 
-!> Same interface as the reference set_viscous_ML (:1898): returns as the reference does without DYNAMIC_VISCOUS_ML
+!> Same interface as the reference set_viscous_ML (:1898): returns as the reference does without DYNAMIC_VISCOUS_ML (:2043); with it,
+!! the viscous surface boundary layer goes to visc%nkml_visc_u / visc%nkml_visc_v (forces%ustar as find_ustar hands it over in
+!! Boussinesq mode, MOM_forcing_type.F90:1265-1274).
 subroutine set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)
   type(ocean_grid_type),   intent(inout) :: G
   type(verticalGrid_type), intent(in)    :: GV
   type(unit_scale_type),   intent(in)    :: US
-  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(in) :: u
-  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(in) :: v
-  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(in) :: h
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, intent(in) :: v
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  target, intent(in) :: h
   type(thermo_var_ptrs),   intent(in)    :: tv
   type(mech_forcing),      intent(in)    :: forces
-  type(vertvisc_type),     intent(inout) :: visc
+  type(vertvisc_type), target, intent(inout) :: visc
   real,                    intent(in)    :: dt
-  type(set_visc_CS),       intent(inout) :: CS
+  type(set_visc_CS),   target, intent(inout) :: CS
+  type(mom6hip_vertvisc_type_t) :: cv
+  type(c_ptr) :: p_T, p_S, p_eos
   integer :: rc
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
-  rc = mom6hip_set_viscous_ml(mom6hip_shared_context(G, GV), CS%st)
+  if (CS%st%dynamic_viscous_ML == 0) return      ! :2043-2044 (ice shelves are refused at initialisation)
+  if (.not.(associated(forces%taux) .and. associated(forces%tauy))) call MOM_error(FATAL, "set_viscous_ML (HIP): "// &
+       "forces%taux and forces%tauy must be associated.")
+  if (.not.associated(forces%ustar)) call MOM_error(FATAL, "set_viscous_ML (HIP): forces%ustar must be associated (the GPU "// &
+       "path is Boussinesq: find_ustar returns forces%ustar).")
+  if (associated(tv%p_surf)) call MOM_error(FATAL, "set_viscous_ML (HIP): tv%p_surf is not provided by the GPU path.")
+  if (.not.(allocated(visc%nkml_visc_u) .and. allocated(visc%nkml_visc_v))) call MOM_error(FATAL, "set_viscous_ML (HIP): "// &
+       "visc%nkml_visc_u/v must be allocated (set_visc_init does it).")
+  cv%Kv_bbl_u = c_null_ptr ; cv%Kv_bbl_v = c_null_ptr ; cv%bbl_thick_u = c_null_ptr ; cv%bbl_thick_v = c_null_ptr
+  cv%Ray_u = c_null_ptr ; cv%Ray_v = c_null_ptr ; cv%Kv_shear = c_null_ptr ; cv%Kv_shear_Bu = c_null_ptr ; cv%reserved(:) = c_null_ptr
+  cv%nkml_visc_u = c_loc(visc%nkml_visc_u) ; cv%nkml_visc_v = c_loc(visc%nkml_visc_v) ; cv%ustar = c_loc(forces%ustar)
+  p_T = c_null_ptr ; p_S = c_null_ptr ; p_eos = c_null_ptr
+  if (associated(tv%eqn_of_state)) then
+    if (.not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "set_viscous_ML (HIP): an equation of state needs tv%T, tv%S.")
+    p_T = c_loc(tv%T) ; p_S = c_loc(tv%S) ; p_eos = c_loc(CS%eos)
+  endif
+  CS%st%Rlay = c_null_ptr ; if (allocated(CS%Rlay)) CS%st%Rlay = c_loc(CS%Rlay)
+  CS%st%nkml = GV%nkml
+  rc = mom6hip_set_viscous_ml(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, p_eos, &
+                              c_loc(forces%taux), c_loc(forces%tauy), cv, real(dt, c_double), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "set_viscous_ML")
 end subroutine set_viscous_ML
 
@@ -133,8 +157,8 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
 # include "version_variable.h"
   character(len=40)  :: mdl = "MOM_set_visc"
   character(len=40)  :: tmpstr
-  logical :: flag, use_EOS, use_temperature, use_regridding
-  real :: Kv_background
+  logical :: flag, flag2, use_EOS, use_temperature, use_regridding
+  real :: Kv_background, val
   integer :: isd, ied, jsd, jed
 
   CS%initialized = .true. ; CS%diag => diag
@@ -142,6 +166,7 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
   if (associated(OBC)) call refuse(.true., "open boundary conditions")
   if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
   CS%st%unsupported(:) = 0 ; CS%st%reserved0(:) = 0.0 ; CS%st%reserved1(:) = c_null_ptr ; CS%st%Rlay = c_null_ptr
+  CS%st%nkml = GV%nkml
   call log_version(param_file, mdl, version, "")
   call get_param(param_file, mdl, "BOTTOMDRAGLAW", flag, &
                  "If true, the bottom stress is calculated with a drag law of the form c_drag*|u|*u.", default=.true.)
@@ -156,7 +181,29 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
   CS%st%linear_drag = merge(1, 0, flag)
   call get_param(param_file, mdl, "USE_JACKSON_PARAM", flag, default=.false., do_not_log=.true.)
   CS%st%RiNo_mix = merge(1, 0, flag)
-  call get_param(param_file, mdl, "DYNAMIC_VISCOUS_ML", flag, default=.false.) ; call refuse(flag, "DYNAMIC_VISCOUS_ML")
+  ! DYNAMIC_VISCOUS_ML and its parameters (:2962-2999)
+  call get_param(param_file, mdl, "DYNAMIC_VISCOUS_ML", flag, &
+                 "If true, use a bulk Richardson number criterion to determine the mixed layer thickness for viscosity.", default=.false.)
+  CS%st%dynamic_viscous_ML = merge(1, 0, flag)
+  CS%st%bulk_Ri_ML = 0.0 ; CS%st%TKE_decay = 0.0 ; CS%st%omega_frac = 0.0 ; CS%st%ustar_min = 0.0
+  if (flag) then
+    call get_param(param_file, mdl, "BULK_RI_ML", val, units="nondim", default=0.0)
+    call get_param(param_file, mdl, "BULK_RI_ML_VISC", CS%st%bulk_Ri_ML, &
+                 "The efficiency with which mean kinetic energy released by mechanically forced entrainment of the mixed layer "// &
+                 "is converted to turbulent kinetic energy.  By default, BULK_RI_ML_VISC = BULK_RI_ML or 0.", units="nondim", default=val)
+    call get_param(param_file, mdl, "TKE_DECAY", val, units="nondim", default=0.0)
+    call get_param(param_file, mdl, "TKE_DECAY_VISC", CS%st%TKE_decay, &
+                 "TKE_DECAY_VISC relates the vertical rate of decay of the TKE available for mechanical entrainment to the natural "// &
+                 "Ekman depth for use in calculating the dynamic mixed layer viscosity.  By default, TKE_DECAY_VISC = TKE_DECAY or 0.", &
+                 units="nondim", default=val)
+    call get_param(param_file, mdl, "ML_USE_OMEGA", flag2, default=.false., do_not_log=.true.)
+    val = 0.0 ; if (flag2) val = 1.0
+    call get_param(param_file, mdl, "ML_OMEGA_FRAC", CS%st%omega_frac, &
+                 "When setting the decay scale for turbulence, use this fraction of the absolute rotation rate blended with the "// &
+                 "local value of f, as sqrt((1-of)*f^2 + of*4*omega^2).", units="nondim", default=val)
+  endif
+  call get_param(param_file, mdl, "OMEGA", CS%st%omega, "The rotation rate of the earth.", units="s-1", default=7.2921e-5, scale=US%T_to_s)
+  if (CS%st%dynamic_viscous_ML /= 0) CS%st%ustar_min = 2e-4*CS%st%omega*(GV%Angstrom_H + GV%H_subroundoff)      ! :2998
   call get_param(param_file, mdl, "HBBL", CS%st%dz_bbl, "The thickness of a bottom boundary layer.", units="m", &
                  fail_if_missing=.true., scale=US%m_to_Z)
   CS%st%Hbbl = CS%st%dz_bbl * GV%Z_to_H      ! :3127
@@ -216,6 +263,10 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
     if (.not.allocated(visc%bbl_thick_v)) allocate(visc%bbl_thick_v(isd:ied,jsd-1:jed), source=0.0)
     if (.not.allocated(visc%Kv_bbl_u)) allocate(visc%Kv_bbl_u(isd-1:ied,jsd:jed), source=0.0)
     if (.not.allocated(visc%Kv_bbl_v)) allocate(visc%Kv_bbl_v(isd:ied,jsd-1:jed), source=0.0)
+  endif
+  if (CS%st%dynamic_viscous_ML /= 0) then      ! :3178-3180
+    if (.not.allocated(visc%nkml_visc_u)) allocate(visc%nkml_visc_u(isd-1:ied,jsd:jed), source=0.0)
+    if (.not.allocated(visc%nkml_visc_v)) allocate(visc%nkml_visc_v(isd:ied,jsd-1:jed), source=0.0)
   endif
   call mom6hip_read_topology(param_file)
 contains

@@ -64,6 +64,9 @@ subroutine visc_struct(visc, cv)
   cv%Ray_v = c_null_ptr ; if (allocated(visc%Ray_v)) cv%Ray_v = c_loc(visc%Ray_v)
   cv%Kv_shear = c_null_ptr ; if (associated(visc%Kv_shear)) cv%Kv_shear = c_loc(visc%Kv_shear)
   cv%Kv_shear_Bu = c_null_ptr ; if (associated(visc%Kv_shear_Bu)) cv%Kv_shear_Bu = c_loc(visc%Kv_shear_Bu)
+  cv%nkml_visc_u = c_null_ptr ; if (allocated(visc%nkml_visc_u)) cv%nkml_visc_u = c_loc(visc%nkml_visc_u)
+  cv%nkml_visc_v = c_null_ptr ; if (allocated(visc%nkml_visc_v)) cv%nkml_visc_v = c_loc(visc%nkml_visc_v)
+  cv%ustar = c_null_ptr      ! (forces%ustar: set by vertvisc_coef)
   cv%reserved(:) = c_null_ptr
 end subroutine visc_struct
 
@@ -147,6 +150,11 @@ subroutine vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, 
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_vert_friction(coef): Module must be initialized before it is used.")
   if (associated(OBC)) call MOM_error(FATAL, "vertvisc_coef (HIP): open boundary conditions are not supported by the GPU path.")
   call bind_arrays(CS) ; call visc_struct(visc, cv)
+  if (CS%st%dynamic_viscous_ML /= 0 .or. CS%st%nkml > 0) then      ! find_ustar(forces, tv, Ustar_2d, ...) :1296, Boussinesq
+    if (.not.associated(forces%ustar)) call MOM_error(FATAL, "vertvisc_coef (HIP): DYNAMIC_VISCOUS_ML / a bulk mixed layer needs "// &
+         "forces%ustar (the GPU path is Boussinesq: find_ustar returns forces%ustar).")
+    cv%ustar = c_loc(forces%ustar)
+  endif
   rc = mom6hip_vertvisc_coef(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(dz), cv, dt, MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "vertvisc_coef")
 end subroutine vertvisc_coef
@@ -227,13 +235,18 @@ subroutine vertvisc_init(MIS, Time, G, GV, US, param_file, diag, ADp, dirs, ntru
   call get_param(param_file, mdl, "DIRECT_STRESS", flag, &
                  "If true, the wind stress is distributed over the topmost HMIX_STRESS of fluid.", default=.false.)
   CS%st%direct_stress = merge(1, 0, flag)
-  call get_param(param_file, mdl, "DYNAMIC_VISCOUS_ML", flag, default=.false.) ; call refuse(flag, "DYNAMIC_VISCOUS_ML")
+  call get_param(param_file, mdl, "DYNAMIC_VISCOUS_ML", flag, &
+                 "If true, use a bulk Richardson number criterion to determine the mixed layer thickness for viscosity.", default=.false.)
+  CS%st%dynamic_viscous_ML = merge(1, 0, flag)
   call get_param(param_file, mdl, "FIXED_DEPTH_LOTW_ML", flag, default=.false.) ; call refuse(flag, "FIXED_DEPTH_LOTW_ML")
   call get_param(param_file, mdl, "LOTW_VISCOUS_ML_FLOOR", flag, default=.false.) ; call refuse(flag, "LOTW_VISCOUS_ML_FLOOR")
   call get_param(param_file, mdl, "USE_GL90_IN_SSW", flag, default=.false.) ; call refuse(flag, "USE_GL90_IN_SSW")
+  ! a bulk mixed layer: its GV%nkml layers are the viscous surface boundary layer (find_coupling_coef :2152-2166)
   call get_param(param_file, "MOM", "BULKMIXEDLAYER", bulkmixedlayer, default=.false., do_not_log=.true.)
-  call refuse(bulkmixedlayer, "BULKMIXEDLAYER")
-  nkml = 0
+  nkml = 0 ; if (bulkmixedlayer) nkml = GV%nkml
+  CS%st%nkml = nkml
+  call get_param(param_file, mdl, "VON_KARMAN_CONST", CS%st%vonKar, "The value the von Karman constant as used for mixed layer viscosity.", &
+                 units="nondim", default=0.41)
   call get_param(param_file, mdl, "HARMONIC_VISC", flag, &
                  "If true, use the harmonic mean thicknesses for calculating the vertical viscosity.", default=.false.)
   CS%st%harmonic_visc = merge(1, 0, flag)

@@ -132,7 +132,10 @@ end type mom6hip_visc_hooks_t
 !> mom6hip_vertvisc_cs_t (vertvisc_CS, src/parameterizations/vertical/MOM_vert_friction.F90:40)
 type, bind(c) :: mom6hip_vertvisc_cs_t
   real(c_double) :: Hmix, Hmix_stress, Kvml_invZ2, Kv, Hbbl, Kv_extra_bbl, harm_BL_val, maxvel, CFL_trunc, vel_underflow, H_to_RZ
-  real(c_double) :: reserved0(5)
+  real(c_double) :: vonKar = 0.41                 !< VON_KARMAN_CONST
+  integer(c_int32_t) :: dynamic_viscous_ML = 0    !< DYNAMIC_VISCOUS_ML
+  integer(c_int32_t) :: nkml = 0                  !< GV%nkml
+  real(c_double) :: reserved0(3)
   integer(c_int32_t) :: bottomdraglaw, harmonic_visc, direct_stress, CFL_based_trunc, answer_date
   integer(c_int32_t) :: unsupported(7)
   integer(c_int64_t) :: ntrunc
@@ -143,17 +146,22 @@ end type mom6hip_vertvisc_cs_t
 !> mom6hip_vertvisc_type_t (the members of vertvisc_type, src/core/MOM_variables.F90:218, that are read)
 type, bind(c) :: mom6hip_vertvisc_type_t
   type(c_ptr) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v, Ray_u, Ray_v, Kv_shear, Kv_shear_Bu
-  type(c_ptr) :: reserved(4)
+  type(c_ptr) :: nkml_visc_u = c_null_ptr, nkml_visc_v = c_null_ptr   !< visc%nkml_visc_u / _v (DYNAMIC_VISCOUS_ML)
+  type(c_ptr) :: ustar = c_null_ptr                                   !< forces%ustar (find_ustar)
+  type(c_ptr) :: reserved(1)
 end type mom6hip_vertvisc_type_t
 
 !> mom6hip_set_visc_cs_t (set_visc_CS, src/parameterizations/vertical/MOM_set_viscosity.F90:48)
 type, bind(c) :: mom6hip_set_visc_cs_t
   real(c_double) :: cdrag, drag_bg_vel, Hbbl, dz_bbl, BBL_thick_min, Kv_BBL_min, BBL_thick_max, H_to_RZ
-  real(c_double) :: reserved0(8)
+  real(c_double) :: omega = 7.2921d-5, omega_frac = 0.0d0, ustar_min = 0.0d0, TKE_decay = 0.0d0, bulk_Ri_ML = 0.0d0
+  real(c_double) :: c_Smag = 0.15d0, Chan_drag_max_vol = -1.0d0
+  real(c_double) :: reserved0(1)
   integer(c_int32_t) :: bottomdraglaw, linear_drag, BBL_use_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix, initialized
   integer(c_int32_t) :: unsupported(9)
   type(c_ptr) :: Rlay           !< c_loc of GV%Rlay (host), read without BBL_USE_EOS
-  type(c_ptr) :: reserved1(3)
+  integer(c_int32_t) :: dynamic_viscous_ML = 0, nkml = 0, Channel_drag = 0, concave_trigonometric_L = 1
+  type(c_ptr) :: reserved1(1)
 end type mom6hip_set_visc_cs_t
 
 !> mom6hip_tracer_hor_diff_cs_t (tracer_hor_diff_CS, src/tracer/MOM_tracer_hor_diff.F90:40)
@@ -197,7 +205,8 @@ type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
                  u_av, v_av, h_av, pbce
   type(c_ptr) :: eta, eta_PF, uhbt, vhbt
   type(c_ptr) :: du_av_inst, dv_av_inst   !< SPLIT_RK2B only (MOM_dynamics_split_RK2b.F90:141-146)
-  type(c_ptr) :: reserved2(2)
+  type(c_ptr) :: set_visc_CSp = c_null_ptr   !< c_loc of a mom6hip_set_visc_cs_t with dynamic_viscous_ML, or c_null_ptr
+  type(c_ptr) :: reserved2(1)
 end type mom6hip_dyn_split_rk2_cs_t
 
 interface
@@ -626,11 +635,15 @@ interface
     integer(c_int) :: rc
   end function mom6hip_set_viscous_bbl
 
-  !> set_viscous_ML (:1898): the reference's early return (:2043)
-  function mom6hip_set_viscous_ml(ctx, cs) bind(c, name="mom6hip_set_viscous_ml") result(rc)
-    import :: c_int, c_ptr, mom6hip_set_visc_cs_t
-    type(c_ptr), value :: ctx
+  !> set_viscous_ML (:1898): the early return (:2043), or with DYNAMIC_VISCOUS_ML the viscous mixed layer into visc%nkml_visc_u/v
+  function mom6hip_set_viscous_ml(ctx, cs, u, v, h, T, S, eos, taux, tauy, visc, dt, memspace) &
+                                  bind(c, name="mom6hip_set_viscous_ml") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_set_visc_cs_t, mom6hip_vertvisc_type_t
+    type(c_ptr), value :: ctx, u, v, h, T, S, eos, taux, tauy
     type(mom6hip_set_visc_cs_t), intent(in) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_set_viscous_ml
 

@@ -10,8 +10,7 @@ from . import _abi
 from ._lib import Mom6HipError, check, lib
 from .tracer_advect import DeviceGrid, _ptr_space
 
-_UNSUPPORTED = {"CHANNEL_DRAG": "Channel_drag", "BBL_USE_TIDAL_BG": "BBL_use_tidal_bg", "DYNAMIC_VISCOUS_ML": "dynamic_viscous_ML",
-                "NKML": "nkml", "NON_BOUSSINESQ": "non_Boussinesq"}
+_UNSUPPORTED = {"CHANNEL_DRAG": "Channel_drag", "BBL_USE_TIDAL_BG": "BBL_use_tidal_bg", "NON_BOUSSINESQ": "non_Boussinesq"}
 
 
 def _setup():
@@ -19,7 +18,8 @@ def _setup():
     if not getattr(L, "_sv_ready", False):
         cs = C.POINTER(_abi.SetViscCS)
         L.mom6hip_set_viscous_bbl.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [C.POINTER(_abi.EOS), C.POINTER(_abi.VertviscType), C.c_int32]
-        L.mom6hip_set_viscous_ml.argtypes = [C.c_void_p, cs]
+        L.mom6hip_set_viscous_ml.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 5 + [C.POINTER(_abi.EOS)] + [C.c_void_p] * 2
+                                             + [C.POINTER(_abi.VertviscType), C.c_double, C.c_int32])
         L._sv_ready = True
     return L
 
@@ -29,9 +29,17 @@ class set_visc_CS:
 
     def __init__(self, G: DeviceGrid, HBBL, KV, CDRAG=0.003, DRAG_BG_VEL=0.0, BBL_THICK_MIN=0.0, KV_BBL_MIN=None, BOTTOMDRAGLAW=True,
                  LINEAR_DRAG=False, BBL_USE_EOS=True, CORRECT_BBL_BOUNDS=False, DRAG_AS_BODY_FORCE=False, USE_JACKSON_PARAM=False,
-                 Rlay=None, **unsupported):
+                 Rlay=None, DYNAMIC_VISCOUS_ML=False, NKML=0, BULK_RI_ML=0.0, BULK_RI_ML_VISC=None, TKE_DECAY=0.0, TKE_DECAY_VISC=None,
+                 ML_OMEGA_FRAC=0.0, OMEGA=7.2921e-5, **unsupported):
         g = G.grid if isinstance(G, DeviceGrid) else G
         st = self.st = _abi.SetViscCS()
+        # DYNAMIC_VISCOUS_ML (:2962) with BULK_RI_ML_VISC (= BULK_RI_ML), TKE_DECAY_VISC (= TKE_DECAY), ML_OMEGA_FRAC, OMEGA; GV%nkml
+        st.dynamic_viscous_ML, st.nkml = int(bool(DYNAMIC_VISCOUS_ML)), int(NKML)
+        st.bulk_Ri_ML = float(BULK_RI_ML if BULK_RI_ML_VISC is None else BULK_RI_ML_VISC)
+        st.TKE_decay = float(TKE_DECAY if TKE_DECAY_VISC is None else TKE_DECAY_VISC)
+        st.omega_frac, st.omega = float(ML_OMEGA_FRAC), float(OMEGA)
+        st.ustar_min = 2e-4 * st.omega * (g.Angstrom_H + g.H_subroundoff)      # :2998
+        st.c_Smag, st.Chan_drag_max_vol, st.concave_trigonometric_L = 0.15, -1.0, 1
         for k, v in unsupported.items():
             if k not in _UNSUPPORTED:
                 raise Mom6HipError(f"set_visc_init: unknown parameter {k}")
@@ -83,8 +91,28 @@ def set_viscous_BBL(u, v, h, tv, visc, G: DeviceGrid, CS: set_visc_CS, pbv=None)
 
 
 def set_viscous_ML(u, v, h, tv, forces, visc, dt, G: DeviceGrid, CS: set_visc_CS):
-    """set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS) -- :1898: returns at once unless DYNAMIC_VISCOUS_ML or an
-    ice shelf is present (:2043), which this build refuses."""
+    """set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS) -- :1898: returns at once unless DYNAMIC_VISCOUS_ML (:2043; ice
+    shelves are not provided).  With it: tv = (T, S, EOS) (EOS None: GV%Rlay from CS), forces = (taux, tauy) with forces%ustar in
+    visc.ustar; writes visc.nkml_visc_u / nkml_visc_v."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
-    check(_setup().mom6hip_set_viscous_ml(G.handle, C.byref(CS.st)), "set_viscous_ML")
+    if not CS.st.dynamic_viscous_ML:
+        check(_setup().mom6hip_set_viscous_ml(G.handle, C.byref(CS.st), None, None, None, None, None, None, None, None,
+                                              C.byref(visc.st), float(dt), _abi.MEM_DEVICE), "set_viscous_ML")
+        return
+    T, S, EOS = tv if tv is not None else (None, None, None)
+    taux, tauy = forces
+    spaces = set()
+    ptrs = []
+    for a in (u, v, h, T, S, taux, tauy):
+        if a is None:
+            ptrs.append(None)
+            continue
+        p, sp = _ptr_space(a)
+        spaces.add(sp); ptrs.append(C.c_void_p(p))
+    if visc.space is not None:
+        spaces.add(visc.space)
+    if len(spaces) != 1:
+        raise Mom6HipError("set_viscous_ML: the fields and visc must be in the same memory space")
+    check(_setup().mom6hip_set_viscous_ml(G.handle, C.byref(CS.st), *ptrs[:5], None if EOS is None else C.byref(EOS), ptrs[5], ptrs[6],
+                                          C.byref(visc.st), float(dt), spaces.pop()), "set_viscous_ML")

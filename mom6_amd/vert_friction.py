@@ -29,7 +29,9 @@ def _setup():
 
 class vertvisc_type:
     """The members of vertvisc_type (src/core/MOM_variables.F90:218-283) the provided branch reads."""
-    FIELDS = ("Kv_bbl_u", "Kv_bbl_v", "bbl_thick_u", "bbl_thick_v", "Ray_u", "Ray_v", "Kv_shear", "Kv_shear_Bu")
+    FIELDS = ("Kv_bbl_u", "Kv_bbl_v", "bbl_thick_u", "bbl_thick_v", "Ray_u", "Ray_v", "Kv_shear", "Kv_shear_Bu",
+              "nkml_visc_u", "nkml_visc_v",      # written by set_viscous_ML (DYNAMIC_VISCOUS_ML), read by vertvisc_coef
+              "ustar")                           # forces%ustar, as find_ustar returns it (Z T-1)
 
     def __init__(self, **arrays):
         for n in arrays:
@@ -54,9 +56,12 @@ class vertvisc_CS:
 
     def __init__(self, G: DeviceGrid, KV, HBBL, HMIX_FIXED=0.0, BOTTOMDRAGLAW=True, HARMONIC_VISC=False, HARMONIC_BL_SCALE=0.0,
                  DIRECT_STRESS=False, HMIX_STRESS=None, KV_ML_INVZ2=0.0, KV_EXTRA_BBL=0.0, MAXVEL=3.0e8, CFL_BASED_TRUNCATIONS=True,
-                 CFL_TRUNCATE=0.5, VEL_UNDERFLOW=0.0, VERT_FRICTION_ANSWER_DATE=99991231, device_arrays=True, **unsupported):
+                 CFL_TRUNCATE=0.5, VEL_UNDERFLOW=0.0, VERT_FRICTION_ANSWER_DATE=99991231, device_arrays=True, DYNAMIC_VISCOUS_ML=False,
+                 NKML=0, VON_KARMAN_CONST=0.41, **unsupported):
         g = G.grid
         st = self.st = _abi.VertviscCS()
+        # DYNAMIC_VISCOUS_ML (:2543), GV%nkml (a bulk mixed layer), VON_KARMAN_CONST (:2590)
+        st.dynamic_viscous_ML, st.nkml, st.vonKar = int(bool(DYNAMIC_VISCOUS_ML)), int(NKML), float(VON_KARMAN_CONST)
         for n, val in unsupported.items():
             if n not in _abi.VERTVISC_UNSUPPORTED:
                 raise Mom6HipError(f"vertvisc_init: unknown parameter {n}")

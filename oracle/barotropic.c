@@ -113,6 +113,14 @@ double orc_cr_pow(double x, double y) {
   if (x == 1.0) return 1.0;
   return dd_exp_round(dd_mul_d(dd_log(x), y));
 }
+/* a correctly rounded exp(t) for -700 < t <= 0 (set_viscous_ML's decay of the bulk Richardson number, MOM_set_viscosity.F90:2178);
+ * exp(t) underflows to 0 beyond */
+double orc_cr_exp(double t) {
+  if (t == 0.0) return 1.0;
+  if (!(t > -700.0)) return 0.0;
+  dd_t d = {t, 0.0};
+  return dd_exp_round(d);
+}
 
 /* ------------------------------------------------------------------------------------------------ */
 

@@ -113,7 +113,9 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       vp[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_inst[V3(i, J, k)] + dt * v_bc_accel[V3(i, J, k)]);
   }
-  /* [set_viscous_ML :592 not provided]; vertvisc_coef, vertvisc_remnant :598-600 (without them visc_rem stays 1) */
+  /* set_viscous_ML :592 (DYNAMIC_VISCOUS_ML); vertvisc_coef, vertvisc_remnant :598-600 (without them visc_rem stays 1) */
+  if (CS->set_visc_CSp && CS->set_visc_CSp->dynamic_viscous_ML)
+    CHECK(orc_set_viscous_ML(G, CS->set_visc_CSp, u_inst, v_inst, h, T, S, CS->eqn_of_state, taux, tauy, CS->visc, dt));
   if (CS->vertvisc_CSp) {
     CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
@@ -305,7 +307,9 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       vp[V3(i, J, k)] = G->mask2dCv[ORC_V2(G, i, J)] * (v_av[V3(i, J, k)] + dt * v_bc_accel[V3(i, J, k)]);
   }
-  /* [set_viscous_ML :598]; vertvisc_coef, vertvisc_remnant :605-606 */
+  /* set_viscous_ML :598 (DYNAMIC_VISCOUS_ML); vertvisc_coef, vertvisc_remnant :605-606 */
+  if (CS->set_visc_CSp && CS->set_visc_CSp->dynamic_viscous_ML)
+    CHECK(orc_set_viscous_ML(G, CS->set_visc_CSp, u_av, v_av, h, T, S, CS->eqn_of_state, taux, tauy, CS->visc, dt));
   if (CS->vertvisc_CSp) {
     CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));

@@ -149,6 +149,7 @@ int orc_pressureforce_fv_nonbouss(const mom6hip_grid_t *G, const mom6hip_pressur
                                   double *PFu, double *PFv, double *pbce, double *eta);
 
 /* ---- MOM_barotropic (oracle/barotropic.c) ----------------------------------------------------- */
+double orc_cr_exp(double t);             /* correctly rounded exp(t), t <= 0 (0 below -700) */
 double orc_cr_pow(double x, double y);   /* correctly rounded x**y, 0 < x <= 1, 0 < y <= 1 */
 int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS);
 int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
@@ -178,7 +179,9 @@ int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *C
 /* ---- MOM_set_viscosity (oracle/set_viscosity.c) ---------------------------------------------------------------------- */
 int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
                         const double *T, const double *S, const mom6hip_eos_t *EOS, const mom6hip_vertvisc_type_t *visc);
-int orc_set_viscous_ML(const mom6hip_set_visc_cs_t *CS);
+int orc_set_viscous_ML(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
+                       const double *T, const double *S, const mom6hip_eos_t *EOS, const double *taux, const double *tauy,
+                       const mom6hip_vertvisc_type_t *visc, double dt);
 
 /* ---- MOM_hor_visc (oracle/hor_visc.c) ------------------------------------------------------------------------------- */
 /* hor_visc_init (the static arrays, :2440-2760) and horizontal_viscosity (:245-1979); all arrays HOST arrays */

@@ -556,7 +556,8 @@ class DynState:
     the step with numpy arrays behind its pointers, and the prognostic state."""
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
-                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, rk2b=False, **bt_kw):
+                 bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, rk2b=False, set_visc=None,
+                 pressureforce=None, **bt_kw):
         """rk2b: SPLIT_RK2B (MOM_dynamics_split_RK2b.F90); u, v are then the filtered velocities."""
         g = self.grid = grid
         self.rk2b = bool(rk2b)
@@ -564,8 +565,8 @@ class DynState:
         self.ccs = continuity_cs(g.nk, g.Angstrom_H)
         self.cor = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES["SADOURNY75_ENERGY"], _abi.KE_SCHEMES["KE_ARAKAWA"], 0, int(bound_coriolis), 0)
         self.cor.F_eff_max_blend, self.cor.wt_lin_blend = 4.0, 0.125
-        self.pcs = pressureforce_cs(g)
-        self.eos = eos(eos_form)
+        self.pcs = pressureforce_cs(g, **(pressureforce or {}))      # e.g. reconstruct=False (RECONSTRUCT_FOR_PRESSURE)
+        self.eos = eos(eos_form) if not isinstance(eos_form, _abi.EOS) else eos_form
         self.bt_arrs, self.bt = make_bt_cont(g, with_h=True) if use_bt_cont else ({}, None)
         self.bcs, self.bcs_arrs = barotropic_cs(g, hvel_scheme="FROM_BT_CONT" if use_bt_cont else "HARMONIC", **bt_kw)
         barotropic_init(g, self.bcs)
@@ -580,6 +581,9 @@ class DynState:
         if hor_visc is not None:      # a hor_visc_cs(...) struct of this module
             self.hvcs = hor_visc
             cs.hor_visc = C.addressof(hor_visc)
+        if set_visc is not None:      # a set_visc_cs(...) struct with dynamic_viscous_ML: set_viscous_ML at :592
+            self.svcs = set_visc
+            cs.set_visc_CSp = C.addressof(set_visc)
         self.arrs = {}
         for n, pos in _abi.RK2_ARRAYS_3D:
             self.arrs[n] = grid.zeros3(pos); setattr(cs, n, self.arrs[n].ctypes.data)
@@ -619,9 +623,10 @@ class DynState:
 # ---- MOM_vert_friction -------------------------------------------------------------------------------------------
 def vertvisc_cs(grid, Kv, Hbbl, Hmix=0.0, bottomdraglaw=True, harmonic_visc=False, harm_BL_val=0.0, direct_stress=False,
                 Hmix_stress=None, Kvml_invZ2=0.0, Kv_extra_bbl=0.0, maxvel=3.0e8, CFL_based_trunc=True, CFL_trunc=0.5,
-                vel_underflow=0.0, answer_date=99991231):
+                vel_underflow=0.0, answer_date=99991231, dynamic_viscous_ML=False, nkml=0, vonKar=0.41):
     """mom6hip_vertvisc_cs_t with numpy arrays behind a_u, a_v, h_u, h_v (kept on the struct as ._arrs)."""
     cs = _abi.VertviscCS()
+    cs.dynamic_viscous_ML, cs.nkml, cs.vonKar = int(dynamic_viscous_ML), int(nkml), float(vonKar)
     cs.Kv, cs.Hbbl, cs.Hmix = Kv, Hbbl, Hmix
     cs.bottomdraglaw, cs.harmonic_visc, cs.direct_stress = int(bottomdraglaw), int(harmonic_visc), int(direct_stress)
     cs.harm_BL_val = harm_BL_val
@@ -669,9 +674,14 @@ def vertvisc_remnant(grid, cs, visc, visc_rem_u, visc_rem_v, dt):
 
 # ---- MOM_set_viscosity -------------------------------------------------------------------------------------------
 def set_visc_cs(grid, Hbbl, Kv, cdrag=0.003, drag_bg_vel=0.0, BBL_thick_min=0.0, Kv_BBL_min=None, bottomdraglaw=True, linear_drag=False,
-                BBL_use_EOS=True, correct_BBL_bounds=False, body_force_drag=False, RiNo_mix=False, Rlay=None, **unsupported):
+                BBL_use_EOS=True, correct_BBL_bounds=False, body_force_drag=False, RiNo_mix=False, Rlay=None, dynamic_viscous_ML=False,
+                nkml=0, bulk_Ri_ML=0.0, TKE_decay=0.0, omega_frac=0.0, omega=7.2921e-5, **unsupported):
     """mom6hip_set_visc_cs_t with the defaults of set_visc_init (MOM_set_viscosity.F90:2886-3190)."""
     cs = _abi.SetViscCS()
+    cs.dynamic_viscous_ML, cs.nkml, cs.bulk_Ri_ML, cs.TKE_decay, cs.omega_frac, cs.omega = (int(dynamic_viscous_ML), int(nkml), bulk_Ri_ML,
+                                                                                          TKE_decay, omega_frac, omega)
+    cs.ustar_min = 2e-4 * omega * (grid.Angstrom_H + grid.H_subroundoff)      # :2998
+    cs.c_Smag, cs.Chan_drag_max_vol, cs.concave_trigonometric_L = 0.15, -1.0, 1
     cs.cdrag, cs.drag_bg_vel, cs.dz_bbl, cs.Hbbl = cdrag, drag_bg_vel, Hbbl, Hbbl * grid.Z_to_H
     cs.BBL_thick_min, cs.Kv_BBL_min, cs.BBL_thick_max = BBL_thick_min, (Kv if Kv_BBL_min is None else Kv_BBL_min), 6.378e6
     cs.H_to_RZ = grid.Rho0 * grid.H_to_Z
@@ -692,6 +702,21 @@ def set_viscous_BBL(grid, cs, u, v, h, T, S, E, visc):
                                C.byref(visc))
     if rc:
         raise RuntimeError(f"orc_set_viscous_BBL rc={rc}")
+
+
+def set_viscous_ML(grid, cs, u, v, h, T, S, E, taux, tauy, visc, dt):
+    """set_viscous_ML (:1898): visc must carry ustar and the (written) nkml_visc_u / nkml_visc_v"""
+    L = lib(); L.orc_set_viscous_ML.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.SetViscCS)] + [_dp] * 5 + [C.POINTER(_abi.EOS)]
+                                               + [_dp, _dp, C.POINTER(_abi.VertviscType), C.c_double])
+    rc = L.orc_set_viscous_ML(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(T), _p(S), None if E is None else C.byref(E),
+                              _p(taux), _p(tauy), C.byref(visc), float(dt))
+    if rc:
+        raise RuntimeError(f"orc_set_viscous_ML rc={rc}")
+
+
+def cr_exp(t):
+    L = lib(); L.orc_cr_exp.argtypes = [C.c_double]; L.orc_cr_exp.restype = C.c_double
+    return L.orc_cr_exp(float(t))
 
 
 # ---- MOM_hor_visc ---------------------------------------------------------------------------------------------------

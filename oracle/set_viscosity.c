@@ -2,7 +2,8 @@
  * set_viscosity.c -- CPU restatement of set_viscous_BBL (TEST INFRASTRUCTURE, see mom6_oracle.h).
  *
  * Reference: src/parameterizations/vertical/MOM_set_viscosity.F90
- *   set_viscous_BBL :134-1100, set_v_at_u :1804, set_u_at_v :1849, set_viscous_ML :1898 (the early return :2043)
+ *   set_viscous_BBL :134-1100, set_v_at_u :1804, set_u_at_v :1849, set_viscous_ML :1898 (the early return :2043, and the
+ *   DYNAMIC_VISCOUS_ML search :2111-2230, :2400-2506; its exp through orc_cr_exp, correctly rounded)
  * Restated branch: BOTTOMDRAGLAW, quadratic or LINEAR_DRAG law, BBL_USE_EOS or GV%Rlay as the density variable, no channel
  * drag, no tidal background velocity, Boussinesq (no tv%SpV_avg), no tv%p_surf, no OBC; DRAG_AS_BODY_FORCE; CORRECT_BBL_BOUNDS.
  * PARITY UNPINNED: the reference holds no known-answer vectors for this module; invariants in tests/test_set_viscosity.py.
@@ -57,9 +58,134 @@ static int unsupported(const mom6hip_set_visc_cs_t *CS) {
   return 0;
 }
 
-int orc_set_viscous_ML(const mom6hip_set_visc_cs_t *CS) {
+/* set_viscous_ML :1898, the DYNAMIC_VISCOUS_ML part (:2111-2230 at u points, :2400-2506 at v points): one velocity column.
+ * dir 0: the face (I,j) between the cells (i,j) and (i+1,j); dir 1: the face (i,J) between (i,j) and (i,j+1).  Boussinesq, no
+ * tv%p_surf, no ice shelf.  The row-wide do_any / exit of the reference only skips work: a column's result does not depend on
+ * its neighbours. */
+static double viscous_ML_column(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
+                                const double *T, const double *S, const mom6hip_eos_t *EOS, const double *taux, const double *tauy,
+                                const double *ustar, double dt, int dir, int i, int j) {
+  const int nz = G->nk, nkml = CS->nkml;
+  const int use_EOS = (EOS != NULL);
+  const double dt_Rho0 = dt / CS->H_to_RZ;
+  const double h_neglect = G->H_subroundoff;
+  const double h_tiny = 2.0 * G->Angstrom_H + h_neglect;
+  const double g_H_Rho0 = (G->g_Earth * G->H_to_Z) / (G->Rho0);
+  const int i2 = dir ? i : i + 1, j2 = dir ? j + 1 : j;      /* the second cell of the face */
+  const double mask = dir ? G->mask2dCv[ORC_V2(G, i, j)] : G->mask2dCu[ORC_U2(G, i, j)];
+  if (mask < 0.5) return (double)nkml;
+  double htot = 0.0, Thtot = 0.0, Shtot = 0.0, Rhtot = 0.0, uhtot, vhtot, absf;
+  int k_massive = nkml;
+  if (!dir) {      /* :2128-2131 */
+    uhtot = dt_Rho0 * taux[ORC_U2(G, i, j)];
+    vhtot = 0.25 * dt_Rho0 * ((tauy[ORC_V2(G, i, j)] + tauy[ORC_V2(G, i + 1, j - 1)]) +
+                              (tauy[ORC_V2(G, i, j - 1)] + tauy[ORC_V2(G, i + 1, j)]));
+  } else {         /* :2411-2413 */
+    vhtot = dt_Rho0 * tauy[ORC_V2(G, i, j)];
+    uhtot = 0.25 * dt_Rho0 * ((taux[ORC_U2(G, i, j)] + taux[ORC_U2(G, i - 1, j + 1)]) +
+                              (taux[ORC_U2(G, i - 1, j)] + taux[ORC_U2(G, i, j + 1)]));
+  }
+  if (CS->omega_frac >= 1.0) absf = 2.0 * CS->omega;      /* :2133-2140 */
+  else {
+    if (!dir) absf = 0.5 * (fabs(G->CoriolisBu[ORC_Q2(G, i, j)]) + fabs(G->CoriolisBu[ORC_Q2(G, i, j - 1)]));
+    else absf = 0.5 * (fabs(G->CoriolisBu[ORC_Q2(G, i - 1, j)]) + fabs(G->CoriolisBu[ORC_Q2(G, i, j)]));
+    if (CS->omega_frac > 0.0) absf = sqrt(CS->omega_frac * 4.0 * (CS->omega * CS->omega) + (1.0 - CS->omega_frac) * (absf * absf));
+  }
+  /* find_ustar(..., H_T_units=.true.), Boussinesq: U_star_2d = GV%Z_to_H * forces%ustar (MOM_forcing_type.F90:1272) */
+  const double U_star = max2(CS->ustar_min, 0.5 * (G->Z_to_H * ustar[ORC_H2(G, i, j)] + G->Z_to_H * ustar[ORC_H2(G, i2, j2)]));
+  const double Idecay_len_TKE = (absf / U_star) * CS->TKE_decay;
+  double dR_dT = 0.0, dR_dS = 0.0, result = 0.0;
+  int active = 1;
+#define HA(k) h[ORC_H3(G, i, j, k)]
+#define HB(k) h[ORC_H3(G, i2, j2, k)]
+  for (int k = 1; k <= nz; k++) {
+    /* the velocity of the other component at this point: v at u (:2168-2169) or u at v (:2449-2450) */
+    if (k > nkml) {
+      if (use_EOS && (k == nkml + 1)) {      /* :2147-2164 */
+        const double press = (CS->H_to_RZ * G->g_Earth) * htot;
+        const int k2 = nkml > 1 ? nkml : 1;
+        const double I_2hlay = 1.0 / (HA(k2) + HB(k2) + h_neglect);
+        const double T_EOS = (HA(k2) * T[ORC_H3(G, i, j, k2)] + HB(k2) * T[ORC_H3(G, i2, j2, k2)]) * I_2hlay;
+        const double S_EOS = (HA(k2) * S[ORC_H3(G, i, j, k2)] + HB(k2) * S[ORC_H3(G, i2, j2, k2)]) * I_2hlay;
+        orc_eos_density_derivs(EOS, T_EOS, S_EOS, press, &dR_dT, &dR_dS);
+      }
+      const double hlay = 0.5 * (HA(k) + HB(k));
+      if (hlay > h_tiny) {
+        const double I_2hlay = 1.0 / (HA(k) + HB(k));
+        double Uh2;
+        if (!dir) {
+          const double v_at_u = 0.5 * (HA(k) * (v[ORC_V3(G, i, j, k)] + v[ORC_V3(G, i, j - 1, k)]) +
+                                       HB(k) * (v[ORC_V3(G, i + 1, j, k)] + v[ORC_V3(G, i + 1, j - 1, k)])) * I_2hlay;
+          const double du = uhtot - htot * u[ORC_U3(G, i, j, k)], dv = vhtot - htot * v_at_u;
+          Uh2 = (du * du + dv * dv);
+        } else {
+          const double u_at_v = 0.5 * (HA(k) * (u[ORC_U3(G, i - 1, j, k)] + u[ORC_U3(G, i, j, k)]) +
+                                       HB(k) * (u[ORC_U3(G, i - 1, j + 1, k)] + u[ORC_U3(G, i, j + 1, k)])) * I_2hlay;
+          const double du = uhtot - htot * u_at_v, dv = vhtot - htot * v[ORC_V3(G, i, j, k)];
+          Uh2 = (du * du + dv * dv);
+        }
+        double gHprime;
+        if (use_EOS) {
+          const double T_lay = (HA(k) * T[ORC_H3(G, i, j, k)] + HB(k) * T[ORC_H3(G, i2, j2, k)]) * I_2hlay;
+          const double S_lay = (HA(k) * S[ORC_H3(G, i, j, k)] + HB(k) * S[ORC_H3(G, i2, j2, k)]) * I_2hlay;
+          gHprime = g_H_Rho0 * (dR_dT * (T_lay * htot - Thtot) + dR_dS * (S_lay * htot - Shtot));
+        } else {
+          gHprime = g_H_Rho0 * (CS->Rlay[k - 1] * htot - Rhtot);
+        }
+        if (gHprime > 0.0) {
+          const double RiBulk = CS->bulk_Ri_ML * orc_cr_exp(-htot * Idecay_len_TKE);
+          if (RiBulk * Uh2 <= (htot * htot) * gHprime) {
+            result = (double)k_massive;
+            active = 0;
+          } else if (RiBulk * Uh2 <= ((htot + hlay) * (htot + hlay)) * gHprime) {
+            result = (double)(k - 1) + (sqrt(RiBulk * Uh2 / gHprime) - htot) / hlay;
+            active = 0;
+          }
+        }
+        k_massive = k;
+      }
+      if (!active) break;
+    }
+    /* :2195-2207 / :2476-2488 */
+    htot = htot + 0.5 * (HA(k) + HB(k));
+    if (!dir) {
+      uhtot = uhtot + 0.5 * (HA(k) + HB(k)) * u[ORC_U3(G, i, j, k)];
+      vhtot = vhtot + 0.25 * (HA(k) * (v[ORC_V3(G, i, j, k)] + v[ORC_V3(G, i, j - 1, k)]) +
+                              HB(k) * (v[ORC_V3(G, i + 1, j, k)] + v[ORC_V3(G, i + 1, j - 1, k)]));
+    } else {
+      vhtot = vhtot + 0.5 * (HA(k) + HB(k)) * v[ORC_V3(G, i, j, k)];
+      uhtot = uhtot + 0.25 * (HA(k) * (u[ORC_U3(G, i - 1, j, k)] + u[ORC_U3(G, i, j, k)]) +
+                              HB(k) * (u[ORC_U3(G, i - 1, j + 1, k)] + u[ORC_U3(G, i, j + 1, k)]));
+    }
+    if (use_EOS) {
+      Thtot = Thtot + 0.5 * (HA(k) * T[ORC_H3(G, i, j, k)] + HB(k) * T[ORC_H3(G, i2, j2, k)]);
+      Shtot = Shtot + 0.5 * (HA(k) * S[ORC_H3(G, i, j, k)] + HB(k) * S[ORC_H3(G, i2, j2, k)]);
+    } else {
+      Rhtot = Rhtot + 0.5 * (HA(k) + HB(k)) * CS->Rlay[k - 1];
+    }
+  }
+#undef HA
+#undef HB
+  if (active) result = (double)k_massive;      /* :2210-2212 */
+  return result;
+}
+
+int orc_set_viscous_ML(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
+                       const double *T, const double *S, const mom6hip_eos_t *EOS, const double *taux, const double *tauy,
+                       const mom6hip_vertvisc_type_t *visc, double dt) {
   if (!CS->initialized) return 3;
-  return unsupported(CS) ? 1 : 0;      /* :2043-2044: nothing to do without DYNAMIC_VISCOUS_ML or an ice shelf */
+  if (unsupported(CS)) return 1;
+  if (!CS->dynamic_viscous_ML) return 0;      /* :2043-2044: nothing to do without DYNAMIC_VISCOUS_ML or an ice shelf */
+  if (!(u && v && h && taux && tauy && visc && visc->ustar && visc->nkml_visc_u && visc->nkml_visc_v)) return 2;
+  if (EOS ? !(T && S) : !CS->Rlay) return 2;
+  double *nu = (double *)visc->nkml_visc_u, *nv = (double *)visc->nkml_visc_v;
+  ORC_PAR
+  for (int j = G->jsc; j <= G->jec; j++) for (int I = G->isc - 1; I <= G->iec; I++)
+    nu[ORC_U2(G, I, j)] = viscous_ML_column(G, CS, u, v, h, T, S, EOS, taux, tauy, visc->ustar, dt, 0, I, j);
+  ORC_PAR
+  for (int J = G->jsc - 1; J <= G->jec; J++) for (int i = G->isc; i <= G->iec; i++)
+    nv[ORC_V2(G, i, J)] = viscous_ML_column(G, CS, u, v, h, T, S, EOS, taux, tauy, visc->ustar, dt, 1, i, J);
+  return 0;
 }
 
 int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,

@@ -19,12 +19,14 @@ static int unsupported(const mom6hip_vertvisc_cs_t *CS) {
   for (int n = 0; n < 7; n++) if (CS->unsupported[n]) return 1;
   return CS->answer_date < 20190101;
 }
+static int surface_bl(const mom6hip_vertvisc_cs_t *CS) { return CS->dynamic_viscous_ML || CS->nkml > 0; }
 
 /* one face column of vertvisc_coef + find_coupling_coef.  c0 / c1: 2-D offsets of the two cells; f2: of the face;
  * hpl / fpl: plane strides of h-point and face arrays. */
 static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
                         const double *vel, const double *h, const double *dz, long c0, long c1, long f2, long hpl, long fpl,
-                        const double *kv_bbl_2d, const double *bbl_thick_2d, double *a_out, double *h_out) {
+                        const double *kv_bbl_2d, const double *bbl_thick_2d, double *a_out, double *h_out, long qA, long qB,
+                        const double *nkml_visc_2d) {
   const int nz = G->nk;
   const double h_neglect = G->H_subroundoff, dz_neglect = G->dZ_subroundoff;
   const double a_cpl_max = 1.0e37 * G->Z_to_H * 1.0;      /* 1.0e37 * GV%m_to_H * US%T_to_s :1283 */
@@ -137,7 +139,35 @@ static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS
         a_cpl[K] = Kv_tot[K] / (h_shear + I_amax * Kv_tot[K]);
       }
     }
-    /* no shelf, no surface boundary layer scheme (:2012-2252 not taken) */
+    /* no shelf (:2012-2045 not taken).  The surface boundary layer :2047-2252, for DYNAMIC_VISCOUS_ML or a bulk mixed layer
+     * (GV%nkml > 0), without FIXED_DEPTH_LOTW_ML / LOTW_VISCOUS_ML_FLOOR; Boussinesq; hvel is dz_vel here */
+    if (surface_bl(CS)) {
+      /* :2098-2116: u_star = the mean of the two cells' (find_ustar: forces%ustar), absf from the two corners */
+      const double u_star = 0.5 * (visc->ustar[c0] + visc->ustar[c1]);
+      const double absf = 0.5 * (fabs(G->CoriolisBu[qA]) + fabs(G->CoriolisBu[qB]));
+      int nk_in_ml = 0;
+      double h_ml = hn;                       /* :2123 / :2163 */
+      if (CS->dynamic_viscous_ML) {           /* :2120-2150 */
+        const double nkv = nkml_visc_2d[f2];
+        nk_in_ml = (int)ceil(nkv);
+        for (int k = 1; k <= nk_in_ml; k++) {
+          if ((double)k <= nkv) h_ml = h_ml + dz_vel[k - 1];
+          else if ((double)k < nkv + 1.0) h_ml = h_ml + ((nkv + 1.0) - (double)k) * dz_vel[k - 1];
+        }
+      } else {                                /* :2152-2166 */
+        nk_in_ml = CS->nkml;
+        for (int k = 1; k <= CS->nkml; k++) h_ml = h_ml + dz_vel[k - 1];
+      }
+      if (u_star <= 0.0) nk_in_ml = 0;        /* :2184 */
+      double z_t = 0.0;
+      for (int K = 2; K <= nk_in_ml; K++) {   /* :2231-2250 (a_cpl(K), K one-based: a_cpl[K-1]) */
+        z_t = z_t + dz_vel[K - 2];
+        const double temp1 = (z_t * h_ml - z_t * z_t);
+        const double visc_ml = u_star * CS->vonKar * (G->Z_to_H * temp1 * u_star) / (absf * temp1 + (h_ml + hn) * u_star);
+        const double a_ml = visc_ml / (0.25 * (dz_vel[K - 1] + dz_vel[K - 2] + hn) + 0.5 * I_amax * visc_ml);
+        a_cpl[K - 1] = max2(a_cpl[K - 1], a_ml);
+      }
+    }
   }
   for (int K = 0; K <= nz; K++) a_out[f2 + fpl * K] = min2(a_cpl_max, a_cpl[K] + 0.0);      /* :1504-1506 (a_cpl_gl90 = 0) */
   for (int k = 0; k < nz; k++) h_out[f2 + fpl * k] = hvel[k] + h_neglect;                  /* :1510 */
@@ -150,19 +180,21 @@ int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const 
   (void)dt;
   if (unsupported(CS) || visc->Kv_shear_Bu) return 1;
   if (CS->bottomdraglaw && !(visc->Kv_bbl_u && visc->Kv_bbl_v && visc->bbl_thick_u && visc->bbl_thick_v)) return 1;
+  if (surface_bl(CS) && !visc->ustar) return 1;
+  if (CS->dynamic_viscous_ML && !(visc->nkml_visc_u && visc->nkml_visc_v)) return 1;
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
   const long nih = ORC_NIH(G), njh = ORC_NJH(G), hpl = nih * njh, upl = (nih + 1) * njh, vpl = nih * (njh + 1);
   ORC_PAR
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
     if (!(G->mask2dCu[ORC_U2(G, I, j)] > 0.0)) continue;
     coef_column(G, CS, visc, u, h, dz, ORC_H2(G, I, j), ORC_H2(G, I + 1, j), ORC_U2(G, I, j), hpl, upl, visc->Kv_bbl_u,
-                visc->bbl_thick_u, CS->a_u, CS->h_u);
+                visc->bbl_thick_u, CS->a_u, CS->h_u, ORC_Q2(G, I, j - 1), ORC_Q2(G, I, j), visc->nkml_visc_u);
   }
   ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
     if (!(G->mask2dCv[ORC_V2(G, i, J)] > 0.0)) continue;
     coef_column(G, CS, visc, v, h, dz, ORC_H2(G, i, J), ORC_H2(G, i, J + 1), ORC_V2(G, i, J), hpl, vpl, visc->Kv_bbl_v,
-                visc->bbl_thick_v, CS->a_v, CS->h_v);
+                visc->bbl_thick_v, CS->a_v, CS->h_v, ORC_Q2(G, i - 1, J), ORC_Q2(G, i, J), visc->nkml_visc_v);
   }
   return 0;
 }

@@ -79,7 +79,7 @@ eos%form = MOM6HIP_EOS_WRIGHT ; eos%reserved = 0 ; eos%Rho_T0_S0 = 1000.0d0 ; eo
 bcs%dtbt = 0.0d0 ; bcs%dtbt_max = 0.0d0 ; bcs%dtbt_fraction = 0.98d0 ; bcs%bebt = 0.1d0 ; bcs%dt_bt_filter = -0.25d0
 bcs%vel_underflow = 0.0d0 ; bcs%G_extra = 0.0d0 ; bcs%BT_Coriolis_scale = 1.0d0 ; bcs%Z_ref = 0.0d0 ; bcs%maxCFL_BT_cont = 0.25d0 ; bcs%reserved0(:) = 0.0d0
 bcs%Sadourny = 1 ; bcs%linearized_BT_PV = 1 ; bcs%strong_drag = 0 ; bcs%visc_rem_u_uh0 = 0 ; bcs%adjust_BT_cont = 0
-bcs%use_wide_halos = 1 ; bcs%hvel_scheme = 4 ; bcs%nstep_last = 0 ; bcs%unsupported(:) = 0 ; bcs%bound_BT_corr = 0 ; bcs%BT_project_velocity = 0 ; bcs%reserved1(:) = 0
+bcs%use_wide_halos = 1 ; bcs%hvel_scheme = 4 ; bcs%nstep_last = 0 ; bcs%unsupported(:) = 0 ; bcs%bound_BT_corr = 0 ; bcs%BT_project_velocity = 0 ; bcs%Nonlinear_continuity = 0 ; bcs%Nonlin_cont_update_period = 1
 bcs%frhatu = dalloc(nu3) ; bcs%frhatv = dalloc(nv3) ; bcs%eta_cor = dalloc(nh2) ; bcs%IDatu = dalloc(nu2) ; bcs%IDatv = dalloc(nv2)
 bcs%ubtav = dalloc(nu2) ; bcs%vbtav = dalloc(nv2) ; bcs%q_D = dalloc(nq2) ; bcs%D_u_Cor = dalloc(nu2) ; bcs%D_v_Cor = dalloc(nv2)
 bcs%reserved2(:) = c_null_ptr
@@ -93,7 +93,7 @@ btc%vBT_SS = dalloc(nv2) ; btc%vBT_NN = dalloc(nv2) ; btc%h_u = dalloc(nu3) ; bt
 
 ! ---- MOM_dyn_split_RK2_CS: parameters, the sub-module structures, the arrays the reference allocates in its CS
 cs%be = 0.6d0 ; cs%begw = 0.0d0 ; cs%BT_use_layer_fluxes = 1 ; cs%store_CAu = 1 ; cs%CAu_pred_stored = 0 ; cs%split_bottom_stress = 0
-cs%reserved0(:) = 0 ; cs%reserved2(:) = c_null_ptr
+cs%reserved0(:) = 0 ; cs%set_visc_CSp = c_null_ptr ; cs%reserved2(:) = c_null_ptr
 cs%continuity_CSp = c_loc(ccs) ; cs%CoriolisAdv = c_loc(cor) ; cs%PressureForce_CSp = c_loc(pcs) ; cs%eqn_of_state = c_loc(eos)
 cs%barotropic_CSp = c_loc(bcs) ; cs%BT_cont = c_loc(btc) ; cs%hooks = c_null_ptr
 cs%vertvisc_CSp = c_null_ptr ; cs%visc = c_null_ptr ; cs%hor_visc = c_null_ptr

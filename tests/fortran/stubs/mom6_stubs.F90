@@ -155,7 +155,7 @@ type :: verticalGrid_type
   integer :: ke
   real :: Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
           Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0
-  integer :: nk_rho_varies = 0
+  integer :: nk_rho_varies = 0, nkml = 0
   logical :: Boussinesq = .true.
   real, allocatable :: Rlay(:), g_prime(:)
 end type verticalGrid_type
@@ -392,6 +392,7 @@ implicit none ; private
 public :: mech_forcing
 type :: mech_forcing
   real, pointer, dimension(:,:) :: taux => NULL(), tauy => NULL()
+  real, pointer, dimension(:,:) :: ustar => NULL()      !< the surface friction velocity [Z T-1]
 end type mech_forcing
 end module MOM_forcing_type
 
@@ -545,6 +546,7 @@ end type thermo_var_ptrs
 type :: vertvisc_type
   real :: Prandtl_turb = 1.0
   real, allocatable, dimension(:,:) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v
+  real, allocatable, dimension(:,:) :: nkml_visc_u, nkml_visc_v
   real, allocatable, dimension(:,:,:) :: Ray_u, Ray_v
   real, pointer, dimension(:,:,:) :: Kv_shear => NULL(), Kv_shear_Bu => NULL()
 end type vertvisc_type

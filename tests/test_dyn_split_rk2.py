@@ -277,3 +277,136 @@ def test_step_with_bt_project_velocity_matches_oracle_bitwise(kw):
                            ("u_av", CS.u_av, ref.arrs["u_av"])):
             assert bits_equal(a.cpu().numpy(), b), (n, name)
     dg.close()
+
+
+# ---- the hot-path switches of the reference's .testing configurations, in the whole step ---------------------------------------
+# (values transcribed from .testing/tc4/MOM_input, tc2/MOM_input and tc1/MOM_input; the Fortran shims read the same sets by name in
+# tests/test_testing_configs.py)
+TC_SETS = {
+    # tc4: 14 x 10 x 2, ALE z*, EQN_OF_STATE = LINEAR with DRHO_DS = 0, RECONSTRUCT_FOR_PRESSURE = False, BE = 0.7, BEBT = 0.2,
+    # BOUND_BT_CORRECTION, CORIOLIS_EN_DIS, DIRECT_STRESS with HMIX_FIXED = 20, KV_ML_INVZ2 = 0.01, KV = 1e-4, HBBL = 10,
+    # SMAGORINSKY_AH with SMAG_BI_CONST = 0.03, ETA_TOLERANCE = 1e-12, DT = 1200
+    "tc4": dict(shape=(14, 10, 2), reentrant_x=False, dt=1200.0, be=0.7, eos=("LINEAR", 1000.0, -0.2, 0.0), pressureforce=dict(reconstruct=False),
+                bt=dict(bebt=0.2, bound_BT_corr=1, maxCFL_BT_cont=0.25),
+                cor=dict(coriolis_en_dis=1, bound_coriolis=0),      # (CORIOLIS_EN_DIS switches BOUND_CORIOLIS off, MOM_CoriolisAdv.F90:1155)
+                vv=dict(Kv=1.0e-4, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=0.01, direct_stress=True, maxvel=10.0, CFL_based_trunc=False),
+                hv=dict(biharmonic=1, Smagorinsky_Ah=1, Smag_bi_const=0.03, use_land_mask=0), tol_eta=1.0e-12, ml=None),
+    # tc2: 10 x 8 x 8, ALE z*, WRIGHT, DT = 3600, BEBT = 0.2, BOUND_BT_CORRECTION, NONLINEAR_BT_CONTINUITY, BT_PROJECT_VELOCITY,
+    # DYNAMIC_VISCOUS_ML with BULK_RI_ML = 0.05, TKE_DECAY = 10, ML_OMEGA_FRAC = 1, HMIX_FIXED = 0.5, KV = 1e-4, HBBL = 10, MAXVEL = 10,
+    # LAPLACIAN + SMAGORINSKY_KH (0.06, KH_VEL_SCALE = 0.05) and SMAGORINSKY_AH (0.06, AH_VEL_SCALE = 0.05), ETA_TOLERANCE = 1e-6,
+    # VELOCITY_TOLERANCE = 1e-3  (CHANNEL_DRAG belongs to set_viscous_BBL, outside the step)
+    "tc2": dict(shape=(10, 8, 8), reentrant_x=False, dt=3600.0, be=0.6, eos=("WRIGHT",), pressureforce=dict(),
+                bt=dict(bebt=0.2, bound_BT_corr=1, maxCFL_BT_cont=0.25, Nonlinear_continuity=1, BT_project_velocity=1), cor=dict(),
+                vv=dict(Kv=1.0e-4, Hbbl=10.0, Hmix=0.5, maxvel=10.0, CFL_based_trunc=False, dynamic_viscous_ML=True),
+                hv=dict(Laplacian=1, biharmonic=1, Smagorinsky_Kh=1, Smag_Lap_const=0.06, Kh_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06,
+                        Ah_vel_scale=0.05, use_land_mask=0), tol_eta=1.0e-6, tol_vel=1.0e-3,
+                ml=dict(bulk_Ri_ML=0.05, TKE_decay=10.0, omega_frac=1.0)),
+    # tc1: 10 x 8 x 8, the same dynamics switches as tc2 with DT = 900 and biharmonic Smagorinsky only (AH_VEL_SCALE = 0.05, 0.06); its
+    # layered (bulk mixed layer) thermodynamics is outside the step: here the step runs with nkml = 2 layers always in the viscous mixed
+    # layer and PressureForce without ALE (int_density_dz, nk_rho_varies = 4 with GV%Rlay)
+    "tc1": dict(shape=(10, 8, 8), reentrant_x=False, dt=900.0, be=0.6, eos=("WRIGHT",),
+                pressureforce=dict(use_ALE=False, nkmb=4, Rlay=np.linspace(1024.0, 1028.0, 8)),
+                bt=dict(bebt=0.2, bound_BT_corr=1, maxCFL_BT_cont=0.25, Nonlinear_continuity=1, BT_project_velocity=1), cor=dict(),
+                vv=dict(Kv=1.0e-4, Hbbl=10.0, maxvel=10.0, CFL_based_trunc=False, dynamic_viscous_ML=True, nkml=2),
+                hv=dict(biharmonic=1, Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.05, use_land_mask=0), tol_eta=1.0e-6, tol_vel=1.0e-3,
+                ml=dict(bulk_Ri_ML=0.05, TKE_decay=10.0, omega_frac=1.0, nkml=2)),
+}
+
+
+def tc_oracle_state(name):
+    c = TC_SETS[name]
+    ni, nj, nk = c["shape"]
+    g, d, taux, tauy = make_case(ni=ni, nj=nj, nk=nk, seed=21, reentrant_x=c["reentrant_x"])
+    rng = np.random.default_rng(17)
+    arrs = _visc_arrays(g)
+    if c["ml"]:
+        arrs.update(ustar=np.ascontiguousarray(0.004 + 0.008 * rng.random(g.shape2(_abi.POS_H))),
+                    nkml_visc_u=g.zeros2(_abi.POS_U), nkml_visc_v=g.zeros2(_abi.POS_V))
+    E = orc.eos(*c["eos"])
+    ccs_kw = dict(tol_eta=c["tol_eta"])
+    st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], c["dt"], be=c["be"], eos_form=E, pressureforce=c["pressureforce"],
+                      vertvisc=orc.vertvisc_cs(g, **c["vv"]), visc=orc.vertvisc_type(**arrs), hor_visc=orc.hor_visc_cs(g, c["dt"], **c["hv"]),
+                      set_visc=orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True, **c["ml"]) if c["ml"] else None, **c["bt"])
+    st.ccs.tol_eta = c["tol_eta"]
+    if "tol_vel" in c:
+        st.ccs.tol_vel = c["tol_vel"]
+    for k, v in c["cor"].items():
+        setattr(st.cor, k, v)
+    return g, d, taux, tauy, arrs, st
+
+
+@pytest.mark.parametrize("name", list(TC_SETS))
+def test_oracle_step_with_the_testing_switch_sets(name):
+    """two steps with each configuration's hot-path switches: finite, volume conserving, and not the default step"""
+    g, d, taux, tauy, arrs, st = tc_oracle_state(name)
+    v0 = volume(g, st.h)
+    for n in range(2):
+        st.step(taux, tauy, calc_dtbt=(n == 0))
+    assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0
+    assert abs(volume(g, st.h) - v0) <= 1e-9 * v0
+    if TC_SETS[name]["ml"]:
+        nkv = st.visc._keep["nkml_visc_u"]
+        assert nkv.max() >= 1.0 and nkv.max() <= g.nk
+
+
+# the same sets by the reference's parameter names, for the library's host mirror
+TC_PARAMS = {
+    "tc4": dict(BE=0.7, EQN_OF_STATE="LINEAR", eos=dict(Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.0), pressure_force=dict(reconstruct=False),
+                barotropic=dict(BEBT=0.2, BOUND_BT_CORRECTION=True), coriolis=dict(bound_coriolis=True, coriolis_en_dis=True),
+                continuity=dict(tol_eta=1.0e-12),
+                vertvisc=dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=20.0, KV_ML_INVZ2=0.01, DIRECT_STRESS=True, MAXVEL=10.0, CFL_BASED_TRUNCATIONS=False),
+                hor_visc=dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.03, USE_LAND_MASK_FOR_HVISC=False)),
+    "tc2": dict(EQN_OF_STATE="WRIGHT",
+                barotropic=dict(BEBT=0.2, BOUND_BT_CORRECTION=True, NONLINEAR_BT_CONTINUITY=True, BT_PROJECT_VELOCITY=True),
+                coriolis=dict(bound_coriolis=True), continuity=dict(tol_eta=1.0e-6, tol_vel=1.0e-3),
+                vertvisc=dict(KV=1.0e-4, HBBL=10.0, HMIX_FIXED=0.5, MAXVEL=10.0, CFL_BASED_TRUNCATIONS=False, DYNAMIC_VISCOUS_ML=True),
+                hor_visc=dict(LAPLACIAN=True, BIHARMONIC=True, SMAGORINSKY_KH=True, SMAG_LAP_CONST=0.06, KH_VEL_SCALE=0.05, SMAGORINSKY_AH=True,
+                              SMAG_BI_CONST=0.06, AH_VEL_SCALE=0.05, USE_LAND_MASK_FOR_HVISC=False),
+                set_visc=dict(HBBL=10.0, KV=1.0e-4, DYNAMIC_VISCOUS_ML=True, BULK_RI_ML=0.05, TKE_DECAY=10.0, ML_OMEGA_FRAC=1.0)),
+    "tc1": dict(EQN_OF_STATE="WRIGHT", pressure_force=dict(use_ALE=False, nk_rho_varies=4, Rlay=np.linspace(1024.0, 1028.0, 8)),
+                barotropic=dict(BEBT=0.2, BOUND_BT_CORRECTION=True, NONLINEAR_BT_CONTINUITY=True, BT_PROJECT_VELOCITY=True),
+                coriolis=dict(bound_coriolis=True), continuity=dict(tol_eta=1.0e-6, tol_vel=1.0e-3),
+                vertvisc=dict(KV=1.0e-4, HBBL=10.0, MAXVEL=10.0, CFL_BASED_TRUNCATIONS=False, DYNAMIC_VISCOUS_ML=True, NKML=2),
+                hor_visc=dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL_SCALE=0.05, USE_LAND_MASK_FOR_HVISC=False),
+                set_visc=dict(HBBL=10.0, KV=1.0e-4, DYNAMIC_VISCOUS_ML=True, BULK_RI_ML=0.05, TKE_DECAY=10.0, ML_OMEGA_FRAC=1.0, NKML=2)),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(TC_SETS))
+def test_step_with_the_testing_switch_sets_matches_oracle_bitwise(name):
+    """the hot-path switch sets of .testing/tc4, tc2 and tc1 in step_MOM_dyn_split_RK2 (three steps, set_dtbt in the first): the
+    library's bits are the oracle's"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    g, d, taux, tauy, arrs, ref = tc_oracle_state(name)
+    c = TC_SETS[name]
+    dt = c["dt"]
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_U), Z(_abi.POS_V), Z(_abi.POS_H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, **TC_PARAMS[name])
+    for n in ("eta", "h_av", "CAu_pred", "u_av", "diffu"):
+        assert bits_equal(CS.arrays[n].cpu().numpy(), ref.arrs[n]), ("init", n)
+    va = {n: T(a) for n, a in arrs.items()}
+    visc = vertvisc_type(**va)
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy, calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        assert CS.barotropic_CSp.st.dtbt == ref.bcs.dtbt and CS.barotropic_CSp.st.nstep_last == ref.bcs.nstep_last
+        checks = [("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("vh", vh, ref.vh), ("eta_av", eta_av, ref.eta_av),
+                  ("eta", CS.eta, ref.arrs["eta"]), ("PFu", CS.PFu, ref.arrs["PFu"]), ("pbce", CS.pbce, ref.arrs["pbce"]),
+                  ("diffu", CS.diffu, ref.arrs["diffu"]), ("visc_rem_u", CS.visc_rem_u, ref.arrs["visc_rem_u"]),
+                  ("a_v", CS.vertvisc_CSp.a_v, ref.vvcs._arrs["a_v"])]
+        if c["ml"]:
+            checks += [("nkml_visc_u", va["nkml_visc_u"], ref.visc._keep["nkml_visc_u"]), ("nkml_visc_v", va["nkml_visc_v"], ref.visc._keep["nkml_visc_v"])]
+        for nm, a, b in checks:
+            an = a.cpu().numpy()
+            assert bits_equal(an, b), (name, n, nm, float(np.abs(an - b).max()))
+    dg.close()

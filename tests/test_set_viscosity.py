@@ -80,19 +80,90 @@ def test_linear_drag_gives_the_analytic_ustar():
     assert np.all(np.abs(bt - col) < 0.02 * col)      # (the upwind-biased harmonic mean differs a little from the arithmetic one)
 
 
-def test_set_viscous_ML_is_the_reference_no_op_and_refuses_the_rest():
+def ml_inputs(g, d, seed=3):
+    """forces%taux / tauy / ustar and the visc arrays set_viscous_ML reads and writes"""
+    rng = np.random.default_rng(seed)
+    su, sv, sh = g.shape2(U), g.shape2(V), g.shape2(H)
+    taux = np.ascontiguousarray(0.1 * np.cos(np.linspace(0, 3, su[0]))[:, None] * g.mask2dCu)
+    tauy = np.ascontiguousarray(0.05 * (rng.random(sv) - 0.3) * g.mask2dCv)
+    ustar = np.ascontiguousarray(0.004 + 0.008 * rng.random(sh))
+    return taux, tauy, dict(ustar=ustar, nkml_visc_u=np.full(su, -1.0), nkml_visc_v=np.full(sv, -1.0))
+
+
+ML_VARIANTS = {
+    "tc_values": dict(bulk_Ri_ML=0.05, TKE_decay=10.0, omega_frac=1.0),              # .testing/tc1, tc2: BULK_RI_ML, TKE_DECAY, ML_OMEGA_FRAC
+    "wright": dict(bulk_Ri_ML=2.0, TKE_decay=1.0),                                   # (the rest: values that spread the answers over the layers)
+    "omega_frac_1": dict(bulk_Ri_ML=2.0, TKE_decay=1.0, omega_frac=1.0),
+    "omega_blend": dict(bulk_Ri_ML=4.0, TKE_decay=0.5, omega_frac=0.4),
+    "nkml2": dict(bulk_Ri_ML=2.0, TKE_decay=1.0, omega_frac=1.0, nkml=2),            # a bulk mixed layer (tc1)
+    "rlay": dict(bulk_Ri_ML=2.0, TKE_decay=1.0, eos=None),                           # no equation of state: GV%Rlay
+    "no_decay": dict(bulk_Ri_ML=0.5, TKE_decay=0.0),
+}
+ML_DT = 7200.0
+
+
+def run_oracle_ml(g, d, taux, tauy, arrs, dt=ML_DT, eos="WRIGHT", **kw):
+    visc = orc.vertvisc_type(**arrs)
+    cs = orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True, Rlay=rlay(g.nk) if eos is None else None, **kw)
+    orc.set_viscous_ML(g, cs, d["u"], d["v"], d["h"], d["T"], d["S"], None if eos is None else orc.eos(eos), taux, tauy, visc, dt)
+    return visc._keep
+
+
+def test_set_viscous_ML_without_the_switch_and_refusals():
+    """without DYNAMIC_VISCOUS_ML set_viscous_ML returns at once (MOM_set_viscosity.F90:2043); CHANNEL_DRAG is still refused"""
     g = xs.make_grid(12, 10, 3)
-    cs = orc.set_visc_cs(g, 10.0, 1.0e-4)
-    L = orc.lib()
-    import ctypes as C
-    L.orc_set_viscous_ML.argtypes = [C.POINTER(_abi.SetViscCS)]
-    assert L.orc_set_viscous_ML(C.byref(cs)) == 0
-    cs2 = orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True)
-    assert L.orc_set_viscous_ML(C.byref(cs2)) != 0
-    cs3 = orc.set_visc_cs(g, 10.0, 1.0e-4, Channel_drag=True)
     d = xs.make_state(g)
+    taux, tauy, arrs = ml_inputs(g, d)
+    visc = orc.vertvisc_type(**arrs)
+    orc.set_viscous_ML(g, orc.set_visc_cs(g, 10.0, 1.0e-4), d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), taux, tauy, visc, 900.0)
+    assert np.all(visc._keep["nkml_visc_u"] == -1.0)
+    cs3 = orc.set_visc_cs(g, 10.0, 1.0e-4, Channel_drag=True)
     with pytest.raises(RuntimeError):
         orc.set_viscous_BBL(g, cs3, d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), orc.vertvisc_type(**visc_arrays(g, d)))
+
+
+def test_cr_exp_is_the_correctly_rounded_exponential():
+    """the decay of the bulk Richardson number, exp(-htot*Idecay_len_TKE) (:2178), is evaluated correctly rounded on both sides:
+    against 200-bit arithmetic it is exact; glibc's exp (< 1 ulp, not correctly rounded) differs from it rarely and by one ulp"""
+    import math
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rng = np.random.default_rng(2)
+    ts = np.concatenate([-rng.random(3000) * 30.0, -10.0 ** rng.uniform(-12, 2.8, 3000), [-0.0, -1e-300, -699.9, -745.0, -1000.0]])
+    nlibm = 0
+    for t in ts:
+        want = float(mp.exp(mp.mpf(float(t)))) if t > -700.0 else 0.0
+        got = orc.cr_exp(t)
+        assert got == want, (t, got, want)
+        nlibm += got != math.exp(t) and t > -700.0
+    assert nlibm < 0.01 * ts.size
+
+
+@pytest.mark.parametrize("name", list(ML_VARIANTS))
+def test_dynamic_viscous_ML_is_sane(name):
+    """DYNAMIC_VISCOUS_ML (.testing/tc1, tc2; :2111-2230, :2400-2506): the fractional number of layers in the viscous mixed layer is
+    between nkml and nz on ocean faces and nkml on land; a more efficient conversion (a larger bulk Richardson number) cannot
+    make the layer shallower; with no conversion at all (BULK_RI_ML = 0) the search stops at the first stratified layer."""
+    kw = dict(ML_VARIANTS[name])
+    g = xs.make_grid(40, 28, 12)
+    d = xs.make_state(g, umax=0.3)
+    taux, tauy, arrs = ml_inputs(g, d)
+    a = run_oracle_ml(g, d, taux, tauy, arrs, **kw)
+    nkml = kw.get("nkml", 0)
+    for n, pos, mk in (("nkml_visc_u", U, g.mask2dCu), ("nkml_visc_v", V, g.mask2dCv)):
+        x = interior(g, a[n], pos); m = interior(g, mk, pos) > 0
+        assert np.all(x[~m] == nkml) and np.all(x[m] >= nkml) and np.all(x[m] <= g.nk)
+        if name != "tc_values":
+            assert np.any(x[m] != np.round(x[m])) and len(np.unique(np.ceil(x[m]))) >= 2      # columns end inside different layers
+    _, _, arrs2 = ml_inputs(g, d)
+    b = run_oracle_ml(g, d, taux, tauy, arrs2, **dict(kw, bulk_Ri_ML=10.0 * kw["bulk_Ri_ML"]))
+    _, _, arrs3 = ml_inputs(g, d)
+    c = run_oracle_ml(g, d, taux, tauy, arrs3, **dict(kw, bulk_Ri_ML=0.0))
+    mu = interior(g, g.mask2dCu, U) > 0
+    xa, xb, xc = (interior(g, q["nkml_visc_u"], U)[mu] for q in (a, b, c))
+    assert np.all(xb >= xa) and np.all(xc <= xa) and np.all(xc == np.round(xc))
+    if name != "tc_values":
+        assert np.any(xb > xa)
 
 
 @pytest.mark.gpu
@@ -119,7 +190,7 @@ def test_gpu_parity(name):
             arrs = {n: X(a) for n, a in visc_arrays(g, d).items()}
             visc = vertvisc_type(**arrs)
             set_viscous_BBL(X(d["u"]), X(d["v"]), X(d["h"]), (X(d["T"]), X(d["S"]), EOS_init("WRIGHT")), visc, dg, CS)
-            set_viscous_ML(None, None, None, None, None, visc, 900.0, dg, CS)
+            set_viscous_ML(None, None, None, None, None, visc, 900.0, dg, CS)      # no DYNAMIC_VISCOUS_ML: the early return
             dg.sync()
             for n in ("bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "Ray_u", "Ray_v"):
                 assert bits_equal(N(arrs[n]), ref[n]), (name, (ni, nj, nk), resident, n, np.argwhere(N(arrs[n]) != ref[n])[:3])
@@ -147,3 +218,37 @@ def test_gpu_parity_unesco_eos():
     for n in ("bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "Ray_u", "Ray_v"):
         assert bits_equal(arrs[n].cpu().numpy(), ref[n]), n
     dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ML_VARIANTS))
+def test_gpu_parity_dynamic_viscous_ML(name):
+    """set_viscous_ML with DYNAMIC_VISCOUS_ML: library == oracle, bit for bit (the exponential included)"""
+    import torch
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.set_viscosity import set_visc_init, set_viscous_ML
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    kw = dict(ML_VARIANTS[name])
+    eos = kw.pop("eos", "WRIGHT")
+    for (ni, nj, nk, topo) in [(70, 21, 8, (True, False)), (44, 40, 3, (True, True)), (10, 8, 30, (False, False)), (200, 9, 75, (True, False))]:
+        if kw.get("nkml", 0) >= nk:
+            continue
+        g = xs.make_grid(ni, nj, nk, reentrant_x=topo[0], reentrant_y=topo[1])
+        d = xs.make_state(g, umax=0.3)
+        taux, tauy, arrs = ml_inputs(g, d, seed=ni)
+        ref = run_oracle_ml(g, d, taux, tauy, {n: a.copy() for n, a in arrs.items()}, eos=eos, **kw)
+        dg = DeviceGrid(g)
+        CS = set_visc_init(dg, HBBL=10.0, KV=1.0e-4, DYNAMIC_VISCOUS_ML=True, BULK_RI_ML=kw["bulk_Ri_ML"], TKE_DECAY=kw["TKE_decay"],
+                           ML_OMEGA_FRAC=kw.get("omega_frac", 0.0), NKML=kw.get("nkml", 0), Rlay=rlay(nk) if eos is None else None)
+        for resident in (True, False):
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a.copy())
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            va = {n: X(a) for n, a in arrs.items()}
+            visc = vertvisc_type(**va)
+            tv = (X(d["T"]), X(d["S"]), EOS_init(eos)) if eos else None
+            set_viscous_ML(X(d["u"]), X(d["v"]), X(d["h"]), tv, (X(taux), X(tauy)), visc, ML_DT, dg, CS)
+            dg.sync()
+            for n in ("nkml_visc_u", "nkml_visc_v"):
+                assert bits_equal(N(va[n]), ref[n]), (name, (ni, nj, nk), resident, n, np.argwhere(N(va[n]) != ref[n])[:3])
+        dg.close()

@@ -17,10 +17,13 @@ VARIANTS = [
     dict(bottomdraglaw=False),
     dict(direct_stress=True, Hmix=15.0),
     dict(CFL_based_trunc=False, maxvel=0.05, vel_underflow=1.0e-3),
+    dict(dynamic_viscous_ML=True),                                 # DYNAMIC_VISCOUS_ML (.testing/tc1, tc2): visc%nkml_visc_u/v, forces%ustar
+    dict(nkml=2),                                                  # the viscous mixed layer of a bulk mixed layer (tc1)
+    dict(dynamic_viscous_ML=True, nkml=2, Kvml_invZ2=1.0e-2, Hmix=20.0),
 ]
 
 
-def vv_case(ni=24, nj=18, nk=7, seed=5, with_shear=False, with_ray=False, umax=0.2, **topo):
+def vv_case(ni=24, nj=18, nk=7, seed=5, with_shear=False, with_ray=False, umax=0.2, with_ml=False, **topo):
     g = synth.make_grid(ni, nj, nk, seed=seed + 40, **topo)
     st = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=umax).items()}
     rng = np.random.default_rng(seed)
@@ -33,6 +36,10 @@ def vv_case(ni=24, nj=18, nk=7, seed=5, with_shear=False, with_ray=False, umax=0
         arrs["Ray_u"] = 1.0e-5 * rng.random(g.shape3(_abi.POS_U)); arrs["Ray_v"] = 1.0e-5 * rng.random(g.shape3(_abi.POS_V))
     taux = np.ascontiguousarray(0.1 * np.cos(np.linspace(0, 3, su[0]))[:, None] * g.mask2dCu)
     tauy = np.ascontiguousarray(0.05 * g.mask2dCv * rng.random(sv))
+    if with_ml:      # what set_viscous_ML leaves in visc (a fractional number of layers) and forces%ustar, with a few calm cells
+        arrs["nkml_visc_u"] = np.clip(nk * rng.random(su) ** 2, 0.0, nk); arrs["nkml_visc_v"] = np.clip(nk * rng.random(sv) ** 2, 0.0, nk)
+        arrs["nkml_visc_u"][::3, ::4] = np.floor(arrs["nkml_visc_u"][::3, ::4])
+        arrs["ustar"] = np.where(rng.random(sh) < 0.05, 0.0, 0.002 + 0.01 * rng.random(sh))
     return g, st, arrs, taux, tauy
 
 
@@ -118,11 +125,13 @@ def test_gpu_parity(oracle, variant):
     pk = dict(KV=1.0e-4, HBBL=10.0)
     names = dict(harmonic_visc="HARMONIC_VISC", harm_BL_val="HARMONIC_BL_SCALE", Kvml_invZ2="KV_ML_INVZ2", Hmix="HMIX_FIXED",
                  bottomdraglaw="BOTTOMDRAGLAW", Kv_extra_bbl="KV_EXTRA_BBL", direct_stress="DIRECT_STRESS",
-                 CFL_based_trunc="CFL_BASED_TRUNCATIONS", maxvel="MAXVEL", vel_underflow="VEL_UNDERFLOW")
+                 CFL_based_trunc="CFL_BASED_TRUNCATIONS", maxvel="MAXVEL", vel_underflow="VEL_UNDERFLOW",
+                 dynamic_viscous_ML="DYNAMIC_VISCOUS_ML", nkml="NKML")
     pk.update({names[k]: v for k, v in kw.items()})
+    ml = bool(kw.get("dynamic_viscous_ML") or kw.get("nkml"))
     for (ni, nj, nk, topo, extra) in [(24, 18, 7, dict(reentrant_x=True), dict()), (70, 9, 3, dict(reentrant_x=False), dict(with_shear=True, with_ray=True)),
                                       (12, 10, 75, dict(reentrant_x=True, reentrant_y=True), dict(with_shear=True))]:
-        g, st, arrs, taux, tauy = vv_case(ni, nj, nk, seed=ni, **extra, **topo)
+        g, st, arrs, taux, tauy = vv_case(ni, nj, nk, seed=ni, with_ml=ml, **extra, **topo)
         dt = 900.0
         dz = np.ascontiguousarray(st["h"] * g.H_to_Z) if nk == 3 else None      # an explicit dz on one of the grids
         rcs = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, **kw)
@@ -175,6 +184,32 @@ def test_gpu_parity(oracle, variant):
             vertvisc_step(u4, v4, h, X(dz), None, visc, dt, dg, CS3, r3u, r3v, False)      # :598-600: velocities untouched
             assert bits_equal(st["u"], N(u4)) and bits_equal(rvru, N(r3u)) and bits_equal(rvrv, N(r3v)), (what, "step, remnant only")
         dg.close()
+
+
+def test_surface_boundary_layer_viscosity(oracle):
+    """DYNAMIC_VISCOUS_ML / a bulk mixed layer (find_coupling_coef :2047-2252): the coupling can only grow, it grows only above the
+    base of the boundary layer (K <= ceil(nkml_visc)), not where the wind is calm, and more with a stronger wind"""
+    g, st, arrs, taux, tauy = vv_case(with_ml=True, nk=12)
+    base = {n: a for n, a in arrs.items() if n not in ("nkml_visc_u", "nkml_visc_v", "ustar")}
+    cs0 = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0)
+    orc.vertvisc_coef(g, cs0, st["u"], st["v"], st["h"], orc.vertvisc_type(**base), 900.0)
+    cs1 = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, dynamic_viscous_ML=True)
+    orc.vertvisc_coef(g, cs1, st["u"], st["v"], st["h"], orc.vertvisc_type(**arrs), 900.0)
+    cs2 = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, dynamic_viscous_ML=True)
+    orc.vertvisc_coef(g, cs2, st["u"], st["v"], st["h"], orc.vertvisc_type(**dict(arrs, ustar=2.0 * arrs["ustar"])), 900.0)
+    a0, m = face_cols(g, cs0._arrs["a_u"], _abi.POS_U); a1, _ = face_cols(g, cs1._arrs["a_u"], _abi.POS_U); a2, _ = face_cols(g, cs2._arrs["a_u"], _abi.POS_U)
+    nkv, _ = face_cols(g, arrs["nkml_visc_u"][None], _abi.POS_U)
+    a0, a1, a2, nkv = a0[:, m], a1[:, m], a2[:, m], nkv[0, m]
+    assert np.all(a1 >= a0) and np.any(a1 > a0) and np.all(a2 >= a1) and np.any(a2 > a1)
+    K = np.arange(a0.shape[0])[:, None] + 1                       # interface number, one-based
+    assert np.all((a1 == a0) | ((K >= 2) & (K <= np.ceil(nkv)[None])))
+    assert bits_equal(cs0._arrs["h_u"], cs1._arrs["h_u"])
+    # the bulk mixed layer: its nkml layers are the boundary layer
+    cs3 = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, nkml=3)
+    orc.vertvisc_coef(g, cs3, st["u"], st["v"], st["h"], orc.vertvisc_type(**dict(base, ustar=arrs["ustar"])), 900.0)
+    a3, _ = face_cols(g, cs3._arrs["a_u"], _abi.POS_U)
+    a3 = a3[:, m]
+    assert np.all((a3 == a0) | ((K >= 2) & (K <= 3))) and np.any(a3 > a0)
 
 
 def test_unsupported_options_are_refused_by_name():
