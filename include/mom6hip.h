@@ -95,8 +95,13 @@ int mom6hip_sync(mom6hip_ctx_t *ctx);
 /* Plain device allocation helpers for hosts without another device allocator (Fortran driver). */
 int mom6hip_malloc(void **dptr, uint64_t bytes);
 int mom6hip_free(void *dptr);
+/* zeroes `bytes` of device memory on the context's stream (what ALLOC_ / allocate(..., source=0.0) do for a device mirror) */
+int mom6hip_memset_zero(mom6hip_ctx_t *ctx, void *dptr, uint64_t bytes);
 int mom6hip_sync_to_device(mom6hip_ctx_t *ctx, void *dptr, const void *hptr, uint64_t bytes);
 int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint64_t bytes);
+/* stats[0..3] = calls and bytes of mom6hip_sync_to_device, calls and bytes of mom6hip_sync_to_host + mom6hip_stage_to_host on this
+ * context since its creation or the last reset: what a device-resident host (MOM_dynamics_split_RK2_hip.F90) moved over PCIe. */
+int mom6hip_transfer_stats(mom6hip_ctx_t *ctx, uint64_t *stats, int32_t reset);
 
 /* ---- restart / diagnostic staging: fields to the host while the model keeps stepping ------ */
 

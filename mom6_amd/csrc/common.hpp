@@ -106,6 +106,7 @@ struct mom6hip_ctx {
   bool hv_pack_ready = false;
   m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
   m6::HostTable tables[m6::TABLE_COUNT];      // cached device copies of short host tables (m6::HostTable)
+  uint64_t xfer[4] = {0, 0, 0, 0};            // calls and bytes of mom6hip_sync_to_device, then of mom6hip_sync_to_host / stage_to_host
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
   std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)

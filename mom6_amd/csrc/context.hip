@@ -118,6 +118,12 @@ int mom6hip_free(void *dptr) {
   return 0;
 }
 
+int mom6hip_memset_zero(mom6hip_ctx_t *ctx, void *dptr, uint64_t bytes) {
+  M6_REQUIRE(ctx != nullptr && dptr != nullptr, "mom6hip_memset_zero: null argument");
+  M6_HIP(hipMemsetAsync(dptr, 0, bytes, ctx->stream));
+  return 0;
+}
+
 int mom6hip_sync(mom6hip_ctx_t *ctx) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_sync: null context");
   M6_HIP(hipStreamSynchronize(ctx->stream));
@@ -128,6 +134,13 @@ int mom6hip_sync_to_device(mom6hip_ctx_t *ctx, void *dptr, const void *hptr, uin
   M6_REQUIRE(ctx != nullptr, "mom6hip_sync_to_device: null context");
   M6_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
   M6_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->xfer[0]++; ctx->xfer[1] += bytes;
+  return 0;
+}
+
+int mom6hip_transfer_stats(mom6hip_ctx_t *ctx, uint64_t *stats, int32_t reset) {
+  M6_REQUIRE(ctx != nullptr && stats != nullptr, "mom6hip_transfer_stats: null argument");
+  for (int q = 0; q < 4; q++) { stats[q] = ctx->xfer[q]; if (reset) ctx->xfer[q] = 0; }
   return 0;
 }
 
@@ -135,6 +148,7 @@ int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint6
   M6_REQUIRE(ctx != nullptr, "mom6hip_sync_to_host: null context");
   M6_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   M6_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->xfer[2]++; ctx->xfer[3] += bytes;
   return 0;
 }
 

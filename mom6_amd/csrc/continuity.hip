@@ -644,6 +644,30 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     fsm[PK_UHBT + fl] = pk_ub; fsm[PK_DLC + fl] = pk_lc;
     fsm[PK_DLF + fl] = F0.dLf; fsm[PK_CM + fl] = F0.cm; fsm[PK_CP + fl] = F0.cp;
   }
+  // ---- blocks whose 32 faces are all land: nothing to solve.  With dy_Cu (dx_Cv) = 0, the face masked, no velocity in any
+  // layer and no barotropic transport asked of it, every pass of the reference multiplies by the zero face length: uh = +0 in
+  // every layer (u = 0 takes flux_layer's own branch), the Newton iteration starts converged (uh_err = 0: du = 0), the
+  // BT_cont sums are zero whatever the limits duL / duR are (FA = +0, uBT = 0: the branches below with all sums +0).  Only
+  // h_u / h_v (flux_thickness has no mask) and u_cor = u + 0*visc_rem still need the layer data.  30 % of the 1/4-degree grid
+  // is land in contiguous continents; a block-uniform vote keeps the barriers of the live blocks uniform.
+  bool dead_lane = (pk_mf == 0.0) & (dLf_r == 0.0) & (pk_ub == 0.0);
+#pragma unroll
+  for (int m = 0; m < KS; m++) dead_lane = dead_lane & ((k0 + m >= nz) | (ru[m] == 0.0));
+  const bool dead = __syncthreads_and(dead_lane ? 1 : 0) != 0;
+  if (dead && !p.set_BT_cont) {
+    const double du_dead = 0.0;
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < KS; m++) {
+        if (k0 + m < nz) {
+          p.uh[f2 + (k0 + m) * fpl] = 0.0;
+          if (p.uhbt && p.u_cor) p.u_cor[f2 + (k0 + m) * fpl] = ru[m] + du_dead * rvr[m];
+        }
+      }
+      if (sb == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du_dead : 0.0;
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     const int k = k0 + m;
@@ -668,6 +692,38 @@ __global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs 
     } else {
       ru[m] = 0.; rvr[m] = 0.; mE[m] = 0.; mD[m] = 0.; mC[m] = 0.; pW[m] = 0.; pD[m] = 0.; pC[m] = 0.;
     }
+  }
+
+  if (dead) {      // (set_BT_cont: the layer data are needed for h_u / h_v and u_cor; every sum of the fits is +0)
+    const double du_dead = 0.0;
+    const bool cor_d = p.uhbt && p.u_cor;
+#pragma unroll
+    for (int m = 0; m < KS; m++) {
+      if (k0 + m < nz) {
+        const long f3 = f2 + (k0 + m) * fpl;
+        const double vr = rvr[m], uk = ru[m];
+        if (valid) p.uh[f3] = 0.0;
+        double uc = uk;
+        if (cor_d) { uc = uk + du_dead * vr; if (valid) p.u_cor[f3] = uc; }
+        if (p.h_face) {      // flux_thickness :976-1057 at uc = 0 (or whatever u + 0*visc_rem is)
+          const bool pos = uc > 0.0;
+          const double E = pos ? mE[m] : pW[m], Dd = pos ? mD[m] : pD[m], Cc = pos ? mC[m] : pC[m], cf = pos ? F0.cm : F0.cp;
+          const double CFL = (fabs(uc) * p.dt) * cf;
+          double h_avg = E + CFL * (0.5 * Dd + Cc * (CFL - 1.5));
+          double h_marg = E + CFL * (Dd + 3.0 * Cc * (CFL - 1.0));
+          if (uc == 0.0) { h_avg = 0.5 * (pW[m] + mE[m]); h_marg = 0.5 * (pW[m] + mE[m]); }
+          double hu = p.o.marginal_faces ? h_marg : h_avg;
+          if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
+          if (valid) p.h_face[f3] = hu;
+        }
+      }
+    }
+    if (sb == 0 && valid) {
+      if (p.du_cor) p.du_cor[f2] = p.uhbt ? du_dead : 0.0;
+      p.FA_0m[f2] = 0.0; p.FA_mm[f2] = 0.0; p.uBT_mm[f2] = 0.0;
+      p.FA_0p[f2] = 0.0; p.FA_pp[f2] = 0.0; p.uBT_pp[f2] = 0.0;
+    }
+    return;
   }
 
   FC_MARK(1);

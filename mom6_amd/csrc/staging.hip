@@ -51,6 +51,7 @@ int mom6hip_stage_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint
   M6_HIP(hipStreamWaitEvent(ctx->copy_stream, s.snap, 0));
   M6_HIP(hipMemcpyAsync(hptr, s.buf.p, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
   M6_HIP(hipEventRecord(s.done, ctx->copy_stream));
+  ctx->xfer[2]++; ctx->xfer[3] += bytes;
   return 0;
 }
 

@@ -26,6 +26,7 @@ implicit none ; private
 #include <MOM_memory.h>
 
 public CorAdCalc, CoriolisAdv_init, CoriolisAdv_end
+public CoriolisAdv_hip_struct      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> Control structure (the members of the reference's CoriolisAdv_CS, :30-88, that the provided options need)
 type, public :: CoriolisAdv_CS ; private
@@ -44,6 +45,17 @@ integer, parameter :: KE_ARAKAWA = 10, KE_SIMPLE_GUDONOV = 11, KE_GUDONOV = 12
 integer, parameter :: PV_ADV_CENTERED = 21, PV_ADV_UPWIND1 = 22
 
 contains
+
+!> (GPU path only) The control structure as the library's struct
+function CoriolisAdv_hip_struct(CS) result(ccs)
+  type(CoriolisAdv_CS), intent(in) :: CS
+  type(mom6hip_coriolisadv_cs_t) :: ccs
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_CoriolisAdv: Module must be initialized before it is used.")
+  ccs%coriolis_scheme = CS%Coriolis_Scheme ; ccs%ke_scheme = CS%KE_Scheme
+  ccs%no_slip = merge(1, 0, CS%no_slip) ; ccs%bound_coriolis = merge(1, 0, CS%bound_Coriolis)
+  ccs%coriolis_en_dis = merge(1, 0, CS%Coriolis_En_Dis) ; ccs%pv_adv_scheme = CS%PV_Adv_Scheme ; ccs%reserved(:) = 0
+  ccs%F_eff_max_blend = CS%F_eff_max_blend ; ccs%wt_lin_blend = CS%wt_lin_blend
+end function CoriolisAdv_hip_struct
 
 !> Same interface as the reference CorAdCalc (:125).
 subroutine CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Waves)

@@ -32,6 +32,7 @@ implicit none ; private
 
 public PressureForce_FV_init
 public PressureForce_FV_Bouss, PressureForce_FV_nonBouss
+public PressureForce_FV_hip_struct      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> Finite volume pressure gradient control structure (the members of the reference's, :36-80, that the provided form reads)
 type, public :: PressureForce_FV_CS ; private
@@ -45,6 +46,29 @@ type, public :: PressureForce_FV_CS ; private
 end type PressureForce_FV_CS
 
 contains
+
+!> (GPU path only) The control structure, and what PressureForce_FV_Bouss takes from its other arguments to choose its branch, as
+!! the library's structs.  use_EOS says whether tv%eqn_of_state is associated (eos is then the equation of state read at
+!! initialisation).  GV must stay in place while ccs is in use (its Rlay and g_prime are referenced, not copied).
+subroutine PressureForce_FV_hip_struct(CS, G, GV, tv, ALE_CSp, ccs, eos, use_EOS)
+  type(PressureForce_FV_CS), intent(in) :: CS
+  type(ocean_grid_type),   intent(in)  :: G
+  type(verticalGrid_type), target, intent(in) :: GV
+  type(thermo_var_ptrs),   intent(in)  :: tv
+  type(ALE_CS),            pointer     :: ALE_CSp
+  type(mom6hip_pressureforce_cs_t), intent(out) :: ccs
+  type(mom6hip_eos_t),     intent(out) :: eos
+  logical,                 intent(out) :: use_EOS
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_PressureForce_FV_Bouss: Module must be initialized before it is used.")
+  use_EOS = associated(tv%eqn_of_state)
+  ccs%Rho0 = CS%Rho0 ; ccs%GFS_scale = CS%GFS_scale ; ccs%Z_ref = G%Z_ref
+  ccs%reconstruct = merge(1, 0, CS%reconstruct) ; ccs%Recon_Scheme = CS%Recon_Scheme
+  ccs%boundary_extrap = merge(1, 0, CS%boundary_extrap) ; ccs%useMassWghtInterp = merge(1, 0, CS%useMassWghtInterp)
+  ccs%use_ALE = merge(1, 0, associated(ALE_CSp)) ; ccs%nkmb = GV%nk_rho_varies ; ccs%P_Ref = tv%P_Ref
+  ccs%Rlay = c_null_ptr ; if (allocated(GV%Rlay)) ccs%Rlay = c_loc(GV%Rlay)
+  ccs%g_prime = c_null_ptr ; if (allocated(GV%g_prime)) ccs%g_prime = c_loc(GV%g_prime)
+  eos = CS%eos
+end subroutine PressureForce_FV_hip_struct
 
 !> Same interface as the reference PressureForce_FV_nonBouss (:89).
 subroutine PressureForce_FV_nonBouss(h, tv, PFu, PFv, G, GV, US, CS, ALE_CSp, p_atm, pbce, eta)

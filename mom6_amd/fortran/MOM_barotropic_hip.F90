@@ -31,6 +31,7 @@ implicit none ; private
 
 public btcalc, bt_mass_source, btstep, barotropic_init, barotropic_end
 public register_barotropic_restarts, set_dtbt, barotropic_get_tav
+public barotropic_hip_struct, barotropic_hip_update      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> Control structure: the library's struct (run-time parameters, dtbt) and the arrays the reference keeps in barotropic_CS
 !! (:104-332) that outlive a call
@@ -56,6 +57,25 @@ subroutine bind_arrays(CS)
   CS%st%q_D = c_loc(CS%q_D) ; CS%st%D_u_Cor = c_loc(CS%D_u_Cor) ; CS%st%D_v_Cor = c_loc(CS%D_v_Cor)
   CS%st%reserved2(:) = c_null_ptr
 end subroutine bind_arrays
+
+!> (GPU path only) The library's struct of this control structure, its pointers bound to the HOST arrays of CS: the
+!! device-resident step of MOM_dynamics_split_RK2 copies the scalars and gives the copy device arrays of its own.
+function barotropic_hip_struct(CS) result(st)
+  type(barotropic_CS), target, intent(inout) :: CS
+  type(mom6hip_barotropic_cs_t) :: st
+  if (.not.CS%module_is_initialized) call MOM_error(FATAL, "btstep: Module MOM_barotropic must be initialized before it is used.")
+  call bind_arrays(CS)
+  st = CS%st
+end function barotropic_hip_struct
+
+!> (GPU path only) What a device-resident step changed in the control structure: the barotropic time step (set_dtbt) and the
+!! number of barotropic steps of the last call
+subroutine barotropic_hip_update(CS, st)
+  type(barotropic_CS), intent(inout) :: CS
+  type(mom6hip_barotropic_cs_t), intent(in) :: st
+  CS%st%dtbt = st%dtbt ; CS%st%dtbt_max = st%dtbt_max ; CS%st%nstep_last = st%nstep_last
+  CS%dtbt = st%dtbt
+end subroutine barotropic_hip_update
 
 !> BT_cont_type as the library's struct of pointers
 subroutine bt_cont_struct(BT_cont, cbt)

@@ -34,6 +34,7 @@ public continuity_zonal_convergence, continuity_merdional_convergence
 public zonal_flux_thickness, meridional_flux_thickness
 public zonal_BT_mass_flux, meridional_BT_mass_flux
 public set_continuity_loop_bounds
+public continuity_PPM_hip_struct      ! (GPU path only) the control structure as the library's struct, for MOM_dynamics_split_RK2
 
 !> Control structure (the reference's members, :35-71)
 type, public :: continuity_PPM_CS ; private
@@ -65,6 +66,15 @@ function c_struct(CS) result(ccs)
   ccs%use_visc_rem_max = merge(1, 0, CS%use_visc_rem_max) ; ccs%marginal_faces = merge(1, 0, CS%marginal_faces)
   ccs%tol_eta = CS%tol_eta ; ccs%tol_vel = CS%tol_vel ; ccs%CFL_limit_adjust = CS%CFL_limit_adjust
 end function c_struct
+
+!> (GPU path only) The control structure as the library's struct: what the device-resident step of MOM_dynamics_split_RK2 hands to
+!! mom6hip_step_dyn_split_rk2
+function continuity_PPM_hip_struct(CS) result(ccs)
+  type(continuity_PPM_CS), intent(in) :: CS
+  type(mom6hip_continuity_cs_t) :: ccs
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_continuity_PPM: Module must be initialized before it is used.")
+  ccs = c_struct(CS)
+end function continuity_PPM_hip_struct
 
 !> What the GPU path does not do: open boundaries and porous barriers (face fractions other than 1)
 subroutine refuse_unsupported(OBC, pbv, who)

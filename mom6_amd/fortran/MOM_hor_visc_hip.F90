@@ -31,6 +31,7 @@ implicit none ; private
 #include <MOM_memory.h>
 
 public horizontal_viscosity, hor_visc_init, hor_visc_end, hor_visc_vel_stencil
+public hor_visc_hip_struct      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> Control structure: the library's struct and the static arrays hor_visc_init computes (h-point *_xx, q-point *_xy)
 type, public :: hor_visc_CS ; private
@@ -57,6 +58,16 @@ subroutine bind_arrays(CS)
   CS%st%reduction_xy = c_loc(CS%reduction_xy)
   CS%st%reserved1(:) = c_null_ptr
 end subroutine bind_arrays
+
+!> (GPU path only) The library's struct of this control structure (pointers bound to the HOST arrays of CS, which hor_visc_init
+!! has filled)
+function hor_visc_hip_struct(CS) result(st)
+  type(hor_visc_CS), target, intent(inout) :: CS
+  type(mom6hip_hor_visc_cs_t) :: st
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_hor_visc: Module must be initialized before it is used.")
+  call bind_arrays(CS)
+  st = CS%st
+end function hor_visc_hip_struct
 
 !> Same interface as the reference horizontal_viscosity (:245).
 subroutine horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, &

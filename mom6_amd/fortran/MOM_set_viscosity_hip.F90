@@ -32,6 +32,7 @@ implicit none ; private
 public set_viscous_BBL, set_viscous_ML, set_visc_init, set_visc_end
 public set_visc_register_restarts, set_u_at_v, set_v_at_u
 public remap_vertvisc_aux_vars
+public set_visc_hip_struct      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> Control structure: the library's struct and the equation of state read at initialisation
 type, public :: set_visc_CS ; private
@@ -43,6 +44,18 @@ type, public :: set_visc_CS ; private
 end type set_visc_CS
 
 contains
+
+!> (GPU path only) The library's struct of this control structure (Rlay bound to the HOST copy kept by CS) and the equation of state
+subroutine set_visc_hip_struct(CS, GV, st, eos)
+  type(set_visc_CS), target, intent(inout) :: CS
+  type(verticalGrid_type), intent(in) :: GV
+  type(mom6hip_set_visc_cs_t), intent(out) :: st
+  type(mom6hip_eos_t), intent(out) :: eos
+  if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
+  CS%st%Rlay = c_null_ptr ; if (allocated(CS%Rlay)) CS%st%Rlay = c_loc(CS%Rlay)
+  CS%st%nkml = GV%nkml
+  st = CS%st ; eos = CS%eos
+end subroutine set_visc_hip_struct
 
 !> Same interface as the reference set_viscous_BBL (:134).
 subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)

@@ -33,6 +33,7 @@ public vertvisc, vertvisc_remnant, vertvisc_coef
 public vertvisc_limit_vel, vertvisc_init, vertvisc_end
 public updateCFLtruncationValue
 public vertFPmix
+public vertvisc_hip_struct, vertvisc_hip_add_ntrunc      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> The control structure: the library's struct and the arrays vertvisc_coef leaves for vertvisc / vertvisc_remnant
 type, public :: vertvisc_CS ; private
@@ -51,6 +52,23 @@ subroutine bind_arrays(CS)
   CS%st%a_u = c_loc(CS%a_u) ; CS%st%a_v = c_loc(CS%a_v) ; CS%st%h_u = c_loc(CS%h_u) ; CS%st%h_v = c_loc(CS%h_v)
   CS%st%reserved1(:) = c_null_ptr
 end subroutine bind_arrays
+
+!> (GPU path only) The library's struct of this control structure (pointers bound to the HOST arrays of CS)
+function vertvisc_hip_struct(CS) result(st)
+  type(vertvisc_CS), pointer :: CS
+  type(mom6hip_vertvisc_cs_t) :: st
+  if (.not.associated(CS)) call MOM_error(FATAL, "MOM_vert_friction(visc): Module must be initialized before it is used.")
+  call bind_arrays(CS)
+  st = CS%st
+end function vertvisc_hip_struct
+
+!> (GPU path only) Velocity truncations counted by a device-resident step
+subroutine vertvisc_hip_add_ntrunc(CS, n)
+  type(vertvisc_CS), pointer :: CS
+  integer(c_int64_t), intent(in) :: n
+  CS%st%ntrunc = CS%st%ntrunc + n
+  if (associated(CS%ntrunc)) CS%ntrunc = CS%ntrunc + int(n)
+end subroutine vertvisc_hip_add_ntrunc
 
 !> vertvisc_type as the library's struct of pointers (members that are not allocated / associated travel as null)
 subroutine visc_struct(visc, cv)

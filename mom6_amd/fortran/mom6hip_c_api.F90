@@ -273,6 +273,21 @@ interface
     integer(c_int) :: rc
   end function mom6hip_free
 
+  function mom6hip_memset_zero(ctx, dptr, bytes) bind(c, name="mom6hip_memset_zero") result(rc)
+    import :: c_int, c_ptr, c_int64_t
+    type(c_ptr), value :: ctx, dptr
+    integer(c_int64_t), value :: bytes
+    integer(c_int) :: rc
+  end function mom6hip_memset_zero
+
+  function mom6hip_transfer_stats(ctx, stats, reset) bind(c, name="mom6hip_transfer_stats") result(rc)
+    import :: c_int, c_ptr, c_int64_t, c_int32_t
+    type(c_ptr), value :: ctx
+    integer(c_int64_t), intent(out) :: stats(4)
+    integer(c_int32_t), value :: reset
+    integer(c_int) :: rc
+  end function mom6hip_transfer_stats
+
   function mom6hip_sync_to_device(ctx, dptr, hptr, bytes) bind(c, name="mom6hip_sync_to_device") result(rc)
     import :: c_int, c_ptr, c_int64_t
     type(c_ptr), value :: ctx, dptr, hptr

@@ -557,14 +557,16 @@ class DynState:
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
                  bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, rk2b=False, set_visc=None,
-                 pressureforce=None, **bt_kw):
+                 pressureforce=None, continuity=None, coriolis=None, **bt_kw):
         """rk2b: SPLIT_RK2B (MOM_dynamics_split_RK2b.F90); u, v are then the filtered velocities."""
         g = self.grid = grid
         self.rk2b = bool(rk2b)
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
-        self.ccs = continuity_cs(g.nk, g.Angstrom_H)
+        self.ccs = continuity_cs(g.nk, g.Angstrom_H, **(continuity or {}))      # e.g. tol_eta (ETA_TOLERANCE), tol_vel
         self.cor = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES["SADOURNY75_ENERGY"], _abi.KE_SCHEMES["KE_ARAKAWA"], 0, int(bound_coriolis), 0)
         self.cor.F_eff_max_blend, self.cor.wt_lin_blend = 4.0, 0.125
+        for k, v in (coriolis or {}).items():      # members of mom6hip_coriolisadv_cs_t, e.g. coriolis_en_dis
+            setattr(self.cor, k, v)
         self.pcs = pressureforce_cs(g, **(pressureforce or {}))      # e.g. reconstruct=False (RECONSTRUCT_FOR_PRESSURE)
         self.eos = eos(eos_form) if not isinstance(eos_form, _abi.EOS) else eos_form
         self.bt_arrs, self.bt = make_bt_cont(g, with_h=True) if use_bt_cont else ({}, None)

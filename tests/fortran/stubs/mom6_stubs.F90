@@ -349,12 +349,27 @@ type :: MOM_restart_CS
   integer :: nfields = 0
 end type MOM_restart_CS
 interface register_restart_field
-  module procedure register_2d, register_0d
+  module procedure register_3d, register_2d, register_0d
 end interface
 interface query_initialized
-  module procedure query_2d, query_0d
+  module procedure query_3d, query_2d, query_0d
 end interface
 contains
+subroutine register_3d(f_ptr, name, mandatory, CS, longname, units, conversion, hor_grid, z_grid, t_grid)
+  real, dimension(:,:,:), target, intent(in) :: f_ptr
+  character(len=*),     intent(in)    :: name
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  character(len=*), optional, intent(in) :: longname, units, hor_grid, z_grid, t_grid
+  real,             optional, intent(in) :: conversion
+  CS%nfields = CS%nfields + 1
+end subroutine register_3d
+logical function query_3d(f_ptr, name, CS)
+  real, dimension(:,:,:), intent(in) :: f_ptr
+  character(len=*),     intent(in) :: name
+  type(MOM_restart_CS), intent(in) :: CS
+  query_3d = .false.
+end function query_3d
 subroutine register_2d(f_ptr, name, mandatory, CS, longname, units, conversion, hor_grid, z_grid, t_grid)
   real, dimension(:,:), target, intent(in) :: f_ptr
   character(len=*),     intent(in)    :: name
@@ -490,13 +505,29 @@ type :: ocean_OBC_type
 end type ocean_OBC_type
 end module MOM_open_boundary
 
+module MOM_boundary_update
+implicit none ; private
+public :: update_OBC_CS
+type :: update_OBC_CS
+  integer :: unused = 0
+end type update_OBC_CS
+end module MOM_boundary_update
+
 module MOM_wave_interface
 implicit none ; private
 public :: Wave_parameters_CS
 type :: Wave_parameters_CS
   logical :: Stokes_VF = .false.
 end type Wave_parameters_CS
-end module MOM_wave_interface
+end module MOM_boundary_update
+implicit none ; private
+public :: update_OBC_CS
+type :: update_OBC_CS
+  integer :: unused = 0
+end type update_OBC_CS
+end module MOM_boundary_update
+
+module MOM_wave_interface
 
 module MOM_tracer_registry
 implicit none ; private

@@ -326,12 +326,8 @@ def tc_oracle_state(name):
     ccs_kw = dict(tol_eta=c["tol_eta"])
     st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], c["dt"], be=c["be"], eos_form=E, pressureforce=c["pressureforce"],
                       vertvisc=orc.vertvisc_cs(g, **c["vv"]), visc=orc.vertvisc_type(**arrs), hor_visc=orc.hor_visc_cs(g, c["dt"], **c["hv"]),
-                      set_visc=orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True, **c["ml"]) if c["ml"] else None, **c["bt"])
-    st.ccs.tol_eta = c["tol_eta"]
-    if "tol_vel" in c:
-        st.ccs.tol_vel = c["tol_vel"]
-    for k, v in c["cor"].items():
-        setattr(st.cor, k, v)
+                      set_visc=orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True, **c["ml"]) if c["ml"] else None,
+                      continuity={k: c[k] for k in ("tol_eta", "tol_vel") if k in c}, coriolis=c["cor"], **c["bt"])
     return g, d, taux, tauy, arrs, st
 
 
