@@ -766,7 +766,7 @@ typedef struct mom6hip_set_visc_cs {
   double bulk_Ri_ML;       /* BULK_RI_ML_VISC (= BULK_RI_ML, 0) */
   double c_Smag;           /* SMAG_CONST_CHANNEL (SMAG_LAP_CONST or 0.15): CHANNEL_DRAG */
   double Chan_drag_max_vol;/* CHANNEL_DRAG_MAX_BBL_THICK [Z] (-1: no fixed limit) */
-  double reserved0[1];
+  double Z_ref;            /* G%Z_ref [Z] (0): the bottom depths at velocity points of CHANNEL_DRAG (:365-370) */
   int32_t bottomdraglaw;   /* BOTTOMDRAGLAW (1): without it set_viscous_BBL returns at once (:321) */
   int32_t linear_drag;     /* LINEAR_DRAG (0) */
   int32_t BBL_use_EOS;     /* BBL_USE_EOS (= USE_EOS) */
@@ -774,12 +774,13 @@ typedef struct mom6hip_set_visc_cs {
   int32_t body_force_drag; /* DRAG_AS_BODY_FORCE (0): needs visc%Ray_u / %Ray_v */
   int32_t RiNo_mix;        /* kappa_shear_is_used (0) */
   int32_t initialized;
-  int32_t unsupported[9];  /* Channel_drag (until provided), BBL_use_tidal_bg, (free), (free), non_Boussinesq, p_surf, OBC, pbv,
+  int32_t unsupported[9];  /* (free), BBL_use_tidal_bg, (free), (free), non_Boussinesq, p_surf, OBC, pbv,
                               ice_shelf: any nonzero is refused */
   const double *Rlay;      /* GV%Rlay(1:nk) [R] (HOST array), read when BBL_use_EOS = 0 (and by set_viscous_ML without an EOS) */
   int32_t dynamic_viscous_ML;       /* DYNAMIC_VISCOUS_ML (0): set_viscous_ML finds the viscous mixed layer (:2111-2230, :2400-2506) */
   int32_t nkml;                     /* GV%nkml (0; 2 with the bulk mixed layer): the layers that are always in the mixed layer */
-  int32_t Channel_drag;             /* CHANNEL_DRAG (0) */
+  int32_t Channel_drag;             /* CHANNEL_DRAG (0): Rayleigh drag on the layers that touch the sloping bottom, visc%Ray_u / %Ray_v,
+                                       and the fraction of the bottom drag left to the viscous boundary layer (:863-1002) */
   int32_t concave_trigonometric_L;  /* TRIG_CHANNEL_DRAG_WIDTHS (1) */
   void *reserved1[1];
 } mom6hip_set_visc_cs_t;
@@ -878,13 +879,19 @@ typedef struct mom6hip_hor_visc_cs {
   int32_t use_land_mask;   /* USE_LAND_MASK_FOR_HVISC (1) */
   int32_t use_cont_thick;  /* USE_CONT_THICKNESS (0) */
   int32_t initialized;     /* set by mom6hip_hor_visc_init */
-  int32_t unsupported[10]; /* Leith_Kh, Leith_Ah, use_Leithy, use_MEKE, use_GME, anisotropic, Re_Ah, Kh_sin_lat, use_Kh_bg_2d,
-                              use_ZB2020: any nonzero is refused */
+  int32_t unsupported[10]; /* Leith_Kh, Leith_Ah, use_Leithy, MEKE backscatter / RES_SCALE_MEKE_VISC, use_GME, anisotropic, Re_Ah,
+                              Kh_sin_lat, use_Kh_bg_2d, use_ZB2020: any nonzero is refused */
   /* h points */
   double *Kh_bg_xx, *Kh_Max_xx, *Ah_bg_xx, *Ah_Max_xx, *Laplac2_const_xx, *Biharm_const_xx, *Biharm_const2_xx, *reduction_xx;
   /* q points */
   double *Kh_bg_xy, *Kh_Max_xy, *Ah_bg_xy, *Ah_Max_xy, *Laplac2_const_xy, *Biharm_const_xy, *Biharm_const2_xy, *reduction_xy;
-  void *reserved1[4];
+  /* The MEKE argument of horizontal_viscosity (MOM_MEKE_types.F90), 2-D h-point arrays in the memory space of the call, NULL = not
+   * allocated: MEKE%Ku is added to the Laplacian viscosity (:1141-1151 at h points, :1537-1541 at q points: it needs valid halos) and
+   * MEKE%Au to the biharmonic one (:1318-1323, :1634-1639); MEKE%mom_src receives the vertical sum of the frictional work
+   * (:1783-1800, :1833-1889 with MEKE%backscatter_Ro_c = 0), layers summed in order. */
+  const double *MEKE_Ku, *MEKE_Au;
+  double *MEKE_mom_src;
+  void *reserved1[1];
 } mom6hip_hor_visc_cs_t;
 
 /* The computational part of hor_visc_init (:2440-2760): the static arrays of the control structure from the grid metrics
@@ -893,7 +900,7 @@ int mom6hip_hor_visc_init(mom6hip_ctx_t *ctx, mom6hip_hor_visc_cs_t *cs, double 
 
 /* horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, CS, tv, dt, OBC, BT, TD, ADp, hu_cont, hv_cont,
  *                      STOCH)                                     src/parameterizations/lateral/MOM_hor_visc.F90:245
- * MEKE, VarMix, OBC, BT, TD, ADp, STOCH belong to branches that are not provided.  hu_cont / hv_cont may be NULL (they
+ * MEKE: the members of the control structure above; VarMix, OBC, BT, TD, ADp, STOCH belong to branches that are not provided.  hu_cont / hv_cont may be NULL (they
  * are read only with USE_CONT_THICKNESS).  diffu is written for I = IscB..IecB, j = jsc..jec, diffv for i = isc..iec,
  * J = JscB..JecB; u, v need valid halos of width 2, h of width 2 (hor_visc_vel_stencil :2879). */
 int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,

@@ -127,14 +127,14 @@ class BarotropicCS(C.Structure):
 
 
 # ---- MOM_set_viscosity ------------------------------------------------------------------------------------
-SET_VISC_UNSUPPORTED = ("Channel_drag", "BBL_use_tidal_bg", "(free)", "(free 2)", "non_Boussinesq", "p_surf", "OBC", "pbv", "ice_shelf")
+SET_VISC_UNSUPPORTED = ("(free 0)", "BBL_use_tidal_bg", "(free)", "(free 2)", "non_Boussinesq", "p_surf", "OBC", "pbv", "ice_shelf")
 
 
 class SetViscCS(C.Structure):
     """mom6hip_set_visc_cs_t (include/mom6hip.h)."""
     _fields_ = ([(n, C.c_double) for n in ("cdrag", "drag_bg_vel", "Hbbl", "dz_bbl", "BBL_thick_min", "Kv_BBL_min", "BBL_thick_max", "H_to_RZ")]
                 + [(n, C.c_double) for n in ("omega", "omega_frac", "ustar_min", "TKE_decay", "bulk_Ri_ML", "c_Smag", "Chan_drag_max_vol")]
-                + [("reserved0", C.c_double * 1)]
+                + [("Z_ref", C.c_double)]
                 + [(n, C.c_int32) for n in ("bottomdraglaw", "linear_drag", "BBL_use_EOS", "correct_BBL_bounds", "body_force_drag", "RiNo_mix",
                                            "initialized")]
                 + [("unsupported", C.c_int32 * 9)]
@@ -144,7 +144,7 @@ class SetViscCS(C.Structure):
 
 
 # ---- MOM_hor_visc -----------------------------------------------------------------------------------------
-HOR_VISC_UNSUPPORTED = ("Leith_Kh", "Leith_Ah", "use_Leithy", "use_MEKE", "use_GME", "anisotropic", "Re_Ah", "Kh_sin_lat", "use_Kh_bg_2d",
+HOR_VISC_UNSUPPORTED = ("Leith_Kh", "Leith_Ah", "use_Leithy", "MEKE_backscatter", "use_GME", "anisotropic", "Re_Ah", "Kh_sin_lat", "use_Kh_bg_2d",
                         "use_ZB2020")
 HOR_VISC_ARRAYS_H = ("Kh_bg_xx", "Kh_Max_xx", "Ah_bg_xx", "Ah_Max_xx", "Laplac2_const_xx", "Biharm_const_xx", "Biharm_const2_xx", "reduction_xx")
 HOR_VISC_ARRAYS_Q = ("Kh_bg_xy", "Kh_Max_xy", "Ah_bg_xy", "Ah_Max_xy", "Laplac2_const_xy", "Biharm_const_xy", "Biharm_const2_xy", "reduction_xy")
@@ -174,7 +174,8 @@ class HorViscCS(C.Structure):
                                            "use_cont_thick", "initialized")]
                 + [("unsupported", C.c_int32 * 10)]
                 + [(n, C.c_void_p) for n in HOR_VISC_ARRAYS_H + HOR_VISC_ARRAYS_Q]
-                + [("reserved1", C.c_void_p * 4)])
+                + [(n, C.c_void_p) for n in ("MEKE_Ku", "MEKE_Au", "MEKE_mom_src")]
+                + [("reserved1", C.c_void_p * 1)])
 
 
 # ---- MOM_dynamics_split_RK2 -----------------------------------------------------------------------------

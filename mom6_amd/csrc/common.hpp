@@ -104,6 +104,7 @@ struct mom6hip_ctx {
   int rk2_scratch_layout = 0;   // which stepper laid the block out last (1: RK2, 2: RK2B); a change of layout zeroes it again
   m6::DevBuf hv_pack;           // the grid metrics of horizontal_viscosity gathered into planes of one shape (hor_visc.hip)
   bool hv_pack_ready = false;
+  m6::DevBuf hv_str;            // the layer-integrated stresses of every layer, kept for MEKE%mom_src (hor_visc.hip)
   m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
   m6::HostTable tables[m6::TABLE_COUNT];      // cached device copies of short host tables (m6::HostTable)
   uint64_t xfer[4] = {0, 0, 0, 0};            // calls and bytes of mom6hip_sync_to_device, then of mom6hip_sync_to_host / stage_to_host

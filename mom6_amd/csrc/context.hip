@@ -384,7 +384,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   ctx->rk2_scratch.release();
   ctx->sv_rlay.release();
   for (auto &t : ctx->tables) t.buf.release();
-  ctx->hv_pack.release();
+  ctx->hv_pack.release(); ctx->hv_str.release();
   ctx->ale_sub.release();
   ctx->vv_ntrunc.release();
   ctx->efp_acc.release();

@@ -1,6 +1,7 @@
 // cr_math.hpp -- correctly rounded transcendentals for the few places where the reference calls libm on the hot path
 // (bt_rem = av_rem ** Instep, MOM_barotropic.F90:1529; exp(-htot*Idecay_len_TKE), MOM_set_viscosity.F90:2178).  The
-// reference gets the pow / exp of its build's libm (documented < 1 ulp, not correctly rounded); here they are evaluated in
+// cos and acos: find_L_open_concave_trigonometric, MOM_set_viscosity.F90:1213-1225 (CHANNEL_DRAG).  The
+// reference gets the pow / exp / cos / acos of its build's libm (documented < 1 ulp, not correctly rounded); here they are evaluated in
 // double-double arithmetic from + - * / fma only and rounded once, so that the test suite's CPU checker -- which repeats this
 // operation order -- agrees bit for bit.
 #pragma once
@@ -92,6 +93,69 @@ __device__ inline double cr_exp(double t0) {
   }
   dd_t res = dd_add_d(sum, 1.0);
   return ldexp(res.hi, (int)kd);
+}
+
+// ---- cos and acos (the test suite's CPU checker repeats this operation order) -----------------------------------------------
+__device__ __forceinline__ dd_t dd_neg(dd_t a) { return {-a.hi, -a.lo}; }
+// a / d for a double d
+__device__ __forceinline__ dd_t dd_div_d(dd_t a, double d) {
+  double q1 = a.hi / d;
+  dd_t p = dd_2prod(q1, d);
+  dd_t r = dd_add(a, dd_neg(p));
+  double q2 = r.hi / d;
+  return dd_fast2sum(q1, q2);
+}
+// sin and cos of r, |r| <= 0.8, by their Taylor series in Horner form: 16 terms each
+__device__ inline void dd_sincos_small(dd_t r, dd_t &s, dd_t &c) {
+  const dd_t r2 = dd_mul(r, r);
+  dd_t ts = {1.0, 0.0}, tc = {1.0, 0.0};
+  for (int n = 15; n >= 1; n--) {
+    ts = dd_add_d(dd_neg(dd_div_d(dd_mul(ts, r2), (double)((2 * n) * (2 * n + 1)))), 1.0);
+    tc = dd_add_d(dd_neg(dd_div_d(dd_mul(tc, r2), (double)((2 * n - 1) * (2 * n)))), 1.0);
+  }
+  s = dd_mul(r, ts);
+  c = tc;
+}
+// sin and cos of y, 0 <= y <= pi
+__device__ inline void dd_sincos_0_pi(dd_t y, dd_t &s, dd_t &c) {
+  const dd_t PI = {3.141592653589793116, 1.2246467991473532072e-16}, PI_2 = {1.570796326794896558, 6.1232339957367660359e-17};
+  dd_t rs, rc;
+  if (y.hi <= 0.78539816339744830962) {
+    dd_sincos_small(y, s, c);
+  } else if (y.hi <= 2.3561944901923449288) {
+    dd_sincos_small(dd_add(y, dd_neg(PI_2)), rs, rc);
+    s = rc; c = dd_neg(rs);
+  } else {
+    dd_sincos_small(dd_add(y, dd_neg(PI)), rs, rc);
+    s = dd_neg(rs); c = dd_neg(rc);
+  }
+}
+// cos(x), |x| <= pi (NaN outside), correctly rounded
+__device__ inline double cr_cos(double x) {
+  if (!(fabs(x) <= 3.1415926535897936)) return __builtin_nan("");
+  dd_t y = {fabs(x), 0.0}, s, c;
+  dd_sincos_0_pi(y, s, c);
+  return c.hi;
+}
+// acos(x), |x| <= 1 (NaN outside), correctly rounded: a polynomial first guess (Abramowitz & Stegun 4.4.46), three Newton steps on
+// cos(y) = x in double-double arithmetic
+__device__ inline double cr_acos(double x) {
+  if (!(fabs(x) <= 1.0)) return __builtin_nan("");
+  if (x == 1.0) return 0.0;
+  if (x == -1.0) return 3.141592653589793116;
+  const double a = fabs(x);
+  double p = -0.0012624911;
+  p = p * a + 0.0066700901; p = p * a + -0.0170881256; p = p * a + 0.0308918810; p = p * a + -0.0501743046;
+  p = p * a + 0.0889789874; p = p * a + -0.2145988016; p = p * a + 1.5707963050;
+  double y0 = sqrt(1.0 - a) * p;
+  if (x < 0.0) y0 = 3.141592653589793116 - y0;
+  dd_t y = {y0, 0.0};
+  for (int it = 0; it < 3; it++) {
+    dd_t s, c;
+    dd_sincos_0_pi(y, s, c);
+    y = dd_add(y, dd_div(dd_add_d(c, -x), s));
+  }
+  return y.hi;
 }
 
 }  // namespace cr

@@ -310,6 +310,10 @@ struct HVFArgs {
   double h_neglect;
   const double *u, *v, *h, *hu_cont, *hv_cont;
   double *diffu, *diffv;
+  // MEKE (generic configuration only): MEKE%Ku, MEKE%Au (h points, may be null); the layer-integrated stresses of every layer for the
+  // frictional work (hv_frictwork_kernel), h- and q-shaped 3-D arrays, null unless MEKE%mom_src is wanted
+  const double *Ku, *Au;
+  double *str_xx_out, *str_xy_out;
 };
 
 
@@ -441,6 +445,7 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
         }
         if (legacy_bound) K_ = min2(K_, AH(A.s.Kh_Max_xx, 0, 0));
         K_ = max2(K_, o.Kh_bg_min);
+        if (CFG == HV_GENERIC && A.Ku) K_ = K_ + AH(A.Ku, 0, 0);      // :1141-1151
         if (o.better_bound_Kh) {
           const double KhM = AH(A.s.Kh_Max_xx, 0, 0);
           if (K_ >= hrat_min * KhM) {
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
           A_ = max2(A_, AhSm);
           if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, AH(A.s.Ah_Max_xx, 0, 0));
         }
+        if (CFG == HV_GENERIC && A.Au) A_ = A_ + AH(A.Au, 0, 0);      // :1318-1323
         if (o.better_bound_Ah) {
           if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * AH(A.s.Ah_Max_xx, 0, 0));
           else A_ = min2(A_, hrat_min * AH(A.s.Ah_Max_xx, 0, 0));
@@ -516,6 +522,8 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
         }
         if (legacy_bound) K_ = min2(K_, AQ(A.s.Kh_Max_xy, 0, 0));
         K_ = max2(K_, o.Kh_bg_min);
+        if (CFG == HV_GENERIC && A.Ku)      // :1537-1541 (meke_res_fn = 1)
+          K_ = K_ + 0.25 * ((AH(A.Ku, 0, 0) + AH(A.Ku, 1, 1)) + (AH(A.Ku, 1, 0) + AH(A.Ku, 0, 1))) * 1.0;
         if (o.better_bound_Kh) {
           const double KhM = AQ(A.s.Kh_Max_xy, 0, 0);
           if (K_ >= hrat_min * KhM) {
@@ -536,6 +544,8 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
           A_ = max2(A_, AhSm);
           if (o.bound_Ah && !o.better_bound_Ah) A_ = min2(A_, AQ(A.s.Ah_Max_xy, 0, 0));
         }
+        if (CFG == HV_GENERIC && A.Au)      // :1634-1639
+          A_ = A_ + 0.25 * ((AH(A.Au, 0, 0) + AH(A.Au, 1, 1)) + (AH(A.Au, 1, 0) + AH(A.Au, 0, 1)));
         if (o.better_bound_Ah) {
           if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * AQ(A.s.Ah_Max_xy, 0, 0));
           else A_ = min2(A_, hrat_min * AQ(A.s.Ah_Max_xy, 0, 0));
@@ -558,6 +568,13 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
 
   // ---- diffu, diffv :1744-1770: the tile's own points (the western / southern edge points belong to the first tiles) ----
   const int Iw = (i0 == A.isc) ? is - 1 : is, Js = (j0 == A.jsc) ? js - 1 : js;
+  if (CFG == HV_GENERIC && A.str_xx_out) {      // the stresses of this layer, for MEKE%mom_src
+    char *sxx_k = (char *)(A.str_xx_out + kH), *sxy_k = (char *)(A.str_xy_out + (size_t)(A.nih + 1) * (A.njh + 1) * k);
+    FOR_POINTS {
+      if (j >= js && j <= je && i >= is && i <= ie) *(double *)(sxx_k + bh) = LX(s_xx, 0, 0);
+      if (J >= Js && J <= je && I >= Iw && I <= ie) *(double *)(sxy_k + bq) = LX(s_xy, 0, 0);
+    } END_POINTS
+  }
   FOR_POINTS {
     if (j >= js && j <= je && I >= Iw && I <= ie)
       *(double *)(du_k + bu) = ((G(P_IDYCU, 0, 0) * (G(P_DY2H, 0, 0) * LX(s_xx, 0, 0) - G(P_DY2H, 1, 0) * LX(s_xx, 1, 0)) +
@@ -580,8 +597,45 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
 #undef END_POINTS
 }
 
+// MEKE%mom_src (:1783-1800, :1833-1889 with MEKE%backscatter_Ro_c = 0): the frictional work of each layer from its layer-integrated
+// stresses, summed over the layers in order.  One lane per column.
+__global__ __launch_bounds__(256) void hv_frictwork_kernel(m6::GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                           const double *__restrict__ sxx, const double *__restrict__ sxy,
+                                                           double *__restrict__ mom_src) {
+  const int i = g.isc + blockIdx.x * 256 + threadIdx.x, j = g.jsc + blockIdx.y;
+  if (i > g.iec) return;
+  const int I = i, J = j;
+  const long hpl = (long)g.nih * g.njh, upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1), qpl = (long)(g.nih + 1) * (g.njh + 1);
+  const double H_to_RZ = g.H_to_Z * g.Rho0;
+  const double IdxT = g.IdxT[g.h2(i, j)], IdyT = g.IdyT[g.h2(i, j)];
+  const double IdyB00 = g.IdyBu[g.q2(I, J)], IdxB00 = g.IdxBu[g.q2(I, J)], IdyBmm = g.IdyBu[g.q2(I - 1, J - 1)], IdxBmm = g.IdxBu[g.q2(I - 1, J - 1)];
+  const double IdyBm0 = g.IdyBu[g.q2(I - 1, J)], IdxBm0 = g.IdxBu[g.q2(I - 1, J)], IdyB0m = g.IdyBu[g.q2(I, J - 1)], IdxB0m = g.IdxBu[g.q2(I, J - 1)];
+  double src = 0.;
+  for (int k = 0; k < g.nk; k++) {
+    const double *uk = u + upl * k, *vk = v + vpl * k, *xy = sxy + qpl * k;
+    const double str_xx = sxx[g.h2(i, j) + hpl * k];
+    const double FrictWork = H_to_RZ * (
+            (str_xx * (uk[g.u2(I, j)] - uk[g.u2(I - 1, j)]) * IdxT
+           - str_xx * (vk[g.v2(i, J)] - vk[g.v2(i, J - 1)]) * IdyT)
+        + 0.25 * ((xy[g.q2(I, J)] *
+                   ((uk[g.u2(I, j + 1)] - uk[g.u2(I, j)]) * IdyB00
+                  + (vk[g.v2(i + 1, J)] - vk[g.v2(i, J)]) * IdxB00)
+                 + xy[g.q2(I - 1, J - 1)] *
+                   ((uk[g.u2(I - 1, j)] - uk[g.u2(I - 1, j - 1)]) * IdyBmm
+                  + (vk[g.v2(i, J - 1)] - vk[g.v2(i - 1, J - 1)]) * IdxBmm))
+                + (xy[g.q2(I - 1, J)] *
+                   ((uk[g.u2(I - 1, j + 1)] - uk[g.u2(I - 1, j)]) * IdyBm0
+                  + (vk[g.v2(i, J)] - vk[g.v2(i - 1, J)]) * IdxBm0)
+                 + xy[g.q2(I, J - 1)] *
+                   ((uk[g.u2(I, j)] - uk[g.u2(I, j - 1)]) * IdyB0m
+                  + (vk[g.v2(i + 1, J - 1)] - vk[g.v2(i, J - 1)]) * IdxB0m))));
+    src = src + FrictWork;
+  }
+  mom_src[g.h2(i, j)] = src;
+}
+
 int check_cs(const mom6hip_hor_visc_cs_t *cs, const char *who) {
-  static const char *names[10] = {"LEITH_KH", "LEITH_AH", "USE_LEITHY", "USE_MEKE", "USE_GME", "ANISOTROPIC_VISCOSITY", "RE_AH", "KH_SIN_LAT",
+  static const char *names[10] = {"LEITH_KH", "LEITH_AH", "USE_LEITHY", "MEKE backscatter (MEKE_BACKSCAT_RO_C) / RES_SCALE_MEKE_VISC", "USE_GME", "ANISOTROPIC_VISCOSITY", "RE_AH", "KH_SIN_LAT",
                                   "USE_KH_BG_2D", "USE_ZB2020"};
   for (int n = 0; n < 10; n++) M6_REQUIRE(!cs->unsupported[n], "%s: %s is not provided by libmom6hip", who, names[n]);
   M6_REQUIRE(!(cs->no_slip && cs->biharmonic), "ERROR: NOSLIP and BIHARMONIC cannot be defined at the same time in MOM.");
@@ -667,6 +721,14 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
   A.isc = g.isc; A.iec = g.iec; A.jsc = g.jsc; A.jec = g.jec; A.isd = g.isd; A.jsd = g.jsd; A.nih = g.nih; A.njh = g.njh; A.nk = g.nk;
   A.h_neglect = g.H_subroundoff;
   A.u = u; A.v = v; A.h = h; A.hu_cont = hu_cont; A.hv_cont = hv_cont; A.diffu = diffu; A.diffv = diffv;
+  A.Ku = cs->Laplacian ? cs->MEKE_Ku : nullptr; A.Au = cs->biharmonic ? cs->MEKE_Au : nullptr;
+  A.str_xx_out = nullptr; A.str_xy_out = nullptr;
+  const bool meke = A.Ku || A.Au || cs->MEKE_mom_src;
+  if (cs->MEKE_mom_src) {
+    const size_t nH3 = (size_t)g.nih * g.njh * g.nk, nQ3 = (size_t)(g.nih + 1) * (g.njh + 1) * g.nk;
+    M6_REQUIRE(ctx->hv_str.reserve(sizeof(double) * (nH3 + nQ3)) == 0, "horizontal_viscosity: out of device memory for MEKE%%mom_src");
+    A.str_xx_out = (double *)ctx->hv_str.p; A.str_xy_out = A.str_xx_out + nH3;
+  }
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
   auto launch = [&](auto kern, int TI, int TJ, int NT) {
     const int ntx = (ni + TI - 1) / TI, nty = (nj + TJ - 1) / TJ, ntiles = ntx * nty;
@@ -678,9 +740,12 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
   // (tiles of 64x8, 64x12, 32x16, 128x8 points and blocks of 256 / 1024 threads all ran within 5% of this one: the kernel is
   // bound by the L2 -> L1 traffic of the metric planes, which every block reads for its tile -- profiles/r02_hor_visc.txt)
   int rc;
-  if (A.flags.bits == HV_BIH_SMAG) rc = launch(hv_fused_kernel<HV_BIH_SMAG, 64, 16, 512, 4>, 64, 16, 512);
+  if (A.flags.bits == HV_BIH_SMAG && !meke) rc = launch(hv_fused_kernel<HV_BIH_SMAG, 64, 16, 512, 4>, 64, 16, 512);
   else rc = launch(hv_fused_kernel<HV_GENERIC, 64, 16, 512, 4>, 64, 16, 512);
   M6_REQUIRE(rc == 0, "horizontal_viscosity: the grid is too large for one launch");
+  if (cs->MEKE_mom_src)
+    hipLaunchKernelGGL(hv_frictwork_kernel, dim3((ni + 255) / 256, nj), dim3(256), 0, ctx->stream, g, u, v, A.str_xx_out, A.str_xy_out,
+                       cs->MEKE_mom_src);
   M6_HIP(hipGetLastError());
   return 0;
 }
@@ -707,6 +772,8 @@ extern "C" int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_ho
   const double *du = st.in(u, bU), *dv = st.in(v, bV), *dh = st.in(h, bH);
   const double *dhu = st.in(hu_cont, bU), *dhv = st.in(hv_cont, bV);
   double *ddu = st.inout(diffu, bU), *ddv = st.inout(diffv, bV);      // (only the compute ranges are written)
+  dcs.MEKE_Ku = st.in(cs->MEKE_Ku, bH2); dcs.MEKE_Au = st.in(cs->MEKE_Au, bH2);
+  dcs.MEKE_mom_src = cs->MEKE_mom_src ? st.inout(cs->MEKE_mom_src, bH2) : nullptr;
   M6_REQUIRE(!st.failed(), "horizontal_viscosity: staging failed");
   if (m6::horizontal_viscosity_dev(ctx, &dcs, du, dv, dh, ddu, ddv, dhu, dhv)) return 1;
   return st.finish();

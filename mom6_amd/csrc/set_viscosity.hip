@@ -24,7 +24,8 @@ struct BBLArgs {
   m6::GridDev g;
   EosDev E;
   double cdrag, drag_bg_vel, Hbbl, dz_bbl, BBL_thick_min, Kv_BBL_min, BBL_thick_max, H_to_RZ;
-  int linear_drag, use_BBL_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix;
+  double c_Smag, Chan_drag_max_vol, Z_ref;
+  int linear_drag, use_BBL_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix, Channel_drag, concave_trig;
   const double *u, *v, *h, *T, *S, *Rlay;      // Rlay: device copy of GV%Rlay
   double *bbl_thick, *Kv_bbl, *Ray;            // of this direction
 };
@@ -67,6 +68,255 @@ __device__ __forceinline__ double transverse_vel(const BBLArgs &A, int i, int j,
     return r;
   }
 }
+
+
+// ---- CHANNEL_DRAG: the normalized open width L(K) of a velocity cell at the interfaces, bottom up (find_L_open_uniform_slope
+// :1104, find_L_open_concave_trigonometric :1144, find_L_open_concave_iterative :1237, find_L_open_convex :1640 with
+// SET_VISC_ANSWER_DATE >= 20190101).  L(K) depends on the volume below the interface, on L(K+1) and, for convex bottoms, on the
+// volume error carried up from the interface below: the sweep keeps these three scalars instead of the reference's arrays.
+struct ChanGeom {
+  static constexpr double C1_3 = 1.0 / 3.0, C1_6 = 1.0 / 6.0, C1_12 = 1.0 / 12.0, C2pi_3 = 8.0 * 0.78539816339744830962 / 3.0;
+  int kind;      // 0 uniform slope, 1 concave (trigonometric), 2 concave (iterative), 3 convex
+  double D_vel, Dp, Dm, slope, crv, crv_3;
+  // uniform
+  double Vol_open, I_slope;
+  // concave
+  double Vol_2_reg, C24_crv, Iapb, apb_4a, a2x48_apb3, ax2_3apb;
+  double L_2_reg, L_inflect_1, vol_inflect_1, vol_inflect_2, slope_crv, smc, C3c_m_s, I_3c_m_s, C4_crv, slope2_4crv, sxcms_c, C3s_m_c, I_3s_m_c,
+      Icrvpslope;
+  // convex
+  double Vol_direct, L_direct, Ibma_2, Vol_err, Angstrom_Z, dZ_subroundoff;
+
+  __device__ void init(double D_vel_, double Dp_, double Dm_, double BBL_thick_min, int concave_trig, double Angstrom_Z_, double dZ_sub) {
+    D_vel = D_vel_; Dp = Dp_; Dm = Dm_;
+    crv = 3.0 * (Dp + Dm - 2.0 * D_vel);
+    slope = Dp - Dm;
+    if (fabs(crv) < 1e-2 * (slope + BBL_thick_min)) crv = 0.0;
+    Vol_err = 0.0; Angstrom_Z = Angstrom_Z_; dZ_subroundoff = dZ_sub;
+    I_3c_m_s = 0.0; I_3s_m_c = 0.0; slope_crv = 0.0; vol_inflect_2 = 0.0; C4_crv = 0.0; slope2_4crv = 0.0; sxcms_c = 0.0; C3s_m_c = 0.0;
+    smc = 0.0; C3c_m_s = 0.0;
+    if (crv == 0.0) {
+      kind = 0;
+      slope = fabs(Dp - Dm);
+      Vol_open = 0.5 * slope; I_slope = (slope == 0.0) ? 0.0 : 1.0 / slope;
+    } else if (crv > 0.0 && concave_trig) {
+      kind = 1;
+      crv_3 = (Dp + Dm - (2.0 * D_vel)); crv = 3.0 * crv_3;
+      if (slope >= crv) {
+        Vol_open = D_vel - Dm; Vol_2_reg = Vol_open;
+      } else {
+        slope_crv = slope / crv;
+        Vol_open = 0.25 * slope * slope_crv + C1_12 * crv;
+        Vol_2_reg = 0.5 * (slope_crv * slope_crv) * (crv - C1_3 * slope);
+      }
+      C24_crv = 24.0 / crv; Iapb = 1.0 / (crv + slope);
+      apb_4a = (slope + crv) / (4.0 * crv); a2x48_apb3 = (48.0 * (crv * crv)) * ((Iapb * Iapb) * Iapb);
+      ax2_3apb = 2.0 * C1_3 * crv * Iapb;
+    } else if (crv > 0.0) {
+      kind = 2;
+      crv_3 = (Dp + Dm - 2.0 * D_vel); crv = 3.0 * crv_3;
+      if (slope >= crv) {
+        Vol_open = D_vel - Dm; Vol_2_reg = Vol_open;
+        L_2_reg = 1.0;
+        if (crv + slope >= 4.0 * crv) {
+          L_inflect_1 = 1.0; vol_inflect_1 = Vol_open;
+        } else {
+          slope_crv = slope / crv;
+          L_inflect_1 = 0.25 + 0.25 * slope_crv;
+          vol_inflect_1 = 0.25 * C1_12 * (((slope_crv + 1.0) * (slope_crv + 1.0)) * (slope + crv));
+        }
+        smc = slope - crv;
+        C3c_m_s = 3.0 * crv - slope;
+        if (C3c_m_s > 2.0 * smc) I_3c_m_s = 1.0 / C3c_m_s;
+      } else {
+        slope_crv = slope / crv;
+        Vol_open = 0.25 * slope * slope_crv + C1_12 * crv;
+        Vol_2_reg = 0.5 * (slope_crv * slope_crv) * (crv - C1_3 * slope);
+        L_2_reg = slope_crv;
+        vol_inflect_1 = 0.25 * C1_12 * (((slope_crv + 1.0) * (slope_crv + 1.0)) * (slope + crv));
+        L_inflect_1 = 0.25 + 0.25 * slope_crv;
+        vol_inflect_2 = 0.25 * slope * slope_crv + 0.125 * crv_3;
+        C4_crv = 4.0 / crv;
+        slope2_4crv = 0.25 * slope * slope_crv;
+        sxcms_c = slope_crv * (crv - slope);
+        C3s_m_c = 3.0 * slope - crv;
+        if (C3s_m_c > 2.0 * sxcms_c) I_3s_m_c = 1.0 / C3s_m_c;
+      }
+      Icrvpslope = 1.0 / (crv + slope);
+    } else {
+      kind = 3;
+      crv_3 = (Dp + Dm - 2.0 * D_vel); crv = 3.0 * crv_3;
+      Vol_open = D_vel - Dm;
+      if (slope >= -crv) {
+        Vol_direct = 0.0; L_direct = 0.0; C24_crv = 0.0;
+      } else {
+        C24_crv = 24.0 / crv;
+        L_direct = 1.0 + slope / crv;
+        Vol_direct = -C1_6 * crv * ((L_direct * L_direct) * L_direct);
+      }
+      Ibma_2 = 2.0 / (slope - crv);
+    }
+  }
+
+  // L(K) from vol_below(K), vol_below(K+1) and L(K+1)
+  __device__ double next_L(double volK, double volKp1, double LKp1) {
+    if (kind == 0) {
+      if (slope == 0.0) return 1.0;
+      if (volK >= Vol_open) return 1.0;
+      return sqrt(2.0 * volK * I_slope);
+    }
+    if (kind == 1) {
+      if (volK >= Vol_open) return 1.0;
+      if (volK < Vol_2_reg) {
+        if (a2x48_apb3 * volK < 1e-8) {
+          const double L0 = sqrt(2.0 * volK * Iapb);
+          return L0 * (1.0 + (ax2_3apb * L0));
+        }
+        return apb_4a * (1.0 - 2.0 * m6::cr::cr_cos(C1_3 * m6::cr::cr_acos((a2x48_apb3 * volK) - 1.0) - C2pi_3));
+      }
+      double t = 1.0 - C24_crv * (Vol_open - volK);
+      t = max2(-1., min2(1., t));
+      return 0.5 - m6::cr::cr_cos(C1_3 * m6::cr::cr_acos(t) - C2pi_3);
+    }
+    if (kind == 2) {
+      const int max_itt = 10;
+      double L, L_max, L_min, vol_err, dVol_dL, vol_err_max;
+      auto VERR1 = [&](double Lk) { return 0.5 * (Lk * Lk) * (slope + crv * (1.0 - 4.0 * C1_3 * Lk)) - volK; };
+      auto VERR2 = [&](double Lk) { return crv_3 * ((Lk * Lk) * (0.75 - 0.5 * Lk)) + (slope2_4crv - volK); };
+      if (volK >= Vol_open) return 1.0;
+      if (volK < Vol_2_reg) {
+        L_max = min2(L_2_reg, 1.0);
+        if (volK <= vol_inflect_1) L_max = min2(L_max, L_inflect_1);
+        L_min = LKp1;
+        if (volK >= vol_inflect_1) L_min = max2(L_min, L_inflect_1);
+        if (2.0 * volK * Icrvpslope > L_min * L_min) L_min = sqrt(2.0 * volK * Icrvpslope);
+        L = L_min;
+        if (volK <= vol_inflect_1) {
+          vol_err = VERR1(L);
+          if (vol_err < 0.0) {
+            dVol_dL = L * (slope + crv * (1.0 - 2.0 * L));
+            if (L * dVol_dL > vol_err + L_max * dVol_dL) L = L_max;
+            else L = L - (vol_err / dVol_dL);
+            for (int itt = 1; itt <= max_itt; itt++) {
+              vol_err = VERR1(L);
+              dVol_dL = L * (slope + crv * (1.0 - 2.0 * L));
+              if (fabs(vol_err) < max2(1.0e-15 * L, 1.0e-25) * dVol_dL) break;
+              L = L - (vol_err / dVol_dL);
+            }
+          }
+        } else {
+          vol_err = VERR1(L);
+          if (vol_err < 0.0) {
+            if (slope < crv) {
+              if ((L_2_reg - L_min) * C3s_m_c > 2.0 * sxcms_c)
+                L_max = (slope_crv * (2.0 * slope) - sqrt(sxcms_c * sxcms_c + 2.0 * C3s_m_c * (Vol_2_reg - volK))) * I_3s_m_c;
+              else
+                L_max = slope_crv;
+            } else {
+              if ((1.0 - L_min) * C3c_m_s > 2.0 * smc)
+                L_max = (2.0 * crv - sqrt(smc * smc + 2.0 * C3c_m_s * (Vol_open - volK))) * I_3c_m_s;
+              else
+                L_max = 1.0;
+            }
+            vol_err_max = VERR1(L_max);
+            if ((vol_err_max < fabs(vol_err)) && (L_max < 1.0)) {
+              dVol_dL = L_max * (slope + crv * (1.0 - 2.0 * L_max));
+              L = max2(L_min, L_max - (vol_err_max / dVol_dL));
+            }
+            for (int itt = 1; itt <= max_itt; itt++) {
+              vol_err = VERR1(L);
+              dVol_dL = L * (slope + crv * (1.0 - 2.0 * L));
+              if (fabs(vol_err) < max2(1.0e-15 * L, 1.0e-25) * dVol_dL) break;
+              L = L - (vol_err / dVol_dL);
+            }
+          }
+        }
+        return L;
+      }
+      if (volK <= vol_inflect_2) {
+        L_min = max2(LKp1, L_2_reg);
+        if ((4.0 * volK - slope * slope_crv) > (crv + 2.0 * C1_3 * slope) * (L_min * L_min))
+          L_min = max2(L_min, sqrt((4.0 * volK - slope * slope_crv) / (crv + 2.0 * C1_3 * slope)));
+        L_max = 0.5;
+        L = L_min;
+        vol_err = crv_3 * (L * L) * (0.75 - 0.5 * L) + (slope2_4crv - volK);
+        if (vol_err < 0.0) {
+          dVol_dL = 0.5 * crv * (L * (1.0 - L));
+          if (L * dVol_dL >= vol_err + L_max * dVol_dL) L = L_max;
+          else L = L - (vol_err / dVol_dL);
+          for (int itt = 1; itt <= max_itt; itt++) {
+            vol_err = VERR2(L);
+            dVol_dL = 0.5 * crv * (L * (1.0 - L));
+            if (fabs(vol_err) < max2(1.0e-15 * L, 1.0e-25) * dVol_dL) break;
+            L = L - (vol_err / dVol_dL);
+          }
+        }
+      } else {
+        L_min = max2(LKp1, 0.5);
+        L = L_min;
+        vol_err = VERR2(L);
+        if (vol_err < 0.0) {
+          L_max = 1.0 - sqrt((Vol_open - volK) * C4_crv);
+          vol_err_max = VERR2(L_max);
+          if ((vol_err_max < fabs(vol_err)) && (L_max < 1.0)) {
+            dVol_dL = 0.5 * crv * (L_max * (1.0 - L_max));
+            L = max2(L_min, L_max - (vol_err_max / dVol_dL));
+          }
+          for (int itt = 1; itt <= max_itt; itt++) {
+            vol_err = VERR2(L);
+            dVol_dL = 0.5 * crv * (L * (1.0 - L));
+            if (fabs(vol_err) < max2(1.0e-15 * L, 1.0e-25) * dVol_dL) break;
+            L = L - (vol_err / dVol_dL);
+          }
+        }
+      }
+      return L;
+    }
+    // convex
+    const int maxitt = 20;
+    auto VERR = [&](double Lk) { return 0.5 * (Lk * Lk) * (slope + crv_3 * (3.0 - 4.0 * Lk)) - volK; };
+    if (volK >= Vol_open) return 1.0;
+    if (volK <= Vol_direct) {
+      const double x = -0.25 * C24_crv * volK;
+      return (x > 0.0) ? m6::cr::cr_pow(x, C1_3) : 0.0;
+    }
+    double L, L0, Vol_0;
+    if (volKp1 + Vol_err <= Vol_direct) { L0 = L_direct; Vol_0 = Vol_direct; }
+    else { L0 = LKp1; Vol_0 = volKp1 + Vol_err; }
+    const double dV_dL2 = 0.5 * (slope + crv) - crv * L0, dVol = (volK - Vol_0);
+    const bool use_L0 = (dVol <= 0.);
+    const double Vol_tol = max2(0.5 * Angstrom_Z + dZ_subroundoff, 1e-14 * volK);
+    const double Vol_quit = max2(0.9 * Angstrom_Z + dZ_subroundoff, 1e-14 * volK);
+    const double curv_tol = Vol_tol * (dV_dL2 * dV_dL2) * (dV_dL2 * Vol_tol - 2.0 * crv * L0 * dVol);
+    const bool do_one_L_iter = (crv * crv * ((dVol * dVol) * dVol)) < curv_tol;
+    if (use_L0) {
+      L = L0;
+      Vol_err = VERR(L);
+    } else if (do_one_L_iter) {
+      L = sqrt(L0 * L0 + dVol / dV_dL2);
+      Vol_err = VERR(L);
+    } else {
+      double L_max, L_min;
+      if (dV_dL2 * (1.0 - L0 * L0) < dVol + dV_dL2 * (Vol_open - volK) * Ibma_2)
+        L_max = sqrt(1.0 - (Vol_open - volK) * Ibma_2);
+      else
+        L_max = sqrt(L0 * L0 + dVol / dV_dL2);
+      L_min = sqrt(L0 * L0 + dVol / (0.5 * (slope + crv) - crv * L_max));
+      const double Vol_err_min = VERR(L_min), Vol_err_max = VERR(L_max);
+      if (fabs(Vol_err_min) <= Vol_quit) {
+        L = L_min; Vol_err = Vol_err_min;
+      } else {
+        L = sqrt(((L_min * L_min) * Vol_err_max - (L_max * L_max) * Vol_err_min) / (Vol_err_max - Vol_err_min));
+        for (int itt = 1; itt <= maxitt; itt++) {
+          Vol_err = VERR(L);
+          if (fabs(Vol_err) <= Vol_quit) break;
+          L = L - Vol_err / (L * (slope + crv - 2.0 * crv * L));
+        }
+      }
+    }
+    return L;
+  }
+};
 
 template <int DIR>
 __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
@@ -225,10 +475,68 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
     bbl_thick = dztot / (0.5 + sqrt(0.25 + htot * htot * C2f * C2f / (ustar * ustar)));
     if (bbl_thick < A.BBL_thick_min) bbl_thick = A.BBL_thick_min;
   }
+  double Vol_bbl_chan = bbl_thick;      // :849
   if ((bbl_thick > 0.5 * A.dz_bbl) && (A.RiNo_mix)) bbl_thick = 0.5 * A.dz_bbl;
   if (A.body_force_drag) bbl_thick = dz_bbl_drag;
-  // not channel drag :1010-1022
   double kv_bbl;
+  if (A.Channel_drag) {      // :863-1002
+    auto D_face = [&](int ii, int jj) {
+      return DIR ? (0.5 * (g.bathyT[g.h2(ii, jj)] + g.bathyT[g.h2(ii, jj + 1)]) + A.Z_ref)
+                 : (0.5 * (g.bathyT[g.h2(ii, jj)] + g.bathyT[g.h2(ii + 1, jj)]) + A.Z_ref);
+    };
+    const double D_vel = D_face(i, j);
+    double tmp = DIR ? g.mask2dCv[g.v2(i + 1, j)] * D_face(i + 1, j) : g.mask2dCu[g.u2(i, j + 1)] * D_face(i, j + 1);
+    double Dp = 2.0 * D_vel * tmp / (D_vel + tmp);
+    tmp = DIR ? g.mask2dCv[g.v2(i - 1, j)] * D_face(i - 1, j) : g.mask2dCu[g.u2(i, j - 1)] * D_face(i, j - 1);
+    double Dm = 2.0 * D_vel * tmp / (D_vel + tmp);
+    if (Dm > Dp) { tmp = Dp; Dp = Dm; Dm = tmp; }
+    ChanGeom geo;
+    geo.init(D_vel, Dp, Dm, A.BBL_thick_min, A.concave_trig, g.Angstrom_H * g.H_to_Z, dz_neglect);
+    if (A.Chan_drag_max_vol >= 0.0) Vol_bbl_chan = min2(Vol_bbl_chan, A.Chan_drag_max_vol);
+    const double Cell_width = DIR ? g.dx_Cv[f2] : g.dy_Cu[f2];
+    double BBL_visc_frac = 0.0, vol_Kp1 = 0.0, L_Kp1 = 0.0;
+    for (int k = nz - 1; k >= 0; k--) {      // (no porous barriers: por_layer_width = por_face_area = 1)
+      const double h0 = A.h[c0 + hpl * k], h1 = A.h[c1 + hpl * k];
+      const double dz_vel = 0.5 * (g.H_to_Z * h0 + g.H_to_Z * h1);
+      const double vol_K = vol_Kp1 + dz_vel;
+      const double L_K = geo.next_L(vol_K, vol_Kp1, L_Kp1);
+      double Rayleigh;
+      if (L_K > L_Kp1) {
+        double BBL_frac;
+        if (vol_Kp1 < Vol_bbl_chan) {
+          const double q = (1.0 - vol_Kp1 / Vol_bbl_chan);
+          BBL_frac = q * q;
+          BBL_visc_frac = BBL_visc_frac + BBL_frac * (L_K - L_Kp1);
+        } else {
+          BBL_frac = 0.0;
+        }
+        const double cdrag_conv = cdrag_L_to_H;
+        const double h_vel_pos = 0.5 * (h0 + h1) + h_neglect;
+        const double gam = 1.0 - L_Kp1 / L_K;
+        Rayleigh = cdrag_conv * (L_K - L_Kp1) * (1.0 - BBL_frac) *
+                   (12.0 * A.c_Smag * h_vel_pos) / (12.0 * A.c_Smag * h_vel_pos +
+                                                   cdrag_conv * gam * (1.0 - gam) * (1.0 - 1.5 * gam) * (L_K * L_K) * Cell_width);
+      } else {
+        Rayleigh = 0.0;
+      }
+      if (Rayleigh > 0.0) {
+        const double vt = transverse_vel<DIR>(A, i, j, hpl * k, upl * k, vpl * k);
+        const double vn = vel[f2 + fpl * k];
+        A.Ray[f2 + fpl * k] = Rayleigh * sqrt(vn * vn + vt * vt + u2_bg);
+      } else {
+        A.Ray[f2 + fpl * k] = 0.0;
+      }
+      vol_Kp1 = vol_K; L_Kp1 = L_K;
+    }
+    if (A.correct_BBL_bounds && cdrag_sqrt * ustar * bbl_thick * BBL_visc_frac <= A.Kv_BBL_min) {
+      kv_bbl = A.Kv_BBL_min;
+      if ((cdrag_sqrt * ustar) * BBL_visc_frac * A.BBL_thick_max > kv_bbl) bbl_thick = kv_bbl / ((cdrag_sqrt * ustar) * BBL_visc_frac);
+      else bbl_thick = A.BBL_thick_max;
+    } else {
+      kv_bbl = (cdrag_sqrt * ustar) * bbl_thick * BBL_visc_frac;
+    }
+  } else
+  // not channel drag :1004-1022
   if (A.correct_BBL_bounds && cdrag_sqrt * ustar * bbl_thick <= A.Kv_BBL_min) {
     kv_bbl = A.Kv_BBL_min;
     if ((cdrag_sqrt * ustar) * A.BBL_thick_max > kv_bbl) bbl_thick = kv_bbl / (cdrag_sqrt * ustar);
@@ -376,7 +684,7 @@ __global__ __launch_bounds__(64) void set_viscous_ml_kernel(MLArgs A) {
 }
 
 int check_cs(const mom6hip_set_visc_cs_t *cs, const char *who) {
-  static const char *names[9] = {"CHANNEL_DRAG", "BBL_USE_TIDAL_BG", "(free)", "(free)",
+  static const char *names[9] = {"(free)", "BBL_USE_TIDAL_BG", "(free)", "(free)",
                                  "non-Boussinesq mode (tv%SpV_avg)", "tv%p_surf", "open boundary conditions", "porous barriers",
                                  "ice shelves"};
   M6_REQUIRE(cs->initialized, "%s: Module must be initialized before it is used.", who);
@@ -402,6 +710,10 @@ int set_viscous_BBL_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, con
   A.Kv_BBL_min = cs->Kv_BBL_min; A.BBL_thick_max = cs->BBL_thick_max; A.H_to_RZ = cs->H_to_RZ;
   A.linear_drag = cs->linear_drag; A.use_BBL_EOS = use_EOS; A.correct_BBL_bounds = cs->correct_BBL_bounds;
   A.body_force_drag = cs->body_force_drag; A.RiNo_mix = cs->RiNo_mix;
+  A.Channel_drag = cs->Channel_drag; A.concave_trig = cs->concave_trigonometric_L; A.c_Smag = cs->c_Smag;
+  A.Chan_drag_max_vol = cs->Chan_drag_max_vol; A.Z_ref = cs->Z_ref;
+  M6_REQUIRE(!(cs->Channel_drag || cs->body_force_drag) || (Ray_u && Ray_v),
+             "set_viscous_BBL: CHANNEL_DRAG and DRAG_AS_BODY_FORCE need visc%%Ray_u and visc%%Ray_v");
   A.u = u; A.v = v; A.h = h; A.T = T; A.S = S; A.Rlay = nullptr;
   if (!use_EOS) {
     M6_REQUIRE(ctx->sv_rlay.reserve(sizeof(double) * (size_t)g.nk) == 0, "set_viscous_BBL: out of device memory");

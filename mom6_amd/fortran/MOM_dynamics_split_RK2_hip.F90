@@ -269,7 +269,7 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
   type(MOM_dyn_split_RK2_CS),        pointer       :: CS
   logical,                           intent(in)    :: calc_dtbt
   type(VarMix_CS),                   intent(inout) :: VarMix
-  type(MEKE_type),                   intent(inout) :: MEKE
+  type(MEKE_type), target,           intent(inout) :: MEKE
   type(thickness_diffuse_CS),        intent(inout) :: thickness_diffuse_CSp
   type(porous_barrier_type),         intent(in)    :: pbv
   type(stochastic_CS), optional,     intent(inout) :: STOCH
@@ -286,8 +286,9 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
   if (allocated(pbv%por_face_areaU)) then
     if (any(pbv%por_face_areaU /= 1.0) .or. any(pbv%por_face_areaV /= 1.0)) call refuse("porous barriers")
   endif
-  if (VarMix%use_variable_mixing) call refuse("resolution-dependent viscosities (VarMix)")
-  if (allocated(MEKE%Kh)) call refuse("MEKE")
+  ! VarMix: the resolution function scales the Laplacian viscosity only (MOM_hor_visc.F90:474-476, :1123, :1525)
+  if (VarMix%use_variable_mixing .and. VarMix%Resoln_scaled_Kh .and. (CS%c_hv%Laplacian /= 0)) call refuse("RESOLN_SCALED_KH with LAPLACIAN")
+  if (present(STOCH)) call refuse("stochastic parameterizations (STOCH)")
   if (.not.(associated(forces%taux) .and. associated(forces%tauy))) call MOM_error(FATAL, "step_MOM_dyn_split_RK2 (HIP): "// &
       "forces%taux and forces%tauy must be associated.")
   if (CS%use_EOS .and. .not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "step_MOM_dyn_split_RK2 (HIP): "// &
@@ -305,6 +306,15 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
   d_eta_av = mirror(CS, c_loc(eta_av), CS%nh2, .false., .true.)
   d_tx = mirror(CS, c_loc(forces%taux), CS%nu2, .true., .false.) ; d_ty = mirror(CS, c_loc(forces%tauy), CS%nv2, .true., .false.)
   call visc_mirrors(CS, visc, forces)
+  ! the MEKE argument of horizontal_viscosity (MOM_hor_visc.F90:1141, :1318, :1537, :1634; :1833-1889)
+  CS%c_hv%MEKE_Ku = c_null_ptr ; CS%c_hv%MEKE_Au = c_null_ptr ; CS%c_hv%MEKE_mom_src = c_null_ptr
+  if (allocated(MEKE%Ku)) CS%c_hv%MEKE_Ku = mirror(CS, c_loc(MEKE%Ku), CS%nh2, .true., .false.)
+  if (allocated(MEKE%Au)) CS%c_hv%MEKE_Au = mirror(CS, c_loc(MEKE%Au), CS%nh2, .true., .false.)
+  if (allocated(MEKE%mom_src)) then
+    if (MEKE%backscatter_Ro_c /= 0.0) call refuse("MEKE_BACKSCAT_RO_C /= 0")
+    CS%c_hv%MEKE_mom_src = mirror(CS, c_loc(MEKE%mom_src), CS%nh2, .true., .true.)
+    if (allocated(MEKE%GME_snk)) MEKE%GME_snk(:,:) = 0.0
+  endif
 
   rc = mom6hip_step_dyn_split_rk2(CS%ctx, CS%c_rk2, d_u, d_v, d_h, d_T, d_S, real(dt, c_double), d_tx, d_ty, &
                                   real(GV%Z_to_H / GV%Rho0, c_double), d_uh, d_vh, d_uhtr, d_vhtr, d_eta_av, &
@@ -447,7 +457,7 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   type(cont_diag_ptrs),     target, intent(inout) :: Cont_diag
   type(ocean_internal_state),       intent(inout) :: MIS
   type(VarMix_CS),                  intent(inout) :: VarMix
-  type(MEKE_type),                  intent(inout) :: MEKE
+  type(MEKE_type), target,          intent(inout) :: MEKE
   type(thickness_diffuse_CS),       intent(inout) :: thickness_diffuse_CSp
   type(ocean_OBC_type),             pointer       :: OBC
   type(update_OBC_CS),              pointer       :: update_OBC_CSp
@@ -564,16 +574,18 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   CS%c_vv = hvv
   CS%c_vv%a_u = dalloc(CS, CS%nu3 + CS%nu2) ; CS%c_vv%a_v = dalloc(CS, CS%nv3 + CS%nv2)
   CS%c_vv%h_u = dalloc(CS, CS%nu3) ; CS%c_vv%h_v = dalloc(CS, CS%nv3) ; CS%c_vv%reserved1(:) = c_null_ptr ; CS%c_vv%ntrunc = 0
-  ! hor_visc_CS: its 16 static arrays computed on the device by the library's hor_visc_init
+  ! hor_visc_CS: the 16 static arrays hor_visc_init has filled on the host
   hhv = hor_visc_hip_struct(CS%hor_visc)
   CS%c_hv = hhv
-  CS%c_hv%Kh_bg_xx = dalloc(CS, CS%nh2) ; CS%c_hv%Kh_Max_xx = dalloc(CS, CS%nh2) ; CS%c_hv%Ah_bg_xx = dalloc(CS, CS%nh2)
-  CS%c_hv%Ah_Max_xx = dalloc(CS, CS%nh2) ; CS%c_hv%Laplac2_const_xx = dalloc(CS, CS%nh2) ; CS%c_hv%Biharm_const_xx = dalloc(CS, CS%nh2)
-  CS%c_hv%Biharm_const2_xx = dalloc(CS, CS%nh2) ; CS%c_hv%reduction_xx = dalloc(CS, CS%nh2)
-  CS%c_hv%Kh_bg_xy = dalloc(CS, CS%nq2) ; CS%c_hv%Kh_Max_xy = dalloc(CS, CS%nq2) ; CS%c_hv%Ah_bg_xy = dalloc(CS, CS%nq2)
-  CS%c_hv%Ah_Max_xy = dalloc(CS, CS%nq2) ; CS%c_hv%Laplac2_const_xy = dalloc(CS, CS%nq2) ; CS%c_hv%Biharm_const_xy = dalloc(CS, CS%nq2)
-  CS%c_hv%Biharm_const2_xy = dalloc(CS, CS%nq2) ; CS%c_hv%reduction_xy = dalloc(CS, CS%nq2) ; CS%c_hv%reserved1(:) = c_null_ptr
-  rc = mom6hip_hor_visc_init(CS%ctx, CS%c_hv, real(dt, c_double), MOM6HIP_MEM_DEVICE) ; call mom6hip_fatal_if(rc, "hor_visc_init (device)")
+  CS%c_hv%Kh_bg_xx = dput(CS, hhv%Kh_bg_xx, CS%nh2) ; CS%c_hv%Kh_Max_xx = dput(CS, hhv%Kh_Max_xx, CS%nh2)
+  CS%c_hv%Ah_bg_xx = dput(CS, hhv%Ah_bg_xx, CS%nh2) ; CS%c_hv%Ah_Max_xx = dput(CS, hhv%Ah_Max_xx, CS%nh2)
+  CS%c_hv%Laplac2_const_xx = dput(CS, hhv%Laplac2_const_xx, CS%nh2) ; CS%c_hv%Biharm_const_xx = dput(CS, hhv%Biharm_const_xx, CS%nh2)
+  CS%c_hv%Biharm_const2_xx = dput(CS, hhv%Biharm_const2_xx, CS%nh2) ; CS%c_hv%reduction_xx = dput(CS, hhv%reduction_xx, CS%nh2)
+  CS%c_hv%Kh_bg_xy = dput(CS, hhv%Kh_bg_xy, CS%nq2) ; CS%c_hv%Kh_Max_xy = dput(CS, hhv%Kh_Max_xy, CS%nq2)
+  CS%c_hv%Ah_bg_xy = dput(CS, hhv%Ah_bg_xy, CS%nq2) ; CS%c_hv%Ah_Max_xy = dput(CS, hhv%Ah_Max_xy, CS%nq2)
+  CS%c_hv%Laplac2_const_xy = dput(CS, hhv%Laplac2_const_xy, CS%nq2) ; CS%c_hv%Biharm_const_xy = dput(CS, hhv%Biharm_const_xy, CS%nq2)
+  CS%c_hv%Biharm_const2_xy = dput(CS, hhv%Biharm_const2_xy, CS%nq2) ; CS%c_hv%reduction_xy = dput(CS, hhv%reduction_xy, CS%nq2)
+  CS%c_hv%reserved1(:) = c_null_ptr
 
   ! MOM_dyn_split_RK2_CS
   CS%c_rk2%be = CS%be ; CS%c_rk2%begw = CS%begw
@@ -594,6 +606,10 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   d_u = mirror(CS, c_loc(u), CS%nu3, .true., .false.) ; d_v = mirror(CS, c_loc(v), CS%nv3, .true., .false.)
   d_h = mirror(CS, c_loc(h), CS%nh3, .true., .false.)
   d_uh = mirror(CS, c_loc(uh), CS%nu3, .true., .true.) ; d_vh = mirror(CS, c_loc(vh), CS%nv3, .true., .true.)
+  ! (horizontal_viscosity at :1543 gets MEKE: its viscosities count, its momentum source is the first step's business)
+  if (allocated(MEKE%Ku)) CS%c_hv%MEKE_Ku = mirror(CS, c_loc(MEKE%Ku), CS%nh2, .true., .false.)
+  if (allocated(MEKE%Au)) CS%c_hv%MEKE_Au = mirror(CS, c_loc(MEKE%Au), CS%nh2, .true., .false.)
+  if (VarMix%use_variable_mixing .and. VarMix%Resoln_scaled_Kh .and. (CS%c_hv%Laplacian /= 0)) call refuse(.true., "RESOLN_SCALED_KH with LAPLACIAN")
   rc = mom6hip_dyn_split_rk2_init(CS%ctx, CS%c_rk2, d_u, d_v, d_h, d_uh, d_vh, real(dt, c_double))
   call mom6hip_fatal_if(rc, "initialize_dyn_split_RK2")
   call from_restart(c_loc(CS%eta), CS%c_rk2%eta, CS%nh2, query_initialized(CS%eta, "sfc", restart_CS))

@@ -31,7 +31,7 @@ implicit none ; private
 #include <MOM_memory.h>
 
 public horizontal_viscosity, hor_visc_init, hor_visc_end, hor_visc_vel_stencil
-public hor_visc_hip_struct      ! (GPU path only) for MOM_dynamics_split_RK2
+public hor_visc_hip_struct, hor_visc_hip_MEKE      ! (GPU path only) for MOM_dynamics_split_RK2
 
 !> Control structure: the library's struct and the static arrays hor_visc_init computes (h-point *_xx, q-point *_xy)
 type, public :: hor_visc_CS ; private
@@ -69,6 +69,23 @@ function hor_visc_hip_struct(CS) result(st)
   st = CS%st
 end function hor_visc_hip_struct
 
+!> (GPU path only) The MEKE argument of horizontal_viscosity in the library's struct: MEKE%Ku, MEKE%Au (added to the viscosities,
+!! :1141, :1318, :1537, :1634) and MEKE%mom_src (the vertically summed frictional work, :1833-1889) as HOST pointers, null when not
+!! allocated.  Refused: the Rossby-number dependent backscatter (MEKE_BACKSCAT_RO_C /= 0).
+subroutine hor_visc_hip_MEKE(st, MEKE)
+  type(mom6hip_hor_visc_cs_t), intent(inout) :: st
+  type(MEKE_type), target,     intent(inout) :: MEKE
+  st%MEKE_Ku = c_null_ptr ; st%MEKE_Au = c_null_ptr ; st%MEKE_mom_src = c_null_ptr
+  if (allocated(MEKE%Ku)) st%MEKE_Ku = c_loc(MEKE%Ku)
+  if (allocated(MEKE%Au)) st%MEKE_Au = c_loc(MEKE%Au)
+  if (allocated(MEKE%mom_src)) then
+    if (MEKE%backscatter_Ro_c /= 0.0) call MOM_error(FATAL, "horizontal_viscosity (HIP): MEKE_BACKSCAT_RO_C /= 0 is not provided "// &
+        "by the GPU path.")
+    st%MEKE_mom_src = c_loc(MEKE%mom_src)
+    if (allocated(MEKE%GME_snk)) MEKE%GME_snk(:,:) = 0.0      ! :1838-1842 (USE_GME is refused)
+  endif
+end subroutine hor_visc_hip_MEKE
+
 !> Same interface as the reference horizontal_viscosity (:245).
 subroutine horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, &
                                 CS, tv, dt, OBC, BT, TD, ADp, hu_cont, hv_cont, STOCH)
@@ -98,9 +115,11 @@ subroutine horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, 
   if (.not.(CS%st%Laplacian /= 0 .or. CS%st%biharmonic /= 0)) return      ! :451
   if (present(OBC)) then ; if (associated(OBC)) &
     call MOM_error(FATAL, "horizontal_viscosity (HIP): open boundary conditions are not supported by the GPU path.") ; endif
-  if (VarMix%use_variable_mixing) call MOM_error(FATAL, "horizontal_viscosity (HIP): resolution-scaled viscosities (VarMix) are "// &
-       "not provided by the GPU path.")
+  ! VarMix: the resolution function scales the Laplacian viscosity only (rescale_Kh, :474-476, :1123, :1525)
+  if (VarMix%use_variable_mixing .and. VarMix%Resoln_scaled_Kh .and. (CS%st%Laplacian /= 0)) &
+    call MOM_error(FATAL, "horizontal_viscosity (HIP): RESOLN_SCALED_KH with LAPLACIAN is not provided by the GPU path.")
   call bind_arrays(CS)
+  call hor_visc_hip_MEKE(CS%st, MEKE)
   p_hu = c_null_ptr ; if (present(hu_cont)) p_hu = c_loc(hu_cont)
   p_hv = c_null_ptr ; if (present(hv_cont)) p_hv = c_loc(hv_cont)
   diffu(:,:,:) = 0.0 ; diffv(:,:,:) = 0.0      ! (intent(out): the library writes the computational ranges only)
@@ -121,7 +140,7 @@ subroutine hor_visc_init(Time, G, GV, US, param_file, diag, CS, ADp)
   type(accel_diag_ptrs), intent(in), optional :: ADp
 # include "version_variable.h"
   character(len=40)  :: mdl = "MOM_hor_visc"
-  logical :: flag, bound_Cor_def
+  logical :: flag, flag2, bound_Cor_def
   real :: val, maxvel, dt
   integer :: isd, ied, jsd, jed, default_answer_date, answer_date, rc
 
@@ -151,7 +170,12 @@ subroutine hor_visc_init(Time, G, GV, US, param_file, diag, CS, ADp)
                  "The nondimensional Laplacian Smagorinsky constant, often 0.15.", units="nondim", default=0.0, &
                  fail_if_missing=(CS%st%Smagorinsky_Kh /= 0))
   call get_param(param_file, mdl, "LEITH_KH", flag, default=.false.) ; call refuse(flag, "LEITH_KH")
-  call get_param(param_file, mdl, "USE_MEKE", flag, default=.false., do_not_log=.true.) ; call refuse(flag, "USE_MEKE")
+  ! USE_MEKE only decides what is logged (:2122-2128): MEKE acts through the MEKE argument of horizontal_viscosity
+  call get_param(param_file, mdl, "USE_MEKE", flag, default=.false., do_not_log=.true.)
+  call get_param(param_file, mdl, "RES_SCALE_MEKE_VISC", flag2, &
+                 "If true, the viscosity contribution from MEKE is scaled by the resolution function.", default=.false., &
+                 do_not_log=.not.((CS%st%Laplacian /= 0) .and. flag))
+  call refuse(flag2 .and. flag .and. (CS%st%Laplacian /= 0), "RES_SCALE_MEKE_VISC")
   call get_param(param_file, mdl, "BOUND_KH", flag, &
                  "If true, the Laplacian coefficient is locally limited to be stable.", default=.true.)
   CS%st%bound_Kh = merge(1, 0, flag)

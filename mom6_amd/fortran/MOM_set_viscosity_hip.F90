@@ -172,13 +172,13 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
   character(len=40)  :: tmpstr
   logical :: flag, flag2, use_EOS, use_temperature, use_regridding
   real :: Kv_background, val
-  integer :: isd, ied, jsd, jed
+  integer :: isd, ied, jsd, jed, default_answer_date, answer_date
 
   CS%initialized = .true. ; CS%diag => diag
   isd = G%isd ; ied = G%ied ; jsd = G%jsd ; jed = G%jed
   if (associated(OBC)) call refuse(.true., "open boundary conditions")
   if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
-  CS%st%unsupported(:) = 0 ; CS%st%reserved0(:) = 0.0 ; CS%st%reserved1(:) = c_null_ptr ; CS%st%Rlay = c_null_ptr
+  CS%st%unsupported(:) = 0 ; CS%st%reserved1(:) = c_null_ptr ; CS%st%Rlay = c_null_ptr
   CS%st%nkml = GV%nkml
   call log_version(param_file, mdl, version, "")
   call get_param(param_file, mdl, "BOTTOMDRAGLAW", flag, &
@@ -188,7 +188,10 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
                  "If true, the bottom stress is imposed as an explicit body force applied over a fixed distance from the bottom.", &
                  default=.false.)
   CS%st%body_force_drag = merge(1, 0, flag)
-  call get_param(param_file, mdl, "CHANNEL_DRAG", flag, default=.false.) ; call refuse(flag, "CHANNEL_DRAG")
+  call get_param(param_file, mdl, "CHANNEL_DRAG", flag, &
+                 "If true, the bottom drag is exerted directly on each layer proportional to the fraction of the bottom it overlies.", &
+                 default=.false.)
+  CS%st%Channel_drag = merge(1, 0, flag)
   call get_param(param_file, mdl, "LINEAR_DRAG", flag, "If LINEAR_DRAG and BOTTOMDRAGLAW are defined the drag law is cdrag*DRAG_BG_VEL*u.", &
                  default=.false.)
   CS%st%linear_drag = merge(1, 0, flag)
@@ -244,6 +247,30 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
                  "If true, uses the correct bounds on the BBL thickness and viscosity so that the bottom layer feels the intended drag.", &
                  default=.false.)
   CS%st%correct_BBL_bounds = merge(1, 0, flag)
+  ! CHANNEL_DRAG (:3092-3122)
+  CS%st%c_Smag = 0.15 ; CS%st%concave_trigonometric_L = 1 ; CS%st%Z_ref = G%Z_ref
+  if (CS%st%Channel_drag /= 0) then
+    call get_param(param_file, mdl, "SMAG_LAP_CONST", val, units="nondim", default=-1.0)
+    if (val < 0.0) val = 0.15
+    call get_param(param_file, mdl, "SMAG_CONST_CHANNEL", CS%st%c_Smag, &
+                 "The nondimensional Laplacian Smagorinsky constant used in calculating the channel drag if it is enabled.  The default "// &
+                 "is to use the same value as SMAG_LAP_CONST if it is defined, or 0.15 if it is not.", units="nondim", default=val)
+    if (CS%st%c_Smag < 0.0) CS%st%c_Smag = 0.15
+    call get_param(param_file, mdl, "TRIG_CHANNEL_DRAG_WIDTHS", flag, &
+                 "If true, use trigonometric expressions to determine the fractional open interface lengths for concave topography.", &
+                 default=.true.)
+    CS%st%concave_trigonometric_L = merge(1, 0, flag)
+    call get_param(param_file, mdl, "DEFAULT_ANSWER_DATE", default_answer_date, default=99991231)
+    call get_param(param_file, mdl, "SET_VISC_ANSWER_DATE", answer_date, default=default_answer_date)
+    call refuse(answer_date < 20190101, "CHANNEL_DRAG with SET_VISC_ANSWER_DATE < 20190101")
+  endif
+  val = -1.0
+  if (CS%st%RiNo_mix /= 0) val = 0.5*CS%st%dz_bbl
+  if (CS%st%body_force_drag /= 0) val = CS%st%dz_bbl
+  call get_param(param_file, mdl, "CHANNEL_DRAG_MAX_BBL_THICK", CS%st%Chan_drag_max_vol, &
+                 "The maximum bottom boundary layer thickness over which the channel drag is exerted, or a negative value for no fixed "// &
+                 "limit.  The default is proportional to HBBL if USE_JACKSON_PARAM or DRAG_AS_BODY_FORCE is true.", &
+                 units="m", default=US%Z_to_m*val, scale=US%m_to_Z, do_not_log=(CS%st%Channel_drag == 0))
   CS%st%BBL_thick_max = 6.378e6      ! G%Rad_Earth_L * US%L_to_Z (:3128)
   CS%st%H_to_RZ = GV%H_to_RZ
   CS%st%initialized = 1
@@ -277,6 +304,10 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
     if (.not.allocated(visc%Kv_bbl_u)) allocate(visc%Kv_bbl_u(isd-1:ied,jsd:jed), source=0.0)
     if (.not.allocated(visc%Kv_bbl_v)) allocate(visc%Kv_bbl_v(isd:ied,jsd-1:jed), source=0.0)
   endif
+  if ((CS%st%Channel_drag /= 0) .or. (CS%st%body_force_drag /= 0)) then      ! :3168-3170
+    if (.not.allocated(visc%Ray_u)) allocate(visc%Ray_u(isd-1:ied,jsd:jed,GV%ke), source=0.0)
+    if (.not.allocated(visc%Ray_v)) allocate(visc%Ray_v(isd:ied,jsd-1:jed,GV%ke), source=0.0)
+  endif
   if (CS%st%dynamic_viscous_ML /= 0) then      ! :3178-3180
     if (.not.allocated(visc%nkml_visc_u)) allocate(visc%nkml_visc_u(isd-1:ied,jsd:jed), source=0.0)
     if (.not.allocated(visc%nkml_visc_v)) allocate(visc%nkml_visc_v(isd:ied,jsd-1:jed), source=0.0)
@@ -295,6 +326,7 @@ subroutine set_visc_end(visc, CS)
   type(vertvisc_type), intent(inout) :: visc
   type(set_visc_CS),   intent(inout) :: CS
   if (allocated(visc%bbl_thick_u)) deallocate(visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v)
+  if (allocated(visc%Ray_u)) deallocate(visc%Ray_u, visc%Ray_v)
   if (allocated(CS%Rlay)) deallocate(CS%Rlay)
   CS%initialized = .false.
 end subroutine set_visc_end

@@ -260,8 +260,8 @@ subroutine vertvisc_init(MIS, Time, G, GV, US, param_file, diag, ADp, dirs, ntru
   call get_param(param_file, mdl, "LOTW_VISCOUS_ML_FLOOR", flag, default=.false.) ; call refuse(flag, "LOTW_VISCOUS_ML_FLOOR")
   call get_param(param_file, mdl, "USE_GL90_IN_SSW", flag, default=.false.) ; call refuse(flag, "USE_GL90_IN_SSW")
   ! a bulk mixed layer: its GV%nkml layers are the viscous surface boundary layer (find_coupling_coef :2152-2166)
-  call get_param(param_file, "MOM", "BULKMIXEDLAYER", bulkmixedlayer, default=.false., do_not_log=.true.)
-  nkml = 0 ; if (bulkmixedlayer) nkml = GV%nkml
+  ! (GV%nkml is zero unless BULKMIXEDLAYER, MOM.F90:2439-2445 / MOM_verticalGrid)
+  nkml = GV%nkml
   CS%st%nkml = nkml
   call get_param(param_file, mdl, "VON_KARMAN_CONST", CS%st%vonKar, "The value the von Karman constant as used for mixed layer viscosity.", &
                  units="nondim", default=0.41)
@@ -271,8 +271,10 @@ subroutine vertvisc_init(MIS, Time, G, GV, US, param_file, diag, ADp, dirs, ntru
   call get_param(param_file, mdl, "HARMONIC_BL_SCALE", CS%st%harm_BL_val, &
                  "A scale to determine when water is in the boundary layers based solely on harmonic mean thicknesses.", &
                  units="nondim", default=0.0)
-  call get_param(param_file, mdl, "HMIX_FIXED", Hmix_m, "The prescribed depth over which the near-surface viscosity is elevated.", &
-                 units="m", default=0.0, scale=US%m_to_Z)
+  Hmix_m = 0.0
+  if (GV%nkml < 1) call get_param(param_file, mdl, "HMIX_FIXED", Hmix_m, &      ! (:2582-2587)
+                 "The prescribed depth over which the near-surface viscosity and diffusivity are elevated when the bulk mixed layer "// &
+                 "is not used.", units="m", scale=US%m_to_Z, fail_if_missing=.true.)
   CS%st%Hmix = Hmix_m
   call get_param(param_file, mdl, "HMIX_STRESS", Hmix_stress_m, &
                  "The depth over which the wind stress is applied if DIRECT_STRESS is true.", units="m", default=Hmix_m*US%Z_to_m, &
@@ -282,7 +284,8 @@ subroutine vertvisc_init(MIS, Time, G, GV, US, param_file, diag, ADp, dirs, ntru
        "HMIX_STRESS must be set to a positive value if DIRECT_STRESS is true.")
   call get_param(param_file, mdl, "KV", CS%st%Kv, "The background kinematic viscosity in the interior.", units="m2 s-1", &
                  fail_if_missing=.true., scale=US%m_to_Z**2*US%T_to_s)
-  call get_param(param_file, mdl, "KV_ML_INVZ2", CS%st%Kvml_invZ2, &
+  CS%st%Kvml_invZ2 = 0.0
+  if (GV%nkml < 1) call get_param(param_file, mdl, "KV_ML_INVZ2", CS%st%Kvml_invZ2, &      ! (:2672-2690)
                  "An extra kinematic viscosity in a mixed layer of thickness HMIX_FIXED, with the actual viscosity scaling as 1/(z*HMIX_FIXED)^2.", &
                  units="m2 s-1", default=0.0, scale=US%m_to_Z**2*US%T_to_s)
   call get_param(param_file, mdl, "KV_EXTRA_BBL", CS%st%Kv_extra_bbl, &

@@ -137,8 +137,9 @@ subroutine mom6hip_context_create(G, GV, ctx, reentrant)
   if (rc == 0) rc = mom6hip_grid_create(cg, c_null_ptr, ctx)
   call mom6hip_fatal_if(rc, "mom6hip_context_create")
 
-  if ((cg%reentrant_x == 0 .and. cg%reentrant_y == 0 .and. cg%tripolar_n == 0) .or. (num_PEs() > 1)) then
+  if ((.not.know_topology) .or. (num_PEs() > 1)) then
     ! every halo update inside a library call is MOM6's own pass_var; sums and minima are MOM_coms'
+    ! (one PE with a known topology, closed basins included: the library's own updates, nothing leaves the device)
     G_cb => G ; ctx_cb = ctx ; nk_cb = GV%ke
     rc = mom6hip_set_domain_callbacks(ctx, c_funloc(halo_cb), c_funloc(sum_cb), c_null_ptr)
     if (rc == 0) rc = mom6hip_set_min_callback(ctx, c_funloc(min_cb), c_null_ptr)

@@ -156,7 +156,7 @@ type, bind(c) :: mom6hip_set_visc_cs_t
   real(c_double) :: cdrag, drag_bg_vel, Hbbl, dz_bbl, BBL_thick_min, Kv_BBL_min, BBL_thick_max, H_to_RZ
   real(c_double) :: omega = 7.2921d-5, omega_frac = 0.0d0, ustar_min = 0.0d0, TKE_decay = 0.0d0, bulk_Ri_ML = 0.0d0
   real(c_double) :: c_Smag = 0.15d0, Chan_drag_max_vol = -1.0d0
-  real(c_double) :: reserved0(1)
+  real(c_double) :: Z_ref = 0.0d0      !< G%Z_ref
   integer(c_int32_t) :: bottomdraglaw, linear_drag, BBL_use_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix, initialized
   integer(c_int32_t) :: unsupported(9)
   type(c_ptr) :: Rlay           !< c_loc of GV%Rlay (host), read without BBL_USE_EOS
@@ -188,7 +188,8 @@ type, bind(c) :: mom6hip_hor_visc_cs_t
   integer(c_int32_t) :: unsupported(10)
   type(c_ptr) :: Kh_bg_xx, Kh_Max_xx, Ah_bg_xx, Ah_Max_xx, Laplac2_const_xx, Biharm_const_xx, Biharm_const2_xx, reduction_xx
   type(c_ptr) :: Kh_bg_xy, Kh_Max_xy, Ah_bg_xy, Ah_Max_xy, Laplac2_const_xy, Biharm_const_xy, Biharm_const2_xy, reduction_xy
-  type(c_ptr) :: reserved1(4)
+  type(c_ptr) :: MEKE_Ku = c_null_ptr, MEKE_Au = c_null_ptr, MEKE_mom_src = c_null_ptr   !< MEKE%Ku, %Au (in), %mom_src (out) or null
+  type(c_ptr) :: reserved1(1)
 end type mom6hip_hor_visc_cs_t
 
 !> mom6hip_dyn_split_rk2_cs_t (MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84); every array is a DEVICE

@@ -19,7 +19,7 @@ _PARAMS = {"LAPLACIAN": "Laplacian", "KH": "Kh", "KH_BG_MIN": "Kh_bg_min", "KH_V
            "BETTER_BOUND_AH": "better_bound_Ah", "BOUND_CORIOLIS_BIHARM": "bound_Coriolis", "BOUND_CORIOLIS_VEL": "bound_Cor_vel",
            "HORVISC_BOUND_COEF": "bound_coef", "NOSLIP": "no_slip", "USE_LAND_MASK_FOR_HVISC": "use_land_mask",
            "USE_CONT_THICKNESS": "use_cont_thick"}
-_UNSUPPORTED = {"LEITH_KH": "Leith_Kh", "LEITH_AH": "Leith_Ah", "USE_LEITHY": "use_Leithy", "USE_MEKE": "use_MEKE", "USE_GME": "use_GME",
+_UNSUPPORTED = {"LEITH_KH": "Leith_Kh", "LEITH_AH": "Leith_Ah", "USE_LEITHY": "use_Leithy", "RES_SCALE_MEKE_VISC": "MEKE_backscatter", "USE_GME": "use_GME",
                 "ANISOTROPIC_VISCOSITY": "anisotropic", "RE_AH": "Re_Ah", "KH_SIN_LAT": "Kh_sin_lat", "USE_KH_BG_2D": "use_Kh_bg_2d",
                 "USE_ZB2020": "use_ZB2020"}
 
@@ -44,6 +44,7 @@ class hor_visc_CS:
                  bound_Kh=True, better_bound_Kh=None, bound_Ah=True, better_bound_Ah=None, bound_Coriolis=False, add_LES_viscosity=False,
                  no_slip=False, use_land_mask=True, use_cont_thick=False)
         st = self.st = _abi.HorViscCS()
+        params.pop("USE_MEKE", None)      # (only decides what hor_visc_init logs, :2122-2128; MEKE acts through the MEKE argument)
         for k, v in params.items():
             if k in _PARAMS:
                 d[_PARAMS[k]] = v
@@ -96,12 +97,24 @@ def hor_visc_vel_stencil(CS):
 def horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G: DeviceGrid, CS: hor_visc_CS, tv=None, dt=None, OBC=None, BT=None, TD=None,
                          ADp=None, hu_cont=None, hv_cont=None, STOCH=None):
     """horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, CS, tv, dt, OBC, BT, TD, ADp, hu_cont, hv_cont, STOCH)
-    -- :245.  MEKE, VarMix, OBC, BT, TD, ADp, STOCH belong to branches this build does not provide and must be None."""
+    -- :245.  MEKE: None, or a dict with any of Ku, Au (h-point 2-D arrays added to the Laplacian / biharmonic viscosity) and mom_src
+    (receives the vertically summed frictional work); VarMix, OBC, BT, TD, ADp, STOCH belong to branches this build does not provide
+    and must be None."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_hor_visc: Module must be initialized before it is used.")
-    if any(x is not None for x in (MEKE, VarMix, OBC, BT, TD, ADp, STOCH)):
-        raise Mom6HipError("horizontal_viscosity (HIP): MEKE, VarMix, OBC, GME (BT, TD), ADp and STOCH are not supported on this path")
+    if any(x is not None for x in (VarMix, OBC, BT, TD, ADp, STOCH)):
+        raise Mom6HipError("horizontal_viscosity (HIP): VarMix, OBC, GME (BT, TD), ADp and STOCH are not supported on this path")
+    MEKE = MEKE or {}
+    if set(MEKE) - {"Ku", "Au", "mom_src"}:
+        raise Mom6HipError("horizontal_viscosity (HIP): of MEKE only Ku, Au and mom_src are provided (no GME_snk, no backscatter)")
     spaces = {CS.space}
+    for n in ("Ku", "Au", "mom_src"):
+        a = MEKE.get(n)
+        if a is None:
+            setattr(CS.st, "MEKE_" + n, None)
+        else:
+            p, s = _ptr_space(a)
+            spaces.add(s); setattr(CS.st, "MEKE_" + n, p)
     ptrs = []
     for a in (u, v, h, diffu, diffv, hu_cont, hv_cont):
         if a is None:

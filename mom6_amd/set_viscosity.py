@@ -10,7 +10,7 @@ from . import _abi
 from ._lib import Mom6HipError, check, lib
 from .tracer_advect import DeviceGrid, _ptr_space
 
-_UNSUPPORTED = {"CHANNEL_DRAG": "Channel_drag", "BBL_USE_TIDAL_BG": "BBL_use_tidal_bg", "NON_BOUSSINESQ": "non_Boussinesq"}
+_UNSUPPORTED = {"BBL_USE_TIDAL_BG": "BBL_use_tidal_bg", "NON_BOUSSINESQ": "non_Boussinesq"}
 
 
 def _setup():
@@ -30,7 +30,8 @@ class set_visc_CS:
     def __init__(self, G: DeviceGrid, HBBL, KV, CDRAG=0.003, DRAG_BG_VEL=0.0, BBL_THICK_MIN=0.0, KV_BBL_MIN=None, BOTTOMDRAGLAW=True,
                  LINEAR_DRAG=False, BBL_USE_EOS=True, CORRECT_BBL_BOUNDS=False, DRAG_AS_BODY_FORCE=False, USE_JACKSON_PARAM=False,
                  Rlay=None, DYNAMIC_VISCOUS_ML=False, NKML=0, BULK_RI_ML=0.0, BULK_RI_ML_VISC=None, TKE_DECAY=0.0, TKE_DECAY_VISC=None,
-                 ML_OMEGA_FRAC=0.0, OMEGA=7.2921e-5, **unsupported):
+                 ML_OMEGA_FRAC=0.0, OMEGA=7.2921e-5, CHANNEL_DRAG=False, SMAG_LAP_CONST=-1.0, SMAG_CONST_CHANNEL=None,
+                 TRIG_CHANNEL_DRAG_WIDTHS=True, CHANNEL_DRAG_MAX_BBL_THICK=None, Z_ref=0.0, **unsupported):
         g = G.grid if isinstance(G, DeviceGrid) else G
         st = self.st = _abi.SetViscCS()
         # DYNAMIC_VISCOUS_ML (:2962) with BULK_RI_ML_VISC (= BULK_RI_ML), TKE_DECAY_VISC (= TKE_DECAY), ML_OMEGA_FRAC, OMEGA; GV%nkml
@@ -39,7 +40,14 @@ class set_visc_CS:
         st.TKE_decay = float(TKE_DECAY if TKE_DECAY_VISC is None else TKE_DECAY_VISC)
         st.omega_frac, st.omega = float(ML_OMEGA_FRAC), float(OMEGA)
         st.ustar_min = 2e-4 * st.omega * (g.Angstrom_H + g.H_subroundoff)      # :2998
-        st.c_Smag, st.Chan_drag_max_vol, st.concave_trigonometric_L = 0.15, -1.0, 1
+        # CHANNEL_DRAG (:3092-3122): SMAG_CONST_CHANNEL defaults to SMAG_LAP_CONST when that is given, else 0.15 (also when negative);
+        # CHANNEL_DRAG_MAX_BBL_THICK to HBBL/2 with USE_JACKSON_PARAM, HBBL with DRAG_AS_BODY_FORCE, else -1 (no fixed limit)
+        st.Channel_drag, st.concave_trigonometric_L, st.Z_ref = int(bool(CHANNEL_DRAG)), int(bool(TRIG_CHANNEL_DRAG_WIDTHS)), float(Z_ref)
+        c_smag = (SMAG_LAP_CONST if SMAG_LAP_CONST >= 0.0 else 0.15) if SMAG_CONST_CHANNEL is None else SMAG_CONST_CHANNEL
+        st.c_Smag = float(c_smag) if c_smag >= 0.0 else 0.15
+        if CHANNEL_DRAG_MAX_BBL_THICK is None:
+            CHANNEL_DRAG_MAX_BBL_THICK = float(HBBL) if DRAG_AS_BODY_FORCE else (0.5 * float(HBBL) if USE_JACKSON_PARAM else -1.0)
+        st.Chan_drag_max_vol = float(CHANNEL_DRAG_MAX_BBL_THICK)
         for k, v in unsupported.items():
             if k not in _UNSUPPORTED:
                 raise Mom6HipError(f"set_visc_init: unknown parameter {k}")

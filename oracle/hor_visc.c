@@ -250,6 +250,8 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
   const long nH = (long)ORC_NIH(G) * ORC_NJH(G), nU = (long)(ORC_NIH(G) + 1) * ORC_NJH(G);
   const long nV = (long)ORC_NIH(G) * (ORC_NJH(G) + 1), nQ = (long)(ORC_NIH(G) + 1) * (ORC_NJH(G) + 1);
 
+  /* MEKE%mom_src: the frictional work of each layer, then its sum over the layers in order (:1833-1889 with backscatter_Ro_c = 0) */
+  double *FrictWork = CS->MEKE_mom_src ? (double *)calloc((size_t)nH * nz, 8) : NULL;
   /* the layers are independent (the reference: !$OMP parallel do over k, :634-680); the 2-D work arrays are per thread */
   _Pragma("omp parallel")
   {
@@ -345,6 +347,7 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
         }
         if (legacy_bound) K_ = min2(K_, CS->Kh_Max_xx[H2(i,j)]);
         K_ = max2(K_, CS->Kh_bg_min);
+        if (CS->MEKE_Ku) K_ = K_ + CS->MEKE_Ku[H2(i,j)];      /* :1141-1151 */
         if (CS->better_bound_Kh) {
           if (K_ >= HQ(hrat_min,i,j) * CS->Kh_Max_xx[H2(i,j)]) {
             HQ(visc_bound_rem,i,j) = 0.0;
@@ -371,6 +374,7 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
           A_ = max2(A_, AhSm);
           if (CS->bound_Ah && !CS->better_bound_Ah) A_ = min2(A_, CS->Ah_Max_xx[H2(i,j)]);
         }
+        if (CS->MEKE_Au) A_ = A_ + CS->MEKE_Au[H2(i,j)];      /* :1318-1323 */
         if (CS->better_bound_Ah) {
           if (CS->better_bound_Kh) A_ = min2(A_, HQ(visc_bound_rem,i,j) * HQ(hrat_min,i,j) * CS->Ah_Max_xx[H2(i,j)]);
           else A_ = min2(A_, HQ(hrat_min,i,j) * CS->Ah_Max_xx[H2(i,j)]);
@@ -443,6 +447,10 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
         }
         if (legacy_bound) K_ = min2(K_, CS->Kh_Max_xy[Q2(I,J)]);
         K_ = max2(K_, CS->Kh_bg_min);
+        if (CS->MEKE_Ku) {      /* :1537-1541 (meke_res_fn = 1) */
+          const int i = I, j = J;
+          K_ = K_ + 0.25 * ((CS->MEKE_Ku[H2(i,j)] + CS->MEKE_Ku[H2(i+1,j+1)]) + (CS->MEKE_Ku[H2(i+1,j)] + CS->MEKE_Ku[H2(i,j+1)])) * 1.0;
+        }
         if (CS->better_bound_Kh) {
           if (K_ >= hrat_min[Q2(I,J)] * CS->Kh_Max_xy[Q2(I,J)]) {
             visc_bound_rem[Q2(I,J)] = 0.0;
@@ -468,6 +476,10 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
             AhSm = CS->Biharm_const_xy[Q2(I,J)] * Shear_mag[Q2(I,J)];
           A_ = max2(A_, AhSm);
           if (CS->bound_Ah && !CS->better_bound_Ah) A_ = min2(A_, CS->Ah_Max_xy[Q2(I,J)]);
+        }
+        if (CS->MEKE_Au) {      /* :1634-1639 */
+          const int i = I, j = J;
+          A_ = A_ + 0.25 * ((CS->MEKE_Au[H2(i,j)] + CS->MEKE_Au[H2(i+1,j+1)]) + (CS->MEKE_Au[H2(i+1,j)] + CS->MEKE_Au[H2(i,j+1)]));
         }
         if (CS->better_bound_Ah) {
           if (CS->better_bound_Kh) A_ = min2(A_, visc_bound_rem[Q2(I,J)] * hrat_min[Q2(I,J)] * CS->Ah_Max_xy[Q2(I,J)]);
@@ -497,10 +509,38 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
                            G->IdxCv[V2(i,J)] * (dx2h(i,j) * str_xx[H2(i,j)] - dx2h(i,j+1) * str_xx[H2(i,j+1)])) *
                           G->IareaCv[V2(i,J)]) / (h_v[V2(i,J)] + h_neglect);
     }
+    if (FrictWork) {      /* :1783-1800 */
+      for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+        const int I = i, J = j;
+        FrictWork[H3(i,j,k)] = G->H_to_Z * G->Rho0 * (
+                (str_xx[H2(i,j)] * (u[U3(I,j,k)] - u[U3(I-1,j,k)]) * G->IdxT[H2(i,j)]
+               - str_xx[H2(i,j)] * (v[V3(i,J,k)] - v[V3(i,J-1,k)]) * G->IdyT[H2(i,j)])
+            + 0.25 * ((str_xy[Q2(I,J)] *
+                       ((u[U3(I,j+1,k)] - u[U3(I,j,k)]) * G->IdyBu[Q2(I,J)]
+                      + (v[V3(i+1,J,k)] - v[V3(i,J,k)]) * G->IdxBu[Q2(I,J)])
+                     + str_xy[Q2(I-1,J-1)] *
+                       ((u[U3(I-1,j,k)] - u[U3(I-1,j-1,k)]) * G->IdyBu[Q2(I-1,J-1)]
+                      + (v[V3(i,J-1,k)] - v[V3(i-1,J-1,k)]) * G->IdxBu[Q2(I-1,J-1)]))
+                    + (str_xy[Q2(I-1,J)] *
+                       ((u[U3(I-1,j+1,k)] - u[U3(I-1,j,k)]) * G->IdyBu[Q2(I-1,J)]
+                      + (v[V3(i,J,k)] - v[V3(i-1,J,k)]) * G->IdxBu[Q2(I-1,J)])
+                     + str_xy[Q2(I,J-1)] *
+                       ((u[U3(I,j,k)] - u[U3(I,j-1,k)]) * G->IdyBu[Q2(I,J-1)]
+                      + (v[V3(i+1,J-1,k)] - v[V3(i,J-1,k)]) * G->IdxBu[Q2(I,J-1)]))));
+      }
+    }
   }
   free(dudx); free(dvdy); free(sh_xx); free(str_xx); free(dvdx); free(dudy); free(sh_xy); free(str_xy); free(hq);
   free(dDel2vdx); free(dDel2udy); free(h_u); free(Del2u); free(h_v); free(Del2v);
   free(Ah); free(Kh); free(Shear_mag); free(hrat_min); free(visc_bound_rem);
+  }
+  if (FrictWork) {
+    for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {
+      double src = 0.;
+      for (int k = 1; k <= nz; k++) src = src + FrictWork[H3(i,j,k)];
+      CS->MEKE_mom_src[H2(i,j)] = src;
+    }
+    free(FrictWork);
   }
   return 0;
 }

@@ -151,6 +151,8 @@ int orc_pressureforce_fv_nonbouss(const mom6hip_grid_t *G, const mom6hip_pressur
 /* ---- MOM_barotropic (oracle/barotropic.c) ----------------------------------------------------- */
 double orc_cr_exp(double t);             /* correctly rounded exp(t), t <= 0 (0 below -700) */
 double orc_cr_pow(double x, double y);   /* correctly rounded x**y, 0 < x <= 1, 0 < y <= 1 */
+double orc_cr_cos(double x);             /* correctly rounded cos(x), |x| <= pi (cr_trig.c) */
+double orc_cr_acos(double x);            /* correctly rounded acos(x), |x| <= 1 (cr_trig.c) */
 int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS);
 int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
                const double *h_v, int may_use_default);

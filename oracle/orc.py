@@ -677,13 +677,18 @@ def vertvisc_remnant(grid, cs, visc, visc_rem_u, visc_rem_v, dt):
 # ---- MOM_set_viscosity -------------------------------------------------------------------------------------------
 def set_visc_cs(grid, Hbbl, Kv, cdrag=0.003, drag_bg_vel=0.0, BBL_thick_min=0.0, Kv_BBL_min=None, bottomdraglaw=True, linear_drag=False,
                 BBL_use_EOS=True, correct_BBL_bounds=False, body_force_drag=False, RiNo_mix=False, Rlay=None, dynamic_viscous_ML=False,
-                nkml=0, bulk_Ri_ML=0.0, TKE_decay=0.0, omega_frac=0.0, omega=7.2921e-5, **unsupported):
+                nkml=0, bulk_Ri_ML=0.0, TKE_decay=0.0, omega_frac=0.0, omega=7.2921e-5, Channel_drag=False, c_Smag=0.15, Chan_drag_max_vol=None,
+                concave_trigonometric_L=True, Z_ref=0.0, **unsupported):
     """mom6hip_set_visc_cs_t with the defaults of set_visc_init (MOM_set_viscosity.F90:2886-3190)."""
     cs = _abi.SetViscCS()
     cs.dynamic_viscous_ML, cs.nkml, cs.bulk_Ri_ML, cs.TKE_decay, cs.omega_frac, cs.omega = (int(dynamic_viscous_ML), int(nkml), bulk_Ri_ML,
                                                                                           TKE_decay, omega_frac, omega)
     cs.ustar_min = 2e-4 * omega * (grid.Angstrom_H + grid.H_subroundoff)      # :2998
-    cs.c_Smag, cs.Chan_drag_max_vol, cs.concave_trigonometric_L = 0.15, -1.0, 1
+    # CHANNEL_DRAG (:3092-3122): CHANNEL_DRAG_MAX_BBL_THICK defaults to HBBL/2 with kappa shear, HBBL with DRAG_AS_BODY_FORCE, else none
+    if Chan_drag_max_vol is None:
+        Chan_drag_max_vol = Hbbl if body_force_drag else (0.5 * Hbbl if RiNo_mix else -1.0)
+    cs.Channel_drag, cs.c_Smag, cs.Chan_drag_max_vol, cs.concave_trigonometric_L, cs.Z_ref = (int(Channel_drag), c_Smag, Chan_drag_max_vol,
+                                                                                            int(concave_trigonometric_L), Z_ref)
     cs.cdrag, cs.drag_bg_vel, cs.dz_bbl, cs.Hbbl = cdrag, drag_bg_vel, Hbbl, Hbbl * grid.Z_to_H
     cs.BBL_thick_min, cs.Kv_BBL_min, cs.BBL_thick_max = BBL_thick_min, (Kv if Kv_BBL_min is None else Kv_BBL_min), 6.378e6
     cs.H_to_RZ = grid.Rho0 * grid.H_to_Z
@@ -721,6 +726,16 @@ def cr_exp(t):
     return L.orc_cr_exp(float(t))
 
 
+def cr_cos(x):
+    L = lib(); L.orc_cr_cos.argtypes = [C.c_double]; L.orc_cr_cos.restype = C.c_double
+    return L.orc_cr_cos(float(x))
+
+
+def cr_acos(x):
+    L = lib(); L.orc_cr_acos.argtypes = [C.c_double]; L.orc_cr_acos.restype = C.c_double
+    return L.orc_cr_acos(float(x))
+
+
 # ---- MOM_hor_visc ---------------------------------------------------------------------------------------------------
 def hor_visc_cs(grid, dt, **kw):
     """mom6hip_hor_visc_cs_t with the defaults of hor_visc_init (MOM_hor_visc.F90:2062-2300), numpy arrays behind its
@@ -752,6 +767,14 @@ def hor_visc_cs(grid, dt, **kw):
     if rc:
         raise RuntimeError(f"orc_hor_visc_init rc={rc}: an option of MOM_hor_visc that is not provided")
     return cs
+
+
+def hor_visc_set_meke(cs, Ku=None, Au=None, mom_src=None):
+    """the MEKE argument of horizontal_viscosity: MEKE%Ku, MEKE%Au, MEKE%mom_src (numpy h-point 2-D arrays or None)"""
+    cs._meke = [None if a is None else np.ascontiguousarray(a) for a in (Ku, Au, mom_src)]
+    for n, a in zip(("MEKE_Ku", "MEKE_Au", "MEKE_mom_src"), cs._meke):
+        setattr(cs, n, None if a is None else a.ctypes.data)
+    return cs._meke[2]
 
 
 def horizontal_viscosity(grid, cs, u, v, h, dt, hu_cont=None, hv_cont=None, diffu=None, diffv=None):

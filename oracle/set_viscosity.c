@@ -4,8 +4,8 @@
  * Reference: src/parameterizations/vertical/MOM_set_viscosity.F90
  *   set_viscous_BBL :134-1100, set_v_at_u :1804, set_u_at_v :1849, set_viscous_ML :1898 (the early return :2043, and the
  *   DYNAMIC_VISCOUS_ML search :2111-2230, :2400-2506; its exp through orc_cr_exp, correctly rounded)
- * Restated branch: BOTTOMDRAGLAW, quadratic or LINEAR_DRAG law, BBL_USE_EOS or GV%Rlay as the density variable, no channel
- * drag, no tidal background velocity, Boussinesq (no tv%SpV_avg), no tv%p_surf, no OBC; DRAG_AS_BODY_FORCE; CORRECT_BBL_BOUNDS.
+ * Restated branch: BOTTOMDRAGLAW, quadratic or LINEAR_DRAG law, BBL_USE_EOS or GV%Rlay as the density variable, CHANNEL_DRAG
+ * (:863-1002 with find_L_open_* :1104-1800), no tidal background velocity, Boussinesq (no tv%SpV_avg), no tv%p_surf, no OBC; DRAG_AS_BODY_FORCE; CORRECT_BBL_BOUNDS.
  * PARITY UNPINNED: the reference holds no known-answer vectors for this module; invariants in tests/test_set_viscosity.py.
  */
 #include <math.h>
@@ -51,6 +51,264 @@ static double set_u_at_v(const mom6hip_grid_t *G, const double *u, const double 
     r = ((hwt[1][0] * u[U3(I, j, k)] + hwt[0][1] * u[U3(I - 1, j + 1, k)]) +
          (hwt[0][0] * u[U3(I - 1, j, k)] + hwt[1][1] * u[U3(I, j + 1, k)])) / hwt_tot;
   return r;
+}
+
+
+/* ---- CHANNEL_DRAG: the normalized open width L(K) of a velocity cell at each interface (arrays indexed 1..nz+1) ------------------- */
+#define C1_3 (1.0 / 3.0)
+#define C1_6 (1.0 / 6.0)
+#define C1_12 (1.0 / 12.0)
+#define C2PI_3 (8.0 * 0.78539816339744830962 / 3.0)      /* 8.0*atan(1.0)/3.0 */
+
+/* find_L_open_uniform_slope :1104-1140 */
+static void find_L_open_uniform_slope(int nz, const double *vol_below, double Dp, double Dm, double *L) {
+  const double slope = fabs(Dp - Dm);
+  if (slope == 0.0) {
+    for (int K = 1; K <= nz; K++) L[K] = 1.0;
+    L[nz + 1] = 0.0;
+  } else {
+    const double Vol_open = 0.5 * slope, I_slope = 1.0 / slope;
+    L[nz + 1] = 0.0;
+    for (int K = nz; K >= 1; K--) {
+      if (vol_below[K] >= Vol_open) L[K] = 1.0;
+      else L[K] = sqrt(2.0 * vol_below[K] * I_slope);
+    }
+  }
+}
+
+/* find_L_open_concave_trigonometric :1144-1231 (cos and acos correctly rounded: cr_trig.c) */
+static void find_L_open_concave_trigonometric(int nz, const double *vol_below, double D_vel, double Dp, double Dm, double *L) {
+  const double crv_3 = (Dp + Dm - (2.0 * D_vel)), crv = 3.0 * crv_3;
+  const double slope = Dp - Dm;
+  double Vol_open, Vol_2_reg;
+  if (slope >= crv) {
+    Vol_open = D_vel - Dm; Vol_2_reg = Vol_open;
+  } else {
+    const double slope_crv = slope / crv;
+    Vol_open = 0.25 * slope * slope_crv + C1_12 * crv;
+    Vol_2_reg = 0.5 * (slope_crv * slope_crv) * (crv - C1_3 * slope);
+  }
+  const double C24_crv = 24.0 / crv, Iapb = 1.0 / (crv + slope);
+  const double apb_4a = (slope + crv) / (4.0 * crv), a2x48_apb3 = (48.0 * (crv * crv)) * ((Iapb * Iapb) * Iapb);
+  const double ax2_3apb = 2.0 * C1_3 * crv * Iapb;
+  L[nz + 1] = 0.0;
+  for (int K = nz; K >= 1; K--) {
+    if (vol_below[K] >= Vol_open) {
+      L[K] = 1.0;
+    } else if (vol_below[K] < Vol_2_reg) {
+      if (a2x48_apb3 * vol_below[K] < 1e-8) {
+        const double L0 = sqrt(2.0 * vol_below[K] * Iapb);
+        L[K] = L0 * (1.0 + (ax2_3apb * L0));
+      } else {
+        L[K] = apb_4a * (1.0 - 2.0 * orc_cr_cos(C1_3 * orc_cr_acos((a2x48_apb3 * vol_below[K]) - 1.0) - C2PI_3));
+      }
+    } else {
+      double tmp_val_m1_to_p1 = 1.0 - C24_crv * (Vol_open - vol_below[K]);
+      tmp_val_m1_to_p1 = max2(-1., min2(1., tmp_val_m1_to_p1));
+      L[K] = 0.5 - orc_cr_cos(C1_3 * orc_cr_acos(tmp_val_m1_to_p1) - C2PI_3);
+    }
+  }
+}
+
+/* find_L_open_concave_iterative :1237-1556 */
+static void find_L_open_concave_iterative(int nz, const double *vol_below, double D_vel, double Dp, double Dm, double *L) {
+  const int max_itt = 10;
+  const double crv_3 = (Dp + Dm - 2.0 * D_vel), crv = 3.0 * crv_3;
+  const double slope = Dp - Dm;
+  double Vol_open, Vol_2_reg, L_2_reg, L_inflect_1, vol_inflect_1, vol_inflect_2 = 0.0, slope_crv = 0.0, smc = 0.0, C3c_m_s = 0.0, I_3c_m_s = 0.0;
+  double C4_crv = 0.0, slope2_4crv = 0.0, sxcms_c = 0.0, C3s_m_c = 0.0, I_3s_m_c = 0.0;
+  if (slope >= crv) {
+    Vol_open = D_vel - Dm; Vol_2_reg = Vol_open;
+    L_2_reg = 1.0;
+    if (crv + slope >= 4.0 * crv) {
+      L_inflect_1 = 1.0; vol_inflect_1 = Vol_open;
+    } else {
+      slope_crv = slope / crv;
+      L_inflect_1 = 0.25 + 0.25 * slope_crv;
+      vol_inflect_1 = 0.25 * C1_12 * (((slope_crv + 1.0) * (slope_crv + 1.0)) * (slope + crv));
+    }
+    smc = slope - crv;
+    C3c_m_s = 3.0 * crv - slope;
+    if (C3c_m_s > 2.0 * smc) I_3c_m_s = 1.0 / C3c_m_s;
+  } else {
+    slope_crv = slope / crv;
+    Vol_open = 0.25 * slope * slope_crv + C1_12 * crv;
+    Vol_2_reg = 0.5 * (slope_crv * slope_crv) * (crv - C1_3 * slope);
+    L_2_reg = slope_crv;
+    vol_inflect_1 = 0.25 * C1_12 * (((slope_crv + 1.0) * (slope_crv + 1.0)) * (slope + crv));
+    L_inflect_1 = 0.25 + 0.25 * slope_crv;
+    vol_inflect_2 = 0.25 * slope * slope_crv + 0.125 * crv_3;
+    C4_crv = 4.0 / crv;
+    slope2_4crv = 0.25 * slope * slope_crv;
+    sxcms_c = slope_crv * (crv - slope);
+    C3s_m_c = 3.0 * slope - crv;
+    if (C3s_m_c > 2.0 * sxcms_c) I_3s_m_c = 1.0 / C3s_m_c;
+  }
+  const double Icrvpslope = 1.0 / (crv + slope);
+#define VERR1(Lk) (0.5 * ((Lk) * (Lk)) * (slope + crv * (1.0 - 4.0 * C1_3 * (Lk))) - vol_below[K])
+#define VERR2(Lk) (crv_3 * (((Lk) * (Lk)) * (0.75 - 0.5 * (Lk))) + (slope2_4crv - vol_below[K]))
+  L[nz + 1] = 0.0;
+  for (int K = nz; K >= 1; K--) {
+    double L_max, L_min, vol_err, dVol_dL, vol_err_max;
+    if (vol_below[K] >= Vol_open) {
+      L[K] = 1.0;
+    } else if (vol_below[K] < Vol_2_reg) {
+      L_max = min2(L_2_reg, 1.0);
+      if (vol_below[K] <= vol_inflect_1) L_max = min2(L_max, L_inflect_1);
+      L_min = L[K + 1];
+      if (vol_below[K] >= vol_inflect_1) L_min = max2(L_min, L_inflect_1);
+      if (2.0 * vol_below[K] * Icrvpslope > L_min * L_min) L_min = sqrt(2.0 * vol_below[K] * Icrvpslope);
+      L[K] = L_min;
+      if (vol_below[K] <= vol_inflect_1) {
+        L[K] = L_min;
+        vol_err = VERR1(L[K]);
+        if (vol_err < 0.0) {
+          dVol_dL = L[K] * (slope + crv * (1.0 - 2.0 * L[K]));
+          if (L[K] * dVol_dL > vol_err + L_max * dVol_dL) L[K] = L_max;
+          else L[K] = L[K] - (vol_err / dVol_dL);
+          for (int itt = 1; itt <= max_itt; itt++) {
+            vol_err = VERR1(L[K]);
+            dVol_dL = L[K] * (slope + crv * (1.0 - 2.0 * L[K]));
+            if (fabs(vol_err) < max2(1.0e-15 * L[K], 1.0e-25) * dVol_dL) break;
+            L[K] = L[K] - (vol_err / dVol_dL);
+          }
+        }
+      } else {
+        L[K] = L_min;
+        vol_err = VERR1(L[K]);
+        if (vol_err < 0.0) {
+          if (slope < crv) {
+            if ((L_2_reg - L_min) * C3s_m_c > 2.0 * sxcms_c)
+              L_max = (slope_crv * (2.0 * slope) - sqrt(sxcms_c * sxcms_c + 2.0 * C3s_m_c * (Vol_2_reg - vol_below[K]))) * I_3s_m_c;
+            else
+              L_max = slope_crv;
+          } else {
+            if ((1.0 - L_min) * C3c_m_s > 2.0 * smc)
+              L_max = (2.0 * crv - sqrt(smc * smc + 2.0 * C3c_m_s * (Vol_open - vol_below[K]))) * I_3c_m_s;
+            else
+              L_max = 1.0;
+          }
+          vol_err_max = VERR1(L_max);
+          if ((vol_err_max < fabs(vol_err)) && (L_max < 1.0)) {
+            dVol_dL = L_max * (slope + crv * (1.0 - 2.0 * L_max));
+            L[K] = max2(L_min, L_max - (vol_err_max / dVol_dL));
+          }
+          for (int itt = 1; itt <= max_itt; itt++) {
+            vol_err = VERR1(L[K]);
+            dVol_dL = L[K] * (slope + crv * (1.0 - 2.0 * L[K]));
+            if (fabs(vol_err) < max2(1.0e-15 * L[K], 1.0e-25) * dVol_dL) break;
+            L[K] = L[K] - (vol_err / dVol_dL);
+          }
+        }
+      }
+    } else {      /* two separate open regions */
+      if (vol_below[K] <= vol_inflect_2) {
+        L_min = max2(L[K + 1], L_2_reg);
+        if ((4.0 * vol_below[K] - slope * slope_crv) > (crv + 2.0 * C1_3 * slope) * (L_min * L_min))
+          L_min = max2(L_min, sqrt((4.0 * vol_below[K] - slope * slope_crv) / (crv + 2.0 * C1_3 * slope)));
+        L_max = 0.5;
+        L[K] = L_min;
+        vol_err = crv_3 * (L[K] * L[K]) * (0.75 - 0.5 * L[K]) + (slope2_4crv - vol_below[K]);
+        if (vol_err < 0.0) {
+          dVol_dL = 0.5 * crv * (L[K] * (1.0 - L[K]));
+          if (L[K] * dVol_dL >= vol_err + L_max * dVol_dL) L[K] = L_max;
+          else L[K] = L[K] - (vol_err / dVol_dL);
+          for (int itt = 1; itt <= max_itt; itt++) {
+            vol_err = VERR2(L[K]);
+            dVol_dL = 0.5 * crv * (L[K] * (1.0 - L[K]));
+            if (fabs(vol_err) < max2(1.0e-15 * L[K], 1.0e-25) * dVol_dL) break;
+            L[K] = L[K] - (vol_err / dVol_dL);
+          }
+        }
+      } else {
+        L_min = max2(L[K + 1], 0.5);
+        L[K] = L_min;
+        vol_err = VERR2(L[K]);
+        if (vol_err < 0.0) {
+          L_max = 1.0 - sqrt((Vol_open - vol_below[K]) * C4_crv);
+          vol_err_max = VERR2(L_max);
+          if ((vol_err_max < fabs(vol_err)) && (L_max < 1.0)) {
+            dVol_dL = 0.5 * crv * (L_max * (1.0 - L_max));
+            L[K] = max2(L_min, L_max - (vol_err_max / dVol_dL));
+          }
+          for (int itt = 1; itt <= max_itt; itt++) {
+            vol_err = VERR2(L[K]);
+            dVol_dL = 0.5 * crv * (L[K] * (1.0 - L[K]));
+            if (fabs(vol_err) < max2(1.0e-15 * L[K], 1.0e-25) * dVol_dL) break;
+            L[K] = L[K] - (vol_err / dVol_dL);
+          }
+        }
+      }
+    }
+  }
+#undef VERR1
+#undef VERR2
+}
+
+/* find_L_open_convex :1640-1800, SET_VISC_ANSWER_DATE >= 20190101; the cube root through orc_cr_pow.  Angstrom_Z = GV%Angstrom_Z,
+ * dZ_subroundoff = GV%dZ_subroundoff */
+static void find_L_open_convex(int nz, const double *vol_below, double D_vel, double Dp, double Dm, double *L, double Angstrom_Z,
+                               double dZ_subroundoff) {
+  const int maxitt = 20;
+  const double crv_3 = (Dp + Dm - 2.0 * D_vel), crv = 3.0 * crv_3;
+  const double slope = Dp - Dm;
+  const double Vol_open = D_vel - Dm;
+  double Vol_direct, L_direct, C24_crv;
+  if (slope >= -crv) {
+    Vol_direct = 0.0; L_direct = 0.0; C24_crv = 0.0;
+  } else {
+    C24_crv = 24.0 / crv;
+    L_direct = 1.0 + slope / crv;
+    Vol_direct = -C1_6 * crv * ((L_direct * L_direct) * L_direct);
+  }
+  const double Ibma_2 = 2.0 / (slope - crv);
+  double Vol_err = 0.0;
+  L[nz + 1] = 0.0;
+#define VERR(Lk) (0.5 * ((Lk) * (Lk)) * (slope + crv_3 * (3.0 - 4.0 * (Lk))) - vol_below[K])
+  for (int K = nz; K >= 1; K--) {
+    if (vol_below[K] >= Vol_open) {
+      L[K] = 1.0;
+    } else if (vol_below[K] <= Vol_direct) {
+      const double x = -0.25 * C24_crv * vol_below[K];
+      L[K] = (x > 0.0) ? orc_cr_pow(x, C1_3) : 0.0;
+    } else {
+      double L0, Vol_0;
+      if (vol_below[K + 1] + Vol_err <= Vol_direct) { L0 = L_direct; Vol_0 = Vol_direct; }
+      else { L0 = L[K + 1]; Vol_0 = vol_below[K + 1] + Vol_err; }
+      const double dV_dL2 = 0.5 * (slope + crv) - crv * L0, dVol = (vol_below[K] - Vol_0);
+      const int use_L0 = (dVol <= 0.);
+      const double Vol_tol = max2(0.5 * Angstrom_Z + dZ_subroundoff, 1e-14 * vol_below[K]);
+      const double Vol_quit = max2(0.9 * Angstrom_Z + dZ_subroundoff, 1e-14 * vol_below[K]);
+      const double curv_tol = Vol_tol * (dV_dL2 * dV_dL2) * (dV_dL2 * Vol_tol - 2.0 * crv * L0 * dVol);
+      const int do_one_L_iter = (crv * crv * ((dVol * dVol) * dVol)) < curv_tol;
+      if (use_L0) {
+        L[K] = L0;
+        Vol_err = VERR(L[K]);
+      } else if (do_one_L_iter) {
+        L[K] = sqrt(L0 * L0 + dVol / dV_dL2);
+        Vol_err = VERR(L[K]);
+      } else {
+        double L_max, L_min;
+        if (dV_dL2 * (1.0 - L0 * L0) < dVol + dV_dL2 * (Vol_open - vol_below[K]) * Ibma_2)
+          L_max = sqrt(1.0 - (Vol_open - vol_below[K]) * Ibma_2);
+        else
+          L_max = sqrt(L0 * L0 + dVol / dV_dL2);
+        L_min = sqrt(L0 * L0 + dVol / (0.5 * (slope + crv) - crv * L_max));
+        const double Vol_err_min = VERR(L_min), Vol_err_max = VERR(L_max);
+        if (fabs(Vol_err_min) <= Vol_quit) {
+          L[K] = L_min; Vol_err = Vol_err_min;
+        } else {
+          L[K] = sqrt(((L_min * L_min) * Vol_err_max - (L_max * L_max) * Vol_err_min) / (Vol_err_max - Vol_err_min));
+          for (int itt = 1; itt <= maxitt; itt++) {
+            Vol_err = VERR(L[K]);
+            if (fabs(Vol_err) <= Vol_quit) break;
+            L[K] = L[K] - Vol_err / (L[K] * (slope + crv - 2.0 * crv * L[K]));
+          }
+        }
+      }
+    }
+  }
+#undef VERR
 }
 
 static int unsupported(const mom6hip_set_visc_cs_t *CS) {
@@ -204,7 +462,7 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
   double *Kv_bbl_u = (double *)visc->Kv_bbl_u, *Kv_bbl_v = (double *)visc->Kv_bbl_v;
   double *Ray_u = (double *)visc->Ray_u, *Ray_v = (double *)visc->Ray_v;
   if (!bbl_thick_u || !bbl_thick_v) return 2;
-  if (CS->body_force_drag && !(Ray_u && Ray_v)) return 2;
+  if ((CS->body_force_drag || CS->Channel_drag) && !(Ray_u && Ray_v)) return 2;
   const double cdrag_sqrt = sqrt(CS->cdrag);
   const double cdrag_sqrt_H = cdrag_sqrt * 1.0 * G->Z_to_H;      /* US%L_to_m*GV%m_to_H */
   const double cdrag_L_to_H = CS->cdrag * 1.0 * G->Z_to_H;
@@ -218,7 +476,8 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
   for (int j = Jsq; j <= Jeq; j++) for (int m = 1; m <= 2; m++) {
     if (m == 1 && j < G->jsc) continue;
     const int is = (m == 1) ? Isq : G->isc, ie = (m == 1) ? Ieq : G->iec;
-    double h_at_vel[nz + 1], dz_at_vel[nz + 1], h_vel[nz + 1], T_vel[nz + 1], S_vel[nz + 1];
+    double h_at_vel[nz + 1], dz_at_vel[nz + 1], h_vel[nz + 1], dz_vel[nz + 1], T_vel[nz + 1], S_vel[nz + 1];
+    double vol_below[nz + 2], L[nz + 2];
     for (int i = is; i <= ie; i++) {
       const int I = i, J = j;
       const int ip = (m == 1) ? i + 1 : i, jp = (m == 1) ? j : j + 1;      /* the cell on the other side of the face */
@@ -237,6 +496,7 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
           dz_at_vel[k] = 0.5 * (d0 + d1);
         }
         h_vel[k] = 0.5 * (h0 + h1);
+        dz_vel[k] = 0.5 * (d0 + d1);
         if (use_BBL_EOS) { T_vel[k] = 0.5 * (T[H3(i, j, k)] + T[H3(ip, jp, k)]); S_vel[k] = 0.5 * (S[H3(i, j, k)] + S[H3(ip, jp, k)]); }
       }
       /* the near-bottom velocity magnitude and ustar :565-660 */
@@ -354,10 +614,85 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
         bbl_thick = dztot / (0.5 + sqrt(0.25 + htot * htot * C2f * C2f / (ustar * ustar)));
         if (bbl_thick < CS->BBL_thick_min) bbl_thick = CS->BBL_thick_min;
       }
+      const double bbl_thick_before_caps = bbl_thick;
       if ((bbl_thick > 0.5 * CS->dz_bbl) && (CS->RiNo_mix)) bbl_thick = 0.5 * CS->dz_bbl;
       if (CS->body_force_drag) bbl_thick = dz_bbl_drag;
-      /* not channel drag :1010-1022 */
+      double Vol_bbl_chan = bbl_thick_before_caps;      /* :849 (stored before the RiNo_mix and body-force overrides) */
       double kv_bbl;
+      if (CS->Channel_drag) {      /* :863-1002 */
+        vol_below[nz + 1] = 0.0;
+        for (int K = nz; K >= 1; K--) vol_below[K] = vol_below[K + 1] + dz_vel[K];
+        double D_vel, Dp, Dm, tmp;
+#define D_U(I_, j_) (0.5 * (G->bathyT[ORC_H2(G, I_, j_)] + G->bathyT[ORC_H2(G, (I_) + 1, j_)]) + CS->Z_ref)
+#define D_V(i_, J_) (0.5 * (G->bathyT[ORC_H2(G, i_, J_)] + G->bathyT[ORC_H2(G, i_, (J_) + 1)]) + CS->Z_ref)
+        if (m == 1) {
+          D_vel = D_U(I, j);
+          tmp = G->mask2dCu[ORC_U2(G, I, j + 1)] * D_U(I, j + 1);
+          Dp = 2.0 * D_vel * tmp / (D_vel + tmp);
+          tmp = G->mask2dCu[ORC_U2(G, I, j - 1)] * D_U(I, j - 1);
+          Dm = 2.0 * D_vel * tmp / (D_vel + tmp);
+        } else {
+          D_vel = D_V(i, J);
+          tmp = G->mask2dCv[ORC_V2(G, i + 1, J)] * D_V(i + 1, J);
+          Dp = 2.0 * D_vel * tmp / (D_vel + tmp);
+          tmp = G->mask2dCv[ORC_V2(G, i - 1, J)] * D_V(i - 1, J);
+          Dm = 2.0 * D_vel * tmp / (D_vel + tmp);
+        }
+#undef D_U
+#undef D_V
+        if (Dm > Dp) { tmp = Dp; Dp = Dm; Dm = tmp; }
+        double crv = 3.0 * (Dp + Dm - 2.0 * D_vel);
+        const double slope = Dp - Dm;
+        if (fabs(crv) < 1e-2 * (slope + CS->BBL_thick_min)) crv = 0.0;
+        if (crv == 0.0) find_L_open_uniform_slope(nz, vol_below, Dp, Dm, L);
+        else if (crv > 0.0) {
+          if (CS->concave_trigonometric_L) find_L_open_concave_trigonometric(nz, vol_below, D_vel, Dp, Dm, L);
+          else find_L_open_concave_iterative(nz, vol_below, D_vel, Dp, Dm, L);
+        } else find_L_open_convex(nz, vol_below, D_vel, Dp, Dm, L, G->Angstrom_H * G->H_to_Z, dz_neglect);
+        if (CS->Chan_drag_max_vol >= 0.0) Vol_bbl_chan = min2(Vol_bbl_chan, CS->Chan_drag_max_vol);
+        double BBL_visc_frac = 0.0;
+        for (int K = nz; K >= 1; K--) {      /* (no porous barriers: por_layer_width = por_face_area = 1) */
+          double Rayleigh;
+          if (L[K] > L[K + 1]) {
+            double BBL_frac;
+            if (vol_below[K + 1] < Vol_bbl_chan) {
+              const double q = (1.0 - vol_below[K + 1] / Vol_bbl_chan);
+              BBL_frac = q * q;
+              BBL_visc_frac = BBL_visc_frac + BBL_frac * (L[K] - L[K + 1]);
+            } else {
+              BBL_frac = 0.0;
+            }
+            const double cdrag_conv = cdrag_L_to_H;
+            const double h_vel_pos = h_vel[K] + h_neglect;
+            const double Cell_width = (m == 1) ? G->dy_Cu[ORC_U2(G, I, j)] : G->dx_Cv[ORC_V2(G, i, J)];
+            const double gam = 1.0 - L[K + 1] / L[K];
+            Rayleigh = cdrag_conv * (L[K] - L[K + 1]) * (1.0 - BBL_frac) *
+                       (12.0 * CS->c_Smag * h_vel_pos) / (12.0 * CS->c_Smag * h_vel_pos +
+                                                          cdrag_conv * gam * (1.0 - gam) * (1.0 - 1.5 * gam) * (L[K] * L[K]) * Cell_width);
+          } else {
+            Rayleigh = 0.0;
+          }
+          if (m == 1) {
+            if (Rayleigh > 0.0) {
+              const double v_at_u = set_v_at_u(G, v, h, i, j, K);
+              Ray_u[U3(I, j, K)] = Rayleigh * sqrt(u[U3(I, j, K)] * u[U3(I, j, K)] + v_at_u * v_at_u + u2_bg);
+            } else Ray_u[U3(I, j, K)] = 0.0;
+          } else {
+            if (Rayleigh > 0.0) {
+              const double u_at_v = set_u_at_v(G, u, h, i, j, K);
+              Ray_v[V3(i, J, K)] = Rayleigh * sqrt(v[V3(i, J, K)] * v[V3(i, J, K)] + u_at_v * u_at_v + u2_bg);
+            } else Ray_v[V3(i, J, K)] = 0.0;
+          }
+        }
+        if (CS->correct_BBL_bounds && cdrag_sqrt * ustar * bbl_thick * BBL_visc_frac <= CS->Kv_BBL_min) {
+          kv_bbl = CS->Kv_BBL_min;
+          if ((cdrag_sqrt * ustar) * BBL_visc_frac * BBL_thick_max > kv_bbl) bbl_thick = kv_bbl / ((cdrag_sqrt * ustar) * BBL_visc_frac);
+          else bbl_thick = BBL_thick_max;
+        } else {
+          kv_bbl = (cdrag_sqrt * ustar) * bbl_thick * BBL_visc_frac;
+        }
+      } else
+      /* not channel drag :1004-1022 */
       if (CS->correct_BBL_bounds && cdrag_sqrt * ustar * bbl_thick <= CS->Kv_BBL_min) {
         kv_bbl = CS->Kv_BBL_min;
         if ((cdrag_sqrt * ustar) * BBL_thick_max > kv_bbl) bbl_thick = kv_bbl / (cdrag_sqrt * ustar);

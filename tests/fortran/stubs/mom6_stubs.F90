@@ -208,8 +208,8 @@ implicit none ; private
 public :: param_file_type, get_param, log_version, param_set
 type :: param_file_type
   integer :: n = 0
-  character(len=64)  :: names(64)
-  character(len=128) :: values(64)
+  character(len=64)  :: names(256)
+  character(len=128) :: values(256)
 end type param_file_type
 interface get_param
   module procedure get_param_logical, get_param_real, get_param_int, get_param_char, get_param_real_array
@@ -484,8 +484,8 @@ module MOM_MEKE_types
 implicit none ; private
 public :: MEKE_type
 type :: MEKE_type
-  real, allocatable :: Kh(:,:)
-  real :: KhTr_fac = 1.0
+  real, allocatable :: Kh(:,:), Ku(:,:), Au(:,:), mom_src(:,:), GME_snk(:,:)
+  real :: KhTr_fac = 1.0, backscatter_Ro_c = 0.0, backscatter_Ro_pow = 0.0
 end type MEKE_type
 end module MOM_MEKE_types
 
@@ -493,7 +493,7 @@ module MOM_lateral_mixing_coeffs
 implicit none ; private
 public :: VarMix_CS
 type :: VarMix_CS
-  logical :: use_variable_mixing = .false., Resoln_scaled_KhTr = .false.
+  logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false.
 end type VarMix_CS
 end module MOM_lateral_mixing_coeffs
 
@@ -519,15 +519,7 @@ public :: Wave_parameters_CS
 type :: Wave_parameters_CS
   logical :: Stokes_VF = .false.
 end type Wave_parameters_CS
-end module MOM_boundary_update
-implicit none ; private
-public :: update_OBC_CS
-type :: update_OBC_CS
-  integer :: unused = 0
-end type update_OBC_CS
-end module MOM_boundary_update
-
-module MOM_wave_interface
+end module MOM_wave_interface
 
 module MOM_tracer_registry
 implicit none ; private

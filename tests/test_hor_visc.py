@@ -89,6 +89,94 @@ def test_refuses_what_it_does_not_provide():
         orc.hor_visc_cs(g, DT, no_slip=1)      # NOSLIP and BIHARMONIC (the default) together
 
 
+def meke_fields(g, seed=11):
+    """MEKE%Ku (may be negative), MEKE%Au on h points with valid halos, and the array MEKE%mom_src goes to"""
+    rng = np.random.default_rng(seed)
+    Ku = np.ascontiguousarray(200.0 * (rng.random(g.shape2(H)) - 0.2) * g.mask2dT)
+    Au = np.ascontiguousarray(2.0e10 * rng.random(g.shape2(H)) * g.mask2dT)
+    orc.halo_update(g, Ku, H); orc.halo_update(g, Au, H)
+    return Ku, Au, np.full(g.shape2(H), -7.0)
+
+
+MEKE_VARIANTS = {
+    # .testing/tc2: LAPLACIAN + SMAGORINSKY_KH (0.06, KH_VEL_SCALE 0.05) and SMAGORINSKY_AH (0.06, AH_VEL_SCALE 0.05), MEKE%Ku
+    "tc2": (dict(Laplacian=1, Kh_vel_scale=0.05, Smagorinsky_Kh=1, Smag_Lap_const=0.06, Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06,
+                 use_land_mask=0), ("Ku", "mom_src")),
+    "ku_au": (dict(Laplacian=1, Kh=100.0, Ah_vel_scale=0.02), ("Ku", "Au", "mom_src")),
+    "au_only_biharmonic": (dict(Ah_vel_scale=0.01, Smagorinsky_Ah=1, Smag_bi_const=0.06), ("Au", "mom_src")),      # (the production kernel's flags)
+    "mom_src_only": (dict(Laplacian=1, Kh=300.0, biharmonic=0, no_slip=1, use_land_mask=0), ("mom_src",)),
+    "legacy_bounds": (dict(Laplacian=1, Kh=500.0, Smagorinsky_Kh=1, Smag_Lap_const=0.15, better_bound_Kh=0, Ah=1.0e11, better_bound_Ah=0,
+                           Smagorinsky_Ah=1, Smag_bi_const=0.06), ("Ku", "Au")),
+}
+
+
+def test_meke_viscosities_and_momentum_source():
+    """MEKE%Ku / MEKE%Au are added to the viscosities (:1141, :1318, :1537, :1634) and MEKE%mom_src is the column's frictional work
+    (:1783-1800, :1888): zero fields change nothing; a positive Ku takes more energy out; the work is negative almost everywhere
+    and, on a doubly periodic grid without land, its area integral is minus the dissipation computed from the accelerations"""
+    g, d = case(ni=36, nj=24, nk=2, land_frac=0.0, uniform=True, reentrant_y=True, spacing=20000.0)
+    for n, p in (("u", U), ("v", V), ("h", H)):
+        orc.halo_update(g, d[n], p)
+    kw = dict(Laplacian=1, Kh=200.0, Ah_vel_scale=0.05, use_land_mask=0)
+    base = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, DT, **kw), d["u"], d["v"], d["h"], DT)
+    cs = orc.hor_visc_cs(g, DT, **kw)
+    src = orc.hor_visc_set_meke(cs, Ku=np.zeros(g.shape2(H)), Au=np.zeros(g.shape2(H)), mom_src=np.full(g.shape2(H), -7.0))
+    same = orc.horizontal_viscosity(g, cs, d["u"], d["v"], d["h"], DT)
+    assert bits_equal(base[0], same[0]) and bits_equal(base[1], same[1])
+    si = interior(g, src, H)
+    assert np.all(src[0] == -7.0)                      # only the compute domain is written
+    assert (si < 0).mean() > 0.9
+    # the energy budget: sum over cells of FrictWork dA = Rho0 * sum over faces of h_face * vel * acceleration * dA (stress divergence by parts)
+    sj, sl = g.csl(H)
+    A = g.areaT[sj, sl][0, 0]
+    hu = 0.5 * (d["h"][:, sj, sl.start - 1:sl.stop] + d["h"][:, sj, sl.start:sl.stop + 1])
+    hv = 0.5 * (d["h"][:, sj.start - 1:sj.stop, sl] + d["h"][:, sj.start:sj.stop + 1, sl])
+    work = float((hu[:, :, 1:] * interior(g, d["u"], U)[:, :, 1:] * interior(g, base[0], U)[:, :, 1:]).sum())
+    work += float((hv[:, 1:, :] * interior(g, d["v"], V)[:, 1:, :] * interior(g, base[1], V)[:, 1:, :]).sum())
+    assert abs(si.sum() - g.Rho0 * g.H_to_Z * work) <= 1e-9 * abs(si.sum())
+    # a positive Ku: more dissipation
+    cs2 = orc.hor_visc_cs(g, DT, **kw)
+    src2 = orc.hor_visc_set_meke(cs2, Ku=np.full(g.shape2(H), 150.0), mom_src=np.zeros(g.shape2(H)))
+    orc.horizontal_viscosity(g, cs2, d["u"], d["v"], d["h"], DT)
+    assert interior(g, src2, H).sum() < 1.02 * si.sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(MEKE_VARIANTS))
+def test_gpu_parity_with_meke(name):
+    """horizontal_viscosity with the MEKE argument (Ku, Au in, mom_src out): library == oracle, bit for bit, staged and resident"""
+    import torch
+    from mom6_amd.hor_visc import hor_visc_init, horizontal_viscosity
+    from mom6_amd.tracer_advect import DeviceGrid
+    kw, members = MEKE_VARIANTS[name]
+    for (ni, nj, nk, topo, land) in [(70, 21, 3, (True, False), 0.25), (44, 40, 2, (True, True), 0.3), (10, 8, 8, (False, False), 0.2),
+                                     (300, 9, 5, (True, False), 0.25)]:
+        g = xs.make_grid(ni, nj, nk, land_frac=land, reentrant_x=topo[0], reentrant_y=topo[1])
+        d = xs.make_state(g, umax=0.3)
+        Ku, Au, src0 = meke_fields(g)
+        fields = {n: a for n, a in (("Ku", Ku), ("Au", Au), ("mom_src", src0)) if n in members}
+        cs_o = orc.hor_visc_cs(g, DT, **kw)
+        src_ref = orc.hor_visc_set_meke(cs_o, **{n: a.copy() for n, a in fields.items()})
+        ref = orc.horizontal_viscosity(g, cs_o, d["u"], d["v"], d["h"], DT)
+        plain = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, DT, **kw), d["u"], d["v"], d["h"], DT)
+        if "Ku" in members or "Au" in members:
+            assert not bits_equal(ref[0], plain[0])
+        dg = DeviceGrid(g)
+        for resident in (True, False):
+            CS = hor_visc_init(dg, DT, device_arrays=resident, USE_MEKE=True, **{REF_NAMES[k]: v for k, v in kw.items()})
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: a.copy())
+            du, dv = X(np.zeros_like(d["u"])), X(np.zeros_like(d["v"]))
+            M = {n: X(a) for n, a in fields.items()}
+            horizontal_viscosity(X(d["u"]), X(d["v"]), X(d["h"]), du, dv, M, None, dg, CS)
+            dg.sync()
+            assert bits_equal(N(du), ref[0]), (name, (ni, nj, nk), resident, "diffu")
+            assert bits_equal(N(dv), ref[1]), (name, (ni, nj, nk), resident, "diffv")
+            if "mom_src" in members:
+                assert bits_equal(N(M["mom_src"]), src_ref), (name, (ni, nj, nk), resident, "mom_src", np.argwhere(N(M["mom_src"]) != src_ref)[:3])
+        dg.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_gpu_parity(name):

@@ -18,9 +18,17 @@ VARIANTS = {
     "body_force": dict(body_force_drag=True),
     "correct_bounds": dict(correct_BBL_bounds=True, BBL_thick_min=0.1, Kv_BBL_min=2.0e-3),
     "rino_mix": dict(RiNo_mix=True),
+    # CHANNEL_DRAG (.testing/tc1, tc2 with USE_JACKSON_PARAM, DRAG_BG_VEL = 0.1, BBL_THICK_MIN = 0.1)
+    "channel_tc": dict(Channel_drag=True, RiNo_mix=True, drag_bg_vel=0.1, BBL_thick_min=0.1),
+    "channel": dict(Channel_drag=True),
+    "channel_iterative": dict(Channel_drag=True, concave_trigonometric_L=False, BBL_thick_min=0.1),
+    "channel_body_force": dict(Channel_drag=True, body_force_drag=True, drag_bg_vel=0.05),
+    "channel_bounds": dict(Channel_drag=True, correct_BBL_bounds=True, BBL_thick_min=0.1, Kv_BBL_min=2.0e-3, Chan_drag_max_vol=3.0, c_Smag=0.06),
 }
 REF = dict(BBL_use_EOS="BBL_USE_EOS", linear_drag="LINEAR_DRAG", drag_bg_vel="DRAG_BG_VEL", BBL_thick_min="BBL_THICK_MIN",
-           body_force_drag="DRAG_AS_BODY_FORCE", correct_BBL_bounds="CORRECT_BBL_BOUNDS", Kv_BBL_min="KV_BBL_MIN", RiNo_mix="USE_JACKSON_PARAM")
+           body_force_drag="DRAG_AS_BODY_FORCE", correct_BBL_bounds="CORRECT_BBL_BOUNDS", Kv_BBL_min="KV_BBL_MIN", RiNo_mix="USE_JACKSON_PARAM",
+           Channel_drag="CHANNEL_DRAG", concave_trigonometric_L="TRIG_CHANNEL_DRAG_WIDTHS", Chan_drag_max_vol="CHANNEL_DRAG_MAX_BBL_THICK",
+           c_Smag="SMAG_CONST_CHANNEL")
 
 
 def visc_arrays(g, d):
@@ -110,14 +118,14 @@ def run_oracle_ml(g, d, taux, tauy, arrs, dt=ML_DT, eos="WRIGHT", **kw):
 
 
 def test_set_viscous_ML_without_the_switch_and_refusals():
-    """without DYNAMIC_VISCOUS_ML set_viscous_ML returns at once (MOM_set_viscosity.F90:2043); CHANNEL_DRAG is still refused"""
+    """without DYNAMIC_VISCOUS_ML set_viscous_ML returns at once (MOM_set_viscosity.F90:2043); BBL_USE_TIDAL_BG is refused"""
     g = xs.make_grid(12, 10, 3)
     d = xs.make_state(g)
     taux, tauy, arrs = ml_inputs(g, d)
     visc = orc.vertvisc_type(**arrs)
     orc.set_viscous_ML(g, orc.set_visc_cs(g, 10.0, 1.0e-4), d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), taux, tauy, visc, 900.0)
     assert np.all(visc._keep["nkml_visc_u"] == -1.0)
-    cs3 = orc.set_visc_cs(g, 10.0, 1.0e-4, Channel_drag=True)
+    cs3 = orc.set_visc_cs(g, 10.0, 1.0e-4, BBL_use_tidal_bg=True)
     with pytest.raises(RuntimeError):
         orc.set_viscous_BBL(g, cs3, d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), orc.vertvisc_type(**visc_arrays(g, d)))
 
@@ -137,6 +145,110 @@ def test_cr_exp_is_the_correctly_rounded_exponential():
         assert got == want, (t, got, want)
         nlibm += got != math.exp(t) and t > -700.0
     assert nlibm < 0.01 * ts.size
+
+
+def test_cr_acos_and_cr_cos_are_correctly_rounded():
+    """find_L_open_concave_trigonometric (:1213-1225) calls cos(acos(x)/3 - 2 pi/3): both functions are evaluated correctly rounded
+    on both sides (oracle/cr_trig.c, csrc/cr_math.hpp): exact against 300-bit arithmetic; libm differs from them rarely, by one ulp"""
+    import math
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 300
+    rng = np.random.default_rng(5)
+    xa = np.concatenate([rng.uniform(-1, 1, 2000), 1 - 10.0 ** rng.uniform(-16, 0, 800), -1 + 10.0 ** rng.uniform(-16, 0, 800),
+                         10.0 ** rng.uniform(-300, -1, 100), [0.0, 1.0, -1.0, 0.5, -0.5]])
+    nl = 0
+    for x in xa:
+        got = orc.cr_acos(x)
+        assert got == float(mp.acos(mp.mpf(float(x)))), x
+        nl += got != math.acos(x)
+    assert nl < 0.01 * xa.size
+    xc = np.concatenate([rng.uniform(-math.pi, math.pi, 2000), rng.uniform(-2.0944, -1.0472, 2000), 10.0 ** rng.uniform(-300, 0, 100),
+                         [0.0, math.pi / 2, -math.pi / 2, math.pi]])
+    nl = 0
+    for x in xc:
+        got = orc.cr_cos(x)
+        assert got == float(mp.cos(mp.mpf(float(x)))), x
+        nl += got != math.cos(x)
+    assert nl < 0.01 * xc.size
+    assert np.isnan(orc.cr_acos(1.0000001)) and np.isnan(orc.cr_cos(4.0))
+
+
+def channel_geometry(g):
+    """the sign of the bottom curvature across each u face (:872-889): 0 uniform slope, +1 concave, -1 convex"""
+    D = 0.5 * (g.bathyT[:, :-1] + g.bathyT[:, 1:])      # D_u at I = isd .. ied-1 (columns 1 .. nih-1 of the u arrays)
+    m = g.mask2dCu[:, 1:-1]
+    Dc = D[1:-1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tp = m[2:] * D[2:]; Dp = 2.0 * Dc * tp / (Dc + tp)
+        tm = m[:-2] * D[:-2]; Dm = 2.0 * Dc * tm / (Dc + tm)
+    lo, hi = np.minimum(Dp, Dm), np.maximum(Dp, Dm)
+    crv = 3.0 * (hi + lo - 2.0 * Dc)
+    kind = np.sign(np.where(np.abs(crv) < 1e-2 * ((hi - lo) + 0.1), 0.0, crv))
+    out = np.full(g.shape2(U), np.nan)
+    out[1:-1, 1:-1] = kind
+    return out
+
+
+@pytest.mark.parametrize("name", [n for n in VARIANTS if n.startswith("channel")])
+def test_channel_drag_is_sane(name):
+    """CHANNEL_DRAG (.testing/tc1, tc2; :863-1002): the Rayleigh drag is non-negative, zero on land and in layers that do not
+    touch the sloping bottom; the fraction of the bottom drag left to the viscous boundary layer is at most one, so Kv_bbl
+    does not exceed the value without the option; all three bottom shapes occur on the test grid"""
+    kw = VARIANTS[name]
+    g = xs.make_grid(40, 28, 12)
+    d = xs.make_state(g, umax=0.3)
+    a = run_oracle(g, d, **kw)
+    plain = run_oracle(g, d, **{k: v for k, v in kw.items() if k not in ("Channel_drag", "concave_trigonometric_L", "Chan_drag_max_vol", "c_Smag")})
+    mu = interior(g, g.mask2dCu, U) > 0
+    Ru = interior(g, a["Ray_u"], U)
+    assert np.all(np.isfinite(Ru)) and Ru.min() >= 0.0 and np.all(Ru[:, ~mu] == 0.0)
+    assert Ru[:, mu].max() > 0.0 and (Ru[:, mu] > 0).mean() < 0.9
+    if not kw.get("body_force_drag") and not kw.get("correct_BBL_bounds"):
+        kv, kv0 = interior(g, a["Kv_bbl_u"], U)[mu], interior(g, plain["Kv_bbl_u"], U)[mu]
+        assert np.all(kv <= kv0 * (1 + 1e-12)) and np.any(kv < 0.99 * kv0)
+        assert bits_equal(a["bbl_thick_u"], plain["bbl_thick_u"])
+    kinds = interior(g, channel_geometry(g), U)[mu]
+    assert {-1.0, 1.0} <= set(np.unique(kinds))      # concave and convex bottoms (a uniform slope: the next test)
+
+
+def sloping_grid(ni=24, nj=16, nk=6, flat=False, **kw):
+    """a bottom that is a plane (flat: level): CHANNEL_DRAG takes find_L_open_uniform_slope everywhere"""
+    g = xs.make_grid(ni, nj, nk, land_frac=0.0, flat_bottom=True, max_depth=600.0, **kw)
+    if not flat:
+        jj, ii = np.meshgrid(np.arange(g.bathyT.shape[0]), np.arange(g.bathyT.shape[1]), indexing="ij")
+        g.bathyT[:] = 300.0 + 2.0 * jj + 1.0 * ii
+        g._struct = None
+    return g
+
+
+def test_channel_drag_over_a_plane_bottom():
+    """a level bottom: every interface is fully open, the only step in L is at the bottom itself, where the whole drag goes to the
+    viscous boundary layer: no Rayleigh drag and the Kv_bbl of the plain scheme.  A tilted plane: uniform-slope widths, some drag"""
+    g = sloping_grid(flat=True)
+    d = xs.make_state(g, umax=0.2, vanish_frac=0.0)
+    a, plain = run_oracle(g, d, Channel_drag=True), run_oracle(g, d)
+    # (next to the closed northern and southern walls the neighbouring face is land: its depth counts as zero, :873-876)
+    assert np.all(interior(g, a["Ray_u"], U)[:, 1:-1] == 0.0) and interior(g, a["Ray_u"], U)[:, 0].max() > 0.0
+    assert bits_equal(interior(g, a["Kv_bbl_u"], U)[1:-1], interior(g, plain["Kv_bbl_u"], U)[1:-1])
+    g = sloping_grid()
+    assert set(np.unique(interior(g, channel_geometry(g), U)[1:-1])) == {0.0}
+    d = xs.make_state(g, umax=0.2, vanish_frac=0.0)
+    a, plain = run_oracle(g, d, Channel_drag=True), run_oracle(g, d)
+    Ru = interior(g, a["Ray_u"], U)
+    assert Ru.max() > 0.0 and Ru.min() >= 0.0
+    assert np.all(interior(g, a["Kv_bbl_u"], U) <= interior(g, plain["Kv_bbl_u"], U))
+
+
+def test_channel_drag_trigonometric_and_iterative_widths_agree():
+    """the reference's own debugging check (:900-925): the two concave solutions are mathematically equivalent; here their Rayleigh
+    drags agree to a relative 1e-8 where there is any"""
+    g = xs.make_grid(40, 28, 12)
+    d = xs.make_state(g, umax=0.3)
+    a = run_oracle(g, d, Channel_drag=True, BBL_thick_min=0.1)
+    b = run_oracle(g, d, Channel_drag=True, BBL_thick_min=0.1, concave_trigonometric_L=False)
+    for n in ("Ray_u", "Ray_v", "Kv_bbl_u", "Kv_bbl_v"):
+        assert np.allclose(a[n], b[n], rtol=1e-8, atol=1e-14), n
+    assert not bits_equal(a["Ray_u"], b["Ray_u"])
 
 
 @pytest.mark.parametrize("name", list(ML_VARIANTS))

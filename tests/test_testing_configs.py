@@ -1,0 +1,382 @@
+"""The hot-path parameter sets of the reference's own test configurations (.testing/tc4, tc2, tc1: MOM_input, transcribed below as
+KEY = VALUE pairs -- data, not source) through the Fortran shims' get_param, from a driver that calls only reference-named procedures
+(tests/fortran/dyn_driver.F90: set_visc_init, register_restarts_dyn_split_RK2, initialize_dyn_split_RK2, set_viscous_BBL,
+step_MOM_dyn_split_RK2) on the configurations' grid sizes (14 x 10 x 2, 10 x 8 x 8), against the oracle configured by hand from the same
+pairs with the reference's defaults (the function `oracle_for` below cites where each default comes from)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mom6_amd import _abi, synth
+from helpers import bits_equal, interior
+from test_fortran_abi import FC, ROOT, FDIR, STUBS, SHIMS
+
+# ---- transcribed from .testing/tc*/MOM_input: every pair a hot-path module reads, plus the switches of neighbouring modules that
+# decide what the hot path is handed (USE_REGRIDDING, THICKNESSDIFFUSE, USE_MEKE ...) ------------------------------------------------------
+TC_INPUT = {
+    "tc4": dict(shape=(14, 10, 2), pairs="""
+        USE_REGRIDDING = True
+        DT = 1200.0
+        DT_THERM = 3600.0
+        USE_PSURF_IN_EOS = False
+        REENTRANT_X = False
+        EQN_OF_STATE = "LINEAR"
+        DRHO_DS = 0.0
+        REMAP_UV_USING_OLD_ALG = True
+        REGRIDDING_COORDINATE_MODE = "Z*"
+        REMAPPING_SCHEME = "PPM_IH4"
+        LINEAR_DRAG = True
+        HBBL = 10.0
+        CDRAG = 0.002
+        DRAG_BG_VEL = 0.05
+        BBL_USE_EOS = True
+        BBL_THICK_MIN = 0.1
+        KV = 1.0E-04
+        KHTH = 500.0
+        BE = 0.7
+        ETA_TOLERANCE = 1.0E-12
+        CORIOLIS_EN_DIS = True
+        BOUND_CORIOLIS = True
+        RECONSTRUCT_FOR_PRESSURE = False
+        SMAGORINSKY_AH = True
+        SMAG_BI_CONST = 0.03
+        USE_LAND_MASK_FOR_HVISC = False
+        DIRECT_STRESS = True
+        HMIX_FIXED = 20.0
+        KV_ML_INVZ2 = 0.01
+        MAXVEL = 10.0
+        BOUND_BT_CORRECTION = True
+        SSH_EXTRA = 10.0
+        BEBT = 0.2
+        DTBT = 10.0
+        DEBUG = True
+        """),
+    "tc2": dict(shape=(10, 8, 8), pairs="""
+        USE_REGRIDDING = True
+        THICKNESSDIFFUSE = True
+        THICKNESSDIFFUSE_FIRST = True
+        MIXEDLAYER_RESTRAT = True
+        DT = 3600.0
+        DT_THERM = 7200.0
+        DTBT_RESET_PERIOD = -.98
+        REGRIDDING_COORDINATE_MODE = "Z*"
+        REMAPPING_SCHEME = "PPM_IH4"
+        USE_MEKE = True
+        MEKE_VISCOSITY_COEFF_KU = 1.0
+        USE_VARIABLE_MIXING = True
+        RESOLN_SCALED_KH = False
+        ETA_TOLERANCE = 1.0E-06
+        VELOCITY_TOLERANCE = 0.001
+        BOUND_CORIOLIS = True
+        LAPLACIAN = True
+        KH_VEL_SCALE = 0.05
+        SMAGORINSKY_KH = True
+        SMAG_LAP_CONST = 0.06
+        AH_VEL_SCALE = 0.05
+        SMAGORINSKY_AH = True
+        SMAG_BI_CONST = 0.06
+        DYNAMIC_VISCOUS_ML = True
+        KV = 1.0E-04
+        HMIX_FIXED = 0.5
+        CHANNEL_DRAG = True
+        HBBL = 10.0
+        MAXVEL = 10.0
+        USE_JACKSON_PARAM = True
+        ML_OMEGA_FRAC = 1.0
+        DRAG_BG_VEL = 0.1
+        BBL_THICK_MIN = 0.1
+        BOUND_BT_CORRECTION = True
+        NONLINEAR_BT_CONTINUITY = True
+        BT_PROJECT_VELOCITY = True
+        BT_THICK_SCHEME = "FROM_BT_CONT"
+        BEBT = 0.2
+        DTBT = -0.95
+        BULK_RI_ML = 0.05
+        TKE_DECAY = 10.0
+        DEBUG = True
+        USE_PSURF_IN_EOS = False
+        REMAP_UV_USING_OLD_ALG = True
+        USE_LAND_MASK_FOR_HVISC = False
+        """),
+    "tc1": dict(shape=(10, 8, 8), pairs="""
+        THICKNESSDIFFUSE = True
+        THICKNESSDIFFUSE_FIRST = True
+        MIXEDLAYER_RESTRAT = True
+        DT = 900.0
+        DT_THERM = 3600.0
+        DTBT_RESET_PERIOD = 0.0
+        USE_VARIABLE_MIXING = True
+        USE_VISBECK = True
+        RESOLN_SCALED_KH = True
+        RESOLN_SCALED_KHTH = True
+        RESOLN_SCALED_KHTR = True
+        ETA_TOLERANCE = 1.0E-06
+        VELOCITY_TOLERANCE = 0.001
+        BOUND_CORIOLIS = True
+        AH_VEL_SCALE = 0.05
+        SMAGORINSKY_AH = True
+        SMAG_BI_CONST = 0.06
+        PRANDTL_TURB = 0.0
+        DYNAMIC_VISCOUS_ML = True
+        KV = 1.0E-04
+        HBBL = 10.0
+        MAXVEL = 10.0
+        USE_JACKSON_PARAM = True
+        ML_OMEGA_FRAC = 1.0
+        DRAG_BG_VEL = 0.1
+        BBL_THICK_MIN = 0.1
+        BOUND_BT_CORRECTION = True
+        NONLINEAR_BT_CONTINUITY = True
+        BT_PROJECT_VELOCITY = True
+        BT_THICK_SCHEME = "FROM_BT_CONT"
+        BEBT = 0.2
+        DTBT = -0.95
+        BULK_RI_ML = 0.05
+        TKE_DECAY = 10.0
+        DEBUG = True
+        USE_PSURF_IN_EOS = False
+        USE_LAND_MASK_FOR_HVISC = False
+        """),
+}
+
+
+def pairs_of(name):
+    out = {}
+    for line in TC_INPUT[name]["pairs"].strip().splitlines():
+        k, v = (s.strip() for s in line.split("=", 1))
+        out[k] = v.strip('"')
+    return out
+
+
+def _b(p, k, default=False):
+    return (p[k].strip().lower().startswith("t")) if k in p else default
+
+
+def _f(p, k, default):
+    return float(p[k]) if k in p else default
+
+
+def build_driver(tmp):
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in SHIMS if "tracer" not in s] + \
+           [os.path.join(FDIR, "MOM_dynamics_split_RK2_hip.F90"), os.path.join(ROOT, "tests", "fortran", "dyn_driver.F90")]
+    for src in srcs:
+        o = str(tmp / (os.path.basename(src)[:-4] + ".o"))
+        subprocess.run([FC, *flags, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    libdir = os.path.join(ROOT, "mom6_amd")
+    exe = str(tmp / "dyn_driver")
+    subprocess.run([FC, *objs, f"-L{libdir}", "-lmom6hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    return exe
+
+
+def case_state(name, seed=21):
+    """a synthetic state on the configuration's grid size (its files -- topography, initial conditions -- are not part of the hot path)"""
+    ni, nj, nk = TC_INPUT[name]["shape"]
+    p = pairs_of(name)
+    g = synth.make_grid(ni, nj, nk, land_frac=0.2, seed=seed + 300, reentrant_x=_b(p, "REENTRANT_X", True), reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.1, eta_amp=0.2).items()}
+    yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu)
+    tauy = np.ascontiguousarray(0.0 * g.mask2dCv)
+    rng = np.random.default_rng(17)
+    ustar = np.ascontiguousarray(0.004 + 0.008 * rng.random(g.shape2(_abi.POS_H)))
+    rng = np.random.default_rng(9)
+    su, sv = g.shape2(_abi.POS_U), g.shape2(_abi.POS_V)
+    bbl = dict(Kv_bbl_u=1.0e-3 * (0.5 + rng.random(su)), Kv_bbl_v=1.0e-3 * (0.5 + rng.random(sv)),
+               bbl_thick_u=2.0 + 8.0 * rng.random(su), bbl_thick_v=2.0 + 8.0 * rng.random(sv))
+    # the vertical grid of a layered run: target densities and reduced gravities (GV%Rlay, GV%g_prime)
+    Rlay = np.linspace(1024.0, 1028.0, nk)
+    g_prime = np.zeros(nk + 1); g_prime[0] = g.g_Earth
+    g_prime[1:nk] = g.g_Earth * np.diff(Rlay) / g.Rho0
+    return g, d, taux, tauy, ustar, bbl, Rlay, g_prime
+
+
+def meke_of(name, g):
+    """USE_MEKE with a nonzero MEKE_VISCOSITY_COEFF_KU: the MEKE module (not part of the hot path) hands horizontal_viscosity MEKE%Ku and
+    takes MEKE%mom_src back (MOM_MEKE.F90:1365, MOM_hor_visc.F90:469, :1833).  A synthetic Ku with valid halos."""
+    from oracle import orc
+    p = pairs_of(name)
+    if not (_b(p, "USE_MEKE") and _f(p, "MEKE_VISCOSITY_COEFF_KU", 0.0) != 0.0):
+        return None
+    rng = np.random.default_rng(31)
+    Ku = np.ascontiguousarray(150.0 * rng.random(g.shape2(_abi.POS_H)) * g.mask2dT)
+    orc.halo_update(g, Ku, _abi.POS_H)
+    return Ku
+
+
+def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
+    """The oracle's control structures as the reference's *_init routines would set them from the pairs (defaults cited)."""
+    from oracle import orc
+    p = pairs_of(name)
+    nk = g.nk
+    dt = float(p["DT"])
+    use_ALE = _b(p, "USE_REGRIDDING")                                   # MOM.F90:2271
+    bulkml = not use_ALE                                               # BULKMIXEDLAYER default (MOM.F90:2296-2303, with temperature)
+    nkml, nkbl = (2, 2) if bulkml else (0, 0)                          # NKML, NKBL defaults (MOM.F90:2439-2444)
+    eosn = p.get("EQN_OF_STATE", "WRIGHT")                             # MOM_EOS.F90 EQN_OF_STATE default
+    E = orc.eos("LINEAR", 1000.0, -0.2, _f(p, "DRHO_DS", 0.8)) if eosn == "LINEAR" else orc.eos(eosn)      # RHO_T0_S0, DRHO_DT, DRHO_DS
+    pf = dict(reconstruct=_b(p, "RECONSTRUCT_FOR_PRESSURE", use_ALE), use_ALE=use_ALE)      # MOM_PressureForce_FV.F90:1078
+    if bulkml:
+        pf.update(nkmb=nkml + nkbl, Rlay=Rlay, g_prime=g_prime)
+    cont = dict(tol_eta=_f(p, "ETA_TOLERANCE", 0.5 * nk * g.Angstrom_H))                    # MOM_continuity_PPM.F90:2717
+    if "VELOCITY_TOLERANCE" in p:
+        cont["tol_vel"] = float(p["VELOCITY_TOLERANCE"])
+    en_dis = _b(p, "CORIOLIS_EN_DIS")
+    cor = dict(coriolis_en_dis=int(en_dis), bound_coriolis=int(_b(p, "BOUND_CORIOLIS") and not en_dis))      # MOM_CoriolisAdv.F90:1150-1158
+    bt = dict(bebt=_f(p, "BEBT", 0.1), bound_BT_corr=int(_b(p, "BOUND_BT_CORRECTION")), maxCFL_BT_cont=0.25,
+              Nonlinear_continuity=int(_b(p, "NONLINEAR_BT_CONTINUITY")), BT_project_velocity=int(_b(p, "BT_PROJECT_VELOCITY")))
+    dtbt_in = _f(p, "DTBT", -0.98)                                     # MOM_barotropic.F90:4700
+    bt["dtbt_fraction"] = -dtbt_in if dtbt_in < 0 else 0.98
+    dyn_ml = _b(p, "DYNAMIC_VISCOUS_ML")
+    vv = dict(Kv=float(p["KV"]), Hbbl=float(p["HBBL"]), Hmix=_f(p, "HMIX_FIXED", 0.0) if nkml < 1 else 0.0,
+              Kvml_invZ2=_f(p, "KV_ML_INVZ2", 0.0) if nkml < 1 else 0.0, direct_stress=_b(p, "DIRECT_STRESS"),
+              maxvel=_f(p, "MAXVEL", 3.0e8), CFL_based_trunc=True, CFL_trunc=0.5, dynamic_viscous_ML=dyn_ml, nkml=nkml)
+    hv = dict(Laplacian=int(_b(p, "LAPLACIAN")), biharmonic=int(_b(p, "BIHARMONIC", True)), Smagorinsky_Kh=int(_b(p, "SMAGORINSKY_KH")),
+              Smag_Lap_const=_f(p, "SMAG_LAP_CONST", 0.0), Kh_vel_scale=_f(p, "KH_VEL_SCALE", 0.0), Smagorinsky_Ah=int(_b(p, "SMAGORINSKY_AH")),
+              Smag_bi_const=_f(p, "SMAG_BI_CONST", 0.0), Ah_vel_scale=_f(p, "AH_VEL_SCALE", 0.0),
+              use_land_mask=int(_b(p, "USE_LAND_MASK_FOR_HVISC", True)),
+              # BOUND_CORIOLIS_BIHARM defaults to BOUND_CORIOLIS, BOUND_CORIOLIS_VEL to MAXVEL (MOM_hor_visc.F90:2247-2264)
+              bound_Coriolis=int(_b(p, "BOUND_CORIOLIS") and _b(p, "SMAGORINSKY_AH")), bound_Cor_vel=_f(p, "MAXVEL", 3.0e8))
+    arrs = {k: v.copy() for k, v in bbl.items()}
+    if dyn_ml or nkml > 0:
+        arrs["ustar"] = ustar
+    # set_visc_CS (MOM_set_viscosity.F90:2920-3130): one structure for set_viscous_BBL and set_viscous_ML
+    chan = _b(p, "CHANNEL_DRAG"); rino = _b(p, "USE_JACKSON_PARAM")
+    c_smag = _f(p, "SMAG_CONST_CHANNEL", _f(p, "SMAG_LAP_CONST", 0.15))      # :3093-3105
+    bulk_Ri = _f(p, "BULK_RI_ML_VISC", _f(p, "BULK_RI_ML", 0.0)); decay = _f(p, "TKE_DECAY_VISC", _f(p, "TKE_DECAY", 0.0))
+    sv = orc.set_visc_cs(g, float(p["HBBL"]), float(p["KV"]), cdrag=_f(p, "CDRAG", 0.003), drag_bg_vel=_f(p, "DRAG_BG_VEL", 0.0),
+                         BBL_thick_min=_f(p, "BBL_THICK_MIN", 0.0), linear_drag=_b(p, "LINEAR_DRAG"), BBL_use_EOS=_b(p, "BBL_USE_EOS", True),
+                         RiNo_mix=rino, Channel_drag=chan, c_Smag=c_smag if c_smag >= 0.0 else 0.15,
+                         dynamic_viscous_ML=dyn_ml, nkml=nkml, bulk_Ri_ML=bulk_Ri if dyn_ml else 0.0, TKE_decay=decay if dyn_ml else 0.0,
+                         omega_frac=_f(p, "ML_OMEGA_FRAC", 0.0) if dyn_ml else 0.0, Rlay=Rlay if bulkml else None)
+    if chan:
+        arrs.update(Ray_u=g.zeros3(_abi.POS_U), Ray_v=g.zeros3(_abi.POS_V))
+    if dyn_ml:
+        arrs.update(nkml_visc_u=g.zeros2(_abi.POS_U), nkml_visc_v=g.zeros2(_abi.POS_V))
+    hvcs = orc.hor_visc_cs(g, dt, **hv)
+    Ku = meke_of(name, g)
+    mom_src = orc.hor_visc_set_meke(hvcs, Ku=Ku, mom_src=g.zeros2(_abi.POS_H)) if Ku is not None else None
+    st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, be=_f(p, "BE", 0.6), eos_form=E, pressureforce=pf,
+                      vertvisc=orc.vertvisc_cs(g, **vv), visc=orc.vertvisc_type(**arrs), hor_visc=hvcs, set_visc=sv if dyn_ml else None,
+                      continuity=cont, coriolis=cor, **bt)
+    # the barotropic time step as barotropic_init leaves it (MOM_barotropic.F90:4899-4914) and MOM.F90's DTBT_RESET_PERIOD (:1227-1234)
+    SSH_extra = _f(p, "SSH_EXTRA", min(10.0, 0.05 * float(g.bathyT.max())))
+    orc.set_dtbt(g, st.bcs, gtot_est=float(sum(g.H_to_Z * g_prime[k] for k in range(nk))), SSH_add=SSH_extra)
+    if dtbt_in > 0:
+        st.bcs.dtbt = dtbt_in
+    reset = _f(p, "DTBT_RESET_PERIOD", -1.0)
+    calc = lambda n: (reset == 0.0)
+    st.mom_src = mom_src
+    st.bbl = lambda: orc.set_viscous_BBL(g, sv, st.u, st.v, st.h, st.T, st.S, E, st.visc)      # MOM.F90:1205
+    return st, calc, dict(use_eos=1, use_ale=int(use_ALE), nk_rho_varies=nkml + nkbl, nkml=nkml)
+
+
+def write_case(tmp, name, nsteps, resident, state, bbl_mode=0):
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    p = pairs_of(name)
+    use_ALE = _b(p, "USE_REGRIDDING")
+    nkml, nkbl = (0, 0) if use_ALE else (2, 2)
+    with open(tmp / "in.bin", "wb") as f:
+        np.array([g.ni, g.nj, g.nk, g.halo, int(_b(p, "REENTRANT_X", True)), 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        Ku = meke_of(name, g)
+        np.array([nsteps, int(resident), 1, int(use_ALE), nkml + nkbl, nkml, bbl_mode, int(Ku is not None)], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, float(p["DT"])], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], d["T"], d["S"], taux, tauy, ustar, Rlay, g_prime):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        if bbl_mode == 0:
+            for n in ("Kv_bbl_u", "Kv_bbl_v", "bbl_thick_u", "bbl_thick_v"):
+                np.ascontiguousarray(bbl[n], dtype="<f8").tofile(f)
+        if Ku is not None:
+            Ku.tofile(f)
+    with open(tmp / "params.txt", "w") as f:
+        for k, v in p.items():
+            f.write(f"{k} = {v}\n")
+
+
+OUT = [("u", _abi.POS_U, 3), ("v", _abi.POS_V, 3), ("h", _abi.POS_H, 3), ("uh", _abi.POS_U, 3), ("vh", _abi.POS_V, 3), ("uhtr", _abi.POS_U, 3),
+       ("vhtr", _abi.POS_V, 3), ("eta_av", _abi.POS_H, 2), ("nkml_visc_u", _abi.POS_U, 2), ("nkml_visc_v", _abi.POS_V, 2)]
+
+
+def read_out(path, g, meke=False):
+    raw = np.fromfile(path, dtype="<f8")
+    out = OUT + ([("mom_src", _abi.POS_H, 2)] if meke else [])
+    shapes = [g.shape3(pos) if nd == 3 else g.shape2(pos) for _, pos, nd in out]
+    sizes = [int(np.prod(s)) for s in shapes]
+    assert raw.size == sum(sizes)
+    return {n: a.reshape(s) for (n, _, _), a, s in zip(out, np.split(raw, np.cumsum(sizes)[:-1]), shapes)}
+
+
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_the_split_RK2_module_shim_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """MOM_dynamics_split_RK2_hip.F90 (the reference's module name and dummy-argument lists) and the driver that uses nothing else
+    compile against the type stand-ins; without a GPU the first library call is a FATAL error with the library's message"""
+    import torch
+    exe = build_driver(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    write_case(tmp_path, "tc4", 1, False, case_state("tc4"))
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "FATAL" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.parametrize("name", list(TC_INPUT))
+def test_oracle_runs_the_transcribed_sets(name):
+    """the oracle configured from the pairs: two steps, finite, positive thicknesses"""
+    state = case_state(name)
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    st, calc, _ = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    for n in range(2):
+        st.bbl()
+        st.step(taux, tauy, calc_dtbt=calc(n))
+    if _b(pairs_of(name), "CHANNEL_DRAG"):
+        assert st.visc._keep["Ray_u"].max() > 0.0
+    assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0 and st.bcs.nstep_last >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("name", list(TC_INPUT))
+def test_reference_named_driver_with_the_testing_sets_matches_oracle_bitwise(tmp_path, name, resident):
+    """every shim's *_init reads the configuration's pairs without refusing one; three steps of step_MOM_dyn_split_RK2 on host arrays
+    are the oracle's bits; with GPU_RESIDENT_DYNAMICS the steps move nothing over PCIe between the first upload and the final
+    dyn_split_RK2_sync_to_host"""
+    nsteps = 3
+    state = case_state(name)
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    exe = build_driver(tmp_path)
+    write_case(tmp_path, name, nsteps, resident, state, bbl_mode=1)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "dyn_driver ok" in r.stdout
+    st, calc, _ = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    for n in range(nsteps):
+        if n == 0 or not resident:      # set_viscous_BBL works on the host's u, v, h: with the fields resident, only before the first step
+            st.bbl()
+        st.step(taux, tauy, calc_dtbt=calc(n))
+    got = read_out(str(tmp_path / "out.bin"), g, meke=st.mom_src is not None)
+    want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+    if st.mom_src is not None:
+        assert bits_equal(interior(g, got["mom_src"], _abi.POS_H), interior(g, st.mom_src, _abi.POS_H)) and st.mom_src.min() < 0.0
+    if "nkml_visc_u" in st.visc._keep:
+        want.update(nkml_visc_u=st.visc._keep["nkml_visc_u"], nkml_visc_v=st.visc._keep["nkml_visc_v"])
+    for n, pos, nd in OUT:
+        if n in want:
+            assert bits_equal(interior(g, got[n], pos), interior(g, want[n], pos)), (name, n, float(np.abs(got[n] - want[n]).max()))
+    # what crossed PCIe after initialisation
+    words = r.stdout.split()
+    stats = {w.split("=")[0]: int(w.split("=")[1]) for w in words if "=" in w}
+    n3 = int(np.prod(g.shape3(_abi.POS_H)))
+    if resident:
+        # one upload of each input (u, v, h are already there from the initialisation), one download of each output and restart field
+        assert stats["h2d_calls"] <= 16 and stats["d2h_calls"] <= 24, stats
+        assert stats["h2d_bytes"] <= 8 * 4 * n3 * 1.3 and stats["d2h_bytes"] <= 8 * 16 * n3 * 1.3, stats
+    else:
+        assert stats["h2d_calls"] >= nsteps * 8
