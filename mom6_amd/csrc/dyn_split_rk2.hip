@@ -50,7 +50,8 @@ int check(const mom6hip_dyn_split_rk2_cs_t *cs, const char *who) {
   M6_REQUIRE(cs != nullptr, "%s: null control structure", who);
   M6_REQUIRE(cs->begw == 0.0, "%s: BEGW /= 0 is not provided", who);
   M6_REQUIRE(!cs->split_bottom_stress, "%s: SPLIT_BOTTOM_STRESS is not provided", who);
-  M6_REQUIRE(cs->continuity_CSp && cs->CoriolisAdv && cs->PressureForce_CSp && cs->eqn_of_state && cs->barotropic_CSp,
+  // (eqn_of_state may be null: no equation of state, the layered PressureForce branch with GV%Rlay / GV%g_prime)
+  M6_REQUIRE(cs->continuity_CSp && cs->CoriolisAdv && cs->PressureForce_CSp && cs->barotropic_CSp,
              "%s: a sub-module control structure is missing", who);
   M6_REQUIRE(cs->CAu && cs->CAv && cs->CAu_pred && cs->CAv_pred && cs->PFu && cs->PFv && cs->diffu && cs->diffv && cs->visc_rem_u &&
                  cs->visc_rem_v && cs->u_accel_bt && cs->v_accel_bt && cs->u_av && cs->v_av && cs->h_av && cs->pbce && cs->eta &&
@@ -132,9 +133,9 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
 int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_inst, double *v_inst, double *h,
                                const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
                                double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int32_t calc_dtbt) {
-  M6_REQUIRE(ctx && u_inst && v_inst && h && T && S && taux && tauy && uh && vh && uhtr && vhtr && eta_av,
-             "step_MOM_dyn_split_RK2: null argument");
+  M6_REQUIRE(ctx && u_inst && v_inst && h && taux && tauy && uh && vh && uhtr && vhtr && eta_av, "step_MOM_dyn_split_RK2: null argument");
   CALL(check(cs, "step_MOM_dyn_split_RK2"));
+  M6_REQUIRE(!cs->eqn_of_state || (T && S), "step_MOM_dyn_split_RK2: an equation of state needs tv%%T and tv%%S");
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);
   hipStream_t s = ctx->stream;
@@ -349,9 +350,9 @@ int mom6hip_dyn_split_rk2b_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
 int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_av, double *v_av, double *h,
                                 const double *T, const double *S, double dt, const double *taux, const double *tauy, double RZ_to_H,
                                 double *uh, double *vh, double *uhtr, double *vhtr, double *eta_av, int32_t calc_dtbt) {
-  M6_REQUIRE(ctx && u_av && v_av && h && T && S && taux && tauy && uh && vh && uhtr && vhtr && eta_av,
-             "step_MOM_dyn_split_RK2b: null argument");
+  M6_REQUIRE(ctx && u_av && v_av && h && taux && tauy && uh && vh && uhtr && vhtr && eta_av, "step_MOM_dyn_split_RK2b: null argument");
   CALL(check(cs, "step_MOM_dyn_split_RK2b"));
+  M6_REQUIRE(!cs->eqn_of_state || (T && S), "step_MOM_dyn_split_RK2b: an equation of state needs tv%%T and tv%%S");
   M6_REQUIRE(cs->du_av_inst && cs->dv_av_inst, "step_MOM_dyn_split_RK2b: du_av_inst / dv_av_inst are not allocated");
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);

@@ -42,7 +42,9 @@ class MOM_dyn_split_RK2_CS:
         self.continuity_CSp = continuity_PPM_init(G, **(continuity or {}))
         self.CoriolisAdv = CoriolisAdv_init(**(coriolis or {}))
         self.PressureForce_CSp = PressureForce_init(g, **(pressure_force or {}))
-        self.eqn_of_state = EOS_init(EQN_OF_STATE, **(eos or {}))      # eos=dict(Rho_T0_S0=..., dRho_dT=..., dRho_dS=...) for LINEAR
+        # eos=dict(Rho_T0_S0=..., dRho_dT=..., dRho_dS=...) for LINEAR; EQN_OF_STATE = None: no equation of state (tv%eqn_of_state not
+        # associated): the layered PressureForce branch with GV%Rlay / GV%g_prime (pressure_force=dict(Rlay=..., g_prime=...))
+        self.eqn_of_state = None if EQN_OF_STATE is None else EOS_init(EQN_OF_STATE, **(eos or {}))
         Z3 = lambda pos: torch.zeros(g.shape3(pos), dtype=torch.float64, device=dev)
         Z2 = lambda pos: torch.zeros(g.shape2(pos), dtype=torch.float64, device=dev)
         self.BT_cont = None
@@ -57,7 +59,8 @@ class MOM_dyn_split_RK2_CS:
         st.BT_use_layer_fluxes, st.store_CAu = int(bool(BT_USE_LAYER_FLUXES)), int(bool(STORE_CORIOLIS_ACCEL))
         self._cor_struct = self.CoriolisAdv.struct()
         st.continuity_CSp = C.addressof(self.continuity_CSp); st.CoriolisAdv = C.addressof(self._cor_struct)
-        st.PressureForce_CSp = C.addressof(self.PressureForce_CSp); st.eqn_of_state = C.addressof(self.eqn_of_state)
+        st.PressureForce_CSp = C.addressof(self.PressureForce_CSp)
+        st.eqn_of_state = None if self.eqn_of_state is None else C.addressof(self.eqn_of_state)
         st.barotropic_CSp = C.addressof(self.barotropic_CSp.st)
         if self.BT_cont is not None:
             self._bt_struct = self.BT_cont.struct(set())
@@ -202,7 +205,9 @@ def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, 
     if p_surf_begin is not None or p_surf_end is not None or Waves is not None or pbv is not None:
         raise Mom6HipError("step_MOM_dyn_split_RK2 (HIP): surface pressure, waves and porous barriers are not supported")
     g = G.grid
-    T, S = tv[0], tv[1]
+    T, S = (tv[0], tv[1]) if tv is not None else (None, None)      # tv None: no equation of state
+    if (T is None or S is None) and CS.eqn_of_state is not None:
+        raise Mom6HipError("step_MOM_dyn_split_RK2: an equation of state needs tv = (T, S)")
     taux, tauy = forces
     if CS.vertvisc_CSp is not None:
         if visc is None:
@@ -212,9 +217,11 @@ def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, 
     elif visc is not None:
         raise Mom6HipError("step_MOM_dyn_split_RK2: visc given but the control structure was made without vertvisc=...")
     for a in (u_inst, v_inst, h, T, S, taux, tauy, uh, vh, uhtr, vhtr, eta_av):
+        if a is None:
+            continue
         if not (a.is_cuda and a.is_contiguous() and a.dtype == torch.float64):
             raise Mom6HipError("step_MOM_dyn_split_RK2: all fields must be contiguous float64 CUDA tensors")
-    P = lambda a: C.c_void_p(a.data_ptr())
+    P = lambda a: None if a is None else C.c_void_p(a.data_ptr())
     if getattr(CS, "split_RK2b", False) != (_entry == "mom6hip_step_dyn_split_rk2b"):
         raise Mom6HipError("step_MOM_dyn_split_RK2: the control structure was initialized for the other split scheme (SPLIT_RK2B)")
     check(getattr(_setup(), _entry)(G.handle, C.byref(CS.st), P(u_inst), P(v_inst), P(h), P(T), P(S), float(dt), P(taux),

@@ -568,14 +568,15 @@ class DynState:
         for k, v in (coriolis or {}).items():      # members of mom6hip_coriolisadv_cs_t, e.g. coriolis_en_dis
             setattr(self.cor, k, v)
         self.pcs = pressureforce_cs(g, **(pressureforce or {}))      # e.g. reconstruct=False (RECONSTRUCT_FOR_PRESSURE)
-        self.eos = eos(eos_form) if not isinstance(eos_form, _abi.EOS) else eos_form
+        # eos_form None: no equation of state (the layered PressureForce branch: pressureforce=dict(use_ALE=False, Rlay=..., g_prime=...))
+        self.eos = None if eos_form is None else (eos(eos_form) if not isinstance(eos_form, _abi.EOS) else eos_form)
         self.bt_arrs, self.bt = make_bt_cont(g, with_h=True) if use_bt_cont else ({}, None)
         self.bcs, self.bcs_arrs = barotropic_cs(g, hvel_scheme="FROM_BT_CONT" if use_bt_cont else "HARMONIC", **bt_kw)
         barotropic_init(g, self.bcs)
         cs = self.cs = _abi.DynSplitRK2CS()
         cs.be, cs.begw, cs.BT_use_layer_fluxes, cs.store_CAu = be, 0.0, int(BT_use_layer_fluxes), int(store_CAu)
         cs.continuity_CSp = C.addressof(self.ccs); cs.CoriolisAdv = C.addressof(self.cor)
-        cs.PressureForce_CSp = C.addressof(self.pcs); cs.eqn_of_state = C.addressof(self.eos)
+        cs.PressureForce_CSp = C.addressof(self.pcs); cs.eqn_of_state = None if self.eos is None else C.addressof(self.eos)
         cs.barotropic_CSp = C.addressof(self.bcs); cs.BT_cont = C.addressof(self.bt) if use_bt_cont else None
         if vertvisc is not None:      # (vertvisc_cs(...) struct, vertvisc_type(...) struct) of this module
             self.vvcs, self.visc = vertvisc, visc

@@ -50,6 +50,71 @@ def test_oracle_balanced_channel_stays_bounded():
     assert np.abs(S.u[0]).max() > 0.2 * np.abs(st["u"][0]).max()
 
 
+def layer_densities(g, g_prime, nk=2):
+    """GV%Rlay and GV%g_prime of the layered Phillips_2layer run (set_coord_from_gprime, MOM_coord_initialization.F90:167-170: the
+    densities follow from the reduced gravities): the densities the LINEAR equation of state gives the two layers' temperatures"""
+    gp = np.zeros(nk + 1); gp[0] = g.g_Earth; gp[nk // 2] = g_prime
+    Rlay = np.zeros(nk); Rlay[0] = 1000.0 - 0.2 * 20.0 + 0.8 * 35.0
+    for k in range(1, nk):
+        Rlay[k] = Rlay[k - 1] + gp[k] * (g.Rho0 / g.g_Earth)
+    return Rlay, gp
+
+
+def test_oracle_phillips_with_layer_densities_and_no_equation_of_state():
+    """Phillips_2layer as the reference runs it: no equation of state (tv%eqn_of_state not associated), PressureForce_FV_Bouss on
+    GV%Rlay and GV%g_prime (MOM_PressureForce_FV.F90:620-640, :868-905).  Bounded like the LINEAR-EOS emulation"""
+    g, st, g_prime = xs.make_phillips(96, 64)
+    dt = 1200.0
+    Rlay, gp = layer_densities(g, g_prime)
+    S = orc.DynState(g, st["u"], st["v"], st["h"], st["T"], st["S"], dt, eos_form=None, pressureforce=dict(use_ALE=False, Rlay=Rlay, g_prime=gp))
+    L = orc.DynState(g, st["u"], st["v"], st["h"], st["T"], st["S"], dt, eos_form="LINEAR")
+    tz = (g.zeros2(U), g.zeros2(V))
+    sj, si = g.csl(H)
+    ke = []
+    for n in range(120):
+        S.step(tz[0], tz[1], calc_dtbt=(n == 0))
+        ke.append(kinetic_energy(g, S))
+        if n == 0:
+            # the same interface slopes and reduced gravity: the first pressure force is that of the LINEAR-EOS emulation to roundoff
+            # (afterwards the two differ: the layered free surface feels g, the emulation g*Rlay(1)/Rho0, MOM_PressureForce_FV.F90:868-905)
+            L.step(tz[0], tz[1], calc_dtbt=True)
+            assert np.abs(S.arrs["PFu"] - L.arrs["PFu"]).max() < 1e-8 * np.abs(L.arrs["PFv"]).max() and not bits_equal(S.arrs["pbce"], L.arrs["pbce"])
+            assert np.all(S.arrs["pbce"][0][sj, si] == g.g_Earth)
+    assert S.bcs.nstep_last >= 20 and np.all(np.isfinite(S.u)) and S.h.min() > 0
+    assert max(ke[90:]) <= 1.05 * max(ke[:30])
+    assert np.abs(S.u[0]).max() > 0.2 * np.abs(st["u"][0]).max()
+
+
+@pytest.mark.gpu
+def test_phillips_with_layer_densities_matches_oracle_bitwise():
+    """the full-size channel without an equation of state: library == oracle, bit for bit"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    g, d, g_prime = xs.make_phillips()
+    dt = 1800.0
+    Rlay, gp = layer_densities(g, g_prime)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, eos_form=None, pressureforce=dict(use_ALE=False, Rlay=Rlay, g_prime=gp))
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h = (T(d[k]) for k in ("u", "v", "h"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, EQN_OF_STATE=None, coriolis=dict(bound_coriolis=True),
+                                  pressure_force=dict(use_ALE=False, Rlay=Rlay, g_prime=gp))
+    tz = (g.zeros2(U), g.zeros2(V)); tx, ty = Z(U, False), Z(V, False)
+    for n in range(3):
+        ref.step(tz[0], tz[1], calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2(u, v, h, None, None, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        assert CS.barotropic_CSp.st.nstep_last == ref.bcs.nstep_last >= 30
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("eta_av", eta_av, ref.eta_av),
+                           ("PFu", CS.PFu, ref.arrs["PFu"]), ("pbce", CS.pbce, ref.arrs["pbce"])):
+            an = a.cpu().numpy()
+            assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+    dg.close()
+
+
 @pytest.mark.gpu
 def test_phillips_step_matches_oracle_bitwise():
     import torch
