@@ -476,7 +476,11 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
 // whose state runs through k (the CFL brackets :663-716 and the duL/duR limits of set_*_BT_cont) are serial chains
 // walked by one (half-)wave; the divisions of the bracket chain do not depend on the running state and are formed by all
 // threads beforehand.
-constexpr int FC_NW = 4;      // waves per block
+#ifndef FC_NW_DEF
+#define FC_NW_DEF 4
+#endif
+constexpr int FC_NW = FC_NW_DEF;      // waves per block (experiments: -DFC_NW_DEF=2 -DFC_OCC=2: 20 layers a thread, one wave a SIMD)
+constexpr int FC_KSMAX = 80 / (2 * FC_NW);      // layers per thread of the largest instance
 constexpr int FC_FL = 32;     // face columns per block: a wave is two half-waves of 32 faces holding different layers
 constexpr int FC_NS = 2 * FC_NW;      // layer slabs per block (one per half-wave)
 
@@ -529,7 +533,10 @@ __device__ unsigned long long fc_trace[16];
 #endif
 
 template <int DIR, int KS>
-__global__ __launch_bounds__(64 * FC_NW, 2) void cont_flux_coop_kernel(FluxArgs p) {
+#ifndef FC_OCC
+#define FC_OCC 2      // blocks per CU the register budget is set for (experiments: tools/build_variant.sh ... -DFC_OCC=1)
+#endif
+__global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(FluxArgs p) {
 #ifdef FC_TRACE
   unsigned long long fc_t0 = __builtin_readcyclecounter();
   if (threadIdx.x == 0) atomicAdd(&fc_trace[15], 1ull);
@@ -1049,7 +1056,7 @@ bool flux_lane_only() {
 bool flux_is_coop(const FluxArgs &f) {
   // (and a 3-D array stays below 4 GB: the kernel addresses its layers with 32-bit byte offsets)
   const bool small = (size_t)(f.g.nih + 1) * (f.g.njh + 1) * f.g.nk * sizeof(double) < ((size_t)1 << 32);
-  return (f.uhbt || f.set_BT_cont) && f.g.nk <= 10 * FC_NS && small && !flux_lane_only();
+  return (f.uhbt || f.set_BT_cont) && f.g.nk <= FC_KSMAX * FC_NS && small && !flux_lane_only();
 }
 
 template <int DIR>
@@ -1070,7 +1077,7 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     };
     if (nk <= FC_NS) return go(cont_flux_coop_kernel<DIR, 1>, 1);
     if (nk <= 4 * FC_NS) return go(cont_flux_coop_kernel<DIR, 4>, 4);
-    return go(cont_flux_coop_kernel<DIR, 10>, 10);
+    return go(cont_flux_coop_kernel<DIR, FC_KSMAX>, FC_KSMAX);
   }
   hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
   return 0;

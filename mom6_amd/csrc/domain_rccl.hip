@@ -144,8 +144,8 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
   hipStream_t cs = D->cstream;
   // the fold is turned from this tile's own rows: the tile must span x and end the domain to the north
   if (G.tripolar_n)
-    M6_REQUIRE(D->hi[1] < 0 && D->lo[0] < 0 && D->hi[0] < 0,
-               "group pass: a tile on the tripolar fold must span x (no x neighbours) and cannot have a northern neighbour");
+    M6_REQUIRE(D->hi[1] < 0 && (D->lo[0] < 0 || D->lo[0] == D->rank) && (D->hi[0] < 0 || D->hi[0] == D->rank),
+               "group pass: a tile on the tripolar fold must span x (no x neighbour but itself) and cannot have a northern neighbour");
   M6_HIP(hipEventRecord(D->ev_ready, ctx->stream));
   M6_HIP(hipStreamWaitEvent(cs, D->ev_ready, 0));
   hipEvent_t t0 = nullptr, t1 = nullptr;
