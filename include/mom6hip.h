@@ -102,6 +102,17 @@ int mom6hip_sync_to_host(mom6hip_ctx_t *ctx, void *hptr, const void *dptr, uint6
 /* stats[0..3] = calls and bytes of mom6hip_sync_to_device, calls and bytes of mom6hip_sync_to_host + mom6hip_stage_to_host on this
  * context since its creation or the last reset: what a device-resident host (MOM_dynamics_split_RK2_hip.F90) moved over PCIe. */
 int mom6hip_transfer_stats(mom6hip_ctx_t *ctx, uint64_t *stats, int32_t reset);
+/* start_group_pass / complete_group_pass (MOM_domain_infra.F90:1141-1182) on device fields (pos: MOM6HIP_POS_* | MOM6HIP_PASS_SCALAR_PAIR,
+ * nk_each: layers of each field): between the two calls the halos are in flight -- nothing may write the fields or read their halos.
+ * With the library's own domain the exchange runs on its communication stream; a tile that spans x has its x halos final when
+ * start returns.  mom6hip_halo_update is the two calls back to back. */
+int mom6hip_start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each, int32_t nfields);
+int mom6hip_complete_group_pass(mom6hip_ctx_t *ctx);
+/* Debugging of the non-blocking group passes (start_group_pass / complete_group_pass, MOM_domain_infra.F90:1141-1182): with
+ * enable != 0 every start fills the halos the pass is going to update with NaNs and leaves the update to the matching complete, so
+ * that a kernel enqueued between the two that reads one of those halos too early yields NaNs deterministically, whatever the
+ * timing of the streams.  One tile and the library's own RCCL domain; not with the host's halo callback. */
+int mom6hip_debug_poison_passes(mom6hip_ctx_t *ctx, int32_t enable);
 
 /* ---- restart / diagnostic staging: fields to the host while the model keeps stepping ------ */
 

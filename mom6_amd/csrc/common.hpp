@@ -126,6 +126,13 @@ struct mom6hip_ctx {
   void *min_user = nullptr;
   void *cb_user = nullptr;
   int num_PEs = 0;              // asked of the domain on first use (coms.hip); 0: not yet known
+  // MOM6HIP debugging of the non-blocking passes (mom6hip_debug_poison_passes): start_group_pass fills the halos the pass is going to
+  // update with NaNs and leaves the update itself to complete_group_pass, so that anything enqueued between the two that reads a
+  // halo too early is found deterministically (a NaN in its result), whatever the streams' timing happens to be
+  bool poison_passes = false;
+  bool split_rows_always = false;      // (tests: the interior / edge-band launches on one tile, where nothing is in flight)
+  int poison_now = 0;           // (transient: the next halo kernel writes NaNs on these sides instead of the update)
+  struct PendingPass { std::vector<double *> f; std::vector<int32_t> pos, nk; } pending;
   m6::DevBuf efp_acc;           // the accumulators of the extended-fixed-point sums (efp.hpp)
   // the depth list of MOM_sum_output (create_depth_list) and the remembered list positions CS%lH (sum_output.hip)
   std::vector<double> DL_depth, DL_area, DL_vol_below;
@@ -168,12 +175,20 @@ struct KTimer {
 int group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
 int start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
 int complete_group_pass(mom6hip_ctx *ctx);
+// Restricts the rows every module computes (the launches take their ranges from ctx->g) to [j0, j1] of the compute domain, for
+// the interior / boundary-strip launches around a non-blocking pass (dyn_split_rk2.hip); row_window_reset restores the tile.
+// whether start_group_pass leaves the x halos final (the tile spans x): then only rows near the tile's y edges wait for the pass
+bool pass_leaves_x_final(mom6hip_ctx *ctx);
+void row_window(mom6hip_ctx *ctx, int j0, int j1);
+void row_window_reset(mom6hip_ctx *ctx);
 int halo_wrap_dir(mom6hip_ctx *ctx, double *f, int pos, int nk, int dir, hipStream_t stream);
 int halo_fold_north(mom6hip_ctx *ctx, double *f, int pos_flags, int nk, hipStream_t stream);      // TRIPOLAR_N
 int halo_pack_on(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each, const int32_t *a0, int32_t nfields,
                  int32_t dir, int32_t width, double *buf, int32_t pack, int64_t *count, hipStream_t stream);
 int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n);
 int native_complete_group_pass(mom6hip_ctx *ctx);
+bool native_x_is_local(mom6hip_ctx *ctx);
+void native_pass_sides(mom6hip_ctx *ctx, int sides[2]);      // which halos a native pass fills: per direction, bit 0 low side, bit 1 high side
 int native_allreduce(mom6hip_ctx *ctx, void *values, int n, bool is_int_sum);
 void native_domain_destroy(mom6hip_ctx *ctx);
 // sum_across_PEs of n host int32 / min_across_PEs of n host doubles, in place (the native domain, the host's callback, or nothing)

@@ -408,6 +408,7 @@ struct HaloDesc {
   int ilo, jlo;        // first allocated index in i, j
   int nis, njs, nk;    // allocated extents
   int ics, ice, jcs, jce, ni, nj, ihi, jhi;
+  int poison;          // debugging: write NaN where the update would write (bit 0: the low side, bit 1: the high side); 0: the update
 };
 
 __global__ void halo_x_kernel(HaloDesc d) {
@@ -423,6 +424,7 @@ __global__ void halo_x_kernel(HaloDesc d) {
     int i, src;
     if (h < nwl) { i = d.ilo + h; src = i + d.ni; } else { i = d.ice + 1 + (h - nwl); src = i - d.ni; }
     long base = (long)d.nis * ((long)(j - d.jlo) + (long)d.njs * k);
+    if (d.poison) { if (d.poison & (h < nwl ? 1 : 2)) d.f[base + (i - d.ilo)] = __builtin_nan(""); continue; }
     d.f[base + (i - d.ilo)] = d.f[base + (src - d.ilo)];
   }
 }
@@ -439,6 +441,7 @@ __global__ void halo_y_kernel(HaloDesc d) {
     int j, src;
     if (h < nws) { j = d.jlo + h; src = j + d.nj; } else { j = d.jce + 1 + (h - nws); src = j - d.nj; }
     long kb = (long)d.nis * d.njs * k;
+    if (d.poison) { if (d.poison & (h < nws ? 1 : 2)) d.f[kb + (long)d.nis * (j - d.jlo) + ii] = __builtin_nan(""); continue; }
     d.f[kb + (long)d.nis * (j - d.jlo) + ii] = d.f[kb + (long)d.nis * (src - d.jlo) + ii];
   }
 }
@@ -457,7 +460,7 @@ __global__ void halo_fold_kernel(HaloDesc d, int isum, int ys, int negate) {
     if (si < d.ilo || si > d.ihi) continue;
     const int j = d.jce + m, sj = ys ? d.jce - m : d.jce + 1 - m;
     const long kb = (long)d.nis * d.njs * k;
-    const double v = d.f[kb + (long)d.nis * (sj - d.jlo) + (si - d.ilo)];
+    const double v = d.poison ? __builtin_nan("") : d.f[kb + (long)d.nis * (sj - d.jlo) + (si - d.ilo)];
     d.f[kb + (long)d.nis * (j - d.jlo) + ii] = negate ? -v : v;
   }
 }
@@ -477,7 +480,7 @@ int halo_fold_north(mom6hip_ctx_t *ctx, double *f, int pos_flags, int nk, hipStr
   d.f = f; d.ilo = G.isd - xs; d.jlo = G.jsd - ys; d.ihi = G.ied; d.jhi = G.jed;
   d.nis = d.ihi - d.ilo + 1; d.njs = d.jhi - d.jlo + 1; d.nk = nk;
   d.ics = G.isc - xs; d.ice = G.iec; d.jcs = G.jsc - ys; d.jce = G.jec;
-  d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1;
+  d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1; d.poison = ctx->poison_now;
   const long total = (long)d.nis * (d.jhi - d.jce) * nk;
   if (total > 0) {
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
@@ -497,7 +500,7 @@ int halo_wrap_dir(mom6hip_ctx_t *ctx, double *f, int pos_flags, int nk, int dir,
   d.f = f; d.ilo = G.isd - xs; d.jlo = G.jsd - ys; d.ihi = G.ied; d.jhi = G.jed;
   d.nis = d.ihi - d.ilo + 1; d.njs = d.jhi - d.jlo + 1; d.nk = nk;
   d.ics = G.isc - xs; d.ice = G.iec; d.jcs = G.jsc - ys; d.jce = G.jec;
-  d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1;
+  d.ni = G.iec - G.isc + 1; d.nj = G.jec - G.jsc + 1; d.poison = ctx->poison_now;
   if (dir == 0) {
     long total = (long)((d.ics - d.ilo) + (d.ihi - d.ice)) * (d.jce - d.jcs + 1) * nk;
     if (total > 0) {
@@ -525,7 +528,8 @@ int halo_update_field(mom6hip_ctx_t *ctx, double *f, int pos, int nk) {
 }
 
 // start_group_pass / complete_group_pass / do_group_pass (MOM_domain_infra.F90:1141-1182)
-int start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
+namespace {
+int start_now(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
   if (ctx->native) return native_start_group_pass(ctx, fields, pos, nk, n);
   if (ctx->halo_cb) {      // the host's collective: the complete update, the tripolar fold included (pos may carry
                            // MOM6HIP_PASS_SCALAR_PAIR: only a fold tells a scalar pair from a vector)
@@ -537,8 +541,46 @@ int start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *p
     if (int rc = halo_update_field(ctx, fields[f], pos[f], nk[f])) return rc;
   return 0;
 }
+}  // namespace
+
+int start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk, int n) {
+  if (!ctx->poison_passes) return start_now(ctx, fields, pos, nk, n);
+  // debugging (mom6hip_debug_poison_passes): NaNs into every halo this pass is going to update, the update itself at
+  // complete_group_pass -- whatever reads one of these halos between the two calls shows up as a NaN, whatever the timing
+  M6_REQUIRE(ctx->pending.f.empty(), "start_group_pass: a pass is already in flight");
+  M6_REQUIRE(!ctx->halo_cb || ctx->native, "mom6hip_debug_poison_passes: not provided for the host's halo callback");
+  const mom6hip_grid_t &G = ctx->host;
+  int sides[2] = {0, G.reentrant_y ? 3 : 0};      // (one tile: the x wrap is done here, as the native pass of a tile that spans x does)
+  if (ctx->native) native_pass_sides(ctx, sides);
+  if (G.reentrant_x && (!ctx->native || native_x_is_local(ctx)))
+    for (int f = 0; f < n; f++)
+      if (int rc = halo_wrap_dir(ctx, fields[f], pos[f], nk[f], 0, ctx->stream)) return rc;
+  for (int f = 0; f < n; f++) {
+    for (int dir = 0; dir < 2; dir++) {
+      if (!sides[dir]) continue;
+      ctx->poison_now = sides[dir];
+      const int rc = halo_wrap_dir(ctx, fields[f], pos[f], nk[f], dir, ctx->stream);
+      ctx->poison_now = 0;
+      if (rc) return rc;
+    }
+    if (G.tripolar_n) {
+      ctx->poison_now = 3;
+      const int rc = halo_fold_north(ctx, fields[f], pos[f], nk[f], ctx->stream);
+      ctx->poison_now = 0;
+      if (rc) return rc;
+    }
+  }
+  ctx->pending.f.assign(fields, fields + n); ctx->pending.pos.assign(pos, pos + n); ctx->pending.nk.assign(nk, nk + n);
+  return 0;
+}
 
 int complete_group_pass(mom6hip_ctx_t *ctx) {
+  if (ctx->poison_passes && !ctx->pending.f.empty()) {
+    auto &P = ctx->pending;
+    const int rc = start_now(ctx, P.f.data(), P.pos.data(), P.nk.data(), (int)P.f.size());
+    P.f.clear(); P.pos.clear(); P.nk.clear();
+    if (rc) return rc;
+  }
   if (ctx->native) return native_complete_group_pass(ctx);
   return 0;
 }
@@ -547,6 +589,10 @@ int group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, co
   if (int rc = start_group_pass(ctx, fields, pos, nk, n)) return rc;
   return complete_group_pass(ctx);
 }
+
+bool pass_leaves_x_final(mom6hip_ctx_t *ctx) { return ctx->native ? native_x_is_local(ctx) : (ctx->halo_cb == nullptr); }
+void row_window(mom6hip_ctx_t *ctx, int j0, int j1) { ctx->g.jsc = j0; ctx->g.jec = j1; }
+void row_window_reset(mom6hip_ctx_t *ctx) { ctx->g.jsc = ctx->host.jsc; ctx->g.jec = ctx->host.jec; }
 
 int sum_across_PEs(mom6hip_ctx_t *ctx, int32_t *values, int n) {
   if (ctx->native) return native_allreduce(ctx, values, n, true);
@@ -561,6 +607,27 @@ int min_across_PEs(mom6hip_ctx_t *ctx, double *values, int n) {
 }
 
 }  // namespace m6
+
+// start_group_pass / complete_group_pass of MOM_domains (MOM_domain_infra.F90:1141-1182) on device fields: the update is in flight
+// between the two calls (on the communication stream of the library's own domain; at once on one tile)
+extern "C" int mom6hip_start_group_pass(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos, const int32_t *nk_each,
+                                        int32_t nfields) {
+  M6_REQUIRE(ctx && fields && pos && nk_each && nfields >= 0, "mom6hip_start_group_pass: null argument");
+  for (int f = 0; f < nfields; f++) M6_REQUIRE(fields[f] != nullptr, "mom6hip_start_group_pass: field %d is null", f);
+  return m6::start_group_pass(ctx, fields, pos, nk_each, nfields);
+}
+extern "C" int mom6hip_complete_group_pass(mom6hip_ctx_t *ctx) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_complete_group_pass: null context");
+  return m6::complete_group_pass(ctx);
+}
+
+extern "C" int mom6hip_debug_poison_passes(mom6hip_ctx_t *ctx, int32_t enable) {
+  M6_REQUIRE(ctx != nullptr, "mom6hip_debug_poison_passes: null context");
+  M6_REQUIRE(ctx->pending.f.empty(), "mom6hip_debug_poison_passes: a pass is in flight");
+  ctx->poison_passes = (enable & 1) != 0;
+  ctx->split_rows_always = (enable & 2) != 0;      // (bit 1: the interior / edge-band launches without the poisoning)
+  return 0;
+}
 
 extern "C" int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,
                                    const int32_t *nk_each, int32_t nfields) {

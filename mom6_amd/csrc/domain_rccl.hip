@@ -146,6 +146,12 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
   if (G.tripolar_n)
     M6_REQUIRE(D->hi[1] < 0 && (D->lo[0] < 0 || D->lo[0] == D->rank) && (D->hi[0] < 0 || D->hi[0] == D->rank),
                "group pass: a tile on the tripolar fold must span x (no x neighbour but itself) and cannot have a northern neighbour");
+  // A tile that spans x wraps its own x halos: on the compute stream, now -- the pass is non-blocking in y only, which is what
+  // lets the caller run the interior rows of the next kernels before complete_group_pass (m6::pass_leaves_x_final)
+  const bool x_local = D->lo[0] < 0 && D->hi[0] < 0;
+  if (x_local && G.reentrant_x)
+    for (int f = 0; f < n; f++)
+      if (int rc = halo_wrap_dir(ctx, fields[f], pos[f], nk[f], 0, ctx->stream)) return rc;
   M6_HIP(hipEventRecord(D->ev_ready, ctx->stream));
   M6_HIP(hipStreamWaitEvent(cs, D->ev_ready, 0));
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -158,8 +164,8 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
   const int w = h;
   for (int dir = 0; dir < 2; dir++) {
     const int lo = D->lo[dir], hi = D->hi[dir];
-    if (lo < 0 && hi < 0) {      // one tile in this direction: the local wrap (or a closed edge)
-      if ((dir == 0 && G.reentrant_x) || (dir == 1 && G.reentrant_y))
+    if (lo < 0 && hi < 0) {      // one tile in this direction: the local wrap (or a closed edge); x was done above
+      if (dir == 1 && G.reentrant_y)
         for (int f = 0; f < n; f++)
           if (int rc = halo_wrap_dir(ctx, fields[f], pos[f], nk[f], dir, cs)) return rc;
       continue;
@@ -210,6 +216,16 @@ int native_start_group_pass(mom6hip_ctx *ctx, double *const *fields, const int32
   D->npasses++;
   return 0;
 }
+
+void native_pass_sides(mom6hip_ctx *ctx, int sides[2]) {
+  const m6_native_domain *D = ctx->native;
+  const mom6hip_grid_t &G = ctx->host;
+  for (int dir = 0; dir < 2; dir++) sides[dir] = (D->lo[dir] >= 0 ? 1 : 0) | (D->hi[dir] >= 0 ? 2 : 0);
+  if (D->lo[1] < 0 && D->hi[1] < 0 && G.reentrant_y) sides[1] = 3;      // (the local y wrap runs on the communication stream)
+}
+
+bool native_x_is_local(mom6hip_ctx *ctx) { return ctx->native->lo[0] < 0 && ctx->native->hi[0] < 0; }
+
 
 int native_complete_group_pass(mom6hip_ctx *ctx) {
   M6_HIP(hipStreamWaitEvent(ctx->stream, ctx->native->ev_done, 0));

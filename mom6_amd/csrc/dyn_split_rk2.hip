@@ -10,6 +10,7 @@
 // synchronises with the host.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <initializer_list>
 #include <utility>
 
@@ -42,6 +43,43 @@ int pass(mom6hip_ctx_t *ctx, std::initializer_list<std::pair<double *, int>> fl,
   std::vector<double *> f; std::vector<int32_t> pos, nk;
   for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second & (3 | MOM6HIP_PASS_SCALAR_PAIR)); nk.push_back((e.second & 4) ? 1 : nk3); }
   return m6::group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size());
+}
+// The non-blocking form (start_group_pass / complete_group_pass, MOM_domain_infra.F90:1141-1182): the exchange runs on the
+// communication stream while the compute stream goes on with whatever does not read the halos in flight.
+int pass_start(mom6hip_ctx_t *ctx, std::initializer_list<std::pair<double *, int>> fl, int nk3, int seam = 0) {
+  std::vector<double *> f; std::vector<int32_t> pos, nk;
+  for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second & (3 | MOM6HIP_PASS_SCALAR_PAIR)); nk.push_back((e.second & 4) ? 1 : nk3); }
+  if (int rc = m6::start_group_pass(ctx, f.data(), pos.data(), nk.data(), (int)f.size())) return rc;
+  // MOM6HIP_BLOCKING_PASSES=1: every pass completes where it starts (G%nonblocking_updates = False; comparison runs)
+  // (=N > 1: a bit mask of the seams of the step, in order, that complete at once -- debugging)
+  static const int blocking = [] { const char *e = getenv("MOM6HIP_BLOCKING_PASSES"); return e ? atoi(e) : 0; }();
+  const bool now = blocking == 1 || (blocking > 1 && ((blocking >> 1) >> seam) & 1);
+  return now ? m6::complete_group_pass(ctx) : 0;
+}
+// Whether the rows of the tile are worth splitting around a pass in flight: the pass must leave the x halos final at its start
+// (the tile spans x) and the tile must be tall enough to have inner rows.
+bool split_rows(mom6hip_ctx_t *ctx) {
+  const int W = ctx->host.isc - ctx->host.isd, nj = ctx->host.jec - ctx->host.jsc + 1;
+  return m6::pass_leaves_x_final(ctx) && nj >= 4 * W + 8 && (m6::multi_tile(ctx) || ctx->poison_passes || ctx->split_rows_always);
+}
+// `work` (kernels that are pure functions of their inputs row by row, taking their rows from ctx->g) around the completion of the
+// pass in flight: the rows at least a halo width inside the tile before it, the two bands along the edges after it.
+template <class F> int around_pass(mom6hip_ctx_t *ctx, F work) {
+  if (!split_rows(ctx)) {
+    if (int rc = m6::complete_group_pass(ctx)) return rc;
+    return work();
+  }
+  const int js = ctx->host.jsc, je = ctx->host.jec, W = ctx->host.isc - ctx->host.isd;
+  m6::row_window(ctx, js + W, je - W);
+  int rc = work();
+  m6::row_window_reset(ctx);
+  if (rc) return rc;
+  if ((rc = m6::complete_group_pass(ctx))) return rc;
+  m6::row_window(ctx, js, js + W - 1);
+  rc = work();
+  if (!rc) { m6::row_window(ctx, je - W + 1, je); rc = work(); }
+  m6::row_window_reset(ctx);
+  return rc;
 }
 constexpr int PH = MOM6HIP_POS_H, PU = MOM6HIP_POS_U, PV = MOM6HIP_POS_V, P2D = 4;
 constexpr int PUs = PU | MOM6HIP_PASS_SCALAR_PAIR, PVs = PV | MOM6HIP_PASS_SCALAR_PAIR;      // To_All+SCALAR_PAIR (:462)
@@ -208,11 +246,14 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     }
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));                 // :610-611
+  // pass_eta, pass_visc_rem :541 / :607-611 / :631: in flight behind btcalc and bt_mass_source, which read no halo (the reference
+  // completes pass_visc_rem at :631 for the same reason: the continuity below forms fluxes in the rows of visc_rem's halo)
+  CALL(pass_start(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz, 0));
 
   // btcalc, bt_mass_source :627-630 ; continuity for BT_cont and the layer fluxes :634-644
   if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));
   CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
+  CALL(m6::complete_group_pass(ctx));
   if (BTC || cs->BT_use_layer_fluxes) {
     CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,
                             cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
@@ -243,24 +284,36 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   } else if (VV) {            // :717-744
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));            // :747, :751
+  // pass_visc_rem, pass_uvp :741-751 (the continuity forms its first direction's fluxes in the halo rows of the second: it reads
+  // the halos of up, vp and visc_rem, and it keeps its intermediate thicknesses in the output array, so its rows cannot be split)
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
                           u_av, v_av, BTC, nullptr, nullptr, D));
-  CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :763
-  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {             // :785-787
-    const long n = g.h3(i, j, k);
-    h_av[n] = 0.5 * (h[n] + hp[n]);
-  });
+  // pass_hp_uv :763 in flight behind bt_mass_source and btcalc (no halos) and behind the rows of h_av, horizontal_viscosity and
+  // CorAdCalc that lie at least a halo width inside the tile; the rows along the two edges follow the completion
+  const bool hv_hook = !cs->hor_visc && hk && hk->horizontal_viscosity;
+  auto after_hp_uv = [&]() -> int {      // (pure functions of their inputs, row by row: a row computed twice gets the same bits)
+    const m6::GridDev w = ctx->g;      // the window
+    launch3d(s, is - 2, ie + 2, w.jsc - 2, w.jec + 2, nz, [=] __device__(int i, int j, int k) {     // :785-787
+      const long n = g.h3(i, j, k);
+      h_av[n] = 0.5 * (h[n] + hp[n]);
+    });
+    if (cs->hor_visc) {   // :860 (hu_cont, hv_cont = BT_cont%h_u, %h_v: read only with USE_CONT_THICKNESS)
+      if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, BTC ? BTC->h_u : nullptr,
+                                       BTC ? BTC->h_v : nullptr)) return 1;
+    }
+    if (!hv_hook) CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
+    return 0;
+  };
+  CALL(pass_start(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz, 2));             // :763
   CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :797
   if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :843
-  if (cs->hor_visc) {   // :860 (hu_cont, hv_cont = BT_cont%h_u, %h_v: read only with USE_CONT_THICKNESS)
-    if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, BTC ? BTC->h_u : nullptr,
-                                     BTC ? BTC->h_v : nullptr)) return 1;
-  } else if (hk && hk->horizontal_viscosity) {
+  CALL(around_pass(ctx, after_hp_uv));
+  if (hv_hook) {
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->horizontal_viscosity(hk->user, u_av, v_av, h_av, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
+    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
   }
-  CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
   bc_accel(cs->CAu, cs->CAv, false);                                                                  // :879-886
   CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :911
                       cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
@@ -284,28 +337,51 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
-  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));     // :1004, :1008
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));     // :991-1008
   CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :1015
                           cs->visc_rem_v, u_av, v_av, nullptr, nullptr, nullptr, D));
-  CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :1018, :1027
-  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {              // :1038-1040
-    const long n = g.h3(i, j, k);
-    h_av[n] = 0.5 * (h_av[n] + h[n]);
-  });
-  launch3d(s, Isq - 2, Ieq + 2, js - 2, je + 2, nz, [=] __device__(int I, int j, int k) {            // :1046-1053
-    const long n = g.u3(I, j, k);
-    uhtr[n] = uhtr[n] + uh[n] * dt;
-  });
-  launch3d(s, is - 2, ie + 2, Jsq - 2, Jeq + 2, nz, [=] __device__(int i, int J, int k) {
-    const long n = g.v3(i, J, k);
-    vhtr[n] = vhtr[n] + vh[n] * dt;
-  });
-  if (cs->store_CAu) {   // :1055-1069
-    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
-    cs->CAu_pred_stored = 1;
+  // pass_h, pass_av_uvh :1018-1043 in flight behind the rows of the three accumulations and of CorAdCalc that need no halo row.
+  // The accumulations work in place: their rows are split exactly (inner rows before the completion, the two edge bands after).
+  auto accumulate = [&](int ja, int jb, int Ja, int Jb) {      // cell rows ja..jb, v-face rows Ja..Jb
+    launch3d(s, is - 2, ie + 2, ja, jb, nz, [=] __device__(int i, int j, int k) {                      // :1038-1040
+      const long n = g.h3(i, j, k);
+      h_av[n] = 0.5 * (h_av[n] + h[n]);
+    });
+    launch3d(s, Isq - 2, Ieq + 2, ja, jb, nz, [=] __device__(int I, int j, int k) {                    // :1046-1053
+      const long n = g.u3(I, j, k);
+      uhtr[n] = uhtr[n] + uh[n] * dt;
+    });
+    launch3d(s, is - 2, ie + 2, Ja, Jb, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      vhtr[n] = vhtr[n] + vh[n] * dt;
+    });
+  };
+  auto next_CA = [&]() -> int {
+    if (cs->store_CAu) CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));   // :1055-1069
+    return 0;
+  };
+  CALL(pass_start(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz, 4));               // :1018, :1027
+  if (split_rows(ctx)) {
+    const int W = is - g.isd;      // the halo width: CorAdCalc's rows at least W inside the tile read rows of the compute domain only
+    accumulate(js + 2, je - 2, Jsq + 2, Jeq - 2);      // (h_av's inner rows reach two rows beyond the window of next_CA below)
+    m6::row_window(ctx, js + W + 2, je - W - 2);
+    int rc = next_CA();
+    m6::row_window_reset(ctx);
+    if (rc) return rc;
+    CALL(m6::complete_group_pass(ctx));
+    accumulate(js - 2, js + 1, Jsq - 2, Jsq + 1);
+    accumulate(je - 1, je + 2, Jeq - 1, Jeq + 2);
+    m6::row_window(ctx, js, js + W + 1);
+    rc = next_CA();
+    if (!rc) { m6::row_window(ctx, je - W - 1, je); rc = next_CA(); }
+    m6::row_window_reset(ctx);
+    if (rc) return rc;
   } else {
-    cs->CAu_pred_stored = 0;
+    CALL(m6::complete_group_pass(ctx));
+    accumulate(js - 2, je + 2, Jsq - 2, Jeq + 2);
+    CALL(next_CA());
   }
+  cs->CAu_pred_stored = cs->store_CAu ? 1 : 0;
   M6_HIP(hipGetLastError());
   return 0;
 }

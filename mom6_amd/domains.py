@@ -49,6 +49,9 @@ class Domain:
         # self_exchange: a re-entrant direction with ONE tile goes through the exchange with this rank as its own neighbour
         # instead of the local wrap (rehearses the native RCCL path on a single GPU)
         self.self_exchange = bool(self_exchange)
+        # self_exchange = "y": only y goes through the exchange; x is the tile's own wrap (what a 1 x N layout does: the rehearsal of
+        # the non-blocking passes with their interior / edge-band launches on one GPU)
+        self.self_exchange_x = bool(self_exchange) and self_exchange != "y"
         self.pi, self.pj = self.rank % self.npi, self.rank // self.npi          # PE numbering: i fastest
         self.i_starts, self.i_sizes = compute_extent(self.NI, self.npi)
         self.j_starts, self.j_sizes = compute_extent(self.NJ, self.npj)
@@ -86,7 +89,7 @@ class Domain:
         if gg.ni != self.NI or gg.nj != self.NJ or gg.halo != self.halo:
             raise ValueError("tile_grid: global grid does not match the domain")
         t = Grid(ni=self.ni, nj=self.nj, nk=gg.nk, halo=self.halo,
-                 reentrant_x=self.reentrant_x and self.npi == 1 and not self.self_exchange,
+                 reentrant_x=self.reentrant_x and self.npi == 1 and not self.self_exchange_x,
                  reentrant_y=self.reentrant_y and self.npj == 1 and not self.self_exchange,
                  tripolar_n=self.on_fold, first_direction=gg.first_direction, Angstrom_H=gg.Angstrom_H, H_to_Z=gg.H_to_Z, Z_to_H=gg.Z_to_H,
                  g_Earth=gg.g_Earth, Rho0=gg.Rho0)
@@ -315,7 +318,7 @@ class Domain:
 
         def nb(dpi, dpj, ntile, reentrant):
             if ntile == 1:
-                return self.rank if (self.self_exchange and reentrant) else -1
+                return self.rank if ((self.self_exchange_x if dpi else self.self_exchange) and reentrant) else -1
             r = self._nbr(dpi, dpj)
             return -1 if r is None else r
         dom = _abi.DomainStruct(self.nranks, self.rank, nb(-1, 0, self.npi, self.reentrant_x), nb(+1, 0, self.npi, self.reentrant_x),

@@ -281,6 +281,28 @@ interface
     integer(c_int) :: rc
   end function mom6hip_memset_zero
 
+  function mom6hip_start_group_pass(ctx, fields, pos, nk_each, nfields) bind(c, name="mom6hip_start_group_pass") result(rc)
+    import :: c_int, c_ptr, c_int32_t
+    type(c_ptr), value :: ctx
+    type(c_ptr), intent(in) :: fields(*)
+    integer(c_int32_t), intent(in) :: pos(*), nk_each(*)
+    integer(c_int32_t), value :: nfields
+    integer(c_int) :: rc
+  end function mom6hip_start_group_pass
+
+  function mom6hip_complete_group_pass(ctx) bind(c, name="mom6hip_complete_group_pass") result(rc)
+    import :: c_int, c_ptr
+    type(c_ptr), value :: ctx
+    integer(c_int) :: rc
+  end function mom6hip_complete_group_pass
+
+  function mom6hip_debug_poison_passes(ctx, enable) bind(c, name="mom6hip_debug_poison_passes") result(rc)
+    import :: c_int, c_ptr, c_int32_t
+    type(c_ptr), value :: ctx
+    integer(c_int32_t), value :: enable
+    integer(c_int) :: rc
+  end function mom6hip_debug_poison_passes
+
   function mom6hip_transfer_stats(ctx, stats, reset) bind(c, name="mom6hip_transfer_stats") result(rc)
     import :: c_int, c_ptr, c_int64_t, c_int32_t
     type(c_ptr), value :: ctx

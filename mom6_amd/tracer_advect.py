@@ -52,6 +52,13 @@ class DeviceGrid:
         check(lib().mom6hip_bt_graph_stats(self.handle, C.byref(a), C.byref(b)), "mom6hip_bt_graph_stats")
         return a.value, b.value
 
+    def debug_poison_passes(self, poison=True, split_rows=False):
+        """mom6hip_debug_poison_passes: NaNs into the halos of every non-blocking pass between its start and its completion (a halo read
+        too early then shows in the results whatever the timing); split_rows: the interior / edge-band launches around the passes
+        even on one tile."""
+        L = lib(); L.mom6hip_debug_poison_passes.argtypes = [C.c_void_p, C.c_int32]
+        check(L.mom6hip_debug_poison_passes(self.handle, int(bool(poison)) | (2 if split_rows else 0)), "mom6hip_debug_poison_passes")
+
     def kernel_timing(self, enable):
         """(ms_total, launches) per timing slot since recording was switched on (mom6hip_kernel_timing)."""
         ms = (C.c_double * 2)(); n = (C.c_int64 * 2)()
@@ -65,6 +72,17 @@ class DeviceGrid:
         pos = (C.c_int32 * n)(*positions)
         nks = (C.c_int32 * n)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
         check(lib().mom6hip_halo_update(self.handle, ptrs, pos, nks, n), "mom6hip_halo_update")
+
+    def start_group_pass(self, fields, positions):
+        """start_group_pass (MOM_domain_infra.F90:1141): the halo update of the fields is in flight until complete_group_pass."""
+        n = len(fields)
+        ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in fields])
+        pos = (C.c_int32 * n)(*positions)
+        nks = (C.c_int32 * n)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
+        check(lib().mom6hip_start_group_pass(self.handle, ptrs, pos, nks, n), "mom6hip_start_group_pass")
+
+    def complete_group_pass(self):
+        check(lib().mom6hip_complete_group_pass(self.handle), "mom6hip_complete_group_pass")
 
     def set_domain(self, domain):
         """Attach a multi-tile Domain (mom6_amd/domains.py): the group pass and sum_across_PEs that happen

@@ -135,3 +135,95 @@ def test_tripolar_fold_in_the_native_exchange():
     for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uhtr", uhtr, ref.uhtr), ("eta", CS.eta, ref.arrs["eta"])):
         assert bits_equal(a.cpu().numpy(), b), name
     dg.close()
+
+
+def _three_viscous_steps(g, dg, poison=None):
+    """three steps of step_MOM_dyn_split_RK2 with vertical and horizontal viscosity on the device grid dg against the oracle on g"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.vert_friction import vertvisc_type
+    d = xs.make_state(g, umax=0.1, terrain_following=True)
+    taux, tauy = xs.wind_stress(g); bbl = xs.bbl_arrays(g)
+    dt = 1800.0
+    hv = dict(Laplacian=1, Kh_vel_scale=0.01, Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06)
+    hvn = dict(LAPLACIAN=1, KH_VEL_SCALE=0.01, AH_VEL_SCALE=0.05, SMAGORINSKY_AH=1, SMAG_BI_CONST=0.06)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0),
+                       visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **hv))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0), hor_visc=hvn)
+    if poison is not None:
+        dg.debug_poison_passes(**poison)
+    visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy, calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        for name, a, b in (("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("vh", vh, ref.vh), ("uhtr", uhtr, ref.uhtr),
+                           ("vhtr", vhtr, ref.vhtr), ("eta_av", eta_av, ref.eta_av), ("h_av", CS.h_av, ref.arrs["h_av"]),
+                           ("CAu_pred", CS.CAu_pred, ref.arrs["CAu_pred"]), ("diffu", CS.diffu, ref.arrs["diffu"])):
+            an = a.cpu().numpy()
+            assert not np.isnan(an).any(), (n, name, "a halo was read while its pass was in flight")
+            assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+
+
+@pytest.mark.gpu
+def test_poisoned_passes_hold_nans_until_they_complete():
+    """the debugging aid itself: between start_group_pass and complete_group_pass every halo the pass fills (and nothing else) is NaN;
+    the completed pass equals the plain update"""
+    import torch
+    from mom6_amd.tracer_advect import DeviceGrid
+    g = xs.make_grid(20, 14, 2, reentrant_x=True, reentrant_y=True)
+    dg = DeviceGrid(g)
+    dg.debug_poison_passes(True)
+    rng = np.random.default_rng(8)
+    for pos in (H, U, V):
+        a = rng.standard_normal(g.shape3(pos))
+        w = a.copy(); orc.halo_update(g, w, pos)
+        f = torch.from_numpy(a).cuda()
+        dg.start_group_pass([f], [pos]); dg.sync()
+        mid = f.cpu().numpy()
+        sj, si = g.csl(pos)
+        assert not np.isnan(mid[:, sj, :]).any()              # x is final when start returns (the tile spans x)
+        assert np.isnan(mid[:, :sj.start, :]).all() and np.isnan(mid[:, sj.stop:, :]).all()
+        dg.complete_group_pass(); dg.sync()
+        assert bits_equal(f.cpu().numpy(), w), pos
+    dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["poison", "poison+split", "split"])
+def test_nothing_reads_a_halo_while_its_pass_is_in_flight(mode):
+    """The step starts its group passes where the reference does (MOM_dynamics_split_RK2.F90:541, :608, :741, :763, :991, :1018) and
+    completes them as late as the next reader of a halo allows, with the rows a halo width inside the tile of h_av, horizontal
+    viscosity, CorAdCalc and the accumulations of uhtr / vhtr / h_av enqueued BEFORE the completion.  Proof that none of this reads a
+    halo too early, independent of any timing: with mom6hip_debug_poison_passes every halo a pass will fill is NaN from its start to
+    its completion -- three viscous steps on a doubly re-entrant tile are still the oracle's bits, without a NaN"""
+    from mom6_amd.tracer_advect import DeviceGrid
+    # (no land: with land along the tile's edges nothing depends on the halos -- a test of nothing)
+    g = xs.make_grid(44, 40, 4, land_frac=0.0, reentrant_x=True, reentrant_y=True)
+    dg = DeviceGrid(g)
+    _three_viscous_steps(g, dg, poison=dict(poison="poison" in mode, split_rows="split" in mode))
+    dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("poison", [False, True])
+def test_row_split_around_the_native_exchange(poison):
+    """the same through the library's own exchange: x is the tile's wrap, y goes through ncclSend / ncclRecv on the communication
+    stream (this rank as its own northern and southern neighbour: a 1 x N layout seen from one tile), inner rows before the
+    completion, edge bands after it"""
+    import torch  # noqa: F401
+    from mom6_amd.domains import Domain
+    from mom6_amd.tracer_advect import DeviceGrid
+    g = xs.make_grid(44, 40, 4, land_frac=0.0, reentrant_x=True, reentrant_y=True)
+    dom = Domain(g.ni, g.nj, (1, 1), 0, g.halo, True, True, self_exchange="y")
+    tg = dom.tile_grid(g)
+    assert tg.reentrant_x and not tg.reentrant_y
+    dg = DeviceGrid(tg)
+    dom.attach_native(dg)
+    _three_viscous_steps(g, dg, poison=dict(poison=poison, split_rows=False))
+    dg.close()
