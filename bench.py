@@ -794,10 +794,26 @@ def main():
         for _ in range(3):
             advect_tracer(ad["h_end"], ad["uhtr"], ad["vhtr"], None, DT_THERM, S.dg, S.adv_cs, ad["tr"])
             t = S.dg.advect_timing(); tx += t.ms_x1 / 3; ty += t.ms_y1 / 3
+        # TRACER_ADVECTION_SCHEME = PPM (the Colella-Woodward edge values, MOM_tracer_advect.F90:722-760) beside the configured
+        # PPM:H3, on the same state (SURVEY.md 8d C2 asks for both)
+        from mom6_amd.tracer_advect import tracer_advect_init
+        cs_ppm = tracer_advect_init(DT, "PPM")
+        px = py = pc = 0.0
+        for q in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            advect_tracer(ad["h_end"], ad["uhtr"], ad["vhtr"], None, DT_THERM, S.dg, cs_ppm, ad["tr"])
+            e1.record(); e1.synchronize()
+            t = S.dg.advect_timing()
+            if q:      # (the first call: work-space allocation)
+                px += t.ms_x1 / 3; py += t.ms_y1 / 3; pc += e0.elapsed_time(e1) / 3
         S.dg.set_timing(False)
         cand = {k: (ALG_BYTES[k] * cells, ms) for k, ms in comp_ms.items() if k in ALG_BYTES}
         cand["adv_x_kernel<4,PPM:H3,first>"] = ((NTR + 2) * 16.0 * cells, tx)
         cand["adv_y_kernel<4,PPM:H3,first>"] = ((NTR + 2) * 16.0 * cells, ty)
+        cand["adv_x_kernel<4,PPM,first>"] = ((NTR + 2) * 16.0 * cells, px)
+        cand["adv_y_kernel<4,PPM,first>"] = ((NTR + 2) * 16.0 * cells, py)
+        out["advect_tracer_PPM_ms_per_call"] = pc
         out.setdefault("roofline", {})["operators"] = {
             k: {"GBs": bb / (m * 1e-3) / 1e9, "frac": bb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": m} for k, (bb, m) in cand.items()}
         S.dg.close()

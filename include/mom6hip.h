@@ -937,6 +937,53 @@ typedef struct mom6hip_visc_hooks {
                               double *diffv);
 } mom6hip_visc_hooks_t;
 
+/* ---- MOM_thickness_diffuse (src/parameterizations/lateral/MOM_thickness_diffuse.F90) ---------------------------------
+ * thickness_diffuse_CS (:40-128) as far as the provided branch reads it, and the fields the reference takes from MEKE / VarMix as
+ * plain arrays.  Provided: isopycnal height diffusion (Gent-McWilliams) with the diffusivity KHTH, bounded by
+ * KHTH_MIN / KHTH_MAX / KHTH_MAX_CFL, plus MEKE%KhTh_fac*sqrt(MEKE%Kh(i)*MEKE%Kh(i+1)), plus the Visbeck term
+ * KHTH_SLOPE_CFF*VarMix%L2u*VarMix%SN_u, times VarMix%Res_fn_u (:182-262); thickness_diffuse_full (:634-1670) with an equation of
+ * state (slopes from the density gradients, vert_fill_TS, the slope-limited "safe" streamfunction) or without one (layer
+ * densities), with stored slopes (VarMix%slope_x/y) or its own, Boussinesq; the work done against the stratification into
+ * MEKE%GM_src (:1196-1209, :1552-1622); the transports into uhtr / vhtr and the thickness tendency (:607-620).
+ * Refused: KHTH_USE_FGNV_STREAMFUNCTION, DETANGLE_INTERFACES, KH_ETA_CONST / KH_ETA_VEL_SCALE, USE_STANLEY_GM, MEKE_GEOMETRIC,
+ * MEKE_GM_SRC_ALT, READ_KHTH, KHTH_USE_EBT_STRUCT, the QG Leith GM coefficient, DEPTH_SCALED_KHTH, USE_KH_IN_MEKE, SKEB,
+ * KHTH_MAX_CFL <= 0, non-Boussinesq, tv%p_surf. */
+typedef struct mom6hip_thickness_diffuse_cs {
+  double Khth;             /* KHTH [L2 T-1] (0) */
+  double Khth_Min;         /* KHTH_MIN (0) */
+  double Khth_Max;         /* KHTH_MAX (0: no maximum) */
+  double max_Khth_CFL;     /* KHTH_MAX_CFL (0.8) */
+  double slope_max;        /* KHTH_SLOPE_MAX [Z L-1] (0.01) */
+  double kappa_smooth;     /* KD_SMOOTH [H Z T-1] (1e-6) */
+  double KHTH_Slope_Cff;   /* KHTH_SLOPE_CFF (0): the Visbeck term needs L2u, L2v, SN_u, SN_v */
+  double KhTh_fac;         /* MEKE%KhTh_fac (1): MEKE_KHTH_FAC, with MEKE_Kh */
+  double reserved0[4];
+  int32_t thickness_diffuse;   /* THICKNESSDIFFUSE (0): without it (or with nothing to diffuse with, :192-194) the call returns at once */
+  int32_t use_GM_work_bug;     /* USE_GM_WORK_BUG (0) */
+  int32_t nkml;                /* GV%nkml (0): the streamfunction goes linearly to zero over max(nkml, 1) layers */
+  int32_t initialized;
+  int32_t use_variable_mixing; /* VarMix%use_variable_mixing (0): with it the call works even with KHTH = 0 (:192-194), and the
+                                  Visbeck term is added when KHTH_SLOPE_CFF > 0 and L2u ... SN_v are given (:205-207, :242-249) */
+  int32_t reserved_i[1];
+  int32_t unsupported[10];     /* FGNV, detangle, Kh_eta, Stanley, MEKE_GEOMETRIC, GM_src_alt, read_khth, ebt_struct / QG Leith / depth
+                                  scaling, Use_KH_in_MEKE, non-Boussinesq / p_surf / SKEB: any nonzero is refused */
+  /* fields of MEKE and VarMix, in the memory space of the call; NULL = not allocated / not in use */
+  const double *MEKE_Kh;       /* MEKE%Kh, h points 2-D (valid halo of 1) */
+  const double *L2u, *L2v, *SN_u, *SN_v;      /* VarMix%L2u ... (use_Visbeck), u / v points 2-D */
+  const double *Res_fn_u, *Res_fn_v;          /* VarMix%Res_fn_u / _v (RESOLN_SCALED_KHTH), 2-D */
+  const double *slope_x, *slope_y;            /* VarMix%slope_x / _y (USE_STORED_SLOPES), u / v points, nk+1 interfaces */
+  double *MEKE_GM_src;         /* MEKE%GM_src, h points 2-D: set to the work of this call (:197-199, :1560) */
+  const double *Rlay;          /* GV%Rlay(1:nk) (HOST array): the work without an equation of state (:827, :1218) */
+  void *reserved1[3];
+} mom6hip_thickness_diffuse_cs_t;
+
+/* thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH)                               :133
+ * tv%T, tv%S, tv%eqn_of_state are passed as T, S, eos (all NULL without an equation of state).  h, uhtr, vhtr are updated on the
+ * compute domain (h needs a valid halo of 1, T and S too); uhGM / vhGM (CDp%uhGM / vhGM) receive the transports when not NULL. */
+int mom6hip_thickness_diffuse(mom6hip_ctx_t *ctx, const mom6hip_thickness_diffuse_cs_t *cs, double *h, double *uhtr, double *vhtr,
+                              const double *T, const double *S, const mom6hip_eos_t *eos, double dt, double *uhGM, double *vhGM,
+                              int32_t memspace);
+
 /*
  * MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84-268: the parameters the provided branch reads, the
  * control structures of the modules the step calls, and the arrays the reference keeps in the control structure

@@ -14,14 +14,13 @@ module MOM_PressureForce_FV
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_read_eos, mom6hip_fatal_if
 use MOM_ALE,              only : ALE_CS
 use MOM_diag_mediator,    only : diag_ctrl, time_type
 use MOM_error_handler,    only : MOM_error, MOM_mesg, FATAL
 use MOM_file_parser,      only : get_param, log_version, param_file_type
 use MOM_grid,             only : ocean_grid_type
 use MOM_self_attr_load,   only : SAL_CS
-use MOM_string_functions, only : uppercase
 use MOM_tidal_forcing,    only : tidal_forcing_CS
 use MOM_unit_scaling,     only : unit_scale_type
 use MOM_variables,        only : thermo_var_ptrs
@@ -161,7 +160,6 @@ subroutine PressureForce_FV_init(Time, G, GV, US, param_file, diag, CS, SAL_CSp,
   type(tidal_forcing_CS), intent(in), target, optional :: tides_CSp
 # include "version_variable.h"
   character(len=40)  :: mdl
-  character(len=40)  :: tmpstr
   logical :: use_ALE, flag
 
   CS%initialized = .true.
@@ -195,28 +193,7 @@ subroutine PressureForce_FV_init(Time, G, GV, US, param_file, diag, CS, SAL_CSp,
   CS%GFS_scale = 1.0
   if (GV%g_prime(1) /= GV%g_Earth) CS%GFS_scale = GV%g_prime(1) / GV%g_Earth
 
-  ! the equation of state, as interpret_eos_selection reads it (MOM_EOS.F90:1474-1520)
-  call get_param(param_file, "MOM_EOS", "EQN_OF_STATE", tmpstr, &
-                 "EQN_OF_STATE determines which ocean equation of state should be used.", default="WRIGHT")
-  CS%eos%reserved = 0 ; CS%eos%Rho_T0_S0 = 1000.0 ; CS%eos%dRho_dT = -0.2 ; CS%eos%dRho_dS = 0.8
-  select case (uppercase(tmpstr))
-    case ("LINEAR")
-      CS%eos%form = MOM6HIP_EOS_LINEAR
-      call get_param(param_file, "MOM_EOS", "RHO_T0_S0", CS%eos%Rho_T0_S0, units="kg m-3", default=1000.0)
-      call get_param(param_file, "MOM_EOS", "DRHO_DT", CS%eos%dRho_dT, units="kg m-3 K-1", default=-0.2)
-      call get_param(param_file, "MOM_EOS", "DRHO_DS", CS%eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
-    case ("WRIGHT")
-      CS%eos%form = MOM6HIP_EOS_WRIGHT
-    case ("UNESCO", "JACKETT_MCD")
-      CS%eos%form = MOM6HIP_EOS_UNESCO
-    case ("WRIGHT_FULL")
-      CS%eos%form = MOM6HIP_EOS_WRIGHT_FULL
-    case ("WRIGHT_REDUCED")
-      CS%eos%form = MOM6HIP_EOS_WRIGHT_REDUCED
-    case default
-      call MOM_error(FATAL, "PressureForce_FV_init (HIP): EQN_OF_STATE "//trim(tmpstr)//" is not provided by the GPU path "// &
-                            "(WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, LINEAR).")
-  end select
+  call mom6hip_read_eos(param_file, CS%eos, "PressureForce_FV_init")
   call mom6hip_read_topology(param_file)
 contains
   subroutine refuse(on, name)

@@ -21,10 +21,11 @@ use MOM_domains,       only : pass_var, CENTER, EAST_FACE, NORTH_FACE, CORNER
 use MOM_error_handler, only : MOM_error, FATAL
 use MOM_file_parser,   only : get_param, param_file_type
 use MOM_grid,          only : ocean_grid_type
+use MOM_string_functions, only : uppercase
 use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
 
-public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_shared_context, mom6hip_shared_context_end
+public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6hip_fatal_if, mom6hip_shared_context, mom6hip_shared_context_end
 
 !> The grid of the (single) ocean instance the callbacks act on
 type(ocean_grid_type), pointer, save :: G_cb => NULL()
@@ -57,6 +58,36 @@ subroutine mom6hip_read_topology(param_file, reentrant)
   topology_known = .true. ; reentrant_saved(:) = re(:) ; tripolar_saved = tripolar_N
   if (present(reentrant)) reentrant(:) = re(:)
 end subroutine mom6hip_read_topology
+
+!> The equation of state as interpret_eos_selection reads it (MOM_EOS.F90:1474-1520): EOS_type is opaque in MOM6, so the shims
+!! that need the equation of state (MOM_PressureForce_FV, MOM_thickness_diffuse) read its selection from the parameter file.
+subroutine mom6hip_read_eos(param_file, eos, who)
+  type(param_file_type), intent(in)  :: param_file
+  type(mom6hip_eos_t),   intent(out) :: eos
+  character(len=*),      intent(in)  :: who
+  character(len=40) :: tmpstr
+  call get_param(param_file, "MOM_EOS", "EQN_OF_STATE", tmpstr, &
+                 "EQN_OF_STATE determines which ocean equation of state should be used.", default="WRIGHT")
+  eos%reserved = 0 ; eos%Rho_T0_S0 = 1000.0 ; eos%dRho_dT = -0.2 ; eos%dRho_dS = 0.8
+  select case (uppercase(tmpstr))
+    case ("LINEAR")
+      eos%form = MOM6HIP_EOS_LINEAR
+      call get_param(param_file, "MOM_EOS", "RHO_T0_S0", eos%Rho_T0_S0, units="kg m-3", default=1000.0)
+      call get_param(param_file, "MOM_EOS", "DRHO_DT", eos%dRho_dT, units="kg m-3 K-1", default=-0.2)
+      call get_param(param_file, "MOM_EOS", "DRHO_DS", eos%dRho_dS, units="kg m-3 ppt-1", default=0.8)
+    case ("WRIGHT")
+      eos%form = MOM6HIP_EOS_WRIGHT
+    case ("UNESCO", "JACKETT_MCD")
+      eos%form = MOM6HIP_EOS_UNESCO
+    case ("WRIGHT_FULL")
+      eos%form = MOM6HIP_EOS_WRIGHT_FULL
+    case ("WRIGHT_REDUCED")
+      eos%form = MOM6HIP_EOS_WRIGHT_REDUCED
+    case default
+      call MOM_error(FATAL, who//" (HIP): EQN_OF_STATE "//trim(tmpstr)//" is not provided by the GPU path "// &
+                            "(WRIGHT, WRIGHT_FULL, WRIGHT_REDUCED, UNESCO, LINEAR).")
+  end select
+end subroutine mom6hip_read_eos
 
 !> The process-wide context (created on the first call, from whichever module gets there first).  The *_init of every
 !! shim calls mom6hip_read_topology, so the one-tile fast path knows REENTRANT_X / REENTRANT_Y by then.

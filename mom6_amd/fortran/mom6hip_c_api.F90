@@ -192,6 +192,20 @@ type, bind(c) :: mom6hip_hor_visc_cs_t
   type(c_ptr) :: reserved1(1)
 end type mom6hip_hor_visc_cs_t
 
+!> mom6hip_thickness_diffuse_cs_t (thickness_diffuse_CS, src/parameterizations/lateral/MOM_thickness_diffuse.F90:40)
+type, bind(c) :: mom6hip_thickness_diffuse_cs_t
+  real(c_double) :: Khth = 0.0, Khth_Min = 0.0, Khth_Max = 0.0, max_Khth_CFL = 0.8, slope_max = 0.01, kappa_smooth = 1.0e-6
+  real(c_double) :: KHTH_Slope_Cff = 0.0, KhTh_fac = 1.0
+  real(c_double) :: reserved0(4) = 0.0
+  integer(c_int32_t) :: thickness_diffuse = 0, use_GM_work_bug = 0, nkml = 0, initialized = 0, use_variable_mixing = 0
+  integer(c_int32_t) :: reserved_i(1) = 0
+  integer(c_int32_t) :: unsupported(10) = 0
+  type(c_ptr) :: MEKE_Kh = c_null_ptr, L2u = c_null_ptr, L2v = c_null_ptr, SN_u = c_null_ptr, SN_v = c_null_ptr
+  type(c_ptr) :: Res_fn_u = c_null_ptr, Res_fn_v = c_null_ptr, slope_x = c_null_ptr, slope_y = c_null_ptr
+  type(c_ptr) :: MEKE_GM_src = c_null_ptr, Rlay = c_null_ptr
+  type(c_ptr) :: reserved1(3) = c_null_ptr
+end type mom6hip_thickness_diffuse_cs_t
+
 !> mom6hip_dyn_split_rk2_cs_t (MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84); every array is a DEVICE
 !! array obtained from mom6hip_malloc
 type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
@@ -684,6 +698,19 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_set_viscous_ml
+
+  !> thickness_diffuse (MOM_thickness_diffuse.F90:133); T, S, eos are c_null_ptr without an equation of state
+  function mom6hip_thickness_diffuse(ctx, cs, h, uhtr, vhtr, T, S, eos, dt, uhGM, vhGM, memspace) &
+      bind(c, name="mom6hip_thickness_diffuse") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_thickness_diffuse_cs_t
+    type(c_ptr), value :: ctx
+    type(mom6hip_thickness_diffuse_cs_t), intent(in) :: cs
+    type(c_ptr), value :: h, uhtr, vhtr, T, S, eos
+    real(c_double), value :: dt
+    type(c_ptr), value :: uhGM, vhGM
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_thickness_diffuse
 
   !> hor_visc_init (MOM_hor_visc.F90:1984): the static arrays of the control structure
   function mom6hip_hor_visc_init(ctx, cs, dt, memspace) bind(c, name="mom6hip_hor_visc_init") result(rc)

@@ -149,6 +149,8 @@ int orc_pressureforce_fv_nonbouss(const mom6hip_grid_t *G, const mom6hip_pressur
                                   double *PFu, double *PFv, double *pbce, double *eta);
 
 /* ---- MOM_barotropic (oracle/barotropic.c) ----------------------------------------------------- */
+int orc_thickness_diffuse(const mom6hip_grid_t *G, const mom6hip_thickness_diffuse_cs_t *CS, double *h, double *uhtr, double *vhtr,
+                          const double *T, const double *S, const mom6hip_eos_t *EOS, double dt, double *uhGM, double *vhGM);
 double orc_cr_exp(double t);             /* correctly rounded exp(t), t <= 0 (0 below -700) */
 double orc_cr_pow(double x, double y);   /* correctly rounded x**y, 0 < x <= 1, 0 < y <= 1 */
 double orc_cr_cos(double x);             /* correctly rounded cos(x), |x| <= pi (cr_trig.c) */

@@ -829,3 +829,37 @@ def ale_remap_velocities(grid, scheme, h_old_u, h_old_v, h_new_u, h_new_v, u, v,
     rc = L.orc_ale_remap_velocities(C.byref(grid.struct()), C.byref(cs), _p(h_old_u), _p(h_old_v), _p(h_new_u), _p(h_new_v), _p(u), _p(v))
     if rc:
         raise RuntimeError(f"orc_ale_remap_velocities rc={rc}")
+
+
+# ---- MOM_thickness_diffuse ----------------------------------------------------------------------------------------
+def thickness_diffuse_cs(grid, Khth=0.0, Khth_Min=0.0, Khth_Max=0.0, max_Khth_CFL=0.8, slope_max=0.01, kappa_smooth=1.0e-6, KHTH_Slope_Cff=0.0,
+                         KhTh_fac=1.0, thickness_diffuse=True, use_GM_work_bug=False, nkml=0, use_variable_mixing=False, **fields):
+    """mom6hip_thickness_diffuse_cs_t with the defaults of thickness_diffuse_init (MOM_thickness_diffuse.F90:2169-2400); fields: the
+    arrays of MEKE / VarMix by the struct's member names (MEKE_Kh, L2u, ..., slope_x, slope_y, MEKE_GM_src, Rlay) or the names of
+    _abi.THICKNESS_DIFFUSE_UNSUPPORTED set to True"""
+    cs = _abi.ThicknessDiffuseCS()
+    cs.Khth, cs.Khth_Min, cs.Khth_Max, cs.max_Khth_CFL, cs.slope_max = Khth, Khth_Min, Khth_Max, max_Khth_CFL, slope_max
+    cs.kappa_smooth, cs.KHTH_Slope_Cff, cs.KhTh_fac = kappa_smooth, KHTH_Slope_Cff, KhTh_fac
+    cs.thickness_diffuse, cs.use_GM_work_bug, cs.nkml, cs.use_variable_mixing = int(thickness_diffuse), int(use_GM_work_bug), int(nkml), int(use_variable_mixing)
+    cs.initialized = 1
+    cs._keep = {}
+    for n, a in fields.items():
+        if n in _abi.THICKNESS_DIFFUSE_UNSUPPORTED:
+            cs.unsupported[_abi.THICKNESS_DIFFUSE_UNSUPPORTED.index(n)] = int(bool(a))
+        elif n in _abi.THICKNESS_DIFFUSE_FIELDS:
+            if a is not None:
+                cs._keep[n] = np.ascontiguousarray(a, dtype=np.float64)
+                setattr(cs, n, cs._keep[n].ctypes.data)
+        else:
+            raise ValueError(n)
+    return cs
+
+
+def thickness_diffuse(grid, cs, h, uhtr, vhtr, T, S, E, dt, uhGM=None, vhGM=None):
+    """thickness_diffuse (h, uhtr, vhtr updated in place); E None: no equation of state"""
+    L = lib()
+    L.orc_thickness_diffuse.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.ThicknessDiffuseCS)] + [_dp] * 5 + [C.POINTER(_abi.EOS), C.c_double, _dp, _dp]
+    rc = L.orc_thickness_diffuse(C.byref(grid.struct()), C.byref(cs), _p(h), _p(uhtr), _p(vhtr), _p(T), _p(S), None if E is None else C.byref(E),
+                                 float(dt), _p(uhGM), _p(vhGM))
+    if rc:
+        raise RuntimeError(f"orc_thickness_diffuse rc={rc}")

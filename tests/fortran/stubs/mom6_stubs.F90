@@ -154,7 +154,7 @@ public :: verticalGrid_type
 type :: verticalGrid_type
   integer :: ke
   real :: Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
-          Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0
+          Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0
   integer :: nk_rho_varies = 0, nkml = 0
   logical :: Boussinesq = .true.
   real, allocatable :: Rlay(:), g_prime(:)
@@ -166,7 +166,7 @@ implicit none ; private
 public :: unit_scale_type
 type :: unit_scale_type
   real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0, &
-          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0
+          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0
 end type unit_scale_type
 end module MOM_unit_scaling
 
@@ -448,19 +448,11 @@ end module MOM_io
 module MOM_barotropic_types_for_hor_visc
 end module MOM_barotropic_types_for_hor_visc
 
-module MOM_thickness_diffuse
-implicit none ; private
-public :: thickness_diffuse_CS
-type :: thickness_diffuse_CS
-  integer :: unused = 0
-end type thickness_diffuse_CS
-end module MOM_thickness_diffuse
-
 module MOM_stochastics
 implicit none ; private
 public :: stochastic_CS
 type :: stochastic_CS
-  integer :: unused = 0
+  logical :: skeb_use_gm = .false.
 end type stochastic_CS
 end module MOM_stochastics
 
@@ -484,8 +476,8 @@ module MOM_MEKE_types
 implicit none ; private
 public :: MEKE_type
 type :: MEKE_type
-  real, allocatable :: Kh(:,:), Ku(:,:), Au(:,:), mom_src(:,:), GME_snk(:,:)
-  real :: KhTr_fac = 1.0, backscatter_Ro_c = 0.0, backscatter_Ro_pow = 0.0
+  real, allocatable :: Kh(:,:), Ku(:,:), Au(:,:), mom_src(:,:), GME_snk(:,:), GM_src(:,:), MEKE(:,:), Rd_dx_h(:,:), Kh_diff(:,:)
+  real :: KhTr_fac = 1.0, KhTh_fac = 1.0, backscatter_Ro_c = 0.0, backscatter_Ro_pow = 0.0
 end type MEKE_type
 end module MOM_MEKE_types
 
@@ -493,7 +485,11 @@ module MOM_lateral_mixing_coeffs
 implicit none ; private
 public :: VarMix_CS
 type :: VarMix_CS
-  logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false.
+  logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false., Resoln_scaled_KhTh = .false.
+  logical :: Depth_scaled_KhTh = .false., use_stored_slopes = .false., khth_use_ebt_struct = .false., use_Visbeck = .false.
+  logical :: use_QG_Leith_GM = .false.
+  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Rd_dx_h, cg1
+  real, allocatable, dimension(:,:,:) :: slope_x, slope_y
 end type VarMix_CS
 end module MOM_lateral_mixing_coeffs
 
@@ -558,7 +554,7 @@ type :: accel_diag_ptrs
   real, pointer, dimension(:,:,:) :: gradKEu => NULL(), gradKEv => NULL(), rv_x_u => NULL(), rv_x_v => NULL()
 end type accel_diag_ptrs
 type :: cont_diag_ptrs
-  real, pointer, dimension(:,:,:) :: uh => NULL(), vh => NULL()
+  real, pointer, dimension(:,:,:) :: uh => NULL(), vh => NULL(), uhGM => NULL(), vhGM => NULL()
 end type cont_diag_ptrs
 type :: thermo_var_ptrs
   real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL()

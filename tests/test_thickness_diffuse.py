@@ -1,0 +1,247 @@
+"""thickness_diffuse (src/parameterizations/lateral/MOM_thickness_diffuse.F90:133, :634): CPU checks of the oracle
+(oracle/thickness_diffuse.c) through what the operator guarantees, and GPU parity of libmom6hip against it (bit-exact fp64).  The
+reference holds no known-answer vectors for this module (parity unpinned)."""
+import numpy as np
+import pytest
+
+import exact_synth as xs
+from helpers import bits_equal, interior
+from mom6_amd import _abi
+from oracle import orc
+
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+DT = 3600.0
+
+
+def case(ni=40, nj=28, nk=6, land_frac=0.2, **kw):
+    g = xs.make_grid(ni, nj, nk, land_frac=land_frac, **kw)
+    d = xs.make_state(g, umax=0.1)
+    for n, p in (("h", H), ("T", H), ("S", H)):
+        orc.halo_update(g, d[n], p)
+    return g, d
+
+
+def fields(g, seed=3):
+    """MEKE%Kh, the Visbeck factors, the resolution function and stored slopes, with the halos the operator reads"""
+    rng = np.random.default_rng(seed)
+    Kh = np.ascontiguousarray(800.0 * rng.random(g.shape2(H)) * g.mask2dT); orc.halo_update(g, Kh, H)
+    su, sv = g.shape2(U), g.shape2(V)
+    out = dict(MEKE_Kh=Kh, L2u=1.0e8 * rng.random(su), L2v=1.0e8 * rng.random(sv), SN_u=1.0e-6 * rng.random(su), SN_v=1.0e-6 * rng.random(sv),
+               Res_fn_u=rng.random(su), Res_fn_v=rng.random(sv))
+    sx = 2.0e-3 * (rng.random((g.nk + 1,) + su) - 0.5) * g.mask2dCu[None]
+    sy = 2.0e-3 * (rng.random((g.nk + 1,) + sv) - 0.5) * g.mask2dCv[None]
+    out.update(slope_x=np.ascontiguousarray(sx), slope_y=np.ascontiguousarray(sy))
+    return out
+
+
+VARIANTS = {
+    "khth": dict(Khth=600.0),                                                        # KHTH alone (tc4: KHTH = 500)
+    "khth_work": dict(Khth=600.0, work=True),                                        # with MEKE%GM_src (find_work)
+    "meke_kh": dict(Khth=1.0, Khth_Max=900.0, use=("MEKE_Kh",), work=True),           # tc2: KHTH = 1, KHTH_MAX = 900, MEKE
+    "visbeck_resfn": dict(Khth=1.0, Khth_Max=900.0, KHTH_Slope_Cff=0.1, use_variable_mixing=True, work=True,      # tc1
+                          use=("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v")),
+    "stored_slopes": dict(Khth=300.0, use_variable_mixing=True, use=("slope_x", "slope_y")),      # tc2: USE_STORED_SLOPES
+    "stored_slopes_work": dict(Khth=300.0, use_variable_mixing=True, use=("slope_x", "slope_y"), work=True, use_GM_work_bug=True),
+    "bulk_ml": dict(Khth=600.0, nkml=2, work=True),                                   # the streamfunction goes to zero over two layers
+    "no_eos": dict(Khth=600.0, eos=None),                                             # layer densities
+    "no_eos_work": dict(Khth=600.0, eos=None, work=True),
+    "khth_min": dict(Khth=50.0, Khth_Min=200.0, max_Khth_CFL=0.05, kappa_smooth=0.0),
+}
+
+
+def run_oracle(g, d, name, dt=DT):
+    kw = dict(VARIANTS[name])
+    eos = kw.pop("eos", "WRIGHT"); use = kw.pop("use", ()); work = kw.pop("work", False)
+    f = fields(g)
+    args = {n: f[n] for n in use}
+    if work:
+        args["MEKE_GM_src"] = np.full(g.shape2(H), 7.0)
+    if eos is None:
+        args["Rlay"] = 1025.0 + 0.5 * np.arange(g.nk)
+    cs = orc.thickness_diffuse_cs(g, **kw, **args)
+    h = d["h"].copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"]); uhGM = np.zeros_like(d["u"]); vhGM = np.zeros_like(d["v"])
+    orc.thickness_diffuse(g, cs, h, uhtr, vhtr, d["T"], d["S"], None if eos is None else orc.eos(eos), dt, uhGM, vhGM)
+    return dict(h=h, uhtr=uhtr, vhtr=vhtr, uhGM=uhGM, vhGM=vhGM, GM_src=cs._keep.get("MEKE_GM_src")), (kw, args, eos)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_thickness_diffusion_conserves_volume_and_has_no_net_transport(name):
+    """the transports of a column sum to zero (a pure overturning: uhD(1) = -sum of the rest, :1517), so the column's total
+    thickness changes only through the floor at Angstrom; volume is conserved; land faces carry nothing; uhtr = uhD*dt"""
+    g, d = case()
+    out, _ = run_oracle(g, d, name)
+    uh, vh = interior(g, out["uhGM"], U), interior(g, out["vhGM"], V)
+    assert np.all(np.isfinite(uh)) and np.abs(uh).max() > 0.0
+    scale = np.abs(uh).sum(0) + 1e-30
+    assert np.all(np.abs(uh.sum(0)) <= 1e-12 * scale)
+    assert np.all(uh[:, interior(g, g.mask2dCu, U) == 0.0] == 0.0) and np.all(vh[:, interior(g, g.mask2dCv, V) == 0.0] == 0.0)
+    assert np.array_equal(out["uhtr"], out["uhGM"] * DT)
+    A = interior(g, g.areaT, H)[None]
+    v0, v1 = float((interior(g, d["h"], H) * A).sum()), float((interior(g, out["h"], H) * A).sum())
+    assert abs(v1 - v0) <= 1e-12 * v0 and interior(g, out["h"], H).min() >= g.Angstrom_H
+    assert not bits_equal(out["h"], d["h"])
+
+
+def test_flat_isopycnals_are_left_alone():
+    """level interfaces and horizontally uniform T, S: no slope, no transport"""
+    g = xs.make_grid(24, 16, 5, land_frac=0.0, flat_bottom=True, max_depth=500.0)
+    d = xs.make_state(g, umax=0.0, vanish_frac=0.0)
+    h = np.ascontiguousarray(np.broadcast_to(np.array([20.0, 50.0, 100.0, 130.0, 200.0])[:, None, None], d["h"].shape).copy())
+    T = np.ascontiguousarray(np.broadcast_to(np.array([20.0, 15.0, 10.0, 6.0, 3.0])[:, None, None], d["h"].shape).copy())
+    S = np.full_like(h, 35.0)
+    cs = orc.thickness_diffuse_cs(g, Khth=1000.0, MEKE_GM_src=np.zeros(g.shape2(H)))
+    h1 = h.copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"])
+    orc.thickness_diffuse(g, cs, h1, uhtr, vhtr, T, S, orc.eos("WRIGHT"), DT)
+    assert bits_equal(h1, h) and np.all(uhtr == 0.0) and np.all(vhtr == 0.0) and np.all(cs._keep["MEKE_GM_src"] == 0.0)
+
+
+def test_interface_height_diffusion_flattens_a_bump_and_releases_potential_energy():
+    """a bump in the interfaces of a stratified ocean: the overturning moves water down the slopes (the interface variance drops),
+    and the work done on the stratification is negative (MEKE%GM_src <= 0: potential energy is released, :1196-1209)"""
+    g = xs.make_grid(32, 24, 4, land_frac=0.0, flat_bottom=True, max_depth=1000.0, reentrant_y=True, uniform=True, spacing=50000.0)
+    d = xs.make_state(g, umax=0.0, vanish_frac=0.0)
+    sj, si = g.csl(H)
+    jj, ii = np.meshgrid(np.arange(g.shape2(H)[0]), np.arange(g.shape2(H)[1]), indexing="ij")
+    bump = 40.0 * np.cos(2 * np.pi * (ii - g.halo) / g.ni) * np.cos(2 * np.pi * (jj - g.halo) / g.nj)
+    h = np.zeros_like(d["h"])
+    h[0] = 200.0 + bump; h[1] = 250.0 - bump; h[2] = 250.0; h[3] = 300.0
+    T = np.ascontiguousarray(np.broadcast_to(np.array([18.0, 10.0, 6.0, 3.0])[:, None, None], h.shape).copy()); S = np.full_like(h, 35.0)
+    src = np.zeros(g.shape2(H))
+    cs = orc.thickness_diffuse_cs(g, Khth=2000.0, MEKE_GM_src=src)
+    h1 = h.copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"])
+    orc.thickness_diffuse(g, cs, h1, uhtr, vhtr, T, S, orc.eos("LINEAR"), 86400.0)
+    e0, e1 = h[0][sj, si], h1[0][sj, si]
+    assert e1.var() < 0.999 * e0.var()
+    gs = cs._keep["MEKE_GM_src"][sj, si]
+    assert gs.sum() < 0.0 and (gs <= 1e-12 * np.abs(gs).max()).mean() > 0.95
+
+
+def test_refuses_what_it_does_not_provide():
+    g, d = case(ni=12, nj=10, nk=3)
+    for n in ("use_FGNV_streamfn", "detangle_interfaces", "MEKE_GEOMETRIC"):
+        cs = orc.thickness_diffuse_cs(g, Khth=100.0, **{n: True})
+        with pytest.raises(RuntimeError):
+            orc.thickness_diffuse(g, cs, d["h"].copy(), np.zeros_like(d["u"]), np.zeros_like(d["v"]), d["T"], d["S"], orc.eos("WRIGHT"), DT)
+    # without THICKNESSDIFFUSE, or with nothing to diffuse with, the call returns at once (:192-194)
+    for kw in (dict(Khth=100.0, thickness_diffuse=False), dict(Khth=0.0)):
+        cs = orc.thickness_diffuse_cs(g, **kw)
+        h = d["h"].copy()
+        orc.thickness_diffuse(g, cs, h, np.zeros_like(d["u"]), np.zeros_like(d["v"]), d["T"], d["S"], orc.eos("WRIGHT"), DT)
+        assert bits_equal(h, d["h"])
+
+
+REF = dict(Khth="KHTH", Khth_Min="KHTH_MIN", Khth_Max="KHTH_MAX", max_Khth_CFL="KHTH_MAX_CFL", kappa_smooth="KD_SMOOTH", KHTH_Slope_Cff="KHTH_SLOPE_CFF",
+           nkml="NKML", use_GM_work_bug="USE_GM_WORK_BUG")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_gpu_parity(name):
+    """thickness_diffuse: library == oracle, bit for bit (h, uhtr, vhtr, CDp%uhGM / vhGM, MEKE%GM_src), device and staged host arrays"""
+    import torch
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.thickness_diffuse import thickness_diffuse, thickness_diffuse_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    for (ni, nj, nk, topo, land) in [(70, 21, 8, (True, False), 0.25), (44, 40, 3, (True, True), 0.0), (10, 8, 30, (False, False), 0.2),
+                                     (200, 9, 75, (True, False), 0.25)]:
+        if VARIANTS[name].get("nkml", 0) >= nk:
+            continue
+        g, d = case(ni, nj, nk, land_frac=land, reentrant_x=topo[0], reentrant_y=topo[1])
+        ref, (kw, args, eos) = run_oracle(g, d, name)
+        dg = DeviceGrid(g)
+        pk = {REF[k]: v for k, v in kw.items() if k in REF}
+        CS = thickness_diffuse_init(dg, THICKNESSDIFFUSE=True, **pk)
+        for resident in (True, False):
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: np.ascontiguousarray(a).copy())
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            h, uhtr, vhtr = X(d["h"]), X(np.zeros_like(d["u"])), X(np.zeros_like(d["v"]))
+            cdp = dict(uhGM=X(np.zeros_like(d["u"])), vhGM=X(np.zeros_like(d["v"])))
+            meke = {}
+            if "MEKE_Kh" in args:
+                meke["Kh"] = X(args["MEKE_Kh"])
+            if "MEKE_GM_src" in args:
+                meke["GM_src"] = X(np.full(g.shape2(H), 7.0))
+            if "Rlay" in args:
+                meke["Rlay"] = args["Rlay"]
+            vm = {n: X(a) for n, a in args.items() if n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y")}
+            varmix = vm if kw.get("use_variable_mixing") else None
+            tv = None if eos is None else (X(d["T"]), X(d["S"]), EOS_init(eos))
+            thickness_diffuse(h, uhtr, vhtr, tv, DT, dg, meke, varmix, cdp, CS)
+            dg.sync()
+            for n, a in (("h", h), ("uhtr", uhtr), ("vhtr", vhtr), ("uhGM", cdp["uhGM"]), ("vhGM", cdp["vhGM"])):
+                assert bits_equal(N(a), ref[n]), (name, (ni, nj, nk), resident, n, np.argwhere(N(a) != ref[n])[:3])
+            if "GM_src" in meke:
+                assert bits_equal(N(meke["GM_src"]), ref["GM_src"]), (name, (ni, nj, nk), resident, "GM_src")
+        dg.close()
+
+
+# ---- the module shim (mom6_amd/fortran/MOM_thickness_diffuse_hip.F90) with the reference's dummy-argument lists -------------------------
+FKEYS = dict(Khth="KHTH", Khth_Min="KHTH_MIN", Khth_Max="KHTH_MAX", max_Khth_CFL="KHTH_MAX_CFL", kappa_smooth="KD_SMOOTH", KHTH_Slope_Cff="KHTH_SLOPE_CFF")
+
+
+def _write_td_case(tmp, g, d, name):
+    """the input and parameter files of tests/fortran/td_driver.F90 for one of VARIANTS, and the oracle's results"""
+    ref, (kw, args, eos) = run_oracle(g, d, name)
+    f = fields(g)
+    opt = [int(eos is not None), int("MEKE_Kh" in args), int("L2u" in args), int("Res_fn_u" in args), int("slope_x" in args), int("MEKE_GM_src" in args),
+           int(kw.get("nkml", 0)), int(bool(kw.get("use_variable_mixing")))]
+    with open(tmp / "in.bin", "wb") as fh:
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, DT], dtype="<f8").tofile(fh)
+        np.array(opt, dtype="<i4").tofile(fh)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
+        for a in (d["h"], d["T"], d["S"], args.get("Rlay", 1025.0 + 0.5 * np.arange(g.nk))):
+            np.ascontiguousarray(a, dtype="<f8").tofile(fh)
+        for n in ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y"):
+            np.ascontiguousarray(f[n], dtype="<f8").tofile(fh)
+    with open(tmp / "params.txt", "w") as fh:
+        fh.write("THICKNESSDIFFUSE = True\n")
+        if eos is not None:
+            fh.write(f"EQN_OF_STATE = {eos}\n")
+        if kw.get("use_GM_work_bug"):
+            fh.write("USE_GM_WORK_BUG = True\n")
+        for k, v in kw.items():
+            if k in FKEYS:
+                fh.write(f"{FKEYS[k]} = {float(v)!r}\n")
+    return ref, opt
+
+
+def _build_td(tmp):
+    from test_fortran_abi import _build_shims
+    return _build_shims(tmp, driver="td_driver")
+
+
+def test_module_shim_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """MOM_thickness_diffuse_hip.F90 compiles with the reference's module name and argument lists; without a GPU the call stops with FATAL"""
+    from test_fortran_abi import FC
+    import os, subprocess, torch
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_td(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    g, d = case(24, 16, 4)
+    _write_td_case(tmp_path, g, d, "khth")
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode != 0 and "FATAL" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_module_shim_matches_oracle(tmp_path):
+    """thickness_diffuse_init + thickness_diffuse called from Fortran with the reference's argument lists on host arrays: the oracle's bits"""
+    from test_fortran_abi import FC
+    import os, subprocess
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_td(tmp_path)
+    g, d = case(36, 22, 6, reentrant_x=True, reentrant_y=False)
+    for name in VARIANTS:
+        ref, opt = _write_td_case(tmp_path, g, d, name)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "td_driver ok" in r.stdout, (name, r.stderr[-600:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+        want = [ref["h"], ref["uhtr"], ref["vhtr"], ref["uhGM"], ref["vhGM"]] + ([ref["GM_src"]] if opt[5] else [])
+        assert raw.size == sum(w.size for w in want), name
+        for n, a, w in zip(("h", "uhtr", "vhtr", "uhGM", "vhGM", "GM_src"), np.split(raw, np.cumsum([w.size for w in want])[:-1]), want):
+            assert bits_equal(a.reshape(w.shape), w), (name, n)
