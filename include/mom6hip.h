@@ -984,6 +984,47 @@ int mom6hip_thickness_diffuse(mom6hip_ctx_t *ctx, const mom6hip_thickness_diffus
                               const double *T, const double *S, const mom6hip_eos_t *eos, double dt, double *uhGM, double *vhGM,
                               int32_t memspace);
 
+/* ---- MOM_mixed_layer_restrat (src/parameterizations/lateral/MOM_mixed_layer_restrat.F90) ------------------------------
+ * mixedlayer_restrat_CS (:40-126) as far as the provided branches read it.  Provided: mixedlayer_restrat (:135)
+ * with its two Fox-Kemper et al. (2008) forms -- mixedlayer_restrat_OM4 (:175; general coordinates: the mixed layer depth from a
+ * density difference MLE_DENSITY_DIFF or from the boundary-layer scheme (MLE_USE_PBL_MLD, h_MLD), MLE_MLD_STRETCH, the two running
+ * means MLE_MLD_DECAY_TIME / _TIME2 kept in MLD_filtered / MLD_filtered_slow, FOX_KEMPER_ML_RESTRAT_COEF / _COEF2, the frontal
+ * length scale MLE_FRONT_LENGTH with VarMix%Rd_dx_h, the shape function mu(sigma, MLE_TAIL_DH) :723) when nkml == 0, and
+ * mixedlayer_restrat_BML (:1209; the bulk mixed layer of nkml layers) otherwise; Boussinesq.
+ * Refused: USE_BODNER23, USE_STANLEY_ML, non-Boussinesq. */
+typedef struct mom6hip_mixedlayer_restrat_cs {
+  double ml_restrat_coef;      /* FOX_KEMPER_ML_RESTRAT_COEF (0) */
+  double ml_restrat_coef2;     /* FOX_KEMPER_ML_RESTRAT_COEF2 (0) */
+  double front_length;         /* MLE_FRONT_LENGTH [L] (0); positive needs Rd_dx_h */
+  double vonKar;               /* VON_KARMAN_CONST (0.41) */
+  double MLE_MLD_decay_time;   /* MLE_MLD_DECAY_TIME [T] (0); positive needs MLD_filtered */
+  double MLE_MLD_decay_time2;  /* MLE_MLD_DECAY_TIME2 [T] (0); positive needs MLD_filtered_slow */
+  double MLE_density_diff;     /* MLE_DENSITY_DIFF [R] (0.03); not positive: MLE_use_PBL_MLD must be set */
+  double MLE_tail_dh;          /* MLE_TAIL_DH (0) */
+  double MLE_MLD_stretch;      /* MLE_MLD_STRETCH (1) */
+  double ustar_min;            /* RESTRAT_USTAR_MIN [H T-1] (2e-4 * OMEGA * (Angstrom_Z + dZ_subroundoff)) */
+  double reserved0[4];
+  int32_t MLE_use_PBL_MLD;     /* MLE_USE_PBL_MLD (0): the mixed layer depth is h_MLD of the call */
+  int32_t nkml;                /* GV%nkml (0): > 0 selects mixedlayer_restrat_BML */
+  int32_t initialized;
+  int32_t reserved_i[1];
+  int32_t unsupported[8];      /* Bodner, Stanley, non-Boussinesq: any nonzero is refused */
+  double *MLD_filtered;        /* CS%MLD_filtered, h points 2-D (state; valid halo of 1; updated over the compute domain + 1) */
+  double *MLD_filtered_slow;   /* CS%MLD_filtered_slow */
+  const double *Rd_dx_h;       /* VarMix%Rd_dx_h, h points 2-D (valid halo of 1) */
+  void *reserved1[3];
+} mom6hip_mixedlayer_restrat_cs_t;
+
+/* mixedlayer_restrat(h, uhtr, vhtr, tv, forces, dt, MLD, h_MLD, bflux, VarMix, G, GV, US, CS)                       :135
+ * tv%T, tv%S, tv%eqn_of_state as T, S, eos (required: the module stops without an equation of state); forces%ustar [Z T-1] as
+ * ustar (valid halo of 1, like h, T, S); h_MLD [H] may be NULL unless MLE_use_PBL_MLD.  h, uhtr, vhtr are updated on the compute
+ * domain; uhml / vhml receive the restratifying transports when not NULL (the diagnostics uhml, vhml). */
+int mom6hip_mixedlayer_restrat(mom6hip_ctx_t *ctx, const mom6hip_mixedlayer_restrat_cs_t *cs, double *h, double *uhtr, double *vhtr,
+                               const double *T, const double *S, const mom6hip_eos_t *eos, const double *ustar, double dt,
+                               const double *h_MLD, double *uhml, double *vhml, int32_t memspace);
+/* mu(sigma, dh) :723, the shape of the streamfunction (host; the known answers of mixedlayer_restrat_unit_tests :1847 hold for it) */
+double mom6hip_mixedlayer_restrat_mu(double sigma, double dh);
+
 /*
  * MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84-268: the parameters the provided branch reads, the
  * control structures of the modules the step calls, and the arrays the reference keeps in the control structure

@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void max_cfl_kernel(m6::GridDev g, const doubl
     const unsigned long long o1 = __shfl_down(b1, off), o2 = __shfl_down(b2, off);
     b1 = o1 > b1 ? o1 : b1; b2 = o2 > b2 ? o2 : b2;
   }
-  if ((threadIdx.x & 63) == 0) { if (b1) atomicMax(&out[0], b1); if (b2) atomicMax(&out[1], b2); }
+  // (the running maxima are read first: nearly every wave finds it has nothing to add and skips the contended atomic)
+  if ((threadIdx.x & 63) == 0) {
+    if (b1 > __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out[0], b1);
+    if (b2 > __hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&out[1], b2);
+  }
 }
 
 }  // namespace

@@ -151,6 +151,10 @@ int orc_pressureforce_fv_nonbouss(const mom6hip_grid_t *G, const mom6hip_pressur
 /* ---- MOM_barotropic (oracle/barotropic.c) ----------------------------------------------------- */
 int orc_thickness_diffuse(const mom6hip_grid_t *G, const mom6hip_thickness_diffuse_cs_t *CS, double *h, double *uhtr, double *vhtr,
                           const double *T, const double *S, const mom6hip_eos_t *EOS, double dt, double *uhGM, double *vhGM);
+int orc_mixedlayer_restrat(const mom6hip_grid_t *G, const mom6hip_mixedlayer_restrat_cs_t *CS, double *h, double *uhtr, double *vhtr,
+                           const double *T, const double *S, const mom6hip_eos_t *EOS, const double *ustar, double dt, const double *h_MLD,
+                           double *uhml, double *vhml);
+double orc_mle_mu(double sigma, double dh);
 double orc_cr_exp(double t);             /* correctly rounded exp(t), t <= 0 (0 below -700) */
 double orc_cr_pow(double x, double y);   /* correctly rounded x**y, 0 < x <= 1, 0 < y <= 1 */
 double orc_cr_cos(double x);             /* correctly rounded cos(x), |x| <= pi (cr_trig.c) */
