@@ -814,6 +814,35 @@ def main():
         cand["adv_x_kernel<4,PPM,first>"] = ((NTR + 2) * 16.0 * cells, px)
         cand["adv_y_kernel<4,PPM,first>"] = ((NTR + 2) * 16.0 * cells, py)
         out["advect_tracer_PPM_ms_per_call"] = pc
+        # the two lateral parameterisations of SURVEY.md 8f #4, beside the step (MOM.F90:1165, :1335), on the same state: thickness_diffuse
+        # as .testing/tc4 sets it (KHTH alone), mixedlayer_restrat as OM4 sets it (the boundary-layer depth, both running means, the
+        # frontal length scale).  Not part of `value`: the workload BASELINE.json names does not call them.
+        try:
+            from mom6_amd.mixedlayer_restrat import mixedlayer_restrat, mixedlayer_restrat_init
+            from mom6_amd.thickness_diffuse import thickness_diffuse, thickness_diffuse_init
+            d = S.dyn
+            sh2 = tuple(d["h"].shape[1:])
+            yy = torch.linspace(0.0, 1.0, sh2[0], device=d["h"].device, dtype=torch.float64)[:, None].expand(sh2).contiguous()
+            td_cs = thickness_diffuse_init(S.dg, THICKNESSDIFFUSE=True, KHTH=600.0)
+            mle_cs = mixedlayer_restrat_init(S.dg, FOX_KEMPER_ML_RESTRAT_COEF=1.0, MLE_FRONT_LENGTH=500.0, MLE_USE_PBL_MLD=True, MLE_MLD_DECAY_TIME=345600.0,
+                                             MLE_MLD_DECAY_TIME2=5184000.0, FOX_KEMPER_ML_RESTRAT_COEF2=0.5,
+                                             MLD_filtered=torch.zeros(sh2, device=d["h"].device, dtype=torch.float64),
+                                             MLD_filtered_slow=torch.zeros(sh2, device=d["h"].device, dtype=torch.float64))
+            ustar, h_MLD, Rd = 0.005 + 0.01 * yy, 20.0 + 80.0 * yy, (0.2 + 1.5 * yy).contiguous()
+            lat = {"thickness_diffuse": 0.0, "mixedlayer_restrat": 0.0}
+            for q in range(4):
+                hh = d["h"].clone(); uq = torch.zeros_like(S.adv["uhtr"]); vq = torch.zeros_like(S.adv["vhtr"])
+                for name, f in (("thickness_diffuse", lambda: thickness_diffuse(hh, uq, vq, (d["T"], d["S"], S.eos), DT_THERM, S.dg, None, None, None, td_cs)),
+                                ("mixedlayer_restrat", lambda: mixedlayer_restrat(hh, uq, vq, (d["T"], d["S"], S.eos), dict(ustar=ustar), DT_THERM, None, h_MLD,
+                                                                                  None, dict(Rd_dx_h=Rd), S.dg, mle_cs))):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); f(); e1.record(); e1.synchronize()
+                    if q:
+                        lat[name] += e0.elapsed_time(e1) / 3
+                del hh, uq, vq
+            out["lateral_parameterizations_ms_per_call"] = lat
+        except Exception as exc:      # (reported, never fatal to the bench line)
+            out["lateral_parameterizations_ms_per_call"] = {"error": repr(exc)}
         out.setdefault("roofline", {})["operators"] = {
             k: {"GBs": bb / (m * 1e-3) / 1e9, "frac": bb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": m} for k, (bb, m) in cand.items()}
         S.dg.close()

@@ -194,6 +194,21 @@ class ThicknessDiffuseCS(C.Structure):
                 + [("reserved1", C.c_void_p * 3)])
 
 
+MIXEDLAYER_RESTRAT_UNSUPPORTED = ("use_Bodner", "use_Stanley_ML", "non_Boussinesq")
+MIXEDLAYER_RESTRAT_FIELDS = ("MLD_filtered", "MLD_filtered_slow", "Rd_dx_h")
+
+
+class MixedlayerRestratCS(C.Structure):
+    """mom6hip_mixedlayer_restrat_cs_t (include/mom6hip.h)."""
+    _fields_ = ([(n, C.c_double) for n in ("ml_restrat_coef", "ml_restrat_coef2", "front_length", "vonKar", "MLE_MLD_decay_time", "MLE_MLD_decay_time2",
+                                            "MLE_density_diff", "MLE_tail_dh", "MLE_MLD_stretch", "ustar_min")]
+                + [("reserved0", C.c_double * 4)]
+                + [(n, C.c_int32) for n in ("MLE_use_PBL_MLD", "nkml", "initialized")]
+                + [("reserved_i", C.c_int32 * 1), ("unsupported", C.c_int32 * 8)]
+                + [(n, C.c_void_p) for n in MIXEDLAYER_RESTRAT_FIELDS]
+                + [("reserved1", C.c_void_p * 3)])
+
+
 # ---- MOM_dynamics_split_RK2 -----------------------------------------------------------------------------
 RK2_ARRAYS_3D = (("CAu", POS_U), ("CAv", POS_V), ("CAu_pred", POS_U), ("CAv_pred", POS_V), ("PFu", POS_U), ("PFv", POS_V),
                  ("diffu", POS_U), ("diffv", POS_V), ("visc_rem_u", POS_U), ("visc_rem_v", POS_V), ("u_accel_bt", POS_U),

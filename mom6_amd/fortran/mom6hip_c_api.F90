@@ -206,6 +206,19 @@ type, bind(c) :: mom6hip_thickness_diffuse_cs_t
   type(c_ptr) :: reserved1(3) = c_null_ptr
 end type mom6hip_thickness_diffuse_cs_t
 
+!> mom6hip_mixedlayer_restrat_cs_t (mixedlayer_restrat_CS, src/parameterizations/lateral/MOM_mixed_layer_restrat.F90:40)
+type, bind(c) :: mom6hip_mixedlayer_restrat_cs_t
+  real(c_double) :: ml_restrat_coef = 0.0, ml_restrat_coef2 = 0.0, front_length = 0.0, vonKar = 0.41
+  real(c_double) :: MLE_MLD_decay_time = 0.0, MLE_MLD_decay_time2 = 0.0, MLE_density_diff = 0.03, MLE_tail_dh = 0.0
+  real(c_double) :: MLE_MLD_stretch = 1.0, ustar_min = 0.0
+  real(c_double) :: reserved0(4) = 0.0
+  integer(c_int32_t) :: MLE_use_PBL_MLD = 0, nkml = 0, initialized = 0
+  integer(c_int32_t) :: reserved_i(1) = 0
+  integer(c_int32_t) :: unsupported(8) = 0
+  type(c_ptr) :: MLD_filtered = c_null_ptr, MLD_filtered_slow = c_null_ptr, Rd_dx_h = c_null_ptr
+  type(c_ptr) :: reserved1(3) = c_null_ptr
+end type mom6hip_mixedlayer_restrat_cs_t
+
 !> mom6hip_dyn_split_rk2_cs_t (MOM_dyn_split_RK2_CS, src/core/MOM_dynamics_split_RK2.F90:84); every array is a DEVICE
 !! array obtained from mom6hip_malloc
 type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
@@ -711,6 +724,25 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_thickness_diffuse
+
+  !> mixedlayer_restrat (MOM_mixed_layer_restrat.F90:135); h_MLD, uhml, vhml may be c_null_ptr
+  function mom6hip_mixedlayer_restrat(ctx, cs, h, uhtr, vhtr, T, S, eos, ustar, dt, h_MLD, uhml, vhml, memspace) &
+      bind(c, name="mom6hip_mixedlayer_restrat") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_mixedlayer_restrat_cs_t
+    type(c_ptr), value :: ctx
+    type(mom6hip_mixedlayer_restrat_cs_t), intent(in) :: cs
+    type(c_ptr), value :: h, uhtr, vhtr, T, S, eos, ustar
+    real(c_double), value :: dt
+    type(c_ptr), value :: h_MLD, uhml, vhml
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_mixedlayer_restrat
+  !> mu(sigma, dh) (MOM_mixed_layer_restrat.F90:723)
+  function mom6hip_mixedlayer_restrat_mu(sigma, dh) bind(c, name="mom6hip_mixedlayer_restrat_mu") result(mu)
+    import :: c_double
+    real(c_double), value :: sigma, dh
+    real(c_double) :: mu
+  end function mom6hip_mixedlayer_restrat_mu
 
   !> hor_visc_init (MOM_hor_visc.F90:1984): the static arrays of the control structure
   function mom6hip_hor_visc_init(ctx, cs, dt, memspace) bind(c, name="mom6hip_hor_visc_init") result(rc)

@@ -863,3 +863,48 @@ def thickness_diffuse(grid, cs, h, uhtr, vhtr, T, S, E, dt, uhGM=None, vhGM=None
                                  float(dt), _p(uhGM), _p(vhGM))
     if rc:
         raise RuntimeError(f"orc_thickness_diffuse rc={rc}")
+
+
+# ---- MOM_mixed_layer_restrat --------------------------------------------------------------------------------------
+def mle_mu(sigma, dh):
+    """mu(sigma, dh), MOM_mixed_layer_restrat.F90:723"""
+    L = lib()
+    L.orc_mle_mu.restype = C.c_double
+    L.orc_mle_mu.argtypes = [C.c_double, C.c_double]
+    return L.orc_mle_mu(float(sigma), float(dh))
+
+
+def mixedlayer_restrat_cs(grid, ml_restrat_coef=0.0, ml_restrat_coef2=0.0, front_length=0.0, vonKar=0.41, MLE_MLD_decay_time=0.0, MLE_MLD_decay_time2=0.0,
+                          MLE_density_diff=0.03, MLE_tail_dh=0.0, MLE_MLD_stretch=1.0, ustar_min=None, MLE_use_PBL_MLD=False, nkml=0, omega=7.2921e-5,
+                          **fields):
+    """mom6hip_mixedlayer_restrat_cs_t with the defaults of mixedlayer_restrat_init (MOM_mixed_layer_restrat.F90:1532-1735); fields:
+    MLD_filtered, MLD_filtered_slow, Rd_dx_h (arrays, kept and updated in place) or the names of _abi.MIXEDLAYER_RESTRAT_UNSUPPORTED"""
+    cs = _abi.MixedlayerRestratCS()
+    cs.ml_restrat_coef, cs.ml_restrat_coef2, cs.front_length, cs.vonKar = ml_restrat_coef, ml_restrat_coef2, front_length, vonKar
+    cs.MLE_MLD_decay_time, cs.MLE_MLD_decay_time2, cs.MLE_tail_dh, cs.MLE_MLD_stretch = MLE_MLD_decay_time, MLE_MLD_decay_time2, MLE_tail_dh, MLE_MLD_stretch
+    cs.MLE_density_diff = -9.0e9 if MLE_use_PBL_MLD else MLE_density_diff      # :1568: not read with MLE_USE_PBL_MLD
+    # RESTRAT_USTAR_MIN :1728-1733: 2e-4 * OMEGA * (GV%Angstrom_Z + GV%dZ_subroundoff) [Z T-1] -> [H T-1]
+    cs.ustar_min = (2.0e-4 * omega * (grid.Angstrom_H * grid.H_to_Z + grid.dZ_subroundoff) if ustar_min is None else ustar_min) * grid.Z_to_H
+    cs.MLE_use_PBL_MLD, cs.nkml, cs.initialized = int(MLE_use_PBL_MLD), int(nkml), 1
+    cs._keep = {}
+    for n, a in fields.items():
+        if n in _abi.MIXEDLAYER_RESTRAT_UNSUPPORTED:
+            cs.unsupported[_abi.MIXEDLAYER_RESTRAT_UNSUPPORTED.index(n)] = int(bool(a))
+        elif n in _abi.MIXEDLAYER_RESTRAT_FIELDS:
+            if a is not None:
+                assert a.dtype == np.float64 and a.flags.c_contiguous
+                cs._keep[n] = a
+                setattr(cs, n, a.ctypes.data)
+        else:
+            raise ValueError(n)
+    return cs
+
+
+def mixedlayer_restrat(grid, cs, h, uhtr, vhtr, T, S, E, ustar, dt, h_MLD=None, uhml=None, vhml=None):
+    """mixedlayer_restrat (h, uhtr, vhtr and the filtered depths of cs updated in place)"""
+    L = lib()
+    L.orc_mixedlayer_restrat.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.MixedlayerRestratCS)] + [_dp] * 5 + [C.POINTER(_abi.EOS), _dp, C.c_double, _dp, _dp, _dp]
+    rc = L.orc_mixedlayer_restrat(C.byref(grid.struct()), C.byref(cs), _p(h), _p(uhtr), _p(vhtr), _p(T), _p(S), None if E is None else C.byref(E),
+                                  _p(ustar), float(dt), _p(h_MLD), _p(uhml), _p(vhml))
+    if rc:
+        raise RuntimeError(f"orc_mixedlayer_restrat rc={rc}")

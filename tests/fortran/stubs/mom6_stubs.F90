@@ -153,7 +153,7 @@ implicit none ; private
 public :: verticalGrid_type
 type :: verticalGrid_type
   integer :: ke
-  real :: Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
+  real :: Angstrom_Z = 1.0e-10, Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
           Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0
   integer :: nk_rho_varies = 0, nkml = 0
   logical :: Boussinesq = .true.
@@ -205,7 +205,8 @@ end module MOM_cpu_clock
 module MOM_file_parser
 use MOM_error_handler, only : MOM_error, FATAL
 implicit none ; private
-public :: param_file_type, get_param, log_version, param_set
+public :: param_file_type, get_param, log_version, param_set, openParameterBlock, closeParameterBlock
+character(len=64), save :: block_prefix = ''      !< "NAME%" inside openParameterBlock(NAME) ... closeParameterBlock
 type :: param_file_type
   integer :: n = 0
   character(len=64)  :: names(256)
@@ -228,9 +229,22 @@ function lookup(CS, name, found) result(val)
   integer :: m
   found = .false. ; val = ''
   do m = 1, CS%n
-    if (trim(CS%names(m)) == trim(name)) then ; val = CS%values(m) ; found = .true. ; endif
+    if (trim(CS%names(m)) == trim(block_prefix)//trim(name)) then ; val = CS%values(m) ; found = .true. ; endif
   enddo
 end function lookup
+subroutine openParameterBlock(CS, blockName, desc, do_not_log)
+  type(param_file_type), intent(in) :: CS
+  character(len=*),      intent(in) :: blockName
+  character(len=*), optional, intent(in) :: desc
+  logical,          optional, intent(in) :: do_not_log
+  block_prefix = trim(block_prefix)//trim(blockName)//'%'
+end subroutine openParameterBlock
+subroutine closeParameterBlock(CS)
+  type(param_file_type), intent(in) :: CS
+  integer :: m
+  m = index(block_prefix(1:max(len_trim(block_prefix)-1,0)), '%', back=.true.)
+  block_prefix = block_prefix(1:m)
+end subroutine closeParameterBlock
 subroutine missing(varname, fail_if_missing)
   character(len=*),  intent(in) :: varname
   logical, optional, intent(in) :: fail_if_missing

@@ -75,7 +75,7 @@ FDIR = os.path.join(ROOT, "mom6_amd", "fortran")
 STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
 SHIMS = ["mom6hip_c_api.F90", "mom6hip_MOM_glue.F90", "MOM_continuity_PPM_hip.F90", "MOM_CoriolisAdv_hip.F90", "MOM_barotropic_hip.F90",
          "MOM_PressureForce_FV_hip.F90", "MOM_tracer_advect_hip.F90", "MOM_tracer_hor_diff_hip.F90", "MOM_set_viscosity_hip.F90",
-         "MOM_vert_friction_hip.F90", "MOM_thickness_diffuse_hip.F90", "MOM_hor_visc_hip.F90"]
+         "MOM_vert_friction_hip.F90", "MOM_thickness_diffuse_hip.F90", "MOM_mixed_layer_restrat_hip.F90", "MOM_hor_visc_hip.F90"]
 
 
 def _build_shims(tmp, driver="shim_driver"):

@@ -1,0 +1,298 @@
+"""mixedlayer_restrat (src/parameterizations/lateral/MOM_mixed_layer_restrat.F90:135, :175, :1209): the shape function
+against the reference's own known answers (tests/golden/mle_mu.json), CPU checks of the oracle (oracle/mixedlayer_restrat.c) through what
+the operator guarantees, and GPU parity of libmom6hip against it (bit-exact fp64)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import exact_synth as xs
+from helpers import bits_equal, interior
+from mom6_amd import _abi
+from oracle import orc
+
+H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+DT = 3600.0
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "mle_mu.json")
+
+
+def case(ni=40, nj=28, nk=8, land_frac=0.2, **kw):
+    g = xs.make_grid(ni, nj, nk, land_frac=land_frac, **kw)
+    d = xs.make_state(g, umax=0.1)
+    for n, p in (("h", H), ("T", H), ("S", H)):
+        orc.halo_update(g, d[n], p)
+    return g, d
+
+
+def fields(g, d, seed=5):
+    """forces%ustar, the boundary-layer thickness h_MLD, VarMix%Rd_dx_h and the two filtered depths, with the halos the operator reads"""
+    rng = np.random.default_rng(seed)
+    sh = g.shape2(H)
+    out = {}
+    for n, a in (("ustar", 2.0e-3 + 0.02 * rng.random(sh)), ("h_MLD", 15.0 + 120.0 * rng.random(sh)), ("Rd_dx_h", 2.0 * rng.random(sh)),
+                 ("MLD_filtered", 40.0 + 60.0 * rng.random(sh)), ("MLD_filtered_slow", 80.0 + 150.0 * rng.random(sh))):
+        a = np.ascontiguousarray(a * g.mask2dT); orc.halo_update(g, a, H); out[n] = a
+    return out
+
+
+VARIANTS = {
+    "fk": dict(ml_restrat_coef=5.0),                                                       # tc2: FOX_KEMPER_ML_RESTRAT_COEF = 5
+    "fk_pbl_mld": dict(ml_restrat_coef=20.0, MLE_use_PBL_MLD=True, MLE_MLD_stretch=1.2),   # OM4: the depth of the boundary-layer scheme
+    "fk_filtered": dict(ml_restrat_coef=15.0, ml_restrat_coef2=8.0, MLE_MLD_decay_time=86400.0, MLE_MLD_decay_time2=2.592e6,
+                        use=("MLD_filtered", "MLD_filtered_slow")),                          # OM4: the two running means
+    "fk_front": dict(ml_restrat_coef=1.0, front_length=500.0, use=("Rd_dx_h",), MLE_MLD_decay_time=345600.0, MLE_use_PBL_MLD=True,
+                     also=("MLD_filtered",)),                                                # OM4: MLE_FRONT_LENGTH = 500 m
+    "fk_tail": dict(ml_restrat_coef=30.0, MLE_tail_dh=0.2),                                # a real power in mu
+    "fk_strong": dict(ml_restrat_coef=4000.0, ml_restrat_coef2=3000.0, MLE_density_diff=0.1, MLE_MLD_decay_time2=1.0e5,
+                      use=("MLD_filtered_slow",)),                                          # both limiters at work
+    "bml": dict(ml_restrat_coef=5.0, nkml=3),                                              # tc1: the bulk mixed layer
+    "bml_strong": dict(ml_restrat_coef=5000.0, nkml=2),
+}
+
+
+def run_oracle(g, d, name, dt=DT, eos="WRIGHT"):
+    kw = dict(VARIANTS[name])
+    use = tuple(kw.pop("use", ())) + tuple(kw.pop("also", ()))
+    f = fields(g, d)
+    state = {n: f[n].copy() for n in use}
+    cs = orc.mixedlayer_restrat_cs(g, **kw, **state)
+    h = d["h"].copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"]); uhml = np.zeros_like(d["u"]); vhml = np.zeros_like(d["v"])
+    orc.mixedlayer_restrat(g, cs, h, uhtr, vhtr, d["T"], d["S"], orc.eos(eos), f["ustar"], dt, f["h_MLD"] if kw.get("MLE_use_PBL_MLD") else None, uhml, vhml)
+    out = dict(h=h, uhtr=uhtr, vhtr=vhtr, uhml=uhml, vhml=vhml)
+    out.update({n: state[n] for n in ("MLD_filtered", "MLD_filtered_slow") if n in state})
+    return out, (kw, f, use)
+
+
+def test_shape_function_has_the_references_known_answers():
+    """mixedlayer_restrat_unit_tests (:1855-1874): mu(sigma, dh) at the reference's ten points, to its own tolerances"""
+    gold = json.load(open(GOLD))
+    assert len(gold["cases"]) == 10
+    for c in gold["cases"]:
+        assert abs(orc.mle_mu(c["sigma"], c["dh"]) - c["mu"]) <= c["tol_eps"] * np.finfo(float).eps, c
+
+
+def test_shape_function_is_a_bump_between_the_surface_and_the_base():
+    """0 at the surface, 1 at mid-depth, 0 below the (extended) mixed layer, symmetric about the middle without a tail, never negative"""
+    s = -np.linspace(0.0, 1.0, 201)
+    m = np.array([orc.mle_mu(x, 0.0) for x in s])
+    assert m[0] == 0.0 and m[100] == 1.0 and m[-1] == 0.0 and np.all(m >= 0.0) and np.all(m <= 1.0)
+    assert np.allclose(m, m[::-1], rtol=0, atol=4e-16)
+    assert np.all(np.diff(m[:101]) > 0.0)
+    for dh in (0.1, 0.3, 0.5):
+        t = np.array([orc.mle_mu(x, dh) for x in -np.linspace(0.0, 1.6, 161)])
+        assert np.all(t >= 0.0) and np.all(np.diff(t[50:]) <= 0.0) and t[-1] == 0.0 and orc.mle_mu(-1.0, dh) > 0.0      # the tail reaches below -1
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_restratification_is_an_overturning_that_conserves_volume(name):
+    """the transports of a face column sum to zero (a(k) telescopes to mu(0) - mu(below the mixed layer) = 0), volume is conserved,
+    land faces carry nothing, uhtr = uhml*dt, no layer is drained below half an Angstrom"""
+    g, d = case()
+    out, (kw, f, use) = run_oracle(g, d, name)
+    uh, vh = interior(g, out["uhml"], U), interior(g, out["vhml"], V)
+    assert np.all(np.isfinite(uh)) and np.abs(uh).max() > 0.0 and np.abs(vh).max() > 0.0
+    for q in (uh, vh):
+        scale = np.abs(q).sum(0) + 1e-30
+        # (the bulk form's a(k) = (hx2/H)(2 - 4 z/H) cancels to 1e-16 of ITS scale, 2, not of the transport a vanished layer pair carries)
+        assert np.all(np.abs(q.sum(0)) <= (1e-3 if kw.get("nkml", 0) else 1e-11) * scale), float((np.abs(q.sum(0)) / scale).max())
+    assert np.all(uh[:, interior(g, g.mask2dCu, U) == 0.0] == 0.0) and np.all(vh[:, interior(g, g.mask2dCv, V) == 0.0] == 0.0)
+    assert np.array_equal(out["uhtr"], out["uhml"] * DT)
+    A = interior(g, g.areaT, H)[None]
+    v0, v1 = float((interior(g, d["h"], H) * A).sum()), float((interior(g, out["h"], H) * A).sum())
+    assert abs(v1 - v0) <= 1e-12 * v0 and interior(g, out["h"], H).min() >= 0.5 * g.Angstrom_H
+    assert not bits_equal(out["h"], d["h"])
+    if kw.get("nkml", 0):      # the bulk mixed layer: nothing below it moves
+        assert bits_equal(out["h"][kw["nkml"]:], d["h"][kw["nkml"]:]) and np.all(out["uhml"][kw["nkml"]:] == 0.0)
+
+
+def front(ni=48, nj=12, nk=6, dT=2.0):
+    g = xs.make_grid(ni, nj, nk, land_frac=0.0, flat_bottom=True, max_depth=600.0, reentrant_y=True, uniform=True, spacing=20000.0, beta_plane=True)
+    d = xs.make_state(g, umax=0.0, vanish_frac=0.0, eta_amp=None)
+    h = np.ascontiguousarray(np.broadcast_to(np.array([10.0, 20.0, 30.0, 60.0, 180.0, 300.0])[:, None, None], d["h"].shape).copy())
+    ii = np.arange(g.shape2(H)[1])[None, None, :] - g.halo
+    warm = 0.5 * (1.0 + np.tanh((ii - ni / 2 + 0.5) / 3.0)) * (np.abs(ii - ni / 2) < ni / 2 - 4)
+    T = np.ascontiguousarray(np.array([18.0, 18.0, 18.0, 12.0, 8.0, 4.0])[:, None, None] + dT * warm * (np.arange(nk) < 3)[:, None, None] + 0 * h)
+    S = np.full_like(h, 35.0)
+    ustar = np.full(g.shape2(H), 0.01)
+    return g, d, h, T, S, ustar
+
+
+def test_light_water_slides_over_dense_water_and_the_front_slumps():
+    """a warm (light) mixed layer east of a cold one: in the upper half of the mixed layer the restratifying transport runs from the
+    light side to the dense side, in the lower half back; nothing moves below the mixed layer or where there is no front"""
+    g, d, h, T, S, ustar = front()
+    cs = orc.mixedlayer_restrat_cs(g, ml_restrat_coef=50.0, MLE_use_PBL_MLD=True)
+    h_MLD = np.full(g.shape2(H), 60.0)
+    h1 = h.copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"]); uhml = np.zeros_like(d["u"]); vhml = np.zeros_like(d["v"])
+    orc.mixedlayer_restrat(g, cs, h1, uhtr, vhtr, T, S, orc.eos("LINEAR"), ustar, DT, h_MLD, uhml, vhml)
+    uh = interior(g, uhml, U)
+    mid = g.ni // 2      # the face in the middle of the front: warm (light) to the east
+    assert np.all(uh[0:2, :, mid] < 0.0) and np.all(uh[2, :, mid] > 0.0)      # 10 + 20 m above mid-depth (30 m), 30 m below
+    assert np.all(uh[3:] == 0.0) and np.all(uh[:, :, :4] == 0.0) and np.all(interior(g, vhml, V) == 0.0)
+    assert bits_equal(h1[3:], h[3:])
+    # the top layer thickens on the dense side and thins on the light side
+    top = interior(g, h1 - h, H)[0]
+    assert top[:, mid - 1].min() > 0.0 and top[:, mid].max() < 0.0
+
+
+def test_no_horizontal_density_gradient_no_transport():
+    g, d, h, T, S, ustar = front(dT=0.0)
+    for kw in (dict(ml_restrat_coef=50.0), dict(ml_restrat_coef=50.0, nkml=3)):
+        cs = orc.mixedlayer_restrat_cs(g, **kw)
+        h1 = h.copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"])
+        orc.mixedlayer_restrat(g, cs, h1, uhtr, vhtr, T, S, orc.eos("LINEAR"), ustar, DT)
+        assert bits_equal(h1, h) and np.all(uhtr == 0.0) and np.all(vhtr == 0.0)
+
+
+def test_mixed_layer_depth_from_the_density_difference_and_its_running_means():
+    """MLE_DENSITY_DIFF: the depth where sigma-0 exceeds the surface's by the difference, interpolated between layer centres
+    (:283-327); MLE_MLD_DECAY_TIME: the running mean follows a deepening at once and a shoaling with the e-folding time (:330-345)"""
+    g, d, h, T, S, ustar = front(dT=0.0)
+    E = orc.eos("LINEAR")      # rho = 1000 - 0.2 T + 0.8 S: layers 1-3 at 18 degC, layer 4 at 12 degC: +1.2 kg m-3
+    filt = np.zeros(g.shape2(H))
+    cs = orc.mixedlayer_restrat_cs(g, ml_restrat_coef=1.0, MLE_density_diff=0.3, MLE_MLD_decay_time=7200.0, MLD_filtered=filt)
+    h1 = h.copy()
+    orc.mixedlayer_restrat(g, cs, h1, np.zeros_like(d["u"]), np.zeros_like(d["v"]), T, S, E, ustar, DT)
+    # centres of layers 3 and 4: 45 m and 90 m; 0.3 of 1.2 kg m-3 is a quarter of the way
+    sj, si = g.csl(H)
+    assert np.allclose(filt[sj, si], 45.0 + 0.25 * 45.0, rtol=1e-14)
+    filt[:] = 200.0      # a deeper mean from before: it decays towards the present depth
+    orc.mixedlayer_restrat(g, cs, h.copy(), np.zeros_like(d["u"]), np.zeros_like(d["v"]), T, S, E, ustar, DT)
+    assert np.allclose(filt[sj, si], (DT * 56.25 + 7200.0 * 200.0) / (DT + 7200.0), rtol=1e-14)
+
+
+def test_refuses_what_it_does_not_provide():
+    g, d = case(ni=12, nj=10, nk=4)
+    f = fields(g, d)
+    z = lambda a: np.zeros_like(a)
+    for n in _abi.MIXEDLAYER_RESTRAT_UNSUPPORTED:
+        cs = orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0, **{n: True})
+        with pytest.raises(RuntimeError):
+            orc.mixedlayer_restrat(g, cs, d["h"].copy(), z(d["u"]), z(d["v"]), d["T"], d["S"], orc.eos("WRIGHT"), f["ustar"], DT)
+    with pytest.raises(RuntimeError):      # "An equation of state must be used with this module."
+        orc.mixedlayer_restrat(g, orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0), d["h"].copy(), z(d["u"]), z(d["v"]), None, None, None, f["ustar"], DT)
+    with pytest.raises(RuntimeError):      # "The resolution argument, Rd/dx, was not associated."
+        orc.mixedlayer_restrat(g, orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0, front_length=100.0), d["h"].copy(), z(d["u"]), z(d["v"]), d["T"], d["S"],
+                               orc.eos("WRIGHT"), f["ustar"], DT)
+    with pytest.raises(RuntimeError):      # "No MLD to use for MLE parameterization."
+        orc.mixedlayer_restrat(g, orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0, MLE_density_diff=0.0), d["h"].copy(), z(d["u"]), z(d["v"]), d["T"], d["S"],
+                               orc.eos("WRIGHT"), f["ustar"], DT)
+    # a bulk mixed layer of fewer than two layers, or no coefficient: the call returns at once (:1284)
+    for kw in (dict(ml_restrat_coef=5.0, nkml=1), dict(ml_restrat_coef=0.0, nkml=3)):
+        h = d["h"].copy()
+        orc.mixedlayer_restrat(g, orc.mixedlayer_restrat_cs(g, **kw), h, z(d["u"]), z(d["v"]), d["T"], d["S"], orc.eos("WRIGHT"), f["ustar"], DT)
+        assert bits_equal(h, d["h"])
+
+
+REF = dict(ml_restrat_coef="FOX_KEMPER_ML_RESTRAT_COEF", ml_restrat_coef2="FOX_KEMPER_ML_RESTRAT_COEF2", front_length="MLE_FRONT_LENGTH",
+           MLE_MLD_decay_time="MLE_MLD_DECAY_TIME", MLE_MLD_decay_time2="MLE_MLD_DECAY_TIME2", MLE_density_diff="MLE_DENSITY_DIFF", MLE_tail_dh="MLE_TAIL_DH",
+           MLE_MLD_stretch="MLE_MLD_STRETCH", MLE_use_PBL_MLD="MLE_USE_PBL_MLD", nkml="NKML")
+
+
+@pytest.mark.gpu
+def test_gpu_shape_function_has_the_references_known_answers():
+    """the ten known answers of mixedlayer_restrat_unit_tests through the library's own mu, and library == oracle on a sweep with tails"""
+    from mom6_amd.mixedlayer_restrat import mu
+    for c in json.load(open(GOLD))["cases"]:
+        assert abs(mu(c["sigma"], c["dh"]) - c["mu"]) <= c["tol_eps"] * np.finfo(float).eps, c
+    rng = np.random.default_rng(2)
+    for sg, dh in zip(-1.8 * rng.random(200) + 0.1, rng.choice([0.0, 0.1, 0.2, 0.37, 0.5], 200)):
+        assert mu(sg, dh) == orc.mle_mu(sg, dh), (sg, dh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_gpu_parity(name):
+    """mixedlayer_restrat: library == oracle, bit for bit (h, uhtr, vhtr, uhml, vhml, the filtered depths), device and staged host arrays"""
+    import torch
+    from mom6_amd.mixedlayer_restrat import mixedlayer_restrat, mixedlayer_restrat_init
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    for (ni, nj, nk, topo, land, eos) in [(70, 21, 8, (True, False), 0.25, "WRIGHT"), (44, 40, 5, (True, True), 0.0, "LINEAR"),
+                                          (10, 8, 30, (False, False), 0.2, "UNESCO"), (200, 9, 75, (True, False), 0.25, "WRIGHT_FULL")]:
+        g, d = case(ni, nj, nk, land_frac=land, reentrant_x=topo[0], reentrant_y=topo[1])
+        ref, (kw, f, use) = run_oracle(g, d, name, eos=eos)
+        dg = DeviceGrid(g)
+        for resident in (True, False):
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: np.ascontiguousarray(a).copy())
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            state = {n: X(f[n]) for n in use if n.startswith("MLD_filtered")}
+            CS = mixedlayer_restrat_init(dg, **{REF[k]: v for k, v in kw.items()}, **state)
+            h, uhtr, vhtr, uhml, vhml = X(d["h"]), X(np.zeros_like(d["u"])), X(np.zeros_like(d["v"])), X(np.zeros_like(d["u"])), X(np.zeros_like(d["v"]))
+            mixedlayer_restrat(h, uhtr, vhtr, (X(d["T"]), X(d["S"]), EOS_init(eos)), dict(ustar=X(f["ustar"])), DT, None,
+                               X(f["h_MLD"]) if kw.get("MLE_use_PBL_MLD") else None, None, dict(Rd_dx_h=X(f["Rd_dx_h"])) if "Rd_dx_h" in use else None,
+                               dg, CS, uhml, vhml)
+            dg.sync()
+            for n, a in (("h", h), ("uhtr", uhtr), ("vhtr", vhtr), ("uhml", uhml), ("vhml", vhml)) + tuple(state.items()):
+                assert bits_equal(N(a), ref[n]), (name, (ni, nj, nk), resident, n, np.argwhere(N(a) != ref[n])[:3])
+        dg.close()
+
+
+# ---- the module shim (mom6_amd/fortran/MOM_mixed_layer_restrat_hip.F90) with the reference's dummy-argument lists --------------------
+def _write_mle_case(tmp, g, d, name, ncalls=2, eos="WRIGHT"):
+    """the input and parameter files of tests/fortran/mle_driver.F90 for one of VARIANTS, and the oracle's results after ncalls calls
+    (the running means start from zero, as mixedlayer_restrat_register_restarts leaves them on a cold start)"""
+    kw = dict(VARIANTS[name])
+    use = tuple(kw.pop("use", ())) + tuple(kw.pop("also", ()))
+    f = fields(g, d)
+    state = {n: (np.zeros_like(f[n]) if n.startswith("MLD_filtered") else f[n].copy()) for n in use}
+    if kw.get("MLE_MLD_decay_time2", 0.0) > 0.0 or kw.get("MLE_MLD_decay_time", 0.0) > 0.0:      # :1819: either time allocates MLD_filtered
+        state.setdefault("MLD_filtered", np.zeros_like(f["ustar"]))
+    cs = orc.mixedlayer_restrat_cs(g, **kw, **{n: a for n, a in state.items() if n != "MLD_filtered" or kw.get("MLE_MLD_decay_time", 0.0) > 0.0})
+    h = d["h"].copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"])
+    for _ in range(ncalls):
+        orc.mixedlayer_restrat(g, cs, h, uhtr, vhtr, d["T"], d["S"], orc.eos(eos), f["ustar"], DT, f["h_MLD"] if kw.get("MLE_use_PBL_MLD") else None)
+    opt = [int(kw.get("nkml", 0)), int(bool(kw.get("MLE_use_PBL_MLD"))), int("Rd_dx_h" in use), ncalls, 0, 0, 0, 0]
+    with open(tmp / "in.bin", "wb") as fh:
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, DT], dtype="<f8").tofile(fh)
+        np.array(opt, dtype="<i4").tofile(fh)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
+        for a in (d["h"], d["T"], d["S"], f["ustar"], f["h_MLD"], f["Rd_dx_h"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(fh)
+    with open(tmp / "params.txt", "w") as fh:
+        fh.write(f"MIXEDLAYER_RESTRAT = True\nEQN_OF_STATE = {eos}\n")
+        for k, v in kw.items():
+            if k in REF and k != "nkml":
+                fh.write(f"{REF[k]} = {v if isinstance(v, bool) else repr(float(v))}\n")
+    nrest = int(kw.get("MLE_MLD_decay_time", 0.0) > 0.0 or kw.get("MLE_MLD_decay_time2", 0.0) > 0.0) + int(kw.get("MLE_MLD_decay_time2", 0.0) > 0.0)
+    return dict(h=h, uhtr=uhtr, vhtr=vhtr), nrest
+
+
+def test_module_shim_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """MOM_mixed_layer_restrat_hip.F90 compiles with the reference's module name and argument lists; without a GPU the call stops with FATAL"""
+    import subprocess
+    import torch
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_shims(tmp_path, driver="mle_driver")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    g, d = case(24, 16, 4)
+    _write_mle_case(tmp_path, g, d, "fk")
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode != 0 and "FATAL" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_module_shim_matches_oracle(tmp_path):
+    """mixedlayer_restrat_register_restarts + mixedlayer_restrat_init + two calls of mixedlayer_restrat from Fortran with the reference's
+    argument lists on host arrays (the running means carried by the control structure between the calls): the oracle's bits"""
+    import subprocess
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_shims(tmp_path, driver="mle_driver")
+    g, d = case(36, 22, 6, reentrant_x=True, reentrant_y=False)
+    for name in VARIANTS:
+        ref, nrest = _write_mle_case(tmp_path, g, d, name)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and f"mle_driver ok restart_fields={nrest}" in r.stdout, (name, r.stdout[-200:], r.stderr[-600:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+        want = [ref["h"], ref["uhtr"], ref["vhtr"]]
+        assert raw.size == sum(w.size for w in want), name
+        for n, a, w in zip(("h", "uhtr", "vhtr"), np.split(raw, np.cumsum([w.size for w in want])[:-1]), want):
+            assert bits_equal(a.reshape(w.shape), w), (name, n)
