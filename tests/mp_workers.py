@@ -151,6 +151,59 @@ def hordiff_layout_worker(rank, world, port, layout, out_dir):
         dist.destroy_process_group()
 
 
+def lateral_layout_worker(rank, world, port, layout, out_dir):
+    """test.layout for thickness_diffuse and mixedlayer_restrat on the GPU (they read one halo point of h, T, S and of the 2-D fields
+    and exchange nothing themselves): the tiles must reproduce the one-tile run bit for bit."""
+    import numpy as np
+    import torch
+    from mom6_amd import _abi, synth
+    from mom6_amd.domains import Domain
+    from mom6_amd.mixedlayer_restrat import mixedlayer_restrat, mixedlayer_restrat_init
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.thickness_diffuse import thickness_diffuse, thickness_diffuse_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    dist = _init(rank, world, port)
+    try:
+        NI, NJ, NK, halo = 60, 36, 6, 4
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+        gg = synth.make_grid(NI, NJ, NK, halo=halo, reentrant_x=True, reentrant_y=False, seed=31)
+        d = synth.make_dynamics_state(gg, seed=4, umax=0.1, eta_amp=0.2)
+        rng = np.random.default_rng(9)
+        two = {n: torch.from_numpy(np.ascontiguousarray(a * gg.mask2dT))
+               for n, a in (("ustar", 2e-3 + 0.02 * rng.random(gg.shape2(H))), ("h_MLD", 15.0 + 100.0 * rng.random(gg.shape2(H))),
+                            ("Kh", 800.0 * rng.random(gg.shape2(H))))}
+        for a in two.values():      # valid halos, as the operators expect of their inputs
+            a[:, :halo] = a[:, NI:NI + halo]; a[:, NI + halo:] = a[:, halo:2 * halo]
+        eos = EOS_init("WRIGHT")
+
+        def run(dg, cut):
+            h, T, S = cut(d["h"], H), cut(d["T"], H), cut(d["S"], H)
+            uhtr, vhtr = torch.zeros_like(cut(d["u"], U)), torch.zeros_like(cut(d["v"], V))
+            td = thickness_diffuse_init(dg, THICKNESSDIFFUSE=True, KHTH=1.0, KHTH_MAX=900.0)
+            thickness_diffuse(h, uhtr, vhtr, (T, S, eos), 3600.0, dg, dict(Kh=cut(two["Kh"], H)), None, None, td)
+            dg.start_group_pass([h], [H]); dg.complete_group_pass()      # call pass_var(h, G%Domain), MOM.F90:1179
+            mle = mixedlayer_restrat_init(dg, FOX_KEMPER_ML_RESTRAT_COEF=20.0, MLE_USE_PBL_MLD=True, MLE_MLD_DECAY_TIME=86400.0,
+                                          MLD_filtered=torch.zeros_like(cut(two["ustar"], H)))
+            mixedlayer_restrat(h, uhtr, vhtr, (T, S, eos), dict(ustar=cut(two["ustar"], H)), 3600.0, None, cut(two["h_MLD"], H), None, None, dg, mle)
+            dg.sync()
+            return h.cpu().numpy(), uhtr.cpu().numpy(), vhtr.cpu().numpy()
+        dom = Domain(NI, NJ, layout, rank, halo, True, False)
+        dg = DeviceGrid(dom.tile_grid(gg))
+        dg.set_domain(dom)
+        h, uh, vh = run(dg, lambda a, pos: dom.cut(a, pos).cuda())
+        q = halo
+        np.savez(os.path.join(out_dir, f"tile{rank}.npz"), h=h[:, q:q + dom.nj, q:q + dom.ni], uh=uh[:, q:q + dom.nj, q:q + dom.ni + 1],
+                 vh=vh[:, q:q + dom.nj + 1, q:q + dom.ni], ij=np.array([dom.i0, dom.j0, dom.ni, dom.nj]))
+        dg.close()
+        if rank == 0:      # the one-tile answer
+            dg1 = DeviceGrid(gg)
+            h, uh, vh = run(dg1, lambda a, pos: a.clone().cuda())
+            np.savez(os.path.join(out_dir, "global.npz"), h=h[:, q:q + NJ, q:q + NI], uh=uh[:, q:q + NJ, q:q + NI + 1], vh=vh[:, q:q + NJ + 1, q:q + NI])
+            dg1.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def btstep_layout_worker(rank, world, port, layout, topo, out_dir):
     """test.layout for btstep on the GPU: each tile runs barotropic_init / btcalc / bt_mass_source / btstep with the
     group passes going through the domain callbacks; the compute-domain results must equal the one-tile oracle run."""

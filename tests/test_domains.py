@@ -97,6 +97,23 @@ def test_tracer_hordiff_layout_independence(tmp_path, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", [(1, 2), (2, 1)])
+def test_lateral_parameterizations_layout_independence(tmp_path, layout):
+    """thickness_diffuse (with MEKE%Kh) then mixedlayer_restrat (with h_MLD and its running mean) on two tiles == on one, to the bit"""
+    import torch.multiprocessing as mp
+    from mp_workers import lateral_layout_worker
+    mp.spawn(lateral_layout_worker, args=(2, free_port(), layout, str(tmp_path)), nprocs=2, join=True)
+    glob = np.load(tmp_path / "global.npz")
+    for r in range(2):
+        t = np.load(tmp_path / f"tile{r}.npz")
+        i0, j0, ni, nj = t["ij"]
+        for n, ex, ey in (("h", 0, 0), ("uh", 1, 0), ("vh", 0, 1)):
+            a = t[n]; b = glob[n][:, j0:j0 + nj + ey, i0:i0 + ni + ex]
+            assert np.abs(b).max() > 0.0
+            assert np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64)), (layout, r, n)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout,topo", [((1, 2), (True, False)), ((2, 1), (True, False)), ((2, 1), (False, False)), ((1, 2), (True, True))])
 def test_btstep_layout_independence(tmp_path, layout, topo):
     import torch.multiprocessing as mp
