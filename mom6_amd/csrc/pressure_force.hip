@@ -76,7 +76,13 @@ struct PgfArgs {
 };
 
 // ---- column kernel -------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pgf_column_kernel(PgfArgs p) {
+#ifndef PGF_COL_OCC
+#define PGF_COL_OCC 4      // waves per SIMD the register allocation aims at (tools/build_variant.sh for experiments)
+#endif
+#ifndef PGF_FACE_OCC
+#define PGF_FACE_OCC 4      // 133 -> 126 VGPRs (20 B of scratch): 12.9 -> 12.3 ms for the pair (profiles/r03_occupancy_experiments.txt)
+#endif
+__global__ __launch_bounds__(64, PGF_COL_OCC) void pgf_column_kernel(PgfArgs p) {
   const m6::GridDev &g = p.g;
   const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
   const int j = g.jsc - 1 + blockIdx.y;
@@ -245,7 +251,7 @@ __device__ __forceinline__ double face_integral(const PgfArgs &p, long oL3, long
   return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
 }
 
-__global__ __launch_bounds__(64) void pgf_face_kernel(PgfArgs p) {
+__global__ __launch_bounds__(64, PGF_FACE_OCC) void pgf_face_kernel(PgfArgs p) {
   const m6::GridDev &g = p.g;
   const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;      // I (x face) / i (y face)
   const int j = g.jsc - 1 + blockIdx.y;                         // j (x face) / J (y face)

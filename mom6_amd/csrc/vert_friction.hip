@@ -406,8 +406,11 @@ __global__ __launch_bounds__(64) void vv_solve_kernel(SolveArgs A) {
 
 // vertvisc_coef followed by the solve(s) of the same column: the coupling coefficients and thicknesses the bottom-up sweep
 // has just stored are read back by the same lane while they are still in L2, instead of by a second kernel from HBM.
+#ifndef VV_OCC
+#define VV_OCC 4      // waves per SIMD the register allocation aims at (121 VGPRs: 4; tools/build_variant.sh for experiments)
+#endif
 template <int DIR>
-__global__ __launch_bounds__(64) void vv_coef_solve_kernel(CoefArgs C, SolveArgs A) {
+__global__ __launch_bounds__(64, VV_OCC) void vv_coef_solve_kernel(CoefArgs C, SolveArgs A) {
   const m6::GridDev &g = A.g;
   const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
   const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
@@ -691,8 +694,11 @@ extern "C" int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
     A.g = g; A.p = C.p; A.a = a[d]; A.hv = hv[d]; A.Ray = nullptr; A.h = dh; A.tau = tau[d]; A.x = update_velocities ? x[d] : nullptr;
     A.xr = xr[d]; A.c1 = c1; A.tbot = tbot[d]; A.dt = dt; A.ntrunc = cnt;
     const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
-    if (d == 0) hipLaunchKernelGGL(vv_coef_solve_kernel<0>, grid, dim3(64), 0, ctx->stream, C, A);
-    else hipLaunchKernelGGL(vv_coef_solve_kernel<1>, grid, dim3(64), 0, ctx->stream, C, A);
+    // MOM6HIP_VV_LDS_BYTES: unused dynamic LDS per block, an occupancy throttle for experiments (a column's intermediates stay in
+    // the memory-side cache only while few enough waves are in flight); 0 = none
+    static const int lds_throttle = [] { const char *e = getenv("MOM6HIP_VV_LDS_BYTES"); return e ? atoi(e) : 0; }();
+    if (d == 0) hipLaunchKernelGGL(vv_coef_solve_kernel<0>, grid, dim3(64), lds_throttle, ctx->stream, C, A);
+    else hipLaunchKernelGGL(vv_coef_solve_kernel<1>, grid, dim3(64), lds_throttle, ctx->stream, C, A);
   }
   M6_HIP(hipGetLastError());
   const int rc = st.finish();
