@@ -713,6 +713,8 @@ def main():
                                                                + ("over RCCL send / recv inside the library (its communication stream)"
                                                                   if exchange == "rccl" else f"through torch.distributed callbacks ({backend})"),
             "exchange": exch,
+            # (row-split groups, continuity calls in two phases, passes completed before anything else ran, 0) of this rank, all steps
+            "overlap_stats": list(M.dg.overlap_stats()),
         },
     }
     # what the device delivers to plain streaming kernels on THIS box (a = b, a = b + s*c over 4 GiB arrays), next to the nominal

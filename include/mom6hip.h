@@ -113,6 +113,11 @@ int mom6hip_complete_group_pass(mom6hip_ctx_t *ctx);
  * that a kernel enqueued between the two that reads one of those halos too early yields NaNs deterministically, whatever the
  * timing of the streams.  One tile and the library's own RCCL domain; not with the host's halo callback. */
 int mom6hip_debug_poison_passes(mom6hip_ctx_t *ctx, int32_t enable);
+/* How often the RK2 step has worked around a pass in flight since the context was made (or since the last reset): stats[0] the
+ * row-split launches of h_av / horizontal_viscosity / CorAdCalc / the accumulations (inner rows before the completion, the edge bands
+ * after it), stats[1] the continuity calls made in two phases, stats[2] the passes completed before anything else ran (one-tile
+ * domains, tiles too short to split, G%first_direction = 1, the tripolar fold), stats[3] reserved. */
+int mom6hip_overlap_stats(mom6hip_ctx_t *ctx, uint64_t *stats, int32_t reset);
 
 /* ---- restart / diagnostic staging: fields to the host while the model keeps stepping ------ */
 

@@ -629,6 +629,12 @@ extern "C" int mom6hip_debug_poison_passes(mom6hip_ctx_t *ctx, int32_t enable) {
   return 0;
 }
 
+extern "C" int mom6hip_overlap_stats(mom6hip_ctx_t *ctx, uint64_t *stats, int32_t reset) {
+  M6_REQUIRE(ctx != nullptr && stats != nullptr, "mom6hip_overlap_stats: null argument");
+  for (int n = 0; n < 4; n++) { stats[n] = ctx->overlap[n]; if (reset) ctx->overlap[n] = 0; }
+  return 0;
+}
+
 extern "C" int mom6hip_halo_update(mom6hip_ctx_t *ctx, double *const *fields, const int32_t *pos,
                                    const int32_t *nk_each, int32_t nfields) {
   M6_REQUIRE(ctx && fields && pos && nk_each, "mom6hip_halo_update: null argument");

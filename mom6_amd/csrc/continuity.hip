@@ -1090,6 +1090,8 @@ struct ConvArgs {
   double *h;
   double dt, h_min;
   int i0, i1, j0, j1;
+  double *h2 = nullptr;      // also stored here in the rows outside j2lo .. j2hi (the phased call: see mom6hip_continuity)
+  int j2lo = 0, j2hi = -1;
 };
 
 template <int DIR>
@@ -1108,7 +1110,9 @@ __global__ __launch_bounds__(256) void cont_conv_kernel(ConvArgs p) {
     const long f = g.u2(i, j) + (long)(g.nih + 1) * g.njh * k;
     uhp = p.uh[f]; uhm = p.uh[f - 1];
   }
-  p.h[o3] = max2(p.hin[o3] - p.dt * g.IareaT[o2] * (uhp - uhm), p.h_min);
+  const double hn = max2(p.hin[o3] - p.dt * g.IareaT[o2] * (uhp - uhm), p.h_min);
+  p.h[o3] = hn;
+  if (p.h2 && (j < p.j2lo || j > p.j2hi)) p.h2[o3] = hn;
 }
 
 }  // namespace
@@ -1172,8 +1176,8 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
   double *h_L = (double *)st.scratch(bH), *h_R = (double *)st.scratch(bH);
   if (st.failed()) return 1;
   // du_cor(:,:) = 0.0 over the whole array, :601
-  if (d_ducor) M6_HIP(hipMemsetAsync(d_ducor, 0, bU2, s));
-  if (d_dvcor) M6_HIP(hipMemsetAsync(d_dvcor, 0, bV2, s));
+  if (d_ducor && ctx->cont_phase != 2) M6_HIP(hipMemsetAsync(d_ducor, 0, bU2, s));
+  if (d_dvcor && ctx->cont_phase != 2) M6_HIP(hipMemsetAsync(d_dvcor, 0, bV2, s));
 
   ContOpts o;
   o.upwind_1st = cs->upwind_1st; o.monotonic = cs->monotonic; o.simple_2nd = cs->simple_2nd;
@@ -1185,7 +1189,9 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
   const bool x_first = (ctx->host.first_direction % 2) == 0;
   const double h_min = g.Angstrom_H;
 
-  auto zonal = [&](const double *hsrc, int jsh, int jeh, double hmin) -> int {
+  // hdst: where the thicknesses after this direction go (the output array, or the scratch of the phased call)
+  auto zonal = [&](const double *hsrc, int jsh, int jeh, double hmin, double *hdst, double *also) -> int {
+    if (jeh < jsh) return 0;
     FluxArgs f; f.g = g; f.o = o; f.u = d_u; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_uhbt; f.visc_rem = d_vru;
     f.uh = d_uh; f.u_cor = d_ucor; f.du_cor = d_ducor;
     f.FA_0m = bt.FA_u_W0; f.FA_mm = bt.FA_u_WW; f.FA_0p = bt.FA_u_E0; f.FA_pp = bt.FA_u_EE; f.uBT_mm = bt.uBT_WW;
@@ -1198,38 +1204,66 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     }
     { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_X);
       if (launch_flux<0>(ctx, f, f.fi1 - f.fi0 + 1, jeh - jsh + 1)) return 1; }
-    ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = d_h; c.dt = dt; c.h_min = hmin;
-    c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh;
+    ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = hdst; c.dt = dt; c.h_min = hmin;
+    c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh; c.h2 = also; c.j2lo = js; c.j2hi = je;
     hipLaunchKernelGGL(cont_conv_kernel<0>, dim3((ie - is + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, c);
     M6_HIP(hipGetLastError());
     return 0;
   };
-  auto merid = [&](const double *hsrc, int ish, int ieh, double hmin) -> int {
+  // faces fj0 .. fj1, then the cells cj0 .. cj1 (the whole call: js-1 .. je and js .. je)
+  auto merid = [&](const double *hsrc, int ish, int ieh, double hmin, int fj0, int fj1, int cj0, int cj1) -> int {
     FluxArgs f; f.g = g; f.o = o; f.u = d_v; f.h_in = hsrc; f.h_L = h_L; f.h_R = h_R; f.uhbt = d_vhbt; f.visc_rem = d_vrv;
     f.uh = d_vh; f.u_cor = d_vcor; f.du_cor = d_dvcor;
     f.FA_0m = bt.FA_v_S0; f.FA_mm = bt.FA_v_SS; f.FA_0p = bt.FA_v_N0; f.FA_pp = bt.FA_v_NN; f.uBT_mm = bt.vBT_SS;
     f.uBT_pp = bt.vBT_NN; f.h_face = bt.h_v; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
-    f.fi0 = ish; f.fi1 = ieh; f.fj0 = js - 1; f.fj1 = je;
-    if (!flux_is_coop(f)) {
-      EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
-      e.i0 = ish; e.i1 = ieh; e.j0 = js - 1; e.j1 = je + 1;
-      hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, s, e);
+    f.fi0 = ish; f.fi1 = ieh; f.fj0 = fj0; f.fj1 = fj1;
+    if (fj1 >= fj0) {
+      if (!flux_is_coop(f)) {
+        EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+        e.i0 = ish; e.i1 = ieh; e.j0 = fj0; e.j1 = fj1 + 1;
+        hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, s, e);
+      }
+      { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_Y);
+        if (launch_flux<1>(ctx, f, ieh - ish + 1, f.fj1 - f.fj0 + 1)) return 1; }
     }
-    { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_Y);
-      if (launch_flux<1>(ctx, f, ieh - ish + 1, f.fj1 - f.fj0 + 1)) return 1; }
-    ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
-    c.i0 = ish; c.i1 = ieh; c.j0 = js; c.j1 = je;
-    hipLaunchKernelGGL(cont_conv_kernel<1>, dim3((ieh - ish + 256) / 256, je - js + 1, g.nk), dim3(256), 0, s, c);
+    if (cj1 >= cj0) {
+      ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
+      c.i0 = ish; c.i1 = ieh; c.j0 = cj0; c.j1 = cj1;
+      hipLaunchKernelGGL(cont_conv_kernel<1>, dim3((ieh - ish + 256) / 256, cj1 - cj0 + 1, g.nk), dim3(256), 0, s, c);
+    }
     M6_HIP(hipGetLastError());
     return 0;
   };
 
+  // ---- the phased call (ctx->cont_phase, set by the RK2 step around a group pass in flight; x first, device arrays) ----------
+  // Phase 1, before the completion: the zonal pass of the tile's own rows (a row's fluxes read that row only), then the
+  // meridional fluxes and thicknesses whose stencil stays inside those rows.  Phase 2, after it: the zonal pass of the halo rows,
+  // then the faces and cells along the two edges.  The thicknesses between the two directions live in a scratch array of the
+  // context, not in the output array as in the one-phase call, so no phase overwrites what the other still reads -- also when
+  // the call works in place (h is hin); the halo rows of the output receive them as well, as the one-phase call leaves them.
+  if (ctx->cont_phase) {
+    M6_REQUIRE(x_first && memspace == MOM6HIP_MEM_DEVICE, "continuity_PPM: the phased call needs x first and device arrays");
+    M6_REQUIRE(je - js + 1 >= 2 * stencil + 2, "continuity_PPM: the phased call needs a taller tile");
+    M6_REQUIRE(ctx->cont_hmid.reserve(bH) == 0 && ctx->cont_hmid.p, "continuity_PPM: out of device memory");
+    double *hm = (double *)ctx->cont_hmid.p;
+    if (ctx->cont_phase == 1) {
+      if (zonal(d_hin, js, je, 0.0, hm, nullptr)) return 1;
+      if (merid(hm, is, ie, h_min, js + stencil - 1, je - stencil, js + stencil, je - stencil)) return 1;
+    } else {
+      if (zonal(d_hin, js - stencil, js - 1, 0.0, hm, d_h)) return 1;
+      if (zonal(d_hin, je + 1, je + stencil, 0.0, hm, d_h)) return 1;
+      if (merid(hm, is, ie, h_min, js - 1, js + stencil - 2, js, js + stencil - 1)) return 1;
+      if (merid(hm, is, ie, h_min, je - stencil + 1, je, je - stencil + 1, je)) return 1;
+    }
+    return st.finish();
+  }
+
   if (x_first) {
-    if (zonal(d_hin, js - stencil, je + stencil, 0.0)) return 1;
-    if (merid(d_h, is, ie, h_min)) return 1;
+    if (zonal(d_hin, js - stencil, je + stencil, 0.0, d_h, nullptr)) return 1;
+    if (merid(d_h, is, ie, h_min, js - 1, je, js, je)) return 1;
   } else {
-    if (merid(d_hin, is - stencil, ie + stencil, 0.0)) return 1;
-    if (zonal(d_h, js, je, h_min)) return 1;
+    if (merid(d_hin, is - stencil, ie + stencil, 0.0, js - 1, je, js, je)) return 1;
+    if (zonal(d_h, js, je, h_min, d_h, nullptr)) return 1;
   }
   return st.finish();
 }

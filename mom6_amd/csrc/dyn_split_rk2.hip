@@ -66,9 +66,11 @@ bool split_rows(mom6hip_ctx_t *ctx) {
 // pass in flight: the rows at least a halo width inside the tile before it, the two bands along the edges after it.
 template <class F> int around_pass(mom6hip_ctx_t *ctx, F work) {
   if (!split_rows(ctx)) {
+    ctx->overlap[2]++;
     if (int rc = m6::complete_group_pass(ctx)) return rc;
     return work();
   }
+  ctx->overlap[0]++;
   const int js = ctx->host.jsc, je = ctx->host.jec, W = ctx->host.isc - ctx->host.isd;
   m6::row_window(ctx, js + W, je - W);
   int rc = work();
@@ -79,6 +81,28 @@ template <class F> int around_pass(mom6hip_ctx_t *ctx, F work) {
   rc = work();
   if (!rc) { m6::row_window(ctx, je - W + 1, je); rc = work(); }
   m6::row_window_reset(ctx);
+  return rc;
+}
+// The continuity around the completion of the pass in flight: its zonal pass reads a row at a time, so the tile's own rows go
+// first, with the meridional faces and cells whose stencil stays inside them (mom6hip_continuity, ctx->cont_phase = 1); the halo
+// rows and the two edges follow the completion (cont_phase = 2).  x first, no fold on this tile, rows worth splitting; otherwise
+// the pass completes and the continuity is the one call it always was.
+template <class F> int continuity_around_pass(mom6hip_ctx_t *ctx, F call) {
+  const bool phased = split_rows(ctx) && (ctx->host.first_direction % 2) == 0 && !ctx->host.tripolar_n;
+  if (!phased) {
+    ctx->overlap[2]++;
+    if (int rc = m6::complete_group_pass(ctx)) return rc;
+    return call();
+  }
+  ctx->overlap[1]++;
+  ctx->cont_phase = 1;
+  int rc = call();
+  ctx->cont_phase = 0;
+  if (rc) return rc;
+  if ((rc = m6::complete_group_pass(ctx))) return rc;
+  ctx->cont_phase = 2;
+  rc = call();
+  ctx->cont_phase = 0;
   return rc;
 }
 constexpr int PH = MOM6HIP_POS_H, PU = MOM6HIP_POS_U, PV = MOM6HIP_POS_V, P2D = 4;
@@ -253,11 +277,14 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   // btcalc, bt_mass_source :627-630 ; continuity for BT_cont and the layer fluxes :634-644
   if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));
   CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
-  CALL(m6::complete_group_pass(ctx));
   if (BTC || cs->BT_use_layer_fluxes) {
-    CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,
-                            cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
+    CALL(continuity_around_pass(ctx, [&]() -> int {
+      return mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,
+                                cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D);
+    }));
     if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));
+  } else {
+    CALL(m6::complete_group_pass(ctx));
   }
   if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));                       // :651
   const bool lf = cs->BT_use_layer_fluxes != 0;
@@ -284,11 +311,12 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   } else if (VV) {            // :717-744
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  // pass_visc_rem, pass_uvp :741-751 (the continuity forms its first direction's fluxes in the halo rows of the second: it reads
-  // the halos of up, vp and visc_rem, and it keeps its intermediate thicknesses in the output array, so its rows cannot be split)
-  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));
-  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
-                          u_av, v_av, BTC, nullptr, nullptr, D));
+  // pass_visc_rem, pass_uvp :741-751 in flight behind the continuity's own rows (continuity_around_pass)
+  CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz, 1));
+  CALL(continuity_around_pass(ctx, [&]() -> int {
+    return mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
+                              u_av, v_av, BTC, nullptr, nullptr, D);
+  }));
   // pass_hp_uv :763 in flight behind bt_mass_source and btcalc (no halos) and behind the rows of h_av, horizontal_viscosity and
   // CorAdCalc that lie at least a halo width inside the tile; the rows along the two edges follow the completion
   const bool hv_hook = !cs->hor_visc && hk && hk->horizontal_viscosity;
@@ -337,9 +365,11 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
   launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
-  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));     // :991-1008
-  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :1015
-                          cs->visc_rem_v, u_av, v_av, nullptr, nullptr, nullptr, D));
+  CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz, 3));     // :991-1008
+  CALL(continuity_around_pass(ctx, [&]() -> int {
+    return mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :1015
+                              cs->visc_rem_v, u_av, v_av, nullptr, nullptr, nullptr, D);
+  }));
   // pass_h, pass_av_uvh :1018-1043 in flight behind the rows of the three accumulations and of CorAdCalc that need no halo row.
   // The accumulations work in place: their rows are split exactly (inner rows before the completion, the two edge bands after).
   auto accumulate = [&](int ja, int jb, int Ja, int Jb) {      // cell rows ja..jb, v-face rows Ja..Jb
@@ -362,6 +392,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   };
   CALL(pass_start(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz, 4));               // :1018, :1027
   if (split_rows(ctx)) {
+    ctx->overlap[0]++;
     const int W = is - g.isd;      // the halo width: CorAdCalc's rows at least W inside the tile read rows of the compute domain only
     accumulate(js + 2, je - 2, Jsq + 2, Jeq - 2);      // (h_av's inner rows reach two rows beyond the window of next_CA below)
     m6::row_window(ctx, js + W + 2, je - W - 2);
@@ -377,6 +408,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     m6::row_window_reset(ctx);
     if (rc) return rc;
   } else {
+    ctx->overlap[2]++;
     CALL(m6::complete_group_pass(ctx));
     accumulate(js - 2, je + 2, Jsq - 2, Jeq + 2);
     CALL(next_CA());

@@ -330,6 +330,14 @@ interface
     integer(c_int) :: rc
   end function mom6hip_debug_poison_passes
 
+  function mom6hip_overlap_stats(ctx, stats, reset) bind(c, name="mom6hip_overlap_stats") result(rc)
+    import :: c_int, c_ptr, c_int64_t, c_int32_t
+    type(c_ptr), value :: ctx
+    integer(c_int64_t), intent(out) :: stats(4)
+    integer(c_int32_t), value :: reset
+    integer(c_int) :: rc
+  end function mom6hip_overlap_stats
+
   function mom6hip_transfer_stats(ctx, stats, reset) bind(c, name="mom6hip_transfer_stats") result(rc)
     import :: c_int, c_ptr, c_int64_t, c_int32_t
     type(c_ptr), value :: ctx

@@ -73,6 +73,13 @@ class DeviceGrid:
         nks = (C.c_int32 * n)(*[1 if f.dim() == 2 else f.shape[0] for f in fields])
         check(lib().mom6hip_halo_update(self.handle, ptrs, pos, nks, n), "mom6hip_halo_update")
 
+    def overlap_stats(self, reset=False):
+        """mom6hip_overlap_stats: (row-split launches, continuity calls in two phases, passes completed before anything else ran, 0)"""
+        L = lib(); L.mom6hip_overlap_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]
+        out = (C.c_uint64 * 4)()
+        check(L.mom6hip_overlap_stats(self.handle, out, int(bool(reset))), "mom6hip_overlap_stats")
+        return tuple(int(x) for x in out)
+
     def start_group_pass(self, fields, positions):
         """start_group_pass (MOM_domain_infra.F90:1141): the halo update of the fields is in flight until complete_group_pass."""
         n = len(fields)

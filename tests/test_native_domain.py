@@ -199,7 +199,8 @@ def test_poisoned_passes_hold_nans_until_they_complete():
 def test_nothing_reads_a_halo_while_its_pass_is_in_flight(mode):
     """The step starts its group passes where the reference does (MOM_dynamics_split_RK2.F90:541, :608, :741, :763, :991, :1018) and
     completes them as late as the next reader of a halo allows, with the rows a halo width inside the tile of h_av, horizontal
-    viscosity, CorAdCalc and the accumulations of uhtr / vhtr / h_av enqueued BEFORE the completion.  Proof that none of this reads a
+    viscosity, CorAdCalc and the accumulations of uhtr / vhtr / h_av, and the continuity's zonal pass of the tile's own rows with the
+    meridional faces and cells whose stencil stays inside them (the three continuity calls in two phases), enqueued BEFORE the completion.  Proof that none of this reads a
     halo too early, independent of any timing: with mom6hip_debug_poison_passes every halo a pass will fill is NaN from its start to
     its completion -- three viscous steps on a doubly re-entrant tile are still the oracle's bits, without a NaN"""
     from mom6_amd.tracer_advect import DeviceGrid
@@ -207,6 +208,20 @@ def test_nothing_reads_a_halo_while_its_pass_is_in_flight(mode):
     g = xs.make_grid(44, 40, 4, land_frac=0.0, reentrant_x=True, reentrant_y=True)
     dg = DeviceGrid(g)
     _three_viscous_steps(g, dg, poison=dict(poison="poison" in mode, split_rows="split" in mode))
+    # per step: two row-split groups (after pass_hp_uv, after pass_h + pass_av_uvh) and the three continuity calls in two phases
+    assert dg.overlap_stats() == (3 * 2, 3 * 3, 0, 0)
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_y_first_continuity_waits_for_its_pass():
+    """G%first_direction = 1: the meridional pass comes first and needs the halo rows at once, so the continuity is not split
+    around its pass (continuity_around_pass falls back to the completed pass); everything else still is"""
+    from mom6_amd.tracer_advect import DeviceGrid
+    g = xs.make_grid(44, 40, 4, land_frac=0.0, reentrant_x=True, reentrant_y=True, first_direction=1)
+    dg = DeviceGrid(g)
+    _three_viscous_steps(g, dg, poison=dict(poison=True, split_rows=True))
+    assert dg.overlap_stats() == (3 * 2, 0, 3 * 3, 0)
     dg.close()
 
 
@@ -226,4 +241,5 @@ def test_row_split_around_the_native_exchange(poison):
     dg = DeviceGrid(tg)
     dom.attach_native(dg)
     _three_viscous_steps(g, dg, poison=dict(poison=poison, split_rows=False))
+    assert dg.overlap_stats() == (3 * 2, 3 * 3, 0, 0)
     dg.close()
