@@ -473,7 +473,10 @@ __global__ __launch_bounds__(256) void adv_x_kernel(AdvArgs p) {
 constexpr int YSEG_MAX = 8;
 
 template <int NT, int SCHEME, bool FIRST>
-__global__ __launch_bounds__(64 * YSEG_MAX, 2) void adv_y_kernel(AdvArgs p, int seglen) {
+#ifndef ADVY_OCC
+#define ADVY_OCC 2      // waves per SIMD the register allocation aims at (tools/build_variant.sh for experiments)
+#endif
+__global__ __launch_bounds__(64 * YSEG_MAX, ADVY_OCC) void adv_y_kernel(AdvArgs p, int seglen) {
   const m6::GridDev &g = p.g;
   constexpr int NHR = (SCHEME == CW) ? 3 : 2;        // foreign T rows needed above the segment's last face
   __shared__ double s_halo[YSEG_MAX][NHR * NT + 2][64];
