@@ -825,23 +825,42 @@ int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, 
 
 /*
  * tracer_hor_diff_CS, src/tracer/MOM_tracer_hor_diff.F90:40-100, as set by tracer_hor_diff_init (:1625-1770).
- * Provided: the along-layer diffusion of tracer_hordiff (:119-680) with a constant diffusivity -- KHTR, MAX_TR_DIFFUSION_CFL,
- * CHECK_DIFFUSIVE_CFL (the iteration count from the largest diffusive CFL number, max_across_PEs), conc_underflow.
+ * Provided: the along-layer diffusion of tracer_hordiff (:119-680) -- KHTR, MAX_TR_DIFFUSION_CFL, CHECK_DIFFUSIVE_CFL (the
+ * iteration count from the largest diffusive CFL number, max_across_PEs), conc_underflow; and, with VarMix%use_variable_mixing
+ * (round 3, :236-281; .testing/tc1, tc2), the diffusivity of every face KHTR + KHTR_SLOPE_CFF * VarMix%L2u * VarMix%SN_u (the
+ * Visbeck form) + MEKE%KhTr_fac * sqrt(MEKE%Kh(i) * MEKE%Kh(i+1)), limited by KHTR_MAX, times the mean of VarMix%Res_fn_h
+ * (RESOLN_SCALED_KHTR), floored by KHTR_MIN, and the passivity factor max(KHTR_PASSIVITY_MIN, KHTR_PASSIVITY_COEFF * Rd/dx): the
+ * fields come in mom6hip_hordiff_fields_t through mom6hip_tracer_hordiff_varmix.
  * Not provided (refused by name, any nonzero `unsupported`): USE_NEUTRAL_DIFFUSION, USE_HORIZONTAL_BOUNDARY_DIFFUSION,
- * DIFFUSE_ML_TO_INTERIOR (tracer_epipycnal_ML_diff), variable mixing (VarMix: KHTR_SLOPE_CFF, resolution scaling,
- * KHTR_USE_EBT_STRUCT, KHTR_PASSIVITY_COEFF), MEKE diffusivities, KHTR_MIN / KHTR_MAX (only read with VarMix), offline
- * khdt arrays, the df_x / df_y flux diagnostics.
+ * DIFFUSE_ML_TO_INTERIOR (tracer_epipycnal_ML_diff), KHTR_USE_EBT_STRUCT, offline khdt arrays, the df_x / df_y flux diagnostics.
  */
 typedef struct mom6hip_tracer_hor_diff_cs {
-  double KhTr;             /* KHTR [L2 T-1] (0: tracer_hordiff returns at once) */
+  double KhTr;             /* KHTR [L2 T-1] (0: tracer_hordiff returns at once unless use_variable_mixing) */
   double max_diff_CFL;     /* MAX_TR_DIFFUSION_CFL (-1: no limit) */
-  double reserved0[6];
+  double KhTr_Slope_Cff;   /* KHTR_SLOPE_CFF (0): > 0 with use_variable_mixing needs L2u, L2v, SN_u, SN_v */
+  double KhTr_fac;         /* MEKE%KhTr_fac (MEKE_KHTR_FAC): read with MEKE_Kh */
+  double KhTr_min;         /* KHTR_MIN [L2 T-1] (0) */
+  double KhTr_max;         /* KHTR_MAX [L2 T-1] (0: none) */
+  double KhTr_passivity_coeff;  /* KHTR_PASSIVITY_COEFF (0): > 0 needs Rd_dx_h */
+  double KhTr_passivity_min;    /* KHTR_PASSIVITY_MIN (0.5) */
   int32_t check_diffusive_CFL;  /* CHECK_DIFFUSIVE_CFL (0) */
   int32_t initialized;
-  int32_t unsupported[8];  /* use_neutral_diffusion, use_hor_bnd_diffusion, Diffuse_ML_interior, use_variable_mixing, MEKE%Kh,
+  int32_t unsupported[8];  /* use_neutral_diffusion, use_hor_bnd_diffusion, Diffuse_ML_interior, (free), (free),
                               KhTr_use_ebt_struct, offline (do_online = false), flux diagnostics */
-  int32_t reserved1[6];
+  int32_t use_variable_mixing;  /* VarMix%use_variable_mixing (0): the diffusivities of :236-281 */
+  int32_t Resoln_scaled_KhTr;   /* VarMix%Resoln_scaled_KhTr (0): needs Res_fn_h */
+  int32_t reserved1[4];
 } mom6hip_tracer_hor_diff_cs_t;
+
+/* the fields of MEKE and VarMix tracer_hordiff reads with use_variable_mixing, in the memory space of the call (NULL: not
+ * allocated / not in use); h-point fields need a valid halo of 1 */
+typedef struct mom6hip_hordiff_fields {
+  const double *MEKE_Kh;            /* MEKE%Kh, h points 2-D */
+  const double *L2u, *L2v, *SN_u, *SN_v;      /* VarMix%L2u ... (KHTR_SLOPE_CFF > 0), u / v points 2-D */
+  const double *Res_fn_h;           /* VarMix%Res_fn_h (RESOLN_SCALED_KHTR), h points 2-D */
+  const double *Rd_dx_h;            /* VarMix%Rd_dx_h (KHTR_PASSIVITY_COEFF > 0), h points 2-D */
+  void *reserved[5];
+} mom6hip_hordiff_fields_t;
 
 typedef struct mom6hip_hordiff_stats {
   int32_t num_itts;        /* iterations of the diffusion (:424-434) */
@@ -855,6 +874,10 @@ typedef struct mom6hip_hordiff_stats {
 int mom6hip_tracer_hordiff(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const double *h, double dt,
                            double *const *tr, const double *conc_underflow, int32_t ntr, int32_t memspace,
                            mom6hip_hordiff_stats_t *stats);
+/* the same with the MEKE and VarMix arguments of the reference (fields may be NULL: the call above) */
+int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_hordiff_fields_t *fields,
+                                  const double *h, double dt, double *const *tr, const double *conc_underflow, int32_t ntr,
+                                  int32_t memspace, mom6hip_hordiff_stats_t *stats);
 
 /* ---- MOM_hor_visc ----------------------------------------------------------------------------- */
 

@@ -156,8 +156,18 @@ TRACER_HORDIFF_UNSUPPORTED = ("USE_NEUTRAL_DIFFUSION", "USE_HORIZONTAL_BOUNDARY_
 
 class TracerHorDiffCS(C.Structure):
     """mom6hip_tracer_hor_diff_cs_t (include/mom6hip.h)."""
-    _fields_ = [("KhTr", C.c_double), ("max_diff_CFL", C.c_double), ("reserved0", C.c_double * 6), ("check_diffusive_CFL", C.c_int32),
-                ("initialized", C.c_int32), ("unsupported", C.c_int32 * 8), ("reserved1", C.c_int32 * 6)]
+    _fields_ = [("KhTr", C.c_double), ("max_diff_CFL", C.c_double), ("KhTr_Slope_Cff", C.c_double), ("KhTr_fac", C.c_double), ("KhTr_min", C.c_double),
+                ("KhTr_max", C.c_double), ("KhTr_passivity_coeff", C.c_double), ("KhTr_passivity_min", C.c_double), ("check_diffusive_CFL", C.c_int32),
+                ("initialized", C.c_int32), ("unsupported", C.c_int32 * 8), ("use_variable_mixing", C.c_int32), ("Resoln_scaled_KhTr", C.c_int32),
+                ("reserved1", C.c_int32 * 4)]
+
+
+HORDIFF_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h")
+
+
+class HorDiffFields(C.Structure):
+    """mom6hip_hordiff_fields_t (include/mom6hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in HORDIFF_FIELDS] + [("reserved", C.c_void_p * 5)]
 
 
 class HorDiffStats(C.Structure):

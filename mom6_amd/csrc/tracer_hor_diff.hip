@@ -19,9 +19,15 @@ namespace {
 
 using m6::min2;
 
+using m6::max2;
+
 struct HDArgs {
   m6::GridDev g;
   double KhTr, max_diff_CFL, dt, scale;
+  // with VarMix%use_variable_mixing (:236-281)
+  int use_VarMix, use_Eady, Resoln_scaled;
+  double KhTr_Slope_Cff, KhTr_fac, KhTr_min, KhTr_max, pass_coeff, pass_min;
+  const double *MEKE_Kh, *L2u, *L2v, *SN_u, *SN_v, *Res_fn_h, *Rd_dx_h;
   const double *h;
   double *khdt_x, *khdt_y;
   double *const *tr;       // device table of ntr tracer pointers
@@ -31,6 +37,23 @@ struct HDArgs {
   int ntr, check_cfl;
 };
 
+// the diffusivity of a face with variable mixing :236-281 (c0, c1: the cells either side; f: the face)
+__device__ __forceinline__ double hd_Kh_face(const HDArgs &A, long c0, long c1, long f, bool dir) {
+  double Kh_loc = A.KhTr;
+  if (A.use_Eady) Kh_loc = Kh_loc + A.KhTr_Slope_Cff * (dir ? A.L2v[f] : A.L2u[f]) * (dir ? A.SN_v[f] : A.SN_u[f]);
+  if (A.MEKE_Kh) Kh_loc = Kh_loc + A.KhTr_fac * sqrt(A.MEKE_Kh[c0] * A.MEKE_Kh[c1]);
+  if (A.KhTr_max > 0.) Kh_loc = min2(Kh_loc, A.KhTr_max);
+  if (A.Resoln_scaled) Kh_loc = Kh_loc * 0.5 * (A.Res_fn_h[c0] + A.Res_fn_h[c1]);
+  double Kh = max2(Kh_loc, A.KhTr_min);
+  if (A.pass_coeff > 0.) {
+    const double Rd_dx = 0.5 * (A.Rd_dx_h[c0] + A.Rd_dx_h[c1]);
+    Kh_loc = Kh * max2(A.pass_min, A.pass_coeff * Rd_dx);
+    if (A.KhTr_max > 0.) Kh_loc = min2(Kh_loc, A.KhTr_max);
+    Kh = max2(Kh_loc, A.KhTr_min);
+  }
+  return Kh;
+}
+
 // thread (i, j) over (is-1 : ie, js-1 : je)
 __global__ __launch_bounds__(256) void hd_khdt_kernel(HDArgs A) {
   const m6::GridDev &g = A.g;
@@ -38,12 +61,14 @@ __global__ __launch_bounds__(256) void hd_khdt_kernel(HDArgs A) {
   if (i > g.iec) return;
   const int I = i, J = j;
   if (j >= g.jsc) {      // khdt_x(I,j), I = is-1 .. ie
-    double kx = A.dt * (A.KhTr * (g.dy_Cu[g.u2(I, j)] * g.IdxCu[g.u2(I, j)]));
+    const double Kh = A.use_VarMix ? hd_Kh_face(A, g.h2(i, j), g.h2(i + 1, j), g.u2(I, j), false) : A.KhTr;
+    double kx = A.dt * (Kh * (g.dy_Cu[g.u2(I, j)] * g.IdxCu[g.u2(I, j)]));
     if (A.max_diff_CFL > 0.0) kx = min2(kx, 0.125 * A.max_diff_CFL * min2(g.areaT[g.h2(i, j)], g.areaT[g.h2(i + 1, j)]));
     A.khdt_x[g.u2(I, j)] = kx;
   }
   if (i >= g.isc) {      // khdt_y(i,J), J = js-1 .. je
-    double ky = A.dt * (A.KhTr * (g.dx_Cv[g.v2(i, J)] * g.IdyCv[g.v2(i, J)]));
+    const double Kh = A.use_VarMix ? hd_Kh_face(A, g.h2(i, j), g.h2(i, j + 1), g.v2(i, J), true) : A.KhTr;
+    double ky = A.dt * (Kh * (g.dx_Cv[g.v2(i, J)] * g.IdyCv[g.v2(i, J)]));
     if (A.max_diff_CFL > 0.0) ky = min2(ky, 0.125 * A.max_diff_CFL * min2(g.areaT[g.h2(i, j)], g.areaT[g.h2(i, j + 1)]));
     A.khdt_y[g.v2(i, J)] = ky;
   }
@@ -105,15 +130,26 @@ __global__ __launch_bounds__(256) void hd_commit_kernel(HDArgs A) {
 extern "C" int mom6hip_tracer_hordiff(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const double *h, double dt,
                                       double *const *tr, const double *conc_underflow, int32_t ntr, int32_t memspace,
                                       mom6hip_hordiff_stats_t *stats) {
+  return mom6hip_tracer_hordiff_varmix(ctx, cs, nullptr, h, dt, tr, conc_underflow, ntr, memspace, stats);
+}
+
+extern "C" int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_hordiff_fields_t *F,
+                                             const double *h, double dt, double *const *tr, const double *conc_underflow, int32_t ntr,
+                                             int32_t memspace, mom6hip_hordiff_stats_t *stats) {
   static const char *names[8] = {"USE_NEUTRAL_DIFFUSION", "USE_HORIZONTAL_BOUNDARY_DIFFUSION", "DIFFUSE_ML_TO_INTERIOR",
-                                 "variable mixing (VarMix)", "MEKE diffusivities", "KHTR_USE_EBT_STRUCT", "offline khdt (do_online = false)",
+                                 "(free)", "(free)", "KHTR_USE_EBT_STRUCT", "offline khdt (do_online = false)",
                                  "the df_x / df_y flux diagnostics"};
   M6_REQUIRE(ctx != nullptr, "MOM_tracer_hor_diff: register_tracer must be called before tracer_hordiff.");
   M6_REQUIRE(cs != nullptr && h != nullptr, "tracer_hordiff: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "tracer_hordiff: bad memspace");
   for (int q = 0; q < 8; q++) M6_REQUIRE(!cs->unsupported[q], "tracer_hordiff: %s is not provided by libmom6hip", names[q]);
   if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
-  if (ntr == 0 || cs->KhTr <= 0.0) return 0;      // :199
+  const bool use_VarMix = cs->use_variable_mixing != 0;
+  if (ntr == 0 || (cs->KhTr <= 0.0 && !use_VarMix)) return 0;      // :197
+  const bool use_Eady = use_VarMix && cs->KhTr_Slope_Cff > 0., Resoln_scaled = use_VarMix && cs->Resoln_scaled_KhTr;
+  M6_REQUIRE(!use_Eady || (F && F->L2u && F->L2v && F->SN_u && F->SN_v), "tracer_hordiff: KHTR_SLOPE_CFF > 0 needs VarMix%%L2u, L2v, SN_u, SN_v");
+  M6_REQUIRE(!Resoln_scaled || (F && F->Res_fn_h), "tracer_hordiff: RESOLN_SCALED_KHTR needs VarMix%%Res_fn_h");
+  M6_REQUIRE(!(use_VarMix && cs->KhTr_passivity_coeff > 0.) || (F && F->Rd_dx_h), "tracer_hordiff: KHTR_PASSIVITY_COEFF > 0 needs VarMix%%Rd_dx_h");
   M6_REQUIRE(tr != nullptr && ntr > 0 && ntr <= 24, "tracer_hordiff: bad tracer list (at most 24 tracers)");
   M6_REQUIRE(dt > 0.0, "tracer_hordiff: dt must be positive");
   const m6::GridDev g = ctx->g;
@@ -126,6 +162,17 @@ extern "C" int mom6hip_tracer_hordiff(mom6hip_ctx_t *ctx, const mom6hip_tracer_h
   HDArgs A;
   A.g = g; A.KhTr = cs->KhTr; A.max_diff_CFL = cs->max_diff_CFL; A.dt = dt; A.ntr = ntr; A.check_cfl = cs->check_diffusive_CFL;
   A.h = st.in(h, bH);
+  A.use_VarMix = use_VarMix; A.use_Eady = use_Eady; A.Resoln_scaled = Resoln_scaled;
+  A.KhTr_Slope_Cff = cs->KhTr_Slope_Cff; A.KhTr_fac = cs->KhTr_fac; A.KhTr_min = cs->KhTr_min; A.KhTr_max = cs->KhTr_max;
+  A.pass_coeff = use_VarMix ? cs->KhTr_passivity_coeff : 0.0; A.pass_min = cs->KhTr_passivity_min;
+  {
+    const size_t bH2 = sizeof(double) * (size_t)g.nih * g.njh;
+    A.MEKE_Kh = (use_VarMix && F) ? st.in(F->MEKE_Kh, bH2) : nullptr;
+    A.L2u = use_Eady ? st.in(F->L2u, bU2) : nullptr; A.L2v = use_Eady ? st.in(F->L2v, bV2) : nullptr;
+    A.SN_u = use_Eady ? st.in(F->SN_u, bU2) : nullptr; A.SN_v = use_Eady ? st.in(F->SN_v, bV2) : nullptr;
+    A.Res_fn_h = Resoln_scaled ? st.in(F->Res_fn_h, bH2) : nullptr;
+    A.Rd_dx_h = (A.pass_coeff > 0.) ? st.in(F->Rd_dx_h, bH2) : nullptr;
+  }
   std::vector<double *> d_tr(ntr), d_work(ntr);
   for (int m = 0; m < ntr; m++) {
     M6_REQUIRE(tr[m] != nullptr, "tracer_hordiff: tracer %d is null", m);

@@ -1,9 +1,11 @@
 !> Drop-in replacement for module MOM_tracer_hor_diff (src/tracer/MOM_tracer_hor_diff.F90): tracer_hordiff (:119),
 !! tracer_hor_diff_init (:1625) and tracer_hor_diff_end (:1772) with the reference's dummy-argument lists, so
 !! step_MOM_tracer_dyn (src/core/MOM.F90:1441) compiles unchanged.  Provided: the along-layer diffusion with a constant
-!! KHTR (MAX_TR_DIFFUSION_CFL, CHECK_DIFFUSIVE_CFL, the tracers' conc_underflow) on the GPU through libmom6hip
-!! (mom6hip_tracer_hordiff, HOST memspace).  Neutral diffusion, horizontal boundary diffusion, DIFFUSE_ML_TO_INTERIOR,
-!! variable mixing / MEKE diffusivities, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
+!! KHTR (MAX_TR_DIFFUSION_CFL, CHECK_DIFFUSIVE_CFL, the tracers' conc_underflow) or, with VarMix%use_variable_mixing, the face
+!! diffusivities of :236-281 (KHTR_SLOPE_CFF with VarMix%L2u / SN_u, MEKE%KhTr_fac with MEKE%Kh, KHTR_MIN / KHTR_MAX,
+!! RESOLN_SCALED_KHTR with VarMix%Res_fn_h, KHTR_PASSIVITY_COEFF / _MIN with VarMix%Rd_dx_h) on the GPU through libmom6hip
+!! (mom6hip_tracer_hordiff_varmix, HOST memspace).  Neutral diffusion, horizontal boundary diffusion, DIFFUSE_ML_TO_INTERIOR,
+!! KHTR_USE_EBT_STRUCT, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
 !!
 !! Compiled INSIDE a MOM6 source tree in place of src/tracer/MOM_tracer_hor_diff.F90; here against tests/fortran/stubs.
 module MOM_tracer_hor_diff
@@ -33,6 +35,11 @@ public tracer_hordiff, tracer_hor_diff_init, tracer_hor_diff_end
 !> Control structure (the members of the reference's tracer_hor_diff_CS, :40-100, that the provided branch reads)
 type, public :: tracer_hor_diff_CS ; private
   real    :: KhTr                 !< The along-isopycnal tracer diffusivity [L2 T-1 ~> m2 s-1].
+  real    :: KhTr_Slope_Cff       !< The non-dimensional coefficient in KhTr formula [nondim]
+  real    :: KhTr_min             !< Minimum along-isopycnal tracer diffusivity [L2 T-1 ~> m2 s-1].
+  real    :: KhTr_max             !< Maximum along-isopycnal tracer diffusivity [L2 T-1 ~> m2 s-1].
+  real    :: KhTr_passivity_coeff !< Passivity coefficient that scales Rd/dx [nondim]
+  real    :: KhTr_passivity_min   !< Passivity minimum [nondim]
   real    :: max_diff_CFL         !< If positive, locally limit the diffusivity to this diffusive CFL [nondim].
   logical :: check_diffusive_CFL  !< If true, use enough iterations that the diffusive equations are stable.
   logical :: Diffuse_ML_interior, use_neutral_diffusion, use_hor_bnd_diffusion
@@ -50,8 +57,8 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
   type(verticalGrid_type),    intent(in)    :: GV
   real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in) :: h
   real,                       intent(in)    :: dt
-  type(MEKE_type),            intent(in)    :: MEKE
-  type(VarMix_CS),            intent(in)    :: VarMix
+  type(MEKE_type), target,    intent(in)    :: MEKE
+  type(VarMix_CS), target,    intent(in)    :: VarMix
   type(vertvisc_type),        intent(in)    :: visc
   type(unit_scale_type),      intent(in)    :: US
   type(tracer_hor_diff_CS),   pointer       :: CS
@@ -62,6 +69,7 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
   real, dimension(SZI_(G),SZJB_(G)), optional, intent(in) :: read_khdt_y
 
   type(mom6hip_tracer_hor_diff_cs_t) :: ccs
+  type(mom6hip_hordiff_fields_t) :: fld
   type(mom6hip_hordiff_stats_t) :: stats
   type(c_ptr), allocatable :: tr(:)
   real(c_double), allocatable, target :: cu(:)
@@ -72,8 +80,6 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
   if (.not. associated(Reg)) call MOM_error(FATAL, "MOM_tracer_hor_diff: "// &
        "register_tracer must be called before tracer_hordiff.")
   if (Reg%ntr == 0 .or. (CS%KhTr <= 0.0 .and. .not. VarMix%use_variable_mixing)) return
-  if (VarMix%use_variable_mixing .or. allocated(MEKE%Kh)) call MOM_error(FATAL, "tracer_hordiff (HIP): "// &
-       "variable mixing (VarMix) and MEKE tracer diffusivities are not provided by the GPU path.")
   if (present(do_online_flag)) then ; if (.not.do_online_flag) &
     call MOM_error(FATAL, "tracer_hordiff (HIP): offline tracer diffusion (read_khdt_x/y) is not provided by the GPU path.")
   endif
@@ -88,11 +94,22 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
     tr(m) = c_loc(Reg%Tr(m)%t)
     cu(m) = Reg%Tr(m)%conc_underflow
   enddo
-  ccs%KhTr = CS%KhTr ; ccs%max_diff_CFL = CS%max_diff_CFL ; ccs%reserved0(:) = 0.0
+  ccs%KhTr = CS%KhTr ; ccs%max_diff_CFL = CS%max_diff_CFL
+  ccs%KhTr_Slope_Cff = CS%KhTr_Slope_Cff ; ccs%KhTr_min = CS%KhTr_min ; ccs%KhTr_max = CS%KhTr_max
+  ccs%KhTr_passivity_coeff = CS%KhTr_passivity_coeff ; ccs%KhTr_passivity_min = CS%KhTr_passivity_min
   ccs%check_diffusive_CFL = merge(1, 0, CS%check_diffusive_CFL) ; ccs%initialized = 1
   ccs%unsupported(:) = 0 ; ccs%reserved1(:) = 0
-  rc = mom6hip_tracer_hordiff(mom6hip_shared_context(G, GV), ccs, c_loc(h), dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), &
-                              MOM6HIP_MEM_HOST, stats)
+  if (VarMix%use_variable_mixing) then      ! :219-224, :236-281
+    ccs%use_variable_mixing = 1
+    if (CS%KhTr_Slope_Cff > 0.) then
+      fld%L2u = c_loc(VarMix%L2u) ; fld%L2v = c_loc(VarMix%L2v) ; fld%SN_u = c_loc(VarMix%SN_u) ; fld%SN_v = c_loc(VarMix%SN_v)
+    endif
+    if (VarMix%Resoln_scaled_KhTr) then ; ccs%Resoln_scaled_KhTr = 1 ; fld%Res_fn_h = c_loc(VarMix%Res_fn_h) ; endif
+    if (CS%KhTr_passivity_coeff > 0.) fld%Rd_dx_h = c_loc(VarMix%Rd_dx_h)
+    if (allocated(MEKE%Kh)) then ; fld%MEKE_Kh = c_loc(MEKE%Kh) ; ccs%KhTr_fac = MEKE%KhTr_fac ; endif
+  endif
+  rc = mom6hip_tracer_hordiff_varmix(mom6hip_shared_context(G, GV), ccs, fld, c_loc(h), dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), &
+                                     MOM6HIP_MEM_HOST, stats)
   call mom6hip_fatal_if(rc, "tracer_hordiff")
   call cpu_clock_end(id_clock_diffuse)
 end subroutine tracer_hordiff
@@ -111,7 +128,6 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
 # include "version_variable.h"
   character(len=40)  :: mdl = "MOM_tracer_hor_diff"
   logical :: flag
-  real :: val
 
   if (associated(CS)) then
     call MOM_error(WARNING, "tracer_hor_diff_init called with associated control structure.")
@@ -123,9 +139,18 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
   call get_param(param_file, mdl, "KHTR", CS%KhTr, "The background along-isopycnal tracer diffusivity.", &
                  units="m2 s-1", default=0.0, scale=US%m_to_L**2*US%T_to_s)
   call get_param(param_file, mdl, "KHTR_USE_EBT_STRUCT", flag, default=.false.) ; call refuse(flag, "KHTR_USE_EBT_STRUCT")
-  call get_param(param_file, mdl, "KHTR_SLOPE_CFF", val, units="nondim", default=0.0) ; call refuse(val /= 0.0, "KHTR_SLOPE_CFF")
-  call get_param(param_file, mdl, "KHTR_PASSIVITY_COEFF", val, units="nondim", default=0.0)
-  call refuse(val /= 0.0, "KHTR_PASSIVITY_COEFF")
+  call get_param(param_file, mdl, "KHTR_SLOPE_CFF", CS%KhTr_Slope_Cff, &
+                 "The scaling coefficient for along-isopycnal tracer diffusivity using a shear-based (Visbeck-like) "//&
+                 "parameterization.  A non-zero value enables this param.", units="nondim", default=0.0)
+  call get_param(param_file, mdl, "KHTR_MIN", CS%KhTr_Min, "The minimum along-isopycnal tracer diffusivity.", &
+                 units="m2 s-1", default=0.0, scale=US%m_to_L**2*US%T_to_s)
+  call get_param(param_file, mdl, "KHTR_MAX", CS%KhTr_Max, "The maximum along-isopycnal tracer diffusivity.", &
+                 units="m2 s-1", default=0.0, scale=US%m_to_L**2*US%T_to_s)
+  call get_param(param_file, mdl, "KHTR_PASSIVITY_COEFF", CS%KhTr_passivity_coeff, &
+                 "The coefficient that scales deformation radius over grid-spacing in passivity.", units="nondim", default=0.0)
+  call get_param(param_file, mdl, "KHTR_PASSIVITY_MIN", CS%KhTr_passivity_min, &
+                 "The minimum passivity which is the ratio between along isopycnal mixing of tracers to thickness mixing.", &
+                 units="nondim", default=0.5)
   call get_param(param_file, mdl, "DIFFUSE_ML_TO_INTERIOR", CS%Diffuse_ML_interior, &
                  "If true, enable epipycnal mixing between the surface boundary layer and the interior.", default=.false.)
   call refuse(CS%Diffuse_ML_interior, "DIFFUSE_ML_TO_INTERIOR")

@@ -167,11 +167,19 @@ end type mom6hip_set_visc_cs_t
 !> mom6hip_tracer_hor_diff_cs_t (tracer_hor_diff_CS, src/tracer/MOM_tracer_hor_diff.F90:40)
 type, bind(c) :: mom6hip_tracer_hor_diff_cs_t
   real(c_double) :: KhTr, max_diff_CFL
-  real(c_double) :: reserved0(6)
+  real(c_double) :: KhTr_Slope_Cff = 0.0, KhTr_fac = 1.0, KhTr_min = 0.0, KhTr_max = 0.0, KhTr_passivity_coeff = 0.0, KhTr_passivity_min = 0.5
   integer(c_int32_t) :: check_diffusive_CFL, initialized
   integer(c_int32_t) :: unsupported(8)
-  integer(c_int32_t) :: reserved1(6)
+  integer(c_int32_t) :: use_variable_mixing = 0, Resoln_scaled_KhTr = 0
+  integer(c_int32_t) :: reserved1(4)
 end type mom6hip_tracer_hor_diff_cs_t
+
+!> mom6hip_hordiff_fields_t: the fields of MEKE and VarMix tracer_hordiff reads with variable mixing
+type, bind(c) :: mom6hip_hordiff_fields_t
+  type(c_ptr) :: MEKE_Kh = c_null_ptr, L2u = c_null_ptr, L2v = c_null_ptr, SN_u = c_null_ptr, SN_v = c_null_ptr
+  type(c_ptr) :: Res_fn_h = c_null_ptr, Rd_dx_h = c_null_ptr
+  type(c_ptr) :: reserved(5) = c_null_ptr
+end type mom6hip_hordiff_fields_t
 
 !> mom6hip_hordiff_stats_t
 type, bind(c) :: mom6hip_hordiff_stats_t
@@ -438,6 +446,19 @@ interface
     type(mom6hip_hordiff_stats_t), intent(out) :: stats
     integer(c_int) :: rc
   end function mom6hip_tracer_hordiff
+
+  function mom6hip_tracer_hordiff_varmix(ctx, cs, fields, h, dt, tr, conc_underflow, ntr, memspace, stats) &
+                                         bind(c, name="mom6hip_tracer_hordiff_varmix") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_tracer_hor_diff_cs_t, mom6hip_hordiff_stats_t, mom6hip_hordiff_fields_t
+    type(c_ptr), value :: ctx, h, conc_underflow
+    type(mom6hip_tracer_hor_diff_cs_t), intent(in) :: cs
+    type(mom6hip_hordiff_fields_t), intent(in) :: fields
+    real(c_double), value :: dt
+    type(c_ptr), intent(in) :: tr(*)
+    integer(c_int32_t), value :: ntr, memspace
+    type(mom6hip_hordiff_stats_t), intent(out) :: stats
+    integer(c_int) :: rc
+  end function mom6hip_tracer_hordiff_varmix
 
   !> subchk / subStats of MOM_checksums (MOM_checksums.F90:1387) on a device or host field of staggering pos
   function mom6hip_chksum(ctx, field, pos, nk, di, dj, symmetric, scale, bitcount, amin, amax, memspace) &

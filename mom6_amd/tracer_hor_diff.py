@@ -1,5 +1,5 @@
 """Host-side mirror of MOM_tracer_hor_diff (reference: src/tracer/MOM_tracer_hor_diff.F90): tracer_hor_diff_init (:1625) and
-tracer_hordiff (:119) -- the along-layer diffusion with a constant KHTR.  The work is done by libmom6hip
+tracer_hordiff (:119) -- the along-layer diffusion with a constant KHTR or the VarMix / MEKE diffusivities of :236-281.  The work is done by libmom6hip
 (mom6_amd/csrc/tracer_hor_diff.hip)."""
 from __future__ import annotations
 
@@ -11,10 +11,10 @@ from . import _abi
 from ._lib import Mom6HipError, check, lib
 from .tracer_advect import DeviceGrid, _ptr_space
 
-_PARAMS = {"KHTR": "KhTr", "MAX_TR_DIFFUSION_CFL": "max_diff_CFL", "CHECK_DIFFUSIVE_CFL": "check_diffusive_CFL"}
+_PARAMS = {"KHTR": "KhTr", "MAX_TR_DIFFUSION_CFL": "max_diff_CFL", "CHECK_DIFFUSIVE_CFL": "check_diffusive_CFL", "KHTR_SLOPE_CFF": "KhTr_Slope_Cff",
+           "KHTR_MIN": "KhTr_min", "KHTR_MAX": "KhTr_max", "KHTR_PASSIVITY_COEFF": "KhTr_passivity_coeff", "KHTR_PASSIVITY_MIN": "KhTr_passivity_min"}
 # parameters of the reference whose branches this build does not provide: accepted at their defaults, refused otherwise
-_REFUSED = {"USE_NEUTRAL_DIFFUSION": 0, "USE_HORIZONTAL_BOUNDARY_DIFFUSION": 1, "DIFFUSE_ML_TO_INTERIOR": 2, "KHTR_SLOPE_CFF": 3,
-            "KHTR_PASSIVITY_COEFF": 3, "KHTR_USE_EBT_STRUCT": 5}
+_REFUSED = {"USE_NEUTRAL_DIFFUSION": 0, "USE_HORIZONTAL_BOUNDARY_DIFFUSION": 1, "DIFFUSE_ML_TO_INTERIOR": 2, "KHTR_USE_EBT_STRUCT": 5}
 
 
 class tracer_hor_diff_CS:
@@ -22,7 +22,7 @@ class tracer_hor_diff_CS:
 
     def __init__(self, **params):
         st = self.st = _abi.TracerHorDiffCS()
-        st.KhTr, st.max_diff_CFL, st.check_diffusive_CFL = 0.0, -1.0, 0
+        st.KhTr, st.max_diff_CFL, st.check_diffusive_CFL, st.KhTr_passivity_min = 0.0, -1.0, 0, 0.5
         for k, v in params.items():
             if k in _PARAMS:
                 a = _PARAMS[k]
@@ -44,20 +44,31 @@ def tracer_hor_diff_init(Time=None, G=None, GV=None, US=None, param_file=None, d
 def tracer_hordiff(h, dt, MEKE, VarMix, visc, G: DeviceGrid, CS: tracer_hor_diff_CS, Reg, tv=None, do_online_flag=None, read_khdt_x=None,
                    read_khdt_y=None, conc_underflow=None):
     """tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_online_flag, read_khdt_x, read_khdt_y) -- :119.
-    Reg: the list of tracer arrays (Reg%Tr(m)%t), updated in place.  MEKE, VarMix belong to branches this build does not
-    provide and must be None.  Returns the iteration statistics."""
+    Reg: the list of tracer arrays (Reg%Tr(m)%t), updated in place.  VarMix: None, or a dict (its presence is
+    VarMix%use_variable_mixing) with any of L2u, L2v, SN_u, SN_v (read with KHTR_SLOPE_CFF > 0), Res_fn_h (its presence is
+    VarMix%Resoln_scaled_KhTr), Rd_dx_h (KHTR_PASSIVITY_COEFF > 0); MEKE: None, or a dict with Kh (MEKE%Kh) and KhTr_fac
+    (MEKE%KhTr_fac); MEKE%Kh is read with variable mixing only, as in the reference.  Returns the iteration statistics."""
     if CS is None or Reg is None:
         raise Mom6HipError("MOM_tracer_hor_diff: register_tracer must be called before tracer_hordiff.")
-    if MEKE is not None or VarMix is not None:
-        raise Mom6HipError("tracer_hordiff (HIP): MEKE and VarMix diffusivities are not supported on this path")
     if do_online_flag is False or read_khdt_x is not None or read_khdt_y is not None:
         raise Mom6HipError("tracer_hordiff (HIP): offline khdt arrays are not supported on this path")
     L = lib()
-    L.mom6hip_tracer_hordiff.argtypes = [C.c_void_p, C.POINTER(_abi.TracerHorDiffCS), C.c_void_p, C.c_double, C.POINTER(C.c_void_p), C.c_void_p,
-                                         C.c_int32, C.c_int32, C.POINTER(_abi.HorDiffStats)]
+    L.mom6hip_tracer_hordiff_varmix.argtypes = [C.c_void_p, C.POINTER(_abi.TracerHorDiffCS), C.POINTER(_abi.HorDiffFields), C.c_void_p, C.c_double,
+                                                C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(_abi.HorDiffStats)]
     tr = list(Reg)
     spaces = set()
     hp, s0 = _ptr_space(h); spaces.add(s0)
+    F = _abi.HorDiffFields()
+    st = CS.st
+    st.use_variable_mixing = int(VarMix is not None)
+    st.Resoln_scaled_KhTr = int(VarMix is not None and VarMix.get("Res_fn_h") is not None)
+    if set(VarMix or {}) - set(_abi.HORDIFF_FIELDS):
+        raise Mom6HipError("tracer_hordiff (HIP): of VarMix only L2u/v, SN_u/v, Res_fn_h and Rd_dx_h are read")
+    for n, a in list((VarMix or {}).items()) + ([("MEKE_Kh", MEKE.get("Kh"))] if MEKE else []):
+        if a is not None:
+            p, s = _ptr_space(a); spaces.add(s); setattr(F, n, p)
+    if MEKE:
+        st.KhTr_fac = float(MEKE.get("KhTr_fac", 1.0))
     ptrs = (C.c_void_p * max(len(tr), 1))()
     for m, t in enumerate(tr):
         p, s = _ptr_space(t); ptrs[m] = p; spaces.add(s)
@@ -65,7 +76,7 @@ def tracer_hordiff(h, dt, MEKE, VarMix, visc, G: DeviceGrid, CS: tracer_hor_diff
         raise Mom6HipError("tracer_hordiff: h and every tracer must be in the same memory space")
     cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
     stats = _abi.HorDiffStats()
-    check(L.mom6hip_tracer_hordiff(G.handle, C.byref(CS.st), C.c_void_p(hp), float(dt), ptrs, None if cu is None else cu.ctypes.data,
-                                   len(tr), spaces.pop(), C.byref(stats)), "tracer_hordiff")
+    check(L.mom6hip_tracer_hordiff_varmix(G.handle, C.byref(CS.st), C.byref(F), C.c_void_p(hp), float(dt), ptrs, None if cu is None else cu.ctypes.data,
+                                          len(tr), spaces.pop(), C.byref(stats)), "tracer_hordiff")
     CS.last = stats
     return stats

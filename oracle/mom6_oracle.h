@@ -55,6 +55,9 @@ extern "C" {
  * tile's own compute domain (corners included), closed edges are left untouched.
  * pos: MOM6HIP_POS_H/U/V/Q.  nk = 1 for a 2-D field. */
 void orc_halo_update(const mom6hip_grid_t *G, double *f, int pos, int nk);
+int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const mom6hip_hordiff_fields_t *F,
+                              const double *h, double dt, double *const *tr, const double *conc_underflow, int ntr,
+                              mom6hip_hordiff_stats_t *stats);
 int orc_tracer_hordiff(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const double *h, double dt,
                        double *const *tr, const double *conc_underflow, int ntr, mom6hip_hordiff_stats_t *stats);
 

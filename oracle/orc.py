@@ -454,19 +454,32 @@ def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy,
     return out
 
 
-def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL=False, conc_underflow=None):
-    """tracer_hordiff (along-layer, constant KHTR) on numpy arrays; tr updated in place.  Returns the stats struct."""
+def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL=False, conc_underflow=None, VarMix=None, MEKE=None, KhTr_Slope_Cff=0.0,
+                   KhTr_min=0.0, KhTr_max=0.0, KhTr_passivity_coeff=0.0, KhTr_passivity_min=0.5):
+    """tracer_hordiff (along-layer; constant KHTR, or with VarMix / MEKE the face diffusivities of :236-281) on numpy arrays; tr updated
+    in place.  VarMix: None or a dict with any of L2u, L2v, SN_u, SN_v, Res_fn_h (its presence is Resoln_scaled_KhTr), Rd_dx_h; MEKE: None
+    or a dict with Kh and KhTr_fac.  Returns the stats struct."""
     L = lib()
-    L.orc_tracer_hordiff.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.TracerHorDiffCS), _dp, C.c_double, C.POINTER(_dp), _dp, C.c_int,
-                                     C.POINTER(_abi.HorDiffStats)]
+    L.orc_tracer_hordiff_varmix.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.TracerHorDiffCS), C.POINTER(_abi.HorDiffFields), _dp, C.c_double,
+                                            C.POINTER(_dp), _dp, C.c_int, C.POINTER(_abi.HorDiffStats)]
     cs = _abi.TracerHorDiffCS(); cs.KhTr = float(KhTr); cs.max_diff_CFL = float(max_diff_CFL); cs.check_diffusive_CFL = int(bool(check_diffusive_CFL))
+    cs.KhTr_Slope_Cff, cs.KhTr_min, cs.KhTr_max, cs.KhTr_passivity_coeff, cs.KhTr_passivity_min = KhTr_Slope_Cff, KhTr_min, KhTr_max, KhTr_passivity_coeff, KhTr_passivity_min
+    F = _abi.HorDiffFields(); keep = []
+    if VarMix is not None:
+        cs.use_variable_mixing = 1
+        cs.Resoln_scaled_KhTr = int("Res_fn_h" in VarMix)
+        for n, a in VarMix.items():
+            keep.append(np.ascontiguousarray(a, dtype=np.float64)); setattr(F, n, keep[-1].ctypes.data)
+    if MEKE is not None:
+        cs.KhTr_fac = float(MEKE.get("KhTr_fac", 1.0))
+        keep.append(np.ascontiguousarray(MEKE["Kh"], dtype=np.float64)); F.MEKE_Kh = keep[-1].ctypes.data
     ntr = len(tr)
     trp = (_dp * max(ntr, 1))(*[_p(t) for t in tr])
     cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
     st = _abi.HorDiffStats()
-    rc = L.orc_tracer_hordiff(C.byref(grid.struct()), C.byref(cs), _p(h), float(dt), trp, _p(cu), ntr, C.byref(st))
+    rc = L.orc_tracer_hordiff_varmix(C.byref(grid.struct()), C.byref(cs), C.byref(F), _p(h), float(dt), trp, _p(cu), ntr, C.byref(st))
     if rc:
-        raise RuntimeError("orc_tracer_hordiff failed")
+        raise RuntimeError(f"orc_tracer_hordiff rc={rc}")
     return st
 
 

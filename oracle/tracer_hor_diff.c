@@ -10,12 +10,26 @@
 
 static inline double min2(double a, double b) { return a < b ? a : b; }
 
+static inline double max2(double a, double b) { return a > b ? a : b; }
+
 int orc_tracer_hordiff(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const double *h, double dt,
                        double *const *tr, const double *conc_underflow, int ntr, mom6hip_hordiff_stats_t *stats)
 {
+  return orc_tracer_hordiff_varmix(G, CS, NULL, h, dt, tr, conc_underflow, ntr, stats);
+}
+
+int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const mom6hip_hordiff_fields_t *F,
+                              const double *h, double dt, double *const *tr, const double *conc_underflow, int ntr,
+                              mom6hip_hordiff_stats_t *stats)
+{
   for (int q = 0; q < 8; q++) if (CS->unsupported[q]) return 2;
   if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
-  if (ntr == 0 || CS->KhTr <= 0.0) return 0;                       /* :199 */
+  const int use_VarMix = CS->use_variable_mixing != 0;
+  if (ntr == 0 || (CS->KhTr <= 0.0 && !use_VarMix)) return 0;      /* :197 */
+  const int use_Eady = use_VarMix && CS->KhTr_Slope_Cff > 0., Resoln_scaled = use_VarMix && CS->Resoln_scaled_KhTr;
+  if (use_Eady && !(F && F->L2u && F->L2v && F->SN_u && F->SN_v)) return 3;
+  if (Resoln_scaled && !(F && F->Res_fn_h)) return 3;
+  if (use_VarMix && CS->KhTr_passivity_coeff > 0. && !(F && F->Rd_dx_h)) return 3;
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int isd = G->isd, jsd = G->jsd;
   const int nih = G->ied - G->isd + 1, njh = G->jed - G->jsd + 1;
@@ -30,11 +44,32 @@ int orc_tracer_hordiff(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs
   double *Coef_y = (double*)calloc((size_t)nih*(njh+1), sizeof(double));
   double *Ihdxdy = (double*)calloc(hpl, sizeof(double));
   double *dTr = (double*)calloc(hpl, sizeof(double));
-  /* a simple constant diffusivity :340-351 */
+  if (use_VarMix) {                                                /* :236-281 */
+    for (int dir = 0; dir < 2; dir++)
+      for (int j = (dir ? js-1 : js); j <= je; j++) for (int i = (dir ? is : is-1); i <= ie; i++) {
+        const size_t c0 = H2(i,j), c1 = dir ? H2(i,j+1) : H2(i+1,j), f = dir ? V2(i,j) : U2(i,j);
+        double Kh_loc = CS->KhTr, Kh;
+        if (use_Eady) Kh_loc = Kh_loc + CS->KhTr_Slope_Cff*(dir ? F->L2v[f] : F->L2u[f])*(dir ? F->SN_v[f] : F->SN_u[f]);
+        if (F && F->MEKE_Kh) Kh_loc = Kh_loc + CS->KhTr_fac*sqrt(F->MEKE_Kh[c0]*F->MEKE_Kh[c1]);
+        if (CS->KhTr_max > 0.) Kh_loc = min2(Kh_loc, CS->KhTr_max);
+        if (Resoln_scaled) Kh_loc = Kh_loc * 0.5*(F->Res_fn_h[c0] + F->Res_fn_h[c1]);
+        Kh = max2(Kh_loc, CS->KhTr_min);
+        if (CS->KhTr_passivity_coeff > 0.) {
+          const double Rd_dx = 0.5*(F->Rd_dx_h[c0] + F->Rd_dx_h[c1]);
+          Kh_loc = Kh*max2(CS->KhTr_passivity_min, CS->KhTr_passivity_coeff*Rd_dx);
+          if (CS->KhTr_max > 0.) Kh_loc = min2(Kh_loc, CS->KhTr_max);
+          Kh = max2(Kh_loc, CS->KhTr_min);
+        }
+        if (dir) khdt_y[f] = dt*(Kh*(G->dx_Cv[f]*G->IdyCv[f]));
+        else khdt_x[f] = dt*(Kh*(G->dy_Cu[f]*G->IdxCu[f]));
+      }
+  } else {
+  /* a simple constant diffusivity :305-328 */
   for (int j = js; j <= je; j++) for (int I = is-1; I <= ie; I++)
     khdt_x[U2(I,j)] = dt*(CS->KhTr*(G->dy_Cu[U2(I,j)]*G->IdxCu[U2(I,j)]));
   for (int J = js-1; J <= je; J++) for (int i = is; i <= ie; i++)
     khdt_y[V2(i,J)] = dt*(CS->KhTr*(G->dx_Cv[V2(i,J)]*G->IdyCv[V2(i,J)]));
+  }
   if (CS->max_diff_CFL > 0.0) {                                    /* :368-398 */
     for (int j = js; j <= je; j++) for (int I = is-1; I <= ie; I++) {
       const int i = I;

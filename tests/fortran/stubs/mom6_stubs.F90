@@ -502,7 +502,7 @@ type :: VarMix_CS
   logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false., Resoln_scaled_KhTh = .false.
   logical :: Depth_scaled_KhTh = .false., use_stored_slopes = .false., khth_use_ebt_struct = .false., use_Visbeck = .false.
   logical :: use_QG_Leith_GM = .false.
-  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Rd_dx_h, cg1
+  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Res_fn_h, Rd_dx_h, cg1
   real, allocatable, dimension(:,:,:) :: slope_x, slope_y
 end type VarMix_CS
 end module MOM_lateral_mixing_coeffs

@@ -107,6 +107,97 @@ def test_tracer_hordiff_refuses_what_it_does_not_provide():
     dh = torch.from_numpy(h).cuda(); dt_ = [torch.from_numpy(tr[0]).cuda()]
     with pytest.raises(Mom6HipError, match="USE_NEUTRAL_DIFFUSION"):
         tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True), dt_)
-    with pytest.raises(Mom6HipError, match="VarMix"):
-        tracer_hordiff(dh, 3600.0, None, object(), None, dg, tracer_hor_diff_init(KHTR=50.0), dt_)
+    with pytest.raises(Mom6HipError, match="L2u"):      # KHTR_SLOPE_CFF > 0 without the Visbeck fields
+        tracer_hordiff(dh, 3600.0, None, {}, None, dg, tracer_hor_diff_init(KHTR=50.0, KHTR_SLOPE_CFF=0.1), dt_)
+    with pytest.raises(Mom6HipError, match="only"):
+        tracer_hordiff(dh, 3600.0, None, dict(ebt_struct=dh), None, dg, tracer_hor_diff_init(KHTR=50.0), dt_)
     dg.close()
+
+
+# ---- the VarMix / MEKE diffusivities (:236-281; .testing/tc1, tc2) ----------------------------------------------------------------
+def varmix_fields(g, seed=4):
+    rng = np.random.default_rng(seed)
+    sh, su, sv = g.shape2(_abi.POS_H), g.shape2(_abi.POS_U), g.shape2(_abi.POS_V)
+    f = dict(L2u=1.0e9 * rng.random(su), L2v=1.0e9 * rng.random(sv), SN_u=1.0e-6 * rng.random(su), SN_v=1.0e-6 * rng.random(sv))
+    for n in f:      # (one value per physical face: the western and the eastern edge of a re-entrant domain are the same faces,
+        f[n] = np.ascontiguousarray(f[n])      # both inside the symmetric compute range, so no halo update makes them agree)
+        if n.endswith("u") and g.reentrant_x:
+            f[n][:, g.halo] = f[n][:, g.halo + g.ni]
+        if n.endswith("v") and g.reentrant_y:
+            f[n][g.halo, :] = f[n][g.halo + g.nj, :]
+        orc.halo_update(g, f[n], _abi.POS_U if n.endswith("u") else _abi.POS_V)
+    for n, a in (("Res_fn_h", rng.random(sh)), ("Rd_dx_h", 2.0 * rng.random(sh)), ("Kh", 900.0 * rng.random(sh) * g.mask2dT)):
+        a = np.ascontiguousarray(a); orc.halo_update(g, a, _abi.POS_H); f[n] = a
+    return f
+
+
+VM = {
+    "tc1": dict(KhTr=1.0, KhTr_Slope_Cff=0.1, use=("L2u", "L2v", "SN_u", "SN_v", "Res_fn_h")),            # Visbeck + RESOLN_SCALED_KHTR
+    "tc2": dict(KhTr=1.0, meke=0.5, use=()),                                                              # MEKE_KHTR_FAC = 0.5
+    "bounds": dict(KhTr=10.0, KhTr_Slope_Cff=0.3, KhTr_min=40.0, KhTr_max=600.0, meke=1.0, use=("L2u", "L2v", "SN_u", "SN_v"), check=True),
+    "passivity": dict(KhTr=100.0, KhTr_passivity_coeff=3.0, KhTr_passivity_min=0.5, KhTr_max=800.0, use=("Rd_dx_h", "Res_fn_h"), max_diff_CFL=1.5),
+    "varmix_only": dict(KhTr=0.0, KhTr_Slope_Cff=0.2, use=("L2u", "L2v", "SN_u", "SN_v")),                 # KHTR = 0 still diffuses with VarMix (:197)
+}
+
+
+def run_vm(g, h, tr, name, dt=3600.0):
+    kw = dict(VM[name]); use = kw.pop("use"); meke = kw.pop("meke", None); check = kw.pop("check", False)
+    f = varmix_fields(g)
+    tr = [t.copy() for t in tr]
+    st = orc.tracer_hordiff(g, h, dt, tr, kw.pop("KhTr"), check_diffusive_CFL=check, VarMix={n: f[n] for n in use},
+                            MEKE=None if meke is None else dict(Kh=f["Kh"], KhTr_fac=meke), **kw)
+    return tr, st, (f, use, meke, check)
+
+
+@pytest.mark.parametrize("name", list(VM))
+def test_oracle_varmix_diffusion_conserves_and_is_bounded(name):
+    g, h, tr = case(40, 26, 4)
+    out, st, _ = run_vm(g, h, tr + [np.full_like(tr[0], -3.5)], name)
+    hh = h + g.H_subroundoff
+    for t0, t1 in zip(tr, out):
+        a, b = inventory(g, hh, t0), inventory(g, hh, t1)
+        assert abs(a - b) <= 1e-11 * max(1.0, abs(a)), (a, b)
+    assert np.array_equal(interior(g, out[-1]), np.full_like(interior(g, out[-1]), -3.5))
+    assert not np.array_equal(interior(g, out[0]), interior(g, tr[0]))
+
+
+def test_oracle_varmix_with_nothing_to_add_is_the_constant_diffusivity():
+    """use_variable_mixing with no slope coefficient, no MEKE, no scaling: Kh = max(KHTR, KHTR_MIN) at every face -- the bits of the
+    constant-KHTR branch (:305-328); with Res_fn_h = 1/2 everywhere the bits of half the diffusivity"""
+    g, h, tr = case()
+    a = [t.copy() for t in tr]; b = [t.copy() for t in tr]; c = [t.copy() for t in tr]; d = [t.copy() for t in tr]
+    orc.tracer_hordiff(g, h, 3600.0, a, 300.0)
+    orc.tracer_hordiff(g, h, 3600.0, b, 300.0, VarMix={})
+    for x, y in zip(a, b):
+        assert bits_equal(x, y)
+    orc.tracer_hordiff(g, h, 3600.0, c, 150.0)
+    orc.tracer_hordiff(g, h, 3600.0, d, 300.0, VarMix=dict(Res_fn_h=np.full(g.shape2(_abi.POS_H), 0.5)))
+    for x, y in zip(c, d):
+        assert bits_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VM))
+def test_varmix_diffusivities_match_oracle(name):
+    """tracer_hordiff with VarMix / MEKE: library == oracle bit for bit, device and staged host arrays, three grids"""
+    import torch
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
+    REF = dict(KhTr="KHTR", KhTr_Slope_Cff="KHTR_SLOPE_CFF", KhTr_min="KHTR_MIN", KhTr_max="KHTR_MAX", KhTr_passivity_coeff="KHTR_PASSIVITY_COEFF",
+               KhTr_passivity_min="KHTR_PASSIVITY_MIN", max_diff_CFL="MAX_TR_DIFFUSION_CFL")
+    for (ni, nj, nk, topo) in [(40, 26, 4, (True, False)), (33, 20, 3, (True, True)), (130, 9, 12, (False, False))]:
+        g, h, tr = case(ni, nj, nk, reentrant=topo)
+        ref, rst, (f, use, meke, check) = run_vm(g, h, tr, name)
+        dg = DeviceGrid(g)
+        for resident in (True, False):
+            X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if resident else (lambda a: np.ascontiguousarray(a).copy())
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            kw = {REF[k]: v for k, v in VM[name].items() if k in REF}
+            CS = tracer_hor_diff_init(CHECK_DIFFUSIVE_CFL=check, **kw)
+            dtr = [X(t) for t in tr]
+            st = tracer_hordiff(X(h), 3600.0, None if meke is None else dict(Kh=X(f["Kh"]), KhTr_fac=meke), {n: X(f[n]) for n in use}, None, dg, CS, dtr)
+            dg.sync()
+            assert st.num_itts == rst.num_itts and st.max_CFL == rst.max_CFL
+            for m, (a, b) in enumerate(zip(dtr, ref)):
+                assert bits_equal(interior(g, N(a)), interior(g, b)), (name, (ni, nj, nk), resident, m)
+        dg.close()
