@@ -24,7 +24,8 @@ use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_MEKE_types,    only : MEKE_type
 use MOM_open_boundary, only : ocean_OBC_type
 use MOM_restart,       only : MOM_restart_CS
-use MOM_thickness_diffuse, only : thickness_diffuse_CS
+use MOM_thickness_diffuse, only : thickness_diffuse_CS, thickness_diffuse_init
+use MOM_mixed_layer_restrat, only : mixedlayer_restrat_CS, mixedlayer_restrat_init, mixedlayer_restrat_register_restarts
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : vertvisc_type, thermo_var_ptrs, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, ocean_internal_state
 use MOM_verticalGrid,  only : verticalGrid_type
@@ -53,6 +54,8 @@ type(cont_diag_ptrs), target :: CDp
 type(MEKE_type), target :: MEKE
 type(VarMix_CS) :: VarMix
 type(thickness_diffuse_CS) :: TD
+type(mixedlayer_restrat_CS) :: MLE
+logical :: mle_on, td_on
 type(ocean_OBC_type), pointer :: OBC => NULL()
 type(update_OBC_CS), pointer :: update_OBC_CSp => NULL()
 type(ALE_CS), pointer :: ALE_CSp => NULL()
@@ -125,6 +128,11 @@ close(u_par)
 
 ! ---- MOM.F90's initialisation order for these modules
 call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
+! the two lateral parameterisations beside the step accept the same parameter file (MOM.F90:2854, :3305-3313)
+call mixedlayer_restrat_register_restarts(HI, GV, US, pf, MLE, restart_CS)
+call thickness_diffuse_init(Time, G, GV, US, pf, diag, CDp, TD)
+mle_on = mixedlayer_restrat_init(Time, G, GV, US, pf, diag, MLE, restart_CS)
+call get_param(pf, "MOM", "THICKNESSDIFFUSE", td_on, default=.false.)
 call register_restarts_dyn_split_RK2(HI, GV, US, pf, CS, restart_CS, uh, vh)
 if (hdr2(7) == 0) then      ! the bottom boundary layer as given (set_viscous_BBL belongs to another test)
   read(u_in) visc%Kv_bbl_u, visc%Kv_bbl_v, visc%bbl_thick_u, visc%bbl_thick_v
@@ -165,6 +173,7 @@ close(u_out)
 call end_dyn_split_RK2(CS)
 call set_visc_end(visc, SV)
 call mom6hip_shared_context_end()
-write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0,a,i0)') "dyn_driver ok cont_stencil=", cont_stencil, " ntrunc=", ntrunc, " h2d_calls=", xfer(1), &
-    " h2d_bytes=", xfer(2), " d2h_calls=", xfer(3), " d2h_bytes=", xfer(4)
+write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0,a,i0,a,i0,a,i0)') "dyn_driver ok cont_stencil=", cont_stencil, " ntrunc=", ntrunc, " h2d_calls=", xfer(1), &
+    " h2d_bytes=", xfer(2), " d2h_calls=", xfer(3), " d2h_bytes=", xfer(4), " thickness_diffuse=", merge(1, 0, td_on), &
+    " mixedlayer_restrat=", merge(1, 0, mle_on)
 end program dyn_driver

@@ -35,6 +35,7 @@ TC_INPUT = {
         BBL_THICK_MIN = 0.1
         KV = 1.0E-04
         KHTH = 500.0
+        USE_GM_WORK_BUG = True
         BE = 0.7
         ETA_TOLERANCE = 1.0E-12
         CORIOLIS_EN_DIS = True
@@ -58,6 +59,12 @@ TC_INPUT = {
         THICKNESSDIFFUSE = True
         THICKNESSDIFFUSE_FIRST = True
         MIXEDLAYER_RESTRAT = True
+        MEKE_KHTH_FAC = 0.5
+        USE_STORED_SLOPES = True
+        KHTH = 1.0
+        KHTH_MAX = 900.0
+        FOX_KEMPER_ML_RESTRAT_COEF = 5.0
+        USE_GM_WORK_BUG = False
         DT = 3600.0
         DT_THERM = 7200.0
         DTBT_RESET_PERIOD = -.98
@@ -104,6 +111,11 @@ TC_INPUT = {
         THICKNESSDIFFUSE = True
         THICKNESSDIFFUSE_FIRST = True
         MIXEDLAYER_RESTRAT = True
+        KHTH_SLOPE_CFF = 0.1
+        KHTH = 1.0
+        KHTH_MAX = 900.0
+        FOX_KEMPER_ML_RESTRAT_COEF = 5.0
+        USE_GM_WORK_BUG = True
         DT = 900.0
         DT_THERM = 3600.0
         DTBT_RESET_PERIOD = 0.0
@@ -373,6 +385,10 @@ def test_reference_named_driver_with_the_testing_sets_matches_oracle_bitwise(tmp
     # what crossed PCIe after initialisation
     words = r.stdout.split()
     stats = {w.split("=")[0]: int(w.split("=")[1]) for w in words if "=" in w}
+    # thickness_diffuse_init and mixedlayer_restrat_init (+ its restart registration) took the same parameter file
+    p = pairs_of(name)
+    assert stats["thickness_diffuse"] == int(p.get("THICKNESSDIFFUSE", "False") == "True")
+    assert stats["mixedlayer_restrat"] == int(p.get("MIXEDLAYER_RESTRAT", "False") == "True")
     n3 = int(np.prod(g.shape3(_abi.POS_H)))
     if resident:
         # one upload of each input (u, v, h are already there from the initialisation), one download of each output and restart field
