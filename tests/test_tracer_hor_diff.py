@@ -201,3 +201,71 @@ def test_varmix_diffusivities_match_oracle(name):
             for m, (a, b) in enumerate(zip(dtr, ref)):
                 assert bits_equal(interior(g, N(a)), interior(g, b)), (name, (ni, nj, nk), resident, m)
         dg.close()
+
+
+# ---- the two tracer module shims (MOM_tracer_advect_hip.F90, MOM_tracer_hor_diff_hip.F90) with the reference's argument lists ---------
+def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3"):
+    """the input and parameter files of tests/fortran/tracer_driver.F90 for one of VM (or None: constant KHTR), and the oracle's tracers
+    after advect_tracer + tracer_hordiff"""
+    from mom6_amd import synth as sy
+    ad = {k: (v if isinstance(v, list) else v.numpy()) for k, v in sy.make_advection_state(g, ntr=1, seed=9).items()}
+    f = varmix_fields(g)
+    kw = dict(VM[name]) if name else dict(KhTr=300.0, use=None)
+    use = kw.pop("use"); meke = kw.pop("meke", None); check = kw.pop("check", False)
+    ref = [t.copy() for t in tr]
+    orc.advect_tracer(g, ad["h_end"], ad["uhtr"], ad["vhtr"], dt, 900.0, scheme, ref)
+    for t in ref:
+        orc.halo_update(g, t, _abi.POS_H)
+    KhTr = kw.pop("KhTr")
+    orc.tracer_hordiff(g, ad["h_end"], dt, ref, KhTr, check_diffusive_CFL=check, VarMix=None if use is None else {n: f[n] for n in use},
+                       MEKE=None if meke is None else dict(Kh=f["Kh"], KhTr_fac=meke), **kw)
+    opt = [len(tr), int(use is not None), int(use is not None and "Res_fn_h" in use), int(meke is not None), 0, 0, 0, 0]
+    with open(tmp / "in.bin", "wb") as fh:
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, 900.0], dtype="<f8").tofile(fh)
+        np.array(opt, dtype="<i4").tofile(fh)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
+        np.array([dt, 1.0 if meke is None else meke], dtype="<f8").tofile(fh)
+        for a in [ad["h_end"], ad["uhtr"], ad["vhtr"]] + tr + [f[n] for n in ("Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h")]:
+            np.ascontiguousarray(a, dtype="<f8").tofile(fh)
+    REF = dict(KhTr_Slope_Cff="KHTR_SLOPE_CFF", KhTr_min="KHTR_MIN", KhTr_max="KHTR_MAX", KhTr_passivity_coeff="KHTR_PASSIVITY_COEFF",
+               KhTr_passivity_min="KHTR_PASSIVITY_MIN", max_diff_CFL="MAX_TR_DIFFUSION_CFL")
+    with open(tmp / "params.txt", "w") as fh:
+        fh.write(f"TRACER_ADVECTION_SCHEME = {scheme}\nDT = 900.0\nKHTR = {KhTr!r}\nCHECK_DIFFUSIVE_CFL = {check}\n")
+        for k, v in kw.items():
+            fh.write(f"{REF[k]} = {float(v)!r}\n")
+    return ref
+
+
+def test_tracer_module_shims_compile_and_fail_loudly_without_gpu(tmp_path):
+    import os, subprocess, torch
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_shims(tmp_path, driver="tracer_driver")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    g, h, tr = case(24, 16, 3)
+    _write_tracer_case(tmp_path, g, h, tr, "tc1")
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode != 0 and "FATAL" in r.stderr and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_tracer_module_shims_match_oracle(tmp_path):
+    """tracer_advect_init / advect_tracer and tracer_hor_diff_init / tracer_hordiff called from Fortran with the reference's argument lists
+    (a tracer registry, MEKE, VarMix) on host arrays, constant KHTR and every variable-mixing set: the oracle's bits"""
+    import os, subprocess
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_shims(tmp_path, driver="tracer_driver")
+    g, h, tr = case(36, 22, 4)
+    for name in [None] + list(VM):
+        ref = _write_tracer_case(tmp_path, g, h, tr, name)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (name, r.stderr[-600:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8").reshape((len(tr),) + tr[0].shape)
+        for m, w in enumerate(ref):
+            assert bits_equal(interior(g, raw[m]), interior(g, w)), (name, m)
