@@ -28,7 +28,8 @@ module MOM_dynamics_split_RK2
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_fatal_if
+use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_fatal_if, mom6hip_read_resident, mom6hip_mirror
+use mom6hip_MOM_glue,          only : mom6hip_mirrors_stage, mom6hip_mirrors_host_was_modified, mom6hip_mirrors_end
 use MOM_variables,             only : vertvisc_type, thermo_var_ptrs, porous_barrier_type
 use MOM_variables,             only : BT_cont_type, alloc_BT_cont_type
 use MOM_variables,             only : accel_diag_ptrs, ocean_internal_state, cont_diag_ptrs
@@ -68,16 +69,6 @@ public step_MOM_dyn_split_RK2, register_restarts_dyn_split_RK2, initialize_dyn_s
 public remap_dyn_split_RK2_aux_vars, end_dyn_split_RK2
 public dyn_split_RK2_sync_to_host, dyn_split_RK2_host_was_modified      ! the two calls of GPU_RESIDENT_DYNAMICS = True
 
-integer, parameter :: MAX_MIRRORS = 48
-
-!> A host array of the caller and its copy in HBM
-type :: dev_mirror
-  type(c_ptr) :: h = c_null_ptr, d = c_null_ptr      !< host base address, device address
-  integer(c_int64_t) :: bytes = 0
-  logical :: dev_current = .false.    !< the device copy holds what the host copy holds, or something newer
-  logical :: host_current = .true.    !< the host copy holds what the device copy holds, or something newer
-end type dev_mirror
-
 !> MOM_dynamics_split_RK2 module control structure (the reference's :84-268: what outlives a call)
 type, public :: MOM_dyn_split_RK2_CS ; private
   ! the restart fields on the host, refreshed by dyn_split_RK2_sync_to_host (register_restarts_dyn_split_RK2 :1210-1269)
@@ -113,8 +104,6 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   type(mom6hip_set_visc_cs_t)      :: c_sv
   type(mom6hip_dyn_split_rk2_cs_t) :: c_rk2
   logical :: use_EOS = .true., use_BT_cont = .true.
-  type(dev_mirror) :: mir(MAX_MIRRORS)
-  integer :: nmir = 0
   integer(c_int64_t) :: nh2 = 0, nu2 = 0, nv2 = 0, nq2 = 0, nh3 = 0, nu3 = 0, nv3 = 0      !< array sizes in doubles
   type(c_ptr) :: d_owned(96) = c_null_ptr      !< what end_dyn_split_RK2 frees
   integer :: n_owned = 0
@@ -151,41 +140,14 @@ function dput(CS, hp, n) result(p)
   call mom6hip_fatal_if(rc, "MOM_dynamics_split_RK2 (upload)")
 end function dput
 
-!> The device mirror of the host array at hp (n doubles): created on first sight; uploaded when the host copy is the newer one or
-!! when `fresh` asks for it (the default mode uploads every input of every step).  written: the step will write it.
+!> The device mirror of the host array at hp: the registry all shims share (mom6hip_MOM_glue)
 function mirror(CS, hp, n, is_input, written) result(d)
   type(MOM_dyn_split_RK2_CS), intent(inout) :: CS
   type(c_ptr),                intent(in)    :: hp
   integer(c_int64_t),         intent(in)    :: n
   logical,                    intent(in)    :: is_input, written
   type(c_ptr) :: d
-  integer :: m, q, rc
-  q = 0
-  do m = 1, CS%nmir
-    if (c_associated(CS%mir(m)%h, hp)) then ; q = m ; exit ; endif
-  enddo
-  if (q > 0) then ; if (CS%mir(q)%bytes /= 8_c_int64_t*n) then      ! the host reallocated something else at this address
-    rc = mom6hip_free(CS%mir(q)%d) ; call mom6hip_fatal_if(rc, "MOM_dynamics_split_RK2 (mirror)")
-    rc = mom6hip_malloc(CS%mir(q)%d, 8_c_int64_t*n) ; call mom6hip_fatal_if(rc, "MOM_dynamics_split_RK2 (mirror)")
-    CS%mir(q)%bytes = 8_c_int64_t*n ; CS%mir(q)%dev_current = .false. ; CS%mir(q)%host_current = .true.
-  endif ; endif
-  if (q == 0) then
-    if (CS%nmir >= MAX_MIRRORS) call MOM_error(FATAL, "MOM_dynamics_split_RK2 (HIP): too many host arrays to mirror.")
-    CS%nmir = CS%nmir + 1 ; q = CS%nmir
-    CS%mir(q)%h = hp ; CS%mir(q)%bytes = 8_c_int64_t*n ; CS%mir(q)%dev_current = .false. ; CS%mir(q)%host_current = .true.
-    rc = mom6hip_malloc(CS%mir(q)%d, CS%mir(q)%bytes) ; call mom6hip_fatal_if(rc, "MOM_dynamics_split_RK2 (mirror)")
-    if (.not.is_input) then
-      rc = mom6hip_memset_zero(CS%ctx, CS%mir(q)%d, CS%mir(q)%bytes) ; call mom6hip_fatal_if(rc, "MOM_dynamics_split_RK2 (mirror)")
-    endif
-  endif
-  if (is_input .and. (.not.CS%mir(q)%dev_current .or. .not.CS%resident)) then
-    if (CS%mir(q)%host_current) then      ! (never overwrite a device copy that is newer than the host's)
-      rc = mom6hip_sync_to_device(CS%ctx, CS%mir(q)%d, hp, CS%mir(q)%bytes) ; call mom6hip_fatal_if(rc, "MOM_dynamics_split_RK2 (upload)")
-    endif
-    CS%mir(q)%dev_current = .true.
-  endif
-  if (written) then ; CS%mir(q)%dev_current = .true. ; CS%mir(q)%host_current = .false. ; endif
-  d = CS%mir(q)%d
+  d = mom6hip_mirror(CS%ctx, hp, n, is_input, written)
 end function mirror
 
 !> (GPU path only) Copy everything the device holds newer than the host back to the host arrays: the step's outputs (u, v, h, uh, vh,
@@ -196,12 +158,7 @@ subroutine dyn_split_RK2_sync_to_host(CS)
   integer :: m, rc
   if (.not.associated(CS)) return
   if (.not.CS%module_is_initialized) return
-  do m = 1, CS%nmir
-    if (.not.CS%mir(m)%host_current) then
-      rc = mom6hip_stage_to_host(CS%ctx, CS%mir(m)%h, CS%mir(m)%d, CS%mir(m)%bytes) ; call mom6hip_fatal_if(rc, "dyn_split_RK2_sync_to_host")
-      CS%mir(m)%host_current = .true.
-    endif
-  enddo
+  call mom6hip_mirrors_stage(CS%ctx)
   call restart_fields(CS, to_host=.true.)
   rc = mom6hip_stage_wait(CS%ctx) ; call mom6hip_fatal_if(rc, "dyn_split_RK2_sync_to_host")
 end subroutine dyn_split_RK2_sync_to_host
@@ -212,11 +169,7 @@ subroutine dyn_split_RK2_host_was_modified(CS)
   type(MOM_dyn_split_RK2_CS), pointer :: CS
   integer :: m
   if (.not.associated(CS)) return
-  do m = 1, CS%nmir
-    if (.not.CS%mir(m)%host_current) call MOM_error(FATAL, "dyn_split_RK2_host_was_modified: the device holds newer values of a "// &
-        "field than the host; call dyn_split_RK2_sync_to_host before the host changes the fields.")
-    CS%mir(m)%dev_current = .false.
-  enddo
+  call mom6hip_mirrors_host_was_modified()
 end subroutine dyn_split_RK2_host_was_modified
 
 !> The restart fields between their host arrays in CS and the device arrays of the library's structs
@@ -517,10 +470,10 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   call refuse(flag, "FPMIX")
   call get_param(param_file, mdl, "VISC_REM_BUG", flag, default=.false., do_not_log=.true.)
   call refuse(flag, "VISC_REM_BUG")
-  call get_param(param_file, mdl, "GPU_RESIDENT_DYNAMICS", CS%resident, &
-                 "(GPU path) If true, the fields the split RK2 step works on stay on the GPU between steps: the host uploads them only "// &
-                 "after dyn_split_RK2_host_was_modified and sees them only after dyn_split_RK2_sync_to_host.  If false, every step "// &
-                 "uploads its inputs and copies its outputs back.", default=.false.)
+  ! GPU_RESIDENT_DYNAMICS (GPU path): if true, the fields the split RK2 step (and the other shims) work on stay on the GPU between
+  ! calls: the host uploads them only after dyn_split_RK2_host_was_modified and sees them only after dyn_split_RK2_sync_to_host.  If
+  ! false, every step uploads its inputs and copies its outputs back.
+  call mom6hip_read_resident(param_file, CS%resident)
 
   ! ---- the modules the step calls (:1490-1519)
   call continuity_PPM_init(Time, G, GV, US, param_file, diag, CS%continuity_CSp)
@@ -661,7 +614,7 @@ subroutine end_dyn_split_RK2(CS)
   type(MOM_dyn_split_RK2_CS), pointer :: CS
   integer :: m, rc
   if (.not.associated(CS)) return
-  do m = 1, CS%nmir ; rc = mom6hip_free(CS%mir(m)%d) ; enddo
+  call mom6hip_mirrors_end()
   do m = 1, CS%n_owned ; rc = mom6hip_free(CS%d_owned(m)) ; enddo
   call barotropic_end(CS%barotropic_CSp)
   if (associated(CS%vertvisc_CSp)) then ; call vertvisc_end(CS%vertvisc_CSp) ; deallocate(CS%vertvisc_CSp) ; endif

@@ -14,6 +14,7 @@ module MOM_mixed_layer_restrat
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_read_eos, mom6hip_fatal_if
+use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
 use MOM_diag_mediator,         only : diag_ctrl, time_type
 use MOM_domains,               only : pass_var
 use MOM_error_handler,         only : MOM_error, FATAL
@@ -73,7 +74,8 @@ subroutine mixedlayer_restrat(h, uhtr, vhtr, tv, forces, dt, MLD, h_MLD, bflux, 
   type(mixedlayer_restrat_CS), target,        intent(inout) :: CS
 
   type(mom6hip_mixedlayer_restrat_cs_t) :: ccs
-  type(c_ptr) :: p_hMLD
+  type(c_ptr) :: p_hMLD, ctx
+  integer :: n2
   integer :: rc
 
   if (.not. CS%initialized) call MOM_error(FATAL, "mixedlayer_restrat: "// &
@@ -104,9 +106,31 @@ subroutine mixedlayer_restrat(h, uhtr, vhtr, tv, forces, dt, MLD, h_MLD, bflux, 
     p_hMLD = c_loc(h_MLD)
   endif
 
-  rc = mom6hip_mixedlayer_restrat(mom6hip_shared_context(G, GV), ccs, c_loc(h), c_loc(uhtr), c_loc(vhtr), c_loc(tv%T), c_loc(tv%S), &
-                                  c_loc(CS%eos), c_loc(forces%ustar), dt, p_hMLD, c_null_ptr, c_null_ptr, MOM6HIP_MEM_HOST)
+  ctx = mom6hip_shared_context(G, GV)
+  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays; the running means of the
+    n2 = size(h(:,:,1))             ! control structure too (restart fields: current on the host after mom6hip_mirrors_to_host)
+    call to_dev(ccs%MLD_filtered, n2, .true.) ; call to_dev(ccs%MLD_filtered_slow, n2, .true.) ; call to_dev(ccs%Rd_dx_h, n2, .false.)
+    call to_dev(p_hMLD, n2, .false.)
+    rc = mom6hip_mixedlayer_restrat(ctx, ccs, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .true.), &
+                                    mom6hip_mirror(ctx, c_loc(uhtr), int(size(uhtr), c_int64_t), .true., .true.), &
+                                    mom6hip_mirror(ctx, c_loc(vhtr), int(size(vhtr), c_int64_t), .true., .true.), &
+                                    mom6hip_mirror(ctx, c_loc(tv%T), int(size(h), c_int64_t), .true., .false.), &
+                                    mom6hip_mirror(ctx, c_loc(tv%S), int(size(h), c_int64_t), .true., .false.), c_loc(CS%eos), &
+                                    mom6hip_mirror(ctx, c_loc(forces%ustar), int(n2, c_int64_t), .true., .false.), dt, p_hMLD, &
+                                    c_null_ptr, c_null_ptr, MOM6HIP_MEM_DEVICE)
+  else
+    rc = mom6hip_mixedlayer_restrat(ctx, ccs, c_loc(h), c_loc(uhtr), c_loc(vhtr), c_loc(tv%T), c_loc(tv%S), &
+                                    c_loc(CS%eos), c_loc(forces%ustar), dt, p_hMLD, c_null_ptr, c_null_ptr, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "mixedlayer_restrat")
+contains
+  !> a host pointer -> its device mirror (an input, or an in/out array the call writes)
+  subroutine to_dev(p, n, written)
+    type(c_ptr), intent(inout) :: p
+    integer,     intent(in)    :: n
+    logical,     intent(in)    :: written
+    if (c_associated(p)) p = mom6hip_mirror(ctx, p, int(n, c_int64_t), .true., written)
+  end subroutine to_dev
 end subroutine mixedlayer_restrat
 
 !> Same interface as the reference mixedlayer_restrat_init (:1532), same parameters and defaults (:1554-1735).
@@ -194,6 +218,7 @@ logical function mixedlayer_restrat_init(Time, G, GV, US, param_file, diag, CS, 
   CS%diag => diag
   call mom6hip_read_eos(param_file, CS%eos, "mixedlayer_restrat_init")
   call mom6hip_read_topology(param_file)
+  call mom6hip_read_resident(param_file)
 
   ! If MLD_filtered is being used, we need to update halo regions after a restart
   if (allocated(CS%MLD_filtered)) call pass_var(CS%MLD_filtered, G%domain)

@@ -15,6 +15,7 @@ module MOM_thickness_diffuse
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_read_eos, mom6hip_fatal_if
+use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
 use MOM_diag_mediator,         only : diag_ctrl, time_type
 use MOM_error_handler,         only : MOM_error, FATAL
 use MOM_file_parser,           only : get_param, log_version, param_file_type
@@ -69,7 +70,8 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
   type(stochastic_CS),                        intent(inout) :: STOCH
 
   type(mom6hip_thickness_diffuse_cs_t) :: ccs
-  type(c_ptr) :: p_T, p_S, p_eos, p_uhGM, p_vhGM
+  type(c_ptr) :: p_T, p_S, p_eos, p_uhGM, p_vhGM, ctx
+  integer :: n2
   real(c_double), allocatable, target :: Rlay(:)
   integer :: i, j, rc
 
@@ -110,8 +112,24 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
   if (associated(CDp%uhGM)) p_uhGM = c_loc(CDp%uhGM)
   if (associated(CDp%vhGM)) p_vhGM = c_loc(CDp%vhGM)
 
-  rc = mom6hip_thickness_diffuse(mom6hip_shared_context(G, GV), ccs, c_loc(h), c_loc(uhtr), c_loc(vhtr), p_T, p_S, p_eos, dt, &
-                                 p_uhGM, p_vhGM, MOM6HIP_MEM_HOST)
+  ctx = mom6hip_shared_context(G, GV)
+  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays (GV%Rlay stays a host table)
+    n2 = size(h(:,:,1))
+    call to_dev(p_T, size(h), .false.) ; call to_dev(p_S, size(h), .false.)
+    call to_dev(p_uhGM, size(uhtr), .true.) ; call to_dev(p_vhGM, size(vhtr), .true.)
+    call to_dev(ccs%MEKE_Kh, n2, .false.) ; call to_dev(ccs%MEKE_GM_src, n2, .true.)
+    call to_dev(ccs%Res_fn_u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%Res_fn_v, size(vhtr(:,:,1)), .false.)
+    call to_dev(ccs%L2u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%SN_u, size(uhtr(:,:,1)), .false.)
+    call to_dev(ccs%L2v, size(vhtr(:,:,1)), .false.) ; call to_dev(ccs%SN_v, size(vhtr(:,:,1)), .false.)
+    call to_dev(ccs%slope_x, size(uhtr(:,:,1))*(GV%ke+1), .false.) ; call to_dev(ccs%slope_y, size(vhtr(:,:,1))*(GV%ke+1), .false.)
+    rc = mom6hip_thickness_diffuse(ctx, ccs, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .true.), &
+                                   mom6hip_mirror(ctx, c_loc(uhtr), int(size(uhtr), c_int64_t), .true., .true.), &
+                                   mom6hip_mirror(ctx, c_loc(vhtr), int(size(vhtr), c_int64_t), .true., .true.), p_T, p_S, p_eos, dt, &
+                                   p_uhGM, p_vhGM, MOM6HIP_MEM_DEVICE)
+  else
+    rc = mom6hip_thickness_diffuse(ctx, ccs, c_loc(h), c_loc(uhtr), c_loc(vhtr), p_T, p_S, p_eos, dt, &
+                                   p_uhGM, p_vhGM, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "thickness_diffuse")
 
   if (VarMix%use_variable_mixing) then
@@ -121,6 +139,14 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
       enddo ; enddo
     endif
   endif
+contains
+  !> a host pointer -> its device mirror (an input, or an in/out array the call writes)
+  subroutine to_dev(p, n, written)
+    type(c_ptr), intent(inout) :: p
+    integer,     intent(in)    :: n
+    logical,     intent(in)    :: written
+    if (c_associated(p)) p = mom6hip_mirror(ctx, p, int(n, c_int64_t), .true., written)
+  end subroutine to_dev
 end subroutine thickness_diffuse
 
 !> Same interface as the reference thickness_diffuse_init (:2169), same parameters and defaults (:2203-2400).
@@ -183,6 +209,7 @@ subroutine thickness_diffuse_init(Time, G, GV, US, param_file, diag, CDp, CS)
                  default=.false.)
   call mom6hip_read_eos(param_file, CS%eos, "thickness_diffuse_init")
   call mom6hip_read_topology(param_file)
+  call mom6hip_read_resident(param_file)
 contains
   subroutine refuse(on, name)
     logical,          intent(in) :: on

@@ -12,6 +12,7 @@ module MOM_tracer_advect
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,    only : mom6hip_context_create, mom6hip_read_topology
+use mom6hip_MOM_glue,     only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
 use MOM_cpu_clock,       only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
 use MOM_diag_mediator,   only : diag_ctrl, time_type
 use MOM_error_handler,   only : MOM_error, FATAL, WARNING
@@ -108,9 +109,20 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
   p_uhr = c_null_ptr ; if (present(uhr_out)) p_uhr = c_loc(uhr_out)
   p_vhr = c_null_ptr ; if (present(vhr_out)) p_vhr = c_loc(vhr_out)
 
-  rc = mom6hip_advect_tracer(CS%ctx, c_loc(h_end), c_loc(uhtr), c_loc(vhtr), dt, ccs, tr, c_loc(cu), &
-                             int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, &
-                             MOM6HIP_MEM_HOST, stats)
+  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays
+    do m=1,Reg%ntr ; tr(m) = mom6hip_mirror(CS%ctx, tr(m), int(size(h_end), c_int64_t), .true., .true.) ; enddo
+    if (present(vol_prev)) p_vol = mom6hip_mirror(CS%ctx, p_vol, int(size(h_end), c_int64_t), .true., .true.)
+    if (present(uhr_out)) p_uhr = mom6hip_mirror(CS%ctx, p_uhr, int(size(uhtr), c_int64_t), .false., .true.)
+    if (present(vhr_out)) p_vhr = mom6hip_mirror(CS%ctx, p_vhr, int(size(vhtr), c_int64_t), .false., .true.)
+    rc = mom6hip_advect_tracer(CS%ctx, mom6hip_mirror(CS%ctx, c_loc(h_end), int(size(h_end), c_int64_t), .true., .false.), &
+                               mom6hip_mirror(CS%ctx, c_loc(uhtr), int(size(uhtr), c_int64_t), .true., .false.), &
+                               mom6hip_mirror(CS%ctx, c_loc(vhtr), int(size(vhtr), c_int64_t), .true., .false.), dt, ccs, tr, c_loc(cu), &
+                               int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, MOM6HIP_MEM_DEVICE, stats)
+  else
+    rc = mom6hip_advect_tracer(CS%ctx, c_loc(h_end), c_loc(uhtr), c_loc(vhtr), dt, ccs, tr, c_loc(cu), &
+                               int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, &
+                               MOM6HIP_MEM_HOST, stats)
+  endif
   if (rc /= 0) call MOM_error(FATAL, "MOM_tracer_advect (HIP): "//mom6hip_error_string())
 
   call cpu_clock_end(id_clock_advect)
@@ -160,6 +172,7 @@ subroutine tracer_advect_init(Time, G, US, param_file, diag, CS)
         desc="If true, use a stencil width of 2 in PPM:H3 tracer advection.", default=.false.)
   endif
   call mom6hip_read_topology(param_file, CS%reentrant)
+  call mom6hip_read_resident(param_file)
   id_clock_advect = cpu_clock_id('(Ocean advect tracer)', grain=CLOCK_MODULE)
 end subroutine tracer_advect_init
 

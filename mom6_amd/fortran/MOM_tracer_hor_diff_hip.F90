@@ -13,6 +13,7 @@ module MOM_tracer_hor_diff
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
 use MOM_cpu_clock,             only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
 use MOM_diabatic_driver,       only : diabatic_CS
 use MOM_diag_mediator,         only : diag_ctrl, time_type
@@ -70,6 +71,7 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
 
   type(mom6hip_tracer_hor_diff_cs_t) :: ccs
   type(mom6hip_hordiff_fields_t) :: fld
+  type(c_ptr) :: ctx
   type(mom6hip_hordiff_stats_t) :: stats
   type(c_ptr), allocatable :: tr(:)
   real(c_double), allocatable, target :: cu(:)
@@ -108,10 +110,29 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
     if (CS%KhTr_passivity_coeff > 0.) fld%Rd_dx_h = c_loc(VarMix%Rd_dx_h)
     if (allocated(MEKE%Kh)) then ; fld%MEKE_Kh = c_loc(MEKE%Kh) ; ccs%KhTr_fac = MEKE%KhTr_fac ; endif
   endif
-  rc = mom6hip_tracer_hordiff_varmix(mom6hip_shared_context(G, GV), ccs, fld, c_loc(h), dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), &
-                                     MOM6HIP_MEM_HOST, stats)
+  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays
+    ctx = mom6hip_shared_context(G, GV)
+    do m=1,Reg%ntr ; tr(m) = mom6hip_mirror(ctx, tr(m), int(size(h), c_int64_t), .true., .true.) ; enddo
+    call to_dev(fld%MEKE_Kh, size(h(:,:,1))) ; call to_dev(fld%Res_fn_h, size(h(:,:,1))) ; call to_dev(fld%Rd_dx_h, size(h(:,:,1)))
+    if (c_associated(fld%L2u)) then
+      call to_dev(fld%L2u, size(VarMix%L2u)) ; call to_dev(fld%SN_u, size(VarMix%SN_u))
+      call to_dev(fld%L2v, size(VarMix%L2v)) ; call to_dev(fld%SN_v, size(VarMix%SN_v))
+    endif
+    rc = mom6hip_tracer_hordiff_varmix(ctx, ccs, fld, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), dt, tr, &
+                                       c_loc(cu), int(Reg%ntr, c_int32_t), MOM6HIP_MEM_DEVICE, stats)
+  else
+    rc = mom6hip_tracer_hordiff_varmix(mom6hip_shared_context(G, GV), ccs, fld, c_loc(h), dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), &
+                                       MOM6HIP_MEM_HOST, stats)
+  endif
   call mom6hip_fatal_if(rc, "tracer_hordiff")
   call cpu_clock_end(id_clock_diffuse)
+contains
+  !> a host pointer of the struct -> its device mirror (an input)
+  subroutine to_dev(p, n)
+    type(c_ptr), intent(inout) :: p
+    integer,     intent(in)    :: n
+    if (c_associated(p)) p = mom6hip_mirror(ctx, p, int(n, c_int64_t), .true., .false.)
+  end subroutine to_dev
 end subroutine tracer_hordiff
 
 !> Same interface as the reference tracer_hor_diff_init (:1625), same parameters and defaults (:1652-1700).
@@ -165,6 +186,7 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
   call get_param(param_file, mdl, "USE_HORIZONTAL_BOUNDARY_DIFFUSION", CS%use_hor_bnd_diffusion, default=.false.)
   call refuse(CS%use_hor_bnd_diffusion, "USE_HORIZONTAL_BOUNDARY_DIFFUSION")
   call mom6hip_read_topology(param_file)
+  call mom6hip_read_resident(param_file)
   id_clock_diffuse = cpu_clock_id('(Ocean diffuse tracer)', grain=CLOCK_MODULE)
 contains
   subroutine refuse(on, name)

@@ -26,6 +26,21 @@ use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
 
 public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6hip_fatal_if, mom6hip_shared_context, mom6hip_shared_context_end
+! the device mirrors of the host's arrays, shared by every module shim (GPU_RESIDENT_DYNAMICS)
+public :: mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirrors_stage, mom6hip_mirrors_to_host
+public :: mom6hip_mirrors_host_was_modified, mom6hip_mirror_host_changed, mom6hip_mirror_zeroed, mom6hip_mirrors_end
+
+integer, parameter :: MAX_MIRRORS = 160
+!> A host array of the caller and its copy in HBM
+type :: dev_mirror
+  type(c_ptr) :: h = c_null_ptr, d = c_null_ptr      !< host base address, device address
+  integer(c_int64_t) :: bytes = 0
+  logical :: dev_current = .false.    !< the device copy holds what the host copy holds, or something newer
+  logical :: host_current = .true.    !< the host copy holds what the device copy holds, or something newer
+end type dev_mirror
+type(dev_mirror), save :: mir(MAX_MIRRORS)
+integer, save :: nmir = 0
+logical, save :: resident_mode = .false.     !< GPU_RESIDENT_DYNAMICS
 
 !> The grid of the (single) ocean instance the callbacks act on
 type(ocean_grid_type), pointer, save :: G_cb => NULL()
@@ -58,6 +73,117 @@ subroutine mom6hip_read_topology(param_file, reentrant)
   topology_known = .true. ; reentrant_saved(:) = re(:) ; tripolar_saved = tripolar_N
   if (present(reentrant)) reentrant(:) = re(:)
 end subroutine mom6hip_read_topology
+
+!> GPU_RESIDENT_DYNAMICS (a parameter of this port, default False), read by every shim that can work on the device mirrors:
+!! False: a call uploads its inputs and copies its outputs back (correct inside an unmodified MOM6); True: the fields stay in HBM
+!! between the calls of all shims, the host arrays are refreshed by mom6hip_mirrors_to_host (dyn_split_RK2_sync_to_host), and the
+!! host announces what it has changed (mom6hip_mirror_host_changed / mom6hip_mirror_zeroed / dyn_split_RK2_host_was_modified).
+subroutine mom6hip_read_resident(param_file, resident)
+  type(param_file_type), intent(in)  :: param_file
+  logical,     optional, intent(out) :: resident
+  logical :: r
+  call get_param(param_file, "mom6hip", "GPU_RESIDENT_DYNAMICS", r, &
+                 "If true, the fields the GPU path works on stay in device memory between its calls.", default=.false.)
+  resident_mode = r
+  if (present(resident)) resident = r
+end subroutine mom6hip_read_resident
+
+logical function mom6hip_resident()
+  mom6hip_resident = resident_mode
+end function mom6hip_resident
+
+!> The device mirror of the host array at hp (n doubles): created on first sight; uploaded when the host copy is the newer one (with
+!! GPU_RESIDENT_DYNAMICS = False: at every call that reads it).  written: the call will write it (the device copy becomes the newer).
+function mom6hip_mirror(ctx, hp, n, is_input, written) result(d)
+  type(c_ptr),        intent(in) :: ctx, hp
+  integer(c_int64_t), intent(in) :: n
+  logical,            intent(in) :: is_input, written
+  type(c_ptr) :: d
+  integer :: m, q, rc
+  q = 0
+  do m = 1, nmir
+    if (c_associated(mir(m)%h, hp)) then ; q = m ; exit ; endif
+  enddo
+  if (q > 0) then ; if (mir(q)%bytes /= 8_c_int64_t*n) then      ! the host reallocated something else at this address
+    rc = mom6hip_free(mir(q)%d) ; call mom6hip_fatal_if(rc, "mom6hip_mirror")
+    rc = mom6hip_malloc(mir(q)%d, 8_c_int64_t*n) ; call mom6hip_fatal_if(rc, "mom6hip_mirror")
+    mir(q)%bytes = 8_c_int64_t*n ; mir(q)%dev_current = .false. ; mir(q)%host_current = .true.
+  endif ; endif
+  if (q == 0) then
+    if (nmir >= MAX_MIRRORS) call MOM_error(FATAL, "mom6hip_mirror: too many host arrays to mirror.")
+    nmir = nmir + 1 ; q = nmir
+    mir(q)%h = hp ; mir(q)%bytes = 8_c_int64_t*n ; mir(q)%dev_current = .false. ; mir(q)%host_current = .true.
+    rc = mom6hip_malloc(mir(q)%d, mir(q)%bytes) ; call mom6hip_fatal_if(rc, "mom6hip_mirror")
+    if (.not.is_input) then
+      rc = mom6hip_memset_zero(ctx, mir(q)%d, mir(q)%bytes) ; call mom6hip_fatal_if(rc, "mom6hip_mirror")
+    endif
+  endif
+  if (is_input .and. (.not.mir(q)%dev_current .or. .not.resident_mode)) then
+    if (mir(q)%host_current) then      ! (never overwrite a device copy that is newer than the host's)
+      rc = mom6hip_sync_to_device(ctx, mir(q)%d, hp, mir(q)%bytes) ; call mom6hip_fatal_if(rc, "mom6hip_mirror (upload)")
+    endif
+    mir(q)%dev_current = .true.
+  endif
+  if (written) then ; mir(q)%dev_current = .true. ; mir(q)%host_current = .false. ; endif
+  d = mir(q)%d
+end function mom6hip_mirror
+
+!> Start copying everything the device holds newer than the host back to the host arrays (snapshots on the compute stream, copies on
+!! the copy stream); mom6hip_stage_wait completes them
+subroutine mom6hip_mirrors_stage(ctx)
+  type(c_ptr), intent(in) :: ctx
+  integer :: m, rc
+  do m = 1, nmir
+    if (.not.mir(m)%host_current) then
+      rc = mom6hip_stage_to_host(ctx, mir(m)%h, mir(m)%d, mir(m)%bytes) ; call mom6hip_fatal_if(rc, "mom6hip_mirrors_stage")
+      mir(m)%host_current = .true.
+    endif
+  enddo
+end subroutine mom6hip_mirrors_stage
+
+!> The same, complete: call it where the host reads the fields
+subroutine mom6hip_mirrors_to_host(ctx)
+  type(c_ptr), intent(in) :: ctx
+  integer :: rc
+  call mom6hip_mirrors_stage(ctx)
+  rc = mom6hip_stage_wait(ctx) ; call mom6hip_fatal_if(rc, "mom6hip_mirrors_to_host")
+end subroutine mom6hip_mirrors_to_host
+
+!> The host has changed fields (thermodynamics, ALE remapping, a new forcing ...): the next calls upload every input again
+subroutine mom6hip_mirrors_host_was_modified()
+  integer :: m
+  do m = 1, nmir
+    if (.not.mir(m)%host_current) call MOM_error(FATAL, "mom6hip_mirrors_host_was_modified: the device holds newer values of a "// &
+        "field than the host; call mom6hip_mirrors_to_host (dyn_split_RK2_sync_to_host) before the host changes the fields.")
+    mir(m)%dev_current = .false.
+  enddo
+end subroutine mom6hip_mirrors_host_was_modified
+
+!> The host has changed this one array (a new wind stress, MEKE%Kh after the MEKE step ...): its next reader uploads it
+subroutine mom6hip_mirror_host_changed(hp)
+  type(c_ptr), intent(in) :: hp
+  integer :: m
+  do m = 1, nmir ; if (c_associated(mir(m)%h, hp)) then
+    mir(m)%dev_current = .false. ; mir(m)%host_current = .true.
+  endif ; enddo
+end subroutine mom6hip_mirror_host_changed
+
+!> The host has set this array to zero (uhtr, vhtr after the tracer advection, MOM.F90:1447): zero the device copy instead of uploading
+subroutine mom6hip_mirror_zeroed(ctx, hp)
+  type(c_ptr), intent(in) :: ctx, hp
+  integer :: m, rc
+  do m = 1, nmir ; if (c_associated(mir(m)%h, hp)) then
+    rc = mom6hip_memset_zero(ctx, mir(m)%d, mir(m)%bytes) ; call mom6hip_fatal_if(rc, "mom6hip_mirror_zeroed")
+    mir(m)%dev_current = .true. ; mir(m)%host_current = .true.
+  endif ; enddo
+end subroutine mom6hip_mirror_zeroed
+
+!> Free the mirrors (the last *_end of the run)
+subroutine mom6hip_mirrors_end()
+  integer :: m, rc
+  do m = 1, nmir ; rc = mom6hip_free(mir(m)%d) ; mir(m)%h = c_null_ptr ; mir(m)%d = c_null_ptr ; enddo
+  nmir = 0
+end subroutine mom6hip_mirrors_end
 
 !> The equation of state as interpret_eos_selection reads it (MOM_EOS.F90:1474-1520): EOS_type is opaque in MOM6, so the shims
 !! that need the equation of state (MOM_PressureForce_FV, MOM_thickness_diffuse) read its selection from the parameter file.

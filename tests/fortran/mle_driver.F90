@@ -19,7 +19,7 @@ use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
-use mom6hip_MOM_glue,   only : mom6hip_shared_context_end
+use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, mom6hip_shared_context, mom6hip_mirrors_to_host, mom6hip_mirrors_end
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -104,9 +104,12 @@ do n=1,opt(4)
   call mixedlayer_restrat(h, uhtr, vhtr, tv, forces, dt, MLD, h_MLD, bflux, VarMix, G, GV, US, CS)
 enddo
 
+! with GPU_RESIDENT_DYNAMICS the results are on the device until the host asks for them
+call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) h, uhtr, vhtr
 close(u_out)
+call mom6hip_mirrors_end()
 call mom6hip_shared_context_end()
 write(*,'(a,i0)') "mle_driver ok restart_fields=", restart_CS%nfields
 end program mle_driver

@@ -16,7 +16,7 @@ use MOM_stochastics,    only : stochastic_CS
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : cont_diag_ptrs, thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
-use mom6hip_MOM_glue,   only : mom6hip_shared_context_end
+use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, mom6hip_shared_context, mom6hip_mirrors_to_host, mom6hip_mirrors_end
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -99,11 +99,14 @@ close(u_par)
 call thickness_diffuse_init(Time, G, GV, US, pf, diag, CDp, CS)
 call thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH)
 
+! with GPU_RESIDENT_DYNAMICS the results are on the device until the host asks for them
+call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) h, uhtr, vhtr, CDp%uhGM, CDp%vhGM
 if (opt(6) /= 0) write(u_out) MEKE%GM_src
 close(u_out)
 call thickness_diffuse_end(CS, CDp)
+call mom6hip_mirrors_end()
 call mom6hip_shared_context_end()
 write(*,'(a)') "td_driver ok"
 end program td_driver

@@ -23,7 +23,7 @@ use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
-use mom6hip_MOM_glue,   only : mom6hip_shared_context_end
+use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, mom6hip_shared_context, mom6hip_mirrors_to_host, mom6hip_mirrors_end
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -111,11 +111,14 @@ call tracer_hor_diff_init(Time, G, GV, US, pf, diag, EOS, diabatic_CSp, DCS)
 call advect_tracer(h, uhtr, vhtr, OBC, dt_therm, G, GV, US, ACS, Reg)
 call tracer_hordiff(h, dt_therm, MEKE, VarMix, visc, G, GV, US, DCS, Reg, tv)
 
+! with GPU_RESIDENT_DYNAMICS the results are on the device until the host asks for them
+call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) trs
 close(u_out)
 call tracer_hor_diff_end(DCS)
 call tracer_advect_end(ACS)
+call mom6hip_mirrors_end()
 call mom6hip_shared_context_end()
 write(*,'(a)') "tracer_driver ok"
 end program tracer_driver

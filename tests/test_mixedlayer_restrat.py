@@ -230,7 +230,7 @@ def test_gpu_parity(name):
 
 
 # ---- the module shim (mom6_amd/fortran/MOM_mixed_layer_restrat_hip.F90) with the reference's dummy-argument lists --------------------
-def _write_mle_case(tmp, g, d, name, ncalls=2, eos="WRIGHT"):
+def _write_mle_case(tmp, g, d, name, ncalls=2, eos="WRIGHT", resident=False):
     """the input and parameter files of tests/fortran/mle_driver.F90 for one of VARIANTS, and the oracle's results after ncalls calls
     (the running means start from zero, as mixedlayer_restrat_register_restarts leaves them on a cold start)"""
     kw = dict(VARIANTS[name])
@@ -253,7 +253,7 @@ def _write_mle_case(tmp, g, d, name, ncalls=2, eos="WRIGHT"):
         for a in (d["h"], d["T"], d["S"], f["ustar"], f["h_MLD"], f["Rd_dx_h"]):
             np.ascontiguousarray(a, dtype="<f8").tofile(fh)
     with open(tmp / "params.txt", "w") as fh:
-        fh.write(f"MIXEDLAYER_RESTRAT = True\nEQN_OF_STATE = {eos}\n")
+        fh.write(f"MIXEDLAYER_RESTRAT = True\nEQN_OF_STATE = {eos}\nGPU_RESIDENT_DYNAMICS = {resident}\n")
         for k, v in kw.items():
             if k in REF and k != "nkml":
                 fh.write(f"{REF[k]} = {v if isinstance(v, bool) else repr(float(v))}\n")
@@ -287,8 +287,8 @@ def test_module_shim_matches_oracle(tmp_path):
         pytest.skip("amdflang not present")
     exe = _build_shims(tmp_path, driver="mle_driver")
     g, d = case(36, 22, 6, reentrant_x=True, reentrant_y=False)
-    for name in VARIANTS:
-        ref, nrest = _write_mle_case(tmp_path, g, d, name)
+    for name, resident in [(n, r) for n in VARIANTS for r in (False, True)]:      # host arrays staged per call, or the shared device mirrors
+        ref, nrest = _write_mle_case(tmp_path, g, d, name, resident=resident)
         r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
         assert r.returncode == 0 and f"mle_driver ok restart_fields={nrest}" in r.stdout, (name, r.stdout[-200:], r.stderr[-600:])
         raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")

@@ -179,7 +179,7 @@ def test_gpu_parity(name):
 FKEYS = dict(Khth="KHTH", Khth_Min="KHTH_MIN", Khth_Max="KHTH_MAX", max_Khth_CFL="KHTH_MAX_CFL", kappa_smooth="KD_SMOOTH", KHTH_Slope_Cff="KHTH_SLOPE_CFF")
 
 
-def _write_td_case(tmp, g, d, name):
+def _write_td_case(tmp, g, d, name, resident=False):
     """the input and parameter files of tests/fortran/td_driver.F90 for one of VARIANTS, and the oracle's results"""
     ref, (kw, args, eos) = run_oracle(g, d, name)
     f = fields(g)
@@ -196,7 +196,7 @@ def _write_td_case(tmp, g, d, name):
         for n in ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y"):
             np.ascontiguousarray(f[n], dtype="<f8").tofile(fh)
     with open(tmp / "params.txt", "w") as fh:
-        fh.write("THICKNESSDIFFUSE = True\n")
+        fh.write(f"THICKNESSDIFFUSE = True\nGPU_RESIDENT_DYNAMICS = {resident}\n")
         if eos is not None:
             fh.write(f"EQN_OF_STATE = {eos}\n")
         if kw.get("use_GM_work_bug"):
@@ -236,8 +236,8 @@ def test_module_shim_matches_oracle(tmp_path):
         pytest.skip("amdflang not present")
     exe = _build_td(tmp_path)
     g, d = case(36, 22, 6, reentrant_x=True, reentrant_y=False)
-    for name in VARIANTS:
-        ref, opt = _write_td_case(tmp_path, g, d, name)
+    for name, resident in [(n, r) for n in VARIANTS for r in (False, True)]:      # host arrays staged per call, or the shared device mirrors
+        ref, opt = _write_td_case(tmp_path, g, d, name, resident)
         r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
         assert r.returncode == 0 and "td_driver ok" in r.stdout, (name, r.stderr[-600:])
         raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")

@@ -204,7 +204,7 @@ def test_varmix_diffusivities_match_oracle(name):
 
 
 # ---- the two tracer module shims (MOM_tracer_advect_hip.F90, MOM_tracer_hor_diff_hip.F90) with the reference's argument lists ---------
-def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3"):
+def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident=False):
     """the input and parameter files of tests/fortran/tracer_driver.F90 for one of VM (or None: constant KHTR), and the oracle's tracers
     after advect_tracer + tracer_hordiff"""
     from mom6_amd import synth as sy
@@ -232,7 +232,7 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3"):
     REF = dict(KhTr_Slope_Cff="KHTR_SLOPE_CFF", KhTr_min="KHTR_MIN", KhTr_max="KHTR_MAX", KhTr_passivity_coeff="KHTR_PASSIVITY_COEFF",
                KhTr_passivity_min="KHTR_PASSIVITY_MIN", max_diff_CFL="MAX_TR_DIFFUSION_CFL")
     with open(tmp / "params.txt", "w") as fh:
-        fh.write(f"TRACER_ADVECTION_SCHEME = {scheme}\nDT = 900.0\nKHTR = {KhTr!r}\nCHECK_DIFFUSIVE_CFL = {check}\n")
+        fh.write(f"TRACER_ADVECTION_SCHEME = {scheme}\nDT = 900.0\nKHTR = {KhTr!r}\nCHECK_DIFFUSIVE_CFL = {check}\nGPU_RESIDENT_DYNAMICS = {resident}\n")
         for k, v in kw.items():
             fh.write(f"{REF[k]} = {float(v)!r}\n")
     return ref
@@ -262,8 +262,8 @@ def test_tracer_module_shims_match_oracle(tmp_path):
         pytest.skip("amdflang not present")
     exe = _build_shims(tmp_path, driver="tracer_driver")
     g, h, tr = case(36, 22, 4)
-    for name in [None] + list(VM):
-        ref = _write_tracer_case(tmp_path, g, h, tr, name)
+    for name, resident in [(n, r) for n in [None] + list(VM) for r in (False, True)]:      # staged host arrays, or the shared device mirrors
+        ref = _write_tracer_case(tmp_path, g, h, tr, name, resident=resident)
         r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
         assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (name, r.stderr[-600:])
         raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8").reshape((len(tr),) + tr[0].shape)
