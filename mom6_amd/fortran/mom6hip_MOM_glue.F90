@@ -29,6 +29,7 @@ public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6h
 ! the device mirrors of the host's arrays, shared by every module shim (GPU_RESIDENT_DYNAMICS)
 public :: mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirrors_stage, mom6hip_mirrors_to_host
 public :: mom6hip_mirrors_host_was_modified, mom6hip_mirror_host_changed, mom6hip_mirror_zeroed, mom6hip_mirrors_end
+public :: mom6hip_mirror_pass_var
 
 integer, parameter :: MAX_MIRRORS = 160
 !> A host array of the caller and its copy in HBM
@@ -177,6 +178,28 @@ subroutine mom6hip_mirror_zeroed(ctx, hp)
     mir(m)%dev_current = .true. ; mir(m)%host_current = .true.
   endif ; enddo
 end subroutine mom6hip_mirror_zeroed
+
+!> pass_var between two calls of the GPU path (MOM.F90:1179, :1338 ...): if the device holds the newer copy of the array at hp, its halos
+!! are updated THERE (the library's group pass: the wrap kernels of a one-tile domain, RCCL, or the host's pass_var behind the
+!! callbacks) and done = .true.; otherwise done = .false. and the caller's own pass_var on the host array is the right one.
+!! position: CENTER / EAST_FACE / NORTH_FACE / CORNER of MOM_domains; nk: the number of layers (1 for a 2-D field).
+subroutine mom6hip_mirror_pass_var(ctx, hp, nk, position, done)
+  type(c_ptr), intent(in)  :: ctx, hp
+  integer,     intent(in)  :: nk, position
+  logical,     intent(out) :: done
+  type(c_ptr) :: f(1)
+  integer(c_int32_t) :: pos(1), nks(1)
+  integer :: m, rc
+  done = .false.
+  do m = 1, nmir ; if (c_associated(mir(m)%h, hp) .and. .not.mir(m)%host_current) then
+    f(1) = mir(m)%d ; nks(1) = nk ; pos(1) = MOM6HIP_POS_H
+    if (position == EAST_FACE) pos(1) = MOM6HIP_POS_U
+    if (position == NORTH_FACE) pos(1) = MOM6HIP_POS_V
+    if (position == CORNER) pos(1) = MOM6HIP_POS_Q
+    rc = mom6hip_halo_update(ctx, f, pos, nks, 1_c_int32_t) ; call mom6hip_fatal_if(rc, "mom6hip_mirror_pass_var")
+    done = .true.
+  endif ; enddo
+end subroutine mom6hip_mirror_pass_var
 
 !> Free the mirrors (the last *_end of the run)
 subroutine mom6hip_mirrors_end()

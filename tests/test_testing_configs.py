@@ -157,6 +157,8 @@ TC_INPUT = {
 def pairs_of(name):
     out = {}
     for line in TC_INPUT[name]["pairs"].strip().splitlines():
+        if "=" not in line:
+            continue
         k, v = (s.strip() for s in line.split("=", 1))
         out[k] = v.strip('"')
     return out
@@ -283,6 +285,7 @@ def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
     reset = _f(p, "DTBT_RESET_PERIOD", -1.0)
     calc = lambda n: (reset == 0.0)
     st.mom_src = mom_src
+    st.E = E
     st.bbl = lambda: orc.set_viscous_BBL(g, sv, st.u, st.v, st.h, st.T, st.S, E, st.visc)      # MOM.F90:1205
     return st, calc, dict(use_eos=1, use_ale=int(use_ALE), nk_rho_varies=nkml + nkbl, nkml=nkml)
 
@@ -399,3 +402,93 @@ def test_reference_named_driver_with_the_testing_sets_matches_oracle_bitwise(tmp
         assert stats["h2d_bytes"] <= 8 * (6 * n3 + 16 * n2) * 1.25 and stats["d2h_bytes"] <= 8 * (16 * n3 + 8 * n2) * 1.25, stats
     else:
         assert stats["h2d_calls"] >= nsteps * 8
+
+
+# ---- one thermodynamic cycle of step_MOM's hot sequence through the shims, staged and resident -------------------------------------------
+CYCLE_PAIRS = """
+        THICKNESSDIFFUSE = True
+        MIXEDLAYER_RESTRAT = True
+        FOX_KEMPER_ML_RESTRAT_COEF = 5.0
+        KHTR = 100.0
+        TRACER_ADVECTION_SCHEME = "PPM:H3"
+        TEST_NCYCLES = 2
+        """
+
+
+def build_cycle_driver(tmp):
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in SHIMS] + \
+           [os.path.join(FDIR, "MOM_dynamics_split_RK2_hip.F90"), os.path.join(ROOT, "tests", "fortran", "cycle_driver.F90")]
+    for src in srcs:
+        o = str(tmp / (os.path.basename(src)[:-4] + ".o"))
+        subprocess.run([FC, *flags, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    libdir = os.path.join(ROOT, "mom6_amd")
+    exe = str(tmp / "cycle_driver")
+    subprocess.run([FC, *objs, f"-L{libdir}", "-lmom6hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    return exe
+
+
+def cycle_oracle(name, state, ncycles, nsteps):
+    """the same sequence on the oracle: thickness_diffuse, pass h, nsteps RK2 steps, mixedlayer_restrat, pass h, advect_tracer and
+    tracer_hordiff of T and S, uhtr = vhtr = 0, pass T and S"""
+    from oracle import orc
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    p = pairs_of(name)
+    dt, dt_therm = float(p["DT"]), float(p["DT_THERM"])
+    st, calc, meta = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    H = _abi.POS_H
+    tdcs = orc.thickness_diffuse_cs(g, Khth=float(p["KHTH"]), use_GM_work_bug=_b(p, "USE_GM_WORK_BUG"))
+    mlecs = orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0)
+    for nc in range(ncycles):
+        orc.thickness_diffuse(g, tdcs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, dt_therm)
+        orc.halo_update(g, st.h, H)
+        for n in range(nsteps):
+            st.step(taux, tauy, calc_dtbt=calc(n))
+        orc.mixedlayer_restrat(g, mlecs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, ustar, dt_therm)
+        orc.halo_update(g, st.h, H)
+        orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, dt_therm, dt, "PPM:H3", [st.T, st.S])
+        orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0)
+        st.uhtr[:] = 0.0; st.vhtr[:] = 0.0
+        orc.halo_update(g, st.T, H); orc.halo_update(g, st.S, H)
+    return st
+
+
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_the_cycle_driver_compiles(tmp_path):
+    """every shim in one program (the split RK2 module, the two lateral parameterisations, the two tracer modules) compiles and links"""
+    build_cycle_driver(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_path, resident):
+    """thickness_diffuse -> step_MOM_dyn_split_RK2 x (DT_THERM / DT) -> mixedlayer_restrat -> advect_tracer -> tracer_hordiff, twice, from a
+    Fortran program that calls reference-named procedures only, with the .testing/tc4 parameter set: u, v, h, T, S and the transports equal
+    the oracle's bit for bit; with GPU_RESIDENT_DYNAMICS the fields cross PCIe once in each direction, whatever the number of cycles"""
+    name = "tc4"
+    TC_INPUT["tc4c"] = dict(shape=TC_INPUT[name]["shape"], pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS)
+    exe = build_cycle_driver(tmp_path)
+    state = case_state("tc4c")
+    g = state[0]
+    p = pairs_of("tc4c")
+    nsteps = int(round(float(p["DT_THERM"]) / float(p["DT"])))
+    want = cycle_oracle("tc4c", state, 2, nsteps)
+    write_case(tmp_path, "tc4c", nsteps, resident, state)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0 and "cycle_driver ok" in r.stdout, r.stderr[-800:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    n3 = int(np.prod(g.shape3(_abi.POS_H)))
+    T_, S_ = raw[-2 * n3:-n3].reshape(g.shape3(_abi.POS_H)), raw[-n3:].reshape(g.shape3(_abi.POS_H))
+    shapes = [g.shape3(pos) if nd == 3 else g.shape2(pos) for _, pos, nd in OUT]
+    got = {n: a.reshape(s) for (n, _, _), a, s in zip(OUT, np.split(raw[:-2 * n3], np.cumsum([int(np.prod(s)) for s in shapes])[:-1]), shapes)}
+    for n, pos in (("u", _abi.POS_U), ("v", _abi.POS_V), ("h", _abi.POS_H), ("uh", _abi.POS_U), ("vh", _abi.POS_V)):
+        assert bits_equal(interior(g, got[n], pos), interior(g, getattr(want, n), pos)), (n, float(np.abs(got[n] - getattr(want, n)).max()))
+    assert bits_equal(interior(g, T_), interior(g, want.T)) and bits_equal(interior(g, S_), interior(g, want.S))
+    assert np.all(got["uhtr"] == 0.0) and np.all(got["vhtr"] == 0.0)
+    stats = {w.split("=")[0]: int(w.split("=")[1]) for w in r.stdout.split() if "=" in w}
+    if resident:
+        n2 = n3 // g.nk
+        assert stats["h2d_bytes"] <= 8 * (10 * n3 + 30 * n2) * 1.25 and stats["d2h_bytes"] <= 8 * (20 * n3 + 20 * n2) * 1.25, stats
