@@ -101,8 +101,11 @@ __global__ __launch_bounds__(64) void td_column_kernel(TDArgs A) {
 }
 
 // One velocity column of thickness_diffuse_full (:812-1209 / :1211-1515, the top layer :1517-1590)
+#ifndef TD_FACE_OCC
+#define TD_FACE_OCC 3      // waves per SIMD the register allocation aims at (tools/build_variant.sh for experiments)
+#endif
 template <int DIR>
-__global__ __launch_bounds__(64) void td_face_kernel(TDArgs A) {
+__global__ __launch_bounds__(64, TD_FACE_OCC) void td_face_kernel(TDArgs A) {
   const m6::GridDev &g = A.g;
   const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
   const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
