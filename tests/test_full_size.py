@@ -165,3 +165,65 @@ def test_rk2_step_conserves_volume_and_stays_sane(world):
     eta_h = _inner(g, h.sum(0) - torch.as_tensor(np.asarray(g.bathyT), device="cuda") * g.Z_to_H)
     m = _inner(g, world["mT"]) > 0
     assert float((eta_h - _inner(g, CS.eta))[m].abs().max()) < 0.05
+
+
+@pytest.mark.gpu
+def test_lateral_parameterizations_are_overturnings_that_conserve_volume(world):
+    """thickness_diffuse and mixedlayer_restrat at full size: every face column's transports sum to zero (pure overturnings), the volume
+    of every water column and of the ocean is conserved, land faces carry nothing, uhtr / vhtr are the transports times dt, and the
+    restratification moves nothing below the deepest mixed layer"""
+    import torch
+    from mom6_amd.mixedlayer_restrat import mixedlayer_restrat, mixedlayer_restrat_init
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.thickness_diffuse import thickness_diffuse, thickness_diffuse_init
+    g, dg, d = world["g"], world["dg"], world["dyn"]
+    eos = EOS_init("WRIGHT")
+    dt = 3600.0
+    A = _inner(g, world["areaT"])[None]
+    sh2 = tuple(d["h"].shape[1:])
+    yy = torch.linspace(0.0, 1.0, sh2[0], device="cuda", dtype=torch.float64)[:, None].expand(sh2).contiguous()
+    h0 = d["h"]
+    col0 = (_inner(g, h0) * A).sum(0)
+    # ---- thickness_diffuse (KHTH with a maximum, MEKE%Kh)
+    h, uhtr, vhtr = h0.clone(), torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
+    uhGM, vhGM = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
+    td = thickness_diffuse_init(dg, THICKNESSDIFFUSE=True, KHTH=300.0, KHTH_MAX=900.0, MEKE_KHTH_FAC=0.5)
+    thickness_diffuse(h, uhtr, vhtr, (d["T"], d["S"], eos), dt, dg, dict(Kh=(600.0 * yy * world["mT"]).contiguous()), None, dict(uhGM=uhGM, vhGM=vhGM), td)
+    dg.sync()
+    for q, m, pos in ((uhGM, world["mu"], U), (vhGM, world["mv"], V)):
+        qi = _inner(g, q, pos)
+        assert bool(torch.isfinite(qi).all()) and float(qi.abs().max()) > 0.0
+        assert float((qi.sum(0).abs() / (qi.abs().sum(0) + 1e-30)).max()) < 1e-10      # the column's transports cancel
+        assert float((qi * (1.0 - _inner(g, m, pos))[None]).abs().max()) == 0.0           # nothing through land
+    assert torch.equal(uhtr, uhGM * dt) and torch.equal(vhtr, vhGM * dt)
+    col1 = (_inner(g, h) * A).sum(0)
+    assert float(((col1 - col0).abs() / (col0.abs() + 1.0)).max()) < 1e-12 and float(_inner(g, h).min()) >= g.Angstrom_H
+    assert abs(float(col1.sum()) - float(col0.sum())) <= 1e-13 * float(col0.sum())
+    # ---- mixedlayer_restrat (OM4's settings: the boundary-layer depth, both running means, the frontal length scale)
+    mld = (20.0 + 80.0 * yy).contiguous()
+    mle = mixedlayer_restrat_init(dg, FOX_KEMPER_ML_RESTRAT_COEF=1.0, FOX_KEMPER_ML_RESTRAT_COEF2=0.5, MLE_FRONT_LENGTH=500.0, MLE_USE_PBL_MLD=True,
+                                  MLE_MLD_DECAY_TIME=345600.0, MLE_MLD_DECAY_TIME2=5184000.0, MLD_filtered=torch.zeros_like(yy),
+                                  MLD_filtered_slow=torch.zeros_like(yy))
+    h2, u2, v2 = h.clone(), torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
+    uhml, vhml = torch.zeros_like(d["u"]), torch.zeros_like(d["v"])
+    mixedlayer_restrat(h2, u2, v2, (d["T"], d["S"], eos), dict(ustar=(0.005 + 0.01 * yy).contiguous()), dt, None, mld, None,
+                       dict(Rd_dx_h=(0.2 + 1.5 * yy).contiguous()), dg, mle, uhml, vhml)
+    dg.sync()
+    for q, pos in ((uhml, U), (vhml, V)):
+        qi = _inner(g, q, pos)
+        assert bool(torch.isfinite(qi).all()) and float(qi.abs().max()) > 0.0
+        assert float((qi.sum(0).abs() / (qi.abs().sum(0) + 1e-30)).max()) < 1e-10
+    assert torch.equal(u2, uhml * dt) and torch.equal(v2, vhml * dt)
+    col2 = (_inner(g, h2) * A).sum(0)
+    assert float(((col2 - col1).abs() / (col1.abs() + 1.0)).max()) < 1e-12
+    # the running means took the boundary-layer depth (they start from zero) and nothing moved where every layer lies below it
+    assert torch.equal(mle.MLD_filtered[g.csl(H)], mld[g.csl(H)])
+    # (a layer's position in the mixed layer is taken at the FACES, from the mean of the two columns: it lies below the deepest mixed
+    # layer, 100 m, at all four faces of a cell if its top does in the cell and in its four neighbours)
+    ztop = torch.cumsum(_inner(g, h), 0) - _inner(g, h)      # depth of the top of each layer
+    zmin = ztop.clone()
+    for sh, ax in ((1, -1), (-1, -1), (1, -2), (-1, -2)):
+        zmin = torch.minimum(zmin, torch.roll(ztop, sh, ax))
+    deep = zmin > 1.05 * 100.0 + 1.0
+    assert float(deep.double().mean()) > 0.3
+    assert float(((_inner(g, h2) - _inner(g, h)).abs() * deep).max()) == 0.0
