@@ -137,7 +137,7 @@ def test_tripolar_fold_in_the_native_exchange():
     dg.close()
 
 
-def _three_viscous_steps(g, dg, poison=None):
+def _three_viscous_steps(g, dg, poison=None, continuity=None):
     """three steps of step_MOM_dyn_split_RK2 with vertical and horizontal viscosity on the device grid dg against the oracle on g"""
     import torch
     from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
@@ -148,12 +148,13 @@ def _three_viscous_steps(g, dg, poison=None):
     hv = dict(Laplacian=1, Kh_vel_scale=0.01, Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06)
     hvn = dict(LAPLACIAN=1, KH_VEL_SCALE=0.01, AH_VEL_SCALE=0.05, SMAGORINSKY_AH=1, SMAG_BI_CONST=0.06)
     ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0),
-                       visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **hv))
+                       visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, **hv), continuity=continuity)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
     Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
     uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
-    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0), hor_visc=hvn)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0), hor_visc=hvn,
+                                  continuity=continuity)
     if poison is not None:
         dg.debug_poison_passes(**poison)
     visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
@@ -209,6 +210,19 @@ def test_nothing_reads_a_halo_while_its_pass_is_in_flight(mode):
     dg = DeviceGrid(g)
     _three_viscous_steps(g, dg, poison=dict(poison="poison" in mode, split_rows="split" in mode))
     # per step: two row-split groups (after pass_hp_uv, after pass_h + pass_av_uvh) and the three continuity calls in two phases
+    assert dg.overlap_stats() == (3 * 2, 3 * 3, 0, 0)
+    dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(simple_2nd=True), dict(upwind_1st=True), dict(monotonic=True)], ids=["simple_2nd", "upwind_1st", "monotonic"])
+def test_two_phase_continuity_with_the_other_stencils(opts):
+    """the two phases follow the continuity's stencil (3 rows for PPM, 2 for SIMPLE_2ND_PPM_CONTINUITY, 1 for UPWIND_1ST_CONTINUITY): with
+    every halo in flight poisoned, three viscous steps are the oracle's bits for each of them"""
+    from mom6_amd.tracer_advect import DeviceGrid
+    g = xs.make_grid(44, 40, 4, land_frac=0.0, reentrant_x=True, reentrant_y=True)
+    dg = DeviceGrid(g)
+    _three_viscous_steps(g, dg, poison=dict(poison=True, split_rows=True), continuity=opts)
     assert dg.overlap_stats() == (3 * 2, 3 * 3, 0, 0)
     dg.close()
 
