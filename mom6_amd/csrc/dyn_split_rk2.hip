@@ -589,9 +589,12 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   } else if (VV) {
     CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));            // :748, :752
-  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :758
-                          u_av, v_av, BTC, nullptr, nullptr, D));
+  // pass_visc_rem, pass_uvp :748, :752 in flight behind the continuity's own rows, as in the RK2 stepping (continuity_around_pass)
+  CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz, 1));
+  CALL(continuity_around_pass(ctx, [&]() -> int {
+    return mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :758
+                              u_av, v_av, BTC, nullptr, nullptr, D);
+  }));
   CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :764
   set_h_av();                                                                                         // :780-782
   CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :790
@@ -620,9 +623,11 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   } else if (VV) {
     CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
   }
-  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));     // :967, :971
-  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :979
-                          cs->visc_rem_v, u_av, v_av, nullptr, cs->du_av_inst, cs->dv_av_inst, D));
+  CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz, 3));     // :967, :971
+  CALL(continuity_around_pass(ctx, [&]() -> int {
+    return mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :979
+                              cs->visc_rem_v, u_av, v_av, nullptr, cs->du_av_inst, cs->dv_av_inst, D);
+  }));
   CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :993
   launch3d(s, Isq - 2, Ieq + 2, js - 2, je + 2, nz, [=] __device__(int I, int j, int k) {            // :1004-1011
     const long n = g.u3(I, j, k);

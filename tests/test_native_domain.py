@@ -257,3 +257,41 @@ def test_row_split_around_the_native_exchange(poison):
     _three_viscous_steps(g, dg, poison=dict(poison=poison, split_rows=False))
     assert dg.overlap_stats() == (3 * 2, 3 * 3, 0, 0)
     dg.close()
+
+
+@pytest.mark.gpu
+def test_rk2b_continuity_in_two_phases_under_poisoned_halos():
+    """SPLIT_RK2B: the two continuity calls that follow pass_visc_rem + pass_uvp / pass_uv (MOM_dynamics_split_RK2b.F90:748-758, :967-979) run
+    in two phases around their passes as in the RK2 stepping (the last one with du_cor / dv_cor): with every halo in flight poisoned three
+    viscous steps are the oracle's bits"""
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2b, step_MOM_dyn_split_RK2b
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    g = xs.make_grid(44, 40, 4, land_frac=0.0, reentrant_x=True, reentrant_y=True)
+    d = xs.make_state(g, umax=0.1, terrain_following=True)
+    taux, tauy = xs.wind_stress(g); bbl = xs.bbl_arrays(g)
+    dt = 1800.0
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, rk2b=True, vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0),
+                       visc=orc.vertvisc_type(**bbl), hor_visc=orc.hor_visc_cs(g, dt, biharmonic=True, Smagorinsky_Ah=True, Smag_bi_const=0.06, Ah_vel_scale=0.01))
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2b(u, v, h, uh, vh, dt, dg, coriolis=dict(bound_coriolis=True), vertvisc=dict(KV=1.0e-3, HBBL=10.0),
+                                   hor_visc=dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL_SCALE=0.01))
+    dg.debug_poison_passes(poison=True, split_rows=True)
+    visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()})
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy, calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2b(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        for name, a, b in (("u_av", u, ref.u), ("v_av", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("vh", vh, ref.vh), ("uhtr", uhtr, ref.uhtr),
+                           ("du_av_inst", CS.du_av_inst, ref.arrs["du_av_inst"]), ("h_av", CS.h_av, ref.arrs["h_av"])):
+            an = a.cpu().numpy()
+            assert not np.isnan(an).any(), (n, name, "a halo was read while its pass was in flight")
+            assert bits_equal(an, b), (n, name, float(np.abs(an - b).max()))
+    assert dg.overlap_stats()[1] == 3 * 2
+    dg.close()
