@@ -32,7 +32,7 @@ use MOM_tracer_hor_diff, only : tracer_hordiff, tracer_hor_diff_init, tracer_hor
 use MOM_tracer_registry, only : tracer_registry_type
 use MOM_stochastics,     only : stochastic_CS
 use MOM_diabatic_driver, only : diabatic_CS
-use MOM_domains,         only : pass_var
+use MOM_domains,         only : pass_var, CENTER
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : vertvisc_type, thermo_var_ptrs, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, ocean_internal_state
 use MOM_verticalGrid,  only : verticalGrid_type
@@ -177,7 +177,7 @@ call get_param(pf, "MOM", "TEST_NCYCLES", ncycles, default=1)
 do nc = 1, ncycles
   ! THICKNESSDIFFUSE_FIRST (MOM.F90:1149-1181)
   call thickness_diffuse(h, uhtr, vhtr, tv, dt_therm, G, GV, US, MEKE, VarMix, CDp, TD, STOCH)
-  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(h), nk, 0, done)
+  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(h), nk, CENTER, done)
   if (.not.done) call pass_var(h, G%Domain)
   do n = 1, nsteps
     calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. (nc == 1) .and. calc_dtbt_init)
@@ -186,7 +186,7 @@ do nc = 1, ncycles
   enddo
   ! MOM.F90:1335-1338
   call mixedlayer_restrat(h, uhtr, vhtr, tv, forces, dt_therm, MLD, h_MLD, bflux, VarMix, G, GV, US, MLE)
-  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(h), nk, 0, done)
+  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(h), nk, CENTER, done)
   if (.not.done) call pass_var(h, G%Domain)
   ! step_MOM_tracer_dyn (MOM.F90:1437-1447)
   call advect_tracer(h, uhtr, vhtr, OBC, dt_therm, G, GV, US, ACS, Reg)
@@ -194,8 +194,8 @@ do nc = 1, ncycles
   uhtr(:,:,:) = 0.0 ; vhtr(:,:,:) = 0.0
   call mom6hip_mirror_zeroed(mom6hip_shared_context(G, GV), c_loc(uhtr)) ; call mom6hip_mirror_zeroed(mom6hip_shared_context(G, GV), c_loc(vhtr))
   ! pass_uv_T_S_h (MOM.F90:1713-1719): of its five fields only T and S have stale halos here (no diabatic step, no ALE in this cycle)
-  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%T), nk, 0, done) ; if (.not.done) call pass_var(tv%T, G%Domain)
-  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%S), nk, 0, done) ; if (.not.done) call pass_var(tv%S, G%Domain)
+  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%T), nk, CENTER, done) ; if (.not.done) call pass_var(tv%T, G%Domain)
+  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%S), nk, CENTER, done) ; if (.not.done) call pass_var(tv%S, G%Domain)
 enddo
 call dyn_split_RK2_sync_to_host(CS)
 call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
