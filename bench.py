@@ -169,11 +169,21 @@ class Model:
         if self.rk2b:
             step_MOM_dyn_split_RK2 = step_MOM_dyn_split_RK2b
         n = self.nstep
+        lat = getattr(self, "lateral", None)      # enable_lateral(): thickness_diffuse and mixedlayer_restrat in the cycle (not the default workload)
+        if lat and n % self.steps_per_advect == 0:      # THICKNESSDIFFUSE_FIRST (MOM.F90:1149-1181)
+            from mom6_amd.thickness_diffuse import thickness_diffuse
+            thickness_diffuse(self.h, self.uhtr, self.vhtr, (self.T, self.S, self.eos), DT_THERM, self.dg, None, None, None, lat["td"])
+            self.dg.halo_update([self.h], [0]) if self.dom.nranks == 1 else self.dom.pass_var([self.h], [0])
         if n % self.steps_per_advect == 0:      # bbl_time_int > 0: the first dynamic step of a thermodynamic cycle (MOM.F90:1200)
             from mom6_amd.set_viscosity import set_viscous_BBL
             set_viscous_BBL(self.u, self.v, self.h, (self.T, self.S, self.eos), self.visc, self.dg, self.set_visc_cs)
         step_MOM_dyn_split_RK2(self.u, self.v, self.h, (self.T, self.S), self.visc, None, DT, (self.taux, self.tauy), None, None,
                                self.uh, self.vh, self.uhtr, self.vhtr, self.eta_av, self.dg, self.CS, calc_dtbt=(n == 0))
+        if lat and (n + 1) % self.steps_per_advect == 0:      # MOM.F90:1335-1338
+            from mom6_amd.mixedlayer_restrat import mixedlayer_restrat
+            mixedlayer_restrat(self.h, self.uhtr, self.vhtr, (self.T, self.S, self.eos), dict(ustar=lat["ustar"]), DT_THERM, None, None, None, None,
+                               self.dg, lat["mle"])
+            self.dg.halo_update([self.h], [0]) if self.dom.nranks == 1 else self.dom.pass_var([self.h], [0])
         if (n + 1) % self.steps_per_advect == 0:      # step_MOM_thermo / step_MOM_tracer_dyn (src/core/MOM.F90:1438, :1662)
             tr = [self.T, self.S] + self.passive
             self.last_adv = advect_tracer(self.h, self.uhtr, self.vhtr, None, DT_THERM, self.dg, self.adv_cs, tr)
@@ -194,6 +204,17 @@ class Model:
             else:
                 self.dom.pass_var(fields, pos)
         self.nstep += 1
+
+    def enable_lateral(self, KHTH=600.0, FOX_KEMPER_ML_RESTRAT_COEF=5.0):
+        """thickness_diffuse (KHTH) before the first dynamic step and mixedlayer_restrat (MLE_DENSITY_DIFF) after the last one of every
+        thermodynamic cycle: tools/model_health.py --lateral, MOM6HIP_BENCH_LATERAL=1"""
+        from mom6_amd.mixedlayer_restrat import mixedlayer_restrat_init
+        from mom6_amd.thickness_diffuse import thickness_diffuse_init
+        rho0 = float(self.g.Rho0)
+        tx = 0.5 * (self.taux[:, 1:] + self.taux[:, :-1]); ty = 0.5 * (self.tauy[1:, :] + self.tauy[:-1, :])
+        ustar = torch.sqrt(torch.sqrt(tx * tx + ty * ty) / rho0).contiguous()      # forces%ustar from the wind stress at h points
+        self.lateral = dict(td=thickness_diffuse_init(self.dg, THICKNESSDIFFUSE=True, KHTH=KHTH),
+                            mle=mixedlayer_restrat_init(self.dg, FOX_KEMPER_ML_RESTRAT_COEF=FOX_KEMPER_ML_RESTRAT_COEF), ustar=ustar)
 
     def health(self):
         """max |u|, max |v|, min h, max |eta|, kinetic energy per unit area, the vanished fraction, any NaN -- the bench
@@ -620,6 +641,9 @@ def main():
     exchange = os.environ.get("MOM6HIP_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "python") if world > 1 else None
     M = Model(grid, dom, device, a.scheme, exchange=exchange)
     exchange = M.exchange
+    LATERAL = os.environ.get("MOM6HIP_BENCH_LATERAL", "0") == "1"      # not the default: the workload of BASELINE.json does not call them
+    if LATERAL:
+        M.enable_lateral()
     cells = NI * NJ * NK
 
     def barrier():
@@ -704,6 +728,7 @@ def main():
                     f"tracer_hordiff [KHTR={TRACER_HORDIFF['KHTR']:.0f}] + ALE regrid/remap [{REMAP_SCHEME}]",
             "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
             "not_yet_in_step": [],
+            "lateral_parameterizations_in_cycle": "thickness_diffuse [KHTH=600] + mixedlayer_restrat [FOX_KEMPER_ML_RESTRAT_COEF=5]" if LATERAL else None,
             "vertvisc": dict(VERTVISC, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)), "hor_visc": HOR_VISC, "set_visc": SET_VISC,
             "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE = 0, the default), remap of T, S + 2 tracers "
                    f"and of u, v [{REMAP_SCHEME}]",
