@@ -12,6 +12,7 @@ module MOM_set_visc
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,     only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
 use MOM_ALE,              only : ALE_CS
 use MOM_diag_mediator,    only : diag_ctrl, time_type
 use MOM_error_handler,    only : MOM_error, FATAL, WARNING
@@ -71,7 +72,7 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   type(porous_barrier_type),intent(in)    :: pbv
   type(mom6hip_vertvisc_type_t) :: cv
   type(mom6hip_eos_t), target :: eos
-  type(c_ptr) :: p_T, p_S
+  type(c_ptr) :: p_T, p_S, ctx
   integer :: rc
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(BBL): Module must be initialized before it is used.")
   if (CS%st%bottomdraglaw == 0) return      ! :307
@@ -95,9 +96,30 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   endif
   eos = CS%eos
   CS%st%Rlay = c_null_ptr ; if (allocated(CS%Rlay)) CS%st%Rlay = c_loc(CS%Rlay)
-  rc = mom6hip_set_viscous_bbl(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, &
-                               MOM6HIP_MEM_HOST)
+  ctx = mom6hip_shared_context(G, GV)
+  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: u, v, h, T, S where the step left them; visc%... where the step reads them
+    call to_dev(cv%Kv_bbl_u, size(visc%Kv_bbl_u), .true.) ; call to_dev(cv%Kv_bbl_v, size(visc%Kv_bbl_v), .true.)
+    call to_dev(cv%bbl_thick_u, size(visc%bbl_thick_u), .true.) ; call to_dev(cv%bbl_thick_v, size(visc%bbl_thick_v), .true.)
+    if (allocated(visc%Ray_u)) then
+      call to_dev(cv%Ray_u, size(visc%Ray_u), .true.) ; call to_dev(cv%Ray_v, size(visc%Ray_v), .true.)
+    endif
+    call to_dev(p_T, size(h), .false.) ; call to_dev(p_S, size(h), .false.)
+    rc = mom6hip_set_viscous_bbl(ctx, CS%st, mom6hip_mirror(ctx, c_loc(u), int(size(u), c_int64_t), .true., .false.), &
+                                 mom6hip_mirror(ctx, c_loc(v), int(size(v), c_int64_t), .true., .false.), &
+                                 mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), p_T, p_S, c_loc(eos), cv, &
+                                 MOM6HIP_MEM_DEVICE)
+  else
+    rc = mom6hip_set_viscous_bbl(ctx, CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "set_viscous_BBL")
+contains
+  !> a host pointer -> its device mirror (an input, or an in/out array the call writes)
+  subroutine to_dev(p, n, written)
+    type(c_ptr), intent(inout) :: p
+    integer,     intent(in)    :: n
+    logical,     intent(in)    :: written
+    if (c_associated(p)) p = mom6hip_mirror(ctx, p, int(n, c_int64_t), .true., written)
+  end subroutine to_dev
 end subroutine set_viscous_BBL
 
 !> Same interface as the reference set_viscous_ML (:1898): returns as the reference does without DYNAMIC_VISCOUS_ML (:2043); with it,
@@ -312,6 +334,7 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
     if (.not.allocated(visc%nkml_visc_u)) allocate(visc%nkml_visc_u(isd-1:ied,jsd:jed), source=0.0)
     if (.not.allocated(visc%nkml_visc_v)) allocate(visc%nkml_visc_v(isd:ied,jsd-1:jed), source=0.0)
   endif
+  call mom6hip_read_resident(param_file)
   call mom6hip_read_topology(param_file)
 contains
   subroutine refuse(on, name)

@@ -155,7 +155,7 @@ if (dtbt_in <= 0.0) call get_param(pf, "MOM", "DTBT_RESET_PERIOD", dtbt_reset_pe
 rc = mom6hip_transfer_stats(mom6hip_shared_context(G, GV), xfer, 1_c_int32_t)
 
 do n = 1, nsteps
-  if (bbl_each_step .and. (n > 1) .and. .not.resident) then      ! (needs the host's u, v, h: only without GPU_RESIDENT_DYNAMICS)
+  if (bbl_each_step .and. (n > 1)) then      ! (resident: on the device mirrors of u, v, h, T, S)
     call set_viscous_BBL(u, v, h, tv, visc, G, GV, US, SV, pbv)
   endif
   calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. calc_dtbt_init)

@@ -373,8 +373,7 @@ def test_reference_named_driver_with_the_testing_sets_matches_oracle_bitwise(tmp
     assert "dyn_driver ok" in r.stdout
     st, calc, _ = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
     for n in range(nsteps):
-        if n == 0 or not resident:      # set_viscous_BBL works on the host's u, v, h: with the fields resident, only before the first step
-            st.bbl()
+        st.bbl()      # set_viscous_BBL before every step (resident: on the device mirrors of u, v, h, T, S, its results straight into the step's)
         st.step(taux, tauy, calc_dtbt=calc(n))
     got = read_out(str(tmp_path / "out.bin"), g, meke=st.mom_src is not None)
     want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
@@ -395,7 +394,9 @@ def test_reference_named_driver_with_the_testing_sets_matches_oracle_bitwise(tmp
     n3 = int(np.prod(g.shape3(_abi.POS_H)))
     if resident:
         # one upload of each input (u, v, h are already there from the initialisation), one download of each output and restart field
-        assert stats["h2d_calls"] <= 16 and stats["d2h_calls"] <= 24, stats
+        # (the six arrays set_viscous_BBL writes -- Kv_bbl_u/v, bbl_thick_u/v, with CHANNEL_DRAG Ray_u/v -- are device-side now: no upload,
+        # one download each at the end)
+        assert stats["h2d_calls"] <= 16 and stats["d2h_calls"] <= 30, stats
         # (independent of the number of steps: T, S, uhtr, vhtr, with CHANNEL_DRAG visc%Ray_u/v, and the 2-D forcing / visc fields
         # go up once; 7 fields + 8 restart fields and a few 2-D ones come down once)
         n2 = n3 // g.nk
