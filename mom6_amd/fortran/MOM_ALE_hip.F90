@@ -13,7 +13,7 @@ module MOM_ALE
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,    only : mom6hip_shared_context, mom6hip_fatal_if
+use mom6hip_MOM_glue,    only : mom6hip_shared_context, mom6hip_fatal_if, mom6hip_mirror_require_host_current
 use MOM_error_handler,   only : MOM_error, FATAL, WARNING
 use MOM_file_parser,     only : get_param, log_version, param_file_type
 use MOM_grid,            only : ocean_grid_type
@@ -238,6 +238,7 @@ subroutine ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, CS, frac_shelf_h, PCM_c
   rcs%min_thickness = CS%min_thickness ; rcs%old_grid_weight = CS%old_grid_weight
   rcs%depth_of_time_filter_shallow = CS%filter_shallow_depth ; rcs%depth_of_time_filter_deep = CS%filter_deep_depth
   rcs%Z_ref = G%Z_ref ; rcs%coordinateResolution = c_loc(res)
+  call mom6hip_mirror_require_host_current(c_loc(h), "ALE_regrid")
   rc = mom6hip_ale_regrid(mom6hip_shared_context(G, GV), rcs, c_loc(h), c_loc(h_new), c_loc(dzRegrid), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "ALE_regrid")
 end subroutine ALE_regrid
@@ -269,6 +270,8 @@ subroutine ALE_remap_tracers(CS, G, GV, h_old, h_new, Reg, debug, dt, PCM_cell)
   enddo
   mcs%remapping_scheme = CS%remap_scheme ; mcs%boundary_extrapolation = merge(1, 0, CS%boundary_extrapolation)
   mcs%force_bounds_in_subcell = 0 ; mcs%answer_date = CS%answer_date
+  call mom6hip_mirror_require_host_current(c_loc(h_old), "ALE_remap_tracers")
+  do m=1,Reg%ntr ; call mom6hip_mirror_require_host_current(tr(m), "ALE_remap_tracers") ; enddo
   rc = mom6hip_ale_remap_tracers(mom6hip_shared_context(G, GV), mcs, c_loc(h_old), c_loc(h_new), tr, c_loc(cu), &
                                  int(ntr, c_int32_t), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "ALE_remap_tracers")
@@ -327,6 +330,7 @@ subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u
   integer :: rc
   mcs%remapping_scheme = CS%vel_remap_scheme ; mcs%boundary_extrapolation = merge(1, 0, CS%boundary_extrapolation)
   mcs%force_bounds_in_subcell = 0 ; mcs%answer_date = CS%answer_date
+  call mom6hip_mirror_require_host_current(c_loc(u), "ALE_remap_velocities") ; call mom6hip_mirror_require_host_current(c_loc(v), "ALE_remap_velocities")
   rc = mom6hip_ale_remap_velocities(mom6hip_shared_context(G, GV), mcs, c_loc(h_old_u), c_loc(h_old_v), c_loc(h_new_u), &
                                     c_loc(h_new_v), c_loc(u), c_loc(v), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "ALE_remap_velocities")

@@ -29,7 +29,7 @@ public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6h
 ! the device mirrors of the host's arrays, shared by every module shim (GPU_RESIDENT_DYNAMICS)
 public :: mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirrors_stage, mom6hip_mirrors_to_host
 public :: mom6hip_mirrors_host_was_modified, mom6hip_mirror_host_changed, mom6hip_mirror_zeroed, mom6hip_mirrors_end
-public :: mom6hip_mirror_pass_var
+public :: mom6hip_mirror_pass_var, mom6hip_mirror_require_host_current
 
 integer, parameter :: MAX_MIRRORS = 160
 !> A host array of the caller and its copy in HBM
@@ -200,6 +200,20 @@ subroutine mom6hip_mirror_pass_var(ctx, hp, nk, position, done)
     done = .true.
   endif ; enddo
 end subroutine mom6hip_mirror_pass_var
+
+!> A shim that works on HOST arrays is about to read the array at hp: stop if the device holds a newer copy of it (the caller forgot
+!! dyn_split_RK2_sync_to_host / mom6hip_mirrors_to_host), instead of computing from stale values
+subroutine mom6hip_mirror_require_host_current(hp, who)
+  type(c_ptr),      intent(in) :: hp
+  character(len=*), intent(in) :: who
+  integer :: m
+  do m = 1, nmir ; if (c_associated(mir(m)%h, hp) .and. .not.mir(m)%host_current) then
+    call MOM_error(FATAL, trim(who)//" (HIP): the device holds a newer copy of an array this call reads on the host; "// &
+                   "call dyn_split_RK2_sync_to_host (mom6hip_mirrors_to_host) first (GPU_RESIDENT_DYNAMICS).")
+  endif ; enddo
+end subroutine mom6hip_mirror_require_host_current
+
+!> The host has changed fields after such a call (ALE remapping ...): mom6hip_mirrors_host_was_modified / mom6hip_mirror_host_changed.
 
 !> Free the mirrors (the last *_end of the run)
 subroutine mom6hip_mirrors_end()
