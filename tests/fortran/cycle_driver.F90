@@ -1,6 +1,6 @@
 !> Drives ONE THERMODYNAMIC CYCLE of step_MOM's hot sequence through the module shims, reference-named procedures only (MOM.F90:1149-1165,
 !! :1205-1260, :1335-1338, :1437-1447), ncycles times:
-!!   thickness_diffuse -> pass_var(h) -> nsteps x step_MOM_dyn_split_RK2 -> mixedlayer_restrat -> pass_var(h) -> advect_tracer (T, S)
+!!   thickness_diffuse -> pass_var(h) -> set_viscous_BBL -> nsteps x step_MOM_dyn_split_RK2 -> mixedlayer_restrat -> pass_var(h) -> advect_tracer (T, S)
 !!   -> tracer_hordiff (T, S) -> uhtr = vhtr = 0
 !! With GPU_RESIDENT_DYNAMICS = True the fields stay in HBM through all of it: the pass_var between the calls runs on the device copies
 !! (mom6hip_mirror_pass_var), the zeroing of uhtr / vhtr is announced (mom6hip_mirror_zeroed), and the host sees the fields after
@@ -179,6 +179,7 @@ do nc = 1, ncycles
   call thickness_diffuse(h, uhtr, vhtr, tv, dt_therm, G, GV, US, MEKE, VarMix, CDp, TD, STOCH)
   call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(h), nk, CENTER, done)
   if (.not.done) call pass_var(h, G%Domain)
+  call set_viscous_BBL(u, v, h, tv, visc, G, GV, US, SV, pbv)      ! the first dynamic step of a thermodynamic cycle (MOM.F90:1200-1207)
   do n = 1, nsteps
     calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. (nc == 1) .and. calc_dtbt_init)
     call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, &

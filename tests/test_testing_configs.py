@@ -432,7 +432,7 @@ def build_cycle_driver(tmp):
 
 
 def cycle_oracle(name, state, ncycles, nsteps):
-    """the same sequence on the oracle: thickness_diffuse, pass h, nsteps RK2 steps, mixedlayer_restrat, pass h, advect_tracer and
+    """the same sequence on the oracle: thickness_diffuse, pass h, set_viscous_BBL, nsteps RK2 steps, mixedlayer_restrat, pass h, advect_tracer and
     tracer_hordiff of T and S, uhtr = vhtr = 0, pass T and S"""
     from oracle import orc
     g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
@@ -445,6 +445,7 @@ def cycle_oracle(name, state, ncycles, nsteps):
     for nc in range(ncycles):
         orc.thickness_diffuse(g, tdcs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, dt_therm)
         orc.halo_update(g, st.h, H)
+        st.bbl()
         for n in range(nsteps):
             st.step(taux, tauy, calc_dtbt=calc(n))
         orc.mixedlayer_restrat(g, mlecs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, ustar, dt_therm)
@@ -466,7 +467,7 @@ def test_the_cycle_driver_compiles(tmp_path):
 @pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
 @pytest.mark.parametrize("resident", [False, True])
 def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_path, resident):
-    """thickness_diffuse -> step_MOM_dyn_split_RK2 x (DT_THERM / DT) -> mixedlayer_restrat -> advect_tracer -> tracer_hordiff, twice, from a
+    """thickness_diffuse -> set_viscous_BBL -> step_MOM_dyn_split_RK2 x (DT_THERM / DT) -> mixedlayer_restrat -> advect_tracer -> tracer_hordiff, twice, from a
     Fortran program that calls reference-named procedures only, with the .testing/tc4 parameter set: u, v, h, T, S and the transports equal
     the oracle's bit for bit; with GPU_RESIDENT_DYNAMICS the fields cross PCIe once in each direction, whatever the number of cycles"""
     name = "tc4"
@@ -477,7 +478,7 @@ def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_pat
     p = pairs_of("tc4c")
     nsteps = int(round(float(p["DT_THERM"]) / float(p["DT"])))
     want = cycle_oracle("tc4c", state, 2, nsteps)
-    write_case(tmp_path, "tc4c", nsteps, resident, state)
+    write_case(tmp_path, "tc4c", nsteps, resident, state, bbl_mode=1)
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
     assert r.returncode == 0 and "cycle_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
