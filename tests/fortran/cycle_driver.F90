@@ -9,9 +9,10 @@
 program cycle_driver
 use, intrinsic :: iso_c_binding
 use MOM_dynamics_split_RK2, only : MOM_dyn_split_RK2_CS, register_restarts_dyn_split_RK2, initialize_dyn_split_RK2
-use MOM_dynamics_split_RK2, only : step_MOM_dyn_split_RK2, end_dyn_split_RK2, dyn_split_RK2_sync_to_host
+use MOM_dynamics_split_RK2, only : step_MOM_dyn_split_RK2, end_dyn_split_RK2, dyn_split_RK2_sync_to_host, dyn_split_RK2_host_was_modified
 use MOM_set_visc,      only : set_visc_CS, set_visc_init, set_viscous_BBL, set_visc_end
-use MOM_ALE,           only : ALE_CS
+use MOM_ALE,           only : ALE_CS, ALE_init, ALE_set_extrap_boundaries, ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers
+use MOM_ALE,           only : ALE_remap_set_h_vel, ALE_remap_velocities, ALE_end
 use MOM_boundary_update, only : update_OBC_CS
 use MOM_diag_mediator, only : diag_ctrl
 use MOM_time_manager,  only : time_type
@@ -32,7 +33,7 @@ use MOM_tracer_hor_diff, only : tracer_hordiff, tracer_hor_diff_init, tracer_hor
 use MOM_tracer_registry, only : tracer_registry_type
 use MOM_stochastics,     only : stochastic_CS
 use MOM_diabatic_driver, only : diabatic_CS
-use MOM_domains,         only : pass_var, CENTER
+use MOM_domains,         only : pass_var, CENTER, EAST_FACE, NORTH_FACE
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : vertvisc_type, thermo_var_ptrs, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, ocean_internal_state
 use MOM_verticalGrid,  only : verticalGrid_type
@@ -71,7 +72,9 @@ type(stochastic_CS) :: STOCH
 type(diabatic_CS), pointer :: diabatic_CSp => NULL()
 type(EOS_type), target :: EOS
 real, dimension(:,:), pointer :: MLD => NULL(), h_MLD => NULL(), bflux => NULL()
-integer :: nc, ncycles
+integer :: nc, ncycles, i, j, k
+logical :: test_ALE
+real, allocatable, target, dimension(:,:,:) :: h_new, dzRegrid, hu0, hv0, hu1, hv1
 type(ocean_OBC_type), pointer :: OBC => NULL()
 type(update_OBC_CS), pointer :: update_OBC_CSp => NULL()
 type(ALE_CS), pointer :: ALE_CSp => NULL()
@@ -124,7 +127,6 @@ allocate(u(isd-1:ied,jsd:jed,nk), v(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk)
 allocate(GV%Rlay(nk), GV%g_prime(nk+1))
 read(u_in) u, v, h, tv%T, tv%S, forces%taux, forces%tauy, forces%ustar, GV%Rlay, GV%g_prime
 if (hdr2(3) /= 0) allocate(tv%eqn_of_state)      ! an equation of state is in use
-if (hdr2(4) /= 0) allocate(ALE_CSp)              ! USE_REGRIDDING
 allocate(uh(isd-1:ied,jsd:jed,nk), vh(isd:ied,jsd-1:jed,nk), uhtr(isd-1:ied,jsd:jed,nk), vhtr(isd:ied,jsd-1:jed,nk), &
          eta(isd:ied,jsd:jed), eta_av(isd:ied,jsd:jed), nk_u(isd-1:ied,jsd:jed), nk_v(isd:ied,jsd-1:jed))
 uh = 0.0 ; vh = 0.0 ; uhtr = 0.0 ; vhtr = 0.0 ; eta = 0.0 ; eta_av = 0.0 ; nk_u = 0.0 ; nk_v = 0.0
@@ -142,6 +144,15 @@ do
 enddo
 close(u_par)
 
+if (hdr2(4) /= 0) then                           ! USE_REGRIDDING: ALE_init (MOM.F90:2772), REMAP_BOUNDARY_EXTRAP after the initialisation (:3136)
+  call ALE_init(pf, GV, US, G%max_depth, ALE_CSp) ; call ALE_set_extrap_boundaries(pf, ALE_CSp)
+endif
+call get_param(pf, "MOM", "TEST_ALE", test_ALE, default=.false.)
+if (test_ALE) then
+  allocate(h_new(isd:ied,jsd:jed,nk), dzRegrid(isd:ied,jsd:jed,nk+1), hu0(isd-1:ied,jsd:jed,nk), hv0(isd:ied,jsd-1:jed,nk), &
+           hu1(isd-1:ied,jsd:jed,nk), hv1(isd:ied,jsd-1:jed,nk))
+  h_new = 0.0 ; dzRegrid = 0.0 ; hu0 = 0.0 ; hv0 = 0.0 ; hu1 = 0.0 ; hv1 = 0.0
+endif
 ! ---- MOM.F90's initialisation order for these modules
 call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
 ! the two lateral parameterisations beside the step accept the same parameter file (MOM.F90:2854, :3305-3313)
@@ -194,9 +205,25 @@ do nc = 1, ncycles
   call tracer_hordiff(h, dt_therm, MEKE, VarMix, visc, G, GV, US, DCS, Reg, tv)
   uhtr(:,:,:) = 0.0 ; vhtr(:,:,:) = 0.0
   call mom6hip_mirror_zeroed(mom6hip_shared_context(G, GV), c_loc(uhtr)) ; call mom6hip_mirror_zeroed(mom6hip_shared_context(G, GV), c_loc(vhtr))
-  ! pass_uv_T_S_h (MOM.F90:1713-1719): of its five fields only T and S have stale halos here (no diabatic step, no ALE in this cycle)
-  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%T), nk, CENTER, done) ; if (.not.done) call pass_var(tv%T, G%Domain)
-  call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%S), nk, CENTER, done) ; if (.not.done) call pass_var(tv%S, G%Domain)
+  if (test_ALE) then
+    ! step_MOM_thermo's ALE block (MOM.F90:1647-1700) works on the HOST arrays (MOM_ALE_hip.F90 stages them per call): the host asks for
+    ! the fields first and announces afterwards that it has changed them -- what a diabatic step on the host needs as well
+    call dyn_split_RK2_sync_to_host(CS) ; call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
+    call ALE_update_regrid_weights(dt_therm, ALE_CSp)
+    call ALE_regrid(G, GV, US, h, h_new, dzRegrid, tv, ALE_CSp)
+    call ALE_remap_tracers(ALE_CSp, G, GV, h, h_new, Reg)
+    call ALE_remap_set_h_vel(ALE_CSp, G, GV, h, hu0, hv0, OBC)
+    call ALE_remap_set_h_vel(ALE_CSp, G, GV, h_new, hu1, hv1, OBC)
+    call ALE_remap_velocities(ALE_CSp, G, GV, hu0, hv0, hu1, hv1, u, v)
+    do k=1,nk ; do j=G%jsc-1,G%jec+1 ; do i=G%isc-1,G%iec+1 ; h(i,j,k) = h_new(i,j,k) ; enddo ; enddo ; enddo      ! :1694-1698
+    call dyn_split_RK2_host_was_modified(CS)
+    call pass_var(u, G%Domain, position=EAST_FACE) ; call pass_var(v, G%Domain, position=NORTH_FACE)      ! pass_uv_T_S_h :1713-1719
+    call pass_var(tv%T, G%Domain) ; call pass_var(tv%S, G%Domain) ; call pass_var(h, G%Domain)
+  else
+    ! pass_uv_T_S_h (MOM.F90:1713-1719): of its five fields only T and S have stale halos here (no diabatic step, no ALE in this cycle)
+    call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%T), nk, CENTER, done) ; if (.not.done) call pass_var(tv%T, G%Domain)
+    call mom6hip_mirror_pass_var(mom6hip_shared_context(G, GV), c_loc(tv%S), nk, CENTER, done) ; if (.not.done) call pass_var(tv%S, G%Domain)
+  endif
 enddo
 call dyn_split_RK2_sync_to_host(CS)
 call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))

@@ -416,10 +416,24 @@ CYCLE_PAIRS = """
         """
 
 
+CYCLE_ALE_PAIRS = """
+        TEST_ALE = True
+        REMAPPING_SCHEME = "PPM_H4"
+        VELOCITY_REMAPPING_SCHEME = "PLM"
+        REMAP_UV_USING_OLD_ALG = False
+        REGRID_TIME_SCALE = 3600.0
+        REGRID_FILTER_DEEP_DEPTH = 500.0
+        REMAP_BOUNDARY_EXTRAP = True
+        INIT_BOUNDARY_EXTRAP = False
+        """
+
+
 def build_cycle_driver(tmp):
     flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
     objs = []
-    srcs = [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in SHIMS] + \
+    # (MOM_ALE right after the glue: its ALE_CS replaces the type-only stand-in before any module that takes one is compiled)
+    shims = SHIMS[:2] + ["MOM_ALE_hip.F90"] + SHIMS[2:]
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(FDIR, s) for s in shims] + \
            [os.path.join(FDIR, "MOM_dynamics_split_RK2_hip.F90"), os.path.join(ROOT, "tests", "fortran", "cycle_driver.F90")]
     for src in srcs:
         o = str(tmp / (os.path.basename(src)[:-4] + ".o"))
@@ -453,6 +467,19 @@ def cycle_oracle(name, state, ncycles, nsteps):
         orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, dt_therm, dt, "PPM:H3", [st.T, st.S])
         orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0)
         st.uhtr[:] = 0.0; st.vhtr[:] = 0.0
+        if _b(p, "TEST_ALE"):      # the ALE block of step_MOM_thermo (MOM.F90:1647-1700) with the parameters of CYCLE_ALE_PAIRS
+            ts = float(p["REGRID_TIME_SCALE"])
+            rcs = orc.regridding_cs(np.full(g.nk, float(g.bathyT.max()) / g.nk), min_thickness=1.0e-3, old_grid_weight=ts / (ts + dt_therm), zs=0.0,
+                                    zd=float(p["REGRID_FILTER_DEEP_DEPTH"]))
+            h_new, _ = orc.ale_regrid(g, rcs, st.h)
+            orc.ale_remap_tracers(g, p["REMAPPING_SCHEME"], st.h, h_new, [st.T, st.S], boundary_extrapolation=True)
+            hu0, hv0 = orc.ale_remap_set_h_vel(g, st.h)
+            hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
+            orc.ale_remap_velocities(g, p["VELOCITY_REMAPPING_SCHEME"], hu0, hv0, hu1, hv1, st.u, st.v, boundary_extrapolation=True)
+            sj, si = g.csl(H)
+            sj, si = slice(sj.start - 1, sj.stop + 1), slice(si.start - 1, si.stop + 1)
+            st.h[:, sj, si] = h_new[:, sj, si]
+            orc.halo_update(g, st.u, _abi.POS_U); orc.halo_update(g, st.v, _abi.POS_V); orc.halo_update(g, st.h, H)
         orc.halo_update(g, st.T, H); orc.halo_update(g, st.S, H)
     return st
 
@@ -466,12 +493,16 @@ def test_the_cycle_driver_compiles(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
 @pytest.mark.parametrize("resident", [False, True])
-def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_path, resident):
+@pytest.mark.parametrize("with_ALE", [False, True], ids=["no_ALE", "ALE"])
+def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_path, resident, with_ALE):
     """thickness_diffuse -> set_viscous_BBL -> step_MOM_dyn_split_RK2 x (DT_THERM / DT) -> mixedlayer_restrat -> advect_tracer -> tracer_hordiff, twice, from a
     Fortran program that calls reference-named procedures only, with the .testing/tc4 parameter set: u, v, h, T, S and the transports equal
     the oracle's bit for bit; with GPU_RESIDENT_DYNAMICS the fields cross PCIe once in each direction, whatever the number of cycles"""
     name = "tc4"
-    TC_INPUT["tc4c"] = dict(shape=TC_INPUT[name]["shape"], pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS)
+    # with_ALE: six layers, and after the tracers the ALE block on the host arrays between dyn_split_RK2_sync_to_host and
+    # dyn_split_RK2_host_was_modified (z* regrid with a time scale, PPM_H4 / PLM remapping of T, S, u, v)
+    TC_INPUT["tc4c"] = dict(shape=(14, 10, 6) if with_ALE else TC_INPUT[name]["shape"],
+                            pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS + (CYCLE_ALE_PAIRS if with_ALE else ""))
     exe = build_cycle_driver(tmp_path)
     state = case_state("tc4c")
     g = state[0]
@@ -491,6 +522,6 @@ def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_pat
     assert bits_equal(interior(g, T_), interior(g, want.T)) and bits_equal(interior(g, S_), interior(g, want.S))
     assert np.all(got["uhtr"] == 0.0) and np.all(got["vhtr"] == 0.0)
     stats = {w.split("=")[0]: int(w.split("=")[1]) for w in r.stdout.split() if "=" in w}
-    if resident:
+    if resident and not with_ALE:
         n2 = n3 // g.nk
         assert stats["h2d_bytes"] <= 8 * (10 * n3 + 30 * n2) * 1.25 and stats["d2h_bytes"] <= 8 * (20 * n3 + 20 * n2) * 1.25, stats
