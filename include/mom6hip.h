@@ -831,7 +831,9 @@ int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, 
  * Visbeck form) + MEKE%KhTr_fac * sqrt(MEKE%Kh(i) * MEKE%Kh(i+1)), limited by KHTR_MAX, times the mean of VarMix%Res_fn_h
  * (RESOLN_SCALED_KHTR), floored by KHTR_MIN, and the passivity factor max(KHTR_PASSIVITY_MIN, KHTR_PASSIVITY_COEFF * Rd/dx): the
  * fields come in mom6hip_hordiff_fields_t through mom6hip_tracer_hordiff_varmix.
- * Not provided (refused by name, any nonzero `unsupported`): USE_NEUTRAL_DIFFUSION, USE_HORIZONTAL_BOUNDARY_DIFFUSION,
+ * USE_NEUTRAL_DIFFUSION (unsupported[0]) is taken by mom6hip_tracer_hordiff_neutral with its own control structure, and refused by
+ * the two entry points that have none.
+ * Not provided (refused by name, any nonzero `unsupported`): USE_HORIZONTAL_BOUNDARY_DIFFUSION,
  * DIFFUSE_ML_TO_INTERIOR (tracer_epipycnal_ML_diff), KHTR_USE_EBT_STRUCT, offline khdt arrays, the df_x / df_y flux diagnostics.
  */
 typedef struct mom6hip_tracer_hor_diff_cs {
@@ -878,6 +880,36 @@ int mom6hip_tracer_hordiff(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_
 int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_hordiff_fields_t *fields,
                                   const double *h, double dt, double *const *tr, const double *conc_underflow, int32_t ntr,
                                   int32_t memspace, mom6hip_hordiff_stats_t *stats);
+
+/*
+ * neutral_diffusion_CS, src/tracer/MOM_neutral_diffusion.F90:38-120, as set by neutral_diffusion_init (:138-330).
+ * Provided: NDIFF_CONTINUOUS = True (the default): interface values of T and S by the PPM edge formula (interface_scalar :1078),
+ * their density derivatives at the interface pressure (or NDIFF_REF_PRES), find_neutral_surface_positions_continuous (:1353),
+ * neutral_surface_flux (:2297) and the update of every tracer (:605-1019), for both values of NDIFF_ANSWER_DATE.
+ * Not provided (refused by name, any nonzero `unsupported`): NDIFF_CONTINUOUS = False (the discontinuous reconstructions),
+ * NDIFF_INTERIOR_ONLY / NDIFF_TAPERING, KHTR_USE_EBT_STRUCT, NDIFF_USE_UNMASKED_TRANSPORT_BUG, the flux / tendency diagnostics.
+ */
+typedef struct mom6hip_neutral_diffusion_cs {
+  double ref_pres;             /* NDIFF_REF_PRES [R L2 T-2] (-1, the default: the pressure of the interface) */
+  double H_to_RZ;              /* GV%H_to_RZ (with GV%g_Earth of the grid: interface pressures, and hEff back to H) */
+  double reserved0[4];
+  int32_t ndiff_answer_date;   /* NDIFF_ANSWER_DATE (20240101): > 20240330 sums the four faces' tendencies symmetrically */
+  int32_t recalc_neutral_surf; /* tracer_hor_diff_CS%recalc_neutral_surf, RECALC_NEUTRAL_SURF (0) */
+  int32_t initialized;
+  int32_t reserved_i[1];
+  int32_t unsupported[8];      /* .not.continuous_reconstruction, interior_only, tapering, KhTh_use_ebt_struct,
+                                  use_unmasked_transport_bug, diagnostics, (free), (free) */
+} mom6hip_neutral_diffusion_cs_t;
+
+/* tracer_hordiff with cs->unsupported[0] (CS%use_neutral_diffusion) set: the branch :474-534.  tr[idx_T] and tr[idx_S] are tv%T
+ * and tv%S (in the reference they are registered tracers, Reg%Tr(:)%t => tv%T, and are diffused with the others); eos is
+ * tv%eqn_of_state, p_surf tv%p_surf (NULL: not associated).  nd may be NULL when cs->unsupported[0] is 0: the call above.
+ * The reference's `stop` in ppm_ave (a neutral layer spanning more than one cell, :1186-1189) is returned as an error. */
+int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs,
+                                   const mom6hip_neutral_diffusion_cs_t *nd, const mom6hip_hordiff_fields_t *fields,
+                                   const double *h, const mom6hip_eos_t *eos, const double *p_surf, double dt, double *const *tr,
+                                   const double *conc_underflow, int32_t ntr, int32_t idx_T, int32_t idx_S, int32_t memspace,
+                                   mom6hip_hordiff_stats_t *stats);
 
 /* ---- MOM_hor_visc ----------------------------------------------------------------------------- */
 

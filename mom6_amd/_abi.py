@@ -170,6 +170,12 @@ class HorDiffFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in HORDIFF_FIELDS] + [("reserved", C.c_void_p * 5)]
 
 
+class NeutralDiffusionCS(C.Structure):
+    """mom6hip_neutral_diffusion_cs_t (include/mom6hip.h)."""
+    _fields_ = [("ref_pres", C.c_double), ("H_to_RZ", C.c_double), ("reserved0", C.c_double * 4), ("ndiff_answer_date", C.c_int32),
+                ("recalc_neutral_surf", C.c_int32), ("initialized", C.c_int32), ("reserved_i", C.c_int32 * 1), ("unsupported", C.c_int32 * 8)]
+
+
 class HorDiffStats(C.Structure):
     _fields_ = [("num_itts", C.c_int32), ("halo_updates", C.c_int32), ("max_CFL", C.c_double)]
 

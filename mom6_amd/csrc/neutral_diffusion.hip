@@ -1,0 +1,424 @@
+// neutral_diffusion.hip -- the continuous-reconstruction branch of MOM_neutral_diffusion (src/tracer/MOM_neutral_diffusion.F90)
+// as gfx950 kernels, called from tracer_hordiff's neutral branch (MOM_tracer_hor_diff.F90:474-534; tracer_hor_diff.hip).
+//
+//   nd_column_kernel      neutral_diffusion_calc_coeffs :337-470 for one h column (halo 1): interface pressures, interface T and S by
+//                         interface_scalar (:1078, PLM_diff + ppm_edge), their density derivatives -> five [nk+1] columns
+//   nd_surfaces_kernel    find_neutral_surface_positions_continuous (:1353) for one face: the merge walk down the 2nk+2 interfaces of
+//                         the two columns; PoL, PoR, KoL, KoR, hEff (back in H units, :570-575) as [surface][face] planes
+//   nd_tracer_cols_kernel interface values and the limited PPM edge values of one tracer (neutral_surface_flux :2373-2377,
+//                         ppm_left_right_edge_values :2541) for one h column
+//   nd_flux_kernel        neutral_surface_flux (:2297) for one face -> Flx [surface][face]
+//   nd_update_kernel      the tendencies of a cell from its four faces in the reference's order of the surfaces (:927-954), accumulated
+//                         per layer in LDS (the layer index is data: KoL / KoR), and the update of the tracer (:955-959)
+// A lane owns a column or a face and walks it: the walks are serial in the surface index and differ from lane to lane, the planes
+// keep the lanes' accesses to one surface coalesced.  Traffic per call: ~30 (nk+1) doubles per column for the surfaces, and per tracer
+// ~5 (2nk+2) doubles per face.
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+#include "eos.hpp"
+
+namespace {
+
+using m6::max2;
+using m6::min2;
+using namespace m6::eos;
+
+__device__ __forceinline__ double fsign(double a, double b) { return copysign(fabs(a), b); }
+__device__ __forceinline__ double signum(double a, double x) { return (x == 0.) ? 0. : fsign(a, x); }      // :1200
+
+// fv_diff :1282
+__device__ __forceinline__ double fv_diff(double hkm1, double hk, double hkp1, double Skm1, double Sk, double Skp1) {
+  double h_sum = (hkm1 + hkp1) + hk;
+  if (h_sum != 0.) h_sum = 1. / h_sum;
+  double hm = hkm1 + hk;
+  if (hm != 0.) hm = 1. / hm;
+  double hp = hkp1 + hk;
+  if (hp != 0.) hp = 1. / hp;
+  return (hk * h_sum) * ((2. * hkm1 + hk) * hp * (Skp1 - Sk) + (2. * hkp1 + hk) * hm * (Sk - Skm1));
+}
+
+// PLM_diff :1211 with c_method = 2, b_method = 1, for layer k (0-based) of the column at n2
+__device__ __forceinline__ double plm_diff(const double *__restrict__ h, const double *__restrict__ S, long n2, long hpl, int k, int nk) {
+  if (k <= 0 || k >= nk - 1) return 0.;
+  const double hkm1 = h[n2 + hpl * (k - 1)], hk = h[n2 + hpl * k], hkp1 = h[n2 + hpl * (k + 1)];
+  if (!((hkp1 + hk) * (hkm1 + hk) > 0.)) return 0.;
+  const double Skm1 = S[n2 + hpl * (k - 1)], Sk = S[n2 + hpl * k], Skp1 = S[n2 + hpl * (k + 1)];
+  const double diff_c = fv_diff(hkm1, hk, hkp1, Skm1, Sk, Skp1);
+  const double diff_l = 2. * (Sk - Skm1), diff_r = 2. * (Skp1 - Sk);
+  if (signum(1., diff_l) * signum(1., diff_r) <= 0.) return 0.;
+  return fsign(min2(min2(fabs(diff_l), fabs(diff_c)), fabs(diff_r)), diff_c);
+}
+
+// ppm_edge :1120
+__device__ __forceinline__ double ppm_edge(double hkm1, double hk, double hkp1, double hkp2, double Ak, double Akp1, double Pk, double Pkp1,
+                                           double h_neglect) {
+  double R_hk_hkp1 = hk + hkp1, e;
+  if (R_hk_hkp1 <= 0.) return 0.5 * (Ak + Akp1);
+  R_hk_hkp1 = 1. / R_hk_hkp1;
+  if (hk < hkp1) e = Ak + (hk * R_hk_hkp1) * (Akp1 - Ak);
+  else e = Akp1 + (hkp1 * R_hk_hkp1) * (Ak - Akp1);
+  const double R_2hk_hkp1 = 1. / ((2. * hk + hkp1) + h_neglect);
+  const double R_hk_2hkp1 = 1. / ((hk + 2. * hkp1) + h_neglect);
+  const double f1 = 1. / ((hk + hkp1) + (hkm1 + hkp2));
+  const double f2 = 2. * (hkp1 * hk) * R_hk_hkp1 * ((hkm1 + hk) * R_2hk_hkp1 - (hkp2 + hkp1) * R_hk_2hkp1);
+  const double f3 = hk * (hkm1 + hk) * R_2hk_hkp1;
+  const double f4 = hkp1 * (hkp1 + hkp2) * R_hk_2hkp1;
+  return e + f1 * (f2 * (Akp1 - Ak) - (f3 * Pkp1 - f4 * Pk));
+}
+
+// interface_scalar :1078 with i_method = 2, walked down the column: call with K = 0 .. nk in order; d_prev carries diff(K-1)
+__device__ __forceinline__ double interface_value(const double *__restrict__ h, const double *__restrict__ S, long n2, long hpl, int K, int nk,
+                                                  double h_neglect, double &d_prev) {
+  if (K == 0) {
+    d_prev = plm_diff(h, S, n2, hpl, 0, nk);
+    return S[n2] - 0.5 * d_prev;
+  }
+  if (K == nk) return S[n2 + hpl * (nk - 1)] + 0.5 * d_prev;
+  const int km2 = (K - 2 > 0) ? K - 2 : 0, kp1 = (K + 1 < nk - 1) ? K + 1 : nk - 1;
+  const double d = plm_diff(h, S, n2, hpl, K, nk);
+  const double v = ppm_edge(h[n2 + hpl * km2], h[n2 + hpl * (K - 1)], h[n2 + hpl * K], h[n2 + hpl * kp1], S[n2 + hpl * (K - 1)], S[n2 + hpl * K],
+                            d_prev, d, h_neglect);
+  d_prev = d;
+  return v;
+}
+
+// interpolate_for_nondim_position :1563
+__device__ __forceinline__ double interp_nondim(double dRhoNeg, double Pneg, double dRhoPos, double Ppos) {
+  if (Ppos <= Pneg) return 0.5;
+  if (dRhoPos - dRhoNeg > 0.) return min2(1., max2(0., -dRhoNeg / (dRhoPos - dRhoNeg)));
+  if (dRhoPos - dRhoNeg == 0) {
+    if (dRhoNeg > 0.) return 0.;
+    if (dRhoNeg < 0.) return 1.;
+    return 0.5;
+  }
+  return 0.5;
+}
+
+// ppm_ave :1166
+__device__ __forceinline__ double ppm_ave(double xL, double xR, double aL, double aR, double aMean, int &bad) {
+  const double dx = xR - xL;
+  const double xave = 0.5 * (xR + xL);
+  const double a6o3 = 2. * aMean - (aL + aR);
+  const double a6 = 3. * a6o3;
+  if (dx < 0. || dx > 1.) { bad = 1; return 0.; }
+  if (dx == 0.) return aL + (aR - aL) * xR + a6 * xR * (1. - xR);
+  return (aL + xave * ((aR - aL) + a6)) - a6o3 * (xR * xR + xR * xL + xL * xL);
+}
+
+struct NDArgs {
+  m6::GridDev g;
+  EosDev E;
+  double ref_pres, gH;              // NDIFF_REF_PRES ; GV%g_Earth*GV%H_to_RZ
+  double pa_to_H, h_neglect, scale; // scale: I_numitts
+  int ns, symmetric;                // 2nk+2 ; ndiff_answer_date > 20240330
+  const double *h, *T, *S, *p_surf;
+  double *Pint, *Tint, *Sint, *dRdT, *dRdS;   // [(nk+1)][h points]
+  double *PoL[2], *PoR[2], *hEff[2], *Flx[2]; // [surface][faces of the direction]
+  int *KoL[2], *KoR[2];
+  const double *khdt[2];
+  double *t;                        // the tracer being diffused
+  double *Ti, *aL, *aR;             // its interface and edge values, [(nk+1)] / [nk][h points]
+  double *stash;                    // [3][nk][h points], the symmetric form's N, S, E tendencies
+  double cu;                        // conc_underflow of the tracer
+  int *bad;
+};
+
+__global__ __launch_bounds__(64) void nd_column_kernel(NDArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk;
+  if (i > g.iec + 1) return;
+  const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
+  double P = A.p_surf ? A.p_surf[n2] : 0., dT = 0., dS = 0.;
+  for (int K = 0; K <= nk; K++) {
+    if (K > 0) P = P + A.h[n2 + hpl * (K - 1)] * A.gH;
+    const double Ti = interface_value(A.h, A.T, n2, hpl, K, nk, A.h_neglect, dT);
+    const double Si = interface_value(A.h, A.S, n2, hpl, K, nk, A.h_neglect, dS);
+    double rT, rS;
+    eos_density_derivs(A.E, Ti, Si, (A.ref_pres >= 0.) ? A.ref_pres : P, rT, rS);
+    A.Pint[n2 + hpl * K] = P; A.Tint[n2 + hpl * K] = Ti; A.Sint[n2 + hpl * K] = Si;
+    A.dRdT[n2 + hpl * K] = rT; A.dRdS[n2 + hpl * K] = rS;
+  }
+}
+
+// find_neutral_surface_positions_continuous :1353 (KoL / KoR keep the reference's 1-based layer numbers)
+template <int DIR>
+__global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x, j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y, nk = g.nk;
+  if (i > g.iec) return;
+  const long f = DIR ? g.v2(i, j) : g.u2(i, j), pl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long hpl = (long)g.nih * g.njh, cl = g.h2(i, j), cr = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  double *__restrict__ PoL = A.PoL[DIR], *__restrict__ PoR = A.PoR[DIR], *__restrict__ hEff = A.hEff[DIR];
+  int *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
+  const int ns = A.ns;
+  if (!((DIR ? g.mask2dCv[f] : g.mask2dCu[f]) > 0.0)) {      // :472-481: what the arrays hold where no surfaces are searched for
+    for (int ks = 0; ks < ns; ks++) {
+      PoL[f + pl * ks] = 0.; PoR[f + pl * ks] = 0.; KoL[f + pl * ks] = 1; KoR[f + pl * ks] = 1;
+      if (ks < ns - 1) hEff[f + pl * ks] = 0.;
+    }
+    return;
+  }
+  const double *__restrict__ Pint = A.Pint, *__restrict__ Tint = A.Tint, *__restrict__ Sint = A.Sint, *__restrict__ dRdT = A.dRdT,
+                             *__restrict__ dRdS = A.dRdS;
+#define LC(a, k) a[cl + hpl * ((k) - 1)]
+#define RC(a, k) a[cr + hpl * ((k) - 1)]
+  int kr = 1, kl = 1, lastK_right = 1, lastK_left = 1;
+  double lastP_right = 0., lastP_left = 0., absL_prev = 0., absR_prev = 0.;
+  bool reached_bottom = false, searching_left = false, searching_right = false;
+  for (int ks = 0; ks < ns; ks++) {
+    int klm1 = (kl - 1 > 1) ? kl - 1 : 1;
+    int krm1 = (kr - 1 > 1) ? kr - 1 : 1;
+    const double Tr_kr = RC(Tint, kr), Sr_kr = RC(Sint, kr), aTr_kr = RC(dRdT, kr), aSr_kr = RC(dRdS, kr);
+    const double Tl_kl = LC(Tint, kl), Sl_kl = LC(Sint, kl), aTl_kl = LC(dRdT, kl), aSl_kl = LC(dRdS, kl);
+    const double dRho = 0.5 * ((aTr_kr + aTl_kl) * (Tr_kr - Tl_kl) + (aSr_kr + aSl_kl) * (Sr_kr - Sl_kl));
+    if (!reached_bottom) {
+      if (dRho < 0.) { searching_left = true; searching_right = false; }
+      else if (dRho > 0.) { searching_right = true; searching_left = false; }
+      else if (kl + kr == 2) { searching_left = true; searching_right = false; }
+      else { searching_left = !searching_left; searching_right = !searching_right; }
+    }
+    double pL, pR;
+    int oKL, oKR;
+    if (searching_left) {
+      const double dRhoTop = 0.5 * ((LC(dRdT, klm1) + aTr_kr) * (LC(Tint, klm1) - Tr_kr) + (LC(dRdS, klm1) + aSr_kr) * (LC(Sint, klm1) - Sr_kr));
+      const double dRhoBot = 0.5 * ((LC(dRdT, klm1 + 1) + aTr_kr) * (LC(Tint, klm1 + 1) - Tr_kr) +
+                                    (LC(dRdS, klm1 + 1) + aSr_kr) * (LC(Sint, klm1 + 1) - Sr_kr));
+      if (dRhoTop > 0. || kr + kl == 2) pL = 0.;
+      else if (dRhoTop >= dRhoBot) pL = 1.;
+      else pL = interp_nondim(dRhoTop, LC(Pint, klm1), dRhoBot, LC(Pint, klm1 + 1));
+      if (pL >= 1. && klm1 < nk) { klm1 = klm1 + 1; pL = pL - 1.; }
+      if ((double)(klm1 - lastK_left) + (pL - lastP_left) < 0.) { pL = lastP_left; klm1 = lastK_left; }
+      oKL = klm1;
+      if (kr <= nk) { pR = 0.; oKR = kr; } else { pR = 1.; oKR = nk; }
+      if (kr <= nk) kr = kr + 1;
+      else { reached_bottom = true; searching_right = true; searching_left = false; }
+    } else {
+      const double dRhoTop = 0.5 * ((RC(dRdT, krm1) + aTl_kl) * (RC(Tint, krm1) - Tl_kl) + (RC(dRdS, krm1) + aSl_kl) * (RC(Sint, krm1) - Sl_kl));
+      const double dRhoBot = 0.5 * ((RC(dRdT, krm1 + 1) + aTl_kl) * (RC(Tint, krm1 + 1) - Tl_kl) +
+                                    (RC(dRdS, krm1 + 1) + aSl_kl) * (RC(Sint, krm1 + 1) - Sl_kl));
+      if (dRhoTop >= 0. || kr + kl == 2) pR = 0.;
+      else if (dRhoTop >= dRhoBot) pR = 1.;
+      else pR = interp_nondim(dRhoTop, RC(Pint, krm1), dRhoBot, RC(Pint, krm1 + 1));
+      if (pR >= 1. && krm1 < nk) { krm1 = krm1 + 1; pR = pR - 1.; }
+      if ((double)(krm1 - lastK_right) + (pR - lastP_right) < 0.) { pR = lastP_right; krm1 = lastK_right; }
+      oKR = krm1;
+      if (kl <= nk) { pL = 0.; oKL = kl; } else { pL = 1.; oKL = nk; }
+      if (kl <= nk) kl = kl + 1;
+      else { reached_bottom = true; searching_right = false; searching_left = true; }
+    }
+    PoL[f + pl * ks] = pL; PoR[f + pl * ks] = pR; KoL[f + pl * ks] = oKL; KoR[f + pl * ks] = oKR;
+    lastK_left = oKL; lastP_left = pL; lastK_right = oKR; lastP_right = pR;
+    // absolute_position :2258 of this surface; that of the one above is the value formed a step ago from the same expression
+    const double PL0 = LC(Pint, oKL), PR0 = RC(Pint, oKR);
+    const double absL = PL0 + pL * (LC(Pint, oKL + 1) - PL0), absR = PR0 + pR * (RC(Pint, oKR + 1) - PR0);
+    if (ks > 0) {
+      const double hL = absL - absL_prev, hR = absR - absR_prev;
+      double he = 0.;
+      if (hL + hR > 0.) he = 2. * hL * hR / (hL + hR);
+      hEff[f + pl * (ks - 1)] = he * A.pa_to_H;      // :570-575
+    }
+    absL_prev = absL; absR_prev = absR;
+  }
+#undef LC
+#undef RC
+}
+
+__global__ __launch_bounds__(64) void nd_tracer_cols_kernel(NDArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk;
+  if (i > g.iec + 1) return;
+  const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
+  double d = 0., Ti_prev = 0.;
+  for (int K = 0; K <= nk; K++) {
+    const double Ti = interface_value(A.h, A.t, n2, hpl, K, nk, A.h_neglect, d);
+    A.Ti[n2 + hpl * K] = Ti;
+    if (K > 0) {      // ppm_left_right_edge_values :2541 of layer K-1
+      const double Tl = A.t[n2 + hpl * (K - 1)];
+      double aL = Ti_prev, aR = Ti;
+      if (signum(1., aR - Tl) * signum(1., Tl - aL) <= 0.0) { aL = Tl; aR = Tl; }
+      else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) > fabs(aR - aL)) aL = Tl + 2.0 * (Tl - aR);
+      else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) < -fabs(aR - aL)) aR = Tl + 2.0 * (Tl - aL);
+      A.aL[n2 + hpl * (K - 1)] = aL; A.aR[n2 + hpl * (K - 1)] = aR;
+    }
+    Ti_prev = Ti;
+  }
+}
+
+// neutral_surface_flux :2297 (continuous, no tapering: khtr_ave = 1)
+template <int DIR>
+__global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x, j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f = DIR ? g.v2(i, j) : g.u2(i, j), pl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long hpl = (long)g.nih * g.njh, cl = g.h2(i, j), cr = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  double *__restrict__ Flx = A.Flx[DIR];
+  const int ns = A.ns;
+  if (!((DIR ? g.mask2dCv[f] : g.mask2dCu[f]) > 0.0)) {
+    for (int ks = 0; ks < ns - 1; ks++) Flx[f + pl * ks] = 0.;
+    return;
+  }
+  const double *__restrict__ PiL = A.PoL[DIR], *__restrict__ PiR = A.PoR[DIR], *__restrict__ hEff = A.hEff[DIR];
+  const int *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
+  const double *__restrict__ Ti = A.Ti, *__restrict__ aL = A.aL, *__restrict__ aR = A.aR, *__restrict__ t = A.t;
+  int bad = 0;
+  double pLt = PiL[f], pRt = PiR[f];
+  int klt = KoL[f] - 1, krt = KoR[f] - 1;
+  for (int ks = 0; ks < ns - 1; ks++) {
+    const double pLb = PiL[f + pl * (ks + 1)], pRb = PiR[f + pl * (ks + 1)];
+    const int klb = KoL[f + pl * (ks + 1)] - 1, krb = KoR[f + pl * (ks + 1)] - 1;
+    const double he = hEff[f + pl * ks];
+    double flx = 0.;
+    if (he != 0.) {
+      const double T_left_bottom = (1. - pLb) * Ti[cl + hpl * klb] + pLb * Ti[cl + hpl * (klb + 1)];
+      const double T_left_top = (1. - pLt) * Ti[cl + hpl * klt] + pLt * Ti[cl + hpl * (klt + 1)];
+      const double T_left_layer = ppm_ave(pLt, pLb + (double)(klb - klt), aL[cl + hpl * klt], aR[cl + hpl * klt], t[cl + hpl * klt], bad);
+      const double T_right_bottom = (1. - pRb) * Ti[cr + hpl * krb] + pRb * Ti[cr + hpl * (krb + 1)];
+      const double T_right_top = (1. - pRt) * Ti[cr + hpl * krt] + pRt * Ti[cr + hpl * (krt + 1)];
+      const double T_right_layer = ppm_ave(pRt, pRb + (double)(krb - krt), aL[cr + hpl * krt], aR[cr + hpl * krt], t[cr + hpl * krt], bad);
+      const double dT_top = T_right_top - T_left_top;
+      const double dT_bottom = T_right_bottom - T_left_bottom;
+      double dT_ave = 0.5 * (dT_top + dT_bottom);
+      const double dT_layer = T_right_layer - T_left_layer;
+      if (signum(1., dT_top) * signum(1., dT_bottom) <= 0. || signum(1., dT_ave) * signum(1., dT_layer) <= 0.) dT_ave = 0.;
+      else dT_ave = dT_layer;
+      flx = dT_ave * he * 1.0;
+    }
+    Flx[f + pl * ks] = flx;
+    pLt = pLb; pRt = pRb; klt = klb; krt = krb;
+  }
+  if (bad) atomicOr(A.bad, 1);
+}
+
+// :921-960: the cell's tendency from the fluxes of its four faces, then the tracer
+__global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
+  extern __shared__ double acc[];      // [nk][64]
+  const m6::GridDev &g = A.g;
+  const int lane = threadIdx.x, i = g.isc + blockIdx.x * 64 + lane, j = g.jsc + blockIdx.y, nk = g.nk;
+  if (i > g.iec) return;
+  const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
+  if (!(g.mask2dT[n2] > 0.)) return;
+  const long upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1);
+  const long uE = g.u2(i, j), uW = g.u2(i - 1, j), vN = g.v2(i, j), vS = g.v2(i, j - 1);
+  const double cE = A.scale * A.khdt[0][uE], cW = A.scale * A.khdt[0][uW], cN = A.scale * A.khdt[1][vN], cS = A.scale * A.khdt[1][vS];
+  const int ns = A.ns;
+  const int *__restrict__ uKoL = A.KoL[0], *__restrict__ uKoR = A.KoR[0], *__restrict__ vKoL = A.KoL[1], *__restrict__ vKoR = A.KoR[1];
+  const double *__restrict__ uFlx = A.Flx[0], *__restrict__ vFlx = A.Flx[1];
+#define ACC(k) acc[(k) * 64 + lane]
+  if (!A.symmetric) {      // :927-938
+    for (int k = 0; k < nk; k++) ACC(k) = 0.;
+    for (int ks = 0; ks < ns - 1; ks++) {
+      int k = uKoL[uE + upl * ks] - 1;
+      ACC(k) = ACC(k) + cE * uFlx[uE + upl * ks];
+      k = uKoR[uW + upl * ks] - 1;
+      ACC(k) = ACC(k) - cW * uFlx[uW + upl * ks];
+      k = vKoL[vN + vpl * ks] - 1;
+      ACC(k) = ACC(k) + cN * vFlx[vN + vpl * ks];
+      k = vKoR[vS + vpl * ks] - 1;
+      ACC(k) = ACC(k) - cS * vFlx[vS + vpl * ks];
+    }
+  } else {                 // :939-954: one face at a time, the first three parked in the stash
+    double *__restrict__ st = A.stash;
+    const long spl = hpl * nk;
+    for (int face = 0; face < 4; face++) {      // N, S, E, W
+      for (int k = 0; k < nk; k++) ACC(k) = 0.;
+      for (int ks = 0; ks < ns - 1; ks++) {
+        if (face == 0) { const int k = vKoL[vN + vpl * ks] - 1; ACC(k) = ACC(k) + cN * vFlx[vN + vpl * ks]; }
+        else if (face == 1) { const int k = vKoR[vS + vpl * ks] - 1; ACC(k) = ACC(k) - cS * vFlx[vS + vpl * ks]; }
+        else if (face == 2) { const int k = uKoL[uE + upl * ks] - 1; ACC(k) = ACC(k) + cE * uFlx[uE + upl * ks]; }
+        else { const int k = uKoR[uW + upl * ks] - 1; ACC(k) = ACC(k) - cW * uFlx[uW + upl * ks]; }
+      }
+      if (face < 3) for (int k = 0; k < nk; k++) st[spl * face + n2 + hpl * k] = ACC(k);
+    }
+    for (int k = 0; k < nk; k++)
+      ACC(k) = (st[n2 + hpl * k] + st[spl + n2 + hpl * k]) + (st[2 * spl + n2 + hpl * k] + ACC(k));
+  }
+  const double IareaT = g.IareaT[n2];
+  for (int k = 0; k < nk; k++) {
+    double x = A.t[n2 + hpl * k] + ACC(k) * (IareaT / (A.h[n2 + hpl * k] + g.H_subroundoff));
+    if (fabs(x) < A.cu) x = 0.0;
+    A.t[n2 + hpl * k] = x;
+  }
+#undef ACC
+}
+
+}  // namespace
+
+namespace m6 {
+
+// the neutral branch of tracer_hordiff (MOM_tracer_hor_diff.F90:474-534) on device arrays; khdt_x, khdt_y and the iteration count
+// are those tracer_hordiff has formed
+int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusion_cs_t *nd, const mom6hip_eos_t *eos, const double *h,
+                   const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
+                   const std::vector<double *> &d_tr, const std::vector<double> &cu, int idx_T, int idx_S, int *halo_updates) {
+  static const char *names[8] = {"NDIFF_CONTINUOUS = False", "NDIFF_INTERIOR_ONLY", "NDIFF_TAPERING", "KHTR_USE_EBT_STRUCT",
+                                 "NDIFF_USE_UNMASKED_TRANSPORT_BUG", "the neutral-diffusion diagnostics", "(free)", "(free)"};
+  const int ntr = (int)d_tr.size();
+  M6_REQUIRE(nd != nullptr && eos != nullptr, "tracer_hordiff: USE_NEUTRAL_DIFFUSION needs the neutral_diffusion control structure and tv%%eqn_of_state");
+  M6_REQUIRE(nd->initialized, "neutral_diffusion: the control structure is not initialised");
+  for (int q = 0; q < 8; q++) M6_REQUIRE(!nd->unsupported[q], "neutral_diffusion: %s is not provided by libmom6hip", names[q]);
+  M6_REQUIRE(idx_T >= 0 && idx_T < ntr && idx_S >= 0 && idx_S < ntr, "tracer_hordiff: tv%%T and tv%%S must be among the tracers (idx_T, idx_S)");
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(g.mask2dT && g.mask2dCu && g.mask2dCv && g.IareaT, "neutral_diffusion: mask2dT, mask2dCu, mask2dCv and IareaT are needed");
+  M6_REQUIRE(g.nk >= 2 && g.nk <= 128, "neutral_diffusion: 2 to 128 layers are supported");
+  hipStream_t s = ctx->stream;
+  const int nk = g.nk, ns = 2 * nk + 2;
+  const size_t hpl = (size_t)g.nih * g.njh, upl = (size_t)(g.nih + 1) * g.njh, vpl = (size_t)g.nih * (g.njh + 1);
+  const size_t fpl = upl > vpl ? upl : vpl;
+  NDArgs A;
+  A.g = g; A.E = EosDev{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS};
+  A.ref_pres = nd->ref_pres; A.gH = g.g_Earth * nd->H_to_RZ; A.pa_to_H = 1. / (nd->H_to_RZ * g.g_Earth);
+  A.h_neglect = g.H_subroundoff; A.scale = I_numitts; A.ns = ns; A.symmetric = nd->ndiff_answer_date > 20240330;
+  A.h = h; A.p_surf = p_surf; A.khdt[0] = khdt_x; A.khdt[1] = khdt_y;
+  double *cols = (double *)st.scratch(sizeof(double) * hpl * (nk + 1) * 5);
+  double *faces = (double *)st.scratch(sizeof(double) * fpl * ns * 8);
+  int *kos = (int *)st.scratch(sizeof(int) * fpl * ns * 4);
+  double *tcols = (double *)st.scratch(sizeof(double) * hpl * (3 * (size_t)nk + 1));
+  double *stash = A.symmetric ? (double *)st.scratch(sizeof(double) * hpl * nk * 3) : nullptr;
+  int *bad = (int *)st.scratch(64);
+  M6_REQUIRE(!st.failed() && cols && faces && kos && tcols && bad && (stash || !A.symmetric), "neutral_diffusion: out of device memory");
+  A.Pint = cols; A.Tint = cols + hpl * (nk + 1); A.Sint = A.Tint + hpl * (nk + 1); A.dRdT = A.Sint + hpl * (nk + 1); A.dRdS = A.dRdT + hpl * (nk + 1);
+  for (int d = 0; d < 2; d++) {
+    A.PoL[d] = faces + fpl * ns * (4 * d); A.PoR[d] = A.PoL[d] + fpl * ns; A.hEff[d] = A.PoR[d] + fpl * ns; A.Flx[d] = A.hEff[d] + fpl * ns;
+    A.KoL[d] = kos + fpl * ns * (2 * d); A.KoR[d] = A.KoL[d] + fpl * ns;
+  }
+  A.Ti = tcols; A.aL = tcols + hpl * (nk + 1); A.aR = A.aL + hpl * nk; A.stash = stash; A.bad = bad;
+  M6_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+
+  const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
+  std::vector<double *> pf(d_tr);
+  std::vector<int32_t> ppos(ntr, MOM6HIP_POS_H), pnk(ntr, nk);
+  auto calc_coeffs = [&]() {      // neutral_diffusion_calc_coeffs :337
+    A.T = d_tr[idx_T]; A.S = d_tr[idx_S];
+    hipLaunchKernelGGL(nd_column_kernel, dim3((ni + 2 + 63) / 64, nj + 2), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(nd_surfaces_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(nd_surfaces_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+  };
+  if (int rc = m6::group_pass(ctx, pf.data(), ppos.data(), pnk.data(), ntr)) return rc;      // do_group_pass(CS%pass_t) :478
+  (*halo_updates)++;
+  calc_coeffs();
+  for (int itt = 1; itt <= num_itts; itt++) {
+    if (itt > 1) {
+      if (int rc = m6::group_pass(ctx, pf.data(), ppos.data(), pnk.data(), ntr)) return rc;
+      (*halo_updates)++;
+      if (nd->recalc_neutral_surf) calc_coeffs();
+    }
+    for (int m = 0; m < ntr; m++) {      // neutral_diffusion :605
+      A.t = d_tr[m]; A.cu = cu[m];
+      hipLaunchKernelGGL(nd_tracer_cols_kernel, dim3((ni + 2 + 63) / 64, nj + 2), dim3(64), 0, s, A);
+      hipLaunchKernelGGL(nd_flux_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
+      hipLaunchKernelGGL(nd_flux_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+      hipLaunchKernelGGL(nd_update_kernel, dim3((ni + 63) / 64, nj), dim3(64), sizeof(double) * 64 * nk, s, A);
+    }
+  }
+  M6_HIP(hipGetLastError());
+  int hbad = 0;
+  M6_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+  M6_HIP(hipStreamSynchronize(s));
+  M6_REQUIRE(!hbad, "ppm_ave: dx<0 or dx>1 should not happened! (a neutral layer spans more than one cell)");
+  return 0;
+}
+
+}  // namespace m6

@@ -1,5 +1,5 @@
-// tracer_hor_diff.hip -- the along-layer diffusion of tracer_hordiff (src/tracer/MOM_tracer_hor_diff.F90:119-680) with a
-// constant KHTR as gfx950 kernels.
+// tracer_hor_diff.hip -- tracer_hordiff (src/tracer/MOM_tracer_hor_diff.F90:119-680) as gfx950 kernels: the along-layer diffusion
+// with KHTR or the VarMix / MEKE diffusivities, and the call of the neutral-diffusion branch (neutral_diffusion.hip).
 //
 //   hd_khdt_kernel    khdt_x, khdt_y (:340-351), their MAX_TR_DIFFUSION_CFL limit (:368-398) and, with CHECK_DIFFUSIVE_CFL,
 //                     the largest diffusive CFL number (:410-416; an atomic max on the bit pattern of positive doubles)
@@ -136,13 +136,29 @@ extern "C" int mom6hip_tracer_hordiff(mom6hip_ctx_t *ctx, const mom6hip_tracer_h
 extern "C" int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_hordiff_fields_t *F,
                                              const double *h, double dt, double *const *tr, const double *conc_underflow, int32_t ntr,
                                              int32_t memspace, mom6hip_hordiff_stats_t *stats) {
+  M6_REQUIRE(cs != nullptr, "tracer_hordiff: null argument");
+  M6_REQUIRE(!cs->unsupported[0], "tracer_hordiff: USE_NEUTRAL_DIFFUSION is not provided by this entry point (mom6hip_tracer_hordiff_neutral takes it)");
+  return mom6hip_tracer_hordiff_neutral(ctx, cs, nullptr, F, h, nullptr, nullptr, dt, tr, conc_underflow, ntr, 0, 0, memspace, stats);
+}
+
+namespace m6 {
+int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusion_cs_t *nd, const mom6hip_eos_t *eos, const double *h,
+                   const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
+                   const std::vector<double *> &d_tr, const std::vector<double> &cu, int idx_T, int idx_S, int *halo_updates);
+}
+
+extern "C" int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_neutral_diffusion_cs_t *nd,
+                                              const mom6hip_hordiff_fields_t *F, const double *h, const mom6hip_eos_t *eos, const double *p_surf,
+                                              double dt, double *const *tr, const double *conc_underflow, int32_t ntr, int32_t idx_T,
+                                              int32_t idx_S, int32_t memspace, mom6hip_hordiff_stats_t *stats) {
   static const char *names[8] = {"USE_NEUTRAL_DIFFUSION", "USE_HORIZONTAL_BOUNDARY_DIFFUSION", "DIFFUSE_ML_TO_INTERIOR",
                                  "(free)", "(free)", "KHTR_USE_EBT_STRUCT", "offline khdt (do_online = false)",
                                  "the df_x / df_y flux diagnostics"};
   M6_REQUIRE(ctx != nullptr, "MOM_tracer_hor_diff: register_tracer must be called before tracer_hordiff.");
   M6_REQUIRE(cs != nullptr && h != nullptr, "tracer_hordiff: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "tracer_hordiff: bad memspace");
-  for (int q = 0; q < 8; q++) M6_REQUIRE(!cs->unsupported[q], "tracer_hordiff: %s is not provided by libmom6hip", names[q]);
+  for (int q = 1; q < 8; q++) M6_REQUIRE(!cs->unsupported[q], "tracer_hordiff: %s is not provided by libmom6hip", names[q]);
+  const bool use_neutral = cs->unsupported[0] != 0;      // CS%use_neutral_diffusion
   if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
   const bool use_VarMix = cs->use_variable_mixing != 0;
   if (ntr == 0 || (cs->KhTr <= 0.0 && !use_VarMix)) return 0;      // :197
@@ -177,7 +193,7 @@ extern "C" int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_t
   for (int m = 0; m < ntr; m++) {
     M6_REQUIRE(tr[m] != nullptr, "tracer_hordiff: tracer %d is null", m);
     d_tr[m] = st.inout(tr[m], bH);
-    d_work[m] = (double *)st.scratch(bH);
+    d_work[m] = use_neutral ? nullptr : (double *)st.scratch(bH);
   }
   A.khdt_x = (double *)st.scratch(bU2); A.khdt_y = (double *)st.scratch(bV2);
   char *tab = (char *)st.scratch(2 * 24 * sizeof(double *) + 24 * sizeof(double) + 16);
@@ -222,6 +238,12 @@ extern "C" int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_t
   std::vector<double *> pf(d_tr);
   std::vector<int32_t> ppos(ntr, MOM6HIP_POS_H), pnk(ntr, g.nk);
   int halo_updates = 0;
+  if (use_neutral) {      // :474-534
+    const double *d_ps = p_surf ? st.in(p_surf, sizeof(double) * (size_t)g.nih * g.njh) : nullptr;
+    M6_REQUIRE(!st.failed(), "tracer_hordiff: staging failed");
+    if (int rc = m6::neutral_branch(ctx, st, nd, eos, A.h, d_ps, A.khdt_x, A.khdt_y, num_itts, A.scale, d_tr, cu, idx_T, idx_S, &halo_updates))
+      return rc;
+  } else
   for (int itt = 1; itt <= num_itts; itt++) {      // :540-614
     if (int rc = m6::group_pass(ctx, pf.data(), ppos.data(), pnk.data(), ntr)) return rc;
     halo_updates++;

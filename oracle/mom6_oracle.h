@@ -60,6 +60,26 @@ int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_
                               mom6hip_hordiff_stats_t *stats);
 int orc_tracer_hordiff(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const double *h, double dt,
                        double *const *tr, const double *conc_underflow, int ntr, mom6hip_hordiff_stats_t *stats);
+/* tracer_hordiff with CS%use_neutral_diffusion (CS->unsupported[0]); tr[idx_T], tr[idx_S] are tv%T, tv%S */
+int orc_tracer_hordiff_neutral(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS,
+                               const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_hordiff_fields_t *F, const double *h,
+                               const mom6hip_eos_t *eos, const double *p_surf, double dt, double *const *tr,
+                               const double *conc_underflow, int ntr, int idx_T, int idx_S, mom6hip_hordiff_stats_t *stats);
+/* MOM_neutral_diffusion column routines (oracle/neutral_diffusion.c) */
+double orc_ndiff_fv_diff(double hkm1, double hk, double hkp1, double Skm1, double Sk, double Skp1);
+double orc_ndiff_fvlsq_slope(double hkm1, double hk, double hkp1, double Skm1, double Sk, double Skp1);
+void orc_ndiff_interface_scalar(int nk, const double *h, const double *S, double *Si, int i_method, double h_neglect);
+double orc_ndiff_interpolate_for_nondim_position(double dRhoNeg, double Pneg, double dRhoPos, double Ppos);
+void orc_ndiff_find_neutral_surface_positions_continuous(int nk, const double *Pl, const double *Tl, const double *Sl,
+    const double *dRdTl, const double *dRdSl, const double *Pr, const double *Tr, const double *Sr, const double *dRdTr,
+    const double *dRdSr, double *PoL, double *PoR, int *KoL, int *KoR, double *hEff);
+int orc_ndiff_neutral_surface_flux(int nk, const double *hl, const double *hr, const double *Tl, const double *Tr,
+                                   const double *PiL, const double *PiR, const int *KoL, const int *KoR, const double *hEff,
+                                   double *Flx, double h_neglect);
+int orc_neutral_branch(const mom6hip_grid_t *G, const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_eos_t *eos,
+                       const double *h, const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts,
+                       double I_numitts, double *const *tr, const double *conc_underflow, int ntr, int idx_T, int idx_S,
+                       int *halo_updates);
 
 /* ---- MOM_tracer_advect -------------------------------------------------------------------- */
 /* advect_tracer, src/tracer/MOM_tracer_advect.F90:52-324 (OBC not associated). */

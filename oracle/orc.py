@@ -455,7 +455,7 @@ def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy,
 
 
 def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL=False, conc_underflow=None, VarMix=None, MEKE=None, KhTr_Slope_Cff=0.0,
-                   KhTr_min=0.0, KhTr_max=0.0, KhTr_passivity_coeff=0.0, KhTr_passivity_min=0.5):
+                   KhTr_min=0.0, KhTr_max=0.0, KhTr_passivity_coeff=0.0, KhTr_passivity_min=0.5, neutral=None):
     """tracer_hordiff (along-layer; constant KHTR, or with VarMix / MEKE the face diffusivities of :236-281) on numpy arrays; tr updated
     in place.  VarMix: None or a dict with any of L2u, L2v, SN_u, SN_v, Res_fn_h (its presence is Resoln_scaled_KhTr), Rd_dx_h; MEKE: None
     or a dict with Kh and KhTr_fac.  Returns the stats struct."""
@@ -477,10 +477,78 @@ def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL
     trp = (_dp * max(ntr, 1))(*[_p(t) for t in tr])
     cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
     st = _abi.HorDiffStats()
-    rc = L.orc_tracer_hordiff_varmix(C.byref(grid.struct()), C.byref(cs), C.byref(F), _p(h), float(dt), trp, _p(cu), ntr, C.byref(st))
+    if neutral is not None:      # USE_NEUTRAL_DIFFUSION: dict(eos=, idx_T=, idx_S=, [ref_pres, ndiff_answer_date, recalc_neutral_surf, p_surf, H_to_RZ])
+        L.orc_tracer_hordiff_neutral.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.TracerHorDiffCS), C.POINTER(_abi.NeutralDiffusionCS),
+                                                 C.POINTER(_abi.HorDiffFields), _dp, C.POINTER(_abi.EOS), _dp, C.c_double, C.POINTER(_dp), _dp,
+                                                 C.c_int, C.c_int, C.c_int, C.POINTER(_abi.HorDiffStats)]
+        cs.unsupported[0] = 1
+        nd = neutral_diffusion_cs(grid, **{k: v for k, v in neutral.items() if k not in ("eos", "idx_T", "idx_S", "p_surf")})
+        ps = neutral.get("p_surf")
+        ps = None if ps is None else np.ascontiguousarray(ps, dtype=np.float64)
+        rc = L.orc_tracer_hordiff_neutral(C.byref(grid.struct()), C.byref(cs), C.byref(nd), C.byref(F), _p(h), C.byref(neutral["eos"]), _p(ps),
+                                          float(dt), trp, _p(cu), ntr, int(neutral.get("idx_T", 0)), int(neutral.get("idx_S", 1)), C.byref(st))
+    else:
+        rc = L.orc_tracer_hordiff_varmix(C.byref(grid.struct()), C.byref(cs), C.byref(F), _p(h), float(dt), trp, _p(cu), ntr, C.byref(st))
     if rc:
         raise RuntimeError(f"orc_tracer_hordiff rc={rc}")
     return st
+
+
+def neutral_diffusion_cs(grid, ref_pres=-1.0, ndiff_answer_date=20240101, recalc_neutral_surf=False, H_to_RZ=None):
+    """neutral_diffusion_CS as neutral_diffusion_init leaves it (NDIFF_CONTINUOUS = True)"""
+    nd = _abi.NeutralDiffusionCS()
+    nd.ref_pres = float(ref_pres); nd.ndiff_answer_date = int(ndiff_answer_date); nd.recalc_neutral_surf = int(bool(recalc_neutral_surf))
+    nd.H_to_RZ = float(grid.Rho0 * grid.H_to_Z if H_to_RZ is None else H_to_RZ); nd.initialized = 1
+    return nd
+
+
+def ndiff_fv_diff(*a):
+    L = lib(); L.orc_ndiff_fv_diff.argtypes = [C.c_double] * 6; L.orc_ndiff_fv_diff.restype = C.c_double
+    return L.orc_ndiff_fv_diff(*[float(x) for x in a])
+
+
+def ndiff_fvlsq_slope(*a):
+    L = lib(); L.orc_ndiff_fvlsq_slope.argtypes = [C.c_double] * 6; L.orc_ndiff_fvlsq_slope.restype = C.c_double
+    return L.orc_ndiff_fvlsq_slope(*[float(x) for x in a])
+
+
+def ndiff_ifndp(*a):
+    L = lib(); f = L.orc_ndiff_interpolate_for_nondim_position; f.argtypes = [C.c_double] * 4; f.restype = C.c_double
+    return f(*[float(x) for x in a])
+
+
+def ndiff_interface_scalar(h, S, i_method, h_neglect):
+    L = lib(); L.orc_ndiff_interface_scalar.argtypes = [C.c_int, _dp, _dp, _dp, C.c_int, C.c_double]; L.orc_ndiff_interface_scalar.restype = None
+    h = np.ascontiguousarray(h, dtype=np.float64); S = np.ascontiguousarray(S, dtype=np.float64); Si = np.zeros(len(h) + 1)
+    L.orc_ndiff_interface_scalar(len(h), _p(h), _p(S), _p(Si), int(i_method), float(h_neglect))
+    return Si
+
+
+def ndiff_find_neutral_surface_positions_continuous(Pl, Tl, Sl, dRdTl, dRdSl, Pr, Tr, Sr, dRdTr, dRdSr):
+    """-> PoL, PoR, KoL, KoR (1-based, as in the reference), hEff"""
+    L = lib(); f = L.orc_ndiff_find_neutral_surface_positions_continuous
+    _ip = C.POINTER(C.c_int)
+    f.argtypes = [C.c_int] + [_dp] * 10 + [_dp, _dp, _ip, _ip, _dp]; f.restype = None
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Pl, Tl, Sl, dRdTl, dRdSl, Pr, Tr, Sr, dRdTr, dRdSr)]
+    nk = len(a[0]) - 1; ns = 2 * nk + 2
+    PoL, PoR, hEff = np.zeros(ns), np.zeros(ns), np.zeros(ns - 1)
+    KoL, KoR = np.zeros(ns, dtype=np.int32), np.zeros(ns, dtype=np.int32)
+    f(nk, *[_p(x) for x in a], _p(PoL), _p(PoR), KoL.ctypes.data_as(_ip), KoR.ctypes.data_as(_ip), _p(hEff))
+    return PoL, PoR, KoL, KoR, hEff
+
+
+def ndiff_neutral_surface_flux(hl, hr, Tl, Tr, PiL, PiR, KoL, KoR, hEff, h_neglect):
+    L = lib(); f = L.orc_ndiff_neutral_surface_flux
+    _ip = C.POINTER(C.c_int)
+    f.argtypes = [C.c_int] + [_dp] * 6 + [_ip, _ip, _dp, _dp, C.c_double]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (hl, hr, Tl, Tr, PiL, PiR)]
+    KoL = np.ascontiguousarray(KoL, dtype=np.int32); KoR = np.ascontiguousarray(KoR, dtype=np.int32)
+    hEff = np.ascontiguousarray(hEff, dtype=np.float64)
+    Flx = np.zeros(len(hEff))
+    rc = f(len(a[0]), *[_p(x) for x in a], KoL.ctypes.data_as(_ip), KoR.ctypes.data_as(_ip), _p(hEff), _p(Flx), float(h_neglect))
+    if rc:
+        raise RuntimeError("ppm_ave: dx<0 or dx>1 should not happened!")
+    return Flx
 
 
 # ---- MOM_coms ---------------------------------------------------------------------------------------------

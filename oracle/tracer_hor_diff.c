@@ -1,6 +1,6 @@
 /* oracle/tracer_hor_diff.c -- TEST INFRASTRUCTURE: a C restatement of the along-layer branch of tracer_hordiff
- * (src/tracer/MOM_tracer_hor_diff.F90:119-680) with a constant KHTR (no VarMix, MEKE, neutral or boundary diffusion, no
- * epipycnal mixed-layer diffusion).  The reference holds no known-answer vectors for this routine: parity unpinned; the
+ * (src/tracer/MOM_tracer_hor_diff.F90:119-680) with KHTR or the VarMix / MEKE diffusivities, and the call of the neutral-diffusion branch
+ * (neutral_diffusion.c); no boundary diffusion, no epipycnal mixed-layer diffusion.  The reference holds no known-answer vectors for this routine: parity unpinned; the
  * tests hold it to exact conservation, preservation of constants and the maximum principle. */
 #include <math.h>
 #include <stdlib.h>
@@ -22,7 +22,21 @@ int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_
                               const double *h, double dt, double *const *tr, const double *conc_underflow, int ntr,
                               mom6hip_hordiff_stats_t *stats)
 {
-  for (int q = 0; q < 8; q++) if (CS->unsupported[q]) return 2;
+  if (CS->unsupported[0]) return 2;
+  return orc_tracer_hordiff_neutral(G, CS, NULL, F, h, NULL, NULL, dt, tr, conc_underflow, ntr, 0, 0, stats);
+}
+
+int orc_tracer_hordiff_neutral(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS,
+                               const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_hordiff_fields_t *F, const double *h,
+                               const mom6hip_eos_t *eos, const double *p_surf, double dt, double *const *tr,
+                               const double *conc_underflow, int ntr, int idx_T, int idx_S, mom6hip_hordiff_stats_t *stats)
+{
+  for (int q = 1; q < 8; q++) if (CS->unsupported[q]) return 2;
+  const int use_neutral = CS->unsupported[0] != 0;
+  if (use_neutral) {
+    if (!ND || !eos || idx_T < 0 || idx_T >= ntr || idx_S < 0 || idx_S >= ntr) return 3;
+    for (int q = 0; q < 8; q++) if (ND->unsupported[q]) return 2;
+  }
   if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
   const int use_VarMix = CS->use_variable_mixing != 0;
   if (ntr == 0 || (CS->KhTr <= 0.0 && !use_VarMix)) return 0;      /* :197 */
@@ -98,7 +112,11 @@ int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_
     I_numitts = 1.0 / ((double)num_itts);
   } else { num_itts = 1; I_numitts = 1.0; }
 
-  int halo_updates = 0;
+  int halo_updates = 0, rc = 0;
+  if (use_neutral)                                                 /* :474-534 */
+    rc = orc_neutral_branch(G, ND, eos, h, p_surf, khdt_x, khdt_y, num_itts, I_numitts, tr, conc_underflow, ntr, idx_T, idx_S,
+                            &halo_updates);
+  else
   for (int itt = 1; itt <= num_itts; itt++) {                      /* :540-604 */
     for (int m = 0; m < ntr; m++) orc_halo_update(G, tr[m], MOM6HIP_POS_H, nz);
     halo_updates++;
@@ -141,5 +159,5 @@ int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_
 #undef U2
 #undef V2
   free(khdt_x); free(khdt_y); free(Coef_x); free(Coef_y); free(Ihdxdy); free(dTr);
-  return 0;
+  return rc;
 }

@@ -1,0 +1,175 @@
+"""MOM_neutral_diffusion, the continuous-reconstruction branch (src/tracer/MOM_neutral_diffusion.F90), as tracer_hordiff calls it
+with USE_NEUTRAL_DIFFUSION (MOM_tracer_hor_diff.F90:474-534).  The oracle is pinned by every known answer of the reference's
+ndiff_unit_tests_continuous (:2576-2835, tests/golden/neutral_diffusion.json) and held to what the scheme guarantees; the library is
+compared with the oracle on the GPU, bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi, synth
+from oracle import orc
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "neutral_diffusion.json")))
+
+
+# ---- the reference's own unit-test answers ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("row", GOLD["fv_diff"], ids=[r[-1] for r in GOLD["fv_diff"]])
+def test_fv_diff_known_answers(row):
+    assert orc.ndiff_fv_diff(*row[:6]) == row[6]
+
+
+@pytest.mark.parametrize("row", GOLD["fvlsq_slope"], ids=[r[-1] for r in GOLD["fvlsq_slope"]])
+def test_fvlsq_slope_known_answers(row):
+    assert orc.ndiff_fvlsq_slope(*row[:6]) == row[6]
+
+
+@pytest.mark.parametrize("c", GOLD["interface_scalar"], ids=[c["title"] for c in GOLD["interface_scalar"]])
+def test_interface_scalar_known_answers(c):
+    assert np.array_equal(orc.ndiff_interface_scalar(c["h"], c["S"], c["i_method"], c["h_neglect"]), np.array(c["Si"]))
+
+
+@pytest.mark.parametrize("row", GOLD["ifndp"], ids=[r[-1] for r in GOLD["ifndp"]])
+def test_interpolate_for_nondim_position_known_answers(row):
+    assert orc.ndiff_ifndp(*row[:4]) == row[4]
+
+
+def _nsp(c):
+    return orc.ndiff_find_neutral_surface_positions_continuous(c["Pl"], c["Tl"], c["Sl"], c["dRdTl"], c["dRdSl"], c["Pr"], c["Tr"], c["Sr"],
+                                                               c["dRdTr"], c["dRdSr"])
+
+
+@pytest.mark.parametrize("c", GOLD["nsp"], ids=[c["title"] for c in GOLD["nsp"]])
+def test_find_neutral_surface_positions_continuous_known_answers(c):
+    PoL, PoR, KoL, KoR, hEff = _nsp(c)
+    assert list(KoL) == c["KoL"] and list(KoR) == c["KoR"]
+    assert np.array_equal(PoL, np.array(c["pL"])) and np.array_equal(PoR, np.array(c["pR"]))
+    assert np.array_equal(hEff, np.array(c["hEff"]))
+    if "abs_left" in c:      # absolute_positions :2277
+        P = np.array(c["Pl"])
+        assert np.array_equal(P[KoL - 1] + PoL * (P[KoL] - P[KoL - 1]), np.array(c["abs_left"]))
+        P = np.array(c["Pr"])
+        assert np.array_equal(P[KoR - 1] + PoR * (P[KoR] - P[KoR - 1]), np.array(c["abs_right"]))
+
+
+@pytest.mark.parametrize("c", GOLD["flux"], ids=[c["title"] for c in GOLD["flux"]])
+def test_neutral_surface_flux_known_answers(c):
+    PoL, PoR, KoL, KoR, hEff = _nsp(GOLD["nsp"][0])      # the surfaces of "Identical columns"
+    Flx = orc.ndiff_neutral_surface_flux(c["hl"], c["hr"], c["Tl"], c["Tr"], PoL, PoR, KoL, KoR, hEff, c["h_neglect"])
+    assert np.array_equal(Flx, np.array(c["Flx"]))
+
+
+# ---- the 3-D branch ----------------------------------------------------------------------------------------------------------------
+def case(ni=26, nj=18, nk=6, seed=3, reentrant=(True, False), land_frac=0.2, ntr=3, thin=True):
+    g = synth.make_grid(ni, nj, nk, land_frac=land_frac, seed=seed + 700, reentrant_x=reentrant[0], reentrant_y=reentrant[1])
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.1, eta_amp=0.2).items()}
+    rng = np.random.default_rng(seed)
+    h = np.ascontiguousarray(d["h"])
+    if thin:      # some vanished and some very thin layers, and a few unstable columns
+        h = np.ascontiguousarray(h * np.where(rng.random(h.shape) < 0.1, 0.0, 1.0) * np.where(rng.random(h.shape) < 0.1, 1.0e-9, 1.0))
+    T = np.ascontiguousarray(d["T"] + 0.5 * rng.standard_normal(h.shape)); S = np.ascontiguousarray(d["S"] + 0.05 * rng.standard_normal(h.shape))
+    tr = [T, S, np.ascontiguousarray((rng.random(h.shape) > 0.7) * 1.0 * g.mask2dT[None])][:ntr]
+    for t in tr + [h]:
+        orc.halo_update(g, t, _abi.POS_H)
+    return g, h, tr
+
+
+def inventory(g, h, t):
+    return float((interior(g, h) * interior(g, g.areaT)[None] * interior(g, t)).sum())
+
+
+@pytest.mark.parametrize("date", [20240101, 20240401])
+def test_oracle_neutral_branch_conserves_and_keeps_constants(date):
+    g, h, tr = case()
+    const = np.full_like(tr[0], 3.5)
+    tr = [t.copy() for t in tr] + [const]
+    before = [t.copy() for t in tr]
+    st = orc.tracer_hordiff(g, h, 3600.0, tr, 800.0, neutral=dict(eos=orc.eos("WRIGHT"), idx_T=0, idx_S=1, ndiff_answer_date=date))
+    assert st.num_itts == 1 and st.halo_updates == 1
+    hh = h + g.H_subroundoff
+    for m, (t0, t1) in enumerate(zip(before, tr)):
+        a, b = inventory(g, hh, t0), inventory(g, hh, t1)
+        assert abs(a - b) <= 1e-10 * max(1.0, abs(a)), (m, a, b)      # every flux leaves one cell and enters its neighbour
+    assert np.array_equal(interior(g, tr[-1]), interior(g, before[-1]))      # no differences, no fluxes: a constant stays to the bit
+    assert not np.array_equal(interior(g, tr[0]), interior(g, before[0]))
+    assert not np.array_equal(interior(g, tr[2]), interior(g, before[2]))
+
+
+def test_oracle_neutral_branch_iterates_and_refuses():
+    g, h, tr = case(ntr=2, thin=False)
+    a = [t.copy() for t in tr]; b = [t.copy() for t in tr]
+    nd = dict(eos=orc.eos("LINEAR"), idx_T=0, idx_S=1)
+    sa = orc.tracer_hordiff(g, h, 3600.0, a, 1.0e9, max_diff_CFL=2.5, neutral=nd)
+    sb = orc.tracer_hordiff(g, h, 3600.0, b, 1.0e9, max_diff_CFL=2.5, neutral=dict(nd, recalc_neutral_surf=True))
+    assert sa.num_itts == 3 and sa.halo_updates == 3 and sb.num_itts == 3      # one pass before the coefficients, one per later iteration
+    assert np.isfinite(a[0]).all() and not np.array_equal(a[0], b[0])          # RECALC_NEUTRAL_SURF moves the surfaces between iterations
+    with pytest.raises(RuntimeError):      # tv%T must be a registered tracer
+        orc.tracer_hordiff(g, h, 3600.0, [t.copy() for t in tr], 50.0, neutral=dict(nd, idx_T=5))
+
+
+ND_CASES = [dict(KhTr=800.0), dict(KhTr=800.0, ndiff_answer_date=20240401), dict(KhTr=1.0e9, max_diff_CFL=2.5),
+            dict(KhTr=1.0e9, max_diff_CFL=2.5, recalc_neutral_surf=True), dict(KhTr=800.0, ref_pres=2.0e7, eos="LINEAR"),
+            dict(KhTr=5.0e7, check_diffusive_CFL=True, reentrant=(True, True)), dict(KhTr=300.0, conc_underflow=[0.0, 0.0, 0.5]),
+            dict(KhTr=800.0, p_surf=True, reentrant=(False, False), ni=70, nj=9, nk=3), dict(KhTr=800.0, nk=2, thin=False),
+            dict(KhTr=800.0, nk=75, ni=12, nj=8)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", ND_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) for c in ND_CASES])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_tracer_hordiff_neutral_matches_oracle_bitwise(kw, space):
+    import torch
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
+    kw = dict(kw)
+    gk = {k: kw.pop(k) for k in ("reentrant", "ni", "nj", "nk", "thin") if k in kw}
+    cu = kw.pop("conc_underflow", None)
+    E = orc.eos(kw.pop("eos", "WRIGHT"))
+    g, h, tr = case(**gk)
+    p_surf = None
+    if kw.pop("p_surf", False):
+        p_surf = np.ascontiguousarray(1.0e4 * np.random.default_rng(8).random(g.shape2(_abi.POS_H)))
+    ndk = {k: kw[k] for k in ("ndiff_answer_date", "recalc_neutral_surf", "ref_pres") if k in kw}
+    ref = [t.copy() for t in tr]
+    rs = orc.tracer_hordiff(g, h, 3600.0, ref, kw["KhTr"], max_diff_CFL=kw.get("max_diff_CFL", -1.0),
+                            check_diffusive_CFL=kw.get("check_diffusive_CFL", False), conc_underflow=cu,
+                            neutral=dict(eos=E, idx_T=0, idx_S=1, p_surf=p_surf, **ndk))
+    dg = DeviceGrid(g)
+    put = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if space == "device" else (lambda a: np.ascontiguousarray(a).copy())
+    dtr = [put(t) for t in tr]
+    CS = tracer_hor_diff_init(KHTR=kw["KhTr"], MAX_TR_DIFFUSION_CFL=kw.get("max_diff_CFL", -1.0), CHECK_DIFFUSIVE_CFL=kw.get("check_diffusive_CFL", False),
+                              USE_NEUTRAL_DIFFUSION=True, NDIFF_REF_PRES=ndk.get("ref_pres", -1.0), NDIFF_ANSWER_DATE=ndk.get("ndiff_answer_date", 20240101),
+                              RECALC_NEUTRAL_SURF=ndk.get("recalc_neutral_surf", False))
+    tv = dict(T=dtr[0], S=dtr[1], eqn_of_state=E, p_surf=None if p_surf is None else put(p_surf))
+    st = tracer_hordiff(put(h), 3600.0, None, None, None, dg, CS, dtr, tv=tv, conc_underflow=cu)
+    dg.sync()
+    assert (st.num_itts, st.halo_updates) == (rs.num_itts, rs.halo_updates) and st.max_CFL == rs.max_CFL
+    for m, (a, b) in enumerate(zip(dtr, ref)):
+        an = a.cpu().numpy() if space == "device" else a
+        assert bits_equal(interior(g, an), interior(g, b)), m
+    assert not np.array_equal(interior(g, ref[0]), interior(g, tr[0]))
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_tracer_hordiff_neutral_refuses_what_it_does_not_provide():
+    import torch
+    from mom6_amd._lib import Mom6HipError
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
+    g, h, tr = case(ntr=2)
+    dg = DeviceGrid(g)
+    dh = torch.from_numpy(h).cuda(); dtr = [torch.from_numpy(t).cuda() for t in tr]
+    tv = dict(T=dtr[0], S=dtr[1], eqn_of_state=orc.eos("WRIGHT"))
+    with pytest.raises(Mom6HipError, match="NDIFF_CONTINUOUS"):
+        tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True, NDIFF_CONTINUOUS=False), dtr, tv=tv)
+    with pytest.raises(Mom6HipError, match="NDIFF_INTERIOR_ONLY"):
+        tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True, NDIFF_INTERIOR_ONLY=True), dtr, tv=tv)
+    with pytest.raises(Mom6HipError, match="tv%T"):
+        tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True), dtr, tv=None)
+    with pytest.raises(Mom6HipError, match="registered"):
+        tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True), dtr,
+                       tv=dict(tv, T=dtr[0].clone()))
+    dg.close()
