@@ -870,6 +870,19 @@ def main():
                     if q:
                         lat[name] += e0.elapsed_time(e1) / 3
                 del hh, uq, vq
+            # tracer_hordiff with USE_NEUTRAL_DIFFUSION (the continuous branch, NTR tracers of which two are T and S, KHTR = 50)
+            from mom6_amd.tracer_hor_diff import tracer_hor_diff_init as _hd_init, tracer_hordiff as _hd
+            nd_cs = _hd_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True)
+            trs = [d["T"].clone(), d["S"].clone()] + [torch.rand_like(d["T"]) for _ in range(max(NTR - 2, 0))]
+            tvn = dict(T=trs[0], S=trs[1], eqn_of_state=S.eos)
+            tn = 0.0
+            for q in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); _hd(d["h"], DT_THERM, None, None, None, S.dg, nd_cs, trs, tv=tvn); e1.record(); e1.synchronize()
+                if q:
+                    tn += e0.elapsed_time(e1) / 2
+            lat[f"tracer_hordiff[neutral,{len(trs)} tracers]"] = tn
+            del trs
             out["lateral_parameterizations_ms_per_call"] = lat
         except Exception as exc:      # (reported, never fatal to the bench line)
             out["lateral_parameterizations_ms_per_call"] = {"error": repr(exc)}

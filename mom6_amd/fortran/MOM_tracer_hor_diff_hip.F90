@@ -4,8 +4,10 @@
 !! KHTR (MAX_TR_DIFFUSION_CFL, CHECK_DIFFUSIVE_CFL, the tracers' conc_underflow) or, with VarMix%use_variable_mixing, the face
 !! diffusivities of :236-281 (KHTR_SLOPE_CFF with VarMix%L2u / SN_u, MEKE%KhTr_fac with MEKE%Kh, KHTR_MIN / KHTR_MAX,
 !! RESOLN_SCALED_KHTR with VarMix%Res_fn_h, KHTR_PASSIVITY_COEFF / _MIN with VarMix%Rd_dx_h) on the GPU through libmom6hip
-!! (mom6hip_tracer_hordiff_varmix, HOST memspace).  Neutral diffusion, horizontal boundary diffusion, DIFFUSE_ML_TO_INTERIOR,
-!! KHTR_USE_EBT_STRUCT, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
+!! (mom6hip_tracer_hordiff_varmix, HOST memspace), and with USE_NEUTRAL_DIFFUSION the continuous branch of MOM_neutral_diffusion
+!! (neutral_diffusion_init :138, neutral_diffusion_calc_coeffs :337, neutral_diffusion :605: NDIFF_REF_PRES, NDIFF_ANSWER_DATE,
+!! RECALC_NEUTRAL_SURF; mom6hip_tracer_hordiff_neutral).  NDIFF_CONTINUOUS = False, NDIFF_INTERIOR_ONLY, horizontal boundary diffusion,
+!! DIFFUSE_ML_TO_INTERIOR, KHTR_USE_EBT_STRUCT, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
 !!
 !! Compiled INSIDE a MOM6 source tree in place of src/tracer/MOM_tracer_hor_diff.F90; here against tests/fortran/stubs.
 module MOM_tracer_hor_diff
@@ -13,7 +15,7 @@ module MOM_tracer_hor_diff
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
-use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
+use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_read_eos
 use MOM_cpu_clock,             only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
 use MOM_diabatic_driver,       only : diabatic_CS
 use MOM_diag_mediator,         only : diag_ctrl, time_type
@@ -45,6 +47,9 @@ type, public :: tracer_hor_diff_CS ; private
   logical :: check_diffusive_CFL  !< If true, use enough iterations that the diffusive equations are stable.
   logical :: Diffuse_ML_interior, use_neutral_diffusion, use_hor_bnd_diffusion
   logical :: first_call = .true.
+  logical :: recalc_neutral_surf  !< If true, recalculate the neutral surfaces if CFL has been exceeded
+  type(mom6hip_neutral_diffusion_cs_t) :: nd   !< neutral_diffusion_CS as the library reads it
+  type(mom6hip_eos_t) :: eos                   !< the equation of state neutral_diffusion_init was given
   type(diag_ctrl), pointer :: diag => NULL()
 end type tracer_hor_diff_CS
 
@@ -75,7 +80,8 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
   type(mom6hip_hordiff_stats_t) :: stats
   type(c_ptr), allocatable :: tr(:)
   real(c_double), allocatable, target :: cu(:)
-  integer :: m, rc
+  type(c_ptr) :: p_surf
+  integer :: m, rc, idx_T, idx_S
 
   if (.not. associated(CS)) call MOM_error(FATAL, "MOM_tracer_hor_diff: "// &
        "register_tracer must be called before tracer_hordiff.")
@@ -110,19 +116,34 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
     if (CS%KhTr_passivity_coeff > 0.) fld%Rd_dx_h = c_loc(VarMix%Rd_dx_h)
     if (allocated(MEKE%Kh)) then ; fld%MEKE_Kh = c_loc(MEKE%Kh) ; ccs%KhTr_fac = MEKE%KhTr_fac ; endif
   endif
+  idx_T = -1 ; idx_S = -1 ; p_surf = c_null_ptr
+  if (CS%use_neutral_diffusion) then      ! :474-534: tv%T and tv%S are registered tracers, found by association
+    ccs%unsupported(1) = 1
+    if (.not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, &
+      "tracer_hordiff (HIP): USE_NEUTRAL_DIFFUSION needs tv%T and tv%S.")
+    do m=1,Reg%ntr
+      if (associated(Reg%Tr(m)%t, tv%T)) idx_T = m-1
+      if (associated(Reg%Tr(m)%t, tv%S)) idx_S = m-1
+    enddo
+    if (idx_T < 0 .or. idx_S < 0) call MOM_error(FATAL, "tracer_hordiff (HIP): tv%T and tv%S must be registered tracers.")
+    if (associated(tv%p_surf)) p_surf = c_loc(tv%p_surf)
+    CS%nd%H_to_RZ = GV%H_to_RZ ; CS%nd%recalc_neutral_surf = merge(1, 0, CS%recalc_neutral_surf)
+  endif
   if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays
     ctx = mom6hip_shared_context(G, GV)
     do m=1,Reg%ntr ; tr(m) = mom6hip_mirror(ctx, tr(m), int(size(h), c_int64_t), .true., .true.) ; enddo
+    call to_dev(p_surf, size(h(:,:,1)))
     call to_dev(fld%MEKE_Kh, size(h(:,:,1))) ; call to_dev(fld%Res_fn_h, size(h(:,:,1))) ; call to_dev(fld%Rd_dx_h, size(h(:,:,1)))
     if (c_associated(fld%L2u)) then
       call to_dev(fld%L2u, size(VarMix%L2u)) ; call to_dev(fld%SN_u, size(VarMix%SN_u))
       call to_dev(fld%L2v, size(VarMix%L2v)) ; call to_dev(fld%SN_v, size(VarMix%SN_v))
     endif
-    rc = mom6hip_tracer_hordiff_varmix(ctx, ccs, fld, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), dt, tr, &
-                                       c_loc(cu), int(Reg%ntr, c_int32_t), MOM6HIP_MEM_DEVICE, stats)
+    rc = mom6hip_tracer_hordiff_neutral(ctx, ccs, CS%nd, fld, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), &
+                                        CS%eos, p_surf, dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), int(idx_T, c_int32_t), &
+                                        int(idx_S, c_int32_t), MOM6HIP_MEM_DEVICE, stats)
   else
-    rc = mom6hip_tracer_hordiff_varmix(mom6hip_shared_context(G, GV), ccs, fld, c_loc(h), dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), &
-                                       MOM6HIP_MEM_HOST, stats)
+    rc = mom6hip_tracer_hordiff_neutral(mom6hip_shared_context(G, GV), ccs, CS%nd, fld, c_loc(h), CS%eos, p_surf, dt, tr, c_loc(cu), &
+                                        int(Reg%ntr, c_int32_t), int(idx_T, c_int32_t), int(idx_S, c_int32_t), MOM6HIP_MEM_HOST, stats)
   endif
   call mom6hip_fatal_if(rc, "tracer_hordiff")
   call cpu_clock_end(id_clock_diffuse)
@@ -181,8 +202,27 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
   call get_param(param_file, mdl, "MAX_TR_DIFFUSION_CFL", CS%max_diff_CFL, &
                  "If positive, locally limit the along-isopycnal tracer diffusivity to keep the diffusive CFL below this.", &
                  units="nondim", default=-1.0)
-  call get_param(param_file, mdl, "USE_NEUTRAL_DIFFUSION", CS%use_neutral_diffusion, default=.false.)
-  call refuse(CS%use_neutral_diffusion, "USE_NEUTRAL_DIFFUSION")
+  call get_param(param_file, mdl, "RECALC_NEUTRAL_SURF", CS%recalc_neutral_surf, &
+                 "If true, then recalculate the neutral surfaces if the CFL has been exceeded", default=.false.)
+  ! neutral_diffusion_init :138-330
+  call get_param(param_file, "MOM_neutral_diffusion", "USE_NEUTRAL_DIFFUSION", CS%use_neutral_diffusion, &
+                 "If true, enables the neutral diffusion module.", default=.false.)
+  if (CS%use_neutral_diffusion) then
+    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_CONTINUOUS", flag, &
+                   "If true, uses a continuous reconstruction of T and S when finding neutral surfaces.", default=.true.)
+    call refuse(.not.flag, "NDIFF_CONTINUOUS = False")
+    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_REF_PRES", CS%nd%ref_pres, &
+                   "The reference pressure (Pa) used for the derivatives of the equation of state. If negative (default), "//&
+                   "local pressure is used.", units="Pa", default=-1., scale=US%Pa_to_RL2_T2)
+    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_INTERIOR_ONLY", flag, default=.false.)
+    call refuse(flag, "NDIFF_INTERIOR_ONLY")
+    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_USE_UNMASKED_TRANSPORT_BUG", flag, default=.false.)
+    call refuse(flag, "NDIFF_USE_UNMASKED_TRANSPORT_BUG")
+    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_ANSWER_DATE", CS%nd%ndiff_answer_date, &
+                   "The vintage of the order of arithmetic to use for the neutral diffusion.", default=20240101)
+    call mom6hip_read_eos(param_file, CS%eos, "neutral_diffusion_init")
+    CS%nd%initialized = 1 ; CS%nd%unsupported(:) = 0
+  endif
   call get_param(param_file, mdl, "USE_HORIZONTAL_BOUNDARY_DIFFUSION", CS%use_hor_bnd_diffusion, default=.false.)
   call refuse(CS%use_hor_bnd_diffusion, "USE_HORIZONTAL_BOUNDARY_DIFFUSION")
   call mom6hip_read_topology(param_file)

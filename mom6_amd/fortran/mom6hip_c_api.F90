@@ -181,6 +181,15 @@ type, bind(c) :: mom6hip_hordiff_fields_t
   type(c_ptr) :: reserved(5) = c_null_ptr
 end type mom6hip_hordiff_fields_t
 
+!> mom6hip_neutral_diffusion_cs_t (neutral_diffusion_CS, src/tracer/MOM_neutral_diffusion.F90:38), the continuous branch
+type, bind(c) :: mom6hip_neutral_diffusion_cs_t
+  real(c_double) :: ref_pres = -1.0, H_to_RZ = 0.0
+  real(c_double) :: reserved0(4) = 0.0
+  integer(c_int32_t) :: ndiff_answer_date = 20240101, recalc_neutral_surf = 0, initialized = 0
+  integer(c_int32_t) :: reserved_i(1) = 0
+  integer(c_int32_t) :: unsupported(8) = 0
+end type mom6hip_neutral_diffusion_cs_t
+
 !> mom6hip_hordiff_stats_t
 type, bind(c) :: mom6hip_hordiff_stats_t
   integer(c_int32_t) :: num_itts, halo_updates
@@ -459,6 +468,23 @@ interface
     type(mom6hip_hordiff_stats_t), intent(out) :: stats
     integer(c_int) :: rc
   end function mom6hip_tracer_hordiff_varmix
+
+  !> tracer_hordiff with CS%use_neutral_diffusion (cs%unsupported(1)); idx_T, idx_S: the 0-based places of tv%T, tv%S in tr
+  function mom6hip_tracer_hordiff_neutral(ctx, cs, nd, fields, h, eos, p_surf, dt, tr, conc_underflow, ntr, idx_T, idx_S, memspace, &
+                                          stats) bind(c, name="mom6hip_tracer_hordiff_neutral") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_tracer_hor_diff_cs_t, mom6hip_hordiff_stats_t, mom6hip_hordiff_fields_t, &
+              mom6hip_neutral_diffusion_cs_t, mom6hip_eos_t
+    type(c_ptr), value :: ctx, h, p_surf, conc_underflow
+    type(mom6hip_tracer_hor_diff_cs_t), intent(in) :: cs
+    type(mom6hip_neutral_diffusion_cs_t), intent(in) :: nd
+    type(mom6hip_hordiff_fields_t), intent(in) :: fields
+    type(mom6hip_eos_t), intent(in) :: eos
+    real(c_double), value :: dt
+    type(c_ptr), intent(in) :: tr(*)
+    integer(c_int32_t), value :: ntr, idx_T, idx_S, memspace
+    type(mom6hip_hordiff_stats_t), intent(out) :: stats
+    integer(c_int) :: rc
+  end function mom6hip_tracer_hordiff_neutral
 
   !> subchk / subStats of MOM_checksums (MOM_checksums.F90:1387) on a device or host field of staggering pos
   function mom6hip_chksum(ctx, field, pos, nk, di, dj, symmetric, scale, bitcount, amin, amax, memspace) &

@@ -166,7 +166,7 @@ implicit none ; private
 public :: unit_scale_type
 type :: unit_scale_type
   real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0, &
-          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0
+          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0, Pa_to_RL2_T2 = 1.0
 end type unit_scale_type
 end module MOM_unit_scaling
 

@@ -94,6 +94,7 @@ VarMix%use_variable_mixing = (opt(2) /= 0) ; VarMix%Resoln_scaled_KhTr = (opt(3)
 if (opt(4) == 0) deallocate(MEKE%Kh)
 allocate(Reg) ; Reg%ntr = ntr
 do m=1,ntr ; Reg%Tr(m)%t => trs(:,:,:,m) ; enddo
+if (ntr >= 2) then ; tv%T => trs(:,:,:,1) ; tv%S => trs(:,:,:,2) ; tv%eqn_of_state => EOS ; endif      ! (read with USE_NEUTRAL_DIFFUSION)
 
 call param_set(pf, "REENTRANT_X", merge("True ", "False", hdr(5) /= 0))
 call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))

@@ -210,7 +210,8 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
     from mom6_amd import synth as sy
     ad = {k: (v if isinstance(v, list) else v.numpy()) for k, v in sy.make_advection_state(g, ntr=1, seed=9).items()}
     f = varmix_fields(g)
-    kw = dict(VM[name]) if name else dict(KhTr=300.0, use=None)
+    neutral = name == "neutral"      # USE_NEUTRAL_DIFFUSION with the first two tracers as tv%T, tv%S
+    kw = dict(VM[name]) if name and not neutral else dict(KhTr=300.0, use=None)
     use = kw.pop("use"); meke = kw.pop("meke", None); check = kw.pop("check", False)
     ref = [t.copy() for t in tr]
     orc.advect_tracer(g, ad["h_end"], ad["uhtr"], ad["vhtr"], dt, 900.0, scheme, ref)
@@ -218,7 +219,8 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
         orc.halo_update(g, t, _abi.POS_H)
     KhTr = kw.pop("KhTr")
     orc.tracer_hordiff(g, ad["h_end"], dt, ref, KhTr, check_diffusive_CFL=check, VarMix=None if use is None else {n: f[n] for n in use},
-                       MEKE=None if meke is None else dict(Kh=f["Kh"], KhTr_fac=meke), **kw)
+                       MEKE=None if meke is None else dict(Kh=f["Kh"], KhTr_fac=meke),
+                       neutral=dict(eos=orc.eos("WRIGHT"), idx_T=0, idx_S=1, ndiff_answer_date=20240401, H_to_RZ=1035.0) if neutral else None, **kw)
     opt = [len(tr), int(use is not None), int(use is not None and "Res_fn_h" in use), int(meke is not None), 0, 0, 0, 0]
     with open(tmp / "in.bin", "wb") as fh:
         np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
@@ -235,6 +237,8 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
         fh.write(f"TRACER_ADVECTION_SCHEME = {scheme}\nDT = 900.0\nKHTR = {KhTr!r}\nCHECK_DIFFUSIVE_CFL = {check}\nGPU_RESIDENT_DYNAMICS = {resident}\n")
         for k, v in kw.items():
             fh.write(f"{REF[k]} = {float(v)!r}\n")
+        if neutral:
+            fh.write("USE_NEUTRAL_DIFFUSION = True\nNDIFF_ANSWER_DATE = 20240401\nEQN_OF_STATE = WRIGHT\n")
     return ref
 
 
@@ -262,7 +266,7 @@ def test_tracer_module_shims_match_oracle(tmp_path):
         pytest.skip("amdflang not present")
     exe = _build_shims(tmp_path, driver="tracer_driver")
     g, h, tr = case(36, 22, 4)
-    for name, resident in [(n, r) for n in [None] + list(VM) for r in (False, True)]:      # staged host arrays, or the shared device mirrors
+    for name, resident in [(n, r) for n in [None, "neutral"] + list(VM) for r in (False, True)]:      # staged host arrays, or the shared device mirrors
         ref = _write_tracer_case(tmp_path, g, h, tr, name, resident=resident)
         r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
         assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (name, r.stderr[-600:])
