@@ -227,3 +227,37 @@ def test_lateral_parameterizations_are_overturnings_that_conserve_volume(world):
     deep = zmin > 1.05 * 100.0 + 1.0
     assert float(deep.double().mean()) > 0.3
     assert float(((_inner(g, h2) - _inner(g, h)).abs() * deep).max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_neutral_diffusion_conserves_keeps_constants_and_mixes_nothing_across_density(world):
+    """tracer_hordiff with USE_NEUTRAL_DIFFUSION at full size: the inventory of every tracer over (h + H_subroundoff) * area is conserved
+    (a flux leaves one cell and enters its neighbour), a constant tracer keeps its bits (no differences, no fluxes), a tracer that is a
+    function of density alone -- here temperature itself under a linear equation of state without a salinity term -- has nothing to
+    flux along neutral surfaces beyond the interpolation's residue, while a passive tracer unrelated to density is mixed"""
+    import torch
+    from mom6_amd.pressure_force import EOS_init
+    from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
+    g, dg, d = world["g"], world["dg"], world["dyn"]
+    h = d["h"]
+    A = _inner(g, world["areaT"])[None]
+    hh = _inner(g, h) + g.H_subroundoff
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    T, S = d["T"].clone(), d["S"].clone()
+    passive = (torch.rand(T.shape, device="cuda", dtype=torch.float64, generator=gen) * world["mT"][None]).contiguous()
+    const = torch.full_like(T, 2.75)
+    trs = [T, S, passive, const]
+    before = [t.clone() for t in trs]
+    CS = tracer_hor_diff_init(KHTR=1000.0, USE_NEUTRAL_DIFFUSION=True)
+    st = tracer_hordiff(h, 7200.0, None, None, None, dg, CS, trs, tv=dict(T=T, S=S, eqn_of_state=EOS_init("LINEAR", dRho_dT=-0.2, dRho_dS=0.0)))
+    dg.sync()
+    assert st.num_itts == 1 and st.halo_updates == 1
+    for m, (a, b) in enumerate(zip(before, trs)):
+        ai, bi = _inner(g, a), _inner(g, b)
+        assert bool(torch.isfinite(bi).all())
+        s0, s1 = float((hh * A * ai).sum()), float((hh * A * bi).sum())
+        assert abs(s1 - s0) <= 1e-11 * max(abs(s0), 1.0), (m, s0, s1)
+    assert torch.equal(_inner(g, trs[3]), _inner(g, before[3]))
+    dT = float((_inner(g, T) - _inner(g, before[0])).abs().max())
+    dP = float((_inner(g, passive) - _inner(g, before[2])).abs().max())
+    assert dP > 1e-3 and dT < 0.05 * dP, (dT, dP)      # density's own tracer barely moves along its own surfaces; the passive one mixes
