@@ -7,7 +7,8 @@
 //                         the two columns; PoL, PoR, KoL, KoR, hEff (back in H units, :570-575) as [surface][face] planes
 //   nd_tracer_cols_kernel interface values and the limited PPM edge values of one tracer (neutral_surface_flux :2373-2377,
 //                         ppm_left_right_edge_values :2541) for one h column
-//   nd_flux_kernel        neutral_surface_flux (:2297) for one face -> Flx [surface][face]
+//   nd_flux_kernel        neutral_surface_flux (:2297) for one face -> Flx [surface][face]; the surfaces of the face are read once for a
+//                         batch of up to 4 tracers (their fluxes are independent of each other)
 //   nd_update_kernel      the tendencies of a cell from its four faces in the reference's order of the surfaces (:927-954), accumulated
 //                         per layer in LDS (the layer index is data: KoL / KoR), and the update of the tracer (:955-959)
 // A lane owns a column or a face and walks it: the walks are serial in the surface index and differ from lane to lane, the planes
@@ -107,6 +108,9 @@ __device__ __forceinline__ double ppm_ave(double xL, double xR, double aL, doubl
   return (aL + xave * ((aR - aL) + a6)) - a6o3 * (xR * xR + xR * xL + xL * xL);
 }
 
+#define ND_BATCH 4
+typedef unsigned char ko_t;      // a layer number 1 .. nk <= 128
+
 struct NDArgs {
   m6::GridDev g;
   EosDev E;
@@ -115,13 +119,15 @@ struct NDArgs {
   int ns, symmetric;                // 2nk+2 ; ndiff_answer_date > 20240330
   const double *h, *T, *S, *p_surf;
   double *Pint, *Tint, *Sint, *dRdT, *dRdS;   // [(nk+1)][h points]
-  double *PoL[2], *PoR[2], *hEff[2], *Flx[2]; // [surface][faces of the direction]
-  int *KoL[2], *KoR[2];
+  double *PoL[2], *PoR[2], *hEff[2], *Flx[2]; // [surface][faces of the direction]; Flx: + flx_stride per tracer of the batch
+  ko_t *KoL[2], *KoR[2];
   const double *khdt[2];
-  double *t;                        // the tracer being diffused
-  double *Ti, *aL, *aR;             // its interface and edge values, [(nk+1)] / [nk][h points]
-  double *stash;                    // [3][nk][h points], the symmetric form's N, S, E tendencies
-  double cu;                        // conc_underflow of the tracer
+  int nb;                           // tracers in this batch (<= ND_BATCH): the surfaces are read once for all of them
+  double *t[ND_BATCH];              // the tracers being diffused
+  double *Ti, *aL, *aR;             // their interface and edge values, [(nk+1)] / [nk][h points], + col_stride per tracer
+  long col_stride, flx_stride;
+  double *stash;                    // [3][nk][h points], the symmetric form's N, S, E tendencies, + 3 nk hpl per tracer
+  double cu[ND_BATCH];              // conc_underflow of the tracers
   int *bad;
 };
 
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
   const long f = DIR ? g.v2(i, j) : g.u2(i, j), pl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
   const long hpl = (long)g.nih * g.njh, cl = g.h2(i, j), cr = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
   double *__restrict__ PoL = A.PoL[DIR], *__restrict__ PoR = A.PoR[DIR], *__restrict__ hEff = A.hEff[DIR];
-  int *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
+  ko_t *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
   const int ns = A.ns;
   if (!((DIR ? g.mask2dCv[f] : g.mask2dCu[f]) > 0.0)) {      // :472-481: what the arrays hold where no surfaces are searched for
     for (int ks = 0; ks < ns; ks++) {
@@ -164,14 +170,22 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
                              *__restrict__ dRdS = A.dRdS;
 #define LC(a, k) a[cl + hpl * ((k) - 1)]
 #define RC(a, k) a[cr + hpl * ((k) - 1)]
+  // The walk reads interface klm1 = max(kl-1, 1), klm1+1 and kl of the left column (and the same of the right): two interfaces a side
+  // are kept in registers -- A at klm1, B at klm1+1; interface kl is A while kl = 1 and B afterwards -- and a step that moves kl or kr
+  // down by one loads one new interface (the lanes of a wave stand at different depths, so every load here is a gather).
+  struct Iface { double P, T, S, rT, rS; };
+  auto loadL = [&](int k) { return Iface{LC(Pint, k), LC(Tint, k), LC(Sint, k), LC(dRdT, k), LC(dRdS, k)}; };
+  auto loadR = [&](int k) { return Iface{RC(Pint, k), RC(Tint, k), RC(Sint, k), RC(dRdT, k), RC(dRdS, k)}; };
+  Iface LA = loadL(1), LB = loadL(2), RA = loadR(1), RB = loadR(2);
   int kr = 1, kl = 1, lastK_right = 1, lastK_left = 1;
   double lastP_right = 0., lastP_left = 0., absL_prev = 0., absR_prev = 0.;
   bool reached_bottom = false, searching_left = false, searching_right = false;
   for (int ks = 0; ks < ns; ks++) {
     int klm1 = (kl - 1 > 1) ? kl - 1 : 1;
     int krm1 = (kr - 1 > 1) ? kr - 1 : 1;
-    const double Tr_kr = RC(Tint, kr), Sr_kr = RC(Sint, kr), aTr_kr = RC(dRdT, kr), aSr_kr = RC(dRdS, kr);
-    const double Tl_kl = LC(Tint, kl), Sl_kl = LC(Sint, kl), aTl_kl = LC(dRdT, kl), aSl_kl = LC(dRdS, kl);
+    const Iface Lk = (kl == 1) ? LA : LB, Rk = (kr == 1) ? RA : RB;
+    const double Tr_kr = Rk.T, Sr_kr = Rk.S, aTr_kr = Rk.rT, aSr_kr = Rk.rS;
+    const double Tl_kl = Lk.T, Sl_kl = Lk.S, aTl_kl = Lk.rT, aSl_kl = Lk.rS;
     const double dRho = 0.5 * ((aTr_kr + aTl_kl) * (Tr_kr - Tl_kl) + (aSr_kr + aSl_kl) * (Sr_kr - Sl_kl));
     if (!reached_bottom) {
       if (dRho < 0.) { searching_left = true; searching_right = false; }
@@ -182,33 +196,35 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
     double pL, pR;
     int oKL, oKR;
     if (searching_left) {
-      const double dRhoTop = 0.5 * ((LC(dRdT, klm1) + aTr_kr) * (LC(Tint, klm1) - Tr_kr) + (LC(dRdS, klm1) + aSr_kr) * (LC(Sint, klm1) - Sr_kr));
-      const double dRhoBot = 0.5 * ((LC(dRdT, klm1 + 1) + aTr_kr) * (LC(Tint, klm1 + 1) - Tr_kr) +
-                                    (LC(dRdS, klm1 + 1) + aSr_kr) * (LC(Sint, klm1 + 1) - Sr_kr));
+      const double dRhoTop = 0.5 * ((LA.rT + aTr_kr) * (LA.T - Tr_kr) + (LA.rS + aSr_kr) * (LA.S - Sr_kr));
+      const double dRhoBot = 0.5 * ((LB.rT + aTr_kr) * (LB.T - Tr_kr) + (LB.rS + aSr_kr) * (LB.S - Sr_kr));
       if (dRhoTop > 0. || kr + kl == 2) pL = 0.;
       else if (dRhoTop >= dRhoBot) pL = 1.;
-      else pL = interp_nondim(dRhoTop, LC(Pint, klm1), dRhoBot, LC(Pint, klm1 + 1));
+      else pL = interp_nondim(dRhoTop, LA.P, dRhoBot, LB.P);
       if (pL >= 1. && klm1 < nk) { klm1 = klm1 + 1; pL = pL - 1.; }
       if ((double)(klm1 - lastK_left) + (pL - lastP_left) < 0.) { pL = lastP_left; klm1 = lastK_left; }
       oKL = klm1;
       if (kr <= nk) { pR = 0.; oKR = kr; } else { pR = 1.; oKR = nk; }
-      if (kr <= nk) kr = kr + 1;
-      else { reached_bottom = true; searching_right = true; searching_left = false; }
+      if (kr <= nk) {
+        kr = kr + 1;
+        if (kr > 2) { RA = RB; RB = loadR(kr); }
+      } else { reached_bottom = true; searching_right = true; searching_left = false; }
     } else {
-      const double dRhoTop = 0.5 * ((RC(dRdT, krm1) + aTl_kl) * (RC(Tint, krm1) - Tl_kl) + (RC(dRdS, krm1) + aSl_kl) * (RC(Sint, krm1) - Sl_kl));
-      const double dRhoBot = 0.5 * ((RC(dRdT, krm1 + 1) + aTl_kl) * (RC(Tint, krm1 + 1) - Tl_kl) +
-                                    (RC(dRdS, krm1 + 1) + aSl_kl) * (RC(Sint, krm1 + 1) - Sl_kl));
+      const double dRhoTop = 0.5 * ((RA.rT + aTl_kl) * (RA.T - Tl_kl) + (RA.rS + aSl_kl) * (RA.S - Sl_kl));
+      const double dRhoBot = 0.5 * ((RB.rT + aTl_kl) * (RB.T - Tl_kl) + (RB.rS + aSl_kl) * (RB.S - Sl_kl));
       if (dRhoTop >= 0. || kr + kl == 2) pR = 0.;
       else if (dRhoTop >= dRhoBot) pR = 1.;
-      else pR = interp_nondim(dRhoTop, RC(Pint, krm1), dRhoBot, RC(Pint, krm1 + 1));
+      else pR = interp_nondim(dRhoTop, RA.P, dRhoBot, RB.P);
       if (pR >= 1. && krm1 < nk) { krm1 = krm1 + 1; pR = pR - 1.; }
       if ((double)(krm1 - lastK_right) + (pR - lastP_right) < 0.) { pR = lastP_right; krm1 = lastK_right; }
       oKR = krm1;
       if (kl <= nk) { pL = 0.; oKL = kl; } else { pL = 1.; oKL = nk; }
-      if (kl <= nk) kl = kl + 1;
-      else { reached_bottom = true; searching_right = false; searching_left = true; }
+      if (kl <= nk) {
+        kl = kl + 1;
+        if (kl > 2) { LA = LB; LB = loadL(kl); }
+      } else { reached_bottom = true; searching_right = false; searching_left = true; }
     }
-    PoL[f + pl * ks] = pL; PoR[f + pl * ks] = pR; KoL[f + pl * ks] = oKL; KoR[f + pl * ks] = oKR;
+    PoL[f + pl * ks] = pL; PoR[f + pl * ks] = pR; KoL[f + pl * ks] = (ko_t)oKL; KoR[f + pl * ks] = (ko_t)oKR;
     lastK_left = oKL; lastP_left = pL; lastK_right = oKR; lastP_right = pR;
     // absolute_position :2258 of this surface; that of the one above is the value formed a step ago from the same expression
     const double PL0 = LC(Pint, oKL), PR0 = RC(Pint, oKR);
@@ -227,20 +243,22 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
 
 __global__ __launch_bounds__(64) void nd_tracer_cols_kernel(NDArgs A) {
   const m6::GridDev &g = A.g;
-  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk;
+  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk, z = blockIdx.z;
   if (i > g.iec + 1) return;
   const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
+  const double *__restrict__ t = A.t[z];
+  double *__restrict__ oTi = A.Ti + A.col_stride * z, *__restrict__ oaL = A.aL + A.col_stride * z, *__restrict__ oaR = A.aR + A.col_stride * z;
   double d = 0., Ti_prev = 0.;
   for (int K = 0; K <= nk; K++) {
-    const double Ti = interface_value(A.h, A.t, n2, hpl, K, nk, A.h_neglect, d);
-    A.Ti[n2 + hpl * K] = Ti;
+    const double Ti = interface_value(A.h, t, n2, hpl, K, nk, A.h_neglect, d);
+    oTi[n2 + hpl * K] = Ti;
     if (K > 0) {      // ppm_left_right_edge_values :2541 of layer K-1
-      const double Tl = A.t[n2 + hpl * (K - 1)];
+      const double Tl = t[n2 + hpl * (K - 1)];
       double aL = Ti_prev, aR = Ti;
       if (signum(1., aR - Tl) * signum(1., Tl - aL) <= 0.0) { aL = Tl; aR = Tl; }
       else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) > fabs(aR - aL)) aL = Tl + 2.0 * (Tl - aR);
       else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) < -fabs(aR - aL)) aR = Tl + 2.0 * (Tl - aL);
-      A.aL[n2 + hpl * (K - 1)] = aL; A.aR[n2 + hpl * (K - 1)] = aR;
+      oaL[n2 + hpl * (K - 1)] = aL; oaR[n2 + hpl * (K - 1)] = aR;
     }
     Ti_prev = Ti;
   }
@@ -255,38 +273,59 @@ __global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
   const long f = DIR ? g.v2(i, j) : g.u2(i, j), pl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
   const long hpl = (long)g.nih * g.njh, cl = g.h2(i, j), cr = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
   double *__restrict__ Flx = A.Flx[DIR];
-  const int ns = A.ns;
+  const int ns = A.ns, nb = A.nb;
   if (!((DIR ? g.mask2dCv[f] : g.mask2dCu[f]) > 0.0)) {
-    for (int ks = 0; ks < ns - 1; ks++) Flx[f + pl * ks] = 0.;
+    for (int z = 0; z < nb; z++)
+      for (int ks = 0; ks < ns - 1; ks++) Flx[A.flx_stride * z + f + pl * ks] = 0.;
     return;
   }
   const double *__restrict__ PiL = A.PoL[DIR], *__restrict__ PiR = A.PoR[DIR], *__restrict__ hEff = A.hEff[DIR];
-  const int *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
-  const double *__restrict__ Ti = A.Ti, *__restrict__ aL = A.aL, *__restrict__ aR = A.aR, *__restrict__ t = A.t;
+  const ko_t *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
   int bad = 0;
   double pLt = PiL[f], pRt = PiR[f];
   int klt = KoL[f] - 1, krt = KoR[f] - 1;
+  // per tracer: the value at the top surface (the reference's T_*_top of a layer is its T_*_bottom of the layer above: the same
+  // expression of the same numbers) and the edge / mean values of the cells klt, krt, reloaded when the surface enters another cell
+  double Ttop_l[ND_BATCH], Ttop_r[ND_BATCH], eL_l[ND_BATCH], eR_l[ND_BATCH], tm_l[ND_BATCH], eL_r[ND_BATCH], eR_r[ND_BATCH], tm_r[ND_BATCH];
+#pragma unroll
+  for (int z = 0; z < ND_BATCH; z++) {
+    if (z < nb) {
+      const double *__restrict__ Ti = A.Ti + A.col_stride * z, *__restrict__ aL = A.aL + A.col_stride * z, *__restrict__ aR = A.aR + A.col_stride * z;
+      Ttop_l[z] = (1. - pLt) * Ti[cl + hpl * klt] + pLt * Ti[cl + hpl * (klt + 1)];
+      Ttop_r[z] = (1. - pRt) * Ti[cr + hpl * krt] + pRt * Ti[cr + hpl * (krt + 1)];
+      eL_l[z] = aL[cl + hpl * klt]; eR_l[z] = aR[cl + hpl * klt]; tm_l[z] = A.t[z][cl + hpl * klt];
+      eL_r[z] = aL[cr + hpl * krt]; eR_r[z] = aR[cr + hpl * krt]; tm_r[z] = A.t[z][cr + hpl * krt];
+    }
+  }
   for (int ks = 0; ks < ns - 1; ks++) {
     const double pLb = PiL[f + pl * (ks + 1)], pRb = PiR[f + pl * (ks + 1)];
     const int klb = KoL[f + pl * (ks + 1)] - 1, krb = KoR[f + pl * (ks + 1)] - 1;
     const double he = hEff[f + pl * ks];
-    double flx = 0.;
-    if (he != 0.) {
-      const double T_left_bottom = (1. - pLb) * Ti[cl + hpl * klb] + pLb * Ti[cl + hpl * (klb + 1)];
-      const double T_left_top = (1. - pLt) * Ti[cl + hpl * klt] + pLt * Ti[cl + hpl * (klt + 1)];
-      const double T_left_layer = ppm_ave(pLt, pLb + (double)(klb - klt), aL[cl + hpl * klt], aR[cl + hpl * klt], t[cl + hpl * klt], bad);
-      const double T_right_bottom = (1. - pRb) * Ti[cr + hpl * krb] + pRb * Ti[cr + hpl * (krb + 1)];
-      const double T_right_top = (1. - pRt) * Ti[cr + hpl * krt] + pRt * Ti[cr + hpl * (krt + 1)];
-      const double T_right_layer = ppm_ave(pRt, pRb + (double)(krb - krt), aL[cr + hpl * krt], aR[cr + hpl * krt], t[cr + hpl * krt], bad);
-      const double dT_top = T_right_top - T_left_top;
-      const double dT_bottom = T_right_bottom - T_left_bottom;
-      double dT_ave = 0.5 * (dT_top + dT_bottom);
-      const double dT_layer = T_right_layer - T_left_layer;
-      if (signum(1., dT_top) * signum(1., dT_bottom) <= 0. || signum(1., dT_ave) * signum(1., dT_layer) <= 0.) dT_ave = 0.;
-      else dT_ave = dT_layer;
-      flx = dT_ave * he * 1.0;
+#pragma unroll
+    for (int z = 0; z < ND_BATCH; z++) {
+      if (z < nb) {
+        const double *__restrict__ Ti = A.Ti + A.col_stride * z, *__restrict__ aL = A.aL + A.col_stride * z, *__restrict__ aR = A.aR + A.col_stride * z;
+        const double T_left_bottom = (1. - pLb) * Ti[cl + hpl * klb] + pLb * Ti[cl + hpl * (klb + 1)];
+        const double T_right_bottom = (1. - pRb) * Ti[cr + hpl * krb] + pRb * Ti[cr + hpl * (krb + 1)];
+        double flx = 0.;
+        if (he != 0.) {
+          const double T_left_top = Ttop_l[z], T_right_top = Ttop_r[z];
+          const double T_left_layer = ppm_ave(pLt, pLb + (double)(klb - klt), eL_l[z], eR_l[z], tm_l[z], bad);
+          const double T_right_layer = ppm_ave(pRt, pRb + (double)(krb - krt), eL_r[z], eR_r[z], tm_r[z], bad);
+          const double dT_top = T_right_top - T_left_top;
+          const double dT_bottom = T_right_bottom - T_left_bottom;
+          double dT_ave = 0.5 * (dT_top + dT_bottom);
+          const double dT_layer = T_right_layer - T_left_layer;
+          if (signum(1., dT_top) * signum(1., dT_bottom) <= 0. || signum(1., dT_ave) * signum(1., dT_layer) <= 0.) dT_ave = 0.;
+          else dT_ave = dT_layer;
+          flx = dT_ave * he * 1.0;
+        }
+        Flx[A.flx_stride * z + f + pl * ks] = flx;
+        Ttop_l[z] = T_left_bottom; Ttop_r[z] = T_right_bottom;
+        if (klb != klt) { eL_l[z] = aL[cl + hpl * klb]; eR_l[z] = aR[cl + hpl * klb]; tm_l[z] = A.t[z][cl + hpl * klb]; }
+        if (krb != krt) { eL_r[z] = aL[cr + hpl * krb]; eR_r[z] = aR[cr + hpl * krb]; tm_r[z] = A.t[z][cr + hpl * krb]; }
+      }
     }
-    Flx[f + pl * ks] = flx;
     pLt = pLb; pRt = pRb; klt = klb; krt = krb;
   }
   if (bad) atomicOr(A.bad, 1);
@@ -296,16 +335,17 @@ __global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
 __global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
   extern __shared__ double acc[];      // [nk][64]
   const m6::GridDev &g = A.g;
-  const int lane = threadIdx.x, i = g.isc + blockIdx.x * 64 + lane, j = g.jsc + blockIdx.y, nk = g.nk;
+  const int lane = threadIdx.x, i = g.isc + blockIdx.x * 64 + lane, j = g.jsc + blockIdx.y, nk = g.nk, z = blockIdx.z;
   if (i > g.iec) return;
   const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
   if (!(g.mask2dT[n2] > 0.)) return;
+  double *__restrict__ t = A.t[z];
   const long upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1);
   const long uE = g.u2(i, j), uW = g.u2(i - 1, j), vN = g.v2(i, j), vS = g.v2(i, j - 1);
   const double cE = A.scale * A.khdt[0][uE], cW = A.scale * A.khdt[0][uW], cN = A.scale * A.khdt[1][vN], cS = A.scale * A.khdt[1][vS];
   const int ns = A.ns;
-  const int *__restrict__ uKoL = A.KoL[0], *__restrict__ uKoR = A.KoR[0], *__restrict__ vKoL = A.KoL[1], *__restrict__ vKoR = A.KoR[1];
-  const double *__restrict__ uFlx = A.Flx[0], *__restrict__ vFlx = A.Flx[1];
+  const ko_t *__restrict__ uKoL = A.KoL[0], *__restrict__ uKoR = A.KoR[0], *__restrict__ vKoL = A.KoL[1], *__restrict__ vKoR = A.KoR[1];
+  const double *__restrict__ uFlx = A.Flx[0] + A.flx_stride * z, *__restrict__ vFlx = A.Flx[1] + A.flx_stride * z;
 #define ACC(k) acc[(k) * 64 + lane]
   if (!A.symmetric) {      // :927-938
     for (int k = 0; k < nk; k++) ACC(k) = 0.;
@@ -320,8 +360,8 @@ __global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
       ACC(k) = ACC(k) - cS * vFlx[vS + vpl * ks];
     }
   } else {                 // :939-954: one face at a time, the first three parked in the stash
-    double *__restrict__ st = A.stash;
     const long spl = hpl * nk;
+    double *__restrict__ st = A.stash + 3 * spl * z;
     for (int face = 0; face < 4; face++) {      // N, S, E, W
       for (int k = 0; k < nk; k++) ACC(k) = 0.;
       for (int ks = 0; ks < ns - 1; ks++) {
@@ -337,9 +377,9 @@ __global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
   }
   const double IareaT = g.IareaT[n2];
   for (int k = 0; k < nk; k++) {
-    double x = A.t[n2 + hpl * k] + ACC(k) * (IareaT / (A.h[n2 + hpl * k] + g.H_subroundoff));
-    if (fabs(x) < A.cu) x = 0.0;
-    A.t[n2 + hpl * k] = x;
+    double x = t[n2 + hpl * k] + ACC(k) * (IareaT / (A.h[n2 + hpl * k] + g.H_subroundoff));
+    if (fabs(x) < A.cu[z]) x = 0.0;
+    t[n2 + hpl * k] = x;
   }
 #undef ACC
 }
@@ -373,17 +413,20 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
   A.h_neglect = g.H_subroundoff; A.scale = I_numitts; A.ns = ns; A.symmetric = nd->ndiff_answer_date > 20240330;
   A.h = h; A.p_surf = p_surf; A.khdt[0] = khdt_x; A.khdt[1] = khdt_y;
   double *cols = (double *)st.scratch(sizeof(double) * hpl * (nk + 1) * 5);
-  double *faces = (double *)st.scratch(sizeof(double) * fpl * ns * 8);
-  int *kos = (int *)st.scratch(sizeof(int) * fpl * ns * 4);
-  double *tcols = (double *)st.scratch(sizeof(double) * hpl * (3 * (size_t)nk + 1));
-  double *stash = A.symmetric ? (double *)st.scratch(sizeof(double) * hpl * nk * 3) : nullptr;
+  const int nbmax = ntr < ND_BATCH ? ntr : ND_BATCH;
+  double *faces = (double *)st.scratch(sizeof(double) * fpl * ns * (6 + 2 * (size_t)nbmax));
+  ko_t *kos = (ko_t *)st.scratch(sizeof(ko_t) * fpl * ns * 4);
+  double *tcols = (double *)st.scratch(sizeof(double) * hpl * (3 * (size_t)nk + 1) * nbmax);
+  double *stash = A.symmetric ? (double *)st.scratch(sizeof(double) * hpl * nk * 3 * nbmax) : nullptr;
   int *bad = (int *)st.scratch(64);
   M6_REQUIRE(!st.failed() && cols && faces && kos && tcols && bad && (stash || !A.symmetric), "neutral_diffusion: out of device memory");
   A.Pint = cols; A.Tint = cols + hpl * (nk + 1); A.Sint = A.Tint + hpl * (nk + 1); A.dRdT = A.Sint + hpl * (nk + 1); A.dRdS = A.dRdT + hpl * (nk + 1);
   for (int d = 0; d < 2; d++) {
-    A.PoL[d] = faces + fpl * ns * (4 * d); A.PoR[d] = A.PoL[d] + fpl * ns; A.hEff[d] = A.PoR[d] + fpl * ns; A.Flx[d] = A.hEff[d] + fpl * ns;
+    A.PoL[d] = faces + fpl * ns * (3 * d); A.PoR[d] = A.PoL[d] + fpl * ns; A.hEff[d] = A.PoR[d] + fpl * ns;
+    A.Flx[d] = faces + fpl * ns * (6 + d);      // the fluxes of tracer z of a batch: + 2 planes sets per tracer
     A.KoL[d] = kos + fpl * ns * (2 * d); A.KoR[d] = A.KoL[d] + fpl * ns;
   }
+  A.flx_stride = (long)(fpl * ns * 2); A.col_stride = (long)(hpl * (3 * (size_t)nk + 1));
   A.Ti = tcols; A.aL = tcols + hpl * (nk + 1); A.aR = A.aL + hpl * nk; A.stash = stash; A.bad = bad;
   M6_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
 
@@ -405,12 +448,13 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
       (*halo_updates)++;
       if (nd->recalc_neutral_surf) calc_coeffs();
     }
-    for (int m = 0; m < ntr; m++) {      // neutral_diffusion :605
-      A.t = d_tr[m]; A.cu = cu[m];
-      hipLaunchKernelGGL(nd_tracer_cols_kernel, dim3((ni + 2 + 63) / 64, nj + 2), dim3(64), 0, s, A);
+    for (int m0 = 0; m0 < ntr; m0 += nbmax) {      // neutral_diffusion :605: the tracers are independent of each other, a batch at a time
+      A.nb = (ntr - m0 < nbmax) ? ntr - m0 : nbmax;
+      for (int z = 0; z < A.nb; z++) { A.t[z] = d_tr[m0 + z]; A.cu[z] = cu[m0 + z]; }
+      hipLaunchKernelGGL(nd_tracer_cols_kernel, dim3((ni + 2 + 63) / 64, nj + 2, A.nb), dim3(64), 0, s, A);
       hipLaunchKernelGGL(nd_flux_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
       hipLaunchKernelGGL(nd_flux_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
-      hipLaunchKernelGGL(nd_update_kernel, dim3((ni + 63) / 64, nj), dim3(64), sizeof(double) * 64 * nk, s, A);
+      hipLaunchKernelGGL(nd_update_kernel, dim3((ni + 63) / 64, nj, A.nb), dim3(64), sizeof(double) * 64 * nk, s, A);
     }
   }
   M6_HIP(hipGetLastError());
