@@ -112,28 +112,31 @@ def advect_layout_worker(rank, world, port, layout, scheme, out_dir):
         dist.destroy_process_group()
 
 
-def hordiff_layout_worker(rank, world, port, layout, out_dir):
+def hordiff_layout_worker(rank, world, port, layout, out_dir, neutral=False):
     """test.layout for tracer_hordiff on the GPU (several iterations: a group pass and the max across PEs of the diffusive CFL
-    number inside the call): the tiles must reproduce the one-tile run bit for bit."""
+    number inside the call), along layers or with USE_NEUTRAL_DIFFUSION: the tiles must reproduce the one-tile run bit for bit."""
     import numpy as np
     import torch
     from mom6_amd import _abi, synth
     from mom6_amd.domains import Domain
     from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.pressure_force import EOS_init
     from mom6_amd.tracer_hor_diff import tracer_hor_diff_init, tracer_hordiff
     dist = _init(rank, world, port)
     try:
         NI, NJ, NK, halo = 70, 40, 3, 4
+        eos = EOS_init("WRIGHT")
+        tvof = lambda t: dict(T=t[0], S=t[1], eqn_of_state=eos) if neutral else None
         gg = synth.make_grid(NI, NJ, NK, halo=halo, reentrant_x=True, reentrant_y=False, seed=78)
         d = synth.make_dynamics_state(gg, seed=3, umax=0.1, eta_amp=0.2)
         trs = [d["T"], d["S"]]
-        CS = tracer_hor_diff_init(KHTR=3.0e7, CHECK_DIFFUSIVE_CFL=True)
+        CS = tracer_hor_diff_init(KHTR=3.0e7, CHECK_DIFFUSIVE_CFL=True, USE_NEUTRAL_DIFFUSION=neutral)
         dom = Domain(NI, NJ, layout, rank, halo, True, False)
         dg = DeviceGrid(dom.tile_grid(gg))
         dg.set_domain(dom)
         cut = lambda a, pos: dom.cut(a, pos).cuda()
         tr = [cut(t, _abi.POS_H) for t in trs]
-        st = tracer_hordiff(cut(d["h"], _abi.POS_H), 3600.0, None, None, None, dg, CS, tr)
+        st = tracer_hordiff(cut(d["h"], _abi.POS_H), 3600.0, None, None, None, dg, CS, tr, tv=tvof(tr))
         dg.sync()
         h = halo
         res = [t.cpu().numpy()[:, h:h + dom.nj, h:h + dom.ni] for t in tr]
@@ -142,7 +145,8 @@ def hordiff_layout_worker(rank, world, port, layout, out_dir):
         if rank == 0:      # the one-tile answer
             dg1 = DeviceGrid(gg)
             tr1 = [t.clone().cuda() for t in trs]
-            s1 = tracer_hordiff(d["h"].cuda(), 3600.0, None, None, None, dg1, tracer_hor_diff_init(KHTR=3.0e7, CHECK_DIFFUSIVE_CFL=True), tr1)
+            s1 = tracer_hordiff(d["h"].cuda(), 3600.0, None, None, None, dg1,
+                                tracer_hor_diff_init(KHTR=3.0e7, CHECK_DIFFUSIVE_CFL=True, USE_NEUTRAL_DIFFUSION=neutral), tr1, tv=tvof(tr1))
             dg1.sync()
             np.savez(os.path.join(out_dir, "global.npz"), *[t.cpu().numpy()[:, h:h + NJ, h:h + NI] for t in tr1],
                      it=np.array([s1.num_itts]), cfl=np.array([s1.max_CFL]))

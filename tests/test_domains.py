@@ -80,11 +80,12 @@ def test_advect_tracer_layout_independence(tmp_path, layout, scheme):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("neutral", [False, True], ids=["along_layer", "neutral"])
 @pytest.mark.parametrize("layout", [(1, 2), (2, 1)])
-def test_tracer_hordiff_layout_independence(tmp_path, layout):
+def test_tracer_hordiff_layout_independence(tmp_path, layout, neutral):
     import torch.multiprocessing as mp
     from mp_workers import hordiff_layout_worker
-    mp.spawn(hordiff_layout_worker, args=(2, free_port(), layout, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(hordiff_layout_worker, args=(2, free_port(), layout, str(tmp_path), neutral), nprocs=2, join=True)
     glob = np.load(tmp_path / "global.npz")
     assert glob["it"][0] > 1
     for r in range(2):
