@@ -465,7 +465,8 @@ def cycle_oracle(name, state, ncycles, nsteps):
         orc.mixedlayer_restrat(g, mlecs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, ustar, dt_therm)
         orc.halo_update(g, st.h, H)
         orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, dt_therm, dt, "PPM:H3", [st.T, st.S])
-        orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0)
+        orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0,
+                           neutral=dict(eos=st.E, idx_T=0, idx_S=1) if _b(p, "USE_NEUTRAL_DIFFUSION") else None)
         st.uhtr[:] = 0.0; st.vhtr[:] = 0.0
         if _b(p, "TEST_ALE"):      # the ALE block of step_MOM_thermo (MOM.F90:1647-1700) with the parameters of CYCLE_ALE_PAIRS
             ts = float(p["REGRID_TIME_SCALE"])
@@ -493,16 +494,19 @@ def test_the_cycle_driver_compiles(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
 @pytest.mark.parametrize("resident", [False, True])
-@pytest.mark.parametrize("with_ALE", [False, True], ids=["no_ALE", "ALE"])
+@pytest.mark.parametrize("with_ALE", [False, True, "neutral"], ids=["no_ALE", "ALE", "neutral_diffusion"])
 def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_path, resident, with_ALE):
     """thickness_diffuse -> set_viscous_BBL -> step_MOM_dyn_split_RK2 x (DT_THERM / DT) -> mixedlayer_restrat -> advect_tracer -> tracer_hordiff, twice, from a
     Fortran program that calls reference-named procedures only, with the .testing/tc4 parameter set: u, v, h, T, S and the transports equal
     the oracle's bit for bit; with GPU_RESIDENT_DYNAMICS the fields cross PCIe once in each direction, whatever the number of cycles"""
     name = "tc4"
+    neutral = with_ALE == "neutral"      # tracer_hordiff with .testing/tc2's USE_NEUTRAL_DIFFUSION = True (six layers, no ALE block)
+    with_ALE = with_ALE is True
     # with_ALE: six layers, and after the tracers the ALE block on the host arrays between dyn_split_RK2_sync_to_host and
     # dyn_split_RK2_host_was_modified (z* regrid with a time scale, PPM_H4 / PLM remapping of T, S, u, v)
-    TC_INPUT["tc4c"] = dict(shape=(14, 10, 6) if with_ALE else TC_INPUT[name]["shape"],
-                            pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS + (CYCLE_ALE_PAIRS if with_ALE else ""))
+    TC_INPUT["tc4c"] = dict(shape=(14, 10, 6) if with_ALE or neutral else TC_INPUT[name]["shape"],
+                            pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS + (CYCLE_ALE_PAIRS if with_ALE else "") +
+                            ("\n        USE_NEUTRAL_DIFFUSION = True\n" if neutral else ""))
     exe = build_cycle_driver(tmp_path)
     state = case_state("tc4c")
     g = state[0]
