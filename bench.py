@@ -188,7 +188,8 @@ class Model:
             tr = [self.T, self.S] + self.passive
             self.last_adv = advect_tracer(self.h, self.uhtr, self.vhtr, None, DT_THERM, self.dg, self.adv_cs, tr)
             from mom6_amd.tracer_hor_diff import tracer_hordiff
-            self.last_hordiff = tracer_hordiff(self.h, DT_THERM, None, None, None, self.dg, self.hordiff_cs, tr)      # MOM.F90:1441
+            tv = dict(T=self.T, S=self.S, eqn_of_state=self.eos) if lat and lat.get("neutral") else None      # USE_NEUTRAL_DIFFUSION
+            self.last_hordiff = tracer_hordiff(self.h, DT_THERM, None, None, None, self.dg, self.hordiff_cs, tr, tv=tv)      # MOM.F90:1441
             self.uhtr.zero_(); self.vhtr.zero_()
             # ALE (src/core/MOM.F90:1647-1700): regrid, remap tracers, remap velocities, adopt the new grid
             dg = self.dg
@@ -205,16 +206,20 @@ class Model:
                 self.dom.pass_var(fields, pos)
         self.nstep += 1
 
-    def enable_lateral(self, KHTH=600.0, FOX_KEMPER_ML_RESTRAT_COEF=5.0):
+    def enable_lateral(self, KHTH=600.0, FOX_KEMPER_ML_RESTRAT_COEF=5.0, neutral=False):
         """thickness_diffuse (KHTH) before the first dynamic step and mixedlayer_restrat (MLE_DENSITY_DIFF) after the last one of every
-        thermodynamic cycle: tools/model_health.py --lateral, MOM6HIP_BENCH_LATERAL=1"""
+        thermodynamic cycle: tools/model_health.py --lateral, MOM6HIP_BENCH_LATERAL=1; neutral (MOM6HIP_BENCH_LATERAL=2, --neutral): tracer_hordiff
+        with USE_NEUTRAL_DIFFUSION as well"""
         from mom6_amd.mixedlayer_restrat import mixedlayer_restrat_init
         from mom6_amd.thickness_diffuse import thickness_diffuse_init
         rho0 = float(self.g.Rho0)
         tx = 0.5 * (self.taux[:, 1:] + self.taux[:, :-1]); ty = 0.5 * (self.tauy[1:, :] + self.tauy[:-1, :])
         ustar = torch.sqrt(torch.sqrt(tx * tx + ty * ty) / rho0).contiguous()      # forces%ustar from the wind stress at h points
         self.lateral = dict(td=thickness_diffuse_init(self.dg, THICKNESSDIFFUSE=True, KHTH=KHTH),
-                            mle=mixedlayer_restrat_init(self.dg, FOX_KEMPER_ML_RESTRAT_COEF=FOX_KEMPER_ML_RESTRAT_COEF), ustar=ustar)
+                            mle=mixedlayer_restrat_init(self.dg, FOX_KEMPER_ML_RESTRAT_COEF=FOX_KEMPER_ML_RESTRAT_COEF), ustar=ustar, neutral=bool(neutral))
+        if neutral:
+            from mom6_amd.tracer_hor_diff import tracer_hor_diff_init
+            self.hordiff_cs = tracer_hor_diff_init(USE_NEUTRAL_DIFFUSION=True, **TRACER_HORDIFF)
 
     def health(self):
         """max |u|, max |v|, min h, max |eta|, kinetic energy per unit area, the vanished fraction, any NaN -- the bench
@@ -641,9 +646,10 @@ def main():
     exchange = os.environ.get("MOM6HIP_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "python") if world > 1 else None
     M = Model(grid, dom, device, a.scheme, exchange=exchange)
     exchange = M.exchange
-    LATERAL = os.environ.get("MOM6HIP_BENCH_LATERAL", "0") == "1"      # not the default: the workload of BASELINE.json does not call them
+    LATERAL = os.environ.get("MOM6HIP_BENCH_LATERAL", "0") in ("1", "2")      # not the default: the workload of BASELINE.json does not call them
+    NEUTRAL = os.environ.get("MOM6HIP_BENCH_LATERAL", "0") == "2"
     if LATERAL:
-        M.enable_lateral()
+        M.enable_lateral(neutral=NEUTRAL)
     cells = NI * NJ * NK
 
     def barrier():
@@ -729,7 +735,8 @@ def main():
                     f"tracer_hordiff [KHTR={TRACER_HORDIFF['KHTR']:.0f}] + ALE regrid/remap [{REMAP_SCHEME}]",
             "btstep_nstep": int(bcs.nstep_last), "dtbt_s": float(bcs.dtbt),
             "not_yet_in_step": [],
-            "lateral_parameterizations_in_cycle": "thickness_diffuse [KHTH=600] + mixedlayer_restrat [FOX_KEMPER_ML_RESTRAT_COEF=5]" if LATERAL else None,
+            "lateral_parameterizations_in_cycle": ("thickness_diffuse [KHTH=600] + mixedlayer_restrat [FOX_KEMPER_ML_RESTRAT_COEF=5]" +
+                                                   (" + tracer_hordiff with USE_NEUTRAL_DIFFUSION" if NEUTRAL else "")) if LATERAL else None,
             "vertvisc": dict(VERTVISC, ntrunc=int(M.CS.vertvisc_CSp.ntrunc)), "hor_visc": HOR_VISC, "set_visc": SET_VISC,
             "ALE": f"z* regrid with old_grid_weight={REGRID_OLD_WEIGHT} (REGRID_TIME_SCALE = 0, the default), remap of T, S + 2 tracers "
                    f"and of u, v [{REMAP_SCHEME}]",

@@ -15,13 +15,14 @@ ap.add_argument("--land", type=float, default=bench.LAND_FRAC)
 ap.add_argument("--no-wind", action="store_true", help="zero wind stress: what the initial state does on its own")
 ap.add_argument("--uniform-ts", action="store_true", help="T and S replaced by their layer means: no baroclinic pressure gradients")
 ap.add_argument("--lateral", action="store_true", help="thickness_diffuse and mixedlayer_restrat in every thermodynamic cycle")
+ap.add_argument("--neutral", action="store_true", help="with --lateral: tracer_hordiff with USE_NEUTRAL_DIFFUSION")
 a = ap.parse_args()
 NI, NJ, NK = bench.shape_of(a.workload)
 grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=a.land, rough_noise=bench.rough_noise(NI) if a.rough is None else a.rough)
 dom = Domain(NI, NJ, (1, 1), 0, grid.halo, grid.reentrant_x, grid.reentrant_y)
 M = bench.Model(grid, dom, torch.device("cuda", 0), bench.SCHEME)
 if a.lateral:
-    M.enable_lateral()
+    M.enable_lateral(neutral=a.neutral)
 if a.no_wind:
     M.taux.zero_(); M.tauy.zero_()
 if a.uniform_ts:
