@@ -347,28 +347,59 @@ __global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
   const ko_t *__restrict__ uKoL = A.KoL[0], *__restrict__ uKoR = A.KoR[0], *__restrict__ vKoL = A.KoL[1], *__restrict__ vKoR = A.KoR[1];
   const double *__restrict__ uFlx = A.Flx[0] + A.flx_stride * z, *__restrict__ vFlx = A.Flx[1] + A.flx_stride * z;
 #define ACC(k) acc[(k) * 64 + lane]
+  // The surfaces are taken eight at a time: the loads of a group (layer numbers and fluxes of the four faces) are issued together, then
+  // the group's contributions are added in the reference's order.  (With the LDS column a CU holds four waves; a global round trip per
+  // surface was what the kernel waited for.)
+  constexpr int NU = 8;
+  const int nl = ns - 1;
   if (!A.symmetric) {      // :927-938
     for (int k = 0; k < nk; k++) ACC(k) = 0.;
-    for (int ks = 0; ks < ns - 1; ks++) {
-      int k = uKoL[uE + upl * ks] - 1;
-      ACC(k) = ACC(k) + cE * uFlx[uE + upl * ks];
-      k = uKoR[uW + upl * ks] - 1;
-      ACC(k) = ACC(k) - cW * uFlx[uW + upl * ks];
-      k = vKoL[vN + vpl * ks] - 1;
-      ACC(k) = ACC(k) + cN * vFlx[vN + vpl * ks];
-      k = vKoR[vS + vpl * ks] - 1;
-      ACC(k) = ACC(k) - cS * vFlx[vS + vpl * ks];
+    for (int ks0 = 0; ks0 < nl; ks0 += NU) {
+      int kE[NU], kW[NU], kN[NU], kS[NU];
+      double fE[NU], fW[NU], fN[NU], fS[NU];
+#pragma unroll
+      for (int q = 0; q < NU; q++) {
+        const int ks = (ks0 + q < nl) ? ks0 + q : nl - 1;
+        kE[q] = uKoL[uE + upl * ks] - 1; fE[q] = uFlx[uE + upl * ks];
+        kW[q] = uKoR[uW + upl * ks] - 1; fW[q] = uFlx[uW + upl * ks];
+        kN[q] = vKoL[vN + vpl * ks] - 1; fN[q] = vFlx[vN + vpl * ks];
+        kS[q] = vKoR[vS + vpl * ks] - 1; fS[q] = vFlx[vS + vpl * ks];
+      }
+#pragma unroll
+      for (int q = 0; q < NU; q++) {
+        if (ks0 + q < nl) {
+          ACC(kE[q]) = ACC(kE[q]) + cE * fE[q];
+          ACC(kW[q]) = ACC(kW[q]) - cW * fW[q];
+          ACC(kN[q]) = ACC(kN[q]) + cN * fN[q];
+          ACC(kS[q]) = ACC(kS[q]) - cS * fS[q];
+        }
+      }
     }
   } else {                 // :939-954: one face at a time, the first three parked in the stash
     const long spl = hpl * nk;
     double *__restrict__ st = A.stash + 3 * spl * z;
     for (int face = 0; face < 4; face++) {      // N, S, E, W
+      const ko_t *__restrict__ Kf = face == 0 ? vKoL + vN : (face == 1 ? vKoR + vS : (face == 2 ? uKoL + uE : uKoR + uW));
+      const double *__restrict__ Ff = face == 0 ? vFlx + vN : (face == 1 ? vFlx + vS : (face == 2 ? uFlx + uE : uFlx + uW));
+      const long fpl_ = face < 2 ? vpl : upl;
+      const double cf = face == 0 ? cN : (face == 1 ? cS : (face == 2 ? cE : cW));
+      const bool plus = (face == 0 || face == 2);
       for (int k = 0; k < nk; k++) ACC(k) = 0.;
-      for (int ks = 0; ks < ns - 1; ks++) {
-        if (face == 0) { const int k = vKoL[vN + vpl * ks] - 1; ACC(k) = ACC(k) + cN * vFlx[vN + vpl * ks]; }
-        else if (face == 1) { const int k = vKoR[vS + vpl * ks] - 1; ACC(k) = ACC(k) - cS * vFlx[vS + vpl * ks]; }
-        else if (face == 2) { const int k = uKoL[uE + upl * ks] - 1; ACC(k) = ACC(k) + cE * uFlx[uE + upl * ks]; }
-        else { const int k = uKoR[uW + upl * ks] - 1; ACC(k) = ACC(k) - cW * uFlx[uW + upl * ks]; }
+      for (int ks0 = 0; ks0 < nl; ks0 += NU) {
+        int kk[NU];
+        double ff[NU];
+#pragma unroll
+        for (int q = 0; q < NU; q++) {
+          const int ks = (ks0 + q < nl) ? ks0 + q : nl - 1;
+          kk[q] = Kf[fpl_ * ks] - 1; ff[q] = Ff[fpl_ * ks];
+        }
+#pragma unroll
+        for (int q = 0; q < NU; q++) {
+          if (ks0 + q < nl) {
+            if (plus) ACC(kk[q]) = ACC(kk[q]) + cf * ff[q];
+            else ACC(kk[q]) = ACC(kk[q]) - cf * ff[q];
+          }
+        }
       }
       if (face < 3) for (int k = 0; k < nk; k++) st[spl * face + n2 + hpl * k] = ACC(k);
     }
