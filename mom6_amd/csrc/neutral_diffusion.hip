@@ -5,8 +5,9 @@
 //                         interface_scalar (:1078, PLM_diff + ppm_edge), their density derivatives -> five [nk+1] columns
 //   nd_surfaces_kernel    find_neutral_surface_positions_continuous (:1353) for one face: the merge walk down the 2nk+2 interfaces of
 //                         the two columns; PoL, PoR, KoL, KoR, hEff (back in H units, :570-575) as [surface][face] planes
-//   nd_tracer_cols_kernel interface values and the limited PPM edge values of one tracer (neutral_surface_flux :2373-2377,
-//                         ppm_left_right_edge_values :2541) for one h column
+//   nd_tracer_cols_kernel interface values of a tracer (neutral_surface_flux :2373-2374) for one h column; the limited PPM edge values of a
+//                         cell (ppm_left_right_edge_values :2541) are formed in the flux kernel from the two interface values it has
+//                         read anyway and the cell mean, when a surface enters the cell
 //   nd_flux_kernel        neutral_surface_flux (:2297) for one face -> Flx [surface][face]; the surfaces of the face are read once for a
 //                         batch of up to 4 tracers (their fluxes are independent of each other)
 //   nd_update_kernel      the tendencies of a cell from its four faces in the reference's order of the surfaces (:927-954), accumulated
@@ -111,6 +112,14 @@ __device__ __forceinline__ double ppm_ave(double xL, double xR, double aL, doubl
 #define ND_BATCH 4
 typedef unsigned char ko_t;      // a layer number 1 .. nk <= 128
 
+// ppm_left_right_edge_values :2541 for one cell: the interface values above and below it and its mean
+__device__ __forceinline__ void ppm_edges(double Ti0, double Ti1, double Tl, double &aL, double &aR) {
+  aL = Ti0; aR = Ti1;
+  if (signum(1., aR - Tl) * signum(1., Tl - aL) <= 0.0) { aL = Tl; aR = Tl; }
+  else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) > fabs(aR - aL)) aL = Tl + 2.0 * (Tl - aR);
+  else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) < -fabs(aR - aL)) aR = Tl + 2.0 * (Tl - aL);
+}
+
 struct NDArgs {
   m6::GridDev g;
   EosDev E;
@@ -124,7 +133,7 @@ struct NDArgs {
   const double *khdt[2];
   int nb;                           // tracers in this batch (<= ND_BATCH): the surfaces are read once for all of them
   double *t[ND_BATCH];              // the tracers being diffused
-  double *Ti, *aL, *aR;             // their interface and edge values, [(nk+1)] / [nk][h points], + col_stride per tracer
+  double *Ti;                       // their interface values, [(nk+1)][h points], + col_stride per tracer
   long col_stride, flx_stride;
   double *stash;                    // [3][nk][h points], the symmetric form's N, S, E tendencies, + 3 nk hpl per tracer
   double cu[ND_BATCH];              // conc_underflow of the tracers
@@ -247,21 +256,9 @@ __global__ __launch_bounds__(64) void nd_tracer_cols_kernel(NDArgs A) {
   if (i > g.iec + 1) return;
   const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
   const double *__restrict__ t = A.t[z];
-  double *__restrict__ oTi = A.Ti + A.col_stride * z, *__restrict__ oaL = A.aL + A.col_stride * z, *__restrict__ oaR = A.aR + A.col_stride * z;
-  double d = 0., Ti_prev = 0.;
-  for (int K = 0; K <= nk; K++) {
-    const double Ti = interface_value(A.h, t, n2, hpl, K, nk, A.h_neglect, d);
-    oTi[n2 + hpl * K] = Ti;
-    if (K > 0) {      // ppm_left_right_edge_values :2541 of layer K-1
-      const double Tl = t[n2 + hpl * (K - 1)];
-      double aL = Ti_prev, aR = Ti;
-      if (signum(1., aR - Tl) * signum(1., Tl - aL) <= 0.0) { aL = Tl; aR = Tl; }
-      else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) > fabs(aR - aL)) aL = Tl + 2.0 * (Tl - aR);
-      else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) < -fabs(aR - aL)) aR = Tl + 2.0 * (Tl - aL);
-      oaL[n2 + hpl * (K - 1)] = aL; oaR[n2 + hpl * (K - 1)] = aR;
-    }
-    Ti_prev = Ti;
-  }
+  double *__restrict__ oTi = A.Ti + A.col_stride * z;
+  double d = 0.;
+  for (int K = 0; K <= nk; K++) oTi[n2 + hpl * K] = interface_value(A.h, t, n2, hpl, K, nk, A.h_neglect, d);
 }
 
 // neutral_surface_flux :2297 (continuous, no tapering: khtr_ave = 1)
@@ -290,11 +287,13 @@ __global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
 #pragma unroll
   for (int z = 0; z < ND_BATCH; z++) {
     if (z < nb) {
-      const double *__restrict__ Ti = A.Ti + A.col_stride * z, *__restrict__ aL = A.aL + A.col_stride * z, *__restrict__ aR = A.aR + A.col_stride * z;
-      Ttop_l[z] = (1. - pLt) * Ti[cl + hpl * klt] + pLt * Ti[cl + hpl * (klt + 1)];
-      Ttop_r[z] = (1. - pRt) * Ti[cr + hpl * krt] + pRt * Ti[cr + hpl * (krt + 1)];
-      eL_l[z] = aL[cl + hpl * klt]; eR_l[z] = aR[cl + hpl * klt]; tm_l[z] = A.t[z][cl + hpl * klt];
-      eL_r[z] = aL[cr + hpl * krt]; eR_r[z] = aR[cr + hpl * krt]; tm_r[z] = A.t[z][cr + hpl * krt];
+      const double *__restrict__ Ti = A.Ti + A.col_stride * z;
+      const double l0 = Ti[cl + hpl * klt], l1 = Ti[cl + hpl * (klt + 1)], r0 = Ti[cr + hpl * krt], r1 = Ti[cr + hpl * (krt + 1)];
+      Ttop_l[z] = (1. - pLt) * l0 + pLt * l1;
+      Ttop_r[z] = (1. - pRt) * r0 + pRt * r1;
+      tm_l[z] = A.t[z][cl + hpl * klt]; tm_r[z] = A.t[z][cr + hpl * krt];
+      ppm_edges(l0, l1, tm_l[z], eL_l[z], eR_l[z]);
+      ppm_edges(r0, r1, tm_r[z], eL_r[z], eR_r[z]);
     }
   }
   for (int ks = 0; ks < ns - 1; ks++) {
@@ -304,9 +303,10 @@ __global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
 #pragma unroll
     for (int z = 0; z < ND_BATCH; z++) {
       if (z < nb) {
-        const double *__restrict__ Ti = A.Ti + A.col_stride * z, *__restrict__ aL = A.aL + A.col_stride * z, *__restrict__ aR = A.aR + A.col_stride * z;
-        const double T_left_bottom = (1. - pLb) * Ti[cl + hpl * klb] + pLb * Ti[cl + hpl * (klb + 1)];
-        const double T_right_bottom = (1. - pRb) * Ti[cr + hpl * krb] + pRb * Ti[cr + hpl * (krb + 1)];
+        const double *__restrict__ Ti = A.Ti + A.col_stride * z;
+        const double l0 = Ti[cl + hpl * klb], l1 = Ti[cl + hpl * (klb + 1)], r0 = Ti[cr + hpl * krb], r1 = Ti[cr + hpl * (krb + 1)];
+        const double T_left_bottom = (1. - pLb) * l0 + pLb * l1;
+        const double T_right_bottom = (1. - pRb) * r0 + pRb * r1;
         double flx = 0.;
         if (he != 0.) {
           const double T_left_top = Ttop_l[z], T_right_top = Ttop_r[z];
@@ -322,8 +322,9 @@ __global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
         }
         Flx[A.flx_stride * z + f + pl * ks] = flx;
         Ttop_l[z] = T_left_bottom; Ttop_r[z] = T_right_bottom;
-        if (klb != klt) { eL_l[z] = aL[cl + hpl * klb]; eR_l[z] = aR[cl + hpl * klb]; tm_l[z] = A.t[z][cl + hpl * klb]; }
-        if (krb != krt) { eL_r[z] = aL[cr + hpl * krb]; eR_r[z] = aR[cr + hpl * krb]; tm_r[z] = A.t[z][cr + hpl * krb]; }
+        // the surface enters another cell: its edge values (ppm_left_right_edge_values :2541) from the two interface values just read
+        if (klb != klt) { tm_l[z] = A.t[z][cl + hpl * klb]; ppm_edges(l0, l1, tm_l[z], eL_l[z], eR_l[z]); }
+        if (krb != krt) { tm_r[z] = A.t[z][cr + hpl * krb]; ppm_edges(r0, r1, tm_r[z], eL_r[z], eR_r[z]); }
       }
     }
     pLt = pLb; pRt = pRb; klt = klb; krt = krb;
@@ -447,7 +448,7 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
   const int nbmax = ntr < ND_BATCH ? ntr : ND_BATCH;
   double *faces = (double *)st.scratch(sizeof(double) * fpl * ns * (6 + 2 * (size_t)nbmax));
   ko_t *kos = (ko_t *)st.scratch(sizeof(ko_t) * fpl * ns * 4);
-  double *tcols = (double *)st.scratch(sizeof(double) * hpl * (3 * (size_t)nk + 1) * nbmax);
+  double *tcols = (double *)st.scratch(sizeof(double) * hpl * ((size_t)nk + 1) * nbmax);
   double *stash = A.symmetric ? (double *)st.scratch(sizeof(double) * hpl * nk * 3 * nbmax) : nullptr;
   int *bad = (int *)st.scratch(64);
   M6_REQUIRE(!st.failed() && cols && faces && kos && tcols && bad && (stash || !A.symmetric), "neutral_diffusion: out of device memory");
@@ -457,8 +458,8 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
     A.Flx[d] = faces + fpl * ns * (6 + d);      // the fluxes of tracer z of a batch: + 2 planes sets per tracer
     A.KoL[d] = kos + fpl * ns * (2 * d); A.KoR[d] = A.KoL[d] + fpl * ns;
   }
-  A.flx_stride = (long)(fpl * ns * 2); A.col_stride = (long)(hpl * (3 * (size_t)nk + 1));
-  A.Ti = tcols; A.aL = tcols + hpl * (nk + 1); A.aR = A.aL + hpl * nk; A.stash = stash; A.bad = bad;
+  A.flx_stride = (long)(fpl * ns * 2); A.col_stride = (long)(hpl * ((size_t)nk + 1));
+  A.Ti = tcols; A.stash = stash; A.bad = bad;
   M6_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
 
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
