@@ -861,7 +861,8 @@ typedef struct mom6hip_hordiff_fields {
   const double *L2u, *L2v, *SN_u, *SN_v;      /* VarMix%L2u ... (KHTR_SLOPE_CFF > 0), u / v points 2-D */
   const double *Res_fn_h;           /* VarMix%Res_fn_h (RESOLN_SCALED_KHTR), h points 2-D */
   const double *Rd_dx_h;            /* VarMix%Rd_dx_h (KHTR_PASSIVITY_COEFF > 0), h points 2-D */
-  void *reserved[5];
+  const double *h_ML;               /* visc%h_ML (NDIFF_INTERIOR_ONLY: the boundary-layer depth neutral diffusion stays below), h points 2-D */
+  void *reserved[4];
 } mom6hip_hordiff_fields_t;
 
 typedef struct mom6hip_hordiff_stats {
@@ -886,8 +887,10 @@ int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_d
  * Provided: NDIFF_CONTINUOUS = True (the default): interface values of T and S by the PPM edge formula (interface_scalar :1078),
  * their density derivatives at the interface pressure (or NDIFF_REF_PRES), find_neutral_surface_positions_continuous (:1353),
  * neutral_surface_flux (:2297) and the update of every tracer (:605-1019), for both values of NDIFF_ANSWER_DATE.
+ * NDIFF_INTERIOR_ONLY (interior_only): the surfaces are kept below the surface boundary layer visc%h_ML (fields->h_ML) -- boundary_k_range
+ * (src/tracer/MOM_hor_bnd_diffusion.F90:609) for every column and the limits of the walk (:1508-1521).
  * Not provided (refused by name, any nonzero `unsupported`): NDIFF_CONTINUOUS = False (the discontinuous reconstructions),
- * NDIFF_INTERIOR_ONLY / NDIFF_TAPERING, KHTR_USE_EBT_STRUCT, NDIFF_USE_UNMASKED_TRANSPORT_BUG, the flux / tendency diagnostics.
+ * NDIFF_TAPERING, KHTR_USE_EBT_STRUCT, NDIFF_USE_UNMASKED_TRANSPORT_BUG, the flux / tendency diagnostics.
  */
 typedef struct mom6hip_neutral_diffusion_cs {
   double ref_pres;             /* NDIFF_REF_PRES [R L2 T-2] (-1, the default: the pressure of the interface) */
@@ -896,8 +899,8 @@ typedef struct mom6hip_neutral_diffusion_cs {
   int32_t ndiff_answer_date;   /* NDIFF_ANSWER_DATE (20240101): > 20240330 sums the four faces' tendencies symmetrically */
   int32_t recalc_neutral_surf; /* tracer_hor_diff_CS%recalc_neutral_surf, RECALC_NEUTRAL_SURF (0) */
   int32_t initialized;
-  int32_t reserved_i[1];
-  int32_t unsupported[8];      /* .not.continuous_reconstruction, interior_only, tapering, KhTh_use_ebt_struct,
+  int32_t interior_only;       /* NDIFF_INTERIOR_ONLY (0): needs fields->h_ML */
+  int32_t unsupported[8];      /* .not.continuous_reconstruction, (free), tapering, KhTh_use_ebt_struct,
                                   use_unmasked_transport_bug, diagnostics, (free), (free) */
 } mom6hip_neutral_diffusion_cs_t;
 

@@ -162,18 +162,18 @@ class TracerHorDiffCS(C.Structure):
                 ("reserved1", C.c_int32 * 4)]
 
 
-HORDIFF_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h")
+HORDIFF_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h", "h_ML")
 
 
 class HorDiffFields(C.Structure):
     """mom6hip_hordiff_fields_t (include/mom6hip.h)."""
-    _fields_ = [(n, C.c_void_p) for n in HORDIFF_FIELDS] + [("reserved", C.c_void_p * 5)]
+    _fields_ = [(n, C.c_void_p) for n in HORDIFF_FIELDS] + [("reserved", C.c_void_p * 4)]
 
 
 class NeutralDiffusionCS(C.Structure):
     """mom6hip_neutral_diffusion_cs_t (include/mom6hip.h)."""
     _fields_ = [("ref_pres", C.c_double), ("H_to_RZ", C.c_double), ("reserved0", C.c_double * 4), ("ndiff_answer_date", C.c_int32),
-                ("recalc_neutral_surf", C.c_int32), ("initialized", C.c_int32), ("reserved_i", C.c_int32 * 1), ("unsupported", C.c_int32 * 8)]
+                ("recalc_neutral_surf", C.c_int32), ("initialized", C.c_int32), ("interior_only", C.c_int32), ("unsupported", C.c_int32 * 8)]
 
 
 class HorDiffStats(C.Structure):

@@ -127,6 +127,9 @@ struct NDArgs {
   double pa_to_H, h_neglect, scale; // scale: I_numitts
   int ns, symmetric;                // 2nk+2 ; ndiff_answer_date > 20240330
   const double *h, *T, *S, *p_surf;
+  int interior;                     // NDIFF_INTERIOR_ONLY
+  const double *hbl;                // the boundary-layer depth visc%h_ML with its halo (interior)
+  int *kbot; double *zbot;          // boundary_k_range of every column: the layer and the fraction of it the boundary layer ends in
   double *Pint, *Tint, *Sint, *dRdT, *dRdS;   // [(nk+1)][h points]
   double *PoL[2], *PoR[2], *hEff[2], *Flx[2]; // [surface][faces of the direction]; Flx: + flx_stride per tracer of the batch
   ko_t *KoL[2], *KoR[2];
@@ -145,6 +148,23 @@ __global__ __launch_bounds__(64) void nd_column_kernel(NDArgs A) {
   const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk;
   if (i > g.iec + 1) return;
   const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
+  if (A.interior) {      // boundary_k_range(SURFACE, ...), src/tracer/MOM_hor_bnd_diffusion.F90:609-647, for wet columns (:381-386)
+    int k_bot = 1;
+    double zeta_bot = 0.;
+    const double hbl = A.hbl[n2];
+    if (g.mask2dT[n2] > 0.0 && hbl != 0.) {
+      double hsum = 0., htot = 0.;
+      for (int k = 0; k < nk; k++) hsum = hsum + A.h[n2 + hpl * k];
+      if (hbl >= hsum) { k_bot = nk; zeta_bot = 1.; }
+      else
+        for (int k = 0; k < nk; k++) {
+          const double hk = A.h[n2 + hpl * k];
+          htot = htot + hk;
+          if (htot >= hbl) { k_bot = k + 1; zeta_bot = 1 - (htot - hbl) / hk; break; }
+        }
+    }
+    A.kbot[n2] = k_bot; A.zbot[n2] = zeta_bot;
+  }
   double P = A.p_surf ? A.p_surf[n2] : 0., dT = 0., dS = 0.;
   for (int K = 0; K <= nk; K++) {
     if (K > 0) P = P + A.h[n2 + hpl * (K - 1)] * A.gH;
@@ -186,6 +206,8 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
   auto loadL = [&](int k) { return Iface{LC(Pint, k), LC(Tint, k), LC(Sint, k), LC(dRdT, k), LC(dRdS, k)}; };
   auto loadR = [&](int k) { return Iface{RC(Pint, k), RC(Tint, k), RC(Sint, k), RC(dRdT, k), RC(dRdS, k)}; };
   Iface LA = loadL(1), LB = loadL(2), RA = loadR(1), RB = loadR(2);
+  const int bl_kl = A.interior ? A.kbot[cl] : 0, bl_kr = A.interior ? A.kbot[cr] : 0;      // :1508-1521 (no layer number is <= 0)
+  const double bl_zl = A.interior ? A.zbot[cl] : 0., bl_zr = A.interior ? A.zbot[cr] : 0.;
   int kr = 1, kl = 1, lastK_right = 1, lastK_left = 1;
   double lastP_right = 0., lastP_left = 0., absL_prev = 0., absR_prev = 0.;
   bool reached_bottom = false, searching_left = false, searching_right = false;
@@ -233,6 +255,8 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
         if (kl > 2) { LA = LB; LB = loadL(kl); }
       } else { reached_bottom = true; searching_right = false; searching_left = true; }
     }
+    if (oKL <= bl_kl) { oKL = bl_kl; if (pL < bl_zl) pL = bl_zl; }
+    if (oKR <= bl_kr) { oKR = bl_kr; if (pR < bl_zr) pR = bl_zr; }
     PoL[f + pl * ks] = pL; PoR[f + pl * ks] = pR; KoL[f + pl * ks] = (ko_t)oKL; KoR[f + pl * ks] = (ko_t)oKR;
     lastK_left = oKL; lastP_left = pL; lastK_right = oKR; lastP_right = pR;
     // absolute_position :2258 of this surface; that of the one above is the value formed a step ago from the same expression
@@ -423,9 +447,9 @@ namespace m6 {
 // the neutral branch of tracer_hordiff (MOM_tracer_hor_diff.F90:474-534) on device arrays; khdt_x, khdt_y and the iteration count
 // are those tracer_hordiff has formed
 int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusion_cs_t *nd, const mom6hip_eos_t *eos, const double *h,
-                   const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
+                   const double *p_surf, const double *h_ML, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
                    const std::vector<double *> &d_tr, const std::vector<double> &cu, int idx_T, int idx_S, int *halo_updates) {
-  static const char *names[8] = {"NDIFF_CONTINUOUS = False", "NDIFF_INTERIOR_ONLY", "NDIFF_TAPERING", "KHTR_USE_EBT_STRUCT",
+  static const char *names[8] = {"NDIFF_CONTINUOUS = False", "(free)", "NDIFF_TAPERING", "KHTR_USE_EBT_STRUCT",
                                  "NDIFF_USE_UNMASKED_TRANSPORT_BUG", "the neutral-diffusion diagnostics", "(free)", "(free)"};
   const int ntr = (int)d_tr.size();
   M6_REQUIRE(nd != nullptr && eos != nullptr, "tracer_hordiff: USE_NEUTRAL_DIFFUSION needs the neutral_diffusion control structure and tv%%eqn_of_state");
@@ -451,6 +475,15 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
   double *tcols = (double *)st.scratch(sizeof(double) * hpl * ((size_t)nk + 1) * nbmax);
   double *stash = A.symmetric ? (double *)st.scratch(sizeof(double) * hpl * nk * 3 * nbmax) : nullptr;
   int *bad = (int *)st.scratch(64);
+  A.interior = nd->interior_only != 0; A.hbl = nullptr; A.kbot = nullptr; A.zbot = nullptr;
+  double *hbl = nullptr;
+  if (A.interior) {      // :370-390: CS%hbl = visc%h_ML, pass_var(CS%hbl, halo=1)
+    M6_REQUIRE(h_ML != nullptr, "hor_bnd_diffusion requires that visc%%h_ML is associated.");
+    hbl = (double *)st.scratch(sizeof(double) * hpl);
+    A.zbot = (double *)st.scratch(sizeof(double) * hpl); A.kbot = (int *)st.scratch(sizeof(int) * hpl);
+    M6_REQUIRE(!st.failed() && hbl && A.zbot && A.kbot, "neutral_diffusion: out of device memory");
+    A.hbl = hbl;
+  }
   M6_REQUIRE(!st.failed() && cols && faces && kos && tcols && bad && (stash || !A.symmetric), "neutral_diffusion: out of device memory");
   A.Pint = cols; A.Tint = cols + hpl * (nk + 1); A.Sint = A.Tint + hpl * (nk + 1); A.dRdT = A.Sint + hpl * (nk + 1); A.dRdS = A.dRdT + hpl * (nk + 1);
   for (int d = 0; d < 2; d++) {
@@ -465,20 +498,26 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
   std::vector<double *> pf(d_tr);
   std::vector<int32_t> ppos(ntr, MOM6HIP_POS_H), pnk(ntr, nk);
-  auto calc_coeffs = [&]() {      // neutral_diffusion_calc_coeffs :337
+  auto calc_coeffs = [&]() -> int {      // neutral_diffusion_calc_coeffs :337
     A.T = d_tr[idx_T]; A.S = d_tr[idx_S];
+    if (A.interior) {
+      M6_HIP(hipMemcpyAsync(hbl, h_ML, sizeof(double) * hpl, hipMemcpyDeviceToDevice, s));
+      double *f1[1] = {hbl}; int32_t p1[1] = {MOM6HIP_POS_H}, n1[1] = {1};
+      if (int rc = m6::group_pass(ctx, f1, p1, n1, 1)) return rc;
+    }
     hipLaunchKernelGGL(nd_column_kernel, dim3((ni + 2 + 63) / 64, nj + 2), dim3(64), 0, s, A);
     hipLaunchKernelGGL(nd_surfaces_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
     hipLaunchKernelGGL(nd_surfaces_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+    return 0;
   };
   if (int rc = m6::group_pass(ctx, pf.data(), ppos.data(), pnk.data(), ntr)) return rc;      // do_group_pass(CS%pass_t) :478
   (*halo_updates)++;
-  calc_coeffs();
+  if (int rc = calc_coeffs()) return rc;
   for (int itt = 1; itt <= num_itts; itt++) {
     if (itt > 1) {
       if (int rc = m6::group_pass(ctx, pf.data(), ppos.data(), pnk.data(), ntr)) return rc;
       (*halo_updates)++;
-      if (nd->recalc_neutral_surf) calc_coeffs();
+      if (nd->recalc_neutral_surf) { if (int rc = calc_coeffs()) return rc; }
     }
     for (int m0 = 0; m0 < ntr; m0 += nbmax) {      // neutral_diffusion :605: the tracers are independent of each other, a batch at a time
       A.nb = (ntr - m0 < nbmax) ? ntr - m0 : nbmax;

@@ -143,7 +143,7 @@ extern "C" int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_t
 
 namespace m6 {
 int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusion_cs_t *nd, const mom6hip_eos_t *eos, const double *h,
-                   const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
+                   const double *p_surf, const double *h_ML, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
                    const std::vector<double *> &d_tr, const std::vector<double> &cu, int idx_T, int idx_S, int *halo_updates);
 }
 
@@ -240,8 +240,9 @@ extern "C" int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_
   int halo_updates = 0;
   if (use_neutral) {      // :474-534
     const double *d_ps = p_surf ? st.in(p_surf, sizeof(double) * (size_t)g.nih * g.njh) : nullptr;
+    const double *d_hml = (nd && nd->interior_only && F && F->h_ML) ? st.in(F->h_ML, sizeof(double) * (size_t)g.nih * g.njh) : nullptr;
     M6_REQUIRE(!st.failed(), "tracer_hordiff: staging failed");
-    if (int rc = m6::neutral_branch(ctx, st, nd, eos, A.h, d_ps, A.khdt_x, A.khdt_y, num_itts, A.scale, d_tr, cu, idx_T, idx_S, &halo_updates))
+    if (int rc = m6::neutral_branch(ctx, st, nd, eos, A.h, d_ps, d_hml, A.khdt_x, A.khdt_y, num_itts, A.scale, d_tr, cu, idx_T, idx_S, &halo_updates))
       return rc;
   } else
   for (int itt = 1; itt <= num_itts; itt++) {      // :540-614

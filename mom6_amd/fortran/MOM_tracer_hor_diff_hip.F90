@@ -6,7 +6,7 @@
 !! RESOLN_SCALED_KHTR with VarMix%Res_fn_h, KHTR_PASSIVITY_COEFF / _MIN with VarMix%Rd_dx_h) on the GPU through libmom6hip
 !! (mom6hip_tracer_hordiff_varmix, HOST memspace), and with USE_NEUTRAL_DIFFUSION the continuous branch of MOM_neutral_diffusion
 !! (neutral_diffusion_init :138, neutral_diffusion_calc_coeffs :337, neutral_diffusion :605: NDIFF_REF_PRES, NDIFF_ANSWER_DATE,
-!! RECALC_NEUTRAL_SURF; mom6hip_tracer_hordiff_neutral).  NDIFF_CONTINUOUS = False, NDIFF_INTERIOR_ONLY, horizontal boundary diffusion,
+!! RECALC_NEUTRAL_SURF, NDIFF_INTERIOR_ONLY with visc%h_ML; mom6hip_tracer_hordiff_neutral).  NDIFF_CONTINUOUS = False, NDIFF_TAPERING, horizontal boundary diffusion,
 !! DIFFUSE_ML_TO_INTERIOR, KHTR_USE_EBT_STRUCT, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
 !!
 !! Compiled INSIDE a MOM6 source tree in place of src/tracer/MOM_tracer_hor_diff.F90; here against tests/fortran/stubs.
@@ -127,12 +127,16 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
     enddo
     if (idx_T < 0 .or. idx_S < 0) call MOM_error(FATAL, "tracer_hordiff (HIP): tv%T and tv%S must be registered tracers.")
     if (associated(tv%p_surf)) p_surf = c_loc(tv%p_surf)
+    if (CS%nd%interior_only /= 0) then      ! MOM_neutral_diffusion.F90:372-378
+      if (.not.associated(visc%h_ML)) call MOM_error(FATAL, "hor_bnd_diffusion requires that visc%h_ML is associated.")
+      fld%h_ML = c_loc(visc%h_ML)
+    endif
     CS%nd%H_to_RZ = GV%H_to_RZ ; CS%nd%recalc_neutral_surf = merge(1, 0, CS%recalc_neutral_surf)
   endif
   if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays
     ctx = mom6hip_shared_context(G, GV)
     do m=1,Reg%ntr ; tr(m) = mom6hip_mirror(ctx, tr(m), int(size(h), c_int64_t), .true., .true.) ; enddo
-    call to_dev(p_surf, size(h(:,:,1)))
+    call to_dev(p_surf, size(h(:,:,1))) ; call to_dev(fld%h_ML, size(h(:,:,1)))
     call to_dev(fld%MEKE_Kh, size(h(:,:,1))) ; call to_dev(fld%Res_fn_h, size(h(:,:,1))) ; call to_dev(fld%Rd_dx_h, size(h(:,:,1)))
     if (c_associated(fld%L2u)) then
       call to_dev(fld%L2u, size(VarMix%L2u)) ; call to_dev(fld%SN_u, size(VarMix%SN_u))
@@ -214,14 +218,20 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
     call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_REF_PRES", CS%nd%ref_pres, &
                    "The reference pressure (Pa) used for the derivatives of the equation of state. If negative (default), "//&
                    "local pressure is used.", units="Pa", default=-1., scale=US%Pa_to_RL2_T2)
-    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_INTERIOR_ONLY", flag, default=.false.)
-    call refuse(flag, "NDIFF_INTERIOR_ONLY")
+    call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_INTERIOR_ONLY", flag, &
+                   "If true, only applies neutral diffusion in the ocean interior. That is, the algorithm will exclude the "//&
+                   "surface and bottom boundary layers.", default=.false.)
+    CS%nd%interior_only = merge(1, 0, flag)
+    if (flag) then
+      call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_TAPERING", flag, default=.false.)
+      call refuse(flag, "NDIFF_TAPERING")
+    endif
     call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_USE_UNMASKED_TRANSPORT_BUG", flag, default=.false.)
     call refuse(flag, "NDIFF_USE_UNMASKED_TRANSPORT_BUG")
     call get_param(param_file, "MOM_neutral_diffusion", "NDIFF_ANSWER_DATE", CS%nd%ndiff_answer_date, &
                    "The vintage of the order of arithmetic to use for the neutral diffusion.", default=20240101)
     call mom6hip_read_eos(param_file, CS%eos, "neutral_diffusion_init")
-    CS%nd%initialized = 1 ; CS%nd%unsupported(:) = 0
+    CS%nd%initialized = 1
   endif
   call get_param(param_file, mdl, "USE_HORIZONTAL_BOUNDARY_DIFFUSION", CS%use_hor_bnd_diffusion, default=.false.)
   call refuse(CS%use_hor_bnd_diffusion, "USE_HORIZONTAL_BOUNDARY_DIFFUSION")

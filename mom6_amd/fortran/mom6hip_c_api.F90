@@ -178,7 +178,8 @@ end type mom6hip_tracer_hor_diff_cs_t
 type, bind(c) :: mom6hip_hordiff_fields_t
   type(c_ptr) :: MEKE_Kh = c_null_ptr, L2u = c_null_ptr, L2v = c_null_ptr, SN_u = c_null_ptr, SN_v = c_null_ptr
   type(c_ptr) :: Res_fn_h = c_null_ptr, Rd_dx_h = c_null_ptr
-  type(c_ptr) :: reserved(5) = c_null_ptr
+  type(c_ptr) :: h_ML = c_null_ptr      !< visc%h_ML (NDIFF_INTERIOR_ONLY)
+  type(c_ptr) :: reserved(4) = c_null_ptr
 end type mom6hip_hordiff_fields_t
 
 !> mom6hip_neutral_diffusion_cs_t (neutral_diffusion_CS, src/tracer/MOM_neutral_diffusion.F90:38), the continuous branch
@@ -186,7 +187,7 @@ type, bind(c) :: mom6hip_neutral_diffusion_cs_t
   real(c_double) :: ref_pres = -1.0, H_to_RZ = 0.0
   real(c_double) :: reserved0(4) = 0.0
   integer(c_int32_t) :: ndiff_answer_date = 20240101, recalc_neutral_surf = 0, initialized = 0
-  integer(c_int32_t) :: reserved_i(1) = 0
+  integer(c_int32_t) :: interior_only = 0
   integer(c_int32_t) :: unsupported(8) = 0
 end type mom6hip_neutral_diffusion_cs_t
 

@@ -17,8 +17,9 @@ _PARAMS = {"KHTR": "KhTr", "MAX_TR_DIFFUSION_CFL": "max_diff_CFL", "CHECK_DIFFUS
 # parameters of the reference whose branches this build does not provide: accepted at their defaults, refused otherwise
 _REFUSED = {"USE_HORIZONTAL_BOUNDARY_DIFFUSION": 1, "DIFFUSE_ML_TO_INTERIOR": 2, "KHTR_USE_EBT_STRUCT": 5}
 # neutral_diffusion_init (src/tracer/MOM_neutral_diffusion.F90:138): the parameters of the continuous branch, and those refused
-_ND_PARAMS = {"NDIFF_REF_PRES": ("ref_pres", float), "NDIFF_ANSWER_DATE": ("ndiff_answer_date", int), "RECALC_NEUTRAL_SURF": ("recalc_neutral_surf", bool)}
-_ND_REFUSED = {"NDIFF_INTERIOR_ONLY": 1, "NDIFF_TAPERING": 2, "NDIFF_USE_UNMASKED_TRANSPORT_BUG": 4}
+_ND_PARAMS = {"NDIFF_REF_PRES": ("ref_pres", float), "NDIFF_ANSWER_DATE": ("ndiff_answer_date", int), "RECALC_NEUTRAL_SURF": ("recalc_neutral_surf", bool),
+              "NDIFF_INTERIOR_ONLY": ("interior_only", bool)}
+_ND_REFUSED = {"NDIFF_TAPERING": 2, "NDIFF_USE_UNMASKED_TRANSPORT_BUG": 4}
 
 
 class tracer_hor_diff_CS:
@@ -69,7 +70,7 @@ def tracer_hordiff(h, dt, MEKE, VarMix, visc, G: DeviceGrid, CS: tracer_hor_diff
     if do_online_flag is False or read_khdt_x is not None or read_khdt_y is not None:
         raise Mom6HipError("tracer_hordiff (HIP): offline khdt arrays are not supported on this path")
     if CS.st.unsupported[0]:
-        return _tracer_hordiff_neutral(h, dt, MEKE, VarMix, G, CS, Reg, tv, conc_underflow)
+        return _tracer_hordiff_neutral(h, dt, MEKE, VarMix, visc, G, CS, Reg, tv, conc_underflow)
     L = lib()
     L.mom6hip_tracer_hordiff_varmix.argtypes = [C.c_void_p, C.POINTER(_abi.TracerHorDiffCS), C.POINTER(_abi.HorDiffFields), C.c_void_p, C.c_double,
                                                 C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(_abi.HorDiffStats)]
@@ -104,9 +105,10 @@ def _same(a, b):
     return a is b or (hasattr(a, "data_ptr") and hasattr(b, "data_ptr") and a.data_ptr() == b.data_ptr())
 
 
-def _tracer_hordiff_neutral(h, dt, MEKE, VarMix, G, CS, Reg, tv, conc_underflow):
+def _tracer_hordiff_neutral(h, dt, MEKE, VarMix, visc, G, CS, Reg, tv, conc_underflow):
     """the USE_NEUTRAL_DIFFUSION branch (:474-534): tv has T, S (two of the arrays of Reg, as in the reference where the registry
-    points at tv%T and tv%S), eqn_of_state (an _abi.EOS) and optionally p_surf -- a dict or an object."""
+    points at tv%T and tv%S), eqn_of_state (an _abi.EOS) and optionally p_surf -- a dict or an object; with NDIFF_INTERIOR_ONLY visc
+    has h_ML (visc%h_ML, the boundary-layer depth)."""
     get = (lambda n: tv.get(n)) if isinstance(tv, dict) else (lambda n: getattr(tv, n, None))
     if tv is None or get("T") is None or get("S") is None or get("eqn_of_state") is None:
         raise Mom6HipError("tracer_hordiff: USE_NEUTRAL_DIFFUSION needs tv%T, tv%S and tv%eqn_of_state")
@@ -135,6 +137,11 @@ def _tracer_hordiff_neutral(h, dt, MEKE, VarMix, G, CS, Reg, tv, conc_underflow)
     ptrs = (C.c_void_p * max(len(tr), 1))()
     for m, t in enumerate(tr):
         p, s = _ptr_space(t); ptrs[m] = p; spaces.add(s)
+    if CS.neutral_diffusion_CSp.interior_only:
+        hml = None if visc is None else (visc.get("h_ML") if isinstance(visc, dict) else getattr(visc, "h_ML", None))
+        if hml is None:
+            raise Mom6HipError("hor_bnd_diffusion requires that visc%h_ML is associated.")
+        p, s = _ptr_space(hml); spaces.add(s); F.h_ML = p
     ps = None
     if get("p_surf") is not None:
         ps, s = _ptr_space(get("p_surf")); spaces.add(s)

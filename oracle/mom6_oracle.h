@@ -73,11 +73,12 @@ double orc_ndiff_interpolate_for_nondim_position(double dRhoNeg, double Pneg, do
 void orc_ndiff_find_neutral_surface_positions_continuous(int nk, const double *Pl, const double *Tl, const double *Sl,
     const double *dRdTl, const double *dRdSl, const double *Pr, const double *Tr, const double *Sr, const double *dRdTr,
     const double *dRdSr, double *PoL, double *PoR, int *KoL, int *KoR, double *hEff);
+void orc_ndiff_boundary_k_range_surface(int nk, const double *h, double hbl, int *k_bot, double *zeta_bot);
 int orc_ndiff_neutral_surface_flux(int nk, const double *hl, const double *hr, const double *Tl, const double *Tr,
                                    const double *PiL, const double *PiR, const int *KoL, const int *KoR, const double *hEff,
                                    double *Flx, double h_neglect);
 int orc_neutral_branch(const mom6hip_grid_t *G, const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_eos_t *eos,
-                       const double *h, const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts,
+                       const double *h, const double *p_surf, const double *h_ML, const double *khdt_x, const double *khdt_y, int num_itts,
                        double I_numitts, double *const *tr, const double *conc_underflow, int ntr, int idx_T, int idx_S,
                        int *halo_updates);
 

@@ -1,7 +1,8 @@
 /* oracle/neutral_diffusion.c -- TEST INFRASTRUCTURE: a C restatement of the continuous-reconstruction branch of
  * MOM_neutral_diffusion (src/tracer/MOM_neutral_diffusion.F90): neutral_diffusion_calc_coeffs :337-602, neutral_diffusion
- * :605-1019 and the column routines they call.  NDIFF_CONTINUOUS = True only (the default); no NDIFF_INTERIOR_ONLY /
- * NDIFF_TAPERING, no KHTR_USE_EBT_STRUCT, no NDIFF_USE_UNMASKED_TRANSPORT_BUG.
+ * :605-1019 and the column routines they call.  NDIFF_CONTINUOUS = True only (the default); no
+ * NDIFF_TAPERING, no KHTR_USE_EBT_STRUCT, no NDIFF_USE_UNMASKED_TRANSPORT_BUG; NDIFF_INTERIOR_ONLY with boundary_k_range of
+ * MOM_hor_bnd_diffusion.F90:609.
  * Pinned by the reference's own known answers: every case of ndiff_unit_tests_continuous (:2576-2835) is held in
  * tests/golden/neutral_diffusion.json and checked by tests/test_neutral_diffusion.py. */
 #include <math.h>
@@ -162,9 +163,37 @@ static double absolute_position(const double *Pint, const int *Karr, const doubl
 /* find_neutral_surface_positions_continuous :1353 (without the optional boundary-layer limits).
  * Columns of nk+1 interface values; PoL, PoR, KoL, KoR hold 2*nk+2 entries, hEff 2*nk+1; KoL / KoR are 1-based as in the
  * reference. */
+static void nsp_continuous(int nk, const double *Pl, const double *Tl, const double *Sl,
+    const double *dRdTl, const double *dRdSl, const double *Pr, const double *Tr, const double *Sr, const double *dRdTr,
+    const double *dRdSr, double *PoL, double *PoR, int *KoL, int *KoR, double *hEff, int interior_limit, int bl_kl, int bl_kr,
+    double bl_zl, double bl_zr);
+
 void orc_ndiff_find_neutral_surface_positions_continuous(int nk, const double *Pl, const double *Tl, const double *Sl,
     const double *dRdTl, const double *dRdSl, const double *Pr, const double *Tr, const double *Sr, const double *dRdTr,
     const double *dRdSr, double *PoL, double *PoR, int *KoL, int *KoR, double *hEff)
+{
+  nsp_continuous(nk, Pl, Tl, Sl, dRdTl, dRdSl, Pr, Tr, Sr, dRdTr, dRdSr, PoL, PoR, KoL, KoR, hEff, 0, 0, 0, 0., 0.);
+}
+
+/* boundary_k_range for the SURFACE boundary layer, src/tracer/MOM_hor_bnd_diffusion.F90:609-647 (k_bot 1-based) */
+void orc_ndiff_boundary_k_range_surface(int nk, const double *h, double hbl, int *k_bot, double *zeta_bot)
+{
+  double htot = 0., hsum = 0.;
+  *k_bot = 1; *zeta_bot = 0.;
+  if (hbl == 0.) return;
+  for (int k = 0; k < nk; k++) hsum = hsum + h[k];
+  if (hbl >= hsum) { *k_bot = nk; *zeta_bot = 1.; return; }
+  for (int k = 0; k < nk; k++) {
+    htot = htot + h[k];
+    if (htot >= hbl) { *k_bot = k+1; *zeta_bot = 1 - (htot - hbl)/h[k]; return; }
+  }
+}
+
+/* with the optional boundary-layer limits bl_kl, bl_kr, bl_zl, bl_zr of the reference (:1508-1521) when interior_limit */
+static void nsp_continuous(int nk, const double *Pl, const double *Tl, const double *Sl,
+    const double *dRdTl, const double *dRdSl, const double *Pr, const double *Tr, const double *Sr, const double *dRdTr,
+    const double *dRdSr, double *PoL, double *PoR, int *KoL, int *KoR, double *hEff, int interior_limit, int bl_kl, int bl_kr,
+    double bl_zl, double bl_zr)
 {
   const int ns = 2*nk + 2;
   int kr = 1, kl = 1, lastK_right = 1, lastK_left = 1;
@@ -207,6 +236,10 @@ void orc_ndiff_find_neutral_surface_positions_continuous(int nk, const double *P
       if (kl <= nk) { PoL[ks] = 0.; KoL[ks] = kl; } else { PoL[ks] = 1.; KoL[ks] = nk; }
       if (kl <= nk) kl = kl + 1;
       else { reached_bottom = 1; searching_right_column = 0; searching_left_column = 1; }
+    }
+    if (interior_limit) {
+      if (KoL[ks] <= bl_kl) { KoL[ks] = bl_kl; if (PoL[ks] < bl_zl) PoL[ks] = bl_zl; }
+      if (KoR[ks] <= bl_kr) { KoR[ks] = bl_kr; if (PoR[ks] < bl_zr) PoR[ks] = bl_zr; }
     }
     lastK_left = KoL[ks]; lastP_left = PoL[ks];
     lastK_right = KoR[ks]; lastP_right = PoR[ks];
@@ -267,7 +300,7 @@ static void gather(const double *a, size_t n2, size_t stride, int n, double *col
 
 /* neutral_diffusion_calc_coeffs :337 */
 static void nd_calc_coeffs(const mom6hip_grid_t *G, const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_eos_t *eos,
-                           const double *h, const double *T, const double *S, const double *p_surf, nd_work_t *W)
+                           const double *h, const double *T, const double *S, const double *p_surf, const double *h_ML, nd_work_t *W)
 {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int isd = G->isd, jsd = G->jsd;
@@ -280,6 +313,20 @@ static void nd_calc_coeffs(const mom6hip_grid_t *G, const mom6hip_neutral_diffus
   const double pa_to_H = 1. / (ND->H_to_RZ * G->g_Earth);
   const int ns = W->nsurf;
   memset(W->dRdT, 0, sizeof(double)*hpl*(nz+1)); memset(W->dRdS, 0, sizeof(double)*hpl*(nz+1));
+  /* :370-390: the boundary-layer depth, its halo, and the layer / fraction it ends in for every wet column */
+  int *k_bot = (int*)calloc(hpl, sizeof(int));
+  double *zeta_bot = (double*)calloc(hpl, sizeof(double)), *hbl = (double*)calloc(hpl, sizeof(double));
+  for (size_t q = 0; q < hpl; q++) k_bot[q] = 1;
+  if (ND->interior_only) {
+    memcpy(hbl, h_ML, sizeof(double)*hpl);
+    orc_halo_update(G, hbl, MOM6HIP_POS_H, 1);
+    double *hcol = (double*)calloc((size_t)nz, sizeof(double));
+    for (int j = js-1; j <= je+1; j++) for (int i = is-1; i <= ie+1; i++) if (G->mask2dT[H2(i,j)] > 0.0) {
+      gather(h, H2(i,j), hpl, nz, hcol);
+      orc_ndiff_boundary_k_range_surface(nz, hcol, hbl[H2(i,j)], &k_bot[H2(i,j)], &zeta_bot[H2(i,j)]);
+    }
+    free(hcol);
+  }
   double *hc = (double*)calloc((size_t)8*(nz+1), sizeof(double));
   double *Tc = hc + (nz+1), *Sc = Tc + (nz+1), *Ti = Sc + (nz+1), *Si = Ti + (nz+1);
   for (int j = js-1; j <= je+1; j++) for (int i = is-1; i <= ie+1; i++) {
@@ -309,8 +356,9 @@ static void nd_calc_coeffs(const mom6hip_grid_t *G, const mom6hip_neutral_diffus
       const size_t cl = H2(i,j), cr = dir ? H2(i,j+1) : H2(i+1,j);
       const double *src[5] = {W->Pint, W->Tint, W->Sint, W->dRdT, W->dRdS};
       for (int q = 0; q < 5; q++) { gather(src[q], cl, hpl, nz+1, c + q*(nz+1)); gather(src[q], cr, hpl, nz+1, c + (5+q)*(nz+1)); }
-      orc_ndiff_find_neutral_surface_positions_continuous(nz, c, c + (nz+1), c + 2*(nz+1), c + 3*(nz+1), c + 4*(nz+1),
-          c + 5*(nz+1), c + 6*(nz+1), c + 7*(nz+1), c + 8*(nz+1), c + 9*(nz+1), PoL, PoR, Ko, Ko + ns, hE);
+      nsp_continuous(nz, c, c + (nz+1), c + 2*(nz+1), c + 3*(nz+1), c + 4*(nz+1),
+          c + 5*(nz+1), c + 6*(nz+1), c + 7*(nz+1), c + 8*(nz+1), c + 9*(nz+1), PoL, PoR, Ko, Ko + ns, hE,
+          ND->interior_only, k_bot[cl], k_bot[cr], zeta_bot[cl], zeta_bot[cr]);
       double *oPoL = dir ? W->vPoL : W->uPoL, *oPoR = dir ? W->vPoR : W->uPoR, *ohE = dir ? W->vhEff : W->uhEff;
       int *oKoL = dir ? W->vKoL : W->uKoL, *oKoR = dir ? W->vKoR : W->uKoR;
       for (int ks = 0; ks < ns; ks++) {
@@ -318,7 +366,7 @@ static void nd_calc_coeffs(const mom6hip_grid_t *G, const mom6hip_neutral_diffus
         if (ks < ns-1) ohE[f + pl*ks] = hE[ks] * pa_to_H;      /* :570-575 */
       }
     }
-  free(c); free(Ko);
+  free(c); free(Ko); free(k_bot); free(zeta_bot); free(hbl);
 #undef H2
 #undef U2
 #undef V2
@@ -401,7 +449,7 @@ static int nd_apply(const mom6hip_grid_t *G, const mom6hip_neutral_diffusion_cs_
 /* the neutral branch of tracer_hordiff, src/tracer/MOM_tracer_hor_diff.F90:474-534: called by orc_tracer_hordiff_neutral
  * (tracer_hor_diff.c) with khdt_x, khdt_y and the iteration count it has formed.  Returns 0, or 4 where ppm_ave stops. */
 int orc_neutral_branch(const mom6hip_grid_t *G, const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_eos_t *eos,
-                       const double *h, const double *p_surf, const double *khdt_x, const double *khdt_y, int num_itts,
+                       const double *h, const double *p_surf, const double *h_ML, const double *khdt_x, const double *khdt_y, int num_itts,
                        double I_numitts, double *const *tr, const double *conc_underflow, int ntr, int idx_T, int idx_S,
                        int *halo_updates)
 {
@@ -419,14 +467,14 @@ int orc_neutral_branch(const mom6hip_grid_t *G, const mom6hip_neutral_diffusion_
   int bad = 0;
   for (int m = 0; m < ntr; m++) orc_halo_update(G, tr[m], MOM6HIP_POS_H, nz);      /* do_group_pass(CS%pass_t) :478 */
   (*halo_updates)++;
-  nd_calc_coeffs(G, ND, eos, h, tr[idx_T], tr[idx_S], p_surf, &W);
+  nd_calc_coeffs(G, ND, eos, h, tr[idx_T], tr[idx_S], p_surf, h_ML, &W);
   for (size_t q = 0; q < upl; q++) Coef_x[q] = I_numitts * khdt_x[q];           /* :489-503 */
   for (size_t q = 0; q < vpl; q++) Coef_y[q] = I_numitts * khdt_y[q];
   for (int itt = 1; itt <= num_itts; itt++) {
     if (itt > 1) {
       for (int m = 0; m < ntr; m++) orc_halo_update(G, tr[m], MOM6HIP_POS_H, nz);
       (*halo_updates)++;
-      if (ND->recalc_neutral_surf) nd_calc_coeffs(G, ND, eos, h, tr[idx_T], tr[idx_S], p_surf, &W);
+      if (ND->recalc_neutral_surf) nd_calc_coeffs(G, ND, eos, h, tr[idx_T], tr[idx_S], p_surf, h_ML, &W);
     }
     for (int m = 0; m < ntr; m++)
       bad |= nd_apply(G, ND, h, Coef_x, Coef_y, tr[m], conc_underflow ? conc_underflow[m] : 0.0, &W);

@@ -482,7 +482,9 @@ def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL
                                                  C.POINTER(_abi.HorDiffFields), _dp, C.POINTER(_abi.EOS), _dp, C.c_double, C.POINTER(_dp), _dp,
                                                  C.c_int, C.c_int, C.c_int, C.POINTER(_abi.HorDiffStats)]
         cs.unsupported[0] = 1
-        nd = neutral_diffusion_cs(grid, **{k: v for k, v in neutral.items() if k not in ("eos", "idx_T", "idx_S", "p_surf")})
+        nd = neutral_diffusion_cs(grid, **{k: v for k, v in neutral.items() if k not in ("eos", "idx_T", "idx_S", "p_surf", "h_ML")})
+        if neutral.get("h_ML") is not None:      # NDIFF_INTERIOR_ONLY: visc%h_ML
+            keep.append(np.ascontiguousarray(neutral["h_ML"], dtype=np.float64)); F.h_ML = keep[-1].ctypes.data; nd.interior_only = 1
         ps = neutral.get("p_surf")
         ps = None if ps is None else np.ascontiguousarray(ps, dtype=np.float64)
         rc = L.orc_tracer_hordiff_neutral(C.byref(grid.struct()), C.byref(cs), C.byref(nd), C.byref(F), _p(h), C.byref(neutral["eos"]), _p(ps),

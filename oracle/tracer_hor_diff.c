@@ -36,6 +36,7 @@ int orc_tracer_hordiff_neutral(const mom6hip_grid_t *G, const mom6hip_tracer_hor
   if (use_neutral) {
     if (!ND || !eos || idx_T < 0 || idx_T >= ntr || idx_S < 0 || idx_S >= ntr) return 3;
     for (int q = 0; q < 8; q++) if (ND->unsupported[q]) return 2;
+    if (ND->interior_only && !(F && F->h_ML)) return 3;
   }
   if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
   const int use_VarMix = CS->use_variable_mixing != 0;
@@ -114,7 +115,7 @@ int orc_tracer_hordiff_neutral(const mom6hip_grid_t *G, const mom6hip_tracer_hor
 
   int halo_updates = 0, rc = 0;
   if (use_neutral)                                                 /* :474-534 */
-    rc = orc_neutral_branch(G, ND, eos, h, p_surf, khdt_x, khdt_y, num_itts, I_numitts, tr, conc_underflow, ntr, idx_T, idx_S,
+    rc = orc_neutral_branch(G, ND, eos, h, p_surf, (ND->interior_only && F) ? F->h_ML : NULL, khdt_x, khdt_y, num_itts, I_numitts, tr, conc_underflow, ntr, idx_T, idx_S,
                             &halo_updates);
   else
   for (int itt = 1; itt <= num_itts; itt++) {                      /* :540-604 */

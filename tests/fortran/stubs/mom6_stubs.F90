@@ -582,6 +582,7 @@ type :: vertvisc_type
   real, allocatable, dimension(:,:) :: nkml_visc_u, nkml_visc_v
   real, allocatable, dimension(:,:,:) :: Ray_u, Ray_v
   real, pointer, dimension(:,:,:) :: Kv_shear => NULL(), Kv_shear_Bu => NULL()
+  real, pointer, dimension(:,:) :: h_ML => NULL()
 end type vertvisc_type
 type :: ocean_internal_state
   integer :: unused = 0

@@ -89,6 +89,9 @@ allocate(MEKE%Kh(isd:ied,jsd:jed), VarMix%L2u(isd-1:ied,jsd:jed), VarMix%L2v(isd
 read(u_in) dt_therm, MEKE%KhTr_fac
 read(u_in) h, uhtr, vhtr, trs
 read(u_in) MEKE%Kh, VarMix%L2u, VarMix%L2v, VarMix%SN_u, VarMix%SN_v, VarMix%Res_fn_h, VarMix%Rd_dx_h
+if (opt(5) /= 0) then      ! visc%h_ML (NDIFF_INTERIOR_ONLY)
+  allocate(visc%h_ML(isd:ied,jsd:jed)) ; read(u_in) visc%h_ML
+endif
 close(u_in)
 VarMix%use_variable_mixing = (opt(2) /= 0) ; VarMix%Resoln_scaled_KhTr = (opt(3) /= 0)
 if (opt(4) == 0) deallocate(MEKE%Kh)

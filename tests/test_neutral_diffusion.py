@@ -109,7 +109,27 @@ def test_oracle_neutral_branch_iterates_and_refuses():
         orc.tracer_hordiff(g, h, 3600.0, [t.copy() for t in tr], 50.0, neutral=dict(nd, idx_T=5))
 
 
-ND_CASES = [dict(KhTr=800.0), dict(KhTr=800.0, ndiff_answer_date=20240401), dict(KhTr=1.0e9, max_diff_CFL=2.5),
+def test_boundary_k_range_and_interior_only_on_the_oracle():
+    """NDIFF_INTERIOR_ONLY: a boundary layer deeper than the ocean leaves nothing to diffuse (every surface is clamped to the bottom of the
+    last layer, hEff = 0), none at all is the unlimited answer, and in between the tracers above the boundary layer's base layer keep their bits"""
+    g, h, tr = case(ntr=2, thin=False, land_frac=0.0)
+    E = orc.eos("WRIGHT")
+    base = [t.copy() for t in tr]
+    orc.tracer_hordiff(g, h, 3600.0, base, 800.0, neutral=dict(eos=E, idx_T=0, idx_S=1))
+    a = [t.copy() for t in tr]
+    orc.tracer_hordiff(g, h, 3600.0, a, 800.0, neutral=dict(eos=E, idx_T=0, idx_S=1, h_ML=np.zeros(g.shape2(_abi.POS_H))))
+    assert all(np.array_equal(x, y) for x, y in zip(a, base))
+    b = [t.copy() for t in tr]
+    orc.tracer_hordiff(g, h, 3600.0, b, 800.0, neutral=dict(eos=E, idx_T=0, idx_S=1, h_ML=np.full(g.shape2(_abi.POS_H), 1.0e6)))
+    assert all(np.array_equal(interior(g, x), interior(g, y)) for x, y in zip(b, tr))
+    c = [t.copy() for t in tr]
+    hml = np.ascontiguousarray(h[:2].sum(0) + 0.25 * h[2])      # the boundary layer ends a quarter into the third layer
+    orc.tracer_hordiff(g, h, 3600.0, c, 800.0, neutral=dict(eos=E, idx_T=0, idx_S=1, h_ML=hml))
+    assert np.array_equal(interior(g, c[0])[:2], interior(g, tr[0])[:2]) and not np.array_equal(interior(g, c[0])[2:], interior(g, tr[0])[2:])
+    assert not np.array_equal(interior(g, c[0]), interior(g, base[0]))
+
+
+ND_CASES = [dict(KhTr=800.0), dict(KhTr=800.0, interior=0.3), dict(KhTr=1.0e9, max_diff_CFL=2.5, interior=0.6, recalc_neutral_surf=True, reentrant=(True, True)), dict(KhTr=800.0, ndiff_answer_date=20240401), dict(KhTr=1.0e9, max_diff_CFL=2.5),
             dict(KhTr=1.0e9, max_diff_CFL=2.5, recalc_neutral_surf=True), dict(KhTr=800.0, ref_pres=2.0e7, eos="LINEAR"),
             dict(KhTr=5.0e7, check_diffusive_CFL=True, reentrant=(True, True)), dict(KhTr=300.0, conc_underflow=[0.0, 0.0, 0.5]),
             dict(KhTr=800.0, p_surf=True, reentrant=(False, False), ni=70, nj=9, nk=3), dict(KhTr=800.0, nk=2, thin=False),
@@ -132,18 +152,22 @@ def test_tracer_hordiff_neutral_matches_oracle_bitwise(kw, space):
     if kw.pop("p_surf", False):
         p_surf = np.ascontiguousarray(1.0e4 * np.random.default_rng(8).random(g.shape2(_abi.POS_H)))
     ndk = {k: kw[k] for k in ("ndiff_answer_date", "recalc_neutral_surf", "ref_pres") if k in kw}
+    h_ML = None
+    if "interior" in kw:      # NDIFF_INTERIOR_ONLY with a boundary layer of a varying fraction of the depth (none at all in places)
+        frac = np.clip(kw.pop("interior") * 2.0 * np.random.default_rng(9).random(g.shape2(_abi.POS_H)) - 0.1, 0.0, 1.2)
+        h_ML = np.ascontiguousarray(frac * h.sum(0))
     ref = [t.copy() for t in tr]
     rs = orc.tracer_hordiff(g, h, 3600.0, ref, kw["KhTr"], max_diff_CFL=kw.get("max_diff_CFL", -1.0),
                             check_diffusive_CFL=kw.get("check_diffusive_CFL", False), conc_underflow=cu,
-                            neutral=dict(eos=E, idx_T=0, idx_S=1, p_surf=p_surf, **ndk))
+                            neutral=dict(eos=E, idx_T=0, idx_S=1, p_surf=p_surf, h_ML=h_ML, **ndk))
     dg = DeviceGrid(g)
     put = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if space == "device" else (lambda a: np.ascontiguousarray(a).copy())
     dtr = [put(t) for t in tr]
     CS = tracer_hor_diff_init(KHTR=kw["KhTr"], MAX_TR_DIFFUSION_CFL=kw.get("max_diff_CFL", -1.0), CHECK_DIFFUSIVE_CFL=kw.get("check_diffusive_CFL", False),
                               USE_NEUTRAL_DIFFUSION=True, NDIFF_REF_PRES=ndk.get("ref_pres", -1.0), NDIFF_ANSWER_DATE=ndk.get("ndiff_answer_date", 20240101),
-                              RECALC_NEUTRAL_SURF=ndk.get("recalc_neutral_surf", False))
+                              RECALC_NEUTRAL_SURF=ndk.get("recalc_neutral_surf", False), NDIFF_INTERIOR_ONLY=h_ML is not None)
     tv = dict(T=dtr[0], S=dtr[1], eqn_of_state=E, p_surf=None if p_surf is None else put(p_surf))
-    st = tracer_hordiff(put(h), 3600.0, None, None, None, dg, CS, dtr, tv=tv, conc_underflow=cu)
+    st = tracer_hordiff(put(h), 3600.0, None, None, None if h_ML is None else dict(h_ML=put(h_ML)), dg, CS, dtr, tv=tv, conc_underflow=cu)
     dg.sync()
     assert (st.num_itts, st.halo_updates) == (rs.num_itts, rs.halo_updates) and st.max_CFL == rs.max_CFL
     for m, (a, b) in enumerate(zip(dtr, ref)):
@@ -165,7 +189,9 @@ def test_tracer_hordiff_neutral_refuses_what_it_does_not_provide():
     tv = dict(T=dtr[0], S=dtr[1], eqn_of_state=orc.eos("WRIGHT"))
     with pytest.raises(Mom6HipError, match="NDIFF_CONTINUOUS"):
         tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True, NDIFF_CONTINUOUS=False), dtr, tv=tv)
-    with pytest.raises(Mom6HipError, match="NDIFF_INTERIOR_ONLY"):
+    with pytest.raises(Mom6HipError, match="NDIFF_TAPERING"):
+        tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True, NDIFF_TAPERING=True), dtr, tv=tv)
+    with pytest.raises(Mom6HipError, match="h_ML"):
         tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True, NDIFF_INTERIOR_ONLY=True), dtr, tv=tv)
     with pytest.raises(Mom6HipError, match="tv%T"):
         tracer_hordiff(dh, 3600.0, None, None, None, dg, tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True), dtr, tv=None)

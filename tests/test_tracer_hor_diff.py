@@ -210,7 +210,10 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
     from mom6_amd import synth as sy
     ad = {k: (v if isinstance(v, list) else v.numpy()) for k, v in sy.make_advection_state(g, ntr=1, seed=9).items()}
     f = varmix_fields(g)
-    neutral = name == "neutral"      # USE_NEUTRAL_DIFFUSION with the first two tracers as tv%T, tv%S
+    neutral = name in ("neutral", "neutral_interior")      # USE_NEUTRAL_DIFFUSION with the first two tracers as tv%T, tv%S
+    h_ML = None
+    if name == "neutral_interior":      # NDIFF_INTERIOR_ONLY below visc%h_ML
+        h_ML = np.ascontiguousarray(np.clip(0.8 * np.random.default_rng(3).random(g.shape2(_abi.POS_H)) - 0.1, 0.0, 1.0) * ad["h_end"].sum(0))
     kw = dict(VM[name]) if name and not neutral else dict(KhTr=300.0, use=None)
     use = kw.pop("use"); meke = kw.pop("meke", None); check = kw.pop("check", False)
     ref = [t.copy() for t in tr]
@@ -220,8 +223,8 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
     KhTr = kw.pop("KhTr")
     orc.tracer_hordiff(g, ad["h_end"], dt, ref, KhTr, check_diffusive_CFL=check, VarMix=None if use is None else {n: f[n] for n in use},
                        MEKE=None if meke is None else dict(Kh=f["Kh"], KhTr_fac=meke),
-                       neutral=dict(eos=orc.eos("WRIGHT"), idx_T=0, idx_S=1, ndiff_answer_date=20240401, H_to_RZ=1035.0) if neutral else None, **kw)
-    opt = [len(tr), int(use is not None), int(use is not None and "Res_fn_h" in use), int(meke is not None), 0, 0, 0, 0]
+                       neutral=dict(eos=orc.eos("WRIGHT"), idx_T=0, idx_S=1, ndiff_answer_date=20240401, H_to_RZ=1035.0, h_ML=h_ML) if neutral else None, **kw)
+    opt = [len(tr), int(use is not None), int(use is not None and "Res_fn_h" in use), int(meke is not None), int(h_ML is not None), 0, 0, 0]
     with open(tmp / "in.bin", "wb") as fh:
         np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, 900.0], dtype="<f8").tofile(fh)
@@ -229,7 +232,8 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
         for n in _abi.ALL_METRICS:
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
         np.array([dt, 1.0 if meke is None else meke], dtype="<f8").tofile(fh)
-        for a in [ad["h_end"], ad["uhtr"], ad["vhtr"]] + tr + [f[n] for n in ("Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h")]:
+        for a in [ad["h_end"], ad["uhtr"], ad["vhtr"]] + tr + [f[n] for n in ("Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h")] + \
+                ([h_ML] if h_ML is not None else []):
             np.ascontiguousarray(a, dtype="<f8").tofile(fh)
     REF = dict(KhTr_Slope_Cff="KHTR_SLOPE_CFF", KhTr_min="KHTR_MIN", KhTr_max="KHTR_MAX", KhTr_passivity_coeff="KHTR_PASSIVITY_COEFF",
                KhTr_passivity_min="KHTR_PASSIVITY_MIN", max_diff_CFL="MAX_TR_DIFFUSION_CFL")
@@ -239,6 +243,7 @@ def _write_tracer_case(tmp, g, h, tr, name, dt=3600.0, scheme="PPM:H3", resident
             fh.write(f"{REF[k]} = {float(v)!r}\n")
         if neutral:
             fh.write("USE_NEUTRAL_DIFFUSION = True\nNDIFF_ANSWER_DATE = 20240401\nEQN_OF_STATE = WRIGHT\n")
+            fh.write(f"NDIFF_INTERIOR_ONLY = {h_ML is not None}\n")
     return ref
 
 
@@ -266,7 +271,7 @@ def test_tracer_module_shims_match_oracle(tmp_path):
         pytest.skip("amdflang not present")
     exe = _build_shims(tmp_path, driver="tracer_driver")
     g, h, tr = case(36, 22, 4)
-    for name, resident in [(n, r) for n in [None, "neutral"] + list(VM) for r in (False, True)]:      # staged host arrays, or the shared device mirrors
+    for name, resident in [(n, r) for n in [None, "neutral", "neutral_interior"] + list(VM) for r in (False, True)]:      # staged host arrays, or the shared device mirrors
         ref = _write_tracer_case(tmp_path, g, h, tr, name, resident=resident)
         r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
         assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (name, r.stderr[-600:])
