@@ -400,6 +400,14 @@ int mom6hip_ale_remap_set_h_vel(mom6hip_ctx_t *ctx, const double *h_new, double 
 int mom6hip_ale_remap_set_h_vel_via_dz(mom6hip_ctx_t *ctx, const double *h_old, const double *dzInterface, double *h_u,
                                        double *h_v, int32_t memspace);
 
+/* ALE_PLM_edge_values(CS, G, GV, h, Q, bdry_extrap, Q_t, Q_b)                      src/ALE/MOM_ALE.F90:1520
+ * (TS_PLM_edge_values :1495 calls it for tv%S and tv%T.)  The top and bottom edge values of every layer of a 3-d scalar at h
+ * points by the monotonised piecewise-linear reconstruction (PLM_slope_wa, PLM_monotonized_slope; the boundary cells piecewise
+ * constant, or by PLM_extrapolate_slope with bdry_extrap), columns isc-1..iec+1 x jsc-1..jec+1, REMAPPING_ANSWER_DATE >= 20190101:
+ * the edge values PressureForce_FV reconstructs T and S with. */
+int mom6hip_ale_plm_edge_values(mom6hip_ctx_t *ctx, const double *h, const double *Q, int32_t bdry_extrap, double *Q_t, double *Q_b,
+                                int32_t memspace);
+
 /* ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
  *                                                                                src/ALE/MOM_ALE.F90:1061
  * cs is CS%vel_remapCS; REMAP_VEL_CONSERVE_KE = False, REMAP_VEL_MASK_BBL_THICK <= 0, no KE diagnostics.

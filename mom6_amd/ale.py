@@ -97,6 +97,7 @@ def _setup_regrid():
         L.mom6hip_ale_remap_set_h_vel.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int32]
         L.mom6hip_ale_remap_set_h_vel_via_dz.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32]
         L.mom6hip_ale_remap_velocities.argtypes = [C.c_void_p, C.POINTER(_abi.RemappingCS)] + [C.c_void_p] * 6 + [C.c_int32]
+        L.mom6hip_ale_plm_edge_values.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L._regrid_ready = True
     return L
 
@@ -117,6 +118,18 @@ def ALE_regrid(G: DeviceGrid, h, h_new, dzRegrid, tv, CS: regridding_CS, frac_sh
         raise Mom6HipError("ALE_regrid (HIP): ice shelves and PCM_cell (hybgen) are not supported")
     p, sp = _ptrs([h, h_new, dzRegrid], "ALE_regrid")
     check(_setup_regrid().mom6hip_ale_regrid(G.handle, C.byref(CS.st), *p, sp), "ALE_regrid")
+
+
+def ALE_PLM_edge_values(CS, G: DeviceGrid, h, Q, bdry_extrap, Q_t, Q_b):
+    """ALE_PLM_edge_values(CS, G, GV, h, Q, bdry_extrap, Q_t, Q_b) -- MOM_ALE.F90:1520: the top and bottom PLM edge values of Q."""
+    p, sp = _ptrs([h, Q, Q_t, Q_b], "ALE_PLM_edge_values")
+    check(_setup_regrid().mom6hip_ale_plm_edge_values(G.handle, p[0], p[1], 1 if bdry_extrap else 0, p[2], p[3], sp), "ALE_PLM_edge_values")
+
+
+def TS_PLM_edge_values(CS, S_t, S_b, T_t, T_b, G: DeviceGrid, tv, h, bdry_extrap):
+    """TS_PLM_edge_values(CS, S_t, S_b, T_t, T_b, G, GV, tv, h, bdry_extrap) -- MOM_ALE.F90:1495; tv = (T, S)."""
+    ALE_PLM_edge_values(CS, G, h, tv[1], bdry_extrap, S_t, S_b)
+    ALE_PLM_edge_values(CS, G, h, tv[0], bdry_extrap, T_t, T_b)
 
 
 def ALE_remap_set_h_vel(CS, G: DeviceGrid, h_new, h_u, h_v, OBC=None, debug=False):

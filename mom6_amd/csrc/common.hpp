@@ -20,6 +20,12 @@ namespace m6 {
 
 // ---- errors --------------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
+// Keeps the message of the error being reported while clean-up calls that may fail themselves (and would overwrite it) run
+struct ErrorKeeper {
+  ErrorKeeper();
+  ~ErrorKeeper();
+  char saved[1024];
+};
 
 #define M6_HIP(call)                                                                        \
   do {                                                                                      \

@@ -20,6 +20,8 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
   g_err = buf;
 }
+ErrorKeeper::ErrorKeeper() { snprintf(saved, sizeof(saved), "%s", g_err.c_str()); }
+ErrorKeeper::~ErrorKeeper() { g_err = saved; }
 
 int DevBuf::reserve(size_t n) {
   if (n <= bytes) return 0;

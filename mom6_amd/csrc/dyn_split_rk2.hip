@@ -75,7 +75,9 @@ template <class F> int around_pass(mom6hip_ctx_t *ctx, F work) {
   m6::row_window(ctx, js + W, je - W);
   int rc = work();
   m6::row_window_reset(ctx);
-  if (rc) return rc;
+  // (an error between start and complete: the exchange in flight is completed all the same, so that the context is left without
+  // a pending pass and the FIRST error is the one reported, not "a pass is already in flight" from the next call)
+  if (rc) { m6::ErrorKeeper keep; m6::complete_group_pass(ctx); return rc; }
   if ((rc = m6::complete_group_pass(ctx))) return rc;
   m6::row_window(ctx, js, js + W - 1);
   rc = work();
@@ -98,7 +100,7 @@ template <class F> int continuity_around_pass(mom6hip_ctx_t *ctx, F call) {
   ctx->cont_phase = 1;
   int rc = call();
   ctx->cont_phase = 0;
-  if (rc) return rc;
+  if (rc) { m6::ErrorKeeper keep; m6::complete_group_pass(ctx); return rc; }
   if ((rc = m6::complete_group_pass(ctx))) return rc;
   ctx->cont_phase = 2;
   rc = call();
@@ -398,7 +400,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     m6::row_window(ctx, js + W + 2, je - W - 2);
     int rc = next_CA();
     m6::row_window_reset(ctx);
-    if (rc) return rc;
+    if (rc) { m6::ErrorKeeper keep; m6::complete_group_pass(ctx); return rc; }
     CALL(m6::complete_group_pass(ctx));
     accumulate(js - 2, js + 1, Jsq - 2, Jsq + 1);
     accumulate(je - 1, je + 2, Jeq - 1, Jeq + 2);

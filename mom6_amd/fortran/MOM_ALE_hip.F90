@@ -8,16 +8,29 @@
 !! Everything else the reference offers here (other coordinates, ice shelves, PCM_cell masks, OBC thicknesses, partial-cell
 !! velocity remapping, the KE-conserving velocity correction, the remapping tendency diagnostics) stops with a FATAL error.
 !!
+!! All 28 public names of the reference module (MOM_ALE.F90:129-155) exist here, so that every `use MOM_ALE, only :` of the
+!! reference tree (MOM.F90:53-59, MOM_state_initialization.F90:91-92, MOM_PressureForce_FV.F90:23, MOM_set_viscosity.F90,
+!! MOM_offline_main.F90, MOM_oda_driver.F90) compiles against this file (tests/test_reference_callers.py).  Beside the step's own
+!! entries these are provided for the z* coordinate: ALE_getCoordinate, ALE_getCoordinateUnits, ALE_updateVerticalGridType,
+!! ALE_remap_init_conds, ALE_register_diags (no diagnostics are registered), adjustGridForIntegrity, pre_ALE_adjustments (nothing to
+!! adjust for z*), pre_ALE_diagnostics (none registered), ALE_PLM_edge_values / TS_PLM_edge_values (the library's PLM edge kernel).
+!! The remaining ones (ALE_initRegridding, ALE_initThicknessToCoord, ALE_offline_inputs, ALE_regrid_accelerated, ALE_remap_scalar,
+!! ALE_remap_interface_vals, ALE_remap_vertex_vals, ALE_writeCoordinateFile, TS_PPM_edge_values) have the reference's argument
+!! lists and stop with a FATAL error that names them.
+!!
 !! Compiled INSIDE a MOM6 source tree in place of src/ALE/MOM_ALE.F90; here against tests/fortran/stubs.
 module MOM_ALE
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,    only : mom6hip_shared_context, mom6hip_fatal_if, mom6hip_mirror_require_host_current
+use MOM_diag_mediator,   only : diag_ctrl, time_type
 use MOM_error_handler,   only : MOM_error, FATAL, WARNING
 use MOM_file_parser,     only : get_param, log_version, param_file_type
 use MOM_grid,            only : ocean_grid_type
 use MOM_open_boundary,   only : ocean_OBC_type
+use MOM_regridding,      only : regridding_CS
+use MOM_remapping,       only : remapping_CS
 use MOM_string_functions, only : uppercase
 use MOM_tracer_registry, only : tracer_registry_type
 use MOM_unit_scaling,    only : unit_scale_type
@@ -29,6 +42,11 @@ implicit none ; private
 
 public ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_set_h_vel_via_dz, ALE_remap_velocities
 public ALE_update_regrid_weights, ALE_set_extrap_boundaries
+! the rest of the reference's public list (MOM_ALE.F90:129-155)
+public ALE_getCoordinate, ALE_getCoordinateUnits, ALE_updateVerticalGridType, ALE_remap_init_conds, ALE_register_diags
+public adjustGridForIntegrity, pre_ALE_adjustments, pre_ALE_diagnostics, ALE_PLM_edge_values, TS_PLM_edge_values, TS_PPM_edge_values
+public ALE_initRegridding, ALE_initThicknessToCoord, ALE_offline_inputs, ALE_regrid_accelerated, ALE_remap_scalar
+public ALE_remap_interface_vals, ALE_remap_vertex_vals, ALE_writeCoordinateFile
 
 !> ALE control structure (the members of the reference's ALE_CS :62-123 and of its regridding_CS / remapping_CS that the
 !! provided branches read)
@@ -45,6 +63,8 @@ type :: ALE_CS ; private
   logical :: partial_cell_vel_remap = .false., conserve_ke = .false.
   real    :: BBL_h_vel_mask = 0.0
   integer :: answer_date = 99991231
+  logical :: remap_after_initialization = .true.      !< REMAP_AFTER_INITIALIZATION (:268)
+  real    :: coord_scale = 1.0                         !< US%Z_to_m for z* (MOM_regridding.F90:520)
 end type ALE_CS
 
 contains
@@ -160,6 +180,10 @@ subroutine ALE_init(param_file, GV, US, max_depth, CS)
   CS%remap_scheme = scheme_of(string) ; CS%vel_remap_scheme = scheme_of(vel_string)
   CS%boundary_extrapolation = init_boundary_extrap      ! initialize_remapping(..., boundary_extrapolation=init_boundary_extrap)
 
+  call get_param(param_file, mdl, "REMAP_AFTER_INITIALIZATION", CS%remap_after_initialization, &
+                 "If true, applies regridding and remapping immediately after initialization so that the state is ALE "//&
+                 "consistent.", default=.true.)
+  CS%coord_scale = US%Z_to_m
   call get_param(param_file, mdl, "PARTIAL_CELL_VELOCITY_REMAP", CS%partial_cell_vel_remap, default=.false.)
   if (CS%partial_cell_vel_remap) call MOM_error(FATAL, "ALE_init (HIP): PARTIAL_CELL_VELOCITY_REMAP is not provided by the GPU path.")
   call get_param(param_file, mdl, "REGRID_TIME_SCALE", CS%regrid_time_scale, &
@@ -335,5 +359,268 @@ subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u
                                     c_loc(h_new_v), c_loc(u), c_loc(v), MOM6HIP_MEM_HOST)
   call mom6hip_fatal_if(rc, "ALE_remap_velocities")
 end subroutine ALE_remap_velocities
+
+! ---- the rest of the reference's public list ------------------------------------------------------------------------------------
+
+!> ALE_getCoordinate (:1688): the interfaces of the target coordinate (getCoordinateInterfaces with undo_scaling,
+!! MOM_regridding.F90:2190-2232: z* counts down from zero)
+function ALE_getCoordinate(CS)
+  type(ALE_CS), pointer    :: CS
+  real, dimension(CS%nk+1) :: ALE_getCoordinate
+  integer :: k
+  ALE_getCoordinate(1) = 0.
+  do k=1,CS%nk
+    ALE_getCoordinate(K+1) = ALE_getCoordinate(K) - CS%coord_scale * CS%coordinateResolution(k)
+  enddo
+end function ALE_getCoordinate
+
+!> ALE_getCoordinateUnits (:1700; getCoordinateUnits, MOM_regridding.F90:2236)
+function ALE_getCoordinateUnits(CS)
+  type(ALE_CS), pointer :: CS
+  character(len=20)     :: ALE_getCoordinateUnits
+  ALE_getCoordinateUnits = 'meter'
+end function ALE_getCoordinateUnits
+
+!> ALE_remap_init_conds (:1711)
+logical function ALE_remap_init_conds(CS)
+  type(ALE_CS), pointer :: CS
+  ALE_remap_init_conds = .false.
+  if (associated(CS)) ALE_remap_init_conds = CS%remap_after_initialization
+end function ALE_remap_init_conds
+
+!> ALE_updateVerticalGridType (:1733): the vertical axis of the output files
+subroutine ALE_updateVerticalGridType(CS, GV)
+  type(ALE_CS),            pointer :: CS
+  type(verticalGrid_type), pointer :: GV
+  integer :: nk
+  nk = GV%ke
+  GV%sInterface(1:nk+1) = ALE_getCoordinate(CS)
+  GV%sLayer(1:nk) = 0.5*( GV%sInterface(1:nk) + GV%sInterface(2:nk+1) )
+  GV%zAxisUnits = ALE_getCoordinateUnits(CS)
+  GV%zAxisLongName = 'pseudo-depth, -z*'      ! getCoordinateShortName, MOM_regridding.F90:2266
+  GV%direction = -1
+end subroutine ALE_updateVerticalGridType
+
+!> ALE_register_diags (:344): the remapping-tendency diagnostics are not provided by the GPU path; nothing is registered, so
+!! that none of them is ever requested from ALE_remap_tracers / ALE_remap_velocities
+subroutine ALE_register_diags(Time, G, GV, US, diag, CS)
+  type(time_type),target,     intent(in)  :: Time
+  type(ocean_grid_type),      intent(in)  :: G
+  type(unit_scale_type),      intent(in)  :: US
+  type(verticalGrid_type),    intent(in)  :: GV
+  type(diag_ctrl), target,    intent(in)  :: diag
+  type(ALE_CS), pointer                   :: CS
+end subroutine ALE_register_diags
+
+!> adjustGridForIntegrity (:1666; inflate_vanished_layers_old, MOM_regridding.F90:1781, old_inflate_layers_1d, coord_rho.F90:362):
+!! every layer of a column at least MIN_THICKNESS thick, the excess taken out of the thickest one.  Called once, while the
+!! model is initialised on the host (MOM.F90:3105), like the rest of the reference's initialisation.
+subroutine adjustGridForIntegrity(CS, G, GV, h)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(inout) :: h
+  integer :: i, j, k, nk, k_max, n_thick
+  real :: added, h_max
+  nk = GV%ke
+  do j=G%jsc-1,G%jec+1 ; do i=G%isc-1,G%iec+1
+    n_thick = 0
+    do k=1,nk ; if (h(i,j,k) > CS%min_thickness) n_thick = n_thick + 1 ; enddo
+    if (n_thick == nk) cycle
+    if (n_thick == 0) then
+      do k=1,nk ; h(i,j,k) = CS%min_thickness ; enddo
+      cycle
+    endif
+    added = 0.0
+    do k=1,nk ; if (h(i,j,k) <= CS%min_thickness) then
+      added = added + (CS%min_thickness - h(i,j,k))
+      h(i,j,k) = h(i,j,k) + (CS%min_thickness - h(i,j,k))
+    endif ; enddo
+    h_max = h(i,j,1) ; k_max = 1
+    do k=1,nk ; if (h(i,j,k) > h_max) then ; h_max = h(i,j,k) ; k_max = k ; endif ; enddo
+    h(i,j,k_max) = h(i,j,k_max) - added
+  enddo ; enddo
+end subroutine adjustGridForIntegrity
+
+!> pre_ALE_adjustments (:455): only the HYCOM1 coordinate adjusts anything before regridding (hybgen_unmix); z* does not
+subroutine pre_ALE_adjustments(G, GV, US, h, tv, Reg, CS, u, v)
+  type(ocean_grid_type),                      intent(in)    :: G
+  type(verticalGrid_type),                    intent(in)    :: GV
+  type(unit_scale_type),                      intent(in)    :: US
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(inout) :: h
+  type(thermo_var_ptrs),                      intent(inout) :: tv
+  type(tracer_registry_type),                 pointer       :: Reg
+  type(ALE_CS),                               pointer       :: CS
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), optional, intent(inout) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), optional, intent(inout) :: v
+end subroutine pre_ALE_adjustments
+
+!> pre_ALE_diagnostics (:428): posts diagnostics of the state before ALE; ALE_register_diags registers none
+subroutine pre_ALE_diagnostics(G, GV, US, h, u, v, tv, CS)
+  type(ocean_grid_type),                      intent(in)    :: G
+  type(verticalGrid_type),                    intent(in)    :: GV
+  type(unit_scale_type),                      intent(in)    :: US
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),  intent(inout) :: h
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(inout) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(inout) :: v
+  type(thermo_var_ptrs),                      intent(inout) :: tv
+  type(ALE_CS),                               pointer       :: CS
+end subroutine pre_ALE_diagnostics
+
+!> ALE_PLM_edge_values (:1520): top and bottom edge values of a 3-d scalar by the monotonised PLM reconstruction, on the GPU
+!! (mom6hip_ale_plm_edge_values: the edge values the pressure force uses)
+subroutine ALE_PLM_edge_values(CS, G, GV, h, Q, bdry_extrap, Q_t, Q_b)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in)    :: h
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(in)    :: Q
+  logical,                                   intent(in)    :: bdry_extrap
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(inout) :: Q_t
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), target, intent(inout) :: Q_b
+  integer :: rc
+  if (CS%answer_date < 20190101) call MOM_error(FATAL, "ALE_PLM_edge_values (HIP): REMAPPING_ANSWER_DATE < 20190101 is not provided.")
+  rc = mom6hip_ale_plm_edge_values(mom6hip_shared_context(G, GV), c_loc(h), c_loc(Q), merge(1_c_int32_t, 0_c_int32_t, bdry_extrap), &
+                                   c_loc(Q_t), c_loc(Q_b), MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "ALE_PLM_edge_values")
+end subroutine ALE_PLM_edge_values
+
+!> TS_PLM_edge_values (:1495)
+subroutine TS_PLM_edge_values(CS, S_t, S_b, T_t, T_b, G, GV, tv, h, bdry_extrap)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(ALE_CS),            intent(inout) :: CS
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(inout) :: S_t, S_b, T_t, T_b
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h
+  logical,                 intent(in)    :: bdry_extrap
+  call ALE_PLM_edge_values(CS, G, GV, h, tv%S, bdry_extrap, S_t, S_b)
+  call ALE_PLM_edge_values(CS, G, GV, h, tv%T, bdry_extrap, T_t, T_b)
+end subroutine TS_PLM_edge_values
+
+subroutine not_provided(name)
+  character(len=*), intent(in) :: name
+  call MOM_error(FATAL, trim(name)//" (HIP): this entry of MOM_ALE is not provided by the GPU path (z* regridding and remapping "// &
+                        "inside the time step are; see mom6_amd/fortran/MOM_ALE_hip.F90).")
+end subroutine not_provided
+
+!> TS_PPM_edge_values (:1582; PRESSURE_RECONSTRUCTION_SCHEME = 2, which PressureForce_FV_init of the shim refuses)
+subroutine TS_PPM_edge_values(CS, S_t, S_b, T_t, T_b, G, GV, tv, h, bdry_extrap)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(ALE_CS),            intent(inout) :: CS
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(inout) :: S_t, S_b, T_t, T_b
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h
+  logical,                 intent(in)    :: bdry_extrap
+  call not_provided("TS_PPM_edge_values")
+end subroutine TS_PPM_edge_values
+
+!> ALE_initRegridding (:1743)
+subroutine ALE_initRegridding(GV, US, max_depth, param_file, mdl, regridCS)
+  type(verticalGrid_type), intent(in)  :: GV
+  type(unit_scale_type),   intent(in)  :: US
+  real,                    intent(in)  :: max_depth
+  type(param_file_type),   intent(in)  :: param_file
+  character(len=*),        intent(in)  :: mdl
+  type(regridding_CS),     intent(out) :: regridCS
+  call not_provided("ALE_initRegridding")
+end subroutine ALE_initRegridding
+
+!> ALE_initThicknessToCoord (:1788)
+subroutine ALE_initThicknessToCoord(CS, G, GV, h, height_units)
+  type(ALE_CS), intent(inout)                            :: CS
+  type(ocean_grid_type), intent(in)                      :: G
+  type(verticalGrid_type), intent(in)                    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(out) :: h
+  logical,                          optional, intent(in) :: height_units
+  call not_provided("ALE_initThicknessToCoord")
+end subroutine ALE_initThicknessToCoord
+
+!> ALE_offline_inputs (:548; offline tracer transport)
+subroutine ALE_offline_inputs(CS, G, GV, US, h, tv, Reg, uhtr, vhtr, Kd, debug, OBC)
+  type(ALE_CS),                                 pointer       :: CS
+  type(ocean_grid_type),                        intent(in   ) :: G
+  type(verticalGrid_type),                      intent(in   ) :: GV
+  type(unit_scale_type),                        intent(in   ) :: US
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),    intent(inout) :: h
+  type(thermo_var_ptrs),                        intent(inout) :: tv
+  type(tracer_registry_type),                   pointer       :: Reg
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)),   intent(inout) :: uhtr
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)),   intent(inout) :: vhtr
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)+1),  intent(inout) :: Kd
+  logical,                                      intent(in   ) :: debug
+  type(ocean_OBC_type),                         pointer       :: OBC
+  call not_provided("ALE_offline_inputs")
+end subroutine ALE_offline_inputs
+
+!> ALE_regrid_accelerated (:609; iterated regridding of the initial state)
+subroutine ALE_regrid_accelerated(CS, G, GV, US, h, tv, n_itt, u, v, OBC, Reg, dt, dzRegrid, initial)
+  type(ALE_CS),            pointer       :: CS
+  type(ocean_grid_type),   intent(inout) :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(inout) :: h
+  type(thermo_var_ptrs),   intent(inout) :: tv
+  integer,                 intent(in)    :: n_itt
+  real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(inout) :: u
+  real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(inout) :: v
+  type(ocean_OBC_type),    pointer       :: OBC
+  type(tracer_registry_type), optional, pointer :: Reg
+  real,                    optional, intent(in)    :: dt
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)+1), optional, intent(inout) :: dzRegrid
+  logical,                 optional, intent(in)    :: initial
+  call not_provided("ALE_regrid_accelerated")
+end subroutine ALE_regrid_accelerated
+
+!> ALE_remap_scalar (:1377; remapping of initial conditions from a file's grid)
+subroutine ALE_remap_scalar(CS, G, GV, nk_src, h_src, s_src, h_dst, s_dst, all_cells, old_remap, &
+                            answers_2018, answer_date, h_neglect, h_neglect_edge)
+  type(remapping_CS),                      intent(in)    :: CS
+  type(ocean_grid_type),                   intent(in)    :: G
+  type(verticalGrid_type),                 intent(in)    :: GV
+  integer,                                 intent(in)    :: nk_src
+  real, dimension(SZI_(G),SZJ_(G),nk_src), intent(in)    :: h_src
+  real, dimension(SZI_(G),SZJ_(G),nk_src), intent(in)    :: s_src
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),intent(in)   :: h_dst
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)),intent(inout) :: s_dst
+  logical, optional,                       intent(in)    :: all_cells
+  logical, optional,                       intent(in)    :: old_remap
+  logical,                       optional, intent(in)    :: answers_2018
+  integer,                       optional, intent(in)    :: answer_date
+  real,                          optional, intent(in)    :: h_neglect
+  real,                          optional, intent(in)    :: h_neglect_edge
+  call not_provided("ALE_remap_scalar")
+end subroutine ALE_remap_scalar
+
+!> ALE_remap_interface_vals (:1274; used by remap_vertvisc_aux_vars, REMAP_AUXILIARY_VARS)
+subroutine ALE_remap_interface_vals(CS, G, GV, h_old, h_new, int_val)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h_old
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h_new
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)+1), intent(inout) :: int_val
+  call not_provided("ALE_remap_interface_vals")
+end subroutine ALE_remap_interface_vals
+
+!> ALE_remap_vertex_vals (:1316; REMAP_AUXILIARY_VARS)
+subroutine ALE_remap_vertex_vals(CS, G, GV, h_old, h_new, vert_val)
+  type(ALE_CS),                              intent(in)    :: CS
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h_old
+  real, dimension(SZI_(G),SZJ_(G),SZK_(GV)), intent(in)    :: h_new
+  real, dimension(SZIB_(G),SZJB_(G),SZK_(GV)+1), intent(inout) :: vert_val
+  call not_provided("ALE_remap_vertex_vals")
+end subroutine ALE_remap_vertex_vals
+
+!> ALE_writeCoordinateFile (:1760; writes Vertical_coordinate.nc through MOM_io)
+subroutine ALE_writeCoordinateFile(CS, GV, directory)
+  type(ALE_CS),            pointer     :: CS
+  type(verticalGrid_type), intent(in)  :: GV
+  character(len=*),        intent(in)  :: directory
+  call MOM_error(WARNING, "ALE_writeCoordinateFile (HIP): Vertical_coordinate.nc is not written by the GPU path.")
+end subroutine ALE_writeCoordinateFile
 
 end module MOM_ALE

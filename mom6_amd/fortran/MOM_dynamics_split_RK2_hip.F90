@@ -37,13 +37,14 @@ use MOM_forcing_type,          only : mech_forcing
 use MOM_diag_mediator,         only : diag_ctrl
 use MOM_error_handler,         only : MOM_error, FATAL, WARNING
 use MOM_file_parser,           only : get_param, log_version, param_file_type
-use MOM_io,                    only : directories
+use MOM_get_input,             only : directories
 use MOM_restart,               only : register_restart_field, query_initialized, MOM_restart_CS
 use MOM_time_manager,          only : time_type
 use MOM_ALE,                   only : ALE_CS
 use MOM_barotropic,            only : barotropic_init, register_barotropic_restarts, barotropic_CS, barotropic_end
 use MOM_barotropic,            only : barotropic_hip_struct, barotropic_hip_update
 use MOM_boundary_update,       only : update_OBC_CS
+use MOM_diabatic_driver,        only : diabatic_CS
 use MOM_continuity_PPM,        only : continuity_PPM_CS, continuity_PPM_init, continuity_PPM_stencil, continuity_PPM_hip_struct
 use MOM_CoriolisAdv,           only : CoriolisAdv_CS, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_hip_struct
 use MOM_grid,                  only : ocean_grid_type
@@ -66,7 +67,7 @@ implicit none ; private
 #include <MOM_memory.h>
 
 public step_MOM_dyn_split_RK2, register_restarts_dyn_split_RK2, initialize_dyn_split_RK2
-public remap_dyn_split_RK2_aux_vars, end_dyn_split_RK2
+public remap_dyn_split_RK2_aux_vars, end_dyn_split_RK2, init_dyn_split_RK2_diabatic
 public dyn_split_RK2_sync_to_host, dyn_split_RK2_host_was_modified      ! the two calls of GPU_RESIDENT_DYNAMICS = True
 
 !> MOM_dynamics_split_RK2 module control structure (the reference's :84-268: what outlives a call)
@@ -225,7 +226,7 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
   type(MEKE_type), target,           intent(inout) :: MEKE
   type(thickness_diffuse_CS),        intent(inout) :: thickness_diffuse_CSp
   type(porous_barrier_type),         intent(in)    :: pbv
-  type(stochastic_CS), optional,     intent(inout) :: STOCH
+  type(stochastic_CS),               intent(inout) :: STOCH      ! not optional in the reference either (:331; MOM.F90:1242-1245)
   type(wave_parameters_CS), optional, pointer      :: Waves
 
   type(c_ptr) :: d_u, d_v, d_h, d_T, d_S, d_uh, d_vh, d_uhtr, d_vhtr, d_eta_av, d_tx, d_ty
@@ -234,14 +235,24 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
 
   if (.not.associated(CS)) call MOM_error(FATAL, "step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
   if (.not.CS%module_is_initialized) call MOM_error(FATAL, "step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
-  if (associated(p_surf_begin) .or. associated(p_surf_end)) call refuse("a surface pressure (p_surf_begin / p_surf_end)")
-  if (present(Waves)) then ; if (associated(Waves)) call refuse("surface waves (Waves)") ; endif
+  ! The reference (:435-442) takes p_surf_end when both pointers are associated (and interpolates eta_PF between the two), else
+  ! forces%p_surf, and hands it to PressureForce as p_atm.  MOM.F90:772 points p_surf_end at forces%p_surf, which the solo driver
+  ! allocates and leaves at zero (MOM_surface_forcing.F90:260): a pressure that is zero everywhere changes no bit of the step
+  ! (x + 0.0 = x, and eta_PF_start = eta_PF - 0.0) and is accepted; a non-zero one is not provided.
+  if (associated(p_surf_begin)) then ; if (any(p_surf_begin(:,:) /= 0.0)) call refuse("a non-zero surface pressure (p_surf_begin)") ; endif
+  if (associated(p_surf_end)) then ; if (any(p_surf_end(:,:) /= 0.0)) call refuse("a non-zero surface pressure (p_surf_end)") ; endif
+  if (associated(forces%p_surf)) then ; if (any(forces%p_surf(:,:) /= 0.0)) call refuse("a non-zero surface pressure (forces%p_surf)") ; endif
+  ! Waves: the Stokes pressure force (Waves%Stokes_PGF, :505-520) and the Stokes terms of CorAdCalc / vertFPmix
+  if (present(Waves)) then ; if (associated(Waves)) then
+    if (Waves%Stokes_PGF .or. Waves%Stokes_VF) call refuse("surface waves (Waves%Stokes_PGF / Waves%Stokes_VF)")
+  endif ; endif
   if (allocated(pbv%por_face_areaU)) then
     if (any(pbv%por_face_areaU /= 1.0) .or. any(pbv%por_face_areaV /= 1.0)) call refuse("porous barriers")
   endif
   ! VarMix: the resolution function scales the Laplacian viscosity only (MOM_hor_visc.F90:474-476, :1123, :1525)
   if (VarMix%use_variable_mixing .and. VarMix%Resoln_scaled_Kh .and. (CS%c_hv%Laplacian /= 0)) call refuse("RESOLN_SCALED_KH with LAPLACIAN")
-  if (present(STOCH)) call refuse("stochastic parameterizations (STOCH)")
+  ! STOCH reaches horizontal_viscosity only (:863), which reads it for the SKEB amplitude (MOM_hor_visc.F90: STOCH%skeb_use_frict)
+  if (STOCH%do_skeb .and. STOCH%skeb_use_frict) call refuse("the stochastic kinetic-energy backscatter (DO_SKEB with SKEB_USE_FRICT)")
   if (.not.(associated(forces%taux) .and. associated(forces%tauy))) call MOM_error(FATAL, "step_MOM_dyn_split_RK2 (HIP): "// &
       "forces%taux and forces%tauy must be associated.")
   if (CS%use_EOS .and. .not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, "step_MOM_dyn_split_RK2 (HIP): "// &
@@ -608,6 +619,15 @@ subroutine bind_structs(CS)
   CS%c_rk2%vertvisc_CSp = c_loc(CS%c_vv) ; CS%c_rk2%visc = c_loc(CS%c_visc) ; CS%c_rk2%hor_visc = c_loc(CS%c_hv)
   CS%c_rk2%set_visc_CSp = c_null_ptr ; if (CS%c_sv%dynamic_viscous_ML /= 0) CS%c_rk2%set_visc_CSp = c_loc(CS%c_sv)
 end subroutine bind_structs
+
+!> Same interface as the reference init_dyn_split_RK2_diabatic (:1306).  MOM.F90:3350-3352 calls it only with FPMIX = True (the
+!! boundary-layer depths of KPP / ePBL for vertFPmix), which initialize_dyn_split_RK2 of this file has already refused by name.
+subroutine init_dyn_split_RK2_diabatic(diabatic_CSp, CS)
+  type(diabatic_CS),                intent(in) :: diabatic_CSp
+  type(MOM_dyn_split_RK2_CS),       pointer    :: CS
+  call MOM_error(FATAL, "init_dyn_split_RK2_diabatic (HIP): FPMIX (the non-local momentum mixing of vertFPmix with the boundary-layer "// &
+                        "depths of KPP or ePBL) is not provided by the GPU path.")
+end subroutine init_dyn_split_RK2_diabatic
 
 !> Same interface as the reference end_dyn_split_RK2 (:1829)
 subroutine end_dyn_split_RK2(CS)

@@ -35,6 +35,7 @@ implicit none ; private
 public mixedlayer_restrat
 public mixedlayer_restrat_init
 public mixedlayer_restrat_register_restarts
+public mixedlayer_restrat_unit_tests
 
 !> Control structure (the members of the reference's mixedlayer_restrat_CS, :40-126, that the provided branches read)
 type, public :: mixedlayer_restrat_CS ; private
@@ -250,5 +251,31 @@ subroutine mixedlayer_restrat_register_restarts(HI, GV, US, param_file, CS, rest
                                 longname="Slower time-filtered MLD for use in MLE", units="m")
   endif
 end subroutine mixedlayer_restrat_register_restarts
+
+!> Same interface as the reference mixedlayer_restrat_unit_tests (:1846; imported by MOM_unit_tests.F90 and the unit-test driver):
+!! the ten known answers of the shape function mu(sigma, dh) (:1855-1874), evaluated by the library's kernel on the GPU
+!! (mom6hip_mixedlayer_restrat_mu).  The four answers of rmean2ts (:1878-1885) belong to the Bodner et al. (2023) form, which this
+!! shim refuses (MLE%USE_BODNER23), and are not evaluated.  Returns true if a test fails.
+logical function mixedlayer_restrat_unit_tests(verbose)
+  logical, intent(in) :: verbose
+  real, parameter :: sig(10)  = (/ 3., 0., -0.25, -0.5, -0.75, -1., -3., -0.5, -1., -1.5 /)
+  real, parameter :: dh(10)   = (/ 0., 0., 0., 0., 0., 0., 0., 0.5, 0.5, 0.5 /)
+  real, parameter :: want(10) = (/ 0., 0., 0.7946428571428572, 1., 0.7946428571428572, 0., 0., 1., 0.25, 0. /)
+  real :: got, tol
+  integer :: n
+  print *,'===== mixedlayer_restrat: mixedlayer_restrat_unit_tests =================='
+  mixedlayer_restrat_unit_tests = .false.
+  do n=1,10
+    got = mom6hip_mixedlayer_restrat_mu(real(sig(n), c_double), real(dh(n), c_double))
+    tol = 0. ; if (n == 3 .or. n == 5) tol = epsilon(1.)
+    if (abs(got - want(n)) > tol) then
+      mixedlayer_restrat_unit_tests = .true.
+      write(0,'(a,2f8.3,a,es23.15,a,es23.15)') "mixedlayer_restrat_unit_tests: mu(", sig(n), dh(n), ") = ", got, " but expected ", want(n)
+    elseif (verbose) then
+      write(*,'(a,2f8.3,a,es23.15)') "  mu(", sig(n), dh(n), ") = ", got
+    endif
+  enddo
+  if (.not. mixedlayer_restrat_unit_tests) print '(a)','  Passed tests of mu(z)'
+end function mixedlayer_restrat_unit_tests
 
 end module MOM_mixed_layer_restrat

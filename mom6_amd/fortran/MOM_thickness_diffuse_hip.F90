@@ -15,7 +15,7 @@ module MOM_thickness_diffuse
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_read_eos, mom6hip_fatal_if
-use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
+use mom6hip_MOM_glue,          only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirror_forget
 use MOM_diag_mediator,         only : diag_ctrl, time_type
 use MOM_error_handler,         only : MOM_error, FATAL
 use MOM_file_parser,           only : get_param, log_version, param_file_type
@@ -232,8 +232,9 @@ end subroutine thickness_diffuse_get_KH
 subroutine thickness_diffuse_end(CS, CDp)
   type(thickness_diffuse_CS), intent(inout) :: CS
   type(cont_diag_ptrs),       intent(inout) :: CDp
-  if (associated(CDp%uhGM)) deallocate(CDp%uhGM)
-  if (associated(CDp%vhGM)) deallocate(CDp%vhGM)
+  ! (the mirrors of arrays that go away are dropped, so that nothing allocated at their addresses later inherits a device copy)
+  if (associated(CDp%uhGM)) then ; call mom6hip_mirror_forget(c_loc(CDp%uhGM)) ; deallocate(CDp%uhGM) ; endif
+  if (associated(CDp%vhGM)) then ; call mom6hip_mirror_forget(c_loc(CDp%vhGM)) ; deallocate(CDp%vhGM) ; endif
   CS%initialized = .false.
 end subroutine thickness_diffuse_end
 

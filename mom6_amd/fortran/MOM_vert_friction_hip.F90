@@ -18,7 +18,7 @@ use MOM_error_handler,         only : MOM_error, FATAL, WARNING
 use MOM_file_parser,           only : get_param, log_version, param_file_type
 use MOM_forcing_type,          only : mech_forcing
 use MOM_grid,                  only : ocean_grid_type
-use MOM_io,                    only : directories
+use MOM_get_input,             only : directories
 use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_open_boundary,         only : ocean_OBC_type
 use MOM_unit_scaling,          only : unit_scale_type

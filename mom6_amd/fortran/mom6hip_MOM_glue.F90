@@ -29,7 +29,7 @@ public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6h
 ! the device mirrors of the host's arrays, shared by every module shim (GPU_RESIDENT_DYNAMICS)
 public :: mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirrors_stage, mom6hip_mirrors_to_host
 public :: mom6hip_mirrors_host_was_modified, mom6hip_mirror_host_changed, mom6hip_mirror_zeroed, mom6hip_mirrors_end
-public :: mom6hip_mirror_pass_var, mom6hip_mirror_require_host_current
+public :: mom6hip_mirror_pass_var, mom6hip_mirror_require_host_current, mom6hip_mirror_forget
 
 integer, parameter :: MAX_MIRRORS = 160
 !> A host array of the caller and its copy in HBM
@@ -215,9 +215,38 @@ end subroutine mom6hip_mirror_require_host_current
 
 !> The host has changed fields after such a call (ALE remapping ...): mom6hip_mirrors_host_was_modified / mom6hip_mirror_host_changed.
 
-!> Free the mirrors (the last *_end of the run)
+!> The host array at hp is about to go away (deallocate, the end of a *_end routine): drop its mirror, so that whatever the host
+!! allocates at that address next is not taken for it.  A device copy newer than the host's is copied back first -- the host array
+!! still exists at this point -- rather than thrown away.  Only PERSISTENT host arrays may be mirrored (module or control-structure
+!! members, the model's state): a mirror of an automatic or temporary array outlives it, and the next array at that address with
+!! the same size would inherit its device copy (INTEGRATION.md section 2c).
+subroutine mom6hip_mirror_forget(hp)
+  type(c_ptr), intent(in) :: hp
+  type(c_ptr) :: ctx
+  integer :: m, q, rc
+  ctx = ctx_shared
+  q = 0
+  do m = 1, nmir ; if (c_associated(mir(m)%h, hp)) then ; q = m ; exit ; endif ; enddo
+  if (q == 0) return
+  if (.not.mir(q)%host_current) then
+    if (.not.c_associated(ctx)) call MOM_error(FATAL, "mom6hip_mirror_forget: a device copy is newer than the host's, and the context has ended.")
+    rc = mom6hip_sync_to_host(ctx, hp, mir(q)%d, mir(q)%bytes) ; call mom6hip_fatal_if(rc, "mom6hip_mirror_forget")
+  endif
+  rc = mom6hip_free(mir(q)%d) ; call mom6hip_fatal_if(rc, "mom6hip_mirror_forget")
+  if (q < nmir) mir(q) = mir(nmir)
+  mir(nmir)%h = c_null_ptr ; mir(nmir)%d = c_null_ptr
+  nmir = nmir - 1
+end subroutine mom6hip_mirror_forget
+
+!> Free the mirrors (the last *_end of the run).  A device copy that is newer than the host's is an error of the calling sequence
+!! (dyn_split_RK2_sync_to_host / mom6hip_mirrors_to_host was not called before the end): stop, as mom6hip_mirrors_host_was_modified
+!! does, instead of discarding the newer values.
 subroutine mom6hip_mirrors_end()
   integer :: m, rc
+  do m = 1, nmir
+    if (.not.mir(m)%host_current) call MOM_error(FATAL, "mom6hip_mirrors_end: the device holds newer values of a field than the "// &
+        "host; call mom6hip_mirrors_to_host (dyn_split_RK2_sync_to_host) before the model ends.")
+  enddo
   do m = 1, nmir ; rc = mom6hip_free(mir(m)%d) ; mir(m)%h = c_null_ptr ; mir(m)%d = c_null_ptr ; enddo
   nmir = 0
 end subroutine mom6hip_mirrors_end

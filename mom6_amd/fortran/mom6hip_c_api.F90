@@ -435,6 +435,14 @@ interface
     integer(c_int) :: rc
   end function mom6hip_ale_remap_set_h_vel_via_dz
 
+  !> ALE_PLM_edge_values (MOM_ALE.F90:1520)
+  function mom6hip_ale_plm_edge_values(ctx, h, Q, bdry_extrap, Q_t, Q_b, memspace) bind(c, name="mom6hip_ale_plm_edge_values") result(rc)
+    import :: c_int, c_int32_t, c_ptr
+    type(c_ptr), value :: ctx, h, Q, Q_t, Q_b
+    integer(c_int32_t), value :: bdry_extrap, memspace
+    integer(c_int) :: rc
+  end function mom6hip_ale_plm_edge_values
+
   function mom6hip_ale_remap_velocities(ctx, cs, h_old_u, h_old_v, h_new_u, h_new_v, u, v, memspace) &
                                         bind(c, name="mom6hip_ale_remap_velocities") result(rc)
     import :: c_int, c_int32_t, c_ptr, mom6hip_remapping_cs_t

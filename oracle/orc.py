@@ -359,6 +359,16 @@ def pressureforce(grid, cs, E, h, T, S, p_atm=None, want_pbce=True, want_eta=Tru
     return PFu, PFv, pbce, eta
 
 
+def ale_plm_edge_values(grid, h, Q, bdry_extrap=False):
+    """ALE_PLM_edge_values (MOM_ALE.F90:1520): (Q_t, Q_b) on the columns isc-1..iec+1 x jsc-1..jec+1"""
+    L = lib()
+    L.orc_ale_plm_edge_values.argtypes = [C.POINTER(_abi.GridStruct), _dp, _dp, C.c_int, _dp, _dp]
+    L.orc_ale_plm_edge_values.restype = None
+    Qt, Qb = grid.zeros3(_abi.POS_H), grid.zeros3(_abi.POS_H)
+    L.orc_ale_plm_edge_values(C.byref(grid.struct()), _p(h), _p(Q), 1 if bdry_extrap else 0, _p(Qt), _p(Qb))
+    return Qt, Qb
+
+
 def pressureforce_nonbouss(grid, cs, E, h, T, S, p_atm=None, H_to_RZ=1.0, want_pbce=True, want_eta=True):
     """PressureForce_FV_nonBouss (h in kg m-2 when H_to_RZ = 1)"""
     L = lib()

@@ -14,12 +14,14 @@ use MOM_ALE,           only : ALE_CS
 use MOM_boundary_update, only : update_OBC_CS
 use MOM_diag_mediator, only : diag_ctrl
 use MOM_time_manager,  only : time_type
+use MOM_wave_interface, only : wave_parameters_CS
+use MOM_stochastics,   only : stochastic_CS
 use MOM_EOS,           only : EOS_type
 use MOM_file_parser,   only : param_file_type, param_set, get_param
 use MOM_forcing_type,  only : mech_forcing
 use MOM_grid,          only : ocean_grid_type
 use MOM_hor_index,     only : hor_index_type
-use MOM_io,            only : directories
+use MOM_get_input,     only : directories
 use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_MEKE_types,    only : MEKE_type
 use MOM_open_boundary, only : ocean_OBC_type
@@ -60,6 +62,8 @@ type(ocean_OBC_type), pointer :: OBC => NULL()
 type(update_OBC_CS), pointer :: update_OBC_CSp => NULL()
 type(ALE_CS), pointer :: ALE_CSp => NULL()
 real, dimension(:,:), pointer :: p_surf_begin => NULL(), p_surf_end => NULL()
+type(wave_parameters_CS), pointer :: Waves => NULL()
+type(stochastic_CS) :: STOCH
 integer(c_int32_t) :: hdr(8), hdr2(8)
 integer(c_int64_t) :: xfer(4)
 integer, target :: ntrunc
@@ -107,6 +111,8 @@ allocate(u(isd-1:ied,jsd:jed,nk), v(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk)
          forces%taux(isd-1:ied,jsd:jed), forces%tauy(isd:ied,jsd-1:jed), forces%ustar(isd:ied,jsd:jed))
 allocate(GV%Rlay(nk), GV%g_prime(nk+1))
 read(u_in) u, v, h, tv%T, tv%S, forces%taux, forces%tauy, forces%ustar, GV%Rlay, GV%g_prime
+! the solo driver allocates forces%p_surf and leaves it at zero (MOM_surface_forcing.F90:260); MOM.F90:772 points p_surf_end at it
+allocate(forces%p_surf(isd:ied,jsd:jed), source=0.0) ; p_surf_end => forces%p_surf
 if (hdr2(3) /= 0) allocate(tv%eqn_of_state)      ! an equation of state is in use
 if (hdr2(4) /= 0) allocate(ALE_CSp)              ! USE_REGRIDDING
 allocate(uh(isd-1:ied,jsd:jed,nk), vh(isd:ied,jsd-1:jed,nk), uhtr(isd-1:ied,jsd:jed,nk), vhtr(isd:ied,jsd-1:jed,nk), &
@@ -160,7 +166,7 @@ do n = 1, nsteps
   endif
   calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. calc_dtbt_init)
   call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, &
-                              calc_dtbt, VarMix, MEKE, TD, pbv)
+                              calc_dtbt, VarMix, MEKE, TD, pbv, STOCH, Waves)      ! as MOM.F90:1242-1245 calls it
 enddo
 call dyn_split_RK2_sync_to_host(CS)
 rc = mom6hip_transfer_stats(mom6hip_shared_context(G, GV), xfer, 0_c_int32_t)

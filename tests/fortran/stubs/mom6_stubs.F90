@@ -1,13 +1,34 @@
 !> TYPE-ONLY stand-ins for the MOM6 framework modules the shims of mom6_amd/fortran `use`, so that this repository can
 !! compile and drive the shims on one PE without a MOM6 source tree.  They carry only the members and procedures the
-!! shims touch, do no model work, pin nothing about the reference and are never used as an oracle.  Inside a MOM6 tree
-!! the real modules take their place.
+!! shims touch -- and, since round 4, the members, constants and procedure interfaces (names, dummy names, optional arguments)
+!! that the reference's own callers of the shims touch, so that /root/reference/src/core/MOM_dynamics_split_RK2.F90,
+!! MOM_continuity.F90 and MOM_PressureForce.F90 compile UNMODIFIED, where they lie, against the shims' .mod files
+!! (tests/test_reference_callers.py).  They do no model work, pin nothing about the reference and are never used as an
+!! oracle.  Inside a MOM6 tree the real modules take their place.
 
 module MOM_error_handler
 implicit none ; private
 public :: MOM_error, MOM_mesg, FATAL, WARNING, NOTE, is_root_pe
+public :: MOM_set_verbosity, callTree_showQuery, callTree_enter, callTree_leave, callTree_waypoint
 integer, parameter :: NOTE = 0, WARNING = 1, FATAL = 2
 contains
+subroutine MOM_set_verbosity(verb)
+  integer, intent(in) :: verb
+end subroutine MOM_set_verbosity
+logical function callTree_showQuery()
+  callTree_showQuery = .false.
+end function callTree_showQuery
+subroutine callTree_enter(mesg, n)
+  character(len=*),  intent(in) :: mesg
+  integer, optional, intent(in) :: n
+end subroutine callTree_enter
+subroutine callTree_leave(mesg)
+  character(len=*),  intent(in) :: mesg
+end subroutine callTree_leave
+subroutine callTree_waypoint(mesg, n)
+  character(len=*),  intent(in) :: mesg
+  integer, optional, intent(in) :: n
+end subroutine callTree_waypoint
 subroutine MOM_error(level, message, all_print)
   integer,           intent(in) :: level
   character(len=*),  intent(in) :: message
@@ -77,10 +98,15 @@ end module MOM_coms
 module MOM_domains
 implicit none ; private
 public :: MOM_domain_type, pass_var, pass_vector, CENTER, EAST_FACE, NORTH_FACE, CORNER, group_pass_type
+public :: To_East, To_West, To_North, To_South, To_All, Omit_Corners, AGRID, BGRID_NE, CGRID_NE, SCALAR_PAIR
+public :: create_group_pass, do_group_pass, start_group_pass, complete_group_pass
 integer, parameter :: CENTER = 0, EAST_FACE = 1, NORTH_FACE = 2, CORNER = 3
+integer, parameter :: To_East = 1, To_West = 2, To_North = 4, To_South = 8, To_All = 15, Omit_Corners = 16
+integer, parameter :: AGRID = 0, BGRID_NE = 1, CGRID_NE = 2, SCALAR_PAIR = 32
 type :: MOM_domain_type
   logical :: reentrant(2) = .false.   !< this stand-in's one-PE topology: its pass_var wraps re-entrant directions
   integer :: nihalo = 0, njhalo = 0, niglobal = 0, njglobal = 0
+  logical :: symmetric = .true.
 end type MOM_domain_type
 type :: group_pass_type
   integer :: unused = 0
@@ -88,20 +114,66 @@ end type group_pass_type
 interface pass_var
   module procedure pass_var_3d, pass_var_2d
 end interface
+interface pass_vector
+  module procedure pass_vector_3d, pass_vector_2d
+end interface
+interface create_group_pass
+  module procedure create_var_group_pass_2d, create_var_group_pass_3d, create_vector_group_pass_2d, create_vector_group_pass_3d
+end interface create_group_pass
 contains
-!> One PE: wrap the re-entrant directions (whole allocation with the halo; position gives the staggering)
-subroutine pass_var_3d(array, MOM_dom, sideflag, complete, position, halo)
+! The group passes of the stand-in remember nothing: the reference's callers are compiled against these interfaces, never run.
+subroutine create_var_group_pass_2d(group, array, MOM_dom, sideflag, position, halo, clock)
+  type(group_pass_type),  intent(inout) :: group
+  real, dimension(:,:),   intent(inout) :: array
+  type(MOM_domain_type),  intent(inout) :: MOM_dom
+  integer,      optional, intent(in)    :: sideflag, position, halo, clock
+end subroutine create_var_group_pass_2d
+subroutine create_var_group_pass_3d(group, array, MOM_dom, sideflag, position, halo, clock)
+  type(group_pass_type),  intent(inout) :: group
   real, dimension(:,:,:), intent(inout) :: array
   type(MOM_domain_type),  intent(inout) :: MOM_dom
-  integer, optional,      intent(in)    :: sideflag, position, halo
+  integer,      optional, intent(in)    :: sideflag, position, halo, clock
+end subroutine create_var_group_pass_3d
+subroutine create_vector_group_pass_2d(group, u_cmpt, v_cmpt, MOM_dom, direction, stagger, halo, clock)
+  type(group_pass_type),  intent(inout) :: group
+  real, dimension(:,:),   intent(inout) :: u_cmpt, v_cmpt
+  type(MOM_domain_type),  intent(inout) :: MOM_dom
+  integer,      optional, intent(in)    :: direction, stagger, halo, clock
+end subroutine create_vector_group_pass_2d
+subroutine create_vector_group_pass_3d(group, u_cmpt, v_cmpt, MOM_dom, direction, stagger, halo, clock)
+  type(group_pass_type),  intent(inout) :: group
+  real, dimension(:,:,:), intent(inout) :: u_cmpt, v_cmpt
+  type(MOM_domain_type),  intent(inout) :: MOM_dom
+  integer,      optional, intent(in)    :: direction, stagger, halo, clock
+end subroutine create_vector_group_pass_3d
+subroutine do_group_pass(group, MOM_dom, clock)
+  type(group_pass_type), intent(inout) :: group
+  type(MOM_domain_type), intent(inout) :: MOM_dom
+  integer,     optional, intent(in)    :: clock
+end subroutine do_group_pass
+subroutine start_group_pass(group, MOM_dom, clock)
+  type(group_pass_type), intent(inout) :: group
+  type(MOM_domain_type), intent(inout) :: MOM_dom
+  integer,     optional, intent(in)    :: clock
+end subroutine start_group_pass
+subroutine complete_group_pass(group, MOM_dom, clock)
+  type(group_pass_type), intent(inout) :: group
+  type(MOM_domain_type), intent(inout) :: MOM_dom
+  integer,     optional, intent(in)    :: clock
+end subroutine complete_group_pass
+!> One PE: wrap the re-entrant directions (whole allocation with the halo; position gives the staggering)
+subroutine pass_var_3d(array, MOM_dom, sideflag, complete, position, halo, clock)
+  real, dimension(:,:,:), intent(inout) :: array
+  type(MOM_domain_type),  intent(inout) :: MOM_dom
+  integer, optional,      intent(in)    :: sideflag, position, halo, clock
   logical, optional,      intent(in)    :: complete
   integer :: k
   do k = 1, size(array, 3) ; call pass_var_2d(array(:,:,k), MOM_dom, position=position) ; enddo
 end subroutine pass_var_3d
-subroutine pass_var_2d(array, MOM_dom, sideflag, complete, position, halo)
+subroutine pass_var_2d(array, MOM_dom, sideflag, complete, position, halo, inner_halo, clock)
   real, dimension(:,:),  intent(inout) :: array
   type(MOM_domain_type), intent(inout) :: MOM_dom
-  integer, optional,     intent(in)    :: sideflag, position, halo
+  integer, optional,     intent(in)    :: sideflag, position, halo, inner_halo, clock
   logical, optional,     intent(in)    :: complete
   integer :: pos, hx, hy, ni, nj, xs, ys, i, j
   pos = CENTER ; if (present(position)) pos = position
@@ -120,18 +192,37 @@ subroutine pass_var_2d(array, MOM_dom, sideflag, complete, position, halo)
     do j = hy + ys + nj + 1, size(array, 2) ; array(:, j) = array(:, j - nj) ; enddo
   endif
 end subroutine pass_var_2d
-subroutine pass_vector(u_cmpt, v_cmpt, MOM_dom, direction, stagger, complete, halo)
+subroutine pass_vector_3d(u_cmpt, v_cmpt, MOM_dom, direction, stagger, complete, halo, clock)
   real, dimension(:,:,:), intent(inout) :: u_cmpt, v_cmpt
   type(MOM_domain_type),  intent(inout) :: MOM_dom
-  integer, optional,      intent(in)    :: direction, stagger, halo
+  integer, optional,      intent(in)    :: direction, stagger, halo, clock
   logical, optional,      intent(in)    :: complete
   call pass_var_3d(u_cmpt, MOM_dom, position=EAST_FACE)
   call pass_var_3d(v_cmpt, MOM_dom, position=NORTH_FACE)
-end subroutine pass_vector
+end subroutine pass_vector_3d
+subroutine pass_vector_2d(u_cmpt, v_cmpt, MOM_dom, direction, stagger, complete, halo, clock)
+  real, dimension(:,:),   intent(inout) :: u_cmpt, v_cmpt
+  type(MOM_domain_type),  intent(inout) :: MOM_dom
+  integer, optional,      intent(in)    :: direction, stagger, halo, clock
+  logical, optional,      intent(in)    :: complete
+  call pass_var_2d(u_cmpt, MOM_dom, position=EAST_FACE)
+  call pass_var_2d(v_cmpt, MOM_dom, position=NORTH_FACE)
+end subroutine pass_vector_2d
 end module MOM_domains
+
+module MOM_hor_index
+implicit none ; private
+public :: hor_index_type
+type :: hor_index_type
+  integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB
+  integer :: idg_offset = 0, jdg_offset = 0
+  logical :: symmetric = .true.
+end type hor_index_type
+end module MOM_hor_index
 
 module MOM_grid
 use MOM_domains, only : MOM_domain_type
+use MOM_hor_index, only : hor_index_type
 implicit none ; private
 public :: ocean_grid_type
 type :: ocean_grid_type
@@ -140,6 +231,8 @@ type :: ocean_grid_type
   integer :: first_direction = 0
   integer :: idg_offset = 0, jdg_offset = 0
   logical :: symmetric = .true.
+  logical :: nonblocking_updates = .false.
+  type(hor_index_type) :: HI
   real :: max_depth = 0.0, Z_ref = 0.0
   real, allocatable, dimension(:,:) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
   real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
@@ -150,15 +243,36 @@ end module MOM_grid
 
 module MOM_verticalGrid
 implicit none ; private
-public :: verticalGrid_type
+public :: verticalGrid_type, get_thickness_units, get_flux_units, get_tr_flux_units
 type :: verticalGrid_type
   integer :: ke
   real :: Angstrom_Z = 1.0e-10, Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
-          Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0
+          Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0, H_to_MKS = 1.0, &
+          H_to_kg_m2 = 1035.0, kg_m2_to_H = 1.0/1035.0, HZ_T_to_m2_s = 1.0, HZ_T_to_MKS = 1.0
   integer :: nk_rho_varies = 0, nkml = 0
   logical :: Boussinesq = .true.
   real, allocatable :: Rlay(:), g_prime(:)
+  character(len=40) :: zAxisUnits = "", zAxisLongName = ""
+  real, allocatable, dimension(:) :: sLayer, sInterface
+  integer :: direction = 1
 end type verticalGrid_type
+contains
+function get_thickness_units(GV)
+  character(len=48)                   :: get_thickness_units
+  type(verticalGrid_type), intent(in) :: GV
+  get_thickness_units = "m"
+end function get_thickness_units
+function get_flux_units(GV)
+  character(len=48)                   :: get_flux_units
+  type(verticalGrid_type), intent(in) :: GV
+  get_flux_units = "m3 s-1"
+end function get_flux_units
+function get_tr_flux_units(GV, tr_units, tr_vol_conc_units, tr_mass_conc_units)
+  character(len=48)                      :: get_tr_flux_units
+  type(verticalGrid_type),    intent(in) :: GV
+  character(len=*), optional, intent(in) :: tr_units, tr_vol_conc_units, tr_mass_conc_units
+  get_tr_flux_units = "m3 s-1"
+end function get_tr_flux_units
 end module MOM_verticalGrid
 
 module MOM_unit_scaling
@@ -166,31 +280,74 @@ implicit none ; private
 public :: unit_scale_type
 type :: unit_scale_type
   real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0, &
-          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0, Pa_to_RL2_T2 = 1.0
+          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0, Pa_to_RL2_T2 = 1.0, L_T2_to_m_s2 = 1.0, &
+          m_s_to_Z_T = 1.0, Z_T_to_m_s = 1.0, RL2_T2_to_Pa = 1.0, RZ_to_kg_m2 = 1.0, Z2_T_to_m2_s = 1.0, m2_s_to_Z2_T = 1.0, &
+          L_T_to_Z_T = 1.0, RZ_T_to_kg_m2s = 1.0, RLZ_T2_to_Pa = 1.0, Pa_to_RLZ_T2 = 1.0, T_to_sec = 1.0, Q_to_J_kg = 1.0, &
+          J_kg_to_Q = 1.0, C_to_degC = 1.0, degC_to_C = 1.0, S_to_ppt = 1.0, ppt_to_S = 1.0, RZ3_T3_to_W_m2 = 1.0, W_m2_to_RZ3_T3 = 1.0
 end type unit_scale_type
 end module MOM_unit_scaling
 
 module MOM_time_manager
 implicit none ; private
-public :: time_type
+public :: time_type, time_type_to_real, real_to_time, operator(+), operator(-), operator(*), operator(/), operator(>), operator(<)
 type :: time_type
   integer :: seconds = 0, days = 0
 end type time_type
+interface operator(+) ; module procedure time_plus ; end interface
+interface operator(-) ; module procedure time_minus ; end interface
+interface operator(*) ; module procedure time_scalar_mult, scalar_time_mult ; end interface
+interface operator(/) ; module procedure time_scalar_divide ; end interface
+interface operator(>) ; module procedure time_gt ; end interface
+interface operator(<) ; module procedure time_lt ; end interface
+contains
+real function time_type_to_real(time)
+  type(time_type), intent(in) :: time
+  time_type_to_real = 86400.0*time%days + time%seconds
+end function time_type_to_real
+type(time_type) function real_to_time(x, err_msg)
+  real, intent(in) :: x
+  character(len=*), optional, intent(out) :: err_msg
+  real_to_time%days = int(x / 86400.0) ; real_to_time%seconds = int(x - 86400.0*real_to_time%days)
+end function real_to_time
+type(time_type) function time_plus(a, b)
+  type(time_type), intent(in) :: a, b
+  time_plus%days = a%days + b%days ; time_plus%seconds = a%seconds + b%seconds
+end function time_plus
+type(time_type) function time_minus(a, b)
+  type(time_type), intent(in) :: a, b
+  time_minus%days = a%days - b%days ; time_minus%seconds = a%seconds - b%seconds
+end function time_minus
+type(time_type) function time_scalar_mult(a, n)
+  type(time_type), intent(in) :: a
+  integer,         intent(in) :: n
+  time_scalar_mult%days = a%days * n ; time_scalar_mult%seconds = a%seconds * n
+end function time_scalar_mult
+type(time_type) function scalar_time_mult(n, a)
+  integer,         intent(in) :: n
+  type(time_type), intent(in) :: a
+  scalar_time_mult = time_scalar_mult(a, n)
+end function scalar_time_mult
+type(time_type) function time_scalar_divide(a, n)
+  type(time_type), intent(in) :: a
+  integer,         intent(in) :: n
+  time_scalar_divide%days = a%days / n ; time_scalar_divide%seconds = a%seconds / n
+end function time_scalar_divide
+logical function time_gt(a, b)
+  type(time_type), intent(in) :: a, b
+  time_gt = (86400.0*a%days + a%seconds) > (86400.0*b%days + b%seconds)
+end function time_gt
+logical function time_lt(a, b)
+  type(time_type), intent(in) :: a, b
+  time_lt = (86400.0*a%days + a%seconds) < (86400.0*b%days + b%seconds)
+end function time_lt
 end module MOM_time_manager
-
-module MOM_diag_mediator
-use MOM_time_manager, only : time_type
-implicit none ; private
-public :: diag_ctrl, time_type
-type :: diag_ctrl
-  integer :: unused = 0
-end type diag_ctrl
-end module MOM_diag_mediator
 
 module MOM_cpu_clock
 implicit none ; private
 public :: cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE, CLOCK_ROUTINE
-integer, parameter :: CLOCK_MODULE = 1, CLOCK_ROUTINE = 2
+public :: CLOCK_COMPONENT, CLOCK_SUBCOMPONENT, CLOCK_MODULE_DRIVER, CLOCK_LOOP, CLOCK_INFRA
+integer, parameter :: CLOCK_COMPONENT = 1, CLOCK_SUBCOMPONENT = 11, CLOCK_MODULE_DRIVER = 21, CLOCK_MODULE = 31, CLOCK_ROUTINE = 41, &
+                      CLOCK_LOOP = 51, CLOCK_INFRA = 61
 contains
 integer function cpu_clock_id(name, grain)
   character(len=*),  intent(in) :: name
@@ -347,28 +504,384 @@ subroutine get_param_char(CS, modulename, varname, value, desc, units, default, 
 end subroutine get_param_char
 end module MOM_file_parser
 
-module MOM_hor_index
+module MOM_diag_mediator
+use MOM_time_manager, only : time_type
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
 implicit none ; private
-public :: hor_index_type
-type :: hor_index_type
-  integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB
-end type hor_index_type
-end module MOM_hor_index
+public :: diag_ctrl, time_type, axes_grp
+public :: diag_mediator_init, enable_averages, enable_averaging, disable_averaging, post_data, safe_alloc_ptr, safe_alloc_alloc
+public :: post_product_u, post_product_sum_u, post_product_v, post_product_sum_v, query_averaging_enabled
+public :: register_diag_field, register_static_field, set_diag_mediator_grid, diag_update_remap_grids
+type :: axes_grp
+  integer :: id = 0
+end type axes_grp
+type :: diag_ctrl
+  integer :: unused = 0
+  type(axes_grp) :: axesBL, axesTL, axesCuL, axesCvL, axesBi, axesTi, axesCui, axesCvi, axesB1, axesT1, axesCu1, axesCv1
+  type(axes_grp) :: axesZi, axesZL, axesNull
+end type diag_ctrl
+interface post_data
+  module procedure post_data_3d, post_data_2d, post_data_0d
+end interface post_data
+interface safe_alloc_ptr
+  module procedure safe_alloc_ptr_3d_2arg, safe_alloc_ptr_3d_3arg, safe_alloc_ptr_3d_6arg, safe_alloc_ptr_2d_2arg, safe_alloc_ptr_2d
+end interface safe_alloc_ptr
+interface safe_alloc_alloc
+  module procedure safe_alloc_allocatable_3d, safe_alloc_allocatable_2d
+end interface safe_alloc_alloc
+contains
+! Nothing is written anywhere: these are the interfaces the reference's callers are compiled against.
+subroutine post_data_0d(diag_field_id, field, diag_cs, is_static)
+  integer,           intent(in) :: diag_field_id
+  real,              intent(in) :: field
+  type(diag_ctrl), target, intent(in) :: diag_CS
+  logical, optional, intent(in) :: is_static
+end subroutine post_data_0d
+subroutine post_data_2d(diag_field_id, field, diag_cs, is_static, mask)
+  integer,           intent(in) :: diag_field_id
+  real,              intent(in) :: field(:,:)
+  type(diag_ctrl), target, intent(in) :: diag_CS
+  logical, optional, intent(in) :: is_static
+  real,    optional, intent(in) :: mask(:,:)
+end subroutine post_data_2d
+subroutine post_data_3d(diag_field_id, field, diag_cs, is_static, mask, alt_h)
+  integer,           intent(in) :: diag_field_id
+  real,              intent(in) :: field(:,:,:)
+  type(diag_ctrl), target, intent(in) :: diag_CS
+  logical, optional, intent(in) :: is_static
+  real,    optional, intent(in) :: mask(:,:,:)
+  real, dimension(:,:,:), target, optional, intent(in) :: alt_h
+end subroutine post_data_3d
+subroutine post_product_u(id, u_a, u_b, G, nz, diag, mask, alt_h)
+  integer,                  intent(in) :: id
+  type(ocean_grid_type),    intent(in) :: G
+  integer,                  intent(in) :: nz
+  real, dimension(G%IsdB:G%IedB, G%jsd:G%jed, nz), intent(in) :: u_a, u_b
+  type(diag_ctrl),          intent(in) :: diag
+  real,           optional, intent(in) :: mask(:,:,:)
+  real, target,   optional, intent(in) :: alt_h(:,:,:)
+end subroutine post_product_u
+subroutine post_product_sum_u(id, u_a, u_b, G, nz, diag)
+  integer,                  intent(in) :: id
+  type(ocean_grid_type),    intent(in) :: G
+  integer,                  intent(in) :: nz
+  real, dimension(G%IsdB:G%IedB, G%jsd:G%jed, nz), intent(in) :: u_a, u_b
+  type(diag_ctrl),          intent(in) :: diag
+end subroutine post_product_sum_u
+subroutine post_product_v(id, v_a, v_b, G, nz, diag, mask, alt_h)
+  integer,                  intent(in) :: id
+  type(ocean_grid_type),    intent(in) :: G
+  integer,                  intent(in) :: nz
+  real, dimension(G%isd:G%ied, G%JsdB:G%JedB, nz), intent(in) :: v_a, v_b
+  type(diag_ctrl),          intent(in) :: diag
+  real,           optional, intent(in) :: mask(:,:,:)
+  real, target,   optional, intent(in) :: alt_h(:,:,:)
+end subroutine post_product_v
+subroutine post_product_sum_v(id, v_a, v_b, G, nz, diag)
+  integer,                  intent(in) :: id
+  type(ocean_grid_type),    intent(in) :: G
+  integer,                  intent(in) :: nz
+  real, dimension(G%isd:G%ied, G%JsdB:G%JedB, nz), intent(in) :: v_a, v_b
+  type(diag_ctrl),          intent(in) :: diag
+end subroutine post_product_sum_v
+subroutine enable_averaging(time_int_in, time_end_in, diag_cs)
+  real,            intent(in)    :: time_int_in
+  type(time_type), intent(in)    :: time_end_in
+  type(diag_ctrl), intent(inout) :: diag_CS
+end subroutine enable_averaging
+subroutine enable_averages(time_int, time_end, diag_CS, T_to_s)
+  real,            intent(in)    :: time_int
+  type(time_type), intent(in)    :: time_end
+  type(diag_ctrl), intent(inout) :: diag_CS
+  real,  optional, intent(in)    :: T_to_s
+end subroutine enable_averages
+subroutine disable_averaging(diag_cs)
+  type(diag_ctrl), intent(inout) :: diag_CS
+end subroutine disable_averaging
+logical function query_averaging_enabled(diag_cs, time_int, time_end)
+  type(diag_ctrl),           intent(in)  :: diag_CS
+  real,            optional, intent(out) :: time_int
+  type(time_type), optional, intent(out) :: time_end
+  query_averaging_enabled = .false.
+  if (present(time_int)) time_int = 0.0
+end function query_averaging_enabled
+integer function register_diag_field(module_name, field_name, axes_in, init_time, &
+            long_name, units, missing_value, range, mask_variant, standard_name,      &
+            verbose, do_not_log, err_msg, interp_method, tile_count, cmor_field_name, &
+            cmor_long_name, cmor_units, cmor_standard_name, cell_methods, &
+            x_cell_method, y_cell_method, v_cell_method, conversion, v_extensive)
+  character(len=*),           intent(in) :: module_name, field_name
+  type(axes_grp),     target, intent(in) :: axes_in
+  type(time_type),            intent(in) :: init_time
+  character(len=*), optional, intent(in) :: long_name, units, standard_name
+  real,             optional, intent(in) :: missing_value, range(2)
+  logical,          optional, intent(in) :: mask_variant, verbose, do_not_log
+  character(len=*), optional, intent(out):: err_msg
+  character(len=*), optional, intent(in) :: interp_method
+  integer,          optional, intent(in) :: tile_count
+  character(len=*), optional, intent(in) :: cmor_field_name, cmor_long_name, cmor_units, cmor_standard_name, cell_methods
+  character(len=*), optional, intent(in) :: x_cell_method, y_cell_method, v_cell_method
+  real,             optional, intent(in) :: conversion
+  logical,          optional, intent(in) :: v_extensive
+  register_diag_field = -1
+end function register_diag_field
+integer function register_static_field(module_name, field_name, axes, &
+            long_name, units, missing_value, range, mask_variant, standard_name, &
+            do_not_log, interp_method, tile_count, &
+            cmor_field_name, cmor_long_name, cmor_units, cmor_standard_name, area, &
+            x_cell_method, y_cell_method, area_cell_method, conversion)
+  character(len=*),           intent(in) :: module_name, field_name
+  type(axes_grp),     target, intent(in) :: axes
+  character(len=*), optional, intent(in) :: long_name, units, standard_name
+  real,             optional, intent(in) :: missing_value, range(2)
+  logical,          optional, intent(in) :: mask_variant, do_not_log
+  character(len=*), optional, intent(in) :: interp_method
+  integer,          optional, intent(in) :: tile_count, area
+  character(len=*), optional, intent(in) :: cmor_field_name, cmor_long_name, cmor_units, cmor_standard_name
+  character(len=*), optional, intent(in) :: x_cell_method, y_cell_method, area_cell_method
+  real,             optional, intent(in) :: conversion
+  register_static_field = -1
+end function register_static_field
+subroutine set_diag_mediator_grid(G, diag_cs)
+  type(ocean_grid_type), intent(inout) :: G
+  type(diag_ctrl),       intent(inout) :: diag_CS
+end subroutine set_diag_mediator_grid
+subroutine diag_update_remap_grids(diag_cs, alt_h, alt_T, alt_S, update_intensive, update_extensive)
+  type(diag_ctrl),        intent(inout) :: diag_cs
+  real, target, optional, intent(in   ) :: alt_h(:,:,:), alt_T(:,:,:), alt_S(:,:,:)
+  logical, optional,      intent(in   ) :: update_intensive, update_extensive
+end subroutine diag_update_remap_grids
+subroutine diag_mediator_init(G, GV, US, nz, param_file, diag_cs, doc_file_dir)
+  use MOM_file_parser, only : param_file_type
+  type(ocean_grid_type), target, intent(inout) :: G
+  type(verticalGrid_type), target, intent(in)  :: GV
+  type(unit_scale_type),   target, intent(in)  :: US
+  integer,                    intent(in)    :: nz
+  type(param_file_type),      intent(in)    :: param_file
+  type(diag_ctrl),            intent(inout) :: diag_cs
+  character(len=*), optional, intent(in)    :: doc_file_dir
+end subroutine diag_mediator_init
+subroutine safe_alloc_ptr_3d_2arg(ptr, ni, nj, nk)
+  real, dimension(:,:,:), pointer :: ptr
+  integer, intent(in) :: ni, nj, nk
+  if (.not.associated(ptr)) then ; allocate(ptr(ni,nj,nk), source=0.0) ; endif
+end subroutine safe_alloc_ptr_3d_2arg
+subroutine safe_alloc_ptr_3d_3arg(ptr, is, ie, js, je, nk)
+  real, dimension(:,:,:), pointer :: ptr
+  integer, intent(in) :: is, ie, js, je, nk
+  if (.not.associated(ptr)) then ; allocate(ptr(is:ie,js:je,nk), source=0.0) ; endif
+end subroutine safe_alloc_ptr_3d_3arg
+subroutine safe_alloc_ptr_3d_6arg(ptr, is, ie, js, je, ks, ke)
+  real, dimension(:,:,:), pointer :: ptr
+  integer, intent(in) :: is, ie, js, je, ks, ke
+  if (.not.associated(ptr)) then ; allocate(ptr(is:ie,js:je,ks:ke), source=0.0) ; endif
+end subroutine safe_alloc_ptr_3d_6arg
+subroutine safe_alloc_ptr_2d_2arg(ptr, ni, nj)
+  real, dimension(:,:), pointer :: ptr
+  integer, intent(in) :: ni, nj
+  if (.not.associated(ptr)) then ; allocate(ptr(ni,nj), source=0.0) ; endif
+end subroutine safe_alloc_ptr_2d_2arg
+subroutine safe_alloc_ptr_2d(ptr, is, ie, js, je)
+  real, dimension(:,:), pointer :: ptr
+  integer, intent(in) :: is, ie, js, je
+  if (.not.associated(ptr)) then ; allocate(ptr(is:ie,js:je), source=0.0) ; endif
+end subroutine safe_alloc_ptr_2d
+subroutine safe_alloc_allocatable_3d(ptr, is, ie, js, je, nk)
+  real, dimension(:,:,:), allocatable :: ptr
+  integer, intent(in) :: is, ie, js, je, nk
+  if (.not.allocated(ptr)) then ; allocate(ptr(is:ie,js:je,nk), source=0.0) ; endif
+end subroutine safe_alloc_allocatable_3d
+subroutine safe_alloc_allocatable_2d(ptr, is, ie, js, je)
+  real, dimension(:,:), allocatable :: ptr
+  integer, intent(in) :: is, ie, js, je
+  if (.not.allocated(ptr)) then ; allocate(ptr(is:ie,js:je), source=0.0) ; endif
+end subroutine safe_alloc_allocatable_2d
+end module MOM_diag_mediator
+
+module MOM_io
+use MOM_domains, only : CENTER, CORNER, EAST_FACE, NORTH_FACE
+implicit none ; private
+public :: vardesc, var_desc, CENTER, CORNER, EAST_FACE, NORTH_FACE, stdout, stderr
+integer, parameter :: stdout = 6, stderr = 0
+type :: vardesc
+  character(len=64)  :: name = ""
+  character(len=48)  :: units = ""
+  character(len=240) :: longname = ""
+  character(len=8)   :: hor_grid = "h", z_grid = "L", t_grid = "s"
+  real :: conversion = 1.0
+  integer :: position = -1
+end type vardesc
+contains
+function var_desc(name, units, longname, hor_grid, z_grid, t_grid, cmor_field_name, &
+                  cmor_units, cmor_longname, conversion, caller, position, dim_names, &
+                  extra_axes, fixed) result(vd)
+  character(len=*),           intent(in) :: name
+  character(len=*), optional, intent(in) :: units, longname, hor_grid, z_grid, t_grid, cmor_field_name, cmor_units, cmor_longname
+  real            , optional, intent(in) :: conversion
+  character(len=*), optional, intent(in) :: caller
+  integer,          optional, intent(in) :: position
+  character(len=*), dimension(:), optional, intent(in) :: dim_names
+  integer,          dimension(:), optional, intent(in) :: extra_axes
+  logical,          optional, intent(in) :: fixed
+  type(vardesc) :: vd
+  vd%name = name
+  if (present(units)) vd%units = units
+  if (present(longname)) vd%longname = longname
+  if (present(hor_grid)) vd%hor_grid = hor_grid
+  if (present(z_grid)) vd%z_grid = z_grid
+  if (present(conversion)) vd%conversion = conversion
+end function var_desc
+end module MOM_io
+
+module MOM_get_input
+implicit none ; private
+public :: directories
+type :: directories
+  character(len=240) :: restart_input_dir = ".", restart_output_dir = ".", output_directory = ".", input_filename = "n"
+end type directories
+end module MOM_get_input
 
 !> Restart registration that remembers nothing: every field reads as "not initialized" (a cold start)
 module MOM_restart
+use MOM_io, only : vardesc
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_time_manager, only : time_type
+use MOM_file_parser, only : param_file_type
 implicit none ; private
 public :: MOM_restart_CS, register_restart_field, query_initialized
+public :: register_restart_pair, set_initialized, save_restart, only_read_from_restarts, restart_init, is_new_run
 type :: MOM_restart_CS
   integer :: nfields = 0
 end type MOM_restart_CS
 interface register_restart_field
-  module procedure register_3d, register_2d, register_0d
+  module procedure register_3d, register_2d, register_0d, register_vd_3d, register_vd_2d
+end interface
+interface register_restart_pair
+  module procedure register_pair_3d, register_pair_2d
 end interface
 interface query_initialized
-  module procedure query_3d, query_2d, query_0d
+  module procedure query_3d, query_2d, query_0d, query_name
+end interface
+interface set_initialized
+  module procedure set_initialized_name, set_initialized_3d_name, set_initialized_2d_name, set_initialized_0d_name
+end interface
+interface only_read_from_restarts
+  module procedure only_read_restart_field_3d, only_read_restart_field_2d, only_read_restart_pair_3d
 end interface
 contains
+subroutine register_vd_3d(f_ptr, var_desc, mandatory, CS, conversion)
+  real, dimension(:,:,:), target, intent(in) :: f_ptr
+  type(vardesc),        intent(in)    :: var_desc
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  real,       optional, intent(in)    :: conversion
+  CS%nfields = CS%nfields + 1
+end subroutine register_vd_3d
+subroutine register_vd_2d(f_ptr, var_desc, mandatory, CS, conversion)
+  real, dimension(:,:), target, intent(in) :: f_ptr
+  type(vardesc),        intent(in)    :: var_desc
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  real,       optional, intent(in)    :: conversion
+  CS%nfields = CS%nfields + 1
+end subroutine register_vd_2d
+subroutine register_pair_3d(a_ptr, b_ptr, a_desc, b_desc, mandatory, CS, conversion)
+  real, dimension(:,:,:), target, intent(in) :: a_ptr, b_ptr
+  type(vardesc),        intent(in)    :: a_desc, b_desc
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  real,       optional, intent(in)    :: conversion
+  CS%nfields = CS%nfields + 2
+end subroutine register_pair_3d
+subroutine register_pair_2d(a_ptr, b_ptr, a_desc, b_desc, mandatory, CS, conversion)
+  real, dimension(:,:), target, intent(in) :: a_ptr, b_ptr
+  type(vardesc),        intent(in)    :: a_desc, b_desc
+  logical,              intent(in)    :: mandatory
+  type(MOM_restart_CS), intent(inout) :: CS
+  real,       optional, intent(in)    :: conversion
+  CS%nfields = CS%nfields + 2
+end subroutine register_pair_2d
+logical function query_name(name, CS)
+  character(len=*),     intent(in) :: name
+  type(MOM_restart_CS), intent(in) :: CS
+  query_name = .false.
+end function query_name
+subroutine set_initialized_name(name, CS)
+  character(len=*),     intent(in)    :: name
+  type(MOM_restart_CS), intent(inout) :: CS
+end subroutine set_initialized_name
+subroutine set_initialized_3d_name(f_ptr, name, CS)
+  real, dimension(:,:,:), intent(in)  :: f_ptr
+  character(len=*),     intent(in)    :: name
+  type(MOM_restart_CS), intent(inout) :: CS
+end subroutine set_initialized_3d_name
+subroutine set_initialized_2d_name(f_ptr, name, CS)
+  real, dimension(:,:), intent(in)    :: f_ptr
+  character(len=*),     intent(in)    :: name
+  type(MOM_restart_CS), intent(inout) :: CS
+end subroutine set_initialized_2d_name
+subroutine set_initialized_0d_name(f_ptr, name, CS)
+  real,                 intent(in)    :: f_ptr
+  character(len=*),     intent(in)    :: name
+  type(MOM_restart_CS), intent(inout) :: CS
+end subroutine set_initialized_0d_name
+logical function is_new_run(CS)
+  type(MOM_restart_CS), intent(in) :: CS
+  is_new_run = .true.
+end function is_new_run
+subroutine save_restart(directory, time, G, CS, time_stamped, filename, GV, num_rest_files, write_IC)
+  character(len=*),        intent(in)    :: directory
+  type(time_type),         intent(in)    :: time
+  type(ocean_grid_type),   intent(inout) :: G
+  type(MOM_restart_CS),    intent(inout) :: CS
+  logical,       optional, intent(in)    :: time_stamped
+  character(len=*), optional, intent(in) :: filename
+  type(verticalGrid_type), optional, intent(in) :: GV
+  integer,       optional, intent(out)   :: num_rest_files
+  logical,       optional, intent(in)    :: write_IC
+end subroutine save_restart
+subroutine restart_init(param_file, CS, restart_root)
+  type(param_file_type), intent(in) :: param_file
+  type(MOM_restart_CS),  pointer    :: CS
+  character(len=*), optional, intent(in) :: restart_root
+  if (.not.associated(CS)) allocate(CS)
+end subroutine restart_init
+subroutine only_read_restart_field_3d(varname, f_ptr, G, CS, position, filename, directory, success, scale)
+  character(len=*),                intent(in)    :: varname
+  real, dimension(:,:,:),          intent(inout) :: f_ptr
+  type(ocean_grid_type),           intent(in)    :: G
+  type(MOM_restart_CS),            intent(in)    :: CS
+  integer,               optional, intent(in)    :: position
+  character(len=*),      optional, intent(in)    :: filename, directory
+  logical,               optional, intent(out)   :: success
+  real,                  optional, intent(in)    :: scale
+  if (present(success)) success = .false.
+end subroutine only_read_restart_field_3d
+subroutine only_read_restart_field_2d(varname, f_ptr, G, CS, position, filename, directory, success, scale)
+  character(len=*),                intent(in)    :: varname
+  real, dimension(:,:),            intent(inout) :: f_ptr
+  type(ocean_grid_type),           intent(in)    :: G
+  type(MOM_restart_CS),            intent(in)    :: CS
+  integer,               optional, intent(in)    :: position
+  character(len=*),      optional, intent(in)    :: filename, directory
+  logical,               optional, intent(out)   :: success
+  real,                  optional, intent(in)    :: scale
+  if (present(success)) success = .false.
+end subroutine only_read_restart_field_2d
+subroutine only_read_restart_pair_3d(a_ptr, b_ptr, a_name, b_name, G, CS, stagger, filename, directory, success, scale)
+  real, dimension(:,:,:),          intent(inout) :: a_ptr, b_ptr
+  character(len=*),                intent(in)    :: a_name, b_name
+  type(ocean_grid_type),           intent(in)    :: G
+  type(MOM_restart_CS),            intent(in)    :: CS
+  integer,               optional, intent(in)    :: stagger
+  character(len=*),      optional, intent(in)    :: filename, directory
+  logical,               optional, intent(out)   :: success
+  real,                  optional, intent(in)    :: scale
+  if (present(success)) success = .false.
+end subroutine only_read_restart_pair_3d
 subroutine register_3d(f_ptr, name, mandatory, CS, longname, units, conversion, hor_grid, z_grid, t_grid)
   real, dimension(:,:,:), target, intent(in) :: f_ptr
   character(len=*),     intent(in)    :: name
@@ -416,22 +929,110 @@ logical function query_0d(f_ptr, name, CS)
 end function query_0d
 end module MOM_restart
 
+module MOM_EOS
+implicit none ; private
+public :: EOS_type
+type :: EOS_type
+  integer :: form_of_EOS = 0
+end type EOS_type
+end module MOM_EOS
+
+module MOM_variables
+use MOM_domains, only : group_pass_type
+use MOM_EOS, only : EOS_type
+implicit none ; private
+public :: BT_cont_type, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, thermo_var_ptrs, vertvisc_type, &
+          ocean_internal_state, alloc_BT_cont_type, dealloc_BT_cont_type
+type :: BT_cont_type
+  real, allocatable :: FA_u_EE(:,:), FA_u_E0(:,:), FA_u_W0(:,:), FA_u_WW(:,:), uBT_WW(:,:), uBT_EE(:,:)
+  real, allocatable :: FA_v_NN(:,:), FA_v_N0(:,:), FA_v_S0(:,:), FA_v_SS(:,:), vBT_SS(:,:), vBT_NN(:,:)
+  real, allocatable :: h_u(:,:,:), h_v(:,:,:)
+  type(group_pass_type) :: pass_polarity_BT, pass_FA_uv
+end type BT_cont_type
+type :: porous_barrier_type
+  real, allocatable :: por_face_areaU(:,:,:), por_face_areaV(:,:,:), por_layer_widthU(:,:,:), por_layer_widthV(:,:,:)
+end type porous_barrier_type
+type :: accel_diag_ptrs
+  real, pointer, dimension(:,:,:) :: diffu => NULL(), diffv => NULL(), CAu => NULL(), CAv => NULL(), PFu => NULL(), PFv => NULL()
+  real, pointer, dimension(:,:,:) :: du_dt_visc => NULL(), dv_dt_visc => NULL(), du_dt_visc_gl90 => NULL(), dv_dt_visc_gl90 => NULL()
+  real, pointer, dimension(:,:,:) :: du_dt_str => NULL(), dv_dt_str => NULL(), du_dt_dia => NULL(), dv_dt_dia => NULL()
+  real, pointer, dimension(:,:,:) :: u_accel_bt => NULL(), v_accel_bt => NULL(), du_other => NULL(), dv_other => NULL()
+  real, pointer, dimension(:,:,:) :: gradKEu => NULL(), gradKEv => NULL(), rv_x_u => NULL(), rv_x_v => NULL()
+  real, pointer, dimension(:,:,:) :: diag_hfrac_u => NULL(), diag_hfrac_v => NULL(), diag_hu => NULL(), diag_hv => NULL()
+  real, pointer, dimension(:,:,:) :: visc_rem_u => NULL(), visc_rem_v => NULL()
+end type accel_diag_ptrs
+type :: cont_diag_ptrs
+  real, pointer, dimension(:,:,:) :: uh => NULL(), vh => NULL(), uhGM => NULL(), vhGM => NULL()
+end type cont_diag_ptrs
+type :: thermo_var_ptrs
+  real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL()
+  real, pointer, dimension(:,:) :: p_surf => NULL()
+  type(EOS_type), pointer :: eqn_of_state => NULL()      !< associated = an equation of state is used (use_EOS)
+  real :: P_Ref = 2.0e7
+end type thermo_var_ptrs
+type :: vertvisc_type
+  real :: Prandtl_turb = 1.0
+  real, allocatable, dimension(:,:) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v
+  real, allocatable, dimension(:,:) :: nkml_visc_u, nkml_visc_v
+  real, allocatable, dimension(:,:,:) :: Ray_u, Ray_v
+  real, pointer, dimension(:,:,:) :: Kv_shear => NULL(), Kv_shear_Bu => NULL()
+  real, pointer, dimension(:,:) :: h_ML => NULL()
+end type vertvisc_type
+type :: ocean_internal_state
+  real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL(), u => NULL(), v => NULL(), h => NULL(), uh => NULL(), vh => NULL()
+  real, pointer, dimension(:,:,:) :: CAu => NULL(), CAv => NULL(), PFu => NULL(), PFv => NULL(), diffu => NULL(), diffv => NULL()
+  real, pointer, dimension(:,:,:) :: pbce => NULL(), u_accel_bt => NULL(), v_accel_bt => NULL()
+  real, pointer, dimension(:,:,:) :: u_av => NULL(), v_av => NULL(), u_prev => NULL(), v_prev => NULL()
+end type ocean_internal_state
+contains
+subroutine alloc_BT_cont_type(BT_cont, isd, ied, jsd, jed, nz, alloc_faces)
+  type(BT_cont_type), pointer :: BT_cont
+  integer, intent(in) :: isd, ied, jsd, jed, nz
+  logical, optional, intent(in) :: alloc_faces
+  allocate(BT_cont)
+  allocate(BT_cont%FA_u_WW(isd-1:ied,jsd:jed), source=0.0) ; allocate(BT_cont%FA_u_W0(isd-1:ied,jsd:jed), source=0.0)
+  allocate(BT_cont%FA_u_E0(isd-1:ied,jsd:jed), source=0.0) ; allocate(BT_cont%FA_u_EE(isd-1:ied,jsd:jed), source=0.0)
+  allocate(BT_cont%uBT_WW(isd-1:ied,jsd:jed), source=0.0)  ; allocate(BT_cont%uBT_EE(isd-1:ied,jsd:jed), source=0.0)
+  allocate(BT_cont%FA_v_SS(isd:ied,jsd-1:jed), source=0.0) ; allocate(BT_cont%FA_v_S0(isd:ied,jsd-1:jed), source=0.0)
+  allocate(BT_cont%FA_v_N0(isd:ied,jsd-1:jed), source=0.0) ; allocate(BT_cont%FA_v_NN(isd:ied,jsd-1:jed), source=0.0)
+  allocate(BT_cont%vBT_SS(isd:ied,jsd-1:jed), source=0.0)  ; allocate(BT_cont%vBT_NN(isd:ied,jsd-1:jed), source=0.0)
+  if (present(alloc_faces)) then ; if (alloc_faces) then
+    allocate(BT_cont%h_u(isd-1:ied,jsd:jed,nz), source=0.0) ; allocate(BT_cont%h_v(isd:ied,jsd-1:jed,nz), source=0.0)
+  endif ; endif
+end subroutine alloc_BT_cont_type
+subroutine dealloc_BT_cont_type(BT_cont)
+  type(BT_cont_type), pointer :: BT_cont
+  if (associated(BT_cont)) deallocate(BT_cont)
+end subroutine dealloc_BT_cont_type
+end module MOM_variables
+
 module MOM_forcing_type
 implicit none ; private
 public :: mech_forcing
 type :: mech_forcing
   real, pointer, dimension(:,:) :: taux => NULL(), tauy => NULL()
   real, pointer, dimension(:,:) :: ustar => NULL()      !< the surface friction velocity [Z T-1]
+  real, pointer, dimension(:,:) :: p_surf => NULL(), p_surf_full => NULL(), net_mass_src => NULL()
+  real, pointer, dimension(:,:) :: rigidity_ice_u => NULL(), rigidity_ice_v => NULL(), frac_shelf_u => NULL(), frac_shelf_v => NULL()
+  real, pointer, dimension(:,:) :: tau_mag => NULL(), omega_w2x => NULL()
 end type mech_forcing
 end module MOM_forcing_type
 
-module MOM_self_attr_load
+module MOM_regridding
 implicit none ; private
-public :: SAL_CS
-type :: SAL_CS
-  integer :: unused = 0
-end type SAL_CS
-end module MOM_self_attr_load
+public :: regridding_CS
+type :: regridding_CS
+  integer :: nk = 0
+end type regridding_CS
+end module MOM_regridding
+
+module MOM_remapping
+implicit none ; private
+public :: remapping_CS
+type :: remapping_CS
+  integer :: remapping_scheme = 0
+end type remapping_CS
+end module MOM_remapping
 
 #ifndef MOM6HIP_WITH_ALE_SHIM
 module MOM_ALE
@@ -443,22 +1044,6 @@ end type ALE_CS
 end module MOM_ALE
 #endif
 
-module MOM_tidal_forcing
-implicit none ; private
-public :: tidal_forcing_CS
-type :: tidal_forcing_CS
-  integer :: unused = 0
-end type tidal_forcing_CS
-end module MOM_tidal_forcing
-
-module MOM_io
-implicit none ; private
-public :: directories
-type :: directories
-  character(len=240) :: output_directory = "."
-end type directories
-end module MOM_io
-
 module MOM_barotropic_types_for_hor_visc
 end module MOM_barotropic_types_for_hor_visc
 
@@ -466,25 +1051,9 @@ module MOM_stochastics
 implicit none ; private
 public :: stochastic_CS
 type :: stochastic_CS
-  logical :: skeb_use_gm = .false.
+  logical :: do_sppt = .false., do_skeb = .false., skeb_use_gm = .false., skeb_use_frict = .false., pert_epbl = .false.
 end type stochastic_CS
 end module MOM_stochastics
-
-module MOM_EOS
-implicit none ; private
-public :: EOS_type
-type :: EOS_type
-  integer :: form_of_EOS = 0
-end type EOS_type
-end module MOM_EOS
-
-module MOM_diabatic_driver
-implicit none ; private
-public :: diabatic_CS
-type :: diabatic_CS
-  integer :: unused = 0
-end type diabatic_CS
-end module MOM_diabatic_driver
 
 module MOM_MEKE_types
 implicit none ; private
@@ -507,30 +1076,6 @@ type :: VarMix_CS
 end type VarMix_CS
 end module MOM_lateral_mixing_coeffs
 
-module MOM_open_boundary
-implicit none ; private
-public :: ocean_OBC_type
-type :: ocean_OBC_type
-  integer :: number_of_segments = 0
-end type ocean_OBC_type
-end module MOM_open_boundary
-
-module MOM_boundary_update
-implicit none ; private
-public :: update_OBC_CS
-type :: update_OBC_CS
-  integer :: unused = 0
-end type update_OBC_CS
-end module MOM_boundary_update
-
-module MOM_wave_interface
-implicit none ; private
-public :: Wave_parameters_CS
-type :: Wave_parameters_CS
-  logical :: Stokes_VF = .false.
-end type Wave_parameters_CS
-end module MOM_wave_interface
-
 module MOM_tracer_registry
 implicit none ; private
 public :: tracer_registry_type, tracer_type
@@ -549,58 +1094,449 @@ type :: tracer_registry_type
 end type tracer_registry_type
 end module MOM_tracer_registry
 
-module MOM_variables
-use MOM_domains, only : group_pass_type
-use MOM_EOS, only : EOS_type
+module MOM_self_attr_load
+use MOM_grid, only : ocean_grid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_file_parser, only : param_file_type
 implicit none ; private
-public :: BT_cont_type, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, thermo_var_ptrs, vertvisc_type, &
-          ocean_internal_state, alloc_BT_cont_type
-type :: BT_cont_type
-  real, allocatable :: FA_u_EE(:,:), FA_u_E0(:,:), FA_u_W0(:,:), FA_u_WW(:,:), uBT_WW(:,:), uBT_EE(:,:)
-  real, allocatable :: FA_v_NN(:,:), FA_v_N0(:,:), FA_v_S0(:,:), FA_v_SS(:,:), vBT_SS(:,:), vBT_NN(:,:)
-  real, allocatable :: h_u(:,:,:), h_v(:,:,:)
-  type(group_pass_type) :: pass_polarity_BT, pass_FA_uv
-end type BT_cont_type
-type :: porous_barrier_type
-  real, allocatable :: por_face_areaU(:,:,:), por_face_areaV(:,:,:), por_layer_widthU(:,:,:), por_layer_widthV(:,:,:)
-end type porous_barrier_type
-type :: accel_diag_ptrs
-  real, pointer, dimension(:,:,:) :: gradKEu => NULL(), gradKEv => NULL(), rv_x_u => NULL(), rv_x_v => NULL()
-end type accel_diag_ptrs
-type :: cont_diag_ptrs
-  real, pointer, dimension(:,:,:) :: uh => NULL(), vh => NULL(), uhGM => NULL(), vhGM => NULL()
-end type cont_diag_ptrs
-type :: thermo_var_ptrs
-  real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL()
-  real, pointer, dimension(:,:) :: p_surf => NULL()
-  type(EOS_type), pointer :: eqn_of_state => NULL()      !< associated = an equation of state is used (use_EOS)
-  real :: P_Ref = 2.0e7
-end type thermo_var_ptrs
-type :: vertvisc_type
-  real :: Prandtl_turb = 1.0
-  real, allocatable, dimension(:,:) :: Kv_bbl_u, Kv_bbl_v, bbl_thick_u, bbl_thick_v
-  real, allocatable, dimension(:,:) :: nkml_visc_u, nkml_visc_v
-  real, allocatable, dimension(:,:,:) :: Ray_u, Ray_v
-  real, pointer, dimension(:,:,:) :: Kv_shear => NULL(), Kv_shear_Bu => NULL()
-  real, pointer, dimension(:,:) :: h_ML => NULL()
-end type vertvisc_type
-type :: ocean_internal_state
+public :: SAL_CS, SAL_init, SAL_end
+type :: SAL_CS
   integer :: unused = 0
-end type ocean_internal_state
+end type SAL_CS
 contains
-subroutine alloc_BT_cont_type(BT_cont, isd, ied, jsd, jed, nz, alloc_faces)
-  type(BT_cont_type), pointer :: BT_cont
-  integer, intent(in) :: isd, ied, jsd, jed, nz
-  logical, optional, intent(in) :: alloc_faces
-  allocate(BT_cont)
-  allocate(BT_cont%FA_u_WW(isd-1:ied,jsd:jed), source=0.0) ; allocate(BT_cont%FA_u_W0(isd-1:ied,jsd:jed), source=0.0)
-  allocate(BT_cont%FA_u_E0(isd-1:ied,jsd:jed), source=0.0) ; allocate(BT_cont%FA_u_EE(isd-1:ied,jsd:jed), source=0.0)
-  allocate(BT_cont%uBT_WW(isd-1:ied,jsd:jed), source=0.0)  ; allocate(BT_cont%uBT_EE(isd-1:ied,jsd:jed), source=0.0)
-  allocate(BT_cont%FA_v_SS(isd:ied,jsd-1:jed), source=0.0) ; allocate(BT_cont%FA_v_S0(isd:ied,jsd-1:jed), source=0.0)
-  allocate(BT_cont%FA_v_N0(isd:ied,jsd-1:jed), source=0.0) ; allocate(BT_cont%FA_v_NN(isd:ied,jsd-1:jed), source=0.0)
-  allocate(BT_cont%vBT_SS(isd:ied,jsd-1:jed), source=0.0)  ; allocate(BT_cont%vBT_NN(isd:ied,jsd-1:jed), source=0.0)
-  if (present(alloc_faces)) then ; if (alloc_faces) then
-    allocate(BT_cont%h_u(isd-1:ied,jsd:jed,nz), source=0.0) ; allocate(BT_cont%h_v(isd:ied,jsd-1:jed,nz), source=0.0)
-  endif ; endif
-end subroutine alloc_BT_cont_type
-end module MOM_variables
+subroutine SAL_init(G, US, param_file, CS)
+  type(ocean_grid_type),  intent(inout) :: G
+  type(unit_scale_type),  intent(in)    :: US
+  type(param_file_type),  intent(in)    :: param_file
+  type(SAL_CS), intent(inout) :: CS
+end subroutine SAL_init
+subroutine SAL_end(CS)
+  type(SAL_CS), intent(inout) :: CS
+end subroutine SAL_end
+end module MOM_self_attr_load
+
+module MOM_tidal_forcing
+use MOM_grid, only : ocean_grid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_file_parser, only : param_file_type
+use MOM_time_manager, only : time_type
+implicit none ; private
+public :: tidal_forcing_CS, tidal_forcing_init, tidal_forcing_end
+type :: tidal_forcing_CS
+  integer :: unused = 0
+end type tidal_forcing_CS
+contains
+subroutine tidal_forcing_init(Time, G, US, param_file, CS)
+  type(time_type),        intent(in)    :: Time
+  type(ocean_grid_type),  intent(inout) :: G
+  type(unit_scale_type),  intent(in)    :: US
+  type(param_file_type),  intent(in)    :: param_file
+  type(tidal_forcing_CS), intent(inout) :: CS
+end subroutine tidal_forcing_init
+subroutine tidal_forcing_end(CS)
+  type(tidal_forcing_CS), intent(inout) :: CS
+end subroutine tidal_forcing_end
+end module MOM_tidal_forcing
+
+module MOM_CVMix_KPP
+use MOM_grid, only : ocean_grid_type
+use MOM_unit_scaling, only : unit_scale_type
+implicit none ; private
+public :: KPP_CS, KPP_get_BLD
+type :: KPP_CS
+  integer :: unused = 0
+end type KPP_CS
+contains
+subroutine KPP_get_BLD(CS, BLD, G, US, m_to_BLD_units)
+  type(KPP_CS),                     pointer     :: CS
+  type(ocean_grid_type),            intent(in)  :: G
+  type(unit_scale_type),            intent(in)  :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(inout) :: BLD
+  real,                   optional, intent(in)  :: m_to_BLD_units
+end subroutine KPP_get_BLD
+end module MOM_CVMix_KPP
+
+module MOM_energetic_PBL
+use MOM_grid, only : ocean_grid_type
+use MOM_unit_scaling, only : unit_scale_type
+implicit none ; private
+public :: energetic_PBL_CS, energetic_PBL_get_MLD
+type :: energetic_PBL_CS
+  integer :: unused = 0
+end type energetic_PBL_CS
+contains
+subroutine energetic_PBL_get_MLD(CS, MLD, G, US, m_to_MLD_units)
+  type(energetic_PBL_CS),           intent(in)  :: CS
+  type(ocean_grid_type),            intent(in)  :: G
+  type(unit_scale_type),            intent(in)  :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(out) :: MLD
+  real,                   optional, intent(in)  :: m_to_MLD_units
+  MLD(:,:) = 0.0
+end subroutine energetic_PBL_get_MLD
+end module MOM_energetic_PBL
+
+module MOM_diabatic_driver
+use MOM_CVMix_KPP, only : KPP_CS
+use MOM_energetic_PBL, only : energetic_PBL_CS
+implicit none ; private
+public :: diabatic_CS, extract_diabatic_member
+type :: diabatic_CS
+  integer :: unused = 0
+end type diabatic_CS
+contains
+subroutine extract_diabatic_member(CS, evap_CFL_limit, minimum_forcing_depth, KPP_CSp, energetic_PBL_CSp, diabatic_halo, use_KPP)
+  type(diabatic_CS), target, intent(in)      :: CS
+  type(KPP_CS),      optional, pointer       :: KPP_CSp
+  type(energetic_PBL_CS), optional, pointer  :: energetic_PBL_CSp
+  real,              optional, intent(  out) :: evap_CFL_limit, minimum_forcing_depth
+  integer,           optional, intent(  out) :: diabatic_halo
+  logical,           optional, intent(  out) :: use_KPP
+end subroutine extract_diabatic_member
+end module MOM_diabatic_driver
+
+module MOM_open_boundary
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_time_manager, only : time_type
+implicit none ; private
+public :: ocean_OBC_type, radiation_open_bdry_conds, open_boundary_zero_normal_flow, open_boundary_query
+public :: open_boundary_test_extern_h, update_OBC_ramp
+type :: ocean_OBC_type
+  integer :: number_of_segments = 0
+  logical :: update_OBC = .false., oblique_BCs_exist_globally = .false., radiation_BCs_exist_globally = .false.
+  logical :: ramp = .false., zero_vorticity = .false., freeslip_vorticity = .false., computed_vorticity = .false.
+  logical :: specified_vorticity = .false., zero_strain = .false., freeslip_strain = .false., computed_strain = .false.
+  logical :: specified_strain = .false.
+end type ocean_OBC_type
+contains
+logical function open_boundary_query(OBC, apply_open_OBC, apply_specified_OBC, apply_Flather_OBC, apply_nudged_OBC, needs_ext_seg_data)
+  type(ocean_OBC_type), pointer    :: OBC
+  logical, optional,    intent(in) :: apply_open_OBC, apply_specified_OBC, apply_Flather_OBC, apply_nudged_OBC, needs_ext_seg_data
+  open_boundary_query = .false.
+end function open_boundary_query
+subroutine open_boundary_zero_normal_flow(OBC, G, GV, u, v)
+  type(ocean_OBC_type),                       pointer       :: OBC
+  type(ocean_grid_type),                      intent(inout) :: G
+  type(verticalGrid_type),                    intent(in)    :: GV
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(inout) :: u
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(inout) :: v
+end subroutine open_boundary_zero_normal_flow
+subroutine open_boundary_test_extern_h(G, GV, OBC, h)
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  type(ocean_OBC_type),                      pointer       :: OBC
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),intent(inout) :: h
+end subroutine open_boundary_test_extern_h
+subroutine update_OBC_ramp(Time, OBC, US, activate)
+  type(time_type), target, intent(in)    :: Time
+  type(ocean_OBC_type),    intent(inout) :: OBC
+  type(unit_scale_type),   intent(in)    :: US
+  logical, optional,       intent(in)    :: activate
+end subroutine update_OBC_ramp
+subroutine radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, GV, US, dt)
+  type(ocean_grid_type),                      intent(inout) :: G
+  type(verticalGrid_type),                    intent(in)    :: GV
+  type(ocean_OBC_type),                       pointer       :: OBC
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(inout) :: u_new
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(in)    :: u_old
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(inout) :: v_new
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(in)    :: v_old
+  type(unit_scale_type),                      intent(in)    :: US
+  real,                                       intent(in)    :: dt
+end subroutine radiation_open_bdry_conds
+end module MOM_open_boundary
+
+module MOM_boundary_update
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_time_manager, only : time_type
+use MOM_variables, only : thermo_var_ptrs
+use MOM_open_boundary, only : ocean_OBC_type
+implicit none ; private
+public :: update_OBC_CS, update_OBC_data
+type :: update_OBC_CS
+  integer :: unused = 0
+end type update_OBC_CS
+contains
+subroutine update_OBC_data(OBC, G, GV, US, tv, h, CS, Time)
+  type(ocean_grid_type),                     intent(in)    :: G
+  type(verticalGrid_type),                   intent(in)    :: GV
+  type(unit_scale_type),                     intent(in)    :: US
+  type(thermo_var_ptrs),                     intent(in)    :: tv
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(inout) :: h
+  type(ocean_OBC_type),                      pointer       :: OBC
+  type(update_OBC_CS),                       pointer       :: CS
+  type(time_type),                           intent(in)    :: Time
+end subroutine update_OBC_data
+end module MOM_boundary_update
+
+module MOM_wave_interface
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+implicit none ; private
+public :: Wave_parameters_CS, Stokes_PGF
+type :: Wave_parameters_CS
+  logical :: Stokes_VF = .false., Stokes_PGF = .false., Passive_Stokes_PGF = .false., Passive_Stokes_VF = .false., Stokes_DDT = .false.
+end type Wave_parameters_CS
+contains
+subroutine Stokes_PGF(G, GV, US, dz, u, v, PFu_Stokes, PFv_Stokes, CS)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   intent(in)    :: dz
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(in)    :: u
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(in)    :: v
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(out)   :: PFu_Stokes
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(out)   :: PFv_Stokes
+  type(Wave_parameters_CS), pointer      :: CS
+  PFu_Stokes(:,:,:) = 0.0 ; PFv_Stokes(:,:,:) = 0.0
+end subroutine Stokes_PGF
+end module MOM_wave_interface
+
+module MOM_interface_heights
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_variables, only : thermo_var_ptrs
+implicit none ; private
+public :: thickness_to_dz, find_col_avg_SpV
+interface thickness_to_dz
+  module procedure thickness_to_dz_3d, thickness_to_dz_jslice
+end interface thickness_to_dz
+contains
+subroutine thickness_to_dz_3d(h, tv, dz, G, GV, US, halo_size)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in)    :: h
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(inout) :: dz
+  type(unit_scale_type),   intent(in)    :: US
+  integer,       optional, intent(in)    :: halo_size
+  dz(:,:,:) = GV%H_to_Z * h(:,:,:)
+end subroutine thickness_to_dz_3d
+subroutine thickness_to_dz_jslice(h, tv, dz, j, G, GV, halo_size)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in)    :: h
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real, dimension(G%isd:G%ied,GV%ke), intent(inout) :: dz
+  integer,                 intent(in)    :: j
+  integer,       optional, intent(in)    :: halo_size
+  dz(:,:) = GV%H_to_Z * h(:,j,:)
+end subroutine thickness_to_dz_jslice
+subroutine find_col_avg_SpV(h, SpV_avg, tv, G, GV, US, halo_size)
+  type(ocean_grid_type),    intent(in)    :: G
+  type(verticalGrid_type),  intent(in)    :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in)    :: h
+  real, dimension(G%isd:G%ied,G%jsd:G%jed),       intent(inout) :: SpV_avg
+  type(thermo_var_ptrs),    intent(in)    :: tv
+  type(unit_scale_type),    intent(in)    :: US
+  integer,        optional, intent(in)    :: halo_size
+end subroutine find_col_avg_SpV
+end module MOM_interface_heights
+
+module MOM_debugging
+use MOM_grid, only : ocean_grid_type
+use MOM_hor_index, only : hor_index_type
+implicit none ; private
+public :: hchksum, uvchksum, Bchksum, check_redundant
+interface hchksum
+  module procedure chksum_h_3d, chksum_h_2d
+end interface
+interface Bchksum
+  module procedure chksum_B_3d, chksum_B_2d
+end interface
+interface uvchksum
+  module procedure chksum_uv_3d, chksum_uv_2d
+end interface
+interface check_redundant
+  module procedure check_redundant_vC3d, check_redundant_vC2d
+end interface
+contains
+subroutine chksum_h_3d(array_m, mesg, HI_m, haloshift, omit_corners, scale, logunit)
+  type(hor_index_type),    target,   intent(in) :: HI_m
+  real, dimension(HI_m%isd:,HI_m%jsd:,:), target, intent(in) :: array_m
+  character(len=*),                  intent(in) :: mesg
+  integer,                 optional, intent(in) :: haloshift, logunit
+  logical,                 optional, intent(in) :: omit_corners
+  real,                    optional, intent(in) :: scale
+end subroutine chksum_h_3d
+subroutine chksum_h_2d(array_m, mesg, HI_m, haloshift, omit_corners, scale, logunit)
+  type(hor_index_type),    target,   intent(in) :: HI_m
+  real, dimension(HI_m%isd:,HI_m%jsd:), target, intent(in) :: array_m
+  character(len=*),                  intent(in) :: mesg
+  integer,                 optional, intent(in) :: haloshift, logunit
+  logical,                 optional, intent(in) :: omit_corners
+  real,                    optional, intent(in) :: scale
+end subroutine chksum_h_2d
+subroutine chksum_B_3d(array_m, mesg, HI_m, haloshift, symmetric, omit_corners, scale, logunit)
+  type(hor_index_type),    target,   intent(in) :: HI_m
+  real, dimension(HI_m%IsdB:,HI_m%JsdB:,:), target, intent(in) :: array_m
+  character(len=*),                  intent(in) :: mesg
+  integer,                 optional, intent(in) :: haloshift, logunit
+  logical,                 optional, intent(in) :: symmetric, omit_corners
+  real,                    optional, intent(in) :: scale
+end subroutine chksum_B_3d
+subroutine chksum_B_2d(array_m, mesg, HI_m, haloshift, symmetric, omit_corners, scale, logunit)
+  type(hor_index_type),    target,   intent(in) :: HI_m
+  real, dimension(HI_m%IsdB:,HI_m%JsdB:), target, intent(in) :: array_m
+  character(len=*),                  intent(in) :: mesg
+  integer,                 optional, intent(in) :: haloshift, logunit
+  logical,                 optional, intent(in) :: symmetric, omit_corners
+  real,                    optional, intent(in) :: scale
+end subroutine chksum_B_2d
+subroutine chksum_uv_3d(mesg, arrayU, arrayV, HI, haloshift, symmetric, omit_corners, scale, logunit, scalar_pair)
+  character(len=*),                    intent(in) :: mesg
+  type(hor_index_type),      target,   intent(in) :: HI
+  real, dimension(HI%IsdB:,HI%jsd:,:), target, intent(in) :: arrayU
+  real, dimension(HI%isd:,HI%JsdB:,:), target, intent(in) :: arrayV
+  integer,                   optional, intent(in) :: haloshift, logunit
+  logical,                   optional, intent(in) :: symmetric, omit_corners, scalar_pair
+  real,                      optional, intent(in) :: scale
+end subroutine chksum_uv_3d
+subroutine chksum_uv_2d(mesg, arrayU, arrayV, HI, haloshift, symmetric, omit_corners, scale, logunit, scalar_pair)
+  character(len=*),                    intent(in) :: mesg
+  type(hor_index_type),      target,   intent(in) :: HI
+  real, dimension(HI%IsdB:,HI%jsd:), target, intent(in) :: arrayU
+  real, dimension(HI%isd:,HI%JsdB:), target, intent(in) :: arrayV
+  integer,                   optional, intent(in) :: haloshift, logunit
+  logical,                   optional, intent(in) :: symmetric, omit_corners, scalar_pair
+  real,                      optional, intent(in) :: scale
+end subroutine chksum_uv_2d
+subroutine check_redundant_vC3d(mesg, u_comp, v_comp, G, is, ie, js, je, direction, unscale)
+  character(len=*),                    intent(in)    :: mesg
+  type(ocean_grid_type),               intent(inout) :: G
+  real, dimension(G%IsdB:,G%jsd:,:),   intent(in)    :: u_comp
+  real, dimension(G%isd:,G%JsdB:,:),   intent(in)    :: v_comp
+  integer,                   optional, intent(in)    :: is, ie, js, je, direction
+  real,                      optional, intent(in)    :: unscale
+end subroutine check_redundant_vC3d
+subroutine check_redundant_vC2d(mesg, u_comp, v_comp, G, is, ie, js, je, direction, unscale)
+  character(len=*),                    intent(in)    :: mesg
+  type(ocean_grid_type),               intent(inout) :: G
+  real, dimension(G%IsdB:,G%jsd:),     intent(in)    :: u_comp
+  real, dimension(G%isd:,G%JsdB:),     intent(in)    :: v_comp
+  integer,                   optional, intent(in)    :: is, ie, js, je, direction
+  real,                      optional, intent(in)    :: unscale
+end subroutine check_redundant_vC2d
+end module MOM_debugging
+
+module MOM_checksum_packages
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_variables, only : thermo_var_ptrs
+implicit none ; private
+public :: MOM_state_chksum, MOM_thermo_chksum, MOM_accel_chksum
+interface MOM_state_chksum
+  module procedure MOM_state_chksum_5arg, MOM_state_chksum_3arg
+end interface
+contains
+subroutine MOM_state_chksum_5arg(mesg, u, v, h, uh, vh, G, GV, US, haloshift, symmetric, omit_corners, vel_scale)
+  character(len=*),        intent(in) :: mesg
+  type(ocean_grid_type),   intent(in) :: G
+  type(verticalGrid_type), intent(in) :: GV
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(in) :: u, uh
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(in) :: v, vh
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   intent(in) :: h
+  type(unit_scale_type),   intent(in) :: US
+  integer,       optional, intent(in) :: haloshift
+  logical,       optional, intent(in) :: symmetric, omit_corners
+  real,          optional, intent(in) :: vel_scale
+end subroutine MOM_state_chksum_5arg
+subroutine MOM_state_chksum_3arg(mesg, u, v, h, G, GV, US, haloshift, symmetric, omit_corners)
+  character(len=*),        intent(in) :: mesg
+  type(ocean_grid_type),   intent(in) :: G
+  type(verticalGrid_type), intent(in) :: GV
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(in) :: u
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(in) :: v
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   intent(in) :: h
+  type(unit_scale_type),   intent(in) :: US
+  integer,       optional, intent(in) :: haloshift
+  logical,       optional, intent(in) :: symmetric, omit_corners
+end subroutine MOM_state_chksum_3arg
+subroutine MOM_thermo_chksum(mesg, tv, G, US, haloshift, omit_corners)
+  character(len=*),         intent(in) :: mesg
+  type(thermo_var_ptrs),    intent(in) :: tv
+  type(ocean_grid_type),    intent(in) :: G
+  type(unit_scale_type),    intent(in) :: US
+  integer,        optional, intent(in) :: haloshift
+  logical,        optional, intent(in) :: omit_corners
+end subroutine MOM_thermo_chksum
+subroutine MOM_accel_chksum(mesg, CAu, CAv, PFu, PFv, diffu, diffv, G, GV, US, pbce, u_accel_bt, v_accel_bt, symmetric)
+  character(len=*),         intent(in) :: mesg
+  type(ocean_grid_type),    intent(in) :: G
+  type(verticalGrid_type),  intent(in) :: GV
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(in) :: CAu, PFu, diffu
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(in) :: CAv, PFv, diffv
+  type(unit_scale_type),    intent(in) :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   optional, intent(in) :: pbce
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), optional, intent(in) :: u_accel_bt
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), optional, intent(in) :: v_accel_bt
+  logical,        optional, intent(in) :: symmetric
+end subroutine MOM_accel_chksum
+end module MOM_checksum_packages
+
+!> The Montgomery-potential pressure force stays the reference's own module in a MOM6 tree (it is not on the path of
+!! ANALYTIC_FV_PGF = True); this is its interface as MOM_PressureForce.F90 uses it.
+module MOM_PressureForce_Mont
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_variables, only : thermo_var_ptrs
+use MOM_time_manager, only : time_type
+use MOM_file_parser, only : param_file_type
+use MOM_diag_mediator, only : diag_ctrl
+use MOM_self_attr_load, only : SAL_CS
+use MOM_tidal_forcing, only : tidal_forcing_CS
+use MOM_error_handler, only : MOM_error, FATAL
+implicit none ; private
+public :: PressureForce_Mont_CS, PressureForce_Mont_Bouss, PressureForce_Mont_nonBouss, PressureForce_Mont_init
+type :: PressureForce_Mont_CS
+  logical :: initialized = .false.
+end type PressureForce_Mont_CS
+contains
+subroutine PressureForce_Mont_Bouss(h, tv, PFu, PFv, G, GV, US, CS, p_atm, pbce, eta)
+  type(ocean_grid_type),                      intent(in)  :: G
+  type(verticalGrid_type),                    intent(in)  :: GV
+  type(unit_scale_type),                      intent(in)  :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   intent(in)  :: h
+  type(thermo_var_ptrs),                      intent(in)  :: tv
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(out) :: PFu
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(out) :: PFv
+  type(PressureForce_Mont_CS),                intent(inout) :: CS
+  real, dimension(:,:),                       pointer     :: p_atm
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), optional, intent(out) :: pbce
+  real, dimension(G%isd:G%ied,G%jsd:G%jed),       optional, intent(out) :: eta
+  call MOM_error(FATAL, "PressureForce_Mont_Bouss: a stand-in; ANALYTIC_FV_PGF = False is the reference's own module.")
+end subroutine PressureForce_Mont_Bouss
+subroutine PressureForce_Mont_nonBouss(h, tv, PFu, PFv, G, GV, US, CS, p_atm, pbce, eta)
+  type(ocean_grid_type),                      intent(in)  :: G
+  type(verticalGrid_type),                    intent(in)  :: GV
+  type(unit_scale_type),                      intent(in)  :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   intent(in)  :: h
+  type(thermo_var_ptrs),                      intent(in)  :: tv
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(out) :: PFu
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(out) :: PFv
+  type(PressureForce_Mont_CS),                intent(inout) :: CS
+  real, dimension(:,:),                       pointer     :: p_atm
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), optional, intent(out) :: pbce
+  real, dimension(G%isd:G%ied,G%jsd:G%jed),       optional, intent(out) :: eta
+  call MOM_error(FATAL, "PressureForce_Mont_nonBouss: a stand-in; ANALYTIC_FV_PGF = False is the reference's own module.")
+end subroutine PressureForce_Mont_nonBouss
+subroutine PressureForce_Mont_init(Time, G, GV, US, param_file, diag, CS, SAL_CSp, tides_CSp)
+  type(time_type), target, intent(in)    :: Time
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  type(param_file_type),   intent(in)    :: param_file
+  type(diag_ctrl), target, intent(inout) :: diag
+  type(PressureForce_Mont_CS), intent(inout) :: CS
+  type(SAL_CS), intent(in), target, optional :: SAL_CSp
+  type(tidal_forcing_CS), intent(in), target, optional :: tides_CSp
+  CS%initialized = .true.
+end subroutine PressureForce_Mont_init
+end module MOM_PressureForce_Mont

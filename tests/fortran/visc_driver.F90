@@ -13,7 +13,7 @@ use MOM_domains,       only : MOM_domain_type
 use MOM_file_parser,   only : param_file_type, param_set
 use MOM_forcing_type,  only : mech_forcing
 use MOM_grid,          only : ocean_grid_type
-use MOM_io,            only : directories
+use MOM_get_input,     only : directories
 use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_MEKE_types,    only : MEKE_type
 use MOM_open_boundary, only : ocean_OBC_type

@@ -178,6 +178,63 @@ def test_gpu_parity(oracle, form, opts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", ["0", "3", "7"])
+def test_gpu_pgf_kernel_forms_agree(oracle, rows, monkeypatch):
+    """MOM6HIP_PGF_FUSED: the column / face pair through memory (0) and the fused kernel with 3 or 7 rows a block give the oracle's
+    bits like the default (4 rows, test_gpu_parity): several blocks in x (63 columns each) and in y, ragged last blocks"""
+    import torch
+    from mom6_amd.pressure_force import PressureForce, PressureForce_init, EOS_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    monkeypatch.setenv("MOM6HIP_PGF_FUSED", rows)
+    for (ni, nj, nk, topo, form, extrap, massw) in [(70, 21, 5, (True, False), "WRIGHT", True, False), (130, 9, 3, (True, False), "UNESCO", False, True),
+                                                    (61, 7, 4, (False, False), "LINEAR", True, True), (62, 8, 2, (True, True), "WRIGHT", False, True),
+                                                    (125, 16, 6, (True, False), "WRIGHT_FULL", True, True)]:
+        g, st = pgf_case(ni, nj, nk, seed=ni, reentrant_x=topo[0], reentrant_y=topo[1])
+        E = oracle.eos(form, 1000.0, -0.2, 0.8)
+        cs = oracle.pressureforce_cs(g, boundary_extrap=extrap, useMassWghtInterp=massw)
+        p_atm = np.ascontiguousarray(1.0e5 + 500.0 * np.random.default_rng(ni).standard_normal(g.shape2(_abi.POS_H)))
+        ref = oracle.pressureforce(g, cs, E, st["h"], st["T"], st["S"], p_atm)
+        dg = DeviceGrid(g)
+        CS = PressureForce_init(g, boundary_extrap=extrap, useMassWghtInterp=massw)
+        EOS = EOS_init(form, 1000.0, -0.2, 0.8)
+        X = lambda a: torch.from_numpy(a.copy()).cuda()
+        PFu, PFv, pbce, eta = X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V)), X(g.zeros3(_abi.POS_H)), X(g.zeros2(_abi.POS_H))
+        PressureForce(X(st["h"]), (X(st["T"]), X(st["S"]), EOS), PFu, PFv, dg, CS, p_atm=X(p_atm), pbce=pbce, eta=eta)
+        dg.sync()
+        for name, a, b in (("PFu", ref[0], PFu), ("PFv", ref[1], PFv), ("pbce", ref[2], pbce), ("eta", ref[3], eta)):
+            assert bits_equal(a, b.cpu().numpy()), (rows, (ni, nj, nk), form, name, np.argwhere(a != b.cpu().numpy())[:3])
+        dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extrap", [False, True])
+def test_gpu_ale_plm_edge_values(oracle, extrap):
+    """ALE_PLM_edge_values / TS_PLM_edge_values (MOM_ALE.F90:1520, :1495) through the library == the oracle, host and device arrays"""
+    import torch
+    from mom6_amd.ale import ALE_PLM_edge_values, TS_PLM_edge_values
+    from mom6_amd.tracer_advect import DeviceGrid
+    for (ni, nj, nk) in [(70, 21, 5), (10, 8, 2), (33, 9, 12)]:
+        g, st = pgf_case(ni, nj, nk, seed=3 * ni)
+        want = oracle.ale_plm_edge_values(g, st["h"], st["T"], extrap)
+        dg = DeviceGrid(g)
+        for resident in (False, True):
+            X = (lambda a: torch.from_numpy(a.copy()).cuda()) if resident else (lambda a: a.copy())
+            N = (lambda a: a.cpu().numpy()) if resident else (lambda a: a)
+            Qt, Qb = X(g.zeros3(_abi.POS_H)), X(g.zeros3(_abi.POS_H))
+            ALE_PLM_edge_values(None, dg, X(st["h"]), X(st["T"]), extrap, Qt, Qb)
+            dg.sync()
+            sj, si = slice(g.halo - 1, g.halo + nj + 1), slice(g.halo - 1, g.halo + ni + 1)
+            assert bits_equal(want[0][:, sj, si], N(Qt)[:, sj, si]) and bits_equal(want[1][:, sj, si], N(Qb)[:, sj, si]), (ni, nj, nk, resident)
+        St, Sb, Tt, Tb = (torch.from_numpy(g.zeros3(_abi.POS_H)).cuda() for _ in range(4))
+        TS_PLM_edge_values(None, St, Sb, Tt, Tb, dg, (torch.from_numpy(st["T"]).cuda(), torch.from_numpy(st["S"]).cuda()),
+                           torch.from_numpy(st["h"]).cuda(), extrap)
+        dg.sync()
+        wS = oracle.ale_plm_edge_values(g, st["h"], st["S"], extrap)
+        assert bits_equal(want[0][:, sj, si], Tt.cpu().numpy()[:, sj, si]) and bits_equal(wS[1][:, sj, si], Sb.cpu().numpy()[:, sj, si])
+        dg.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["WRIGHT", "UNESCO", "LINEAR", "WRIGHT_FULL", "WRIGHT_REDUCED"])
 @pytest.mark.parametrize("opts", [(True, False), (False, True)])
 def test_gpu_parity_nonbouss(oracle, form, opts):
