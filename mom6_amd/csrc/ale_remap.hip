@@ -1210,6 +1210,445 @@ __device__ void w_integrate_sub_cells(const WCol &c, int lane, int n0, int n1, i
   wsync();
 }
 
+// ======== the streaming form (round 4): one lane per column, no arrays ================================================================
+// remapping_core_h for REMAPPING_SCHEME = PPM_H4 without boundary extrapolation, as ONE top-down walk per lane with a constant
+// amount of state, for NF fields that share the column's two grids:
+//   * the outer loop runs over the SOURCE cells (the same index in every lane: the loads of h_old and of the fields are coalesced
+//     rows, issued a cell ahead of their use); the inner loop creates the sub-cells of that source cell exactly as
+//     remap_via_sub_cells :519-651 does (the four cases of the merge);
+//   * the reconstruction of a source cell (edge_values_explicit_h4 with end_value_h4 at the two ends, bound_edge_values,
+//     check_discontinuous_edge_values, PPM_limiter_standard: MOM_remapping.F90:257-386) needs the cells m-2 .. m+2 only: a register
+//     window; the weights of the edge values depend on the thicknesses alone and are formed once for the NF fields;
+//   * h0_eff of a source cell (:560-620: the sum of its sub-cells' dh, which average_value_ppoly's xb divides by) is needed at its
+//     first sub-cell: a look-ahead repeats the merge arithmetic on a copy of the two supplies until the cell closes;
+//   * "adjust_thickest_subcell" (:703-719) rewrites uh_sub of the LAST thickest sub-cell of a source cell with the cell's total minus
+//     the others, summed in order: two running sums (all sub-cells so far; all but the current candidate) give that in any case.
+//     A (source, target) pair meets in exactly one sub-cell, so the candidate's target cell has either just been closed by that very
+//     sub-cell -- then it waits, as the ONE pending target a lane can have, until the candidate moves on or the source cell closes --
+//     or is still open when the source cell closes, and the adjusted value goes into its sum in the reference's order;
+//   * a target cell is written when it is final (:721-766: the bounded mean of its sub-cells, or the first sub-cell's value of a
+//     vanished cell; conc_underflow of ALE_remap_tracers): stores at the lane's own layer.
+// The fields are remapped IN PLACE.  A lane has read the layers 0 .. m+3 when it works on source cell m; a target cell below that
+// (the new grid far ahead of the old one: thin target cells in a thick source cell) would overwrite values the lane has yet to read,
+// so such a value goes to a side array instead, the layer is marked in a 128-bit register mask, and the lane copies its marked layers
+// back when it is done.  With z* grids a few time steps apart this never happens; the walk is correct for any pair of grids.
+// The same operations on the same numbers in the same order as the wave-per-column kernel and the oracle: bit-identical results
+// (tests/test_ale_gpu.py runs both forms).  nk >= 6; other schemes, boundary extrapolation and fewer layers use the wave kernel.
+struct SRemapArgs {
+  m6::GridDev g;
+  const double *h_old, *h_new;
+  double *const *fld;      // device array of field pointers, or null with `single`
+  double *single;
+  const double *cu;        // underflow per field or null
+  int f0, pos;             // first field of this launch; staggering
+  double h_neglect, h_neglect_edge;
+  double *side;            // NF arrays of the fields' size: values of target cells that lie below what the lane has read so far
+  long side_stride;        // doubles between the side arrays of two fields
+};
+
+struct EdgeW { double A1, A2, B, Cc, Hs; };
+// the thickness-only factors of edge_values_explicit_h4 (regrid_edge_values.F90:262-300) at the interface above cell i
+__device__ __forceinline__ EdgeW edge_weights_h4(double h0, double h1, double h2, double h3, double hNeglect) {
+  const double hMinFrac = 1.e-5;
+  if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
+    const double h_min = hMinFrac * fmax(hNeglect, (h0 + h1) + (h2 + h3));
+    h0 = fmax(h_min, h0); h1 = fmax(h_min, h1); h2 = fmax(h_min, h2); h3 = fmax(h_min, h3);
+  }
+  const double I_h12 = 1.0 / (h1 + h2);
+  const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)); const double I_h012 = (h0 + h1) * I_den_et2;
+  const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)); const double I_h123 = (h2 + h3) * I_den_et3;
+  EdgeW w;
+  w.A1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3));
+  w.A2 = (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1));
+  w.B = (h1 * (h2 * (h2 + h3)) * I_den_et2);
+  w.Cc = (h2 * (h1 * (h0 + h1)) * I_den_et3);
+  w.Hs = (h0 + h1) + (h2 + h3);
+  return w;
+}
+__device__ __forceinline__ double edge_value_h4(const EdgeW &w, double um2, double um1, double u0, double up1) {
+  const double et1 = w.A1 * um1 + w.A2 * u0;
+  const double et2 = w.B * (um1 - um2);
+  const double et3 = w.Cc * (u0 - up1);
+  return (et1 + (et2 + et3)) / w.Hs;
+}
+// the slope of bound_edge_values (regrid_edge_values.F90:71-82) with hr = h(k) / ((h(km1) + h(kp1)) + 2 h(k)) or a negative hr for "no slope"
+__device__ __forceinline__ double bound_slope(double ukm1, double uk, double ukp1, double hr) {
+  double slope_x_h = 0.0;
+  if (hr >= 0.0) {
+    const double sigma_l = (uk - ukm1);
+    const double sigma_c = (ukp1 - ukm1) * hr;
+    const double sigma_r = (ukp1 - uk);
+    if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(min3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+  }
+  return slope_x_h;
+}
+__device__ __forceinline__ double bound_left(double EL, double ukm1, double uk, double slope) {
+  if ((ukm1 - EL) * (EL - uk) < 0.0) EL = uk - fsign(fmin(fabs(slope), fabs(EL - uk)), slope);
+  return fmax(fmin(EL, fmax(ukm1, uk)), fmin(ukm1, uk));
+}
+__device__ __forceinline__ double bound_right(double ER, double ukp1, double uk, double slope) {
+  if ((ukp1 - ER) * (ER - uk) < 0.0) ER = uk + fsign(fmin(fabs(slope), fabs(ER - uk)), slope);
+  return fmax(fmin(ER, fmax(ukp1, uk)), fmin(ukp1, uk));
+}
+// PPM_limiter_standard for an interior cell (PPM_functions.F90:84-121)
+__device__ __forceinline__ void ppm_limit_cell(double u_l, double u_c, double u_r, double &edge_l, double &edge_r) {
+  if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
+    edge_l = u_c; edge_r = u_c;
+  } else {
+    const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
+    const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
+    if (expr1 > expr2) {
+      edge_l = u_c + 2.0 * (u_c - edge_r);
+      edge_l = fmax(fmin(edge_l, fmax(u_l, u_c)), fmin(u_l, u_c));
+    } else if (expr1 < -expr2) {
+      edge_r = u_c + 2.0 * (u_c - edge_l);
+      edge_r = fmax(fmin(edge_r, fmax(u_r, u_c)), fmin(u_r, u_c));
+    }
+  }
+  if (fabs(edge_r - edge_l) < fmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
+}
+// average_value_ppoly for INT_PPM (MOM_remapping.F90:998-1099)
+__device__ __forceinline__ double average_ppm(double a_L, double a_R, double u_c, double xa, double xb) {
+  if (xb > xa) {
+    const double mx = 0.5 * (xa + xb);
+    const double a_c = 0.5 * ((u_c - a_L) + (u_c - a_R));
+    if (mx < 0.5) {
+      const double xa2b2ab = (xa * xa + xb * xb) + xa * xb;
+      return a_L + ((a_R - a_L) * mx + a_c * (3. * (xb + xa) - 2. * xa2b2ab));
+    } else {
+      const double Ya = 1. - xa, Yb = 1. - xb;
+      const double my = 0.5 * (Ya + Yb);
+      const double Ya2b2ab = (Ya * Ya + Yb * Yb) + Ya * Yb;
+      return a_R + ((a_L - a_R) * my + a_c * (3. * (Yb + Ya) - 2. * Ya2b2ab));
+    }
+  }
+  const double Ya = 1. - xa;
+  const double a_c = 3. * ((u_c - a_L) + (u_c - a_R));
+  if (xa < 0.5) return a_L + xa * ((a_R - a_L) + a_c * Ya);
+  return a_R + Ya * ((a_L - a_R) + a_c * xa);
+}
+
+// waves per SIMD the register allocation aims at: one field fits 128 VGPRs (4 waves: 13.7 / 6.0 ms for 4 tracers / u and v at
+// 1440x1080x75 against 15.2 / 6.6 with 3), two fields need 168 (3 waves: 10.0 ms for 4 tracers; 19 ms when squeezed into 128); four
+// fields a launch spill 268 registers (31 ms) -- profiles/r04_ale_stream.txt
+template <int NF>
+__global__ __launch_bounds__(64, NF == 1 ? 4 : 3) void ale_remap_stream_kernel(SRemapArgs a) {
+  const m6::GridDev &g = a.g;
+  const int n = g.nk;      // n0 = n1 = n
+  const int xs = (a.pos == MOM6HIP_POS_U) ? 1 : 0, ys = (a.pos == MOM6HIP_POS_V) ? 1 : 0;
+  const int i = g.isc - xs + blockIdx.x * 64 + threadIdx.x, j = g.jsc - ys + blockIdx.y;
+  if (i > g.iec) return;
+  const long base = a.pos == MOM6HIP_POS_U ? g.u2(i, j) : (a.pos == MOM6HIP_POS_V ? g.v2(i, j) : g.h2(i, j));
+  const double msk = a.pos == MOM6HIP_POS_U ? g.mask2dCu[base] : (a.pos == MOM6HIP_POS_V ? g.mask2dCv[base] : g.mask2dT[base]);
+  if (!(msk > 0.)) return;
+  const long stride = (long)(g.nih + xs) * (g.njh + ys);
+  const double *h0p = a.h_old + base, *h1p = a.h_new + base;
+  double *fp[NF];
+  double cu[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) {
+    fp[f] = (a.fld ? a.fld[a.f0 + f] : a.single) + base;
+    cu[f] = a.cu ? a.cu[a.f0 + f] : 0.0;
+  }
+  auto H0 = [&](int k) -> double { return (k >= 0 && k < n) ? h0p[k * stride] : 0.0; };
+  auto H1 = [&](int k) -> double { return (k >= 0 && k < n) ? h1p[k * stride] : 0.0; };
+  const double hNe = a.h_neglect_edge;
+  const int ns = 2 * n + 1;
+
+  // ---- the two ends of edge_values_explicit_h4 (:329-362): V[0], V[1] from the first four cells, V[n-1], V[n] from the last four ----
+  double Vt0[NF], Vt1[NF], Vb1[NF], Vb0[NF];
+  {
+    double dz[4], ut[4], C[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) dz[q] = fmax(hNe, H0(q));
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) ut[q] = fp[f][q * stride];
+      end_value_h4(dz, ut, C);
+      Vt0[f] = C[0];
+      Vt1[f] = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) dz[q] = fmax(hNe, H0(n - 1 - q));
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) ut[q] = fp[f][(long)(n - 1 - q) * stride];
+      end_value_h4(dz, ut, C);
+      Vb0[f] = C[0];
+      Vb1[f] = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
+    }
+  }
+
+  // ---- windows: thicknesses and values of the cells m-1 .. m+2 (and m+3 on its way) ----
+  double hm1 = 0., hc = H0(0), hp1 = H0(1), hp2 = H0(2), hp3 = H0(3);
+  double um1[NF], uc[NF], up1[NF], up2[NF], up3[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) { um1[f] = 0.; uc[f] = fp[f][0]; up1[f] = fp[f][stride]; up2[f] = fp[f][2 * stride]; up3[f] = fp[f][3 * stride]; }
+  double elC[NF], slope_c[NF];      // the left edge of cell m after bound + check; the bound slope of cell m
+  {
+    // cell 0: km1 = 0, kp1 = 1
+    const double den = (hc + hp1) + 2.0 * hc;
+    const double hr = den > 0.0 ? hc / den : -1.0;
+#pragma unroll
+    for (int f = 0; f < NF; f++) { slope_c[f] = bound_slope(uc[f], uc[f], up1[f], hr); elC[f] = bound_left(Vt0[f], uc[f], uc[f], slope_c[f]); }
+  }
+
+  // ---- the merge state (remap_via_sub_cells :519-560) ----
+  int i0 = 1, i1 = 1, i_sub = 1;
+  double h0s = hc, h1s = H1(0);
+  double h1_open = h1s;                 // h1 of the open target cell
+  bool src = true, tgt = true;
+  double dh_max = 0.;
+  // the second loop's state (:653-700)
+  double xa = 0., dh0_eff_i = 0.;
+  // the open target cell
+  double dh_t = 0.;
+  double duh_t[NF], umin_t[NF], umax_t[NF], ufirst_t[NF];
+  // the sums of the open source cell: all sub-cells so far, and all but the candidate for the thickest
+  double S_incl[NF], S_excl[NF], cand_uh[NF];
+  double cand_hsub = 0.;
+  // the pending target cell (closed by the candidate sub-cell of the open source cell)
+  bool pend = false;
+  int pend_i1 = 0;
+  bool pend_thick = false;
+  double pend_dh = 0.;
+  double pend_pre[NF], pend_min[NF], pend_max[NF], pend_first[NF];
+  double aL[NF], aR[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) { duh_t[f] = 0.; S_incl[f] = 0.; S_excl[f] = 0.; cand_uh[f] = 0.; aL[f] = uc[f]; aR[f] = uc[f]; }
+
+  int m_read = 3;      // the lane has read the layers 0 .. m_read
+  unsigned long long ahead_lo = 0ull, ahead_hi = 0ull;      // layers whose new value waits in the side array
+  auto store_target = [&](int t1, bool thick, double dh, const double *duh, const double *mn, const double *mx, const double *first) {
+    const int kt = t1 - 1;
+    const bool ahead = kt > m_read;
+    if (ahead) { if (kt < 64) ahead_lo |= 1ull << kt; else ahead_hi |= 1ull << (kt - 64); }
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+      double r;
+      if (thick) { r = duh[f] / dh; r = fmax(mn[f], fmin(mx[f], r)); }
+      else r = first[f];
+      if (cu[f] > 0.0 && fabs(r) < cu[f]) r = 0.0;      // ALE_remap_tracers: conc_underflow, MOM_ALE.F90:812-814
+      if (ahead) a.side[a.side_stride * f + base + (long)kt * stride] = r;
+      else fp[f][(long)kt * stride] = r;
+    }
+  };
+  auto finalize_pending = [&](const double *uh_last) {      // the pending target with the (adjusted or not) value of its last sub-cell
+    double duh[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) duh[f] = pend_pre[f] + uh_last[f];
+    store_target(pend_i1, pend_thick, pend_dh, duh, pend_min, pend_max, pend_first);
+    pend = false;
+  };
+
+  // sub-cell 1 (:531-536, :655-656): no thickness, the left edge of the first cell
+  // (cell 0 of PPM_H4 without extrapolation is piecewise constant: E(1,1) = u0(1))
+#pragma unroll
+  for (int f = 0; f < NF; f++) { umin_t[f] = uc[f]; umax_t[f] = uc[f]; ufirst_t[f] = uc[f]; }
+  bool first_of_target = false;
+
+  double h0_eff_cur = 0.;
+  double hcell = hc;      // h0 of the open source cell
+  double ucell[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) ucell[f] = uc[f];
+
+  // one sub-cell of the walk; returns true when it closed the open source cell
+  auto sub_cell = [&]() -> bool {
+    i_sub++;
+    const double dh = fmin(h0s, h1s);
+    const bool in_src = src, in_tgt = tgt;
+    const bool is_cand = in_src && (dh >= dh_max);
+    if (dh >= dh_max) dh_max = dh;
+    double hsub = dh;
+    bool end_src = false, end_tgt = false;
+    if (h0s <= h1s && src) { h1s = h1s - dh; end_src = true; }
+    else if (h0s >= h1s && tgt) { h0s = h0s - dh; end_tgt = true; }
+    else if (src) { hsub = h0s; end_src = true; }
+    else if (tgt) { hsub = h1s; end_tgt = true; }
+    // the value of the sub-cell (:657-690; the last one :691-692)
+    double usub[NF], uh[NF];
+    double xb = 1.;
+    if (i_sub < ns) {
+      dh0_eff_i = dh0_eff_i + hsub;
+      if (h0_eff_cur > 0.) {
+        xb = dh0_eff_i / h0_eff_cur;
+        xb = fmin(1., xb);
+#pragma unroll
+        for (int f = 0; f < NF; f++) usub[f] = average_ppm(aL[f], aR[f], ucell[f], xa, xb);
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; f++) usub[f] = ucell[f];
+      }
+#pragma unroll
+      for (int f = 0; f < NF; f++) uh[f] = hsub * usub[f];
+    } else {
+#pragma unroll
+      for (int f = 0; f < NF; f++) { usub[f] = aR[f]; uh[f] = aR[f] * hsub; }
+    }
+    // the thickest sub-cell of the open source cell (:703-719)
+    double uh_here[NF];      // what this sub-cell contributes to its target's sum
+#pragma unroll
+    for (int f = 0; f < NF; f++) uh_here[f] = uh[f];
+    bool make_pending = false;
+    if (in_src) {
+      if (is_cand) {
+        if (pend) finalize_pending(cand_uh);      // the previous candidate stays as it was
+#pragma unroll
+        for (int f = 0; f < NF; f++) { S_excl[f] = S_incl[f]; S_incl[f] = S_incl[f] + uh[f]; cand_uh[f] = uh[f]; }
+        cand_hsub = hsub;
+        if (end_src) {
+          if (hsub > 0.) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) uh_here[f] = ucell[f] * hcell - S_excl[f];
+          }
+        } else {
+          make_pending = true;      // closes its target while the source cell goes on
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; f++) { S_excl[f] = S_excl[f] + uh[f]; S_incl[f] = S_incl[f] + uh[f]; }
+        if (end_src && pend) {
+          double adj[NF];
+#pragma unroll
+          for (int f = 0; f < NF; f++) adj[f] = (cand_hsub > 0.) ? (ucell[f] * hcell - S_excl[f]) : cand_uh[f];
+          finalize_pending(adj);
+        }
+      }
+    }
+    // the open target cell (:721-766)
+    if (in_tgt) {
+      if (first_of_target) {
+#pragma unroll
+        for (int f = 0; f < NF; f++) { umin_t[f] = usub[f]; umax_t[f] = usub[f]; ufirst_t[f] = usub[f]; }
+        first_of_target = false;
+      }
+      dh_t = dh_t + hsub;
+#pragma unroll
+      for (int f = 0; f < NF; f++) { umin_t[f] = fmin(umin_t[f], usub[f]); umax_t[f] = fmax(umax_t[f], usub[f]); }
+      if (end_tgt) {
+        const bool thick = h1_open > 0.;
+        if (make_pending) {
+          pend = true; pend_i1 = i1; pend_thick = thick; pend_dh = dh_t;
+#pragma unroll
+          for (int f = 0; f < NF; f++) { pend_pre[f] = duh_t[f]; pend_min[f] = umin_t[f]; pend_max[f] = umax_t[f]; pend_first[f] = ufirst_t[f]; }
+        } else {
+#pragma unroll
+          for (int f = 0; f < NF; f++) duh_t[f] = duh_t[f] + uh_here[f];
+          store_target(i1, thick, dh_t, duh_t, umin_t, umax_t, ufirst_t);
+        }
+        dh_t = 0.;
+#pragma unroll
+        for (int f = 0; f < NF; f++) duh_t[f] = 0.;
+        first_of_target = true;
+        if (i1 < n) { i1 = i1 + 1; h1s = H1(i1 - 1); h1_open = h1s; }
+        else { h1s = 0.; tgt = false; }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; f++) duh_t[f] = duh_t[f] + uh_here[f];
+      }
+    }
+    // the next sub-cell's place in its source cell (:693-699)
+    if (end_src) {
+      dh_max = 0.;
+#pragma unroll
+      for (int f = 0; f < NF; f++) { S_incl[f] = 0.; S_excl[f] = 0.; }
+      if (i0 < n) { dh0_eff_i = 0.; xa = 0.; }
+      else { xa = xb; h0s = 0.; src = false; }
+    } else {
+      xa = xb;
+    }
+    return end_src;
+  };
+
+  // sub-cell 1 belongs to source cell 1 and target cell 1 with no thickness and uh = 0 (:531-536, :655): S = 0 + 0, dh = 0 + 0
+  for (int m = 0; m < n; m++) {
+    // ---- the reconstruction of cell m (edge value at its lower interface, bounds, discontinuity check, limiter) ----
+    {
+      const int K = m + 1;      // the interface below cell m
+      double Vn[NF];
+      if (K >= 2 && K <= n - 2) {
+        const EdgeW w = edge_weights_h4(hm1, hc, hp1, hp2, hNe);
+#pragma unroll
+        for (int f = 0; f < NF; f++) Vn[f] = edge_value_h4(w, um1[f], uc[f], up1[f], up2[f]);
+      } else {
+#pragma unroll
+        for (int f = 0; f < NF; f++) Vn[f] = (K == 1) ? Vt1[f] : ((K == n - 1) ? Vb1[f] : Vb0[f]);
+      }
+      double hr_n = -1.0;
+      if (m + 1 <= n - 1) {      // cell m+1: km1 = m, kp1 = min(m+2, n-1)
+        const double hk = hp1, hkp = (m + 2 <= n - 1) ? hp2 : hp1;
+        const double den = (hc + hkp) + 2.0 * hk;
+        if (den > 0.0) hr_n = hk / den;
+      }
+#pragma unroll
+      for (int f = 0; f < NF; f++) {
+        const double ukp1 = (m + 1 <= n - 1) ? up1[f] : uc[f];
+        double erB = bound_right(Vn[f], ukp1, uc[f], slope_c[f]);
+        double el_next = 0., slope_n = 0.;
+        if (m + 1 <= n - 1) {
+          const double ukp2 = (m + 2 <= n - 1) ? up2[f] : up1[f];
+          slope_n = bound_slope(uc[f], up1[f], ukp2, hr_n);
+          el_next = bound_left(Vn[f], uc[f], up1[f], slope_n);
+          if ((el_next - erB) * (up1[f] - uc[f]) < 0.0) {      // check_discontinuous_edge_values :141-159
+            double u0_avg = 0.5 * (erB + el_next);
+            u0_avg = fmax(fmin(u0_avg, fmax(uc[f], up1[f])), fmin(uc[f], up1[f]));
+            erB = u0_avg; el_next = u0_avg;
+          }
+        }
+        double eL = elC[f], eR = erB;
+        if (m == 0 || m == n - 1) { eL = uc[f]; eR = uc[f]; }
+        else ppm_limit_cell(um1[f], uc[f], up1[f], eL, eR);
+        aL[f] = eL; aR[f] = eR; ucell[f] = uc[f];
+        elC[f] = el_next; slope_c[f] = slope_n;
+      }
+      hcell = hc;
+    }
+    // ---- h0_eff of this source cell (:560-620) by a look-ahead on copies of the supplies ----
+    {
+      double eff = 0., s0 = h0s, s1 = h1s;
+      bool t = tgt;
+      int jj = i1;
+      for (int it = 0; it < ns; it++) {
+        const double d = fmin(s0, s1);
+        eff = eff + fmin(d, s0);
+        if (s0 <= s1) break;
+        if (s0 >= s1 && t) {
+          s0 = s0 - d;
+          if (jj < n) { jj = jj + 1; s1 = H1(jj - 1); }      // (a register window of the next thicknesses was measured: 8 % slower)
+          else { s1 = 0.; t = false; }
+        } else break;
+      }
+      h0_eff_cur = eff;
+    }
+    // ---- the sub-cells of this source cell ----
+    for (int it = 0; it < ns && i_sub < ns; it++)
+      if (sub_cell()) break;
+    // ---- advance the windows ----
+    m_read = m + 4;
+    if (m + 1 < n) { i0 = m + 2; h0s = hp1; }
+    hm1 = hc; hc = hp1; hp1 = hp2; hp2 = hp3; hp3 = H0(m + 4);
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+      um1[f] = uc[f]; uc[f] = up1[f]; up1[f] = up2[f]; up2[f] = up3[f];
+      up3[f] = (m + 4 < n) ? fp[f][(long)(m + 4) * stride] : 0.0;
+    }
+  }
+  // ---- what is left of the target grid below the last source cell (:621-640) ----
+  for (int it = 0; it < ns && i_sub < ns; it++) sub_cell();
+  if (pend) finalize_pending(cand_uh);
+  // the layers that were written ahead of the reads
+  while (ahead_lo | ahead_hi) {
+    int kt;
+    if (ahead_lo) { kt = __ffsll((long long)ahead_lo) - 1; ahead_lo &= ahead_lo - 1; }
+    else { kt = 64 + __ffsll((long long)ahead_hi) - 1; ahead_hi &= ahead_hi - 1; }
+#pragma unroll
+    for (int f = 0; f < NF; f++) fp[f][(long)kt * stride] = a.side[a.side_stride * f + base + (long)kt * stride];
+  }
+}
+
 bool lane_per_column_env() {
   static const int v = [] { const char *e = getenv("MOM6HIP_ALE_LANE_PER_COLUMN"); return (e && e[0] == '1') ? 1 : 0; }();
   return v != 0;
@@ -1298,10 +1737,33 @@ bool lane_per_column() {
   return v != 0;
 }
 
-// the two launches of the wave-cooperative path over the compute range of the given staggering
+// MOM6HIP_ALE_STREAM: 0 = never the streaming kernel; 1 = one field a launch; 2 (default) = two fields a launch (read at every
+// call: the tests switch between the forms)
+int stream_fields() { const char *e = getenv("MOM6HIP_ALE_STREAM"); return e ? atoi(e) : 2; }
+
+// the two launches of the wave-cooperative path over the compute range of the given staggering -- or, for PPM_H4 without boundary
+// extrapolation on at least 6 layers, the streaming kernel (fields two at a time)
 int launch_wave_remap(mom6hip_ctx_t *ctx, WRemapArgs a) {
   const m6::GridDev &g = a.g;
   const int xs = (a.pos == MOM6HIP_POS_U) ? 1 : 0, ys = (a.pos == MOM6HIP_POS_V) ? 1 : 0;
+  const int nf_stream = stream_fields();
+  if (nf_stream > 0 && a.scheme == REMAP_PPM_H4 && !a.extrap && g.nk >= 6) {
+    const size_t fbytes = sizeof(double) * (size_t)(g.nih + 1) * (g.njh + 1) * g.nk;      // (covers every staggering)
+    M6_REQUIRE(ctx->ale_side.reserve(2 * fbytes) == 0, "ALE remap: out of device memory");
+    SRemapArgs sa;
+    sa.g = g; sa.h_old = a.h_old; sa.h_new = a.h_new; sa.fld = a.fld; sa.single = a.single; sa.cu = a.cu; sa.pos = a.pos;
+    sa.h_neglect = a.h_neglect; sa.h_neglect_edge = a.h_neglect_edge; sa.side = (double *)ctx->ale_side.p; sa.side_stride = (long)(fbytes / 8);
+    const int ncol = g.iec - g.isc + 1 + xs, nrow = g.jec - g.jsc + 1 + ys;
+    const dim3 grid((ncol + 63) / 64, nrow);
+    int f = 0;
+    while (f < a.nfld) {
+      sa.f0 = f;
+      if (nf_stream >= 2 && a.nfld - f >= 2 && a.fld) { hipLaunchKernelGGL(ale_remap_stream_kernel<2>, grid, dim3(64), 0, ctx->stream, sa); f += 2; }
+      else { hipLaunchKernelGGL(ale_remap_stream_kernel<1>, grid, dim3(64), 0, ctx->stream, sa); f += 1; }
+    }
+    M6_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t lds = wcol_bytes(g.nk) * WR_NCOL;
   M6_REQUIRE(lds <= 160 * 1024, "ALE remap: too many layers for the LDS-resident kernel");
   std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context

@@ -118,6 +118,7 @@ struct mom6hip_ctx {
   m6::HostTable tables[m6::TABLE_COUNT];      // cached device copies of short host tables (m6::HostTable)
   uint64_t xfer[4] = {0, 0, 0, 0};            // calls and bytes of mom6hip_sync_to_device, then of mom6hip_sync_to_host / stage_to_host
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
+  m6::DevBuf ale_side;          // the streaming remap kernel's side arrays (target cells below what a lane has read)
   std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)
   bool vv_ntrunc_ready = false;

@@ -388,6 +388,7 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &t : ctx->tables) t.buf.release();
   ctx->hv_pack.release(); ctx->hv_str.release();
   ctx->ale_sub.release();
+  ctx->ale_side.release();
   ctx->vv_ntrunc.release();
   ctx->efp_acc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);

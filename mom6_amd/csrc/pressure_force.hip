@@ -1095,7 +1095,10 @@ extern "C" int mom6hip_calculate_density(mom6hip_ctx_t *ctx, const mom6hip_eos_t
 }
 
 namespace {
-int pgf_fused_rows() { const char *e = getenv("MOM6HIP_PGF_FUSED"); return e ? atoi(e) : 4; }
+// 0 (default): the column / face pair; 3, 4 or 7: the fused kernel with that many rows a block.  Measured at 1440x1080x75 (round 4,
+// profiles/r04_pgf_fused.txt): pair 12.1 ms, fused 14.6 (3 rows) / 27.7 (4) / 17.2 (7) -- the fused form moves a third of the bytes but
+// its 168 VGPRs and the barrier a layer leave 2.25 productive waves a SIMD against the pair's 4, and this operator is bound by fp64 issue.
+int pgf_fused_rows() { const char *e = getenv("MOM6HIP_PGF_FUSED"); return e ? atoi(e) : 0; }
 }  // namespace
 
 extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs,
@@ -1166,7 +1169,7 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
   a.nkmb = use_EOS ? cs->nkmb : 0; a.P_Ref = cs->P_Ref;
   const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
   const dim3 gc((ncol_i + 63) / 64, ncol_j), gf((ncol_i - 1 + 63) / 64, ncol_j - 1);
-  // MOM6HIP_PGF_FUSED: 0 = the column / face pair through memory, 3, 4 (default) or 7 = the fused kernel with that many rows a block
+  // MOM6HIP_PGF_FUSED: 0 (default) = the column / face pair through memory, 3, 4 or 7 = the fused kernel with that many rows a block
   const int fused_rows = pgf_fused_rows();      // (read at every call: the tests switch between the forms)
   if (use_ALE && fused_rows > 0) {
     hipLaunchKernelGGL(pgf_e_kernel, gc, dim3(64), 0, s, a);

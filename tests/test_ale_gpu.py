@@ -53,6 +53,45 @@ def test_remap_tracers_parity(oracle, scheme, extrap, nk):
     dg.close()
 
 
+@pytest.mark.parametrize("form", ["0", "1", "2"])
+@pytest.mark.parametrize("nk", [6, 7, 20, 75, 100])
+def test_remap_stream_and_wave_kernels_agree(oracle, form, nk, monkeypatch):
+    """PPM_H4 without boundary extrapolation on >= 6 layers takes the streaming kernel (MOM6HIP_ALE_STREAM = 1: a field a launch, 2: two
+    fields a launch; 0: the wave-per-column kernel): the oracle's bits in every form -- random grids with vanished layers, columns whose
+    new grid runs far ahead of the old one (the values written to the side array) or far behind it, identical grids, z*-like shifts,
+    deeper and shallower targets, a conc_underflow"""
+    monkeypatch.setenv("MOM6HIP_ALE_STREAM", form)
+    g, h_old, h_new, tr = remap_case(70, 12, nk, ntr=5, seed=100 + nk)
+    rng = np.random.default_rng(nk)
+    H = h_old.sum(0)
+    hl = g.halo
+    # rows of special columns
+    j = hl + 1      # everything in the top layer of the old grid, a uniform new grid: the targets run ahead of the sources
+    h_old[:, j, :] = 0.0; h_old[0, j, :] = H[j, :]; h_new[:, j, :] = H[j, :] / nk
+    j = hl + 2      # the reverse: a uniform old grid, everything in the bottom layer of the new one
+    h_old[:, j, :] = H[j, :] / nk; h_new[:, j, :] = 0.0; h_new[nk - 1, j, :] = H[j, :]
+    j = hl + 3      # identical grids
+    h_new[:, j, :] = h_old[:, j, :]
+    j = hl + 4      # z*-like: the old grid stretched by a few per cent, vanished layers at the bottom
+    h_old[:, j, :] = np.linspace(2.0, 80.0, nk)[:, None]; h_old[nk - nk // 4:, j, :] = 1.0e-3
+    h_new[:, j, :] = h_old[:, j, :] * (1.0 + 0.03 * rng.standard_normal(h_old.shape[2]))[None, :]; h_new[nk - nk // 4:, j, :] = 1.0e-3
+    j = hl + 5      # thin targets in thick sources in the middle of the column, then the reverse
+    h_old[:, j, :] = 1.0e-9; h_old[nk // 3, j, :] = 50.0; h_old[2 * nk // 3, j, :] = 50.0
+    h_new[:, j, :] = (100.0 + nk * 1.0e-9) / nk
+    ref = [t.copy() for t in tr]
+    cu = [0.0, 0.0, 1.0e-2, 0.0, 0.3]
+    oracle.ale_remap_tracers(g, "PPM_H4", h_old, h_new, ref, conc_underflow=cu)
+    dg = DeviceGrid(g)
+    CS = initialize_remapping("PPM_H4")
+    d = [torch.from_numpy(t.copy()).cuda() for t in tr]
+    ALE_remap_tracers(CS, dg, torch.from_numpy(h_old).cuda(), torch.from_numpy(h_new).cuda(), d, conc_underflow=cu)
+    dg.sync()
+    for m in range(len(tr)):
+        got = d[m].cpu().numpy()
+        assert bits_equal(ref[m], got), (form, nk, m, np.argwhere(ref[m] != got)[:5])
+    dg.close()
+
+
 def test_remap_conserves_on_gpu(oracle):
     g, h_old, h_new, tr = remap_case(40, 10, 30, ntr=2, seed=4)
     h_new = h_new.copy(); h_new[:, 5, 6] /= 1.25; h_new[:, 6, 7] /= 0.8     # equal column totals again

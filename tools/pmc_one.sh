@@ -10,6 +10,7 @@ while [ "$1" != "--" ]; do GRPS+=("$1"); shift; done
 shift
 n=0
 for grp in "${GRPS[@]}"; do
+  echo "pmc_one: $TAG pass $n: $grp" | tee -a gpurun_out/pmc_${TAG}_progress.txt
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_${TAG}_$n -o p -- python3 "$@" > /tmp/pmc_${TAG}_$n.out 2> /tmp/pmc_${TAG}_$n.err
   python3 tools/rocpd_pmc.py $(find /tmp/pmc_${TAG}_$n -name "*.db" | head -n 1) > gpurun_out/pmc_${TAG}_$n.txt
   n=$((n+1))
