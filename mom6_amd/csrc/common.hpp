@@ -216,6 +216,12 @@ int set_viscous_BBL_dev(mom6hip_ctx *ctx, const mom6hip_set_visc_cs_t *cs, const
                         const double *T, const double *S, const mom6hip_eos_t *eos, double *bbl_thick_u, double *bbl_thick_v,
                         double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v);
 
+// the velocities of vertvisc_coef / vertvisc as the increment the RK2 step applies just before them:
+// u = mask2dCu * (u0 + dtv * (a1u [+ a2u])), v likewise (device pointers; a2u / a2v may be null)
+struct VelIncrement { const double *u0, *v0, *a1u, *a1v, *a2u, *a2v; double dtv; };
+int vertvisc_step_inc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *dz,
+                      const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, int32_t update_velocities,
+                      double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v, const VelIncrement *inc, int32_t memspace);
 // set_viscous_ML on device arrays (set_viscosity.hip); called by the split RK2 step at :592
 int set_viscous_ML_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
                        const double *T, const double *S, const mom6hip_eos_t *eos, const double *taux, const double *tauy,

@@ -241,9 +241,12 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   // Without viscosity hooks diffu = diffv = +0.0 everywhere (set by dyn_split_rk2_init): (a + 0.0) is a, except that
   // -0.0 + 0.0 = +0.0, so the array need not be read; and the first up, vp (:582-589) are only read by vertvisc_coef.
   const bool inviscid = (hk == nullptr) && (cs->hor_visc == nullptr);      // diffu = diffv = 0
+  // The library's own vertical viscosity forms the velocity increments of :582-589, :667-676 and :930-939 inside its coefficient
+  // sweep (m6::vertvisc_step_inc: the same expression on the same numbers), so the step's sweeps for them are not launched.
+  const bool vv_fused = VV && !(hk && (hk->visc_remnant_pred || hk->vertvisc));
   auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
     const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
-    const bool need_up = first_up && (!inviscid || VV);
+    const bool need_up = first_up && (!inviscid || VV) && !vv_fused;
     launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
       const long n = g.u3(I, j, k);
       double a = (CAu[n] + PFu[n]);
@@ -270,7 +273,9 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
       CALL(m6::set_viscous_ML_dev(ctx, cs->set_visc_CSp, u_inst, v_inst, h, T, S, cs->eqn_of_state, taux, tauy, cs->visc->ustar,
                                   (double *)cs->visc->nkml_visc_u, (double *)cs->visc->nkml_visc_v, dt));
     }
-    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+    const m6::VelIncrement inc1{u_inst, v_inst, u_bc, v_bc, nullptr, nullptr, dt};      // up = mask * (u + dt * u_bc_accel) :582-589
+    CALL(m6::vertvisc_step_inc(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v,
+                               vv_fused ? &inc1 : nullptr, D));
   }
   // pass_eta, pass_visc_rem :541 / :607-611 / :631: in flight behind btcalc and bt_mass_source, which read no halo (the reference
   // completes pass_visc_rem at :631 for the same reason: the continuity below forms fluxes in the rows of visc_rem's halo)
@@ -296,7 +301,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
 
   // up = u + dt_pred*(u_bc_accel + u_accel_bt) :663-676
   const double dt_pred = dt * cs->be;
-  {
+  if (!vv_fused) {
     const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
     launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
       const long n = g.v3(i, J, k);
@@ -310,8 +315,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (hk && hk->vertvisc) {   // vertvisc_coef, vertvisc, vertvisc_remnant :717-744
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, up, vp, h, dt_pred, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
-  } else if (VV) {            // :717-744
-    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+  } else if (VV) {            // :717-744, with the increment of :667-676 formed in the coefficient sweep
+    const m6::VelIncrement inc2{u_inst, v_inst, u_bc, v_bc, cs->u_accel_bt, cs->v_accel_bt, dt_pred};
+    CALL(m6::vertvisc_step_inc(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v,
+                               vv_fused ? &inc2 : nullptr, D));
   }
   // pass_visc_rem, pass_uvp :741-751 in flight behind the continuity's own rows (continuity_around_pass)
   CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz, 1));
@@ -349,7 +356,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
                       cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
                       nullptr, lf ? uh : nullptr, lf ? vh : nullptr, lf ? u_av : nullptr, lf ? v_av : nullptr, eta_av, D));
   launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :918
-  {   // u = u + dt*(u_bc_accel + u_accel_bt) :928-939
+  if (!vv_fused) {   // u = u + dt*(u_bc_accel + u_accel_bt) :928-939
     const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
     launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
       const long n = g.u3(I, j, k);
@@ -363,8 +370,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (hk && hk->vertvisc) {   // :974-994
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, u_inst, v_inst, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
-  } else if (VV) {            // :974-994
-    CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+  } else if (VV) {            // :974-994, with the increment of :930-939 formed in place in the coefficient sweep
+    const m6::VelIncrement inc3{u_inst, v_inst, u_bc, v_bc, cs->u_accel_bt, cs->v_accel_bt, dt};
+    CALL(m6::vertvisc_step_inc(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v,
+                               vv_fused ? &inc3 : nullptr, D));
   }
   launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
   CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz, 3));     // :991-1008

@@ -306,263 +306,6 @@ __global__ __launch_bounds__(64, PGF_FACE_OCC) void pgf_face_kernel(PgfArgs p) {
   }
 }
 
-// ======== the fused form of the PLM pair (round 4) =========================================================================
-// pgf_column_kernel streams seven intermediates out (e, T_t, T_b, S_t, S_b, dpa, intz_dpa: 8 GB at 1440x1080x75) and
-// pgf_face_kernel reads them straight back for three columns each (11.5 GB): 24.5 GB of traffic against 7.5 GB algorithmic.
-// The fused kernel keeps everything but e on the chip:
-//   pgf_e_kernel          per column, bottom-up: the interface heights e (their sums run against the top-down sums of pa, so one
-//                         of the two has to pass through memory) and eta;
-//   pgf_fused_kernel<R>   a block of R+1 waves owns R rows of 63 columns.  Wave r works on row j0+r: every lane forms its own
-//                         column's layer (PLM edge values with the rolling window, the 5 EOS evaluations of dpa / intz_dpa, pbce)
-//                         exactly as pgf_column_kernel does, hands the 8 numbers a neighbouring face needs to the lane WEST of it
-//                         through __shfl_down (the x face (I,j) lies between lanes l and l+1) and to the wave SOUTH of it through
-//                         a double-buffered LDS plane (the y face (i,J) between waves r and r+1; one barrier a layer), then
-//                         evaluates its two face integrals (15 + 15 EOS evaluations) and PFu / PFv as pgf_face_kernel does.
-//                         Lane 63 and wave R only supply columns (1.6 % + 1/R of the column work is done twice); a column's
-//                         running pa and the interface heights of the neighbours are carried by the face's own lane as before.
-// Same arithmetic in the same order as the pair: bit-identical results (tests/test_pressure_force.py runs both).
-__global__ __launch_bounds__(64) void pgf_e_kernel(PgfArgs p) {
-  const m6::GridDev &g = p.g;
-  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x;
-  const int j = g.jsc - 1 + blockIdx.y;
-  if (i > g.iec + 1) return;
-  const int nz = g.nk;
-  const long o2 = g.h2(i, j), pl = (long)g.nih * g.njh;
-  double ek = -g.bathyT[o2];      // :572 / :646-648, bottom-up
-  p.e[o2 + pl * nz] = ek;
-  for (int k = nz - 1; k >= 0; k--) {
-    ek = ek + p.h[o2 + pl * k] * g.H_to_Z;
-    p.e[o2 + pl * k] = ek;
-  }
-  if (p.eta) p.eta[o2] = ek * g.Z_to_H;      // :842
-}
-
-// 15 EOS evaluations across one face, the columns' values in registers (face_integral with its loads lifted out)
-struct FaceCol { double Tt, Tb, St, Sb, dpa, e_K, e_Kp1, bathy; };
-__device__ __forceinline__ double face_integral_r(const PgfArgs &p, const FaceCol &L, const FaceCol &R) {
-  const m6::GridDev &g = p.g;
-  const double G_e = g.g_Earth, GxRho = G_e * p.rho_ref, rho_ref = p.rho_ref;
-  const double C1_90 = 1.0 / 90.0;
-  double Ttl, Tbl, Ttr, Tbr, Stl, Sbl, Str, Sbr;
-  double hWght = (p.massw ? 1. : 0.) * max3(0., -L.bathy - R.e_K, -R.bathy - L.e_K);
-  if (hWght > 0.) {
-    const double hL = (L.e_K - L.e_Kp1) + g.dZ_subroundoff;
-    const double hR = (R.e_K - R.e_Kp1) + g.dZ_subroundoff;
-    const double rr = (hL - hR) / (hL + hR);
-    hWght = hWght * (rr * rr);
-    const double iDenom = 1. / (hWght * (hR + hL) + hL * hR);
-    Ttl = ((hWght * hR) * R.Tt + (hWght * hL + hR * hL) * L.Tt) * iDenom;
-    Ttr = ((hWght * hL) * L.Tt + (hWght * hR + hR * hL) * R.Tt) * iDenom;
-    Tbl = ((hWght * hR) * R.Tb + (hWght * hL + hR * hL) * L.Tb) * iDenom;
-    Tbr = ((hWght * hL) * L.Tb + (hWght * hR + hR * hL) * R.Tb) * iDenom;
-    Stl = ((hWght * hR) * R.St + (hWght * hL + hR * hL) * L.St) * iDenom;
-    Str = ((hWght * hL) * L.St + (hWght * hR + hR * hL) * R.St) * iDenom;
-    Sbl = ((hWght * hR) * R.Sb + (hWght * hL + hR * hL) * L.Sb) * iDenom;
-    Sbr = ((hWght * hL) * L.Sb + (hWght * hR + hR * hL) * R.Sb) * iDenom;
-  } else {
-    Ttl = L.Tt; Tbl = L.Tb; Ttr = R.Tt; Tbr = R.Tb;
-    Stl = L.St; Sbl = L.Sb; Str = R.St; Sbr = R.Sb;
-  }
-  double intz[5];
-  intz[0] = L.dpa; intz[4] = R.dpa;
-#pragma unroll
-  for (int m = 2; m <= 4; m++) {
-    const double w_left = 0.25 * (double)(5 - m), w_right = 1.0 - w_left;
-    const double dz_x = w_left * (L.e_K - L.e_Kp1) + w_right * (R.e_K - R.e_Kp1);
-    const double T1 = w_left * Ttl + w_right * Ttr, T5 = w_left * Tbl + w_right * Tbr;
-    const double S1 = w_left * Stl + w_right * Str, S5 = w_left * Sbl + w_right * Sbr;
-    double pn = -GxRho * ((w_left * L.e_K + w_right * R.e_K) - p.Z_ref);
-    double r[5];
-#pragma unroll
-    for (int n = 1; n <= 5; n++) {
-      if (n > 1) pn = pn + GxRho * 0.25 * dz_x;
-      double Tn, Sn;
-      if (n == 1) { Tn = T1; Sn = S1; }
-      else if (n == 5) { Tn = T5; Sn = S5; }
-      else {
-        const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
-        Sn = wt_t * S1 + wt_b * S5;
-        Tn = wt_t * T1 + wt_b * T5;
-      }
-      r[n - 1] = eos_density_anomaly(p.eos, Tn, Sn, pn, rho_ref);
-    }
-    intz[m - 1] = G_e * dz_x * (C1_90 * (7.0 * (r[0] + r[4]) + 32.0 * (r[1] + r[3]) + 12.0 * r[2]));
-  }
-  return C1_90 * (7.0 * (intz[0] + intz[4]) + 32.0 * (intz[1] + intz[3]) + 12.0 * intz[2]);
-}
-
-#ifndef PGF_FUSED_OCC
-#define PGF_FUSED_OCC 3      // waves per SIMD the register allocation aims at
-#endif
-__device__ __forceinline__ double shfl_east(double v) { return __shfl_down(v, 1, 64); }
-
-template <int ROWS>
-__global__ __launch_bounds__(64 * (ROWS + 1), PGF_FUSED_OCC) void pgf_fused_kernel(PgfArgs p) {
-  const m6::GridDev &g = p.g;
-  __shared__ double sh[2][ROWS][8][64];      // [buffer][row - 1][value][lane]: what the wave south of a row needs of it
-  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int i_raw = g.isc - 1 + blockIdx.x * 63 + lane;
-  const int j_raw = g.jsc - 1 + blockIdx.y * ROWS + r;
-  const bool in = (i_raw <= g.iec + 1) && (j_raw <= g.jec + 1);
-  const int i = i_raw <= g.iec + 1 ? i_raw : g.iec + 1, j = j_raw <= g.jec + 1 ? j_raw : g.jec + 1;      // lanes past the edge repeat it
-  const bool own_col = in && (lane < 63 || i_raw == g.iec + 1) && (r < ROWS || j_raw == g.jec + 1);
-  const bool do_x = in && lane < 63 && r < ROWS && i_raw <= g.iec && j_raw >= g.jsc && j_raw <= g.jec;
-  const bool do_y = in && lane < 63 && r < ROWS && i_raw >= g.isc && i_raw <= g.iec && j_raw <= g.jec;
-  const int nz = g.nk;
-  const long o2 = g.h2(i, j), pl = (long)g.nih * g.njh, plU = (long)(g.nih + 1) * g.njh, plV = (long)g.nih * (g.njh + 1);
-  const double h_neglect = g.H_subroundoff, I_Rho0 = 1.0 / g.Rho0;
-  const double G_e = g.g_Earth, rho_0 = p.rho_ref, rho_ref = p.rho_ref;
-  const double GxRho = G_e * rho_0;
-  const double C1_90 = 1.0 / 90.0;
-  const double Rho0xG = p.rho_ref * g.g_Earth, G_Rho0 = g.g_Earth / g.Rho0;
-  const double rg = p.rho_ref * g.g_Earth;
-
-  // ---- the column's own state (pgf_column_kernel) ----
-  const double bathy_c = g.bathyT[o2];
-  const double e_top = p.e[o2], e_bot = -bathy_c;
-  const double Ihtot = g.H_to_Z / ((e_top - e_bot) + g.dZ_subroundoff);
-  auto ld = [&](const double *a, int kk) -> double { return (kk >= 0 && kk < nz) ? a[o2 + pl * kk] : 0.0; };
-  double h_m = 0., h_c = ld(p.h, 0), h_p = ld(p.h, 1), h_q = ld(p.h, 2);
-  double T_m = 0., T_c = ld(p.T, 0), T_p = ld(p.T, 1), T_q = ld(p.T, 2);
-  double S_m = 0., S_c = ld(p.S, 0), S_p = ld(p.S, 1), S_q = ld(p.S, 2);
-  double sT_m = 0., sT_c = 0., sT_p = 0., sS_m = 0., sS_c = 0., sS_p = 0.;
-  if (nz >= 3) {
-    sT_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, T_c, T_p, T_q);
-    sS_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, S_c, S_p, S_q);
-  }
-  double e_K = e_top, pbce_prev = 0.0;
-
-  // ---- the two faces' state (pgf_face_kernel): the surface pressure anomaly of the three columns, the running integrals ----
-  double pa_c = rg * (e_top - p.Z_ref);
-  if (p.p_atm) pa_c = pa_c + p.p_atm[o2];
-  double pa_e = shfl_east(pa_c), ee_K = shfl_east(e_top);
-  const double bathy_e = shfl_east(bathy_c);
-  // the row north of this one: its surface values through the first LDS plane
-  if (r >= 1) { sh[0][r - 1][0][lane] = pa_c; sh[0][r - 1][1][lane] = e_top; sh[0][r - 1][2][lane] = bathy_c; }
-  __syncthreads();
-  double pa_n = 0., en_K = 0., bathy_n = 0.;
-  if (r < ROWS) { pa_n = sh[0][r][0][lane]; en_K = sh[0][r][1][lane]; bathy_n = sh[0][r][2][lane]; }
-  __syncthreads();
-  double intx_pa = 0.5 * (pa_c + pa_e), inty_pa = 0.5 * (pa_c + pa_n);
-  const double fx = do_x ? (2.0 * I_Rho0 * g.IdxCu[g.u2(i, j)]) : 0.0;
-  const double fy = do_y ? (2.0 * I_Rho0 * g.IdyCv[g.v2(i, j)]) : 0.0;
-  const long ou = g.u2(i, j), ov = g.v2(i, j);
-
-  for (int kk = 0; kk < nz; kk++) {
-    const long o3 = o2 + pl * kk;
-    // ---- ALE_PLM_edge_values :1549-1576 ----
-    FaceCol C;
-    if (kk >= 1 && kk <= nz - 2) {
-      const double mT = plm_monotonized_slope(T_m, T_c, T_p, sT_m, sT_c, sT_p);
-      C.Tt = T_c - 0.5 * mT; C.Tb = T_c + 0.5 * mT;
-      const double mS = plm_monotonized_slope(S_m, S_c, S_p, sS_m, sS_c, sS_p);
-      C.St = S_c - 0.5 * mS; C.Sb = S_c + 0.5 * mS;
-    } else if (p.boundary_extrap) {
-      if (kk == 0) {
-        const double mT = -plm_extrapolate_slope(h_p, h_c, h_neglect, T_p, T_c);
-        C.Tt = T_c - 0.5 * mT; C.Tb = T_c + 0.5 * mT;
-        const double mS = -plm_extrapolate_slope(h_p, h_c, h_neglect, S_p, S_c);
-        C.St = S_c - 0.5 * mS; C.Sb = S_c + 0.5 * mS;
-      } else {
-        const double mT = plm_extrapolate_slope(h_m, h_c, h_neglect, T_m, T_c);
-        C.Tt = T_c - 0.5 * mT; C.Tb = T_c + 0.5 * mT;
-        const double mS = plm_extrapolate_slope(h_m, h_c, h_neglect, S_m, S_c);
-        C.St = S_c - 0.5 * mS; C.Sb = S_c + 0.5 * mS;
-      }
-    } else {
-      C.Tt = T_c; C.Tb = T_c; C.St = S_c; C.Sb = S_c;
-    }
-    // ---- vertical integrals, MOM_density_integrals.F90:519-554 ----
-    const double e_Kp1 = p.e[o3 + pl];
-    const double dz = e_K - e_Kp1;
-    double r5[5];
-#pragma unroll
-    for (int n = 1; n <= 5; n++) {
-      const double wt_t = 0.25 * (double)(5 - n), wt_b = 1.0 - wt_t;
-      const double p5 = -GxRho * ((e_K - p.Z_ref) - 0.25 * (double)(n - 1) * dz);
-      const double S5 = wt_t * C.St + wt_b * C.Sb;
-      const double T5 = wt_t * C.Tt + wt_b * C.Tb;
-      r5[n - 1] = eos_density_anomaly(p.eos, T5, S5, p5, rho_ref);
-    }
-    const double rho_anom = C1_90 * (7.0 * (r5[0] + r5[4]) + 32.0 * (r5[1] + r5[3]) + 12.0 * r5[2]);
-    C.dpa = G_e * dz * rho_anom;
-    const double iz = 0.5 * G_e * (dz * dz) * (rho_anom - C1_90 * (16.0 * (r5[3] - r5[1]) + 7.0 * (r5[4] - r5[0])));
-    const double iz_c = iz * g.Z_to_H;      // MOM_PressureForce_FV.F90:772
-    C.e_K = e_K; C.e_Kp1 = e_Kp1; C.bathy = bathy_c;
-
-    // ---- Set_pbce_Bouss :702-729 ----
-    if (p.pbce) {
-      const double press = -Rho0xG * (e_K - p.Z_ref);
-      double pb;
-      if (kk == 0) {
-        const double rho_in_situ = eos_density(p.eos, T_c, S_c, press);
-        pb = G_Rho0 * (p.GFS_scale * rho_in_situ) * g.H_to_Z;
-      } else {
-        const double T_int = 0.5 * (T_m + T_c), S_int = 0.5 * (S_m + S_c);
-        double dR_dT, dR_dS;
-        eos_density_derivs(p.eos, T_int, S_int, press, dR_dT, dR_dS);
-        pb = pbce_prev + G_Rho0 * ((e_K - e_bot) * Ihtot) * (dR_dT * (T_c - T_m) + dR_dS * (S_c - S_m));
-      }
-      if (own_col) p.pbce[o3] = pb;
-      pbce_prev = pb;
-    }
-
-    // ---- hand the layer to the faces west and south of this column ----
-    const int b = kk & 1;
-    if (r >= 1) {
-      double (*o)[64] = sh[b][r - 1];
-      o[0][lane] = C.Tt; o[1][lane] = C.Tb; o[2][lane] = C.St; o[3][lane] = C.Sb;
-      o[4][lane] = C.dpa; o[5][lane] = iz_c; o[6][lane] = h_c; o[7][lane] = e_Kp1;
-    }
-    FaceCol E;
-    E.Tt = shfl_east(C.Tt); E.Tb = shfl_east(C.Tb); E.St = shfl_east(C.St); E.Sb = shfl_east(C.Sb);
-    E.dpa = shfl_east(C.dpa); E.e_K = ee_K; E.e_Kp1 = shfl_east(e_Kp1); E.bathy = bathy_e;
-    const double iz_e = shfl_east(iz_c), h_e = shfl_east(h_c);
-    __syncthreads();
-    // ---- PFu :794-802 ----
-    if (do_x) {
-      const double intx_dpa = face_integral_r(p, C, E);
-      p.PFu[ou + plU * kk] = (((pa_c * h_c + iz_c) - (pa_e * h_e + iz_e)) +
-                              ((h_e - h_c) * intx_pa - (E.e_Kp1 - e_Kp1) * intx_dpa * g.Z_to_H)) *
-                             (fx / ((h_c + h_e) + h_neglect));
-      intx_pa = intx_pa + intx_dpa;
-    }
-    pa_e = pa_e + E.dpa;
-    ee_K = E.e_Kp1;
-    // ---- PFv :803-811 ----
-    if (r < ROWS) {
-      const double (*n)[64] = sh[b][r];
-      FaceCol N;
-      N.Tt = n[0][lane]; N.Tb = n[1][lane]; N.St = n[2][lane]; N.Sb = n[3][lane];
-      N.dpa = n[4][lane]; N.e_K = en_K; N.e_Kp1 = n[7][lane]; N.bathy = bathy_n;
-      const double iz_n = n[5][lane], h_n = n[6][lane];
-      if (do_y) {
-        const double inty_dpa = face_integral_r(p, C, N);
-        p.PFv[ov + plV * kk] = (((pa_c * h_c + iz_c) - (pa_n * h_n + iz_n)) +
-                                ((h_n - h_c) * inty_pa - (N.e_Kp1 - e_Kp1) * inty_dpa * g.Z_to_H)) *
-                               (fy / ((h_c + h_n) + h_neglect));
-        inty_pa = inty_pa + inty_dpa;
-      }
-      pa_n = pa_n + N.dpa;
-      en_K = N.e_Kp1;
-    }
-    pa_c = pa_c + C.dpa;
-
-    // ---- advance the window ----
-    e_K = e_Kp1;
-    h_m = h_c; h_c = h_p; h_p = h_q; h_q = ld(p.h, kk + 3);
-    T_m = T_c; T_c = T_p; T_p = T_q; T_q = ld(p.T, kk + 3);
-    S_m = S_c; S_c = S_p; S_p = S_q; S_q = ld(p.S, kk + 3);
-    sT_m = sT_c; sT_c = sT_p; sS_m = sS_c; sS_c = sS_p;
-    if (kk + 2 <= nz - 2) {
-      sT_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, T_c, T_p, T_q);
-      sS_p = plm_slope_wa(h_c, h_p, h_q, h_neglect, S_c, S_p, S_q);
-    } else {
-      sT_p = 0.; sS_p = 0.;
-    }
-  }
-}
-
 // ---- ALE_PLM_edge_values (MOM_ALE.F90:1520-1579) of one 3-d scalar: the reconstruction above for a caller's own field ----
 struct PlmEdgeArgs { m6::GridDev g; const double *h, *Q; double *Q_t, *Q_b; int bdry_extrap; };
 __global__ __launch_bounds__(64) void plm_edge_kernel(PlmEdgeArgs p) {
@@ -1094,13 +837,6 @@ extern "C" int mom6hip_calculate_density(mom6hip_ctx_t *ctx, const mom6hip_eos_t
   return st.finish();
 }
 
-namespace {
-// 0 (default): the column / face pair; 3, 4 or 7: the fused kernel with that many rows a block.  Measured at 1440x1080x75 (round 4,
-// profiles/r04_pgf_fused.txt): pair 12.1 ms, fused 14.6 (3 rows) / 27.7 (4) / 17.2 (7) -- the fused form moves a third of the bytes but
-// its 168 VGPRs and the barrier a layer leave 2.25 productive waves a SIMD against the pair's 4, and this operator is bound by fp64 issue.
-int pgf_fused_rows() { const char *e = getenv("MOM6HIP_PGF_FUSED"); return e ? atoi(e) : 0; }
-}  // namespace
-
 extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_pressureforce_cs_t *cs,
                                               const mom6hip_eos_t *eos, const double *h, const double *T,
                                               const double *S, const double *p_atm, double *PFu, double *PFv,
@@ -1156,29 +892,18 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
   a.PFu = st.inout(PFu, bU); a.PFv = st.inout(PFv, bV); a.pbce = st.inout(pbce, bH); a.eta = st.inout(eta, bH2);
   a.e = (double *)st.scratch(bH + bH2);
   a.T_t = a.T_b = a.S_t = a.S_b = nullptr;
-  a.dpa = a.intz_dpa = nullptr;
-  const bool pgf_pair = pgf_fused_rows() == 0;
-  if (use_ALE && pgf_pair) {
+  if (use_ALE) {
     a.T_t = (double *)st.scratch(bH); a.T_b = (double *)st.scratch(bH);
     a.S_t = (double *)st.scratch(bH); a.S_b = (double *)st.scratch(bH);
   }
-  if (!use_ALE || pgf_pair) { a.dpa = (double *)st.scratch(bH); a.intz_dpa = (double *)st.scratch(bH); }
+  a.dpa = (double *)st.scratch(bH); a.intz_dpa = (double *)st.scratch(bH);
   if (st.failed()) return 1;
   a.rho_ref = cs->Rho0; a.Z_ref = cs->Z_ref; a.GFS_scale = cs->GFS_scale; a.za0 = nullptr; a.H_to_RZ = 0.0;
   a.boundary_extrap = cs->boundary_extrap; a.massw = cs->useMassWghtInterp;
   a.nkmb = use_EOS ? cs->nkmb : 0; a.P_Ref = cs->P_Ref;
   const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
   const dim3 gc((ncol_i + 63) / 64, ncol_j), gf((ncol_i - 1 + 63) / 64, ncol_j - 1);
-  // MOM6HIP_PGF_FUSED: 0 (default) = the column / face pair through memory, 3, 4 or 7 = the fused kernel with that many rows a block
-  const int fused_rows = pgf_fused_rows();      // (read at every call: the tests switch between the forms)
-  if (use_ALE && fused_rows > 0) {
-    hipLaunchKernelGGL(pgf_e_kernel, gc, dim3(64), 0, s, a);
-    const int R = fused_rows == 7 ? 7 : (fused_rows == 3 ? 3 : 4);
-    const dim3 gb((ncol_i - 1 + 62) / 63, (ncol_j - 1 + R - 1) / R);
-    if (R == 7) hipLaunchKernelGGL(pgf_fused_kernel<7>, gb, dim3(64 * 8), 0, s, a);
-    else if (R == 3) hipLaunchKernelGGL(pgf_fused_kernel<3>, gb, dim3(64 * 4), 0, s, a);
-    else hipLaunchKernelGGL(pgf_fused_kernel<4>, gb, dim3(64 * 5), 0, s, a);
-  } else if (use_ALE) {
+  if (use_ALE) {
     hipLaunchKernelGGL(pgf_column_kernel, gc, dim3(64), 0, s, a);
     hipLaunchKernelGGL(pgf_face_kernel, gf, dim3(64), 0, s, a);
   } else if (mode == PCM_LINEAR) {

@@ -40,7 +40,20 @@ struct CoefArgs {
   // the surface boundary layer of DYNAMIC_VISCOUS_ML / a bulk mixed layer (find_coupling_coef :2047-2252)
   const double *ustar, *nkml_visc;      // forces%ustar (h points), visc%nkml_visc_u or _v
   double *dzv;                          // scratch: dz_vel of every layer of the column (written bottom-up, read top-down)
+  // the velocity as the increment the RK2 step applies just before the call (MOM_dynamics_split_RK2.F90:582-589, :667-676, :930-939):
+  // vel = mask * (f_u0 + f_dt * (f_a1 [+ f_a2])) formed here instead of by a sweep of its own; f_u0 = null: vel is read as it is.
+  // f_store (the solve's x): where the sweep leaves the velocity for the solve (null: the velocities are not updated)
+  const double *f_u0, *f_a1, *f_a2;
+  double f_dt;
+  double *f_store;
 };
+
+// the velocity of layer k of the face column at f2: read, or formed from the step's increment (the reference's expression)
+__device__ __forceinline__ double coef_vel(const CoefArgs &A, long n, double mask) {
+  if (!A.f_u0) return A.vel[n];
+  const double acc = A.f_a2 ? (A.f_a1[n] + A.f_a2[n]) : A.f_a1[n];
+  return mask * (A.f_u0[n] + A.f_dt * acc);
+}
 
 // vertvisc_coef + find_coupling_coef for the face column (i, j); the caller has checked do_i
 template <int DIR>
@@ -62,6 +75,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
     I_Hbbl = 1.0 / bbl_thick;
   }
   const double hn = dz_neglect, I_amax = 0.0;                        // find_coupling_coef :1846, :1858
+  const double fmask = A.f_u0 ? (DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) : 0.0;
   auto DZ = [&](long c, int k) { return A.dz ? A.dz[c + hpl * k] : g.H_to_Z * A.h[c + hpl * k]; };
 
   // ---- KV_ML_INVZ2: the top-down viscosity profile :1873-1886, parked in a(K) ----
@@ -105,7 +119,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
       if (k >= 0) {
         b_h0[q] = A.h[c0 + hpl * k]; b_h1[q] = A.h[c1 + hpl * k];
         if (A.dz) { b_d0[q] = A.dz[c0 + hpl * k]; b_d1[q] = A.dz[c1 + hpl * k]; }
-        b_vel[q] = A.vel[f2 + fpl * k];
+        b_vel[q] = coef_vel(A, f2 + fpl * k, fmask);
         if (k + 1 < nz) {
           if (kvml) b_kvml[q] = A.a[f2 + fpl * (k + 1)];
           if (A.Kv_shear) b_ksh[q] = 0.5 * (A.Kv_shear[c0 + hpl * (k + 1)] + A.Kv_shear[c1 + hpl * (k + 1)]);
@@ -153,6 +167,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
       }
     }
     A.hv[f2 + fpl * k] = hvel + h_neglect;                           // :1510
+    if (A.f_store) A.f_store[f2 + fpl * k] = vel;                     // (the solve below reads it back: same lane)
     if (A.dzv) A.dzv[f2 + fpl * k] = dz_vel;
 
     // the interface below this layer, K = k+1 (find_coupling_coef :1948-2007 with hvel = dz_vel)
@@ -416,8 +431,26 @@ __global__ __launch_bounds__(64, VV_OCC) void vv_coef_solve_kernel(CoefArgs C, S
   const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
   if (i > g.iec) return;
   const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
-  if ((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0) coef_column<DIR>(C, i, j);
+  const double mask = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2];
+  if (mask > 0.0) coef_column<DIR>(C, i, j);
+  else if (C.f_u0 && C.f_store) {      // a masked column: the increment alone (0 * (...)), as the step's sweep would have left it
+    const long fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+    for (int k = 0; k < g.nk; k++) C.f_store[f2 + fpl * k] = coef_vel(C, f2 + fpl * k, mask);
+  }
   solve_column<DIR>(A, i, j);
+}
+
+// the increment as a sweep of its own, for the forms of the step that go through the separate entries
+template <int DIR>
+__global__ __launch_bounds__(256) void vv_increment_kernel(m6::GridDev g, const double *u0, const double *a1, const double *a2, double dtv,
+                                                           double *out) {
+  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 256 + threadIdx.x;
+  const int j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  if (i > g.iec) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const long n = f2 + (DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh) * blockIdx.z;
+  const double acc = a2 ? (a1[n] + a2[n]) : a1[n];
+  out[n] = (DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) * (u0[n] + dtv * acc);
 }
 
 struct LimitArgs {
@@ -523,7 +556,10 @@ extern "C" int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
   const Sz sz = sizes(g);
   m6::Stager st(ctx, memspace);
   CoefArgs A[2];
-  for (int d = 0; d < 2; d++) { A[d].ustar = A[d].nkml_visc = nullptr; A[d].dzv = nullptr; }
+  for (int d = 0; d < 2; d++) {
+    A[d].ustar = A[d].nkml_visc = nullptr; A[d].dzv = nullptr;
+    A[d].f_u0 = A[d].f_a1 = A[d].f_a2 = nullptr; A[d].f_dt = 0.0; A[d].f_store = nullptr;
+  }
   if (surface_bl) {
     const double *dus = st.in(visc->ustar, sz.h2);
     A[0].ustar = A[1].ustar = dus;
@@ -642,12 +678,31 @@ extern "C" int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
                                      const double *dz, const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc,
                                      double dt, int32_t update_velocities, double *taux_bot, double *tauy_bot, double *visc_rem_u,
                                      double *visc_rem_v, int32_t memspace) {
+  return m6::vertvisc_step_inc(ctx, cs, u, v, h, dz, taux, tauy, visc, dt, update_velocities, taux_bot, tauy_bot, visc_rem_u, visc_rem_v,
+                               nullptr, memspace);
+}
+
+// mom6hip_vertvisc_step with the velocities given as the increment of the RK2 step (inc, device pointers; null: u and v as they
+// are).  With update_velocities the incremented velocities are what u and v hold on entry of the reference's vertvisc_coef, so
+// they are stored to u and v before the solve reads them; without it they are only used.  u, v may be the increment's own u0, v0.
+int m6::vertvisc_step_inc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *dz,
+                          const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, int32_t update_velocities,
+                          double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v, const m6::VelIncrement *inc,
+                          int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(visc): Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && visc && visc_rem_u && visc_rem_v, "vertvisc_step: null argument");
   M6_REQUIRE(!update_velocities || (taux && tauy), "vertvisc_step: the wind stress is needed to update the velocities");
+  M6_REQUIRE(!inc || memspace == MOM6HIP_MEM_DEVICE, "vertvisc_step: the increment form works on device arrays");
   // the Rayleigh-drag bottom stress needs the separate truncation pass, the surface boundary layer of DYNAMIC_VISCOUS_ML / a
   // bulk mixed layer its own scratch: the plain sequence
   if (visc->Ray_u || visc->Ray_v || cs->dynamic_viscous_ML || cs->nkml > 0) {
+    if (inc) {      // the increment as its own sweep (into u and v: they are the step's work arrays when the velocities stay untouched)
+      const m6::GridDev gg = ctx->g;
+      const dim3 gu((gg.iec - gg.isc + 2 + 255) / 256, gg.jec - gg.jsc + 1, gg.nk), gv((gg.iec - gg.isc + 1 + 255) / 256, gg.jec - gg.jsc + 2, gg.nk);
+      hipLaunchKernelGGL(vv_increment_kernel<0>, gu, dim3(256), 0, ctx->stream, gg, inc->u0, inc->a1u, inc->a2u, inc->dtv, u);
+      hipLaunchKernelGGL(vv_increment_kernel<1>, gv, dim3(256), 0, ctx->stream, gg, inc->v0, inc->a1v, inc->a2v, inc->dtv, v);
+      M6_HIP(hipGetLastError());
+    }
     if (int rc = mom6hip_vertvisc_coef(ctx, cs, u, v, h, dz, visc, dt, memspace)) return rc;
     if (update_velocities)
       if (int rc = mom6hip_vertvisc(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, memspace)) return rc;
@@ -690,6 +745,11 @@ extern "C" int mom6hip_vertvisc_step(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
     CoefArgs C;
     C.g = g; C.p = par_of(cs); C.vel = x[d]; C.h = dh; C.dz = ddz; C.kv_bbl = kvb[d]; C.bbl_thick = bth[d]; C.Kv_shear = dks;
     C.a = a[d]; C.hv = hv[d]; C.ustar = C.nkml_visc = nullptr; C.dzv = nullptr;
+    C.f_u0 = C.f_a1 = C.f_a2 = nullptr; C.f_dt = 0.0; C.f_store = nullptr;
+    if (inc) {
+      C.f_u0 = d ? inc->v0 : inc->u0; C.f_a1 = d ? inc->a1v : inc->a1u; C.f_a2 = d ? inc->a2v : inc->a2u; C.f_dt = inc->dtv;
+      C.f_store = update_velocities ? x[d] : nullptr;
+    }
     SolveArgs A;
     A.g = g; A.p = C.p; A.a = a[d]; A.hv = hv[d]; A.Ray = nullptr; A.h = dh; A.tau = tau[d]; A.x = update_velocities ? x[d] : nullptr;
     A.xr = xr[d]; A.c1 = c1; A.tbot = tbot[d]; A.dt = dt; A.ntrunc = cnt;

@@ -65,7 +65,7 @@ type(MEKE_type), target :: MEKE
 type(VarMix_CS) :: VarMix
 type(thickness_diffuse_CS) :: TD
 type(mixedlayer_restrat_CS) :: MLE
-logical :: mle_on, td_on, done
+logical :: mle_on, td_on, done, lflag
 type(tracer_advect_CS), pointer :: ACS => NULL()
 type(tracer_hor_diff_CS), pointer :: DCS => NULL()
 type(tracer_registry_type), pointer :: Reg => NULL()
@@ -174,6 +174,25 @@ if (hdr2(8) /= 0) then      ! USE_MEKE with MEKE_VISCOSITY_COEFF_KU: MEKE%Ku as 
   allocate(MEKE%Ku(isd:ied,jsd:jed), MEKE%mom_src(isd:ied,jsd:jed), MEKE%GME_snk(isd:ied,jsd:jed))
   read(u_in) MEKE%Ku
   MEKE%mom_src(:,:) = 0.0 ; MEKE%GME_snk(:,:) = 1.0
+endif
+if (hdr(8) /= 0) then      ! the fields the modules beside the hot path hand to it (MOM_MEKE, MOM_lateral_mixing_coeffs: .testing/tc2, tc1)
+  allocate(MEKE%Kh(isd:ied,jsd:jed), VarMix%L2u(isd-1:ied,jsd:jed), VarMix%L2v(isd:ied,jsd-1:jed), VarMix%SN_u(isd-1:ied,jsd:jed), &
+           VarMix%SN_v(isd:ied,jsd-1:jed), VarMix%Res_fn_u(isd-1:ied,jsd:jed), VarMix%Res_fn_v(isd:ied,jsd-1:jed), &
+           VarMix%Res_fn_h(isd:ied,jsd:jed), VarMix%Rd_dx_h(isd:ied,jsd:jed), &
+           VarMix%slope_x(isd-1:ied,jsd:jed,nk+1), VarMix%slope_y(isd:ied,jsd-1:jed,nk+1))
+  read(u_in) MEKE%Kh, VarMix%L2u, VarMix%L2v, VarMix%SN_u, VarMix%SN_v, VarMix%Res_fn_u, VarMix%Res_fn_v, VarMix%Res_fn_h, VarMix%Rd_dx_h, &
+             VarMix%slope_x, VarMix%slope_y
+  call get_param(pf, "MOM", "USE_MEKE", lflag, default=.false.)
+  if (.not.lflag) deallocate(MEKE%Kh)
+  call get_param(pf, "MOM", "MEKE_KHTH_FAC", MEKE%KhTh_fac, default=0.0)      ! MOM_MEKE.F90: the factors default to zero
+  call get_param(pf, "MOM", "MEKE_KHTR_FAC", MEKE%KhTr_fac, default=0.0)
+  ! VarMix_init (MOM_lateral_mixing_coeffs.F90:1168-1300)
+  call get_param(pf, "MOM", "USE_VARIABLE_MIXING", VarMix%use_variable_mixing, default=.false.)
+  call get_param(pf, "MOM", "USE_VISBECK", VarMix%use_Visbeck, default=.false.)
+  call get_param(pf, "MOM", "RESOLN_SCALED_KH", VarMix%Resoln_scaled_Kh, default=.false.)
+  call get_param(pf, "MOM", "RESOLN_SCALED_KHTH", VarMix%Resoln_scaled_KhTh, default=.false.)
+  call get_param(pf, "MOM", "RESOLN_SCALED_KHTR", VarMix%Resoln_scaled_KhTr, default=.false.)
+  call get_param(pf, "MOM", "USE_STORED_SLOPES", VarMix%use_stored_slopes, default=.false.)
 endif
 close(u_in)
 call initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, pf, diag, CS, restart_CS, dt, ADp, CDp, MIS, VarMix, MEKE, TD, &

@@ -178,35 +178,6 @@ def test_gpu_parity(oracle, form, opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", ["3", "4", "7"])
-def test_gpu_pgf_kernel_forms_agree(oracle, rows, monkeypatch):
-    """MOM6HIP_PGF_FUSED: the fused kernel with 3, 4 or 7 rows a block gives the oracle's bits like the default (the column / face pair
-    through memory, test_gpu_parity): several blocks in x (63 columns each) and in y, ragged last blocks"""
-    import torch
-    from mom6_amd.pressure_force import PressureForce, PressureForce_init, EOS_init
-    from mom6_amd.tracer_advect import DeviceGrid
-    monkeypatch.setenv("MOM6HIP_PGF_FUSED", rows)
-    for (ni, nj, nk, topo, form, extrap, massw) in [(70, 21, 5, (True, False), "WRIGHT", True, False), (130, 9, 3, (True, False), "UNESCO", False, True),
-                                                    (61, 7, 4, (False, False), "LINEAR", True, True), (62, 8, 2, (True, True), "WRIGHT", False, True),
-                                                    (125, 16, 6, (True, False), "WRIGHT_FULL", True, True)]:
-        g, st = pgf_case(ni, nj, nk, seed=ni, reentrant_x=topo[0], reentrant_y=topo[1])
-        E = oracle.eos(form, 1000.0, -0.2, 0.8)
-        cs = oracle.pressureforce_cs(g, boundary_extrap=extrap, useMassWghtInterp=massw)
-        p_atm = np.ascontiguousarray(1.0e5 + 500.0 * np.random.default_rng(ni).standard_normal(g.shape2(_abi.POS_H)))
-        ref = oracle.pressureforce(g, cs, E, st["h"], st["T"], st["S"], p_atm)
-        dg = DeviceGrid(g)
-        CS = PressureForce_init(g, boundary_extrap=extrap, useMassWghtInterp=massw)
-        EOS = EOS_init(form, 1000.0, -0.2, 0.8)
-        X = lambda a: torch.from_numpy(a.copy()).cuda()
-        PFu, PFv, pbce, eta = X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V)), X(g.zeros3(_abi.POS_H)), X(g.zeros2(_abi.POS_H))
-        PressureForce(X(st["h"]), (X(st["T"]), X(st["S"]), EOS), PFu, PFv, dg, CS, p_atm=X(p_atm), pbce=pbce, eta=eta)
-        dg.sync()
-        for name, a, b in (("PFu", ref[0], PFu), ("PFv", ref[1], PFv), ("pbce", ref[2], pbce), ("eta", ref[3], eta)):
-            assert bits_equal(a, b.cpu().numpy()), (rows, (ni, nj, nk), form, name, np.argwhere(a != b.cpu().numpy())[:3])
-        dg.close()
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("extrap", [False, True])
 def test_gpu_ale_plm_edge_values(oracle, extrap):
     """ALE_PLM_edge_values / TS_PLM_edge_values (MOM_ALE.F90:1520, :1495) through the library == the oracle, host and device arrays"""

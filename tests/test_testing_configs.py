@@ -222,6 +222,32 @@ def meke_of(name, g):
     return Ku
 
 
+def lateral_fields(name, g):
+    """USE_MEKE / USE_VARIABLE_MIXING: what MOM_MEKE and MOM_lateral_mixing_coeffs (beside the hot path) hand to thickness_diffuse,
+    mixedlayer_restrat and tracer_hordiff through the reference's arguments -- MEKE%Kh, VarMix%L2u/v, SN_u/v, Res_fn_u/v/h, Rd_dx_h and the
+    stored slopes.  Synthetic, with valid halos.  None: the set uses neither."""
+    from oracle import orc
+    p = pairs_of(name)
+    if not (_b(p, "USE_MEKE") or _b(p, "USE_VARIABLE_MIXING")):
+        return None
+    rng = np.random.default_rng(77)
+    H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+    f = dict(MEKE_Kh=300.0 * rng.random(g.shape2(H)) * g.mask2dT,
+             L2u=4.0e8 * (0.2 + rng.random(g.shape2(U))), L2v=4.0e8 * (0.2 + rng.random(g.shape2(V))),
+             SN_u=1.0e-6 * rng.random(g.shape2(U)) * g.mask2dCu, SN_v=1.0e-6 * rng.random(g.shape2(V)) * g.mask2dCv,
+             Res_fn_u=rng.random(g.shape2(U)), Res_fn_v=rng.random(g.shape2(V)), Res_fn_h=rng.random(g.shape2(H)),
+             Rd_dx_h=0.2 + 2.0 * rng.random(g.shape2(H)),
+             slope_x=2.0e-3 * (rng.random((g.nk + 1,) + g.shape2(U)) - 0.5) * g.mask2dCu[None],
+             slope_y=2.0e-3 * (rng.random((g.nk + 1,) + g.shape2(V)) - 0.5) * g.mask2dCv[None])
+    f = {k: np.ascontiguousarray(v) for k, v in f.items()}
+    for k, pos in (("MEKE_Kh", H), ("L2u", U), ("L2v", V), ("SN_u", U), ("SN_v", V), ("Res_fn_u", U), ("Res_fn_v", V), ("Res_fn_h", H), ("Rd_dx_h", H)):
+        orc.halo_update(g, f[k], pos)
+    return f
+
+
+LATERAL_ORDER = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "Res_fn_h", "Rd_dx_h", "slope_x", "slope_y")
+
+
 def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
     """The oracle's control structures as the reference's *_init routines would set them from the pairs (defaults cited)."""
     from oracle import orc
@@ -296,7 +322,8 @@ def write_case(tmp, name, nsteps, resident, state, bbl_mode=0):
     use_ALE = _b(p, "USE_REGRIDDING")
     nkml, nkbl = (0, 0) if use_ALE else (2, 2)
     with open(tmp / "in.bin", "wb") as f:
-        np.array([g.ni, g.nj, g.nk, g.halo, int(_b(p, "REENTRANT_X", True)), 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        lat = lateral_fields(name, g)
+        np.array([g.ni, g.nj, g.nk, g.halo, int(_b(p, "REENTRANT_X", True)), 0, g.first_direction, int(lat is not None)], dtype="<i4").tofile(f)
         Ku = meke_of(name, g)
         np.array([nsteps, int(resident), 1, int(use_ALE), nkml + nkbl, nkml, bbl_mode, int(Ku is not None)], dtype="<i4").tofile(f)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, float(p["DT"])], dtype="<f8").tofile(f)
@@ -309,6 +336,9 @@ def write_case(tmp, name, nsteps, resident, state, bbl_mode=0):
                 np.ascontiguousarray(bbl[n], dtype="<f8").tofile(f)
         if Ku is not None:
             Ku.tofile(f)
+        if lat is not None:      # (read by cycle_driver.F90 only)
+            for k in LATERAL_ORDER:
+                np.ascontiguousarray(lat[k], dtype="<f8").tofile(f)
     with open(tmp / "params.txt", "w") as f:
         for k, v in p.items():
             f.write(f"{k} = {v}\n")
@@ -454,8 +484,28 @@ def cycle_oracle(name, state, ncycles, nsteps):
     dt, dt_therm = float(p["DT"]), float(p["DT_THERM"])
     st, calc, meta = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
     H = _abi.POS_H
-    tdcs = orc.thickness_diffuse_cs(g, Khth=float(p["KHTH"]), use_GM_work_bug=_b(p, "USE_GM_WORK_BUG"))
-    mlecs = orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0)
+    lat = lateral_fields(name, g)
+    varmix = _b(p, "USE_VARIABLE_MIXING")
+    tdf = {}
+    if lat is not None:      # what MOM_thickness_diffuse_hip.F90 hands the library from VarMix and MEKE (thickness_diffuse :133-330)
+        if _b(p, "USE_MEKE"):
+            tdf["MEKE_Kh"] = lat["MEKE_Kh"]
+        if varmix and _b(p, "USE_VISBECK") and _f(p, "KHTH_SLOPE_CFF", 0.0) > 0.0:
+            tdf.update({k: lat[k] for k in ("L2u", "L2v", "SN_u", "SN_v")})
+        if varmix and _b(p, "RESOLN_SCALED_KHTH"):
+            tdf.update(Res_fn_u=lat["Res_fn_u"], Res_fn_v=lat["Res_fn_v"])
+        if varmix and _b(p, "USE_STORED_SLOPES"):
+            tdf.update(slope_x=lat["slope_x"], slope_y=lat["slope_y"])
+    if meta["nkml"] > 0:
+        tdf["Rlay"] = Rlay
+    tdcs = orc.thickness_diffuse_cs(g, Khth=float(p["KHTH"]), Khth_Max=_f(p, "KHTH_MAX", 0.0), KHTH_Slope_Cff=_f(p, "KHTH_SLOPE_CFF", 0.0),
+                                    KhTh_fac=_f(p, "MEKE_KHTH_FAC", 0.0) if _b(p, "USE_MEKE") else 1.0, use_GM_work_bug=_b(p, "USE_GM_WORK_BUG", False),
+                                    nkml=meta["nkml"], use_variable_mixing=varmix, **tdf)
+    mlecs = orc.mixedlayer_restrat_cs(g, ml_restrat_coef=5.0, nkml=meta["nkml"])
+    hd_varmix = None
+    if varmix:      # tracer_hordiff :219-281: KHTR_SLOPE_CFF is not set in these sets; RESOLN_SCALED_KHTR scales with Res_fn_h
+        hd_varmix = dict(Res_fn_h=lat["Res_fn_h"]) if _b(p, "RESOLN_SCALED_KHTR") else {}
+    hd_meke = dict(Kh=lat["MEKE_Kh"], KhTr_fac=_f(p, "MEKE_KHTR_FAC", 0.0)) if (varmix and _b(p, "USE_MEKE")) else None
     for nc in range(ncycles):
         orc.thickness_diffuse(g, tdcs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, dt_therm)
         orc.halo_update(g, st.h, H)
@@ -465,7 +515,7 @@ def cycle_oracle(name, state, ncycles, nsteps):
         orc.mixedlayer_restrat(g, mlecs, st.h, st.uhtr, st.vhtr, st.T, st.S, st.E, ustar, dt_therm)
         orc.halo_update(g, st.h, H)
         orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, dt_therm, dt, "PPM:H3", [st.T, st.S])
-        orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0,
+        orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0, VarMix=hd_varmix, MEKE=hd_meke,
                            neutral=dict(eos=st.E, idx_T=0, idx_S=1) if _b(p, "USE_NEUTRAL_DIFFUSION") else None)
         st.uhtr[:] = 0.0; st.vhtr[:] = 0.0
         if _b(p, "TEST_ALE"):      # the ALE block of step_MOM_thermo (MOM.F90:1647-1700) with the parameters of CYCLE_ALE_PAIRS
@@ -529,3 +579,39 @@ def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_pat
     if resident and not with_ALE:
         n2 = n3 // g.nk
         assert stats["h2d_bytes"] <= 8 * (10 * n3 + 30 * n2) * 1.25 and stats["d2h_bytes"] <= 8 * (20 * n3 + 20 * n2) * 1.25, stats
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("name", ["tc2", "tc1"])
+def test_thermodynamic_cycle_with_the_tc2_and_tc1_sets(tmp_path, name, resident):
+    """The same composed cycle with the other two parameter sets: tc2 (MEKE%Kh with MEKE_KHTH_FAC, KHTH_MAX, the stored slopes of
+    USE_STORED_SLOPES in thickness_diffuse; the OM4 form of mixedlayer_restrat; DYNAMIC_VISCOUS_ML, CHANNEL_DRAG, MEKE viscosity in the steps)
+    and tc1 (no ALE: the bulk mixed layer -- mixedlayer_restrat_BML, the layered pressure force; the Visbeck term KHTH_SLOPE_CFF with VarMix%L2u /
+    SN_u and RESOLN_SCALED_KHTH / _KHTR with the resolution functions), the fields of MOM_MEKE / MOM_lateral_mixing_coeffs synthetic
+    (lateral_fields).  tc1's DIFFUSE_ML_TO_INTERIOR stays out (refused by the tracer_hor_diff shim)."""
+    cname = name + "c"
+    TC_INPUT[cname] = dict(shape=TC_INPUT[name]["shape"], pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS)
+    exe = build_cycle_driver(tmp_path)
+    state = case_state(cname)
+    g = state[0]
+    p = pairs_of(cname)
+    nsteps = int(round(float(p["DT_THERM"]) / float(p["DT"])))
+    want = cycle_oracle(cname, state, 2, nsteps)
+    write_case(tmp_path, cname, nsteps, resident, state, bbl_mode=1)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0 and "cycle_driver ok" in r.stdout, r.stderr[-1500:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    n3 = int(np.prod(g.shape3(_abi.POS_H)))
+    n2 = n3 // g.nk
+    if want.mom_src is not None:      # (written last: MEKE%mom_src of the last step)
+        mom_src, raw = raw[-n2:].reshape(g.shape2(_abi.POS_H)), raw[:-n2]
+        assert bits_equal(interior(g, mom_src, _abi.POS_H), interior(g, want.mom_src, _abi.POS_H))
+    T_, S_ = raw[-2 * n3:-n3].reshape(g.shape3(_abi.POS_H)), raw[-n3:].reshape(g.shape3(_abi.POS_H))
+    shapes = [g.shape3(pos) if nd == 3 else g.shape2(pos) for _, pos, nd in OUT]
+    got = {n: a.reshape(s) for (n, _, _), a, s in zip(OUT, np.split(raw[:-2 * n3], np.cumsum([int(np.prod(s)) for s in shapes])[:-1]), shapes)}
+    for n, pos in (("u", _abi.POS_U), ("v", _abi.POS_V), ("h", _abi.POS_H), ("uh", _abi.POS_U), ("vh", _abi.POS_V)):
+        assert bits_equal(interior(g, got[n], pos), interior(g, getattr(want, n), pos)), (name, n, float(np.abs(got[n] - getattr(want, n)).max()))
+    assert bits_equal(interior(g, T_), interior(g, want.T)) and bits_equal(interior(g, S_), interior(g, want.S)), name
+    assert "thickness_diffuse=1" in r.stdout and "mixedlayer_restrat=1" in r.stdout

@@ -16,7 +16,12 @@ ap.add_argument("--no-wind", action="store_true", help="zero wind stress: what t
 ap.add_argument("--uniform-ts", action="store_true", help="T and S replaced by their layer means: no baroclinic pressure gradients")
 ap.add_argument("--lateral", action="store_true", help="thickness_diffuse and mixedlayer_restrat in every thermodynamic cycle")
 ap.add_argument("--neutral", action="store_true", help="with --lateral: tracer_hordiff with USE_NEUTRAL_DIFFUSION")
+ap.add_argument("--ts-amp", type=float, default=None); ap.add_argument("--ts-decay", type=float, default=None)
+ap.add_argument("--umax", type=float, default=None); ap.add_argument("--u-noise", type=float, default=None)
 a = ap.parse_args()
+for k, v in (("ts_amp", a.ts_amp), ("ts_decay", a.ts_decay), ("umax", a.umax), ("u_noise", a.u_noise)):      # the bench's state, varied
+    if v is not None:
+        bench.STATE[k] = v
 NI, NJ, NK = bench.shape_of(a.workload)
 grid = synth.make_grid(NI, NJ, NK, seed=20241020, land_frac=a.land, rough_noise=bench.rough_noise(NI) if a.rough is None else a.rough)
 dom = Domain(NI, NJ, (1, 1), 0, grid.halo, grid.reentrant_x, grid.reentrant_y)
