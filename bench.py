@@ -90,6 +90,44 @@ def attach_exchange(dom, dg, device, exchange):
     return "python"
 
 
+def exchange_preflight(dom, dg, device, exchange):
+    """Before anything is timed on more than one GPU: one group pass of NaN-poisoned, rank-coded fields (h, u and v points, two layers)
+    through the exchange the run is going to use, compared bit for bit with the same pass through the torch.distributed callbacks (the
+    path the gloo layout tests cover).  Every rank takes the same decision (all_reduce of the verdict).  Returns a string for the
+    JSON line: "ok", or what failed."""
+    import torch.distributed as dist
+    if os.environ.get("MOM6HIP_BENCH_PREFLIGHT", "1") == "0" or dom.nranks == 1:
+        return "skipped"
+    g = dg.grid
+    dev = str(device)
+    fields, pos = [], [0, 1, 2]
+    for p_ in pos:
+        shp = (2,) + g.shape2(p_)
+        jj = torch.arange(shp[1], device=dev, dtype=torch.float64)[:, None] + dom.j0
+        ii = torch.arange(shp[2], device=dev, dtype=torch.float64)[None, :] + dom.i0
+        f = (1000.0 * jj + ii + 0.25 * p_)[None].repeat(2, 1, 1).contiguous()
+        f[1] += 0.5
+        h = g.halo
+        poisoned = torch.full_like(f, float("nan"))
+        xs = 1 if p_ == 1 else 0; ys = 1 if p_ == 2 else 0
+        poisoned[:, h:h + dom.nj + ys, h:h + dom.ni + xs] = f[:, h:h + dom.nj + ys, h:h + dom.ni + xs]
+        fields.append(poisoned)
+    ref = [f.clone() for f in fields]
+    was_native = getattr(dom, "native", False)
+    try:
+        dom.pass_var(fields, pos)                 # the exchange of the run
+        dom.native = False
+        dom.pass_var(ref, pos)                    # the callbacks
+    finally:
+        dom.native = was_native
+    torch.cuda.synchronize()
+    same = all(torch.equal(a.view(torch.int64), b.view(torch.int64)) for a, b in zip(fields, ref))
+    filled = all(bool(torch.isfinite(a[:, g.halo:g.halo + dom.nj, :g.halo]).all()) for a in fields[:1]) if g.reentrant_x or dom.npi > 1 else True
+    ok = torch.tensor([1 if (same and filled) else 0], device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return "ok" if int(ok.item()) == 1 else f"FAILED on some rank (rank {dom.rank}: same={same}, filled={filled})"
+
+
 def shape_of(name):
     from mom6_amd import synth
     if name in synth.CONFIGS:
@@ -653,6 +691,9 @@ def main():
     exchange = os.environ.get("MOM6HIP_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "python") if world > 1 else None
     M = Model(grid, dom, device, a.scheme, exchange=exchange)
     exchange = M.exchange
+    preflight = exchange_preflight(dom, M.dg, device, exchange) if world > 1 else "one tile"
+    if world > 1 and preflight not in ("ok", "skipped"):
+        sys.exit(f"bench.py: the halo exchange ({exchange}) failed its preflight on {world} ranks: {preflight}")
     LATERAL = os.environ.get("MOM6HIP_BENCH_LATERAL", "0") in ("1", "2")      # not the default: the workload of BASELINE.json does not call them
     NEUTRAL = os.environ.get("MOM6HIP_BENCH_LATERAL", "0") == "2"
     if LATERAL:
@@ -757,7 +798,7 @@ def main():
             "parallelism": "1 tile" if world == 1 else f"layout 1x{world}: {world} latitude bands, one per GPU, group passes "
                                                                + ("over RCCL send / recv inside the library (its communication stream)"
                                                                   if exchange == "rccl" else f"through torch.distributed callbacks ({backend})"),
-            "exchange": exch,
+            "exchange": exch, "exchange_preflight": preflight,
             # (row-split groups, continuity calls in two phases, passes completed before anything else ran, 0) of this rank, all steps
             "overlap_stats": list(M.dg.overlap_stats()),
         },

@@ -1,13 +1,15 @@
-// ale_remap.hip -- ALE vertical remapping of tracer columns (ALE_remap_tracers, src/ALE/MOM_ALE.F90:737-867)
-// as a gfx950 kernel: remapping_core_h (src/ALE/MOM_remapping.F90:160-201) = build_reconstructions_1d
-// (:257-386; PCM, PLM, PPM_H4, latest answer date) + remap_via_sub_cells (:463-852).
+// ale_remap.hip -- the ALE block of step_MOM_thermo (src/core/MOM.F90:1647-1700) as gfx950 kernels: ALE_regrid for z*
+// (MOM_regridding.F90:763-889), ALE_remap_set_h_vel (MOM_ALE.F90:870, :912) and the vertical remapping of tracers and velocities
+// (ALE_remap_tracers :737, ALE_remap_velocities :1061 = remapping_core_h, src/ALE/MOM_remapping.F90:160-201: build_reconstructions_1d
+// :257-386 + remap_via_sub_cells :463-852).
 //
-// Mapping: one lane per (i,j) column, 64 consecutive i per wavefront, so that every k-strided global
-// access (stride nih*njh) is a contiguous 512-byte row across the wave.  The column work arrays live in
-// per-lane scratch memory (the sub-cell merge is a serial, data-dependent walk over n0+n1+1 entries).
-// The sub-cell decomposition depends only on (h_old, h_new): it is built once per column and reused
-// for every tracer (the reference rebuilds it per tracer; the results are identical).
-// Algorithmic traffic: read h_old, h_new once + read/write each tracer = (16 + 16*ntr) B per cell.
+// Remapping has two forms, both with lanes along i so that every k-strided access is a contiguous row across the wave:
+//   ale_remap_stream_kernel<NF>   PPM_H4 without boundary extrapolation on >= 6 layers (the OM4-class setting): one lane per column,
+//                                 one top-down walk with a constant amount of state and no arrays (its header below);
+//   ale_sub_cells_kernel + ale_remap_wave_kernel   every scheme (PCM, PLM, PPM_H4, PPM_IH4, PPM_CW, the three HYBGEN ones), with
+//                                 or without extrapolation: the sub-cell structure per column, then one WAVE per column with the
+//                                 column's arrays in LDS.
+// Algorithmic traffic: read h_old, h_new once per launch + read/write each field = (16 / NF + 16) B per cell and field.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -66,57 +68,6 @@ __device__ double plm_extrapolate_slope(double h_l, double h_c, double h_neglect
   return 2.0 * (u_c - left_edge);
 }
 
-// Column storage: E(k,side) = E[side*NK + k], coef(k,d) = C[d*NK + k] with NK the compile-time capacity.
-template <int NK>
-struct Col {
-  double h0[NK], h1[NK], u0[NK];
-  double E[2 * NK], C[3 * NK];
-  double h_sub[2 * NK + 2], u_sub[2 * NK + 2], uh_sub[2 * NK + 2];
-  double h0_eff[NK + 1];
-  short isub_src[2 * NK + 3];
-  short isrc_start[NK + 1], isrc_end[NK + 1], isrc_max[NK + 1], itgt_start[NK + 1], itgt_end[NK + 1];
-  double tmp1[NK], tmp2[NK];   // slp / mslp
-};
-
-// PLM_reconstruction :190-260 (+ PLM_boundary_extrapolation :272-307)
-template <int NK>
-__device__ void plm_reconstruction(Col<NK> &c, int n, double h_neglect, bool extrap) {
-  const double almost_one = 1. - DBL_EPSILON;
-  double *slp = c.tmp1, *mslp = c.tmp2;
-  for (int k = 1; k < n - 1; k++)
-    slp[k] = plm_slope_wa(c.h0[k - 1], c.h0[k], c.h0[k + 1], h_neglect, c.u0[k - 1], c.u0[k], c.u0[k + 1]);
-  slp[0] = 0.; slp[n - 1] = 0.;
-  for (int k = 1; k < n - 1; k++)
-    mslp[k] = plm_monotonized_slope(c.u0[k - 1], c.u0[k], c.u0[k + 1], slp[k - 1], slp[k], slp[k + 1]);
-  mslp[0] = 0.; mslp[n - 1] = 0.;
-  const double *u = c.u0;
-  c.E[0] = u[0]; c.E[NK] = u[0]; c.C[0] = u[0]; c.C[NK] = 0.;
-  for (int k = 1; k < n - 1; k++) {
-    const double slope = mslp[k];
-    const double u_l = u[k] - 0.5 * slope;
-    const double u_r = u[k] + 0.5 * slope;
-    c.E[k] = u_l; c.E[NK + k] = u_r;
-    c.C[k] = u_l;
-    c.C[NK + k] = (u_r - u_l);
-    const double edge = c.C[NK + k] + c.C[k];
-    const double e_r = u[k + 1] - 0.5 * fsign(mslp[k + 1], slp[k + 1]);
-    if ((edge - u[k]) * (e_r - edge) < 0.) c.C[NK + k] = c.C[NK + k] * almost_one;
-  }
-  c.E[n - 1] = u[n - 1]; c.E[NK + n - 1] = u[n - 1]; c.C[n - 1] = u[n - 1]; c.C[NK + n - 1] = 0.;
-  if (extrap) {
-    double slope = -plm_extrapolate_slope(c.h0[1], c.h0[0], h_neglect, u[1], u[0]);
-    c.E[0] = u[0] - 0.5 * slope;
-    c.E[NK] = u[0] + 0.5 * slope;
-    c.C[0] = c.E[0];
-    c.C[NK] = c.E[NK] - c.E[0];
-    slope = plm_extrapolate_slope(c.h0[n - 2], c.h0[n - 1], h_neglect, u[n - 2], u[n - 1]);
-    c.E[n - 1] = u[n - 1] - 0.5 * slope;
-    c.E[NK + n - 1] = u[n - 1] + 0.5 * slope;
-    c.C[n - 1] = c.E[n - 1];
-    c.C[NK + n - 1] = c.E[NK + n - 1] - c.E[n - 1];
-  }
-}
-
 // ---- regrid_edge_values.F90 -----------------------------------------------------------------------
 // end_value_h4 :658-771
 __device__ void end_value_h4(const double dz[4], const double u[4], double Csys[4]) {
@@ -152,366 +103,6 @@ __device__ void end_value_h4(const double dz[4], const double u[4], double Csys[
   Csys[1] = (W12 * (u[1] - u[0]) + W22 * (u[2] - u[1])) + W32 * (u[3] - u[2]);
   Csys[2] = (W13 * (u[1] - u[0]) + W23 * (u[2] - u[1])) + W33 * (u[3] - u[2]);
   Csys[3] = (W14 * (u[1] - u[0]) + W24 * (u[2] - u[1])) + W34 * (u[3] - u[2]);
-}
-
-// edge_values_explicit_h4 :222-363 (answer_date >= 20190101); n >= 4
-template <int NK>
-__device__ void edge_values_explicit_h4(Col<NK> &c, int n, double hNeglect) {
-  const double hMinFrac = 1.e-5;
-  const double *h = c.h0, *u = c.u0;
-  for (int i = 2; i <= n - 2; i++) {
-    double h0 = h[i - 2], h1 = h[i - 1], h2 = h[i], h3 = h[i + 1];
-    if (h0 + h1 == 0.0 || h1 + h2 == 0.0 || h2 + h3 == 0.0) {
-      const double h_min = hMinFrac * fmax(hNeglect, (h0 + h1) + (h2 + h3));
-      h0 = fmax(h_min, h[i - 2]);
-      h1 = fmax(h_min, h[i - 1]);
-      h2 = fmax(h_min, h[i]);
-      h3 = fmax(h_min, h[i + 1]);
-    }
-    const double I_h12 = 1.0 / (h1 + h2);
-    const double I_den_et2 = 1.0 / (((h0 + h1) + h2) * (h0 + h1)); const double I_h012 = (h0 + h1) * I_den_et2;
-    const double I_den_et3 = 1.0 / ((h1 + (h2 + h3)) * (h2 + h3)); const double I_h123 = (h2 + h3) * I_den_et3;
-    const double et1 = (1.0 + (h1 * I_h012 + (h0 + h1) * I_h123)) * I_h12 * (h2 * (h2 + h3)) * u[i - 1] +
-                       (1.0 + (h2 * I_h123 + (h2 + h3) * I_h012)) * I_h12 * (h1 * (h0 + h1)) * u[i];
-    const double et2 = (h1 * (h2 * (h2 + h3)) * I_den_et2) * (u[i - 1] - u[i - 2]);
-    const double et3 = (h2 * (h1 * (h0 + h1)) * I_den_et3) * (u[i] - u[i + 1]);
-    c.E[i] = (et1 + (et2 + et3)) / ((h0 + h1) + (h2 + h3));
-    c.E[NK + i - 1] = c.E[i];
-  }
-  double dz[4], ut[4], C[4];
-  for (int i = 0; i < 4; i++) { dz[i] = fmax(hNeglect, h[i]); ut[i] = u[i]; }
-  end_value_h4(dz, ut, C);
-  c.E[0] = C[0];
-  c.E[NK] = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
-  c.E[1] = c.E[NK];
-  for (int i = 0; i < 4; i++) { dz[i] = fmax(hNeglect, h[n - 1 - i]); ut[i] = u[n - 1 - i]; }
-  end_value_h4(dz, ut, C);
-  c.E[NK + n - 1] = C[0];
-  c.E[n - 1] = C[0] + dz[0] * (C[1] + dz[0] * (C[2] + dz[0] * C[3]));
-  c.E[NK + n - 2] = c.E[n - 1];
-}
-
-// bound_edge_values :44-110 (new answers), check_discontinuous_edge_values :141-159,
-// PPM_limiter_standard (PPM_functions.F90:62-128), PPM_reconstruction (:28-57)
-template <int NK>
-__device__ void ppm_reconstruction(Col<NK> &c, int n) {
-  const double *h = c.h0, *u = c.u0;
-  double *EL = c.E, *ER = c.E + NK;
-  for (int k = 0; k < n; k++) {
-    const int km1 = (k - 1 > 0) ? k - 1 : 0, kp1 = (k + 1 < n - 1) ? k + 1 : n - 1;
-    double slope_x_h = 0.0;
-    if (((h[km1] + h[kp1]) + 2.0 * h[k]) > 0.0) {
-      const double sigma_l = (u[k] - u[km1]);
-      const double sigma_c = (u[kp1] - u[km1]) * (h[k] / ((h[km1] + h[kp1]) + 2.0 * h[k]));
-      const double sigma_r = (u[kp1] - u[k]);
-      if ((sigma_l * sigma_r) > 0.0) slope_x_h = fsign(min3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
-    }
-    if ((u[km1] - EL[k]) * (EL[k] - u[k]) < 0.0)
-      EL[k] = u[k] - fsign(fmin(fabs(slope_x_h), fabs(EL[k] - u[k])), slope_x_h);
-    if ((u[kp1] - ER[k]) * (ER[k] - u[k]) < 0.0)
-      ER[k] = u[k] + fsign(fmin(fabs(slope_x_h), fabs(ER[k] - u[k])), slope_x_h);
-    EL[k] = fmax(fmin(EL[k], fmax(u[km1], u[k])), fmin(u[km1], u[k]));
-    ER[k] = fmax(fmin(ER[k], fmax(u[kp1], u[k])), fmin(u[kp1], u[k]));
-  }
-  for (int k = 0; k < n - 1; k++) {
-    if ((EL[k + 1] - ER[k]) * (u[k + 1] - u[k]) < 0.0) {
-      double u0_avg = 0.5 * (ER[k] + EL[k + 1]);
-      u0_avg = fmax(fmin(u0_avg, fmax(u[k], u[k + 1])), fmin(u[k], u[k + 1]));
-      ER[k] = u0_avg;
-      EL[k + 1] = u0_avg;
-    }
-  }
-  for (int k = 1; k < n - 1; k++) {
-    const double u_l = u[k - 1], u_c = u[k], u_r = u[k + 1];
-    double edge_l = EL[k], edge_r = ER[k];
-    if ((u_r - u_c) * (u_c - u_l) <= 0.0) {
-      edge_l = u_c; edge_r = u_c;
-    } else {
-      const double expr1 = 3.0 * (edge_r - edge_l) * ((u_c - edge_l) + (u_c - edge_r));
-      const double expr2 = (edge_r - edge_l) * (edge_r - edge_l);
-      if (expr1 > expr2) {
-        edge_l = u_c + 2.0 * (u_c - edge_r);
-        edge_l = fmax(fmin(edge_l, fmax(u_l, u_c)), fmin(u_l, u_c));
-      } else if (expr1 < -expr2) {
-        edge_r = u_c + 2.0 * (u_c - edge_l);
-        edge_r = fmax(fmin(edge_r, fmax(u_r, u_c)), fmin(u_r, u_c));
-      }
-    }
-    if (fabs(edge_r - edge_l) < fmax(1.e-60, DBL_EPSILON * fabs(u_c))) { edge_l = u_c; edge_r = u_c; }
-    EL[k] = edge_l; ER[k] = edge_r;
-  }
-  EL[0] = u[0]; ER[0] = u[0];
-  EL[n - 1] = u[n - 1]; ER[n - 1] = u[n - 1];
-  for (int k = 0; k < n; k++) {
-    const double edge_l = EL[k], edge_r = ER[k];
-    c.C[k] = edge_l;
-    c.C[NK + k] = 4.0 * (u[k] - edge_l) + 2.0 * (u[k] - edge_r);
-    c.C[2 * NK + k] = 3.0 * ((edge_r - u[k]) + (edge_l - u[k]));
-  }
-}
-
-// PPM_boundary_extrapolation, PPM_functions.F90:162-316
-template <int NK>
-__device__ void ppm_boundary_extrapolation(Col<NK> &c, int n, double hNeglect) {
-  const double *h = c.h0, *u = c.u0;
-  double *EL = c.E, *ER = c.E + NK;
-  int i0 = 0, i1 = 1;
-  double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1];
-  double b = c.C[NK + i1];
-  double u1_r = b * ((h0 + hNeglect) / (h1 + hNeglect));
-  double slope = 2.0 * (u1 - u0);
-  if (fabs(u1_r) > fabs(slope)) u1_r = slope;
-  double u0_r = EL[i1];
-  double u0_l = 3.0 * u0 + 0.5 * u1_r - 2.0 * u0_r;
-  double exp1 = (u0_r - u0_l) * (u0 - 0.5 * (u0_l + u0_r));
-  double exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
-  if (exp1 > exp2) u0_l = 3.0 * u0 - 2.0 * u0_r;
-  if (exp1 < -exp2) u0_r = 3.0 * u0 - 2.0 * u0_l;
-  EL[i0] = u0_l; ER[i0] = u0_r;
-  c.C[i0] = u0_l;
-  c.C[NK + i0] = 6.0 * u0 - 4.0 * u0_l - 2.0 * u0_r;
-  c.C[2 * NK + i0] = 3.0 * (u0_r + u0_l - 2.0 * u0);
-
-  i0 = n - 2; i1 = n - 1;
-  h0 = h[i0]; h1 = h[i1]; u0 = u[i0]; u1 = u[i1];
-  b = c.C[NK + i0];
-  const double cc = c.C[2 * NK + i0];
-  double u1_l = (b + 2 * cc);
-  u1_l = u1_l * ((h1 + hNeglect) / (h0 + hNeglect));
-  slope = 2.0 * (u1 - u0);
-  if (fabs(u1_l) > fabs(slope)) u1_l = slope;
-  u0_l = ER[i0];
-  u0_r = 3.0 * u1 - 0.5 * u1_l - 2.0 * u0_l;
-  exp1 = (u0_r - u0_l) * (u1 - 0.5 * (u0_l + u0_r));
-  exp2 = (u0_r - u0_l) * (u0_r - u0_l) / 6.0;
-  if (exp1 > exp2) u0_l = 3.0 * u1 - 2.0 * u0_r;
-  if (exp1 < -exp2) u0_r = 3.0 * u1 - 2.0 * u0_l;
-  EL[i1] = u0_l; ER[i1] = u0_r;
-  c.C[i1] = u0_l;
-  c.C[NK + i1] = 6.0 * u1 - 4.0 * u0_l - 2.0 * u0_r;
-  c.C[2 * NK + i1] = 3.0 * (u0_r + u0_l - 2.0 * u1);
-}
-
-// build_reconstructions_1d, MOM_remapping.F90:257-386.  Returns the integration method.
-template <int NK>
-__device__ int build_reconstructions(Col<NK> &c, int scheme, bool extrap, int n0, double h_neglect, double h_neglect_edge) {
-  for (int k = 0; k < n0; k++) { c.E[k] = 0.; c.E[NK + k] = 0.; c.C[k] = 0.; c.C[NK + k] = 0.; c.C[2 * NK + k] = 0.; }
-  int local = scheme;
-  if (n0 <= 1) local = REMAP_PCM;
-  else if (n0 <= 3) local = (local < REMAP_PLM) ? local : REMAP_PLM;
-  else if (n0 <= 4) local = (local < REMAP_PPM_H4) ? local : REMAP_PPM_H4;
-  if (local == REMAP_PCM) {
-    for (int k = 0; k < n0; k++) { c.C[k] = c.u0[k]; c.E[k] = c.u0[k]; c.E[NK + k] = c.u0[k]; }
-    return INT_PCM;
-  } else if (local == REMAP_PLM) {
-    plm_reconstruction(c, n0, h_neglect, extrap);
-    return INT_PLM;
-  } else {
-    edge_values_explicit_h4(c, n0, h_neglect_edge);
-    ppm_reconstruction(c, n0);
-    if (extrap) ppm_boundary_extrapolation(c, n0, h_neglect);
-    return INT_PPM;
-  }
-}
-
-// average_value_ppoly, MOM_remapping.F90:998-1099
-template <int NK>
-__device__ double average_value_ppoly(const Col<NK> &c, int method, int i0, double xa, double xb) {
-  if (xb > xa) {
-    if (method == INT_PCM) return c.u0[i0];
-    if (method == INT_PLM) return (c.C[i0] + c.C[NK + i0] * 0.5 * (xb + xa));
-    const double mx = 0.5 * (xa + xb);
-    const double a_L = c.E[i0], a_R = c.E[NK + i0], u_c = c.u0[i0];
-    const double a_c = 0.5 * ((u_c - a_L) + (u_c - a_R));
-    if (mx < 0.5) {
-      const double xa2b2ab = (xa * xa + xb * xb) + xa * xb;
-      return a_L + ((a_R - a_L) * mx + a_c * (3. * (xb + xa) - 2. * xa2b2ab));
-    } else {
-      const double Ya = 1. - xa, Yb = 1. - xb;
-      const double my = 0.5 * (Ya + Yb);
-      const double Ya2b2ab = (Ya * Ya + Yb * Yb) + Ya * Yb;
-      return a_R + ((a_L - a_R) * my + a_c * (3. * (Yb + Ya) - 2. * Ya2b2ab));
-    }
-  } else {
-    if (method == INT_PCM) return c.C[i0];
-    const double a_L = c.E[i0], a_R = c.E[NK + i0];
-    const double Ya = 1. - xa;
-    if (method == INT_PLM) {
-      if (xa < 0.5) return a_L + xa * (a_R - a_L);
-      return a_R + Ya * (a_L - a_R);
-    }
-    const double u_c = c.u0[i0];
-    const double a_c = 3. * ((u_c - a_L) + (u_c - a_R));
-    if (xa < 0.5) return a_L + xa * ((a_R - a_L) + a_c * Ya);
-    return a_R + Ya * ((a_L - a_R) + a_c * xa);
-  }
-}
-
-// The (h0,h1)-only part of remap_via_sub_cells, MOM_remapping.F90:519-651 (1-based indices kept).
-template <int NK>
-__device__ int build_sub_cells(Col<NK> &c, int n0, int n1) {
-  int i0_last_thick_cell = 0;
-  for (int i0 = 1; i0 <= n0; i0++) if (c.h0[i0 - 1] > 0.) i0_last_thick_cell = i0;
-  double h0_supply = c.h0[0], h1_supply = c.h1[0];
-  bool src_has_volume = true, tgt_has_volume = true;
-  int i0 = 1, i1 = 1, i_start0 = 1, i_start1 = 1, i_max = 1;
-  double dh_max = 0., dh0_eff = 0.;
-  c.h_sub[1] = 0.;
-  c.isrc_start[1] = 1; c.isrc_end[1] = 1; c.isrc_max[1] = 1; c.isub_src[1] = 1;
-  const int ns = n0 + n1 + 1;
-  for (int i_sub = 2; i_sub <= ns; i_sub++) {
-    const double dh = fmin(h0_supply, h1_supply);
-    dh0_eff = dh0_eff + fmin(dh, h0_supply);
-    c.isub_src[i_sub] = (short)i0;
-    c.h_sub[i_sub] = dh;
-    if (dh >= dh_max) { i_max = i_sub; dh_max = dh; }
-    if (h0_supply <= h1_supply && src_has_volume) {
-      h1_supply = h1_supply - dh;
-      c.isrc_start[i0] = (short)i_start0; c.isrc_end[i0] = (short)i_sub; i_start0 = i_sub + 1;
-      c.isrc_max[i0] = (short)i_max; i_max = i_sub + 1; dh_max = 0.;
-      c.h0_eff[i0] = dh0_eff;
-      if (i0 < n0) { i0 = i0 + 1; h0_supply = c.h0[i0 - 1]; dh0_eff = 0.; }
-      else { h0_supply = 0.; src_has_volume = false; }
-    } else if (h0_supply >= h1_supply && tgt_has_volume) {
-      h0_supply = h0_supply - dh;
-      c.itgt_start[i1] = (short)i_start1; c.itgt_end[i1] = (short)i_sub; i_start1 = i_sub + 1;
-      if (i1 < n1) { i1 = i1 + 1; h1_supply = c.h1[i1 - 1]; }
-      else { h1_supply = 0.; tgt_has_volume = false; }
-    } else if (src_has_volume) {
-      c.h_sub[i_sub] = h0_supply;
-      c.isrc_start[i0] = (short)i_start0; c.isrc_end[i0] = (short)i_sub; i_start0 = i_sub + 1;
-      c.isrc_max[i0] = (short)i_max; i_max = i_sub + 1; dh_max = 0.;
-      c.h0_eff[i0] = dh0_eff;
-      if (i0 < n0) { i0 = i0 + 1; h0_supply = c.h0[i0 - 1]; dh0_eff = 0.; }
-      else { h0_supply = 0.; src_has_volume = false; }
-    } else if (tgt_has_volume) {
-      c.h_sub[i_sub] = h1_supply;
-      c.itgt_start[i1] = (short)i_start1; c.itgt_end[i1] = (short)i_sub; i_start1 = i_sub + 1;
-      if (i1 < n1) { i1 = i1 + 1; h1_supply = c.h1[i1 - 1]; }
-      else { h1_supply = 0.; tgt_has_volume = false; }
-    }
-    // the reference's final `else stop` cannot be reached: one of the four cases always holds
-  }
-  c.isub_src[ns + 1] = 0;
-  return i0_last_thick_cell;
-}
-
-// The field-dependent part of remap_via_sub_cells, :653-766, writing u1 into `out[k*stride]`
-// (force_bounds_in_subcell = .false.; adjust_thickest_subcell and force_bounds_in_target = .true.).
-template <int NK>
-__device__ void integrate_sub_cells(Col<NK> &c, int n0, int n1, int method, int i0_last_thick_cell,
-                                    double cu, double *out, long stride) {
-  const int ns = n0 + n1 + 1;
-  double xa = 0., xb, dh0_eff = 0.;
-  c.uh_sub[1] = 0.;
-  c.u_sub[1] = c.E[0];
-  for (int i_sub = 2; i_sub <= n0 + n1; i_sub++) {
-    const double dh = c.h_sub[i_sub];
-    const int i0 = c.isub_src[i_sub];
-    dh0_eff = dh0_eff + dh;
-    if (c.h0_eff[i0] > 0.) {
-      xb = dh0_eff / c.h0_eff[i0];
-      xb = fmin(1., xb);
-      c.u_sub[i_sub] = average_value_ppoly(c, method, i0 - 1, xa, xb);
-    } else {
-      xb = 1.;
-      c.u_sub[i_sub] = c.u0[i0 - 1];
-    }
-    c.uh_sub[i_sub] = dh * c.u_sub[i_sub];
-    if (c.isub_src[i_sub + 1] != i0) { dh0_eff = 0.; xa = 0.; }
-    else { xa = xb; }
-  }
-  c.u_sub[ns] = c.E[NK + n0 - 1];
-  c.uh_sub[ns] = c.E[NK + n0 - 1] * c.h_sub[ns];
-
-  for (int i0 = 1; i0 <= i0_last_thick_cell; i0++) {
-    const int i_max = c.isrc_max[i0];
-    const double dh_max = c.h_sub[i_max];
-    if (dh_max > 0.) {
-      double duh = 0.;
-      for (int i_sub = c.isrc_start[i0]; i_sub <= c.isrc_end[i0]; i_sub++)
-        if (i_sub != i_max) duh = duh + c.uh_sub[i_sub];
-      c.uh_sub[i_max] = c.u0[i0 - 1] * c.h0[i0 - 1] - duh;
-    }
-  }
-
-  for (int i1 = 1; i1 <= n1; i1++) {
-    double r;
-    if (c.h1[i1 - 1] > 0.) {
-      double duh = 0., dh = 0.;
-      int i_sub = c.itgt_start[i1];
-      double u1min = c.u_sub[i_sub], u1max = c.u_sub[i_sub];
-      for (i_sub = c.itgt_start[i1]; i_sub <= c.itgt_end[i1]; i_sub++) {
-        u1min = fmin(u1min, c.u_sub[i_sub]);
-        u1max = fmax(u1max, c.u_sub[i_sub]);
-        dh = dh + c.h_sub[i_sub];
-        duh = duh + c.uh_sub[i_sub];
-      }
-      r = duh / dh;
-      r = fmax(u1min, fmin(u1max, r));
-    } else {
-      r = c.u_sub[c.itgt_start[i1]];
-    }
-    // ALE_remap_tracers: conc_underflow, MOM_ALE.F90:812-814
-    if (cu > 0.0 && fabs(r) < cu) r = 0.0;
-    out[(long)(i1 - 1) * stride] = r;
-  }
-}
-
-struct RemapArgs {
-  m6::GridDev g;
-  const double *h_old, *h_new;
-  double *const *tr;          // device array of ntr pointers
-  const double *cu;           // device array of ntr underflow values (or null)
-  int ntr, scheme, extrap;
-  double h_neglect, h_neglect_edge;
-};
-
-template <int NK>
-__global__ __launch_bounds__(64) void ale_remap_tracers_kernel(RemapArgs a) {
-  const m6::GridDev &g = a.g;
-  const int i = g.isc + blockIdx.x * 64 + threadIdx.x;
-  const int j = g.jsc + blockIdx.y;
-  if (i > g.iec) return;
-  if (!(g.mask2dT[g.h2(i, j)] > 0.)) return;       // MOM_ALE.F90:799
-  const long base = g.h2(i, j), stride = (long)g.nih * g.njh;
-  const int nz = g.nk;
-  Col<NK> c;
-  for (int k = 0; k < nz; k++) { c.h0[k] = a.h_old[base + k * stride]; c.h1[k] = a.h_new[base + k * stride]; }
-  const int last_thick = build_sub_cells(c, nz, nz);
-  for (int m = 0; m < a.ntr; m++) {
-    double *t = a.tr[m] + base;
-    for (int k = 0; k < nz; k++) c.u0[k] = t[k * stride];
-    const int method = build_reconstructions(c, a.scheme, a.extrap != 0, nz, a.h_neglect, a.h_neglect_edge);
-    integrate_sub_cells(c, nz, nz, method, last_thick, a.cu ? a.cu[m] : 0.0, t, stride);
-  }
-}
-
-// ---- ALE_remap_velocities (MOM_ALE.F90:1061): the tracer kernel at velocity points -----------------------------
-struct VelRemapArgs {
-  m6::GridDev g;
-  const double *h_old, *h_new;   // h_old_u / h_new_u (DIR 0) or h_old_v / h_new_v (DIR 1)
-  double *vel;
-  int scheme, extrap, dir;
-  double h_neglect, h_neglect_edge;
-};
-
-template <int NK>
-__global__ __launch_bounds__(64) void ale_remap_velocity_kernel(VelRemapArgs a) {
-  const m6::GridDev &g = a.g;
-  const int i = (a.dir ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
-  const int j = (a.dir ? g.jsc - 1 : g.jsc) + blockIdx.y;
-  if (i > g.iec) return;
-  const long base = a.dir ? g.v2(i, j) : g.u2(i, j);
-  const long stride = a.dir ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
-  if (!((a.dir ? g.mask2dCv[base] : g.mask2dCu[base]) > 0.)) return;     // :1137, :1205
-  const int nz = g.nk;
-  Col<NK> c;
-  double *t = a.vel + base;
-  for (int k = 0; k < nz; k++) { c.h0[k] = a.h_old[base + k * stride]; c.h1[k] = a.h_new[base + k * stride]; c.u0[k] = t[k * stride]; }
-  const int last_thick = build_sub_cells(c, nz, nz);
-  const int method = build_reconstructions(c, a.scheme, a.extrap != 0, nz, a.h_neglect, a.h_neglect_edge);
-  integrate_sub_cells(c, nz, nz, method, last_thick, 0.0, t, stride);
 }
 
 // ---- ALE_regrid, z* (MOM_regridding.F90:763-889, :1174-1284; coord_zlike.F90:63-144) ------------------------------
@@ -1601,6 +1192,9 @@ __global__ __launch_bounds__(64, NF == 1 ? 4 : 3) void ale_remap_stream_kernel(S
         double eL = elC[f], eR = erB;
         if (m == 0 || m == n - 1) { eL = uc[f]; eR = uc[f]; }
         else ppm_limit_cell(um1[f], uc[f], up1[f], eL, eR);
+#if defined(SR_EXP) && SR_EXP == 2
+        eL = uc[f]; eR = uc[f];      // (experiment: no reconstruction)
+#endif
         aL[f] = eL; aR[f] = eR; ucell[f] = uc[f];
         elC[f] = el_next; slope_c[f] = slope_n;
       }
@@ -1622,6 +1216,9 @@ __global__ __launch_bounds__(64, NF == 1 ? 4 : 3) void ale_remap_stream_kernel(S
         } else break;
       }
       h0_eff_cur = eff;
+#if defined(SR_EXP) && SR_EXP == 1
+      h0_eff_cur = hcell;      // (experiment: no look-ahead)
+#endif
     }
     // ---- the sub-cells of this source cell ----
     for (int it = 0; it < ns && i_sub < ns; it++)
@@ -1647,11 +1244,6 @@ __global__ __launch_bounds__(64, NF == 1 ? 4 : 3) void ale_remap_stream_kernel(S
 #pragma unroll
     for (int f = 0; f < NF; f++) fp[f][(long)kt * stride] = a.side[a.side_stride * f + base + (long)kt * stride];
   }
-}
-
-bool lane_per_column_env() {
-  static const int v = [] { const char *e = getenv("MOM6HIP_ALE_LANE_PER_COLUMN"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v != 0;
 }
 
 struct WRemapArgs {
@@ -1724,17 +1316,10 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
   }
 }
 
-// PPM_IH4, PPM_CW and the three HYBGEN schemes exist in the wave-per-column kernel only
 bool scheme_provided(int scheme) {
   if (scheme == REMAP_PCM || scheme == REMAP_PLM || scheme == REMAP_PPM_H4) return true;
   return (scheme == REMAP_PPM_IH4 || scheme == REMAP_PPM_CW || scheme == REMAP_PLM_HYBGEN || scheme == REMAP_PPM_HYBGEN ||
-          scheme == REMAP_WENO_HYBGEN) && !lane_per_column_env();
-}
-
-// MOM6HIP_ALE_LANE_PER_COLUMN=1 selects the older lane-per-column kernels (kept for comparison runs)
-bool lane_per_column() {
-  static const int v = [] { const char *e = getenv("MOM6HIP_ALE_LANE_PER_COLUMN"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v != 0;
+          scheme == REMAP_WENO_HYBGEN);
 }
 
 // MOM6HIP_ALE_STREAM: 0 = never the streaming kernel; 1 = one field a launch; 2 (default) = two fields a launch (read at every
@@ -1830,22 +1415,12 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
   M6_HIP(hipMemcpyAsync(d_cu, cu.data(), ntr * sizeof(double), hipMemcpyHostToDevice, s));
   M6_HIP(hipStreamSynchronize(s));   // the tables above live on the host stack
 
-  RemapArgs a;
-  a.g = g; a.h_old = d_hold; a.h_new = d_hnew; a.tr = d_ptrs; a.cu = d_cu; a.ntr = ntr;
-  a.scheme = cs->remapping_scheme; a.extrap = cs->boundary_extrapolation;
-  // MOM_ALE.F90:770-771 (answer_date >= 20190101)
-  a.h_neglect = g.H_subroundoff; a.h_neglect_edge = g.H_subroundoff;
-  if (!lane_per_column()) {
+  {
     WRemapArgs w;
     w.g = g; w.h_old = d_hold; w.h_new = d_hnew; w.fld = d_ptrs; w.single = nullptr; w.cu = d_cu; w.nfld = ntr;
-    w.scheme = a.scheme; w.extrap = a.extrap; w.pos = MOM6HIP_POS_H; w.h_neglect = a.h_neglect; w.h_neglect_edge = a.h_neglect_edge;
+    w.scheme = cs->remapping_scheme; w.extrap = cs->boundary_extrapolation; w.pos = MOM6HIP_POS_H;
+    w.h_neglect = g.H_subroundoff; w.h_neglect_edge = g.H_subroundoff;      // MOM_ALE.F90:770-771 (answer_date >= 20190101)
     if (launch_wave_remap(ctx, w)) return 1;
-  } else {
-  dim3 grid((g.iec - g.isc + 1 + 63) / 64, g.jec - g.jsc + 1);
-  if (g.nk <= 8) hipLaunchKernelGGL(ale_remap_tracers_kernel<8>, grid, dim3(64), 0, s, a);
-  else if (g.nk <= 32) hipLaunchKernelGGL(ale_remap_tracers_kernel<32>, grid, dim3(64), 0, s, a);
-  else if (g.nk <= 80) hipLaunchKernelGGL(ale_remap_tracers_kernel<80>, grid, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(ale_remap_tracers_kernel<128>, grid, dim3(64), 0, s, a);
   }
   M6_HIP(hipGetLastError());
   if (memspace == MOM6HIP_MEM_HOST) {
@@ -1932,26 +1507,15 @@ extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_re
   M6_REQUIRE(g.nk <= 128 && g.mask2dCu && g.mask2dCv, "ALE_remap_velocities: at most 128 layers; face masks are needed");
   const size_t bu = sizeof(double) * (size_t)g.nu3(), bv = sizeof(double) * (size_t)g.nv3();
   m6::Stager st(ctx, memspace);
-  VelRemapArgs a[2];
-  a[0].h_old = st.in(h_old_u, bu); a[0].h_new = st.in(h_new_u, bu); a[0].vel = st.inout(u, bu); a[0].dir = 0;
-  a[1].h_old = st.in(h_old_v, bv); a[1].h_new = st.in(h_new_v, bv); a[1].vel = st.inout(v, bv); a[1].dir = 1;
+  const double *ho[2] = {st.in(h_old_u, bu), st.in(h_old_v, bv)}, *hn[2] = {st.in(h_new_u, bu), st.in(h_new_v, bv)};
+  double *vel[2] = {st.inout(u, bu), st.inout(v, bv)};
   M6_REQUIRE(!st.failed(), "ALE_remap_velocities: staging failed");
   for (int d = 0; d < 2; d++) {
-    a[d].g = g; a[d].scheme = cs->remapping_scheme; a[d].extrap = cs->boundary_extrapolation;
-    a[d].h_neglect = g.H_subroundoff; a[d].h_neglect_edge = g.H_subroundoff;      // :1118-1119
-    if (!lane_per_column()) {
-      WRemapArgs w;
-      w.g = g; w.h_old = a[d].h_old; w.h_new = a[d].h_new; w.fld = nullptr; w.single = a[d].vel; w.cu = nullptr; w.nfld = 1;
-      w.scheme = a[d].scheme; w.extrap = a[d].extrap; w.pos = d ? MOM6HIP_POS_V : MOM6HIP_POS_U;
-      w.h_neglect = a[d].h_neglect; w.h_neglect_edge = a[d].h_neglect_edge;
-      if (launch_wave_remap(ctx, w)) return 1;
-      continue;
-    }
-    dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
-    if (g.nk <= 8) hipLaunchKernelGGL(ale_remap_velocity_kernel<8>, grid, dim3(64), 0, ctx->stream, a[d]);
-    else if (g.nk <= 32) hipLaunchKernelGGL(ale_remap_velocity_kernel<32>, grid, dim3(64), 0, ctx->stream, a[d]);
-    else if (g.nk <= 80) hipLaunchKernelGGL(ale_remap_velocity_kernel<80>, grid, dim3(64), 0, ctx->stream, a[d]);
-    else hipLaunchKernelGGL(ale_remap_velocity_kernel<128>, grid, dim3(64), 0, ctx->stream, a[d]);
+    WRemapArgs w;
+    w.g = g; w.h_old = ho[d]; w.h_new = hn[d]; w.fld = nullptr; w.single = vel[d]; w.cu = nullptr; w.nfld = 1;
+    w.scheme = cs->remapping_scheme; w.extrap = cs->boundary_extrapolation; w.pos = d ? MOM6HIP_POS_V : MOM6HIP_POS_U;
+    w.h_neglect = g.H_subroundoff; w.h_neglect_edge = g.H_subroundoff;      // :1118-1119
+    if (launch_wave_remap(ctx, w)) return 1;
   }
   M6_HIP(hipGetLastError());
   return st.finish();

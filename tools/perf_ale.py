@@ -1,5 +1,5 @@
-"""Times the ALE remapping entries on the benchmark grid (device-resident).  MOM6HIP_ALE_LANE_PER_COLUMN=1 selects the
-older lane-per-column kernels for comparison."""
+"""Times the ALE remapping entries on the benchmark grid (device-resident).  MOM6HIP_ALE_STREAM = 0 / 1 / 2 selects the wave-per-column
+kernel or the streaming kernel with one or two fields a launch for PPM_H4."""
 import sys, json; sys.path.insert(0, '.')
 import torch
 from mom6_amd import synth, _abi
