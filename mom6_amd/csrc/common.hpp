@@ -114,6 +114,9 @@ struct mom6hip_ctx {
   m6::DevBuf cont_hmid;         // continuity in two phases around a pass in flight: the thicknesses after the first direction
   uint64_t overlap[4] = {0, 0, 0, 0};      // mom6hip_overlap_stats
   int cont_phase = 0;           // 0: the whole continuity; 1: what needs no halo row (before the completion); 2: the rest (after it)
+  bool cont_fluxes_only = false;   // the caller reads the transports and BT_cont of this continuity call but not its thicknesses (the RK2 step's
+                                   // first call, MOM_dynamics_split_RK2.F90:634: hp is rewritten by :757 before anything reads it): the second
+                                   // direction's convergence is not launched
   m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
   m6::HostTable tables[m6::TABLE_COUNT];      // cached device copies of short host tables (m6::HostTable)
   uint64_t xfer[4] = {0, 0, 0, 0};            // calls and bytes of mom6hip_sync_to_device, then of mom6hip_sync_to_host / stage_to_host

@@ -1204,6 +1204,7 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     }
     { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_X);
       if (launch_flux<0>(ctx, f, f.fi1 - f.fi0 + 1, jeh - jsh + 1)) return 1; }
+    if (!x_first && ctx->cont_fluxes_only) return 0;      // (the second direction's thicknesses are not wanted: see the context)
     ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = hdst; c.dt = dt; c.h_min = hmin;
     c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh; c.h2 = also; c.j2lo = js; c.j2hi = je;
     hipLaunchKernelGGL(cont_conv_kernel<0>, dim3((ie - is + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, c);
@@ -1226,7 +1227,7 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
       { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_Y);
         if (launch_flux<1>(ctx, f, ieh - ish + 1, f.fj1 - f.fj0 + 1)) return 1; }
     }
-    if (cj1 >= cj0) {
+    if (cj1 >= cj0 && !(x_first && ctx->cont_fluxes_only)) {
       ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
       c.i0 = ish; c.i1 = ieh; c.j0 = cj0; c.j1 = cj1;
       hipLaunchKernelGGL(cont_conv_kernel<1>, dim3((ieh - ish + 256) / 256, cj1 - cj0 + 1, g.nk), dim3(256), 0, s, c);

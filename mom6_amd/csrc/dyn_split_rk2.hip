@@ -285,10 +285,15 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));
   CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
   if (BTC || cs->BT_use_layer_fluxes) {
-    CALL(continuity_around_pass(ctx, [&]() -> int {
+    // (this call is made for uh_in, vh_in and BT_cont: the thicknesses it would leave in hp are rewritten by the call at :757 before
+    // anything reads them, so the convergence of its second direction is not launched)
+    ctx->cont_fluxes_only = true;
+    const int rc_c = continuity_around_pass(ctx, [&]() -> int {
       return mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,
                                 cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D);
-    }));
+    });
+    ctx->cont_fluxes_only = false;
+    if (rc_c) return rc_c;
     if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));
   } else {
     CALL(m6::complete_group_pass(ctx));
