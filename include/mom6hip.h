@@ -841,8 +841,10 @@ int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, 
  * fields come in mom6hip_hordiff_fields_t through mom6hip_tracer_hordiff_varmix.
  * USE_NEUTRAL_DIFFUSION (unsupported[0]) is taken by mom6hip_tracer_hordiff_neutral with its own control structure, and refused by
  * the two entry points that have none.
+ * DIFFUSE_ML_TO_INTERIOR (unsupported[2]) is taken by mom6hip_tracer_hordiff_epipycnal with its own control structure (round 4),
+ * and refused by the entry points that have none.
  * Not provided (refused by name, any nonzero `unsupported`): USE_HORIZONTAL_BOUNDARY_DIFFUSION,
- * DIFFUSE_ML_TO_INTERIOR (tracer_epipycnal_ML_diff), KHTR_USE_EBT_STRUCT, offline khdt arrays, the df_x / df_y flux diagnostics.
+ * KHTR_USE_EBT_STRUCT, offline khdt arrays, the df_x / df_y flux diagnostics.
  */
 typedef struct mom6hip_tracer_hor_diff_cs {
   double KhTr;             /* KHTR [L2 T-1] (0: tracer_hordiff returns at once unless use_variable_mixing) */
@@ -921,6 +923,34 @@ int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_
                                    const double *h, const mom6hip_eos_t *eos, const double *p_surf, double dt, double *const *tr,
                                    const double *conc_underflow, int32_t ntr, int32_t idx_T, int32_t idx_S, int32_t memspace,
                                    mom6hip_hordiff_stats_t *stats);
+
+/*
+ * DIFFUSE_ML_TO_INTERIOR (cs->unsupported[2], CS%Diffuse_ML_interior; .testing/tc1): tracer_hordiff scales the along-layer
+ * diffusion of the mixed layers (k <= GV%nkml) by ML_KHTR_SCALE, leaves the buffer layers out (:544-550), and then calls
+ * tracer_epipycnal_ML_diff (:700-1621) -- the coordinate density of the nk_rho_varies variable-density layers at tv%P_Ref, the
+ * density-sorted columns, the pairings of every face with their thicknesses, and for every tracer the limited fluxes between the
+ * paired layers -- with both forms of HOR_DIFF_ANSWER_DATE and HOR_DIFF_LIMIT_BUG.  The df2d_x / df2d_y diagnostics are not provided.
+ */
+typedef struct mom6hip_epipycnal_cs {
+  double ML_KhTr_scale;    /* ML_KHTR_SCALE (1.0) */
+  double P_Ref;            /* tv%P_Ref [R L2 T-2] */
+  double reserved0[4];
+  const double *Rlay;      /* GV%Rlay(1:nk) [R] (HOST array) */
+  int32_t nkml;            /* GV%nkml */
+  int32_t nk_rho_varies;   /* GV%nk_rho_varies (nkmb) */
+  int32_t answer_date;     /* HOR_DIFF_ANSWER_DATE (20240101): > 20240330 keeps the four faces' fluxes apart and sums them symmetrically */
+  int32_t limit_bug;       /* HOR_DIFF_LIMIT_BUG (1; read with answer_date <= 20240330) */
+  int32_t reserved1[4];
+} mom6hip_epipycnal_cs_t;
+
+/* tracer_hordiff with cs->unsupported[2] (CS%Diffuse_ML_interior) set.  tr[idx_T] and tr[idx_S] are tv%T and tv%S (registered
+ * tracers, diffused with the others; the coordinate density is formed from them after the along-layer diffusion), eos is
+ * tv%eqn_of_state.  The halo must be at least 2 points wide.  epi may be NULL when cs->unsupported[2] is 0: mom6hip_tracer_hordiff_varmix.
+ * USE_NEUTRAL_DIFFUSION with DIFFUSE_ML_TO_INTERIOR is refused as the reference refuses it (:1732). */
+int mom6hip_tracer_hordiff_epipycnal(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_epipycnal_cs_t *epi,
+                                     const mom6hip_hordiff_fields_t *fields, const double *h, const mom6hip_eos_t *eos, double dt,
+                                     double *const *tr, const double *conc_underflow, int32_t ntr, int32_t idx_T, int32_t idx_S,
+                                     int32_t memspace, mom6hip_hordiff_stats_t *stats);
 
 /* ---- MOM_hor_visc ----------------------------------------------------------------------------- */
 

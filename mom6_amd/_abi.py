@@ -176,6 +176,12 @@ class NeutralDiffusionCS(C.Structure):
                 ("recalc_neutral_surf", C.c_int32), ("initialized", C.c_int32), ("interior_only", C.c_int32), ("unsupported", C.c_int32 * 8)]
 
 
+class EpipycnalCS(C.Structure):
+    """mom6hip_epipycnal_cs_t (include/mom6hip.h)."""
+    _fields_ = [("ML_KhTr_scale", C.c_double), ("P_Ref", C.c_double), ("reserved0", C.c_double * 4), ("Rlay", C.c_void_p), ("nkml", C.c_int32),
+                ("nk_rho_varies", C.c_int32), ("answer_date", C.c_int32), ("limit_bug", C.c_int32), ("reserved1", C.c_int32 * 4)]
+
+
 class HorDiffStats(C.Structure):
     _fields_ = [("num_itts", C.c_int32), ("halo_updates", C.c_int32), ("max_CFL", C.c_double)]
 

@@ -1,5 +1,7 @@
 // tracer_hor_diff.hip -- tracer_hordiff (src/tracer/MOM_tracer_hor_diff.F90:119-680) as gfx950 kernels: the along-layer diffusion
-// with KHTR or the VarMix / MEKE diffusivities, and the call of the neutral-diffusion branch (neutral_diffusion.hip).
+// with KHTR or the VarMix / MEKE diffusivities, the call of the neutral-diffusion branch (neutral_diffusion.hip), and with
+// DIFFUSE_ML_TO_INTERIOR the scaled / skipped variable-density layers (:544-550) and the call of tracer_epipycnal_ML_diff
+// (epipycnal_diff.hip).
 //
 //   hd_khdt_kernel    khdt_x, khdt_y (:340-351), their MAX_TR_DIFFUSION_CFL limit (:368-398) and, with CHECK_DIFFUSIVE_CFL,
 //                     the largest diffusive CFL number (:410-416; an atomic max on the bit pattern of positive doubles)
@@ -35,7 +37,22 @@ struct HDArgs {
   const double *cu;        // conc_underflow per tracer (device) or null
   unsigned long long *cfl_bits;
   int ntr, check_cfl;
+  int nkml, nkmb;          // CS%Diffuse_ML_interior: GV%nkml, GV%nk_rho_varies (nkmb = 0: not in use)
+  double ML_KhTr_scale;
 };
+
+// the scale of layer k (0-based) :543-550; false: the layer is left out of the along-layer diffusion
+__device__ __forceinline__ bool hd_layer_scale(const HDArgs &A, int k, double &scale) {
+  scale = A.scale;
+  if (A.nkmb > 0) {
+    if (k + 1 <= A.nkml) {
+      if (A.ML_KhTr_scale <= 0.0) return false;
+      scale = A.scale * A.ML_KhTr_scale;
+    }
+    if ((k + 1 > A.nkml) && (k + 1 <= A.nkmb)) return false;
+  }
+  return true;
+}
 
 // the diffusivity of a face with variable mixing :236-281 (c0, c1: the cells either side; f: the face)
 __device__ __forceinline__ double hd_Kh_face(const HDArgs &A, long c0, long c1, long f, bool dir) {
@@ -96,7 +113,9 @@ __global__ __launch_bounds__(256) void hd_step_kernel(HDArgs A) {
   const int I = i, J = j;
   const long kH = (long)g.nih * g.njh * k;
   const double *h = A.h + kH;
-  const double h_neglect = g.H_subroundoff, scale = A.scale;
+  const double h_neglect = g.H_subroundoff;
+  double scale;
+  if (!hd_layer_scale(A, k, scale)) return;
   const double hc = h[g.h2(i, j)], hw = h[g.h2(i - 1, j)], he = h[g.h2(i + 1, j)], hs = h[g.h2(i, j - 1)], hn = h[g.h2(i, j + 1)];
   // Coef_x(I-1,j), Coef_x(I,j), Coef_y(i,J-1), Coef_y(i,J) :552-561
   const double CxW = ((scale * A.khdt_x[g.u2(I - 1, j)]) * 2.0 * (hw * hc)) / (hw + hc + h_neglect);
@@ -118,8 +137,10 @@ __global__ __launch_bounds__(256) void hd_commit_kernel(HDArgs A) {
   const int i = g.isc + blockIdx.x * blockDim.x + threadIdx.x, j = g.jsc + blockIdx.y, k = blockIdx.z;
   if (i > g.iec) return;
   const long n = (long)g.nih * g.njh * k + g.h2(i, j);
+  double scale;
+  const bool stepped = hd_layer_scale(A, k, scale);      // a layer that was left out has no work copy: only the underflow applies
   for (int m = 0; m < A.ntr; m++) {
-    double x = A.work[m][n];
+    double x = stepped ? A.work[m][n] : A.tr[m][n];
     if (A.cu && A.cu[m] > 0.0 && fabs(x) < A.cu[m]) x = 0.0;
     A.tr[m][n] = x;
   }
@@ -142,22 +163,50 @@ extern "C" int mom6hip_tracer_hordiff_varmix(mom6hip_ctx_t *ctx, const mom6hip_t
 }
 
 namespace m6 {
+int epipycnal_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_epipycnal_cs_t *epi, const mom6hip_eos_t *eos, const double *h,
+                     const double *khdt_x, const double *khdt_y, int num_itts, const std::vector<double *> &d_tr,
+                     const std::vector<double> &cu, int idx_T, int idx_S, int *halo_updates);
 int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusion_cs_t *nd, const mom6hip_eos_t *eos, const double *h,
                    const double *p_surf, const double *h_ML, const double *khdt_x, const double *khdt_y, int num_itts, double I_numitts,
                    const std::vector<double *> &d_tr, const std::vector<double> &cu, int idx_T, int idx_S, int *halo_updates);
 }
 
+static int hordiff_impl(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_neutral_diffusion_cs_t *nd,
+                        const mom6hip_epipycnal_cs_t *epi, const mom6hip_hordiff_fields_t *F, const double *h, const mom6hip_eos_t *eos,
+                        const double *p_surf, double dt, double *const *tr, const double *conc_underflow, int32_t ntr, int32_t idx_T,
+                        int32_t idx_S, int32_t memspace, mom6hip_hordiff_stats_t *stats);
+
 extern "C" int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_neutral_diffusion_cs_t *nd,
                                               const mom6hip_hordiff_fields_t *F, const double *h, const mom6hip_eos_t *eos, const double *p_surf,
                                               double dt, double *const *tr, const double *conc_underflow, int32_t ntr, int32_t idx_T,
                                               int32_t idx_S, int32_t memspace, mom6hip_hordiff_stats_t *stats) {
+  M6_REQUIRE(cs != nullptr, "tracer_hordiff: null argument");
+  M6_REQUIRE(!cs->unsupported[2], "tracer_hordiff: DIFFUSE_ML_TO_INTERIOR is not provided by this entry point (mom6hip_tracer_hordiff_epipycnal takes it)");
+  return hordiff_impl(ctx, cs, nd, nullptr, F, h, eos, p_surf, dt, tr, conc_underflow, ntr, idx_T, idx_S, memspace, stats);
+}
+
+extern "C" int mom6hip_tracer_hordiff_epipycnal(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_epipycnal_cs_t *epi,
+                                                const mom6hip_hordiff_fields_t *F, const double *h, const mom6hip_eos_t *eos, double dt,
+                                                double *const *tr, const double *conc_underflow, int32_t ntr, int32_t idx_T, int32_t idx_S,
+                                                int32_t memspace, mom6hip_hordiff_stats_t *stats) {
+  M6_REQUIRE(cs != nullptr, "tracer_hordiff: null argument");
+  M6_REQUIRE(!cs->unsupported[0], "MOM_tracer_hor_diff: USE_NEUTRAL_DIFFUSION and DIFFUSE_ML_TO_INTERIOR are mutually exclusive!");      // :1732
+  M6_REQUIRE(!cs->unsupported[2] || epi != nullptr, "tracer_hordiff: DIFFUSE_ML_TO_INTERIOR needs its control structure (mom6hip_epipycnal_cs_t)");
+  return hordiff_impl(ctx, cs, nullptr, cs->unsupported[2] ? epi : nullptr, F, h, eos, nullptr, dt, tr, conc_underflow, ntr, idx_T, idx_S, memspace, stats);
+}
+
+static int hordiff_impl(mom6hip_ctx_t *ctx, const mom6hip_tracer_hor_diff_cs_t *cs, const mom6hip_neutral_diffusion_cs_t *nd,
+                        const mom6hip_epipycnal_cs_t *epi, const mom6hip_hordiff_fields_t *F, const double *h, const mom6hip_eos_t *eos,
+                        const double *p_surf, double dt, double *const *tr, const double *conc_underflow, int32_t ntr, int32_t idx_T,
+                        int32_t idx_S, int32_t memspace, mom6hip_hordiff_stats_t *stats) {
   static const char *names[8] = {"USE_NEUTRAL_DIFFUSION", "USE_HORIZONTAL_BOUNDARY_DIFFUSION", "DIFFUSE_ML_TO_INTERIOR",
                                  "(free)", "(free)", "KHTR_USE_EBT_STRUCT", "offline khdt (do_online = false)",
                                  "the df_x / df_y flux diagnostics"};
   M6_REQUIRE(ctx != nullptr, "MOM_tracer_hor_diff: register_tracer must be called before tracer_hordiff.");
   M6_REQUIRE(cs != nullptr && h != nullptr, "tracer_hordiff: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "tracer_hordiff: bad memspace");
-  for (int q = 1; q < 8; q++) M6_REQUIRE(!cs->unsupported[q], "tracer_hordiff: %s is not provided by libmom6hip", names[q]);
+  for (int q = 1; q < 8; q++) M6_REQUIRE(q == 2 || !cs->unsupported[q], "tracer_hordiff: %s is not provided by libmom6hip", names[q]);
+  M6_REQUIRE(!cs->unsupported[2] || epi != nullptr, "tracer_hordiff: %s is not provided by this entry point", names[2]);
   const bool use_neutral = cs->unsupported[0] != 0;      // CS%use_neutral_diffusion
   if (stats) { stats->num_itts = 0; stats->halo_updates = 0; stats->max_CFL = 0.0; }
   const bool use_VarMix = cs->use_variable_mixing != 0;
@@ -178,6 +227,7 @@ extern "C" int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_
   HDArgs A;
   A.g = g; A.KhTr = cs->KhTr; A.max_diff_CFL = cs->max_diff_CFL; A.dt = dt; A.ntr = ntr; A.check_cfl = cs->check_diffusive_CFL;
   A.h = st.in(h, bH);
+  A.nkml = epi ? epi->nkml : 0; A.nkmb = epi ? epi->nk_rho_varies : 0; A.ML_KhTr_scale = epi ? epi->ML_KhTr_scale : 1.0;
   A.use_VarMix = use_VarMix; A.use_Eady = use_Eady; A.Resoln_scaled = Resoln_scaled;
   A.KhTr_Slope_Cff = cs->KhTr_Slope_Cff; A.KhTr_fac = cs->KhTr_fac; A.KhTr_min = cs->KhTr_min; A.KhTr_max = cs->KhTr_max;
   A.pass_coeff = use_VarMix ? cs->KhTr_passivity_coeff : 0.0; A.pass_min = cs->KhTr_passivity_min;
@@ -252,9 +302,13 @@ extern "C" int mom6hip_tracer_hordiff_neutral(mom6hip_ctx_t *ctx, const mom6hip_
     hipLaunchKernelGGL(hd_commit_kernel, dim3((ni + 255) / 256, nj, g.nk), dim3(256), 0, s, A);
   }
   M6_HIP(hipGetLastError());
+  if (epi) {      // :613-620
+    if (int rc = m6::epipycnal_branch(ctx, st, epi, eos, A.h, A.khdt_x, A.khdt_y, num_itts, d_tr, cu, idx_T, idx_S, &halo_updates)) return rc;
+  }
   if (stats) { stats->num_itts = num_itts; stats->halo_updates = halo_updates; stats->max_CFL = max_CFL; }
   return st.finish();
 }
 
 extern "C" uint64_t mom6hip_abi_sizeof_tracer_hor_diff_cs(void) { return sizeof(mom6hip_tracer_hor_diff_cs_t); }
+extern "C" uint64_t mom6hip_abi_sizeof_epipycnal_cs(void) { return sizeof(mom6hip_epipycnal_cs_t); }
 extern "C" uint64_t mom6hip_abi_sizeof_hordiff_stats(void) { return sizeof(mom6hip_hordiff_stats_t); }

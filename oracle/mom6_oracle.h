@@ -60,6 +60,11 @@ int orc_tracer_hordiff_varmix(const mom6hip_grid_t *G, const mom6hip_tracer_hor_
                               mom6hip_hordiff_stats_t *stats);
 int orc_tracer_hordiff(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const double *h, double dt,
                        double *const *tr, const double *conc_underflow, int ntr, mom6hip_hordiff_stats_t *stats);
+/* tracer_hordiff with CS%Diffuse_ML_interior (CS->unsupported[2]) and tracer_epipycnal_ML_diff */
+int orc_tracer_hordiff_epipycnal(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS, const mom6hip_epipycnal_cs_t *EP,
+                                 const mom6hip_hordiff_fields_t *F, const double *h, const mom6hip_eos_t *eos, double dt,
+                                 double *const *tr, const double *conc_underflow, int ntr, int idx_T, int idx_S,
+                                 mom6hip_hordiff_stats_t *stats);
 /* tracer_hordiff with CS%use_neutral_diffusion (CS->unsupported[0]); tr[idx_T], tr[idx_S] are tv%T, tv%S */
 int orc_tracer_hordiff_neutral(const mom6hip_grid_t *G, const mom6hip_tracer_hor_diff_cs_t *CS,
                                const mom6hip_neutral_diffusion_cs_t *ND, const mom6hip_hordiff_fields_t *F, const double *h,

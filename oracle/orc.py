@@ -465,7 +465,7 @@ def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy,
 
 
 def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL=False, conc_underflow=None, VarMix=None, MEKE=None, KhTr_Slope_Cff=0.0,
-                   KhTr_min=0.0, KhTr_max=0.0, KhTr_passivity_coeff=0.0, KhTr_passivity_min=0.5, neutral=None):
+                   KhTr_min=0.0, KhTr_max=0.0, KhTr_passivity_coeff=0.0, KhTr_passivity_min=0.5, neutral=None, epipycnal=None):
     """tracer_hordiff (along-layer; constant KHTR, or with VarMix / MEKE the face diffusivities of :236-281) on numpy arrays; tr updated
     in place.  VarMix: None or a dict with any of L2u, L2v, SN_u, SN_v, Res_fn_h (its presence is Resoln_scaled_KhTr), Rd_dx_h; MEKE: None
     or a dict with Kh and KhTr_fac.  Returns the stats struct."""
@@ -499,11 +499,29 @@ def tracer_hordiff(grid, h, dt, tr, KhTr, max_diff_CFL=-1.0, check_diffusive_CFL
         ps = None if ps is None else np.ascontiguousarray(ps, dtype=np.float64)
         rc = L.orc_tracer_hordiff_neutral(C.byref(grid.struct()), C.byref(cs), C.byref(nd), C.byref(F), _p(h), C.byref(neutral["eos"]), _p(ps),
                                           float(dt), trp, _p(cu), ntr, int(neutral.get("idx_T", 0)), int(neutral.get("idx_S", 1)), C.byref(st))
+    elif epipycnal is not None:      # DIFFUSE_ML_TO_INTERIOR: dict(eos=, Rlay=, nkml=, nk_rho_varies=, [idx_T, idx_S, ML_KhTr_scale, P_Ref, answer_date, limit_bug])
+        L.orc_tracer_hordiff_epipycnal.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.TracerHorDiffCS), C.POINTER(_abi.EpipycnalCS),
+                                                   C.POINTER(_abi.HorDiffFields), _dp, C.POINTER(_abi.EOS), C.c_double, C.POINTER(_dp), _dp,
+                                                   C.c_int, C.c_int, C.c_int, C.POINTER(_abi.HorDiffStats)]
+        cs.unsupported[2] = 1
+        ep = epipycnal_cs(**{k: v for k, v in epipycnal.items() if k not in ("eos", "idx_T", "idx_S")})
+        rc = L.orc_tracer_hordiff_epipycnal(C.byref(grid.struct()), C.byref(cs), C.byref(ep), C.byref(F), _p(h), C.byref(epipycnal["eos"]),
+                                            float(dt), trp, _p(cu), ntr, int(epipycnal.get("idx_T", 0)), int(epipycnal.get("idx_S", 1)), C.byref(st))
     else:
         rc = L.orc_tracer_hordiff_varmix(C.byref(grid.struct()), C.byref(cs), C.byref(F), _p(h), float(dt), trp, _p(cu), ntr, C.byref(st))
     if rc:
         raise RuntimeError(f"orc_tracer_hordiff rc={rc}")
     return st
+
+
+def epipycnal_cs(Rlay, nkml, nk_rho_varies, ML_KhTr_scale=1.0, P_Ref=2.0e7, answer_date=20240101, limit_bug=True):
+    """mom6hip_epipycnal_cs_t as tracer_hor_diff_init (:1687-1727) and the vertical grid leave it; Rlay is kept alive on the struct"""
+    ep = _abi.EpipycnalCS()
+    ep._Rlay = np.ascontiguousarray(Rlay, dtype=np.float64)
+    ep.Rlay = ep._Rlay.ctypes.data
+    ep.nkml, ep.nk_rho_varies, ep.ML_KhTr_scale, ep.P_Ref = int(nkml), int(nk_rho_varies), float(ML_KhTr_scale), float(P_Ref)
+    ep.answer_date, ep.limit_bug = int(answer_date), int(bool(limit_bug))
+    return ep
 
 
 def neutral_diffusion_cs(grid, ref_pres=-1.0, ndiff_answer_date=20240101, recalc_neutral_surf=False, H_to_RZ=None):

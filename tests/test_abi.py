@@ -33,7 +33,7 @@ def test_struct_layout_matches():
                  ("pressureforce_cs", _abi.PressureForceCS), ("barotropic_cs", _abi.BarotropicCS),
                  ("dyn_split_rk2_cs", _abi.DynSplitRK2CS), ("vertvisc_cs", _abi.VertviscCS), ("vertvisc_type", _abi.VertviscType),
                  ("hor_visc_cs", _abi.HorViscCS), ("set_visc_cs", _abi.SetViscCS),
-                 ("tracer_hor_diff_cs", _abi.TracerHorDiffCS), ("hordiff_stats", _abi.HorDiffStats), ("energy_sums", _abi.EnergySums)):
+                 ("tracer_hor_diff_cs", _abi.TracerHorDiffCS), ("hordiff_stats", _abi.HorDiffStats), ("epipycnal_cs", _abi.EpipycnalCS), ("energy_sums", _abi.EnergySums)):
         f = getattr(L, f"mom6hip_abi_sizeof_{n}"); f.restype = C.c_uint64
         assert f() == C.sizeof(t), n
 
