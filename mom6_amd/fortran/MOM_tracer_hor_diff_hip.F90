@@ -6,8 +6,11 @@
 !! RESOLN_SCALED_KHTR with VarMix%Res_fn_h, KHTR_PASSIVITY_COEFF / _MIN with VarMix%Rd_dx_h) on the GPU through libmom6hip
 !! (mom6hip_tracer_hordiff_varmix, HOST memspace), and with USE_NEUTRAL_DIFFUSION the continuous branch of MOM_neutral_diffusion
 !! (neutral_diffusion_init :138, neutral_diffusion_calc_coeffs :337, neutral_diffusion :605: NDIFF_REF_PRES, NDIFF_ANSWER_DATE,
-!! RECALC_NEUTRAL_SURF, NDIFF_INTERIOR_ONLY with visc%h_ML; mom6hip_tracer_hordiff_neutral).  NDIFF_CONTINUOUS = False, NDIFF_TAPERING, horizontal boundary diffusion,
-!! DIFFUSE_ML_TO_INTERIOR, KHTR_USE_EBT_STRUCT, offline khdt arrays and the df_x / df_y flux diagnostics stop with a FATAL error.
+!! RECALC_NEUTRAL_SURF, NDIFF_INTERIOR_ONLY with visc%h_ML; mom6hip_tracer_hordiff_neutral), and with DIFFUSE_ML_TO_INTERIOR the
+!! epipycnal diffusion between the variable-density layers and the interior of a layered run (tracer_epipycnal_ML_diff :700,
+!! ML_KHTR_SCALE, HOR_DIFF_ANSWER_DATE, HOR_DIFF_LIMIT_BUG; mom6hip_tracer_hordiff_epipycnal).  NDIFF_CONTINUOUS = False,
+!! NDIFF_TAPERING, horizontal boundary diffusion, KHTR_USE_EBT_STRUCT, offline khdt arrays and the df_x / df_y flux diagnostics stop
+!! with a FATAL error.
 !!
 !! Compiled INSIDE a MOM6 source tree in place of src/tracer/MOM_tracer_hor_diff.F90; here against tests/fortran/stubs.
 module MOM_tracer_hor_diff
@@ -49,7 +52,8 @@ type, public :: tracer_hor_diff_CS ; private
   logical :: first_call = .true.
   logical :: recalc_neutral_surf  !< If true, recalculate the neutral surfaces if CFL has been exceeded
   type(mom6hip_neutral_diffusion_cs_t) :: nd   !< neutral_diffusion_CS as the library reads it
-  type(mom6hip_eos_t) :: eos                   !< the equation of state neutral_diffusion_init was given
+  type(mom6hip_epipycnal_cs_t) :: epi          !< the parameters of tracer_epipycnal_ML_diff as the library reads them
+  type(mom6hip_eos_t) :: eos                   !< the equation of state tracer_hor_diff_init was given
   type(diag_ctrl), pointer :: diag => NULL()
 end type tracer_hor_diff_CS
 
@@ -81,6 +85,7 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
   type(c_ptr), allocatable :: tr(:)
   real(c_double), allocatable, target :: cu(:)
   type(c_ptr) :: p_surf
+  real(c_double), allocatable, target :: Rlay(:)
   integer :: m, rc, idx_T, idx_S
 
   if (.not. associated(CS)) call MOM_error(FATAL, "MOM_tracer_hor_diff: "// &
@@ -133,6 +138,18 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
     endif
     CS%nd%H_to_RZ = GV%H_to_RZ ; CS%nd%recalc_neutral_surf = merge(1, 0, CS%recalc_neutral_surf)
   endif
+  if (CS%Diffuse_ML_interior) then      ! :544-550, :613-620: tv%T and tv%S are registered tracers, found by association
+    ccs%unsupported(3) = 1
+    if (.not.(associated(tv%T) .and. associated(tv%S))) call MOM_error(FATAL, &
+      "tracer_hordiff (HIP): DIFFUSE_ML_TO_INTERIOR needs tv%T and tv%S.")
+    do m=1,Reg%ntr
+      if (associated(Reg%Tr(m)%t, tv%T)) idx_T = m-1
+      if (associated(Reg%Tr(m)%t, tv%S)) idx_S = m-1
+    enddo
+    if (idx_T < 0 .or. idx_S < 0) call MOM_error(FATAL, "tracer_hordiff (HIP): tv%T and tv%S must be registered tracers.")
+    allocate(Rlay(GV%ke)) ; Rlay(:) = GV%Rlay(1:GV%ke)
+    CS%epi%Rlay = c_loc(Rlay) ; CS%epi%nkml = GV%nkml ; CS%epi%nk_rho_varies = GV%nk_rho_varies ; CS%epi%P_Ref = tv%P_Ref
+  endif
   if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: the shared device mirrors of the host arrays
     ctx = mom6hip_shared_context(G, GV)
     do m=1,Reg%ntr ; tr(m) = mom6hip_mirror(ctx, tr(m), int(size(h), c_int64_t), .true., .true.) ; enddo
@@ -142,13 +159,23 @@ subroutine tracer_hordiff(h, dt, MEKE, VarMix, visc, G, GV, US, CS, Reg, tv, do_
       call to_dev(fld%L2u, size(VarMix%L2u)) ; call to_dev(fld%SN_u, size(VarMix%SN_u))
       call to_dev(fld%L2v, size(VarMix%L2v)) ; call to_dev(fld%SN_v, size(VarMix%SN_v))
     endif
+    if (CS%Diffuse_ML_interior) then
+      rc = mom6hip_tracer_hordiff_epipycnal(ctx, ccs, CS%epi, fld, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), &
+                                            CS%eos, dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), int(idx_T, c_int32_t), &
+                                            int(idx_S, c_int32_t), MOM6HIP_MEM_DEVICE, stats)
+    else
     rc = mom6hip_tracer_hordiff_neutral(ctx, ccs, CS%nd, fld, mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), &
                                         CS%eos, p_surf, dt, tr, c_loc(cu), int(Reg%ntr, c_int32_t), int(idx_T, c_int32_t), &
                                         int(idx_S, c_int32_t), MOM6HIP_MEM_DEVICE, stats)
+    endif
+  elseif (CS%Diffuse_ML_interior) then
+    rc = mom6hip_tracer_hordiff_epipycnal(mom6hip_shared_context(G, GV), ccs, CS%epi, fld, c_loc(h), CS%eos, dt, tr, c_loc(cu), &
+                                          int(Reg%ntr, c_int32_t), int(idx_T, c_int32_t), int(idx_S, c_int32_t), MOM6HIP_MEM_HOST, stats)
   else
     rc = mom6hip_tracer_hordiff_neutral(mom6hip_shared_context(G, GV), ccs, CS%nd, fld, c_loc(h), CS%eos, p_surf, dt, tr, c_loc(cu), &
                                         int(Reg%ntr, c_int32_t), int(idx_T, c_int32_t), int(idx_S, c_int32_t), MOM6HIP_MEM_HOST, stats)
   endif
+  CS%epi%Rlay = c_null_ptr
   call mom6hip_fatal_if(rc, "tracer_hordiff")
   call cpu_clock_end(id_clock_diffuse)
 contains
@@ -199,7 +226,6 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
                  units="nondim", default=0.5)
   call get_param(param_file, mdl, "DIFFUSE_ML_TO_INTERIOR", CS%Diffuse_ML_interior, &
                  "If true, enable epipycnal mixing between the surface boundary layer and the interior.", default=.false.)
-  call refuse(CS%Diffuse_ML_interior, "DIFFUSE_ML_TO_INTERIOR")
   call get_param(param_file, mdl, "CHECK_DIFFUSIVE_CFL", CS%check_diffusive_CFL, &
                  "If true, use enough iterations the diffusion to ensure that the diffusive equations are stable.", &
                  default=.false.)
@@ -208,6 +234,23 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
                  units="nondim", default=-1.0)
   call get_param(param_file, mdl, "RECALC_NEUTRAL_SURF", CS%recalc_neutral_surf, &
                  "If true, then recalculate the neutral surfaces if the CFL has been exceeded", default=.false.)
+  call get_param(param_file, mdl, "HOR_DIFF_ANSWER_DATE", CS%epi%answer_date, &
+                 "The vintage of the order of arithmetic to use for the tracer diffusion.", default=20240101, &
+                 do_not_log=.not.CS%Diffuse_ML_interior)
+  call get_param(param_file, mdl, "HOR_DIFF_LIMIT_BUG", flag, &
+                 "If true and the answer date is 20240330 or below, use a rotational symmetry breaking bug when limiting the "//&
+                 "tracer properties in tracer_epipycnal_ML_diff.", default=.true., &
+                 do_not_log=((.not.CS%Diffuse_ML_interior).or.(CS%epi%answer_date>=20240331)))
+  CS%epi%limit_bug = merge(1, 0, flag)
+  CS%epi%ML_KhTr_scale = 1.0
+  if (CS%Diffuse_ML_interior) then
+    call get_param(param_file, mdl, "ML_KHTR_SCALE", CS%epi%ML_KhTr_scale, &
+                 "With Diffuse_ML_interior, the ratio of the truly horizontal diffusivity in the mixed layer to the "//&
+                 "epipycnal diffusivity.  The valid range is 0 to 1.", units="nondim", default=1.0)
+    if (GV%nk_rho_varies < 1 .or. GV%nk_rho_varies >= GV%ke) call MOM_error(FATAL, "tracer_hor_diff_init (HIP): "// &
+      "DIFFUSE_ML_TO_INTERIOR is provided for layered runs with variable-density layers above an interior (0 < nk_rho_varies < nk).")
+    call mom6hip_read_eos(param_file, CS%eos, "tracer_hor_diff_init")
+  endif
   ! neutral_diffusion_init :138-330
   call get_param(param_file, "MOM_neutral_diffusion", "USE_NEUTRAL_DIFFUSION", CS%use_neutral_diffusion, &
                  "If true, enables the neutral diffusion module.", default=.false.)
@@ -233,6 +276,8 @@ subroutine tracer_hor_diff_init(Time, G, GV, US, param_file, diag, EOS, diabatic
     call mom6hip_read_eos(param_file, CS%eos, "neutral_diffusion_init")
     CS%nd%initialized = 1
   endif
+  if (CS%use_neutral_diffusion .and. CS%Diffuse_ML_interior) call MOM_error(FATAL, "MOM_tracer_hor_diff: "// &
+       "USE_NEUTRAL_DIFFUSION and DIFFUSE_ML_TO_INTERIOR are mutually exclusive!")
   call get_param(param_file, mdl, "USE_HORIZONTAL_BOUNDARY_DIFFUSION", CS%use_hor_bnd_diffusion, default=.false.)
   call refuse(CS%use_hor_bnd_diffusion, "USE_HORIZONTAL_BOUNDARY_DIFFUSION")
   call mom6hip_read_topology(param_file)

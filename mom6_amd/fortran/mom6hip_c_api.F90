@@ -191,6 +191,15 @@ type, bind(c) :: mom6hip_neutral_diffusion_cs_t
   integer(c_int32_t) :: unsupported(8) = 0
 end type mom6hip_neutral_diffusion_cs_t
 
+!> mom6hip_epipycnal_cs_t (DIFFUSE_ML_TO_INTERIOR: tracer_epipycnal_ML_diff, src/tracer/MOM_tracer_hor_diff.F90:700)
+type, bind(c) :: mom6hip_epipycnal_cs_t
+  real(c_double) :: ML_KhTr_scale = 1.0, P_Ref = 0.0
+  real(c_double) :: reserved0(4) = 0.0
+  type(c_ptr) :: Rlay = c_null_ptr
+  integer(c_int32_t) :: nkml = 0, nk_rho_varies = 0, answer_date = 20240101, limit_bug = 1
+  integer(c_int32_t) :: reserved1(4) = 0
+end type mom6hip_epipycnal_cs_t
+
 !> mom6hip_hordiff_stats_t
 type, bind(c) :: mom6hip_hordiff_stats_t
   integer(c_int32_t) :: num_itts, halo_updates
@@ -494,6 +503,23 @@ interface
     type(mom6hip_hordiff_stats_t), intent(out) :: stats
     integer(c_int) :: rc
   end function mom6hip_tracer_hordiff_neutral
+
+  !> tracer_hordiff with CS%Diffuse_ML_interior (cs%unsupported(3)); idx_T, idx_S: the 0-based places of tv%T, tv%S in tr
+  function mom6hip_tracer_hordiff_epipycnal(ctx, cs, epi, fields, h, eos, dt, tr, conc_underflow, ntr, idx_T, idx_S, memspace, &
+                                            stats) bind(c, name="mom6hip_tracer_hordiff_epipycnal") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_tracer_hor_diff_cs_t, mom6hip_hordiff_stats_t, mom6hip_hordiff_fields_t, &
+              mom6hip_epipycnal_cs_t, mom6hip_eos_t
+    type(c_ptr), value :: ctx, h, conc_underflow
+    type(mom6hip_tracer_hor_diff_cs_t), intent(in) :: cs
+    type(mom6hip_epipycnal_cs_t), intent(in) :: epi
+    type(mom6hip_hordiff_fields_t), intent(in) :: fields
+    type(mom6hip_eos_t), intent(in) :: eos
+    real(c_double), value :: dt
+    type(c_ptr), intent(in) :: tr(*)
+    integer(c_int32_t), value :: ntr, idx_T, idx_S, memspace
+    type(mom6hip_hordiff_stats_t), intent(out) :: stats
+    integer(c_int) :: rc
+  end function mom6hip_tracer_hordiff_epipycnal
 
   !> subchk / subStats of MOM_checksums (MOM_checksums.F90:1387) on a device or host field of staggering pos
   function mom6hip_chksum(ctx, field, pos, nk, di, dj, symmetric, scale, bitcount, amin, amax, memspace) &

@@ -66,7 +66,7 @@ G%Domain%nihalo = halo ; G%Domain%njhalo = halo ; G%Domain%niglobal = ni ; G%Dom
 read(u_in) scal, dt
 GV%Angstrom_H = scal(1) ; GV%H_subroundoff = scal(2) ; GV%dZ_subroundoff = scal(3) ; GV%H_to_Z = scal(4) ; GV%Z_to_H = scal(5)
 GV%g_Earth = scal(6) ; GV%Rho0 = scal(7)
-! opt = [ntr, VarMix%use_variable_mixing, VarMix%Resoln_scaled_KhTr, MEKE%Kh allocated, ...]
+! opt = [ntr, VarMix%use_variable_mixing, VarMix%Resoln_scaled_KhTr, MEKE%Kh allocated, visc%h_ML follows, GV%nk_rho_varies, GV%nkml, -]
 read(u_in) opt
 ntr = opt(1)
 
@@ -91,6 +91,11 @@ read(u_in) h, uhtr, vhtr, trs
 read(u_in) MEKE%Kh, VarMix%L2u, VarMix%L2v, VarMix%SN_u, VarMix%SN_v, VarMix%Res_fn_h, VarMix%Rd_dx_h
 if (opt(5) /= 0) then      ! visc%h_ML (NDIFF_INTERIOR_ONLY)
   allocate(visc%h_ML(isd:ied,jsd:jed)) ; read(u_in) visc%h_ML
+endif
+if (opt(6) /= 0) then      ! a layered run with opt(6) variable-density layers, opt(7) of them mixed layers (DIFFUSE_ML_TO_INTERIOR)
+  GV%nk_rho_varies = opt(6) ; GV%nkml = opt(7)
+  if (allocated(GV%Rlay)) deallocate(GV%Rlay)
+  allocate(GV%Rlay(nk)) ; read(u_in) GV%Rlay, tv%P_Ref
 endif
 close(u_in)
 VarMix%use_variable_mixing = (opt(2) /= 0) ; VarMix%Resoln_scaled_KhTr = (opt(3) /= 0)

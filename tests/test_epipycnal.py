@@ -170,3 +170,56 @@ def test_epipycnal_entry_points_refuse_what_they_cannot_take():
     with pytest.raises(Mom6HipError, match="nk_rho_varies"):      # not a layered run
         tracer_hordiff(torch.from_numpy(h).cuda(), 3600.0, None, None, None, dg, CS, dtr, tv=tv, GV=dict(Rlay=Rlay, nkml=0, nk_rho_varies=0))
     dg.close()
+
+
+def _write_layered_tracer_case(tmp, g, h, tr, eos_name, Rlay, params, resident):
+    """the input and parameter files of tests/fortran/tracer_driver.F90 for a layered state at rest (no transports: advect_tracer is
+    called and has nothing to move)"""
+    zu = np.zeros(g.shape3(_abi.POS_U)); zv = np.zeros(g.shape3(_abi.POS_V)); z2 = {n: np.zeros(g.shape2(p)) for n, p in
+        (("Kh", _abi.POS_H), ("L2u", _abi.POS_U), ("L2v", _abi.POS_V), ("SN_u", _abi.POS_U), ("SN_v", _abi.POS_V), ("Res_fn_h", _abi.POS_H), ("Rd_dx_h", _abi.POS_H))}
+    opt = [len(tr), 0, 0, 0, 0, NKMB, NKML, 0]
+    dt = 86400.0
+    with open(tmp / "in.bin", "wb") as fh:
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, 900.0], dtype="<f8").tofile(fh)
+        np.array(opt, dtype="<i4").tofile(fh)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
+        np.array([dt, 1.0], dtype="<f8").tofile(fh)
+        for a in [h, zu, zv] + tr + [z2[n] for n in ("Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_h", "Rd_dx_h")]:
+            np.ascontiguousarray(a, dtype="<f8").tofile(fh)
+        np.ascontiguousarray(Rlay, dtype="<f8").tofile(fh)
+        np.array([2.0e7], dtype="<f8").tofile(fh)
+    with open(tmp / "params.txt", "w") as fh:
+        fh.write(f"TRACER_ADVECTION_SCHEME = PPM:H3\nDT = 900.0\nGPU_RESIDENT_DYNAMICS = {resident}\nEQN_OF_STATE = {eos_name}\n")
+        fh.write("DIFFUSE_ML_TO_INTERIOR = True\n")
+        for k, v in params.items():
+            fh.write(f"{k} = {v}\n")
+    return dt
+
+
+@pytest.mark.gpu
+def test_epipycnal_diffusion_from_fortran(tmp_path):
+    """tracer_hor_diff_init / tracer_hordiff of the shim with DIFFUSE_ML_TO_INTERIOR as .testing/tc1 sets it (ML_KHTR_SCALE = 0), and with the
+    later answer date: GV%Rlay, GV%nkml, GV%nk_rho_varies and tv%P_Ref come from the reference's own types; the oracle's bits"""
+    import os, subprocess
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_shims(tmp_path, driver="tracer_driver")
+    g, h, tr, eos, Rlay = layered_case(ni=30, nj=16, nk=8)
+    for params, resident in [(dict(KHTR=800.0, ML_KHTR_SCALE=0.0), False), (dict(KHTR=800.0, ML_KHTR_SCALE=0.0), True),
+                             (dict(KHTR=2.0e5, CHECK_DIFFUSIVE_CFL=True, HOR_DIFF_ANSWER_DATE=20240401), False)]:
+        dt = _write_layered_tracer_case(tmp_path, g, h, tr, "WRIGHT", Rlay, params, resident)
+        ref = [t.copy() for t in tr]
+        orc.advect_tracer(g, h, np.zeros(g.shape3(_abi.POS_U)), np.zeros(g.shape3(_abi.POS_V)), dt, 900.0, "PPM:H3", ref)
+        for t in ref:
+            orc.halo_update(g, t, _abi.POS_H)
+        orc.tracer_hordiff(g, h, dt, ref, params["KHTR"], check_diffusive_CFL=params.get("CHECK_DIFFUSIVE_CFL", False),
+                           epipycnal=epi(eos, Rlay, ML_KhTr_scale=params.get("ML_KHTR_SCALE", 1.0), answer_date=params.get("HOR_DIFF_ANSWER_DATE", 20240101)))
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (params, r.stderr[-600:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8").reshape((len(tr),) + tr[0].shape)
+        for m, w in enumerate(ref):
+            assert bits_equal(interior(g, raw[m]), interior(g, w)), (params, m)
+        assert not bits_equal(interior(g, raw[2]), interior(g, tr[2]))

@@ -150,6 +150,8 @@ TC_INPUT = {
         DEBUG = True
         USE_PSURF_IN_EOS = False
         USE_LAND_MASK_FOR_HVISC = False
+                DIFFUSE_ML_TO_INTERIOR = True
+        ML_KHTR_SCALE = 0.0
         """),
 }
 
@@ -516,7 +518,9 @@ def cycle_oracle(name, state, ncycles, nsteps):
         orc.halo_update(g, st.h, H)
         orc.advect_tracer(g, st.h, st.uhtr, st.vhtr, dt_therm, dt, "PPM:H3", [st.T, st.S])
         orc.tracer_hordiff(g, st.h, dt_therm, [st.T, st.S], 100.0, VarMix=hd_varmix, MEKE=hd_meke,
-                           neutral=dict(eos=st.E, idx_T=0, idx_S=1) if _b(p, "USE_NEUTRAL_DIFFUSION") else None)
+                           neutral=dict(eos=st.E, idx_T=0, idx_S=1) if _b(p, "USE_NEUTRAL_DIFFUSION") else None,
+                           epipycnal=dict(eos=st.E, Rlay=Rlay, nkml=meta["nkml"], nk_rho_varies=meta["nk_rho_varies"], idx_T=0, idx_S=1,
+                                          ML_KhTr_scale=_f(p, "ML_KHTR_SCALE", 1.0)) if (_b(p, "DIFFUSE_ML_TO_INTERIOR") and meta["nkml"] > 0) else None)
         st.uhtr[:] = 0.0; st.vhtr[:] = 0.0
         if _b(p, "TEST_ALE"):      # the ALE block of step_MOM_thermo (MOM.F90:1647-1700) with the parameters of CYCLE_ALE_PAIRS
             ts = float(p["REGRID_TIME_SCALE"])
@@ -590,7 +594,8 @@ def test_thermodynamic_cycle_with_the_tc2_and_tc1_sets(tmp_path, name, resident)
     USE_STORED_SLOPES in thickness_diffuse; the OM4 form of mixedlayer_restrat; DYNAMIC_VISCOUS_ML, CHANNEL_DRAG, MEKE viscosity in the steps)
     and tc1 (no ALE: the bulk mixed layer -- mixedlayer_restrat_BML, the layered pressure force; the Visbeck term KHTH_SLOPE_CFF with VarMix%L2u /
     SN_u and RESOLN_SCALED_KHTH / _KHTR with the resolution functions), the fields of MOM_MEKE / MOM_lateral_mixing_coeffs synthetic
-    (lateral_fields).  tc1's DIFFUSE_ML_TO_INTERIOR stays out (refused by the tracer_hor_diff shim)."""
+    (lateral_fields), and tc1's DIFFUSE_ML_TO_INTERIOR with ML_KHTR_SCALE = 0: tracer_epipycnal_ML_diff between the four variable-density layers
+    and the interior."""
     cname = name + "c"
     TC_INPUT[cname] = dict(shape=TC_INPUT[name]["shape"], pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS)
     exe = build_cycle_driver(tmp_path)
