@@ -746,9 +746,10 @@ def main():
     # growth over the timed steps is refused as well as NaNs (a number from a run that is blowing up is not a benchmark): the
     # largest speed may not pass 1 m/s nor 4x its value after the warm-up, the free surface may not pass 3 m nor 3x its value after
     # the warm-up (+ 0.5 m), no velocity may have been truncated, and the kinetic energy per mass (write_energy) may not grow by more
-    # than 12 % per step over the timed window nor pass 1e-2 m2 s-2.  What growth there is in this workload is the release of the
-    # available potential energy of the synthetic T(y), S(x,y) fields: 7 % per step at the start, 0.5 % per step from step 50 on,
-    # levelling off without wind after ~85 steps; with uniform T and S the same operators lose energy (profiles/r03_health_om4.json).
+    # than 3 % per step over the timed window nor pass 1e-2 m2 s-2.  What growth there is in this workload is the release of the
+    # available potential energy of the synthetic T(y), S(x,y) fields while the state adjusts: 4 % per step in the first steps, 0.3 %
+    # per step after the SPINUP untimed steps (profiles/r04_health_om4.json); a run that skips the spin-up (--spinup 0: the profiling
+    # tools, which only want the kernels) is held to 12 % per step instead.
     speed = max(health["umax"], health["vmax"]); speed_w = max(health_w["umax"], health_w["vmax"])
     growing = speed > max(1.0, 4.0 * speed_w) or health["eta_max"] > min(3.0, 3.0 * health_w["eta_max"] + 0.5) or ntrunc > 0
     ke_growth = None
@@ -758,7 +759,8 @@ def main():
         # (the rate gate is calibrated on the two global workloads; a 44 x 40 x 2 basin adjusts to its synthetic start within a few steps
         # at 20 % per step and is held to the absolute bounds only)
         # (the folded world of MOM6HIP_BENCH_TRIPOLAR=1 has its open ocean on the fold and adjusts faster in its first dozen steps: 14 %)
-        growing = growing or (ke_growth > (0.20 if TRIPOLAR else 0.03) and cells >= 1000000) or ke_e > 1.0e-2
+        rate_gate = 0.20 if TRIPOLAR else (0.03 if (a.spinup is None or a.spinup >= SPINUP) else 0.12)
+        growing = growing or (ke_growth > rate_gate and cells >= 1000000) or ke_e > 1.0e-2
     if health["nan"] or health["hmin"] < 0.0 or growing:
         sys.exit(f"bench.py: the model state is not healthy after {M.nstep} steps (KE growth per step {ke_growth}): start {health0}, "
                  f"after warm-up {health_w}, at the end {health}")

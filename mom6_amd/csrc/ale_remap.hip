@@ -921,7 +921,7 @@ __device__ __forceinline__ double average_ppm(double a_L, double a_R, double u_c
 
 // waves per SIMD the register allocation aims at: one field fits 128 VGPRs (4 waves: 13.7 / 6.0 ms for 4 tracers / u and v at
 // 1440x1080x75 against 15.2 / 6.6 with 3), two fields need 168 (3 waves: 10.0 ms for 4 tracers; 19 ms when squeezed into 128); four
-// fields a launch spill 268 registers (31 ms) -- profiles/r04_ale_stream.txt
+// fields a launch spill 268 registers (31 ms) -- profiles/r04_experiments.txt
 template <int NF>
 __global__ __launch_bounds__(64, NF == 1 ? 4 : 3) void ale_remap_stream_kernel(SRemapArgs a) {
   const m6::GridDev &g = a.g;

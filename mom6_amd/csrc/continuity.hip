@@ -525,8 +525,9 @@ __device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int fl, 
 
 #ifdef FC_TRACE
 // phase clock of the cooperative kernel (experiments only: tools/build_variant.sh ... -DFC_TRACE): thread 0 of every block adds
-// the s_memtime ticks between marks; slot 15 counts blocks, slot 14 counts Newton passes
-__device__ unsigned long long fc_trace[16];
+// the s_memtime ticks between marks; slot 15 counts blocks, slot 14 counts Newton passes; slots 16-39: faces by the number of
+// evaluation passes they were alive for in a solve, slots 40-63: the solves of the blocks by the number of passes they ran
+__device__ unsigned long long fc_trace[64];
 #define FC_MARK(n) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&fc_trace[n], t_ - fc_t0); fc_t0 = t_; } } while (0)
 #else
 #define FC_MARK(n) do { } while (0)
@@ -847,6 +848,9 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
     fsm[pv] = fsm[CO + fl]; fsm[pv + PVS] = fsm[CO + FC_FL + fl]; fsm[pv + 2 * PVS] = fabs(uh_err);      // du_max, du_min, uh_err_best
     fsm[pv + 3 * PVS] = 0.0;      // du_eval: du of this face's last re-evaluation of the transports (what uh_3d holds in the reference)
     bool do_I = true, alive = valid;
+#ifdef FC_TRACE
+    int fc_np_face = 0, fc_np_block = 0;
+#endif
 #pragma unroll 1
     for (int itt = 1; itt <= max_itts; itt++) {
       bool domore = false;
@@ -892,6 +896,7 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
       if ((itt < max_itts) || write_uh) {
 #ifdef FC_TRACE
         if (threadIdx.x == 0) atomicAdd(&fc_trace[14], 1ull);
+        fc_np_block++; if (alive) fc_np_face++;
 #endif
         if (alive) fsm[pv + 3 * PVS] = du;
         FaceConst F; F.dLf = fsm[PK_DLF + fl]; F.cm = fsm[PK_CM + fl]; F.cp = fsm[PK_CP + fl]; F.dt = p.dt;
@@ -913,6 +918,10 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
       }
     }
     du_ph[phase] = du;
+#ifdef FC_TRACE
+    if (sb == 0 && valid) atomicAdd(&fc_trace[16 + min(fc_np_face, 23)], 1ull);
+    if (threadIdx.x == 0) atomicAdd(&fc_trace[40 + min(fc_np_block, 23)], 1ull);
+#endif
     FC_MARK(4 + phase);
     if (write_uh && valid) {
       // The reference stores the layer transports on every re-evaluation (uh_3d); what remains is the last one of each
@@ -1119,8 +1128,8 @@ __global__ __launch_bounds__(256) void cont_conv_kernel(ConvArgs p) {
 
 #ifdef FC_TRACE
 extern "C" int mom6hip_fc_trace(unsigned long long *out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_trace), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fc_trace), z, sizeof(z)) != hipSuccess) return 1; }
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_trace), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fc_trace), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
 }
 #endif
