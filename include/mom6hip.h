@@ -495,6 +495,54 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
                        double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor,
                        int32_t memspace);
 
+/*
+ * Open boundaries (src/core/MOM_open_boundary.F90): what continuity_PPM reads of ocean_OBC_type (:266-386) and of its segments
+ * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc); every other entry point
+ * of the library still requires that OBC is not associated, so a configuration with open boundaries cannot be stepped yet.
+ * Index ranges are in the index space of mom6hip_grid_t (isd, jsd, ...).
+ */
+#define MOM6HIP_OBC_NONE 0            /* OBC_NONE :79 */
+#define MOM6HIP_OBC_DIRECTION_N 100   /* :80-83 */
+#define MOM6HIP_OBC_DIRECTION_S 200
+#define MOM6HIP_OBC_DIRECTION_E 300
+#define MOM6HIP_OBC_DIRECTION_W 400
+
+typedef struct mom6hip_obc_segment {
+  int32_t direction;       /* MOM6HIP_OBC_DIRECTION_* */
+  int32_t open;            /* segment%open: open for the continuity solver */
+  int32_t specified;       /* segment%specified: the normal velocity and transport are the external values */
+  int32_t on_pe;           /* segment%on_pe */
+  int32_t is_E_or_W, is_N_or_S;
+  int32_t IsdB, IedB, JsdB, JedB;      /* segment%HI: the segment's face range on this PE's data domain */
+  int32_t isd, ied, jsd, jed;          /* segment%HI: its cell range */
+  int32_t reserved[6];
+  /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where
+   * `specified`; in the memory space of the call; may be NULL otherwise */
+  const double *normal_trans, *normal_vel;
+  void *reserved_p[4];
+} mom6hip_obc_segment_t;
+
+typedef struct mom6hip_obc {
+  int32_t number_of_segments;
+  int32_t OBC_pe;                                   /* OBC%OBC_pe: some segment touches this PE */
+  int32_t open_u_BCs_exist_globally, open_v_BCs_exist_globally;
+  int32_t specified_u_BCs_exist_globally, specified_v_BCs_exist_globally;
+  int32_t Flather_u_BCs_exist_globally, Flather_v_BCs_exist_globally;
+  int32_t reserved[8];
+  const mom6hip_obc_segment_t *segment;             /* number_of_segments entries (HOST array) */
+  const int32_t *segnum_u, *segnum_v;               /* OBC%segnum_u(IsdB:IedB, jsd:jed), segnum_v(isd:ied, JsdB:JedB): the segment number
+                                                       (1-based) of a face, MOM6HIP_OBC_NONE elsewhere; HOST arrays */
+  void *reserved_p[4];
+} mom6hip_obc_t;
+
+/* continuity_PPM with OBC associated (:86-194; the OBC branches of PPM_reconstruction_x/y :2385-2432 / :2521-2568, of
+ * zonal/merid_flux_layer :956-971 / :1854-1870, of zonal/meridional_mass_flux :629-634, :722-734, :744-748, :759-779, :782-805 and
+ * their twins, of zonal/meridional_flux_thickness :1058-1088 / :1960-1990).  obc == NULL: mom6hip_continuity. */
+int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, const mom6hip_obc_t *obc, const double *u,
+                           const double *v, const double *hin, double *h, double *uh, double *vh, double dt, const double *uhbt,
+                           const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor, double *v_cor,
+                           const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor, int32_t memspace);
+
 /* ---- MOM_EOS / MOM_PressureForce_FV --------------------------------------------------------- */
 
 /* EQN_OF_STATE forms provided (src/equation_of_state/MOM_EOS.F90:145-173; default "WRIGHT") */

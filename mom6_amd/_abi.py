@@ -182,6 +182,25 @@ class EpipycnalCS(C.Structure):
                 ("nk_rho_varies", C.c_int32), ("answer_date", C.c_int32), ("limit_bug", C.c_int32), ("reserved1", C.c_int32 * 4)]
 
 
+OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W = 0, 100, 200, 300, 400
+
+
+class ObcSegment(C.Structure):
+    """mom6hip_obc_segment_t (include/mom6hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("direction", "open", "specified", "on_pe", "is_E_or_W", "is_N_or_S", "IsdB", "IedB", "JsdB", "JedB",
+                                         "isd", "ied", "jsd", "jed")] + \
+               [("reserved", C.c_int32 * 6), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("reserved_p", C.c_void_p * 4)]
+
+
+class Obc(C.Structure):
+    """mom6hip_obc_t (include/mom6hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("number_of_segments", "OBC_pe", "open_u_BCs_exist_globally", "open_v_BCs_exist_globally",
+                                         "specified_u_BCs_exist_globally", "specified_v_BCs_exist_globally",
+                                         "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally")] + \
+               [("reserved", C.c_int32 * 8), ("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
+                ("reserved_p", C.c_void_p * 4)]
+
+
 class HorDiffStats(C.Structure):
     _fields_ = [("num_itts", C.c_int32), ("halo_updates", C.c_int32), ("max_CFL", C.c_double)]
 

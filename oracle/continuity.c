@@ -8,7 +8,7 @@
  *   {zonal,meridional}_mass_flux :519-820 / :1413-1717, {zonal,merid}_flux_layer :896-972 / :1788-1869,
  *   {zonal,meridional}_flux_thickness :976-1090 / :1873-1986, {zonal,meridional}_flux_adjust :1094-1243 /
  *   :1990-2140, set_{zonal,merid}_BT_cont :1247-1410 / :2144-2307, set_continuity_loop_bounds :2772-2799
- * for the hot-path configuration: OBC not associated, porous barriers = 1.
+ * for porous barriers = 1, with the OBC branches of those routines (orc_continuity_obc; OBC == NULL: not associated).
  *
  * The meridional routines of the reference are index-for-index mirror images of the zonal ones (checked
  * line by line; the two places where they differ textually -- CFL_dt for I_dt under aggress_adjust at
@@ -35,7 +35,29 @@ typedef struct {
   const double *dL_T;         /* dxT   | dyT */
   const double *dLC_face;     /* dxCu  | dyCv */
   const double *mask_face;    /* mask2dCu | mask2dCv */
+  /* open boundaries (NULL: not associated): the flags of this direction, OBC%segnum_u | segnum_v, and the direction whose interior
+   * cell is the face's minus-side cell (OBC_DIRECTION_E | _N; the other one, _W | _S, has it on the plus side) */
+  const mom6hip_obc_t *OBC;
+  int open_BC, specified_BC, Flather_BC, dir_plus, dir_minus;
+  const int32_t *segnum;
 } dirx_t;
+
+/* the segments of this direction: the face index along the direction and the range across it (segment%HI) */
+static inline int seg_in_dir(const dirx_t *D, const mom6hip_obc_segment_t *S) { return S->direction == D->dir_plus || S->direction == D->dir_minus; }
+static inline int seg_face(const dirx_t *D, const mom6hip_obc_segment_t *S) { return D->dir ? S->JsdB : S->IsdB; }
+static inline int seg_c0(const dirx_t *D, const mom6hip_obc_segment_t *S) { return D->dir ? S->isd : S->jsd; }
+static inline int seg_c1(const dirx_t *D, const mom6hip_obc_segment_t *S) { return D->dir ? S->ied : S->jed; }
+/* segment%normal_trans / normal_vel (IsdB:IedB, jsd:jed, nk) | (isd:ied, JsdB:JedB, nk) at face (A, c), layer k (1-based) */
+static inline double seg_val(const dirx_t *D, const mom6hip_obc_segment_t *S, const double *f, int A, int c, int k) {
+  if (D->dir) { const long ni = S->ied - S->isd + 1, nJ = S->JedB - S->JsdB + 1; return f[(c - S->isd) + ni*((A - S->JsdB) + nJ*(long)(k-1))]; }
+  const long nI = S->IedB - S->IsdB + 1, nj = S->jed - S->jsd + 1;
+  return f[(A - S->IsdB) + nI*((c - S->jsd) + nj*(long)(k-1))];
+}
+static inline const mom6hip_obc_segment_t *seg_at(const dirx_t *D, int A, int c) {
+  if (!D->OBC) return NULL;
+  const int l = D->segnum[D->dir ? ORC_V2(D->G, c, A) : ORC_U2(D->G, A, c)];
+  return (l != MOM6HIP_OBC_NONE) ? &D->OBC->segment[l-1] : NULL;
+}
 
 static inline long H2d(const dirx_t *D, int a, int c) { return D->dir ? ORC_H2(D->G, c, a) : ORC_H2(D->G, a, c); }
 static inline long F2d(const dirx_t *D, int A, int c) { return D->dir ? ORC_V2(D->G, c, A) : ORC_U2(D->G, A, c); }
@@ -91,11 +113,37 @@ static void edge_thickness(const dirx_t *D, const mom6hip_continuity_cs_t *CS, c
         }
         slp[H2d(D,a,c)] = s;
       }
+      if (D->open_BC) {                     /* :2385-2398 / :2521-2534 */
+        for (int n = 0; n < D->OBC->number_of_segments; n++) {
+          const mom6hip_obc_segment_t *S = &D->OBC->segment[n];
+          if (!S->on_pe || !seg_in_dir(D, S)) continue;
+          const int A = seg_face(D, S);
+          for (int c = seg_c0(D, S); c <= seg_c1(D, S); c++) { slp[H2d(D,A+1,c)] = 0.0; slp[H2d(D,A,c)] = 0.0; }
+        }
+      }
       for (int c = c0; c <= c1; c++) for (int a = al; a <= ah; a++) {
         double h_m1 = MT(a-1,c) * HI(a-1,c) + (1.0-MT(a-1,c)) * HI(a,c);
         double h_p1 = MT(a+1,c) * HI(a+1,c) + (1.0-MT(a+1,c)) * HI(a,c);
         h_L[H3d(D,a,c,k)] = 0.5*( h_m1 + HI(a,c) ) + oneSixth*( slp[H2d(D,a-1,c)] - slp[H2d(D,a,c)] );
         h_R[H3d(D,a,c,k)] = 0.5*( h_p1 + HI(a,c) ) + oneSixth*( slp[H2d(D,a,c)] - slp[H2d(D,a+1,c)] );
+      }
+    }
+    if (D->open_BC) {                       /* :2411-2432 / :2547-2568 */
+      for (int n = 0; n < D->OBC->number_of_segments; n++) {
+        const mom6hip_obc_segment_t *S = &D->OBC->segment[n];
+        if (!S->on_pe) continue;
+        const int A = seg_face(D, S), a = A;
+        if (S->direction == D->dir_plus) {
+          for (int c = seg_c0(D, S); c <= seg_c1(D, S); c++) {
+            h_L[H3d(D,a+1,c,k)] = HI(a,c); h_R[H3d(D,a+1,c,k)] = HI(a,c);
+            h_L[H3d(D,a,c,k)] = HI(a,c); h_R[H3d(D,a,c,k)] = HI(a,c);
+          }
+        } else if (S->direction == D->dir_minus) {
+          for (int c = seg_c0(D, S); c <= seg_c1(D, S); c++) {
+            h_L[H3d(D,a,c,k)] = HI(a+1,c); h_R[H3d(D,a,c,k)] = HI(a+1,c);
+            h_L[H3d(D,a+1,c,k)] = HI(a+1,c); h_R[H3d(D,a+1,c,k)] = HI(a+1,c);
+          }
+        }
       }
     }
     if (CS->monotonic) {                    /* PPM_limit_CW84 :2625 */
@@ -165,6 +213,14 @@ static double flux_layer(const dirx_t *D, const mom6hip_continuity_cs_t *CS, dou
     h_marg = 0.5 * (h_L[H3d(D,a+1,c,k)] + h_R[H3d(D,a,c,k)]);
   }
   *duhdu = (dLf * 1.0) * h_marg * visc_rem;
+  if (D->open_BC) {                         /* :956-971 / :1854-1870 */
+    const mom6hip_obc_segment_t *S = seg_at(D, A, c);
+    if (S && S->open) {
+      const double hi = (S->direction == D->dir_plus) ? h[H3d(D,a,c,k)] : h[H3d(D,a+1,c,k)];
+      uh = (dLf * 1.0) * u * hi;
+      *duhdu = (dLf * 1.0) * hi * visc_rem;
+    }
+  }
   return uh;
 }
 
@@ -263,8 +319,16 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
     for (int k = 1; k <= nz; k++) {
       vr[k] = use_visc_rem ? visc_rem_u[F3d(D,A,c,k)] : 1.0;
       uh[F3d(D,A,c,k)] = flux_layer(D, CS, u[F3d(D,A,c,k)], h_in, h_L, h_R, vr[k], dt, A, c, k, &duhdu[k]);
+      if (D->specified_BC) {                /* :629-634 */
+        const mom6hip_obc_segment_t *S = seg_at(D, A, c);
+        if (S && S->specified) uh[F3d(D,A,c,k)] = seg_val(D, S, S->normal_trans, A, c, k);
+      }
     }
     if (!(uhbt || set_BT_cont)) continue;
+    /* transports are not reconciled where they are specified :722-734 */
+    const mom6hip_obc_segment_t *S_simple = NULL;
+    if (D->specified_BC || D->Flather_BC) { const mom6hip_obc_segment_t *S = seg_at(D, A, c); if (S && S->specified) S_simple = S; }
+    const int do_I = (S_simple == NULL);
     double visc_rem_max;
     if (use_visc_rem && CS->use_visc_rem_max) {
       visc_rem_max = 0.0;
@@ -312,13 +376,27 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
     du_min_CFL = min2(du_min_CFL,0.0);
 
     if (uhbt) {
-      double du = flux_adjust(D, CS, u, h_in, h_L, h_R, uhbt[F2d(D,A,c)], uh_tot_0, duhdu_tot_0,
-                              du_max_CFL, du_min_CFL, dt, vr, A, c, uh);
-      if (u_cor) for (int k = 1; k <= nz; k++) u_cor[F3d(D,A,c,k)] = u[F3d(D,A,c,k)] + du * vr[k];
+      double du = 0.0;                      /* (a face left out of the adjustment keeps du = 0 and its transports) */
+      if (do_I) du = flux_adjust(D, CS, u, h_in, h_L, h_R, uhbt[F2d(D,A,c)], uh_tot_0, duhdu_tot_0,
+                                 du_max_CFL, du_min_CFL, dt, vr, A, c, uh);
+      if (u_cor) for (int k = 1; k <= nz; k++) {
+        u_cor[F3d(D,A,c,k)] = u[F3d(D,A,c,k)] + du * vr[k];
+        if (S_simple) u_cor[F3d(D,A,c,k)] = seg_val(D, S_simple, S_simple->normal_vel, A, c, k);      /* :744-748 */
+      }
       if (du_cor) du_cor[F2d(D,A,c)] = du;
     }
 
-    if (set_BT_cont) {      /* set_zonal_BT_cont :1247-1410 */
+    if (set_BT_cont && !do_I) {             /* :1400-1404 (the face is not solved for), then :759-779 */
+      double FAuI = G->H_subroundoff*D->dL_face[F2d(D,A,c)];
+      for (int k = 1; k <= nz; k++) {
+        const double nv = seg_val(D, S_simple, S_simple->normal_vel, A, c, k);
+        if ((fabs(nv) > 0.0) && S_simple->specified) FAuI = FAuI + seg_val(D, S_simple, S_simple->normal_trans, A, c, k) / nv;
+      }
+      BT->FA_0m[F2d(D,A,c)] = FAuI; BT->FA_0p[F2d(D,A,c)] = FAuI; BT->FA_mm[F2d(D,A,c)] = FAuI; BT->FA_pp[F2d(D,A,c)] = FAuI;
+      BT->uBT_mm[F2d(D,A,c)] = 0.0; BT->uBT_pp[F2d(D,A,c)] = 0.0;
+    } else if (set_BT_cont) {      /* set_zonal_BT_cont :1247-1410: its calls of flux_adjust and flux_layer do not pass OBC */
+      dirx_t Dn = *D; Dn.OBC = NULL; Dn.open_BC = 0; Dn.specified_BC = 0; Dn.Flather_BC = 0;
+      const dirx_t *D0 = D; D = &Dn;
       const double min_visc_rem = 0.1, CFL_min = 1e-6;
       double du0 = flux_adjust(D, CS, u, h_in, h_L, h_R, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
                                dt, vr, A, c, NULL);
@@ -359,9 +437,25 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
       BT->FA_0p[F2d(D,A,c)] = FA_0; BT->FA_pp[F2d(D,A,c)] = FAmt_R;
       if (fabs(FAmt_R - FA_0) <= 1e-12*FA_0) BT->uBT_pp[F2d(D,A,c)] = 0.0;
       else BT->uBT_pp[F2d(D,A,c)] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+      D = D0;
     }
   }
   free(vr); free(duhdu);
+  }
+
+  /* the face areas of open segments :782-805 / :1672-1695 (after every row) */
+  if (D->open_BC && set_BT_cont) {
+    for (int n = 0; n < D->OBC->number_of_segments; n++) {
+      const mom6hip_obc_segment_t *S = &D->OBC->segment[n];
+      if (!(S->open && (D->dir ? S->is_N_or_S : S->is_E_or_W))) continue;
+      const int A = seg_face(D, S), ai = (S->direction == D->dir_plus) ? A : A + 1;
+      for (int c = seg_c0(D, S); c <= seg_c1(D, S); c++) {
+        double FA_u = 0.0;
+        for (int k = 1; k <= nz; k++) FA_u = FA_u + h_in[H3d(D,ai,c,k)]*(D->dL_face[F2d(D,A,c)]*1.0);
+        BT->FA_0m[F2d(D,A,c)] = FA_u; BT->FA_0p[F2d(D,A,c)] = FA_u; BT->FA_mm[F2d(D,A,c)] = FA_u; BT->FA_pp[F2d(D,A,c)] = FA_u;
+        BT->uBT_mm[F2d(D,A,c)] = 0.0; BT->uBT_pp[F2d(D,A,c)] = 0.0;
+      }
+    }
   }
 
   /* zonal_flux_thickness :976-1057 */
@@ -395,6 +489,17 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
       else hu = hu * 1.0;
       BT->h_face[F3d(D,A,c,k)] = hu;
     }
+    if (D->open_BC) {                       /* :1058-1088 / :1960-1990 */
+      for (int n = 0; n < D->OBC->number_of_segments; n++) {
+        const mom6hip_obc_segment_t *S = &D->OBC->segment[n];
+        if (!(S->open && (D->dir ? S->is_N_or_S : S->is_E_or_W))) continue;
+        const int A = seg_face(D, S), ai = (S->direction == D->dir_plus) ? A : A + 1;
+        for (int k = 1; k <= nz; k++) for (int c = seg_c0(D, S); c <= seg_c1(D, S); c++) {
+          if (visc_rem_u) BT->h_face[F3d(D,A,c,k)] = h_in[H3d(D,ai,c,k)] * (visc_rem_u[F3d(D,A,c,k)] * 1.0);
+          else BT->h_face[F3d(D,A,c,k)] = h_in[H3d(D,ai,c,k)] * 1.0;
+        }
+      }
+    }
   }
 }
 
@@ -417,14 +522,33 @@ int orc_continuity(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, c
                    const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor,
                    double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor)
 {
+  return orc_continuity_obc(G, CS, NULL, u, v, hin, h, uh, vh, dt, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor, dv_cor);
+}
+
+int orc_continuity_obc(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, const mom6hip_obc_t *OBC, const double *u,
+                       const double *v, const double *hin, double *h, double *uh, double *vh, double dt, const double *uhbt,
+                       const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor, double *v_cor,
+                       const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor)
+{
   if ((visc_rem_u != NULL) != (visc_rem_v != NULL)) return 2;
   const double h_min = G->Angstrom_H;
   const int x_first = ((G->first_direction % 2) == 0);
   int stencil = 3; if (CS->simple_2nd) stencil = 2; if (CS->upwind_1st) stencil = 1;
   const long n3 = (long)ORC_NIH(G)*ORC_NJH(G)*G->nk;
   double *h_L = calloc(n3, sizeof(double)), *h_R = calloc(n3, sizeof(double));
-  dirx_t X = { G, 0, G->dy_Cu, G->IdxT, G->dxT, G->dxCu, G->mask2dCu };
-  dirx_t Y = { G, 1, G->dx_Cv, G->IdyT, G->dyT, G->dyCv, G->mask2dCv };
+  dirx_t X = { G, 0, G->dy_Cu, G->IdxT, G->dxT, G->dxCu, G->mask2dCu, NULL, 0, 0, 0, MOM6HIP_OBC_DIRECTION_E, MOM6HIP_OBC_DIRECTION_W, NULL };
+  dirx_t Y = { G, 1, G->dx_Cv, G->IdyT, G->dyT, G->dyCv, G->mask2dCv, NULL, 0, 0, 0, MOM6HIP_OBC_DIRECTION_N, MOM6HIP_OBC_DIRECTION_S, NULL };
+  if (OBC) {
+    if (OBC->number_of_segments > 0 && !(OBC->segment && OBC->segnum_u && OBC->segnum_v)) return 3;
+    X.OBC = OBC; Y.OBC = OBC; X.segnum = OBC->segnum_u; Y.segnum = OBC->segnum_v;
+    /* PPM_reconstruction_x/y, flux_layer and flux_thickness test OBC%open_*_BCs_exist_globally alone (:2341, :932, :1060); the mass
+     * flux routines test OBC%OBC_pe first (:595-599) */
+    X.open_BC = OBC->open_u_BCs_exist_globally != 0; Y.open_BC = OBC->open_v_BCs_exist_globally != 0;
+    if (OBC->OBC_pe) {
+      X.specified_BC = OBC->specified_u_BCs_exist_globally != 0; Y.specified_BC = OBC->specified_v_BCs_exist_globally != 0;
+      X.Flather_BC = OBC->Flather_u_BCs_exist_globally != 0; Y.Flather_BC = OBC->Flather_v_BCs_exist_globally != 0;
+    }
+  }
   btc_dir_t bx, by, *pbx = NULL, *pby = NULL;
   if (BT_cont) {
     bx.FA_0m = BT_cont->FA_u_W0; bx.FA_mm = BT_cont->FA_u_WW; bx.FA_0p = BT_cont->FA_u_E0; bx.FA_pp = BT_cont->FA_u_EE;

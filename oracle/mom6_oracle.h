@@ -161,6 +161,11 @@ int orc_continuity(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, c
                    const double *hin, double *h, double *uh, double *vh, double dt, const double *uhbt,
                    const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor,
                    double *v_cor, const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor);
+/* continuity_PPM with OBC associated (obc may be NULL: the call above) */
+int orc_continuity_obc(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, const mom6hip_obc_t *OBC, const double *u,
+                       const double *v, const double *hin, double *h, double *uh, double *vh, double dt, const double *uhbt,
+                       const double *vhbt, const double *visc_rem_u, const double *visc_rem_v, double *u_cor, double *v_cor,
+                       const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor);
 
 /* ---- MOM_EOS / MOM_PressureForce_FV (oracle/pressure_force.c) ------------------------------ */
 double orc_eos_density(const mom6hip_eos_t *E, double T, double S, double p);

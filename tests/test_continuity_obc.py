@@ -1,0 +1,217 @@
+"""The OBC branches of continuity_PPM (src/core/MOM_continuity_PPM.F90 with an associated OBC: PPM_reconstruction_x/y :2385-2432, flux_layer
+:956-971, the mass-flux blocks :629-634, :722-779, :782-805, flux_thickness :1058-1088) and the placement of segments from their
+MOM_input strings (mom6_amd/open_boundary.py after MOM_open_boundary.F90:1211-1610).  The oracle against what those branches state,
+on the CPU; the library against the oracle on the GPU, bit for bit.  (The reference holds no known-answer vectors: parity unpinned.)"""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi, synth
+from mom6_amd.open_boundary import ocean_OBC_type, parse_segment_str
+from oracle import orc
+from rotation import rot, rot_vector, rotate_grid, unrot, unrot_vector
+
+TC3 = ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,FLATHER,ORLANSKI", "I=0,J=N:0,FLATHER,ORLANSKI"]      # .testing/tc3
+
+
+def open_faces(g, OBC):
+    """a regional grid's edge faces are walls in the synthetic grid: open the faces of the segments (face length and mask), as the
+    reference's grid has them with OBCs along the edge of the domain"""
+    m = dict(g.metrics)
+    for n in ("mask2dCu", "dy_Cu", "mask2dCv", "dx_Cv"):
+        m[n] = m[n].copy()
+    su, sv = OBC.segnum_u != 0, OBC.segnum_v != 0
+    m["mask2dCu"][su] = 1.0; m["dy_Cu"][su] = m["dyCu"][su]
+    m["mask2dCv"][sv] = 1.0; m["dx_Cv"][sv] = m["dxCv"][sv]
+    for n in ("mask2dCu", "dy_Cu", "mask2dCv", "dx_Cv"):
+        g.set_metric(n, m[n])
+
+
+def obc_case(segs, ni=22, nj=16, nk=4, seed=4, first_direction=0, land_frac=0.1, specified_data=True):
+    g = synth.make_grid(ni, nj, nk, seed=seed + 30, first_direction=first_direction, reentrant_x=False, reentrant_y=False, land_frac=land_frac)
+    OBC = ocean_OBC_type(g, segs)
+    open_faces(g, OBC)
+    st = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed).items()}
+    rng = np.random.default_rng(seed)
+    # flow through the boundary, thicknesses outside it that differ from the inside (the OBC branches must not read them)
+    st["u"] = np.ascontiguousarray(st["u"] + 0.05 * rng.standard_normal(st["u"].shape) * (OBC.segnum_u != 0)[None])
+    st["v"] = np.ascontiguousarray(st["v"] + 0.05 * rng.standard_normal(st["v"].shape) * (OBC.segnum_v != 0)[None])
+    kk = (np.arange(nk) + 0.5) / nk
+    st["visc_rem_u"] = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 4 + 0.0 * st["u"], 0.05, 1.0) * (0.9 + 0.1 * rng.random(st["u"].shape)))
+    st["visc_rem_v"] = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 4 + 0.0 * st["v"], 0.05, 1.0) * (0.9 + 0.1 * rng.random(st["v"].shape)))
+    if specified_data:
+        for s in OBC.segment:
+            if s.specified and s.on_pe:
+                s.normal_vel[:] = 0.1 * rng.standard_normal(s.normal_vel.shape)
+                s.normal_vel[rng.random(s.normal_vel.shape) < 0.2] = 0.0      # (the face area skips layers at rest :766)
+                s.normal_trans[:] = s.normal_vel * (3.0e4 * (5.0 + 50.0 * rng.random(s.normal_vel.shape)))
+    return g, st, OBC
+
+
+def run(g, st, OBC, dt=900.0, uhbt=True, bt=True, **cskw):
+    cs = orc.continuity_cs(g.nk, g.Angstrom_H, **cskw)
+    out = dict(h=st["h"].copy(), uh=np.zeros_like(st["u"]), vh=np.zeros_like(st["v"]))
+    kw = dict(visc_rem_u=st["visc_rem_u"], visc_rem_v=st["visc_rem_v"])
+    if uhbt:
+        uh0, vh0 = np.zeros_like(st["u"]), np.zeros_like(st["v"])
+        orc.continuity(g, cs, st["u"], st["v"], st["h"].copy(), st["h"].copy(), uh0, vh0, dt, OBC=OBC, **kw)
+        out["uhbt"] = np.ascontiguousarray(uh0.sum(0) * 1.05 + 0.02 * np.abs(uh0).sum(0))
+        out["vhbt"] = np.ascontiguousarray(vh0.sum(0) * 0.95 - 0.02 * np.abs(vh0).sum(0))
+        out.update(u_cor=np.zeros_like(st["u"]), v_cor=np.zeros_like(st["v"]), du_cor=g.zeros2(_abi.POS_U), dv_cor=g.zeros2(_abi.POS_V))
+        kw.update(uhbt=out["uhbt"], vhbt=out["vhbt"], u_cor=out["u_cor"], v_cor=out["v_cor"], du_cor=out["du_cor"], dv_cor=out["dv_cor"])
+    if bt:
+        arrs, btst = orc.make_bt_cont(g, with_h=True)
+        out["bt"] = arrs; kw["bt_cont"] = btst
+    orc.continuity(g, cs, st["u"], st["v"], st["h"].copy(), out["h"], out["uh"], out["vh"], dt, OBC=OBC, **kw)
+    return out
+
+
+def test_segment_strings_are_placed_as_the_reference_places_them():
+    g = synth.make_grid(10, 8, 2, reentrant_x=False, reentrant_y=False)
+    assert parse_segment_str(10, 8, "I=N-2,J=3:N+1,ORLANSKI,NUDGED") == (8, 3, 9, ["ORLANSKI", "NUDGED"])
+    OBC = ocean_OBC_type(g, TC3)
+    d = [s.direction for s in OBC.segment]
+    assert d == [_abi.OBC_DIRECTION_N, _abi.OBC_DIRECTION_S, _abi.OBC_DIRECTION_E, _abi.OBC_DIRECTION_W]
+    assert all(s.open and s.Flather and s.radiation and s.on_pe for s in OBC.segment)
+    assert OBC.open_u_BCs_exist_globally and OBC.Flather_v_BCs_exist_globally and not OBC.specified_u_BCs_exist_globally
+    h = g.halo
+    # the four sides of the 10 x 8 domain: v faces of the rows J = 0 and N, u faces of the columns I = 0 and N, over the cells 1 .. N
+    assert (OBC.segnum_v[h + 8, h:h + 10] == 1).all() and (OBC.segnum_v[h, h:h + 10] == 2).all() and (OBC.segnum_v != 0).sum() == 20
+    assert (OBC.segnum_u[h:h + 8, h + 10] == 3).all() and (OBC.segnum_u[h:h + 8, h] == 4).all() and (OBC.segnum_u != 0).sum() == 16
+    N, S, E, W = OBC.segment
+    assert (E.HI["IsdB"], E.HI["jsd"], E.HI["jed"]) == (h + 10, h + 1, h + 8) and (W.HI["IsdB"], W.HI["isd"]) == (h, h + 1)
+    assert (N.HI["JsdB"], N.HI["isd"], N.HI["ied"]) == (h + 8, h + 1, h + 10) and (S.HI["JsdB"], S.HI["jsd"]) == (h, h + 1)
+    with pytest.raises(Exception, match="cannot be used together"):
+        ocean_OBC_type(g, ["I=N,J=0:N,ORLANSKI,OBLIQUE"])
+    with pytest.raises(Exception, match="not understood"):
+        ocean_OBC_type(g, ["I=N,J=0:N,SOMETHING"])
+
+
+@pytest.mark.parametrize("first_direction", [0, 1])
+def test_no_segments_is_no_obc(first_direction):
+    g, st, OBC = obc_case([], first_direction=first_direction)
+    a, b = run(g, st, OBC), run(g, st, None)
+    for n in ("h", "uh", "vh", "u_cor", "v_cor", "du_cor", "dv_cor"):
+        assert bits_equal(a[n], b[n]), n
+    for n in a["bt"]:
+        assert bits_equal(a["bt"][n], b["bt"][n]), n
+
+
+@pytest.mark.parametrize("first_direction", [0, 1])
+def test_open_faces_carry_the_interior_thickness(first_direction):
+    segs = TC3 + ["I=9,J=4:11,ORLANSKI", "J=7,I=15:3,GRADIENT"]      # the four sides and two segments inside the domain
+    g, st, OBC = obc_case(segs, first_direction=first_direction)
+    o = run(g, st, OBC, uhbt=False)
+    x_first = first_direction % 2 == 0
+    hsrc = {True: st["h"], False: o["h"]}      # (the second direction sees the thicknesses the first one left; checked on faces of the first)
+    for seg in OBC.segment:
+        H = seg.HI
+        if seg.is_E_or_W and x_first:
+            I = H["IsdB"]; jj = slice(H["jsd"] - g.jsd, H["jed"] - g.jsd + 1)
+            ci = (I - g.isd) if seg.direction == _abi.OBC_DIRECTION_E else (I + 1 - g.isd)
+            hi = st["h"][:, jj, ci]; fI = I - (g.isd - 1)
+            dy = g.dy_Cu[jj, fI]
+            assert bits_equal(o["uh"][:, jj, fI], (dy * 1.0) * st["u"][:, jj, fI] * hi)
+            assert bits_equal(o["bt"]["h_u"][:, jj, fI], hi * (st["visc_rem_u"][:, jj, fI] * 1.0))
+            FA = np.zeros_like(dy)
+            for k in range(g.nk):
+                FA = FA + hi[k] * (dy * 1.0)
+            for n in ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE"):
+                assert bits_equal(o["bt"][n][jj, fI], FA), n
+            assert not o["bt"]["uBT_WW"][jj, fI].any() and not o["bt"]["uBT_EE"][jj, fI].any()
+        if seg.is_N_or_S and not x_first:
+            J = H["JsdB"]; ii = slice(H["isd"] - g.isd, H["ied"] - g.isd + 1)
+            cj = (J - g.jsd) if seg.direction == _abi.OBC_DIRECTION_N else (J + 1 - g.jsd)
+            hi = st["h"][:, cj, ii]; fJ = J - (g.jsd - 1)
+            dx = g.dx_Cv[fJ, ii]
+            assert bits_equal(o["vh"][:, fJ, ii], (dx * 1.0) * st["v"][:, fJ, ii] * hi)
+            assert bits_equal(o["bt"]["h_v"][:, fJ, ii], hi * (st["visc_rem_v"][:, fJ, ii] * 1.0))
+
+
+@pytest.mark.parametrize("first_direction", [0, 1])
+def test_segments_act_locally(first_direction):
+    """away from every segment nothing changes (the reconstruction's stencil, then the other direction's, then the convergence)"""
+    g, st, OBC = obc_case(["I=0,J=N:0,FLATHER,ORLANSKI", "J=0,I=0:12,ORLANSKI"], ni=40, nj=30, first_direction=first_direction)
+    o, n = run(g, st, OBC), run(g, st, None)
+    near = np.zeros(g.shape2(_abi.POS_H), dtype=bool)
+    near |= (OBC.segnum_u[:, 1:] != 0) | (OBC.segnum_u[:, :-1] != 0) | (OBC.segnum_v[1:, :] != 0) | (OBC.segnum_v[:-1, :] != 0)
+    for _ in range(6):
+        near[1:, :] |= near[:-1, :].copy(); near[:-1, :] |= near[1:, :].copy(); near[:, 1:] |= near[:, :-1].copy(); near[:, :-1] |= near[:, 1:].copy()
+    far = ~near
+    assert far[g.csl(_abi.POS_H)].sum() > 300
+    assert bits_equal(np.where(far[None], o["h"], 0.0), np.where(far[None], n["h"], 0.0))
+    assert bits_equal(np.where(far[None], o["uh"][:, :, 1:], 0.0), np.where(far[None], n["uh"][:, :, 1:], 0.0))
+    assert not bits_equal(interior(g, o["h"]), interior(g, n["h"]))
+
+
+@pytest.mark.parametrize("first_direction", [0, 1])
+def test_specified_faces_take_the_external_transports(first_direction):
+    segs = ["I=N,J=0:N,SIMPLE", "J=0,I=0:N,SIMPLE", "I=0,J=N:0,FLATHER,ORLANSKI"]
+    g, st, OBC = obc_case(segs, first_direction=first_direction)
+    o = run(g, st, OBC)
+    E, S = OBC.segment[0], OBC.segment[1]
+    fI = E.HI["IsdB"] - (g.isd - 1); jj = slice(E.HI["jsd"] - g.jsd, E.HI["jed"] - g.jsd + 1)
+    assert bits_equal(o["uh"][:, jj, fI], E.normal_trans[:, :, 0]) and bits_equal(o["u_cor"][:, jj, fI], E.normal_vel[:, :, 0])
+    assert not o["du_cor"][jj, fI].any()
+    FA = g.H_subroundoff * g.dy_Cu[jj, fI]
+    for k in range(g.nk):
+        nv = E.normal_vel[k, :, 0]
+        FA = np.where(np.abs(nv) > 0.0, FA + E.normal_trans[k, :, 0] / np.where(nv == 0.0, 1.0, nv), FA)
+    for n in ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE"):
+        assert bits_equal(o["bt"][n][jj, fI], FA), n
+    fJ = S.HI["JsdB"] - (g.jsd - 1); ii = slice(S.HI["isd"] - g.isd, S.HI["ied"] - g.isd + 1)
+    assert bits_equal(o["vh"][:, fJ, ii], S.normal_trans[:, 0, :]) and bits_equal(o["v_cor"][:, fJ, ii], S.normal_vel[:, 0, :])
+    # the barotropic transport is still matched on the faces that are solved for
+    uh_sum = o["uh"].sum(0)
+    solved = (OBC.segnum_u == 0) & (g.mask2dCu > 0)
+    sj, si = g.csl(_abi.POS_U)
+    err = np.abs(uh_sum - o["uhbt"])[sj, si][solved[sj, si]]
+    assert err.max() <= 1e-6 * np.abs(o["uhbt"]).max()
+
+
+def turned_segments(segs, ni, nj):
+    """the segment strings of the grid turned by tests/rotation.py (x' = y, y' = -x): E -> S, N -> E, W -> N, S -> W"""
+    out = []
+    for s in segs:
+        l, m, n, act = parse_segment_str(ni, nj, s)
+        if s.replace(" ", "")[:2] == "I=":
+            out.append(",".join([f"J={ni - l}", f"I={m}:{n}"] + act))
+        else:
+            out.append(",".join([f"I={l}", f"J={ni - m}:{ni - n}"] + act))
+    return out
+
+
+@pytest.mark.parametrize("first_direction", [0, 1])
+@pytest.mark.parametrize("segs", [TC3 + ["I=9,J=4:11,ORLANSKI"], ["I=N,J=0:N,SIMPLE", "J=N,I=N:0,SIMPLE", "I=0,J=N:0,FLATHER", "J=5,I=3:14,GRADIENT"]],
+                         ids=["tc3+inner", "simple"])
+def test_oracle_turns_with_the_grid(segs, first_direction):
+    """continuity_PPM's two directions are one text in the oracle and two in the reference: a quarter turn of the grid, the state and the
+    segments gives the turned answers to the bit (the reference's rotational-reproducibility test applied to the OBC branches)"""
+    g, st, OBC = obc_case(segs, first_direction=first_direction)
+    o = run(g, st, OBC)
+    gr = rotate_grid(g)
+    OBCr = ocean_OBC_type(gr, turned_segments(segs, g.ni, g.nj))
+    ur, vr = rot_vector(st["u"], st["v"])
+    str_ = dict(u=ur, v=vr, h=rot(st["h"]), visc_rem_u=rot(st["visc_rem_v"]), visc_rem_v=rot(st["visc_rem_u"]))
+    for s, sr in zip(OBC.segment, OBCr.segment):      # the external values of a u segment become those of the v' segment it turns into
+        if s.specified and s.on_pe:
+            if s.is_E_or_W:      # u (nk, j, 1) -> v' = -u at i' = j: (nk, 1, i')
+                sr.normal_vel[:] = -np.swapaxes(s.normal_vel, 1, 2); sr.normal_trans[:] = -np.swapaxes(s.normal_trans, 1, 2)
+            else:                # v (nk, 1, i) -> u' = v at j' = ni - 1 - i: (nk, j', 1)
+                sr.normal_vel[:] = np.swapaxes(s.normal_vel, 1, 2)[:, ::-1, :]; sr.normal_trans[:] = np.swapaxes(s.normal_trans, 1, 2)[:, ::-1, :]
+    cs = orc.continuity_cs(g.nk, g.Angstrom_H)
+    hr = str_["h"].copy(); uhr = np.zeros_like(ur); vhr = np.zeros_like(vr)
+    ubr, vbr = rot_vector(o["uhbt"], o["vhbt"])
+    ucr, vcr = np.zeros_like(ur), np.zeros_like(vr)
+    arrs, btst = orc.make_bt_cont(gr, with_h=True)
+    orc.continuity(gr, cs, ur, vr, str_["h"].copy(), hr, uhr, vhr, 900.0, uhbt=ubr, vhbt=vbr, visc_rem_u=str_["visc_rem_u"],
+                   visc_rem_v=str_["visc_rem_v"], u_cor=ucr, v_cor=vcr, bt_cont=btst, OBC=OBCr)
+    assert bits_equal(interior(g, unrot(hr)), interior(g, o["h"]))
+    same = np.array_equal      # (a vector component changes sign with the turn: zero transports come back as -0)
+    uh_b, vh_b = unrot_vector(uhr, vhr)
+    assert same(interior(g, uh_b, _abi.POS_U), interior(g, o["uh"], _abi.POS_U)) and same(interior(g, vh_b, _abi.POS_V), interior(g, o["vh"], _abi.POS_V))
+    uc_b, vc_b = unrot_vector(ucr, vcr)
+    assert same(interior(g, uc_b, _abi.POS_U), interior(g, o["u_cor"], _abi.POS_U)) and same(interior(g, vc_b, _abi.POS_V), interior(g, o["v_cor"], _abi.POS_V))
+    # h_u of the original frame is h_v' turned back (a thickness: no sign)
+    assert bits_equal(interior(g, unrot(arrs["h_v"]), _abi.POS_U), interior(g, o["bt"]["h_u"], _abi.POS_U))
+    assert bits_equal(interior(g, unrot(arrs["h_u"]), _abi.POS_V), interior(g, o["bt"]["h_v"], _abi.POS_V))
