@@ -499,7 +499,7 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
  * Open boundaries (src/core/MOM_open_boundary.F90): what continuity_PPM reads of ocean_OBC_type (:266-386) and of its segments
  * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc); every other entry point
  * of the library still requires that OBC is not associated, so a configuration with open boundaries cannot be stepped yet.
- * Index ranges are in the index space of mom6hip_grid_t (isd, jsd, ...).
+ * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */
 #define MOM6HIP_OBC_NONE 0            /* OBC_NONE :79 */
 #define MOM6HIP_OBC_DIRECTION_N 100   /* :80-83 */

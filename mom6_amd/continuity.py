@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
+
 from . import _abi
 from ._lib import Mom6HipError, check, lib
 from .tracer_advect import DeviceGrid, _ptr_space
@@ -55,8 +57,8 @@ def continuity(u, v, hin, h, uh, vh, dt, G: DeviceGrid, CS, OBC=None, pbv=None, 
     u_cor, v_cor, BT_cont, du_cor, dv_cor) -- MOM_continuity_PPM.F90:86."""
     if CS is None:
         raise Mom6HipError("MOM_continuity_PPM: Module must be initialized before it is used.")
-    if OBC is not None or pbv is not None:
-        raise Mom6HipError("MOM_continuity_PPM (HIP): open boundaries and porous barriers are not supported")
+    if pbv is not None:
+        raise Mom6HipError("MOM_continuity_PPM (HIP): porous barriers are not supported")
     spaces = set()
 
     def P(a):
@@ -72,5 +74,21 @@ def continuity(u, v, hin, h, uh, vh, dt, G: DeviceGrid, CS, OBC=None, pbv=None, 
     tail = [P(du_cor), P(dv_cor)]
     if len(spaces) != 1:
         raise Mom6HipError("continuity_PPM: all fields must be in the same memory space")
+    space = spaces.pop()
+    if OBC is not None:      # an ocean_OBC_type (mom6_amd/open_boundary.py): the OBC branches of continuity_PPM
+        def to_ptr(a):      # the external values of a segment, in the memory space of the call
+            if space == _abi.MEM_DEVICE:
+                import torch
+                t = a if hasattr(a, "data_ptr") else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+                return t.data_ptr(), t
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            return a.ctypes.data, a
+        obc = OBC.struct(to_ptr)
+        L = lib()
+        L.mom6hip_continuity_obc.argtypes = [C.c_void_p, C.POINTER(_abi.ContinuityCS), C.POINTER(_abi.Obc)] + [C.c_void_p] * 6 + [C.c_double] + \
+            [C.c_void_p] * 6 + [C.POINTER(_abi.BTCont)] + [C.c_void_p] * 2 + [C.c_int32]
+        check(L.mom6hip_continuity_obc(G.handle, C.byref(CS), C.byref(obc), *args, float(dt), *opt, None if bt is None else C.byref(bt), *tail, space),
+              "continuity_PPM")
+        return
     check(lib().mom6hip_continuity(G.handle, C.byref(CS), *args, float(dt), *opt,
-                                   None if bt is None else C.byref(bt), *tail, spaces.pop()), "continuity_PPM")
+                                   None if bt is None else C.byref(bt), *tail, space), "continuity_PPM")

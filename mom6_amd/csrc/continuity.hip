@@ -63,6 +63,10 @@ struct EdgeArgs {
   const double *h_in;
   double *h_L, *h_R;
   int i0, i1, j0, j1;      // cells to reconstruct (already including the +-1 along the direction)
+  // open boundaries (null: none): a code per cell for this direction, PPM_reconstruction_x/y :2385-2432 / :2521-2568 --
+  // bit 0: the slope is zero (the two cells either side of a segment's faces); bits 1-2: the edge values are the thickness of
+  // 1 the cell itself, 2 the cell before it, 3 the cell after it along the direction (set before the limiter)
+  const int32_t *cell_code;
 };
 
 // slope of a cell from its neighbours along the direction, masked (:2371-2381)
@@ -77,7 +81,7 @@ __device__ __forceinline__ double ppm_slope(double hl, double hcc, double hr, do
 // the edge values of a cell from its own and its neighbours' thicknesses, their masks and (PPM) the three slopes, then the
 // limiter: the part of PPM_reconstruction_x/y (:2383-2420) + PPM_limit_pos / PPM_limit_CW84 after the slopes
 __device__ __forceinline__ void edge_finish(const ContOpts &o, double Angstrom_H, double hm, double hc, double hp, double mm, double mp,
-                                            double slp_m, double slp_c, double slp_p, double &L, double &R) {
+                                            double slp_m, double slp_c, double slp_p, double &L, double &R, int obc_src = 0) {
   const double h_m1 = mm * hm + (1.0 - mm) * hc;
   const double h_p1 = mp * hp + (1.0 - mp) * hc;
   if (o.simple_2nd) {
@@ -88,6 +92,7 @@ __device__ __forceinline__ void edge_finish(const ContOpts &o, double Angstrom_H
     L = 0.5 * (h_m1 + hc) + oneSixth * (slp_m - slp_c);
     R = 0.5 * (h_p1 + hc) + oneSixth * (slp_c - slp_p);
   }
+  if (obc_src) { const double hv = (obc_src == 1) ? hc : ((obc_src == 2) ? hm : hp); L = hv; R = hv; }      // :2411-2432
   if (o.monotonic) {          // PPM_limit_CW84 :2625
     if ((R - hc) * (hc - L) <= 0.) {
       L = hc; R = hc;
@@ -120,15 +125,15 @@ __device__ __forceinline__ void edge_finish(const ContOpts &o, double Angstrom_H
 // PPM_reconstruction + limiter for one cell from its five-point stencil along the direction (:2310-2662)
 __device__ __forceinline__ void edge_values(const ContOpts &o, double Angstrom_H, double hmm, double hm, double hc, double hp,
                                             double hpp, double mmm, double mm, double mc, double mp, double mpp, double &L,
-                                            double &R) {
+                                            double &R, int code_m = 0, int code_c = 0, int code_p = 0) {
   if (o.upwind_1st) { L = hc; R = hc; return; }
   double slp_m = 0.0, slp_c = 0.0, slp_p = 0.0;
-  if (!o.simple_2nd) {      // slopes of cells a-1, a, a+1
-    slp_m = ppm_slope(hmm, hm, hc, mmm, mm, mc);
-    slp_c = ppm_slope(hm, hc, hp, mm, mc, mp);
-    slp_p = ppm_slope(hc, hp, hpp, mc, mp, mpp);
+  if (!o.simple_2nd) {      // slopes of cells a-1, a, a+1 (zero beside an open-boundary segment :2385-2398)
+    slp_m = (code_m & 1) ? 0.0 : ppm_slope(hmm, hm, hc, mmm, mm, mc);
+    slp_c = (code_c & 1) ? 0.0 : ppm_slope(hm, hc, hp, mm, mc, mp);
+    slp_p = (code_p & 1) ? 0.0 : ppm_slope(hc, hp, hpp, mc, mp, mpp);
   }
-  edge_finish(o, Angstrom_H, hm, hc, hp, mm, mp, slp_m, slp_c, slp_p, L, R);
+  edge_finish(o, Angstrom_H, hm, hc, hp, mm, mp, slp_m, slp_c, slp_p, L, R, (code_c >> 1) & 3);
 }
 
 // the same for two neighbouring cells a, a+1 from the six thicknesses a-2 .. a+3: the slopes of a and a+1 serve both
@@ -164,9 +169,11 @@ __global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
     const double *h = p.h_in + o3;
     const double *m = g.mask2dT + o2;
     double L, R;
+    int cm = 0, cc = 0, cp = 0;
+    if (p.cell_code) { const int32_t *c = p.cell_code + o2; cm = c[-1]; cc = c[0]; cp = c[1]; }
     if (p.o.upwind_1st) { L = h[0]; R = h[0]; }
     else edge_values(p.o, g.Angstrom_H, wide ? h[-2] : 0.0, h[-1], h[0], h[1], wide ? h[2] : 0.0, wide ? m[-2] : 0.0, m[-1], m[0],
-                     m[1], wide ? m[2] : 0.0, L, R);
+                     m[1], wide ? m[2] : 0.0, L, R, cm, cc, cp);
     p.h_L[o3] = L; p.h_R[o3] = R;
   } else {
     const int ja = p.j0 + blockIdx.y * EDGE_RJ;
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
     for (int j = ja; j <= jb; j++) {
       const double hpp = wide ? h[2 * s] : 0.0, mpp = wide ? m[2 * s] : 0.0;
       double L, R;
-      edge_values(p.o, g.Angstrom_H, hmm, hm, hc, hp, hpp, mmm, mm, mc, mp, mpp, L, R);
+      int cm = 0, cc = 0, cp = 0;
+      if (p.cell_code) { const int32_t *c = p.cell_code + g.h2(i, j); cm = c[-s]; cc = c[0]; cp = c[s]; }
+      edge_values(p.o, g.Angstrom_H, hmm, hm, hc, hp, hpp, mmm, mm, mc, mp, mpp, L, R, cm, cc, cp);
       p.h_L[o3] = L; p.h_R[o3] = R;
       hmm = hm; hm = hc; hc = hp; hp = wide ? hpp : (j < jb ? h[2 * s] : 0.0);
       mmm = mm; mm = mc; mc = mp; mp = wide ? mpp : (j < jb ? m[2 * s] : 0.0);
@@ -203,12 +212,35 @@ struct FluxArgs {
   int set_BT_cont;
   double dt;
   int fi0, fi1, fj0, fj1;    // face index ranges: zonal (I = ish-1..ieh, j = jsh..jeh); meridional (i, J)
+  // open boundaries (obc_on = 0: OBC not associated; the lane-per-column kernel only)
+  int obc_on, obc_open, obc_simple;      // any; OBC%open_*_BCs_exist_globally; specified_* or Flather_*_BCs_exist_globally (with OBC%OBC_pe)
+  int obc_specified;                     // OBC%specified_*_BCs_exist_globally (with OBC%OBC_pe)
+  int obc_dir_plus;                      // OBC_DIRECTION_E | _N: the interior cell is the face's minus-side cell
+  const int32_t *segnum;                 // OBC%segnum_u | segnum_v
+  const int32_t *fa_code;                // faces of the open segments of this direction over their whole range (:782-805, :1058-1088):
+                                         // 1 interior = minus-side cell, 2 interior = plus-side cell (the last segment wins)
+  const struct SegDev *segs;             // the segments (device table)
 };
+
+// what the kernels read of a segment (mom6hip_obc_segment_t with device pointers)
+struct SegDev {
+  int direction, open, specified, pad;
+  int IsdB, IedB, JsdB, JedB, isd, ied, jsd, jed;
+  const double *normal_trans, *normal_vel;
+};
+
+// segment%normal_trans / normal_vel at face (fi, fj), layer k (0-based) :632, :746
+template <int DIR>
+__device__ __forceinline__ double seg_val(const SegDev &S, const double *f, int fi, int fj, int k) {
+  if (DIR) { const long ni = S.ied - S.isd + 1, nJ = S.JedB - S.JsdB + 1; return f[(fi - S.isd) + ni * ((fj - S.JsdB) + nJ * (long)k)]; }
+  const long nI = S.IedB - S.IsdB + 1, nj = S.jed - S.jsd + 1;
+  return f[(fi - S.IsdB) + nI * ((fj - S.jsd) + nj * (long)k)];
+}
 
 // flux_layer :896-972 for one face; o = offset of the minus-side cell in the h-point arrays
 template <int DIR>
 __device__ __forceinline__ double flux_layer(const FluxArgs &p, const Dir<DIR> &D, double u, long o3, long o2, long f2,
-                                             double visc_rem, double &duhdu) {
+                                             double visc_rem, double &duhdu, bool obc = false) {
   const m6::GridDev &g = p.g;
   const long s = D.sa();
   const double dLf = D.dL_face()[f2];
@@ -232,7 +264,44 @@ __device__ __forceinline__ double flux_layer(const FluxArgs &p, const Dir<DIR> &
     h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
   }
   duhdu = (dLf * 1.0) * h_marg * visc_rem;
+  if (obc && p.obc_open) {      // an open face carries the thickness of the interior cell :956-971 / :1854-1870
+    const int l = p.segnum[f2];
+    if (l != MOM6HIP_OBC_NONE && p.segs[l - 1].open) {
+      const double hi = (p.segs[l - 1].direction == p.obc_dir_plus) ? p.h_in[o3] : p.h_in[o3 + s];
+      uh = (dLf * 1.0) * u * hi;
+      duhdu = (dLf * 1.0) * hi * visc_rem;
+    }
+  }
   return uh;
+}
+
+// flux_thickness :976-1057 for one face and layer (uc: u, or u_cor if present :809-815)
+template <int DIR>
+__device__ __forceinline__ double flux_thickness_layer(const FluxArgs &p, const Dir<DIR> &D, double uc, long o3, long o2, long f2, double vr) {
+  const m6::GridDev &g = p.g;
+  const long s = D.sa();
+  double CFL, curv_3, h_avg, h_marg;
+  if (uc > 0.0) {
+    if (p.o.vol_CFL) CFL = (uc * p.dt) * (D.dL_face()[f2] * g.IareaT[o2]);
+    else CFL = uc * p.dt * D.IdL_T()[o2];
+    const double hW = p.h_L[o3], hE = p.h_R[o3];
+    curv_3 = hW + hE - 2.0 * p.h_in[o3];
+    h_avg = hE + CFL * (0.5 * (hW - hE) + curv_3 * (CFL - 1.5));
+    h_marg = hE + CFL * ((hW - hE) + 3.0 * curv_3 * (CFL - 1.0));
+  } else if (uc < 0.0) {
+    if (p.o.vol_CFL) CFL = (-uc * p.dt) * (D.dL_face()[f2] * g.IareaT[o2 + s]);
+    else CFL = -uc * p.dt * D.IdL_T()[o2 + s];
+    const double hW = p.h_L[o3 + s], hE = p.h_R[o3 + s];
+    curv_3 = hW + hE - 2.0 * p.h_in[o3 + s];
+    h_avg = hW + CFL * (0.5 * (hE - hW) + curv_3 * (CFL - 1.5));
+    h_marg = hW + CFL * ((hE - hW) + 3.0 * curv_3 * (CFL - 1.0));
+  } else {
+    h_avg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+    h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
+  }
+  double hu = p.o.marginal_faces ? h_marg : h_avg;
+  if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
+  return hu;
 }
 
 __device__ __forceinline__ double ratio_max(double a, double b, double maxrat) {
@@ -245,7 +314,7 @@ __device__ __forceinline__ double ratio_max(double a, double b, double maxrat) {
 template <int DIR>
 __device__ double flux_adjust(const FluxArgs &p, const Dir<DIR> &D, long o3_0, long o2, long f3_0, long f2, double uhbt,
                               double uh_tot_0, double duhdu_tot_0, double du_max_CFL, double du_min_CFL,
-                              bool write_uh) {
+                              bool write_uh, bool obc = false) {
   const m6::GridDev &g = p.g;
   const int nz = g.nk, max_itts = 20;
   const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
@@ -295,7 +364,7 @@ __device__ double flux_adjust(const FluxArgs &p, const Dir<DIR> &D, long o3_0, l
         const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
         const double u_new = p.u[f3_0 + k * fpl] + du * vr;
         double dd;
-        const double uhk = flux_layer<DIR>(p, D, u_new, o3_0 + k * hpl, o2, f2, vr, dd);
+        const double uhk = flux_layer<DIR>(p, D, u_new, o3_0 + k * hpl, o2, f2, vr, dd, obc);
         if (write_uh) p.uh[f3_0 + k * fpl] = uhk;
         usum = usum + uhk; dsum = dsum + dd;
       }
@@ -322,12 +391,20 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
   const long o2 = g.h2(fi, fj), o3_0 = o2;
   const long f2 = D.f2(fi, fj), f3_0 = f2;
 
+  // open boundaries: the segment of this face, whether its transports are the external ones (simple_OBC_pt :722-734)
+  const bool obc = p.obc_on != 0;
+  const SegDev *S_simple = nullptr, *S_spec = nullptr;
+  if (obc && (p.obc_simple || p.obc_specified)) {
+    const int l = p.segnum[f2];
+    if (l != MOM6HIP_OBC_NONE && p.segs[l - 1].specified) { if (p.obc_simple) S_simple = &p.segs[l - 1]; if (p.obc_specified) S_spec = &p.segs[l - 1]; }
+  }
   // layer transports and marginal areas, :622-635
   double uh_tot_0 = 0.0, duhdu_tot_0 = 0.0, visc_rem_max = 0.0;
   for (int k = 0; k < nz; k++) {
     const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
     double dd;
-    const double uhk = flux_layer<DIR>(p, D, p.u[f3_0 + k * fpl], o3_0 + k * hpl, o2, f2, vr, dd);
+    double uhk = flux_layer<DIR>(p, D, p.u[f3_0 + k * fpl], o3_0 + k * hpl, o2, f2, vr, dd, obc);
+    if (S_spec) uhk = seg_val<DIR>(*S_spec, S_spec->normal_trans, fi, fj, k);      // :629-634
     p.uh[f3_0 + k * fpl] = uhk;
     duhdu_tot_0 = duhdu_tot_0 + dd;
     uh_tot_0 = uh_tot_0 + uhk;
@@ -377,17 +454,31 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
   du_min_CFL = min2(du_min_CFL, 0.0);
 
   double du = 0.0;
-  if (p.uhbt) {      // :737-754
-    du = flux_adjust<DIR>(p, D, o3_0, o2, f3_0, f2, p.uhbt[f2], uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL, true);
-    if (p.u_cor && !p.set_BT_cont)      // with BT_cont, u_cor is written in the pass that evaluates the three fits below
+  if (p.uhbt) {      // :737-754 (a face whose transports are specified is left out of the adjustment: du = 0)
+    if (!S_simple) du = flux_adjust<DIR>(p, D, o3_0, o2, f3_0, f2, p.uhbt[f2], uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL, true, obc);
+    if (p.u_cor && (!p.set_BT_cont || S_simple))      // with BT_cont, u_cor is written in the pass that evaluates the three fits below
       for (int k = 0; k < nz; k++) {
         const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
-        p.u_cor[f3_0 + k * fpl] = p.u[f3_0 + k * fpl] + du * vr;
+        p.u_cor[f3_0 + k * fpl] = S_simple ? seg_val<DIR>(*S_simple, S_simple->normal_vel, fi, fj, k) : p.u[f3_0 + k * fpl] + du * vr;      // :744-748
       }
     if (p.du_cor) p.du_cor[f2] = du;
   }
 
-  if (p.set_BT_cont) {      // set_zonal_BT_cont :1247-1410
+  if (p.set_BT_cont && S_simple) {      // :1400-1404 (not solved for), then :759-779
+    double FAuI = g.H_subroundoff * D.dL_face()[f2];
+    for (int k = 0; k < nz; k++) {
+      const double nv = seg_val<DIR>(*S_simple, S_simple->normal_vel, fi, fj, k);
+      if ((fabs(nv) > 0.0) && S_simple->specified) FAuI = FAuI + seg_val<DIR>(*S_simple, S_simple->normal_trans, fi, fj, k) / nv;
+    }
+    p.FA_0m[f2] = FAuI; p.FA_0p[f2] = FAuI; p.FA_mm[f2] = FAuI; p.FA_pp[f2] = FAuI; p.uBT_mm[f2] = 0.0; p.uBT_pp[f2] = 0.0;
+    if (p.h_face) {      // flux_thickness :976-1057 with u_cor (= normal_vel) if present :809-815
+      for (int k = 0; k < nz; k++) {
+        const double vr = p.visc_rem ? p.visc_rem[f3_0 + k * fpl] : 1.0;
+        const double uc = (p.uhbt && p.u_cor) ? p.u_cor[f3_0 + k * fpl] : p.u[f3_0 + k * fpl];
+        p.h_face[f3_0 + k * fpl] = flux_thickness_layer<DIR>(p, D, uc, o3_0 + k * hpl, o2, f2, vr);
+      }
+    }
+  } else if (p.set_BT_cont) {      // set_zonal_BT_cont :1247-1410 (its own calls of flux_adjust and flux_layer do not pass OBC)
     const double min_visc_rem = 0.1, CFL_min = 1e-6;
     const double du0 = flux_adjust<DIR>(p, D, o3_0, o2, f3_0, f2, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL, false);
     const double du_CFL = (CFL_min * I_dt) * D.dLC_face()[f2];
@@ -417,31 +508,7 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
       // u_cor (:744-748) and flux_thickness (:976-1057, with u_cor if present :809-815) ride on the same layer data
       double uc = uk;
       if (cor) { uc = uk + du * vr; p.u_cor[f3_0 + k * fpl] = uc; }
-      if (p.h_face) {
-        const long o3 = o3_0 + k * hpl;
-        double CFL, curv_3, h_avg, h_marg;
-        if (uc > 0.0) {
-          if (p.o.vol_CFL) CFL = (uc * p.dt) * (D.dL_face()[f2] * g.IareaT[o2]);
-          else CFL = uc * p.dt * D.IdL_T()[o2];
-          const double hW = p.h_L[o3], hE = p.h_R[o3];
-          curv_3 = hW + hE - 2.0 * p.h_in[o3];
-          h_avg = hE + CFL * (0.5 * (hW - hE) + curv_3 * (CFL - 1.5));
-          h_marg = hE + CFL * ((hW - hE) + 3.0 * curv_3 * (CFL - 1.0));
-        } else if (uc < 0.0) {
-          if (p.o.vol_CFL) CFL = (-uc * p.dt) * (D.dL_face()[f2] * g.IareaT[o2 + s]);
-          else CFL = -uc * p.dt * D.IdL_T()[o2 + s];
-          const double hW = p.h_L[o3 + s], hE = p.h_R[o3 + s];
-          curv_3 = hW + hE - 2.0 * p.h_in[o3 + s];
-          h_avg = hW + CFL * (0.5 * (hE - hW) + curv_3 * (CFL - 1.5));
-          h_marg = hW + CFL * ((hE - hW) + 3.0 * curv_3 * (CFL - 1.0));
-        } else {
-          h_avg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
-          h_marg = 0.5 * (p.h_L[o3 + s] + p.h_R[o3]);
-        }
-        double hu = p.o.marginal_faces ? h_marg : h_avg;
-        if (p.visc_rem) hu = hu * (vr * 1.0); else hu = hu * 1.0;
-        p.h_face[f3_0 + k * fpl] = hu;
-      }
+      if (p.h_face) p.h_face[f3_0 + k * fpl] = flux_thickness_layer<DIR>(p, D, uc, o3_0 + k * hpl, o2, f2, vr);
     }
     double FA_0 = FAmt_0, FA_avg = FAmt_0;
     if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
@@ -459,6 +526,18 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
     if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) p.uBT_pp[f2] = 0.0;
     else p.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
 
+  }
+  // the faces of open segments: the face areas and thicknesses of the interior cell (:782-805 / :1058-1088, after every row in the
+  // reference: the last word on these faces)
+  if (obc && p.obc_open && p.set_BT_cont && p.fa_code[f2]) {
+    const long oi = (p.fa_code[f2] == 1) ? o3_0 : o3_0 + s;
+    const double dLf = D.dL_face()[f2];
+    double FA_u = 0.0;
+    for (int k = 0; k < nz; k++) FA_u = FA_u + p.h_in[oi + k * hpl] * (dLf * 1.0);
+    p.FA_0m[f2] = FA_u; p.FA_0p[f2] = FA_u; p.FA_mm[f2] = FA_u; p.FA_pp[f2] = FA_u; p.uBT_mm[f2] = 0.0; p.uBT_pp[f2] = 0.0;
+    if (p.h_face)
+      for (int k = 0; k < nz; k++)
+        p.h_face[f3_0 + k * fpl] = p.visc_rem ? p.h_in[oi + k * hpl] * (p.visc_rem[f3_0 + k * fpl] * 1.0) : p.h_in[oi + k * hpl] * 1.0;
   }
 }
 
@@ -1065,7 +1144,7 @@ bool flux_lane_only() {
 bool flux_is_coop(const FluxArgs &f) {
   // (and a 3-D array stays below 4 GB: the kernel addresses its layers with 32-bit byte offsets)
   const bool small = (size_t)(f.g.nih + 1) * (f.g.njh + 1) * f.g.nk * sizeof(double) < ((size_t)1 << 32);
-  return (f.uhbt || f.set_BT_cont) && f.g.nk <= FC_KSMAX * FC_NS && small && !flux_lane_only();
+  return (f.uhbt || f.set_BT_cont) && f.g.nk <= FC_KSMAX * FC_NS && small && !flux_lane_only() && !f.obc_on;      // (OBC: the lane kernel)
 }
 
 template <int DIR>
@@ -1140,6 +1219,15 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
                                   const double *uhbt, const double *vhbt, const double *visc_rem_u,
                                   const double *visc_rem_v, double *u_cor, double *v_cor,
                                   const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor, int32_t memspace) {
+  return mom6hip_continuity_obc(ctx, cs, nullptr, u, v, hin, h, uh, vh, dt, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor,
+                                dv_cor, memspace);
+}
+
+extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, const mom6hip_obc_t *obc, const double *u,
+                                      const double *v, const double *hin, double *h, double *uh, double *vh, double dt,
+                                      const double *uhbt, const double *vhbt, const double *visc_rem_u,
+                                      const double *visc_rem_v, double *u_cor, double *v_cor,
+                                      const mom6hip_bt_cont_t *BT_cont, double *du_cor, double *dv_cor, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_continuity_PPM: Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && hin && h && uh && vh, "continuity_PPM: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "continuity_PPM: bad memspace");
@@ -1198,6 +1286,78 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
   const bool x_first = (ctx->host.first_direction % 2) == 0;
   const double h_min = g.Angstrom_H;
 
+  // ---- open boundaries: what the kernels read of OBC, on the device (built at every call: regional configurations are small) ----
+  struct ObcDir { int on = 0, open = 0, simple = 0, specified = 0; const int32_t *segnum = nullptr, *cell = nullptr, *fa = nullptr; } ob[2];
+  const SegDev *d_segs = nullptr;
+  if (obc && obc->number_of_segments > 0) {
+    M6_REQUIRE(ctx->cont_phase == 0, "continuity_PPM: open boundaries with a continuity call in two phases are not provided");
+    M6_REQUIRE(obc->segment && obc->segnum_u && obc->segnum_v, "continuity_PPM: OBC%%segment, segnum_u and segnum_v are required");
+    const int nseg = obc->number_of_segments;
+    M6_REQUIRE(nseg <= 1024, "continuity_PPM: at most 1024 OBC segments");
+    const size_t nH2 = (size_t)g.nih * g.njh, nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1);
+    std::vector<SegDev> segs(nseg);
+    std::vector<int32_t> cell[2] = {std::vector<int32_t>(nH2, 0), std::vector<int32_t>(nH2, 0)};
+    std::vector<int32_t> fa[2] = {std::vector<int32_t>(nU2, 0), std::vector<int32_t>(nV2, 0)};
+    const int open_d[2] = {obc->open_u_BCs_exist_globally != 0, obc->open_v_BCs_exist_globally != 0};
+    for (int n = 0; n < nseg; n++) {
+      const mom6hip_obc_segment_t &S = obc->segment[n];
+      SegDev &d = segs[n];
+      d.direction = S.direction; d.open = S.open; d.specified = S.specified; d.pad = 0;
+      d.IsdB = S.IsdB; d.IedB = S.IedB; d.JsdB = S.JsdB; d.JedB = S.JedB; d.isd = S.isd; d.ied = S.ied; d.jsd = S.jsd; d.jed = S.jed;
+      d.normal_trans = nullptr; d.normal_vel = nullptr;
+      const bool ew = S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_W;
+      const bool ns = S.direction == MOM6HIP_OBC_DIRECTION_N || S.direction == MOM6HIP_OBC_DIRECTION_S;
+      if (!S.on_pe) continue;
+      M6_REQUIRE(ew || ns, "continuity_PPM: OBC segment %d has no direction", n + 1);
+      // (setup_u/v_point_obc leave a segment off the PE unless its faces lie two points inside the data domain :1448, :1588)
+      M6_REQUIRE(ew ? (S.IsdB >= g.isd + 1 && S.IsdB <= g.ied - 2 && S.jsd >= g.jsd && S.jed <= g.jed)
+                    : (S.JsdB >= g.jsd + 1 && S.JsdB <= g.jed - 2 && S.isd >= g.isd && S.ied <= g.ied),
+                 "continuity_PPM: OBC segment %d lies outside the data domain", n + 1);
+      if (S.specified) {
+        M6_REQUIRE(S.normal_trans && S.normal_vel, "continuity_PPM: segment %d is specified: normal_trans and normal_vel are required", n + 1);
+        const size_t cnt = ew ? (size_t)(S.IedB - S.IsdB + 1) * (S.jed - S.jsd + 1) * g.nk : (size_t)(S.ied - S.isd + 1) * (S.JedB - S.JsdB + 1) * g.nk;
+        d.normal_trans = st.in(S.normal_trans, cnt * 8); d.normal_vel = st.in(S.normal_vel, cnt * 8);
+      }
+      const int dd = ew ? 0 : 1;
+      const int A = ew ? S.IsdB : S.JsdB, c0 = ew ? S.jsd : S.isd, c1 = ew ? S.jed : S.ied;
+      const bool plus = S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_N;
+      for (int c = c0; c <= c1; c++) {
+        const long ca = ew ? g.h2(A, c) : g.h2(c, A), cb = ew ? g.h2(A + 1, c) : g.h2(c, A + 1);
+        if (open_d[dd]) {      // PPM_reconstruction_x/y :2385-2432: zero slopes, then the edge values (a later segment has the last word)
+          cell[dd][ca] = 1 | ((plus ? 1 : 3) << 1);
+          cell[dd][cb] = 1 | ((plus ? 2 : 1) << 1);
+          if (S.open && (ew ? S.is_E_or_W : S.is_N_or_S)) fa[dd][ew ? g.u2(A, c) : g.v2(c, A)] = plus ? 1 : 2;      // :782-805, :1058-1088
+        }
+      }
+    }
+    SegDev *ds = (SegDev *)st.scratch(sizeof(SegDev) * nseg);
+    int32_t *dsu = (int32_t *)st.scratch(4 * nU2), *dsv = (int32_t *)st.scratch(4 * nV2);
+    int32_t *dcx = (int32_t *)st.scratch(4 * nH2), *dcy = (int32_t *)st.scratch(4 * nH2);
+    int32_t *dfx = (int32_t *)st.scratch(4 * nU2), *dfy = (int32_t *)st.scratch(4 * nV2);
+    M6_REQUIRE(!st.failed() && ds && dsu && dsv && dcx && dcy && dfx && dfy, "continuity_PPM: staging of the open boundaries failed");
+    M6_HIP(hipMemcpyAsync(ds, segs.data(), sizeof(SegDev) * nseg, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(dsu, obc->segnum_u, 4 * nU2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(dsv, obc->segnum_v, 4 * nV2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(dcx, cell[0].data(), 4 * nH2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(dcy, cell[1].data(), 4 * nH2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(dfx, fa[0].data(), 4 * nU2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(dfy, fa[1].data(), 4 * nV2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipStreamSynchronize(s));      // (the host vectors go out of scope)
+    d_segs = ds;
+    const int pe = obc->OBC_pe != 0;
+    ob[0].on = ob[1].on = 1;
+    ob[0].open = open_d[0]; ob[1].open = open_d[1];
+    ob[0].specified = pe && obc->specified_u_BCs_exist_globally; ob[1].specified = pe && obc->specified_v_BCs_exist_globally;
+    ob[0].simple = pe && (obc->specified_u_BCs_exist_globally || obc->Flather_u_BCs_exist_globally);
+    ob[1].simple = pe && (obc->specified_v_BCs_exist_globally || obc->Flather_v_BCs_exist_globally);
+    ob[0].segnum = dsu; ob[1].segnum = dsv; ob[0].cell = dcx; ob[1].cell = dcy; ob[0].fa = dfx; ob[1].fa = dfy;
+  }
+  auto set_obc = [&](FluxArgs &f, int dd) {
+    f.obc_on = ob[dd].on; f.obc_open = ob[dd].open; f.obc_simple = ob[dd].simple; f.obc_specified = ob[dd].specified;
+    f.obc_dir_plus = dd ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E;
+    f.segnum = ob[dd].segnum; f.fa_code = ob[dd].fa; f.segs = d_segs;
+  };
+
   // hdst: where the thicknesses after this direction go (the output array, or the scratch of the phased call)
   auto zonal = [&](const double *hsrc, int jsh, int jeh, double hmin, double *hdst, double *also) -> int {
     if (jeh < jsh) return 0;
@@ -1206,8 +1366,9 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     f.FA_0m = bt.FA_u_W0; f.FA_mm = bt.FA_u_WW; f.FA_0p = bt.FA_u_E0; f.FA_pp = bt.FA_u_EE; f.uBT_mm = bt.uBT_WW;
     f.uBT_pp = bt.uBT_EE; f.h_face = bt.h_u; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = is - 1; f.fi1 = ie; f.fj0 = jsh; f.fj1 = jeh;
+    set_obc(f, 0);
     if (!flux_is_coop(f)) {
-      EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+      EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[0].open ? ob[0].cell : nullptr;
       e.i0 = is - 1; e.i1 = ie + 1; e.j0 = jsh; e.j1 = jeh;
       hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, jeh - jsh + 1, g.nk), dim3(256), 0, s, e);
     }
@@ -1227,9 +1388,10 @@ extern "C" int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_c
     f.FA_0m = bt.FA_v_S0; f.FA_mm = bt.FA_v_SS; f.FA_0p = bt.FA_v_N0; f.FA_pp = bt.FA_v_NN; f.uBT_mm = bt.vBT_SS;
     f.uBT_pp = bt.vBT_NN; f.h_face = bt.h_v; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = ish; f.fi1 = ieh; f.fj0 = fj0; f.fj1 = fj1;
+    set_obc(f, 1);
     if (fj1 >= fj0) {
       if (!flux_is_coop(f)) {
-        EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R;
+        EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[1].open ? ob[1].cell : nullptr;
         e.i0 = ish; e.i1 = ieh; e.j0 = fj0; e.j1 = fj1 + 1;
         hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((ieh - ish + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, s, e);
       }

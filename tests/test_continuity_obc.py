@@ -215,3 +215,61 @@ def test_oracle_turns_with_the_grid(segs, first_direction):
     # h_u of the original frame is h_v' turned back (a thickness: no sign)
     assert bits_equal(interior(g, unrot(arrs["h_v"]), _abi.POS_U), interior(g, o["bt"]["h_u"], _abi.POS_U))
     assert bits_equal(interior(g, unrot(arrs["h_u"]), _abi.POS_V), interior(g, o["bt"]["h_v"], _abi.POS_V))
+
+
+OBC_GPU_CASES = [dict(segs=TC3 + ["I=9,J=4:11,ORLANSKI", "J=7,I=15:3,GRADIENT"]), dict(segs=TC3, cs=dict(simple_2nd=True)),
+                 dict(segs=TC3 + ["I=9,J=4:11,ORLANSKI"], cs=dict(monotonic=True)), dict(segs=TC3, cs=dict(upwind_1st=True)),
+                 dict(segs=["I=N,J=0:N,SIMPLE", "J=0,I=0:N,SIMPLE", "I=0,J=N:0,FLATHER,ORLANSKI", "J=N,I=N:0,SIMPLE,FLATHER"]),
+                 dict(segs=["I=N,J=0:N,SIMPLE", "J=5,I=3:14,GRADIENT"], uhbt=False), dict(segs=TC3, bt=False),
+                 dict(segs=TC3 + ["I=9,J=4:11,ORLANSKI"], cs=dict(aggress_adjust=True)), dict(segs=[], cs={}),
+                 dict(segs=TC3 + ["J=7,I=15:3,GRADIENT", "J=7,I=12:5,SIMPLE"], nk=12, ni=70, nj=20)]      # (overlapping segments: the later one's number)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", OBC_GPU_CASES, ids=[str(n) for n in range(len(OBC_GPU_CASES))])
+@pytest.mark.parametrize("first_direction", [0, 1])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_continuity_with_open_boundaries_matches_oracle_bitwise(case, first_direction, space):
+    import torch
+    from mom6_amd.continuity import BT_cont_type, continuity, continuity_PPM_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    case = dict(case)
+    cskw = case.pop("cs", {}); uhbt = case.pop("uhbt", True); bt = case.pop("bt", True)
+    g, st, OBC = obc_case(case.pop("segs"), first_direction=first_direction, **case)
+    want = run(g, st, OBC, uhbt=uhbt, bt=bt, **cskw)
+    dg = DeviceGrid(g)
+    put = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if space == "device" else (lambda a: np.ascontiguousarray(a).copy())
+    get = (lambda a: a.cpu().numpy()) if space == "device" else (lambda a: a)
+    CS = continuity_PPM_init(dg, **cskw)
+    o = dict(h=put(st["h"]), uh=put(np.zeros_like(st["u"])), vh=put(np.zeros_like(st["v"])))
+    kw = dict(visc_rem_u=put(st["visc_rem_u"]), visc_rem_v=put(st["visc_rem_v"]))
+    if uhbt:
+        o.update(u_cor=put(np.zeros_like(st["u"])), v_cor=put(np.zeros_like(st["v"])), du_cor=put(g.zeros2(_abi.POS_U)), dv_cor=put(g.zeros2(_abi.POS_V)))
+        kw.update(uhbt=put(want["uhbt"]), vhbt=put(want["vhbt"]), u_cor=o["u_cor"], v_cor=o["v_cor"], du_cor=o["du_cor"], dv_cor=o["dv_cor"])
+    if bt:
+        arrs = {n: put(np.zeros_like(a)) for n, a in want["bt"].items()}
+        kw["BT_cont"] = BT_cont_type(**arrs)
+    continuity(put(st["u"]), put(st["v"]), put(st["h"]), o["h"], o["uh"], o["vh"], 900.0, dg, CS, OBC=OBC, **kw)
+    dg.sync()
+    for n, pos in (("h", _abi.POS_H), ("uh", _abi.POS_U), ("vh", _abi.POS_V)) + ((("u_cor", _abi.POS_U), ("v_cor", _abi.POS_V), ("du_cor", _abi.POS_U), ("dv_cor", _abi.POS_V)) if uhbt else ()):
+        assert bits_equal(interior(g, get(o[n]), pos), interior(g, want[n], pos)), n
+    if bt:
+        for n in want["bt"]:
+            pos = _abi.POS_U if (n in _abi.BT_CONT_U or n == "h_u") else _abi.POS_V
+            assert bits_equal(interior(g, get(arrs[n]), pos), interior(g, want["bt"][n], pos)), n
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_gpu_continuity_refuses_a_broken_obc():
+    import torch
+    from mom6_amd._lib import Mom6HipError
+    from mom6_amd.continuity import continuity, continuity_PPM_init
+    from mom6_amd.tracer_advect import DeviceGrid
+    g, st, OBC = obc_case(["I=N,J=0:N,SIMPLE"])
+    dg = DeviceGrid(g)
+    OBC.segment[0].normal_vel = None
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in st.items()}
+    with pytest.raises(Mom6HipError, match="normal_trans and normal_vel are required"):
+        continuity(d["u"], d["v"], d["h"], d["h"].clone(), torch.zeros_like(d["u"]), torch.zeros_like(d["v"]), 900.0, dg, continuity_PPM_init(dg), OBC=OBC)
+    dg.close()
