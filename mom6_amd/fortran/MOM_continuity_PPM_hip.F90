@@ -18,7 +18,7 @@ use MOM_diag_mediator, only : time_type, diag_ctrl
 use MOM_error_handler, only : MOM_error, FATAL
 use MOM_file_parser,   only : get_param, log_version, param_file_type
 use MOM_grid,          only : ocean_grid_type
-use MOM_open_boundary, only : ocean_OBC_type
+use MOM_open_boundary, only : ocean_OBC_type, OBC_segment_type
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : BT_cont_type, porous_barrier_type
 use MOM_verticalGrid,  only : verticalGrid_type
@@ -77,11 +77,14 @@ function continuity_PPM_hip_struct(CS) result(ccs)
 end function continuity_PPM_hip_struct
 
 !> What the GPU path does not do: open boundaries and porous barriers (face fractions other than 1)
-subroutine refuse_unsupported(OBC, pbv, who)
+subroutine refuse_unsupported(OBC, pbv, who, obc_ok)
   type(ocean_OBC_type),      pointer    :: OBC
   type(porous_barrier_type), intent(in) :: pbv
   character(len=*),          intent(in) :: who
-  if (associated(OBC)) call MOM_error(FATAL, who//" (HIP): open boundary conditions are not supported by the GPU path.")
+  logical, optional, intent(in) :: obc_ok   !< continuity_PPM itself takes an associated OBC (round 4); its other entry points do not
+  logical :: ok
+  ok = .false. ; if (present(obc_ok)) ok = obc_ok
+  if (associated(OBC) .and. .not.ok) call MOM_error(FATAL, who//" (HIP): open boundary conditions are not supported by the GPU path.")
   if (allocated(pbv%por_face_areaU)) then
     if (any(pbv%por_face_areaU /= 1.0)) call MOM_error(FATAL, who//" (HIP): porous barriers are not supported by the GPU path.")
   endif
@@ -118,12 +121,14 @@ subroutine continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhb
 
   type(mom6hip_bt_cont_t), target :: cbt
   type(c_ptr) :: p_uhbt, p_vhbt, p_vru, p_vrv, p_ucor, p_vcor, p_bt, p_du, p_dv
-  integer :: rc
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
+  integer :: rc, n
 
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_continuity_PPM: Module must be initialized before it is used.")
   if (present(visc_rem_u) .neqv. present(visc_rem_v)) call MOM_error(FATAL, "MOM_continuity_PPM: "//&
         "Either both visc_rem_u and visc_rem_v or neither one must be present in call to continuity_PPM.")
-  call refuse_unsupported(OBC, pbv, "MOM_continuity_PPM")
+  call refuse_unsupported(OBC, pbv, "MOM_continuity_PPM", obc_ok=.true.)
 
   p_uhbt = c_null_ptr ; if (present(uhbt)) p_uhbt = c_loc(uhbt)
   p_vhbt = c_null_ptr ; if (present(vhbt)) p_vhbt = c_loc(vhbt)
@@ -146,9 +151,47 @@ subroutine continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhb
     p_bt = c_loc(cbt)
   endif ; endif
 
+  if (associated(OBC)) then      ! what continuity_PPM reads of ocean_OBC_type and its segments (MOM_open_boundary.F90:146-386)
+    allocate(csegs(max(OBC%number_of_segments, 1)))
+    do n=1,OBC%number_of_segments
+      call segment_to_c(OBC%segment(n), csegs(n))
+    enddo
+    cobc%number_of_segments = OBC%number_of_segments ; cobc%OBC_pe = merge(1, 0, OBC%OBC_pe)
+    cobc%open_u_BCs_exist_globally = merge(1, 0, OBC%open_u_BCs_exist_globally)
+    cobc%open_v_BCs_exist_globally = merge(1, 0, OBC%open_v_BCs_exist_globally)
+    cobc%specified_u_BCs_exist_globally = merge(1, 0, OBC%specified_u_BCs_exist_globally)
+    cobc%specified_v_BCs_exist_globally = merge(1, 0, OBC%specified_v_BCs_exist_globally)
+    cobc%Flather_u_BCs_exist_globally = merge(1, 0, OBC%Flather_u_BCs_exist_globally)
+    cobc%Flather_v_BCs_exist_globally = merge(1, 0, OBC%Flather_v_BCs_exist_globally)
+    cobc%segment = c_loc(csegs)
+    if (OBC%number_of_segments > 0) then
+      if (.not.(allocated(OBC%segnum_u) .and. allocated(OBC%segnum_v))) call MOM_error(FATAL, &
+        "MOM_continuity_PPM (HIP): OBC%segnum_u and OBC%segnum_v must be allocated.")
+      if (size(OBC%segnum_u) /= size(uh(:,:,1)) .or. size(OBC%segnum_v) /= size(vh(:,:,1))) call MOM_error(FATAL, &
+        "MOM_continuity_PPM (HIP): OBC%segnum_u / segnum_v do not have the shape of the u / v points of the data domain.")
+      cobc%segnum_u = c_loc(OBC%segnum_u) ; cobc%segnum_v = c_loc(OBC%segnum_v)
+    endif
+    rc = mom6hip_continuity_obc(mom6hip_shared_context(G, GV), c_struct(CS), cobc, c_loc(u), c_loc(v), c_loc(hin), c_loc(h), c_loc(uh), &
+                                c_loc(vh), dt, p_uhbt, p_vhbt, p_vru, p_vrv, p_ucor, p_vcor, p_bt, p_du, p_dv, MOM6HIP_MEM_HOST)
+  else
   rc = mom6hip_continuity(mom6hip_shared_context(G, GV), c_struct(CS), c_loc(u), c_loc(v), c_loc(hin), c_loc(h), c_loc(uh), &
                           c_loc(vh), dt, p_uhbt, p_vhbt, p_vru, p_vrv, p_ucor, p_vcor, p_bt, p_du, p_dv, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "MOM_continuity_PPM")
+contains
+  subroutine segment_to_c(seg, c)
+    type(OBC_segment_type), target, intent(in) :: seg
+    type(mom6hip_obc_segment_t), intent(out) :: c
+    c%direction = seg%direction ; c%open = merge(1, 0, seg%open) ; c%specified = merge(1, 0, seg%specified)
+    c%on_pe = merge(1, 0, seg%on_pe) ; c%is_E_or_W = merge(1, 0, seg%is_E_or_W) ; c%is_N_or_S = merge(1, 0, seg%is_N_or_S)
+    c%IsdB = seg%HI%IsdB ; c%IedB = seg%HI%IedB ; c%JsdB = seg%HI%JsdB ; c%JedB = seg%HI%JedB
+    c%isd = seg%HI%isd ; c%ied = seg%HI%ied ; c%jsd = seg%HI%jsd ; c%jed = seg%HI%jed
+    if (seg%specified .and. seg%on_pe) then
+      if (.not.(allocated(seg%normal_trans) .and. allocated(seg%normal_vel))) call MOM_error(FATAL, &
+        "MOM_continuity_PPM (HIP): a specified segment needs normal_trans and normal_vel.")
+      c%normal_trans = c_loc(seg%normal_trans) ; c%normal_vel = c_loc(seg%normal_vel)
+    endif
+  end subroutine segment_to_c
 end subroutine continuity_PPM
 
 !> Same interface as the reference continuity_3d_fluxes (:200): the transports without the thickness update

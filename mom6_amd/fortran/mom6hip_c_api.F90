@@ -191,6 +191,25 @@ type, bind(c) :: mom6hip_neutral_diffusion_cs_t
   integer(c_int32_t) :: unsupported(8) = 0
 end type mom6hip_neutral_diffusion_cs_t
 
+!> mom6hip_obc_segment_t / mom6hip_obc_t: what continuity_PPM reads of OBC_segment_type / ocean_OBC_type (src/core/MOM_open_boundary.F90:146, :266)
+integer(c_int32_t), parameter :: MOM6HIP_OBC_NONE = 0, MOM6HIP_OBC_DIRECTION_N = 100, MOM6HIP_OBC_DIRECTION_S = 200, &
+                                 MOM6HIP_OBC_DIRECTION_E = 300, MOM6HIP_OBC_DIRECTION_W = 400
+type, bind(c) :: mom6hip_obc_segment_t
+  integer(c_int32_t) :: direction = 0, open = 0, specified = 0, on_pe = 0, is_E_or_W = 0, is_N_or_S = 0
+  integer(c_int32_t) :: IsdB = 0, IedB = 0, JsdB = 0, JedB = 0, isd = 0, ied = 0, jsd = 0, jed = 0
+  integer(c_int32_t) :: reserved(6) = 0
+  type(c_ptr) :: normal_trans = c_null_ptr, normal_vel = c_null_ptr
+  type(c_ptr) :: reserved_p(4) = c_null_ptr
+end type mom6hip_obc_segment_t
+type, bind(c) :: mom6hip_obc_t
+  integer(c_int32_t) :: number_of_segments = 0, OBC_pe = 0, open_u_BCs_exist_globally = 0, open_v_BCs_exist_globally = 0
+  integer(c_int32_t) :: specified_u_BCs_exist_globally = 0, specified_v_BCs_exist_globally = 0
+  integer(c_int32_t) :: Flather_u_BCs_exist_globally = 0, Flather_v_BCs_exist_globally = 0
+  integer(c_int32_t) :: reserved(8) = 0
+  type(c_ptr) :: segment = c_null_ptr, segnum_u = c_null_ptr, segnum_v = c_null_ptr
+  type(c_ptr) :: reserved_p(4) = c_null_ptr
+end type mom6hip_obc_t
+
 !> mom6hip_epipycnal_cs_t (DIFFUSE_ML_TO_INTERIOR: tracer_epipycnal_ML_diff, src/tracer/MOM_tracer_hor_diff.F90:700)
 type, bind(c) :: mom6hip_epipycnal_cs_t
   real(c_double) :: ML_KhTr_scale = 1.0, P_Ref = 0.0
@@ -624,6 +643,18 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_continuity
+
+  !> continuity_PPM with OBC associated: obc holds host pointers (its segment table and segnum arrays) whatever the memory space
+  function mom6hip_continuity_obc(ctx, cs, obc, u, v, hin, h, uh, vh, dt, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, &
+                                  BT_cont, du_cor, dv_cor, memspace) bind(c, name="mom6hip_continuity_obc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_continuity_cs_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v, hin, h, uh, vh, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont, du_cor, dv_cor
+    type(mom6hip_continuity_cs_t), intent(in) :: cs
+    type(mom6hip_obc_t), intent(in) :: obc
+    real(c_double), value :: dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_continuity_obc
 
   !> eos: c_loc of a mom6hip_eos_t, or c_null_ptr without an equation of state (use_EOS = .false.; T and S may be null then)
   function mom6hip_pressureforce_fv_bouss(ctx, cs, eos, h, T, S, p_atm, PFu, PFv, pbce, eta, memspace) &

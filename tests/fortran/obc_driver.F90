@@ -1,0 +1,122 @@
+!> Drives continuity_PPM of the module shim with an associated OBC the way step_MOM_dyn_split_RK2 calls it
+!! (MOM_dynamics_split_RK2.F90:757): an ocean_grid_type and an ocean_OBC_type -- its segments with their hor_index ranges and
+!! flags, segnum_u / segnum_v, the external transports and velocities of the specified segments -- filled from a file written by
+!! tests/test_continuity_obc.py, then
+!!   continuity(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont)
+!! on plain host arrays; the results go to the output file, which the test compares with the oracle bit for bit.
+!! Usage: obc_driver <input file> <output file>
+program obc_driver
+use, intrinsic :: iso_c_binding
+use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_PPM_CS
+use MOM_diag_mediator,  only : diag_ctrl, time_type
+use MOM_domains,        only : MOM_domain_type
+use MOM_file_parser,    only : param_file_type, param_set
+use MOM_grid,           only : ocean_grid_type
+use MOM_open_boundary,  only : ocean_OBC_type, OBC_segment_type
+use MOM_unit_scaling,   only : unit_scale_type
+use MOM_variables,      only : BT_cont_type, porous_barrier_type, alloc_BT_cont_type
+use MOM_verticalGrid,   only : verticalGrid_type
+use mom6hip_MOM_glue,   only : mom6hip_shared_context_end
+implicit none
+
+type(ocean_grid_type), target :: G
+type(verticalGrid_type) :: GV
+type(unit_scale_type) :: US
+type(param_file_type) :: pf
+type(time_type), target :: Time
+type(diag_ctrl), target :: diag
+type(continuity_PPM_CS) :: CS
+type(ocean_OBC_type), pointer :: OBC => NULL()
+type(porous_barrier_type) :: pbv
+type(BT_cont_type), pointer :: BT => NULL()
+integer(c_int32_t) :: hdr(8), oflags(8), sflags(14)
+integer(c_int32_t), allocatable :: su(:,:), sv(:,:)
+integer :: ni, nj, nk, halo, u_in, u_out, isd, ied, jsd, jed, n, nseg
+real :: scal(7), dt
+real, allocatable, dimension(:,:,:) :: u, v, h, hp, uh, vh, vru, vrv, u_cor, v_cor
+real, allocatable, dimension(:,:) :: uhbt, vhbt
+character(len=512) :: f_in, f_out
+
+call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
+open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
+read(u_in) hdr
+ni = hdr(1) ; nj = hdr(2) ; nk = hdr(3) ; halo = hdr(4)
+isd = 1 ; ied = ni + 2*halo ; jsd = 1 ; jed = nj + 2*halo
+G%isd = isd ; G%ied = ied ; G%jsd = jsd ; G%jed = jed ; G%IsdB = isd-1 ; G%IedB = ied ; G%JsdB = jsd-1 ; G%JedB = jed
+G%isc = isd+halo ; G%iec = ied-halo ; G%jsc = jsd+halo ; G%jec = jed-halo
+G%IscB = G%isc-1 ; G%IecB = G%iec ; G%JscB = G%jsc-1 ; G%JecB = G%jec ; G%ke = nk ; GV%ke = nk
+G%first_direction = hdr(7) ; G%symmetric = .true.
+allocate(G%Domain)
+G%Domain%reentrant(1) = (hdr(5) /= 0) ; G%Domain%reentrant(2) = (hdr(6) /= 0)
+G%Domain%nihalo = halo ; G%Domain%njhalo = halo ; G%Domain%niglobal = ni ; G%Domain%njglobal = nj
+read(u_in) scal, dt
+GV%Angstrom_H = scal(1) ; GV%H_subroundoff = scal(2) ; GV%dZ_subroundoff = scal(3) ; GV%H_to_Z = scal(4) ; GV%Z_to_H = scal(5)
+GV%g_Earth = scal(6) ; GV%Rho0 = scal(7)
+
+allocate(G%mask2dT(isd:ied,jsd:jed), G%areaT(isd:ied,jsd:jed), G%IareaT(isd:ied,jsd:jed), G%dxT(isd:ied,jsd:jed), &
+         G%dyT(isd:ied,jsd:jed), G%IdxT(isd:ied,jsd:jed), G%IdyT(isd:ied,jsd:jed), G%bathyT(isd:ied,jsd:jed))
+allocate(G%mask2dCu(isd-1:ied,jsd:jed), G%dxCu(isd-1:ied,jsd:jed), G%dyCu(isd-1:ied,jsd:jed), G%dy_Cu(isd-1:ied,jsd:jed), &
+         G%IdxCu(isd-1:ied,jsd:jed), G%IdyCu(isd-1:ied,jsd:jed), G%areaCu(isd-1:ied,jsd:jed), G%IareaCu(isd-1:ied,jsd:jed))
+allocate(G%mask2dCv(isd:ied,jsd-1:jed), G%dxCv(isd:ied,jsd-1:jed), G%dyCv(isd:ied,jsd-1:jed), G%dx_Cv(isd:ied,jsd-1:jed), &
+         G%IdxCv(isd:ied,jsd-1:jed), G%IdyCv(isd:ied,jsd-1:jed), G%areaCv(isd:ied,jsd-1:jed), G%IareaCv(isd:ied,jsd-1:jed))
+allocate(G%mask2dBu(isd-1:ied,jsd-1:jed), G%dxBu(isd-1:ied,jsd-1:jed), G%dyBu(isd-1:ied,jsd-1:jed), G%areaBu(isd-1:ied,jsd-1:jed), &
+         G%IareaBu(isd-1:ied,jsd-1:jed), G%CoriolisBu(isd-1:ied,jsd-1:jed), G%IdxBu(isd-1:ied,jsd-1:jed), G%IdyBu(isd-1:ied,jsd-1:jed))
+read(u_in) G%mask2dT, G%areaT, G%IareaT, G%dxT, G%dyT, G%IdxT, G%IdyT, G%bathyT
+read(u_in) G%mask2dCu, G%dxCu, G%dyCu, G%dy_Cu, G%IdxCu, G%IdyCu, G%areaCu, G%IareaCu
+read(u_in) G%mask2dCv, G%dxCv, G%dyCv, G%dx_Cv, G%IdxCv, G%IdyCv, G%areaCv, G%IareaCv
+read(u_in) G%mask2dBu, G%dxBu, G%dyBu, G%areaBu, G%IareaBu, G%CoriolisBu, G%IdxBu, G%IdyBu
+
+allocate(u(isd-1:ied,jsd:jed,nk), v(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk), uhbt(isd-1:ied,jsd:jed), vhbt(isd:ied,jsd-1:jed), &
+         vru(isd-1:ied,jsd:jed,nk), vrv(isd:ied,jsd-1:jed,nk))
+read(u_in) u, v, h, uhbt, vhbt, vru, vrv
+
+! ocean_OBC_type as open_boundary_config leaves it: [number_of_segments, OBC_pe, open_u, open_v, specified_u, specified_v, Flather_u, Flather_v],
+! per segment [direction, open, specified, on_pe, is_E_or_W, is_N_or_S, IsdB, IedB, JsdB, JedB, isd, ied, jsd, jed], segnum_u, segnum_v,
+! and for the specified segments on the PE normal_trans, normal_vel on the segment's own index ranges
+allocate(OBC)
+read(u_in) oflags
+nseg = oflags(1)
+OBC%number_of_segments = nseg ; OBC%OBC_pe = (oflags(2) /= 0)
+OBC%open_u_BCs_exist_globally = (oflags(3) /= 0) ; OBC%open_v_BCs_exist_globally = (oflags(4) /= 0)
+OBC%specified_u_BCs_exist_globally = (oflags(5) /= 0) ; OBC%specified_v_BCs_exist_globally = (oflags(6) /= 0)
+OBC%Flather_u_BCs_exist_globally = (oflags(7) /= 0) ; OBC%Flather_v_BCs_exist_globally = (oflags(8) /= 0)
+allocate(OBC%segment(nseg))
+do n=1,nseg
+  read(u_in) sflags
+  OBC%segment(n)%direction = sflags(1) ; OBC%segment(n)%open = (sflags(2) /= 0) ; OBC%segment(n)%specified = (sflags(3) /= 0)
+  OBC%segment(n)%on_pe = (sflags(4) /= 0) ; OBC%segment(n)%is_E_or_W = (sflags(5) /= 0) ; OBC%segment(n)%is_N_or_S = (sflags(6) /= 0)
+  OBC%segment(n)%HI%IsdB = sflags(7) ; OBC%segment(n)%HI%IedB = sflags(8) ; OBC%segment(n)%HI%JsdB = sflags(9) ; OBC%segment(n)%HI%JedB = sflags(10)
+  OBC%segment(n)%HI%isd = sflags(11) ; OBC%segment(n)%HI%ied = sflags(12) ; OBC%segment(n)%HI%jsd = sflags(13) ; OBC%segment(n)%HI%jed = sflags(14)
+enddo
+allocate(su(isd-1:ied,jsd:jed), sv(isd:ied,jsd-1:jed), OBC%segnum_u(isd-1:ied,jsd:jed), OBC%segnum_v(isd:ied,jsd-1:jed))
+read(u_in) su, sv
+OBC%segnum_u(:,:) = su(:,:) ; OBC%segnum_v(:,:) = sv(:,:)
+do n=1,nseg ; if (OBC%segment(n)%specified .and. OBC%segment(n)%on_pe) then
+  if (OBC%segment(n)%is_E_or_W) then
+    allocate(OBC%segment(n)%normal_trans(OBC%segment(n)%HI%IsdB:OBC%segment(n)%HI%IedB, OBC%segment(n)%HI%jsd:OBC%segment(n)%HI%jed, nk))
+    allocate(OBC%segment(n)%normal_vel(OBC%segment(n)%HI%IsdB:OBC%segment(n)%HI%IedB, OBC%segment(n)%HI%jsd:OBC%segment(n)%HI%jed, nk))
+  else
+    allocate(OBC%segment(n)%normal_trans(OBC%segment(n)%HI%isd:OBC%segment(n)%HI%ied, OBC%segment(n)%HI%JsdB:OBC%segment(n)%HI%JedB, nk))
+    allocate(OBC%segment(n)%normal_vel(OBC%segment(n)%HI%isd:OBC%segment(n)%HI%ied, OBC%segment(n)%HI%JsdB:OBC%segment(n)%HI%JedB, nk))
+  endif
+  read(u_in) OBC%segment(n)%normal_trans, OBC%segment(n)%normal_vel
+endif ; enddo
+close(u_in)
+
+allocate(hp(isd:ied,jsd:jed,nk), uh(isd-1:ied,jsd:jed,nk), vh(isd:ied,jsd-1:jed,nk), u_cor(isd-1:ied,jsd:jed,nk), v_cor(isd:ied,jsd-1:jed,nk))
+hp = h ; uh = 0.0 ; vh = 0.0 ; u_cor = 0.0 ; v_cor = 0.0
+call param_set(pf, "REENTRANT_X", merge("True ", "False", hdr(5) /= 0))
+call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))
+call continuity_PPM_init(Time, G, GV, US, pf, diag, CS)
+call alloc_BT_cont_type(BT, isd, ied, jsd, jed, nk, alloc_faces=.true.)
+
+call continuity_PPM(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, vru, vrv, u_cor, v_cor, BT_cont=BT)
+
+open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
+write(u_out) hp, uh, vh, u_cor, v_cor
+write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_EE
+write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
+close(u_out)
+call mom6hip_shared_context_end()
+write(*,'(a)') "obc_driver ok"
+end program obc_driver

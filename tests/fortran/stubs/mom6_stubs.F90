@@ -1195,6 +1195,7 @@ end subroutine extract_diabatic_member
 end module MOM_diabatic_driver
 
 module MOM_open_boundary
+use MOM_hor_index, only : hor_index_type
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
 use MOM_unit_scaling, only : unit_scale_type
@@ -1202,7 +1203,22 @@ use MOM_time_manager, only : time_type
 implicit none ; private
 public :: ocean_OBC_type, radiation_open_bdry_conds, open_boundary_zero_normal_flow, open_boundary_query
 public :: open_boundary_test_extern_h, update_OBC_ramp
+public :: OBC_segment_type, OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W
+integer, parameter :: OBC_NONE = 0, OBC_DIRECTION_N = 100, OBC_DIRECTION_S = 200, OBC_DIRECTION_E = 300, OBC_DIRECTION_W = 400
+type :: OBC_segment_type
+  logical :: Flather = .false., radiation = .false., oblique = .false., nudged = .false., specified = .false., open = .false.
+  logical :: gradient = .false., on_pe = .false., is_N_or_S = .false., is_E_or_W = .false.
+  integer :: direction = 0
+  type(hor_index_type) :: HI
+  real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:)
+end type OBC_segment_type
 type :: ocean_OBC_type
+  logical :: OBC_pe = .false.
+  logical :: open_u_BCs_exist_globally = .false., open_v_BCs_exist_globally = .false.
+  logical :: Flather_u_BCs_exist_globally = .false., Flather_v_BCs_exist_globally = .false.
+  logical :: specified_u_BCs_exist_globally = .false., specified_v_BCs_exist_globally = .false.
+  type(OBC_segment_type), allocatable :: segment(:)
+  integer, allocatable :: segnum_u(:,:), segnum_v(:,:)
   integer :: number_of_segments = 0
   logical :: update_OBC = .false., oblique_BCs_exist_globally = .false., radiation_BCs_exist_globally = .false.
   logical :: ramp = .false., zero_vorticity = .false., freeslip_vorticity = .false., computed_vorticity = .false.

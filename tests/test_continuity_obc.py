@@ -273,3 +273,57 @@ def test_gpu_continuity_refuses_a_broken_obc():
     with pytest.raises(Mom6HipError, match="normal_trans and normal_vel are required"):
         continuity(d["u"], d["v"], d["h"], d["h"].clone(), torch.zeros_like(d["u"]), torch.zeros_like(d["v"]), 900.0, dg, continuity_PPM_init(dg), OBC=OBC)
     dg.close()
+
+
+def _write_obc_case(path, g, st, OBC, uhbt, vhbt, dt=900.0):
+    """the input file of tests/fortran/obc_driver.F90"""
+    with open(path, "wb") as f:
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (st["u"], st["v"], st["h"], uhbt, vhbt, st["visc_rem_u"], st["visc_rem_v"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        np.array([OBC.number_of_segments, OBC.OBC_pe, OBC.open_u_BCs_exist_globally, OBC.open_v_BCs_exist_globally, OBC.specified_u_BCs_exist_globally,
+                  OBC.specified_v_BCs_exist_globally, OBC.Flather_u_BCs_exist_globally, OBC.Flather_v_BCs_exist_globally], dtype="<i4").tofile(f)
+        for s in OBC.segment:
+            np.array([s.direction, s.open, s.specified, s.on_pe, s.is_E_or_W, s.is_N_or_S] +
+                     [s.HI.get(k, 0) for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed")], dtype="<i4").tofile(f)
+        OBC.segnum_u.astype("<i4").tofile(f); OBC.segnum_v.astype("<i4").tofile(f)
+        for s in OBC.segment:
+            if s.specified and s.on_pe:
+                np.ascontiguousarray(s.normal_trans, dtype="<f8").tofile(f); np.ascontiguousarray(s.normal_vel, dtype="<f8").tofile(f)
+
+
+def test_obc_driver_compiles(tmp_path):
+    import os
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    _build_shims(tmp_path, driver="obc_driver")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("segs", [TC3 + ["I=9,J=4:11,ORLANSKI"], ["I=N,J=0:N,SIMPLE", "J=0,I=0:N,SIMPLE", "I=0,J=N:0,FLATHER,ORLANSKI", "J=N,I=N:0,GRADIENT"]],
+                         ids=["tc3+inner", "simple"])
+def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
+    """continuity_PPM of the module shim with the reference's ocean_OBC_type (its segments, segnum arrays and external values) on host arrays:
+    the oracle's bits"""
+    import os, subprocess
+    from test_fortran_abi import FC, _build_shims
+    if not os.path.exists(FC):
+        pytest.skip("amdflang not present")
+    exe = _build_shims(tmp_path, driver="obc_driver")
+    g, st, OBC = obc_case(segs)
+    want = run(g, st, OBC)
+    _write_obc_case(str(tmp_path / "in.bin"), g, st, OBC, want["uhbt"], want["vhbt"])
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
+             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"]
+    arrs = [want[n] if n in want else want["bt"][n] for n in names]
+    got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
+    for n, a, w in zip(names, got, arrs):
+        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
