@@ -457,6 +457,14 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
                       const double *h, const double *uh, const double *vh, double *CAu, double *CAv,
                       int32_t memspace);
 
+struct mom6hip_obc;
+/* CorAdCalc with OBC associated (:249-269 the areas across a segment, :337-420 the circulation and the thicknesses projected onto the
+ * velocity points of a segment, :422-455 onto its corner points, gradKE :1037-1050); additionally needs the metrics dxBu, dyBu with
+ * OBC%specified_vorticity.  obc == NULL: mom6hip_coradcalc. */
+int mom6hip_coradcalc_obc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, const struct mom6hip_obc *obc, const double *u,
+                          const double *v, const double *h, const double *uh, const double *vh, double *CAu, double *CAv,
+                          int32_t memspace);
+
 /* ---- MOM_continuity_PPM --------------------------------------------------------------------- */
 
 /* continuity_PPM_CS, src/core/MOM_continuity_PPM.F90:35-67; defaults of continuity_PPM_init :2679-2757 */
@@ -497,8 +505,9 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 
 /*
  * Open boundaries (src/core/MOM_open_boundary.F90): what continuity_PPM reads of ocean_OBC_type (:266-386) and of its segments
- * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc); every other entry point
- * of the library still requires that OBC is not associated, so a configuration with open boundaries cannot be stepped yet.
+ * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc) and of CorAdCalc
+ * (mom6hip_coradcalc_obc); every other entry point of the library still requires that OBC is not associated, so a configuration
+ * with open boundaries cannot be stepped yet.
  * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */
 #define MOM6HIP_OBC_NONE 0            /* OBC_NONE :79 */
@@ -519,7 +528,10 @@ typedef struct mom6hip_obc_segment {
   /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where
    * `specified`; in the memory space of the call; may be NULL otherwise */
   const double *normal_trans, *normal_vel;
-  void *reserved_p[4];
+  /* segment%tangential_vel, segment%tangential_grad (IsdB:IedB, JsdB:JedB, nk): read by CorAdCalc with OBC%computed_vorticity /
+   * OBC%specified_vorticity; may be NULL otherwise */
+  const double *tangential_vel, *tangential_grad;
+  void *reserved_p[2];
 } mom6hip_obc_segment_t;
 
 typedef struct mom6hip_obc {
@@ -528,7 +540,8 @@ typedef struct mom6hip_obc {
   int32_t open_u_BCs_exist_globally, open_v_BCs_exist_globally;
   int32_t specified_u_BCs_exist_globally, specified_v_BCs_exist_globally;
   int32_t Flather_u_BCs_exist_globally, Flather_v_BCs_exist_globally;
-  int32_t reserved[8];
+  int32_t zero_vorticity, freeslip_vorticity, computed_vorticity, specified_vorticity;      /* OBC_ZERO_VORTICITY ... (read by CorAdCalc) */
+  int32_t reserved[4];
   const mom6hip_obc_segment_t *segment;             /* number_of_segments entries (HOST array) */
   const int32_t *segnum_u, *segnum_v;               /* OBC%segnum_u(IsdB:IedB, jsd:jed), segnum_v(isd:ied, JsdB:JedB): the segment number
                                                        (1-based) of a face, MOM6HIP_OBC_NONE elsewhere; HOST arrays */

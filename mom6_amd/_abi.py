@@ -189,15 +189,17 @@ class ObcSegment(C.Structure):
     """mom6hip_obc_segment_t (include/mom6hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("direction", "open", "specified", "on_pe", "is_E_or_W", "is_N_or_S", "IsdB", "IedB", "JsdB", "JedB",
                                          "isd", "ied", "jsd", "jed")] + \
-               [("reserved", C.c_int32 * 6), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("reserved_p", C.c_void_p * 4)]
+               [("reserved", C.c_int32 * 6), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("tangential_vel", C.c_void_p),
+                ("tangential_grad", C.c_void_p), ("reserved_p", C.c_void_p * 2)]
 
 
 class Obc(C.Structure):
     """mom6hip_obc_t (include/mom6hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("number_of_segments", "OBC_pe", "open_u_BCs_exist_globally", "open_v_BCs_exist_globally",
                                          "specified_u_BCs_exist_globally", "specified_v_BCs_exist_globally",
-                                         "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally")] + \
-               [("reserved", C.c_int32 * 8), ("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
+                                         "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally", "zero_vorticity",
+                                         "freeslip_vorticity", "computed_vorticity", "specified_vorticity")] + \
+               [("reserved", C.c_int32 * 4), ("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
                 ("reserved_p", C.c_void_p * 4)]
 
 

@@ -198,14 +198,15 @@ type, bind(c) :: mom6hip_obc_segment_t
   integer(c_int32_t) :: direction = 0, open = 0, specified = 0, on_pe = 0, is_E_or_W = 0, is_N_or_S = 0
   integer(c_int32_t) :: IsdB = 0, IedB = 0, JsdB = 0, JedB = 0, isd = 0, ied = 0, jsd = 0, jed = 0
   integer(c_int32_t) :: reserved(6) = 0
-  type(c_ptr) :: normal_trans = c_null_ptr, normal_vel = c_null_ptr
-  type(c_ptr) :: reserved_p(4) = c_null_ptr
+  type(c_ptr) :: normal_trans = c_null_ptr, normal_vel = c_null_ptr, tangential_vel = c_null_ptr, tangential_grad = c_null_ptr
+  type(c_ptr) :: reserved_p(2) = c_null_ptr
 end type mom6hip_obc_segment_t
 type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: number_of_segments = 0, OBC_pe = 0, open_u_BCs_exist_globally = 0, open_v_BCs_exist_globally = 0
   integer(c_int32_t) :: specified_u_BCs_exist_globally = 0, specified_v_BCs_exist_globally = 0
   integer(c_int32_t) :: Flather_u_BCs_exist_globally = 0, Flather_v_BCs_exist_globally = 0
-  integer(c_int32_t) :: reserved(8) = 0
+  integer(c_int32_t) :: zero_vorticity = 0, freeslip_vorticity = 0, computed_vorticity = 0, specified_vorticity = 0
+  integer(c_int32_t) :: reserved(4) = 0
   type(c_ptr) :: segment = c_null_ptr, segnum_u = c_null_ptr, segnum_v = c_null_ptr
   type(c_ptr) :: reserved_p(4) = c_null_ptr
 end type mom6hip_obc_t

@@ -72,14 +72,21 @@ class OBC_segment_type:
         self.Is_obc = self.Ie_obc = self.Js_obc = self.Je_obc = 0
         self.normal_trans = None      # (nk, jsd:jed, IsdB:IedB) for E / W, (nk, JsdB:JedB, isd:ied) for N / S (C order = the Fortran layout)
         self.normal_vel = None
+        self.tangential_vel = None    # (nk, JsdB:JedB, IsdB:IedB): the corner points along the segment
+        self.tangential_grad = None
 
 
 class ocean_OBC_type:
     """ocean_OBC_type :266-386 as open_boundary_config leaves it on one tile.  grid: the tile's Grid; idg_offset / jdg_offset: global
     index = local index + offset (one tile with isd = 1: -halo)."""
 
-    def __init__(self, grid, segment_strs, idg_offset=None, jdg_offset=None, ni_global=None, nj_global=None):
+    def __init__(self, grid, segment_strs, idg_offset=None, jdg_offset=None, ni_global=None, nj_global=None, **flags):
         g = self.grid = grid
+        # OBC_ZERO_VORTICITY, OBC_FREESLIP_VORTICITY, OBC_COMPUTED_VORTICITY, OBC_SPECIFIED_VORTICITY (:470-500), read by CorAdCalc
+        for n in ("zero_vorticity", "freeslip_vorticity", "computed_vorticity", "specified_vorticity"):
+            setattr(self, n, bool(flags.pop(n, False)))
+        if flags:
+            raise Mom6HipError(f"open_boundary_config: unknown option {sorted(flags)}")
         self.idg_offset = -g.halo if idg_offset is None else idg_offset
         self.jdg_offset = -g.halo if jdg_offset is None else jdg_offset
         self.ieg = g.ni if ni_global is None else ni_global
@@ -180,6 +187,8 @@ class ocean_OBC_type:
         else:
             shp = (nk, H["JedB"] - H["JsdB"] + 1, H["ied"] - H["isd"] + 1)
         seg.normal_trans = np.zeros(shp); seg.normal_vel = np.zeros(shp)
+        shq = (nk, H["JedB"] - H["JsdB"] + 1, H["IedB"] - H["IsdB"] + 1)
+        seg.tangential_vel = np.zeros(shq); seg.tangential_grad = np.zeros(shq)
 
     def _setup_u_point_obc(self, seg, sstr, l_seg):      # :1333-1471
         g = self.grid
@@ -240,9 +249,10 @@ class ocean_OBC_type:
             c.is_E_or_W, c.is_N_or_S = int(s.is_E_or_W), int(s.is_N_or_S)
             for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed"):
                 setattr(c, k, int(s.HI.get(k, 0)))
-            for k in ("normal_trans", "normal_vel"):
+            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad"):
                 a = getattr(s, k)
-                if a is not None and s.specified:
+                need = s.specified if k.startswith("normal") else (self.computed_vorticity if k == "tangential_vel" else self.specified_vorticity)
+                if a is not None and need and s.on_pe:
                     if to_ptr is None:
                         a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); setattr(c, k, a.ctypes.data)
                     else:
@@ -250,7 +260,8 @@ class ocean_OBC_type:
         o = _abi.Obc()
         o.number_of_segments, o.OBC_pe = self.number_of_segments, int(self.OBC_pe)
         for k in ("open_u_BCs_exist_globally", "open_v_BCs_exist_globally", "specified_u_BCs_exist_globally", "specified_v_BCs_exist_globally",
-                  "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally"):
+                  "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally", "zero_vorticity", "freeslip_vorticity", "computed_vorticity",
+                  "specified_vorticity"):
             setattr(o, k, int(getattr(self, k)))
         o.segment = C.cast(segs, C.POINTER(_abi.ObcSegment))
         o.segnum_u, o.segnum_v = self.segnum_u.ctypes.data, self.segnum_v.ctypes.data

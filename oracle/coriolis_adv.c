@@ -21,6 +21,27 @@ static inline double min4(double a, double b, double c, double d) { return min2(
 int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const double *u, const double *v,
                   const double *h, const double *uh, const double *vh, double *CAu, double *CAv)
 {
+  return orc_coradcalc_obc(G, CS, NULL, u, v, h, uh, vh, CAu, CAv);
+}
+
+/* segment%tangential_vel / tangential_grad (IsdB:IedB, JsdB:JedB, nk) at the corner point (I, J), layer k (1-based) */
+static inline double seg_q(const mom6hip_obc_segment_t *S, const double *f, int I, int J, int k) {
+  const long nI = S->IedB - S->IsdB + 1, nJ = S->JedB - S->JsdB + 1;
+  return f[(I - S->IsdB) + nI*((J - S->JsdB) + nJ*(long)(k-1))];
+}
+static inline int imax2(int a, int b) { return a > b ? a : b; }
+static inline int imin2(int a, int b) { return a < b ? a : b; }
+
+int orc_coradcalc_obc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const mom6hip_obc_t *OBC, const double *u,
+                      const double *v, const double *h, const double *uh, const double *vh, double *CAu, double *CAv)
+{
+  const int nseg = OBC ? OBC->number_of_segments : 0;
+  if (nseg > 0 && !OBC->segment) return 3;
+  for (int n = 0; n < nseg; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (S->on_pe && OBC->computed_vorticity && !S->tangential_vel) return 3;
+    if (S->on_pe && OBC->specified_vorticity && !(S->tangential_grad && G->dxBu && G->dyBu)) return 3;
+  }
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int Isq = G->isc-1, Ieq = G->iec, Jsq = G->jsc-1, Jeq = G->jec;
   const double vol_neglect = G->H_subroundoff * (1e-4 * 1.0)*(1e-4 * 1.0);   /* :241, US%m_to_L = 1 */
@@ -45,6 +66,25 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   /* :246-248 */
   for (int j = Jsq-1; j <= Jeq+2; j++) for (int i = Isq-1; i <= Ieq+2; i++)
     Area_h[H2(i,j)] = G->mask2dT[H2(i,j)] * G->areaT[H2(i,j)];
+  /* :249-269: the areas of the cells outside a segment are those of the cells inside it */
+  for (int n = 0; n < nseg; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->on_pe) continue;
+    const int I = S->IsdB, J = S->JsdB;
+    if (S->is_N_or_S && (J >= Jsq-1) && (J <= Jeq+1)) {
+      for (int i = imax2(Isq-1,S->isd); i <= imin2(Ieq+2,S->ied); i++) {
+        const int j = J;
+        if (S->direction == MOM6HIP_OBC_DIRECTION_N) Area_h[H2(i,j+1)] = Area_h[H2(i,j)];
+        else Area_h[H2(i,j)] = Area_h[H2(i,j+1)];
+      }
+    } else if (S->is_E_or_W && (I >= Isq-1) && (I <= Ieq+1)) {
+      for (int j = imax2(Jsq-1,S->jsd); j <= imin2(Jeq+2,S->jed); j++) {
+        const int i = I;
+        if (S->direction == MOM6HIP_OBC_DIRECTION_E) Area_h[H2(i+1,j)] = Area_h[H2(i,j)];
+        else Area_h[H2(i,j)] = Area_h[H2(i+1,j)];
+      }
+    }
+  }
   /* :271-274 */
   for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++)
     Area_q[Q2(I,J)] = (Area_h[H2(I,J)] + Area_h[H2(I+1,J+1)]) + (Area_h[H2(I+1,J)] + Area_h[H2(I,J+1)]);
@@ -58,6 +98,7 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   double *a = calloc(nU, 8), *b = calloc(nU, 8), *c = calloc(nU, 8), *d = calloc(nU, 8);
   double *ep_u = calloc(nH, 8), *ep_v = calloc(nH, 8);
   double *uh_min = calloc(nU, 8), *uh_max = calloc(nU, 8), *vh_min = calloc(nV, 8), *vh_max = calloc(nV, 8);
+  double *uh_center = calloc(nU, 8), *vh_center = calloc(nV, 8);
   _Pragma("omp for schedule(static)")
   for (int k = 1; k <= nz; k++) {
     /* :314-324 */
@@ -73,6 +114,97 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
     for (int j = Jsq-1; j <= Jeq+2; j++) for (int I = Isq-1; I <= Ieq+1; I++) {
       const int i = I;
       hArea_u[U2(I,j)] = 0.5*(Area_h[H2(i,j)] * h[H3(i,j,k)] + Area_h[H2(i+1,j)] * h[H3(i+1,j,k)]);
+    }
+    if (en_dis) {                                               /* :326-333 */
+      for (int j = Jsq; j <= Jeq+1; j++) for (int I = is-1; I <= ie; I++) {
+        const int i = I;
+        uh_center[U2(I,j)] = 0.5 * ((G->dy_Cu[U2(I,j)]*1.0) * u[U3(I,j,k)]) * (h[H3(i,j,k)] + h[H3(i+1,j,k)]);
+      }
+      for (int J = js-1; J <= je; J++) for (int i = Isq; i <= Ieq+1; i++) {
+        const int j = J;
+        vh_center[V2(i,J)] = 0.5 * ((G->dx_Cv[V2(i,J)]*1.0) * v[V3(i,J,k)]) * (h[H3(i,j,k)] + h[H3(i,j+1,k)]);
+      }
+    }
+    /* :337-420: the circulation and the thicknesses projected onto the velocity points of the open boundaries */
+    for (int n = 0; n < nseg; n++) {
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (!S->on_pe) continue;
+      if (S->is_N_or_S && (S->JsdB >= Jsq-1) && (S->JsdB <= Jeq+1)) {
+        const int J = S->JsdB, j = J;
+        if (OBC->zero_vorticity) for (int I = S->IsdB; I <= S->IedB; I++) { dvdx[Q2(I,J)] = 0.; dudy[Q2(I,J)] = 0.; }
+        if (OBC->freeslip_vorticity) for (int I = S->IsdB; I <= S->IedB; I++) dudy[Q2(I,J)] = 0.;
+        if (OBC->computed_vorticity) for (int I = S->IsdB; I <= S->IedB; I++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_N) dudy[Q2(I,J)] = 2.0*(seg_q(S, S->tangential_vel, I, J, k) - u[U3(I,j,k)])*G->dxCu[U2(I,j)];
+          else dudy[Q2(I,J)] = 2.0*(u[U3(I,j+1,k)] - seg_q(S, S->tangential_vel, I, J, k))*G->dxCu[U2(I,j+1)];
+        }
+        if (OBC->specified_vorticity) for (int I = S->IsdB; I <= S->IedB; I++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_N) dudy[Q2(I,J)] = seg_q(S, S->tangential_grad, I, J, k)*G->dxCu[U2(I,j)]*G->dyBu[Q2(I,J)];
+          else dudy[Q2(I,J)] = seg_q(S, S->tangential_grad, I, J, k)*G->dxCu[U2(I,j+1)]*G->dyBu[Q2(I,J)];
+        }
+        for (int i = imax2(Isq-1,S->isd); i <= imin2(Ieq+2,S->ied); i++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_N) hArea_v[V2(i,J)] = 0.5 * (Area_h[H2(i,j)] + Area_h[H2(i,j+1)]) * h[H3(i,j,k)];
+          else hArea_v[V2(i,J)] = 0.5 * (Area_h[H2(i,j)] + Area_h[H2(i,j+1)]) * h[H3(i,j+1,k)];
+        }
+        if (en_dis) for (int i = imax2(Isq-1,S->isd); i <= imin2(Ieq+2,S->ied); i++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_N) vh_center[V2(i,J)] = (G->dx_Cv[V2(i,J)]*1.0) * v[V3(i,J,k)] * h[H3(i,j,k)];
+          else vh_center[V2(i,J)] = (G->dx_Cv[V2(i,J)]*1.0) * v[V3(i,J,k)] * h[H3(i,j+1,k)];
+        }
+      } else if (S->is_E_or_W && (S->IsdB >= Isq-1) && (S->IsdB <= Ieq+1)) {
+        const int I = S->IsdB, i = I;
+        if (OBC->zero_vorticity) for (int J = S->JsdB; J <= S->JedB; J++) { dvdx[Q2(I,J)] = 0.; dudy[Q2(I,J)] = 0.; }
+        if (OBC->freeslip_vorticity) for (int J = S->JsdB; J <= S->JedB; J++) dvdx[Q2(I,J)] = 0.;
+        if (OBC->computed_vorticity) for (int J = S->JsdB; J <= S->JedB; J++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_E) dvdx[Q2(I,J)] = 2.0*(seg_q(S, S->tangential_vel, I, J, k) - v[V3(i,J,k)])*G->dyCv[V2(i,J)];
+          else dvdx[Q2(I,J)] = 2.0*(v[V3(i+1,J,k)] - seg_q(S, S->tangential_vel, I, J, k))*G->dyCv[V2(i+1,J)];
+        }
+        if (OBC->specified_vorticity) for (int J = S->JsdB; J <= S->JedB; J++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_E) dvdx[Q2(I,J)] = seg_q(S, S->tangential_grad, I, J, k)*G->dyCv[V2(i,J)]*G->dxBu[Q2(I,J)];
+          else dvdx[Q2(I,J)] = seg_q(S, S->tangential_grad, I, J, k)*G->dyCv[V2(i+1,J)]*G->dxBu[Q2(I,J)];
+        }
+        for (int j = imax2(Jsq-1,S->jsd); j <= imin2(Jeq+2,S->jed); j++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_E) hArea_u[U2(I,j)] = 0.5*(Area_h[H2(i,j)] + Area_h[H2(i+1,j)]) * h[H3(i,j,k)];
+          else hArea_u[U2(I,j)] = 0.5*(Area_h[H2(i,j)] + Area_h[H2(i+1,j)]) * h[H3(i+1,j,k)];
+        }
+        if (en_dis) for (int j = imax2(Jsq-1,S->jsd); j <= imin2(Jeq+2,S->jed); j++) {
+          if (S->direction == MOM6HIP_OBC_DIRECTION_E) uh_center[U2(I,j)] = (G->dy_Cu[U2(I,j)]*1.0) * u[U3(I,j,k)] * h[H3(i,j,k)];
+          else uh_center[U2(I,j)] = (G->dy_Cu[U2(I,j)]*1.0) * u[U3(I,j,k)] * h[H3(i+1,j,k)];
+        }
+      }
+    }
+    /* :422-455: then onto the corner points of the open boundaries (in sequence: the two projections cannot be combined) */
+    for (int n = 0; n < nseg; n++) {
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (!S->on_pe) continue;
+      if (S->is_N_or_S && (S->JsdB >= Jsq-1) && (S->JsdB <= Jeq+1)) {
+        const int J = S->JsdB, j = J;
+        for (int I = imax2(Isq-1,S->IsdB); I <= imin2(Ieq+1,S->IedB); I++) {
+          const int i = I;
+          if (S->direction == MOM6HIP_OBC_DIRECTION_N) {
+            if (Area_h[H2(i,j)] + Area_h[H2(i+1,j)] > 0.0)
+              hArea_u[U2(I,j+1)] = hArea_u[U2(I,j)] * ((Area_h[H2(i,j+1)] + Area_h[H2(i+1,j+1)]) / (Area_h[H2(i,j)] + Area_h[H2(i+1,j)]));
+            else hArea_u[U2(I,j+1)] = 0.0;
+          } else {
+            if (Area_h[H2(i,j+1)] + Area_h[H2(i+1,j+1)] > 0.0)
+              hArea_u[U2(I,j)] = hArea_u[U2(I,j+1)] * ((Area_h[H2(i,j)] + Area_h[H2(i+1,j)]) / (Area_h[H2(i,j+1)] + Area_h[H2(i+1,j+1)]));
+            else hArea_u[U2(I,j)] = 0.0;
+          }
+        }
+      } else if (S->is_E_or_W && (S->IsdB >= Isq-1) && (S->IsdB <= Ieq+1)) {
+        const int I = S->IsdB, i = I;
+        for (int J = imax2(Jsq-1,S->JsdB); J <= imin2(Jeq+1,S->JedB); J++) {
+          const int j = J;
+          if (S->direction == MOM6HIP_OBC_DIRECTION_E) {
+            if (Area_h[H2(i,j)] + Area_h[H2(i,j+1)] > 0.0)
+              hArea_v[V2(i+1,J)] = hArea_v[V2(i,J)] * ((Area_h[H2(i+1,j)] + Area_h[H2(i+1,j+1)]) / (Area_h[H2(i,j)] + Area_h[H2(i,j+1)]));
+            else hArea_v[V2(i+1,J)] = 0.0;
+          } else {
+            hArea_v[V2(i,J)] = 0.5 * (Area_h[H2(i,j)] + Area_h[H2(i,j+1)]) * h[H3(i,j+1,k)];      /* (:449, overwritten below) */
+            if (Area_h[H2(i+1,j)] + Area_h[H2(i+1,j+1)] > 0.0)
+              hArea_v[V2(i,J)] = hArea_v[V2(i+1,J)] * ((Area_h[H2(i,j)] + Area_h[H2(i,j+1)]) / (Area_h[H2(i+1,j)] + Area_h[H2(i+1,j+1)]));
+            else hArea_v[V2(i,J)] = 0.0;
+          }
+        }
+      }
     }
     /* :459-473 */
     for (int J = Jsq-1; J <= Jeq+1; J++) for (int I = Isq-1; I <= Ieq+1; I++) {
@@ -152,7 +284,8 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
       const double c1 = 1.0-1.5*0.5, c2 = 1.0-0.5, c3 = 2.0, slope = 0.5;
       for (int j = Jsq; j <= Jeq+1; j++) for (int I = is-1; I <= ie; I++) {
         const int i = I;
-        double uhc = 0.5 * ((G->dy_Cu[U2(I,j)]*1.0) * u[U3(I,j,k)]) * (h[H3(i,j,k)] + h[H3(i+1,j,k)]);      /* uh_center :328 */
+        (void)i;
+        double uhc = uh_center[U2(I,j)];
         double uhm = uh[U3(I,j,k)];
         if (G->dy_Cu[U2(I,j)] == 0.0) uhc = uhm;
         if (fabs(uhc) < 0.1*fabs(uhm)) {
@@ -167,7 +300,8 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
       }
       for (int J = js-1; J <= je; J++) for (int i = Isq; i <= Ieq+1; i++) {
         const int j = J;
-        double vhc = 0.5 * ((G->dx_Cv[V2(i,J)]*1.0) * v[V3(i,J,k)]) * (h[H3(i,j,k)] + h[H3(i,j+1,k)]);      /* vh_center :331 */
+        (void)j;
+        double vhc = vh_center[V2(i,J)];
         double vhm = vh[V3(i,J,k)];
         if (G->dx_Cv[V2(i,J)] == 0.0) vhc = vhm;
         if (fabs(vhc) < 0.1*fabs(vhm)) {
@@ -208,6 +342,11 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
       KEx[U2(I,j)] = (KE[H2(I+1,j)] - KE[H2(I,j)]) * G->IdxCu[U2(I,j)];
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       KEy[V2(i,J)] = (KE[H2(i,J+1)] - KE[H2(i,J)]) * G->IdyCv[V2(i,J)];
+    for (int n = 0; n < nseg; n++) {                              /* gradKE :1037-1050 */
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (S->is_N_or_S) { for (int i = S->isd; i <= S->ied; i++) KEy[V2(i,S->JsdB)] = 0.; }
+      else if (S->is_E_or_W) { for (int j = S->jsd; j <= S->jed; j++) KEx[U2(S->IsdB,j)] = 0.; }
+    }
 
     /* CAu, :644-752 */
     for (int j = js; j <= je; j++) for (int I = Isq; I <= Ieq; I++) {
@@ -353,7 +492,7 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
   }
   free(q); free(Ih_q); free(abs_vort); free(dvdx); free(dudy); free(rel_vort);
   free(hArea_u); free(hArea_v); free(KE); free(KEx); free(KEy); free(a); free(b); free(c); free(d);
-  free(ep_u); free(ep_v); free(uh_min); free(uh_max); free(vh_min); free(vh_max);
+  free(ep_u); free(ep_v); free(uh_center); free(vh_center); free(uh_min); free(uh_max); free(vh_min); free(vh_max);
   }
   free(Area_h); free(Area_q);
   return 0;

@@ -155,6 +155,9 @@ int orc_ale_remap_velocities(const mom6hip_grid_t *G, const mom6hip_remapping_cs
 /* ---- MOM_CoriolisAdv (oracle/coriolis_adv.c) ------------------------------------------------ */
 int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const double *u, const double *v,
                   const double *h, const double *uh, const double *vh, double *CAu, double *CAv);
+/* CorAdCalc with OBC associated (OBC may be NULL: the call above) */
+int orc_coradcalc_obc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const mom6hip_obc_t *OBC, const double *u,
+                      const double *v, const double *h, const double *uh, const double *vh, double *CAu, double *CAv);
 
 /* ---- MOM_continuity_PPM (oracle/continuity.c) ---------------------------------------------- */
 int orc_continuity(const mom6hip_grid_t *G, const mom6hip_continuity_cs_t *CS, const double *u, const double *v,

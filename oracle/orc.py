@@ -254,17 +254,19 @@ def ale_remap_tracers(grid, scheme, h_old, h_new, tr, conc_underflow=None, bound
 
 def coradcalc(grid, u, v, h, uh, vh, coriolis_scheme="SADOURNY75_ENERGY", ke_scheme="KE_ARAKAWA", no_slip=False,
               bound_coriolis=False, coriolis_en_dis=False, pv_adv_scheme="PV_ADV_CENTERED", coriolis_blend_wt_lin=0.125,
-              coriolis_blend_f_eff_max=4.0):
-    """CorAdCalc on numpy arrays; returns (CAu, CAv) (zero outside the computed ranges)."""
+              coriolis_blend_f_eff_max=4.0, OBC=None):
+    """CorAdCalc on numpy arrays; returns (CAu, CAv) (zero outside the computed ranges).  OBC: None or an ocean_OBC_type"""
     L = lib()
-    L.orc_coradcalc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.CoriolisAdvCS)] + [_dp] * 7
+    L.orc_coradcalc_obc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.CoriolisAdvCS), C.POINTER(_abi.Obc)] + [_dp] * 7
     if (coriolis_en_dis and coriolis_scheme == "SADOURNY75_ENERGY") or coriolis_scheme == "ROBUST_ENSTRO":
         bound_coriolis = False      # CoriolisAdv_init :1155-1156
     cs = _abi.CoriolisAdvCS(_abi.CORIOLIS_SCHEMES[coriolis_scheme], _abi.KE_SCHEMES[ke_scheme], int(no_slip),
                             int(bound_coriolis), int(bool(coriolis_en_dis)), _abi.PV_ADV_SCHEMES[pv_adv_scheme])
     cs.F_eff_max_blend = float(coriolis_blend_f_eff_max); cs.wt_lin_blend = min(1.0, max(float(coriolis_blend_wt_lin), 1e-16))
     CAu = np.zeros_like(u); CAv = np.zeros_like(v)
-    rc = L.orc_coradcalc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(uh), _p(vh), _p(CAu), _p(CAv))
+    obc = None if OBC is None else OBC.struct()
+    rc = L.orc_coradcalc_obc(C.byref(grid.struct()), C.byref(cs), None if obc is None else C.byref(obc), _p(u), _p(v), _p(h), _p(uh), _p(vh),
+                             _p(CAu), _p(CAv))
     if rc:
         raise RuntimeError("orc_coradcalc failed")
     return CAu, CAv
