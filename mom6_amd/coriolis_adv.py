@@ -46,8 +46,8 @@ def CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, G: DeviceGrid, CS: CoriolisAdvCS, 
     """CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Waves) -- MOM_CoriolisAdv.F90:125."""
     if CS is None:
         raise Mom6HipError("MOM_CoriolisAdv: Module must be initialized before it is used.")
-    if OBC is not None or Waves is not None:
-        raise Mom6HipError("MOM_CoriolisAdv (HIP): open boundaries and Stokes vortex force are not supported")
+    if Waves is not None:
+        raise Mom6HipError("MOM_CoriolisAdv (HIP): the Stokes vortex force is not supported")
     g = G.grid
     shp = {"h": g.shape3(_abi.POS_H), "u": g.shape3(_abi.POS_U), "v": g.shape3(_abi.POS_V)}
     spaces = set()
@@ -64,4 +64,20 @@ def CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, G: DeviceGrid, CS: CoriolisAdvCS, 
     if len(spaces) != 1:
         raise Mom6HipError("CorAdCalc: all fields must be in the same memory space")
     cs = CS.struct()
-    check(lib().mom6hip_coradcalc(G.handle, C.byref(cs), *args, spaces.pop()), "CorAdCalc")
+    space = spaces.pop()
+    if OBC is not None:      # an ocean_OBC_type (mom6_amd/open_boundary.py): the OBC branches of CorAdCalc
+        import numpy as np
+
+        def to_ptr(a):      # a segment's own array in the memory space of the call
+            if space == _abi.MEM_DEVICE:
+                import torch
+                t = a if hasattr(a, "data_ptr") else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+                return t.data_ptr(), t
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            return a.ctypes.data, a
+        obc = OBC.struct(to_ptr)
+        L = lib()
+        L.mom6hip_coradcalc_obc.argtypes = [C.c_void_p, C.POINTER(type(cs)), C.POINTER(_abi.Obc)] + [C.c_void_p] * 7 + [C.c_int32]
+        check(L.mom6hip_coradcalc_obc(G.handle, C.byref(cs), C.byref(obc), *args, space), "CorAdCalc")
+        return
+    check(lib().mom6hip_coradcalc(G.handle, C.byref(cs), *args, space), "CorAdCalc")

@@ -28,6 +28,12 @@ struct CorArgs {
   // the schemes beyond the production three (coradcalc_kernel<true>)
   int en_dis, upwind1;
   double Fe_m2, rat_lin, wt_lin_blend, eps_vel, h_tiny;
+  // open boundaries (coradcalc_kernel<true>; null: OBC not associated): the reference's 2-D work arrays of every layer after the
+  // segments have been projected onto them (cor_obc_* below) -- the circulation at the corner points, the layer volumes at the velocity
+  // points, the centred transports of CORIOLIS_EN_DIS -- Area_q with the areas carried across the segments, and the faces of segments,
+  // where gradKE leaves no gradient
+  const double *o_dvdx, *o_dudy, *o_hArea_u, *o_hArea_v, *o_uh_center, *o_vh_center, *o_Area_q;
+  const int32_t *o_seg_u, *o_seg_v;
 };
 
 using m6::max2;
@@ -74,9 +80,13 @@ __device__ __forceinline__ Quad al_quad(const CorArgs &p, double q11, double q00
 
 // uh_min / uh_max (or vh_min / vh_max) of CORIOLIS_EN_DIS at one face (:594-642): hc = the centred estimate of the transport
 // (uh_center / vh_center :328, :331), hm = the transport of the continuity solver, dL = dy_Cu / dx_Cv
+__device__ __forceinline__ void en_dis_range_hc(double dL, double hc, double hm, double &tmin, double &tmax);
 __device__ __forceinline__ void en_dis_range(double dL, double vel, double hsum, double hm, double &tmin, double &tmax) {
+  en_dis_range_hc(dL, 0.5 * ((dL * 1.0) * vel) * hsum, hm, tmin, tmax);
+}
+// the same from the centred transport itself (with open boundaries it is read from the projected array)
+__device__ __forceinline__ void en_dis_range_hc(double dL, double hc, double hm, double &tmin, double &tmax) {
   const double c1 = 1.0 - 1.5 * 0.5, c2 = 1.0 - 0.5, c3 = 2.0, slope = 0.5;
-  double hc = 0.5 * ((dL * 1.0) * vel) * hsum;
   if (dL == 0.0) hc = hm;
   if (fabs(hc) < 0.1 * fabs(hm)) {
     hm = 10.0 * hc;
@@ -186,14 +196,24 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
         const int ov = (I - g.isd) + nih * (J - g.jsd + 1);           // v2(i, J)
         const QMet &m = qm[sl];
         const double A00 = m.A00, A10 = m.A10, A01 = m.A01, A11 = m.A11;
-        const double Area_q = m.Area_q;
-        const double dvdx = (vk[ov + 1] * m.dyCv1 - vk[ov] * m.dyCv0);
-        const double dudy = (uk[ou + sU] * m.dxCu1 - uk[ou] * m.dxCu0);
+        double Area_q = m.Area_q;
+        double dvdx, dudy, hArea_u0, hArea_u1, hArea_v0, hArea_v1;
+        if (EXT && p.o_dvdx) {      // open boundaries: the work arrays with the segments projected onto them
+          const int oq = ou + sU;                                     // q2(I, J)
+          const long kQ = (long)sU * (g.njh + 1) * k;
+          dvdx = p.o_dvdx[kQ + oq]; dudy = p.o_dudy[kQ + oq];
+          hArea_u0 = p.o_hArea_u[kU + ou]; hArea_u1 = p.o_hArea_u[kU + ou + sU];
+          hArea_v0 = p.o_hArea_v[kV + ov]; hArea_v1 = p.o_hArea_v[kV + ov + 1];
+          Area_q = p.o_Area_q[oq];
+        } else {
+        dvdx = (vk[ov + 1] * m.dyCv1 - vk[ov] * m.dyCv0);
+        dudy = (uk[ou + sU] * m.dxCu1 - uk[ou] * m.dxCu0);
         const double h00 = hk[oh], h10 = hk[oh + 1], h01 = hk[oh + nih], h11 = hk[oh + nih + 1];
-        const double hArea_u0 = 0.5 * (A00 * h00 + A10 * h10);     // hArea_u(I,j)
-        const double hArea_u1 = 0.5 * (A01 * h01 + A11 * h11);     // hArea_u(I,j+1)
-        const double hArea_v0 = 0.5 * (A00 * h00 + A01 * h01);     // hArea_v(i,J)
-        const double hArea_v1 = 0.5 * (A10 * h10 + A11 * h11);     // hArea_v(i+1,J)
+        hArea_u0 = 0.5 * (A00 * h00 + A10 * h10);     // hArea_u(I,j)
+        hArea_u1 = 0.5 * (A01 * h01 + A11 * h11);     // hArea_u(I,j+1)
+        hArea_v0 = 0.5 * (A00 * h00 + A01 * h01);     // hArea_v(i,J)
+        hArea_v1 = 0.5 * (A10 * h10 + A11 * h11);     // hArea_v(i+1,J)
+        }
         const double rel_vort = m.fac * (dvdx - dudy) * m.IareaBu;
         av = m.Cor + rel_vort;
         const double hArea_q = (hArea_u0 + hArea_u1) + (hArea_v0 + hArea_v1);
@@ -245,10 +265,18 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       const double uI = uk[ou];
       // vh_min / vh_max at the faces (i, J), (i+1, J), (i, J-1), (i+1, J-1)
       double mnN0, mxN0, mnN1, mxN1, mnS0, mxS0, mnS1, mxS1;
+      if (p.o_vh_center) {
+        const double *vc = p.o_vh_center + kV;
+        en_dis_range_hc(g.dx_Cv[ov], vc[ov], vh_nw, mnN0, mxN0);
+        en_dis_range_hc(g.dx_Cv[ov + 1], vc[ov + 1], vh_ne, mnN1, mxN1);
+        en_dis_range_hc(g.dx_Cv[ov - nih], vc[ov - nih], vh_sw, mnS0, mxS0);
+        en_dis_range_hc(g.dx_Cv[ov - nih + 1], vc[ov - nih + 1], vh_se, mnS1, mxS1);
+      } else {
       en_dis_range(g.dx_Cv[ov], vk[ov], hk[oh] + hk[oh + nih], vh_nw, mnN0, mxN0);
       en_dis_range(g.dx_Cv[ov + 1], vk[ov + 1], hk[oh + 1] + hk[oh + nih + 1], vh_ne, mnN1, mxN1);
       en_dis_range(g.dx_Cv[ov - nih], vk[ov - nih], hk[oh - nih] + hk[oh], vh_sw, mnS0, mxS0);
       en_dis_range(g.dx_Cv[ov - nih + 1], vk[ov - nih + 1], hk[oh - nih + 1] + hk[oh + 1], vh_se, mnS1, mxS1);
+      }
       double temp1, temp2;
       if (qN * uI == 0.0) temp1 = qN * ((mxN0 + mxN1) + (mnN0 + mnN1)) * 0.5;
       else if (qN * uI < 0.0) temp1 = qN * (mxN0 + mxN1);
@@ -297,7 +325,8 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       ca = min2(ca, max4(fv1, fv2, fv3, fv4));
       ca = max2(ca, min4(fv1, fv2, fv3, fv4));
     }
-    const double KEx = (s_ke[ty][tx + 1] - s_ke[ty][tx]) * IdxCu;
+    double KEx = (s_ke[ty][tx + 1] - s_ke[ty][tx]) * IdxCu;
+    if (EXT && p.o_seg_u && p.o_seg_u[ou]) KEx = 0.;      // gradKE :1037-1050
     p.CAu[kU + ou] = ca - KEx;
   }
   // ---- CAv(i, J), i = I >= isc, J <= jec : :763-876 ----
@@ -312,10 +341,18 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       const double vJ = vk[ov];
       // uh_min / uh_max at the faces (I-1, j), (I-1, j+1), (I, j), (I, j+1)
       double mnW0, mxW0, mnW1, mxW1, mnE0, mxE0, mnE1, mxE1;
+      if (p.o_uh_center) {
+        const double *uc = p.o_uh_center + kU;
+        en_dis_range_hc(g.dy_Cu[ou - 1], uc[ou - 1], uh_sw, mnW0, mxW0);
+        en_dis_range_hc(g.dy_Cu[ou - 1 + sU], uc[ou - 1 + sU], uh_nw, mnW1, mxW1);
+        en_dis_range_hc(g.dy_Cu[ou], uc[ou], uh_se, mnE0, mxE0);
+        en_dis_range_hc(g.dy_Cu[ou + sU], uc[ou + sU], uh_ne, mnE1, mxE1);
+      } else {
       en_dis_range(g.dy_Cu[ou - 1], uk[ou - 1], hk[oh - 1] + hk[oh], uh_sw, mnW0, mxW0);
       en_dis_range(g.dy_Cu[ou - 1 + sU], uk[ou - 1 + sU], hk[oh + nih - 1] + hk[oh + nih], uh_nw, mnW1, mxW1);
       en_dis_range(g.dy_Cu[ou], uk[ou], hk[oh] + hk[oh + 1], uh_se, mnE0, mxE0);
       en_dis_range(g.dy_Cu[ou + sU], uk[ou + sU], hk[oh + nih] + hk[oh + nih + 1], uh_ne, mnE1, mxE1);
+      }
       double temp1, temp2;
       if (qW * vJ == 0.0) temp1 = qW * ((mxW0 + mxW1) + (mnW0 + mnW1)) * 0.5;
       else if (qW * vJ > 0.0) temp1 = qW * (mxW0 + mxW1);
@@ -365,10 +402,151 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       ca = min2(ca, max4(fu1, fu2, fu3, fu4));
       ca = max2(ca, min4(fu1, fu2, fu3, fu4));
     }
-    const double KEy = (s_ke[ty + 1][tx] - s_ke[ty][tx]) * IdyCv;
+    double KEy = (s_ke[ty + 1][tx] - s_ke[ty][tx]) * IdyCv;
+    if (EXT && p.o_seg_v && p.o_seg_v[ov]) KEy = 0.;
     p.CAv[kV + ov] = ca - KEy;
   }
   }      // the layers of the chunk
+}
+
+// ---- open boundaries: the reference's 2-D work arrays of every layer, with the segments projected onto them in the reference's order ----
+// (a small-configuration path: plain kernels, one thread a point; the segments are applied by one launch each, in sequence, because a
+// later segment overwrites what an earlier one left)
+struct CorObc {
+  m6::GridDev g;
+  const double *u, *v, *h;
+  double *Area_h, *Area_q, *dvdx, *dudy, *hArea_u, *hArea_v, *uh_center, *vh_center;      // (uh_center, vh_center null without CORIOLIS_EN_DIS)
+  int zero_vorticity, freeslip_vorticity, computed_vorticity, specified_vorticity;
+};
+struct CorSeg {      // one segment (mom6hip_obc_segment_t with device pointers)
+  int direction, is_N_or_S, is_E_or_W, pad;
+  int IsdB, IedB, JsdB, JedB, isd, ied, jsd, jed;
+  const double *tangential_vel, *tangential_grad;
+};
+__device__ __forceinline__ double cor_seg_q(const CorSeg &S, const double *f, int I, int J, int k) {
+  const long nI = S.IedB - S.IsdB + 1, nJ = S.JedB - S.JsdB + 1;
+  return f[(I - S.IsdB) + nI * ((J - S.JsdB) + nJ * (long)k)];
+}
+
+// :246-248 (what = 0) and :271-274 (what = 1) over the ranges of the reference
+__global__ __launch_bounds__(256) void cor_obc_area_kernel(CorObc a, int what) {
+  const m6::GridDev &g = a.g;
+  const int i = g.isc - 2 + blockIdx.x * 256 + threadIdx.x, j = g.jsc - 2 + blockIdx.y;
+  if (what == 0) { if (i <= g.iec + 2) a.Area_h[g.h2(i, j)] = g.mask2dT[g.h2(i, j)] * g.areaT[g.h2(i, j)]; return; }
+  if (i <= g.iec + 1 && j <= g.jec + 1)
+    a.Area_q[g.q2(i, j)] = (a.Area_h[g.h2(i, j)] + a.Area_h[g.h2(i + 1, j + 1)]) + (a.Area_h[g.h2(i + 1, j)] + a.Area_h[g.h2(i, j + 1)]);
+}
+
+// the layer's work arrays :314-333; thread (i, j, k) over (Isq-1 : Ieq+2, Jsq-1 : Jeq+2)
+__global__ __launch_bounds__(256) void cor_obc_fields_kernel(CorObc a) {
+  const m6::GridDev &g = a.g;
+  const int i = g.isc - 2 + blockIdx.x * 256 + threadIdx.x, j = g.jsc - 2 + blockIdx.y, k = blockIdx.z;
+  if (i > g.iec + 2) return;
+  const int I = i, J = j, Isq = g.isc - 1, Ieq = g.iec, Jsq = g.jsc - 1, Jeq = g.jec;
+  const double *u = a.u + (long)(g.nih + 1) * g.njh * k, *v = a.v + (long)g.nih * (g.njh + 1) * k, *h = a.h + (long)g.nih * g.njh * k;
+  const long kQ = (long)(g.nih + 1) * (g.njh + 1) * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
+  if (I <= Ieq + 1 && J <= Jeq + 1) {
+    a.dvdx[kQ + g.q2(I, J)] = (v[g.v2(i + 1, J)] * g.dyCv[g.v2(i + 1, J)] - v[g.v2(i, J)] * g.dyCv[g.v2(i, J)]);
+    a.dudy[kQ + g.q2(I, J)] = (u[g.u2(I, j + 1)] * g.dxCu[g.u2(I, j + 1)] - u[g.u2(I, j)] * g.dxCu[g.u2(I, j)]);
+  }
+  if (J <= Jeq + 1) a.hArea_v[kV + g.v2(i, J)] = 0.5 * (a.Area_h[g.h2(i, j)] * h[g.h2(i, j)] + a.Area_h[g.h2(i, j + 1)] * h[g.h2(i, j + 1)]);
+  if (I <= Ieq + 1) a.hArea_u[kU + g.u2(I, j)] = 0.5 * (a.Area_h[g.h2(i, j)] * h[g.h2(i, j)] + a.Area_h[g.h2(i + 1, j)] * h[g.h2(i + 1, j)]);
+  if (a.uh_center) {
+    if (j >= Jsq && j <= Jeq + 1 && I >= g.isc - 1 && I <= g.iec)
+      a.uh_center[kU + g.u2(I, j)] = 0.5 * ((g.dy_Cu[g.u2(I, j)] * 1.0) * u[g.u2(I, j)]) * (h[g.h2(i, j)] + h[g.h2(i + 1, j)]);
+    if (J >= g.jsc - 1 && J <= g.jec && i >= Isq && i <= Ieq + 1)
+      a.vh_center[kV + g.v2(i, J)] = 0.5 * ((g.dx_Cv[g.v2(i, J)] * 1.0) * v[g.v2(i, J)]) * (h[g.h2(i, j)] + h[g.h2(i, j + 1)]);
+  }
+}
+
+// one segment; thread t along it (corner points IsdB : IedB or JsdB : JedB: they span its cells too), blockIdx.y = k (phases 1, 2).
+// phase 0 :249-269 the areas; 1 :337-420 the velocity points; 2 :422-455 the corner points
+__global__ __launch_bounds__(64) void cor_obc_segment_kernel(CorObc a, CorSeg S, int phase) {
+  const m6::GridDev &g = a.g;
+  const int Isq = g.isc - 1, Ieq = g.iec, Jsq = g.jsc - 1, Jeq = g.jec;
+  const int k = blockIdx.y;
+  const bool ns = S.is_N_or_S && (S.JsdB >= Jsq - 1) && (S.JsdB <= Jeq + 1);
+  const bool ew = !ns && S.is_E_or_W && (S.IsdB >= Isq - 1) && (S.IsdB <= Ieq + 1);      // (the reference's elseif)
+  if (S.is_N_or_S && !ns) return;
+  if (!ns && !ew) return;
+  const int t = (ns ? S.IsdB : S.JsdB) + blockIdx.x * 64 + threadIdx.x;
+  if (t > (ns ? S.IedB : S.JedB)) return;
+  const double *u = a.u + (long)(g.nih + 1) * g.njh * k, *v = a.v + (long)g.nih * (g.njh + 1) * k, *h = a.h + (long)g.nih * g.njh * k;
+  const long kQ = (long)(g.nih + 1) * (g.njh + 1) * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
+  double *Ah = a.Area_h;
+  if (ns) {
+    const int J = S.JsdB, j = J, I = t, i = t;
+    const bool N = S.direction == MOM6HIP_OBC_DIRECTION_N;
+    if (phase == 0) {
+      if (i >= max(Isq - 1, S.isd) && i <= min(Ieq + 2, S.ied)) { if (N) Ah[g.h2(i, j + 1)] = Ah[g.h2(i, j)]; else Ah[g.h2(i, j)] = Ah[g.h2(i, j + 1)]; }
+    } else if (phase == 1) {
+      double *dvdx = a.dvdx + kQ, *dudy = a.dudy + kQ;
+      if (a.zero_vorticity) { dvdx[g.q2(I, J)] = 0.; dudy[g.q2(I, J)] = 0.; }
+      if (a.freeslip_vorticity) dudy[g.q2(I, J)] = 0.;
+      if (a.computed_vorticity) {
+        if (N) dudy[g.q2(I, J)] = 2.0 * (cor_seg_q(S, S.tangential_vel, I, J, k) - u[g.u2(I, j)]) * g.dxCu[g.u2(I, j)];
+        else dudy[g.q2(I, J)] = 2.0 * (u[g.u2(I, j + 1)] - cor_seg_q(S, S.tangential_vel, I, J, k)) * g.dxCu[g.u2(I, j + 1)];
+      }
+      if (a.specified_vorticity) {
+        if (N) dudy[g.q2(I, J)] = cor_seg_q(S, S.tangential_grad, I, J, k) * g.dxCu[g.u2(I, j)] * g.dyBu[g.q2(I, J)];
+        else dudy[g.q2(I, J)] = cor_seg_q(S, S.tangential_grad, I, J, k) * g.dxCu[g.u2(I, j + 1)] * g.dyBu[g.q2(I, J)];
+      }
+      if (i >= max(Isq - 1, S.isd) && i <= min(Ieq + 2, S.ied)) {
+        const double hi = N ? h[g.h2(i, j)] : h[g.h2(i, j + 1)];
+        a.hArea_v[kV + g.v2(i, J)] = 0.5 * (Ah[g.h2(i, j)] + Ah[g.h2(i, j + 1)]) * hi;
+        if (a.vh_center) a.vh_center[kV + g.v2(i, J)] = (g.dx_Cv[g.v2(i, J)] * 1.0) * v[g.v2(i, J)] * hi;
+      }
+    } else {
+      if (I >= max(Isq - 1, S.IsdB) && I <= min(Ieq + 1, S.IedB)) {
+        double *hu = a.hArea_u + kU;
+        if (N) {
+          if (Ah[g.h2(i, j)] + Ah[g.h2(i + 1, j)] > 0.0)
+            hu[g.u2(I, j + 1)] = hu[g.u2(I, j)] * ((Ah[g.h2(i, j + 1)] + Ah[g.h2(i + 1, j + 1)]) / (Ah[g.h2(i, j)] + Ah[g.h2(i + 1, j)]));
+          else hu[g.u2(I, j + 1)] = 0.0;
+        } else {
+          if (Ah[g.h2(i, j + 1)] + Ah[g.h2(i + 1, j + 1)] > 0.0)
+            hu[g.u2(I, j)] = hu[g.u2(I, j + 1)] * ((Ah[g.h2(i, j)] + Ah[g.h2(i + 1, j)]) / (Ah[g.h2(i, j + 1)] + Ah[g.h2(i + 1, j + 1)]));
+          else hu[g.u2(I, j)] = 0.0;
+        }
+      }
+    }
+  } else {
+    const int I = S.IsdB, i = I, J = t, j = t;
+    const bool E = S.direction == MOM6HIP_OBC_DIRECTION_E;
+    if (phase == 0) {
+      if (j >= max(Jsq - 1, S.jsd) && j <= min(Jeq + 2, S.jed)) { if (E) Ah[g.h2(i + 1, j)] = Ah[g.h2(i, j)]; else Ah[g.h2(i, j)] = Ah[g.h2(i + 1, j)]; }
+    } else if (phase == 1) {
+      double *dvdx = a.dvdx + kQ, *dudy = a.dudy + kQ;
+      if (a.zero_vorticity) { dvdx[g.q2(I, J)] = 0.; dudy[g.q2(I, J)] = 0.; }
+      if (a.freeslip_vorticity) dvdx[g.q2(I, J)] = 0.;
+      if (a.computed_vorticity) {
+        if (E) dvdx[g.q2(I, J)] = 2.0 * (cor_seg_q(S, S.tangential_vel, I, J, k) - v[g.v2(i, J)]) * g.dyCv[g.v2(i, J)];
+        else dvdx[g.q2(I, J)] = 2.0 * (v[g.v2(i + 1, J)] - cor_seg_q(S, S.tangential_vel, I, J, k)) * g.dyCv[g.v2(i + 1, J)];
+      }
+      if (a.specified_vorticity) {
+        if (E) dvdx[g.q2(I, J)] = cor_seg_q(S, S.tangential_grad, I, J, k) * g.dyCv[g.v2(i, J)] * g.dxBu[g.q2(I, J)];
+        else dvdx[g.q2(I, J)] = cor_seg_q(S, S.tangential_grad, I, J, k) * g.dyCv[g.v2(i + 1, J)] * g.dxBu[g.q2(I, J)];
+      }
+      if (j >= max(Jsq - 1, S.jsd) && j <= min(Jeq + 2, S.jed)) {
+        const double hi = E ? h[g.h2(i, j)] : h[g.h2(i + 1, j)];
+        a.hArea_u[kU + g.u2(I, j)] = 0.5 * (Ah[g.h2(i, j)] + Ah[g.h2(i + 1, j)]) * hi;
+        if (a.uh_center) a.uh_center[kU + g.u2(I, j)] = (g.dy_Cu[g.u2(I, j)] * 1.0) * u[g.u2(I, j)] * hi;
+      }
+    } else {
+      if (J >= max(Jsq - 1, S.JsdB) && J <= min(Jeq + 1, S.JedB)) {
+        double *hv = a.hArea_v + kV;
+        if (E) {
+          if (Ah[g.h2(i, j)] + Ah[g.h2(i, j + 1)] > 0.0)
+            hv[g.v2(i + 1, J)] = hv[g.v2(i, J)] * ((Ah[g.h2(i + 1, j)] + Ah[g.h2(i + 1, j + 1)]) / (Ah[g.h2(i, j)] + Ah[g.h2(i, j + 1)]));
+          else hv[g.v2(i + 1, J)] = 0.0;
+        } else {      // (:449 sets hArea_v(i,J) from h(i,j+1) first; both branches below overwrite it)
+          if (Ah[g.h2(i + 1, j)] + Ah[g.h2(i + 1, j + 1)] > 0.0)
+            hv[g.v2(i, J)] = hv[g.v2(i + 1, J)] * ((Ah[g.h2(i, j)] + Ah[g.h2(i, j + 1)]) / (Ah[g.h2(i + 1, j)] + Ah[g.h2(i + 1, j + 1)]));
+          else hv[g.v2(i, J)] = 0.0;
+        }
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -376,6 +554,12 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
 extern "C" int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, const double *u,
                                  const double *v, const double *h, const double *uh, const double *vh,
                                  double *CAu, double *CAv, int32_t memspace) {
+  return mom6hip_coradcalc_obc(ctx, cs, nullptr, u, v, h, uh, vh, CAu, CAv, memspace);
+}
+
+extern "C" int mom6hip_coradcalc_obc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, const mom6hip_obc_t *obc, const double *u,
+                                     const double *v, const double *h, const double *uh, const double *vh,
+                                     double *CAu, double *CAv, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_CoriolisAdv: Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && uh && vh && CAu && CAv, "CorAdCalc: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "CorAdCalc: bad memspace");
@@ -385,8 +569,9 @@ extern "C" int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_c
   M6_REQUIRE(cs->pv_adv_scheme == 0 || cs->pv_adv_scheme == MOM6HIP_PV_ADV_CENTERED || cs->pv_adv_scheme == MOM6HIP_PV_ADV_UPWIND1,
              "CoriolisAdv_init: #DEFINE PV_ADV_SCHEME in input file is invalid.");
   const bool en_dis = cs->coriolis_en_dis && cs->coriolis_scheme == MOM6HIP_SADOURNY75_ENERGY;      // (read by that scheme only)
+  const bool with_obc = obc && obc->number_of_segments > 0;
   const bool ext = en_dis || cs->coriolis_scheme == MOM6HIP_ROBUST_ENSTRO || cs->coriolis_scheme == MOM6HIP_ARAKAWA_LAMB81 ||
-                   cs->coriolis_scheme == MOM6HIP_AL_BLEND;
+                   cs->coriolis_scheme == MOM6HIP_AL_BLEND || with_obc;
   m6::GridDev &g = ctx->g;
   M6_REQUIRE(g.mask2dT && g.areaT && g.IareaT && g.dxCu && g.IdxCu && g.areaCu && g.dyCv && g.IdyCv && g.areaCv &&
              g.mask2dBu && g.IareaBu && g.CoriolisBu, "CorAdCalc: a required grid metric is missing");
@@ -418,6 +603,68 @@ extern "C" int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_c
   a.Fe_m2 = cs->F_eff_max_blend - 2.0;                     // :544-548
   a.rat_lin = 1.5 * a.Fe_m2 / fmax(cs->wt_lin_blend, 1.0e-16);
   if (cs->F_eff_max_blend <= 2.0) { a.Fe_m2 = -1.; a.rat_lin = -1.0; }
+  a.o_dvdx = a.o_dudy = a.o_hArea_u = a.o_hArea_v = a.o_uh_center = a.o_vh_center = a.o_Area_q = nullptr;
+  a.o_seg_u = a.o_seg_v = nullptr;
+  m6::Stager st(ctx, memspace);      // (the segments' own arrays and the work arrays of the open-boundary path)
+  if (with_obc) {
+    M6_REQUIRE(obc->segment, "CorAdCalc: OBC%%segment is required");
+    M6_REQUIRE(!obc->specified_vorticity || (g.dxBu && g.dyBu), "CorAdCalc: OBC_SPECIFIED_VORTICITY needs the metrics dxBu, dyBu");
+    const int nseg = obc->number_of_segments;
+    const size_t nH2 = (size_t)g.nih * g.njh, nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1), nQ2 = (size_t)(g.nih + 1) * (g.njh + 1);
+    CorObc o;
+    o.g = g; o.u = a.u; o.v = a.v; o.h = a.h;
+    o.Area_h = (double *)st.scratch(8 * nH2); o.Area_q = (double *)st.scratch(8 * nQ2);
+    o.dvdx = (double *)st.scratch(8 * nQ2 * g.nk); o.dudy = (double *)st.scratch(8 * nQ2 * g.nk);
+    o.hArea_u = (double *)st.scratch(bU); o.hArea_v = (double *)st.scratch(bV);
+    o.uh_center = en_dis ? (double *)st.scratch(bU) : nullptr; o.vh_center = en_dis ? (double *)st.scratch(bV) : nullptr;
+    o.zero_vorticity = obc->zero_vorticity; o.freeslip_vorticity = obc->freeslip_vorticity;
+    o.computed_vorticity = obc->computed_vorticity; o.specified_vorticity = obc->specified_vorticity;
+    int32_t *d_su = (int32_t *)st.scratch(4 * nU2), *d_sv = (int32_t *)st.scratch(4 * nV2);
+    M6_REQUIRE(!st.failed() && o.Area_h && o.Area_q && o.dvdx && o.dudy && o.hArea_u && o.hArea_v && d_su && d_sv, "CorAdCalc: staging of the open boundaries failed");
+    // gradKE :1037-1050: the faces of every segment of the PE over its whole range (segnum holds them when it is given; the table is
+    // rebuilt here from the segments, which is what the reference loops over)
+    std::vector<int32_t> su(nU2, 0), sv(nV2, 0);
+    std::vector<CorSeg> segs(nseg);
+    for (int n = 0; n < nseg; n++) {
+      const mom6hip_obc_segment_t &S = obc->segment[n];
+      CorSeg &d = segs[n];
+      d.direction = S.direction; d.is_N_or_S = S.is_N_or_S && S.on_pe; d.is_E_or_W = S.is_E_or_W && S.on_pe; d.pad = 0;
+      d.IsdB = S.IsdB; d.IedB = S.IedB; d.JsdB = S.JsdB; d.JedB = S.JedB; d.isd = S.isd; d.ied = S.ied; d.jsd = S.jsd; d.jed = S.jed;
+      d.tangential_vel = nullptr; d.tangential_grad = nullptr;
+      if (!S.on_pe) continue;
+      const bool ew = S.is_E_or_W != 0, ns = S.is_N_or_S != 0;
+      M6_REQUIRE(ew != ns, "CorAdCalc: OBC segment %d is neither E/W nor N/S", n + 1);
+      M6_REQUIRE(S.IsdB >= g.isd - 1 && S.IedB <= g.ied && S.JsdB >= g.jsd - 1 && S.JedB <= g.jed && S.isd >= g.isd && S.ied <= g.ied &&
+                 S.jsd >= g.jsd && S.jed <= g.jed && (ew ? (S.IsdB >= g.isd && S.IsdB < g.ied) : (S.JsdB >= g.jsd && S.JsdB < g.jed)),
+                 "CorAdCalc: OBC segment %d lies outside the data domain", n + 1);
+      const size_t cnt = (size_t)(S.IedB - S.IsdB + 1) * (S.JedB - S.JsdB + 1) * g.nk;
+      if (obc->computed_vorticity) { M6_REQUIRE(S.tangential_vel, "CorAdCalc: OBC_COMPUTED_VORTICITY needs segment%%tangential_vel"); d.tangential_vel = st.in(S.tangential_vel, cnt * 8); }
+      if (obc->specified_vorticity) { M6_REQUIRE(S.tangential_grad, "CorAdCalc: OBC_SPECIFIED_VORTICITY needs segment%%tangential_grad"); d.tangential_grad = st.in(S.tangential_grad, cnt * 8); }
+      if (ns) for (int i = S.isd; i <= S.ied; i++) sv[g.v2(i, S.JsdB)] = 1;
+      else for (int j = S.jsd; j <= S.jed; j++) su[g.u2(S.IsdB, j)] = 1;
+    }
+    M6_REQUIRE(!st.failed(), "CorAdCalc: staging of the open boundaries failed");
+    M6_HIP(hipMemcpyAsync(d_su, su.data(), 4 * nU2, hipMemcpyHostToDevice, s));
+    M6_HIP(hipMemcpyAsync(d_sv, sv.data(), 4 * nV2, hipMemcpyHostToDevice, s));
+    const int ni2 = g.iec - g.isc + 5, nj2 = g.jec - g.jsc + 5;      // (is-2 : ie+2, js-2 : je+2)
+    hipLaunchKernelGGL(cor_obc_area_kernel, dim3((ni2 + 255) / 256, nj2), dim3(256), 0, s, o, 0);
+    auto seg_launch = [&](int phase) {
+      for (int n = 0; n < nseg; n++) {
+        if (!obc->segment[n].on_pe) continue;
+        const int len = (segs[n].is_N_or_S ? segs[n].IedB - segs[n].IsdB : segs[n].JedB - segs[n].JsdB) + 1;
+        hipLaunchKernelGGL(cor_obc_segment_kernel, dim3((len + 63) / 64, phase == 0 ? 1 : g.nk), dim3(64), 0, s, o, segs[n], phase);
+      }
+    };
+    seg_launch(0);
+    hipLaunchKernelGGL(cor_obc_area_kernel, dim3((ni2 + 255) / 256, nj2), dim3(256), 0, s, o, 1);
+    hipLaunchKernelGGL(cor_obc_fields_kernel, dim3((ni2 + 255) / 256, nj2, g.nk), dim3(256), 0, s, o);
+    seg_launch(1);
+    seg_launch(2);
+    M6_HIP(hipGetLastError());
+    M6_HIP(hipStreamSynchronize(s));      // (the host tables go out of scope)
+    a.o_dvdx = o.dvdx; a.o_dudy = o.dudy; a.o_hArea_u = o.hArea_u; a.o_hArea_v = o.hArea_v; a.o_uh_center = o.uh_center;
+    a.o_vh_center = o.vh_center; a.o_Area_q = o.Area_q; a.o_seg_u = d_su; a.o_seg_v = d_sv;
+  }
   if (ext) hipLaunchKernelGGL(coradcalc_kernel<true>, grid, dim3(TI, TJ), 0, s, a);
   else hipLaunchKernelGGL(coradcalc_kernel<false>, grid, dim3(TI, TJ), 0, s, a);
   M6_HIP(hipGetLastError());
