@@ -10,7 +10,7 @@ module MOM_CoriolisAdv
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_obc_to_c
 use MOM_diag_mediator,    only : diag_ctrl, time_type
 use MOM_error_handler,    only : MOM_error, MOM_mesg, FATAL, WARNING
 use MOM_file_parser,      only : get_param, log_version, param_file_type
@@ -76,10 +76,11 @@ subroutine CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Wav
   type(Wave_parameters_CS), optional, pointer :: Waves
 
   type(mom6hip_coriolisadv_cs_t) :: ccs
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
   integer :: rc
 
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_CoriolisAdv: Module must be initialized before it is used.")
-  if (associated(OBC)) call MOM_error(FATAL, "MOM_CoriolisAdv (HIP): open boundary conditions are not supported by the GPU path.")
   if (allocated(pbv%por_face_areaU)) then
     if (any(pbv%por_face_areaU /= 1.0) .or. any(pbv%por_face_areaV /= 1.0)) &
       call MOM_error(FATAL, "MOM_CoriolisAdv (HIP): porous barriers are not supported by the GPU path.")
@@ -95,8 +96,14 @@ subroutine CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv, Wav
   ccs%no_slip = merge(1, 0, CS%no_slip) ; ccs%bound_coriolis = merge(1, 0, CS%bound_Coriolis)
   ccs%coriolis_en_dis = merge(1, 0, CS%Coriolis_En_Dis) ; ccs%pv_adv_scheme = CS%PV_Adv_Scheme ; ccs%reserved(:) = 0
   ccs%F_eff_max_blend = CS%F_eff_max_blend ; ccs%wt_lin_blend = CS%wt_lin_blend
+  if (associated(OBC)) then      ! the OBC branches of CorAdCalc (:249-269, :337-455, gradKE :1037-1050)
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(CAu(:,:,1)), size(CAv(:,:,1)), "MOM_CoriolisAdv")
+    rc = mom6hip_coradcalc_obc(mom6hip_shared_context(G, GV), ccs, cobc, c_loc(u), c_loc(v), c_loc(h), c_loc(uh), c_loc(vh), c_loc(CAu), &
+                               c_loc(CAv), MOM6HIP_MEM_HOST)
+  else
   rc = mom6hip_coradcalc(mom6hip_shared_context(G, GV), ccs, c_loc(u), c_loc(v), c_loc(h), c_loc(uh), c_loc(vh), c_loc(CAu), &
                          c_loc(CAv), MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "MOM_CoriolisAdv")
 end subroutine CorAdCalc
 

@@ -13,12 +13,12 @@ module MOM_continuity_PPM
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,  only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,  only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_obc_to_c
 use MOM_diag_mediator, only : time_type, diag_ctrl
 use MOM_error_handler, only : MOM_error, FATAL
 use MOM_file_parser,   only : get_param, log_version, param_file_type
 use MOM_grid,          only : ocean_grid_type
-use MOM_open_boundary, only : ocean_OBC_type, OBC_segment_type
+use MOM_open_boundary, only : ocean_OBC_type
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : BT_cont_type, porous_barrier_type
 use MOM_verticalGrid,  only : verticalGrid_type
@@ -123,7 +123,7 @@ subroutine continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhb
   type(c_ptr) :: p_uhbt, p_vhbt, p_vru, p_vrv, p_ucor, p_vcor, p_bt, p_du, p_dv
   type(mom6hip_obc_t) :: cobc
   type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
-  integer :: rc, n
+  integer :: rc
 
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_continuity_PPM: Module must be initialized before it is used.")
   if (present(visc_rem_u) .neqv. present(visc_rem_v)) call MOM_error(FATAL, "MOM_continuity_PPM: "//&
@@ -152,25 +152,7 @@ subroutine continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhb
   endif ; endif
 
   if (associated(OBC)) then      ! what continuity_PPM reads of ocean_OBC_type and its segments (MOM_open_boundary.F90:146-386)
-    allocate(csegs(max(OBC%number_of_segments, 1)))
-    do n=1,OBC%number_of_segments
-      call segment_to_c(OBC%segment(n), csegs(n))
-    enddo
-    cobc%number_of_segments = OBC%number_of_segments ; cobc%OBC_pe = merge(1, 0, OBC%OBC_pe)
-    cobc%open_u_BCs_exist_globally = merge(1, 0, OBC%open_u_BCs_exist_globally)
-    cobc%open_v_BCs_exist_globally = merge(1, 0, OBC%open_v_BCs_exist_globally)
-    cobc%specified_u_BCs_exist_globally = merge(1, 0, OBC%specified_u_BCs_exist_globally)
-    cobc%specified_v_BCs_exist_globally = merge(1, 0, OBC%specified_v_BCs_exist_globally)
-    cobc%Flather_u_BCs_exist_globally = merge(1, 0, OBC%Flather_u_BCs_exist_globally)
-    cobc%Flather_v_BCs_exist_globally = merge(1, 0, OBC%Flather_v_BCs_exist_globally)
-    cobc%segment = c_loc(csegs)
-    if (OBC%number_of_segments > 0) then
-      if (.not.(allocated(OBC%segnum_u) .and. allocated(OBC%segnum_v))) call MOM_error(FATAL, &
-        "MOM_continuity_PPM (HIP): OBC%segnum_u and OBC%segnum_v must be allocated.")
-      if (size(OBC%segnum_u) /= size(uh(:,:,1)) .or. size(OBC%segnum_v) /= size(vh(:,:,1))) call MOM_error(FATAL, &
-        "MOM_continuity_PPM (HIP): OBC%segnum_u / segnum_v do not have the shape of the u / v points of the data domain.")
-      cobc%segnum_u = c_loc(OBC%segnum_u) ; cobc%segnum_v = c_loc(OBC%segnum_v)
-    endif
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(uh(:,:,1)), size(vh(:,:,1)), "MOM_continuity_PPM")
     rc = mom6hip_continuity_obc(mom6hip_shared_context(G, GV), c_struct(CS), cobc, c_loc(u), c_loc(v), c_loc(hin), c_loc(h), c_loc(uh), &
                                 c_loc(vh), dt, p_uhbt, p_vhbt, p_vru, p_vrv, p_ucor, p_vcor, p_bt, p_du, p_dv, MOM6HIP_MEM_HOST)
   else
@@ -178,20 +160,6 @@ subroutine continuity_PPM(u, v, hin, h, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhb
                           c_loc(vh), dt, p_uhbt, p_vhbt, p_vru, p_vrv, p_ucor, p_vcor, p_bt, p_du, p_dv, MOM6HIP_MEM_HOST)
   endif
   call mom6hip_fatal_if(rc, "MOM_continuity_PPM")
-contains
-  subroutine segment_to_c(seg, c)
-    type(OBC_segment_type), target, intent(in) :: seg
-    type(mom6hip_obc_segment_t), intent(out) :: c
-    c%direction = seg%direction ; c%open = merge(1, 0, seg%open) ; c%specified = merge(1, 0, seg%specified)
-    c%on_pe = merge(1, 0, seg%on_pe) ; c%is_E_or_W = merge(1, 0, seg%is_E_or_W) ; c%is_N_or_S = merge(1, 0, seg%is_N_or_S)
-    c%IsdB = seg%HI%IsdB ; c%IedB = seg%HI%IedB ; c%JsdB = seg%HI%JsdB ; c%JedB = seg%HI%JedB
-    c%isd = seg%HI%isd ; c%ied = seg%HI%ied ; c%jsd = seg%HI%jsd ; c%jed = seg%HI%jed
-    if (seg%specified .and. seg%on_pe) then
-      if (.not.(allocated(seg%normal_trans) .and. allocated(seg%normal_vel))) call MOM_error(FATAL, &
-        "MOM_continuity_PPM (HIP): a specified segment needs normal_trans and normal_vel.")
-      c%normal_trans = c_loc(seg%normal_trans) ; c%normal_vel = c_loc(seg%normal_vel)
-    endif
-  end subroutine segment_to_c
 end subroutine continuity_PPM
 
 !> Same interface as the reference continuity_3d_fluxes (:200): the transports without the thickness update

@@ -21,6 +21,7 @@ use MOM_domains,       only : pass_var, CENTER, EAST_FACE, NORTH_FACE, CORNER
 use MOM_error_handler, only : MOM_error, FATAL
 use MOM_file_parser,   only : get_param, param_file_type
 use MOM_grid,          only : ocean_grid_type
+use MOM_open_boundary, only : ocean_OBC_type, OBC_segment_type
 use MOM_string_functions, only : uppercase
 use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
@@ -30,6 +31,7 @@ public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6h
 public :: mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirrors_stage, mom6hip_mirrors_to_host
 public :: mom6hip_mirrors_host_was_modified, mom6hip_mirror_host_changed, mom6hip_mirror_zeroed, mom6hip_mirrors_end
 public :: mom6hip_mirror_pass_var, mom6hip_mirror_require_host_current, mom6hip_mirror_forget
+public :: mom6hip_obc_to_c
 
 integer, parameter :: MAX_MIRRORS = 160
 !> A host array of the caller and its copy in HBM
@@ -434,5 +436,55 @@ function min_cb(user, values, n) bind(c) result(rc)
   enddo
   rc = 0
 end function min_cb
+
+!> What the library reads of ocean_OBC_type and its segments (MOM_open_boundary.F90:146-386) as a mom6hip_obc_t of host pointers:
+!! the caller keeps csegs (and OBC) alive for the call.  Provided entry points: continuity_PPM and CorAdCalc (round 4).
+subroutine mom6hip_obc_to_c(OBC, cobc, csegs, n_u2, n_v2, who)
+  type(ocean_OBC_type), target, intent(in)  :: OBC
+  type(mom6hip_obc_t),          intent(out) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target, intent(inout) :: csegs(:)
+  integer,                      intent(in)  :: n_u2, n_v2   !< the sizes of a 2-D array at the u and v points of the data domain
+  character(len=*),             intent(in)  :: who
+  integer :: n
+  if (allocated(csegs)) deallocate(csegs)
+  allocate(csegs(max(OBC%number_of_segments, 1)))
+  do n=1,OBC%number_of_segments
+    call segment_to_c(OBC%segment(n), csegs(n))
+  enddo
+  cobc%number_of_segments = OBC%number_of_segments ; cobc%OBC_pe = merge(1, 0, OBC%OBC_pe)
+  cobc%open_u_BCs_exist_globally = merge(1, 0, OBC%open_u_BCs_exist_globally)
+  cobc%open_v_BCs_exist_globally = merge(1, 0, OBC%open_v_BCs_exist_globally)
+  cobc%specified_u_BCs_exist_globally = merge(1, 0, OBC%specified_u_BCs_exist_globally)
+  cobc%specified_v_BCs_exist_globally = merge(1, 0, OBC%specified_v_BCs_exist_globally)
+  cobc%Flather_u_BCs_exist_globally = merge(1, 0, OBC%Flather_u_BCs_exist_globally)
+  cobc%Flather_v_BCs_exist_globally = merge(1, 0, OBC%Flather_v_BCs_exist_globally)
+  cobc%zero_vorticity = merge(1, 0, OBC%zero_vorticity) ; cobc%freeslip_vorticity = merge(1, 0, OBC%freeslip_vorticity)
+  cobc%computed_vorticity = merge(1, 0, OBC%computed_vorticity) ; cobc%specified_vorticity = merge(1, 0, OBC%specified_vorticity)
+  cobc%segment = c_loc(csegs)
+  if (OBC%number_of_segments > 0) then
+    if (.not.(allocated(OBC%segnum_u) .and. allocated(OBC%segnum_v))) call MOM_error(FATAL, &
+      who//" (HIP): OBC%segnum_u and OBC%segnum_v must be allocated.")
+    if (size(OBC%segnum_u) /= n_u2 .or. size(OBC%segnum_v) /= n_v2) call MOM_error(FATAL, &
+      who//" (HIP): OBC%segnum_u / segnum_v do not have the shape of the u / v points of the data domain.")
+    cobc%segnum_u = c_loc(OBC%segnum_u) ; cobc%segnum_v = c_loc(OBC%segnum_v)
+  endif
+contains
+  subroutine segment_to_c(seg, c)
+    type(OBC_segment_type), target, intent(in) :: seg
+    type(mom6hip_obc_segment_t), intent(out) :: c
+    c%direction = seg%direction ; c%open = merge(1, 0, seg%open) ; c%specified = merge(1, 0, seg%specified)
+    c%on_pe = merge(1, 0, seg%on_pe) ; c%is_E_or_W = merge(1, 0, seg%is_E_or_W) ; c%is_N_or_S = merge(1, 0, seg%is_N_or_S)
+    c%IsdB = seg%HI%IsdB ; c%IedB = seg%HI%IedB ; c%JsdB = seg%HI%JsdB ; c%JedB = seg%HI%JedB
+    c%isd = seg%HI%isd ; c%ied = seg%HI%ied ; c%jsd = seg%HI%jsd ; c%jed = seg%HI%jed
+    if (.not.seg%on_pe) return
+    if (seg%specified) then
+      if (.not.(allocated(seg%normal_trans) .and. allocated(seg%normal_vel))) call MOM_error(FATAL, &
+        who//" (HIP): a specified segment needs normal_trans and normal_vel.")
+      c%normal_trans = c_loc(seg%normal_trans) ; c%normal_vel = c_loc(seg%normal_vel)
+    endif
+    if (allocated(seg%tangential_vel)) c%tangential_vel = c_loc(seg%tangential_vel)
+    if (allocated(seg%tangential_grad)) c%tangential_grad = c_loc(seg%tangential_grad)
+  end subroutine segment_to_c
+end subroutine mom6hip_obc_to_c
 
 end module mom6hip_MOM_glue

@@ -645,6 +645,16 @@ interface
     integer(c_int) :: rc
   end function mom6hip_continuity
 
+  !> CorAdCalc with OBC associated
+  function mom6hip_coradcalc_obc(ctx, cs, obc, u, v, h, uh, vh, CAu, CAv, memspace) bind(c, name="mom6hip_coradcalc_obc") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_coriolisadv_cs_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v, h, uh, vh, CAu, CAv
+    type(mom6hip_coriolisadv_cs_t), intent(in) :: cs
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_coradcalc_obc
+
   !> continuity_PPM with OBC associated: obc holds host pointers (its segment table and segnum arrays) whatever the memory space
   function mom6hip_continuity_obc(ctx, cs, obc, u, v, hin, h, uh, vh, dt, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, &
                                   BT_cont, du_cor, dv_cor, memspace) bind(c, name="mom6hip_continuity_obc") result(rc)

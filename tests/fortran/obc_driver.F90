@@ -3,11 +3,14 @@
 !! flags, segnum_u / segnum_v, the external transports and velocities of the specified segments -- filled from a file written by
 !! tests/test_continuity_obc.py, then
 !!   continuity(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont)
+!!   CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv)                         (MOM_dynamics_split_RK2.F90:869)
 !! on plain host arrays; the results go to the output file, which the test compares with the oracle bit for bit.
 !! Usage: obc_driver <input file> <output file>
 program obc_driver
 use, intrinsic :: iso_c_binding
 use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_PPM_CS
+use MOM_CoriolisAdv,    only : CorAdCalc, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_CS
+use MOM_variables,      only : accel_diag_ptrs
 use MOM_diag_mediator,  only : diag_ctrl, time_type
 use MOM_domains,        only : MOM_domain_type
 use MOM_file_parser,    only : param_file_type, param_set
@@ -26,6 +29,10 @@ type(param_file_type) :: pf
 type(time_type), target :: Time
 type(diag_ctrl), target :: diag
 type(continuity_PPM_CS) :: CS
+type(CoriolisAdv_CS) :: CCS
+type(accel_diag_ptrs), target :: AD
+integer(c_int32_t) :: vflags(4)
+real, allocatable, dimension(:,:,:) :: CAu, CAv
 type(ocean_OBC_type), pointer :: OBC => NULL()
 type(porous_barrier_type) :: pbv
 type(BT_cont_type), pointer :: BT => NULL()
@@ -101,6 +108,16 @@ do n=1,nseg ; if (OBC%segment(n)%specified .and. OBC%segment(n)%on_pe) then
   endif
   read(u_in) OBC%segment(n)%normal_trans, OBC%segment(n)%normal_vel
 endif ; enddo
+! OBC_ZERO_VORTICITY, OBC_FREESLIP_VORTICITY, OBC_COMPUTED_VORTICITY, OBC_SPECIFIED_VORTICITY, then tangential_vel and tangential_grad of every
+! segment on the PE (IsdB:IedB, JsdB:JedB, nk)
+read(u_in) vflags
+OBC%zero_vorticity = (vflags(1) /= 0) ; OBC%freeslip_vorticity = (vflags(2) /= 0)
+OBC%computed_vorticity = (vflags(3) /= 0) ; OBC%specified_vorticity = (vflags(4) /= 0)
+do n=1,nseg ; if (OBC%segment(n)%on_pe) then
+  allocate(OBC%segment(n)%tangential_vel(OBC%segment(n)%HI%IsdB:OBC%segment(n)%HI%IedB, OBC%segment(n)%HI%JsdB:OBC%segment(n)%HI%JedB, nk))
+  allocate(OBC%segment(n)%tangential_grad(OBC%segment(n)%HI%IsdB:OBC%segment(n)%HI%IedB, OBC%segment(n)%HI%JsdB:OBC%segment(n)%HI%JedB, nk))
+  read(u_in) OBC%segment(n)%tangential_vel, OBC%segment(n)%tangential_grad
+endif ; enddo
 close(u_in)
 
 allocate(hp(isd:ied,jsd:jed,nk), uh(isd-1:ied,jsd:jed,nk), vh(isd:ied,jsd-1:jed,nk), u_cor(isd-1:ied,jsd:jed,nk), v_cor(isd:ied,jsd-1:jed,nk))
@@ -111,12 +128,18 @@ call continuity_PPM_init(Time, G, GV, US, pf, diag, CS)
 call alloc_BT_cont_type(BT, isd, ied, jsd, jed, nk, alloc_faces=.true.)
 
 call continuity_PPM(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, vru, vrv, u_cor, v_cor, BT_cont=BT)
+call param_set(pf, "BOUND_CORIOLIS", "True")
+call CoriolisAdv_init(Time, G, GV, US, pf, diag, AD, CCS)
+allocate(CAu(isd-1:ied,jsd:jed,nk), CAv(isd:ied,jsd-1:jed,nk)) ; CAu = 0.0 ; CAv = 0.0
+call CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CCS, pbv)
 
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) hp, uh, vh, u_cor, v_cor
 write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_EE
 write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
+write(u_out) CAu, CAv
 close(u_out)
+call CoriolisAdv_end(CCS)
 call mom6hip_shared_context_end()
 write(*,'(a)') "obc_driver ok"
 end program obc_driver

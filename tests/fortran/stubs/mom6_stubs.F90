@@ -1210,7 +1210,7 @@ type :: OBC_segment_type
   logical :: gradient = .false., on_pe = .false., is_N_or_S = .false., is_E_or_W = .false.
   integer :: direction = 0
   type(hor_index_type) :: HI
-  real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:)
+  real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:), tangential_vel(:,:,:), tangential_grad(:,:,:)
 end type OBC_segment_type
 type :: ocean_OBC_type
   logical :: OBC_pe = .false.

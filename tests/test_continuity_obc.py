@@ -293,6 +293,10 @@ def _write_obc_case(path, g, st, OBC, uhbt, vhbt, dt=900.0):
         for s in OBC.segment:
             if s.specified and s.on_pe:
                 np.ascontiguousarray(s.normal_trans, dtype="<f8").tofile(f); np.ascontiguousarray(s.normal_vel, dtype="<f8").tofile(f)
+        np.array([OBC.zero_vorticity, OBC.freeslip_vorticity, OBC.computed_vorticity, OBC.specified_vorticity], dtype="<i4").tofile(f)
+        for s in OBC.segment:
+            if s.on_pe:
+                np.ascontiguousarray(s.tangential_vel, dtype="<f8").tofile(f); np.ascontiguousarray(s.tangential_grad, dtype="<f8").tofile(f)
 
 
 def test_obc_driver_compiles(tmp_path):
@@ -315,15 +319,22 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
         pytest.skip("amdflang not present")
     exe = _build_shims(tmp_path, driver="obc_driver")
     g, st, OBC = obc_case(segs)
+    OBC.freeslip_vorticity = segs is not None and len(segs) == 5      # tc3's OBC_FREESLIP_VORTICITY; the other set: the computed vorticity
+    OBC.computed_vorticity = not OBC.freeslip_vorticity
+    rng = np.random.default_rng(12)
+    for s in OBC.segment:
+        if s.on_pe:
+            s.tangential_vel[:] = 0.1 * rng.standard_normal(s.tangential_vel.shape)
     want = run(g, st, OBC)
+    want["CAu"], want["CAv"] = orc.coradcalc(g, st["u"], st["v"], st["h"], want["uh"], want["vh"], bound_coriolis=True, OBC=OBC)
     _write_obc_case(str(tmp_path / "in.bin"), g, st, OBC, want["uhbt"], want["vhbt"])
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
-             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"]
+             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv"]
     arrs = [want[n] if n in want else want["bt"][n] for n in names]
     got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
     for n, a, w in zip(names, got, arrs):
-        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
         assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
