@@ -41,7 +41,7 @@ HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL
 SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
-PMC_PROFILE = "r03_c_pmc.json"      # the counter passes `roofline.traffic` is read from (profiles/)
+PMC_PROFILE = "r04_c_pmc.json"      # the counter passes `roofline.traffic` is read from (profiles/)
 LAND_FRAC = 0.30
 # grid-scale bathymetric roughness (white noise, as a fraction of the depth range) with a fixed SLOPE: 0.04 on a 3-degree
 # grid, 0.0025 (14 m rms) at 1/4 degree.  With the amplitude held at 0.04 the 1/4-degree bathymetry had 200 m steps between

@@ -396,7 +396,7 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
       BT->uBT_mm[F2d(D,A,c)] = 0.0; BT->uBT_pp[F2d(D,A,c)] = 0.0;
     } else if (set_BT_cont) {      /* set_zonal_BT_cont :1247-1410: its calls of flux_adjust and flux_layer do not pass OBC */
       dirx_t Dn = *D; Dn.OBC = NULL; Dn.open_BC = 0; Dn.specified_BC = 0; Dn.Flather_BC = 0;
-      const dirx_t *D0 = D; D = &Dn;
+      const dirx_t *const D = &Dn;      /* (a name of this block: the rows of this loop run on several threads) */
       const double min_visc_rem = 0.1, CFL_min = 1e-6;
       double du0 = flux_adjust(D, CS, u, h_in, h_L, h_R, 0.0, uh_tot_0, duhdu_tot_0, du_max_CFL, du_min_CFL,
                                dt, vr, A, c, NULL);
@@ -437,7 +437,6 @@ static void mass_flux(const dirx_t *D, const mom6hip_continuity_cs_t *CS, const 
       BT->FA_0p[F2d(D,A,c)] = FA_0; BT->FA_pp[F2d(D,A,c)] = FAmt_R;
       if (fabs(FAmt_R - FA_0) <= 1e-12*FA_0) BT->uBT_pp[F2d(D,A,c)] = 0.0;
       else BT->uBT_pp[F2d(D,A,c)] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
-      D = D0;
     }
   }
   free(vr); free(duhdu);
