@@ -458,6 +458,19 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
                       int32_t memspace);
 
 struct mom6hip_obc;
+/* radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, GV, US, dt)            src/core/MOM_open_boundary.F90:2196
+ * The normal component: Orlanski radiation (segment%radiation: the phase speed from the two faces inside the boundary, capped by
+ * OBC%rx_max = OBC_RADIATION_MAX, averaged in time with OBC%gamma_uv = OBC_RAD_VEL_WT into the restart fields OBC%rx_normal /
+ * ry_normal), the gradient condition (segment%gradient), nudging towards segment%nudged_normal_vel; then
+ * open_boundary_apply_normal_flow (:3337) and pass_vector(u_new, v_new).  segment%normal_vel is written.  Not provided (refused):
+ * oblique radiation, the tangential velocity and gradient forms, tracer reservoirs.
+ * rx_normal (u points, 3-D) and ry_normal (v points, 3-D) may be NULL when gamma_uv >= 1. */
+int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const struct mom6hip_obc *obc, double gamma_uv, double rx_max, double *rx_normal,
+                                      double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old, double dt,
+                                      int32_t memspace);
+/* open_boundary_zero_normal_flow(OBC, G, GV, u, v) :3374 (the RK2 step applies it to the accelerations :566, :888) */
+int mom6hip_open_boundary_zero_normal_flow(mom6hip_ctx_t *ctx, const struct mom6hip_obc *obc, double *u, double *v, int32_t memspace);
+
 /* CorAdCalc with OBC associated (:249-269 the areas across a segment, :337-420 the circulation and the thicknesses projected onto the
  * velocity points of a segment, :422-455 onto its corner points, gradKE :1037-1050); additionally needs the metrics dxBu, dyBu with
  * OBC%specified_vorticity.  obc == NULL: mom6hip_coradcalc. */
@@ -524,14 +537,20 @@ typedef struct mom6hip_obc_segment {
   int32_t is_E_or_W, is_N_or_S;
   int32_t IsdB, IedB, JsdB, JedB;      /* segment%HI: the segment's face range on this PE's data domain */
   int32_t isd, ied, jsd, jed;          /* segment%HI: its cell range */
-  int32_t reserved[6];
+  int32_t radiation, gradient, nudged; /* segment%radiation (Orlanski), %gradient, %nudged: read by radiation_open_bdry_conds */
+  int32_t oblique;                     /* segment%oblique: not provided (refused by mom6hip_radiation_open_bdry_conds) */
+  int32_t radiation_tan_or_grad;       /* segment%radiation_tan .or. %radiation_grad .or. the oblique / nudged counterparts: not provided */
+  int32_t reserved[1];
   /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where
    * `specified`; in the memory space of the call; may be NULL otherwise */
-  const double *normal_trans, *normal_vel;
+  const double *normal_trans;
+  double *normal_vel;                  /* (written by radiation_open_bdry_conds for radiation / gradient segments) */
   /* segment%tangential_vel, segment%tangential_grad (IsdB:IedB, JsdB:JedB, nk): read by CorAdCalc with OBC%computed_vorticity /
    * OBC%specified_vorticity; may be NULL otherwise */
   const double *tangential_vel, *tangential_grad;
-  void *reserved_p[2];
+  const double *nudged_normal_vel;     /* segment%nudged_normal_vel, the layout of normal_vel: read where `nudged` */
+  void *reserved_p[1];
+  double Velocity_nudging_timescale_in, Velocity_nudging_timescale_out;      /* [T] */
 } mom6hip_obc_segment_t;
 
 typedef struct mom6hip_obc {

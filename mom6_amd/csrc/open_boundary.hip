@@ -1,0 +1,167 @@
+// open_boundary.hip -- the part of src/core/MOM_open_boundary.F90 the RK2 step calls with the settings of .testing/tc3, on the device:
+// radiation_open_bdry_conds :2196 for the normal component (Orlanski radiation with its restart fields rx_normal / ry_normal, the
+// gradient condition, nudging), open_boundary_apply_normal_flow :3337, the pass of u_new, v_new, and open_boundary_zero_normal_flow
+// :3374.  One launch a segment (thread per point along the segment and layer): a configuration has a handful of segments, a point of
+// a segment reads the two faces inside the boundary and writes its own face only, and a later segment has the last word where two
+// overlap, as in the reference's loop over the segments.  Oblique radiation, the tangential forms and the tracer reservoirs are refused.
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+using m6::min2;
+
+struct RadSeg {
+  int ew, d1, A, c0, c1, radiation, gradient, nudged;      // d1 = -1 (E, N: inside towards smaller indices) or +1
+  int a0, cs0;             // the first index of the segment's own arrays along / across (IsdB | JsdB, jsd | isd)
+  long nA, nc;             // their extents
+  double tau_in, tau_out;
+  double *normal_vel;
+  const double *nudged_normal_vel;
+};
+
+__device__ __forceinline__ long rad_idx(const RadSeg &S, int c, int k) {      // (A - a0 = 0: a segment is one face wide)
+  return S.ew ? (long)0 + S.nA * ((c - S.cs0) + S.nc * (long)k) : (long)(c - S.cs0) + S.nc * ((long)0 + S.nA * (long)k);
+}
+
+// :2326-2400 (E), :2571 (W), :2816 (N), :3060 (S): the normal velocity of the segment's faces
+__global__ __launch_bounds__(64) void rad_segment_kernel(m6::GridDev g, RadSeg S, double gamma_u, double rx_max, double dt, const double *xn,
+                                                         const double *xo, double *r_normal) {
+  const int c = S.c0 + blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (c > S.c1) return;
+  const long pl = S.ew ? (long)(g.nih + 1) * g.njh : (long)g.nih * (g.njh + 1);
+  const long f0 = (S.ew ? g.u2(S.A, c) : g.v2(c, S.A)) + pl * k;
+  const long step = S.ew ? 1 : g.nih;      // one face along the direction
+  const long f1 = f0 + S.d1 * step, f2 = f0 + 2 * S.d1 * step;
+  double dhdt = 0.0, dhdx = 0.0;
+  double nv = S.normal_vel[rad_idx(S, c, k)];
+  if (S.radiation) {
+    dhdt = (xo[f1] - xn[f1]);
+    dhdx = (xn[f1] - xn[f2]);
+    double rx_new = 0.0, rx_avg;
+    if (dhdt * dhdx > 0.0) rx_new = min2((dhdt / dhdx), rx_max);
+    if (gamma_u < 1.0) rx_avg = (1.0 - gamma_u) * r_normal[f0] + gamma_u * rx_new;
+    else rx_avg = rx_new;
+    nv = (xn[f0] + rx_avg * xn[f1]) / (1.0 + rx_avg);
+    if (gamma_u < 1.0) r_normal[f0] = rx_avg;
+  } else if (S.gradient) {
+    nv = xn[f1];
+  }
+  if (S.radiation && S.nudged) {
+    const double tau = (dhdt * dhdx <= 0.0) ? S.tau_in : S.tau_out;
+    const double gamma_2 = dt / (tau + dt);
+    nv = (1.0 - gamma_2) * nv + gamma_2 * S.nudged_normal_vel[rad_idx(S, c, k)];
+  }
+  S.normal_vel[rad_idx(S, c, k)] = nv;
+}
+
+// open_boundary_apply_normal_flow :3337 (from = the segment's normal_vel) / open_boundary_zero_normal_flow :3374 (from = null)
+__global__ __launch_bounds__(64) void obc_face_store_kernel(m6::GridDev g, RadSeg S, double *x, int from_normal_vel) {
+  const int c = S.c0 + blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (c > S.c1) return;
+  const long pl = S.ew ? (long)(g.nih + 1) * g.njh : (long)g.nih * (g.njh + 1);
+  x[(S.ew ? g.u2(S.A, c) : g.v2(c, S.A)) + pl * k] = from_normal_vel ? S.normal_vel[rad_idx(S, c, k)] : 0.;
+}
+
+// the geometry of a segment for these kernels; false: not on the PE or neither E/W nor N/S
+bool rad_segment(const m6::GridDev &g, const mom6hip_obc_segment_t &S, RadSeg &d) {
+  if (!S.on_pe) return false;
+  const bool ew = S.is_E_or_W != 0;
+  if (!ew && !S.is_N_or_S) return false;
+  d.ew = ew ? 1 : 0;
+  d.d1 = (S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_N) ? -1 : 1;
+  d.A = ew ? S.IsdB : S.JsdB; d.c0 = ew ? S.jsd : S.isd; d.c1 = ew ? S.jed : S.ied;
+  d.a0 = d.A; d.cs0 = d.c0;
+  d.nA = ew ? (S.IedB - S.IsdB + 1) : (S.JedB - S.JsdB + 1); d.nc = d.c1 - d.c0 + 1;
+  d.radiation = S.radiation; d.gradient = S.gradient; d.nudged = S.nudged;
+  d.tau_in = S.Velocity_nudging_timescale_in; d.tau_out = S.Velocity_nudging_timescale_out;
+  d.normal_vel = nullptr; d.nudged_normal_vel = nullptr;
+  return true;
+}
+
+int check_segment_range(const m6::GridDev &g, const mom6hip_obc_segment_t &S, int n, const char *who) {
+  const bool ew = S.is_E_or_W != 0;
+  M6_REQUIRE(ew ? (S.IsdB == S.IedB && S.IsdB >= g.isd + 1 && S.IsdB <= g.ied - 2 && S.jsd >= g.jsd && S.jed <= g.jed)
+                : (S.JsdB == S.JedB && S.JsdB >= g.jsd + 1 && S.JsdB <= g.jed - 2 && S.isd >= g.isd && S.ied <= g.ied),
+             "%s: OBC segment %d lies outside the data domain", who, n + 1);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6hip_obc_t *obc, double gamma_uv, double rx_max, double *rx_normal,
+                                                 double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old,
+                                                 double dt, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "radiation_open_bdry_conds: the context is required");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "radiation_open_bdry_conds: bad memspace");
+  if (!obc) return 0;      // .not.associated(OBC) :2240
+  if (!(obc->open_u_BCs_exist_globally || obc->open_v_BCs_exist_globally)) return 0;      // :2242
+  M6_REQUIRE(u_new && u_old && v_new && v_old, "radiation_open_bdry_conds: null argument");
+  M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "radiation_open_bdry_conds: OBC%%segment is required");
+  const m6::GridDev g = ctx->g;
+  hipStream_t s = ctx->stream;
+  const size_t bU = (size_t)g.nu3() * 8, bV = (size_t)g.nv3() * 8;
+  m6::Stager st(ctx, memspace);
+  double *d_un = st.inout(u_new, bU), *d_vn = st.inout(v_new, bV);
+  const double *d_uo = st.in(u_old, bU), *d_vo = st.in(v_old, bV);
+  double *d_rx = st.inout(rx_normal, bU), *d_ry = st.inout(ry_normal, bV);
+  std::vector<RadSeg> segs;
+  for (int n = 0; n < obc->number_of_segments; n++) {
+    const mom6hip_obc_segment_t &S = obc->segment[n];
+    RadSeg d;
+    if (!rad_segment(g, S, d)) continue;
+    M6_REQUIRE(!S.oblique, "radiation_open_bdry_conds: oblique radiation (OBLIQUE, segment %d) is not provided by libmom6hip", n + 1);
+    M6_REQUIRE(!S.radiation_tan_or_grad, "radiation_open_bdry_conds: the tangential forms (ORLANSKI_TAN / _GRAD, OBLIQUE_TAN / _GRAD, NUDGED_TAN / "
+               "_GRAD; segment %d) are not provided by libmom6hip", n + 1);
+    if (check_segment_range(g, S, n, "radiation_open_bdry_conds")) return 1;
+    if (S.radiation || S.gradient) {
+      M6_REQUIRE(S.normal_vel, "radiation_open_bdry_conds: segment %d needs normal_vel", n + 1);
+      M6_REQUIRE(!(S.radiation && gamma_uv < 1.0) || (d.ew ? rx_normal : ry_normal), "radiation_open_bdry_conds: OBC_RAD_VEL_WT < 1 needs OBC%%rx_normal / ry_normal");
+      M6_REQUIRE(!(S.radiation && S.nudged) || S.nudged_normal_vel, "radiation_open_bdry_conds: segment %d is nudged: nudged_normal_vel is required", n + 1);
+      const size_t cnt = (size_t)d.nA * d.nc * g.nk * 8;
+      d.normal_vel = st.inout(S.normal_vel, cnt);
+      d.nudged_normal_vel = (S.radiation && S.nudged) ? st.in(S.nudged_normal_vel, cnt) : nullptr;
+    }
+    segs.push_back(d);
+  }
+  M6_REQUIRE(!st.failed(), "radiation_open_bdry_conds: staging failed");
+  for (const RadSeg &d : segs) {
+    if (!(d.radiation || d.gradient)) continue;
+    // I < IscB (E), I > IecB (W), J < JscB (N), J > JecB (S): the segment is skipped :2329, :2573, :2818, :3062
+    const int lo = d.ew ? g.isc - 1 : g.jsc - 1, hi = d.ew ? g.iec : g.jec;
+    if (d.d1 < 0 ? (d.A < lo) : (d.A > hi)) continue;
+    hipLaunchKernelGGL(rad_segment_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, s, g, d, gamma_uv, rx_max, dt, d.ew ? d_un : d_vn,
+                       d.ew ? d_uo : d_vo, d.ew ? d_rx : d_ry);
+  }
+  for (const RadSeg &d : segs) {      // open_boundary_apply_normal_flow :3337 (radiation, oblique or gradient segments)
+    if (!(d.radiation || d.gradient)) continue;
+    hipLaunchKernelGGL(obc_face_store_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, s, g, d, d.ew ? d_un : d_vn, 1);
+  }
+  M6_HIP(hipGetLastError());
+  double *pf[2] = {d_un, d_vn};
+  const int32_t ppos[2] = {MOM6HIP_POS_U, MOM6HIP_POS_V}, pnk[2] = {g.nk, g.nk};
+  if (int rc = m6::group_pass(ctx, pf, ppos, pnk, 2)) return rc;      // pass_vector(u_new, v_new) :3309
+  return st.finish();
+}
+
+extern "C" int mom6hip_open_boundary_zero_normal_flow(mom6hip_ctx_t *ctx, const mom6hip_obc_t *obc, double *u, double *v, int32_t memspace) {
+  M6_REQUIRE(ctx != nullptr, "open_boundary_zero_normal_flow: the context is required");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "open_boundary_zero_normal_flow: bad memspace");
+  if (!obc) return 0;
+  M6_REQUIRE(u && v, "open_boundary_zero_normal_flow: null argument");
+  M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "open_boundary_zero_normal_flow: OBC%%segment is required");
+  const m6::GridDev g = ctx->g;
+  m6::Stager st(ctx, memspace);
+  double *d_u = st.inout(u, (size_t)g.nu3() * 8), *d_v = st.inout(v, (size_t)g.nv3() * 8);
+  M6_REQUIRE(!st.failed(), "open_boundary_zero_normal_flow: staging failed");
+  for (int n = 0; n < obc->number_of_segments; n++) {
+    RadSeg d;
+    if (!rad_segment(g, obc->segment[n], d)) continue;
+    if (check_segment_range(g, obc->segment[n], n, "open_boundary_zero_normal_flow")) return 1;
+    hipLaunchKernelGGL(obc_face_store_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, ctx->stream, g, d, d.ew ? d_u : d_v, 0);
+  }
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}

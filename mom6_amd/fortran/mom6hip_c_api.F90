@@ -197,9 +197,12 @@ integer(c_int32_t), parameter :: MOM6HIP_OBC_NONE = 0, MOM6HIP_OBC_DIRECTION_N =
 type, bind(c) :: mom6hip_obc_segment_t
   integer(c_int32_t) :: direction = 0, open = 0, specified = 0, on_pe = 0, is_E_or_W = 0, is_N_or_S = 0
   integer(c_int32_t) :: IsdB = 0, IedB = 0, JsdB = 0, JedB = 0, isd = 0, ied = 0, jsd = 0, jed = 0
-  integer(c_int32_t) :: reserved(6) = 0
+  integer(c_int32_t) :: radiation = 0, gradient = 0, nudged = 0, oblique = 0, radiation_tan_or_grad = 0
+  integer(c_int32_t) :: reserved(1) = 0
   type(c_ptr) :: normal_trans = c_null_ptr, normal_vel = c_null_ptr, tangential_vel = c_null_ptr, tangential_grad = c_null_ptr
-  type(c_ptr) :: reserved_p(2) = c_null_ptr
+  type(c_ptr) :: nudged_normal_vel = c_null_ptr
+  type(c_ptr) :: reserved_p(1) = c_null_ptr
+  real(c_double) :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
 end type mom6hip_obc_segment_t
 type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: number_of_segments = 0, OBC_pe = 0, open_u_BCs_exist_globally = 0, open_v_BCs_exist_globally = 0
@@ -644,6 +647,25 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_continuity
+
+  !> radiation_open_bdry_conds (the normal component: Orlanski, gradient, nudging), apply_normal_flow and the pass of u_new, v_new
+  function mom6hip_radiation_open_bdry_conds(ctx, obc, gamma_uv, rx_max, rx_normal, ry_normal, u_new, u_old, v_new, v_old, dt, memspace) &
+                                             bind(c, name="mom6hip_radiation_open_bdry_conds") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_obc_t
+    type(c_ptr), value :: ctx, rx_normal, ry_normal, u_new, u_old, v_new, v_old
+    type(mom6hip_obc_t), intent(in) :: obc
+    real(c_double), value :: gamma_uv, rx_max, dt
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_radiation_open_bdry_conds
+
+  function mom6hip_open_boundary_zero_normal_flow(ctx, obc, u, v, memspace) bind(c, name="mom6hip_open_boundary_zero_normal_flow") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_open_boundary_zero_normal_flow
 
   !> CorAdCalc with OBC associated
   function mom6hip_coradcalc_obc(ctx, cs, obc, u, v, h, uh, vh, CAu, CAv, memspace) bind(c, name="mom6hip_coradcalc_obc") result(rc)

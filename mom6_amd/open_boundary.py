@@ -3,7 +3,8 @@ open_boundary_config (:429), parse_segment_str (:1612), setup_segment_indices (:
 :1473) -- the segment strings of MOM_input ("I=N,J=0:N,FLATHER,ORLANSKI") become an ocean_OBC_type with the reference's member names,
 and `struct()` hands the library what continuity_PPM reads of it (mom6hip_obc_t, include/mom6hip.h).
 
-Round 4 provides the OBC branches of continuity_PPM only (mom6_amd.continuity.continuity(..., OBC=)); every other operator still
+Round 4 provides the OBC branches of continuity_PPM and CorAdCalc (continuity(..., OBC=), CorAdCalc(..., OBC, ...)) and, here,
+radiation_open_bdry_conds for the normal component (:2196) and open_boundary_zero_normal_flow (:3374); every other operator still
 refuses an associated OBC."""
 from __future__ import annotations
 
@@ -74,6 +75,8 @@ class OBC_segment_type:
         self.normal_vel = None
         self.tangential_vel = None    # (nk, JsdB:JedB, IsdB:IedB): the corner points along the segment
         self.tangential_grad = None
+        self.nudged_normal_vel = None      # the layout of normal_vel
+        self.Velocity_nudging_timescale_in = self.Velocity_nudging_timescale_out = 0.0
 
 
 class ocean_OBC_type:
@@ -85,6 +88,10 @@ class ocean_OBC_type:
         # OBC_ZERO_VORTICITY, OBC_FREESLIP_VORTICITY, OBC_COMPUTED_VORTICITY, OBC_SPECIFIED_VORTICITY (:470-500), read by CorAdCalc
         for n in ("zero_vorticity", "freeslip_vorticity", "computed_vorticity", "specified_vorticity"):
             setattr(self, n, bool(flags.pop(n, False)))
+        # OBC_RAD_VEL_WT, OBC_RADIATION_MAX (:629-640) and the restart fields of the radiation (arrays at u / v points, nk layers, in the
+        # memory space of the calls; None with gamma_uv >= 1)
+        self.gamma_uv, self.rx_max = float(flags.pop("gamma_uv", 0.3)), float(flags.pop("rx_max", 1.0))
+        self.rx_normal = self.ry_normal = None
         if flags:
             raise Mom6HipError(f"open_boundary_config: unknown option {sorted(flags)}")
         self.idg_offset = -g.halo if idg_offset is None else idg_offset
@@ -186,7 +193,7 @@ class ocean_OBC_type:
             shp = (nk, H["jed"] - H["jsd"] + 1, H["IedB"] - H["IsdB"] + 1)
         else:
             shp = (nk, H["JedB"] - H["JsdB"] + 1, H["ied"] - H["isd"] + 1)
-        seg.normal_trans = np.zeros(shp); seg.normal_vel = np.zeros(shp)
+        seg.normal_trans = np.zeros(shp); seg.normal_vel = np.zeros(shp); seg.nudged_normal_vel = np.zeros(shp)
         shq = (nk, H["JedB"] - H["JsdB"] + 1, H["IedB"] - H["IsdB"] + 1)
         seg.tangential_vel = np.zeros(shq); seg.tangential_grad = np.zeros(shq)
 
@@ -249,9 +256,13 @@ class ocean_OBC_type:
             c.is_E_or_W, c.is_N_or_S = int(s.is_E_or_W), int(s.is_N_or_S)
             for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed"):
                 setattr(c, k, int(s.HI.get(k, 0)))
-            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad"):
+            c.radiation, c.gradient, c.nudged, c.oblique = int(s.radiation), int(s.gradient), int(s.nudged), int(s.oblique)
+            c.radiation_tan_or_grad = int(s.radiation_tan or s.radiation_grad or s.oblique_tan or s.oblique_grad or s.nudged_tan or s.nudged_grad)
+            c.Velocity_nudging_timescale_in, c.Velocity_nudging_timescale_out = float(s.Velocity_nudging_timescale_in), float(s.Velocity_nudging_timescale_out)
+            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel"):
                 a = getattr(s, k)
-                need = s.specified if k.startswith("normal") else (self.computed_vorticity if k == "tangential_vel" else self.specified_vorticity)
+                need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient, "nudged_normal_vel": s.nudged,
+                        "tangential_vel": self.computed_vorticity, "tangential_grad": self.specified_vorticity}[k]
                 if a is not None and need and s.on_pe:
                     if to_ptr is None:
                         a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); setattr(c, k, a.ctypes.data)
@@ -272,3 +283,52 @@ class ocean_OBC_type:
 def open_boundary_config(G, segment_strs, **kw):
     """open_boundary_config(G, US, param_file, OBC) :429 for OBC_NUMBER_OF_SEGMENTS = len(segment_strs), OBC_SEGMENT_%%% = segment_strs"""
     return ocean_OBC_type(G.grid if hasattr(G, "grid") else G, list(segment_strs), **kw)
+
+
+def _obc_call_space(arrays):
+    from .tracer_advect import _ptr_space
+    spaces, ptrs = set(), []
+    for a in arrays:
+        if a is None:
+            ptrs.append(None); continue
+        p, sp = _ptr_space(a); spaces.add(sp); ptrs.append(C.c_void_p(p))
+    if len(spaces) != 1:
+        raise Mom6HipError("MOM_open_boundary: all fields must be in the same memory space")
+    return ptrs, spaces.pop()
+
+
+def _seg_to_ptr(space):
+    def to_ptr(a):      # a segment's own array in the memory space of the call (device: a torch tensor kept on the segment by the caller)
+        if hasattr(a, "data_ptr"):
+            return a.data_ptr(), a
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if space == _abi.MEM_DEVICE:
+            raise Mom6HipError("MOM_open_boundary: with device fields the segments' arrays (normal_vel ...) must be device tensors too")
+        return a.ctypes.data, a
+    return to_ptr
+
+
+def radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, dt):
+    """radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, GV, US, dt) -- :2196: the normal component (Orlanski radiation, the
+    gradient condition, nudging), open_boundary_apply_normal_flow and the pass of u_new, v_new; segment%normal_vel and OBC%rx_normal /
+    ry_normal are updated in place"""
+    from ._lib import check, lib
+    if OBC is None:
+        return
+    ptrs, space = _obc_call_space([OBC.rx_normal, OBC.ry_normal, u_new, u_old, v_new, v_old])
+    obc = OBC.struct(_seg_to_ptr(space))
+    L = lib()
+    L.mom6hip_radiation_open_bdry_conds.argtypes = [C.c_void_p, C.POINTER(_abi.Obc), C.c_double, C.c_double] + [C.c_void_p] * 6 + [C.c_double, C.c_int32]
+    check(L.mom6hip_radiation_open_bdry_conds(G.handle, C.byref(obc), OBC.gamma_uv, OBC.rx_max, *ptrs, float(dt), space), "radiation_open_bdry_conds")
+
+
+def open_boundary_zero_normal_flow(OBC, G, u, v):
+    """open_boundary_zero_normal_flow(OBC, G, GV, u, v) -- :3374"""
+    from ._lib import check, lib
+    if OBC is None:
+        return
+    ptrs, space = _obc_call_space([u, v])
+    obc = OBC.struct(_seg_to_ptr(space))
+    L = lib()
+    L.mom6hip_open_boundary_zero_normal_flow.argtypes = [C.c_void_p, C.POINTER(_abi.Obc), C.c_void_p, C.c_void_p, C.c_int32]
+    check(L.mom6hip_open_boundary_zero_normal_flow(G.handle, C.byref(obc), *ptrs, space), "open_boundary_zero_normal_flow")

@@ -1,0 +1,91 @@
+/* oracle/open_boundary.c -- TEST INFRASTRUCTURE: a C restatement of the part of src/core/MOM_open_boundary.F90 the hot path calls with
+ * the settings of .testing/tc3: radiation_open_bdry_conds :2196-3336 for the normal component (Orlanski radiation, the gradient condition,
+ * nudging), open_boundary_apply_normal_flow :3337-3370, open_boundary_zero_normal_flow :3374-3403.  The reference writes the four
+ * directions out separately (E :2326, W :2571, N :2816, S :3060); they differ in the direction of "inside" only and are restated once.
+ * Oblique radiation, the tangential forms and the tracer reservoirs are not restated (the callers refuse them).
+ * PARITY UNPINNED: the reference holds no known-answer vectors for these routines. */
+#include <math.h>
+#include <stdlib.h>
+#include "mom6_oracle.h"
+
+static inline double min2(double a, double b) { return a < b ? a : b; }
+
+/* segment arrays on the segment's own index ranges (IsdB:IedB, jsd:jed, nk) | (isd:ied, JsdB:JedB, nk); face (A along, c across), k 1-based */
+static inline long seg_idx(const mom6hip_obc_segment_t *S, int ew, int A, int c, int k) {
+  if (!ew) { const long ni = S->ied - S->isd + 1, nJ = S->JedB - S->JsdB + 1; return (c - S->isd) + ni*((A - S->JsdB) + nJ*(long)(k-1)); }
+  const long nI = S->IedB - S->IsdB + 1, nj = S->jed - S->jsd + 1;
+  return (A - S->IsdB) + nI*((c - S->jsd) + nj*(long)(k-1));
+}
+
+int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *OBC, double gamma_uv, double rx_max, double *rx_normal,
+                                  double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old, double dt)
+{
+  if (!OBC) return 0;
+  if (!(OBC->open_u_BCs_exist_globally || OBC->open_v_BCs_exist_globally)) return 0;      /* :2242 */
+  const int nz = G->nk;
+  const double gamma_u = gamma_uv;
+  for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->on_pe) continue;
+    if (S->oblique || S->radiation_tan_or_grad) return 2;
+    if ((S->radiation || S->gradient) && !S->normal_vel) return 3;
+    if (S->radiation && gamma_u < 1.0 && !(S->is_E_or_W ? rx_normal : ry_normal)) return 3;
+    if ((S->radiation && S->nudged) && !S->nudged_normal_vel) return 3;
+    const int ew = S->direction == MOM6HIP_OBC_DIRECTION_E || S->direction == MOM6HIP_OBC_DIRECTION_W;
+    const int plus = S->direction == MOM6HIP_OBC_DIRECTION_E || S->direction == MOM6HIP_OBC_DIRECTION_N;      /* inside = towards smaller indices */
+    const int A = ew ? S->IsdB : S->JsdB, c0 = ew ? S->jsd : S->isd, c1 = ew ? S->jed : S->ied;
+    if (ew) { if (plus ? (A < G->isc-1) : (A > G->iec)) continue; }      /* I < IscB, I > IecB :2329, :2573 */
+    else    { if (plus ? (A < G->jsc-1) : (A > G->jec)) continue; }
+    const int d1 = plus ? -1 : 1, d2 = plus ? -2 : 2;                   /* the two faces inside the boundary */
+    double *xn = ew ? u_new : v_new, *r_normal = ew ? rx_normal : ry_normal;
+    const double *xo = ew ? u_old : v_old;
+#define F3(a,c,k) (ew ? ORC_U3(G,a,c,k) : ORC_V3(G,c,a,k))
+    for (int k = 1; k <= nz; k++) for (int c = c0; c <= c1; c++) {
+      double dhdt = 0.0, dhdx = 0.0;
+      double *nv = &S->normal_vel[seg_idx(S, ew, A, c, k)];
+      if (S->radiation) {
+        dhdt = (xo[F3(A+d1,c,k)] - xn[F3(A+d1,c,k)]);
+        dhdx = (xn[F3(A+d1,c,k)] - xn[F3(A+d2,c,k)]);
+        double rx_new = 0.0, rx_avg;
+        if (dhdt*dhdx > 0.0) rx_new = min2( (dhdt/dhdx), rx_max);
+        if (gamma_u < 1.0) rx_avg = (1.0-gamma_u)*r_normal[F3(A,c,k)] + gamma_u*rx_new;      /* segment%rx_norm_rad = OBC%rx_normal :2250-2262 */
+        else rx_avg = rx_new;
+        *nv = (xn[F3(A,c,k)] + rx_avg*xn[F3(A+d1,c,k)]) / (1.0+rx_avg);
+        if (gamma_u < 1.0) r_normal[F3(A,c,k)] = rx_avg;
+      } else if (S->gradient) {
+        *nv = xn[F3(A+d1,c,k)];
+      }
+      if (S->radiation && S->nudged) {
+        const double tau = (dhdt*dhdx <= 0.0) ? S->Velocity_nudging_timescale_in : S->Velocity_nudging_timescale_out;
+        const double gamma_2 = dt / (tau + dt);
+        *nv = (1.0 - gamma_2) * *nv + gamma_2 * S->nudged_normal_vel[seg_idx(S, ew, A, c, k)];
+      }
+    }
+  }
+  /* open_boundary_apply_normal_flow :3337 */
+  for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->on_pe) continue;
+    if (!(S->radiation || S->oblique || S->gradient)) continue;
+    const int ew = S->is_E_or_W != 0;
+    if (!ew && !S->is_N_or_S) continue;
+    const int A = ew ? S->IsdB : S->JsdB, c0 = ew ? S->jsd : S->isd, c1 = ew ? S->jed : S->ied;
+    double *xn = ew ? u_new : v_new;
+    for (int k = 1; k <= nz; k++) for (int c = c0; c <= c1; c++) xn[F3(A,c,k)] = S->normal_vel[seg_idx(S, ew, A, c, k)];
+  }
+#undef F3
+  orc_halo_update(G, u_new, MOM6HIP_POS_U, nz); orc_halo_update(G, v_new, MOM6HIP_POS_V, nz);      /* pass_vector(u_new, v_new) :3309 */
+  return 0;
+}
+
+int orc_open_boundary_zero_normal_flow(const mom6hip_grid_t *G, const mom6hip_obc_t *OBC, double *u, double *v)
+{
+  if (!OBC) return 0;
+  for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->on_pe) continue;
+    if (S->is_E_or_W) { for (int k = 1; k <= G->nk; k++) for (int j = S->jsd; j <= S->jed; j++) u[ORC_U3(G,S->IsdB,j,k)] = 0.; }
+    else if (S->is_N_or_S) { for (int k = 1; k <= G->nk; k++) for (int i = S->isd; i <= S->ied; i++) v[ORC_V3(G,i,S->JsdB,k)] = 0.; }
+  }
+  return 0;
+}

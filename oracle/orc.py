@@ -313,6 +313,25 @@ def continuity(grid, cs, u, v, hin, h, uh, vh, dt, uhbt=None, vhbt=None, visc_re
                            "in call to continuity_PPM.")
 
 
+def radiation_open_bdry_conds(grid, OBC, u_new, u_old, v_new, v_old, dt, gamma_uv=0.3, rx_max=1.0, rx_normal=None, ry_normal=None):
+    """radiation_open_bdry_conds (the normal component) + apply_normal_flow + the halo update; u_new, v_new, the segments' normal_vel and
+    rx_normal / ry_normal are updated in place (OBC_RAD_VEL_WT = 0.3 and OBC_RADIATION_MAX = 1.0 are the reference's defaults)"""
+    L = lib()
+    L.orc_radiation_open_bdry_conds.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.Obc), C.c_double, C.c_double] + [_dp] * 6 + [C.c_double]
+    obc = OBC.struct()
+    rc = L.orc_radiation_open_bdry_conds(C.byref(grid.struct()), C.byref(obc), float(gamma_uv), float(rx_max), _p(rx_normal), _p(ry_normal), _p(u_new),
+                                         _p(u_old), _p(v_new), _p(v_old), float(dt))
+    if rc:
+        raise RuntimeError(f"orc_radiation_open_bdry_conds rc={rc}")
+
+
+def open_boundary_zero_normal_flow(grid, OBC, u, v):
+    L = lib()
+    L.orc_open_boundary_zero_normal_flow.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.Obc), _dp, _dp]
+    obc = OBC.struct()
+    L.orc_open_boundary_zero_normal_flow(C.byref(grid.struct()), C.byref(obc), _p(u), _p(v))
+
+
 def eos(form="WRIGHT", Rho_T0_S0=1000.0, dRho_dT=-0.2, dRho_dS=0.8):
     return _abi.EOS(_abi.EOS_FORMS[form], 0, Rho_T0_S0, dRho_dT, dRho_dS)
 

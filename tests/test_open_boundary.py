@@ -1,0 +1,182 @@
+"""radiation_open_bdry_conds for the normal component (src/core/MOM_open_boundary.F90:2196: Orlanski radiation, the gradient condition,
+nudging), open_boundary_apply_normal_flow (:3337) and open_boundary_zero_normal_flow (:3374): the oracle against what the routines state
+and against a quarter turn of the grid (the reference writes E, W, N, S out separately), on the CPU; the library against the oracle on the
+GPU, bit for bit.  (The reference holds no known-answer vectors: parity unpinned.)"""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi, synth
+from mom6_amd.open_boundary import ocean_OBC_type
+from oracle import orc
+from rotation import rot_vector, rotate_grid, unrot_vector
+from test_continuity_obc import TC3, open_faces, turned_segments
+
+SEGS = TC3 + ["I=9,J=4:11,ORLANSKI", "J=7,I=15:3,GRADIENT", "I=14,J=12:2,ORLANSKI,NUDGED"]
+
+
+def rad_case(segs=SEGS, ni=22, nj=16, nk=3, seed=8, reentrant=(False, False)):
+    g = synth.make_grid(ni, nj, nk, seed=seed + 50, reentrant_x=reentrant[0], reentrant_y=reentrant[1], land_frac=0.1)
+    OBC = ocean_OBC_type(g, segs)
+    open_faces(g, OBC)
+    st = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed).items()}
+    rng = np.random.default_rng(seed)
+    d = dict(u_old=np.ascontiguousarray(st["u"] + 0.05 * rng.standard_normal(st["u"].shape)),
+             v_old=np.ascontiguousarray(st["v"] + 0.05 * rng.standard_normal(st["v"].shape)))
+    d["u_new"] = np.ascontiguousarray(d["u_old"] + 0.03 * rng.standard_normal(st["u"].shape))
+    d["v_new"] = np.ascontiguousarray(d["v_old"] + 0.03 * rng.standard_normal(st["v"].shape))
+    d["rx"] = np.ascontiguousarray(0.5 * rng.random(st["u"].shape)); d["ry"] = np.ascontiguousarray(0.5 * rng.random(st["v"].shape))
+    for s in OBC.segment:
+        if s.on_pe and s.nudged:
+            s.nudged_normal_vel[:] = 0.2 * rng.standard_normal(s.nudged_normal_vel.shape)
+            s.Velocity_nudging_timescale_in, s.Velocity_nudging_timescale_out = 3600.0, 86400.0
+    return g, d, OBC
+
+
+def run(g, d, OBC, gamma_uv=0.3, rx_max=1.0, dt=900.0):
+    o = {k: v.copy() for k, v in d.items()}
+    orc.radiation_open_bdry_conds(g, OBC, o["u_new"], o["u_old"], o["v_new"], o["v_old"], dt, gamma_uv=gamma_uv, rx_max=rx_max,
+                                  rx_normal=o["rx"], ry_normal=o["ry"])
+    o["normal_vel"] = [None if s.normal_vel is None else s.normal_vel.copy() for s in OBC.segment]
+    return o
+
+
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+def test_what_the_branches_state(gamma_uv):
+    g, d, OBC = rad_case()
+    o = run(g, d, OBC, gamma_uv=gamma_uv)
+    touched_u = np.zeros(g.shape2(_abi.POS_U), dtype=bool); touched_v = np.zeros(g.shape2(_abi.POS_V), dtype=bool)
+    for n, s in enumerate(OBC.segment):
+        H = s.HI
+        if s.is_E_or_W:
+            I = H["IsdB"] - (g.isd - 1); jj = slice(H["jsd"] - g.jsd, H["jed"] - g.jsd + 1)
+            d1 = -1 if s.direction == _abi.OBC_DIRECTION_E else 1
+            touched_u[jj, I] = True
+            if n == len(OBC.segment) - 1 or not s.nudged:      # (later segments may overwrite shared faces: none here)
+                pass
+            un = d["u_new"]
+            if s.gradient:
+                assert bits_equal(o["u_new"][:, jj, I], un[:, jj, I + d1])
+            elif s.radiation and not s.nudged:
+                dhdt = d["u_old"][:, jj, I + d1] - un[:, jj, I + d1]; dhdx = un[:, jj, I + d1] - un[:, jj, I + 2 * d1]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    rx_new = np.where(dhdt * dhdx > 0.0, np.minimum(dhdt / dhdx, 1.0), 0.0)
+                rx_avg = (1.0 - gamma_uv) * d["rx"][:, jj, I] + gamma_uv * rx_new if gamma_uv < 1.0 else rx_new
+                assert bits_equal(o["u_new"][:, jj, I], (un[:, jj, I] + rx_avg * un[:, jj, I + d1]) / (1.0 + rx_avg))
+                if gamma_uv < 1.0:
+                    assert bits_equal(o["rx"][:, jj, I], rx_avg)
+                assert (rx_new >= 0.0).all() and (rx_new <= 1.0).all() and (rx_new > 0).any() and (rx_new == 0).any()
+        else:
+            J = H["JsdB"] - (g.jsd - 1); ii = slice(H["isd"] - g.isd, H["ied"] - g.isd + 1)
+            touched_v[J, ii] = True
+            if s.gradient:
+                d1 = -1 if s.direction == _abi.OBC_DIRECTION_N else 1
+                assert bits_equal(o["v_new"][:, J, ii], d["v_new"][:, J + d1, ii])
+    # nothing but the segments' faces changes (the domain is closed: the halo update moves nothing)
+    assert bits_equal(np.where(touched_u[None], 0.0, o["u_new"]), np.where(touched_u[None], 0.0, d["u_new"]))
+    assert bits_equal(np.where(touched_v[None], 0.0, o["v_new"]), np.where(touched_v[None], 0.0, d["v_new"]))
+    if gamma_uv >= 1.0:
+        assert bits_equal(o["rx"], d["rx"]) and bits_equal(o["ry"], d["ry"])
+
+
+def test_zero_normal_flow():
+    g, d, OBC = rad_case()
+    u, v = d["u_new"].copy(), d["v_new"].copy()
+    orc.open_boundary_zero_normal_flow(g, OBC, u, v)
+    su = np.zeros(g.shape2(_abi.POS_U), dtype=bool); sv = np.zeros(g.shape2(_abi.POS_V), dtype=bool)
+    for s in OBC.segment:
+        H = s.HI
+        if s.is_E_or_W:
+            su[H["jsd"] - g.jsd:H["jed"] - g.jsd + 1, H["IsdB"] - (g.isd - 1)] = True
+        else:
+            sv[H["JsdB"] - (g.jsd - 1), H["isd"] - g.isd:H["ied"] - g.isd + 1] = True
+    assert not u[:, su].any() and not v[:, sv].any()
+    assert bits_equal(u[:, ~su], d["u_new"][:, ~su]) and bits_equal(v[:, ~sv], d["v_new"][:, ~sv])
+
+
+def test_oracle_turns_with_the_grid():
+    g, d, OBC = rad_case()
+    o = run(g, d, OBC)
+    gr = rotate_grid(g)
+    OBCr = ocean_OBC_type(gr, turned_segments(SEGS, g.ni, g.nj))
+    for s, sr in zip(OBC.segment, OBCr.segment):
+        sr.Velocity_nudging_timescale_in, sr.Velocity_nudging_timescale_out = s.Velocity_nudging_timescale_in, s.Velocity_nudging_timescale_out
+        if s.on_pe and s.nudged:      # u (nk, j, 1) -> v' = -u at i' = j ; v (nk, 1, i) -> u' = v at j' = ni - 1 - i
+            sr.nudged_normal_vel[:] = -np.swapaxes(s.nudged_normal_vel, 1, 2) if s.is_E_or_W else np.swapaxes(s.nudged_normal_vel, 1, 2)[:, ::-1, :]
+    dr = {}
+    dr["u_new"], dr["v_new"] = rot_vector(d["u_new"], d["v_new"]); dr["u_old"], dr["v_old"] = rot_vector(d["u_old"], d["v_old"])
+    # the phase speeds are ratios of two differences of the same component: no sign; rx at u faces becomes ry' at v' faces and back
+    from rotation import rot, unrot
+    dr["rx"], dr["ry"] = rot(d["ry"]), rot(d["rx"])
+    orr = run(gr, dr, OBCr)
+    bu, bv = unrot_vector(orr["u_new"], orr["v_new"])
+    assert np.array_equal(interior(g, bu, _abi.POS_U), interior(g, o["u_new"], _abi.POS_U))
+    assert np.array_equal(interior(g, bv, _abi.POS_V), interior(g, o["v_new"], _abi.POS_V))
+    assert np.array_equal(interior(g, unrot(orr["ry"]), _abi.POS_U), interior(g, o["rx"], _abi.POS_U))
+    assert np.array_equal(interior(g, unrot(orr["rx"]), _abi.POS_V), interior(g, o["ry"], _abi.POS_V))
+
+
+def test_refused_forms():
+    g, d, _ = rad_case()
+    for bad in (["I=N,J=0:N,OBLIQUE"], ["I=N,J=0:N,ORLANSKI,ORLANSKI_TAN"]):
+        OBC = ocean_OBC_type(g, bad)
+        with pytest.raises(RuntimeError, match="rc=2"):
+            run(g, d, OBC)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+@pytest.mark.parametrize("reentrant", [(False, False), (True, False)])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_radiation_matches_oracle_bitwise(gamma_uv, reentrant, space):
+    import torch
+    from mom6_amd.open_boundary import open_boundary_zero_normal_flow, radiation_open_bdry_conds
+    from mom6_amd.tracer_advect import DeviceGrid
+    segs = SEGS if not reentrant[0] else ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "I=9,J=4:11,ORLANSKI", "J=7,I=15:3,GRADIENT",
+                                           "I=14,J=12:2,ORLANSKI,NUDGED"]
+    g, d, OBC = rad_case(segs, reentrant=reentrant)
+    OBC.gamma_uv = gamma_uv
+    want = run(g, d, OBC, gamma_uv=gamma_uv)
+    g2, d2, OBC2 = rad_case(segs, reentrant=reentrant)      # (the oracle wrote into the first set's segments)
+    OBC2.gamma_uv = gamma_uv
+    dg = DeviceGrid(g2)
+    put = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if space == "device" else (lambda a: np.ascontiguousarray(a).copy())
+    get = (lambda a: a.cpu().numpy()) if space == "device" else (lambda a: a)
+    o = {k: put(v) for k, v in d2.items()}
+    OBC2.rx_normal, OBC2.ry_normal = (o["rx"], o["ry"]) if gamma_uv < 1.0 else (None, None)
+    for s in OBC2.segment:
+        if s.on_pe:
+            s.normal_vel = put(s.normal_vel); s.nudged_normal_vel = put(s.nudged_normal_vel)
+    radiation_open_bdry_conds(OBC2, o["u_new"], o["u_old"], o["v_new"], o["v_old"], dg, 900.0)
+    dg.sync()
+    assert bits_equal(get(o["u_new"]), want["u_new"]) and bits_equal(get(o["v_new"]), want["v_new"])      # (the halos as well: the pass is part of it)
+    assert bits_equal(get(o["rx"]), want["rx"]) and bits_equal(get(o["ry"]), want["ry"])
+    for s, w in zip(OBC2.segment, want["normal_vel"]):
+        if s.on_pe and (s.radiation or s.gradient):
+            assert bits_equal(get(s.normal_vel), w)
+    u, v = put(d2["u_new"]), put(d2["v_new"])
+    open_boundary_zero_normal_flow(OBC2, dg, u, v)
+    dg.sync()
+    uw, vw = d2["u_new"].copy(), d2["v_new"].copy()
+    orc.open_boundary_zero_normal_flow(g, OBC, uw, vw)
+    assert bits_equal(get(u), uw) and bits_equal(get(v), vw)
+    dg.close()
+
+
+@pytest.mark.gpu
+def test_gpu_radiation_refuses_what_it_does_not_provide():
+    import torch
+    from mom6_amd._lib import Mom6HipError
+    from mom6_amd.open_boundary import radiation_open_bdry_conds
+    from mom6_amd.tracer_advect import DeviceGrid
+    g, d, _ = rad_case()
+    dg = DeviceGrid(g)
+    o = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    for bad, msg in ((["I=N,J=0:N,OBLIQUE"], "oblique"), (["I=N,J=0:N,ORLANSKI,ORLANSKI_TAN"], "tangential")):
+        OBC = ocean_OBC_type(g, bad)
+        OBC.rx_normal, OBC.ry_normal = o["rx"], o["ry"]
+        for s in OBC.segment:
+            s.normal_vel = torch.from_numpy(s.normal_vel).cuda()
+        with pytest.raises(Mom6HipError, match=msg):
+            radiation_open_bdry_conds(OBC, o["u_new"], o["u_old"], o["v_new"], o["v_old"], dg, 900.0)
+    dg.close()
