@@ -518,8 +518,9 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 
 /*
  * Open boundaries (src/core/MOM_open_boundary.F90): what continuity_PPM reads of ocean_OBC_type (:266-386) and of its segments
- * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc) and of CorAdCalc
- * (mom6hip_coradcalc_obc); every other entry point of the library still requires that OBC is not associated, so a configuration
+ * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc), of CorAdCalc
+ * (mom6hip_coradcalc_obc), of vertvisc_coef / vertvisc (mom6hip_vertvisc_coef_obc, mom6hip_vertvisc_obc), and radiation_open_bdry_conds
+ * / open_boundary_zero_normal_flow for the normal component; every other entry point of the library still requires that OBC is not associated, so a configuration
  * with open boundaries cannot be stepped yet.
  * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */
@@ -818,6 +819,17 @@ int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, const d
 int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *taux,
                      const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
                      int32_t memspace);
+
+/* vertvisc_coef and vertvisc with OBC associated.  vertvisc_coef: at the faces of the open-boundary segments the thicknesses, the
+ * depth, visc%Kv_shear and ustar of the cell inside the boundary replace the two-cell means (:1335-1355, :1546-1566, :1901-1925,
+ * :2061-2110).  vertvisc: the normal_vel of the specified segments is stored over the result (:988-1006).  obc == NULL: the entries
+ * above.  (mom6hip_vertvisc_step and mom6hip_vertvisc_and_remnant have no OBC form: call the separate entries.) */
+int mom6hip_vertvisc_coef_obc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, const double *u, const double *v, const double *h,
+                              const double *dz, const mom6hip_vertvisc_type_t *visc, double dt, const struct mom6hip_obc *obc,
+                              int32_t memspace);
+int mom6hip_vertvisc_obc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *taux,
+                         const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
+                         const struct mom6hip_obc *obc, int32_t memspace);
 
 /* vertvisc followed by vertvisc_remnant with the same dt -- the pair the split RK2 step calls at :731-744 and :985-994 --
  * in one pass over the coupling coefficients; the results are those of the two calls. */

@@ -225,6 +225,10 @@ struct VelIncrement { const double *u0, *v0, *a1u, *a1v, *a2u, *a2v; double dtv;
 int vertvisc_step_inc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *dz,
                       const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, int32_t update_velocities,
                       double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v, const VelIncrement *inc, int32_t memspace);
+// open boundaries (open_boundary.hip): the side maps of the zero-gradient projections, and the store of the specified segments' velocities
+class Stager;
+int obc_side_maps(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_obc_t *obc, const int32_t **side_u, const int32_t **side_v, const char *who);
+int obc_store_specified(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_obc_t *obc, double *d_u, double *d_v, const char *who);
 // set_viscous_ML on device arrays (set_viscosity.hip); called by the split RK2 step at :592
 int set_viscous_ML_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
                        const double *T, const double *S, const mom6hip_eos_t *eos, const double *taux, const double *tauy,

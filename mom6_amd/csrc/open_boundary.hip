@@ -91,6 +91,55 @@ int check_segment_range(const m6::GridDev &g, const mom6hip_obc_segment_t &S, in
 
 }  // namespace
 
+// Per face of the u and v grids, the cell an open-boundary face takes its cell-centred fields from (the zero-gradient
+// projections of vertvisc_coef, set_viscous_BBL, ...): -1 the first cell (OBC_DIRECTION_E | N), +1 the second (W | S), 0 elsewhere.
+// From OBC%segnum_u / segnum_v and the segments' directions; device arrays that live as long as `st`.  null maps: no segments.
+int m6::obc_side_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, const int32_t **side_u, const int32_t **side_v,
+                      const char *who) {
+  *side_u = *side_v = nullptr;
+  if (!obc || obc->number_of_segments <= 0) return 0;
+  M6_REQUIRE(obc->segment && obc->segnum_u && obc->segnum_v, "%s: OBC%%segment, segnum_u and segnum_v are required", who);
+  const m6::GridDev g = ctx->g;
+  const size_t nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1);
+  std::vector<int32_t> m(nU2 + nV2, 0);
+  for (int d = 0; d < 2; d++) {
+    const int32_t *segnum = d ? obc->segnum_v : obc->segnum_u;
+    int32_t *o = m.data() + (d ? nU2 : 0);
+    for (size_t n = 0; n < (d ? nV2 : nU2); n++) {
+      const int l = segnum[n];
+      if (l == MOM6HIP_OBC_NONE) continue;
+      M6_REQUIRE(l >= 1 && l <= obc->number_of_segments, "%s: OBC%%segnum_%c holds %d, with %d segments", who, d ? 'v' : 'u', l, obc->number_of_segments);
+      const int dir = obc->segment[l - 1].direction;
+      if (dir == (d ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E)) o[n] = -1;
+      else if (dir == (d ? MOM6HIP_OBC_DIRECTION_S : MOM6HIP_OBC_DIRECTION_W)) o[n] = 1;
+    }
+  }
+  int32_t *dm = (int32_t *)st.scratch(4 * (nU2 + nV2));
+  M6_REQUIRE(!st.failed() && dm, "%s: staging of the open boundaries failed", who);
+  M6_HIP(hipMemcpyAsync(dm, m.data(), 4 * (nU2 + nV2), hipMemcpyHostToDevice, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));      // (the host vector goes out of scope)
+  *side_u = dm; *side_v = dm + nU2;
+  return 0;
+}
+
+// u, v (device) = the normal_vel of the specified segments on their faces: the loop that ends vertvisc (MOM_vert_friction.F90:988-1006)
+int m6::obc_store_specified(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, double *d_u, double *d_v, const char *who) {
+  if (!obc) return 0;
+  const m6::GridDev g = ctx->g;
+  for (int n = 0; n < obc->number_of_segments; n++) {
+    const mom6hip_obc_segment_t &S = obc->segment[n];
+    RadSeg d;
+    if (!S.specified || !rad_segment(g, S, d)) continue;
+    if (check_segment_range(g, S, n, who)) return 1;
+    M6_REQUIRE(S.normal_vel, "%s: segment %d is specified: normal_vel is required", who, n + 1);
+    d.normal_vel = (double *)st.in(S.normal_vel, (size_t)d.nA * d.nc * g.nk * 8);
+    M6_REQUIRE(!st.failed() && d.normal_vel, "%s: staging failed", who);
+    hipLaunchKernelGGL(obc_face_store_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, ctx->stream, g, d, d.ew ? d_u : d_v, 1);
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6hip_obc_t *obc, double gamma_uv, double rx_max, double *rx_normal,
                                                  double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old,
                                                  double dt, int32_t memspace) {

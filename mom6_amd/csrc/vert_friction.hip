@@ -46,6 +46,9 @@ struct CoefArgs {
   const double *f_u0, *f_a1, *f_a2;
   double f_dt;
   double *f_store;
+  // open boundaries (the OBC instantiation only): per face, the cell the thicknesses, the depth, Kv_shear and ustar are projected
+  // outward from, -1 the first (OBC_DIRECTION_E | N), +1 the second (W | S), 0 not on a segment (m6::obc_side_maps)
+  const int32_t *side;
 };
 
 // the velocity of layer k of the face column at f2: read, or formed from the step's increment (the reference's expression)
@@ -56,7 +59,7 @@ __device__ __forceinline__ double coef_vel(const CoefArgs &A, long n, double mas
 }
 
 // vertvisc_coef + find_coupling_coef for the face column (i, j); the caller has checked do_i
-template <int DIR>
+template <int DIR, bool OBC = false>
 __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   const m6::GridDev &g = A.g;
   const VVPar &P = A.p;
@@ -77,6 +80,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   const double hn = dz_neglect, I_amax = 0.0;                        // find_coupling_coef :1846, :1858
   const double fmask = A.f_u0 ? (DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) : 0.0;
   auto DZ = [&](long c, int k) { return A.dz ? A.dz[c + hpl * k] : g.H_to_Z * A.h[c + hpl * k]; };
+  const int side = OBC ? A.side[f2] : 0;      // :1335-1355 / :1546-1566 (zi_dir)
 
   // ---- KV_ML_INVZ2: the top-down viscosity profile :1873-1886, parked in a(K) ----
   const bool kvml = P.Kvml_invZ2 > 0.0;
@@ -96,7 +100,8 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
         const int K = Kb + q;
         if (K >= nz) break;
         const double d0 = b_d0[q], d1 = b_d1[q];
-        const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+        double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+        if (OBC && side) dz_harm = (side < 0) ? d0 : d1;
         z_t = z_t + dz_harm * I_Hmix;
         A.a[f2 + fpl * K] = P.Kv + P.Kvml_invZ2 / ((z_t * z_t) * (1.0 + 0.09 * z_t * z_t * z_t * z_t * z_t * z_t));
       }
@@ -104,7 +109,8 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   }
 
   // ---- the bottom-up sweep ----
-  const double Dmin = min2(g.bathyT[c0], g.bathyT[c1]);              // :1331
+  double Dmin = min2(g.bathyT[c0], g.bathyT[c1]);                    // :1331
+  if (OBC && side) Dmin = (side < 0) ? g.bathyT[c0] : g.bathyT[c1];    // :1342, :1349
   double zh = 0.0, zcol0 = -g.bathyT[c0], zcol1 = -g.bathyT[c1];
   double z_i_below = 0.0;        // z_i(k+1)
   double dzv_below = 0.0;        // dz_vel(k+1)
@@ -122,7 +128,10 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
         b_vel[q] = coef_vel(A, f2 + fpl * k, fmask);
         if (k + 1 < nz) {
           if (kvml) b_kvml[q] = A.a[f2 + fpl * (k + 1)];
-          if (A.Kv_shear) b_ksh[q] = 0.5 * (A.Kv_shear[c0 + hpl * (k + 1)] + A.Kv_shear[c1 + hpl * (k + 1)]);
+          if (A.Kv_shear) {
+            b_ksh[q] = 0.5 * (A.Kv_shear[c0 + hpl * (k + 1)] + A.Kv_shear[c1 + hpl * (k + 1)]);
+            if (OBC && side) b_ksh[q] = A.Kv_shear[((side < 0) ? c0 : c1) + hpl * (k + 1)];      // :1901-1909, :1917-1925
+          }
         }
       }
     }
@@ -131,12 +140,17 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
     const int k = kb - q;
     if (k < 0) break;
     const double h0 = b_h0[q], h1 = b_h1[q];
-    const double h_harm = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);      // :1324-1330
-    const double h_arith = 0.5 * (h1 + h0);
-    const double h_delta = h1 - h0;
+    double h_harm = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);            // :1324-1330
+    double h_arith = 0.5 * (h1 + h0);
+    double h_delta = h1 - h0;
     const double d0 = A.dz ? b_d0[q] : g.H_to_Z * h0, d1 = A.dz ? b_d1[q] : g.H_to_Z * h1;
-    const double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
-    const double dz_arith = 0.5 * (d1 + d0);
+    double dz_harm = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
+    double dz_arith = 0.5 * (d1 + d0);
+    if (OBC && side) {                                               // :1338-1341, :1345-1348
+      const double hs = (side < 0) ? h0 : h1, ds = (side < 0) ? d0 : d1;
+      h_harm = hs; h_arith = hs; h_delta = 0.;
+      dz_harm = ds; dz_arith = ds;
+    }
     const double vel = b_vel[q];
     double hvel, dz_vel, z_i;
     if (P.harmonic_visc) {                                           // :1363-1375
@@ -150,7 +164,9 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
     } else {                                                         // :1376-1408
       zcol0 = zcol0 + d0; zcol1 = zcol1 + d1;
       zh = zh + dz_harm;
-      const double z_clear = max2(zcol0, zcol1) + Dmin;
+      double z_clear = max2(zcol0, zcol1) + Dmin;
+      if (OBC && side < 0) z_clear = zcol0 + Dmin;                   // :1381-1382
+      if (OBC && side > 0) z_clear = zcol1 + Dmin;
       z_i = max2(zh, z_clear) * I_Hbbl;
       hvel = h_arith; dz_vel = dz_arith;
       if (vel * h_delta > 0) {
@@ -215,7 +231,8 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   A.a[f2] = min2(a_cpl_max, 0.0 + 0.0);                               // a_cpl(:,1) = 0 (the boundary-layer scheme starts at K = 2)
   // ---- the surface boundary layer :2047-2252 (no LOTW floor; Boussinesq): top-down over the few layers in it ----
   if (A.dzv) {
-    const double u_star = 0.5 * (A.ustar[c0] + A.ustar[c1]);          // :2098-2112 (find_ustar: forces%ustar)
+    double u_star = 0.5 * (A.ustar[c0] + A.ustar[c1]);                // :2098-2112 (find_ustar: forces%ustar)
+    if (OBC && side) u_star = A.ustar[(side < 0) ? c0 : c1];
     const double absf = DIR ? 0.5 * (fabs(g.CoriolisBu[g.q2(i - 1, j)]) + fabs(g.CoriolisBu[g.q2(i, j)]))
                             : 0.5 * (fabs(g.CoriolisBu[g.q2(i, j - 1)]) + fabs(g.CoriolisBu[g.q2(i, j)]));
     int nk_in_ml;
@@ -248,7 +265,7 @@ __device__ __forceinline__ void coef_column(const CoefArgs &A, int i, int j) {
   }
 }
 
-template <int DIR>
+template <int DIR, bool OBC>
 __global__ __launch_bounds__(64) void vv_coef_kernel(CoefArgs A) {
   const m6::GridDev &g = A.g;
   const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(64) void vv_coef_kernel(CoefArgs A) {
   if (i > g.iec) return;
   const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
   if (!((DIR ? g.mask2dCv[f2] : g.mask2dCu[f2]) > 0.0)) return;      // do_i
-  coef_column<DIR>(A, i, j);
+  coef_column<DIR, OBC>(A, i, j);
 }
 
 struct SolveArgs {
@@ -535,6 +552,14 @@ Sz sizes(const m6::GridDev &g) {
 extern "C" int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, const double *u, const double *v,
                                      const double *h, const double *dz, const mom6hip_vertvisc_type_t *visc, double dt,
                                      int32_t memspace) {
+  return mom6hip_vertvisc_coef_obc(ctx, cs, u, v, h, dz, visc, dt, nullptr, memspace);
+}
+
+// vertvisc_coef with OBC associated: at the faces of the open-boundary segments the thicknesses, the depth, Kv_shear and ustar are
+// those of the cell inside (:1335-1355, :1546-1566, :1901-1925, :2061-2110)
+extern "C" int mom6hip_vertvisc_coef_obc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, const double *u, const double *v,
+                                         const double *h, const double *dz, const mom6hip_vertvisc_type_t *visc, double dt,
+                                         const mom6hip_obc_t *obc, int32_t memspace) {
   (void)dt;
   M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(coef): Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && visc, "vertvisc_coef: null argument");
@@ -573,11 +598,18 @@ extern "C" int mom6hip_vertvisc_coef(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *
   A[0].a = st.inout(cs->a_u, sz.ui); A[1].a = st.inout(cs->a_v, sz.vi);
   A[0].hv = st.inout(cs->h_u, sz.u3); A[1].hv = st.inout(cs->h_v, sz.v3);
   M6_REQUIRE(!st.failed(), "vertvisc_coef: staging failed");
+  A[0].side = A[1].side = nullptr;
+  if (m6::obc_side_maps(ctx, st, obc, &A[0].side, &A[1].side, "vertvisc_coef")) return 1;
   for (int d = 0; d < 2; d++) {
     A[d].g = g; A[d].p = par_of(cs); A[d].h = dh; A[d].dz = ddz; A[d].Kv_shear = dks;
     const dim3 grid((g.iec - g.isc + 1 + (d ? 0 : 1) + 63) / 64, g.jec - g.jsc + 1 + (d ? 1 : 0));
-    if (d == 0) hipLaunchKernelGGL(vv_coef_kernel<0>, grid, dim3(64), 0, ctx->stream, A[d]);
-    else hipLaunchKernelGGL(vv_coef_kernel<1>, grid, dim3(64), 0, ctx->stream, A[d]);
+    if (A[d].side) {
+      if (d == 0) hipLaunchKernelGGL((vv_coef_kernel<0, true>), grid, dim3(64), 0, ctx->stream, A[d]);
+      else hipLaunchKernelGGL((vv_coef_kernel<1, true>), grid, dim3(64), 0, ctx->stream, A[d]);
+    } else {
+      if (d == 0) hipLaunchKernelGGL((vv_coef_kernel<0, false>), grid, dim3(64), 0, ctx->stream, A[d]);
+      else hipLaunchKernelGGL((vv_coef_kernel<1, false>), grid, dim3(64), 0, ctx->stream, A[d]);
+    }
   }
   M6_HIP(hipGetLastError());
   return st.finish();
@@ -627,7 +659,7 @@ int run_solve(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_vertvisc_cs_t *c
 
 int vertvisc_impl(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h, const double *taux,
                   const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
-                  double *visc_rem_u, double *visc_rem_v, int32_t memspace) {
+                  double *visc_rem_u, double *visc_rem_v, const mom6hip_obc_t *obc, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_vert_friction(visc): Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && taux && tauy && visc, "vertvisc: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "vertvisc: bad memspace");
@@ -649,6 +681,7 @@ int vertvisc_impl(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, doub
   double *tbot[2] = {st.inout(taux_bot, sz.u2), st.inout(tauy_bot, sz.v2)};      // (only the compute rows are written)
   M6_REQUIRE(!st.failed(), "vertvisc: staging failed");
   if (run_solve(ctx, st, cs, a, hv, Ray, dh, tau, x, xr, tbot, dt, true)) return 1;      // incl. vertvisc_limit_vel :986
+  if (m6::obc_store_specified(ctx, st, obc, x[0], x[1], "vertvisc")) return 1;           // :988-1006
   const int rc = st.finish();
   if (rc == 0 && memspace == MOM6HIP_MEM_HOST) return mom6hip_vertvisc_ntrunc(ctx, cs);
   return rc;
@@ -658,7 +691,14 @@ int vertvisc_impl(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, doub
 extern "C" int mom6hip_vertvisc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
                                 const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
                                 double *taux_bot, double *tauy_bot, int32_t memspace) {
-  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, nullptr, nullptr, memspace);
+  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, nullptr, nullptr, nullptr, memspace);
+}
+
+// vertvisc with OBC associated: the velocities of the specified segments are stored over the result (:988-1006)
+extern "C" int mom6hip_vertvisc_obc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, double *v, const double *h,
+                                    const double *taux, const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt,
+                                    double *taux_bot, double *tauy_bot, const mom6hip_obc_t *obc, int32_t memspace) {
+  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, nullptr, nullptr, obc, memspace);
 }
 
 // vertvisc followed by vertvisc_remnant with the same dt -- the pair step_MOM_dyn_split_RK2 calls at :731-744 and :985-994
@@ -668,7 +708,7 @@ extern "C" int mom6hip_vertvisc_and_remnant(mom6hip_ctx_t *ctx, mom6hip_vertvisc
                                             double *taux_bot, double *tauy_bot, double *visc_rem_u, double *visc_rem_v,
                                             int32_t memspace) {
   M6_REQUIRE(visc_rem_u && visc_rem_v, "vertvisc_and_remnant: null argument");
-  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, visc_rem_u, visc_rem_v, memspace);
+  return vertvisc_impl(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, visc_rem_u, visc_rem_v, nullptr, memspace);
 }
 
 // vertvisc_coef, then (update_velocities) vertvisc, then vertvisc_remnant, all with the same dt: the sequences of
@@ -745,7 +785,7 @@ int m6::vertvisc_step_inc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double 
     CoefArgs C;
     C.g = g; C.p = par_of(cs); C.vel = x[d]; C.h = dh; C.dz = ddz; C.kv_bbl = kvb[d]; C.bbl_thick = bth[d]; C.Kv_shear = dks;
     C.a = a[d]; C.hv = hv[d]; C.ustar = C.nkml_visc = nullptr; C.dzv = nullptr;
-    C.f_u0 = C.f_a1 = C.f_a2 = nullptr; C.f_dt = 0.0; C.f_store = nullptr;
+    C.f_u0 = C.f_a1 = C.f_a2 = nullptr; C.f_dt = 0.0; C.f_store = nullptr; C.side = nullptr;
     if (inc) {
       C.f_u0 = d ? inc->v0 : inc->u0; C.f_a1 = d ? inc->a1v : inc->a1u; C.f_a2 = d ? inc->a2v : inc->a2u; C.f_dt = inc->dtv;
       C.f_store = update_velocities ? x[d] : nullptr;

@@ -12,7 +12,7 @@ module MOM_vert_friction
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_obc_to_c
 use MOM_diag_mediator,         only : diag_ctrl, time_type
 use MOM_error_handler,         only : MOM_error, FATAL, WARNING
 use MOM_file_parser,           only : get_param, log_version, param_file_type
@@ -108,11 +108,12 @@ subroutine vertvisc(u, v, h, forces, visc, dt, OBC, ADp, CDp, G, GV, US, CS, tau
   logical,         optional, intent(in)  :: fpmix
   type(wave_parameters_CS), optional, pointer :: Waves
   type(mom6hip_vertvisc_type_t) :: cv
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
   type(c_ptr) :: p_tx, p_ty
   integer :: rc
   if (.not.associated(CS)) call MOM_error(FATAL, "MOM_vert_friction(visc): Module must be initialized before it is used.")
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_vert_friction(visc): Module must be initialized before it is used.")
-  if (associated(OBC)) call MOM_error(FATAL, "vertvisc (HIP): open boundary conditions are not supported by the GPU path.")
   if (present(fpmix)) then ; if (fpmix) call MOM_error(FATAL, "vertvisc (HIP): FPMIX is not provided by the GPU path.") ; endif
   if (present(Waves)) then ; if (associated(Waves)) &
     call MOM_error(FATAL, "vertvisc (HIP): Stokes mixing (Waves) is not provided by the GPU path.") ; endif
@@ -121,8 +122,14 @@ subroutine vertvisc(u, v, h, forces, visc, dt, OBC, ADp, CDp, G, GV, US, CS, tau
   call bind_arrays(CS) ; call visc_struct(visc, cv)
   p_tx = c_null_ptr ; if (present(taux_bot)) p_tx = c_loc(taux_bot)
   p_ty = c_null_ptr ; if (present(tauy_bot)) p_ty = c_loc(tauy_bot)
-  rc = mom6hip_vertvisc(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(forces%taux), c_loc(forces%tauy), &
-                        cv, dt, p_tx, p_ty, MOM6HIP_MEM_HOST)
+  if (associated(OBC)) then      ! the velocities of the specified segments end the call (:988-1006)
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(u(:,:,1)), size(v(:,:,1)), "MOM_vert_friction")
+    rc = mom6hip_vertvisc_obc(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(forces%taux), &
+                              c_loc(forces%tauy), cv, dt, p_tx, p_ty, cobc, MOM6HIP_MEM_HOST)
+  else
+    rc = mom6hip_vertvisc(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(forces%taux), c_loc(forces%tauy), &
+                          cv, dt, p_tx, p_ty, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "vertvisc")
   if (associated(CS%ntrunc)) CS%ntrunc = int(CS%st%ntrunc)
 end subroutine vertvisc
@@ -163,17 +170,24 @@ subroutine vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, 
   type(ocean_OBC_type),    pointer       :: OBC
   type(VarMix_CS),         intent(in)    :: VarMix
   type(mom6hip_vertvisc_type_t) :: cv
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
   integer :: rc
   if (.not.associated(CS)) call MOM_error(FATAL, "MOM_vert_friction(coef): Module must be initialized before it is used.")
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_vert_friction(coef): Module must be initialized before it is used.")
-  if (associated(OBC)) call MOM_error(FATAL, "vertvisc_coef (HIP): open boundary conditions are not supported by the GPU path.")
   call bind_arrays(CS) ; call visc_struct(visc, cv)
   if (CS%st%dynamic_viscous_ML /= 0 .or. CS%st%nkml > 0) then      ! find_ustar(forces, tv, Ustar_2d, ...) :1296, Boussinesq
     if (.not.associated(forces%ustar)) call MOM_error(FATAL, "vertvisc_coef (HIP): DYNAMIC_VISCOUS_ML / a bulk mixed layer needs "// &
          "forces%ustar (the GPU path is Boussinesq: find_ustar returns forces%ustar).")
     cv%ustar = c_loc(forces%ustar)
   endif
-  rc = mom6hip_vertvisc_coef(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(dz), cv, dt, MOM6HIP_MEM_HOST)
+  if (associated(OBC)) then      ! the zero-gradient projections across the segments' faces (:1335-1355, :1546-1566, :1901-1925, :2061-2110)
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(u(:,:,1)), size(v(:,:,1)), "MOM_vert_friction")
+    rc = mom6hip_vertvisc_coef_obc(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(dz), cv, dt, cobc, &
+                                   MOM6HIP_MEM_HOST)
+  else
+    rc = mom6hip_vertvisc_coef(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(dz), cv, dt, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "vertvisc_coef")
 end subroutine vertvisc_coef
 

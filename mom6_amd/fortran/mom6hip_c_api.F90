@@ -800,6 +800,29 @@ interface
     integer(c_int) :: rc
   end function mom6hip_vertvisc
 
+  !> vertvisc_coef and vertvisc with OBC associated (the projections at the segments' faces; the specified segments' velocities)
+  function mom6hip_vertvisc_coef_obc(ctx, cs, u, v, h, dz, visc, dt, obc, memspace) bind(c, name="mom6hip_vertvisc_coef_obc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v, h, dz
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_coef_obc
+  function mom6hip_vertvisc_obc(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, obc, memspace) &
+                                bind(c, name="mom6hip_vertvisc_obc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_vertvisc_cs_t, mom6hip_vertvisc_type_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v, h, taux, tauy, taux_bot, tauy_bot
+    type(mom6hip_vertvisc_cs_t), intent(inout) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    real(c_double), value :: dt
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_vertvisc_obc
+
   !> vertvisc followed by vertvisc_remnant with the same dt, in one pass
   function mom6hip_vertvisc_and_remnant(ctx, cs, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, visc_rem_u, visc_rem_v, &
                                         memspace) bind(c, name="mom6hip_vertvisc_and_remnant") result(rc)

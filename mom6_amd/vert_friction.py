@@ -10,6 +10,7 @@ import numpy as np
 
 from . import _abi
 from ._lib import Mom6HipError, check, lib
+from .open_boundary import _seg_to_ptr
 from .tracer_advect import DeviceGrid, _ptr_space
 
 
@@ -19,6 +20,9 @@ def _setup():
         cs, vt = C.POINTER(_abi.VertviscCS), C.POINTER(_abi.VertviscType)
         L.mom6hip_vertvisc_coef.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 4 + [vt, C.c_double, C.c_int32]
         L.mom6hip_vertvisc.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [vt, C.c_double, C.c_void_p, C.c_void_p, C.c_int32]
+        L.mom6hip_vertvisc_coef_obc.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 4 + [vt, C.c_double, C.POINTER(_abi.Obc), C.c_int32]
+        L.mom6hip_vertvisc_obc.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 5 + [vt, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(_abi.Obc),
+                                            C.c_int32])
         L.mom6hip_vertvisc_remnant.argtypes = [C.c_void_p, cs, vt, C.c_void_p, C.c_void_p, C.c_double, C.c_int32]
         L.mom6hip_vertvisc_ntrunc.argtypes = [C.c_void_p, cs]
         L.mom6hip_vertvisc_and_remnant.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [vt, C.c_double] + [C.c_void_p] * 4 + [C.c_int32]
@@ -124,11 +128,14 @@ def vertvisc_coef(u, v, h, dz, forces, visc: vertvisc_type, tv, dt, G: DeviceGri
     thickness_to_dz.  forces and tv are only read by branches this build does not provide."""
     if CS is None:
         raise Mom6HipError("MOM_vert_friction(coef): Module must be initialized before it is used.")
-    if OBC is not None:
-        raise Mom6HipError("vertvisc_coef (HIP): open boundary conditions are not supported on this path")
     (pu, pv, ph, pdz), space = _space_of(CS, (u, v, h, dz), "vertvisc_coef")
     if visc.space not in (None, space):
         raise Mom6HipError("vertvisc_coef: visc must be in the same memory space as the fields")
+    if OBC is not None:      # an ocean_OBC_type (mom6_amd/open_boundary.py): the zero-gradient projections at the segments' faces
+        obc = OBC.struct(_seg_to_ptr(space))
+        check(_setup().mom6hip_vertvisc_coef_obc(G.handle, C.byref(CS.st), pu, pv, ph, pdz, C.byref(visc.st), float(dt), C.byref(obc), space),
+              "vertvisc_coef")
+        return
     check(_setup().mom6hip_vertvisc_coef(G.handle, C.byref(CS.st), pu, pv, ph, pdz, C.byref(visc.st), float(dt), space), "vertvisc_coef")
 
 
@@ -138,12 +145,17 @@ def vertvisc(u, v, h, forces, visc: vertvisc_type, dt, OBC, ADp, CDp, G: DeviceG
     forces = (taux, tauy); u, v are updated in place."""
     if CS is None:
         raise Mom6HipError("MOM_vert_friction(visc): Module must be initialized before it is used.")
-    if OBC is not None or Waves is not None or fpmix:
-        raise Mom6HipError("vertvisc (HIP): OBC, Waves and FPMIX are not supported on this path")
+    if Waves is not None or fpmix:
+        raise Mom6HipError("vertvisc (HIP): Waves and FPMIX are not supported on this path")
     taux, tauy = forces
     (pu, pv, ph, ptx, pty, pbx, pby), space = _space_of(CS, (u, v, h, taux, tauy, taux_bot, tauy_bot), "vertvisc")
     if visc.space not in (None, space):
         raise Mom6HipError("vertvisc: visc must be in the same memory space as the fields")
+    if OBC is not None:      # the velocities of the specified segments are stored over the result (:988-1006)
+        obc = OBC.struct(_seg_to_ptr(space))
+        check(_setup().mom6hip_vertvisc_obc(G.handle, C.byref(CS.st), pu, pv, ph, ptx, pty, C.byref(visc.st), float(dt), pbx, pby,
+                                            C.byref(obc), space), "vertvisc")
+        return
     check(_setup().mom6hip_vertvisc(G.handle, C.byref(CS.st), pu, pv, ph, ptx, pty, C.byref(visc.st), float(dt), pbx, pby, space),
           "vertvisc")
 

@@ -222,6 +222,12 @@ int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const 
                       const double *dz, const mom6hip_vertvisc_type_t *visc, double dt);
 int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, double *v, const double *h, const double *taux,
                  const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot);
+/* the two above with OBC associated (MOM_vert_friction.F90:1335-1355, :1546-1566, :1901-1925, :2061-2110; :988-1006) */
+int orc_vertvisc_coef_obc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const double *u, const double *v, const double *h,
+                          const double *dz, const mom6hip_vertvisc_type_t *visc, double dt, const mom6hip_obc_t *OBC);
+int orc_vertvisc_obc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, double *v, const double *h, const double *taux,
+                     const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
+                     const mom6hip_obc_t *OBC);
 int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
                          double *visc_rem_u, double *visc_rem_v, double dt);
 

@@ -789,17 +789,23 @@ def vertvisc_type(**arrays):
     return vt
 
 
-def vertvisc_coef(grid, cs, u, v, h, visc, dt, dz=None):
-    L = lib(); L.orc_vertvisc_coef.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS)] + [_dp] * 4 + [C.POINTER(_abi.VertviscType), C.c_double]
-    rc = L.orc_vertvisc_coef(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), None if dz is None else _p(dz), C.byref(visc), dt)
+def vertvisc_coef(grid, cs, u, v, h, visc, dt, dz=None, OBC=None):
+    L = lib(); L.orc_vertvisc_coef_obc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS)] + [_dp] * 4 + [C.POINTER(_abi.VertviscType), C.c_double,
+                                                                                                                    C.POINTER(_abi.Obc)]
+    obc = None if OBC is None else OBC.struct()
+    rc = L.orc_vertvisc_coef_obc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), None if dz is None else _p(dz), C.byref(visc), dt,
+                                 None if obc is None else C.byref(obc))
     if rc:
         raise RuntimeError(f"orc_vertvisc_coef rc={rc}")
 
 
-def vertvisc(grid, cs, u, v, h, taux, tauy, visc, dt, taux_bot=None, tauy_bot=None):
-    L = lib(); L.orc_vertvisc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS)] + [_dp] * 5 + [C.POINTER(_abi.VertviscType), C.c_double, _dp, _dp]
-    rc = L.orc_vertvisc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(taux), _p(tauy), C.byref(visc), dt,
-                        None if taux_bot is None else _p(taux_bot), None if tauy_bot is None else _p(tauy_bot))
+def vertvisc(grid, cs, u, v, h, taux, tauy, visc, dt, taux_bot=None, tauy_bot=None, OBC=None):
+    L = lib(); L.orc_vertvisc_obc.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.VertviscCS)] + [_dp] * 5
+                                             + [C.POINTER(_abi.VertviscType), C.c_double, _dp, _dp, C.POINTER(_abi.Obc)])
+    obc = None if OBC is None else OBC.struct()
+    rc = L.orc_vertvisc_obc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(taux), _p(tauy), C.byref(visc), dt,
+                            None if taux_bot is None else _p(taux_bot), None if tauy_bot is None else _p(tauy_bot),
+                            None if obc is None else C.byref(obc))
     if rc:
         raise RuntimeError(f"orc_vertvisc rc={rc}")
 

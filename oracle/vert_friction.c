@@ -22,11 +22,13 @@ static int unsupported(const mom6hip_vertvisc_cs_t *CS) {
 static int surface_bl(const mom6hip_vertvisc_cs_t *CS) { return CS->dynamic_viscous_ML || CS->nkml > 0; }
 
 /* one face column of vertvisc_coef + find_coupling_coef.  c0 / c1: 2-D offsets of the two cells; f2: of the face;
- * hpl / fpl: plane strides of h-point and face arrays. */
+ * hpl / fpl: plane strides of h-point and face arrays.  side: 0, or for a face of an open-boundary segment the cell the
+ * thicknesses, the depth, Kv_shear and ustar are projected outward from (:1335-1355 / :1546-1566, :1901-1925, :2061-2110):
+ * -1 the first cell (OBC_DIRECTION_E | N), +1 the second (OBC_DIRECTION_W | S). */
 static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS, const mom6hip_vertvisc_type_t *visc,
                         const double *vel, const double *h, const double *dz, long c0, long c1, long f2, long hpl, long fpl,
                         const double *kv_bbl_2d, const double *bbl_thick_2d, double *a_out, double *h_out, long qA, long qB,
-                        const double *nkml_visc_2d) {
+                        const double *nkml_visc_2d, int side) {
   const int nz = G->nk;
   const double h_neglect = G->H_subroundoff, dz_neglect = G->dZ_subroundoff;
   const double a_cpl_max = 1.0e37 * G->Z_to_H * 1.0;      /* 1.0e37 * GV%m_to_H * US%T_to_s :1283 */
@@ -50,8 +52,14 @@ static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS
     const double d0 = DZ(c0, k), d1 = DZ(c1, k);
     dz_harm[k] = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
     dz_arith[k] = 0.5 * (d1 + d0);
+    if (side) {      /* :1338-1341 / :1345-1348: a zero-gradient condition across the open boundary */
+      const double hs = (side < 0) ? h0 : h1, ds = (side < 0) ? d0 : d1;
+      h_harm[k] = hs; h_arith[k] = hs; h_delta[k] = 0.;
+      dz_harm[k] = ds; dz_arith[k] = ds;
+    }
   }
-  const double Dmin = min2(G->bathyT[c0], G->bathyT[c1]);      /* :1331 */
+  double Dmin = min2(G->bathyT[c0], G->bathyT[c1]);      /* :1331 */
+  if (side) Dmin = (side < 0) ? G->bathyT[c0] : G->bathyT[c1];      /* :1342, :1349; zi_dir = side */
   if (CS->harmonic_visc) {      /* :1363-1375 */
     z_i[nz] = 0.0;
     for (int k = nz - 1; k >= 0; k--) {
@@ -70,7 +78,9 @@ static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS
     for (int k = nz - 1; k >= 0; k--) {
       zcol0 = zcol0 + DZ(c0, k); zcol1 = zcol1 + DZ(c1, k);
       zh = zh + dz_harm[k];
-      const double z_clear = max2(zcol0, zcol1) + Dmin;
+      double z_clear = max2(zcol0, zcol1) + Dmin;
+      if (side < 0) z_clear = zcol0 + Dmin;      /* :1381-1382 */
+      if (side > 0) z_clear = zcol1 + Dmin;
       z_i[k] = max2(zh, z_clear) * I_Hbbl;
       hvel[k] = h_arith[k];
       dz_vel[k] = dz_arith[k];
@@ -107,7 +117,8 @@ static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS
     }
     if (visc->Kv_shear) {                             /* :1888-1928 */
       for (int K = 1; K < nz; K++) {
-        const double Kv_add = 0.5 * (visc->Kv_shear[c0 + hpl * K] + visc->Kv_shear[c1 + hpl * K]);
+        double Kv_add = 0.5 * (visc->Kv_shear[c0 + hpl * K] + visc->Kv_shear[c1 + hpl * K]);
+        if (side) Kv_add = visc->Kv_shear[((side < 0) ? c0 : c1) + hpl * K];      /* :1901-1909, :1917-1925 */
         Kv_tot[K] = Kv_tot[K] + Kv_add;
       }
     }
@@ -143,7 +154,8 @@ static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS
      * (GV%nkml > 0), without FIXED_DEPTH_LOTW_ML / LOTW_VISCOUS_ML_FLOOR; Boussinesq; hvel is dz_vel here */
     if (surface_bl(CS)) {
       /* :2098-2116: u_star = the mean of the two cells' (find_ustar: forces%ustar), absf from the two corners */
-      const double u_star = 0.5 * (visc->ustar[c0] + visc->ustar[c1]);
+      double u_star = 0.5 * (visc->ustar[c0] + visc->ustar[c1]);
+      if (side) u_star = visc->ustar[(side < 0) ? c0 : c1];      /* :2095-2110 */
       const double absf = 0.5 * (fabs(G->CoriolisBu[qA]) + fabs(G->CoriolisBu[qB]));
       int nk_in_ml = 0;
       double h_ml = hn;                       /* :2123 / :2163 */
@@ -175,9 +187,24 @@ static void coef_column(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *CS
   free(w);
 }
 
+/* the cell an open-boundary face projects from: the segment of OBC%segnum_u | segnum_v at the face, by its direction */
+static int obc_side(const mom6hip_obc_t *OBC, const int32_t *segnum, long f2) {
+  if (!OBC || OBC->number_of_segments <= 0 || segnum[f2] == MOM6HIP_OBC_NONE) return 0;
+  const int dir = OBC->segment[segnum[f2] - 1].direction;
+  if (dir == MOM6HIP_OBC_DIRECTION_E || dir == MOM6HIP_OBC_DIRECTION_N) return -1;
+  if (dir == MOM6HIP_OBC_DIRECTION_W || dir == MOM6HIP_OBC_DIRECTION_S) return 1;
+  return 0;
+}
+
 int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const double *u, const double *v, const double *h,
                       const double *dz, const mom6hip_vertvisc_type_t *visc, double dt) {
+  return orc_vertvisc_coef_obc(G, CS, u, v, h, dz, visc, dt, NULL);
+}
+
+int orc_vertvisc_coef_obc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const double *u, const double *v, const double *h,
+                          const double *dz, const mom6hip_vertvisc_type_t *visc, double dt, const mom6hip_obc_t *OBC) {
   (void)dt;
+  if (OBC && OBC->number_of_segments > 0 && !(OBC->segment && OBC->segnum_u && OBC->segnum_v)) return 1;
   if (unsupported(CS) || visc->Kv_shear_Bu) return 1;
   if (CS->bottomdraglaw && !(visc->Kv_bbl_u && visc->Kv_bbl_v && visc->bbl_thick_u && visc->bbl_thick_v)) return 1;
   if (surface_bl(CS) && !visc->ustar) return 1;
@@ -188,13 +215,15 @@ int orc_vertvisc_coef(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, const 
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
     if (!(G->mask2dCu[ORC_U2(G, I, j)] > 0.0)) continue;
     coef_column(G, CS, visc, u, h, dz, ORC_H2(G, I, j), ORC_H2(G, I + 1, j), ORC_U2(G, I, j), hpl, upl, visc->Kv_bbl_u,
-                visc->bbl_thick_u, CS->a_u, CS->h_u, ORC_Q2(G, I, j - 1), ORC_Q2(G, I, j), visc->nkml_visc_u);
+                visc->bbl_thick_u, CS->a_u, CS->h_u, ORC_Q2(G, I, j - 1), ORC_Q2(G, I, j), visc->nkml_visc_u,
+                obc_side(OBC, OBC ? OBC->segnum_u : NULL, ORC_U2(G, I, j)));
   }
   ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
     if (!(G->mask2dCv[ORC_V2(G, i, J)] > 0.0)) continue;
     coef_column(G, CS, visc, v, h, dz, ORC_H2(G, i, J), ORC_H2(G, i, J + 1), ORC_V2(G, i, J), hpl, vpl, visc->Kv_bbl_v,
-                visc->bbl_thick_v, CS->a_v, CS->h_v, ORC_Q2(G, i - 1, J), ORC_Q2(G, i, J), visc->nkml_visc_v);
+                visc->bbl_thick_v, CS->a_v, CS->h_v, ORC_Q2(G, i - 1, J), ORC_Q2(G, i, J), visc->nkml_visc_v,
+                obc_side(OBC, OBC ? OBC->segnum_v : NULL, ORC_V2(G, i, J)));
   }
   return 0;
 }
@@ -222,6 +251,12 @@ static void solve_column(int nz, double dt, const double *a, const double *hv, c
 
 int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, double *v, const double *h, const double *taux,
                  const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot) {
+  return orc_vertvisc_obc(G, CS, u, v, h, taux, tauy, visc, dt, taux_bot, tauy_bot, NULL);
+}
+
+int orc_vertvisc_obc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, double *v, const double *h, const double *taux,
+                     const double *tauy, const mom6hip_vertvisc_type_t *visc, double dt, double *taux_bot, double *tauy_bot,
+                     const mom6hip_obc_t *OBC) {
   if (unsupported(CS)) return 1;
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const long nih = ORC_NIH(G), njh = ORC_NJH(G), hpl = nih * njh, upl = (nih + 1) * njh, vpl = nih * (njh + 1);
@@ -296,6 +331,23 @@ int orc_vertvisc(const mom6hip_grid_t *G, mom6hip_vertvisc_cs_t *CS, double *u, 
         }
       }
       CS->ntrunc = CS->ntrunc + ntr;
+    }
+  }
+  /* :988-1006: the velocities of the specified open-boundary segments */
+  if (OBC) for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->specified || !S->on_pe) continue;
+    if (!S->normal_vel) return 1;
+    const long nA = S->is_N_or_S ? (S->ied - S->isd + 1) : (S->IedB - S->IsdB + 1);      /* the segment's own arrays: (i, j, k) */
+    const long nB = S->is_N_or_S ? (S->JedB - S->JsdB + 1) : (S->jed - S->jsd + 1);
+    if (S->is_N_or_S) {
+      const int J = S->JsdB;
+      for (int k = 0; k < nz; k++) for (int i = S->isd; i <= S->ied; i++)
+        v[ORC_V2(G, i, J) + vpl * k] = S->normal_vel[(i - S->isd) + nA * ((J - S->JsdB) + nB * (long)k)];
+    } else if (S->is_E_or_W) {
+      const int I = S->IsdB;
+      for (int k = 0; k < nz; k++) for (int j = S->jsd; j <= S->jed; j++)
+        u[ORC_U2(G, I, j) + upl * k] = S->normal_vel[(I - S->IsdB) + nA * ((j - S->jsd) + nB * (long)k)];
     }
   }
   return 0;

@@ -4,13 +4,18 @@
 !! tests/test_continuity_obc.py, then
 !!   continuity(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont)
 !!   CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv)                         (MOM_dynamics_split_RK2.F90:869)
+!!   vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, VarMix) ; vertvisc(u, v, h, forces, visc, dt, OBC, ...)   (:717-731)
 !! on plain host arrays; the results go to the output file, which the test compares with the oracle bit for bit.
 !! Usage: obc_driver <input file> <output file>
 program obc_driver
 use, intrinsic :: iso_c_binding
 use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_PPM_CS
 use MOM_CoriolisAdv,    only : CorAdCalc, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_CS
-use MOM_variables,      only : accel_diag_ptrs
+use MOM_vert_friction,  only : vertvisc_CS, vertvisc_init, vertvisc_coef, vertvisc, vertvisc_end
+use MOM_variables,      only : accel_diag_ptrs, cont_diag_ptrs, vertvisc_type, thermo_var_ptrs, ocean_internal_state
+use MOM_forcing_type,   only : mech_forcing
+use MOM_get_input,      only : directories
+use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_diag_mediator,  only : diag_ctrl, time_type
 use MOM_domains,        only : MOM_domain_type
 use MOM_file_parser,    only : param_file_type, param_set
@@ -43,6 +48,16 @@ real :: scal(7), dt
 real, allocatable, dimension(:,:,:) :: u, v, h, hp, uh, vh, vru, vrv, u_cor, v_cor
 real, allocatable, dimension(:,:) :: uhbt, vhbt
 character(len=512) :: f_in, f_out
+type(ocean_internal_state), target :: MIS
+type(directories) :: dirs
+type(vertvisc_CS), pointer :: VV => NULL()
+type(vertvisc_type) :: visc
+type(thermo_var_ptrs) :: tv
+type(mech_forcing) :: forces
+type(cont_diag_ptrs) :: CDp
+type(VarMix_CS) :: VarMix
+integer, target :: ntrunc
+real, allocatable, dimension(:,:,:) :: dz, u1, v1
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
@@ -58,7 +73,7 @@ G%Domain%reentrant(1) = (hdr(5) /= 0) ; G%Domain%reentrant(2) = (hdr(6) /= 0)
 G%Domain%nihalo = halo ; G%Domain%njhalo = halo ; G%Domain%niglobal = ni ; G%Domain%njglobal = nj
 read(u_in) scal, dt
 GV%Angstrom_H = scal(1) ; GV%H_subroundoff = scal(2) ; GV%dZ_subroundoff = scal(3) ; GV%H_to_Z = scal(4) ; GV%Z_to_H = scal(5)
-GV%g_Earth = scal(6) ; GV%Rho0 = scal(7)
+GV%g_Earth = scal(6) ; GV%Rho0 = scal(7) ; GV%RZ_to_H = GV%Z_to_H / GV%Rho0 ; GV%H_to_RZ = GV%H_to_Z * GV%Rho0
 
 allocate(G%mask2dT(isd:ied,jsd:jed), G%areaT(isd:ied,jsd:jed), G%IareaT(isd:ied,jsd:jed), G%dxT(isd:ied,jsd:jed), &
          G%dyT(isd:ied,jsd:jed), G%IdxT(isd:ied,jsd:jed), G%IdyT(isd:ied,jsd:jed), G%bathyT(isd:ied,jsd:jed))
@@ -133,12 +148,28 @@ call CoriolisAdv_init(Time, G, GV, US, pf, diag, AD, CCS)
 allocate(CAu(isd-1:ied,jsd:jed,nk), CAv(isd:ied,jsd-1:jed,nk)) ; CAu = 0.0 ; CAv = 0.0
 call CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CCS, pbv)
 
+! the vertical viscosity of the predictor (:717-731) with the bottom boundary layer and the wind stress as plain functions of the grid
+allocate(visc%Kv_bbl_u(isd-1:ied,jsd:jed), visc%bbl_thick_u(isd-1:ied,jsd:jed), visc%Kv_bbl_v(isd:ied,jsd-1:jed), &
+         visc%bbl_thick_v(isd:ied,jsd-1:jed), forces%taux(isd-1:ied,jsd:jed), forces%tauy(isd:ied,jsd-1:jed))
+visc%Kv_bbl_u(:,:) = 1.0e-3 + 2.0e-4*G%mask2dCu(:,:) ; visc%bbl_thick_u(:,:) = 3.0 + 1.0e-4*G%dxCu(:,:)
+visc%Kv_bbl_v(:,:) = 2.0e-3 - 3.0e-4*G%mask2dCv(:,:) ; visc%bbl_thick_v(:,:) = 4.0 + 1.0e-4*G%dyCv(:,:)
+forces%taux(:,:) = 0.05*G%mask2dCu(:,:) ; forces%tauy(:,:) = -0.02*G%mask2dCv(:,:)
+allocate(dz(isd:ied,jsd:jed,nk), u1(isd-1:ied,jsd:jed,nk), v1(isd:ied,jsd-1:jed,nk))
+dz(:,:,:) = GV%H_to_Z * h(:,:,:) ; u1 = u ; v1 = v
+call param_set(pf, "HBBL", "10.0") ; call param_set(pf, "KV", "1.0e-4") ; call param_set(pf, "DT", "900.0")
+call param_set(pf, "HMIX_FIXED", "20.0")
+call vertvisc_init(MIS, Time, G, GV, US, pf, diag, AD, dirs, ntrunc, VV)
+call vertvisc_coef(u1, v1, h, dz, forces, visc, tv, dt, G, GV, US, VV, OBC, VarMix)
+call vertvisc(u1, v1, h, forces, visc, dt, OBC, AD, CDp, G, GV, US, VV)
+
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) hp, uh, vh, u_cor, v_cor
 write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_EE
 write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
 write(u_out) CAu, CAv
+write(u_out) u1, v1
 close(u_out)
+call vertvisc_end(VV)
 call CoriolisAdv_end(CCS)
 call mom6hip_shared_context_end()
 write(*,'(a)') "obc_driver ok"

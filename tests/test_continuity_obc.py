@@ -327,14 +327,23 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
             s.tangential_vel[:] = 0.1 * rng.standard_normal(s.tangential_vel.shape)
     want = run(g, st, OBC)
     want["CAu"], want["CAv"] = orc.coradcalc(g, st["u"], st["v"], st["h"], want["uh"], want["vh"], bound_coriolis=True, OBC=OBC)
+    # vertvisc_coef / vertvisc with the bottom boundary layer and the wind stress the driver states
+    m = g.metrics
+    visc = orc.vertvisc_type(Kv_bbl_u=1.0e-3 + 2.0e-4 * m["mask2dCu"], bbl_thick_u=3.0 + 1.0e-4 * m["dxCu"],
+                             Kv_bbl_v=2.0e-3 - 3.0e-4 * m["mask2dCv"], bbl_thick_v=4.0 + 1.0e-4 * m["dyCv"])
+    vcs = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, Hmix=20.0)
+    want["u1"], want["v1"] = st["u"].copy(), st["v"].copy()
+    orc.vertvisc_coef(g, vcs, want["u1"], want["v1"], st["h"], visc, 900.0, OBC=OBC)
+    orc.vertvisc(g, vcs, want["u1"], want["v1"], st["h"], np.ascontiguousarray(0.05 * m["mask2dCu"]), np.ascontiguousarray(-0.02 * m["mask2dCv"]),
+                 visc, 900.0, OBC=OBC)
     _write_obc_case(str(tmp_path / "in.bin"), g, st, OBC, want["uhbt"], want["vhbt"])
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
-             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv"]
+             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "u1", "v1"]
     arrs = [want[n] if n in want else want["bt"][n] for n in names]
     got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
     for n, a, w in zip(names, got, arrs):
-        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu", "u1") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv", "v1") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
         assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
