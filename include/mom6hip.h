@@ -708,9 +708,13 @@ typedef struct mom6hip_barotropic_cs {
 int mom6hip_barotropic_init(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, int32_t memspace);
 
 /* btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC)              src/core/MOM_barotropic.F90:3394
- * h_u / h_v may be NULL; OBC must not be associated. */
+ * h_u / h_v may be NULL; without OBC (with: mom6hip_btcalc_obc). */
 int mom6hip_btcalc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *h_u,
                    const double *h_v, int32_t may_use_default, int32_t memspace);
+/* btcalc with OBC associated: the weights of the faces of the open-boundary segments are those of the cell inside (:3610-3664).
+ * obc == NULL: mom6hip_btcalc. */
+int mom6hip_btcalc_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *h_u, const double *h_v,
+                       int32_t may_use_default, const struct mom6hip_obc *obc, int32_t memspace);
 
 /* bt_mass_source(h, eta, set_cor, G, GV, CS)                         src/core/MOM_barotropic.F90:4318 */
 int mom6hip_bt_mass_source(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *eta,
@@ -909,6 +913,12 @@ typedef struct mom6hip_set_visc_cs {
 int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
                             const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
                             const mom6hip_vertvisc_type_t *visc, int32_t memspace);
+/* set_viscous_BBL with CS%OBC associated (set_visc_init :2903): one-sided depths and masks of the faces at and beside the segments
+ * (:374-413), the zero-gradient projection of the thicknesses, T and S across the segments' faces (:502-580), the weights of
+ * set_v_at_u / set_u_at_v (:1829-1838, :1874-1883).  obc == NULL: mom6hip_set_viscous_bbl. */
+int mom6hip_set_viscous_bbl_obc(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
+                                const double *T, const double *S, const mom6hip_eos_t *eos, const mom6hip_vertvisc_type_t *visc,
+                                const struct mom6hip_obc *obc, int32_t memspace);
 
 /* set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)                                                :1898
  * Returns at once unless DYNAMIC_VISCOUS_ML (ice shelves are not provided) (:2043-2044).  With it: the bulk-Richardson-number

@@ -106,6 +106,7 @@ def _setup():
         cs = C.POINTER(_abi.BarotropicCS)
         L.mom6hip_barotropic_init.argtypes = [C.c_void_p, cs, C.c_int32]
         L.mom6hip_btcalc.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.mom6hip_btcalc_obc.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(_abi.Obc), C.c_int32]
         L.mom6hip_bt_mass_source.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.mom6hip_set_dtbt.argtypes = [C.c_void_p, cs, C.c_void_p, C.POINTER(_abi.BTCont), C.c_double, C.c_double, C.c_int32]
         L.mom6hip_set_dtbt_eta.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.POINTER(_abi.BTCont), C.c_double, C.c_double, C.c_int32]
@@ -138,10 +139,13 @@ def btcalc(h, G: DeviceGrid, CS: barotropic_CS, h_u=None, h_v=None, may_use_defa
     """btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC) -- :3394."""
     if not CS.module_is_initialized:
         raise Mom6HipError("btcalc: Module MOM_barotropic must be initialized before it is used.")
-    if OBC is not None:
-        raise Mom6HipError("btcalc (HIP): open boundaries are not supported")
     sp = set()
     args = [_P(sp, h), _P(sp, h_u), _P(sp, h_v)]
+    if OBC is not None:      # an ocean_OBC_type: the weights at the segments' faces are those of the cell inside (:3610-3664)
+        obc = OBC.struct(lambda a: (0, None))      # (none of the segments' own arrays is read)
+        check(_setup().mom6hip_btcalc_obc(G.handle, C.byref(CS.st), *args, int(bool(may_use_default)), C.byref(obc),
+                                          _one_space(sp, CS, "btcalc")), "btcalc")
+        return
     check(_setup().mom6hip_btcalc(G.handle, C.byref(CS.st), *args, int(bool(may_use_default)), _one_space(sp, CS, "btcalc")), "btcalc")
 
 

@@ -391,6 +391,12 @@ int mom6hip_barotropic_init(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, int
 
 int mom6hip_btcalc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *h_u, const double *h_v,
                    int32_t may_use_default, int32_t memspace) {
+  return mom6hip_btcalc_obc(ctx, cs, h, h_u, h_v, may_use_default, nullptr, memspace);
+}
+
+// btcalc with OBC associated: at the faces of the open-boundary segments the weights are those of the cell inside (:3610-3664)
+int mom6hip_btcalc_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *h, const double *h_u, const double *h_v,
+                       int32_t may_use_default, const mom6hip_obc_t *obc, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr && cs != nullptr && h != nullptr, "btcalc: null argument");
   const m6::GridDev g = ctx->g;
   const int sch = cs->hvel_scheme;
@@ -407,8 +413,12 @@ int mom6hip_btcalc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   M6_REQUIRE(!st.failed(), "btcalc: staging failed");
   const double h_neglect = g.H_subroundoff, Z_to_H = g.Z_to_H;
   const int hybrid = (sch == MOM6HIP_BT_HYBRID || use_default), arith = (sch == MOM6HIP_BT_ARITHMETIC);
+  // the segment at a face is the last one placed there (OBC%segnum_u / segnum_v): what the reference's loop over the segments leaves
+  const int32_t *side_d[2] = {nullptr, nullptr};
+  if (obc && obc->OBC_pe && m6::obc_side_maps(ctx, st, obc, &side_d[0], &side_d[1], "btcalc")) return 1;
   for (int dir = 0; dir < 2; dir++) {
     const double *hw = dir ? dhv : dhu;
+    const int32_t *side = side_d[dir];
     double *fr = dir ? frv : fru;
     const long fstr = dir ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh, hstr = (long)g.nih * g.njh;
     launch2d(ctx->stream, dir ? g.isc : g.isc - 1, g.iec, dir ? g.jsc - 1 : g.jsc, g.jec, [=] __device__(int i, int j) {
@@ -417,6 +427,14 @@ int mom6hip_btcalc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       const double mask = dir ? g.mask2dCv[f2] : g.mask2dCu[f2];
       const int nz = g.nk;
       double tot;
+      if (side && side[f2]) {      // :3610-3664
+        const long hc = side[f2] < 0 ? hm : hp;
+        tot = dh[hc];
+        for (int k = 1; k < nz; k++) tot = tot + dh[hc + hstr * k];
+        const double Ihtot = mask / (tot + h_neglect);
+        for (int k = 0; k < nz; k++) fr[f2 + fstr * k] = dh[hc + hstr * k] * Ihtot;
+        return;
+      }
       if (hw) {
         tot = hw[f2];
         for (int k = 1; k < nz; k++) tot = tot + hw[f2 + fstr * k];

@@ -214,10 +214,11 @@ void staging_destroy(mom6hip_ctx *ctx);      // staging.hip
 int horizontal_viscosity_dev(mom6hip_ctx *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,
                              double *diffu, double *diffv, const double *hu_cont, const double *hv_cont);
 
-// set_viscous_BBL on device arrays (set_viscosity.hip)
+// set_viscous_BBL on device arrays (set_viscosity.hip); ob: what the OBC branches read (device arrays), null without OBC
+struct BBLObcDev { const int32_t *side_u = nullptr, *side_v = nullptr; const double *D_u = nullptr, *D_v = nullptr, *mask_u = nullptr, *mask_v = nullptr; };
 int set_viscous_BBL_dev(mom6hip_ctx *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
                         const double *T, const double *S, const mom6hip_eos_t *eos, double *bbl_thick_u, double *bbl_thick_v,
-                        double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v);
+                        double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v, const BBLObcDev *ob = nullptr);
 
 // the velocities of vertvisc_coef / vertvisc as the increment the RK2 step applies just before them:
 // u = mask2dCu * (u0 + dtv * (a1u [+ a2u])), v likewise (device pointers; a2u / a2v may be null)

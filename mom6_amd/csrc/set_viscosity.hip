@@ -28,10 +28,14 @@ struct BBLArgs {
   int linear_drag, use_BBL_EOS, correct_BBL_bounds, body_force_drag, RiNo_mix, Channel_drag, concave_trig;
   const double *u, *v, *h, *T, *S, *Rlay;      // Rlay: device copy of GV%Rlay
   double *bbl_thick, *Kv_bbl, *Ray;            // of this direction
+  // open boundaries (the OBC instantiation only): per face the cell inside a segment (m6::obc_side_maps: -1 the first cell, +1 the
+  // second, 0 no segment), and the reference's work arrays D_u, D_v, mask_u, mask_v after its two loops over the segments :374-413
+  const int32_t *side_u, *side_v;
+  const double *D_u, *D_v, *mask_u, *mask_v;
 };
 
-// set_v_at_u :1804-1846 / set_u_at_v :1849-1891 (no OBC): the transverse velocity at the face (i, j) of layer k
-template <int DIR>
+// set_v_at_u :1804-1846 / set_u_at_v :1849-1891: the transverse velocity at the face (i, j) of layer k
+template <int DIR, bool OBC = false>
 __device__ __forceinline__ double transverse_vel(const BBLArgs &A, int i, int j, long kH, long kU, long kV) {
   const m6::GridDev &g = A.g;
   if (DIR == 0) {      // v at the u point (I = i, j)
@@ -42,7 +46,14 @@ __device__ __forceinline__ double transverse_vel(const BBLArgs &A, int i, int j,
 #pragma unroll
       for (int i0 = 0; i0 <= 1; i0++) {
         const int i1 = i + i0, J1 = J + j0;
-        hwt[i0][j0 + 1] = (A.h[g.h2(i1, J1) + kH] + A.h[g.h2(i1, J1 + 1) + kH]) * g.mask2dCv[g.v2(i1, J1)];
+        const long fv = g.v2(i1, J1);
+        const double mk = OBC ? A.mask_v[fv] : g.mask2dCv[fv];
+        hwt[i0][j0 + 1] = (A.h[g.h2(i1, J1) + kH] + A.h[g.h2(i1, J1 + 1) + kH]) * mk;
+        if (OBC) {      // :1829-1838
+          const int sd = A.side_v[fv];
+          if (sd < 0) hwt[i0][j0 + 1] = 2.0 * A.h[g.h2(i1, J1) + kH] * mk;
+          else if (sd > 0) hwt[i0][j0 + 1] = 2.0 * A.h[g.h2(i1, J1 + 1) + kH] * mk;
+        }
       }
     const double hwt_tot = (hwt[0][0] + hwt[1][1]) + (hwt[1][0] + hwt[0][1]);
     double r = 0.0;
@@ -58,7 +69,14 @@ __device__ __forceinline__ double transverse_vel(const BBLArgs &A, int i, int j,
 #pragma unroll
       for (int i0 = -1; i0 <= 0; i0++) {
         const int I1 = I + i0, j1 = j + j0;
-        hwt[i0 + 1][j0] = (A.h[g.h2(I1, j1) + kH] + A.h[g.h2(I1 + 1, j1) + kH]) * g.mask2dCu[g.u2(I1, j1)];
+        const long fu = g.u2(I1, j1);
+        const double mk = OBC ? A.mask_u[fu] : g.mask2dCu[fu];
+        hwt[i0 + 1][j0] = (A.h[g.h2(I1, j1) + kH] + A.h[g.h2(I1 + 1, j1) + kH]) * mk;
+        if (OBC) {      // :1874-1883
+          const int sd = A.side_u[fu];
+          if (sd < 0) hwt[i0 + 1][j0] = 2.0 * A.h[g.h2(I1, j1) + kH] * mk;
+          else if (sd > 0) hwt[i0 + 1][j0] = 2.0 * A.h[g.h2(I1 + 1, j1) + kH] * mk;
+        }
       }
     const double hwt_tot = (hwt[0][0] + hwt[1][1]) + (hwt[1][0] + hwt[0][1]);
     double r = 0.0;
@@ -318,7 +336,7 @@ struct ChanGeom {
   }
 };
 
-template <int DIR>
+template <int DIR, bool OBC>
 __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
   const m6::GridDev &g = A.g;
   const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x;
@@ -329,9 +347,13 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
   const int nz = g.nk;
   const long hpl = (long)g.nih * g.njh, upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1);
   const long fpl = DIR ? vpl : upl;
-  const long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
+  long c0 = g.h2(i, j), c1 = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
   const double *vel = DIR ? A.v : A.u;
   const double h_neglect = g.H_subroundoff, dz_neglect = g.dZ_subroundoff;
+  // a face of an open-boundary segment: the thicknesses, T and S are those of the cell inside (:502-580); every two-cell mean below
+  // is written so that it returns its argument when the two cells are the same one, except h_at_vel / dz_at_vel (at_vel)
+  const int side = OBC ? (DIR ? A.side_v[f2] : A.side_u[f2]) : 0;
+  if (OBC && side) { if (side < 0) c1 = c0; else c0 = c1; }
   const double Rho0x400_G = 400.0 * (A.H_to_RZ / (1.0 * 1.0 * g.g_Earth));
   const double cdrag_sqrt = sqrt(A.cdrag);
   const double cdrag_sqrt_H = cdrag_sqrt * 1.0 * g.Z_to_H;
@@ -342,6 +364,7 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
   auto at_vel = [&](int k, double &hat, double &dzat) {
     const double h0 = A.h[c0 + hpl * k], h1 = A.h[c1 + hpl * k];
     const double d0 = g.H_to_Z * h0, d1 = g.H_to_Z * h1;
+    if (OBC && side) { hat = h0; dzat = d0; return; }
     if (vel[f2 + fpl * k] * (h1 - h0) >= 0) {
       hat = 2.0 * h0 * h1 / (h0 + h1 + h_neglect);
       dzat = 2.0 * d0 * d1 / (d0 + d1 + dz_neglect);
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
       dztot_vel = dztot_vel + dzat;
       dzwtot = dzwtot + dzweight;
       if ((!A.linear_drag) && (hweight >= 0.0)) {
-        const double vt = transverse_vel<DIR>(A, i, j, hpl * k, upl * k, vpl * k);
+        const double vt = transverse_vel<DIR, OBC>(A, i, j, hpl * k, upl * k, vpl * k);
         const double vn = vel[f2 + fpl * k];
         hutot = hutot + hweight * sqrt(vn * vn + vt * vt + u2_bg);
       }
@@ -481,13 +504,18 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
   double kv_bbl;
   if (A.Channel_drag) {      // :863-1002
     auto D_face = [&](int ii, int jj) {
+      if (OBC) return DIR ? A.D_v[g.v2(ii, jj)] : A.D_u[g.u2(ii, jj)];
       return DIR ? (0.5 * (g.bathyT[g.h2(ii, jj)] + g.bathyT[g.h2(ii, jj + 1)]) + A.Z_ref)
                  : (0.5 * (g.bathyT[g.h2(ii, jj)] + g.bathyT[g.h2(ii + 1, jj)]) + A.Z_ref);
     };
+    auto mask_face = [&](int ii, int jj) {
+      if (OBC) return DIR ? A.mask_v[g.v2(ii, jj)] : A.mask_u[g.u2(ii, jj)];
+      return DIR ? g.mask2dCv[g.v2(ii, jj)] : g.mask2dCu[g.u2(ii, jj)];
+    };
     const double D_vel = D_face(i, j);
-    double tmp = DIR ? g.mask2dCv[g.v2(i + 1, j)] * D_face(i + 1, j) : g.mask2dCu[g.u2(i, j + 1)] * D_face(i, j + 1);
+    double tmp = DIR ? mask_face(i + 1, j) * D_face(i + 1, j) : mask_face(i, j + 1) * D_face(i, j + 1);
     double Dp = 2.0 * D_vel * tmp / (D_vel + tmp);
-    tmp = DIR ? g.mask2dCv[g.v2(i - 1, j)] * D_face(i - 1, j) : g.mask2dCu[g.u2(i, j - 1)] * D_face(i, j - 1);
+    tmp = DIR ? mask_face(i - 1, j) * D_face(i - 1, j) : mask_face(i, j - 1) * D_face(i, j - 1);
     double Dm = 2.0 * D_vel * tmp / (D_vel + tmp);
     if (Dm > Dp) { tmp = Dp; Dp = Dm; Dm = tmp; }
     ChanGeom geo;
@@ -520,7 +548,7 @@ __global__ __launch_bounds__(64) void set_viscous_bbl_kernel(BBLArgs A) {
         Rayleigh = 0.0;
       }
       if (Rayleigh > 0.0) {
-        const double vt = transverse_vel<DIR>(A, i, j, hpl * k, upl * k, vpl * k);
+        const double vt = transverse_vel<DIR, OBC>(A, i, j, hpl * k, upl * k, vpl * k);
         const double vn = vel[f2 + fpl * k];
         A.Ray[f2 + fpl * k] = Rayleigh * sqrt(vn * vn + vt * vt + u2_bg);
       } else {
@@ -698,7 +726,7 @@ int check_cs(const mom6hip_set_visc_cs_t *cs, const char *who) {
 namespace m6 {
 int set_viscous_BBL_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,
                         const double *T, const double *S, const mom6hip_eos_t *eos, double *bbl_thick_u, double *bbl_thick_v,
-                        double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v) {
+                        double *Kv_bbl_u, double *Kv_bbl_v, double *Ray_u, double *Ray_v, const BBLObcDev *ob) {
   const m6::GridDev g = ctx->g;
   hipStream_t s = ctx->stream;
   const bool use_EOS = (eos != nullptr) && cs->BBL_use_EOS;
@@ -723,10 +751,14 @@ int set_viscous_BBL_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, con
   if (Ray_u) M6_HIP(hipMemsetAsync(Ray_u, 0, sizeof(double) * (size_t)g.nu3(), s));      // :416-417
   if (Ray_v) M6_HIP(hipMemsetAsync(Ray_v, 0, sizeof(double) * (size_t)g.nv3(), s));
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
+  A.side_u = A.side_v = nullptr; A.D_u = A.D_v = A.mask_u = A.mask_v = nullptr;
+  if (ob) { A.side_u = ob->side_u; A.side_v = ob->side_v; A.D_u = ob->D_u; A.D_v = ob->D_v; A.mask_u = ob->mask_u; A.mask_v = ob->mask_v; }
   A.bbl_thick = bbl_thick_u; A.Kv_bbl = Kv_bbl_u; A.Ray = Ray_u;
-  hipLaunchKernelGGL(set_viscous_bbl_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
+  if (ob) hipLaunchKernelGGL((set_viscous_bbl_kernel<0, true>), dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
+  else hipLaunchKernelGGL((set_viscous_bbl_kernel<0, false>), dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
   A.bbl_thick = bbl_thick_v; A.Kv_bbl = Kv_bbl_v; A.Ray = Ray_v;
-  hipLaunchKernelGGL(set_viscous_bbl_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+  if (ob) hipLaunchKernelGGL((set_viscous_bbl_kernel<1, true>), dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+  else hipLaunchKernelGGL((set_viscous_bbl_kernel<1, false>), dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
   M6_HIP(hipGetLastError());
   if (!use_EOS) M6_HIP(hipStreamSynchronize(s));      // (the host's Rlay may change after the call)
   return 0;
@@ -789,9 +821,50 @@ extern "C" int mom6hip_set_viscous_ml(mom6hip_ctx_t *ctx, const mom6hip_set_visc
   return st.finish();
 }
 
+namespace {
+// the reference's work arrays D_u, mask_u (DIR 0) or D_v, mask_v (DIR 1) before its loops over the segments :363-372, over the data domain
+template <int DIR>
+__global__ __launch_bounds__(256) void bbl_obc_fill_kernel(m6::GridDev g, double Z_ref, double *D, double *mask) {
+  const int i = (DIR ? g.isd : g.isd - 1) + blockIdx.x * 256 + threadIdx.x, j = (DIR ? g.jsd - 1 : g.jsd) + blockIdx.y;
+  if (i > g.ied) return;
+  const long f2 = DIR ? g.v2(i, j) : g.u2(i, j);
+  const bool inside = DIR ? (j >= g.jsd && j + 1 <= g.jed) : (i >= g.isd && i + 1 <= g.ied);
+  D[f2] = inside ? 0.5 * (g.bathyT[g.h2(i, j)] + g.bathyT[DIR ? g.h2(i, j + 1) : g.h2(i + 1, j)]) + Z_ref : 0.0;
+  mask[f2] = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2];
+}
+
+struct BBLSeg { int ew, plus, A, c0, c1; };      // a segment: E/W or N/S, the cell inside is the first (E, N: plus) or the second, its face index, the range along it
+
+// phase 0 :374-389: the depth of the segment's own faces from the cell inside; phase 1 :390-413: the depths and masks of the faces of
+// the other direction just outside, across the segment's corner points
+__global__ __launch_bounds__(64) void bbl_obc_segment_kernel(m6::GridDev g, BBLSeg S, int phase, double Z_ref, double *D_u, double *D_v, double *mask_u,
+                                                             double *mask_v) {
+  const int c = S.c0 + blockIdx.x * 64 + threadIdx.x;
+  if (c > S.c1) return;
+  if (phase == 0) {
+    if (S.ew) D_u[g.u2(S.A, c)] = g.bathyT[g.h2(S.plus ? S.A : S.A + 1, c)] + Z_ref;
+    else D_v[g.v2(c, S.A)] = g.bathyT[g.h2(c, S.plus ? S.A : S.A + 1)] + Z_ref;
+  } else if (S.ew) {      // c = J: D_v(i+1,J) = D_v(i,J) (E) | D_v(i,J) = D_v(i+1,J) (W), i = the segment's I
+    const long in = g.v2(S.plus ? S.A : S.A + 1, c), out = g.v2(S.plus ? S.A + 1 : S.A, c);
+    D_v[out] = D_v[in]; mask_v[out] = 0.0;
+  } else {                // c = I: D_u(I,j+1) = D_u(I,j) (N) | D_u(I,j) = D_u(I,j+1) (S), j = the segment's J
+    const long in = g.u2(c, S.plus ? S.A : S.A + 1), out = g.u2(c, S.plus ? S.A + 1 : S.A);
+    D_u[out] = D_u[in]; mask_u[out] = 0.0;
+  }
+}
+}  // namespace
+
 extern "C" int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
                                        const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
                                        const mom6hip_vertvisc_type_t *visc, int32_t memspace) {
+  return mom6hip_set_viscous_bbl_obc(ctx, cs, u, v, h, T, S, eos, visc, nullptr, memspace);
+}
+
+// set_viscous_BBL with CS%OBC associated: the depths and masks of the faces at and beside the segments :374-413, the zero-gradient
+// projection of the thicknesses, T and S :502-580, the weights of set_v_at_u / set_u_at_v :1829-1838, :1874-1883
+extern "C" int mom6hip_set_viscous_bbl_obc(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v,
+                                           const double *h, const double *T, const double *S, const mom6hip_eos_t *eos,
+                                           const mom6hip_vertvisc_type_t *visc, const mom6hip_obc_t *obc, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "MOM_set_viscosity(BBL): Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && visc, "set_viscous_BBL: null argument");
   M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "set_viscous_BBL: bad memspace");
@@ -816,6 +889,49 @@ extern "C" int mom6hip_set_viscous_bbl(mom6hip_ctx_t *ctx, const mom6hip_set_vis
   double *kvu = st.inout((double *)visc->Kv_bbl_u, bU2), *kvv = st.inout((double *)visc->Kv_bbl_v, bV2);
   double *ru = st.inout((double *)visc->Ray_u, bU), *rv = st.inout((double *)visc->Ray_v, bV);
   M6_REQUIRE(!st.failed(), "set_viscous_BBL: staging failed");
-  if (m6::set_viscous_BBL_dev(ctx, cs, du, dv, dh, dT, dS, eos, btu, btv, kvu, kvv, ru, rv)) return 1;
+  m6::BBLObcDev ob;
+  const bool with_obc = obc != nullptr;      // (associated(OBC): the branches are taken whatever the number of segments)
+  if (with_obc) {
+    M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "set_viscous_BBL: OBC%%segment is required");
+    if (m6::obc_side_maps(ctx, st, obc, &ob.side_u, &ob.side_v, "set_viscous_BBL")) return 1;
+    const size_t nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1);
+    if (!ob.side_u) {      // no segments: maps of zeros
+      int32_t *z = (int32_t *)st.scratch(4 * (nU2 + nV2));
+      M6_REQUIRE(!st.failed() && z, "set_viscous_BBL: out of device memory");
+      M6_HIP(hipMemsetAsync(z, 0, 4 * (nU2 + nV2), ctx->stream));
+      ob.side_u = z; ob.side_v = z + nU2;
+    }
+    double *w = (double *)st.scratch(8 * 2 * (nU2 + nV2));
+    M6_REQUIRE(!st.failed() && w, "set_viscous_BBL: out of device memory");
+    double *D_u = w, *mask_u = w + nU2, *D_v = mask_u + nU2, *mask_v = D_v + nV2;
+    hipLaunchKernelGGL(bbl_obc_fill_kernel<0>, dim3((g.nih + 1 + 255) / 256, g.njh), dim3(256), 0, ctx->stream, g, cs->Z_ref, D_u, mask_u);
+    hipLaunchKernelGGL(bbl_obc_fill_kernel<1>, dim3((g.nih + 255) / 256, g.njh + 1), dim3(256), 0, ctx->stream, g, cs->Z_ref, D_v, mask_v);
+    const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec;
+    for (int phase = 0; phase < 2; phase++) for (int n = 0; n < obc->number_of_segments; n++) {
+      const mom6hip_obc_segment_t &Sg = obc->segment[n];
+      if (!Sg.on_pe) continue;
+      BBLSeg d;
+      d.plus = (Sg.direction == MOM6HIP_OBC_DIRECTION_E || Sg.direction == MOM6HIP_OBC_DIRECTION_N) ? 1 : 0;
+      const bool known = d.plus || Sg.direction == MOM6HIP_OBC_DIRECTION_W || Sg.direction == MOM6HIP_OBC_DIRECTION_S;
+      if (Sg.is_N_or_S && Sg.JsdB >= js - 1 && Sg.JsdB <= je) {
+        d.ew = 0; d.A = Sg.JsdB;
+        M6_REQUIRE(Sg.JsdB >= g.jsd && Sg.JsdB + 1 <= g.jed, "set_viscous_BBL: OBC segment %d lies outside the data domain", n + 1);
+        if (phase == 0) { d.c0 = std::max(is - 1, Sg.isd); d.c1 = std::min(ie + 1, Sg.ied); }
+        else { d.c0 = std::max(is - 1, Sg.IsdB); d.c1 = std::min(ie, Sg.IedB); }
+      } else if (Sg.is_E_or_W && Sg.IsdB >= is - 1 && Sg.IsdB <= ie) {
+        d.ew = 1; d.A = Sg.IsdB;
+        M6_REQUIRE(Sg.IsdB >= g.isd && Sg.IsdB + 1 <= g.ied, "set_viscous_BBL: OBC segment %d lies outside the data domain", n + 1);
+        if (phase == 0) { d.c0 = std::max(js - 1, Sg.jsd); d.c1 = std::min(je + 1, Sg.jed); }
+        else { d.c0 = std::max(js - 1, Sg.JsdB); d.c1 = std::min(je, Sg.JedB); }
+      } else continue;
+      // (a segment whose direction does not go with its orientation changes nothing: the reference's tests on %direction)
+      if (!known || (d.ew != (Sg.direction == MOM6HIP_OBC_DIRECTION_E || Sg.direction == MOM6HIP_OBC_DIRECTION_W))) continue;
+      if (d.c1 < d.c0) continue;
+      hipLaunchKernelGGL(bbl_obc_segment_kernel, dim3((d.c1 - d.c0 + 1 + 63) / 64), dim3(64), 0, ctx->stream, g, d, phase, cs->Z_ref, D_u, D_v, mask_u, mask_v);
+    }
+    M6_HIP(hipGetLastError());
+    ob.D_u = D_u; ob.D_v = D_v; ob.mask_u = mask_u; ob.mask_v = mask_v;
+  }
+  if (m6::set_viscous_BBL_dev(ctx, cs, du, dv, dh, dT, dS, eos, btu, btv, kvu, kvv, ru, rv, with_obc ? &ob : nullptr)) return 1;
   return st.finish();
 }

@@ -12,7 +12,7 @@ module MOM_barotropic
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,   only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,   only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_obc_to_c
 use MOM_diag_mediator,  only : diag_ctrl, time_type
 use MOM_error_handler,  only : MOM_error, MOM_mesg, FATAL, WARNING
 use MOM_file_parser,    only : get_param, log_version, param_file_type
@@ -203,17 +203,24 @@ subroutine btcalc(h, G, GV, CS, h_u, h_v, may_use_default, OBC)
   real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, optional, intent(in) :: h_v
   logical,       optional, intent(in)    :: may_use_default
   type(ocean_OBC_type), optional, pointer :: OBC
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
   type(c_ptr) :: p_hu, p_hv
   integer :: rc, mud
+  logical :: with_OBC
   if (.not.CS%module_is_initialized) call MOM_error(FATAL, "btcalc: Module MOM_barotropic must be initialized before it is used.")
   if (.not.CS%split) return
-  if (present(OBC)) then ; if (associated(OBC)) &
-    call MOM_error(FATAL, "btcalc (HIP): open boundary conditions are not supported by the GPU path.") ; endif
+  with_OBC = .false. ; if (present(OBC)) with_OBC = associated(OBC)
   call bind_arrays(CS)
   p_hu = c_null_ptr ; if (present(h_u)) p_hu = c_loc(h_u)
   p_hv = c_null_ptr ; if (present(h_v)) p_hv = c_loc(h_v)
   mud = 0 ; if (present(may_use_default)) mud = merge(1, 0, may_use_default)
-  rc = mom6hip_btcalc(mom6hip_shared_context(G, GV), CS%st, c_loc(h), p_hu, p_hv, int(mud, c_int32_t), MOM6HIP_MEM_HOST)
+  if (with_OBC) then      ! the weights at the faces of the segments are those of the cell inside (:3610-3664)
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(CS%frhatu(:,:,1)), size(CS%frhatv(:,:,1)), "MOM_barotropic")
+    rc = mom6hip_btcalc_obc(mom6hip_shared_context(G, GV), CS%st, c_loc(h), p_hu, p_hv, int(mud, c_int32_t), cobc, MOM6HIP_MEM_HOST)
+  else
+    rc = mom6hip_btcalc(mom6hip_shared_context(G, GV), CS%st, c_loc(h), p_hu, p_hv, int(mud, c_int32_t), MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "btcalc")
 end subroutine btcalc
 

@@ -12,7 +12,7 @@ module MOM_set_visc
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,     only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
-use mom6hip_MOM_glue,     only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
+use mom6hip_MOM_glue,     only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_obc_to_c
 use MOM_ALE,              only : ALE_CS
 use MOM_diag_mediator,    only : diag_ctrl, time_type
 use MOM_error_handler,    only : MOM_error, FATAL, WARNING
@@ -42,6 +42,7 @@ type, public :: set_visc_CS ; private
   type(mom6hip_eos_t) :: eos
   real, allocatable :: Rlay(:)
   type(diag_ctrl), pointer :: diag => NULL()
+  type(ocean_OBC_type), pointer :: OBC => NULL()      !< Open boundaries control structure (set_visc_init :2903)
 end type set_visc_CS
 
 contains
@@ -72,6 +73,8 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   type(porous_barrier_type),intent(in)    :: pbv
   type(mom6hip_vertvisc_type_t) :: cv
   type(mom6hip_eos_t), target :: eos
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
   type(c_ptr) :: p_T, p_S, ctx
   integer :: rc
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(BBL): Module must be initialized before it is used.")
@@ -97,7 +100,11 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   eos = CS%eos
   CS%st%Rlay = c_null_ptr ; if (allocated(CS%Rlay)) CS%st%Rlay = c_loc(CS%Rlay)
   ctx = mom6hip_shared_context(G, GV)
-  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: u, v, h, T, S where the step left them; visc%... where the step reads them
+  if (associated(CS%OBC)) then      ! the OBC branches :374-413, :502-580 and those of set_v_at_u / set_u_at_v, on the host arrays
+    if (mom6hip_resident()) call MOM_error(FATAL, "set_viscous_BBL (HIP): open boundaries with GPU_RESIDENT_DYNAMICS are not provided.")
+    call mom6hip_obc_to_c(CS%OBC, cobc, csegs, size(u(:,:,1)), size(v(:,:,1)), "MOM_set_viscosity")
+    rc = mom6hip_set_viscous_bbl_obc(ctx, CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, cobc, MOM6HIP_MEM_HOST)
+  elseif (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: u, v, h, T, S where the step left them; visc%... where the step reads them
     call to_dev(cv%Kv_bbl_u, size(visc%Kv_bbl_u), .true.) ; call to_dev(cv%Kv_bbl_v, size(visc%Kv_bbl_v), .true.)
     call to_dev(cv%bbl_thick_u, size(visc%bbl_thick_u), .true.) ; call to_dev(cv%bbl_thick_v, size(visc%bbl_thick_v), .true.)
     if (allocated(visc%Ray_u)) then
@@ -142,6 +149,8 @@ subroutine set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)
   integer :: rc
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
   if (CS%st%dynamic_viscous_ML == 0) return      ! :2043-2044 (ice shelves are refused at initialisation)
+  if (associated(CS%OBC)) call MOM_error(FATAL, "set_viscous_ML (HIP): DYNAMIC_VISCOUS_ML with open boundary conditions "// &
+       "(the masks and projections of :2099-2117) is not provided by the GPU path.")
   if (.not.(associated(forces%taux) .and. associated(forces%tauy))) call MOM_error(FATAL, "set_viscous_ML (HIP): "// &
        "forces%taux and forces%tauy must be associated.")
   if (.not.associated(forces%ustar)) call MOM_error(FATAL, "set_viscous_ML (HIP): forces%ustar must be associated (the GPU "// &
@@ -198,7 +207,7 @@ subroutine set_visc_init(Time, G, GV, US, param_file, diag, visc, CS, restart_CS
 
   CS%initialized = .true. ; CS%diag => diag
   isd = G%isd ; ied = G%ied ; jsd = G%jsd ; jed = G%jed
-  if (associated(OBC)) call refuse(.true., "open boundary conditions")
+  CS%OBC => OBC      ! :2903
   if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
   CS%st%unsupported(:) = 0 ; CS%st%reserved1(:) = c_null_ptr ; CS%st%Rlay = c_null_ptr
   CS%st%nkml = GV%nkml

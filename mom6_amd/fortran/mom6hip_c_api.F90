@@ -737,6 +737,16 @@ interface
     integer(c_int) :: rc
   end function mom6hip_btcalc
 
+  !> btcalc with OBC associated
+  function mom6hip_btcalc_obc(ctx, cs, h, h_u, h_v, may_use_default, obc, memspace) bind(c, name="mom6hip_btcalc_obc") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_barotropic_cs_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, h, h_u, h_v
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: may_use_default, memspace
+    integer(c_int) :: rc
+  end function mom6hip_btcalc_obc
+
   function mom6hip_bt_mass_source(ctx, cs, h, eta, set_cor, memspace) bind(c, name="mom6hip_bt_mass_source") result(rc)
     import :: c_int, c_int32_t, c_ptr, mom6hip_barotropic_cs_t
     type(c_ptr), value :: ctx, h, eta
@@ -876,6 +886,17 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_set_viscous_bbl
+
+  !> set_viscous_BBL with CS%OBC associated
+  function mom6hip_set_viscous_bbl_obc(ctx, cs, u, v, h, T, S, eos, visc, obc, memspace) bind(c, name="mom6hip_set_viscous_bbl_obc") result(rc)
+    import :: c_int, c_int32_t, c_ptr, mom6hip_set_visc_cs_t, mom6hip_vertvisc_type_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v, h, T, S, eos
+    type(mom6hip_set_visc_cs_t), intent(in) :: cs
+    type(mom6hip_vertvisc_type_t), intent(in) :: visc
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_set_viscous_bbl_obc
 
   !> set_viscous_ML (:1898): the early return (:2043), or with DYNAMIC_VISCOUS_ML the viscous mixed layer into visc%nkml_visc_u/v
   function mom6hip_set_viscous_ml(ctx, cs, u, v, h, T, S, eos, taux, tauy, visc, dt, memspace) &

@@ -31,8 +31,9 @@ class set_visc_CS:
                  LINEAR_DRAG=False, BBL_USE_EOS=True, CORRECT_BBL_BOUNDS=False, DRAG_AS_BODY_FORCE=False, USE_JACKSON_PARAM=False,
                  Rlay=None, DYNAMIC_VISCOUS_ML=False, NKML=0, BULK_RI_ML=0.0, BULK_RI_ML_VISC=None, TKE_DECAY=0.0, TKE_DECAY_VISC=None,
                  ML_OMEGA_FRAC=0.0, OMEGA=7.2921e-5, CHANNEL_DRAG=False, SMAG_LAP_CONST=-1.0, SMAG_CONST_CHANNEL=None,
-                 TRIG_CHANNEL_DRAG_WIDTHS=True, CHANNEL_DRAG_MAX_BBL_THICK=None, Z_ref=0.0, **unsupported):
+                 TRIG_CHANNEL_DRAG_WIDTHS=True, CHANNEL_DRAG_MAX_BBL_THICK=None, Z_ref=0.0, OBC=None, **unsupported):
         g = G.grid if isinstance(G, DeviceGrid) else G
+        self.OBC = OBC      # CS%OBC => OBC :2903 (an ocean_OBC_type of mom6_amd/open_boundary.py, or None)
         st = self.st = _abi.SetViscCS()
         # DYNAMIC_VISCOUS_ML (:2962) with BULK_RI_ML_VISC (= BULK_RI_ML), TKE_DECAY_VISC (= TKE_DECAY), ML_OMEGA_FRAC, OMEGA; GV%nkml
         st.dynamic_viscous_ML, st.nkml = int(bool(DYNAMIC_VISCOUS_ML)), int(NKML)
@@ -94,6 +95,14 @@ def set_viscous_BBL(u, v, h, tv, visc, G: DeviceGrid, CS: set_visc_CS, pbv=None)
         spaces.add(visc.space)
     if len(spaces) != 1:
         raise Mom6HipError("set_viscous_BBL: the fields and visc must be in the same memory space")
+    if CS.OBC is not None:      # the OBC branches :374-413, :502-580, :1829-1838, :1874-1883
+        obc = CS.OBC.struct(lambda a: (0, None))      # (none of the segments' own arrays is read)
+        L = _setup()
+        L.mom6hip_set_viscous_bbl_obc.argtypes = ([C.c_void_p, C.POINTER(_abi.SetViscCS)] + [C.c_void_p] * 5
+                                                  + [C.POINTER(_abi.EOS), C.POINTER(_abi.VertviscType), C.POINTER(_abi.Obc), C.c_int32])
+        check(L.mom6hip_set_viscous_bbl_obc(G.handle, C.byref(CS.st), *ptrs, None if EOS is None else C.byref(EOS), C.byref(visc.st),
+                                            C.byref(obc), spaces.pop()), "set_viscous_BBL")
+        return
     check(_setup().mom6hip_set_viscous_bbl(G.handle, C.byref(CS.st), *ptrs, None if EOS is None else C.byref(EOS), C.byref(visc.st),
                                            spaces.pop()), "set_viscous_BBL")
 
@@ -104,6 +113,8 @@ def set_viscous_ML(u, v, h, tv, forces, visc, dt, G: DeviceGrid, CS: set_visc_CS
     visc.ustar; writes visc.nkml_visc_u / nkml_visc_v."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
+    if CS.st.dynamic_viscous_ML and getattr(CS, "OBC", None) is not None:
+        raise Mom6HipError("set_viscous_ML (HIP): DYNAMIC_VISCOUS_ML with open boundary conditions is not provided")
     if not CS.st.dynamic_viscous_ML:
         check(_setup().mom6hip_set_viscous_ml(G.handle, C.byref(CS.st), None, None, None, None, None, None, None, None,
                                               C.byref(visc.st), float(dt), _abi.MEM_DEVICE), "set_viscous_ML")

@@ -335,6 +335,11 @@ int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS) {
 /* btcalc :3394 */
 int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
                const double *h_v, int may_use_default) {
+  return orc_btcalc_obc(G, CS, h, h_u, h_v, may_use_default, NULL);
+}
+
+int orc_btcalc_obc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
+                   const double *h_v, int may_use_default, const mom6hip_obc_t *OBC) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const double h_neglect = G->H_subroundoff;
   int use_default = 0;
@@ -398,6 +403,28 @@ int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
 #undef F3
 #undef HP
 #undef HM
+    }
+  }
+  /* :3610-3664: at the faces of the open-boundary segments the weights are those of the cell inside (segment by segment: a
+   * later one has the last word) */
+  if (OBC && OBC->OBC_pe && OBC->number_of_segments > 0) for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->on_pe) continue;
+    const int ns = S->direction == MOM6HIP_OBC_DIRECTION_N || S->direction == MOM6HIP_OBC_DIRECTION_S;
+    if (!ns && !(S->direction == MOM6HIP_OBC_DIRECTION_E || S->direction == MOM6HIP_OBC_DIRECTION_W)) return 3;
+    const int in1 = (S->direction == MOM6HIP_OBC_DIRECTION_S || S->direction == MOM6HIP_OBC_DIRECTION_W) ? 1 : 0;      /* the cell inside */
+    const int A = ns ? S->JsdB : S->IsdB;
+    if (!(A >= (ns ? js : is) - 1 && A <= (ns ? je : ie))) continue;
+    const int c0 = ns ? (is > S->isd ? is : S->isd) : (js > S->jsd ? js : S->jsd), c1 = ns ? (ie < S->ied ? ie : S->ied) : (je < S->jed ? je : S->jed);
+    for (int c = c0; c <= c1; c++) {
+      const int i = ns ? c : A, j = ns ? A : c, ic = ns ? i : i + in1, jc = ns ? j + in1 : j;
+      double htot = h[ORC_H3(G, ic, jc, 1)];
+      for (int k = 2; k <= nz; k++) htot = htot + h[ORC_H3(G, ic, jc, k)];
+      const double Ihtot = (ns ? G->mask2dCv[ORC_V2(G, i, j)] : G->mask2dCu[ORC_U2(G, i, j)]) / (htot + h_neglect);
+      for (int k = 1; k <= nz; k++) {
+        if (ns) CS->frhatv[ORC_V3(G, i, j, k)] = h[ORC_H3(G, ic, jc, k)] * Ihtot;
+        else CS->frhatu[ORC_U3(G, i, j, k)] = h[ORC_H3(G, ic, jc, k)] * Ihtot;
+      }
     }
   }
   return 0;

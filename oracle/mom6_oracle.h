@@ -203,6 +203,9 @@ double orc_cr_acos(double x);            /* correctly rounded acos(x), |x| <= 1 
 int orc_barotropic_init(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS);
 int orc_btcalc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
                const double *h_v, int may_use_default);
+/* btcalc with OBC associated (:3610-3664) */
+int orc_btcalc_obc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *h_u,
+                   const double *h_v, int may_use_default, const mom6hip_obc_t *OBC);
 int orc_bt_mass_source(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *h, const double *eta, int set_cor);
 int orc_set_dtbt_eta(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *eta, const double *pbce,
                      const mom6hip_bt_cont_t *BT_cont, double gtot_est, double SSH_add);
@@ -234,6 +237,10 @@ int orc_vertvisc_remnant(const mom6hip_grid_t *G, const mom6hip_vertvisc_cs_t *C
 /* ---- MOM_set_viscosity (oracle/set_viscosity.c) ---------------------------------------------------------------------- */
 int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
                         const double *T, const double *S, const mom6hip_eos_t *EOS, const mom6hip_vertvisc_type_t *visc);
+/* set_viscous_BBL with CS%OBC associated (:374-413, :502-580, set_v_at_u / set_u_at_v :1829-1838, :1874-1883) */
+int orc_set_viscous_BBL_obc(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
+                            const double *T, const double *S, const mom6hip_eos_t *EOS, const mom6hip_vertvisc_type_t *visc,
+                            const mom6hip_obc_t *OBC);
 int orc_set_viscous_ML(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
                        const double *T, const double *S, const mom6hip_eos_t *EOS, const double *taux, const double *tauy,
                        const mom6hip_vertvisc_type_t *visc, double dt);

@@ -446,9 +446,10 @@ def barotropic_init(grid, cs):
         raise RuntimeError("orc_barotropic_init: unsupported configuration")
 
 
-def btcalc(grid, cs, h, h_u=None, h_v=None, may_use_default=False):
-    L = lib(); L.orc_btcalc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, _dp, _dp, C.c_int]
-    if L.orc_btcalc(C.byref(grid.struct()), C.byref(cs), _p(h), _p(h_u), _p(h_v), int(may_use_default)):
+def btcalc(grid, cs, h, h_u=None, h_v=None, may_use_default=False, OBC=None):
+    L = lib(); L.orc_btcalc_obc.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS), _dp, _dp, _dp, C.c_int, C.POINTER(_abi.Obc)]
+    obc = None if OBC is None else OBC.struct()
+    if L.orc_btcalc_obc(C.byref(grid.struct()), C.byref(cs), _p(h), _p(h_u), _p(h_v), int(may_use_default), None if obc is None else C.byref(obc)):
         raise RuntimeError("btcalc: Inconsistent settings of optional arguments and hvel_scheme.")
 
 
@@ -845,11 +846,13 @@ def set_visc_cs(grid, Hbbl, Kv, cdrag=0.003, drag_bg_vel=0.0, BBL_thick_min=0.0,
     return cs
 
 
-def set_viscous_BBL(grid, cs, u, v, h, T, S, E, visc):
-    L = lib(); L.orc_set_viscous_BBL.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.SetViscCS)] + [_dp] * 5
-                                                + [C.POINTER(_abi.EOS), C.POINTER(_abi.VertviscType)])
-    rc = L.orc_set_viscous_BBL(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(T), _p(S), None if E is None else C.byref(E),
-                               C.byref(visc))
+def set_viscous_BBL(grid, cs, u, v, h, T, S, E, visc, OBC=None):
+    L = lib(); L.orc_set_viscous_BBL_obc.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.SetViscCS)] + [_dp] * 5
+                                                    + [C.POINTER(_abi.EOS), C.POINTER(_abi.VertviscType), C.POINTER(_abi.Obc)])
+    obc = None if OBC is None else OBC.struct()
+    rc = L.orc_set_viscous_BBL_obc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), None if T is None else _p(T),
+                                   None if S is None else _p(S), None if E is None else C.byref(E), C.byref(visc),
+                                   None if obc is None else C.byref(obc))
     if rc:
         raise RuntimeError(f"orc_set_viscous_BBL rc={rc}")
 

@@ -21,13 +21,23 @@ static inline double max2(double a, double b) { return a > b ? a : b; }
 #define U3(i,j,k) ORC_U3(G,i,j,k)
 #define V3(i,j,k) ORC_V3(G,i,j,k)
 
-/* set_v_at_u :1804-1846 (no OBC) */
-static double set_v_at_u(const mom6hip_grid_t *G, const double *v, const double *h, int i, int j, int k) {
+/* the direction of the segment at a face (OBC%segment(OBC%segnum(...))%direction), 0 without one */
+static int seg_dir(const mom6hip_obc_t *OBC, const int32_t *segnum, long f2) {
+  if (!OBC || OBC->number_of_segments <= 0 || segnum[f2] == MOM6HIP_OBC_NONE) return 0;
+  return OBC->segment[segnum[f2] - 1].direction;
+}
+
+/* set_v_at_u :1804-1846; mask2dCv: the mask the caller passes (set_viscous_BBL: its work array mask_v) */
+static double set_v_at_u(const mom6hip_grid_t *G, const double *v, const double *h, int i, int j, int k, const double *mask2dCv,
+                         const mom6hip_obc_t *OBC) {
   const int J = j;
   double hwt[2][2];      /* hwt(i0, j0), i0 = 0:1, j0 = -1:0 -> hwt[i0][j0+1] */
   for (int j0 = -1; j0 <= 0; j0++) for (int i0 = 0; i0 <= 1; i0++) {
     const int i1 = i + i0, J1 = J + j0;
-    hwt[i0][j0 + 1] = (h[H3(i1, J1, k)] + h[H3(i1, J1 + 1, k)]) * G->mask2dCv[ORC_V2(G, i1, J1)];
+    hwt[i0][j0 + 1] = (h[H3(i1, J1, k)] + h[H3(i1, J1 + 1, k)]) * mask2dCv[ORC_V2(G, i1, J1)];
+    const int dir = seg_dir(OBC, OBC ? OBC->segnum_v : NULL, ORC_V2(G, i1, J1));      /* :1829-1838 */
+    if (dir == MOM6HIP_OBC_DIRECTION_N) hwt[i0][j0 + 1] = 2.0 * h[H3(i1, J1, k)] * mask2dCv[ORC_V2(G, i1, J1)];
+    else if (dir == MOM6HIP_OBC_DIRECTION_S) hwt[i0][j0 + 1] = 2.0 * h[H3(i1, J1 + 1, k)] * mask2dCv[ORC_V2(G, i1, J1)];
   }
   const double hwt_tot = (hwt[0][0] + hwt[1][1]) + (hwt[1][0] + hwt[0][1]);
   double r = 0.0;
@@ -37,13 +47,17 @@ static double set_v_at_u(const mom6hip_grid_t *G, const double *v, const double 
   return r;
 }
 
-/* set_u_at_v :1849-1891 (no OBC) */
-static double set_u_at_v(const mom6hip_grid_t *G, const double *u, const double *h, int i, int j, int k) {
+/* set_u_at_v :1849-1891 */
+static double set_u_at_v(const mom6hip_grid_t *G, const double *u, const double *h, int i, int j, int k, const double *mask2dCu,
+                         const mom6hip_obc_t *OBC) {
   const int I = i;
   double hwt[2][2];      /* hwt(i0, j0), i0 = -1:0, j0 = 0:1 -> hwt[i0+1][j0] */
   for (int j0 = 0; j0 <= 1; j0++) for (int i0 = -1; i0 <= 0; i0++) {
     const int I1 = I + i0, j1 = j + j0;
-    hwt[i0 + 1][j0] = (h[H3(I1, j1, k)] + h[H3(I1 + 1, j1, k)]) * G->mask2dCu[ORC_U2(G, I1, j1)];
+    hwt[i0 + 1][j0] = (h[H3(I1, j1, k)] + h[H3(I1 + 1, j1, k)]) * mask2dCu[ORC_U2(G, I1, j1)];
+    const int dir = seg_dir(OBC, OBC ? OBC->segnum_u : NULL, ORC_U2(G, I1, j1));      /* :1874-1883 */
+    if (dir == MOM6HIP_OBC_DIRECTION_E) hwt[i0 + 1][j0] = 2.0 * h[H3(I1, j1, k)] * mask2dCu[ORC_U2(G, I1, j1)];
+    else if (dir == MOM6HIP_OBC_DIRECTION_W) hwt[i0 + 1][j0] = 2.0 * h[H3(I1 + 1, j1, k)] * mask2dCu[ORC_U2(G, I1, j1)];
   }
   const double hwt_tot = (hwt[0][0] + hwt[1][1]) + (hwt[1][0] + hwt[0][1]);
   double r = 0.0;
@@ -448,6 +462,14 @@ int orc_set_viscous_ML(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS,
 
 int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
                         const double *T, const double *S, const mom6hip_eos_t *EOS, const mom6hip_vertvisc_type_t *visc) {
+  return orc_set_viscous_BBL_obc(G, CS, u, v, h, T, S, EOS, visc, NULL);
+}
+
+/* set_viscous_BBL with CS%OBC associated (set_visc_init :2903): the depths and masks of the faces at and beside the segments
+ * :374-413, the zero-gradient projection of the thicknesses, T and S :502-580, the weights of set_v_at_u / set_u_at_v */
+int orc_set_viscous_BBL_obc(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS, const double *u, const double *v, const double *h,
+                            const double *T, const double *S, const mom6hip_eos_t *EOS, const mom6hip_vertvisc_type_t *visc,
+                            const mom6hip_obc_t *OBC) {
   if (!CS->initialized) return 3;      /* "MOM_set_viscosity(BBL): Module must be initialized before it is used." */
   if (unsupported(CS)) return 1;
   if (!CS->bottomdraglaw) return 0;      /* :321 */
@@ -469,6 +491,58 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
   const double BBL_thick_max = CS->BBL_thick_max;
   const int K2 = 2;      /* max(nkmb+1, 2) with nkmb = 0 */
   const long upl = (long)(ORC_NIH(G) + 1) * ORC_NJH(G), vpl = (long)ORC_NIH(G) * (ORC_NJH(G) + 1);
+  if (OBC && OBC->number_of_segments > 0 && !(OBC->segment && OBC->segnum_u && OBC->segnum_v)) return 2;
+  /* :363-413: the depths and the masks of the faces, as work arrays (over the ranges the reference fills) */
+  double *D_u = (double *)calloc((size_t)(2 * upl + 2 * vpl), sizeof(double)), *mask_u = D_u + upl, *D_v = mask_u + upl, *mask_v = D_v + vpl;
+  {
+    const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec;
+    for (int J = js - 1; J <= je; J++) for (int i = is - 1; i <= ie + 1; i++) {
+      D_v[ORC_V2(G, i, J)] = 0.5 * (G->bathyT[ORC_H2(G, i, J)] + G->bathyT[ORC_H2(G, i, J + 1)]) + CS->Z_ref;
+      mask_v[ORC_V2(G, i, J)] = G->mask2dCv[ORC_V2(G, i, J)];
+    }
+    for (int j = js - 1; j <= je + 1; j++) for (int I = is - 1; I <= ie; I++) {
+      D_u[ORC_U2(G, I, j)] = 0.5 * (G->bathyT[ORC_H2(G, I, j)] + G->bathyT[ORC_H2(G, I + 1, j)]) + CS->Z_ref;
+      mask_u[ORC_U2(G, I, j)] = G->mask2dCu[ORC_U2(G, I, j)];
+    }
+#define MAX2I(a, b) ((a) > (b) ? (a) : (b))
+#define MIN2I(a, b) ((a) < (b) ? (a) : (b))
+    if (OBC) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :374-389: a one-sided projection of the depths at the segments' faces */
+      const mom6hip_obc_segment_t *Sg = &OBC->segment[n];
+      if (!Sg->on_pe) continue;
+      const int I = Sg->IsdB, J = Sg->JsdB;
+      if (Sg->is_N_or_S && (J >= js - 1) && (J <= je)) {
+        for (int i = MAX2I(is - 1, Sg->isd); i <= MIN2I(ie + 1, Sg->ied); i++) {
+          if (Sg->direction == MOM6HIP_OBC_DIRECTION_N) D_v[ORC_V2(G, i, J)] = G->bathyT[ORC_H2(G, i, J)] + CS->Z_ref;
+          if (Sg->direction == MOM6HIP_OBC_DIRECTION_S) D_v[ORC_V2(G, i, J)] = G->bathyT[ORC_H2(G, i, J + 1)] + CS->Z_ref;
+        }
+      } else if (Sg->is_E_or_W && (I >= is - 1) && (I <= ie)) {
+        for (int j = MAX2I(js - 1, Sg->jsd); j <= MIN2I(je + 1, Sg->jed); j++) {
+          if (Sg->direction == MOM6HIP_OBC_DIRECTION_E) D_u[ORC_U2(G, I, j)] = G->bathyT[ORC_H2(G, I, j)] + CS->Z_ref;
+          if (Sg->direction == MOM6HIP_OBC_DIRECTION_W) D_u[ORC_U2(G, I, j)] = G->bathyT[ORC_H2(G, I + 1, j)] + CS->Z_ref;
+        }
+      }
+    }
+    if (OBC) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :390-413: then across the corner points of the segments */
+      const mom6hip_obc_segment_t *Sg = &OBC->segment[n];
+      if (!Sg->on_pe) continue;
+      const int I0 = Sg->IsdB, J0 = Sg->JsdB;
+      if (Sg->is_N_or_S && (J0 >= js - 1) && (J0 <= je)) {
+        const int j = J0;
+        for (int I = MAX2I(is - 1, Sg->IsdB); I <= MIN2I(ie, Sg->IedB); I++) {
+          if (Sg->direction == MOM6HIP_OBC_DIRECTION_N) { D_u[ORC_U2(G, I, j + 1)] = D_u[ORC_U2(G, I, j)]; mask_u[ORC_U2(G, I, j + 1)] = 0.0; }
+          else if (Sg->direction == MOM6HIP_OBC_DIRECTION_S) { D_u[ORC_U2(G, I, j)] = D_u[ORC_U2(G, I, j + 1)]; mask_u[ORC_U2(G, I, j)] = 0.0; }
+        }
+      } else if (Sg->is_E_or_W && (I0 >= is - 1) && (I0 <= ie)) {
+        const int i = I0;
+        for (int J = MAX2I(js - 1, Sg->JsdB); J <= MIN2I(je, Sg->JedB); J++) {
+          if (Sg->direction == MOM6HIP_OBC_DIRECTION_E) { D_v[ORC_V2(G, i + 1, J)] = D_v[ORC_V2(G, i, J)]; mask_v[ORC_V2(G, i + 1, J)] = 0.0; }
+          else if (Sg->direction == MOM6HIP_OBC_DIRECTION_W) { D_v[ORC_V2(G, i, J)] = D_v[ORC_V2(G, i + 1, J)]; mask_v[ORC_V2(G, i, J)] = 0.0; }
+        }
+      }
+    }
+#undef MAX2I
+#undef MIN2I
+  }
   if (Ray_u) memset(Ray_u, 0, sizeof(double) * upl * nz);      /* :416-417 */
   if (Ray_v) memset(Ray_v, 0, sizeof(double) * vpl * nz);
 
@@ -499,6 +573,18 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
         dz_vel[k] = 0.5 * (d0 + d1);
         if (use_BBL_EOS) { T_vel[k] = 0.5 * (T[H3(i, j, k)] + T[H3(ip, jp, k)]); S_vel[k] = 0.5 * (S[H3(i, j, k)] + S[H3(ip, jp, k)]); }
       }
+      {      /* :502-580: a zero-gradient projection of the thicknesses, T and S across the faces of the segments */
+        const int dir = (m == 1) ? seg_dir(OBC, OBC ? OBC->segnum_u : NULL, ORC_U2(G, I, j)) : seg_dir(OBC, OBC ? OBC->segnum_v : NULL, ORC_V2(G, i, J));
+        const int first = (dir == MOM6HIP_OBC_DIRECTION_E || dir == MOM6HIP_OBC_DIRECTION_N);
+        if (first || dir == MOM6HIP_OBC_DIRECTION_W || dir == MOM6HIP_OBC_DIRECTION_S) {
+          const int ic = first ? i : ip, jc = first ? j : jp;
+          if ((m == 1) == (dir == MOM6HIP_OBC_DIRECTION_E || dir == MOM6HIP_OBC_DIRECTION_W)) for (int k = 1; k <= nz; k++) {
+            h_at_vel[k] = h[H3(ic, jc, k)]; h_vel[k] = h[H3(ic, jc, k)];
+            dz_at_vel[k] = G->H_to_Z * h[H3(ic, jc, k)]; dz_vel[k] = G->H_to_Z * h[H3(ic, jc, k)];
+            if (use_BBL_EOS) { T_vel[k] = T[H3(ic, jc, k)]; S_vel[k] = S[H3(ic, jc, k)]; }
+          }
+        }
+      }
       /* the near-bottom velocity magnitude and ustar :565-660 */
       double ustar, umag_avg = 0.0, h_bbl_drag = 0.0, dz_bbl_drag = 0.0, T_EOS = 0.0, S_EOS = 0.0;
       if (use_BBL_EOS || CS->body_force_drag || !CS->linear_drag) {
@@ -515,10 +601,10 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
           dzwtot = dzwtot + dzweight;
           if ((!CS->linear_drag) && (hweight >= 0.0)) {
             if (m == 1) {
-              const double v_at_u = set_v_at_u(G, v, h, i, j, k);
+              const double v_at_u = set_v_at_u(G, v, h, i, j, k, mask_v, OBC);
               hutot = hutot + hweight * sqrt(u[U3(I, j, k)] * u[U3(I, j, k)] + v_at_u * v_at_u + u2_bg);
             } else {
-              const double u_at_v = set_u_at_v(G, u, h, i, j, k);
+              const double u_at_v = set_u_at_v(G, u, h, i, j, k, mask_u, OBC);
               hutot = hutot + hweight * sqrt(v[V3(i, J, k)] * v[V3(i, J, k)] + u_at_v * u_at_v + u2_bg);
             }
           }
@@ -623,19 +709,19 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
         vol_below[nz + 1] = 0.0;
         for (int K = nz; K >= 1; K--) vol_below[K] = vol_below[K + 1] + dz_vel[K];
         double D_vel, Dp, Dm, tmp;
-#define D_U(I_, j_) (0.5 * (G->bathyT[ORC_H2(G, I_, j_)] + G->bathyT[ORC_H2(G, (I_) + 1, j_)]) + CS->Z_ref)
-#define D_V(i_, J_) (0.5 * (G->bathyT[ORC_H2(G, i_, J_)] + G->bathyT[ORC_H2(G, i_, (J_) + 1)]) + CS->Z_ref)
+#define D_U(I_, j_) D_u[ORC_U2(G, I_, j_)]
+#define D_V(i_, J_) D_v[ORC_V2(G, i_, J_)]
         if (m == 1) {
           D_vel = D_U(I, j);
-          tmp = G->mask2dCu[ORC_U2(G, I, j + 1)] * D_U(I, j + 1);
+          tmp = mask_u[ORC_U2(G, I, j + 1)] * D_U(I, j + 1);
           Dp = 2.0 * D_vel * tmp / (D_vel + tmp);
-          tmp = G->mask2dCu[ORC_U2(G, I, j - 1)] * D_U(I, j - 1);
+          tmp = mask_u[ORC_U2(G, I, j - 1)] * D_U(I, j - 1);
           Dm = 2.0 * D_vel * tmp / (D_vel + tmp);
         } else {
           D_vel = D_V(i, J);
-          tmp = G->mask2dCv[ORC_V2(G, i + 1, J)] * D_V(i + 1, J);
+          tmp = mask_v[ORC_V2(G, i + 1, J)] * D_V(i + 1, J);
           Dp = 2.0 * D_vel * tmp / (D_vel + tmp);
-          tmp = G->mask2dCv[ORC_V2(G, i - 1, J)] * D_V(i - 1, J);
+          tmp = mask_v[ORC_V2(G, i - 1, J)] * D_V(i - 1, J);
           Dm = 2.0 * D_vel * tmp / (D_vel + tmp);
         }
 #undef D_U
@@ -674,12 +760,12 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
           }
           if (m == 1) {
             if (Rayleigh > 0.0) {
-              const double v_at_u = set_v_at_u(G, v, h, i, j, K);
+              const double v_at_u = set_v_at_u(G, v, h, i, j, K, mask_v, OBC);
               Ray_u[U3(I, j, K)] = Rayleigh * sqrt(u[U3(I, j, K)] * u[U3(I, j, K)] + v_at_u * v_at_u + u2_bg);
             } else Ray_u[U3(I, j, K)] = 0.0;
           } else {
             if (Rayleigh > 0.0) {
-              const double u_at_v = set_u_at_v(G, u, h, i, j, K);
+              const double u_at_v = set_u_at_v(G, u, h, i, j, K, mask_u, OBC);
               Ray_v[V3(i, J, K)] = Rayleigh * sqrt(v[V3(i, J, K)] * v[V3(i, J, K)] + u_at_v * u_at_v + u2_bg);
             } else Ray_v[V3(i, J, K)] = 0.0;
           }
@@ -726,5 +812,6 @@ int orc_set_viscous_BBL(const mom6hip_grid_t *G, const mom6hip_set_visc_cs_t *CS
 #undef VEL
     }
   }
+  free(D_u);
   return 0;
 }

@@ -4,6 +4,7 @@
 !! tests/test_continuity_obc.py, then
 !!   continuity(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont)
 !!   CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv)                         (MOM_dynamics_split_RK2.F90:869)
+!!   set_visc_init(..., OBC) ; set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)     (MOM.F90:1205; layer mode, as .testing/tc3)
 !!   vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, VarMix) ; vertvisc(u, v, h, forces, visc, dt, OBC, ...)   (:717-731)
 !! on plain host arrays; the results go to the output file, which the test compares with the oracle bit for bit.
 !! Usage: obc_driver <input file> <output file>
@@ -11,6 +12,8 @@ program obc_driver
 use, intrinsic :: iso_c_binding
 use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_PPM_CS
 use MOM_CoriolisAdv,    only : CorAdCalc, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_CS
+use MOM_set_visc,       only : set_visc_CS, set_visc_init, set_viscous_BBL, set_visc_end
+use MOM_restart,        only : MOM_restart_CS
 use MOM_vert_friction,  only : vertvisc_CS, vertvisc_init, vertvisc_coef, vertvisc, vertvisc_end
 use MOM_variables,      only : accel_diag_ptrs, cont_diag_ptrs, vertvisc_type, thermo_var_ptrs, ocean_internal_state
 use MOM_forcing_type,   only : mech_forcing
@@ -52,6 +55,8 @@ type(ocean_internal_state), target :: MIS
 type(directories) :: dirs
 type(vertvisc_CS), pointer :: VV => NULL()
 type(vertvisc_type) :: visc
+type(set_visc_CS) :: SVC
+type(MOM_restart_CS) :: restart_CS
 type(thermo_var_ptrs) :: tv
 type(mech_forcing) :: forces
 type(cont_diag_ptrs) :: CDp
@@ -148,16 +153,19 @@ call CoriolisAdv_init(Time, G, GV, US, pf, diag, AD, CCS)
 allocate(CAu(isd-1:ied,jsd:jed,nk), CAv(isd:ied,jsd-1:jed,nk)) ; CAu = 0.0 ; CAv = 0.0
 call CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CCS, pbv)
 
-! the vertical viscosity of the predictor (:717-731) with the bottom boundary layer and the wind stress as plain functions of the grid
-allocate(visc%Kv_bbl_u(isd-1:ied,jsd:jed), visc%bbl_thick_u(isd-1:ied,jsd:jed), visc%Kv_bbl_v(isd:ied,jsd-1:jed), &
-         visc%bbl_thick_v(isd:ied,jsd-1:jed), forces%taux(isd-1:ied,jsd:jed), forces%tauy(isd:ied,jsd-1:jed))
-visc%Kv_bbl_u(:,:) = 1.0e-3 + 2.0e-4*G%mask2dCu(:,:) ; visc%bbl_thick_u(:,:) = 3.0 + 1.0e-4*G%dxCu(:,:)
-visc%Kv_bbl_v(:,:) = 2.0e-3 - 3.0e-4*G%mask2dCv(:,:) ; visc%bbl_thick_v(:,:) = 4.0 + 1.0e-4*G%dyCv(:,:)
+! the bottom boundary layer in layer mode (ENABLE_THERMODYNAMICS = False: GV%Rlay), then the vertical viscosity of the predictor
+! (:717-731) with the wind stress as a plain function of the grid
+allocate(GV%Rlay(nk))
+do n=1,nk ; GV%Rlay(n) = 1025.0 + 0.5*real(n-1) ; enddo
+call param_set(pf, "ENABLE_THERMODYNAMICS", "False") ; call param_set(pf, "HBBL", "10.0") ; call param_set(pf, "KV", "1.0e-4")
+call param_set(pf, "DRAG_BG_VEL", "0.05") ; call param_set(pf, "BBL_THICK_MIN", "0.1") ; call param_set(pf, "CDRAG", "0.002")
+call set_visc_init(Time, G, GV, US, pf, diag, visc, SVC, restart_CS, OBC)
+call set_viscous_BBL(u, v, h, tv, visc, G, GV, US, SVC, pbv)
+allocate(forces%taux(isd-1:ied,jsd:jed), forces%tauy(isd:ied,jsd-1:jed))
 forces%taux(:,:) = 0.05*G%mask2dCu(:,:) ; forces%tauy(:,:) = -0.02*G%mask2dCv(:,:)
 allocate(dz(isd:ied,jsd:jed,nk), u1(isd-1:ied,jsd:jed,nk), v1(isd:ied,jsd-1:jed,nk))
 dz(:,:,:) = GV%H_to_Z * h(:,:,:) ; u1 = u ; v1 = v
-call param_set(pf, "HBBL", "10.0") ; call param_set(pf, "KV", "1.0e-4") ; call param_set(pf, "DT", "900.0")
-call param_set(pf, "HMIX_FIXED", "20.0")
+call param_set(pf, "DT", "900.0") ; call param_set(pf, "HMIX_FIXED", "20.0")
 call vertvisc_init(MIS, Time, G, GV, US, pf, diag, AD, dirs, ntrunc, VV)
 call vertvisc_coef(u1, v1, h, dz, forces, visc, tv, dt, G, GV, US, VV, OBC, VarMix)
 call vertvisc(u1, v1, h, forces, visc, dt, OBC, AD, CDp, G, GV, US, VV)
@@ -167,9 +175,9 @@ write(u_out) hp, uh, vh, u_cor, v_cor
 write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_EE
 write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
 write(u_out) CAu, CAv
-write(u_out) u1, v1
+write(u_out) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v, u1, v1
 close(u_out)
-call vertvisc_end(VV)
+call vertvisc_end(VV) ; call set_visc_end(visc, SVC)
 call CoriolisAdv_end(CCS)
 call mom6hip_shared_context_end()
 write(*,'(a)') "obc_driver ok"

@@ -327,10 +327,13 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
             s.tangential_vel[:] = 0.1 * rng.standard_normal(s.tangential_vel.shape)
     want = run(g, st, OBC)
     want["CAu"], want["CAv"] = orc.coradcalc(g, st["u"], st["v"], st["h"], want["uh"], want["vh"], bound_coriolis=True, OBC=OBC)
-    # vertvisc_coef / vertvisc with the bottom boundary layer and the wind stress the driver states
+    # set_viscous_BBL in layer mode (tc3's CDRAG, DRAG_BG_VEL, BBL_THICK_MIN), then vertvisc_coef / vertvisc with the wind stress the driver states
     m = g.metrics
-    visc = orc.vertvisc_type(Kv_bbl_u=1.0e-3 + 2.0e-4 * m["mask2dCu"], bbl_thick_u=3.0 + 1.0e-4 * m["dxCu"],
-                             Kv_bbl_v=2.0e-3 - 3.0e-4 * m["mask2dCv"], bbl_thick_v=4.0 + 1.0e-4 * m["dyCv"])
+    visc = orc.vertvisc_type(Kv_bbl_u=g.zeros2(_abi.POS_U), bbl_thick_u=g.zeros2(_abi.POS_U), Kv_bbl_v=g.zeros2(_abi.POS_V), bbl_thick_v=g.zeros2(_abi.POS_V))
+    orc.set_viscous_BBL(g, orc.set_visc_cs(g, 10.0, 1.0e-4, cdrag=0.002, drag_bg_vel=0.05, BBL_thick_min=0.1, BBL_use_EOS=False,
+                                           Rlay=1025.0 + 0.5 * np.arange(g.nk)), st["u"], st["v"], st["h"], None, None, None, visc, OBC=OBC)
+    for n in ("bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v"):
+        want[n] = visc._keep[n]
     vcs = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, Hmix=20.0)
     want["u1"], want["v1"] = st["u"].copy(), st["v"].copy()
     orc.vertvisc_coef(g, vcs, want["u1"], want["v1"], st["h"], visc, 900.0, OBC=OBC)
@@ -341,9 +344,9 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
     assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
-             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "u1", "v1"]
+             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u1", "v1"]
     arrs = [want[n] if n in want else want["bt"][n] for n in names]
     got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
     for n, a, w in zip(names, got, arrs):
-        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu", "u1") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv", "v1") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu", "u1", "bbl_thick_u", "Kv_bbl_u") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv", "v1", "bbl_thick_v", "Kv_bbl_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
         assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
