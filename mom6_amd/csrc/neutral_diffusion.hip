@@ -2,19 +2,21 @@
 // as gfx950 kernels, called from tracer_hordiff's neutral branch (MOM_tracer_hor_diff.F90:474-534; tracer_hor_diff.hip).
 //
 //   nd_column_kernel      neutral_diffusion_calc_coeffs :337-470 for one h column (halo 1): interface pressures, interface T and S by
-//                         interface_scalar (:1078, PLM_diff + ppm_edge), their density derivatives -> five [nk+1] columns
+//                         interface_scalar (:1078, PLM_diff + ppm_edge), their density derivatives -> one record of five numbers an interface
 //   nd_surfaces_kernel    find_neutral_surface_positions_continuous (:1353) for one face: the merge walk down the 2nk+2 interfaces of
 //                         the two columns; PoL, PoR, KoL, KoR, hEff (back in H units, :570-575) as [surface][face] planes
-//   nd_tracer_cols_kernel interface values of a tracer (neutral_surface_flux :2373-2374) for one h column; the limited PPM edge values of a
-//                         cell (ppm_left_right_edge_values :2541) are formed in the flux kernel from the two interface values it has
-//                         read anyway and the cell mean, when a surface enters the cell
-//   nd_flux_kernel        neutral_surface_flux (:2297) for one face -> Flx [surface][face]; the surfaces of the face are read once for a
-//                         batch of up to 4 tracers (their fluxes are independent of each other)
-//   nd_update_kernel      the tendencies of a cell from its four faces in the reference's order of the surfaces (:927-954), accumulated
-//                         per layer in LDS (the layer index is data: KoL / KoR), and the update of the tracer (:955-959)
-// A lane owns a column or a face and walks it: the walks are serial in the surface index and differ from lane to lane, the planes
-// keep the lanes' accesses to one surface coalesced.  Traffic per call: ~30 (nk+1) doubles per column for the surfaces, and per tracer
-// ~5 (2nk+2) doubles per face.
+//   nd_tracer_cols_kernel interface values of a batch of up to 4 tracers (neutral_surface_flux :2373-2374) for one h column, with the means
+//                         of the cells: one record of eight numbers an interface
+//   nd_flux_kernel        neutral_surface_flux (:2297) for one face and the batch.  With the sums in the symmetric order
+//                         (NDIFF_ANSWER_DATE > 20240330, :939-954: a face at a time) the kernel leaves the tendencies of the layers of the
+//                         two cells of the face -- a surface never lies above the one before it, so a layer's sum is a run of consecutive
+//                         surfaces and is kept in a register -- and nd_update_sym_kernel adds the four faces of a cell and updates the
+//                         tracer (:955-959).  With the older order (:927-938: surface by surface round the four faces) it leaves the
+//                         fluxes [surface][face] and nd_update_kernel accumulates them per layer in LDS.
+// A lane owns a column or a face and walks it: the walks are serial in the surface index and differ from lane to lane.  What a walk
+// reads at a depth of its own (the interfaces of a column) is stored as records, so that a gather is one or two sectors and not one a
+// number, and kept in registers while the walk stays in the cell: a step down a column loads one record.  What all lanes read at the
+// same step (the surfaces of a face) is stored as planes.  The blocks are dealt to the XCDs by their range of i (xcd_block).
 #include <cfloat>
 #include <cmath>
 
@@ -41,12 +43,9 @@ __device__ __forceinline__ double fv_diff(double hkm1, double hk, double hkp1, d
   return (hk * h_sum) * ((2. * hkm1 + hk) * hp * (Skp1 - Sk) + (2. * hkp1 + hk) * hm * (Sk - Skm1));
 }
 
-// PLM_diff :1211 with c_method = 2, b_method = 1, for layer k (0-based) of the column at n2
-__device__ __forceinline__ double plm_diff(const double *__restrict__ h, const double *__restrict__ S, long n2, long hpl, int k, int nk) {
-  if (k <= 0 || k >= nk - 1) return 0.;
-  const double hkm1 = h[n2 + hpl * (k - 1)], hk = h[n2 + hpl * k], hkp1 = h[n2 + hpl * (k + 1)];
+// PLM_diff :1211 with c_method = 2, b_method = 1, for an interior layer from its own and its two neighbours' thicknesses and values
+__device__ __forceinline__ double plm_diff(double hkm1, double hk, double hkp1, double Skm1, double Sk, double Skp1) {
   if (!((hkp1 + hk) * (hkm1 + hk) > 0.)) return 0.;
-  const double Skm1 = S[n2 + hpl * (k - 1)], Sk = S[n2 + hpl * k], Skp1 = S[n2 + hpl * (k + 1)];
   const double diff_c = fv_diff(hkm1, hk, hkp1, Skm1, Sk, Skp1);
   const double diff_l = 2. * (Sk - Skm1), diff_r = 2. * (Skp1 - Sk);
   if (signum(1., diff_l) * signum(1., diff_r) <= 0.) return 0.;
@@ -70,20 +69,40 @@ __device__ __forceinline__ double ppm_edge(double hkm1, double hk, double hkp1, 
   return e + f1 * (f2 * (Akp1 - Ak) - (f3 * Pkp1 - f4 * Pk));
 }
 
-// interface_scalar :1078 with i_method = 2, walked down the column: call with K = 0 .. nk in order; d_prev carries diff(K-1)
-__device__ __forceinline__ double interface_value(const double *__restrict__ h, const double *__restrict__ S, long n2, long hpl, int K, int nk,
-                                                  double h_neglect, double &d_prev) {
-  if (K == 0) {
-    d_prev = plm_diff(h, S, n2, hpl, 0, nk);
-    return S[n2] - 0.5 * d_prev;
+// interface_scalar :1078 with i_method = 2 for NZ fields of one column, walked down the interfaces K = 0 .. nk: out(K, v, m) gets the
+// interface values v[z] and the means m[z] of the cell below the interface (0 at K = nk).  The walk keeps the four thicknesses and three
+// values an interface reads in registers and loads one new layer a step (the reference's expressions on the same numbers).
+template <int NZ, typename F>
+__device__ __forceinline__ void walk_interfaces(const double *__restrict__ h, const double *const *S, int nz, long n2, long hpl, int nk,
+                                                double h_neglect, F out) {
+  const int k2 = (2 < nk - 1) ? 2 : nk - 1;
+  double hB = h[n2], hC = h[n2 + hpl], hD = h[n2 + hpl * k2], hA = hB;
+  double sB[NZ], sC[NZ], sD[NZ], dp[NZ], v[NZ];
+#pragma unroll
+  for (int z = 0; z < NZ; z++) {
+    sB[z] = sC[z] = sD[z] = 0.; dp[z] = 0.;      // plm_diff of the top layer is 0
+    if (z < nz) { sB[z] = S[z][n2]; sC[z] = S[z][n2 + hpl]; sD[z] = S[z][n2 + hpl * k2]; }
   }
-  if (K == nk) return S[n2 + hpl * (nk - 1)] + 0.5 * d_prev;
-  const int km2 = (K - 2 > 0) ? K - 2 : 0, kp1 = (K + 1 < nk - 1) ? K + 1 : nk - 1;
-  const double d = plm_diff(h, S, n2, hpl, K, nk);
-  const double v = ppm_edge(h[n2 + hpl * km2], h[n2 + hpl * (K - 1)], h[n2 + hpl * K], h[n2 + hpl * kp1], S[n2 + hpl * (K - 1)], S[n2 + hpl * K],
-                            d_prev, d, h_neglect);
-  d_prev = d;
-  return v;
+#pragma unroll
+  for (int z = 0; z < NZ; z++) v[z] = sB[z] - 0.5 * dp[z];
+  out(0, v, sB);
+  for (int K = 1; K < nk; K++) {      // hA, hB, hC, hD = h(max(K-2, 0)), h(K-1), h(K), h(min(K+1, nk-1)); sB, sC, sD = S(K-1), S(K), S(min(K+1, nk-1))
+#pragma unroll
+    for (int z = 0; z < NZ; z++) {
+      const double d = (K < nk - 1) ? plm_diff(hB, hC, hD, sB[z], sC[z], sD[z]) : 0.;
+      v[z] = ppm_edge(hA, hB, hC, hD, sB[z], sC[z], dp[z], d, h_neglect);
+      dp[z] = d;
+    }
+    out(K, v, sC);
+    const int kn = (K + 2 < nk - 1) ? K + 2 : nk - 1;
+    hA = hB; hB = hC; hC = hD; hD = h[n2 + hpl * kn];
+#pragma unroll
+    for (int z = 0; z < NZ; z++) { sB[z] = sC[z]; sC[z] = sD[z]; if (z < nz) sD[z] = S[z][n2 + hpl * kn]; }
+  }
+  double zero[NZ];
+#pragma unroll
+  for (int z = 0; z < NZ; z++) { v[z] = sB[z] + 0.5 * dp[z]; zero[z] = 0.; }
+  out(nk, v, zero);
 }
 
 // interpolate_for_nondim_position :1563
@@ -120,6 +139,17 @@ __device__ __forceinline__ void ppm_edges(double Ti0, double Ti1, double Tl, dou
   else if (fsign(3., aR - aL) * ((Tl - aL) + (Tl - aR)) < -fabs(aR - aL)) aR = Tl + 2.0 * (Tl - aL);
 }
 
+constexpr int IREC = 5;      // an interface of a column: P, T, S, drho/dT, drho/dS
+#ifndef ND_IREC_AOS
+#define ND_IREC_AOS 0
+#endif
+// where field q of interface K (0-based) of the column c is: planes [field][K][h points] (the columns of a wave stand at nearly the same
+// depth of their walks: a load of the wave is a few lines) or records [K][h points][field]
+__device__ __forceinline__ long irec_at(long K, long c, int q, long hpl, int nk) {
+  return ND_IREC_AOS ? (K * hpl + c) * IREC + q : ((long)q * (nk + 1) + K) * hpl + c;
+}
+constexpr int TREC = 2 * ND_BATCH;      // an interface of a column for a batch of tracers: their interface values, the means of the cell below
+
 struct NDArgs {
   m6::GridDev g;
   EosDev E;
@@ -130,22 +160,39 @@ struct NDArgs {
   int interior;                     // NDIFF_INTERIOR_ONLY
   const double *hbl;                // the boundary-layer depth visc%h_ML with its halo (interior)
   int *kbot; double *zbot;          // boundary_k_range of every column: the layer and the fraction of it the boundary layer ends in
-  double *Pint, *Tint, *Sint, *dRdT, *dRdS;   // [(nk+1)][h points]
-  double *PoL[2], *PoR[2], *hEff[2], *Flx[2]; // [surface][faces of the direction]; Flx: + flx_stride per tracer of the batch
+  double *irec;                     // [(nk+1)][h points][IREC]: the interfaces of the columns as records (a walk's gather reads one record)
+  double *PoL[2], *PoR[2], *hEff[2]; // [surface][faces of the direction]
+  double *Flx[2];                   // (the order of 2024 and before) [surface][faces], + flx_stride per tracer of the batch
+  double *tend[2][2];               // (the symmetric order) [direction][side of the face: the cell it is the E | N face of, the W | S face of]
+                                    // [layer][faces]: the tendency of the cell's layer from this face, + flx_stride per tracer
   ko_t *KoL[2], *KoR[2];
   const double *khdt[2];
   int nb;                           // tracers in this batch (<= ND_BATCH): the surfaces are read once for all of them
   double *t[ND_BATCH];              // the tracers being diffused
-  double *Ti;                       // their interface values, [(nk+1)][h points], + col_stride per tracer
-  long col_stride, flx_stride;
-  double *stash;                    // [3][nk][h points], the symmetric form's N, S, E tendencies, + 3 nk hpl per tracer
+  double *trec;                     // [(nk+1)][h points][TREC]: interface values and cell means of the batch's tracers
+  long flx_stride;
   double cu[ND_BATCH];              // conc_underflow of the tracers
   int *bad;
 };
 
-__global__ __launch_bounds__(64) void nd_column_kernel(NDArgs A) {
+// Workgroups go round the eight XCDs by their index; a face reads the columns on its two sides, so the blocks of one range of i are given
+// to one XCD, row after row: the column a row's faces read on their far side is in that XCD's L2 when the next row asks for it.
+#ifndef ND_XCD
+#define ND_XCD 0      // (measured: no gain on the benchmark grid, profiles/r04_experiments.txt section 9)
+#endif
+__device__ __forceinline__ bool xcd_block(int nbx, int nby, int &bx, int &by) {
+  const int L = blockIdx.x, xcd = L & 7, q = L >> 3, per = (nbx + 7) >> 3;
+  if (ND_XCD) { bx = xcd + 8 * (q % per); by = q / per; }
+  else { const int nb8 = 8 * per; bx = L % nb8; by = L / nb8; }
+  return bx < nbx && by < nby;
+}
+inline int xcd_grid(int nbx, int nby) { return 8 * ((nbx + 7) >> 3) * nby; }
+
+__global__ __launch_bounds__(64) void nd_column_kernel(NDArgs A, int nbx, int nby) {
   const m6::GridDev &g = A.g;
-  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk;
+  int bx, by;
+  if (!xcd_block(nbx, nby, bx, by)) return;
+  const int i = g.isc - 1 + bx * 64 + threadIdx.x, j = g.jsc - 1 + by, nk = g.nk;
   if (i > g.iec + 1) return;
   const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
   if (A.interior) {      // boundary_k_range(SURFACE, ...), src/tracer/MOM_hor_bnd_diffusion.F90:609-647, for wet columns (:381-386)
@@ -165,23 +212,28 @@ __global__ __launch_bounds__(64) void nd_column_kernel(NDArgs A) {
     }
     A.kbot[n2] = k_bot; A.zbot[n2] = zeta_bot;
   }
-  double P = A.p_surf ? A.p_surf[n2] : 0., dT = 0., dS = 0.;
-  for (int K = 0; K <= nk; K++) {
-    if (K > 0) P = P + A.h[n2 + hpl * (K - 1)] * A.gH;
-    const double Ti = interface_value(A.h, A.T, n2, hpl, K, nk, A.h_neglect, dT);
-    const double Si = interface_value(A.h, A.S, n2, hpl, K, nk, A.h_neglect, dS);
+  double P = A.p_surf ? A.p_surf[n2] : 0.;
+  const double *TS[2] = {A.T, A.S};
+  double h_above = 0.;
+  walk_interfaces<2>(A.h, TS, 2, n2, hpl, nk, A.h_neglect, [&](int K, const double *v, const double *m) {
+    (void)m;
+    if (K > 0) P = P + h_above * A.gH;
+    if (K < nk) h_above = A.h[n2 + hpl * K];
     double rT, rS;
-    eos_density_derivs(A.E, Ti, Si, (A.ref_pres >= 0.) ? A.ref_pres : P, rT, rS);
-    A.Pint[n2 + hpl * K] = P; A.Tint[n2 + hpl * K] = Ti; A.Sint[n2 + hpl * K] = Si;
-    A.dRdT[n2 + hpl * K] = rT; A.dRdS[n2 + hpl * K] = rS;
-  }
+    eos_density_derivs(A.E, v[0], v[1], (A.ref_pres >= 0.) ? A.ref_pres : P, rT, rS);
+    double *r = A.irec;
+    r[irec_at(K, n2, 0, hpl, nk)] = P; r[irec_at(K, n2, 1, hpl, nk)] = v[0]; r[irec_at(K, n2, 2, hpl, nk)] = v[1];
+    r[irec_at(K, n2, 3, hpl, nk)] = rT; r[irec_at(K, n2, 4, hpl, nk)] = rS;
+  });
 }
 
 // find_neutral_surface_positions_continuous :1353 (KoL / KoR keep the reference's 1-based layer numbers)
 template <int DIR>
-__global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
+__global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A, int nbx, int nby) {
   const m6::GridDev &g = A.g;
-  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x, j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y, nk = g.nk;
+  int bx, by;
+  if (!xcd_block(nbx, nby, bx, by)) return;
+  const int i = (DIR ? g.isc : g.isc - 1) + bx * 64 + threadIdx.x, j = (DIR ? g.jsc - 1 : g.jsc) + by, nk = g.nk;
   if (i > g.iec) return;
   const long f = DIR ? g.v2(i, j) : g.u2(i, j), pl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
   const long hpl = (long)g.nih * g.njh, cl = g.h2(i, j), cr = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
@@ -195,16 +247,19 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
     }
     return;
   }
-  const double *__restrict__ Pint = A.Pint, *__restrict__ Tint = A.Tint, *__restrict__ Sint = A.Sint, *__restrict__ dRdT = A.dRdT,
-                             *__restrict__ dRdS = A.dRdS;
-#define LC(a, k) a[cl + hpl * ((k) - 1)]
-#define RC(a, k) a[cr + hpl * ((k) - 1)]
+  const double *__restrict__ irec = A.irec;
   // The walk reads interface klm1 = max(kl-1, 1), klm1+1 and kl of the left column (and the same of the right): two interfaces a side
   // are kept in registers -- A at klm1, B at klm1+1; interface kl is A while kl = 1 and B afterwards -- and a step that moves kl or kr
-  // down by one loads one new interface (the lanes of a wave stand at different depths, so every load here is a gather).
+  // down by one loads one new interface: one record (the lanes of a wave stand at different depths, so every load here is a gather).
   struct Iface { double P, T, S, rT, rS; };
-  auto loadL = [&](int k) { return Iface{LC(Pint, k), LC(Tint, k), LC(Sint, k), LC(dRdT, k), LC(dRdS, k)}; };
-  auto loadR = [&](int k) { return Iface{RC(Pint, k), RC(Tint, k), RC(Sint, k), RC(dRdT, k), RC(dRdS, k)}; };
+  auto load = [&](long c, int k) {
+    return Iface{irec[irec_at(k - 1, c, 0, hpl, nk)], irec[irec_at(k - 1, c, 1, hpl, nk)], irec[irec_at(k - 1, c, 2, hpl, nk)],
+                 irec[irec_at(k - 1, c, 3, hpl, nk)], irec[irec_at(k - 1, c, 4, hpl, nk)]};
+  };
+  auto loadL = [&](int k) { return load(cl, k); };
+  auto loadR = [&](int k) { return load(cr, k); };
+  auto PL = [&](int k) { return irec[irec_at(k - 1, cl, 0, hpl, nk)]; };
+  auto PR = [&](int k) { return irec[irec_at(k - 1, cr, 0, hpl, nk)]; };
   Iface LA = loadL(1), LB = loadL(2), RA = loadR(1), RB = loadR(2);
   const int bl_kl = A.interior ? A.kbot[cl] : 0, bl_kr = A.interior ? A.kbot[cr] : 0;      // :1508-1521 (no layer number is <= 0)
   const double bl_zl = A.interior ? A.zbot[cl] : 0., bl_zr = A.interior ? A.zbot[cr] : 0.;
@@ -260,8 +315,8 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
     PoL[f + pl * ks] = pL; PoR[f + pl * ks] = pR; KoL[f + pl * ks] = (ko_t)oKL; KoR[f + pl * ks] = (ko_t)oKR;
     lastK_left = oKL; lastP_left = pL; lastK_right = oKR; lastP_right = pR;
     // absolute_position :2258 of this surface; that of the one above is the value formed a step ago from the same expression
-    const double PL0 = LC(Pint, oKL), PR0 = RC(Pint, oKR);
-    const double absL = PL0 + pL * (LC(Pint, oKL + 1) - PL0), absR = PR0 + pR * (RC(Pint, oKR + 1) - PR0);
+    const double PL0 = PL(oKL), PR0 = PR(oKR);
+    const double absL = PL0 + pL * (PL(oKL + 1) - PL0), absR = PR0 + pR * (PR(oKR + 1) - PR0);
     if (ks > 0) {
       const double hL = absL - absL_prev, hR = absR - absR_prev;
       double he = 0.;
@@ -270,93 +325,187 @@ __global__ __launch_bounds__(64) void nd_surfaces_kernel(NDArgs A) {
     }
     absL_prev = absL; absR_prev = absR;
   }
-#undef LC
-#undef RC
 }
 
-__global__ __launch_bounds__(64) void nd_tracer_cols_kernel(NDArgs A) {
+// the interface values of the batch's tracers (neutral_surface_flux :2373-2374) and the means of their cells, as records
+__global__ __launch_bounds__(64) void nd_tracer_cols_kernel(NDArgs A, int nbx, int nby) {
   const m6::GridDev &g = A.g;
-  const int i = g.isc - 1 + blockIdx.x * 64 + threadIdx.x, j = g.jsc - 1 + blockIdx.y, nk = g.nk, z = blockIdx.z;
+  int bx, by;
+  if (!xcd_block(nbx, nby, bx, by)) return;
+  const int i = g.isc - 1 + bx * 64 + threadIdx.x, j = g.jsc - 1 + by, nk = g.nk;
   if (i > g.iec + 1) return;
   const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
-  const double *__restrict__ t = A.t[z];
-  double *__restrict__ oTi = A.Ti + A.col_stride * z;
-  double d = 0.;
-  for (int K = 0; K <= nk; K++) oTi[n2 + hpl * K] = interface_value(A.h, t, n2, hpl, K, nk, A.h_neglect, d);
+  const double *ts[ND_BATCH];
+#pragma unroll
+  for (int z = 0; z < ND_BATCH; z++) ts[z] = A.t[z < A.nb ? z : 0];
+  walk_interfaces<ND_BATCH>(A.h, ts, A.nb, n2, hpl, nk, A.h_neglect, [&](int K, const double *v, const double *m) {
+    double2 *r = (double2 *)(A.trec + ((long)K * hpl + n2) * TREC);
+    r[0] = make_double2(v[0], v[1]); r[1] = make_double2(v[2], v[3]);
+    r[2] = make_double2(m[0], m[1]); r[3] = make_double2(m[2], m[3]);
+  });
 }
 
-// neutral_surface_flux :2297 (continuous, no tapering: khtr_ave = 1)
-template <int DIR>
-__global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A) {
+// neutral_surface_flux :2297 (continuous, no tapering: khtr_ave = 1).  SYM: the tendencies of the two cells of the face from its fluxes,
+// layer by layer (the order of the sums of neutral_diffusion :939-954: a face at a time, its surfaces top down); otherwise the fluxes
+template <int DIR, bool SYM>
+__global__ __launch_bounds__(64) void nd_flux_kernel(NDArgs A, int nbx, int nby) {
   const m6::GridDev &g = A.g;
-  const int i = (DIR ? g.isc : g.isc - 1) + blockIdx.x * 64 + threadIdx.x, j = (DIR ? g.jsc - 1 : g.jsc) + blockIdx.y;
+  int bx, by;
+  if (!xcd_block(nbx, nby, bx, by)) return;
+  const int i = (DIR ? g.isc : g.isc - 1) + bx * 64 + threadIdx.x, j = (DIR ? g.jsc - 1 : g.jsc) + by;
   if (i > g.iec) return;
   const long f = DIR ? g.v2(i, j) : g.u2(i, j), pl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
   const long hpl = (long)g.nih * g.njh, cl = g.h2(i, j), cr = DIR ? g.h2(i, j + 1) : g.h2(i + 1, j);
   double *__restrict__ Flx = A.Flx[DIR];
-  const int ns = A.ns, nb = A.nb;
+  double *__restrict__ tdL = A.tend[DIR][0], *__restrict__ tdR = A.tend[DIR][1];
+  const int ns = A.ns, nb = A.nb, nk = g.nk;
   if (!((DIR ? g.mask2dCv[f] : g.mask2dCu[f]) > 0.0)) {
-    for (int z = 0; z < nb; z++)
-      for (int ks = 0; ks < ns - 1; ks++) Flx[A.flx_stride * z + f + pl * ks] = 0.;
+    for (int z = 0; z < nb; z++) {
+      if (SYM) for (int k = 0; k < nk; k++) { tdL[A.flx_stride * z + f + pl * k] = 0.; tdR[A.flx_stride * z + f + pl * k] = 0.; }
+      else for (int ks = 0; ks < ns - 1; ks++) Flx[A.flx_stride * z + f + pl * ks] = 0.;
+    }
     return;
   }
   const double *__restrict__ PiL = A.PoL[DIR], *__restrict__ PiR = A.PoR[DIR], *__restrict__ hEff = A.hEff[DIR];
   const ko_t *__restrict__ KoL = A.KoL[DIR], *__restrict__ KoR = A.KoR[DIR];
+  const double cf = A.scale * A.khdt[DIR][f];
   int bad = 0;
   double pLt = PiL[f], pRt = PiR[f];
   int klt = KoL[f] - 1, krt = KoR[f] - 1;
-  // per tracer: the value at the top surface (the reference's T_*_top of a layer is its T_*_bottom of the layer above: the same
-  // expression of the same numbers) and the edge / mean values of the cells klt, krt, reloaded when the surface enters another cell
-  double Ttop_l[ND_BATCH], Ttop_r[ND_BATCH], eL_l[ND_BATCH], eR_l[ND_BATCH], tm_l[ND_BATCH], eL_r[ND_BATCH], eR_r[ND_BATCH], tm_r[ND_BATCH];
+  // A side of the face: the cell the surface is in, with the records of the interfaces above and below it (the interface values i0, i1 of
+  // the batch's tracers, the means m0 of the cell and m1 of the cell below), the limited edge values of the cell
+  // (ppm_left_right_edge_values :2541) and the value at the surface above (the reference's T_*_top of a sublayer is its T_*_bottom of the
+  // sublayer above: the same expression of the same numbers).  A surface that enters the next cell needs one new record.
+  struct Side { double i0[ND_BATCH], i1[ND_BATCH], m0[ND_BATCH], m1[ND_BATCH], eL[ND_BATCH], eR[ND_BATCH], top[ND_BATCH]; };
+  auto load = [&](long c, int K, double *iv, double *mv) {
+    const double2 *r = (const double2 *)(A.trec + ((long)K * hpl + c) * TREC);
+    const double2 a = r[0], b = r[1], c2 = r[2], d = r[3];
+    iv[0] = a.x; iv[1] = a.y; iv[2] = b.x; iv[3] = b.y; mv[0] = c2.x; mv[1] = c2.y; mv[2] = d.x; mv[3] = d.y;
+  };
+  auto enter = [&](Side &s, long c, int k_old, int k_new) {      // the records of the cell k_new
+    if (k_new == k_old + 1) {
+#pragma unroll
+      for (int z = 0; z < ND_BATCH; z++) { s.i0[z] = s.i1[z]; s.m0[z] = s.m1[z]; }
+    } else {
+      load(c, k_new, s.i0, s.m0);
+    }
+    load(c, k_new + 1, s.i1, s.m1);
+  };
+  Side sl, sr;
+  load(cl, klt, sl.i0, sl.m0); load(cl, klt + 1, sl.i1, sl.m1);
+  load(cr, krt, sr.i0, sr.m0); load(cr, krt + 1, sr.i1, sr.m1);
 #pragma unroll
   for (int z = 0; z < ND_BATCH; z++) {
-    if (z < nb) {
-      const double *__restrict__ Ti = A.Ti + A.col_stride * z;
-      const double l0 = Ti[cl + hpl * klt], l1 = Ti[cl + hpl * (klt + 1)], r0 = Ti[cr + hpl * krt], r1 = Ti[cr + hpl * (krt + 1)];
-      Ttop_l[z] = (1. - pLt) * l0 + pLt * l1;
-      Ttop_r[z] = (1. - pRt) * r0 + pRt * r1;
-      tm_l[z] = A.t[z][cl + hpl * klt]; tm_r[z] = A.t[z][cr + hpl * krt];
-      ppm_edges(l0, l1, tm_l[z], eL_l[z], eR_l[z]);
-      ppm_edges(r0, r1, tm_r[z], eL_r[z], eR_r[z]);
+    sl.top[z] = (1. - pLt) * sl.i0[z] + pLt * sl.i1[z];
+    sr.top[z] = (1. - pRt) * sr.i0[z] + pRt * sr.i1[z];
+    ppm_edges(sl.i0[z], sl.i1[z], sl.m0[z], sl.eL[z], sl.eR[z]);
+    ppm_edges(sr.i0[z], sr.i1[z], sr.m0[z], sr.eL[z], sr.eR[z]);
+  }
+  // SYM: the running sums of the layers klt, krt; every layer of the two columns is stored once (zero where no sublayer lies in it)
+  double accL[ND_BATCH], accR[ND_BATCH];
+#pragma unroll
+  for (int z = 0; z < ND_BATCH; z++) { accL[z] = 0.; accR[z] = 0.; }
+  if (SYM) {
+    for (int z = 0; z < nb; z++) {
+      for (int k = 0; k < klt; k++) tdL[A.flx_stride * z + f + pl * k] = 0.;
+      for (int k = 0; k < krt; k++) tdR[A.flx_stride * z + f + pl * k] = 0.;
     }
   }
   for (int ks = 0; ks < ns - 1; ks++) {
     const double pLb = PiL[f + pl * (ks + 1)], pRb = PiR[f + pl * (ks + 1)];
     const int klb = KoL[f + pl * (ks + 1)] - 1, krb = KoR[f + pl * (ks + 1)] - 1;
     const double he = hEff[f + pl * ks];
+    if (klb < klt || krb < krt) bad |= 2;      // (the positions of the surfaces never move up a column)
+    double lay_l[ND_BATCH], lay_r[ND_BATCH];   // the means of the sublayer in the cells klt, krt
+    if (he != 0.) {
+#pragma unroll
+      for (int z = 0; z < ND_BATCH; z++) {
+        lay_l[z] = ppm_ave(pLt, pLb + (double)(klb - klt), sl.eL[z], sl.eR[z], sl.m0[z], bad);
+        lay_r[z] = ppm_ave(pRt, pRb + (double)(krb - krt), sr.eL[z], sr.eR[z], sr.m0[z], bad);
+      }
+    }
+    if (klb != klt) enter(sl, cl, klt, klb);
+    if (krb != krt) enter(sr, cr, krt, krb);
 #pragma unroll
     for (int z = 0; z < ND_BATCH; z++) {
-      if (z < nb) {
-        const double *__restrict__ Ti = A.Ti + A.col_stride * z;
-        const double l0 = Ti[cl + hpl * klb], l1 = Ti[cl + hpl * (klb + 1)], r0 = Ti[cr + hpl * krb], r1 = Ti[cr + hpl * (krb + 1)];
-        const double T_left_bottom = (1. - pLb) * l0 + pLb * l1;
-        const double T_right_bottom = (1. - pRb) * r0 + pRb * r1;
-        double flx = 0.;
-        if (he != 0.) {
-          const double T_left_top = Ttop_l[z], T_right_top = Ttop_r[z];
-          const double T_left_layer = ppm_ave(pLt, pLb + (double)(klb - klt), eL_l[z], eR_l[z], tm_l[z], bad);
-          const double T_right_layer = ppm_ave(pRt, pRb + (double)(krb - krt), eL_r[z], eR_r[z], tm_r[z], bad);
-          const double dT_top = T_right_top - T_left_top;
-          const double dT_bottom = T_right_bottom - T_left_bottom;
-          double dT_ave = 0.5 * (dT_top + dT_bottom);
-          const double dT_layer = T_right_layer - T_left_layer;
-          if (signum(1., dT_top) * signum(1., dT_bottom) <= 0. || signum(1., dT_ave) * signum(1., dT_layer) <= 0.) dT_ave = 0.;
-          else dT_ave = dT_layer;
-          flx = dT_ave * he * 1.0;
+      const double T_left_bottom = (1. - pLb) * sl.i0[z] + pLb * sl.i1[z];
+      const double T_right_bottom = (1. - pRb) * sr.i0[z] + pRb * sr.i1[z];
+      double flx = 0.;
+      if (he != 0.) {
+        const double T_left_top = sl.top[z], T_right_top = sr.top[z];
+        const double T_left_layer = lay_l[z], T_right_layer = lay_r[z];
+        const double dT_top = T_right_top - T_left_top;
+        const double dT_bottom = T_right_bottom - T_left_bottom;
+        double dT_ave = 0.5 * (dT_top + dT_bottom);
+        const double dT_layer = T_right_layer - T_left_layer;
+        if (signum(1., dT_top) * signum(1., dT_bottom) <= 0. || signum(1., dT_ave) * signum(1., dT_layer) <= 0.) dT_ave = 0.;
+        else dT_ave = dT_layer;
+        flx = dT_ave * he * 1.0;
+      }
+      if (SYM) { accL[z] = accL[z] + cf * flx; accR[z] = accR[z] - cf * flx; }
+      else if (z < nb) Flx[A.flx_stride * z + f + pl * ks] = flx;
+      sl.top[z] = T_left_bottom; sr.top[z] = T_right_bottom;
+    }
+    // the surface enters another cell: its edge values from the interface values and the mean just read; SYM: the layer it leaves is done
+    if (klb != klt) {
+#pragma unroll
+      for (int z = 0; z < ND_BATCH; z++) {
+        ppm_edges(sl.i0[z], sl.i1[z], sl.m0[z], sl.eL[z], sl.eR[z]);
+        if (SYM) {
+          if (z < nb) {
+            tdL[A.flx_stride * z + f + pl * klt] = accL[z];
+            for (int k = klt + 1; k < klb; k++) tdL[A.flx_stride * z + f + pl * k] = 0.;
+          }
+          accL[z] = 0.;
         }
-        Flx[A.flx_stride * z + f + pl * ks] = flx;
-        Ttop_l[z] = T_left_bottom; Ttop_r[z] = T_right_bottom;
-        // the surface enters another cell: its edge values (ppm_left_right_edge_values :2541) from the two interface values just read
-        if (klb != klt) { tm_l[z] = A.t[z][cl + hpl * klb]; ppm_edges(l0, l1, tm_l[z], eL_l[z], eR_l[z]); }
-        if (krb != krt) { tm_r[z] = A.t[z][cr + hpl * krb]; ppm_edges(r0, r1, tm_r[z], eL_r[z], eR_r[z]); }
+      }
+    }
+    if (krb != krt) {
+#pragma unroll
+      for (int z = 0; z < ND_BATCH; z++) {
+        ppm_edges(sr.i0[z], sr.i1[z], sr.m0[z], sr.eL[z], sr.eR[z]);
+        if (SYM) {
+          if (z < nb) {
+            tdR[A.flx_stride * z + f + pl * krt] = accR[z];
+            for (int k = krt + 1; k < krb; k++) tdR[A.flx_stride * z + f + pl * k] = 0.;
+          }
+          accR[z] = 0.;
+        }
       }
     }
     pLt = pLb; pRt = pRb; klt = klb; krt = krb;
   }
-  if (bad) atomicOr(A.bad, 1);
+  if (SYM) {
+    for (int z = 0; z < nb; z++) {
+      tdL[A.flx_stride * z + f + pl * klt] = accL[z];
+      for (int k = klt + 1; k < nk; k++) tdL[A.flx_stride * z + f + pl * k] = 0.;
+      tdR[A.flx_stride * z + f + pl * krt] = accR[z];
+      for (int k = krt + 1; k < nk; k++) tdR[A.flx_stride * z + f + pl * k] = 0.;
+    }
+  }
+  if (bad) atomicOr(A.bad, bad);
 }
 
-// :921-960: the cell's tendency from the fluxes of its four faces, then the tracer
+// :955-959 after the sums of :939-954 (the symmetric order): the four faces' tendencies of the layer, then the tracer
+__global__ __launch_bounds__(256) void nd_update_sym_kernel(NDArgs A) {
+  const m6::GridDev &g = A.g;
+  const int i = g.isc + blockIdx.x * 256 + threadIdx.x, j = g.jsc + blockIdx.y, k = blockIdx.z % g.nk, z = blockIdx.z / g.nk;
+  if (i > g.iec) return;
+  const long n2 = g.h2(i, j), hpl = (long)g.nih * g.njh;
+  if (!(g.mask2dT[n2] > 0.)) return;
+  const long upl = (long)(g.nih + 1) * g.njh, vpl = (long)g.nih * (g.njh + 1);
+  const double tN = A.tend[1][0][A.flx_stride * z + g.v2(i, j) + vpl * k], tS = A.tend[1][1][A.flx_stride * z + g.v2(i, j - 1) + vpl * k];
+  const double tE = A.tend[0][0][A.flx_stride * z + g.u2(i, j) + upl * k], tW = A.tend[0][1][A.flx_stride * z + g.u2(i - 1, j) + upl * k];
+  const double tendency = (tN + tS) + (tE + tW);
+  double *__restrict__ t = A.t[z];
+  double x = t[n2 + hpl * k] + tendency * (g.IareaT[n2] / (A.h[n2 + hpl * k] + g.H_subroundoff));
+  if (fabs(x) < A.cu[z]) x = 0.0;
+  t[n2 + hpl * k] = x;
+}
+
+// :921-938, :955-959 (the order of 2024 and before): the cell's tendency from the fluxes of its four faces, surface by surface round the
+// faces E, W, N, S, accumulated per layer in LDS (the layer index is data: KoL / KoR), then the tracer.  (A thread per layer that walks
+// the runs of its four faces -- no LDS, full occupancy -- reads the fluxes as gathers and is slower: profiles/r04_experiments.txt.)
 __global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
   extern __shared__ double acc[];      // [nk][64]
   const m6::GridDev &g = A.g;
@@ -373,63 +522,30 @@ __global__ __launch_bounds__(64) void nd_update_kernel(NDArgs A) {
   const double *__restrict__ uFlx = A.Flx[0] + A.flx_stride * z, *__restrict__ vFlx = A.Flx[1] + A.flx_stride * z;
 #define ACC(k) acc[(k) * 64 + lane]
   // The surfaces are taken eight at a time: the loads of a group (layer numbers and fluxes of the four faces) are issued together, then
-  // the group's contributions are added in the reference's order.  (With the LDS column a CU holds four waves; a global round trip per
-  // surface was what the kernel waited for.)
+  // the group's contributions are added in the reference's order.
   constexpr int NU = 8;
   const int nl = ns - 1;
-  if (!A.symmetric) {      // :927-938
-    for (int k = 0; k < nk; k++) ACC(k) = 0.;
-    for (int ks0 = 0; ks0 < nl; ks0 += NU) {
-      int kE[NU], kW[NU], kN[NU], kS[NU];
-      double fE[NU], fW[NU], fN[NU], fS[NU];
+  for (int k = 0; k < nk; k++) ACC(k) = 0.;
+  for (int ks0 = 0; ks0 < nl; ks0 += NU) {
+    int kE[NU], kW[NU], kN[NU], kS[NU];
+    double fE[NU], fW[NU], fN[NU], fS[NU];
 #pragma unroll
-      for (int q = 0; q < NU; q++) {
-        const int ks = (ks0 + q < nl) ? ks0 + q : nl - 1;
-        kE[q] = uKoL[uE + upl * ks] - 1; fE[q] = uFlx[uE + upl * ks];
-        kW[q] = uKoR[uW + upl * ks] - 1; fW[q] = uFlx[uW + upl * ks];
-        kN[q] = vKoL[vN + vpl * ks] - 1; fN[q] = vFlx[vN + vpl * ks];
-        kS[q] = vKoR[vS + vpl * ks] - 1; fS[q] = vFlx[vS + vpl * ks];
-      }
+    for (int q = 0; q < NU; q++) {
+      const int ks = (ks0 + q < nl) ? ks0 + q : nl - 1;
+      kE[q] = uKoL[uE + upl * ks] - 1; fE[q] = uFlx[uE + upl * ks];
+      kW[q] = uKoR[uW + upl * ks] - 1; fW[q] = uFlx[uW + upl * ks];
+      kN[q] = vKoL[vN + vpl * ks] - 1; fN[q] = vFlx[vN + vpl * ks];
+      kS[q] = vKoR[vS + vpl * ks] - 1; fS[q] = vFlx[vS + vpl * ks];
+    }
 #pragma unroll
-      for (int q = 0; q < NU; q++) {
-        if (ks0 + q < nl) {
-          ACC(kE[q]) = ACC(kE[q]) + cE * fE[q];
-          ACC(kW[q]) = ACC(kW[q]) - cW * fW[q];
-          ACC(kN[q]) = ACC(kN[q]) + cN * fN[q];
-          ACC(kS[q]) = ACC(kS[q]) - cS * fS[q];
-        }
+    for (int q = 0; q < NU; q++) {
+      if (ks0 + q < nl) {
+        ACC(kE[q]) = ACC(kE[q]) + cE * fE[q];
+        ACC(kW[q]) = ACC(kW[q]) - cW * fW[q];
+        ACC(kN[q]) = ACC(kN[q]) + cN * fN[q];
+        ACC(kS[q]) = ACC(kS[q]) - cS * fS[q];
       }
     }
-  } else {                 // :939-954: one face at a time, the first three parked in the stash
-    const long spl = hpl * nk;
-    double *__restrict__ st = A.stash + 3 * spl * z;
-    for (int face = 0; face < 4; face++) {      // N, S, E, W
-      const ko_t *__restrict__ Kf = face == 0 ? vKoL + vN : (face == 1 ? vKoR + vS : (face == 2 ? uKoL + uE : uKoR + uW));
-      const double *__restrict__ Ff = face == 0 ? vFlx + vN : (face == 1 ? vFlx + vS : (face == 2 ? uFlx + uE : uFlx + uW));
-      const long fpl_ = face < 2 ? vpl : upl;
-      const double cf = face == 0 ? cN : (face == 1 ? cS : (face == 2 ? cE : cW));
-      const bool plus = (face == 0 || face == 2);
-      for (int k = 0; k < nk; k++) ACC(k) = 0.;
-      for (int ks0 = 0; ks0 < nl; ks0 += NU) {
-        int kk[NU];
-        double ff[NU];
-#pragma unroll
-        for (int q = 0; q < NU; q++) {
-          const int ks = (ks0 + q < nl) ? ks0 + q : nl - 1;
-          kk[q] = Kf[fpl_ * ks] - 1; ff[q] = Ff[fpl_ * ks];
-        }
-#pragma unroll
-        for (int q = 0; q < NU; q++) {
-          if (ks0 + q < nl) {
-            if (plus) ACC(kk[q]) = ACC(kk[q]) + cf * ff[q];
-            else ACC(kk[q]) = ACC(kk[q]) - cf * ff[q];
-          }
-        }
-      }
-      if (face < 3) for (int k = 0; k < nk; k++) st[spl * face + n2 + hpl * k] = ACC(k);
-    }
-    for (int k = 0; k < nk; k++)
-      ACC(k) = (st[n2 + hpl * k] + st[spl + n2 + hpl * k]) + (st[2 * spl + n2 + hpl * k] + ACC(k));
   }
   const double IareaT = g.IareaT[n2];
   for (int k = 0; k < nk; k++) {
@@ -468,12 +584,14 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
   A.ref_pres = nd->ref_pres; A.gH = g.g_Earth * nd->H_to_RZ; A.pa_to_H = 1. / (nd->H_to_RZ * g.g_Earth);
   A.h_neglect = g.H_subroundoff; A.scale = I_numitts; A.ns = ns; A.symmetric = nd->ndiff_answer_date > 20240330;
   A.h = h; A.p_surf = p_surf; A.khdt[0] = khdt_x; A.khdt[1] = khdt_y;
-  double *cols = (double *)st.scratch(sizeof(double) * hpl * (nk + 1) * 5);
+  double *irec = (double *)st.scratch(sizeof(double) * hpl * (nk + 1) * IREC);
   const int nbmax = ntr < ND_BATCH ? ntr : ND_BATCH;
-  double *faces = (double *)st.scratch(sizeof(double) * fpl * ns * (6 + 2 * (size_t)nbmax));
+  // per direction PoL, PoR, hEff [surface][faces]; then per tracer of a batch either the fluxes [surface][faces] of the two directions or
+  // the tendencies [layer][faces] of the two sides of the faces of the two directions
+  const size_t per_tracer = A.symmetric ? fpl * nk * 4 : fpl * ns * 2;
+  double *faces = (double *)st.scratch(sizeof(double) * (fpl * ns * 6 + per_tracer * (size_t)nbmax));
   ko_t *kos = (ko_t *)st.scratch(sizeof(ko_t) * fpl * ns * 4);
-  double *tcols = (double *)st.scratch(sizeof(double) * hpl * ((size_t)nk + 1) * nbmax);
-  double *stash = A.symmetric ? (double *)st.scratch(sizeof(double) * hpl * nk * 3 * nbmax) : nullptr;
+  double *trec = (double *)st.scratch(sizeof(double) * hpl * ((size_t)nk + 1) * TREC);
   int *bad = (int *)st.scratch(64);
   A.interior = nd->interior_only != 0; A.hbl = nullptr; A.kbot = nullptr; A.zbot = nullptr;
   double *hbl = nullptr;
@@ -484,18 +602,20 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
     M6_REQUIRE(!st.failed() && hbl && A.zbot && A.kbot, "neutral_diffusion: out of device memory");
     A.hbl = hbl;
   }
-  M6_REQUIRE(!st.failed() && cols && faces && kos && tcols && bad && (stash || !A.symmetric), "neutral_diffusion: out of device memory");
-  A.Pint = cols; A.Tint = cols + hpl * (nk + 1); A.Sint = A.Tint + hpl * (nk + 1); A.dRdT = A.Sint + hpl * (nk + 1); A.dRdS = A.dRdT + hpl * (nk + 1);
+  M6_REQUIRE(!st.failed() && irec && faces && kos && trec && bad, "neutral_diffusion: out of device memory");
+  A.irec = irec; A.trec = trec; A.bad = bad;
+  double *per = faces + fpl * ns * 6;
   for (int d = 0; d < 2; d++) {
     A.PoL[d] = faces + fpl * ns * (3 * d); A.PoR[d] = A.PoL[d] + fpl * ns; A.hEff[d] = A.PoR[d] + fpl * ns;
-    A.Flx[d] = faces + fpl * ns * (6 + d);      // the fluxes of tracer z of a batch: + 2 planes sets per tracer
     A.KoL[d] = kos + fpl * ns * (2 * d); A.KoR[d] = A.KoL[d] + fpl * ns;
+    A.Flx[d] = A.symmetric ? nullptr : per + fpl * ns * d;
+    A.tend[d][0] = A.symmetric ? per + fpl * nk * (2 * d) : nullptr; A.tend[d][1] = A.symmetric ? per + fpl * nk * (2 * d + 1) : nullptr;
   }
-  A.flx_stride = (long)(fpl * ns * 2); A.col_stride = (long)(hpl * ((size_t)nk + 1));
-  A.Ti = tcols; A.stash = stash; A.bad = bad;
+  A.flx_stride = (long)per_tracer;
   M6_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
 
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
+  const int nbc = (ni + 2 + 63) / 64, nbu = (ni + 1 + 63) / 64, nbv = (ni + 63) / 64;      // blocks along i: columns with the halo, u faces, v faces
   std::vector<double *> pf(d_tr);
   std::vector<int32_t> ppos(ntr, MOM6HIP_POS_H), pnk(ntr, nk);
   auto calc_coeffs = [&]() -> int {      // neutral_diffusion_calc_coeffs :337
@@ -505,9 +625,9 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
       double *f1[1] = {hbl}; int32_t p1[1] = {MOM6HIP_POS_H}, n1[1] = {1};
       if (int rc = m6::group_pass(ctx, f1, p1, n1, 1)) return rc;
     }
-    hipLaunchKernelGGL(nd_column_kernel, dim3((ni + 2 + 63) / 64, nj + 2), dim3(64), 0, s, A);
-    hipLaunchKernelGGL(nd_surfaces_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
-    hipLaunchKernelGGL(nd_surfaces_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(nd_column_kernel, dim3(xcd_grid(nbc, nj + 2)), dim3(64), 0, s, A, nbc, nj + 2);
+    hipLaunchKernelGGL(nd_surfaces_kernel<0>, dim3(xcd_grid(nbu, nj)), dim3(64), 0, s, A, nbu, nj);
+    hipLaunchKernelGGL(nd_surfaces_kernel<1>, dim3(xcd_grid(nbv, nj + 1)), dim3(64), 0, s, A, nbv, nj + 1);
     return 0;
   };
   if (int rc = m6::group_pass(ctx, pf.data(), ppos.data(), pnk.data(), ntr)) return rc;      // do_group_pass(CS%pass_t) :478
@@ -522,17 +642,25 @@ int neutral_branch(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_neutral_diffusi
     for (int m0 = 0; m0 < ntr; m0 += nbmax) {      // neutral_diffusion :605: the tracers are independent of each other, a batch at a time
       A.nb = (ntr - m0 < nbmax) ? ntr - m0 : nbmax;
       for (int z = 0; z < A.nb; z++) { A.t[z] = d_tr[m0 + z]; A.cu[z] = cu[m0 + z]; }
-      hipLaunchKernelGGL(nd_tracer_cols_kernel, dim3((ni + 2 + 63) / 64, nj + 2, A.nb), dim3(64), 0, s, A);
-      hipLaunchKernelGGL(nd_flux_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
-      hipLaunchKernelGGL(nd_flux_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
-      hipLaunchKernelGGL(nd_update_kernel, dim3((ni + 63) / 64, nj, A.nb), dim3(64), sizeof(double) * 64 * nk, s, A);
+      for (int z = A.nb; z < ND_BATCH; z++) { A.t[z] = nullptr; A.cu[z] = 0.; }
+      hipLaunchKernelGGL(nd_tracer_cols_kernel, dim3(xcd_grid(nbc, nj + 2)), dim3(64), 0, s, A, nbc, nj + 2);
+      if (A.symmetric) {
+        hipLaunchKernelGGL((nd_flux_kernel<0, true>), dim3(xcd_grid(nbu, nj)), dim3(64), 0, s, A, nbu, nj);
+        hipLaunchKernelGGL((nd_flux_kernel<1, true>), dim3(xcd_grid(nbv, nj + 1)), dim3(64), 0, s, A, nbv, nj + 1);
+        hipLaunchKernelGGL(nd_update_sym_kernel, dim3((ni + 255) / 256, nj, nk * A.nb), dim3(256), 0, s, A);
+      } else {
+        hipLaunchKernelGGL((nd_flux_kernel<0, false>), dim3(xcd_grid(nbu, nj)), dim3(64), 0, s, A, nbu, nj);
+        hipLaunchKernelGGL((nd_flux_kernel<1, false>), dim3(xcd_grid(nbv, nj + 1)), dim3(64), 0, s, A, nbv, nj + 1);
+        hipLaunchKernelGGL(nd_update_kernel, dim3((ni + 63) / 64, nj, A.nb), dim3(64), sizeof(double) * 64 * nk, s, A);
+      }
     }
   }
   M6_HIP(hipGetLastError());
   int hbad = 0;
   M6_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
   M6_HIP(hipStreamSynchronize(s));
-  M6_REQUIRE(!hbad, "ppm_ave: dx<0 or dx>1 should not happened! (a neutral layer spans more than one cell)");
+  M6_REQUIRE(!(hbad & 1), "ppm_ave: dx<0 or dx>1 should not happened! (a neutral layer spans more than one cell)");
+  M6_REQUIRE(!(hbad & 2), "neutral_diffusion: a neutral surface lies above the one before it in a column");
   return 0;
 }
 

@@ -32,6 +32,8 @@ hh = d["h"].clone()
 nd = tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True)
 trs = [d["T"].clone(), d["S"].clone(), torch.rand_like(d["T"]), torch.rand_like(d["T"])]
 tv = dict(T=trs[0], S=trs[1], eqn_of_state=eos)
-print(json.dumps({"tracer_hordiff_neutral_4tr_ms": T(lambda: tracer_hordiff(hh, 3600.0, None, None, None, dg, nd, trs, tv=tv), n=2),
+nd_sym = tracer_hor_diff_init(KHTR=50.0, USE_NEUTRAL_DIFFUSION=True, NDIFF_ANSWER_DATE=20250101)
+print(json.dumps({"tracer_hordiff_neutral_4tr_symmetric_ms": T(lambda: tracer_hordiff(hh, 3600.0, None, None, None, dg, nd_sym, trs, tv=tv), n=2),
+                  "tracer_hordiff_neutral_4tr_ms": T(lambda: tracer_hordiff(hh, 3600.0, None, None, None, dg, nd, trs, tv=tv), n=2),
                   "thickness_diffuse_ms": T(lambda: thickness_diffuse(hh, uq, vq, (d["T"], d["S"], eos), 3600.0, dg, None, None, None, td)),
                   "mixedlayer_restrat_ms": T(lambda: mixedlayer_restrat(hh, uq, vq, (d["T"], d["S"], eos), dict(ustar=ustar), 3600.0, None, h_MLD, None, dict(Rd_dx_h=Rd), dg, mle))}))
