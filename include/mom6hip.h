@@ -561,7 +561,9 @@ typedef struct mom6hip_obc {
   int32_t specified_u_BCs_exist_globally, specified_v_BCs_exist_globally;
   int32_t Flather_u_BCs_exist_globally, Flather_v_BCs_exist_globally;
   int32_t zero_vorticity, freeslip_vorticity, computed_vorticity, specified_vorticity;      /* OBC_ZERO_VORTICITY ... (read by CorAdCalc) */
-  int32_t reserved[4];
+  int32_t zero_strain, freeslip_strain, computed_strain;      /* OBC_ZERO_STRAIN ... (read by horizontal_viscosity; OBC_SPECIFIED_STRAIN has
+                                                                 no effect there: its branch hangs behind the other three, MOM_hor_visc.F90:735-750) */
+  int32_t zero_biharmonic;                                    /* OBC_ZERO_BIHARMONIC */
   const mom6hip_obc_segment_t *segment;             /* number_of_segments entries (HOST array) */
   const int32_t *segnum_u, *segnum_v;               /* OBC%segnum_u(IsdB:IedB, jsd:jed), segnum_v(isd:ied, JsdB:JedB): the segment number
                                                        (1-based) of a face, MOM6HIP_OBC_NONE elsewhere; HOST arrays */
@@ -1120,6 +1122,12 @@ int mom6hip_hor_visc_init(mom6hip_ctx_t *ctx, mom6hip_hor_visc_cs_t *cs, double 
 int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,
                                  const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
                                  const double *hv_cont, int32_t memspace);
+/* horizontal_viscosity with OBC associated (and OBC%OBC_pe): OBC_ZERO_STRAIN / OBC_FREESLIP_STRAIN at the corner points of the segments
+ * (:733-790, :1388-1409), the thicknesses at and beside their faces (:791-849), OBC_ZERO_BIHARMONIC (:889-903), no viscous acceleration
+ * of the segments' own faces (:1751-1782).  OBC_COMPUTED_STRAIN is refused.  obc == NULL: mom6hip_horizontal_viscosity. */
+int mom6hip_horizontal_viscosity_obc(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,
+                                     const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
+                                     const double *hv_cont, const struct mom6hip_obc *obc, int32_t memspace);
 
 /* ---- MOM_dynamics_split_RK2 ------------------------------------------------------------------ */
 

@@ -199,8 +199,9 @@ class Obc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("number_of_segments", "OBC_pe", "open_u_BCs_exist_globally", "open_v_BCs_exist_globally",
                                          "specified_u_BCs_exist_globally", "specified_v_BCs_exist_globally",
                                          "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally", "zero_vorticity",
-                                         "freeslip_vorticity", "computed_vorticity", "specified_vorticity")] + \
-               [("reserved", C.c_int32 * 4), ("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
+                                         "freeslip_vorticity", "computed_vorticity", "specified_vorticity", "zero_strain", "freeslip_strain",
+                                         "computed_strain", "zero_biharmonic")] + \
+               [("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
                 ("reserved_p", C.c_void_p * 4)]
 
 

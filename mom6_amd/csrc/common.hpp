@@ -211,8 +211,10 @@ inline bool multi_tile(const mom6hip_ctx *ctx);
 void staging_destroy(mom6hip_ctx *ctx);      // staging.hip
 
 // horizontal_viscosity on device arrays (hor_visc.hip); called by the split RK2 step at :860 and :1543
+// ob: the maps of the open boundaries (hor_visc.hip, HVFArgs), null without
+struct HVObcDev { const int32_t *q = nullptr, *fu = nullptr, *fv = nullptr, *hu = nullptr, *hv = nullptr; };
 int horizontal_viscosity_dev(mom6hip_ctx *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,
-                             double *diffu, double *diffv, const double *hu_cont, const double *hv_cont);
+                             double *diffu, double *diffv, const double *hu_cont, const double *hv_cont, const HVObcDev *ob = nullptr);
 
 // set_viscous_BBL on device arrays (set_viscosity.hip); ob: what the OBC branches read (device arrays), null without OBC
 struct BBLObcDev { const int32_t *side_u = nullptr, *side_v = nullptr; const double *D_u = nullptr, *D_v = nullptr, *mask_u = nullptr, *mask_v = nullptr; };

@@ -8,6 +8,7 @@
 // multiplications of grid metrics and are evaluated in place (the same bits as the stored arrays).
 // Algorithmic traffic: read u, v, h, write diffu, diffv = 40 B per cell.
 #include <cmath>
+#include <vector>
 
 #include "common.hpp"
 
@@ -314,6 +315,12 @@ struct HVFArgs {
   // frictional work (hv_frictwork_kernel), h- and q-shaped 3-D arrays, null unless MEKE%mom_src is wanted
   const double *Ku, *Au;
   double *str_xx_out, *str_xy_out;
+  // open boundaries (generic configuration only; null without): what the reference's loops over the segments leave, as maps
+  //   obc_q [q points]   bit 0: dvdx = 0, bit 1: dudy = 0 (:733-790), bit 2: dDel2vdx = 0, bit 3: dDel2udy = 0 (:1388-1409)
+  //   obc_fu, obc_fv     bit 0: Del2u | Del2v = 0 (:889-903), bit 1: diffu | diffv = 0 (:1751-1782), bits 2-3: the thickness of the face is that
+  //                      of its first (1) or second (2) cell (:791-819)
+  //   obc_hu, obc_hv     the face whose thickness this face takes after the projections across the segments' corner points (:821-849), -1: its own
+  const int32_t *obc_q, *obc_fu, *obc_fv, *obc_hu, *obc_hv;
 };
 
 
@@ -350,6 +357,28 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
   char *du_k = (char *)(A.diffu + kU), *dv_k = (char *)(A.diffv + kV);
   const char *pk = A.pk;
   const unsigned PB = A.plane_bytes;
+  const bool obc = (CFG == HV_GENERIC) && A.obc_q != nullptr;
+  // the thickness of the face fs of direction d (0: u, 1: v) with open boundaries: that of the face the projections across the segments'
+  // corner points take it from, there the cell inside a segment or the plain interpolation (:740-849)
+  auto h_face_obc = [&](int d, int fs) -> double {
+    const int32_t *hs = d ? A.obc_hv : A.obc_hu, *fc = d ? A.obc_fv : A.obc_fu;
+    const int f = hs[fs] >= 0 ? hs[fs] : fs;
+    const int side = (fc[f] >> 2) & 3;
+    const int nw = d ? A.nih : A.nih + 1, r = f / nw, c = f - r * nw;
+    // the two cells of the face in the h-shaped arrays, and in the packed planes (q-shaped, offset by one point)
+    const int h0 = d ? (r - 1) * A.nih + c : r * A.nih + c - 1, h1 = d ? r * A.nih + c : r * A.nih + c;
+    const double *hk = (const double *)h_k;
+    if (side == 1) return hk[h0];
+    if (side == 2) return hk[h1];
+    if (d == 0 && huc_k && (c - 1 + A.isd) >= A.isc - 2) return ((const double *)huc_k)[f];
+    if (d == 1 && hvc_k && (r - 1 + A.jsd) >= A.jsc - 2) return ((const double *)hvc_k)[f];
+    if (o.use_land_mask) {
+      const double *mT = (const double *)(pk + (size_t)P_MASKT * PB);
+      const int q0 = d ? r * (A.nih + 1) + c + 1 : (r + 1) * (A.nih + 1) + c, q1 = d ? (r + 1) * (A.nih + 1) + c + 1 : (r + 1) * (A.nih + 1) + c + 1;
+      return 0.5 * (mT[q0] * hk[h0] + mT[q1] * hk[h1]);
+    }
+    return 0.5 * (hk[h0] + hk[h1]);
+  };
 
 #define LX(a, di, dj) a[lo + (dj) * HV_W + (di)]
 // loads at the point (i + di, j + dj): packed metric plane m; an h-, u-, v- or q-shaped array with base pointer b
@@ -386,14 +415,25 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
       LX(s_xx, 0, 0) = dudx - dvdy;
     }
     if (J >= js - 2 && J <= Jeq + 1 && I >= is - 2 && I <= Ieq + 1) {      // shearing strain :702-705, :852-864
-      const double dvdx = G(P_DYDXBU, 0, 0) * (AV(v_k, 1, 0) * G(P_IDYCV, 1, 0) - AV(v_k, 0, 0) * G(P_IDYCV, 0, 0));
-      const double dudy = G(P_DXDYBU, 0, 0) * (AU(u_k, 0, 1) * G(P_IDXCU, 0, 1) - AU(u_k, 0, 0) * G(P_IDXCU, 0, 0));
+      double dvdx = G(P_DYDXBU, 0, 0) * (AV(v_k, 1, 0) * G(P_IDYCV, 1, 0) - AV(v_k, 0, 0) * G(P_IDYCV, 0, 0));
+      double dudy = G(P_DXDYBU, 0, 0) * (AU(u_k, 0, 1) * G(P_IDXCU, 0, 1) - AU(u_k, 0, 0) * G(P_IDXCU, 0, 0));
+      if (obc) {
+        const int qc = A.obc_q[bq >> 3];
+        if (qc & 1) dvdx = 0.;
+        if (qc & 2) dudy = 0.;
+      }
       if (o.no_slip) LX(s_xy, 0, 0) = (2.0 - G(P_MASKBU, 0, 0)) * (dvdx + dudy);
       else LX(s_xy, 0, 0) = G(P_MASKBU, 0, 0) * (dvdx + dudy);
     }
-    if (j >= js - 1 && j <= je + 1 && I >= is - 2 && I <= ie + 1) LX(s_hu, 0, 0) = HU_AT(0);      // :740-765
+    if (j >= js - 1 && j <= je + 1 && I >= is - 2 && I <= ie + 1) {      // :740-765
+      const int fs = obc ? (int)(bu >> 3) : 0;
+      if (obc && (A.obc_hu[fs] >= 0 || (A.obc_fu[fs] & 12))) LX(s_hu, 0, 0) = h_face_obc(0, fs);
+      else LX(s_hu, 0, 0) = HU_AT(0);
+    }
     if (J >= js - 2 && J <= je + 1 && i >= is - 1 && i <= ie + 1) {
-      if (hvc_k && J >= A.jsc - 2) LX(s_hv, 0, 0) = AV(hvc_k, 0, 0);
+      const int fs = obc ? (int)(bv >> 3) : 0;
+      if (obc && (A.obc_hv[fs] >= 0 || (A.obc_fv[fs] & 12))) LX(s_hv, 0, 0) = h_face_obc(1, fs);
+      else if (hvc_k && J >= A.jsc - 2) LX(s_hv, 0, 0) = AV(hvc_k, 0, 0);
       else if (o.use_land_mask) LX(s_hv, 0, 0) = 0.5 * (G(P_MASKT, 0, 0) * AH(h_k, 0, 0) + G(P_MASKT, 0, 1) * AH(h_k, 0, 1));
       else LX(s_hv, 0, 0) = 0.5 * (AH(h_k, 0, 0) + AH(h_k, 0, 1));
     }
@@ -403,12 +443,16 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
   // ---- the Laplacian of the velocity :882-891 ----
   if (o.biharmonic) {
     FOR_POINTS {
-      if (j >= js - 1 && j <= Jeq + 1 && I >= Isq - 1 && I <= Ieq + 1)
+      if (j >= js - 1 && j <= Jeq + 1 && I >= Isq - 1 && I <= Ieq + 1) {
         LX(s_d2u, 0, 0) = G(P_IDXDY2U, 0, 0) * (G(P_DY2H, 1, 0) * LX(s_xx, 1, 0) - G(P_DY2H, 0, 0) * LX(s_xx, 0, 0)) +
                           G(P_IDX2DYCU, 0, 0) * (G(P_DX2Q, 0, 0) * LX(s_xy, 0, 0) - G(P_DX2Q, 0, -1) * LX(s_xy, 0, -1));
-      if (J >= Jsq - 1 && J <= Jeq + 1 && i >= is - 1 && i <= Ieq + 1)
+        if (obc && (A.obc_fu[bu >> 3] & 1)) LX(s_d2u, 0, 0) = 0.;
+      }
+      if (J >= Jsq - 1 && J <= Jeq + 1 && i >= is - 1 && i <= Ieq + 1) {
         LX(s_d2v, 0, 0) = G(P_IDXDY2V, 0, 0) * (G(P_DY2Q, 0, 0) * LX(s_xy, 0, 0) - G(P_DY2Q, -1, 0) * LX(s_xy, -1, 0)) -
                           G(P_IDX2DYCV, 0, 0) * (G(P_DX2H, 0, 1) * LX(s_xx, 0, 1) - G(P_DX2H, 0, 0) * LX(s_xx, 0, 0));
+        if (obc && (A.obc_fv[bv >> 3] & 1)) LX(s_d2v, 0, 0) = 0.;
+      }
     } END_POINTS
     __syncthreads();
   }
@@ -550,8 +594,13 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
           if (o.better_bound_Kh) A_ = min2(A_, visc_bound_rem * hrat_min * AQ(A.s.Ah_Max_xy, 0, 0));
           else A_ = min2(A_, hrat_min * AQ(A.s.Ah_Max_xy, 0, 0));
         }
-        const double dDel2vdx = G(P_DYDXBU, 0, 0) * (LX(s_d2v, 1, 0) * G(P_IDYCV, 1, 0) - LX(s_d2v, 0, 0) * G(P_IDYCV, 0, 0));
-        const double dDel2udy = G(P_DXDYBU, 0, 0) * (LX(s_d2u, 0, 1) * G(P_IDXCU, 0, 1) - LX(s_d2u, 0, 0) * G(P_IDXCU, 0, 0));
+        double dDel2vdx = G(P_DYDXBU, 0, 0) * (LX(s_d2v, 1, 0) * G(P_IDYCV, 1, 0) - LX(s_d2v, 0, 0) * G(P_IDYCV, 0, 0));
+        double dDel2udy = G(P_DXDYBU, 0, 0) * (LX(s_d2u, 0, 1) * G(P_IDXCU, 0, 1) - LX(s_d2u, 0, 0) * G(P_IDXCU, 0, 0));
+        if (obc) {
+          const int qc = A.obc_q[bq >> 3];
+          if (qc & 4) dDel2vdx = 0.;
+          if (qc & 8) dDel2udy = 0.;
+        }
         const double d_str = A_ * (dDel2vdx + dDel2udy);
         str = str + d_str;
       }
@@ -577,11 +626,11 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
   }
   FOR_POINTS {
     if (j >= js && j <= je && I >= Iw && I <= ie)
-      *(double *)(du_k + bu) = ((G(P_IDYCU, 0, 0) * (G(P_DY2H, 0, 0) * LX(s_xx, 0, 0) - G(P_DY2H, 1, 0) * LX(s_xx, 1, 0)) +
+      *(double *)(du_k + bu) = (obc && (A.obc_fu[bu >> 3] & 2)) ? 0. : ((G(P_IDYCU, 0, 0) * (G(P_DY2H, 0, 0) * LX(s_xx, 0, 0) - G(P_DY2H, 1, 0) * LX(s_xx, 1, 0)) +
                                  G(P_IDXCU, 0, 0) * (G(P_DX2Q, 0, -1) * LX(s_xy, 0, -1) - G(P_DX2Q, 0, 0) * LX(s_xy, 0, 0))) *
                                 G(P_IAREACU, 0, 0)) / (LX(s_hu, 0, 0) + h_neglect);
     if (i >= is && i <= ie && J >= Js && J <= je)
-      *(double *)(dv_k + bv) = ((G(P_IDYCV, 0, 0) * (G(P_DY2Q, -1, 0) * LX(s_xy, -1, 0) - G(P_DY2Q, 0, 0) * LX(s_xy, 0, 0)) -
+      *(double *)(dv_k + bv) = (obc && (A.obc_fv[bv >> 3] & 2)) ? 0. : ((G(P_IDYCV, 0, 0) * (G(P_DY2Q, -1, 0) * LX(s_xy, -1, 0) - G(P_DY2Q, 0, 0) * LX(s_xy, 0, 0)) -
                                  G(P_IDXCV, 0, 0) * (G(P_DX2H, 0, 0) * LX(s_xx, 0, 0) - G(P_DX2H, 0, 1) * LX(s_xx, 0, 1))) *
                                 G(P_IAREACV, 0, 0)) / (LX(s_hv, 0, 0) + h_neglect);
   } END_POINTS
@@ -695,7 +744,7 @@ extern "C" int mom6hip_hor_visc_init(mom6hip_ctx_t *ctx, mom6hip_hor_visc_cs_t *
 // the launches of horizontal_viscosity on device arrays (also called by the split RK2 step at :860 and :1543)
 namespace m6 {
 int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,
-                             double *diffu, double *diffv, const double *hu_cont, const double *hv_cont) {
+                             double *diffu, double *diffv, const double *hu_cont, const double *hv_cont, const HVObcDev *ob) {
   const m6::GridDev g = ctx->g;
   if (!(cs->Laplacian || cs->biharmonic)) return 0;      // :451
   const size_t plane = sizeof(double) * (size_t)(g.nih + 1) * (g.njh + 1);
@@ -723,6 +772,8 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
   A.u = u; A.v = v; A.h = h; A.hu_cont = hu_cont; A.hv_cont = hv_cont; A.diffu = diffu; A.diffv = diffv;
   A.Ku = cs->Laplacian ? cs->MEKE_Ku : nullptr; A.Au = cs->biharmonic ? cs->MEKE_Au : nullptr;
   A.str_xx_out = nullptr; A.str_xy_out = nullptr;
+  A.obc_q = A.obc_fu = A.obc_fv = A.obc_hu = A.obc_hv = nullptr;
+  if (ob) { A.obc_q = ob->q; A.obc_fu = ob->fu; A.obc_fv = ob->fv; A.obc_hu = ob->hu; A.obc_hv = ob->hv; }
   const bool meke = A.Ku || A.Au || cs->MEKE_mom_src;
   if (cs->MEKE_mom_src) {
     const size_t nH3 = (size_t)g.nih * g.njh * g.nk, nQ3 = (size_t)(g.nih + 1) * (g.njh + 1) * g.nk;
@@ -740,7 +791,7 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
   // (tiles of 64x8, 64x12, 32x16, 128x8 points and blocks of 256 / 1024 threads all ran within 5% of this one: the kernel is
   // bound by the L2 -> L1 traffic of the metric planes, which every block reads for its tile -- profiles/r02_hor_visc.txt)
   int rc;
-  if (A.flags.bits == HV_BIH_SMAG && !meke) rc = launch(hv_fused_kernel<HV_BIH_SMAG, 64, 16, 512, 4>, 64, 16, 512);
+  if (A.flags.bits == HV_BIH_SMAG && !meke && !ob) rc = launch(hv_fused_kernel<HV_BIH_SMAG, 64, 16, 512, 4>, 64, 16, 512);
   else rc = launch(hv_fused_kernel<HV_GENERIC, 64, 16, 512, 4>, 64, 16, 512);
   M6_REQUIRE(rc == 0, "horizontal_viscosity: the grid is too large for one launch");
   if (cs->MEKE_mom_src)
@@ -754,6 +805,98 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
 extern "C" int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,
                                             const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
                                             const double *hv_cont, int32_t memspace) {
+  return mom6hip_horizontal_viscosity_obc(ctx, cs, u, v, h, diffu, diffv, dt, hu_cont, hv_cont, nullptr, memspace);
+}
+
+namespace {
+// What the reference's loops over the segments leave (MOM_hor_visc.F90:733-849, :889-903, :1388-1409, :1751-1782), as maps over the q points
+// and the faces: the loops are run here on the indices alone, in the reference's order and with its ranges.
+int hv_obc_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, m6::HVObcDev &ob) {
+  const m6::GridDev g = ctx->g;
+  M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "horizontal_viscosity: OBC%%segment is required");
+  M6_REQUIRE(!obc->computed_strain, "horizontal_viscosity: OBC_COMPUTED_STRAIN is not provided by libmom6hip");
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec, Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+  const int is_vort = is - 2, ie_vort = Ieq + 1, js_vort = js - 2, je_vort = Jeq + 1;
+  const size_t nU = (size_t)(g.nih + 1) * g.njh, nV = (size_t)g.nih * (g.njh + 1), nQ = (size_t)(g.nih + 1) * (g.njh + 1);
+  std::vector<int32_t> m(nQ + 2 * nU + 2 * nV, 0);
+  int32_t *q = m.data(), *fu = q + nQ, *fv = fu + nU, *hu = fv + nV, *hv = hu + nU;
+  for (size_t n = 0; n < nU; n++) hu[n] = -1;
+  for (size_t n = 0; n < nV; n++) hv[n] = -1;
+  auto imax = [](int a, int b) { return a > b ? a : b; };
+  auto imin = [](int a, int b) { return a < b ? a : b; };
+  const int nseg = obc->number_of_segments;
+  for (int n = 0; n < nseg; n++) {
+    const mom6hip_obc_segment_t &S = obc->segment[n];
+    if (!S.on_pe) continue;      // (a segment off the PE carries no index ranges)
+    M6_REQUIRE(S.IsdB >= g.isd - 1 && S.IedB <= g.ied && S.JsdB >= g.jsd - 1 && S.JedB <= g.jed && S.isd >= g.isd && S.ied <= g.ied &&
+                   S.jsd >= g.jsd && S.jed <= g.jed, "horizontal_viscosity: OBC segment %d lies outside the data domain", n + 1);
+    const int J = S.JsdB, I = S.IsdB;
+    if (obc->zero_strain || obc->freeslip_strain) {      // :735-790
+      if (S.is_N_or_S && J >= js_vort && J <= je_vort) {
+        for (int Iq = imax(S.IsdB, is_vort); Iq <= imin(S.IedB, ie_vort); Iq++) q[g.q2(Iq, J)] |= obc->zero_strain ? 3 : 2;
+      } else if (S.is_E_or_W && I >= is_vort && I <= ie_vort) {
+        for (int Jq = imax(S.JsdB, js_vort); Jq <= imin(S.JedB, je_vort); Jq++) q[g.q2(I, Jq)] |= obc->zero_strain ? 3 : 1;
+      }
+    }
+    // :791-819: the thickness of the cell inside at the segment's faces (a later segment has the last word)
+    if (S.direction == MOM6HIP_OBC_DIRECTION_N || S.direction == MOM6HIP_OBC_DIRECTION_S) {
+      if (J >= js - 2 && J <= Jeq + 1)
+        for (int i = imax(is - 2, S.isd); i <= imin(ie + 2, S.ied); i++) {
+          int32_t &c = fv[g.v2(i, J)];
+          c = (c & ~12) | ((S.direction == MOM6HIP_OBC_DIRECTION_N ? 1 : 2) << 2);
+        }
+    } else if (S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_W) {
+      if (I >= is - 2 && I <= Ieq + 1)
+        for (int j = imax(js - 2, S.jsd); j <= imin(je + 2, S.jed); j++) {
+          int32_t &c = fu[g.u2(I, j)];
+          c = (c & ~12) | ((S.direction == MOM6HIP_OBC_DIRECTION_E ? 1 : 2) << 2);
+        }
+    }
+  }
+  // :821-849: then across the corner points, segment by segment: a face takes the thickness another face holds at that moment
+  auto copy = [](int32_t *src, long dst, long from) { src[dst] = src[from] >= 0 ? src[from] : (int32_t)from; };
+  for (int n = 0; n < nseg; n++) {
+    const mom6hip_obc_segment_t &S = obc->segment[n];
+    if (!S.on_pe) continue;
+    const int J = S.JsdB, I = S.IsdB;
+    if (S.direction == MOM6HIP_OBC_DIRECTION_N) {
+      if (J >= js - 2 && J <= je) for (int Iq = imax(is - 2, S.IsdB); Iq <= imin(Ieq + 1, S.IedB); Iq++) copy(hu, g.u2(Iq, J + 1), g.u2(Iq, J));
+    } else if (S.direction == MOM6HIP_OBC_DIRECTION_S) {
+      if (J >= js - 1 && J <= je + 1) for (int Iq = imax(is - 2, S.isd); Iq <= imin(Ieq + 1, S.ied); Iq++) copy(hu, g.u2(Iq, J), g.u2(Iq, J + 1));
+    } else if (S.direction == MOM6HIP_OBC_DIRECTION_E) {
+      if (I >= is - 2 && I <= ie) for (int Jq = imax(js - 2, S.jsd); Jq <= imin(Jeq + 1, S.jed); Jq++) copy(hv, g.v2(I + 1, Jq), g.v2(I, Jq));
+    } else if (S.direction == MOM6HIP_OBC_DIRECTION_W) {
+      if (I >= is - 1 && I <= ie + 1) for (int Jq = imax(js - 2, S.jsd); Jq <= imin(Jeq + 1, S.jed); Jq++) copy(hv, g.v2(I, Jq), g.v2(I + 1, Jq));
+    }
+  }
+  for (int n = 0; n < nseg; n++) {
+    const mom6hip_obc_segment_t &S = obc->segment[n];
+    if (!S.on_pe) continue;
+    const int J = S.JsdB, I = S.IsdB;
+    if (obc->zero_biharmonic) {      // :889-903
+      if (S.is_N_or_S && J >= Jsq - 1 && J <= Jeq + 1) { for (int i = S.isd; i <= S.ied; i++) fv[g.v2(i, J)] |= 1; }
+      else if (S.is_E_or_W && I >= Isq - 1 && I <= Ieq + 1) { for (int j = S.jsd; j <= S.jed; j++) fu[g.u2(I, j)] |= 1; }
+    }
+    if (obc->zero_strain || obc->freeslip_strain) {      // :1388-1409
+      if (S.is_N_or_S && J >= js - 1 && J <= Jeq) { for (int Iq = S.IsdB; Iq <= S.IedB; Iq++) q[g.q2(Iq, J)] |= obc->zero_strain ? 12 : 8; }
+      else if (S.is_E_or_W && I >= is - 1 && I <= Ieq) { for (int Jq = S.JsdB; Jq <= S.JedB; Jq++) q[g.q2(I, Jq)] |= obc->zero_strain ? 12 : 4; }
+    }
+    if (S.is_E_or_W) for (int j = S.jsd; j <= S.jed; j++) fu[g.u2(I, j)] |= 2;      // :1751-1762
+    if (S.is_N_or_S) for (int i = S.isd; i <= S.ied; i++) fv[g.v2(i, J)] |= 2;      // :1771-1782
+  }
+  int32_t *dm = (int32_t *)st.scratch(4 * m.size());
+  M6_REQUIRE(!st.failed() && dm, "horizontal_viscosity: staging of the open boundaries failed");
+  M6_HIP(hipMemcpyAsync(dm, m.data(), 4 * m.size(), hipMemcpyHostToDevice, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));      // (the host vector goes out of scope)
+  ob.q = dm; ob.fu = dm + nQ; ob.fv = ob.fu + nU; ob.hu = ob.fv + nV; ob.hv = ob.hu + nU;
+  return 0;
+}
+}  // namespace
+
+// horizontal_viscosity with OBC associated; obc == NULL or not OBC%OBC_pe: mom6hip_horizontal_viscosity
+extern "C" int mom6hip_horizontal_viscosity_obc(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,
+                                                const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
+                                                const double *hv_cont, const mom6hip_obc_t *obc, int32_t memspace) {
   (void)dt;
   M6_REQUIRE(ctx != nullptr, "MOM_hor_visc: Module must be initialized before it is used.");
   M6_REQUIRE(cs && u && v && h && diffu && diffv, "horizontal_viscosity: null argument");
@@ -775,6 +918,9 @@ extern "C" int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_ho
   dcs.MEKE_Ku = st.in(cs->MEKE_Ku, bH2); dcs.MEKE_Au = st.in(cs->MEKE_Au, bH2);
   dcs.MEKE_mom_src = cs->MEKE_mom_src ? st.inout(cs->MEKE_mom_src, bH2) : nullptr;
   M6_REQUIRE(!st.failed(), "horizontal_viscosity: staging failed");
-  if (m6::horizontal_viscosity_dev(ctx, &dcs, du, dv, dh, ddu, ddv, dhu, dhv)) return 1;
+  m6::HVObcDev ob;
+  const bool apply_OBC = obc && obc->OBC_pe;      // :449-452
+  if (apply_OBC && hv_obc_maps(ctx, st, obc, ob)) return 1;
+  if (m6::horizontal_viscosity_dev(ctx, &dcs, du, dv, dh, ddu, ddv, dhu, dhv, apply_OBC ? &ob : nullptr)) return 1;
   return st.finish();
 }

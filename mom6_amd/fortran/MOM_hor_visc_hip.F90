@@ -12,7 +12,7 @@ module MOM_hor_visc
 
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
-use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if
+use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_read_topology, mom6hip_fatal_if, mom6hip_obc_to_c
 use MOM_barotropic,            only : barotropic_CS
 use MOM_diag_mediator,         only : diag_ctrl, time_type
 use MOM_error_handler,         only : MOM_error, FATAL, WARNING
@@ -110,11 +110,14 @@ subroutine horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, 
   real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), target, optional, intent(in) :: hv_cont
   type(stochastic_CS), intent(inout), optional :: STOCH
   type(c_ptr) :: p_hu, p_hv
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
+  logical :: apply_OBC
   integer :: rc
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_hor_visc: Module must be initialized before it is used.")
   if (.not.(CS%st%Laplacian /= 0 .or. CS%st%biharmonic /= 0)) return      ! :451
-  if (present(OBC)) then ; if (associated(OBC)) &
-    call MOM_error(FATAL, "horizontal_viscosity (HIP): open boundary conditions are not supported by the GPU path.") ; endif
+  apply_OBC = .false.      ! :449-452
+  if (present(OBC)) then ; if (associated(OBC)) then ; if (OBC%OBC_pe) apply_OBC = .true. ; endif ; endif
   ! VarMix: the resolution function scales the Laplacian viscosity only (rescale_Kh, :474-476, :1123, :1525)
   if (VarMix%use_variable_mixing .and. VarMix%Resoln_scaled_Kh .and. (CS%st%Laplacian /= 0)) &
     call MOM_error(FATAL, "horizontal_viscosity (HIP): RESOLN_SCALED_KH with LAPLACIAN is not provided by the GPU path.")
@@ -123,8 +126,14 @@ subroutine horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, 
   p_hu = c_null_ptr ; if (present(hu_cont)) p_hu = c_loc(hu_cont)
   p_hv = c_null_ptr ; if (present(hv_cont)) p_hv = c_loc(hv_cont)
   diffu(:,:,:) = 0.0 ; diffv(:,:,:) = 0.0      ! (intent(out): the library writes the computational ranges only)
-  rc = mom6hip_horizontal_viscosity(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(diffu), c_loc(diffv), dt, &
-                                    p_hu, p_hv, MOM6HIP_MEM_HOST)
+  if (apply_OBC) then      ! the strains, thicknesses and Laplacians at the segments (:733-849, :889-903, :1388-1409, :1751-1782)
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(u(:,:,1)), size(v(:,:,1)), "MOM_hor_visc")
+    rc = mom6hip_horizontal_viscosity_obc(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(diffu), &
+                                          c_loc(diffv), dt, p_hu, p_hv, cobc, MOM6HIP_MEM_HOST)
+  else
+    rc = mom6hip_horizontal_viscosity(mom6hip_shared_context(G, GV), CS%st, c_loc(u), c_loc(v), c_loc(h), c_loc(diffu), c_loc(diffv), dt, &
+                                      p_hu, p_hv, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "horizontal_viscosity")
 end subroutine horizontal_viscosity
 

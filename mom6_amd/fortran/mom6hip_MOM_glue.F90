@@ -460,6 +460,8 @@ subroutine mom6hip_obc_to_c(OBC, cobc, csegs, n_u2, n_v2, who)
   cobc%Flather_v_BCs_exist_globally = merge(1, 0, OBC%Flather_v_BCs_exist_globally)
   cobc%zero_vorticity = merge(1, 0, OBC%zero_vorticity) ; cobc%freeslip_vorticity = merge(1, 0, OBC%freeslip_vorticity)
   cobc%computed_vorticity = merge(1, 0, OBC%computed_vorticity) ; cobc%specified_vorticity = merge(1, 0, OBC%specified_vorticity)
+  cobc%zero_strain = merge(1, 0, OBC%zero_strain) ; cobc%freeslip_strain = merge(1, 0, OBC%freeslip_strain)
+  cobc%computed_strain = merge(1, 0, OBC%computed_strain) ; cobc%zero_biharmonic = merge(1, 0, OBC%zero_biharmonic)
   cobc%segment = c_loc(csegs)
   if (OBC%number_of_segments > 0) then
     if (.not.(allocated(OBC%segnum_u) .and. allocated(OBC%segnum_v))) call MOM_error(FATAL, &

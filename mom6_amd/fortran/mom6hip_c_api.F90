@@ -209,7 +209,7 @@ type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: specified_u_BCs_exist_globally = 0, specified_v_BCs_exist_globally = 0
   integer(c_int32_t) :: Flather_u_BCs_exist_globally = 0, Flather_v_BCs_exist_globally = 0
   integer(c_int32_t) :: zero_vorticity = 0, freeslip_vorticity = 0, computed_vorticity = 0, specified_vorticity = 0
-  integer(c_int32_t) :: reserved(4) = 0
+  integer(c_int32_t) :: zero_strain = 0, freeslip_strain = 0, computed_strain = 0, zero_biharmonic = 0
   type(c_ptr) :: segment = c_null_ptr, segnum_u = c_null_ptr, segnum_v = c_null_ptr
   type(c_ptr) :: reserved_p(4) = c_null_ptr
 end type mom6hip_obc_t
@@ -962,6 +962,18 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_horizontal_viscosity
+
+  !> horizontal_viscosity with OBC associated
+  function mom6hip_horizontal_viscosity_obc(ctx, cs, u, v, h, diffu, diffv, dt, hu_cont, hv_cont, obc, memspace) &
+                                            bind(c, name="mom6hip_horizontal_viscosity_obc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_hor_visc_cs_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, u, v, h, diffu, diffv, hu_cont, hv_cont
+    type(mom6hip_hor_visc_cs_t), intent(in) :: cs
+    real(c_double), value :: dt
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_horizontal_viscosity_obc
 
   function mom6hip_dyn_split_rk2_init(ctx, cs, u, v, h, uh, vh, dt) bind(c, name="mom6hip_dyn_split_rk2_init") result(rc)
     import :: c_int, c_double, c_ptr, mom6hip_dyn_split_rk2_cs_t

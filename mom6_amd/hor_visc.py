@@ -30,6 +30,8 @@ def _setup():
         cs = C.POINTER(_abi.HorViscCS)
         L.mom6hip_hor_visc_init.argtypes = [C.c_void_p, cs, C.c_double, C.c_int32]
         L.mom6hip_horizontal_viscosity.argtypes = [C.c_void_p, cs] + [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_void_p, C.c_int32]
+        L.mom6hip_horizontal_viscosity_obc.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_void_p,
+                                                                                              C.POINTER(_abi.Obc), C.c_int32])
         L._hv_ready = True
     return L
 
@@ -98,12 +100,12 @@ def horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G: DeviceGrid, CS:
                          ADp=None, hu_cont=None, hv_cont=None, STOCH=None):
     """horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, CS, tv, dt, OBC, BT, TD, ADp, hu_cont, hv_cont, STOCH)
     -- :245.  MEKE: None, or a dict with any of Ku, Au (h-point 2-D arrays added to the Laplacian / biharmonic viscosity) and mom_src
-    (receives the vertically summed frictional work); VarMix, OBC, BT, TD, ADp, STOCH belong to branches this build does not provide
-    and must be None."""
+    (receives the vertically summed frictional work); OBC: None or an ocean_OBC_type (mom6_amd/open_boundary.py); VarMix, BT, TD, ADp,
+    STOCH belong to branches this build does not provide and must be None."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_hor_visc: Module must be initialized before it is used.")
-    if any(x is not None for x in (VarMix, OBC, BT, TD, ADp, STOCH)):
-        raise Mom6HipError("horizontal_viscosity (HIP): VarMix, OBC, GME (BT, TD), ADp and STOCH are not supported on this path")
+    if any(x is not None for x in (VarMix, BT, TD, ADp, STOCH)):
+        raise Mom6HipError("horizontal_viscosity (HIP): VarMix, GME (BT, TD), ADp and STOCH are not supported on this path")
     MEKE = MEKE or {}
     if set(MEKE) - {"Ku", "Au", "mom_src"}:
         raise Mom6HipError("horizontal_viscosity (HIP): of MEKE only Ku, Au and mom_src are provided (no GME_snk, no backscatter)")
@@ -124,5 +126,11 @@ def horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G: DeviceGrid, CS:
         spaces.add(s); ptrs.append(C.c_void_p(p))
     if len(spaces) != 1:
         raise Mom6HipError("horizontal_viscosity: the fields and the arrays of the control structure must be in the same memory space")
+    if OBC is not None:      # the branches of an associated OBC on the PE (:449-452)
+        obc = OBC.struct(lambda a: (0, None))      # (none of the segments' own arrays is read: OBC_COMPUTED_STRAIN is refused)
+        check(_setup().mom6hip_horizontal_viscosity_obc(G.handle, C.byref(CS.st), ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                                                        float(CS.dt if dt is None else dt), ptrs[5], ptrs[6], C.byref(obc), CS.space),
+              "horizontal_viscosity")
+        return
     check(_setup().mom6hip_horizontal_viscosity(G.handle, C.byref(CS.st), ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
                                                 float(CS.dt if dt is None else dt), ptrs[5], ptrs[6], CS.space), "horizontal_viscosity")

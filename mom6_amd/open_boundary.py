@@ -86,8 +86,13 @@ class ocean_OBC_type:
     def __init__(self, grid, segment_strs, idg_offset=None, jdg_offset=None, ni_global=None, nj_global=None, **flags):
         g = self.grid = grid
         # OBC_ZERO_VORTICITY, OBC_FREESLIP_VORTICITY, OBC_COMPUTED_VORTICITY, OBC_SPECIFIED_VORTICITY (:470-500), read by CorAdCalc
-        for n in ("zero_vorticity", "freeslip_vorticity", "computed_vorticity", "specified_vorticity"):
+        # OBC_ZERO_STRAIN, OBC_FREESLIP_STRAIN, OBC_COMPUTED_STRAIN (:492-506), OBC_ZERO_BIHARMONIC (:518), read by horizontal_viscosity
+        for n in ("zero_vorticity", "freeslip_vorticity", "computed_vorticity", "specified_vorticity", "zero_strain", "freeslip_strain",
+                  "computed_strain", "zero_biharmonic"):
             setattr(self, n, bool(flags.pop(n, False)))
+        if (self.zero_strain and self.freeslip_strain) or (self.zero_strain and self.computed_strain) or (self.freeslip_strain and self.computed_strain):
+            raise Mom6HipError("MOM_open_boundary.F90, open_boundary_config: Only one of OBC_ZERO_STRAIN, OBC_FREESLIP_STRAIN, "
+                               "OBC_COMPUTED_STRAIN and OBC_IMPORTED_STRAIN can be True at once.")      # :507-514
         # OBC_RAD_VEL_WT, OBC_RADIATION_MAX (:629-640) and the restart fields of the radiation (arrays at u / v points, nk layers, in the
         # memory space of the calls; None with gamma_uv >= 1)
         self.gamma_uv, self.rx_max = float(flags.pop("gamma_uv", 0.3)), float(flags.pop("rx_max", 1.0))
@@ -262,7 +267,7 @@ class ocean_OBC_type:
             for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel"):
                 a = getattr(s, k)
                 need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient, "nudged_normal_vel": s.nudged,
-                        "tangential_vel": self.computed_vorticity, "tangential_grad": self.specified_vorticity}[k]
+                        "tangential_vel": self.computed_vorticity or self.computed_strain, "tangential_grad": self.specified_vorticity}[k]
                 if a is not None and need and s.on_pe:
                     if to_ptr is None:
                         a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); setattr(c, k, a.ctypes.data)
@@ -272,7 +277,7 @@ class ocean_OBC_type:
         o.number_of_segments, o.OBC_pe = self.number_of_segments, int(self.OBC_pe)
         for k in ("open_u_BCs_exist_globally", "open_v_BCs_exist_globally", "specified_u_BCs_exist_globally", "specified_v_BCs_exist_globally",
                   "Flather_u_BCs_exist_globally", "Flather_v_BCs_exist_globally", "zero_vorticity", "freeslip_vorticity", "computed_vorticity",
-                  "specified_vorticity"):
+                  "specified_vorticity", "zero_strain", "freeslip_strain", "computed_strain", "zero_biharmonic"):
             setattr(o, k, int(getattr(self, k)))
         o.segment = C.cast(segs, C.POINTER(_abi.ObcSegment))
         o.segnum_u, o.segnum_v = self.segnum_u.ctypes.data, self.segnum_v.ctypes.data

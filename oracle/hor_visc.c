@@ -234,7 +234,28 @@ int orc_hor_visc_init(const mom6hip_grid_t *G, mom6hip_hor_visc_cs_t *CS, double
 int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_t *CS, const double *u, const double *v,
                              const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
                              const double *hv_cont) {
+  return orc_horizontal_viscosity_obc(G, CS, u, v, h, diffu, diffv, dt, hu_cont, hv_cont, NULL);
+}
+
+#define MAX2I(a, b) ((a) > (b) ? (a) : (b))
+#define MIN2I(a, b) ((a) < (b) ? (a) : (b))
+/* a segment's tangential_vel on its own index ranges (IsdB:IedB, JsdB:JedB, nk), k 1-based */
+static inline double seg_tang(const mom6hip_obc_segment_t *S, int I, int J, int k) {
+  const long nI = S->IedB - S->IsdB + 1, nJ = S->JedB - S->JsdB + 1;
+  return S->tangential_vel[(I - S->IsdB) + nI * ((J - S->JsdB) + nJ * (long)(k - 1))];
+}
+
+/* horizontal_viscosity with OBC associated (and OBC%OBC_pe): the strains at the corner points of the segments :733-790, the thicknesses at
+ * and beside their faces :791-849, OBC_ZERO_BIHARMONIC :889-903, the gradient of the Laplacian :1388-1409, the accelerations of the
+ * segments' own faces :1751-1780.  (A segment that is not on the PE carries no index ranges here: it is skipped.) */
+int orc_horizontal_viscosity_obc(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_t *CS, const double *u, const double *v,
+                                 const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
+                                 const double *hv_cont, const mom6hip_obc_t *OBC) {
   (void)dt;
+  const int apply_OBC = OBC && OBC->OBC_pe;      /* :449-452 */
+  if (apply_OBC && OBC->number_of_segments > 0 && !OBC->segment) return 2;
+  if (apply_OBC && OBC->computed_strain)
+    for (int n = 0; n < OBC->number_of_segments; n++) if (OBC->segment[n].on_pe && !OBC->segment[n].tangential_vel) return 2;
   if (!CS->initialized) return 3;      /* "MOM_hor_visc: Module must be initialized before it is used." */
   if (unsupported(CS)) return 1;
   if (!(CS->Laplacian || CS->biharmonic)) return 0;      /* :451 */
@@ -301,6 +322,69 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
       for (int j = js - 2; j <= je + 2; j++) for (int I = Isq - 1; I <= Ieq + 1; I++) h_u[U2(I,j)] = hu_cont[U3(I,j,k)];
       for (int J = Jsq - 1; J <= Jeq + 1; J++) for (int i = is - 2; i <= ie + 2; i++) h_v[V2(i,J)] = hv_cont[V3(i,J,k)];
     }
+    if (apply_OBC) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :733-819 */
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (!S->on_pe) continue;
+      const int J = S->JsdB, I = S->IsdB;
+      if (OBC->zero_strain || OBC->freeslip_strain || OBC->computed_strain) {
+        if (S->is_N_or_S && (J >= js_vort) && (J <= je_vort)) {
+          const int j = J;
+          for (int Iq = MAX2I(S->IsdB, is_vort); Iq <= MIN2I(S->IedB, ie_vort); Iq++) {
+            if (OBC->zero_strain) { dvdx[Q2(Iq,J)] = 0.; dudy[Q2(Iq,J)] = 0.; }
+            else if (OBC->freeslip_strain) dudy[Q2(Iq,J)] = 0.;
+            else if (OBC->computed_strain) {
+              if (S->direction == MOM6HIP_OBC_DIRECTION_N)
+                dudy[Q2(Iq,J)] = 2.0 * DX_dyBu(Iq,J) * (seg_tang(S, Iq, J, k) - u[U3(Iq,j,k)]) * G->IdxCu[U2(Iq,j)];
+              else
+                dudy[Q2(Iq,J)] = 2.0 * DX_dyBu(Iq,J) * (u[U3(Iq,j+1,k)] - seg_tang(S, Iq, J, k)) * G->IdxCu[U2(Iq,j+1)];
+            }
+          }
+        } else if (S->is_E_or_W && (I >= is_vort) && (I <= ie_vort)) {
+          const int i = I;
+          for (int Jq = MAX2I(S->JsdB, js_vort); Jq <= MIN2I(S->JedB, je_vort); Jq++) {
+            if (OBC->zero_strain) { dvdx[Q2(I,Jq)] = 0.; dudy[Q2(I,Jq)] = 0.; }
+            else if (OBC->freeslip_strain) dvdx[Q2(I,Jq)] = 0.;
+            else if (OBC->computed_strain) {
+              if (S->direction == MOM6HIP_OBC_DIRECTION_E)
+                dvdx[Q2(I,Jq)] = 2.0 * DY_dxBu(I,Jq) * (seg_tang(S, I, Jq, k) - v[V3(i,Jq,k)]) * G->IdyCv[V2(i,Jq)];
+              else
+                dvdx[Q2(I,Jq)] = 2.0 * DY_dxBu(I,Jq) * (v[V3(i+1,Jq,k)] - seg_tang(S, I, Jq, k)) * G->IdyCv[V2(i+1,Jq)];
+            }
+          }
+        }
+      }
+      if (S->direction == MOM6HIP_OBC_DIRECTION_N) {      /* :791-819: the thickness of the cell inside at the segment's faces */
+        if ((J >= js - 2) && (J <= Jeq + 1))
+          for (int i = MAX2I(is - 2, S->isd); i <= MIN2I(ie + 2, S->ied); i++) h_v[V2(i,J)] = h[H3(i,J,k)];
+      } else if (S->direction == MOM6HIP_OBC_DIRECTION_S) {
+        if ((J >= js - 2) && (J <= Jeq + 1))
+          for (int i = MAX2I(is - 2, S->isd); i <= MIN2I(ie + 2, S->ied); i++) h_v[V2(i,J)] = h[H3(i,J+1,k)];
+      } else if (S->direction == MOM6HIP_OBC_DIRECTION_E) {
+        if ((I >= is - 2) && (I <= Ieq + 1))
+          for (int j = MAX2I(js - 2, S->jsd); j <= MIN2I(je + 2, S->jed); j++) h_u[U2(I,j)] = h[H3(I,j,k)];
+      } else if (S->direction == MOM6HIP_OBC_DIRECTION_W) {
+        if ((I >= is - 2) && (I <= Ieq + 1))
+          for (int j = MAX2I(js - 2, S->jsd); j <= MIN2I(je + 2, S->jed); j++) h_u[U2(I,j)] = h[H3(I+1,j,k)];
+      }
+    }
+    if (apply_OBC) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :821-849: then across the corner points of the segments */
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (!S->on_pe) continue;
+      const int J = S->JsdB, I = S->IsdB;
+      if (S->direction == MOM6HIP_OBC_DIRECTION_N) {
+        if ((J >= js - 2) && (J <= je))
+          for (int Iq = MAX2I(is - 2, S->IsdB); Iq <= MIN2I(Ieq + 1, S->IedB); Iq++) h_u[U2(Iq,J+1)] = h_u[U2(Iq,J)];
+      } else if (S->direction == MOM6HIP_OBC_DIRECTION_S) {
+        if ((J >= js - 1) && (J <= je + 1))
+          for (int Iq = MAX2I(is - 2, S->isd); Iq <= MIN2I(Ieq + 1, S->ied); Iq++) h_u[U2(Iq,J)] = h_u[U2(Iq,J+1)];
+      } else if (S->direction == MOM6HIP_OBC_DIRECTION_E) {
+        if ((I >= is - 2) && (I <= ie))
+          for (int Jq = MAX2I(js - 2, S->jsd); Jq <= MIN2I(Jeq + 1, S->jed); Jq++) h_v[V2(I+1,Jq)] = h_v[V2(I,Jq)];
+      } else if (S->direction == MOM6HIP_OBC_DIRECTION_W) {
+        if ((I >= is - 1) && (I <= ie + 1))
+          for (int Jq = MAX2I(js - 2, S->jsd); Jq <= MIN2I(Jeq + 1, S->jed); Jq++) h_v[V2(I,Jq)] = h_v[V2(I+1,Jq)];
+      }
+    }
     /* shearing strain :852-864 */
     for (int J = js - 2; J <= Jeq + 1; J++) for (int I = is - 2; I <= Ieq + 1; I++) {
       if (CS->no_slip) sh_xy[Q2(I,J)] = (2.0 - G->mask2dBu[Q2(I,J)]) * (dvdx[Q2(I,J)] + dudy[Q2(I,J)]);
@@ -317,6 +401,16 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
         const int I = i, j = J;
         Del2v[V2(i,J)] = Idxdy2v(i,J) * (dy2q(I,J) * sh_xy[Q2(I,J)] - dy2q(I-1,J) * sh_xy[Q2(I-1,J)]) -
                          Idx2dyCv(i,J) * (dx2h(i,j+1) * sh_xx[H2(i,j+1)] - dx2h(i,j) * sh_xx[H2(i,j)]);
+      }
+      if (apply_OBC && OBC->zero_biharmonic) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :889-903 */
+        const mom6hip_obc_segment_t *S = &OBC->segment[n];
+        if (!S->on_pe) continue;
+        const int I = S->IsdB, J = S->JsdB;
+        if (S->is_N_or_S && (J >= Jsq - 1) && (J <= Jeq + 1)) {
+          for (int i = S->isd; i <= S->ied; i++) Del2v[V2(i,J)] = 0.;
+        } else if (S->is_E_or_W && (I >= Isq - 1) && (I <= Ieq + 1)) {
+          for (int j = S->jsd; j <= S->jed; j++) Del2u[U2(I,j)] = 0.;
+        }
       }
     }
     /* Smagorinsky shear magnitude at h points :1056-1063 */
@@ -393,6 +487,22 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
         const int i = I, j = J;
         dDel2vdx[Q2(I,J)] = DY_dxBu(I,J) * (Del2v[V2(i+1,J)] * G->IdyCv[V2(i+1,J)] - Del2v[V2(i,J)] * G->IdyCv[V2(i,J)]);
         dDel2udy[Q2(I,J)] = DX_dyBu(I,J) * (Del2u[U2(I,j+1)] * G->IdxCu[U2(I,j+1)] - Del2u[U2(I,j)] * G->IdxCu[U2(I,j)]);
+      }
+      if (apply_OBC && (OBC->zero_strain || OBC->freeslip_strain)) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :1388-1409 */
+        const mom6hip_obc_segment_t *S = &OBC->segment[n];
+        if (!S->on_pe) continue;
+        const int J = S->JsdB, I = S->IsdB;
+        if (S->is_N_or_S && (J >= js - 1) && (J <= Jeq)) {
+          for (int Iq = S->IsdB; Iq <= S->IedB; Iq++) {
+            if (OBC->zero_strain) { dDel2vdx[Q2(Iq,J)] = 0.; dDel2udy[Q2(Iq,J)] = 0.; }
+            else if (OBC->freeslip_strain) dDel2udy[Q2(Iq,J)] = 0.;
+          }
+        } else if (S->is_E_or_W && (I >= is - 1) && (I <= Ieq)) {
+          for (int Jq = S->JsdB; Jq <= S->JedB; Jq++) {
+            if (OBC->zero_strain) { dDel2vdx[Q2(I,Jq)] = 0.; dDel2udy[Q2(I,Jq)] = 0.; }
+            else if (OBC->freeslip_strain) dDel2vdx[Q2(I,Jq)] = 0.;
+          }
+        }
       }
     }
     /* ---- q points ---- */
@@ -503,11 +613,19 @@ int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_
                            G->IdxCu[U2(I,j)] * (dx2q(I,J-1) * str_xy[Q2(I,J-1)] - dx2q(I,J) * str_xy[Q2(I,J)])) *
                           G->IareaCu[U2(I,j)]) / (h_u[U2(I,j)] + h_neglect);
     }
+    if (apply_OBC) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :1751-1762 */
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (S->on_pe && S->is_E_or_W) for (int j = S->jsd; j <= S->jed; j++) diffu[U3(S->IsdB,j,k)] = 0.;
+    }
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++) {
       const int I = i, j = J;
       diffv[V3(i,J,k)] = ((G->IdyCv[V2(i,J)] * (dy2q(I-1,J) * str_xy[Q2(I-1,J)] - dy2q(I,J) * str_xy[Q2(I,J)]) -
                            G->IdxCv[V2(i,J)] * (dx2h(i,j) * str_xx[H2(i,j)] - dx2h(i,j+1) * str_xx[H2(i,j+1)])) *
                           G->IareaCv[V2(i,J)]) / (h_v[V2(i,J)] + h_neglect);
+    }
+    if (apply_OBC) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :1771-1782 */
+      const mom6hip_obc_segment_t *S = &OBC->segment[n];
+      if (S->on_pe && S->is_N_or_S) for (int i = S->isd; i <= S->ied; i++) diffv[V3(i,S->JsdB,k)] = 0.;
     }
     if (FrictWork) {      /* :1783-1800 */
       for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) {

@@ -251,6 +251,10 @@ int orc_hor_visc_init(const mom6hip_grid_t *G, mom6hip_hor_visc_cs_t *CS, double
 int orc_horizontal_viscosity(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_t *CS, const double *u, const double *v,
                              const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
                              const double *hv_cont);
+/* horizontal_viscosity with OBC associated (:733-849, :889-903, :1388-1409, :1751-1782) */
+int orc_horizontal_viscosity_obc(const mom6hip_grid_t *G, const mom6hip_hor_visc_cs_t *CS, const double *u, const double *v,
+                                 const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
+                                 const double *hv_cont, const mom6hip_obc_t *OBC);
 
 int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *CS, const double *u, const double *v,
                            const double *h, double *uh, double *vh, double dt);

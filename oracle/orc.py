@@ -923,12 +923,14 @@ def hor_visc_set_meke(cs, Ku=None, Au=None, mom_src=None):
     return cs._meke[2]
 
 
-def horizontal_viscosity(grid, cs, u, v, h, dt, hu_cont=None, hv_cont=None, diffu=None, diffv=None):
-    L = lib(); L.orc_horizontal_viscosity.argtypes = [C.POINTER(_abi.GridStruct), C.POINTER(_abi.HorViscCS)] + [_dp] * 5 + [C.c_double, _dp, _dp]
+def horizontal_viscosity(grid, cs, u, v, h, dt, hu_cont=None, hv_cont=None, diffu=None, diffv=None, OBC=None):
+    L = lib(); L.orc_horizontal_viscosity_obc.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.HorViscCS)] + [_dp] * 5
+                                                         + [C.c_double, _dp, _dp, C.POINTER(_abi.Obc)])
     diffu = grid.zeros3(_abi.POS_U) if diffu is None else diffu
     diffv = grid.zeros3(_abi.POS_V) if diffv is None else diffv
-    rc = L.orc_horizontal_viscosity(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(diffu), _p(diffv), float(dt),
-                                    _p(hu_cont), _p(hv_cont))
+    obc = None if OBC is None else OBC.struct()
+    rc = L.orc_horizontal_viscosity_obc(C.byref(grid.struct()), C.byref(cs), _p(u), _p(v), _p(h), _p(diffu), _p(diffv), float(dt),
+                                        _p(hu_cont), _p(hv_cont), None if obc is None else C.byref(obc))
     if rc:
         raise RuntimeError(f"orc_horizontal_viscosity rc={rc}")
     return diffu, diffv

@@ -5,6 +5,7 @@
 !!   continuity(u, v, h, hp, uh, vh, dt, G, GV, US, CS, OBC, pbv, uhbt, vhbt, visc_rem_u, visc_rem_v, u_cor, v_cor, BT_cont)
 !!   CorAdCalc(u, v, h, uh, vh, CAu, CAv, OBC, AD, G, GV, US, CS, pbv)                         (MOM_dynamics_split_RK2.F90:869)
 !!   set_visc_init(..., OBC) ; set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)     (MOM.F90:1205; layer mode, as .testing/tc3)
+!!   hor_visc_init ; horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, CS, tv, dt, OBC=OBC)          (:860; tc3's viscosities)
 !!   vertvisc_coef(u, v, h, dz, forces, visc, tv, dt, G, GV, US, CS, OBC, VarMix) ; vertvisc(u, v, h, forces, visc, dt, OBC, ...)   (:717-731)
 !! on plain host arrays; the results go to the output file, which the test compares with the oracle bit for bit.
 !! Usage: obc_driver <input file> <output file>
@@ -14,6 +15,8 @@ use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_P
 use MOM_CoriolisAdv,    only : CorAdCalc, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_CS
 use MOM_set_visc,       only : set_visc_CS, set_visc_init, set_viscous_BBL, set_visc_end
 use MOM_restart,        only : MOM_restart_CS
+use MOM_hor_visc,       only : hor_visc_CS, hor_visc_init, horizontal_viscosity, hor_visc_end
+use MOM_MEKE_types,     only : MEKE_type
 use MOM_vert_friction,  only : vertvisc_CS, vertvisc_init, vertvisc_coef, vertvisc, vertvisc_end
 use MOM_variables,      only : accel_diag_ptrs, cont_diag_ptrs, vertvisc_type, thermo_var_ptrs, ocean_internal_state
 use MOM_forcing_type,   only : mech_forcing
@@ -56,6 +59,10 @@ type(directories) :: dirs
 type(vertvisc_CS), pointer :: VV => NULL()
 type(vertvisc_type) :: visc
 type(set_visc_CS) :: SVC
+type(hor_visc_CS) :: HV
+type(MEKE_type) :: MEKE
+integer(c_int32_t) :: stflags(4)
+real, allocatable, dimension(:,:,:) :: diffu, diffv
 type(MOM_restart_CS) :: restart_CS
 type(thermo_var_ptrs) :: tv
 type(mech_forcing) :: forces
@@ -138,6 +145,10 @@ do n=1,nseg ; if (OBC%segment(n)%on_pe) then
   allocate(OBC%segment(n)%tangential_grad(OBC%segment(n)%HI%IsdB:OBC%segment(n)%HI%IedB, OBC%segment(n)%HI%JsdB:OBC%segment(n)%HI%JedB, nk))
   read(u_in) OBC%segment(n)%tangential_vel, OBC%segment(n)%tangential_grad
 endif ; enddo
+! OBC_ZERO_STRAIN, OBC_FREESLIP_STRAIN, OBC_COMPUTED_STRAIN, OBC_ZERO_BIHARMONIC
+read(u_in) stflags
+OBC%zero_strain = (stflags(1) /= 0) ; OBC%freeslip_strain = (stflags(2) /= 0)
+OBC%computed_strain = (stflags(3) /= 0) ; OBC%zero_biharmonic = (stflags(4) /= 0)
 close(u_in)
 
 allocate(hp(isd:ied,jsd:jed,nk), uh(isd-1:ied,jsd:jed,nk), vh(isd:ied,jsd-1:jed,nk), u_cor(isd-1:ied,jsd:jed,nk), v_cor(isd:ied,jsd-1:jed,nk))
@@ -170,14 +181,22 @@ call vertvisc_init(MIS, Time, G, GV, US, pf, diag, AD, dirs, ntrunc, VV)
 call vertvisc_coef(u1, v1, h, dz, forces, visc, tv, dt, G, GV, US, VV, OBC, VarMix)
 call vertvisc(u1, v1, h, forces, visc, dt, OBC, AD, CDp, G, GV, US, VV)
 
+! the horizontal viscosity of the corrector (:860) with tc3's coefficients
+call param_set(pf, "LAPLACIAN", "True") ; call param_set(pf, "KH", "25.0") ; call param_set(pf, "KH_VEL_SCALE", "0.003")
+call param_set(pf, "SMAGORINSKY_KH", "True") ; call param_set(pf, "SMAG_LAP_CONST", "0.15") ; call param_set(pf, "AH_VEL_SCALE", "0.003")
+call param_set(pf, "SMAGORINSKY_AH", "True") ; call param_set(pf, "SMAG_BI_CONST", "0.06")
+call hor_visc_init(Time, G, GV, US, pf, diag, HV)
+allocate(diffu(isd-1:ied,jsd:jed,nk), diffv(isd:ied,jsd-1:jed,nk))
+call horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, HV, tv, dt, OBC=OBC)
+
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) hp, uh, vh, u_cor, v_cor
 write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_EE
 write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
 write(u_out) CAu, CAv
-write(u_out) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v, u1, v1
+write(u_out) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v, u1, v1, diffu, diffv
 close(u_out)
-call vertvisc_end(VV) ; call set_visc_end(visc, SVC)
+call hor_visc_end(HV) ; call vertvisc_end(VV) ; call set_visc_end(visc, SVC)
 call CoriolisAdv_end(CCS)
 call mom6hip_shared_context_end()
 write(*,'(a)') "obc_driver ok"

@@ -1223,7 +1223,7 @@ type :: ocean_OBC_type
   logical :: update_OBC = .false., oblique_BCs_exist_globally = .false., radiation_BCs_exist_globally = .false.
   logical :: ramp = .false., zero_vorticity = .false., freeslip_vorticity = .false., computed_vorticity = .false.
   logical :: specified_vorticity = .false., zero_strain = .false., freeslip_strain = .false., computed_strain = .false.
-  logical :: specified_strain = .false.
+  logical :: specified_strain = .false., zero_biharmonic = .false.
 end type ocean_OBC_type
 contains
 logical function open_boundary_query(OBC, apply_open_OBC, apply_specified_OBC, apply_Flather_OBC, apply_nudged_OBC, needs_ext_seg_data)

@@ -297,6 +297,7 @@ def _write_obc_case(path, g, st, OBC, uhbt, vhbt, dt=900.0):
         for s in OBC.segment:
             if s.on_pe:
                 np.ascontiguousarray(s.tangential_vel, dtype="<f8").tofile(f); np.ascontiguousarray(s.tangential_grad, dtype="<f8").tofile(f)
+        np.array([OBC.zero_strain, OBC.freeslip_strain, OBC.computed_strain, OBC.zero_biharmonic], dtype="<i4").tofile(f)
 
 
 def test_obc_driver_compiles(tmp_path):
@@ -321,6 +322,8 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
     g, st, OBC = obc_case(segs)
     OBC.freeslip_vorticity = segs is not None and len(segs) == 5      # tc3's OBC_FREESLIP_VORTICITY; the other set: the computed vorticity
     OBC.computed_vorticity = not OBC.freeslip_vorticity
+    OBC.freeslip_strain = OBC.zero_biharmonic = OBC.freeslip_vorticity      # tc3's OBC_FREESLIP_STRAIN, OBC_ZERO_BIHARMONIC; the other set: OBC_ZERO_STRAIN
+    OBC.zero_strain = not OBC.freeslip_strain
     rng = np.random.default_rng(12)
     for s in OBC.segment:
         if s.on_pe:
@@ -339,14 +342,19 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
     orc.vertvisc_coef(g, vcs, want["u1"], want["v1"], st["h"], visc, 900.0, OBC=OBC)
     orc.vertvisc(g, vcs, want["u1"], want["v1"], st["h"], np.ascontiguousarray(0.05 * m["mask2dCu"]), np.ascontiguousarray(-0.02 * m["mask2dCv"]),
                  visc, 900.0, OBC=OBC)
+    # (BOUND_CORIOLIS = True, set for CoriolisAdv_init as in tc3, is the default of BOUND_CORIOLIS_BIHARM; BOUND_CORIOLIS_VEL defaults to MAXVEL)
+    want["diffu"], want["diffv"] = orc.horizontal_viscosity(
+        g, orc.hor_visc_cs(g, 900.0, Laplacian=1, Kh=25.0, Kh_vel_scale=0.003, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Ah_vel_scale=0.003, Smagorinsky_Ah=1,
+                           Smag_bi_const=0.06, bound_Coriolis=1, bound_Cor_vel=3.0e8), st["u"], st["v"], st["h"], 900.0, OBC=OBC)
     _write_obc_case(str(tmp_path / "in.bin"), g, st, OBC, want["uhbt"], want["vhbt"])
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
-             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u1", "v1"]
+             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u1", "v1", "diffu", "diffv"]
     arrs = [want[n] if n in want else want["bt"][n] for n in names]
     got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
     for n, a, w in zip(names, got, arrs):
-        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu", "u1", "bbl_thick_u", "Kv_bbl_u") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv", "v1", "bbl_thick_v", "Kv_bbl_v") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
-        assert bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)), n
+        pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu", "u1", "bbl_thick_u", "Kv_bbl_u", "diffu") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv", "v1", "bbl_thick_v", "Kv_bbl_v", "diffv") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
+        ga, wa = interior(g, a.reshape(w.shape), pos), interior(g, w, pos)
+        assert bits_equal(ga, wa), (n, np.argwhere(ga != wa)[:6].tolist(), ga[ga != wa][:4], wa[ga != wa][:4])
