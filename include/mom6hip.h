@@ -519,8 +519,10 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 /*
  * Open boundaries (src/core/MOM_open_boundary.F90): what continuity_PPM reads of ocean_OBC_type (:266-386) and of its segments
  * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc), of CorAdCalc
- * (mom6hip_coradcalc_obc), of vertvisc_coef / vertvisc (mom6hip_vertvisc_coef_obc, mom6hip_vertvisc_obc), and radiation_open_bdry_conds
- * / open_boundary_zero_normal_flow for the normal component; every other entry point of the library still requires that OBC is not associated, so a configuration
+ * (mom6hip_coradcalc_obc), of vertvisc_coef / vertvisc (mom6hip_vertvisc_coef_obc, mom6hip_vertvisc_obc), of btcalc and btstep
+ * (mom6hip_btcalc_obc, mom6hip_btstep_obc), of set_viscous_BBL (mom6hip_set_viscous_bbl_obc), of horizontal_viscosity
+ * (mom6hip_horizontal_viscosity_obc), and radiation_open_bdry_conds / open_boundary_zero_normal_flow for the normal component; every
+ * other entry point (advect_tracer, tracer_hordiff, the RK2 steppers) of the library still requires that OBC is not associated, so a configuration
  * with open boundaries cannot be stepped yet.
  * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */
@@ -541,7 +543,7 @@ typedef struct mom6hip_obc_segment {
   int32_t radiation, gradient, nudged; /* segment%radiation (Orlanski), %gradient, %nudged: read by radiation_open_bdry_conds */
   int32_t oblique;                     /* segment%oblique: not provided (refused by mom6hip_radiation_open_bdry_conds) */
   int32_t radiation_tan_or_grad;       /* segment%radiation_tan .or. %radiation_grad .or. the oblique / nudged counterparts: not provided */
-  int32_t reserved[1];
+  int32_t Flather;                     /* segment%Flather: read by btstep */
   /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where
    * `specified`; in the memory space of the call; may be NULL otherwise */
   const double *normal_trans;
@@ -550,7 +552,9 @@ typedef struct mom6hip_obc_segment {
    * OBC%specified_vorticity; may be NULL otherwise */
   const double *tangential_vel, *tangential_grad;
   const double *nudged_normal_vel;     /* segment%nudged_normal_vel, the layout of normal_vel: read where `nudged` */
-  void *reserved_p[1];
+  /* segment%normal_vel_bt, segment%SSH (IsdB:IedB, jsd:jed) for E / W, (isd:ied, JsdB:JedB) for N / S: the external barotropic velocity
+   * and sea surface height of a Flather segment, read by btstep (set_up_BT_OBC); may be NULL otherwise */
+  const double *normal_vel_bt, *SSH;
   double Velocity_nudging_timescale_in, Velocity_nudging_timescale_out;      /* [T] */
 } mom6hip_obc_segment_t;
 
@@ -756,6 +760,18 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
                    const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
                    const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
                    const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav, int32_t memspace);
+/* btstep with OBC associated: specified, Flather and gradient segments -- the summed gravity projected across the segments (:1089-1110),
+ * set_up_BT_OBC (:3172; the external values segment%normal_vel_bt, %SSH, %normal_trans), the velocities of the segments' faces kept
+ * through the time step and set by apply_velocity_OBCs (:2931) with their running sums, e_anom across the segments (:2490-2519), the
+ * accelerations of the segments' faces (:2591-2606).  A radiation-only segment has no barotropic velocity in the reference and is
+ * refused.  obc == NULL: mom6hip_btstep. */
+int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *U_in, const double *V_in, const double *eta_in,
+                       double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux, const double *tauy,
+                       double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor, const double *V_Cor,
+                       double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav, double *vhbtav,
+                       const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont, const double *eta_PF_start,
+                       const double *taux_bot, const double *tauy_bot, const double *uh0, const double *vh0, const double *u_uh0,
+                       const double *v_vh0, double *etaav, const struct mom6hip_obc *obc, int32_t memspace);
 
 /* ---- MOM_vert_friction ------------------------------------------------------------------------ */
 

@@ -189,8 +189,8 @@ class ObcSegment(C.Structure):
     """mom6hip_obc_segment_t (include/mom6hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("direction", "open", "specified", "on_pe", "is_E_or_W", "is_N_or_S", "IsdB", "IedB", "JsdB", "JedB",
                                          "isd", "ied", "jsd", "jed", "radiation", "gradient", "nudged", "oblique", "radiation_tan_or_grad")] + \
-               [("reserved", C.c_int32 * 1), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("tangential_vel", C.c_void_p),
-                ("tangential_grad", C.c_void_p), ("nudged_normal_vel", C.c_void_p), ("reserved_p", C.c_void_p * 1),
+               [("Flather", C.c_int32), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("tangential_vel", C.c_void_p),
+                ("tangential_grad", C.c_void_p), ("nudged_normal_vel", C.c_void_p), ("normal_vel_bt", C.c_void_p), ("SSH", C.c_void_p),
                 ("Velocity_nudging_timescale_in", C.c_double), ("Velocity_nudging_timescale_out", C.c_double)]
 
 

@@ -112,6 +112,8 @@ def _setup():
         L.mom6hip_set_dtbt_eta.argtypes = [C.c_void_p, cs, C.c_void_p, C.c_void_p, C.POINTER(_abi.BTCont), C.c_double, C.c_double, C.c_int32]
         L.mom6hip_btstep.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4 + [C.c_double]
                                      + [C.c_void_p] * 11 + [C.POINTER(_abi.BTCont)] + [C.c_void_p] * 8 + [C.c_int32])
+        L.mom6hip_btstep_obc.argtypes = ([C.c_void_p, cs] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4 + [C.c_double]
+                                         + [C.c_void_p] * 11 + [C.POINTER(_abi.BTCont)] + [C.c_void_p] * 8 + [C.POINTER(_abi.Obc), C.c_int32])
         L._bt_ready = True
     return L
 
@@ -187,8 +189,6 @@ def btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_
     `forces` is a (taux, tauy) pair of 2-D wind-stress arrays [Pa] (mech_forcing%taux, %tauy)."""
     if not CS.module_is_initialized:
         raise Mom6HipError("btstep: Module MOM_barotropic must be initialized before it is used.")
-    if OBC is not None:
-        raise Mom6HipError("btstep (HIP): open boundaries are not supported")
     if (uh0 is not None) and (vh0 is None or u_uh0 is None or v_vh0 is None):
         raise Mom6HipError("btstep: vh0, u_uh0, and v_vh0 must be associated if uh0 is used.")
     g = CS.grid
@@ -201,5 +201,12 @@ def btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, eta_PF_
     bt = None if BT_cont is None else BT_cont.struct(sp)
     a4 = [P(x) for x in (eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav)]
     RZ_to_H = g.Z_to_H / g.Rho0          # GV%RZ_to_H, Boussinesq (MOM_verticalGrid.F90)
+    space = _one_space(sp, CS, "btstep")
+    if OBC is not None:      # an ocean_OBC_type (mom6_amd/open_boundary.py): specified, Flather and gradient segments
+        from .open_boundary import _seg_to_ptr
+        obc = OBC.struct(_seg_to_ptr(space))
+        check(_setup().mom6hip_btstep_obc(G.handle, C.byref(CS.st), *a1, float(dt), *a2, float(RZ_to_H), *a3,
+                                          None if bt is None else C.byref(bt), *a4, C.byref(obc), space), "btstep")
+        return
     check(_setup().mom6hip_btstep(G.handle, C.byref(CS.st), *a1, float(dt), *a2, float(RZ_to_H), *a3,
-                                  None if bt is None else C.byref(bt), *a4, _one_space(sp, CS, "btstep")), "btstep")
+                                  None if bt is None else C.byref(bt), *a4, space), "btstep")

@@ -72,7 +72,63 @@ struct Work {
       *eta_src, *e_anom;
   double *q;
   Btcl BU, BV;
+  // open boundaries (null without): the code of every face of a segment (OB_*, from OBC%segnum_u / segnum_v and the segments' flags), the
+  // arrays of BT_OBC_type :71-101 that set_up_BT_OBC fills, the velocities before the time step and before the first one, and the
+  // time-filtered velocity of the segments' faces
+  const int32_t *obc_u, *obc_v;
+  double *ob_Cg_u, *ob_dZ_u, *ob_uhbt, *ob_ubt_outer, *ob_SSH_u, *ubt_old, *ubt_first, *ubt_wtd;
+  double *ob_Cg_v, *ob_dZ_v, *ob_vhbt, *ob_vbt_outer, *ob_SSH_v, *vbt_old, *vbt_first, *vbt_wtd;
 };
+enum { OB_SPEC = 1, OB_FLATHER = 2, OB_GRAD = 4, OB_PLUS = 8, OB_MINUS = 16 };      // PLUS: OBC_DIRECTION_E | N (the cell inside is the first one)
+
+// uhbt_to_ubt :3733 / vhbt_to_vbt :3866
+__device__ double uhbt_to_ubt(double uhbt, const Btcl &B, long n) {
+  const double tol = 1.0e-10;
+  const int max_itt = 20;
+  double ubt, ubt_min, ubt_max, uherr_min, uherr_max;
+  if (uhbt == 0.0) {
+    ubt = 0.0;
+  } else if (uhbt < B.uh_EE[n]) {
+    ubt = B.uBT_EE[n] + (uhbt - B.uh_EE[n]) / B.FA_EE[n];
+  } else if (uhbt < 0.0) {
+    ubt_min = B.uBT_EE[n]; uherr_min = B.uh_EE[n] - uhbt;
+    ubt_max = 0.0; uherr_max = -uhbt;
+    ubt = B.uBT_EE[n] * (uhbt / B.uh_EE[n]);
+    for (int itt = 1; itt <= max_itt; itt++) {
+      const double uhbt_err = ubt * (B.FA_E0[n] + B.uh_crvE[n] * (ubt * ubt)) - uhbt;
+      if (fabs(uhbt_err) < tol * fabs(uhbt)) break;
+      if (uhbt_err > 0.0) { ubt_max = ubt; uherr_max = uhbt_err; }
+      if (uhbt_err < 0.0) { ubt_min = ubt; uherr_min = uhbt_err; }
+      const double derr_du = B.FA_E0[n] + 3.0 * B.uh_crvE[n] * (ubt * ubt);
+      if ((uhbt_err >= derr_du * (ubt - ubt_min)) || (-uhbt_err >= derr_du * (ubt_max - ubt)) || (derr_du <= 0.0)) {
+        ubt = ubt_max + (ubt_min - ubt_max) * (uherr_max / (uherr_max - uherr_min));
+      } else {
+        ubt = ubt - uhbt_err / derr_du;
+        if (fabs(uhbt_err) < (0.01 * tol) * fabs(ubt_min * derr_du)) break;
+      }
+    }
+  } else if (uhbt <= B.uh_WW[n]) {
+    ubt_min = 0.0; uherr_min = -uhbt;
+    ubt_max = B.uBT_WW[n]; uherr_max = B.uh_WW[n] - uhbt;
+    ubt = B.uBT_WW[n] * (uhbt / B.uh_WW[n]);
+    for (int itt = 1; itt <= max_itt; itt++) {
+      const double uhbt_err = ubt * (B.FA_W0[n] + B.uh_crvW[n] * (ubt * ubt)) - uhbt;
+      if (fabs(uhbt_err) < tol * fabs(uhbt)) break;
+      if (uhbt_err > 0.0) { ubt_max = ubt; uherr_max = uhbt_err; }
+      if (uhbt_err < 0.0) { ubt_min = ubt; uherr_min = uhbt_err; }
+      const double derr_du = B.FA_W0[n] + 3.0 * B.uh_crvW[n] * (ubt * ubt);
+      if ((uhbt_err >= derr_du * (ubt - ubt_min)) || (-uhbt_err >= derr_du * (ubt_max - ubt)) || (derr_du <= 0.0)) {
+        ubt = ubt_min + (ubt_max - ubt_min) * (-uherr_min / (uherr_max - uherr_min));
+      } else {
+        ubt = ubt - uhbt_err / derr_du;
+        if (fabs(uhbt_err) < (0.01 * tol) * (ubt_max * derr_du)) break;
+      }
+    }
+  } else {
+    ubt = B.uBT_WW[n] + (uhbt - B.uh_WW[n]) / B.FA_WW[n];
+  }
+  return ubt;
+}
 
 // scalars of one btstep call
 struct Par {
@@ -202,6 +258,7 @@ bt_vbt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, doub
   if (i > i1 || J > j1) return;
   const int j = J;
   const long n = g.v2(i, J);
+  if (w.obc_v && w.obc_v[n]) return;      // a face of a segment keeps its velocity and transport (:2043-2048, :2287-2292): bt_obc_kernel sets them
   const double Cor_v = -1.0 * ((w.amer[g.u2(i - 1, j)] * w.ubt[g.u2(i - 1, j)] + w.cmer[g.u2(i, j + 1)] * w.ubt[g.u2(i, j + 1)]) +
                                (w.bmer[g.u2(i, j)] * w.ubt[g.u2(i, j)] + w.dmer[g.u2(i - 1, j + 1)] * w.ubt[g.u2(i - 1, j + 1)])) -
                        w.Cor_ref_v[n];
@@ -234,6 +291,7 @@ bt_ubt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, doub
   if (I > i1 || j > j1) return;
   const int i = I;
   const long n = g.u2(I, j);
+  if (w.obc_u && w.obc_u[n]) return;      // (:2121-2126, :2198-2203)
   const double Cor_u = ((w.azon[n] * w.vbt[g.v2(i + 1, j)] + w.czon[n] * w.vbt[g.v2(i, j - 1)]) +
                         (w.bzon[n] * w.vbt[g.v2(i, j)] + w.dzon[n] * w.vbt[g.v2(i + 1, j - 1)])) - w.Cor_ref_u[n];
   const long hw = g.h2(i, j), he = g.h2(i + 1, j);
@@ -254,6 +312,73 @@ bt_ubt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, doub
   if (I >= g.isc - 1 && I <= g.iec && j >= g.jsc && j <= g.jec) {
     ubt_sum[n] = ubt_sum[n] + wt_trans * utrans;
     uhbt_sum[n] = uhbt_sum[n] + wt_trans * uh;
+  }
+}
+
+// apply_velocity_OBCs :2931-3168 for the faces of the segments of one direction (halo = iev - ie: the window of this time step), with the
+// running sums from the values the faces had before the step (:2367-2395) and the predictor transport of the next step (:1882-1893)
+template <int DIR>
+__global__ void __launch_bounds__(256)
+bt_obc_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, double bebt, double wt_trans, double wt_vel,
+              double *__restrict__ xbt_sum, double *__restrict__ xhbt_sum) {
+  const int i = i0 + blockIdx.x * 64 + threadIdx.x, j = j0 + blockIdx.y * 4 + threadIdx.y;
+  if (i > i1 || j > j1) return;
+  const long f = DIR ? g.v2(i, j) : g.u2(i, j);
+  const int code = DIR ? w.obc_v[f] : w.obc_u[f];
+  if (!code) return;
+  double *xbt = DIR ? w.vbt : w.ubt, *xhbt = DIR ? w.vhbt : w.uhbt, *xhbtp = DIR ? w.vhbtp : w.uhbtp, *xwtd = DIR ? w.vbt_wtd : w.ubt_wtd;
+  const double *xold = DIR ? w.vbt_old : w.ubt_old, *o_hbt = DIR ? w.ob_vhbt : w.ob_uhbt, *o_outer = DIR ? w.ob_vbt_outer : w.ob_ubt_outer,
+               *o_dZ = DIR ? w.ob_dZ_v : w.ob_dZ_u, *o_Cg = DIR ? w.ob_Cg_v : w.ob_Cg_u, *o_SSH = DIR ? w.ob_SSH_v : w.ob_SSH_u;
+  const double Idx = DIR ? g.IdyCv[f] : g.IdxCu[f], Dat = DIR ? w.Datv[f] : w.Datu[f], xhbt0 = DIR ? w.vhbt0[f] : w.uhbt0[f];
+  const Btcl &B = DIR ? w.BV : w.BU;
+  const long df = DIR ? g.nih : 1, dh = DIR ? g.nih : 1;      // one face | one cell along the direction
+  const long c0 = g.h2(i, j);                                 // the first cell of the face
+  double vel_trans = 0.0, vb = xbt[f];
+  if (code & OB_SPEC) {
+    xhbt[f] = o_hbt[f];
+    vb = o_outer[f];
+    vel_trans = vb;
+  } else if (code & OB_PLUS) {
+    if (code & OB_FLATHER) {
+      const double cfl = p.dtbt * o_Cg[f] * Idx;
+      const double u_inlet = cfl * xold[f - df] + (1.0 - cfl) * xold[f];
+      const double ssh_in = g.H_to_Z * (w.eta[c0] + (0.5 - cfl) * (w.eta[c0] - w.eta[c0 - dh]));
+      if (o_dZ[f] > 0.0) {
+        const double vel_prev = vb;
+        vb = 0.5 * ((u_inlet + o_outer[f]) + (o_Cg[f] / o_dZ[f]) * (ssh_in - o_SSH[f]));
+        vel_trans = (1.0 - bebt) * vel_prev + bebt * vb;
+      } else { vb = 0.0; vel_trans = 0.0; }
+    } else {      // gradient
+      vb = xbt[f - df];
+      vel_trans = vb;
+    }
+  } else {
+    if (code & OB_FLATHER) {
+      const double cfl = p.dtbt * o_Cg[f] * Idx;
+      const double u_inlet = cfl * xold[f + df] + (1.0 - cfl) * xold[f];
+      const double ssh_in = g.H_to_Z * (w.eta[c0 + dh] + (0.5 - cfl) * (w.eta[c0 + dh] - w.eta[c0 + 2 * dh]));
+      if (o_dZ[f] > 0.0) {
+        const double vel_prev = vb;
+        vb = 0.5 * ((u_inlet + o_outer[f]) + (o_Cg[f] / o_dZ[f]) * (o_SSH[f] - ssh_in));
+        vel_trans = (1.0 - bebt) * vel_prev + bebt * vb;
+      } else { vb = 0.0; vel_trans = 0.0; }
+    } else {
+      vb = xbt[f + df];
+      vel_trans = vb;
+    }
+  }
+  xbt[f] = vb;
+  double xh = xhbt[f];
+  if (!(code & OB_SPEC)) {
+    xh = (p.use_BT_cont ? find_uhbt(vel_trans, B, f) : Dat * vel_trans) + xhbt0;
+    xhbt[f] = xh;
+  }
+  xhbtp[f] = (p.use_BT_cont ? find_uhbt(vb, B, f) : Dat * vb) + xhbt0;
+  const bool own = DIR ? (i >= g.isc && i <= g.iec && j >= g.jsc - 1 && j <= g.jec) : (i >= g.isc - 1 && i <= g.iec && j >= g.jsc && j <= g.jec);
+  if (own) {
+    xbt_sum[f] = xbt_sum[f] + wt_trans * vel_trans;
+    xhbt_sum[f] = xhbt_sum[f] + wt_trans * xh;
+    xwtd[f] = xwtd[f] + wt_vel * vb;
   }
 }
 
@@ -598,6 +723,20 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
                    const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont, const double *eta_PF_start,
                    const double *taux_bot, const double *tauy_bot, const double *uh0, const double *vh0, const double *u_uh0,
                    const double *v_vh0, double *etaav, int32_t memspace) {
+  return mom6hip_btstep_obc(ctx, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, RZ_to_H, pbce, eta_PF_in, U_Cor, V_Cor,
+                            accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, BT_cont, eta_PF_start, taux_bot,
+                            tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav, nullptr, memspace);
+}
+
+// btstep with OBC associated: specified, Flather and gradient segments (:1089-1110, set_up_BT_OBC :3172, :1236-1250, apply_velocity_OBCs
+// :2931 inside the time steps, :2490-2519, :2591-2606)
+int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *U_in, const double *V_in, const double *eta_in,
+                   double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux, const double *tauy,
+                   double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor, const double *V_Cor,
+                   double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav, double *vhbtav,
+                   const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont, const double *eta_PF_start,
+                   const double *taux_bot, const double *tauy_bot, const double *uh0, const double *vh0, const double *u_uh0,
+                   const double *v_vh0, double *etaav, const mom6hip_obc_t *obc, int32_t memspace) {
   M6_REQUIRE(ctx != nullptr, "btstep: null context");
   if (int rc = check_cs(cs, "btstep")) return rc;
   M6_REQUIRE(U_in && V_in && eta_in && bc_accel_u && bc_accel_v && taux && tauy && pbce && eta_PF_in && U_Cor && V_Cor &&
@@ -719,6 +858,90 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     w.gtot_E = H(); w.gtot_W = H(); w.gtot_N = H(); w.gtot_S = H(); w.eta_src = H(); w.e_anom = H();
     w.q = (double *)q;
   }
+  // ---- open boundaries :770-780
+  w.obc_u = w.obc_v = nullptr;
+  w.ob_Cg_u = w.ob_dZ_u = w.ob_uhbt = w.ob_ubt_outer = w.ob_SSH_u = w.ubt_old = w.ubt_first = w.ubt_wtd = nullptr;
+  w.ob_Cg_v = w.ob_dZ_v = w.ob_vhbt = w.ob_vbt_outer = w.ob_SSH_v = w.vbt_old = w.vbt_first = w.vbt_wtd = nullptr;
+  bool apply_OBCs = false, apply_u_OBCs = false, apply_v_OBCs = false;
+  if (obc) {
+    apply_u_OBCs = obc->open_u_BCs_exist_globally || obc->specified_u_BCs_exist_globally;
+    apply_v_OBCs = obc->open_v_BCs_exist_globally || obc->specified_v_BCs_exist_globally;
+    apply_OBCs = obc->specified_u_BCs_exist_globally || obc->specified_v_BCs_exist_globally || obc->Flather_u_BCs_exist_globally ||
+                 obc->Flather_v_BCs_exist_globally || obc->open_u_BCs_exist_globally || obc->open_v_BCs_exist_globally;
+  }
+  if (apply_OBCs) {
+    M6_REQUIRE(obc->number_of_segments == 0 || (obc->segment && obc->segnum_u && obc->segnum_v), "btstep: OBC%%segment, segnum_u and segnum_v are required");
+    const size_t nU = sz.u2 / 8, nV = sz.v2 / 8;
+    std::vector<int32_t> codes(nU + nV, 0);
+    for (int d = 0; d < 2; d++) {
+      if (!(d ? apply_v_OBCs : apply_u_OBCs)) continue;      // (the loops of the reference are inside BT_OBC%apply_u_OBCs | apply_v_OBCs)
+      const int32_t *segnum = d ? obc->segnum_v : obc->segnum_u;
+      int32_t *o = codes.data() + (d ? nU : 0);
+      for (size_t n = 0; n < (d ? nV : nU); n++) {
+        const int l = segnum[n];
+        if (l == MOM6HIP_OBC_NONE) continue;
+        M6_REQUIRE(l >= 1 && l <= obc->number_of_segments, "btstep: OBC%%segnum_%c holds %d, with %d segments", d ? 'v' : 'u', l, obc->number_of_segments);
+        const mom6hip_obc_segment_t &S = obc->segment[l - 1];
+        int c = 0;
+        if (S.direction == (d ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E)) c = OB_PLUS;
+        else if (S.direction == (d ? MOM6HIP_OBC_DIRECTION_S : MOM6HIP_OBC_DIRECTION_W)) c = OB_MINUS;
+        if (S.specified) c |= OB_SPEC;
+        else {
+          M6_REQUIRE(c != 0, "btstep: OBC segment %d does not lie along the faces it is listed on", l);
+          if (S.Flather) c |= OB_FLATHER;
+          else if (S.gradient) c |= OB_GRAD;
+          else M6_REQUIRE(false, "btstep: OBC segment %d is neither specified, Flather nor gradient: its barotropic velocity is not defined "
+                                 "(apply_velocity_OBCs, MOM_barotropic.F90:3021-3092)", l);
+        }
+        o[n] = c;
+      }
+    }
+    int32_t *dcodes = (int32_t *)st.scratch(4 * (nU + nV));
+    char *ob = (char *)st.scratch(8 * sz.u2 + 8 * sz.v2);
+    M6_REQUIRE(!st.failed() && dcodes && ob, "btstep: out of device memory for the open boundaries");
+    M6_HIP(hipMemcpyAsync(dcodes, codes.data(), 4 * (nU + nV), hipMemcpyHostToDevice, s));
+    M6_HIP(hipStreamSynchronize(s));      // (the host vector goes out of scope)
+    M6_HIP(hipMemsetAsync(ob, 0, 8 * sz.u2 + 8 * sz.v2, s));
+    w.obc_u = dcodes; w.obc_v = dcodes + nU;
+    double **pu[8] = {&w.ob_Cg_u, &w.ob_dZ_u, &w.ob_uhbt, &w.ob_ubt_outer, &w.ob_SSH_u, &w.ubt_old, &w.ubt_first, &w.ubt_wtd};
+    double **pv[8] = {&w.ob_Cg_v, &w.ob_dZ_v, &w.ob_vhbt, &w.ob_vbt_outer, &w.ob_SSH_v, &w.vbt_old, &w.vbt_first, &w.vbt_wtd};
+    for (int q = 0; q < 8; q++) { *pu[q] = (double *)(ob + q * sz.u2); *pv[q] = (double *)(ob + 8 * sz.u2 + q * sz.v2); }
+  }
+  // the part of set_up_BT_OBC :3234-3262, :3296-3322 for the specified segments: the external transports summed over the layers, and
+  // the barotropic velocities that carry them
+  auto setup_specified = [&]() -> int {
+    const int halo = ievf - ie, s_is = is - halo, s_ie = ie + halo, s_js = js - halo, s_je = je + halo;
+    for (int d = 0; d < 2; d++) {
+      if (!(d ? apply_v_OBCs : apply_u_OBCs)) continue;
+      if (!(d ? obc->specified_v_BCs_exist_globally : obc->specified_u_BCs_exist_globally)) continue;
+      double *o_hbt = d ? w.ob_vhbt : w.ob_uhbt, *o_outer = d ? w.ob_vbt_outer : w.ob_ubt_outer;
+      const int32_t *code = d ? w.obc_v : w.obc_u;
+      const Btcl B = d ? w.BV : w.BU;
+      const double *Dat = d ? w.Datv : w.Datu;
+      const int nk = g.nk;
+      for (int n = 0; n < obc->number_of_segments; n++) {
+        const mom6hip_obc_segment_t &S = obc->segment[n];
+        if (!((d ? S.is_N_or_S : S.is_E_or_W) && S.specified)) continue;
+        M6_REQUIRE(S.normal_trans, "btstep: segment %d is specified: normal_trans is required", n + 1);
+        const int a0 = d ? S.isd : S.IsdB, a1 = d ? S.ied : S.IedB, b0 = d ? S.JsdB : S.jsd, b1 = d ? S.JedB : S.jed;
+        const long na = a1 - a0 + 1, nb = b1 - b0 + 1;
+        const double *nt_ = st.in(S.normal_trans, (size_t)na * nb * nk * 8);
+        M6_REQUIRE(!st.failed() && nt_, "btstep: staging failed");
+        launch2d(s, a0, a1, b0, b1, [=] __device__(int a, int b) {
+          double sum = 0.;
+          for (int k = 0; k < nk; k++) sum = sum + nt_[(a - a0) + na * ((b - b0) + nb * (long)k)];
+          o_hbt[d ? g.v2(a, b) : g.u2(a, b)] = sum;
+        });
+      }
+      launch2d(s, d ? s_is : s_is - 1, s_ie, d ? s_js - 1 : s_js, s_je, [=] __device__(int i, int j) {
+        const long f = d ? g.v2(i, j) : g.u2(i, j);
+        if (!(code[f] & OB_SPEC)) return;
+        if (use_BT_cont) o_outer[f] = uhbt_to_ubt(o_hbt[f], B, f);
+        else if (Dat[f] > 0.0) o_outer[f] = o_hbt[f] / Dat[f];
+      });
+    }
+    return 0;
+  };
   auto pass = [&](std::initializer_list<std::pair<double *, int>> fl) -> int {
     std::vector<double *> f; std::vector<int32_t> pos, nk;
     for (auto &e : fl) { f.push_back(e.first); pos.push_back(e.second); nk.push_back(1); }
@@ -826,6 +1049,9 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
     } else {
       btcl_derive(0);
     }
+    // (with ADJUST_BT_CONT the external velocities of the specified faces are inverted from the fits as they are here, before the
+    // adjustment: the place of set_up_BT_OBC in the reference)
+    if (apply_OBCs && early_btcl_pass) { if (int rc = setup_specified()) return rc; }
   } else if (nonlin_cont) {   // :1137-1138
     face_areas_eta(s, 1);
   } else {   // find_face_areas :4297-4310, halo 1
@@ -849,6 +1075,32 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
                      dU, dbu, dtx, dtbx, c.IDatu);
   hipLaunchKernelGGL(bt_pre_face_kernel<1>, grid2d(is, ie, js - 1, je), dim3(64, 4), 0, s, g, w, p, c.frhatv, dvrv, dVc, dpb, dvh0, dvv0,
                      dV, dbv, dty, dtby, c.IDatv);
+
+  if (apply_OBCs) {
+    // :1089-1110: the summed gravity of the cell inside a segment projected across it, segment by segment
+    for (int n = 0; n < obc->number_of_segments; n++) {
+      const mom6hip_obc_segment_t &S = obc->segment[n];
+      if (!S.on_pe) continue;
+      const int I = S.IsdB, J = S.JsdB, Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+      const int dirn = S.direction;
+      if (S.is_N_or_S && (J >= Jsq - 1) && (J <= Jeq + 1)) {
+        M6_REQUIRE(J >= g.jsd && J + 1 <= g.jed && S.isd >= g.isd && S.ied <= g.ied, "btstep: OBC segment %d lies outside the data domain", n + 1);
+        launch2d(s, std::max(Isq - 1, S.isd), std::min(Ieq + 2, S.ied), J, J, [=] __device__(int i, int j) {
+          if (dirn == MOM6HIP_OBC_DIRECTION_N) w.gtot_S[g.h2(i, j + 1)] = w.gtot_S[g.h2(i, j)];
+          else w.gtot_N[g.h2(i, j)] = w.gtot_N[g.h2(i, j + 1)];
+        });
+      } else if (S.is_E_or_W && (I >= Isq - 1) && (I <= Ieq + 1)) {
+        M6_REQUIRE(I >= g.isd && I + 1 <= g.ied && S.jsd >= g.jsd && S.jed <= g.jed, "btstep: OBC segment %d lies outside the data domain", n + 1);
+        launch2d(s, I, I, std::max(Jsq - 1, S.jsd), std::min(Jeq + 2, S.jed), [=] __device__(int i, int j) {
+          if (dirn == MOM6HIP_OBC_DIRECTION_E) w.gtot_W[g.h2(i + 1, j)] = w.gtot_W[g.h2(i, j)];
+          else w.gtot_E[g.h2(i, j)] = w.gtot_E[g.h2(i + 1, j)];
+        });
+      }
+    }
+    // :1289-1291: the velocities before the first time step
+    M6_HIP(hipMemcpyAsync(w.ubt_first, w.ubt, sz.u2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.vbt_first, w.vbt, sz.v2, hipMemcpyDeviceToDevice, s));
+  }
 
   // ---- uhbt0, vhbt0 :1165-1252
   if (add_uh0) {
@@ -890,6 +1142,8 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       const long n = g.v2(i, J);
       w.vhbt0[n] = w.vhbtS[n] - (use_BT_cont ? find_uhbt(w.vbt0[n], w.BV, n) : w.Datv[n] * w.vbt0[n]);
     });
+    if (apply_u_OBCs) launch2d(s, is - 1, ie, js, je, [=] __device__(int I, int j) { if (w.obc_u[g.u2(I, j)]) w.uhbt0[g.u2(I, j)] = 0.0; });      // :1236-1247
+    if (apply_v_OBCs) launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) { if (w.obc_v[g.v2(i, J)]) w.vhbt0[g.v2(i, J)] = 0.0; });
   }
 
   // ---- weighted Coriolis parameters :1421-1458
@@ -1011,6 +1265,49 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   launch2d(s, is, ie, js - 1, je, [=] __device__(int i, int J) { c.vbtav[g.v2(i, J)] = 0.0; dvhbtav[g.v2(i, J)] = 0.0; });
   M6_HIP(hipGetLastError());
 
+  // ---- set_up_BT_OBC :3172-3365 (Boussinesq, BTHALO = 0), here because the fits of BT_cont are complete on the widened range only now;
+  // nothing before the time steps reads what it sets
+  if (apply_OBCs) {
+    if (!early_btcl_pass) { if (int rc = setup_specified()) return rc; }
+    const int halo = ievf - ie, s_is = is - halo, s_ie = ie + halo, s_js = js - halo, s_je = je + halo;
+    const double g_prime1 = g.g_Earth, H_to_Z = g.H_to_Z, Z_ref = cs->Z_ref;      // GV%g_prime(1): GFS, default the gravity of the Earth
+    for (int d = 0; d < 2; d++) {
+      if (!(d ? apply_v_OBCs : apply_u_OBCs)) continue;
+      double *o_outer = d ? w.ob_vbt_outer : w.ob_ubt_outer, *o_dZ = d ? w.ob_dZ_v : w.ob_dZ_u,
+             *o_Cg = d ? w.ob_Cg_v : w.ob_Cg_u, *o_SSH = d ? w.ob_SSH_v : w.ob_SSH_u;
+      const int32_t *code = d ? w.obc_v : w.obc_u;
+      launch2d(s, d ? s_is : s_is - 1, s_ie, d ? s_js - 1 : s_js, s_je, [=] __device__(int i, int j) {
+        const long f = d ? g.v2(i, j) : g.u2(i, j);
+        const int c = code[f];
+        if (!c || (c & OB_SPEC)) return;      // (the specified faces: setup_specified)
+        {
+          const long cc = (c & OB_PLUS) ? g.h2(i, j) : (d ? g.h2(i, j + 1) : g.h2(i + 1, j));
+          const double dZ = g.bathyT[cc] + H_to_Z * w.eta[cc];
+          o_dZ[f] = dZ;
+          o_Cg[f] = sqrt(1.0 * g_prime1 * dZ);
+        }
+      });
+      if (d ? obc->Flather_v_BCs_exist_globally : obc->Flather_u_BCs_exist_globally)
+        for (int n = 0; n < obc->number_of_segments; n++) {
+          const mom6hip_obc_segment_t &S = obc->segment[n];
+          if (!((d ? S.is_N_or_S : S.is_E_or_W) && S.Flather)) continue;
+          M6_REQUIRE(S.normal_vel_bt && S.SSH, "btstep: segment %d is a Flather segment: normal_vel_bt and SSH are required", n + 1);
+          const int a0 = d ? S.isd : S.IsdB, a1 = d ? S.ied : S.IedB, b0 = d ? S.JsdB : S.jsd, b1 = d ? S.JedB : S.jed;
+          const long na = a1 - a0 + 1, nb = b1 - b0 + 1;
+          const double *nv = st.in(S.normal_vel_bt, (size_t)na * nb * 8), *ssh = st.in(S.SSH, (size_t)na * nb * 8);
+          M6_REQUIRE(!st.failed() && nv && ssh, "btstep: staging failed");
+          launch2d(s, a0, a1, b0, b1, [=] __device__(int a, int b) {
+            const long f = d ? g.v2(a, b) : g.u2(a, b), q = (a - a0) + na * (b - b0);
+            o_outer[f] = nv[q];
+            o_SSH[f] = ssh[q] + Z_ref;
+          });
+        }
+    }
+    // do_group_pass(BT_OBC%pass_uv | pass_uhvh | pass_eta_outer | pass_h | pass_cg) :3359-3363
+    if (int rc = pass({{w.ob_ubt_outer, PU}, {w.ob_vbt_outer, PV}, {w.ob_uhbt, PU}, {w.ob_vhbt, PV}, {w.ob_SSH_u, PUs}, {w.ob_SSH_v, PVs},
+                       {w.ob_dZ_u, PUs}, {w.ob_dZ_v, PVs}, {w.ob_Cg_u, PUs}, {w.ob_Cg_v, PVs}})) return rc;
+  }
+
   // ---- the barotropic time steps :1812-2462
   // (replayed from hipGraphs: see graph_of below)
   // the valid range of step n and whether a group pass precedes it (:1842-1861): a function of n alone
@@ -1049,6 +1346,10 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       hipLaunchKernelGGL(bt_eta_pred_kernel, grid2d(isv - 1, iev + 1, jsv - 1, jev + 1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev + 1,
                          jsv - 1, jev + 1, wt_accel2[n]);
       const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;
+      if (apply_OBCs) {      // :1938-1947: the velocities before this time step (the faces inside a Flather face are read by bt_obc_kernel)
+        (void)hipMemcpyAsync(w.ubt_old, w.ubt, sz.u2, hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(w.vbt_old, w.vbt, sz.v2, hipMemcpyDeviceToDevice, st);
+      }
       for (int ps = 0; ps < 2; ps++) {
         const bool do_v = (ps == 0) ? v_first : !v_first;
         if (do_v) {
@@ -1060,6 +1361,15 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
           hipLaunchKernelGGL(bt_ubt_kernel, grid2d(isv - 1, iev, j0, j1), dim3(64, 4), 0, st, g, w, p, isv - 1, iev, j0, j1, wt_accel[n],
                              wt_trans[n], wt_end, c.ubtav, duhbtav);
         }
+      }
+      if (apply_OBCs) {      // apply_velocity_OBCs :2357-2395 (halo = iev - ie)
+        const int halo = iev - ie;
+        if (apply_u_OBCs)
+          hipLaunchKernelGGL(bt_obc_kernel<0>, grid2d(is - halo - 1, ie + halo, js - halo, je + halo), dim3(64, 4), 0, st, g, w, p, is - halo - 1,
+                             ie + halo, js - halo, je + halo, cs->bebt, wt_trans[n], wt_vel[n], c.ubtav, duhbtav);
+        if (apply_v_OBCs)
+          hipLaunchKernelGGL(bt_obc_kernel<1>, grid2d(is - halo, ie + halo, js - halo - 1, je + halo), dim3(64, 4), 0, st, g, w, p, is - halo,
+                             ie + halo, js - halo - 1, je + halo, cs->bebt, wt_trans[n], wt_vel[n], c.vbtav, dvhbtav);
       }
       hipLaunchKernelGGL(bt_eta_kernel, grid2d(isv, iev, jsv, jev), dim3(64, 4), 0, st, g, w, p, isv, iev, jsv, jev, wt_eta[n]);
     }
@@ -1078,6 +1388,7 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
   {
     auto add = [&](const void *q, size_t nbytes) { base_key.append((const char *)q, nbytes); };
     add(&w, sizeof(w)); add(&p, sizeof(p)); add(&nt, sizeof(nt)); add(&ctx->host.first_direction, sizeof(int32_t));
+    { const double ob_key[3] = {apply_u_OBCs ? 1.0 : 0.0, apply_v_OBCs ? 1.0 : 0.0, cs->bebt}; add(ob_key, sizeof(ob_key)); }
     { const int32_t nl[2] = {nonlin_update ? 1 : 0, cs->Nonlin_cont_update_period}; add(nl, sizeof(nl)); }
     add(&c.ubtav, sizeof(double *)); add(&c.vbtav, sizeof(double *)); add(&duhbtav, sizeof(double *)); add(&dvhbtav, sizeof(double *));
     add(wt_vel.data(), sizeof(double) * wt_vel.size()); add(wt_eta.data(), sizeof(double) * wt_eta.size());
@@ -1161,11 +1472,35 @@ int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double
       if (find_etaav) detaav[n] = w.eta_sum[n] * 1.0;
       deta_out[n] = w.eta_wtd[n] * 1.0;
     });
+    for (int d = 0; d < 2 && apply_OBCs; d++) {      // :2490-2519: e_anom across the faces of the segments, the u faces first
+      if (!(d ? apply_v_OBCs : apply_u_OBCs)) continue;
+      const int32_t *code = d ? w.obc_v : w.obc_u;
+      launch2d(s, d ? is : is - 1, ie, d ? js - 1 : js, je, [=] __device__(int i, int j) {
+        const int cde = code[d ? g.v2(i, j) : g.u2(i, j)];
+        const long c0 = g.h2(i, j), c1 = d ? g.h2(i, j + 1) : g.h2(i + 1, j);
+        if (cde & OB_PLUS) w.e_anom[c1] = w.e_anom[c0];      // OBC_DIRECTION_E | N
+        else if (cde & OB_MINUS) w.e_anom[c0] = w.e_anom[c1];
+      });
+    }
     // pass_etaav, pass_e_anom and pass_ubta_uhbta (:2527-2570) as one group
     if (find_etaav) { if (int rc = pass({{detaav, PH}, {w.e_anom, PH}, {c.ubtav, PU}, {c.vbtav, PV}, {duhbtav, PU}, {dvhbtav, PV}})) return rc; }
     else { if (int rc = pass({{w.e_anom, PH}, {c.ubtav, PU}, {c.vbtav, PV}, {duhbtav, PU}, {dvhbtav, PV}})) return rc; }
     hipLaunchKernelGGL(bt_accel_layer_kernel<0>, grid2d(is - 1, ie, js, je), dim3(64, 4), 0, s, g, w, dpb, dalu, accel_underflow);
     hipLaunchKernelGGL(bt_accel_layer_kernel<1>, grid2d(is, ie, js - 1, je), dim3(64, 4), 0, s, g, w, dpb, dalv, accel_underflow);
+    for (int d = 0; d < 2 && apply_OBCs; d++) {      // :2591-2606: the accelerations of the segments' faces from their own velocities
+      if (!(d ? apply_v_OBCs : apply_u_OBCs)) continue;
+      const int32_t *code = d ? w.obc_v : w.obc_u;
+      const double *wtd = d ? w.vbt_wtd : w.ubt_wtd, *first = d ? w.vbt_first : w.ubt_first;
+      double *accel = d ? dalv : dalu;
+      const long fstr = d ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+      const int nk = g.nk;
+      launch2d(s, d ? is : is - 1, ie, d ? js - 1 : js, je, [=] __device__(int i, int j) {
+        const long f = d ? g.v2(i, j) : g.u2(i, j);
+        if (!code[f]) return;
+        const double a = (wtd[f] - first[f]) / dt;
+        for (int k = 0; k < nk; k++) accel[f + fstr * k] = a;
+      });
+    }
   }
   M6_HIP(hipGetLastError());
   return st.finish();

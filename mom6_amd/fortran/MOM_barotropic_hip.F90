@@ -134,11 +134,12 @@ subroutine btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, 
 
   type(mom6hip_bt_cont_t), target :: cbt
   type(c_ptr) :: p_bt, p_pfs, p_txb, p_tyb, p_uh0, p_vh0, p_uuh0, p_vvh0, p_etaav
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
   integer :: rc
 
   if (.not.CS%module_is_initialized) call MOM_error(FATAL, "btstep: Module MOM_barotropic must be initialized before it is used.")
   if (.not.CS%split) return
-  if (associated(OBC)) call MOM_error(FATAL, "btstep (HIP): open boundary conditions are not supported by the GPU path.")
   if (.not.(associated(forces%taux) .and. associated(forces%tauy))) &
     call MOM_error(FATAL, "btstep (HIP): forces%taux and forces%tauy must be associated.")
   call bind_arrays(CS)
@@ -153,11 +154,20 @@ subroutine btstep(U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, forces, pbce, 
   p_vvh0 = c_null_ptr ; if (associated(v_vh0)) p_vvh0 = c_loc(v_vh0)
   p_etaav = c_null_ptr ; if (present(etaav)) p_etaav = c_loc(etaav)
 
-  rc = mom6hip_btstep(mom6hip_shared_context(G, GV), CS%st, c_loc(U_in), c_loc(V_in), c_loc(eta_in), dt, c_loc(bc_accel_u), &
+  if (associated(OBC)) then      ! specified, Flather and gradient segments (set_up_BT_OBC :3172, apply_velocity_OBCs :2931, ...)
+    call mom6hip_obc_to_c(OBC, cobc, csegs, size(uhbtav), size(vhbtav), "MOM_barotropic")
+    rc = mom6hip_btstep_obc(mom6hip_shared_context(G, GV), CS%st, c_loc(U_in), c_loc(V_in), c_loc(eta_in), dt, c_loc(bc_accel_u), &
+                      c_loc(bc_accel_v), c_loc(forces%taux), c_loc(forces%tauy), GV%RZ_to_H, c_loc(pbce), c_loc(eta_PF_in), &
+                      c_loc(U_Cor), c_loc(V_Cor), c_loc(accel_layer_u), c_loc(accel_layer_v), c_loc(eta_out), c_loc(uhbtav), &
+                      c_loc(vhbtav), c_loc(visc_rem_u), c_loc(visc_rem_v), p_bt, p_pfs, p_txb, p_tyb, p_uh0, p_vh0, p_uuh0, &
+                      p_vvh0, p_etaav, cobc, MOM6HIP_MEM_HOST)
+  else
+    rc = mom6hip_btstep(mom6hip_shared_context(G, GV), CS%st, c_loc(U_in), c_loc(V_in), c_loc(eta_in), dt, c_loc(bc_accel_u), &
                       c_loc(bc_accel_v), c_loc(forces%taux), c_loc(forces%tauy), GV%RZ_to_H, c_loc(pbce), c_loc(eta_PF_in), &
                       c_loc(U_Cor), c_loc(V_Cor), c_loc(accel_layer_u), c_loc(accel_layer_v), c_loc(eta_out), c_loc(uhbtav), &
                       c_loc(vhbtav), c_loc(visc_rem_u), c_loc(visc_rem_v), p_bt, p_pfs, p_txb, p_tyb, p_uh0, p_vh0, p_uuh0, &
                       p_vvh0, p_etaav, MOM6HIP_MEM_HOST)
+  endif
   call mom6hip_fatal_if(rc, "btstep")
   CS%dtbt = CS%st%dtbt
 end subroutine btstep

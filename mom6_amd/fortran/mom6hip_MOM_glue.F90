@@ -484,6 +484,10 @@ contains
         who//" (HIP): a specified segment needs normal_trans and normal_vel.")
       c%normal_trans = c_loc(seg%normal_trans) ; c%normal_vel = c_loc(seg%normal_vel)
     endif
+    c%Flather = merge(1, 0, seg%Flather) ; c%radiation = merge(1, 0, seg%radiation) ; c%gradient = merge(1, 0, seg%gradient)
+    c%nudged = merge(1, 0, seg%nudged) ; c%oblique = merge(1, 0, seg%oblique)
+    if (allocated(seg%normal_vel_bt)) c%normal_vel_bt = c_loc(seg%normal_vel_bt)
+    if (allocated(seg%SSH)) c%SSH = c_loc(seg%SSH)
     if (allocated(seg%tangential_vel)) c%tangential_vel = c_loc(seg%tangential_vel)
     if (allocated(seg%tangential_grad)) c%tangential_grad = c_loc(seg%tangential_grad)
   end subroutine segment_to_c

@@ -198,10 +198,9 @@ type, bind(c) :: mom6hip_obc_segment_t
   integer(c_int32_t) :: direction = 0, open = 0, specified = 0, on_pe = 0, is_E_or_W = 0, is_N_or_S = 0
   integer(c_int32_t) :: IsdB = 0, IedB = 0, JsdB = 0, JedB = 0, isd = 0, ied = 0, jsd = 0, jed = 0
   integer(c_int32_t) :: radiation = 0, gradient = 0, nudged = 0, oblique = 0, radiation_tan_or_grad = 0
-  integer(c_int32_t) :: reserved(1) = 0
+  integer(c_int32_t) :: Flather = 0
   type(c_ptr) :: normal_trans = c_null_ptr, normal_vel = c_null_ptr, tangential_vel = c_null_ptr, tangential_grad = c_null_ptr
-  type(c_ptr) :: nudged_normal_vel = c_null_ptr
-  type(c_ptr) :: reserved_p(1) = c_null_ptr
+  type(c_ptr) :: nudged_normal_vel = c_null_ptr, normal_vel_bt = c_null_ptr, SSH = c_null_ptr
   real(c_double) :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
 end type mom6hip_obc_segment_t
 type, bind(c) :: mom6hip_obc_t
@@ -786,6 +785,22 @@ interface
     integer(c_int32_t), value :: memspace
     integer(c_int) :: rc
   end function mom6hip_btstep
+
+  !> btstep with OBC associated (specified, Flather and gradient segments)
+  function mom6hip_btstep_obc(ctx, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, RZ_to_H, pbce, eta_PF_in, &
+                              U_Cor, V_Cor, accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, &
+                              BT_cont, eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav, obc, memspace) &
+                              bind(c, name="mom6hip_btstep_obc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_barotropic_cs_t, mom6hip_obc_t
+    type(c_ptr), value :: ctx, U_in, V_in, eta_in, bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor, &
+                          accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, BT_cont, &
+                          eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav
+    type(mom6hip_barotropic_cs_t), intent(inout) :: cs
+    real(c_double), value :: dt, RZ_to_H
+    type(mom6hip_obc_t), intent(in) :: obc
+    integer(c_int32_t), value :: memspace
+    integer(c_int) :: rc
+  end function mom6hip_btstep_obc
 
   !> vertvisc_coef (MOM_vert_friction.F90:1168); dz = c_null_ptr stands for the Boussinesq thickness_to_dz
   function mom6hip_vertvisc_coef(ctx, cs, u, v, h, dz, visc, dt, memspace) bind(c, name="mom6hip_vertvisc_coef") result(rc)

@@ -76,6 +76,7 @@ class OBC_segment_type:
         self.tangential_vel = None    # (nk, JsdB:JedB, IsdB:IedB): the corner points along the segment
         self.tangential_grad = None
         self.nudged_normal_vel = None      # the layout of normal_vel
+        self.normal_vel_bt = self.SSH = None      # (jsd:jed, IsdB:IedB) | (JsdB:JedB, isd:ied): the external barotropic velocity and surface height
         self.Velocity_nudging_timescale_in = self.Velocity_nudging_timescale_out = 0.0
 
 
@@ -199,6 +200,7 @@ class ocean_OBC_type:
         else:
             shp = (nk, H["JedB"] - H["JsdB"] + 1, H["ied"] - H["isd"] + 1)
         seg.normal_trans = np.zeros(shp); seg.normal_vel = np.zeros(shp); seg.nudged_normal_vel = np.zeros(shp)
+        seg.normal_vel_bt = np.zeros(shp[1:]); seg.SSH = np.zeros(shp[1:])
         shq = (nk, H["JedB"] - H["JsdB"] + 1, H["IedB"] - H["IsdB"] + 1)
         seg.tangential_vel = np.zeros(shq); seg.tangential_grad = np.zeros(shq)
 
@@ -262,11 +264,13 @@ class ocean_OBC_type:
             for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed"):
                 setattr(c, k, int(s.HI.get(k, 0)))
             c.radiation, c.gradient, c.nudged, c.oblique = int(s.radiation), int(s.gradient), int(s.nudged), int(s.oblique)
+            c.Flather = int(s.Flather)
             c.radiation_tan_or_grad = int(s.radiation_tan or s.radiation_grad or s.oblique_tan or s.oblique_grad or s.nudged_tan or s.nudged_grad)
             c.Velocity_nudging_timescale_in, c.Velocity_nudging_timescale_out = float(s.Velocity_nudging_timescale_in), float(s.Velocity_nudging_timescale_out)
-            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel"):
+            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH"):
                 a = getattr(s, k)
                 need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient, "nudged_normal_vel": s.nudged,
+                        "normal_vel_bt": s.Flather, "SSH": s.Flather,
                         "tangential_vel": self.computed_vorticity or self.computed_strain, "tangential_grad": self.specified_vorticity}[k]
                 if a is not None and need and s.on_pe:
                     if to_ptr is None:

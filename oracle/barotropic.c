@@ -506,6 +506,55 @@ int orc_set_dtbt_eta(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const
 }
 
 /* btstep :423 */
+/* uhbt_to_ubt :3733 (vhbt_to_vbt :3866 is the same function of the v-point structure) */
+static double uhbt_to_ubt(double uhbt, const btcl_t *B, long n) {
+  const double tol = 1.0e-10;
+  const int max_itt = 20;
+  double ubt, ubt_min, ubt_max, uherr_min, uherr_max;
+  if (uhbt == 0.0) {
+    ubt = 0.0;
+  } else if (uhbt < B->uh_EE[n]) {
+    ubt = B->uBT_EE[n] + (uhbt - B->uh_EE[n]) / B->FA_EE[n];
+  } else if (uhbt < 0.0) {
+    ubt_min = B->uBT_EE[n]; uherr_min = B->uh_EE[n] - uhbt;
+    ubt_max = 0.0; uherr_max = -uhbt;
+    ubt = B->uBT_EE[n] * (uhbt / B->uh_EE[n]);
+    for (int itt = 1; itt <= max_itt; itt++) {
+      const double uhbt_err = ubt * (B->FA_E0[n] + B->uh_crvE[n] * (ubt * ubt)) - uhbt;
+      if (fabs(uhbt_err) < tol * fabs(uhbt)) break;
+      if (uhbt_err > 0.0) { ubt_max = ubt; uherr_max = uhbt_err; }
+      if (uhbt_err < 0.0) { ubt_min = ubt; uherr_min = uhbt_err; }
+      const double derr_du = B->FA_E0[n] + 3.0 * B->uh_crvE[n] * (ubt * ubt);
+      if ((uhbt_err >= derr_du * (ubt - ubt_min)) || (-uhbt_err >= derr_du * (ubt_max - ubt)) || (derr_du <= 0.0)) {
+        ubt = ubt_max + (ubt_min - ubt_max) * (uherr_max / (uherr_max - uherr_min));
+      } else {
+        ubt = ubt - uhbt_err / derr_du;
+        if (fabs(uhbt_err) < (0.01 * tol) * fabs(ubt_min * derr_du)) break;
+      }
+    }
+  } else if (uhbt <= B->uh_WW[n]) {
+    ubt_min = 0.0; uherr_min = -uhbt;
+    ubt_max = B->uBT_WW[n]; uherr_max = B->uh_WW[n] - uhbt;
+    ubt = B->uBT_WW[n] * (uhbt / B->uh_WW[n]);
+    for (int itt = 1; itt <= max_itt; itt++) {
+      const double uhbt_err = ubt * (B->FA_W0[n] + B->uh_crvW[n] * (ubt * ubt)) - uhbt;
+      if (fabs(uhbt_err) < tol * fabs(uhbt)) break;
+      if (uhbt_err > 0.0) { ubt_max = ubt; uherr_max = uhbt_err; }
+      if (uhbt_err < 0.0) { ubt_min = ubt; uherr_min = uhbt_err; }
+      const double derr_du = B->FA_W0[n] + 3.0 * B->uh_crvW[n] * (ubt * ubt);
+      if ((uhbt_err >= derr_du * (ubt - ubt_min)) || (-uhbt_err >= derr_du * (ubt_max - ubt)) || (derr_du <= 0.0)) {
+        ubt = ubt_min + (ubt_max - ubt_min) * (-uherr_min / (uherr_max - uherr_min));
+      } else {
+        ubt = ubt - uhbt_err / derr_du;
+        if (fabs(uhbt_err) < (0.01 * tol) * (ubt_max * derr_du)) break;
+      }
+    }
+  } else {
+    ubt = B->uBT_WW[n] + (uhbt - B->uh_WW[n]) / B->FA_WW[n];
+  }
+  return ubt;
+}
+
 int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *U_in, const double *V_in,
                const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux,
                const double *tauy, double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor,
@@ -513,6 +562,28 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                double *vhbtav, const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
                const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
                const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav) {
+  return orc_btstep_obc(G, CS, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, RZ_to_H, pbce, eta_PF_in, U_Cor, V_Cor,
+                        accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav, visc_rem_u, visc_rem_v, BT_cont, eta_PF_start, taux_bot,
+                        tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav, NULL);
+}
+
+/* a segment's 2-D array (normal_vel_bt, SSH) on its own index ranges */
+static inline long seg2(const mom6hip_obc_segment_t *S, int i, int j) {
+  if (S->is_N_or_S) return (i - S->isd) + (long)(S->ied - S->isd + 1) * (j - S->JsdB);
+  return (i - S->IsdB) + (long)(S->IedB - S->IsdB + 1) * (j - S->jsd);
+}
+
+/* btstep with OBC associated: the gravity of the cell inside a segment projected across it :1089-1110, set_up_BT_OBC :3172, the
+ * transports of the segments' faces left out of uhbt0 :1236-1250, the velocities of those faces kept through the time step's own
+ * update :1949-1970, :2043-2048, :2121-2126, :2198-2203, :2287-2292 and set by apply_velocity_OBCs :2931 (specified, Flather, gradient)
+ * with the running sums :2357-2395, e_anom across the segments :2490-2519, the accelerations of the segments' faces :2591-2606 */
+int orc_btstep_obc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *U_in, const double *V_in,
+               const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux,
+               const double *tauy, double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor,
+               const double *V_Cor, double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav,
+               double *vhbtav, const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
+               const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
+               const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav, const mom6hip_obc_t *OBC) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int isd = G->isd, ied = G->ied, jsd = G->jsd, jed = G->jed;
   const int isdw = isd, jsdw = jsd; /* BTHALO = 0 */
@@ -529,6 +600,18 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   const int find_etaav = etaav != NULL;
   const int add_uh0 = uh0 != NULL;
   (void)h_neglect;
+  /* :770-780 */
+  int apply_OBCs = 0, apply_u_OBCs = 0, apply_v_OBCs = 0, apply_OBC_flather = 0, apply_OBC_open = 0;
+  if (OBC) {
+    apply_u_OBCs = OBC->open_u_BCs_exist_globally || OBC->specified_u_BCs_exist_globally;
+    apply_v_OBCs = OBC->open_v_BCs_exist_globally || OBC->specified_v_BCs_exist_globally;
+    apply_OBC_flather = OBC->Flather_u_BCs_exist_globally || OBC->Flather_v_BCs_exist_globally;
+    apply_OBC_open = OBC->open_u_BCs_exist_globally || OBC->open_v_BCs_exist_globally;
+    apply_OBCs = (OBC->specified_u_BCs_exist_globally || OBC->specified_v_BCs_exist_globally) || apply_OBC_flather || apply_OBC_open;
+    if (OBC->number_of_segments > 0 && !(OBC->segment && OBC->segnum_u && OBC->segnum_v)) return 2;
+  }
+#define SEGU(I, j) (OBC->segnum_u[U2(I, j)])
+#define SEGV(i, J) (OBC->segnum_v[V2(i, J)])
 
   int num_cycles = 1;
   if (CS->use_wide_halos) num_cycles = (is - isdw) / stencil < (js - jsdw) / stencil ? (is - isdw) / stencil : (js - jsdw) / stencil;
@@ -644,6 +727,24 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     gtot_N[H2(i, J)] = gtot_N[H2(i, J)] + pbce[ORC_H3(G, i, J, k)] * wt_v[ORC_V3(G, i, J, k)];
     gtot_S[H2(i, J + 1)] = gtot_S[H2(i, J + 1)] + pbce[ORC_H3(G, i, J + 1, k)] * wt_v[ORC_V3(G, i, J, k)];
   }
+  if (apply_OBCs) for (int n = 0; n < OBC->number_of_segments; n++) {      /* :1089-1110 */
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->on_pe) continue;
+    const int I = S->IsdB, J = S->JsdB, Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+    if (S->is_N_or_S && (J >= Jsq - 1) && (J <= Jeq + 1)) {
+      const int i0 = (Isq - 1 > S->isd) ? Isq - 1 : S->isd, i1 = (Ieq + 2 < S->ied) ? Ieq + 2 : S->ied;
+      for (int i = i0; i <= i1; i++) {
+        if (S->direction == MOM6HIP_OBC_DIRECTION_N) gtot_S[H2(i, J + 1)] = gtot_S[H2(i, J)];
+        else gtot_N[H2(i, J)] = gtot_N[H2(i, J + 1)];
+      }
+    } else if (S->is_E_or_W && (I >= Isq - 1) && (I <= Ieq + 1)) {
+      const int j0 = (Jsq - 1 > S->jsd) ? Jsq - 1 : S->jsd, j1 = (Jeq + 2 < S->jed) ? Jeq + 2 : S->jed;
+      for (int j = j0; j <= j1; j++) {
+        if (S->direction == MOM6HIP_OBC_DIRECTION_E) gtot_W[H2(I + 1, j)] = gtot_W[H2(I, j)];
+        else gtot_E[H2(I, j)] = gtot_E[H2(I + 1, j)];
+      }
+    }
+  }
   const double dgeo_de = 1.0 + CS->G_extra; /* .not.calculate_SAL :1127 */
 
   /* ---- open face areas :1136-1148 */
@@ -656,6 +757,70 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     find_face_areas_eta(G, CS, Datu, Datv, 1, eta);
   } else {
     find_face_areas(G, CS, Datu, Datv, 1, 0, 0.0);
+  }
+
+  /* ---- set_up_BT_OBC :3172-3365 (Boussinesq; BTHALO = 0; the arrays of BT_OBC are read at the segments' faces only) */
+  NEWU(ob_Cg_u); NEWU(ob_dZ_u); NEWU(ob_uhbt); NEWU(ob_ubt_outer); NEWU(ob_SSH_u); NEWU(ubt_old); NEWU(ubt_first);
+  NEWU(ubt_prev); NEWU(uhbt_prev); NEWU(ubt_sum_prev); NEWU(uhbt_sum_prev); NEWU(ubt_wtd_prev);
+  NEWV(ob_Cg_v); NEWV(ob_dZ_v); NEWV(ob_vhbt); NEWV(ob_vbt_outer); NEWV(ob_SSH_v); NEWV(vbt_old); NEWV(vbt_first);
+  NEWV(vbt_prev); NEWV(vhbt_prev); NEWV(vbt_sum_prev); NEWV(vhbt_sum_prev); NEWV(vbt_wtd_prev);
+  if (apply_OBCs) {
+    const int halo = ievf - ie, s_is = is - halo, s_ie = ie + halo, s_js = js - halo, s_je = je + halo;
+    const double g_prime1 = G->g_Earth;      /* GV%g_prime(1): GFS, default the gravity of the Earth */
+    for (int dir = 0; dir < 2; dir++) {
+      if (!(dir ? apply_v_OBCs : apply_u_OBCs)) continue;
+      double *o_hbt = dir ? ob_vhbt : ob_uhbt, *o_outer = dir ? ob_vbt_outer : ob_ubt_outer, *o_dZ = dir ? ob_dZ_v : ob_dZ_u,
+             *o_Cg = dir ? ob_Cg_v : ob_Cg_u, *o_SSH = dir ? ob_SSH_v : ob_SSH_u;
+      const int32_t *segnum = dir ? OBC->segnum_v : OBC->segnum_u;
+      const btcl_t *B = dir ? &BV : &BU;
+      const double *Dat = dir ? Datv : Datu;
+      if (dir ? OBC->specified_v_BCs_exist_globally : OBC->specified_u_BCs_exist_globally)
+        for (int n = 0; n < OBC->number_of_segments; n++) {
+          const mom6hip_obc_segment_t *S = &OBC->segment[n];
+          if (!((dir ? S->is_N_or_S : S->is_E_or_W) && S->specified)) continue;
+          if (!S->normal_trans) return 2;
+          const int a0 = dir ? S->isd : S->IsdB, a1 = dir ? S->ied : S->IedB, b0 = dir ? S->JsdB : S->jsd, b1 = dir ? S->JedB : S->jed;
+          const long na = a1 - a0 + 1, nb = b1 - b0 + 1;
+          for (int b = b0; b <= b1; b++) for (int a = a0; a <= a1; a++) o_hbt[dir ? V2(a, b) : U2(a, b)] = 0.;
+          for (int k = 0; k < nz; k++) for (int b = b0; b <= b1; b++) for (int a = a0; a <= a1; a++) {
+            const long f = dir ? V2(a, b) : U2(a, b);
+            o_hbt[f] = o_hbt[f] + S->normal_trans[(a - a0) + na * ((b - b0) + nb * (long)k)];
+          }
+        }
+      for (int j = (dir ? s_js - 1 : s_js); j <= s_je; j++) for (int i = (dir ? s_is : s_is - 1); i <= s_ie; i++) {
+        const long f = dir ? V2(i, j) : U2(i, j);
+        if (segnum[f] == MOM6HIP_OBC_NONE) continue;
+        const mom6hip_obc_segment_t *S = &OBC->segment[segnum[f] - 1];
+        if (S->specified) {
+          if (use_BT_cont) o_outer[f] = uhbt_to_ubt(o_hbt[f], B, f);
+          else if (Dat[f] > 0.0) o_outer[f] = o_hbt[f] / Dat[f];
+        } else {      /* "This is assuming Flather as only other option" */
+          if (S->direction == (dir ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E))
+            o_dZ[f] = BTH(i, j) + G->H_to_Z * eta[H2(i, j)];
+          else if (S->direction == (dir ? MOM6HIP_OBC_DIRECTION_S : MOM6HIP_OBC_DIRECTION_W))
+            o_dZ[f] = dir ? BTH(i, j + 1) + G->H_to_Z * eta[H2(i, j + 1)] : BTH(i + 1, j) + G->H_to_Z * eta[H2(i + 1, j)];
+          o_Cg[f] = sqrt(1.0 * g_prime1 * o_dZ[f]);
+        }
+      }
+      if (dir ? OBC->Flather_v_BCs_exist_globally : OBC->Flather_u_BCs_exist_globally)
+        for (int n = 0; n < OBC->number_of_segments; n++) {
+          const mom6hip_obc_segment_t *S = &OBC->segment[n];
+          if (!((dir ? S->is_N_or_S : S->is_E_or_W) && S->Flather)) continue;
+          if (!(S->normal_vel_bt && S->SSH)) return 2;
+          const int a0 = dir ? S->isd : S->IsdB, a1 = dir ? S->ied : S->IedB, b0 = dir ? S->JsdB : S->jsd, b1 = dir ? S->JedB : S->jed;
+          for (int b = b0; b <= b1; b++) for (int a = a0; a <= a1; a++) {
+            const long f = dir ? V2(a, b) : U2(a, b);
+            o_outer[f] = S->normal_vel_bt[seg2(S, a, b)];
+            o_SSH[f] = S->SSH[seg2(S, a, b)] + CS->Z_ref;
+          }
+        }
+    }
+    /* do_group_pass(BT_OBC%pass_uv | pass_uhvh | pass_eta_outer | pass_h | pass_cg) :3359-3363 */
+    orc_halo_update(G, ob_ubt_outer, MOM6HIP_POS_U, 1); orc_halo_update(G, ob_vbt_outer, MOM6HIP_POS_V, 1);
+    orc_halo_update(G, ob_uhbt, MOM6HIP_POS_U, 1); orc_halo_update(G, ob_vhbt, MOM6HIP_POS_V, 1);
+    orc_halo_update(G, ob_SSH_u, MOM6HIP_POS_U, 1); orc_halo_update(G, ob_SSH_v, MOM6HIP_POS_V, 1);
+    orc_halo_update(G, ob_dZ_u, MOM6HIP_POS_U, 1); orc_halo_update(G, ob_dZ_v, MOM6HIP_POS_V, 1);
+    orc_halo_update(G, ob_Cg_u, MOM6HIP_POS_U, 1); orc_halo_update(G, ob_Cg_v, MOM6HIP_POS_V, 1);
   }
 
   /* ---- uhbt0, vhbt0 :1165-1252 */
@@ -695,6 +860,8 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++)
         vhbt0[V2(i, J)] = vhbt[V2(i, J)] - Datv[V2(i, J)] * vbt[V2(i, J)];
     }
+    if (apply_u_OBCs) for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) if (SEGU(I, j) != MOM6HIP_OBC_NONE) uhbt0[U2(I, j)] = 0.0;      /* :1236-1247 */
+    if (apply_v_OBCs) for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) if (SEGV(i, J) != MOM6HIP_OBC_NONE) vhbt0[V2(i, J)] = 0.0;
   }
 
   /* ---- initial barotropic velocities :1254-1291 */
@@ -712,6 +879,8 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
   for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) if (fabs(ubt[U2(I, j)]) < CS->vel_underflow) ubt[U2(I, j)] = 0.0;
   ORC_PAR
   for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) if (fabs(vbt[V2(i, J)]) < CS->vel_underflow) vbt[V2(i, J)] = 0.0;
+
+  if (apply_OBCs) { memcpy(ubt_first, ubt, sizeof(double) * (size_t)NU); memcpy(vbt_first, vbt, sizeof(double) * (size_t)NV); }      /* :1289-1291 */
 
   /* ---- BT_force :1303-1372 (.not.nonlin_stress) */
   ORC_PAR
@@ -936,6 +1105,21 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     }
 
     const int v_first = ((n + G->first_direction) % 2) == 1;
+    if (apply_OBC_flather || apply_OBC_open) {      /* :1938-1947 */
+      for (int j = jsv; j <= jev; j++) for (int I = isv - 2; I <= iev + 1; I++) ubt_old[U2(I, j)] = ubt[U2(I, j)];
+      for (int J = jsv - 2; J <= jev + 1; J++) for (int i = isv; i <= iev; i++) vbt_old[V2(i, J)] = vbt[V2(i, J)];
+    }
+    if (apply_OBCs) {      /* :1949-1970 */
+      const int ioff = v_first ? 1 : 0, joff = v_first ? 0 : 1;
+      if (apply_u_OBCs) for (int j = jsv - joff; j <= jev + joff; j++) for (int I = isv - 1; I <= iev; I++) {
+        ubt_prev[U2(I, j)] = ubt[U2(I, j)]; uhbt_prev[U2(I, j)] = uhbt[U2(I, j)];
+        ubt_sum_prev[U2(I, j)] = ubt_sum[U2(I, j)]; uhbt_sum_prev[U2(I, j)] = uhbt_sum[U2(I, j)]; ubt_wtd_prev[U2(I, j)] = ubt_wtd[U2(I, j)];
+      }
+      if (apply_v_OBCs) for (int J = jsv - 1; J <= jev; J++) for (int i = isv - ioff; i <= iev + ioff; i++) {
+        vbt_prev[V2(i, J)] = vbt[V2(i, J)]; vhbt_prev[V2(i, J)] = vhbt[V2(i, J)];
+        vbt_sum_prev[V2(i, J)] = vbt_sum[V2(i, J)]; vhbt_sum_prev[V2(i, J)] = vhbt_sum[V2(i, J)]; vbt_wtd_prev[V2(i, J)] = vbt_wtd[V2(i, J)];
+      }
+    }
     for (int pass = 0; pass < 2; pass++) {
       const int do_v = (pass == 0) ? v_first : !v_first;
       if (do_v) {
@@ -948,6 +1132,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                                     (bmer[U2(i, j)] * ubt[U2(i, j)] + dmer[U2(i - 1, j + 1)] * ubt[U2(i - 1, j + 1)])) - Cor_ref_v[V2(i, J)];
           PFv[V2(i, J)] = ((eta_PF_BT[H2(i, j)] - eta_PF[H2(i, j)]) * gtot_N[H2(i, j)] -
                            (eta_PF_BT[H2(i, j + 1)] - eta_PF[H2(i, j + 1)]) * gtot_S[H2(i, j + 1)]) * dgeo_de * G->IdyCv[V2(i, J)];
+          if (apply_v_OBCs && SEGV(i, J) != MOM6HIP_OBC_NONE) PFv[V2(i, J)] = 0.0;      /* :1992-1998, :2236-2242: no pressure force across the boundary */
         }
         ORC_PAR
         for (int J = jsv - 1; J <= jev; J++) for (int i = i0; i <= i1; i++) {
@@ -959,6 +1144,10 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
           if (use_BT_cont) vhbt[V2(i, J)] = find_uhbt(vbt_trans[V2(i, J)], &BV, V2(i, J)) + vhbt0[V2(i, J)];
           else vhbt[V2(i, J)] = Datv[V2(i, J)] * vbt_trans[V2(i, J)] + vhbt0[V2(i, J)];
         }
+        if (apply_v_OBCs)      /* :2043-2048, :2287-2292: the faces of the segments keep their values */
+          for (int J = jsv - 1; J <= jev; J++) for (int i = i0; i <= i1; i++) if (SEGV(i, J) != MOM6HIP_OBC_NONE) {
+            vbt[V2(i, J)] = vbt_prev[V2(i, J)]; vhbt[V2(i, J)] = vhbt_prev[V2(i, J)];
+          }
       } else {
         /* u-second: j=jsv..jev (:2047) ; u-first: j=jsv-1..jev+1 (:2130) */
         const int j0 = v_first ? jsv : jsv - 1, j1 = v_first ? jev : jev + 1;
@@ -969,6 +1158,7 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                              (bzon[U2(I, j)] * vbt[V2(i, j)] + dzon[U2(I, j)] * vbt[V2(i + 1, j - 1)])) - Cor_ref_u[U2(I, j)];
           PFu[U2(I, j)] = ((eta_PF_BT[H2(i, j)] - eta_PF[H2(i, j)]) * gtot_E[H2(i, j)] -
                            (eta_PF_BT[H2(i + 1, j)] - eta_PF[H2(i + 1, j)]) * gtot_W[H2(i + 1, j)]) * dgeo_de * G->IdxCu[U2(I, j)];
+          if (apply_u_OBCs && SEGU(I, j) != MOM6HIP_OBC_NONE) PFu[U2(I, j)] = 0.0;      /* :2069-2075, :2148-2154 */
         }
         ORC_PAR
         for (int j = j0; j <= j1; j++) for (int I = isv - 1; I <= iev; I++) {
@@ -980,6 +1170,10 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
           if (use_BT_cont) uhbt[U2(I, j)] = find_uhbt(ubt_trans[U2(I, j)], &BU, U2(I, j)) + uhbt0[U2(I, j)];
           else uhbt[U2(I, j)] = Datu[U2(I, j)] * ubt_trans[U2(I, j)] + uhbt0[U2(I, j)];
         }
+        if (apply_u_OBCs)      /* :2121-2126, :2198-2203 */
+          for (int j = j0; j <= j1; j++) for (int I = isv - 1; I <= iev; I++) if (SEGU(I, j) != MOM6HIP_OBC_NONE) {
+            ubt[U2(I, j)] = ubt_prev[U2(I, j)]; uhbt[U2(I, j)] = uhbt_prev[U2(I, j)];
+          }
       }
     }
 
@@ -995,6 +1189,75 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       vbt_sum[V2(i, J)] = vbt_sum[V2(i, J)] + wt_trans[n] * vbt_trans[V2(i, J)];
       vhbt_sum[V2(i, J)] = vhbt_sum[V2(i, J)] + wt_trans[n] * vhbt[V2(i, J)];
       vbt_wtd[V2(i, J)] = vbt_wtd[V2(i, J)] + wt_vel[n] * vbt[V2(i, J)];
+    }
+    if (apply_OBCs) {      /* apply_velocity_OBCs :2931-3168 (halo = iev - ie), then the sums from their saved values :2367-2395 */
+      const int halo = iev - ie, a_is = is - halo, a_ie = ie + halo, a_js = js - halo, a_je = je + halo;
+      for (int dir = 0; dir < 2; dir++) {
+        if (!(dir ? apply_v_OBCs : apply_u_OBCs)) continue;
+        double *xbt = dir ? vbt : ubt, *xhbt = dir ? vhbt : uhbt, *xtrans = dir ? vbt_trans : ubt_trans;
+        const double *xold = dir ? vbt_old : ubt_old, *o_hbt = dir ? ob_vhbt : ob_uhbt, *o_outer = dir ? ob_vbt_outer : ob_ubt_outer,
+                     *o_dZ = dir ? ob_dZ_v : ob_dZ_u, *o_Cg = dir ? ob_Cg_v : ob_Cg_u, *o_SSH = dir ? ob_SSH_v : ob_SSH_u,
+                     *Idx = dir ? G->IdyCv : G->IdxCu, *Dat = dir ? Datv : Datu, *xhbt0 = dir ? vhbt0 : uhbt0;
+        const int32_t *segnum = dir ? OBC->segnum_v : OBC->segnum_u;
+        const btcl_t *B = dir ? &BV : &BU;
+        const int di = dir ? 0 : 1, dj = dir ? 1 : 0;      /* one face | cell along the direction */
+        for (int j = (dir ? a_js - 1 : a_js); j <= a_je; j++) for (int i = (dir ? a_is : a_is - 1); i <= a_ie; i++) {
+#define XF(ii, jj) (dir ? V2(ii, jj) : U2(ii, jj))
+          const long f = XF(i, j);
+          if (segnum[f] == MOM6HIP_OBC_NONE) continue;
+          const mom6hip_obc_segment_t *S = &OBC->segment[segnum[f] - 1];
+          double vel_trans = 0.0;      /* (a segment that is none of the three keeps the reference's stale value: not provided) */
+          if (S->specified) {
+            xhbt[f] = o_hbt[f];
+            xbt[f] = o_outer[f];
+            vel_trans = xbt[f];
+          } else if (S->direction == (dir ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E)) {
+            if (S->Flather) {
+              const double cfl = dtbt * o_Cg[f] * Idx[f];
+              const double u_inlet = cfl * xold[XF(i - di, j - dj)] + (1.0 - cfl) * xold[f];
+              const double ssh_in = G->H_to_Z * (eta[H2(i, j)] + (0.5 - cfl) * (eta[H2(i, j)] - eta[H2(i - di, j - dj)]));
+              if (o_dZ[f] > 0.0) {
+                const double vel_prev = xbt[f];
+                xbt[f] = 0.5 * ((u_inlet + o_outer[f]) + (o_Cg[f] / o_dZ[f]) * (ssh_in - o_SSH[f]));
+                vel_trans = (1.0 - bebt) * vel_prev + bebt * xbt[f];
+              } else { xbt[f] = 0.0; vel_trans = 0.0; }
+            } else if (S->gradient) {
+              xbt[f] = xbt[XF(i - di, j - dj)];
+              vel_trans = xbt[f];
+            } else return 5;
+          } else if (S->direction == (dir ? MOM6HIP_OBC_DIRECTION_S : MOM6HIP_OBC_DIRECTION_W)) {
+            if (S->Flather) {
+              const double cfl = dtbt * o_Cg[f] * Idx[f];
+              const double u_inlet = cfl * xold[XF(i + di, j + dj)] + (1.0 - cfl) * xold[f];
+              const double ssh_in = G->H_to_Z * (eta[H2(i + di, j + dj)] + (0.5 - cfl) * (eta[H2(i + di, j + dj)] - eta[H2(i + 2 * di, j + 2 * dj)]));
+              if (o_dZ[f] > 0.0) {
+                const double vel_prev = xbt[f];
+                xbt[f] = 0.5 * ((u_inlet + o_outer[f]) + (o_Cg[f] / o_dZ[f]) * (o_SSH[f] - ssh_in));
+                vel_trans = (1.0 - bebt) * vel_prev + bebt * xbt[f];
+              } else { xbt[f] = 0.0; vel_trans = 0.0; }
+            } else if (S->gradient) {
+              xbt[f] = xbt[XF(i + di, j + dj)];
+              vel_trans = xbt[f];
+            } else return 5;
+          } else return 5;
+          if (!S->specified) {
+            if (use_BT_cont) xhbt[f] = find_uhbt(vel_trans, B, f) + xhbt0[f];
+            else xhbt[f] = Dat[f] * vel_trans + xhbt0[f];
+          }
+          xtrans[f] = vel_trans;
+#undef XF
+        }
+      }
+      if (apply_u_OBCs) for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) if (SEGU(I, j) != MOM6HIP_OBC_NONE) {
+        ubt_sum[U2(I, j)] = ubt_sum_prev[U2(I, j)] + wt_trans[n] * ubt_trans[U2(I, j)];
+        uhbt_sum[U2(I, j)] = uhbt_sum_prev[U2(I, j)] + wt_trans[n] * uhbt[U2(I, j)];
+        ubt_wtd[U2(I, j)] = ubt_wtd_prev[U2(I, j)] + wt_vel[n] * ubt[U2(I, j)];
+      }
+      if (apply_v_OBCs) for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) if (SEGV(i, J) != MOM6HIP_OBC_NONE) {
+        vbt_sum[V2(i, J)] = vbt_sum_prev[V2(i, J)] + wt_trans[n] * vbt_trans[V2(i, J)];
+        vhbt_sum[V2(i, J)] = vhbt_sum_prev[V2(i, J)] + wt_trans[n] * vhbt[V2(i, J)];
+        vbt_wtd[V2(i, J)] = vbt_wtd_prev[V2(i, J)] + wt_vel[n] * vbt[V2(i, J)];
+      }
     }
     /* corrector continuity :2414-2421 */
     ORC_PAR
@@ -1014,6 +1277,20 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
       e_anom[H2(i, j)] = dgeo_de * (0.5 * (eta[H2(i, j)] + eta_in[H2(i, j)]) - (eta_PF_1[H2(i, j)] + 0.5 * d_eta_PF[H2(i, j)]));
     else
       e_anom[H2(i, j)] = dgeo_de * (0.5 * (eta[H2(i, j)] + eta_in[H2(i, j)]) - eta_PF[H2(i, j)]);
+  }
+  if (apply_OBCs) {      /* :2490-2519: e_anom across the faces of the segments, the u faces first */
+    if (apply_u_OBCs) for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
+      if (SEGU(I, j) == MOM6HIP_OBC_NONE) continue;
+      const int dir = OBC->segment[SEGU(I, j) - 1].direction;
+      if (dir == MOM6HIP_OBC_DIRECTION_E) e_anom[H2(I + 1, j)] = e_anom[H2(I, j)];
+      else if (dir == MOM6HIP_OBC_DIRECTION_W) e_anom[H2(I, j)] = e_anom[H2(I + 1, j)];
+    }
+    if (apply_v_OBCs) for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
+      if (SEGV(i, J) == MOM6HIP_OBC_NONE) continue;
+      const int dir = OBC->segment[SEGV(i, J) - 1].direction;
+      if (dir == MOM6HIP_OBC_DIRECTION_N) e_anom[H2(i, J + 1)] = e_anom[H2(i, J)];
+      else if (dir == MOM6HIP_OBC_DIRECTION_S) e_anom[H2(i, J)] = e_anom[H2(i, J + 1)];
+    }
   }
   ORC_PAR
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta_out[H2(i, j)] = eta_wtd[H2(i, j)] * 1.0;
@@ -1045,6 +1322,22 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
     }
   }
 
+  if (apply_OBCs) {      /* :2591-2606: the accelerations of the segments' faces from their own velocities */
+    if (apply_u_OBCs) for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) if (SEGU(I, j) != MOM6HIP_OBC_NONE) {
+      u_accel_bt[U2(I, j)] = (ubt_wtd[U2(I, j)] - ubt_first[U2(I, j)]) / dt;
+      for (int k = 1; k <= nz; k++) accel_layer_u[ORC_U3(G, I, j, k)] = u_accel_bt[U2(I, j)];
+    }
+    if (apply_v_OBCs) for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) if (SEGV(i, J) != MOM6HIP_OBC_NONE) {
+      v_accel_bt[V2(i, J)] = (vbt_wtd[V2(i, J)] - vbt_first[V2(i, J)]) / dt;
+      for (int k = 1; k <= nz; k++) accel_layer_v[ORC_V3(G, i, J, k)] = v_accel_bt[V2(i, J)];
+    }
+  }
+  {
+    double *obs[] = {ob_Cg_u, ob_dZ_u, ob_uhbt, ob_ubt_outer, ob_SSH_u, ubt_old, ubt_first, ubt_prev, uhbt_prev, ubt_sum_prev, uhbt_sum_prev,
+                     ubt_wtd_prev, ob_Cg_v, ob_dZ_v, ob_vhbt, ob_vbt_outer, ob_SSH_v, vbt_old, vbt_first, vbt_prev, vhbt_prev, vbt_sum_prev,
+                     vhbt_sum_prev, vbt_wtd_prev};
+    for (size_t a = 0; a < sizeof(obs) / sizeof(obs[0]); a++) free(obs[a]);
+  }
   double *all[] = {q, ubt, bt_rem_u, BT_force_u, u_accel_bt, uhbt, uhbt0, ubt_sum, uhbt_sum, ubt_wtd, ubt_trans, azon, bzon, czon,
                    dzon, Cor_u, Cor_ref_u, PFu, DCor_u, Datu, ubt_Cor, av_rem_u, vbt, bt_rem_v, BT_force_v, v_accel_bt, vhbt,
                    vhbt0, vbt_sum, vhbt_sum, vbt_wtd, vbt_trans, amer, bmer, cmer, dmer, Cor_v, Cor_ref_v, PFv, DCor_v, Datv,

@@ -218,6 +218,14 @@ int orc_btstep(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const doubl
                double *vhbtav, const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
                const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
                const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav);
+/* btstep with OBC associated (Flather, gradient and specified segments; :1089-1110, set_up_BT_OBC :3172, apply_velocity_OBCs :2931, ...) */
+int orc_btstep_obc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const double *U_in, const double *V_in,
+               const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v, const double *taux,
+               const double *tauy, double RZ_to_H, const double *pbce, const double *eta_PF_in, const double *U_Cor,
+               const double *V_Cor, double *accel_layer_u, double *accel_layer_v, double *eta_out, double *uhbtav,
+               double *vhbtav, const double *visc_rem_u, const double *visc_rem_v, const mom6hip_bt_cont_t *BT_cont,
+               const double *eta_PF_start, const double *taux_bot, const double *tauy_bot, const double *uh0,
+               const double *vh0, const double *u_uh0, const double *v_vh0, double *etaav, const mom6hip_obc_t *OBC);
 
 /* ---- MOM_dynamics_split_RK2 (oracle/dyn_split_rk2.c); every pointer in CS is a HOST pointer ------------------- */
 /* ---- MOM_vert_friction (oracle/vert_friction.c) ---- */

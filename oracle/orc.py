@@ -469,22 +469,23 @@ def set_dtbt(grid, cs, pbce=None, bt_cont=None, gtot_est=0.0, SSH_add=0.0, eta=N
 
 def btstep(grid, cs, U_in, V_in, eta_in, dt, bc_accel_u, bc_accel_v, taux, tauy, pbce, eta_PF_in, U_Cor, V_Cor,
            visc_rem_u, visc_rem_v, RZ_to_H=None, bt_cont=None, eta_PF_start=None, taux_bot=None, tauy_bot=None, uh0=None,
-           vh0=None, u_uh0=None, v_vh0=None, want_etaav=False):
+           vh0=None, u_uh0=None, v_vh0=None, want_etaav=False, OBC=None):
     """btstep on numpy arrays.  Returns dict(accel_layer_u, accel_layer_v, eta_out, uhbtav, vhbtav[, etaav])."""
     L = lib()
-    L.orc_btstep.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS)] + [_dp] * 3 + [C.c_double] + [_dp] * 4
-                             + [C.c_double] + [_dp] * 11 + [C.POINTER(_abi.BTCont)] + [_dp] * 8)
+    L.orc_btstep_obc.argtypes = ([C.POINTER(_abi.GridStruct), C.POINTER(_abi.BarotropicCS)] + [_dp] * 3 + [C.c_double] + [_dp] * 4
+                                 + [C.c_double] + [_dp] * 11 + [C.POINTER(_abi.BTCont)] + [_dp] * 8 + [C.POINTER(_abi.Obc)])
+    obc = None if OBC is None else OBC.struct()
     out = dict(accel_layer_u=grid.zeros3(_abi.POS_U), accel_layer_v=grid.zeros3(_abi.POS_V), eta_out=grid.zeros2(_abi.POS_H),
                uhbtav=grid.zeros2(_abi.POS_U), vhbtav=grid.zeros2(_abi.POS_V))
     if want_etaav:
         out["etaav"] = grid.zeros2(_abi.POS_H)
     rz = grid.Z_to_H / grid.Rho0 if RZ_to_H is None else RZ_to_H
-    rc = L.orc_btstep(C.byref(grid.struct()), C.byref(cs), _p(U_in), _p(V_in), _p(eta_in), float(dt), _p(bc_accel_u),
+    rc = L.orc_btstep_obc(C.byref(grid.struct()), C.byref(cs), _p(U_in), _p(V_in), _p(eta_in), float(dt), _p(bc_accel_u),
                       _p(bc_accel_v), _p(taux), _p(tauy), float(rz), _p(pbce), _p(eta_PF_in), _p(U_Cor), _p(V_Cor),
                       _p(out["accel_layer_u"]), _p(out["accel_layer_v"]), _p(out["eta_out"]), _p(out["uhbtav"]),
                       _p(out["vhbtav"]), _p(visc_rem_u), _p(visc_rem_v), None if bt_cont is None else C.byref(bt_cont),
                       _p(eta_PF_start), _p(taux_bot), _p(tauy_bot), _p(uh0), _p(vh0), _p(u_uh0), _p(v_vh0),
-                      _p(out.get("etaav")))
+                      _p(out.get("etaav")), None if obc is None else C.byref(obc))
     if rc:
         raise RuntimeError(f"orc_btstep failed rc={rc}")
     return out

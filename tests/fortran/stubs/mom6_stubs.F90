@@ -1211,6 +1211,7 @@ type :: OBC_segment_type
   integer :: direction = 0
   type(hor_index_type) :: HI
   real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:), tangential_vel(:,:,:), tangential_grad(:,:,:)
+  real, allocatable :: SSH(:,:)
 end type OBC_segment_type
 type :: ocean_OBC_type
   logical :: OBC_pe = .false.

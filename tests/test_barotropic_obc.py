@@ -102,3 +102,181 @@ def test_gpu_btcalc_with_open_boundaries_matches_oracle_bitwise(scheme, space):
     assert bits_equal(interior(g, N(CS.arrays["frhatu"]), _abi.POS_U), interior(g, fu, _abi.POS_U))
     assert bits_equal(interior(g, N(CS.arrays["frhatv"]), _abi.POS_V), interior(g, fv, _abi.POS_V))
     dg.close()
+
+
+# ---- btstep -----------------------------------------------------------------------------------------------------------------------------------
+BT_SEGS = ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,FLATHER,ORLANSKI", "I=0,J=N:0,GRADIENT", "I=9,J=4:11,SIMPLE",
+           "J=7,I=15:3,SIMPLE"]
+
+
+def btstep_obc_case(segs, ni=22, nj=16, nk=4, seed=5, dt=900.0, use_bt_cont=True, bump=False, **cs_kw):
+    """the inputs of btstep as step_MOM_dyn_split_RK2 forms them (tests/helpers.py barotropic_case), on a regional grid with open boundaries:
+    BT_cont and the layer transports from continuity_PPM with the OBC, frhatu / frhatv from btcalc with the OBC"""
+    from helpers import barotropic_case      # (for the recipe; rebuilt here with the OBC in every call that takes one)
+    g = synth.make_grid(ni, nj, nk, land_frac=0.1, seed=seed + 200, reentrant_x=False, reentrant_y=False)
+    OBC = ocean_OBC_type(g, segs)
+    open_faces(g, OBC)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.3).items()}
+    rng = np.random.default_rng(seed)
+    d["u"] = np.ascontiguousarray(d["u"] + 0.05 * rng.standard_normal(d["u"].shape) * (OBC.segnum_u != 0)[None])
+    d["v"] = np.ascontiguousarray(d["v"] + 0.05 * rng.standard_normal(d["v"].shape) * (OBC.segnum_v != 0)[None])
+    for s in OBC.segment:
+        if not s.on_pe:
+            continue
+        if s.specified:
+            s.normal_vel[:] = 0.1 * rng.standard_normal(s.normal_vel.shape)
+            s.normal_trans[:] = s.normal_vel * (3.0e4 * (5.0 + 50.0 * rng.random(s.normal_vel.shape)))
+        if s.Flather:
+            s.normal_vel_bt[:] = 0.02 * rng.standard_normal(s.normal_vel_bt.shape); s.SSH[:] = 0.05 * rng.standard_normal(s.SSH.shape)
+    kk = (np.arange(nk) + 0.5) / nk
+    vru = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["u"], 0.0, 1.0) * (g.mask2dCu[None] > 0))
+    vrv = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["v"], 0.0, 1.0) * (g.mask2dCv[None] > 0))
+    PFu, PFv, pbce, eta_PF = orc.pressureforce(g, orc.pressureforce_cs(g), orc.eos("WRIGHT"), d["h"], d["T"], d["S"])
+    hp = d["h"].copy(); uh = np.zeros_like(d["u"]); vh = np.zeros_like(d["v"])
+    ccs = orc.continuity_cs(nk, g.Angstrom_H)
+    arrs, bt = orc.make_bt_cont(g, with_h=True)
+    orc.continuity(g, ccs, d["u"], d["v"], d["h"], hp, uh, vh, dt, visc_rem_u=vru, visc_rem_v=vrv, bt_cont=bt, OBC=OBC)
+    orc.halo_update(g, uh, _abi.POS_U); orc.halo_update(g, vh, _abi.POS_V)
+    hvel = "FROM_BT_CONT" if use_bt_cont else "HARMONIC"
+    cs, cs_arrs = orc.barotropic_cs(g, hvel_scheme=hvel, **cs_kw)
+    orc.barotropic_init(g, cs)
+    if use_bt_cont:
+        orc.btcalc(g, cs, d["h"], arrs["h_u"], arrs["h_v"], OBC=OBC)
+    else:
+        orc.btcalc(g, cs, d["h"], OBC=OBC)
+    eta = np.ascontiguousarray(d["h"].sum(0) - g.bathyT * g.Z_to_H)
+    eta = eta + 0.01 * rng.standard_normal(eta.shape) * g.mask2dT
+    if bump:
+        jj, ii = np.meshgrid(np.arange(eta.shape[0]), np.arange(eta.shape[1]), indexing="ij")
+        eta = eta + 0.5 * np.exp(-((ii - eta.shape[1] / 2) ** 2 + (jj - eta.shape[0] / 2) ** 2) / 30.0) * g.mask2dT
+    orc.halo_update(g, eta, _abi.POS_H)
+    orc.bt_mass_source(g, cs, d["h"], eta, True)
+    orc.set_dtbt(g, cs, pbce=pbce, bt_cont=bt if use_bt_cont else None, gtot_est=g.g_Earth, SSH_add=10.0)
+    cs.dtbt = min(cs.dtbt, dt / 12.6)
+    case = dict(U_in=d["u"], V_in=d["v"], eta_in=eta, dt=dt,
+                bc_accel_u=np.ascontiguousarray((PFu + 1e-6 * rng.standard_normal(PFu.shape)) * (g.mask2dCu[None] > 0)),
+                bc_accel_v=np.ascontiguousarray((PFv + 1e-6 * rng.standard_normal(PFv.shape)) * (g.mask2dCv[None] > 0)),
+                taux=np.ascontiguousarray(0.1 * np.cos(np.linspace(0, 3, g.shape2(_abi.POS_U)[0]))[:, None] * g.mask2dCu),
+                tauy=np.ascontiguousarray(0.02 * rng.standard_normal(g.shape2(_abi.POS_V)) * g.mask2dCv),
+                pbce=pbce, eta_PF_in=eta_PF, U_Cor=d["u"], V_Cor=d["v"], visc_rem_u=vru, visc_rem_v=vrv,
+                bt_cont=bt if use_bt_cont else None, uh0=uh, vh0=vh, u_uh0=d["u"], v_vh0=d["v"])
+    keep = dict(bt_arrs=arrs, cs_arrs=cs_arrs, h=d["h"])
+    return g, cs, case, keep, OBC
+
+
+def test_btstep_without_segments_is_btstep():
+    g, cs, case, keep, OBC = btstep_obc_case([])
+    a = orc.btstep(g, cs, **case, OBC=OBC)
+    g, cs, case, keep, OBC = btstep_obc_case([])
+    b = orc.btstep(g, cs, **case)
+    for n in a:
+        assert bits_equal(a[n], b[n]), n
+
+
+@pytest.mark.parametrize("use_bt_cont", [True, False])
+def test_btstep_specified_faces_carry_the_external_transport(use_bt_cont):
+    """a specified face has uhbt = the sum of the segment's normal_trans at every barotropic step (apply_velocity_OBCs :3023-3026): so has the
+    time-filtered transport (the weights sum to one), and its acceleration is that of the barotropic velocity alone (:2591-2606)"""
+    g, cs, case, keep, OBC = btstep_obc_case(BT_SEGS, use_bt_cont=use_bt_cont)
+    o = orc.btstep(g, cs, **case, OBC=OBC)
+    n_spec = 0
+    for s in OBC.segment:
+        if not (s.specified and s.on_pe):
+            continue
+        if s.is_E_or_W:
+            I = s.HI["IsdB"] - g.isd + 1; js = slice(s.HI["jsd"] - g.jsd, s.HI["jed"] - g.jsd + 1)
+            ok = np.zeros(o["uhbtav"].shape, dtype=bool); ok[js, I] = True
+            ok &= (OBC.segnum_u == OBC.segment.index(s) + 1)
+            ok[: g.jsc - g.jsd, :] = False; ok[g.jec - g.jsd + 1:, :] = False
+            want = s.normal_trans[:, :, 0].sum(0)[ok[js, I]]
+            assert np.allclose(o["uhbtav"][ok], want, rtol=1e-12, atol=1e-9) and ok.any()
+            assert np.all(o["accel_layer_u"][:, ok] == o["accel_layer_u"][0][ok][None])
+        else:
+            J = s.HI["JsdB"] - g.jsd + 1; is_ = slice(s.HI["isd"] - g.isd, s.HI["ied"] - g.isd + 1)
+            ok = np.zeros(o["vhbtav"].shape, dtype=bool); ok[J, is_] = True
+            ok &= (OBC.segnum_v == OBC.segment.index(s) + 1)
+            ok[:, : g.isc - g.isd] = False; ok[:, g.iec - g.isd + 1:] = False
+            want = s.normal_trans[:, 0, :].sum(0)[ok[J, is_]]
+            assert np.allclose(o["vhbtav"][ok], want, rtol=1e-12, atol=1e-9) and ok.any()
+        n_spec += 1
+    assert n_spec == 2
+    closed = orc.btstep(g, cs, **case)
+    assert not bits_equal(o["eta_out"], closed["eta_out"])
+
+
+def test_btstep_a_bump_leaves_through_flather_boundaries():
+    """a surface bump in the middle of a basin that is open on all sides: after a few calls the Flather faces carry water out on every
+    side, and the basin holds less of it than the same basin with walls"""
+    segs = ["J=N,I=N:0,FLATHER", "J=0,I=0:N,FLATHER", "I=N,J=0:N,FLATHER", "I=0,J=N:0,FLATHER"]
+    g, cs, case, keep, OBC = btstep_obc_case(segs, bump=True, seed=9)
+    for s in OBC.segment:
+        s.normal_vel_bt[:] = 0.0; s.SSH[:] = 0.0
+    o = orc.btstep(g, cs, **case, OBC=OBC)
+    on_u, on_v = OBC.segnum_u != 0, OBC.segnum_v != 0
+    east = on_u & (np.arange(on_u.shape[1])[None, :] > on_u.shape[1] // 2); west = on_u & ~east
+    north = on_v & (np.arange(on_v.shape[0])[:, None] > on_v.shape[0] // 2); south = on_v & ~north
+    cu, cv = interior(g, np.ones_like(o["uhbtav"]), _abi.POS_U) > 0, None
+    inner_u = np.zeros_like(on_u); inner_u[g.jsc - g.jsd: g.jec - g.jsd + 1, g.isc - g.isd: g.iec - g.isd + 2] = True
+    inner_v = np.zeros_like(on_v); inner_v[g.jsc - g.jsd: g.jec - g.jsd + 2, g.isc - g.isd: g.iec - g.isd + 1] = True
+    out = (o["uhbtav"][east & inner_u].sum() - o["uhbtav"][west & inner_u].sum()) + (o["vhbtav"][north & inner_v].sum() - o["vhbtav"][south & inner_v].sum())
+    assert np.isfinite(out) and np.all(np.isfinite(o["eta_out"]))
+    assert np.abs(o["uhbtav"][on_u & inner_u]).max() > 0 and np.abs(o["vhbtav"][on_v & inner_v]).max() > 0
+
+
+BT_OBC_CASES = [dict(), dict(use_bt_cont=False), dict(use_bt_cont=False, BT_project_velocity=1), dict(use_wide_halos=0), dict(adjust_BT_cont=1),
+                dict(strong_drag=1, Sadourny=0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("space", ["device", "host"])
+@pytest.mark.parametrize("kw", BT_OBC_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in BT_OBC_CASES])
+def test_gpu_btstep_with_open_boundaries_matches_oracle_bitwise(kw, space):
+    import torch
+    from mom6_amd.barotropic import barotropic_init, bt_mass_source, btcalc, btstep, set_dtbt
+    from mom6_amd.continuity import BT_cont_type
+    from mom6_amd.tracer_advect import DeviceGrid
+    device = "cuda" if space == "device" else "cpu"
+    T = (lambda a: torch.from_numpy(np.ascontiguousarray(a).copy()).cuda()) if space == "device" else (lambda a: np.ascontiguousarray(a).copy())
+    N = (lambda a: a.cpu().numpy()) if space == "device" else (lambda a: np.asarray(a))
+    for (ni, nj, nk) in [(22, 16, 4), (60, 30, 3)]:
+        g, cs_o, case, keep, OBC = btstep_obc_case(BT_SEGS, ni=ni, nj=nj, nk=nk, seed=ni, **kw)
+        ref = orc.btstep(g, cs_o, **case, want_etaav=True, OBC=OBC)
+        other = btstep_obc_case(BT_SEGS, ni=ni, nj=nj, nk=nk, seed=ni, **kw)      # (kept: the control structure points into its arrays)
+        closed = orc.btstep(other[0], other[1], **case, want_etaav=True)
+        assert not bits_equal(ref["eta_out"], closed["eta_out"])
+        dg = DeviceGrid(g)
+        use_bt = kw.get("use_bt_cont", True)
+        cs_kw = {k: v for k, v in kw.items() if k in ("strong_drag", "Sadourny", "adjust_BT_cont")}
+        if "BT_project_velocity" in kw:
+            cs_kw["BT_PROJECT_VELOCITY"] = bool(kw["BT_project_velocity"])
+        if "use_wide_halos" in kw:
+            cs_kw["BT_USE_WIDE_HALOS"] = bool(kw["use_wide_halos"])
+        CS = barotropic_init(dg, device=device, BT_THICK_SCHEME="FROM_BT_CONT" if use_bt else "HARMONIC", USE_BT_CONT_TYPE=True, **cs_kw)
+        bt_arrs = {n: T(a) for n, a in keep["bt_arrs"].items()}
+        BT = BT_cont_type(**bt_arrs)
+        h = T(keep["h"])
+        if use_bt:
+            btcalc(h, dg, CS, bt_arrs["h_u"], bt_arrs["h_v"], OBC=OBC)
+        else:
+            btcalc(h, dg, CS, OBC=OBC)
+        bt_mass_source(h, T(case["eta_in"]), True, dg, CS)
+        set_dtbt(dg, CS, pbce=T(case["pbce"]), BT_cont=BT if use_bt else None, gtot_est=g.g_Earth, SSH_add=10.0)
+        CS.st.dtbt = cs_o.dtbt
+        if space == "device":      # the segments' own arrays in the memory space of the call
+            for s in OBC.segment:
+                for k in ("normal_vel", "normal_trans", "nudged_normal_vel", "tangential_vel", "tangential_grad", "normal_vel_bt", "SSH"):
+                    if s.on_pe and isinstance(getattr(s, k, None), np.ndarray):
+                        setattr(s, k, T(getattr(s, k)))
+        out = dict(accel_layer_u=T(g.zeros3(_abi.POS_U)), accel_layer_v=T(g.zeros3(_abi.POS_V)), eta_out=T(g.zeros2(_abi.POS_H)),
+                   uhbtav=T(g.zeros2(_abi.POS_U)), vhbtav=T(g.zeros2(_abi.POS_V)), etaav=T(g.zeros2(_abi.POS_H)))
+        c = {k: T(v) for k, v in case.items() if isinstance(v, np.ndarray)}
+        for rep in range(2):      # (the second call replays the captured graph of the time steps)
+            btstep(c["U_in"], c["V_in"], c["eta_in"], case["dt"], c["bc_accel_u"], c["bc_accel_v"], (c["taux"], c["tauy"]), c["pbce"],
+                   c["eta_PF_in"], c["U_Cor"], c["V_Cor"], out["accel_layer_u"], out["accel_layer_v"], out["eta_out"], out["uhbtav"],
+                   out["vhbtav"], dg, CS, c["visc_rem_u"], c["visc_rem_v"], OBC=OBC, BT_cont=BT if use_bt else None, uh0=c["uh0"], vh0=c["vh0"],
+                   u_uh0=c["u_uh0"], v_vh0=c["v_vh0"], etaav=out["etaav"])
+            dg.sync()
+            for n in ("uhbtav", "vhbtav", "eta_out", "etaav", "accel_layer_u", "accel_layer_v"):
+                a, b = N(out[n]), ref[n]
+                assert bits_equal(a, b), (kw, (ni, nj, nk), rep, n, float(np.abs(a - b).max()), np.argwhere(a != b)[:4].tolist())
+        dg.close()
