@@ -311,8 +311,8 @@ def _seg_to_ptr(space):
         if hasattr(a, "data_ptr"):
             return a.data_ptr(), a
         a = np.ascontiguousarray(a, dtype=np.float64)
-        if space == _abi.MEM_DEVICE:
-            raise Mom6HipError("MOM_open_boundary: with device fields the segments' arrays (normal_vel ...) must be device tensors too")
+        if space == _abi.MEM_DEVICE:      # not on the device: handed over as absent (the library names what a call needs and does not find)
+            return 0, None
         return a.ctypes.data, a
     return to_ptr
 
