@@ -532,6 +532,15 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 #define MOM6HIP_OBC_DIRECTION_E 300
 #define MOM6HIP_OBC_DIRECTION_W 400
 
+/* OBC_segment_tracer_type (:119-137) as advect_tracer reads it: one registered tracer of a segment's registry (segment%tr_Reg%Tr(m)) */
+typedef struct mom6hip_obc_segment_tracer {
+  int32_t ntr_index;           /* %ntr_index: which tracer of the registry (1-based: the order of the tracers handed to advect_tracer) */
+  int32_t reserved;
+  const double *tres;          /* %tres, the tracer reservoir on the segment's faces, (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk)
+                                  for N / S, in the memory space of the call; NULL (not allocated): OBC_inflow_conc is used */
+  double OBC_inflow_conc;      /* %OBC_inflow_conc */
+} mom6hip_obc_segment_tracer_t;
+
 typedef struct mom6hip_obc_segment {
   int32_t direction;       /* MOM6HIP_OBC_DIRECTION_* */
   int32_t open;            /* segment%open: open for the continuity solver */
@@ -556,6 +565,9 @@ typedef struct mom6hip_obc_segment {
    * and sea surface height of a Flather segment, read by btstep (set_up_BT_OBC); may be NULL otherwise */
   const double *normal_vel_bt, *SSH;
   double Velocity_nudging_timescale_in, Velocity_nudging_timescale_out;      /* [T] */
+  /* segment%tr_Reg: NULL (not associated) or tr_Reg%ntseg entries, a HOST array; read by advect_tracer */
+  const mom6hip_obc_segment_tracer_t *tr_Reg;
+  int32_t ntseg, reserved_i;
 } mom6hip_obc_segment_t;
 
 typedef struct mom6hip_obc {

@@ -185,13 +185,19 @@ class EpipycnalCS(C.Structure):
 OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W = 0, 100, 200, 300, 400
 
 
+class ObcSegmentTracer(C.Structure):
+    """mom6hip_obc_segment_tracer_t (include/mom6hip.h)."""
+    _fields_ = [("ntr_index", C.c_int32), ("reserved", C.c_int32), ("tres", C.c_void_p), ("OBC_inflow_conc", C.c_double)]
+
+
 class ObcSegment(C.Structure):
     """mom6hip_obc_segment_t (include/mom6hip.h)."""
     _fields_ = [(n, C.c_int32) for n in ("direction", "open", "specified", "on_pe", "is_E_or_W", "is_N_or_S", "IsdB", "IedB", "JsdB", "JedB",
                                          "isd", "ied", "jsd", "jed", "radiation", "gradient", "nudged", "oblique", "radiation_tan_or_grad")] + \
                [("Flather", C.c_int32), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("tangential_vel", C.c_void_p),
                 ("tangential_grad", C.c_void_p), ("nudged_normal_vel", C.c_void_p), ("normal_vel_bt", C.c_void_p), ("SSH", C.c_void_p),
-                ("Velocity_nudging_timescale_in", C.c_double), ("Velocity_nudging_timescale_out", C.c_double)]
+                ("Velocity_nudging_timescale_in", C.c_double), ("Velocity_nudging_timescale_out", C.c_double),
+                ("tr_Reg", C.POINTER(ObcSegmentTracer)), ("ntseg", C.c_int32), ("reserved_i", C.c_int32)]
 
 
 class Obc(C.Structure):

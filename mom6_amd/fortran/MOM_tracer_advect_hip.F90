@@ -79,8 +79,14 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
   if (.not. associated(Reg)) call MOM_error(FATAL, "MOM_tracer_advect: "// &
        "register_tracer must be called before advect_tracer.")
   if (Reg%ntr==0) return
-  if (associated(OBC)) call MOM_error(FATAL, "MOM_tracer_advect (HIP): open boundary conditions "// &
-       "are not supported by the GPU tracer advection.")
+  ! advect_x / advect_y read of an associated OBC only the tracer registries of its segments (segment%tr_Reg: the reservoirs and inflow
+  ! concentrations, :442-477, :580-627 and their twins): without one on any segment the advection is that of a closed domain
+  if (associated(OBC)) then ; if (OBC%OBC_pe) then
+    do m=1,OBC%number_of_segments
+      if (associated(OBC%segment(m)%tr_Reg)) call MOM_error(FATAL, "MOM_tracer_advect (HIP): open boundary segments with a "// &
+           "tracer registry (reservoirs or inflow concentrations) are not provided by the GPU tracer advection.")
+    enddo
+  endif ; endif
   call cpu_clock_begin(id_clock_advect)
 
   ! the context: metrics on the GPU, the device of this PE, and MOM6's pass_var / sum_across_PEs behind the group pass

@@ -194,6 +194,12 @@ end type mom6hip_neutral_diffusion_cs_t
 !> mom6hip_obc_segment_t / mom6hip_obc_t: what continuity_PPM reads of OBC_segment_type / ocean_OBC_type (src/core/MOM_open_boundary.F90:146, :266)
 integer(c_int32_t), parameter :: MOM6HIP_OBC_NONE = 0, MOM6HIP_OBC_DIRECTION_N = 100, MOM6HIP_OBC_DIRECTION_S = 200, &
                                  MOM6HIP_OBC_DIRECTION_E = 300, MOM6HIP_OBC_DIRECTION_W = 400
+!> mom6hip_obc_segment_tracer_t: one registered tracer of a segment (segment%tr_Reg%Tr(m))
+type, bind(c) :: mom6hip_obc_segment_tracer_t
+  integer(c_int32_t) :: ntr_index = 0, reserved = 0
+  type(c_ptr) :: tres = c_null_ptr
+  real(c_double) :: OBC_inflow_conc = 0.0
+end type mom6hip_obc_segment_tracer_t
 type, bind(c) :: mom6hip_obc_segment_t
   integer(c_int32_t) :: direction = 0, open = 0, specified = 0, on_pe = 0, is_E_or_W = 0, is_N_or_S = 0
   integer(c_int32_t) :: IsdB = 0, IedB = 0, JsdB = 0, JedB = 0, isd = 0, ied = 0, jsd = 0, jed = 0
@@ -202,6 +208,8 @@ type, bind(c) :: mom6hip_obc_segment_t
   type(c_ptr) :: normal_trans = c_null_ptr, normal_vel = c_null_ptr, tangential_vel = c_null_ptr, tangential_grad = c_null_ptr
   type(c_ptr) :: nudged_normal_vel = c_null_ptr, normal_vel_bt = c_null_ptr, SSH = c_null_ptr
   real(c_double) :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
+  type(c_ptr) :: tr_Reg = c_null_ptr
+  integer(c_int32_t) :: ntseg = 0, reserved_i = 0
 end type mom6hip_obc_segment_t
 type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: number_of_segments = 0, OBC_pe = 0, open_u_BCs_exist_globally = 0, open_v_BCs_exist_globally = 0

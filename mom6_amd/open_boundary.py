@@ -78,6 +78,9 @@ class OBC_segment_type:
         self.nudged_normal_vel = None      # the layout of normal_vel
         self.normal_vel_bt = self.SSH = None      # (jsd:jed, IsdB:IedB) | (JsdB:JedB, isd:ied): the external barotropic velocity and surface height
         self.Velocity_nudging_timescale_in = self.Velocity_nudging_timescale_out = 0.0
+        # segment%tr_Reg: None, or a list of dicts(ntr_index = 1-based place of the tracer in the registry, tres = the reservoir on the
+        # segment's faces in the layout of normal_vel or None, OBC_inflow_conc) -- register_segment_tracer :5213
+        self.tr_Reg = None
 
 
 class ocean_OBC_type:
@@ -277,6 +280,20 @@ class ocean_OBC_type:
                         a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); setattr(c, k, a.ctypes.data)
                     else:
                         p, owner = to_ptr(a); keep.append(owner); setattr(c, k, p)
+        for n, s in enumerate(self.segment):      # the tracer registries of the segments (read by advect_tracer)
+            if s.tr_Reg is None:
+                continue
+            trs = (_abi.ObcSegmentTracer * max(len(s.tr_Reg), 1))()
+            for m, t in enumerate(s.tr_Reg):
+                trs[m].ntr_index, trs[m].OBC_inflow_conc = int(t["ntr_index"]), float(t.get("OBC_inflow_conc", 0.0))
+                a = t.get("tres")
+                if a is not None:
+                    if to_ptr is None:
+                        a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); trs[m].tres = a.ctypes.data
+                    else:
+                        p, owner = to_ptr(a); keep.append(owner); trs[m].tres = p
+            keep.append(trs)
+            segs[n].tr_Reg = C.cast(trs, C.POINTER(_abi.ObcSegmentTracer)); segs[n].ntseg = len(s.tr_Reg)
         o = _abi.Obc()
         o.number_of_segments, o.OBC_pe = self.number_of_segments, int(self.OBC_pe)
         for k in ("open_u_BCs_exist_globally", "open_v_BCs_exist_globally", "specified_u_BCs_exist_globally", "specified_v_BCs_exist_globally",

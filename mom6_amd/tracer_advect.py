@@ -217,8 +217,11 @@ def advect_tracer(h_end, uhtr, vhtr, OBC, dt, G: DeviceGrid, CS: TracerAdvectCS,
         raise Mom6HipError("MOM_tracer_advect: tracer_advect_init must be called before advect_tracer.")
     if Reg is None:
         raise Mom6HipError("MOM_tracer_advect: register_tracer must be called before advect_tracer.")
-    if OBC is not None:
-        raise Mom6HipError("MOM_tracer_advect (HIP): open boundary conditions are not supported on this path")
+    # advect_x / advect_y read of an associated OBC only the tracer registries of its segments (segment%tr_Reg, :442-477, :580-627 and
+    # their twins): without one on any segment the advection is that of a closed domain
+    if OBC is not None and any(getattr(s, "tr_Reg", None) is not None for s in OBC.segment):
+        raise Mom6HipError("MOM_tracer_advect (HIP): open boundary segments with a tracer registry (reservoirs or inflow concentrations) "
+                           "are not provided")
     ntr = len(Reg)
     st = _abi.AdvectStats()
     if ntr == 0:

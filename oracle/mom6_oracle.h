@@ -94,6 +94,12 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
                       double *const *tr, const double *conc_underflow, int ntr,
                       int x_first_in, double *vol_prev, int max_iter_in, int update_vol_prev,
                       double *uhr_out, double *vhr_out, mom6hip_advect_stats_t *stats);
+/* advect_tracer with OBC associated (the segments' tracer registries: MOM_tracer_advect.F90:441-477, :580-627, :823-861, :965-1014) */
+int orc_advect_tracer_obc(const mom6hip_grid_t *G, const double *h_end, const double *uhtr,
+                          const double *vhtr, double dt, const mom6hip_tracer_advect_cs_t *cs,
+                          double *const *tr, const double *conc_underflow, int ntr,
+                          int x_first_in, double *vol_prev, int max_iter_in, int update_vol_prev,
+                          double *uhr_out, double *vhr_out, mom6hip_advect_stats_t *stats, const mom6hip_obc_t *OBC);
 
 /* ---- ALE reconstruction + remapping (oracle/remapping.c) ------------------------------------ */
 /* REMAPPING_* and INTEGRATION_* of src/ALE/MOM_remapping.F90:50-64 */

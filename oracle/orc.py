@@ -76,18 +76,22 @@ def halo_update(grid, f, pos):
 
 def advect_tracer(grid, h_end, uhtr, vhtr, dt, cs_dt, scheme, tr, conc_underflow=None,
                   x_first=None, vol_prev=None, max_iter=None, update_vol_prev=False,
-                  uhr_out=None, vhr_out=None, use_huynh_stencil_bug=False):
+                  uhr_out=None, vhr_out=None, use_huynh_stencil_bug=False, OBC=None):
     """advect_tracer on numpy arrays (tracers updated in place).  Returns AdvectStats."""
+    L = lib()
+    L.orc_advect_tracer_obc.argtypes = [C.POINTER(_abi.GridStruct), _dp, _dp, _dp, C.c_double, C.POINTER(_abi.TracerAdvectCS), C.POINTER(_dp), _dp,
+                                        C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.POINTER(_abi.AdvectStats), C.POINTER(_abi.Obc)]
+    obc = None if OBC is None else OBC.struct()
     cs = _abi.TracerAdvectCS(float(cs_dt), _abi.ADV_SCHEMES[scheme], int(use_huynh_stencil_bug))
     ntr = len(tr)
     trp = (_dp * ntr)(*[_p(t) for t in tr])
     cu = None if conc_underflow is None else np.ascontiguousarray(conc_underflow, dtype=np.float64)
     st = _abi.AdvectStats()
-    rc = lib().orc_advect_tracer(
+    rc = L.orc_advect_tracer_obc(
         C.byref(grid.struct()), _p(h_end), _p(uhtr), _p(vhtr), float(dt), C.byref(cs), trp, _p(cu),
         ntr, -1 if x_first is None else int(bool(x_first)), _p(vol_prev),
         0 if max_iter is None else int(max_iter), int(bool(update_vol_prev)), _p(uhr_out),
-        _p(vhr_out), C.byref(st))
+        _p(vhr_out), C.byref(st), None if obc is None else C.byref(obc))
     if rc != 0:
         raise RuntimeError(f"orc_advect_tracer failed rc={rc}")
     return st

@@ -31,7 +31,17 @@ typedef struct {
   double *hprev, *uhr, *vhr, *uh_neglect, *vh_neglect;
   unsigned char *domore_u;   /* (jsd:jed, nk) */
   unsigned char *domore_v;   /* (jsd-1:jed, nk) */
+  const mom6hip_obc_t *OBC;  /* NULL, or the open boundaries: the tracer registries of the segments are read (:442-477, :580-627, ...) */
 } adv_t;
+
+/* the value a registered tracer takes outside a segment: its reservoir at the face (a, b) = (I, j) | (i, J) of layer k, or the inflow
+ * concentration */
+static inline double seg_tracer(const mom6hip_obc_segment_t *S, const mom6hip_obc_segment_tracer_t *T, int a, int b, int k) {
+  if (!T->tres) return T->OBC_inflow_conc;
+  const int a0 = S->is_N_or_S ? S->isd : S->IsdB, a1 = S->is_N_or_S ? S->ied : S->IedB;
+  const int b0 = S->is_N_or_S ? S->JsdB : S->jsd, b1 = S->is_N_or_S ? S->JedB : S->jed;
+  return T->tres[(a - a0) + (long)(a1 - a0 + 1) * ((b - b0) + (long)(b1 - b0 + 1) * (k - 1))];
+}
 
 #define DU(A,j,k) (A)->domore_u[((j)-G->jsd) + (long)ORC_NJH(G)*((k)-1)]
 #define DV(A,J,k) (A)->domore_v[((J)-G->jsd+1) + (long)(ORC_NJH(G)+1)*((k)-1)]
@@ -113,6 +123,25 @@ static void advect_x(adv_t *A, int is, int ie, int js, int je, int k)
 
     for (int m = 0; m < ntr; m++)
       for (int i = G->isd; i <= G->ied; i++) WM(T_tmp,i,m) = A->tr[m][ORC_H3(G,i,j,k)];
+    /* :441-477: the registered tracers take their reservoir (or inflow) values in the cell outside a segment, and the slopes of the three
+     * cells about its face are formed again */
+    if (A->OBC && A->OBC->OBC_pe) for (int n = 0; n < A->OBC->number_of_segments; n++) {
+      const mom6hip_obc_segment_t *S = &A->OBC->segment[n];
+      if (!S->tr_Reg) continue;
+      if (S->is_E_or_W && j >= S->jsd && j <= S->jed) {
+        const int I = S->IsdB;
+        for (int q = 0; q < S->ntseg; q++) {
+          const int m = S->tr_Reg[q].ntr_index - 1;
+          const double val = seg_tracer(S, &S->tr_Reg[q], I, j, k);
+          if (S->direction == MOM6HIP_OBC_DIRECTION_W) WM(T_tmp,I,m) = val;
+          else WM(T_tmp,I+1,m) = val;
+        }
+        for (int m = 0; m < ntr; m++) for (int i = I-1; i <= I+1; i++) {
+          double Tp = WM(T_tmp,i+1,m), Tc = WM(T_tmp,i,m), Tm = WM(T_tmp,i-1,m);
+          WM(slope_x,i,m) = plm_slope(Tp, Tc, Tm, G->mask2dCu[ORC_U2(G,I,j)]*G->mask2dCu[ORC_U2(G,I-1,j)]);
+        }
+      }
+    }
 
     /* :485-514 */
     for (int I = is-1; I <= ie; I++) {
@@ -169,6 +198,39 @@ static void advect_x(adv_t *A, int is, int ie, int js, int je, int k)
           WM(flux_x,I,m) = W(uhh,I)*( Tc - 0.5 * WM(slope_x,i+1,m) * ( 1. - W(CFL,I) ) );
         }
       }
+    }
+
+    if (A->OBC && A->OBC->OBC_pe) {      /* :580-627 */
+      const mom6hip_obc_t *OBC = A->OBC;
+      if (OBC->specified_u_BCs_exist_globally || OBC->open_u_BCs_exist_globally)
+        for (int n = 0; n < OBC->number_of_segments; n++) {
+          const mom6hip_obc_segment_t *S = &OBC->segment[n];
+          if (!S->tr_Reg) continue;
+          if (S->is_E_or_W && j >= S->jsd && j <= S->jed) {
+            const int I = S->IsdB;
+            const double u = A->uhr[ORC_U3(G,I,j,k)];
+            if (((u > 0.0) && (S->direction == MOM6HIP_OBC_DIRECTION_W)) || ((u < 0.0) && (S->direction == MOM6HIP_OBC_DIRECTION_E))) {
+              W(uhh,I) = u;
+              for (int q = 0; q < S->ntseg; q++)
+                WM(flux_x,I,S->tr_Reg[q].ntr_index - 1) = W(uhh,I) * seg_tracer(S, &S->tr_Reg[q], I, j, k);
+            }
+          }
+        }
+      if (OBC->open_u_BCs_exist_globally)
+        for (int n = 0; n < OBC->number_of_segments; n++) {
+          const mom6hip_obc_segment_t *S = &OBC->segment[n];
+          const int I = S->IsdB;
+          if (S->is_E_or_W && (j >= S->jsd && j <= S->jed)) {
+            if (S->specified) continue;
+            if (!S->tr_Reg) continue;
+            const double u = A->uhr[ORC_U3(G,I,j,k)];
+            if (((u > 0.0) && (G->mask2dT[ORC_H2(G,I,j)] < 0.5)) || ((u < 0.0) && (G->mask2dT[ORC_H2(G,I+1,j)] < 0.5))) {
+              W(uhh,I) = u;
+              for (int q = 0; q < S->ntseg; q++)
+                WM(flux_x,I,S->tr_Reg[q].ntr_index - 1) = W(uhh,I) * seg_tracer(S, &S->tr_Reg[q], I, j, k);
+            }
+          }
+        }
     }
 
     /* :632-649 */
@@ -269,6 +331,27 @@ static void advect_y(adv_t *A, int is, int ie, int js, int je, int k)
   for (int j = G->jsd; j <= G->jed; j++) for (int m = 0; m < ntr; m++)
     for (int i = G->isd; i <= G->ied; i++) S3(T_tmp,i,m,j) = A->tr[m][ORC_H3(G,i,j,k)];
 
+  /* :823-861: the registered tracers outside the segments, and the slopes of the three cells about their faces */
+  if (A->OBC && A->OBC->OBC_pe) for (int n = 0; n < A->OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &A->OBC->segment[n];
+    if (!S->tr_Reg) continue;
+    for (int i = is; i <= ie; i++) {
+      if (S->is_N_or_S && i >= S->isd && i <= S->ied) {
+        const int J = S->JsdB;
+        for (int q = 0; q < S->ntseg; q++) {
+          const int m = S->tr_Reg[q].ntr_index - 1;
+          const double val = seg_tracer(S, &S->tr_Reg[q], i, J, k);
+          if (S->direction == MOM6HIP_OBC_DIRECTION_S) S3(T_tmp,i,m,J) = val;
+          else S3(T_tmp,i,m,J+1) = val;
+        }
+        for (int m = 0; m < ntr; m++) for (int j = J-1; j <= J+1; j++) {
+          double Tp = S3(T_tmp,i,m,j+1), Tc = S3(T_tmp,i,m,j), Tm = S3(T_tmp,i,m,j-1);
+          S3(slope_y,i,m,j) = plm_slope(Tp, Tc, Tm, G->mask2dCv[ORC_V2(G,i,J)]*G->mask2dCv[ORC_V2(G,i,J-1)]);
+        }
+      }
+    }
+  }
+
   /* :868-1019 */
   for (int J = js-1; J <= je; J++) {
     const int j = J;
@@ -327,6 +410,39 @@ static void advect_y(adv_t *A, int is, int ie, int js, int je, int k)
             S3(flux_y,i,m,J) = V2W(vhh,i,J)*( Tc - 0.5 * S3(slope_y,i,m,j+1) * ( 1. - W(CFL,i) ) );
           }
         }
+      }
+      if (A->OBC && A->OBC->OBC_pe) {      /* :965-1014 */
+        const mom6hip_obc_t *OBC = A->OBC;
+        if (OBC->specified_v_BCs_exist_globally || OBC->open_v_BCs_exist_globally)
+          for (int n = 0; n < OBC->number_of_segments; n++) {
+            const mom6hip_obc_segment_t *S = &OBC->segment[n];
+            if (!S->specified) continue;
+            if (!S->tr_Reg) continue;
+            if (S->is_N_or_S && J >= S->JsdB && J <= S->JedB)
+              for (int i = S->isd; i <= S->ied; i++) {
+                const double v = A->vhr[ORC_V3(G,i,J,k)];
+                if (((v > 0.0) && (S->direction == MOM6HIP_OBC_DIRECTION_S)) || ((v < 0.0) && (S->direction == MOM6HIP_OBC_DIRECTION_N))) {
+                  V2W(vhh,i,J) = v;
+                  for (int q = 0; q < S->ntseg; q++)
+                    S3(flux_y,i,S->tr_Reg[q].ntr_index - 1,J) = V2W(vhh,i,J) * seg_tracer(S, &S->tr_Reg[q], i, J, k);
+                }
+              }
+          }
+        if (OBC->open_v_BCs_exist_globally)
+          for (int n = 0; n < OBC->number_of_segments; n++) {
+            const mom6hip_obc_segment_t *S = &OBC->segment[n];
+            if (S->specified) continue;
+            if (!S->tr_Reg) continue;
+            if (S->is_N_or_S && (J >= S->JsdB && J <= S->JedB))
+              for (int i = S->isd; i <= S->ied; i++) {
+                const double v = A->vhr[ORC_V3(G,i,J,k)];
+                if (((v > 0.0) && (G->mask2dT[ORC_H2(G,i,j)] < 0.5)) || ((v < 0.0) && (G->mask2dT[ORC_H2(G,i,j+1)] < 0.5))) {
+                  V2W(vhh,i,J) = v;
+                  for (int q = 0; q < S->ntseg; q++)
+                    S3(flux_y,i,S->tr_Reg[q].ntr_index - 1,J) = V2W(vhh,i,J) * seg_tracer(S, &S->tr_Reg[q], i, J, k);
+                }
+              }
+          }
       }
     } else {
       for (int i = is; i <= ie; i++) V2W(vhh,i,J) = 0.0;
@@ -388,6 +504,21 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
                       int x_first_in, double *vol_prev, int max_iter_in, int update_vol_prev,
                       double *uhr_out, double *vhr_out, mom6hip_advect_stats_t *stats)
 {
+  return orc_advect_tracer_obc(G, h_end, uhtr, vhtr, dt, cs, tr, conc_underflow, ntr, x_first_in, vol_prev, max_iter_in, update_vol_prev,
+                               uhr_out, vhr_out, stats, NULL);
+}
+
+/* advect_tracer with OBC associated: the tracer registries of the segments (reservoirs, inflow concentrations) */
+int orc_advect_tracer_obc(const mom6hip_grid_t *G, const double *h_end, const double *uhtr,
+                          const double *vhtr, double dt, const mom6hip_tracer_advect_cs_t *cs,
+                          double *const *tr, const double *conc_underflow, int ntr,
+                          int x_first_in, double *vol_prev, int max_iter_in, int update_vol_prev,
+                          double *uhr_out, double *vhr_out, mom6hip_advect_stats_t *stats, const mom6hip_obc_t *OBC)
+{
+  if (OBC) for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (S->tr_Reg) for (int q = 0; q < S->ntseg; q++) if (S->tr_Reg[q].ntr_index < 1 || S->tr_Reg[q].ntr_index > ntr) return 3;
+  }
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   const int isd = G->isd, ied = G->ied, jsd = G->jsd, jed = G->jed;
   const int IsdB = isd-1, IedB = ied, JsdB = jsd-1, JedB = jed;
@@ -410,7 +541,7 @@ int orc_advect_tracer(const mom6hip_grid_t *G, const double *h_end, const double
 
   adv_t A;
   A.G = G; A.ntr = ntr; A.usePPM = usePPM; A.useHuynh = useHuynh; A.tr = tr;
-  A.conc_underflow = conc_underflow;
+  A.conc_underflow = conc_underflow; A.OBC = OBC;
   A.hprev = calloc(nh3, sizeof(double));
   A.uhr = calloc(nu3, sizeof(double));
   A.vhr = calloc(nv3, sizeof(double));

@@ -1205,7 +1205,11 @@ public :: ocean_OBC_type, radiation_open_bdry_conds, open_boundary_zero_normal_f
 public :: open_boundary_test_extern_h, update_OBC_ramp
 public :: OBC_segment_type, OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W
 integer, parameter :: OBC_NONE = 0, OBC_DIRECTION_N = 100, OBC_DIRECTION_S = 200, OBC_DIRECTION_E = 300, OBC_DIRECTION_W = 400
+type :: segment_tracer_registry_type
+  integer :: ntseg = 0
+end type segment_tracer_registry_type
 type :: OBC_segment_type
+  type(segment_tracer_registry_type), pointer :: tr_Reg => NULL()
   logical :: Flather = .false., radiation = .false., oblique = .false., nudged = .false., specified = .false., open = .false.
   logical :: gradient = .false., on_pe = .false., is_N_or_S = .false., is_E_or_W = .false.
   integer :: direction = 0

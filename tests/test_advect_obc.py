@@ -1,0 +1,100 @@
+"""advect_tracer with an associated OBC whose segments carry tracer registries (src/tracer/MOM_tracer_advect.F90:441-477, :580-627 in
+advect_x, :823-861, :965-1014 in advect_y): a registered tracer takes its reservoir value (or its inflow concentration) in the cell outside a
+segment, the slopes of the three cells about the segment's face are formed again, and an inflow through the face carries the reservoir value
+with the whole remaining transport.  The oracle against what those lines state and against a quarter turn of the grid, on the CPU; the
+library against the oracle on the GPU, bit for bit.  (The reference holds no known-answer vectors for this routine: parity unpinned.)"""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi, synth
+from mom6_amd.open_boundary import ocean_OBC_type
+from oracle import orc
+from rotation import rot, rot_vector, rotate_grid, unrot
+from test_continuity_obc import open_faces, turned_segments
+
+SCHEMES = ["PLM", "PPM:H3", "PPM"]
+# the four sides (the cells outside lie in the halo, masked), two specified segments inside the domain
+SEGS = ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER,ORLANSKI", "I=9,J=0:N,SIMPLE",
+        "J=7,I=N:0,SIMPLE"]
+
+
+def adv_obc_case(segs, ni=22, nj=16, nk=3, ntr=3, seed=3, registry=True, land_frac=0.1):
+    g = synth.make_grid(ni, nj, nk, halo=4, land_frac=land_frac, seed=seed + 100, reentrant_x=False, reentrant_y=False)
+    OBC = ocean_OBC_type(g, segs)
+    open_faces(g, OBC)
+    st = synth.make_advection_state(g, ntr=ntr, seed=seed, hot_frac=0.004, vanish_frac=0.05, cfl=0.15)
+    case = {k: (v.numpy() if k != "tr" else [t.numpy() for t in v]) for k, v in st.items()}
+    rng = np.random.default_rng(seed)      # (the faces of the segments are open when the transports are made: they carry flow in and out)
+    if registry:
+        for n, s in enumerate(OBC.segment):
+            if not s.on_pe:
+                continue
+            # tracer 1 with a reservoir, tracer 3 with an inflow concentration; tracer 2 is not registered
+            s.tr_Reg = [dict(ntr_index=1, tres=5.0 + rng.random(s.normal_vel.shape)), dict(ntr_index=3, OBC_inflow_conc=0.25 + 0.1 * n)]
+    return g, case, OBC
+
+
+def run(g, case, OBC, scheme, x_first=None, **kw):
+    tr = [t.copy() for t in case["tr"]]
+    uhr = g.zeros3(_abi.POS_U); vhr = g.zeros3(_abi.POS_V)
+    st = orc.advect_tracer(g, case["h_end"], case["uhtr"], case["vhtr"], 3600.0, 900.0, scheme, tr, x_first=x_first, uhr_out=uhr, vhr_out=vhr,
+                           OBC=OBC, **kw)
+    return dict(tr=tr, uhr=uhr, vhr=vhr, stats=st)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_segments_without_a_registry_change_nothing(scheme):
+    g, case, OBC = adv_obc_case(SEGS, registry=False)
+    a, b = run(g, case, OBC, scheme), run(g, case, None, scheme)
+    assert all(bits_equal(x, y) for x, y in zip(a["tr"], b["tr"])) and bits_equal(a["uhr"], b["uhr"])
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_an_unregistered_tracer_and_the_far_field_are_untouched_and_inflow_brings_the_reservoir(scheme):
+    g, case, OBC = adv_obc_case(SEGS)
+    a, b = run(g, case, OBC, scheme), run(g, case, None, scheme)
+    near = np.zeros(g.shape2(_abi.POS_H), dtype=bool)
+    on_u, on_v = OBC.segnum_u != 0, OBC.segnum_v != 0
+    near |= on_u[:, 1:] | on_u[:, :-1] | on_v[1:, :] | on_v[:-1, :]
+    for _ in range(4 * 4):      # (a few passes of the advection, a stencil of at most 3 cells each)
+        near[1:, :] |= near[:-1, :].copy(); near[:-1, :] |= near[1:, :].copy(); near[:, 1:] |= near[:, :-1].copy(); near[:, :-1] |= near[:, 1:].copy()
+    assert not bits_equal(a["tr"][0], b["tr"][0]) and not bits_equal(a["tr"][2], b["tr"][2])
+    # a uniform tracer stays uniform in a closed advection; with a reservoir of another value the cells inside an inflow face change
+    g2, case2, OBC2 = adv_obc_case(SEGS)
+    case2["tr"][0][:] = 1.0
+    for s in OBC2.segment:
+        if s.on_pe:
+            s.tr_Reg = [dict(ntr_index=1, OBC_inflow_conc=3.0)]
+    c = run(g2, case2, OBC2, scheme)
+    t = interior(g2, c["tr"][0]); wet = interior(g2, np.asarray(g2.mask2dT)) > 0
+    # (no bound holds: an inflow takes the whole remaining transport of its face at once, past the limiter of the cell's volume :593)
+    assert np.all(np.isfinite(t)) and t[:, wet].max() > 1.0 + 1e-6
+
+
+# The reference is not symmetric under the quarter turn for every segment: the three cells whose slopes it forms again are I-1 .. I+1 and
+# J-1 .. J+1 whatever the side the segment opens to (:466, :850), with the masks of the faces I, I-1 and J, J-1, so an eastern segment and the
+# southern one it turns into refresh different cells; and a non-specified segment inside the domain takes its inflow value in advect_x only
+# (:586-599 against :969).  Northern and southern segments turn into eastern and western ones that do the same arithmetic: each of the four
+# branches (E, W in advect_x; N, S in advect_y) is on one side of such a pair.
+SEGS_TURN = ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "J=7,I=N:0,SIMPLE", "J=11,I=0:N,SIMPLE"]
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("x_first", [True, False])
+def test_oracle_turns_with_the_grid(scheme, x_first):
+    g, case, OBC = adv_obc_case(SEGS_TURN)
+    a = run(g, case, OBC, scheme, x_first=x_first)
+    gr = rotate_grid(g)
+    OBCr = ocean_OBC_type(gr, turned_segments(SEGS_TURN, g.ni, g.nj))
+    assert sorted(s.direction for s in OBCr.segment) == [_abi.OBC_DIRECTION_E] * 2 + [_abi.OBC_DIRECTION_W] * 2
+    for s, sr in zip(OBC.segment, OBCr.segment):
+        if s.on_pe:      # a scalar on the faces of a u segment (nk, j, 1) -> on those of the v' segment (nk, 1, i' = j); of a v segment -> (nk, j' = ni - 1 - i, 1)
+            tres = s.tr_Reg[0]["tres"]
+            tr_ = np.swapaxes(tres, 1, 2) if s.is_E_or_W else np.swapaxes(tres, 1, 2)[:, ::-1, :]
+            sr.tr_Reg = [dict(ntr_index=1, tres=np.ascontiguousarray(tr_)), dict(s.tr_Reg[1])]
+    ur, vr = rot_vector(case["uhtr"], case["vhtr"])
+    cr = dict(h_end=rot(case["h_end"]), uhtr=ur, vhtr=vr, tr=[rot(t) for t in case["tr"]])
+    b = run(gr, cr, OBCr, scheme, x_first=not x_first)      # x' = y: the turned grid does y first where this one does x first
+    for m in range(3):
+        assert bits_equal(interior(g, unrot(b["tr"][m])), interior(g, a["tr"][m])), m

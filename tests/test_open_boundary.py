@@ -180,3 +180,27 @@ def test_gpu_radiation_refuses_what_it_does_not_provide():
         with pytest.raises(Mom6HipError, match=msg):
             radiation_open_bdry_conds(OBC, o["u_new"], o["u_old"], o["v_new"], o["v_old"], dg, 900.0)
     dg.close()
+
+
+@pytest.mark.gpu
+def test_gpu_advect_tracer_with_segments_without_a_tracer_registry_is_the_closed_advection():
+    """advect_x / advect_y read of an associated OBC only the tracer registries of its segments (segment%tr_Reg,
+    MOM_tracer_advect.F90:442-477, :580-627): without one the answers are those of OBC => NULL(); with one the call is refused"""
+    from helpers import advect_case
+    from mom6_amd._lib import Mom6HipError
+    from mom6_amd.tracer_advect import DeviceGrid, advect_tracer, tracer_advect_init
+    from test_continuity_obc import TC3
+    g, case = advect_case(ni=24, nj=18, nk=3, ntr=2, reentrant_x=False, reentrant_y=False)
+    OBC = ocean_OBC_type(g, TC3)
+    dg = DeviceGrid(g)
+    CS = tracer_advect_init(900.0, "PLM")
+    out = []
+    for obc in (None, OBC):
+        tr = [t.copy() for t in case["tr"]]
+        advect_tracer(case["h_end"], case["uhtr"], case["vhtr"], obc, 3600.0, dg, CS, tr)
+        out.append(tr)
+    assert all(bits_equal(a, b) for a, b in zip(*out))
+    OBC.segment[0].tr_Reg = object()
+    with pytest.raises(Mom6HipError, match="tracer registry"):
+        advect_tracer(case["h_end"], case["uhtr"], case["vhtr"], OBC, 3600.0, dg, CS, [t.copy() for t in case["tr"]])
+    dg.close()
