@@ -75,6 +75,7 @@ typedef struct mom6hip_grid {
 
 /* Opaque handle: device copies of the metrics + scratch owned by the library. */
 typedef struct mom6hip_ctx mom6hip_ctx_t;
+struct mom6hip_obc;      /* the open boundaries: mom6hip_obc_t, below */
 
 /* ---- library / context ------------------------------------------------------------------- */
 
@@ -311,6 +312,14 @@ int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, const double 
                           int32_t x_first_in, double *vol_prev, int32_t max_iter_in,
                           int32_t update_vol_prev, double *uhr_out, double *vhr_out,
                           int32_t memspace, mom6hip_advect_stats_t *stats);
+/* advect_tracer with OBC associated.  advect_x / advect_y read of the OBC the tracer registries of its segments (segment%tr_Reg,
+ * MOM_tracer_advect.F90:441-477, :580-627, :823-861, :965-1014: the reservoir or inflow value of a registered tracer in the cell outside a
+ * segment, the slopes about the segment's face, the inflow fluxes).  Without a registry on any segment the call is mom6hip_advect_tracer;
+ * with one it takes the library's general kernels (a thread a face, a thread a cell).  obc == NULL: mom6hip_advect_tracer. */
+int mom6hip_advect_tracer_obc(mom6hip_ctx_t *ctx, const double *h_end, const double *uhtr, const double *vhtr, double dt,
+                              const mom6hip_tracer_advect_cs_t *cs, double *const *tr, const double *conc_underflow, int32_t ntr,
+                              int32_t x_first_in, double *vol_prev, int32_t max_iter_in, int32_t update_vol_prev, double *uhr_out,
+                              double *vhr_out, const struct mom6hip_obc *obc, int32_t memspace, mom6hip_advect_stats_t *stats);
 
 /* Per-kernel device time of the last advect_tracer call, from HIP events on the context's stream:
  * ms_x / ms_y are the summed durations of the advect_x / advect_y kernels, n_x / n_y their launch
@@ -457,7 +466,6 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
                       const double *h, const double *uh, const double *vh, double *CAu, double *CAv,
                       int32_t memspace);
 
-struct mom6hip_obc;
 /* radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, GV, US, dt)            src/core/MOM_open_boundary.F90:2196
  * The normal component: Orlanski radiation (segment%radiation: the phase speed from the two faces inside the boundary, capped by
  * OBC%rx_max = OBC_RADIATION_MAX, averaged in time with OBC%gamma_uv = OBC_RAD_VEL_WT into the restart fields OBC%rx_normal /

@@ -118,6 +118,9 @@ struct mom6hip_ctx {
                                    // first call, MOM_dynamics_split_RK2.F90:634: hp is rewritten by :757 before anything reads it): the second
                                    // direction's convergence is not launched
   m6::DevBuf sv_rlay;           // device copy of GV%Rlay for set_viscous_BBL (set_viscosity.hip)
+  m6::DevBuf adv_gen;           // the general path of advect_tracer: the transports and fluxes of a pass, the segments' tables (tracer_advect.hip)
+  m6::DevBuf adv_obc[64];       // device copies of the segments' tracer reservoirs handed over as host arrays
+  int adv_obc_n = 0;
   m6::HostTable tables[m6::TABLE_COUNT];      // cached device copies of short host tables (m6::HostTable)
   uint64_t xfer[4] = {0, 0, 0, 0};            // calls and bytes of mom6hip_sync_to_device, then of mom6hip_sync_to_host / stage_to_host
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel

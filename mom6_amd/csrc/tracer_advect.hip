@@ -689,6 +689,181 @@ void launch_y(int scheme, bool first, dim3 grid, int nseg, int seglen, hipStream
   else launch_y2<NT, false>(scheme, grid, nseg, seglen, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The general form of advect_x / advect_y: two plain kernels a pass, a thread a face (the transport taken through the face and the fluxes
+// of every tracer, :485-627 / :868-1014, into scratch) and a thread a cell (:632-687 / :1021-1066).  It is the path of an OBC whose
+// segments carry tracer registries (segment%tr_Reg: a registered tracer takes its reservoir value or inflow concentration in the cell outside
+// the segment :441-462 / :823-846, the slopes of the three cells about the segment's face are formed again with the masks of the faces I, I-1
+// | J, J-1 :463-473 / :847-856, an inflow carries the reservoir value with the whole remaining transport :580-627 / :965-1014); regional
+// configurations are small, and the marching kernels above stay as they are.  MOM6HIP_ADV_GENERIC=1 takes this path without OBC (tests).
+constexpr int GEN_MAXTR = 64;
+struct GenTr { double *t[GEN_MAXTR]; double cu[GEN_MAXTR]; int ntr; };
+struct GenSeg {      // a segment of the direction of the pass that has a tracer registry
+  int plus;          // OBC_DIRECTION_E | N: the cell outside is the second cell of its faces
+  int specified, A, c0, c1;      // the face index (IsdB | JsdB) and the range across it (jsd:jed | isd:ied)
+  int a0, na, b0, nb;            // its own arrays: element (a, b, k) at (a - a0) + na * ((b - b0) + nb * k)
+  int r0, ntseg;                 // its registry: regs[r0 .. r0 + ntseg)
+};
+struct GenReg { int m; const double *tres; double conc; };
+struct GenArgs {
+  m6::GridDev g;
+  GenTr T;
+  double *hprev, *xr;            // xr: uhr | vhr
+  double *hh, *flux;             // scratch: the transport taken through every face in this pass; the fluxes, + fstride a tracer
+  long fstride;
+  int *dom_in, *dom_new;         // the rows' flags on entry; where a limited face flags its row for another pass
+  const int *domore_k;
+  const double *neglect;         // uh_neglect | vh_neglect
+  int is, ie, js, je;
+  int nseg; const GenSeg *segs; const GenReg *regs;
+  int obc_any, obc_open;         // OBC%specified_?_BCs_exist_globally .or. OBC%open_?_BCs_exist_globally ; OBC%open_?_BCs_exist_globally
+};
+
+template <int DIR> __device__ __forceinline__ long gen_h2(const m6::GridDev &g, int n, int c) { return DIR ? g.h2(c, n) : g.h2(n, c); }
+template <int DIR> __device__ __forceinline__ long gen_f2(const m6::GridDev &g, int n, int c) { return DIR ? g.v2(c, n) : g.u2(n, c); }
+
+__device__ __forceinline__ double gen_seg_value(const GenSeg &s, const GenReg &r, int a, int b, int k) {
+  if (!r.tres) return r.conc;
+  return r.tres[(a - s.a0) + (long)s.na * ((b - s.b0) + (long)s.nb * k)];
+}
+
+template <int DIR, int SCHEME>
+__global__ __launch_bounds__(256) void gen_flux_kernel(GenArgs p) {
+  const m6::GridDev &g = p.g;
+  const int tx = blockIdx.x * 256 + threadIdx.x, k = blockIdx.z;
+  const int n = (DIR ? p.js - 1 + (int)blockIdx.y : p.is - 1 + tx);      // the face index along the direction
+  const int c = (DIR ? p.is + tx : p.js + (int)blockIdx.y);             // the index across it
+  if (DIR ? (c > p.ie) : (n > p.ie)) return;
+  if (p.domore_k[k] <= 0) return;
+  const long hpl = (long)g.nih * g.njh, fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long f2 = gen_f2<DIR>(g, n, c), f3 = f2 + fpl * k;
+  const long fstep = DIR ? g.nih : 1;      // to the next face along the direction
+  const int row = DIR ? (n - g.jsd + 1) + (g.njh + 1) * k : (c - g.jsd) + g.njh * k;
+  const bool active = p.dom_in[row] != 0;
+  if (!active) {
+    if (DIR) { p.hh[f3] = 0.0; for (int m = 0; m < p.T.ntr; m++) p.flux[p.fstride * m + f3] = 0.0; }
+    return;
+  }
+  const double min_h = 0.1 * g.Angstrom_H;
+  const int nlo = DIR ? g.jsd : g.isd, nhi = DIR ? g.jed : g.ied;      // cells of the data domain along the direction
+  const double *mask = DIR ? g.mask2dCv : g.mask2dCu;
+  auto fmask = [&](int nn) { return mask[gen_f2<DIR>(g, nn, c)]; };
+  // T_tmp of tracer m at the cell nn of this line
+  auto Tt = [&](int m, int nn) -> double {
+    double v = (nn >= nlo && nn <= nhi) ? p.T.t[m][gen_h2<DIR>(g, nn, c) + hpl * k] : 0.0;
+    for (int q = 0; q < p.nseg; q++) {
+      const GenSeg &s = p.segs[q];
+      if (c < s.c0 || c > s.c1 || nn != (s.plus ? s.A + 1 : s.A)) continue;
+      for (int r = s.r0; r < s.r0 + s.ntseg; r++)
+        if (p.regs[r].m == m) v = DIR ? gen_seg_value(s, p.regs[r], c, s.A, k) : gen_seg_value(s, p.regs[r], s.A, c, k);
+    }
+    return v;
+  };
+  auto Traw = [&](int m, int nn) -> double { return (nn >= nlo && nn <= nhi) ? p.T.t[m][gen_h2<DIR>(g, nn, c) + hpl * k] : 0.0; };
+  // the slopes are those of the tracer itself (:425-436), but for the three cells about a segment's face, formed again from T_tmp (:466-474)
+  auto slope = [&](int m, int nn) -> double {
+    for (int q = 0; q < p.nseg; q++) {
+      const GenSeg &s = p.segs[q];
+      if (c >= s.c0 && c <= s.c1 && nn >= s.A - 1 && nn <= s.A + 1)
+        return plm_slope(Tt(m, nn + 1), Tt(m, nn), Tt(m, nn - 1), fmask(s.A) * fmask(s.A - 1));
+    }
+    return plm_slope(Traw(m, nn + 1), Traw(m, nn), Traw(m, nn - 1), fmask(nn) * fmask(nn - 1));
+  };
+  const long hm = gen_h2<DIR>(g, n, c), hp = gen_h2<DIR>(g, n + 1, c);
+  double hh, CFL;
+  bool lim;
+  face_transport(p.xr[f3], p.xr[f3 - fstep], p.xr[f3 + fstep], p.hprev[hm + hpl * k], p.hprev[hp + hpl * k], g.areaT[hm], g.areaT[hp], min_h,
+                 hh, CFL, lim);
+  if (lim) atomicOr(&p.dom_new[row], 1);
+  const int up = (hh >= 0.0) ? 0 : 1, cu = n + up;
+  for (int m = 0; m < p.T.ntr; m++) {
+    double fl;
+    if (SCHEME == PLM) {
+      const double Tc = Tt(m, cu), sl = slope(m, cu);
+      if (hh >= 0.0) fl = hh * (Tc + 0.5 * sl * (1. - CFL));
+      else           fl = hh * (Tc - 0.5 * sl * (1. - CFL));
+    } else {
+      const double Tp = Tt(m, cu + 1), Tc = Tt(m, cu), Tm = Tt(m, cu - 1);
+      double sm = 0., sc = 0., sp = 0.;
+      if (SCHEME == CW) { sm = slope(m, cu - 1); sc = slope(m, cu); sp = slope(m, cu + 1); }
+      fl = ppm_flux<SCHEME>(Tp, Tc, Tm, sm, sc, sp, fmask(cu) * fmask(cu - 1), hh, CFL);
+    }
+    p.flux[p.fstride * m + f3] = fl;
+  }
+  // the inflows through the faces of the segments (two loops over the segments, as the reference)
+  if (p.nseg > 0 && p.obc_any) {
+    const double r = p.xr[f3];
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1 && !p.obc_open) break;
+      for (int q = 0; q < p.nseg; q++) {
+        const GenSeg &s = p.segs[q];
+        if (n != s.A || c < s.c0 || c > s.c1) continue;
+        bool inflow;
+        if (pass == 0) {
+          if (DIR && !s.specified) continue;      // (advect_y :969; advect_x takes every segment :583)
+          inflow = ((r > 0.0) && !s.plus) || ((r < 0.0) && s.plus);
+        } else {
+          if (s.specified) continue;
+          inflow = ((r > 0.0) && (g.mask2dT[hm] < 0.5)) || ((r < 0.0) && (g.mask2dT[hp] < 0.5));
+        }
+        if (!inflow) continue;
+        hh = r;
+        for (int t = s.r0; t < s.r0 + s.ntseg; t++)
+          p.flux[p.fstride * p.regs[t].m + f3] = hh * (DIR ? gen_seg_value(s, p.regs[t], c, s.A, k) : gen_seg_value(s, p.regs[t], s.A, c, k));
+      }
+    }
+  }
+  p.hh[f3] = hh;
+}
+
+template <int DIR>
+__global__ __launch_bounds__(256) void gen_update_kernel(GenArgs p) {
+  const m6::GridDev &g = p.g;
+  const int tx = blockIdx.x * 256 + threadIdx.x, k = blockIdx.z;
+  const int n = (DIR ? p.js - 1 + (int)blockIdx.y : p.is - 1 + tx);
+  const int c = (DIR ? p.is + tx : p.js + (int)blockIdx.y);
+  if (DIR ? (c > p.ie) : (n > p.ie)) return;
+  if (p.domore_k[k] <= 0) return;
+  const long hpl = (long)g.nih * g.njh, fpl = DIR ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  const long f2 = gen_f2<DIR>(g, n, c), f3 = f2 + fpl * k;
+  const long fstep = DIR ? g.nih : 1;
+  const bool active = DIR ? true : (p.dom_in[(c - g.jsd) + g.njh * k] != 0);
+  const bool cell = n >= (DIR ? p.js : p.is);
+  const long h2 = gen_h2<DIR>(g, n, c), h3 = h2 + hpl * k;
+  if (active) {
+    const double hh = p.hh[f3];
+    double r = p.xr[f3] - hh;      // :632-635 / :1021-1024
+    if (fabs(r) < p.neglect[f2]) r = 0.0;
+    p.xr[f3] = r;
+    if (cell) {
+      const double hh_m = p.hh[f3 - fstep], h_old = p.hprev[h3];
+      double h_new, hlst, Ihnew;
+      const bool do_i = DIR ? cell_volume<true>(hh, hh_m, h_old, g.areaT[h2], g.H_subroundoff, h_new, hlst, Ihnew)
+                            : cell_volume<false>(hh, hh_m, h_old, g.areaT[h2], g.H_subroundoff, h_new, hlst, Ihnew);
+      if (changed(h_new, h_old)) p.hprev[h3] = h_new;
+      if (do_i && Ihnew > 0.0)
+        for (int m = 0; m < p.T.ntr; m++) {
+          const double t_old = p.T.t[m][h3];
+          p.T.t[m][h3] = (t_old * hlst - (p.flux[p.fstride * m + f3] - p.flux[p.fstride * m + f3 - fstep])) * Ihnew;
+        }
+    }
+  }
+  if (cell)      // :683-687 / :1062-1066
+    for (int m = 0; m < p.T.ntr; m++) if (p.T.cu[m] > 0.0) {
+      const double t = p.T.t[m][h3];
+      if (fabs(t) < p.T.cu[m] && changed(t, 0.0)) p.T.t[m][h3] = 0.0;
+    }
+}
+
+// advect_x: the flags of the rows that were processed take what the pass found (:413, :497, :507)
+__global__ void gen_xflags_kernel(m6::GridDev g, int *dom, const int *dom_new, const int *domore_k, int js, int je) {
+  const int n = g.njh * g.nk;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int k = t / g.njh, j = g.jsd + (t - k * g.njh);
+    if (domore_k[k] > 0 && j >= js && j <= je && dom[t]) dom[t] = dom_new[t];
+  }
+}
+
 struct Timer {
   hipEvent_t a = nullptr, b = nullptr;
   bool on = false;
@@ -721,6 +896,18 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
                                      int32_t x_first_in, double *vol_prev, int32_t max_iter_in,
                                      int32_t update_vol_prev, double *uhr_out, double *vhr_out,
                                      int32_t memspace, mom6hip_advect_stats_t *stats) {
+  return mom6hip_advect_tracer_obc(ctx, h_end, uhtr, vhtr, dt, cs, tr, conc_underflow, ntr, x_first_in, vol_prev, max_iter_in, update_vol_prev,
+                                   uhr_out, vhr_out, nullptr, memspace, stats);
+}
+
+// advect_tracer with OBC associated: of the OBC, advect_x / advect_y read the tracer registries of the segments (segment%tr_Reg); without
+// any the marching kernels run as for a closed domain, with one the general kernels (gen_flux_kernel, gen_update_kernel)
+extern "C" int mom6hip_advect_tracer_obc(mom6hip_ctx_t *ctx, const double *h_end, const double *uhtr,
+                                         const double *vhtr, double dt, const mom6hip_tracer_advect_cs_t *cs,
+                                         double *const *tr, const double *conc_underflow, int32_t ntr,
+                                         int32_t x_first_in, double *vol_prev, int32_t max_iter_in,
+                                         int32_t update_vol_prev, double *uhr_out, double *vhr_out, const mom6hip_obc_t *obc,
+                                         int32_t memspace, mom6hip_advect_stats_t *stats) {
   M6_REQUIRE(ctx != nullptr, "advect_tracer: null context (tracer_advect_init must be called before advect_tracer)");
   if (stats) memset(stats, 0, sizeof(*stats));
   M6_REQUIRE(ntr >= 0, "advect_tracer: ntr < 0");
@@ -789,6 +976,78 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
   for (int k = 0; k < nz; k++) ctx->h_domore_k[k] = 1;
   M6_HIP(hipMemcpyAsync(domore_k, ctx->h_domore_k, nz * sizeof(int), hipMemcpyHostToDevice, s));
 
+  // ---- the general path: the tracer registries of the segments (OBC%OBC_pe), or on request ----
+  bool generic = getenv("MOM6HIP_ADV_GENERIC") && atoi(getenv("MOM6HIP_ADV_GENERIC")) != 0;
+  std::vector<GenSeg> gsegs[2];
+  std::vector<GenReg> gregs;
+  if (obc && obc->OBC_pe) {
+    M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "advect_tracer: OBC%%segment is required");
+    for (int n = 0; n < obc->number_of_segments; n++) {
+      const mom6hip_obc_segment_t &S = obc->segment[n];
+      if (!S.tr_Reg) continue;
+      if (!(S.is_E_or_W || S.is_N_or_S)) continue;      // (not on this PE: read by neither advect_x nor advect_y)
+      generic = true;
+      const int d = S.is_N_or_S ? 1 : 0;
+      GenSeg q;
+      q.plus = (S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_N) ? 1 : 0;
+      q.specified = S.specified; q.A = d ? S.JsdB : S.IsdB; q.c0 = d ? S.isd : S.jsd; q.c1 = d ? S.ied : S.jed;
+      q.a0 = d ? S.isd : S.IsdB; q.na = d ? (S.ied - S.isd + 1) : (S.IedB - S.IsdB + 1);
+      q.b0 = d ? S.JsdB : S.jsd; q.nb = d ? (S.JedB - S.JsdB + 1) : (S.jed - S.jsd + 1);
+      M6_REQUIRE(q.A >= (d ? g.jsd : g.isd) + 2 && q.A <= (d ? g.jed : g.ied) - 3 && q.c0 >= (d ? g.isd : g.jsd) && q.c1 <= (d ? g.ied : g.jed),
+                 "advect_tracer: OBC segment %d lies outside the data domain", n + 1);
+      q.r0 = (int)gregs.size(); q.ntseg = S.ntseg;
+      for (int t = 0; t < S.ntseg; t++) {
+        const mom6hip_obc_segment_tracer_t &R = S.tr_Reg[t];
+        M6_REQUIRE(R.ntr_index >= 1 && R.ntr_index <= ntr, "advect_tracer: the registry of OBC segment %d names tracer %d of %d", n + 1, R.ntr_index, ntr);
+        GenReg r; r.m = R.ntr_index - 1; r.conc = R.OBC_inflow_conc; r.tres = nullptr;
+        if (R.tres) {
+          const size_t bytes = (size_t)q.na * q.nb * nz * 8;
+          if (memspace == MOM6HIP_MEM_HOST) {
+            M6_REQUIRE(ctx->adv_obc_n < 64 && ctx->adv_obc[ctx->adv_obc_n].reserve(bytes) == 0, "advect_tracer: out of device memory for the tracer reservoirs");
+            M6_HIP(hipMemcpyAsync(ctx->adv_obc[ctx->adv_obc_n].p, R.tres, bytes, hipMemcpyHostToDevice, s));
+            r.tres = (const double *)ctx->adv_obc[ctx->adv_obc_n++].p;
+          } else r.tres = R.tres;
+        }
+        gregs.push_back(r);
+      }
+      // the slopes about a segment are formed again with the tracer values of that moment: two segments with registries within three
+      // cells of each other on a line would make the order of the reference's loop over the segments matter
+      for (const GenSeg &o : gsegs[d])
+        M6_REQUIRE(o.c1 < q.c0 || o.c0 > q.c1 || abs(o.A - q.A) > 3, "advect_tracer: OBC segments with tracer registries closer than four cells are not provided");
+      gsegs[d].push_back(q);
+    }
+  }
+  ctx->adv_obc_n = 0;
+  M6_REQUIRE(!generic || ntr <= GEN_MAXTR, "advect_tracer: at most %d tracers on the general path", GEN_MAXTR);
+  GenSeg *d_gsegs[2] = {nullptr, nullptr};
+  GenReg *d_gregs = nullptr;
+  double *gen_scratch = nullptr;
+  int *gen_flags = nullptr;
+  const size_t fmax_el = (size_t)(g.nu3() > g.nv3() ? g.nu3() : g.nv3());
+  if (generic) {
+    const size_t bs0 = sizeof(GenSeg) * (gsegs[0].size() + 1), bs1 = sizeof(GenSeg) * (gsegs[1].size() + 1), br = sizeof(GenReg) * (gregs.size() + 1);
+    if (ctx->adv_gen.reserve(bs0 + bs1 + br + 64 + nfu * sizeof(int) + fmax_el * 8 * ((size_t)ntr + 1))) return 1;
+    char *q = (char *)ctx->adv_gen.p;
+    gen_scratch = (double *)q; q += fmax_el * 8 * ((size_t)ntr + 1);
+    d_gsegs[0] = (GenSeg *)q; q += bs0; d_gsegs[1] = (GenSeg *)q; q += bs1; d_gregs = (GenReg *)q; q += br;
+    q = (char *)(((uintptr_t)q + 15) & ~(uintptr_t)15);
+    gen_flags = (int *)q;
+    if (!gsegs[0].empty()) M6_HIP(hipMemcpyAsync(d_gsegs[0], gsegs[0].data(), sizeof(GenSeg) * gsegs[0].size(), hipMemcpyHostToDevice, s));
+    if (!gsegs[1].empty()) M6_HIP(hipMemcpyAsync(d_gsegs[1], gsegs[1].data(), sizeof(GenSeg) * gsegs[1].size(), hipMemcpyHostToDevice, s));
+    if (!gregs.empty()) M6_HIP(hipMemcpyAsync(d_gregs, gregs.data(), sizeof(GenReg) * gregs.size(), hipMemcpyHostToDevice, s));
+    M6_HIP(hipStreamSynchronize(s));      // (the host vectors are read by the copies)
+  }
+  auto gen_args = [&](int d, GenArgs &a) {
+    a.g = g; a.T.ntr = ntr;
+    for (int m = 0; m < ntr; m++) { a.T.t[m] = d_tr[m]; a.T.cu[m] = conc_underflow ? conc_underflow[m] : 0.0; }
+    a.hprev = hprev; a.xr = d ? vhr : uhr; a.hh = gen_scratch; a.flux = gen_scratch + fmax_el; a.fstride = (long)fmax_el;
+    a.domore_k = domore_k; a.neglect = d ? g.vh_neglect : g.uh_neglect;
+    a.nseg = (int)gsegs[d].size(); a.segs = d_gsegs[d]; a.regs = d_gregs;
+    a.obc_any = obc ? (d ? (obc->specified_v_BCs_exist_globally || obc->open_v_BCs_exist_globally)
+                         : (obc->specified_u_BCs_exist_globally || obc->open_u_BCs_exist_globally)) : 0;
+    a.obc_open = obc ? (d ? obc->open_v_BCs_exist_globally : obc->open_u_BCs_exist_globally) : 0;
+  };
+
   // ---- :152-178 ----
   t_k.start();
   {
@@ -817,6 +1076,21 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
   };
   auto run_x = [&](int xis, int xie, int xjs, int xje) -> int {
     t_k.start();
+    if (generic) {
+      GenArgs a; gen_args(0, a);
+      a.is = xis; a.ie = xie; a.js = xjs; a.je = xje; a.dom_in = domore_u; a.dom_new = gen_flags;
+      M6_HIP(hipMemsetAsync(gen_flags, 0, nfu * sizeof(int), s));
+      const dim3 grid((xie - xis + 2 + 255) / 256, xje - xjs + 1, nz);
+      if (cs->scheme == PLM) hipLaunchKernelGGL((gen_flux_kernel<0, PLM>), grid, dim3(256), 0, s, a);
+      else if (cs->scheme == H3) hipLaunchKernelGGL((gen_flux_kernel<0, H3>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gen_flux_kernel<0, CW>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gen_update_kernel<0>, grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gen_xflags_kernel, dim3(64), dim3(256), 0, s, g, domore_u, (const int *)gen_flags, (const int *)domore_k, xjs, xje);
+      M6_HIP(hipGetLastError());
+      tm.n_x++;
+      { const double ms = t_k.stop(); tm.ms_x += ms; if (itt == 1) tm.ms_x1 += ms; }
+      return 0;
+    }
     for (int grp = 0; grp < ngroups; grp++) {
       AdvArgs a; const int n = group_args(grp, a);
       a.is = xis; a.ie = xie; a.js = xjs; a.je = xje;
@@ -838,6 +1112,20 @@ extern "C" int mom6hip_advect_tracer(mom6hip_ctx_t *ctx, const double *h_end, co
     t_k.start();
     hipLaunchKernelGGL(adv_vflags_prep_kernel, dim3(64), dim3(256), 0, s, g, (const int *)domore_v, domore_v2,
                        (const int *)domore_k, yjs, yje);
+    if (generic) {
+      GenArgs a; gen_args(1, a);
+      a.is = yis; a.ie = yie; a.js = yjs; a.je = yje; a.dom_in = domore_v; a.dom_new = domore_v2;
+      const dim3 grid((yie - yis + 1 + 255) / 256, yje - yjs + 2, nz);
+      if (cs->scheme == PLM) hipLaunchKernelGGL((gen_flux_kernel<1, PLM>), grid, dim3(256), 0, s, a);
+      else if (cs->scheme == H3) hipLaunchKernelGGL((gen_flux_kernel<1, H3>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gen_flux_kernel<1, CW>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL(gen_update_kernel<1>, grid, dim3(256), 0, s, a);
+      M6_HIP(hipGetLastError());
+      tm.n_y++;
+      { int *t = domore_v; domore_v = domore_v2; domore_v2 = t; }
+      { const double ms = t_k.stop(); tm.ms_y += ms; if (itt == 1) tm.ms_y1 += ms; }
+      return 0;
+    }
     for (int grp = 0; grp < ngroups; grp++) {
       AdvArgs a; const int n = group_args(grp, a);
       a.is = yis; a.ie = yie; a.js = yjs; a.je = yje;

@@ -12,7 +12,7 @@ module MOM_tracer_advect
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,    only : mom6hip_context_create, mom6hip_read_topology
-use mom6hip_MOM_glue,     only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror
+use mom6hip_MOM_glue,     only : mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_obc_to_c
 use MOM_cpu_clock,       only : cpu_clock_id, cpu_clock_begin, cpu_clock_end, CLOCK_MODULE
 use MOM_diag_mediator,   only : diag_ctrl, time_type
 use MOM_error_handler,   only : MOM_error, FATAL, WARNING
@@ -73,6 +73,11 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
   type(c_ptr) :: p_vol, p_uhr, p_vhr
   integer(c_int32_t) :: xf, mi, uv
   integer :: m, rc
+  type(mom6hip_obc_t), target :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
+  type(mom6hip_obc_segment_tracer_t), allocatable, target :: ctrs(:)
+  type(c_ptr) :: p_obc
+  logical :: registries
 
   if (.not. associated(CS)) call MOM_error(FATAL, "MOM_tracer_advect: "// &
        "tracer_advect_init must be called before advect_tracer.")
@@ -81,11 +86,17 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
   if (Reg%ntr==0) return
   ! advect_x / advect_y read of an associated OBC only the tracer registries of its segments (segment%tr_Reg: the reservoirs and inflow
   ! concentrations, :442-477, :580-627 and their twins): without one on any segment the advection is that of a closed domain
+  p_obc = c_null_ptr ; registries = .false.
   if (associated(OBC)) then ; if (OBC%OBC_pe) then
     do m=1,OBC%number_of_segments
-      if (associated(OBC%segment(m)%tr_Reg)) call MOM_error(FATAL, "MOM_tracer_advect (HIP): open boundary segments with a "// &
-           "tracer registry (reservoirs or inflow concentrations) are not provided by the GPU tracer advection.")
+      if (associated(OBC%segment(m)%tr_Reg)) registries = .true.
     enddo
+    if (registries) then
+      if (mom6hip_resident()) call MOM_error(FATAL, "MOM_tracer_advect (HIP): open boundary segments with a tracer registry are not "// &
+           "provided with GPU_RESIDENT_DYNAMICS (their reservoirs live on the host).")
+      call mom6hip_obc_to_c(OBC, cobc, csegs, size(uhtr(:,:,1)), size(vhtr(:,:,1)), "MOM_tracer_advect", ctrs)
+      p_obc = c_loc(cobc)
+    endif
   endif ; endif
   call cpu_clock_begin(id_clock_advect)
 
@@ -125,9 +136,9 @@ subroutine advect_tracer(h_end, uhtr, vhtr, OBC, dt, G, GV, US, CS, Reg, x_first
                                mom6hip_mirror(CS%ctx, c_loc(vhtr), int(size(vhtr), c_int64_t), .true., .false.), dt, ccs, tr, c_loc(cu), &
                                int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, MOM6HIP_MEM_DEVICE, stats)
   else
-    rc = mom6hip_advect_tracer(CS%ctx, c_loc(h_end), c_loc(uhtr), c_loc(vhtr), dt, ccs, tr, c_loc(cu), &
-                               int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, &
-                               MOM6HIP_MEM_HOST, stats)
+    rc = mom6hip_advect_tracer_obc(CS%ctx, c_loc(h_end), c_loc(uhtr), c_loc(vhtr), dt, ccs, tr, c_loc(cu), &
+                                   int(Reg%ntr, c_int32_t), xf, p_vol, mi, uv, p_uhr, p_vhr, p_obc, &
+                                   MOM6HIP_MEM_HOST, stats)
   endif
   if (rc /= 0) call MOM_error(FATAL, "MOM_tracer_advect (HIP): "//mom6hip_error_string())
 

@@ -439,18 +439,36 @@ end function min_cb
 
 !> What the library reads of ocean_OBC_type and its segments (MOM_open_boundary.F90:146-386) as a mom6hip_obc_t of host pointers:
 !! the caller keeps csegs (and OBC) alive for the call.  Provided entry points: continuity_PPM and CorAdCalc (round 4).
-subroutine mom6hip_obc_to_c(OBC, cobc, csegs, n_u2, n_v2, who)
+subroutine mom6hip_obc_to_c(OBC, cobc, csegs, n_u2, n_v2, who, ctrs)
   type(ocean_OBC_type), target, intent(in)  :: OBC
   type(mom6hip_obc_t),          intent(out) :: cobc
   type(mom6hip_obc_segment_t), allocatable, target, intent(inout) :: csegs(:)
   integer,                      intent(in)  :: n_u2, n_v2   !< the sizes of a 2-D array at the u and v points of the data domain
   character(len=*),             intent(in)  :: who
-  integer :: n
+  type(mom6hip_obc_segment_tracer_t), allocatable, target, optional, intent(inout) :: ctrs(:) !< with it, the tracer registries of the
+                                                            !! segments (segment%tr_Reg) are handed over as well (advect_tracer)
+  integer :: n, m, nt
   if (allocated(csegs)) deallocate(csegs)
   allocate(csegs(max(OBC%number_of_segments, 1)))
   do n=1,OBC%number_of_segments
     call segment_to_c(OBC%segment(n), csegs(n))
   enddo
+  if (present(ctrs)) then
+    if (allocated(ctrs)) deallocate(ctrs)
+    nt = 0
+    do n=1,OBC%number_of_segments ; if (associated(OBC%segment(n)%tr_Reg)) nt = nt + OBC%segment(n)%tr_Reg%ntseg ; enddo
+    allocate(ctrs(nt+1))
+    nt = 0
+    do n=1,OBC%number_of_segments ; if (associated(OBC%segment(n)%tr_Reg)) then
+      csegs(n)%tr_Reg = c_loc(ctrs(nt+1)) ; csegs(n)%ntseg = OBC%segment(n)%tr_Reg%ntseg
+      do m=1,OBC%segment(n)%tr_Reg%ntseg
+        nt = nt + 1
+        ctrs(nt)%ntr_index = OBC%segment(n)%tr_Reg%Tr(m)%ntr_index
+        ctrs(nt)%OBC_inflow_conc = OBC%segment(n)%tr_Reg%Tr(m)%OBC_inflow_conc
+        if (allocated(OBC%segment(n)%tr_Reg%Tr(m)%tres)) ctrs(nt)%tres = c_loc(OBC%segment(n)%tr_Reg%Tr(m)%tres)
+      enddo
+    endif ; enddo
+  endif
   cobc%number_of_segments = OBC%number_of_segments ; cobc%OBC_pe = merge(1, 0, OBC%OBC_pe)
   cobc%open_u_BCs_exist_globally = merge(1, 0, OBC%open_u_BCs_exist_globally)
   cobc%open_v_BCs_exist_globally = merge(1, 0, OBC%open_v_BCs_exist_globally)

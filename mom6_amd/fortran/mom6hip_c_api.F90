@@ -345,6 +345,26 @@ interface
     integer(c_int) :: rc
   end function mom6hip_advect_tracer
 
+  function mom6hip_advect_tracer_obc(ctx, h_end, uhtr, vhtr, dt, cs, tr, conc_underflow, ntr, x_first_in, &
+                                     vol_prev, max_iter_in, update_vol_prev, uhr_out, vhr_out, obc, memspace, stats) &
+                                     bind(c, name="mom6hip_advect_tracer_obc") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_tracer_advect_cs_t, mom6hip_advect_stats_t
+    type(c_ptr), value :: ctx
+    type(c_ptr), value :: h_end, uhtr, vhtr
+    real(c_double), value :: dt
+    type(mom6hip_tracer_advect_cs_t), intent(in) :: cs
+    type(c_ptr), intent(in) :: tr(*)          !< c_loc of each Reg%Tr(m)%t
+    type(c_ptr), value :: conc_underflow      !< c_loc of a real(c_double) array, or c_null_ptr
+    integer(c_int32_t), value :: ntr, x_first_in
+    type(c_ptr), value :: vol_prev
+    integer(c_int32_t), value :: max_iter_in, update_vol_prev
+    type(c_ptr), value :: uhr_out, vhr_out
+    type(c_ptr), value :: obc                 !< c_loc of a mom6hip_obc_t (with the tracer registries of its segments), or c_null_ptr
+    integer(c_int32_t), value :: memspace
+    type(mom6hip_advect_stats_t), intent(out) :: stats
+    integer(c_int) :: rc
+  end function mom6hip_advect_tracer_obc
+
   function mom6hip_malloc(dptr, bytes) bind(c, name="mom6hip_malloc") result(rc)
     import :: c_int, c_ptr, c_int64_t
     type(c_ptr), intent(out) :: dptr

@@ -255,9 +255,11 @@ class ocean_OBC_type:
         seg.Is_obc, seg.Ie_obc = Is_obc, Ie_obc; seg.Js_obc = seg.Je_obc = J_obc
         self._alloc(seg)
 
-    def struct(self, to_ptr=None):
+    def struct(self, to_ptr=None, tres_ptr=None):
         """mom6hip_obc_t for a call.  to_ptr(array) -> address of a segment's data array in the memory space of the call (default: the numpy
-        array itself: HOST); the struct keeps what it points at alive."""
+        array itself: HOST); tres_ptr: the same for the tracer reservoirs of the registries (default: to_ptr); the struct keeps what it
+        points at alive."""
+        tres_ptr = tres_ptr or to_ptr
         segs = (_abi.ObcSegment * max(self.number_of_segments, 1))()
         keep = [segs, self.segnum_u, self.segnum_v]
         for n, s in enumerate(self.segment):
@@ -288,10 +290,10 @@ class ocean_OBC_type:
                 trs[m].ntr_index, trs[m].OBC_inflow_conc = int(t["ntr_index"]), float(t.get("OBC_inflow_conc", 0.0))
                 a = t.get("tres")
                 if a is not None:
-                    if to_ptr is None:
+                    if tres_ptr is None:
                         a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); trs[m].tres = a.ctypes.data
                     else:
-                        p, owner = to_ptr(a); keep.append(owner); trs[m].tres = p
+                        p, owner = tres_ptr(a); keep.append(owner); trs[m].tres = p
             keep.append(trs)
             segs[n].tr_Reg = C.cast(trs, C.POINTER(_abi.ObcSegmentTracer)); segs[n].ntseg = len(s.tr_Reg)
         o = _abi.Obc()

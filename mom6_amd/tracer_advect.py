@@ -219,9 +219,6 @@ def advect_tracer(h_end, uhtr, vhtr, OBC, dt, G: DeviceGrid, CS: TracerAdvectCS,
         raise Mom6HipError("MOM_tracer_advect: register_tracer must be called before advect_tracer.")
     # advect_x / advect_y read of an associated OBC only the tracer registries of its segments (segment%tr_Reg, :442-477, :580-627 and
     # their twins): without one on any segment the advection is that of a closed domain
-    if OBC is not None and any(getattr(s, "tr_Reg", None) is not None for s in OBC.segment):
-        raise Mom6HipError("MOM_tracer_advect (HIP): open boundary segments with a tracer registry (reservoirs or inflow concentrations) "
-                           "are not provided")
     ntr = len(Reg)
     st = _abi.AdvectStats()
     if ntr == 0:
@@ -250,12 +247,37 @@ def advect_tracer(h_end, uhtr, vhtr, OBC, dt, G: DeviceGrid, CS: TracerAdvectCS,
         if cu.shape != (ntr,):
             raise Mom6HipError("advect_tracer: conc_underflow must have one entry per tracer")
     cs = CS.struct()
-    rc = lib().mom6hip_advect_tracer(
+    space = spaces.pop()
+    obc = None
+    if OBC is not None:
+        def tres_ptr(a):      # a reservoir of a segment's registry, (IsdB:IedB, jsd:jed, nz) of the segment, in the memory space of the call
+            if hasattr(a, "data_ptr"):
+                if space != _abi.MEM_DEVICE:
+                    raise Mom6HipError("advect_tracer: the tracer reservoirs of the OBC segments must be in the memory space of the fields")
+                return a.data_ptr(), a
+            if space != _abi.MEM_HOST:
+                raise Mom6HipError("advect_tracer: the tracer reservoirs of the OBC segments must be in the memory space of the fields")
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            return a.ctypes.data, a
+        obc = OBC.struct(lambda a: (0, None), tres_ptr)
+        for s in OBC.segment:
+            for t in (s.tr_Reg or []):
+                a = t.get("tres")
+                if a is not None and s.on_pe:
+                    hi = s.HI
+                    want = ((g.nk, hi["jed"] - hi["jsd"] + 1, hi["IedB"] - hi["IsdB"] + 1) if s.is_E_or_W
+                            else (g.nk, hi["JedB"] - hi["JsdB"] + 1, hi["ied"] - hi["isd"] + 1))
+                    if tuple(a.shape) != want:
+                        raise Mom6HipError(f"advect_tracer: a tracer reservoir of an OBC segment has shape {tuple(a.shape)}, expected {want}")
+    L = lib()
+    L.mom6hip_advect_tracer_obc.argtypes = ([C.c_void_p] * 4 + [C.c_double, C.c_void_p, C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p])
+    rc = L.mom6hip_advect_tracer_obc(
         G.handle, ph, pu, pv, float(dt), C.byref(cs), trp,
         None if cu is None else cu.ctypes.data_as(_dp), ntr,
         -1 if x_first_in is None else int(bool(x_first_in)), pvol,
         0 if max_iter_in is None else int(max_iter_in), int(bool(update_vol_prev)), puo, pvo,
-        spaces.pop(), C.byref(st))
+        None if obc is None else C.byref(obc), space, C.byref(st))
     check(rc, "advect_tracer")
     return st
 

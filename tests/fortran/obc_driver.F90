@@ -27,6 +27,8 @@ use MOM_domains,        only : MOM_domain_type
 use MOM_file_parser,    only : param_file_type, param_set
 use MOM_grid,           only : ocean_grid_type
 use MOM_open_boundary,  only : ocean_OBC_type, OBC_segment_type
+use MOM_tracer_advect,  only : tracer_advect_CS, tracer_advect_init, advect_tracer, tracer_advect_end
+use MOM_tracer_registry, only : tracer_registry_type
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : BT_cont_type, porous_barrier_type, alloc_BT_cont_type
 use MOM_verticalGrid,   only : verticalGrid_type
@@ -70,6 +72,10 @@ type(cont_diag_ptrs) :: CDp
 type(VarMix_CS) :: VarMix
 integer, target :: ntrunc
 real, allocatable, dimension(:,:,:) :: dz, u1, v1
+type(tracer_advect_CS), pointer :: TA => NULL()
+type(tracer_registry_type), pointer :: Reg => NULL()
+real, allocatable, dimension(:,:,:) :: uhtr, vhtr
+integer :: i, j, k, i0, i1, j0, j1
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
@@ -195,6 +201,35 @@ write(u_out) BT%FA_u_W0, BT%FA_u_WW, BT%FA_u_E0, BT%FA_u_EE, BT%uBT_WW, BT%uBT_E
 write(u_out) BT%FA_v_S0, BT%FA_v_SS, BT%FA_v_N0, BT%FA_v_NN, BT%vBT_SS, BT%vBT_NN, BT%h_u, BT%h_v
 write(u_out) CAu, CAv
 write(u_out) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v, u1, v1, diffu, diffv
+
+! advect_tracer (PPM:H3) of two tracers with the transports of the continuity step, every segment on the PE with a registry: tracer 1 with a
+! reservoir, tracer 2 with an inflow concentration (the values: exact quotients of small integers, the same in the test)
+allocate(Reg) ; Reg%ntr = 2
+allocate(Reg%Tr(1)%t(isd:ied,jsd:jed,nk), Reg%Tr(2)%t(isd:ied,jsd:jed,nk), uhtr(isd-1:ied,jsd:jed,nk), vhtr(isd:ied,jsd-1:jed,nk))
+do k=1,nk ; do j=jsd,jed ; do i=isd,ied
+  Reg%Tr(1)%t(i,j,k) = 1.0 + real(mod(3*i + 5*j + 7*k, 11)) / 11.0
+  Reg%Tr(2)%t(i,j,k) = real(mod(2*i + 3*j + k, 7)) / 7.0
+enddo ; enddo ; enddo
+uhtr(:,:,:) = dt * uh(:,:,:) ; vhtr(:,:,:) = dt * vh(:,:,:)
+do n=1,nseg ; if (OBC%segment(n)%on_pe) then
+  allocate(OBC%segment(n)%tr_Reg) ; OBC%segment(n)%tr_Reg%ntseg = 2
+  if (OBC%segment(n)%is_E_or_W) then
+    i0 = OBC%segment(n)%HI%IsdB ; i1 = OBC%segment(n)%HI%IedB ; j0 = OBC%segment(n)%HI%jsd ; j1 = OBC%segment(n)%HI%jed
+  else
+    i0 = OBC%segment(n)%HI%isd ; i1 = OBC%segment(n)%HI%ied ; j0 = OBC%segment(n)%HI%JsdB ; j1 = OBC%segment(n)%HI%JedB
+  endif
+  allocate(OBC%segment(n)%tr_Reg%Tr(1)%tres(i0:i1,j0:j1,nk))
+  do k=1,nk ; do j=j0,j1 ; do i=i0,i1
+    OBC%segment(n)%tr_Reg%Tr(1)%tres(i,j,k) = 5.0 + real(mod(i + 2*j + 3*k, 13)) / 13.0
+  enddo ; enddo ; enddo
+  OBC%segment(n)%tr_Reg%Tr(1)%ntr_index = 1
+  OBC%segment(n)%tr_Reg%Tr(2)%ntr_index = 2 ; OBC%segment(n)%tr_Reg%Tr(2)%OBC_inflow_conc = 0.25 + 0.125 * n
+endif ; enddo
+call param_set(pf, "TRACER_ADVECTION_SCHEME", "PPM:H3")
+call tracer_advect_init(Time, G, US, pf, diag, TA)
+call advect_tracer(hp, uhtr, vhtr, OBC, dt, G, GV, US, TA, Reg)
+write(u_out) Reg%Tr(1)%t, Reg%Tr(2)%t
+call tracer_advect_end(TA)
 close(u_out)
 call hor_visc_end(HV) ; call vertvisc_end(VV) ; call set_visc_end(visc, SVC)
 call CoriolisAdv_end(CCS)

@@ -1203,10 +1203,17 @@ use MOM_time_manager, only : time_type
 implicit none ; private
 public :: ocean_OBC_type, radiation_open_bdry_conds, open_boundary_zero_normal_flow, open_boundary_query
 public :: open_boundary_test_extern_h, update_OBC_ramp
+public :: OBC_segment_tracer_type, segment_tracer_registry_type
 public :: OBC_segment_type, OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W
 integer, parameter :: OBC_NONE = 0, OBC_DIRECTION_N = 100, OBC_DIRECTION_S = 200, OBC_DIRECTION_E = 300, OBC_DIRECTION_W = 400
+type :: OBC_segment_tracer_type
+  real :: OBC_inflow_conc = 0.0
+  real, allocatable :: tres(:,:,:)
+  integer :: ntr_index = -1
+end type OBC_segment_tracer_type
 type :: segment_tracer_registry_type
   integer :: ntseg = 0
+  type(OBC_segment_tracer_type) :: Tr(50)
 end type segment_tracer_registry_type
 type :: OBC_segment_type
   type(segment_tracer_registry_type), pointer :: tr_Reg => NULL()

@@ -98,3 +98,87 @@ def test_oracle_turns_with_the_grid(scheme, x_first):
     b = run(gr, cr, OBCr, scheme, x_first=not x_first)      # x' = y: the turned grid does y first where this one does x first
     for m in range(3):
         assert bits_equal(interior(g, unrot(b["tr"][m])), interior(g, a["tr"][m])), m
+
+
+# ---- the library against the oracle, on the GPU ----
+
+def run_hip(g, case, OBC, scheme, space, x_first=None, max_iter=None, conc_underflow=None):
+    import torch
+    from mom6_amd.tracer_advect import DeviceGrid, advect_tracer, tracer_advect_init
+    dev = space == "device"
+    X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if dev else (lambda a: a.copy())
+    N = (lambda a: a.cpu().numpy()) if dev else (lambda a: a)
+    if OBC is not None and dev:      # the reservoirs in the memory space of the call
+        for s in OBC.segment:
+            for t in (s.tr_Reg or []):
+                if t.get("tres") is not None and not hasattr(t["tres"], "data_ptr"):
+                    t["tres"] = X(t["tres"])
+    dg = DeviceGrid(g)
+    CS = tracer_advect_init(900.0, scheme)
+    tr = [X(t) for t in case["tr"]]
+    uhr, vhr = X(g.zeros3(_abi.POS_U)), X(g.zeros3(_abi.POS_V))
+    st = advect_tracer(X(case["h_end"]), X(case["uhtr"]), X(case["vhtr"]), OBC, 3600.0, dg, CS, tr, x_first_in=x_first, uhr_out=uhr, vhr_out=vhr,
+                       max_iter_in=max_iter, conc_underflow=conc_underflow)
+    dg.sync()
+    out = dict(tr=[N(t) for t in tr], uhr=N(uhr), vhr=N(vhr), stats=st)
+    dg.close()
+    return out
+
+
+def same(a, b, what):
+    for m, (x, y) in enumerate(zip(a["tr"], b["tr"])):
+        assert bits_equal(x, y), (what, "tracer", m + 1, np.argwhere(x != y)[:4])
+    assert bits_equal(a["uhr"], b["uhr"]), (what, "uhr", np.argwhere(a["uhr"] != b["uhr"])[:4])
+    assert bits_equal(a["vhr"], b["vhr"]), (what, "vhr", np.argwhere(a["vhr"] != b["vhr"])[:4])
+    assert a["stats"].iterations == b["stats"].iterations and a["stats"].domore_remaining == b["stats"].domore_remaining, what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("x_first", [True, False])
+def test_gpu_general_kernels_match_oracle_in_a_closed_domain(scheme, x_first, monkeypatch):
+    """the general kernels (a thread a face, a thread a cell) without any OBC: the arithmetic of the marching ones"""
+    monkeypatch.setenv("MOM6HIP_ADV_GENERIC", "1")
+    for (ni, nj, nk, seed) in [(22, 16, 3, 3), (150, 40, 2, 5)]:
+        g, case, _ = adv_obc_case([], ni=ni, nj=nj, nk=nk, seed=seed, registry=False)
+        ref = run(g, case, None, scheme, x_first=x_first, conc_underflow=[1e-3, 0.0, 0.0])
+        for space in ("device", "host"):
+            same(run_hip(g, case, None, scheme, space, x_first=x_first, conc_underflow=[1e-3, 0.0, 0.0]), ref, (scheme, x_first, ni, space))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("x_first", [True, False])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_advect_tracer_with_segment_registries_matches_oracle_bitwise(scheme, x_first, space):
+    for (ni, nj, nk, seed) in [(22, 16, 3, 3), (150, 40, 2, 5), (64, 48, 4, 9)]:
+        g, case, OBC = adv_obc_case(SEGS, ni=ni, nj=nj, nk=nk, seed=seed)
+        ref = run(g, case, OBC, scheme, x_first=x_first)
+        closed = run(g, case, None, scheme, x_first=x_first)
+        assert not bits_equal(ref["tr"][0], closed["tr"][0])
+        same(run_hip(g, case, OBC, scheme, space, x_first=x_first), ref, (scheme, x_first, ni, space))
+
+
+@pytest.mark.gpu
+def test_gpu_advect_tracer_registries_few_iterations_and_no_registry():
+    g, case, OBC = adv_obc_case(SEGS)
+    ref = run(g, case, OBC, "PPM", max_iter=1)
+    same(run_hip(g, case, OBC, "PPM", "host", max_iter=1), ref, "max_iter=1")
+    g, case, OBC = adv_obc_case(SEGS, registry=False)
+    same(run_hip(g, case, OBC, "PPM", "device"), run(g, case, None, "PPM"), "no registry")
+
+
+@pytest.mark.gpu
+def test_gpu_advect_tracer_refuses_bad_registries():
+    from mom6_amd._lib import Mom6HipError
+    g, case, OBC = adv_obc_case(SEGS)
+    OBC.segment[0].tr_Reg[0]["ntr_index"] = 7
+    with pytest.raises(Mom6HipError, match="names tracer"):
+        run_hip(g, case, OBC, "PLM", "host")
+    g, case, OBC = adv_obc_case(["I=9,J=0:N,SIMPLE", "I=11,J=0:N,SIMPLE"])
+    with pytest.raises(Mom6HipError, match="closer than four cells"):
+        run_hip(g, case, OBC, "PLM", "host")
+    g, case, OBC = adv_obc_case(SEGS)
+    OBC.segment[0].tr_Reg[0]["tres"] = np.zeros((3, 2, 2))
+    with pytest.raises(Mom6HipError, match="shape"):
+        run_hip(g, case, OBC, "PLM", "host")

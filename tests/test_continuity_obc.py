@@ -347,11 +347,25 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
         g, orc.hor_visc_cs(g, 900.0, Laplacian=1, Kh=25.0, Kh_vel_scale=0.003, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Ah_vel_scale=0.003, Smagorinsky_Ah=1,
                            Smag_bi_const=0.06, bound_Coriolis=1, bound_Cor_vel=3.0e8), st["u"], st["v"], st["h"], 900.0, OBC=OBC)
     _write_obc_case(str(tmp_path / "in.bin"), g, st, OBC, want["uhbt"], want["vhbt"])
+    # advect_tracer (PPM:H3) of two tracers with the transports of the continuity step, every segment with a registry; the values as the driver
+    # states them (exact quotients of small integers of the Fortran indices)
+    shp = g.shape3(_abi.POS_H)
+    fk, fj, fi = (np.arange(n)[sl] + 1 for n, sl in zip(shp, ((slice(None), None, None), (None, slice(None), None), (None, None, slice(None)))))
+    tr = [1.0 + ((3 * fi + 5 * fj + 7 * fk) % 11).astype(np.float64) / 11.0, ((2 * fi + 3 * fj + fk) % 7).astype(np.float64) / 7.0]
+    for n, s in enumerate(OBC.segment):
+        if s.on_pe:
+            i0, j0 = (s.HI["IsdB"], s.HI["jsd"]) if s.is_E_or_W else (s.HI["isd"], s.HI["JsdB"])
+            nk_, nj_, ni_ = s.normal_vel.shape
+            si, sj, sk = i0 + np.arange(ni_)[None, None, :], j0 + np.arange(nj_)[None, :, None], 1 + np.arange(nk_)[:, None, None]
+            s.tr_Reg = [dict(ntr_index=1, tres=5.0 + ((si + 2 * sj + 3 * sk) % 13).astype(np.float64) / 13.0),
+                        dict(ntr_index=2, OBC_inflow_conc=0.25 + 0.125 * (n + 1))]
+    orc.advect_tracer(g, want["h"], 900.0 * want["uh"], 900.0 * want["vh"], 900.0, 900.0, "PPM:H3", tr, OBC=OBC)
+    want["tr1"], want["tr2"] = tr
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
-             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u1", "v1", "diffu", "diffv"]
+             "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u1", "v1", "diffu", "diffv", "tr1", "tr2"]
     arrs = [want[n] if n in want else want["bt"][n] for n in names]
     got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
     for n, a, w in zip(names, got, arrs):

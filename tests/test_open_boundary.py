@@ -185,7 +185,7 @@ def test_gpu_radiation_refuses_what_it_does_not_provide():
 @pytest.mark.gpu
 def test_gpu_advect_tracer_with_segments_without_a_tracer_registry_is_the_closed_advection():
     """advect_x / advect_y read of an associated OBC only the tracer registries of its segments (segment%tr_Reg,
-    MOM_tracer_advect.F90:442-477, :580-627): without one the answers are those of OBC => NULL(); with one the call is refused"""
+    MOM_tracer_advect.F90:442-477, :580-627): without one the answers are those of OBC => NULL() (with one: tests/test_advect_obc.py)"""
     from helpers import advect_case
     from mom6_amd._lib import Mom6HipError
     from mom6_amd.tracer_advect import DeviceGrid, advect_tracer, tracer_advect_init
@@ -200,7 +200,4 @@ def test_gpu_advect_tracer_with_segments_without_a_tracer_registry_is_the_closed
         advect_tracer(case["h_end"], case["uhtr"], case["vhtr"], obc, 3600.0, dg, CS, tr)
         out.append(tr)
     assert all(bits_equal(a, b) for a, b in zip(*out))
-    OBC.segment[0].tr_Reg = object()
-    with pytest.raises(Mom6HipError, match="tracer registry"):
-        advect_tracer(case["h_end"], case["uhtr"], case["vhtr"], OBC, 3600.0, dg, CS, [t.copy() for t in case["tr"]])
     dg.close()
