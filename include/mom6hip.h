@@ -529,9 +529,10 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
  * (OBC_segment_type :146-263).  Round 4 provides the OBC branches of continuity_PPM (mom6hip_continuity_obc), of CorAdCalc
  * (mom6hip_coradcalc_obc), of vertvisc_coef / vertvisc (mom6hip_vertvisc_coef_obc, mom6hip_vertvisc_obc), of btcalc and btstep
  * (mom6hip_btcalc_obc, mom6hip_btstep_obc), of set_viscous_BBL (mom6hip_set_viscous_bbl_obc), of horizontal_viscosity
- * (mom6hip_horizontal_viscosity_obc), and radiation_open_bdry_conds / open_boundary_zero_normal_flow for the normal component; every
- * other entry point (advect_tracer, tracer_hordiff, the RK2 steppers) of the library still requires that OBC is not associated, so a configuration
- * with open boundaries cannot be stepped yet.
+ * (mom6hip_horizontal_viscosity_obc), of advect_tracer (mom6hip_advect_tracer_obc: the tracer registries of the segments), and
+ * radiation_open_bdry_conds / open_boundary_zero_normal_flow for the normal component; every other entry point (tracer_hordiff, the RK2
+ * steppers) of the library still requires that OBC is not associated: a configuration with open boundaries is stepped by the reference's
+ * own MOM_dynamics_split_RK2 and MOM_open_boundary over these operators.
  * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */
 #define MOM6HIP_OBC_NONE 0            /* OBC_NONE :79 */
