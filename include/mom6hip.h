@@ -592,7 +592,11 @@ typedef struct mom6hip_obc {
   const mom6hip_obc_segment_t *segment;             /* number_of_segments entries (HOST array) */
   const int32_t *segnum_u, *segnum_v;               /* OBC%segnum_u(IsdB:IedB, jsd:jed), segnum_v(isd:ied, JsdB:JedB): the segment number
                                                        (1-based) of a face, MOM6HIP_OBC_NONE elsewhere; HOST arrays */
-  void *reserved_p[4];
+  /* OBC%rx_normal(IsdB:IedB, jsd:jed, nk), OBC%ry_normal(isd:ied, JsdB:JedB, nk): the radiation rates the Orlanski segments keep between
+   * steps (restart fields), in the memory space of the call; OBC%gamma_uv, OBC%rx_max (OBC_RADIATION_MAX).  Read and written by the RK2
+   * step (its calls of radiation_open_bdry_conds); mom6hip_radiation_open_bdry_conds takes them as arguments. */
+  double *rx_normal, *ry_normal;
+  double gamma_uv, rx_max;
 } mom6hip_obc_t;
 
 /* continuity_PPM with OBC associated (:86-194; the OBC branches of PPM_reconstruction_x/y :2385-2432 / :2521-2568, of
@@ -1307,7 +1311,8 @@ typedef struct mom6hip_dyn_split_rk2_cs {
   double *du_av_inst, *dv_av_inst;
   const mom6hip_set_visc_cs_t *set_visc_CSp;  /* NULL, or with dynamic_viscous_ML: set_viscous_ML is called at :592 (visc->ustar,
                                                  visc->nkml_visc_u/v must be set) */
-  void *reserved2[1];
+  const struct mom6hip_obc *OBC;              /* CS%OBC (:253): NULL, or the open boundaries (the arrays of its segments, rx_normal and
+                                                 ry_normal DEVICE arrays): step_MOM_dyn_split_RK2 only, see mom6hip_step_dyn_split_rk2 */
 } mom6hip_dyn_split_rk2_cs_t;
 
 /* The part of initialize_dyn_split_RK2 (:1326) that sets state: eta from the layer thicknesses (:1521-1535),

@@ -208,7 +208,7 @@ class Obc(C.Structure):
                                          "freeslip_vorticity", "computed_vorticity", "specified_vorticity", "zero_strain", "freeslip_strain",
                                          "computed_strain", "zero_biharmonic")] + \
                [("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
-                ("reserved_p", C.c_void_p * 4)]
+                ("rx_normal", C.c_void_p), ("ry_normal", C.c_void_p), ("gamma_uv", C.c_double), ("rx_max", C.c_double)]
 
 
 class HorDiffStats(C.Structure):
@@ -275,7 +275,7 @@ class DynSplitRK2CS(C.Structure):
                  ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
                  ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("hor_visc", C.c_void_p)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
-                + [("set_visc_CSp", C.c_void_p), ("reserved2", C.c_void_p * 1)])
+                + [("set_visc_CSp", C.c_void_p), ("OBC", C.c_void_p)])
 
 
 # ---- MOM_vert_friction ------------------------------------------------------------------------------------

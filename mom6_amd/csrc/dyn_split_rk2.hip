@@ -125,6 +125,153 @@ int check(const mom6hip_dyn_split_rk2_cs_t *cs, const char *who) {
 
 #define CALL(x) do { if (int rc_ = (x)) return rc_; } while (0)
 
+// step_MOM_dyn_split_RK2 with CS%OBC associated: the reference's sequence of calls one after the other, every operator through its entry
+// point with the OBC (regional grids are small: no fused sweeps, no work around the passes in flight), plus the step's own lines for
+// the open boundaries: the starting velocities of the radiation (:444-456), open_boundary_zero_normal_flow on the accelerations
+// (:565-567, :887-889), radiation_open_bdry_conds on u_av (:765-775) and u_inst (:1030-1034).
+int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_inst, double *v_inst, double *h, const double *T, const double *S,
+                  double dt, const double *taux, const double *tauy, double RZ_to_H, double *uh, double *vh, double *uhtr, double *vhtr,
+                  double *eta_av, int32_t calc_dtbt) {
+  const mom6hip_obc_t *OBC = cs->OBC;
+  const m6::GridDev g = ctx->g;
+  const Sz sz = sizes(g);
+  hipStream_t s = ctx->stream;
+  const int D = MOM6HIP_MEM_DEVICE;
+  const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec, nz = g.nk;
+  const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
+  mom6hip_barotropic_cs_t *BT = cs->barotropic_CSp;
+  const mom6hip_bt_cont_t *BTC = cs->BT_cont;
+  const bool BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
+  mom6hip_vertvisc_cs_t *VV = cs->vertvisc_CSp;
+  M6_REQUIRE(!cs->hooks, "step_MOM_dyn_split_RK2: host-side parameterisations (hooks) are not provided with an associated OBC");
+  M6_REQUIRE(!m6::multi_tile(ctx), "step_MOM_dyn_split_RK2: an associated OBC is provided on one tile");
+  M6_REQUIRE(!(cs->set_visc_CSp && cs->set_visc_CSp->dynamic_viscous_ML), "step_MOM_dyn_split_RK2: DYNAMIC_VISCOUS_ML is not provided with an associated OBC");
+
+  // the step's automatic arrays (:336-369), with u_old_rad_OBC, v_old_rad_OBC (:360-363)
+  const size_t blk_bytes = 4 * sz.u3 + 4 * sz.v3 + sz.h3 + sz.h2;
+  const bool fresh = ctx->rk2_scratch.bytes < blk_bytes || ctx->rk2_scratch_layout != 3;
+  M6_REQUIRE(ctx->rk2_scratch.reserve(blk_bytes) == 0, "step_MOM_dyn_split_RK2: out of device memory");
+  ctx->rk2_scratch_layout = 3;
+  char *blk = (char *)ctx->rk2_scratch.p;
+  double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3), *u_old = (double *)(blk + 3 * sz.u3);
+  char *vb = blk + 4 * sz.u3;
+  double *vp = (double *)vb, *v_bc = (double *)(vb + sz.v3), *vh_in = (double *)(vb + 2 * sz.v3), *v_old = (double *)(vb + 3 * sz.v3);
+  double *hp = (double *)(vb + 4 * sz.v3), *eta_pred = (double *)(vb + 4 * sz.v3 + sz.h3);
+  double *u_av = cs->u_av, *v_av = cs->v_av, *h_av = cs->h_av, *eta = cs->eta;
+  if (fresh) M6_HIP(hipMemsetAsync(blk, 0, blk_bytes, s));                                           // :419-421
+  M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :422
+  M6_HIP(hipMemcpyAsync(u_old, u_av, sz.u3, hipMemcpyDeviceToDevice, s));                            // :450-455
+  M6_HIP(hipMemcpyAsync(v_old, v_av, sz.v3, hipMemcpyDeviceToDevice, s));
+
+  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,   // :495
+                                      cs->eta_PF, D));
+  if (!cs->CAu_pred_stored)   // :544-552
+    CALL(mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+  auto bc_accel = [&](const double *CAu, const double *CAv) -> int {      // :557-567, :879-889
+    const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      u_bc[n] = (CAu[n] + PFu[n]) + diffu[n];
+    });
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      v_bc[n] = (CAv[n] + PFv[n]) + diffv[n];
+    });
+    return mom6hip_open_boundary_zero_normal_flow(ctx, OBC, u_bc, v_bc, D);
+  };
+  auto increment = [&](double *uo, double *vo, double dtx, bool with_bt) {      // :582-589, :667-676, :930-939
+    const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
+    launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+      const long n = g.v3(i, J, k);
+      vo[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dtx * (with_bt ? (v_bc[n] + abv[n]) : v_bc[n]));
+    });
+    launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+      const long n = g.u3(I, j, k);
+      uo[n] = g.mask2dCu[g.u2(I, j)] * (u_inst[n] + dtx * (with_bt ? (u_bc[n] + abu[n]) : u_bc[n]));
+    });
+  };
+  CALL(bc_accel(cs->CAu_pred, cs->CAv_pred));
+  increment(up, vp, dt, false);
+  if (VV) {      // vertvisc_coef, vertvisc_remnant :598-600
+    CALL(mom6hip_vertvisc_coef_obc(ctx, VV, up, vp, h, nullptr, cs->visc, dt, OBC, D));
+    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt, D));
+  }
+  CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));            // :610-611
+  if (!BT_cont_BT_thick) CALL(mom6hip_btcalc_obc(ctx, BT, h, nullptr, nullptr, 0, OBC, D));          // :618
+  CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
+  if (BTC || cs->BT_use_layer_fluxes) {      // :634-644
+    CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,
+                                cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
+    if (BT_cont_BT_thick) CALL(mom6hip_btcalc_obc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, OBC, D));
+  }
+  if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));           // :651
+  const bool lf = cs->BT_use_layer_fluxes != 0;
+  CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :655
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          nullptr, lf ? uh_in : nullptr, lf ? vh_in : nullptr, lf ? u_inst : nullptr, lf ? v_inst : nullptr, nullptr, OBC, D));
+  const double dt_pred = dt * cs->be;
+  increment(up, vp, dt_pred, true);                                                                    // :663-676
+  if (VV) {      // :717-744
+    CALL(mom6hip_vertvisc_coef_obc(ctx, VV, up, vp, h, nullptr, cs->visc, dt_pred, OBC, D));
+    CALL(mom6hip_vertvisc_obc(ctx, VV, up, vp, h, taux, tauy, cs->visc, dt_pred, nullptr, nullptr, OBC, D));
+    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt_pred, D));
+  }
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz));          // :747-751
+  CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :757
+                              u_av, v_av, BTC, nullptr, nullptr, D));
+  CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                       // :763
+  CALL(mom6hip_radiation_open_bdry_conds(ctx, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_av, u_old, v_av, v_old,   // :770
+                                         dt_pred, D));
+  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {              // :785-787
+    const long n = g.h3(i, j, k);
+    h_av[n] = 0.5 * (h[n] + hp[n]);
+  });
+  CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :797
+  if (BT_cont_BT_thick) CALL(mom6hip_btcalc_obc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, OBC, D));         // :843
+  if (cs->hor_visc)      // :860
+    CALL(mom6hip_horizontal_viscosity_obc(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, dt, BTC ? BTC->h_u : nullptr,
+                                          BTC ? BTC->h_v : nullptr, OBC, D));
+  CALL(mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
+  CALL(bc_accel(cs->CAu, cs->CAv));                                                                   // :879-889
+  CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :911
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          nullptr, lf ? uh : nullptr, lf ? vh : nullptr, lf ? u_av : nullptr, lf ? v_av : nullptr, eta_av, OBC, D));
+  launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :918
+  increment(u_inst, v_inst, dt, true);                                                                 // :928-939 (in place: a point reads itself)
+  if (VV) {      // :974-994
+    CALL(mom6hip_vertvisc_coef_obc(ctx, VV, u_inst, v_inst, h, nullptr, cs->visc, dt, OBC, D));
+    CALL(mom6hip_vertvisc_obc(ctx, VV, u_inst, v_inst, h, taux, tauy, cs->visc, dt, nullptr, nullptr, OBC, D));
+    CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt, D));
+  }
+  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) { h_av[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });   // :1000
+  CALL(pass(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz));  // :1004-1008
+  CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,   // :1015
+                              cs->visc_rem_v, u_av, v_av, nullptr, nullptr, nullptr, D));
+  CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :1018, :1027
+  CALL(mom6hip_radiation_open_bdry_conds(ctx, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_inst, u_old, v_inst, v_old,   // :1033
+                                         dt, D));
+  launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {              // :1038-1040
+    const long n = g.h3(i, j, k);
+    h_av[n] = 0.5 * (h_av[n] + h[n]);
+  });
+  launch3d(s, Isq - 2, Ieq + 2, js - 2, je + 2, nz, [=] __device__(int I, int j, int k) {            // :1046-1053
+    const long n = g.u3(I, j, k);
+    uhtr[n] = uhtr[n] + uh[n] * dt;
+  });
+  launch3d(s, is - 2, ie + 2, Jsq - 2, Jeq + 2, nz, [=] __device__(int i, int J, int k) {
+    const long n = g.v3(i, J, k);
+    vhtr[n] = vhtr[n] + vh[n] * dt;
+  });
+  if (cs->store_CAu) {      // :1055-1069
+    CALL(mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+    cs->CAu_pred_stored = 1;
+  } else {
+    cs->CAu_pred_stored = 0;
+  }
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -154,7 +301,8 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (cs->hor_visc) {   // :1543-1550
     const mom6hip_bt_cont_t *B = cs->BT_cont;
     M6_REQUIRE(cs->hor_visc->initialized, "MOM_hor_visc: Module must be initialized before it is used.");
-    if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u, v, h, cs->diffu, cs->diffv, B ? B->h_u : nullptr, B ? B->h_v : nullptr)) return 1;
+    if (cs->OBC) CALL(mom6hip_horizontal_viscosity_obc(ctx, cs->hor_visc, u, v, h, cs->diffu, cs->diffv, dt, B ? B->h_u : nullptr, B ? B->h_v : nullptr, cs->OBC, D));
+    else if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u, v, h, cs->diffu, cs->diffv, B ? B->h_u : nullptr, B ? B->h_v : nullptr)) return 1;
   } else if (cs->hooks && cs->hooks->horizontal_viscosity) {
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(cs->hooks->horizontal_viscosity(cs->hooks->user, u, v, h, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
@@ -172,8 +320,8 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
     M6_REQUIRE(sz.u3 >= sz.h3, "dyn_split_rk2_init: internal scratch too small");
     M6_HIP(hipMemcpyAsync(h_tmp, h, sz.h3, hipMemcpyDeviceToDevice, s));
     const double *uu = cs->store_CAu ? cs->u_av : u, *vv = cs->store_CAu ? cs->v_av : v;
-    CALL(mom6hip_continuity(ctx, cs->continuity_CSp, uu, vv, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, nullptr, nullptr, D));
+    CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, cs->OBC, uu, vv, h, h_tmp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, nullptr, nullptr, D));
     CALL(pass(ctx, {{h_tmp, PH}}, g.nk));
     double *h_av = cs->h_av;
     launch3d(s, g.isd, g.ied, g.jsd, g.jed, g.nk, [=] __device__(int i, int j, int k) {
@@ -183,7 +331,7 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   }
   if (cs->store_CAu) {
     CALL(pass(ctx, {{cs->u_av, PU}, {cs->v_av, PV}, {uh, PU}, {vh, PV}}, g.nk));
-    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, cs->u_av, cs->v_av, cs->h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+    CALL(mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, cs->OBC, cs->u_av, cs->v_av, cs->h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
     cs->CAu_pred_stored = 1;
     CALL(pass(ctx, {{cs->u_av, PU}, {cs->v_av, PV}, {cs->CAu_pred, PU}, {cs->CAv_pred, PV}}, g.nk));   // :1615-1622
   } else {
@@ -200,6 +348,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   M6_REQUIRE(ctx && u_inst && v_inst && h && taux && tauy && uh && vh && uhtr && vhtr && eta_av, "step_MOM_dyn_split_RK2: null argument");
   CALL(check(cs, "step_MOM_dyn_split_RK2"));
   M6_REQUIRE(!cs->eqn_of_state || (T && S), "step_MOM_dyn_split_RK2: an equation of state needs tv%%T and tv%%S");
+  if (cs->OBC) return step_with_obc(ctx, cs, u_inst, v_inst, h, T, S, dt, taux, tauy, RZ_to_H, uh, vh, uhtr, vhtr, eta_av, calc_dtbt);
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);
   hipStream_t s = ctx->stream;
@@ -478,6 +627,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   CALL(check(cs, "step_MOM_dyn_split_RK2b"));
   M6_REQUIRE(!cs->eqn_of_state || (T && S), "step_MOM_dyn_split_RK2b: an equation of state needs tv%%T and tv%%S");
   M6_REQUIRE(cs->du_av_inst && cs->dv_av_inst, "step_MOM_dyn_split_RK2b: du_av_inst / dv_av_inst are not allocated");
+  M6_REQUIRE(!cs->OBC, "step_MOM_dyn_split_RK2b: an associated OBC is provided with SPLIT_RK2B = False only");
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);
   hipStream_t s = ctx->stream;

@@ -35,7 +35,7 @@ class MOM_dyn_split_RK2_CS:
 
     def __init__(self, G: DeviceGrid, BE=0.6, BEGW=0.0, BT_USE_LAYER_FLUXES=True, STORE_CORIOLIS_ACCEL=True, USE_BT_CONT_TYPE=True,
                  EQN_OF_STATE="WRIGHT", continuity=None, coriolis=None, pressure_force=None, barotropic=None, vertvisc=None, hor_visc=None,
-                 DT=None, set_visc=None, eos=None):
+                 DT=None, set_visc=None, eos=None, OBC=None):
         g = G.grid
         dev = "cuda"
         self.G = G
@@ -90,6 +90,17 @@ class MOM_dyn_split_RK2_CS:
             from .set_viscosity import set_visc_init
             self.set_visc_CSp = set_visc_init(G, **set_visc)
             st.set_visc_CSp = C.addressof(self.set_visc_CSp.st)
+        # CS%OBC => OBC (:1516-1519): an ocean_OBC_type whose arrays (the segments' own, rx_normal, ry_normal) are CUDA tensors
+        # (ocean_OBC_type.cuda()); the step updates segment%normal_vel and OBC%rx_normal / ry_normal in place
+        self.OBC = OBC
+        if OBC is not None:
+            from .open_boundary import _seg_to_ptr
+            for a in [OBC.rx_normal, OBC.ry_normal] + [getattr(sg, k) for sg in OBC.segment if sg.on_pe
+                                                        for k in ("normal_vel", "normal_trans", "normal_vel_bt", "SSH", "tangential_vel", "tangential_grad", "nudged_normal_vel")]:
+                if a is not None and not hasattr(a, "data_ptr"):
+                    raise Mom6HipError("initialize_dyn_split_RK2: the arrays of the OBC must be CUDA tensors (ocean_OBC_type.cuda())")
+            self._obc = OBC.struct(_seg_to_ptr(_abi.MEM_DEVICE))
+            st.OBC = C.addressof(self._obc)
         self.module_is_initialized = False
 
     def __getattr__(self, n):

@@ -555,7 +555,7 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   CS%c_rk2%be = CS%be ; CS%c_rk2%begw = CS%begw
   CS%c_rk2%BT_use_layer_fluxes = merge(1, 0, CS%BT_use_layer_fluxes) ; CS%c_rk2%store_CAu = merge(1, 0, CS%store_CAu)
   CS%c_rk2%CAu_pred_stored = 0 ; CS%c_rk2%split_bottom_stress = 0 ; CS%c_rk2%reserved0(:) = 0
-  CS%c_rk2%hooks = c_null_ptr ; CS%c_rk2%reserved2(:) = c_null_ptr
+  CS%c_rk2%hooks = c_null_ptr ; CS%c_rk2%OBC = c_null_ptr
   CS%c_rk2%CAu = dalloc(CS, CS%nu3) ; CS%c_rk2%CAv = dalloc(CS, CS%nv3) ; CS%c_rk2%CAu_pred = dalloc(CS, CS%nu3)
   CS%c_rk2%CAv_pred = dalloc(CS, CS%nv3) ; CS%c_rk2%PFu = dalloc(CS, CS%nu3) ; CS%c_rk2%PFv = dalloc(CS, CS%nv3)
   CS%c_rk2%diffu = dalloc(CS, CS%nu3) ; CS%c_rk2%diffv = dalloc(CS, CS%nv3) ; CS%c_rk2%visc_rem_u = dalloc(CS, CS%nu3)

@@ -218,7 +218,8 @@ type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: zero_vorticity = 0, freeslip_vorticity = 0, computed_vorticity = 0, specified_vorticity = 0
   integer(c_int32_t) :: zero_strain = 0, freeslip_strain = 0, computed_strain = 0, zero_biharmonic = 0
   type(c_ptr) :: segment = c_null_ptr, segnum_u = c_null_ptr, segnum_v = c_null_ptr
-  type(c_ptr) :: reserved_p(4) = c_null_ptr
+  type(c_ptr) :: rx_normal = c_null_ptr, ry_normal = c_null_ptr
+  real(c_double) :: gamma_uv = 0.0, rx_max = 0.0
 end type mom6hip_obc_t
 
 !> mom6hip_epipycnal_cs_t (DIFFUSE_ML_TO_INTERIOR: tracer_epipycnal_ML_diff, src/tracer/MOM_tracer_hor_diff.F90:700)
@@ -291,7 +292,7 @@ type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
   type(c_ptr) :: eta, eta_PF, uhbt, vhbt
   type(c_ptr) :: du_av_inst, dv_av_inst   !< SPLIT_RK2B only (MOM_dynamics_split_RK2b.F90:141-146)
   type(c_ptr) :: set_visc_CSp = c_null_ptr   !< c_loc of a mom6hip_set_visc_cs_t with dynamic_viscous_ML, or c_null_ptr
-  type(c_ptr) :: reserved2(1)
+  type(c_ptr) :: OBC = c_null_ptr      !< CS%OBC: c_loc of a mom6hip_obc_t of DEVICE arrays, or c_null_ptr
 end type mom6hip_dyn_split_rk2_cs_t
 
 interface

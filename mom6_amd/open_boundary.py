@@ -255,6 +255,19 @@ class ocean_OBC_type:
         seg.Is_obc, seg.Ie_obc = Is_obc, Ie_obc; seg.Js_obc = seg.Je_obc = J_obc
         self._alloc(seg)
 
+    def cuda(self):
+        """the arrays of the OBC and of its segments as CUDA tensors (what a device-resident caller keeps): in place, returns self"""
+        import torch
+        T = lambda a: a if a is None or hasattr(a, "data_ptr") else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+        self.rx_normal, self.ry_normal = T(self.rx_normal), T(self.ry_normal)
+        for s in self.segment:
+            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH"):
+                setattr(s, k, T(getattr(s, k)))
+            for t in (s.tr_Reg or []):
+                if t.get("tres") is not None:
+                    t["tres"] = T(t["tres"])
+        return self
+
     def struct(self, to_ptr=None, tres_ptr=None):
         """mom6hip_obc_t for a call.  to_ptr(array) -> address of a segment's data array in the memory space of the call (default: the numpy
         array itself: HOST); tres_ptr: the same for the tracer reservoirs of the registries (default: to_ptr); the struct keeps what it
@@ -304,6 +317,14 @@ class ocean_OBC_type:
             setattr(o, k, int(getattr(self, k)))
         o.segment = C.cast(segs, C.POINTER(_abi.ObcSegment))
         o.segnum_u, o.segnum_v = self.segnum_u.ctypes.data, self.segnum_v.ctypes.data
+        o.gamma_uv, o.rx_max = self.gamma_uv, self.rx_max      # (read by the RK2 step; radiation_open_bdry_conds takes them as arguments)
+        for k in ("rx_normal", "ry_normal"):
+            a = getattr(self, k)
+            if a is not None:
+                if to_ptr is None:
+                    keep.append(a); setattr(o, k, a.ctypes.data)
+                else:
+                    ptr, owner = to_ptr(a); keep.append(owner); setattr(o, k, ptr)
         o._keep = keep
         return o
 

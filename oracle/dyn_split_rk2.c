@@ -30,14 +30,15 @@ int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
                            const double *h, double *uh, double *vh, double dt) {
   const int is = G->isc, ie = G->iec, js = G->jsc, je = G->jec, nz = G->nk;
   if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || (CS->vertvisc_CSp && !CS->visc)) return 1;
+  const mom6hip_obc_t *OBC = CS->OBC;      /* :1516-1519 */
   /* eta :1521-1535 */
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) CS->eta[H2(i, j)] = -G->Z_to_H * G->bathyT[H2(i, j)];
   for (int k = 1; k <= nz; k++) for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++)
     CS->eta[H2(i, j)] = CS->eta[H2(i, j)] + h[H3(i, j, k)];
   memset(CS->diffu, 0, sizeof(double) * n_u3(G)); memset(CS->diffv, 0, sizeof(double) * n_v3(G));
   if (CS->hor_visc) {   /* :1543-1550 */
-    int rc = orc_horizontal_viscosity(G, CS->hor_visc, u, v, h, CS->diffu, CS->diffv, dt, CS->BT_cont ? CS->BT_cont->h_u : NULL,
-                                      CS->BT_cont ? CS->BT_cont->h_v : NULL);
+    int rc = orc_horizontal_viscosity_obc(G, CS->hor_visc, u, v, h, CS->diffu, CS->diffv, dt, CS->BT_cont ? CS->BT_cont->h_u : NULL,
+                                          CS->BT_cont ? CS->BT_cont->h_v : NULL, OBC);
     if (rc) return rc;
   }
   for (long n = 0; n < n_u3(G); n++) CS->visc_rem_u[n] = 1.0;
@@ -46,20 +47,20 @@ int orc_dyn_split_rk2_init(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   if (CS->store_CAu) {   /* :1560-1588 */
     double *h_tmp = (double *)malloc(sizeof(double) * n_h3(G));
     memcpy(h_tmp, h, sizeof(double) * n_h3(G));
-    int rc = orc_continuity(G, CS->continuity_CSp, CS->u_av, CS->v_av, h, h_tmp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL,
+    int rc = orc_continuity_obc(G, CS->continuity_CSp, OBC, CS->u_av, CS->v_av, h, h_tmp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL,
                             NULL, NULL, NULL);
     if (rc) { free(h_tmp); return rc; }
     pass3(G, h_tmp, MOM6HIP_POS_H);
     for (long n = 0; n < n_h3(G); n++) CS->h_av[n] = 0.5 * (h[n] + h_tmp[n]);
     free(h_tmp);
     pass3(G, CS->u_av, MOM6HIP_POS_U); pass3(G, CS->v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
-    rc = orc_coradcalc(G, CS->CoriolisAdv, CS->u_av, CS->v_av, CS->h_av, uh, vh, CS->CAu_pred, CS->CAv_pred);
+    rc = orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, CS->u_av, CS->v_av, CS->h_av, uh, vh, CS->CAu_pred, CS->CAv_pred);
     if (rc) return rc;
     CS->CAu_pred_stored = 1;
   } else {
     double *h_tmp = (double *)malloc(sizeof(double) * n_h3(G));
     memcpy(h_tmp, h, sizeof(double) * n_h3(G));
-    int rc = orc_continuity(G, CS->continuity_CSp, u, v, h, h_tmp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+    int rc = orc_continuity_obc(G, CS->continuity_CSp, OBC, u, v, h, h_tmp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
     if (rc) { free(h_tmp); return rc; }
     pass3(G, h_tmp, MOM6HIP_POS_H);
     for (long n = 0; n < n_h3(G); n++) CS->h_av[n] = 0.5 * (h[n] + h_tmp[n]);
@@ -92,11 +93,18 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   double *u_av = CS->u_av, *v_av = CS->v_av, *h_av = CS->h_av, *eta = CS->eta;
   int rc = 0;
 #define CHECK(call) do { rc = (call); if (rc) goto done; } while (0)
+  /* CS%OBC: the starting velocities of the radiation conditions (:444-456) */
+  const mom6hip_obc_t *OBC = CS->OBC;
+  double *u_old_rad_OBC = NULL, *v_old_rad_OBC = NULL;
+  if (OBC) {
+    u_old_rad_OBC = (double *)malloc(sizeof(double) * NU); v_old_rad_OBC = (double *)malloc(sizeof(double) * NV);
+    memcpy(u_old_rad_OBC, u_av, sizeof(double) * NU); memcpy(v_old_rad_OBC, v_av, sizeof(double) * NV);
+  }
 
   /* PressureForce :495 */
   CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, NULL, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
   if (!CS->CAu_pred_stored)   /* :544-552 */
-    CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
+    CHECK(orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
   /* u_bc_accel :557-564 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -105,6 +113,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       v_bc_accel[V3(i, J, k)] = (CS->CAv_pred[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
   }
+  if (OBC) CHECK(orc_open_boundary_zero_normal_flow(G, OBC, u_bc_accel, v_bc_accel));                  /* :565-567 */
   /* up :582-589 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -117,28 +126,28 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   if (CS->set_visc_CSp && CS->set_visc_CSp->dynamic_viscous_ML)
     CHECK(orc_set_viscous_ML(G, CS->set_visc_CSp, u_inst, v_inst, h, T, S, CS->eqn_of_state, taux, tauy, CS->visc, dt));
   if (CS->vertvisc_CSp) {
-    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt));
+    CHECK(orc_vertvisc_coef_obc(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt, OBC));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
   }
   /* pass_eta, pass_visc_rem :610-611 */
   orc_halo_update(G, eta, MOM6HIP_POS_H, 1);
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   /* btcalc, bt_mass_source :627-630 */
-  if (!BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, NULL, NULL, 0));
+  if (!BT_cont_BT_thick) CHECK(orc_btcalc_obc(G, BT, h, NULL, NULL, 0, OBC));
   orc_bt_mass_source(G, BT, h, eta, 1);
   /* continuity for BT_cont and the layer fluxes :634-644 */
   if (BTC || CS->BT_use_layer_fluxes) {
-    CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL, CS->visc_rem_u, CS->visc_rem_v,
+    CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL, CS->visc_rem_u, CS->visc_rem_v,
                          NULL, NULL, BTC, NULL, NULL));
-    if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));
+    if (BT_cont_BT_thick) CHECK(orc_btcalc_obc(G, BT, h, BTC->h_u, BTC->h_v, 0, OBC));
   }
   if (calc_dtbt) orc_set_dtbt_eta(G, BT, eta, CS->pbce, NULL, 0.0, 0.0);                                        /* :651 */
   /* predictor btstep :655 */
   {
     const int lf = CS->BT_use_layer_fluxes;
-    CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
+    CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
                      CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
-                     NULL, lf ? uh_in : NULL, lf ? vh_in : NULL, lf ? u_inst : NULL, lf ? v_inst : NULL, NULL));
+                     NULL, lf ? uh_in : NULL, lf ? vh_in : NULL, lf ? u_inst : NULL, lf ? v_inst : NULL, NULL, OBC));
   }
   /* up = u + dt_pred*(u_bc_accel + u_accel_bt) :663-676 */
   const double dt_pred = dt * CS->be;
@@ -151,29 +160,32 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
   /* vertvisc_coef, vertvisc, vertvisc_remnant :717-744 */
   if (CS->vertvisc_CSp) {
-    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt_pred));
-    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL));
+    CHECK(orc_vertvisc_coef_obc(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt_pred, OBC));
+    CHECK(orc_vertvisc_obc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL, OBC));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt_pred));
   }
   /* pass_visc_rem :747, pass_uvp :751 */
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   pass3(G, up, MOM6HIP_POS_U); pass3(G, vp, MOM6HIP_POS_V);
   /* continuity :757 */
-  CHECK(orc_continuity(G, CS->continuity_CSp, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
+  CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
                        BTC, NULL, NULL));
   /* pass_hp_uv :763 */
   pass3(G, hp, MOM6HIP_POS_H); pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  if (OBC)                                                                                              /* :765-775 */
+    CHECK(orc_radiation_open_bdry_conds(G, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_av, u_old_rad_OBC, v_av,
+                                        v_old_rad_OBC, dt_pred));
   /* h_av :785-787 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
   orc_bt_mass_source(G, BT, hp, eta_pred, 0);                                                          /* :797 */
-  if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                           /* :843 */
+  if (BT_cont_BT_thick) CHECK(orc_btcalc_obc(G, BT, h, BTC->h_u, BTC->h_v, 0, OBC));                           /* :843 */
   /* horizontal_viscosity :860 (without it diffu stays 0) */
   if (CS->hor_visc)
-    CHECK(orc_horizontal_viscosity(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL));
+    CHECK(orc_horizontal_viscosity_obc(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL, OBC));
   /* CorAdCalc :869 */
-  CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
+  CHECK(orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
   /* u_bc_accel :879-886 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -182,12 +194,13 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       v_bc_accel[V3(i, J, k)] = (CS->CAv[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
   }
+  if (OBC) CHECK(orc_open_boundary_zero_normal_flow(G, OBC, u_bc_accel, v_bc_accel));                  /* :887-889 */
   /* corrector btstep :911 */
   {
     const int lf = CS->BT_use_layer_fluxes;
-    CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
+    CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
                      CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
-                     NULL, lf ? uh : NULL, lf ? vh : NULL, lf ? u_av : NULL, lf ? v_av : NULL, eta_av));
+                     NULL, lf ? uh : NULL, lf ? vh : NULL, lf ? u_av : NULL, lf ? v_av : NULL, eta_av, OBC));
   }
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[H2(i, j)] = eta_pred[H2(i, j)];   /* :918 */
   /* u = u + dt*(u_bc_accel + u_accel_bt) :928-939 */
@@ -200,8 +213,8 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
   /* vertvisc_coef, vertvisc, vertvisc_remnant :974-994 */
   if (CS->vertvisc_CSp) {
-    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, u_inst, v_inst, h, NULL, CS->visc, dt));
-    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL));
+    CHECK(orc_vertvisc_coef_obc(G, CS->vertvisc_CSp, u_inst, v_inst, h, NULL, CS->visc, dt, OBC));
+    CHECK(orc_vertvisc_obc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL, OBC));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
   }
   /* h_av = h :1000-1002 */
@@ -212,11 +225,14 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);
   /* continuity :1015 */
-  CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,
+  CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,
                        v_av, NULL, NULL, NULL));
   /* pass_h :1018, pass_av_uvh :1027 */
   pass3(G, h, MOM6HIP_POS_H);
   pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  if (OBC)                                                                                              /* :1030-1034 */
+    CHECK(orc_radiation_open_bdry_conds(G, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_inst, u_old_rad_OBC, v_inst,
+                                        v_old_rad_OBC, dt));
   /* h_av :1038-1040 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
@@ -230,13 +246,14 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
       vhtr[V3(i, J, k)] = vhtr[V3(i, J, k)] + vh[V3(i, J, k)] * dt;
   }
   if (CS->store_CAu) {   /* :1055-1069 */
-    CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
+    CHECK(orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
     CS->CAu_pred_stored = 1;
   } else {
     CS->CAu_pred_stored = 0;
   }
 done:
   free(up); free(vp); free(hp); free(u_bc_accel); free(v_bc_accel); free(uh_in); free(vh_in); free(eta_pred);
+  free(u_old_rad_OBC); free(v_old_rad_OBC);
   return rc;
 }
 
@@ -263,6 +280,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
   if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || (CS->vertvisc_CSp && !CS->visc) || !CS->du_av_inst || !CS->dv_av_inst)
     return 1;
+  if (CS->OBC) return 1;      /* (the open boundaries are built for SPLIT_RK2B = False only) */
   mom6hip_barotropic_cs_t *BT = CS->barotropic_CSp;
   const mom6hip_bt_cont_t *BTC = CS->BT_cont;
   const int BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;

@@ -699,8 +699,9 @@ class DynState:
 
     def __init__(self, grid, u, v, h, T, S, dt, use_bt_cont=True, be=0.6, BT_use_layer_fluxes=True, store_CAu=True,
                  bound_coriolis=True, dtbt=None, vertvisc=None, visc=None, eos_form="WRIGHT", hor_visc=None, rk2b=False, set_visc=None,
-                 pressureforce=None, continuity=None, coriolis=None, **bt_kw):
-        """rk2b: SPLIT_RK2B (MOM_dynamics_split_RK2b.F90); u, v are then the filtered velocities."""
+                 pressureforce=None, continuity=None, coriolis=None, OBC=None, **bt_kw):
+        """rk2b: SPLIT_RK2B (MOM_dynamics_split_RK2b.F90); u, v are then the filtered velocities.  OBC: CS%OBC (an ocean_OBC_type of
+        mom6_amd/open_boundary.py with numpy arrays: its segments' normal_vel and its rx_normal / ry_normal are updated in place)."""
         g = self.grid = grid
         self.rk2b = bool(rk2b)
         self.u, self.v, self.h, self.T, self.S = (np.ascontiguousarray(a).copy() for a in (u, v, h, T, S))
@@ -729,6 +730,10 @@ class DynState:
         if set_visc is not None:      # a set_visc_cs(...) struct with dynamic_viscous_ML: set_viscous_ML at :592
             self.svcs = set_visc
             cs.set_visc_CSp = C.addressof(set_visc)
+        if OBC is not None:
+            self.OBC = OBC
+            self.obc = OBC.struct()
+            cs.OBC = C.addressof(self.obc)
         self.arrs = {}
         for n, pos in _abi.RK2_ARRAYS_3D:
             self.arrs[n] = grid.zeros3(pos); setattr(cs, n, self.arrs[n].ctypes.data)

@@ -1,0 +1,185 @@
+"""step_MOM_dyn_split_RK2 with CS%OBC associated (src/core/MOM_dynamics_split_RK2.F90:444-456 the starting velocities of the radiation,
+:565-567 and :887-889 open_boundary_zero_normal_flow on u_bc_accel, :765-775 and :1030-1034 radiation_open_bdry_conds on u_av and u_inst, and
+the OBC argument of vertvisc_coef, btcalc, continuity, btstep, vertvisc, horizontal_viscosity and CorAdCalc): the oracle's step with the
+segments of .testing/tc3 (four FLATHER,ORLANSKI segments with zero external data, OBC_FREESLIP_VORTICITY, OBC_FREESLIP_STRAIN,
+OBC_ZERO_BIHARMONIC) against what those lines state and against a quarter turn of the grid, on the CPU; the library's step against the
+oracle on the GPU, bit for bit.  (The reference holds no answers for tc3 in the tree: parity unpinned.)"""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi, synth
+from mom6_amd.open_boundary import ocean_OBC_type
+from oracle import orc
+from rotation import rot, rot_vector, rotate_grid, unrot, unrot_vector
+from test_continuity_obc import TC3, open_faces, turned_segments
+
+U, V, H = _abi.POS_U, _abi.POS_V, _abi.POS_H
+DT = 900.0
+TC3_FLAGS = dict(freeslip_vorticity=True, freeslip_strain=True, zero_biharmonic=True)
+HV = dict(Laplacian=1, Kh_vel_scale=0.01, Ah_vel_scale=0.05, Smagorinsky_Ah=1, Smag_bi_const=0.06)
+
+
+def rk2_obc_case(segs=TC3, ni=22, nj=16, nk=3, seed=4, flags=TC3_FLAGS, land_frac=0.1, gamma_uv=0.3):
+    g = synth.make_grid(ni, nj, nk, land_frac=land_frac, seed=seed + 300, reentrant_x=False, reentrant_y=False)
+    OBC = None
+    if segs is not None:
+        OBC = ocean_OBC_type(g, segs, gamma_uv=gamma_uv, rx_max=10.0, **flags)
+        open_faces(g, OBC)
+        OBC.rx_normal, OBC.ry_normal = g.zeros3(U), g.zeros3(V)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.1, eta_amp=0.2).items()}
+    yy = np.linspace(0.0, np.pi, g.shape2(U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu)
+    tauy = np.ascontiguousarray(0.0 * g.mask2dCv)
+    return g, d, taux, tauy, OBC
+
+
+def visc_arrays(g, seed=9):
+    rng = np.random.default_rng(seed)
+    su, sv = g.shape2(U), g.shape2(V)
+    return dict(Kv_bbl_u=1.0e-3 * (0.5 + rng.random(su)), Kv_bbl_v=1.0e-3 * (0.5 + rng.random(sv)),
+                bbl_thick_u=2.0 + 8.0 * rng.random(su), bbl_thick_v=2.0 + 8.0 * rng.random(sv))
+
+
+def oracle_state(g, d, OBC, viscous=True, bbl=None, **kw):
+    extra = {}
+    if viscous:
+        extra = dict(vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0), visc=orc.vertvisc_type(**(bbl or visc_arrays(g))),
+                     hor_visc=orc.hor_visc_cs(g, DT, **HV))
+    st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], DT, OBC=OBC, **extra, **kw)
+    st.bcs.dtbt = DT / 12.6
+    return st
+
+
+def test_an_OBC_without_segments_is_the_closed_step():
+    g, d, taux, tauy, _ = rk2_obc_case(segs=None)
+    a = oracle_state(g, d, None); b = oracle_state(g, d, ocean_OBC_type(g, []))
+    for n in range(2):
+        a.step(taux, tauy); b.step(taux, tauy)
+    assert bits_equal(a.u, b.u) and bits_equal(a.h, b.h) and bits_equal(a.uh, b.uh)
+
+
+@pytest.mark.parametrize("viscous", [False, True])
+def test_oracle_step_with_tc3_segments_lets_the_flow_through(viscous):
+    g, d, taux, tauy, OBC = rk2_obc_case()
+    st = oracle_state(g, d, OBC, viscous)
+    closed_g, cd, _, _, _ = rk2_obc_case(segs=None)
+    cl = oracle_state(closed_g, cd, None, viscous)
+    vol = lambda gg, h: float((interior(gg, h) * interior(gg, gg.areaT)[None] * interior(gg, gg.mask2dT)[None]).sum())
+    v0 = vol(g, st.h)
+    for n in range(4):
+        st.step(taux, tauy); cl.step(taux, tauy)
+        assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0
+    on_u, on_v = OBC.segnum_u != 0, OBC.segnum_v != 0
+    # the faces of the segments carry flow (they are walls in the closed domain) and the volume of the domain changes with it
+    assert np.abs(st.u[:, on_u]).max() > 1e-4 and np.abs(st.v[:, on_v]).max() > 1e-4
+    assert np.abs(cl.u[:, on_u]).max() == 0.0
+    assert abs(vol(g, st.h) - v0) > 1e-9 * v0 and abs(vol(closed_g, cl.h) - vol(closed_g, cd["h"])) <= 1e-9 * v0
+    # the radiation left its rates and the velocities it set on the segments (:2345)
+    assert np.abs(OBC.rx_normal[:, on_u]).max() > 0 and np.abs(OBC.ry_normal[:, on_v]).max() > 0
+    assert any(np.abs(s.normal_vel).max() > 0 for s in OBC.segment if s.on_pe)
+    # the normal velocity of a radiating face is the one radiation_open_bdry_conds kept for it (open_boundary_apply_normal_flow :3337)
+    for s in OBC.segment:
+        hi = s.HI
+        if s.is_E_or_W:
+            got = st.u[:, hi["jsd"] - 1:hi["jed"], hi["IsdB"]]
+            assert bits_equal(got[:, 4:-4], s.normal_vel[:, 4:-4, 0])
+        else:
+            got = st.v[:, hi["JsdB"], hi["isd"] - 1:hi["ied"]]
+            assert bits_equal(got[:, 4:-4], s.normal_vel[:, 0, 4:-4])
+
+
+@pytest.mark.parametrize("viscous", [False, True])
+def test_oracle_step_turns_with_the_grid(viscous):
+    """the reference writes E / W / N / S and u / v out separately in every operator of the step: a quarter turn of the grid, the state and
+    the segments gives the turned answers bit for bit"""
+    g, d, taux, tauy, OBC = rk2_obc_case()
+    bbl = visc_arrays(g)
+    a = oracle_state(g, d, OBC, viscous, bbl=bbl)
+    gr = rotate_grid(g)
+    OBCr = ocean_OBC_type(gr, turned_segments(TC3, g.ni, g.nj), gamma_uv=0.3, rx_max=10.0, **TC3_FLAGS)
+    OBCr.rx_normal, OBCr.ry_normal = gr.zeros3(U), gr.zeros3(V)
+    ur, vr = rot_vector(d["u"], d["v"])
+    dr = dict(u=ur, v=vr, h=rot(d["h"]), T=rot(d["T"]), S=rot(d["S"]))
+    # (positive definite face fields turn as a scalar pair)
+    bblr = dict(Kv_bbl_u=rot(bbl["Kv_bbl_v"]), Kv_bbl_v=rot(bbl["Kv_bbl_u"]), bbl_thick_u=rot(bbl["bbl_thick_v"]), bbl_thick_v=rot(bbl["bbl_thick_u"]))
+    b = oracle_state(gr, dr, OBCr, viscous, bbl=bblr)
+    txr, tyr = rot_vector(taux, tauy)
+    for n in range(3):
+        a.step(taux, tauy); b.step(txr, tyr)
+        bu, bv = unrot_vector(b.u, b.v)      # (a zero that changes sign with its component is still that zero: values, not bits)
+        assert np.array_equal(interior(g, bu, U), interior(g, a.u, U)), (n, "u")
+        assert np.array_equal(interior(g, bv, V), interior(g, a.v, V)), (n, "v")
+        assert bits_equal(interior(g, unrot(b.h)), interior(g, a.h)), (n, "h")
+    assert np.array_equal(interior(g, unrot(OBCr.ry_normal), U), interior(g, OBC.rx_normal, U))
+
+
+# ---- the library against the oracle, on the GPU ----
+
+def gpu_run(g, d, taux, tauy, OBC, viscous, bbl, nsteps, check):
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    from test_hor_visc import REF_NAMES
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    kw = dict(vertvisc=dict(KV=1.0e-3, HBBL=10.0), hor_visc={REF_NAMES[k]: x for k, x in HV.items()}) if viscous else {}
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, DT, dg, coriolis=dict(bound_coriolis=True), OBC=None if OBC is None else OBC.cuda(), **kw)
+    CS.barotropic_CSp.st.dtbt = DT / 12.6
+    visc = vertvisc_type(**{n: T(a) for n, a in bbl.items()}) if viscous else None
+    tx, ty = T(taux), T(tauy)
+    for n in range(nsteps):
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, DT, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS)
+        dg.sync()
+        check(n, dict(u=u, v=v, h=h, uh=uh, vh=vh, uhtr=uhtr, eta_av=eta_av, u_av=CS.u_av, v_av=CS.v_av, diffu=CS.diffu, eta=CS.eta,
+                      CAu_pred=CS.CAu_pred))
+    dg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("viscous", [False, True])
+@pytest.mark.parametrize("segs", [TC3, TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"], ["I=N,J=0:N,FLATHER,ORLANSKI", "J=7,I=N:0,SIMPLE"]],
+                         ids=["tc3", "mixed", "inner"])
+def test_gpu_step_with_open_boundaries_matches_oracle_bitwise(segs, viscous):
+    for (ni, nj, nk, seed) in [(22, 16, 3, 4), (60, 44, 2, 7)]:
+        g, d, taux, tauy, OBC = rk2_obc_case(segs, ni=ni, nj=nj, nk=nk, seed=seed)
+        rng = np.random.default_rng(seed)
+        for s in OBC.segment:      # external values of the specified and Flather segments
+            if s.on_pe and s.specified:
+                s.normal_vel[:] = 0.05 * rng.standard_normal(s.normal_vel.shape)
+                s.normal_trans[:] = s.normal_vel * (3.0e4 * (5.0 + 50.0 * rng.random(s.normal_vel.shape)))
+            if s.on_pe and s.Flather:
+                s.normal_vel_bt[:] = 0.02 * rng.standard_normal(s.normal_vel_bt.shape); s.SSH[:] = 0.05 * rng.standard_normal(s.SSH.shape)
+        bbl = visc_arrays(g)
+        import copy
+        OBCo = copy.deepcopy(OBC)
+        ref = oracle_state(g, d, OBCo, viscous, bbl=bbl)
+
+        def check(n, f):
+            ref.step(taux, tauy)
+            want = dict(u=ref.u, v=ref.v, h=ref.h, uh=ref.uh, vh=ref.vh, uhtr=ref.uhtr, eta_av=ref.eta_av, u_av=ref.arrs["u_av"], v_av=ref.arrs["v_av"],
+                        diffu=ref.arrs["diffu"], eta=ref.arrs["eta"], CAu_pred=ref.arrs["CAu_pred"])
+            for name, a in f.items():
+                an = a.cpu().numpy()
+                assert bits_equal(an, want[name]), (segs, viscous, ni, n, name, np.argwhere(an != want[name])[:4].tolist())
+            assert bits_equal(OBC.rx_normal.cpu().numpy(), OBCo.rx_normal) and bits_equal(OBC.ry_normal.cpu().numpy(), OBCo.ry_normal), (n, "rx_normal")
+            for s, so in zip(OBC.segment, OBCo.segment):
+                if s.on_pe and s.normal_vel is not None:
+                    assert bits_equal(s.normal_vel.cpu().numpy(), so.normal_vel), (n, "segment%normal_vel")
+        gpu_run(g, d, taux, tauy, OBC, viscous, bbl, 3, check)
+
+
+@pytest.mark.gpu
+def test_gpu_step_with_an_OBC_without_segments_is_the_closed_step():
+    g, d, taux, tauy, _ = rk2_obc_case(segs=None)
+    bbl = visc_arrays(g)
+    out = []
+    for OBC in (None, ocean_OBC_type(g, [])):
+        got = {}
+        gpu_run(g, d, taux, tauy, OBC, True, bbl, 2, lambda n, f: got.update({k: a.cpu().numpy().copy() for k, a in f.items()}))
+        out.append(got)
+    assert all(bits_equal(out[0][k], out[1][k]) for k in out[0])
