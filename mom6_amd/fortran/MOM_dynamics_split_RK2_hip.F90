@@ -29,7 +29,7 @@ module MOM_dynamics_split_RK2
 use, intrinsic :: iso_c_binding
 use mom6hip_c_api
 use mom6hip_MOM_glue,          only : mom6hip_shared_context, mom6hip_fatal_if, mom6hip_read_resident, mom6hip_mirror
-use mom6hip_MOM_glue,          only : mom6hip_mirrors_stage, mom6hip_mirrors_host_was_modified, mom6hip_mirrors_end
+use mom6hip_MOM_glue,          only : mom6hip_mirrors_stage, mom6hip_mirrors_host_was_modified, mom6hip_mirrors_end, mom6hip_obc_to_c
 use MOM_variables,             only : vertvisc_type, thermo_var_ptrs, porous_barrier_type
 use MOM_variables,             only : BT_cont_type, alloc_BT_cont_type
 use MOM_variables,             only : accel_diag_ptrs, ocean_internal_state, cont_diag_ptrs
@@ -52,7 +52,7 @@ use MOM_hor_index,             only : hor_index_type
 use MOM_hor_visc,              only : hor_visc_CS, hor_visc_init, hor_visc_end, hor_visc_hip_struct
 use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_MEKE_types,            only : MEKE_type
-use MOM_open_boundary,         only : ocean_OBC_type
+use MOM_open_boundary,         only : ocean_OBC_type, OBC_segment_type
 use MOM_PressureForce_FV,      only : PressureForce_FV_CS, PressureForce_FV_init, PressureForce_FV_hip_struct
 use MOM_set_visc,              only : set_visc_CS, set_visc_hip_struct
 use MOM_stochastics,           only : stochastic_CS
@@ -104,6 +104,9 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   type(mom6hip_hor_visc_cs_t)      :: c_hv
   type(mom6hip_set_visc_cs_t)      :: c_sv
   type(mom6hip_dyn_split_rk2_cs_t) :: c_rk2
+  type(ocean_OBC_type), pointer :: OBC => NULL()     !< CS%OBC (:253)
+  type(mom6hip_obc_t) :: c_obc                       !< the library's view of it: device mirrors of the segments' arrays
+  type(mom6hip_obc_segment_t), allocatable :: c_obc_segs(:)
   logical :: use_EOS = .true., use_BT_cont = .true.
   integer(c_int64_t) :: nh2 = 0, nu2 = 0, nv2 = 0, nq2 = 0, nh3 = 0, nu3 = 0, nv3 = 0      !< array sizes in doubles
   type(c_ptr) :: d_owned(96) = c_null_ptr      !< what end_dyn_split_RK2 frees
@@ -280,6 +283,7 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
     if (allocated(MEKE%GME_snk)) MEKE%GME_snk(:,:) = 0.0
   endif
 
+  call obc_mirrors(CS)
   rc = mom6hip_step_dyn_split_rk2(CS%ctx, CS%c_rk2, d_u, d_v, d_h, d_T, d_S, real(dt, c_double), d_tx, d_ty, &
                                   real(GV%Z_to_H / GV%Rho0, c_double), d_uh, d_vh, d_uhtr, d_vhtr, d_eta_av, &
                                   merge(1_c_int32_t, 0_c_int32_t, calc_dtbt))
@@ -297,6 +301,45 @@ contains
     call MOM_error(FATAL, "step_MOM_dyn_split_RK2 (HIP): "//what//" is not provided by the GPU path.")
   end subroutine refuse
 end subroutine step_MOM_dyn_split_RK2
+
+!> CS%OBC as the library's step reads it: the flags, segnum_u / segnum_v and the segments' ranges as mom6hip_obc_to_c states them (host
+!! tables), the segments' own arrays and OBC%rx_normal / ry_normal as device mirrors (the step writes segment%normal_vel of the radiating
+!! segments and the two rates).  A host routine that changes a segment's data between steps says so with mom6hip_mirror_host_changed.
+subroutine obc_mirrors(CS)
+  type(MOM_dyn_split_RK2_CS), target, intent(inout) :: CS
+  type(OBC_segment_type), pointer :: seg
+  integer :: n
+  logical :: rad
+  CS%c_rk2%OBC = c_null_ptr
+  if (.not.associated(CS%OBC)) return
+  call mom6hip_obc_to_c(CS%OBC, CS%c_obc, CS%c_obc_segs, int(CS%nu2), int(CS%nv2), "MOM_dynamics_split_RK2")
+  do n = 1, CS%OBC%number_of_segments
+    seg => CS%OBC%segment(n)
+    if (.not.seg%on_pe) cycle
+    rad = seg%radiation .or. seg%gradient .or. seg%nudged
+    CS%c_obc_segs(n)%normal_trans = c_null_ptr ; CS%c_obc_segs(n)%normal_vel = c_null_ptr ; CS%c_obc_segs(n)%normal_vel_bt = c_null_ptr
+    CS%c_obc_segs(n)%SSH = c_null_ptr ; CS%c_obc_segs(n)%tangential_vel = c_null_ptr ; CS%c_obc_segs(n)%tangential_grad = c_null_ptr
+    CS%c_obc_segs(n)%nudged_normal_vel = c_null_ptr
+    if (allocated(seg%normal_trans)) CS%c_obc_segs(n)%normal_trans = &
+        mirror(CS, c_loc(seg%normal_trans), int(size(seg%normal_trans), c_int64_t), .true., .false.)
+    if (allocated(seg%normal_vel)) CS%c_obc_segs(n)%normal_vel = &
+        mirror(CS, c_loc(seg%normal_vel), int(size(seg%normal_vel), c_int64_t), .true., rad)
+    if (allocated(seg%normal_vel_bt)) CS%c_obc_segs(n)%normal_vel_bt = &
+        mirror(CS, c_loc(seg%normal_vel_bt), int(size(seg%normal_vel_bt), c_int64_t), .true., .false.)
+    if (allocated(seg%SSH)) CS%c_obc_segs(n)%SSH = mirror(CS, c_loc(seg%SSH), int(size(seg%SSH), c_int64_t), .true., .false.)
+    if (allocated(seg%tangential_vel)) CS%c_obc_segs(n)%tangential_vel = &
+        mirror(CS, c_loc(seg%tangential_vel), int(size(seg%tangential_vel), c_int64_t), .true., .false.)
+    if (allocated(seg%tangential_grad)) CS%c_obc_segs(n)%tangential_grad = &
+        mirror(CS, c_loc(seg%tangential_grad), int(size(seg%tangential_grad), c_int64_t), .true., .false.)
+    if (allocated(seg%nudged_normal_vel)) CS%c_obc_segs(n)%nudged_normal_vel = &
+        mirror(CS, c_loc(seg%nudged_normal_vel), int(size(seg%nudged_normal_vel), c_int64_t), .true., .false.)
+  enddo
+  CS%c_obc%gamma_uv = CS%OBC%gamma_uv ; CS%c_obc%rx_max = CS%OBC%rx_max
+  CS%c_obc%rx_normal = c_null_ptr ; CS%c_obc%ry_normal = c_null_ptr
+  if (allocated(CS%OBC%rx_normal)) CS%c_obc%rx_normal = mirror(CS, c_loc(CS%OBC%rx_normal), CS%nu3, .true., .true.)
+  if (allocated(CS%OBC%ry_normal)) CS%c_obc%ry_normal = mirror(CS, c_loc(CS%OBC%ry_normal), CS%nv3, .true., .true.)
+  CS%c_rk2%OBC = c_loc(CS%c_obc)
+end subroutine obc_mirrors
 
 !> The members of visc and forces%ustar that the step reads (or, for nkml_visc_u/v, writes), as device mirrors in the library's struct
 subroutine visc_mirrors(CS, visc, forces)
@@ -452,7 +495,12 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   endif
   CS%module_is_initialized = .true.
   CS%diag => diag
-  if (associated(OBC)) call refuse(.true., "open boundary conditions")
+  if (associated(OBC)) then      ! :1516-1519.  The segments' data are the host's business (MOM_open_boundary, MOM_boundary_update)
+    CS%OBC => OBC
+    call refuse(OBC%update_OBC, "OBC%update_OBC (update_OBC_data inside the step)")
+    call refuse(OBC%ramp, "OBC_RAMP")
+    call refuse(OBC%oblique_BCs_exist_globally, "oblique open boundary conditions")
+  endif
   if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
 
   call log_version(param_file, mdl, version, "")
@@ -574,6 +622,7 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   if (allocated(MEKE%Ku)) CS%c_hv%MEKE_Ku = mirror(CS, c_loc(MEKE%Ku), CS%nh2, .true., .false.)
   if (allocated(MEKE%Au)) CS%c_hv%MEKE_Au = mirror(CS, c_loc(MEKE%Au), CS%nh2, .true., .false.)
   if (VarMix%use_variable_mixing .and. VarMix%Resoln_scaled_Kh .and. (CS%c_hv%Laplacian /= 0)) call refuse(.true., "RESOLN_SCALED_KH with LAPLACIAN")
+  call obc_mirrors(CS)
   rc = mom6hip_dyn_split_rk2_init(CS%ctx, CS%c_rk2, d_u, d_v, d_h, d_uh, d_vh, real(dt, c_double))
   call mom6hip_fatal_if(rc, "initialize_dyn_split_RK2")
   call from_restart(c_loc(CS%eta), CS%c_rk2%eta, CS%nh2, query_initialized(CS%eta, "sfc", restart_CS))

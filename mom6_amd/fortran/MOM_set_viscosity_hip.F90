@@ -100,21 +100,29 @@ subroutine set_viscous_BBL(u, v, h, tv, visc, G, GV, US, CS, pbv)
   eos = CS%eos
   CS%st%Rlay = c_null_ptr ; if (allocated(CS%Rlay)) CS%st%Rlay = c_loc(CS%Rlay)
   ctx = mom6hip_shared_context(G, GV)
-  if (associated(CS%OBC)) then      ! the OBC branches :374-413, :502-580 and those of set_v_at_u / set_u_at_v, on the host arrays
-    if (mom6hip_resident()) call MOM_error(FATAL, "set_viscous_BBL (HIP): open boundaries with GPU_RESIDENT_DYNAMICS are not provided.")
-    call mom6hip_obc_to_c(CS%OBC, cobc, csegs, size(u(:,:,1)), size(v(:,:,1)), "MOM_set_viscosity")
-    rc = mom6hip_set_viscous_bbl_obc(ctx, CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, cobc, MOM6HIP_MEM_HOST)
-  elseif (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: u, v, h, T, S where the step left them; visc%... where the step reads them
+  ! the OBC branches :374-413, :502-580 and those of set_v_at_u / set_u_at_v read the segments' directions and ranges (host tables), none of
+  ! their arrays
+  if (associated(CS%OBC)) call mom6hip_obc_to_c(CS%OBC, cobc, csegs, size(u(:,:,1)), size(v(:,:,1)), "MOM_set_viscosity")
+  if (mom6hip_resident()) then      ! GPU_RESIDENT_DYNAMICS: u, v, h, T, S where the step left them; visc%... where the step reads them
     call to_dev(cv%Kv_bbl_u, size(visc%Kv_bbl_u), .true.) ; call to_dev(cv%Kv_bbl_v, size(visc%Kv_bbl_v), .true.)
     call to_dev(cv%bbl_thick_u, size(visc%bbl_thick_u), .true.) ; call to_dev(cv%bbl_thick_v, size(visc%bbl_thick_v), .true.)
     if (allocated(visc%Ray_u)) then
       call to_dev(cv%Ray_u, size(visc%Ray_u), .true.) ; call to_dev(cv%Ray_v, size(visc%Ray_v), .true.)
     endif
     call to_dev(p_T, size(h), .false.) ; call to_dev(p_S, size(h), .false.)
-    rc = mom6hip_set_viscous_bbl(ctx, CS%st, mom6hip_mirror(ctx, c_loc(u), int(size(u), c_int64_t), .true., .false.), &
-                                 mom6hip_mirror(ctx, c_loc(v), int(size(v), c_int64_t), .true., .false.), &
-                                 mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), p_T, p_S, c_loc(eos), cv, &
-                                 MOM6HIP_MEM_DEVICE)
+    if (associated(CS%OBC)) then
+      rc = mom6hip_set_viscous_bbl_obc(ctx, CS%st, mom6hip_mirror(ctx, c_loc(u), int(size(u), c_int64_t), .true., .false.), &
+                                       mom6hip_mirror(ctx, c_loc(v), int(size(v), c_int64_t), .true., .false.), &
+                                       mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), p_T, p_S, c_loc(eos), cv, &
+                                       cobc, MOM6HIP_MEM_DEVICE)
+    else
+      rc = mom6hip_set_viscous_bbl(ctx, CS%st, mom6hip_mirror(ctx, c_loc(u), int(size(u), c_int64_t), .true., .false.), &
+                                   mom6hip_mirror(ctx, c_loc(v), int(size(v), c_int64_t), .true., .false.), &
+                                   mom6hip_mirror(ctx, c_loc(h), int(size(h), c_int64_t), .true., .false.), p_T, p_S, c_loc(eos), cv, &
+                                   MOM6HIP_MEM_DEVICE)
+    endif
+  elseif (associated(CS%OBC)) then
+    rc = mom6hip_set_viscous_bbl_obc(ctx, CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, cobc, MOM6HIP_MEM_HOST)
   else
     rc = mom6hip_set_viscous_bbl(ctx, CS%st, c_loc(u), c_loc(v), c_loc(h), p_T, p_S, c_loc(eos), cv, MOM6HIP_MEM_HOST)
   endif

@@ -508,6 +508,9 @@ contains
     if (allocated(seg%SSH)) c%SSH = c_loc(seg%SSH)
     if (allocated(seg%tangential_vel)) c%tangential_vel = c_loc(seg%tangential_vel)
     if (allocated(seg%tangential_grad)) c%tangential_grad = c_loc(seg%tangential_grad)
+    if (allocated(seg%nudged_normal_vel)) c%nudged_normal_vel = c_loc(seg%nudged_normal_vel)
+    c%Velocity_nudging_timescale_in = seg%Velocity_nudging_timescale_in
+    c%Velocity_nudging_timescale_out = seg%Velocity_nudging_timescale_out
   end subroutine segment_to_c
 end subroutine mom6hip_obc_to_c
 

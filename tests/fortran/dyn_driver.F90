@@ -73,9 +73,14 @@ real :: scal(7), dt, dtbt_in, dtbt_reset_period, dt_therm
 real, allocatable, target, dimension(:,:,:) :: u, v, h, uh, vh, uhtr, vhtr
 real, allocatable, target, dimension(:,:) :: eta, eta_av
 real, allocatable, dimension(:,:) :: nk_u, nk_v
-character(len=512) :: f_in, f_out, f_par, line
+character(len=512) :: f_in, f_out, f_par, f_obc, line
+integer(c_int32_t) :: oflags(8), sflags(20), gflags(8)
+integer(c_int32_t), allocatable :: seg_u(:,:), seg_v(:,:)
+integer :: u_obc, nseg, m, i0, i1, j0, j1
+real :: oscal(2)
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out) ; call get_command_argument(3, f_par)
+f_obc = "" ; if (command_argument_count() >= 4) call get_command_argument(4, f_obc)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
 read(u_in) hdr, hdr2
 ni = hdr(1) ; nj = hdr(2) ; nk = hdr(3) ; halo = hdr(4)
@@ -132,6 +137,51 @@ do
 enddo
 close(u_par)
 
+! ---- the open boundaries as open_boundary_config / open_boundary_init and the first update_OBC_segment_data leave them (a fourth argument):
+! [number_of_segments, OBC_pe, open_u, open_v, specified_u, specified_v, Flather_u, Flather_v], [zero_vorticity, freeslip_vorticity,
+! computed_vorticity, specified_vorticity, zero_strain, freeslip_strain, computed_strain, zero_biharmonic], gamma_uv, rx_max, per segment
+! [direction, open, specified, on_pe, is_E_or_W, is_N_or_S, IsdB, IedB, JsdB, JedB, isd, ied, jsd, jed, Flather, radiation, gradient,
+! nudged, 0, 0], segnum_u, segnum_v, and for every segment on the PE normal_vel, normal_trans, normal_vel_bt, SSH
+if (len_trim(f_obc) > 0) then
+  open(newunit=u_obc, file=trim(f_obc), access="stream", form="unformatted", status="old")
+  allocate(OBC)
+  read(u_obc) oflags, gflags, oscal
+  nseg = oflags(1)
+  OBC%number_of_segments = nseg ; OBC%OBC_pe = (oflags(2) /= 0)
+  OBC%open_u_BCs_exist_globally = (oflags(3) /= 0) ; OBC%open_v_BCs_exist_globally = (oflags(4) /= 0)
+  OBC%specified_u_BCs_exist_globally = (oflags(5) /= 0) ; OBC%specified_v_BCs_exist_globally = (oflags(6) /= 0)
+  OBC%Flather_u_BCs_exist_globally = (oflags(7) /= 0) ; OBC%Flather_v_BCs_exist_globally = (oflags(8) /= 0)
+  OBC%zero_vorticity = (gflags(1) /= 0) ; OBC%freeslip_vorticity = (gflags(2) /= 0) ; OBC%computed_vorticity = (gflags(3) /= 0)
+  OBC%specified_vorticity = (gflags(4) /= 0) ; OBC%zero_strain = (gflags(5) /= 0) ; OBC%freeslip_strain = (gflags(6) /= 0)
+  OBC%computed_strain = (gflags(7) /= 0) ; OBC%zero_biharmonic = (gflags(8) /= 0)
+  OBC%gamma_uv = oscal(1) ; OBC%rx_max = oscal(2)
+  allocate(OBC%segment(nseg))
+  do m=1,nseg
+    read(u_obc) sflags
+    OBC%segment(m)%direction = sflags(1) ; OBC%segment(m)%open = (sflags(2) /= 0) ; OBC%segment(m)%specified = (sflags(3) /= 0)
+    OBC%segment(m)%on_pe = (sflags(4) /= 0) ; OBC%segment(m)%is_E_or_W = (sflags(5) /= 0) ; OBC%segment(m)%is_N_or_S = (sflags(6) /= 0)
+    OBC%segment(m)%HI%IsdB = sflags(7) ; OBC%segment(m)%HI%IedB = sflags(8) ; OBC%segment(m)%HI%JsdB = sflags(9) ; OBC%segment(m)%HI%JedB = sflags(10)
+    OBC%segment(m)%HI%isd = sflags(11) ; OBC%segment(m)%HI%ied = sflags(12) ; OBC%segment(m)%HI%jsd = sflags(13) ; OBC%segment(m)%HI%jed = sflags(14)
+    OBC%segment(m)%Flather = (sflags(15) /= 0) ; OBC%segment(m)%radiation = (sflags(16) /= 0) ; OBC%segment(m)%gradient = (sflags(17) /= 0)
+    OBC%segment(m)%nudged = (sflags(18) /= 0)
+  enddo
+  allocate(seg_u(isd-1:ied,jsd:jed), seg_v(isd:ied,jsd-1:jed), OBC%segnum_u(isd-1:ied,jsd:jed), OBC%segnum_v(isd:ied,jsd-1:jed))
+  read(u_obc) seg_u, seg_v
+  OBC%segnum_u(:,:) = seg_u(:,:) ; OBC%segnum_v(:,:) = seg_v(:,:)
+  do m=1,nseg ; if (OBC%segment(m)%on_pe) then
+    if (OBC%segment(m)%is_E_or_W) then
+      i0 = OBC%segment(m)%HI%IsdB ; i1 = OBC%segment(m)%HI%IedB ; j0 = OBC%segment(m)%HI%jsd ; j1 = OBC%segment(m)%HI%jed
+    else
+      i0 = OBC%segment(m)%HI%isd ; i1 = OBC%segment(m)%HI%ied ; j0 = OBC%segment(m)%HI%JsdB ; j1 = OBC%segment(m)%HI%JedB
+    endif
+    allocate(OBC%segment(m)%normal_vel(i0:i1,j0:j1,nk), OBC%segment(m)%normal_trans(i0:i1,j0:j1,nk), OBC%segment(m)%normal_vel_bt(i0:i1,j0:j1), &
+             OBC%segment(m)%SSH(i0:i1,j0:j1))
+    read(u_obc) OBC%segment(m)%normal_vel, OBC%segment(m)%normal_trans, OBC%segment(m)%normal_vel_bt, OBC%segment(m)%SSH
+  endif ; enddo
+  allocate(OBC%rx_normal(isd-1:ied,jsd:jed,nk), source=0.0) ; allocate(OBC%ry_normal(isd:ied,jsd-1:jed,nk), source=0.0)
+  close(u_obc)
+endif
+
 ! ---- MOM.F90's initialisation order for these modules
 call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
 ! the two lateral parameterisations beside the step accept the same parameter file (MOM.F90:2854, :3305-3313)
@@ -175,6 +225,10 @@ if (allocated(visc%nkml_visc_u)) then ; nk_u = visc%nkml_visc_u ; nk_v = visc%nk
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) u, v, h, uh, vh, uhtr, vhtr, eta_av, nk_u, nk_v
 if (allocated(MEKE%mom_src)) write(u_out) MEKE%mom_src
+if (associated(OBC)) then
+  write(u_out) OBC%rx_normal, OBC%ry_normal
+  do m=1,OBC%number_of_segments ; if (OBC%segment(m)%on_pe) write(u_out) OBC%segment(m)%normal_vel ; enddo
+endif
 close(u_out)
 call end_dyn_split_RK2(CS)
 call set_visc_end(visc, SV)

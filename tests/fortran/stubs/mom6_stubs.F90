@@ -1222,7 +1222,8 @@ type :: OBC_segment_type
   integer :: direction = 0
   type(hor_index_type) :: HI
   real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:), tangential_vel(:,:,:), tangential_grad(:,:,:)
-  real, allocatable :: SSH(:,:)
+  real, allocatable :: SSH(:,:), nudged_normal_vel(:,:,:)
+  real :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
 end type OBC_segment_type
 type :: ocean_OBC_type
   logical :: OBC_pe = .false.
@@ -1236,6 +1237,8 @@ type :: ocean_OBC_type
   logical :: ramp = .false., zero_vorticity = .false., freeslip_vorticity = .false., computed_vorticity = .false.
   logical :: specified_vorticity = .false., zero_strain = .false., freeslip_strain = .false., computed_strain = .false.
   logical :: specified_strain = .false., zero_biharmonic = .false.
+  real :: gamma_uv = 0.3, rx_max = 1.0
+  real, allocatable :: rx_normal(:,:,:), ry_normal(:,:,:)
 end type ocean_OBC_type
 contains
 logical function open_boundary_query(OBC, apply_open_OBC, apply_specified_OBC, apply_Flather_OBC, apply_nudged_OBC, needs_ext_seg_data)

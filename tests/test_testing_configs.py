@@ -250,19 +250,22 @@ def lateral_fields(name, g):
 LATERAL_ORDER = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "Res_fn_h", "Rd_dx_h", "slope_x", "slope_y")
 
 
-def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
+def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime, OBC=None):
     """The oracle's control structures as the reference's *_init routines would set them from the pairs (defaults cited)."""
     from oracle import orc
     p = pairs_of(name)
     nk = g.nk
     dt = float(p["DT"])
     use_ALE = _b(p, "USE_REGRIDDING")                                   # MOM.F90:2271
-    bulkml = not use_ALE                                               # BULKMIXEDLAYER default (MOM.F90:2296-2303, with temperature)
+    thermo = _b(p, "ENABLE_THERMODYNAMICS", True)                      # MOM.F90:2253 (False: no temperature, no equation of state)
+    bulkml = (not use_ALE) and thermo                                  # BULKMIXEDLAYER default (MOM.F90:2296-2303, with temperature)
     nkml, nkbl = (2, 2) if bulkml else (0, 0)                          # NKML, NKBL defaults (MOM.F90:2439-2444)
     eosn = p.get("EQN_OF_STATE", "WRIGHT")                             # MOM_EOS.F90 EQN_OF_STATE default
     E = orc.eos("LINEAR", 1000.0, -0.2, _f(p, "DRHO_DS", 0.8)) if eosn == "LINEAR" else orc.eos(eosn)      # RHO_T0_S0, DRHO_DT, DRHO_DS
+    if not thermo:
+        E = None
     pf = dict(reconstruct=_b(p, "RECONSTRUCT_FOR_PRESSURE", use_ALE), use_ALE=use_ALE)      # MOM_PressureForce_FV.F90:1078
-    if bulkml:
+    if bulkml or not thermo:
         pf.update(nkmb=nkml + nkbl, Rlay=Rlay, g_prime=g_prime)
     cont = dict(tol_eta=_f(p, "ETA_TOLERANCE", 0.5 * nk * g.Angstrom_H))                    # MOM_continuity_PPM.F90:2717
     if "VELOCITY_TOLERANCE" in p:
@@ -276,8 +279,9 @@ def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
     dyn_ml = _b(p, "DYNAMIC_VISCOUS_ML")
     vv = dict(Kv=float(p["KV"]), Hbbl=float(p["HBBL"]), Hmix=_f(p, "HMIX_FIXED", 0.0) if nkml < 1 else 0.0,
               Kvml_invZ2=_f(p, "KV_ML_INVZ2", 0.0) if nkml < 1 else 0.0, direct_stress=_b(p, "DIRECT_STRESS"),
-              maxvel=_f(p, "MAXVEL", 3.0e8), CFL_based_trunc=True, CFL_trunc=0.5, dynamic_viscous_ML=dyn_ml, nkml=nkml)
-    hv = dict(Laplacian=int(_b(p, "LAPLACIAN")), biharmonic=int(_b(p, "BIHARMONIC", True)), Smagorinsky_Kh=int(_b(p, "SMAGORINSKY_KH")),
+              maxvel=_f(p, "MAXVEL", 3.0e8), CFL_based_trunc=True, CFL_trunc=0.5, dynamic_viscous_ML=dyn_ml, nkml=nkml,
+              harmonic_visc=_b(p, "HARMONIC_VISC"))
+    hv = dict(Kh=_f(p, "KH", 0.0), Laplacian=int(_b(p, "LAPLACIAN")), biharmonic=int(_b(p, "BIHARMONIC", True)), Smagorinsky_Kh=int(_b(p, "SMAGORINSKY_KH")),
               Smag_Lap_const=_f(p, "SMAG_LAP_CONST", 0.0), Kh_vel_scale=_f(p, "KH_VEL_SCALE", 0.0), Smagorinsky_Ah=int(_b(p, "SMAGORINSKY_AH")),
               Smag_bi_const=_f(p, "SMAG_BI_CONST", 0.0), Ah_vel_scale=_f(p, "AH_VEL_SCALE", 0.0),
               use_land_mask=int(_b(p, "USE_LAND_MASK_FOR_HVISC", True)),
@@ -291,10 +295,10 @@ def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
     c_smag = _f(p, "SMAG_CONST_CHANNEL", _f(p, "SMAG_LAP_CONST", 0.15))      # :3093-3105
     bulk_Ri = _f(p, "BULK_RI_ML_VISC", _f(p, "BULK_RI_ML", 0.0)); decay = _f(p, "TKE_DECAY_VISC", _f(p, "TKE_DECAY", 0.0))
     sv = orc.set_visc_cs(g, float(p["HBBL"]), float(p["KV"]), cdrag=_f(p, "CDRAG", 0.003), drag_bg_vel=_f(p, "DRAG_BG_VEL", 0.0),
-                         BBL_thick_min=_f(p, "BBL_THICK_MIN", 0.0), linear_drag=_b(p, "LINEAR_DRAG"), BBL_use_EOS=_b(p, "BBL_USE_EOS", True),
+                         BBL_thick_min=_f(p, "BBL_THICK_MIN", 0.0), linear_drag=_b(p, "LINEAR_DRAG"), BBL_use_EOS=_b(p, "BBL_USE_EOS", thermo),
                          RiNo_mix=rino, Channel_drag=chan, c_Smag=c_smag if c_smag >= 0.0 else 0.15,
                          dynamic_viscous_ML=dyn_ml, nkml=nkml, bulk_Ri_ML=bulk_Ri if dyn_ml else 0.0, TKE_decay=decay if dyn_ml else 0.0,
-                         omega_frac=_f(p, "ML_OMEGA_FRAC", 0.0) if dyn_ml else 0.0, Rlay=Rlay if bulkml else None)
+                         omega_frac=_f(p, "ML_OMEGA_FRAC", 0.0) if dyn_ml else 0.0, Rlay=Rlay if (bulkml or not thermo) else None)
     if chan:
         arrs.update(Ray_u=g.zeros3(_abi.POS_U), Ray_v=g.zeros3(_abi.POS_V))
     if dyn_ml:
@@ -304,7 +308,7 @@ def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
     mom_src = orc.hor_visc_set_meke(hvcs, Ku=Ku, mom_src=g.zeros2(_abi.POS_H)) if Ku is not None else None
     st = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, be=_f(p, "BE", 0.6), eos_form=E, pressureforce=pf,
                       vertvisc=orc.vertvisc_cs(g, **vv), visc=orc.vertvisc_type(**arrs), hor_visc=hvcs, set_visc=sv if dyn_ml else None,
-                      continuity=cont, coriolis=cor, **bt)
+                      continuity=cont, coriolis=cor, OBC=OBC, **bt)
     # the barotropic time step as barotropic_init leaves it (MOM_barotropic.F90:4899-4914) and MOM.F90's DTBT_RESET_PERIOD (:1227-1234)
     SSH_extra = _f(p, "SSH_EXTRA", min(10.0, 0.05 * float(g.bathyT.max())))
     orc.set_dtbt(g, st.bcs, gtot_est=float(sum(g.H_to_Z * g_prime[k] for k in range(nk))), SSH_add=SSH_extra)
@@ -314,20 +318,22 @@ def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime):
     calc = lambda n: (reset == 0.0)
     st.mom_src = mom_src
     st.E = E
-    st.bbl = lambda: orc.set_viscous_BBL(g, sv, st.u, st.v, st.h, st.T, st.S, E, st.visc)      # MOM.F90:1205
-    return st, calc, dict(use_eos=1, use_ale=int(use_ALE), nk_rho_varies=nkml + nkbl, nkml=nkml)
+    st.bbl = lambda: orc.set_viscous_BBL(g, sv, st.u, st.v, st.h, st.T if thermo else None, st.S if thermo else None, E, st.visc,
+                                         **({} if OBC is None else dict(OBC=OBC)))      # MOM.F90:1205
+    return st, calc, dict(use_eos=int(thermo), use_ale=int(use_ALE), nk_rho_varies=nkml + nkbl, nkml=nkml)
 
 
 def write_case(tmp, name, nsteps, resident, state, bbl_mode=0):
     g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
     p = pairs_of(name)
     use_ALE = _b(p, "USE_REGRIDDING")
-    nkml, nkbl = (0, 0) if use_ALE else (2, 2)
+    nkml, nkbl = (0, 0) if (use_ALE or not _b(p, "ENABLE_THERMODYNAMICS", True)) else (2, 2)
     with open(tmp / "in.bin", "wb") as f:
         lat = lateral_fields(name, g)
         np.array([g.ni, g.nj, g.nk, g.halo, int(_b(p, "REENTRANT_X", True)), 0, g.first_direction, int(lat is not None)], dtype="<i4").tofile(f)
         Ku = meke_of(name, g)
-        np.array([nsteps, int(resident), 1, int(use_ALE), nkml + nkbl, nkml, bbl_mode, int(Ku is not None)], dtype="<i4").tofile(f)
+        np.array([nsteps, int(resident), int(_b(p, "ENABLE_THERMODYNAMICS", True)), int(use_ALE), nkml + nkbl, nkml, bbl_mode, int(Ku is not None)],
+                 dtype="<i4").tofile(f)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, float(p["DT"])], dtype="<f8").tofile(f)
         for n in _abi.ALL_METRICS:
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
@@ -350,10 +356,13 @@ OUT = [("u", _abi.POS_U, 3), ("v", _abi.POS_V, 3), ("h", _abi.POS_H, 3), ("uh", 
        ("vhtr", _abi.POS_V, 3), ("eta_av", _abi.POS_H, 2), ("nkml_visc_u", _abi.POS_U, 2), ("nkml_visc_v", _abi.POS_V, 2)]
 
 
-def read_out(path, g, meke=False):
+def read_out(path, g, meke=False, OBC=None):
     raw = np.fromfile(path, dtype="<f8")
     out = OUT + ([("mom_src", _abi.POS_H, 2)] if meke else [])
     shapes = [g.shape3(pos) if nd == 3 else g.shape2(pos) for _, pos, nd in out]
+    if OBC is not None:      # OBC%rx_normal, OBC%ry_normal, then segment%normal_vel of every segment on the PE
+        out = out + [("rx_normal", _abi.POS_U, 3), ("ry_normal", _abi.POS_V, 3)] + [(f"normal_vel_{n + 1}", None, 3) for n, s in enumerate(OBC.segment) if s.on_pe]
+        shapes = shapes + [g.shape3(_abi.POS_U), g.shape3(_abi.POS_V)] + [s.normal_vel.shape for s in OBC.segment if s.on_pe]
     sizes = [int(np.prod(s)) for s in shapes]
     assert raw.size == sum(sizes)
     return {n: a.reshape(s) for (n, _, _), a, s in zip(out, np.split(raw, np.cumsum(sizes)[:-1]), shapes)}
@@ -620,3 +629,126 @@ def test_thermodynamic_cycle_with_the_tc2_and_tc1_sets(tmp_path, name, resident)
         assert bits_equal(interior(g, got[n], pos), interior(g, getattr(want, n), pos)), (name, n, float(np.abs(got[n] - getattr(want, n)).max()))
     assert bits_equal(interior(g, T_), interior(g, want.T)) and bits_equal(interior(g, S_), interior(g, want.S)), name
     assert "thickness_diffuse=1" in r.stdout and "mixedlayer_restrat=1" in r.stdout
+
+
+# ---- .testing/tc3: the open boundaries (four FLATHER,ORLANSKI segments with zero external data) under the RK2 module shim -----------------
+TC3_PAIRS = """
+        REENTRANT_X = False
+        ENABLE_THERMODYNAMICS = False
+        DT = 120.0
+        DTBT_RESET_PERIOD = -1.0
+        CDRAG = 0.002
+        BOUND_CORIOLIS = True
+        LAPLACIAN = True
+        KH = 25.0
+        KH_VEL_SCALE = 0.003
+        SMAGORINSKY_KH = True
+        SMAG_LAP_CONST = 0.15
+        AH_VEL_SCALE = 0.003
+        SMAGORINSKY_AH = True
+        SMAG_BI_CONST = 0.06
+        DIRECT_STRESS = True
+        HARMONIC_VISC = True
+        HMIX_FIXED = 20.0
+        KV = 1.0E-04
+        KV_ML_INVZ2 = 0.01
+        HBBL = 10.0
+        MAXVEL = 10.0
+        USE_JACKSON_PARAM = True
+        DRAG_BG_VEL = 0.05
+        BBL_THICK_MIN = 0.1
+        BOUND_BT_CORRECTION = True
+        NONLINEAR_BT_CONTINUITY = True
+        BT_PROJECT_VELOCITY = True
+        BT_THICK_SCHEME = "FROM_BT_CONT"
+        BT_STRONG_DRAG = False
+        BEBT = 0.2
+        DTBT = -0.95
+        DEBUG = True
+        USE_LAND_MASK_FOR_HVISC = False
+        """
+TC3_SEGMENTS = ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,FLATHER,ORLANSKI", "I=0,J=N:0,FLATHER,ORLANSKI"]
+TC3_OBC = dict(freeslip_vorticity=True, freeslip_strain=True, zero_biharmonic=True, gamma_uv=0.3, rx_max=10.0)      # OBC_RADIATION_MAX = 10.0
+
+
+def write_obc_file(path, g, OBC):
+    """ocean_OBC_type as open_boundary_config / open_boundary_init and the first update_OBC_segment_data leave it (dyn_driver.F90)"""
+    with open(path, "wb") as f:
+        np.array([OBC.number_of_segments, OBC.OBC_pe, OBC.open_u_BCs_exist_globally, OBC.open_v_BCs_exist_globally, OBC.specified_u_BCs_exist_globally,
+                  OBC.specified_v_BCs_exist_globally, OBC.Flather_u_BCs_exist_globally, OBC.Flather_v_BCs_exist_globally], dtype="<i4").tofile(f)
+        np.array([OBC.zero_vorticity, OBC.freeslip_vorticity, OBC.computed_vorticity, OBC.specified_vorticity, OBC.zero_strain, OBC.freeslip_strain,
+                  OBC.computed_strain, OBC.zero_biharmonic], dtype="<i4").tofile(f)
+        np.array([OBC.gamma_uv, OBC.rx_max], dtype="<f8").tofile(f)
+        for s in OBC.segment:
+            np.array([s.direction, s.open, s.specified, s.on_pe, s.is_E_or_W, s.is_N_or_S] +
+                     [s.HI.get(k, 0) for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed")] +
+                     [s.Flather, s.radiation, s.gradient, s.nudged, 0, 0], dtype="<i4").tofile(f)
+        OBC.segnum_u.astype("<i4").tofile(f); OBC.segnum_v.astype("<i4").tofile(f)
+        for s in OBC.segment:
+            if s.on_pe:
+                for a in (s.normal_vel, s.normal_trans, s.normal_vel_bt, s.SSH):
+                    np.ascontiguousarray(a, dtype="<f8").tofile(f)
+
+
+def tc3_case():
+    from mom6_amd.open_boundary import ocean_OBC_type
+    from test_continuity_obc import open_faces
+    TC_INPUT["tc3"] = dict(shape=(10, 8, 10), pairs=TC3_PAIRS)
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = case_state("tc3")
+    OBC = ocean_OBC_type(g, TC3_SEGMENTS, **TC3_OBC)
+    open_faces(g, OBC)
+    OBC.rx_normal, OBC.ry_normal = g.zeros3(_abi.POS_U), g.zeros3(_abi.POS_V)
+    for s in OBC.segment:      # the value-type data of the segments (U = V = SSH = 0) as the first update_OBC_segment_data leaves them
+        s.normal_vel_bt = np.zeros(s.normal_vel.shape[1:]); s.SSH = np.zeros(s.normal_vel.shape[1:])
+    taux, tauy = 0.0 * taux, 0.0 * tauy      # WIND_CONFIG = "zero"
+    return (g, d, taux, tauy, ustar, bbl, Rlay, g_prime), OBC
+
+
+def test_oracle_runs_the_tc3_set_with_its_open_boundaries():
+    try:
+        state, OBC = tc3_case()
+        g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+        st, calc, info = oracle_for("tc3", g, d, ustar, bbl, Rlay, g_prime, OBC=OBC)
+        assert info["use_eos"] == 0 and info["nkml"] == 0
+        for n in range(3):
+            st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+        assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0
+        assert np.abs(st.u[:, OBC.segnum_u != 0]).max() > 0 and np.abs(OBC.rx_normal).max() > 0
+    finally:
+        TC_INPUT.pop("tc3", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+def test_tc3_with_its_open_boundaries_from_fortran_matches_oracle_bitwise(tmp_path, resident):
+    """the transcribed parameter set of .testing/tc3 (ENABLE_THERMODYNAMICS = False: the layered pressure force; HARMONIC_VISC; its four
+    FLATHER,ORLANSKI segments with OBC_FREESLIP_VORTICITY, OBC_FREESLIP_STRAIN, OBC_ZERO_BIHARMONIC, OBC_RADIATION_MAX = 10) through the
+    reference-named driver: set_visc_init(OBC), initialize_dyn_split_RK2(OBC), then set_viscous_BBL and step_MOM_dyn_split_RK2 three
+    times; the prognostic fields, OBC%rx_normal / ry_normal and segment%normal_vel are the oracle's bits"""
+    import copy
+    nsteps = 3
+    try:
+        state, OBC = tc3_case()
+        g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+        exe = build_driver(tmp_path)
+        write_case(tmp_path, "tc3", nsteps, resident, state, bbl_mode=1)
+        write_obc_file(str(tmp_path / "obc.bin"), g, OBC)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt"), str(tmp_path / "obc.bin")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-2000:]
+        st, calc, _ = oracle_for("tc3", g, d, ustar, bbl, Rlay, g_prime, OBC=OBC)
+        for n in range(nsteps):
+            st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+        got = read_out(str(tmp_path / "out.bin"), g, OBC=OBC)
+        want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+        for n, pos, nd in OUT:
+            if n in want:
+                assert bits_equal(interior(g, got[n], pos), interior(g, want[n], pos)), (n, float(np.abs(got[n] - want[n]).max()))
+        assert np.abs(st.u[:, OBC.segnum_u != 0]).max() > 0      # (the boundaries are open)
+        assert bits_equal(interior(g, got["rx_normal"], _abi.POS_U), interior(g, OBC.rx_normal, _abi.POS_U)) and np.abs(OBC.rx_normal).max() > 0
+        assert bits_equal(interior(g, got["ry_normal"], _abi.POS_V), interior(g, OBC.ry_normal, _abi.POS_V))
+        for n, s in enumerate(OBC.segment):
+            assert bits_equal(got[f"normal_vel_{n + 1}"], s.normal_vel), n
+    finally:
+        TC_INPUT.pop("tc3", None)
