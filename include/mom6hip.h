@@ -530,9 +530,9 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
  * (mom6hip_coradcalc_obc), of vertvisc_coef / vertvisc (mom6hip_vertvisc_coef_obc, mom6hip_vertvisc_obc), of btcalc and btstep
  * (mom6hip_btcalc_obc, mom6hip_btstep_obc), of set_viscous_BBL (mom6hip_set_viscous_bbl_obc), of horizontal_viscosity
  * (mom6hip_horizontal_viscosity_obc), of advect_tracer (mom6hip_advect_tracer_obc: the tracer registries of the segments), and
- * radiation_open_bdry_conds / open_boundary_zero_normal_flow for the normal component; every other entry point (tracer_hordiff, the RK2
- * steppers) of the library still requires that OBC is not associated: a configuration with open boundaries is stepped by the reference's
- * own MOM_dynamics_split_RK2 and MOM_open_boundary over these operators.
+ * radiation_open_bdry_conds / open_boundary_zero_normal_flow for the normal component, and of step_MOM_dyn_split_RK2 (cs->OBC of
+ * mom6hip_dyn_split_rk2_cs_t); tracer_hordiff and step_MOM_dyn_split_RK2b still require that OBC is not associated.  The segments' data
+ * (update_OBC_segment_data) are the host's business: MOM_open_boundary stays the reference's.
  * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */
 #define MOM6HIP_OBC_NONE 0            /* OBC_NONE :79 */
@@ -1326,10 +1326,15 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
  * step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
  *                        vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves)
  *                                                                  src/core/MOM_dynamics_split_RK2.F90:289
- * tv%T, tv%S are passed as T, S; forces%taux, %tauy as taux, tauy with RZ_to_H; p_surf_begin / p_surf_end, OBC, Waves,
+ * tv%T, tv%S are passed as T, S; forces%taux, %tauy as taux, tauy with RZ_to_H; p_surf_begin / p_surf_end, Waves,
  * FPMIX and BEGW /= 0 are not provided.  All arrays are DEVICE arrays.  The whole step is enqueued on the context's
  * stream without host synchronisation, except for set_dtbt when calc_dtbt /= 0, the group passes of a multi-tile
  * domain and the hooks.
+ * With cs->OBC (CS%OBC associated): the step's lines for the open boundaries -- u_old_rad_OBC = u_av :444-456,
+ * open_boundary_zero_normal_flow on u_bc_accel :565-567 and :887-889, radiation_open_bdry_conds on u_av :765-775 and on u_inst
+ * :1030-1034 (segment%normal_vel, OBC%rx_normal, OBC%ry_normal are updated in place) -- and the OBC in every operator that takes
+ * one, as the plain sequence of the library's OBC entry points; update_OBC_data (:534-536, OBC%update_OBC) is the caller's business
+ * before the call; one tile, no hooks, no DYNAMIC_VISCOUS_ML.  mom6hip_dyn_split_rk2_init reads cs->OBC as well (:1543-1593).
  */
 int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_inst, double *v_inst,
                                double *h, const double *T, const double *S, double dt, const double *taux,
