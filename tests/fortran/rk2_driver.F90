@@ -93,7 +93,7 @@ btc%vBT_SS = dalloc(nv2) ; btc%vBT_NN = dalloc(nv2) ; btc%h_u = dalloc(nu3) ; bt
 
 ! ---- MOM_dyn_split_RK2_CS: parameters, the sub-module structures, the arrays the reference allocates in its CS
 cs%be = 0.6d0 ; cs%begw = 0.0d0 ; cs%BT_use_layer_fluxes = 1 ; cs%store_CAu = 1 ; cs%CAu_pred_stored = 0 ; cs%split_bottom_stress = 0
-cs%reserved0(:) = 0 ; cs%set_visc_CSp = c_null_ptr ; cs%reserved2(:) = c_null_ptr
+cs%reserved0(:) = 0 ; cs%set_visc_CSp = c_null_ptr ; cs%OBC = c_null_ptr
 cs%continuity_CSp = c_loc(ccs) ; cs%CoriolisAdv = c_loc(cor) ; cs%PressureForce_CSp = c_loc(pcs) ; cs%eqn_of_state = c_loc(eos)
 cs%barotropic_CSp = c_loc(bcs) ; cs%BT_cont = c_loc(btc) ; cs%hooks = c_null_ptr
 cs%vertvisc_CSp = c_null_ptr ; cs%visc = c_null_ptr ; cs%hor_visc = c_null_ptr
