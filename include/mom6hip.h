@@ -479,6 +479,16 @@ int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const struct mom6hip_o
 /* open_boundary_zero_normal_flow(OBC, G, GV, u, v) :3374 (the RK2 step applies it to the accelerations :566, :888) */
 int mom6hip_open_boundary_zero_normal_flow(mom6hip_ctx_t *ctx, const struct mom6hip_obc *obc, double *u, double *v, int32_t memspace);
 
+/* update_segment_tracer_reservoirs(G, GV, uhr, vhr, h, OBC, dt, Reg)                    src/core/MOM_open_boundary.F90:5373
+ * (step_MOM_tracer_dyn calls it after advect_tracer and tracer_hordiff with the accumulated transports, MOM.F90:1447.)  The reservoirs
+ * tres of the registered tracers of every segment with a registry, one backward-Euler step: outflow carries the tracer of the cell inside
+ * (tr[ntr_index - 1]) into the reservoir, inflow restores it towards the external values t, with the inverse length scales
+ * Tr_InvLscale_out / _in (zero: the value is taken over at once).  tr: the tracer arrays of the registry (read); tres and t of the
+ * segments in the memory space of the call.  OBC%tres_x / tres_y (the restart copies, I_scale * tres) are the caller's to refresh. */
+int mom6hip_update_segment_tracer_reservoirs(mom6hip_ctx_t *ctx, const double *uhr, const double *vhr, const double *h,
+                                             const struct mom6hip_obc *obc, double dt, const double *const *tr, int32_t ntr,
+                                             int32_t memspace);
+
 /* CorAdCalc with OBC associated (:249-269 the areas across a segment, :337-420 the circulation and the thicknesses projected onto the
  * velocity points of a segment, :422-455 onto its corner points, gradKE :1037-1050); additionally needs the metrics dxBu, dyBu with
  * OBC%specified_vorticity.  obc == NULL: mom6hip_coradcalc. */
@@ -546,8 +556,12 @@ typedef struct mom6hip_obc_segment_tracer {
   int32_t ntr_index;           /* %ntr_index: which tracer of the registry (1-based: the order of the tracers handed to advect_tracer) */
   int32_t reserved;
   const double *tres;          /* %tres, the tracer reservoir on the segment's faces, (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk)
-                                  for N / S, in the memory space of the call; NULL (not allocated): OBC_inflow_conc is used */
+                                  for N / S, in the memory space of the call; NULL (not allocated): OBC_inflow_conc is used.  (Written by
+                                  mom6hip_update_segment_tracer_reservoirs.) */
   double OBC_inflow_conc;      /* %OBC_inflow_conc */
+  const double *t;             /* %t, the external tracer values on the segment's faces (the layout of tres): read by
+                                  update_segment_tracer_reservoirs; may be NULL otherwise */
+  double resrv_lfac_in, resrv_lfac_out;      /* segment%field(fd_index)%resrv_lfac_in / _out; 1.0 with fd_index = -1 (:5431-5437) */
 } mom6hip_obc_segment_tracer_t;
 
 typedef struct mom6hip_obc_segment {
@@ -577,6 +591,7 @@ typedef struct mom6hip_obc_segment {
   /* segment%tr_Reg: NULL (not associated) or tr_Reg%ntseg entries, a HOST array; read by advect_tracer */
   const mom6hip_obc_segment_tracer_t *tr_Reg;
   int32_t ntseg, reserved_i;
+  double Tr_InvLscale_in, Tr_InvLscale_out;      /* segment%Tr_InvLscale_in / _out [L-1]: read by update_segment_tracer_reservoirs */
 } mom6hip_obc_segment_t;
 
 typedef struct mom6hip_obc {

@@ -187,7 +187,8 @@ OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W = 0
 
 class ObcSegmentTracer(C.Structure):
     """mom6hip_obc_segment_tracer_t (include/mom6hip.h)."""
-    _fields_ = [("ntr_index", C.c_int32), ("reserved", C.c_int32), ("tres", C.c_void_p), ("OBC_inflow_conc", C.c_double)]
+    _fields_ = [("ntr_index", C.c_int32), ("reserved", C.c_int32), ("tres", C.c_void_p), ("OBC_inflow_conc", C.c_double),
+                ("t", C.c_void_p), ("resrv_lfac_in", C.c_double), ("resrv_lfac_out", C.c_double)]
 
 
 class ObcSegment(C.Structure):
@@ -197,7 +198,8 @@ class ObcSegment(C.Structure):
                [("Flather", C.c_int32), ("normal_trans", C.c_void_p), ("normal_vel", C.c_void_p), ("tangential_vel", C.c_void_p),
                 ("tangential_grad", C.c_void_p), ("nudged_normal_vel", C.c_void_p), ("normal_vel_bt", C.c_void_p), ("SSH", C.c_void_p),
                 ("Velocity_nudging_timescale_in", C.c_double), ("Velocity_nudging_timescale_out", C.c_double),
-                ("tr_Reg", C.POINTER(ObcSegmentTracer)), ("ntseg", C.c_int32), ("reserved_i", C.c_int32)]
+                ("tr_Reg", C.POINTER(ObcSegmentTracer)), ("ntseg", C.c_int32), ("reserved_i", C.c_int32),
+                ("Tr_InvLscale_in", C.c_double), ("Tr_InvLscale_out", C.c_double)]
 
 
 class Obc(C.Structure):

@@ -65,6 +65,31 @@ __global__ __launch_bounds__(64) void obc_face_store_kernel(m6::GridDev g, RadSe
   x[(S.ew ? g.u2(S.A, c) : g.v2(c, S.A)) + pl * k] = from_normal_vel ? S.normal_vel[rad_idx(S, c, k)] : 0.;
 }
 
+// update_segment_tracer_reservoirs :5439-5456 / :5483-5496: one registered tracer of a segment, a thread a face and layer
+struct ResArgs { double *tres; const double *t, *tr; double InvL_in, InvL_out, lfac_in, lfac_out; };
+__global__ __launch_bounds__(64) void obc_reservoir_kernel(m6::GridDev g, RadSeg S, ResArgs a, const double *xr3, const double *h) {
+  const int c = S.c0 + blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (c > S.c1) return;
+  // d1 = +1 (W, S): the nearest interior tracer cell is A + 1 and the flow into the reservoir is the negative one; -1 (E, N): A, positive
+  const int shift = S.d1 > 0 ? 1 : 0;
+  const double dir = S.d1 > 0 ? -1.0 : 1.0;
+  const long cell2 = S.ew ? g.h2(S.A + shift, c) : g.h2(c, S.A + shift);
+  if (g.mask2dT[cell2] == 0.0) return;
+  const long cell3 = cell2 + (long)g.nih * g.njh * k;
+  const long f2 = S.ew ? g.u2(S.A, c) : g.v2(c, S.A);
+  const long pl = S.ew ? (long)(g.nih + 1) * g.njh : (long)g.nih * (g.njh + 1);
+  const double len = S.ew ? g.dyCu[f2] : g.dxCv[f2];
+  const double b_in = (a.InvL_in == 0.0) ? 1.0 : 0.0, b_out = (a.InvL_out == 0.0) ? 1.0 : 0.0;
+  const double xr = dir * xr3[f2 + pl * k];
+  const double a_out = b_out * m6::max2(0.0, copysign(1.0, xr));
+  const double a_in  = b_in  * m6::min2(0.0, copysign(1.0, xr));
+  const double L_out = m6::max2(0.0, xr * a.InvL_out * a.lfac_out / ((h[cell3] + g.H_subroundoff) * len));
+  const double L_in  = m6::min2(0.0, xr * a.InvL_in * a.lfac_in / ((h[cell3] + g.H_subroundoff) * len));
+  const double fac1 = (1.0 - (a_out - a_in)) + ((L_out + a_out) - (L_in + a_in));
+  const long s3 = rad_idx(S, c, k);
+  a.tres[s3] = (1.0 / fac1) * ((1.0 - a_out + a_in) * a.tres[s3] + ((L_out + a_out) * a.tr[cell3] - (L_in + a_in) * a.t[s3]));
+}
+
 // the geometry of a segment for these kernels; false: not on the PE or neither E/W nor N/S
 bool rad_segment(const m6::GridDev &g, const mom6hip_obc_segment_t &S, RadSeg &d) {
   if (!S.on_pe) return false;
@@ -210,6 +235,50 @@ extern "C" int mom6hip_open_boundary_zero_normal_flow(mom6hip_ctx_t *ctx, const 
     if (!rad_segment(g, obc->segment[n], d)) continue;
     if (check_segment_range(g, obc->segment[n], n, "open_boundary_zero_normal_flow")) return 1;
     hipLaunchKernelGGL(obc_face_store_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, ctx->stream, g, d, d.ew ? d_u : d_v, 0);
+  }
+  M6_HIP(hipGetLastError());
+  return st.finish();
+}
+
+// update_segment_tracer_reservoirs(G, GV, uhr, vhr, h, OBC, dt, Reg) :5373
+extern "C" int mom6hip_update_segment_tracer_reservoirs(mom6hip_ctx_t *ctx, const double *uhr, const double *vhr, const double *h,
+                                                        const mom6hip_obc_t *obc, double dt, const double *const *tr, int32_t ntr,
+                                                        int32_t memspace) {
+  (void)dt;
+  M6_REQUIRE(ctx != nullptr, "update_segment_tracer_reservoirs: the context is required");
+  M6_REQUIRE(memspace == MOM6HIP_MEM_HOST || memspace == MOM6HIP_MEM_DEVICE, "update_segment_tracer_reservoirs: bad memspace");
+  if (!obc || !obc->OBC_pe) return 0;      // :5410
+  M6_REQUIRE(uhr && vhr && h && (tr || ntr == 0), "update_segment_tracer_reservoirs: null argument");
+  M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "update_segment_tracer_reservoirs: OBC%%segment is required");
+  const m6::GridDev g = ctx->g;
+  m6::Stager st(ctx, memspace);
+  const double *d_uhr = nullptr, *d_vhr = nullptr, *d_h = nullptr;
+  std::vector<const double *> d_tr(ntr > 0 ? ntr : 0, nullptr);
+  for (int n = 0; n < obc->number_of_segments; n++) {
+    const mom6hip_obc_segment_t &S = obc->segment[n];
+    if (!S.tr_Reg) continue;
+    RadSeg d;
+    if (!rad_segment(g, S, d)) continue;
+    if (check_segment_range(g, S, n, "update_segment_tracer_reservoirs")) return 1;
+    M6_REQUIRE(d.A + (d.d1 > 0 ? 1 : 0) >= (d.ew ? g.isd : g.jsd) && d.A + (d.d1 > 0 ? 1 : 0) <= (d.ew ? g.ied : g.jed),
+               "update_segment_tracer_reservoirs: segment %d has no cell inside it in the data domain", n + 1);
+    if (!d_h) {      // (staged at the first segment that needs them)
+      d_uhr = st.in(uhr, (size_t)g.nu3() * 8); d_vhr = st.in(vhr, (size_t)g.nv3() * 8); d_h = st.in(h, (size_t)g.nh3() * 8);
+    }
+    for (int q = 0; q < S.ntseg; q++) {
+      const mom6hip_obc_segment_tracer_t &T = S.tr_Reg[q];
+      if (!T.tres) continue;      // .not.allocated(tres) :5439
+      M6_REQUIRE(T.ntr_index >= 1 && T.ntr_index <= ntr, "update_segment_tracer_reservoirs: the registry of OBC segment %d names tracer %d of %d",
+                 n + 1, T.ntr_index, ntr);
+      M6_REQUIRE(T.t, "update_segment_tracer_reservoirs: segment %d: the external values tr_Reg%%Tr(%d)%%t are required", n + 1, q + 1);
+      if (!d_tr[T.ntr_index - 1]) d_tr[T.ntr_index - 1] = st.in(tr[T.ntr_index - 1], (size_t)g.nh3() * 8);
+      const size_t cnt = (size_t)d.nA * d.nc * g.nk * 8;
+      ResArgs a;
+      a.tres = st.inout((double *)T.tres, cnt); a.t = st.in(T.t, cnt); a.tr = d_tr[T.ntr_index - 1];
+      a.InvL_in = S.Tr_InvLscale_in; a.InvL_out = S.Tr_InvLscale_out; a.lfac_in = T.resrv_lfac_in; a.lfac_out = T.resrv_lfac_out;
+      M6_REQUIRE(!st.failed() && a.tres && a.t && a.tr && d_h, "update_segment_tracer_reservoirs: staging failed");
+      hipLaunchKernelGGL(obc_reservoir_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, ctx->stream, g, d, a, d.ew ? d_uhr : d_vhr, d_h);
+    }
   }
   M6_HIP(hipGetLastError());
   return st.finish();

@@ -21,7 +21,7 @@ use MOM_domains,       only : pass_var, CENTER, EAST_FACE, NORTH_FACE, CORNER
 use MOM_error_handler, only : MOM_error, FATAL
 use MOM_file_parser,   only : get_param, param_file_type
 use MOM_grid,          only : ocean_grid_type
-use MOM_open_boundary, only : ocean_OBC_type, OBC_segment_type
+use MOM_open_boundary, only : ocean_OBC_type, OBC_segment_type, OBC_DIRECTION_W, OBC_DIRECTION_S
 use MOM_string_functions, only : uppercase
 use MOM_verticalGrid,  only : verticalGrid_type
 implicit none ; private
@@ -31,7 +31,7 @@ public :: mom6hip_context_create, mom6hip_read_topology, mom6hip_read_eos, mom6h
 public :: mom6hip_read_resident, mom6hip_resident, mom6hip_mirror, mom6hip_mirrors_stage, mom6hip_mirrors_to_host
 public :: mom6hip_mirrors_host_was_modified, mom6hip_mirror_host_changed, mom6hip_mirror_zeroed, mom6hip_mirrors_end
 public :: mom6hip_mirror_pass_var, mom6hip_mirror_require_host_current, mom6hip_mirror_forget
-public :: mom6hip_obc_to_c
+public :: mom6hip_obc_to_c, update_segment_tracer_reservoirs_hip
 
 integer, parameter :: MAX_MIRRORS = 160
 !> A host array of the caller and its copy in HBM
@@ -466,7 +466,13 @@ subroutine mom6hip_obc_to_c(OBC, cobc, csegs, n_u2, n_v2, who, ctrs)
         ctrs(nt)%ntr_index = OBC%segment(n)%tr_Reg%Tr(m)%ntr_index
         ctrs(nt)%OBC_inflow_conc = OBC%segment(n)%tr_Reg%Tr(m)%OBC_inflow_conc
         if (allocated(OBC%segment(n)%tr_Reg%Tr(m)%tres)) ctrs(nt)%tres = c_loc(OBC%segment(n)%tr_Reg%Tr(m)%tres)
+        if (allocated(OBC%segment(n)%tr_Reg%Tr(m)%t)) ctrs(nt)%t = c_loc(OBC%segment(n)%tr_Reg%Tr(m)%t)
+        if (OBC%segment(n)%tr_Reg%Tr(m)%fd_index /= -1) then      ! (update_segment_tracer_reservoirs :5431-5437)
+          ctrs(nt)%resrv_lfac_in = OBC%segment(n)%field(OBC%segment(n)%tr_Reg%Tr(m)%fd_index)%resrv_lfac_in
+          ctrs(nt)%resrv_lfac_out = OBC%segment(n)%field(OBC%segment(n)%tr_Reg%Tr(m)%fd_index)%resrv_lfac_out
+        endif
       enddo
+      csegs(n)%Tr_InvLscale_in = OBC%segment(n)%Tr_InvLscale_in ; csegs(n)%Tr_InvLscale_out = OBC%segment(n)%Tr_InvLscale_out
     endif ; enddo
   endif
   cobc%number_of_segments = OBC%number_of_segments ; cobc%OBC_pe = merge(1, 0, OBC%OBC_pe)
@@ -513,5 +519,59 @@ contains
     c%Velocity_nudging_timescale_out = seg%Velocity_nudging_timescale_out
   end subroutine segment_to_c
 end subroutine mom6hip_obc_to_c
+
+!> update_segment_tracer_reservoirs(G, GV, uhr, vhr, h, OBC, dt, Reg) of MOM_open_boundary (:5373) on the GPU, with the reference's
+!! argument list: MOM.F90:1447 calls this instead (MOM_open_boundary itself stays the reference's).  The reservoirs
+!! segment%tr_Reg%Tr(m)%tres are updated in place, and OBC%tres_x / tres_y (the restart copies) after them on the host.
+subroutine update_segment_tracer_reservoirs_hip(G, GV, uhr, vhr, h, OBC, dt, Reg)
+  use MOM_tracer_registry, only : tracer_registry_type
+  type(ocean_grid_type),      intent(inout) :: G
+  type(verticalGrid_type),    intent(in)    :: GV
+  real, dimension(G%IsdB:,G%jsd:,:), target, intent(in) :: uhr
+  real, dimension(G%isd:,G%JsdB:,:), target, intent(in) :: vhr
+  real, dimension(G%isd:,G%jsd:,:),  target, intent(in) :: h
+  type(ocean_OBC_type),       pointer       :: OBC
+  real,                       intent(in)    :: dt
+  type(tracer_registry_type), pointer       :: Reg
+  type(mom6hip_obc_t) :: cobc
+  type(mom6hip_obc_segment_t), allocatable, target :: csegs(:)
+  type(mom6hip_obc_segment_tracer_t), allocatable, target :: ctrs(:)
+  type(c_ptr), allocatable :: tr(:)
+  type(c_ptr) :: ctx
+  integer :: n, m, i, j, k, rc, sh
+  real :: I_scale
+  logical :: any_reg
+  if (.not.associated(OBC)) return
+  if (.not.OBC%OBC_pe) return
+  any_reg = .false.
+  do n=1,OBC%number_of_segments ; if (associated(OBC%segment(n)%tr_Reg)) any_reg = .true. ; enddo
+  if (.not.any_reg) return
+  if (resident_mode) call MOM_error(FATAL, "update_segment_tracer_reservoirs (HIP): the tracer reservoirs of the open boundaries live "// &
+                                    "on the host; GPU_RESIDENT_DYNAMICS is not provided for them.")
+  ctx = mom6hip_shared_context(G, GV)
+  call mom6hip_obc_to_c(OBC, cobc, csegs, size(uhr(:,:,1)), size(vhr(:,:,1)), "update_segment_tracer_reservoirs", ctrs)
+  allocate(tr(Reg%ntr))
+  do m=1,Reg%ntr ; tr(m) = c_loc(Reg%Tr(m)%t) ; enddo
+  rc = mom6hip_update_segment_tracer_reservoirs(ctx, c_loc(uhr), c_loc(vhr), c_loc(h), cobc, real(dt, c_double), tr, &
+                                                int(Reg%ntr, c_int32_t), MOM6HIP_MEM_HOST)
+  call mom6hip_fatal_if(rc, "update_segment_tracer_reservoirs")
+  ! :5455, :5495: the restart copies where the reservoirs were updated
+  do n=1,OBC%number_of_segments ; if (associated(OBC%segment(n)%tr_Reg)) then
+    do m=1,OBC%segment(n)%tr_Reg%ntseg ; if (allocated(OBC%segment(n)%tr_Reg%Tr(m)%tres)) then
+      I_scale = 1.0 ; if (OBC%segment(n)%tr_Reg%Tr(m)%scale /= 0.0) I_scale = 1.0 / OBC%segment(n)%tr_Reg%Tr(m)%scale
+      if (OBC%segment(n)%is_E_or_W .and. allocated(OBC%tres_x)) then
+        i = OBC%segment(n)%HI%IsdB ; sh = 0 ; if (OBC%segment(n)%direction == OBC_DIRECTION_W) sh = 1
+        do k=1,GV%ke ; do j=OBC%segment(n)%HI%jsd,OBC%segment(n)%HI%jed ; if (G%mask2dT(i+sh,j) /= 0.0) then
+          OBC%tres_x(i,j,k,m) = I_scale * OBC%segment(n)%tr_Reg%Tr(m)%tres(i,j,k)
+        endif ; enddo ; enddo
+      elseif (OBC%segment(n)%is_N_or_S .and. allocated(OBC%tres_y)) then
+        j = OBC%segment(n)%HI%JsdB ; sh = 0 ; if (OBC%segment(n)%direction == OBC_DIRECTION_S) sh = 1
+        do k=1,GV%ke ; do i=OBC%segment(n)%HI%isd,OBC%segment(n)%HI%ied ; if (G%mask2dT(i,j+sh) /= 0.0) then
+          OBC%tres_y(i,j,k,m) = I_scale * OBC%segment(n)%tr_Reg%Tr(m)%tres(i,j,k)
+        endif ; enddo ; enddo
+      endif
+    endif ; enddo
+  endif ; enddo
+end subroutine update_segment_tracer_reservoirs_hip
 
 end module mom6hip_MOM_glue

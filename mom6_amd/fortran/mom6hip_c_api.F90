@@ -199,6 +199,8 @@ type, bind(c) :: mom6hip_obc_segment_tracer_t
   integer(c_int32_t) :: ntr_index = 0, reserved = 0
   type(c_ptr) :: tres = c_null_ptr
   real(c_double) :: OBC_inflow_conc = 0.0
+  type(c_ptr) :: t = c_null_ptr
+  real(c_double) :: resrv_lfac_in = 1.0, resrv_lfac_out = 1.0
 end type mom6hip_obc_segment_tracer_t
 type, bind(c) :: mom6hip_obc_segment_t
   integer(c_int32_t) :: direction = 0, open = 0, specified = 0, on_pe = 0, is_E_or_W = 0, is_N_or_S = 0
@@ -210,6 +212,7 @@ type, bind(c) :: mom6hip_obc_segment_t
   real(c_double) :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
   type(c_ptr) :: tr_Reg = c_null_ptr
   integer(c_int32_t) :: ntseg = 0, reserved_i = 0
+  real(c_double) :: Tr_InvLscale_in = 0.0, Tr_InvLscale_out = 0.0
 end type mom6hip_obc_segment_t
 type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: number_of_segments = 0, OBC_pe = 0, open_u_BCs_exist_globally = 0, open_v_BCs_exist_globally = 0
@@ -365,6 +368,17 @@ interface
     type(mom6hip_advect_stats_t), intent(out) :: stats
     integer(c_int) :: rc
   end function mom6hip_advect_tracer_obc
+
+  function mom6hip_update_segment_tracer_reservoirs(ctx, uhr, vhr, h, obc, dt, tr, ntr, memspace) &
+                                                    bind(c, name="mom6hip_update_segment_tracer_reservoirs") result(rc)
+    import :: c_int, c_int32_t, c_double, c_ptr, mom6hip_obc_t
+    type(c_ptr), value :: ctx, uhr, vhr, h
+    type(mom6hip_obc_t), intent(in) :: obc
+    real(c_double), value :: dt
+    type(c_ptr), intent(in) :: tr(*)          !< c_loc of each Reg%Tr(m)%t
+    integer(c_int32_t), value :: ntr, memspace
+    integer(c_int) :: rc
+  end function mom6hip_update_segment_tracer_reservoirs
 
   function mom6hip_malloc(dptr, bytes) bind(c, name="mom6hip_malloc") result(rc)
     import :: c_int, c_ptr, c_int64_t

@@ -79,8 +79,10 @@ class OBC_segment_type:
         self.normal_vel_bt = self.SSH = None      # (jsd:jed, IsdB:IedB) | (JsdB:JedB, isd:ied): the external barotropic velocity and surface height
         self.Velocity_nudging_timescale_in = self.Velocity_nudging_timescale_out = 0.0
         # segment%tr_Reg: None, or a list of dicts(ntr_index = 1-based place of the tracer in the registry, tres = the reservoir on the
-        # segment's faces in the layout of normal_vel or None, OBC_inflow_conc) -- register_segment_tracer :5213
+        # segment's faces in the layout of normal_vel or None, OBC_inflow_conc; for update_segment_tracer_reservoirs t = the external
+        # values in the layout of tres, resrv_lfac_in / resrv_lfac_out = 1.0) -- register_segment_tracer :5213
         self.tr_Reg = None
+        self.Tr_InvLscale_in = self.Tr_InvLscale_out = 0.0      # OBC_TRACER_RESERVOIR_LENGTH_SCALE_IN / _OUT, inverted (:655-667)
 
 
 class ocean_OBC_type:
@@ -264,8 +266,9 @@ class ocean_OBC_type:
             for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH"):
                 setattr(s, k, T(getattr(s, k)))
             for t in (s.tr_Reg or []):
-                if t.get("tres") is not None:
-                    t["tres"] = T(t["tres"])
+                for k in ("tres", "t"):
+                    if t.get(k) is not None:
+                        t[k] = T(t[k])
         return self
 
     def struct(self, to_ptr=None, tres_ptr=None):
@@ -285,6 +288,7 @@ class ocean_OBC_type:
             c.Flather = int(s.Flather)
             c.radiation_tan_or_grad = int(s.radiation_tan or s.radiation_grad or s.oblique_tan or s.oblique_grad or s.nudged_tan or s.nudged_grad)
             c.Velocity_nudging_timescale_in, c.Velocity_nudging_timescale_out = float(s.Velocity_nudging_timescale_in), float(s.Velocity_nudging_timescale_out)
+            c.Tr_InvLscale_in, c.Tr_InvLscale_out = float(s.Tr_InvLscale_in), float(s.Tr_InvLscale_out)
             for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH"):
                 a = getattr(s, k)
                 need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient, "nudged_normal_vel": s.nudged,
@@ -301,12 +305,16 @@ class ocean_OBC_type:
             trs = (_abi.ObcSegmentTracer * max(len(s.tr_Reg), 1))()
             for m, t in enumerate(s.tr_Reg):
                 trs[m].ntr_index, trs[m].OBC_inflow_conc = int(t["ntr_index"]), float(t.get("OBC_inflow_conc", 0.0))
-                a = t.get("tres")
-                if a is not None:
-                    if tres_ptr is None:
-                        a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); trs[m].tres = a.ctypes.data
-                    else:
-                        p, owner = tres_ptr(a); keep.append(owner); trs[m].tres = p
+                trs[m].resrv_lfac_in, trs[m].resrv_lfac_out = float(t.get("resrv_lfac_in", 1.0)), float(t.get("resrv_lfac_out", 1.0))
+                for key in ("tres", "t"):      # the reservoir (updated in place by update_segment_tracer_reservoirs) and the external values
+                    a = t.get(key)
+                    if a is not None:
+                        if tres_ptr is None:
+                            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous):
+                                raise Mom6HipError(f"the segments' tr_Reg {key} arrays must be contiguous float64")
+                            keep.append(a); setattr(trs[m], key, a.ctypes.data)
+                        else:
+                            p, owner = tres_ptr(a); keep.append(owner); setattr(trs[m], key, p)
             keep.append(trs)
             segs[n].tr_Reg = C.cast(trs, C.POINTER(_abi.ObcSegmentTracer)); segs[n].ntseg = len(s.tr_Reg)
         o = _abi.Obc()
@@ -369,6 +377,30 @@ def radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, dt):
     L = lib()
     L.mom6hip_radiation_open_bdry_conds.argtypes = [C.c_void_p, C.POINTER(_abi.Obc), C.c_double, C.c_double] + [C.c_void_p] * 6 + [C.c_double, C.c_int32]
     check(L.mom6hip_radiation_open_bdry_conds(G.handle, C.byref(obc), OBC.gamma_uv, OBC.rx_max, *ptrs, float(dt), space), "radiation_open_bdry_conds")
+
+
+def update_segment_tracer_reservoirs(G, uhr, vhr, h, OBC, dt, Reg):
+    """update_segment_tracer_reservoirs(G, GV, uhr, vhr, h, OBC, dt, Reg) -- :5373: the reservoirs tr_Reg[m]["tres"] of the segments are
+    updated in place (arrays in the memory space of the fields); Reg: the list of tracer arrays"""
+    from ._lib import check, lib
+    if OBC is None or not any(s.tr_Reg for s in OBC.segment):
+        return
+    ptrs, space = _obc_call_space([uhr, vhr, h] + list(Reg))
+
+    def tres_ptr(a):
+        if hasattr(a, "data_ptr"):
+            if space != _abi.MEM_DEVICE:
+                raise Mom6HipError("update_segment_tracer_reservoirs: the segments' tracer arrays must be in the memory space of the fields")
+            return a.data_ptr(), a
+        if space != _abi.MEM_HOST or not (a.dtype == np.float64 and a.flags.c_contiguous):
+            raise Mom6HipError("update_segment_tracer_reservoirs: the segments' tracer arrays must be contiguous float64 in the memory space of the fields")
+        return a.ctypes.data, a
+    obc = OBC.struct(lambda a: (0, None), tres_ptr)
+    trp = (C.c_void_p * len(Reg))(*ptrs[3:])
+    L = lib()
+    L.mom6hip_update_segment_tracer_reservoirs.argtypes = [C.c_void_p] * 4 + [C.POINTER(_abi.Obc), C.c_double, C.c_void_p, C.c_int32, C.c_int32]
+    check(L.mom6hip_update_segment_tracer_reservoirs(G.handle, ptrs[0], ptrs[1], ptrs[2], C.byref(obc), float(dt), trp, len(Reg), space),
+          "update_segment_tracer_reservoirs")
 
 
 def open_boundary_zero_normal_flow(OBC, G, u, v):

@@ -165,6 +165,8 @@ int orc_coradcalc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, c
 int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *OBC, double gamma_uv, double rx_max, double *rx_normal,
                                   double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old, double dt);
 int orc_open_boundary_zero_normal_flow(const mom6hip_grid_t *G, const mom6hip_obc_t *OBC, double *u, double *v);
+int orc_update_segment_tracer_reservoirs(const mom6hip_grid_t *G, const double *uhr, const double *vhr, const double *h,
+                                         const mom6hip_obc_t *OBC, double dt, const double *const *tr, int ntr);
 /* CorAdCalc with OBC associated (OBC may be NULL: the call above) */
 int orc_coradcalc_obc(const mom6hip_grid_t *G, const mom6hip_coriolisadv_cs_t *CS, const mom6hip_obc_t *OBC, const double *u,
                       const double *v, const double *h, const double *uh, const double *vh, double *CAu, double *CAv);

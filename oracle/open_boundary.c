@@ -89,3 +89,48 @@ int orc_open_boundary_zero_normal_flow(const mom6hip_grid_t *G, const mom6hip_ob
   }
   return 0;
 }
+
+/* update_segment_tracer_reservoirs :5373-5502 (OBC%tres_x / tres_y, the restart copies, are not kept here) */
+int orc_update_segment_tracer_reservoirs(const mom6hip_grid_t *G, const double *uhr, const double *vhr, const double *h,
+                                         const mom6hip_obc_t *OBC, double dt, const double *const *tr, int ntr)
+{
+  (void)dt;
+  if (!OBC || !OBC->OBC_pe) return 0;
+  const int nz = G->nk;
+  for (int n = 0; n < OBC->number_of_segments; n++) {
+    const mom6hip_obc_segment_t *S = &OBC->segment[n];
+    if (!S->tr_Reg) continue;
+    const double b_in = (S->Tr_InvLscale_in == 0.0) ? 1.0 : 0.0, b_out = (S->Tr_InvLscale_out == 0.0) ? 1.0 : 0.0;
+    const int ew = S->is_E_or_W != 0;
+    if (!ew && !S->is_N_or_S) continue;
+    const int A = ew ? S->IsdB : S->JsdB, c0 = ew ? S->jsd : S->isd, c1 = ew ? S->jed : S->ied;
+    /* shift + A: the nearest interior tracer cell; dir switches the sign of the flow so that positive is into the reservoir */
+    const int minus = (S->direction == MOM6HIP_OBC_DIRECTION_W) || (S->direction == MOM6HIP_OBC_DIRECTION_S);
+    const int shift = minus ? 1 : 0;
+    const double dir = minus ? -1.0 : 1.0;
+    for (int c = c0; c <= c1; c++) {
+      const long cell2 = ew ? ORC_H2(G, A + shift, c) : ORC_H2(G, c, A + shift);
+      if (G->mask2dT[cell2] == 0.0) continue;
+      const double len = ew ? G->dyCu[ORC_U2(G, A, c)] : G->dxCv[ORC_V2(G, c, A)];
+      for (int q = 0; q < S->ntseg; q++) {
+        const mom6hip_obc_segment_tracer_t *T = &S->tr_Reg[q];
+        if (!T->tres) continue;
+        if (T->ntr_index < 1 || T->ntr_index > ntr || !T->t) return 4;
+        double *tres = (double *)T->tres;
+        for (int k = 1; k <= nz; k++) {
+          const double xr = dir * (ew ? uhr[ORC_U3(G, A, c, k)] : vhr[ORC_V3(G, c, A, k)]);
+          const double hc = ew ? h[ORC_H3(G, A + shift, c, k)] : h[ORC_H3(G, c, A + shift, k)];
+          const double tc = ew ? tr[T->ntr_index - 1][ORC_H3(G, A + shift, c, k)] : tr[T->ntr_index - 1][ORC_H3(G, c, A + shift, k)];
+          const double a_out = b_out * fmax(0.0, copysign(1.0, xr));
+          const double a_in  = b_in  * fmin(0.0, copysign(1.0, xr));
+          const double L_out = fmax(0.0, xr*S->Tr_InvLscale_out*T->resrv_lfac_out / ((hc + G->H_subroundoff)*len));
+          const double L_in  = fmin(0.0, xr*S->Tr_InvLscale_in*T->resrv_lfac_in / ((hc + G->H_subroundoff)*len));
+          const double fac1 = (1.0 - (a_out - a_in)) + ((L_out + a_out) - (L_in + a_in));
+          const long s3 = seg_idx(S, ew, A, c, k);
+          tres[s3] = (1.0/fac1) * ((1.0-a_out+a_in)*tres[s3] + ((L_out+a_out)*tc - (L_in+a_in)*T->t[s3]));
+        }
+      }
+    }
+  }
+  return 0;
+}

@@ -97,6 +97,17 @@ def advect_tracer(grid, h_end, uhtr, vhtr, dt, cs_dt, scheme, tr, conc_underflow
     return st
 
 
+def update_segment_tracer_reservoirs(grid, uhr, vhr, h, OBC, dt, tr):
+    """update_segment_tracer_reservoirs on numpy arrays: the reservoirs tr_Reg[m]["tres"] of the segments are updated in place"""
+    L = lib()
+    L.orc_update_segment_tracer_reservoirs.argtypes = [C.POINTER(_abi.GridStruct), _dp, _dp, _dp, C.POINTER(_abi.Obc), C.c_double, C.POINTER(_dp), C.c_int]
+    obc = OBC.struct()
+    trp = (_dp * len(tr))(*[_p(t) for t in tr])
+    rc = L.orc_update_segment_tracer_reservoirs(C.byref(grid.struct()), _p(uhr), _p(vhr), _p(h), C.byref(obc), float(dt), trp, len(tr))
+    if rc != 0:
+        raise RuntimeError(f"orc_update_segment_tracer_reservoirs failed rc={rc}")
+
+
 # ---- ALE reconstruction + remapping ---------------------------------------------------------------
 REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PLM_HYBGEN": 3, "PPM_H4": 4, "PPM_IH4": 5, "PPM_HYBGEN": 6, "WENO_HYBGEN": 7, "PPM_CW": 10}
 INT_PCM, INT_PLM, INT_PPM = 0, 1, 3

@@ -32,7 +32,7 @@ use MOM_tracer_registry, only : tracer_registry_type
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : BT_cont_type, porous_barrier_type, alloc_BT_cont_type
 use MOM_verticalGrid,   only : verticalGrid_type
-use mom6hip_MOM_glue,   only : mom6hip_shared_context_end
+use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, update_segment_tracer_reservoirs_hip
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -230,6 +230,20 @@ call tracer_advect_init(Time, G, US, pf, diag, TA)
 call advect_tracer(hp, uhtr, vhtr, OBC, dt, G, GV, US, TA, Reg)
 write(u_out) Reg%Tr(1)%t, Reg%Tr(2)%t
 call tracer_advect_end(TA)
+
+! update_segment_tracer_reservoirs (MOM.F90:1447) with the same transports: the reservoir of tracer 1 on every segment, external values
+! and inverse length scales as the test states them
+do n=1,nseg ; if (OBC%segment(n)%on_pe) then
+  OBC%segment(n)%Tr_InvLscale_in = 1.0e-4 ; OBC%segment(n)%Tr_InvLscale_out = merge(0.0, 3.0e-5, mod(n, 2) == 0)
+  i0 = lbound(OBC%segment(n)%tr_Reg%Tr(1)%tres, 1) ; i1 = ubound(OBC%segment(n)%tr_Reg%Tr(1)%tres, 1)
+  j0 = lbound(OBC%segment(n)%tr_Reg%Tr(1)%tres, 2) ; j1 = ubound(OBC%segment(n)%tr_Reg%Tr(1)%tres, 2)
+  allocate(OBC%segment(n)%tr_Reg%Tr(1)%t(i0:i1,j0:j1,nk))
+  do k=1,nk ; do j=j0,j1 ; do i=i0,i1
+    OBC%segment(n)%tr_Reg%Tr(1)%t(i,j,k) = 7.0 + real(mod(2*i + j + k, 5)) / 5.0
+  enddo ; enddo ; enddo
+endif ; enddo
+call update_segment_tracer_reservoirs_hip(G, GV, uhtr, vhtr, hp, OBC, dt, Reg)
+do n=1,nseg ; if (OBC%segment(n)%on_pe) write(u_out) OBC%segment(n)%tr_Reg%Tr(1)%tres ; enddo
 close(u_out)
 call hor_visc_end(HV) ; call vertvisc_end(VV) ; call set_visc_end(visc, SVC)
 call CoriolisAdv_end(CCS)

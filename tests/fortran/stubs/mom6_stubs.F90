@@ -1203,13 +1203,17 @@ use MOM_time_manager, only : time_type
 implicit none ; private
 public :: ocean_OBC_type, radiation_open_bdry_conds, open_boundary_zero_normal_flow, open_boundary_query
 public :: open_boundary_test_extern_h, update_OBC_ramp
-public :: OBC_segment_tracer_type, segment_tracer_registry_type
+public :: OBC_segment_tracer_type, segment_tracer_registry_type, OBC_segment_data_type
 public :: OBC_segment_type, OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W
 integer, parameter :: OBC_NONE = 0, OBC_DIRECTION_N = 100, OBC_DIRECTION_S = 200, OBC_DIRECTION_E = 300, OBC_DIRECTION_W = 400
+type :: OBC_segment_data_type
+  real :: resrv_lfac_in = 1., resrv_lfac_out = 1.
+end type OBC_segment_data_type
 type :: OBC_segment_tracer_type
   real :: OBC_inflow_conc = 0.0
-  real, allocatable :: tres(:,:,:)
-  integer :: ntr_index = -1
+  real, allocatable :: t(:,:,:), tres(:,:,:)
+  real :: scale = 1.0
+  integer :: ntr_index = -1, fd_index = -1
 end type OBC_segment_tracer_type
 type :: segment_tracer_registry_type
   integer :: ntseg = 0
@@ -1224,6 +1228,8 @@ type :: OBC_segment_type
   real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:), tangential_vel(:,:,:), tangential_grad(:,:,:)
   real, allocatable :: SSH(:,:), nudged_normal_vel(:,:,:)
   real :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
+  real :: Tr_InvLscale_in = 0.0, Tr_InvLscale_out = 0.0
+  type(OBC_segment_data_type), pointer :: field(:) => NULL()
 end type OBC_segment_type
 type :: ocean_OBC_type
   logical :: OBC_pe = .false.
@@ -1239,6 +1245,7 @@ type :: ocean_OBC_type
   logical :: specified_strain = .false., zero_biharmonic = .false.
   real :: gamma_uv = 0.3, rx_max = 1.0
   real, allocatable :: rx_normal(:,:,:), ry_normal(:,:,:)
+  real, allocatable :: tres_x(:,:,:,:), tres_y(:,:,:,:)
 end type ocean_OBC_type
 contains
 logical function open_boundary_query(OBC, apply_open_OBC, apply_specified_OBC, apply_Flather_OBC, apply_nudged_OBC, needs_ext_seg_data)

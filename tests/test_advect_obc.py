@@ -182,3 +182,112 @@ def test_gpu_advect_tracer_refuses_bad_registries():
     OBC.segment[0].tr_Reg[0]["tres"] = np.zeros((3, 2, 2))
     with pytest.raises(Mom6HipError, match="shape"):
         run_hip(g, case, OBC, "PLM", "host")
+
+
+# ---- update_segment_tracer_reservoirs (src/core/MOM_open_boundary.F90:5373), called after advect_tracer in step_MOM_tracer_dyn (MOM.F90:1447) ----
+
+def reservoir_case(InvL=(0.0, 0.0), seed=3, segs=SEGS, **kw):
+    g, case, OBC = adv_obc_case(segs, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 50)
+    for s in OBC.segment:
+        if not s.on_pe:
+            continue
+        s.Tr_InvLscale_in, s.Tr_InvLscale_out = InvL
+        s.tr_Reg = [dict(ntr_index=1, tres=5.0 + rng.random(s.normal_vel.shape), t=7.0 + rng.random(s.normal_vel.shape)),
+                    dict(ntr_index=3, OBC_inflow_conc=0.25),      # (no reservoir: not updated)
+                    dict(ntr_index=2, tres=1.0 + rng.random(s.normal_vel.shape), t=2.0 + rng.random(s.normal_vel.shape), resrv_lfac_in=0.5, resrv_lfac_out=2.0)]
+    return g, case, OBC
+
+
+def seg_faces(g, s, a3):
+    """the values of a 3-D face field on a segment's faces, in the layout of its own arrays"""
+    hi = s.HI
+    if s.is_E_or_W:
+        return a3[:, hi["jsd"] - 1:hi["jed"], hi["IsdB"]:hi["IsdB"] + 1]
+    return a3[:, hi["JsdB"]:hi["JsdB"] + 1, hi["isd"] - 1:hi["ied"]]
+
+
+def seg_inside(g, s, a3):
+    """the values of a 3-D cell field in the cells inside a segment"""
+    hi = s.HI
+    plus = s.direction in (_abi.OBC_DIRECTION_E, _abi.OBC_DIRECTION_N)
+    if s.is_E_or_W:
+        i = hi["IsdB"] - 1 + (0 if plus else 1)      # cell I (E) or I + 1 (W), 1-based -> 0-based
+        return a3[:, hi["jsd"] - 1:hi["jed"], i:i + 1]
+    j = hi["JsdB"] - 1 + (0 if plus else 1)
+    return a3[:, j:j + 1, hi["isd"] - 1:hi["ied"]]
+
+
+@pytest.mark.parametrize("InvL", [(0.0, 0.0), (1.0e-4, 3.0e-5), (0.0, 3.0e-5)])
+def test_oracle_reservoirs_take_the_inside_value_on_outflow_and_the_external_one_on_inflow(InvL):
+    g, case, OBC = reservoir_case(InvL)
+    before = [[None if t.get("tres") is None else t["tres"].copy() for t in s.tr_Reg] for s in OBC.segment]
+    orc.update_segment_tracer_reservoirs(g, case["uhtr"], case["vhtr"], case["h_end"], OBC, 3600.0, case["tr"])
+    changed = 0
+    for s, b in zip(OBC.segment, before):
+        xr = seg_faces(g, s, case["uhtr"] if s.is_E_or_W else case["vhtr"])
+        out = (xr > 0) if s.direction in (_abi.OBC_DIRECTION_E, _abi.OBC_DIRECTION_N) else (xr < 0)      # flow out of the domain, into the reservoir
+        wet = seg_inside(g, s, np.broadcast_to(np.asarray(g.mask2dT)[None], case["h_end"].shape)) > 0
+        for q, t in enumerate(s.tr_Reg):
+            if t.get("tres") is None:
+                continue
+            inside = seg_inside(g, s, case["tr"][t["ntr_index"] - 1])
+            new, old = t["tres"], b[q]
+            assert bits_equal(new[~wet], old[~wet])      # (a land cell inside: skipped :5426)
+            changed += int((new != old).sum())
+            lo, hi_ = np.minimum(old, np.minimum(inside, t["t"])), np.maximum(old, np.maximum(inside, t["t"]))
+            assert np.all(new >= lo - 1e-12) and np.all(new <= hi_ + 1e-12)      # a backward-Euler blend of the three
+            if InvL[1] == 0.0:      # no length scale outwards: the reservoir takes the value inside at once
+                m = wet & out & (xr != 0)
+                assert np.allclose(new[m], inside[m], rtol=0, atol=1e-12)
+            if InvL[0] == 0.0:      # none inwards: the external value at once
+                m = wet & ~out & (xr != 0)
+                assert np.allclose(new[m], t["t"][m], rtol=0, atol=1e-12)
+    assert changed > 0
+
+
+def test_oracle_reservoirs_turn_with_the_grid():
+    g, case, OBC = reservoir_case((1.0e-4, 3.0e-5), segs=SEGS_TURN)
+    gr = rotate_grid(g)
+    OBCr = ocean_OBC_type(gr, turned_segments(SEGS_TURN, g.ni, g.nj))
+    T_ = lambda a, s: np.ascontiguousarray(np.swapaxes(a, 1, 2) if s.is_E_or_W else np.swapaxes(a, 1, 2)[:, ::-1, :])
+    for s, sr in zip(OBC.segment, OBCr.segment):
+        sr.Tr_InvLscale_in, sr.Tr_InvLscale_out = s.Tr_InvLscale_in, s.Tr_InvLscale_out
+        sr.tr_Reg = [{k: (T_(v, s) if isinstance(v, np.ndarray) else v) for k, v in t.items()} for t in s.tr_Reg]
+    ur, vr = rot_vector(case["uhtr"], case["vhtr"])
+    orc.update_segment_tracer_reservoirs(g, case["uhtr"], case["vhtr"], case["h_end"], OBC, 3600.0, case["tr"])
+    orc.update_segment_tracer_reservoirs(gr, ur, vr, rot(case["h_end"]), OBCr, 3600.0, [rot(t) for t in case["tr"]])
+    for s, sr in zip(OBC.segment, OBCr.segment):
+        for t, tr_ in zip(s.tr_Reg, sr.tr_Reg):
+            if t.get("tres") is not None:
+                assert bits_equal(T_(t["tres"], s), tr_["tres"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("InvL", [(0.0, 0.0), (1.0e-4, 3.0e-5), (0.0, 3.0e-5)])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_update_segment_tracer_reservoirs_matches_oracle_bitwise(InvL, space):
+    import copy
+    import torch
+    from mom6_amd.open_boundary import update_segment_tracer_reservoirs
+    from mom6_amd.tracer_advect import DeviceGrid
+    for (ni, nj, nk, seed) in [(22, 16, 3, 3), (150, 40, 2, 5)]:
+        g, case, OBC = reservoir_case(InvL, seed=seed, ni=ni, nj=nj, nk=nk)
+        ref = copy.deepcopy(OBC)
+        orc.update_segment_tracer_reservoirs(g, case["uhtr"], case["vhtr"], case["h_end"], ref, 3600.0, case["tr"])
+        dev = space == "device"
+        X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if dev else (lambda a: a)
+        if dev:
+            OBC.cuda()
+        dg = DeviceGrid(g)
+        update_segment_tracer_reservoirs(dg, X(case["uhtr"]), X(case["vhtr"]), X(case["h_end"]), OBC, 3600.0, [X(t) for t in case["tr"]])
+        dg.sync()
+        n = 0
+        for s, sr in zip(OBC.segment, ref.segment):
+            for t, tr_ in zip(s.tr_Reg, sr.tr_Reg):
+                if t.get("tres") is not None:
+                    got = t["tres"].cpu().numpy() if dev else t["tres"]
+                    assert bits_equal(got, tr_["tres"]), (InvL, space, ni, np.argwhere(got != tr_["tres"])[:4])
+                    n += 1
+        assert n == 2 * len(OBC.segment)
+        dg.close()

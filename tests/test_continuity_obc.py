@@ -361,12 +361,26 @@ def test_continuity_with_an_associated_OBC_from_fortran(tmp_path, segs):
                         dict(ntr_index=2, OBC_inflow_conc=0.25 + 0.125 * (n + 1))]
     orc.advect_tracer(g, want["h"], 900.0 * want["uh"], 900.0 * want["vh"], 900.0, 900.0, "PPM:H3", tr, OBC=OBC)
     want["tr1"], want["tr2"] = tr
+    # update_segment_tracer_reservoirs with the same transports (the values as the driver states them)
+    for n, s in enumerate(OBC.segment):
+        if s.on_pe:
+            s.Tr_InvLscale_in, s.Tr_InvLscale_out = 1.0e-4, (0.0 if (n + 1) % 2 == 0 else 3.0e-5)
+            i0, j0 = (s.HI["IsdB"], s.HI["jsd"]) if s.is_E_or_W else (s.HI["isd"], s.HI["JsdB"])
+            nk_, nj_, ni_ = s.normal_vel.shape
+            si, sj, sk = i0 + np.arange(ni_)[None, None, :], j0 + np.arange(nj_)[None, :, None], 1 + np.arange(nk_)[:, None, None]
+            s.tr_Reg[0]["t"] = np.ascontiguousarray(7.0 + ((2 * si + sj + sk) % 5).astype(np.float64) / 5.0)
+    orc.update_segment_tracer_reservoirs(g, 900.0 * want["uh"], 900.0 * want["vh"], want["h"], OBC, 900.0, tr)
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0 and "obc_driver ok" in r.stdout, r.stderr[-800:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
     names = ["h", "uh", "vh", "u_cor", "v_cor", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0",
              "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v", "CAu", "CAv", "bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u1", "v1", "diffu", "diffv", "tr1", "tr2"]
     arrs = [want[n] if n in want else want["bt"][n] for n in names]
+    tres = [s.tr_Reg[0]["tres"] for s in OBC.segment if s.on_pe]
+    raw, raw_tres = raw[:sum(a.size for a in arrs)], raw[sum(a.size for a in arrs):]
+    assert raw_tres.size == sum(a.size for a in tres)
+    for n, (a, w) in enumerate(zip(np.split(raw_tres, np.cumsum([a.size for a in tres])[:-1]), tres)):
+        assert bits_equal(a.reshape(w.shape), w), ("tres", n, np.argwhere(a.reshape(w.shape) != w)[:4].tolist())
     got = np.split(raw, np.cumsum([a.size for a in arrs])[:-1])
     for n, a, w in zip(names, got, arrs):
         pos = _abi.POS_U if n in ("uh", "u_cor", "h_u", "CAu", "u1", "bbl_thick_u", "Kv_bbl_u", "diffu") or n.startswith(("FA_u", "uBT")) else (_abi.POS_V if n in ("vh", "v_cor", "h_v", "CAv", "v1", "bbl_thick_v", "Kv_bbl_v", "diffv") or n.startswith(("FA_v", "vBT")) else _abi.POS_H)
