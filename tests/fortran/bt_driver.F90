@@ -42,9 +42,14 @@ real, allocatable, dimension(:,:,:) :: u, v, h, bcu, bcv, pbce, vru, vrv, alu, a
 real, pointer, dimension(:,:,:) :: uh0 => NULL(), vh0 => NULL(), u_uh0 => NULL(), v_vh0 => NULL()
 real, pointer, dimension(:,:) :: eta_PF_start => NULL(), taux_bot => NULL(), tauy_bot => NULL()
 real, allocatable, dimension(:,:) :: eta, eta_PF, eta_out, uhbtav, vhbtav, etaav, SpV, ubtav, vbtav
-character(len=512) :: f_in, f_out
+character(len=512) :: f_in, f_out, f_obc
+integer(c_int32_t) :: oflags(8), sflags(20), gflags(8)
+integer(c_int32_t), allocatable :: seg_u(:,:), seg_v(:,:)
+integer :: u_obc, nseg, m, i0, i1, j0, j1
+real :: oscal(2)
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
+f_obc = "" ; if (command_argument_count() >= 3) call get_command_argument(3, f_obc)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
 read(u_in) hdr
 ni = hdr(1) ; nj = hdr(2) ; nk = hdr(3) ; halo = hdr(4)
@@ -92,13 +97,49 @@ allocate(alu(isd-1:ied,jsd:jed,nk), alv(isd:ied,jsd-1:jed,nk), eta_out(isd:ied,j
          vhbtav(isd:ied,jsd-1:jed), etaav(isd:ied,jsd:jed), SpV(isd:ied,jsd:jed), ubtav(isd-1:ied,jsd:jed), vbtav(isd:ied,jsd-1:jed))
 alu = 0.0 ; alv = 0.0 ; eta_out = 0.0 ; uhbtav = 0.0 ; vhbtav = 0.0 ; etaav = 0.0 ; SpV = 1.0 ; ubtav = 0.0 ; vbtav = 0.0
 
+! the open boundaries (a third argument): the file of dyn_driver.F90
+if (len_trim(f_obc) > 0) then
+  open(newunit=u_obc, file=trim(f_obc), access="stream", form="unformatted", status="old")
+  allocate(OBC)
+  read(u_obc) oflags, gflags, oscal
+  nseg = oflags(1)
+  OBC%number_of_segments = nseg ; OBC%OBC_pe = (oflags(2) /= 0)
+  OBC%open_u_BCs_exist_globally = (oflags(3) /= 0) ; OBC%open_v_BCs_exist_globally = (oflags(4) /= 0)
+  OBC%specified_u_BCs_exist_globally = (oflags(5) /= 0) ; OBC%specified_v_BCs_exist_globally = (oflags(6) /= 0)
+  OBC%Flather_u_BCs_exist_globally = (oflags(7) /= 0) ; OBC%Flather_v_BCs_exist_globally = (oflags(8) /= 0)
+  allocate(OBC%segment(nseg))
+  do m=1,nseg
+    read(u_obc) sflags
+    OBC%segment(m)%direction = sflags(1) ; OBC%segment(m)%open = (sflags(2) /= 0) ; OBC%segment(m)%specified = (sflags(3) /= 0)
+    OBC%segment(m)%on_pe = (sflags(4) /= 0) ; OBC%segment(m)%is_E_or_W = (sflags(5) /= 0) ; OBC%segment(m)%is_N_or_S = (sflags(6) /= 0)
+    OBC%segment(m)%HI%IsdB = sflags(7) ; OBC%segment(m)%HI%IedB = sflags(8) ; OBC%segment(m)%HI%JsdB = sflags(9) ; OBC%segment(m)%HI%JedB = sflags(10)
+    OBC%segment(m)%HI%isd = sflags(11) ; OBC%segment(m)%HI%ied = sflags(12) ; OBC%segment(m)%HI%jsd = sflags(13) ; OBC%segment(m)%HI%jed = sflags(14)
+    OBC%segment(m)%Flather = (sflags(15) /= 0) ; OBC%segment(m)%radiation = (sflags(16) /= 0) ; OBC%segment(m)%gradient = (sflags(17) /= 0)
+    OBC%segment(m)%nudged = (sflags(18) /= 0)
+  enddo
+  allocate(seg_u(isd-1:ied,jsd:jed), seg_v(isd:ied,jsd-1:jed), OBC%segnum_u(isd-1:ied,jsd:jed), OBC%segnum_v(isd:ied,jsd-1:jed))
+  read(u_obc) seg_u, seg_v
+  OBC%segnum_u(:,:) = seg_u(:,:) ; OBC%segnum_v(:,:) = seg_v(:,:)
+  do m=1,nseg ; if (OBC%segment(m)%on_pe) then
+    if (OBC%segment(m)%is_E_or_W) then
+      i0 = OBC%segment(m)%HI%IsdB ; i1 = OBC%segment(m)%HI%IedB ; j0 = OBC%segment(m)%HI%jsd ; j1 = OBC%segment(m)%HI%jed
+    else
+      i0 = OBC%segment(m)%HI%isd ; i1 = OBC%segment(m)%HI%ied ; j0 = OBC%segment(m)%HI%JsdB ; j1 = OBC%segment(m)%HI%JedB
+    endif
+    allocate(OBC%segment(m)%normal_vel(i0:i1,j0:j1,nk), OBC%segment(m)%normal_trans(i0:i1,j0:j1,nk), OBC%segment(m)%normal_vel_bt(i0:i1,j0:j1), &
+             OBC%segment(m)%SSH(i0:i1,j0:j1))
+    read(u_obc) OBC%segment(m)%normal_vel, OBC%segment(m)%normal_trans, OBC%segment(m)%normal_vel_bt, OBC%segment(m)%SSH
+  endif ; enddo
+  close(u_obc)
+endif
+
 call param_set(pf, "REENTRANT_X", merge("True ", "False", hdr(5) /= 0))
 call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))
 write(str, '(es24.16)') dtbt ; call param_set(pf, "DTBT", str)
 call register_barotropic_restarts(HI, GV, US, pf, CS, restart_CS)
 call barotropic_init(u, v, h, eta, Time, G, GV, US, pf, diag, CS, restart_CS, calc_dtbt, BT)
 call barotropic_get_tav(CS, ubtav, vbtav, G, US)
-call btcalc(h, G, GV, CS, BT%h_u, BT%h_v)
+call btcalc(h, G, GV, CS, BT%h_u, BT%h_v, OBC=OBC)
 call bt_mass_source(h, eta, .true., G, GV, CS)
 call btstep(u, v, eta, dt, bcu, bcv, forces, pbce, eta_PF, u, v, alu, alv, eta_out, uhbtav, vhbtav, G, GV, US, CS, &
             vru, vrv, SpV, ADp, OBC, BT, eta_PF_start, taux_bot, tauy_bot, uh0, vh0, u_uh0, v_vh0, etaav=etaav)

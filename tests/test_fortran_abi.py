@@ -225,6 +225,43 @@ def test_barotropic_shim_matches_oracle(tmp_path):
         assert bits_equal(interior(g, a, pos), interior(g, w, pos)), n
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+def test_barotropic_shim_with_open_boundaries_matches_oracle(tmp_path):
+    """btcalc and btstep of the MOM_barotropic shim with the reference's ocean_OBC_type (Flather, gradient and specified segments, two of
+    them inside the domain; segment%normal_vel_bt, %SSH, %normal_trans on host arrays): the oracle's bits"""
+    from helpers import interior
+    from oracle import orc
+    from test_barotropic_obc import BT_SEGS, btstep_obc_case
+    from test_testing_configs import write_obc_file
+    exe = _build_shims(tmp_path, "bt_driver")
+    g, cs, case, keep, OBC = btstep_obc_case(BT_SEGS, ni=26, nj=14)
+    h, bt = keep["h"], keep["bt_arrs"]
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([g.ni, g.nj, g.nk, g.halo, 0, 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, case["dt"], cs.dtbt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (case["U_in"], case["V_in"], h, case["eta_in"], case["bc_accel_u"], case["bc_accel_v"], case["taux"], case["tauy"], case["pbce"],
+                  case["eta_PF_in"], case["visc_rem_u"], case["visc_rem_v"], case["uh0"], case["vh0"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        for n in ("FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE", "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"):
+            np.ascontiguousarray(bt[n], dtype="<f8").tofile(f)
+    write_obc_file(str(tmp_path / "obc.bin"), g, OBC)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "obc.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and "bt_driver ok" in r.stdout, r.stderr[-1500:]
+    out = orc.btstep(g, cs, want_etaav=True, OBC=OBC, **case)
+    closed = orc.btstep(g, cs, want_etaav=True, **case)
+    assert not bits_equal(out["eta_out"], closed["eta_out"])
+    names = ["accel_layer_u", "accel_layer_v", "eta_out", "uhbtav", "vhbtav", "etaav"]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [out[n].size for n in names]
+    for n, a in zip(names, np.split(raw[:sum(sizes)], np.cumsum(sizes)[:-1])):
+        a = a.reshape(out[n].shape)
+        pos = _abi.POS_U if n in ("accel_layer_u", "uhbtav") else (_abi.POS_V if n in ("accel_layer_v", "vhbtav") else _abi.POS_H)
+        assert bits_equal(interior(g, a, pos), interior(g, out[n], pos)), (n, np.argwhere(interior(g, a, pos) != interior(g, out[n], pos))[:4].tolist())
+
+
 # ---- the device-resident step, from Fortran through mom6hip_c_api only ---------------------------------------------
 def _build_rk2_driver(tmp):
     flags = ["-O0", "-ffp-contract=off"]
