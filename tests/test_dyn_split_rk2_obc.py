@@ -174,6 +174,33 @@ def test_gpu_step_with_open_boundaries_matches_oracle_bitwise(segs, viscous):
 
 
 @pytest.mark.gpu
+def test_gpu_step_with_open_boundaries_on_a_larger_grid_matches_oracle_bitwise():
+    """300 x 200 x 5 (many blocks in every kernel of the OBC path), tc3's segments and two inside the domain"""
+    segs = TC3 + ["I=120,J=40:160,SIMPLE", "J=90,I=250:30,FLATHER"]
+    g, d, taux, tauy, OBC = rk2_obc_case(segs, ni=300, nj=200, nk=5, seed=11)
+    rng = np.random.default_rng(11)
+    for s in OBC.segment:
+        if s.on_pe and s.specified:
+            s.normal_vel[:] = 0.05 * rng.standard_normal(s.normal_vel.shape)
+            s.normal_trans[:] = s.normal_vel * (3.0e4 * (5.0 + 50.0 * rng.random(s.normal_vel.shape)))
+        if s.on_pe and s.Flather:
+            s.normal_vel_bt[:] = 0.02 * rng.standard_normal(s.normal_vel_bt.shape); s.SSH[:] = 0.05 * rng.standard_normal(s.SSH.shape)
+    bbl = visc_arrays(g)
+    import copy
+    OBCo = copy.deepcopy(OBC)
+    ref = oracle_state(g, d, OBCo, True, bbl=bbl)
+
+    def check(n, f):
+        ref.step(taux, tauy)
+        want = dict(u=ref.u, v=ref.v, h=ref.h, uh=ref.uh, vh=ref.vh, uhtr=ref.uhtr, eta_av=ref.eta_av)
+        for name in want:
+            an = f[name].cpu().numpy()
+            assert bits_equal(an, want[name]), (n, name, np.argwhere(an != want[name])[:4].tolist())
+        assert bits_equal(OBC.rx_normal.cpu().numpy(), OBCo.rx_normal) and bits_equal(OBC.ry_normal.cpu().numpy(), OBCo.ry_normal)
+    gpu_run(g, d, taux, tauy, OBC, True, bbl, 2, check)
+
+
+@pytest.mark.gpu
 def test_gpu_step_with_an_OBC_without_segments_is_the_closed_step():
     g, d, taux, tauy, _ = rk2_obc_case(segs=None)
     bbl = visc_arrays(g)
