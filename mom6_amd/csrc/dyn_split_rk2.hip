@@ -145,7 +145,6 @@ int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_
   mom6hip_vertvisc_cs_t *VV = cs->vertvisc_CSp;
   M6_REQUIRE(!cs->hooks, "step_MOM_dyn_split_RK2: host-side parameterisations (hooks) are not provided with an associated OBC");
   M6_REQUIRE(!m6::multi_tile(ctx), "step_MOM_dyn_split_RK2: an associated OBC is provided on one tile");
-  M6_REQUIRE(!(cs->set_visc_CSp && cs->set_visc_CSp->dynamic_viscous_ML), "step_MOM_dyn_split_RK2: DYNAMIC_VISCOUS_ML is not provided with an associated OBC");
 
   // the step's automatic arrays (:336-369), with u_old_rad_OBC, v_old_rad_OBC (:360-363)
   const size_t blk_bytes = 4 * sz.u3 + 4 * sz.v3 + sz.h3 + sz.h2;
@@ -192,6 +191,12 @@ int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_
   };
   CALL(bc_accel(cs->CAu_pred, cs->CAv_pred));
   increment(up, vp, dt, false);
+  if (VV && cs->set_visc_CSp && cs->set_visc_CSp->dynamic_viscous_ML) {      // set_viscous_ML :592 (the OBC acts there under ice shelves only)
+    M6_REQUIRE(cs->visc && cs->visc->ustar && cs->visc->nkml_visc_u && cs->visc->nkml_visc_v,
+               "step_MOM_dyn_split_RK2: DYNAMIC_VISCOUS_ML needs forces%%ustar (visc->ustar) and visc%%nkml_visc_u / nkml_visc_v");
+    CALL(m6::set_viscous_ML_dev(ctx, cs->set_visc_CSp, u_inst, v_inst, h, T, S, cs->eqn_of_state, taux, tauy, cs->visc->ustar,
+                                (double *)cs->visc->nkml_visc_u, (double *)cs->visc->nkml_visc_v, dt));
+  }
   if (VV) {      // vertvisc_coef, vertvisc_remnant :598-600
     CALL(mom6hip_vertvisc_coef_obc(ctx, VV, up, vp, h, nullptr, cs->visc, dt, OBC, D));
     CALL(mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dt, D));

@@ -157,8 +157,8 @@ subroutine set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, CS)
   integer :: rc
   if (.not.CS%initialized) call MOM_error(FATAL, "MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
   if (CS%st%dynamic_viscous_ML == 0) return      ! :2043-2044 (ice shelves are refused at initialisation)
-  if (associated(CS%OBC)) call MOM_error(FATAL, "set_viscous_ML (HIP): DYNAMIC_VISCOUS_ML with open boundary conditions "// &
-       "(the masks and projections of :2099-2117) is not provided by the GPU path.")
+  ! (an associated CS%OBC: the masks of :2099-2117 are read by set_v_at_u / set_u_at_v under ice shelves only (:2242-2391, :2519-2670),
+  ! which set_visc_init has refused: the open boundaries leave set_viscous_ML as it is)
   if (.not.(associated(forces%taux) .and. associated(forces%tauy))) call MOM_error(FATAL, "set_viscous_ML (HIP): "// &
        "forces%taux and forces%tauy must be associated.")
   if (.not.associated(forces%ustar)) call MOM_error(FATAL, "set_viscous_ML (HIP): forces%ustar must be associated (the GPU "// &

@@ -113,8 +113,7 @@ def set_viscous_ML(u, v, h, tv, forces, visc, dt, G: DeviceGrid, CS: set_visc_CS
     visc.ustar; writes visc.nkml_visc_u / nkml_visc_v."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_set_viscosity(visc_ML): Module must be initialized before it is used.")
-    if CS.st.dynamic_viscous_ML and getattr(CS, "OBC", None) is not None:
-        raise Mom6HipError("set_viscous_ML (HIP): DYNAMIC_VISCOUS_ML with open boundary conditions is not provided")
+    # (CS%OBC: its masks :2099-2117 are read under ice shelves only, which are not provided: open boundaries leave set_viscous_ML as it is)
     if not CS.st.dynamic_viscous_ML:
         check(_setup().mom6hip_set_viscous_ml(G.handle, C.byref(CS.st), None, None, None, None, None, None, None, None,
                                               C.byref(visc.st), float(dt), _abi.MEM_DEVICE), "set_viscous_ML")

@@ -210,3 +210,47 @@ def test_gpu_step_with_an_OBC_without_segments_is_the_closed_step():
         gpu_run(g, d, taux, tauy, OBC, True, bbl, 2, lambda n, f: got.update({k: a.cpu().numpy().copy() for k, a in f.items()}))
         out.append(got)
     assert all(bits_equal(out[0][k], out[1][k]) for k in out[0])
+
+
+@pytest.mark.gpu
+def test_gpu_step_with_open_boundaries_and_the_tc2_switch_set_matches_oracle_bitwise():
+    """DYNAMIC_VISCOUS_ML (set_viscous_ML at :592: its OBC masks are read under ice shelves only), NONLINEAR_BT_CONTINUITY, BT_PROJECT_VELOCITY,
+    BOUND_BT_CORRECTION, Laplacian + biharmonic Smagorinsky -- the hot-path switches of .testing/tc2 -- with tc3's open boundaries"""
+    import copy
+    import torch
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    from test_dyn_split_rk2 import TC_PARAMS, TC_SETS
+    c = TC_SETS["tc2"]
+    ni, nj, nk = c["shape"]
+    g, d, taux, tauy, OBC = rk2_obc_case(TC3, ni=ni + 8, nj=nj + 6, nk=nk, seed=21)
+    rng = np.random.default_rng(17)
+    arrs = visc_arrays(g)
+    arrs.update(ustar=np.ascontiguousarray(0.004 + 0.008 * rng.random(g.shape2(H))), nkml_visc_u=g.zeros2(U), nkml_visc_v=g.zeros2(V))
+    dt = c["dt"] / 4
+    OBCo = copy.deepcopy(OBC)
+    ref = orc.DynState(g, d["u"], d["v"], d["h"], d["T"], d["S"], dt, be=c["be"], eos_form=orc.eos(*c["eos"]), pressureforce=c["pressureforce"],
+                       vertvisc=orc.vertvisc_cs(g, **c["vv"]), visc=orc.vertvisc_type(**arrs), hor_visc=orc.hor_visc_cs(g, dt, **c["hv"]),
+                       set_visc=orc.set_visc_cs(g, 10.0, 1.0e-4, dynamic_viscous_ML=True, **c["ml"]),
+                       continuity={k: c[k] for k in ("tol_eta", "tol_vel") if k in c}, coriolis=c["cor"], OBC=OBCo, **c["bt"])
+    dg = DeviceGrid(g)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u, v, h, Tt, Ss = (T(d[k]) for k in ("u", "v", "h", "T", "S"))
+    Z = lambda pos, k3=True: torch.zeros(g.shape3(pos) if k3 else g.shape2(pos), dtype=torch.float64, device="cuda")
+    uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+    CS = initialize_dyn_split_RK2(u, v, h, uh, vh, dt, dg, OBC=OBC.cuda(), **TC_PARAMS["tc2"])
+    va = {n: T(a) for n, a in arrs.items()}
+    visc = vertvisc_type(**va)
+    tx, ty = T(taux), T(tauy)
+    for n in range(3):
+        ref.step(taux, tauy, calc_dtbt=(n == 0))
+        step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, dt, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS, calc_dtbt=(n == 0))
+        dg.sync()
+        for nm, a, b in [("u", u, ref.u), ("v", v, ref.v), ("h", h, ref.h), ("uh", uh, ref.uh), ("eta_av", eta_av, ref.eta_av),
+                         ("nkml_visc_u", va["nkml_visc_u"], ref.visc._keep["nkml_visc_u"]), ("nkml_visc_v", va["nkml_visc_v"], ref.visc._keep["nkml_visc_v"]),
+                         ("rx_normal", OBC.rx_normal, OBCo.rx_normal)]:
+            an = a.cpu().numpy()
+            assert bits_equal(an, b), (n, nm, float(np.abs(an - b).max()))
+    assert ref.visc._keep["nkml_visc_u"].max() > 1 and np.abs(ref.u[:, OBC.segnum_u != 0]).max() > 0
+    dg.close()
