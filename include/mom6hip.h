@@ -541,7 +541,7 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
  * (mom6hip_btcalc_obc, mom6hip_btstep_obc), of set_viscous_BBL (mom6hip_set_viscous_bbl_obc), of horizontal_viscosity
  * (mom6hip_horizontal_viscosity_obc), of advect_tracer (mom6hip_advect_tracer_obc: the tracer registries of the segments), and
  * radiation_open_bdry_conds / open_boundary_zero_normal_flow for the normal component, and of step_MOM_dyn_split_RK2 (cs->OBC of
- * mom6hip_dyn_split_rk2_cs_t); tracer_hordiff and step_MOM_dyn_split_RK2b still require that OBC is not associated.  The segments' data
+ * mom6hip_dyn_split_rk2_cs_t); step_MOM_dyn_split_RK2b reads cs->OBC likewise (tracer_hordiff takes no OBC in the reference).  The segments' data
  * (update_OBC_segment_data) are the host's business: MOM_open_boundary stays the reference's.
  * Index ranges are in the local index space of the grid structure: isd, jsd and so on.
  */

@@ -632,7 +632,11 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   CALL(check(cs, "step_MOM_dyn_split_RK2b"));
   M6_REQUIRE(!cs->eqn_of_state || (T && S), "step_MOM_dyn_split_RK2b: an equation of state needs tv%%T and tv%%S");
   M6_REQUIRE(cs->du_av_inst && cs->dv_av_inst, "step_MOM_dyn_split_RK2b: du_av_inst / dv_av_inst are not allocated");
-  M6_REQUIRE(!cs->OBC, "step_MOM_dyn_split_RK2b: an associated OBC is provided with SPLIT_RK2B = False only");
+  // CS%OBC: the OBC entry points of the operators, open_boundary_zero_normal_flow on the accelerations (:571-573, :866-868) and
+  // radiation_open_bdry_conds on u_av (:766-774, :1000-1002), as in step_with_obc
+  const mom6hip_obc_t *OBC = cs->OBC;
+  M6_REQUIRE(!OBC || !cs->hooks, "step_MOM_dyn_split_RK2b: host-side parameterisations (hooks) are not provided with an associated OBC");
+  M6_REQUIRE(!OBC || !m6::multi_tile(ctx), "step_MOM_dyn_split_RK2b: an associated OBC is provided on one tile");
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);
   hipStream_t s = ctx->stream;
@@ -646,12 +650,12 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   mom6hip_vertvisc_cs_t *VV = cs->vertvisc_CSp;
   M6_REQUIRE(!VV || cs->visc, "step_MOM_dyn_split_RK2b: vertvisc_CSp needs the visc argument (cs->visc)");
 
-  const size_t blk_bytes = 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2;
+  const size_t blk_bytes = 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2 + (OBC ? sz.u3 + sz.v3 : 0);
   // (the block is shared with step_MOM_dyn_split_RK2, whose layout differs: after the other stepper the faces that rely on
   // being zero hold other arrays' values, so a change of stepper zeroes the block like a new allocation)
   const bool fresh = ctx->rk2_scratch.bytes < blk_bytes || ctx->rk2_scratch_layout != 2;
   M6_REQUIRE(ctx->rk2_scratch.reserve(blk_bytes) == 0, "step_MOM_dyn_split_RK2b: out of device memory");
-  ctx->rk2_scratch_layout = 2;
+  ctx->rk2_scratch_layout = 2;      // (with an OBC: u_old_rad_OBC, v_old_rad_OBC behind the same layout)
   char *blk = (char *)ctx->rk2_scratch.p;
   double *up = (double *)blk, *u_bc = (double *)(blk + sz.u3), *uh_in = (double *)(blk + 2 * sz.u3);
   double *vp = (double *)(blk + 3 * sz.u3), *v_bc = (double *)(blk + 3 * sz.u3 + sz.v3), *vh_in = (double *)(blk + 3 * sz.u3 + 2 * sz.v3);
@@ -661,10 +665,31 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   // zeroed when allocated (the block) and by dyn_split_rk2b_init (u_inst, v_inst).
   if (fresh) M6_HIP(hipMemsetAsync(blk, 0, blk_bytes, s));
   M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :403
+  double *u_old = nullptr, *v_old = nullptr;
+  if (OBC) {                                                                                          // :436-442
+    u_old = (double *)(blk + 3 * sz.u3 + 3 * sz.v3 + sz.h3 + sz.h2); v_old = (double *)((char *)u_old + sz.u3);
+    M6_HIP(hipMemcpyAsync(u_old, u_av, sz.u3, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(v_old, v_av, sz.v3, hipMemcpyDeviceToDevice, s));
+  }
+  // the operators, with the OBC where one is associated
+  auto coradcalc = [&](double *CAu, double *CAv) -> int {
+    return OBC ? mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, OBC, u_av, v_av, cs->h_av, uh, vh, CAu, CAv, D)
+               : mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, cs->h_av, uh, vh, CAu, CAv, D);
+  };
+  auto btcalc = [&](const double *hu, const double *hv) -> int {
+    return OBC ? mom6hip_btcalc_obc(ctx, BT, h, hu, hv, 0, OBC, D) : mom6hip_btcalc(ctx, BT, h, hu, hv, 0, D);
+  };
+  auto vertvisc_step = [&](double *uu, double *vv, double dtx, int update) -> int {
+    if (!OBC) return mom6hip_vertvisc_step(ctx, VV, uu, vv, h, nullptr, update ? taux : nullptr, update ? tauy : nullptr, cs->visc, dtx, update, nullptr,
+                                           nullptr, cs->visc_rem_u, cs->visc_rem_v, D);
+    CALL(mom6hip_vertvisc_coef_obc(ctx, VV, uu, vv, h, nullptr, cs->visc, dtx, OBC, D));
+    if (update) CALL(mom6hip_vertvisc_obc(ctx, VV, uu, vv, h, taux, tauy, cs->visc, dtx, nullptr, nullptr, OBC, D));
+    return mom6hip_vertvisc_remnant(ctx, VV, cs->visc, cs->visc_rem_u, cs->visc_rem_v, dtx, D);
+  };
 
   // continuity with the filtered velocities :488, PressureForce :498, pass_hp_uhvh :535, h_av :540-542
-  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_av, v_av, h, hp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                          nullptr, nullptr, nullptr, D));
+  CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, u_av, v_av, h, hp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, D));
   CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,
                                       cs->eta_PF, D));
   CALL(pass(ctx, {{hp, PH}, {uh, PU}, {vh, PV}}, nz));
@@ -676,7 +701,10 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   };
   set_h_av();
   auto hor_visc = [&]() -> int {
-    if (cs->hor_visc) {
+    if (cs->hor_visc && OBC) {
+      CALL(mom6hip_horizontal_viscosity_obc(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, dt, BTC ? BTC->h_u : nullptr,
+                                            BTC ? BTC->h_v : nullptr, OBC, D));
+    } else if (cs->hor_visc) {
       if (m6::horizontal_viscosity_dev(ctx, cs->hor_visc, u_av, v_av, h_av, cs->diffu, cs->diffv, BTC ? BTC->h_u : nullptr,
                                        BTC ? BTC->h_v : nullptr)) return 1;
     } else if (hk && hk->horizontal_viscosity) {
@@ -685,13 +713,13 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
     }
     return 0;
   };
-  CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));   // :548
+  CALL(coradcalc(cs->CAu_pred, cs->CAv_pred));                                                            // :548
   CALL(hor_visc());                                                                                          // :555
 
   // u_bc_accel :561-568 ; up = mask*(u_av + dt*u_bc_accel) :587-594 (read only by vertvisc_coef)
   auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
     const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
-    const bool need_up = first_up && (VV || (hk && hk->visc_remnant_pred));
+    const bool need_up = first_up && (VV || (hk && hk->visc_remnant_pred)) && !OBC;      // (with an OBC: after the accelerations are zeroed on the segments)
     launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
       const long n = g.u3(I, j, k);
       const double a = (CAu[n] + PFu[n]) + diffu[n];
@@ -706,6 +734,19 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
     });
   };
   bc_accel(cs->CAu_pred, cs->CAv_pred, true);
+  if (OBC) {
+    CALL(mom6hip_open_boundary_zero_normal_flow(ctx, OBC, u_bc, v_bc, D));                            // :571-573
+    if (VV) {                                                                                         // :587-594
+      launch3d(s, Isq, Ieq, js, je, nz, [=] __device__(int I, int j, int k) {
+        const long n = g.u3(I, j, k);
+        up[n] = g.mask2dCu[g.u2(I, j)] * (u_av[n] + dt * u_bc[n]);
+      });
+      launch3d(s, is, ie, Jsq, Jeq, nz, [=] __device__(int i, int J, int k) {
+        const long n = g.v3(i, J, k);
+        vp[n] = g.mask2dCv[g.v2(i, J)] * (v_av[n] + dt * v_bc[n]);
+      });
+    }
+  }
   if (hk && hk->visc_remnant_pred) {   // set_viscous_ML, vertvisc_coef, vertvisc_remnant :598-606
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
@@ -716,10 +757,10 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
       CALL(m6::set_viscous_ML_dev(ctx, cs->set_visc_CSp, u_av, v_av, h, T, S, cs->eqn_of_state, taux, tauy, cs->visc->ustar,
                                   (double *)cs->visc->nkml_visc_u, (double *)cs->visc->nkml_visc_v, dt));
     }
-    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, nullptr, nullptr, cs->visc, dt, 0, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+    CALL(vertvisc_step(up, vp, dt, 0));
   }
   CALL(pass(ctx, {{eta, PH | P2D}, {cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}}, nz));                 // :616-617
-  if (!BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, nullptr, nullptr, 0, D));                     // :623-625
+  if (!BT_cont_BT_thick) CALL(btcalc(nullptr, nullptr));                                                 // :623-625
   CALL(mom6hip_bt_mass_source(ctx, BT, h, eta, 1, D));
   {   // the instantaneous velocities :641-646, pass_uv_inst :648
     const double *du = cs->du_av_inst, *dv = cs->dv_av_inst, *vru = cs->visc_rem_u, *vrv = cs->visc_rem_v;
@@ -733,13 +774,13 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
     });
   }
   CALL(pass(ctx, {{u_inst, PU}, {v_inst, PV}}, nz));
-  CALL(mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,      // :652
-                          cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
-  if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :655-658
+  CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, u_inst, v_inst, h, hp, uh_in, vh_in, dt, nullptr, nullptr, cs->visc_rem_u,      // :652
+                              cs->visc_rem_v, nullptr, nullptr, BTC, nullptr, nullptr, D));
+  if (BT_cont_BT_thick) CALL(btcalc(BTC->h_u, BTC->h_v));                                                // :655-658
   if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));                       // :664
-  CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :668
-                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
-                      nullptr, uh_in, vh_in, u_inst, v_inst, nullptr, D));
+  CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :668
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          nullptr, uh_in, vh_in, u_inst, v_inst, nullptr, OBC, D));
 
   // up = u_inst + dt_pred*(u_bc_accel + u_accel_bt) :675-686
   const double dt_pred = dt * cs->be;
@@ -758,24 +799,32 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, up, vp, h, dt_pred, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
   } else if (VV) {
-    CALL(mom6hip_vertvisc_step(ctx, VV, up, vp, h, nullptr, taux, tauy, cs->visc, dt_pred, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+    CALL(vertvisc_step(up, vp, dt_pred, 1));
   }
   // pass_visc_rem, pass_uvp :748, :752 in flight behind the continuity's own rows, as in the RK2 stepping (continuity_around_pass)
   CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {up, PU}, {vp, PV}}, nz, 1));
+  if (OBC) {
+    CALL(m6::complete_group_pass(ctx));
+    CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,
+                                u_av, v_av, BTC, nullptr, nullptr, D));
+  } else
   CALL(continuity_around_pass(ctx, [&]() -> int {
     return mom6hip_continuity(ctx, cs->continuity_CSp, up, vp, h, hp, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v,   // :758
                               u_av, v_av, BTC, nullptr, nullptr, D);
   }));
   CALL(pass(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                      // :764
+  if (OBC) CALL(mom6hip_radiation_open_bdry_conds(ctx, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_av, u_old, v_av, v_old,   // :770
+                                                  dt_pred, D));
   set_h_av();                                                                                         // :780-782
   CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :790
-  if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :824-827
+  if (BT_cont_BT_thick) CALL(btcalc(BTC->h_u, BTC->h_v));                                                // :824-827
   CALL(hor_visc());                                                                                   // :841
-  CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));     // :848
+  CALL(coradcalc(cs->CAu, cs->CAv));                                                                  // :848
   bc_accel(cs->CAu, cs->CAv, false);                                                                  // :854-861
-  CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :889
-                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
-                      nullptr, uh, vh, u_av, v_av, eta_av, D));
+  if (OBC) CALL(mom6hip_open_boundary_zero_normal_flow(ctx, OBC, u_bc, v_bc, D));                     // :866-868
+  CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :889
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          nullptr, uh, vh, u_av, v_av, eta_av, OBC, D));
   launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :898
   {   // u_inst = u_inst + dt*(u_bc_accel + u_accel_bt) :908-919
     const double *abu = cs->u_accel_bt, *abv = cs->v_accel_bt;
@@ -792,14 +841,21 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->vertvisc(hk->user, u_inst, v_inst, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "vertvisc hook failed");
   } else if (VV) {
-    CALL(mom6hip_vertvisc_step(ctx, VV, u_inst, v_inst, h, nullptr, taux, tauy, cs->visc, dt, 1, nullptr, nullptr, cs->visc_rem_u, cs->visc_rem_v, D));
+    CALL(vertvisc_step(u_inst, v_inst, dt, 1));
   }
   CALL(pass_start(ctx, {{cs->visc_rem_u, PUs}, {cs->visc_rem_v, PVs}, {u_inst, PU}, {v_inst, PV}}, nz, 3));     // :967, :971
+  if (OBC) {
+    CALL(m6::complete_group_pass(ctx));
+    CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,
+                                cs->visc_rem_v, u_av, v_av, nullptr, cs->du_av_inst, cs->dv_av_inst, D));
+  } else
   CALL(continuity_around_pass(ctx, [&]() -> int {
     return mom6hip_continuity(ctx, cs->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, cs->uhbt, cs->vhbt, cs->visc_rem_u,      // :979
                               cs->visc_rem_v, u_av, v_av, nullptr, cs->du_av_inst, cs->dv_av_inst, D);
   }));
   CALL(pass(ctx, {{h, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz));                        // :993
+  if (OBC) CALL(mom6hip_radiation_open_bdry_conds(ctx, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_av, u_old, v_av, v_old,   // :1001
+                                                  dt, D));
   launch3d(s, Isq - 2, Ieq + 2, js - 2, je + 2, nz, [=] __device__(int I, int j, int k) {            // :1004-1011
     const long n = g.u3(I, j, k);
     uhtr[n] = uhtr[n] + uh[n] * dt;

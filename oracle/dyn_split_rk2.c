@@ -280,7 +280,6 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   const int Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
   if (CS->begw != 0.0 || CS->split_bottom_stress || CS->hooks || (CS->vertvisc_CSp && !CS->visc) || !CS->du_av_inst || !CS->dv_av_inst)
     return 1;
-  if (CS->OBC) return 1;      /* (the open boundaries are built for SPLIT_RK2B = False only) */
   mom6hip_barotropic_cs_t *BT = CS->barotropic_CSp;
   const mom6hip_bt_cont_t *BTC = CS->BT_cont;
   const int BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
@@ -294,9 +293,16 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   memcpy(hp, h, sizeof(double) * NH);                                                                   /* :403 */
   memset(u_inst, 0, sizeof(double) * NU); memset(v_inst, 0, sizeof(double) * NV);                      /* :404 */
   int rc = 0;
+  /* CS%OBC: the starting velocities of the radiation conditions (:431-443) */
+  const mom6hip_obc_t *OBC = CS->OBC;
+  double *u_old_rad_OBC = NULL, *v_old_rad_OBC = NULL;
+  if (OBC) {
+    u_old_rad_OBC = (double *)malloc(sizeof(double) * NU); v_old_rad_OBC = (double *)malloc(sizeof(double) * NV);
+    memcpy(u_old_rad_OBC, u_av, sizeof(double) * NU); memcpy(v_old_rad_OBC, v_av, sizeof(double) * NV);
+  }
 
   /* continuity with the filtered velocities :488 */
-  CHECK(orc_continuity(G, CS->continuity_CSp, u_av, v_av, h, hp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL));
+  CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, u_av, v_av, h, hp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL));
   /* PressureForce :498 */
   CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, NULL, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
   /* pass_hp_uhvh :535 */
@@ -306,9 +312,9 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
   /* CorAdCalc :548, horizontal_viscosity :555 */
-  CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
+  CHECK(orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
   if (CS->hor_visc)
-    CHECK(orc_horizontal_viscosity(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL));
+    CHECK(orc_horizontal_viscosity_obc(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL, OBC));
   /* u_bc_accel :561-568 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -317,6 +323,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       v_bc_accel[V3(i, J, k)] = (CS->CAv_pred[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
   }
+  if (OBC) CHECK(orc_open_boundary_zero_normal_flow(G, OBC, u_bc_accel, v_bc_accel));                  /* :571-573 */
   /* up :587-594 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -329,14 +336,14 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   if (CS->set_visc_CSp && CS->set_visc_CSp->dynamic_viscous_ML)
     CHECK(orc_set_viscous_ML(G, CS->set_visc_CSp, u_av, v_av, h, T, S, CS->eqn_of_state, taux, tauy, CS->visc, dt));
   if (CS->vertvisc_CSp) {
-    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt));
+    CHECK(orc_vertvisc_coef_obc(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt, OBC));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
   }
   /* pass_eta, pass_visc_rem :616-617 */
   orc_halo_update(G, eta, MOM6HIP_POS_H, 1);
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);
   /* btcalc, bt_mass_source :623-625 */
-  if (!BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, NULL, NULL, 0));
+  if (!BT_cont_BT_thick) CHECK(orc_btcalc_obc(G, BT, h, NULL, NULL, 0, OBC));
   orc_bt_mass_source(G, BT, h, eta, 1);
   /* the instantaneous velocities :641-646 */
   ORC_PAR
@@ -348,14 +355,14 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   }
   pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);                                    /* :648 */
   /* continuity for BT_cont and the layer fluxes :652 */
-  CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL, CS->visc_rem_u, CS->visc_rem_v,
+  CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, u_inst, v_inst, h, hp, uh_in, vh_in, dt, NULL, NULL, CS->visc_rem_u, CS->visc_rem_v,
                        NULL, NULL, BTC, NULL, NULL));
-  if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                            /* :655-658 */
+  if (BT_cont_BT_thick) CHECK(orc_btcalc_obc(G, BT, h, BTC->h_u, BTC->h_v, 0, OBC));                            /* :655-658 */
   if (calc_dtbt) orc_set_dtbt_eta(G, BT, eta, CS->pbce, NULL, 0.0, 0.0);                                        /* :664 */
   /* predictor btstep :668 */
-  CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
+  CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
                    CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
-                   NULL, uh_in, vh_in, u_inst, v_inst, NULL));
+                   NULL, uh_in, vh_in, u_inst, v_inst, NULL, OBC));
   /* up = u_inst + dt_pred*(u_bc_accel + u_accel_bt) :675-686 */
   const double dt_pred = dt * CS->be;
   ORC_PAR
@@ -367,27 +374,30 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   }
   /* vertvisc_coef, vertvisc, vertvisc_remnant :724-745 */
   if (CS->vertvisc_CSp) {
-    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt_pred));
-    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL));
+    CHECK(orc_vertvisc_coef_obc(G, CS->vertvisc_CSp, up, vp, h, NULL, CS->visc, dt_pred, OBC));
+    CHECK(orc_vertvisc_obc(G, CS->vertvisc_CSp, up, vp, h, taux, tauy, CS->visc, dt_pred, NULL, NULL, OBC));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt_pred));
   }
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);                    /* :748 */
   pass3(G, up, MOM6HIP_POS_U); pass3(G, vp, MOM6HIP_POS_V);                                            /* :752 */
   /* continuity :758 */
-  CHECK(orc_continuity(G, CS->continuity_CSp, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
+  CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, up, vp, h, hp, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av, v_av,
                        BTC, NULL, NULL));
   /* pass_hp_uv :764 */
   pass3(G, hp, MOM6HIP_POS_H); pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  if (OBC)                                                                                              /* :766-774 */
+    CHECK(orc_radiation_open_bdry_conds(G, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_av, u_old_rad_OBC, v_av,
+                                        v_old_rad_OBC, dt_pred));
   /* h_av :780-782 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) for (int j = js - 2; j <= je + 2; j++) for (int i = is - 2; i <= ie + 2; i++)
     h_av[H3(i, j, k)] = 0.5 * (h[H3(i, j, k)] + hp[H3(i, j, k)]);
   orc_bt_mass_source(G, BT, hp, eta_pred, 0);                                                          /* :790 */
-  if (BT_cont_BT_thick) CHECK(orc_btcalc(G, BT, h, BTC->h_u, BTC->h_v, 0));                           /* :824-827 */
+  if (BT_cont_BT_thick) CHECK(orc_btcalc_obc(G, BT, h, BTC->h_u, BTC->h_v, 0, OBC));                           /* :824-827 */
   /* horizontal_viscosity :841, CorAdCalc :848 */
   if (CS->hor_visc)
-    CHECK(orc_horizontal_viscosity(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL));
-  CHECK(orc_coradcalc(G, CS->CoriolisAdv, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
+    CHECK(orc_horizontal_viscosity_obc(G, CS->hor_visc, u_av, v_av, h_av, CS->diffu, CS->diffv, dt, BTC ? BTC->h_u : NULL, BTC ? BTC->h_v : NULL, OBC));
+  CHECK(orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, CS->CAu, CS->CAv));
   /* u_bc_accel :854-861 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -396,10 +406,11 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
     for (int J = Jsq; J <= Jeq; J++) for (int i = is; i <= ie; i++)
       v_bc_accel[V3(i, J, k)] = (CS->CAv[V3(i, J, k)] + CS->PFv[V3(i, J, k)]) + CS->diffv[V3(i, J, k)];
   }
+  if (OBC) CHECK(orc_open_boundary_zero_normal_flow(G, OBC, u_bc_accel, v_bc_accel));                  /* :866-868 */
   /* corrector btstep :889 */
-  CHECK(orc_btstep(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
+  CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
                    CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
-                   NULL, uh, vh, u_av, v_av, eta_av));
+                   NULL, uh, vh, u_av, v_av, eta_av, OBC));
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[H2(i, j)] = eta_pred[H2(i, j)];   /* :898 */
   /* u_inst = u_inst + dt*(u_bc_accel + u_accel_bt) :908-919 */
   ORC_PAR
@@ -411,18 +422,21 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   }
   /* vertvisc_coef, vertvisc, vertvisc_remnant :946-963 */
   if (CS->vertvisc_CSp) {
-    CHECK(orc_vertvisc_coef(G, CS->vertvisc_CSp, u_inst, v_inst, h, NULL, CS->visc, dt));
-    CHECK(orc_vertvisc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL));
+    CHECK(orc_vertvisc_coef_obc(G, CS->vertvisc_CSp, u_inst, v_inst, h, NULL, CS->visc, dt, OBC));
+    CHECK(orc_vertvisc_obc(G, CS->vertvisc_CSp, u_inst, v_inst, h, taux, tauy, CS->visc, dt, NULL, NULL, OBC));
     CHECK(orc_vertvisc_remnant(G, CS->vertvisc_CSp, CS->visc, CS->visc_rem_u, CS->visc_rem_v, dt));
   }
   pass3(G, CS->visc_rem_u, MOM6HIP_POS_U | MOM6HIP_PASS_SCALAR_PAIR); pass3(G, CS->visc_rem_v, MOM6HIP_POS_V | MOM6HIP_PASS_SCALAR_PAIR);                    /* :967 */
   pass3(G, u_inst, MOM6HIP_POS_U); pass3(G, v_inst, MOM6HIP_POS_V);                                    /* :971 */
   /* continuity :979-981, returning the barotropic increments */
-  CHECK(orc_continuity(G, CS->continuity_CSp, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,
+  CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, u_inst, v_inst, h, h, uh, vh, dt, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, u_av,
                        v_av, NULL, CS->du_av_inst, CS->dv_av_inst));
   /* pass_h_uv :993 */
   pass3(G, h, MOM6HIP_POS_H);
   pass3(G, u_av, MOM6HIP_POS_U); pass3(G, v_av, MOM6HIP_POS_V); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
+  if (OBC)                                                                                              /* :1000-1002 */
+    CHECK(orc_radiation_open_bdry_conds(G, OBC, OBC->gamma_uv, OBC->rx_max, OBC->rx_normal, OBC->ry_normal, u_av, u_old_rad_OBC, v_av,
+                                        v_old_rad_OBC, dt));
   /* uhtr, vhtr :1004-1011 */
   ORC_PAR
   for (int k = 1; k <= nz; k++) {
@@ -433,5 +447,6 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   }
 done:
   free(up); free(vp); free(hp); free(u_bc_accel); free(v_bc_accel); free(uh_in); free(vh_in); free(eta_pred);
+  free(u_old_rad_OBC); free(v_old_rad_OBC);
   return rc;
 }

@@ -41,7 +41,7 @@ def visc_arrays(g, seed=9):
                 bbl_thick_u=2.0 + 8.0 * rng.random(su), bbl_thick_v=2.0 + 8.0 * rng.random(sv))
 
 
-def oracle_state(g, d, OBC, viscous=True, bbl=None, **kw):
+def oracle_state(g, d, OBC, viscous=True, bbl=None, **kw):      # kw: rk2b=True for SPLIT_RK2B
     extra = {}
     if viscous:
         extra = dict(vertvisc=orc.vertvisc_cs(g, Kv=1.0e-3, Hbbl=10.0), visc=orc.vertvisc_type(**(bbl or visc_arrays(g))),
@@ -89,13 +89,14 @@ def test_oracle_step_with_tc3_segments_lets_the_flow_through(viscous):
             assert bits_equal(got[:, 4:-4], s.normal_vel[:, 0, 4:-4])
 
 
+@pytest.mark.parametrize("rk2b", [False, True], ids=["RK2", "RK2B"])
 @pytest.mark.parametrize("viscous", [False, True])
-def test_oracle_step_turns_with_the_grid(viscous):
+def test_oracle_step_turns_with_the_grid(viscous, rk2b):
     """the reference writes E / W / N / S and u / v out separately in every operator of the step: a quarter turn of the grid, the state and
     the segments gives the turned answers bit for bit"""
     g, d, taux, tauy, OBC = rk2_obc_case()
     bbl = visc_arrays(g)
-    a = oracle_state(g, d, OBC, viscous, bbl=bbl)
+    a = oracle_state(g, d, OBC, viscous, bbl=bbl, rk2b=rk2b)
     gr = rotate_grid(g)
     OBCr = ocean_OBC_type(gr, turned_segments(TC3, g.ni, g.nj), gamma_uv=0.3, rx_max=10.0, **TC3_FLAGS)
     OBCr.rx_normal, OBCr.ry_normal = gr.zeros3(U), gr.zeros3(V)
@@ -103,7 +104,7 @@ def test_oracle_step_turns_with_the_grid(viscous):
     dr = dict(u=ur, v=vr, h=rot(d["h"]), T=rot(d["T"]), S=rot(d["S"]))
     # (positive definite face fields turn as a scalar pair)
     bblr = dict(Kv_bbl_u=rot(bbl["Kv_bbl_v"]), Kv_bbl_v=rot(bbl["Kv_bbl_u"]), bbl_thick_u=rot(bbl["bbl_thick_v"]), bbl_thick_v=rot(bbl["bbl_thick_u"]))
-    b = oracle_state(gr, dr, OBCr, viscous, bbl=bblr)
+    b = oracle_state(gr, dr, OBCr, viscous, bbl=bblr, rk2b=rk2b)
     txr, tyr = rot_vector(taux, tauy)
     for n in range(3):
         a.step(taux, tauy); b.step(txr, tyr)
@@ -116,9 +117,11 @@ def test_oracle_step_turns_with_the_grid(viscous):
 
 # ---- the library against the oracle, on the GPU ----
 
-def gpu_run(g, d, taux, tauy, OBC, viscous, bbl, nsteps, check):
+def gpu_run(g, d, taux, tauy, OBC, viscous, bbl, nsteps, check, rk2b=False):
     import torch
     from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    if rk2b:
+        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2b as initialize_dyn_split_RK2, step_MOM_dyn_split_RK2b as step_MOM_dyn_split_RK2
     from mom6_amd.tracer_advect import DeviceGrid
     from mom6_amd.vert_friction import vertvisc_type
     from test_hor_visc import REF_NAMES
@@ -254,3 +257,43 @@ def test_gpu_step_with_open_boundaries_and_the_tc2_switch_set_matches_oracle_bit
             assert bits_equal(an, b), (n, nm, float(np.abs(an - b).max()))
     assert ref.visc._keep["nkml_visc_u"].max() > 1 and np.abs(ref.u[:, OBC.segnum_u != 0]).max() > 0
     dg.close()
+
+
+@pytest.mark.parametrize("viscous", [False, True])
+def test_oracle_rk2b_step_with_tc3_segments_lets_the_flow_through(viscous):
+    g, d, taux, tauy, OBC = rk2_obc_case()
+    st = oracle_state(g, d, OBC, viscous, rk2b=True)
+    for n in range(4):
+        st.step(taux, tauy)
+        assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0
+    assert np.abs(st.u[:, OBC.segnum_u != 0]).max() > 1e-4 and np.abs(OBC.rx_normal).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("viscous", [False, True])
+@pytest.mark.parametrize("segs", [TC3, TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"]], ids=["tc3", "mixed"])
+def test_gpu_rk2b_step_with_open_boundaries_matches_oracle_bitwise(segs, viscous):
+    """SPLIT_RK2B (MOM_dynamics_split_RK2b.F90:431-443, :571-573, :766-774, :866-868, :1000-1002 and the OBC argument of its operators)"""
+    import copy
+    for (ni, nj, nk, seed) in [(22, 16, 3, 4), (60, 44, 2, 7)]:
+        g, d, taux, tauy, OBC = rk2_obc_case(segs, ni=ni, nj=nj, nk=nk, seed=seed)
+        rng = np.random.default_rng(seed)
+        for s in OBC.segment:
+            if s.on_pe and s.specified:
+                s.normal_vel[:] = 0.05 * rng.standard_normal(s.normal_vel.shape)
+                s.normal_trans[:] = s.normal_vel * (3.0e4 * (5.0 + 50.0 * rng.random(s.normal_vel.shape)))
+            if s.on_pe and s.Flather:
+                s.normal_vel_bt[:] = 0.02 * rng.standard_normal(s.normal_vel_bt.shape); s.SSH[:] = 0.05 * rng.standard_normal(s.SSH.shape)
+        bbl = visc_arrays(g)
+        OBCo = copy.deepcopy(OBC)
+        ref = oracle_state(g, d, OBCo, viscous, bbl=bbl, rk2b=True)
+
+        def check(n, f):
+            ref.step(taux, tauy)
+            want = dict(u=ref.u, v=ref.v, h=ref.h, uh=ref.uh, vh=ref.vh, uhtr=ref.uhtr, eta_av=ref.eta_av, u_av=ref.arrs["u_av"], diffu=ref.arrs["diffu"],
+                        eta=ref.arrs["eta"])
+            for name, b in want.items():
+                an = f[name].cpu().numpy()
+                assert bits_equal(an, b), (segs, viscous, ni, n, name, np.argwhere(an != b)[:4].tolist())
+            assert bits_equal(OBC.rx_normal.cpu().numpy(), OBCo.rx_normal) and bits_equal(OBC.ry_normal.cpu().numpy(), OBCo.ry_normal), (n, "rx_normal")
+        gpu_run(g, d, taux, tauy, OBC, viscous, bbl, 3, check, rk2b=True)
