@@ -980,6 +980,7 @@ extern "C" int mom6hip_advect_tracer_obc(mom6hip_ctx_t *ctx, const double *h_end
   bool generic = getenv("MOM6HIP_ADV_GENERIC") && atoi(getenv("MOM6HIP_ADV_GENERIC")) != 0;
   std::vector<GenSeg> gsegs[2];
   std::vector<GenReg> gregs;
+  ctx->adv_obc_n = 0;      // (the staged reservoirs of this call: counted from zero whatever a refused call left behind)
   if (obc && obc->OBC_pe) {
     M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "advect_tracer: OBC%%segment is required");
     for (int n = 0; n < obc->number_of_segments; n++) {
