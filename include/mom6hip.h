@@ -470,8 +470,9 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
  * The normal component: Orlanski radiation (segment%radiation: the phase speed from the two faces inside the boundary, capped by
  * OBC%rx_max = OBC_RADIATION_MAX, averaged in time with OBC%gamma_uv = OBC_RAD_VEL_WT into the restart fields OBC%rx_normal /
  * ry_normal), the gradient condition (segment%gradient), nudging towards segment%nudged_normal_vel; then
- * open_boundary_apply_normal_flow (:3337) and pass_vector(u_new, v_new).  segment%normal_vel is written.  Not provided (refused):
- * oblique radiation, the tangential velocity and gradient forms, tracer reservoirs.
+ * open_boundary_apply_normal_flow (:3337) and pass_vector(u_new, v_new).  segment%normal_vel is written.  The tangential forms
+ * (segment%radiation_tan, %radiation_grad, %nudged_tan, %nudged_grad: :2403-2455 and its three twins) write segment%tangential_vel /
+ * tangential_grad at the corner points of the segment.  Not provided (refused): oblique radiation and its tangential forms.
  * rx_normal (u points, 3-D) and ry_normal (v points, 3-D) may be NULL when gamma_uv >= 1. */
 int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const struct mom6hip_obc *obc, double gamma_uv, double rx_max, double *rx_normal,
                                       double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old, double dt,
@@ -550,6 +551,14 @@ int mom6hip_continuity(mom6hip_ctx_t *ctx, const mom6hip_continuity_cs_t *cs, co
 #define MOM6HIP_OBC_DIRECTION_S 200
 #define MOM6HIP_OBC_DIRECTION_E 300
 #define MOM6HIP_OBC_DIRECTION_W 400
+/* mom6hip_obc_segment_t.radiation_tan_or_grad: segment%radiation_tan (ORLANSKI_TAN), %radiation_grad (ORLANSKI_GRAD), %nudged_tan, %nudged_grad,
+ * %oblique_tan, %oblique_grad */
+#define MOM6HIP_OBC_TAN_RADIATION 1
+#define MOM6HIP_OBC_GRAD_RADIATION 2
+#define MOM6HIP_OBC_TAN_NUDGED 4
+#define MOM6HIP_OBC_GRAD_NUDGED 8
+#define MOM6HIP_OBC_TAN_OBLIQUE 16
+#define MOM6HIP_OBC_GRAD_OBLIQUE 32
 
 /* OBC_segment_tracer_type (:119-137) as advect_tracer reads it: one registered tracer of a segment's registry (segment%tr_Reg%Tr(m)) */
 typedef struct mom6hip_obc_segment_tracer {
@@ -574,15 +583,15 @@ typedef struct mom6hip_obc_segment {
   int32_t isd, ied, jsd, jed;          /* segment%HI: its cell range */
   int32_t radiation, gradient, nudged; /* segment%radiation (Orlanski), %gradient, %nudged: read by radiation_open_bdry_conds */
   int32_t oblique;                     /* segment%oblique: not provided (refused by mom6hip_radiation_open_bdry_conds) */
-  int32_t radiation_tan_or_grad;       /* segment%radiation_tan .or. %radiation_grad .or. the oblique / nudged counterparts: not provided */
+  int32_t radiation_tan_or_grad;       /* the tangential forms, a bit each: MOM6HIP_OBC_TAN_* below (the oblique ones are not provided) */
   int32_t Flather;                     /* segment%Flather: read by btstep */
   /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where
    * `specified`; in the memory space of the call; may be NULL otherwise */
   const double *normal_trans;
   double *normal_vel;                  /* (written by radiation_open_bdry_conds for radiation / gradient segments) */
   /* segment%tangential_vel, segment%tangential_grad (IsdB:IedB, JsdB:JedB, nk): read by CorAdCalc with OBC%computed_vorticity /
-   * OBC%specified_vorticity; may be NULL otherwise */
-  const double *tangential_vel, *tangential_grad;
+   * OBC%specified_vorticity; written by radiation_open_bdry_conds with the tangential forms; may be NULL otherwise */
+  double *tangential_vel, *tangential_grad;
   const double *nudged_normal_vel;     /* segment%nudged_normal_vel, the layout of normal_vel: read where `nudged` */
   /* segment%normal_vel_bt, segment%SSH (IsdB:IedB, jsd:jed) for E / W, (isd:ied, JsdB:JedB) for N / S: the external barotropic velocity
    * and sea surface height of a Flather segment, read by btstep (set_up_BT_OBC); may be NULL otherwise */
@@ -592,6 +601,8 @@ typedef struct mom6hip_obc_segment {
   const mom6hip_obc_segment_tracer_t *tr_Reg;
   int32_t ntseg, reserved_i;
   double Tr_InvLscale_in, Tr_InvLscale_out;      /* segment%Tr_InvLscale_in / _out [L-1]: read by update_segment_tracer_reservoirs */
+  /* segment%nudged_tangential_vel, %nudged_tangential_grad (the layout of tangential_vel): read with MOM6HIP_OBC_TAN_NUDGED / _GRAD_NUDGED */
+  const double *nudged_tangential_vel, *nudged_tangential_grad;
 } mom6hip_obc_segment_t;
 
 typedef struct mom6hip_obc {

@@ -185,6 +185,9 @@ class EpipycnalCS(C.Structure):
 OBC_NONE, OBC_DIRECTION_N, OBC_DIRECTION_S, OBC_DIRECTION_E, OBC_DIRECTION_W = 0, 100, 200, 300, 400
 
 
+OBC_TAN_RADIATION, OBC_GRAD_RADIATION, OBC_TAN_NUDGED, OBC_GRAD_NUDGED, OBC_TAN_OBLIQUE, OBC_GRAD_OBLIQUE = 1, 2, 4, 8, 16, 32
+
+
 class ObcSegmentTracer(C.Structure):
     """mom6hip_obc_segment_tracer_t (include/mom6hip.h)."""
     _fields_ = [("ntr_index", C.c_int32), ("reserved", C.c_int32), ("tres", C.c_void_p), ("OBC_inflow_conc", C.c_double),
@@ -199,7 +202,8 @@ class ObcSegment(C.Structure):
                 ("tangential_grad", C.c_void_p), ("nudged_normal_vel", C.c_void_p), ("normal_vel_bt", C.c_void_p), ("SSH", C.c_void_p),
                 ("Velocity_nudging_timescale_in", C.c_double), ("Velocity_nudging_timescale_out", C.c_double),
                 ("tr_Reg", C.POINTER(ObcSegmentTracer)), ("ntseg", C.c_int32), ("reserved_i", C.c_int32),
-                ("Tr_InvLscale_in", C.c_double), ("Tr_InvLscale_out", C.c_double)]
+                ("Tr_InvLscale_in", C.c_double), ("Tr_InvLscale_out", C.c_double),
+                ("nudged_tangential_vel", C.c_void_p), ("nudged_tangential_grad", C.c_void_p)]
 
 
 class Obc(C.Structure):

@@ -57,6 +57,53 @@ __global__ __launch_bounds__(64) void rad_segment_kernel(m6::GridDev g, RadSeg S
   S.normal_vel[rad_idx(S, c, k)] = nv;
 }
 
+// the tangential forms :2403-2455 (E), :2648-2700 (W), :2892-2945 (N), :3137-3190 (S): the rate at a corner point of the segment, then
+// segment%tangential_vel (ORLANSKI_TAN, NUDGED_TAN) and segment%tangential_grad (ORLANSKI_GRAD, NUDGED_GRAD); a thread a corner and layer
+struct TanArgs {
+  int bits, q0, q1;            // MOM6HIP_OBC_TAN_* ; the corner points along the segment (JsdB:JedB | IsdB:IedB)
+  long nq;                     // their number: the segment's arrays (IsdB:IedB, JsdB:JedB, nk) are one point wide
+  double *tangential_vel, *tangential_grad;
+  const double *nudged_vel, *nudged_grad;
+};
+__global__ __launch_bounds__(64) void rad_tangential_kernel(m6::GridDev g, RadSeg S, TanArgs a, double gamma_u, double rx_max, double dt,
+                                                            const double *tn, const double *to, const double *r_normal) {
+  const int q = a.q0 + blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (q > a.q1) return;
+  const bool plus = S.d1 < 0;      // E, N: the cells inside lie towards smaller indices
+  const int t0 = plus ? S.A : S.A + 1, st = plus ? -1 : 1;      // the first row of cells inside, and the step further in
+  // the tangential component at the corner q in the row / column t of cells: v(t, Q) for E / W, u(Q, t) for N / S
+  const long tpl = S.ew ? (long)g.nih * (g.njh + 1) : (long)(g.nih + 1) * g.njh;
+  auto T3 = [&](int t) -> long { return (S.ew ? g.v2(t, q) : g.u2(q, t)) + tpl * k; };
+  const long npl = S.ew ? (long)(g.nih + 1) * g.njh : (long)g.nih * (g.njh + 1);
+  auto F3 = [&](int c) -> long { return (S.ew ? g.u2(S.A, c) : g.v2(c, S.A)) + npl * k; };
+  double r_tang;
+  if (gamma_u < 1.0) {      // segment%rx_norm_rad at the two faces about the corner (the ends: the one face there is)
+    if (q == a.q0) r_tang = r_normal[F3(S.c0)];
+    else if (q == a.q1) r_tang = r_normal[F3(S.c1)];
+    else r_tang = 0.5 * (r_normal[F3(q)] + r_normal[F3(q + 1)]);
+  } else {
+    const int ta = (!S.ew && plus) ? t0 + st : t0;      // (the northern segment looks one row further in than the other three, :2904-2905)
+    const double dhdt = to[T3(ta)] - tn[T3(ta)];
+    const double dhdx = tn[T3(ta)] - tn[T3(ta + st)];
+    r_tang = 0.0;
+    if (dhdt * dhdx > 0.0) r_tang = min2((dhdt / dhdx), rx_max);
+  }
+  const double tau = (r_tang <= 0.0) ? S.tau_in : S.tau_out;
+  const double gamma_2 = dt / (tau + dt);
+  const long s3 = (long)(q - a.q0) + a.nq * (long)k;
+  if (a.bits & MOM6HIP_OBC_TAN_RADIATION) a.tangential_vel[s3] = (tn[T3(t0)] + r_tang * tn[T3(t0 + st)]) / (1.0 + r_tang);
+  if (a.bits & MOM6HIP_OBC_TAN_NUDGED) a.tangential_vel[s3] = (1.0 - gamma_2) * a.tangential_vel[s3] + gamma_2 * a.nudged_vel[s3];
+  const int g0 = (S.ew ? g.jsd : g.isd) + 1, g1 = (S.ew ? g.jed : g.ied) - 1;
+  if ((a.bits & MOM6HIP_OBC_GRAD_RADIATION) && q >= g0 && q <= g1) {
+    // differences towards larger indices, with the metric of the corner point between the two rows
+    const int lo1 = plus ? t0 - 1 : t0, lo2 = plus ? t0 - 2 : t0 + 1;
+    const double *Idm = S.ew ? g.IdxBu : g.IdyBu;
+    auto QM = [&](int t) -> long { return S.ew ? g.q2(t, q) : g.q2(q, t); };
+    a.tangential_grad[s3] = ((tn[T3(lo1 + 1)] - tn[T3(lo1)]) * Idm[QM(lo1)] + r_tang * (tn[T3(lo2 + 1)] - tn[T3(lo2)]) * Idm[QM(lo2)]) / (1.0 + r_tang);
+  }
+  if (a.bits & MOM6HIP_OBC_GRAD_NUDGED) a.tangential_grad[s3] = (1.0 - gamma_2) * a.tangential_grad[s3] + gamma_2 * a.nudged_grad[s3];
+}
+
 // open_boundary_apply_normal_flow :3337 (from = the segment's normal_vel) / open_boundary_zero_normal_flow :3374 (from = null)
 __global__ __launch_bounds__(64) void obc_face_store_kernel(m6::GridDev g, RadSeg S, double *x, int from_normal_vel) {
   const int c = S.c0 + blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
@@ -182,13 +229,14 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
   const double *d_uo = st.in(u_old, bU), *d_vo = st.in(v_old, bV);
   double *d_rx = st.inout(rx_normal, bU), *d_ry = st.inout(ry_normal, bV);
   std::vector<RadSeg> segs;
+  std::vector<TanArgs> tans;
   for (int n = 0; n < obc->number_of_segments; n++) {
     const mom6hip_obc_segment_t &S = obc->segment[n];
     RadSeg d;
     if (!rad_segment(g, S, d)) continue;
     M6_REQUIRE(!S.oblique, "radiation_open_bdry_conds: oblique radiation (OBLIQUE, segment %d) is not provided by libmom6hip", n + 1);
-    M6_REQUIRE(!S.radiation_tan_or_grad, "radiation_open_bdry_conds: the tangential forms (ORLANSKI_TAN / _GRAD, OBLIQUE_TAN / _GRAD, NUDGED_TAN / "
-               "_GRAD; segment %d) are not provided by libmom6hip", n + 1);
+    M6_REQUIRE(!(S.radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)), "radiation_open_bdry_conds: the oblique tangential "
+               "forms (OBLIQUE_TAN / _GRAD; segment %d) are not provided by libmom6hip", n + 1);
     if (check_segment_range(g, S, n, "radiation_open_bdry_conds")) return 1;
     if (S.radiation || S.gradient) {
       M6_REQUIRE(S.normal_vel, "radiation_open_bdry_conds: segment %d needs normal_vel", n + 1);
@@ -198,16 +246,49 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
       d.normal_vel = st.inout(S.normal_vel, cnt);
       d.nudged_normal_vel = (S.radiation && S.nudged) ? st.in(S.nudged_normal_vel, cnt) : nullptr;
     }
-    segs.push_back(d);
+    TanArgs a;
+    a.bits = S.radiation_tan_or_grad; a.q0 = d.ew ? S.JsdB : S.IsdB; a.q1 = d.ew ? S.JedB : S.IedB; a.nq = a.q1 - a.q0 + 1;
+    a.tangential_vel = a.tangential_grad = nullptr; a.nudged_vel = a.nudged_grad = nullptr;
+    if (!(a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_GRAD_RADIATION))) a.bits = 0;      // (the block of the tangential forms :2403)
+    if (a.bits) {
+      const int plus = d.d1 < 0;
+      M6_REQUIRE(a.q0 >= (d.ew ? g.jsd : g.isd) - 1 && a.q1 <= (d.ew ? g.jed : g.ied) && a.q1 >= a.q0,
+                 "radiation_open_bdry_conds: the corner points of OBC segment %d lie outside the data domain", n + 1);
+      M6_REQUIRE(plus ? (d.A - 2 >= (d.ew ? g.isd : g.jsd)) : (d.A + 3 <= (d.ew ? g.ied : g.jed)),
+                 "radiation_open_bdry_conds: OBC segment %d: the tangential forms need three rows of cells inside the segment in the data domain", n + 1);
+      M6_REQUIRE(gamma_uv >= 1.0 || (d.ew ? rx_normal : ry_normal), "radiation_open_bdry_conds: OBC_RAD_VEL_WT < 1 needs OBC%%rx_normal / ry_normal");
+      const size_t cnt = (size_t)a.nq * g.nk * 8;
+      if (a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_TAN_NUDGED)) {
+        M6_REQUIRE(S.tangential_vel, "radiation_open_bdry_conds: segment %d: tangential_vel is required", n + 1);
+        a.tangential_vel = st.inout(S.tangential_vel, cnt);
+      }
+      if (a.bits & (MOM6HIP_OBC_GRAD_RADIATION | MOM6HIP_OBC_GRAD_NUDGED)) {
+        M6_REQUIRE(S.tangential_grad, "radiation_open_bdry_conds: segment %d: tangential_grad is required", n + 1);
+        a.tangential_grad = st.inout(S.tangential_grad, cnt);
+      }
+      if (a.bits & MOM6HIP_OBC_TAN_NUDGED) {
+        M6_REQUIRE(S.nudged_tangential_vel, "radiation_open_bdry_conds: segment %d: nudged_tangential_vel is required", n + 1);
+        a.nudged_vel = st.in(S.nudged_tangential_vel, cnt);
+      }
+      if (a.bits & MOM6HIP_OBC_GRAD_NUDGED) {
+        M6_REQUIRE(S.nudged_tangential_grad, "radiation_open_bdry_conds: segment %d: nudged_tangential_grad is required", n + 1);
+        a.nudged_grad = st.in(S.nudged_tangential_grad, cnt);
+      }
+    }
+    segs.push_back(d); tans.push_back(a);
   }
   M6_REQUIRE(!st.failed(), "radiation_open_bdry_conds: staging failed");
-  for (const RadSeg &d : segs) {
-    if (!(d.radiation || d.gradient)) continue;
+  for (size_t m = 0; m < segs.size(); m++) {
+    const RadSeg &d = segs[m];
     // I < IscB (E), I > IecB (W), J < JscB (N), J > JecB (S): the segment is skipped :2329, :2573, :2818, :3062
     const int lo = d.ew ? g.isc - 1 : g.jsc - 1, hi = d.ew ? g.iec : g.jec;
     if (d.d1 < 0 ? (d.A < lo) : (d.A > hi)) continue;
-    hipLaunchKernelGGL(rad_segment_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, s, g, d, gamma_uv, rx_max, dt, d.ew ? d_un : d_vn,
-                       d.ew ? d_uo : d_vo, d.ew ? d_rx : d_ry);
+    if (d.radiation || d.gradient)
+      hipLaunchKernelGGL(rad_segment_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, s, g, d, gamma_uv, rx_max, dt, d.ew ? d_un : d_vn,
+                         d.ew ? d_uo : d_vo, d.ew ? d_rx : d_ry);
+    if (tans[m].bits)      // (after the rates of the segment's own faces; the tangential component of u_new, v_new is not changed by this routine)
+      hipLaunchKernelGGL(rad_tangential_kernel, dim3((tans[m].nq + 63) / 64, g.nk), dim3(64), 0, s, g, d, tans[m], gamma_uv, rx_max, dt,
+                         d.ew ? d_vn : d_un, d.ew ? d_vo : d_uo, d.ew ? d_rx : d_ry);
   }
   for (const RadSeg &d : segs) {      // open_boundary_apply_normal_flow :3337 (radiation, oblique or gradient segments)
     if (!(d.radiation || d.gradient)) continue;

@@ -319,7 +319,8 @@ subroutine obc_mirrors(CS)
     rad = seg%radiation .or. seg%gradient .or. seg%nudged
     CS%c_obc_segs(n)%normal_trans = c_null_ptr ; CS%c_obc_segs(n)%normal_vel = c_null_ptr ; CS%c_obc_segs(n)%normal_vel_bt = c_null_ptr
     CS%c_obc_segs(n)%SSH = c_null_ptr ; CS%c_obc_segs(n)%tangential_vel = c_null_ptr ; CS%c_obc_segs(n)%tangential_grad = c_null_ptr
-    CS%c_obc_segs(n)%nudged_normal_vel = c_null_ptr
+    CS%c_obc_segs(n)%nudged_normal_vel = c_null_ptr ; CS%c_obc_segs(n)%nudged_tangential_vel = c_null_ptr
+    CS%c_obc_segs(n)%nudged_tangential_grad = c_null_ptr
     if (allocated(seg%normal_trans)) CS%c_obc_segs(n)%normal_trans = &
         mirror(CS, c_loc(seg%normal_trans), int(size(seg%normal_trans), c_int64_t), .true., .false.)
     if (allocated(seg%normal_vel)) CS%c_obc_segs(n)%normal_vel = &
@@ -327,10 +328,15 @@ subroutine obc_mirrors(CS)
     if (allocated(seg%normal_vel_bt)) CS%c_obc_segs(n)%normal_vel_bt = &
         mirror(CS, c_loc(seg%normal_vel_bt), int(size(seg%normal_vel_bt), c_int64_t), .true., .false.)
     if (allocated(seg%SSH)) CS%c_obc_segs(n)%SSH = mirror(CS, c_loc(seg%SSH), int(size(seg%SSH), c_int64_t), .true., .false.)
+    ! (the tangential forms of the radiation write segment%tangential_vel / tangential_grad)
     if (allocated(seg%tangential_vel)) CS%c_obc_segs(n)%tangential_vel = &
-        mirror(CS, c_loc(seg%tangential_vel), int(size(seg%tangential_vel), c_int64_t), .true., .false.)
+        mirror(CS, c_loc(seg%tangential_vel), int(size(seg%tangential_vel), c_int64_t), .true., seg%radiation_tan .or. seg%nudged_tan)
     if (allocated(seg%tangential_grad)) CS%c_obc_segs(n)%tangential_grad = &
-        mirror(CS, c_loc(seg%tangential_grad), int(size(seg%tangential_grad), c_int64_t), .true., .false.)
+        mirror(CS, c_loc(seg%tangential_grad), int(size(seg%tangential_grad), c_int64_t), .true., seg%radiation_grad .or. seg%nudged_grad)
+    if (allocated(seg%nudged_tangential_vel)) CS%c_obc_segs(n)%nudged_tangential_vel = &
+        mirror(CS, c_loc(seg%nudged_tangential_vel), int(size(seg%nudged_tangential_vel), c_int64_t), .true., .false.)
+    if (allocated(seg%nudged_tangential_grad)) CS%c_obc_segs(n)%nudged_tangential_grad = &
+        mirror(CS, c_loc(seg%nudged_tangential_grad), int(size(seg%nudged_tangential_grad), c_int64_t), .true., .false.)
     if (allocated(seg%nudged_normal_vel)) CS%c_obc_segs(n)%nudged_normal_vel = &
         mirror(CS, c_loc(seg%nudged_normal_vel), int(size(seg%nudged_normal_vel), c_int64_t), .true., .false.)
   enddo

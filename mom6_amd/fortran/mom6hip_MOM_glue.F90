@@ -515,6 +515,11 @@ contains
     if (allocated(seg%tangential_vel)) c%tangential_vel = c_loc(seg%tangential_vel)
     if (allocated(seg%tangential_grad)) c%tangential_grad = c_loc(seg%tangential_grad)
     if (allocated(seg%nudged_normal_vel)) c%nudged_normal_vel = c_loc(seg%nudged_normal_vel)
+    c%radiation_tan_or_grad = merge(MOM6HIP_OBC_TAN_RADIATION, 0, seg%radiation_tan) + merge(MOM6HIP_OBC_GRAD_RADIATION, 0, seg%radiation_grad) + &
+                              merge(MOM6HIP_OBC_TAN_NUDGED, 0, seg%nudged_tan) + merge(MOM6HIP_OBC_GRAD_NUDGED, 0, seg%nudged_grad) + &
+                              merge(MOM6HIP_OBC_TAN_OBLIQUE, 0, seg%oblique_tan) + merge(MOM6HIP_OBC_GRAD_OBLIQUE, 0, seg%oblique_grad)
+    if (allocated(seg%nudged_tangential_vel)) c%nudged_tangential_vel = c_loc(seg%nudged_tangential_vel)
+    if (allocated(seg%nudged_tangential_grad)) c%nudged_tangential_grad = c_loc(seg%nudged_tangential_grad)
     c%Velocity_nudging_timescale_in = seg%Velocity_nudging_timescale_in
     c%Velocity_nudging_timescale_out = seg%Velocity_nudging_timescale_out
   end subroutine segment_to_c

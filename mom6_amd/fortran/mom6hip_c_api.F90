@@ -192,6 +192,8 @@ type, bind(c) :: mom6hip_neutral_diffusion_cs_t
 end type mom6hip_neutral_diffusion_cs_t
 
 !> mom6hip_obc_segment_t / mom6hip_obc_t: what continuity_PPM reads of OBC_segment_type / ocean_OBC_type (src/core/MOM_open_boundary.F90:146, :266)
+integer(c_int32_t), parameter :: MOM6HIP_OBC_TAN_RADIATION = 1, MOM6HIP_OBC_GRAD_RADIATION = 2, MOM6HIP_OBC_TAN_NUDGED = 4, &
+                                 MOM6HIP_OBC_GRAD_NUDGED = 8, MOM6HIP_OBC_TAN_OBLIQUE = 16, MOM6HIP_OBC_GRAD_OBLIQUE = 32
 integer(c_int32_t), parameter :: MOM6HIP_OBC_NONE = 0, MOM6HIP_OBC_DIRECTION_N = 100, MOM6HIP_OBC_DIRECTION_S = 200, &
                                  MOM6HIP_OBC_DIRECTION_E = 300, MOM6HIP_OBC_DIRECTION_W = 400
 !> mom6hip_obc_segment_tracer_t: one registered tracer of a segment (segment%tr_Reg%Tr(m))
@@ -213,6 +215,7 @@ type, bind(c) :: mom6hip_obc_segment_t
   type(c_ptr) :: tr_Reg = c_null_ptr
   integer(c_int32_t) :: ntseg = 0, reserved_i = 0
   real(c_double) :: Tr_InvLscale_in = 0.0, Tr_InvLscale_out = 0.0
+  type(c_ptr) :: nudged_tangential_vel = c_null_ptr, nudged_tangential_grad = c_null_ptr
 end type mom6hip_obc_segment_t
 type, bind(c) :: mom6hip_obc_t
   integer(c_int32_t) :: number_of_segments = 0, OBC_pe = 0, open_u_BCs_exist_globally = 0, open_v_BCs_exist_globally = 0

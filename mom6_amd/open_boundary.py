@@ -76,6 +76,7 @@ class OBC_segment_type:
         self.tangential_vel = None    # (nk, JsdB:JedB, IsdB:IedB): the corner points along the segment
         self.tangential_grad = None
         self.nudged_normal_vel = None      # the layout of normal_vel
+        self.nudged_tangential_vel = self.nudged_tangential_grad = None      # the layout of tangential_vel (NUDGED_TAN, NUDGED_GRAD)
         self.normal_vel_bt = self.SSH = None      # (jsd:jed, IsdB:IedB) | (JsdB:JedB, isd:ied): the external barotropic velocity and surface height
         self.Velocity_nudging_timescale_in = self.Velocity_nudging_timescale_out = 0.0
         # segment%tr_Reg: None, or a list of dicts(ntr_index = 1-based place of the tracer in the registry, tres = the reservoir on the
@@ -263,7 +264,8 @@ class ocean_OBC_type:
         T = lambda a: a if a is None or hasattr(a, "data_ptr") else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
         self.rx_normal, self.ry_normal = T(self.rx_normal), T(self.ry_normal)
         for s in self.segment:
-            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH"):
+            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH",
+                      "nudged_tangential_vel", "nudged_tangential_grad"):
                 setattr(s, k, T(getattr(s, k)))
             for t in (s.tr_Reg or []):
                 for k in ("tres", "t"):
@@ -286,14 +288,19 @@ class ocean_OBC_type:
                 setattr(c, k, int(s.HI.get(k, 0)))
             c.radiation, c.gradient, c.nudged, c.oblique = int(s.radiation), int(s.gradient), int(s.nudged), int(s.oblique)
             c.Flather = int(s.Flather)
-            c.radiation_tan_or_grad = int(s.radiation_tan or s.radiation_grad or s.oblique_tan or s.oblique_grad or s.nudged_tan or s.nudged_grad)
+            c.radiation_tan_or_grad = (_abi.OBC_TAN_RADIATION * int(s.radiation_tan) | _abi.OBC_GRAD_RADIATION * int(s.radiation_grad) |
+                                       _abi.OBC_TAN_NUDGED * int(s.nudged_tan) | _abi.OBC_GRAD_NUDGED * int(s.nudged_grad) |
+                                       _abi.OBC_TAN_OBLIQUE * int(s.oblique_tan) | _abi.OBC_GRAD_OBLIQUE * int(s.oblique_grad))
             c.Velocity_nudging_timescale_in, c.Velocity_nudging_timescale_out = float(s.Velocity_nudging_timescale_in), float(s.Velocity_nudging_timescale_out)
             c.Tr_InvLscale_in, c.Tr_InvLscale_out = float(s.Tr_InvLscale_in), float(s.Tr_InvLscale_out)
-            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH"):
+            for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH",
+                      "nudged_tangential_vel", "nudged_tangential_grad"):
                 a = getattr(s, k)
                 need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient, "nudged_normal_vel": s.nudged,
                         "normal_vel_bt": s.Flather, "SSH": s.Flather,
-                        "tangential_vel": self.computed_vorticity or self.computed_strain, "tangential_grad": self.specified_vorticity}[k]
+                        "tangential_vel": self.computed_vorticity or self.computed_strain or s.radiation_tan or s.nudged_tan,
+                        "tangential_grad": self.specified_vorticity or s.radiation_grad or s.nudged_grad,
+                        "nudged_tangential_vel": s.nudged_tan, "nudged_tangential_grad": s.nudged_grad}[k]
                 if a is not None and need and s.on_pe:
                     if to_ptr is None:
                         a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); setattr(c, k, a.ctypes.data)

@@ -27,7 +27,7 @@ int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *
   for (int n = 0; n < OBC->number_of_segments; n++) {
     const mom6hip_obc_segment_t *S = &OBC->segment[n];
     if (!S->on_pe) continue;
-    if (S->oblique || S->radiation_tan_or_grad) return 2;
+    if (S->oblique || (S->radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE))) return 2;
     if ((S->radiation || S->gradient) && !S->normal_vel) return 3;
     if (S->radiation && gamma_u < 1.0 && !(S->is_E_or_W ? rx_normal : ry_normal)) return 3;
     if ((S->radiation && S->nudged) && !S->nudged_normal_vel) return 3;
@@ -60,6 +60,58 @@ int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *
         const double gamma_2 = dt / (tau + dt);
         *nv = (1.0 - gamma_2) * *nv + gamma_2 * S->nudged_normal_vel[seg_idx(S, ew, A, c, k)];
       }
+    }
+    /* the tangential forms :2403-2455 (E), :2648-2700 (W), :2892-2945 (N), :3137-3190 (S): the rate at the corner points of the segment, then
+     * segment%tangential_vel (ORLANSKI_TAN, NUDGED_TAN) and segment%tangential_grad (ORLANSKI_GRAD, NUDGED_GRAD) */
+    if (S->radiation_tan_or_grad & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_GRAD_RADIATION)) {
+      const int bits = S->radiation_tan_or_grad;
+      const int q0 = ew ? S->JsdB : S->IsdB, q1 = ew ? S->JedB : S->IedB;      /* the corner points along the segment */
+      /* the tangential component at the corner q in the row / column t of cells: v(t, Q) for E / W, u(Q, t) for N / S */
+      double *tn = ew ? v_new : u_new;
+      const double *to = ew ? v_old : u_old;
+#define T3(t,q,k) (ew ? ORC_V3(G,t,q,k) : ORC_U3(G,q,t,k))
+#define TIDX(q,k) (ew ? (long)(A - S->IsdB) + (long)(S->IedB - S->IsdB + 1)*(((q) - S->JsdB) + (long)(S->JedB - S->JsdB + 1)*((k)-1)) \
+                      : (long)((q) - S->IsdB) + (long)(S->IedB - S->IsdB + 1)*((A - S->JsdB) + (long)(S->JedB - S->JsdB + 1)*((k)-1)))
+      const int t0 = plus ? A : A + 1, st = plus ? -1 : 1;      /* the first row of cells inside, and the step further in */
+      if ((bits & MOM6HIP_OBC_TAN_RADIATION) && !S->tangential_vel) return 3;
+      if ((bits & MOM6HIP_OBC_GRAD_RADIATION) && !S->tangential_grad) return 3;
+      if ((bits & MOM6HIP_OBC_TAN_NUDGED) && !(S->tangential_vel && S->nudged_tangential_vel)) return 3;
+      if ((bits & MOM6HIP_OBC_GRAD_NUDGED) && !(S->tangential_grad && S->nudged_tangential_grad)) return 3;
+      const double *Idm = ew ? G->IdxBu : G->IdyBu;
+#define QM(t,q) (ew ? ORC_Q2(G,t,q) : ORC_Q2(G,q,t))      /* the corner point between the rows t and t+1 of cells */
+      const int g0 = (ew ? G->jsd : G->isd) + 1, g1 = (ew ? G->jed : G->ied) - 1;
+      for (int k = 1; k <= nz; k++) for (int q = q0; q <= q1; q++) {
+        double r_tang;
+        if (gamma_u < 1.0) {      /* segment%rx_norm_rad at the two faces about the corner (the ends: the one face there is) */
+          if (q == q0) r_tang = r_normal[F3(A,c0,k)];
+          else if (q == q1) r_tang = r_normal[F3(A,c1,k)];
+          else r_tang = 0.5*(r_normal[F3(A,q,k)] + r_normal[F3(A,q+1,k)]);
+        } else {
+          /* (the northern segment looks one row further in than the other three, :2904-2905) */
+          const int ta = (!ew && plus) ? t0 + st : t0;
+          const double dhdt = to[T3(ta,q,k)] - tn[T3(ta,q,k)];
+          const double dhdx = tn[T3(ta,q,k)] - tn[T3(ta+st,q,k)];
+          r_tang = 0.0;
+          if (dhdt*dhdx > 0.0) r_tang = min2( (dhdt/dhdx), rx_max);
+        }
+        const double tau = (r_tang <= 0.0) ? S->Velocity_nudging_timescale_in : S->Velocity_nudging_timescale_out;
+        const double gamma_2 = dt / (tau + dt);
+        if (bits & MOM6HIP_OBC_TAN_RADIATION)
+          S->tangential_vel[TIDX(q,k)] = (tn[T3(t0,q,k)] + r_tang*tn[T3(t0+st,q,k)]) / (1.0+r_tang);
+        if (bits & MOM6HIP_OBC_TAN_NUDGED)
+          S->tangential_vel[TIDX(q,k)] = (1.0 - gamma_2) * S->tangential_vel[TIDX(q,k)] + gamma_2 * S->nudged_tangential_vel[TIDX(q,k)];
+        if ((bits & MOM6HIP_OBC_GRAD_RADIATION) && q >= g0 && q <= g1 && q >= q0 && q <= q1) {
+          /* differences towards larger indices, with the metric of the corner point between the two rows */
+          const int lo1 = plus ? t0 - 1 : t0, lo2 = plus ? t0 - 2 : t0 + 1;
+          S->tangential_grad[TIDX(q,k)] = ((tn[T3(lo1+1,q,k)] - tn[T3(lo1,q,k)])*Idm[QM(lo1,q)] +
+                                           r_tang*(tn[T3(lo2+1,q,k)] - tn[T3(lo2,q,k)])*Idm[QM(lo2,q)]) / (1.0+r_tang);
+        }
+        if (bits & MOM6HIP_OBC_GRAD_NUDGED)
+          S->tangential_grad[TIDX(q,k)] = (1.0 - gamma_2) * S->tangential_grad[TIDX(q,k)] + gamma_2 * S->nudged_tangential_grad[TIDX(q,k)];
+      }
+#undef T3
+#undef TIDX
+#undef QM
     }
   }
   /* open_boundary_apply_normal_flow :3337 */

@@ -1223,10 +1223,12 @@ type :: OBC_segment_type
   type(segment_tracer_registry_type), pointer :: tr_Reg => NULL()
   logical :: Flather = .false., radiation = .false., oblique = .false., nudged = .false., specified = .false., open = .false.
   logical :: gradient = .false., on_pe = .false., is_N_or_S = .false., is_E_or_W = .false.
+  logical :: radiation_tan = .false., radiation_grad = .false., nudged_tan = .false., nudged_grad = .false.
+  logical :: oblique_tan = .false., oblique_grad = .false.
   integer :: direction = 0
   type(hor_index_type) :: HI
   real, allocatable :: normal_vel(:,:,:), normal_trans(:,:,:), normal_vel_bt(:,:), tangential_vel(:,:,:), tangential_grad(:,:,:)
-  real, allocatable :: SSH(:,:), nudged_normal_vel(:,:,:)
+  real, allocatable :: SSH(:,:), nudged_normal_vel(:,:,:), nudged_tangential_vel(:,:,:), nudged_tangential_grad(:,:,:)
   real :: Velocity_nudging_timescale_in = 0.0, Velocity_nudging_timescale_out = 0.0
   real :: Tr_InvLscale_in = 0.0, Tr_InvLscale_out = 0.0
   type(OBC_segment_data_type), pointer :: field(:) => NULL()

@@ -118,7 +118,7 @@ def test_oracle_turns_with_the_grid():
 
 def test_refused_forms():
     g, d, _ = rad_case()
-    for bad in (["I=N,J=0:N,OBLIQUE"], ["I=N,J=0:N,ORLANSKI,ORLANSKI_TAN"]):
+    for bad in (["I=N,J=0:N,OBLIQUE"], ["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"]):
         OBC = ocean_OBC_type(g, bad)
         with pytest.raises(RuntimeError, match="rc=2"):
             run(g, d, OBC)
@@ -172,7 +172,7 @@ def test_gpu_radiation_refuses_what_it_does_not_provide():
     g, d, _ = rad_case()
     dg = DeviceGrid(g)
     o = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
-    for bad, msg in ((["I=N,J=0:N,OBLIQUE"], "oblique"), (["I=N,J=0:N,ORLANSKI,ORLANSKI_TAN"], "tangential")):
+    for bad, msg in ((["I=N,J=0:N,OBLIQUE"], "oblique"), (["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"], "oblique")):
         OBC = ocean_OBC_type(g, bad)
         OBC.rx_normal, OBC.ry_normal = o["rx"], o["ry"]
         for s in OBC.segment:
@@ -201,3 +201,142 @@ def test_gpu_advect_tracer_with_segments_without_a_tracer_registry_is_the_closed
         out.append(tr)
     assert all(bits_equal(a, b) for a, b in zip(*out))
     dg.close()
+
+
+# ---- the tangential forms: ORLANSKI_TAN / ORLANSKI_GRAD / NUDGED_TAN / NUDGED_GRAD (:2403-2455 E, :2648-2700 W, :2892-2945 N, :3137-3190 S) ----
+TAN_SEGS = ["J=N,I=N:0,ORLANSKI,ORLANSKI_TAN,ORLANSKI_GRAD", "J=0,I=0:N,ORLANSKI,ORLANSKI_TAN,NUDGED_TAN", "I=N,J=0:N,ORLANSKI,ORLANSKI_GRAD,NUDGED_GRAD",
+            "I=0,J=N:0,ORLANSKI,NUDGED,ORLANSKI_TAN,ORLANSKI_GRAD,NUDGED_TAN,NUDGED_GRAD", "I=9,J=4:11,ORLANSKI,ORLANSKI_TAN,ORLANSKI_GRAD",
+            "J=7,I=15:3,ORLANSKI,ORLANSKI_TAN,ORLANSKI_GRAD"]
+
+
+def tan_case(seed=8, **kw):
+    g, d, OBC = rad_case(TAN_SEGS, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 7)
+    for s in OBC.segment:
+        if not s.on_pe:
+            continue
+        shp = s.tangential_vel.shape
+        s.tangential_vel[:] = 0.1 * rng.standard_normal(shp); s.tangential_grad[:] = 1e-5 * rng.standard_normal(shp)
+        s.nudged_tangential_vel = 0.2 * rng.standard_normal(shp); s.nudged_tangential_grad = 2e-5 * rng.standard_normal(shp)
+        s.Velocity_nudging_timescale_in, s.Velocity_nudging_timescale_out = 3600.0, 86400.0
+    return g, d, OBC
+
+
+def expected_tangential(g, d, s, r_normal, tv0, tg0, gamma_uv, rx_max, dt):
+    """the four blocks of the reference written out one by one (Fortran indices; arrays here are [k, j - jsd, i - isd (+1 for face / corner arrays)])"""
+    H = s.HI
+    nk = g.nk
+    tv, tg = tv0.copy(), tg0.copy()
+    ew = s.is_E_or_W
+    vn, vo = (d["v_new"], d["v_old"]) if ew else (d["u_new"], d["u_old"])
+    Id = np.asarray(g.IdxBu if ew else g.IdyBu)
+    V = lambda i, J, k: vn[k, J - (g.jsd - 1), i - g.isd]       # v(i, J, k)
+    Vo = lambda i, J, k: vo[k, J - (g.jsd - 1), i - g.isd]
+    Uu = lambda I, j, k: vn[k, j - g.jsd, I - (g.isd - 1)]      # u(I, j, k)
+    Uo = lambda I, j, k: vo[k, j - g.jsd, I - (g.isd - 1)]
+    Q = lambda I, J: Id[J - (g.jsd - 1), I - (g.isd - 1)]
+    if ew:
+        I = H["IsdB"]; R = lambda j, k: r_normal[k, j - g.jsd, I - (g.isd - 1)]
+        east = s.direction == _abi.OBC_DIRECTION_E
+        for k in range(nk):
+            for J in range(H["JsdB"], H["JedB"] + 1):
+                if gamma_uv < 1.0:
+                    r = R(H["jsd"], k) if J == H["JsdB"] else (R(H["jed"], k) if J == H["JedB"] else 0.5 * (R(J, k) + R(J + 1, k)))
+                else:
+                    a, b = (I, I - 1) if east else (I + 1, I + 2)
+                    dhdt = Vo(a, J, k) - V(a, J, k); dhdx = V(a, J, k) - V(b, J, k)
+                    r = min(dhdt / dhdx, rx_max) if dhdt * dhdx > 0.0 else 0.0
+                tau = s.Velocity_nudging_timescale_in if r <= 0.0 else s.Velocity_nudging_timescale_out
+                g2 = dt / (tau + dt)
+                jj = J - H["JsdB"]
+                if s.radiation_tan:
+                    tv[k, jj, 0] = ((V(I, J, k) + r * V(I - 1, J, k)) if east else (V(I + 1, J, k) + r * V(I + 2, J, k))) / (1.0 + r)
+                if s.nudged_tan:
+                    tv[k, jj, 0] = (1.0 - g2) * tv[k, jj, 0] + g2 * s.nudged_tangential_vel[k, jj, 0]
+                if s.radiation_grad and max(H["JsdB"], g.jsd + 1) <= J <= min(H["JedB"], g.jed - 1):
+                    if east:
+                        tg[k, jj, 0] = ((V(I, J, k) - V(I - 1, J, k)) * Q(I - 1, J) + r * (V(I - 1, J, k) - V(I - 2, J, k)) * Q(I - 2, J)) / (1.0 + r)
+                    else:
+                        tg[k, jj, 0] = ((V(I + 2, J, k) - V(I + 1, J, k)) * Q(I + 1, J) + r * (V(I + 3, J, k) - V(I + 2, J, k)) * Q(I + 2, J)) / (1.0 + r)
+                if s.nudged_grad:
+                    tg[k, jj, 0] = (1.0 - g2) * tg[k, jj, 0] + g2 * s.nudged_tangential_grad[k, jj, 0]
+    else:
+        J = H["JsdB"]; R = lambda i, k: r_normal[k, J - (g.jsd - 1), i - g.isd]
+        north = s.direction == _abi.OBC_DIRECTION_N
+        for k in range(nk):
+            for I in range(H["IsdB"], H["IedB"] + 1):
+                if gamma_uv < 1.0:
+                    r = R(H["isd"], k) if I == H["IsdB"] else (R(H["ied"], k) if I == H["IedB"] else 0.5 * (R(I, k) + R(I + 1, k)))
+                else:
+                    a, b = (J - 1, J - 2) if north else (J + 1, J + 2)
+                    dhdt = Uo(I, a, k) - Uu(I, a, k); dhdy = Uu(I, a, k) - Uu(I, b, k)
+                    r = min(dhdt / dhdy, rx_max) if dhdt * dhdy > 0.0 else 0.0
+                tau = s.Velocity_nudging_timescale_in if r <= 0.0 else s.Velocity_nudging_timescale_out
+                g2 = dt / (tau + dt)
+                ii = I - H["IsdB"]
+                if s.radiation_tan:
+                    tv[k, 0, ii] = ((Uu(I, J, k) + r * Uu(I, J - 1, k)) if north else (Uu(I, J + 1, k) + r * Uu(I, J + 2, k))) / (1.0 + r)
+                if s.nudged_tan:
+                    tv[k, 0, ii] = (1.0 - g2) * tv[k, 0, ii] + g2 * s.nudged_tangential_vel[k, 0, ii]
+                if s.radiation_grad and max(H["IsdB"], g.isd + 1) <= I <= min(H["IedB"], g.ied - 1):
+                    if north:
+                        tg[k, 0, ii] = ((Uu(I, J, k) - Uu(I, J - 1, k)) * Q(I, J - 1) + r * (Uu(I, J - 1, k) - Uu(I, J - 2, k)) * Q(I, J - 2)) / (1.0 + r)
+                    else:
+                        tg[k, 0, ii] = ((Uu(I, J + 2, k) - Uu(I, J + 1, k)) * Q(I, J + 1) + r * (Uu(I, J + 3, k) - Uu(I, J + 2, k)) * Q(I, J + 2)) / (1.0 + r)
+                if s.nudged_grad:
+                    tg[k, 0, ii] = (1.0 - g2) * tg[k, 0, ii] + g2 * s.nudged_tangential_grad[k, 0, ii]
+    return tv, tg
+
+
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+def test_oracle_tangential_forms_are_the_four_blocks_of_the_reference(gamma_uv):
+    g, d, OBC = tan_case()
+    before = [(s.tangential_vel.copy(), s.tangential_grad.copy()) for s in OBC.segment]
+    o = run(g, d, OBC, gamma_uv=gamma_uv)
+    # the normal part is what it is without the tangential forms
+    OBCn = ocean_OBC_type(g, [",".join(w for w in t.split(",") if not w.endswith(("_TAN", "_GRAD"))) for t in TAN_SEGS])
+    for s, sn in zip(OBC.segment, OBCn.segment):
+        sn.Velocity_nudging_timescale_in, sn.Velocity_nudging_timescale_out = s.Velocity_nudging_timescale_in, s.Velocity_nudging_timescale_out
+        if s.nudged:
+            sn.nudged_normal_vel[:] = s.nudged_normal_vel
+    on = run(g, d, OBCn, gamma_uv=gamma_uv)
+    assert bits_equal(o["u_new"], on["u_new"]) and bits_equal(o["rx"], on["rx"]) and bits_equal(o["ry"], on["ry"])
+    n_changed = 0
+    for s, (tv0, tg0) in zip(OBC.segment, before):
+        r_normal = o["rx"] if s.is_E_or_W else o["ry"]      # segment%rx_norm_rad as the normal part has just left it
+        tv, tg = expected_tangential(g, d, s, r_normal, tv0, tg0, gamma_uv, 1.0, 900.0)
+        assert bits_equal(s.tangential_vel, tv), (s.direction, "tangential_vel", np.argwhere(s.tangential_vel != tv)[:4].tolist())
+        assert bits_equal(s.tangential_grad, tg), (s.direction, "tangential_grad", np.argwhere(s.tangential_grad != tg)[:4].tolist())
+        n_changed += int((tv != tv0).sum() + (tg != tg0).sum())
+    assert n_changed > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_tangential_forms_match_oracle_bitwise(gamma_uv, space):
+    import copy
+    import torch
+    from mom6_amd.open_boundary import radiation_open_bdry_conds
+    from mom6_amd.tracer_advect import DeviceGrid
+    for kw in (dict(), dict(ni=150, nj=40, nk=2, seed=5)):
+        g, d, OBC = tan_case(**kw)
+        OBC.gamma_uv, OBC.rx_max = gamma_uv, 1.0
+        ref = copy.deepcopy(OBC)
+        o = run(g, d, ref, gamma_uv=gamma_uv)
+        dev = space == "device"
+        X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if dev else (lambda a: a.copy())
+        N = (lambda a: a.cpu().numpy()) if dev else (lambda a: a)
+        f = {k: X(v) for k, v in d.items()}
+        OBC.rx_normal, OBC.ry_normal = f["rx"], f["ry"]
+        if dev:
+            OBC.cuda()
+        dg = DeviceGrid(g)
+        radiation_open_bdry_conds(OBC, f["u_new"], f["u_old"], f["v_new"], f["v_old"], dg, 900.0)
+        dg.sync()
+        assert bits_equal(N(f["u_new"]), o["u_new"]) and bits_equal(N(f["v_new"]), o["v_new"]) and bits_equal(N(f["rx"]), o["rx"])
+        for n, (s, sr) in enumerate(zip(OBC.segment, ref.segment)):
+            assert bits_equal(N(s.tangential_vel), sr.tangential_vel), (n, "tangential_vel", np.argwhere(N(s.tangential_vel) != sr.tangential_vel)[:4].tolist())
+            assert bits_equal(N(s.tangential_grad), sr.tangential_grad), (n, "tangential_grad")
+            assert bits_equal(N(s.normal_vel), sr.normal_vel), (n, "normal_vel")
+        dg.close()
