@@ -472,7 +472,9 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
  * ry_normal), the gradient condition (segment%gradient), nudging towards segment%nudged_normal_vel; then
  * open_boundary_apply_normal_flow (:3337) and pass_vector(u_new, v_new).  segment%normal_vel is written.  The tangential forms
  * (segment%radiation_tan, %radiation_grad, %nudged_tan, %nudged_grad: :2403-2455 and its three twins) write segment%tangential_vel /
- * tangential_grad at the corner points of the segment.  Not provided (refused): oblique radiation and its tangential forms.
+ * tangential_grad at the corner points of the segment.  Oblique radiation (segment%oblique: :2349-2383 and its three twins, with the
+ * gradients along the boundary of gradient_at_q_points :3407 and the restart fields obc->rx_oblique_u ... cff_normal_v).  Not provided
+ * (refused): the tangential forms of the oblique radiation (OBLIQUE_TAN, OBLIQUE_GRAD).
  * rx_normal (u points, 3-D) and ry_normal (v points, 3-D) may be NULL when gamma_uv >= 1. */
 int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const struct mom6hip_obc *obc, double gamma_uv, double rx_max, double *rx_normal,
                                       double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old, double dt,
@@ -623,6 +625,10 @@ typedef struct mom6hip_obc {
    * step (its calls of radiation_open_bdry_conds); mom6hip_radiation_open_bdry_conds takes them as arguments. */
   double *rx_normal, *ry_normal;
   double gamma_uv, rx_max;
+  /* OBC%rx_oblique_u, ry_oblique_u, cff_normal_u (the layout of rx_normal), OBC%rx_oblique_v, ry_oblique_v, cff_normal_v (of ry_normal): what
+   * the oblique segments keep between steps (restart fields), in the memory space of the call; read and written by
+   * radiation_open_bdry_conds for OBLIQUE segments with gamma_uv < 1; may be NULL otherwise */
+  double *rx_oblique_u, *ry_oblique_u, *cff_normal_u, *rx_oblique_v, *ry_oblique_v, *cff_normal_v;
 } mom6hip_obc_t;
 
 /* continuity_PPM with OBC associated (:86-194; the OBC branches of PPM_reconstruction_x/y :2385-2432 / :2521-2568, of

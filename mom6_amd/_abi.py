@@ -214,7 +214,8 @@ class Obc(C.Structure):
                                          "freeslip_vorticity", "computed_vorticity", "specified_vorticity", "zero_strain", "freeslip_strain",
                                          "computed_strain", "zero_biharmonic")] + \
                [("segment", C.POINTER(ObcSegment)), ("segnum_u", C.c_void_p), ("segnum_v", C.c_void_p),
-                ("rx_normal", C.c_void_p), ("ry_normal", C.c_void_p), ("gamma_uv", C.c_double), ("rx_max", C.c_double)]
+                ("rx_normal", C.c_void_p), ("ry_normal", C.c_void_p), ("gamma_uv", C.c_double), ("rx_max", C.c_double)] + \
+               [(n, C.c_void_p) for n in ("rx_oblique_u", "ry_oblique_u", "cff_normal_u", "rx_oblique_v", "ry_oblique_v", "cff_normal_v")]
 
 
 class HorDiffStats(C.Structure):

@@ -15,6 +15,8 @@ using m6::min2;
 
 struct RadSeg {
   int ew, d1, A, c0, c1, radiation, gradient, nudged;      // d1 = -1 (E, N: inside towards smaller indices) or +1
+  int oblique, gq0, gq1;   // segment%oblique; the corner points gradient_at_q_points computes segment%grad_normal at (zero beyond)
+  double *rn_st, *rt_st, *cf_st;      // OBC%rx_oblique_u | ry_oblique_v (the rate along the normal), ry_oblique_u | rx_oblique_v, cff_normal_u | _v
   int a0, cs0;             // the first index of the segment's own arrays along / across (IsdB | JsdB, jsd | isd)
   long nA, nc;             // their extents
   double tau_in, tau_out;
@@ -37,7 +39,34 @@ __global__ __launch_bounds__(64) void rad_segment_kernel(m6::GridDev g, RadSeg S
   const long f1 = f0 + S.d1 * step, f2 = f0 + 2 * S.d1 * step;
   double dhdt = 0.0, dhdx = 0.0;
   double nv = S.normal_vel[rad_idx(S, c, k)];
-  if (S.radiation) {
+  if (S.oblique && !S.radiation) {      // :2349-2383 (E), :2593-2628 (W), :2838-2872 (N), :3082-3117 (S)
+    // segment%grad_normal(q, 1 | 2, k) of gradient_at_q_points (:3407): the difference of the normal component along the boundary at the corner
+    // point q, one face inside (a = A + d1) | on the boundary (a = A)
+    const long cstep = S.ew ? (g.nih + 1) : 1;      // one face along the boundary
+    auto GN = [&](int q, long fa, int a) -> double {      // fa: the face (a, q) of this layer
+      if (q < S.gq0 || q > S.gq1) return 0.0;
+      return (xn[fa + cstep] - xn[fa]) * g.mask2dBu[S.ew ? g.q2(a, q) : g.q2(q, a)];
+    };
+    dhdt = (xo[f1] - xn[f1]);
+    dhdx = (xn[f1] - xn[f2]);
+    const double g1c = GN(c, f1, S.A + S.d1), g1m = GN(c - 1, f1 - cstep, S.A + S.d1);
+    double dhdy;
+    if (dhdt * (g1c + g1m) > 0.0) dhdy = g1m;
+    else if (dhdt * (g1c + g1m) == 0.0) dhdy = 0.0;
+    else dhdy = g1c;
+    if (dhdt * dhdx < 0.0) dhdt = 0.0;
+    const double cff_new = m6::max2(dhdx * dhdx + dhdy * dhdy, 1.0e-20);
+    const double rn_new = min2(dhdt * dhdx, cff_new * rx_max);
+    const double rt_new = min2(cff_new, m6::max2(dhdt * dhdy, -cff_new));
+    double rn_avg, rt_avg, cff_avg;
+    if (gamma_u < 1.0) {
+      rn_avg = (1.0 - gamma_u) * S.rn_st[f0] + gamma_u * rn_new;
+      rt_avg = (1.0 - gamma_u) * S.rt_st[f0] + gamma_u * rt_new;
+      cff_avg = (1.0 - gamma_u) * S.cf_st[f0] + gamma_u * cff_new;
+    } else { rn_avg = rn_new; rt_avg = rt_new; cff_avg = cff_new; }
+    nv = ((cff_avg * xn[f0] + rn_avg * xn[f1]) - (m6::max2(rt_avg, 0.0) * GN(c - 1, f0 - cstep, S.A) + min2(rt_avg, 0.0) * GN(c, f0, S.A))) / (cff_avg + rn_avg);
+    if (gamma_u < 1.0) { S.rn_st[f0] = rn_avg; S.rt_st[f0] = rt_avg; S.cf_st[f0] = cff_avg; }
+  } else if (S.radiation) {
     dhdt = (xo[f1] - xn[f1]);
     dhdx = (xn[f1] - xn[f2]);
     double rx_new = 0.0, rx_avg;
@@ -49,7 +78,7 @@ __global__ __launch_bounds__(64) void rad_segment_kernel(m6::GridDev g, RadSeg S
   } else if (S.gradient) {
     nv = xn[f1];
   }
-  if (S.radiation && S.nudged) {
+  if ((S.radiation || S.oblique) && S.nudged) {
     const double tau = (dhdt * dhdx <= 0.0) ? S.tau_in : S.tau_out;
     const double gamma_2 = dt / (tau + dt);
     nv = (1.0 - gamma_2) * nv + gamma_2 * S.nudged_normal_vel[rad_idx(S, c, k)];
@@ -147,7 +176,12 @@ bool rad_segment(const m6::GridDev &g, const mom6hip_obc_segment_t &S, RadSeg &d
   d.A = ew ? S.IsdB : S.JsdB; d.c0 = ew ? S.jsd : S.isd; d.c1 = ew ? S.jed : S.ied;
   d.a0 = d.A; d.cs0 = d.c0;
   d.nA = ew ? (S.IedB - S.IsdB + 1) : (S.JedB - S.JsdB + 1); d.nc = d.c1 - d.c0 + 1;
-  d.radiation = S.radiation; d.gradient = S.gradient; d.nudged = S.nudged;
+  d.radiation = S.radiation; d.gradient = S.gradient; d.nudged = S.nudged; d.oblique = S.oblique;
+  {
+    const int q0 = ew ? S.JsdB : S.IsdB, q1 = ew ? S.JedB : S.IedB, lo = ew ? g.jsd : g.isd, hi = (ew ? g.jed : g.ied) - 1;
+    d.gq0 = q0 > lo ? q0 : lo; d.gq1 = q1 < hi ? q1 : hi;
+  }
+  d.rn_st = d.rt_st = d.cf_st = nullptr;
   d.tau_in = S.Velocity_nudging_timescale_in; d.tau_out = S.Velocity_nudging_timescale_out;
   d.normal_vel = nullptr; d.nudged_normal_vel = nullptr;
   return true;
@@ -230,21 +264,32 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
   double *d_rx = st.inout(rx_normal, bU), *d_ry = st.inout(ry_normal, bV);
   std::vector<RadSeg> segs;
   std::vector<TanArgs> tans;
+  double *d_ob[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int n = 0; n < obc->number_of_segments; n++) {
     const mom6hip_obc_segment_t &S = obc->segment[n];
     RadSeg d;
     if (!rad_segment(g, S, d)) continue;
-    M6_REQUIRE(!S.oblique, "radiation_open_bdry_conds: oblique radiation (OBLIQUE, segment %d) is not provided by libmom6hip", n + 1);
+    M6_REQUIRE(!(S.oblique && S.radiation), "radiation_open_bdry_conds: segment %d: Orlanski and Oblique OBC options cannot be used together", n + 1);
     M6_REQUIRE(!(S.radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)), "radiation_open_bdry_conds: the oblique tangential "
                "forms (OBLIQUE_TAN / _GRAD; segment %d) are not provided by libmom6hip", n + 1);
     if (check_segment_range(g, S, n, "radiation_open_bdry_conds")) return 1;
-    if (S.radiation || S.gradient) {
+    if (S.oblique && gamma_uv < 1.0) {      // what the oblique segments keep between steps, staged once for all of them
+      if (!d_ob[0]) {
+        double *src[6] = {obc->rx_oblique_u, obc->ry_oblique_u, obc->cff_normal_u, obc->rx_oblique_v, obc->ry_oblique_v, obc->cff_normal_v};
+        for (int m = 0; m < 6; m++) {
+          M6_REQUIRE(src[m], "radiation_open_bdry_conds: OBLIQUE with OBC_RAD_VEL_WT < 1 needs OBC%%rx_oblique_u, ry_oblique_u, cff_normal_u and their _v twins");
+          d_ob[m] = st.inout(src[m], m < 3 ? bU : bV);
+        }
+      }
+      d.rn_st = d.ew ? d_ob[0] : d_ob[4]; d.rt_st = d.ew ? d_ob[1] : d_ob[3]; d.cf_st = d.ew ? d_ob[2] : d_ob[5];
+    }
+    if (S.radiation || S.gradient || S.oblique) {
       M6_REQUIRE(S.normal_vel, "radiation_open_bdry_conds: segment %d needs normal_vel", n + 1);
       M6_REQUIRE(!(S.radiation && gamma_uv < 1.0) || (d.ew ? rx_normal : ry_normal), "radiation_open_bdry_conds: OBC_RAD_VEL_WT < 1 needs OBC%%rx_normal / ry_normal");
-      M6_REQUIRE(!(S.radiation && S.nudged) || S.nudged_normal_vel, "radiation_open_bdry_conds: segment %d is nudged: nudged_normal_vel is required", n + 1);
+      M6_REQUIRE(!((S.radiation || S.oblique) && S.nudged) || S.nudged_normal_vel, "radiation_open_bdry_conds: segment %d is nudged: nudged_normal_vel is required", n + 1);
       const size_t cnt = (size_t)d.nA * d.nc * g.nk * 8;
       d.normal_vel = st.inout(S.normal_vel, cnt);
-      d.nudged_normal_vel = (S.radiation && S.nudged) ? st.in(S.nudged_normal_vel, cnt) : nullptr;
+      d.nudged_normal_vel = ((S.radiation || S.oblique) && S.nudged) ? st.in(S.nudged_normal_vel, cnt) : nullptr;
     }
     TanArgs a;
     a.bits = S.radiation_tan_or_grad; a.q0 = d.ew ? S.JsdB : S.IsdB; a.q1 = d.ew ? S.JedB : S.IedB; a.nq = a.q1 - a.q0 + 1;
@@ -283,7 +328,7 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
     // I < IscB (E), I > IecB (W), J < JscB (N), J > JecB (S): the segment is skipped :2329, :2573, :2818, :3062
     const int lo = d.ew ? g.isc - 1 : g.jsc - 1, hi = d.ew ? g.iec : g.jec;
     if (d.d1 < 0 ? (d.A < lo) : (d.A > hi)) continue;
-    if (d.radiation || d.gradient)
+    if (d.radiation || d.gradient || d.oblique)
       hipLaunchKernelGGL(rad_segment_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, s, g, d, gamma_uv, rx_max, dt, d.ew ? d_un : d_vn,
                          d.ew ? d_uo : d_vo, d.ew ? d_rx : d_ry);
     if (tans[m].bits)      // (after the rates of the segment's own faces; the tangential component of u_new, v_new is not changed by this routine)
@@ -291,7 +336,7 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
                          d.ew ? d_vn : d_un, d.ew ? d_vo : d_uo, d.ew ? d_rx : d_ry);
   }
   for (const RadSeg &d : segs) {      // open_boundary_apply_normal_flow :3337 (radiation, oblique or gradient segments)
-    if (!(d.radiation || d.gradient)) continue;
+    if (!(d.radiation || d.gradient || d.oblique)) continue;
     hipLaunchKernelGGL(obc_face_store_kernel, dim3((d.nc + 63) / 64, g.nk), dim3(64), 0, s, g, d, d.ew ? d_un : d_vn, 1);
   }
   M6_HIP(hipGetLastError());

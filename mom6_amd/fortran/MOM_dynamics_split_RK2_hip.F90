@@ -316,7 +316,7 @@ subroutine obc_mirrors(CS)
   do n = 1, CS%OBC%number_of_segments
     seg => CS%OBC%segment(n)
     if (.not.seg%on_pe) cycle
-    rad = seg%radiation .or. seg%gradient .or. seg%nudged
+    rad = seg%radiation .or. seg%gradient .or. seg%nudged .or. seg%oblique
     CS%c_obc_segs(n)%normal_trans = c_null_ptr ; CS%c_obc_segs(n)%normal_vel = c_null_ptr ; CS%c_obc_segs(n)%normal_vel_bt = c_null_ptr
     CS%c_obc_segs(n)%SSH = c_null_ptr ; CS%c_obc_segs(n)%tangential_vel = c_null_ptr ; CS%c_obc_segs(n)%tangential_grad = c_null_ptr
     CS%c_obc_segs(n)%nudged_normal_vel = c_null_ptr ; CS%c_obc_segs(n)%nudged_tangential_vel = c_null_ptr
@@ -344,6 +344,15 @@ subroutine obc_mirrors(CS)
   CS%c_obc%rx_normal = c_null_ptr ; CS%c_obc%ry_normal = c_null_ptr
   if (allocated(CS%OBC%rx_normal)) CS%c_obc%rx_normal = mirror(CS, c_loc(CS%OBC%rx_normal), CS%nu3, .true., .true.)
   if (allocated(CS%OBC%ry_normal)) CS%c_obc%ry_normal = mirror(CS, c_loc(CS%OBC%ry_normal), CS%nv3, .true., .true.)
+  ! what the oblique segments keep between steps (OBLIQUE_TAN / OBLIQUE_GRAD are refused by the library's radiation_open_bdry_conds)
+  CS%c_obc%rx_oblique_u = c_null_ptr ; CS%c_obc%ry_oblique_u = c_null_ptr ; CS%c_obc%cff_normal_u = c_null_ptr
+  CS%c_obc%rx_oblique_v = c_null_ptr ; CS%c_obc%ry_oblique_v = c_null_ptr ; CS%c_obc%cff_normal_v = c_null_ptr
+  if (allocated(CS%OBC%rx_oblique_u)) CS%c_obc%rx_oblique_u = mirror(CS, c_loc(CS%OBC%rx_oblique_u), CS%nu3, .true., .true.)
+  if (allocated(CS%OBC%ry_oblique_u)) CS%c_obc%ry_oblique_u = mirror(CS, c_loc(CS%OBC%ry_oblique_u), CS%nu3, .true., .true.)
+  if (allocated(CS%OBC%cff_normal_u)) CS%c_obc%cff_normal_u = mirror(CS, c_loc(CS%OBC%cff_normal_u), CS%nu3, .true., .true.)
+  if (allocated(CS%OBC%rx_oblique_v)) CS%c_obc%rx_oblique_v = mirror(CS, c_loc(CS%OBC%rx_oblique_v), CS%nv3, .true., .true.)
+  if (allocated(CS%OBC%ry_oblique_v)) CS%c_obc%ry_oblique_v = mirror(CS, c_loc(CS%OBC%ry_oblique_v), CS%nv3, .true., .true.)
+  if (allocated(CS%OBC%cff_normal_v)) CS%c_obc%cff_normal_v = mirror(CS, c_loc(CS%OBC%cff_normal_v), CS%nv3, .true., .true.)
   CS%c_rk2%OBC = c_loc(CS%c_obc)
 end subroutine obc_mirrors
 
@@ -505,7 +514,6 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
     CS%OBC => OBC
     call refuse(OBC%update_OBC, "OBC%update_OBC (update_OBC_data inside the step)")
     call refuse(OBC%ramp, "OBC_RAMP")
-    call refuse(OBC%oblique_BCs_exist_globally, "oblique open boundary conditions")
   endif
   if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
 

@@ -510,6 +510,7 @@ contains
     endif
     c%Flather = merge(1, 0, seg%Flather) ; c%radiation = merge(1, 0, seg%radiation) ; c%gradient = merge(1, 0, seg%gradient)
     c%nudged = merge(1, 0, seg%nudged) ; c%oblique = merge(1, 0, seg%oblique)
+    if ((seg%gradient .or. seg%radiation .or. seg%oblique) .and. allocated(seg%normal_vel)) c%normal_vel = c_loc(seg%normal_vel)
     if (allocated(seg%normal_vel_bt)) c%normal_vel_bt = c_loc(seg%normal_vel_bt)
     if (allocated(seg%SSH)) c%SSH = c_loc(seg%SSH)
     if (allocated(seg%tangential_vel)) c%tangential_vel = c_loc(seg%tangential_vel)

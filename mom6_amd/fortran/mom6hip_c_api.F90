@@ -226,6 +226,8 @@ type, bind(c) :: mom6hip_obc_t
   type(c_ptr) :: segment = c_null_ptr, segnum_u = c_null_ptr, segnum_v = c_null_ptr
   type(c_ptr) :: rx_normal = c_null_ptr, ry_normal = c_null_ptr
   real(c_double) :: gamma_uv = 0.0, rx_max = 0.0
+  type(c_ptr) :: rx_oblique_u = c_null_ptr, ry_oblique_u = c_null_ptr, cff_normal_u = c_null_ptr
+  type(c_ptr) :: rx_oblique_v = c_null_ptr, ry_oblique_v = c_null_ptr, cff_normal_v = c_null_ptr
 end type mom6hip_obc_t
 
 !> mom6hip_epipycnal_cs_t (DIFFUSE_ML_TO_INTERIOR: tracer_epipycnal_ML_diff, src/tracer/MOM_tracer_hor_diff.F90:700)

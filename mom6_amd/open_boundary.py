@@ -104,6 +104,8 @@ class ocean_OBC_type:
         # memory space of the calls; None with gamma_uv >= 1)
         self.gamma_uv, self.rx_max = float(flags.pop("gamma_uv", 0.3)), float(flags.pop("rx_max", 1.0))
         self.rx_normal = self.ry_normal = None
+        # what the oblique segments keep between steps (:355-362), the layouts of rx_normal (u) and ry_normal (v)
+        self.rx_oblique_u = self.ry_oblique_u = self.cff_normal_u = self.rx_oblique_v = self.ry_oblique_v = self.cff_normal_v = None
         if flags:
             raise Mom6HipError(f"open_boundary_config: unknown option {sorted(flags)}")
         self.idg_offset = -g.halo if idg_offset is None else idg_offset
@@ -262,7 +264,8 @@ class ocean_OBC_type:
         """the arrays of the OBC and of its segments as CUDA tensors (what a device-resident caller keeps): in place, returns self"""
         import torch
         T = lambda a: a if a is None or hasattr(a, "data_ptr") else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
-        self.rx_normal, self.ry_normal = T(self.rx_normal), T(self.ry_normal)
+        for k in ("rx_normal", "ry_normal", "rx_oblique_u", "ry_oblique_u", "cff_normal_u", "rx_oblique_v", "ry_oblique_v", "cff_normal_v"):
+            setattr(self, k, T(getattr(self, k)))
         for s in self.segment:
             for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH",
                       "nudged_tangential_vel", "nudged_tangential_grad"):
@@ -296,7 +299,7 @@ class ocean_OBC_type:
             for k in ("normal_trans", "normal_vel", "tangential_vel", "tangential_grad", "nudged_normal_vel", "normal_vel_bt", "SSH",
                       "nudged_tangential_vel", "nudged_tangential_grad"):
                 a = getattr(s, k)
-                need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient, "nudged_normal_vel": s.nudged,
+                need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient or s.oblique, "nudged_normal_vel": s.nudged,
                         "normal_vel_bt": s.Flather, "SSH": s.Flather,
                         "tangential_vel": self.computed_vorticity or self.computed_strain or s.radiation_tan or s.nudged_tan,
                         "tangential_grad": self.specified_vorticity or s.radiation_grad or s.nudged_grad,
@@ -333,7 +336,7 @@ class ocean_OBC_type:
         o.segment = C.cast(segs, C.POINTER(_abi.ObcSegment))
         o.segnum_u, o.segnum_v = self.segnum_u.ctypes.data, self.segnum_v.ctypes.data
         o.gamma_uv, o.rx_max = self.gamma_uv, self.rx_max      # (read by the RK2 step; radiation_open_bdry_conds takes them as arguments)
-        for k in ("rx_normal", "ry_normal"):
+        for k in ("rx_normal", "ry_normal", "rx_oblique_u", "ry_oblique_u", "cff_normal_u", "rx_oblique_v", "ry_oblique_v", "cff_normal_v"):
             a = getattr(self, k)
             if a is not None:
                 if to_ptr is None:

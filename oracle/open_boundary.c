@@ -9,6 +9,9 @@
 #include "mom6_oracle.h"
 
 static inline double min2(double a, double b) { return a < b ? a : b; }
+static inline double max2(double a, double b) { return a > b ? a : b; }
+static inline int max2i(int a, int b) { return a > b ? a : b; }
+static inline int min2i(int a, int b) { return a < b ? a : b; }
 
 /* segment arrays on the segment's own index ranges (IsdB:IedB, jsd:jed, nk) | (isd:ied, JsdB:JedB, nk); face (A along, c across), k 1-based */
 static inline long seg_idx(const mom6hip_obc_segment_t *S, int ew, int A, int c, int k) {
@@ -27,8 +30,11 @@ int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *
   for (int n = 0; n < OBC->number_of_segments; n++) {
     const mom6hip_obc_segment_t *S = &OBC->segment[n];
     if (!S->on_pe) continue;
-    if (S->oblique || (S->radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE))) return 2;
-    if ((S->radiation || S->gradient) && !S->normal_vel) return 3;
+    if (S->radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)) return 2;
+    if ((S->radiation || S->gradient || S->oblique) && !S->normal_vel) return 3;
+    if (S->oblique && gamma_u < 1.0 && !(S->is_E_or_W ? (OBC->rx_oblique_u && OBC->ry_oblique_u && OBC->cff_normal_u)
+                                                       : (OBC->rx_oblique_v && OBC->ry_oblique_v && OBC->cff_normal_v))) return 3;
+    if ((S->oblique && S->nudged) && !S->nudged_normal_vel) return 3;
     if (S->radiation && gamma_u < 1.0 && !(S->is_E_or_W ? rx_normal : ry_normal)) return 3;
     if ((S->radiation && S->nudged) && !S->nudged_normal_vel) return 3;
     const int ew = S->direction == MOM6HIP_OBC_DIRECTION_E || S->direction == MOM6HIP_OBC_DIRECTION_W;
@@ -52,10 +58,39 @@ int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *
         else rx_avg = rx_new;
         *nv = (xn[F3(A,c,k)] + rx_avg*xn[F3(A+d1,c,k)]) / (1.0+rx_avg);
         if (gamma_u < 1.0) r_normal[F3(A,c,k)] = rx_avg;
+      } else if (S->oblique) {      /* :2349-2383 (E), :2593-2628 (W), :2838-2872 (N), :3082-3117 (S) */
+        /* segment%grad_normal(q, 1 | 2, k) of gradient_at_q_points (:3407): the difference of the normal component along the boundary at the
+         * corner point q, one face inside | on the boundary; zero beyond the corner points it is computed at */
+        const int q0 = (ew ? S->JsdB : S->IsdB), q1 = (ew ? S->JedB : S->IedB);
+        const int gq0 = max2i(q0, (ew ? G->jsd : G->isd)), gq1 = min2i(q1, (ew ? G->jed : G->ied) - 1);      /* (G%HI%JsdB + 1 = jsd) */
+#define GN(q,a) (((q) < gq0 || (q) > gq1) ? 0.0 : (xn[F3(a,(q)+1,k)] - xn[F3(a,(q),k)]) * (ew ? G->mask2dBu[ORC_Q2(G,a,q)] : G->mask2dBu[ORC_Q2(G,q,a)]))
+        dhdt = (xo[F3(A+d1,c,k)] - xn[F3(A+d1,c,k)]);
+        dhdx = (xn[F3(A+d1,c,k)] - xn[F3(A+d2,c,k)]);
+        const double g1c = GN(c, A+d1), g1m = GN(c-1, A+d1);
+        double dhdy;
+        if (dhdt*(g1c + g1m) > 0.0) dhdy = g1m;
+        else if (dhdt*(g1c + g1m) == 0.0) dhdy = 0.0;
+        else dhdy = g1c;
+        if (dhdt*dhdx < 0.0) dhdt = 0.0;
+        const double cff_new = max2(dhdx*dhdx + dhdy*dhdy, 1.0e-20);      /* eps = 1.0e-20*US%m_s_to_L_T**2 :2245 */
+        const double rn_new = min2(dhdt*dhdx, cff_new*rx_max);
+        const double rt_new = min2(cff_new, max2(dhdt*dhdy, -cff_new));
+        /* the rate along the normal is rx for E / W and ry for N / S; the stored fields are OBC%rx_oblique_u ... cff_normal_v */
+        double *rn_st = ew ? OBC->rx_oblique_u : OBC->ry_oblique_v, *rt_st = ew ? OBC->ry_oblique_u : OBC->rx_oblique_v;
+        double *cf_st = ew ? OBC->cff_normal_u : OBC->cff_normal_v;
+        double rn_avg, rt_avg, cff_avg;
+        if (gamma_u < 1.0) {
+          rn_avg = (1.0-gamma_u)*rn_st[F3(A,c,k)] + gamma_u*rn_new;
+          rt_avg = (1.0-gamma_u)*rt_st[F3(A,c,k)] + gamma_u*rt_new;
+          cff_avg = (1.0-gamma_u)*cf_st[F3(A,c,k)] + gamma_u*cff_new;
+        } else { rn_avg = rn_new; rt_avg = rt_new; cff_avg = cff_new; }
+        *nv = ((cff_avg*xn[F3(A,c,k)] + rn_avg*xn[F3(A+d1,c,k)]) - (max2(rt_avg,0.0)*GN(c-1, A) + min2(rt_avg,0.0)*GN(c, A))) / (cff_avg + rn_avg);
+        if (gamma_u < 1.0) { rn_st[F3(A,c,k)] = rn_avg; rt_st[F3(A,c,k)] = rt_avg; cf_st[F3(A,c,k)] = cff_avg; }
+#undef GN
       } else if (S->gradient) {
         *nv = xn[F3(A+d1,c,k)];
       }
-      if (S->radiation && S->nudged) {
+      if ((S->radiation || S->oblique) && S->nudged) {
         const double tau = (dhdt*dhdx <= 0.0) ? S->Velocity_nudging_timescale_in : S->Velocity_nudging_timescale_out;
         const double gamma_2 = dt / (tau + dt);
         *nv = (1.0 - gamma_2) * *nv + gamma_2 * S->nudged_normal_vel[seg_idx(S, ew, A, c, k)];

@@ -1248,6 +1248,7 @@ type :: ocean_OBC_type
   real :: gamma_uv = 0.3, rx_max = 1.0
   real, allocatable :: rx_normal(:,:,:), ry_normal(:,:,:)
   real, allocatable :: tres_x(:,:,:,:), tres_y(:,:,:,:)
+  real, allocatable :: rx_oblique_u(:,:,:), ry_oblique_u(:,:,:), cff_normal_u(:,:,:), rx_oblique_v(:,:,:), ry_oblique_v(:,:,:), cff_normal_v(:,:,:)
 end type ocean_OBC_type
 contains
 logical function open_boundary_query(OBC, apply_open_OBC, apply_specified_OBC, apply_Flather_OBC, apply_nudged_OBC, needs_ext_seg_data)

@@ -27,6 +27,9 @@ def rk2_obc_case(segs=TC3, ni=22, nj=16, nk=3, seed=4, flags=TC3_FLAGS, land_fra
         OBC = ocean_OBC_type(g, segs, gamma_uv=gamma_uv, rx_max=10.0, **flags)
         open_faces(g, OBC)
         OBC.rx_normal, OBC.ry_normal = g.zeros3(U), g.zeros3(V)
+        if any(sg.oblique for sg in OBC.segment):      # what the oblique segments keep between steps
+            OBC.rx_oblique_u, OBC.ry_oblique_u, OBC.cff_normal_u = g.zeros3(U), g.zeros3(U), g.zeros3(U)
+            OBC.rx_oblique_v, OBC.ry_oblique_v, OBC.cff_normal_v = g.zeros3(V), g.zeros3(V), g.zeros3(V)
     d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed, umax=0.1, eta_amp=0.2).items()}
     yy = np.linspace(0.0, np.pi, g.shape2(U)[0])
     taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu)
@@ -145,8 +148,9 @@ def gpu_run(g, d, taux, tauy, OBC, viscous, bbl, nsteps, check, rk2b=False):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("viscous", [False, True])
-@pytest.mark.parametrize("segs", [TC3, TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"], ["I=N,J=0:N,FLATHER,ORLANSKI", "J=7,I=N:0,SIMPLE"]],
-                         ids=["tc3", "mixed", "inner"])
+@pytest.mark.parametrize("segs", [TC3, TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"], ["I=N,J=0:N,FLATHER,ORLANSKI", "J=7,I=N:0,SIMPLE"],
+                                  ["J=N,I=N:0,FLATHER,OBLIQUE", "J=0,I=0:N,FLATHER,OBLIQUE", "I=N,J=0:N,FLATHER,OBLIQUE", "I=0,J=N:0,FLATHER,ORLANSKI,ORLANSKI_TAN"]],
+                         ids=["tc3", "mixed", "inner", "oblique"])
 def test_gpu_step_with_open_boundaries_matches_oracle_bitwise(segs, viscous):
     for (ni, nj, nk, seed) in [(22, 16, 3, 4), (60, 44, 2, 7)]:
         g, d, taux, tauy, OBC = rk2_obc_case(segs, ni=ni, nj=nj, nk=nk, seed=seed)
@@ -170,9 +174,14 @@ def test_gpu_step_with_open_boundaries_matches_oracle_bitwise(segs, viscous):
                 an = a.cpu().numpy()
                 assert bits_equal(an, want[name]), (segs, viscous, ni, n, name, np.argwhere(an != want[name])[:4].tolist())
             assert bits_equal(OBC.rx_normal.cpu().numpy(), OBCo.rx_normal) and bits_equal(OBC.ry_normal.cpu().numpy(), OBCo.ry_normal), (n, "rx_normal")
+            if OBCo.rx_oblique_u is not None:
+                assert bits_equal(OBC.rx_oblique_u.cpu().numpy(), OBCo.rx_oblique_u) and bits_equal(OBC.cff_normal_v.cpu().numpy(), OBCo.cff_normal_v)
+                assert np.abs(OBCo.cff_normal_v).max() > 0
             for s, so in zip(OBC.segment, OBCo.segment):
                 if s.on_pe and s.normal_vel is not None:
                     assert bits_equal(s.normal_vel.cpu().numpy(), so.normal_vel), (n, "segment%normal_vel")
+                if s.on_pe and s.radiation_tan:
+                    assert bits_equal(s.tangential_vel.cpu().numpy(), so.tangential_vel) and np.abs(so.tangential_vel).max() > 0
         gpu_run(g, d, taux, tauy, OBC, viscous, bbl, 3, check)
 
 

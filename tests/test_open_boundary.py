@@ -118,7 +118,7 @@ def test_oracle_turns_with_the_grid():
 
 def test_refused_forms():
     g, d, _ = rad_case()
-    for bad in (["I=N,J=0:N,OBLIQUE"], ["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"]):
+    for bad in (["I=N,J=0:N,OBLIQUE,OBLIQUE_GRAD"], ["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"]):
         OBC = ocean_OBC_type(g, bad)
         with pytest.raises(RuntimeError, match="rc=2"):
             run(g, d, OBC)
@@ -172,7 +172,7 @@ def test_gpu_radiation_refuses_what_it_does_not_provide():
     g, d, _ = rad_case()
     dg = DeviceGrid(g)
     o = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
-    for bad, msg in ((["I=N,J=0:N,OBLIQUE"], "oblique"), (["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"], "oblique")):
+    for bad, msg in ((["I=N,J=0:N,OBLIQUE,OBLIQUE_GRAD"], "oblique"), (["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"], "oblique")):
         OBC = ocean_OBC_type(g, bad)
         OBC.rx_normal, OBC.ry_normal = o["rx"], o["ry"]
         for s in OBC.segment:
@@ -339,4 +339,136 @@ def test_gpu_tangential_forms_match_oracle_bitwise(gamma_uv, space):
             assert bits_equal(N(s.tangential_vel), sr.tangential_vel), (n, "tangential_vel", np.argwhere(N(s.tangential_vel) != sr.tangential_vel)[:4].tolist())
             assert bits_equal(N(s.tangential_grad), sr.tangential_grad), (n, "tangential_grad")
             assert bits_equal(N(s.normal_vel), sr.normal_vel), (n, "normal_vel")
+        dg.close()
+
+
+# ---- oblique radiation (OBLIQUE: :2349-2383 E, :2593-2628 W, :2838-2872 N, :3082-3117 S; gradient_at_q_points :3407) ----
+OBL_SEGS = ["J=N,I=N:0,OBLIQUE", "J=0,I=0:N,OBLIQUE,NUDGED", "I=N,J=0:N,OBLIQUE", "I=0,J=N:0,OBLIQUE", "I=9,J=4:11,OBLIQUE", "J=7,I=15:3,OBLIQUE,NUDGED"]
+OBL_FIELDS = ("rx_oblique_u", "ry_oblique_u", "cff_normal_u", "rx_oblique_v", "ry_oblique_v", "cff_normal_v")
+
+
+def obl_case(seed=8, **kw):
+    g, d, OBC = rad_case(OBL_SEGS, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 3)
+    for n in OBL_FIELDS:
+        shp = g.shape3(_abi.POS_U if n.endswith("_u") else _abi.POS_V)
+        setattr(OBC, n, np.ascontiguousarray((1e-4 * rng.random(shp)) if n.startswith("cff") else 1e-4 * rng.standard_normal(shp)))
+    return g, d, OBC
+
+
+def expected_oblique(g, d, s, OBC0, gamma_uv, rx_max, dt):
+    """the block of one direction written out with the reference's own indices; returns normal_vel and the three stored fields on the faces"""
+    H = s.HI; nk = g.nk; eps = 1.0e-20
+    mB = np.asarray(g.mask2dBu)
+    U = lambda a, I, j, k: a[k, j - g.jsd, I - (g.isd - 1)]
+    V = lambda a, i, J, k: a[k, J - (g.jsd - 1), i - g.isd]
+    MB = lambda I, J: mB[J - (g.jsd - 1), I - (g.isd - 1)]
+    un, uo, vn, vo = d["u_new"], d["u_old"], d["v_new"], d["v_old"]
+    nv = s.normal_vel.copy()
+    st = {n: getattr(OBC0, n).copy() for n in OBL_FIELDS}
+    fmax = lambda a, b: a if a > b else b
+    fmin = lambda a, b: a if a < b else b
+    if s.is_E_or_W:
+        I = H["IsdB"]; d1 = -1 if s.direction == _abi.OBC_DIRECTION_E else 1
+        lo, hi = max(H["JsdB"], g.jsd), min(H["JedB"], g.jed - 1)
+        GN = lambda J, m, k: 0.0 if not (lo <= J <= hi) else (U(un, I + (d1 if m == 1 else 0), J + 1, k) - U(un, I + (d1 if m == 1 else 0), J, k)) * MB(I + (d1 if m == 1 else 0), J)
+        for k in range(nk):
+            for j in range(H["jsd"], H["jed"] + 1):
+                J = j
+                dhdt = U(uo, I + d1, j, k) - U(un, I + d1, j, k); dhdx = U(un, I + d1, j, k) - U(un, I + 2 * d1, j, k)
+                ssum = GN(J, 1, k) + GN(J - 1, 1, k)
+                dhdy = GN(J - 1, 1, k) if dhdt * ssum > 0.0 else (0.0 if dhdt * ssum == 0.0 else GN(J, 1, k))
+                if dhdt * dhdx < 0.0:
+                    dhdt = 0.0
+                cff = fmax(dhdx * dhdx + dhdy * dhdy, eps); rx = fmin(dhdt * dhdx, cff * rx_max); ry = fmin(cff, fmax(dhdt * dhdy, -cff))
+                idx = (k, j - g.jsd, I - (g.isd - 1))
+                if gamma_uv < 1.0:
+                    rx = (1.0 - gamma_uv) * OBC0.rx_oblique_u[idx] + gamma_uv * rx; ry = (1.0 - gamma_uv) * OBC0.ry_oblique_u[idx] + gamma_uv * ry
+                    cff = (1.0 - gamma_uv) * OBC0.cff_normal_u[idx] + gamma_uv * cff
+                    st["rx_oblique_u"][idx], st["ry_oblique_u"][idx], st["cff_normal_u"][idx] = rx, ry, cff
+                val = ((cff * U(un, I, j, k) + rx * U(un, I + d1, j, k)) - (fmax(ry, 0.0) * GN(J - 1, 2, k) + fmin(ry, 0.0) * GN(J, 2, k))) / (cff + rx)
+                if s.nudged:
+                    tau = s.Velocity_nudging_timescale_in if dhdt * dhdx <= 0.0 else s.Velocity_nudging_timescale_out
+                    g2 = dt / (tau + dt)
+                    val = (1.0 - g2) * val + g2 * s.nudged_normal_vel[k, j - H["jsd"], 0]
+                nv[k, j - H["jsd"], 0] = val
+    else:
+        J = H["JsdB"]; d1 = -1 if s.direction == _abi.OBC_DIRECTION_N else 1
+        lo, hi = max(H["IsdB"], g.isd), min(H["IedB"], g.ied - 1)
+        GN = lambda I, m, k: 0.0 if not (lo <= I <= hi) else (V(vn, I + 1, J + (d1 if m == 1 else 0), k) - V(vn, I, J + (d1 if m == 1 else 0), k)) * MB(I, J + (d1 if m == 1 else 0))
+        for k in range(nk):
+            for i in range(H["isd"], H["ied"] + 1):
+                I = i
+                dhdt = V(vo, i, J + d1, k) - V(vn, i, J + d1, k); dhdy = V(vn, i, J + d1, k) - V(vn, i, J + 2 * d1, k)
+                ssum = GN(I, 1, k) + GN(I - 1, 1, k)
+                dhdx = GN(I - 1, 1, k) if dhdt * ssum > 0.0 else (0.0 if dhdt * ssum == 0.0 else GN(I, 1, k))
+                if dhdt * dhdy < 0.0:
+                    dhdt = 0.0
+                cff = fmax(dhdx * dhdx + dhdy * dhdy, eps); ry = fmin(dhdt * dhdy, cff * rx_max); rx = fmin(cff, fmax(dhdt * dhdx, -cff))
+                idx = (k, J - (g.jsd - 1), i - g.isd)
+                if gamma_uv < 1.0:
+                    rx = (1.0 - gamma_uv) * OBC0.rx_oblique_v[idx] + gamma_uv * rx; ry = (1.0 - gamma_uv) * OBC0.ry_oblique_v[idx] + gamma_uv * ry
+                    cff = (1.0 - gamma_uv) * OBC0.cff_normal_v[idx] + gamma_uv * cff
+                    st["rx_oblique_v"][idx], st["ry_oblique_v"][idx], st["cff_normal_v"][idx] = rx, ry, cff
+                val = ((cff * V(vn, i, J, k) + ry * V(vn, i, J + d1, k)) - (fmax(rx, 0.0) * GN(I - 1, 2, k) + fmin(rx, 0.0) * GN(I, 2, k))) / (cff + ry)
+                if s.nudged:
+                    tau = s.Velocity_nudging_timescale_in if dhdt * dhdy <= 0.0 else s.Velocity_nudging_timescale_out
+                    g2 = dt / (tau + dt)
+                    val = (1.0 - g2) * val + g2 * s.nudged_normal_vel[k, 0, i - H["isd"]]
+                nv[k, 0, i - H["isd"]] = val
+    return nv, st
+
+
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+def test_oracle_oblique_radiation_is_the_four_blocks_of_the_reference(gamma_uv):
+    import copy
+    g, d, OBC = obl_case()
+    OBC0 = copy.deepcopy(OBC)
+    o = run(g, d, OBC, gamma_uv=gamma_uv)
+    for n, (s, s0) in enumerate(zip(OBC.segment, OBC0.segment)):
+        nv, st = expected_oblique(g, d, s0, OBC0, gamma_uv, 1.0, 900.0)
+        assert bits_equal(s.normal_vel, nv), (n, s.direction, np.argwhere(s.normal_vel != nv)[:4].tolist())
+        H = s.HI
+        for name in OBL_FIELDS:      # (on this segment's own faces; other segments own other faces)
+            a, b = getattr(OBC, name), st[name]
+            if s.is_E_or_W and name.endswith("_u"):
+                sl = (slice(None), slice(H["jsd"] - g.jsd, H["jed"] - g.jsd + 1), H["IsdB"] - (g.isd - 1))
+            elif s.is_N_or_S and name.endswith("_v"):
+                sl = (slice(None), H["JsdB"] - (g.jsd - 1), slice(H["isd"] - g.isd, H["ied"] - g.isd + 1))
+            else:
+                continue
+            assert bits_equal(a[sl], b[sl]), (n, name)
+        # the faces of the segment carry its normal_vel afterwards (open_boundary_apply_normal_flow)
+    assert not bits_equal(OBC.rx_oblique_u, OBC0.rx_oblique_u) or gamma_uv >= 1.0
+    assert (gamma_uv < 1.0) or all(bits_equal(getattr(OBC, n), getattr(OBC0, n)) for n in OBL_FIELDS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_oblique_radiation_matches_oracle_bitwise(gamma_uv, space):
+    import copy
+    import torch
+    from mom6_amd.open_boundary import radiation_open_bdry_conds
+    from mom6_amd.tracer_advect import DeviceGrid
+    for kw in (dict(), dict(ni=150, nj=40, nk=2, seed=5)):
+        g, d, OBC = obl_case(**kw)
+        OBC.gamma_uv, OBC.rx_max = gamma_uv, 1.0
+        ref = copy.deepcopy(OBC)
+        o = run(g, d, ref, gamma_uv=gamma_uv)
+        dev = space == "device"
+        X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if dev else (lambda a: a.copy())
+        N = (lambda a: a.cpu().numpy()) if dev else (lambda a: a)
+        f = {k: X(v) for k, v in d.items()}
+        OBC.rx_normal, OBC.ry_normal = f["rx"], f["ry"]
+        if dev:
+            OBC.cuda()
+        dg = DeviceGrid(g)
+        radiation_open_bdry_conds(OBC, f["u_new"], f["u_old"], f["v_new"], f["v_old"], dg, 900.0)
+        dg.sync()
+        assert bits_equal(N(f["u_new"]), o["u_new"]) and bits_equal(N(f["v_new"]), o["v_new"])
+        for name in OBL_FIELDS:
+            assert bits_equal(N(getattr(OBC, name)), getattr(ref, name)), name
+        for n, (s, sr) in enumerate(zip(OBC.segment, ref.segment)):
+            assert bits_equal(N(s.normal_vel), sr.normal_vel), (n, "normal_vel", np.argwhere(N(s.normal_vel) != sr.normal_vel)[:4].tolist())
         dg.close()
