@@ -1197,7 +1197,7 @@ int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t
                                  const double *hv_cont, int32_t memspace);
 /* horizontal_viscosity with OBC associated (and OBC%OBC_pe): OBC_ZERO_STRAIN / OBC_FREESLIP_STRAIN at the corner points of the segments
  * (:733-790, :1388-1409), the thicknesses at and beside their faces (:791-849), OBC_ZERO_BIHARMONIC (:889-903), no viscous acceleration
- * of the segments' own faces (:1751-1782).  OBC_COMPUTED_STRAIN is refused.  obc == NULL: mom6hip_horizontal_viscosity. */
+ * of the segments' own faces (:1751-1782).  OBC_COMPUTED_STRAIN reads segment%tangential_vel (in the memory space of the call).  obc == NULL: mom6hip_horizontal_viscosity. */
 int mom6hip_horizontal_viscosity_obc(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v,
                                      const double *h, double *diffu, double *diffv, double dt, const double *hu_cont,
                                      const double *hv_cont, const struct mom6hip_obc *obc, int32_t memspace);

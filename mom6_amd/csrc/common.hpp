@@ -215,7 +215,10 @@ void staging_destroy(mom6hip_ctx *ctx);      // staging.hip
 
 // horizontal_viscosity on device arrays (hor_visc.hip); called by the split RK2 step at :860 and :1543
 // ob: the maps of the open boundaries (hor_visc.hip, HVFArgs), null without
-struct HVObcDev { const int32_t *q = nullptr, *fu = nullptr, *fv = nullptr, *hu = nullptr, *hv = nullptr; };
+struct HVObcDev {
+  const int32_t *q = nullptr, *fu = nullptr, *fv = nullptr, *hu = nullptr, *hv = nullptr;
+  const double *tang_u = nullptr, *tang_v = nullptr;      // OBC_COMPUTED_STRAIN: segment%tangential_vel at the q points (3-D), of N / S and of E / W segments
+};
 int horizontal_viscosity_dev(mom6hip_ctx *ctx, const mom6hip_hor_visc_cs_t *cs, const double *u, const double *v, const double *h,
                              double *diffu, double *diffv, const double *hu_cont, const double *hv_cont, const HVObcDev *ob = nullptr);
 

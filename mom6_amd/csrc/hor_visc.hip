@@ -316,11 +316,14 @@ struct HVFArgs {
   const double *Ku, *Au;
   double *str_xx_out, *str_xy_out;
   // open boundaries (generic configuration only; null without): what the reference's loops over the segments leave, as maps
-  //   obc_q [q points]   bit 0: dvdx = 0, bit 1: dudy = 0 (:733-790), bit 2: dDel2vdx = 0, bit 3: dDel2udy = 0 (:1388-1409)
+  //   obc_q [q points]   bit 0: dvdx = 0, bit 1: dudy = 0 (:733-790), bit 2: dDel2vdx = 0, bit 3: dDel2udy = 0 (:1388-1409);
+  //                      OBC_COMPUTED_STRAIN (:741-748, :766-773): bit 4 / 5: dudy from obc_tang_u at a northern / southern segment,
+  //                      bit 6 / 7: dvdx from obc_tang_v at an eastern / western one
   //   obc_fu, obc_fv     bit 0: Del2u | Del2v = 0 (:889-903), bit 1: diffu | diffv = 0 (:1751-1782), bits 2-3: the thickness of the face is that
   //                      of its first (1) or second (2) cell (:791-819)
   //   obc_hu, obc_hv     the face whose thickness this face takes after the projections across the segments' corner points (:821-849), -1: its own
   const int32_t *obc_q, *obc_fu, *obc_fv, *obc_hu, *obc_hv;
+  const double *obc_tang_u, *obc_tang_v;      // segment%tangential_vel at the q points, all layers
 };
 
 
@@ -421,6 +424,13 @@ __global__ __launch_bounds__(HV_NT, WPE) void hv_fused_kernel(HVFArgs A, int ntx
         const int qc = A.obc_q[bq >> 3];
         if (qc & 1) dvdx = 0.;
         if (qc & 2) dudy = 0.;
+        if (qc & 0xf0) {      // OBC_COMPUTED_STRAIN
+          const size_t q3 = (size_t)(bq >> 3) + (size_t)(A.nih + 1) * (A.njh + 1) * k;
+          if (qc & 16) dudy = 2.0 * G(P_DXDYBU, 0, 0) * (A.obc_tang_u[q3] - AU(u_k, 0, 0)) * G(P_IDXCU, 0, 0);
+          if (qc & 32) dudy = 2.0 * G(P_DXDYBU, 0, 0) * (AU(u_k, 0, 1) - A.obc_tang_u[q3]) * G(P_IDXCU, 0, 1);
+          if (qc & 64) dvdx = 2.0 * G(P_DYDXBU, 0, 0) * (A.obc_tang_v[q3] - AV(v_k, 0, 0)) * G(P_IDYCV, 0, 0);
+          if (qc & 128) dvdx = 2.0 * G(P_DYDXBU, 0, 0) * (AV(v_k, 1, 0) - A.obc_tang_v[q3]) * G(P_IDYCV, 1, 0);
+        }
       }
       if (o.no_slip) LX(s_xy, 0, 0) = (2.0 - G(P_MASKBU, 0, 0)) * (dvdx + dudy);
       else LX(s_xy, 0, 0) = G(P_MASKBU, 0, 0) * (dvdx + dudy);
@@ -773,7 +783,8 @@ int horizontal_viscosity_dev(mom6hip_ctx_t *ctx, const mom6hip_hor_visc_cs_t *cs
   A.Ku = cs->Laplacian ? cs->MEKE_Ku : nullptr; A.Au = cs->biharmonic ? cs->MEKE_Au : nullptr;
   A.str_xx_out = nullptr; A.str_xy_out = nullptr;
   A.obc_q = A.obc_fu = A.obc_fv = A.obc_hu = A.obc_hv = nullptr;
-  if (ob) { A.obc_q = ob->q; A.obc_fu = ob->fu; A.obc_fv = ob->fv; A.obc_hu = ob->hu; A.obc_hv = ob->hv; }
+  A.obc_tang_u = A.obc_tang_v = nullptr;
+  if (ob) { A.obc_q = ob->q; A.obc_fu = ob->fu; A.obc_fv = ob->fv; A.obc_hu = ob->hu; A.obc_hv = ob->hv; A.obc_tang_u = ob->tang_u; A.obc_tang_v = ob->tang_v; }
   const bool meke = A.Ku || A.Au || cs->MEKE_mom_src;
   if (cs->MEKE_mom_src) {
     const size_t nH3 = (size_t)g.nih * g.njh * g.nk, nQ3 = (size_t)(g.nih + 1) * (g.njh + 1) * g.nk;
@@ -811,13 +822,22 @@ extern "C" int mom6hip_horizontal_viscosity(mom6hip_ctx_t *ctx, const mom6hip_ho
 namespace {
 // What the reference's loops over the segments leave (MOM_hor_visc.F90:733-849, :889-903, :1388-1409, :1751-1782), as maps over the q points
 // and the faces: the loops are run here on the indices alone, in the reference's order and with its ranges.
+// OBC_COMPUTED_STRAIN: a segment's tangential_vel (IsdB:IedB, JsdB:JedB, nk) at its corner points a0..a1 of the line `fixed`, into the q-shaped 3-D array
+__global__ __launch_bounds__(64) void hv_tang_scatter_kernel(m6::GridDev g, double *dst, const double *src, int along_i, int a0, int a1, int fixed,
+                                                             int IsdB, int JsdB, int nI, int nJ) {
+  const int a = a0 + blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
+  if (a > a1) return;
+  const int I = along_i ? a : fixed, J = along_i ? fixed : a;
+  dst[g.q2(I, J) + (long)(g.nih + 1) * (g.njh + 1) * k] = src[(I - IsdB) + (long)nI * ((J - JsdB) + (long)nJ * k)];
+}
+
 int hv_obc_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, m6::HVObcDev &ob) {
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(obc->number_of_segments == 0 || obc->segment, "horizontal_viscosity: OBC%%segment is required");
-  M6_REQUIRE(!obc->computed_strain, "horizontal_viscosity: OBC_COMPUTED_STRAIN is not provided by libmom6hip");
   const int is = g.isc, ie = g.iec, js = g.jsc, je = g.jec, Isq = is - 1, Ieq = ie, Jsq = js - 1, Jeq = je;
   const int is_vort = is - 2, ie_vort = Ieq + 1, js_vort = js - 2, je_vort = Jeq + 1;
   const size_t nU = (size_t)(g.nih + 1) * g.njh, nV = (size_t)g.nih * (g.njh + 1), nQ = (size_t)(g.nih + 1) * (g.njh + 1);
+  double *tang_u = nullptr, *tang_v = nullptr;
   std::vector<int32_t> m(nQ + 2 * nU + 2 * nV, 0);
   int32_t *q = m.data(), *fu = q + nQ, *fv = fu + nU, *hu = fv + nV, *hv = hu + nU;
   for (size_t n = 0; n < nU; n++) hu[n] = -1;
@@ -836,6 +856,26 @@ int hv_obc_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, m6
         for (int Iq = imax(S.IsdB, is_vort); Iq <= imin(S.IedB, ie_vort); Iq++) q[g.q2(Iq, J)] |= obc->zero_strain ? 3 : 2;
       } else if (S.is_E_or_W && I >= is_vort && I <= ie_vort) {
         for (int Jq = imax(S.JsdB, js_vort); Jq <= imin(S.JedB, je_vort); Jq++) q[g.q2(I, Jq)] |= obc->zero_strain ? 3 : 1;
+      }
+    } else if (obc->computed_strain) {      // :741-748, :766-773: from the segment's tangential_vel (a later segment has the last word)
+      M6_REQUIRE(S.tangential_vel, "horizontal_viscosity: OBC_COMPUTED_STRAIN needs the tangential_vel of segment %d", n + 1);
+      if (!tang_u) {      // the tangential velocities at the q points, for the segments' scatter kernels
+        tang_u = (double *)st.scratch(2 * nQ * g.nk * 8); tang_v = tang_u ? tang_u + nQ * g.nk : nullptr;
+        M6_REQUIRE(!st.failed() && tang_u, "horizontal_viscosity: staging of the open boundaries failed");
+      }
+      const size_t cnt = (size_t)(S.IedB - S.IsdB + 1) * (S.JedB - S.JsdB + 1) * g.nk * 8;
+      const double *tv = st.in(S.tangential_vel, cnt);
+      M6_REQUIRE(!st.failed() && tv, "horizontal_viscosity: staging of the open boundaries failed");
+      if (S.is_N_or_S && J >= js_vort && J <= je_vort) {
+        const int a0 = imax(S.IsdB, is_vort), a1 = imin(S.IedB, ie_vort);
+        for (int Iq = a0; Iq <= a1; Iq++) { int32_t &c = q[g.q2(Iq, J)]; c = (c & ~48) | (S.direction == MOM6HIP_OBC_DIRECTION_N ? 16 : 32); }
+        if (a1 >= a0) hipLaunchKernelGGL(hv_tang_scatter_kernel, dim3((a1 - a0 + 64) / 64, g.nk), dim3(64), 0, ctx->stream, g, tang_u, tv, 1, a0, a1, J,
+                                         S.IsdB, S.JsdB, S.IedB - S.IsdB + 1, S.JedB - S.JsdB + 1);
+      } else if (S.is_E_or_W && I >= is_vort && I <= ie_vort) {
+        const int a0 = imax(S.JsdB, js_vort), a1 = imin(S.JedB, je_vort);
+        for (int Jq = a0; Jq <= a1; Jq++) { int32_t &c = q[g.q2(I, Jq)]; c = (c & ~192) | (S.direction == MOM6HIP_OBC_DIRECTION_E ? 64 : 128); }
+        if (a1 >= a0) hipLaunchKernelGGL(hv_tang_scatter_kernel, dim3((a1 - a0 + 64) / 64, g.nk), dim3(64), 0, ctx->stream, g, tang_v, tv, 0, a0, a1, I,
+                                         S.IsdB, S.JsdB, S.IedB - S.IsdB + 1, S.JedB - S.JsdB + 1);
       }
     }
     // :791-819: the thickness of the cell inside at the segment's faces (a later segment has the last word)
@@ -889,6 +929,8 @@ int hv_obc_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, m6
   M6_HIP(hipMemcpyAsync(dm, m.data(), 4 * m.size(), hipMemcpyHostToDevice, ctx->stream));
   M6_HIP(hipStreamSynchronize(ctx->stream));      // (the host vector goes out of scope)
   ob.q = dm; ob.fu = dm + nQ; ob.fv = ob.fu + nU; ob.hu = ob.fv + nV; ob.hv = ob.hu + nU;
+  ob.tang_u = tang_u; ob.tang_v = tang_v;
+  M6_HIP(hipGetLastError());
   return 0;
 }
 }  // namespace

@@ -127,7 +127,8 @@ def horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G: DeviceGrid, CS:
     if len(spaces) != 1:
         raise Mom6HipError("horizontal_viscosity: the fields and the arrays of the control structure must be in the same memory space")
     if OBC is not None:      # the branches of an associated OBC on the PE (:449-452)
-        obc = OBC.struct(lambda a: (0, None))      # (none of the segments' own arrays is read: OBC_COMPUTED_STRAIN is refused)
+        from .open_boundary import _seg_to_ptr
+        obc = OBC.struct(_seg_to_ptr(CS.space))      # (segment%tangential_vel is read with OBC_COMPUTED_STRAIN, in the memory space of the fields)
         check(_setup().mom6hip_horizontal_viscosity_obc(G.handle, C.byref(CS.st), ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
                                                         float(CS.dt if dt is None else dt), ptrs[5], ptrs[6], C.byref(obc), CS.space),
               "horizontal_viscosity")
