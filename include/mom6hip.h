@@ -473,8 +473,8 @@ int mom6hip_coradcalc(mom6hip_ctx_t *ctx, const mom6hip_coriolisadv_cs_t *cs, co
  * open_boundary_apply_normal_flow (:3337) and pass_vector(u_new, v_new).  segment%normal_vel is written.  The tangential forms
  * (segment%radiation_tan, %radiation_grad, %nudged_tan, %nudged_grad: :2403-2455 and its three twins) write segment%tangential_vel /
  * tangential_grad at the corner points of the segment.  Oblique radiation (segment%oblique: :2349-2383 and its three twins, with the
- * gradients along the boundary of gradient_at_q_points :3407 and the restart fields obc->rx_oblique_u ... cff_normal_v).  Not provided
- * (refused): the tangential forms of the oblique radiation (OBLIQUE_TAN, OBLIQUE_GRAD).
+ * gradients along the boundary of gradient_at_q_points :3407 and the restart fields obc->rx_oblique_u ... cff_normal_v), with its
+ * tangential forms OBLIQUE_TAN, OBLIQUE_GRAD (:2456-2556 and twins).
  * rx_normal (u points, 3-D) and ry_normal (v points, 3-D) may be NULL when gamma_uv >= 1. */
 int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const struct mom6hip_obc *obc, double gamma_uv, double rx_max, double *rx_normal,
                                       double *ry_normal, double *u_new, const double *u_old, double *v_new, const double *v_old, double dt,
@@ -585,7 +585,7 @@ typedef struct mom6hip_obc_segment {
   int32_t isd, ied, jsd, jed;          /* segment%HI: its cell range */
   int32_t radiation, gradient, nudged; /* segment%radiation (Orlanski), %gradient, %nudged: read by radiation_open_bdry_conds */
   int32_t oblique;                     /* segment%oblique: not provided (refused by mom6hip_radiation_open_bdry_conds) */
-  int32_t radiation_tan_or_grad;       /* the tangential forms, a bit each: MOM6HIP_OBC_TAN_* below (the oblique ones are not provided) */
+  int32_t radiation_tan_or_grad;       /* the tangential forms, a bit each: MOM6HIP_OBC_TAN_* / _GRAD_* above */
   int32_t Flather;                     /* segment%Flather: read by btstep */
   /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where
    * `specified`; in the memory space of the call; may be NULL otherwise */

@@ -93,6 +93,7 @@ struct TanArgs {
   long nq;                     // their number: the segment's arrays (IsdB:IedB, JsdB:JedB, nk) are one point wide
   double *tangential_vel, *tangential_grad;
   const double *nudged_vel, *nudged_grad;
+  const double *rn_st, *rt_st, *cf_st;      // OBLIQUE_TAN / _GRAD: what the segment's faces keep (the rate along the normal, along the boundary, cff)
 };
 __global__ __launch_bounds__(64) void rad_tangential_kernel(m6::GridDev g, RadSeg S, TanArgs a, double gamma_u, double rx_max, double dt,
                                                             const double *tn, const double *to, const double *r_normal) {
@@ -105,6 +106,58 @@ __global__ __launch_bounds__(64) void rad_tangential_kernel(m6::GridDev g, RadSe
   auto T3 = [&](int t) -> long { return (S.ew ? g.v2(t, q) : g.u2(q, t)) + tpl * k; };
   const long npl = S.ew ? (long)(g.nih + 1) * g.njh : (long)g.nih * (g.njh + 1);
   auto F3 = [&](int c) -> long { return (S.ew ? g.u2(S.A, c) : g.v2(c, S.A)) + npl * k; };
+  const long s3 = (long)(q - a.q0) + a.nq * (long)k;
+  const int lo1 = plus ? t0 - 1 : t0, lo2 = plus ? t0 - 2 : t0 + 1;      // the low rows of the two differences across the boundary
+  const double *Idm = S.ew ? g.IdxBu : g.IdyBu;
+  auto QM = [&](int t, int qq) -> long { return S.ew ? g.q2(t, qq) : g.q2(qq, t); };
+  const int g0 = (S.ew ? g.jsd : g.isd) + 1, g1 = (S.ew ? g.jed : g.ied) - 1;
+  if (a.bits & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)) {      // :2456-2556 (E) and its three twins
+    const long tstep = S.ew ? g.nih : 1;      // one corner point along the boundary, in the tangential component's array
+    auto TQ = [&](int t, int qq) -> double { return tn[(S.ew ? g.v2(t, qq) : g.u2(qq, t)) + tpl * k]; };
+    const int cd0 = S.ew ? g.jsd : g.isd, cd1 = S.ew ? g.jed : g.ied;
+    const int gt0 = (S.c0 - 1 > cd0) ? S.c0 - 1 : cd0, gt1 = (S.c1 + 1 < cd1) ? S.c1 + 1 : cd1;
+    const int gg0 = (S.c0 > cd0 + 1) ? S.c0 : cd0 + 1, gg1 = (S.c1 < cd1 - 1) ? S.c1 : cd1 - 1;
+    // segment%grad_tan(c, 1 | 2) (the rows t0 + st | t0) and segment%grad_gradient(c, 2) of gradient_at_q_points, zero where it does not compute them
+    auto GT = [&](int c, int t) -> double {
+      if (c < gt0 || c > gt1) return 0.0;
+      return (TQ(t, c) - TQ(t, c - 1)) * g.mask2dT[S.ew ? g.h2(t, c) : g.h2(c, t)];
+    };
+    auto GG2 = [&](int c) -> double {
+      if (c < gg0 || c > gg1) return 0.0;
+      const double *maskC = S.ew ? g.mask2dCu : g.mask2dCv;
+      return (((TQ(lo1 + 1, c) - TQ(lo1, c)) * Idm[QM(lo1, c)]) - (TQ(lo1 + 1, c - 1) - TQ(lo1, c - 1)) * Idm[QM(lo1, c - 1)]) *
+             maskC[S.ew ? g.u2(lo1, c) : g.v2(c, lo1)];
+    };
+    (void)tstep;
+    double rn, rt, cff;
+    if (gamma_u < 1.0) {
+      if (q == a.q0)      { rn = a.rn_st[F3(S.c0)]; rt = a.rt_st[F3(S.c0)]; cff = a.cf_st[F3(S.c0)]; }
+      else if (q == a.q1) { rn = a.rn_st[F3(S.c1)]; rt = a.rt_st[F3(S.c1)]; cff = a.cf_st[F3(S.c1)]; }
+      else { rn = 0.5 * (a.rn_st[F3(q)] + a.rn_st[F3(q + 1)]); rt = 0.5 * (a.rt_st[F3(q)] + a.rt_st[F3(q + 1)]); cff = 0.5 * (a.cf_st[F3(q)] + a.cf_st[F3(q + 1)]); }
+    } else {
+      double dhdt = to[T3(t0)] - tn[T3(t0)];
+      const double dhdn = tn[T3(t0)] - tn[T3(t0 + st)];
+      const double ga = GT(q, t0 + st), gb = GT(q + 1, t0 + st);
+      double dhdl;
+      if (dhdt * (ga + gb) > 0.0) dhdl = ga;
+      else if (dhdt * (ga + gb) == 0.0) dhdl = 0.0;
+      else dhdl = gb;
+      if (dhdt * dhdn < 0.0) dhdt = 0.0;
+      cff = m6::max2(dhdn * dhdn + dhdl * dhdl, 1.0e-20);
+      rn = min2(dhdt * dhdn, cff * rx_max);
+      rt = min2(cff, m6::max2(dhdt * dhdl, -cff));
+    }
+    const double tau = (rn <= 0.0) ? S.tau_in : S.tau_out;
+    const double gamma_2 = dt / (tau + dt);
+    if (a.bits & MOM6HIP_OBC_TAN_OBLIQUE)
+      a.tangential_vel[s3] = ((cff * tn[T3(t0)] + rn * tn[T3(t0 + st)]) - (m6::max2(rt, 0.0) * GT(q, t0) + min2(rt, 0.0) * GT(q + 1, t0))) / (cff + rn);
+    if (a.bits & MOM6HIP_OBC_TAN_NUDGED) a.tangential_vel[s3] = (1.0 - gamma_2) * a.tangential_vel[s3] + gamma_2 * a.nudged_vel[s3];
+    if ((a.bits & MOM6HIP_OBC_GRAD_OBLIQUE) && q >= a.q0 + 1 && q <= a.q1 - 1)
+      a.tangential_grad[s3] = ((cff * (tn[T3(lo1 + 1)] - tn[T3(lo1)]) * Idm[QM(lo1, q)] + rn * (tn[T3(lo2 + 1)] - tn[T3(lo2)]) * Idm[QM(lo2, q)]) -
+                               (m6::max2(rt, 0.0) * GG2(q) + min2(rt, 0.0) * GG2(q + 1))) / (cff + rn);
+    if (a.bits & MOM6HIP_OBC_GRAD_NUDGED) a.tangential_grad[s3] = (1.0 - gamma_2) * a.tangential_grad[s3] + gamma_2 * a.nudged_grad[s3];
+    return;
+  }
   double r_tang;
   if (gamma_u < 1.0) {      // segment%rx_norm_rad at the two faces about the corner (the ends: the one face there is)
     if (q == a.q0) r_tang = r_normal[F3(S.c0)];
@@ -119,17 +172,10 @@ __global__ __launch_bounds__(64) void rad_tangential_kernel(m6::GridDev g, RadSe
   }
   const double tau = (r_tang <= 0.0) ? S.tau_in : S.tau_out;
   const double gamma_2 = dt / (tau + dt);
-  const long s3 = (long)(q - a.q0) + a.nq * (long)k;
   if (a.bits & MOM6HIP_OBC_TAN_RADIATION) a.tangential_vel[s3] = (tn[T3(t0)] + r_tang * tn[T3(t0 + st)]) / (1.0 + r_tang);
   if (a.bits & MOM6HIP_OBC_TAN_NUDGED) a.tangential_vel[s3] = (1.0 - gamma_2) * a.tangential_vel[s3] + gamma_2 * a.nudged_vel[s3];
-  const int g0 = (S.ew ? g.jsd : g.isd) + 1, g1 = (S.ew ? g.jed : g.ied) - 1;
-  if ((a.bits & MOM6HIP_OBC_GRAD_RADIATION) && q >= g0 && q <= g1) {
-    // differences towards larger indices, with the metric of the corner point between the two rows
-    const int lo1 = plus ? t0 - 1 : t0, lo2 = plus ? t0 - 2 : t0 + 1;
-    const double *Idm = S.ew ? g.IdxBu : g.IdyBu;
-    auto QM = [&](int t) -> long { return S.ew ? g.q2(t, q) : g.q2(q, t); };
-    a.tangential_grad[s3] = ((tn[T3(lo1 + 1)] - tn[T3(lo1)]) * Idm[QM(lo1)] + r_tang * (tn[T3(lo2 + 1)] - tn[T3(lo2)]) * Idm[QM(lo2)]) / (1.0 + r_tang);
-  }
+  if ((a.bits & MOM6HIP_OBC_GRAD_RADIATION) && q >= g0 && q <= g1)      // differences towards larger indices, with the metric of the corner point between the rows
+    a.tangential_grad[s3] = ((tn[T3(lo1 + 1)] - tn[T3(lo1)]) * Idm[QM(lo1, q)] + r_tang * (tn[T3(lo2 + 1)] - tn[T3(lo2)]) * Idm[QM(lo2, q)]) / (1.0 + r_tang);
   if (a.bits & MOM6HIP_OBC_GRAD_NUDGED) a.tangential_grad[s3] = (1.0 - gamma_2) * a.tangential_grad[s3] + gamma_2 * a.nudged_grad[s3];
 }
 
@@ -270,8 +316,6 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
     RadSeg d;
     if (!rad_segment(g, S, d)) continue;
     M6_REQUIRE(!(S.oblique && S.radiation), "radiation_open_bdry_conds: segment %d: Orlanski and Oblique OBC options cannot be used together", n + 1);
-    M6_REQUIRE(!(S.radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)), "radiation_open_bdry_conds: the oblique tangential "
-               "forms (OBLIQUE_TAN / _GRAD; segment %d) are not provided by libmom6hip", n + 1);
     if (check_segment_range(g, S, n, "radiation_open_bdry_conds")) return 1;
     if (S.oblique && gamma_uv < 1.0) {      // what the oblique segments keep between steps, staged once for all of them
       if (!d_ob[0]) {
@@ -294,20 +338,30 @@ extern "C" int mom6hip_radiation_open_bdry_conds(mom6hip_ctx_t *ctx, const mom6h
     TanArgs a;
     a.bits = S.radiation_tan_or_grad; a.q0 = d.ew ? S.JsdB : S.IsdB; a.q1 = d.ew ? S.JedB : S.IedB; a.nq = a.q1 - a.q0 + 1;
     a.tangential_vel = a.tangential_grad = nullptr; a.nudged_vel = a.nudged_grad = nullptr;
-    if (!(a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_GRAD_RADIATION))) a.bits = 0;      // (the block of the tangential forms :2403)
+    a.rn_st = a.rt_st = a.cf_st = nullptr;
+    // (the blocks of the tangential forms :2403 and, oblique, :2456)
+    if (!(a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_GRAD_RADIATION | MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE))) a.bits = 0;
+    if (a.bits & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)) {
+      M6_REQUIRE(!(a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_GRAD_RADIATION)), "radiation_open_bdry_conds: segment %d: Orlanski and Oblique OBC "
+                 "options cannot be used together", n + 1);
+      M6_REQUIRE(gamma_uv >= 1.0 || d.rn_st, "radiation_open_bdry_conds: segment %d: OBLIQUE_TAN / OBLIQUE_GRAD with OBC_RAD_VEL_WT < 1 belong to an OBLIQUE "
+                 "segment (its stored rates)", n + 1);
+      a.rn_st = d.rn_st; a.rt_st = d.rt_st; a.cf_st = d.cf_st;
+    }
     if (a.bits) {
       const int plus = d.d1 < 0;
       M6_REQUIRE(a.q0 >= (d.ew ? g.jsd : g.isd) - 1 && a.q1 <= (d.ew ? g.jed : g.ied) && a.q1 >= a.q0,
                  "radiation_open_bdry_conds: the corner points of OBC segment %d lie outside the data domain", n + 1);
       M6_REQUIRE(plus ? (d.A - 2 >= (d.ew ? g.isd : g.jsd)) : (d.A + 3 <= (d.ew ? g.ied : g.jed)),
                  "radiation_open_bdry_conds: OBC segment %d: the tangential forms need three rows of cells inside the segment in the data domain", n + 1);
-      M6_REQUIRE(gamma_uv >= 1.0 || (d.ew ? rx_normal : ry_normal), "radiation_open_bdry_conds: OBC_RAD_VEL_WT < 1 needs OBC%%rx_normal / ry_normal");
+      M6_REQUIRE(gamma_uv >= 1.0 || !(a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_GRAD_RADIATION)) || (d.ew ? rx_normal : ry_normal),
+                 "radiation_open_bdry_conds: OBC_RAD_VEL_WT < 1 needs OBC%%rx_normal / ry_normal");
       const size_t cnt = (size_t)a.nq * g.nk * 8;
-      if (a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_TAN_NUDGED)) {
+      if (a.bits & (MOM6HIP_OBC_TAN_RADIATION | MOM6HIP_OBC_TAN_NUDGED | MOM6HIP_OBC_TAN_OBLIQUE)) {
         M6_REQUIRE(S.tangential_vel, "radiation_open_bdry_conds: segment %d: tangential_vel is required", n + 1);
         a.tangential_vel = st.inout(S.tangential_vel, cnt);
       }
-      if (a.bits & (MOM6HIP_OBC_GRAD_RADIATION | MOM6HIP_OBC_GRAD_NUDGED)) {
+      if (a.bits & (MOM6HIP_OBC_GRAD_RADIATION | MOM6HIP_OBC_GRAD_NUDGED | MOM6HIP_OBC_GRAD_OBLIQUE)) {
         M6_REQUIRE(S.tangential_grad, "radiation_open_bdry_conds: segment %d: tangential_grad is required", n + 1);
         a.tangential_grad = st.inout(S.tangential_grad, cnt);
       }

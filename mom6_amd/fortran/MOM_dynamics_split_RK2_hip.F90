@@ -330,9 +330,9 @@ subroutine obc_mirrors(CS)
     if (allocated(seg%SSH)) CS%c_obc_segs(n)%SSH = mirror(CS, c_loc(seg%SSH), int(size(seg%SSH), c_int64_t), .true., .false.)
     ! (the tangential forms of the radiation write segment%tangential_vel / tangential_grad)
     if (allocated(seg%tangential_vel)) CS%c_obc_segs(n)%tangential_vel = &
-        mirror(CS, c_loc(seg%tangential_vel), int(size(seg%tangential_vel), c_int64_t), .true., seg%radiation_tan .or. seg%nudged_tan)
+        mirror(CS, c_loc(seg%tangential_vel), int(size(seg%tangential_vel), c_int64_t), .true., seg%radiation_tan .or. seg%nudged_tan .or. seg%oblique_tan)
     if (allocated(seg%tangential_grad)) CS%c_obc_segs(n)%tangential_grad = &
-        mirror(CS, c_loc(seg%tangential_grad), int(size(seg%tangential_grad), c_int64_t), .true., seg%radiation_grad .or. seg%nudged_grad)
+        mirror(CS, c_loc(seg%tangential_grad), int(size(seg%tangential_grad), c_int64_t), .true., seg%radiation_grad .or. seg%nudged_grad .or. seg%oblique_grad)
     if (allocated(seg%nudged_tangential_vel)) CS%c_obc_segs(n)%nudged_tangential_vel = &
         mirror(CS, c_loc(seg%nudged_tangential_vel), int(size(seg%nudged_tangential_vel), c_int64_t), .true., .false.)
     if (allocated(seg%nudged_tangential_grad)) CS%c_obc_segs(n)%nudged_tangential_grad = &
@@ -344,7 +344,7 @@ subroutine obc_mirrors(CS)
   CS%c_obc%rx_normal = c_null_ptr ; CS%c_obc%ry_normal = c_null_ptr
   if (allocated(CS%OBC%rx_normal)) CS%c_obc%rx_normal = mirror(CS, c_loc(CS%OBC%rx_normal), CS%nu3, .true., .true.)
   if (allocated(CS%OBC%ry_normal)) CS%c_obc%ry_normal = mirror(CS, c_loc(CS%OBC%ry_normal), CS%nv3, .true., .true.)
-  ! what the oblique segments keep between steps (OBLIQUE_TAN / OBLIQUE_GRAD are refused by the library's radiation_open_bdry_conds)
+  ! what the oblique segments keep between steps
   CS%c_obc%rx_oblique_u = c_null_ptr ; CS%c_obc%ry_oblique_u = c_null_ptr ; CS%c_obc%cff_normal_u = c_null_ptr
   CS%c_obc%rx_oblique_v = c_null_ptr ; CS%c_obc%ry_oblique_v = c_null_ptr ; CS%c_obc%cff_normal_v = c_null_ptr
   if (allocated(CS%OBC%rx_oblique_u)) CS%c_obc%rx_oblique_u = mirror(CS, c_loc(CS%OBC%rx_oblique_u), CS%nu3, .true., .true.)

@@ -301,8 +301,8 @@ class ocean_OBC_type:
                 a = getattr(s, k)
                 need = {"normal_trans": s.specified, "normal_vel": s.specified or s.radiation or s.gradient or s.oblique, "nudged_normal_vel": s.nudged,
                         "normal_vel_bt": s.Flather, "SSH": s.Flather,
-                        "tangential_vel": self.computed_vorticity or self.computed_strain or s.radiation_tan or s.nudged_tan,
-                        "tangential_grad": self.specified_vorticity or s.radiation_grad or s.nudged_grad,
+                        "tangential_vel": self.computed_vorticity or self.computed_strain or s.radiation_tan or s.nudged_tan or s.oblique_tan,
+                        "tangential_grad": self.specified_vorticity or s.radiation_grad or s.nudged_grad or s.oblique_grad,
                         "nudged_tangential_vel": s.nudged_tan, "nudged_tangential_grad": s.nudged_grad}[k]
                 if a is not None and need and s.on_pe:
                     if to_ptr is None:

@@ -30,7 +30,6 @@ int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *
   for (int n = 0; n < OBC->number_of_segments; n++) {
     const mom6hip_obc_segment_t *S = &OBC->segment[n];
     if (!S->on_pe) continue;
-    if (S->radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)) return 2;
     if ((S->radiation || S->gradient || S->oblique) && !S->normal_vel) return 3;
     if (S->oblique && gamma_u < 1.0 && !(S->is_E_or_W ? (OBC->rx_oblique_u && OBC->ry_oblique_u && OBC->cff_normal_u)
                                                        : (OBC->rx_oblique_v && OBC->ry_oblique_v && OBC->cff_normal_v))) return 3;
@@ -147,6 +146,79 @@ int orc_radiation_open_bdry_conds(const mom6hip_grid_t *G, const mom6hip_obc_t *
 #undef T3
 #undef TIDX
 #undef QM
+    }
+    /* the tangential forms of the oblique radiation :2456-2556 (E), :2701-2801 (W), :2946-3046 (N), :3191-3291 (S), with segment%grad_tan and
+     * segment%grad_gradient of gradient_at_q_points (:3426-3443 and its twins) evaluated in place */
+    if (S->radiation_tan_or_grad & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)) {
+      const int bits = S->radiation_tan_or_grad;
+      const int q0 = ew ? S->JsdB : S->IsdB, q1 = ew ? S->JedB : S->IedB;
+      double *tn = ew ? v_new : u_new;
+      const double *to = ew ? v_old : u_old;
+#define T3(t,q,k) (ew ? ORC_V3(G,t,q,k) : ORC_U3(G,q,t,k))
+#define TIDX(q,k) (ew ? (long)(A - S->IsdB) + (long)(S->IedB - S->IsdB + 1)*(((q) - S->JsdB) + (long)(S->JedB - S->JsdB + 1)*((k)-1)) \
+                      : (long)((q) - S->IsdB) + (long)(S->IedB - S->IsdB + 1)*((A - S->JsdB) + (long)(S->JedB - S->JsdB + 1)*((k)-1)))
+      const int t0 = plus ? A : A + 1, st = plus ? -1 : 1;
+      if ((bits & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_TAN_NUDGED)) && !S->tangential_vel) return 3;
+      if ((bits & (MOM6HIP_OBC_GRAD_OBLIQUE | MOM6HIP_OBC_GRAD_NUDGED)) && !S->tangential_grad) return 3;
+      if ((bits & MOM6HIP_OBC_TAN_NUDGED) && !S->nudged_tangential_vel) return 3;
+      if ((bits & MOM6HIP_OBC_GRAD_NUDGED) && !S->nudged_tangential_grad) return 3;
+      const double *Idm = ew ? G->IdxBu : G->IdyBu;
+      const double *maskC = ew ? G->mask2dCu : G->mask2dCv;
+#define QM(t,q) (ew ? ORC_Q2(G,t,q) : ORC_Q2(G,q,t))
+#define CELL2(t,c) (ew ? ORC_H2(G,t,c) : ORC_H2(G,c,t))
+#define FACE2(t,c) (ew ? ORC_U2(G,t,c) : ORC_V2(G,c,t))
+      const int cd0 = ew ? G->jsd : G->isd, cd1 = ew ? G->jed : G->ied;      /* the cells of the data domain along the boundary */
+      const int gt0 = max2i(c0 - 1, cd0), gt1 = min2i(c1 + 1, cd1);          /* where grad_tan is computed (zero beyond) */
+      const int gg0 = max2i(c0, cd0 + 1), gg1 = min2i(c1, cd1 - 1);          /* where grad_gradient is */
+      /* grad_tan(c, 1 | 2): the difference of the tangential component along the boundary in the cell c of the row t0 + st | t0 */
+#define GT(c,t) (((c) < gt0 || (c) > gt1) ? 0.0 : (tn[T3(t,c,k)] - tn[T3(t,(c)-1,k)]) * G->mask2dT[CELL2(t,c)])
+      /* grad_gradient(c, 2): the difference along the boundary of the gradient across it, between the rows lo1 and lo1 + 1 */
+      const int lo1 = plus ? t0 - 1 : t0, lo2 = plus ? t0 - 2 : t0 + 1;
+#define GG2(c) (((c) < gg0 || (c) > gg1) ? 0.0 : (((tn[T3(lo1+1,c,k)] - tn[T3(lo1,c,k)])*Idm[QM(lo1,c)]) - \
+                                                     (tn[T3(lo1+1,(c)-1,k)] - tn[T3(lo1,(c)-1,k)])*Idm[QM(lo1,(c)-1)]) * maskC[FACE2(lo1,c)])
+      double *rn_st = ew ? OBC->rx_oblique_u : OBC->ry_oblique_v, *rt_st = ew ? OBC->ry_oblique_u : OBC->rx_oblique_v;
+      double *cf_st = ew ? OBC->cff_normal_u : OBC->cff_normal_v;
+      if (gamma_u < 1.0 && !(rn_st && rt_st && cf_st)) return 3;
+      for (int k = 1; k <= nz; k++) for (int q = q0; q <= q1; q++) {
+        double rn, rt, cff;
+        if (gamma_u < 1.0) {      /* the stored fields of the two faces about the corner (the ends: of the one face there is) */
+          if (q == q0)      { rn = rn_st[F3(A,c0,k)]; rt = rt_st[F3(A,c0,k)]; cff = cf_st[F3(A,c0,k)]; }
+          else if (q == q1) { rn = rn_st[F3(A,c1,k)]; rt = rt_st[F3(A,c1,k)]; cff = cf_st[F3(A,c1,k)]; }
+          else { rn = 0.5*(rn_st[F3(A,q,k)] + rn_st[F3(A,q+1,k)]); rt = 0.5*(rt_st[F3(A,q,k)] + rt_st[F3(A,q+1,k)]);
+                 cff = 0.5*(cf_st[F3(A,q,k)] + cf_st[F3(A,q+1,k)]); }
+        } else {
+          double dhdt = to[T3(t0,q,k)] - tn[T3(t0,q,k)];
+          const double dhdn = tn[T3(t0,q,k)] - tn[T3(t0+st,q,k)];
+          const double ga = GT(q, t0+st), gb = GT(q+1, t0+st);
+          double dhdl;
+          if (dhdt*(ga + gb) > 0.0) dhdl = ga;
+          else if (dhdt*(ga + gb) == 0.0) dhdl = 0.0;
+          else dhdl = gb;
+          if (dhdt*dhdn < 0.0) dhdt = 0.0;
+          cff = max2(dhdn*dhdn + dhdl*dhdl, 1.0e-20);
+          rn = min2(dhdt*dhdn, cff*rx_max);
+          rt = min2(cff, max2(dhdt*dhdl, -cff));
+        }
+        const double tau = (rn <= 0.0) ? S->Velocity_nudging_timescale_in : S->Velocity_nudging_timescale_out;
+        const double gamma_2 = dt / (tau + dt);
+        if (bits & MOM6HIP_OBC_TAN_OBLIQUE)
+          S->tangential_vel[TIDX(q,k)] = ((cff*tn[T3(t0,q,k)] + rn*tn[T3(t0+st,q,k)]) - (max2(rt,0.0)*GT(q, t0) + min2(rt,0.0)*GT(q+1, t0))) / (cff + rn);
+        if (bits & MOM6HIP_OBC_TAN_NUDGED)
+          S->tangential_vel[TIDX(q,k)] = (1.0 - gamma_2) * S->tangential_vel[TIDX(q,k)] + gamma_2 * S->nudged_tangential_vel[TIDX(q,k)];
+        if ((bits & MOM6HIP_OBC_GRAD_OBLIQUE) && q >= q0 + 1 && q <= q1 - 1)
+          S->tangential_grad[TIDX(q,k)] = ((cff*(tn[T3(lo1+1,q,k)] - tn[T3(lo1,q,k)])*Idm[QM(lo1,q)] +
+                                            rn*(tn[T3(lo2+1,q,k)] - tn[T3(lo2,q,k)])*Idm[QM(lo2,q)]) -
+                                           (max2(rt,0.0)*GG2(q) + min2(rt,0.0)*GG2(q+1))) / (cff + rn);
+        if (bits & MOM6HIP_OBC_GRAD_NUDGED)
+          S->tangential_grad[TIDX(q,k)] = (1.0 - gamma_2) * S->tangential_grad[TIDX(q,k)] + gamma_2 * S->nudged_tangential_grad[TIDX(q,k)];
+      }
+#undef T3
+#undef TIDX
+#undef QM
+#undef CELL2
+#undef FACE2
+#undef GT
+#undef GG2
     }
   }
   /* open_boundary_apply_normal_flow :3337 */

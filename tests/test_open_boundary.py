@@ -116,12 +116,13 @@ def test_oracle_turns_with_the_grid():
     assert np.array_equal(interior(g, unrot(orr["rx"]), _abi.POS_V), interior(g, o["ry"], _abi.POS_V))
 
 
-def test_refused_forms():
+def test_every_form_of_the_radiation_is_provided():
     g, d, _ = rad_case()
-    for bad in (["I=N,J=0:N,OBLIQUE,OBLIQUE_GRAD"], ["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"]):
-        OBC = ocean_OBC_type(g, bad)
-        with pytest.raises(RuntimeError, match="rc=2"):
-            run(g, d, OBC)
+    for segs in (["I=N,J=0:N,OBLIQUE,OBLIQUE_GRAD"], ["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"]):
+        OBC = ocean_OBC_type(g, segs)
+        for n in OBL_FIELDS:
+            setattr(OBC, n, g.zeros3(_abi.POS_U if n.endswith("_u") else _abi.POS_V))
+        run(g, d, OBC)
 
 
 @pytest.mark.gpu
@@ -160,25 +161,6 @@ def test_gpu_radiation_matches_oracle_bitwise(gamma_uv, reentrant, space):
     uw, vw = d2["u_new"].copy(), d2["v_new"].copy()
     orc.open_boundary_zero_normal_flow(g, OBC, uw, vw)
     assert bits_equal(get(u), uw) and bits_equal(get(v), vw)
-    dg.close()
-
-
-@pytest.mark.gpu
-def test_gpu_radiation_refuses_what_it_does_not_provide():
-    import torch
-    from mom6_amd._lib import Mom6HipError
-    from mom6_amd.open_boundary import radiation_open_bdry_conds
-    from mom6_amd.tracer_advect import DeviceGrid
-    g, d, _ = rad_case()
-    dg = DeviceGrid(g)
-    o = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
-    for bad, msg in ((["I=N,J=0:N,OBLIQUE,OBLIQUE_GRAD"], "oblique"), (["I=N,J=0:N,OBLIQUE,OBLIQUE_TAN"], "oblique")):
-        OBC = ocean_OBC_type(g, bad)
-        OBC.rx_normal, OBC.ry_normal = o["rx"], o["ry"]
-        for s in OBC.segment:
-            s.normal_vel = torch.from_numpy(s.normal_vel).cuda()
-        with pytest.raises(Mom6HipError, match=msg):
-            radiation_open_bdry_conds(OBC, o["u_new"], o["u_old"], o["v_new"], o["v_old"], dg, 900.0)
     dg.close()
 
 
@@ -471,4 +453,128 @@ def test_gpu_oblique_radiation_matches_oracle_bitwise(gamma_uv, space):
             assert bits_equal(N(getattr(OBC, name)), getattr(ref, name)), name
         for n, (s, sr) in enumerate(zip(OBC.segment, ref.segment)):
             assert bits_equal(N(s.normal_vel), sr.normal_vel), (n, "normal_vel", np.argwhere(N(s.normal_vel) != sr.normal_vel)[:4].tolist())
+        dg.close()
+
+
+# ---- the tangential forms of the oblique radiation: OBLIQUE_TAN / OBLIQUE_GRAD (:2456-2556 E, :2701-2801 W, :2946-3046 N, :3191-3291 S) ----
+OBLT_SEGS = ["J=N,I=N:0,OBLIQUE,OBLIQUE_TAN,OBLIQUE_GRAD", "J=0,I=0:N,OBLIQUE,OBLIQUE_TAN,NUDGED_TAN", "I=N,J=0:N,OBLIQUE,OBLIQUE_GRAD,NUDGED_GRAD",
+             "I=0,J=N:0,OBLIQUE,NUDGED,OBLIQUE_TAN,OBLIQUE_GRAD,NUDGED_TAN,NUDGED_GRAD", "I=9,J=4:11,OBLIQUE,OBLIQUE_TAN,OBLIQUE_GRAD",
+             "J=7,I=15:3,OBLIQUE,OBLIQUE_TAN,OBLIQUE_GRAD"]
+# per direction, from the reference's text: the rows (offsets from the segment's index) of the tangential component in the rates and in
+# tangential_vel [first inside, second], the row pairs (low row) and metric rows of the two gradient terms, the rows of grad_tan(., 1 | 2)
+OBLT_ROWS = {_abi.OBC_DIRECTION_E: dict(r0=0, r1=-1, g1=-1, g2=-2, gt1=-1, gt2=0), _abi.OBC_DIRECTION_W: dict(r0=1, r1=2, g1=1, g2=2, gt1=2, gt2=1),
+             _abi.OBC_DIRECTION_N: dict(r0=0, r1=-1, g1=-1, g2=-2, gt1=-1, gt2=0), _abi.OBC_DIRECTION_S: dict(r0=1, r1=2, g1=1, g2=2, gt1=2, gt2=1)}
+
+
+def oblt_case(seed=8, **kw):
+    g, d, OBC = rad_case(OBLT_SEGS, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 11)
+    for n in OBL_FIELDS:
+        shp = g.shape3(_abi.POS_U if n.endswith("_u") else _abi.POS_V)
+        setattr(OBC, n, np.ascontiguousarray((1e-4 * rng.random(shp)) if n.startswith("cff") else 1e-4 * rng.standard_normal(shp)))
+    for s in OBC.segment:
+        if s.on_pe:
+            shp = s.tangential_vel.shape
+            s.tangential_vel[:] = 0.1 * rng.standard_normal(shp); s.tangential_grad[:] = 1e-5 * rng.standard_normal(shp)
+            s.nudged_tangential_vel = 0.2 * rng.standard_normal(shp); s.nudged_tangential_grad = 2e-5 * rng.standard_normal(shp)
+            s.Velocity_nudging_timescale_in, s.Velocity_nudging_timescale_out = 3600.0, 86400.0
+    return g, d, OBC
+
+
+def expected_oblique_tangential(g, d, s, OBCa, tv0, tg0, gamma_uv, rx_max, dt):
+    """OBCa: the OBC after the normal part (its stored fields are the segment's rx_norm_obl, ry_norm_obl, cff_normal)"""
+    H = s.HI; nk = g.nk; eps = 1.0e-20
+    R = OBLT_ROWS[s.direction]
+    ew = s.is_E_or_W
+    tn, to = (d["v_new"], d["v_old"]) if ew else (d["u_new"], d["u_old"])
+    A = H["IsdB"] if ew else H["JsdB"]
+    mT = np.asarray(g.mask2dT); Id = np.asarray(g.IdxBu if ew else g.IdyBu); mC = np.asarray(g.mask2dCu if ew else g.mask2dCv)
+    # the tangential component in the row t of cells at the corner point q; masks and metrics likewise (t: across the boundary, q / c: along it)
+    Tn = (lambda t, q, k: tn[k, q - (g.jsd - 1), t - g.isd]) if ew else (lambda t, q, k: tn[k, t - g.jsd, q - (g.isd - 1)])
+    To = (lambda t, q, k: to[k, q - (g.jsd - 1), t - g.isd]) if ew else (lambda t, q, k: to[k, t - g.jsd, q - (g.isd - 1)])
+    MT = (lambda t, c: mT[c - g.jsd, t - g.isd]) if ew else (lambda t, c: mT[t - g.jsd, c - g.isd])
+    IDM = (lambda t, q: Id[q - (g.jsd - 1), t - (g.isd - 1)]) if ew else (lambda t, q: Id[t - (g.jsd - 1), q - (g.isd - 1)])
+    MC = (lambda t, c: mC[c - g.jsd, t - (g.isd - 1)]) if ew else (lambda t, c: mC[t - (g.jsd - 1), c - g.isd])
+    c0, c1 = (H["jsd"], H["jed"]) if ew else (H["isd"], H["ied"])
+    q0, q1 = (H["JsdB"], H["JedB"]) if ew else (H["IsdB"], H["IedB"])
+    cd0, cd1 = (g.jsd, g.jed) if ew else (g.isd, g.ied)
+    GT = lambda c, m, k: 0.0 if not (max(c0 - 1, cd0) <= c <= min(c1 + 1, cd1)) else \
+        (Tn(A + (R["gt1"] if m == 1 else R["gt2"]), c, k) - Tn(A + (R["gt1"] if m == 1 else R["gt2"]), c - 1, k)) * MT(A + (R["gt1"] if m == 1 else R["gt2"]), c)
+    lo1 = A + R["g1"]; lo2 = A + R["g2"]
+    GG2 = lambda c, k: 0.0 if not (max(c0, cd0 + 1) <= c <= min(c1, cd1 - 1)) else \
+        (((Tn(lo1 + 1, c, k) - Tn(lo1, c, k)) * IDM(lo1, c)) - (Tn(lo1 + 1, c - 1, k) - Tn(lo1, c - 1, k)) * IDM(lo1, c - 1)) * MC(lo1, c)
+    names = ("rx_oblique_u", "ry_oblique_u", "cff_normal_u") if ew else ("ry_oblique_v", "rx_oblique_v", "cff_normal_v")      # (normal, along, cff)
+    ST = [getattr(OBCa, n) for n in names]
+    F = (lambda a, c, k: a[k, c - g.jsd, A - (g.isd - 1)]) if ew else (lambda a, c, k: a[k, A - (g.jsd - 1), c - g.isd])
+    fmax = lambda a, b: a if a > b else b
+    fmin = lambda a, b: a if a < b else b
+    tv, tg = tv0.copy(), tg0.copy()
+    for k in range(nk):
+        for q in range(q0, q1 + 1):
+            if gamma_uv < 1.0:
+                rn, rt, cff = [(F(a, c0, k) if q == q0 else (F(a, c1, k) if q == q1 else 0.5 * (F(a, q, k) + F(a, q + 1, k)))) for a in ST]
+            else:
+                dhdt = To(A + R["r0"], q, k) - Tn(A + R["r0"], q, k); dhdn = Tn(A + R["r0"], q, k) - Tn(A + R["r1"], q, k)
+                ssum = GT(q, 1, k) + GT(q + 1, 1, k)
+                dhdl = GT(q, 1, k) if dhdt * ssum > 0.0 else (0.0 if dhdt * ssum == 0.0 else GT(q + 1, 1, k))
+                if dhdt * dhdn < 0.0:
+                    dhdt = 0.0
+                cff = fmax(dhdn * dhdn + dhdl * dhdl, eps); rn = fmin(dhdt * dhdn, cff * rx_max); rt = fmin(cff, fmax(dhdt * dhdl, -cff))
+            tau = s.Velocity_nudging_timescale_in if rn <= 0.0 else s.Velocity_nudging_timescale_out
+            g2 = dt / (tau + dt)
+            idx = (k, q - q0, 0) if ew else (k, 0, q - q0)
+            if s.oblique_tan:
+                tv[idx] = ((cff * Tn(A + R["r0"], q, k) + rn * Tn(A + R["r1"], q, k)) - (fmax(rt, 0.0) * GT(q, 2, k) + fmin(rt, 0.0) * GT(q + 1, 2, k))) / (cff + rn)
+            if s.nudged_tan:
+                tv[idx] = (1.0 - g2) * tv[idx] + g2 * s.nudged_tangential_vel[idx]
+            if s.oblique_grad and q0 + 1 <= q <= q1 - 1:
+                tg[idx] = ((cff * (Tn(lo1 + 1, q, k) - Tn(lo1, q, k)) * IDM(lo1, q) + rn * (Tn(lo2 + 1, q, k) - Tn(lo2, q, k)) * IDM(lo2, q)) -
+                           (fmax(rt, 0.0) * GG2(q, k) + fmin(rt, 0.0) * GG2(q + 1, k))) / (cff + rn)
+            if s.nudged_grad:
+                tg[idx] = (1.0 - g2) * tg[idx] + g2 * s.nudged_tangential_grad[idx]
+    return tv, tg
+
+
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+def test_oracle_oblique_tangential_forms_are_the_blocks_of_the_reference(gamma_uv):
+    g, d, OBC = oblt_case()
+    before = [(s.tangential_vel.copy(), s.tangential_grad.copy()) for s in OBC.segment]
+    run(g, d, OBC, gamma_uv=gamma_uv)
+    n_changed = 0
+    for s, (tv0, tg0) in zip(OBC.segment, before):
+        tv, tg = expected_oblique_tangential(g, d, s, OBC, tv0, tg0, gamma_uv, 1.0, 900.0)
+        assert bits_equal(s.tangential_vel, tv), (s.direction, "tangential_vel", np.argwhere(s.tangential_vel != tv)[:4].tolist())
+        assert bits_equal(s.tangential_grad, tg), (s.direction, "tangential_grad", np.argwhere(s.tangential_grad != tg)[:4].tolist())
+        n_changed += int((tv != tv0).sum() + (tg != tg0).sum())
+    assert n_changed > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+@pytest.mark.parametrize("space", ["device", "host"])
+def test_gpu_oblique_tangential_forms_match_oracle_bitwise(gamma_uv, space):
+    import copy
+    import torch
+    from mom6_amd.open_boundary import radiation_open_bdry_conds
+    from mom6_amd.tracer_advect import DeviceGrid
+    for kw in (dict(), dict(ni=150, nj=40, nk=2, seed=5)):
+        g, d, OBC = oblt_case(**kw)
+        OBC.gamma_uv, OBC.rx_max = gamma_uv, 1.0
+        ref = copy.deepcopy(OBC)
+        o = run(g, d, ref, gamma_uv=gamma_uv)
+        dev = space == "device"
+        X = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if dev else (lambda a: a.copy())
+        N = (lambda a: a.cpu().numpy()) if dev else (lambda a: a)
+        f = {k: X(v) for k, v in d.items()}
+        OBC.rx_normal, OBC.ry_normal = f["rx"], f["ry"]
+        if dev:
+            OBC.cuda()
+        dg = DeviceGrid(g)
+        radiation_open_bdry_conds(OBC, f["u_new"], f["u_old"], f["v_new"], f["v_old"], dg, 900.0)
+        dg.sync()
+        assert bits_equal(N(f["u_new"]), o["u_new"]) and bits_equal(N(f["v_new"]), o["v_new"])
+        for n, (s, sr) in enumerate(zip(OBC.segment, ref.segment)):
+            assert bits_equal(N(s.tangential_vel), sr.tangential_vel), (n, "tangential_vel", np.argwhere(N(s.tangential_vel) != sr.tangential_vel)[:4].tolist())
+            assert bits_equal(N(s.tangential_grad), sr.tangential_grad), (n, "tangential_grad")
+            assert bits_equal(N(s.normal_vel), sr.normal_vel), (n, "normal_vel")
         dg.close()
