@@ -38,7 +38,7 @@ use MOM_diag_mediator,         only : diag_ctrl
 use MOM_error_handler,         only : MOM_error, FATAL, WARNING
 use MOM_file_parser,           only : get_param, log_version, param_file_type
 use MOM_get_input,             only : directories
-use MOM_restart,               only : register_restart_field, query_initialized, MOM_restart_CS
+use MOM_restart,               only : register_restart_field, query_initialized, MOM_restart_CS, is_new_run
 use MOM_time_manager,          only : time_type
 use MOM_ALE,                   only : ALE_CS
 use MOM_barotropic,            only : barotropic_init, register_barotropic_restarts, barotropic_CS, barotropic_end
@@ -52,7 +52,7 @@ use MOM_hor_index,             only : hor_index_type
 use MOM_hor_visc,              only : hor_visc_CS, hor_visc_init, hor_visc_end, hor_visc_hip_struct
 use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_MEKE_types,            only : MEKE_type
-use MOM_open_boundary,         only : ocean_OBC_type, OBC_segment_type
+use MOM_open_boundary,         only : ocean_OBC_type, OBC_segment_type, update_OBC_ramp
 use MOM_PressureForce_FV,      only : PressureForce_FV_CS, PressureForce_FV_init, PressureForce_FV_hip_struct
 use MOM_set_visc,              only : set_visc_CS, set_visc_hip_struct
 use MOM_stochastics,           only : stochastic_CS
@@ -283,6 +283,7 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
     if (allocated(MEKE%GME_snk)) MEKE%GME_snk(:,:) = 0.0
   endif
 
+  if (associated(CS%OBC)) call update_OBC_ramp(Time_local, CS%OBC, US)      ! :448
   call obc_mirrors(CS)
   rc = mom6hip_step_dyn_split_rk2(CS%ctx, CS%c_rk2, d_u, d_v, d_h, d_T, d_S, real(dt, c_double), d_tx, d_ty, &
                                   real(GV%Z_to_H / GV%Rho0, c_double), d_uh, d_vh, d_uhtr, d_vhtr, d_eta_av, &
@@ -513,7 +514,8 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   if (associated(OBC)) then      ! :1516-1519.  The segments' data are the host's business (MOM_open_boundary, MOM_boundary_update)
     CS%OBC => OBC
     call refuse(OBC%update_OBC, "OBC%update_OBC (update_OBC_data inside the step)")
-    call refuse(OBC%ramp, "OBC_RAMP")
+    ! (OBC%ramp_value scales the external data in update_OBC_segment_data, a host routine of the reference's MOM_open_boundary)
+    if (OBC%ramp) call update_OBC_ramp(Time, CS%OBC, US, activate=is_new_run(restart_CS))      ! :1518
   endif
   if (.not.GV%Boussinesq) call refuse(.true., "a non-Boussinesq vertical grid")
 
