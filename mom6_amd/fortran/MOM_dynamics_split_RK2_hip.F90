@@ -43,7 +43,7 @@ use MOM_time_manager,          only : time_type
 use MOM_ALE,                   only : ALE_CS
 use MOM_barotropic,            only : barotropic_init, register_barotropic_restarts, barotropic_CS, barotropic_end
 use MOM_barotropic,            only : barotropic_hip_struct, barotropic_hip_update
-use MOM_boundary_update,       only : update_OBC_CS
+use MOM_boundary_update,       only : update_OBC_CS, update_OBC_data
 use MOM_diabatic_driver,        only : diabatic_CS
 use MOM_continuity_PPM,        only : continuity_PPM_CS, continuity_PPM_init, continuity_PPM_stencil, continuity_PPM_hip_struct
 use MOM_CoriolisAdv,           only : CoriolisAdv_CS, CoriolisAdv_init, CoriolisAdv_end, CoriolisAdv_hip_struct
@@ -105,6 +105,7 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   type(mom6hip_set_visc_cs_t)      :: c_sv
   type(mom6hip_dyn_split_rk2_cs_t) :: c_rk2
   type(ocean_OBC_type), pointer :: OBC => NULL()     !< CS%OBC (:253)
+  type(update_OBC_CS), pointer :: update_OBC_CSp => NULL()      !< (:258)
   type(mom6hip_obc_t) :: c_obc                       !< the library's view of it: device mirrors of the segments' arrays
   type(mom6hip_obc_segment_t), allocatable :: c_obc_segs(:)
   logical :: use_EOS = .true., use_BT_cont = .true.
@@ -283,7 +284,16 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
     if (allocated(MEKE%GME_snk)) MEKE%GME_snk(:,:) = 0.0
   endif
 
-  if (associated(CS%OBC)) call update_OBC_ramp(Time_local, CS%OBC, US)      ! :448
+  if (associated(CS%OBC)) then
+    call update_OBC_ramp(Time_local, CS%OBC, US)      ! :448
+    ! :534-536: the external data of the segments, by the reference's own MOM_boundary_update on the host.  It reads h (and tv), which the
+    ! step does not change before its line :534, so calling it ahead of the step is the reference's order; staged, the segments' arrays
+    ! are uploaded with every call; resident, the host's h may be stale and the mirrors of the segments would not see the new data.
+    if (CS%OBC%update_OBC) then
+      if (CS%resident) call refuse("OBC%update_OBC (update_OBC_data inside the step) with GPU_RESIDENT_DYNAMICS")
+      call update_OBC_data(CS%OBC, G, GV, US, tv, h, CS%update_OBC_CSp, Time_local)
+    endif
+  endif
   call obc_mirrors(CS)
   rc = mom6hip_step_dyn_split_rk2(CS%ctx, CS%c_rk2, d_u, d_v, d_h, d_T, d_S, real(dt, c_double), d_tx, d_ty, &
                                   real(GV%Z_to_H / GV%Rho0, c_double), d_uh, d_vh, d_uhtr, d_vhtr, d_eta_av, &
@@ -513,7 +523,8 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   CS%diag => diag
   if (associated(OBC)) then      ! :1516-1519.  The segments' data are the host's business (MOM_open_boundary, MOM_boundary_update)
     CS%OBC => OBC
-    call refuse(OBC%update_OBC, "OBC%update_OBC (update_OBC_data inside the step)")
+    if (associated(update_OBC_CSp)) CS%update_OBC_CSp => update_OBC_CSp      ! :1520
+    ! (OBC%update_OBC: update_OBC_data is the reference's own host routine, called before the step: see step_MOM_dyn_split_RK2)
     ! (OBC%ramp_value scales the external data in update_OBC_segment_data, a host routine of the reference's MOM_open_boundary)
     if (OBC%ramp) call update_OBC_ramp(Time, CS%OBC, US, activate=is_new_run(restart_CS))      ! :1518
   endif
