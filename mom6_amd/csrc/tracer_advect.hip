@@ -693,8 +693,8 @@ void launch_y(int scheme, bool first, dim3 grid, int nseg, int seglen, hipStream
 // The general form of advect_x / advect_y: two plain kernels a pass, a thread a face (the transport taken through the face and the fluxes
 // of every tracer, :485-627 / :868-1014, into scratch) and a thread a cell (:632-687 / :1021-1066).  It is the path of an OBC whose
 // segments carry tracer registries (segment%tr_Reg: a registered tracer takes its reservoir value or inflow concentration in the cell outside
-// the segment :441-462 / :823-846, the slopes of the three cells about the segment's face are formed again with the masks of the faces I, I-1
-// | J, J-1 :463-473 / :847-856, an inflow carries the reservoir value with the whole remaining transport :580-627 / :965-1014); regional
+// the segment :441-462 / :823-846, the slopes of the three cells about the segment's face are formed again, each with the masks of its own two
+// faces (the loop index of :466 / :850 is the I / J of the mask expression: Fortran does not tell the cases apart) :463-473 / :847-856, an inflow carries the reservoir value with the whole remaining transport :580-627 / :965-1014); regional
 // configurations are small, and the marching kernels above stay as they are.  MOM6HIP_ADV_GENERIC=1 takes this path without OBC (tests).
 constexpr int GEN_MAXTR = 64;
 struct GenTr { double *t[GEN_MAXTR]; double cu[GEN_MAXTR]; int ntr; };
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void gen_flux_kernel(GenArgs p) {
     for (int q = 0; q < p.nseg; q++) {
       const GenSeg &s = p.segs[q];
       if (c >= s.c0 && c <= s.c1 && nn >= s.A - 1 && nn <= s.A + 1)
-        return plm_slope(Tt(m, nn + 1), Tt(m, nn), Tt(m, nn - 1), fmask(s.A) * fmask(s.A - 1));
+        return plm_slope(Tt(m, nn + 1), Tt(m, nn), Tt(m, nn - 1), fmask(nn) * fmask(nn - 1));      // (:472, :854: Fortran's I is i -- the loop cell's masks)
     }
     return plm_slope(Traw(m, nn + 1), Traw(m, nn), Traw(m, nn - 1), fmask(nn) * fmask(nn - 1));
   };

@@ -138,7 +138,7 @@ static void advect_x(adv_t *A, int is, int ie, int js, int je, int k)
         }
         for (int m = 0; m < ntr; m++) for (int i = I-1; i <= I+1; i++) {
           double Tp = WM(T_tmp,i+1,m), Tc = WM(T_tmp,i,m), Tm = WM(T_tmp,i-1,m);
-          WM(slope_x,i,m) = plm_slope(Tp, Tc, Tm, G->mask2dCu[ORC_U2(G,I,j)]*G->mask2dCu[ORC_U2(G,I-1,j)]);
+          WM(slope_x,i,m) = plm_slope(Tp, Tc, Tm, G->mask2dCu[ORC_U2(G,i,j)]*G->mask2dCu[ORC_U2(G,i-1,j)]);   /* :472 (Fortran does not tell I from i: the masks are the loop cell's) */
         }
       }
     }
@@ -346,7 +346,7 @@ static void advect_y(adv_t *A, int is, int ie, int js, int je, int k)
         }
         for (int m = 0; m < ntr; m++) for (int j = J-1; j <= J+1; j++) {
           double Tp = S3(T_tmp,i,m,j+1), Tc = S3(T_tmp,i,m,j), Tm = S3(T_tmp,i,m,j-1);
-          S3(slope_y,i,m,j) = plm_slope(Tp, Tc, Tm, G->mask2dCv[ORC_V2(G,i,J)]*G->mask2dCv[ORC_V2(G,i,J-1)]);
+          S3(slope_y,i,m,j) = plm_slope(Tp, Tc, Tm, G->mask2dCv[ORC_V2(G,i,j)]*G->mask2dCv[ORC_V2(G,i,j-1)]);   /* :854 (J is j in Fortran: the loop cell's masks) */
         }
       }
     }

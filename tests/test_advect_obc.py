@@ -73,7 +73,7 @@ def test_an_unregistered_tracer_and_the_far_field_are_untouched_and_inflow_bring
 
 
 # The reference is not symmetric under the quarter turn for every segment: the three cells whose slopes it forms again are I-1 .. I+1 and
-# J-1 .. J+1 whatever the side the segment opens to (:466, :850), with the masks of the faces I, I-1 and J, J-1, so an eastern segment and the
+# J-1 .. J+1 whatever the side the segment opens to (:466, :850; each with the masks of its own two faces), so an eastern segment and the
 # southern one it turns into refresh different cells; and a non-specified segment inside the domain takes its inflow value in advect_x only
 # (:586-599 against :969).  Northern and southern segments turn into eastern and western ones that do the same arithmetic: each of the four
 # branches (E, W in advect_x; N, S in advect_y) is on one side of such a pair.
@@ -98,6 +98,183 @@ def test_oracle_turns_with_the_grid(scheme, x_first):
     b = run(gr, cr, OBCr, scheme, x_first=not x_first)      # x' = y: the turned grid does y first where this one does x first
     for m in range(3):
         assert bits_equal(interior(g, unrot(b["tr"][m])), interior(g, a["tr"][m])), m
+
+
+# ---- the reference's own lines, written out once more for one row (PLM) ----
+# The reference holds no vectors for advect_x; what can be checked without the oracle's author reading the same lines the same way twice is a
+# second, separate transcription of the row loop of advect_x (:408-662) in Python scalars, for the branches this case reaches (the transports
+# stay below the limiter of :488-514, which the test asserts).  It pins the point ADVICE r04 found: Fortran does not tell `I` from `i`, so
+# `do i=segment%HI%IsdB-1,segment%HI%IsdB+1` (:466) runs the I of `G%mask2dCu(I,j)*G%mask2dCu(I-1,j)` (:472) with it -- the three slopes
+# formed again about a segment take the masks of their own faces; with land outside a western segment the first cell inside keeps its slope.
+def _sign(a, b):
+    return abs(a) if b >= 0.0 else -abs(a)
+
+
+def ref_advect_x_row_plm(g, OBC, j, k, T, hprev, uhr, uh_neglect):
+    """one (j, k) row of advect_x, usePPM = False; T: list of 1-D rows indexed by i - isd, updated in place; hprev, uhr rows likewise"""
+    isd, ied, is_, ie = g.isd, g.ied, g.isc, g.iec
+    X = lambda i: i - isd          # h-point column of cell i
+    U = lambda I: I - isd + 1      # u-point column of face I
+    mCu = np.asarray(g.mask2dCu)[j - g.jsd]; areaT = np.asarray(g.areaT)[j - g.jsd]
+    min_h = 0.1 * g.Angstrom_H; tiny_h = np.finfo(np.float64).tiny; h_neglect = g.H_subroundoff
+    ntr = len(T); stencil = 1
+    slope = [dict() for _ in range(ntr)]
+    for m in range(ntr):                                              # :409-436
+        for i in range(is_ - stencil, ie + stencil + 1):
+            Tp, Tc, Tm = T[m][X(i + 1)], T[m][X(i)], T[m][X(i - 1)]
+            dMx = max(Tp, Tc, Tm) - Tc; dMn = Tc - min(Tp, Tc, Tm)
+            slope[m][i] = mCu[U(i)] * mCu[U(i - 1)] * _sign(min(0.5 * abs(Tp - Tm), 2.0 * dMx, 2.0 * dMn), Tp - Tm)
+    T_tmp = [t.copy() for t in T]                                     # :439-443
+    for s in OBC.segment:                                             # :445-481
+        if not s.tr_Reg or not s.is_E_or_W or not (s.HI['jsd'] <= j <= s.HI['jed']):
+            continue
+        I = s.HI['IsdB']
+        for reg in s.tr_Reg:
+            m = reg["ntr_index"] - 1
+            val = reg["tres"][k, j - s.HI['jsd'], 0] if reg.get("tres") is not None else reg["OBC_inflow_conc"]
+            if s.direction == _abi.OBC_DIRECTION_W:
+                T_tmp[m][X(I)] = val
+            else:
+                T_tmp[m][X(I + 1)] = val
+        for m in range(ntr):
+            for i in range(s.HI['IsdB'] - 1, s.HI['IsdB'] + 2):                   # (the loop variable is the I of the masks below)
+                I = i
+                Tp, Tc, Tm = T_tmp[m][X(i + 1)], T_tmp[m][X(i)], T_tmp[m][X(i - 1)]
+                dMx = max(Tp, Tc, Tm) - Tc; dMn = Tc - min(Tp, Tc, Tm)
+                slope[m][i] = mCu[U(I)] * mCu[U(I - 1)] * _sign(min(0.5 * abs(Tp - Tm), 2.0 * dMx, 2.0 * dMn), Tp - Tm)
+    uhh, CFL = {}, {}
+    for I in range(is_ - 1, ie + 1):                                  # :485-514
+        i = I; u = uhr[U(I)]
+        if u == 0.0 or (u < 0.0 and hprev[X(i + 1)] <= tiny_h) or (u > 0.0 and hprev[X(i)] <= tiny_h):
+            uhh[I] = 0.0; CFL[I] = 0.0
+        elif u < 0.0:
+            hup = hprev[X(i + 1)] - areaT[X(i + 1)] * min_h; hlos = max(0.0, uhr[U(I + 1)])
+            assert not ((((hup - hlos) + u) < 0.0) and ((0.5 * hup + u) < 0.0)), "the case must stay below the limiter"
+            uhh[I] = u; CFL[I] = -uhh[I] / hprev[X(i + 1)]
+        else:
+            hup = hprev[X(i)] - areaT[X(i)] * min_h; hlos = max(0.0, -uhr[U(I - 1)])
+            assert not ((((hup - hlos) - u) < 0.0) and ((0.5 * hup - u) < 0.0)), "the case must stay below the limiter"
+            uhh[I] = u; CFL[I] = uhh[I] / hprev[X(i)]
+    flux = [dict() for _ in range(ntr)]
+    for m in range(ntr):                                              # :560-578
+        for I in range(is_ - 1, ie + 1):
+            i = I
+            if uhh[I] >= 0.0:
+                Tc = T_tmp[m][X(i)]; flux[m][I] = uhh[I] * (Tc + 0.5 * slope[m][i] * (1. - CFL[I]))
+            else:
+                Tc = T_tmp[m][X(i + 1)]; flux[m][I] = uhh[I] * (Tc - 0.5 * slope[m][i + 1] * (1. - CFL[I]))
+    if OBC.specified_u_BCs_exist_globally or OBC.open_u_BCs_exist_globally:      # :581-603
+        for s in OBC.segment:
+            if not s.tr_Reg or not s.is_E_or_W or not (s.HI['jsd'] <= j <= s.HI['jed']):
+                continue
+            I = s.HI['IsdB']
+            if (uhr[U(I)] > 0.0 and s.direction == _abi.OBC_DIRECTION_W) or (uhr[U(I)] < 0.0 and s.direction == _abi.OBC_DIRECTION_E):
+                uhh[I] = uhr[U(I)]
+                for reg in s.tr_Reg:
+                    m = reg["ntr_index"] - 1
+                    flux[m][I] = uhh[I] * (reg["tres"][k, j - s.HI['jsd'], 0] if reg.get("tres") is not None else reg["OBC_inflow_conc"])
+    if OBC.open_u_BCs_exist_globally:                                 # :605-627
+        mT = np.asarray(g.mask2dT)[j - g.jsd]
+        for s in OBC.segment:
+            I = s.HI['IsdB']; i = I
+            if s.is_E_or_W and (s.HI['jsd'] <= j <= s.HI['jed']):
+                if s.specified or not s.tr_Reg:
+                    continue
+                if (uhr[U(I)] > 0.0 and mT[X(i)] < 0.5) or (uhr[U(I)] < 0.0 and mT[X(i + 1)] < 0.5):
+                    uhh[I] = uhr[U(I)]
+                    for reg in s.tr_Reg:
+                        m = reg["ntr_index"] - 1
+                        flux[m][I] = uhh[I] * (reg["tres"][k, j - s.HI['jsd'], 0] if reg.get("tres") is not None else reg["OBC_inflow_conc"])
+    for I in range(is_ - 1, ie + 1):                                  # :632-635
+        uhr[U(I)] = uhr[U(I)] - uhh[I]
+        if abs(uhr[U(I)]) < uh_neglect[U(I)]:
+            uhr[U(I)] = 0.0
+    for i in range(is_, ie + 1):                                      # :636-662
+        I = i
+        if uhh[I] != 0.0 or uhh[I - 1] != 0.0:
+            do_i = True
+            hlst = hprev[X(i)]
+            hprev[X(i)] = hprev[X(i)] - (uhh[I] - uhh[I - 1])
+            if hprev[X(i)] <= 0.0:
+                do_i = False
+            elif hprev[X(i)] < h_neglect * areaT[X(i)]:
+                hlst = hlst + (h_neglect * areaT[X(i)] - hprev[X(i)]); Ihnew = 1.0 / (h_neglect * areaT[X(i)])
+            else:
+                Ihnew = 1.0 / hprev[X(i)]
+            if do_i and Ihnew > 0.0:
+                for m in range(ntr):
+                    T[m][X(i)] = (T[m][X(i)] * hlst - (flux[m][I] - flux[m][I - 1])) * Ihnew
+    return slope
+
+
+@pytest.mark.parametrize("side", ["W", "E"])
+def test_oracle_advect_x_row_equals_a_second_transcription_of_the_reference_with_land_outside_a_segment(side):
+    """a segment two columns inside the domain with LAND in the column outside it (the case of ADVICE r04): vhtr = 0, one pass of advect_x"""
+    ni, nj, nk = 14, 6, 2
+    g = synth.make_grid(ni, nj, nk, halo=4, land_frac=0.0, seed=77, reentrant_x=False, reentrant_y=False)
+    A = 3 if side == "W" else ni - 3          # the segment's face I (global index = Fortran I of an unshifted domain)
+    segs = [f"I={A},J=N:0,FLATHER,ORLANSKI" if side == "W" else f"I={A},J=0:N,FLATHER,ORLANSKI"]
+    OBC = ocean_OBC_type(g, segs)
+    s = OBC.segment[0]
+    assert s.direction == (_abi.OBC_DIRECTION_W if side == "W" else _abi.OBC_DIRECTION_E)
+    # land outside the segment: the columns beyond the outside cell are masked and the face beyond the outside cell is a wall
+    m = {n: np.asarray(g.metrics[n]).copy() for n in ("mask2dT", "mask2dCu", "dy_Cu", "mask2dCv", "dx_Cv")}
+    Ic = s.HI['IsdB'] - g.isd            # h-column of cell I
+    out = slice(0, Ic + 1) if side == "W" else slice(Ic + 1, None)
+    m["mask2dT"][:, out] = 0.0; m["mask2dCv"][:, out] = 0.0; m["dx_Cv"][:, out] = 0.0
+    uc = s.HI['IsdB'] - g.isd + 1        # u-column of face I
+    if side == "W":
+        m["mask2dCu"][:, :uc] = 0.0; m["dy_Cu"][:, :uc] = 0.0
+    else:
+        m["mask2dCu"][:, uc + 1:] = 0.0; m["dy_Cu"][:, uc + 1:] = 0.0
+    for n, a in m.items():
+        g.set_metric(n, a)
+    open_faces(g, OBC)
+    assert np.asarray(g.mask2dCu)[4, uc] == 1.0 and np.asarray(g.mask2dCu)[4, uc + (-1 if side == "W" else 1)] == 0.0
+    rng = np.random.default_rng(5)
+    h = np.ascontiguousarray(50.0 + 10.0 * rng.random(g.shape3(_abi.POS_H)))
+    T1 = np.ascontiguousarray(10.0 + np.cumsum(rng.random(g.shape3(_abi.POS_H)), axis=2))      # monotone in i: the slopes do not vanish
+    T2 = np.ascontiguousarray(rng.random(g.shape3(_abi.POS_H)))
+    areaT = np.asarray(g.areaT)
+    uhtr = np.ascontiguousarray((0.02 + 0.01 * rng.random(g.shape3(_abi.POS_U))) * (1.0 if side == "W" else -1.0) * areaT.mean() * 50.0
+                                * np.asarray(g.mask2dCu)[None])
+    vhtr = g.zeros3(_abi.POS_V)
+    # the reservoir lies between the tracer of the cells either side of the outside cell: the profile stays monotone across the segment, so
+    # a slope there vanishes only through its masks
+    xo = s.HI['IsdB'] - g.isd + (0 if side == "W" else 1)      # h-column of the outside cell
+    tres = 0.5 * (T1[:, s.HI['jsd'] - g.jsd:s.HI['jed'] - g.jsd + 1, xo - 1] + T1[:, s.HI['jsd'] - g.jsd:s.HI['jed'] - g.jsd + 1, xo + 1])
+    s.tr_Reg = [dict(ntr_index=1, tres=np.ascontiguousarray(tres[:, :, None])), dict(ntr_index=2, OBC_inflow_conc=0.7)]
+    assert s.tr_Reg[0]["tres"].shape == s.normal_vel.shape
+    tr = [T1.copy(), T2.copy()]
+    uhr_o = g.zeros3(_abi.POS_U); vhr_o = g.zeros3(_abi.POS_V)
+    st = orc.advect_tracer(g, h, uhtr, vhtr, 3600.0, 900.0, "PLM", tr, x_first=True, uhr_out=uhr_o, vhr_out=vhr_o, OBC=OBC, max_iter=1)
+    # the second transcription: hprev (:160-164), uh_neglect (:175-177), then the row loop for every (j, k)
+    want = [T1.copy(), T2.copy()]
+    first_inside = s.HI['IsdB'] + 1 if side == "W" else s.HI['IsdB']
+    slopes_seen = []
+    for k in range(nk):
+        for j in range(g.jsc, g.jec + 1):
+            jj = j - g.jsd
+            hprev = np.zeros(g.nih); uhr = uhtr[k, jj].copy()
+            for i in range(g.isc, g.iec + 1):
+                x = i - g.isd
+                hp = max(0.0, areaT[jj, x] * h[k, jj, x] + ((uhr[x + 1] - uhr[x]) + (0.0 - 0.0)))
+                hprev[x] = hp + max(0.0, 1.0e-13 * hp - areaT[jj, x] * h[k, jj, x])
+            uh_neglect = np.zeros(g.nih + 1)
+            for I in range(g.isd, g.ied):
+                uh_neglect[I - g.isd + 1] = g.H_subroundoff * min(areaT[jj, I - g.isd], areaT[jj, I - g.isd + 1])
+            rows = [want[0][k, jj], want[1][k, jj]]
+            sl = ref_advect_x_row_plm(g, OBC, j, k, rows, hprev, uhr, uh_neglect)
+            slopes_seen.append((sl[0][first_inside], sl[0][s.HI['IsdB'] + (0 if side == "W" else 1)]))
+            cols = slice(g.isc - 1 - g.isd + 1, g.iec - g.isd + 2)      # the faces I = is-1 .. ie the row loop owns
+            assert bits_equal(uhr[cols], uhr_o[k, jj][cols]), (k, j)
+    # the first cell inside keeps its slope although the face beyond the outside cell is land, and the outside cell has none (the reading
+    # ADVICE r04 corrected: with the masks of the faces IsdB, IsdB-1 for all three cells a western segment lost the first and an eastern
+    # one gave the second)
+    assert all(a != 0.0 and b == 0.0 for a, b in slopes_seen)
+    for mtr in range(2):
+        assert bits_equal(want[mtr], tr[mtr]), (side, mtr, np.argwhere(want[mtr] != tr[mtr])[:4])
+    assert not bits_equal(tr[0], T1)
 
 
 # ---- the library against the oracle, on the GPU ----
