@@ -606,8 +606,8 @@ __device__ __forceinline__ void ksums(double *fsm, int plane, int roff, int fl, 
 // phase clock of the cooperative kernel (experiments only: tools/build_variant.sh ... -DFC_TRACE): thread 0 of every block adds
 // the s_memtime ticks between marks; slot 15 counts blocks, slot 14 counts Newton passes; slots 16-39: faces by the number of
 // evaluation passes they were alive for in a solve, slots 40-63: the solves of the blocks by the number of passes they ran
-__device__ unsigned long long fc_trace[64];
-#define FC_MARK(n) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&fc_trace[n], t_ - fc_t0); fc_t0 = t_; } } while (0)
+__device__ unsigned long long fc_trace[128];      // [direction][slot]
+#define FC_MARK(n) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&fc_trace[64 * DIR + (n)], t_ - fc_t0); fc_t0 = t_; } } while (0)
 #else
 #define FC_MARK(n) do { } while (0)
 #endif
@@ -619,7 +619,7 @@ template <int DIR, int KS>
 __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(FluxArgs p) {
 #ifdef FC_TRACE
   unsigned long long fc_t0 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) atomicAdd(&fc_trace[15], 1ull);
+  if (threadIdx.x == 0) atomicAdd(&fc_trace[64 * DIR + 15], 1ull);
 #endif
   extern __shared__ double fsm[];      // three [KS*FC_NS][FC_FL] planes of layer values, then results [8][FC_FL], visc_rem max [FC_NS][FC_FL]
   const m6::GridDev &g = p.g;
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
       if (!__any(alive)) break;      // the same in every wave of the block: they hold the same values
       if ((itt < max_itts) || write_uh) {
 #ifdef FC_TRACE
-        if (threadIdx.x == 0) atomicAdd(&fc_trace[14], 1ull);
+        if (threadIdx.x == 0) atomicAdd(&fc_trace[64 * DIR + 14], 1ull);
         fc_np_block++; if (alive) fc_np_face++;
 #endif
         if (alive) fsm[pv + 3 * PVS] = du;
@@ -998,8 +998,8 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
     }
     du_ph[phase] = du;
 #ifdef FC_TRACE
-    if (sb == 0 && valid) atomicAdd(&fc_trace[16 + min(fc_np_face, 23)], 1ull);
-    if (threadIdx.x == 0) atomicAdd(&fc_trace[40 + min(fc_np_block, 23)], 1ull);
+    if (sb == 0 && valid) atomicAdd(&fc_trace[64 * DIR + 16 + min(fc_np_face, 23)], 1ull);
+    if (threadIdx.x == 0) atomicAdd(&fc_trace[64 * DIR + 40 + min(fc_np_block, 23)], 1ull);
 #endif
     FC_MARK(4 + phase);
     if (write_uh && valid) {
@@ -1133,6 +1133,595 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
   }
 }
 
+// ---- mass fluxes, block-cooperative form at three or four waves a SIMD (round 5) -------------------------------------
+// The same decomposition as cont_flux_coop_kernel (a half-wave = 32 face columns x one slab of KS layers, the slabs of a face
+// spread over the NW waves of a block, k-ordered sums through LDS planes), with the per-layer register set cut so that three
+// (6 waves x 7 layers) or four (8 waves x 5 layers) waves fit a SIMD without scratch:
+//  * a cell is held as (h_L, h_R, curvature): the upwind edge E, the other edge O and the curvature C are picked by selects and
+//    the edge difference of flux_layer is O - E in both of its branches (the reference's own subtraction);
+//  * zonal: a lane holds ONE cell, the minus-side cell of its face; the plus-side cell is the next lane's, fetched in every
+//    evaluation by a DPP wave shift (no LDS, no registers).  Meridional: both cells (the next row belongs to another block);
+//  * visc_rem lives in an LDS plane for the whole kernel (the chain walkers read it there anyway), a thread reads its own slots;
+//  * the Newton bracket and best error of a face are one LDS copy per block and phase (every half-wave computes the same values).
+// Zonal 4 doubles a layer in registers, meridional 7 (cont_flux_coop_kernel: 8).
+__device__ __forceinline__ double dpp_next_lane(double x) {      // the value of lane + 1 (0 in lane 63)
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);      // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// flux_layer :896-972 from the edge values and curvature of the two cells of a face
+__device__ __forceinline__ double flux_lrc(const FaceConst &F, double u, double vr, double mL, double mR, double mC, double pL, double pR,
+                                           double pC, double &duhdu) {
+  const bool pos = u > 0.0;
+  const double E = pos ? mR : pL, O = pos ? mL : pR, Cc = pos ? mC : pC, cf = pos ? F.cm : F.cp;
+  const double Dd = O - E;
+  const double CFL = (fabs(u) * F.dt) * cf;
+  double uh = (F.dLf * 1.0) * u * (E + CFL * (0.5 * Dd + Cc * (CFL - 1.5)));
+  double h_marg = E + CFL * (Dd + 3.0 * Cc * (CFL - 1.0));
+  if (u == 0.0) { uh = 0.0; h_marg = 0.5 * (pL + mR); }
+  duhdu = (F.dLf * 1.0) * h_marg * vr;
+  return uh;
+}
+
+// flux_thickness :976-1057 likewise
+__device__ __forceinline__ double thick_lrc(const FaceConst &F, int marginal, bool have_vr, double uc, double vr, double mL, double mR,
+                                            double mC, double pL, double pR, double pC) {
+  const bool pos = uc > 0.0;
+  const double E = pos ? mR : pL, O = pos ? mL : pR, Cc = pos ? mC : pC, cf = pos ? F.cm : F.cp;
+  const double Dd = O - E;
+  const double CFL = (fabs(uc) * F.dt) * cf;
+  double h_avg = E + CFL * (0.5 * Dd + Cc * (CFL - 1.5));
+  double h_marg = E + CFL * (Dd + 3.0 * Cc * (CFL - 1.0));
+  if (uc == 0.0) { h_avg = 0.5 * (pL + mR); h_marg = 0.5 * (pL + mR); }
+  double hu = marginal ? h_marg : h_avg;
+  if (have_vr) hu = hu * (vr * 1.0); else hu = hu * 1.0;
+  return hu;
+}
+
+#ifndef FC3_GRP
+#define FC3_GRP 2      // layers of a thread the scheduler may interleave in an evaluation pass (bounds the temporaries)
+#endif
+#define FC3_SCHED(m) do { if (((m) + 1) % FC3_GRP == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+// The evaluation passes run over all KS layers of a thread without a test on k (layers past nk hold zeros: u = 0 gives uh = +0
+// and a marginal thickness of 0; their rows of the planes exist and no sum reads them), so that a pass is one basic block the
+// scheduler can interleave FC3_GRP layers in; only the stores to global memory stay conditional.
+#ifndef FC3_CHAIN_UNROLL
+#define FC3_CHAIN_UNROLL 8      // LDS reads a chain walker issues ahead of its dependent arithmetic
+#endif
+#ifndef FC3_UNCOND
+#define FC3_UNCOND 1
+#endif
+#define FC3_LIVE(m) (FC3_UNCOND || (k0 + (m) < nz))
+
+__device__ __forceinline__ void ksums3(double *fsm, int plane, int roff, int fl, int sb, int nz, int nsum, double i0, double i1,
+                                       double i2, double &r0, double &r1, double &r2) {
+  __syncthreads();
+  if (sb < nsum) {
+    double acc = (sb == 0) ? i0 : ((sb == 1) ? i1 : i2);
+    const int base = sb * plane + fl;
+#pragma unroll 8
+    for (int k = 0; k < nz; k++) acc = acc + fsm[base + k * FC_FL];
+    fsm[roff + sb * FC_FL + fl] = acc;
+  }
+  __syncthreads();
+  r0 = fsm[roff + fl];
+  r1 = (nsum > 1) ? fsm[roff + FC_FL + fl] : 0.;
+  r2 = (nsum > 2) ? fsm[roff + 2 * FC_FL + fl] : 0.;
+}
+
+template <int KS, int NW>
+constexpr size_t fc3_lds_bytes() { return ((size_t)3 * KS * 2 * NW * FC_FL + 8 * FC_FL + 2 * NW * FC_FL + 15 * FC_FL + 6 * FC_FL) * sizeof(double); }
+
+template <int DIR, int KS, int NW, int WPE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void cont_flux_coop3_kernel(FluxArgs p) {
+  // two work planes [KS*NS][FC_FL] of layer values and the plane of visc_rem, then results [8][FC_FL], visc_rem max [NS][FC_FL],
+  // per-face values [15][FC_FL], the Newton bracket [2 phases][3][FC_FL]
+#ifdef FC_TRACE
+  unsigned long long fc_t0 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) atomicAdd(&fc_trace[64 * DIR + 15], 1ull);
+#endif
+  extern __shared__ double fsm[];
+  constexpr int NS = 2 * NW;
+  const m6::GridDev &g = p.g;
+  const Dir<DIR> D(g);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int fl = lane & (FC_FL - 1), sb = 2 * w + (lane >> 5);      // face within the block; layer slab of this half-wave
+  const int nz = g.nk;
+  constexpr int FPB = (DIR == 0) ? FC_FL - 1 : FC_FL;      // faces per block (the last zonal lane only serves its neighbour)
+  const int fi_raw = p.fi0 + blockIdx.x * FPB + fl;
+  const bool valid = fl < FPB && fi_raw <= p.fi1;
+  const int fi_last = (DIR == 0) ? p.fi1 + 1 : p.fi1;
+  const int fi = (fi_raw <= fi_last) ? fi_raw : fi_last;
+  const int fj = p.fj0 + blockIdx.y;
+  const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
+  const long s = D.sa(), fs = D.fsa();
+  const long o2 = g.h2(fi, fj), f2 = D.f2(fi, fj);
+  constexpr int PL = KS * NS * FC_FL;          // one plane
+  constexpr int RO = 3 * PL, VO = RO + 8 * FC_FL; // results, visc_rem max
+  constexpr int CO = VO + NS * FC_FL;          // per-face values parked between the phases
+  constexpr int PK_DXW = CO + 6 * FC_FL, PK_DXE = CO + 7 * FC_FL, PK_MF = CO + 8 * FC_FL, PK_IAT = CO + 9 * FC_FL,
+                PK_UHBT = CO + 10 * FC_FL, PK_DLC = CO + 11 * FC_FL, PK_DLF = CO + 12 * FC_FL, PK_CM = CO + 13 * FC_FL,
+                PK_CP = CO + 14 * FC_FL;
+  constexpr int PV = CO + 15 * FC_FL;
+  const int k0 = sb * KS;
+  const int sl = k0 * FC_FL + fl;                 // this thread's slot of layer k0 in a plane
+#define VR(m) fsm[2 * PL + sl + (m) * FC_FL]
+
+  // ---- the thread's layers into registers (every global load issued before anything is computed from one of them)
+  const bool wide = !(p.o.upwind_1st || p.o.simple_2nd);      // the 5-point stencil is only read by the PPM branch
+  const long s2w = wide ? 2 * s : 0, s3w = (wide && DIR == 1) ? 3 * s : 0;
+  double dLf_r = D.dL_face()[f2];
+  double cm_r = (p.o.vol_CFL ? g.IareaT : D.IdL_T())[o2], cp_r = (p.o.vol_CFL ? g.IareaT : D.IdL_T())[o2 + s];
+  double mk[6];                                               // mask2dT of cells -2 .. +3 along the direction
+  {
+    const double *mm = g.mask2dT + o2;
+    mk[0] = mm[-s2w]; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s];
+    mk[5] = mm[s3w];      // (only the meridional pair of reconstructions reads cell +3)
+  }
+  double pk_aW = g.areaT[o2], pk_aE = g.areaT[o2 + s], pk_dW = D.dL_T()[o2], pk_dE = D.dL_T()[o2 + s], pk_mf = D.mask_face()[f2];
+  double pk_iW = g.IareaT[o2], pk_iE = g.IareaT[o2 + s], pk_ub = p.uhbt ? p.uhbt[f2] : 0.0, pk_lc = D.dLC_face()[f2];
+  constexpr int KP = (DIR == 1) ? KS : 1;      // the plus-side cell is held only meridionally
+  double ru[KS], sL[KS], sR[KS], sC[KS], tL[KP], tR[KP], tC[KP];
+  constexpr int NH = (DIR == 0) ? 5 : 6;      // cells -2 .. +2 along the direction (+3 for the meridional pair)
+  double hr[KS][NH];
+  {
+    double rvr[KS];
+    {
+      const char *ub = (const char *)p.u, *vb = p.visc_rem ? (const char *)p.visc_rem : ub;      // (no branch around a load)
+      const char *hb[NH];
+#pragma unroll
+      for (int q = 0; q < NH; q++) {
+        const long disp = (q == 0) ? -s2w : ((q == 5) ? s3w : (q - 2) * s);
+        hb[q] = (const char *)(p.h_in + disp);
+      }
+      const unsigned o2b = (unsigned)(o2 * 8), f2b = (unsigned)(f2 * 8), hstep = (unsigned)(hpl * 8), fstep = (unsigned)(fpl * 8);
+#pragma unroll
+      for (int m = 0; m < KS; m++) {
+        const unsigned k = (unsigned)((k0 + m < nz) ? k0 + m : nz - 1);
+        const unsigned vh = o2b + k * hstep, vf = f2b + k * fstep;
+        ru[m] = *(const double *)(ub + vf);
+        rvr[m] = *(const double *)(vb + vf);
+#pragma unroll
+        for (int q = 0; q < NH; q++) hr[m][q] = *(const double *)(hb[q] + vh);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < KS; m++) {      // (a use of every loaded value here: none of the loads can sink into the code below)
+      pin(ru[m]); pin(rvr[m]);
+#pragma unroll
+      for (int q = 0; q < NH; q++) pin(hr[m][q]);
+    }
+    pin(dLf_r); pin(cm_r); pin(cp_r);
+    FC_MARK(0);
+    double vmax_w = 0.0;
+#pragma unroll
+    for (int m = 0; m < KS; m++) {      // visc_rem to its plane (zero past nk, one without visc_rem); its maximum over the thread's layers
+      double vr = p.visc_rem ? rvr[m] : 1.0;
+      if (k0 + m >= nz) { vr = 0.0; ru[m] = 0.0; }
+      VR(m) = vr;
+      vmax_w = max2(vmax_w, vr);
+    }
+    fsm[VO + sb * FC_FL + fl] = vmax_w;
+#pragma unroll
+    for (int q = 0; q < 6; q++) pin(mk[q]);
+    if (!wide) { mk[0] = 0.0; mk[5] = 0.0; }
+    if (DIR == 0) mk[5] = 0.0;
+  }
+  // The per-face values of the later phases go to LDS at once (every half-wave stores the same values: no ordering between them
+  // is needed, and none of them is held in registers through the reconstruction); the face constants of flux_layer are read
+  // back from there by every pass
+  bool dead_lane;
+  {
+    const double dLf = dLf_r;
+    const double cm = p.o.vol_CFL ? (dLf * cm_r) : cm_r;      // the CFL factor of the minus / plus side cell
+    const double cp = p.o.vol_CFL ? (dLf * cp_r) : cp_r;
+    pin(pk_aW); pin(pk_aE); pin(pk_dW); pin(pk_dE); pin(pk_mf); pin(pk_iW); pin(pk_iE); pin(pk_ub); pin(pk_lc);
+    double dxw, dxe;
+    if (p.o.vol_CFL) {
+      dxw = ratio_max(pk_aW, dLf, 1000.0 * pk_dW);
+      dxe = ratio_max(pk_aE, dLf, 1000.0 * pk_dE);
+    } else { dxw = pk_dW; dxe = pk_dE; }
+    fsm[PK_DXW + fl] = dxw; fsm[PK_DXE + fl] = dxe; fsm[PK_MF + fl] = pk_mf; fsm[PK_IAT + fl] = min2(pk_iW, pk_iE);
+    fsm[PK_UHBT + fl] = pk_ub; fsm[PK_DLC + fl] = pk_lc;
+    fsm[PK_DLF + fl] = dLf; fsm[PK_CM + fl] = cm; fsm[PK_CP + fl] = cp;
+    dead_lane = (pk_mf == 0.0) & (dLf_r == 0.0) & (pk_ub == 0.0);
+  }
+#define FC3_FACE(F) FaceConst F; F.dLf = fsm[PK_DLF + fl]; F.cm = fsm[PK_CM + fl]; F.cp = fsm[PK_CP + fl]; F.dt = p.dt
+  // the plus-side cell of layer m: the next lane's cell (zonal; fetched outside every condition: a DPP fetch needs its source
+  // lane active), or the thread's own registers (meridional)
+#define FC3_PLUS(m) \
+  const double pL_ = DIR ? tL[DIR ? (m) : 0] : dpp_next_lane(sL[m]), pR_ = DIR ? tR[DIR ? (m) : 0] : dpp_next_lane(sR[m]), \
+               pC_ = DIR ? tC[DIR ? (m) : 0] : dpp_next_lane(sC[m])
+
+  // ---- blocks whose 32 faces are all land: nothing to solve (see cont_flux_coop_kernel)
+#pragma unroll
+  for (int m = 0; m < KS; m++) dead_lane = dead_lane & (ru[m] == 0.0);      // (layers past nk hold zero)
+  const bool dead = __syncthreads_and(dead_lane ? 1 : 0) != 0;
+  if (dead && !p.set_BT_cont) {
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < KS; m++) {
+        if (k0 + m < nz) {
+          p.uh[f2 + (k0 + m) * fpl] = 0.0;
+          if (p.uhbt && p.u_cor) p.u_cor[f2 + (k0 + m) * fpl] = ru[m] + 0.0 * VR(m);
+        }
+      }
+      if (sb == 0 && p.du_cor) p.du_cor[f2] = 0.0;
+    }
+    return;
+  }
+  // the edge values of the cells (cont_edge_kernel's arithmetic, PPM_reconstruction_x/y :2310-2662): h_L / h_R never go through memory
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    const int k = k0 + m;
+    if (k < nz) {
+      const double hm1 = hr[m][1], hc0 = hr[m][2], hp1 = hr[m][3], hp2 = hr[m][4];
+      double Lm, Rm;
+      if (DIR == 0) {
+        if (p.o.upwind_1st) { Lm = hc0; Rm = hc0; }
+        else edge_values(p.o, g.Angstrom_H, hr[m][0], hm1, hc0, hp1, wide ? hp2 : 0.0, mk[0], mk[1], mk[2], mk[3],
+                         wide ? mk[4] : 0.0, Lm, Rm);
+      } else {      // both cells at once: the slopes of the two cells serve both reconstructions
+        const double h6[6] = {hr[m][0], hm1, hc0, hp1, hp2, hr[m][NH - 1]};
+        double Lp, Rp;
+        edge_values2(p.o, g.Angstrom_H, h6, mk, Lm, Rm, Lp, Rp);
+        tL[DIR ? m : 0] = Lp; tR[DIR ? m : 0] = Rp; tC[DIR ? m : 0] = Lp + Rp - 2.0 * hp1;
+      }
+      sL[m] = Lm; sR[m] = Rm; sC[m] = Lm + Rm - 2.0 * hc0;
+    } else {
+      sL[m] = 0.; sR[m] = 0.; sC[m] = 0.;
+      if (DIR) { tL[DIR ? m : 0] = 0.; tR[DIR ? m : 0] = 0.; tC[DIR ? m : 0] = 0.; }
+    }
+  }
+  FC_MARK(1);
+  if (dead) {      // (set_BT_cont: the layer data are needed for h_u / h_v and u_cor; every sum of the fits is +0)
+    FC3_FACE(F0);
+    const double du_dead = 0.0;
+    const bool cor_d = p.uhbt && p.u_cor;
+#pragma unroll
+    for (int m = 0; m < KS; m++) {
+      FC3_PLUS(m);
+      if (k0 + m < nz) {
+        const long f3 = f2 + (k0 + m) * fpl;
+        const double vr = VR(m), uk = ru[m];
+        if (valid) p.uh[f3] = 0.0;
+        double uc = uk;
+        if (cor_d) { uc = uk + du_dead * vr; if (valid) p.u_cor[f3] = uc; }
+        if (p.h_face) {
+          const double hu = thick_lrc(F0, p.o.marginal_faces, p.visc_rem != nullptr, uc, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_);
+          if (valid) p.h_face[f3] = hu;
+        }
+      }
+    }
+    if (sb == 0 && valid) {
+      if (p.du_cor) p.du_cor[f2] = p.uhbt ? du_dead : 0.0;
+      p.FA_0m[f2] = 0.0; p.FA_mm[f2] = 0.0; p.uBT_mm[f2] = 0.0;
+      p.FA_0p[f2] = 0.0; p.FA_pp[f2] = 0.0; p.uBT_pp[f2] = 0.0;
+    }
+    return;
+  }
+
+  // ---- layer transports and marginal areas, :622-635
+  {
+  FC3_FACE(F0);
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    FC3_PLUS(m);
+    if (FC3_LIVE(m)) {
+      double dd;
+      const double uhk = flux_lrc(F0, ru[m], VR(m), sL[m], sR[m], sC[m], pL_, pR_, pC_, dd);
+      if (valid && !p.uhbt && k0 + m < nz) p.uh[f2 + (k0 + m) * fpl] = uhk;      // (with uhbt, uh is stored once, after the solve)
+      fsm[sl + m * FC_FL] = uhk; fsm[PL + sl + m * FC_FL] = dd;
+    }
+    FC3_SCHED(m);
+  }
+  }
+  double uh_tot_0, duhdu_tot_0, dummy;
+  ksums3(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, uh_tot_0, duhdu_tot_0, dummy);
+  double visc_rem_max = 0.0;
+  for (int q = 0; q < NS; q++) visc_rem_max = max2(visc_rem_max, fsm[VO + q * FC_FL + fl]);      // (max is order-free)
+  if (!(p.visc_rem && p.o.use_visc_rem_max)) visc_rem_max = 1.0;
+  FC_MARK(2);
+
+  // ---- the CFL brackets of the velocity correction, :637-716: two chains through k; what a layer hands to the chain -- the bound
+  // the bracket is tested against and the value it takes when the test fails (a division) -- does not depend on the running state
+  // and is formed by all threads for their own layers first (work planes 0 / 1 = bound, new bracket; visc_rem in its own plane)
+  double CFL_dt = p.o.CFL_limit_adjust / p.dt;
+  const double I_dt = 1.0 / p.dt;
+  if (p.o.aggress_adjust) CFL_dt = I_dt;
+  double I_vrm = 0.0;
+  if (visc_rem_max > 0.0) I_vrm = 1.0 / visc_rem_max;
+  {
+    const double dx_W = fsm[PK_DXW + fl], dx_E = fsm[PK_DXE + fl], mface = fsm[PK_MF + fl];
+    // (no barrier needed before the planes are rewritten: every read of them lies between the two barriers of ksums3)
+#pragma unroll
+    for (int m = 0; m < KS; m++) {
+      if (k0 + m < nz) {
+        const double uk = ru[m], vr = VR(m);
+        double bound, cand;
+        if (p.o.aggress_adjust) {
+          bound = 0.499 * ((dx_W * I_dt - uk) + min2(0.0, p.u[f2 + (k0 + m) * fpl - fs]));
+          cand = p.visc_rem ? bound / vr : bound;
+        } else if (p.visc_rem) {
+          bound = dx_W * CFL_dt - uk * mface; cand = (dx_W * CFL_dt - uk) / vr;
+        } else {
+          bound = dx_W * CFL_dt - uk; cand = bound;
+        }
+        fsm[sl + m * FC_FL] = bound; fsm[PL + sl + m * FC_FL] = cand;
+      }
+    }
+    __syncthreads();
+    if (sb == 0) {
+      double du_max_CFL = 2.0 * (CFL_dt * dx_W) * I_vrm;
+      if (p.visc_rem) {
+#pragma unroll FC3_CHAIN_UNROLL
+        for (int k = 0; k < nz; k++) {      // (all three loads up front: no LDS round trip inside the dependent chain)
+          const double vr = fsm[2 * PL + k * FC_FL + fl], bound = fsm[k * FC_FL + fl], cand = fsm[PL + k * FC_FL + fl];
+          du_max_CFL = (du_max_CFL * vr > bound) ? cand : du_max_CFL;
+        }
+      } else {
+#pragma unroll FC3_CHAIN_UNROLL
+        for (int k = 0; k < nz; k++) du_max_CFL = min2(du_max_CFL, fsm[PL + k * FC_FL + fl]);
+      }
+      fsm[CO + fl] = max2(du_max_CFL, 0.0);
+      fsm[CO + 2 * FC_FL + fl] = uh_tot_0; fsm[CO + 3 * FC_FL + fl] = duhdu_tot_0; fsm[CO + 4 * FC_FL + fl] = visc_rem_max;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < KS; m++) {
+      if (k0 + m < nz) {
+        const double uk = ru[m], vr = VR(m);
+        double bound, cand;
+        if (p.o.aggress_adjust) {
+          bound = 0.499 * ((-dx_E * I_dt - uk) + max2(0.0, p.u[f2 + (k0 + m) * fpl + fs]));
+          cand = p.visc_rem ? bound / vr : bound;
+        } else if (p.visc_rem) {
+          bound = -dx_E * CFL_dt - uk * mface; cand = -(dx_E * CFL_dt + uk) / vr;
+        } else {
+          bound = -(dx_E * CFL_dt + uk); cand = bound;
+        }
+        fsm[sl + m * FC_FL] = bound; fsm[PL + sl + m * FC_FL] = cand;
+      }
+    }
+    __syncthreads();
+    if (sb == 0) {
+      double du_min_CFL = -2.0 * (CFL_dt * dx_E) * I_vrm;
+      if (p.visc_rem) {
+#pragma unroll FC3_CHAIN_UNROLL
+        for (int k = 0; k < nz; k++) {
+          const double vr = fsm[2 * PL + k * FC_FL + fl], bound = fsm[k * FC_FL + fl], cand = fsm[PL + k * FC_FL + fl];
+          du_min_CFL = (du_min_CFL * vr < bound) ? cand : du_min_CFL;
+        }
+      } else {
+#pragma unroll FC3_CHAIN_UNROLL
+        for (int k = 0; k < nz; k++) du_min_CFL = max2(du_min_CFL, fsm[PL + k * FC_FL + fl]);
+      }
+      fsm[CO + FC_FL + fl] = min2(du_min_CFL, 0.0);
+    }
+    __syncthreads();
+  }
+  FC_MARK(3);
+
+  // ---- flux_adjust :1094-1243 for the faces of the block: phase 0 matches uhbt (:737-754, storing the transports),
+  // phase 1 finds the correction that gives no net transport for set_*_BT_cont (:1290-1292)
+  double du_ph[2] = {0.0, 0.0};
+#pragma unroll 1
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 0 ? (p.uhbt == nullptr) : !p.set_BT_cont) continue;
+    const bool write_uh = (phase == 0);
+    const double uhbt = (phase == 0) ? fsm[PK_UHBT + fl] : 0.0;
+    const int max_itts = 20;
+    double du = 0.0;
+    double uh_err = fsm[CO + 2 * FC_FL + fl] - uhbt, duhdu_tot = fsm[CO + 3 * FC_FL + fl];
+    // du_max, du_min, uh_err_best: one copy per phase (a half-wave that leaves the loop of phase 0 early must not see phase 1's)
+    const int pv = PV + phase * 3 * FC_FL + fl;
+    fsm[pv] = fsm[CO + fl]; fsm[pv + FC_FL] = fsm[CO + FC_FL + fl]; fsm[pv + 2 * FC_FL] = fabs(uh_err);
+    double du_eval = 0.0;      // du of this face's last re-evaluation of the transports (what uh_3d holds in the reference)
+    bool do_I = true, alive = valid;
+#pragma unroll 1
+    for (int itt = 1; itt <= max_itts; itt++) {
+      bool domore = false;
+      if (alive) {
+        double tol_eta;
+        if (itt <= 1) tol_eta = 1e-6 * p.o.tol_eta;
+        else if (itt == 2) tol_eta = 1e-4 * p.o.tol_eta;
+        else if (itt == 3) tol_eta = 1e-2 * p.o.tol_eta;
+        else tol_eta = p.o.tol_eta;
+        const double tol_vel = p.o.tol_vel;
+        double du_max = fsm[pv], du_min = fsm[pv + FC_FL];
+        const double uh_err_best = fsm[pv + 2 * FC_FL], IaT = fsm[PK_IAT + fl];
+        if (uh_err > 0.0) { du_max = du; fsm[pv] = du; }
+        else if (uh_err < 0.0) { du_min = du; fsm[pv + FC_FL] = du; }
+        else do_I = false;
+        if (do_I) {
+          if ((p.dt * IaT * fabs(uh_err) > tol_eta) ||
+              (p.o.better_iter && ((fabs(uh_err) > tol_vel * duhdu_tot) || (fabs(uh_err) > uh_err_best)))) {
+            const double ddu = -uh_err / duhdu_tot;
+            const double du_prev = du;
+            du = du + ddu;
+            if (fabs(ddu) < 1.0e-15 * fabs(du)) {
+              do_I = false;
+            } else if (ddu > 0.0) {
+              if (du >= du_max) {
+                du = 0.5 * (du_prev + du_max);
+                if (du_max - du_prev < 1.0e-15 * fabs(du)) do_I = false;
+              }
+            } else {
+              if (du <= du_min) {
+                du = 0.5 * (du_prev + du_min);
+                if (du_prev - du_min < 1.0e-15 * fabs(du)) do_I = false;
+              }
+            }
+            if (do_I) domore = true;
+          } else {
+            do_I = false;
+          }
+        }
+        if (!domore) alive = false;
+      }
+      if (!__any(alive)) break;      // the same in every wave of the block: they hold the same values
+      if ((itt < max_itts) || write_uh) {
+#ifdef FC_TRACE
+        if (threadIdx.x == 0) atomicAdd(&fc_trace[64 * DIR + 14], 1ull);
+#endif
+        if (alive) du_eval = du;
+        FC3_FACE(F);
+#pragma unroll
+        for (int m = 0; m < KS; m++) {
+          pin(sC[m]);
+          FC3_PLUS(m);
+          if (FC3_LIVE(m)) {
+            double dd;
+            const double vr = VR(m);
+            const double uhk = flux_lrc(F, ru[m] + du * vr, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_, dd);
+            fsm[sl + m * FC_FL] = uhk; fsm[PL + sl + m * FC_FL] = dd;
+          }
+          FC3_SCHED(m);
+        }
+        double usum, dsum, d2;
+        ksums3(fsm, PL, RO, fl, sb, nz, 2, -uhbt, 0.0, 0.0, usum, dsum, d2);
+        if (alive && itt < max_itts) {
+          uh_err = usum; duhdu_tot = dsum;
+          fsm[pv + 2 * FC_FL] = min2(fsm[pv + 2 * FC_FL], fabs(uh_err));
+        }
+      }
+    }
+    du_ph[phase] = du;
+    FC_MARK(4 + phase);
+    if (write_uh) {
+      // The reference stores the layer transports on every re-evaluation (uh_3d); what remains is the last one of each
+      // face, or the first evaluation for a face that never iterated (du_eval = 0: u + 0*visc_rem is u).  Stored once here.
+      FC3_FACE(F);
+#pragma unroll
+      for (int m = 0; m < KS; m++) {
+        pin(sC[m]);
+        FC3_PLUS(m);
+        if (FC3_LIVE(m)) {
+          double dd;
+          const double vr = VR(m);
+          const double uhk = flux_lrc(F, ru[m] + du_eval * vr, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_, dd);
+          if (valid && k0 + m < nz) p.uh[f2 + (k0 + m) * fpl] = uhk;
+        }
+        FC3_SCHED(m);
+      }
+    }
+  }
+  const double du = du_ph[0], du0 = du_ph[1];
+
+  if (valid) {
+    if (p.uhbt && p.u_cor && !p.set_BT_cont) {      // with BT_cont, u_cor is written in the pass of the fits below
+#pragma unroll
+      for (int m = 0; m < KS; m++)
+        if (k0 + m < nz) p.u_cor[f2 + (k0 + m) * fpl] = ru[m] + du * VR(m);
+    }
+    if (sb == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
+  }
+  FC_MARK(6);
+  if (!p.set_BT_cont) return;
+  FC3_FACE(F);
+
+  // ---- set_zonal_BT_cont :1247-1410
+  const double min_visc_rem = 0.1, CFL_min = 1e-6;
+  const double du_CFL = (CFL_min * I_dt) * fsm[PK_DLC + fl];
+  // The duR / duL limits (:1321-1330) are chains through k as well: the quotient a layer hands to the chain when its test fires
+  // is formed by all threads for their own layers first (work planes 0 / 1 = u, quotient; one chain at a time)
+  const double lim0 = min_visc_rem * fsm[CO + 4 * FC_FL + fl];
+#pragma unroll 1
+  for (int side = 0; side < 2; side++) {      // 0: duR (c = du_CFL, test ">"), 1: duL (c = -du_CFL, test "<")
+    const double c = side ? -du_CFL : du_CFL;
+#pragma unroll
+    for (int m = 0; m < KS; m++) {
+      if (k0 + m < nz) {
+        const double vr = VR(m), uk = ru[m];
+        const double visc_rem_lim = max2(vr, lim0);
+        if (side == 0) fsm[sl + m * FC_FL] = uk;
+        fsm[PL + sl + m * FC_FL] = (visc_rem_lim > 0.0) ? -(uk + c * vr) / visc_rem_lim : 0.0;
+      }
+    }
+    __syncthreads();
+    if (sb == 0) {
+      double dlim = side ? max2(0.0, du0 - c) : min2(0.0, du0 - c);
+      // branch-free steps (the tests combined with &, the sense of the comparison carried by a sign: x < y is -x > -y to the bit)
+      const double mc = -c, sg = side ? -1.0 : 1.0;
+#pragma unroll FC3_CHAIN_UNROLL
+      for (int k = 0; k < nz; k++) {
+        const double uk = fsm[k * FC_FL + fl], vr = fsm[2 * PL + k * FC_FL + fl], q = fsm[PL + k * FC_FL + fl];
+        const double visc_rem_lim = max2(vr, lim0);
+        const double t = uk + dlim * visc_rem_lim, r = mc * vr;
+        const bool fire = (visc_rem_lim > 0.0) & (sg * t > sg * r);
+        dlim = fire ? q : dlim;
+      }
+      fsm[RO + side * FC_FL + fl] = dlim;
+    }
+    __syncthreads();
+  }
+  const double duR = fsm[RO + fl], duL = fsm[RO + FC_FL + fl];
+  FC_MARK(7);
+  const bool cor = p.uhbt && p.u_cor;
+  // The three evaluations of every layer, each done once.  First round: the one at duL (sums FAmt_L and uhtot_L), with u_cor
+  // (:744-748) and flux_thickness (:976-1057, with u_cor if present :809-815) riding on the same layer data.  Second round: the
+  // ones at duR and du0 (FAmt_R, uhtot_R, FAmt_0): it is the last use of visc_rem, whose plane takes the third set of values.
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    pin(sC[m]);
+    FC3_PLUS(m);
+    if (FC3_LIVE(m)) {
+      const long f3 = f2 + (k0 + m) * fpl;
+      const double vr = VR(m), uk = ru[m];
+      const bool st = valid && (k0 + m < nz);
+      double dL;
+      const double uh_L = flux_lrc(F, uk + duL * vr, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_, dL);
+      fsm[sl + m * FC_FL] = dL; fsm[PL + sl + m * FC_FL] = uh_L;
+      double uc = uk;
+      if (cor) { uc = uk + du * vr; if (st) p.u_cor[f3] = uc; }
+      if (p.h_face) {
+        const double hu = thick_lrc(F, p.o.marginal_faces, p.visc_rem != nullptr, uc, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_);
+        if (st) p.h_face[f3] = hu;
+      }
+    }
+    FC3_SCHED(m);
+  }
+  double FAmt_0, FAmt_L, FAmt_R, uhtot_L, uhtot_R, d2;
+  ksums3(fsm, PL, RO, fl, sb, nz, 2, 0.0, 0.0, 0.0, FAmt_L, uhtot_L, d2);
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    pin(sC[m]);
+    FC3_PLUS(m);
+    if (FC3_LIVE(m)) {
+      double dR, d0;
+      const double vr = VR(m), uk = ru[m];
+      const double uh_R = flux_lrc(F, uk + duR * vr, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_, dR);
+      (void)flux_lrc(F, uk + du0 * vr, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_, d0);
+      fsm[sl + m * FC_FL] = dR; fsm[PL + sl + m * FC_FL] = uh_R; VR(m) = d0;
+    }
+    FC3_SCHED(m);
+  }
+  ksums3(fsm, PL, RO, fl, sb, nz, 3, 0.0, 0.0, 0.0, FAmt_R, uhtot_R, FAmt_0);
+  FC_MARK(8);
+  if (sb == 0 && valid) {
+    double FA_0 = FAmt_0, FA_avg = FAmt_0;
+    if ((duL - du0) != 0.0) FA_avg = uhtot_L / (duL - du0);
+    if (FA_avg > max2(FA_0, FAmt_L)) FA_avg = max2(FA_0, FAmt_L);
+    else if (FA_avg < min2(FA_0, FAmt_L)) FA_0 = FA_avg;
+    p.FA_0m[f2] = FA_0; p.FA_mm[f2] = FAmt_L;
+    if (fabs(FA_0 - FAmt_L) <= 1e-12 * FA_0) p.uBT_mm[f2] = 0.0;
+    else p.uBT_mm[f2] = (1.5 * (duL - du0)) * ((FAmt_L - FA_avg) / (FAmt_L - FA_0));
+
+    FA_0 = FAmt_0; FA_avg = FAmt_0;
+    if ((duR - du0) != 0.0) FA_avg = uhtot_R / (duR - du0);
+    if (FA_avg > max2(FA_0, FAmt_R)) FA_avg = max2(FA_0, FAmt_R);
+    else if (FA_avg < min2(FA_0, FAmt_R)) FA_0 = FA_avg;
+    p.FA_0p[f2] = FA_0; p.FA_pp[f2] = FAmt_R;
+    if (fabs(FAmt_R - FA_0) <= 1e-12 * FA_0) p.uBT_pp[f2] = 0.0;
+    else p.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
+  }
+#undef FC3_PLUS
+#undef FC3_FACE
+#undef VR
+}
+
 // MOM6HIP_CONT_FLUX_LANE=1 keeps the lane-per-column kernel for every call (comparison runs)
 bool flux_lane_only() {
   static const int v = [] { const char *e = getenv("MOM6HIP_CONT_FLUX_LANE"); return (e && e[0] == '1') ? 1 : 0; }();
@@ -1141,10 +1730,30 @@ bool flux_lane_only() {
 
 // Whether a flux launch takes the block-cooperative kernel (which forms the edge values itself): when there is a velocity
 // correction or BT_cont to compute and the layers fit its registers; the single-pass lane-per-column kernel otherwise.
+// The shape of the block-cooperative kernel for deep columns: MOM6HIP_CONT_COOP=4x10 keeps round 1's (4 waves x 10 layers a thread, two
+// waves a SIMD); 6x7 and 8x5 are round 5's cont_flux_coop3_kernel at three and four waves a SIMD
+// (defaults from profiles/r05_experiments.txt: zonally 8 x 5 at four waves a SIMD; meridionally the thread holds both cells of a
+// face, 7 doubles a layer, and spills at every shape that fits three or four waves: round 1's kernel stays)
+#ifndef FC3_DEFAULT_X
+#define FC3_DEFAULT_X 85
+#endif
+#ifndef FC3_DEFAULT_Y
+#define FC3_DEFAULT_Y 410
+#endif
+int flux_coop_shape(int dir) {      // 410, 67 or 85
+  static const int v[2] = {
+      [] { const char *e = getenv("MOM6HIP_CONT_COOP_X"); if (!e) e = getenv("MOM6HIP_CONT_COOP"); return e ? (strcmp(e, "4x10") == 0 ? 410 : (strcmp(e, "8x5") == 0 ? 85 : 67)) : FC3_DEFAULT_X; }(),
+      [] { const char *e = getenv("MOM6HIP_CONT_COOP_Y"); if (!e) e = getenv("MOM6HIP_CONT_COOP"); return e ? (strcmp(e, "4x10") == 0 ? 410 : (strcmp(e, "8x5") == 0 ? 85 : 67)) : FC3_DEFAULT_Y; }()};
+  return v[dir];
+}
+int flux_coop_nk_max() { return std::min(flux_coop_shape(0) == 410 ? FC_KSMAX * FC_NS : (flux_coop_shape(0) == 67 ? 84 : 80),
+                                         flux_coop_shape(1) == 410 ? FC_KSMAX * FC_NS : (flux_coop_shape(1) == 67 ? 84 : 80)); }
+
 bool flux_is_coop(const FluxArgs &f) {
   // (and a 3-D array stays below 4 GB: the kernel addresses its layers with 32-bit byte offsets)
   const bool small = (size_t)(f.g.nih + 1) * (f.g.njh + 1) * f.g.nk * sizeof(double) < ((size_t)1 << 32);
-  return (f.uhbt || f.set_BT_cont) && f.g.nk <= FC_KSMAX * FC_NS && small && !flux_lane_only() && !f.obc_on;      // (OBC: the lane kernel)
+  const int nk_max = flux_coop_nk_max();
+  return (f.uhbt || f.set_BT_cont) && f.g.nk <= nk_max && small && !flux_lane_only() && !f.obc_on;      // (OBC: the lane kernel)
 }
 
 template <int DIR>
@@ -1165,6 +1774,18 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     };
     if (nk <= FC_NS) return go(cont_flux_coop_kernel<DIR, 1>, 1);
     if (nk <= 4 * FC_NS) return go(cont_flux_coop_kernel<DIR, 4>, 4);
+    auto go3 = [&](auto kern, int nw, size_t lds) -> int {
+      std::vector<const void *> &configured = ctx->lds_configured;
+      if (std::find(configured.begin(), configured.end(), (const void *)kern) == configured.end()) {
+        M6_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured.push_back((const void *)kern);
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, ctx->stream, f);
+      return 0;
+    };
+    const int shape = flux_coop_shape(DIR);
+    if (shape == 67) return go3(cont_flux_coop3_kernel<DIR, 7, 6, 3>, 6, fc3_lds_bytes<7, 6>());
+    if (shape == 85) return go3(cont_flux_coop3_kernel<DIR, 5, 8, 4>, 8, fc3_lds_bytes<5, 8>());
     return go(cont_flux_coop_kernel<DIR, FC_KSMAX>, FC_KSMAX);
   }
   hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
@@ -1207,8 +1828,8 @@ __global__ __launch_bounds__(256) void cont_conv_kernel(ConvArgs p) {
 
 #ifdef FC_TRACE
 extern "C" int mom6hip_fc_trace(unsigned long long *out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_trace), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
-  if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fc_trace), z, sizeof(z)) != hipSuccess) return 1; }
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fc_trace), sizeof(unsigned long long) * 128) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[128] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(fc_trace), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
 }
 #endif

@@ -111,12 +111,13 @@ def test_gpu_parity(oracle, variant, first_direction):
     from mom6_amd.continuity import BT_cont_type, continuity
     from mom6_amd.tracer_advect import DeviceGrid
     cskw = VARIANTS[variant]
-    # nk = 20 and 75 reach the 4- and 10-layers-per-slab forms of the block-cooperative flux kernel, nk = 90 is past its
-    # register budget and takes the lane-per-column kernels
+    # nk = 20 and 75 reach the 4-layers-per-slab form and the deep form (6 waves x 7 layers, or MOM6HIP_CONT_COOP = 8x5 / 4x10) of the
+    # block-cooperative flux kernel, nk = 83 the last, partly filled slab of the 6 x 7 form; nk = 90 is past its register budget and
+    # takes the lane-per-column kernels
     # the last grid has halo = the PPM stencil (3): the first pass then runs to the very edge of the data domain
     for (ni, nj, nk, topo, halo) in [(70, 21, 4, (True, False), 4), (44, 40, 2, (True, True), 4), (10, 8, 8, (False, False), 4),
                                      (36, 13, 20, (True, True), 4), (67, 9, 75, (True, False), 4), (14, 9, 90, (True, False), 4),
-                                     (61, 12, 12, (True, True), 3)]:
+                                     (61, 12, 12, (True, True), 3), (33, 8, 83, (True, False), 4)]:
         g, st = cont_case(ni, nj, nk, seed=ni, first_direction=first_direction, reentrant_x=topo[0], reentrant_y=topo[1], halo=halo)
         dg = DeviceGrid(g)
         cs = oracle.continuity_cs(g.nk, g.Angstrom_H, **cskw)

@@ -31,12 +31,14 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 dg.kernel_timing(True)
 f(); torch.cuda.synchronize()
 t = dg.kernel_timing(False)
-out = (C.c_uint64 * 64)()
-L.mom6hip_fc_trace(out, 0)
-nb = out[15]
-tot = sum(out[i] for i in range(13))
-print(f"blocks {nb}  flux x {t[0][0]:.2f} ms  y {t[1][0]:.2f} ms   ticks/block {tot / nb:.0f}   newton passes/block {out[14] / nb:.2f}")
-for i in range(13):
-    print(f"  {names[i]:20s} {out[i] / nb:10.0f} ticks  {100.0 * out[i] / tot:5.1f} %")
-print("faces by passes alive :", [out[16 + n] for n in range(24)])
-print("solves by passes run  :", [out[40 + n] for n in range(24)])
+both = (C.c_uint64 * 128)()
+L.mom6hip_fc_trace(both, 0)
+for d in (0, 1):
+    out = both[64 * d:64 * d + 64]
+    nb = max(out[15], 1)
+    tot = max(sum(out[i] for i in range(13)), 1)
+    print(f"direction {'xy'[d]}: blocks {nb}  flux {t[d][0]:.2f} ms   ticks/block {tot / nb:.0f}   newton passes/block {out[14] / nb:.2f}")
+    for i in range(13):
+        print(f"  {names[i]:20s} {out[i] / nb:10.0f} ticks  {100.0 * out[i] / tot:5.1f} %")
+    print("faces by passes alive :", [out[16 + n] for n in range(24)])
+    print("solves by passes run  :", [out[40 + n] for n in range(24)])
