@@ -96,7 +96,9 @@ end subroutine max_real_0d
 end module MOM_coms
 
 module MOM_domains
+use MOM_coms, only : sum_across_PEs, min_across_PEs, max_across_PEs
 implicit none ; private
+public :: sum_across_PEs, min_across_PEs, max_across_PEs
 public :: MOM_domain_type, pass_var, pass_vector, CENTER, EAST_FACE, NORTH_FACE, CORNER, group_pass_type
 public :: To_East, To_West, To_North, To_South, To_All, Omit_Corners, AGRID, BGRID_NE, CGRID_NE, SCALAR_PAIR
 public :: create_group_pass, do_group_pass, start_group_pass, complete_group_pass
@@ -246,7 +248,7 @@ implicit none ; private
 public :: verticalGrid_type, get_thickness_units, get_flux_units, get_tr_flux_units
 type :: verticalGrid_type
   integer :: ke
-  real :: Angstrom_Z = 1.0e-10, Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
+  real :: Angstrom_m = 1.0e-10, Angstrom_Z = 1.0e-10, Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
           Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0, H_to_MKS = 1.0, &
           H_to_kg_m2 = 1035.0, kg_m2_to_H = 1.0/1035.0, HZ_T_to_m2_s = 1.0, HZ_T_to_MKS = 1.0
   integer :: nk_rho_varies = 0, nkml = 0
@@ -1321,6 +1323,7 @@ implicit none ; private
 public :: Wave_parameters_CS, Stokes_PGF
 type :: Wave_parameters_CS
   logical :: Stokes_VF = .false., Stokes_PGF = .false., Passive_Stokes_PGF = .false., Passive_Stokes_VF = .false., Stokes_DDT = .false.
+  real, allocatable, dimension(:,:,:) :: Us_x, Us_y
 end type Wave_parameters_CS
 contains
 subroutine Stokes_PGF(G, GV, US, dz, u, v, PFu_Stokes, PFv_Stokes, CS)

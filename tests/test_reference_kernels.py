@@ -1,0 +1,120 @@
+"""The reference's own kernels run beside the oracle (build container only: needs /root/reference and amdflang).
+
+The unmodified /root/reference/src/core/MOM_continuity_PPM.F90, MOM_CoriolisAdv.F90 and src/tracer/MOM_tracer_advect.F90 are compiled
+where they lie (amdflang -O0 -ffp-contract=off, the reference's own memory headers by -I) against the stand-ins of tests/fortran/stubs
+(parameter table, one-PE pass_var, empty diagnostics) and driven by tests/fortran/ref_kernels_driver.F90 on the inputs the oracle gets:
+continuity_PPM in the two call forms of the RK2 step (BT_cont; uhbt + u_cor + BT_cont), CorAdCalc, advect_tracer.  Their outputs have to
+equal oracle/*.c bit for bit.
+
+What this is and is not: SUPPLEMENTARY evidence.  A reference build that stands on hand-written stand-ins for
+MOM_grid / MOM_domains / MOM_file_parser ... pins nothing by this tier's rule, and the parity grade of these operators stays "unpinned".
+It does catch a misreading shared by oracle and kernel (ADVICE r04's `I` / `i` in advect_x would have failed here), and it is the
+per-kernel CPU calibration of bench.py's port (tools/calibrate_ref_kernels.py).  Nothing of it travels to the GPU box."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import bits_equal, interior
+from mom6_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+FC = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
+STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
+REF_SOURCES = ("src/core/MOM_continuity_PPM.F90", "src/core/MOM_CoriolisAdv.F90", "src/tracer/MOM_tracer_advect.F90")
+SCHEMES = {"PLM": 0, "PPM:H3": 1, "PPM": 2}
+
+pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference is not mounted (GPU box)"),
+              pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")]
+
+
+def build_ref_kernels(tmp, opt="-O0", openmp=False):
+    """the stand-ins, the three reference files (in place) and the driver -> an executable in tmp"""
+    flags = ["-cpp", "-fdefault-real-8", opt, "-ffp-contract=off", f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)] + (["-fopenmp"] if openmp else [])
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(REF, r) for r in REF_SOURCES] + \
+               [os.path.join(ROOT, "tests", "fortran", "ref_kernels_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "ref_kernels_driver")
+    r = subprocess.run([FC, *objs, "-o", exe] + (["-fopenmp"] if openmp else []), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def write_case(path, ni=30, nj=14, nk=4, scheme="PPM:H3", x_first=-1, seed=77, ntr=3, land_frac=0.2):
+    """the input file of ref_kernels_driver.F90; returns the grid, the oracle's inputs and what the oracle makes of them.
+    Closed in x and y: the stand-in's group passes (advect_tracer's) do nothing, which is what one closed tile needs."""
+    from mom6_amd import synth
+    from oracle import orc
+    halo = 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=land_frac, seed=seed, reentrant_x=False, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=5, umax=0.3, eta_amp=0.2).items()}
+    kk = (np.arange(nk) + 0.5) / nk
+    vru = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["u"], 0.0, 1.0) * (g.mask2dCu[None] > 0))
+    vrv = np.ascontiguousarray(np.clip(1.0 - 0.8 * kk[:, None, None] ** 2 + 0 * d["v"], 0.0, 1.0) * (g.mask2dCv[None] > 0))
+    dt = 900.0
+    ccs = orc.continuity_cs(nk, g.Angstrom_H)
+    hp = d["h"].copy(); uh = np.zeros_like(d["u"]); vh = np.zeros_like(d["v"])
+    arrs, bt = orc.make_bt_cont(g, with_h=True)
+    orc.continuity(g, ccs, d["u"], d["v"], d["h"], hp, uh, vh, dt, visc_rem_u=vru, visc_rem_v=vrv, bt_cont=bt)
+    first = {n: arrs[n].copy() for n in arrs}
+    uhbt = np.ascontiguousarray(uh.sum(0) * 1.02); vhbt = np.ascontiguousarray(vh.sum(0) * 0.98)
+    adv = synth.make_advection_state(g, ntr=ntr, seed=seed + 1, hot_frac=0.01, vanish_frac=0.05)
+    adv = {k: (v.numpy() if k != "tr" else [t.numpy() for t in v]) for k, v in adv.items()}
+    dt_adv = 3600.0
+    with open(path, "wb") as f:
+        np.array([ni, nj, nk, halo, 0, 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], uhbt, vhbt, vru, vrv, d["T"], d["S"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        np.array([ntr, x_first, 0, SCHEMES[scheme]], dtype="<i4").tofile(f)
+        np.array([dt_adv], dtype="<f8").tofile(f)
+        for a in [adv["h_end"], adv["uhtr"], adv["vhtr"]] + adv["tr"]:
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+    hp2 = d["h"].copy(); uh2 = np.zeros_like(d["u"]); vh2 = np.zeros_like(d["v"]); ucor = np.zeros_like(d["u"]); vcor = np.zeros_like(d["v"])
+    orc.continuity(g, ccs, d["u"], d["v"], d["h"], hp2, uh2, vh2, dt, uhbt=uhbt, vhbt=vhbt, visc_rem_u=vru, visc_rem_v=vrv, u_cor=ucor,
+                   v_cor=vcor, bt_cont=bt)
+    CAu, CAv = orc.coradcalc(g, d["u"], d["v"], d["h"], uh2, vh2, bound_coriolis=True)
+    tr = [t.copy() for t in adv["tr"]]
+    orc.advect_tracer(g, adv["h_end"], adv["uhtr"], adv["vhtr"], dt_adv, 900.0, scheme, tr, x_first=None if x_first < 0 else bool(x_first))
+    names = ["hp", "uh", "vh", "hp2", "uh2", "vh2", "u_cor", "v_cor", "CAu", "CAv", "FA_u_W0", "FA_u_WW", "FA_u_E0", "FA_u_EE", "uBT_WW", "uBT_EE",
+             "FA_v_S0", "FA_v_SS", "FA_v_N0", "FA_v_NN", "vBT_SS", "vBT_NN", "h_u", "h_v"] + [f"tr{m + 1}" for m in range(ntr)]
+    want = [hp, uh, vh, hp2, uh2, vh2, ucor, vcor, CAu, CAv] + [arrs[n] for n in names[10:24]] + tr
+    return g, names, want, dict(d=d, adv=adv, vru=vru, vrv=vrv, uhbt=uhbt, vhbt=vhbt, dt=dt, dt_adv=dt_adv, first_bt=first)
+
+
+def position_of(n):
+    if n in ("uh", "uh2", "u_cor", "CAu", "h_u") or n.startswith(("FA_u", "uBT")):
+        return _abi.POS_U
+    if n in ("vh", "vh2", "v_cor", "CAv", "h_v") or n.startswith(("FA_v", "vBT")):
+        return _abi.POS_V
+    return _abi.POS_H
+
+
+@pytest.fixture(scope="module")
+def ref_exe(tmp_path_factory):
+    return build_ref_kernels(tmp_path_factory.mktemp("ref_kernels"))
+
+
+@pytest.mark.parametrize("scheme,x_first,shape", [("PPM:H3", -1, (30, 14, 4)), ("PLM", 0, (22, 17, 3)), ("PPM", 1, (26, 12, 5))])
+def test_the_reference_kernels_equal_the_oracle_bit_for_bit(ref_exe, tmp_path, scheme, x_first, shape):
+    g, names, want, _ = write_case(str(tmp_path / "in.bin"), *shape, scheme=scheme, x_first=x_first, seed=70 + shape[0])
+    r = subprocess.run([ref_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ref_kernels_driver ok" in r.stdout, r.stderr[-2000:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        a = a.reshape(w.shape)
+        pos = position_of(n)
+        assert bits_equal(interior(g, a, pos), interior(g, w, pos)), (n, np.argwhere(interior(g, a, pos) != interior(g, w, pos))[:4])
+    assert not bits_equal(want[-1], np.zeros_like(want[-1]))
