@@ -1345,6 +1345,11 @@ typedef struct mom6hip_dyn_split_rk2_cs {
                                                  visc->nkml_visc_u/v must be set) */
   const struct mom6hip_obc *OBC;              /* CS%OBC (:253): NULL, or the open boundaries (the arrays of its segments, rx_normal and
                                                  ry_normal DEVICE arrays): step_MOM_dyn_split_RK2 only, see mom6hip_step_dyn_split_rk2 */
+  /* The surface pressures of the call in progress (arguments of step_MOM_dyn_split_RK2 :289 / _RK2b :274, set before the call; NULL =
+   * not associated; DEVICE h-point arrays [R L2 T-2 ~> Pa]): with p_surf_begin and p_surf_end both given, PressureForce takes
+   * p_surf_end as p_atm and btstep takes eta_PF_start = eta_PF - (p_surf_begin - p_surf_end) / (g_Earth H_to_RZ) (:435-442, :495-503);
+   * otherwise PressureForce takes p_surf = forces%p_surf (or nothing). */
+  const double *p_surf_begin, *p_surf_end, *p_surf;
 } mom6hip_dyn_split_rk2_cs_t;
 
 /* The part of initialize_dyn_split_RK2 (:1326) that sets state: eta from the layer thicknesses (:1521-1535),
@@ -1358,8 +1363,8 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
  * step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
  *                        vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves)
  *                                                                  src/core/MOM_dynamics_split_RK2.F90:289
- * tv%T, tv%S are passed as T, S; forces%taux, %tauy as taux, tauy with RZ_to_H; p_surf_begin / p_surf_end, Waves,
- * FPMIX and BEGW /= 0 are not provided.  All arrays are DEVICE arrays.  The whole step is enqueued on the context's
+ * tv%T, tv%S are passed as T, S; forces%taux, %tauy as taux, tauy with RZ_to_H; p_surf_begin, p_surf_end and forces%p_surf
+ * through cs->p_surf_begin, cs->p_surf_end, cs->p_surf; Waves, FPMIX and BEGW /= 0 are not provided.  All arrays are DEVICE arrays.  The whole step is enqueued on the context's
  * stream without host synchronisation, except for set_dtbt when calc_dtbt /= 0, the group passes of a multi-tile
  * domain and the hooks.
  * With cs->OBC (CS%OBC associated): the step's lines for the open boundaries -- u_old_rad_OBC = u_av :444-456,

@@ -282,7 +282,8 @@ class DynSplitRK2CS(C.Structure):
                  ("eqn_of_state", C.c_void_p), ("barotropic_CSp", C.c_void_p), ("BT_cont", C.c_void_p), ("hooks", C.c_void_p),
                  ("vertvisc_CSp", C.c_void_p), ("visc", C.c_void_p), ("hor_visc", C.c_void_p)]
                 + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_3D] + [(n, C.c_void_p) for n, _ in RK2_ARRAYS_2D]
-                + [("set_visc_CSp", C.c_void_p), ("OBC", C.c_void_p)])
+                + [("set_visc_CSp", C.c_void_p), ("OBC", C.c_void_p), ("p_surf_begin", C.c_void_p), ("p_surf_end", C.c_void_p),
+                   ("p_surf", C.c_void_p)])
 
 
 # ---- MOM_vert_friction ------------------------------------------------------------------------------------

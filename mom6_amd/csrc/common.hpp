@@ -107,6 +107,7 @@ struct mom6hip_ctx {
   m6::DevBuf hprev, uhr, vhr, flags, stage[16], tr_stage[64];
   m6::DevBuf pool[64];          // staging / scratch buffers handed out by m6::Stager, in call order
   m6::DevBuf rk2_scratch;       // the automatic arrays of step_MOM_dyn_split_RK2
+  m6::DevBuf rk2_eta_PF_start;  // eta_PF_start of a step with p_surf_begin and p_surf_end (MOM_dynamics_split_RK2.F90:438)
   int rk2_scratch_layout = 0;   // which stepper laid the block out last (1: RK2, 2: RK2B, 3: RK2 with an OBC); a change of layout zeroes it again
   m6::DevBuf hv_pack;           // the grid metrics of horizontal_viscosity gathered into planes of one shape (hor_visc.hip)
   bool hv_pack_ready = false;

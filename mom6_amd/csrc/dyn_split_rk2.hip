@@ -125,6 +125,30 @@ int check(const mom6hip_dyn_split_rk2_cs_t *cs, const char *who) {
 
 #define CALL(x) do { if (int rc_ = (x)) return rc_; } while (0)
 
+// The surface pressure of a step (MOM_dynamics_split_RK2.F90:435-442): p_surf_end when both p_surf_begin and p_surf_end are given
+// (dyn_p_surf), else forces%p_surf; and, after PressureForce, the eta that corresponds to the starting pressure (:497-503), which
+// btstep takes as eta_PF_start (null without dyn_p_surf).
+const double *step_p_surf(const mom6hip_dyn_split_rk2_cs_t *cs) {
+  return (cs->p_surf_begin && cs->p_surf_end) ? cs->p_surf_end : cs->p_surf;
+}
+int step_eta_PF_start(mom6hip_ctx_t *ctx, const mom6hip_dyn_split_rk2_cs_t *cs, double **out) {
+  *out = nullptr;
+  if (!(cs->p_surf_begin && cs->p_surf_end)) return 0;
+  const m6::GridDev g = ctx->g;
+  const size_t bytes = (size_t)g.nih * g.njh * sizeof(double);
+  M6_REQUIRE(ctx->rk2_eta_PF_start.reserve(bytes) == 0 && ctx->rk2_eta_PF_start.p, "step_MOM_dyn_split_RK2: out of device memory");
+  double *eps = (double *)ctx->rk2_eta_PF_start.p;
+  M6_HIP(hipMemsetAsync(eps, 0, bytes, ctx->stream));                                                // :439
+  const double pres_to_eta = 1.0 / (g.g_Earth * (g.Rho0 * g.H_to_Z));                                // 1 / (GV%g_Earth * GV%H_to_RZ), Boussinesq
+  const double *eta_PF = cs->eta_PF, *pb = cs->p_surf_begin, *pe = cs->p_surf_end;
+  launch3d(ctx->stream, g.isc - 1, g.iec + 1, g.jsc - 1, g.jec + 1, 1, [=] __device__(int i, int j, int) {      // Isq .. Ieq+1, Jsq .. Jeq+1
+    const long n = g.h2(i, j);
+    eps[n] = eta_PF[n] - pres_to_eta * (pb[n] - pe[n]);
+  });
+  *out = eps;
+  return 0;
+}
+
 // step_MOM_dyn_split_RK2 with CS%OBC associated: the reference's sequence of calls one after the other, every operator through its entry
 // point with the OBC (regional grids are small: no fused sweeps, no work around the passes in flight), plus the step's own lines for
 // the open boundaries: the starting velocities of the radiation (:444-456), open_boundary_zero_normal_flow on the accelerations
@@ -162,8 +186,10 @@ int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_
   M6_HIP(hipMemcpyAsync(u_old, u_av, sz.u3, hipMemcpyDeviceToDevice, s));                            // :450-455
   M6_HIP(hipMemcpyAsync(v_old, v_av, sz.v3, hipMemcpyDeviceToDevice, s));
 
-  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,   // :495
+  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, step_p_surf(cs), cs->PFu, cs->PFv, cs->pbce,   // :495
                                       cs->eta_PF, D));
+  double *eta_PF_start = nullptr;
+  CALL(step_eta_PF_start(ctx, cs, &eta_PF_start));                                                   // :497-503
   if (!cs->CAu_pred_stored)   // :544-552
     CALL(mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
   auto bc_accel = [&](const double *CAu, const double *CAv) -> int {      // :557-567, :879-889
@@ -212,7 +238,7 @@ int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_
   if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));           // :651
   const bool lf = cs->BT_use_layer_fluxes != 0;
   CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :655
-                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                           nullptr, lf ? uh_in : nullptr, lf ? vh_in : nullptr, lf ? u_inst : nullptr, lf ? v_inst : nullptr, nullptr, OBC, D));
   const double dt_pred = dt * cs->be;
   increment(up, vp, dt_pred, true);                                                                    // :663-676
@@ -239,7 +265,7 @@ int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_
   CALL(mom6hip_coradcalc_obc(ctx, cs->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
   CALL(bc_accel(cs->CAu, cs->CAv));                                                                   // :879-889
   CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :911
-                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                           nullptr, lf ? uh : nullptr, lf ? vh : nullptr, lf ? u_av : nullptr, lf ? v_av : nullptr, eta_av, OBC, D));
   launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :918
   increment(u_inst, v_inst, dt, true);                                                                 // :928-939 (in place: a point reads itself)
@@ -386,8 +412,10 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :422
 
   // PressureForce :495
-  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,
+  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, step_p_surf(cs), cs->PFu, cs->PFv, cs->pbce,
                                       cs->eta_PF, D));
+  double *eta_PF_start = nullptr;
+  CALL(step_eta_PF_start(ctx, cs, &eta_PF_start));                                                   // :497-503
   if (!cs->CAu_pred_stored)   // :544-552
     CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
 
@@ -455,7 +483,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));                       // :651
   const bool lf = cs->BT_use_layer_fluxes != 0;
   CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :655
-                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                       nullptr, lf ? uh_in : nullptr, lf ? vh_in : nullptr, lf ? u_inst : nullptr, lf ? v_inst : nullptr, nullptr, D));
 
   // up = u + dt_pred*(u_bc_accel + u_accel_bt) :663-676
@@ -512,7 +540,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   }
   bc_accel(cs->CAu, cs->CAv, false);                                                                  // :879-886
   CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :911
-                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                      cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                       nullptr, lf ? uh : nullptr, lf ? vh : nullptr, lf ? u_av : nullptr, lf ? v_av : nullptr, eta_av, D));
   launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :918
   if (!vv_fused) {   // u = u + dt*(u_bc_accel + u_accel_bt) :928-939
@@ -690,8 +718,10 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   // continuity with the filtered velocities :488, PressureForce :498, pass_hp_uhvh :535, h_av :540-542
   CALL(mom6hip_continuity_obc(ctx, cs->continuity_CSp, OBC, u_av, v_av, h, hp, uh, vh, dt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                               nullptr, nullptr, nullptr, D));
-  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, nullptr, cs->PFu, cs->PFv, cs->pbce,
+  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, step_p_surf(cs), cs->PFu, cs->PFv, cs->pbce,
                                       cs->eta_PF, D));
+  double *eta_PF_start = nullptr;
+  CALL(step_eta_PF_start(ctx, cs, &eta_PF_start));                                                   // :497-503
   CALL(pass(ctx, {{hp, PH}, {uh, PU}, {vh, PV}}, nz));
   auto set_h_av = [&]() {
     launch3d(s, is - 2, ie + 2, js - 2, je + 2, nz, [=] __device__(int i, int j, int k) {
@@ -779,7 +809,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   if (BT_cont_BT_thick) CALL(btcalc(BTC->h_u, BTC->h_v));                                                // :655-658
   if (calc_dtbt) CALL(mom6hip_set_dtbt_eta(ctx, BT, eta, cs->pbce, nullptr, 0.0, 0.0, D));                       // :664
   CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :668
-                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                           nullptr, uh_in, vh_in, u_inst, v_inst, nullptr, OBC, D));
 
   // up = u_inst + dt_pred*(u_bc_accel + u_accel_bt) :675-686
@@ -823,7 +853,7 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   bc_accel(cs->CAu, cs->CAv, false);                                                                  // :854-861
   if (OBC) CALL(mom6hip_open_boundary_zero_normal_flow(ctx, OBC, u_bc, v_bc, D));                     // :866-868
   CALL(mom6hip_btstep_obc(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :889
-                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, nullptr, nullptr,
+                          cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                           nullptr, uh, vh, u_av, v_av, eta_av, OBC, D));
   launch3d(s, is, ie, js, je, 1, [=] __device__(int i, int j, int) { eta[g.h2(i, j)] = eta_pred[g.h2(i, j)]; });   // :898
   {   // u_inst = u_inst + dt*(u_bc_accel + u_accel_bt) :908-919

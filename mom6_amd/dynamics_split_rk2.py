@@ -208,18 +208,28 @@ def step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, 
                            thickness_diffuse_CSp=None, pbv=None, STOCH=None, Waves=None, _entry="mom6hip_step_dyn_split_rk2"):
     """step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr,
     vhtr, eta_av, G, GV, US, CS, calc_dtbt, VarMix, MEKE, thickness_diffuse_CSp, pbv, STOCH, Waves) -- :289.
-    tv = (T, S); forces = (taux, tauy); visc is a vert_friction.vertvisc_type (device arrays) when the control structure
+    tv = (T, S); forces = (taux, tauy) or (taux, tauy, p_surf) with forces%p_surf; p_surf_begin, p_surf_end: the surface pressures at
+    the start and the end of the step (device h-point arrays or None: with both, PressureForce takes p_surf_end and btstep the
+    interpolated eta_PF :435-442, :497-503); visc is a vert_friction.vertvisc_type (device arrays) when the control structure
     was made with vertvisc=..., else None.  VarMix / MEKE / ... belong to parameterisations this build does not provide
     and must be None."""
     if CS is None or not CS.module_is_initialized:
         raise Mom6HipError("step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
-    if p_surf_begin is not None or p_surf_end is not None or Waves is not None or pbv is not None:
-        raise Mom6HipError("step_MOM_dyn_split_RK2 (HIP): surface pressure, waves and porous barriers are not supported")
+    if Waves is not None or pbv is not None:
+        raise Mom6HipError("step_MOM_dyn_split_RK2 (HIP): waves and porous barriers are not supported")
     g = G.grid
     T, S = (tv[0], tv[1]) if tv is not None else (None, None)      # tv None: no equation of state
     if (T is None or S is None) and CS.eqn_of_state is not None:
         raise Mom6HipError("step_MOM_dyn_split_RK2: an equation of state needs tv = (T, S)")
-    taux, tauy = forces
+    taux, tauy = forces[0], forces[1]
+    p_surf = forces[2] if len(forces) > 2 else None
+    for a in (p_surf_begin, p_surf_end, p_surf):
+        if a is not None and not (a.is_cuda and a.is_contiguous() and a.dtype == torch.float64 and tuple(a.shape) == tuple(g.shape2(_abi.POS_H))):
+            raise Mom6HipError("step_MOM_dyn_split_RK2: a surface pressure must be a contiguous float64 CUDA tensor on the h points")
+    CS._p_surf = (p_surf_begin, p_surf_end, p_surf)      # (kept alive for the call)
+    CS.st.p_surf_begin = None if p_surf_begin is None else p_surf_begin.data_ptr()
+    CS.st.p_surf_end = None if p_surf_end is None else p_surf_end.data_ptr()
+    CS.st.p_surf = None if p_surf is None else p_surf.data_ptr()
     if CS.vertvisc_CSp is not None:
         if visc is None:
             raise Mom6HipError("step_MOM_dyn_split_RK2: the control structure has vertical viscosity on, visc is required")

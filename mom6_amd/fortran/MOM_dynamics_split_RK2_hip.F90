@@ -239,13 +239,8 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
 
   if (.not.associated(CS)) call MOM_error(FATAL, "step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
   if (.not.CS%module_is_initialized) call MOM_error(FATAL, "step_MOM_dyn_split_RK2: Module must be initialized before it is used.")
-  ! The reference (:435-442) takes p_surf_end when both pointers are associated (and interpolates eta_PF between the two), else
-  ! forces%p_surf, and hands it to PressureForce as p_atm.  MOM.F90:772 points p_surf_end at forces%p_surf, which the solo driver
-  ! allocates and leaves at zero (MOM_surface_forcing.F90:260): a pressure that is zero everywhere changes no bit of the step
-  ! (x + 0.0 = x, and eta_PF_start = eta_PF - 0.0) and is accepted; a non-zero one is not provided.
-  if (associated(p_surf_begin)) then ; if (any(p_surf_begin(:,:) /= 0.0)) call refuse("a non-zero surface pressure (p_surf_begin)") ; endif
-  if (associated(p_surf_end)) then ; if (any(p_surf_end(:,:) /= 0.0)) call refuse("a non-zero surface pressure (p_surf_end)") ; endif
-  if (associated(forces%p_surf)) then ; if (any(forces%p_surf(:,:) /= 0.0)) call refuse("a non-zero surface pressure (forces%p_surf)") ; endif
+  ! (the surface pressures -- p_surf_end when both pointers are associated, with eta_PF interpolated between the two, else forces%p_surf
+  ! :435-442 -- go to the library with the other arguments below)
   ! Waves: the Stokes pressure force (Waves%Stokes_PGF, :505-520) and the Stokes terms of CorAdCalc / vertFPmix
   if (present(Waves)) then ; if (associated(Waves)) then
     if (Waves%Stokes_PGF .or. Waves%Stokes_VF) call refuse("surface waves (Waves%Stokes_PGF / Waves%Stokes_VF)")
@@ -274,6 +269,11 @@ subroutine step_MOM_dyn_split_RK2(u_inst, v_inst, h, tv, visc, Time_local, dt, f
   d_eta_av = mirror(CS, c_loc(eta_av), CS%nh2, .false., .true.)
   d_tx = mirror(CS, c_loc(forces%taux), CS%nu2, .true., .false.) ; d_ty = mirror(CS, c_loc(forces%tauy), CS%nv2, .true., .false.)
   call visc_mirrors(CS, visc, forces)
+  ! the surface pressures :435-442 (the library takes p_surf_end and interpolates eta_PF when both are there, else forces%p_surf)
+  CS%c_rk2%p_surf_begin = c_null_ptr ; CS%c_rk2%p_surf_end = c_null_ptr ; CS%c_rk2%p_surf = c_null_ptr
+  if (associated(p_surf_begin)) CS%c_rk2%p_surf_begin = mirror(CS, c_loc(p_surf_begin), CS%nh2, .true., .false.)
+  if (associated(p_surf_end)) CS%c_rk2%p_surf_end = mirror(CS, c_loc(p_surf_end), CS%nh2, .true., .false.)
+  if (associated(forces%p_surf)) CS%c_rk2%p_surf = mirror(CS, c_loc(forces%p_surf), CS%nh2, .true., .false.)
   ! the MEKE argument of horizontal_viscosity (MOM_hor_visc.F90:1141, :1318, :1537, :1634; :1833-1889)
   CS%c_hv%MEKE_Ku = c_null_ptr ; CS%c_hv%MEKE_Au = c_null_ptr ; CS%c_hv%MEKE_mom_src = c_null_ptr
   if (allocated(MEKE%Ku)) CS%c_hv%MEKE_Ku = mirror(CS, c_loc(MEKE%Ku), CS%nh2, .true., .false.)

@@ -301,6 +301,9 @@ type, bind(c) :: mom6hip_dyn_split_rk2_cs_t
   type(c_ptr) :: du_av_inst, dv_av_inst   !< SPLIT_RK2B only (MOM_dynamics_split_RK2b.F90:141-146)
   type(c_ptr) :: set_visc_CSp = c_null_ptr   !< c_loc of a mom6hip_set_visc_cs_t with dynamic_viscous_ML, or c_null_ptr
   type(c_ptr) :: OBC = c_null_ptr      !< CS%OBC: c_loc of a mom6hip_obc_t of DEVICE arrays, or c_null_ptr
+  !> The surface pressures of the call in progress (DEVICE h-point arrays or c_null_ptr): the step's arguments p_surf_begin,
+  !! p_surf_end and forces%p_surf (MOM_dynamics_split_RK2.F90:435-442, :495-503)
+  type(c_ptr) :: p_surf_begin = c_null_ptr, p_surf_end = c_null_ptr, p_surf = c_null_ptr
 end type mom6hip_dyn_split_rk2_cs_t
 
 interface

@@ -95,6 +95,10 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
 #define CHECK(call) do { rc = (call); if (rc) goto done; } while (0)
   /* CS%OBC: the starting velocities of the radiation conditions (:444-456) */
   const mom6hip_obc_t *OBC = CS->OBC;
+  /* the surface pressure of the step :435-442 (RK2b :422-429) */
+  const int dyn_p_surf = CS->p_surf_begin && CS->p_surf_end;
+  const double *p_surf = dyn_p_surf ? CS->p_surf_end : CS->p_surf;
+  double *eta_PF_start = dyn_p_surf ? (double *)calloc((size_t)ORC_NIH(G) * ORC_NJH(G), sizeof(double)) : NULL;
   double *u_old_rad_OBC = NULL, *v_old_rad_OBC = NULL;
   if (OBC) {
     u_old_rad_OBC = (double *)malloc(sizeof(double) * NU); v_old_rad_OBC = (double *)malloc(sizeof(double) * NV);
@@ -102,7 +106,12 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
 
   /* PressureForce :495 */
-  CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, NULL, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
+  CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, p_surf, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
+  if (dyn_p_surf) {      /* :497-503 / RK2b :500-506 */
+    const double pres_to_eta = 1.0 / (G->g_Earth * (G->Rho0 * G->H_to_Z));      /* 1 / (GV%g_Earth * GV%H_to_RZ), Boussinesq */
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+      eta_PF_start[ORC_H2(G,i,j)] = CS->eta_PF[ORC_H2(G,i,j)] - pres_to_eta * (CS->p_surf_begin[ORC_H2(G,i,j)] - CS->p_surf_end[ORC_H2(G,i,j)]);
+  }
   if (!CS->CAu_pred_stored)   /* :544-552 */
     CHECK(orc_coradcalc_obc(G, CS->CoriolisAdv, OBC, u_av, v_av, h_av, uh, vh, CS->CAu_pred, CS->CAv_pred));
   /* u_bc_accel :557-564 */
@@ -146,7 +155,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   {
     const int lf = CS->BT_use_layer_fluxes;
     CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
-                     CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
+                     CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, eta_PF_start, NULL,
                      NULL, lf ? uh_in : NULL, lf ? vh_in : NULL, lf ? u_inst : NULL, lf ? v_inst : NULL, NULL, OBC));
   }
   /* up = u + dt_pred*(u_bc_accel + u_accel_bt) :663-676 */
@@ -199,7 +208,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   {
     const int lf = CS->BT_use_layer_fluxes;
     CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
-                     CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
+                     CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, eta_PF_start, NULL,
                      NULL, lf ? uh : NULL, lf ? vh : NULL, lf ? u_av : NULL, lf ? v_av : NULL, eta_av, OBC));
   }
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[H2(i, j)] = eta_pred[H2(i, j)];   /* :918 */
@@ -253,7 +262,7 @@ int orc_step_dyn_split_rk2(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t *
   }
 done:
   free(up); free(vp); free(hp); free(u_bc_accel); free(v_bc_accel); free(uh_in); free(vh_in); free(eta_pred);
-  free(u_old_rad_OBC); free(v_old_rad_OBC);
+  free(u_old_rad_OBC); free(v_old_rad_OBC); free(eta_PF_start);
   return rc;
 }
 
@@ -295,6 +304,10 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   int rc = 0;
   /* CS%OBC: the starting velocities of the radiation conditions (:431-443) */
   const mom6hip_obc_t *OBC = CS->OBC;
+  /* the surface pressure of the step :435-442 (RK2b :422-429) */
+  const int dyn_p_surf = CS->p_surf_begin && CS->p_surf_end;
+  const double *p_surf = dyn_p_surf ? CS->p_surf_end : CS->p_surf;
+  double *eta_PF_start = dyn_p_surf ? (double *)calloc((size_t)ORC_NIH(G) * ORC_NJH(G), sizeof(double)) : NULL;
   double *u_old_rad_OBC = NULL, *v_old_rad_OBC = NULL;
   if (OBC) {
     u_old_rad_OBC = (double *)malloc(sizeof(double) * NU); v_old_rad_OBC = (double *)malloc(sizeof(double) * NV);
@@ -304,7 +317,12 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   /* continuity with the filtered velocities :488 */
   CHECK(orc_continuity_obc(G, CS->continuity_CSp, OBC, u_av, v_av, h, hp, uh, vh, dt, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL));
   /* PressureForce :498 */
-  CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, NULL, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
+  CHECK(orc_pressureforce_fv_bouss(G, CS->PressureForce_CSp, CS->eqn_of_state, h, T, S, p_surf, CS->PFu, CS->PFv, CS->pbce, CS->eta_PF));
+  if (dyn_p_surf) {      /* :497-503 / RK2b :500-506 */
+    const double pres_to_eta = 1.0 / (G->g_Earth * (G->Rho0 * G->H_to_Z));      /* 1 / (GV%g_Earth * GV%H_to_RZ), Boussinesq */
+    for (int j = Jsq; j <= Jeq+1; j++) for (int i = Isq; i <= Ieq+1; i++)
+      eta_PF_start[ORC_H2(G,i,j)] = CS->eta_PF[ORC_H2(G,i,j)] - pres_to_eta * (CS->p_surf_begin[ORC_H2(G,i,j)] - CS->p_surf_end[ORC_H2(G,i,j)]);
+  }
   /* pass_hp_uhvh :535 */
   pass3(G, hp, MOM6HIP_POS_H); pass3(G, uh, MOM6HIP_POS_U); pass3(G, vh, MOM6HIP_POS_V);
   /* h_av :540-542 */
@@ -361,7 +379,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   if (calc_dtbt) orc_set_dtbt_eta(G, BT, eta, CS->pbce, NULL, 0.0, 0.0);                                        /* :664 */
   /* predictor btstep :668 */
   CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
-                   CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
+                   CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, eta_PF_start, NULL,
                    NULL, uh_in, vh_in, u_inst, v_inst, NULL, OBC));
   /* up = u_inst + dt_pred*(u_bc_accel + u_accel_bt) :675-686 */
   const double dt_pred = dt * CS->be;
@@ -409,7 +427,7 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   if (OBC) CHECK(orc_open_boundary_zero_normal_flow(G, OBC, u_bc_accel, v_bc_accel));                  /* :866-868 */
   /* corrector btstep :889 */
   CHECK(orc_btstep_obc(G, BT, u_inst, v_inst, eta, dt, u_bc_accel, v_bc_accel, taux, tauy, RZ_to_H, CS->pbce, CS->eta_PF, u_av, v_av,
-                   CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, NULL, NULL,
+                   CS->u_accel_bt, CS->v_accel_bt, eta_pred, CS->uhbt, CS->vhbt, CS->visc_rem_u, CS->visc_rem_v, BTC, eta_PF_start, NULL,
                    NULL, uh, vh, u_av, v_av, eta_av, OBC));
   for (int j = js; j <= je; j++) for (int i = is; i <= ie; i++) eta[H2(i, j)] = eta_pred[H2(i, j)];   /* :898 */
   /* u_inst = u_inst + dt*(u_bc_accel + u_accel_bt) :908-919 */
@@ -447,6 +465,6 @@ int orc_step_dyn_split_rk2b(const mom6hip_grid_t *G, mom6hip_dyn_split_rk2_cs_t 
   }
 done:
   free(up); free(vp); free(hp); free(u_bc_accel); free(v_bc_accel); free(uh_in); free(vh_in); free(eta_pred);
-  free(u_old_rad_OBC); free(v_old_rad_OBC);
+  free(u_old_rad_OBC); free(v_old_rad_OBC); free(eta_PF_start);
   return rc;
 }

@@ -770,8 +770,12 @@ class DynState:
             self.bcs.dtbt = float(dtbt)
         self.nsteps = 0
 
-    def step(self, taux, tauy, calc_dtbt=False):
+    def step(self, taux, tauy, calc_dtbt=False, p_surf_begin=None, p_surf_end=None, p_surf=None):
+        """p_surf_begin, p_surf_end: the step's pointer arguments; p_surf: forces%p_surf (h-point arrays or None) :435-442"""
         g = self.grid
+        self._p_surf = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (p_surf_begin, p_surf_end, p_surf)]
+        for name, a in zip(("p_surf_begin", "p_surf_end", "p_surf"), self._p_surf):
+            setattr(self.cs, name, None if a is None else a.ctypes.data)
         f = lib().orc_step_dyn_split_rk2b if self.rk2b else lib().orc_step_dyn_split_rk2
         rc = f(C.byref(g.struct()), C.byref(self.cs), _p(self.u), _p(self.v), _p(self.h), _p(self.T),
                _p(self.S), self.dt, _p(taux), _p(tauy), g.Z_to_H / g.Rho0, _p(self.uh), _p(self.vh),

@@ -32,7 +32,7 @@ use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : vertvisc_type, thermo_var_ptrs, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, ocean_internal_state
 use MOM_verticalGrid,  only : verticalGrid_type
 use mom6hip_c_api,     only : mom6hip_transfer_stats
-use mom6hip_MOM_glue,  only : mom6hip_shared_context, mom6hip_shared_context_end
+use mom6hip_MOM_glue,  only : mom6hip_shared_context, mom6hip_shared_context_end, mom6hip_mirror_host_changed
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -67,7 +67,7 @@ type(stochastic_CS) :: STOCH
 integer(c_int32_t) :: hdr(8), hdr2(8)
 integer(c_int64_t) :: xfer(4)
 integer, target :: ntrunc
-integer :: ni, nj, nk, halo, u_in, u_out, u_par, isd, ied, jsd, jed, n, nsteps, ios, eq, cont_stencil, rc
+integer :: ni, nj, nk, halo, u_in, u_out, u_par, isd, ied, jsd, jed, n, nsteps, ios, eq, cont_stencil, rc, psurf_mode, i, j
 logical :: resident, calc_dtbt, calc_dtbt_init, bbl_each_step
 real :: scal(7), dt, dtbt_in, dtbt_reset_period, dt_therm
 real, allocatable, target, dimension(:,:,:) :: u, v, h, uh, vh, uhtr, vhtr
@@ -210,9 +210,24 @@ dtbt_reset_period = -1.0
 if (dtbt_in <= 0.0) call get_param(pf, "MOM", "DTBT_RESET_PERIOD", dtbt_reset_period, default=dt_therm)
 rc = mom6hip_transfer_stats(mom6hip_shared_context(G, GV), xfer, 1_c_int32_t)
 
+! DRIVER_P_SURF (read by this driver only): 1 a surface pressure in forces%p_surf, with p_surf_end pointing at it as MOM.F90:772 has it
+! (p_surf_begin is not associated: PressureForce takes forces%p_surf); 2 both p_surf_begin and p_surf_end (the pressure force takes
+! p_surf_end, btstep the eta_PF interpolated between the two, MOM_dynamics_split_RK2.F90:435-442, :497-503).  The pressures are made of
+! integers, so that the test forms the same bits: 1e5 + 8 mod(7i + 13j, 97) + 16 n at the end of step n, 4 mod(3i + 5j, 31) less at its start.
+call get_param(pf, "dyn_driver", "DRIVER_P_SURF", psurf_mode, default=0)
+if (psurf_mode == 2) allocate(p_surf_begin(isd:ied,jsd:jed), source=0.0)
+
 do n = 1, nsteps
   if (bbl_each_step .and. (n > 1)) then      ! (resident: on the device mirrors of u, v, h, T, S)
     call set_viscous_BBL(u, v, h, tv, visc, G, GV, US, SV, pbv)
+  endif
+  if (psurf_mode > 0) then
+    do j=jsd,jed ; do i=isd,ied
+      forces%p_surf(i,j) = 1.0e5 + 8.0*real(mod(7*i + 13*j, 97)) + 16.0*real(n)
+      if (psurf_mode == 2) p_surf_begin(i,j) = forces%p_surf(i,j) - 4.0*real(mod(3*i + 5*j, 31))
+    enddo ; enddo
+    call mom6hip_mirror_host_changed(c_loc(forces%p_surf))      ! (a new forcing field: its next reader uploads it)
+    if (psurf_mode == 2) call mom6hip_mirror_host_changed(c_loc(p_surf_begin))
   endif
   calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. calc_dtbt_init)
   call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, &

@@ -323,9 +323,9 @@ def oracle_for(name, g, d, ustar, bbl, Rlay, g_prime, OBC=None):
     return st, calc, dict(use_eos=int(thermo), use_ale=int(use_ALE), nk_rho_varies=nkml + nkbl, nkml=nkml)
 
 
-def write_case(tmp, name, nsteps, resident, state, bbl_mode=0):
+def write_case(tmp, name, nsteps, resident, state, bbl_mode=0, extra_pairs=None):
     g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
-    p = pairs_of(name)
+    p = dict(pairs_of(name), **(extra_pairs or {}))
     use_ALE = _b(p, "USE_REGRIDDING")
     nkml, nkbl = (0, 0) if (use_ALE or not _b(p, "ENABLE_THERMODYNAMICS", True)) else (2, 2)
     with open(tmp / "in.bin", "wb") as f:
@@ -394,6 +394,46 @@ def test_oracle_runs_the_transcribed_sets(name):
     if _b(pairs_of(name), "CHANNEL_DRAG"):
         assert st.visc._keep["Ray_u"].max() > 0.0
     assert np.all(np.isfinite(st.u)) and np.all(np.isfinite(st.h)) and st.h.min() > 0 and st.bcs.nstep_last >= 1
+
+
+def driver_p_surf(g, n, mode):
+    """the pressures tests/fortran/dyn_driver.F90 makes for step n (1-based) with DRIVER_P_SURF = mode: integers, the same bits on both sides"""
+    sh = g.shape2(_abi.POS_H)
+    jj, ii = np.meshgrid(np.arange(1, sh[0] + 1), np.arange(1, sh[1] + 1), indexing="ij")      # the driver's isd = jsd = 1
+    p_end = 1.0e5 + 8.0 * np.mod(7 * ii + 13 * jj, 97) + 16.0 * n
+    p_begin = p_end - 4.0 * np.mod(3 * ii + 5 * jj, 31)
+    return (np.ascontiguousarray(p_begin) if mode == 2 else None), np.ascontiguousarray(p_end)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_reference_named_driver_with_surface_pressures_matches_oracle_bitwise(tmp_path, mode, resident):
+    """step_MOM_dyn_split_RK2 through the module shim with a non-zero forces%p_surf (p_surf_end => forces%p_surf, MOM.F90:772), and with
+    p_surf_begin as well (dyn_p_surf: PressureForce with p_surf_end, btstep with eta_PF_start; MOM_dynamics_split_RK2.F90:435-442,
+    :497-503): the coupled models' calling form, which the shim refused until round 5"""
+    name, nsteps = "tc4", 3
+    state = case_state(name)
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    exe = build_driver(tmp_path)
+    write_case(tmp_path, name, nsteps, resident, state, bbl_mode=1, extra_pairs={"DRIVER_P_SURF": str(mode)})
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-2000:]
+    st, calc, _ = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    plain, _, _ = oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    for n in range(nsteps):
+        st.bbl(); plain.bbl()
+        pb, pe = driver_p_surf(g, n + 1, mode)
+        # mode 1: p_surf_begin is not associated, so forces%p_surf decides (:441); p_surf_end (=> forces%p_surf) alone changes nothing
+        st.step(taux, tauy, calc_dtbt=calc(n), p_surf_begin=pb, p_surf_end=pe, p_surf=pe)
+        plain.step(taux, tauy, calc_dtbt=calc(n))
+    got = read_out(str(tmp_path / "out.bin"), g, meke=st.mom_src is not None)
+    want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+    for n, pos, nd in OUT:
+        if n in want:
+            assert bits_equal(interior(g, got[n], pos), interior(g, want[n], pos)), (mode, n, float(np.abs(got[n] - want[n]).max()))
+    assert not bits_equal(st.u, plain.u)
 
 
 @pytest.mark.gpu
