@@ -584,7 +584,7 @@ typedef struct mom6hip_obc_segment {
   int32_t IsdB, IedB, JsdB, JedB;      /* segment%HI: the segment's face range on this PE's data domain */
   int32_t isd, ied, jsd, jed;          /* segment%HI: its cell range */
   int32_t radiation, gradient, nudged; /* segment%radiation (Orlanski), %gradient, %nudged: read by radiation_open_bdry_conds */
-  int32_t oblique;                     /* segment%oblique: not provided (refused by mom6hip_radiation_open_bdry_conds) */
+  int32_t oblique;                     /* segment%oblique: oblique radiation (:2349-2383), with obc->rx_oblique_u ... cff_normal_v */
   int32_t radiation_tan_or_grad;       /* the tangential forms, a bit each: MOM6HIP_OBC_TAN_* / _GRAD_* above */
   int32_t Flather;                     /* segment%Flather: read by btstep */
   /* segment%normal_trans, segment%normal_vel (IsdB:IedB, jsd:jed, nk) for E / W, (isd:ied, JsdB:JedB, nk) for N / S; read where

@@ -315,6 +315,159 @@ bt_ubt_kernel(m6::GridDev g, Work w, Par p, int i0, int i1, int j0, int j1, doub
   }
 }
 
+// ---- one barotropic step as ONE kernel with LDS-staged halo tiles (round 5) -----------------------------------------
+// The four kernels above pass eta_pred, the new velocity of the first direction and the two corrector transports through HBM
+// and read eta, eta_src and IareaT twice.  Here a block of 256 threads owns a tile of BTF_TX x BTF_TY cells of the step's
+// cell space [isv-1, iev+1] x [jsv-1, jev+1] (the predictor's range) with the faces on their east and north sides, and works
+// through the step with the intermediates in LDS:
+//   1. eta_pred (:1882-1909) and D = eta_pred - eta_PF (the bracket of the pressure force, :1975 ...) on the tile + a rim of 1;
+//   2. the velocity of the first direction (:1975-2044 | :2130-2207) on the tile's faces + a rim of 1 (the Coriolis term of
+//      the second direction reads it at four points, the corrector reads its transport);
+//   3. the velocity of the second direction (:2047-2127 | :2217-2290) on the tile's faces + the one column | row of faces on
+//      its low side that the corrector of the tile's cells reads;
+//   4. the corrector continuity (:2414-2421) on the tile's cells.
+// Rim values are recomputed by the neighbouring tile from the same inputs (the same bits); only the owner stores and
+// accumulates.  A tile reads the OLD eta, ubt, vbt, uhbtp, vhbtp of its rim while its neighbours write their new values, so
+// these five fields alternate between two sets of arrays from step to step (in / out); every point a step reads was
+// written by the step before it or refreshed by the group pass between them (the wide-halo march, :1842-1861), so nothing
+// has to be copied through.  Not taken with open boundaries or NONLINEAR_BT_CONTINUITY (the four kernels stay).
+#ifndef BTF_TY_DEF
+#define BTF_TY_DEF 16
+#endif
+constexpr int BTF_TX = 64, BTF_TY = BTF_TY_DEF, BTF_W = BTF_TX + 2, BTF_H = BTF_TY + 2;
+struct BtFused {
+  const double *eta_in, *ubt_in, *vbt_in, *uhbtp_in, *vhbtp_in;
+  double *eta_out, *ubt_out, *vbt_out, *uhbtp_out, *vhbtp_out;
+  int isv, iev, jsv, jev;
+  double wt_accel, wt_accel2, wt_trans, wt_eta, wt_end;
+  double *ubt_sum, *uhbt_sum, *vbt_sum, *vhbt_sum;
+};
+
+template <bool VFIRST>
+__global__ void __launch_bounds__(256) bt_step_fused_kernel(m6::GridDev g, Work w, Par p, BtFused a) {
+  __shared__ double sD[BTF_H][BTF_W];       // eta_pred (or eta with BT_PROJECT_VELOCITY) minus eta_PF at the tile's cells + rim
+  __shared__ double sV1[BTF_H][BTF_W];      // the new velocity of the first direction at its faces
+  __shared__ double sH1[BTF_H][BTF_W];      // its corrector transport (uhbt | vhbt)
+  __shared__ double sH2[BTF_H][BTF_W];      // the corrector transport of the second direction
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int ti0 = a.isv - 1 + blockIdx.x * BTF_TX, tj0 = a.jsv - 1 + blockIdx.y * BTF_TY;      // the tile's first cell
+  const int ib = ti0 - 1, jb = tj0 - 1;     // cell / face (ib + li, jb + lj) sits at [lj][li]
+  const int ti1 = min(ti0 + BTF_TX - 1, a.iev + 1), tj1 = min(tj0 + BTF_TY - 1, a.jev + 1);      // its last cell
+  // ---- 1. the predictor continuity on the tile and a rim of one cell
+  for (int idx = tid; idx < BTF_W * BTF_H; idx += 256) {
+    const int li = idx % BTF_W, lj = idx / BTF_W, i = ib + li, j = jb + lj;
+    double d = 0.0;
+    if (i >= a.isv - 1 && i <= a.iev + 1 && j >= a.jsv - 1 && j <= a.jev + 1 && i <= ti1 + 1 && j <= tj1 + 1) {
+      const long n = g.h2(i, j);
+      double ep;
+      if (p.project_velocity) {
+        ep = a.eta_in[n];
+      } else {
+        ep = (a.eta_in[n] + w.eta_src[n]) + (p.dtbt * g.IareaT[n]) *
+            ((a.uhbtp_in[g.u2(i - 1, j)] - a.uhbtp_in[g.u2(i, j)]) + (a.vhbtp_in[g.v2(i, j - 1)] - a.vhbtp_in[g.v2(i, j)]));
+      }
+      const bool own = li >= 1 && lj >= 1 && i <= ti1 && j <= tj1;
+      if (own) {
+        if (!p.project_velocity) w.eta_pred[n] = ep;
+        if (p.find_etaav && i >= g.isc && i <= g.iec && j >= g.jsc && j <= g.jec) w.eta_sum[n] = w.eta_sum[n] + a.wt_accel2 * ep;
+      }
+      d = ep - eta_pf_at(w, p, n, a.wt_end);
+    }
+    sD[lj][li] = d;
+  }
+  __syncthreads();
+  // ---- 2. + 3. the two velocity updates: pass 0 the first direction (old velocity of the other one from memory), pass 1 the second
+  // (the new velocity of the first from LDS)
+#pragma unroll
+  for (int ps = 0; ps < 2; ps++) {
+    const bool do_v = (ps == 0) ? VFIRST : !VFIRST;
+    for (int idx = tid; idx < BTF_W * BTF_H; idx += 256) {
+      const int li = idx % BTF_W, lj = idx / BTF_W, i = ib + li, j = jb + lj;
+      if (do_v) {
+        // faces (i, J = j): first direction i in [isv-1, iev+1], second i in [isv, iev]; J in [jsv-1, jev]
+        const int i0 = VFIRST ? a.isv - 1 : a.isv, i1 = VFIRST ? a.iev + 1 : a.iev;
+        const bool in_tile = VFIRST ? (i <= ti1 + 1 && j <= tj1) : (li >= 1 && i <= ti1 && j <= tj1);
+        if (!(i >= i0 && i <= i1 && j >= a.jsv - 1 && j <= a.jev && in_tile)) continue;
+        const long n = g.v2(i, j);
+        double u00, u01, u10, u11;      // ubt at (I-1, j), (I, j), (I-1, j+1), (I, j+1)
+        if (VFIRST) {
+          u00 = a.ubt_in[g.u2(i - 1, j)]; u01 = a.ubt_in[g.u2(i, j)]; u10 = a.ubt_in[g.u2(i - 1, j + 1)]; u11 = a.ubt_in[g.u2(i, j + 1)];
+        } else {
+          u00 = sV1[lj][li - 1]; u01 = sV1[lj][li]; u10 = sV1[lj + 1][li - 1]; u11 = sV1[lj + 1][li];
+        }
+        const double Cor_v = -1.0 * ((w.amer[g.u2(i - 1, j)] * u00 + w.cmer[g.u2(i, j + 1)] * u11) +
+                                     (w.bmer[g.u2(i, j)] * u01 + w.dmer[g.u2(i - 1, j + 1)] * u10)) - w.Cor_ref_v[n];
+        const long hs = g.h2(i, j), hn = g.h2(i, j + 1);
+        const double PFv = (sD[lj][li] * w.gtot_N[hs] - sD[lj + 1][li] * w.gtot_S[hn]) * p.dgeo_de * g.IdyCv[n];
+        const double vel_prev = a.vbt_in[n];
+        double vb = w.bt_rem_v[n] * (vel_prev + p.dtbt * ((w.BT_force_v[n] + Cor_v) + PFv));
+        if (fabs(vb) < p.vel_underflow) vb = 0.0;
+        const double vtrans = p.trans_wt1 * vb + p.trans_wt2 * vel_prev;
+        const double vh0 = w.vhbt0[n];
+        double vh, vhp;
+        if (p.use_BT_cont) { vh = find_uhbt(vtrans, w.BV, n) + vh0; vhp = find_uhbt(vb, w.BV, n) + vh0; }
+        else { const double Dv = w.Datv[n]; vh = Dv * vtrans + vh0; vhp = Dv * vb + vh0; }
+        if (VFIRST) { sV1[lj][li] = vb; sH1[lj][li] = vh; } else { sH2[lj][li] = vh; }
+        if (li >= 1 && lj >= 1 && i <= ti1 && j <= tj1) {      // the owner
+          a.vbt_out[n] = vb;
+          w.v_accel_bt[n] = w.v_accel_bt[n] + a.wt_accel * (Cor_v + PFv);
+          w.vhbt[n] = vh; a.vhbtp_out[n] = vhp;
+          if (i >= g.isc && i <= g.iec && j >= g.jsc - 1 && j <= g.jec) {
+            a.vbt_sum[n] = a.vbt_sum[n] + a.wt_trans * vtrans;
+            a.vhbt_sum[n] = a.vhbt_sum[n] + a.wt_trans * vh;
+          }
+        }
+      } else {
+        // faces (I = i, j): I in [isv-1, iev]; first direction j in [jsv-1, jev+1], second j in [jsv, jev]
+        const int j0 = VFIRST ? a.jsv : a.jsv - 1, j1 = VFIRST ? a.jev : a.jev + 1;
+        const bool in_tile = VFIRST ? (lj >= 1 && i <= ti1 && j <= tj1) : (i <= ti1 && j <= tj1 + 1);
+        if (!(i >= a.isv - 1 && i <= a.iev && j >= j0 && j <= j1 && in_tile)) continue;
+        const long n = g.u2(i, j);
+        double v00, v01, v10, v11;      // vbt at (i, J-1), (i+1, J-1), (i, J), (i+1, J)
+        if (VFIRST) {
+          v00 = sV1[lj - 1][li]; v01 = sV1[lj - 1][li + 1]; v10 = sV1[lj][li]; v11 = sV1[lj][li + 1];
+        } else {
+          v00 = a.vbt_in[g.v2(i, j - 1)]; v01 = a.vbt_in[g.v2(i + 1, j - 1)]; v10 = a.vbt_in[g.v2(i, j)]; v11 = a.vbt_in[g.v2(i + 1, j)];
+        }
+        const double Cor_u = ((w.azon[n] * v11 + w.czon[n] * v00) + (w.bzon[n] * v10 + w.dzon[n] * v01)) - w.Cor_ref_u[n];
+        const long hw = g.h2(i, j), he = g.h2(i + 1, j);
+        const double PFu = (sD[lj][li] * w.gtot_E[hw] - sD[lj][li + 1] * w.gtot_W[he]) * p.dgeo_de * g.IdxCu[n];
+        const double vel_prev = a.ubt_in[n];
+        double ub = w.bt_rem_u[n] * (vel_prev + p.dtbt * ((w.BT_force_u[n] + Cor_u) + PFu));
+        if (fabs(ub) < p.vel_underflow) ub = 0.0;
+        const double utrans = p.trans_wt1 * ub + p.trans_wt2 * vel_prev;
+        const double uh0 = w.uhbt0[n];
+        double uh, uhp;
+        if (p.use_BT_cont) { uh = find_uhbt(utrans, w.BU, n) + uh0; uhp = find_uhbt(ub, w.BU, n) + uh0; }
+        else { const double Du = w.Datu[n]; uh = Du * utrans + uh0; uhp = Du * ub + uh0; }
+        if (!VFIRST) { sV1[lj][li] = ub; sH1[lj][li] = uh; } else { sH2[lj][li] = uh; }
+        if (li >= 1 && lj >= 1 && i <= ti1 && j <= tj1) {      // the owner
+          a.ubt_out[n] = ub;
+          w.u_accel_bt[n] = w.u_accel_bt[n] + a.wt_accel * (Cor_u + PFu);
+          w.uhbt[n] = uh; a.uhbtp_out[n] = uhp;
+          if (i >= g.isc - 1 && i <= g.iec && j >= g.jsc && j <= g.jec) {
+            a.ubt_sum[n] = a.ubt_sum[n] + a.wt_trans * utrans;
+            a.uhbt_sum[n] = a.uhbt_sum[n] + a.wt_trans * uh;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- 4. the corrector continuity on the tile's cells
+  for (int idx = tid; idx < BTF_TX * BTF_TY; idx += 256) {
+    const int li = 1 + idx % BTF_TX, lj = 1 + idx / BTF_TX, i = ib + li, j = jb + lj;
+    if (!(i >= a.isv && i <= a.iev && j >= a.jsv && j <= a.jev)) continue;
+    const long n = g.h2(i, j);
+    const double (*sU)[BTF_W] = VFIRST ? sH2 : sH1;      // uhbt at [lj][I - ib]
+    const double (*sV)[BTF_W] = VFIRST ? sH1 : sH2;      // vhbt at [J - jb][li]
+    const double e = (a.eta_in[n] + w.eta_src[n]) + (p.dtbt * g.IareaT[n]) *
+        ((sU[lj][li - 1] - sU[lj][li]) + (sV[lj - 1][li] - sV[lj][li]));
+    a.eta_out[n] = e;
+    w.eta_wtd[n] = w.eta_wtd[n] + e * a.wt_eta;
+  }
+}
+
 // apply_velocity_OBCs :2931-3168 for the faces of the segments of one direction (halo = iev - ie: the window of this time step), with the
 // running sums from the values the faces had before the step (:2367-2395) and the predictor transport of the next step (:1882-1893)
 template <int DIR>
@@ -858,6 +1011,15 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
     w.gtot_E = H(); w.gtot_W = H(); w.gtot_N = H(); w.gtot_S = H(); w.eta_src = H(); w.e_anom = H();
     w.q = (double *)q;
   }
+  // the second set of the five fields that alternate between the steps of the fused kernel (bt_step_fused_kernel)
+  double *alt_eta = nullptr, *alt_ubt = nullptr, *alt_vbt = nullptr, *alt_uhbtp = nullptr, *alt_vhbtp = nullptr;
+  {
+    char *q = (char *)st.scratch(2 * sz.u2 + 2 * sz.v2 + sz.h2);
+    M6_REQUIRE(!st.failed() && q, "btstep: staging failed");
+    M6_HIP(hipMemsetAsync(q, 0, 2 * sz.u2 + 2 * sz.v2 + sz.h2, s));
+    alt_ubt = (double *)q; alt_uhbtp = (double *)(q + sz.u2); alt_vbt = (double *)(q + 2 * sz.u2); alt_vhbtp = (double *)(q + 2 * sz.u2 + sz.v2);
+    alt_eta = (double *)(q + 2 * sz.u2 + 2 * sz.v2);
+  }
   // ---- open boundaries :770-780
   w.obc_u = w.obc_v = nullptr;
   w.ob_Cg_u = w.ob_dZ_u = w.ob_uhbt = w.ob_ubt_outer = w.ob_SSH_u = w.ubt_old = w.ubt_first = w.ubt_wtd = nullptr;
@@ -896,11 +1058,10 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
         o[n] = c;
       }
     }
-    int32_t *dcodes = (int32_t *)st.scratch(4 * (nU + nV));
+    // (the codes change only with the OBC: uploaded when they differ from the copy the context keeps, never waited for)
+    const int32_t *dcodes = (const int32_t *)m6::obc_table_content(ctx, m6::OBC_SITE_BT_CODES, m6::obc_fingerprint(ctx, obc), codes.data(), 4 * (nU + nV));
     char *ob = (char *)st.scratch(8 * sz.u2 + 8 * sz.v2);
     M6_REQUIRE(!st.failed() && dcodes && ob, "btstep: out of device memory for the open boundaries");
-    M6_HIP(hipMemcpyAsync(dcodes, codes.data(), 4 * (nU + nV), hipMemcpyHostToDevice, s));
-    M6_HIP(hipStreamSynchronize(s));      // (the host vector goes out of scope)
     M6_HIP(hipMemsetAsync(ob, 0, 8 * sz.u2 + 8 * sz.v2, s));
     w.obc_u = dcodes; w.obc_v = dcodes + nU;
     double **pu[8] = {&w.ob_Cg_u, &w.ob_dZ_u, &w.ob_uhbt, &w.ob_ubt_outer, &w.ob_SSH_u, &w.ubt_old, &w.ubt_first, &w.ubt_wtd};
@@ -1322,12 +1483,38 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
       rng[n] = {isv, iev, jsv, jev, pf};
     }
   }
-  auto do_pass = [&]() -> int { return pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}}); };
+  // MOM6HIP_BT_FUSED=1: one fused kernel a step (bt_step_fused_kernel; not with open boundaries or face areas that follow eta).  Bit-exact
+  // and slower than the four kernels at every tile height measured (profiles/r05_experiments.txt section 2): not the default.  Its five
+  // alternating fields: step n reads set A (the Work arrays) when n is odd, set B when it is even.  (Read at every call: tests switch it.)
+  const char *fused_env = getenv("MOM6HIP_BT_FUSED");
+  const bool fused = fused_env && atoi(fused_env) == 1 && !apply_OBCs && !nonlin_update;
+  auto eta_at = [&](int n) { return (fused && n % 2 == 0) ? alt_eta : w.eta; };        // the set step n reads (and a pass before it updates)
+  auto do_pass = [&](int n) -> int {
+    if (fused && n % 2 == 0) return pass({{alt_eta, PH}, {alt_ubt, PU}, {alt_vbt, PV}, {alt_uhbtp, PU}, {alt_vhbtp, PV}});
+    return pass({{w.eta, PH}, {w.ubt, PU}, {w.vbt, PV}, {w.uhbtp, PU}, {w.vhbtp, PV}});
+  };
+  (void)eta_at;
   // the kernels of steps n0 .. n1 (no group pass)
   auto run_steps = [&](hipStream_t st, int n0, int n1) {
     for (int n = n0; n <= n1; n++) {
       const int isv = rng[n].isv, iev = rng[n].iev, jsv = rng[n].jsv, jev = rng[n].jev;
       const double wt_end = n * p.Instep;
+      if (fused) {
+        BtFused a;
+        const bool odd = (n % 2) == 1;
+        a.eta_in = odd ? w.eta : alt_eta; a.ubt_in = odd ? w.ubt : alt_ubt; a.vbt_in = odd ? w.vbt : alt_vbt;
+        a.uhbtp_in = odd ? w.uhbtp : alt_uhbtp; a.vhbtp_in = odd ? w.vhbtp : alt_vhbtp;
+        a.eta_out = odd ? alt_eta : w.eta; a.ubt_out = odd ? alt_ubt : w.ubt; a.vbt_out = odd ? alt_vbt : w.vbt;
+        a.uhbtp_out = odd ? alt_uhbtp : w.uhbtp; a.vhbtp_out = odd ? alt_vhbtp : w.vhbtp;
+        a.isv = isv; a.iev = iev; a.jsv = jsv; a.jev = jev;
+        a.wt_accel = wt_accel[n]; a.wt_accel2 = wt_accel2[n]; a.wt_trans = wt_trans[n]; a.wt_eta = wt_eta[n]; a.wt_end = wt_end;
+        a.ubt_sum = c.ubtav; a.uhbt_sum = duhbtav; a.vbt_sum = c.vbtav; a.vhbt_sum = dvhbtav;
+        const dim3 grid((iev - isv + 3 + BTF_TX - 1) / BTF_TX, (jev - jsv + 3 + BTF_TY - 1) / BTF_TY);
+        const bool v_first = ((n + ctx->host.first_direction) % 2) == 1;
+        if (v_first) hipLaunchKernelGGL(bt_step_fused_kernel<true>, grid, dim3(64, 4), 0, st, g, w, p, a);
+        else hipLaunchKernelGGL(bt_step_fused_kernel<false>, grid, dim3(64, 4), 0, st, g, w, p, a);
+        continue;
+      }
       if (nonlin_update && (n > 1) && ((n - 1) % cs->Nonlin_cont_update_period == 0)) {      // :1852-1856
         face_areas_eta(st, 1 + iev - ie);
         // the predictor transports of this step were formed by the velocity kernels of the previous one, with the old face
@@ -1377,7 +1564,7 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
   // steps n0 .. n1 with their group passes, enqueued one by one on `st`
   auto run_loop = [&](hipStream_t st, int n0, int n1) -> int {
     for (int n = n0; n <= n1; n++) {
-      if (rng[n].pass_first) { if (int rc = do_pass()) return rc; }
+      if (rng[n].pass_first) { if (int rc = do_pass(n)) return rc; }
       run_steps(st, n, n);
     }
     return 0;
@@ -1388,6 +1575,7 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
   {
     auto add = [&](const void *q, size_t nbytes) { base_key.append((const char *)q, nbytes); };
     add(&w, sizeof(w)); add(&p, sizeof(p)); add(&nt, sizeof(nt)); add(&ctx->host.first_direction, sizeof(int32_t));
+    { const void *fk[2] = {fused ? (const void *)alt_eta : nullptr, fused ? (const void *)alt_ubt : nullptr}; add(fk, sizeof(fk)); }
     { const double ob_key[3] = {apply_u_OBCs ? 1.0 : 0.0, apply_v_OBCs ? 1.0 : 0.0, cs->bebt}; add(ob_key, sizeof(ob_key)); }
     { const int32_t nl[2] = {nonlin_update ? 1 : 0, cs->Nonlin_cont_update_period}; add(nl, sizeof(nl)); }
     add(&c.ubtav, sizeof(double *)); add(&c.vbtav, sizeof(double *)); add(&duhbtav, sizeof(double *)); add(&dvhbtav, sizeof(double *));
@@ -1445,7 +1633,7 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
     while (n0 <= nt) {
       int n1 = n0;
       while (n1 + 1 <= nt && !rng[n1 + 1].pass_first) n1++;
-      if (rng[n0].pass_first) { if (int rc = do_pass()) return rc; }
+      if (rng[n0].pass_first) { if (int rc = do_pass(n0)) return rc; }
       hipGraphExec_t exec = nullptr;
       if (int rc = graph_of(n0, n1, false, &exec)) return rc;
       M6_HIP(hipGraphLaunch(exec, s));
@@ -1459,6 +1647,13 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
     ctx->bt_graph_launches++;
   }
   M6_HIP(hipGetLastError());
+  if (fused && nt % 2 == 1) {      // the last step wrote set B: the epilogue (and a caller that looks at the work arrays) reads set A
+    M6_HIP(hipMemcpyAsync(w.eta, alt_eta, sz.h2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.ubt, alt_ubt, sz.u2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.vbt, alt_vbt, sz.v2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.uhbtp, alt_uhbtp, sz.u2, hipMemcpyDeviceToDevice, s));
+    M6_HIP(hipMemcpyAsync(w.vhbtp, alt_vhbtp, sz.v2, hipMemcpyDeviceToDevice, s));
+  }
 
   // ---- epilogue :2467-2590
   {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -127,6 +128,11 @@ struct mom6hip_ctx {
   m6::DevBuf ale_sub;           // sub-cell structure of the two grids, handed from ale_sub_cells_kernel to the remap kernel
   m6::DevBuf ale_side;          // the streaming remap kernel's side arrays (target cells below what a lane has read)
   std::vector<const void *> lds_configured;      // kernels whose dynamic-LDS limit has been raised on this context's device
+  // The device tables the operators derive from an OBC (face / corner / side maps, segment tables): built and uploaded once per
+  // (operator site, fingerprint of the OBC) and kept -- the segments do not move after initialisation (m6::obc_table, open_boundary.hip)
+  struct ObcTable { int site; uint64_t key; m6::DevBuf buf; size_t bytes; uint64_t last_use; std::vector<char> host; };
+  std::vector<ObcTable> obc_tables;
+  uint64_t obc_table_clock = 0, obc_table_builds = 0;
   m6::DevBuf vv_ntrunc;         // device counter of vertvisc_limit_vel's truncations (vert_friction.hip)
   bool vv_ntrunc_ready = false;
   // hipGraphs of the barotropic subcycle, keyed on everything baked into their nodes (barotropic.hip)
@@ -238,6 +244,18 @@ int vertvisc_step_inc(mom6hip_ctx_t *ctx, mom6hip_vertvisc_cs_t *cs, double *u, 
 // open boundaries (open_boundary.hip): the side maps of the zero-gradient projections, and the store of the specified segments' velocities
 class Stager;
 int obc_side_maps(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_obc_t *obc, const int32_t **side_u, const int32_t **side_v, const char *who);
+// A fingerprint of what the maps of an OBC depend on: its flags, the segments' directions, flags and index ranges, and the identity of
+// the segnum arrays (their addresses and a sample of their values) -- not the segments' data arrays
+uint64_t obc_fingerprint(const mom6hip_ctx_t *ctx, const mom6hip_obc_t *obc);
+inline uint64_t obc_mix(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h; }
+// The device copy of a host table that `build` fills (bytes long), cached per (site, key): `build` runs, and the table is uploaded (one
+// synchronising copy), only when the pair has not been seen on this context.  nullptr on failure (error set).
+enum { OBC_SITE_SIDE = 1, OBC_SITE_CONT, OBC_SITE_CORAD, OBC_SITE_HORVISC, OBC_SITE_BT_CODES, OBC_SITE_SETVISC, OBC_SITE_RK2 };
+const void *obc_table(mom6hip_ctx_t *ctx, int site, uint64_t key, size_t bytes, const std::function<int(void *)> &build);
+// The same for a table the caller has just formed on the host (its loop over the segments also launches kernels, so it runs at every
+// call): uploaded only when its CONTENT differs from what the (site, key) entry holds; the entry keeps its own host copy, so the upload
+// never has to be waited for.
+const void *obc_table_content(mom6hip_ctx_t *ctx, int site, uint64_t key, const void *host, size_t bytes);
 int obc_store_specified(mom6hip_ctx_t *ctx, Stager &st, const mom6hip_obc_t *obc, double *d_u, double *d_v, const char *who);
 // set_viscous_ML on device arrays (set_viscosity.hip); called by the split RK2 step at :592
 int set_viscous_ML_dev(mom6hip_ctx_t *ctx, const mom6hip_set_visc_cs_t *cs, const double *u, const double *v, const double *h,

@@ -383,7 +383,8 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   for (auto &b : ctx->stage) b.release();
   for (auto &b : ctx->tr_stage) b.release();
   for (auto &b : ctx->pool) b.release();
-  ctx->rk2_scratch.release();
+  ctx->rk2_scratch.release(); ctx->rk2_eta_PF_start.release(); ctx->cont_hmid.release();
+  for (auto &e : ctx->obc_tables) e.buf.release();
   ctx->sv_rlay.release();
   for (auto &t : ctx->tables) t.buf.release();
   ctx->hv_pack.release(); ctx->hv_str.release();

@@ -1184,14 +1184,17 @@ __device__ __forceinline__ double thick_lrc(const FaceConst &F, int marginal, bo
 #define FC3_GRP 2      // layers of a thread the scheduler may interleave in an evaluation pass (bounds the temporaries)
 #endif
 #define FC3_SCHED(m) do { if (((m) + 1) % FC3_GRP == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
-// The evaluation passes run over all KS layers of a thread without a test on k (layers past nk hold zeros: u = 0 gives uh = +0
-// and a marginal thickness of 0; their rows of the planes exist and no sum reads them), so that a pass is one basic block the
-// scheduler can interleave FC3_GRP layers in; only the stores to global memory stay conditional.
+// FC3_UNCOND = 1: the evaluation passes run over all KS layers of a thread without a test on k (layers past nk hold zeros: u = 0 gives
+// uh = +0 and a marginal thickness of 0; their rows of the planes exist and no sum reads them), one basic block the scheduler can
+// interleave FC3_GRP layers in.  Measured (profiles/r05_experiments.txt): the test on k is the faster form (the slabs past nk do nothing).
+#ifndef FC3_PF
+#define FC3_PF 2      // layers of thicknesses a thread has in flight ahead of its reconstruction (>= KS: all of them at once)
+#endif
 #ifndef FC3_CHAIN_UNROLL
 #define FC3_CHAIN_UNROLL 8      // LDS reads a chain walker issues ahead of its dependent arithmetic
 #endif
 #ifndef FC3_UNCOND
-#define FC3_UNCOND 1
+#define FC3_UNCOND 0
 #endif
 #define FC3_LIVE(m) (FC3_UNCOND || (k0 + (m) < nz))
 
@@ -1247,6 +1250,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
   constexpr int PV = CO + 15 * FC_FL;
   const int k0 = sb * KS;
   const int sl = k0 * FC_FL + fl;                 // this thread's slot of layer k0 in a plane
+  // the offset of layer m of this face, formed where it is used from an opaque copy of the 2-D offset: hoisted out of the passes, the
+  // 64-bit offsets of every layer and output array are registers held for the whole kernel
+  auto f3_at = [&](int m) -> long { long q = f2; asm volatile("" : "+v"(q)); return q + (long)(k0 + m) * fpl; };
+#define FC3_F3(m) f3_at(m)
 #define VR(m) fsm[2 * PL + sl + (m) * FC_FL]
 
   // ---- the thread's layers into registers (every global load issued before anything is computed from one of them)
@@ -1260,39 +1267,45 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     mk[0] = mm[-s2w]; mk[1] = mm[-s]; mk[2] = mm[0]; mk[3] = mm[s]; mk[4] = mm[2 * s];
     mk[5] = mm[s3w];      // (only the meridional pair of reconstructions reads cell +3)
   }
-  double pk_aW = g.areaT[o2], pk_aE = g.areaT[o2 + s], pk_dW = D.dL_T()[o2], pk_dE = D.dL_T()[o2 + s], pk_mf = D.mask_face()[f2];
-  double pk_iW = g.IareaT[o2], pk_iE = g.IareaT[o2 + s], pk_ub = p.uhbt ? p.uhbt[f2] : 0.0, pk_lc = D.dLC_face()[f2];
+  double pk_mf = D.mask_face()[f2], pk_ub = p.uhbt ? p.uhbt[f2] : 0.0;
   constexpr int KP = (DIR == 1) ? KS : 1;      // the plus-side cell is held only meridionally
   double ru[KS], sL[KS], sR[KS], sC[KS], tL[KP], tR[KP], tC[KP];
   constexpr int NH = (DIR == 0) ? 5 : 6;      // cells -2 .. +2 along the direction (+3 for the meridional pair)
+  // The loads of a thread are a software pipeline over its layers (round 5): u, visc_rem, the 2-D values and the thicknesses of the
+  // first FC3_PF layers are issued at once; the reconstruction of layer m then runs behind the loads of layer m + FC3_PF.  With every
+  // load of the thread in flight at once (cont_flux_coop_kernel) the landing registers of KS x (NH + 2) values are the peak of the
+  // kernel's register demand -- 200 VGPRs meridionally, the budget of four waves a SIMD is 128 -- and what does not fit goes to
+  // scratch memory for the whole kernel.
   double hr[KS][NH];
+  const char *hb[NH];
+#pragma unroll
+  for (int q = 0; q < NH; q++) {
+    const long disp = (q == 0) ? -s2w : ((q == 5) ? s3w : (q - 2) * s);
+    hb[q] = (const char *)(p.h_in + disp);
+  }
+  const unsigned o2b = (unsigned)(o2 * 8), hstep = (unsigned)(hpl * 8);
+#define FC3_LOAD_H(m) do { \
+    const unsigned k_ = (unsigned)((k0 + (m) < nz) ? k0 + (m) : nz - 1); \
+    const unsigned vh_ = o2b + k_ * hstep; \
+    _Pragma("unroll") for (int q = 0; q < NH; q++) hr[m][q] = *(const double *)(hb[q] + vh_); \
+  } while (0)
   {
     double rvr[KS];
     {
       const char *ub = (const char *)p.u, *vb = p.visc_rem ? (const char *)p.visc_rem : ub;      // (no branch around a load)
-      const char *hb[NH];
-#pragma unroll
-      for (int q = 0; q < NH; q++) {
-        const long disp = (q == 0) ? -s2w : ((q == 5) ? s3w : (q - 2) * s);
-        hb[q] = (const char *)(p.h_in + disp);
-      }
-      const unsigned o2b = (unsigned)(o2 * 8), f2b = (unsigned)(f2 * 8), hstep = (unsigned)(hpl * 8), fstep = (unsigned)(fpl * 8);
+      const unsigned f2b = (unsigned)(f2 * 8), fstep = (unsigned)(fpl * 8);
 #pragma unroll
       for (int m = 0; m < KS; m++) {
         const unsigned k = (unsigned)((k0 + m < nz) ? k0 + m : nz - 1);
-        const unsigned vh = o2b + k * hstep, vf = f2b + k * fstep;
+        const unsigned vf = f2b + k * fstep;
         ru[m] = *(const double *)(ub + vf);
         rvr[m] = *(const double *)(vb + vf);
-#pragma unroll
-        for (int q = 0; q < NH; q++) hr[m][q] = *(const double *)(hb[q] + vh);
       }
+#pragma unroll
+      for (int m = 0; m < KS; m++) if (m < FC3_PF) FC3_LOAD_H(m);
     }
 #pragma unroll
-    for (int m = 0; m < KS; m++) {      // (a use of every loaded value here: none of the loads can sink into the code below)
-      pin(ru[m]); pin(rvr[m]);
-#pragma unroll
-      for (int q = 0; q < NH; q++) pin(hr[m][q]);
-    }
+    for (int m = 0; m < KS; m++) { pin(ru[m]); pin(rvr[m]); }
     pin(dLf_r); pin(cm_r); pin(cp_r);
     FC_MARK(0);
     double vmax_w = 0.0;
@@ -1309,22 +1322,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     if (!wide) { mk[0] = 0.0; mk[5] = 0.0; }
     if (DIR == 0) mk[5] = 0.0;
   }
-  // The per-face values of the later phases go to LDS at once (every half-wave stores the same values: no ordering between them
-  // is needed, and none of them is held in registers through the reconstruction); the face constants of flux_layer are read
-  // back from there by every pass
+  // The face constants of flux_layer go to LDS at once (every half-wave stores the same values: no ordering between them is needed,
+  // and none of them is held in registers through the reconstruction): every pass reads them back from there
   bool dead_lane;
   {
     const double dLf = dLf_r;
     const double cm = p.o.vol_CFL ? (dLf * cm_r) : cm_r;      // the CFL factor of the minus / plus side cell
     const double cp = p.o.vol_CFL ? (dLf * cp_r) : cp_r;
-    pin(pk_aW); pin(pk_aE); pin(pk_dW); pin(pk_dE); pin(pk_mf); pin(pk_iW); pin(pk_iE); pin(pk_ub); pin(pk_lc);
-    double dxw, dxe;
-    if (p.o.vol_CFL) {
-      dxw = ratio_max(pk_aW, dLf, 1000.0 * pk_dW);
-      dxe = ratio_max(pk_aE, dLf, 1000.0 * pk_dE);
-    } else { dxw = pk_dW; dxe = pk_dE; }
-    fsm[PK_DXW + fl] = dxw; fsm[PK_DXE + fl] = dxe; fsm[PK_MF + fl] = pk_mf; fsm[PK_IAT + fl] = min2(pk_iW, pk_iE);
-    fsm[PK_UHBT + fl] = pk_ub; fsm[PK_DLC + fl] = pk_lc;
+    pin(pk_mf); pin(pk_ub);
+    fsm[PK_MF + fl] = pk_mf; fsm[PK_UHBT + fl] = pk_ub;
     fsm[PK_DLF + fl] = dLf; fsm[PK_CM + fl] = cm; fsm[PK_CP + fl] = cp;
     dead_lane = (pk_mf == 0.0) & (dLf_r == 0.0) & (pk_ub == 0.0);
   }
@@ -1356,6 +1362,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
 #pragma unroll
   for (int m = 0; m < KS; m++) {
     const int k = k0 + m;
+    if (m + FC3_PF < KS) FC3_LOAD_H(m + FC3_PF);
+#pragma unroll
+    for (int q = 0; q < NH; q++) pin(hr[m][q]);      // (the wait for layer m leaves the later layers in flight)
     if (k < nz) {
       const double hm1 = hr[m][1], hc0 = hr[m][2], hp1 = hr[m][3], hp2 = hr[m][4];
       double Lm, Rm;
@@ -1403,6 +1412,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     return;
   }
 
+  // What the phases after the first k-ordered sums read of the 2-D metrics is fetched now (the layer loads have landed and been
+  // consumed: these seven values are not in flight beside them) and parked in LDS; the first evaluation pass covers their latency
+  {
+    double pk_aW = g.areaT[o2], pk_aE = g.areaT[o2 + s], pk_dW = D.dL_T()[o2], pk_dE = D.dL_T()[o2 + s];
+    double pk_iW = g.IareaT[o2], pk_iE = g.IareaT[o2 + s], pk_lc = D.dLC_face()[f2];
+    double dxw, dxe;
+    if (p.o.vol_CFL) {
+      const double dLf = fsm[PK_DLF + fl];
+      dxw = ratio_max(pk_aW, dLf, 1000.0 * pk_dW);
+      dxe = ratio_max(pk_aE, dLf, 1000.0 * pk_dE);
+    } else { dxw = pk_dW; dxe = pk_dE; }
+    fsm[PK_DXW + fl] = dxw; fsm[PK_DXE + fl] = dxe; fsm[PK_IAT + fl] = min2(pk_iW, pk_iE); fsm[PK_DLC + fl] = pk_lc;
+  }
   // ---- layer transports and marginal areas, :622-635
   {
   FC3_FACE(F0);
@@ -1412,7 +1434,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     if (FC3_LIVE(m)) {
       double dd;
       const double uhk = flux_lrc(F0, ru[m], VR(m), sL[m], sR[m], sC[m], pL_, pR_, pC_, dd);
-      if (valid && !p.uhbt && k0 + m < nz) p.uh[f2 + (k0 + m) * fpl] = uhk;      // (with uhbt, uh is stored once, after the solve)
+      if (valid && !p.uhbt && k0 + m < nz) p.uh[FC3_F3(m)] = uhk;      // (with uhbt, uh is stored once, after the solve)
       fsm[sl + m * FC_FL] = uhk; fsm[PL + sl + m * FC_FL] = dd;
     }
     FC3_SCHED(m);
@@ -1602,7 +1624,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
           double dd;
           const double vr = VR(m);
           const double uhk = flux_lrc(F, ru[m] + du_eval * vr, vr, sL[m], sR[m], sC[m], pL_, pR_, pC_, dd);
-          if (valid && k0 + m < nz) p.uh[f2 + (k0 + m) * fpl] = uhk;
+          if (valid && k0 + m < nz) p.uh[FC3_F3(m)] = uhk;
         }
         FC3_SCHED(m);
       }
@@ -1614,7 +1636,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     if (p.uhbt && p.u_cor && !p.set_BT_cont) {      // with BT_cont, u_cor is written in the pass of the fits below
 #pragma unroll
       for (int m = 0; m < KS; m++)
-        if (k0 + m < nz) p.u_cor[f2 + (k0 + m) * fpl] = ru[m] + du * VR(m);
+        if (k0 + m < nz) p.u_cor[FC3_F3(m)] = ru[m] + du * VR(m);
     }
     if (sb == 0 && p.du_cor) p.du_cor[f2] = p.uhbt ? du : 0.0;
   }
@@ -1668,7 +1690,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     pin(sC[m]);
     FC3_PLUS(m);
     if (FC3_LIVE(m)) {
-      const long f3 = f2 + (k0 + m) * fpl;
+      const long f3 = FC3_F3(m);
       const double vr = VR(m), uk = ru[m];
       const bool st = valid && (k0 + m < nz);
       double dL;
@@ -1718,7 +1740,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
     else p.uBT_pp[f2] = (1.5 * (duR - du0)) * ((FAmt_R - FA_avg) / (FAmt_R - FA_0));
   }
 #undef FC3_PLUS
+#undef FC3_F3
 #undef FC3_FACE
+#undef FC3_LOAD_H
 #undef VR
 }
 
@@ -1740,14 +1764,24 @@ bool flux_lane_only() {
 #ifndef FC3_DEFAULT_Y
 #define FC3_DEFAULT_Y 410
 #endif
-int flux_coop_shape(int dir) {      // 410, 67 or 85
+int flux_coop_shape(int dir) {      // 410: round 1's kernel; 67, 85: cont_flux_coop3_kernel; 853 (8x5w3), 163 (16x3): experiments of round 5
+  auto parse = [](const char *e, int dflt) {
+    if (!e) return dflt;
+    if (strcmp(e, "4x10") == 0) return 410;
+    if (strcmp(e, "8x5") == 0) return 85;
+    if (strcmp(e, "8x5w3") == 0) return 853;
+    if (strcmp(e, "16x3") == 0) return 163;
+    return 67;
+  };
   static const int v[2] = {
-      [] { const char *e = getenv("MOM6HIP_CONT_COOP_X"); if (!e) e = getenv("MOM6HIP_CONT_COOP"); return e ? (strcmp(e, "4x10") == 0 ? 410 : (strcmp(e, "8x5") == 0 ? 85 : 67)) : FC3_DEFAULT_X; }(),
-      [] { const char *e = getenv("MOM6HIP_CONT_COOP_Y"); if (!e) e = getenv("MOM6HIP_CONT_COOP"); return e ? (strcmp(e, "4x10") == 0 ? 410 : (strcmp(e, "8x5") == 0 ? 85 : 67)) : FC3_DEFAULT_Y; }()};
+      [&] { const char *e = getenv("MOM6HIP_CONT_COOP_X"); if (!e) e = getenv("MOM6HIP_CONT_COOP"); return parse(e, FC3_DEFAULT_X); }(),
+      [&] { const char *e = getenv("MOM6HIP_CONT_COOP_Y"); if (!e) e = getenv("MOM6HIP_CONT_COOP"); return parse(e, FC3_DEFAULT_Y); }()};
   return v[dir];
 }
-int flux_coop_nk_max() { return std::min(flux_coop_shape(0) == 410 ? FC_KSMAX * FC_NS : (flux_coop_shape(0) == 67 ? 84 : 80),
-                                         flux_coop_shape(1) == 410 ? FC_KSMAX * FC_NS : (flux_coop_shape(1) == 67 ? 84 : 80)); }
+int flux_coop_nk_max() {
+  auto cap = [](int shape) { return shape == 410 ? FC_KSMAX * FC_NS : (shape == 67 ? 84 : (shape == 163 ? 96 : 80)); };
+  return std::min(cap(flux_coop_shape(0)), cap(flux_coop_shape(1)));
+}
 
 bool flux_is_coop(const FluxArgs &f) {
   // (and a 3-D array stays below 4 GB: the kernel addresses its layers with 32-bit byte offsets)
@@ -1786,6 +1820,8 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     const int shape = flux_coop_shape(DIR);
     if (shape == 67) return go3(cont_flux_coop3_kernel<DIR, 7, 6, 3>, 6, fc3_lds_bytes<7, 6>());
     if (shape == 85) return go3(cont_flux_coop3_kernel<DIR, 5, 8, 4>, 8, fc3_lds_bytes<5, 8>());
+    if (shape == 853) return go3(cont_flux_coop3_kernel<DIR, 5, 8, 3>, 8, fc3_lds_bytes<5, 8>());
+    if (shape == 163) return go3(cont_flux_coop3_kernel<DIR, 3, 16, 4>, 16, fc3_lds_bytes<3, 16>());
     return go(cont_flux_coop_kernel<DIR, FC_KSMAX>, FC_KSMAX);
   }
   hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
@@ -1907,7 +1943,7 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
   const bool x_first = (ctx->host.first_direction % 2) == 0;
   const double h_min = g.Angstrom_H;
 
-  // ---- open boundaries: what the kernels read of OBC, on the device (built at every call: regional configurations are small) ----
+  // ---- open boundaries: what the kernels read of OBC, on the device (built once per OBC and kept with the context) ----
   struct ObcDir { int on = 0, open = 0, simple = 0, specified = 0; const int32_t *segnum = nullptr, *cell = nullptr, *fa = nullptr; } ob[2];
   const SegDev *d_segs = nullptr;
   if (obc && obc->number_of_segments > 0) {
@@ -1916,10 +1952,12 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
     const int nseg = obc->number_of_segments;
     M6_REQUIRE(nseg <= 1024, "continuity_PPM: at most 1024 OBC segments");
     const size_t nH2 = (size_t)g.nih * g.njh, nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1);
+    // The validity of the segments and the device pointers of the specified ones' data (checked and staged at every call: the data may be
+    // host arrays), then the two device tables, each built and uploaded once per OBC (m6::obc_table): the maps -- segnum_u, segnum_v, the
+    // cells' reconstruction codes of either direction, the open faces' interior side -- and the segment table (keyed on the data pointers too)
     std::vector<SegDev> segs(nseg);
-    std::vector<int32_t> cell[2] = {std::vector<int32_t>(nH2, 0), std::vector<int32_t>(nH2, 0)};
-    std::vector<int32_t> fa[2] = {std::vector<int32_t>(nU2, 0), std::vector<int32_t>(nV2, 0)};
     const int open_d[2] = {obc->open_u_BCs_exist_globally != 0, obc->open_v_BCs_exist_globally != 0};
+    uint64_t key = m6::obc_fingerprint(ctx, obc), key_segs = key;
     for (int n = 0; n < nseg; n++) {
       const mom6hip_obc_segment_t &S = obc->segment[n];
       SegDev &d = segs[n];
@@ -1939,31 +1977,36 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
         const size_t cnt = ew ? (size_t)(S.IedB - S.IsdB + 1) * (S.jed - S.jsd + 1) * g.nk : (size_t)(S.ied - S.isd + 1) * (S.JedB - S.JsdB + 1) * g.nk;
         d.normal_trans = st.in(S.normal_trans, cnt * 8); d.normal_vel = st.in(S.normal_vel, cnt * 8);
       }
-      const int dd = ew ? 0 : 1;
-      const int A = ew ? S.IsdB : S.JsdB, c0 = ew ? S.jsd : S.isd, c1 = ew ? S.jed : S.ied;
-      const bool plus = S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_N;
-      for (int c = c0; c <= c1; c++) {
-        const long ca = ew ? g.h2(A, c) : g.h2(c, A), cb = ew ? g.h2(A + 1, c) : g.h2(c, A + 1);
-        if (open_d[dd]) {      // PPM_reconstruction_x/y :2385-2432: zero slopes, then the edge values (a later segment has the last word)
-          cell[dd][ca] = 1 | ((plus ? 1 : 3) << 1);
-          cell[dd][cb] = 1 | ((plus ? 2 : 1) << 1);
-          if (S.open && (ew ? S.is_E_or_W : S.is_N_or_S)) fa[dd][ew ? g.u2(A, c) : g.v2(c, A)] = plus ? 1 : 2;      // :782-805, :1058-1088
+      key_segs = m6::obc_mix(m6::obc_mix(key_segs, (uint64_t)(uintptr_t)d.normal_trans), (uint64_t)(uintptr_t)d.normal_vel);
+    }
+    M6_REQUIRE(!st.failed(), "continuity_PPM: staging of the open boundaries failed");
+    const size_t n_maps = 2 * nU2 + 2 * nV2 + 2 * nH2;
+    const int32_t *maps = (const int32_t *)m6::obc_table(ctx, m6::OBC_SITE_CONT, key, 4 * n_maps, [&](void *host) -> int {
+      int32_t *su = (int32_t *)host, *sv = su + nU2, *cx = sv + nV2, *cy = cx + nH2, *fx = cy + nH2, *fy = fx + nU2;
+      memcpy(su, obc->segnum_u, 4 * nU2); memcpy(sv, obc->segnum_v, 4 * nV2);
+      int32_t *cell[2] = {cx, cy}, *fa[2] = {fx, fy};
+      for (int n = 0; n < nseg; n++) {
+        const mom6hip_obc_segment_t &S = obc->segment[n];
+        if (!S.on_pe) continue;
+        const bool ew = S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_W;
+        const int dd = ew ? 0 : 1;
+        const int A = ew ? S.IsdB : S.JsdB, c0 = ew ? S.jsd : S.isd, c1 = ew ? S.jed : S.ied;
+        const bool plus = S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_N;
+        for (int c = c0; c <= c1; c++) {
+          const long ca = ew ? g.h2(A, c) : g.h2(c, A), cb = ew ? g.h2(A + 1, c) : g.h2(c, A + 1);
+          if (open_d[dd]) {      // PPM_reconstruction_x/y :2385-2432: zero slopes, then the edge values (a later segment has the last word)
+            cell[dd][ca] = 1 | ((plus ? 1 : 3) << 1);
+            cell[dd][cb] = 1 | ((plus ? 2 : 1) << 1);
+            if (S.open && (ew ? S.is_E_or_W : S.is_N_or_S)) fa[dd][ew ? g.u2(A, c) : g.v2(c, A)] = plus ? 1 : 2;      // :782-805, :1058-1088
+          }
         }
       }
-    }
-    SegDev *ds = (SegDev *)st.scratch(sizeof(SegDev) * nseg);
-    int32_t *dsu = (int32_t *)st.scratch(4 * nU2), *dsv = (int32_t *)st.scratch(4 * nV2);
-    int32_t *dcx = (int32_t *)st.scratch(4 * nH2), *dcy = (int32_t *)st.scratch(4 * nH2);
-    int32_t *dfx = (int32_t *)st.scratch(4 * nU2), *dfy = (int32_t *)st.scratch(4 * nV2);
-    M6_REQUIRE(!st.failed() && ds && dsu && dsv && dcx && dcy && dfx && dfy, "continuity_PPM: staging of the open boundaries failed");
-    M6_HIP(hipMemcpyAsync(ds, segs.data(), sizeof(SegDev) * nseg, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(dsu, obc->segnum_u, 4 * nU2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(dsv, obc->segnum_v, 4 * nV2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(dcx, cell[0].data(), 4 * nH2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(dcy, cell[1].data(), 4 * nH2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(dfx, fa[0].data(), 4 * nU2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(dfy, fa[1].data(), 4 * nV2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipStreamSynchronize(s));      // (the host vectors go out of scope)
+      return 0;
+    });
+    const SegDev *ds = (const SegDev *)m6::obc_table(ctx, m6::OBC_SITE_CONT, m6::obc_mix(key_segs, 0x5e95ull), sizeof(SegDev) * nseg,
+                                                     [&](void *host) -> int { memcpy(host, segs.data(), sizeof(SegDev) * nseg); return 0; });
+    if (!maps || !ds) return 1;
+    const int32_t *dsu = maps, *dsv = dsu + nU2, *dcx = dsv + nV2, *dcy = dcx + nH2, *dfx = dcy + nH2, *dfy = dfx + nU2;
     d_segs = ds;
     const int pe = obc->OBC_pe != 0;
     ob[0].on = ob[1].on = 1;

@@ -619,11 +619,7 @@ extern "C" int mom6hip_coradcalc_obc(mom6hip_ctx_t *ctx, const mom6hip_coriolisa
     o.uh_center = en_dis ? (double *)st.scratch(bU) : nullptr; o.vh_center = en_dis ? (double *)st.scratch(bV) : nullptr;
     o.zero_vorticity = obc->zero_vorticity; o.freeslip_vorticity = obc->freeslip_vorticity;
     o.computed_vorticity = obc->computed_vorticity; o.specified_vorticity = obc->specified_vorticity;
-    int32_t *d_su = (int32_t *)st.scratch(4 * nU2), *d_sv = (int32_t *)st.scratch(4 * nV2);
-    M6_REQUIRE(!st.failed() && o.Area_h && o.Area_q && o.dvdx && o.dudy && o.hArea_u && o.hArea_v && d_su && d_sv, "CorAdCalc: staging of the open boundaries failed");
-    // gradKE :1037-1050: the faces of every segment of the PE over its whole range (segnum holds them when it is given; the table is
-    // rebuilt here from the segments, which is what the reference loops over)
-    std::vector<int32_t> su(nU2, 0), sv(nV2, 0);
+    M6_REQUIRE(!st.failed() && o.Area_h && o.Area_q && o.dvdx && o.dudy && o.hArea_u && o.hArea_v, "CorAdCalc: staging of the open boundaries failed");
     std::vector<CorSeg> segs(nseg);
     for (int n = 0; n < nseg; n++) {
       const mom6hip_obc_segment_t &S = obc->segment[n];
@@ -640,12 +636,22 @@ extern "C" int mom6hip_coradcalc_obc(mom6hip_ctx_t *ctx, const mom6hip_coriolisa
       const size_t cnt = (size_t)(S.IedB - S.IsdB + 1) * (S.JedB - S.JsdB + 1) * g.nk;
       if (obc->computed_vorticity) { M6_REQUIRE(S.tangential_vel, "CorAdCalc: OBC_COMPUTED_VORTICITY needs segment%%tangential_vel"); d.tangential_vel = st.in(S.tangential_vel, cnt * 8); }
       if (obc->specified_vorticity) { M6_REQUIRE(S.tangential_grad, "CorAdCalc: OBC_SPECIFIED_VORTICITY needs segment%%tangential_grad"); d.tangential_grad = st.in(S.tangential_grad, cnt * 8); }
-      if (ns) for (int i = S.isd; i <= S.ied; i++) sv[g.v2(i, S.JsdB)] = 1;
-      else for (int j = S.jsd; j <= S.jed; j++) su[g.u2(S.IsdB, j)] = 1;
     }
     M6_REQUIRE(!st.failed(), "CorAdCalc: staging of the open boundaries failed");
-    M6_HIP(hipMemcpyAsync(d_su, su.data(), 4 * nU2, hipMemcpyHostToDevice, s));
-    M6_HIP(hipMemcpyAsync(d_sv, sv.data(), 4 * nV2, hipMemcpyHostToDevice, s));
+    // gradKE :1037-1050: the faces of every segment of the PE over its whole range (segnum holds them when it is given; the table is
+    // rebuilt from the segments, which is what the reference loops over) -- once per OBC, kept with the context (m6::obc_table)
+    const int32_t *d_su = (const int32_t *)m6::obc_table(ctx, m6::OBC_SITE_CORAD, m6::obc_fingerprint(ctx, obc), 4 * (nU2 + nV2), [&](void *host) -> int {
+      int32_t *su = (int32_t *)host, *sv = su + nU2;
+      for (int n = 0; n < nseg; n++) {
+        const mom6hip_obc_segment_t &S = obc->segment[n];
+        if (!S.on_pe) continue;
+        if (S.is_N_or_S) for (int i = S.isd; i <= S.ied; i++) sv[g.v2(i, S.JsdB)] = 1;
+        else for (int j = S.jsd; j <= S.jed; j++) su[g.u2(S.IsdB, j)] = 1;
+      }
+      return 0;
+    });
+    if (!d_su) return 1;
+    const int32_t *d_sv = d_su + nU2;
     const int ni2 = g.iec - g.isc + 5, nj2 = g.jec - g.jsc + 5;      // (is-2 : ie+2, js-2 : je+2)
     hipLaunchKernelGGL(cor_obc_area_kernel, dim3((ni2 + 255) / 256, nj2), dim3(256), 0, s, o, 0);
     auto seg_launch = [&](int phase) {
@@ -661,7 +667,6 @@ extern "C" int mom6hip_coradcalc_obc(mom6hip_ctx_t *ctx, const mom6hip_coriolisa
     seg_launch(1);
     seg_launch(2);
     M6_HIP(hipGetLastError());
-    M6_HIP(hipStreamSynchronize(s));      // (the host tables go out of scope)
     a.o_dvdx = o.dvdx; a.o_dudy = o.dudy; a.o_hArea_u = o.hArea_u; a.o_hArea_v = o.hArea_v; a.o_uh_center = o.uh_center;
     a.o_vh_center = o.vh_center; a.o_Area_q = o.Area_q; a.o_seg_u = d_su; a.o_seg_v = d_sv;
   }

@@ -924,10 +924,9 @@ int hv_obc_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, m6
     if (S.is_E_or_W) for (int j = S.jsd; j <= S.jed; j++) fu[g.u2(I, j)] |= 2;      // :1751-1762
     if (S.is_N_or_S) for (int i = S.isd; i <= S.ied; i++) fv[g.v2(i, J)] |= 2;      // :1771-1782
   }
-  int32_t *dm = (int32_t *)st.scratch(4 * m.size());
-  M6_REQUIRE(!st.failed() && dm, "horizontal_viscosity: staging of the open boundaries failed");
-  M6_HIP(hipMemcpyAsync(dm, m.data(), 4 * m.size(), hipMemcpyHostToDevice, ctx->stream));
-  M6_HIP(hipStreamSynchronize(ctx->stream));      // (the host vector goes out of scope)
+  // (the maps change only with the OBC: uploaded when their content differs from the copy the context keeps, never waited for)
+  const int32_t *dm = (const int32_t *)m6::obc_table_content(ctx, m6::OBC_SITE_HORVISC, m6::obc_fingerprint(ctx, obc), m.data(), 4 * m.size());
+  if (!dm) return 1;
   ob.q = dm; ob.fu = dm + nQ; ob.fv = ob.fu + nU; ob.hu = ob.fv + nV; ob.hv = ob.hu + nU;
   ob.tang_u = tang_u; ob.tang_v = tang_v;
   M6_HIP(hipGetLastError());

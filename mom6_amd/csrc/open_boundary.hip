@@ -3,7 +3,10 @@
 // gradient condition, nudging), open_boundary_apply_normal_flow :3337, the pass of u_new, v_new, and open_boundary_zero_normal_flow
 // :3374.  One launch a segment (thread per point along the segment and layer): a configuration has a handful of segments, a point of
 // a segment reads the two faces inside the boundary and writes its own face only, and a later segment has the last word where two
-// overlap, as in the reference's loop over the segments.  Oblique radiation, the tangential forms and the tracer reservoirs are refused.
+// overlap, as in the reference's loop over the segments.  Provided as well (round 4): oblique radiation (rad_segment_kernel's oblique branch
+// with the rates kept in OBC%rx_oblique_u ... cff_normal_v), the tangential forms ORLANSKI_ / NUDGED_ / OBLIQUE_TAN and _GRAD
+// (rad_tangential_kernel: segment%tangential_vel, tangential_grad at the corner points) and update_segment_tracer_reservoirs
+// (obc_reservoir_kernel).
 #include <cmath>
 #include <vector>
 
@@ -112,7 +115,6 @@ __global__ __launch_bounds__(64) void rad_tangential_kernel(m6::GridDev g, RadSe
   auto QM = [&](int t, int qq) -> long { return S.ew ? g.q2(t, qq) : g.q2(qq, t); };
   const int g0 = (S.ew ? g.jsd : g.isd) + 1, g1 = (S.ew ? g.jed : g.ied) - 1;
   if (a.bits & (MOM6HIP_OBC_TAN_OBLIQUE | MOM6HIP_OBC_GRAD_OBLIQUE)) {      // :2456-2556 (E) and its three twins
-    const long tstep = S.ew ? g.nih : 1;      // one corner point along the boundary, in the tangential component's array
     auto TQ = [&](int t, int qq) -> double { return tn[(S.ew ? g.v2(t, qq) : g.u2(qq, t)) + tpl * k]; };
     const int cd0 = S.ew ? g.jsd : g.isd, cd1 = S.ew ? g.jed : g.ied;
     const int gt0 = (S.c0 - 1 > cd0) ? S.c0 - 1 : cd0, gt1 = (S.c1 + 1 < cd1) ? S.c1 + 1 : cd1;
@@ -128,7 +130,6 @@ __global__ __launch_bounds__(64) void rad_tangential_kernel(m6::GridDev g, RadSe
       return (((TQ(lo1 + 1, c) - TQ(lo1, c)) * Idm[QM(lo1, c)]) - (TQ(lo1 + 1, c - 1) - TQ(lo1, c - 1)) * Idm[QM(lo1, c - 1)]) *
              maskC[S.ew ? g.u2(lo1, c) : g.v2(c, lo1)];
     };
-    (void)tstep;
     double rn, rt, cff;
     if (gamma_u < 1.0) {
       if (q == a.q0)      { rn = a.rn_st[F3(S.c0)]; rt = a.rt_st[F3(S.c0)]; cff = a.cf_st[F3(S.c0)]; }
@@ -246,31 +247,102 @@ int check_segment_range(const m6::GridDev &g, const mom6hip_obc_segment_t &S, in
 // Per face of the u and v grids, the cell an open-boundary face takes its cell-centred fields from (the zero-gradient
 // projections of vertvisc_coef, set_viscous_BBL, ...): -1 the first cell (OBC_DIRECTION_E | N), +1 the second (W | S), 0 elsewhere.
 // From OBC%segnum_u / segnum_v and the segments' directions; device arrays that live as long as `st`.  null maps: no segments.
+uint64_t m6::obc_fingerprint(const mom6hip_ctx_t *ctx, const mom6hip_obc_t *obc) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  if (!obc) return h;
+  const m6::GridDev &g = ctx->g;
+  const int32_t *flags = &obc->number_of_segments;      // the int32 members up to zero_biharmonic
+  for (int q = 0; q < 16; q++) h = m6::obc_mix(h, (uint64_t)(uint32_t)flags[q]);
+  h = m6::obc_mix(h, (uint64_t)g.nih); h = m6::obc_mix(h, (uint64_t)g.njh);
+  for (int n = 0; n < obc->number_of_segments && obc->segment; n++) {
+    const int32_t *sp = &obc->segment[n].direction;      // direction ... Flather: 20 int32 members
+    for (int q = 0; q < 20; q++) h = m6::obc_mix(h, (uint64_t)(uint32_t)sp[q]);
+  }
+  h = m6::obc_mix(h, (uint64_t)(uintptr_t)obc->segnum_u); h = m6::obc_mix(h, (uint64_t)(uintptr_t)obc->segnum_v);
+  // a sample of the two maps (every 61st value): an array reused at the same address for another configuration gives another key
+  const size_t nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1);
+  if (obc->segnum_u) for (size_t q = 0; q < nU2; q += 61) h = m6::obc_mix(h, (uint64_t)(uint32_t)obc->segnum_u[q]);
+  if (obc->segnum_v) for (size_t q = 0; q < nV2; q += 61) h = m6::obc_mix(h, (uint64_t)(uint32_t)obc->segnum_v[q]);
+  return h;
+}
+
+const void *m6::obc_table(mom6hip_ctx_t *ctx, int site, uint64_t key, size_t bytes, const std::function<int(void *)> &build) {
+  ctx->obc_table_clock++;
+  for (auto &e : ctx->obc_tables)
+    if (e.site == site && e.key == key && e.bytes == bytes) { e.last_use = ctx->obc_table_clock; return e.buf.p; }
+  std::vector<char> host(bytes ? bytes : 1, 0);
+  if (build(host.data())) return nullptr;
+  if (ctx->obc_tables.size() >= 64) {      // drop the entry that has not been used for the longest time
+    size_t old = 0;
+    for (size_t q = 1; q < ctx->obc_tables.size(); q++) if (ctx->obc_tables[q].last_use < ctx->obc_tables[old].last_use) old = q;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { m6::set_error("obc_table: hipStreamSynchronize failed"); return nullptr; }
+    ctx->obc_tables[old].buf.release();
+    ctx->obc_tables.erase(ctx->obc_tables.begin() + (long)old);
+  }
+  mom6hip_ctx::ObcTable e;
+  e.site = site; e.key = key; e.bytes = bytes; e.last_use = ctx->obc_table_clock;
+  if (e.buf.reserve(bytes ? bytes : 8) != 0 || !e.buf.p) { m6::set_error("obc_table: out of device memory"); return nullptr; }
+  if (hipMemcpyAsync(e.buf.p, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {      // (the host vector goes out of scope; once per OBC and site)
+    m6::set_error("obc_table: the upload of an open-boundary table failed");
+    e.buf.release();
+    return nullptr;
+  }
+  ctx->obc_table_builds++;
+  ctx->obc_tables.push_back(e);
+  return ctx->obc_tables.back().buf.p;
+}
+
+const void *m6::obc_table_content(mom6hip_ctx_t *ctx, int site, uint64_t key, const void *host, size_t bytes) {
+  ctx->obc_table_clock++;
+  mom6hip_ctx::ObcTable *e = nullptr;
+  for (auto &q : ctx->obc_tables) if (q.site == site && q.key == key) { e = &q; break; }
+  if (e && e->bytes == bytes && e->host.size() == bytes && memcmp(e->host.data(), host, bytes) == 0) { e->last_use = ctx->obc_table_clock; return e->buf.p; }
+  if (!e) {
+    mom6hip_ctx::ObcTable n;
+    n.site = site; n.key = key; n.bytes = 0; n.last_use = 0;
+    ctx->obc_tables.push_back(n);
+    e = &ctx->obc_tables.back();
+  }
+  if (e->buf.reserve(bytes ? bytes : 8) != 0 || !e->buf.p) { m6::set_error("obc_table: out of device memory"); return nullptr; }
+  // (the entry's former contents are still being read by host-to-device copies only if one is in flight from them: wait for it)
+  if (!e->host.empty() && hipStreamSynchronize(ctx->stream) != hipSuccess) { m6::set_error("obc_table: hipStreamSynchronize failed"); return nullptr; }
+  e->host.assign((const char *)host, (const char *)host + bytes);
+  e->bytes = bytes; e->last_use = ctx->obc_table_clock;
+  if (hipMemcpyAsync(e->buf.p, e->host.data(), bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    m6::set_error("obc_table: the upload of an open-boundary table failed");
+    return nullptr;
+  }
+  ctx->obc_table_builds++;
+  return e->buf.p;
+}
+
 int m6::obc_side_maps(mom6hip_ctx_t *ctx, m6::Stager &st, const mom6hip_obc_t *obc, const int32_t **side_u, const int32_t **side_v,
                       const char *who) {
+  (void)st;
   *side_u = *side_v = nullptr;
   if (!obc || obc->number_of_segments <= 0) return 0;
   M6_REQUIRE(obc->segment && obc->segnum_u && obc->segnum_v, "%s: OBC%%segment, segnum_u and segnum_v are required", who);
   const m6::GridDev g = ctx->g;
   const size_t nU2 = (size_t)(g.nih + 1) * g.njh, nV2 = (size_t)g.nih * (g.njh + 1);
-  std::vector<int32_t> m(nU2 + nV2, 0);
-  for (int d = 0; d < 2; d++) {
-    const int32_t *segnum = d ? obc->segnum_v : obc->segnum_u;
-    int32_t *o = m.data() + (d ? nU2 : 0);
-    for (size_t n = 0; n < (d ? nV2 : nU2); n++) {
-      const int l = segnum[n];
-      if (l == MOM6HIP_OBC_NONE) continue;
-      M6_REQUIRE(l >= 1 && l <= obc->number_of_segments, "%s: OBC%%segnum_%c holds %d, with %d segments", who, d ? 'v' : 'u', l, obc->number_of_segments);
-      const int dir = obc->segment[l - 1].direction;
-      if (dir == (d ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E)) o[n] = -1;
-      else if (dir == (d ? MOM6HIP_OBC_DIRECTION_S : MOM6HIP_OBC_DIRECTION_W)) o[n] = 1;
+  const void *dm = m6::obc_table(ctx, m6::OBC_SITE_SIDE, m6::obc_fingerprint(ctx, obc), 4 * (nU2 + nV2), [&](void *host) -> int {
+    int32_t *m = (int32_t *)host;
+    for (int d = 0; d < 2; d++) {
+      const int32_t *segnum = d ? obc->segnum_v : obc->segnum_u;
+      int32_t *o = m + (d ? nU2 : 0);
+      for (size_t n = 0; n < (d ? nV2 : nU2); n++) {
+        const int l = segnum[n];
+        if (l == MOM6HIP_OBC_NONE) continue;
+        M6_REQUIRE(l >= 1 && l <= obc->number_of_segments, "%s: OBC%%segnum_%c holds %d, with %d segments", who, d ? 'v' : 'u', l, obc->number_of_segments);
+        const int dir = obc->segment[l - 1].direction;
+        if (dir == (d ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E)) o[n] = -1;
+        else if (dir == (d ? MOM6HIP_OBC_DIRECTION_S : MOM6HIP_OBC_DIRECTION_W)) o[n] = 1;
+      }
     }
-  }
-  int32_t *dm = (int32_t *)st.scratch(4 * (nU2 + nV2));
-  M6_REQUIRE(!st.failed() && dm, "%s: staging of the open boundaries failed", who);
-  M6_HIP(hipMemcpyAsync(dm, m.data(), 4 * (nU2 + nV2), hipMemcpyHostToDevice, ctx->stream));
-  M6_HIP(hipStreamSynchronize(ctx->stream));      // (the host vector goes out of scope)
-  *side_u = dm; *side_v = dm + nU2;
+    return 0;
+  });
+  if (!dm) return 1;
+  *side_u = (const int32_t *)dm; *side_v = (const int32_t *)dm + nU2;
   return 0;
 }
 

@@ -556,6 +556,9 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   call refuse(flag, "FPMIX")
   call get_param(param_file, mdl, "VISC_REM_BUG", flag, default=.false., do_not_log=.true.)
   call refuse(flag, "VISC_REM_BUG")
+  ! DEBUG_OBC (:1444): open_boundary_test_extern_h on h (:445) and open_boundary_zero_normal_flow on PFu, PFv (:537) in the step
+  call get_param(param_file, mdl, "DEBUG_OBC", flag, default=.false., do_not_log=.true.)
+  call refuse(flag .and. associated(OBC), "DEBUG_OBC with open boundaries")
   ! GPU_RESIDENT_DYNAMICS (GPU path): if true, the fields the split RK2 step (and the other shims) work on stay on the GPU between
   ! calls: the host uploads them only after dyn_split_RK2_host_was_modified and sees them only after dyn_split_RK2_sync_to_host.  If
   ! false, every step uploads its inputs and copies its outputs back.

@@ -2,7 +2,9 @@
  * the settings of .testing/tc3: radiation_open_bdry_conds :2196-3336 for the normal component (Orlanski radiation, the gradient condition,
  * nudging), open_boundary_apply_normal_flow :3337-3370, open_boundary_zero_normal_flow :3374-3403.  The reference writes the four
  * directions out separately (E :2326, W :2571, N :2816, S :3060); they differ in the direction of "inside" only and are restated once.
- * Oblique radiation, the tangential forms and the tracer reservoirs are not restated (the callers refuse them).
+ * Restated as well (round 4): oblique radiation (:2349-2383 and its three twins, with gradient_at_q_points :3407 evaluated in place and
+ * the restart fields rx_oblique_u ... cff_normal_v), the tangential forms ORLANSKI_TAN / _GRAD, NUDGED_TAN / _GRAD, OBLIQUE_TAN / _GRAD
+ * (:2403-2556 E and twins: segment%tangential_vel, tangential_grad), and update_segment_tracer_reservoirs :5373-5502.
  * PARITY UNPINNED: the reference holds no known-answer vectors for these routines. */
 #include <math.h>
 #include <stdlib.h>

@@ -248,6 +248,18 @@ def test_btstep_matches_oracle_bitwise(kw, space):
     dg.close()
 
 
+FUSED_CASES = [BT_CASES[0], BT_CASES[1], BT_CASES[3], BT_CASES[4], BT_CASES[8], BT_CASES[9]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", FUSED_CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in FUSED_CASES])
+def test_btstep_with_the_fused_step_kernel_matches_oracle_bitwise(kw, monkeypatch):
+    """MOM6HIP_BT_FUSED=1: one kernel a barotropic step with LDS-staged halo tiles and alternating field sets (bt_step_fused_kernel,
+    round 5: bit-exact, slower than the four kernels -- profiles/r05_experiments.txt -- and therefore not the default)"""
+    monkeypatch.setenv("MOM6HIP_BT_FUSED", "1")
+    test_btstep_matches_oracle_bitwise(kw, "device")
+
+
 @pytest.mark.gpu
 def test_btstep_optional_arguments_gpu():
     """Predictor-style call: no etaav, eta_PF_start given, bottom stress given, no layer fluxes; eta_out aliases eta_in."""

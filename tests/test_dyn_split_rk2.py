@@ -197,6 +197,14 @@ def test_step_matches_oracle_bitwise(kw):
     dg.close()
 
 
+@pytest.mark.gpu
+def test_step_with_the_fused_barotropic_kernel_matches_oracle_bitwise(monkeypatch):
+    """the subcycle replayed from its hipGraph with the fused step kernel (MOM6HIP_BT_FUSED=1), three RK2 steps"""
+    monkeypatch.setenv("MOM6HIP_BT_FUSED", "1")
+    test_step_matches_oracle_bitwise(dict(ni=70, nj=10, nk=2, seed=8))
+    test_step_matches_oracle_bitwise(dict(reentrant_y=True))
+
+
 def _visc_arrays(g, seed=9):
     rng = np.random.default_rng(seed)
     su, sv = g.shape2(_abi.POS_U), g.shape2(_abi.POS_V)

@@ -211,6 +211,52 @@ def case_state(name, seed=21):
     return g, d, taux, tauy, ustar, bbl, Rlay, g_prime
 
 
+def config_state(name):
+    """The configuration's own analytic initial state on its grid (tests/config_ics.py): tc1 -- `benchmark` topography, thicknesses and
+    temperatures on the `ts_range` coordinate (.testing/tc1/MOM_input: TOPO_CONFIG, THICKNESS_CONFIG, TS_CONFIG = "benchmark", COORD_CONFIG =
+    "ts_range", SOUTHLAT = -41, LENLAT = 41, LENLON = 90, MAXIMUM_DEPTH = 5500, MINIMUM_DEPTH = 1); tc3 -- a flat 600 m box of 100 km with the
+    disc of `circle_obcs` (DISK_RADIUS = 24) in ten layers of `layer_ref` densities; the ocean at rest (VELOCITY_CONFIG = "zero").  The
+    horizontal metrics stay the synthetic grid's (they are inputs of both sides); wind and boundary-layer inputs as in case_state."""
+    import config_ics as ci
+    from oracle import orc
+    ni, nj, nk = TC_INPUT[name]["shape"]
+    p = pairs_of(name)
+    g = synth.make_grid(ni, nj, nk, land_frac=0.0, seed=321, reentrant_x=_b(p, "REENTRANT_X", True), reentrant_y=False)
+    if name == "tc1":
+        west, len_lon, south, len_lat, max_depth, min_depth = 0.0, 90.0, -41.0, 41.0, 5500.0, 1.0
+        lon, lat = ci.cell_coordinates(g, west, len_lon, south, len_lat)
+        D = ci.benchmark_topography(lon, lat, west, len_lon, south, len_lat, max_depth, min_depth)
+        ci.set_bathymetry(g, D, min_depth)
+        E = orc.eos("WRIGHT"); P_Ref = 2.0e7; nkmb = 4      # NKML + NKBL (bulk mixed layer: MOM.F90:2439-2444)
+        Rlay, g_prime = ci.coord_from_TS_range(nk, E, P_Ref, 25.0, 3.0, 5.0, g.g_Earth, g.Rho0, nk_rho_varies=nkmb)      # TS_RANGE_*
+        h_c = ci.benchmark_thickness(D, lat, south, len_lat, max_depth, Rlay, E, P_Ref, g.Angstrom_H * g.H_to_Z, nk_rho_varies=nkmb) * g.Z_to_H
+        h_c = np.where(D[None] > min_depth, h_c, g.Angstrom_H)
+        T_c, S_c = ci.benchmark_temperature_salinity(lat, south, len_lat, Rlay, E, P_Ref, nk_rho_varies=nkmb)
+    elif name == "tc3":
+        west, len_lon, south, len_lat, max_depth, min_depth = 0.0, 100.0, 0.0, 100.0, 600.0, 1.0
+        lon, lat = ci.cell_coordinates(g, west, len_lon, south, len_lat)
+        D = np.full((nj, ni), max_depth)
+        ci.set_bathymetry(g, D, min_depth)
+        Rlay = 1030.0 + 2.0 * np.arange(nk) / float(nk - 1)      # COORD_CONFIG = "layer_ref": LIGHTEST_DENSITY = 1030, DENSITY_RANGE = 2 (default)
+        g_prime = np.zeros(nk + 1); g_prime[0] = g.g_Earth; g_prime[1:nk] = (g.g_Earth / g.Rho0) * np.diff(Rlay)
+        h_c = ci.circle_obcs_thickness(D, lon, lat, west, len_lon, south, len_lat, max_depth, nk, g.Angstrom_H * g.H_to_Z, 24.0) * g.Z_to_H
+        T_c = np.full((nk, nj, ni), 10.0); S_c = np.full((nk, nj, ni), 35.0)
+    else:
+        raise ValueError(name)
+    d = dict(u=g.zeros3(_abi.POS_U), v=g.zeros3(_abi.POS_V), h=ci.embed3(g, h_c, fill=g.Angstrom_H), T=ci.embed3(g, T_c, fill=10.0),
+             S=ci.embed3(g, S_c, fill=35.0))
+    yy = np.linspace(0.0, np.pi, g.shape2(_abi.POS_U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu)
+    tauy = np.ascontiguousarray(0.0 * g.mask2dCv)
+    rng = np.random.default_rng(17)
+    ustar = np.ascontiguousarray(0.004 + 0.008 * rng.random(g.shape2(_abi.POS_H)))
+    rng = np.random.default_rng(9)
+    su, sv = g.shape2(_abi.POS_U), g.shape2(_abi.POS_V)
+    bbl = dict(Kv_bbl_u=1.0e-3 * (0.5 + rng.random(su)), Kv_bbl_v=1.0e-3 * (0.5 + rng.random(sv)),
+               bbl_thick_u=2.0 + 8.0 * rng.random(su), bbl_thick_v=2.0 + 8.0 * rng.random(sv))
+    return g, d, taux, tauy, ustar, bbl, Rlay, g_prime
+
+
 def meke_of(name, g):
     """USE_MEKE with a nonzero MEKE_VISCOSITY_COEFF_KU: the MEKE module (not part of the hot path) hands horizontal_viscosity MEKE%Ku and
     takes MEKE%mom_src back (MOM_MEKE.F90:1365, MOM_hor_visc.F90:469, :1833).  A synthetic Ku with valid halos."""
@@ -730,11 +776,11 @@ def write_obc_file(path, g, OBC):
                     np.ascontiguousarray(a, dtype="<f8").tofile(f)
 
 
-def tc3_case():
+def tc3_case(ic="synthetic"):
     from mom6_amd.open_boundary import ocean_OBC_type
     from test_continuity_obc import open_faces
     TC_INPUT["tc3"] = dict(shape=(10, 8, 10), pairs=TC3_PAIRS)
-    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = case_state("tc3")
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = case_state("tc3") if ic == "synthetic" else config_state("tc3")
     OBC = ocean_OBC_type(g, TC3_SEGMENTS, **TC3_OBC)
     open_faces(g, OBC)
     OBC.rx_normal, OBC.ry_normal = g.zeros3(_abi.POS_U), g.zeros3(_abi.POS_V)
@@ -790,5 +836,83 @@ def test_tc3_with_its_open_boundaries_from_fortran_matches_oracle_bitwise(tmp_pa
         assert bits_equal(interior(g, got["ry_normal"], _abi.POS_V), interior(g, OBC.ry_normal, _abi.POS_V))
         for n, s in enumerate(OBC.segment):
             assert bits_equal(got[f"normal_vel_{n + 1}"], s.normal_vel), n
+    finally:
+        TC_INPUT.pop("tc3", None)
+
+
+# ---- the configurations' own initial conditions (tests/config_ics.py) ------------------------------------------------------------------------
+def test_oracle_runs_tc1_from_its_benchmark_state():
+    """`benchmark` thicknesses over the `benchmark` basin: vanished buffer layers, a mixed layer of 50 m, interfaces that outcrop polewards"""
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = config_state("tc1")
+    wet = interior(g, np.asarray(g.mask2dT)) > 0
+    col = interior(g, d["h"]).sum(0)
+    assert np.allclose(col[wet] * g.H_to_Z, interior(g, np.asarray(g.bathyT))[wet], rtol=1e-9) and 0.05 < 1.0 - wet.mean() < 0.5
+    assert np.all(np.diff(Rlay[4:]) > 0) and interior(g, d["h"])[0][wet].max() == pytest.approx(50.0 * g.Z_to_H)
+    st, calc, _ = oracle_for("tc1", g, d, ustar, bbl, Rlay, g_prime)
+    for n in range(3):
+        st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+    assert np.all(np.isfinite(st.u)) and st.h.min() > 0 and np.abs(st.u).max() < 1.0
+
+
+def test_oracle_runs_tc3_from_its_disc_for_its_whole_run():
+    """DAYMAX = 0.25 (6 h) at DT = 120 s: 180 steps of the disc of circle_obcs spreading through the four open boundaries"""
+    try:
+        state, OBC = tc3_case(ic="config")
+        g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+        st, calc, _ = oracle_for("tc3", g, d, ustar, bbl, Rlay, g_prime, OBC=OBC)
+        eta0 = interior(g, st.h.sum(0))
+        for n in range(180):
+            st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+        assert np.all(np.isfinite(st.u)) and st.h.min() > 0 and np.abs(st.u).max() < 2.0
+        eta1 = interior(g, st.h.sum(0))
+        assert np.ptp(eta1) < np.ptp(eta0)      # the depression of the column height has spread
+    finally:
+        TC_INPUT.pop("tc3", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+def test_tc1_from_its_benchmark_state_from_fortran_matches_oracle_bitwise(tmp_path, resident):
+    nsteps = 3
+    state = config_state("tc1")
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    exe = build_driver(tmp_path)
+    write_case(tmp_path, "tc1", nsteps, resident, state, bbl_mode=1)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-2000:]
+    st, calc, _ = oracle_for("tc1", g, d, ustar, bbl, Rlay, g_prime)
+    for n in range(nsteps):
+        st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+    got = read_out(str(tmp_path / "out.bin"), g, meke=st.mom_src is not None)
+    want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+    for n, pos, nd in OUT:
+        if n in want:
+            assert bits_equal(interior(g, got[n], pos), interior(g, want[n], pos)), (n, float(np.abs(got[n] - want[n]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
+@pytest.mark.parametrize("resident", [False, True])
+def test_tc3_from_its_disc_for_its_whole_run_from_fortran_matches_oracle_bitwise(tmp_path, resident):
+    """.testing/tc3 as it runs: the disc of circle_obcs, four FLATHER,ORLANSKI segments, DAYMAX = 6 h = 180 steps, through the RK2 module shim"""
+    nsteps = 180
+    try:
+        state, OBC = tc3_case(ic="config")
+        g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+        exe = build_driver(tmp_path)
+        write_case(tmp_path, "tc3", nsteps, resident, state, bbl_mode=1)
+        write_obc_file(str(tmp_path / "obc.bin"), g, OBC)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt"), str(tmp_path / "obc.bin")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-2000:]
+        st, calc, _ = oracle_for("tc3", g, d, ustar, bbl, Rlay, g_prime, OBC=OBC)
+        for n in range(nsteps):
+            st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+        got = read_out(str(tmp_path / "out.bin"), g, OBC=OBC)
+        want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+        for n, pos, nd in OUT:
+            if n in want:
+                assert bits_equal(interior(g, got[n], pos), interior(g, want[n], pos)), (n, float(np.abs(got[n] - want[n]).max()))
     finally:
         TC_INPUT.pop("tc3", None)
