@@ -4,7 +4,9 @@
 !! writes their results; the test compares them with the oracle bit for bit, tools/calibrate_ref_kernels.py times them beside the
 !! oracle's port.  Build container only (the reference is not on the GPU box); supplementary evidence: a build against
 !! stand-ins pins nothing (DESIGN.md section 5).
-!! Usage: ref_kernels_driver <input file> <output file> [repetitions for the timing lines]
+!! Usage: ref_kernels_driver <input file> <output file> [repetitions for the timing lines [OBC file]]
+!! The OBC file (tests/test_reference_kernels.py: write_obc): the ocean_OBC_type as open_boundary_config / open_boundary_init leave it --
+!! dyn_driver.F90's format, then the segments' tangential_vel and tangential_grad, then their tracer registries.
 program ref_kernels_driver
 use, intrinsic :: iso_c_binding
 use MOM_continuity_PPM, only : continuity_PPM, continuity_PPM_init, continuity_PPM_CS
@@ -15,7 +17,7 @@ use MOM_diag_mediator,  only : diag_ctrl, time_type
 use MOM_domains,        only : MOM_domain_type, pass_var, EAST_FACE, NORTH_FACE
 use MOM_file_parser,    only : param_file_type, param_set
 use MOM_grid,           only : ocean_grid_type
-use MOM_open_boundary,  only : ocean_OBC_type
+use MOM_open_boundary,  only : ocean_OBC_type, segment_tracer_registry_type
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : BT_cont_type, porous_barrier_type, accel_diag_ptrs, alloc_BT_cont_type
 use MOM_verticalGrid,   only : verticalGrid_type
@@ -35,7 +37,11 @@ type(tracer_registry_type), pointer :: Reg => NULL()
 type(ocean_OBC_type), pointer :: OBC => NULL()
 type(porous_barrier_type) :: pbv
 type(BT_cont_type), pointer :: BT => NULL()
-integer(c_int32_t) :: hdr(8), ahdr(4)
+integer(c_int32_t) :: hdr(8), ahdr(4), oflags(8), sflags(20), gflags(8), rflags(2)
+integer(c_int32_t), allocatable :: seg_u(:,:), seg_v(:,:)
+integer :: u_obc, nseg, i0, i1, j0, j1, q, nreg
+real :: oscal(2), conc
+character(len=512) :: f_obc
 integer :: ni, nj, nk, halo, u_in, u_out, isd, ied, jsd, jed, nrep, n, m, ntr
 integer(kind=8) :: c0, c1, crate
 real :: scal(7), dt, dt_adv
@@ -89,6 +95,73 @@ hp = h ; hp2 = h ; uh = 0.0 ; vh = 0.0 ; uh2 = 0.0 ; vh2 = 0.0 ; u_cor = 0.0 ; v
 allocate(pbv%por_face_areaU(isd-1:ied,jsd:jed,nk), pbv%por_face_areaV(isd:ied,jsd-1:jed,nk))
 allocate(pbv%por_layer_widthU(isd-1:ied,jsd:jed,nk+1), pbv%por_layer_widthV(isd:ied,jsd-1:jed,nk+1))
 pbv%por_face_areaU = 1.0 ; pbv%por_face_areaV = 1.0 ; pbv%por_layer_widthU = 1.0 ; pbv%por_layer_widthV = 1.0
+
+! ---- the open boundaries (optional fourth argument)
+f_obc = ""
+if (command_argument_count() >= 4) call get_command_argument(4, f_obc)
+if (len_trim(f_obc) > 0) then
+  open(newunit=u_obc, file=trim(f_obc), access="stream", form="unformatted", status="old")
+  allocate(OBC)
+  read(u_obc) oflags, gflags, oscal
+  nseg = oflags(1)
+  OBC%number_of_segments = nseg ; OBC%OBC_pe = (oflags(2) /= 0)
+  OBC%open_u_BCs_exist_globally = (oflags(3) /= 0) ; OBC%open_v_BCs_exist_globally = (oflags(4) /= 0)
+  OBC%specified_u_BCs_exist_globally = (oflags(5) /= 0) ; OBC%specified_v_BCs_exist_globally = (oflags(6) /= 0)
+  OBC%Flather_u_BCs_exist_globally = (oflags(7) /= 0) ; OBC%Flather_v_BCs_exist_globally = (oflags(8) /= 0)
+  OBC%zero_vorticity = (gflags(1) /= 0) ; OBC%freeslip_vorticity = (gflags(2) /= 0) ; OBC%computed_vorticity = (gflags(3) /= 0)
+  OBC%specified_vorticity = (gflags(4) /= 0) ; OBC%zero_strain = (gflags(5) /= 0) ; OBC%freeslip_strain = (gflags(6) /= 0)
+  OBC%computed_strain = (gflags(7) /= 0) ; OBC%zero_biharmonic = (gflags(8) /= 0)
+  OBC%gamma_uv = oscal(1) ; OBC%rx_max = oscal(2)
+  allocate(OBC%segment(nseg))
+  do m=1,nseg
+    read(u_obc) sflags
+    OBC%segment(m)%direction = sflags(1) ; OBC%segment(m)%open = (sflags(2) /= 0) ; OBC%segment(m)%specified = (sflags(3) /= 0)
+    OBC%segment(m)%on_pe = (sflags(4) /= 0) ; OBC%segment(m)%is_E_or_W = (sflags(5) /= 0) ; OBC%segment(m)%is_N_or_S = (sflags(6) /= 0)
+    OBC%segment(m)%HI%IsdB = sflags(7) ; OBC%segment(m)%HI%IedB = sflags(8) ; OBC%segment(m)%HI%JsdB = sflags(9) ; OBC%segment(m)%HI%JedB = sflags(10)
+    OBC%segment(m)%HI%isd = sflags(11) ; OBC%segment(m)%HI%ied = sflags(12) ; OBC%segment(m)%HI%jsd = sflags(13) ; OBC%segment(m)%HI%jed = sflags(14)
+    OBC%segment(m)%Flather = (sflags(15) /= 0) ; OBC%segment(m)%radiation = (sflags(16) /= 0) ; OBC%segment(m)%gradient = (sflags(17) /= 0)
+    OBC%segment(m)%nudged = (sflags(18) /= 0)
+  enddo
+  allocate(seg_u(isd-1:ied,jsd:jed), seg_v(isd:ied,jsd-1:jed), OBC%segnum_u(isd-1:ied,jsd:jed), OBC%segnum_v(isd:ied,jsd-1:jed))
+  read(u_obc) seg_u, seg_v
+  OBC%segnum_u(:,:) = seg_u(:,:) ; OBC%segnum_v(:,:) = seg_v(:,:)
+  do m=1,nseg ; if (OBC%segment(m)%on_pe) then
+    if (OBC%segment(m)%is_E_or_W) then
+      i0 = OBC%segment(m)%HI%IsdB ; i1 = OBC%segment(m)%HI%IedB ; j0 = OBC%segment(m)%HI%jsd ; j1 = OBC%segment(m)%HI%jed
+    else
+      i0 = OBC%segment(m)%HI%isd ; i1 = OBC%segment(m)%HI%ied ; j0 = OBC%segment(m)%HI%JsdB ; j1 = OBC%segment(m)%HI%JedB
+    endif
+    allocate(OBC%segment(m)%normal_vel(i0:i1,j0:j1,nk), OBC%segment(m)%normal_trans(i0:i1,j0:j1,nk), OBC%segment(m)%normal_vel_bt(i0:i1,j0:j1), &
+             OBC%segment(m)%SSH(i0:i1,j0:j1))
+    read(u_obc) OBC%segment(m)%normal_vel, OBC%segment(m)%normal_trans, OBC%segment(m)%normal_vel_bt, OBC%segment(m)%SSH
+  endif ; enddo
+  ! segment%tangential_vel, tangential_grad at the corner points of the segment (IsdB:IedB, JsdB:JedB, nk)
+  do m=1,nseg ; if (OBC%segment(m)%on_pe) then
+    i0 = OBC%segment(m)%HI%IsdB ; i1 = OBC%segment(m)%HI%IedB ; j0 = OBC%segment(m)%HI%JsdB ; j1 = OBC%segment(m)%HI%JedB
+    allocate(OBC%segment(m)%tangential_vel(i0:i1,j0:j1,nk), OBC%segment(m)%tangential_grad(i0:i1,j0:j1,nk))
+    read(u_obc) OBC%segment(m)%tangential_vel, OBC%segment(m)%tangential_grad
+  endif ; enddo
+  ! the segments' tracer registries: [ntseg], then per entry [ntr_index, has a reservoir], OBC_inflow_conc, [tres in the layout of normal_vel]
+  do m=1,nseg ; if (OBC%segment(m)%on_pe) then
+    read(u_obc) rflags(1)
+    nreg = rflags(1)
+    if (nreg > 0) then
+      allocate(OBC%segment(m)%tr_Reg)
+      OBC%segment(m)%tr_Reg%ntseg = nreg
+      do q=1,nreg
+        read(u_obc) rflags
+        read(u_obc) conc
+        OBC%segment(m)%tr_Reg%Tr(q)%ntr_index = rflags(1) ; OBC%segment(m)%tr_Reg%Tr(q)%OBC_inflow_conc = conc
+        if (rflags(2) /= 0) then
+          allocate(OBC%segment(m)%tr_Reg%Tr(q)%tres(lbound(OBC%segment(m)%normal_vel,1):ubound(OBC%segment(m)%normal_vel,1), &
+                   lbound(OBC%segment(m)%normal_vel,2):ubound(OBC%segment(m)%normal_vel,2), nk))
+          read(u_obc) OBC%segment(m)%tr_Reg%Tr(q)%tres
+        endif
+      enddo
+    endif
+  endif ; enddo
+  close(u_obc)
+endif
 
 call param_set(pf, "REENTRANT_X", merge("True ", "False", hdr(5) /= 0))
 call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))
