@@ -2,6 +2,8 @@
 !! list (DTBT > 0, so the time step is the file's), btcalc with the BT_cont face thicknesses, bt_mass_source, btstep with
 !! every optional pointer of the RK2 call (:655) on plain host arrays.  tests/test_fortran_abi.py writes the input file and
 !! compares the output with the oracle bit for bit.   Usage: bt_driver <input file> <output file>
+!! With -DREFERENCE_KERNELS the same program drives the reference's own MOM_barotropic.F90 compiled against the stand-ins
+!! (tests/test_reference_kernels.py; the library's glue is not linked).
 program bt_driver
 use, intrinsic :: iso_c_binding
 use MOM_barotropic,    only : barotropic_CS, barotropic_init, btcalc, bt_mass_source, btstep, barotropic_end, &
@@ -17,7 +19,9 @@ use MOM_restart,       only : MOM_restart_CS
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : BT_cont_type, accel_diag_ptrs, alloc_BT_cont_type
 use MOM_verticalGrid,  only : verticalGrid_type
+#ifndef REFERENCE_KERNELS
 use mom6hip_MOM_glue,  only : mom6hip_shared_context_end
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -133,9 +137,15 @@ if (len_trim(f_obc) > 0) then
   close(u_obc)
 endif
 
+allocate(ADp)      ! (MOM.F90 always hands btstep an allocated accel_diag_ptrs; its members stay unassociated)
 call param_set(pf, "REENTRANT_X", merge("True ", "False", hdr(5) /= 0))
 call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))
 write(str, '(es24.16)') dtbt ; call param_set(pf, "DTBT", str)
+do m = 4, command_argument_count()      ! further NAME=VALUE pairs of the parameter file
+  call get_command_argument(m, f_obc)
+  i0 = index(f_obc, "=")
+  if (i0 > 1) call param_set(pf, f_obc(1:i0-1), trim(f_obc(i0+1:)))
+enddo
 call register_barotropic_restarts(HI, GV, US, pf, CS, restart_CS)
 call barotropic_init(u, v, h, eta, Time, G, GV, US, pf, diag, CS, restart_CS, calc_dtbt, BT)
 call barotropic_get_tav(CS, ubtav, vbtav, G, US)
@@ -148,6 +158,8 @@ open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", statu
 write(u_out) alu, alv, eta_out, uhbtav, vhbtav, etaav, ubtav, vbtav
 close(u_out)
 call barotropic_end(CS)
+#ifndef REFERENCE_KERNELS
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a,l2)') "bt_driver ok calc_dtbt=", calc_dtbt
 end program bt_driver

@@ -101,7 +101,7 @@ implicit none ; private
 public :: sum_across_PEs, min_across_PEs, max_across_PEs
 public :: MOM_domain_type, pass_var, pass_vector, CENTER, EAST_FACE, NORTH_FACE, CORNER, group_pass_type
 public :: To_East, To_West, To_North, To_South, To_All, Omit_Corners, AGRID, BGRID_NE, CGRID_NE, SCALAR_PAIR
-public :: create_group_pass, do_group_pass, start_group_pass, complete_group_pass
+public :: create_group_pass, do_group_pass, start_group_pass, complete_group_pass, clone_MOM_domain, deallocate_MOM_domain
 integer, parameter :: CENTER = 0, EAST_FACE = 1, NORTH_FACE = 2, CORNER = 3
 integer, parameter :: To_East = 1, To_West = 2, To_North = 4, To_South = 8, To_All = 15, Omit_Corners = 16
 integer, parameter :: AGRID = 0, BGRID_NE = 1, CGRID_NE = 2, SCALAR_PAIR = 32
@@ -123,6 +123,27 @@ interface create_group_pass
   module procedure create_var_group_pass_2d, create_var_group_pass_3d, create_vector_group_pass_2d, create_vector_group_pass_3d
 end interface create_group_pass
 contains
+!> A copy of a domain with halos of at least min_halo (which returns the halos taken): one PE, the same topology
+subroutine clone_MOM_domain(MD_in, MOM_dom, min_halo, halo_size, symmetric, domain_name, turns, refine, extra_halo)
+  type(MOM_domain_type),           intent(in)    :: MD_in
+  type(MOM_domain_type),           pointer       :: MOM_dom
+  integer, dimension(2), optional, intent(inout) :: min_halo
+  integer,               optional, intent(in)    :: halo_size, turns, refine, extra_halo
+  logical,               optional, intent(in)    :: symmetric
+  character(len=*),      optional, intent(in)    :: domain_name
+  if (.not.associated(MOM_dom)) allocate(MOM_dom)
+  MOM_dom = MD_in
+  if (present(min_halo)) then
+    MOM_dom%nihalo = max(MOM_dom%nihalo, min_halo(1)) ; min_halo(1) = MOM_dom%nihalo
+    MOM_dom%njhalo = max(MOM_dom%njhalo, min_halo(2)) ; min_halo(2) = MOM_dom%njhalo
+  endif
+  if (present(symmetric)) MOM_dom%symmetric = symmetric
+end subroutine clone_MOM_domain
+subroutine deallocate_MOM_domain(MOM_domain, cursory)
+  type(MOM_domain_type), pointer :: MOM_domain
+  logical,     optional, intent(in) :: cursory
+  if (associated(MOM_domain)) deallocate(MOM_domain)
+end subroutine deallocate_MOM_domain
 ! The group passes of the stand-in remember nothing: the reference's callers are compiled against these interfaces, never run.
 subroutine create_var_group_pass_2d(group, array, MOM_dom, sideflag, position, halo, clock)
   type(group_pass_type),  intent(inout) :: group
@@ -217,7 +238,7 @@ implicit none ; private
 public :: hor_index_type
 type :: hor_index_type
   integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB
-  integer :: idg_offset = 0, jdg_offset = 0
+  integer :: idg_offset = 0, jdg_offset = 0, turns = 0
   logical :: symmetric = .true.
 end type hor_index_type
 end module MOM_hor_index
@@ -240,6 +261,8 @@ type :: ocean_grid_type
   real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
   real, allocatable, dimension(:,:) :: mask2dCv, dxCv, dyCv, dx_Cv, IdxCv, IdyCv, areaCv, IareaCv
   real, allocatable, dimension(:,:) :: mask2dBu, dxBu, dyBu, areaBu, IareaBu, CoriolisBu, IdxBu, IdyBu
+  real, allocatable, dimension(:,:) :: geoLonT, geoLatT
+  integer :: isd_global = 0, jsd_global = 0
 end type ocean_grid_type
 end module MOM_grid
 
@@ -364,7 +387,7 @@ end module MOM_cpu_clock
 module MOM_file_parser
 use MOM_error_handler, only : MOM_error, FATAL
 implicit none ; private
-public :: param_file_type, get_param, log_version, param_set, openParameterBlock, closeParameterBlock
+public :: param_file_type, get_param, log_version, param_set, openParameterBlock, closeParameterBlock, log_param
 character(len=64), save :: block_prefix = ''      !< "NAME%" inside openParameterBlock(NAME) ... closeParameterBlock
 type :: param_file_type
   integer :: n = 0
@@ -374,7 +397,39 @@ end type param_file_type
 interface get_param
   module procedure get_param_logical, get_param_real, get_param_int, get_param_char, get_param_real_array
 end interface
+interface log_param
+  module procedure log_param_logical, log_param_real, log_param_int, log_param_char
+end interface
 contains
+subroutine log_param_logical(CS, modulename, varname, value, desc, units, default, layoutParam, debuggingParam, like_default)
+  type(param_file_type), intent(in) :: CS
+  character(len=*),      intent(in) :: modulename, varname
+  logical,               intent(in) :: value
+  character(len=*), optional, intent(in) :: desc, units
+  logical,          optional, intent(in) :: default, layoutParam, debuggingParam, like_default
+end subroutine log_param_logical
+subroutine log_param_real(CS, modulename, varname, value, desc, units, default, debuggingParam, like_default, unscale)
+  type(param_file_type), intent(in) :: CS
+  character(len=*),      intent(in) :: modulename, varname
+  real,                  intent(in) :: value
+  character(len=*), optional, intent(in) :: desc, units
+  real,             optional, intent(in) :: default, unscale
+  logical,          optional, intent(in) :: debuggingParam, like_default
+end subroutine log_param_real
+subroutine log_param_int(CS, modulename, varname, value, desc, units, default, layoutParam, debuggingParam, like_default)
+  type(param_file_type), intent(in) :: CS
+  character(len=*),      intent(in) :: modulename, varname
+  integer,               intent(in) :: value
+  character(len=*), optional, intent(in) :: desc, units
+  integer,          optional, intent(in) :: default
+  logical,          optional, intent(in) :: layoutParam, debuggingParam, like_default
+end subroutine log_param_int
+subroutine log_param_char(CS, modulename, varname, value, desc, units, default, layoutParam, debuggingParam, like_default)
+  type(param_file_type), intent(in) :: CS
+  character(len=*),      intent(in) :: modulename, varname, value
+  character(len=*), optional, intent(in) :: desc, units, default
+  logical,          optional, intent(in) :: layoutParam, debuggingParam, like_default
+end subroutine log_param_char
 subroutine param_set(CS, name, value)
   type(param_file_type), intent(inout) :: CS
   character(len=*),      intent(in)    :: name, value
@@ -705,7 +760,7 @@ end module MOM_diag_mediator
 module MOM_io
 use MOM_domains, only : CENTER, CORNER, EAST_FACE, NORTH_FACE
 implicit none ; private
-public :: vardesc, var_desc, CENTER, CORNER, EAST_FACE, NORTH_FACE, stdout, stderr
+public :: vardesc, var_desc, CENTER, CORNER, EAST_FACE, NORTH_FACE, stdout, stderr, MOM_read_data, slasher
 integer, parameter :: stdout = 6, stderr = 0
 type :: vardesc
   character(len=64)  :: name = ""
@@ -735,6 +790,24 @@ function var_desc(name, units, longname, hor_grid, z_grid, t_grid, cmor_field_na
   if (present(z_grid)) vd%z_grid = z_grid
   if (present(conversion)) vd%conversion = conversion
 end function var_desc
+!> No files in the stand-in: a read is an error
+subroutine MOM_read_data(filename, fieldname, data, MOM_Domain, timelevel, position, scale, global_file, file_may_be_4d)
+  use MOM_domains, only : MOM_domain_type
+  use MOM_error_handler, only : MOM_error, FATAL
+  character(len=*),       intent(in)    :: filename, fieldname
+  real, dimension(:,:),   intent(inout) :: data
+  type(MOM_domain_type),  intent(in)    :: MOM_Domain
+  integer,      optional, intent(in)    :: timelevel, position
+  real,         optional, intent(in)    :: scale
+  logical,      optional, intent(in)    :: global_file, file_may_be_4d
+  call MOM_error(FATAL, "MOM_read_data (stand-in): no files, asked for "//trim(fieldname)//" of "//trim(filename))
+end subroutine MOM_read_data
+function slasher(dir)
+  character(len=*), intent(in) :: dir
+  character(len=len(dir)+1) :: slasher
+  slasher = trim(dir)
+  if (len_trim(dir) > 0) then ; if (dir(len_trim(dir):len_trim(dir)) /= "/") slasher = trim(dir)//"/" ; endif
+end function slasher
 end module MOM_io
 
 module MOM_get_input
@@ -945,6 +1018,9 @@ use MOM_EOS, only : EOS_type
 implicit none ; private
 public :: BT_cont_type, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, thermo_var_ptrs, vertvisc_type, &
           ocean_internal_state, alloc_BT_cont_type, dealloc_BT_cont_type
+interface alloc_BT_cont_type
+  module procedure alloc_BT_cont_type_ranges, alloc_BT_cont_type_grid
+end interface
 type :: BT_cont_type
   real, allocatable :: FA_u_EE(:,:), FA_u_E0(:,:), FA_u_W0(:,:), FA_u_WW(:,:), uBT_WW(:,:), uBT_EE(:,:)
   real, allocatable :: FA_v_NN(:,:), FA_v_N0(:,:), FA_v_S0(:,:), FA_v_SS(:,:), vBT_SS(:,:), vBT_NN(:,:)
@@ -987,7 +1063,7 @@ type :: ocean_internal_state
   real, pointer, dimension(:,:,:) :: u_av => NULL(), v_av => NULL(), u_prev => NULL(), v_prev => NULL()
 end type ocean_internal_state
 contains
-subroutine alloc_BT_cont_type(BT_cont, isd, ied, jsd, jed, nz, alloc_faces)
+subroutine alloc_BT_cont_type_ranges(BT_cont, isd, ied, jsd, jed, nz, alloc_faces)
   type(BT_cont_type), pointer :: BT_cont
   integer, intent(in) :: isd, ied, jsd, jed, nz
   logical, optional, intent(in) :: alloc_faces
@@ -1001,7 +1077,18 @@ subroutine alloc_BT_cont_type(BT_cont, isd, ied, jsd, jed, nz, alloc_faces)
   if (present(alloc_faces)) then ; if (alloc_faces) then
     allocate(BT_cont%h_u(isd-1:ied,jsd:jed,nz), source=0.0) ; allocate(BT_cont%h_v(isd:ied,jsd-1:jed,nz), source=0.0)
   endif ; endif
-end subroutine alloc_BT_cont_type
+end subroutine alloc_BT_cont_type_ranges
+!> The reference's form (MOM_variables.F90: alloc_BT_cont_type(BT_cont, G, GV, alloc_faces))
+subroutine alloc_BT_cont_type_grid(BT_cont, G, GV, alloc_faces)
+  use MOM_grid, only : ocean_grid_type
+  use MOM_verticalGrid, only : verticalGrid_type
+  type(BT_cont_type),      pointer    :: BT_cont
+  type(ocean_grid_type),   intent(in) :: G
+  type(verticalGrid_type), intent(in) :: GV
+  logical,       optional, intent(in) :: alloc_faces
+  if (associated(BT_cont)) return
+  call alloc_BT_cont_type_ranges(BT_cont, G%isd, G%ied, G%jsd, G%jed, GV%ke, alloc_faces)
+end subroutine alloc_BT_cont_type_grid
 subroutine dealloc_BT_cont_type(BT_cont)
   type(BT_cont_type), pointer :: BT_cont
   if (associated(BT_cont)) deallocate(BT_cont)
@@ -1101,11 +1188,16 @@ use MOM_grid, only : ocean_grid_type
 use MOM_unit_scaling, only : unit_scale_type
 use MOM_file_parser, only : param_file_type
 implicit none ; private
-public :: SAL_CS, SAL_init, SAL_end
+public :: SAL_CS, SAL_init, SAL_end, scalar_SAL_sensitivity
 type :: SAL_CS
   integer :: unused = 0
 end type SAL_CS
 contains
+subroutine scalar_SAL_sensitivity(CS, deta_geo_dpbot)
+  type(SAL_CS), intent(in)  :: CS
+  real,         intent(out) :: deta_geo_dpbot
+  deta_geo_dpbot = 0.0
+end subroutine scalar_SAL_sensitivity
 subroutine SAL_init(G, US, param_file, CS)
   type(ocean_grid_type),  intent(inout) :: G
   type(unit_scale_type),  intent(in)    :: US
@@ -1381,6 +1473,18 @@ subroutine find_col_avg_SpV(h, SpV_avg, tv, G, GV, US, halo_size)
   integer,        optional, intent(in)    :: halo_size
 end subroutine find_col_avg_SpV
 end module MOM_interface_heights
+
+module MOM_checksums
+implicit none ; private
+public :: chksum0
+contains
+subroutine chksum0(scalar, mesg, scale, logunit, unscale)
+  real,              intent(in) :: scalar
+  character(len=*),  intent(in) :: mesg
+  real,    optional, intent(in) :: scale, unscale
+  integer, optional, intent(in) :: logunit
+end subroutine chksum0
+end module MOM_checksums
 
 module MOM_debugging
 use MOM_grid, only : ocean_grid_type

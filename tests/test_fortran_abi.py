@@ -175,14 +175,14 @@ def test_module_shims_match_oracle(tmp_path, reentrant):
         assert bits_equal(ia, iw), n
 
 
-def _bt_case(path):
+def _bt_case(path, reentrant=(True, True), **kw):
     """the input file of tests/fortran/bt_driver.F90 (the btstep inputs of helpers.barotropic_case) and the oracle's results"""
     from helpers import barotropic_case
     from oracle import orc
-    g, cs, case, keep = barotropic_case(orc, ni=26, nj=14, nk=4, reentrant_x=True, reentrant_y=True, dt=900.0)
+    g, cs, case, keep = barotropic_case(orc, **dict(dict(ni=26, nj=14, nk=4, reentrant_x=reentrant[0], reentrant_y=reentrant[1], dt=900.0), **kw))
     h = keep["h"]; bt = keep["bt_arrs"]
     with open(path, "wb") as f:
-        np.array([g.ni, g.nj, g.nk, g.halo, 1, 1, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.ni, g.nj, g.nk, g.halo, int(reentrant[0]), int(reentrant[1]), g.first_direction, 0], dtype="<i4").tofile(f)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, case["dt"], cs.dtbt], dtype="<f8").tofile(f)
         for n in _abi.ALL_METRICS:
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)

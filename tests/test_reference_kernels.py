@@ -223,3 +223,59 @@ def test_the_reference_kernels_with_open_boundaries_equal_the_oracle_bit_for_bit
         a = a.reshape(w.shape)
         pos = position_of(n)
         assert bits_equal(interior(g, a, pos), interior(g, w, pos)), (case, n, np.argwhere(interior(g, a, pos) != interior(g, w, pos))[:4])
+
+
+# ---- MOM_barotropic: btstep --------------------------------------------------------------------------------------------------------------
+def build_ref_module_driver(tmp, ref_sources, driver, opt="-O0"):
+    """the stand-ins, reference files (in place) and one of the repository's module drivers compiled with -DREFERENCE_KERNELS (the same
+    program that drives the module shim on the GPU, without the library's glue)"""
+    flags = ["-cpp", "-DREFERENCE_KERNELS", "-fdefault-real-8", opt, "-ffp-contract=off", f"-I{REF}/config_src/memory/dynamic_symmetric",
+             f"-I{REF}/src/framework", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(REF, r) for r in ref_sources] + \
+               [os.path.join(ROOT, "tests", "fortran", driver + ".F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), driver + "_ref")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def ref_bt_exe(tmp_path_factory):
+    return build_ref_module_driver(tmp_path_factory.mktemp("ref_bt"), ["src/core/MOM_barotropic.F90"], "bt_driver")
+
+
+@pytest.mark.parametrize("kw,params,exact", [(dict(strong_drag=1), ["BT_STRONG_DRAG=True"], True), (dict(strong_drag=1, ni=40, nj=30, seed=11), ["BT_STRONG_DRAG=True"], True),
+                                             (dict(), [], False), (dict(ni=40, nj=30, seed=11), [], False)])
+def test_the_reference_btstep_equals_the_oracle(ref_bt_exe, tmp_path, kw, params, exact):
+    """barotropic_init, btcalc, bt_mass_source and btstep of the reference's MOM_barotropic.F90 with the argument list of the RK2 step's
+    call (BT_cont, layer fluxes, eta_av; 13 barotropic steps) on a closed basin (the stand-in's group passes do nothing, which is what one
+    closed tile needs).  With BT_STRONG_DRAG (no real power in bt_rem, :1525): every output bit for bit.  With the default, bt_rem =
+    av_rem ** (1/nstep) (:1529) is the libm power of the build, where oracle and library take a correctly rounded one (DESIGN.md section 3:
+    one ulp apart in ~0.1 % of arguments): the outputs agree in every bit except downstream of the one or two faces where the two powers
+    differ, and there within a few ulps -- the documented deviation, seen here against the reference itself."""
+    from test_fortran_abi import _bt_case
+    g, names, want, nstep = _bt_case(str(tmp_path / "in.bin"), reentrant=(False, False), **kw)
+    assert nstep >= 10
+    r = subprocess.run([ref_bt_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), ""] + params, capture_output=True, text=True)
+    assert r.returncode == 0 and "bt_driver ok" in r.stdout, r.stderr[-2000:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    ndiff = 0
+    for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        a = a.reshape(w.shape)
+        pos = _abi.POS_U if n in ("accel_layer_u", "uhbtav", "ubtav") else (_abi.POS_V if n in ("accel_layer_v", "vhbtav", "vbtav") else _abi.POS_H)
+        ia, iw = interior(g, a, pos), interior(g, w, pos)
+        if exact:
+            assert bits_equal(ia, iw), (n, np.argwhere(ia != iw)[:4])
+        else:
+            d = ia != iw
+            ndiff += int(d.sum())
+            assert d.mean() <= 0.01 and np.all(np.abs(ia - iw)[d] <= 1.0e-14 * np.abs(iw)[d] + 1.0e-30), (n, int(d.sum()))
+    if not exact:
+        assert ndiff > 0      # (if this ever fails the libm power has become correctly rounded on these arguments: tighten the test)
