@@ -41,7 +41,20 @@ HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL
 SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
-PMC_PROFILE = "r04_c_pmc.json"      # the counter passes `roofline.traffic` is read from (profiles/)
+PMC_PROFILE = "r05_a_pmc.json"
+FP64_VECTOR_TFLOPS = 78.6            # 256 CUs x 4 SIMDs x 16 fp64 lanes per cycle x 2 (fma) x 2.4 GHz
+
+
+def _pmc_kernel(prefix, source):
+    """The counter record of a kernel from profiles/PMC_PROFILE, or None when `source` (a file of mom6_amd/csrc) has changed since the
+    counters were taken (the profile carries the SHA-256 of every source).  Returns (record, sha)."""
+    import hashlib
+    prof = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
+    sha = hashlib.sha256(open(os.path.join(ROOT, "mom6_amd", "csrc", source), "rb").read()).hexdigest()
+    if prof.get("source_sha256", {}).get(source) != sha:
+        return None, sha
+    rec = [v for k, v in prof["kernels"].items() if k.startswith(prefix)]
+    return (rec[0] if rec else None), sha      # the counter passes `roofline.traffic` is read from (profiles/)
 LAND_FRAC = 0.30           # SURVEY.md section 8d, C4
 # grid-scale bathymetric roughness (white noise, as a fraction of the depth range) with a fixed SLOPE: 0.04 on a 3-degree
 # grid, 0.0025 (14 m rms) at 1/4 degree.  With the amplitude held at 0.04 the 1/4-degree bathymetry had 200 m steps between
@@ -837,6 +850,12 @@ def main():
         L.mom6hip_stream_bandwidth.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         check(L.mom6hip_stream_bandwidth(M.dg.handle, 4 << 30, 10, C.byref(cp), C.byref(tr)), "mom6hip_stream_bandwidth")
         measured_bw = {"copy_GBs": cp.value, "triad_GBs": tr.value, "bytes_per_array": 4 << 30, "launches": 10}
+    bt_floor = None
+    if rank == 0 and world == 1:
+        nodes = M.dg.bt_graph_nodes()
+        if nodes > 0:
+            pts = (NI + 2 * 4) * (NJ + 2 * 4)
+            bt_floor = {"graph_nodes": nodes, "points": pts, "us_per_node": M.dg.graph_node_floor(nodes, pts, 20)}
     M.dg.close()
     del M
     torch.cuda.empty_cache()
@@ -857,11 +876,8 @@ def main():
             # continuity.hip, and a different source (or workload) makes `traffic` null instead of stale
             traffic, traffic_from, valu = None, None, None
             try:
-                import hashlib
-                prof = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
-                sha = hashlib.sha256(open(os.path.join(ROOT, "mom6_amd", "csrc", "continuity.hip"), "rb").read()).hexdigest()
-                pmc = [v for k, v in prof["kernels"].items() if k.startswith("cont_flux_coop_kernel<1")][0]
-                if a.workload == "om4_025" and world == 1 and prof.get("source_sha256", {}).get("continuity.hip") == sha:
+                pmc, sha = _pmc_kernel("cont_flux_coop_kernel<1", "continuity.hip")
+                if a.workload == "om4_025" and world == 1 and pmc is not None:
                     traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
                     traffic_from = f"profiles/{PMC_PROFILE} (continuity.hip sha256 {sha[:12]})"
                     if "SQ_INSTS_VALU" in pmc:      # what actually bounds this kernel: fp64 VALU issue (4 cycles per wave instruction)
@@ -875,10 +891,45 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_from": traffic_from, "fp64_valu": valu,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": int(n_y),
-                "also": {"cont_flux_coop_kernel<0,10>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
+                # the zonal flux kernel is the round-5 one-cell-per-lane layout (3 waves/SIMD, neighbours by DPP); the meridional one
+                # spills in that layout and stays on the round-3 kernel (profiles/r05_experiments.txt section 1)
+                "also": {"cont_flux_coop3_kernel<0,5,8,4>": {"avg_launch_ms": ms_x / max(n_x, 1), "launches_timed": int(n_x)}},
                 "measured_streaming_bandwidth": measured_bw,
                 "frac_of_measured_triad": None if not measured_bw else alg / (avg_ms * 1e-3) / 1e9 / measured_bw["triad_GBs"],
             }
+
+    if rank == 0:
+        # microseconds per barotropic time step against the launch floor.  HIP events around the replay of the
+        # subcycle's hipGraph (barotropic.hip), inside the timed region; 4 kernels + the x-halo wraps per barotropic step.
+        ms_bt, n_bt = ktime[2]
+        if n_bt > 0 and int(bcs.nstep_last) > 0 and bt_floor is not None:
+            nstep, nodes, node_us = int(bcs.nstep_last), bt_floor["graph_nodes"], bt_floor["us_per_node"]
+            per = ms_bt / n_bt / nstep * 1e3
+            out["barotropic_subcycle"] = {
+                "us_per_barotropic_step": per, "nstep": nstep, "graph_replays_timed": int(n_bt),
+                "ms_per_btstep_call_in_subcycle": ms_bt / n_bt, "graph_nodes": nodes, "kernels_per_barotropic_step": nodes / nstep,
+                # the launch floor measured here: the same number of dependent kernel nodes in a replayed hipGraph, each one
+                # read-modify-write pass over a 2-D array of the tile's size (mom6hip_graph_node_floor)
+                "launch_floor_us_per_node": node_us, "launch_floor_us_per_barotropic_step": node_us * nodes / nstep,
+                "frac_of_launch_floor": node_us * nodes / nstep / per, "points_2d_per_tile": bt_floor["points"],
+            }
+        ms_pgf, n_pgf = ktime[3]
+        if n_pgf > 0:
+            # pgf_face_kernel against the FP64 vector roof: wave instructions from the committed counter pass (valid for the source
+            # it was taken with) x 4 cycles each / (1024 SIMDs x 2.4 GHz), over the duration measured live
+            fp64 = {"kernel": "pgf_face_kernel", "avg_launch_ms": ms_pgf / n_pgf, "launches_timed": int(n_pgf),
+                    "peak_TFLOPs_fp64_vector": FP64_VECTOR_TFLOPS}
+            try:
+                pmc, sha = _pmc_kernel("pgf_face_kernel", "pressure_force.hip")
+                if a.workload == "om4_025" and world == 1 and pmc is not None and "SQ_INSTS_VALU" in pmc:
+                    issue_ms = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9) * 1e3
+                    fp64.update({"valu_wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "issue_ms_at_full_rate": issue_ms,
+                                 "frac_of_fp64_issue": issue_ms / (ms_pgf / n_pgf),
+                                 "instructions_per_cell": pmc["SQ_INSTS_VALU"] * 64.0 / cells,
+                                 "counters_from": f"profiles/{PMC_PROFILE} (pressure_force.hip sha256 {sha[:12]})"})
+            except Exception:
+                pass
+            out["pressure_force_fp64"] = fp64
 
     if world == 1 and not a.no_roofline:
         # per-operator device time on a stationary synthetic state, HIP events on the stream the library launches on

@@ -144,6 +144,11 @@ int mom6hip_stage_wait(mom6hip_ctx_t *ctx);
  * the nominal HBM peak that the roofline fractions of bench.py are quoted against. */
 int mom6hip_stream_bandwidth(mom6hip_ctx_t *ctx, uint64_t bytes_per_array, int32_t reps, double *copy_GBs, double *triad_GBs);
 
+/* The launch floor of the barotropic subcycle, measured where the model runs: a hipGraph of `nodes` dependent kernel nodes, each
+ * a one-pass read-modify-write of `points` doubles (the 2-D tile), replayed `reps` times on the context's stream between HIP events;
+ * microseconds per node.  bench.py quotes `us per barotropic step` against kernels-per-step times this. */
+int mom6hip_graph_node_floor(mom6hip_ctx_t *ctx, int32_t nodes, int64_t points, int32_t reps, double *us_per_node);
+
 /* ---- MOM_checksums: the bit-count checksum of a field, on the device ----------------------- */
 
 /* subchk of chksum_h_3d / chksum_u_3d / chksum_v_3d / chksum_B_3d (src/framework/MOM_checksums.F90:1387-1401, :1042-1059,
@@ -337,7 +342,9 @@ int mom6hip_set_timing(mom6hip_ctx_t *ctx, int32_t enable);
  * number of launches since then (it synchronises the stream) and, with enable = 0, stops recording. */
 #define MOM6HIP_KT_CONT_FLUX_X 0
 #define MOM6HIP_KT_CONT_FLUX_Y 1
-#define MOM6HIP_KT_SLOTS 2
+#define MOM6HIP_KT_BT_SUBCYCLE 2      /* the barotropic time steps of one btstep call (the replay of their hipGraph, one tile) */
+#define MOM6HIP_KT_PGF_FACE 3         /* pgf_face_kernel of PressureForce_FV_Bouss */
+#define MOM6HIP_KT_SLOTS 4
 int mom6hip_kernel_timing(mom6hip_ctx_t *ctx, int32_t enable, double *ms_total, int64_t *launches);
 int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t);
 
@@ -808,6 +815,8 @@ int mom6hip_set_dtbt(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const doub
  */
 /* How often btstep captured its subcycle as a hipGraph and how often it replayed one (one-tile domains). */
 int mom6hip_bt_graph_stats(mom6hip_ctx_t *ctx, int64_t *captures, int64_t *launches);
+/* the number of nodes (kernels) of the subcycle graph captured last */
+int mom6hip_bt_graph_nodes(mom6hip_ctx_t *ctx, int64_t *nodes);
 
 int mom6hip_btstep(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const double *U_in, const double *V_in,
                    const double *eta_in, double dt, const double *bc_accel_u, const double *bc_accel_v,

@@ -19,11 +19,11 @@ EXPORTS = (
     "mom6hip_advect_get_timing", "mom6hip_ale_remap_tracers", "mom6hip_ale_plm_edge_values", "mom6hip_coradcalc", "mom6hip_continuity", "mom6hip_pressureforce_fv_bouss", "mom6hip_pressureforce_fv_nonbouss", "mom6hip_calculate_density", "mom6hip_set_domain_callbacks",
     "mom6hip_barotropic_init", "mom6hip_btcalc", "mom6hip_bt_mass_source", "mom6hip_set_dtbt", "mom6hip_memset_zero", "mom6hip_transfer_stats", "mom6hip_debug_poison_passes", "mom6hip_tracer_hordiff_varmix", "mom6hip_tracer_hordiff_neutral", "mom6hip_tracer_hordiff_epipycnal", "mom6hip_continuity_obc", "mom6hip_coradcalc_obc", "mom6hip_vertvisc_coef_obc", "mom6hip_update_segment_tracer_reservoirs", "mom6hip_advect_tracer_obc", "mom6hip_btstep_obc", "mom6hip_horizontal_viscosity_obc", "mom6hip_set_viscous_bbl_obc", "mom6hip_btcalc_obc", "mom6hip_vertvisc_obc", "mom6hip_radiation_open_bdry_conds", "mom6hip_open_boundary_zero_normal_flow", "mom6hip_overlap_stats", "mom6hip_thickness_diffuse", "mom6hip_mixedlayer_restrat", "mom6hip_mixedlayer_restrat_mu", "mom6hip_start_group_pass", "mom6hip_complete_group_pass", "mom6hip_set_dtbt_eta", "mom6hip_btstep",
     "mom6hip_dyn_split_rk2_init", "mom6hip_step_dyn_split_rk2", "mom6hip_dyn_split_rk2b_init", "mom6hip_step_dyn_split_rk2b",
-    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_set_h_vel_via_dz", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats",
+    "mom6hip_ale_regrid", "mom6hip_ale_remap_set_h_vel", "mom6hip_ale_remap_set_h_vel_via_dz", "mom6hip_ale_remap_velocities", "mom6hip_halo_pack", "mom6hip_set_min_callback", "mom6hip_kernel_timing", "mom6hip_set_callback_stream_ordered", "mom6hip_bt_graph_stats", "mom6hip_bt_graph_nodes",
     "mom6hip_vertvisc_coef", "mom6hip_vertvisc", "mom6hip_vertvisc_remnant", "mom6hip_vertvisc_ntrunc", "mom6hip_vertvisc_and_remnant", "mom6hip_vertvisc_step",
     "mom6hip_hor_visc_init", "mom6hip_horizontal_viscosity", "mom6hip_set_viscous_bbl", "mom6hip_set_viscous_ml",
     "mom6hip_chksum", "mom6hip_reproducing_sum", "mom6hip_write_energy_sums", "mom6hip_depth_list_create", "mom6hip_write_energy_ape", "mom6hip_host_register", "mom6hip_host_unregister", "mom6hip_stage_to_host",
-    "mom6hip_stage_query", "mom6hip_stage_wait", "mom6hip_stream_bandwidth", "mom6hip_tracer_hordiff", "mom6hip_rccl_get_unique_id", "mom6hip_domain_init_rccl", "mom6hip_domain_exchange_timing",
+    "mom6hip_stage_query", "mom6hip_stage_wait", "mom6hip_stream_bandwidth", "mom6hip_graph_node_floor", "mom6hip_tracer_hordiff", "mom6hip_rccl_get_unique_id", "mom6hip_domain_init_rccl", "mom6hip_domain_exchange_timing",
 )
 
 

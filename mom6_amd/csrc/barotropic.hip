@@ -1601,6 +1601,7 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
     ctx->stream = saved;
     M6_REQUIRE(rc == 0 && e1 == hipSuccess && graph, "btstep: capturing the barotropic subcycle as a hipGraph failed (%s)",
                hipGetErrorString(e1));
+    { size_t nn = 0; if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess) ctx->bt_graph_nodes_last = (long)nn; }
     hipGraphExec_t exec = nullptr;
     hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -1643,6 +1644,7 @@ int mom6hip_btstep_obc(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const do
   } else {
     hipGraphExec_t exec = nullptr;
     if (int rc = graph_of(1, nt, true, &exec)) return rc;
+    m6::KTimer kt(ctx, MOM6HIP_KT_BT_SUBCYCLE);
     M6_HIP(hipGraphLaunch(exec, s));
     ctx->bt_graph_launches++;
   }

@@ -240,6 +240,12 @@ int mom6hip_bt_graph_stats(mom6hip_ctx_t *ctx, int64_t *captures, int64_t *launc
   return 0;
 }
 
+int mom6hip_bt_graph_nodes(mom6hip_ctx_t *ctx, int64_t *nodes) {
+  M6_REQUIRE(ctx != nullptr && nodes != nullptr, "mom6hip_bt_graph_nodes: null argument");
+  *nodes = ctx->bt_graph_nodes_last;
+  return 0;
+}
+
 int mom6hip_set_callback_stream_ordered(mom6hip_ctx_t *ctx, int32_t stream_ordered) {
   M6_REQUIRE(ctx != nullptr, "mom6hip_set_callback_stream_ordered: null context");
   ctx->cb_stream_ordered = stream_ordered != 0;

@@ -905,7 +905,7 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
   const dim3 gc((ncol_i + 63) / 64, ncol_j), gf((ncol_i - 1 + 63) / 64, ncol_j - 1);
   if (use_ALE) {
     hipLaunchKernelGGL(pgf_column_kernel, gc, dim3(64), 0, s, a);
-    hipLaunchKernelGGL(pgf_face_kernel, gf, dim3(64), 0, s, a);
+    { m6::KTimer kt(ctx, MOM6HIP_KT_PGF_FACE); hipLaunchKernelGGL(pgf_face_kernel, gf, dim3(64), 0, s, a); }
   } else if (mode == PCM_LINEAR) {
     hipLaunchKernelGGL(pgf_pcm_column_kernel<PCM_LINEAR>, gc, dim3(64), 0, s, a);
     hipLaunchKernelGGL(pgf_pcm_face_kernel<PCM_LINEAR>, gf, dim3(64), 0, s, a);

@@ -124,4 +124,44 @@ int mom6hip_stream_bandwidth(mom6hip_ctx_t *ctx, uint64_t bytes_per_array, int32
   return 0;
 }
 
+// ---- the cost of a kernel node in a replayed hipGraph: the floor of the barotropic subcycle (bench.py) ----
+namespace {
+__global__ __launch_bounds__(256) void floor_touch_kernel(double *__restrict__ a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += 1.0;
+}
+}  // namespace
+
+int mom6hip_graph_node_floor(mom6hip_ctx_t *ctx, int32_t nodes, int64_t points, int32_t reps, double *us_per_node) {
+  M6_REQUIRE(ctx && nodes >= 1 && nodes <= 4096 && points >= 1 && reps >= 1 && us_per_node, "mom6hip_graph_node_floor: bad argument");
+  double *a = nullptr;
+  M6_HIP(hipMalloc((void **)&a, (size_t)points * sizeof(double)));
+  hipStream_t s = ctx->stream;
+  (void)hipMemsetAsync(a, 0, (size_t)points * sizeof(double), s);
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  const dim3 grid((unsigned)((points + 255) / 256)), block(256);
+  hipStream_t cap = nullptr;      // (the context's stream may be the null stream, which cannot be captured)
+  M6_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  M6_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+  for (int n = 0; n < nodes; n++) hipLaunchKernelGGL(floor_touch_kernel, grid, block, 0, cap, a, (size_t)points);
+  M6_HIP(hipStreamEndCapture(cap, &graph));
+  (void)hipStreamDestroy(cap);
+  M6_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  M6_HIP(hipGraphLaunch(exec, s));      // warm-up
+  (void)hipEventRecord(e0, s);
+  for (int r = 0; r < reps; r++) (void)hipGraphLaunch(exec, s);
+  (void)hipEventRecord(e1, s);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_node = (double)ms * 1.0e3 / ((double)reps * nodes);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+  (void)hipFree(a);
+  M6_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -46,6 +46,23 @@ class DeviceGrid:
         check(lib().mom6hip_advect_get_timing(self.handle, C.byref(t)), "mom6hip_advect_get_timing")
         return t
 
+    def bt_graph_nodes(self):
+        """Kernel nodes of the subcycle graph captured last (mom6hip_bt_graph_nodes)."""
+        n = C.c_int64(0)
+        L = lib()
+        L.mom6hip_bt_graph_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        check(L.mom6hip_bt_graph_nodes(self.handle, C.byref(n)), "mom6hip_bt_graph_nodes")
+        return int(n.value)
+
+    def graph_node_floor(self, nodes, points, reps=20):
+        """Microseconds per kernel node of a replayed hipGraph of `nodes` dependent one-pass kernels over `points` doubles
+        (mom6hip_graph_node_floor): the launch floor the barotropic subcycle is quoted against."""
+        us = C.c_double(0.0)
+        L = lib()
+        L.mom6hip_graph_node_floor.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
+        check(L.mom6hip_graph_node_floor(self.handle, int(nodes), int(points), int(reps), C.byref(us)), "mom6hip_graph_node_floor")
+        return float(us.value)
+
     def bt_graph_stats(self):
         """(captures, launches) of the hipGraph of btstep's subcycle (mom6hip_bt_graph_stats)."""
         a, b = C.c_int64(0), C.c_int64(0)
@@ -61,9 +78,9 @@ class DeviceGrid:
 
     def kernel_timing(self, enable):
         """(ms_total, launches) per timing slot since recording was switched on (mom6hip_kernel_timing)."""
-        ms = (C.c_double * 2)(); n = (C.c_int64 * 2)()
+        ms = (C.c_double * 4)(); n = (C.c_int64 * 4)()      # MOM6HIP_KT_SLOTS: cont flux x, y, the barotropic subcycle, pgf_face_kernel
         check(lib().mom6hip_kernel_timing(self.handle, int(bool(enable)), ms, n), "mom6hip_kernel_timing")
-        return [(ms[q], n[q]) for q in range(2)]
+        return [(ms[q], n[q]) for q in range(4)]
 
     def halo_update(self, fields, positions):
         """pass_var / pass_vector on this one-tile domain for torch CUDA tensors."""
