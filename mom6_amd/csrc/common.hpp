@@ -116,6 +116,11 @@ struct mom6hip_ctx {
   m6::DevBuf cont_hmid;         // continuity in two phases around a pass in flight: the thicknesses after the first direction
   uint64_t overlap[4] = {0, 0, 0, 0};      // mom6hip_overlap_stats
   int cont_phase = 0;           // 0: the whole continuity; 1: what needs no halo row (before the completion); 2: the rest (after it)
+  // u_bc_accel = (CAu + PFu) + diffu of the RK2 step (MOM_dynamics_split_RK2.F90:557-564, :879-886) formed by the kernel that produces the
+  // later of CAu and PFu (pgf_face_kernel or coradcalc_kernel) instead of a sweep of its own: set by the stepper around that call; the
+  // module sets `done` when its kernel has taken it (other forms of the module leave it, and the stepper launches the sweep)
+  struct BcAccelFuse { const double *au, *av, *diffu, *diffv; double *u_bc, *v_bc; int inviscid; bool done; };
+  BcAccelFuse *bc_fuse = nullptr;
   bool cont_fluxes_only = false;   // the caller reads the transports and BT_cont of this continuity call but not its thicknesses (the RK2 step's
                                    // first call, MOM_dynamics_split_RK2.F90:634: hp is rewritten by :757 before anything reads it): the second
                                    // direction's convergence is not launched

@@ -34,6 +34,10 @@ struct CorArgs {
   // where gradKE leaves no gradient
   const double *o_dvdx, *o_dudy, *o_hArea_u, *o_hArea_v, *o_uh_center, *o_vh_center, *o_Area_q;
   const int32_t *o_seg_u, *o_seg_v;
+  // the RK2 step's u_bc_accel = (CAu + PFu) + diffu formed here (mom6hip_ctx::BcAccelFuse; null: not asked for)
+  const double *bc_PFu, *bc_PFv, *bc_diffu, *bc_diffv;
+  double *bc_u, *bc_v;
+  int bc_inviscid;
 };
 
 using m6::max2;
@@ -327,7 +331,13 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     }
     double KEx = (s_ke[ty][tx + 1] - s_ke[ty][tx]) * IdxCu;
     if (EXT && p.o_seg_u && p.o_seg_u[ou]) KEx = 0.;      // gradKE :1037-1050
-    p.CAu[kU + ou] = ca - KEx;
+    const double cau = ca - KEx;
+    p.CAu[kU + ou] = cau;
+    if (p.bc_u) {
+      double a = cau + p.bc_PFu[kU + ou];
+      if (p.bc_inviscid) a = (a == 0.0) ? 0.0 : a; else a = a + p.bc_diffu[kU + ou];
+      p.bc_u[kU + ou] = a;
+    }
   }
   // ---- CAv(i, J), i = I >= isc, J <= jec : :763-876 ----
   if (do_v) {
@@ -404,7 +414,13 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
     }
     double KEy = (s_ke[ty + 1][tx] - s_ke[ty][tx]) * IdyCv;
     if (EXT && p.o_seg_v && p.o_seg_v[ov]) KEy = 0.;
-    p.CAv[kV + ov] = ca - KEy;
+    const double cav = ca - KEy;
+    p.CAv[kV + ov] = cav;
+    if (p.bc_v) {
+      double a = cav + p.bc_PFv[kV + ov];
+      if (p.bc_inviscid) a = (a == 0.0) ? 0.0 : a; else a = a + p.bc_diffv[kV + ov];
+      p.bc_v[kV + ov] = a;
+    }
   }
   }      // the layers of the chunk
 }
@@ -669,6 +685,13 @@ extern "C" int mom6hip_coradcalc_obc(mom6hip_ctx_t *ctx, const mom6hip_coriolisa
     M6_HIP(hipGetLastError());
     a.o_dvdx = o.dvdx; a.o_dudy = o.dudy; a.o_hArea_u = o.hArea_u; a.o_hArea_v = o.hArea_v; a.o_uh_center = o.uh_center;
     a.o_vh_center = o.vh_center; a.o_Area_q = o.Area_q; a.o_seg_u = d_su; a.o_seg_v = d_sv;
+  }
+  a.bc_PFu = a.bc_PFv = a.bc_diffu = a.bc_diffv = nullptr; a.bc_u = a.bc_v = nullptr; a.bc_inviscid = 0;
+  if (ctx->bc_fuse && memspace == MOM6HIP_MEM_DEVICE) {
+    mom6hip_ctx::BcAccelFuse *f = ctx->bc_fuse;
+    a.bc_PFu = f->au; a.bc_PFv = f->av; a.bc_diffu = f->diffu; a.bc_diffv = f->diffv; a.bc_u = f->u_bc; a.bc_v = f->v_bc;
+    a.bc_inviscid = f->inviscid;
+    f->done = true;
   }
   if (ext) hipLaunchKernelGGL(coradcalc_kernel<true>, grid, dim3(TI, TJ), 0, s, a);
   else hipLaunchKernelGGL(coradcalc_kernel<false>, grid, dim3(TI, TJ), 0, s, a);

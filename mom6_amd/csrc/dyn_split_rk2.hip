@@ -409,23 +409,50 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   // closed edge (every other point of up, vp is recomputed or refilled by pass_uvp each step; u_bc_accel, uh_in and
   // eta_pred are read only where they are written), so the block is zeroed when it is allocated, not every step.
   if (fresh) M6_HIP(hipMemsetAsync(blk, 0, blk_bytes, s));
-  M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));                                  // :422
+  // hp = h (:422).  The continuity calls at :634 and :757 write every cell of the compute domain (continuity.hip: the convergence of
+  // the last direction covers is..ie, js..je) and nothing reads hp before them, so only the frame outside the compute domain is copied:
+  // what the calls and pass_hp_uv do not overwrite there keeps h, as in the reference.
+  static const bool hp_whole = getenv("MOM6HIP_HP_COPY_WHOLE") && atoi(getenv("MOM6HIP_HP_COPY_WHOLE")) == 1;
+  if (hp_whole) {
+    M6_HIP(hipMemcpyAsync(hp, h, sz.h3, hipMemcpyDeviceToDevice, s));
+  } else {
+    auto copy_rect = [&](int i0, int i1, int j0, int j1) {
+      launch3d(s, i0, i1, j0, j1, nz, [=] __device__(int i, int j, int k) { hp[g.h3(i, j, k)] = h[g.h3(i, j, k)]; });
+    };
+    copy_rect(g.isd, g.ied, g.jsd, js - 1); copy_rect(g.isd, g.ied, je + 1, g.jed);
+    copy_rect(g.isd, is - 1, js, je); copy_rect(ie + 1, g.ied, js, je);
+  }
 
+  // u_bc_accel = (CAu_pred + PFu) + diffu (:557-564) is formed by the kernel that produces the later of its terms: pgf_face_kernel when
+  // CAu_pred was stored by the step before, coradcalc_kernel otherwise (mom6hip_ctx::BcAccelFuse); the sweep below runs only when
+  // neither took it (another form of PressureForce) or when the first up, vp are wanted from it (hooks)
+  const bool inviscid = (cs->hooks == nullptr) && (cs->hor_visc == nullptr);      // diffu = diffv = 0
+  const bool vv_fused = VV && !(hk && (hk->visc_remnant_pred || hk->vertvisc));
+  const bool need_up1 = (!inviscid || VV) && !vv_fused;
+  mom6hip_ctx::BcAccelFuse fuse1{nullptr, nullptr, cs->diffu, cs->diffv, u_bc, v_bc, inviscid ? 1 : 0, false};
+  static const bool fuse_off = getenv("MOM6HIP_BC_FUSE") && atoi(getenv("MOM6HIP_BC_FUSE")) == 0;
+  const bool try_fuse1 = !need_up1 && !fuse_off;
   // PressureForce :495
-  CALL(mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, step_p_surf(cs), cs->PFu, cs->PFv, cs->pbce,
-                                      cs->eta_PF, D));
+  if (try_fuse1 && cs->CAu_pred_stored) { fuse1.au = cs->CAu_pred; fuse1.av = cs->CAv_pred; ctx->bc_fuse = &fuse1; }
+  const int rc_pf = mom6hip_pressureforce_fv_bouss(ctx, cs->PressureForce_CSp, cs->eqn_of_state, h, T, S, step_p_surf(cs), cs->PFu, cs->PFv,
+                                                   cs->pbce, cs->eta_PF, D);
+  ctx->bc_fuse = nullptr;
+  if (rc_pf) return rc_pf;
   double *eta_PF_start = nullptr;
   CALL(step_eta_PF_start(ctx, cs, &eta_PF_start));                                                   // :497-503
-  if (!cs->CAu_pred_stored)   // :544-552
-    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D));
+  if (!cs->CAu_pred_stored) {   // :544-552
+    if (try_fuse1) { fuse1.au = cs->PFu; fuse1.av = cs->PFv; ctx->bc_fuse = &fuse1; }
+    const int rc_ca = mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu_pred, cs->CAv_pred, D);
+    ctx->bc_fuse = nullptr;
+    if (rc_ca) return rc_ca;
+  }
 
   // u_bc_accel = (CAu_pred + PFu) + diffu ; up = mask*(u + dt*u_bc_accel)   :557-564, :582-589
   // Without viscosity hooks diffu = diffv = +0.0 everywhere (set by dyn_split_rk2_init): (a + 0.0) is a, except that
   // -0.0 + 0.0 = +0.0, so the array need not be read; and the first up, vp (:582-589) are only read by vertvisc_coef.
-  const bool inviscid = (hk == nullptr) && (cs->hor_visc == nullptr);      // diffu = diffv = 0
-  // The library's own vertical viscosity forms the velocity increments of :582-589, :667-676 and :930-939 inside its coefficient
-  // sweep (m6::vertvisc_step_inc: the same expression on the same numbers), so the step's sweeps for them are not launched.
-  const bool vv_fused = VV && !(hk && (hk->visc_remnant_pred || hk->vertvisc));
+  // (inviscid, vv_fused above) The library's own vertical viscosity forms the velocity increments of :582-589, :667-676 and :930-939
+  // inside its coefficient sweep (m6::vertvisc_step_inc: the same expression on the same numbers), so the step's sweeps for them are
+  // not launched.
   auto bc_accel = [&](const double *CAu, const double *CAv, bool first_up) {
     const double *PFu = cs->PFu, *PFv = cs->PFv, *diffu = cs->diffu, *diffv = cs->diffv;
     const bool need_up = first_up && (!inviscid || VV) && !vv_fused;
@@ -444,7 +471,7 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
       if (need_up) vp[n] = g.mask2dCv[g.v2(i, J)] * (v_inst[n] + dt * a);
     });
   };
-  bc_accel(cs->CAu_pred, cs->CAv_pred, true);
+  if (!fuse1.done) bc_accel(cs->CAu_pred, cs->CAv_pred, true);
   if (hk && hk->visc_remnant_pred) {   // set_viscous_ML, vertvisc_coef, vertvisc_remnant :592-600
     M6_HIP(hipStreamSynchronize(s));
     M6_REQUIRE(hk->visc_remnant_pred(hk->user, up, vp, h, dt, cs->visc_rem_u, cs->visc_rem_v) == 0, "visc_remnant_pred hook failed");
@@ -532,13 +559,21 @@ int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
   CALL(pass_start(ctx, {{hp, PH}, {u_av, PU}, {v_av, PV}, {uh, PU}, {vh, PV}}, nz, 2));             // :763
   CALL(mom6hip_bt_mass_source(ctx, BT, hp, eta_pred, 0, D));                                           // :797
   if (BT_cont_BT_thick) CALL(mom6hip_btcalc(ctx, BT, h, BTC->h_u, BTC->h_v, 0, D));                    // :843
-  CALL(around_pass(ctx, after_hp_uv));
-  if (hv_hook) {
-    M6_HIP(hipStreamSynchronize(s));
-    M6_REQUIRE(hk->horizontal_viscosity(hk->user, u_av, v_av, h_av, cs->diffu, cs->diffv) == 0, "horizontal_viscosity hook failed");
-    CALL(mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D));   // :869
+  // u_bc_accel = (CAu + PFu) + diffu (:879-886) formed by coradcalc_kernel, row window by row window (diffu of a row is complete
+  // before CorAdCalc of that row is launched)
+  mom6hip_ctx::BcAccelFuse fuse2{cs->PFu, cs->PFv, cs->diffu, cs->diffv, u_bc, v_bc, inviscid ? 1 : 0, false};
+  if (!fuse_off) ctx->bc_fuse = &fuse2;
+  int rc_ap = around_pass(ctx, after_hp_uv);
+  if (rc_ap == 0 && hv_hook) {
+    rc_ap = hipStreamSynchronize(s) == hipSuccess ? 0 : 1;
+    if (rc_ap == 0 && hk->horizontal_viscosity(hk->user, u_av, v_av, h_av, cs->diffu, cs->diffv) != 0) {
+      m6::set_error("horizontal_viscosity hook failed"); rc_ap = 1;
+    }
+    if (rc_ap == 0) rc_ap = mom6hip_coradcalc(ctx, cs->CoriolisAdv, u_av, v_av, h_av, uh, vh, cs->CAu, cs->CAv, D);   // :869
   }
-  bc_accel(cs->CAu, cs->CAv, false);                                                                  // :879-886
+  ctx->bc_fuse = nullptr;
+  if (rc_ap) return rc_ap;
+  if (!fuse2.done) bc_accel(cs->CAu, cs->CAv, false);                                                 // :879-886
   CALL(mom6hip_btstep(ctx, BT, u_inst, v_inst, eta, dt, u_bc, v_bc, taux, tauy, RZ_to_H, cs->pbce, cs->eta_PF, u_av, v_av,   // :911
                       cs->u_accel_bt, cs->v_accel_bt, eta_pred, cs->uhbt, cs->vhbt, cs->visc_rem_u, cs->visc_rem_v, BTC, eta_PF_start, nullptr,
                       nullptr, lf ? uh : nullptr, lf ? vh : nullptr, lf ? u_av : nullptr, lf ? v_av : nullptr, eta_av, D));

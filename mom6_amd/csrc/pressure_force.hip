@@ -73,6 +73,10 @@ struct PgfArgs {
   const double *Rlay, *g_prime;     // device copies of GV%Rlay(1:nk), GV%g_prime(1:nk+1) (or null)
   int nkmb;                         // GV%nk_rho_varies
   double P_Ref;                     // tv%P_Ref
+  // the RK2 step's u_bc_accel = (CAu + PFu) + diffu formed by pgf_face_kernel (mom6hip_ctx::BcAccelFuse; null: not asked for)
+  const double *bc_CAu, *bc_CAv, *bc_diffu, *bc_diffv;
+  double *bc_u, *bc_v;
+  int bc_inviscid;
 };
 
 // ---- column kernel -------------------------------------------------------------------------------
@@ -282,9 +286,16 @@ __global__ __launch_bounds__(64, PGF_FACE_OCC) void pgf_face_kernel(PgfArgs p) {
       const double ee_Kp1 = p.e[e3 + pl];
       const double h_e = p.h[e3];
       const double intx_dpa = face_integral(p, c3, e3, oc, oe, ec_K, ec_Kp1, ee_K, ee_Kp1);
-      p.PFu[g.u2(i, j) + plU * k] = (((pa_c * h_c + iz_c) - (pa_e * h_e + p.intz_dpa[e3])) +
-                                     ((h_e - h_c) * intx_pa - (ee_Kp1 - ec_Kp1) * intx_dpa * g.Z_to_H)) *
-                                    (fx / ((h_c + h_e) + h_neglect));
+      const double pfu = (((pa_c * h_c + iz_c) - (pa_e * h_e + p.intz_dpa[e3])) +
+                          ((h_e - h_c) * intx_pa - (ee_Kp1 - ec_Kp1) * intx_dpa * g.Z_to_H)) *
+                         (fx / ((h_c + h_e) + h_neglect));
+      p.PFu[g.u2(i, j) + plU * k] = pfu;
+      if (p.bc_u) {
+        const long n = g.u2(i, j) + plU * k;
+        double a = p.bc_CAu[n] + pfu;
+        if (p.bc_inviscid) a = (a == 0.0) ? 0.0 : a; else a = a + p.bc_diffu[n];
+        p.bc_u[n] = a;
+      }
       intx_pa = intx_pa + intx_dpa;
       pa_e = pa_e + p.dpa[e3];
       ee_K = ee_Kp1;
@@ -294,9 +305,16 @@ __global__ __launch_bounds__(64, PGF_FACE_OCC) void pgf_face_kernel(PgfArgs p) {
       const double en_Kp1 = p.e[n3 + pl];
       const double h_n = p.h[n3];
       const double inty_dpa = face_integral(p, c3, n3, oc, on, ec_K, ec_Kp1, en_K, en_Kp1);
-      p.PFv[g.v2(i, j) + plV * k] = (((pa_c * h_c + iz_c) - (pa_n * h_n + p.intz_dpa[n3])) +
-                                     ((h_n - h_c) * inty_pa - (en_Kp1 - ec_Kp1) * inty_dpa * g.Z_to_H)) *
-                                    (fy / ((h_c + h_n) + h_neglect));
+      const double pfv = (((pa_c * h_c + iz_c) - (pa_n * h_n + p.intz_dpa[n3])) +
+                          ((h_n - h_c) * inty_pa - (en_Kp1 - ec_Kp1) * inty_dpa * g.Z_to_H)) *
+                         (fy / ((h_c + h_n) + h_neglect));
+      p.PFv[g.v2(i, j) + plV * k] = pfv;
+      if (p.bc_v) {
+        const long n = g.v2(i, j) + plV * k;
+        double a = p.bc_CAv[n] + pfv;
+        if (p.bc_inviscid) a = (a == 0.0) ? 0.0 : a; else a = a + p.bc_diffv[n];
+        p.bc_v[n] = a;
+      }
       inty_pa = inty_pa + inty_dpa;
       pa_n = pa_n + p.dpa[n3];
       en_K = en_Kp1;
@@ -877,6 +895,7 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
   const size_t bH2 = (size_t)g.nih * g.njh * 8;
   PgfArgs a;
   a.Rlay = a.g_prime = nullptr;
+  a.bc_CAu = a.bc_CAv = a.bc_diffu = a.bc_diffv = nullptr; a.bc_u = a.bc_v = nullptr; a.bc_inviscid = 0;
   if (cs->Rlay && (mode == PCM_NOEOS || cs->nkmb > 0)) {
     a.Rlay = ctx->tables[m6::TABLE_PGF_RLAY].get(cs->Rlay, (size_t)g.nk);
     if (!a.Rlay) return 1;
@@ -904,6 +923,12 @@ extern "C" int mom6hip_pressureforce_fv_bouss(mom6hip_ctx_t *ctx, const mom6hip_
   const int ncol_i = g.iec - g.isc + 3, ncol_j = g.jec - g.jsc + 3;
   const dim3 gc((ncol_i + 63) / 64, ncol_j), gf((ncol_i - 1 + 63) / 64, ncol_j - 1);
   if (use_ALE) {
+    if (ctx->bc_fuse && memspace == MOM6HIP_MEM_DEVICE) {
+      mom6hip_ctx::BcAccelFuse *f = ctx->bc_fuse;
+      a.bc_CAu = f->au; a.bc_CAv = f->av; a.bc_diffu = f->diffu; a.bc_diffv = f->diffv; a.bc_u = f->u_bc; a.bc_v = f->v_bc;
+      a.bc_inviscid = f->inviscid;
+      f->done = true;
+    }
     hipLaunchKernelGGL(pgf_column_kernel, gc, dim3(64), 0, s, a);
     { m6::KTimer kt(ctx, MOM6HIP_KT_PGF_FACE); hipLaunchKernelGGL(pgf_face_kernel, gf, dim3(64), 0, s, a); }
   } else if (mode == PCM_LINEAR) {
@@ -942,6 +967,7 @@ extern "C" int mom6hip_pressureforce_fv_nonbouss(mom6hip_ctx_t *ctx, const mom6h
   const size_t bH2 = (size_t)g.nih * g.njh * 8;
   m6::Stager st(ctx, memspace);
   PgfArgs a;
+  a.bc_CAu = a.bc_CAv = a.bc_diffu = a.bc_diffv = nullptr; a.bc_u = a.bc_v = nullptr; a.bc_inviscid = 0;
   a.g = g;
   a.eos = EosDev{eos->form, eos->Rho_T0_S0, eos->dRho_dT, eos->dRho_dS};
   a.h = st.in(h, bH); a.T = st.in(T, bH); a.S = st.in(S, bH); a.p_atm = st.in(p_atm, bH2);
