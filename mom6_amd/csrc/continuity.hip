@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void cont_edge_kernel(EdgeArgs p) {
 }
 
 // ---- mass fluxes ---------------------------------------------------------------------------------
+constexpr int OBC_STRIP = 3;      // faces either side of an open segment that the lane kernel forms (continuity_PPM below)
 struct FluxArgs {
   m6::GridDev g;
   ContOpts o;
@@ -220,6 +221,8 @@ struct FluxArgs {
   const int32_t *fa_code;                // faces of the open segments of this direction over their whole range (:782-805, :1058-1088):
                                          // 1 interior = minus-side cell, 2 interior = plus-side cell (the last segment wins)
   const struct SegDev *segs;             // the segments (device table)
+  const int32_t *skip;                   // block-cooperative kernels: faces they leave alone (null: none) -- the strips around the open
+                                         // segments, which the lane kernel forms with the OBC (continuity_PPM below)
 };
 
 // what the kernels read of a segment (mom6hip_obc_segment_t with device pointers)
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
   const int nz = g.nk;
   constexpr int FPB = (DIR == 0) ? FC_FL - 1 : FC_FL;      // faces per block
   const int fi_raw = p.fi0 + blockIdx.x * FPB + fl;
-  const bool valid = fl < FPB && fi_raw <= p.fi1;
+  const bool valid = fl < FPB && fi_raw <= p.fi1 && !(p.skip && p.skip[D.f2(min(fi_raw, p.fi1), p.fj0 + (int)blockIdx.y)]);
   // lanes past the row (and the last lane of a zonal half-wave) do everything but store, so barriers stay uniform; they sit
   // on the cell after the last face, whose reconstruction the last face needs, and never iterate (see `alive`)
   // (meridionally nothing is handed between lanes: idle lanes sit on the last face, which is always inside the row)
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
   const int nz = g.nk;
   constexpr int FPB = (DIR == 0) ? FC_FL - 1 : FC_FL;      // faces per block (the last zonal lane only serves its neighbour)
   const int fi_raw = p.fi0 + blockIdx.x * FPB + fl;
-  const bool valid = fl < FPB && fi_raw <= p.fi1;
+  const bool valid = fl < FPB && fi_raw <= p.fi1 && !(p.skip && p.skip[D.f2(min(fi_raw, p.fi1), p.fj0 + (int)blockIdx.y)]);
   const int fi_last = (DIR == 0) ? p.fi1 + 1 : p.fi1;
   const int fi = (fi_raw <= fi_last) ? fi_raw : fi_last;
   const int fj = p.fj0 + blockIdx.y;
@@ -1764,13 +1767,15 @@ bool flux_lane_only() {
 #ifndef FC3_DEFAULT_Y
 #define FC3_DEFAULT_Y 410
 #endif
-int flux_coop_shape(int dir) {      // 410: round 1's kernel; 67, 85: cont_flux_coop3_kernel; 853 (8x5w3), 163 (16x3): experiments of round 5
+int flux_coop_shape(int dir) {      // 410: round 1's kernel; 67, 85: cont_flux_coop3_kernel; 853 (8x5w3), 163 (16x3), 124 (12x4), 104 (10x4): experiments of round 5
   auto parse = [](const char *e, int dflt) {
     if (!e) return dflt;
     if (strcmp(e, "4x10") == 0) return 410;
     if (strcmp(e, "8x5") == 0) return 85;
     if (strcmp(e, "8x5w3") == 0) return 853;
     if (strcmp(e, "16x3") == 0) return 163;
+    if (strcmp(e, "12x4") == 0) return 124;
+    if (strcmp(e, "10x4") == 0) return 104;
     return 67;
   };
   static const int v[2] = {
@@ -1779,7 +1784,7 @@ int flux_coop_shape(int dir) {      // 410: round 1's kernel; 67, 85: cont_flux_
   return v[dir];
 }
 int flux_coop_nk_max() {
-  auto cap = [](int shape) { return shape == 410 ? FC_KSMAX * FC_NS : (shape == 67 ? 84 : (shape == 163 ? 96 : 80)); };
+  auto cap = [](int shape) { return shape == 410 ? FC_KSMAX * FC_NS : (shape == 67 ? 84 : ((shape == 163 || shape == 124) ? 96 : 80)); };
   return std::min(cap(flux_coop_shape(0)), cap(flux_coop_shape(1)));
 }
 
@@ -1822,6 +1827,8 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     if (shape == 85) return go3(cont_flux_coop3_kernel<DIR, 5, 8, 4>, 8, fc3_lds_bytes<5, 8>());
     if (shape == 853) return go3(cont_flux_coop3_kernel<DIR, 5, 8, 3>, 8, fc3_lds_bytes<5, 8>());
     if (shape == 163) return go3(cont_flux_coop3_kernel<DIR, 3, 16, 4>, 16, fc3_lds_bytes<3, 16>());
+    if (shape == 124) return go3(cont_flux_coop3_kernel<DIR, 4, 12, 3>, 12, fc3_lds_bytes<4, 12>());
+    if (shape == 104) return go3(cont_flux_coop3_kernel<DIR, 4, 10, 3>, 10, fc3_lds_bytes<4, 10>());
     return go(cont_flux_coop_kernel<DIR, FC_KSMAX>, FC_KSMAX);
   }
   hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
@@ -1944,7 +1951,7 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
   const double h_min = g.Angstrom_H;
 
   // ---- open boundaries: what the kernels read of OBC, on the device (built once per OBC and kept with the context) ----
-  struct ObcDir { int on = 0, open = 0, simple = 0, specified = 0; const int32_t *segnum = nullptr, *cell = nullptr, *fa = nullptr; } ob[2];
+  struct ObcDir { int on = 0, open = 0, simple = 0, specified = 0; const int32_t *segnum = nullptr, *cell = nullptr, *fa = nullptr, *skip = nullptr; } ob[2];
   const SegDev *d_segs = nullptr;
   if (obc && obc->number_of_segments > 0) {
     M6_REQUIRE(ctx->cont_phase == 0, "continuity_PPM: open boundaries with a continuity call in two phases are not provided");
@@ -1980,11 +1987,13 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
       key_segs = m6::obc_mix(m6::obc_mix(key_segs, (uint64_t)(uintptr_t)d.normal_trans), (uint64_t)(uintptr_t)d.normal_vel);
     }
     M6_REQUIRE(!st.failed(), "continuity_PPM: staging of the open boundaries failed");
-    const size_t n_maps = 2 * nU2 + 2 * nV2 + 2 * nH2;
+    const size_t n_maps = 3 * nU2 + 3 * nV2 + 2 * nH2;
     const int32_t *maps = (const int32_t *)m6::obc_table(ctx, m6::OBC_SITE_CONT, key, 4 * n_maps, [&](void *host) -> int {
       int32_t *su = (int32_t *)host, *sv = su + nU2, *cx = sv + nV2, *cy = cx + nH2, *fx = cy + nH2, *fy = fx + nU2;
+      int32_t *kx = fy + nV2, *ky = kx + nU2;
+      memset(cx, 0, 4 * (2 * nH2 + 2 * nU2 + 2 * nV2));
       memcpy(su, obc->segnum_u, 4 * nU2); memcpy(sv, obc->segnum_v, 4 * nV2);
-      int32_t *cell[2] = {cx, cy}, *fa[2] = {fx, fy};
+      int32_t *cell[2] = {cx, cy}, *fa[2] = {fx, fy}, *skip[2] = {kx, ky};
       for (int n = 0; n < nseg; n++) {
         const mom6hip_obc_segment_t &S = obc->segment[n];
         if (!S.on_pe) continue;
@@ -1993,6 +2002,8 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
         const int A = ew ? S.IsdB : S.JsdB, c0 = ew ? S.jsd : S.isd, c1 = ew ? S.jed : S.ied;
         const bool plus = S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_N;
         for (int c = c0; c <= c1; c++) {
+          for (int a = A - OBC_STRIP; a <= A + OBC_STRIP; a++)      // the faces the lane kernel forms (OBC_STRIP above)
+            if (a >= (ew ? g.isd - 1 : g.jsd - 1) && a <= (ew ? g.ied : g.jed)) skip[dd][ew ? g.u2(a, c) : g.v2(c, a)] = 1;
           const long ca = ew ? g.h2(A, c) : g.h2(c, A), cb = ew ? g.h2(A + 1, c) : g.h2(c, A + 1);
           if (open_d[dd]) {      // PPM_reconstruction_x/y :2385-2432: zero slopes, then the edge values (a later segment has the last word)
             cell[dd][ca] = 1 | ((plus ? 1 : 3) << 1);
@@ -2007,6 +2018,7 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
                                                      [&](void *host) -> int { memcpy(host, segs.data(), sizeof(SegDev) * nseg); return 0; });
     if (!maps || !ds) return 1;
     const int32_t *dsu = maps, *dsv = dsu + nU2, *dcx = dsv + nV2, *dcy = dcx + nH2, *dfx = dcy + nH2, *dfy = dfx + nU2;
+    ob[0].skip = dfy + nV2; ob[1].skip = ob[0].skip + nU2;
     d_segs = ds;
     const int pe = obc->OBC_pe != 0;
     ob[0].on = ob[1].on = 1;
@@ -2019,9 +2031,37 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
   auto set_obc = [&](FluxArgs &f, int dd) {
     f.obc_on = ob[dd].on; f.obc_open = ob[dd].open; f.obc_simple = ob[dd].simple; f.obc_specified = ob[dd].specified;
     f.obc_dir_plus = dd ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E;
-    f.segnum = ob[dd].segnum; f.fa_code = ob[dd].fa; f.segs = d_segs;
+    f.segnum = ob[dd].segnum; f.fa_code = ob[dd].fa; f.segs = d_segs; f.skip = nullptr;
   };
 
+  // With open boundaries the block-cooperative kernels run over the whole range as on a closed domain but leave the faces a segment can
+  // reach alone (FluxArgs::skip); those are formed by the lane kernel with the OBC, on the side stream at the same time (a face's column
+  // depends on its own inputs only, and both kernels leave the same bits where no segment reaches; the lane kernel's walk of a column
+  // takes as long for a strip as for the grid, so it has to run beside the block kernel, not after it).  What a segment at face A of its direction reaches: the face itself (flux_layer :956-971, the
+  // specified transports :629-634, the face areas :782-805) and, through the zeroed slopes and the copied edge values of the cells A
+  // and A+1 (PPM_reconstruction :2385-2432) that enter the edge values of A-1 .. A+2, the faces A-2 .. A+2 -- along the segment's own
+  // extent (its cell codes and face codes are set there only).  OBC_STRIP = 3 faces either side.
+  static const bool strips_off = getenv("MOM6HIP_CONT_OBC_STRIPS") && atoi(getenv("MOM6HIP_CONT_OBC_STRIPS")) == 0;
+  auto side_fork = [&]() -> int {      // the side stream waits for what the compute stream has been given so far
+    if (!ctx->side_stream) {
+      M6_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+      for (hipEvent_t &e : ctx->side_ev) M6_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    M6_HIP(hipEventRecord(ctx->side_ev[0], s));
+    M6_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+    return 0;
+  };
+  auto side_join = [&]() -> int {      // the compute stream waits for the side stream
+    M6_HIP(hipGetLastError());
+    M6_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+    M6_HIP(hipStreamWaitEvent(s, ctx->side_ev[1], 0));
+    return 0;
+  };
+  auto obc_strips = [&](const FluxArgs &f) -> bool {
+    if (!f.obc_on || strips_off) return false;
+    FluxArgs c = f; c.obc_on = 0;
+    return flux_is_coop(c);
+  };
   // hdst: where the thicknesses after this direction go (the output array, or the scratch of the phased call)
   auto zonal = [&](const double *hsrc, int jsh, int jeh, double hmin, double *hdst, double *also) -> int {
     if (jeh < jsh) return 0;
@@ -2031,6 +2071,23 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
     f.uBT_pp = bt.uBT_EE; f.h_face = bt.h_u; f.set_BT_cont = BT_cont != nullptr; f.dt = dt;
     f.fi0 = is - 1; f.fi1 = ie; f.fj0 = jsh; f.fj1 = jeh;
     set_obc(f, 0);
+    const bool strips = obc_strips(f);
+    if (strips) {      // the faces an E or W segment can reach: the lane kernel with the OBC, on the side stream beside the block kernel
+      if (side_fork()) return 1;
+      for (int n = 0; n < obc->number_of_segments; n++) {
+        const mom6hip_obc_segment_t &S = obc->segment[n];
+        if (!S.on_pe || !(S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_W)) continue;
+        FluxArgs fl = f;
+        fl.fi0 = std::max(is - 1, S.IsdB - OBC_STRIP); fl.fi1 = std::min(ie, S.IsdB + OBC_STRIP);
+        fl.fj0 = std::max(jsh, S.jsd); fl.fj1 = std::min(jeh, S.jed);
+        if (fl.fi1 < fl.fi0 || fl.fj1 < fl.fj0) continue;
+        EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[0].open ? ob[0].cell : nullptr;
+        e.i0 = fl.fi0; e.i1 = fl.fi1 + 1; e.j0 = fl.fj0; e.j1 = fl.fj1;
+        hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, e.j1 - e.j0 + 1, g.nk), dim3(256), 0, ctx->side_stream, e);
+        hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((fl.fi1 - fl.fi0 + 64) / 64, fl.fj1 - fl.fj0 + 1), dim3(64), 0, ctx->side_stream, fl);
+      }
+      f.obc_on = 0; f.skip = ob[0].skip;
+    }
     if (!flux_is_coop(f)) {
       EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[0].open ? ob[0].cell : nullptr;
       e.i0 = is - 1; e.i1 = ie + 1; e.j0 = jsh; e.j1 = jeh;
@@ -2038,6 +2095,7 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
     }
     { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_X);
       if (launch_flux<0>(ctx, f, f.fi1 - f.fi0 + 1, jeh - jsh + 1)) return 1; }
+    if (strips && side_join()) return 1;
     if (!x_first && ctx->cont_fluxes_only) return 0;      // (the second direction's thicknesses are not wanted: see the context)
     ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_uh; c.h = hdst; c.dt = dt; c.h_min = hmin;
     c.i0 = is; c.i1 = ie; c.j0 = jsh; c.j1 = jeh; c.h2 = also; c.j2lo = js; c.j2hi = je;
@@ -2054,6 +2112,24 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
     f.fi0 = ish; f.fi1 = ieh; f.fj0 = fj0; f.fj1 = fj1;
     set_obc(f, 1);
     if (fj1 >= fj0) {
+      const bool strips = obc_strips(f);
+      if (strips) {      // the faces a N or S segment can reach: the lane kernel with the OBC, on the side stream beside the block kernel
+        if (side_fork()) return 1;
+        for (int n = 0; n < obc->number_of_segments; n++) {
+          const mom6hip_obc_segment_t &S = obc->segment[n];
+          if (!S.on_pe || !(S.direction == MOM6HIP_OBC_DIRECTION_N || S.direction == MOM6HIP_OBC_DIRECTION_S)) continue;
+          FluxArgs fl = f;
+          fl.fi0 = std::max(ish, S.isd); fl.fi1 = std::min(ieh, S.ied);
+          fl.fj0 = std::max(fj0, S.JsdB - OBC_STRIP); fl.fj1 = std::min(fj1, S.JsdB + OBC_STRIP);
+          if (fl.fi1 < fl.fi0 || fl.fj1 < fl.fj0) continue;
+          EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[1].open ? ob[1].cell : nullptr;
+          e.i0 = fl.fi0; e.i1 = fl.fi1; e.j0 = fl.fj0; e.j1 = fl.fj1 + 1;
+          hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((e.i1 - e.i0 + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0,
+                             ctx->side_stream, e);
+          hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((fl.fi1 - fl.fi0 + 64) / 64, fl.fj1 - fl.fj0 + 1), dim3(64), 0, ctx->side_stream, fl);
+        }
+        f.obc_on = 0; f.skip = ob[1].skip;
+      }
       if (!flux_is_coop(f)) {
         EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[1].open ? ob[1].cell : nullptr;
         e.i0 = ish; e.i1 = ieh; e.j0 = fj0; e.j1 = fj1 + 1;
@@ -2061,6 +2137,7 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
       }
       { m6::KTimer kt(ctx, MOM6HIP_KT_CONT_FLUX_Y);
         if (launch_flux<1>(ctx, f, ieh - ish + 1, f.fj1 - f.fj0 + 1)) return 1; }
+      if (strips && side_join()) return 1;
     }
     if (cj1 >= cj0 && !(x_first && ctx->cont_fluxes_only)) {
       ConvArgs c; c.g = g; c.hin = hsrc; c.uh = d_vh; c.h = d_h; c.dt = dt; c.h_min = hmin;
