@@ -892,15 +892,21 @@ int mom6hip_set_dtbt_eta(mom6hip_ctx_t *ctx, mom6hip_barotropic_cs_t *cs, const 
   hipLaunchKernelGGL(bt_dtbt_kernel, grid2d(g.isc, g.iec, g.jsc, g.jec), dim3(64, 4), 0, s, g, dp, fru, frv, Datu, Datv, gtot_est,
                      cs->bebt, cs->BT_Coriolis_scale, res);
   M6_HIP(hipGetLastError());
+  // min_across_PEs(dtbt_max) :2915 is taken of the tile's minimum where it lies, before the square root: dtbt_max = sqrt(min / dgeo_de) is
+  // a non-decreasing function of it (the clamp to 1e38, the division and the correctly rounded square root all are), so the minimum over
+  // the PEs of the tiles' dtbt_max is the dtbt_max of the minimum, bit for bit
   unsigned long long bits = 0;
-  M6_HIP(hipMemcpyAsync(&bits, res, sizeof(bits), hipMemcpyDeviceToHost, s));
-  M6_HIP(hipStreamSynchronize(s));
+  if (m6::multi_tile(ctx)) {
+    if (int rc = m6::min_across_PEs_dev_u64(ctx, (unsigned long long *)res, 1, &bits)) return rc;
+  } else {
+    M6_HIP(hipMemcpyAsync(&bits, res, sizeof(bits), hipMemcpyDeviceToHost, s));
+    M6_HIP(hipStreamSynchronize(s));
+  }
   double min_max_dt2;
   memcpy(&min_max_dt2, &bits, sizeof(double));
   if (!(min_max_dt2 < 1.0e38)) min_max_dt2 = 1.0e38;
   const double dgeo_de = 1.0 + (cs->G_extra > 0.0 ? cs->G_extra : 0.0);
-  double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
-  if (int rc = m6::min_across_PEs(ctx, &dtbt_max, 1)) return rc;      // min_across_PEs(dtbt_max) :2915
+  const double dtbt_max = sqrt(min_max_dt2 / dgeo_de);
   cs->dtbt = cs->dtbt_fraction * dtbt_max;
   cs->dtbt_max = dtbt_max;
   return st.finish();

@@ -220,6 +220,13 @@ int native_complete_group_pass(mom6hip_ctx *ctx);
 bool native_x_is_local(mom6hip_ctx *ctx);
 void native_pass_sides(mom6hip_ctx *ctx, int sides[2]);      // which halos a native pass fills: per direction, bit 0 low side, bit 1 high side
 int native_allreduce(mom6hip_ctx *ctx, void *values, int n, bool is_int_sum);
+int native_allreduce_dev(mom6hip_ctx *ctx, void *dvalues, int n, int kind, void *host_copy);      // kind 0: int32 sum, 1: f64 min, 2: u64 min
+// sum_across_PEs of n DEVICE int32 / min_across_PEs of n DEVICE uint64 (bit patterns of non-negative doubles), in place, ordered behind the
+// compute stream's work so far; the compute stream sees the result.  host_copy (pinned, optional) receives it too and the call returns when
+// it is there.  With the native domain nothing passes through the host on the way; with the host's callbacks the values are read back,
+// reduced by the callback and sent up again.
+int sum_across_PEs_dev(mom6hip_ctx *ctx, int32_t *dvalues, int n, int32_t *host_copy);
+int min_across_PEs_dev_u64(mom6hip_ctx *ctx, unsigned long long *dvalues, int n, unsigned long long *host_copy);
 void native_domain_destroy(mom6hip_ctx *ctx);
 // sum_across_PEs of n host int32 / min_across_PEs of n host doubles, in place (the native domain, the host's callback, or nothing)
 int sum_across_PEs(mom6hip_ctx *ctx, int32_t *values, int n);

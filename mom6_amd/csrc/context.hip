@@ -612,6 +612,35 @@ int sum_across_PEs(mom6hip_ctx_t *ctx, int32_t *values, int n) {
   return 0;
 }
 
+int sum_across_PEs_dev(mom6hip_ctx_t *ctx, int32_t *dvalues, int n, int32_t *host_copy) {
+  if (ctx->native) return native_allreduce_dev(ctx, dvalues, n, 0, host_copy);
+  std::vector<int32_t> tmp;
+  int32_t *h = host_copy;
+  if (!h) { tmp.resize((size_t)n); h = tmp.data(); }
+  M6_HIP(hipMemcpyAsync(h, dvalues, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  if (!ctx->sum_cb) return 0;
+  M6_REQUIRE(ctx->sum_cb(ctx->cb_user, h, n) == 0, "the host's sum_across_PEs failed");
+  M6_HIP(hipMemcpyAsync(dvalues, h, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if (!host_copy) M6_HIP(hipStreamSynchronize(ctx->stream));      // (tmp goes out of scope)
+  return 0;
+}
+
+int min_across_PEs_dev_u64(mom6hip_ctx_t *ctx, unsigned long long *dvalues, int n, unsigned long long *host_copy) {
+  if (ctx->native) return native_allreduce_dev(ctx, dvalues, n, 2, host_copy);
+  std::vector<double> h((size_t)n);      // the bit patterns of non-negative doubles order as the doubles do
+  M6_HIP(hipMemcpyAsync(h.data(), dvalues, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  M6_HIP(hipStreamSynchronize(ctx->stream));
+  for (double &v : h) if (v != v) v = HUGE_VAL;      // all ones (nothing found on this tile) is above every value: +inf for the callback
+  if (ctx->min_cb) {
+    M6_REQUIRE(ctx->min_cb(ctx->min_user, h.data(), n) == 0, "the host's min_across_PEs failed");
+    M6_HIP(hipMemcpyAsync(dvalues, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    M6_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (host_copy) memcpy(host_copy, h.data(), sizeof(double) * (size_t)n);
+  return 0;
+}
+
 int min_across_PEs(mom6hip_ctx_t *ctx, double *values, int n) {
   if (ctx->native) return native_allreduce(ctx, values, n, false);
   if (ctx->min_cb) M6_REQUIRE(ctx->min_cb(ctx->min_user, values, n) == 0, "the host's min_across_PEs failed");

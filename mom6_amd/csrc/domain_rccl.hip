@@ -23,7 +23,7 @@ extern "C" {
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
-typedef enum { ncclInt32 = 2, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclInt32 = 2, ncclUint64 = 5, ncclFloat64 = 8 } ncclDataType_t;
 typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
 }
 
@@ -78,6 +78,7 @@ struct m6_native_domain {
   ncclComm_t comm = nullptr;
   hipStream_t cstream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_red[2] = {nullptr, nullptr};   // the device-side reductions: compute stream -> communication stream and back
   int rank = 0, nranks = 1;
   int lo[2] = {-1, -1}, hi[2] = {-1, -1};      // neighbour ranks per direction (x, y); -1: none
   m6::DevBuf sbuf[2][2], rbuf[2][2];           // [direction][0: to / from hi, 1: to / from lo]
@@ -113,6 +114,7 @@ extern "C" int mom6hip_domain_init_rccl(mom6hip_ctx_t *ctx, const mom6hip_domain
   M6_HIP(hipStreamCreateWithFlags(&D->cstream, hipStreamNonBlocking));
   M6_HIP(hipEventCreateWithFlags(&D->ev_ready, hipEventDisableTiming));
   M6_HIP(hipEventCreateWithFlags(&D->ev_done, hipEventDisableTiming));
+  for (hipEvent_t &e : D->ev_red) M6_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   ctx->native = D;
   return 0;
 }
@@ -128,6 +130,7 @@ void native_domain_destroy(mom6hip_ctx *ctx) {
   for (int d = 0; d < 2; d++) for (int s = 0; s < 2; s++) { D->sbuf[d][s].release(); D->rbuf[d][s].release(); }
   D->red.release();
   (void)hipEventDestroy(D->ev_ready); (void)hipEventDestroy(D->ev_done);
+  for (hipEvent_t e : D->ev_red) if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(D->cstream);
   delete D;
   ctx->native = nullptr;
@@ -242,6 +245,24 @@ int native_allreduce(mom6hip_ctx *ctx, void *values, int n, bool is_int_sum) {
                            D->cstream));
   M6_HIP(hipMemcpyAsync(values, D->red.p, bytes, hipMemcpyDeviceToHost, D->cstream));
   M6_HIP(hipStreamSynchronize(D->cstream));
+  return 0;
+}
+
+// The same on n DEVICE values in place (sum of int32, or min of doubles / of the bit patterns of non-negative doubles as uint64): the
+// all-reduce runs on the communication stream behind what the compute stream has been given so far, and the compute stream waits for
+// it -- no host copy on the way.  host_copy (optional): the result for the host, read back behind the all-reduce; the call then returns
+// when it has arrived (the one synchronisation of a loop that the host ends on the result, MOM_tracer_advect.F90:305).
+int native_allreduce_dev(mom6hip_ctx *ctx, void *dvalues, int n, int kind, void *host_copy) {
+  m6_native_domain *D = ctx->native;
+  const ncclDataType_t ty = kind == 0 ? ncclInt32 : (kind == 1 ? ncclFloat64 : ncclUint64);
+  const size_t bytes = (kind == 0 ? sizeof(int32_t) : sizeof(double)) * (size_t)n;
+  M6_HIP(hipEventRecord(D->ev_red[0], ctx->stream));
+  M6_HIP(hipStreamWaitEvent(D->cstream, D->ev_red[0], 0));
+  M6_NCCL(rccl().AllReduce(dvalues, dvalues, (size_t)n, ty, kind == 0 ? ncclSum : ncclMin, D->comm, D->cstream));
+  if (host_copy) M6_HIP(hipMemcpyAsync(host_copy, dvalues, bytes, hipMemcpyDeviceToHost, D->cstream));
+  M6_HIP(hipEventRecord(D->ev_red[1], D->cstream));
+  M6_HIP(hipStreamWaitEvent(ctx->stream, D->ev_red[1], 0));
+  if (host_copy) M6_HIP(hipStreamSynchronize(D->cstream));
   return 0;
 }
 

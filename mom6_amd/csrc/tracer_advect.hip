@@ -1206,12 +1206,13 @@ extern "C" int mom6hip_advect_tracer_obc(mom6hip_ctx_t *ctx, const double *h_end
     if (itt >= max_iter) break;
     if (isv > is - stencil) {
       // sum_across_PEs(domore_k), :305 -- the one host read-back per iteration
-      M6_HIP(hipMemcpyAsync(ctx->h_domore_k, domore_k, nz * sizeof(int), hipMemcpyDeviceToHost, s));
-      M6_HIP(hipStreamSynchronize(s));
       if (m6::multi_tile(ctx)) {
-        // domore_k becomes the global count and is what the next iteration tests (:215, :252)
-        if (int rc = m6::sum_across_PEs(ctx, ctx->h_domore_k, nz)) return rc;
-        M6_HIP(hipMemcpyAsync(domore_k, ctx->h_domore_k, nz * sizeof(int), hipMemcpyHostToDevice, s));
+        // domore_k becomes the global count and is what the next iteration tests (:215, :252): reduced where it lies (an all-reduce on the
+        // communication stream with the native domain), the host's copy read back behind it
+        if (int rc = m6::sum_across_PEs_dev(ctx, domore_k, nz, ctx->h_domore_k)) return rc;
+      } else {
+        M6_HIP(hipMemcpyAsync(ctx->h_domore_k, domore_k, nz * sizeof(int), hipMemcpyDeviceToHost, s));
+        M6_HIP(hipStreamSynchronize(s));
       }
       remaining = 0;
       for (int k = 0; k < nz; k++) remaining += ctx->h_domore_k[k];
