@@ -14,5 +14,8 @@ for n, cn, v in rows:
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     n = re.sub(r"\((?:[^()]|\([^()]*\))*\)( \[clone [^\]]*\])?$", "", n)[:70]
     a = agg.setdefault((n, cn), [0, 0.0]); a[0] += 1; a[1] += v
-for (n, cn), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"{n:70s} {cn:12s} dispatches {a[0]:5d}  avg {a[1]/a[0]:16.1f}  total {a[1]:18.1f}")
+# the 40 largest kernels of every counter (a listing cut over all counters together loses the instruction counts behind the cycle counts)
+for counter in sorted({cn for _, cn in agg}):
+    mine = [(k, a) for k, a in agg.items() if k[1] == counter]
+    for (n, cn), a in sorted(mine, key=lambda kv: -kv[1][1])[:40]:
+        print(f"{n:70s} {cn:12s} dispatches {a[0]:5d}  avg {a[1]/a[0]:16.1f}  total {a[1]:18.1f}")
