@@ -221,6 +221,8 @@ struct FluxArgs {
   const int32_t *fa_code;                // faces of the open segments of this direction over their whole range (:782-805, :1058-1088):
                                          // 1 interior = minus-side cell, 2 interior = plus-side cell (the last segment wins)
   const struct SegDev *segs;             // the segments (device table)
+  int xcd_w, nbx;                        // block-cooperative kernels, meridional: blocks dealt to the 8 XCDs in strips of xcd_w block columns
+                                         // (0: the launch order), of nbx real block columns (xcd_block below)
   const int32_t *skip;                   // block-cooperative kernels: faces they leave alone (null: none) -- the strips around the open
                                          // segments, which the lane kernel forms with the OBC (continuity_PPM below)
 };
@@ -544,6 +546,20 @@ __global__ __launch_bounds__(64) void cont_flux_kernel(FluxArgs p) {
   }
 }
 
+// The block a workgroup works on.  Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest), each XCD with an L2 of its
+// own; a meridional block reads six rows of h of which the block of the next row reads five again.  With xcd_w > 0 the launch has 8 * xcd_w
+// block columns and the workgroups of one XCD (launch index mod 8) walk a strip of xcd_w adjacent real columns row by row, so a row's
+// re-reads hit that XCD's L2 instead of arriving once per XCD.  Placement only: any mapping gives the same results.  Returns false for
+// the workgroups beyond the last real column (they leave before any barrier).
+__device__ __forceinline__ bool xcd_block(int xcd_w, int nbx, int &bx, int &by) {
+  bx = blockIdx.x; by = blockIdx.y;
+  if (xcd_w <= 0) return true;
+  const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+  const unsigned xcd = L & 7u, slot = L >> 3;
+  bx = (int)(xcd * xcd_w + slot % xcd_w); by = (int)(slot / xcd_w);
+  return bx < nbx;
+}
+
 // ---- mass fluxes, block-cooperative form -----------------------------------------------------------
 // cont_flux_kernel re-reads five 3-D arrays on every pass over k (the first evaluation, every Newton iteration of
 // flux_adjust, the BT_cont fits): 3.6x the algorithmic bytes on the 1/4-degree grid, and that traffic is its run time.
@@ -631,14 +647,16 @@ __global__ __launch_bounds__(64 * FC_NW, FC_OCC) void cont_flux_coop_kernel(Flux
   const int fl = lane & (FC_FL - 1), sb = 2 * w + (lane >> 5);      // face within the block; layer slab of this half-wave
   const int nz = g.nk;
   constexpr int FPB = (DIR == 0) ? FC_FL - 1 : FC_FL;      // faces per block
-  const int fi_raw = p.fi0 + blockIdx.x * FPB + fl;
-  const bool valid = fl < FPB && fi_raw <= p.fi1 && !(p.skip && p.skip[D.f2(min(fi_raw, p.fi1), p.fj0 + (int)blockIdx.y)]);
+  int bx, by;
+  if (!xcd_block(p.xcd_w, p.nbx, bx, by)) return;
+  const int fi_raw = p.fi0 + bx * FPB + fl;
+  const bool valid = fl < FPB && fi_raw <= p.fi1 && !(p.skip && p.skip[D.f2(min(fi_raw, p.fi1), p.fj0 + by)]);
   // lanes past the row (and the last lane of a zonal half-wave) do everything but store, so barriers stay uniform; they sit
   // on the cell after the last face, whose reconstruction the last face needs, and never iterate (see `alive`)
   // (meridionally nothing is handed between lanes: idle lanes sit on the last face, which is always inside the row)
   const int fi_last = (DIR == 0) ? p.fi1 + 1 : p.fi1;
   const int fi = (fi_raw <= fi_last) ? fi_raw : fi_last;
-  const int fj = p.fj0 + blockIdx.y;
+  const int fj = p.fj0 + by;
   const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
   const long s = D.sa(), fs = D.fsa();
   const long o2 = g.h2(fi, fj), f2 = D.f2(fi, fj);
@@ -1236,11 +1254,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WP
   const int fl = lane & (FC_FL - 1), sb = 2 * w + (lane >> 5);      // face within the block; layer slab of this half-wave
   const int nz = g.nk;
   constexpr int FPB = (DIR == 0) ? FC_FL - 1 : FC_FL;      // faces per block (the last zonal lane only serves its neighbour)
-  const int fi_raw = p.fi0 + blockIdx.x * FPB + fl;
-  const bool valid = fl < FPB && fi_raw <= p.fi1 && !(p.skip && p.skip[D.f2(min(fi_raw, p.fi1), p.fj0 + (int)blockIdx.y)]);
+  int bx, by;
+  if (!xcd_block(p.xcd_w, p.nbx, bx, by)) return;
+  const int fi_raw = p.fi0 + bx * FPB + fl;
+  const bool valid = fl < FPB && fi_raw <= p.fi1 && !(p.skip && p.skip[D.f2(min(fi_raw, p.fi1), p.fj0 + by)]);
   const int fi_last = (DIR == 0) ? p.fi1 + 1 : p.fi1;
   const int fi = (fi_raw <= fi_last) ? fi_raw : fi_last;
-  const int fj = p.fj0 + blockIdx.y;
+  const int fj = p.fj0 + by;
   const long hpl = (long)g.nih * g.njh, fpl = D.fplane();
   const long s = D.sa(), fs = D.fsa();
   const long o2 = g.h2(fi, fj), f2 = D.f2(fi, fj);
@@ -1796,11 +1816,18 @@ bool flux_is_coop(const FluxArgs &f) {
 }
 
 template <int DIR>
-int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) {
-  const int nk = f.g.nk;
+int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f_in, int n_along, int n_rows) {
+  const int nk = f_in.g.nk;
   dim3 grid((n_along + 63) / 64, n_rows);
-  if (flux_is_coop(f)) {
+  if (flux_is_coop(f_in)) {
     grid.x = (DIR == 0) ? (n_along + FC_FL - 2) / (FC_FL - 1) : (n_along + FC_FL - 1) / FC_FL;      // a zonal block yields 31 faces
+    FluxArgs f = f_in;
+    f.xcd_w = 0; f.nbx = (int)grid.x;
+    static const int xcd_mode = getenv("MOM6HIP_CONT_XCD") ? atoi(getenv("MOM6HIP_CONT_XCD")) : 0;      // 0: launch order (the default: the strips measured slower, profiles/r05_experiments.txt section 5); 1: meridional; 3: both
+    if (((DIR == 1 && xcd_mode >= 1) || (DIR == 0 && xcd_mode >= 3)) && grid.x >= 16 && n_rows >= 8) {      // (xcd_block)
+      f.xcd_w = ((int)grid.x + 7) / 8;
+      grid.x = 8 * f.xcd_w;
+    }
     auto go = [&](auto kern, int KS) -> int {
       const size_t lds = ((size_t)3 * KS * FC_NS * FC_FL + 8 * FC_FL + FC_NS * FC_FL + 15 * FC_FL + 4 * FC_NS * FC_FL) * sizeof(double);
       std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context
@@ -1831,7 +1858,7 @@ int launch_flux(mom6hip_ctx_t *ctx, const FluxArgs &f, int n_along, int n_rows) 
     if (shape == 104) return go3(cont_flux_coop3_kernel<DIR, 4, 10, 3>, 10, fc3_lds_bytes<4, 10>());
     return go(cont_flux_coop_kernel<DIR, FC_KSMAX>, FC_KSMAX);
   }
-  hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f);
+  hipLaunchKernelGGL(cont_flux_kernel<DIR>, grid, dim3(64), 0, ctx->stream, f_in);
   return 0;
 }
 
@@ -2031,7 +2058,7 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
   auto set_obc = [&](FluxArgs &f, int dd) {
     f.obc_on = ob[dd].on; f.obc_open = ob[dd].open; f.obc_simple = ob[dd].simple; f.obc_specified = ob[dd].specified;
     f.obc_dir_plus = dd ? MOM6HIP_OBC_DIRECTION_N : MOM6HIP_OBC_DIRECTION_E;
-    f.segnum = ob[dd].segnum; f.fa_code = ob[dd].fa; f.segs = d_segs; f.skip = nullptr;
+    f.segnum = ob[dd].segnum; f.fa_code = ob[dd].fa; f.segs = d_segs; f.skip = nullptr; f.xcd_w = 0; f.nbx = 0;
   };
 
   // With open boundaries the block-cooperative kernels run over the whole range as on a closed domain but leave the faces a segment can
