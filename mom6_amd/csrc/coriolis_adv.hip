@@ -115,10 +115,13 @@ __device__ __forceinline__ double robust_heff(double tr, double IdL, double vel,
 template <bool EXT>
 __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   const m6::GridDev &g = p.g;
-  __shared__ double s_ihq[EXT ? TJ + 2 : 1][EXT ? TI + 2 : 1];      // Ih_q at the q-points of s_q (ARAKAWA_LAMB_BLEND)
-  __shared__ double s_q[TJ + 2][TI + 2];      // q(I0-1 .. I0+64, J0-1 .. J0+8) (the +1 column/row: Arakawa-Hsu)
-  __shared__ double s_av[TJ + 2][TI + 2];     // abs_vort, same points
-  __shared__ double s_ke[TJ + 1][TI + 1];     // KE(i = I0 .. I0+64, j = J0 .. J0+8)
+  // (two sets of tiles, alternating from layer to layer: a layer's tiles are written while the previous layer's are still read, and ONE
+  // barrier a layer -- between writing a set and reading it -- orders everything: nobody writes set b again before the barrier of the layer
+  // in between, which every thread passes only after its reads of set b)
+  __shared__ double sb_ihq[2][EXT ? TJ + 2 : 1][EXT ? TI + 2 : 1];      // Ih_q at the q-points of s_q (ARAKAWA_LAMB_BLEND)
+  __shared__ double sb_q[2][TJ + 2][TI + 2];      // q(I0-1 .. I0+64, J0-1 .. J0+8) (the +1 column/row: Arakawa-Hsu)
+  __shared__ double sb_av[2][TJ + 2][TI + 2];     // abs_vort, same points
+  __shared__ double sb_ke[2][TJ + 1][TI + 1];     // KE(i = I0 .. I0+64, j = J0 .. J0+8)
   // A block works through COR_KCH consecutive layers of its tile: what a point reads of the 2-D metrics (15 values for the vorticity
   // and the layer volume at a q point, 5 for the kinetic energy at an h point, 2 for the results) is loaded ONCE into registers and
   // serves every layer of the chunk -- per layer and point that was 22 loads from L2 beside the 9 of the layer's own fields, in a
@@ -179,7 +182,10 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   for (int kk = 0; kk < COR_KCH; kk++) {
   const int k = blockIdx.x * COR_KCH + kk;
   if (k >= g.nk) break;      // (uniform over the block)
-  if (kk > 0) __syncthreads();      // the tiles of the previous layer have been read
+  double (*s_ihq)[EXT ? TI + 2 : 1] = sb_ihq[kk & 1];
+  double (*s_q)[TI + 2] = sb_q[kk & 1];
+  double (*s_av)[TI + 2] = sb_av[kk & 1];
+  double (*s_ke)[TI + 1] = sb_ke[kk & 1];
   // uk / vk / hk ...: the layer's planes (wave-uniform pointers)
   const long kH = (long)g.nih * g.njh * k, kU = (long)(g.nih + 1) * g.njh * k, kV = (long)g.nih * (g.njh + 1) * k;
   const double *__restrict__ hk = p.h + kH, *__restrict__ uk = p.u + kU, *__restrict__ vk = p.v + kV;
@@ -253,6 +259,10 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
       s_ke[ty][tx] = ke;
     }
   }
+  // the transports the second half reads, asked for before the barrier so that they travel while the block gathers at it
+  double vh_ne = 0., vh_nw = 0., vh_sw = 0., vh_se = 0., uh_sw = 0., uh_nw = 0., uh_se = 0., uh_ne = 0.;
+  if (do_u) { vh_ne = vhk[ov + 1]; vh_nw = vhk[ov]; vh_sw = vhk[ov - nih]; vh_se = vhk[ov - nih + 1]; }
+  if (do_v) { uh_sw = uhk[ou - 1]; uh_nw = uhk[ou - 1 + sU]; uh_se = uhk[ou]; uh_ne = uhk[ou + sU]; }
   __syncthreads();
 
   // tile coordinates: q(I,J) = s_q[ty+1][tx+1]; KE(i,j) = s_ke[ty][tx]
@@ -260,7 +270,6 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   // ---- CAu(I, j), j = J >= jsc, I <= iec : :644-752 ----
   if (do_u) {
     const double qN = s_q[ty + 1][tx + 1], qS = s_q[ty][tx + 1];           // q(I,J), q(I,J-1)
-    const double vh_ne = vhk[ov + 1], vh_nw = vhk[ov], vh_sw = vhk[ov - nih], vh_se = vhk[ov - nih + 1];
     const double IdxCu = IdxCu_r;
     double ca;
     const bool al = EXT && (p.scheme == MOM6HIP_ARAKAWA_LAMB81 || p.scheme == MOM6HIP_AL_BLEND);
@@ -342,7 +351,6 @@ __global__ __launch_bounds__(TI * TJ) void coradcalc_kernel(CorArgs p) {
   // ---- CAv(i, J), i = I >= isc, J <= jec : :763-876 ----
   if (do_v) {
     const double qE = s_q[ty + 1][tx + 1], qW = s_q[ty + 1][tx];           // q(I,J), q(I-1,J)
-    const double uh_sw = uhk[ou - 1], uh_nw = uhk[ou - 1 + sU], uh_se = uhk[ou], uh_ne = uhk[ou + sU];
     const double IdyCv = IdyCv_r;
     double ca;
     const bool al = EXT && (p.scheme == MOM6HIP_ARAKAWA_LAMB81 || p.scheme == MOM6HIP_AL_BLEND);
