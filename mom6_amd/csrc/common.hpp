@@ -143,8 +143,10 @@ struct mom6hip_ctx {
   // hipGraphs of the barotropic subcycle, keyed on everything baked into their nodes (barotropic.hip)
   std::vector<std::pair<std::string, void *>> bt_graphs;
   hipStream_t cap_stream = nullptr;
-  hipStream_t side_stream = nullptr;       // small launches that run beside a large one of the compute stream (continuity's OBC strips)
-  hipEvent_t side_ev[2] = {nullptr, nullptr};      // fork (compute -> side), join (side -> compute)
+  static constexpr int NSIDE = 4;
+  hipStream_t side_stream[NSIDE] = {nullptr, nullptr, nullptr, nullptr};      // small launches that run beside a large one of the compute
+                                                                              // stream and beside each other (continuity's OBC strips)
+  hipEvent_t side_fork = nullptr, side_join[NSIDE] = {nullptr, nullptr, nullptr, nullptr};      // compute -> side streams, each side -> compute
   long bt_graph_captures = 0, bt_graph_launches = 0, bt_graph_nodes_last = 0;
   int *h_domore_k = nullptr;    // pinned host mirror of domore_k
   m6_native_domain *native = nullptr;      // set by mom6hip_domain_init_rccl: the group pass and the reductions are the library's own

@@ -400,8 +400,9 @@ int mom6hip_grid_destroy(mom6hip_ctx_t *ctx) {
   ctx->efp_acc.release();
   for (auto &e : ctx->bt_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.second);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
-  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-  for (hipEvent_t e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t st : ctx->side_stream) if (st) (void)hipStreamDestroy(st);
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+  for (hipEvent_t e : ctx->side_join) if (e) (void)hipEventDestroy(e);
   m6::staging_destroy(ctx);
   if (ctx->h_domore_k) (void)hipHostFree(ctx->h_domore_k);
   delete ctx;

@@ -2069,19 +2069,22 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
   // and A+1 (PPM_reconstruction :2385-2432) that enter the edge values of A-1 .. A+2, the faces A-2 .. A+2 -- along the segment's own
   // extent (its cell codes and face codes are set there only).  OBC_STRIP = 3 faces either side.
   static const bool strips_off = getenv("MOM6HIP_CONT_OBC_STRIPS") && atoi(getenv("MOM6HIP_CONT_OBC_STRIPS")) == 0;
-  auto side_fork = [&]() -> int {      // the side stream waits for what the compute stream has been given so far
-    if (!ctx->side_stream) {
-      M6_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-      for (hipEvent_t &e : ctx->side_ev) M6_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  auto side_fork = [&]() -> int {      // the side streams wait for what the compute stream has been given so far
+    if (!ctx->side_fork) {
+      for (hipStream_t &st : ctx->side_stream) M6_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      M6_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+      for (hipEvent_t &e : ctx->side_join) M6_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    M6_HIP(hipEventRecord(ctx->side_ev[0], s));
-    M6_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+    M6_HIP(hipEventRecord(ctx->side_fork, s));
+    for (hipStream_t st : ctx->side_stream) M6_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
     return 0;
   };
-  auto side_join = [&]() -> int {      // the compute stream waits for the side stream
+  auto side_join = [&]() -> int {      // the compute stream waits for the side streams
     M6_HIP(hipGetLastError());
-    M6_HIP(hipEventRecord(ctx->side_ev[1], ctx->side_stream));
-    M6_HIP(hipStreamWaitEvent(s, ctx->side_ev[1], 0));
+    for (int q = 0; q < mom6hip_ctx::NSIDE; q++) {
+      M6_HIP(hipEventRecord(ctx->side_join[q], ctx->side_stream[q]));
+      M6_HIP(hipStreamWaitEvent(s, ctx->side_join[q], 0));
+    }
     return 0;
   };
   auto obc_strips = [&](const FluxArgs &f) -> bool {
@@ -2101,17 +2104,19 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
     const bool strips = obc_strips(f);
     if (strips) {      // the faces an E or W segment can reach: the lane kernel with the OBC, on the side stream beside the block kernel
       if (side_fork()) return 1;
+      int nstrip = 0;
       for (int n = 0; n < obc->number_of_segments; n++) {
         const mom6hip_obc_segment_t &S = obc->segment[n];
         if (!S.on_pe || !(S.direction == MOM6HIP_OBC_DIRECTION_E || S.direction == MOM6HIP_OBC_DIRECTION_W)) continue;
+        hipStream_t ss = ctx->side_stream[nstrip++ % mom6hip_ctx::NSIDE];      // (a strip's walk is latency: strips run beside each other)
         FluxArgs fl = f;
         fl.fi0 = std::max(is - 1, S.IsdB - OBC_STRIP); fl.fi1 = std::min(ie, S.IsdB + OBC_STRIP);
         fl.fj0 = std::max(jsh, S.jsd); fl.fj1 = std::min(jeh, S.jed);
         if (fl.fi1 < fl.fi0 || fl.fj1 < fl.fj0) continue;
         EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[0].open ? ob[0].cell : nullptr;
         e.i0 = fl.fi0; e.i1 = fl.fi1 + 1; e.j0 = fl.fj0; e.j1 = fl.fj1;
-        hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, e.j1 - e.j0 + 1, g.nk), dim3(256), 0, ctx->side_stream, e);
-        hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((fl.fi1 - fl.fi0 + 64) / 64, fl.fj1 - fl.fj0 + 1), dim3(64), 0, ctx->side_stream, fl);
+        hipLaunchKernelGGL(cont_edge_kernel<0>, dim3((e.i1 - e.i0 + 256) / 256, e.j1 - e.j0 + 1, g.nk), dim3(256), 0, ss, e);
+        hipLaunchKernelGGL(cont_flux_kernel<0>, dim3((fl.fi1 - fl.fi0 + 64) / 64, fl.fj1 - fl.fj0 + 1), dim3(64), 0, ss, fl);
       }
       f.obc_on = 0; f.skip = ob[0].skip;
     }
@@ -2142,18 +2147,19 @@ extern "C" int mom6hip_continuity_obc(mom6hip_ctx_t *ctx, const mom6hip_continui
       const bool strips = obc_strips(f);
       if (strips) {      // the faces a N or S segment can reach: the lane kernel with the OBC, on the side stream beside the block kernel
         if (side_fork()) return 1;
+        int nstrip = 0;
         for (int n = 0; n < obc->number_of_segments; n++) {
           const mom6hip_obc_segment_t &S = obc->segment[n];
           if (!S.on_pe || !(S.direction == MOM6HIP_OBC_DIRECTION_N || S.direction == MOM6HIP_OBC_DIRECTION_S)) continue;
+          hipStream_t ss = ctx->side_stream[nstrip++ % mom6hip_ctx::NSIDE];
           FluxArgs fl = f;
           fl.fi0 = std::max(ish, S.isd); fl.fi1 = std::min(ieh, S.ied);
           fl.fj0 = std::max(fj0, S.JsdB - OBC_STRIP); fl.fj1 = std::min(fj1, S.JsdB + OBC_STRIP);
           if (fl.fi1 < fl.fi0 || fl.fj1 < fl.fj0) continue;
           EdgeArgs e; e.g = g; e.o = o; e.h_in = hsrc; e.h_L = h_L; e.h_R = h_R; e.cell_code = ob[1].open ? ob[1].cell : nullptr;
           e.i0 = fl.fi0; e.i1 = fl.fi1; e.j0 = fl.fj0; e.j1 = fl.fj1 + 1;
-          hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((e.i1 - e.i0 + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0,
-                             ctx->side_stream, e);
-          hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((fl.fi1 - fl.fi0 + 64) / 64, fl.fj1 - fl.fj0 + 1), dim3(64), 0, ctx->side_stream, fl);
+          hipLaunchKernelGGL(cont_edge_kernel<1>, dim3((e.i1 - e.i0 + 256) / 256, (e.j1 - e.j0 + EDGE_RJ) / EDGE_RJ, g.nk), dim3(256), 0, ss, e);
+          hipLaunchKernelGGL(cont_flux_kernel<1>, dim3((fl.fi1 - fl.fi0 + 64) / 64, fl.fj1 - fl.fj0 + 1), dim3(64), 0, ss, fl);
         }
         f.obc_on = 0; f.skip = ob[1].skip;
       }
