@@ -60,11 +60,16 @@ def run(ni, nj, nk, steps, with_obc):
 
 
 if __name__ == "__main__":
+    only = None      # --only obc | closed: one of the two runs (for a kernel trace of that step alone)
+    if "--only" in sys.argv:
+        q = sys.argv.index("--only"); only = sys.argv[q + 1]; del sys.argv[q:q + 2]
     a = [int(x) for x in sys.argv[1:]]
     ni, nj, nk = (a + [720, 540, 20])[:3] if len(a) < 3 else a[:3]
     steps = a[3] if len(a) > 3 else 10
     out = {"grid": [ni, nj, nk], "steps": steps}
     for name, flag in (("closed_tuned_step_ms", False), ("obc_step_ms", True)):
+        if only and (only == "obc") != flag:
+            continue
         ms, ok = run(ni, nj, nk, steps, flag)
         out[name] = round(ms, 3); out[name.replace("_ms", "_finite")] = ok
         print(json.dumps(out), flush=True)
