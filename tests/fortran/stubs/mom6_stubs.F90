@@ -261,7 +261,8 @@ type :: ocean_grid_type
   real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
   real, allocatable, dimension(:,:) :: mask2dCv, dxCv, dyCv, dx_Cv, IdxCv, IdyCv, areaCv, IareaCv
   real, allocatable, dimension(:,:) :: mask2dBu, dxBu, dyBu, areaBu, IareaBu, CoriolisBu, IdxBu, IdyBu
-  real, allocatable, dimension(:,:) :: geoLonT, geoLatT
+  real, allocatable, dimension(:,:) :: geoLonT, geoLatT, geoLonBu, geoLatBu
+  real, allocatable, dimension(:,:) :: dF_dx, dF_dy      !< (the Leith viscosities only)
   integer :: isd_global = 0, jsd_global = 0
 end type ocean_grid_type
 end module MOM_grid
@@ -374,8 +375,9 @@ public :: CLOCK_COMPONENT, CLOCK_SUBCOMPONENT, CLOCK_MODULE_DRIVER, CLOCK_LOOP, 
 integer, parameter :: CLOCK_COMPONENT = 1, CLOCK_SUBCOMPONENT = 11, CLOCK_MODULE_DRIVER = 21, CLOCK_MODULE = 31, CLOCK_ROUTINE = 41, &
                       CLOCK_LOOP = 51, CLOCK_INFRA = 61
 contains
-integer function cpu_clock_id(name, grain)
+integer function cpu_clock_id(name, sync, grain)
   character(len=*),  intent(in) :: name
+  logical, optional, intent(in) :: sync
   integer, optional, intent(in) :: grain
   cpu_clock_id = 0
 end function cpu_clock_id
@@ -1047,6 +1049,9 @@ type :: thermo_var_ptrs
   real, pointer, dimension(:,:) :: p_surf => NULL()
   type(EOS_type), pointer :: eqn_of_state => NULL()      !< associated = an equation of state is used (use_EOS)
   real :: P_Ref = 2.0e7
+  real, allocatable, dimension(:,:,:) :: SpV_avg      !< (non-Boussinesq runs only)
+  real, pointer, dimension(:,:,:) :: varT => NULL(), varS => NULL(), covarTS => NULL()      !< (the Stanley parameterisations only)
+  integer :: valid_SpV_halo = -1
 end type thermo_var_ptrs
 type :: vertvisc_type
   real :: Prandtl_turb = 1.0
@@ -1055,6 +1060,12 @@ type :: vertvisc_type
   real, allocatable, dimension(:,:,:) :: Ray_u, Ray_v
   real, pointer, dimension(:,:,:) :: Kv_shear => NULL(), Kv_shear_Bu => NULL()
   real, pointer, dimension(:,:) :: h_ML => NULL()
+  ! members the reference's own MOM_vert_friction / MOM_set_viscosity name (ice shelves, the slow viscosity, the shear-mixing outputs); never
+  ! allocated by the tests
+  real, allocatable, dimension(:,:) :: taux_shelf, tauy_shelf, tbl_thick_shelf_u, tbl_thick_shelf_v, kv_tbl_shelf_u, kv_tbl_shelf_v
+  real, allocatable, dimension(:,:) :: ustar_BBL, TKE_BBL, sfc_buoy_flx, MLD
+  real, allocatable, dimension(:,:,:) :: Kd_shear, TKE_turb
+  real, pointer, dimension(:,:,:) :: Kv_slow => NULL()
 end type vertvisc_type
 type :: ocean_internal_state
   real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL(), u => NULL(), v => NULL(), h => NULL(), uh => NULL(), vh => NULL()
@@ -1096,8 +1107,18 @@ end subroutine dealloc_BT_cont_type
 end module MOM_variables
 
 module MOM_forcing_type
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_unit_scaling, only : unit_scale_type
+use MOM_variables, only : thermo_var_ptrs
 implicit none ; private
-public :: mech_forcing
+public :: mech_forcing, forcing, find_ustar
+interface find_ustar
+  module procedure find_ustar_fluxes, find_ustar_mech_forcing
+end interface find_ustar
+type :: forcing
+  real, pointer, dimension(:,:) :: ustar => NULL(), tau_mag => NULL(), buoy => NULL()
+end type forcing
 type :: mech_forcing
   real, pointer, dimension(:,:) :: taux => NULL(), tauy => NULL()
   real, pointer, dimension(:,:) :: ustar => NULL()      !< the surface friction velocity [Z T-1]
@@ -1105,6 +1126,34 @@ type :: mech_forcing
   real, pointer, dimension(:,:) :: rigidity_ice_u => NULL(), rigidity_ice_v => NULL(), frac_shelf_u => NULL(), frac_shelf_v => NULL()
   real, pointer, dimension(:,:) :: tau_mag => NULL(), omega_w2x => NULL()
 end type mech_forcing
+contains
+!> find_ustar in Boussinesq mode with forces%ustar associated (MOM_forcing_type.F90:1236-1297: a copy over the halo asked for)
+subroutine find_ustar_mech_forcing(forces, tv, U_star, G, GV, US, halo, H_T_units)
+  type(ocean_grid_type),   intent(in)  :: G
+  type(verticalGrid_type), intent(in)  :: GV
+  type(unit_scale_type),   intent(in)  :: US
+  type(mech_forcing),      intent(in)  :: forces
+  type(thermo_var_ptrs),   intent(in)  :: tv
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(out) :: U_star
+  integer,       optional, intent(in)  :: halo
+  logical,       optional, intent(in)  :: H_T_units
+  integer :: i, j, hs
+  if (present(H_T_units)) then ; if (H_T_units) error stop "find_ustar stand-in: H_T_units is not provided" ; endif
+  if (.not.associated(forces%ustar)) error stop "find_ustar stand-in: forces%ustar is needed"
+  hs = 0 ; if (present(halo)) hs = max(halo, 0)
+  do j=G%jsc-hs,G%jec+hs ; do i=G%isc-hs,G%iec+hs ; U_star(i,j) = forces%ustar(i,j) ; enddo ; enddo
+end subroutine find_ustar_mech_forcing
+subroutine find_ustar_fluxes(fluxes, tv, U_star, G, GV, US, halo, H_T_units)
+  type(ocean_grid_type),   intent(in)  :: G
+  type(verticalGrid_type), intent(in)  :: GV
+  type(unit_scale_type),   intent(in)  :: US
+  type(forcing),           intent(in)  :: fluxes
+  type(thermo_var_ptrs),   intent(in)  :: tv
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(out) :: U_star
+  integer,       optional, intent(in)  :: halo
+  logical,       optional, intent(in)  :: H_T_units
+  error stop "find_ustar(fluxes) stand-in: not provided"
+end subroutine find_ustar_fluxes
 end module MOM_forcing_type
 
 module MOM_regridding
@@ -1141,6 +1190,8 @@ implicit none ; private
 public :: stochastic_CS
 type :: stochastic_CS
   logical :: do_sppt = .false., do_skeb = .false., skeb_use_gm = .false., skeb_use_frict = .false., pert_epbl = .false.
+  real, allocatable, dimension(:,:,:) :: skeb_diss
+  real :: skeb_frict_coef = 0.0
 end type stochastic_CS
 end module MOM_stochastics
 
@@ -1153,17 +1204,6 @@ type :: MEKE_type
 end type MEKE_type
 end module MOM_MEKE_types
 
-module MOM_lateral_mixing_coeffs
-implicit none ; private
-public :: VarMix_CS
-type :: VarMix_CS
-  logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false., Resoln_scaled_KhTh = .false.
-  logical :: Depth_scaled_KhTh = .false., use_stored_slopes = .false., khth_use_ebt_struct = .false., use_Visbeck = .false.
-  logical :: use_QG_Leith_GM = .false.
-  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Res_fn_h, Rd_dx_h, cg1
-  real, allocatable, dimension(:,:,:) :: slope_x, slope_y
-end type VarMix_CS
-end module MOM_lateral_mixing_coeffs
 
 module MOM_tracer_registry
 implicit none ; private
@@ -1382,6 +1422,55 @@ subroutine radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, GV, US,
 end subroutine radiation_open_bdry_conds
 end module MOM_open_boundary
 
+module MOM_lateral_mixing_coeffs
+implicit none ; private
+public :: VarMix_CS, calc_QG_slopes, calc_QG_Leith_viscosity
+type :: VarMix_CS
+  logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false., Resoln_scaled_KhTh = .false.
+  logical :: Depth_scaled_KhTh = .false., use_stored_slopes = .false., khth_use_ebt_struct = .false., use_Visbeck = .false.
+  logical :: use_QG_Leith_GM = .false., kdgl90_use_ebt_struct = .false.
+  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Res_fn_h, Res_fn_q, Rd_dx_h, cg1
+  real, allocatable, dimension(:,:,:) :: slope_x, slope_y, ebt_struct
+end type VarMix_CS
+contains
+subroutine calc_QG_slopes(h, tv, dt, G, GV, US, slope_x, slope_y, CS, OBC)
+  use MOM_grid, only : ocean_grid_type
+  use MOM_verticalGrid, only : verticalGrid_type
+  use MOM_unit_scaling, only : unit_scale_type
+  use MOM_variables, only : thermo_var_ptrs
+  use MOM_open_boundary, only : ocean_OBC_type
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real,                    intent(in)    :: dt
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke+1), intent(inout) :: slope_x
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke+1), intent(inout) :: slope_y
+  type(VarMix_CS),         intent(in)    :: CS
+  type(ocean_OBC_type),    pointer       :: OBC
+  error stop "calc_QG_slopes stand-in: not provided"
+end subroutine calc_QG_slopes
+subroutine calc_QG_Leith_viscosity(CS, G, GV, US, h, dz, k, div_xx_dx, div_xx_dy, slope_x, slope_y, vort_xy_dx, vort_xy_dy)
+  use MOM_grid, only : ocean_grid_type
+  use MOM_verticalGrid, only : verticalGrid_type
+  use MOM_unit_scaling, only : unit_scale_type
+  type(VarMix_CS),         intent(inout) :: CS
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(unit_scale_type),   intent(in)    :: US
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h, dz
+  integer,                 intent(in)    :: k
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed), intent(in) :: div_xx_dx
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB), intent(in) :: div_xx_dy
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke+1), intent(in) :: slope_x
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke+1), intent(in) :: slope_y
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB), intent(inout) :: vort_xy_dx
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed), intent(inout) :: vort_xy_dy
+  error stop "calc_QG_Leith_viscosity stand-in: not provided"
+end subroutine calc_QG_Leith_viscosity
+end module MOM_lateral_mixing_coeffs
+
 module MOM_boundary_update
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
@@ -1416,6 +1505,9 @@ public :: Wave_parameters_CS, Stokes_PGF
 type :: Wave_parameters_CS
   logical :: Stokes_VF = .false., Stokes_PGF = .false., Passive_Stokes_PGF = .false., Passive_Stokes_VF = .false., Stokes_DDT = .false.
   real, allocatable, dimension(:,:,:) :: Us_x, Us_y
+  real, allocatable, dimension(:,:,:) :: Ustk_Hb, Vstk_Hb      !< (the surface-band Stokes drift: FPMIX / Stokes mixing only)
+  integer :: NumBands = 0
+  real, allocatable, dimension(:) :: WaveNum_Cen
 end type Wave_parameters_CS
 contains
 subroutine Stokes_PGF(G, GV, US, dz, u, v, PFu_Stokes, PFv_Stokes, CS)
@@ -1474,17 +1566,6 @@ subroutine find_col_avg_SpV(h, SpV_avg, tv, G, GV, US, halo_size)
 end subroutine find_col_avg_SpV
 end module MOM_interface_heights
 
-module MOM_checksums
-implicit none ; private
-public :: chksum0
-contains
-subroutine chksum0(scalar, mesg, scale, logunit, unscale)
-  real,              intent(in) :: scalar
-  character(len=*),  intent(in) :: mesg
-  real,    optional, intent(in) :: scale, unscale
-  integer, optional, intent(in) :: logunit
-end subroutine chksum0
-end module MOM_checksums
 
 module MOM_debugging
 use MOM_grid, only : ocean_grid_type
@@ -1571,6 +1652,20 @@ subroutine check_redundant_vC2d(mesg, u_comp, v_comp, G, is, ie, js, je, directi
   real,                      optional, intent(in)    :: unscale
 end subroutine check_redundant_vC2d
 end module MOM_debugging
+
+module MOM_checksums
+use MOM_debugging, only : hchksum, Bchksum, uvchksum
+implicit none ; private
+public :: chksum0, hchksum, Bchksum, uvchksum
+contains
+subroutine chksum0(scalar, mesg, scale, logunit, unscale)
+  real,              intent(in) :: scalar
+  character(len=*),  intent(in) :: mesg
+  real,    optional, intent(in) :: scale, unscale
+  integer, optional, intent(in) :: logunit
+end subroutine chksum0
+end module MOM_checksums
+
 
 module MOM_checksum_packages
 use MOM_grid, only : ocean_grid_type

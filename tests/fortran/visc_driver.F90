@@ -3,9 +3,15 @@
 !! vertvisc_remnant (RK2 :717-744), hor_visc_init / horizontal_viscosity (RK2 :860), on plain host arrays, parameters by name.
 !! tests/test_fortran_abi.py writes the input file and compares the output with the oracle bit for bit.
 !! Usage: visc_driver <input file> <output file>
+!! Built with -DREFERENCE_KERNELS (tests/test_reference_kernels.py) the same program drives the reference's OWN MOM_vert_friction.F90 and
+!! MOM_hor_visc.F90, compiled in place against the stand-ins of tests/fortran/stubs: MOM_set_viscosity.F90 is not part of that build (its
+!! imports reach the shear-mixing and CVMix modules), so the bottom boundary layer's viscosities and thicknesses are read from the input
+!! file (the oracle's) and set_viscous_BBL / set_viscous_ML are not called.
 program visc_driver
 use, intrinsic :: iso_c_binding
+#ifndef REFERENCE_KERNELS
 use MOM_set_visc,      only : set_visc_CS, set_visc_init, set_viscous_BBL, set_viscous_ML, set_visc_end
+#endif
 use MOM_vert_friction, only : vertvisc_CS, vertvisc_init, vertvisc_coef, vertvisc, vertvisc_remnant, vertvisc_end
 use MOM_hor_visc,      only : hor_visc_CS, hor_visc_init, horizontal_viscosity, hor_visc_end, hor_visc_vel_stencil
 use MOM_diag_mediator, only : diag_ctrl, time_type
@@ -21,7 +27,9 @@ use MOM_restart,       only : MOM_restart_CS
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : vertvisc_type, thermo_var_ptrs, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, ocean_internal_state
 use MOM_verticalGrid,  only : verticalGrid_type
+#ifndef REFERENCE_KERNELS
 use mom6hip_MOM_glue,  only : mom6hip_shared_context_end
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -33,7 +41,9 @@ type(diag_ctrl), target :: diag
 type(MOM_restart_CS) :: restart_CS
 type(ocean_internal_state), target :: MIS
 type(directories) :: dirs
+#ifndef REFERENCE_KERNELS
 type(set_visc_CS) :: SV
+#endif
 type(vertvisc_CS), pointer :: VV => NULL()
 type(hor_visc_CS) :: HV
 type(vertvisc_type) :: visc
@@ -51,7 +61,8 @@ integer :: ni, nj, nk, halo, u_in, u_out, isd, ied, jsd, jed
 real :: scal(7), dt
 real, allocatable, dimension(:,:,:) :: u, v, h, dz, u1, v1, vru, vrv, diffu, diffv
 real, allocatable, dimension(:,:) :: tbx, tby
-character(len=512) :: f_in, f_out
+character(len=512) :: f_in, f_out, f_arg
+integer :: m
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
@@ -83,6 +94,15 @@ read(u_in) G%mask2dBu, G%dxBu, G%dyBu, G%areaBu, G%IareaBu, G%CoriolisBu, G%IdxB
 allocate(u(isd-1:ied,jsd:jed,nk), v(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk), tv%T(isd:ied,jsd:jed,nk), tv%S(isd:ied,jsd:jed,nk), &
          forces%taux(isd-1:ied,jsd:jed), forces%tauy(isd:ied,jsd-1:jed))
 read(u_in) u, v, h, tv%T, tv%S, forces%taux, forces%tauy
+#ifdef REFERENCE_KERNELS
+allocate(visc%bbl_thick_u(isd-1:ied,jsd:jed), visc%bbl_thick_v(isd:ied,jsd-1:jed), visc%Kv_bbl_u(isd-1:ied,jsd:jed), &
+         visc%Kv_bbl_v(isd:ied,jsd-1:jed))
+read(u_in) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v
+allocate(forces%ustar(isd:ied,jsd:jed), source=0.0)      ! vertvisc_coef asks find_ustar for it whether or not a surface boundary layer reads it (:1307)
+G%HI%isd = isd ; G%HI%ied = ied ; G%HI%jsd = jsd ; G%HI%jed = jed ; G%HI%IsdB = isd-1 ; G%HI%IedB = ied ; G%HI%JsdB = jsd-1 ; G%HI%JedB = jed
+G%HI%isc = G%isc ; G%HI%iec = G%iec ; G%HI%jsc = G%jsc ; G%HI%jec = G%jec
+G%HI%IscB = G%IscB ; G%HI%IecB = G%IecB ; G%HI%JscB = G%JscB ; G%HI%JecB = G%JecB
+#endif
 close(u_in)
 allocate(dz(isd:ied,jsd:jed,nk), u1(isd-1:ied,jsd:jed,nk), v1(isd:ied,jsd-1:jed,nk), vru(isd-1:ied,jsd:jed,nk), vrv(isd:ied,jsd-1:jed,nk), &
          diffu(isd-1:ied,jsd:jed,nk), diffv(isd:ied,jsd-1:jed,nk), tbx(isd-1:ied,jsd:jed), tby(isd:ied,jsd-1:jed))
@@ -94,10 +114,16 @@ call param_set(pf, "REENTRANT_Y", merge("True ", "False", hdr(6) /= 0))
 call param_set(pf, "HBBL", "10.0") ; call param_set(pf, "KV", "1.0e-4") ; call param_set(pf, "DT", "900.0")
 call param_set(pf, "HMIX_FIXED", "20.0") ; call param_set(pf, "KV_ML_INVZ2", "1.0e-2")
 call param_set(pf, "SMAGORINSKY_AH", "True") ; call param_set(pf, "SMAG_BI_CONST", "0.06") ; call param_set(pf, "AH_VEL_SCALE", "0.01")
+do m = 3, command_argument_count()      ! further NAME=VALUE pairs of the parameter file (they replace the ones above)
+  call get_command_argument(m, f_arg)
+  if (index(f_arg, "=") > 1) call param_set(pf, f_arg(1:index(f_arg, "=")-1), trim(f_arg(index(f_arg, "=")+1:)))
+enddo
 
+#ifndef REFERENCE_KERNELS
 call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
 call set_viscous_BBL(u, v, h, tv, visc, G, GV, US, SV, pbv)
 call set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, SV)
+#endif
 call vertvisc_init(MIS, Time, G, GV, US, pf, diag, ADp, dirs, ntrunc, VV)
 call vertvisc_coef(u1, v1, h, dz, forces, visc, tv, dt, G, GV, US, VV, OBC, VarMix)
 call vertvisc(u1, v1, h, forces, visc, dt, OBC, ADp, CDp, G, GV, US, VV, taux_bot=tbx, tauy_bot=tby)
@@ -109,7 +135,10 @@ call horizontal_viscosity(u, v, h, diffu, diffv, MEKE, VarMix, G, GV, US, HV, tv
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v, u1, v1, vru, vrv, tbx, tby, diffu, diffv
 close(u_out)
-call hor_visc_end(HV) ; call vertvisc_end(VV) ; call set_visc_end(visc, SV)
+call hor_visc_end(HV) ; call vertvisc_end(VV)
+#ifndef REFERENCE_KERNELS
+call set_visc_end(visc, SV)
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a,i0)') "visc_driver ok ntrunc=", ntrunc
 end program visc_driver

@@ -279,3 +279,96 @@ def test_the_reference_btstep_equals_the_oracle(ref_bt_exe, tmp_path, kw, params
             assert d.mean() <= 0.01 and np.all(np.abs(ia - iw)[d] <= 1.0e-14 * np.abs(iw)[d] + 1.0e-30), (n, int(d.sum()))
     if not exact:
         assert ndiff > 0      # (if this ever fails the libm power has become correctly rounded on these arguments: tighten the test)
+
+
+# ---- the reference's own MOM_vert_friction.F90 and MOM_hor_visc.F90 beside the oracle ----------------------------------------------------
+VISC_SOURCES = ("src/parameterizations/vertical/MOM_vert_friction.F90", "src/parameterizations/lateral/MOM_Zanna_Bolton.F90",
+                "src/core/MOM_barotropic.F90", "src/parameterizations/lateral/MOM_hor_visc.F90")
+
+
+def build_ref_visc_driver(tmp):
+    """the stand-ins (+ tests/fortran/stubs/mom6_stubs_visc.F90), the reference's vert_friction and hor_visc with the two modules hor_visc
+    imports types from (in place), and tests/fortran/visc_driver.F90 built with -DREFERENCE_KERNELS"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", f"-I{REF}/config_src/memory/dynamic_symmetric",
+             f"-I{REF}/src/framework", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(STUBS, "mom6_stubs_visc.F90")] + \
+               [os.path.join(REF, r) for r in VISC_SOURCES] + [os.path.join(ROOT, "tests", "fortran", "visc_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "visc_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+# option sets: (NAME=VALUE arguments of the driver, the oracle's vertvisc_cs keywords, its hor_visc_cs keywords)
+VISC_SETS = {
+    "default": ([], {}, dict(Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.01)),
+    "harmonic_laplacian": (["HARMONIC_VISC=True", "HARMONIC_BL_SCALE=0.5", "KV_EXTRA_BBL=2.0e-4", "LAPLACIAN=True", "KH=20.0", "KH_VEL_SCALE=0.005",
+                            "SMAGORINSKY_KH=True", "SMAG_LAP_CONST=0.15", "SMAGORINSKY_AH=False", "AH=1.0e9"],
+                           dict(harmonic_visc=True, harm_BL_val=0.5, Kv_extra_bbl=2.0e-4),
+                           dict(Laplacian=1, Kh=20.0, Kh_vel_scale=0.005, Smagorinsky_Kh=1, Smag_Lap_const=0.15, Smagorinsky_Ah=0, Ah=1.0e9,
+                                Ah_vel_scale=0.01)),
+    "laplacian_noslip": (["LAPLACIAN=True", "BIHARMONIC=False", "KH_VEL_SCALE=0.01", "SMAGORINSKY_KH=True", "SMAG_LAP_CONST=0.15", "NOSLIP=True",
+                          "SMAGORINSKY_AH=False", "BETTER_BOUND_KH=False"], {},
+                         dict(Laplacian=1, biharmonic=0, Kh_vel_scale=0.01, Smagorinsky_Kh=1, Smag_Lap_const=0.15, no_slip=1, better_bound_Kh=0)),
+    "direct_stress_maxvel": (["DIRECT_STRESS=True", "HMIX_STRESS=15.0", "CFL_BASED_TRUNCATIONS=False", "MAXVEL=0.25", "VEL_UNDERFLOW=1.0e-30",
+                              "BOUND_CORIOLIS=True", "BETTER_BOUND_AH=False"],
+                             dict(direct_stress=True, Hmix_stress=15.0, CFL_based_trunc=False, maxvel=0.25, vel_underflow=1.0e-30),
+                             dict(Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.01, bound_Coriolis=1, better_bound_Ah=0, bound_Cor_vel=0.25)),
+}
+
+
+@pytest.mark.parametrize("ni,nj,nk,seed,opts", [(34, 18, 5, 55, "default"), (21, 26, 9, 7, "default"), (34, 18, 5, 56, "harmonic_laplacian"),
+                                                (30, 22, 6, 57, "direct_stress_maxvel"), (26, 20, 4, 58, "laplacian_noslip")])
+def test_reference_vert_friction_and_hor_visc_equal_the_oracle(tmp_path, ni, nj, nk, seed, opts):
+    """vertvisc_init / vertvisc_coef / vertvisc / vertvisc_remnant and hor_visc_init / horizontal_viscosity of the reference's own modules, with
+    the parameters tests/fortran/visc_driver.F90 sets by name (the set tests/test_fortran_abi.py runs through the shims on the GPU) and the
+    bottom boundary layer the oracle's set_viscous_BBL leaves: velocities, visc_rem, the bottom stresses and the viscous accelerations
+    equal the oracle's bit for bit"""
+    from mom6_amd import synth
+    from oracle import orc
+    exe = build_ref_visc_driver(tmp_path)
+    halo = 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=seed, reentrant_x=False, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=8, umax=0.3, eta_amp=0.2).items()}
+    U, V = _abi.POS_U, _abi.POS_V
+    yy = np.linspace(0.0, np.pi, g.shape2(U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = np.ascontiguousarray(0.02 * g.mask2dCv)
+    dt = 900.0
+    bb = dict(Kv_bbl_u=g.zeros2(U), Kv_bbl_v=g.zeros2(V), bbl_thick_u=g.zeros2(U), bbl_thick_v=g.zeros2(V))
+    visc = orc.vertvisc_type(**bb)
+    orc.set_viscous_BBL(g, orc.set_visc_cs(g, 10.0, 1.0e-4), d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), visc)
+    bb = visc._keep
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([ni, nj, nk, halo, 0, 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], d["T"], d["S"], taux, tauy, bb["bbl_thick_u"], bb["bbl_thick_v"], bb["Kv_bbl_u"], bb["Kv_bbl_v"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+    args, vv_kw, hv_kw = VISC_SETS[opts]
+    vcs = orc.vertvisc_cs(g, **dict(dict(Kv=1.0e-4, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=1.0e-2), **vv_kw))
+    u1, v1 = d["u"].copy(), d["v"].copy()
+    orc.vertvisc_coef(g, vcs, u1, v1, d["h"], visc, dt)
+    tbx, tby = g.zeros2(U), g.zeros2(V)
+    orc.vertvisc(g, vcs, u1, v1, d["h"], taux, tauy, visc, dt, taux_bot=tbx, tauy_bot=tby)
+    vru, vrv = g.zeros3(U), g.zeros3(V)
+    orc.vertvisc_remnant(g, vcs, visc, vru, vrv, dt)
+    diffu, diffv = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, dt, **hv_kw), d["u"], d["v"], d["h"], dt)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    want = [bb["bbl_thick_u"], bb["bbl_thick_v"], bb["Kv_bbl_u"], bb["Kv_bbl_v"], u1, v1, vru, vrv, tbx, tby, diffu, diffv]
+    names = ["bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u", "v", "visc_rem_u", "visc_rem_v", "taux_bot", "tauy_bot", "diffu", "diffv"]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    bad = []
+    for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        pos = V if n.endswith("_v") or n in ("v", "tauy_bot", "diffv") else U
+        if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
+            bad.append(n)
+    assert not bad, bad
