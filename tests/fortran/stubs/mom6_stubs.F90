@@ -276,7 +276,7 @@ type :: verticalGrid_type
           Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0, H_to_MKS = 1.0, &
           H_to_kg_m2 = 1035.0, kg_m2_to_H = 1.0/1035.0, HZ_T_to_m2_s = 1.0, HZ_T_to_MKS = 1.0
   integer :: nk_rho_varies = 0, nkml = 0
-  logical :: Boussinesq = .true.
+  logical :: Boussinesq = .true., semi_Boussinesq = .false.
   real, allocatable :: Rlay(:), g_prime(:)
   character(len=40) :: zAxisUnits = "", zAxisLongName = ""
   real, allocatable, dimension(:) :: sLayer, sInterface
@@ -1006,6 +1006,9 @@ logical function query_0d(f_ptr, name, CS)
 end function query_0d
 end module MOM_restart
 
+#ifdef REF_EOS
+#include "mom6_stubs_eos.inc"
+#else
 module MOM_EOS
 implicit none ; private
 public :: EOS_type
@@ -1013,6 +1016,7 @@ type :: EOS_type
   integer :: form_of_EOS = 0
 end type EOS_type
 end module MOM_EOS
+#endif
 
 module MOM_variables
 use MOM_domains, only : group_pass_type
@@ -1172,13 +1176,77 @@ type :: remapping_CS
 end type remapping_CS
 end module MOM_remapping
 
+#ifdef REF_PF
+! The reference's PLM_functions.F90, compiled where it lies (cpp #include by -I/root/reference/src/ALE), for the stand-in below.
+#include "PLM_functions.F90"
+#endif
 #ifndef MOM6HIP_WITH_ALE_SHIM
 module MOM_ALE
+#ifdef REF_PF
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+use MOM_variables, only : thermo_var_ptrs
+use PLM_functions, only : PLM_slope_wa, PLM_monotonized_slope, PLM_extrapolate_slope
+#endif
 implicit none ; private
 public :: ALE_CS
 type :: ALE_CS
   integer :: unused = 0
 end type ALE_CS
+#ifdef REF_PF
+! What MOM_PressureForce_FV imports from MOM_ALE.  MOM_ALE.F90 itself stands on the regridding and tracer-registry modules and is not part of
+! this build: this stand-in forms the edge values of T and S of a column from the reference's OWN slope functions (PLM_functions.F90 above), the
+! way ALE_PLM_edge_values does for REMAPPING_ANSWER_DATE >= 20190101 (MOM_ALE.F90:1520-1577).  The glue is ours; the arithmetic is theirs.
+public :: TS_PLM_edge_values, TS_PPM_edge_values
+contains
+subroutine plm_edges(G, GV, h, Q, bdry_extrap, Q_t, Q_b)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in)    :: h, Q
+  logical,                 intent(in)    :: bdry_extrap
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(inout) :: Q_t, Q_b
+  real :: s(GV%ke), ms, hn
+  integer :: i, j, k, nz
+  nz = GV%ke ; hn = GV%H_subroundoff
+  do j=G%jsc-1,G%jec+1 ; do i=G%isc-1,G%iec+1
+    s(1) = 0. ; s(nz) = 0.
+    do k=2,nz-1 ; s(k) = PLM_slope_wa(h(i,j,k-1), h(i,j,k), h(i,j,k+1), hn, Q(i,j,k-1), Q(i,j,k), Q(i,j,k+1)) ; enddo
+    do k=2,nz-1
+      ms = PLM_monotonized_slope(Q(i,j,k-1), Q(i,j,k), Q(i,j,k+1), s(k-1), s(k), s(k+1))
+      Q_t(i,j,k) = Q(i,j,k) - 0.5 * ms ; Q_b(i,j,k) = Q(i,j,k) + 0.5 * ms
+    enddo
+    if (bdry_extrap) then
+      ms = - PLM_extrapolate_slope(h(i,j,2), h(i,j,1), hn, Q(i,j,2), Q(i,j,1))
+      Q_t(i,j,1) = Q(i,j,1) - 0.5 * ms ; Q_b(i,j,1) = Q(i,j,1) + 0.5 * ms
+      ms = PLM_extrapolate_slope(h(i,j,nz-1), h(i,j,nz), hn, Q(i,j,nz-1), Q(i,j,nz))
+      Q_t(i,j,nz) = Q(i,j,nz) - 0.5 * ms ; Q_b(i,j,nz) = Q(i,j,nz) + 0.5 * ms
+    else
+      Q_t(i,j,1) = Q(i,j,1) ; Q_b(i,j,1) = Q(i,j,1) ; Q_t(i,j,nz) = Q(i,j,nz) ; Q_b(i,j,nz) = Q(i,j,nz)
+    endif
+  enddo ; enddo
+end subroutine plm_edges
+subroutine TS_PLM_edge_values(CS, S_t, S_b, T_t, T_b, G, GV, tv, h, bdry_extrap)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(ALE_CS),            intent(inout) :: CS
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(inout) :: S_t, S_b, T_t, T_b
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in)    :: h
+  logical,                 intent(in)    :: bdry_extrap
+  call plm_edges(G, GV, h, tv%S, bdry_extrap, S_t, S_b)
+  call plm_edges(G, GV, h, tv%T, bdry_extrap, T_t, T_b)
+end subroutine TS_PLM_edge_values
+subroutine TS_PPM_edge_values(CS, S_t, S_b, T_t, T_b, G, GV, tv, h, bdry_extrap)
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  type(ALE_CS),            intent(inout) :: CS
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(inout) :: S_t, S_b, T_t, T_b
+  type(thermo_var_ptrs),   intent(in)    :: tv
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in)    :: h
+  logical,                 intent(in)    :: bdry_extrap
+  error stop "TS_PPM_edge_values stand-in: PRESSURE_RECONSTRUCTION_SCHEME = 2 is not provided"
+end subroutine TS_PPM_edge_values
+#endif
 end module MOM_ALE
 #endif
 
@@ -1228,11 +1296,20 @@ use MOM_grid, only : ocean_grid_type
 use MOM_unit_scaling, only : unit_scale_type
 use MOM_file_parser, only : param_file_type
 implicit none ; private
-public :: SAL_CS, SAL_init, SAL_end, scalar_SAL_sensitivity
+public :: SAL_CS, SAL_init, SAL_end, scalar_SAL_sensitivity, calc_SAL
 type :: SAL_CS
   integer :: unused = 0
 end type SAL_CS
 contains
+subroutine calc_SAL(eta, eta_sal, G, CS, tmp_scale)
+  type(ocean_grid_type), intent(in)  :: G
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(in)  :: eta
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(out) :: eta_sal
+  type(SAL_CS), intent(inout) :: CS
+  real, optional, intent(in) :: tmp_scale
+  eta_sal(:,:) = 0.0
+  error stop "calc_SAL stand-in: self-attraction and loading is not provided"
+end subroutine calc_SAL
 subroutine scalar_SAL_sensitivity(CS, deta_geo_dpbot)
   type(SAL_CS), intent(in)  :: CS
   real,         intent(out) :: deta_geo_dpbot
@@ -1255,11 +1332,30 @@ use MOM_unit_scaling, only : unit_scale_type
 use MOM_file_parser, only : param_file_type
 use MOM_time_manager, only : time_type
 implicit none ; private
-public :: tidal_forcing_CS, tidal_forcing_init, tidal_forcing_end
+public :: tidal_forcing_CS, tidal_forcing_init, tidal_forcing_end, calc_tidal_forcing, calc_tidal_forcing_legacy
 type :: tidal_forcing_CS
   integer :: unused = 0
 end type tidal_forcing_CS
 contains
+subroutine calc_tidal_forcing(Time, e_tide_eq, e_tide_sal, G, US, CS)
+  type(ocean_grid_type),            intent(in)  :: G
+  type(time_type),                  intent(in)  :: Time
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(out) :: e_tide_eq, e_tide_sal
+  type(unit_scale_type),            intent(in)  :: US
+  type(tidal_forcing_CS),           intent(in)  :: CS
+  e_tide_eq(:,:) = 0.0 ; e_tide_sal(:,:) = 0.0
+  error stop "calc_tidal_forcing stand-in: tides are not provided"
+end subroutine calc_tidal_forcing
+subroutine calc_tidal_forcing_legacy(Time, e_sal, e_sal_tide, e_tide_eq, e_tide_sal, G, US, CS)
+  type(ocean_grid_type),            intent(in)  :: G
+  type(time_type),                  intent(in)  :: Time
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(in)  :: e_sal
+  real, dimension(G%isd:G%ied,G%jsd:G%jed), intent(out) :: e_sal_tide, e_tide_eq, e_tide_sal
+  type(unit_scale_type),            intent(in)  :: US
+  type(tidal_forcing_CS),           intent(in)  :: CS
+  e_sal_tide(:,:) = 0.0 ; e_tide_eq(:,:) = 0.0 ; e_tide_sal(:,:) = 0.0
+  error stop "calc_tidal_forcing_legacy stand-in: tides are not provided"
+end subroutine calc_tidal_forcing_legacy
 subroutine tidal_forcing_init(Time, G, US, param_file, CS)
   type(time_type),        intent(in)    :: Time
   type(ocean_grid_type),  intent(inout) :: G
@@ -1725,6 +1821,7 @@ end module MOM_checksum_packages
 
 !> The Montgomery-potential pressure force stays the reference's own module in a MOM6 tree (it is not on the path of
 !! ANALYTIC_FV_PGF = True); this is its interface as MOM_PressureForce.F90 uses it.
+#ifndef REF_PF_MONT
 module MOM_PressureForce_Mont
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
@@ -1783,3 +1880,4 @@ subroutine PressureForce_Mont_init(Time, G, GV, US, param_file, diag, CS, SAL_CS
   CS%initialized = .true.
 end subroutine PressureForce_Mont_init
 end module MOM_PressureForce_Mont
+#endif

@@ -372,3 +372,74 @@ def test_reference_vert_friction_and_hor_visc_equal_the_oracle(tmp_path, ni, nj,
         if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
             bad.append(n)
     assert not bad, bad
+
+
+# ---- the reference's own PressureForce_FV_Bouss (with its density integrals and equation-of-state stack) beside the oracle ------------------
+PF_SOURCES = ("src/core/MOM_density_integrals.F90", "src/core/MOM_PressureForce_Montgomery.F90", "src/core/MOM_PressureForce_FV.F90")
+
+
+def build_ref_pf_driver(tmp):
+    """the stand-ins with the reference's whole src/equation_of_state and src/ALE/PLM_functions.F90 #included in place (-DREF_EOS -DREF_PF), the
+    reference's density integrals, Montgomery module (Set_pbce_Bouss) and PressureForce_FV, and tests/fortran/ref_pf_driver.F90"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREF_EOS", "-DREF_PF", "-DREF_PF_MONT",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(REF, r) for r in PF_SOURCES] + \
+               [os.path.join(ROOT, "tests", "fortran", "ref_pf_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "ref_pf_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+# (NAME=VALUE arguments of the driver, the oracle's equation of state, its pressureforce_cs keywords, a surface pressure?)
+PF_SETS = {
+    "wright_plm": ([], "WRIGHT", {}, False),
+    "wright_plm_massw_psurf": (["MASS_WEIGHT_IN_PRESSURE_GRADIENT=True", "BOUNDARY_EXTRAPOLATION_PRESSURE=False"], "WRIGHT",
+                               dict(useMassWghtInterp=True, boundary_extrap=False), True),
+    "wright_pcm": (["RECONSTRUCT_FOR_PRESSURE=False"], "WRIGHT", dict(reconstruct=False), False),
+    "linear_plm": (["EQN_OF_STATE=LINEAR", "RHO_T0_S0=1000.0", "DRHO_DT=-0.2", "DRHO_DS=0.8"], "LINEAR", {}, False),
+    "wright_full_plm": (["EQN_OF_STATE=WRIGHT_FULL"], "WRIGHT_FULL", {}, True),
+    "unesco_plm": (["EQN_OF_STATE=UNESCO"], "UNESCO", {}, False),
+}
+
+
+@pytest.mark.parametrize("ni,nj,nk,seed,opts", [(30, 14, 6, 61, "wright_plm"), (22, 25, 9, 62, "wright_plm_massw_psurf"), (30, 14, 6, 63, "wright_pcm"),
+                                                (26, 18, 5, 64, "linear_plm"), (26, 18, 5, 65, "wright_full_plm"), (24, 16, 5, 66, "unesco_plm")])
+def test_reference_pressureforce_equals_the_oracle(tmp_path, ni, nj, nk, seed, opts):
+    """PressureForce_FV_Bouss of the reference -- int_density_dz_generic_plm / int_density_dz, the PLM edge values of T and S from its own slope
+    functions, its equation-of-state modules, Set_pbce_Bouss -- on the oracle's inputs: PFu, PFv, pbce and eta equal the oracle's bit for bit"""
+    from mom6_amd import synth
+    from oracle import orc
+    exe = build_ref_pf_driver(tmp_path)
+    args, eos_form, cs_kw, with_p = PF_SETS[opts]
+    halo = 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=seed, reentrant_x=False, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed + 1, umax=0.3, eta_amp=0.3).items()}
+    H = _abi.POS_H
+    rng = np.random.default_rng(seed)
+    p_atm = np.ascontiguousarray(1.0e5 + 2.0e3 * rng.standard_normal(g.shape2(H))) if with_p else None
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([ni, nj, nk, halo, 0, 0, g.first_direction, 1 if with_p else 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, 900.0], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["h"], d["T"], d["S"]) + ((p_atm,) if with_p else ()):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+    PFu, PFv, pbce, eta = orc.pressureforce(g, orc.pressureforce_cs(g, **cs_kw), orc.eos(eos_form), d["h"], d["T"], d["S"], p_atm=p_atm)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    want = [PFu, PFv, pbce, eta]
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    bad = []
+    for n, a, w, pos in zip(("PFu", "PFv", "pbce", "eta"), np.split(raw, np.cumsum(sizes)[:-1]), want, (_abi.POS_U, _abi.POS_V, H, H)):
+        if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
+            bad.append(n)
+    assert not bad, bad
