@@ -256,7 +256,7 @@ type :: ocean_grid_type
   logical :: symmetric = .true.
   logical :: nonblocking_updates = .false.
   type(hor_index_type) :: HI
-  real :: max_depth = 0.0, Z_ref = 0.0
+  real :: max_depth = 0.0, Z_ref = 0.0, Rad_Earth_L = 6.378e6
   real, allocatable, dimension(:,:) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
   real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
   real, allocatable, dimension(:,:) :: mask2dCv, dxCv, dyCv, dx_Cv, IdxCv, IdyCv, areaCv, IareaCv
@@ -759,6 +759,12 @@ subroutine safe_alloc_allocatable_2d(ptr, is, ie, js, je)
 end subroutine safe_alloc_allocatable_2d
 end module MOM_diag_mediator
 
+module MOM_safe_alloc      ! (the reference's MOM_diag_mediator re-exports MOM_safe_alloc's generics: here it is the other way round)
+use MOM_diag_mediator, only : safe_alloc_ptr, safe_alloc_alloc
+implicit none ; private
+public :: safe_alloc_ptr, safe_alloc_alloc
+end module MOM_safe_alloc
+
 module MOM_io
 use MOM_domains, only : CENTER, CORNER, EAST_FACE, NORTH_FACE
 implicit none ; private
@@ -828,7 +834,7 @@ use MOM_verticalGrid, only : verticalGrid_type
 use MOM_time_manager, only : time_type
 use MOM_file_parser, only : param_file_type
 implicit none ; private
-public :: MOM_restart_CS, register_restart_field, query_initialized
+public :: MOM_restart_CS, register_restart_field, query_initialized, register_restart_field_as_obsolete
 public :: register_restart_pair, set_initialized, save_restart, only_read_from_restarts, restart_init, is_new_run
 type :: MOM_restart_CS
   integer :: nfields = 0
@@ -849,6 +855,10 @@ interface only_read_from_restarts
   module procedure only_read_restart_field_3d, only_read_restart_field_2d, only_read_restart_pair_3d
 end interface
 contains
+subroutine register_restart_field_as_obsolete(field_name, replacement_name, CS)
+  character(*), intent(in) :: field_name, replacement_name
+  type(MOM_restart_CS), intent(inout) :: CS
+end subroutine register_restart_field_as_obsolete
 subroutine register_vd_3d(f_ptr, var_desc, mandatory, CS, conversion)
   real, dimension(:,:,:), target, intent(in) :: f_ptr
   type(vardesc),        intent(in)    :: var_desc
@@ -1067,9 +1077,9 @@ type :: vertvisc_type
   ! members the reference's own MOM_vert_friction / MOM_set_viscosity name (ice shelves, the slow viscosity, the shear-mixing outputs); never
   ! allocated by the tests
   real, allocatable, dimension(:,:) :: taux_shelf, tauy_shelf, tbl_thick_shelf_u, tbl_thick_shelf_v, kv_tbl_shelf_u, kv_tbl_shelf_v
-  real, allocatable, dimension(:,:) :: ustar_BBL, TKE_BBL, sfc_buoy_flx, MLD
-  real, allocatable, dimension(:,:,:) :: Kd_shear, TKE_turb
-  real, pointer, dimension(:,:,:) :: Kv_slow => NULL()
+  real, allocatable, dimension(:,:) :: ustar_BBL, TKE_BBL
+  real, pointer, dimension(:,:) :: sfc_buoy_flx => NULL(), MLD => NULL()
+  real, pointer, dimension(:,:,:) :: Kv_slow => NULL(), Kd_shear => NULL(), TKE_turb => NULL()
 end type vertvisc_type
 type :: ocean_internal_state
   real, pointer, dimension(:,:,:) :: T => NULL(), S => NULL(), u => NULL(), v => NULL(), h => NULL(), uh => NULL(), vh => NULL()
@@ -1182,9 +1192,11 @@ end module MOM_remapping
 #endif
 #ifndef MOM6HIP_WITH_ALE_SHIM
 module MOM_ALE
-#ifdef REF_PF
+#if defined(REF_PF) || defined(REF_SET_VISC)
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
+#endif
+#ifdef REF_PF
 use MOM_variables, only : thermo_var_ptrs
 use PLM_functions, only : PLM_slope_wa, PLM_monotonized_slope, PLM_extrapolate_slope
 #endif
@@ -1193,12 +1205,50 @@ public :: ALE_CS
 type :: ALE_CS
   integer :: unused = 0
 end type ALE_CS
+#ifdef REF_SET_VISC
+public :: ALE_remap_velocities, ALE_remap_interface_vals, ALE_remap_vertex_vals
+#endif
 #ifdef REF_PF
 ! What MOM_PressureForce_FV imports from MOM_ALE.  MOM_ALE.F90 itself stands on the regridding and tracer-registry modules and is not part of
 ! this build: this stand-in forms the edge values of T and S of a column from the reference's OWN slope functions (PLM_functions.F90 above), the
 ! way ALE_PLM_edge_values does for REMAPPING_ANSWER_DATE >= 20190101 (MOM_ALE.F90:1520-1577).  The glue is ours; the arithmetic is theirs.
 public :: TS_PLM_edge_values, TS_PPM_edge_values
+#endif
+#if defined(REF_PF) || defined(REF_SET_VISC)
 contains
+#endif
+#ifdef REF_SET_VISC
+! What MOM_set_viscosity imports from MOM_ALE for remap_vertvisc_aux_vars (REMAP_AUXILIARY_VARS: not reached by the tests)
+subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
+  type(ALE_CS),            intent(in)    :: CS
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(in)    :: h_old_u, h_new_u
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(in)    :: h_old_v, h_new_v
+  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke), intent(inout) :: u
+  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke), intent(inout) :: v
+  logical, optional, intent(in) :: debug, allow_preserve_variance
+  real,    optional, intent(in) :: dt
+  error stop "ALE_remap_velocities stand-in: not provided"
+end subroutine ALE_remap_velocities
+subroutine ALE_remap_interface_vals(CS, G, GV, h_old, h_new, int_val)
+  type(ALE_CS),            intent(in)    :: CS
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),   intent(in)    :: h_old, h_new
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke+1), intent(inout) :: int_val
+  error stop "ALE_remap_interface_vals stand-in: not provided"
+end subroutine ALE_remap_interface_vals
+subroutine ALE_remap_vertex_vals(CS, G, GV, h_old, h_new, vert_val)
+  type(ALE_CS),            intent(in)    :: CS
+  type(ocean_grid_type),   intent(in)    :: G
+  type(verticalGrid_type), intent(in)    :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke),       intent(in)    :: h_old, h_new
+  real, dimension(G%IsdB:G%IedB,G%JsdB:G%JedB,GV%ke+1), intent(inout) :: vert_val
+  error stop "ALE_remap_vertex_vals stand-in: not provided"
+end subroutine ALE_remap_vertex_vals
+#endif
+#ifdef REF_PF
 subroutine plm_edges(G, GV, h, Q, bdry_extrap, Q_t, Q_b)
   type(ocean_grid_type),   intent(in)    :: G
   type(verticalGrid_type), intent(in)    :: GV

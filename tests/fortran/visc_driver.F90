@@ -6,11 +6,15 @@
 !! Built with -DREFERENCE_KERNELS (tests/test_reference_kernels.py) the same program drives the reference's OWN MOM_vert_friction.F90 and
 !! MOM_hor_visc.F90, compiled in place against the stand-ins of tests/fortran/stubs: MOM_set_viscosity.F90 is not part of that build (its
 !! imports reach the shear-mixing and CVMix modules), so the bottom boundary layer's viscosities and thicknesses are read from the input
-!! file (the oracle's) and set_viscous_BBL / set_viscous_ML are not called.
+!! file (the oracle's) and set_viscous_BBL / set_viscous_ML are not called -- unless -DREF_SET_VISC (and -DREF_EOS) is given as well: then
+!! the reference's MOM_set_viscosity.F90 is part of the build (with further stand-ins, mom6_stubs_setvisc.F90) and the whole sequence runs.
 program visc_driver
 use, intrinsic :: iso_c_binding
-#ifndef REFERENCE_KERNELS
+#if !defined(REFERENCE_KERNELS) || defined(REF_SET_VISC)
 use MOM_set_visc,      only : set_visc_CS, set_visc_init, set_viscous_BBL, set_viscous_ML, set_visc_end
+#endif
+#ifdef REF_EOS
+use MOM_EOS,           only : EOS_init
 #endif
 use MOM_vert_friction, only : vertvisc_CS, vertvisc_init, vertvisc_coef, vertvisc, vertvisc_remnant, vertvisc_end
 use MOM_hor_visc,      only : hor_visc_CS, hor_visc_init, horizontal_viscosity, hor_visc_end, hor_visc_vel_stencil
@@ -41,7 +45,7 @@ type(diag_ctrl), target :: diag
 type(MOM_restart_CS) :: restart_CS
 type(ocean_internal_state), target :: MIS
 type(directories) :: dirs
-#ifndef REFERENCE_KERNELS
+#if !defined(REFERENCE_KERNELS) || defined(REF_SET_VISC)
 type(set_visc_CS) :: SV
 #endif
 type(vertvisc_CS), pointer :: VV => NULL()
@@ -95,9 +99,11 @@ allocate(u(isd-1:ied,jsd:jed,nk), v(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk)
          forces%taux(isd-1:ied,jsd:jed), forces%tauy(isd:ied,jsd-1:jed))
 read(u_in) u, v, h, tv%T, tv%S, forces%taux, forces%tauy
 #ifdef REFERENCE_KERNELS
+#ifndef REF_SET_VISC
 allocate(visc%bbl_thick_u(isd-1:ied,jsd:jed), visc%bbl_thick_v(isd:ied,jsd-1:jed), visc%Kv_bbl_u(isd-1:ied,jsd:jed), &
          visc%Kv_bbl_v(isd:ied,jsd-1:jed))
 read(u_in) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v
+#endif
 allocate(forces%ustar(isd:ied,jsd:jed), source=0.0)      ! vertvisc_coef asks find_ustar for it whether or not a surface boundary layer reads it (:1307)
 G%HI%isd = isd ; G%HI%ied = ied ; G%HI%jsd = jsd ; G%HI%jed = jed ; G%HI%IsdB = isd-1 ; G%HI%IedB = ied ; G%HI%JsdB = jsd-1 ; G%HI%JedB = jed
 G%HI%isc = G%isc ; G%HI%iec = G%iec ; G%HI%jsc = G%jsc ; G%HI%jec = G%jec
@@ -119,7 +125,12 @@ do m = 3, command_argument_count()      ! further NAME=VALUE pairs of the parame
   if (index(f_arg, "=") > 1) call param_set(pf, f_arg(1:index(f_arg, "=")-1), trim(f_arg(index(f_arg, "=")+1:)))
 enddo
 
-#ifndef REFERENCE_KERNELS
+#if !defined(REFERENCE_KERNELS) || defined(REF_SET_VISC)
+#ifdef REF_EOS
+if (hdr(8) /= 0) then      ! an equation of state for BBL_USE_EOS (the reference's own MOM_EOS; EQN_OF_STATE from the parameter list)
+  allocate(tv%eqn_of_state) ; call EOS_init(pf, tv%eqn_of_state, US)
+endif
+#endif
 call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
 call set_viscous_BBL(u, v, h, tv, visc, G, GV, US, SV, pbv)
 call set_viscous_ML(u, v, h, tv, forces, visc, dt, G, GV, US, SV)
@@ -136,8 +147,10 @@ open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", statu
 write(u_out) visc%bbl_thick_u, visc%bbl_thick_v, visc%Kv_bbl_u, visc%Kv_bbl_v, u1, v1, vru, vrv, tbx, tby, diffu, diffv
 close(u_out)
 call hor_visc_end(HV) ; call vertvisc_end(VV)
-#ifndef REFERENCE_KERNELS
+#if !defined(REFERENCE_KERNELS) || defined(REF_SET_VISC)
 call set_visc_end(visc, SV)
+#endif
+#ifndef REFERENCE_KERNELS
 call mom6hip_shared_context_end()
 #endif
 write(*,'(a,i0)') "visc_driver ok ntrunc=", ntrunc

@@ -443,3 +443,85 @@ def test_reference_pressureforce_equals_the_oracle(tmp_path, ni, nj, nk, seed, o
         if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
             bad.append(n)
     assert not bad, bad
+
+
+# ---- the same with the reference's own MOM_set_viscosity.F90 (set_viscous_BBL with BBL_USE_EOS through its own MOM_EOS) in front ------------
+def build_ref_visc_driver_full(tmp):
+    """as build_ref_visc_driver, with src/parameterizations/vertical/MOM_set_viscosity.F90, src/framework/MOM_intrinsic_functions.F90 and the
+    reference's equation-of-state stack in place (-DREF_EOS -DREF_SET_VISC; tests/fortran/stubs/mom6_stubs_setvisc.F90)"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_SET_VISC",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(STUBS, "mom6_stubs_setvisc.F90"),
+            os.path.join(REF, "src/framework/MOM_intrinsic_functions.F90"), os.path.join(REF, "src/parameterizations/vertical/MOM_set_viscosity.F90"),
+            os.path.join(STUBS, "mom6_stubs_visc.F90")] + [os.path.join(REF, r) for r in VISC_SOURCES] + \
+           [os.path.join(ROOT, "tests", "fortran", "visc_driver.F90")]
+    objs = []
+    for src in srcs:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "visc_ref_driver_full")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+BBL_SETS = {
+    "bbl_default": ([], {}),
+    "bbl_linear_correct": (["LINEAR_DRAG=True", "CORRECT_BBL_BOUNDS=True", "DRAG_BG_VEL=0.05"],
+                           dict(linear_drag=True, correct_BBL_bounds=True, drag_bg_vel=0.05)),
+    "bbl_thin_min": (["BBL_THICK_MIN=0.5", "CDRAG=0.002", "KV_BBL_MIN=2.0e-4"], dict(BBL_thick_min=0.5, cdrag=0.002, Kv_BBL_min=2.0e-4)),
+}
+
+
+@pytest.mark.parametrize("ni,nj,nk,seed,opts", [(34, 18, 5, 71, "bbl_default"), (22, 24, 8, 72, "bbl_linear_correct"), (28, 16, 6, 73, "bbl_thin_min")])
+def test_reference_set_viscous_bbl_and_the_viscosities_equal_the_oracle(tmp_path, ni, nj, nk, seed, opts):
+    """set_visc_init / set_viscous_BBL (BBL_USE_EOS, Wright through the reference's MOM_EOS) / set_viscous_ML, then the vertical and horizontal
+    viscosities on what it leaves -- all the reference's own modules: the bottom boundary layer's thicknesses and viscosities and everything
+    downstream equal the oracle's bit for bit"""
+    from mom6_amd import synth
+    from oracle import orc
+    exe = build_ref_visc_driver_full(tmp_path)
+    args, sv_kw = BBL_SETS[opts]
+    halo = 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=seed, reentrant_x=False, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=seed + 1, umax=0.3, eta_amp=0.2).items()}
+    U, V = _abi.POS_U, _abi.POS_V
+    yy = np.linspace(0.0, np.pi, g.shape2(U)[0])
+    taux = np.ascontiguousarray(0.1 * np.cos(2 * yy)[:, None] * g.mask2dCu); tauy = np.ascontiguousarray(0.02 * g.mask2dCv)
+    dt = 900.0
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([ni, nj, nk, halo, 0, 0, g.first_direction, 1], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], d["T"], d["S"], taux, tauy):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+    bb = dict(Kv_bbl_u=g.zeros2(U), Kv_bbl_v=g.zeros2(V), bbl_thick_u=g.zeros2(U), bbl_thick_v=g.zeros2(V))
+    visc = orc.vertvisc_type(**bb)
+    orc.set_viscous_BBL(g, orc.set_visc_cs(g, 10.0, 1.0e-4, **sv_kw), d["u"], d["v"], d["h"], d["T"], d["S"], orc.eos("WRIGHT"), visc)
+    bb = visc._keep
+    vcs = orc.vertvisc_cs(g, Kv=1.0e-4, Hbbl=10.0, Hmix=20.0, Kvml_invZ2=1.0e-2)
+    u1, v1 = d["u"].copy(), d["v"].copy()
+    orc.vertvisc_coef(g, vcs, u1, v1, d["h"], visc, dt)
+    tbx, tby = g.zeros2(U), g.zeros2(V)
+    orc.vertvisc(g, vcs, u1, v1, d["h"], taux, tauy, visc, dt, taux_bot=tbx, tauy_bot=tby)
+    vru, vrv = g.zeros3(U), g.zeros3(V)
+    orc.vertvisc_remnant(g, vcs, visc, vru, vrv, dt)
+    diffu, diffv = orc.horizontal_viscosity(g, orc.hor_visc_cs(g, dt, Smagorinsky_Ah=1, Smag_bi_const=0.06, Ah_vel_scale=0.01), d["u"], d["v"],
+                                            d["h"], dt)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "EQN_OF_STATE=WRIGHT"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    want = [bb["bbl_thick_u"], bb["bbl_thick_v"], bb["Kv_bbl_u"], bb["Kv_bbl_v"], u1, v1, vru, vrv, tbx, tby, diffu, diffv]
+    names = ["bbl_thick_u", "bbl_thick_v", "Kv_bbl_u", "Kv_bbl_v", "u", "v", "visc_rem_u", "visc_rem_v", "taux_bot", "tauy_bot", "diffu", "diffv"]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [w.size for w in want]
+    assert raw.size == sum(sizes)
+    bad = []
+    for n, a, w in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        pos = V if n.endswith("_v") or n in ("v", "tauy_bot", "diffv") else U
+        if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
+            bad.append(n)
+    assert not bad, bad
