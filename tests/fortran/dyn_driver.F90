@@ -5,10 +5,19 @@
 !! get_param under the reference's names.  With GPU_RESIDENT_DYNAMICS = True the fields stay in HBM between the steps; the
 !! driver then asks for them once, at the end (dyn_split_RK2_sync_to_host), and prints what crossed PCIe.
 !! Usage: dyn_driver <input file> <output file> <parameter file>
+!! Built with -DREFERENCE_KERNELS (tests/test_reference_kernels.py) the same program drives the reference's OWN dynamical core on the CPU:
+!! MOM_dynamics_split_RK2.F90 with MOM_continuity(_PPM), MOM_CoriolisAdv, MOM_PressureForce(_FV, _Montgomery), MOM_density_integrals, the
+!! equation-of-state stack, MOM_barotropic, MOM_vert_friction, MOM_set_viscosity, MOM_hor_visc -- every one compiled where it lies against
+!! the stand-ins of tests/fortran/stubs -- and the test compares its fields with the oracle's, bit for bit.  The two lateral
+!! parameterisations beside the step and the transfer statistics belong to the shims' build only.
 program dyn_driver
 use, intrinsic :: iso_c_binding
 use MOM_dynamics_split_RK2, only : MOM_dyn_split_RK2_CS, register_restarts_dyn_split_RK2, initialize_dyn_split_RK2
+#ifdef REFERENCE_KERNELS
+use MOM_dynamics_split_RK2, only : step_MOM_dyn_split_RK2, end_dyn_split_RK2
+#else
 use MOM_dynamics_split_RK2, only : step_MOM_dyn_split_RK2, end_dyn_split_RK2, dyn_split_RK2_sync_to_host
+#endif
 use MOM_set_visc,      only : set_visc_CS, set_visc_init, set_viscous_BBL, set_visc_end
 use MOM_ALE,           only : ALE_CS
 use MOM_boundary_update, only : update_OBC_CS
@@ -26,13 +35,20 @@ use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_MEKE_types,    only : MEKE_type
 use MOM_open_boundary, only : ocean_OBC_type
 use MOM_restart,       only : MOM_restart_CS
+#ifdef REFERENCE_KERNELS
+use MOM_thickness_diffuse, only : thickness_diffuse_CS
+use MOM_EOS,           only : EOS_init
+#else
 use MOM_thickness_diffuse, only : thickness_diffuse_CS, thickness_diffuse_init
 use MOM_mixed_layer_restrat, only : mixedlayer_restrat_CS, mixedlayer_restrat_init, mixedlayer_restrat_register_restarts
+#endif
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_variables,     only : vertvisc_type, thermo_var_ptrs, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, ocean_internal_state
 use MOM_verticalGrid,  only : verticalGrid_type
+#ifndef REFERENCE_KERNELS
 use mom6hip_c_api,     only : mom6hip_transfer_stats
 use mom6hip_MOM_glue,  only : mom6hip_shared_context, mom6hip_shared_context_end, mom6hip_mirror_host_changed
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -56,7 +72,9 @@ type(cont_diag_ptrs), target :: CDp
 type(MEKE_type), target :: MEKE
 type(VarMix_CS) :: VarMix
 type(thickness_diffuse_CS) :: TD
+#ifndef REFERENCE_KERNELS
 type(mixedlayer_restrat_CS) :: MLE
+#endif
 logical :: mle_on, td_on
 type(ocean_OBC_type), pointer :: OBC => NULL()
 type(update_OBC_CS), pointer :: update_OBC_CSp => NULL()
@@ -183,12 +201,22 @@ if (len_trim(f_obc) > 0) then
 endif
 
 ! ---- MOM.F90's initialisation order for these modules
+#ifdef REFERENCE_KERNELS
+G%HI = HI ; G%Domain%symmetric = .true.
+! the porous-barrier weights as MOM.F90 allocates them without the parameterisation: 1 everywhere (the shims do not read them)
+allocate(pbv%por_face_areaU(isd-1:ied,jsd:jed,nk), source=1.0) ; allocate(pbv%por_face_areaV(isd:ied,jsd-1:jed,nk), source=1.0)
+allocate(pbv%por_layer_widthU(isd-1:ied,jsd:jed,nk+1), source=1.0) ; allocate(pbv%por_layer_widthV(isd:ied,jsd-1:jed,nk+1), source=1.0)
+if (associated(tv%eqn_of_state)) call EOS_init(pf, tv%eqn_of_state, US)      ! the reference's own MOM_EOS (MOM.F90:2746)
+mle_on = .false. ; td_on = .false.
+call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
+#else
 call set_visc_init(Time, G, GV, US, pf, diag, visc, SV, restart_CS, OBC)
 ! the two lateral parameterisations beside the step accept the same parameter file (MOM.F90:2854, :3305-3313)
 call mixedlayer_restrat_register_restarts(HI, GV, US, pf, MLE, restart_CS)
 call thickness_diffuse_init(Time, G, GV, US, pf, diag, CDp, TD)
 mle_on = mixedlayer_restrat_init(Time, G, GV, US, pf, diag, MLE, restart_CS)
 call get_param(pf, "MOM", "THICKNESSDIFFUSE", td_on, default=.false.)
+#endif
 call register_restarts_dyn_split_RK2(HI, GV, US, pf, CS, restart_CS, uh, vh)
 if (hdr2(7) == 0) then      ! the bottom boundary layer as given (set_viscous_BBL belongs to another test)
   read(u_in) visc%Kv_bbl_u, visc%Kv_bbl_v, visc%bbl_thick_u, visc%bbl_thick_v
@@ -208,7 +236,11 @@ call get_param(pf, "MOM", "DT_THERM", dt_therm, default=dt)
 call get_param(pf, "MOM", "DTBT", dtbt_in, default=-0.98)
 dtbt_reset_period = -1.0
 if (dtbt_in <= 0.0) call get_param(pf, "MOM", "DTBT_RESET_PERIOD", dtbt_reset_period, default=dt_therm)
+#ifndef REFERENCE_KERNELS
 rc = mom6hip_transfer_stats(mom6hip_shared_context(G, GV), xfer, 1_c_int32_t)
+#else
+xfer(:) = 0
+#endif
 
 ! DRIVER_P_SURF (read by this driver only): 1 a surface pressure in forces%p_surf, with p_surf_end pointing at it as MOM.F90:772 has it
 ! (p_surf_begin is not associated: PressureForce takes forces%p_surf); 2 both p_surf_begin and p_surf_end (the pressure force takes
@@ -226,15 +258,19 @@ do n = 1, nsteps
       forces%p_surf(i,j) = 1.0e5 + 8.0*real(mod(7*i + 13*j, 97)) + 16.0*real(n)
       if (psurf_mode == 2) p_surf_begin(i,j) = forces%p_surf(i,j) - 4.0*real(mod(3*i + 5*j, 31))
     enddo ; enddo
+#ifndef REFERENCE_KERNELS
     call mom6hip_mirror_host_changed(c_loc(forces%p_surf))      ! (a new forcing field: its next reader uploads it)
     if (psurf_mode == 2) call mom6hip_mirror_host_changed(c_loc(p_surf_begin))
+#endif
   endif
   calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. calc_dtbt_init)
   call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, &
                               calc_dtbt, VarMix, MEKE, TD, pbv, STOCH, Waves)      ! as MOM.F90:1242-1245 calls it
 enddo
+#ifndef REFERENCE_KERNELS
 call dyn_split_RK2_sync_to_host(CS)
 rc = mom6hip_transfer_stats(mom6hip_shared_context(G, GV), xfer, 0_c_int32_t)
+#endif
 if (allocated(visc%nkml_visc_u)) then ; nk_u = visc%nkml_visc_u ; nk_v = visc%nkml_visc_v ; endif
 
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
@@ -247,7 +283,9 @@ endif
 close(u_out)
 call end_dyn_split_RK2(CS)
 call set_visc_end(visc, SV)
+#ifndef REFERENCE_KERNELS
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a,i0,a,i0,a,i0,a,i0,a,i0,a,i0,a,i0,a,i0)') "dyn_driver ok cont_stencil=", cont_stencil, " ntrunc=", ntrunc, " h2d_calls=", xfer(1), &
     " h2d_bytes=", xfer(2), " d2h_calls=", xfer(3), " d2h_bytes=", xfer(4), " thickness_diffuse=", merge(1, 0, td_on), &
     " mixedlayer_restrat=", merge(1, 0, mle_on)

@@ -1152,10 +1152,16 @@ subroutine find_ustar_mech_forcing(forces, tv, U_star, G, GV, US, halo, H_T_unit
   integer,       optional, intent(in)  :: halo
   logical,       optional, intent(in)  :: H_T_units
   integer :: i, j, hs
-  if (present(H_T_units)) then ; if (H_T_units) error stop "find_ustar stand-in: H_T_units is not provided" ; endif
+  real :: fac
   if (.not.associated(forces%ustar)) error stop "find_ustar stand-in: forces%ustar is needed"
+  if (.not.GV%Boussinesq) error stop "find_ustar stand-in: Boussinesq mode only"
   hs = 0 ; if (present(halo)) hs = max(halo, 0)
-  do j=G%jsc-hs,G%jec+hs ; do i=G%isc-hs,G%iec+hs ; U_star(i,j) = forces%ustar(i,j) ; enddo ; enddo
+  fac = 1.0 ; if (present(H_T_units)) then ; if (H_T_units) fac = GV%Z_to_H ; endif      ! (in thickness units over time, :1271)
+  if (fac == 1.0) then
+    do j=G%jsc-hs,G%jec+hs ; do i=G%isc-hs,G%iec+hs ; U_star(i,j) = forces%ustar(i,j) ; enddo ; enddo
+  else
+    do j=G%jsc-hs,G%jec+hs ; do i=G%isc-hs,G%iec+hs ; U_star(i,j) = fac * forces%ustar(i,j) ; enddo ; enddo
+  endif
 end subroutine find_ustar_mech_forcing
 subroutine find_ustar_fluxes(fluxes, tv, U_star, G, GV, US, halo, H_T_units)
   type(ocean_grid_type),   intent(in)  :: G

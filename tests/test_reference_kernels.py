@@ -525,3 +525,82 @@ def test_reference_set_viscous_bbl_and_the_viscosities_equal_the_oracle(tmp_path
         if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
             bad.append(n)
     assert not bad, bad
+
+
+# ---- the reference's whole split RK2 dynamical core beside the oracle -----------------------------------------------------------------------
+CORE_SOURCES = ("src/core/MOM_density_integrals.F90", "src/core/MOM_PressureForce_Montgomery.F90", "src/core/MOM_PressureForce_FV.F90",
+                "src/core/MOM_PressureForce.F90", "src/core/MOM_continuity_PPM.F90", "src/core/MOM_continuity.F90", "src/core/MOM_CoriolisAdv.F90",
+                "src/core/MOM_dynamics_split_RK2.F90")
+
+
+def build_ref_dyn_driver(tmp):
+    """tests/fortran/dyn_driver.F90 (-DREFERENCE_KERNELS) on the reference's OWN MOM_dynamics_split_RK2.F90 and everything it steps through:
+    set_viscosity, vert_friction, hor_visc, barotropic, the pressure force with its density integrals and equation-of-state stack,
+    continuity, CoriolisAdv -- each compiled where it lies against the stand-ins"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF", "-DREF_PF_MONT", "-DREF_SET_VISC",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(STUBS, "mom6_stubs_setvisc.F90"),
+            os.path.join(REF, "src/framework/MOM_intrinsic_functions.F90"), os.path.join(REF, "src/parameterizations/vertical/MOM_set_viscosity.F90"),
+            os.path.join(STUBS, "mom6_stubs_visc.F90")] + [os.path.join(REF, r) for r in VISC_SOURCES + CORE_SOURCES] + \
+           [os.path.join(ROOT, "tests", "fortran", "dyn_driver.F90")]
+    objs = []
+    for src in srcs:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "dyn_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+# the settings of bench.py's step (DESIGN.md section 7) as a parameter file: Wright, PLM pressure reconstruction, BT_cont from the layer
+# continuity, Sadourny energy with BOUND_CORIOLIS, biharmonic Smagorinsky with the better bounds, BOTTOMDRAGLAW with BBL_USE_EOS, KV_ML_INVZ2
+BENCH_LIKE = dict(shape=(16, 12, 6), pairs="""
+        USE_REGRIDDING = True
+        DT = 900.0
+        BOUND_CORIOLIS = True
+        SMAGORINSKY_AH = True
+        SMAG_BI_CONST = 0.06
+        AH_VEL_SCALE = 0.01
+        KV = 1.0E-04
+        HMIX_FIXED = 20.0
+        KV_ML_INVZ2 = 0.01
+        HBBL = 10.0
+        CDRAG = 0.003
+        """)
+
+
+@pytest.mark.parametrize("name", ["tc4", "tc2", "tc1", "bench_like"])
+def test_reference_dynamical_core_equals_the_oracle(tmp_path, name, monkeypatch):
+    """three steps of the reference's step_MOM_dyn_split_RK2 (after its own set_viscous_BBL each), every module of the dynamical core the
+    reference's own, with the transcribed parameter sets of .testing/tc4, tc2 and tc1 and with the settings of bench.py's step, on a closed
+    basin (REENTRANT_X = False: the stand-in's group passes do nothing): u, v, h, uh, vh, uhtr, vhtr, eta_av (and MEKE%mom_src, visc%nkml_visc_u/v where the set has them) equal the
+    oracle's DynState.step bit for bit"""
+    import test_testing_configs as tc
+    exe = build_ref_dyn_driver(tmp_path)
+    nsteps = 3
+    base = BENCH_LIKE if name == "bench_like" else tc.TC_INPUT[name]
+    monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + "\n        REENTRANT_X = False\n"))
+    state = tc.case_state(name)
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    assert not g.reentrant_x and not g.reentrant_y      # (the stand-in's group passes do nothing: a closed tile)
+    tc.write_case(tmp_path, name, nsteps, False, state, bbl_mode=1)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    assert "dyn_driver ok" in r.stdout
+    st, calc, _ = tc.oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    for n in range(nsteps):
+        st.bbl()
+        st.step(taux, tauy, calc_dtbt=calc(n))
+    got = tc.read_out(str(tmp_path / "out.bin"), g, meke=st.mom_src is not None)
+    want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+    if "nkml_visc_u" in st.visc._keep:
+        want.update(nkml_visc_u=st.visc._keep["nkml_visc_u"], nkml_visc_v=st.visc._keep["nkml_visc_v"])
+    bad = [(n, float(np.abs(got[n] - want[n]).max())) for n, pos, nd in tc.OUT
+           if n in want and not bits_equal(interior(g, got[n], pos), interior(g, want[n], pos))]
+    if st.mom_src is not None and not bits_equal(interior(g, got["mom_src"], _abi.POS_H), interior(g, st.mom_src, _abi.POS_H)):
+        bad.append(("mom_src", float(np.abs(got["mom_src"] - st.mom_src).max())))
+    assert not bad, bad
