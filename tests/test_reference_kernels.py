@@ -30,6 +30,26 @@ SCHEMES = {"PLM": 0, "PPM:H3": 1, "PPM": 2}
 pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference is not mounted (GPU box)"),
               pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")]
 
+@pytest.fixture(scope="module")
+def visc_exe(tmp_path_factory):
+    return build_ref_visc_driver(tmp_path_factory.mktemp("ref_visc"))
+
+
+@pytest.fixture(scope="module")
+def visc_full_exe(tmp_path_factory):
+    return build_ref_visc_driver_full(tmp_path_factory.mktemp("ref_visc_full"))
+
+
+@pytest.fixture(scope="module")
+def pf_exe(tmp_path_factory):
+    return build_ref_pf_driver(tmp_path_factory.mktemp("ref_pf"))
+
+
+@pytest.fixture(scope="module")
+def dyn_exe(tmp_path_factory):
+    return build_ref_dyn_driver(tmp_path_factory.mktemp("ref_dyn"))
+
+
 
 def build_ref_kernels(tmp, opt="-O0", openmp=False):
     """the stand-ins, the three reference files (in place) and the driver -> an executable in tmp"""
@@ -324,14 +344,14 @@ VISC_SETS = {
 
 @pytest.mark.parametrize("ni,nj,nk,seed,opts", [(34, 18, 5, 55, "default"), (21, 26, 9, 7, "default"), (34, 18, 5, 56, "harmonic_laplacian"),
                                                 (30, 22, 6, 57, "direct_stress_maxvel"), (26, 20, 4, 58, "laplacian_noslip")])
-def test_reference_vert_friction_and_hor_visc_equal_the_oracle(tmp_path, ni, nj, nk, seed, opts):
+def test_reference_vert_friction_and_hor_visc_equal_the_oracle(tmp_path, visc_exe, ni, nj, nk, seed, opts):
     """vertvisc_init / vertvisc_coef / vertvisc / vertvisc_remnant and hor_visc_init / horizontal_viscosity of the reference's own modules, with
     the parameters tests/fortran/visc_driver.F90 sets by name (the set tests/test_fortran_abi.py runs through the shims on the GPU) and the
     bottom boundary layer the oracle's set_viscous_BBL leaves: velocities, visc_rem, the bottom stresses and the viscous accelerations
     equal the oracle's bit for bit"""
     from mom6_amd import synth
     from oracle import orc
-    exe = build_ref_visc_driver(tmp_path)
+    exe = visc_exe
     halo = 4
     g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=seed, reentrant_x=False, reentrant_y=False)
     d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=8, umax=0.3, eta_amp=0.2).items()}
@@ -411,12 +431,12 @@ PF_SETS = {
 
 @pytest.mark.parametrize("ni,nj,nk,seed,opts", [(30, 14, 6, 61, "wright_plm"), (22, 25, 9, 62, "wright_plm_massw_psurf"), (30, 14, 6, 63, "wright_pcm"),
                                                 (26, 18, 5, 64, "linear_plm"), (26, 18, 5, 65, "wright_full_plm"), (24, 16, 5, 66, "unesco_plm")])
-def test_reference_pressureforce_equals_the_oracle(tmp_path, ni, nj, nk, seed, opts):
+def test_reference_pressureforce_equals_the_oracle(tmp_path, pf_exe, ni, nj, nk, seed, opts):
     """PressureForce_FV_Bouss of the reference -- int_density_dz_generic_plm / int_density_dz, the PLM edge values of T and S from its own slope
     functions, its equation-of-state modules, Set_pbce_Bouss -- on the oracle's inputs: PFu, PFv, pbce and eta equal the oracle's bit for bit"""
     from mom6_amd import synth
     from oracle import orc
-    exe = build_ref_pf_driver(tmp_path)
+    exe = pf_exe
     args, eos_form, cs_kw, with_p = PF_SETS[opts]
     halo = 4
     g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=seed, reentrant_x=False, reentrant_y=False)
@@ -477,13 +497,13 @@ BBL_SETS = {
 
 
 @pytest.mark.parametrize("ni,nj,nk,seed,opts", [(34, 18, 5, 71, "bbl_default"), (22, 24, 8, 72, "bbl_linear_correct"), (28, 16, 6, 73, "bbl_thin_min")])
-def test_reference_set_viscous_bbl_and_the_viscosities_equal_the_oracle(tmp_path, ni, nj, nk, seed, opts):
+def test_reference_set_viscous_bbl_and_the_viscosities_equal_the_oracle(tmp_path, visc_full_exe, ni, nj, nk, seed, opts):
     """set_visc_init / set_viscous_BBL (BBL_USE_EOS, Wright through the reference's MOM_EOS) / set_viscous_ML, then the vertical and horizontal
     viscosities on what it leaves -- all the reference's own modules: the bottom boundary layer's thicknesses and viscosities and everything
     downstream equal the oracle's bit for bit"""
     from mom6_amd import synth
     from oracle import orc
-    exe = build_ref_visc_driver_full(tmp_path)
+    exe = visc_full_exe
     args, sv_kw = BBL_SETS[opts]
     halo = 4
     g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=seed, reentrant_x=False, reentrant_y=False)
@@ -574,13 +594,13 @@ BENCH_LIKE = dict(shape=(16, 12, 6), pairs="""
 
 
 @pytest.mark.parametrize("name", ["tc4", "tc2", "tc1", "bench_like"])
-def test_reference_dynamical_core_equals_the_oracle(tmp_path, name, monkeypatch):
+def test_reference_dynamical_core_equals_the_oracle(tmp_path, dyn_exe, name, monkeypatch):
     """three steps of the reference's step_MOM_dyn_split_RK2 (after its own set_viscous_BBL each), every module of the dynamical core the
     reference's own, with the transcribed parameter sets of .testing/tc4, tc2 and tc1 and with the settings of bench.py's step, on a closed
     basin (REENTRANT_X = False: the stand-in's group passes do nothing): u, v, h, uh, vh, uhtr, vhtr, eta_av (and MEKE%mom_src, visc%nkml_visc_u/v where the set has them) equal the
     oracle's DynState.step bit for bit"""
     import test_testing_configs as tc
-    exe = build_ref_dyn_driver(tmp_path)
+    exe = dyn_exe
     nsteps = 3
     base = BENCH_LIKE if name == "bench_like" else tc.TC_INPUT[name]
     monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + "\n        REENTRANT_X = False\n"))
