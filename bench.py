@@ -41,7 +41,7 @@ HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL
 SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
-PMC_PROFILE = "r05_a_pmc.json"
+PMC_PROFILE = "r05_b_pmc.json"
 FP64_VECTOR_TFLOPS = 78.6            # 256 CUs x 4 SIMDs x 16 fp64 lanes per cycle x 2 (fma) x 2.4 GHz
 
 
@@ -627,6 +627,17 @@ def _port_calibration():
         out["grid"] = cal["grid"]; out["threads"] = cal["threads"]
         out["note"] = ("the reference files are compiled unmodified against hand-written stand-ins for MOM_grid / MOM_domains / MOM_file_parser "
                        "(FMS is not vendored): a calibration of the port, not a reference build; the bench's baseline stays kind = port")
+    except (OSError, KeyError, ValueError):
+        pass
+    # the whole step: the reference's own dynamical core (MOM_dynamics_split_RK2.F90 and the 18 files it steps through, in place, amdflang -O2)
+    # against DynState.step (tools/calibrate_ref_core.py; bitwise equal once the oracle takes the host's libm pow in btstep's one power)
+    try:
+        with open(os.path.join(os.path.dirname(path), "r05_calibrate_ref_core.json")) as f:
+            core = json.load(f)
+        out["step_MOM_dyn_split_RK2"] = {"port_over_reference_1thr": core["port_over_reference_1thr"], "grid": core["grid"],
+                                         "ns_per_gridpoint_step": core["ns_per_gridpoint_step"],
+                                         "reference_equals_port_bitwise_with_libm_pow": core["reference_O2_against_oracle_with_libm_pow"]["bitwise_equal"],
+                                         "source": "profiles/r05_calibrate_ref_core.json"}
     except (OSError, KeyError, ValueError):
         pass
     return out

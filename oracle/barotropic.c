@@ -982,15 +982,20 @@ int orc_btstep_obc(const mom6hip_grid_t *G, mom6hip_barotropic_cs_t *CS, const d
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++)
       bt_rem_v[V2(i, J)] = G->mask2dCv[V2(i, J)] * ((nstep * av_rem_v[V2(i, J)]) / (1.0 + (nstep - 1) * av_rem_v[V2(i, J)]));
   } else {
+    /* ORC_BT_LIBM_POW (environment; tests/test_reference_kernels.py and tools/calibrate_ref_core.py only): the power as a reference build
+     * takes it, the libm pow of the host, to show that it is the ONE operation in which the oracle leaves such a build */
+    const int libm_pow = getenv("ORC_BT_LIBM_POW") != NULL;
     ORC_PAR
     for (int j = js; j <= je; j++) for (int I = is - 1; I <= ie; I++) {
       bt_rem_u[U2(I, j)] = 0.0;
-      if (G->mask2dCu[U2(I, j)] * av_rem_u[U2(I, j)] > 0.0) bt_rem_u[U2(I, j)] = G->mask2dCu[U2(I, j)] * orc_cr_pow(av_rem_u[U2(I, j)], Instep);
+      if (G->mask2dCu[U2(I, j)] * av_rem_u[U2(I, j)] > 0.0)
+        bt_rem_u[U2(I, j)] = G->mask2dCu[U2(I, j)] * (libm_pow ? pow(av_rem_u[U2(I, j)], Instep) : orc_cr_pow(av_rem_u[U2(I, j)], Instep));
     }
     ORC_PAR
     for (int J = js - 1; J <= je; J++) for (int i = is; i <= ie; i++) {
       bt_rem_v[V2(i, J)] = 0.0;
-      if (G->mask2dCv[V2(i, J)] * av_rem_v[V2(i, J)] > 0.0) bt_rem_v[V2(i, J)] = G->mask2dCv[V2(i, J)] * orc_cr_pow(av_rem_v[V2(i, J)], Instep);
+      if (G->mask2dCv[V2(i, J)] * av_rem_v[V2(i, J)] > 0.0)
+        bt_rem_v[V2(i, J)] = G->mask2dCv[V2(i, J)] * (libm_pow ? pow(av_rem_v[V2(i, J)], Instep) : orc_cr_pow(av_rem_v[V2(i, J)], Instep));
     }
   }
 

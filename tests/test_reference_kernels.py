@@ -553,11 +553,11 @@ CORE_SOURCES = ("src/core/MOM_density_integrals.F90", "src/core/MOM_PressureForc
                 "src/core/MOM_dynamics_split_RK2.F90")
 
 
-def build_ref_dyn_driver(tmp):
+def build_ref_dyn_driver(tmp, opt="-O0"):
     """tests/fortran/dyn_driver.F90 (-DREFERENCE_KERNELS) on the reference's OWN MOM_dynamics_split_RK2.F90 and everything it steps through:
     set_viscosity, vert_friction, hor_visc, barotropic, the pressure force with its density integrals and equation-of-state stack,
     continuity, CoriolisAdv -- each compiled where it lies against the stand-ins"""
-    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF", "-DREF_PF_MONT", "-DREF_SET_VISC",
+    flags = ["-cpp", "-fdefault-real-8", opt, "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF", "-DREF_PF_MONT", "-DREF_SET_VISC",
              f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
              f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
     srcs = [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(STUBS, "mom6_stubs_setvisc.F90"),
