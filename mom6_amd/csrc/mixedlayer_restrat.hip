@@ -143,13 +143,16 @@ template <int DIR, bool BML> __global__ __launch_bounds__(64) void mle_face_kern
   const double u_star = max2(A.ustar_min, 0.5 * (g.Z_to_H * A.ustar[c0] + g.Z_to_H * A.ustar[c1]));
   const double absf = DIR ? 0.5 * (fabs(g.CoriolisBu[g.q2(i - 1, j)]) + fabs(g.CoriolisBu[g.q2(i, j)]))
                           : 0.5 * (fabs(g.CoriolisBu[g.q2(i, j - 1)]) + fabs(g.CoriolisBu[g.q2(i, j)]));
-  const double geom = DIR ? g.mask2dCv[f2] * g.dxCv[f2] * g.IdyCv[f2] : g.mask2dCu[f2] * g.dyCu[f2] * g.IdxCu[f2];
+  // timescale * G%OBCmaskCu * G%dyCu * G%IdxCu * (...) * (h_vel**2) associates from the left (MOM_mixed_layer_restrat.F90:523-524, :538-539,
+  // :1371-1372): the three metric factors multiply the timescale one after the other (found by running the reference's own module beside
+  // the oracle, round 5: as a product of their own they moved 5-10 % of the face transports by an ulp)
+  const double gm = DIR ? g.mask2dCv[f2] : g.mask2dCu[f2], gl = DIR ? g.dxCv[f2] : g.dyCu[f2], gi = DIR ? g.IdyCv[f2] : g.IdxCu[f2];
   auto h_avail = [&](long c, double aT, int k) { return max2(I4dt * aT * (A.h[c + hpl * k] - g.Angstrom_H), 0.0); };
   if (BML) {      // :1328-1374 / :1378-1424
     const double ht0 = A.htot_fast[c0], ht1 = A.htot_fast[c1];
     const double h_vel = 0.5 * (ht0 + ht1);
     const double timescale = mle_timescale(A.vonKar_x_pi2, u_star, absf, h_vel, h_neglect, A.ml_restrat_coef);
-    double Dml = timescale * geom * (A.Rml_fast[c1] - A.Rml_fast[c0]) * (h_vel * h_vel);
+    double Dml = timescale * gm * gl * gi * (A.Rml_fast[c1] - A.Rml_fast[c0]) * (h_vel * h_vel);
     if (Dml == 0) {
       for (int k = 0; k < A.nkml; k++) A.hml[f2 + fpl * k] = 0.0;
     } else {
@@ -189,11 +192,11 @@ template <int DIR, bool BML> __global__ __launch_bounds__(64) void mle_face_kern
   double h_vel = 0.5 * ((hf0 + hf1) + h_neglect);
   double timescale = mle_timescale(A.vonKar_x_pi2, u_star, absf, h_vel, h_neglect, A.ml_restrat_coef);
   if (A.res_upscale) timescale = timescale * res_scaling_fac;
-  double Dml = timescale * geom * (A.Rml_fast[c1] - A.Rml_fast[c0]) * (h_vel * h_vel);
+  double Dml = timescale * gm * gl * gi * (A.Rml_fast[c1] - A.Rml_fast[c0]) * (h_vel * h_vel);
   h_vel = 0.5 * ((hs0 + hs1) + h_neglect);
   timescale = mle_timescale(A.vonKar_x_pi2, u_star, absf, h_vel, h_neglect, A.ml_restrat_coef2);
   if (A.res_upscale) timescale = timescale * res_scaling_fac;
-  double Dml_slow = timescale * geom * (A.Rml_slow[c1] - A.Rml_slow[c0]) * (h_vel * h_vel);
+  double Dml_slow = timescale * gm * gl * gi * (A.Rml_slow[c1] - A.Rml_slow[c0]) * (h_vel * h_vel);
 
   if (Dml + Dml_slow == 0.) {
     for (int k = 0; k < nz; k++) A.hml[f2 + fpl * k] = 0.0;

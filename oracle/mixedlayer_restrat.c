@@ -138,18 +138,20 @@ static int restrat_OM4(const mom6hip_grid_t *G, const mom6hip_mixedlayer_restrat
       const double dx = dir ? G->dxCv[V2(i,j)] : G->dxCu[U2(i,j)], dy = dir ? G->dyCv[V2(i,j)] : G->dyCu[U2(i,j)];
       double res_scaling_fac = 0.0;
       if (res_upscale) res_scaling_fac = (sqrt(0.5 * (dx * dx + dy * dy)) * I_LFront) * min2(1., 0.5 * (CS->Rd_dx_h[c0] + CS->Rd_dx_h[c1]));
-      const double geom = dir ? G->mask2dCv[V2(i,j)] * G->dxCv[V2(i,j)] * G->IdyCv[V2(i,j)]
-                              : G->mask2dCu[U2(i,j)] * G->dyCu[U2(i,j)] * G->IdxCu[U2(i,j)];
+      /* timescale * G%OBCmaskCu * G%dyCu * G%IdxCu * (...) * (h_vel**2) associates from the left (:523-524, :538-539, :1371-1372): the three
+       * metric factors multiply the timescale one after the other, they are NOT a product of their own */
+      const double gm = dir ? G->mask2dCv[V2(i,j)] : G->mask2dCu[U2(i,j)], gl = dir ? G->dxCv[V2(i,j)] : G->dyCu[U2(i,j)],
+                   gi = dir ? G->IdyCv[V2(i,j)] : G->IdxCu[U2(i,j)];
 
       double h_vel = 0.5 * ((htot_fast[c0] + htot_fast[c1]) + h_neglect);
       double timescale = timescale_of(vonKar_x_pi2, u_star, absf, h_vel, h_neglect, CS->ml_restrat_coef);
       if (res_upscale) timescale = timescale * res_scaling_fac;
-      double Dml = timescale * geom * (Rml_av_fast[c1] - Rml_av_fast[c0]) * (h_vel * h_vel);
+      double Dml = timescale * gm * gl * gi * (Rml_av_fast[c1] - Rml_av_fast[c0]) * (h_vel * h_vel);
 
       h_vel = 0.5 * ((htot_slow[c0] + htot_slow[c1]) + h_neglect);
       timescale = timescale_of(vonKar_x_pi2, u_star, absf, h_vel, h_neglect, CS->ml_restrat_coef2);
       if (res_upscale) timescale = timescale * res_scaling_fac;
-      double Dml_slow = timescale * geom * (Rml_av_slow[c1] - Rml_av_slow[c0]) * (h_vel * h_vel);
+      double Dml_slow = timescale * gm * gl * gi * (Rml_av_slow[c1] - Rml_av_slow[c0]) * (h_vel * h_vel);
 
       double *hml = dir ? vhml : uhml, *htr = dir ? vhtr : uhtr;
       if (Dml + Dml_slow == 0.) {
@@ -234,9 +236,11 @@ static int restrat_BML(const mom6hip_grid_t *G, const mom6hip_mixedlayer_restrat
       const double absf = dir ? 0.5 * (fabs(G->CoriolisBu[Q2(i-1,j)]) + fabs(G->CoriolisBu[Q2(i,j)]))
                               : 0.5 * (fabs(G->CoriolisBu[Q2(i,j-1)]) + fabs(G->CoriolisBu[Q2(i,j)]));
       const double timescale = timescale_of(vonKar_x_pi2, u_star, absf, h_vel, h_neglect, CS->ml_restrat_coef);
-      const double geom = dir ? G->mask2dCv[V2(i,j)] * G->dxCv[V2(i,j)] * G->IdyCv[V2(i,j)]
-                              : G->mask2dCu[U2(i,j)] * G->dyCu[U2(i,j)] * G->IdxCu[U2(i,j)];
-      double Dml = timescale * geom * (Rml_av[c1] - Rml_av[c0]) * (h_vel * h_vel);
+      /* timescale * G%OBCmaskCu * G%dyCu * G%IdxCu * (...) * (h_vel**2) associates from the left (:523-524, :538-539, :1371-1372): the three
+       * metric factors multiply the timescale one after the other, they are NOT a product of their own */
+      const double gm = dir ? G->mask2dCv[V2(i,j)] : G->mask2dCu[U2(i,j)], gl = dir ? G->dxCv[V2(i,j)] : G->dyCu[U2(i,j)],
+                   gi = dir ? G->IdyCv[V2(i,j)] : G->IdxCu[U2(i,j)];
+      double Dml = timescale * gm * gl * gi * (Rml_av[c1] - Rml_av[c0]) * (h_vel * h_vel);
       double *hml = dir ? vhml : uhml, *htr = dir ? vhtr : uhtr;
       if (Dml == 0) {
         for (int k = 1; k <= nkml; k++) hml[dir ? V3(i,j,k) : U3(i,j,k)] = 0.0;

@@ -19,7 +19,11 @@ use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
+#ifdef REFERENCE_KERNELS
+use MOM_EOS,            only : EOS_init      ! (built with -DREFERENCE_KERNELS -DREF_EOS: the reference's OWN MOM_mixed_layer_restrat.F90 and MOM_EOS)
+#else
 use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, mom6hip_shared_context, mom6hip_mirrors_to_host, mom6hip_mirrors_end
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -97,6 +101,14 @@ enddo
 close(u_par)
 
 HI%isc = G%isc ; HI%iec = G%iec ; HI%jsc = G%jsc ; HI%jec = G%jec ; HI%isd = isd ; HI%ied = ied ; HI%jsd = jsd ; HI%jed = jed
+#ifdef REFERENCE_KERNELS
+HI%IsdB = isd-1 ; HI%IedB = ied ; HI%JsdB = jsd-1 ; HI%JedB = jed ; HI%IscB = G%IscB ; HI%IecB = G%IecB ; HI%JscB = G%JscB ; HI%JecB = G%JecB
+G%HI = HI
+allocate(G%OBCmaskCu(isd-1:ied,jsd:jed), G%OBCmaskCv(isd:ied,jsd-1:jed))      ! no open boundaries: the masks of the faces (MOM_grid.F90)
+G%OBCmaskCu(:,:) = G%mask2dCu(:,:) ; G%OBCmaskCv(:,:) = G%mask2dCv(:,:)
+GV%RZ_to_H = GV%Z_to_H / GV%Rho0 ; GV%H_to_RZ = GV%H_to_Z * GV%Rho0
+call EOS_init(pf, tv%eqn_of_state, US)
+#endif
 call mixedlayer_restrat_register_restarts(HI, GV, US, pf, CS, restart_CS)
 on = mixedlayer_restrat_init(Time, G, GV, US, pf, diag, CS, restart_CS)
 if (.not.on) error stop "mle_driver: MIXEDLAYER_RESTRAT is not set"
@@ -104,12 +116,16 @@ do n=1,opt(4)
   call mixedlayer_restrat(h, uhtr, vhtr, tv, forces, dt, MLD, h_MLD, bflux, VarMix, G, GV, US, CS)
 enddo
 
+#ifndef REFERENCE_KERNELS
 ! with GPU_RESIDENT_DYNAMICS the results are on the device until the host asks for them
 call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
+#endif
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) h, uhtr, vhtr
 close(u_out)
+#ifndef REFERENCE_KERNELS
 call mom6hip_mirrors_end()
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a,i0)') "mle_driver ok restart_fields=", restart_CS%nfields
 end program mle_driver

@@ -258,7 +258,7 @@ type :: ocean_grid_type
   type(hor_index_type) :: HI
   real :: max_depth = 0.0, Z_ref = 0.0, Rad_Earth_L = 6.378e6
   real, allocatable, dimension(:,:) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
-  real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu
+  real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu, OBCmaskCu, OBCmaskCv
   real, allocatable, dimension(:,:) :: mask2dCv, dxCv, dyCv, dx_Cv, IdxCv, IdyCv, areaCv, IareaCv
   real, allocatable, dimension(:,:) :: mask2dBu, dxBu, dyBu, areaBu, IareaBu, CoriolisBu, IdxBu, IdyBu
   real, allocatable, dimension(:,:) :: geoLonT, geoLatT, geoLonBu, geoLatBu

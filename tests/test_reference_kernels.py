@@ -664,3 +664,45 @@ def test_reference_dynamical_core_at_a_size_where_the_two_powers_differ(tmp_path
             assert dd.mean() <= 0.05 and np.all(np.abs(a - b)[dd] <= 1.0e-10 * np.abs(b)[dd] + 1.0e-30), (n, int(dd.sum()))
             ndiff += int(dd.sum())
     assert ndiff > 0      # (the two powers did differ somewhere: otherwise this test shows nothing)
+
+
+# ---- the reference's own MOM_mixed_layer_restrat.F90 beside the oracle ------------------------------------------------------------------------
+def build_ref_mle_driver(tmp):
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", f"-I{REF}/config_src/memory/dynamic_symmetric",
+             f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(REF, "src/framework/MOM_intrinsic_functions.F90"),
+                os.path.join(REF, "src/parameterizations/lateral/MOM_mixed_layer_restrat.F90"), os.path.join(ROOT, "tests", "fortran", "mle_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "mle_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def mle_exe(tmp_path_factory):
+    return build_ref_mle_driver(tmp_path_factory.mktemp("ref_mle"))
+
+
+def test_reference_mixedlayer_restrat_equals_the_oracle(tmp_path, mle_exe):
+    """mixedlayer_restrat_register_restarts, mixedlayer_restrat_init and two calls of mixedlayer_restrat of the reference's own module (the OM4
+    form and the bulk-mixed-layer form; the running means of the mixed layer depth; its own MOM_EOS), every variant of
+    tests/test_mixedlayer_restrat.py on a closed basin: h, uhtr, vhtr equal the oracle's bit for bit"""
+    import test_mixedlayer_restrat as tm
+    g, d = tm.case(36, 22, 6, reentrant_x=False, reentrant_y=False)
+    bad = []
+    for name in tm.VARIANTS:
+        ref, nrest = tm._write_mle_case(tmp_path, g, d, name)
+        r = subprocess.run([mle_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "mle_driver ok" in r.stdout, (name, r.stdout[-200:], r.stderr[-1500:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+        want = [ref["h"], ref["uhtr"], ref["vhtr"]]
+        assert raw.size == sum(w.size for w in want), name
+        for n, a, w, pos in zip(("h", "uhtr", "vhtr"), np.split(raw, np.cumsum([w.size for w in want])[:-1]), want, (_abi.POS_H, _abi.POS_U, _abi.POS_V)):
+            if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
+                bad.append((name, n, float(np.abs(a.reshape(w.shape) - w).max())))
+    assert not bad, bad
