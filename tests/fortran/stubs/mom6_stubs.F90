@@ -1315,7 +1315,7 @@ public :: stochastic_CS
 type :: stochastic_CS
   logical :: do_sppt = .false., do_skeb = .false., skeb_use_gm = .false., skeb_use_frict = .false., pert_epbl = .false.
   real, allocatable, dimension(:,:,:) :: skeb_diss
-  real :: skeb_frict_coef = 0.0
+  real :: skeb_frict_coef = 0.0, skeb_gm_coef = 0.0
 end type stochastic_CS
 end module MOM_stochastics
 
@@ -1581,8 +1581,8 @@ type :: VarMix_CS
   logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false., Resoln_scaled_KhTh = .false.
   logical :: Depth_scaled_KhTh = .false., use_stored_slopes = .false., khth_use_ebt_struct = .false., use_Visbeck = .false.
   logical :: use_QG_Leith_GM = .false., kdgl90_use_ebt_struct = .false.
-  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Res_fn_h, Res_fn_q, Rd_dx_h, cg1
-  real, allocatable, dimension(:,:,:) :: slope_x, slope_y, ebt_struct
+  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Res_fn_h, Res_fn_q, Rd_dx_h, cg1, Depth_fn_u, Depth_fn_v
+  real, allocatable, dimension(:,:,:) :: slope_x, slope_y, ebt_struct, KH_u_QG, KH_v_QG
 end type VarMix_CS
 contains
 subroutine calc_QG_slopes(h, tv, dt, G, GV, US, slope_x, slope_y, CS, OBC)
@@ -1676,6 +1676,7 @@ subroutine Stokes_PGF(G, GV, US, dz, u, v, PFu_Stokes, PFv_Stokes, CS)
 end subroutine Stokes_PGF
 end module MOM_wave_interface
 
+#ifndef REF_INTERFACE_HEIGHTS
 module MOM_interface_heights
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
@@ -1717,6 +1718,7 @@ subroutine find_col_avg_SpV(h, SpV_avg, tv, G, GV, US, halo_size)
   integer,        optional, intent(in)    :: halo_size
 end subroutine find_col_avg_SpV
 end module MOM_interface_heights
+#endif
 
 
 module MOM_debugging

@@ -16,7 +16,12 @@ use MOM_stochastics,    only : stochastic_CS
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : cont_diag_ptrs, thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
+#ifdef REFERENCE_KERNELS
+use MOM_EOS,            only : EOS_init      ! (built with -DREFERENCE_KERNELS -DREF_EOS -DREF_INTERFACE_HEIGHTS: the reference's OWN MOM_thickness_diffuse.F90,
+                                             ! MOM_isopycnal_slopes.F90, MOM_interface_heights.F90, MOM_density_integrals.F90 and MOM_EOS)
+#else
 use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, mom6hip_shared_context, mom6hip_mirrors_to_host, mom6hip_mirrors_end
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -32,7 +37,7 @@ type(VarMix_CS) :: VarMix
 type(cont_diag_ptrs) :: CDp
 type(stochastic_CS) :: STOCH
 integer(c_int32_t) :: hdr(8), opt(8)
-integer :: ni, nj, nk, halo, u_in, u_out, u_par, isd, ied, jsd, jed, ios, eq
+integer :: ni, nj, nk, halo, u_in, u_out, u_par, isd, ied, jsd, jed, ios, eq, m
 real :: scal(7), dt
 real, allocatable, dimension(:,:,:) :: h, uhtr, vhtr
 character(len=512) :: f_in, f_out, f_par, line
@@ -96,17 +101,33 @@ do
 enddo
 close(u_par)
 
+#ifdef REFERENCE_KERNELS
+G%HI%isd = isd ; G%HI%ied = ied ; G%HI%jsd = jsd ; G%HI%jed = jed ; G%HI%IsdB = isd-1 ; G%HI%IedB = ied ; G%HI%JsdB = jsd-1 ; G%HI%JedB = jed
+G%HI%isc = G%isc ; G%HI%iec = G%iec ; G%HI%jsc = G%jsc ; G%HI%jec = G%jec
+G%HI%IscB = G%IscB ; G%HI%IecB = G%IecB ; G%HI%JscB = G%JscB ; G%HI%JecB = G%JecB
+allocate(G%OBCmaskCu(isd-1:ied,jsd:jed), G%OBCmaskCv(isd:ied,jsd-1:jed))      ! no open boundaries: the masks of the faces (MOM_grid.F90)
+G%OBCmaskCu(:,:) = G%mask2dCu(:,:) ; G%OBCmaskCv(:,:) = G%mask2dCv(:,:)
+GV%RZ_to_H = GV%Z_to_H / GV%Rho0 ; GV%H_to_RZ = GV%H_to_Z * GV%Rho0
+if (associated(tv%eqn_of_state)) call EOS_init(pf, tv%eqn_of_state, US)
+allocate(GV%g_prime(nk+1))      ! (read without an equation of state for the stratification of the FGNV solve, :1095; from Rlay as MOM_coord_initialization sets it)
+GV%g_prime(:) = 0.0 ; GV%g_prime(1) = GV%g_Earth
+do m=2,nk ; GV%g_prime(m) = (GV%g_Earth/GV%Rho0) * (GV%Rlay(m) - GV%Rlay(m-1)) ; enddo
+#endif
 call thickness_diffuse_init(Time, G, GV, US, pf, diag, CDp, CS)
 call thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH)
 
+#ifndef REFERENCE_KERNELS
 ! with GPU_RESIDENT_DYNAMICS the results are on the device until the host asks for them
 call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
+#endif
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) h, uhtr, vhtr, CDp%uhGM, CDp%vhGM
 if (opt(6) /= 0) write(u_out) MEKE%GM_src
 close(u_out)
 call thickness_diffuse_end(CS, CDp)
+#ifndef REFERENCE_KERNELS
 call mom6hip_mirrors_end()
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a)') "td_driver ok"
 end program td_driver

@@ -706,3 +706,49 @@ def test_reference_mixedlayer_restrat_equals_the_oracle(tmp_path, mle_exe):
             if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
                 bad.append((name, n, float(np.abs(a.reshape(w.shape) - w).max())))
     assert not bad, bad
+
+
+# ---- the reference's own MOM_thickness_diffuse.F90 beside the oracle --------------------------------------------------------------------------
+def build_ref_td_driver(tmp):
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_INTERFACE_HEIGHTS",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(REF, "src/core/MOM_density_integrals.F90"),
+                os.path.join(REF, "src/core/MOM_interface_heights.F90"), os.path.join(REF, "src/core/MOM_isopycnal_slopes.F90"),
+                os.path.join(REF, "src/parameterizations/lateral/MOM_thickness_diffuse.F90"), os.path.join(ROOT, "tests", "fortran", "td_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "td_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def td_exe(tmp_path_factory):
+    return build_ref_td_driver(tmp_path_factory.mktemp("ref_td"))
+
+
+def test_reference_thickness_diffuse_equals_the_oracle(tmp_path, td_exe):
+    """thickness_diffuse_init and thickness_diffuse of the reference's own module -- with its MOM_isopycnal_slopes (vert_fill_TS),
+    MOM_interface_heights (find_eta), density integrals and equation of state -- for every variant of tests/test_thickness_diffuse.py on a
+    closed basin: h, uhtr, vhtr, CDp%uhGM, CDp%vhGM and MEKE%GM_src equal the oracle's bit for bit"""
+    import test_thickness_diffuse as tt
+    g, d = tt.case(36, 22, 6, reentrant_x=False, reentrant_y=False)
+    bad = []
+    for name in tt.VARIANTS:
+        ref, opt = tt._write_td_case(tmp_path, g, d, name)
+        r = subprocess.run([td_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "td_driver ok" in r.stdout, (name, r.stdout[-200:], r.stderr[-1500:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+        want = [ref["h"], ref["uhtr"], ref["vhtr"], ref["uhGM"], ref["vhGM"]] + ([ref["GM_src"]] if opt[5] else [])
+        assert raw.size == sum(w.size for w in want), name
+        poss = (_abi.POS_H, _abi.POS_U, _abi.POS_V, _abi.POS_U, _abi.POS_V, _abi.POS_H)
+        for n, a, w, pos in zip(("h", "uhtr", "vhtr", "uhGM", "vhGM", "GM_src"), np.split(raw, np.cumsum([w.size for w in want])[:-1]), want, poss):
+            if not bits_equal(interior(g, a.reshape(w.shape), pos), interior(g, w, pos)):
+                dd = interior(g, a.reshape(w.shape), pos) != interior(g, w, pos)
+                bad.append((name, n, int(dd.sum()), float(np.abs(a.reshape(w.shape) - w).max())))
+    assert not bad, bad
