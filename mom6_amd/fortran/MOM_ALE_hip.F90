@@ -59,7 +59,10 @@ type :: ALE_CS ; private
   real    :: filter_shallow_depth = 0.0, filter_deep_depth = 0.0
   real, allocatable :: coordinateResolution(:)      !< nominal layer thicknesses [Z ~> m]
   integer :: remap_scheme = MOM6HIP_REMAP_PLM, vel_remap_scheme = MOM6HIP_REMAP_PLM
-  logical :: boundary_extrapolation = .false.
+  logical :: boundary_extrapolation = .false.      !< of CS%remapCS: INIT_BOUNDARY_EXTRAP at ALE_init, REMAP_BOUNDARY_EXTRAP after ALE_set_extrap_boundaries
+  logical :: vel_boundary_extrapolation = .false.  !< of CS%vel_remapCS: INIT_BOUNDARY_EXTRAP for the whole run -- ALE_set_extrap_boundaries sets
+                                                   !! CS%remapCS only (MOM_ALE.F90:256-261, :336; found by running the reference's own MOM_ALE beside
+                                                   !! the oracle, round 5: the shim had one flag for both)
   logical :: partial_cell_vel_remap = .false., conserve_ke = .false.
   real    :: BBL_h_vel_mask = 0.0
   integer :: answer_date = 99991231
@@ -179,6 +182,7 @@ subroutine ALE_init(param_file, GV, US, max_depth, CS)
                                                        "the GPU path.")
   CS%remap_scheme = scheme_of(string) ; CS%vel_remap_scheme = scheme_of(vel_string)
   CS%boundary_extrapolation = init_boundary_extrap      ! initialize_remapping(..., boundary_extrapolation=init_boundary_extrap)
+  CS%vel_boundary_extrapolation = init_boundary_extrap  ! (both CS%remapCS and CS%vel_remapCS, :250-261)
 
   call get_param(param_file, mdl, "REMAP_AFTER_INITIALIZATION", CS%remap_after_initialization, &
                  "If true, applies regridding and remapping immediately after initialization so that the state is ALE "//&
@@ -352,7 +356,7 @@ subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u
   logical,                         optional, intent(in)    :: allow_preserve_variance
   type(mom6hip_remapping_cs_t) :: mcs
   integer :: rc
-  mcs%remapping_scheme = CS%vel_remap_scheme ; mcs%boundary_extrapolation = merge(1, 0, CS%boundary_extrapolation)
+  mcs%remapping_scheme = CS%vel_remap_scheme ; mcs%boundary_extrapolation = merge(1, 0, CS%vel_boundary_extrapolation)
   mcs%force_bounds_in_subcell = 0 ; mcs%answer_date = CS%answer_date
   call mom6hip_mirror_require_host_current(c_loc(u), "ALE_remap_velocities") ; call mom6hip_mirror_require_host_current(c_loc(v), "ALE_remap_velocities")
   rc = mom6hip_ale_remap_velocities(mom6hip_shared_context(G, GV), mcs, c_loc(h_old_u), c_loc(h_old_v), c_loc(h_new_u), &

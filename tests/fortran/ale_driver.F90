@@ -1,7 +1,7 @@
 !> Drives the MOM_ALE shim the way step_MOM_thermo does (src/core/MOM.F90:1647-1700): ALE_init (parameters by name),
 !! ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers on a two-tracer registry, ALE_remap_set_h_vel for the old and the
 !! new grid, ALE_remap_velocities -- on plain host arrays.  tests/test_fortran_abi.py writes the input file and compares the
-!! output with the oracle bit for bit.   Usage: ale_driver <input file> <output file>
+!! output with the oracle bit for bit.   Usage: ale_driver <input file> <output file> [NAME=VALUE ...]
 program ale_driver
 use, intrinsic :: iso_c_binding
 use MOM_ALE,             only : ALE_CS, ALE_init, ALE_end, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel, ALE_remap_velocities, &
@@ -14,7 +14,9 @@ use MOM_tracer_registry, only : tracer_registry_type
 use MOM_unit_scaling,    only : unit_scale_type
 use MOM_variables,       only : thermo_var_ptrs
 use MOM_verticalGrid,    only : verticalGrid_type
+#ifndef REFERENCE_KERNELS
 use mom6hip_MOM_glue,    only : mom6hip_shared_context_end
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -30,8 +32,9 @@ integer :: ni, nj, nk, halo, u_in, u_out, isd, ied, jsd, jed
 real :: scal(7), dt, max_depth
 real, allocatable, dimension(:,:,:) :: u, v, h, h_new, dzRegrid, hu0, hv0, hu1, hv1
 real, allocatable, dimension(:,:,:), target :: T, S
-character(len=512) :: f_in, f_out
+character(len=512) :: f_in, f_out, f_arg
 character(len=32) :: str
+integer :: m
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
@@ -75,6 +78,21 @@ call param_set(pf, "REMAPPING_SCHEME", "PPM_H4") ; call param_set(pf, "VELOCITY_
 call param_set(pf, "REGRID_TIME_SCALE", "3600.0") ; call param_set(pf, "REGRID_FILTER_DEEP_DEPTH", "500.0")
 call param_set(pf, "REMAP_BOUNDARY_EXTRAP", "True") ; call param_set(pf, "INIT_BOUNDARY_EXTRAP", "False")
 
+do m = 3, command_argument_count()      ! further NAME=VALUE pairs of the parameter file (they replace the ones above)
+  call get_command_argument(m, f_arg)
+  if (index(f_arg, "=") > 1) call param_set(pf, f_arg(1:index(f_arg, "=")-1), trim(f_arg(index(f_arg, "=")+1:)))
+enddo
+#ifdef REFERENCE_KERNELS
+! (built with -DREFERENCE_KERNELS -DREF_ALE: the reference's OWN MOM_ALE.F90, MOM_regridding.F90, MOM_remapping.F90 and the 22 files under them)
+G%HI%isd = isd ; G%HI%ied = ied ; G%HI%jsd = jsd ; G%HI%jed = jed ; G%HI%IsdB = isd-1 ; G%HI%IedB = ied ; G%HI%JsdB = jsd-1 ; G%HI%JedB = jed
+G%HI%isc = G%isc ; G%HI%iec = G%iec ; G%HI%jsc = G%jsc ; G%HI%jec = G%jec
+G%HI%IscB = G%IscB ; G%HI%IecB = G%IecB ; G%HI%JscB = G%JscB ; G%HI%JecB = G%JecB
+allocate(G%US) ; G%max_depth = max_depth
+allocate(GV%Rlay(nk), GV%g_prime(nk+1), GV%sInterface(nk+1), GV%sLayer(nk))      ! (initialize_regridding reads GV%Rlay for the density range of a uniform
+GV%g_prime(:) = 0.0 ; GV%g_prime(1) = GV%g_Earth                                  !  coordinate whatever the coordinate is, :350)
+do m=1,nk ; GV%Rlay(m) = 1025.0 + 0.5*real(m-1) ; GV%sLayer(m) = real(m) ; enddo
+do m=1,nk+1 ; GV%sInterface(m) = real(m) - 0.5 ; enddo
+#endif
 call ALE_init(pf, GV, US, max_depth, CS)
 call ALE_set_extrap_boundaries(pf, CS)       ! MOM.F90:3136: the run switches to REMAP_BOUNDARY_EXTRAP after initialisation
 allocate(Reg)
@@ -92,6 +110,8 @@ open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", statu
 write(u_out) h_new, dzRegrid, T, S, hu1, hv1, u, v
 close(u_out)
 call ALE_end(CS)
+#ifndef REFERENCE_KERNELS
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a)') "ale_driver ok"
 end program ale_driver

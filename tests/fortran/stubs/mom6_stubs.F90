@@ -8,13 +8,18 @@
 
 module MOM_error_handler
 implicit none ; private
-public :: MOM_error, MOM_mesg, FATAL, WARNING, NOTE, is_root_pe
+public :: MOM_error, MOM_mesg, FATAL, WARNING, NOTE, is_root_pe, assert
 public :: MOM_set_verbosity, callTree_showQuery, callTree_enter, callTree_leave, callTree_waypoint
 integer, parameter :: NOTE = 0, WARNING = 1, FATAL = 2
 contains
 subroutine MOM_set_verbosity(verb)
   integer, intent(in) :: verb
 end subroutine MOM_set_verbosity
+subroutine assert(logical_arg, msg)
+  logical, intent(in) :: logical_arg
+  character(len=*), intent(in) :: msg
+  if (.not.logical_arg) call MOM_error(FATAL, msg)
+end subroutine assert
 logical function callTree_showQuery()
   callTree_showQuery = .false.
 end function callTree_showQuery
@@ -52,6 +57,10 @@ logical function is_root_pe()
 end function is_root_pe
 end module MOM_error_handler
 
+#ifdef REF_ALE
+! the reference's own MOM_string_functions.F90 (no dependencies), compiled where it lies: MOM_regridding parses coordinate definitions with it
+#include "MOM_string_functions.F90"
+#else
 module MOM_string_functions
 implicit none ; private
 public :: uppercase
@@ -67,6 +76,7 @@ function uppercase(input_string)
   enddo
 end function uppercase
 end module MOM_string_functions
+#endif
 
 module MOM_coms
 implicit none ; private
@@ -243,9 +253,22 @@ type :: hor_index_type
 end type hor_index_type
 end module MOM_hor_index
 
+module MOM_unit_scaling
+implicit none ; private
+public :: unit_scale_type
+type :: unit_scale_type
+  real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0, &
+          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0, Pa_to_RL2_T2 = 1.0, L_T2_to_m_s2 = 1.0, &
+          m_s_to_Z_T = 1.0, Z_T_to_m_s = 1.0, RL2_T2_to_Pa = 1.0, RZ_to_kg_m2 = 1.0, Z2_T_to_m2_s = 1.0, m2_s_to_Z2_T = 1.0, &
+          L_T_to_Z_T = 1.0, RZ_T_to_kg_m2s = 1.0, RLZ_T2_to_Pa = 1.0, Pa_to_RLZ_T2 = 1.0, T_to_sec = 1.0, Q_to_J_kg = 1.0, &
+          J_kg_to_Q = 1.0, C_to_degC = 1.0, degC_to_C = 1.0, S_to_ppt = 1.0, ppt_to_S = 1.0, RZ3_T3_to_W_m2 = 1.0, W_m2_to_RZ3_T3 = 1.0
+end type unit_scale_type
+end module MOM_unit_scaling
+
 module MOM_grid
 use MOM_domains, only : MOM_domain_type
 use MOM_hor_index, only : hor_index_type
+use MOM_unit_scaling, only : unit_scale_type
 implicit none ; private
 public :: ocean_grid_type
 type :: ocean_grid_type
@@ -256,6 +279,7 @@ type :: ocean_grid_type
   logical :: symmetric = .true.
   logical :: nonblocking_updates = .false.
   type(hor_index_type) :: HI
+  type(unit_scale_type), pointer :: US => NULL()
   real :: max_depth = 0.0, Z_ref = 0.0, Rad_Earth_L = 6.378e6
   real, allocatable, dimension(:,:) :: mask2dT, areaT, IareaT, dxT, dyT, IdxT, IdyT, bathyT
   real, allocatable, dimension(:,:) :: mask2dCu, dxCu, dyCu, dy_Cu, IdxCu, IdyCu, areaCu, IareaCu, OBCmaskCu, OBCmaskCv
@@ -301,17 +325,6 @@ function get_tr_flux_units(GV, tr_units, tr_vol_conc_units, tr_mass_conc_units)
 end function get_tr_flux_units
 end module MOM_verticalGrid
 
-module MOM_unit_scaling
-implicit none ; private
-public :: unit_scale_type
-type :: unit_scale_type
-  real :: m_to_Z = 1.0, Z_to_m = 1.0, m_to_L = 1.0, L_to_m = 1.0, s_to_T = 1.0, T_to_s = 1.0, m_s_to_L_T = 1.0, L_T_to_m_s = 1.0, &
-          R_to_kg_m3 = 1.0, kg_m3_to_R = 1.0, L_to_Z = 1.0, Z_to_L = 1.0, Pa_to_RL2_T2 = 1.0, L_T2_to_m_s2 = 1.0, &
-          m_s_to_Z_T = 1.0, Z_T_to_m_s = 1.0, RL2_T2_to_Pa = 1.0, RZ_to_kg_m2 = 1.0, Z2_T_to_m2_s = 1.0, m2_s_to_Z2_T = 1.0, &
-          L_T_to_Z_T = 1.0, RZ_T_to_kg_m2s = 1.0, RLZ_T2_to_Pa = 1.0, Pa_to_RLZ_T2 = 1.0, T_to_sec = 1.0, Q_to_J_kg = 1.0, &
-          J_kg_to_Q = 1.0, C_to_degC = 1.0, degC_to_C = 1.0, S_to_ppt = 1.0, ppt_to_S = 1.0, RZ3_T3_to_W_m2 = 1.0, W_m2_to_RZ3_T3 = 1.0
-end type unit_scale_type
-end module MOM_unit_scaling
 
 module MOM_time_manager
 implicit none ; private
@@ -400,9 +413,18 @@ interface get_param
   module procedure get_param_logical, get_param_real, get_param_int, get_param_char, get_param_real_array
 end interface
 interface log_param
-  module procedure log_param_logical, log_param_real, log_param_int, log_param_char
+  module procedure log_param_logical, log_param_real, log_param_int, log_param_char, log_param_real_array
 end interface
 contains
+subroutine log_param_real_array(CS, modulename, varname, value, desc, units, default, debuggingParam, like_default, unscale)
+  type(param_file_type), intent(in) :: CS
+  character(len=*),      intent(in) :: modulename, varname
+  real, dimension(:),    intent(in) :: value
+  character(len=*), optional, intent(in) :: desc
+  character(len=*),           intent(in) :: units
+  real,             optional, intent(in) :: default, unscale
+  logical,          optional, intent(in) :: debuggingParam, like_default
+end subroutine log_param_real_array
 subroutine log_param_logical(CS, modulename, varname, value, desc, units, default, layoutParam, debuggingParam, like_default)
   type(param_file_type), intent(in) :: CS
   character(len=*),      intent(in) :: modulename, varname
@@ -769,7 +791,26 @@ module MOM_io
 use MOM_domains, only : CENTER, CORNER, EAST_FACE, NORTH_FACE
 implicit none ; private
 public :: vardesc, var_desc, CENTER, CORNER, EAST_FACE, NORTH_FACE, stdout, stderr, MOM_read_data, slasher
+public :: file_exists, field_exists, field_size, SINGLE_FILE, MULTIPLE, create_MOM_file, MOM_write_field, MOM_file, MOM_infra_file, MOM_netCDF_file, MOM_field
+public :: verify_variable_units
+interface MOM_read_data
+  module procedure MOM_read_data_2d, MOM_read_data_1d
+end interface MOM_read_data
 integer, parameter :: stdout = 6, stderr = 0
+integer, parameter :: SINGLE_FILE = 1, MULTIPLE = 2
+!> the file handles and field descriptors the coordinate-file writers of MOM_regridding / MOM_hybgen_regrid declare (nothing is ever written)
+type :: MOM_field
+  character(len=64) :: label = ""
+end type MOM_field
+type :: MOM_file
+  logical :: is_open = .false.
+contains
+  procedure :: close => close_MOM_file
+end type MOM_file
+type, extends(MOM_file) :: MOM_infra_file
+end type MOM_infra_file
+type, extends(MOM_file) :: MOM_netCDF_file
+end type MOM_netCDF_file
 type :: vardesc
   character(len=64)  :: name = ""
   character(len=48)  :: units = ""
@@ -779,6 +820,51 @@ type :: vardesc
   integer :: position = -1
 end type vardesc
 contains
+subroutine close_MOM_file(handle)
+  class(MOM_file), intent(inout) :: handle
+  handle%is_open = .false.
+end subroutine close_MOM_file
+logical function file_exists(filename, MOM_Domain)
+  use MOM_domains, only : MOM_domain_type
+  character(len=*), intent(in) :: filename
+  type(MOM_domain_type), optional, intent(in) :: MOM_Domain
+  inquire(file=trim(filename), exist=file_exists)
+end function file_exists
+logical function field_exists(filename, field_name, MOM_domain)
+  use MOM_domains, only : MOM_domain_type
+  character(len=*), intent(in) :: filename, field_name
+  type(MOM_domain_type), target, optional, intent(in) :: MOM_domain
+  field_exists = .false.
+end function field_exists
+subroutine field_size(filename, fieldname, sizes, field_found, no_domain, ndims, ncid_in)
+  character(len=*),      intent(in)    :: filename, fieldname
+  integer, dimension(:), intent(inout) :: sizes
+  logical,     optional, intent(out)   :: field_found
+  logical,     optional, intent(in)    :: no_domain
+  integer,     optional, intent(out)   :: ndims
+  integer,     optional, intent(in)    :: ncid_in
+  sizes(:) = 0
+  if (present(field_found)) field_found = .false.
+  if (present(ndims)) ndims = 0
+end subroutine field_size
+subroutine create_MOM_file(IO_handle, filename, vars, novars, fields, threading, timeunit, G, dG, GV, checksums, extra_axes, global_atts)
+  class(MOM_file),       intent(inout) :: IO_handle
+  character(len=*),      intent(in)    :: filename
+  type(vardesc),         intent(in)    :: vars(:)
+  integer,               intent(in)    :: novars
+  type(MOM_field),       intent(inout) :: fields(:)
+  integer,     optional, intent(in)    :: threading
+  real,        optional, intent(in)    :: timeunit
+  class(*),    optional, intent(in)    :: G, dG, GV, extra_axes(:), global_atts(:)
+  integer(kind=8), optional, intent(in) :: checksums(:,:)
+  IO_handle%is_open = .true.
+end subroutine create_MOM_file
+subroutine MOM_write_field(IO_handle, field_md, field, tstamp, scale)
+  class(MOM_file),    intent(inout) :: IO_handle
+  type(MOM_field),    intent(in)    :: field_md
+  real, dimension(:), intent(in)    :: field
+  real,     optional, intent(in)    :: tstamp, scale
+end subroutine MOM_write_field
 function var_desc(name, units, longname, hor_grid, z_grid, t_grid, cmor_field_name, &
                   cmor_units, cmor_longname, conversion, caller, position, dim_names, &
                   extra_axes, fixed) result(vd)
@@ -799,7 +885,7 @@ function var_desc(name, units, longname, hor_grid, z_grid, t_grid, cmor_field_na
   if (present(conversion)) vd%conversion = conversion
 end function var_desc
 !> No files in the stand-in: a read is an error
-subroutine MOM_read_data(filename, fieldname, data, MOM_Domain, timelevel, position, scale, global_file, file_may_be_4d)
+subroutine MOM_read_data_2d(filename, fieldname, data, MOM_Domain, timelevel, position, scale, global_file, file_may_be_4d)
   use MOM_domains, only : MOM_domain_type
   use MOM_error_handler, only : MOM_error, FATAL
   character(len=*),       intent(in)    :: filename, fieldname
@@ -809,7 +895,24 @@ subroutine MOM_read_data(filename, fieldname, data, MOM_Domain, timelevel, posit
   real,         optional, intent(in)    :: scale
   logical,      optional, intent(in)    :: global_file, file_may_be_4d
   call MOM_error(FATAL, "MOM_read_data (stand-in): no files, asked for "//trim(fieldname)//" of "//trim(filename))
-end subroutine MOM_read_data
+end subroutine MOM_read_data_2d
+subroutine MOM_read_data_1d(filename, fieldname, data, timelevel, scale, MOM_Domain)
+  use MOM_domains, only : MOM_domain_type
+  use MOM_error_handler, only : MOM_error, FATAL
+  character(len=*),       intent(in)    :: filename, fieldname
+  real, dimension(:),     intent(inout) :: data
+  integer,      optional, intent(in)    :: timelevel
+  real,         optional, intent(in)    :: scale
+  type(MOM_domain_type), optional, intent(in) :: MOM_Domain
+  call MOM_error(FATAL, "MOM_read_data (stand-in): no files, asked for "//trim(fieldname)//" of "//trim(filename))
+end subroutine MOM_read_data_1d
+subroutine verify_variable_units(filename, varname, expected_units, msg, ierr, alt_units)
+  character(len=*),           intent(in)    :: filename, varname, expected_units
+  character(len=*),           intent(inout) :: msg
+  logical,                    intent(out)   :: ierr
+  character(len=*), optional, intent(in)    :: alt_units
+  ierr = .true.
+end subroutine verify_variable_units
 function slasher(dir)
   character(len=*), intent(in) :: dir
   character(len=len(dir)+1) :: slasher
@@ -1030,10 +1133,11 @@ end module MOM_EOS
 
 module MOM_variables
 use MOM_domains, only : group_pass_type
+use MOM_grid, only : ocean_grid_type
 use MOM_EOS, only : EOS_type
 implicit none ; private
 public :: BT_cont_type, porous_barrier_type, accel_diag_ptrs, cont_diag_ptrs, thermo_var_ptrs, vertvisc_type, &
-          ocean_internal_state, alloc_BT_cont_type, dealloc_BT_cont_type
+          ocean_internal_state, alloc_BT_cont_type, dealloc_BT_cont_type, ocean_grid_type
 interface alloc_BT_cont_type
   module procedure alloc_BT_cont_type_ranges, alloc_BT_cont_type_grid
 end interface
@@ -1176,6 +1280,7 @@ subroutine find_ustar_fluxes(fluxes, tv, U_star, G, GV, US, halo, H_T_units)
 end subroutine find_ustar_fluxes
 end module MOM_forcing_type
 
+#ifndef REF_ALE
 module MOM_regridding
 implicit none ; private
 public :: regridding_CS
@@ -1191,12 +1296,13 @@ type :: remapping_CS
   integer :: remapping_scheme = 0
 end type remapping_CS
 end module MOM_remapping
+#endif
 
 #ifdef REF_PF
 ! The reference's PLM_functions.F90, compiled where it lies (cpp #include by -I/root/reference/src/ALE), for the stand-in below.
 #include "PLM_functions.F90"
 #endif
-#ifndef MOM6HIP_WITH_ALE_SHIM
+#if !defined(MOM6HIP_WITH_ALE_SHIM) && !defined(REF_ALE)
 module MOM_ALE
 #if defined(REF_PF) || defined(REF_SET_VISC)
 use MOM_grid, only : ocean_grid_type
@@ -1330,8 +1436,13 @@ end module MOM_MEKE_types
 
 
 module MOM_tracer_registry
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
 implicit none ; private
-public :: tracer_registry_type, tracer_type
+public :: tracer_registry_type, tracer_type, MOM_tracer_chkinv
+interface MOM_tracer_chkinv
+  module procedure tracer_array_chkinv, tracer_Reg_chkinv
+end interface MOM_tracer_chkinv
 type :: tracer_type
   real, dimension(:,:,:), pointer :: t => NULL()
   real :: conc_underflow = 0.0
@@ -1340,11 +1451,29 @@ type :: tracer_type
   real, dimension(:,:,:), pointer :: df_x => NULL(), df_y => NULL()
   real, dimension(:,:),   pointer :: df2d_x => NULL(), df2d_y => NULL()
   character(len=32) :: name = ""
+  integer :: id_remap_conc = -1, id_remap_cont = -1, id_remap_cont_2d = -1      !< (diagnostics of ALE_remap_tracers: never registered)
 end type tracer_type
 type :: tracer_registry_type
   integer :: ntr = 0
   type(tracer_type) :: Tr(16)
 end type tracer_registry_type
+contains
+!> the debugging inventories of MOM_tracer_registry.F90 (printed with DEBUG only): nothing is printed here
+subroutine tracer_array_chkinv(mesg, G, GV, h, Tr, ntr)
+  character(len=*),         intent(in) :: mesg
+  type(ocean_grid_type),    intent(in) :: G
+  type(verticalGrid_type),  intent(in) :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h
+  type(tracer_type), dimension(:), intent(in) :: Tr
+  integer,                  intent(in) :: ntr
+end subroutine tracer_array_chkinv
+subroutine tracer_Reg_chkinv(mesg, G, GV, h, Reg)
+  character(len=*),           intent(in) :: mesg
+  type(ocean_grid_type),      intent(in) :: G
+  type(verticalGrid_type),    intent(in) :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h
+  type(tracer_registry_type), pointer    :: Reg
+end subroutine tracer_Reg_chkinv
 end module MOM_tracer_registry
 
 module MOM_self_attr_load
@@ -1725,7 +1854,7 @@ module MOM_debugging
 use MOM_grid, only : ocean_grid_type
 use MOM_hor_index, only : hor_index_type
 implicit none ; private
-public :: hchksum, uvchksum, Bchksum, check_redundant
+public :: hchksum, uvchksum, Bchksum, check_redundant, check_column_integrals
 interface hchksum
   module procedure chksum_h_3d, chksum_h_2d
 end interface
@@ -1739,6 +1868,15 @@ interface check_redundant
   module procedure check_redundant_vC3d, check_redundant_vC2d
 end interface
 contains
+!> (ALE_offline_inputs only, which no test reaches)
+logical function check_column_integrals(nk_1, field_1, nk_2, field_2, missing_value)
+  integer,               intent(in) :: nk_1, nk_2
+  real, dimension(nk_1), intent(in) :: field_1
+  real, dimension(nk_2), intent(in) :: field_2
+  real, optional,        intent(in) :: missing_value
+  check_column_integrals = .false.
+  error stop "check_column_integrals stand-in: not provided"
+end function check_column_integrals
 subroutine chksum_h_3d(array_m, mesg, HI_m, haloshift, omit_corners, scale, logunit)
   type(hor_index_type),    target,   intent(in) :: HI_m
   real, dimension(HI_m%isd:,HI_m%jsd:,:), target, intent(in) :: array_m

@@ -434,7 +434,8 @@ def test_ale_shim_matches_oracle(tmp_path):
     hu0, hv0 = orc.ale_remap_set_h_vel(g, d["h"])
     hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
     u, v = d["u"].copy(), d["v"].copy()
-    orc.ale_remap_velocities(g, "PLM", hu0, hv0, hu1, hv1, u, v, boundary_extrapolation=True)
+    # (the velocities' remapping structure keeps INIT_BOUNDARY_EXTRAP = False: ALE_set_extrap_boundaries sets the tracers' only, MOM_ALE.F90:336)
+    orc.ale_remap_velocities(g, "PLM", hu0, hv0, hu1, hv1, u, v, boundary_extrapolation=False)
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "ale_driver ok" in r.stdout

@@ -752,3 +752,88 @@ def test_reference_thickness_diffuse_equals_the_oracle(tmp_path, td_exe):
                 dd = interior(g, a.reshape(w.shape), pos) != interior(g, w, pos)
                 bad.append((name, n, int(dd.sum()), float(np.abs(a.reshape(w.shape) - w).max())))
     assert not bad, bad
+
+
+# ---- the reference's own MOM_ALE.F90 (z* regridding, remapping of tracers and velocities) beside the oracle --------------------------------------
+ALE_SOURCES = ("src/core/MOM_density_integrals.F90", "src/core/MOM_interface_heights.F90", "src/ALE/regrid_consts.F90", "src/ALE/regrid_solvers.F90",
+               "src/ALE/polynomial_functions.F90", "src/ALE/regrid_edge_values.F90", "src/ALE/PCM_functions.F90", "src/ALE/PLM_functions.F90",
+               "src/ALE/PPM_functions.F90", "src/ALE/PQM_functions.F90", "src/ALE/P1M_functions.F90", "src/ALE/P3M_functions.F90",
+               "src/ALE/regrid_interp.F90", "src/ALE/MOM_hybgen_remap.F90", "src/ALE/remapping_attic.F90", "src/ALE/MOM_remapping.F90",
+               "src/ALE/coord_zlike.F90", "src/ALE/coord_sigma.F90", "src/ALE/coord_rho.F90", "src/ALE/coord_hycom.F90", "src/ALE/coord_adapt.F90",
+               "src/ALE/MOM_hybgen_regrid.F90", "src/ALE/MOM_hybgen_unmix.F90", "src/ALE/MOM_regridding.F90", "src/ALE/MOM_ALE.F90")
+
+
+def build_ref_ale_driver(tmp):
+    """tests/fortran/ale_driver.F90 (-DREFERENCE_KERNELS) on the reference's OWN MOM_ALE.F90 with all of src/ALE under it (25 files in place; the
+    stand-ins #include the reference's MOM_string_functions.F90 and equation-of-state stack as well: -DREF_ALE -DREF_EOS)"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_INTERFACE_HEIGHTS", "-DREF_ALE",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(REF, r) for r in ALE_SOURCES] + [os.path.join(ROOT, "tests", "fortran", "ale_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "ale_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def ale_exe(tmp_path_factory):
+    return build_ref_ale_driver(tmp_path_factory.mktemp("ref_ale"))
+
+
+@pytest.mark.parametrize("scheme,vel_scheme,extrap", [("PPM_H4", "PLM", True), ("PPM_H4", "PPM_H4", False), ("PLM", "PLM", False), ("PPM_IH4", "PLM", True),
+                                                      ("PCM", "PCM", False), ("PPM_CW", "PPM_CW", False), ("PPM_HYBGEN", "PLM_HYBGEN", False),
+                                                      ("WENO_HYBGEN", "PLM", False)])
+def test_reference_ale_regrid_and_remap_equal_the_oracle(tmp_path, ale_exe, scheme, vel_scheme, extrap):
+    """ALE_init (Z*, UNIFORM resolution, REGRID_TIME_SCALE with the deep filter), ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers,
+    ALE_remap_set_h_vel x2, ALE_remap_velocities of the reference's own MOM_ALE / MOM_regridding / coord_zlike / MOM_remapping, the sequence of
+    MOM.F90:1647-1700: the new grid, the interface movement, the remapped T, S, u, v and the face thicknesses equal the oracle's bit for bit,
+    for the eight remapping schemes the library provides"""
+    from mom6_amd import synth
+    from oracle import orc
+    ni, nj, nk, halo = 34, 18, 6, 4
+    g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=21, reentrant_x=False, reentrant_y=False)
+    d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=9, umax=0.3, eta_amp=0.5).items()}
+    dt = 1800.0
+    max_depth = float(g.bathyT.max())
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([ni, nj, nk, halo, 0, 0, g.first_direction, 0], dtype="<i4").tofile(f)
+        np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in (d["u"], d["v"], d["h"], d["T"], d["S"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        np.array([max_depth], dtype="<f8").tofile(f)
+    res = np.full(nk, max_depth / nk)
+    w = 3600.0 / (3600.0 + dt)
+    rcs = orc.regridding_cs(res, min_thickness=1.0e-3, old_grid_weight=w, zs=0.0, zd=500.0)
+    h_new, dz = orc.ale_regrid(g, rcs, d["h"])
+    T, S = d["T"].copy(), d["S"].copy()
+    orc.ale_remap_tracers(g, scheme, d["h"], h_new, [T, S], conc_underflow=np.array([0.0, 1.0e-30]), boundary_extrapolation=extrap)
+    hu0, hv0 = orc.ale_remap_set_h_vel(g, d["h"])
+    hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
+    u, v = d["u"].copy(), d["v"].copy()
+    # (the velocities' remapping structure keeps INIT_BOUNDARY_EXTRAP = False: ALE_set_extrap_boundaries sets the tracers' only, MOM_ALE.F90:336)
+    orc.ale_remap_velocities(g, vel_scheme, hu0, hv0, hu1, hv1, u, v, boundary_extrapolation=False)
+    args = [f"REMAPPING_SCHEME={scheme}", f"VELOCITY_REMAPPING_SCHEME={vel_scheme}", f"REMAP_BOUNDARY_EXTRAP={extrap}"]
+    r = subprocess.run([ale_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")] + args, capture_output=True, text=True)
+    assert r.returncode == 0 and "ale_driver ok" in r.stdout, r.stderr[-2000:]
+    want = [h_new, dz, T, S, hu1, hv1, u, v]
+    names = ["h_new", "dzRegrid", "T", "S", "h_new_u", "h_new_v", "u", "v"]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    sizes = [x.size for x in want]
+    assert raw.size == sum(sizes)
+    U, V, H = _abi.POS_U, _abi.POS_V, _abi.POS_H
+    bad = []
+    for n, a, x in zip(names, np.split(raw, np.cumsum(sizes)[:-1]), want):
+        pos = U if n in ("h_new_u", "u") else (V if n in ("h_new_v", "v") else H)
+        if not bits_equal(interior(g, a.reshape(x.shape), pos), interior(g, x, pos)):
+            dd = interior(g, a.reshape(x.shape), pos) != interior(g, x, pos)
+            bad.append((n, int(dd.sum()), float(np.abs(a.reshape(x.shape) - x).max())))
+    assert not bad, bad
+    assert not np.array_equal(interior(g, h_new), interior(g, d["h"]))
