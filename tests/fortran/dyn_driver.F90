@@ -10,6 +10,15 @@
 !! equation-of-state stack, MOM_barotropic, MOM_vert_friction, MOM_set_viscosity, MOM_hor_visc -- every one compiled where it lies against
 !! the stand-ins of tests/fortran/stubs -- and the test compares its fields with the oracle's, bit for bit.  The two lateral
 !! parameterisations beside the step and the transfer statistics belong to the shims' build only.
+#ifdef REF_RK2B
+! (with -DREFERENCE_KERNELS -DREF_RK2B: the reference's own MOM_dynamics_split_RK2b.F90 -- SPLIT_RK2B -- under the same driver)
+#define MOM_dynamics_split_RK2 MOM_dynamics_split_RK2b
+#define MOM_dyn_split_RK2_CS MOM_dyn_split_RK2b_CS
+#define register_restarts_dyn_split_RK2 register_restarts_dyn_split_RK2b
+#define initialize_dyn_split_RK2 initialize_dyn_split_RK2b
+#define step_MOM_dyn_split_RK2 step_MOM_dyn_split_RK2b
+#define end_dyn_split_RK2 end_dyn_split_RK2b
+#endif
 program dyn_driver
 use, intrinsic :: iso_c_binding
 use MOM_dynamics_split_RK2, only : MOM_dyn_split_RK2_CS, register_restarts_dyn_split_RK2, initialize_dyn_split_RK2
@@ -264,8 +273,13 @@ do n = 1, nsteps
 #endif
   endif
   calc_dtbt = (dtbt_reset_period == 0.0) .or. ((dtbt_reset_period > 0.0) .and. (n == 1) .and. calc_dtbt_init)
+#ifdef REF_RK2B
+  call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, &
+                              calc_dtbt, VarMix, MEKE, TD, pbv, Waves)             ! as MOM.F90:1250-1253 calls it
+#else
   call step_MOM_dyn_split_RK2(u, v, h, tv, visc, Time, dt, forces, p_surf_begin, p_surf_end, uh, vh, uhtr, vhtr, eta_av, G, GV, US, CS, &
                               calc_dtbt, VarMix, MEKE, TD, pbv, STOCH, Waves)      ! as MOM.F90:1242-1245 calls it
+#endif
 enddo
 #ifndef REFERENCE_KERNELS
 call dyn_split_RK2_sync_to_host(CS)

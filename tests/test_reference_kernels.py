@@ -553,17 +553,20 @@ CORE_SOURCES = ("src/core/MOM_density_integrals.F90", "src/core/MOM_PressureForc
                 "src/core/MOM_dynamics_split_RK2.F90")
 
 
-def build_ref_dyn_driver(tmp, opt="-O0"):
+def build_ref_dyn_driver(tmp, opt="-O0", rk2b=False):
     """tests/fortran/dyn_driver.F90 (-DREFERENCE_KERNELS) on the reference's OWN MOM_dynamics_split_RK2.F90 and everything it steps through:
     set_viscosity, vert_friction, hor_visc, barotropic, the pressure force with its density integrals and equation-of-state stack,
     continuity, CoriolisAdv -- each compiled where it lies against the stand-ins"""
-    flags = ["-cpp", "-fdefault-real-8", opt, "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF", "-DREF_PF_MONT", "-DREF_SET_VISC",
+    flags = ["-cpp", "-fdefault-real-8", opt, "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF", "-DREF_PF_MONT", "-DREF_SET_VISC"] + \
+            (["-DREF_RK2B"] if rk2b else []) + [
              f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
              f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
     srcs = [os.path.join(STUBS, "mom6_stubs.F90"), os.path.join(STUBS, "mom6_stubs_setvisc.F90"),
             os.path.join(REF, "src/framework/MOM_intrinsic_functions.F90"), os.path.join(REF, "src/parameterizations/vertical/MOM_set_viscosity.F90"),
             os.path.join(STUBS, "mom6_stubs_visc.F90")] + [os.path.join(REF, r) for r in VISC_SOURCES + CORE_SOURCES] + \
            [os.path.join(ROOT, "tests", "fortran", "dyn_driver.F90")]
+    if rk2b:
+        srcs.insert(-1, os.path.join(REF, "src/core/MOM_dynamics_split_RK2b.F90"))
     objs = []
     for src in srcs:
         o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
@@ -837,3 +840,37 @@ def test_reference_ale_regrid_and_remap_equal_the_oracle(tmp_path, ale_exe, sche
             bad.append((n, int(dd.sum()), float(np.abs(a.reshape(x.shape) - x).max())))
     assert not bad, bad
     assert not np.array_equal(interior(g, h_new), interior(g, d["h"]))
+
+
+@pytest.fixture(scope="module")
+def dyn_rk2b_exe(tmp_path_factory):
+    return build_ref_dyn_driver(tmp_path_factory.mktemp("ref_dyn_rk2b"), rk2b=True)
+
+
+@pytest.mark.parametrize("name", ["tc4", "bench_like"])
+def test_reference_rk2b_core_equals_the_oracle(tmp_path, dyn_rk2b_exe, name, monkeypatch):
+    """SPLIT_RK2B: three steps of the reference's own step_MOM_dyn_split_RK2b (MOM_dynamics_split_RK2b.F90 in place, every module under it the
+    reference's) with the tc4 set and the bench's settings on a closed basin: the filtered velocities, h, the transports and eta_av equal the
+    oracle's DynState(rk2b=True).step bit for bit"""
+    import functools
+    import test_testing_configs as tc
+    from oracle import orc
+    base = BENCH_LIKE if name == "bench_like" else tc.TC_INPUT[name]
+    monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + "\n        REENTRANT_X = False\n"))
+    monkeypatch.setattr(orc, "DynState", functools.partial(orc.DynState, rk2b=True))
+    nsteps = 3
+    state = tc.case_state(name)
+    g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    tc.write_case(tmp_path, name, nsteps, False, state, bbl_mode=1)
+    r = subprocess.run([dyn_rk2b_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+    assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-3000:] + r.stdout[-2000:]
+    st, calc, _ = tc.oracle_for(name, g, d, ustar, bbl, Rlay, g_prime)
+    assert st.rk2b
+    for n in range(nsteps):
+        st.bbl()
+        st.step(taux, tauy, calc_dtbt=calc(n))
+    got = tc.read_out(str(tmp_path / "out.bin"), g, meke=False)
+    want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+    bad = [(n, float(np.abs(got[n] - want[n]).max())) for n, pos, nd in tc.OUT
+           if n in want and not bits_equal(interior(g, got[n], pos), interior(g, want[n], pos))]
+    assert not bad, bad
