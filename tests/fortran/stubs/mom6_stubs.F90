@@ -298,7 +298,7 @@ type :: verticalGrid_type
   integer :: ke
   real :: Angstrom_m = 1.0e-10, Angstrom_Z = 1.0e-10, Angstrom_H = 1.0e-10, H_subroundoff = 1.0e-30, dZ_subroundoff = 1.0e-30, H_to_Z = 1.0, Z_to_H = 1.0, g_Earth = 9.8, &
           Rho0 = 1035.0, m_to_H = 1.0, H_to_m = 1.0, RZ_to_H = 1.0/1035.0, H_to_RZ = 1035.0, m2_s_to_HZ_T = 1.0, H_to_MKS = 1.0, &
-          H_to_kg_m2 = 1035.0, kg_m2_to_H = 1.0/1035.0, HZ_T_to_m2_s = 1.0, HZ_T_to_MKS = 1.0
+          H_to_kg_m2 = 1035.0, kg_m2_to_H = 1.0/1035.0, HZ_T_to_m2_s = 1.0, HZ_T_to_MKS = 1.0, H_to_Pa = 9.8*1035.0
   integer :: nk_rho_varies = 0, nkml = 0
   logical :: Boussinesq = .true., semi_Boussinesq = .false.
   real, allocatable :: Rlay(:), g_prime(:)
@@ -1439,7 +1439,10 @@ module MOM_tracer_registry
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
 implicit none ; private
-public :: tracer_registry_type, tracer_type, MOM_tracer_chkinv
+public :: tracer_registry_type, tracer_type, MOM_tracer_chkinv, MOM_tracer_chksum
+interface MOM_tracer_chksum
+  module procedure tracer_array_chksum, tracer_Reg_chksum
+end interface MOM_tracer_chksum
 interface MOM_tracer_chkinv
   module procedure tracer_array_chkinv, tracer_Reg_chkinv
 end interface MOM_tracer_chkinv
@@ -1452,6 +1455,9 @@ type :: tracer_type
   real, dimension(:,:),   pointer :: df2d_x => NULL(), df2d_y => NULL()
   character(len=32) :: name = ""
   integer :: id_remap_conc = -1, id_remap_cont = -1, id_remap_cont_2d = -1      !< (diagnostics of ALE_remap_tracers: never registered)
+  integer :: id_dfxy_cont = -1, id_dfxy_cont_2d = -1, id_dfxy_conc = -1, id_dfx_2d = -1, id_dfy_2d = -1      !< (of the neutral diffusion)
+  integer :: id_hbdxy_cont = -1, id_hbdxy_cont_2d = -1, id_hbdxy_conc = -1, id_hbd_dfx = -1, id_hbd_dfy = -1, id_hbd_dfx_2d = -1, id_hbd_dfy_2d = -1
+  real :: conc_scale = 1.0
 end type tracer_type
 type :: tracer_registry_type
   integer :: ntr = 0
@@ -1459,6 +1465,17 @@ type :: tracer_registry_type
 end type tracer_registry_type
 contains
 !> the debugging inventories of MOM_tracer_registry.F90 (printed with DEBUG only): nothing is printed here
+subroutine tracer_array_chksum(mesg, Tr, ntr, G)      ! (debugging checksums: nothing is printed)
+  character(len=*),      intent(in) :: mesg
+  type(tracer_type),     intent(in) :: Tr(:)
+  integer,               intent(in) :: ntr
+  type(ocean_grid_type), intent(in) :: G
+end subroutine tracer_array_chksum
+subroutine tracer_Reg_chksum(mesg, Reg, G)
+  character(len=*),           intent(in) :: mesg
+  type(tracer_registry_type), pointer    :: Reg
+  type(ocean_grid_type),      intent(in) :: G
+end subroutine tracer_Reg_chksum
 subroutine tracer_array_chkinv(mesg, G, GV, h, Tr, ntr)
   character(len=*),         intent(in) :: mesg
   type(ocean_grid_type),    intent(in) :: G
@@ -1597,6 +1614,7 @@ implicit none ; private
 public :: diabatic_CS, extract_diabatic_member
 type :: diabatic_CS
   integer :: unused = 0
+  type(energetic_PBL_CS), pointer :: ePBL => NULL()      ! (the reference's diabatic_CS%ePBL: associated when ePBL is the boundary layer scheme)
 end type diabatic_CS
 contains
 subroutine extract_diabatic_member(CS, evap_CFL_limit, minimum_forcing_depth, KPP_CSp, energetic_PBL_CSp, diabatic_halo, use_KPP)
@@ -1606,6 +1624,7 @@ subroutine extract_diabatic_member(CS, evap_CFL_limit, minimum_forcing_depth, KP
   real,              optional, intent(  out) :: evap_CFL_limit, minimum_forcing_depth
   integer,           optional, intent(  out) :: diabatic_halo
   logical,           optional, intent(  out) :: use_KPP
+  if (present(energetic_PBL_CSp)) energetic_PBL_CSp => CS%ePBL
 end subroutine extract_diabatic_member
 end module MOM_diabatic_driver
 
@@ -2077,3 +2096,22 @@ subroutine PressureForce_Mont_init(Time, G, GV, US, param_file, diag, CS, SAL_CS
 end subroutine PressureForce_Mont_init
 end module MOM_PressureForce_Mont
 #endif
+
+
+module MOM_spatial_means      ! src/diagnostics/MOM_spatial_means.F90: the global integral MOM_hor_bnd_diffusion prints in its debugging branch
+use MOM_grid, only : ocean_grid_type
+use MOM_verticalGrid, only : verticalGrid_type
+implicit none ; private
+public :: global_mass_integral
+contains
+function global_mass_integral(h, G, GV, var, on_PE_only, scale, tmp_scale)
+  type(ocean_grid_type),   intent(in)  :: G
+  type(verticalGrid_type), intent(in)  :: GV
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h
+  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), optional, intent(in) :: var
+  logical,       optional, intent(in)  :: on_PE_only
+  real,          optional, intent(in)  :: scale, tmp_scale
+  real :: global_mass_integral
+  global_mass_integral = 0.0
+end function global_mass_integral
+end module MOM_spatial_means

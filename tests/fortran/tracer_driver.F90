@@ -23,7 +23,12 @@ use MOM_lateral_mixing_coeffs, only : VarMix_CS
 use MOM_unit_scaling,   only : unit_scale_type
 use MOM_variables,      only : thermo_var_ptrs
 use MOM_verticalGrid,   only : verticalGrid_type
+#ifdef REFERENCE_KERNELS
+use MOM_EOS,            only : EOS_init      ! (built with -DREFERENCE_KERNELS -DREF_EOS -DREF_INTERFACE_HEIGHTS -DREF_ALE: the reference's OWN MOM_tracer_advect.F90,
+                                             ! MOM_tracer_hor_diff.F90, MOM_neutral_diffusion.F90, MOM_hor_bnd_diffusion.F90, the ALE remapping stack and MOM_EOS)
+#else
 use mom6hip_MOM_glue,   only : mom6hip_shared_context_end, mom6hip_shared_context, mom6hip_mirrors_to_host, mom6hip_mirrors_end
+#endif
 implicit none
 
 type(ocean_grid_type), target :: G
@@ -115,19 +120,35 @@ do
 enddo
 close(u_par)
 
+#ifdef REFERENCE_KERNELS
+G%HI%isd = isd ; G%HI%ied = ied ; G%HI%jsd = jsd ; G%HI%jed = jed ; G%HI%IsdB = isd-1 ; G%HI%IedB = ied ; G%HI%JsdB = jsd-1 ; G%HI%JedB = jed
+G%HI%isc = G%isc ; G%HI%iec = G%iec ; G%HI%jsc = G%jsc ; G%HI%jec = G%jec
+G%HI%IscB = G%IscB ; G%HI%IecB = G%IecB ; G%HI%JscB = G%JscB ; G%HI%JecB = G%JecB
+allocate(G%OBCmaskCu(isd-1:ied,jsd:jed), G%OBCmaskCv(isd:ied,jsd-1:jed))      ! no open boundaries: the masks of the faces (MOM_grid.F90)
+G%OBCmaskCu(:,:) = G%mask2dCu(:,:) ; G%OBCmaskCv(:,:) = G%mask2dCv(:,:)
+GV%RZ_to_H = GV%Z_to_H / GV%Rho0 ; GV%H_to_RZ = GV%H_to_Z * GV%Rho0 ; GV%H_to_Pa = GV%g_Earth * GV%H_to_RZ
+call EOS_init(pf, EOS, US)
+if (opt(5) /= 0) then      ! NDIFF_INTERIOR_ONLY asks for a boundary layer scheme to be there (MOM_neutral_diffusion.F90:281-285); visc%h_ML is what it reads
+  allocate(diabatic_CSp) ; allocate(diabatic_CSp%ePBL)
+endif
+#endif
 call tracer_advect_init(Time, G, US, pf, diag, ACS)
 call tracer_hor_diff_init(Time, G, GV, US, pf, diag, EOS, diabatic_CSp, DCS)
 call advect_tracer(h, uhtr, vhtr, OBC, dt_therm, G, GV, US, ACS, Reg)
 call tracer_hordiff(h, dt_therm, MEKE, VarMix, visc, G, GV, US, DCS, Reg, tv)
 
+#ifndef REFERENCE_KERNELS
 ! with GPU_RESIDENT_DYNAMICS the results are on the device until the host asks for them
 call mom6hip_mirrors_to_host(mom6hip_shared_context(G, GV))
+#endif
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) trs
 close(u_out)
 call tracer_hor_diff_end(DCS)
 call tracer_advect_end(ACS)
+#ifndef REFERENCE_KERNELS
 call mom6hip_mirrors_end()
 call mom6hip_shared_context_end()
+#endif
 write(*,'(a)') "tracer_driver ok"
 end program tracer_driver

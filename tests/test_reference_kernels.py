@@ -874,3 +874,73 @@ def test_reference_rk2b_core_equals_the_oracle(tmp_path, dyn_rk2b_exe, name, mon
     bad = [(n, float(np.abs(got[n] - want[n]).max())) for n, pos, nd in tc.OUT
            if n in want and not bits_equal(interior(g, got[n], pos), interior(g, want[n], pos))]
     assert not bad, bad
+
+
+# ---- the reference's own MOM_tracer_advect.F90 and MOM_tracer_hor_diff.F90 (with neutral diffusion and the epipycnal mixed-layer exchange) ------------
+TRACER_SOURCES = tuple(s for s in ALE_SOURCES if s != "src/ALE/MOM_ALE.F90" and "hybgen_unmix" not in s) + (
+    "src/tracer/MOM_tracer_advect.F90", "src/tracer/MOM_hor_bnd_diffusion.F90", "src/tracer/MOM_neutral_diffusion.F90", "src/tracer/MOM_tracer_hor_diff.F90")
+
+
+def build_ref_tracer_driver(tmp):
+    """tests/fortran/tracer_driver.F90 (-DREFERENCE_KERNELS) on the reference's OWN MOM_tracer_advect.F90 and MOM_tracer_hor_diff.F90, with its
+    MOM_neutral_diffusion.F90, MOM_hor_bnd_diffusion.F90, remapping stack and equation of state in place under them"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_INTERFACE_HEIGHTS", "-DREF_ALE",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(REF, r) for r in TRACER_SOURCES] + [os.path.join(ROOT, "tests", "fortran", "tracer_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "tracer_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def tracer_exe(tmp_path_factory):
+    return build_ref_tracer_driver(tmp_path_factory.mktemp("ref_tracer"))
+
+
+def test_reference_tracer_advect_and_hordiff_equal_the_oracle(tmp_path, tracer_exe):
+    """advect_tracer then tracer_hordiff of the reference's own modules on a closed basin, for constant KHTR, every variable-mixing set of
+    tests/test_tracer_hor_diff.py and neutral diffusion (whole column, and below visc%h_ML): the tracers equal the oracle's bit for bit"""
+    import test_tracer_hor_diff as th
+    g, h, tr = th.case(36, 22, 4, reentrant=(False, False))
+    bad = []
+    for name in [None, "neutral", "neutral_interior"] + list(th.VM):
+        ref = th._write_tracer_case(tmp_path, g, h, tr, name)
+        r = subprocess.run([tracer_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (name, r.stdout[-200:], r.stderr[-1500:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8").reshape((len(tr),) + tr[0].shape)
+        for m, w in enumerate(ref):
+            if not bits_equal(interior(g, raw[m]), interior(g, w)):
+                bad.append((name, m, int((interior(g, raw[m]) != interior(g, w)).sum()), float(np.abs(interior(g, raw[m]) - interior(g, w)).max())))
+    assert not bad, bad
+
+
+def test_reference_epipycnal_diffusion_equals_the_oracle(tmp_path, tracer_exe):
+    """DIFFUSE_ML_TO_INTERIOR of the reference's own tracer_epipycnal_ML_diff on a layered state at rest in a closed basin, as .testing/tc1 sets it
+    and with the later answer date: the tracers equal the oracle's bit for bit"""
+    import test_epipycnal as te
+    from oracle import orc
+    g, h, tr, eos, Rlay = te.layered_case(ni=30, nj=16, nk=8, reentrant=(False, False))
+    bad = []
+    for params in [dict(KHTR=800.0, ML_KHTR_SCALE=0.0), dict(KHTR=800.0), dict(KHTR=2.0e5, CHECK_DIFFUSIVE_CFL=True, HOR_DIFF_ANSWER_DATE=20240401)]:
+        dt = te._write_layered_tracer_case(tmp_path, g, h, tr, "WRIGHT", Rlay, params, False)
+        ref = [t.copy() for t in tr]
+        orc.advect_tracer(g, h, np.zeros(g.shape3(_abi.POS_U)), np.zeros(g.shape3(_abi.POS_V)), dt, 900.0, "PPM:H3", ref)
+        for t in ref:
+            orc.halo_update(g, t, _abi.POS_H)
+        orc.tracer_hordiff(g, h, dt, ref, params["KHTR"], check_diffusive_CFL=params.get("CHECK_DIFFUSIVE_CFL", False),
+                           epipycnal=te.epi(eos, Rlay, ML_KhTr_scale=params.get("ML_KHTR_SCALE", 1.0), answer_date=params.get("HOR_DIFF_ANSWER_DATE", 20240101)))
+        r = subprocess.run([tracer_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
+        assert r.returncode == 0 and "tracer_driver ok" in r.stdout, (params, r.stdout[-200:], r.stderr[-1500:])
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8").reshape((len(tr),) + tr[0].shape)
+        for m, w in enumerate(ref):
+            if not bits_equal(interior(g, raw[m]), interior(g, w)):
+                bad.append((params, m, int((interior(g, raw[m]) != interior(g, w)).sum()), float(np.abs(interior(g, raw[m]) - interior(g, w)).max())))
+        assert not bits_equal(interior(g, raw[2]), interior(g, tr[2]))
+    assert not bad, bad
