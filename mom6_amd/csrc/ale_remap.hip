@@ -19,8 +19,8 @@
 namespace {
 
 constexpr int REMAP_PCM = 0, REMAP_PLM = 2, REMAP_PLM_HYBGEN = 3, REMAP_PPM_H4 = 4, REMAP_PPM_IH4 = 5, REMAP_PPM_HYBGEN = 6,
-              REMAP_WENO_HYBGEN = 7, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-56
-constexpr int INT_PCM = 0, INT_PLM = 1, INT_PPM = 3;            // :61-63
+              REMAP_WENO_HYBGEN = 7, REMAP_PQM_IH4IH3 = 8, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-58
+constexpr int INT_PCM = 0, INT_PLM = 1, INT_PPM = 3, INT_PQM = 5;   // :61-64
 
 __device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
 __device__ __forceinline__ double min3(double a, double b, double c) { return fmin(fmin(a, b), c); }
@@ -328,16 +328,19 @@ __global__ __launch_bounds__(64) void ale_sub_cells_kernel(SubArgs a) {
 
 struct WCol {   // LDS arrays of one column (doubles first, then shorts); the first block mirrors the structure tile's rows
   double *h_sub, *h0_eff, *h0, *u0, *EL, *ER, *C1, *u_sub, *uh_sub;
+  double *SR;                              // PQM only (xd = nz doubles more a column): the right edge slopes; the left ones live in C1
   short *isrc_end, *isrc_max, *itgt_end;   // (+ last_thick at itgt_end[nz + 1])
 };
-__host__ __device__ inline size_t wcol_doubles(int nz) { return (size_t)sub_drows(nz) + 5 * nz + 2 * (2 * nz + 2); }
-__host__ __device__ inline size_t wcol_bytes(int nz) { return (wcol_doubles(nz) * 8 + (size_t)sub_srows(nz) * 2 + 7) / 8 * 8; }
-__device__ inline WCol wcol_at(char *base, int nz) {
+__host__ __device__ inline int wcol_extra(int scheme, int nz) { return scheme == REMAP_PQM_IH4IH3 ? nz : 0; }
+__host__ __device__ inline size_t wcol_doubles(int nz, int xd) { return (size_t)sub_drows(nz) + 5 * nz + 2 * (2 * nz + 2) + xd; }
+__host__ __device__ inline size_t wcol_bytes(int nz, int xd) { return (wcol_doubles(nz, xd) * 8 + (size_t)sub_srows(nz) * 2 + 7) / 8 * 8; }
+__device__ inline WCol wcol_at(char *base, int nz, int xd) {
   WCol c;
   double *d = (double *)base;
   c.h_sub = d; d += 2 * nz + 2; c.h0_eff = d; d += nz + 1;
   c.h0 = d; d += nz; c.u0 = d; d += nz; c.EL = d; d += nz; c.ER = d; d += nz; c.C1 = d; d += nz;
   c.u_sub = d; d += 2 * nz + 2; c.uh_sub = d; d += 2 * nz + 2;
+  c.SR = d; d += xd;
   short *sh = (short *)d;
   c.isrc_end = sh; sh += nz + 1; c.isrc_max = sh; sh += nz + 1; c.itgt_end = sh;
   return c;
@@ -345,6 +348,46 @@ __device__ inline WCol wcol_at(char *base, int nz) {
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+// The quartic of a cell from its mean, width, edge values and edge slopes (PQM_functions.F90:51-55); coefficient a is the left edge value
+struct Quartic { double b, c, d, e; };
+__device__ __forceinline__ Quartic pqm_quartic(double um, double hc, double u0_l, double u0_r, double u1_l, double u1_r) {
+  Quartic q;
+  q.b = hc * u1_l;
+  q.c = 30.0 * um - 12.0 * u0_r - 18.0 * u0_l + 1.5 * hc * (u1_r - 3.0 * u1_l);
+  q.d = -60.0 * um + hc * (6.0 * u1_l - 4.0 * u1_r) + 28.0 * u0_r + 32.0 * u0_l;
+  q.e = 30.0 * um + 2.5 * hc * (u1_r - u1_l) - 15.0 * (u0_l + u0_r);
+  return q;
+}
+// 4.0 * e * (x**3) + 3.0 * d * (x**2) + 2.0 * c * x + b with the Fortran's association
+__device__ __forceinline__ double pqm_gradient(const Quartic &q, double x) {
+  return 4.0 * q.e * ((x * x) * x) + 3.0 * q.d * (x * x) + 2.0 * q.c * x + q.b;
+}
+// Does the quartic have an inflexion point inside the cell where its gradient opposes `slope`?  PQM_limiter :161-237 tests the closed
+// interval with a chain of cases (closed = true), PQM_boundary_extrapolation_v1 :597-632 the open one for each root on its own
+__device__ bool pqm_bad_inflexion(const Quartic &q, double slope, bool closed) {
+  const double alpha1 = 6 * q.e, alpha2 = 3 * q.d, alpha3 = q.c;
+  const double rho = alpha2 * alpha2 - 4.0 * alpha1 * alpha3;
+  bool bad = false;
+  if ((alpha1 != 0.0) && (rho >= 0.0)) {
+    const double sqrt_rho = sqrt(rho);
+    const double x1 = 0.5 * (-alpha2 - sqrt_rho) / alpha1;
+    const double x2 = 0.5 * (-alpha2 + sqrt_rho) / alpha1;
+    const bool in1 = closed ? ((x1 >= 0.0) && (x1 <= 1.0)) : ((x1 > 0.0) && (x1 < 1.0));
+    const bool in2 = closed ? ((x2 >= 0.0) && (x2 <= 1.0)) : ((x2 > 0.0) && (x2 < 1.0));
+    if (in1 && (pqm_gradient(q, x1) * slope < 0.0)) bad = true;
+    if (in2 && (pqm_gradient(q, x2) * slope < 0.0)) bad = true;
+  }
+  if ((alpha1 == 0.0) && (alpha2 != 0.0)) {
+    const double x1 = -alpha3 / alpha2;
+    if ((x1 >= 0.0) && (x1 <= 1.0)) {
+      // (the limiter keeps the cubic term, 4 e x^3 with e = 0; the boundary routine drops it: e = alpha1 / 6 = 0 either way, and
+      // 4.0 * 0.0 * x^3 + y = y for finite x)
+      if (pqm_gradient(q, x1) * slope < 0.0) bad = true;
+    }
+  }
+  return bad;
 }
 
 // build_reconstructions_1d across the lanes; returns the integration method (uniform over the wave).
@@ -477,8 +520,8 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     }
     wsync();
   } else
-  if (local == REMAP_PPM_IH4) {
-    // ---- PPM_IH4: edge_values_implicit_h4 (regrid_edge_values.F90:491-654, answer_date >= 20190101).  The rows of the
+  if (local == REMAP_PPM_IH4 || local == REMAP_PQM_IH4IH3) {
+    // ---- PPM_IH4, PQM_IH4IH3: edge_values_implicit_h4 (regrid_edge_values.F90:491-654, answer_date >= 20190101).  The rows of the
     // tridiagonal system across the lanes, the two closing rows on the last two lanes, solve_diag_dominant_tridiag
     // (regrid_solvers.F90:246-280) as a serial walk by one lane (the solution overwrites the right-hand side).
     const double hNeglect = h_neglect_edge;
@@ -608,7 +651,55 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     }
     wsync();
   }
-  // ---- PPM_reconstruction: bound_edge_values, check_discontinuous_edge_values, PPM_limiter_standard
+  if (local == REMAP_PQM_IH4IH3) {
+    // ---- edge_slopes_implicit_h3 (regrid_edge_values.F90:803-972, answer_date >= 20190101): the same shape of system as the edge
+    // values', with h_neglect; the left slopes go to C1 (the solver's work array until then), the right ones to SR
+    const double hNeglect = h_neglect;
+    double *tri_l = c.u_sub, *tri_c = c.u_sub + (n + 1), *tri_u = c.uh_sub, *tri_b = c.uh_sub + (n + 1), *c1 = c.C1;
+    for (int i = lane; i < n - 1; i += 64) {
+      double h0 = fmax(h[i], hNeglect);
+      double h1 = fmax(h[i + 1], hNeglect);
+      const double I_h = 1.0 / (h0 + h1);
+      h0 = h0 * I_h; h1 = h1 * I_h;
+      const double h0h1 = h0 * h1, h0_2 = h0 * h0, h1_2 = h1 * h1;
+      const double h0_3 = h0_2 * h0, h1_3 = h1_2 * h1;
+      const double I_d = 1.0 / (4.0 * h0h1 * (h0 + h1) + h1_3 + h0_3);
+      tri_l[i + 1] = (h1 * ((h0_2 + h0h1) - h1_2)) * I_d;
+      tri_c[i + 1] = 2.0 * ((h0_2 + h1_2) * (h0 + h1)) * I_d;
+      tri_u[i + 1] = (h0 * ((h1_2 + h0h1) - h0_2)) * I_d;
+      tri_b[i + 1] = 12.0 * (h0h1 * I_d) * ((u[i + 1] - u[i]) * I_h);
+    }
+    if (lane >= 62) {      // the first (lane 62) and the last (lane 63) edge slope
+      const bool last = lane == 63;
+      double dz[4], ut[4], Cs[4];
+      for (int i = 0; i < 4; i++) { const int q = last ? n - 1 - i : i; dz[i] = fmax(hNeglect, h[q]); ut[i] = u[q]; }
+      end_value_h4(dz, ut, Cs);
+      const int row = last ? n : 0;
+      tri_b[row] = last ? -Cs[1] : Cs[1]; tri_c[row] = 1.0; tri_u[row] = 0.0; tri_l[row] = 0.0;
+    }
+    wsync();
+    if (lane == 0) {      // solve_diag_dominant_tridiag
+      const int N = n + 1;
+      double I_pivot = 1.0 / (tri_c[0] + tri_u[0]);
+      double d1 = tri_c[0] * I_pivot;
+      c1[0] = tri_u[0] * I_pivot;
+      tri_b[0] = tri_b[0] * I_pivot;
+      for (int k = 1; k < N - 1; k++) {
+        const double denom_t1 = tri_c[k] + d1 * tri_l[k];
+        I_pivot = 1.0 / (denom_t1 + tri_u[k]);
+        d1 = denom_t1 * I_pivot;
+        c1[k] = tri_u[k] * I_pivot;
+        tri_b[k] = (tri_b[k] - tri_l[k] * tri_b[k - 1]) * I_pivot;
+      }
+      I_pivot = 1.0 / (tri_c[N - 1] + d1 * tri_l[N - 1]);
+      tri_b[N - 1] = (tri_b[N - 1] - tri_l[N - 1] * tri_b[N - 2]) * I_pivot;
+      for (int k = N - 2; k >= 0; k--) tri_b[k] = tri_b[k] - c1[k] * tri_b[k + 1];
+    }
+    wsync();
+    for (int k = lane; k < n; k += 64) { c.C1[k] = tri_b[k]; c.SR[k] = tri_b[k + 1]; }
+    wsync();
+  }
+  // ---- PPM_reconstruction / PQM_limiter: bound_edge_values, check_discontinuous_edge_values, then the scheme's limiter
   for (int k = lane; k < n; k += 64) {
     const int km1 = (k - 1 > 0) ? k - 1 : 0, kp1 = (k + 1 < n - 1) ? k + 1 : n - 1;
     double slope_x_h = 0.0;
@@ -634,6 +725,138 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     }
   }
   wsync();
+  if (local == REMAP_PQM_IH4IH3) {
+    // ---- PQM_limiter (PQM_functions.F90:103-337): a cell reads its own edge values and slopes and its neighbours' means and widths
+    const double hNeglect = h_neglect;
+    double *SL = c.C1, *SR = c.SR;
+    for (int k = lane; k < n; k += 64) {
+      double u0_l = u[k], u0_r = u[k], u1_l = 0.0, u1_r = 0.0;      // the boundary cells :331-335
+      if (k >= 1 && k < n - 1) {
+        u0_l = EL[k]; u0_r = ER[k]; u1_l = SL[k]; u1_r = SR[k];
+        const double h_l = h[k - 1], h_c = h[k], h_r = h[k + 1];
+        const double u_l = u[k - 1], u_c = u[k], u_r = u[k + 1];
+        const double sigma_l = 2.0 * (u_c - u_l) / (h_c + hNeglect);
+        const double sigma_c = 2.0 * (u_r - u_l) / (h_l + 2.0 * h_c + h_r + hNeglect);
+        const double sigma_r = 2.0 * (u_r - u_c) / (h_c + hNeglect);
+        double slope = 0.0;
+        if ((sigma_l * sigma_r) > 0.0) slope = fsign(min3(fabs(sigma_l), fabs(sigma_c), fabs(sigma_r)), sigma_c);
+        if (u1_l * slope <= 0.0) u1_l = slope;
+        if (u1_r * slope <= 0.0) u1_r = slope;
+        int inflexion = 0;      // 1: collapse the inflexion points onto the left edge, 2: onto the right edge
+        if ((u0_r - u_c) * (u_c - u0_l) <= 0.0) {      // a local extremum: flat
+          u0_l = u_c; u0_r = u_c; u1_l = 0.0; u1_r = 0.0;
+        } else if (pqm_bad_inflexion(pqm_quartic(u_c, h_c, u0_l, u0_r, u1_l, u1_r), slope, true)) {
+          inflexion = (fabs(sigma_l) < fabs(sigma_r)) ? 1 : 2;
+        }
+        if (inflexion == 1) {
+          u1_l = (10.0 * u_c - 2.0 * u0_r - 8.0 * u0_l) / (3.0 * h_c + hNeglect);
+          u1_r = (-10.0 * u_c + 6.0 * u0_r + 4.0 * u0_l) / (h_c + hNeglect);
+          if (u1_l * slope < 0.0) {
+            u1_l = 0.0;
+            u0_r = 5.0 * u_c - 4.0 * u0_l;
+            u1_r = 20.0 * (u_c - u0_l) / (h_c + hNeglect);
+          } else if (u1_r * slope < 0.0) {
+            u1_r = 0.0;
+            u0_l = (5.0 * u_c - 3.0 * u0_r) / 2.0;
+            u1_l = 10.0 * (-u_c + u0_r) / (3.0 * h_c + hNeglect);
+          }
+        } else if (inflexion == 2) {
+          u1_r = (-10.0 * u_c + 8.0 * u0_r + 2.0 * u0_l) / (3.0 * h_c + hNeglect);
+          u1_l = (10.0 * u_c - 4.0 * u0_r - 6.0 * u0_l) / (h_c + hNeglect);
+          if (u1_l * slope < 0.0) {
+            u1_l = 0.0;
+            u0_r = (5.0 * u_c - 3.0 * u0_l) / 2.0;
+            u1_r = 10.0 * (u_c - u0_l) / (3.0 * h_c + hNeglect);
+          } else if (u1_r * slope < 0.0) {
+            u1_r = 0.0;
+            u0_l = 5.0 * u_c - 4.0 * u0_r;
+            u1_l = 20.0 * (-u_c + u0_r) / (h_c + hNeglect);
+          }
+        }
+      }
+      EL[k] = u0_l; ER[k] = u0_r; SL[k] = u1_l; SR[k] = u1_r;
+    }
+    wsync();
+    if (extrap && lane >= 62) {      // PQM_boundary_extrapolation_v1 (PQM_functions.F90:502-831): lane 62 the top cell, lane 63 the bottom cell
+      const bool bottom = lane == 63;
+      double u0_l, u0_r, u1_l, u1_r, slope, um, hb;
+      if (!bottom) {
+        const double h0 = h[0], h1 = h[1], u0 = u[0], u1 = u[1];
+        um = u0; hb = h0;
+        slope = 2.0 * (u1 - u0) / ((h0 + h1) + hNeglect);
+        slope = slope * h0;
+        u0_r = EL[1];                                   // ppoly_coef(i1,1)
+        u1_r = (h1 * SL[1]) / (h1 + hNeglect);          // ppoly_coef(i1,2) / (h1 + hNeglect)
+        double beta = 0.;
+        if (u1_r != 0.) beta = 2.0 * (u0_r - um) / ((h0 + hNeglect) * u1_r) - 1.0;
+        const double br = u0_r + beta * u0_r - um;
+        const double ar = um + beta * um - br;
+        u0_l = ar;
+        const double u_plm = um - 0.5 * slope;
+        if (fabs(um - u0_l) < fabs(um - u_plm)) {
+          u1_l = 2.0 * (br - ar * beta);
+          u1_l = u1_l / (h0 + hNeglect);
+        } else {
+          u0_l = u_plm;
+          u1_l = slope / (h0 + hNeglect);
+        }
+        if (pqm_bad_inflexion(pqm_quartic(um, h0, u0_l, u0_r, u1_l, u1_r), slope, false)) {
+          u1_l = (10.0 * um - 2.0 * u0_r - 8.0 * u0_l) / (3.0 * h0 + hNeglect);
+          u1_r = (-10.0 * um + 6.0 * u0_r + 4.0 * u0_l) / (h0 + hNeglect);
+          if (u1_l * slope < 0.0) {
+            u1_l = 0.0;
+            u0_r = 5.0 * um - 4.0 * u0_l;
+            u1_r = 20.0 * (um - u0_l) / (h0 + hNeglect);
+          } else if (u1_r * slope < 0.0) {
+            u1_r = 0.0;
+            u0_l = (5.0 * um - 3.0 * u0_r) / 2.0;
+            u1_l = 10.0 * (-um + u0_r) / (3.0 * h0 + hNeglect);
+          }
+        }
+      } else {
+        const int i0 = n - 2, i1 = n - 1;
+        const double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1];
+        um = u1; hb = h1;
+        slope = 2.0 * (u1 - u0) / (h0 + h1);
+        slope = slope * h1;
+        const Quartic q0 = pqm_quartic(u0, h0, EL[i0], ER[i0], SL[i0], SR[i0]);      // ppoly_coef(i0,:), a = EL[i0]
+        u0_l = EL[i0] + q0.b + q0.c + q0.d + q0.e;
+        u1_l = (q0.b + 2 * q0.c + 3 * q0.d + 4 * q0.e) / h0;
+        double beta = 0.;
+        if (um - u0_l != 0.) beta = 0.5 * h1 * u1_l / (um - u0_l) - 1.0;
+        const double br = beta * um + um - u0_l;
+        const double ar = u0_l;
+        if (1 + beta != 0.) u0_r = (ar + 2 * br + beta * br) / ((1 + beta) * (1 + beta));
+        else u0_r = um + 0.5 * slope;
+        const double u_plm = um + 0.5 * slope;
+        if (fabs(um - u0_r) < fabs(um - u_plm)) {
+          u1_r = 2.0 * (br - ar * beta) / ((1 + beta) * (1 + beta) * (1 + beta));
+          u1_r = u1_r / h1;
+        } else {
+          u0_r = u_plm;
+          u1_r = slope / h1;
+        }
+        if (pqm_bad_inflexion(pqm_quartic(um, h1, u0_l, u0_r, u1_l, u1_r), slope, false)) {
+          u1_r = (-10.0 * um + 8.0 * u0_r + 2.0 * u0_l) / (3.0 * h1);
+          u1_l = (10.0 * um - 4.0 * u0_r - 6.0 * u0_l) / h1;
+          if (u1_l * slope < 0.0) {
+            u1_l = 0.0;
+            u0_r = (5.0 * um - 3.0 * u0_l) / 2.0;
+            u1_r = 10.0 * (um - u0_l) / (3.0 * h1);
+          } else if (u1_r * slope < 0.0) {
+            u1_r = 0.0;
+            u0_l = 5.0 * um - 4.0 * u0_r;
+            u1_l = 20.0 * (-um + u0_r) / h1;
+          }
+        }
+      }
+      (void)hb;
+      const int kb = bottom ? n - 1 : 0;      // (the two lanes read cells 1 and n-2 and write cells 0 and n-1: n >= 5 here)
+      EL[kb] = u0_l; ER[kb] = u0_r; SL[kb] = u1_l; SR[kb] = u1_r;
+    }
+    wsync();
+    return INT_PQM;
+  }
   for (int k = lane; k < n; k += 64) {
     double edge_l, edge_r;
     if (k >= 1 && k < n - 1) {
@@ -698,6 +921,18 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
 
 // average_value_ppoly :998-1099 on the LDS column
 __device__ __forceinline__ double w_average_value_ppoly(const WCol &c, int method, int i0, double xa, double xb) {
+  if (method == INT_PQM) {      // the quartic's coefficients from the cell's edge values and slopes, by the expressions that define them
+    const double a = c.EL[i0];
+    const Quartic q = pqm_quartic(c.u0[i0], c.h0[i0], a, c.ER[i0], c.C1[i0], c.SR[i0]);
+    if (xb > xa) {
+      const double r_3 = 1.0 / 3.0;
+      const double xa_2 = xa * xa, xb_2 = xb * xb;
+      const double xa2pxb2 = xa_2 + xb_2, xapxb = xa + xb;
+      return (a + (q.b * 0.5 * (xapxb) + (q.c * r_3 * (xa2pxb2 + xa * xb) + (q.d * 0.25 * (xa2pxb2 * xapxb) +
+                                                                             q.e * 0.2 * ((xb * xb_2 + xa * xa_2) * xapxb + xa_2 * xb_2)))));
+    }
+    return a + xa * (q.b + xa * (q.c + xa * (q.d + xa * q.e)));
+  }
   if (xb > xa) {
     if (method == INT_PCM) return c.u0[i0];
     if (method == INT_PLM) return (c.EL[i0] + c.C1[i0] * 0.5 * (xb + xa));
@@ -1272,8 +1507,9 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
     const double m = a.pos == MOM6HIP_POS_U ? g.mask2dCu[n2] : (a.pos == MOM6HIP_POS_V ? g.mask2dCv[n2] : g.mask2dT[n2]);
     return m > 0.;
   };
-  const size_t cb = wcol_bytes(nz);
-  const WCol c = wcol_at(wsm + cb * wv, nz);
+  const int xd = wcol_extra(a.scheme, nz);
+  const size_t cb = wcol_bytes(nz, xd);
+  const WCol c = wcol_at(wsm + cb * wv, nz, xd);
   const bool mine = active(i_first + wv);
   const int nd = sub_drows(nz), nsr = sub_srows(nz);
 
@@ -1285,7 +1521,7 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
     for (int t = threadIdx.x; t < nd * WR_NCOL; t += 64 * WR_NCOL)
       ((double *)(wsm + cb * (t % WR_NCOL)))[t / WR_NCOL] = td[t];
     const short *ts = (const short *)(td + (size_t)nd * WR_NCOL);
-    const size_t soff = wcol_doubles(nz) * 8;
+    const size_t soff = wcol_doubles(nz, xd) * 8;
     for (int t = threadIdx.x; t < nsr * WR_NCOL; t += 64 * WR_NCOL)
       ((short *)(wsm + cb * (t % WR_NCOL) + soff))[t / WR_NCOL] = ts[t];
   }
@@ -1319,7 +1555,7 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
 bool scheme_provided(int scheme) {
   if (scheme == REMAP_PCM || scheme == REMAP_PLM || scheme == REMAP_PPM_H4) return true;
   return (scheme == REMAP_PPM_IH4 || scheme == REMAP_PPM_CW || scheme == REMAP_PLM_HYBGEN || scheme == REMAP_PPM_HYBGEN ||
-          scheme == REMAP_WENO_HYBGEN);
+          scheme == REMAP_WENO_HYBGEN || scheme == REMAP_PQM_IH4IH3);
 }
 
 // MOM6HIP_ALE_STREAM: 0 = never the streaming kernel; 1 = one field a launch; 2 (default) = two fields a launch (read at every
@@ -1349,7 +1585,7 @@ int launch_wave_remap(mom6hip_ctx_t *ctx, WRemapArgs a) {
     M6_HIP(hipGetLastError());
     return 0;
   }
-  const size_t lds = wcol_bytes(g.nk) * WR_NCOL;
+  const size_t lds = wcol_bytes(g.nk, wcol_extra(a.scheme, g.nk)) * WR_NCOL;
   M6_REQUIRE(lds <= 160 * 1024, "ALE remap: too many layers for the LDS-resident kernel");
   std::vector<const void *> &configured = ctx->lds_configured;      // the attribute is per device: kept with the context
   if (std::find(configured.begin(), configured.end(), (const void *)ale_remap_wave_kernel) == configured.end()) {
@@ -1380,7 +1616,7 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
   M6_REQUIRE(tr != nullptr && ntr <= 64, "ALE_remap_tracers: bad tracer list");
   M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN and PPM_CW)");
+             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW and PQM_IH4IH3)");
   M6_REQUIRE(cs->answer_date >= 20190101, "ALE_remap_tracers: only REMAPPING_ANSWER_DATE >= 20190101 is provided");
   M6_REQUIRE(!cs->force_bounds_in_subcell, "ALE_remap_tracers: REMAP_BOUND_INTERMEDIATE_VALUES is not provided");
   M6_REQUIRE(ctx->g.mask2dT != nullptr, "ALE_remap_tracers: mask2dT is required");
@@ -1501,7 +1737,7 @@ extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_re
   M6_REQUIRE(ctx && cs && h_old_u && h_old_v && h_new_u && h_new_v && u && v, "ALE_remap_velocities: null argument");
   M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN and PPM_CW)");
+             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW and PQM_IH4IH3)");
   M6_REQUIRE(cs->answer_date >= 20190101 && !cs->force_bounds_in_subcell, "ALE_remap_velocities: unsupported remapping options");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.nk <= 128 && g.mask2dCu && g.mask2dCv, "ALE_remap_velocities: at most 128 layers; face masks are needed");

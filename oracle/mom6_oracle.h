@@ -111,9 +111,11 @@ int orc_advect_tracer_obc(const mom6hip_grid_t *G, const double *h_end, const do
 #define ORC_REMAP_WENO_HYBGEN 7
 #define ORC_REMAP_PPM_IH4 5
 #define ORC_REMAP_PPM_CW  10
+#define ORC_REMAP_PQM_IH4IH3 8
 #define ORC_INT_PCM 0
 #define ORC_INT_PLM 1
 #define ORC_INT_PPM 3
+#define ORC_INT_PQM 5
 /* E(k,1:2) and coef(k,1:3) are Fortran-ordered: E[side*n + k], coef[d*n + k]. */
 void orc_pcm_reconstruction(int n, const double *u, double *E, double *coef);
 double orc_plm_slope_wa(double h_l, double h_c, double h_r, double h_neglect, double u_l, double u_c, double u_r);
@@ -140,6 +142,10 @@ double orc_average_value_ppoly(int n, const double *u0, const double *E, const d
 void orc_remap_via_sub_cells(int n0, const double *h0, const double *u0, const double *E, const double *coef,
                              int n1, const double *h1, int method, int force_bounds_in_subcell,
                              double *u1, double *uh_err);
+void orc_edge_slopes_implicit_h3(int n, const double *h, const double *u, double *S, double h_neglect);
+void orc_pqm_limiter(int n, const double *h, const double *u, double *E, double *S, double h_neglect);
+void orc_pqm_reconstruction(int n, const double *h, const double *u, double *E, double *S, double *coef, double h_neglect);
+void orc_pqm_boundary_extrapolation_v1(int n, const double *h, const double *u, double *E, double *S, double *coef, double h_neglect);
 int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                                  double *coef, double *E, double h_neglect, double h_neglect_edge);
 int orc_remapping_core_h(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,

@@ -467,8 +467,275 @@ void orc_ppm_boundary_extrapolation(int n, const double *h, const double *u, dou
   C_(coef,i1,2) = 3.0 * ( u0_r + u0_l - 2.0 * u1 );
 }
 
+/* ---- PQM (piecewise quartic method) -------------------------------------------------------- */
+/* edge_slopes_implicit_h3 (answer_date >= 20190101), regrid_edge_values.F90:803-972.  S(k,1:2) stored like E.  n >= 4. */
+void orc_edge_slopes_implicit_h3(int n, const double *h, const double *u, double *S, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  const int m = n + 1;
+  double *tri_l = (double*)calloc(5*(size_t)m, sizeof(double));
+  double *tri_c = tri_l + m, *tri_u = tri_c + m, *tri_b = tri_u + m, *tri_x = tri_b + m;
+  for (int i = 0; i < n-1; i++) {            /* Fortran i = 1..N-1; row i+1 */
+    double h0 = max2(h[i], hNeglect);
+    double h1 = max2(h[i+1], hNeglect);
+    const double I_h = 1.0 / (h0 + h1);
+    h0 = h0 * I_h; h1 = h1 * I_h;
+    const double h0h1 = h0 * h1, h0_2 = h0 * h0, h1_2 = h1 * h1;
+    const double h0_3 = h0_2 * h0, h1_3 = h1_2 * h1;
+    const double I_d = 1.0 / (4.0 * h0h1 * ( h0 + h1 ) + h1_3 + h0_3);
+    tri_l[i+1] = (h1 * ((h0_2 + h0h1) - h1_2)) * I_d;
+    tri_c[i+1] = 2.0 * ((h0_2 + h1_2) * (h0 + h1)) * I_d;
+    tri_u[i+1] = (h0 * ((h1_2 + h0h1) - h0_2)) * I_d;
+    tri_b[i+1] = 12.0 * (h0h1 * I_d) * ((u[i+1] - u[i]) * I_h);
+  }
+  double dz[4], ut[4], C[4];
+  for (int i = 0; i < 4; i++) { dz[i] = max2(hNeglect, h[i]); ut[i] = u[i]; }
+  orc_end_value_h4(dz, ut, C);
+  tri_b[0] = C[1]; tri_c[0] = 1.0; tri_u[0] = 0.0;
+  for (int i = 0; i < 4; i++) { dz[i] = max2(hNeglect, h[n-1-i]); ut[i] = u[n-1-i]; }
+  orc_end_value_h4(dz, ut, C);
+  tri_b[n] = -C[1]; tri_c[n] = 1.0; tri_l[n] = 0.0;
+  orc_solve_diag_dominant_tridiag(tri_l, tri_c, tri_u, tri_b, tri_x, m);
+  for (int i = 1; i < n; i++) { E_(S,i,0) = tri_x[i]; E_(S,i-1,1) = tri_x[i]; }
+  E_(S,0,0) = tri_x[0];
+  E_(S,n-1,1) = tri_x[n];
+  free(tri_l);
+}
+
+/* The quartic of a cell from its edge values, edge slopes and mean (PQM_functions.F90:51-55, :150-154, :585-589, ...) */
+static inline void pqm_quartic(double um, double hc, double u0_l, double u0_r, double u1_l, double u1_r,
+                               double *a, double *b, double *c, double *d, double *e)
+{
+  *a = u0_l;
+  *b = hc * u1_l;
+  *c = 30.0 * um - 12.0*u0_r - 18.0*u0_l + 1.5*hc*(u1_r - 3.0*u1_l);
+  *d = -60.0 * um + hc *(6.0*u1_l - 4.0*u1_r) + 28.0*u0_r + 32.0*u0_l;
+  *e = 30.0 * um + 2.5*hc*(u1_r - u1_l) - 15.0*(u0_l + u0_r);
+}
+/* 4.0 * e * (x**3) + 3.0 * d * (x**2) + 2.0 * c * x + b, as the Fortran associates it */
+static inline double pqm_gradient(double b, double c, double d, double e, double x)
+{
+  return 4.0 * e * ((x*x)*x) + 3.0 * d * (x*x) + 2.0 * c * x + b;
+}
+
+/* PQM_limiter, PQM_functions.F90:75-337 (answer_date >= 20190101 in bound_edge_values) */
+void orc_pqm_limiter(int n, const double *h, const double *u, double *E, double *S, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  orc_bound_edge_values(n, h, u, E);
+  orc_check_discontinuous_edge_values(n, u, E);
+  for (int k = 1; k < n-1; k++) {
+    int inflexion_l = 0, inflexion_r = 0;
+    double u0_l = E_(E,k,0), u0_r = E_(E,k,1), u1_l = E_(S,k,0), u1_r = E_(S,k,1);
+    const double h_l = h[k-1], h_c = h[k], h_r = h[k+1];
+    const double u_l = u[k-1], u_c = u[k], u_r = u[k+1];
+    const double sigma_l = 2.0 * ( u_c - u_l ) / ( h_c + hNeglect );
+    const double sigma_c = 2.0 * ( u_r - u_l ) / ( h_l + 2.0*h_c + h_r + hNeglect );
+    const double sigma_r = 2.0 * ( u_r - u_c ) / ( h_c + hNeglect );
+    double slope;
+    if ( (sigma_l * sigma_r) > 0.0 ) slope = fsign( min3(fabs(sigma_l),fabs(sigma_c),fabs(sigma_r)), sigma_c );
+    else slope = 0.0;
+    if ( u1_l*slope <= 0.0 ) u1_l = slope;
+    if ( u1_r*slope <= 0.0 ) u1_r = slope;
+    if ( (u0_r - u_c) * (u_c - u0_l) <= 0.0) {      /* local extremum: flatten */
+      u0_l = u_c; u0_r = u_c; u1_l = 0.0; u1_r = 0.0;
+      inflexion_l = -1; inflexion_r = -1;
+    }
+    if ( (inflexion_l == 0) && (inflexion_r == 0) ) {
+      double a, b, c, d, e;
+      pqm_quartic(u[k], h_c, u0_l, u0_r, u1_l, u1_r, &a, &b, &c, &d, &e);
+      const double alpha1 = 6*e, alpha2 = 3*d, alpha3 = c;
+      const double rho = alpha2 * alpha2 - 4.0 * alpha1 * alpha3;
+      int bad = 0;
+      if (( alpha1 != 0.0 ) && ( rho >= 0.0 )) {
+        const double sqrt_rho = sqrt( rho );
+        const double x1 = 0.5 * ( - alpha2 - sqrt_rho ) / alpha1;
+        const double x2 = 0.5 * ( - alpha2 + sqrt_rho ) / alpha1;
+        const int in1 = (x1 >= 0.0) && (x1 <= 1.0), in2 = (x2 >= 0.0) && (x2 <= 1.0);
+        if (in1 && in2) {
+          const double gradient1 = pqm_gradient(b, c, d, e, x1), gradient2 = pqm_gradient(b, c, d, e, x2);
+          if ( (gradient1 * slope < 0.0) || (gradient2 * slope < 0.0) ) bad = 1;
+        } else if (in1) {
+          if ( pqm_gradient(b, c, d, e, x1) * slope < 0.0 ) bad = 1;
+        } else if (in2) {
+          if ( pqm_gradient(b, c, d, e, x2) * slope < 0.0 ) bad = 1;
+        }
+        if (bad) { if ( fabs(sigma_l) < fabs(sigma_r) ) inflexion_l = 1; else inflexion_r = 1; }
+      }
+      if (( alpha1 == 0.0 ) && ( alpha2 != 0.0 )) {      /* the second derivative is a straight line */
+        const double x1 = - alpha3 / alpha2;
+        if ( (x1 >= 0.0) && (x1 <= 1.0) ) {
+          if ( pqm_gradient(b, c, d, e, x1) * slope < 0.0 ) {
+            if ( fabs(sigma_l) < fabs(sigma_r) ) inflexion_l = 1; else inflexion_r = 1;
+          }
+        }
+      }
+    }
+    if ( inflexion_l == 1 ) {      /* both inflexion points collapse onto the left edge */
+      u1_l = ( 10.0 * u_c - 2.0 * u0_r - 8.0 * u0_l ) / (3.0*h_c + hNeglect );
+      u1_r = ( -10.0 * u_c + 6.0 * u0_r + 4.0 * u0_l ) / ( h_c + hNeglect );
+      if ( u1_l * slope < 0.0 ) {
+        u1_l = 0.0;
+        u0_r = 5.0 * u_c - 4.0 * u0_l;
+        u1_r = 20.0 * (u_c - u0_l) / ( h_c + hNeglect );
+      } else if ( u1_r * slope < 0.0 ) {
+        u1_r = 0.0;
+        u0_l = (5.0*u_c - 3.0*u0_r) / 2.0;
+        u1_l = 10.0 * (-u_c + u0_r) / (3.0 * h_c + hNeglect);
+      }
+    } else if ( inflexion_r == 1 ) {      /* onto the right edge */
+      u1_r = ( -10.0 * u_c + 8.0 * u0_r + 2.0 * u0_l ) / (3.0 * h_c + hNeglect);
+      u1_l = ( 10.0 * u_c - 4.0 * u0_r - 6.0 * u0_l ) / (h_c + hNeglect);
+      if ( u1_l * slope < 0.0 ) {
+        u1_l = 0.0;
+        u0_r = ( 5.0 * u_c - 3.0 * u0_l ) / 2.0;
+        u1_r = 10.0 * (u_c - u0_l) / (3.0 * h_c + hNeglect);
+      } else if ( u1_r * slope < 0.0 ) {
+        u1_r = 0.0;
+        u0_l = 5.0 * u_c - 4.0 * u0_r;
+        u1_l = 20.0 * ( -u_c + u0_r ) / (h_c + hNeglect);
+      }
+    }
+    E_(E,k,0) = u0_l; E_(E,k,1) = u0_r; E_(S,k,0) = u1_l; E_(S,k,1) = u1_r;
+  }
+  E_(E,0,0) = u[0]; E_(E,0,1) = u[0]; E_(S,0,0) = 0.0; E_(S,0,1) = 0.0;
+  E_(E,n-1,0) = u[n-1]; E_(E,n-1,1) = u[n-1]; E_(S,n-1,0) = 0.0; E_(S,n-1,1) = 0.0;
+}
+
+/* PQM_reconstruction, PQM_functions.F90:20-66.  coef holds 5*n doubles. */
+void orc_pqm_reconstruction(int n, const double *h, const double *u, double *E, double *S, double *coef, double h_neglect)
+{
+  orc_pqm_limiter(n, h, u, E, S, h_neglect);
+  for (int k = 0; k < n; k++)
+    pqm_quartic(u[k], h[k], E_(E,k,0), E_(E,k,1), E_(S,k,0), E_(S,k,1),
+                &C_(coef,k,0), &C_(coef,k,1), &C_(coef,k,2), &C_(coef,k,3), &C_(coef,k,4));
+}
+
+/* PQM_boundary_extrapolation_v1, PQM_functions.F90:502-831 */
+void orc_pqm_boundary_extrapolation_v1(int n, const double *h, const double *u, double *E, double *S, double *coef, double h_neglect)
+{
+  const double hNeglect = h_neglect;
+  double a, b, c, d, e;
+  /* ----- left boundary (top) ----- */
+  {
+    const int i0 = 0, i1 = 1;
+    const double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1], um = u0;
+    double slope = 2.0 * ( u1 - u0 ) / ( ( h0 + h1 ) + hNeglect );
+    slope = slope * h0;
+    a = C_(coef,i1,0); b = C_(coef,i1,1);
+    double u0_r = a;
+    double u1_r = b / (h1 + hNeglect);
+    double beta;
+    if (u1_r != 0.) beta = 2.0 * ( u0_r - um ) / ( (h0 + hNeglect)*u1_r) - 1.0;
+    else beta = 0.;
+    const double br = u0_r + beta*u0_r - um;
+    const double ar = um + beta*um - br;
+    double u0_l = ar, u1_l;
+    const double u_plm = um - 0.5 * slope;
+    if ( fabs(um-u0_l) < fabs(um-u_plm) ) {
+      u1_l = 2.0 * ( br - ar*beta);
+      u1_l = u1_l / (h0 + hNeglect);
+    } else {
+      u0_l = u_plm;
+      u1_l = slope / (h0 + hNeglect);
+    }
+    int inflexion_l = 0;
+    pqm_quartic(um, h0, u0_l, u0_r, u1_l, u1_r, &a, &b, &c, &d, &e);
+    const double alpha1 = 6*e, alpha2 = 3*d, alpha3 = c;
+    const double rho = alpha2 * alpha2 - 4.0 * alpha1 * alpha3;
+    if (( alpha1 != 0.0 ) && ( rho >= 0.0 )) {
+      const double sqrt_rho = sqrt( rho );
+      const double x1 = 0.5 * ( - alpha2 - sqrt_rho ) / alpha1;
+      if ( (x1 > 0.0) && (x1 < 1.0) ) { if ( pqm_gradient(b, c, d, e, x1) * slope < 0.0 ) inflexion_l = 1; }
+      const double x2 = 0.5 * ( - alpha2 + sqrt_rho ) / alpha1;
+      if ( (x2 > 0.0) && (x2 < 1.0) ) { if ( pqm_gradient(b, c, d, e, x2) * slope < 0.0 ) inflexion_l = 1; }
+    }
+    if (( alpha1 == 0.0 ) && ( alpha2 != 0.0 )) {
+      const double x1 = - alpha3 / alpha2;
+      if ( (x1 >= 0.0) && (x1 <= 1.0) ) {
+        const double gradient1 = 3.0 * d * (x1*x1) + 2.0 * c * x1 + b;
+        if ( gradient1 * slope < 0.0 ) inflexion_l = 1;
+      }
+    }
+    if ( inflexion_l == 1 ) {
+      u1_l = ( 10.0 * um - 2.0 * u0_r - 8.0 * u0_l ) / (3.0*h0 + hNeglect);
+      u1_r = ( -10.0 * um + 6.0 * u0_r + 4.0 * u0_l ) / (h0 + hNeglect);
+      if ( u1_l * slope < 0.0 ) {
+        u1_l = 0.0;
+        u0_r = 5.0 * um - 4.0 * u0_l;
+        u1_r = 20.0 * (um - u0_l) / ( h0 + hNeglect );
+      } else if ( u1_r * slope < 0.0 ) {
+        u1_r = 0.0;
+        u0_l = (5.0*um - 3.0*u0_r) / 2.0;
+        u1_l = 10.0 * (-um + u0_r) / (3.0 * h0 + hNeglect );
+      }
+    }
+    E_(E,i0,0) = u0_l; E_(E,i0,1) = u0_r; E_(S,i0,0) = u1_l; E_(S,i0,1) = u1_r;
+    pqm_quartic(um, h0, u0_l, u0_r, u1_l, u1_r, &C_(coef,i0,0), &C_(coef,i0,1), &C_(coef,i0,2), &C_(coef,i0,3), &C_(coef,i0,4));
+  }
+  /* ----- right boundary (bottom) ----- */
+  {
+    const int i0 = n-2, i1 = n-1;
+    const double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1], um = u1;
+    double slope = 2.0 * ( u1 - u0 ) / ( h0 + h1 );
+    slope = slope * h1;
+    a = C_(coef,i0,0); b = C_(coef,i0,1); c = C_(coef,i0,2); d = C_(coef,i0,3); e = C_(coef,i0,4);
+    double u0_l = a + b + c + d + e;
+    double u1_l = (b + 2*c + 3*d + 4*e) / h0;
+    double beta;
+    if (um-u0_l != 0.) beta = 0.5*h1*u1_l / (um-u0_l) - 1.0;
+    else beta = 0.;
+    const double br = beta*um + um - u0_l;
+    const double ar = u0_l;
+    double u0_r, u1_r;
+    if (1+beta != 0.) u0_r = (ar + 2*br + beta*br ) / ((1+beta)*(1+beta));
+    else u0_r = um + 0.5 * slope;
+    const double u_plm = um + 0.5 * slope;
+    if ( fabs(um-u0_r) < fabs(um-u_plm) ) {
+      u1_r = 2.0 * ( br - ar*beta ) / ( (1+beta)*(1+beta)*(1+beta) );
+      u1_r = u1_r / h1;
+    } else {
+      u0_r = u_plm;
+      u1_r = slope / h1;
+    }
+    int inflexion_r = 0;
+    pqm_quartic(um, h1, u0_l, u0_r, u1_l, u1_r, &a, &b, &c, &d, &e);
+    const double alpha1 = 6*e, alpha2 = 3*d, alpha3 = c;
+    const double rho = alpha2 * alpha2 - 4.0 * alpha1 * alpha3;
+    if (( alpha1 != 0.0 ) && ( rho >= 0.0 )) {
+      const double sqrt_rho = sqrt( rho );
+      const double x1 = 0.5 * ( - alpha2 - sqrt_rho ) / alpha1;
+      if ( (x1 > 0.0) && (x1 < 1.0) ) { if ( pqm_gradient(b, c, d, e, x1) * slope < 0.0 ) inflexion_r = 1; }
+      const double x2 = 0.5 * ( - alpha2 + sqrt_rho ) / alpha1;
+      if ( (x2 > 0.0) && (x2 < 1.0) ) { if ( pqm_gradient(b, c, d, e, x2) * slope < 0.0 ) inflexion_r = 1; }
+    }
+    if (( alpha1 == 0.0 ) && ( alpha2 != 0.0 )) {
+      const double x1 = - alpha3 / alpha2;
+      if ( (x1 >= 0.0) && (x1 <= 1.0) ) {
+        const double gradient1 = 3.0 * d * (x1*x1) + 2.0 * c * x1 + b;
+        if ( gradient1 * slope < 0.0 ) inflexion_r = 1;
+      }
+    }
+    if ( inflexion_r == 1 ) {
+      u1_r = ( -10.0 * um + 8.0 * u0_r + 2.0 * u0_l ) / (3.0 * h1);
+      u1_l = ( 10.0 * um - 4.0 * u0_r - 6.0 * u0_l ) / h1;
+      if ( u1_l * slope < 0.0 ) {
+        u1_l = 0.0;
+        u0_r = ( 5.0 * um - 3.0 * u0_l ) / 2.0;
+        u1_r = 10.0 * (um - u0_l) / (3.0 * h1);
+      } else if ( u1_r * slope < 0.0 ) {
+        u1_r = 0.0;
+        u0_l = 5.0 * um - 4.0 * u0_r;
+        u1_l = 20.0 * ( -um + u0_r ) / h1;
+      }
+    }
+    E_(E,i1,0) = u0_l; E_(E,i1,1) = u0_r; E_(S,i1,0) = u1_l; E_(S,i1,1) = u1_r;
+    pqm_quartic(um, h1, u0_l, u0_r, u1_l, u1_r, &C_(coef,i1,0), &C_(coef,i1,1), &C_(coef,i1,2), &C_(coef,i1,3), &C_(coef,i1,4));
+  }
+}
+
 /* ---- remapping ---------------------------------------------------------------------------- */
-/* average_value_ppoly, MOM_remapping.F90:998-1099 (method: ORC_INT_PCM/PLM/PPM; i0 0-based) */
+/* average_value_ppoly, MOM_remapping.F90:998-1099 (method: ORC_INT_PCM/PLM/PPM/PQM; i0 0-based) */
 double orc_average_value_ppoly(int n, const double *u0, const double *E, const double *coef, int method,
                                int i0, double xa, double xb)
 {
@@ -478,6 +745,15 @@ double orc_average_value_ppoly(int n, const double *u0, const double *E, const d
       u_ave = u0[i0];
     } else if (method == ORC_INT_PLM) {
       u_ave = ( C_(coef,i0,0) + C_(coef,i0,1) * 0.5 * ( xb + xa ) );
+    } else if (method == ORC_INT_PQM) {
+      const double r_3 = 1.0/3.0;
+      const double xa_2 = xa*xa, xb_2 = xb*xb;
+      const double xa2pxb2 = xa_2 + xb_2, xapxb = xa + xb;
+      u_ave = ( C_(coef,i0,0)
+          + ( C_(coef,i0,1) * 0.5 * ( xapxb )
+          + ( C_(coef,i0,2) * r_3 * ( xa2pxb2 + xa*xb )
+          + ( C_(coef,i0,3) * 0.25* ( xa2pxb2 * xapxb )
+          +   C_(coef,i0,4) * 0.2 * ( ( xb*xb_2 + xa*xa_2 ) * xapxb + xa_2*xb_2 ) ) ) ) );
     } else {
       double mx = 0.5 * ( xa + xb );
       double a_L = E_(E,i0,0), a_R = E_(E,i0,1), u_c = u0[i0];
@@ -500,6 +776,8 @@ double orc_average_value_ppoly(int n, const double *u0, const double *E, const d
       double Ya = 1. - xa;
       if (xa < 0.5) u_ave = a_L + xa * ( a_R - a_L );
       else          u_ave = a_R + Ya * ( a_L - a_R );
+    } else if (method == ORC_INT_PQM) {
+      u_ave = C_(coef,i0,0) + xa * ( C_(coef,i0,1) + xa * ( C_(coef,i0,2) + xa * ( C_(coef,i0,3) + xa * C_(coef,i0,4) ) ) );
     } else {
       double a_L = E_(E,i0,0), a_R = E_(E,i0,1), u_c = u0[i0];
       double a_c = 3. * ( ( u_c - a_L ) + ( u_c - a_R ) );
@@ -802,14 +1080,14 @@ void orc_hybgen_weno_coefs(int nk, const double *s, const double *h_src, double 
 }
 
 /* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN,
- * PPM_CW; no PCM_cell).
- * E and coef must hold 2*n0 and 3*n0 doubles.  Returns the integration method. */
+ * PPM_CW, PQM_IH4IH3; no PCM_cell).
+ * E and coef must hold 2*n0 and 5*n0 doubles.  Returns the integration method. */
 int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                                  double *coef, double *E, double h_neglect, double h_neglect_edge)
 {
   const int n = n0;
   memset(E, 0, sizeof(double)*2*n0);
-  memset(coef, 0, sizeof(double)*3*n0);
+  memset(coef, 0, sizeof(double)*5*n0);
   int local = scheme;
   if (n0 <= 1) local = ORC_REMAP_PCM;
   else if (n0 <= 3) local = (local < ORC_REMAP_PLM) ? local : ORC_REMAP_PLM;
@@ -858,6 +1136,15 @@ int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0,
       orc_ppm_reconstruction(n0, h0, u0, E, coef);
       if (boundary_extrapolation) orc_ppm_boundary_extrapolation(n0, h0, u0, E, coef, h_neglect);
       return ORC_INT_PPM;
+    case ORC_REMAP_PQM_IH4IH3: {   /* :351-360 */
+      double *S = (double*)calloc((size_t)2*n0, sizeof(double));
+      orc_edge_values_implicit_h4(n0, h0, u0, E, h_neglect_edge);
+      orc_edge_slopes_implicit_h3(n0, h0, u0, S, h_neglect);
+      orc_pqm_reconstruction(n0, h0, u0, E, S, coef, h_neglect);
+      if (boundary_extrapolation) orc_pqm_boundary_extrapolation_v1(n0, h0, u0, E, S, coef, h_neglect);
+      free(S);
+      return ORC_INT_PQM;
+    }
     default:
       return -999;   /* 'The selected remapping method is invalid' */
   }
@@ -867,7 +1154,7 @@ int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0,
 int orc_remapping_core_h(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                          int n1, const double *h1, double *u1, double h_neglect, double h_neglect_edge)
 {
-  double *E = calloc((size_t)2*n0, sizeof(double)), *coef = calloc((size_t)3*n0, sizeof(double));
+  double *E = calloc((size_t)2*n0, sizeof(double)), *coef = calloc((size_t)5*n0, sizeof(double));
   int method = orc_build_reconstructions_1d(scheme, boundary_extrapolation, n0, h0, u0, coef, E, h_neglect, h_neglect_edge);
   if (method < 0) { free(E); free(coef); return 1; }
   double uh_err;

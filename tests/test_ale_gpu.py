@@ -31,11 +31,15 @@ def remap_case(ni, nj, nk, ntr=3, seed=0, vanish=0.15):
     return g, np.ascontiguousarray(h_old), np.ascontiguousarray(h_new), tr
 
 
-@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PLM_HYBGEN", "PPM_H4", "PPM_IH4", "PPM_HYBGEN", "WENO_HYBGEN", "PPM_CW"])
+@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PLM_HYBGEN", "PPM_H4", "PPM_IH4", "PPM_HYBGEN", "WENO_HYBGEN", "PPM_CW", "PQM_IH4IH3"])
 @pytest.mark.parametrize("extrap", [False, True])
-@pytest.mark.parametrize("nk", [2, 3, 4, 8, 20, 75])
+@pytest.mark.parametrize("nk", [2, 3, 4, 5, 8, 20, 75])
 def test_remap_tracers_parity(oracle, scheme, extrap, nk):
     g, h_old, h_new, tr = remap_case(70, 12, nk, seed=nk)
+    if scheme.startswith("PQM") and extrap:
+        # PQM_boundary_extrapolation_v1 divides by the widths of the two cells at the bottom (PQM_functions.F90:672, :682, :709): a vanished
+        # cell there is 0/0 in the reference too, with a NaN whose sign depends on the machine; the layers keep a minimum thickness instead
+        h_old = np.maximum(h_old, 1.0e-3)
     ref = [t.copy() for t in tr]
     oracle.ale_remap_tracers(g, scheme, h_old, h_new, ref, boundary_extrapolation=extrap)
     dg = DeviceGrid(g)
@@ -108,7 +112,7 @@ def test_remap_conserves_on_gpu(oracle):
 def test_remap_errors():
     from mom6_amd._lib import Mom6HipError
     with pytest.raises(Mom6HipError, match="REMAPPING_SCHEME"):
-        initialize_remapping("PQM_IH4IH3")
+        initialize_remapping("PQM_IH6IH5")
     g, h_old, h_new, tr = remap_case(10, 8, 4, ntr=1)
     dg = DeviceGrid(g)
     with pytest.raises(Mom6HipError, match="ANSWER_DATE"):

@@ -791,17 +791,22 @@ def ale_exe(tmp_path_factory):
 
 @pytest.mark.parametrize("scheme,vel_scheme,extrap", [("PPM_H4", "PLM", True), ("PPM_H4", "PPM_H4", False), ("PLM", "PLM", False), ("PPM_IH4", "PLM", True),
                                                       ("PCM", "PCM", False), ("PPM_CW", "PPM_CW", False), ("PPM_HYBGEN", "PLM_HYBGEN", False),
-                                                      ("WENO_HYBGEN", "PLM", False)])
+                                                      ("WENO_HYBGEN", "PLM", False), ("PQM_IH4IH3", "PQM_IH4IH3", True), ("PQM_IH4IH3", "PLM", False)])
 def test_reference_ale_regrid_and_remap_equal_the_oracle(tmp_path, ale_exe, scheme, vel_scheme, extrap):
     """ALE_init (Z*, UNIFORM resolution, REGRID_TIME_SCALE with the deep filter), ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers,
     ALE_remap_set_h_vel x2, ALE_remap_velocities of the reference's own MOM_ALE / MOM_regridding / coord_zlike / MOM_remapping, the sequence of
     MOM.F90:1647-1700: the new grid, the interface movement, the remapped T, S, u, v and the face thicknesses equal the oracle's bit for bit,
-    for the eight remapping schemes the library provides"""
+    for the nine remapping schemes the library provides"""
     from mom6_amd import synth
     from oracle import orc
-    ni, nj, nk, halo = 34, 18, 6, 4
+    ni, nj, nk, halo = 34, 18, (14 if scheme.startswith("PQM") else 6), 4
     g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=21, reentrant_x=False, reentrant_y=False)
     d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=9, umax=0.3, eta_amp=0.5).items()}
+    if scheme.startswith("PQM"):      # rough columns beside smooth ones: the limiter's inflexion branches and the boundary cells' rational functions
+        rng = np.random.default_rng(5)
+        for n, amp in (("T", 3.0), ("S", 1.0), ("u", 0.2), ("v", 0.2)):
+            col = rng.choice([0.0, 0.02, 1.0], size=d[n].shape[1:])[None]
+            d[n] = np.ascontiguousarray(d[n] + amp * col * rng.standard_normal(d[n].shape) * (d[n] != 0.0))
     dt = 1800.0
     max_depth = float(g.bathyT.max())
     with open(tmp_path / "in.bin", "wb") as f:
