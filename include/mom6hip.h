@@ -359,6 +359,7 @@ int mom6hip_advect_get_timing(mom6hip_ctx_t *ctx, mom6hip_advect_timing_t *t);
 #define MOM6HIP_REMAP_PPM_HYBGEN  6
 #define MOM6HIP_REMAP_WENO_HYBGEN 7
 #define MOM6HIP_REMAP_PQM_IH4IH3 8
+#define MOM6HIP_REMAP_PQM_IH6IH5 9
 #define MOM6HIP_REMAP_PPM_CW  10
 
 /* remapping_CS, src/ALE/MOM_remapping.F90:25-41 */

@@ -57,7 +57,7 @@ class AdvectTiming(C.Structure):
                 ("n_y", C.c_int32)]
 
 
-REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PLM_HYBGEN": 3, "PPM_H4": 4, "PPM_IH4": 5, "PPM_HYBGEN": 6, "WENO_HYBGEN": 7, "PQM_IH4IH3": 8, "PPM_CW": 10}
+REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PLM_HYBGEN": 3, "PPM_H4": 4, "PPM_IH4": 5, "PPM_HYBGEN": 6, "WENO_HYBGEN": 7, "PQM_IH4IH3": 8, "PQM_IH6IH5": 9, "PPM_CW": 10}
 
 
 class RemappingCS(C.Structure):

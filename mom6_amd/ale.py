@@ -21,7 +21,7 @@ class RemappingCS:
         if remapping_scheme not in _abi.REMAP_SCHEMES:
             # setReconstructionType, MOM_remapping.F90:1282-1326
             raise Mom6HipError("setReconstructionType: Unrecognized choice for REMAPPING_SCHEME ("
-                               + str(remapping_scheme) + "); libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3")
+                               + str(remapping_scheme) + "); libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3, PQM_IH6IH5")
         self.remapping_scheme = remapping_scheme
         self.boundary_extrapolation = bool(boundary_extrapolation)
         self.force_bounds_in_subcell = bool(force_bounds_in_subcell)

@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int REMAP_PCM = 0, REMAP_PLM = 2, REMAP_PLM_HYBGEN = 3, REMAP_PPM_H4 = 4, REMAP_PPM_IH4 = 5, REMAP_PPM_HYBGEN = 6,
-              REMAP_WENO_HYBGEN = 7, REMAP_PQM_IH4IH3 = 8, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-58
+              REMAP_WENO_HYBGEN = 7, REMAP_PQM_IH4IH3 = 8, REMAP_PQM_IH6IH5 = 9, REMAP_PPM_CW = 10;   // MOM_remapping.F90:50-59
 constexpr int INT_PCM = 0, INT_PLM = 1, INT_PPM = 3, INT_PQM = 5;   // :61-64
 
 __device__ __forceinline__ double max3(double a, double b, double c) { return fmax(fmax(a, b), c); }
@@ -331,7 +331,7 @@ struct WCol {   // LDS arrays of one column (doubles first, then shorts); the fi
   double *SR;                              // PQM only (xd = nz doubles more a column): the right edge slopes; the left ones live in C1
   short *isrc_end, *isrc_max, *itgt_end;   // (+ last_thick at itgt_end[nz + 1])
 };
-__host__ __device__ inline int wcol_extra(int scheme, int nz) { return scheme == REMAP_PQM_IH4IH3 ? nz : 0; }
+__host__ __device__ inline int wcol_extra(int scheme, int nz) { return (scheme == REMAP_PQM_IH4IH3 || scheme == REMAP_PQM_IH6IH5) ? nz : 0; }
 __host__ __device__ inline size_t wcol_doubles(int nz, int xd) { return (size_t)sub_drows(nz) + 5 * nz + 2 * (2 * nz + 2) + xd; }
 __host__ __device__ inline size_t wcol_bytes(int nz, int xd) { return (wcol_doubles(nz, xd) * 8 + (size_t)sub_srows(nz) * 2 + 7) / 8 * 8; }
 __device__ inline WCol wcol_at(char *base, int nz, int xd) {
@@ -388,6 +388,196 @@ __device__ bool pqm_bad_inflexion(const Quartic &q, double slope, bool closed) {
     }
   }
   return bad;
+}
+
+// ---- PQM_IH6IH5: the 6x6 systems behind edge_values_implicit_h6 and edge_slopes_implicit_h5 (regrid_edge_values.F90:977-1454)
+// linear_solver (regrid_solvers.F90:115-176): Gaussian elimination with the first nonzero pivot, A[row][col].  A singular system (a
+// FATAL error in the reference) leaves NaNs.
+__device__ void linear_solver6(double A[6][6], double R[6], double X[6]) {
+  const int N = 6;
+  bool singular = false;
+  for (int i = 0; i < N - 1; i++) {
+    int k = i;
+    while (k < N && !(fabs(A[k][i]) > 0.0)) k++;
+    if (k >= N) { singular = true; break; }
+    if (k != i) {
+      for (int j = i; j < N; j++) { const double swap = A[i][j]; A[i][j] = A[k][j]; A[k][j] = swap; }
+      const double swap = R[i]; R[i] = R[k]; R[k] = swap;
+    }
+    const double I_pivot = 1.0 / A[i][i];
+    A[i][i] = 1.0;
+    for (int j = i + 1; j < N; j++) A[i][j] = A[i][j] * I_pivot;
+    R[i] = R[i] * I_pivot;
+    for (int kk = i + 1; kk < N; kk++) {
+      const double factor = A[kk][i];
+      for (int j = i + 1; j < N; j++) A[kk][j] = A[kk][j] - factor * A[i][j];
+      R[kk] = R[kk] - factor * R[i];
+    }
+  }
+  if (singular || A[N - 1][N - 1] == 0.0) {
+    for (int i = 0; i < N; i++) X[i] = __builtin_nan("");
+    return;
+  }
+  X[N - 1] = R[N - 1] / A[N - 1][N - 1];
+  for (int i = N - 2; i >= 0; i--) {
+    X[i] = R[i];
+    for (int j = i + 1; j < N; j++) X[i] = X[i] - A[i][j] * X[j];
+  }
+}
+// ((a+b)^(m+2) - a^(m+2)) / b, m = 0..4, as the reference writes them (a the inner cell, b the outer one)
+__device__ void ih_polys(double a, double b, double P[5]) {
+  const double a_2 = a * a, a_3 = a_2 * a, a_4 = a_2 * a_2, a_5 = a_3 * a_2;
+  P[0] = (2.0 * a + b);
+  P[1] = (3.0 * a_2 + b * (3.0 * a + b));
+  P[2] = (4.0 * a_3 + b * (6.0 * a_2 + b * (4.0 * a + b)));
+  P[3] = (5.0 * a_4 + b * (10.0 * a_3 + b * (10.0 * a_2 + b * (5.0 * a + b))));
+  P[4] = (6.0 * a_5 + b * (15.0 * a_4 + b * (20.0 * a_3 + b * (15.0 * a_2 + b * (6.0 * a + b)))));
+}
+// a row of the boundary systems :1169-1171, :1367-1369
+__device__ void ih_boundary_row(double xavg, double dx, double row[6]) {
+  const double C1_12 = 1.0 / 12.0, C5_6 = 5.0 / 6.0;
+  const double x2 = xavg * xavg, x4 = x2 * x2, d2 = dx * dx, d4 = d2 * d2;
+  row[0] = 1.0; row[1] = xavg; row[2] = (x2 + C1_12 * d2); row[3] = xavg * (x2 + 0.25 * d2);
+  row[4] = (x4 + 0.5 * x2 * d2 + 0.0125 * d4);
+  row[5] = xavg * (x4 + C5_6 * x2 * d2 + 0.0625 * d4);
+}
+// The coefficients of one row of the tridiagonal system (alpha, beta and the four weights of the cell means).  SLOPES: the system of
+// edge_slopes_implicit_h5, else of edge_values_implicit_h6; which: 0 the centred stencil, 1 the right-biased one (second row), 2 the
+// left-biased one (second to last row)
+template <bool SLOPES>
+__device__ void ih_coefs(double h0, double h1, double h2, double h3, int which, double C[6]) {
+  double A[6][6], B[6], Pl[5], Pr[5];
+  const double h1_2 = h1 * h1, h1_3 = h1_2 * h1, h1_4 = h1_2 * h1_2, h1_5 = h1_3 * h1_2;
+  const double h2_2 = h2 * h2, h2_3 = h2_2 * h2, h2_4 = h2_2 * h2_2, h2_5 = h2_3 * h2_2;
+  ih_polys(h1, h0, Pl); ih_polys(h2, h3, Pr);
+  if (SLOPES) {
+    const double r3[6] = {1.0, Pl[0], Pl[1], -Pl[2], Pl[3], -Pl[4]};
+    const double r4[6] = {1.0, h1, h1_2, -h1_3, h1_4, -h1_5};
+    const double r5[6] = {1.0, -h2, h2_2, h2_3, h2_4, h2_5};
+    const double r6[6] = {1.0, -Pr[0], Pr[1], Pr[2], Pr[3], Pr[4]};
+    for (int n = 0; n < 6; n++) { A[n][2] = r3[n]; A[n][3] = r4[n]; A[n][4] = r5[n]; A[n][5] = r6[n]; }
+    A[0][0] = 0.0; A[0][1] = 0.0; A[1][0] = 2.0; A[1][1] = 2.0;
+    if (which == 0) {
+      A[2][0] = 6.0 * h1;      A[2][1] = -6.0 * h2;
+      A[3][0] = -12.0 * h1_2;  A[3][1] = -12.0 * h2_2;
+      A[4][0] = 20.0 * h1_3;   A[4][1] = -20.0 * h2_3;
+      A[5][0] = -30.0 * h1_4;  A[5][1] = -30.0 * h2_4;
+      B[0] = 0.0; B[1] = -2.0; B[2] = 0.0; B[3] = 0.0; B[4] = 0.0; B[5] = 0.0;
+    } else if (which == 1) {
+      const double h01 = h0 + h1, h01_2 = h01 * h01;
+      A[2][0] = 6.0 * h01;                A[2][1] = 0.0;
+      A[3][0] = -12.0 * h01_2;            A[3][1] = 0.0;
+      A[4][0] = 20.0 * (h01 * h01_2);     A[4][1] = 0.0;
+      A[5][0] = -30.0 * (h01_2 * h01_2);  A[5][1] = 0.0;
+      B[0] = 0.0; B[1] = -2.0; B[2] = -6.0 * h1; B[3] = 12.0 * h1_2; B[4] = -20.0 * h1_3; B[5] = 30.0 * h1_4;
+    } else {
+      const double h23 = h2 + h3, h23_2 = h23 * h23;
+      A[2][0] = 0.0; A[2][1] = -6.0 * h23;
+      A[3][0] = 0.0; A[3][1] = -12.0 * h23_2;
+      A[4][0] = 0.0; A[4][1] = -20.0 * (h23 * h23_2);
+      A[5][0] = 0.0; A[5][1] = -30.0 * (h23_2 * h23_2);
+      B[0] = 0.0; B[1] = -2.0; B[2] = 6.0 * h2; B[3] = 12.0 * h2_2; B[4] = 20.0 * h2_3; B[5] = 30.0 * h2_4;
+    }
+  } else {
+    const double r3[6] = {-1.0, Pl[0], -Pl[1], Pl[2], -Pl[3], Pl[4]};
+    const double r4[6] = {-1.0, h1, -h1_2, h1_3, -h1_4, h1_5};
+    const double r5[6] = {-1.0, -h2, -h2_2, -h2_3, -h2_4, -h2_5};
+    const double r6[6] = {-1.0, -Pr[0], -Pr[1], -Pr[2], -Pr[3], -Pr[4]};
+    for (int n = 0; n < 6; n++) { A[n][2] = r3[n]; A[n][3] = r4[n]; A[n][4] = r5[n]; A[n][5] = r6[n]; }
+    A[0][0] = 1.0; A[0][1] = 1.0;
+    if (which == 0) {
+      A[1][0] = -2.0 * h1;    A[1][1] = 2.0 * h2;
+      A[2][0] = 3.0 * h1_2;   A[2][1] = 3.0 * h2_2;
+      A[3][0] = -4.0 * h1_3;  A[3][1] = 4.0 * h2_3;
+      A[4][0] = 5.0 * h1_4;   A[4][1] = 5.0 * h2_4;
+      A[5][0] = -6.0 * h1_5;  A[5][1] = 6.0 * h2_5;
+      B[0] = -1.0; B[1] = 0.0; B[2] = 0.0; B[3] = 0.0; B[4] = 0.0; B[5] = 0.0;
+    } else if (which == 1) {
+      const double h01 = h0 + h1, h01_2 = h01 * h01, h01_3 = h01 * h01_2;
+      A[1][0] = -2.0 * h01;              A[1][1] = 0.0;
+      A[2][0] = 3.0 * h01_2;             A[2][1] = 0.0;
+      A[3][0] = -4.0 * h01_3;            A[3][1] = 0.0;
+      A[4][0] = 5.0 * (h01_2 * h01_2);   A[4][1] = 0.0;
+      A[5][0] = -6.0 * (h01_3 * h01_2);  A[5][1] = 0.0;
+      B[0] = -1.0; B[1] = 2.0 * h1; B[2] = -3.0 * h1_2; B[3] = 4.0 * h1_3; B[4] = -5.0 * h1_4; B[5] = 6.0 * h1_5;
+    } else {
+      const double h23 = h2 + h3, h23_2 = h23 * h23, h23_3 = h23 * h23_2;
+      A[1][0] = 0.0; A[1][1] = 2.0 * h23;
+      A[2][0] = 0.0; A[2][1] = 3.0 * h23_2;
+      A[3][0] = 0.0; A[3][1] = 4.0 * h23_3;
+      A[4][0] = 0.0; A[4][1] = 5.0 * (h23_2 * h23_2);
+      A[5][0] = 0.0; A[5][1] = 6.0 * (h23_3 * h23_2);
+      B[0] = -1.0; B[1] = -2.0 * h2; B[2] = -3.0 * h2_2; B[3] = -4.0 * h2_3; B[4] = -5.0 * h2_4; B[5] = -6.0 * h2_5;
+    }
+  }
+  linear_solver6(A, B, C);
+}
+// The tridiagonal system of edge_values_implicit_h6 (SLOPES = false) or edge_slopes_implicit_h5 (true) built across the lanes -- the
+// interior rows a lane each, the four special rows on the last four lanes -- and solved by one lane with solve_tridiagonal_system's
+// 2008-2018 expressions (both routines call it without an answer date, regrid_solvers.F90:199-217).  The solution is left in
+// c.uh_sub[0 .. n] (the central diagonal is 1 in every row and is not stored).  n >= 6.
+template <bool SLOPES>
+__device__ void w_ih65_system(const WCol &c, int lane, int n, double hNeglect) {
+  const double *h = c.h0, *u = c.u0;
+  const double frac = SLOPES ? 1.0e-4 : 1.e-5;      // h_Min_Frac of :1042 / hMinFrac of :30
+  double *tri_l = c.u_sub, *tri_u = c.u_sub + (n + 1), *tri_b = c.uh_sub, *pivot = c.uh_sub + (n + 1);
+  double C[6];
+  for (int k = lane + 1; k <= n - 3; k += 64) {      // Fortran k = 2 .. N-2, row k+1
+    const double hMin = fmax(hNeglect, frac * ((h[k - 1] + h[k]) + (h[k + 1] + h[k + 2])));
+    ih_coefs<SLOPES>(fmax(h[k - 1], hMin), fmax(h[k], hMin), fmax(h[k + 1], hMin), fmax(h[k + 2], hMin), 0, C);
+    tri_l[k + 1] = C[0]; tri_u[k + 1] = C[1];
+    tri_b[k + 1] = C[2] * u[k - 1] + C[3] * u[k] + C[4] * u[k + 1] + C[5] * u[k + 2];
+  }
+  if (lane == 60 || lane == 61) {      // the right-biased second row, the left-biased second to last row
+    const int q = (lane == 60) ? 0 : n - 4;
+    const double hMin = fmax(hNeglect, frac * ((h[q] + h[q + 1]) + (h[q + 2] + h[q + 3])));
+    ih_coefs<SLOPES>(fmax(h[q], hMin), fmax(h[q + 1], hMin), fmax(h[q + 2], hMin), fmax(h[q + 3], hMin), (lane == 60) ? 1 : 2, C);
+    const int row = (lane == 60) ? 1 : n - 1;
+    tri_l[row] = C[0]; tri_u[row] = C[1];
+    tri_b[row] = C[2] * u[q] + C[3] * u[q + 1] + C[4] * u[q + 2] + C[5] * u[q + 3];
+  }
+  if (lane >= 62) {      // the boundary conditions: a fifth-degree polynomial through the means of the six cells at the end
+    const bool last = lane == 63;
+    double hMin = 0.0;      // (the slopes' routine takes the widths as they are, :1166, :1212)
+    if (!SLOPES) {
+      if (!last) hMin = fmax(hNeglect, frac * ((h[0] + h[1]) + (h[4] + h[5]) + (h[2] + h[3])));
+      else hMin = fmax(hNeglect, frac * (h[n - 4] + h[n - 3]) + ((h[n - 2] + h[n - 1]) + (h[n - 6] + h[n - 5])));      // (as :1436 has it)
+    }
+    double A[6][6], B[6], x = 0.0;
+    for (int i = 0; i < 6; i++) {
+      const int q = last ? n - 1 - i : i;
+      const double dx = SLOPES ? h[q] : fmax(hMin, h[q]);
+      const double xavg = x + 0.5 * dx;
+      ih_boundary_row(xavg, dx, A[i]);
+      B[i] = u[q];
+      x = x + dx;
+    }
+    linear_solver6(A, B, C);
+    double rhs;
+    if (SLOPES) rhs = last ? -C[1] : C[1];
+    else if (last) rhs = C[0];
+    else {      // evaluation_polynomial( Csys, 6, 0.0 )
+      rhs = 0.0;
+      rhs = rhs + C[0] * 1.0;
+      for (int k = 1; k < 6; k++) rhs = rhs + C[k] * 0.0;
+    }
+    const int row = last ? n : 0;
+    tri_l[row] = 0.0; tri_u[row] = 0.0; tri_b[row] = rhs;
+  }
+  wsync();
+  if (lane == 0) {
+    const int N = n + 1;
+    const double R_last = tri_b[N - 1];
+    pivot[0] = 1.0;
+    for (int k = 1; k < N; k++) {
+      const double Al_piv = tri_l[k] / pivot[k - 1];
+      pivot[k] = 1.0 - Al_piv * tri_u[k - 1];
+      tri_b[k] = tri_b[k] - Al_piv * tri_b[k - 1];
+    }
+    tri_b[N - 1] = R_last / pivot[N - 1];
+    for (int k = N - 2; k >= 0; k--) tri_b[k] = (tri_b[k] - tri_u[k] * tri_b[k + 1]) / pivot[k];
+  }
+  wsync();
 }
 
 // build_reconstructions_1d across the lanes; returns the integration method (uniform over the wave).
@@ -569,6 +759,10 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     wsync();
     for (int k = lane; k < n; k += 64) { EL[k] = tri_b[k]; ER[k] = tri_b[k + 1]; }
     wsync();
+  } else if (local == REMAP_PQM_IH6IH5) {
+    w_ih65_system<false>(c, lane, n, h_neglect_edge);      // edge_values_implicit_h6
+    for (int k = lane; k < n; k += 64) { EL[k] = c.uh_sub[k]; ER[k] = c.uh_sub[k + 1]; }
+    wsync();
   } else if (local == REMAP_PPM_CW || local == REMAP_PPM_HYBGEN) {
     // ---- PPM_CW: edge_values_explicit_h4cw (regrid_edge_values.F90:381-463) and PPM_monotonicity (PPM_functions.F90:132).
     // ---- PPM_HYBGEN: hybgen_ppm_coefs (MOM_hybgen_remap.F90:91-222), the HYCOM routine the two above re-express: the same
@@ -699,6 +893,11 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     for (int k = lane; k < n; k += 64) { c.C1[k] = tri_b[k]; c.SR[k] = tri_b[k + 1]; }
     wsync();
   }
+  if (local == REMAP_PQM_IH6IH5) {
+    w_ih65_system<true>(c, lane, n, h_neglect);      // edge_slopes_implicit_h5
+    for (int k = lane; k < n; k += 64) { c.C1[k] = c.uh_sub[k]; c.SR[k] = c.uh_sub[k + 1]; }
+    wsync();
+  }
   // ---- PPM_reconstruction / PQM_limiter: bound_edge_values, check_discontinuous_edge_values, then the scheme's limiter
   for (int k = lane; k < n; k += 64) {
     const int km1 = (k - 1 > 0) ? k - 1 : 0, kp1 = (k + 1 < n - 1) ? k + 1 : n - 1;
@@ -725,7 +924,7 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     }
   }
   wsync();
-  if (local == REMAP_PQM_IH4IH3) {
+  if (local == REMAP_PQM_IH4IH3 || local == REMAP_PQM_IH6IH5) {
     // ---- PQM_limiter (PQM_functions.F90:103-337): a cell reads its own edge values and slopes and its neighbours' means and widths
     const double hNeglect = h_neglect;
     double *SL = c.C1, *SR = c.SR;
@@ -1555,7 +1754,7 @@ __global__ __launch_bounds__(64 * WR_NCOL) void ale_remap_wave_kernel(WRemapArgs
 bool scheme_provided(int scheme) {
   if (scheme == REMAP_PCM || scheme == REMAP_PLM || scheme == REMAP_PPM_H4) return true;
   return (scheme == REMAP_PPM_IH4 || scheme == REMAP_PPM_CW || scheme == REMAP_PLM_HYBGEN || scheme == REMAP_PPM_HYBGEN ||
-          scheme == REMAP_WENO_HYBGEN || scheme == REMAP_PQM_IH4IH3);
+          scheme == REMAP_WENO_HYBGEN || scheme == REMAP_PQM_IH4IH3 || scheme == REMAP_PQM_IH6IH5);
 }
 
 // MOM6HIP_ALE_STREAM: 0 = never the streaming kernel; 1 = one field a launch; 2 (default) = two fields a launch (read at every
@@ -1616,7 +1815,9 @@ extern "C" int mom6hip_ale_remap_tracers(mom6hip_ctx_t *ctx, const mom6hip_remap
   M6_REQUIRE(tr != nullptr && ntr <= 64, "ALE_remap_tracers: bad tracer list");
   M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW and PQM_IH4IH3)");
+             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3 and PQM_IH6IH5)");
+  // (edge_values_implicit_h6 and edge_slopes_implicit_h5 read the six cells at either end of a column, whatever its length)
+  M6_REQUIRE(cs->remapping_scheme != REMAP_PQM_IH6IH5 || ctx->g.nk >= 6 || ctx->g.nk <= 4, "PQM_IH6IH5 needs at least six layers (or at most four, where build_reconstructions_1d takes a lower scheme)");
   M6_REQUIRE(cs->answer_date >= 20190101, "ALE_remap_tracers: only REMAPPING_ANSWER_DATE >= 20190101 is provided");
   M6_REQUIRE(!cs->force_bounds_in_subcell, "ALE_remap_tracers: REMAP_BOUND_INTERMEDIATE_VALUES is not provided");
   M6_REQUIRE(ctx->g.mask2dT != nullptr, "ALE_remap_tracers: mask2dT is required");
@@ -1737,7 +1938,9 @@ extern "C" int mom6hip_ale_remap_velocities(mom6hip_ctx_t *ctx, const mom6hip_re
   M6_REQUIRE(ctx && cs && h_old_u && h_old_v && h_new_u && h_new_v && u && v, "ALE_remap_velocities: null argument");
   M6_REQUIRE(scheme_provided(cs->remapping_scheme),
              "MOM_remapping, build_reconstructions_1d: The selected remapping method is invalid "
-             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW and PQM_IH4IH3)");
+             "(libmom6hip provides PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3 and PQM_IH6IH5)");
+  // (edge_values_implicit_h6 and edge_slopes_implicit_h5 read the six cells at either end of a column, whatever its length)
+  M6_REQUIRE(cs->remapping_scheme != REMAP_PQM_IH6IH5 || ctx->g.nk >= 6 || ctx->g.nk <= 4, "PQM_IH6IH5 needs at least six layers (or at most four, where build_reconstructions_1d takes a lower scheme)");
   M6_REQUIRE(cs->answer_date >= 20190101 && !cs->force_bounds_in_subcell, "ALE_remap_velocities: unsupported remapping options");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.nk <= 128 && g.mask2dCu && g.mask2dCv, "ALE_remap_velocities: at most 128 layers; face masks are needed");

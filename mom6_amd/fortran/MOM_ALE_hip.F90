@@ -3,7 +3,7 @@
 !! (:328), ALE_regrid (:484), ALE_remap_tracers (:737), ALE_remap_set_h_vel (:870) and ALE_remap_velocities (:1061) with the
 !! reference's dummy-argument lists, parameter names and defaults, on the GPU through libmom6hip (HOST memspace).
 !! Provided: REGRIDDING_COORDINATE_MODE = Z* (ZSTAR) with ALE_COORDINATE_CONFIG = UNIFORM[:N[,dz]] or PARAM (ALE_RESOLUTION),
-!! REMAPPING_SCHEME / VELOCITY_REMAPPING_SCHEME in PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3,
+!! REMAPPING_SCHEME / VELOCITY_REMAPPING_SCHEME in PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3, PQM_IH6IH5 (every scheme of the reference),
 !! REMAPPING_ANSWER_DATE >= 20190101.
 !! Everything else the reference offers here (other coordinates, ice shelves, PCM_cell masks, OBC thicknesses, partial-cell
 !! velocity remapping, the KE-conserving velocity correction, the remapping tendency diagnostics) stops with a FATAL error.
@@ -85,10 +85,7 @@ integer function scheme_of(string)
     case ("WENO_HYBGEN") ; scheme_of = MOM6HIP_REMAP_WENO_HYBGEN
     case ("PPM_CW") ;  scheme_of = MOM6HIP_REMAP_PPM_CW
     case ("PQM_IH4IH3") ;  scheme_of = MOM6HIP_REMAP_PQM_IH4IH3
-    case ("PQM_IH6IH5")
-      scheme_of = -1
-      call MOM_error(FATAL, "ALE_init (HIP): REMAPPING_SCHEME = "//trim(string)//" is not provided by the GPU path "// &
-                            "(PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN, PPM_CW, PQM_IH4IH3 are).")
+    case ("PQM_IH6IH5") ;  scheme_of = MOM6HIP_REMAP_PQM_IH6IH5
     case default
       scheme_of = -1
       call MOM_error(FATAL, "setReconstructionType: Unrecognized choice for REMAPPING_SCHEME ("//trim(string)//").")

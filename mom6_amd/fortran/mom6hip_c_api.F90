@@ -17,7 +17,8 @@ integer(c_int32_t), parameter :: MOM6HIP_EOS_LINEAR = 1, MOM6HIP_EOS_UNESCO = 2,
 !> REMAPPING_* of src/ALE/MOM_remapping.F90:51-59 and REGRIDDING_ZSTAR of regrid_consts.F90:14
 integer(c_int32_t), parameter :: MOM6HIP_REMAP_PCM = 0, MOM6HIP_REMAP_PLM = 2, MOM6HIP_REMAP_PPM_H4 = 4, MOM6HIP_REMAP_PPM_IH4 = 5, &
                                  MOM6HIP_REMAP_PPM_CW = 10, MOM6HIP_REMAP_PLM_HYBGEN = 3, MOM6HIP_REMAP_PPM_HYBGEN = 6, &
-                                 MOM6HIP_REMAP_WENO_HYBGEN = 7, MOM6HIP_REMAP_PQM_IH4IH3 = 8, MOM6HIP_REGRIDDING_ZSTAR = 2
+                                 MOM6HIP_REMAP_WENO_HYBGEN = 7, MOM6HIP_REMAP_PQM_IH4IH3 = 8, MOM6HIP_REMAP_PQM_IH6IH5 = 9, &
+                                 MOM6HIP_REGRIDDING_ZSTAR = 2
 
 !> mom6hip_grid_t of include/mom6hip.h
 type, bind(c) :: mom6hip_grid_t

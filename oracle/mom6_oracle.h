@@ -112,6 +112,7 @@ int orc_advect_tracer_obc(const mom6hip_grid_t *G, const double *h_end, const do
 #define ORC_REMAP_PPM_IH4 5
 #define ORC_REMAP_PPM_CW  10
 #define ORC_REMAP_PQM_IH4IH3 8
+#define ORC_REMAP_PQM_IH6IH5 9
 #define ORC_INT_PCM 0
 #define ORC_INT_PLM 1
 #define ORC_INT_PPM 3
@@ -143,6 +144,9 @@ void orc_remap_via_sub_cells(int n0, const double *h0, const double *u0, const d
                              int n1, const double *h1, int method, int force_bounds_in_subcell,
                              double *u1, double *uh_err);
 void orc_edge_slopes_implicit_h3(int n, const double *h, const double *u, double *S, double h_neglect);
+int orc_linear_solver6(double A[6][6], double R[6], double X[6]);
+int orc_edge_slopes_implicit_h5(int n, const double *h, const double *u, double *S, double h_neglect);
+int orc_edge_values_implicit_h6(int n, const double *h, const double *u, double *E, double h_neglect_edge);
 void orc_pqm_limiter(int n, const double *h, const double *u, double *E, double *S, double h_neglect);
 void orc_pqm_reconstruction(int n, const double *h, const double *u, double *E, double *S, double *coef, double h_neglect);
 void orc_pqm_boundary_extrapolation_v1(int n, const double *h, const double *u, double *E, double *S, double *coef, double h_neglect);

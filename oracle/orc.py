@@ -109,7 +109,7 @@ def update_segment_tracer_reservoirs(grid, uhr, vhr, h, OBC, dt, tr):
 
 
 # ---- ALE reconstruction + remapping ---------------------------------------------------------------
-REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PLM_HYBGEN": 3, "PPM_H4": 4, "PPM_IH4": 5, "PPM_HYBGEN": 6, "WENO_HYBGEN": 7, "PQM_IH4IH3": 8, "PPM_CW": 10}
+REMAP_SCHEMES = {"PCM": 0, "PLM": 2, "PLM_HYBGEN": 3, "PPM_H4": 4, "PPM_IH4": 5, "PPM_HYBGEN": 6, "WENO_HYBGEN": 7, "PQM_IH4IH3": 8, "PQM_IH6IH5": 9, "PPM_CW": 10}
 INT_PCM, INT_PLM, INT_PPM = 0, 1, 3
 _ip = C.POINTER(C.c_int)
 

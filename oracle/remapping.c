@@ -734,6 +734,276 @@ void orc_pqm_boundary_extrapolation_v1(int n, const double *h, const double *u, 
   }
 }
 
+/* ---- PQM_IH6IH5: the sixth-order edge values and fifth-order edge slopes ---------------------------------------- */
+/* linear_solver, regrid_solvers.F90:115-176 (Gaussian elimination, the first nonzero pivot; A[row][col]).  Returns nonzero when the
+ * system is singular (the reference stops with a FATAL error). */
+int orc_linear_solver6(double A[6][6], double R[6], double X[6])
+{
+  const int N = 6;
+  for (int i = 0; i < N-1; i++) {
+    int k = i;
+    while (k < N && !(fabs(A[k][i]) > 0.0)) k++;
+    if (k >= N) return 1;
+    if (k != i) {
+      for (int j = i; j < N; j++) { const double swap = A[i][j]; A[i][j] = A[k][j]; A[k][j] = swap; }
+      const double swap = R[i]; R[i] = R[k]; R[k] = swap;
+    }
+    const double I_pivot = 1.0 / A[i][i];
+    A[i][i] = 1.0;
+    for (int j = i+1; j < N; j++) A[i][j] = A[i][j] * I_pivot;
+    R[i] = R[i] * I_pivot;
+    for (int kk = i+1; kk < N; kk++) {
+      const double factor = A[kk][i];
+      for (int j = i+1; j < N; j++) A[kk][j] = A[kk][j] - factor * A[i][j];
+      R[kk] = R[kk] - factor * R[i];
+    }
+  }
+  if (A[N-1][N-1] == 0.0) return 2;
+  X[N-1] = R[N-1] / A[N-1][N-1];
+  for (int i = N-2; i >= 0; i--) {
+    X[i] = R[i];
+    for (int j = i+1; j < N; j++) X[i] = X[i] - A[i][j] * X[j];
+  }
+  return 0;
+}
+
+/* solve_tridiagonal_system without an answer_date (the 2008-2018 expressions), regrid_solvers.F90:183-217 */
+void orc_solve_tridiagonal_system_2018(const double *Al, const double *Ad, const double *Au, const double *R, double *X, int N)
+{
+  double *pivot = (double*)calloc((size_t)N, sizeof(double));
+  pivot[0] = Ad[0];
+  X[0] = R[0];
+  for (int k = 1; k < N; k++) {
+    const double Al_piv = Al[k] / pivot[k-1];
+    pivot[k] = Ad[k] - Al_piv * Au[k-1];
+    X[k] = R[k] - Al_piv * X[k-1];
+  }
+  X[N-1] = R[N-1] / pivot[N-1];
+  for (int k = N-2; k >= 0; k--) X[k] = ( X[k] - Au[k]*X[k+1] ) / pivot[k];
+  free(pivot);
+}
+
+/* The polynomials of the cell widths that both routines' matrices share (Eq. 48 and 52 of White and Adcroft 2009):
+ * P[m] = ((a+b)^(m+2) - a^(m+2)) / b for m = 0..4 as the reference writes them, with a the inner and b the outer cell */
+static void ih_polys(double a, double b, double P[5])
+{
+  const double a_2 = a * a, a_3 = a_2 * a, a_4 = a_2 * a_2, a_5 = a_3 * a_2;
+  P[0] = (2.0*a + b);
+  P[1] = (3.0*a_2 + b*(3.0*a + b));
+  P[2] = (4.0*a_3 + b*(6.0*a_2 + b*(4.0*a + b)));
+  P[3] = (5.0*a_4 + b*(10.0*a_3 + b*(10.0*a_2 + b*(5.0*a + b))));
+  P[4] = (6.0*a_5 + b*(15.0*a_4 + b*(20.0*a_3 + b*(15.0*a_2 + b*(6.0*a + b)))));
+}
+/* A row of the boundary systems (the cell average of 1, x, .., x^5 over a cell of width dx centred on xavg), :1169-1171, :1367-1369 */
+static void ih_boundary_row(double xavg, double dx, double row[6])
+{
+  const double C1_12 = 1.0 / 12.0, C5_6 = 5.0 / 6.0;
+  const double x2 = xavg*xavg, x4 = x2*x2, d2 = dx*dx, d4 = d2*d2;
+  row[0] = 1.0; row[1] = xavg; row[2] = (x2 + C1_12*d2); row[3] = xavg * (x2 + 0.25*d2);
+  row[4] = (x4 + 0.5*x2*d2 + 0.0125*d4);
+  row[5] = xavg * (x4 + C5_6*x2*d2 + 0.0625*d4);
+}
+
+/* which: 0 the centred stencil, 1 the right-biased one of the second row, 2 the left-biased one of the second to last row */
+static int ih5_coefs(double h0, double h1, double h2, double h3, int which, double C[6])
+{
+  double A[6][6], B[6], Pl[5], Pr[5];
+  const double h1_2 = h1 * h1, h1_3 = h1_2 * h1, h1_4 = h1_2 * h1_2, h1_5 = h1_3 * h1_2;
+  const double h2_2 = h2 * h2, h2_3 = h2_2 * h2, h2_4 = h2_2 * h2_2, h2_5 = h2_3 * h2_2;
+  ih_polys(h1, h0, Pl); ih_polys(h2, h3, Pr);
+  const double r3[6] = {1.0, Pl[0], Pl[1], -Pl[2], Pl[3], -Pl[4]};
+  const double r4[6] = {1.0, h1, h1_2, -h1_3, h1_4, -h1_5};
+  const double r5[6] = {1.0, -h2, h2_2, h2_3, h2_4, h2_5};
+  const double r6[6] = {1.0, -Pr[0], Pr[1], Pr[2], Pr[3], Pr[4]};
+  for (int n = 0; n < 6; n++) { A[n][2] = r3[n]; A[n][3] = r4[n]; A[n][4] = r5[n]; A[n][5] = r6[n]; }
+  A[0][0] = 0.0; A[0][1] = 0.0; A[1][0] = 2.0; A[1][1] = 2.0;
+  if (which == 0) {
+    A[2][0] = 6.0*h1;     A[2][1] = -6.0* h2;
+    A[3][0] = -12.0*h1_2; A[3][1] = -12.0*h2_2;
+    A[4][0] = 20.0*h1_3;  A[4][1] = -20.0*h2_3;
+    A[5][0] = -30.0*h1_4; A[5][1] = -30.0*h2_4;
+    B[0] = 0.0; B[1] = -2.0; B[2] = 0.0; B[3] = 0.0; B[4] = 0.0; B[5] = 0.0;
+  } else if (which == 1) {
+    const double h01 = h0 + h1, h01_2 = h01 * h01;
+    A[2][0] = 6.0*h01;             A[2][1] = 0.0;
+    A[3][0] = -12.0*h01_2;         A[3][1] = 0.0;
+    A[4][0] = 20.0*(h01*h01_2);    A[4][1] = 0.0;
+    A[5][0] = -30.0*(h01_2*h01_2); A[5][1] = 0.0;
+    B[0] = 0.0; B[1] = -2.0; B[2] = -6.0*h1; B[3] = 12.0*h1_2; B[4] = -20.0*h1_3; B[5] = 30.0*h1_4;
+  } else {
+    const double h23 = h2 + h3, h23_2 = h23 * h23;
+    A[2][0] = 0.0; A[2][1] = -6.0*h23;
+    A[3][0] = 0.0; A[3][1] = -12.0*h23_2;
+    A[4][0] = 0.0; A[4][1] = -20.0*(h23*h23_2);
+    A[5][0] = 0.0; A[5][1] = -30.0*(h23_2*h23_2);
+    B[0] = 0.0; B[1] = -2.0; B[2] = 6.0*h2; B[3] = 12.0*h2_2; B[4] = 20.0*h2_3; B[5] = 30.0*h2_4;
+  }
+  return orc_linear_solver6(A, B, C);
+}
+
+/* edge_slopes_implicit_h5, regrid_edge_values.F90:977-1227.  n >= 6.  Returns nonzero if one of the 6x6 systems is singular. */
+int orc_edge_slopes_implicit_h5(int n, const double *h, const double *u, double *S, double h_neglect)
+{
+  const double hNeglect = h_neglect, h_Min_Frac = 1.0e-4;
+  const int m = n + 1;
+  int rc = 0;
+  double *tri_l = (double*)calloc(5*(size_t)m, sizeof(double));
+  double *tri_d = tri_l + m, *tri_u = tri_d + m, *tri_b = tri_u + m, *tri_x = tri_b + m;
+  double C[6];
+  for (int k = 1; k <= n-3; k++) {           /* Fortran k = 2..N-2: cells k-1..k+2 are 0-based k-1..k+2; row k+1 is 0-based k+1 */
+    const double hMin = max2(hNeglect, h_Min_Frac*((h[k-1] + h[k]) + (h[k+1] + h[k+2])));
+    rc |= ih5_coefs(max2(h[k-1], hMin), max2(h[k], hMin), max2(h[k+1], hMin), max2(h[k+2], hMin), 0, C);
+    tri_l[k+1] = C[0]; tri_d[k+1] = 1.0; tri_u[k+1] = C[1];
+    tri_b[k+1] = C[2] * u[k-1] + C[3] * u[k] + C[4] * u[k+1] + C[5] * u[k+2];
+  }
+  {
+    const double hMin = max2(hNeglect, h_Min_Frac*((h[0] + h[1]) + (h[2] + h[3])));
+    rc |= ih5_coefs(max2(h[0], hMin), max2(h[1], hMin), max2(h[2], hMin), max2(h[3], hMin), 1, C);
+    tri_l[1] = C[0]; tri_d[1] = 1.0; tri_u[1] = C[1];
+    tri_b[1] = C[2] * u[0] + C[3] * u[1] + C[4] * u[2] + C[5] * u[3];
+  }
+  {
+    double A[6][6], B[6], x = 0.0;
+    for (int i = 0; i < 6; i++) {
+      const double dx = h[i];
+      const double xavg = x + 0.5 * dx;
+      ih_boundary_row(xavg, dx, A[i]);
+      B[i] = u[i];
+      x = x + dx;
+    }
+    rc |= orc_linear_solver6(A, B, C);
+    tri_d[0] = 1.0; tri_u[0] = 0.0; tri_b[0] = C[1];
+  }
+  {
+    const double hMin = max2(hNeglect, h_Min_Frac*((h[n-4] + h[n-3]) + (h[n-2] + h[n-1])));
+    rc |= ih5_coefs(max2(h[n-4], hMin), max2(h[n-3], hMin), max2(h[n-2], hMin), max2(h[n-1], hMin), 2, C);
+    tri_l[n-1] = C[0]; tri_d[n-1] = 1.0; tri_u[n-1] = C[1];
+    tri_b[n-1] = C[2] * u[n-4] + C[3] * u[n-3] + C[4] * u[n-2] + C[5] * u[n-1];
+  }
+  {
+    double A[6][6], B[6], x = 0.0;
+    for (int i = 0; i < 6; i++) {
+      const double dx = h[n-1-i];
+      const double xavg = x + 0.5*dx;
+      ih_boundary_row(xavg, dx, A[i]);
+      B[i] = u[n-1-i];
+      x = x + dx;
+    }
+    rc |= orc_linear_solver6(A, B, C);
+    tri_l[n] = 0.0; tri_d[n] = 1.0; tri_u[n] = 0.0; tri_b[n] = -C[1];
+  }
+  orc_solve_tridiagonal_system_2018(tri_l, tri_d, tri_u, tri_b, tri_x, m);
+  for (int i = 1; i < n; i++) { E_(S,i,0) = tri_x[i]; E_(S,i-1,1) = tri_x[i]; }
+  E_(S,0,0) = tri_x[0];
+  E_(S,n-1,1) = tri_x[n];
+  free(tri_l);
+  return rc;
+}
+
+static int ih6_coefs(double h0, double h1, double h2, double h3, int which, double C[6])
+{
+  double A[6][6], B[6], Pl[5], Pr[5];
+  const double h1_2 = h1 * h1, h1_3 = h1_2 * h1, h1_4 = h1_2 * h1_2, h1_5 = h1_3 * h1_2;
+  const double h2_2 = h2 * h2, h2_3 = h2_2 * h2, h2_4 = h2_2 * h2_2, h2_5 = h2_3 * h2_2;
+  ih_polys(h1, h0, Pl); ih_polys(h2, h3, Pr);
+  const double r3[6] = {-1.0, Pl[0], -Pl[1], Pl[2], -Pl[3], Pl[4]};
+  const double r4[6] = {-1.0, h1, -h1_2, h1_3, -h1_4, h1_5};
+  const double r5[6] = {-1.0, -h2, -h2_2, -h2_3, -h2_4, -h2_5};
+  const double r6[6] = {-1.0, -Pr[0], -Pr[1], -Pr[2], -Pr[3], -Pr[4]};
+  for (int n = 0; n < 6; n++) { A[n][2] = r3[n]; A[n][3] = r4[n]; A[n][4] = r5[n]; A[n][5] = r6[n]; }
+  A[0][0] = 1.0; A[0][1] = 1.0;
+  if (which == 0) {
+    A[1][0] = -2.0*h1;   A[1][1] = 2.0*h2;
+    A[2][0] = 3.0*h1_2;  A[2][1] = 3.0*h2_2;
+    A[3][0] = -4.0*h1_3; A[3][1] = 4.0*h2_3;
+    A[4][0] = 5.0*h1_4;  A[4][1] = 5.0*h2_4;
+    A[5][0] = -6.0*h1_5; A[5][1] = 6.0*h2_5;
+    B[0] = -1.0; B[1] = 0.0; B[2] = 0.0; B[3] = 0.0; B[4] = 0.0; B[5] = 0.0;
+  } else if (which == 1) {
+    const double h01 = h0 + h1, h01_2 = h01 * h01, h01_3 = h01 * h01_2;
+    A[1][0] = -2.0*h01;            A[1][1] = 0.0;
+    A[2][0] = 3.0*h01_2;           A[2][1] = 0.0;
+    A[3][0] = -4.0*h01_3;          A[3][1] = 0.0;
+    A[4][0] = 5.0*(h01_2*h01_2);   A[4][1] = 0.0;
+    A[5][0] = -6.0*(h01_3*h01_2);  A[5][1] = 0.0;
+    B[0] = -1.0; B[1] = 2.0*h1; B[2] = -3.0*h1_2; B[3] = 4.0*h1_3; B[4] = -5.0*h1_4; B[5] = 6.0*h1_5;
+  } else {
+    const double h23 = h2 + h3, h23_2 = h23 * h23, h23_3 = h23 * h23_2;
+    A[1][0] = 0.0; A[1][1] = 2.0*h23;
+    A[2][0] = 0.0; A[2][1] = 3.0*h23_2;
+    A[3][0] = 0.0; A[3][1] = 4.0*h23_3;
+    A[4][0] = 0.0; A[4][1] = 5.0*(h23_2*h23_2);
+    A[5][0] = 0.0; A[5][1] = 6.0*(h23_3*h23_2);
+    B[0] = -1.0; B[1] = -2.0*h2; B[2] = -3.0*h2_2; B[3] = -4.0*h2_3; B[4] = -5.0*h2_4; B[5] = -6.0*h2_5;
+  }
+  return orc_linear_solver6(A, B, C);
+}
+
+/* edge_values_implicit_h6, regrid_edge_values.F90:1252-1454.  n >= 6. */
+int orc_edge_values_implicit_h6(int n, const double *h, const double *u, double *E, double h_neglect_edge)
+{
+  const double hNeglect = h_neglect_edge;
+  const int m = n + 1;
+  int rc = 0;
+  double *tri_l = (double*)calloc(5*(size_t)m, sizeof(double));
+  double *tri_d = tri_l + m, *tri_u = tri_d + m, *tri_b = tri_u + m, *tri_x = tri_b + m;
+  double C[6];
+  for (int k = 1; k <= n-3; k++) {
+    const double hMin = max2(hNeglect, hMinFrac*((h[k-1] + h[k]) + (h[k+1] + h[k+2])));
+    rc |= ih6_coefs(max2(h[k-1], hMin), max2(h[k], hMin), max2(h[k+1], hMin), max2(h[k+2], hMin), 0, C);
+    tri_l[k+1] = C[0]; tri_d[k+1] = 1.0; tri_u[k+1] = C[1];
+    tri_b[k+1] = C[2] * u[k-1] + C[3] * u[k] + C[4] * u[k+1] + C[5] * u[k+2];
+  }
+  {
+    const double hMin = max2(hNeglect, hMinFrac*((h[0] + h[1]) + (h[2] + h[3])));
+    rc |= ih6_coefs(max2(h[0], hMin), max2(h[1], hMin), max2(h[2], hMin), max2(h[3], hMin), 1, C);
+    tri_l[1] = C[0]; tri_d[1] = 1.0; tri_u[1] = C[1];
+    tri_b[1] = C[2] * u[0] + C[3] * u[1] + C[4] * u[2] + C[5] * u[3];
+  }
+  {
+    const double hMin = max2( hNeglect, hMinFrac*((h[0]+h[1]) + (h[4]+h[5]) + (h[2]+h[3])) );
+    double A[6][6], B[6], x = 0.0;
+    for (int i = 0; i < 6; i++) {
+      const double dx = max2( hMin, h[i] );
+      const double xavg = x + 0.5*dx;
+      ih_boundary_row(xavg, dx, A[i]);
+      B[i] = u[i];
+      x = x + dx;
+    }
+    rc |= orc_linear_solver6(A, B, C);
+    double f = 0.0;                            /* evaluation_polynomial( Csys, 6, x(1) = 0.0 ): 0.0**0 = 1.0 */
+    f = f + C[0] * 1.0;
+    for (int k = 1; k < 6; k++) f = f + C[k] * 0.0;
+    tri_l[0] = 0.0; tri_d[0] = 1.0; tri_u[0] = 0.0; tri_b[0] = f;
+  }
+  {
+    const double hMin = max2(hNeglect, hMinFrac*((h[n-4] + h[n-3]) + (h[n-2] + h[n-1])));
+    rc |= ih6_coefs(max2(h[n-4], hMin), max2(h[n-3], hMin), max2(h[n-2], hMin), max2(h[n-1], hMin), 2, C);
+    tri_l[n-1] = C[0]; tri_d[n-1] = 1.0; tri_u[n-1] = C[1];
+    tri_b[n-1] = C[2] * u[n-4] + C[3] * u[n-3] + C[4] * u[n-2] + C[5] * u[n-1];
+  }
+  {
+    /* (as the reference has it: hMinFrac multiplies the first pair only, :1436) */
+    const double hMin = max2( hNeglect, hMinFrac*(h[n-4] + h[n-3]) + ((h[n-2] + h[n-1]) + (h[n-6] + h[n-5])) );
+    double A[6][6], B[6], x = 0.0;
+    for (int i = 0; i < 6; i++) {
+      const double dx = max2( hMin, h[n-1-i] );
+      const double xavg = x + 0.5 * dx;
+      ih_boundary_row(xavg, dx, A[i]);
+      B[i] = u[n-1-i];
+      x = x + dx;
+    }
+    rc |= orc_linear_solver6(A, B, C);
+    tri_l[n] = 0.0; tri_d[n] = 1.0; tri_u[n] = 0.0; tri_b[n] = C[0];
+  }
+  orc_solve_tridiagonal_system_2018(tri_l, tri_d, tri_u, tri_b, tri_x, m);
+  for (int i = 1; i < n; i++) { E_(E,i,0) = tri_x[i]; E_(E,i-1,1) = tri_x[i]; }
+  E_(E,0,0) = tri_x[0];
+  E_(E,n-1,1) = tri_x[n];
+  free(tri_l);
+  return rc;
+}
+
 /* ---- remapping ---------------------------------------------------------------------------- */
 /* average_value_ppoly, MOM_remapping.F90:998-1099 (method: ORC_INT_PCM/PLM/PPM/PQM; i0 0-based) */
 double orc_average_value_ppoly(int n, const double *u0, const double *E, const double *coef, int method,
@@ -1080,7 +1350,7 @@ void orc_hybgen_weno_coefs(int nk, const double *s, const double *h_src, double 
 }
 
 /* build_reconstructions_1d, MOM_remapping.F90:257-386 (schemes PCM, PLM, PLM_HYBGEN, PPM_H4, PPM_IH4, PPM_HYBGEN, WENO_HYBGEN,
- * PPM_CW, PQM_IH4IH3; no PCM_cell).
+ * PPM_CW, PQM_IH4IH3, PQM_IH6IH5; no PCM_cell).
  * E and coef must hold 2*n0 and 5*n0 doubles.  Returns the integration method. */
 int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0, const double *h0, const double *u0,
                                  double *coef, double *E, double h_neglect, double h_neglect_edge)
@@ -1140,6 +1410,17 @@ int orc_build_reconstructions_1d(int scheme, int boundary_extrapolation, int n0,
       double *S = (double*)calloc((size_t)2*n0, sizeof(double));
       orc_edge_values_implicit_h4(n0, h0, u0, E, h_neglect_edge);
       orc_edge_slopes_implicit_h3(n0, h0, u0, S, h_neglect);
+      orc_pqm_reconstruction(n0, h0, u0, E, S, coef, h_neglect);
+      if (boundary_extrapolation) orc_pqm_boundary_extrapolation_v1(n0, h0, u0, E, S, coef, h_neglect);
+      free(S);
+      return ORC_INT_PQM;
+    }
+    case ORC_REMAP_PQM_IH6IH5: {   /* :361-370 (six cells at least: the boundary systems of both routines read cells 1..6) */
+      if (n0 < 6) return -998;
+      double *S = (double*)calloc((size_t)2*n0, sizeof(double));
+      int rc = orc_edge_values_implicit_h6(n0, h0, u0, E, h_neglect_edge);
+      rc |= orc_edge_slopes_implicit_h5(n0, h0, u0, S, h_neglect);
+      if (rc) { free(S); return -997; }      /* 'The linear system is singular !' */
       orc_pqm_reconstruction(n0, h0, u0, E, S, coef, h_neglect);
       if (boundary_extrapolation) orc_pqm_boundary_extrapolation_v1(n0, h0, u0, E, S, coef, h_neglect);
       free(S);

@@ -31,11 +31,17 @@ def remap_case(ni, nj, nk, ntr=3, seed=0, vanish=0.15):
     return g, np.ascontiguousarray(h_old), np.ascontiguousarray(h_new), tr
 
 
-@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PLM_HYBGEN", "PPM_H4", "PPM_IH4", "PPM_HYBGEN", "WENO_HYBGEN", "PPM_CW", "PQM_IH4IH3"])
+@pytest.mark.parametrize("scheme", ["PCM", "PLM", "PLM_HYBGEN", "PPM_H4", "PPM_IH4", "PPM_HYBGEN", "WENO_HYBGEN", "PPM_CW", "PQM_IH4IH3", "PQM_IH6IH5"])
 @pytest.mark.parametrize("extrap", [False, True])
 @pytest.mark.parametrize("nk", [2, 3, 4, 5, 8, 20, 75])
 def test_remap_tracers_parity(oracle, scheme, extrap, nk):
+    if scheme == "PQM_IH6IH5" and nk == 5:
+        pytest.skip("the reference's edge_values_implicit_h6 reads six cells of a five-cell column")
     g, h_old, h_new, tr = remap_case(70, 12, nk, seed=nk)
+    if scheme == "PQM_IH6IH5":
+        # edge_slopes_implicit_h5 takes the six widths at either end as they are (regrid_edge_values.F90:1166): two vanished cells among them make
+        # its system singular, a FATAL error in the reference
+        h_old = np.maximum(h_old, 1.0e-3)
     if scheme.startswith("PQM") and extrap:
         # PQM_boundary_extrapolation_v1 divides by the widths of the two cells at the bottom (PQM_functions.F90:672, :682, :709): a vanished
         # cell there is 0/0 in the reference too, with a NaN whose sign depends on the machine; the layers keep a minimum thickness instead
@@ -112,7 +118,7 @@ def test_remap_conserves_on_gpu(oracle):
 def test_remap_errors():
     from mom6_amd._lib import Mom6HipError
     with pytest.raises(Mom6HipError, match="REMAPPING_SCHEME"):
-        initialize_remapping("PQM_IH6IH5")
+        initialize_remapping("P3M_IH4IH3")
     g, h_old, h_new, tr = remap_case(10, 8, 4, ntr=1)
     dg = DeviceGrid(g)
     with pytest.raises(Mom6HipError, match="ANSWER_DATE"):

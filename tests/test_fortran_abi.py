@@ -403,7 +403,8 @@ def test_ale_shim_compiles():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
-def test_ale_shim_matches_oracle(tmp_path):
+@pytest.mark.parametrize("scheme,vel_scheme,nk", [("PPM_H4", "PLM", 6), ("PQM_IH4IH3", "PQM_IH6IH5", 12)])
+def test_ale_shim_matches_oracle(tmp_path, scheme, vel_scheme, nk):
     """ALE_init (Z*, UNIFORM, PPM_H4 / PLM, REGRID_TIME_SCALE with a deep filter, REMAP_BOUNDARY_EXTRAP through
     ALE_set_extrap_boundaries), ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers, ALE_remap_set_h_vel x2,
     ALE_remap_velocities through the MOM_ALE shim on Fortran host arrays, the sequence of MOM.F90:1647-1700: the oracle's bits"""
@@ -411,7 +412,7 @@ def test_ale_shim_matches_oracle(tmp_path):
     from oracle import orc
     from helpers import interior
     exe = _build_ale_shim(tmp_path)
-    ni, nj, nk, halo = 34, 18, 6, 4
+    ni, nj, halo = 34, 18, 4
     g = synth.make_grid(ni, nj, nk, halo=halo, land_frac=0.2, seed=21, reentrant_x=True, reentrant_y=False)
     d = {k: v.numpy() for k, v in synth.make_dynamics_state(g, seed=9, umax=0.3, eta_amp=0.5).items()}
     dt = 1800.0
@@ -430,13 +431,14 @@ def test_ale_shim_matches_oracle(tmp_path):
     rcs = orc.regridding_cs(res, min_thickness=1.0e-3, old_grid_weight=w, zs=0.0, zd=500.0)
     h_new, dz = orc.ale_regrid(g, rcs, d["h"])
     T, S = d["T"].copy(), d["S"].copy()
-    orc.ale_remap_tracers(g, "PPM_H4", d["h"], h_new, [T, S], conc_underflow=np.array([0.0, 1.0e-30]), boundary_extrapolation=True)
+    orc.ale_remap_tracers(g, scheme, d["h"], h_new, [T, S], conc_underflow=np.array([0.0, 1.0e-30]), boundary_extrapolation=True)
     hu0, hv0 = orc.ale_remap_set_h_vel(g, d["h"])
     hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
     u, v = d["u"].copy(), d["v"].copy()
     # (the velocities' remapping structure keeps INIT_BOUNDARY_EXTRAP = False: ALE_set_extrap_boundaries sets the tracers' only, MOM_ALE.F90:336)
-    orc.ale_remap_velocities(g, "PLM", hu0, hv0, hu1, hv1, u, v, boundary_extrapolation=False)
-    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    orc.ale_remap_velocities(g, vel_scheme, hu0, hv0, hu1, hv1, u, v, boundary_extrapolation=False)
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), f"REMAPPING_SCHEME={scheme}", f"VELOCITY_REMAPPING_SCHEME={vel_scheme}"],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "ale_driver ok" in r.stdout
     want = [h_new, dz, T, S, hu1, hv1, u, v]

@@ -791,12 +791,13 @@ def ale_exe(tmp_path_factory):
 
 @pytest.mark.parametrize("scheme,vel_scheme,extrap", [("PPM_H4", "PLM", True), ("PPM_H4", "PPM_H4", False), ("PLM", "PLM", False), ("PPM_IH4", "PLM", True),
                                                       ("PCM", "PCM", False), ("PPM_CW", "PPM_CW", False), ("PPM_HYBGEN", "PLM_HYBGEN", False),
-                                                      ("WENO_HYBGEN", "PLM", False), ("PQM_IH4IH3", "PQM_IH4IH3", True), ("PQM_IH4IH3", "PLM", False)])
+                                                      ("WENO_HYBGEN", "PLM", False), ("PQM_IH4IH3", "PQM_IH4IH3", True), ("PQM_IH4IH3", "PLM", False),
+                                                      ("PQM_IH6IH5", "PQM_IH6IH5", True), ("PQM_IH6IH5", "PLM", False)])
 def test_reference_ale_regrid_and_remap_equal_the_oracle(tmp_path, ale_exe, scheme, vel_scheme, extrap):
     """ALE_init (Z*, UNIFORM resolution, REGRID_TIME_SCALE with the deep filter), ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers,
     ALE_remap_set_h_vel x2, ALE_remap_velocities of the reference's own MOM_ALE / MOM_regridding / coord_zlike / MOM_remapping, the sequence of
     MOM.F90:1647-1700: the new grid, the interface movement, the remapped T, S, u, v and the face thicknesses equal the oracle's bit for bit,
-    for the nine remapping schemes the library provides"""
+    for the ten remapping schemes the library provides"""
     from mom6_amd import synth
     from oracle import orc
     ni, nj, nk, halo = 34, 18, (14 if scheme.startswith("PQM") else 6), 4
