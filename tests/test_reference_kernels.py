@@ -31,23 +31,41 @@ pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), re
               pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")]
 
 @pytest.fixture(scope="module")
-def visc_exe(tmp_path_factory):
-    return build_ref_visc_driver(tmp_path_factory.mktemp("ref_visc"))
+def ref_builds(tmp_path_factory):
+    """every reference executable of this file, built side by side (each build is a chain of modules, the builds are independent of each other):
+    the fixtures below wait for their own"""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = {
+        "visc_exe": (build_ref_visc_driver, "ref_visc", {}), "visc_full_exe": (build_ref_visc_driver_full, "ref_visc_full", {}),
+        "pf_exe": (build_ref_pf_driver, "ref_pf", {}), "dyn_exe": (build_ref_dyn_driver, "ref_dyn", {}), "ref_exe": (build_ref_kernels, "ref_kernels", {}),
+        "ref_bt_exe": (lambda tmp: build_ref_module_driver(tmp, ["src/core/MOM_barotropic.F90"], "bt_driver"), "ref_bt", {}),
+        "mle_exe": (build_ref_mle_driver, "ref_mle", {}), "td_exe": (build_ref_td_driver, "ref_td", {}), "ale_exe": (build_ref_ale_driver, "ref_ale", {}),
+        "dyn_rk2b_exe": (build_ref_dyn_driver, "ref_dyn_rk2b", dict(rk2b=True)), "tracer_exe": (build_ref_tracer_driver, "ref_tracer", {}),
+    }
+    pool = ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1))
+    futures = {name: pool.submit(f, tmp_path_factory.mktemp(d), **kw) for name, (f, d, kw) in jobs.items()}
+    yield futures
+    pool.shutdown(wait=True, cancel_futures=True)
 
 
 @pytest.fixture(scope="module")
-def visc_full_exe(tmp_path_factory):
-    return build_ref_visc_driver_full(tmp_path_factory.mktemp("ref_visc_full"))
+def visc_exe(ref_builds):
+    return ref_builds["visc_exe"].result()
 
 
 @pytest.fixture(scope="module")
-def pf_exe(tmp_path_factory):
-    return build_ref_pf_driver(tmp_path_factory.mktemp("ref_pf"))
+def visc_full_exe(ref_builds):
+    return ref_builds["visc_full_exe"].result()
 
 
 @pytest.fixture(scope="module")
-def dyn_exe(tmp_path_factory):
-    return build_ref_dyn_driver(tmp_path_factory.mktemp("ref_dyn"))
+def pf_exe(ref_builds):
+    return ref_builds["pf_exe"].result()
+
+
+@pytest.fixture(scope="module")
+def dyn_exe(ref_builds):
+    return ref_builds["dyn_exe"].result()
 
 
 
@@ -121,8 +139,8 @@ def position_of(n):
 
 
 @pytest.fixture(scope="module")
-def ref_exe(tmp_path_factory):
-    return build_ref_kernels(tmp_path_factory.mktemp("ref_kernels"))
+def ref_exe(ref_builds):
+    return ref_builds["ref_exe"].result()
 
 
 @pytest.mark.parametrize("scheme,x_first,shape", [("PPM:H3", -1, (30, 14, 4)), ("PLM", 0, (22, 17, 3)), ("PPM", 1, (26, 12, 5))])
@@ -265,8 +283,8 @@ def build_ref_module_driver(tmp, ref_sources, driver, opt="-O0"):
 
 
 @pytest.fixture(scope="module")
-def ref_bt_exe(tmp_path_factory):
-    return build_ref_module_driver(tmp_path_factory.mktemp("ref_bt"), ["src/core/MOM_barotropic.F90"], "bt_driver")
+def ref_bt_exe(ref_builds):
+    return ref_builds["ref_bt_exe"].result()
 
 
 @pytest.mark.parametrize("kw,params,exact", [(dict(strong_drag=1), ["BT_STRONG_DRAG=True"], True), (dict(strong_drag=1, ni=40, nj=30, seed=11), ["BT_STRONG_DRAG=True"], True),
@@ -687,8 +705,8 @@ def build_ref_mle_driver(tmp):
 
 
 @pytest.fixture(scope="module")
-def mle_exe(tmp_path_factory):
-    return build_ref_mle_driver(tmp_path_factory.mktemp("ref_mle"))
+def mle_exe(ref_builds):
+    return ref_builds["mle_exe"].result()
 
 
 def test_reference_mixedlayer_restrat_equals_the_oracle(tmp_path, mle_exe):
@@ -731,8 +749,8 @@ def build_ref_td_driver(tmp):
 
 
 @pytest.fixture(scope="module")
-def td_exe(tmp_path_factory):
-    return build_ref_td_driver(tmp_path_factory.mktemp("ref_td"))
+def td_exe(ref_builds):
+    return ref_builds["td_exe"].result()
 
 
 def test_reference_thickness_diffuse_equals_the_oracle(tmp_path, td_exe):
@@ -785,8 +803,8 @@ def build_ref_ale_driver(tmp):
 
 
 @pytest.fixture(scope="module")
-def ale_exe(tmp_path_factory):
-    return build_ref_ale_driver(tmp_path_factory.mktemp("ref_ale"))
+def ale_exe(ref_builds):
+    return ref_builds["ale_exe"].result()
 
 
 @pytest.mark.parametrize("scheme,vel_scheme,extrap", [("PPM_H4", "PLM", True), ("PPM_H4", "PPM_H4", False), ("PLM", "PLM", False), ("PPM_IH4", "PLM", True),
@@ -849,8 +867,8 @@ def test_reference_ale_regrid_and_remap_equal_the_oracle(tmp_path, ale_exe, sche
 
 
 @pytest.fixture(scope="module")
-def dyn_rk2b_exe(tmp_path_factory):
-    return build_ref_dyn_driver(tmp_path_factory.mktemp("ref_dyn_rk2b"), rk2b=True)
+def dyn_rk2b_exe(ref_builds):
+    return ref_builds["dyn_rk2b_exe"].result()
 
 
 @pytest.mark.parametrize("name", ["tc4", "bench_like"])
@@ -906,8 +924,8 @@ def build_ref_tracer_driver(tmp):
 
 
 @pytest.fixture(scope="module")
-def tracer_exe(tmp_path_factory):
-    return build_ref_tracer_driver(tmp_path_factory.mktemp("ref_tracer"))
+def tracer_exe(ref_builds):
+    return ref_builds["tracer_exe"].result()
 
 
 def test_reference_tracer_advect_and_hordiff_equal_the_oracle(tmp_path, tracer_exe):

@@ -622,10 +622,12 @@ def cycle_oracle(name, state, ncycles, nsteps):
             rcs = orc.regridding_cs(np.full(g.nk, float(g.bathyT.max()) / g.nk), min_thickness=1.0e-3, old_grid_weight=ts / (ts + dt_therm), zs=0.0,
                                     zd=float(p["REGRID_FILTER_DEEP_DEPTH"]))
             h_new, _ = orc.ale_regrid(g, rcs, st.h)
-            orc.ale_remap_tracers(g, p["REMAPPING_SCHEME"], st.h, h_new, [st.T, st.S], boundary_extrapolation=True)
+            # (ALE_set_extrap_boundaries switches the tracers' remapping structure to REMAP_BOUNDARY_EXTRAP, MOM_ALE.F90:336; the velocities'
+            # keeps INIT_BOUNDARY_EXTRAP, :256-261 -- as the reference's own MOM_ALE shows in tests/test_reference_kernels.py)
+            orc.ale_remap_tracers(g, p["REMAPPING_SCHEME"], st.h, h_new, [st.T, st.S], boundary_extrapolation=_b(p, "REMAP_BOUNDARY_EXTRAP"))
             hu0, hv0 = orc.ale_remap_set_h_vel(g, st.h)
             hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
-            orc.ale_remap_velocities(g, p["VELOCITY_REMAPPING_SCHEME"], hu0, hv0, hu1, hv1, st.u, st.v, boundary_extrapolation=True)
+            orc.ale_remap_velocities(g, p["VELOCITY_REMAPPING_SCHEME"], hu0, hv0, hu1, hv1, st.u, st.v, boundary_extrapolation=_b(p, "INIT_BOUNDARY_EXTRAP"))
             sj, si = g.csl(H)
             sj, si = slice(sj.start - 1, sj.stop + 1), slice(si.start - 1, si.stop + 1)
             st.h[:, sj, si] = h_new[:, sj, si]
