@@ -204,6 +204,11 @@ if (len_trim(f_obc) > 0) then
     allocate(OBC%segment(m)%normal_vel(i0:i1,j0:j1,nk), OBC%segment(m)%normal_trans(i0:i1,j0:j1,nk), OBC%segment(m)%normal_vel_bt(i0:i1,j0:j1), &
              OBC%segment(m)%SSH(i0:i1,j0:j1))
     read(u_obc) OBC%segment(m)%normal_vel, OBC%segment(m)%normal_trans, OBC%segment(m)%normal_vel_bt, OBC%segment(m)%SSH
+#ifdef REF_OBC
+    ! (the reference's own MOM_open_boundary.F90: what allocate_OBC_segment_data gives a radiating segment, :3642, :3678)
+    if (OBC%segment(m)%radiation .and. OBC%segment(m)%is_E_or_W) allocate(OBC%segment(m)%rx_norm_rad(i0:i1,j0:j1,nk), source=0.0)
+    if (OBC%segment(m)%radiation .and. OBC%segment(m)%is_N_or_S) allocate(OBC%segment(m)%ry_norm_rad(i0:i1,j0:j1,nk), source=0.0)
+#endif
   endif ; enddo
   allocate(OBC%rx_normal(isd-1:ied,jsd:jed,nk), source=0.0) ; allocate(OBC%ry_normal(isd:ied,jsd-1:jed,nk), source=0.0)
   close(u_obc)

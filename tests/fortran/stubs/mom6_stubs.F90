@@ -80,9 +80,9 @@ end module MOM_string_functions
 
 module MOM_coms
 implicit none ; private
-public :: num_PEs, PE_here, sum_across_PEs, min_across_PEs, max_across_PEs
+public :: num_PEs, PE_here, sum_across_PEs, min_across_PEs, max_across_PEs, Set_PElist, Get_PElist
 interface sum_across_PEs
-  module procedure sum_int_1d
+  module procedure sum_int_1d, sum_int_0d
 end interface
 interface min_across_PEs
   module procedure min_real_0d
@@ -93,6 +93,21 @@ end interface
 contains
 integer function num_PEs() ; num_PEs = 1 ; end function num_PEs
 integer function PE_here() ; PE_here = 0 ; end function PE_here
+subroutine Set_PElist(pelist, no_sync)      ! (one PE: nothing to set)
+  integer, optional, intent(in) :: pelist(:)
+  logical, optional, intent(in) :: no_sync
+end subroutine Set_PElist
+subroutine Get_PElist(pelist, name, commID)
+  integer,                    intent(out) :: pelist(:)
+  character(len=*), optional, intent(out) :: name
+  integer,          optional, intent(out) :: commID
+  pelist(:) = 0
+  if (present(name)) name = "one PE"
+  if (present(commID)) commID = 0
+end subroutine Get_PElist
+subroutine sum_int_0d(field)      ! (one PE)
+  integer, intent(inout) :: field
+end subroutine sum_int_0d
 subroutine sum_int_1d(field, length)
   integer, intent(inout) :: field(:)
   integer, intent(in)    :: length
@@ -248,6 +263,7 @@ implicit none ; private
 public :: hor_index_type
 type :: hor_index_type
   integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB
+  integer :: isg = 0, ieg = 0, jsg = 0, jeg = 0, IsgB = 0, IegB = 0, JsgB = 0, JegB = 0
   integer :: idg_offset = 0, jdg_offset = 0, turns = 0
   logical :: symmetric = .true.
 end type hor_index_type
@@ -270,7 +286,7 @@ use MOM_domains, only : MOM_domain_type
 use MOM_hor_index, only : hor_index_type
 use MOM_unit_scaling, only : unit_scale_type
 implicit none ; private
-public :: ocean_grid_type
+public :: ocean_grid_type, hor_index_type
 type :: ocean_grid_type
   type(MOM_domain_type), pointer :: Domain => NULL()
   integer :: isc, iec, jsc, jec, isd, ied, jsd, jed, IscB, IecB, JscB, JecB, IsdB, IedB, JsdB, JedB, ke
@@ -328,7 +344,7 @@ end module MOM_verticalGrid
 
 module MOM_time_manager
 implicit none ; private
-public :: time_type, time_type_to_real, real_to_time, operator(+), operator(-), operator(*), operator(/), operator(>), operator(<)
+public :: time_type, time_type_to_real, real_to_time, set_date, operator(+), operator(-), operator(*), operator(/), operator(>), operator(<)
 type :: time_type
   integer :: seconds = 0, days = 0
 end type time_type
@@ -348,6 +364,13 @@ type(time_type) function real_to_time(x, err_msg)
   character(len=*), optional, intent(out) :: err_msg
   real_to_time%days = int(x / 86400.0) ; real_to_time%seconds = int(x - 86400.0*real_to_time%days)
 end function real_to_time
+type(time_type) function set_date(year, month, day, hour, minute, second, err_msg)      ! (tidal reference dates only: no calendar in the stand-in)
+  integer,                    intent(in)  :: year, month, day
+  integer,          optional, intent(in)  :: hour, minute, second
+  character(len=*), optional, intent(out) :: err_msg
+  set_date%days = 0 ; set_date%seconds = 0
+  error stop "set_date stand-in: no calendar"
+end function set_date
 type(time_type) function time_plus(a, b)
   type(time_type), intent(in) :: a, b
   time_plus%days = a%days + b%days ; time_plus%seconds = a%seconds + b%seconds
@@ -410,7 +433,7 @@ type :: param_file_type
   character(len=128) :: values(256)
 end type param_file_type
 interface get_param
-  module procedure get_param_logical, get_param_real, get_param_int, get_param_char, get_param_real_array
+  module procedure get_param_logical, get_param_real, get_param_int, get_param_char, get_param_real_array, get_param_int_array
 end interface
 interface log_param
   module procedure log_param_logical, log_param_real, log_param_int, log_param_char, log_param_real_array
@@ -550,6 +573,23 @@ subroutine get_param_real_array(CS, modulename, varname, value, desc, units, def
   endif
   if (present(scale)) value(:) = scale * value(:)
 end subroutine get_param_real_array
+subroutine get_param_int_array(CS, modulename, varname, value, desc, units, default, fail_if_missing, do_not_read, do_not_log, &
+                               layoutParam, debuggingParam)
+  type(param_file_type), intent(in)    :: CS
+  character(len=*),      intent(in)    :: modulename, varname
+  integer, dimension(:), intent(inout) :: value
+  character(len=*), optional, intent(in) :: desc, units
+  integer, optional,     intent(in)    :: default
+  logical, optional,     intent(in)    :: fail_if_missing, do_not_read, do_not_log, layoutParam, debuggingParam
+  character(len=128) :: v ; logical :: found
+  v = lookup(CS, varname, found)
+  if (found) then
+    read(v, *) value
+  else
+    if (present(default)) value(:) = default
+    call missing(varname, fail_if_missing)
+  endif
+end subroutine get_param_int_array
 subroutine get_param_int(CS, modulename, varname, value, desc, units, default, fail_if_missing, do_not_read, do_not_log, &
                          layoutParam, debuggingParam)
   type(param_file_type), intent(in)    :: CS
@@ -790,7 +830,7 @@ end module MOM_safe_alloc
 module MOM_io
 use MOM_domains, only : CENTER, CORNER, EAST_FACE, NORTH_FACE
 implicit none ; private
-public :: vardesc, var_desc, CENTER, CORNER, EAST_FACE, NORTH_FACE, stdout, stderr, MOM_read_data, slasher
+public :: vardesc, var_desc, query_vardesc, CENTER, CORNER, EAST_FACE, NORTH_FACE, stdout, stderr, MOM_read_data, slasher
 public :: file_exists, field_exists, field_size, SINGLE_FILE, MULTIPLE, create_MOM_file, MOM_write_field, MOM_file, MOM_infra_file, MOM_netCDF_file, MOM_field
 public :: verify_variable_units
 interface MOM_read_data
@@ -884,6 +924,27 @@ function var_desc(name, units, longname, hor_grid, z_grid, t_grid, cmor_field_na
   if (present(z_grid)) vd%z_grid = z_grid
   if (present(conversion)) vd%conversion = conversion
 end function var_desc
+subroutine query_vardesc(vd, name, units, longname, hor_grid, z_grid, t_grid, cmor_field_name, cmor_units, cmor_longname, conversion, caller, &
+                         position, dim_names)
+  type(vardesc),              intent(in)  :: vd
+  character(len=*), optional, intent(out) :: name, units, longname, hor_grid, z_grid, t_grid, cmor_field_name, cmor_units, cmor_longname
+  real            , optional, intent(out) :: conversion
+  character(len=*), optional, intent(in)  :: caller
+  integer,          optional, intent(out) :: position
+  character(len=*), dimension(:), optional, intent(out) :: dim_names
+  if (present(name)) name = vd%name
+  if (present(units)) units = vd%units
+  if (present(longname)) longname = vd%longname
+  if (present(hor_grid)) hor_grid = vd%hor_grid
+  if (present(z_grid)) z_grid = vd%z_grid
+  if (present(t_grid)) t_grid = vd%t_grid
+  if (present(cmor_field_name)) cmor_field_name = ""
+  if (present(cmor_units)) cmor_units = ""
+  if (present(cmor_longname)) cmor_longname = ""
+  if (present(conversion)) conversion = vd%conversion
+  if (present(position)) position = vd%position
+  if (present(dim_names)) dim_names(:) = ""
+end subroutine query_vardesc
 !> No files in the stand-in: a read is an error
 subroutine MOM_read_data_2d(filename, fieldname, data, MOM_Domain, timelevel, position, scale, global_file, file_may_be_4d)
   use MOM_domains, only : MOM_domain_type
@@ -1439,7 +1500,7 @@ module MOM_tracer_registry
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
 implicit none ; private
-public :: tracer_registry_type, tracer_type, MOM_tracer_chkinv, MOM_tracer_chksum
+public :: tracer_registry_type, tracer_type, MOM_tracer_chkinv, MOM_tracer_chksum, tracer_name_lookup
 interface MOM_tracer_chksum
   module procedure tracer_array_chksum, tracer_Reg_chksum
 end interface MOM_tracer_chksum
@@ -1464,6 +1525,19 @@ type :: tracer_registry_type
   type(tracer_type) :: Tr(16)
 end type tracer_registry_type
 contains
+subroutine tracer_name_lookup(Reg, n, tr_ptr, name)      ! MOM_tracer_registry.F90:912 (names compared as they are: the stand-in has no lowercase here)
+  type(tracer_registry_type), pointer    :: Reg
+  type(tracer_type), pointer             :: tr_ptr
+  character(len=32), intent(in)          :: name
+  integer, intent(out)                   :: n
+  do n=1,Reg%ntr
+    if (trim(Reg%Tr(n)%name) == trim(name)) then
+      tr_ptr => Reg%Tr(n)
+      return
+    endif
+  enddo
+  error stop "MOM cannot find registered tracer"
+end subroutine tracer_name_lookup
 !> the debugging inventories of MOM_tracer_registry.F90 (printed with DEBUG only): nothing is printed here
 subroutine tracer_array_chksum(mesg, Tr, ntr, G)      ! (debugging checksums: nothing is printed)
   character(len=*),      intent(in) :: mesg
@@ -1535,10 +1609,39 @@ use MOM_file_parser, only : param_file_type
 use MOM_time_manager, only : time_type
 implicit none ; private
 public :: tidal_forcing_CS, tidal_forcing_init, tidal_forcing_end, calc_tidal_forcing, calc_tidal_forcing_legacy
+public :: astro_longitudes, astro_longitudes_init, eq_phase, nodal_fu, tidal_frequency
+type :: astro_longitudes
+  real :: s = 0.0, h = 0.0, p = 0.0, N = 0.0
+end type astro_longitudes
 type :: tidal_forcing_CS
   integer :: unused = 0
 end type tidal_forcing_CS
 contains
+subroutine astro_longitudes_init(time_ref, longitudes)      ! (tidal segment data: not provided)
+  type(time_type), intent(in) :: time_ref
+  type(astro_longitudes), intent(out) :: longitudes
+  error stop "astro_longitudes_init stand-in: tides are not provided"
+end subroutine astro_longitudes_init
+function eq_phase(constit, longitudes)
+  character (len=2), intent(in) :: constit
+  type(astro_longitudes), intent(in) :: longitudes
+  real :: eq_phase
+  eq_phase = 0.0
+  error stop "eq_phase stand-in: tides are not provided"
+end function eq_phase
+function tidal_frequency(constit)
+  character (len=2), intent(in) :: constit
+  real :: tidal_frequency
+  tidal_frequency = 0.0
+  error stop "tidal_frequency stand-in: tides are not provided"
+end function tidal_frequency
+subroutine nodal_fu(constit, nodelon, fn, un)
+  character (len=2), intent(in)  :: constit
+  real,              intent(in)  :: nodelon
+  real,              intent(out) :: fn, un
+  fn = 1.0 ; un = 0.0
+  error stop "nodal_fu stand-in: tides are not provided"
+end subroutine nodal_fu
 subroutine calc_tidal_forcing(Time, e_tide_eq, e_tide_sal, G, US, CS)
   type(ocean_grid_type),            intent(in)  :: G
   type(time_type),                  intent(in)  :: Time
@@ -1628,6 +1731,7 @@ subroutine extract_diabatic_member(CS, evap_CFL_limit, minimum_forcing_depth, KP
 end subroutine extract_diabatic_member
 end module MOM_diabatic_driver
 
+#ifndef REF_OBC
 module MOM_open_boundary
 use MOM_hor_index, only : hor_index_type
 use MOM_grid, only : ocean_grid_type
@@ -1722,79 +1826,9 @@ subroutine radiation_open_bdry_conds(OBC, u_new, u_old, v_new, v_old, G, GV, US,
 end subroutine radiation_open_bdry_conds
 end module MOM_open_boundary
 
-module MOM_lateral_mixing_coeffs
-implicit none ; private
-public :: VarMix_CS, calc_QG_slopes, calc_QG_Leith_viscosity
-type :: VarMix_CS
-  logical :: use_variable_mixing = .false., Resoln_scaled_Kh = .false., Resoln_scaled_KhTr = .false., Resoln_scaled_KhTh = .false.
-  logical :: Depth_scaled_KhTh = .false., use_stored_slopes = .false., khth_use_ebt_struct = .false., use_Visbeck = .false.
-  logical :: use_QG_Leith_GM = .false., kdgl90_use_ebt_struct = .false.
-  real, allocatable, dimension(:,:) :: L2u, L2v, SN_u, SN_v, Res_fn_u, Res_fn_v, Res_fn_h, Res_fn_q, Rd_dx_h, cg1, Depth_fn_u, Depth_fn_v
-  real, allocatable, dimension(:,:,:) :: slope_x, slope_y, ebt_struct, KH_u_QG, KH_v_QG
-end type VarMix_CS
-contains
-subroutine calc_QG_slopes(h, tv, dt, G, GV, US, slope_x, slope_y, CS, OBC)
-  use MOM_grid, only : ocean_grid_type
-  use MOM_verticalGrid, only : verticalGrid_type
-  use MOM_unit_scaling, only : unit_scale_type
-  use MOM_variables, only : thermo_var_ptrs
-  use MOM_open_boundary, only : ocean_OBC_type
-  type(ocean_grid_type),   intent(in)    :: G
-  type(verticalGrid_type), intent(in)    :: GV
-  type(unit_scale_type),   intent(in)    :: US
-  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h
-  type(thermo_var_ptrs),   intent(in)    :: tv
-  real,                    intent(in)    :: dt
-  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke+1), intent(inout) :: slope_x
-  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke+1), intent(inout) :: slope_y
-  type(VarMix_CS),         intent(in)    :: CS
-  type(ocean_OBC_type),    pointer       :: OBC
-  error stop "calc_QG_slopes stand-in: not provided"
-end subroutine calc_QG_slopes
-subroutine calc_QG_Leith_viscosity(CS, G, GV, US, h, dz, k, div_xx_dx, div_xx_dy, slope_x, slope_y, vort_xy_dx, vort_xy_dy)
-  use MOM_grid, only : ocean_grid_type
-  use MOM_verticalGrid, only : verticalGrid_type
-  use MOM_unit_scaling, only : unit_scale_type
-  type(VarMix_CS),         intent(inout) :: CS
-  type(ocean_grid_type),   intent(in)    :: G
-  type(verticalGrid_type), intent(in)    :: GV
-  type(unit_scale_type),   intent(in)    :: US
-  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(in) :: h, dz
-  integer,                 intent(in)    :: k
-  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed), intent(in) :: div_xx_dx
-  real, dimension(G%isd:G%ied,G%JsdB:G%JedB), intent(in) :: div_xx_dy
-  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed,GV%ke+1), intent(in) :: slope_x
-  real, dimension(G%isd:G%ied,G%JsdB:G%JedB,GV%ke+1), intent(in) :: slope_y
-  real, dimension(G%isd:G%ied,G%JsdB:G%JedB), intent(inout) :: vort_xy_dx
-  real, dimension(G%IsdB:G%IedB,G%jsd:G%jed), intent(inout) :: vort_xy_dy
-  error stop "calc_QG_Leith_viscosity stand-in: not provided"
-end subroutine calc_QG_Leith_viscosity
-end module MOM_lateral_mixing_coeffs
+#include "mom6_stubs_after_obc.inc"
+#endif
 
-module MOM_boundary_update
-use MOM_grid, only : ocean_grid_type
-use MOM_verticalGrid, only : verticalGrid_type
-use MOM_unit_scaling, only : unit_scale_type
-use MOM_time_manager, only : time_type
-use MOM_variables, only : thermo_var_ptrs
-use MOM_open_boundary, only : ocean_OBC_type
-implicit none ; private
-public :: update_OBC_CS, update_OBC_data
-type :: update_OBC_CS
-  integer :: unused = 0
-end type update_OBC_CS
-contains
-subroutine update_OBC_data(OBC, G, GV, US, tv, h, CS, Time)
-  type(ocean_grid_type),                     intent(in)    :: G
-  type(verticalGrid_type),                   intent(in)    :: GV
-  type(unit_scale_type),                     intent(in)    :: US
-  type(thermo_var_ptrs),                     intent(in)    :: tv
-  real, dimension(G%isd:G%ied,G%jsd:G%jed,GV%ke), intent(inout) :: h
-  type(ocean_OBC_type),                      pointer       :: OBC
-  type(update_OBC_CS),                       pointer       :: CS
-  type(time_type),                           intent(in)    :: Time
-end subroutine update_OBC_data
-end module MOM_boundary_update
 
 module MOM_wave_interface
 use MOM_grid, only : ocean_grid_type

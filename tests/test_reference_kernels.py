@@ -27,6 +27,11 @@ STUBS = os.path.join(ROOT, "tests", "fortran", "stubs")
 REF_SOURCES = ("src/core/MOM_continuity_PPM.F90", "src/core/MOM_CoriolisAdv.F90", "src/tracer/MOM_tracer_advect.F90")
 SCHEMES = {"PLM": 0, "PPM:H3": 1, "PPM": 2}
 
+def _unlimited_stack():      # (the reference's automatic arrays)
+    import resource
+    resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+
+
 pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference is not mounted (GPU box)"),
               pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")]
 
@@ -41,6 +46,7 @@ def ref_builds(tmp_path_factory):
         "ref_bt_exe": (lambda tmp: build_ref_module_driver(tmp, ["src/core/MOM_barotropic.F90"], "bt_driver"), "ref_bt", {}),
         "mle_exe": (build_ref_mle_driver, "ref_mle", {}), "td_exe": (build_ref_td_driver, "ref_td", {}), "ale_exe": (build_ref_ale_driver, "ref_ale", {}),
         "dyn_rk2b_exe": (build_ref_dyn_driver, "ref_dyn_rk2b", dict(rk2b=True)), "tracer_exe": (build_ref_tracer_driver, "ref_tracer", {}),
+        "dyn_obc_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc", {}),
     }
     pool = ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1))
     futures = {name: pool.submit(f, tmp_path_factory.mktemp(d), **kw) for name, (f, d, kw) in jobs.items()}
@@ -968,3 +974,92 @@ def test_reference_epipycnal_diffusion_equals_the_oracle(tmp_path, tracer_exe):
                 bad.append((params, m, int((interior(g, raw[m]) != interior(g, w)).sum()), float(np.abs(interior(g, raw[m]) - interior(g, w)).max())))
         assert not bits_equal(interior(g, raw[2]), interior(g, tr[2]))
     assert not bad, bad
+
+
+# ---- the reference's whole dynamical core WITH ITS OWN MOM_open_boundary.F90 beside the oracle --------------------------------------------------------
+def build_ref_dyn_obc_driver(tmp):
+    """tests/fortran/dyn_driver.F90 (-DREFERENCE_KERNELS -DREF_OBC) on the reference's own MOM_open_boundary.F90 (6116 lines, in place; under it the
+    reference's MOM_interface_heights, remapping / regridding stack and MOM_array_transform; stand-ins for the grid type of the initialisation, file
+    interpolation, tides and the obsolete-parameter checks) and, compiled against IT, the reference's MOM_dynamics_split_RK2.F90 with every module
+    it steps through (continuity, CoriolisAdv, PressureForce, barotropic, set_viscosity, vert_friction, hor_visc)"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF_MONT", "-DREF_SET_VISC",
+             "-DREF_INTERFACE_HEIGHTS", "-DREF_ALE", "-DREF_OBC",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    S, R = (lambda n: os.path.join(STUBS, n)), (lambda n: os.path.join(REF, n))
+    srcs = [S("mom6_stubs.F90")] + [R(r) for r in ALE_SOURCES[:-1]] + [R("src/framework/MOM_array_transform.F90"), S("mom6_stubs_obc.F90"),
+            R("src/core/MOM_open_boundary.F90"), R(ALE_SOURCES[-1]), S("mom6_stubs_after_obc.F90"), S("mom6_stubs_setvisc.F90"), R("src/framework/MOM_intrinsic_functions.F90"),
+            R("src/parameterizations/vertical/MOM_set_viscosity.F90"), S("mom6_stubs_visc.F90")] + \
+           [R(r) for r in VISC_SOURCES + CORE_SOURCES if r != "src/core/MOM_density_integrals.F90"] + [os.path.join(ROOT, "tests", "fortran", "dyn_driver.F90")]
+    objs = []
+    for src in srcs:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "dyn_obc_ref_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def dyn_obc_exe(ref_builds):
+    return ref_builds["dyn_obc_exe"].result()
+
+
+TC3 = ["J=N,I=N:0,FLATHER,ORLANSKI", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,FLATHER,ORLANSKI", "I=0,J=N:0,FLATHER,ORLANSKI"]
+OBC_DYN_CASES = {
+    "tc3": (TC3, "synthetic", 3),                                              # the transcribed parameter set of .testing/tc3 on a random state
+    "tc3_as_it_runs": (TC3, "config", 180),                                    # the disc of circle_obcs for DAYMAX = 6 h
+    "mixed": (TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"], "synthetic", 3),      # a specified and a Flather-only segment with external data
+    "gradient": (["J=N,I=N:0,GRADIENT", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,FLATHER,GRADIENT", "I=0,J=N:0,SIMPLE"], "synthetic", 3),
+    "inner": (["I=N,J=0:N,FLATHER,ORLANSKI", "J=5,I=N:0,SIMPLE"], "synthetic", 3),       # a segment inside the domain
+}
+
+
+@pytest.mark.parametrize("case", list(OBC_DYN_CASES))
+def test_reference_dynamical_core_with_its_own_open_boundaries_equals_the_oracle(tmp_path, dyn_obc_exe, case, monkeypatch):
+    """set_visc_init(OBC), initialize_dyn_split_RK2(OBC), then set_viscous_BBL and step_MOM_dyn_split_RK2 of the reference with its own
+    MOM_open_boundary.F90 (radiation_open_bdry_conds, open_boundary_zero_normal_flow, the OBC branches of every operator, btstep's
+    apply_velocity_OBCs / set_up_BT_OBC): the prognostic fields, the transports, eta_av, OBC%rx_normal / ry_normal and every segment's normal_vel
+    equal the oracle's bit for bit -- for .testing/tc3 as it runs (its own initial condition, all 180 steps) and for sets with specified,
+    Flather-only, gradient and interior segments carrying external data"""
+    import test_testing_configs as tc
+    segs, ic, nsteps = OBC_DYN_CASES[case]
+    monkeypatch.setattr(tc, "TC3_SEGMENTS", segs)
+    try:
+        state, OBC = tc.tc3_case(ic=ic)
+        g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+        rng = np.random.default_rng(11)
+        for s in OBC.segment:      # external values of the specified and Flather segments (zero in tc3 itself)
+            if case.startswith("tc3") or not s.on_pe:
+                continue
+            if s.specified:
+                s.normal_vel[:] = 0.05 * rng.standard_normal(s.normal_vel.shape)
+                s.normal_trans[:] = s.normal_vel * (3.0e4 * (5.0 + 50.0 * rng.random(s.normal_vel.shape)))
+            if s.Flather:
+                s.normal_vel_bt[:] = 0.02 * rng.standard_normal(s.normal_vel_bt.shape); s.SSH[:] = 0.05 * rng.standard_normal(s.SSH.shape)
+        tc.write_case(tmp_path, "tc3", nsteps, False, state, bbl_mode=1)
+        tc.write_obc_file(str(tmp_path / "obc.bin"), g, OBC)
+        r = subprocess.run([dyn_obc_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt"), str(tmp_path / "obc.bin")],
+                           capture_output=True, text=True, preexec_fn=_unlimited_stack)
+        assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-3000:]
+        st, calc, _ = tc.oracle_for("tc3", g, d, ustar, bbl, Rlay, g_prime, OBC=OBC)
+        for n in range(nsteps):
+            st.bbl(); st.step(taux, tauy, calc_dtbt=calc(n))
+        got = tc.read_out(str(tmp_path / "out.bin"), g, OBC=OBC)
+        want = dict(u=st.u, v=st.v, h=st.h, uh=st.uh, vh=st.vh, uhtr=st.uhtr, vhtr=st.vhtr, eta_av=st.eta_av)
+        bad = [(n, float(np.abs(got[n] - want[n]).max())) for n, pos, nd in tc.OUT
+               if n in want and not bits_equal(interior(g, got[n], pos), interior(g, want[n], pos))]
+        if not bits_equal(interior(g, got["rx_normal"], _abi.POS_U), interior(g, OBC.rx_normal, _abi.POS_U)):
+            bad.append("rx_normal")
+        if not bits_equal(interior(g, got["ry_normal"], _abi.POS_V), interior(g, OBC.ry_normal, _abi.POS_V)):
+            bad.append("ry_normal")
+        bad += [f"normal_vel_{n + 1}" for n, s in enumerate(OBC.segment) if s.on_pe and not bits_equal(got[f"normal_vel_{n + 1}"], s.normal_vel)]
+        assert not bad, bad
+        assert np.abs(st.u[:, OBC.segnum_u != 0]).max() > 0      # (the boundaries are open)
+        if any("ORLANSKI" in s for s in segs):
+            assert max(np.abs(OBC.rx_normal).max(), np.abs(OBC.ry_normal).max()) > 0
+    finally:
+        tc.TC_INPUT.pop("tc3", None)
