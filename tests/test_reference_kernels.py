@@ -46,7 +46,7 @@ def ref_builds(tmp_path_factory):
         "ref_bt_exe": (lambda tmp: build_ref_module_driver(tmp, ["src/core/MOM_barotropic.F90"], "bt_driver"), "ref_bt", {}),
         "mle_exe": (build_ref_mle_driver, "ref_mle", {}), "td_exe": (build_ref_td_driver, "ref_td", {}), "ale_exe": (build_ref_ale_driver, "ref_ale", {}),
         "dyn_rk2b_exe": (build_ref_dyn_driver, "ref_dyn_rk2b", dict(rk2b=True)), "tracer_exe": (build_ref_tracer_driver, "ref_tracer", {}),
-        "dyn_obc_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc", {}),
+        "dyn_obc_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc", {}), "rad_exe": (build_ref_rad_driver, "ref_rad", {}),
     }
     pool = ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1))
     futures = {name: pool.submit(f, tmp_path_factory.mktemp(d), **kw) for name, (f, d, kw) in jobs.items()}
@@ -1063,3 +1063,110 @@ def test_reference_dynamical_core_with_its_own_open_boundaries_equals_the_oracle
             assert max(np.abs(OBC.rx_normal).max(), np.abs(OBC.ry_normal).max()) > 0
     finally:
         tc.TC_INPUT.pop("tc3", None)
+
+
+# ---- the reference's own radiation_open_bdry_conds, every form, beside the oracle --------------------------------------------------------------------
+def build_ref_rad_driver(tmp):
+    """tests/fortran/ref_rad_driver.F90 on the reference's own MOM_open_boundary.F90 (-DREF_OBC; the modules under it in place)"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_INTERFACE_HEIGHTS", "-DREF_ALE", "-DREF_OBC",
+             f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
+             f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    srcs = [os.path.join(STUBS, "mom6_stubs.F90")] + [os.path.join(REF, r) for r in ALE_SOURCES[:-1]] + \
+           [os.path.join(REF, "src/framework/MOM_array_transform.F90"), os.path.join(STUBS, "mom6_stubs_obc.F90"),
+            os.path.join(REF, "src/core/MOM_open_boundary.F90"), os.path.join(ROOT, "tests", "fortran", "ref_rad_driver.F90")]
+    objs = []
+    for src in srcs:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "ref_rad_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def rad_exe(ref_builds):
+    return ref_builds["rad_exe"].result()
+
+
+def _write_rad_case(path, g, d, OBC, gamma_uv, rx_max, dt, ncall, oblique):
+    with open(path, "wb") as f:
+        np.array([g.ni, g.nj, g.nk, g.halo, OBC.number_of_segments, int(oblique), ncall, 0], dtype="<i4").tofile(f)
+        np.array([gamma_uv, rx_max, dt], dtype="<f8").tofile(f)
+        for n in _abi.ALL_METRICS:
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for k in ("u_new", "u_old", "v_new", "v_old", "rx", "ry"):
+            np.ascontiguousarray(d[k], dtype="<f8").tofile(f)
+        if oblique:
+            for k in ("rx_oblique_u", "ry_oblique_u", "cff_normal_u", "rx_oblique_v", "ry_oblique_v", "cff_normal_v"):
+                np.ascontiguousarray(getattr(OBC, k), dtype="<f8").tofile(f)
+        OBC.segnum_u.astype("<i4").tofile(f); OBC.segnum_v.astype("<i4").tofile(f)
+        for s in OBC.segment:
+            np.array([s.direction, s.open, s.specified, s.on_pe, s.is_E_or_W, s.is_N_or_S] +
+                     [s.HI.get(k, 0) for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed")] +
+                     [s.Flather, s.radiation, s.gradient, s.nudged, s.oblique, s.radiation_tan, s.radiation_grad, s.oblique_tan, s.oblique_grad,
+                      int(s.nudged_tan) + 2 * int(s.nudged_grad)], dtype="<i4").tofile(f)
+            np.array([s.Velocity_nudging_timescale_in, s.Velocity_nudging_timescale_out], dtype="<f8").tofile(f)
+            if not s.on_pe:
+                continue
+            np.ascontiguousarray(s.normal_vel, dtype="<f8").tofile(f)
+            if s.nudged:
+                np.ascontiguousarray(s.nudged_normal_vel, dtype="<f8").tofile(f)
+            if s.radiation_tan or s.nudged_tan or s.oblique_tan or s.radiation_grad or s.nudged_grad or s.oblique_grad:
+                np.ascontiguousarray(s.tangential_vel, dtype="<f8").tofile(f); np.ascontiguousarray(s.tangential_grad, dtype="<f8").tofile(f)
+            if s.nudged_tan:
+                np.ascontiguousarray(s.nudged_tangential_vel, dtype="<f8").tofile(f)
+            if s.nudged_grad:
+                np.ascontiguousarray(s.nudged_tangential_grad, dtype="<f8").tofile(f)
+
+
+@pytest.mark.parametrize("gamma_uv", [0.3, 1.0])
+@pytest.mark.parametrize("form", ["normal", "tangential", "oblique", "oblique_tangential"])
+def test_reference_radiation_open_bdry_conds_equals_the_oracle(tmp_path, rad_exe, form, gamma_uv, monkeypatch):
+    """radiation_open_bdry_conds of the reference's own MOM_open_boundary.F90, two calls in a row (what it keeps between calls is carried): Orlanski
+    radiation, the gradient condition and nudging of the normal component; ORLANSKI_TAN / _GRAD and NUDGED_TAN / _GRAD; OBLIQUE with nudging;
+    OBLIQUE_TAN / _GRAD -- on segments of all four directions at the edges and inside the domain.  u_new, v_new, OBC%rx_normal / ry_normal, the
+    oblique arrays, every segment's normal_vel, tangential_vel and tangential_grad equal the oracle's bit for bit.  (Round 4 had checked the
+    tangential and oblique forms against the reference's four blocks written out as a table of their rows; this is the routine itself.)"""
+    import copy
+    import test_open_boundary as ob
+    from oracle import orc
+    if form == "oblique_tangential" and gamma_uv == 1.0:
+        # with OBC_RAD_VEL_WT = 1 the reference forms the tangential rates from segment%grad_tan (:2487-2506), which allocate_OBC_segment_data
+        # gives only to OBLIQUE_TAN segments (:3665): an OBLIQUE_GRAD segment without OBLIQUE_TAN reads an unallocated array there.  The
+        # library and the oracle evaluate the gradients where they are used; here every such segment has both
+        monkeypatch.setattr(ob, "OBLT_SEGS", [s if "OBLIQUE_TAN" in s else s.replace("OBLIQUE,", "OBLIQUE,OBLIQUE_TAN,") for s in ob.OBLT_SEGS])
+    g, d, OBC = {"normal": ob.rad_case, "tangential": ob.tan_case, "oblique": ob.obl_case, "oblique_tangential": ob.oblt_case}[form]()
+    oblique = form.startswith("oblique")
+    rx_max, dt, ncall = 1.0, 900.0, 2
+    OBC.gamma_uv, OBC.rx_max = gamma_uv, rx_max
+    _write_rad_case(tmp_path / "in.bin", g, d, OBC, gamma_uv, rx_max, dt, ncall, oblique)
+    r = subprocess.run([rad_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, preexec_fn=_unlimited_stack)
+    assert r.returncode == 0 and "ref_rad_driver ok" in r.stdout, r.stderr[-3000:]
+    ref = copy.deepcopy(OBC)
+    o = {k: v.copy() for k, v in d.items()}
+    for n in range(ncall):
+        orc.radiation_open_bdry_conds(g, ref, o["u_new"], o["u_old"], o["v_new"], o["v_old"], dt, gamma_uv=gamma_uv, rx_max=rx_max,
+                                      rx_normal=o["rx"], ry_normal=o["ry"])
+        if n < ncall - 1:
+            o["u_old"][:] = o["u_new"]; o["v_old"][:] = o["v_new"]
+            o["u_new"][:] = 0.5 * o["u_new"] + 0.01; o["v_new"][:] = 0.5 * o["v_new"] - 0.01
+    want = [("u_new", o["u_new"]), ("v_new", o["v_new"]), ("rx_normal", o["rx"]), ("ry_normal", o["ry"])]
+    if oblique:
+        want += [(k, getattr(ref, k)) for k in ob.OBL_FIELDS]
+    for n, s in enumerate(ref.segment):
+        if s.on_pe:
+            want.append((f"normal_vel_{n + 1}", s.normal_vel))
+            if s.radiation_tan or s.nudged_tan or s.oblique_tan or s.radiation_grad or s.nudged_grad or s.oblique_grad:
+                want += [(f"tangential_vel_{n + 1}", s.tangential_vel), (f"tangential_grad_{n + 1}", s.tangential_grad)]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    assert raw.size == sum(w.size for _, w in want), (raw.size, sum(w.size for _, w in want))
+    bad = []
+    for (name, w), a in zip(want, np.split(raw, np.cumsum([w.size for _, w in want])[:-1])):
+        a = a.reshape(w.shape)
+        if not bits_equal(a, w):
+            bad.append((name, int((a != w).sum()), float(np.nanmax(np.abs(a - w)))))
+    assert not bad, bad
+    assert not bits_equal(o["u_new"], d["u_new"])
