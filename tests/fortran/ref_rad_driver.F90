@@ -3,12 +3,14 @@
 !! oblique radiation of the normal component, the gradient condition, nudging, the tangential velocities and their gradients in their
 !! radiating, oblique and nudged forms -- `ncall` calls in a row, so that what the routine keeps between calls (OBC%rx_normal, ry_normal,
 !! the oblique arrays) is carried.  The outputs are compared with the oracle bit for bit.  Build container only; nothing of the library is used.
-!! Usage: ref_rad_driver <input file> <output file>
+!! With a third argument "reservoirs" it drives the reference's update_segment_tracer_reservoirs (:5373-5502) instead, on its own input layout.
+!! Usage: ref_rad_driver <input file> <output file> [reservoirs]
 program ref_rad_driver
 use, intrinsic :: iso_c_binding
 use MOM_domains,       only : MOM_domain_type
 use MOM_grid,          only : ocean_grid_type
-use MOM_open_boundary, only : ocean_OBC_type, radiation_open_bdry_conds
+use MOM_open_boundary, only : ocean_OBC_type, radiation_open_bdry_conds, update_segment_tracer_reservoirs
+use MOM_tracer_registry, only : tracer_registry_type
 use MOM_unit_scaling,  only : unit_scale_type
 use MOM_verticalGrid,  only : verticalGrid_type
 implicit none
@@ -22,10 +24,16 @@ integer(c_int32_t), allocatable :: seg_u(:,:), seg_v(:,:)
 integer :: ni, nj, nk, halo, u_in, u_out, isd, ied, jsd, jed, nseg, ncall, m, n, i0, i1, j0, j1
 real :: scal(3), tscale(2), dt
 real, allocatable, dimension(:,:,:) :: u_new, u_old, v_new, v_old
-character(len=512) :: f_in, f_out
+character(len=512) :: f_in, f_out, f_mode
 logical :: tan_any, grad_any
 
 call get_command_argument(1, f_in) ; call get_command_argument(2, f_out)
+f_mode = "" ; if (command_argument_count() >= 3) call get_command_argument(3, f_mode)
+if (trim(f_mode) == "reservoirs") then
+  call reservoirs(trim(f_in), trim(f_out))
+  write(*,'(a)') "ref_rad_driver ok"
+  stop
+endif
 open(newunit=u_in, file=trim(f_in), access="stream", form="unformatted", status="old")
 ! hdr = [ni, nj, nk, halo, number of segments, oblique segments exist, calls, -]
 read(u_in) hdr
@@ -151,4 +159,79 @@ do m=1,nseg ; if (OBC%segment(m)%on_pe) then
 endif ; enddo
 close(u_out)
 write(*,'(a)') "ref_rad_driver ok"
+
+contains
+
+!> update_segment_tracer_reservoirs(G, GV, uhr, vhr, h, OBC, dt, Reg) on a file: [ni, nj, nk, halo, segments, tracers, -, -], [H_subroundoff, dt],
+!! mask2dT, dyCu, dxCv, uhr, vhr, h, the tracers, then per segment [direction, on_pe, is_E_or_W, is_N_or_S, IsdB, IedB, JsdB, JedB, isd, ied, jsd,
+!! jed], [Tr_InvLscale_in, Tr_InvLscale_out] and on the PE the number of registry entries, per entry [ntr_index, has a reservoir, has length-scale
+!! factors], [resrv_lfac_in, resrv_lfac_out], and tres, t in the layout of normal_vel.  The reservoirs go to the output file.
+subroutine reservoirs(fi, fo)
+  character(len=*), intent(in) :: fi, fo
+  type(ocean_grid_type), target :: G
+  type(verticalGrid_type) :: GV
+  type(ocean_OBC_type), pointer :: OBC => NULL()
+  type(tracer_registry_type), pointer :: Reg => NULL()
+  integer(c_int32_t) :: hdr(8), sf(12), ef(3)
+  integer(c_int32_t) :: nreg(1)
+  integer :: ni, nj, nk, halo, ui, uo, isd, ied, jsd, jed, nseg, ntr, m, q, i0, i1, j0, j1
+  real :: sc(2), ls(2), lf(2)
+  real, allocatable, dimension(:,:,:) :: uhr, vhr, h
+  real, allocatable, target, dimension(:,:,:,:) :: tr
+  open(newunit=ui, file=fi, access="stream", form="unformatted", status="old")
+  read(ui) hdr
+  ni = hdr(1) ; nj = hdr(2) ; nk = hdr(3) ; halo = hdr(4) ; nseg = hdr(5) ; ntr = hdr(6)
+  isd = 1 ; ied = ni + 2*halo ; jsd = 1 ; jed = nj + 2*halo
+  G%isd = isd ; G%ied = ied ; G%jsd = jsd ; G%jed = jed ; G%IsdB = isd-1 ; G%IedB = ied ; G%JsdB = jsd-1 ; G%JedB = jed
+  G%isc = isd+halo ; G%iec = ied-halo ; G%jsc = jsd+halo ; G%jec = jed-halo ; G%ke = nk ; GV%ke = nk
+  read(ui) sc
+  GV%H_subroundoff = sc(1)
+  allocate(G%mask2dT(isd:ied,jsd:jed), G%dyCu(isd-1:ied,jsd:jed), G%dxCv(isd:ied,jsd-1:jed))
+  read(ui) G%mask2dT, G%dyCu, G%dxCv
+  allocate(uhr(isd-1:ied,jsd:jed,nk), vhr(isd:ied,jsd-1:jed,nk), h(isd:ied,jsd:jed,nk), tr(isd:ied,jsd:jed,nk,ntr))
+  read(ui) uhr, vhr, h, tr
+  allocate(Reg) ; Reg%ntr = ntr
+  do m=1,ntr ; Reg%Tr(m)%t => tr(:,:,:,m) ; enddo
+  allocate(OBC) ; OBC%number_of_segments = nseg ; OBC%OBC_pe = .true. ; OBC%ke = nk ; OBC%ntr = ntr
+  allocate(OBC%segment(nseg))
+  do m=1,nseg
+    read(ui) sf, ls
+    OBC%segment(m)%direction = sf(1) ; OBC%segment(m)%on_pe = (sf(2) /= 0) ; OBC%segment(m)%is_E_or_W = (sf(3) /= 0) ; OBC%segment(m)%is_N_or_S = (sf(4) /= 0)
+    OBC%segment(m)%HI%IsdB = sf(5) ; OBC%segment(m)%HI%IedB = sf(6) ; OBC%segment(m)%HI%JsdB = sf(7) ; OBC%segment(m)%HI%JedB = sf(8)
+    OBC%segment(m)%HI%isd = sf(9) ; OBC%segment(m)%HI%ied = sf(10) ; OBC%segment(m)%HI%jsd = sf(11) ; OBC%segment(m)%HI%jed = sf(12)
+    OBC%segment(m)%Tr_InvLscale_in = ls(1) ; OBC%segment(m)%Tr_InvLscale_out = ls(2)
+    if (.not.OBC%segment(m)%on_pe) cycle
+    if (OBC%segment(m)%is_E_or_W) then
+      i0 = sf(5) ; i1 = sf(6) ; j0 = sf(11) ; j1 = sf(12)
+    else
+      i0 = sf(9) ; i1 = sf(10) ; j0 = sf(7) ; j1 = sf(8)
+    endif
+    read(ui) nreg
+    if (nreg(1) <= 0) cycle
+    allocate(OBC%segment(m)%tr_Reg) ; OBC%segment(m)%tr_Reg%ntseg = nreg(1)
+    allocate(OBC%segment(m)%field(nreg(1)))
+    do q=1,nreg(1)
+      read(ui) ef, lf
+      OBC%segment(m)%tr_Reg%Tr(q)%ntr_index = ef(1)
+      OBC%segment(m)%tr_Reg%Tr(q)%fd_index = -1
+      if (ef(3) /= 0) then      ! the field's factors on the reservoir length scales (segment%field(fd_index)%resrv_lfac_in | _out)
+        OBC%segment(m)%tr_Reg%Tr(q)%fd_index = q
+        OBC%segment(m)%field(q)%resrv_lfac_in = lf(1) ; OBC%segment(m)%field(q)%resrv_lfac_out = lf(2)
+      endif
+      if (ef(2) /= 0) then
+        allocate(OBC%segment(m)%tr_Reg%Tr(q)%tres(i0:i1,j0:j1,nk), OBC%segment(m)%tr_Reg%Tr(q)%t(i0:i1,j0:j1,nk))
+        read(ui) OBC%segment(m)%tr_Reg%Tr(q)%tres, OBC%segment(m)%tr_Reg%Tr(q)%t
+      endif
+    enddo
+  enddo
+  close(ui)
+  call update_segment_tracer_reservoirs(G, GV, uhr, vhr, h, OBC, sc(2), Reg)
+  open(newunit=uo, file=fo, access="stream", form="unformatted", status="replace")
+  do m=1,nseg ; if (OBC%segment(m)%on_pe) then ; if (associated(OBC%segment(m)%tr_Reg)) then
+    do q=1,OBC%segment(m)%tr_Reg%ntseg
+      if (allocated(OBC%segment(m)%tr_Reg%Tr(q)%tres)) write(uo) OBC%segment(m)%tr_Reg%Tr(q)%tres
+    enddo
+  endif ; endif ; enddo
+  close(uo)
+end subroutine reservoirs
 end program ref_rad_driver

@@ -47,6 +47,7 @@ def ref_builds(tmp_path_factory):
         "mle_exe": (build_ref_mle_driver, "ref_mle", {}), "td_exe": (build_ref_td_driver, "ref_td", {}), "ale_exe": (build_ref_ale_driver, "ref_ale", {}),
         "dyn_rk2b_exe": (build_ref_dyn_driver, "ref_dyn_rk2b", dict(rk2b=True)), "tracer_exe": (build_ref_tracer_driver, "ref_tracer", {}),
         "dyn_obc_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc", {}), "rad_exe": (build_ref_rad_driver, "ref_rad", {}),
+        "dyn_obc_rk2b_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc_rk2b", dict(rk2b=True)),
     }
     pool = ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1))
     futures = {name: pool.submit(f, tmp_path_factory.mktemp(d), **kw) for name, (f, d, kw) in jobs.items()}
@@ -977,20 +978,21 @@ def test_reference_epipycnal_diffusion_equals_the_oracle(tmp_path, tracer_exe):
 
 
 # ---- the reference's whole dynamical core WITH ITS OWN MOM_open_boundary.F90 beside the oracle --------------------------------------------------------
-def build_ref_dyn_obc_driver(tmp):
+def build_ref_dyn_obc_driver(tmp, rk2b=False):
     """tests/fortran/dyn_driver.F90 (-DREFERENCE_KERNELS -DREF_OBC) on the reference's own MOM_open_boundary.F90 (6116 lines, in place; under it the
     reference's MOM_interface_heights, remapping / regridding stack and MOM_array_transform; stand-ins for the grid type of the initialisation, file
     interpolation, tides and the obsolete-parameter checks) and, compiled against IT, the reference's MOM_dynamics_split_RK2.F90 with every module
     it steps through (continuity, CoriolisAdv, PressureForce, barotropic, set_viscosity, vert_friction, hor_visc)"""
     flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", "-DREFERENCE_KERNELS", "-DREF_EOS", "-DREF_PF_MONT", "-DREF_SET_VISC",
-             "-DREF_INTERFACE_HEIGHTS", "-DREF_ALE", "-DREF_OBC",
+             "-DREF_INTERFACE_HEIGHTS", "-DREF_ALE", "-DREF_OBC"] + (["-DREF_RK2B"] if rk2b else []) + [
              f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework", f"-I{REF}/src/equation_of_state", f"-I{REF}/src/ALE",
              f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
     S, R = (lambda n: os.path.join(STUBS, n)), (lambda n: os.path.join(REF, n))
     srcs = [S("mom6_stubs.F90")] + [R(r) for r in ALE_SOURCES[:-1]] + [R("src/framework/MOM_array_transform.F90"), S("mom6_stubs_obc.F90"),
             R("src/core/MOM_open_boundary.F90"), R(ALE_SOURCES[-1]), S("mom6_stubs_after_obc.F90"), S("mom6_stubs_setvisc.F90"), R("src/framework/MOM_intrinsic_functions.F90"),
             R("src/parameterizations/vertical/MOM_set_viscosity.F90"), S("mom6_stubs_visc.F90")] + \
-           [R(r) for r in VISC_SOURCES + CORE_SOURCES if r != "src/core/MOM_density_integrals.F90"] + [os.path.join(ROOT, "tests", "fortran", "dyn_driver.F90")]
+           [R(r) for r in VISC_SOURCES + CORE_SOURCES if r != "src/core/MOM_density_integrals.F90"] + \
+           ([R("src/core/MOM_dynamics_split_RK2b.F90")] if rk2b else []) + [os.path.join(ROOT, "tests", "fortran", "dyn_driver.F90")]
     objs = []
     for src in srcs:
         o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
@@ -1087,6 +1089,21 @@ def build_ref_rad_driver(tmp):
 
 
 @pytest.fixture(scope="module")
+def dyn_obc_rk2b_exe(ref_builds):
+    return ref_builds["dyn_obc_rk2b_exe"].result()
+
+
+@pytest.mark.parametrize("case", ["tc3", "mixed"])
+def test_reference_rk2b_core_with_its_own_open_boundaries_equals_the_oracle(tmp_path, dyn_obc_rk2b_exe, case, monkeypatch):
+    """SPLIT_RK2B with open boundaries: the reference's step_MOM_dyn_split_RK2b on its own MOM_open_boundary.F90 equals DynState(rk2b=True).step
+    bit for bit (tc3's segments; a specified and a Flather-only segment with external data)"""
+    import functools
+    from oracle import orc
+    monkeypatch.setattr(orc, "DynState", functools.partial(orc.DynState, rk2b=True))
+    test_reference_dynamical_core_with_its_own_open_boundaries_equals_the_oracle(tmp_path, dyn_obc_rk2b_exe, case, monkeypatch)
+
+
+@pytest.fixture(scope="module")
 def rad_exe(ref_builds):
     return ref_builds["rad_exe"].result()
 
@@ -1170,3 +1187,48 @@ def test_reference_radiation_open_bdry_conds_equals_the_oracle(tmp_path, rad_exe
             bad.append((name, int((a != w).sum()), float(np.nanmax(np.abs(a - w)))))
     assert not bad, bad
     assert not bits_equal(o["u_new"], d["u_new"])
+
+
+@pytest.mark.parametrize("InvL", [(0.0, 0.0), (1.0e-4, 3.0e-5), (0.0, 3.0e-5)])
+def test_reference_update_segment_tracer_reservoirs_equals_the_oracle(tmp_path, rad_exe, InvL):
+    """update_segment_tracer_reservoirs of the reference's own MOM_open_boundary.F90 (the backward-Euler blend of the reservoir, the value inside and
+    the external value; zero and non-zero reservoir length scales, per-field factors on them, registry entries without a reservoir, land inside a
+    segment): every reservoir equals the oracle's bit for bit"""
+    import copy
+    import test_advect_obc as ao
+    from oracle import orc
+    g, case, OBC = ao.reservoir_case(InvL)
+    ref = copy.deepcopy(OBC)
+    dt = 3600.0
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([g.ni, g.nj, g.nk, g.halo, OBC.number_of_segments, len(case["tr"]), 0, 0], dtype="<i4").tofile(f)
+        np.array([g.H_subroundoff, dt], dtype="<f8").tofile(f)
+        for n in ("mask2dT", "dyCu", "dxCv"):
+            np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
+        for a in [case["uhtr"], case["vhtr"], case["h_end"]] + list(case["tr"]):
+            np.ascontiguousarray(a, dtype="<f8").tofile(f)
+        for s in OBC.segment:
+            np.array([s.direction, s.on_pe, s.is_E_or_W, s.is_N_or_S] + [s.HI.get(k, 0) for k in ("IsdB", "IedB", "JsdB", "JedB", "isd", "ied", "jsd", "jed")],
+                     dtype="<i4").tofile(f)
+            np.array([s.Tr_InvLscale_in, s.Tr_InvLscale_out], dtype="<f8").tofile(f)
+            if not s.on_pe:
+                continue
+            regs = s.tr_Reg or []
+            np.array([len(regs)], dtype="<i4").tofile(f)
+            for t in regs:
+                has_l = "resrv_lfac_in" in t or "resrv_lfac_out" in t
+                np.array([t["ntr_index"], int(t.get("tres") is not None), int(has_l)], dtype="<i4").tofile(f)
+                np.array([t.get("resrv_lfac_in", 1.0), t.get("resrv_lfac_out", 1.0)], dtype="<f8").tofile(f)
+                if t.get("tres") is not None:
+                    np.ascontiguousarray(t["tres"], dtype="<f8").tofile(f); np.ascontiguousarray(t["t"], dtype="<f8").tofile(f)
+    r = subprocess.run([rad_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), "reservoirs"], capture_output=True, text=True, preexec_fn=_unlimited_stack)
+    assert r.returncode == 0 and "ref_rad_driver ok" in r.stdout, r.stderr[-3000:]
+    orc.update_segment_tracer_reservoirs(g, case["uhtr"], case["vhtr"], case["h_end"], ref, dt, case["tr"])
+    want = [t["tres"] for s in ref.segment if s.on_pe for t in (s.tr_Reg or []) if t.get("tres") is not None]
+    before = [t["tres"] for s in OBC.segment if s.on_pe for t in (s.tr_Reg or []) if t.get("tres") is not None]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    assert raw.size == sum(w.size for w in want)
+    bad = [(n, int((a.reshape(w.shape) != w).sum()), float(np.abs(a.reshape(w.shape) - w).max()))
+           for n, (w, a) in enumerate(zip(want, np.split(raw, np.cumsum([w.size for w in want])[:-1]))) if not bits_equal(a.reshape(w.shape), w)]
+    assert not bad, bad
+    assert any(not bits_equal(w, b) for w, b in zip(want, before))
