@@ -6,7 +6,7 @@
 !! Usage: ref_pf_driver <input file> <output file> [NAME=VALUE ...]
 program ref_pf_driver
 use, intrinsic :: iso_c_binding
-use MOM_PressureForce_FV, only : PressureForce_FV_Bouss, PressureForce_FV_init, PressureForce_FV_CS
+use MOM_PressureForce_FV, only : PressureForce_FV_Bouss, PressureForce_FV_nonBouss, PressureForce_FV_init, PressureForce_FV_CS
 use MOM_ALE,            only : ALE_CS
 use MOM_EOS,            only : EOS_init
 use MOM_diag_mediator,  only : diag_ctrl, time_type
@@ -77,12 +77,19 @@ do m = 3, command_argument_count()      ! further NAME=VALUE pairs of the parame
   call get_command_argument(m, f_arg)
   i0 = index(f_arg, "=")
   if (i0 > 1) call param_set(pf, f_arg(1:i0-1), trim(f_arg(i0+1:)))
+  if (trim(f_arg) == "BOUSSINESQ=False") then      ! thicknesses in kg m-2 (H_TO_KG_M2 = 1): verticalGridInit's non-Boussinesq factors
+    GV%Boussinesq = .false. ; GV%H_to_RZ = 1.0 ; GV%RZ_to_H = 1.0 ; GV%H_to_Z = 1.0 / GV%Rho0 ; GV%Z_to_H = GV%Rho0
+  endif
 enddo
 allocate(tv%eqn_of_state)
 call EOS_init(pf, tv%eqn_of_state, US)
 call PressureForce_FV_init(Time, G, GV, US, pf, diag, PCS)
 allocate(ALE_CSp)
-call PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, PCS, ALE_CSp, p_atm, pbce, eta)
+if (GV%Boussinesq) then
+  call PressureForce_FV_Bouss(h, tv, PFu, PFv, G, GV, US, PCS, ALE_CSp, p_atm, pbce, eta)
+else
+  call PressureForce_FV_nonBouss(h, tv, PFu, PFv, G, GV, US, PCS, ALE_CSp, p_atm, pbce, eta)
+endif
 
 open(newunit=u_out, file=trim(f_out), access="stream", form="unformatted", status="replace")
 write(u_out) PFu, PFv, pbce, eta

@@ -451,11 +451,17 @@ PF_SETS = {
     "linear_plm": (["EQN_OF_STATE=LINEAR", "RHO_T0_S0=1000.0", "DRHO_DT=-0.2", "DRHO_DS=0.8"], "LINEAR", {}, False),
     "wright_full_plm": (["EQN_OF_STATE=WRIGHT_FULL"], "WRIGHT_FULL", {}, True),
     "unesco_plm": (["EQN_OF_STATE=UNESCO"], "UNESCO", {}, False),
+    # BOUSSINESQ = False: PressureForce_FV_nonBouss (int_spec_vol_dp_generic_plm, Set_pbce_nonBouss), thicknesses in kg m-2
+    "nonbouss_wright": (["BOUSSINESQ=False"], "WRIGHT", {}, True),
+    "nonbouss_unesco_massw": (["BOUSSINESQ=False", "EQN_OF_STATE=UNESCO", "MASS_WEIGHT_IN_PRESSURE_GRADIENT=True", "BOUNDARY_EXTRAPOLATION_PRESSURE=False"],
+                              "UNESCO", dict(useMassWghtInterp=True, boundary_extrap=False), False),
+    "nonbouss_linear": (["BOUSSINESQ=False", "EQN_OF_STATE=LINEAR", "RHO_T0_S0=1000.0", "DRHO_DT=-0.2", "DRHO_DS=0.8"], "LINEAR", {}, False),
 }
 
 
 @pytest.mark.parametrize("ni,nj,nk,seed,opts", [(30, 14, 6, 61, "wright_plm"), (22, 25, 9, 62, "wright_plm_massw_psurf"), (30, 14, 6, 63, "wright_pcm"),
-                                                (26, 18, 5, 64, "linear_plm"), (26, 18, 5, 65, "wright_full_plm"), (24, 16, 5, 66, "unesco_plm")])
+                                                (26, 18, 5, 64, "linear_plm"), (26, 18, 5, 65, "wright_full_plm"), (24, 16, 5, 66, "unesco_plm"),
+                                                (28, 16, 6, 67, "nonbouss_wright"), (22, 20, 5, 68, "nonbouss_unesco_massw"), (24, 14, 5, 69, "nonbouss_linear")])
 def test_reference_pressureforce_equals_the_oracle(tmp_path, pf_exe, ni, nj, nk, seed, opts):
     """PressureForce_FV_Bouss of the reference -- int_density_dz_generic_plm / int_density_dz, the PLM edge values of T and S from its own slope
     functions, its equation-of-state modules, Set_pbce_Bouss -- on the oracle's inputs: PFu, PFv, pbce and eta equal the oracle's bit for bit"""
@@ -469,6 +475,9 @@ def test_reference_pressureforce_equals_the_oracle(tmp_path, pf_exe, ni, nj, nk,
     H = _abi.POS_H
     rng = np.random.default_rng(seed)
     p_atm = np.ascontiguousarray(1.0e5 + 2.0e3 * rng.standard_normal(g.shape2(H))) if with_p else None
+    nonbouss = "BOUSSINESQ=False" in args
+    if nonbouss:
+        d["h"] = np.ascontiguousarray(d["h"] * g.Rho0)      # layer masses [kg m-2]
     with open(tmp_path / "in.bin", "wb") as f:
         np.array([ni, nj, nk, halo, 0, 0, g.first_direction, 1 if with_p else 0], dtype="<i4").tofile(f)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, 900.0], dtype="<f8").tofile(f)
@@ -476,7 +485,10 @@ def test_reference_pressureforce_equals_the_oracle(tmp_path, pf_exe, ni, nj, nk,
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(f)
         for a in (d["h"], d["T"], d["S"]) + ((p_atm,) if with_p else ()):
             np.ascontiguousarray(a, dtype="<f8").tofile(f)
-    PFu, PFv, pbce, eta = orc.pressureforce(g, orc.pressureforce_cs(g, **cs_kw), orc.eos(eos_form), d["h"], d["T"], d["S"], p_atm=p_atm)
+    if nonbouss:
+        PFu, PFv, pbce, eta = orc.pressureforce_nonbouss(g, orc.pressureforce_cs(g, **cs_kw), orc.eos(eos_form), d["h"], d["T"], d["S"], p_atm, H_to_RZ=1.0)
+    else:
+        PFu, PFv, pbce, eta = orc.pressureforce(g, orc.pressureforce_cs(g, **cs_kw), orc.eos(eos_form), d["h"], d["T"], d["S"], p_atm=p_atm)
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")] + args, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
