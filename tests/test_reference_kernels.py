@@ -47,7 +47,7 @@ def ref_builds(tmp_path_factory):
         "mle_exe": (build_ref_mle_driver, "ref_mle", {}), "td_exe": (build_ref_td_driver, "ref_td", {}), "ale_exe": (build_ref_ale_driver, "ref_ale", {}),
         "dyn_rk2b_exe": (build_ref_dyn_driver, "ref_dyn_rk2b", dict(rk2b=True)), "tracer_exe": (build_ref_tracer_driver, "ref_tracer", {}),
         "dyn_obc_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc", {}), "rad_exe": (build_ref_rad_driver, "ref_rad", {}),
-        "dyn_obc_rk2b_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc_rk2b", dict(rk2b=True)),
+        "dyn_obc_rk2b_exe": (build_ref_dyn_obc_driver, "ref_dyn_obc_rk2b", dict(rk2b=True)), "coms_exe": (build_ref_coms_driver, "ref_coms", {}),
     }
     pool = ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1))
     futures = {name: pool.submit(f, tmp_path_factory.mktemp(d), **kw) for name, (f, d, kw) in jobs.items()}
@@ -1244,3 +1244,65 @@ def test_reference_update_segment_tracer_reservoirs_equals_the_oracle(tmp_path, 
            for n, (w, a) in enumerate(zip(want, np.split(raw, np.cumsum([w.size for w in want])[:-1]))) if not bits_equal(a.reshape(w.shape), w)]
     assert not bad, bad
     assert any(not bits_equal(w, b) for w, b in zip(want, before))
+
+
+# ---- the reference's own reproducing_sum (MOM_coms.F90) beside the oracle ---------------------------------------------------------------------------
+def build_ref_coms_driver(tmp):
+    """tests/fortran/ref_coms_driver.F90 on the reference's own src/framework/MOM_coms.F90, compiled in place against a one-PE stand-in of
+    MOM_coms_infra (tests/fortran/stubs/mom6_stubs_coms_infra.F90; the rest of the stand-ins are not in this build)"""
+    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{REF}/config_src/memory/dynamic_symmetric", f"-I{REF}/src/framework",
+             f"-I{tmp}", "-J", str(tmp)]
+    objs = []
+    for src in [os.path.join(STUBS, "mom6_stubs_coms_infra.F90"), os.path.join(REF, "src/framework/MOM_coms.F90"),
+                os.path.join(ROOT, "tests", "fortran", "ref_coms_driver.F90")]:
+        o = os.path.join(str(tmp), os.path.basename(src)[:-4] + ".o")
+        r = subprocess.run([FC, *flags, "-c", src, "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, f"{src}:\n" + r.stderr[-3000:]
+        objs.append(o)
+    exe = os.path.join(str(tmp), "ref_coms_driver")
+    r = subprocess.run([FC, *objs, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+@pytest.fixture(scope="module")
+def coms_exe(ref_builds):
+    return ref_builds["coms_exe"].result()
+
+
+@pytest.mark.parametrize("kind", ["unit", "wide", "cancelling", "tiny"])
+def test_reference_reproducing_sum_equals_the_oracle(tmp_path, coms_exe, kind):
+    """reproducing_sum_3d / _2d of the reference's own MOM_coms.F90 (the extended-fixed-point sum of Hallberg & Adcroft 2014) over the h-point
+    computational domain: the total, the sums by layer and EFP_to_real of the extended-fixed-point results equal the oracle's bit for bit -- on fields of order one, over twenty decades, with near-total cancellation, and near the smallest representable increment"""
+    from mom6_amd import synth
+    from oracle import orc
+    g = synth.make_grid(37, 23, 5, halo=4, land_frac=0.2, seed=3)
+    rng = np.random.default_rng({"unit": 1, "wide": 2, "cancelling": 3, "tiny": 4}[kind])
+    shp = g.shape3(_abi.POS_H)
+    a = rng.standard_normal(shp)
+    if kind == "wide":
+        a = a * 10.0 ** rng.uniform(-8, 12, shp)
+    elif kind == "cancelling":
+        a = a * 1.0e9; a[:, :, 1::2] = -a[:, :, 0:-1:2][:, :, :a[:, :, 1::2].shape[2]] * (1.0 + 1.0e-13)
+    elif kind == "tiny":
+        a = a * 1.0e-38
+    a = np.ascontiguousarray(a)
+    i0 = g.halo
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([shp[2], shp[1], shp[0], i0 + 1, i0 + g.ni, i0 + 1, i0 + g.nj, 0], dtype="<i4").tofile(f)
+        a.astype("<f8").tofile(f)
+    r = subprocess.run([coms_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ref_coms_driver ok" in r.stdout, r.stderr[-2000:]
+    raw = np.fromfile(str(tmp_path / "out.bin"), dtype="<f8")
+    nk = shp[0]
+    s3, s2, tot_r, diff = raw[:4]; sums, lay_r = raw[4:4 + nk], raw[4 + nk:4 + 2 * nk]
+    o3 = orc.reproducing_sum(g, a, _abi.POS_H, by_layer=True)
+    o2 = orc.reproducing_sum(g, a[0], _abi.POS_H)
+    bits = lambda x: np.float64(x).view(np.uint64)
+    assert bits(s3) == bits(o3["sum"]) and bits(tot_r) == bits(o3["sum"]), (s3, o3["sum"])
+    assert bits(s2) == bits(o2["sum"]), (s2, o2["sum"])
+    assert all(bits(x) == bits(y) for x, y in zip(sums, o3["sums"])) and all(bits(x) == bits(y) for x, y in zip(lay_r, o3["sums"]))
+    # EFP_real_diff(total, first layer): the reference's own extended-fixed-point subtraction; the oracle has no such entry, so this one value is
+    # checked to rounding against the sum of the other layers (not bitwise)
+    assert np.isclose(diff, sum(o3["sums"][1:]), rtol=1e-12, atol=abs(s3) * 1e-15 + 1e-300)
+    assert s3 != 0.0
