@@ -208,6 +208,12 @@ if (len_trim(f_obc) > 0) then
     ! (the reference's own MOM_open_boundary.F90: what allocate_OBC_segment_data gives a radiating segment, :3642, :3678)
     if (OBC%segment(m)%radiation .and. OBC%segment(m)%is_E_or_W) allocate(OBC%segment(m)%rx_norm_rad(i0:i1,j0:j1,nk), source=0.0)
     if (OBC%segment(m)%radiation .and. OBC%segment(m)%is_N_or_S) allocate(OBC%segment(m)%ry_norm_rad(i0:i1,j0:j1,nk), source=0.0)
+    ! (:3649-3658: the velocities and gradients along the segment that the computed / specified vorticity and strain read; zero, as value-type
+    ! segment data leave them)
+    if (OBC%computed_vorticity .or. OBC%computed_strain) &
+      allocate(OBC%segment(m)%tangential_vel(OBC%segment(m)%HI%IsdB:OBC%segment(m)%HI%IedB,OBC%segment(m)%HI%JsdB:OBC%segment(m)%HI%JedB,nk), source=0.0)
+    if (OBC%specified_vorticity .or. OBC%specified_strain) &
+      allocate(OBC%segment(m)%tangential_grad(OBC%segment(m)%HI%IsdB:OBC%segment(m)%HI%IedB,OBC%segment(m)%HI%JsdB:OBC%segment(m)%HI%JedB,nk), source=0.0)
 #endif
   endif ; enddo
   allocate(OBC%rx_normal(isd-1:ied,jsd:jed,nk), source=0.0) ; allocate(OBC%ry_normal(isd:ied,jsd-1:jed,nk), source=0.0)

@@ -1029,6 +1029,10 @@ OBC_DYN_CASES = {
     "mixed": (TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"], "synthetic", 3),      # a specified and a Flather-only segment with external data
     "gradient": (["J=N,I=N:0,GRADIENT", "J=0,I=0:N,FLATHER,ORLANSKI", "I=N,J=0:N,FLATHER,GRADIENT", "I=0,J=N:0,SIMPLE"], "synthetic", 3),
     "inner": (["I=N,J=0:N,FLATHER,ORLANSKI", "J=5,I=N:0,SIMPLE"], "synthetic", 3),       # a segment inside the domain
+    # the other vorticity / strain options of CorAdCalc and horizontal_viscosity at the segments (tc3 has the free-slip pair and OBC_ZERO_BIHARMONIC)
+    "zero_vort_strain": (TC3, "synthetic", 3, dict(zero_vorticity=True, zero_strain=True, gamma_uv=0.3, rx_max=10.0)),
+    "computed_vort_strain": (TC3, "synthetic", 3, dict(computed_vorticity=True, computed_strain=True, gamma_uv=0.3, rx_max=10.0)),
+    "specified_vort": (TC3[:2] + ["I=N,J=0:N,SIMPLE", "I=0,J=N:0,FLATHER"], "synthetic", 3, dict(specified_vorticity=True, freeslip_strain=True, zero_biharmonic=True)),
 }
 
 
@@ -1040,8 +1044,10 @@ def test_reference_dynamical_core_with_its_own_open_boundaries_equals_the_oracle
     equal the oracle's bit for bit -- for .testing/tc3 as it runs (its own initial condition, all 180 steps) and for sets with specified,
     Flather-only, gradient and interior segments carrying external data"""
     import test_testing_configs as tc
-    segs, ic, nsteps = OBC_DYN_CASES[case]
+    segs, ic, nsteps = OBC_DYN_CASES[case][:3]
     monkeypatch.setattr(tc, "TC3_SEGMENTS", segs)
+    if len(OBC_DYN_CASES[case]) > 3:
+        monkeypatch.setattr(tc, "TC3_OBC", OBC_DYN_CASES[case][3])
     try:
         state, OBC = tc.tc3_case(ic=ic)
         g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
