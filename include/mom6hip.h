@@ -1382,7 +1382,9 @@ int mom6hip_dyn_split_rk2_init(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *c
  * open_boundary_zero_normal_flow on u_bc_accel :565-567 and :887-889, radiation_open_bdry_conds on u_av :765-775 and on u_inst
  * :1030-1034 (segment%normal_vel, OBC%rx_normal, OBC%ry_normal are updated in place) -- and the OBC in every operator that takes
  * one, as the plain sequence of the library's OBC entry points; update_OBC_data (:534-536, OBC%update_OBC) is the caller's business
- * before the call; one tile, no hooks.  mom6hip_dyn_split_rk2_init reads cs->OBC as well (:1543-1593).
+ * before the call; no hooks.  On several tiles every tile passes the segments clipped to its own data domain, as open_boundary_config
+ * leaves them on a PE (a segment that runs along a cut between tiles must keep more than a halo width from it: the reference's placement
+ * rule, MOM_open_boundary.F90:1379, does not place it on the neighbouring tile).  mom6hip_dyn_split_rk2_init reads cs->OBC as well (:1543-1593).
  */
 int mom6hip_step_dyn_split_rk2(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_inst, double *v_inst,
                                double *h, const double *T, const double *S, double dt, const double *taux,

@@ -168,7 +168,10 @@ int step_with_obc(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *cs, double *u_
   const bool BT_cont_BT_thick = BTC && BTC->h_u && BTC->h_v;
   mom6hip_vertvisc_cs_t *VV = cs->vertvisc_CSp;
   M6_REQUIRE(!cs->hooks, "step_MOM_dyn_split_RK2: host-side parameterisations (hooks) are not provided with an associated OBC");
-  M6_REQUIRE(!m6::multi_tile(ctx), "step_MOM_dyn_split_RK2: an associated OBC is provided on one tile");
+  // (an associated OBC on several tiles: every tile holds the segments clipped to its data domain, as open_boundary_config leaves them on a PE;
+  // tests/test_domains.py::test_rk2_step_with_open_boundaries_layout_independence.  MOM6HIP_OBC_ONE_TILE=1 brings the old refusal back)
+  static const bool obc_one_tile = getenv("MOM6HIP_OBC_ONE_TILE") && atoi(getenv("MOM6HIP_OBC_ONE_TILE")) == 1;
+  M6_REQUIRE(!obc_one_tile || !m6::multi_tile(ctx), "step_MOM_dyn_split_RK2: an associated OBC is provided on one tile (MOM6HIP_OBC_ONE_TILE)");
 
   // the step's automatic arrays (:336-369), with u_old_rad_OBC, v_old_rad_OBC (:360-363)
   const size_t blk_bytes = 4 * sz.u3 + 4 * sz.v3 + sz.h3 + sz.h2;
@@ -699,7 +702,8 @@ int mom6hip_step_dyn_split_rk2b(mom6hip_ctx_t *ctx, mom6hip_dyn_split_rk2_cs_t *
   // radiation_open_bdry_conds on u_av (:766-774, :1000-1002), as in step_with_obc
   const mom6hip_obc_t *OBC = cs->OBC;
   M6_REQUIRE(!OBC || !cs->hooks, "step_MOM_dyn_split_RK2b: host-side parameterisations (hooks) are not provided with an associated OBC");
-  M6_REQUIRE(!OBC || !m6::multi_tile(ctx), "step_MOM_dyn_split_RK2b: an associated OBC is provided on one tile");
+  static const bool obc_one_tile = getenv("MOM6HIP_OBC_ONE_TILE") && atoi(getenv("MOM6HIP_OBC_ONE_TILE")) == 1;
+  M6_REQUIRE(!OBC || !obc_one_tile || !m6::multi_tile(ctx), "step_MOM_dyn_split_RK2b: an associated OBC is provided on one tile (MOM6HIP_OBC_ONE_TILE)");
   const m6::GridDev g = ctx->g;
   const Sz sz = sizes(g);
   hipStream_t s = ctx->stream;

@@ -317,6 +317,86 @@ def rk2_layout_worker(rank, world, port, layout, topo, out_dir):
         dist.destroy_process_group()
 
 
+def _obc_data_from_fields(OBC, fu, fv, f2u, f2v):
+    """external data of the specified and Flather segments sampled from fields on the grid of the OBC (global or a tile's cut of the same fields):
+    the same numbers whatever the layout"""
+    for s in OBC.segment:
+        if not s.on_pe:
+            continue
+        hi = s.HI
+        if s.is_E_or_W:
+            sl3 = (slice(None), slice(hi["jsd"] - 1, hi["jed"]), slice(hi["IsdB"], hi["IsdB"] + 1)); f3, f2 = fu, f2u
+        else:
+            sl3 = (slice(None), slice(hi["JsdB"], hi["JsdB"] + 1), slice(hi["isd"] - 1, hi["ied"])); f3, f2 = fv, f2v
+        if s.specified:
+            s.normal_vel[:] = 0.05 * f3[sl3]; s.normal_trans[:] = s.normal_vel * 9.0e5
+        if s.Flather:
+            s.normal_vel_bt[:] = 0.02 * f2[sl3[1:]]; s.SSH[:] = 0.05 * f2[sl3[1:]] ** 2
+
+
+def rk2_obc_layout_worker(rank, world, port, layout, segs, viscous, rk2b, out_dir):
+    """the split RK2 / RK2B step with an associated OBC on two tiles: every tile places the segments with its own offsets, as open_boundary_config
+    does on a PE, and holds its part of the segments' data"""
+    import numpy as np
+    import torch
+    from mom6_amd import _abi
+    from mom6_amd.domains import Domain
+    from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2, step_MOM_dyn_split_RK2
+    if rk2b:
+        from mom6_amd.dynamics_split_rk2 import initialize_dyn_split_RK2b as initialize_dyn_split_RK2, step_MOM_dyn_split_RK2b as step_MOM_dyn_split_RK2
+    from mom6_amd.open_boundary import ocean_OBC_type
+    from mom6_amd.tracer_advect import DeviceGrid
+    from mom6_amd.vert_friction import vertvisc_type
+    from test_dyn_split_rk2_obc import DT, HV, TC3_FLAGS, oracle_state, rk2_obc_case, visc_arrays
+    from test_hor_visc import REF_NAMES
+    dist = _init(rank, world, port)
+    try:
+        gg, d, taux, tauy, OBCg = rk2_obc_case(segs, ni=32, nj=24, nk=3, seed=6)
+        H, U, V = _abi.POS_H, _abi.POS_U, _abi.POS_V
+        rng = np.random.default_rng(77)
+        fu, fv = rng.standard_normal(gg.shape3(U)), rng.standard_normal(gg.shape3(V))
+        f2u, f2v = rng.standard_normal(gg.shape2(U)), rng.standard_normal(gg.shape2(V))
+        _obc_data_from_fields(OBCg, fu, fv, f2u, f2v)
+        dom = Domain(gg.ni, gg.nj, layout, rank, gg.halo, False, False)
+        tg = dom.tile_grid(gg)
+        dg = DeviceGrid(tg)
+        dg.set_domain(dom)
+        OBC = ocean_OBC_type(tg, segs, idg_offset=dom.i0 - gg.halo, jdg_offset=dom.j0 - gg.halo, ni_global=gg.ni, nj_global=gg.nj, gamma_uv=0.3,
+                             rx_max=10.0, **TC3_FLAGS)
+        OBC.rx_normal, OBC.ry_normal = tg.zeros3(U), tg.zeros3(V)
+        if any(sg.oblique for sg in OBC.segment):
+            OBC.rx_oblique_u, OBC.ry_oblique_u, OBC.cff_normal_u = tg.zeros3(U), tg.zeros3(U), tg.zeros3(U)
+            OBC.rx_oblique_v, OBC.ry_oblique_v, OBC.cff_normal_v = tg.zeros3(V), tg.zeros3(V), tg.zeros3(V)
+        _obc_data_from_fields(OBC, dom.cut(fu, U), dom.cut(fv, V), dom.cut(f2u, U), dom.cut(f2v, V))
+        T = lambda a, p: torch.from_numpy(dom.cut(a, p)).cuda()
+        u, v, h, Tt, Ss = T(d["u"], U), T(d["v"], V), T(d["h"], H), T(d["T"], H), T(d["S"], H)
+        Z = lambda p, k3=True: torch.zeros(tg.shape3(p) if k3 else tg.shape2(p), dtype=torch.float64, device="cuda")
+        uh, vh, uhtr, vhtr, eta_av = Z(U), Z(V), Z(U), Z(V), Z(H, False)
+        bbl = visc_arrays(gg)
+        kw = dict(vertvisc=dict(KV=1.0e-3, HBBL=10.0), hor_visc={REF_NAMES[k]: x for k, x in HV.items()}) if viscous else {}
+        CS = initialize_dyn_split_RK2(u, v, h, uh, vh, DT, dg, coriolis=dict(bound_coriolis=True), OBC=OBC.cuda(), **kw)
+        CS.barotropic_CSp.st.dtbt = DT / 12.6
+        pos_of = dict(Kv_bbl_u=U, Kv_bbl_v=V, bbl_thick_u=U, bbl_thick_v=V)
+        visc = vertvisc_type(**{n: T(a, pos_of[n]) for n, a in bbl.items()}) if viscous else None
+        tx, ty = T(taux, U), T(tauy, V)
+        nsteps = 3
+        for n in range(nsteps):
+            step_MOM_dyn_split_RK2(u, v, h, (Tt, Ss), visc, None, DT, (tx, ty), None, None, uh, vh, uhtr, vhtr, eta_av, dg, CS)
+        dg.sync()
+        np.savez(os.path.join(out_dir, f"obc_tile{rank}.npz"), ij=np.array([dom.i0, dom.j0, dom.ni, dom.nj]), u=u.cpu().numpy(),
+                 v=v.cpu().numpy(), h=h.cpu().numpy(), eta=CS.eta.cpu().numpy(), uhtr=uhtr.cpu().numpy(), rx=OBC.rx_normal.cpu().numpy(),
+                 ry=OBC.ry_normal.cpu().numpy())
+        dg.close()
+        if rank == 0:
+            ref = oracle_state(gg, d, OBCg, viscous, bbl=bbl, rk2b=rk2b)
+            for n in range(nsteps):
+                ref.step(taux, tauy)
+            np.savez(os.path.join(out_dir, "obc_global.npz"), u=ref.u, v=ref.v, h=ref.h, eta=ref.arrs["eta"], uhtr=ref.uhtr, rx=OBCg.rx_normal,
+                     ry=OBCg.ry_normal)
+    finally:
+        dist.destroy_process_group()
+
+
 def phillips_layout_worker(rank, world, port, layout, out_dir, nsteps=2):
     """test.layout on BASELINE configs[3] (Phillips_2layer 480x320x2, LINEAR equation of state): the tiles of the layout
     against the one-tile oracle run; the barotropic subcycle has dozens of steps between its group passes."""
