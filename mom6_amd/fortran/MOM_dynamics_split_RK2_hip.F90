@@ -19,8 +19,7 @@
 !!     restart file are uploaded at initialisation (query_initialized).
 !!
 !! Provided: what mom6hip_step_dyn_split_rk2 provides (include/mom6hip.h); refused by name with a FATAL error: BEGW /= 0,
-!! SPLIT_BOTTOM_STRESS, FPMIX, TIDES / CALCULATE_SAL, open boundaries, porous barriers, Stokes PGF, STOCH, REMAP_AUXILIARY_VARS
-!! (remap_dyn_split_RK2_aux_vars), and everything the sub-modules' shims refuse.
+!! SPLIT_BOTTOM_STRESS, FPMIX, TIDES / CALCULATE_SAL, porous barriers, Stokes PGF, STOCH, and everything the sub-modules' shims refuse.
 !!
 !! Compiled INSIDE a MOM6 source tree in place of src/core/MOM_dynamics_split_RK2.F90 (together with the other *_hip.F90 shims);
 !! here against tests/fortran/stubs.
@@ -40,7 +39,8 @@ use MOM_file_parser,           only : get_param, log_version, param_file_type
 use MOM_get_input,             only : directories
 use MOM_restart,               only : register_restart_field, query_initialized, MOM_restart_CS, is_new_run
 use MOM_time_manager,          only : time_type
-use MOM_ALE,                   only : ALE_CS
+use MOM_ALE,                   only : ALE_CS, ALE_remap_velocities
+use MOM_domains,               only : pass_vector
 use MOM_barotropic,            only : barotropic_init, register_barotropic_restarts, barotropic_CS, barotropic_end
 use MOM_barotropic,            only : barotropic_hip_struct, barotropic_hip_update
 use MOM_boundary_update,       only : update_OBC_CS, update_OBC_data
@@ -77,7 +77,7 @@ type, public :: MOM_dyn_split_RK2_CS ; private
   real, allocatable, dimension(:,:)   :: eta
   real, pointer, dimension(:,:,:) :: uh_rst => NULL(), vh_rst => NULL()      !< the uh, vh handed to register_restarts (restart fields)
   real :: be = 0.6, begw = 0.0
-  logical :: BT_use_layer_fluxes = .true., store_CAu = .true., split_bottom_stress = .false.
+  logical :: BT_use_layer_fluxes = .true., store_CAu = .true., split_bottom_stress = .false., remap_aux = .false.
   logical :: resident = .false.                !< GPU_RESIDENT_DYNAMICS
   logical :: module_is_initialized = .false.
   ! the control structures of the modules the step calls (the reference's pointers :228-262)
@@ -448,7 +448,9 @@ subroutine register_restarts_dyn_split_RK2(HI, GV, US, param_file, CS, restart_C
   call register_barotropic_restarts(HI, GV, US, param_file, CS%barotropic_CSp, restart_CS)
 end subroutine register_restarts_dyn_split_RK2
 
-!> Same interface as the reference remap_dyn_split_RK2_aux_vars (:1273) (REMAP_AUXILIARY_VARS = True): not provided
+!> Same interface as the reference remap_dyn_split_RK2_aux_vars (:1273) (REMAP_AUXILIARY_VARS = True): the restart fields u_av, v_av, CAu_pred,
+!! CAv_pred (with STORE_CORIOLIS_ACCEL) and diffu, diffv are brought to the host, remapped by ALE_remap_velocities (the MOM_ALE shim: on the GPU,
+!! HOST memspace) with the reference's two passes, and handed back to the device arrays of the library's control structure.
 subroutine remap_dyn_split_RK2_aux_vars(G, GV, CS, h_old_u, h_old_v, h_new_u, h_new_v, ALE_CSp)
   type(ocean_grid_type),            intent(inout) :: G
   type(verticalGrid_type),          intent(in)    :: GV
@@ -458,7 +460,18 @@ subroutine remap_dyn_split_RK2_aux_vars(G, GV, CS, h_old_u, h_old_v, h_new_u, h_
   real, dimension(SZIB_(G),SZJ_(G),SZK_(GV)), intent(in) :: h_new_u
   real, dimension(SZI_(G),SZJB_(G),SZK_(GV)), intent(in) :: h_new_v
   type(ALE_CS),                     pointer       :: ALE_CSp
-  call MOM_error(FATAL, "remap_dyn_split_RK2_aux_vars (HIP): REMAP_AUXILIARY_VARS = True is not provided by the GPU path.")
+  integer :: rc
+  if (.not.CS%remap_aux) return
+  call restart_fields(CS, to_host=.true.)
+  rc = mom6hip_stage_wait(CS%ctx) ; call mom6hip_fatal_if(rc, "remap_dyn_split_RK2_aux_vars")
+  if (CS%store_CAu) then
+    call ALE_remap_velocities(ALE_CSp, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, CS%u_av, CS%v_av)
+    call pass_vector(CS%u_av, CS%v_av, G%Domain, complete=.false.)
+    call ALE_remap_velocities(ALE_CSp, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, CS%CAu_pred, CS%CAv_pred)
+    call pass_vector(CS%CAu_pred, CS%CAv_pred, G%Domain, complete=.true.)
+  endif
+  call ALE_remap_velocities(ALE_CSp, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, CS%diffu, CS%diffv)
+  call restart_fields(CS, to_host=.false.)
 end subroutine remap_dyn_split_RK2_aux_vars
 
 !> Same interface as the reference initialize_dyn_split_RK2 (:1317), same parameters and defaults: the control structures of the
@@ -545,12 +558,16 @@ subroutine initialize_dyn_split_RK2(u, v, h, tv, uh, vh, eta, Time, G, GV, US, p
   call get_param(param_file, mdl, "SPLIT_BOTTOM_STRESS", CS%split_bottom_stress, &
                  "If true, provide the bottom stress calculated by the vertical viscosity to the barotropic solver.", default=.false.)
   call refuse(CS%split_bottom_stress, "SPLIT_BOTTOM_STRESS")
+  call get_param(param_file, mdl, "REMAP_AUXILIARY_VARS", CS%remap_aux, &
+                 "If true, apply ALE remapping to all of the auxiliary 3-dimensional variables that are needed to reproduce across "// &
+                 "restarts, similarly to what is already being done with the primary state variables.", default=.false., do_not_log=.true.)
   call get_param(param_file, mdl, "BT_USE_LAYER_FLUXES", CS%BT_use_layer_fluxes, &
                  "If true, use the summed layered fluxes plus an adjustment due to the change in the barotropic velocity in the "// &
                  "barotropic continuity equation.", default=.true.)
   call get_param(param_file, mdl, "STORE_CORIOLIS_ACCEL", CS%store_CAu, &
                  "If true, calculate the Coriolis accelerations at the end of each timestep for use in the predictor step of the "// &
                  "next split RK2 timestep.", default=.true.)
+  if (CS%remap_aux .and. .not.CS%store_CAu) call MOM_error(FATAL, "REMAP_AUXILIARY_VARS requires that STORE_CORIOLIS_ACCEL = True.")      ! :1439
   call get_param(param_file, mdl, "FPMIX", flag, "If true, add non-local momentum flux increments and diffuse down the Eulerian gradient.", &
                  default=.false.)
   call refuse(flag, "FPMIX")

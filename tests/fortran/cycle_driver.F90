@@ -10,6 +10,7 @@ program cycle_driver
 use, intrinsic :: iso_c_binding
 use MOM_dynamics_split_RK2, only : MOM_dyn_split_RK2_CS, register_restarts_dyn_split_RK2, initialize_dyn_split_RK2
 use MOM_dynamics_split_RK2, only : step_MOM_dyn_split_RK2, end_dyn_split_RK2, dyn_split_RK2_sync_to_host, dyn_split_RK2_host_was_modified
+use MOM_dynamics_split_RK2, only : remap_dyn_split_RK2_aux_vars
 use MOM_set_visc,      only : set_visc_CS, set_visc_init, set_viscous_BBL, set_visc_end
 use MOM_ALE,           only : ALE_CS, ALE_init, ALE_set_extrap_boundaries, ALE_update_regrid_weights, ALE_regrid, ALE_remap_tracers
 use MOM_ALE,           only : ALE_remap_set_h_vel, ALE_remap_velocities, ALE_end
@@ -238,6 +239,7 @@ do nc = 1, ncycles
     call ALE_remap_set_h_vel(ALE_CSp, G, GV, h, hu0, hv0, OBC)
     call ALE_remap_set_h_vel(ALE_CSp, G, GV, h_new, hu1, hv1, OBC)
     call ALE_remap_velocities(ALE_CSp, G, GV, hu0, hv0, hu1, hv1, u, v)
+    call remap_dyn_split_RK2_aux_vars(G, GV, CS, hu0, hv0, hu1, hv1, ALE_CSp)      ! (REMAP_AUXILIARY_VARS, MOM.F90:1678-1683; returns without it)
     do k=1,nk ; do j=G%jsc-1,G%jec+1 ; do i=G%isc-1,G%iec+1 ; h(i,j,k) = h_new(i,j,k) ; enddo ; enddo ; enddo      ! :1694-1698
     call dyn_split_RK2_host_was_modified(CS)
     call pass_var(u, G%Domain, position=EAST_FACE) ; call pass_var(v, G%Domain, position=NORTH_FACE)      ! pass_uv_T_S_h :1713-1719

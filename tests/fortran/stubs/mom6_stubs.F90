@@ -1365,10 +1365,8 @@ end module MOM_remapping
 #endif
 #if !defined(MOM6HIP_WITH_ALE_SHIM) && !defined(REF_ALE)
 module MOM_ALE
-#if defined(REF_PF) || defined(REF_SET_VISC)
 use MOM_grid, only : ocean_grid_type
 use MOM_verticalGrid, only : verticalGrid_type
-#endif
 #ifdef REF_PF
 use MOM_variables, only : thermo_var_ptrs
 use PLM_functions, only : PLM_slope_wa, PLM_monotonized_slope, PLM_extrapolate_slope
@@ -1378,20 +1376,16 @@ public :: ALE_CS
 type :: ALE_CS
   integer :: unused = 0
 end type ALE_CS
-#ifdef REF_SET_VISC
 public :: ALE_remap_velocities, ALE_remap_interface_vals, ALE_remap_vertex_vals
-#endif
 #ifdef REF_PF
 ! What MOM_PressureForce_FV imports from MOM_ALE.  MOM_ALE.F90 itself stands on the regridding and tracer-registry modules and is not part of
 ! this build: this stand-in forms the edge values of T and S of a column from the reference's OWN slope functions (PLM_functions.F90 above), the
 ! way ALE_PLM_edge_values does for REMAPPING_ANSWER_DATE >= 20190101 (MOM_ALE.F90:1520-1577).  The glue is ours; the arithmetic is theirs.
 public :: TS_PLM_edge_values, TS_PPM_edge_values
 #endif
-#if defined(REF_PF) || defined(REF_SET_VISC)
 contains
-#endif
-#ifdef REF_SET_VISC
-! What MOM_set_viscosity imports from MOM_ALE for remap_vertvisc_aux_vars (REMAP_AUXILIARY_VARS: not reached by the tests)
+! What MOM_set_viscosity and MOM_dynamics_split_RK2 import from MOM_ALE for remap_vertvisc_aux_vars / remap_dyn_split_RK2_aux_vars
+! (REMAP_AUXILIARY_VARS: reached only in builds with the MOM_ALE shim or the reference's own MOM_ALE, which take this module's place)
 subroutine ALE_remap_velocities(CS, G, GV, h_old_u, h_old_v, h_new_u, h_new_v, u, v, debug, dt, allow_preserve_variance)
   type(ALE_CS),            intent(in)    :: CS
   type(ocean_grid_type),   intent(in)    :: G
@@ -1420,7 +1414,6 @@ subroutine ALE_remap_vertex_vals(CS, G, GV, h_old, h_new, vert_val)
   real, dimension(G%IsdB:G%IedB,G%JsdB:G%JedB,GV%ke+1), intent(inout) :: vert_val
   error stop "ALE_remap_vertex_vals stand-in: not provided"
 end subroutine ALE_remap_vertex_vals
-#endif
 #ifdef REF_PF
 subroutine plm_edges(G, GV, h, Q, bdry_extrap, Q_t, Q_b)
   type(ocean_grid_type),   intent(in)    :: G

@@ -556,7 +556,8 @@ CYCLE_ALE_PAIRS = """
 
 
 def build_cycle_driver(tmp):
-    flags = ["-cpp", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
+    # (-DMOM6HIP_WITH_ALE_SHIM: the MOM_ALE shim takes the place of the stand-in module of the same name)
+    flags = ["-cpp", "-DMOM6HIP_WITH_ALE_SHIM", "-fdefault-real-8", "-O0", "-ffp-contract=off", f"-I{STUBS}", f"-I{tmp}", "-J", str(tmp)]
     objs = []
     # (MOM_ALE right after the glue: its ALE_CS replaces the type-only stand-in before any module that takes one is compiled)
     shims = SHIMS[:2] + ["MOM_ALE_hip.F90"] + SHIMS[2:]
@@ -628,6 +629,12 @@ def cycle_oracle(name, state, ncycles, nsteps):
             hu0, hv0 = orc.ale_remap_set_h_vel(g, st.h)
             hu1, hv1 = orc.ale_remap_set_h_vel(g, h_new)
             orc.ale_remap_velocities(g, p["VELOCITY_REMAPPING_SCHEME"], hu0, hv0, hu1, hv1, st.u, st.v, boundary_extrapolation=_b(p, "INIT_BOUNDARY_EXTRAP"))
+            if _b(p, "REMAP_AUXILIARY_VARS"):      # remap_dyn_split_RK2_aux_vars (MOM_dynamics_split_RK2.F90:1273-1301; STORE_CORIOLIS_ACCEL is the default)
+                A = st.arrs
+                for a, b in (("u_av", "v_av"), ("CAu_pred", "CAv_pred"), ("diffu", "diffv")):
+                    orc.ale_remap_velocities(g, p["VELOCITY_REMAPPING_SCHEME"], hu0, hv0, hu1, hv1, A[a], A[b], boundary_extrapolation=_b(p, "INIT_BOUNDARY_EXTRAP"))
+                    if a != "diffu":      # the two pass_vector calls of the routine
+                        orc.halo_update(g, A[a], _abi.POS_U); orc.halo_update(g, A[b], _abi.POS_V)
             sj, si = g.csl(H)
             sj, si = slice(sj.start - 1, sj.stop + 1), slice(si.start - 1, si.stop + 1)
             st.h[:, sj, si] = h_new[:, sj, si]
@@ -645,19 +652,21 @@ def test_the_cycle_driver_compiles(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(FC), reason="amdflang not present")
 @pytest.mark.parametrize("resident", [False, True])
-@pytest.mark.parametrize("with_ALE", [False, True, "neutral"], ids=["no_ALE", "ALE", "neutral_diffusion"])
+@pytest.mark.parametrize("with_ALE", [False, True, "neutral", "remap_aux"], ids=["no_ALE", "ALE", "neutral_diffusion", "ALE_remap_aux"])
 def test_one_thermodynamic_cycle_of_step_MOM_from_fortran_matches_oracle(tmp_path, resident, with_ALE):
     """thickness_diffuse -> set_viscous_BBL -> step_MOM_dyn_split_RK2 x (DT_THERM / DT) -> mixedlayer_restrat -> advect_tracer -> tracer_hordiff, twice, from a
     Fortran program that calls reference-named procedures only, with the .testing/tc4 parameter set: u, v, h, T, S and the transports equal
     the oracle's bit for bit; with GPU_RESIDENT_DYNAMICS the fields cross PCIe once in each direction, whatever the number of cycles"""
     name = "tc4"
     neutral = with_ALE == "neutral"      # tracer_hordiff with .testing/tc2's USE_NEUTRAL_DIFFUSION = True (six layers, no ALE block)
-    with_ALE = with_ALE is True
+    remap_aux = with_ALE == "remap_aux"      # REMAP_AUXILIARY_VARS = True: remap_dyn_split_RK2_aux_vars in the ALE block (MOM.F90:1678-1683)
+    with_ALE = with_ALE is True or remap_aux
     # with_ALE: six layers, and after the tracers the ALE block on the host arrays between dyn_split_RK2_sync_to_host and
     # dyn_split_RK2_host_was_modified (z* regrid with a time scale, PPM_H4 / PLM remapping of T, S, u, v)
     TC_INPUT["tc4c"] = dict(shape=(14, 10, 6) if with_ALE or neutral else TC_INPUT[name]["shape"],
                             pairs=TC_INPUT[name]["pairs"] + CYCLE_PAIRS + (CYCLE_ALE_PAIRS if with_ALE else "") +
-                            ("\n        USE_NEUTRAL_DIFFUSION = True\n" if neutral else ""))
+                            ("\n        USE_NEUTRAL_DIFFUSION = True\n" if neutral else "") +
+                            ("\n        REMAP_AUXILIARY_VARS = True\n" if remap_aux else ""))
     exe = build_cycle_driver(tmp_path)
     state = case_state("tc4c")
     g = state[0]
