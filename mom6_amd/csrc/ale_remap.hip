@@ -978,10 +978,10 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
     wsync();
     if (extrap && lane >= 62) {      // PQM_boundary_extrapolation_v1 (PQM_functions.F90:502-831): lane 62 the top cell, lane 63 the bottom cell
       const bool bottom = lane == 63;
-      double u0_l, u0_r, u1_l, u1_r, slope, um, hb;
+      double u0_l, u0_r, u1_l, u1_r, slope, um;
       if (!bottom) {
         const double h0 = h[0], h1 = h[1], u0 = u[0], u1 = u[1];
-        um = u0; hb = h0;
+        um = u0;
         slope = 2.0 * (u1 - u0) / ((h0 + h1) + hNeglect);
         slope = slope * h0;
         u0_r = EL[1];                                   // ppoly_coef(i1,1)
@@ -1015,7 +1015,7 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
       } else {
         const int i0 = n - 2, i1 = n - 1;
         const double h0 = h[i0], h1 = h[i1], u0 = u[i0], u1 = u[i1];
-        um = u1; hb = h1;
+        um = u1;
         slope = 2.0 * (u1 - u0) / (h0 + h1);
         slope = slope * h1;
         const Quartic q0 = pqm_quartic(u0, h0, EL[i0], ER[i0], SL[i0], SR[i0]);      // ppoly_coef(i0,:), a = EL[i0]
@@ -1049,7 +1049,6 @@ __device__ int w_build_reconstructions(const WCol &c, int lane, int scheme, bool
           }
         }
       }
-      (void)hb;
       const int kb = bottom ? n - 1 : 0;      // (the two lanes read cells 1 and n-2 and write cells 0 and n-1: n >= 5 here)
       EL[kb] = u0_l; ER[kb] = u0_r; SL[kb] = u1_l; SR[kb] = u1_r;
     }
