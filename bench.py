@@ -41,7 +41,7 @@ HOR_VISC = dict(BIHARMONIC=True, SMAGORINSKY_AH=True, SMAG_BI_CONST=0.06, AH_VEL
 SET_VISC = dict(HBBL=10.0, KV=1.0e-4, CDRAG=0.003, BBL_USE_EOS=True)      # set_visc_init: the bottom boundary layer of set_viscous_BBL
 HOT_FRAC = 2.0e-5
 REGRID_OLD_WEIGHT = 0.0    # REGRID_TIME_SCALE = 0 (the reference's default): every ALE call regrids all the way to z*
-PMC_PROFILE = "r05_b_pmc.json"
+PMC_PROFILE = "r05_c_pmc.json"
 FP64_VECTOR_TFLOPS = 78.6            # 256 CUs x 4 SIMDs x 16 fp64 lanes per cycle x 2 (fma) x 2.4 GHz
 
 
