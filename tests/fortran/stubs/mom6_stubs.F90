@@ -135,8 +135,17 @@ type :: MOM_domain_type
   integer :: nihalo = 0, njhalo = 0, niglobal = 0, njglobal = 0
   logical :: symmetric = .true.
 end type MOM_domain_type
+!> the fields of a group pass (one PE: do_group_pass wraps each of them in the re-entrant directions, as pass_var does).  As in FMS, a call of
+!! create_group_pass after the group has been used replaces the fields one after the other, in the order of the first round of calls
+!! (mpp_reset_group_update_field): the reference creates its groups anew in every call of btstep / step_MOM_dyn_split_RK2 on that call's arrays.
+type :: group_entry
+  real, pointer :: a2(:,:) => NULL(), a3(:,:,:) => NULL()
+  integer :: pos = 0
+end type group_entry
 type :: group_pass_type
-  integer :: unused = 0
+  integer :: n = 0, ridx = 0
+  logical :: used = .false.
+  type(group_entry) :: e(24)
 end type group_pass_type
 interface pass_var
   module procedure pass_var_3d, pass_var_2d
@@ -170,46 +179,88 @@ subroutine deallocate_MOM_domain(MOM_domain, cursory)
   if (associated(MOM_domain)) deallocate(MOM_domain)
 end subroutine deallocate_MOM_domain
 ! The group passes of the stand-in remember nothing: the reference's callers are compiled against these interfaces, never run.
+subroutine group_slot(group, k)
+  type(group_pass_type), intent(inout) :: group
+  integer,               intent(out)   :: k
+  if (group%used) then      ! a later round of create_group_pass calls: the fields are replaced in order
+    group%ridx = group%ridx + 1 ; if (group%ridx > group%n) group%ridx = 1
+    k = group%ridx
+  else
+    group%n = group%n + 1 ; k = group%n
+    if (k > size(group%e)) error stop "group_pass stand-in: too many fields in a group"
+  endif
+  group%e(k)%a2 => NULL() ; group%e(k)%a3 => NULL()
+end subroutine group_slot
+subroutine vector_positions(stagger, pu, pv)
+  integer, optional, intent(in)  :: stagger
+  integer,           intent(out) :: pu, pv
+  pu = EAST_FACE ; pv = NORTH_FACE
+  if (present(stagger)) then
+    if (stagger == AGRID) then ; pu = CENTER ; pv = CENTER ; endif
+    if (stagger == BGRID_NE) then ; pu = CORNER ; pv = CORNER ; endif
+  endif
+end subroutine vector_positions
 subroutine create_var_group_pass_2d(group, array, MOM_dom, sideflag, position, halo, clock)
   type(group_pass_type),  intent(inout) :: group
-  real, dimension(:,:),   intent(inout) :: array
+  real, dimension(:,:), target, intent(inout) :: array
   type(MOM_domain_type),  intent(inout) :: MOM_dom
   integer,      optional, intent(in)    :: sideflag, position, halo, clock
+  integer :: k
+  call group_slot(group, k)
+  group%e(k)%a2 => array ; group%e(k)%pos = CENTER ; if (present(position)) group%e(k)%pos = position
 end subroutine create_var_group_pass_2d
 subroutine create_var_group_pass_3d(group, array, MOM_dom, sideflag, position, halo, clock)
   type(group_pass_type),  intent(inout) :: group
-  real, dimension(:,:,:), intent(inout) :: array
+  real, dimension(:,:,:), target, intent(inout) :: array
   type(MOM_domain_type),  intent(inout) :: MOM_dom
   integer,      optional, intent(in)    :: sideflag, position, halo, clock
+  integer :: k
+  call group_slot(group, k)
+  group%e(k)%a3 => array ; group%e(k)%pos = CENTER ; if (present(position)) group%e(k)%pos = position
 end subroutine create_var_group_pass_3d
 subroutine create_vector_group_pass_2d(group, u_cmpt, v_cmpt, MOM_dom, direction, stagger, halo, clock)
   type(group_pass_type),  intent(inout) :: group
-  real, dimension(:,:),   intent(inout) :: u_cmpt, v_cmpt
+  real, dimension(:,:), target, intent(inout) :: u_cmpt, v_cmpt
   type(MOM_domain_type),  intent(inout) :: MOM_dom
   integer,      optional, intent(in)    :: direction, stagger, halo, clock
+  integer :: k, pu, pv
+  call vector_positions(stagger, pu, pv)
+  call group_slot(group, k) ; group%e(k)%a2 => u_cmpt ; group%e(k)%pos = pu
+  call group_slot(group, k) ; group%e(k)%a2 => v_cmpt ; group%e(k)%pos = pv
 end subroutine create_vector_group_pass_2d
 subroutine create_vector_group_pass_3d(group, u_cmpt, v_cmpt, MOM_dom, direction, stagger, halo, clock)
   type(group_pass_type),  intent(inout) :: group
-  real, dimension(:,:,:), intent(inout) :: u_cmpt, v_cmpt
+  real, dimension(:,:,:), target, intent(inout) :: u_cmpt, v_cmpt
   type(MOM_domain_type),  intent(inout) :: MOM_dom
   integer,      optional, intent(in)    :: direction, stagger, halo, clock
+  integer :: k, pu, pv
+  call vector_positions(stagger, pu, pv)
+  call group_slot(group, k) ; group%e(k)%a3 => u_cmpt ; group%e(k)%pos = pu
+  call group_slot(group, k) ; group%e(k)%a3 => v_cmpt ; group%e(k)%pos = pv
 end subroutine create_vector_group_pass_3d
 subroutine do_group_pass(group, MOM_dom, clock)
   type(group_pass_type), intent(inout) :: group
   type(MOM_domain_type), intent(inout) :: MOM_dom
   integer,     optional, intent(in)    :: clock
+  integer :: k
+  group%used = .true. ; group%ridx = 0
+  if (.not.(MOM_dom%reentrant(1) .or. MOM_dom%reentrant(2))) return
+  do k = 1, group%n
+    if (associated(group%e(k)%a2)) call pass_var_2d(group%e(k)%a2, MOM_dom, position=group%e(k)%pos)
+    if (associated(group%e(k)%a3)) call pass_var_3d(group%e(k)%a3, MOM_dom, position=group%e(k)%pos)
+  enddo
 end subroutine do_group_pass
 subroutine start_group_pass(group, MOM_dom, clock)
   type(group_pass_type), intent(inout) :: group
   type(MOM_domain_type), intent(inout) :: MOM_dom
   integer,     optional, intent(in)    :: clock
+  call do_group_pass(group, MOM_dom)
 end subroutine start_group_pass
 subroutine complete_group_pass(group, MOM_dom, clock)
   type(group_pass_type), intent(inout) :: group
   type(MOM_domain_type), intent(inout) :: MOM_dom
   integer,     optional, intent(in)    :: clock
 end subroutine complete_group_pass
-!> One PE: wrap the re-entrant directions (whole allocation with the halo; position gives the staggering)
 subroutine pass_var_3d(array, MOM_dom, sideflag, complete, position, halo, clock)
   real, dimension(:,:,:), intent(inout) :: array
   type(MOM_domain_type),  intent(inout) :: MOM_dom

@@ -298,8 +298,8 @@ def ref_bt_exe(ref_builds):
                                              (dict(), [], False), (dict(ni=40, nj=30, seed=11), [], False)])
 def test_the_reference_btstep_equals_the_oracle(ref_bt_exe, tmp_path, kw, params, exact):
     """barotropic_init, btcalc, bt_mass_source and btstep of the reference's MOM_barotropic.F90 with the argument list of the RK2 step's
-    call (BT_cont, layer fluxes, eta_av; 13 barotropic steps) on a closed basin (the stand-in's group passes do nothing, which is what one
-    closed tile needs).  With BT_STRONG_DRAG (no real power in bt_rem, :1525): every output bit for bit.  With the default, bt_rem =
+    call (BT_cont, layer fluxes, eta_av; 13 barotropic steps) on a closed basin (the re-entrant form of btstep, with the exchanges of its wide-halo
+    march, runs inside test_reference_dynamical_core_equals_the_oracle[*-reentrant_x], where its inputs carry the halos a step gives them).  With BT_STRONG_DRAG (no real power in bt_rem, :1525): every output bit for bit.  With the default, bt_rem =
     av_rem ** (1/nstep) (:1529) is the libm power of the build, where oracle and library take a correctly rounded one (DESIGN.md section 3:
     one ulp apart in ~0.1 % of arguments): the outputs agree in every bit except downstream of the one or two faces where the two powers
     differ, and there within a few ulps -- the documented deviation, seen here against the reference itself."""
@@ -633,20 +633,26 @@ BENCH_LIKE = dict(shape=(16, 12, 6), pairs="""
         """)
 
 
+@pytest.mark.parametrize("reentrant", [False, True], ids=["closed", "reentrant_x"])
 @pytest.mark.parametrize("name", ["tc4", "tc2", "tc1", "bench_like"])
-def test_reference_dynamical_core_equals_the_oracle(tmp_path, dyn_exe, name, monkeypatch):
+def test_reference_dynamical_core_equals_the_oracle(tmp_path, dyn_exe, name, reentrant, monkeypatch):
     """three steps of the reference's step_MOM_dyn_split_RK2 (after its own set_viscous_BBL each), every module of the dynamical core the
     reference's own, with the transcribed parameter sets of .testing/tc4, tc2 and tc1 and with the settings of bench.py's step, on a closed
-    basin (REENTRANT_X = False: the stand-in's group passes do nothing): u, v, h, uh, vh, uhtr, vhtr, eta_av (and MEKE%mom_src, visc%nkml_visc_u/v where the set has them) equal the
-    oracle's DynState.step bit for bit"""
+    basin and on a zonally re-entrant one (the stand-in's pass_var and group passes wrap the re-entrant direction on the one PE: every pass of
+    the step and of btstep's wide-halo march is exercised): u, v, h, uh, vh, uhtr, vhtr, eta_av (and MEKE%mom_src, visc%nkml_visc_u/v where the
+    set has them) equal the oracle's DynState.step bit for bit"""
     import test_testing_configs as tc
+    from oracle import orc
     exe = dyn_exe
     nsteps = 3
     base = BENCH_LIKE if name == "bench_like" else tc.TC_INPUT[name]
-    monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + "\n        REENTRANT_X = False\n"))
+    monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + f"\n        REENTRANT_X = {reentrant}\n"))
     state = tc.case_state(name)
     g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
-    assert not g.reentrant_x and not g.reentrant_y      # (the stand-in's group passes do nothing: a closed tile)
+    assert g.reentrant_x == reentrant and not g.reentrant_y
+    if reentrant:      # the forcing's halos as a run has them (the synthetic friction velocity is drawn halo and all: not periodic)
+        ustar = np.ascontiguousarray(ustar); orc.halo_update(g, ustar, _abi.POS_H)
+        state = (g, d, taux, tauy, ustar, bbl, Rlay, g_prime)
     tc.write_case(tmp_path, name, nsteps, False, state, bbl_mode=1)
     r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
@@ -728,12 +734,13 @@ def mle_exe(ref_builds):
     return ref_builds["mle_exe"].result()
 
 
-def test_reference_mixedlayer_restrat_equals_the_oracle(tmp_path, mle_exe):
+@pytest.mark.parametrize("topo", [(False, False), (True, False)], ids=["closed", "reentrant_x"])
+def test_reference_mixedlayer_restrat_equals_the_oracle(tmp_path, mle_exe, topo):
     """mixedlayer_restrat_register_restarts, mixedlayer_restrat_init and two calls of mixedlayer_restrat of the reference's own module (the OM4
     form and the bulk-mixed-layer form; the running means of the mixed layer depth; its own MOM_EOS), every variant of
     tests/test_mixedlayer_restrat.py on a closed basin: h, uhtr, vhtr equal the oracle's bit for bit"""
     import test_mixedlayer_restrat as tm
-    g, d = tm.case(36, 22, 6, reentrant_x=False, reentrant_y=False)
+    g, d = tm.case(36, 22, 6, reentrant_x=topo[0], reentrant_y=topo[1])
     bad = []
     for name in tm.VARIANTS:
         ref, nrest = tm._write_mle_case(tmp_path, g, d, name)
@@ -772,12 +779,13 @@ def td_exe(ref_builds):
     return ref_builds["td_exe"].result()
 
 
-def test_reference_thickness_diffuse_equals_the_oracle(tmp_path, td_exe):
+@pytest.mark.parametrize("topo", [(False, False), (True, False)], ids=["closed", "reentrant_x"])
+def test_reference_thickness_diffuse_equals_the_oracle(tmp_path, td_exe, topo):
     """thickness_diffuse_init and thickness_diffuse of the reference's own module -- with its MOM_isopycnal_slopes (vert_fill_TS),
     MOM_interface_heights (find_eta), density integrals and equation of state -- for every variant of tests/test_thickness_diffuse.py on a
     closed basin: h, uhtr, vhtr, CDp%uhGM, CDp%vhGM and MEKE%GM_src equal the oracle's bit for bit"""
     import test_thickness_diffuse as tt
-    g, d = tt.case(36, 22, 6, reentrant_x=False, reentrant_y=False)
+    g, d = tt.case(36, 22, 6, reentrant_x=topo[0], reentrant_y=topo[1])
     bad = []
     for name in tt.VARIANTS:
         ref, opt = tt._write_td_case(tmp_path, g, d, name)
@@ -890,8 +898,9 @@ def dyn_rk2b_exe(ref_builds):
     return ref_builds["dyn_rk2b_exe"].result()
 
 
+@pytest.mark.parametrize("reentrant", [False, True], ids=["closed", "reentrant_x"])
 @pytest.mark.parametrize("name", ["tc4", "bench_like"])
-def test_reference_rk2b_core_equals_the_oracle(tmp_path, dyn_rk2b_exe, name, monkeypatch):
+def test_reference_rk2b_core_equals_the_oracle(tmp_path, dyn_rk2b_exe, name, reentrant, monkeypatch):
     """SPLIT_RK2B: three steps of the reference's own step_MOM_dyn_split_RK2b (MOM_dynamics_split_RK2b.F90 in place, every module under it the
     reference's) with the tc4 set and the bench's settings on a closed basin: the filtered velocities, h, the transports and eta_av equal the
     oracle's DynState(rk2b=True).step bit for bit"""
@@ -899,11 +908,14 @@ def test_reference_rk2b_core_equals_the_oracle(tmp_path, dyn_rk2b_exe, name, mon
     import test_testing_configs as tc
     from oracle import orc
     base = BENCH_LIKE if name == "bench_like" else tc.TC_INPUT[name]
-    monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + "\n        REENTRANT_X = False\n"))
+    monkeypatch.setitem(tc.TC_INPUT, name, dict(base, pairs=base["pairs"] + f"\n        REENTRANT_X = {reentrant}\n"))
     monkeypatch.setattr(orc, "DynState", functools.partial(orc.DynState, rk2b=True))
     nsteps = 3
     state = tc.case_state(name)
     g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    if reentrant:
+        ustar = np.ascontiguousarray(ustar); orc.halo_update(g, ustar, _abi.POS_H)
+        state = (g, d, taux, tauy, ustar, bbl, Rlay, g_prime)
     tc.write_case(tmp_path, name, nsteps, False, state, bbl_mode=1)
     r = subprocess.run([dyn_rk2b_exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "params.txt")], capture_output=True, text=True)
     assert r.returncode == 0 and "dyn_driver ok" in r.stdout, r.stderr[-3000:] + r.stdout[-2000:]
@@ -947,11 +959,12 @@ def tracer_exe(ref_builds):
     return ref_builds["tracer_exe"].result()
 
 
-def test_reference_tracer_advect_and_hordiff_equal_the_oracle(tmp_path, tracer_exe):
+@pytest.mark.parametrize("topo", [(False, False), (True, False)], ids=["closed", "reentrant_x"])
+def test_reference_tracer_advect_and_hordiff_equal_the_oracle(tmp_path, tracer_exe, topo):
     """advect_tracer then tracer_hordiff of the reference's own modules on a closed basin, for constant KHTR, every variable-mixing set of
     tests/test_tracer_hor_diff.py and neutral diffusion (whole column, and below visc%h_ML): the tracers equal the oracle's bit for bit"""
     import test_tracer_hor_diff as th
-    g, h, tr = th.case(36, 22, 4, reentrant=(False, False))
+    g, h, tr = th.case(36, 22, 4, reentrant=topo)
     bad = []
     for name in [None, "neutral", "neutral_interior"] + list(th.VM):
         ref = th._write_tracer_case(tmp_path, g, h, tr, name)
@@ -964,12 +977,13 @@ def test_reference_tracer_advect_and_hordiff_equal_the_oracle(tmp_path, tracer_e
     assert not bad, bad
 
 
-def test_reference_epipycnal_diffusion_equals_the_oracle(tmp_path, tracer_exe):
+@pytest.mark.parametrize("topo", [(False, False), (True, False)], ids=["closed", "reentrant_x"])
+def test_reference_epipycnal_diffusion_equals_the_oracle(tmp_path, tracer_exe, topo):
     """DIFFUSE_ML_TO_INTERIOR of the reference's own tracer_epipycnal_ML_diff on a layered state at rest in a closed basin, as .testing/tc1 sets it
     and with the later answer date: the tracers equal the oracle's bit for bit"""
     import test_epipycnal as te
     from oracle import orc
-    g, h, tr, eos, Rlay = te.layered_case(ni=30, nj=16, nk=8, reentrant=(False, False))
+    g, h, tr, eos, Rlay = te.layered_case(ni=30, nj=16, nk=8, reentrant=topo)
     bad = []
     for params in [dict(KHTR=800.0, ML_KHTR_SCALE=0.0), dict(KHTR=800.0), dict(KHTR=2.0e5, CHECK_DIFFUSIVE_CFL=True, HOR_DIFF_ANSWER_DATE=20240401)]:
         dt = te._write_layered_tracer_case(tmp_path, g, h, tr, "WRIGHT", Rlay, params, False)
