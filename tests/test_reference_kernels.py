@@ -672,17 +672,23 @@ def test_reference_dynamical_core_equals_the_oracle(tmp_path, dyn_exe, name, ree
     assert not bad, bad
 
 
-def test_reference_dynamical_core_at_a_size_where_the_two_powers_differ(tmp_path, dyn_exe, monkeypatch):
+@pytest.mark.parametrize("reentrant", [False, True], ids=["closed", "reentrant_x"])
+def test_reference_dynamical_core_at_a_size_where_the_two_powers_differ(tmp_path, dyn_exe, reentrant, monkeypatch):
     """On a larger basin btstep's one real power, bt_rem = av_rem ** (1/nstep) (MOM_barotropic.F90:1529), meets arguments where the host's
     libm pow (the reference build's) and the correctly rounded power of oracle and library are an ulp apart.  With the
-    oracle told to take libm's (ORC_BT_LIBM_POW) two steps of the reference's dynamical core at 120x80x20 equal it bit for bit; with its own, the two
+    oracle told to take libm's (ORC_BT_LIBM_POW) two steps of the reference's dynamical core at 120x80x20 (closed, and zonally re-entrant as the
+    bench's domain is) equal it bit for bit; with its own, the two
     agree except downstream of those faces, there within 1e-10 relative."""
     import test_testing_configs as tc
     name = "bench_like"
-    monkeypatch.setitem(tc.TC_INPUT, name, dict(shape=(120, 80, 20), pairs=BENCH_LIKE["pairs"] + "\n        REENTRANT_X = False\n"))
+    monkeypatch.setitem(tc.TC_INPUT, name, dict(shape=(120, 80, 20), pairs=BENCH_LIKE["pairs"] + f"\n        REENTRANT_X = {reentrant}\n"))
     nsteps = 2
     state = tc.case_state(name)
     g, d, taux, tauy, ustar, bbl, Rlay, g_prime = state
+    if reentrant:      # (the forcing's halos as a run has them)
+        from oracle import orc
+        ustar = np.ascontiguousarray(ustar); orc.halo_update(g, ustar, _abi.POS_H)
+        state = (g, d, taux, tauy, ustar, bbl, Rlay, g_prime)
     tc.write_case(tmp_path, name, nsteps, False, state, bbl_mode=1)
     import resource
     unlimited = lambda: resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))      # (the reference's automatic arrays)
