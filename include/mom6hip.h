@@ -1252,15 +1252,18 @@ typedef struct mom6hip_thickness_diffuse_cs {
   double kappa_smooth;     /* KD_SMOOTH [H Z T-1] (1e-6) */
   double KHTH_Slope_Cff;   /* KHTH_SLOPE_CFF (0): the Visbeck term needs L2u, L2v, SN_u, SN_v */
   double KhTh_fac;         /* MEKE%KhTh_fac (1): MEKE_KHTH_FAC, with MEKE_Kh */
-  double reserved0[4];
+  double FGNV_scale;       /* FGNV_FILTER_SCALE (1): the coefficient of the vertical smoothing term of the streamfunction equation (:58) */
+  double N2_floor;         /* (FGNV_STRAT_FLOOR * OMEGA)**2 (:2337): the floor of N2 in the elliptic solve */
+  double reserved0[2];
   int32_t thickness_diffuse;   /* THICKNESSDIFFUSE (0): without it (or with nothing to diffuse with, :192-194) the call returns at once */
   int32_t use_GM_work_bug;     /* USE_GM_WORK_BUG (0) */
   int32_t nkml;                /* GV%nkml (0): the streamfunction goes linearly to zero over max(nkml, 1) layers */
   int32_t initialized;
   int32_t use_variable_mixing; /* VarMix%use_variable_mixing (0): with it the call works even with KHTH = 0 (:192-194), and the
                                   Visbeck term is added when KHTH_SLOPE_CFF > 0 and L2u ... SN_v are given (:205-207, :242-249) */
-  int32_t reserved_i[1];
-  int32_t unsupported[10];     /* FGNV, detangle, Kh_eta, Stanley, MEKE_GEOMETRIC, GM_src_alt, read_khth, ebt_struct / QG Leith / depth
+  int32_t use_FGNV_streamfn;   /* KHTH_USE_FGNV_STREAMFUNCTION (0): the streamfunction of Ferrari et al. (2010) (:1105-1124, streamfn_solver :1673);
+                                  needs cg1 (and g_prime without an equation of state) */
+  int32_t unsupported[10];     /* (unused), detangle, Kh_eta, Stanley, MEKE_GEOMETRIC, GM_src_alt, read_khth, ebt_struct / QG Leith / depth
                                   scaling, Use_KH_in_MEKE, non-Boussinesq / p_surf / SKEB: any nonzero is refused */
   /* fields of MEKE and VarMix, in the memory space of the call; NULL = not allocated / not in use */
   const double *MEKE_Kh;       /* MEKE%Kh, h points 2-D (valid halo of 1) */
@@ -1269,7 +1272,9 @@ typedef struct mom6hip_thickness_diffuse_cs {
   const double *slope_x, *slope_y;            /* VarMix%slope_x / _y (USE_STORED_SLOPES), u / v points, nk+1 interfaces */
   double *MEKE_GM_src;         /* MEKE%GM_src, h points 2-D: set to the work of this call (:197-199, :1560) */
   const double *Rlay;          /* GV%Rlay(1:nk) (HOST array): the work without an equation of state (:827, :1218) */
-  void *reserved1[3];
+  const double *cg1;           /* VarMix%cg1, h points 2-D (valid halo of 1): the first baroclinic gravity wave speed, with use_FGNV_streamfn */
+  const double *g_prime;       /* GV%g_prime(1:nk+1) (HOST array): dzN2 without an equation of state (:1095), with use_FGNV_streamfn */
+  void *reserved1[1];
 } mom6hip_thickness_diffuse_cs_t;
 
 /* thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH)                               :133

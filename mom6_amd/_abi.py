@@ -237,19 +237,20 @@ class HorViscCS(C.Structure):
 
 
 # ---- MOM_thickness_diffuse --------------------------------------------------------------------------------
-THICKNESS_DIFFUSE_UNSUPPORTED = ("use_FGNV_streamfn", "detangle_interfaces", "Kh_eta", "use_stanley_gm", "MEKE_GEOMETRIC", "GM_src_alt", "read_khth",
+THICKNESS_DIFFUSE_UNSUPPORTED = ("unused_0", "detangle_interfaces", "Kh_eta", "use_stanley_gm", "MEKE_GEOMETRIC", "GM_src_alt", "read_khth",
                                  "ebt_struct", "Use_KH_in_MEKE", "non_Boussinesq")
-THICKNESS_DIFFUSE_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "MEKE_GM_src", "Rlay")
+THICKNESS_DIFFUSE_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "MEKE_GM_src", "Rlay", "cg1", "g_prime")
 
 
 class ThicknessDiffuseCS(C.Structure):
     """mom6hip_thickness_diffuse_cs_t (include/mom6hip.h)."""
-    _fields_ = ([(n, C.c_double) for n in ("Khth", "Khth_Min", "Khth_Max", "max_Khth_CFL", "slope_max", "kappa_smooth", "KHTH_Slope_Cff", "KhTh_fac")]
-                + [("reserved0", C.c_double * 4)]
-                + [(n, C.c_int32) for n in ("thickness_diffuse", "use_GM_work_bug", "nkml", "initialized", "use_variable_mixing")]
-                + [("reserved_i", C.c_int32 * 1), ("unsupported", C.c_int32 * 10)]
+    _fields_ = ([(n, C.c_double) for n in ("Khth", "Khth_Min", "Khth_Max", "max_Khth_CFL", "slope_max", "kappa_smooth", "KHTH_Slope_Cff", "KhTh_fac",
+                                            "FGNV_scale", "N2_floor")]
+                + [("reserved0", C.c_double * 2)]
+                + [(n, C.c_int32) for n in ("thickness_diffuse", "use_GM_work_bug", "nkml", "initialized", "use_variable_mixing", "use_FGNV_streamfn")]
+                + [("unsupported", C.c_int32 * 10)]
                 + [(n, C.c_void_p) for n in THICKNESS_DIFFUSE_FIELDS]
-                + [("reserved1", C.c_void_p * 3)])
+                + [("reserved1", C.c_void_p * 1)])
 
 
 MIXEDLAYER_RESTRAT_UNSUPPORTED = ("use_Bodner", "use_Stanley_ML", "non_Boussinesq")

@@ -92,7 +92,7 @@ struct HostTable {
   std::vector<double> last;
   const double *get(const double *host, size_t n);      // nullptr on failure (error set)
 };
-enum { TABLE_PGF_RLAY = 0, TABLE_PGF_GPRIME, TABLE_SVML_RLAY, TABLE_TD_RLAY, TABLE_COUNT = 8 };
+enum { TABLE_PGF_RLAY = 0, TABLE_PGF_GPRIME, TABLE_SVML_RLAY, TABLE_TD_RLAY, TABLE_TD_GPRIME, TABLE_COUNT = 8 };
 
 }  // namespace m6
 

@@ -49,6 +49,8 @@ type, public :: thickness_diffuse_CS ; private
   logical :: use_GME_thickness_diffuse = .false.
   type(mom6hip_eos_t) :: eos             !< the equation of state, as read from the parameter file
   type(diag_ctrl), pointer :: diag => NULL()
+  logical :: use_FGNV_streamfn = .false. !< KHTH_USE_FGNV_STREAMFUNCTION: the streamfunction of Ferrari et al. (2010)
+  real :: FGNV_scale = 1.0, N2_floor = 0.0 !< FGNV_FILTER_SCALE and (FGNV_STRAT_FLOOR * OMEGA)**2
 end type thickness_diffuse_CS
 
 contains
@@ -72,7 +74,7 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
   type(mom6hip_thickness_diffuse_cs_t) :: ccs
   type(c_ptr) :: p_T, p_S, p_eos, p_uhGM, p_vhGM, ctx
   integer :: n2
-  real(c_double), allocatable, target :: Rlay(:)
+  real(c_double), allocatable, target :: Rlay(:), g_prime(:)
   integer :: i, j, rc
 
   if (.not. CS%initialized) call MOM_error(FATAL, "MOM_thickness_diffuse: "//&
@@ -102,6 +104,12 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
   if (allocated(MEKE%Kh)) then ; ccs%MEKE_Kh = c_loc(MEKE%Kh) ; ccs%KhTh_fac = MEKE%KhTh_fac ; endif
   if (allocated(MEKE%GM_src)) ccs%MEKE_GM_src = c_loc(MEKE%GM_src)
   if (allocated(GV%Rlay)) then ; allocate(Rlay(GV%ke)) ; Rlay(:) = GV%Rlay(1:GV%ke) ; ccs%Rlay = c_loc(Rlay) ; endif
+  if (CS%use_FGNV_streamfn) then      ! :217, :860, :1095: VarMix%cg1, and GV%g_prime for the stratification without an equation of state
+    ccs%use_FGNV_streamfn = 1 ; ccs%FGNV_scale = CS%FGNV_scale ; ccs%N2_floor = CS%N2_floor
+    if (.not.(VarMix%use_variable_mixing .and. allocated(VarMix%cg1))) call MOM_error(FATAL, "cg1 must be associated when using FGNV streamfunction.")
+    ccs%cg1 = c_loc(VarMix%cg1)
+    if (allocated(GV%g_prime)) then ; allocate(g_prime(GV%ke+1)) ; g_prime(:) = GV%g_prime(1:GV%ke+1) ; ccs%g_prime = c_loc(g_prime) ; endif
+  endif
 
   p_T = c_null_ptr ; p_S = c_null_ptr ; p_eos = c_null_ptr ; p_uhGM = c_null_ptr ; p_vhGM = c_null_ptr
   if (associated(tv%eqn_of_state)) then
@@ -117,7 +125,7 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
     n2 = size(h(:,:,1))
     call to_dev(p_T, size(h), .false.) ; call to_dev(p_S, size(h), .false.)
     call to_dev(p_uhGM, size(uhtr), .true.) ; call to_dev(p_vhGM, size(vhtr), .true.)
-    call to_dev(ccs%MEKE_Kh, n2, .false.) ; call to_dev(ccs%MEKE_GM_src, n2, .true.)
+    call to_dev(ccs%MEKE_Kh, n2, .false.) ; call to_dev(ccs%MEKE_GM_src, n2, .true.) ; call to_dev(ccs%cg1, n2, .false.)
     call to_dev(ccs%Res_fn_u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%Res_fn_v, size(vhtr(:,:,1)), .false.)
     call to_dev(ccs%L2u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%SN_u, size(uhtr(:,:,1)), .false.)
     call to_dev(ccs%L2v, size(vhtr(:,:,1)), .false.) ; call to_dev(ccs%SN_v, size(vhtr(:,:,1)), .false.)
@@ -162,7 +170,7 @@ subroutine thickness_diffuse_init(Time, G, GV, US, param_file, diag, CDp, CS)
 # include "version_variable.h"
   character(len=40)  :: mdl = "MOM_thickness_diffuse"
   logical :: flag
-  real :: val, val2
+  real :: val, val2, strat_floor, omega
 
   CS%initialized = .true.
   CS%diag => diag
@@ -196,8 +204,18 @@ subroutine thickness_diffuse_init(Time, G, GV, US, param_file, diag, CDp, CS)
   call get_param(param_file, mdl, "KD_SMOOTH", CS%kappa_smooth, &
                  "A diapycnal diffusivity that is used to interpolate more sensible values of T & S into thin layers.", &
                  units="m2 s-1", default=1.0e-6, scale=GV%m2_s_to_HZ_T)
-  call get_param(param_file, mdl, "KHTH_USE_FGNV_STREAMFUNCTION", flag, default=.false.)
-  call refuse(flag, "KHTH_USE_FGNV_STREAMFUNCTION")
+  call get_param(param_file, mdl, "KHTH_USE_FGNV_STREAMFUNCTION", CS%use_FGNV_streamfn, &
+                 "If true, use the streamfunction formulation of Ferrari et al., 2010, which effectively emphasizes graver vertical modes "// &
+                 "by smoothing in the vertical.", default=.false.)
+  call get_param(param_file, mdl, "FGNV_FILTER_SCALE", CS%FGNV_scale, &
+                 "A coefficient scaling the vertical smoothing term in the Ferrari et al., 2010, streamfunction formulation.", &
+                 units="nondim", default=1., do_not_log=.not.CS%use_FGNV_streamfn)
+  call get_param(param_file, mdl, "FGNV_STRAT_FLOOR", strat_floor, &
+                 "A floor for Brunt-Vasaila frequency in the Ferrari et al., 2010, streamfunction formulation, in units of the Coriolis "// &
+                 "frequency.", default=1.e-15, units="nondim", do_not_log=.not.CS%use_FGNV_streamfn)
+  call get_param(param_file, mdl, "OMEGA", omega, "The rotation rate of the earth.", default=7.2921e-5, units="s-1", scale=US%T_to_s, &
+                 do_not_log=.not.CS%use_FGNV_streamfn)
+  if (CS%use_FGNV_streamfn) CS%N2_floor = (strat_floor*omega)**2      ! :2337
   call get_param(param_file, mdl, "USE_STANLEY_GM", flag, default=.false.) ; call refuse(flag, "USE_STANLEY_GM")
   call get_param(param_file, mdl, "MEKE_GM_SRC_ALT", flag, default=.false.) ; call refuse(flag, "MEKE_GM_SRC_ALT")
   call get_param(param_file, mdl, "MEKE_GEOMETRIC", flag, default=.false.) ; call refuse(flag, "MEKE_GEOMETRIC")

@@ -262,15 +262,15 @@ end type mom6hip_hor_visc_cs_t
 !> mom6hip_thickness_diffuse_cs_t (thickness_diffuse_CS, src/parameterizations/lateral/MOM_thickness_diffuse.F90:40)
 type, bind(c) :: mom6hip_thickness_diffuse_cs_t
   real(c_double) :: Khth = 0.0, Khth_Min = 0.0, Khth_Max = 0.0, max_Khth_CFL = 0.8, slope_max = 0.01, kappa_smooth = 1.0e-6
-  real(c_double) :: KHTH_Slope_Cff = 0.0, KhTh_fac = 1.0
-  real(c_double) :: reserved0(4) = 0.0
+  real(c_double) :: KHTH_Slope_Cff = 0.0, KhTh_fac = 1.0, FGNV_scale = 1.0, N2_floor = 0.0
+  real(c_double) :: reserved0(2) = 0.0
   integer(c_int32_t) :: thickness_diffuse = 0, use_GM_work_bug = 0, nkml = 0, initialized = 0, use_variable_mixing = 0
-  integer(c_int32_t) :: reserved_i(1) = 0
+  integer(c_int32_t) :: use_FGNV_streamfn = 0
   integer(c_int32_t) :: unsupported(10) = 0
   type(c_ptr) :: MEKE_Kh = c_null_ptr, L2u = c_null_ptr, L2v = c_null_ptr, SN_u = c_null_ptr, SN_v = c_null_ptr
   type(c_ptr) :: Res_fn_u = c_null_ptr, Res_fn_v = c_null_ptr, slope_x = c_null_ptr, slope_y = c_null_ptr
-  type(c_ptr) :: MEKE_GM_src = c_null_ptr, Rlay = c_null_ptr
-  type(c_ptr) :: reserved1(3) = c_null_ptr
+  type(c_ptr) :: MEKE_GM_src = c_null_ptr, Rlay = c_null_ptr, cg1 = c_null_ptr, g_prime = c_null_ptr
+  type(c_ptr) :: reserved1(1) = c_null_ptr
 end type mom6hip_thickness_diffuse_cs_t
 
 !> mom6hip_mixedlayer_restrat_cs_t (mixedlayer_restrat_CS, src/parameterizations/lateral/MOM_mixed_layer_restrat.F90:40)

@@ -9,7 +9,7 @@ from ._lib import Mom6HipError, check, lib
 from .tracer_advect import DeviceGrid, _ptr_space
 
 # parameter of the reference -> member of _abi.THICKNESS_DIFFUSE_UNSUPPORTED
-_UNSUPPORTED = {"KHTH_USE_FGNV_STREAMFUNCTION": "use_FGNV_streamfn", "DETANGLE_INTERFACES": "detangle_interfaces", "USE_STANLEY_GM": "use_stanley_gm",
+_UNSUPPORTED = {"DETANGLE_INTERFACES": "detangle_interfaces", "USE_STANLEY_GM": "use_stanley_gm",
                 "MEKE_GEOMETRIC": "MEKE_GEOMETRIC", "MEKE_GM_SRC_ALT": "GM_src_alt", "READ_KHTH": "read_khth", "KHTH_USE_EBT_STRUCT": "ebt_struct",
                 "USE_KH_IN_MEKE": "Use_KH_in_MEKE"}
 
@@ -28,12 +28,15 @@ class thickness_diffuse_CS:
 
     def __init__(self, G: DeviceGrid, THICKNESSDIFFUSE=False, KHTH=0.0, KHTH_MIN=0.0, KHTH_MAX=0.0, KHTH_MAX_CFL=0.8, KHTH_SLOPE_MAX=0.01,
                  KD_SMOOTH=1.0e-6, KHTH_SLOPE_CFF=0.0, MEKE_KHTH_FAC=1.0, USE_GM_WORK_BUG=False, NKML=0, KH_ETA_CONST=0.0, KH_ETA_VEL_SCALE=0.0,
-                 **unsupported):
+                 KHTH_USE_FGNV_STREAMFUNCTION=False, FGNV_FILTER_SCALE=1.0, FGNV_STRAT_FLOOR=1.0e-15, OMEGA=7.2921e-5, **unsupported):
         st = self.st = _abi.ThicknessDiffuseCS()
         st.thickness_diffuse = int(bool(THICKNESSDIFFUSE))
         st.Khth, st.Khth_Min, st.Khth_Max, st.max_Khth_CFL, st.slope_max = float(KHTH), float(KHTH_MIN), float(KHTH_MAX), float(KHTH_MAX_CFL), float(KHTH_SLOPE_MAX)
         st.kappa_smooth, st.KHTH_Slope_Cff, st.KhTh_fac = float(KD_SMOOTH), float(KHTH_SLOPE_CFF), float(MEKE_KHTH_FAC)
         st.use_GM_work_bug, st.nkml = int(bool(USE_GM_WORK_BUG)), int(NKML)
+        # KHTH_USE_FGNV_STREAMFUNCTION (:2305-2337): the streamfunction of Ferrari et al. (2010); N2_floor = (FGNV_STRAT_FLOOR * OMEGA)**2
+        st.use_FGNV_streamfn, st.FGNV_scale = int(bool(KHTH_USE_FGNV_STREAMFUNCTION)), float(FGNV_FILTER_SCALE)
+        st.N2_floor = (float(FGNV_STRAT_FLOOR) * float(OMEGA)) ** 2 if KHTH_USE_FGNV_STREAMFUNCTION else 0.0
         if KH_ETA_CONST > 0.0 or KH_ETA_VEL_SCALE > 0.0:
             st.unsupported[_abi.THICKNESS_DIFFUSE_UNSUPPORTED.index("Kh_eta")] = 1
         for k, v in unsupported.items():
@@ -51,9 +54,9 @@ def thickness_diffuse_init(G: DeviceGrid, **params) -> thickness_diffuse_CS:
 
 def thickness_diffuse(h, uhtr, vhtr, tv, dt, G: DeviceGrid, MEKE, VarMix, CDp, CS: thickness_diffuse_CS, STOCH=None):
     """thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH) -- :133.  tv = (T, S, EOS) or None (no equation
-    of state; the work then needs VarMix-independent GV%Rlay in MEKE["Rlay"]); MEKE: None or a dict with Kh (MEKE%Kh), GM_src (MEKE%GM_src,
+    of state; the work then needs VarMix-independent GV%Rlay in MEKE["Rlay"], the FGNV streamfunction GV%g_prime in MEKE["g_prime"]); MEKE: None or a dict with Kh (MEKE%Kh), GM_src (MEKE%GM_src,
     output), Rlay; VarMix: None or a dict with any of L2u, L2v, SN_u, SN_v (use_Visbeck), Res_fn_u, Res_fn_v (Resoln_scaled_KhTh),
-    slope_x, slope_y (use_stored_slopes) -- its presence is VarMix%use_variable_mixing; CDp: None or a dict with uhGM, vhGM (outputs)."""
+    slope_x, slope_y (use_stored_slopes), cg1 (with KHTH_USE_FGNV_STREAMFUNCTION) -- its presence is VarMix%use_variable_mixing; CDp: None or a dict with uhGM, vhGM (outputs)."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_thickness_diffuse: Module must be initialized before it is used.")
     if STOCH is not None:
@@ -63,10 +66,10 @@ def thickness_diffuse(h, uhtr, vhtr, tv, dt, G: DeviceGrid, MEKE, VarMix, CDp, C
     st = CS.st
     st.use_variable_mixing = int(VarMix is not None)
     fields = {"MEKE_Kh": MEKE.get("Kh"), "MEKE_GM_src": MEKE.get("GM_src")}
-    for n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y"):
+    for n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "cg1"):
         fields[n] = (VarMix or {}).get(n)
     if set(VarMix or {}) - set(fields):
-        raise Mom6HipError("thickness_diffuse (HIP): of VarMix only L2u/v, SN_u/v, Res_fn_u/v and slope_x/y are provided")
+        raise Mom6HipError("thickness_diffuse (HIP): of VarMix only L2u/v, SN_u/v, Res_fn_u/v, slope_x/y and cg1 are provided")
     spaces = set()
     for n, a in fields.items():
         if a is None:
@@ -79,6 +82,11 @@ def thickness_diffuse(h, uhtr, vhtr, tv, dt, G: DeviceGrid, MEKE, VarMix, CDp, C
         import numpy as np
         CS._keep["Rlay"] = np.ascontiguousarray(rl, dtype=np.float64)
         st.Rlay = CS._keep["Rlay"].ctypes.data
+    gp = MEKE.get("g_prime")      # GV%g_prime(1:nk+1), host: the stratification of the FGNV solve without an equation of state
+    if gp is not None:
+        import numpy as np
+        CS._keep["g_prime"] = np.ascontiguousarray(gp, dtype=np.float64)
+        st.g_prime = CS._keep["g_prime"].ctypes.data
     ptrs = []
     for a in (h, uhtr, vhtr, T, S, CDp.get("uhGM"), CDp.get("vhGM")):
         if a is None:

@@ -1005,7 +1005,8 @@ def ale_remap_velocities(grid, scheme, h_old_u, h_old_v, h_new_u, h_new_v, u, v,
 
 # ---- MOM_thickness_diffuse ----------------------------------------------------------------------------------------
 def thickness_diffuse_cs(grid, Khth=0.0, Khth_Min=0.0, Khth_Max=0.0, max_Khth_CFL=0.8, slope_max=0.01, kappa_smooth=1.0e-6, KHTH_Slope_Cff=0.0,
-                         KhTh_fac=1.0, thickness_diffuse=True, use_GM_work_bug=False, nkml=0, use_variable_mixing=False, **fields):
+                         KhTh_fac=1.0, thickness_diffuse=True, use_GM_work_bug=False, nkml=0, use_variable_mixing=False, use_FGNV_streamfn=False,
+                         FGNV_scale=1.0, FGNV_strat_floor=1.0e-15, omega=7.2921e-5, **fields):
     """mom6hip_thickness_diffuse_cs_t with the defaults of thickness_diffuse_init (MOM_thickness_diffuse.F90:2169-2400); fields: the
     arrays of MEKE / VarMix by the struct's member names (MEKE_Kh, L2u, ..., slope_x, slope_y, MEKE_GM_src, Rlay) or the names of
     _abi.THICKNESS_DIFFUSE_UNSUPPORTED set to True"""
@@ -1013,6 +1014,8 @@ def thickness_diffuse_cs(grid, Khth=0.0, Khth_Min=0.0, Khth_Max=0.0, max_Khth_CF
     cs.Khth, cs.Khth_Min, cs.Khth_Max, cs.max_Khth_CFL, cs.slope_max = Khth, Khth_Min, Khth_Max, max_Khth_CFL, slope_max
     cs.kappa_smooth, cs.KHTH_Slope_Cff, cs.KhTh_fac = kappa_smooth, KHTH_Slope_Cff, KhTh_fac
     cs.thickness_diffuse, cs.use_GM_work_bug, cs.nkml, cs.use_variable_mixing = int(thickness_diffuse), int(use_GM_work_bug), int(nkml), int(use_variable_mixing)
+    cs.use_FGNV_streamfn, cs.FGNV_scale = int(use_FGNV_streamfn), float(FGNV_scale)
+    cs.N2_floor = (FGNV_strat_floor * omega) ** 2 if use_FGNV_streamfn else 0.0      # :2337
     cs.initialized = 1
     cs._keep = {}
     for n, a in fields.items():

@@ -105,19 +105,27 @@ static double face_column(const tdf_t *A, int dir, int i, int j, double KH, cons
   const long fpl = dir ? (long)ORC_NIH(G) * (ORC_NJH(G) + 1) : (long)(ORC_NIH(G) + 1) * ORC_NJH(G);
   const long f2 = dir ? V2(i,j) : U2(i,j);
   double htot = 0.0, Work = 0.0;
-  double drdiA = 0.0, drdiB = 0.0, drdkL = 0.0, drdkR = 0.0, drdkDe = 0.0;
+  double drdiA = 0.0, drdiB = 0.0, drdkL = 0.0, drdkR = 0.0;
+  /* what the first sweep over the interfaces (:872-1101) hands the second (:1126-1209); with KHTH_USE_FGNV_STREAMFUNCTION the elliptic solve
+   * of Ferrari et al. (2010) sits between them (:1105-1124) */
+  const int use_FGNV = CS->use_FGNV_streamfn != 0;
+  double *W = (double *)calloc((size_t)6 * (nz + 2), sizeof(double));
+  double *Sfn_u = W, *s2R = W + (nz + 2), *dkDe = W + 2 * (nz + 2), *di_k = W + 3 * (nz + 2), *dzN2 = W + 4 * (nz + 2), *c2_dz = W + 5 * (nz + 2);
+  const double G_rho0 = G->g_Earth / G->Rho0, N2_floor = CS->N2_floor, dz_neglect2 = dz_neglect * dz_neglect;
 #define HL(k) h[H3(i,j,k)]
 #define HR(k) h[H3(i2,j2,k)]
 #define EL(K) e[E3(i,j,K)]
 #define ER(K) e[E3(i2,j2,K)]
+#define DZL(k) (G->H_to_Z * HL(k))      /* thickness_to_dz, Boussinesq (MOM_interface_heights.F90:780) */
+#define DZR(k) (G->H_to_Z * HR(k))
   for (int K = nz; K >= 2; K--) {
     const int k = K;
-    double Sfn_unlim, slope2_Ratio = 0.0, drdi_k = 0.0;
+    double Sfn_unlim, slope2_Ratio = 0.0, drdi_k = 0.0, drdkDe = 0.0;
     if (find_work && !use_EOS) {      /* :824-828 */
       drdiA = 0.0; drdiB = 0.0;
       drdkL = CS->Rlay[k - 1] - CS->Rlay[k - 2]; drdkR = drdkL;
     }
-    const int calc_derivatives = use_EOS && (k >= nk_linear) && (find_work || !present_slope);
+    const int calc_derivatives = use_EOS && (k >= nk_linear) && (find_work || !present_slope || use_FGNV);
     if (calc_derivatives) {      /* :833-842, :855-865 */
       const double pres_u = 0.5 * (A->pres[E3(i,j,K)] + A->pres[E3(i2,j2,K)]);
       const double T_u = 0.25 * ((T[H3(i,j,k)] + T[H3(i2,j2,k)]) + (T[H3(i,j,k-1)] + T[H3(i2,j2,k-1)]));
@@ -136,7 +144,7 @@ static double face_column(const tdf_t *A, int dir, int i, int j, double KH, cons
     if (k > nk_linear) {
       if (use_EOS) {
         double hg2A = 0.0, hg2B = 0.0, haA = 0.0, haB = 0.0, drdz = 0.0, Slope;
-        if (find_work || !present_slope) {      /* :882-917 (Boussinesq) */
+        if (use_FGNV || find_work || !present_slope) {      /* :982-1024 (Boussinesq) */
           const double hg2L = HL(k-1) * HL(k) + h_neglect2;
           const double hg2R = HR(k-1) * HR(k) + h_neglect2;
           const double haL = 0.5 * (HL(k-1) + HL(k)) + h_neglect;
@@ -148,11 +156,17 @@ static double face_column(const tdf_t *A, int dir, int i, int j, double KH, cons
           hg2B = HL(k) * HR(k) + h_neglect2;
           haA = 0.5 * (HL(k-1) + HR(k-1)) + h_neglect;
           haB = 0.5 * (HL(k) + HR(k)) + h_neglect;
+          const double N2_unlim = drdz * G_rho0;
+          const double dzg2A = DZL(k-1) * DZR(k-1) + dz_neglect2;
+          const double dzg2B = DZL(k) * DZR(k) + dz_neglect2;
+          const double dzaA = 0.5 * (DZL(k-1) + DZR(k-1)) + dz_neglect;
+          const double dzaB = 0.5 * (DZL(k) + DZR(k)) + dz_neglect;
+          dzN2[K] = (0.5 * ( dzg2A / dzaA + dzg2B / dzaB )) * max2(N2_unlim, N2_floor);      /* :1021 */
         }
-        if (present_slope) {      /* :919-921 */
+        if (present_slope) {      /* :1027-1029 */
           Slope = slope_st[f2 + fpl * (K - 1)];
           slope2_Ratio = (Slope * Slope) * I_slope_max2;
-        } else {                  /* :922-936 */
+        } else {                  /* :1030-1044 */
           const double wtA = hg2A * haB, wtB = hg2B * haA;
           const double drdx = ((wtA * drdiA + wtB * drdiB) / (wtA + wtB) - drdz * (EL(K) - ER(K))) * IdL;
           const double mag_grad2 = (1.0 * drdx) * (1.0 * drdx) + drdz * drdz;      /* US%Z_to_L = 1 */
@@ -164,26 +178,63 @@ static double face_column(const tdf_t *A, int dir, int i, int j, double KH, cons
             slope2_Ratio = 1.0e20;
           }
         }
-        /* :939-943 with int_slope = 0 */
+        /* :1047-1051 with int_slope = 0 */
         Slope = (1.0 - 0.0) * Slope + 0.0 * ((ER(K) - EL(K)) * IdL);
         slope2_Ratio = (1.0 - 0.0) * slope2_Ratio;
-        Sfn_unlim = -(KH * dLf) * Slope;      /* :956 */
-        if (Sfn_unlim > 0.0) {                 /* :959-975 */
+        Sfn_unlim = -(KH * dLf) * Slope;      /* :1064 */
+        if (Sfn_unlim > 0.0) {                 /* :1067-1084 */
           if (EL(K) < ER(nz + 1)) Sfn_unlim = 0.0;
           else if (ER(nz + 1) > EL(K + 1)) Sfn_unlim = Sfn_unlim * ((EL(K) - ER(nz + 1)) / ((EL(K) - EL(K + 1)) + dz_neglect));
         } else {
           if (ER(K) < EL(nz + 1)) Sfn_unlim = 0.0;
           else if (EL(nz + 1) > ER(K + 1)) Sfn_unlim = Sfn_unlim * ((ER(K) - EL(nz + 1)) / ((ER(K) - ER(K + 1)) + dz_neglect));
         }
-      } else {      /* :979-988 */
+      } else {      /* :1086-1095 */
         double Slope;
         if (present_slope) Slope = slope_st[f2 + fpl * (K - 1)];
         else Slope = ((EL(K) - ER(K)) * IdL) * OBCmask;
         Sfn_unlim = ((KH * dLf) * Slope);
+        if (use_FGNV) dzN2[K] = CS->g_prime[K - 1];      /* GV%g_prime(K) */
       }
     } else {
+      dzN2[K] = N2_floor * dz_neglect;      /* :1098 */
       Sfn_unlim = 0.;
     }
+    Sfn_u[K] = Sfn_unlim; s2R[K] = slope2_Ratio; dkDe[K] = drdkDe; di_k[k] = drdi_k;
+  }
+  if (use_FGNV) {      /* :1105-1124: the streamfunction of Ferrari et al. (2010): streamfn_solver :1673-1707 */
+    if (OBCmask > 0.) {
+      const double *cg1 = CS->cg1;
+      for (int k = 1; k <= nz; k++) {
+        const double dz_harm = max2( dz_neglect, 2. * DZL(k) * DZR(k) / ( ( DZL(k) + DZR(k) ) + dz_neglect ) );
+        const double cg = 0.5*( cg1[H2(i,j)] + cg1[H2(i2,j2)] );
+        c2_dz[k] = CS->FGNV_scale * ( cg * cg ) / dz_harm;
+      }
+      for (int K = 2; K <= nz; K++) Sfn_u[K] = (1. + CS->FGNV_scale) * Sfn_u[K];
+      double *c1 = (double *)calloc((size_t)nz + 2, sizeof(double));
+      Sfn_u[1] = 0.;
+      double b_denom = dzN2[2] + c2_dz[1];
+      double beta = 1.0 / ( b_denom + c2_dz[2] );
+      double d1 = beta * b_denom;
+      Sfn_u[2] = ( beta * dzN2[2] )*Sfn_u[2];
+      for (int K = 3; K <= nz; K++) {
+        c1[K-1] = beta * c2_dz[K-1];
+        b_denom = dzN2[K] + d1*c2_dz[K-1];
+        beta = 1.0 / (b_denom + c2_dz[K]);
+        d1 = beta * b_denom;
+        Sfn_u[K] = beta * (dzN2[K]*Sfn_u[K] + c2_dz[K-1]*Sfn_u[K-1]);
+      }
+      c1[nz] = beta * c2_dz[nz];
+      Sfn_u[nz+1] = 0.;
+      for (int K = nz; K >= 2; K--) Sfn_u[K] = Sfn_u[K] + c1[K]*Sfn_u[K+1];
+      free(c1);
+    } else {
+      for (int K = 2; K <= nz; K++) Sfn_u[K] = 0.;
+    }
+  }
+  for (int K = nz; K >= 2; K--) {
+    const int k = K;
+    const double Sfn_unlim = Sfn_u[K], slope2_Ratio = s2R[K], drdkDe = dkDe[K], drdi_k = di_k[k];
     /* ---- the transport of layer k :1148-1209 */
     const double Z_to_H = G->Z_to_H;
     double hDk;
@@ -208,6 +259,7 @@ static double face_column(const tdf_t *A, int dir, int i, int j, double KH, cons
     if (find_work)      /* :1196-1209 */
       Work = Work + G_scale * (htot * drdkDe - (hDk * drdi_k) * 0.25 * ((EL(K) + EL(K + 1)) + (ER(K) + ER(K + 1))));
   }
+  free(W);
   /* ---- the top layer :1517-1590 */
   const double hD1 = -htot;
   hD[f2] = hD1;
@@ -226,6 +278,8 @@ static double face_column(const tdf_t *A, int dir, int i, int j, double KH, cons
 #undef HR
 #undef EL
 #undef ER
+#undef DZL
+#undef DZR
   return Work;
 }
 
@@ -238,6 +292,8 @@ int orc_thickness_diffuse(const mom6hip_grid_t *G, const mom6hip_thickness_diffu
                           const double *T_in, const double *S_in, const mom6hip_eos_t *EOS, double dt, double *uhGM, double *vhGM) {
   if (!CS->initialized) return 3;      /* "MOM_thickness_diffuse: Module must be initialized before it is used." */
   if (unsupported(CS)) return 1;
+  if (CS->use_FGNV_streamfn && !CS->cg1) return 4;      /* "cg1 must be associated when using FGNV streamfunction." :860 */
+  if (CS->use_FGNV_streamfn && !EOS && !CS->g_prime) return 4;
   /* use_VarMix .and. use_Visbeck :205-207, :242 */
   const int use_VarMix = CS->use_variable_mixing && (CS->KHTH_Slope_Cff > 0.) && CS->L2u && CS->L2v && CS->SN_u && CS->SN_v;
   if (!CS->thickness_diffuse || !(CS->Khth > 0.0 || CS->use_variable_mixing)) return 0;      /* :192-194 */

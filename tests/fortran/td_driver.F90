@@ -83,6 +83,9 @@ allocate(MEKE%Kh(isd:ied,jsd:jed), VarMix%L2u(isd-1:ied,jsd:jed), VarMix%L2v(isd
          VarMix%SN_v(isd:ied,jsd-1:jed), VarMix%Res_fn_u(isd-1:ied,jsd:jed), VarMix%Res_fn_v(isd:ied,jsd-1:jed), &
          VarMix%slope_x(isd-1:ied,jsd:jed,nk+1), VarMix%slope_y(isd:ied,jsd-1:jed,nk+1))
 read(u_in) MEKE%Kh, VarMix%L2u, VarMix%L2v, VarMix%SN_u, VarMix%SN_v, VarMix%Res_fn_u, VarMix%Res_fn_v, VarMix%slope_x, VarMix%slope_y
+if (hdr(8) /= 0) then      ! VarMix%cg1 (KHTH_USE_FGNV_STREAMFUNCTION)
+  allocate(VarMix%cg1(isd:ied,jsd:jed)) ; read(u_in) VarMix%cg1
+endif
 close(u_in)
 if (opt(2) == 0) deallocate(MEKE%Kh)
 VarMix%use_variable_mixing = (opt(8) /= 0) ; VarMix%use_Visbeck = (opt(3) /= 0) ; VarMix%Resoln_scaled_KhTh = (opt(4) /= 0)
@@ -109,10 +112,10 @@ allocate(G%OBCmaskCu(isd-1:ied,jsd:jed), G%OBCmaskCv(isd:ied,jsd-1:jed))      ! 
 G%OBCmaskCu(:,:) = G%mask2dCu(:,:) ; G%OBCmaskCv(:,:) = G%mask2dCv(:,:)
 GV%RZ_to_H = GV%Z_to_H / GV%Rho0 ; GV%H_to_RZ = GV%H_to_Z * GV%Rho0
 if (associated(tv%eqn_of_state)) call EOS_init(pf, tv%eqn_of_state, US)
+#endif
 allocate(GV%g_prime(nk+1))      ! (read without an equation of state for the stratification of the FGNV solve, :1095; from Rlay as MOM_coord_initialization sets it)
 GV%g_prime(:) = 0.0 ; GV%g_prime(1) = GV%g_Earth
 do m=2,nk ; GV%g_prime(m) = (GV%g_Earth/GV%Rho0) * (GV%Rlay(m) - GV%Rlay(m-1)) ; enddo
-#endif
 call thickness_diffuse_init(Time, G, GV, US, pf, diag, CDp, CS)
 call thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH)
 

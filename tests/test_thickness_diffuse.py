@@ -31,6 +31,8 @@ def fields(g, seed=3):
     sx = 2.0e-3 * (rng.random((g.nk + 1,) + su) - 0.5) * g.mask2dCu[None]
     sy = 2.0e-3 * (rng.random((g.nk + 1,) + sv) - 0.5) * g.mask2dCv[None]
     out.update(slope_x=np.ascontiguousarray(sx), slope_y=np.ascontiguousarray(sy))
+    cg1 = np.ascontiguousarray(0.5 + 2.5 * rng.random(g.shape2(H))); orc.halo_update(g, cg1, H)      # VarMix%cg1 [m s-1]
+    out.update(cg1=cg1)
     return out
 
 
@@ -46,6 +48,11 @@ VARIANTS = {
     "no_eos": dict(Khth=600.0, eos=None),                                             # layer densities
     "no_eos_work": dict(Khth=600.0, eos=None, work=True),
     "khth_min": dict(Khth=50.0, Khth_Min=200.0, max_Khth_CFL=0.05, kappa_smooth=0.0),
+    # KHTH_USE_FGNV_STREAMFUNCTION: the streamfunction of Ferrari et al. (2010), with VarMix%cg1
+    "fgnv": dict(Khth=600.0, use_variable_mixing=True, use_FGNV_streamfn=True, FGNV_scale=0.1, use=("cg1",)),
+    "fgnv_stored_slopes_work": dict(Khth=300.0, use_variable_mixing=True, use_FGNV_streamfn=True, use=("cg1", "slope_x", "slope_y"), work=True),
+    "fgnv_bulk_ml": dict(Khth=600.0, nkml=2, use_variable_mixing=True, use_FGNV_streamfn=True, FGNV_scale=0.5, use=("cg1",), work=True),
+    "fgnv_no_eos": dict(Khth=600.0, eos=None, use_variable_mixing=True, use_FGNV_streamfn=True, use=("cg1",)),
 }
 
 
@@ -58,6 +65,9 @@ def run_oracle(g, d, name, dt=DT):
         args["MEKE_GM_src"] = np.full(g.shape2(H), 7.0)
     if eos is None:
         args["Rlay"] = 1025.0 + 0.5 * np.arange(g.nk)
+        if kw.get("use_FGNV_streamfn"):      # GV%g_prime as MOM_coord_initialization sets it from Rlay
+            gp = np.zeros(g.nk + 1); gp[0] = g.g_Earth; gp[1:g.nk] = (g.g_Earth / g.Rho0) * np.diff(args["Rlay"])
+            args["g_prime"] = gp
     cs = orc.thickness_diffuse_cs(g, **kw, **args)
     h = d["h"].copy(); uhtr = np.zeros_like(d["u"]); vhtr = np.zeros_like(d["v"]); uhGM = np.zeros_like(d["u"]); vhGM = np.zeros_like(d["v"])
     orc.thickness_diffuse(g, cs, h, uhtr, vhtr, d["T"], d["S"], None if eos is None else orc.eos(eos), dt, uhGM, vhGM)
@@ -131,7 +141,7 @@ def test_refuses_what_it_does_not_provide():
 
 
 REF = dict(Khth="KHTH", Khth_Min="KHTH_MIN", Khth_Max="KHTH_MAX", max_Khth_CFL="KHTH_MAX_CFL", kappa_smooth="KD_SMOOTH", KHTH_Slope_Cff="KHTH_SLOPE_CFF",
-           nkml="NKML", use_GM_work_bug="USE_GM_WORK_BUG")
+           nkml="NKML", use_GM_work_bug="USE_GM_WORK_BUG", use_FGNV_streamfn="KHTH_USE_FGNV_STREAMFUNCTION", FGNV_scale="FGNV_FILTER_SCALE")
 
 
 @pytest.mark.gpu
@@ -163,7 +173,9 @@ def test_gpu_parity(name):
                 meke["GM_src"] = X(np.full(g.shape2(H), 7.0))
             if "Rlay" in args:
                 meke["Rlay"] = args["Rlay"]
-            vm = {n: X(a) for n, a in args.items() if n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y")}
+            if "g_prime" in args:
+                meke["g_prime"] = args["g_prime"]
+            vm = {n: X(a) for n, a in args.items() if n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "cg1")}
             varmix = vm if kw.get("use_variable_mixing") else None
             tv = None if eos is None else (X(d["T"]), X(d["S"]), EOS_init(eos))
             thickness_diffuse(h, uhtr, vhtr, tv, DT, dg, meke, varmix, cdp, CS)
@@ -186,14 +198,14 @@ def _write_td_case(tmp, g, d, name, resident=False):
     opt = [int(eos is not None), int("MEKE_Kh" in args), int("L2u" in args), int("Res_fn_u" in args), int("slope_x" in args), int("MEKE_GM_src" in args),
            int(kw.get("nkml", 0)), int(bool(kw.get("use_variable_mixing")))]
     with open(tmp / "in.bin", "wb") as fh:
-        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, 0], dtype="<i4").tofile(fh)
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, int("cg1" in args)], dtype="<i4").tofile(fh)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, DT], dtype="<f8").tofile(fh)
         np.array(opt, dtype="<i4").tofile(fh)
         for n in _abi.ALL_METRICS:
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
         for a in (d["h"], d["T"], d["S"], args.get("Rlay", 1025.0 + 0.5 * np.arange(g.nk))):
             np.ascontiguousarray(a, dtype="<f8").tofile(fh)
-        for n in ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y"):
+        for n in ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y") + (("cg1",) if "cg1" in args else ()):
             np.ascontiguousarray(f[n], dtype="<f8").tofile(fh)
     with open(tmp / "params.txt", "w") as fh:
         fh.write(f"THICKNESSDIFFUSE = True\nGPU_RESIDENT_DYNAMICS = {resident}\n")
@@ -201,6 +213,8 @@ def _write_td_case(tmp, g, d, name, resident=False):
             fh.write(f"EQN_OF_STATE = {eos}\n")
         if kw.get("use_GM_work_bug"):
             fh.write("USE_GM_WORK_BUG = True\n")
+        if kw.get("use_FGNV_streamfn"):
+            fh.write(f"KHTH_USE_FGNV_STREAMFUNCTION = True\nFGNV_FILTER_SCALE = {float(kw.get('FGNV_scale', 1.0))!r}\n")
         for k, v in kw.items():
             if k in FKEYS:
                 fh.write(f"{FKEYS[k]} = {float(v)!r}\n")
