@@ -1263,8 +1263,8 @@ typedef struct mom6hip_thickness_diffuse_cs {
                                   Visbeck term is added when KHTH_SLOPE_CFF > 0 and L2u ... SN_v are given (:205-207, :242-249) */
   int32_t use_FGNV_streamfn;   /* KHTH_USE_FGNV_STREAMFUNCTION (0): the streamfunction of Ferrari et al. (2010) (:1105-1124, streamfn_solver :1673);
                                   needs cg1 (and g_prime without an equation of state) */
-  int32_t unsupported[10];     /* (unused), detangle, Kh_eta, Stanley, MEKE_GEOMETRIC, GM_src_alt, read_khth, ebt_struct / QG Leith / depth
-                                  scaling, Use_KH_in_MEKE, non-Boussinesq / p_surf / SKEB: any nonzero is refused */
+  int32_t unsupported[10];     /* (unused), detangle, Kh_eta, Stanley, MEKE_GEOMETRIC, GM_src_alt, read_khth, ebt_struct / QG Leith,
+                                  Use_KH_in_MEKE, non-Boussinesq / p_surf / SKEB: any nonzero is refused */
   /* fields of MEKE and VarMix, in the memory space of the call; NULL = not allocated / not in use */
   const double *MEKE_Kh;       /* MEKE%Kh, h points 2-D (valid halo of 1) */
   const double *L2u, *L2v, *SN_u, *SN_v;      /* VarMix%L2u ... (use_Visbeck), u / v points 2-D */
@@ -1274,7 +1274,7 @@ typedef struct mom6hip_thickness_diffuse_cs {
   const double *Rlay;          /* GV%Rlay(1:nk) (HOST array): the work without an equation of state (:827, :1218) */
   const double *cg1;           /* VarMix%cg1, h points 2-D (valid halo of 1): the first baroclinic gravity wave speed, with use_FGNV_streamfn */
   const double *g_prime;       /* GV%g_prime(1:nk+1) (HOST array): dzN2 without an equation of state (:1095), with use_FGNV_streamfn */
-  void *reserved1[1];
+  const double *Depth_fn_u, *Depth_fn_v;      /* VarMix%Depth_fn_u / _v (DEPTH_SCALED_KHTH, :284-289), u / v points 2-D */
 } mom6hip_thickness_diffuse_cs_t;
 
 /* thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH)                               :133

@@ -239,7 +239,7 @@ class HorViscCS(C.Structure):
 # ---- MOM_thickness_diffuse --------------------------------------------------------------------------------
 THICKNESS_DIFFUSE_UNSUPPORTED = ("unused_0", "detangle_interfaces", "Kh_eta", "use_stanley_gm", "MEKE_GEOMETRIC", "GM_src_alt", "read_khth",
                                  "ebt_struct", "Use_KH_in_MEKE", "non_Boussinesq")
-THICKNESS_DIFFUSE_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "MEKE_GM_src", "Rlay", "cg1", "g_prime")
+THICKNESS_DIFFUSE_FIELDS = ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "MEKE_GM_src", "Rlay", "cg1", "g_prime", "Depth_fn_u", "Depth_fn_v")
 
 
 class ThicknessDiffuseCS(C.Structure):
@@ -249,8 +249,7 @@ class ThicknessDiffuseCS(C.Structure):
                 + [("reserved0", C.c_double * 2)]
                 + [(n, C.c_int32) for n in ("thickness_diffuse", "use_GM_work_bug", "nkml", "initialized", "use_variable_mixing", "use_FGNV_streamfn")]
                 + [("unsupported", C.c_int32 * 10)]
-                + [(n, C.c_void_p) for n in THICKNESS_DIFFUSE_FIELDS]
-                + [("reserved1", C.c_void_p * 1)])
+                + [(n, C.c_void_p) for n in THICKNESS_DIFFUSE_FIELDS])
 
 
 MIXEDLAYER_RESTRAT_UNSUPPORTED = ("use_Bodner", "use_Stanley_ML", "non_Boussinesq")

@@ -33,7 +33,7 @@ struct TDArgs {
   double Khth, Khth_Min, Khth_Max, max_Khth_CFL, slope_max, kappa_dt, KHTH_Slope_Cff, KhTh_fac, dt;
   const double *h, *T_in, *S_in;
   double *e, *pres, *rsum, *T, *S, *c1;      // column scratch (e, pres, rsum: nk+1 interfaces)
-  const double *MEKE_Kh, *L2, *SN, *Res_fn, *slope, *Rlay;      // of the direction of the launch
+  const double *MEKE_Kh, *L2, *SN, *Res_fn, *Depth_fn, *slope, *Rlay;      // of the direction of the launch
   double *hD, *Work;
   // KHTH_USE_FGNV_STREAMFUNCTION (td_face_fgnv_kernel): what the first sweep hands the second, nk+1 planes of faces each
   int use_FGNV;
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64, TD_FACE_OCC) void td_face_kernel(TDArgs A) {
   if (A.use_Visbeck) Kh = Kh + A.KHTH_Slope_Cff * A.L2[f2] * A.SN[f2];
   if (A.MEKE_Kh) Kh = Kh + A.KhTh_fac * sqrt(A.MEKE_Kh[cL] * A.MEKE_Kh[cR]);
   if (A.Res_fn) Kh = Kh * A.Res_fn[f2];
+  if (A.Depth_fn) Kh = Kh * A.Depth_fn[f2];      // DEPTH_SCALED_KHTH :284-289
   if (A.Khth_Max > 0) Kh = max2(A.Khth_Min, min2(Kh, A.Khth_Max));
   else Kh = max2(A.Khth_Min, Kh);
   const double KH = min2(KH_CFL, Kh);
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64, TD_FACE_OCC) void td_face_fgnv_kernel(TDArgs A)
   if (A.use_Visbeck) Kh = Kh + A.KHTH_Slope_Cff * A.L2[f2] * A.SN[f2];
   if (A.MEKE_Kh) Kh = Kh + A.KhTh_fac * sqrt(A.MEKE_Kh[cL] * A.MEKE_Kh[cR]);
   if (A.Res_fn) Kh = Kh * A.Res_fn[f2];
+  if (A.Depth_fn) Kh = Kh * A.Depth_fn[f2];      // DEPTH_SCALED_KHTH :284-289
   if (A.Khth_Max > 0) Kh = max2(A.Khth_Min, min2(Kh, A.Khth_Max));
   else Kh = max2(A.Khth_Min, Kh);
   const double KH = min2(KH_CFL, Kh);
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void td_update_kernel(UpdArgs A) {
 
 int check_cs(const mom6hip_thickness_diffuse_cs_t *cs) {
   static const char *names[10] = {"(unused)", "DETANGLE_INTERFACES", "KH_ETA_CONST / KH_ETA_VEL_SCALE", "USE_STANLEY_GM",
-                                  "MEKE_GEOMETRIC", "MEKE_GM_SRC_ALT", "READ_KHTH", "KHTH_USE_EBT_STRUCT / QG Leith GM / DEPTH_SCALED_KHTH",
+                                  "MEKE_GEOMETRIC", "MEKE_GM_SRC_ALT", "READ_KHTH", "KHTH_USE_EBT_STRUCT / QG Leith GM",
                                   "USE_KH_IN_MEKE", "non-Boussinesq mode / tv%p_surf / SKEB"};
   M6_REQUIRE(cs->initialized, "MOM_thickness_diffuse: Module must be initialized before it is used.");
   for (int n = 0; n < 10; n++) M6_REQUIRE(!cs->unsupported[n], "thickness_diffuse: %s is not provided by libmom6hip", names[n]);
@@ -575,6 +577,7 @@ extern "C" int mom6hip_thickness_diffuse(mom6hip_ctx_t *ctx, const mom6hip_thick
   M6_REQUIRE(!eos || (T && S), "thickness_diffuse: an equation of state needs tv%%T and tv%%S");
   M6_REQUIRE(!cs->MEKE_GM_src || eos || cs->Rlay, "thickness_diffuse: the work without an equation of state needs GV%%Rlay");
   M6_REQUIRE((cs->slope_x != nullptr) == (cs->slope_y != nullptr), "thickness_diffuse: slope_x and slope_y come together");
+  M6_REQUIRE((cs->Depth_fn_u != nullptr) == (cs->Depth_fn_v != nullptr), "thickness_diffuse: Depth_fn_u and Depth_fn_v come together");
   const m6::GridDev g = ctx->g;
   M6_REQUIRE(g.isc - g.isd >= 1 && g.jsc - g.jsd >= 1, "thickness_diffuse: the halo must be at least 1 point wide");
   M6_REQUIRE(g.areaT && g.IareaT && g.bathyT && g.IdxCu && g.IdyCu && g.IdxCv && g.IdyCv && g.dy_Cu && g.dx_Cv && g.mask2dCu && g.mask2dCv,
@@ -598,6 +601,7 @@ extern "C" int mom6hip_thickness_diffuse(mom6hip_ctx_t *ctx, const mom6hip_thick
   A.MEKE_Kh = st.in(cs->MEKE_Kh, bH2);
   const double *L2u = st.in(cs->L2u, bU2), *L2v = st.in(cs->L2v, bV2), *SNu = st.in(cs->SN_u, bU2), *SNv = st.in(cs->SN_v, bV2);
   const double *Ru = st.in(cs->Res_fn_u, bU2), *Rv = st.in(cs->Res_fn_v, bV2);
+  const double *Du = st.in(cs->Depth_fn_u, bU2), *Dv = st.in(cs->Depth_fn_v, bV2);
   const double *sx = st.in(cs->slope_x, bU2 * (nz + 1)), *sy = st.in(cs->slope_y, bV2 * (nz + 1));
   double *d_src = cs->MEKE_GM_src ? st.inout(cs->MEKE_GM_src, bH2) : nullptr;
   A.e = (double *)st.scratch(bH2 * (nz + 1)); A.pres = (double *)st.scratch(bH2 * (nz + 1)); A.rsum = (double *)st.scratch(bH2 * (nz + 1));
@@ -622,10 +626,10 @@ extern "C" int mom6hip_thickness_diffuse(mom6hip_ctx_t *ctx, const mom6hip_thick
   }
   const int ni = g.iec - g.isc + 1, nj = g.jec - g.jsc + 1;
   hipLaunchKernelGGL(td_column_kernel, dim3((ni + 2 + 63) / 64, nj + 2), dim3(64), 0, s, A);
-  A.L2 = L2u; A.SN = SNu; A.Res_fn = Ru; A.slope = sx; A.hD = uhD; A.Work = Work_u;
+  A.L2 = L2u; A.SN = SNu; A.Res_fn = Ru; A.Depth_fn = Du; A.slope = sx; A.hD = uhD; A.Work = Work_u;
   if (A.use_FGNV) hipLaunchKernelGGL(td_face_fgnv_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
   else hipLaunchKernelGGL(td_face_kernel<0>, dim3((ni + 1 + 63) / 64, nj), dim3(64), 0, s, A);
-  A.L2 = L2v; A.SN = SNv; A.Res_fn = Rv; A.slope = sy; A.hD = vhD; A.Work = Work_v;
+  A.L2 = L2v; A.SN = SNv; A.Res_fn = Rv; A.Depth_fn = Dv; A.slope = sy; A.hD = vhD; A.Work = Work_v;
   if (A.use_FGNV) hipLaunchKernelGGL(td_face_fgnv_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
   else hipLaunchKernelGGL(td_face_kernel<1>, dim3((ni + 63) / 64, nj + 1), dim3(64), 0, s, A);
   UpdArgs Up;

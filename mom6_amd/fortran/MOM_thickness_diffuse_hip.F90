@@ -89,8 +89,11 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
   ccs%thickness_diffuse = 1 ; ccs%use_GM_work_bug = merge(1, 0, CS%use_GM_work_bug) ; ccs%nkml = GV%nkml ; ccs%initialized = 1
   if (VarMix%use_variable_mixing) then
     ccs%use_variable_mixing = 1
-    if (VarMix%Depth_scaled_KhTh .or. VarMix%khth_use_ebt_struct .or. VarMix%use_QG_Leith_GM) call MOM_error(FATAL, &
-        "thickness_diffuse (HIP): DEPTH_SCALED_KHTH, KHTH_USE_EBT_STRUCT and USE_QG_LEITH_GM are not provided by the GPU path.")
+    if (VarMix%khth_use_ebt_struct .or. VarMix%use_QG_Leith_GM) call MOM_error(FATAL, &
+        "thickness_diffuse (HIP): KHTH_USE_EBT_STRUCT and USE_QG_LEITH_GM are not provided by the GPU path.")
+    if (VarMix%Depth_scaled_KhTh) then      ! DEPTH_SCALED_KHTH :284-289
+      ccs%Depth_fn_u = c_loc(VarMix%Depth_fn_u) ; ccs%Depth_fn_v = c_loc(VarMix%Depth_fn_v)
+    endif
     if (VarMix%use_Visbeck .and. (CS%Khth_Slope_Cff > 0.)) then
       ccs%L2u = c_loc(VarMix%L2u) ; ccs%L2v = c_loc(VarMix%L2v) ; ccs%SN_u = c_loc(VarMix%SN_u) ; ccs%SN_v = c_loc(VarMix%SN_v)
     endif
@@ -127,6 +130,7 @@ subroutine thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp
     call to_dev(p_uhGM, size(uhtr), .true.) ; call to_dev(p_vhGM, size(vhtr), .true.)
     call to_dev(ccs%MEKE_Kh, n2, .false.) ; call to_dev(ccs%MEKE_GM_src, n2, .true.) ; call to_dev(ccs%cg1, n2, .false.)
     call to_dev(ccs%Res_fn_u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%Res_fn_v, size(vhtr(:,:,1)), .false.)
+    call to_dev(ccs%Depth_fn_u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%Depth_fn_v, size(vhtr(:,:,1)), .false.)
     call to_dev(ccs%L2u, size(uhtr(:,:,1)), .false.) ; call to_dev(ccs%SN_u, size(uhtr(:,:,1)), .false.)
     call to_dev(ccs%L2v, size(vhtr(:,:,1)), .false.) ; call to_dev(ccs%SN_v, size(vhtr(:,:,1)), .false.)
     call to_dev(ccs%slope_x, size(uhtr(:,:,1))*(GV%ke+1), .false.) ; call to_dev(ccs%slope_y, size(vhtr(:,:,1))*(GV%ke+1), .false.)

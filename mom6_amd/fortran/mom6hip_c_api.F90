@@ -270,7 +270,7 @@ type, bind(c) :: mom6hip_thickness_diffuse_cs_t
   type(c_ptr) :: MEKE_Kh = c_null_ptr, L2u = c_null_ptr, L2v = c_null_ptr, SN_u = c_null_ptr, SN_v = c_null_ptr
   type(c_ptr) :: Res_fn_u = c_null_ptr, Res_fn_v = c_null_ptr, slope_x = c_null_ptr, slope_y = c_null_ptr
   type(c_ptr) :: MEKE_GM_src = c_null_ptr, Rlay = c_null_ptr, cg1 = c_null_ptr, g_prime = c_null_ptr
-  type(c_ptr) :: reserved1(1) = c_null_ptr
+  type(c_ptr) :: Depth_fn_u = c_null_ptr, Depth_fn_v = c_null_ptr
 end type mom6hip_thickness_diffuse_cs_t
 
 !> mom6hip_mixedlayer_restrat_cs_t (mixedlayer_restrat_CS, src/parameterizations/lateral/MOM_mixed_layer_restrat.F90:40)

@@ -55,7 +55,7 @@ def thickness_diffuse_init(G: DeviceGrid, **params) -> thickness_diffuse_CS:
 def thickness_diffuse(h, uhtr, vhtr, tv, dt, G: DeviceGrid, MEKE, VarMix, CDp, CS: thickness_diffuse_CS, STOCH=None):
     """thickness_diffuse(h, uhtr, vhtr, tv, dt, G, GV, US, MEKE, VarMix, CDp, CS, STOCH) -- :133.  tv = (T, S, EOS) or None (no equation
     of state; the work then needs VarMix-independent GV%Rlay in MEKE["Rlay"], the FGNV streamfunction GV%g_prime in MEKE["g_prime"]); MEKE: None or a dict with Kh (MEKE%Kh), GM_src (MEKE%GM_src,
-    output), Rlay; VarMix: None or a dict with any of L2u, L2v, SN_u, SN_v (use_Visbeck), Res_fn_u, Res_fn_v (Resoln_scaled_KhTh),
+    output), Rlay; VarMix: None or a dict with any of L2u, L2v, SN_u, SN_v (use_Visbeck), Res_fn_u, Res_fn_v (Resoln_scaled_KhTh), Depth_fn_u, Depth_fn_v (Depth_scaled_KhTh),
     slope_x, slope_y (use_stored_slopes), cg1 (with KHTH_USE_FGNV_STREAMFUNCTION) -- its presence is VarMix%use_variable_mixing; CDp: None or a dict with uhGM, vhGM (outputs)."""
     if CS is None or not CS.st.initialized:
         raise Mom6HipError("MOM_thickness_diffuse: Module must be initialized before it is used.")
@@ -66,10 +66,10 @@ def thickness_diffuse(h, uhtr, vhtr, tv, dt, G: DeviceGrid, MEKE, VarMix, CDp, C
     st = CS.st
     st.use_variable_mixing = int(VarMix is not None)
     fields = {"MEKE_Kh": MEKE.get("Kh"), "MEKE_GM_src": MEKE.get("GM_src")}
-    for n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "cg1"):
+    for n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "cg1", "Depth_fn_u", "Depth_fn_v"):
         fields[n] = (VarMix or {}).get(n)
     if set(VarMix or {}) - set(fields):
-        raise Mom6HipError("thickness_diffuse (HIP): of VarMix only L2u/v, SN_u/v, Res_fn_u/v, slope_x/y and cg1 are provided")
+        raise Mom6HipError("thickness_diffuse (HIP): of VarMix only L2u/v, SN_u/v, Res_fn_u/v, Depth_fn_u/v, slope_x/y and cg1 are provided")
     spaces = set()
     for n, a in fields.items():
         if a is None:

@@ -346,6 +346,7 @@ int orc_thickness_diffuse(const mom6hip_grid_t *G, const mom6hip_thickness_diffu
     if (use_VarMix) Kh = Kh + CS->KHTH_Slope_Cff * CS->L2u[U2(I,j)] * CS->SN_u[U2(I,j)];
     if (CS->MEKE_Kh) Kh = Kh + CS->KhTh_fac * sqrt(CS->MEKE_Kh[H2(i,j)] * CS->MEKE_Kh[H2(i+1,j)]);
     if (CS->Res_fn_u) Kh = Kh * CS->Res_fn_u[U2(I,j)];
+    if (CS->Depth_fn_u) Kh = Kh * CS->Depth_fn_u[U2(I,j)];      /* DEPTH_SCALED_KHTH :284-289 */
     if (CS->Khth_Max > 0) Kh = max2(CS->Khth_Min, min2(Kh, CS->Khth_Max));
     else Kh = max2(CS->Khth_Min, Kh);
     const double KH = min2(KH_CFL, Kh);
@@ -358,6 +359,7 @@ int orc_thickness_diffuse(const mom6hip_grid_t *G, const mom6hip_thickness_diffu
     if (use_VarMix) Kh = Kh + CS->KHTH_Slope_Cff * CS->L2v[V2(i,J)] * CS->SN_v[V2(i,J)];
     if (CS->MEKE_Kh) Kh = Kh + CS->KhTh_fac * sqrt(CS->MEKE_Kh[H2(i,j)] * CS->MEKE_Kh[H2(i,j+1)]);
     if (CS->Res_fn_v) Kh = Kh * CS->Res_fn_v[V2(i,J)];
+    if (CS->Depth_fn_v) Kh = Kh * CS->Depth_fn_v[V2(i,J)];
     if (CS->Khth_Max > 0) Kh = max2(CS->Khth_Min, min2(Kh, CS->Khth_Max));
     else Kh = max2(CS->Khth_Min, Kh);
     const double KH = min2(KH_CFL, Kh);

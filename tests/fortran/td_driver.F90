@@ -83,8 +83,12 @@ allocate(MEKE%Kh(isd:ied,jsd:jed), VarMix%L2u(isd-1:ied,jsd:jed), VarMix%L2v(isd
          VarMix%SN_v(isd:ied,jsd-1:jed), VarMix%Res_fn_u(isd-1:ied,jsd:jed), VarMix%Res_fn_v(isd:ied,jsd-1:jed), &
          VarMix%slope_x(isd-1:ied,jsd:jed,nk+1), VarMix%slope_y(isd:ied,jsd-1:jed,nk+1))
 read(u_in) MEKE%Kh, VarMix%L2u, VarMix%L2v, VarMix%SN_u, VarMix%SN_v, VarMix%Res_fn_u, VarMix%Res_fn_v, VarMix%slope_x, VarMix%slope_y
-if (hdr(8) /= 0) then      ! VarMix%cg1 (KHTH_USE_FGNV_STREAMFUNCTION)
+if (iand(hdr(8), 1) /= 0) then      ! VarMix%cg1 (KHTH_USE_FGNV_STREAMFUNCTION)
   allocate(VarMix%cg1(isd:ied,jsd:jed)) ; read(u_in) VarMix%cg1
+endif
+if (iand(hdr(8), 2) /= 0) then      ! VarMix%Depth_fn_u / _v (DEPTH_SCALED_KHTH)
+  allocate(VarMix%Depth_fn_u(isd-1:ied,jsd:jed), VarMix%Depth_fn_v(isd:ied,jsd-1:jed)) ; read(u_in) VarMix%Depth_fn_u, VarMix%Depth_fn_v
+  VarMix%Depth_scaled_KhTh = .true.
 endif
 close(u_in)
 if (opt(2) == 0) deallocate(MEKE%Kh)

@@ -33,6 +33,7 @@ def fields(g, seed=3):
     out.update(slope_x=np.ascontiguousarray(sx), slope_y=np.ascontiguousarray(sy))
     cg1 = np.ascontiguousarray(0.5 + 2.5 * rng.random(g.shape2(H))); orc.halo_update(g, cg1, H)      # VarMix%cg1 [m s-1]
     out.update(cg1=cg1)
+    out.update(Depth_fn_u=rng.random(su), Depth_fn_v=rng.random(sv))      # VarMix%Depth_fn_u / _v (DEPTH_SCALED_KHTH)
     return out
 
 
@@ -52,6 +53,10 @@ VARIANTS = {
     "fgnv": dict(Khth=600.0, use_variable_mixing=True, use_FGNV_streamfn=True, FGNV_scale=0.1, use=("cg1",)),
     "fgnv_stored_slopes_work": dict(Khth=300.0, use_variable_mixing=True, use_FGNV_streamfn=True, use=("cg1", "slope_x", "slope_y"), work=True),
     "fgnv_bulk_ml": dict(Khth=600.0, nkml=2, use_variable_mixing=True, use_FGNV_streamfn=True, FGNV_scale=0.5, use=("cg1",), work=True),
+    # DEPTH_SCALED_KHTH (:284-289), alone and on top of the resolution function
+    "depth_scaled": dict(Khth=600.0, use_variable_mixing=True, use=("Depth_fn_u", "Depth_fn_v"), work=True),
+    "depth_scaled_visbeck_resfn": dict(Khth=1.0, Khth_Max=900.0, KHTH_Slope_Cff=0.1, use_variable_mixing=True,
+                                       use=("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "Depth_fn_u", "Depth_fn_v")),
     "fgnv_no_eos": dict(Khth=600.0, eos=None, use_variable_mixing=True, use_FGNV_streamfn=True, use=("cg1",)),
 }
 
@@ -175,7 +180,7 @@ def test_gpu_parity(name):
                 meke["Rlay"] = args["Rlay"]
             if "g_prime" in args:
                 meke["g_prime"] = args["g_prime"]
-            vm = {n: X(a) for n, a in args.items() if n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "cg1")}
+            vm = {n: X(a) for n, a in args.items() if n in ("L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y", "cg1", "Depth_fn_u", "Depth_fn_v")}
             varmix = vm if kw.get("use_variable_mixing") else None
             tv = None if eos is None else (X(d["T"]), X(d["S"]), EOS_init(eos))
             thickness_diffuse(h, uhtr, vhtr, tv, DT, dg, meke, varmix, cdp, CS)
@@ -198,14 +203,15 @@ def _write_td_case(tmp, g, d, name, resident=False):
     opt = [int(eos is not None), int("MEKE_Kh" in args), int("L2u" in args), int("Res_fn_u" in args), int("slope_x" in args), int("MEKE_GM_src" in args),
            int(kw.get("nkml", 0)), int(bool(kw.get("use_variable_mixing")))]
     with open(tmp / "in.bin", "wb") as fh:
-        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, int("cg1" in args)], dtype="<i4").tofile(fh)
+        np.array([g.ni, g.nj, g.nk, g.halo, int(g.reentrant_x), int(g.reentrant_y), g.first_direction, int("cg1" in args) + 2 * int("Depth_fn_u" in args)], dtype="<i4").tofile(fh)
         np.array([g.Angstrom_H, g.H_subroundoff, g.dZ_subroundoff, g.H_to_Z, g.Z_to_H, g.g_Earth, g.Rho0, DT], dtype="<f8").tofile(fh)
         np.array(opt, dtype="<i4").tofile(fh)
         for n in _abi.ALL_METRICS:
             np.ascontiguousarray(g.metrics[n], dtype="<f8").tofile(fh)
         for a in (d["h"], d["T"], d["S"], args.get("Rlay", 1025.0 + 0.5 * np.arange(g.nk))):
             np.ascontiguousarray(a, dtype="<f8").tofile(fh)
-        for n in ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y") + (("cg1",) if "cg1" in args else ()):
+        for n in ("MEKE_Kh", "L2u", "L2v", "SN_u", "SN_v", "Res_fn_u", "Res_fn_v", "slope_x", "slope_y") + (("cg1",) if "cg1" in args else ()) \
+                + (("Depth_fn_u", "Depth_fn_v") if "Depth_fn_u" in args else ()):
             np.ascontiguousarray(f[n], dtype="<f8").tofile(fh)
     with open(tmp / "params.txt", "w") as fh:
         fh.write(f"THICKNESSDIFFUSE = True\nGPU_RESIDENT_DYNAMICS = {resident}\n")
